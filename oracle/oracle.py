@@ -1,0 +1,532 @@
+"""ctypes binding of the CPU oracle (oracle/vg_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg — never by the product package (vecgo_amd).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+_HERE = Path(__file__).resolve().parent
+
+METRIC_L2, METRIC_COSINE, METRIC_DOT, METRIC_HAMMING = 0, 1, 2, 3
+VAMANA_F32, VAMANA_PQ, VAMANA_RABITQ = 0, 1, 2
+
+_f32p = C.POINTER(C.c_float)
+_u8p = C.POINTER(C.c_uint8)
+_i8p = C.POINTER(C.c_int8)
+_u32p = C.POINTER(C.c_uint32)
+_i32p = C.POINTER(C.c_int32)
+_u64p = C.POINTER(C.c_uint64)
+
+
+def _cpu_flags() -> set:
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("flags"):
+                return set(line.split(":", 1)[1].split())
+    except OSError:
+        pass
+    return set()
+
+
+def _load() -> C.CDLL:
+    want = "liboracle_v4.so" if "avx512f" in _cpu_flags() else "liboracle_v3.so"
+    path = _HERE / want
+    if not path.exists():
+        subprocess.check_call(["make", "-C", str(_HERE), want], stdout=subprocess.DEVNULL)
+    return C.CDLL(str(path))
+
+
+class PQ(C.Structure):
+    _fields_ = [("dim", C.c_int32), ("m", C.c_int32), ("k", C.c_int32), ("subdim", C.c_int32),
+                ("codebooks", _i8p), ("scales", _f32p), ("offsets", _f32p)]
+
+
+class HnswGraph(C.Structure):
+    _fields_ = [("n", C.c_int64), ("dim", C.c_int32), ("metric", C.c_int32), ("base", _f32p),
+                ("m0", C.c_int32), ("l0", _u32p), ("max_level", C.c_int32), ("m", C.c_int32),
+                ("slot", C.POINTER(_u32p)), ("adj", C.POINTER(_u32p)),
+                ("entry_point", C.c_uint32)]
+
+
+class Vamana(C.Structure):
+    _fields_ = [("n", C.c_int64), ("dim", C.c_int32), ("r", C.c_int32), ("graph", _u32p),
+                ("entry_point", C.c_uint32), ("kind", C.c_int32), ("metric", C.c_int32),
+                ("base", _f32p), ("pq", C.POINTER(PQ)), ("codes", _u8p)]
+
+
+class SearchStats(C.Structure):
+    _fields_ = [("nodes_visited", C.c_int64), ("distance_computations", C.c_int64),
+                ("distance_short_circuits", C.c_int64), ("pops", C.c_int64)]
+
+
+lib = _load()
+
+
+def _sig(name, restype, *argtypes):
+    f = getattr(lib, name)
+    f.restype = restype
+    f.argtypes = list(argtypes)
+    return f
+
+
+_sig("vgo_dot_avx512", C.c_float, _f32p, _f32p, C.c_int64)
+_sig("vgo_l2_avx512", C.c_float, _f32p, _f32p, C.c_int64)
+_sig("vgo_l2_batch_avx512", None, _f32p, _f32p, C.c_int64, C.c_int64, _f32p)
+_sig("vgo_dot_batch_avx512", None, _f32p, _f32p, C.c_int64, C.c_int64, _f32p)
+_sig("vgo_l2_bounded_avx512", None, _f32p, _f32p, C.c_int64, C.c_float, _f32p, _i32p)
+_sig("vgo_adc_avx512", C.c_float, _f32p, _u8p, C.c_int64)
+_sig("vgo_adc_generic", C.c_float, _f32p, _u8p, C.c_int64)
+_sig("vgo_hamming", C.c_int64, _u8p, _u8p, C.c_int64)
+_sig("vgo_scale", None, _f32p, C.c_int64, C.c_float)
+_sig("vgo_sqrt", C.c_float, C.c_float)
+_sig("vgo_l2_int8_deq", C.c_float, _f32p, _i8p, C.c_int64, C.c_float, C.c_float)
+_sig("vgo_build_table_int8", None, _f32p, _i8p, C.c_int64, C.c_int64, C.c_float, C.c_float, _f32p)
+_sig("vgo_nearest_centroid_int8", C.c_int64, _f32p, _i8p, C.c_int64, C.c_int64, C.c_float, C.c_float)
+_sig("vgo_pq_build_table", None, C.POINTER(PQ), _f32p, _f32p)
+_sig("vgo_pq_encode", None, C.POINTER(PQ), _f32p, _u8p)
+_sig("vgo_pq_decode", None, C.POINTER(PQ), _u8p, _f32p)
+_sig("vgo_pq_asym_distance", C.c_float, C.POINTER(PQ), _f32p, _u8p)
+_sig("vgo_pq_quantize_centroids", None, _f32p, C.c_int64, _i8p, _f32p, _f32p)
+_sig("vgo_pq_train", C.c_int, _f32p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+     C.c_uint64, _i8p, _f32p, _f32p, _f32p)
+_sig("vgo_rabitq_code_bytes", C.c_int64, C.c_int32)
+_sig("vgo_rabitq_encode", None, _f32p, C.c_int32, _u8p)
+_sig("vgo_rabitq_distance", C.c_float, _f32p, C.c_int32, _u8p)
+_sig("vgo_binary_encode_u64", None, _f32p, C.c_int32, C.c_float, _u64p)
+_sig("vgo_kmeans_train", C.c_int, _f32p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+     C.c_uint64, _f32p)
+_sig("vgo_assign_partition", C.c_int32, _f32p, _f32p, C.c_int32, C.c_int32, C.c_int32)
+_sig("vgo_find_closest_centroids", C.c_int, _f32p, _f32p, C.c_int32, C.c_int32, C.c_int32,
+     C.c_int32, _i32p)
+_sig("vgo_rng_u64", C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64)
+_sig("vgo_flat_search_f32", C.c_int32, _f32p, C.c_int64, C.c_int32, C.c_int32, _f32p, C.c_int32,
+     _u32p, _f32p)
+_sig("vgo_flat_search_pq", C.c_int32, C.POINTER(PQ), _u8p, C.c_int64, _f32p, C.c_int32, _u32p, _f32p)
+_sig("vgo_flat_search_rabitq", C.c_int32, _u8p, C.c_int64, C.c_int32, _f32p, C.c_int32, _u32p, _f32p)
+_sig("vgo_rerank_f32", None, _f32p, C.c_int32, C.c_int32, _f32p, _u32p, C.c_int32, _f32p)
+_sig("vgo_hnsw_search", C.c_int32, C.POINTER(HnswGraph), _f32p, C.c_int32, C.c_int32, _u32p,
+     _f32p, C.POINTER(SearchStats))
+_sig("vgo_vamana_search", C.c_int32, C.POINTER(Vamana), _f32p, C.c_int32, _u32p, _f32p,
+     C.POINTER(SearchStats))
+
+
+def _f(a):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    return a, a.ctypes.data_as(_f32p)
+
+
+def _u8(a):
+    a = np.ascontiguousarray(a, dtype=np.uint8)
+    return a, a.ctypes.data_as(_u8p)
+
+
+def _i8(a):
+    a = np.ascontiguousarray(a, dtype=np.int8)
+    return a, a.ctypes.data_as(_i8p)
+
+
+def _u32(a):
+    a = np.ascontiguousarray(a, dtype=np.uint32)
+    return a, a.ctypes.data_as(_u32p)
+
+
+# ---- L0 -------------------------------------------------------------------
+def dot(a, b):
+    a, pa = _f(a); b, pb = _f(b)
+    return np.float32(lib.vgo_dot_avx512(pa, pb, a.size))
+
+
+def l2(a, b):
+    a, pa = _f(a); b, pb = _f(b)
+    return np.float32(lib.vgo_l2_avx512(pa, pb, a.size))
+
+
+def l2_batch(q, targets, dim):
+    q, pq_ = _f(q); t, pt = _f(targets)
+    n = t.size // dim if dim else 0
+    out = np.empty(n, np.float32)
+    lib.vgo_l2_batch_avx512(pq_, pt, dim, n, out.ctypes.data_as(_f32p))
+    return out
+
+
+def dot_batch(q, targets, dim):
+    q, pq_ = _f(q); t, pt = _f(targets)
+    n = t.size // dim if dim else 0
+    out = np.empty(n, np.float32)
+    lib.vgo_dot_batch_avx512(pq_, pt, dim, n, out.ctypes.data_as(_f32p))
+    return out
+
+
+def l2_bounded(a, b, bound):
+    a, pa = _f(a); b, pb = _f(b)
+    r = C.c_float(); e = C.c_int32()
+    lib.vgo_l2_bounded_avx512(pa, pb, a.size, C.c_float(bound), C.byref(r), C.byref(e))
+    return np.float32(r.value), bool(e.value)
+
+
+def adc(table, codes, m):
+    t, pt = _f(table); c, pc = _u8(codes)
+    return np.float32(lib.vgo_adc_avx512(pt, pc, m))
+
+
+def adc_generic(table, codes, m):
+    t, pt = _f(table); c, pc = _u8(codes)
+    return np.float32(lib.vgo_adc_generic(pt, pc, m))
+
+
+def hamming(a, b):
+    a, pa = _u8(a); b, pb = _u8(b)
+    return int(lib.vgo_hamming(pa, pb, a.size))
+
+
+def l2_int8_deq(q, code, scale, offset):
+    q, pq_ = _f(q); c, pc = _i8(code)
+    return np.float32(lib.vgo_l2_int8_deq(pq_, pc, q.size, scale, offset))
+
+
+def build_table_int8(q, codebook, subdim, scale, offset):
+    q, pq_ = _f(q); cb, pcb = _i8(codebook)
+    k = cb.size // subdim
+    out = np.empty(k, np.float32)
+    lib.vgo_build_table_int8(pq_, pcb, subdim, k, scale, offset, out.ctypes.data_as(_f32p))
+    return out
+
+
+def nearest_centroid_int8(q, codebook, subdim, scale, offset):
+    q, pq_ = _f(q); cb, pcb = _i8(codebook)
+    return int(lib.vgo_nearest_centroid_int8(pq_, pcb, subdim, cb.size // subdim, scale, offset))
+
+
+# ---- PQ ---------------------------------------------------------------------
+class ProductQuantizer:
+    """Oracle-side PQ state (internal/quantization/pq.go:20-29)."""
+
+    def __init__(self, dim, m, k=256):
+        assert dim % m == 0 and 0 < k <= 256
+        self.dim, self.m, self.k, self.subdim = dim, m, k, dim // m
+        self.codebooks = np.zeros(m * k * self.subdim, np.int8)
+        self.scales = np.zeros(m, np.float32)
+        self.offsets = np.zeros(m, np.float32)
+        self.centroids_f32 = None
+        self.trained = False
+
+    def _c(self):
+        return PQ(self.dim, self.m, self.k, self.subdim, self.codebooks.ctypes.data_as(_i8p),
+                  self.scales.ctypes.data_as(_f32p), self.offsets.ctypes.data_as(_f32p))
+
+    def set_codebooks(self, codebooks, scales, offsets):
+        self.codebooks = np.ascontiguousarray(codebooks, np.int8).reshape(-1)
+        self.scales = np.ascontiguousarray(scales, np.float32)
+        self.offsets = np.ascontiguousarray(offsets, np.float32)
+        self.trained = True
+
+    def train(self, vectors, iters=20, seed=1):
+        v, pv = _f(vectors)
+        n = v.size // self.dim
+        self.centroids_f32 = np.zeros(self.m * self.k * self.subdim, np.float32)
+        rc = lib.vgo_pq_train(pv, n, self.dim, self.m, self.k, iters, seed,
+                              self.codebooks.ctypes.data_as(_i8p),
+                              self.scales.ctypes.data_as(_f32p),
+                              self.offsets.ctypes.data_as(_f32p),
+                              self.centroids_f32.ctypes.data_as(_f32p))
+        if rc != 0:
+            raise ValueError("pq train failed")
+        self.trained = True
+
+    def encode(self, vec):
+        v, pv = _f(vec)
+        out = np.empty(self.m, np.uint8)
+        c = self._c()
+        lib.vgo_pq_encode(C.byref(c), pv, out.ctypes.data_as(_u8p))
+        return out
+
+    def encode_batch(self, vecs):
+        v = np.ascontiguousarray(vecs, np.float32).reshape(-1, self.dim)
+        out = np.empty((v.shape[0], self.m), np.uint8)
+        c = self._c()
+        for i in range(v.shape[0]):
+            lib.vgo_pq_encode(C.byref(c), v[i].ctypes.data_as(_f32p), out[i].ctypes.data_as(_u8p))
+        return out
+
+    def decode(self, codes):
+        cd, pc = _u8(codes)
+        out = np.empty(self.dim, np.float32)
+        c = self._c()
+        lib.vgo_pq_decode(C.byref(c), pc, out.ctypes.data_as(_f32p))
+        return out
+
+    def build_table(self, query):
+        q, pq_ = _f(query)
+        out = np.empty(self.m * self.k, np.float32)
+        c = self._c()
+        lib.vgo_pq_build_table(C.byref(c), pq_, out.ctypes.data_as(_f32p))
+        return out
+
+    def asym_distance(self, query, codes):
+        q, pq_ = _f(query); cd, pc = _u8(codes)
+        c = self._c()
+        return np.float32(lib.vgo_pq_asym_distance(C.byref(c), pq_, pc))
+
+
+def pq_quantize_centroids(centroids):
+    c, pc = _f(centroids)
+    out = np.empty(c.size, np.int8)
+    s = C.c_float(); o = C.c_float()
+    lib.vgo_pq_quantize_centroids(pc, c.size, out.ctypes.data_as(_i8p), C.byref(s), C.byref(o))
+    return out, np.float32(s.value), np.float32(o.value)
+
+
+# ---- RaBitQ -----------------------------------------------------------------
+def rabitq_code_bytes(dim):
+    return int(lib.vgo_rabitq_code_bytes(dim))
+
+
+def rabitq_encode(v):
+    v, pv = _f(v)
+    out = np.empty(rabitq_code_bytes(v.size), np.uint8)
+    lib.vgo_rabitq_encode(pv, v.size, out.ctypes.data_as(_u8p))
+    return out
+
+
+def rabitq_encode_batch(vecs, dim):
+    v = np.ascontiguousarray(vecs, np.float32).reshape(-1, dim)
+    out = np.empty((v.shape[0], rabitq_code_bytes(dim)), np.uint8)
+    for i in range(v.shape[0]):
+        lib.vgo_rabitq_encode(v[i].ctypes.data_as(_f32p), dim, out[i].ctypes.data_as(_u8p))
+    return out
+
+
+def rabitq_distance(query, code):
+    q, pq_ = _f(query); c, pc = _u8(code)
+    return np.float32(lib.vgo_rabitq_distance(pq_, q.size, pc))
+
+
+def binary_encode_u64(v, threshold=0.0):
+    v, pv = _f(v)
+    out = np.zeros((v.size + 63) // 64, np.uint64)
+    lib.vgo_binary_encode_u64(pv, v.size, threshold, out.ctypes.data_as(_u64p))
+    return out
+
+
+# ---- kmeans -------------------------------------------------------------------
+def kmeans_train(vectors, dim, k, metric=METRIC_L2, max_iter=10, seed=1):
+    v, pv = _f(vectors)
+    n = v.size // dim
+    out = np.zeros(k * dim, np.float32)
+    rc = lib.vgo_kmeans_train(pv, n, dim, k, metric, max_iter, seed, out.ctypes.data_as(_f32p))
+    if rc == 1:
+        return None
+    if rc < 0:
+        raise ValueError("unsupported metric")
+    return out
+
+
+def assign_partition(vec, centroids, dim, metric=METRIC_L2):
+    v, pv = _f(vec); c, pc = _f(centroids)
+    return int(lib.vgo_assign_partition(pv, pc, dim, c.size // dim, metric))
+
+
+def find_closest_centroids(query, centroids, dim, n, metric=METRIC_L2):
+    q, pq_ = _f(query); c, pc = _f(centroids)
+    k = c.size // dim
+    out = np.empty(max(min(n, k), 1), np.int32)
+    r = lib.vgo_find_closest_centroids(pq_, pc, dim, k, n, metric, out.ctypes.data_as(_i32p))
+    if r < 0:
+        raise ValueError("unsupported metric")
+    return out[:r]
+
+
+def rng_u64(seed, a, b, c):
+    return int(lib.vgo_rng_u64(seed, a, b, c))
+
+
+# ---- scans --------------------------------------------------------------------
+def flat_search_f32(base, dim, query, k, metric=METRIC_L2):
+    b, pb = _f(base); q, pq_ = _f(query)
+    n = b.size // dim
+    ids = np.empty(k, np.uint32); sc = np.empty(k, np.float32)
+    r = lib.vgo_flat_search_f32(pb, n, dim, metric, pq_, k, ids.ctypes.data_as(_u32p),
+                                sc.ctypes.data_as(_f32p))
+    return ids[:r], sc[:r]
+
+
+def flat_search_pq(pq: ProductQuantizer, codes, query, k):
+    cd, pc = _u8(codes); q, pq_ = _f(query)
+    n = cd.size // pq.m
+    ids = np.empty(k, np.uint32); sc = np.empty(k, np.float32)
+    c = pq._c()
+    r = lib.vgo_flat_search_pq(C.byref(c), pc, n, pq_, k, ids.ctypes.data_as(_u32p),
+                               sc.ctypes.data_as(_f32p))
+    return ids[:r], sc[:r]
+
+
+def flat_search_rabitq(codes, dim, query, k):
+    cd, pc = _u8(codes); q, pq_ = _f(query)
+    n = cd.size // rabitq_code_bytes(dim)
+    ids = np.empty(k, np.uint32); sc = np.empty(k, np.float32)
+    r = lib.vgo_flat_search_rabitq(pc, n, dim, pq_, k, ids.ctypes.data_as(_u32p),
+                                   sc.ctypes.data_as(_f32p))
+    return ids[:r], sc[:r]
+
+
+def rerank_f32(base, dim, query, ids, metric=METRIC_L2):
+    b, pb = _f(base); q, pq_ = _f(query); i, pi = _u32(ids)
+    out = np.empty(i.size, np.float32)
+    lib.vgo_rerank_f32(pb, dim, metric, pq_, pi, i.size, out.ctypes.data_as(_f32p))
+    return out
+
+
+class HnswIndex:
+    """Host-side graph in the layout the C-ABI uploads (see include/vecgo_hip.h)."""
+
+    def __init__(self, base, dim, l0, upper=(), entry_point=0, metric=METRIC_L2, m=None):
+        self.base = np.ascontiguousarray(base, np.float32).reshape(-1, dim)
+        self.dim = dim
+        self.n = self.base.shape[0]
+        self.l0 = np.ascontiguousarray(l0, np.uint32)
+        self.m0 = self.l0.shape[1]
+        # upper: list of (slot[n] u32, adj[count, m] u32) for levels 1..L
+        self.upper = [(np.ascontiguousarray(s, np.uint32), np.ascontiguousarray(a, np.uint32))
+                      for s, a in upper]
+        self.m = m if m is not None else (self.upper[0][1].shape[1] if self.upper else self.m0 // 2)
+        self.entry_point = entry_point
+        self.metric = metric
+
+    def _c(self):
+        nl = len(self.upper)
+        self._slots = (_u32p * max(nl, 1))(*[s.ctypes.data_as(_u32p) for s, _ in self.upper])
+        self._adjs = (_u32p * max(nl, 1))(*[a.ctypes.data_as(_u32p) for _, a in self.upper])
+        return HnswGraph(self.n, self.dim, self.metric, self.base.ctypes.data_as(_f32p), self.m0,
+                         self.l0.ctypes.data_as(_u32p), nl, self.m, self._slots, self._adjs,
+                         self.entry_point)
+
+    def search(self, query, k, ef):
+        q, pq_ = _f(query)
+        ids = np.empty(max(k, 1), np.uint32); sc = np.empty(max(k, 1), np.float32)
+        st = SearchStats()
+        g = self._c()
+        r = lib.vgo_hnsw_search(C.byref(g), pq_, k, ef, ids.ctypes.data_as(_u32p),
+                                sc.ctypes.data_as(_f32p), C.byref(st))
+        return ids[:r], sc[:r], st
+
+
+class VamanaIndex:
+    def __init__(self, graph, entry_point, dim, kind=VAMANA_F32, metric=METRIC_L2, base=None,
+                 pq: ProductQuantizer | None = None, codes=None):
+        self.graph = np.ascontiguousarray(graph, np.uint32)
+        self.n, self.r = self.graph.shape
+        self.entry_point, self.dim, self.kind, self.metric = entry_point, dim, kind, metric
+        self.base = None if base is None else np.ascontiguousarray(base, np.float32)
+        self.pq = pq
+        self.codes = None if codes is None else np.ascontiguousarray(codes, np.uint8)
+
+    def search(self, query, k):
+        q, pq_ = _f(query)
+        ids = np.empty(max(k, 1), np.uint32); sc = np.empty(max(k, 1), np.float32)
+        st = SearchStats()
+        pqc = self.pq._c() if self.pq is not None else None
+        v = Vamana(self.n, self.dim, self.r, self.graph.ctypes.data_as(_u32p), self.entry_point,
+                   self.kind, self.metric,
+                   self.base.ctypes.data_as(_f32p) if self.base is not None else None,
+                   C.pointer(pqc) if pqc is not None else None,
+                   self.codes.ctypes.data_as(_u8p) if self.codes is not None else None)
+        r = lib.vgo_vamana_search(C.byref(v), pq_, k, ids.ctypes.data_as(_u32p),
+                                  sc.ctypes.data_as(_f32p), C.byref(st))
+        return ids[:r], sc[:r], st
+
+
+# ---- the compiled reference objects (only where oracle/_ref was built) -------
+def load_ref():
+    """oracle/_ref/libvecgo_ref_avx512.so: the reference's own AVX-512 C kernels compiled
+    from /root/reference (never copied). Returns None when absent or the CPU lacks AVX-512."""
+    path = _HERE / "_ref" / "libvecgo_ref_avx512.so"
+    need = {"avx512f", "avx512dq", "avx512bw", "avx512vl", "avx512_vpopcntdq"}
+    if not path.exists() or not need <= _cpu_flags():
+        return None
+    r = C.CDLL(str(path))
+    vp = C.c_void_p
+    r.dotProductAvx512.argtypes = [vp, vp, C.c_int64, vp]
+    r.squaredL2Avx512.argtypes = [vp, vp, C.c_int64, vp]
+    r.squaredL2BatchAvx512.argtypes = [vp, vp, C.c_int64, C.c_int64, vp]
+    r.dotBatchAvx512.argtypes = [vp, vp, C.c_int64, C.c_int64, vp]
+    r.squaredL2BoundedAvx512.argtypes = [vp, vp, C.c_int64, C.c_float, vp, vp]
+    r.pqAdcLookupAvx512.argtypes = [vp, vp, C.c_int64, vp, vp]
+    r.hammingAvx512.argtypes = [vp, vp, C.c_int64]
+    r.hammingAvx512.restype = C.c_longlong
+    for n in ("dotProductAvx512", "squaredL2Avx512", "squaredL2BatchAvx512", "dotBatchAvx512",
+              "squaredL2BoundedAvx512", "pqAdcLookupAvx512"):
+        getattr(r, n).restype = None
+    return r
+
+
+class Ref:
+    """numpy-friendly calls into the compiled reference kernels."""
+
+    def __init__(self):
+        self.lib = load_ref()
+        # kernels_amd64.go:38-44 pqAdcOffsets[i] = i*256
+        self._off = (np.arange(256, dtype=np.int32) * 256)
+
+    @property
+    def ok(self):
+        return self.lib is not None
+
+    def dot(self, a, b):
+        a = np.ascontiguousarray(a, np.float32); b = np.ascontiguousarray(b, np.float32)
+        r = np.zeros(1, np.float32)
+        if a.size:  # kernels_amd64.go:291-297: empty → 0
+            self.lib.dotProductAvx512(a.ctypes.data, b.ctypes.data, a.size, r.ctypes.data)
+        return r[0]
+
+    def l2(self, a, b):
+        a = np.ascontiguousarray(a, np.float32); b = np.ascontiguousarray(b, np.float32)
+        r = np.zeros(1, np.float32)
+        if a.size:
+            self.lib.squaredL2Avx512(a.ctypes.data, b.ctypes.data, a.size, r.ctypes.data)
+        return r[0]
+
+    def l2_batch(self, q, t, dim):
+        q = np.ascontiguousarray(q, np.float32); t = np.ascontiguousarray(t, np.float32)
+        n = t.size // dim
+        out = np.zeros(n, np.float32)
+        if n:
+            self.lib.squaredL2BatchAvx512(q.ctypes.data, t.ctypes.data, dim, n, out.ctypes.data)
+        return out
+
+    def dot_batch(self, q, t, dim):
+        q = np.ascontiguousarray(q, np.float32); t = np.ascontiguousarray(t, np.float32)
+        n = t.size // dim
+        out = np.zeros(n, np.float32)
+        if n:
+            self.lib.dotBatchAvx512(q.ctypes.data, t.ctypes.data, dim, n, out.ctypes.data)
+        return out
+
+    def l2_bounded(self, a, b, bound):
+        a = np.ascontiguousarray(a, np.float32); b = np.ascontiguousarray(b, np.float32)
+        if a.size == 0:
+            return np.float32(0), False  # kernels_amd64.go:308-310
+        r = np.zeros(1, np.float32); e = np.zeros(1, np.int32)
+        self.lib.squaredL2BoundedAvx512(a.ctypes.data, b.ctypes.data, a.size, C.c_float(bound),
+                                        r.ctypes.data, e.ctypes.data)
+        return r[0], bool(e[0])
+
+    def adc(self, table, codes, m):
+        t = np.ascontiguousarray(table, np.float32); c = np.ascontiguousarray(codes, np.uint8)
+        r = np.zeros(1, np.float32)
+        if m > 0:
+            self.lib.pqAdcLookupAvx512(t.ctypes.data, c.ctypes.data, m, r.ctypes.data,
+                                       self._off.ctypes.data)
+        return r[0]
+
+    def hamming(self, a, b):
+        a = np.ascontiguousarray(a, np.uint8); b = np.ascontiguousarray(b, np.uint8)
+        if a.size == 0:
+            return 0
+        return int(self.lib.hammingAvx512(a.ctypes.data, b.ctypes.data, a.size))

@@ -1,0 +1,1186 @@
+/*
+ * vg_oracle.c — CPU restatement of vecgo's distance + quantization hot path.
+ * TEST INFRASTRUCTURE ONLY (see vg_oracle.h).  Own code; follows the
+ * reference's arithmetic, cites file:line (relative to the vecgo root).
+ */
+#include "vg_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#elif defined(__GNUC__)
+#pragma GCC optimize("fp-contract=off")
+#endif
+
+#define FMA(a, b, c) __builtin_fmaf((a), (b), (c))
+
+/* ------------------------------------------------------------------ */
+/* reductions                                                          */
+/* ------------------------------------------------------------------ */
+
+/* _mm512_reduce_add_ps as clang lowers it (internal/simd/floats_avx512.s:
+ * extractf64x4 + add, extractf128 + add, permilpd/shufpd + add, movshdup + add):
+ * (i,i+8) -> (i,i+4) -> (i,i+2) -> (0,1). */
+static inline float reduce16(const float *s)
+{
+    float a[8], b[4], c[2];
+    for (int i = 0; i < 8; i++) a[i] = s[i] + s[i + 8];
+    for (int i = 0; i < 4; i++) b[i] = a[i] + a[i + 4];
+    for (int i = 0; i < 2; i++) c[i] = b[i] + b[i + 2];
+    return c[0] + c[1];
+}
+
+/* hsum512 of internal/simd/src/bounded_l2_avx512.c:6-16: 256-halves, 128-halves,
+ * then two _mm_hadd_ps: ((b0+b1)+(b2+b3)). */
+static inline float hsum512(const float *s)
+{
+    float a[8], b[4];
+    for (int i = 0; i < 8; i++) a[i] = s[i] + s[i + 8];
+    for (int i = 0; i < 4; i++) b[i] = a[i] + a[i + 4];
+    return (b[0] + b[1]) + (b[2] + b[3]);
+}
+
+/* (sum1+sum2) , (sum3+sum4), then their sum — floats_avx512.c:50-53 */
+static inline void combine4(float acc[4][16], float *s)
+{
+    for (int l = 0; l < 16; l++) s[l] = (acc[0][l] + acc[1][l]) + (acc[2][l] + acc[3][l]);
+}
+
+/* ------------------------------------------------------------------ */
+/* L0 kernels                                                          */
+/* ------------------------------------------------------------------ */
+
+/* internal/simd/src/floats_avx512.c:12-65 dotProductAvx512 */
+float vgo_dot_avx512(const float *a, const float *b, int64_t n)
+{
+    float acc[4][16];
+    memset(acc, 0, sizeof acc);
+    int64_t epoch = n / 64;
+    for (int64_t e = 0; e < epoch; e++) {
+        const float *pa = a + e * 64, *pb = b + e * 64;
+        for (int k = 0; k < 4; k++)
+            for (int l = 0; l < 16; l++)
+                acc[k][l] = FMA(pa[k * 16 + l], pb[k * 16 + l], acc[k][l]);
+    }
+    float s[16];
+    combine4(acc, s);
+    float total = reduce16(s);
+    /* scalar tail: clang contracts `total += a*b` into vfmadd231ss (floats_avx512.s) */
+    for (int64_t i = epoch * 64; i < n; i++) total = FMA(a[i], b[i], total);
+    return total;
+}
+
+/* internal/simd/src/floats_avx512.c:69-129 squaredL2Avx512 */
+float vgo_l2_avx512(const float *a, const float *b, int64_t n)
+{
+    float acc[4][16];
+    memset(acc, 0, sizeof acc);
+    int64_t epoch = n / 64;
+    for (int64_t e = 0; e < epoch; e++) {
+        const float *pa = a + e * 64, *pb = b + e * 64;
+        for (int k = 0; k < 4; k++)
+            for (int l = 0; l < 16; l++) {
+                float d = pa[k * 16 + l] - pb[k * 16 + l];
+                acc[k][l] = FMA(d, d, acc[k][l]);
+            }
+    }
+    float s[16];
+    combine4(acc, s);
+    float total = reduce16(s);
+    for (int64_t i = epoch * 64; i < n; i++) {
+        float d = a[i] - b[i];
+        total = FMA(d, d, total);
+    }
+    return total;
+}
+
+/* internal/simd/src/batch_avx512.c:19-83 squaredL2BatchAvx512 (one target) */
+static float l2_batch_one(const float *q, const float *t, int64_t dim)
+{
+    float acc[4][16];
+    memset(acc, 0, sizeof acc);
+    int64_t j = 0;
+    for (; j <= dim - 64; j += 64)
+        for (int k = 0; k < 4; k++)
+            for (int l = 0; l < 16; l++) {
+                float d = q[j + k * 16 + l] - t[j + k * 16 + l];
+                acc[k][l] = FMA(d, d, acc[k][l]);
+            }
+    float s[16];
+    combine4(acc, s);
+    for (; j <= dim - 16; j += 16) /* 16-wide tail goes into the combined register */
+        for (int l = 0; l < 16; l++) {
+            float d = q[j + l] - t[j + l];
+            s[l] = FMA(d, d, s[l]);
+        }
+    float total = reduce16(s);
+    for (; j < dim; j++) {
+        float d = q[j] - t[j];
+        total = FMA(d, d, total);
+    }
+    return total;
+}
+
+/* internal/simd/src/batch_avx512.c:86-143 dotBatchAvx512 (one target) */
+static float dot_batch_one(const float *q, const float *t, int64_t dim)
+{
+    float acc[4][16];
+    memset(acc, 0, sizeof acc);
+    int64_t j = 0;
+    for (; j <= dim - 64; j += 64)
+        for (int k = 0; k < 4; k++)
+            for (int l = 0; l < 16; l++)
+                acc[k][l] = FMA(q[j + k * 16 + l], t[j + k * 16 + l], acc[k][l]);
+    float s[16];
+    combine4(acc, s);
+    for (; j <= dim - 16; j += 16)
+        for (int l = 0; l < 16; l++) s[l] = FMA(q[j + l], t[j + l], s[l]);
+    float total = reduce16(s);
+    for (; j < dim; j++) total = FMA(q[j], t[j], total);
+    return total;
+}
+
+void vgo_l2_batch_avx512(const float *query, const float *targets, int64_t dim, int64_t n,
+                         float *out)
+{
+    for (int64_t i = 0; i < n; i++) out[i] = l2_batch_one(query, targets + i * dim, dim);
+}
+
+void vgo_dot_batch_avx512(const float *query, const float *targets, int64_t dim, int64_t n,
+                          float *out)
+{
+    for (int64_t i = 0; i < n; i++) out[i] = dot_batch_one(query, targets + i * dim, dim);
+}
+
+/* internal/simd/src/bounded_l2_avx512.c:19-108 squaredL2BoundedAvx512 */
+void vgo_l2_bounded_avx512(const float *a, const float *b, int64_t n, float bound,
+                           float *result, int32_t *exceeded)
+{
+    float acc[4][16];
+    memset(acc, 0, sizeof acc);
+    float total = 0.0f;
+    float s[16];
+    int64_t i = 0;
+    while (i + 64 <= n) {
+        for (int k = 0; k < 4; k++)
+            for (int l = 0; l < 16; l++) {
+                float d = a[i + k * 16 + l] - b[i + k * 16 + l];
+                acc[k][l] = FMA(d, d, acc[k][l]);
+            }
+        i += 64;
+        combine4(acc, s);
+        total = hsum512(s);
+        if (total > bound) {
+            *result = total;
+            *exceeded = 1;
+            return;
+        }
+    }
+    combine4(acc, s);
+    total = hsum512(s);
+    for (; i + 8 <= n; i += 8) { /* AVX2 8-wide remainder: mul (no FMA), hadd tree */
+        float q[8];
+        for (int l = 0; l < 8; l++) {
+            float d = a[i + l] - b[i + l];
+            q[l] = d * d;
+        }
+        float p0 = q[0] + q[4], p1 = q[1] + q[5], p2 = q[2] + q[6], p3 = q[3] + q[7];
+        total += (p0 + p1) + (p2 + p3);
+    }
+    for (; i < n; i++) {
+        float d = a[i] - b[i];
+        total = FMA(d, d, total);
+    }
+    *result = total;
+    *exceeded = (total > bound) ? 1 : 0;
+}
+
+/* internal/simd/src/floats_avx512.c:135-167 pqAdcLookupAvx512 (table stride is 256
+ * regardless of K: kernels_amd64.go:38-44) */
+float vgo_adc_avx512(const float *table, const uint8_t *codes, int64_t m)
+{
+    float s[16];
+    memset(s, 0, sizeof s);
+    int64_t i = 0;
+    for (; i <= m - 16; i += 16)
+        for (int l = 0; l < 16; l++) s[l] = s[l] + table[(i + l) * 256 + codes[i + l]];
+    float total = reduce16(s);
+    for (; i < m; i++) total += table[i * 256 + codes[i]];
+    return total;
+}
+
+/* internal/simd/kernels.go:247-253 pqAdcLookupGeneric */
+float vgo_adc_generic(const float *table, const uint8_t *codes, int64_t m)
+{
+    float sum = 0.0f;
+    for (int64_t i = 0; i < m; i++) sum += table[i * 256 + codes[i]];
+    return sum;
+}
+
+/* internal/simd/src/popcount_avx512.c:25-46 hammingAvx512 (integer: order-free) */
+int64_t vgo_hamming(const uint8_t *a, const uint8_t *b, int64_t n)
+{
+    int64_t r = 0;
+    int64_t i = 0;
+    for (; i + 8 <= n; i += 8) {
+        uint64_t x, y;
+        memcpy(&x, a + i, 8);
+        memcpy(&y, b + i, 8);
+        r += __builtin_popcountll(x ^ y);
+    }
+    for (; i < n; i++) r += __builtin_popcount((unsigned)(a[i] ^ b[i]));
+    return r;
+}
+
+/* internal/simd/src/floats_avx512.c:174-218 scaleAvx512 */
+void vgo_scale(float *a, int64_t n, float s)
+{
+    for (int64_t i = 0; i < n; i++) a[i] *= s;
+}
+
+/* internal/simd/doc.go:58-60 Sqrt = float32(math.Sqrt(float64(x))) */
+float vgo_sqrt(float x) { return (float)sqrt((double)x); }
+
+/* internal/simd/kernels.go:354-362 squaredL2Int8DequantizedGeneric — Go on
+ * amd64 (GOAMD64=v1) does not fuse: mul, add, sub, mul, add each rounded. */
+float vgo_l2_int8_deq(const float *query, const int8_t *code, int64_t n, float scale,
+                      float offset)
+{
+    float sum = 0.0f;
+    for (int64_t i = 0; i < n; i++) {
+        float v = (float)code[i] * scale;
+        v = v + offset;
+        float d = query[i] - v;
+        float dd = d * d;
+        sum = sum + dd;
+    }
+    return sum;
+}
+
+/* internal/simd/kernels.go:364-374 buildDistanceTableInt8Generic */
+void vgo_build_table_int8(const float *qsub, const int8_t *codebook, int64_t subdim, int64_t k,
+                          float scale, float offset, float *out)
+{
+    if (subdim <= 0) return;
+    for (int64_t c = 0; c < k; c++)
+        out[c] = vgo_l2_int8_deq(qsub, codebook + c * subdim, subdim, scale, offset);
+}
+
+/* internal/simd/kernels.go:376-396 findNearestCentroidInt8Generic (strict <) */
+int64_t vgo_nearest_centroid_int8(const float *qsub, const int8_t *codebook, int64_t subdim,
+                                  int64_t k, float scale, float offset)
+{
+    if (subdim <= 0 || k <= 0) return 0;
+    int64_t best = 0;
+    float bd = vgo_l2_int8_deq(qsub, codebook, subdim, scale, offset);
+    for (int64_t c = 1; c < k; c++) {
+        float d = vgo_l2_int8_deq(qsub, codebook + c * subdim, subdim, scale, offset);
+        if (d < bd) {
+            bd = d;
+            best = c;
+        }
+    }
+    return best;
+}
+
+/* ------------------------------------------------------------------ */
+/* deterministic RNG (the reference uses unseeded math/rand: pq.go:294,   */
+/* kmeans.go:25 — construction is "parity unpinned"; this stream makes the */
+/* oracle and the device code agree with each other)                       */
+/* ------------------------------------------------------------------ */
+static inline uint64_t splitmix64(uint64_t x)
+{
+    x += 0x9e3779b97f4a7c15ULL;
+    x = (x ^ (x >> 30)) * 0xbf58476d1ce4e5b9ULL;
+    x = (x ^ (x >> 27)) * 0x94d049bb133111ebULL;
+    return x ^ (x >> 31);
+}
+
+uint64_t vgo_rng_u64(uint64_t seed, uint64_t a, uint64_t b, uint64_t c)
+{
+    uint64_t h = splitmix64(seed);
+    h = splitmix64(h ^ a);
+    h = splitmix64(h ^ b);
+    h = splitmix64(h ^ c);
+    return h;
+}
+
+/* uniform float in [0,1) with 24 random bits */
+static inline float rng_f32(uint64_t r) { return (float)(r >> 40) * (1.0f / 16777216.0f); }
+
+/* ------------------------------------------------------------------ */
+/* Product quantizer                                                    */
+/* ------------------------------------------------------------------ */
+
+/* internal/quantization/pq.go:468-491 BuildDistanceTable */
+void vgo_pq_build_table(const vgo_pq *pq, const float *query, float *table)
+{
+    for (int m = 0; m < pq->m; m++)
+        vgo_build_table_int8(query + (int64_t)m * pq->subdim,
+                             pq->codebooks + (int64_t)m * pq->k * pq->subdim, pq->subdim,
+                             pq->k, pq->scales[m], pq->offsets[m], table + (int64_t)m * pq->k);
+}
+
+/* internal/quantization/pq.go:147-176 Encode */
+void vgo_pq_encode(const vgo_pq *pq, const float *vec, uint8_t *codes)
+{
+    for (int m = 0; m < pq->m; m++)
+        codes[m] = (uint8_t)vgo_nearest_centroid_int8(
+            vec + (int64_t)m * pq->subdim, pq->codebooks + (int64_t)m * pq->k * pq->subdim,
+            pq->subdim, pq->k, pq->scales[m], pq->offsets[m]);
+}
+
+/* internal/quantization/pq.go:185-229 Decode */
+void vgo_pq_decode(const vgo_pq *pq, const uint8_t *codes, float *out)
+{
+    for (int m = 0; m < pq->m; m++) {
+        const int8_t *src =
+            pq->codebooks + ((int64_t)m * pq->k + codes[m]) * pq->subdim;
+        for (int i = 0; i < pq->subdim; i++) {
+            float v = (float)src[i] * pq->scales[m];
+            out[m * pq->subdim + i] = v + pq->offsets[m];
+        }
+    }
+}
+
+/* internal/quantization/pq.go:234-260 ComputeAsymmetricDistance (sequential over m) */
+float vgo_pq_asym_distance(const vgo_pq *pq, const float *query, const uint8_t *codes)
+{
+    float distance = 0.0f;
+    for (int m = 0; m < pq->m; m++) {
+        const int8_t *c = pq->codebooks + ((int64_t)m * pq->k + codes[m]) * pq->subdim;
+        distance += vgo_l2_int8_deq(query + (int64_t)m * pq->subdim, c, pq->subdim,
+                                    pq->scales[m], pq->offsets[m]);
+    }
+    return distance;
+}
+
+/* internal/quantization/pq.go:97-136: scale=(max-min)/255, offset=min+128*scale,
+ * q = clamp(round((v-min)/scale),0,255)-128 ; math.Round = half away from zero */
+void vgo_pq_quantize_centroids(const float *centroids, int64_t count, int8_t *out, float *scale,
+                               float *offset)
+{
+    float mn = 3.40282346638528859811704183484516925440e+38f, mx = -mn;
+    for (int64_t i = 0; i < count; i++) {
+        if (centroids[i] < mn) mn = centroids[i];
+        if (centroids[i] > mx) mx = centroids[i];
+    }
+    if (mx == mn) mx = mn + 1e-6f;
+    float sc = (mx - mn) / 255.0f;
+    float of = mn + 128.0f * sc;
+    *scale = sc;
+    *offset = of;
+    for (int64_t i = 0; i < count; i++) {
+        float t = (centroids[i] - mn) / sc;
+        double r = round((double)t);
+        int val = (int)r;
+        if (val < 0) val = 0;
+        if (val > 255) val = 255;
+        out[i] = (int8_t)(val - 128);
+    }
+}
+
+/* pq.go:416-433 findNearestCentroid over fp32 centroids (strict <, from MaxFloat32) */
+static int nearest_f32(const float *v, const float *centroids, int k, int sd)
+{
+    float best = 3.40282346638528859811704183484516925440e+38f;
+    int bi = 0;
+    for (int c = 0; c < k; c++) {
+        float d = vgo_l2_avx512(v, centroids + (int64_t)c * sd, sd);
+        if (d < best) {
+            best = d;
+            bi = c;
+        }
+    }
+    return bi;
+}
+
+/* pq.go:275-414 kmeans for ONE subspace.  RNG draws come from
+ * vgo_rng_u64(seed, subspace, purpose, counter) in place of math/rand. */
+static void pq_kmeans_subspace(const float *vectors, int64_t n, int dim, int sub, int sd, int k,
+                               int iters, uint64_t seed, float *cent)
+{
+    const float *base = vectors + (int64_t)sub * sd;
+    /* initializeCentroids pq.go:281-338 */
+    if (n < k) {
+        for (int i = 0; i < k; i++)
+            memcpy(cent + (int64_t)i * sd, base + (i % n) * (int64_t)dim, sizeof(float) * sd);
+    } else {
+        uint64_t ctr = 0;
+        int64_t first = (int64_t)(vgo_rng_u64(seed, (uint64_t)sub, 1, ctr++) % (uint64_t)n);
+        memcpy(cent, base + first * dim, sizeof(float) * sd);
+        float *mind = (float *)malloc(sizeof(float) * n);
+        float sum = 0.0f;
+        for (int64_t i = 0; i < n; i++) {
+            float d = vgo_l2_avx512(base + i * dim, cent, sd);
+            mind[i] = d;
+            sum += d;
+        }
+        for (int c = 1; c < k; c++) {
+            if (sum == 0.0f) {
+                int64_t idx = (int64_t)(vgo_rng_u64(seed, (uint64_t)sub, 1, ctr++) % (uint64_t)n);
+                memcpy(cent + (int64_t)c * sd, base + idx * dim, sizeof(float) * sd);
+                continue;
+            }
+            float target = rng_f32(vgo_rng_u64(seed, (uint64_t)sub, 1, ctr++)) * sum;
+            float cum = 0.0f;
+            int64_t chosen = 0;
+            for (int64_t i = 0; i < n; i++) {
+                cum += mind[i];
+                if (cum >= target) {
+                    chosen = i;
+                    break;
+                }
+            }
+            memcpy(cent + (int64_t)c * sd, base + chosen * dim, sizeof(float) * sd);
+            sum = 0.0f;
+            for (int64_t i = 0; i < n; i++) {
+                float d = vgo_l2_avx512(base + i * dim, cent + (int64_t)c * sd, sd);
+                if (d < mind[i]) mind[i] = d;
+                sum += mind[i];
+            }
+        }
+        free(mind);
+    }
+    /* runKMeansIterations pq.go:340-351 */
+    int32_t *assign = (int32_t *)calloc((size_t)n, sizeof(int32_t));
+    int64_t *counts = (int64_t *)malloc(sizeof(int64_t) * k);
+    float *nc = (float *)malloc(sizeof(float) * (size_t)k * sd);
+    for (int it = 0; it < iters; it++) {
+        int changed = 0;
+        for (int64_t i = 0; i < n; i++) { /* assignClusters pq.go:353-386 */
+            int a = nearest_f32(base + i * dim, cent, k, sd);
+            if (assign[i] != a) {
+                assign[i] = a;
+                changed = 1;
+            }
+        }
+        if (!changed) break;
+        /* updateCentroids pq.go:388-414: sequential fp32 sums, then / float32(count) */
+        memset(counts, 0, sizeof(int64_t) * k);
+        memset(nc, 0, sizeof(float) * (size_t)k * sd);
+        for (int64_t i = 0; i < n; i++) {
+            int c = assign[i];
+            counts[c]++;
+            for (int j = 0; j < sd; j++) nc[(int64_t)c * sd + j] += base[i * dim + j];
+        }
+        for (int c = 0; c < k; c++) {
+            if (counts[c] > 0) {
+                for (int j = 0; j < sd; j++)
+                    cent[(int64_t)c * sd + j] = nc[(int64_t)c * sd + j] / (float)counts[c];
+            } else {
+                int64_t idx = (int64_t)(vgo_rng_u64(seed, (uint64_t)sub, 2 + (uint64_t)it,
+                                                    (uint64_t)c) %
+                                        (uint64_t)n);
+                memcpy(cent + (int64_t)c * sd, base + idx * dim, sizeof(float) * sd);
+            }
+        }
+    }
+    free(assign);
+    free(counts);
+    free(nc);
+}
+
+/* internal/quantization/pq.go:68-143 Train */
+int vgo_pq_train(const float *vectors, int64_t n, int32_t dim, int32_t m, int32_t k,
+                 int32_t iters, uint64_t seed, int8_t *codebooks, float *scales,
+                 float *offsets, float *centroids_f32)
+{
+    if (n <= 0 || m <= 0 || dim % m != 0 || k <= 0 || k > 256) return -1;
+    int sd = dim / m;
+    float *cent = (float *)malloc(sizeof(float) * (size_t)k * sd);
+    for (int sub = 0; sub < m; sub++) {
+        pq_kmeans_subspace(vectors, n, dim, sub, sd, k, iters, seed, cent);
+        if (centroids_f32)
+            memcpy(centroids_f32 + (int64_t)sub * k * sd, cent, sizeof(float) * (size_t)k * sd);
+        vgo_pq_quantize_centroids(cent, (int64_t)k * sd, codebooks + (int64_t)sub * k * sd,
+                                  &scales[sub], &offsets[sub]);
+    }
+    free(cent);
+    return 0;
+}
+
+/* ------------------------------------------------------------------ */
+/* RaBitQ / binary                                                      */
+/* ------------------------------------------------------------------ */
+int64_t vgo_rabitq_code_bytes(int32_t dim) { return (int64_t)((dim + 63) / 64) * 8 + 4; }
+
+/* internal/quantization/rabitq.go:51-78 Encode */
+void vgo_rabitq_encode(const float *v, int32_t dim, uint8_t *out)
+{
+    int64_t nb = (int64_t)((dim + 63) / 64) * 8;
+    memset(out, 0, (size_t)nb + 4);
+    float norm = vgo_sqrt(vgo_dot_avx512(v, v, dim));
+    for (int i = 0; i < dim; i++)
+        if (v[i] >= 0.0f) out[(i / 64) * 8 + (i % 64) / 8] |= (uint8_t)(1u << (i % 8));
+    memcpy(out + nb, &norm, 4); /* little endian f32 */
+}
+
+/* internal/quantization/binary.go:130-154 EncodeUint64Into */
+void vgo_binary_encode_u64(const float *v, int32_t dim, float threshold, uint64_t *dst)
+{
+    int nw = (dim + 63) / 64;
+    memset(dst, 0, sizeof(uint64_t) * (size_t)nw);
+    for (int i = 0; i < dim; i++)
+        if (v[i] >= threshold) dst[i / 64] |= (uint64_t)1 << (i % 64);
+}
+
+/* internal/quantization/rabitq.go:119-176 Distance */
+float vgo_rabitq_distance(const float *query, int32_t dim, const uint8_t *code)
+{
+    int nw = (dim + 63) / 64;
+    int64_t nb = (int64_t)nw * 8;
+    float ynorm;
+    memcpy(&ynorm, code + nb, 4);
+    float qnorm = vgo_sqrt(vgo_dot_avx512(query, query, dim));
+    uint64_t qc[64];
+    uint64_t *q = nw <= 64 ? qc : (uint64_t *)malloc(sizeof(uint64_t) * (size_t)nw);
+    vgo_binary_encode_u64(query, dim, 0.0f, q);
+    float hamming = (float)vgo_hamming((const uint8_t *)q, code, nb);
+    if (q != qc) free(q);
+    float t1 = qnorm - ynorm;
+    float t1sq = t1 * t1;
+    float t2 = 4.0f * qnorm;
+    t2 = t2 * ynorm;
+    t2 = t2 / (float)dim;
+    t2 = t2 * hamming;
+    return t1sq + t2;
+}
+
+/* ------------------------------------------------------------------ */
+/* internal/kmeans                                                      */
+/* ------------------------------------------------------------------ */
+static int argbest_batch(const float *vec, const float *centroids, int dim, int k, int metric,
+                         float *dists)
+{
+    if (metric == VGO_METRIC_L2) { /* kmeans.go:60-70 */
+        vgo_l2_batch_avx512(vec, centroids, dim, k, dists);
+        int best = 0;
+        float md = dists[0];
+        for (int j = 1; j < k; j++)
+            if (dists[j] < md) {
+                md = dists[j];
+                best = j;
+            }
+        return best;
+    }
+    /* kmeans.go:71-81 Dot/Cosine: higher is better */
+    vgo_dot_batch_avx512(vec, centroids, dim, k, dists);
+    int best = 0;
+    float mx = dists[0];
+    for (int j = 1; j < k; j++)
+        if (dists[j] > mx) {
+            mx = dists[j];
+            best = j;
+        }
+    return best;
+}
+
+/* internal/kmeans/kmeans.go:16-138 TrainKMeans.  rand.Perm / rand.Intn replaced by
+ * the deterministic stream (Fisher-Yates over vgo_rng_u64). Returns 1 when n<k
+ * (reference returns (nil,nil)), -1 on bad metric, 0 ok. */
+int vgo_kmeans_train(const float *vectors, int64_t n, int32_t dim, int32_t k, int32_t metric,
+                     int32_t max_iter, uint64_t seed, float *centroids)
+{
+    if (metric != VGO_METRIC_L2 && metric != VGO_METRIC_DOT && metric != VGO_METRIC_COSINE)
+        return -1;
+    if (n < k) return 1;
+    int64_t *perm = (int64_t *)malloc(sizeof(int64_t) * (size_t)n);
+    for (int64_t i = 0; i < n; i++) perm[i] = i;
+    for (int64_t i = 0; i < k && i < n - 1; i++) { /* partial Fisher-Yates: first k entries */
+        int64_t j = i + (int64_t)(vgo_rng_u64(seed, 0, 1, (uint64_t)i) % (uint64_t)(n - i));
+        int64_t t = perm[i];
+        perm[i] = perm[j];
+        perm[j] = t;
+    }
+    for (int i = 0; i < k; i++)
+        memcpy(centroids + (int64_t)i * dim, vectors + perm[i] * dim, sizeof(float) * dim);
+    free(perm);
+
+    int32_t *assign = (int32_t *)calloc((size_t)n, sizeof(int32_t));
+    int64_t *counts = (int64_t *)malloc(sizeof(int64_t) * k);
+    float *sums = (float *)malloc(sizeof(float) * (size_t)k * dim);
+    float *dists = (float *)malloc(sizeof(float) * k);
+    for (int it = 0; it < max_iter; it++) {
+        int changed = 0;
+        for (int64_t i = 0; i < n; i++) {
+            int b = argbest_batch(vectors + i * dim, centroids, dim, k, metric, dists);
+            if (assign[i] != b) {
+                assign[i] = b;
+                changed = 1;
+            }
+        }
+        if (!changed) break;
+        memset(sums, 0, sizeof(float) * (size_t)k * dim);
+        memset(counts, 0, sizeof(int64_t) * k);
+        for (int64_t i = 0; i < n; i++) { /* kmeans.go:107-119 */
+            int c = assign[i];
+            for (int d = 0; d < dim; d++) sums[(int64_t)c * dim + d] += vectors[i * dim + d];
+            counts[c]++;
+        }
+        for (int j = 0; j < k; j++) { /* kmeans.go:121-135: sums * (1/count) */
+            if (counts[j] > 0) {
+                float scale = 1.0f / (float)counts[j];
+                for (int d = 0; d < dim; d++)
+                    centroids[(int64_t)j * dim + d] = sums[(int64_t)j * dim + d] * scale;
+            } else {
+                int64_t idx = (int64_t)(vgo_rng_u64(seed, 0, 2 + (uint64_t)it, (uint64_t)j) %
+                                        (uint64_t)n);
+                memcpy(centroids + (int64_t)j * dim, vectors + idx * dim, sizeof(float) * dim);
+            }
+        }
+    }
+    free(assign);
+    free(counts);
+    free(sums);
+    free(dists);
+    return 0;
+}
+
+/* internal/kmeans/kmeans.go:142-196 AssignPartition */
+int32_t vgo_assign_partition(const float *vec, const float *centroids, int32_t dim, int32_t k,
+                             int32_t metric)
+{
+    if (metric != VGO_METRIC_L2 && metric != VGO_METRIC_DOT && metric != VGO_METRIC_COSINE)
+        return -1;
+    float *dists = (float *)malloc(sizeof(float) * k);
+    int b = argbest_batch(vec, centroids, dim, k, metric, dists);
+    free(dists);
+    return b;
+}
+
+typedef struct {
+    int32_t id;
+    float dist;
+} cdist;
+
+/* internal/kmeans/kmeans.go:217-280 FindClosestCentroids.  The selection path
+ * (n <= k/4 && n < 16) is restated exactly; the full-sort path uses
+ * slices.SortFunc (pdqsort, unstable) in the reference — ties there are
+ * "unpinned"; this restatement breaks ties by id. */
+int vgo_find_closest_centroids(const float *query, const float *centroids, int32_t dim,
+                               int32_t k, int32_t n, int32_t metric, int32_t *out)
+{
+    if (metric != VGO_METRIC_L2 && metric != VGO_METRIC_DOT && metric != VGO_METRIC_COSINE)
+        return -1;
+    if (n > k) n = k;
+    cdist *d = (cdist *)malloc(sizeof(cdist) * k);
+    float *vals = (float *)malloc(sizeof(float) * k);
+    if (metric == VGO_METRIC_L2) {
+        vgo_l2_batch_avx512(query, centroids, dim, k, vals);
+        for (int i = 0; i < k; i++) d[i] = (cdist){i, vals[i]};
+    } else {
+        vgo_dot_batch_avx512(query, centroids, dim, k, vals);
+        for (int i = 0; i < k; i++) d[i] = (cdist){i, -vals[i]};
+    }
+    if (n <= k / 4 && n < 16) {
+        for (int i = 0; i < n; i++) {
+            int mi = i;
+            for (int j = i + 1; j < k; j++)
+                if (d[j].dist < d[mi].dist) mi = j;
+            cdist t = d[i];
+            d[i] = d[mi];
+            d[mi] = t;
+            out[i] = d[i].id;
+        }
+    } else {
+        /* insertion sort by (dist, id): k is small (partitions) */
+        for (int i = 1; i < k; i++) {
+            cdist x = d[i];
+            int j = i - 1;
+            while (j >= 0 && (d[j].dist > x.dist || (d[j].dist == x.dist && d[j].id > x.id))) {
+                d[j + 1] = d[j];
+                j--;
+            }
+            d[j + 1] = x;
+        }
+        for (int i = 0; i < n; i++) out[i] = d[i].id;
+    }
+    free(d);
+    free(vals);
+    return n;
+}
+
+/* ------------------------------------------------------------------ */
+/* searcher.PriorityQueue — internal/searcher/queue.go:25-290 (4-ary)   */
+/* ------------------------------------------------------------------ */
+void vgo_prioq_init(vgo_prioq *q, int is_max, int32_t cap)
+{
+    q->is_max = is_max;
+    q->len = 0;
+    q->cap = cap > 16 ? cap : 16;
+    q->items = (vgo_pq_item *)malloc(sizeof(vgo_pq_item) * (size_t)q->cap);
+}
+void vgo_prioq_free(vgo_prioq *q)
+{
+    free(q->items);
+    q->items = NULL;
+}
+
+static void prioq_sift_up(vgo_prioq *q, int i) /* queue.go:161-183 */
+{
+    vgo_pq_item it = q->items[i];
+    if (q->is_max) {
+        while (i > 0) {
+            int p = (i - 1) / 4;
+            if (it.dist <= q->items[p].dist) break;
+            q->items[i] = q->items[p];
+            i = p;
+        }
+    } else {
+        while (i > 0) {
+            int p = (i - 1) / 4;
+            if (it.dist >= q->items[p].dist) break;
+            q->items[i] = q->items[p];
+            i = p;
+        }
+    }
+    q->items[i] = it;
+}
+
+static void prioq_sift_down(vgo_prioq *q, int i) /* queue.go:221-290 */
+{
+    int n = q->len;
+    vgo_pq_item it = q->items[i];
+    for (;;) {
+        int fc = 4 * i + 1;
+        if (fc >= n) break;
+        int best = fc;
+        float bd = q->items[fc].dist;
+        int lc = fc + 4;
+        if (lc > n) lc = n;
+        if (q->is_max) {
+            for (int c = fc + 1; c < lc; c++)
+                if (q->items[c].dist > bd) {
+                    best = c;
+                    bd = q->items[c].dist;
+                }
+            if (it.dist >= bd) break;
+        } else {
+            for (int c = fc + 1; c < lc; c++)
+                if (q->items[c].dist < bd) {
+                    best = c;
+                    bd = q->items[c].dist;
+                }
+            if (it.dist <= bd) break;
+        }
+        q->items[i] = q->items[best];
+        i = best;
+    }
+    q->items[i] = it;
+}
+
+void vgo_prioq_push(vgo_prioq *q, vgo_pq_item it) /* queue.go:59-62 */
+{
+    if (q->len == q->cap) {
+        q->cap *= 2;
+        q->items = (vgo_pq_item *)realloc(q->items, sizeof(vgo_pq_item) * (size_t)q->cap);
+    }
+    q->items[q->len++] = it;
+    prioq_sift_up(q, q->len - 1);
+}
+
+void vgo_prioq_push_bounded(vgo_prioq *q, vgo_pq_item it, int32_t capacity) /* queue.go:67-92 */
+{
+    if (q->len < capacity) {
+        vgo_prioq_push(q, it);
+        return;
+    }
+    vgo_pq_item top = q->items[0];
+    if (q->is_max) {
+        if (it.dist < top.dist) {
+            q->items[0] = it;
+            prioq_sift_down(q, 0);
+        }
+    } else {
+        if (it.dist > top.dist) {
+            q->items[0] = it;
+            prioq_sift_down(q, 0);
+        }
+    }
+}
+
+int vgo_prioq_try_push_bounded(vgo_prioq *q, vgo_pq_item it, int32_t max_size) /* :190-215 */
+{
+    if (q->len < max_size) {
+        vgo_prioq_push(q, it);
+        return 1;
+    }
+    vgo_pq_item top = q->items[0];
+    if (q->is_max) {
+        if (it.dist >= top.dist) return 0;
+    } else {
+        if (it.dist <= top.dist) return 0;
+    }
+    q->items[0] = it;
+    prioq_sift_down(q, 0);
+    return 1;
+}
+
+int vgo_prioq_pop(vgo_prioq *q, vgo_pq_item *out) /* queue.go:114-129 */
+{
+    if (q->len == 0) return 0;
+    *out = q->items[0];
+    q->items[0] = q->items[q->len - 1];
+    q->len--;
+    if (q->len > 0) prioq_sift_down(q, 0);
+    return 1;
+}
+
+/* ------------------------------------------------------------------ */
+/* searcher.CandidateHeap — internal/searcher/candidate_queue.go        */
+/* ------------------------------------------------------------------ */
+int vgo_cand_better(vgo_cand a, vgo_cand b, int desc) /* :12-23 */
+{
+    if (a.score != b.score) return desc ? a.score > b.score : a.score < b.score;
+    if (a.segment_id != b.segment_id) return a.segment_id < b.segment_id;
+    return a.row_id < b.row_id;
+}
+static int cand_worse(vgo_cand a, vgo_cand b, int desc) /* :27-38 */
+{
+    if (a.score != b.score) return desc ? a.score < b.score : a.score > b.score;
+    if (a.segment_id != b.segment_id) return a.segment_id > b.segment_id;
+    return a.row_id > b.row_id;
+}
+void vgo_candheap_init(vgo_candheap *h, int32_t cap, int descending)
+{
+    h->cap = cap > 4 ? cap : 4;
+    h->len = 0;
+    h->descending = descending;
+    h->c = (vgo_cand *)malloc(sizeof(vgo_cand) * (size_t)h->cap);
+}
+void vgo_candheap_free(vgo_candheap *h)
+{
+    free(h->c);
+    h->c = NULL;
+}
+static void cand_up(vgo_candheap *h, int j) /* :141-152 */
+{
+    vgo_cand it = h->c[j];
+    while (j > 0) {
+        int i = (j - 1) / 4;
+        if (!cand_worse(it, h->c[i], h->descending)) break;
+        h->c[j] = h->c[i];
+        j = i;
+    }
+    h->c[j] = it;
+}
+static void cand_down(vgo_candheap *h, int i, int n) /* :156-183 */
+{
+    vgo_cand it = h->c[i];
+    for (;;) {
+        int fc = 4 * i + 1;
+        if (fc >= n) break;
+        int best = fc, lc = fc + 4;
+        if (lc > n) lc = n;
+        for (int c = fc + 1; c < lc; c++)
+            if (cand_worse(h->c[c], h->c[best], h->descending)) best = c;
+        if (!cand_worse(h->c[best], it, h->descending)) break;
+        h->c[i] = h->c[best];
+        i = best;
+    }
+    h->c[i] = it;
+}
+int vgo_candheap_try_push_bounded(vgo_candheap *h, vgo_cand x, int32_t k) /* :120-132 */
+{
+    if (h->len < k) {
+        if (h->len == h->cap) {
+            h->cap *= 2;
+            h->c = (vgo_cand *)realloc(h->c, sizeof(vgo_cand) * (size_t)h->cap);
+        }
+        h->c[h->len++] = x;
+        cand_up(h, h->len - 1);
+        return 1;
+    }
+    if (h->len > 0 && vgo_cand_better(x, h->c[0], h->descending)) {
+        h->c[0] = x;
+        cand_down(h, 0, h->len);
+        return 1;
+    }
+    return 0;
+}
+/* SortedResults :191-211 — (score, segment, row) is a total order, so any correct
+ * sort gives the reference's sequence; insertion sort keeps this file dependency-free */
+int32_t vgo_candheap_sorted(const vgo_candheap *h, vgo_cand *dst)
+{
+    for (int i = 0; i < h->len; i++) {
+        vgo_cand x = h->c[i];
+        int j = i - 1;
+        while (j >= 0 && vgo_cand_better(x, dst[j], h->descending)) {
+            dst[j + 1] = dst[j];
+            j--;
+        }
+        dst[j + 1] = x;
+    }
+    return h->len;
+}
+
+/* ------------------------------------------------------------------ */
+/* flat scans — internal/segment/flat/segment.go:606-723                */
+/* ------------------------------------------------------------------ */
+static int32_t emit_sorted(vgo_candheap *h, uint32_t *ids, float *scores)
+{
+    vgo_cand *tmp = (vgo_cand *)malloc(sizeof(vgo_cand) * (size_t)(h->len + 1));
+    int32_t n = vgo_candheap_sorted(h, tmp);
+    for (int i = 0; i < n; i++) {
+        ids[i] = tmp[i].row_id;
+        scores[i] = tmp[i].score;
+    }
+    free(tmp);
+    return n;
+}
+
+int32_t vgo_flat_search_f32(const float *base, int64_t n, int32_t dim, int32_t metric,
+                            const float *query, int32_t k, uint32_t *ids, float *scores)
+{
+    int desc = metric != VGO_METRIC_L2; /* segment.go:449 */
+    vgo_candheap h;
+    vgo_candheap_init(&h, k, desc);
+    for (int64_t i = 0; i < n; i++) { /* segment.go:691-701 */
+        float d = desc ? vgo_dot_avx512(query, base + i * dim, dim)
+                       : vgo_l2_avx512(query, base + i * dim, dim);
+        vgo_candheap_try_push_bounded(&h, (vgo_cand){0, (uint32_t)i, d}, k);
+    }
+    int32_t r = emit_sorted(&h, ids, scores);
+    vgo_candheap_free(&h);
+    return r;
+}
+
+int32_t vgo_flat_search_pq(const vgo_pq *pq, const uint8_t *codes, int64_t n,
+                           const float *query, int32_t k, uint32_t *ids, float *scores)
+{
+    /* the reference builds the table with stride K but looks it up with stride 256
+     * (pq.go:474 vs kernels.go:249): only K == 256 is self-consistent */
+    float *table = (float *)calloc((size_t)pq->m * 256, sizeof(float));
+    float *t = (float *)malloc(sizeof(float) * (size_t)pq->m * pq->k);
+    vgo_pq_build_table(pq, query, t);
+    for (int m = 0; m < pq->m; m++)
+        memcpy(table + (int64_t)m * 256, t + (int64_t)m * pq->k, sizeof(float) * pq->k);
+    free(t);
+    vgo_candheap h;
+    vgo_candheap_init(&h, k, 0);
+    for (int64_t i = 0; i < n; i++) { /* segment.go:678-689 */
+        float d = vgo_adc_avx512(table, codes + i * pq->m, pq->m);
+        vgo_candheap_try_push_bounded(&h, (vgo_cand){0, (uint32_t)i, d}, k);
+    }
+    int32_t r = emit_sorted(&h, ids, scores);
+    vgo_candheap_free(&h);
+    free(table);
+    return r;
+}
+
+int32_t vgo_flat_search_rabitq(const uint8_t *codes, int64_t n, int32_t dim,
+                               const float *query, int32_t k, uint32_t *ids, float *scores)
+{
+    int64_t cb = vgo_rabitq_code_bytes(dim);
+    vgo_candheap h;
+    vgo_candheap_init(&h, k, 0);
+    for (int64_t i = 0; i < n; i++) {
+        float d = vgo_rabitq_distance(query, dim, codes + i * cb);
+        vgo_candheap_try_push_bounded(&h, (vgo_cand){0, (uint32_t)i, d}, k);
+    }
+    int32_t r = emit_sorted(&h, ids, scores);
+    vgo_candheap_free(&h);
+    return r;
+}
+
+void vgo_rerank_f32(const float *base, int32_t dim, int32_t metric, const float *query,
+                    const uint32_t *ids, int32_t n, float *scores)
+{
+    for (int i = 0; i < n; i++) { /* flat/segment.go:766-772 */
+        const float *v = base + (int64_t)ids[i] * dim;
+        scores[i] = metric == VGO_METRIC_L2 ? vgo_l2_avx512(query, v, dim)
+                                            : vgo_dot_avx512(query, v, dim);
+    }
+}
+
+/* ------------------------------------------------------------------ */
+/* HNSW search — internal/hnsw/hnsw.go                                  */
+/* ------------------------------------------------------------------ */
+/* vectorstore/columnar.go:29-50 snapshot distance: L2, -Dot, 0.5*L2 */
+static float hnsw_dist(const vgo_hnsw_graph *g, const float *q, uint32_t id)
+{
+    const float *v = g->base + (int64_t)id * g->dim;
+    switch (g->metric) {
+    case VGO_METRIC_L2:
+        return vgo_l2_avx512(v, q, g->dim);
+    case VGO_METRIC_DOT:
+        return -vgo_dot_avx512(v, q, g->dim);
+    default:
+        return 0.5f * vgo_l2_avx512(v, q, g->dim);
+    }
+}
+
+int32_t vgo_hnsw_search(const vgo_hnsw_graph *g, const float *query, int32_t k, int32_t ef,
+                        uint32_t *ids, float *scores, vgo_search_stats *stats)
+{
+    vgo_search_stats st = {0, 0, 0, 0};
+    if (ef < k) ef = k; /* determineEF hnsw.go:1891-1894 */
+
+    /* greedySearch hnsw.go:1897-1934 */
+    uint32_t cur = g->entry_point;
+    float cur_d = hnsw_dist(g, query, cur);
+    for (int level = g->max_level; level > 0; level--) {
+        int changed = 1;
+        while (changed) {
+            changed = 0;
+            uint32_t slot = g->slot[level - 1][cur];
+            if (slot == 0xFFFFFFFFu) continue;
+            const uint32_t *nb = g->adj[level - 1] + (int64_t)slot * g->m;
+            for (int i = 0; i < g->m && nb[i] != 0xFFFFFFFFu; i++) {
+                float d = hnsw_dist(g, query, nb[i]);
+                if (d < cur_d) {
+                    cur = nb[i];
+                    cur_d = d;
+                    changed = 1;
+                }
+            }
+        }
+    }
+
+    /* searchLayerUnfiltered hnsw.go:1220-1396 */
+    uint8_t *visited = (uint8_t *)calloc((size_t)g->n, 1);
+    vgo_prioq cand, res;
+    vgo_prioq_init(&cand, 0, ef * 2);
+    vgo_prioq_init(&res, 1, ef);
+    visited[cur] = 1;
+    vgo_prioq_push(&cand, (vgo_pq_item){cur, cur_d});
+    vgo_prioq_push(&res, (vgo_pq_item){cur, cur_d});
+
+    int use_sc = g->metric == VGO_METRIC_L2;
+    int cap = ef * 2;
+    int stagnant = 0;
+    float last_best = 3.40282346638528859811704183484516925440e+38f;
+    const int min_cap = ef + ef * 3 / 4;
+
+    vgo_pq_item c;
+    while (cand.len > 0) {
+        vgo_prioq_pop(&cand, &c);
+        st.pops++;
+        if (res.len > 0) {
+            vgo_pq_item worst = res.items[0];
+            if (c.dist > worst.dist && res.len >= ef) break;
+            if (worst.dist < last_best * 0.999f) { /* float32 * untyped const → float32 */
+                last_best = worst.dist;
+                stagnant = 0;
+            } else if (res.len >= ef) {
+                stagnant++;
+                if (stagnant >= 8 && cap > min_cap) {
+                    cap -= ef / 8;
+                    if (cap < min_cap) cap = min_cap;
+                    stagnant = 0;
+                }
+            }
+        }
+        const uint32_t *nb = g->l0 + (int64_t)c.node * g->m0;
+        int has_bound = res.len >= ef;
+        float bound = has_bound ? res.items[0].dist : 0.0f;
+        for (int i = 0; i < g->m0 && nb[i] != 0xFFFFFFFFu; i++) {
+            uint32_t id = nb[i];
+            if (visited[id]) continue;
+            visited[id] = 1;
+            st.nodes_visited++;
+            float nd;
+            if (use_sc && has_bound) {
+                int32_t ex;
+                vgo_l2_bounded_avx512(query, g->base + (int64_t)id * g->dim, g->dim, bound, &nd,
+                                      &ex);
+                st.distance_computations++;
+                if (ex) {
+                    st.distance_short_circuits++;
+                    continue;
+                }
+            } else {
+                nd = hnsw_dist(g, query, id);
+                st.distance_computations++;
+            }
+            if (has_bound && nd > bound) continue;
+            vgo_prioq_try_push_bounded(&cand, (vgo_pq_item){id, nd}, cap);
+            vgo_prioq_push_bounded(&res, (vgo_pq_item){id, nd}, ef);
+            if (res.len >= ef) {
+                bound = res.items[0].dist;
+                has_bound = 1;
+            }
+        }
+    }
+    /* knnSearchInternal extraction hnsw.go:1732-1751 */
+    vgo_pq_item it;
+    while (res.len > k) vgo_prioq_pop(&res, &it);
+    int32_t nres = res.len;
+    for (int i = nres - 1; i >= 0; i--) {
+        vgo_prioq_pop(&res, &it);
+        ids[i] = it.node;
+        scores[i] = it.dist;
+    }
+    vgo_prioq_free(&cand);
+    vgo_prioq_free(&res);
+    free(visited);
+    if (stats) *stats = st;
+    return nres;
+}
+
+/* ------------------------------------------------------------------ */
+/* Vamana beam search — internal/segment/diskann/segment.go:503-706     */
+/* ------------------------------------------------------------------ */
+static float vamana_dist(const vgo_vamana *v, const float *q, uint32_t id)
+{
+    switch (v->kind) {
+    case VGO_VAMANA_PQ: /* segment.go:536-541 */
+        return vgo_pq_asym_distance(v->pq, q, v->codes + (int64_t)id * v->pq->m);
+    case VGO_VAMANA_RABITQ: /* segment.go:512-519 */
+        return vgo_rabitq_distance(q, v->dim, v->codes + (int64_t)id * vgo_rabitq_code_bytes(v->dim));
+    default: /* segment.go:582-588, distFunc = Provider(metric) */
+        return v->metric == VGO_METRIC_L2
+                   ? vgo_l2_avx512(q, v->base + (int64_t)id * v->dim, v->dim)
+                   : vgo_dot_avx512(q, v->base + (int64_t)id * v->dim, v->dim);
+    }
+}
+
+int32_t vgo_vamana_search(const vgo_vamana *v, const float *query, int32_t k, uint32_t *ids,
+                          float *scores, vgo_search_stats *stats)
+{
+    vgo_search_stats st = {0, 0, 0, 0};
+    int desc = v->metric != VGO_METRIC_L2; /* segment.go:597 */
+    uint8_t *visited = (uint8_t *)calloc((size_t)v->n, 1);
+    vgo_prioq cand;
+    vgo_prioq_init(&cand, 0, 256);
+    vgo_candheap heap;
+    vgo_candheap_init(&heap, k, desc);
+
+    uint32_t start = v->entry_point;
+    visited[start] = 1;
+    float sd = vamana_dist(v, query, start);
+    st.distance_computations++;
+    vgo_prioq_push(&cand, (vgo_pq_item){start, sd});
+    vgo_candheap_try_push_bounded(&heap, (vgo_cand){0, start, sd}, k);
+
+    vgo_pq_item c;
+    while (cand.len > 0) {
+        vgo_prioq_pop(&cand, &c);
+        st.pops++;
+        if (heap.len >= k) {
+            if (c.dist > heap.c[0].score) break;
+        }
+        const uint32_t *nb = v->graph + (int64_t)c.node * v->r;
+        for (int i = 0; i < v->r; i++) {
+            uint32_t id = nb[i];
+            if (id == 0xFFFFFFFFu) continue;
+            if (visited[id]) continue;
+            visited[id] = 1;
+            st.nodes_visited++;
+            float d = vamana_dist(v, query, id);
+            st.distance_computations++;
+            vgo_prioq_push(&cand, (vgo_pq_item){id, d});
+            vgo_candheap_try_push_bounded(&heap, (vgo_cand){0, id, d}, k);
+        }
+    }
+    int32_t r = emit_sorted(&heap, ids, scores);
+    vgo_prioq_free(&cand);
+    vgo_candheap_free(&heap);
+    free(visited);
+    if (stats) *stats = st;
+    return r;
+}

@@ -1,0 +1,182 @@
+/*
+ * vg_oracle.h — CPU restatement of vecgo's distance + quantization hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing in the product path (vecgo_amd/, the
+ * C-ABI library) may include, link or call this.  Only tests/, the smoke()
+ * check in __graft_entry__.py and bench.py's cpu_baseline leg use it, and
+ * only as the checker / the reported CPU baseline.
+ *
+ * Every function cites the reference file:line (relative to the vecgo repo
+ * root) whose arithmetic it follows.  The float kernels reproduce the
+ * accumulation ORDER of the reference's AVX-512 C kernels (4x16 lane
+ * accumulators, FMA, _mm512_reduce_add_ps tree) in scalar C, so results are
+ * bit-identical to the clang-built reference objects (pinned by
+ * tests/golden/ fixtures generated from those objects, see
+ * tests/golden/make_golden.py, and cross-checked live against oracle/_ref
+ * when that library is present).
+ *
+ * Build: gcc/clang, -ffp-contract=off (every FMA below is an explicit
+ * __builtin_fmaf; everything else is a separately rounded IEEE fp32 op).
+ */
+#ifndef VG_ORACLE_H
+#define VG_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- L0 kernels (internal/simd) ------------------------------------- */
+float vgo_dot_avx512(const float *a, const float *b, int64_t n);
+float vgo_l2_avx512(const float *a, const float *b, int64_t n);
+void vgo_l2_batch_avx512(const float *query, const float *targets, int64_t dim,
+                         int64_t n, float *out);
+void vgo_dot_batch_avx512(const float *query, const float *targets, int64_t dim,
+                          int64_t n, float *out);
+void vgo_l2_bounded_avx512(const float *a, const float *b, int64_t n, float bound,
+                           float *result, int32_t *exceeded);
+float vgo_adc_avx512(const float *table, const uint8_t *codes, int64_t m);
+float vgo_adc_generic(const float *table, const uint8_t *codes, int64_t m);
+int64_t vgo_hamming(const uint8_t *a, const uint8_t *b, int64_t n);
+void vgo_scale(float *a, int64_t n, float s);
+float vgo_sqrt(float x);
+
+/* int8-codebook PQ helpers: the pure-Go generics that amd64 actually runs */
+float vgo_l2_int8_deq(const float *query, const int8_t *code, int64_t n, float scale,
+                      float offset);
+void vgo_build_table_int8(const float *qsub, const int8_t *codebook, int64_t subdim,
+                          int64_t k, float scale, float offset, float *out);
+int64_t vgo_nearest_centroid_int8(const float *qsub, const int8_t *codebook,
+                                  int64_t subdim, int64_t k, float scale, float offset);
+
+/* ---- L1 codecs (internal/quantization) ------------------------------- */
+typedef struct {
+    int32_t dim, m, k, subdim;
+    const int8_t *codebooks; /* m*k*subdim */
+    const float *scales;     /* m */
+    const float *offsets;    /* m */
+} vgo_pq;
+
+void vgo_pq_build_table(const vgo_pq *pq, const float *query, float *table /* m*k */);
+void vgo_pq_encode(const vgo_pq *pq, const float *vec, uint8_t *codes /* m */);
+void vgo_pq_decode(const vgo_pq *pq, const uint8_t *codes, float *out /* dim */);
+float vgo_pq_asym_distance(const vgo_pq *pq, const float *query, const uint8_t *codes);
+/* int8-quantise fp32 centroids of one subspace (pq.go:97-136) */
+void vgo_pq_quantize_centroids(const float *centroids, int64_t count, int8_t *out,
+                               float *scale, float *offset);
+/* Lloyd iterations + k-means++ init for one subspace, deterministic RNG */
+int vgo_pq_train(const float *vectors, int64_t n, int32_t dim, int32_t m, int32_t k,
+                 int32_t iters, uint64_t seed, int8_t *codebooks, float *scales,
+                 float *offsets, float *centroids_f32 /* optional m*k*subdim */);
+
+int64_t vgo_rabitq_code_bytes(int32_t dim);
+void vgo_rabitq_encode(const float *v, int32_t dim, uint8_t *out);
+float vgo_rabitq_distance(const float *query, int32_t dim, const uint8_t *code);
+void vgo_binary_encode_u64(const float *v, int32_t dim, float threshold, uint64_t *dst);
+
+/* ---- internal/kmeans -------------------------------------------------- */
+enum { VGO_METRIC_L2 = 0, VGO_METRIC_COSINE = 1, VGO_METRIC_DOT = 2, VGO_METRIC_HAMMING = 3 };
+int vgo_kmeans_train(const float *vectors, int64_t n, int32_t dim, int32_t k, int32_t metric,
+                     int32_t max_iter, uint64_t seed, float *centroids);
+int32_t vgo_assign_partition(const float *vec, const float *centroids, int32_t dim, int32_t k,
+                             int32_t metric);
+int vgo_find_closest_centroids(const float *query, const float *centroids, int32_t dim,
+                               int32_t k, int32_t n, int32_t metric, int32_t *out);
+
+/* deterministic counter-based RNG shared with the device code */
+uint64_t vgo_rng_u64(uint64_t seed, uint64_t a, uint64_t b, uint64_t c);
+
+/* ---- internal/searcher heaps ------------------------------------------ */
+typedef struct {
+    uint32_t node;
+    float dist;
+} vgo_pq_item;
+typedef struct {
+    vgo_pq_item *items;
+    int32_t len, cap;
+    int32_t is_max;
+} vgo_prioq;
+void vgo_prioq_init(vgo_prioq *q, int is_max, int32_t cap);
+void vgo_prioq_free(vgo_prioq *q);
+void vgo_prioq_push(vgo_prioq *q, vgo_pq_item it);
+void vgo_prioq_push_bounded(vgo_prioq *q, vgo_pq_item it, int32_t capacity);
+int vgo_prioq_try_push_bounded(vgo_prioq *q, vgo_pq_item it, int32_t max_size);
+int vgo_prioq_pop(vgo_prioq *q, vgo_pq_item *out);
+
+typedef struct {
+    uint32_t segment_id, row_id;
+    float score;
+} vgo_cand;
+typedef struct {
+    vgo_cand *c;
+    int32_t len, cap;
+    int32_t descending;
+} vgo_candheap;
+void vgo_candheap_init(vgo_candheap *h, int32_t cap, int descending);
+void vgo_candheap_free(vgo_candheap *h);
+int vgo_cand_better(vgo_cand a, vgo_cand b, int descending);
+int vgo_candheap_try_push_bounded(vgo_candheap *h, vgo_cand x, int32_t k);
+/* best-first copy (SortedResults) */
+int32_t vgo_candheap_sorted(const vgo_candheap *h, vgo_cand *dst);
+
+/* ---- scan / search loops ---------------------------------------------- */
+/* flat/segment.go:606-723 — every row scored, CandidateHeap top-k; outputs
+ * best-first. Returns number of results (min(k, rows)). */
+int32_t vgo_flat_search_f32(const float *base, int64_t n, int32_t dim, int32_t metric,
+                            const float *query, int32_t k, uint32_t *ids, float *scores);
+int32_t vgo_flat_search_pq(const vgo_pq *pq, const uint8_t *codes, int64_t n,
+                           const float *query, int32_t k, uint32_t *ids, float *scores);
+int32_t vgo_flat_search_rabitq(const uint8_t *codes, int64_t n, int32_t dim,
+                               const float *query, int32_t k, uint32_t *ids, float *scores);
+/* segment Rerank: exact distance for given ids (flat/segment.go:754-780) */
+void vgo_rerank_f32(const float *base, int32_t dim, int32_t metric, const float *query,
+                    const uint32_t *ids, int32_t n, float *scores);
+
+typedef struct {
+    int64_t n;
+    int32_t dim;
+    int32_t metric;      /* VGO_METRIC_* ; distances as hnsw wraps them */
+    const float *base;   /* n*dim */
+    int32_t m0;          /* layer-0 max degree */
+    const uint32_t *l0;  /* n*m0, 0xFFFFFFFF = end of list */
+    int32_t max_level;   /* highest level with nodes (0 = only layer 0) */
+    int32_t m;           /* upper-layer max degree */
+    /* upper layers: for level L in 1..max_level, slot[L-1][node] = row into
+     * adj[L-1] or 0xFFFFFFFF; adj[L-1] is count*m ids, 0xFFFFFFFF-padded */
+    const uint32_t *const *slot;
+    const uint32_t *const *adj;
+    uint32_t entry_point;
+} vgo_hnsw_graph;
+
+typedef struct {
+    int64_t nodes_visited, distance_computations, distance_short_circuits, pops;
+} vgo_search_stats;
+
+/* hnsw.go:1791 searchExecute = greedySearch + searchLayerUnfiltered(level 0),
+ * then knnSearchInternal's extraction: best-first k results. */
+int32_t vgo_hnsw_search(const vgo_hnsw_graph *g, const float *query, int32_t k, int32_t ef,
+                        uint32_t *ids, float *scores, vgo_search_stats *stats);
+
+enum { VGO_VAMANA_F32 = 0, VGO_VAMANA_PQ = 1, VGO_VAMANA_RABITQ = 2 };
+typedef struct {
+    int64_t n;
+    int32_t dim;
+    int32_t r;             /* max degree */
+    const uint32_t *graph; /* n*r, 0xFFFFFFFF = none */
+    uint32_t entry_point;
+    int32_t kind;
+    int32_t metric;        /* for VGO_VAMANA_F32: L2 / Dot */
+    const float *base;     /* F32 */
+    const vgo_pq *pq;      /* PQ */
+    const uint8_t *codes;  /* PQ: n*m ; RABITQ: n*code_bytes */
+} vgo_vamana;
+/* diskann/segment.go:503-706 searchInternal, no filters */
+int32_t vgo_vamana_search(const vgo_vamana *v, const float *query, int32_t k,
+                          uint32_t *ids, float *scores, vgo_search_stats *stats);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
