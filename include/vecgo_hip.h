@@ -1,0 +1,116 @@
+/*
+ * vecgo_hip.h — C ABI of libvecgo_hip.so: the MI355X (gfx950) implementation of
+ * vecgo's distance + quantization hot path.
+ *
+ * This is the drop-in boundary.  Every entry point names the reference interface
+ * (file:line under the vecgo repository root) it stands in for.  Plain C types,
+ * caller-owned buffers, no callbacks; INTEGRATION.md shows the cgo binding a
+ * vecgo maintainer would add (internal/simd/kernels_hip.go + quantization shims).
+ *
+ * Conventions
+ *   - Every function returns a vg_status (0 = ok, negative = error) and never
+ *     aborts; vg_last_error() gives the message for the calling thread.
+ *   - Data pointers may be HOST or DEVICE (HBM) pointers; the library detects
+ *     which (hipPointerGetAttributes).  Host buffers are staged through HBM and
+ *     the call returns after the results are back in the caller's buffer (the Go
+ *     `//go:noescape` contract: no pointer is retained).  When every buffer of a
+ *     call is a device pointer the call only enqueues work on `stream` and
+ *     returns; results are ready when the stream reaches that point.
+ *   - `stream` is a hipStream_t passed as void*; NULL = the context's own stream.
+ *   - Index / quantizer handles may be used from many threads at once for the
+ *     read-only calls (search, encode, build table); create / set / train /
+ *     destroy must be externally serialised (internal/quantization/doc.go:120-123).
+ *   - Zero-length inputs succeed and produce empty / zero outputs
+ *     (internal/simd/kernels_amd64.go:291-297).
+ *   - Result ids are uint32 row ids (model.RowID); unused result slots hold
+ *     id 0xFFFFFFFF and score +Inf (L2-like) or -Inf (Dot).
+ */
+#ifndef VECGO_HIP_H
+#define VECGO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VG_ABI_VERSION 1
+#define VG_INVALID_ID 0xFFFFFFFFu
+
+/* error conventions: Go (value, error) strings in parentheses are what the Go
+ * shim maps each code to (internal/quantization/pq.go:148-153,190,496;
+ * rabitq.go:53,124) */
+typedef enum vg_status {
+    VG_OK = 0,
+    VG_ERR_INVALID_ARG = -1,        /* nil/negative/inconsistent arguments */
+    VG_ERR_DIM_MISMATCH = -2,       /* "vector dimension mismatch" */
+    VG_ERR_NOT_TRAINED = -3,        /* "ProductQuantizer not trained" */
+    VG_ERR_CODE_LENGTH = -4,        /* "codes length mismatch" / "invalid code length" */
+    VG_ERR_UNSUPPORTED = -5,        /* "unsupported metric for float32: ..." / shape not supported */
+    VG_ERR_OUT_OF_MEMORY = -6,
+    VG_ERR_HIP = -7,                /* a HIP runtime call failed */
+    VG_ERR_NO_DEVICE = -8,          /* no gfx950 device / extension not usable */
+    VG_ERR_NOT_READY = -9           /* index lacks the data this search needs */
+} vg_status;
+
+/* distance.Metric — distance/distance.go:66-73 */
+typedef enum vg_metric {
+    VG_METRIC_L2 = 0,
+    VG_METRIC_COSINE = 1,
+    VG_METRIC_DOT = 2,
+    VG_METRIC_HAMMING = 3
+} vg_metric;
+
+typedef struct vg_ctx vg_ctx;     /* one per (process, GPU) */
+typedef struct vg_pq vg_pq;       /* quantization.ProductQuantizer — pq.go:20-29 */
+typedef struct vg_index vg_index; /* device-resident rows / codes / graph of one segment */
+
+/* ---- context ------------------------------------------------------------ */
+int32_t vg_abi_version(void);
+/* device = HIP ordinal (LOCAL_RANK in a one-process-per-GPU job) */
+int32_t vg_ctx_create(int32_t device, vg_ctx **out);
+int32_t vg_ctx_destroy(vg_ctx *ctx);
+int32_t vg_ctx_synchronize(vg_ctx *ctx, void *stream);
+const char *vg_last_error(void);
+const char *vg_status_string(int32_t status);
+/* name (e.g. "gfx950"), CU count and HBM bytes of the context's device */
+int32_t vg_ctx_device_info(vg_ctx *ctx, char *arch, int32_t arch_len, int32_t *compute_units,
+                           int64_t *hbm_bytes);
+
+/* ---- ProductQuantizer (internal/quantization/pq.go) ------------------------ */
+/* NewProductQuantizer pq.go:36-64: dim % m == 0, 0 < k <= 256 */
+int32_t vg_pq_create(vg_ctx *ctx, int32_t dim, int32_t m, int32_t k, vg_pq **out);
+int32_t vg_pq_destroy(vg_pq *pq);
+/* SetCodebooks pq.go:458-464: int8 codebooks m*k*(dim/m), scales[m], offsets[m] */
+int32_t vg_pq_set_codebooks(vg_pq *pq, const int8_t *codebooks, const float *scales,
+                            const float *offsets);
+/* Codebooks pq.go:452-455 (copies out) */
+int32_t vg_pq_get_codebooks(vg_pq *pq, int8_t *codebooks, float *scales, float *offsets);
+int32_t vg_pq_is_trained(vg_pq *pq);
+/* BuildDistanceTable pq.go:468-491, batched: tables[nq][m*k] (entry = a8 term,
+ * internal/simd/kernels.go:354-374 generic order, no FMA) */
+int32_t vg_pq_build_distance_table(vg_pq *pq, const float *queries, int64_t nq, float *tables,
+                                   void *stream);
+
+/* ---- resident index ---------------------------------------------------------- */
+int32_t vg_index_create(vg_ctx *ctx, int64_t n, int32_t dim, int32_t metric, vg_index **out);
+int32_t vg_index_destroy(vg_index *idx);
+/* PQ codes of a flat / DiskANN segment: n*m bytes row-major
+ * (flat/segment.go:678-680 `codes[i*m:(i+1)*m]`, diskann/segment.go:316).  The
+ * library keeps its own HBM copy (re-tiled for coalesced 16-byte loads); the
+ * quantizer handle must outlive the index. */
+int32_t vg_index_set_pq_codes(vg_index *idx, vg_pq *pq, const uint8_t *codes, void *stream);
+
+/* ---- searches ---------------------------------------------------------------- */
+/* flat.Segment.Search, PQ branch (flat/segment.go:476-483 LUT, :678-689 ADC
+ * = simd.PqAdcLookup in pqAdcLookupAvx512 order, :714-721 top-k with the
+ * (Score, RowID) tie-break of searcher/candidate_queue.go:12-23).
+ * queries[nq*dim] → ids[nq*k], scores[nq*k], best first.  k <= 1024. */
+int32_t vg_search_pq_adc(vg_index *idx, const float *queries, int64_t nq, int32_t k,
+                         uint32_t *ids, float *scores, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VECGO_HIP_H */

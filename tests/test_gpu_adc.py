@@ -1,0 +1,157 @@
+"""PQ-ADC flat scan on the GPU vs the CPU oracle: bit-exact ids and scores.
+
+Mirrors flat/pq_test.go + internal/simd/floats_test.go:328-447 (ADC) at the segment
+level: every row scored with BuildDistanceTable + pqAdcLookupAvx512 order, top-k with
+the (Score, RowID) tie-break."""
+import numpy as np
+import pytest
+
+from oracle import oracle as o
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(x):
+    return np.asarray(x, np.float32).view(np.uint32)
+
+
+@pytest.fixture(scope="module")
+def vg():
+    import vecgo_amd
+    return vecgo_amd
+
+
+@pytest.fixture(scope="module")
+def ctx(vg):
+    return vg.Context(0)
+
+
+def _random_pq(rng, dim, m, k=256):
+    sd = dim // m
+    opq = o.ProductQuantizer(dim, m, k)
+    cb = rng.integers(-128, 128, m * k * sd).astype(np.int8)
+    scales = (rng.random(m) * 0.02 + 0.005).astype(np.float32)
+    offsets = ((rng.random(m) * 2 - 1) * 0.1).astype(np.float32)
+    opq.set_codebooks(cb, scales, offsets)
+    return opq
+
+
+def _mk(vg, ctx, opq, codes, n):
+    pq = vg.ProductQuantizer(ctx, opq.dim, opq.m, opq.k)
+    pq.set_codebooks(opq.codebooks, opq.scales, opq.offsets)
+    idx = vg.Index(ctx, n, opq.dim, vg.Metric.L2)
+    idx.set_pq_codes(pq, codes)
+    return pq, idx
+
+
+@pytest.mark.parametrize("dim,m", [(768, 96), (128, 8), (128, 16), (200, 25), (64, 1), (272, 17),
+                                   (512, 64)])
+def test_build_distance_table_bit_exact(vg, ctx, dim, m):
+    rng = np.random.default_rng(dim * 1000 + m)
+    opq = _random_pq(rng, dim, m)
+    pq = vg.ProductQuantizer(ctx, dim, m, 256)
+    pq.set_codebooks(opq.codebooks, opq.scales, opq.offsets)
+    q = rng.standard_normal((3, dim)).astype(np.float32)
+    got = pq.build_distance_table(q)
+    for i in range(3):
+        assert np.array_equal(bits(got[i]), bits(opq.build_table(q[i])))
+
+
+@pytest.mark.parametrize("n,dim,m,k,nq", [
+    (10000, 768, 96, 10, 3),     # BASELINE shape, several tiles per wave
+    (777, 768, 96, 10, 2),       # ragged last tile
+    (64, 128, 16, 10, 1),        # exactly one tile
+    (5, 128, 16, 10, 1),         # fewer rows than k
+    (3000, 128, 8, 7, 2),        # m < 16: tail-only path
+    (3000, 200, 25, 10, 2),      # one full group + 9 tail
+    (3000, 272, 17, 1, 2),       # k = 1
+    (20000, 128, 16, 200, 2),    # larger k
+    (70000, 64, 4, 1000, 1),     # k near the fused limit, many compactions
+])
+def test_adc_scan_matches_oracle(vg, ctx, n, dim, m, k, nq):
+    rng = np.random.default_rng(n + dim + m + k)
+    opq = _random_pq(rng, dim, m)
+    codes = rng.integers(0, 256, (n, m)).astype(np.uint8)
+    pq, idx = _mk(vg, ctx, opq, codes, n)
+    queries = rng.standard_normal((nq, dim)).astype(np.float32)
+    ids, scores = idx.search_pq_adc(queries, k)
+    assert ids.shape == (nq, k)
+    for qi in range(nq):
+        eid, esc = o.flat_search_pq(opq, codes, queries[qi], k)
+        r = eid.size
+        assert np.array_equal(ids[qi, :r], eid)
+        assert np.array_equal(bits(scores[qi, :r]), bits(esc))
+        assert np.all(ids[qi, r:] == 0xFFFFFFFF) and np.all(np.isinf(scores[qi, r:]))
+
+
+def test_adc_ties_break_by_row_id(vg, ctx):
+    """Duplicate codes → equal scores: the reference keeps the lower RowID
+    (searcher/candidate_queue.go:12-23)."""
+    rng = np.random.default_rng(11)
+    dim, m, n, k = 128, 16, 4096, 16
+    opq = _random_pq(rng, dim, m)
+    codes = np.tile(rng.integers(0, 256, (8, m)).astype(np.uint8), (n // 8, 1))
+    pq, idx = _mk(vg, ctx, opq, codes, n)
+    q = rng.standard_normal((2, dim)).astype(np.float32)
+    ids, scores = idx.search_pq_adc(q, k)
+    for qi in range(2):
+        eid, esc = o.flat_search_pq(opq, codes, q[qi], k)
+        assert np.array_equal(ids[qi], eid)
+        assert np.array_equal(bits(scores[qi]), bits(esc))
+
+
+def test_adc_many_queries_share_slices(vg, ctx):
+    rng = np.random.default_rng(12)
+    dim, m, n, k, nq = 128, 16, 30000, 10, 300
+    opq = _random_pq(rng, dim, m)
+    codes = rng.integers(0, 256, (n, m)).astype(np.uint8)
+    pq, idx = _mk(vg, ctx, opq, codes, n)
+    q = rng.standard_normal((nq, dim)).astype(np.float32)
+    ids, scores = idx.search_pq_adc(q, k)
+    for qi in range(0, nq, 17):
+        eid, esc = o.flat_search_pq(opq, codes, q[qi], k)
+        assert np.array_equal(ids[qi], eid)
+        assert np.array_equal(bits(scores[qi]), bits(esc))
+
+
+def test_adc_device_buffers(vg, ctx):
+    torch = pytest.importorskip("torch")
+    rng = np.random.default_rng(13)
+    dim, m, n, k, nq = 768, 96, 20000, 10, 5
+    opq = _random_pq(rng, dim, m)
+    codes = rng.integers(0, 256, (n, m)).astype(np.uint8)
+    pq = vg.ProductQuantizer(ctx, dim, m, 256)
+    pq.set_codebooks(opq.codebooks, opq.scales, opq.offsets)
+    idx = vg.Index(ctx, n, dim, vg.Metric.L2)
+    idx.set_pq_codes(pq, torch.from_numpy(codes).cuda())
+    q = rng.standard_normal((nq, dim)).astype(np.float32)
+    tq = torch.from_numpy(q).cuda()
+    st = torch.cuda.current_stream()
+    ids, scores = idx.search_pq_adc(tq, k, stream=st)
+    torch.cuda.synchronize()
+    ids = ids.cpu().numpy().view(np.uint32); scores = scores.cpu().numpy()
+    for qi in range(nq):
+        eid, esc = o.flat_search_pq(opq, codes, q[qi], k)
+        assert np.array_equal(ids[qi], eid)
+        assert np.array_equal(bits(scores[qi]), bits(esc))
+
+
+def test_adc_errors(vg, ctx):
+    opq = _random_pq(np.random.default_rng(1), 128, 16)
+    pq = vg.ProductQuantizer(ctx, 128, 16, 256)
+    idx = vg.Index(ctx, 10, 128, vg.Metric.L2)
+    with pytest.raises(vg.VecgoHipError) as e:  # pq.go:148-150
+        idx.set_pq_codes(pq, np.zeros((10, 16), np.uint8))
+    assert e.value.status == -3 and "not trained" in e.value.message
+    with pytest.raises(vg.VecgoHipError) as e:
+        idx.search_pq_adc(np.zeros((1, 128), np.float32), 5)
+    assert e.value.status == -9
+    with pytest.raises(vg.VecgoHipError):  # pq.go:40-42
+        vg.ProductQuantizer(ctx, 100, 7, 256)
+    with pytest.raises(vg.VecgoHipError):  # pq.go:47-49
+        vg.ProductQuantizer(ctx, 128, 8, 257)
+    # zero queries / zero k succeed with empty outputs
+    pq.set_codebooks(opq.codebooks, opq.scales, opq.offsets)
+    idx.set_pq_codes(pq, np.zeros((10, 16), np.uint8))
+    ids, sc = idx.search_pq_adc(np.zeros((0, 128), np.float32), 5)
+    assert ids.shape == (0, 5)

@@ -1,0 +1,204 @@
+"""Python mirror of the reference interfaces over the C ABI (tests + bench driver).
+
+Arrays may be numpy (host) or torch CUDA tensors (HBM); the library detects which.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import enum
+
+import numpy as np
+
+from . import _lib
+from ._lib import VecgoHipError, check
+
+try:  # torch is plumbing only: device buffers and streams
+    import torch
+except Exception:  # pragma: no cover
+    torch = None
+
+
+class Metric(enum.IntEnum):
+    """distance.Metric (distance/distance.go:66-73)."""
+    L2 = 0
+    COSINE = 1
+    DOT = 2
+    HAMMING = 3
+
+
+def _is_torch(x) -> bool:
+    return torch is not None and isinstance(x, torch.Tensor)
+
+
+def _ptr(x, dtype, count=None):
+    """(keepalive, void*) of a contiguous numpy array or torch tensor of `dtype`."""
+    if x is None:
+        return None, None
+    if _is_torch(x):
+        tdt = {np.float32: torch.float32, np.uint8: torch.uint8, np.int8: torch.int8,
+               np.uint32: torch.int32, np.int32: torch.int32, np.uint64: torch.int64,
+               np.int64: torch.int64}[dtype]
+        if x.dtype != tdt:
+            raise TypeError(f"expected torch dtype {tdt}, got {x.dtype}")
+        if not x.is_contiguous():
+            x = x.contiguous()
+        if count is not None and x.numel() < count:
+            raise ValueError(f"buffer has {x.numel()} elements, need {count}")
+        return x, C.c_void_p(x.data_ptr())
+    a = np.ascontiguousarray(x, dtype=dtype)
+    if count is not None and a.size < count:
+        raise ValueError(f"buffer has {a.size} elements, need {count}")
+    return a, C.c_void_p(a.ctypes.data)
+
+
+def _stream_ptr(stream):
+    if stream is None:
+        return None
+    if torch is not None and isinstance(stream, torch.cuda.Stream):
+        return C.c_void_p(stream.cuda_stream)
+    return C.c_void_p(int(stream))
+
+
+class Context:
+    """One per (process, GPU)."""
+
+    def __init__(self, device: int = 0):
+        self._lib = _lib.load()
+        h = C.c_void_p()
+        check(self._lib.vg_ctx_create(C.c_int32(device), C.byref(h)))
+        self._h = h
+        self.device = device
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.vg_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def synchronize(self, stream=None):
+        check(self._lib.vg_ctx_synchronize(self._h, _stream_ptr(stream)))
+
+    def device_info(self):
+        arch = C.create_string_buffer(64)
+        cus = C.c_int32()
+        hbm = C.c_int64()
+        check(self._lib.vg_ctx_device_info(self._h, arch, 64, C.byref(cus), C.byref(hbm)))
+        return {"arch": arch.value.decode(), "compute_units": cus.value, "hbm_bytes": hbm.value}
+
+
+class ProductQuantizer:
+    """quantization.ProductQuantizer (internal/quantization/pq.go:20-29)."""
+
+    def __init__(self, ctx: Context, dimension: int, num_subvectors: int, num_centroids: int = 256):
+        self._lib = ctx._lib
+        self.ctx = ctx
+        h = C.c_void_p()
+        check(self._lib.vg_pq_create(ctx._h, dimension, num_subvectors, num_centroids, C.byref(h)))
+        self._h = h
+        self.dimension, self.num_subvectors, self.num_centroids = dimension, num_subvectors, num_centroids
+        self.subvector_dim = dimension // num_subvectors
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.vg_pq_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def is_trained(self) -> bool:
+        return bool(self._lib.vg_pq_is_trained(self._h))
+
+    def set_codebooks(self, codebooks, scales, offsets):
+        n = self.num_subvectors * self.num_centroids * self.subvector_dim
+        a, pa = _ptr(codebooks, np.int8, n)
+        s, ps = _ptr(scales, np.float32, self.num_subvectors)
+        o, po = _ptr(offsets, np.float32, self.num_subvectors)
+        check(self._lib.vg_pq_set_codebooks(self._h, pa, ps, po))
+
+    def codebooks(self):
+        n = self.num_subvectors * self.num_centroids * self.subvector_dim
+        cb = np.empty(n, np.int8); s = np.empty(self.num_subvectors, np.float32)
+        o = np.empty(self.num_subvectors, np.float32)
+        check(self._lib.vg_pq_get_codebooks(self._h, C.c_void_p(cb.ctypes.data),
+                                            C.c_void_p(s.ctypes.data), C.c_void_p(o.ctypes.data)))
+        return cb, s, o
+
+    def build_distance_table(self, queries, out=None, stream=None):
+        """BuildDistanceTable (pq.go:468-491), batched: returns [nq, m*k]."""
+        nq = _rows(queries, self.dimension)
+        q, pq_ = _ptr(queries, np.float32)
+        if out is None:
+            out = _empty_like(queries, (nq, self.num_subvectors * self.num_centroids), np.float32)
+        t, pt = _ptr(out, np.float32, nq * self.num_subvectors * self.num_centroids)
+        check(self._lib.vg_pq_build_distance_table(self._h, pq_, C.c_int64(nq), pt, _stream_ptr(stream)))
+        return out
+
+
+def _rows(x, dim) -> int:
+    n = x.numel() if _is_torch(x) else np.asarray(x).size
+    if dim <= 0 or n % dim:
+        raise VecgoHipError(-2, "vector dimension mismatch")
+    return n // dim
+
+
+def _empty_like(ref, shape, dtype):
+    if _is_torch(ref):
+        tdt = {np.float32: torch.float32, np.uint32: torch.int32, np.uint8: torch.uint8,
+               np.int32: torch.int32}[dtype]
+        return torch.empty(shape, dtype=tdt, device=ref.device)
+    return np.empty(shape, dtype)
+
+
+class Index:
+    """Device-resident rows / codes / graph of one segment."""
+
+    def __init__(self, ctx: Context, n: int, dim: int, metric: Metric = Metric.L2):
+        self._lib = ctx._lib
+        self.ctx = ctx
+        h = C.c_void_p()
+        check(self._lib.vg_index_create(ctx._h, C.c_int64(n), dim, int(metric), C.byref(h)))
+        self._h = h
+        self.n, self.dim, self.metric = n, dim, Metric(metric)
+        self._keep = []
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.vg_index_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_pq_codes(self, pq: ProductQuantizer, codes, stream=None):
+        c, pc = _ptr(codes, np.uint8, self.n * pq.num_subvectors)
+        self._keep.append(pq)
+        check(self._lib.vg_index_set_pq_codes(self._h, pq._h, pc, _stream_ptr(stream)))
+
+    def _search(self, fn, queries, k, extra=(), out=None, stream=None):
+        nq = _rows(queries, self.dim)
+        q, pq_ = _ptr(queries, np.float32)
+        if out is None:
+            ids = _empty_like(queries, (nq, k), np.uint32)
+            scores = _empty_like(queries, (nq, k), np.float32)
+        else:
+            ids, scores = out
+        i, pi = _ptr(ids, np.uint32, nq * k)
+        s, ps = _ptr(scores, np.float32, nq * k)
+        check(fn(self._h, pq_, C.c_int64(nq), C.c_int32(k), *extra, pi, ps, _stream_ptr(stream)))
+        return ids, scores
+
+    def search_pq_adc(self, queries, k, out=None, stream=None):
+        """flat.Segment.Search PQ branch (flat/segment.go:476-483,678-689,714-721)."""
+        return self._search(self._lib.vg_search_pq_adc, queries, k, out=out, stream=stream)

@@ -1,0 +1,147 @@
+// k_pq.hip — quantization.ProductQuantizer on the device (internal/quantization/pq.go).
+#include "vg_device.hpp"
+#include "vg_internal.hpp"
+
+namespace vg {
+
+// One (query, subspace) per workgroup, one centroid per thread.
+// Entry = squaredL2Int8DequantizedGeneric (internal/simd/kernels.go:354-362):
+//   v = float32(code)*scale + offset ; d = q - v ; sum += d*d   — five separately
+// rounded fp32 ops per term, sequential over the sub-dimension (Go on amd64 does not
+// fuse; this TU is built with -ffp-contract=off).
+__global__ void pq_build_table_kernel(const float *__restrict__ queries,
+                                      const int8_t *__restrict__ codebooks,
+                                      const float *__restrict__ scales,
+                                      const float *__restrict__ offsets, int dim, int m, int k,
+                                      int subdim, float *__restrict__ tables)
+{
+    const int q = blockIdx.y;
+    const int j = blockIdx.x;
+    const float scale = scales[j];
+    const float offset = offsets[j];
+    const float *qs = queries + static_cast<int64_t>(q) * dim + j * subdim;
+    for (int c = threadIdx.x; c < k; c += blockDim.x) {
+        const int8_t *cb = codebooks + (static_cast<int64_t>(j) * k + c) * subdim;
+        float sum = 0.0f;
+        for (int i = 0; i < subdim; i++) {
+            float v = static_cast<float>(cb[i]) * scale;
+            v = v + offset;
+            float d = qs[i] - v;
+            float dd = d * d;
+            sum = sum + dd;
+        }
+        tables[(static_cast<int64_t>(q) * m + j) * k + c] = sum;
+    }
+}
+
+int32_t launch_pq_build_table(const vg_pq *pq, const float *d_queries, int64_t nq,
+                              float *d_tables, hipStream_t st)
+{
+    if (nq == 0) return VG_OK;
+    const int64_t maxy = 65535;
+    for (int64_t q0 = 0; q0 < nq; q0 += maxy) {
+        int64_t cnt = nq - q0 < maxy ? nq - q0 : maxy;
+        dim3 grid(static_cast<unsigned>(pq->m), static_cast<unsigned>(cnt));
+        hipLaunchKernelGGL(pq_build_table_kernel, grid, dim3(256), 0, st,
+                           d_queries + q0 * pq->dim, pq->d_codebooks, pq->d_scales,
+                           pq->d_offsets, pq->dim, pq->m, pq->k, pq->subdim,
+                           d_tables + q0 * pq->m * pq->k);
+    }
+    VG_HIP(hipGetLastError());
+    return VG_OK;
+}
+
+}  // namespace vg
+
+VG_API int32_t vg_pq_create(vg_ctx *ctx, int32_t dim, int32_t m, int32_t k, vg_pq **out)
+{
+    VG_CHECK(ctx && out, VG_ERR_INVALID_ARG, "vg_pq_create: NULL argument");
+    *out = nullptr;
+    // NewProductQuantizer pq.go:36-50
+    VG_CHECK(dim > 0 && m > 0, VG_ERR_INVALID_ARG,
+             "dimension and numSubvectors must be positive");
+    VG_CHECK(dim % m == 0, VG_ERR_INVALID_ARG, "dimension must be divisible by numSubvectors");
+    VG_CHECK(k > 0, VG_ERR_INVALID_ARG, "numCentroids must be positive");
+    VG_CHECK(k <= 256, VG_ERR_INVALID_ARG, "numCentroids must be <= 256 for uint8 encoding");
+    VG_HIP(hipSetDevice(ctx->device));
+    vg_pq *pq = new vg_pq();
+    pq->ctx = ctx;
+    pq->dim = dim;
+    pq->m = m;
+    pq->k = k;
+    pq->subdim = dim / m;
+    size_t cb = static_cast<size_t>(m) * k * pq->subdim;
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&pq->d_codebooks), cb);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&pq->d_scales), sizeof(float) * m);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&pq->d_offsets), sizeof(float) * m);
+    if (e != hipSuccess) {
+        vg::set_error("vg_pq_create: hipMalloc failed: %s", hipGetErrorString(e));
+        vg_pq_destroy(pq);
+        return VG_ERR_OUT_OF_MEMORY;
+    }
+    *out = pq;
+    return VG_OK;
+}
+
+VG_API int32_t vg_pq_destroy(vg_pq *pq)
+{
+    if (!pq) return VG_OK;
+    (void)hipSetDevice(pq->ctx->device);
+    if (pq->d_codebooks) (void)hipFree(pq->d_codebooks);
+    if (pq->d_scales) (void)hipFree(pq->d_scales);
+    if (pq->d_offsets) (void)hipFree(pq->d_offsets);
+    delete pq;
+    return VG_OK;
+}
+
+VG_API int32_t vg_pq_set_codebooks(vg_pq *pq, const int8_t *codebooks, const float *scales,
+                                   const float *offsets)
+{
+    VG_CHECK(pq && codebooks && scales && offsets, VG_ERR_INVALID_ARG,
+             "vg_pq_set_codebooks: NULL argument");
+    VG_HIP(hipSetDevice(pq->ctx->device));
+    hipStream_t st = pq->ctx->stream;
+    size_t cb = static_cast<size_t>(pq->m) * pq->k * pq->subdim;
+    VG_HIP(hipMemcpyAsync(pq->d_codebooks, codebooks, cb, hipMemcpyDefault, st));
+    VG_HIP(hipMemcpyAsync(pq->d_scales, scales, sizeof(float) * pq->m, hipMemcpyDefault, st));
+    VG_HIP(hipMemcpyAsync(pq->d_offsets, offsets, sizeof(float) * pq->m, hipMemcpyDefault, st));
+    VG_HIP(hipStreamSynchronize(st));
+    pq->trained = true;
+    return VG_OK;
+}
+
+VG_API int32_t vg_pq_get_codebooks(vg_pq *pq, int8_t *codebooks, float *scales, float *offsets)
+{
+    VG_CHECK(pq, VG_ERR_INVALID_ARG, "vg_pq_get_codebooks: NULL quantizer");
+    VG_CHECK(pq->trained, VG_ERR_NOT_TRAINED, "ProductQuantizer not trained");
+    VG_HIP(hipSetDevice(pq->ctx->device));
+    hipStream_t st = pq->ctx->stream;
+    size_t cb = static_cast<size_t>(pq->m) * pq->k * pq->subdim;
+    if (codebooks) VG_HIP(hipMemcpyAsync(codebooks, pq->d_codebooks, cb, hipMemcpyDefault, st));
+    if (scales) VG_HIP(hipMemcpyAsync(scales, pq->d_scales, sizeof(float) * pq->m, hipMemcpyDefault, st));
+    if (offsets) VG_HIP(hipMemcpyAsync(offsets, pq->d_offsets, sizeof(float) * pq->m, hipMemcpyDefault, st));
+    VG_HIP(hipStreamSynchronize(st));
+    return VG_OK;
+}
+
+VG_API int32_t vg_pq_is_trained(vg_pq *pq) { return pq && pq->trained ? 1 : 0; }
+
+VG_API int32_t vg_pq_build_distance_table(vg_pq *pq, const float *queries, int64_t nq,
+                                          float *tables, void *stream)
+{
+    VG_CHECK(pq, VG_ERR_INVALID_ARG, "vg_pq_build_distance_table: NULL quantizer");
+    VG_CHECK(pq->trained, VG_ERR_NOT_TRAINED, "ProductQuantizer not trained");
+    VG_CHECK(nq >= 0, VG_ERR_INVALID_ARG, "vg_pq_build_distance_table: nq < 0");
+    if (nq == 0) return VG_OK;
+    VG_CHECK(queries && tables, VG_ERR_INVALID_ARG, "vg_pq_build_distance_table: NULL buffer");
+    VG_HIP(hipSetDevice(pq->ctx->device));
+    hipStream_t st = vg::pick_stream(pq->ctx, stream);
+    vg::DevIn<float> q;
+    vg::DevOut<float> t;
+    VG_TRY(q.init(queries, static_cast<size_t>(nq) * pq->dim, st));
+    VG_TRY(t.init(tables, static_cast<size_t>(nq) * pq->m * pq->k, st));
+    VG_TRY(vg::launch_pq_build_table(pq, q.ptr, nq, t.ptr, st));
+    VG_TRY(t.finish());
+    if (t.on_host()) VG_HIP(hipStreamSynchronize(st));
+    return VG_OK;
+}

@@ -1,0 +1,145 @@
+// vg_api.hip — context, error plumbing and handle lifetime of the C ABI.
+#include "vg_internal.hpp"
+
+namespace vg {
+
+static thread_local std::string g_last_error;
+
+void set_error(const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+}
+
+bool is_device_ptr(const void *p)
+{
+    if (!p) return false;
+    hipPointerAttribute_t a;
+    hipError_t e = hipPointerGetAttributes(&a, p);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();  // plain malloc'd host memory
+        return false;
+    }
+    return a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeManaged;
+}
+
+}  // namespace vg
+
+VG_API int32_t vg_abi_version(void) { return VG_ABI_VERSION; }
+
+VG_API const char *vg_last_error(void) { return vg::g_last_error.c_str(); }
+
+VG_API const char *vg_status_string(int32_t s)
+{
+    switch (s) {
+    case VG_OK: return "ok";
+    case VG_ERR_INVALID_ARG: return "invalid argument";
+    case VG_ERR_DIM_MISMATCH: return "vector dimension mismatch";
+    case VG_ERR_NOT_TRAINED: return "ProductQuantizer not trained";
+    case VG_ERR_CODE_LENGTH: return "codes length mismatch";
+    case VG_ERR_UNSUPPORTED: return "unsupported";
+    case VG_ERR_OUT_OF_MEMORY: return "out of device memory";
+    case VG_ERR_HIP: return "HIP runtime error";
+    case VG_ERR_NO_DEVICE: return "no usable gfx950 device";
+    case VG_ERR_NOT_READY: return "index lacks the data this search needs";
+    default: return "unknown status";
+    }
+}
+
+VG_API int32_t vg_ctx_create(int32_t device, vg_ctx **out)
+{
+    VG_CHECK(out != nullptr, VG_ERR_INVALID_ARG, "vg_ctx_create: out is NULL");
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
+        (void)hipGetLastError();
+        vg::set_error("vg_ctx_create: no HIP device visible (the HIP path has no CPU fallback)");
+        return VG_ERR_NO_DEVICE;
+    }
+    VG_CHECK(device >= 0 && device < count, VG_ERR_INVALID_ARG,
+             "vg_ctx_create: device %d out of range (%d visible)", device, count);
+    VG_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    VG_HIP(hipGetDeviceProperties(&prop, device));
+    vg_ctx *ctx = new vg_ctx();
+    ctx->device = device;
+    ctx->compute_units = prop.multiProcessorCount;
+    ctx->hbm_bytes = static_cast<int64_t>(prop.totalGlobalMem);
+    snprintf(ctx->arch, sizeof ctx->arch, "%s", prop.gcnArchName);
+    if (strncmp(ctx->arch, "gfx950", 6) != 0) {
+        vg::set_error("vg_ctx_create: device %d is %s; this library carries gfx950 code only",
+                      device, ctx->arch);
+        delete ctx;
+        return VG_ERR_NO_DEVICE;
+    }
+    hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        vg::set_error("hipStreamCreate failed: %s", hipGetErrorString(e));
+        delete ctx;
+        return VG_ERR_HIP;
+    }
+    *out = ctx;
+    return VG_OK;
+}
+
+VG_API int32_t vg_ctx_destroy(vg_ctx *ctx)
+{
+    if (!ctx) return VG_OK;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) {
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipStreamDestroy(ctx->stream);
+    }
+    delete ctx;
+    return VG_OK;
+}
+
+VG_API int32_t vg_ctx_synchronize(vg_ctx *ctx, void *stream)
+{
+    VG_CHECK(ctx != nullptr, VG_ERR_INVALID_ARG, "vg_ctx_synchronize: ctx is NULL");
+    VG_HIP(hipSetDevice(ctx->device));
+    VG_HIP(hipStreamSynchronize(vg::pick_stream(ctx, stream)));
+    return VG_OK;
+}
+
+VG_API int32_t vg_ctx_device_info(vg_ctx *ctx, char *arch, int32_t arch_len,
+                                  int32_t *compute_units, int64_t *hbm_bytes)
+{
+    VG_CHECK(ctx != nullptr, VG_ERR_INVALID_ARG, "vg_ctx_device_info: ctx is NULL");
+    if (arch && arch_len > 0) snprintf(arch, static_cast<size_t>(arch_len), "%s", ctx->arch);
+    if (compute_units) *compute_units = ctx->compute_units;
+    if (hbm_bytes) *hbm_bytes = ctx->hbm_bytes;
+    return VG_OK;
+}
+
+VG_API int32_t vg_index_create(vg_ctx *ctx, int64_t n, int32_t dim, int32_t metric,
+                               vg_index **out)
+{
+    VG_CHECK(ctx && out, VG_ERR_INVALID_ARG, "vg_index_create: NULL argument");
+    *out = nullptr;
+    VG_CHECK(n >= 0 && n < 0xFFFFFFFFll, VG_ERR_INVALID_ARG,
+             "vg_index_create: n=%lld out of range (row ids are uint32)", (long long)n);
+    VG_CHECK(dim > 0, VG_ERR_INVALID_ARG, "vg_index_create: dim must be positive");
+    VG_CHECK(metric >= VG_METRIC_L2 && metric <= VG_METRIC_HAMMING, VG_ERR_UNSUPPORTED,
+             "vg_index_create: unknown metric %d", metric);
+    vg_index *idx = new vg_index();
+    idx->ctx = ctx;
+    idx->n = n;
+    idx->dim = dim;
+    idx->metric = metric;
+    *out = idx;
+    return VG_OK;
+}
+
+VG_API int32_t vg_index_destroy(vg_index *idx)
+{
+    if (!idx) return VG_OK;
+    (void)hipSetDevice(idx->ctx->device);
+    if (idx->d_pq_tiles) (void)hipFree(idx->d_pq_tiles);
+    delete idx;
+    return VG_OK;
+}
