@@ -10,6 +10,18 @@
 // so every wave-level load is one fully coalesced 1 KiB request and the scan streams
 // exactly N*G*16 bytes (= N*m when 16 | m).
 //
+// LDS bank conflicts: a 256-entry table row per sub-quantizer puts a wave's 64 random
+// lookups on random banks (ds_read_b32: 32 lanes over 32 banks, ~3.4 cycles per 32-lane
+// group instead of 1).  Full 16-wide groups therefore use a ROTATED image: lane i
+// (r = i & 15) reads, in slot s, sub-quantizer l = (s + r) & 15 of the group, and the LUT is
+// stored [g][c][l] so that bank = 16*(c & 1) + l — the 16 rotations of a 32-lane group never
+// collide, only the two lanes sharing a rotation can (p = 1/2).  The code bytes are
+// pre-rotated per lane at re-tile time so slot s is byte s of the lane's 16-byte word.
+// The rotation does not change the arithmetic: slot s accumulates the same
+// sub-quantizers (g ascending) as reference lane l = (s+r)&15, and the
+// _mm512_reduce_add_ps tree (i,i+8),(i,i+4),(i,i+2),(0,1) is invariant under a cyclic
+// rotation of its 16 inputs because fp32 addition is commutative.
+//
 // Per-row arithmetic = pqAdcLookupAvx512 (internal/simd/src/floats_avx512.c:135-167):
 // 16 lane accumulators acc[l] += table[(16g+l)*256 + code[16g+l]] for g ascending, the
 // _mm512_reduce_add_ps tree, then the m%16 tail added sequentially.  fp32 adds only.
@@ -18,7 +30,8 @@
 
 namespace vg {
 
-constexpr int kAdcWaves = 16;                 // 1024 threads: one workgroup per CU (LDS-bound)
+constexpr int kAdcWaves = 8;                  // 512 threads, one workgroup per CU (LDS holds the LUT):
+                                              // 2 waves/SIMD leaves each wave 256 VGPRs for deep prefetch
 constexpr int kAdcThreads = kAdcWaves * kWave;
 constexpr int kAdcSyncEvery = 2;              // iterations between candidate-buffer checks
 constexpr int kAdcBuf = 4096;                 // candidate keys in LDS (32 KiB)
@@ -39,8 +52,13 @@ __global__ void pq_retile_kernel(const uint8_t *__restrict__ codes, int64_t n, i
     if (row < n) {
         const uint8_t *src = codes + row * m + g * 16;
         int cnt = m - g * 16;
-        if (cnt > 16) cnt = 16;
-        for (int b = 0; b < cnt; b++) w[b >> 2] |= static_cast<uint32_t>(src[b]) << (8 * (b & 3));
+        if (cnt >= 16) {  // full group: slot s holds sub-quantizer (s + lane) & 15
+            for (int b = 0; b < 16; b++)
+                w[b >> 2] |= static_cast<uint32_t>(src[(b + lane) & 15]) << (8 * (b & 3));
+        } else {          // m % 16 tail: natural order (summed sequentially)
+            for (int b = 0; b < cnt; b++)
+                w[b >> 2] |= static_cast<uint32_t>(src[b]) << (8 * (b & 3));
+        }
     }
     tiles[gid] = make_uint4(w[0], w[1], w[2], w[3]);
 }
@@ -49,6 +67,59 @@ __device__ __forceinline__ uint32_t code_byte(const uint4 &c, int l)
 {
     uint32_t w = (l < 4) ? c.x : (l < 8) ? c.y : (l < 12) ? c.z : c.w;
     return (w >> (8 * (l & 3))) & 0xFFu;
+}
+
+
+// ---- hand-pipelined LDS gathers -------------------------------------------------------------
+// hipcc waits after every few ds_read_b32 of an unrolled gather, which at 2 waves/SIMD leaves the
+// LDS pipe mostly idle.  The scan issues each 16-lookup group as 16 back-to-back ds_read_b32 in
+// inline asm and retires it with a COUNTED s_waitcnt while the next group's 16 reads are already
+// in flight.  hipcc does not track asm loads: every value is an in/out operand of the wait
+// statement, so no consumer can be scheduled above it (cdna_hip_programming.md §5.7).
+struct Vals8 {
+    float v[8];
+};
+
+template <int OFF>
+__device__ __forceinline__ float lds_read_off(uint32_t addr)
+{
+    float v;
+    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+    return v;
+}
+
+// wait until at most N (<= 15: lgkmcnt is 4 bits) LGKM operations are outstanding; ties the 8
+// values to the wait so no consumer can move above it
+template <int N>
+__device__ __forceinline__ void lds_wait(Vals8 &x)
+{
+    asm volatile("s_waitcnt lgkmcnt(%8)"
+                 : "+v"(x.v[0]), "+v"(x.v[1]), "+v"(x.v[2]), "+v"(x.v[3]), "+v"(x.v[4]),
+                   "+v"(x.v[5]), "+v"(x.v[6]), "+v"(x.v[7])
+                 : "n"(N));
+}
+
+// issue 8 rotated lookups (half H of group G) for code word c: slot s reads
+// lut[g][code byte s][(s + rot) & 15]; byte address = G*16384 + byte*64 + rotoff[s]
+template <int G, int H>
+__device__ __forceinline__ void issue_half(Vals8 &dst, const uint4 &c, const uint32_t (&rotoff)[16])
+{
+    // ds offsets are 16-bit: groups 4+ go through a base bumped by 64 KiB
+    constexpr int OFF = (G & 3) * 16384;
+    constexpr uint32_t BUMP = (G >> 2) * 65536u;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const int sl = H * 8 + i;
+        const uint32_t addr = (code_byte(c, sl) << 6) + rotoff[sl] + BUMP;
+        dst.v[i] = lds_read_off<OFF>(addr);
+    }
+}
+
+template <int H>
+__device__ __forceinline__ void accumulate_half(float (&acc)[16], const Vals8 &x)
+{
+#pragma unroll
+    for (int i = 0; i < 8; i++) acc[H * 8 + i] = acc[H * 8 + i] + x.v[i];
 }
 
 struct AdcShared {
@@ -60,7 +131,9 @@ struct AdcShared {
 
 // GF = number of full 16-wide groups when known at compile time (m = 16*GF exactly),
 // or -1 for the generic shape (runtime full groups + tail).
-template <int GF>
+// SMALLK: k <= 64 — each wave keeps its top-k in registers (WaveTopK) and the scan loop has
+// no workgroup barrier; otherwise candidates go through the shared LDS buffer.
+template <int GF, bool SMALLK>
 __global__ __launch_bounds__(kAdcThreads) void pq_adc_scan_kernel(
     const uint4 *__restrict__ tiles, int64_t n_rows, int64_t n_tiles, int m, int groups,
     const float *__restrict__ tables, int slices, int nq, int k, uint64_t *__restrict__ partial)
@@ -84,11 +157,25 @@ __global__ __launch_bounds__(kAdcThreads) void pq_adc_scan_kernel(
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
+    const int rot = lane & 15;
+    const float *lut_rot = lut;  // full groups: [g][c][l]; tail rows follow in [j][c] order
 
     {   // stage this query's lookup table (m KiB) into LDS with 16-byte loads
         const float4 *src = reinterpret_cast<const float4 *>(tables + static_cast<int64_t>(q) * m * 256);
         float4 *dst = reinterpret_cast<float4 *>(lut);
-        for (int i = tid; i < m * 64; i += kAdcThreads) dst[i] = src[i];
+        // 4 independent 16-byte loads in flight per thread.  No per-load guards: a guarded load
+        // makes hipcc branch around it and wait vmcnt(0) each time (serialized L2 round trips).
+        const int n4 = m * 64;
+        const int rounds = n4 / kAdcThreads;
+        int r = 0;
+        for (; r + 4 <= rounds; r += 4) {
+            float4 tmp[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) tmp[u] = src[(r + u) * kAdcThreads + tid];
+#pragma unroll
+            for (int u = 0; u < 4; u++) dst[(r + u) * kAdcThreads + tid] = tmp[u];
+        }
+        for (int i = r * kAdcThreads + tid; i < n4; i += kAdcThreads) dst[i] = src[i];
     }
     if (tid == 0) {
         sh->cnt = 0;
@@ -96,12 +183,28 @@ __global__ __launch_bounds__(kAdcThreads) void pq_adc_scan_kernel(
     }
     __syncthreads();
     uint64_t tau = kKeyMax;
+    WaveTopK wtk;
+    wtk.init(k);
 
     const int gfull = (GF >= 0) ? GF : (m >> 4);
     const int tail = (GF >= 0) ? 0 : (m & 15);
     const int64_t span = t1 - t0;
     const int iters = static_cast<int>((span + kAdcWaves - 1) / kAdcWaves);
 
+    // software pipeline: the next tile's 16-byte code words are in flight while this
+    // tile's lookups run (GF known at compile time)
+    uint4 nxt[GF > 0 ? GF : 1];
+    uint32_t rotoff[16];
+#pragma unroll
+    for (int sl = 0; sl < 16; sl++) rotoff[sl] = static_cast<uint32_t>(((sl + rot) & 15) * 4);
+    if (GF > 0) {
+        const int64_t tile0 = t0 + wave;
+        if (tile0 < t1) {
+            const uint4 *tp0 = tiles + (tile0 * groups) * 64 + lane;
+#pragma unroll
+            for (int g = 0; g < GF; g++) nxt[g] = tp0[g * 64];
+        }
+    }
     for (int it = 0; it < iters; it++) {
         const int64_t tile = t0 + static_cast<int64_t>(it) * kAdcWaves + wave;
         if (tile < t1) {
@@ -109,22 +212,58 @@ __global__ __launch_bounds__(kAdcThreads) void pq_adc_scan_kernel(
             float acc[16];
 #pragma unroll
             for (int l = 0; l < 16; l++) acc[l] = 0.0f;
-            if (GF >= 0) {
+            if (GF == 6) {
+                uint4 c[6];
+#pragma unroll
+                for (int g = 0; g < 6; g++) c[g] = nxt[g];
+                if (tile + kAdcWaves < t1) {
+                    const uint4 *tn = tp + static_cast<int64_t>(kAdcWaves) * groups * 64;
+#pragma unroll
+                    for (int g = 0; g < 6; g++) nxt[g] = tn[g * 64];
+                }
+                // two register sets ping-pong: the next 8 lookups are in flight while the
+                // previous 8 retire (same order of additions per slot: g ascending)
+                Vals8 va, vb;
+                issue_half<0, 0>(va, c[0], rotoff);
+#define VG_STEP(GA, HA, GB, HB, X, Y)            \
+    issue_half<GB, HB>(Y, c[GB], rotoff);        \
+    lds_wait<8>(X);                              \
+    accumulate_half<HA>(acc, X);
+                VG_STEP(0, 0, 0, 1, va, vb)
+                VG_STEP(0, 1, 1, 0, vb, va)
+                VG_STEP(1, 0, 1, 1, va, vb)
+                VG_STEP(1, 1, 2, 0, vb, va)
+                VG_STEP(2, 0, 2, 1, va, vb)
+                VG_STEP(2, 1, 3, 0, vb, va)
+                VG_STEP(3, 0, 3, 1, va, vb)
+                VG_STEP(3, 1, 4, 0, vb, va)
+                VG_STEP(4, 0, 4, 1, va, vb)
+                VG_STEP(4, 1, 5, 0, vb, va)
+                VG_STEP(5, 0, 5, 1, va, vb)
+#undef VG_STEP
+                lds_wait<0>(vb);
+                accumulate_half<1>(acc, vb);
+            } else if (GF >= 0) {
                 uint4 c[GF > 0 ? GF : 1];
 #pragma unroll
-                for (int g = 0; g < GF; g++) c[g] = tp[g * 64];
+                for (int g = 0; g < GF; g++) c[g] = nxt[g];
+                if (tile + kAdcWaves < t1) {
+                    const uint4 *tn = tp + static_cast<int64_t>(kAdcWaves) * groups * 64;
+#pragma unroll
+                    for (int g = 0; g < GF; g++) nxt[g] = tn[g * 64];
+                }
 #pragma unroll
                 for (int g = 0; g < GF; g++) {
 #pragma unroll
-                    for (int l = 0; l < 16; l++)
-                        acc[l] = acc[l] + lut[(g * 16 + l) * 256 + code_byte(c[g], l)];
+                    for (int sl = 0; sl < 16; sl++)
+                        acc[sl] = acc[sl] + lut_rot[(g * 256 + code_byte(c[g], sl)) * 16 + ((sl + rot) & 15)];
                 }
             } else {
                 for (int g = 0; g < gfull; g++) {
                     uint4 c = tp[g * 64];
 #pragma unroll
-                    for (int l = 0; l < 16; l++)
-                        acc[l] = acc[l] + lut[(g * 16 + l) * 256 + code_byte(c, l)];
+                    for (int sl = 0; sl < 16; sl++)
+                        acc[sl] = acc[sl] + lut_rot[(g * 256 + code_byte(c, sl)) * 16 + ((sl + rot) & 15)];
                 }
             }
             float total = reduce16_regs(acc);
@@ -134,14 +273,16 @@ __global__ __launch_bounds__(kAdcThreads) void pq_adc_scan_kernel(
                     total = total + lut[(gfull * 16 + l) * 256 + code_byte(c, l)];
             }
             const int64_t row = tile * 64 + lane;
-            if (row < n_rows) {
-                uint64_t key = make_key(total, static_cast<uint32_t>(row), false);
-                if (key < tau) {
-                    int pos = atomicAdd(&sh->cnt, 1);
-                    buf[pos] = key;  // pos < kAdcBuf by the sync protocol below
-                }
+            uint64_t key = (row < n_rows) ? make_key(total, static_cast<uint32_t>(row), false)
+                                          : kKeyMax;
+            if (SMALLK) {
+                wtk.offer(key, lane);
+            } else if (key < tau) {
+                int pos = atomicAdd(&sh->cnt, 1);
+                buf[pos] = key;  // pos < kAdcBuf by the sync protocol below
             }
         }
+        if (SMALLK) continue;
         // Every kAdcSyncEvery iterations at most kAdcSyncEvery*1024 keys were appended;
         // compact when the next round could overflow the buffer.
         if ((it % kAdcSyncEvery) == kAdcSyncEvery - 1 || it == iters - 1) {
@@ -163,12 +304,35 @@ __global__ __launch_bounds__(kAdcThreads) void pq_adc_scan_kernel(
         }
     }
     uint64_t *out = partial + (static_cast<int64_t>(q) * slices + s) * k;
+    if (SMALLK) {
+        // Rank-merge the 16 per-wave sorted lists: a key's final position is its own index
+        // plus the number of smaller keys in every other wave's list (keys are unique).
+        uint64_t *lists = buf;              // [kAdcWaves][64]
+        int *valid = reinterpret_cast<int *>(buf + kAdcWaves * 64);
+        lists[wave * 64 + lane] = wtk.list;
+        const int nvalid = __popcll(__ballot(wtk.list != kKeyMax));
+        if (lane == 0) valid[wave] = nvalid;
+        __syncthreads();
+        const uint64_t e = wtk.list;
+        if (e != kKeyMax) {
+            int rank = lane;
+            for (int w = 0; w < kAdcWaves; w++)
+                if (w != wave) rank += lower_bound64(lists + w * 64, e);
+            if (rank < k) out[rank] = e;
+        }
+        int total = 0;
+        for (int w = 0; w < kAdcWaves; w++) total += valid[w];
+        for (int i = total + tid; i < k; i += kAdcThreads) out[i] = kKeyMax;
+        return;
+    }
     const int have = sh->cnt;
     for (int i = tid; i < k; i += kAdcThreads) out[i] = (i < have) ? buf[i] : kKeyMax;
 }
 
-// One workgroup per query: merges `lists` sorted-or-not key lists of length k each into
-// the k best keys, best first, and decodes them to (id, score).
+// One workgroup per query: merges `lists` ascending key lists of length k (kKeyMax padded)
+// into the k best keys, best first, and decodes them to (id, score).
+// Pruning: the k-th key of any single list bounds the global k-th key from above, so only
+// keys <= T = min_l list_l[k-1] can make the result; typically ~k*H(lists) keys survive.
 constexpr int kMergeThreads = 256;
 constexpr int kMergeBuf = 4096;
 __global__ __launch_bounds__(kMergeThreads) void topk_merge_kernel(
@@ -176,31 +340,86 @@ __global__ __launch_bounds__(kMergeThreads) void topk_merge_kernel(
     uint32_t *__restrict__ ids, float *__restrict__ scores)
 {
     __shared__ uint64_t buf[kMergeBuf];
+    __shared__ unsigned long long tmin;
+    __shared__ int cnt;
     const int q = blockIdx.x;
     const int tid = threadIdx.x;
     const uint64_t *src = partial + static_cast<int64_t>(q) * lists * k;
     const int64_t total = static_cast<int64_t>(lists) * k;
-    int have = 0;  // running best keys occupy buf[0..have)
-    int64_t pos = 0;
-    do {
-        int room = kMergeBuf - have;
-        int take = static_cast<int>((total - pos) < room ? (total - pos) : room);
-        for (int i = tid; i < take; i += kMergeThreads) buf[have + i] = src[pos + i];
-        for (int i = have + take + tid; i < kMergeBuf; i += kMergeThreads) buf[i] = kKeyMax;
-        __syncthreads();
-        bitonic_sort_lds(buf, kMergeBuf, tid, kMergeThreads);
-        pos += take;
-        have = k;  // k <= kAdcMaxK < kMergeBuf; slots past the real keys hold kKeyMax
-    } while (pos < total);
-    for (int i = tid; i < k; i += kMergeThreads) {
-        uint64_t key = buf[i];
-        if (key == kKeyMax) {
-            ids[static_cast<int64_t>(q) * k + i] = VG_INVALID_ID;
-            scores[static_cast<int64_t>(q) * k + i] = descending ? -INFINITY : INFINITY;
-        } else {
-            ids[static_cast<int64_t>(q) * k + i] = key_row(key);
-            scores[static_cast<int64_t>(q) * k + i] = key_score(key, descending);
+    uint32_t *oid = ids + static_cast<int64_t>(q) * k;
+    float *osc = scores + static_cast<int64_t>(q) * k;
+    if (tid == 0) {
+        tmin = kKeyMax;
+        cnt = 0;
+    }
+    __syncthreads();
+    uint64_t t = kKeyMax;
+    for (int l = tid; l < lists; l += kMergeThreads) {
+        uint64_t v = src[static_cast<int64_t>(l) * k + (k - 1)];
+        t = v < t ? v : t;
+    }
+    if (t != kKeyMax) atomicMin(&tmin, static_cast<unsigned long long>(t));
+    __syncthreads();
+    const uint64_t T = tmin;
+    // lists are ascending: walk each from its head while keys stay <= T (usually 0-2 steps)
+    for (int l = tid; l < lists; l += kMergeThreads) {
+        const uint64_t *lp = src + static_cast<int64_t>(l) * k;
+        for (int i = 0; i < k; i++) {
+            const uint64_t key = lp[i];
+            if (key == kKeyMax || key > T) break;
+            int pos = atomicAdd(&cnt, 1);
+            if (pos < kMergeBuf) buf[pos] = key;
         }
+    }
+    __syncthreads();
+    const int c = cnt;
+    int have;
+    if (c <= 1024) {
+        // brute-force rank among the survivors (keys are unique)
+        for (int i = tid; i < c; i += kMergeThreads) {
+            const uint64_t e = buf[i];
+            int rank = 0;
+            for (int j = 0; j < c; j++) rank += (buf[j] < e) ? 1 : 0;
+            if (rank < k) {
+                oid[rank] = key_row(e);
+                osc[rank] = key_score(e, descending);
+            }
+        }
+        have = c < k ? c : k;
+    } else {
+        // many survivors (heavy ties / adversarial order): chunked sort of everything
+        int kept = 0;
+        int64_t pos = 0;
+        __syncthreads();
+        do {
+            int room = kMergeBuf - kept;
+            int take = static_cast<int>((total - pos) < room ? (total - pos) : room);
+            for (int i = tid; i < take; i += kMergeThreads) buf[kept + i] = src[pos + i];
+            for (int i = kept + take + tid; i < kMergeBuf; i += kMergeThreads) buf[i] = kKeyMax;
+            __syncthreads();
+            bitonic_sort_lds(buf, kMergeBuf, tid, kMergeThreads);
+            pos += take;
+            kept = k;  // k <= kAdcMaxK < kMergeBuf; slots past the real keys hold kKeyMax
+        } while (pos < total);
+        have = 0;
+        for (int i = tid; i < k; i += kMergeThreads) {
+            const uint64_t e = buf[i];
+            if (e != kKeyMax) {
+                oid[i] = key_row(e);
+                osc[i] = key_score(e, descending);
+            }
+        }
+        // count real keys among the first k (uniform across threads)
+        int lo = 0, hi = k;
+        while (lo < hi) {
+            int mid = (lo + hi) >> 1;
+            if (buf[mid] != kKeyMax) lo = mid + 1; else hi = mid;
+        }
+        have = lo;
+    }
+    for (int i = have + tid; i < k; i += kMergeThreads) {
+        oid[i] = VG_INVALID_ID;
+        osc[i] = descending ? -INFINITY : INFINITY;
     }
 }
 
@@ -215,7 +434,7 @@ int32_t launch_topk_merge(const uint64_t *partial, int64_t nq, int lists, int k,
 }
 
 int32_t launch_pq_build_table(const vg_pq *pq, const float *d_queries, int64_t nq,
-                              float *d_tables, hipStream_t st);
+                              float *d_tables, bool scan_layout, hipStream_t st);
 
 static int adc_slices(int64_t nq, int64_t n_tiles, int cus)
 {
@@ -231,14 +450,14 @@ static int adc_slices(int64_t nq, int64_t n_tiles, int cus)
     return static_cast<int>(s);
 }
 
-template <int GF>
+template <int GF, bool SMALLK>
 static int32_t launch_scan(const vg_index *idx, const float *tables, int64_t nq, int k,
                            int slices, uint64_t *partial, hipStream_t st)
 {
     const vg_pq *pq = idx->pq;
     size_t lds = static_cast<size_t>(pq->m) * 256 * sizeof(float) + kAdcBuf * sizeof(uint64_t) +
                  sizeof(AdcShared);
-    auto kern = pq_adc_scan_kernel<GF>;
+    auto kern = pq_adc_scan_kernel<GF, SMALLK>;
     VG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
     // grid.x limit is 2^31-1; chunk the queries if needed
@@ -327,11 +546,15 @@ VG_API int32_t vg_search_pq_adc(vg_index *idx, const float *queries, int64_t nq,
         vg::DevTmp<uint64_t> partial;
         VG_TRY(tables.init(static_cast<size_t>(nq) * pq->m * 256, st));
         VG_TRY(partial.init(static_cast<size_t>(nq) * slices * k, st));
-        VG_TRY(vg::launch_pq_build_table(pq, q.ptr, nq, tables.ptr, st));
-        if (pq->m == 96)
-            VG_TRY(vg::launch_scan<6>(idx, tables.ptr, nq, k, slices, partial.ptr, st));
+        VG_TRY(vg::launch_pq_build_table(pq, q.ptr, nq, tables.ptr, true, st));
+        if (pq->m == 96 && k <= 64)
+            VG_TRY((vg::launch_scan<6, true>(idx, tables.ptr, nq, k, slices, partial.ptr, st)));
+        else if (pq->m == 96)
+            VG_TRY((vg::launch_scan<6, false>(idx, tables.ptr, nq, k, slices, partial.ptr, st)));
+        else if (k <= 64)
+            VG_TRY((vg::launch_scan<-1, true>(idx, tables.ptr, nq, k, slices, partial.ptr, st)));
         else
-            VG_TRY(vg::launch_scan<-1>(idx, tables.ptr, nq, k, slices, partial.ptr, st));
+            VG_TRY((vg::launch_scan<-1, false>(idx, tables.ptr, nq, k, slices, partial.ptr, st)));
         VG_TRY(vg::launch_topk_merge(partial.ptr, nq, slices, k, false, oid.ptr, osc.ptr, st));
     }
     VG_TRY(oid.finish());

@@ -9,6 +9,9 @@ namespace vg {
 //   v = float32(code)*scale + offset ; d = q - v ; sum += d*d   — five separately
 // rounded fp32 ops per term, sequential over the sub-dimension (Go on amd64 does not
 // fuse; this TU is built with -ffp-contract=off).
+// SCAN_LAYOUT: write the image the ADC scan keeps in LDS (k_adc.hip): sub-quantizers of the
+// full 16-wide groups as [g][c][l], the m%16 tail rows after them as [j][c].  Same values.
+template <bool SCAN_LAYOUT>
 __global__ void pq_build_table_kernel(const float *__restrict__ queries,
                                       const int8_t *__restrict__ codebooks,
                                       const float *__restrict__ scales,
@@ -30,22 +33,24 @@ __global__ void pq_build_table_kernel(const float *__restrict__ queries,
             float dd = d * d;
             sum = sum + dd;
         }
-        tables[(static_cast<int64_t>(q) * m + j) * k + c] = sum;
+        int64_t at = static_cast<int64_t>(j) * k + c;
+        if (SCAN_LAYOUT && j < (m & ~15)) at = (static_cast<int64_t>(j >> 4) * 256 + c) * 16 + (j & 15);
+        tables[static_cast<int64_t>(q) * m * k + at] = sum;
     }
 }
 
 int32_t launch_pq_build_table(const vg_pq *pq, const float *d_queries, int64_t nq,
-                              float *d_tables, hipStream_t st)
+                              float *d_tables, bool scan_layout, hipStream_t st)
 {
     if (nq == 0) return VG_OK;
     const int64_t maxy = 65535;
     for (int64_t q0 = 0; q0 < nq; q0 += maxy) {
         int64_t cnt = nq - q0 < maxy ? nq - q0 : maxy;
         dim3 grid(static_cast<unsigned>(pq->m), static_cast<unsigned>(cnt));
-        hipLaunchKernelGGL(pq_build_table_kernel, grid, dim3(256), 0, st,
-                           d_queries + q0 * pq->dim, pq->d_codebooks, pq->d_scales,
-                           pq->d_offsets, pq->dim, pq->m, pq->k, pq->subdim,
-                           d_tables + q0 * pq->m * pq->k);
+        auto kern = scan_layout ? pq_build_table_kernel<true> : pq_build_table_kernel<false>;
+        hipLaunchKernelGGL(kern, grid, dim3(256), 0, st, d_queries + q0 * pq->dim,
+                           pq->d_codebooks, pq->d_scales, pq->d_offsets, pq->dim, pq->m, pq->k,
+                           pq->subdim, d_tables + q0 * pq->m * pq->k);
     }
     VG_HIP(hipGetLastError());
     return VG_OK;
@@ -140,7 +145,7 @@ VG_API int32_t vg_pq_build_distance_table(vg_pq *pq, const float *queries, int64
     vg::DevOut<float> t;
     VG_TRY(q.init(queries, static_cast<size_t>(nq) * pq->dim, st));
     VG_TRY(t.init(tables, static_cast<size_t>(nq) * pq->m * pq->k, st));
-    VG_TRY(vg::launch_pq_build_table(pq, q.ptr, nq, t.ptr, st));
+    VG_TRY(vg::launch_pq_build_table(pq, q.ptr, nq, t.ptr, false, st));
     VG_TRY(t.finish());
     if (t.on_host()) VG_HIP(hipStreamSynchronize(st));
     return VG_OK;

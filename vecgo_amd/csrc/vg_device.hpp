@@ -79,4 +79,58 @@ __device__ __forceinline__ float reduce16_regs(const float (&s)[16])
     return c[0] + c[1];
 }
 
+// ---------------------------------------------------------------------------------
+// Per-wave top-k (k <= 64) held in registers: lane i owns the i-th best key seen by this
+// wave.  Insertion is branch-uniform and touches no LDS memory, so a streaming scan needs no
+// workgroup barrier.  After the first tile the pass rate is ~k/rows_seen, so the insert
+// loop is cold.
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t readlane_u64(uint64_t v, int lane)
+{
+    uint32_t lo = __builtin_amdgcn_readlane(static_cast<uint32_t>(v), lane);
+    uint32_t hi = __builtin_amdgcn_readlane(static_cast<uint32_t>(v >> 32), lane);
+    return (static_cast<uint64_t>(hi) << 32) | lo;
+}
+
+struct WaveTopK {
+    uint64_t list;  // lane i: i-th smallest key of this wave so far
+    uint64_t tau;   // wave-uniform: key at lane k-1 (kKeyMax until k keys were seen)
+    int k;
+    __device__ __forceinline__ void init(int k_)
+    {
+        list = kKeyMax;
+        tau = kKeyMax;
+        k = k_;
+    }
+    // every lane offers one key (kKeyMax = nothing)
+    __device__ __forceinline__ void offer(uint64_t key, int lane)
+    {
+        uint64_t mask = __ballot(key < tau);
+        while (mask) {
+            const int j = __builtin_ctzll(mask);
+            mask &= mask - 1;
+            const uint64_t c = readlane_u64(key, j);
+            if (c < tau) {  // wave-uniform: tau may have dropped since the ballot
+                uint32_t llo = __shfl_up(static_cast<uint32_t>(list), 1);
+                uint32_t lhi = __shfl_up(static_cast<uint32_t>(list >> 32), 1);
+                const uint64_t left = (static_cast<uint64_t>(lhi) << 32) | llo;
+                const bool keep = list < c;
+                const bool left_lt = (lane == 0) || (left < c);
+                list = keep ? list : (left_lt ? c : left);
+                tau = readlane_u64(list, k - 1);
+            }
+        }
+    }
+};
+
+// number of keys < e in sorted[0..64) (ascending; unused slots hold kKeyMax)
+__device__ __forceinline__ int lower_bound64(const uint64_t *sorted, uint64_t e)
+{
+    int pos = 0;
+#pragma unroll
+    for (int step = 32; step > 0; step >>= 1)
+        if (sorted[pos + step - 1] < e) pos += step;
+    return pos + (sorted[pos] < e ? 1 : 0);
+}
+
 }  // namespace vg
