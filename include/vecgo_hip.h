@@ -102,7 +102,32 @@ int32_t vg_index_destroy(vg_index *idx);
  * quantizer handle must outlive the index. */
 int32_t vg_index_set_pq_codes(vg_index *idx, vg_pq *pq, const uint8_t *codes, void *stream);
 
+/* fp32 rows of the segment, n*dim row-major — the layout of
+ * vectorstore.ColumnarStore (internal/vectorstore/columnar.go:21-24) and of
+ * flat.Segment.vectors (flat/segment.go:692).  Copied to HBM. */
+int32_t vg_index_set_vectors(vg_index *idx, const float *base, void *stream);
+
+/* ---- L0 batch kernels: the dispatch seam (internal/simd/kernels.go:11-30) ------- */
+/* simd.SquaredL2Batch / simd.DotBatch (kernels.go:61-68 → batch_avx512.c:19-143):
+ * one query against n contiguous targets; out[n].  Bit-identical to the AVX-512
+ * kernels (4x16 FMA accumulators, 16-wide tail, reduce_add tree, FMA scalar tail). */
+int32_t vg_squared_l2_batch(vg_ctx *ctx, const float *query, const float *targets, int64_t dim,
+                            int64_t n, float *out, void *stream);
+int32_t vg_dot_batch(vg_ctx *ctx, const float *query, const float *targets, int64_t dim,
+                     int64_t n, float *out, void *stream);
+
 /* ---- searches ---------------------------------------------------------------- */
+/* Segment.Rerank (flat/segment.go:754-780, diskann/segment.go:1093-1116,
+ * engine/search.go:914-965): exact distance.SquaredL2 / distance.Dot
+ * (squaredL2Avx512 / dotProductAvx512 order) of each query against its own nc
+ * candidate rows, then the best k by (Score, RowID).  cand_ids[nq*nc] may hold
+ * VG_INVALID_ID (skipped).  k <= nc; k <= 64 per call. */
+int32_t vg_rerank(vg_index *idx, const float *queries, int64_t nq, const uint32_t *cand_ids,
+                  int32_t nc, int32_t k, uint32_t *ids, float *scores, void *stream);
+/* exact scores only, scores[nq*nc] in candidate order (invalid ids → +Inf / -Inf) */
+int32_t vg_score_candidates(vg_index *idx, const float *queries, int64_t nq,
+                            const uint32_t *cand_ids, int32_t nc, float *scores, void *stream);
+
 /* flat.Segment.Search, PQ branch (flat/segment.go:476-483 LUT, :678-689 ADC
  * = simd.PqAdcLookup in pqAdcLookupAvx512 order, :714-721 top-k with the
  * (Score, RowID) tie-break of searcher/candidate_queue.go:12-23).

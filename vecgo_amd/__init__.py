@@ -4,6 +4,8 @@ The product is libvecgo_hip.so (C ABI: include/vecgo_hip.h).  This package is th
 Python binding the tests and bench.py drive it with; names mirror the reference's Go
 interfaces (distance.Metric, quantization.ProductQuantizer, ...).
 """
-from .api import (Context, Index, Metric, ProductQuantizer, VecgoHipError)  # noqa: F401
+from .api import (Context, Index, Metric, ProductQuantizer, VecgoHipError, dot_batch,  # noqa: F401
+                  squared_l2_batch)
 
-__all__ = ["Context", "Index", "Metric", "ProductQuantizer", "VecgoHipError"]
+__all__ = ["Context", "Index", "Metric", "ProductQuantizer", "VecgoHipError", "dot_batch",
+           "squared_l2_batch"]

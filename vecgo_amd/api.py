@@ -91,6 +91,27 @@ class Context:
         return {"arch": arch.value.decode(), "compute_units": cus.value, "hbm_bytes": hbm.value}
 
 
+def squared_l2_batch(ctx: Context, query, targets, dim: int, out=None, stream=None):
+    """simd.SquaredL2Batch (internal/simd/kernels.go:66-68)."""
+    return _batch(ctx, ctx._lib.vg_squared_l2_batch, query, targets, dim, out, stream)
+
+
+def dot_batch(ctx: Context, query, targets, dim: int, out=None, stream=None):
+    """simd.DotBatch (internal/simd/kernels.go:61-63)."""
+    return _batch(ctx, ctx._lib.vg_dot_batch, query, targets, dim, out, stream)
+
+
+def _batch(ctx, fn, query, targets, dim, out, stream):
+    n = (targets.numel() if _is_torch(targets) else np.asarray(targets).size) // dim if dim > 0 else 0
+    q, pq_ = _ptr(query, np.float32)
+    t, pt = _ptr(targets, np.float32)
+    if out is None:
+        out = _empty_like(targets, (n,), np.float32)
+    o, po = _ptr(out, np.float32, n)
+    check(fn(ctx._h, pq_, pt, C.c_int64(dim), C.c_int64(n), po, _stream_ptr(stream)))
+    return out
+
+
 class ProductQuantizer:
     """quantization.ProductQuantizer (internal/quantization/pq.go:20-29)."""
 
@@ -185,6 +206,37 @@ class Index:
         c, pc = _ptr(codes, np.uint8, self.n * pq.num_subvectors)
         self._keep.append(pq)
         check(self._lib.vg_index_set_pq_codes(self._h, pq._h, pc, _stream_ptr(stream)))
+
+    def set_vectors(self, base, stream=None):
+        """fp32 rows, n*dim row-major (vectorstore/columnar.go:21-24)."""
+        b, pb = _ptr(base, np.float32, self.n * self.dim)
+        check(self._lib.vg_index_set_vectors(self._h, pb, _stream_ptr(stream)))
+
+    def rerank(self, queries, cand_ids, k, out=None, stream=None):
+        """Segment.Rerank + top-k (flat/segment.go:754-780): cand_ids is [nq, nc]."""
+        nq = _rows(queries, self.dim)
+        nc = (cand_ids.numel() if _is_torch(cand_ids) else np.asarray(cand_ids).size) // max(nq, 1)
+        q, pq_ = _ptr(queries, np.float32)
+        c, pc = _ptr(cand_ids, np.uint32, nq * nc)
+        if out is None:
+            out = (_empty_like(queries, (nq, k), np.uint32), _empty_like(queries, (nq, k), np.float32))
+        i, pi = _ptr(out[0], np.uint32, nq * k)
+        s, ps = _ptr(out[1], np.float32, nq * k)
+        check(self._lib.vg_rerank(self._h, pq_, C.c_int64(nq), pc, C.c_int32(nc), C.c_int32(k), pi, ps,
+                                  _stream_ptr(stream)))
+        return out
+
+    def score_candidates(self, queries, cand_ids, out=None, stream=None):
+        nq = _rows(queries, self.dim)
+        nc = (cand_ids.numel() if _is_torch(cand_ids) else np.asarray(cand_ids).size) // max(nq, 1)
+        q, pq_ = _ptr(queries, np.float32)
+        c, pc = _ptr(cand_ids, np.uint32, nq * nc)
+        if out is None:
+            out = _empty_like(queries, (nq, nc), np.float32)
+        s, ps = _ptr(out, np.float32, nq * nc)
+        check(self._lib.vg_score_candidates(self._h, pq_, C.c_int64(nq), pc, C.c_int32(nc), ps,
+                                            _stream_ptr(stream)))
+        return out
 
     def _search(self, fn, queries, k, extra=(), out=None, stream=None):
         nq = _rows(queries, self.dim)

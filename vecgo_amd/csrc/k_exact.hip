@@ -1,0 +1,245 @@
+// k_exact.hip — exact fp32 scoring in the reference's summation order: simd batch kernels,
+// Segment.Rerank, candidate scoring.  16 lanes per (query, row) pair, 4 pairs per wave.
+#include "vg_device.hpp"
+#include "vg_exact.hpp"
+#include "vg_internal.hpp"
+
+namespace vg {
+
+constexpr int kExactThreads = 256;  // 4 waves = 16 pair-groups per workgroup
+
+// simd.SquaredL2Batch / DotBatch: one query, n contiguous targets.
+template <bool DOT>
+__global__ __launch_bounds__(kExactThreads) void batch_kernel(const float *__restrict__ query,
+                                                              const float *__restrict__ targets,
+                                                              int dim, int64_t n,
+                                                              float *__restrict__ out)
+{
+    const Sub16 sub = Sub16::make(threadIdx.x);
+    const int64_t groups = static_cast<int64_t>(gridDim.x) * (kExactThreads / 16);
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * (kExactThreads / 16) + (threadIdx.x >> 4);
+         i < n; i += groups) {
+        const float v = exact_pair16<DOT, kBatch>(targets + i * dim, query, dim, sub);
+        if ((threadIdx.x & 15) == 0) out[i] = v;
+    }
+}
+
+// scores[q][c] = exact distance(query q, row cand[q][c]); one workgroup per (query, chunk)
+template <bool DOT>
+__global__ __launch_bounds__(kExactThreads) void score_candidates_kernel(
+    const float *__restrict__ base, int64_t n, int dim, const float *__restrict__ queries,
+    const uint32_t *__restrict__ cand, int nc, float *__restrict__ scores)
+{
+    const Sub16 sub = Sub16::make(threadIdx.x);
+    const int64_t q = blockIdx.y;
+    const float *qv = queries + q * dim;
+    const int stride = gridDim.x * (kExactThreads / 16);
+    for (int c = blockIdx.x * (kExactThreads / 16) + (threadIdx.x >> 4); c < nc; c += stride) {
+        const uint32_t id = cand[q * nc + c];
+        float v = DOT ? -INFINITY : INFINITY;
+        if (id != VG_INVALID_ID && id < n)
+            v = exact_pair16<DOT, kPair>(base + static_cast<int64_t>(id) * dim, qv, dim, sub);
+        if ((threadIdx.x & 15) == 0) scores[q * nc + c] = v;
+    }
+}
+
+// Rerank: exact scores of nc candidates, then the k best by (score, id); one workgroup per query
+template <bool DOT>
+__global__ __launch_bounds__(kExactThreads) void rerank_kernel(
+    const float *__restrict__ base, int64_t n, int dim, const float *__restrict__ queries,
+    const uint32_t *__restrict__ cand, int nc, int k, uint32_t *__restrict__ ids,
+    float *__restrict__ scores)
+{
+    extern __shared__ uint64_t keys[];  // nc keys
+    const Sub16 sub = Sub16::make(threadIdx.x);
+    const int64_t q = blockIdx.x;
+    const float *qv = queries + q * dim;
+    for (int c = threadIdx.x >> 4; c < nc; c += kExactThreads / 16) {
+        const uint32_t id = cand[q * nc + c];
+        uint64_t key = kKeyMax;
+        if (id != VG_INVALID_ID && id < n) {
+            const float v = exact_pair16<DOT, kPair>(base + static_cast<int64_t>(id) * dim, qv, dim, sub);
+            key = make_key(v, id, DOT);
+        }
+        if ((threadIdx.x & 15) == 0) keys[c] = key;
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {  // wave 0 selects the k best (k <= 64)
+        const int lane = threadIdx.x;
+        WaveTopK tk;
+        tk.init(k);
+        for (int c0 = 0; c0 < nc; c0 += 64) {
+            const int c = c0 + lane;
+            uint64_t key = c < nc ? keys[c] : kKeyMax;
+            // the same row may appear twice in a candidate list: keep one copy (keys are equal)
+            tk.offer(key, lane);
+        }
+        if (lane < k) {
+            const uint64_t e = tk.list;
+            ids[q * k + lane] = e == kKeyMax ? VG_INVALID_ID : key_row(e);
+            scores[q * k + lane] = e == kKeyMax ? (DOT ? -INFINITY : INFINITY) : key_score(e, DOT);
+        }
+    }
+}
+
+__global__ void row_norms_kernel(const float *__restrict__ base, int64_t n, int dim,
+                                 float *__restrict__ norms)
+{
+    // ||x||^2 for the GEMM-form candidate generation only (never reported): plain order
+    const int64_t row = static_cast<int64_t>(blockIdx.x) * (blockDim.x / 64) + (threadIdx.x >> 6);
+    if (row >= n) return;
+    const int lane = threadIdx.x & 63;
+    float s = 0.0f;
+    for (int j = lane; j < dim; j += 64) {
+        const float v = base[row * dim + j];
+        s = __builtin_fmaf(v, v, s);
+    }
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if (lane == 0) norms[row] = s;
+}
+
+}  // namespace vg
+
+static bool metric_is_dot(int32_t metric) { return metric != VG_METRIC_L2; }
+
+VG_API int32_t vg_index_set_vectors(vg_index *idx, const float *base, void *stream)
+{
+    VG_CHECK(idx, VG_ERR_INVALID_ARG, "vg_index_set_vectors: NULL index");
+    VG_CHECK(idx->n == 0 || base, VG_ERR_INVALID_ARG, "vg_index_set_vectors: base is NULL");
+    VG_CHECK(idx->metric != VG_METRIC_HAMMING, VG_ERR_UNSUPPORTED,
+             "unsupported metric for float32: Hamming");
+    VG_HIP(hipSetDevice(idx->ctx->device));
+    hipStream_t st = vg::pick_stream(idx->ctx, stream);
+    if (idx->d_vectors) {
+        VG_HIP(hipStreamSynchronize(st));
+        VG_HIP(hipFree(idx->d_vectors));
+        VG_HIP(hipFree(idx->d_norms));
+        idx->d_vectors = idx->d_norms = nullptr;
+    }
+    if (idx->n == 0) return VG_OK;
+    size_t count = static_cast<size_t>(idx->n) * idx->dim;
+    VG_HIP(hipMalloc(reinterpret_cast<void **>(&idx->d_vectors), count * sizeof(float)));
+    VG_HIP(hipMalloc(reinterpret_cast<void **>(&idx->d_norms), static_cast<size_t>(idx->n) * sizeof(float)));
+    VG_HIP(hipMemcpyAsync(idx->d_vectors, base, count * sizeof(float), hipMemcpyDefault, st));
+    hipLaunchKernelGGL(vg::row_norms_kernel, dim3(static_cast<unsigned>((idx->n + 3) / 4)), dim3(256),
+                       0, st, idx->d_vectors, idx->n, idx->dim, idx->d_norms);
+    VG_HIP(hipGetLastError());
+    VG_HIP(hipStreamSynchronize(st));
+    return VG_OK;
+}
+
+static int32_t batch_impl(vg_ctx *ctx, bool dot, const float *query, const float *targets,
+                          int64_t dim, int64_t n, float *out, void *stream)
+{
+    VG_CHECK(ctx, VG_ERR_INVALID_ARG, "batch kernel: ctx is NULL");
+    // simd/kernels.go:255-257: the generic silently returns on bad dims; mirror that as success
+    if (dim <= 0 || n <= 0) return VG_OK;
+    VG_CHECK(query && targets && out, VG_ERR_INVALID_ARG, "batch kernel: NULL buffer");
+    VG_CHECK(dim < (1 << 30), VG_ERR_INVALID_ARG, "batch kernel: dim too large");
+    VG_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = vg::pick_stream(ctx, stream);
+    vg::DevIn<float> q, t;
+    vg::DevOut<float> o;
+    VG_TRY(q.init(query, static_cast<size_t>(dim), st));
+    VG_TRY(t.init(targets, static_cast<size_t>(n) * dim, st));
+    VG_TRY(o.init(out, static_cast<size_t>(n), st));
+    int64_t blocks = (n + 15) / 16;
+    if (blocks > 4096) blocks = 4096;
+    if (dot)
+        hipLaunchKernelGGL(vg::batch_kernel<true>, dim3(static_cast<unsigned>(blocks)),
+                           dim3(vg::kExactThreads), 0, st, q.ptr, t.ptr, static_cast<int>(dim), n, o.ptr);
+    else
+        hipLaunchKernelGGL(vg::batch_kernel<false>, dim3(static_cast<unsigned>(blocks)),
+                           dim3(vg::kExactThreads), 0, st, q.ptr, t.ptr, static_cast<int>(dim), n, o.ptr);
+    VG_HIP(hipGetLastError());
+    VG_TRY(o.finish());
+    if (o.on_host()) VG_HIP(hipStreamSynchronize(st));
+    return VG_OK;
+}
+
+VG_API int32_t vg_squared_l2_batch(vg_ctx *ctx, const float *query, const float *targets,
+                                   int64_t dim, int64_t n, float *out, void *stream)
+{
+    return batch_impl(ctx, false, query, targets, dim, n, out, stream);
+}
+
+VG_API int32_t vg_dot_batch(vg_ctx *ctx, const float *query, const float *targets, int64_t dim,
+                            int64_t n, float *out, void *stream)
+{
+    return batch_impl(ctx, true, query, targets, dim, n, out, stream);
+}
+
+VG_API int32_t vg_score_candidates(vg_index *idx, const float *queries, int64_t nq,
+                                   const uint32_t *cand_ids, int32_t nc, float *scores,
+                                   void *stream)
+{
+    VG_CHECK(idx, VG_ERR_INVALID_ARG, "vg_score_candidates: NULL index");
+    VG_CHECK(nq >= 0 && nc >= 0, VG_ERR_INVALID_ARG, "vg_score_candidates: negative count");
+    if (nq == 0 || nc == 0) return VG_OK;
+    VG_CHECK(idx->d_vectors, VG_ERR_NOT_READY, "vg_score_candidates: index has no fp32 vectors");
+    VG_CHECK(queries && cand_ids && scores, VG_ERR_INVALID_ARG, "vg_score_candidates: NULL buffer");
+    VG_HIP(hipSetDevice(idx->ctx->device));
+    hipStream_t st = vg::pick_stream(idx->ctx, stream);
+    vg::DevIn<float> q;
+    vg::DevIn<uint32_t> c;
+    vg::DevOut<float> o;
+    VG_TRY(q.init(queries, static_cast<size_t>(nq) * idx->dim, st));
+    VG_TRY(c.init(cand_ids, static_cast<size_t>(nq) * nc, st));
+    VG_TRY(o.init(scores, static_cast<size_t>(nq) * nc, st));
+    const bool dot = metric_is_dot(idx->metric);
+    const int64_t maxy = 65535;
+    unsigned gx = static_cast<unsigned>((nc + 15) / 16);
+    if (gx > 64) gx = 64;
+    for (int64_t q0 = 0; q0 < nq; q0 += maxy) {
+        int64_t cnt = nq - q0 < maxy ? nq - q0 : maxy;
+        dim3 grid(gx, static_cast<unsigned>(cnt));
+        if (dot)
+            hipLaunchKernelGGL(vg::score_candidates_kernel<true>, grid, dim3(vg::kExactThreads), 0, st,
+                               idx->d_vectors, idx->n, idx->dim, q.ptr + q0 * idx->dim,
+                               c.ptr + q0 * nc, nc, o.ptr + q0 * nc);
+        else
+            hipLaunchKernelGGL(vg::score_candidates_kernel<false>, grid, dim3(vg::kExactThreads), 0, st,
+                               idx->d_vectors, idx->n, idx->dim, q.ptr + q0 * idx->dim,
+                               c.ptr + q0 * nc, nc, o.ptr + q0 * nc);
+    }
+    VG_HIP(hipGetLastError());
+    VG_TRY(o.finish());
+    if (o.on_host()) VG_HIP(hipStreamSynchronize(st));
+    return VG_OK;
+}
+
+VG_API int32_t vg_rerank(vg_index *idx, const float *queries, int64_t nq, const uint32_t *cand_ids,
+                         int32_t nc, int32_t k, uint32_t *ids, float *scores, void *stream)
+{
+    VG_CHECK(idx, VG_ERR_INVALID_ARG, "vg_rerank: NULL index");
+    VG_CHECK(nq >= 0 && nc >= 0 && k >= 0, VG_ERR_INVALID_ARG, "vg_rerank: negative count");
+    if (nq == 0 || k == 0) return VG_OK;
+    VG_CHECK(idx->d_vectors, VG_ERR_NOT_READY, "vg_rerank: index has no fp32 vectors");
+    VG_CHECK(queries && ids && scores && (nc == 0 || cand_ids), VG_ERR_INVALID_ARG,
+             "vg_rerank: NULL buffer");
+    VG_CHECK(k <= 64, VG_ERR_UNSUPPORTED, "vg_rerank: k=%d exceeds 64", k);
+    VG_CHECK(static_cast<size_t>(nc) * 8 <= 160 * 1024 - 1024, VG_ERR_UNSUPPORTED,
+             "vg_rerank: nc=%d candidates per query exceed the LDS key buffer", nc);
+    VG_HIP(hipSetDevice(idx->ctx->device));
+    hipStream_t st = vg::pick_stream(idx->ctx, stream);
+    vg::DevIn<float> q;
+    vg::DevIn<uint32_t> c;
+    vg::DevOut<uint32_t> oid;
+    vg::DevOut<float> osc;
+    VG_TRY(q.init(queries, static_cast<size_t>(nq) * idx->dim, st));
+    VG_TRY(c.init(cand_ids, static_cast<size_t>(nq) * nc, st));
+    VG_TRY(oid.init(ids, static_cast<size_t>(nq) * k, st));
+    VG_TRY(osc.init(scores, static_cast<size_t>(nq) * k, st));
+    const bool dot = metric_is_dot(idx->metric);
+    size_t lds = static_cast<size_t>(nc > 0 ? nc : 1) * 8;
+    auto kern = dot ? vg::rerank_kernel<true> : vg::rerank_kernel<false>;
+    VG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+    hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(nq)), dim3(vg::kExactThreads), lds, st,
+                       idx->d_vectors, idx->n, idx->dim, q.ptr, c.ptr, nc, k, oid.ptr, osc.ptr);
+    VG_HIP(hipGetLastError());
+    VG_TRY(oid.finish());
+    VG_TRY(osc.finish());
+    if (oid.on_host() || osc.on_host()) VG_HIP(hipStreamSynchronize(st));
+    return VG_OK;
+}

@@ -20,10 +20,10 @@ bool is_device_ptr(const void *p)
     if (!p) return false;
     hipPointerAttribute_t a;
     hipError_t e = hipPointerGetAttributes(&a, p);
-    if (e != hipSuccess) {
-        (void)hipGetLastError();  // plain malloc'd host memory
-        return false;
-    }
+    // plain malloc'd host memory: some ROCm versions return an error, others succeed with
+    // hipMemoryTypeUnregistered but still latch a sticky "last error" — clear it either way
+    (void)hipGetLastError();
+    if (e != hipSuccess) return false;
     return a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeManaged;
 }
 
@@ -140,6 +140,8 @@ VG_API int32_t vg_index_destroy(vg_index *idx)
     if (!idx) return VG_OK;
     (void)hipSetDevice(idx->ctx->device);
     if (idx->d_pq_tiles) (void)hipFree(idx->d_pq_tiles);
+    if (idx->d_vectors) (void)hipFree(idx->d_vectors);
+    if (idx->d_norms) (void)hipFree(idx->d_norms);
     delete idx;
     return VG_OK;
 }

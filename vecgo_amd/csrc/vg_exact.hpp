@@ -1,0 +1,139 @@
+// vg_exact.hpp — fp32 L2 / dot product of one (query, row) pair by a 16-lane group, bit-identical
+// to the reference's AVX-512 kernels:
+//   PAIR   squaredL2Avx512 / dotProductAvx512   (internal/simd/src/floats_avx512.c:12-129)
+//   BATCH  squaredL2BatchAvx512 / dotBatchAvx512 (internal/simd/src/batch_avx512.c:19-143)
+//   BOUND  squaredL2BoundedAvx512                (internal/simd/src/bounded_l2_avx512.c:19-108)
+//
+// The reference keeps 4 zmm accumulators x 16 lanes: element e*64 + k*16 + l of block e goes to
+// acc[k][l] with one FMA.  Here 16 GPU lanes share a row; each owns one 16-byte piece of every
+// 64-float block, i.e. accumulator k and lanes l = 4*lq .. 4*lq+3 of it (4 fp32 accumulators
+// per GPU lane).  The lane -> (k, lq) map is chosen so that every step of the reference's
+// reduction is ONE DPP add inside the 16-lane row:
+//   (acc0+acc1), (acc2+acc3)        partner lane i^7   row_half_mirror
+//   their sum                       partner lane 15-i  row_mirror
+//   reduce_add (l,l+8)              lq^2               quad_perm [2,3,0,1]
+//   reduce_add (l,l+4)              lq^1               quad_perm [1,0,3,2]
+//   reduce_add (l,l+2), (0,1)       in-lane
+// fp32 addition is commutative, so both partners of a step hold the same bits afterwards.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+namespace vg {
+
+constexpr int kDppQuadXor1 = 0xB1;       // quad_perm [1,0,3,2]
+constexpr int kDppQuadXor2 = 0x4E;       // quad_perm [2,3,0,1]
+constexpr int kDppRowMirror = 0x140;     // lane i <- lane 15-i
+constexpr int kDppRowHalfMirror = 0x141; // lane i <- lane i^7 (within 8)
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_partner_add(float x)
+{
+    int y = __builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xF, 0xF, false);
+    return x + __int_as_float(y);
+}
+
+struct Sub16 {
+    int f4;  // which float4 of a 64-float block this lane owns (= k*4 + lq)
+    int lq;  // which float4 of a 16-float block this lane owns in the 16-wide tail
+    __device__ __forceinline__ static Sub16 make(int lane)
+    {
+        const int i = lane & 15;
+        const int j = (i & 8) ? 15 - i : i;
+        const int lq = (j & 4) ? 3 - (j & 3) : (j & 3);
+        const int k = ((i & 8) ? 2 : 0) + ((j & 4) ? 1 : 0);
+        Sub16 s;
+        s.f4 = k * 4 + lq;
+        s.lq = lq;
+        return s;
+    }
+};
+
+enum ExactMode { kPair = 0, kBatch = 1, kBounded = 2 };
+
+// One pair.  `row` and `q` point at dim floats (16-byte aligned when dim % 4 == 0, which the
+// fast path requires; other dims take the scalar route below).  All 16 lanes of the group
+// return the same value.
+template <bool DOT, int MODE>
+__device__ __forceinline__ float exact_pair16(const float *__restrict__ row,
+                                              const float *__restrict__ q, int dim, Sub16 sub)
+{
+    float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    const int nblk = dim >> 6;
+    const float4 *r4 = reinterpret_cast<const float4 *>(row) + sub.f4;
+    const float4 *q4 = reinterpret_cast<const float4 *>(q) + sub.f4;
+    for (int e = 0; e < nblk; e++) {
+        const float4 a = q4[e * 16];
+        const float4 b = r4[e * 16];
+        if (DOT) {
+            acc[0] = __builtin_fmaf(a.x, b.x, acc[0]);
+            acc[1] = __builtin_fmaf(a.y, b.y, acc[1]);
+            acc[2] = __builtin_fmaf(a.z, b.z, acc[2]);
+            acc[3] = __builtin_fmaf(a.w, b.w, acc[3]);
+        } else {
+            const float d0 = a.x - b.x, d1 = a.y - b.y, d2 = a.z - b.z, d3 = a.w - b.w;
+            acc[0] = __builtin_fmaf(d0, d0, acc[0]);
+            acc[1] = __builtin_fmaf(d1, d1, acc[1]);
+            acc[2] = __builtin_fmaf(d2, d2, acc[2]);
+            acc[3] = __builtin_fmaf(d3, d3, acc[3]);
+        }
+    }
+    float s[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        const float p = dpp_partner_add<kDppRowHalfMirror>(acc[t]);  // (acc0+acc1) | (acc2+acc3)
+        s[t] = dpp_partner_add<kDppRowMirror>(p);                    // sum of the two
+    }
+    int j = nblk << 6;
+    if (MODE == kBatch) {  // batch_avx512.c:60-66: 16-wide blocks go into the combined register
+        for (; j + 16 <= dim; j += 16) {
+            const float4 a = *(reinterpret_cast<const float4 *>(q + j) + sub.lq);
+            const float4 b = *(reinterpret_cast<const float4 *>(row + j) + sub.lq);
+            if (DOT) {
+                s[0] = __builtin_fmaf(a.x, b.x, s[0]);
+                s[1] = __builtin_fmaf(a.y, b.y, s[1]);
+                s[2] = __builtin_fmaf(a.z, b.z, s[2]);
+                s[3] = __builtin_fmaf(a.w, b.w, s[3]);
+            } else {
+                const float d0 = a.x - b.x, d1 = a.y - b.y, d2 = a.z - b.z, d3 = a.w - b.w;
+                s[0] = __builtin_fmaf(d0, d0, s[0]);
+                s[1] = __builtin_fmaf(d1, d1, s[1]);
+                s[2] = __builtin_fmaf(d2, d2, s[2]);
+                s[3] = __builtin_fmaf(d3, d3, s[3]);
+            }
+        }
+    }
+    float b[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        const float a = dpp_partner_add<kDppQuadXor2>(s[t]);  // (l, l+8)
+        b[t] = dpp_partner_add<kDppQuadXor1>(a);              // (l, l+4)
+    }
+    float total;
+    if (MODE == kBounded) {
+        total = (b[0] + b[1]) + (b[2] + b[3]);  // hsum512: two _mm_hadd_ps
+        for (; j + 8 <= dim; j += 8) {          // AVX2 8-wide remainder: mul, hadd tree
+            float qv[8];
+#pragma unroll
+            for (int l = 0; l < 8; l++) {
+                const float d = q[j + l] - row[j + l];
+                qv[l] = d * d;
+            }
+            const float p0 = qv[0] + qv[4], p1 = qv[1] + qv[5], p2 = qv[2] + qv[6], p3 = qv[3] + qv[7];
+            total = total + ((p0 + p1) + (p2 + p3));
+        }
+    } else {
+        total = (b[0] + b[2]) + (b[1] + b[3]);  // reduce_add: (l,l+2) then (0,1)
+    }
+    for (; j < dim; j++) {  // scalar tail: clang contracts `total += d*d` to one FMA
+        if (DOT) {
+            total = __builtin_fmaf(q[j], row[j], total);
+        } else {
+            const float d = q[j] - row[j];
+            total = __builtin_fmaf(d, d, total);
+        }
+    }
+    return total;
+}
+
+}  // namespace vg

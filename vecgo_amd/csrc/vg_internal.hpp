@@ -170,4 +170,7 @@ struct vg_index {
     uint8_t *d_pq_tiles = nullptr;
     int64_t n_tiles = 0;
     int32_t pq_groups = 0;  // ceil(m/16)
+    // fp32 rows, row-major n*dim (reference layout), plus ||x||^2 for the GEMM path
+    float *d_vectors = nullptr;
+    float *d_norms = nullptr;
 };
