@@ -93,6 +93,24 @@ int32_t vg_pq_is_trained(vg_pq *pq);
 int32_t vg_pq_build_distance_table(vg_pq *pq, const float *queries, int64_t nq, float *tables,
                                    void *stream);
 
+/* Train pq.go:68-143: per sub-quantizer k-means++ init + <= iters Lloyd iterations on fp32
+ * sub-vectors, then int8 quantisation of the centroids (pq.go:97-136).  vectors[n*dim].
+ * The reference draws from the unseeded global math/rand (pq.go:294,308,314,409), so trained
+ * codebooks are not reproducible there; here every draw comes from a counter-based stream
+ * keyed by `seed` (the CPU oracle uses the same stream, so GPU == oracle bit for bit).
+ * The reference uses iters = 20. */
+int32_t vg_pq_train(vg_pq *pq, const float *vectors, int64_t n, int32_t iters, uint64_t seed,
+                    void *stream);
+/* Encode pq.go:147-176, batched: codes[n*m]; code = FindNearestCentroidInt8
+ * (internal/simd/kernels.go:376-396: strict '<', lowest index wins ties) */
+int32_t vg_pq_encode(vg_pq *pq, const float *vectors, int64_t n, uint8_t *codes, void *stream);
+/* Decode pq.go:185-229, batched: out[n*dim] = float32(code)*scale + offset */
+int32_t vg_pq_decode(vg_pq *pq, const uint8_t *codes, int64_t n, float *out, void *stream);
+/* ComputeAsymmetricDistance pq.go:234-260 (no LUT, terms summed sequentially over the
+ * sub-quantizers), one query against n codes: out[n] */
+int32_t vg_pq_asymmetric_distance_batch(vg_pq *pq, const float *query, const uint8_t *codes,
+                                        int64_t n, float *out, void *stream);
+
 /* ---- resident index ---------------------------------------------------------- */
 int32_t vg_index_create(vg_ctx *ctx, int64_t n, int32_t dim, int32_t metric, vg_index **out);
 int32_t vg_index_destroy(vg_index *idx);

@@ -153,6 +153,53 @@ class ProductQuantizer:
                                             C.c_void_p(s.ctypes.data), C.c_void_p(o.ctypes.data)))
         return cb, s, o
 
+    def train(self, vectors, iters: int = 20, seed: int = 1, stream=None):
+        """Train (pq.go:68-143); the reference uses 20 Lloyd iterations."""
+        n = _rows(vectors, self.dimension)
+        v, pv = _ptr(vectors, np.float32)
+        check(self._lib.vg_pq_train(self._h, pv, C.c_int64(n), C.c_int32(iters), C.c_uint64(seed),
+                                    _stream_ptr(stream)))
+
+    def encode(self, vectors, out=None, stream=None):
+        """Encode (pq.go:147-176), batched: returns [n, m] uint8."""
+        n = _rows(vectors, self.dimension)
+        v, pv = _ptr(vectors, np.float32)
+        if out is None:
+            out = _empty_like(vectors, (n, self.num_subvectors), np.uint8)
+        c, pc = _ptr(out, np.uint8, n * self.num_subvectors)
+        check(self._lib.vg_pq_encode(self._h, pv, C.c_int64(n), pc, _stream_ptr(stream)))
+        return out
+
+    def decode(self, codes, out=None, stream=None):
+        """Decode (pq.go:185-229), batched: returns [n, dim] float32."""
+        total = codes.numel() if _is_torch(codes) else np.asarray(codes).size
+        if total % self.num_subvectors:
+            raise VecgoHipError(-4, "invalid code length")
+        n = total // self.num_subvectors
+        c, pc = _ptr(codes, np.uint8)
+        if out is None:
+            out = _empty_like(codes, (n, self.dimension), np.float32)
+        o, po = _ptr(out, np.float32, n * self.dimension)
+        check(self._lib.vg_pq_decode(self._h, pc, C.c_int64(n), po, _stream_ptr(stream)))
+        return out
+
+    def asymmetric_distance(self, query, codes, out=None, stream=None):
+        """ComputeAsymmetricDistance (pq.go:234-260) of one query against n codes."""
+        if _rows(query, self.dimension) != 1:
+            raise VecgoHipError(-2, "vector dimension mismatch")
+        total = codes.numel() if _is_torch(codes) else np.asarray(codes).size
+        if total % self.num_subvectors:
+            raise VecgoHipError(-4, "codes length mismatch")
+        n = total // self.num_subvectors
+        q, pq_ = _ptr(query, np.float32)
+        c, pc = _ptr(codes, np.uint8)
+        if out is None:
+            out = _empty_like(codes, (n,), np.float32)
+        o, po = _ptr(out, np.float32, n)
+        check(self._lib.vg_pq_asymmetric_distance_batch(self._h, pq_, pc, C.c_int64(n), po,
+                                                        _stream_ptr(stream)))
+        return out
+
     def build_distance_table(self, queries, out=None, stream=None):
         """BuildDistanceTable (pq.go:468-491), batched: returns [nq, m*k]."""
         nq = _rows(queries, self.dimension)
