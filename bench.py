@@ -1,0 +1,266 @@
+#!/usr/bin/env python3
+"""bench.py — the hot path's headline benchmark on MI355X.
+
+Workload (BASELINE.json configs[1], the configuration the metric's QPS is quoted on that fits
+one GPU): exact brute-force L2 top-10 over 1M x 768 fp32 rows for a batch of 1024 queries per
+step — fp32 MFMA GEMM candidate generation, exact re-score in the reference's AVX-512 summation
+order, proof-or-fallback (vecgo_amd/csrc/k_flat.hip).  Recall@10 = 1.0 by construction and is
+re-measured here against an independent fp64 ground truth.
+
+N > 1: the 1M-row corpus is sharded by rows over the ranks (strong scaling), every rank scores
+the same query batch against its shard, ONE all-gather of per-shard top-k (RCCL over xGMI),
+merge with the reference tie-break (vecgo_amd/sharded.py).
+
+One JSON line on rank 0; extra objects: `roofline` (dominant kernel of the timed region, HIP
+events from inside the library), `adc_scan` (PQ-ADC scan, BASELINE configs[3]: 10M x 96 B codes,
+HBM roofline), `cpu_baseline` (the CPU oracle = port of the reference's AVX-512 path, timed on
+this host's cores on a bounded sample).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import threading
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+N_ROWS, DIM, K, Q_BATCH = 1_000_000, 768, 10, 1024
+SEED_BASE, SEED_QUERY = 20260130, 20260131
+BLOCK = 65536  # rows per generation block: data is identical for every world size
+PEAK_MFMA_F32_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32-input MFMA dense peak
+PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E spec peak
+
+
+def gen_rows(lo: int, hi: int, device) -> torch.Tensor:
+    """Rows [lo, hi) of the synthetic corpus: i.i.d. standard normal (testutil.go:128-145
+    GaussianVectors analogue), generated per 65536-row block with its own seed."""
+    out = torch.empty((hi - lo, DIM), dtype=torch.float32, device=device)
+    b = lo // BLOCK
+    while b * BLOCK < hi:
+        g = torch.Generator(device=device)
+        g.manual_seed(SEED_BASE * 4096 + b)  # disjoint from SEED_QUERY's stream
+        blk = torch.randn((BLOCK, DIM), generator=g, device=device, dtype=torch.float32)
+        s, e = max(lo, b * BLOCK), min(hi, (b + 1) * BLOCK)
+        out[s - lo:e - lo] = blk[s - b * BLOCK:e - b * BLOCK]
+        b += 1
+    return out
+
+
+def gen_queries(n_batches: int, device) -> torch.Tensor:
+    g = torch.Generator(device=device)
+    g.manual_seed(SEED_QUERY)
+    return torch.randn((n_batches, Q_BATCH, DIM), generator=g, device=device, dtype=torch.float32)
+
+
+def fp64_topk_local(rows: torch.Tensor, q: torch.Tensor, lo: int, k: int):
+    """Independent ground truth (checker only, outside the timed region): fp64 distances."""
+    qd = q.double()
+    best_s = torch.full((q.shape[0], k), float("inf"), dtype=torch.float64, device=q.device)
+    best_i = torch.full((q.shape[0], k), -1, dtype=torch.int64, device=q.device)
+    qn = (qd * qd).sum(1, keepdim=True)
+    for s in range(0, rows.shape[0], 131072):
+        blk = rows[s:s + 131072].double()
+        d = qn + (blk * blk).sum(1)[None, :] - 2.0 * (qd @ blk.T)
+        cs = torch.cat([best_s, d], 1)
+        ci = torch.cat([best_i, torch.arange(s, s + blk.shape[0], device=q.device)[None, :].expand(q.shape[0], -1) + lo], 1)
+        top = torch.topk(cs, k, dim=1, largest=False)
+        best_s, best_i = top.values, torch.gather(ci, 1, top.indices)
+    return best_i, best_s
+
+
+def cpu_baseline(rows_host: np.ndarray, queries_host: np.ndarray, k: int):
+    """The CPU oracle (oracle/vg_oracle.c: restatement of the reference's AVX-512 path, pinned
+    bit-for-bit to the compiled reference kernels) on this host: one query per thread, the
+    reference's concurrency model (one goroutine per query)."""
+    from oracle import oracle as o
+    cores = os.cpu_count() or 1
+    nthreads = min(cores, queries_host.shape[0])
+    per = queries_host.shape[0] // nthreads
+    done = [0] * nthreads
+
+    def work(t):
+        for i in range(t * per, (t + 1) * per):
+            o.flat_search_f32(rows_host, DIM, queries_host[i], k)
+            done[t] += 1
+
+    th = [threading.Thread(target=work, args=(t,)) for t in range(nthreads)]
+    t0 = time.time()
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    dt = time.time() - t0
+    n = sum(done)
+    return {"value": n / dt, "unit": "queries/s", "cores": nthreads, "kind": "port",
+            "sample": f"{n} queries x {rows_host.shape[0]} rows x {DIM} fp32, exact L2 top-{k}, "
+                      f"{nthreads} threads (1 query/thread), {dt:.1f} s"}
+
+
+def adc_scan_roofline(vg, ctx, stream, device):
+    """BASELINE configs[3]: PQ (m=96, K=256) ADC scan over 10M codes, one query per pass:
+    algorithmic bytes = N*m per launch."""
+    n, m = 10_000_000, 96
+    g = torch.Generator(device=device)
+    g.manual_seed(7)
+    codes = torch.randint(0, 256, (n, m), dtype=torch.uint8, device=device, generator=g)
+    rng = np.random.default_rng(0)
+    pq = vg.ProductQuantizer(ctx, DIM, m, 256)
+    pq.set_codebooks(rng.integers(-128, 128, m * 256 * (DIM // m)).astype(np.int8),
+                     (rng.random(m) * 0.02 + 0.005).astype(np.float32), np.zeros(m, np.float32))
+    idx = vg.Index(ctx, n, DIM)
+    idx.set_pq_codes(pq, codes)
+    del codes
+    q = torch.randn((1, DIM), device=device)
+    out = (torch.empty((1, K), dtype=torch.int32, device=device), torch.empty((1, K), device=device))
+    for _ in range(5):
+        idx.search_pq_adc(q, K, out=out, stream=stream)
+    torch.cuda.synchronize()
+    ctx.profile_read("pq_adc_scan")
+    ctx.profile_enable(True)
+    reps = 20
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(stream)
+    for _ in range(reps):
+        idx.search_pq_adc(q, K, out=out, stream=stream)
+    e1.record(stream)
+    torch.cuda.synchronize()
+    launches, ms = ctx.profile_read("pq_adc_scan")
+    ctx.profile_enable(False)
+    kern_ms = ms / max(launches, 1)
+    achieved = n * m / (kern_ms * 1e-3) / 1e9
+    res = {"workload": "pq_adc_scan_10Mx768_m96_K256_k10_nq1", "bound": "hbm", "achieved": achieved,
+           "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": achieved / PEAK_HBM_GBS, "traffic": None,
+           "kernel": "pq_adc_scan_kernel<6,true>", "kernel_ms": kern_ms,
+           "bytes_per_launch": n * m, "search_call_ms": e0.elapsed_time(e1) / reps,
+           "qps_single_query_passes": 1e3 / (e0.elapsed_time(e1) / reps)}
+    idx.close()
+    pq.close()
+    return res
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-adc", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=device)
+    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    import vecgo_amd as vg
+    from vecgo_amd import sharded
+
+    ctx = vg.Context(local_rank)
+    stream = torch.cuda.current_stream()
+    bounds = sharded.partition(N_ROWS, world)
+    lo, hi = bounds[rank], bounds[rank + 1]
+    rows = gen_rows(lo, hi, device)
+    index = sharded.ShardedFlatIndex(ctx, rows, DIM, bounds, metric=0)
+    n_batches = 8
+    queries = gen_queries(n_batches, device)
+
+    def step(i):
+        return index.search(queries[i % n_batches], K, stream=stream)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    barrier()
+    ctx.profile_read("flat_gemm")
+    ctx.profile_enable(True)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        res = step(i)
+    barrier()
+    dt = time.perf_counter() - t0
+    ctx.profile_enable(False)
+    launches, gemm_ms = ctx.profile_read("flat_gemm")
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    qps = args.steps * Q_BATCH / dt
+
+    # ---- recall@10 against an independent fp64 ground truth (checker, untimed) ----------------
+    nrec = 64
+    qrec = queries[0][:nrec]
+    got_ids, _ = index.search(qrec, K, stream=stream)
+    gi, gs = fp64_topk_local(rows, qrec, lo, K)
+    if world > 1:
+        gl_i = [torch.empty_like(gi) for _ in range(world)]
+        gl_s = [torch.empty_like(gs) for _ in range(world)]
+        dist.all_gather(gl_i, gi)
+        dist.all_gather(gl_s, gs)
+        ci, cs = torch.cat(gl_i, 1), torch.cat(gl_s, 1)
+        top = torch.topk(cs, K, dim=1, largest=False)
+        gi = torch.gather(ci, 1, top.indices)
+    got = got_ids.cpu().numpy().view(np.uint32).astype(np.int64)
+    gt = gi.cpu().numpy()
+    recall = float(np.mean([len(set(got[i]) & set(gt[i])) / K for i in range(nrec)]))
+
+    if rank != 0:
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    rows_local = hi - lo
+    # a step's query batch runs as ceil(Q / chunk) GEMM launches (the score matrix of one launch
+    # is capped at 2 GiB): algorithmic flops per launch = 2 * (queries in the launch) * rows * dim,
+    # averaged over the launches of the timed region
+    flops_per_launch = 2.0 * Q_BATCH * rows_local * DIM * args.steps / max(launches, 1)
+    gemm_avg_ms = gemm_ms / max(launches, 1)
+    achieved_tf = flops_per_launch / (gemm_avg_ms * 1e-3) / 1e12 if launches else 0.0
+    out = {
+        "metric": "QPS at recall@10>=0.95, 1M x 768 (exact brute force, fp32 MFMA GEMM + exact re-score)",
+        "value": qps, "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+        "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "flat_exact_l2_1Mx768_top10 (BASELINE configs[1])", "rows": N_ROWS,
+                   "dim": DIM, "k": K, "queries_per_step": Q_BATCH,
+                   "parallelism": f"row-shard x{world}, all-gather of per-shard top-k" if world > 1 else "1 GPU"},
+        "recall_at_10": recall,
+        "roofline": {"bound": "mfma", "achieved": achieved_tf, "peak": PEAK_MFMA_F32_TFLOPS,
+                     "unit": "TFLOP/s", "frac": achieved_tf / PEAK_MFMA_F32_TFLOPS, "traffic": None,
+                     "kernel": "flat_gemm_kernel<false>", "kernel_ms": gemm_avg_ms,
+                     "launches": launches, "flops_per_launch": flops_per_launch},
+    }
+    if world == 1 and not args.no_adc:
+        del index
+        out["adc_scan"] = adc_scan_roofline(vg, ctx, stream, device)
+    if world == 1 and not args.no_cpu_baseline:
+        nsample = 2 * (os.cpu_count() or 1)
+        out["cpu_baseline"] = cpu_baseline(rows.cpu().numpy(), queries[1][:nsample].cpu().numpy(), K)
+    print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

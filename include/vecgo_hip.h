@@ -16,7 +16,10 @@
  *     `//go:noescape` contract: no pointer is retained).  When every buffer of a
  *     call is a device pointer the call only enqueues work on `stream` and
  *     returns; results are ready when the stream reaches that point.
- *   - `stream` is a hipStream_t passed as void*; NULL = the context's own stream.
+ *   - `stream` is a hipStream_t passed as void*.  NULL = the context's own (non-blocking)
+ *     stream — right for host-buffer callers such as cgo.  A caller that produces device
+ *     buffers on HIP's legacy default stream (handle 0, e.g. PyTorch's default stream) must
+ *     pass VG_STREAM_LEGACY so that its work and the library's are ordered.
  *   - Index / quantizer handles may be used from many threads at once for the
  *     read-only calls (search, encode, build table); create / set / train /
  *     destroy must be externally serialised (internal/quantization/doc.go:120-123).
@@ -37,6 +40,7 @@ extern "C" {
 
 #define VG_ABI_VERSION 1
 #define VG_INVALID_ID 0xFFFFFFFFu
+#define VG_STREAM_LEGACY ((void *)1) /* == hipStreamLegacy */
 
 /* error conventions: Go (value, error) strings in parentheses are what the Go
  * shim maps each code to (internal/quantization/pq.go:148-153,190,496;
@@ -77,6 +81,15 @@ const char *vg_status_string(int32_t status);
 /* name (e.g. "gfx950"), CU count and HBM bytes of the context's device */
 int32_t vg_ctx_device_info(vg_ctx *ctx, char *arch, int32_t arch_len, int32_t *compute_units,
                            int64_t *hbm_bytes);
+
+/* per-kernel timing with HIP events on the launching stream (the analogue of the reference's
+ * per-query FilterGateStats.SearchTimeNanos, searcher/searcher.go:114-137).  While enabled,
+ * every launch of the named hot kernels is bracketed by an event pair.  vg_profile_read
+ * synchronises, then returns the number of launches and their summed duration since the last
+ * read for `kernel` ("flat_gemm", "pq_adc_scan", "rabitq_scan", "flat_select", "topk_merge",
+ * "hnsw_search", "vamana_search"), and clears those records. */
+int32_t vg_profile_enable(vg_ctx *ctx, int32_t on);
+int32_t vg_profile_read(vg_ctx *ctx, const char *kernel, int64_t *launches, double *total_ms);
 
 /* ---- ProductQuantizer (internal/quantization/pq.go) ------------------------ */
 /* NewProductQuantizer pq.go:36-64: dim % m == 0, 0 < k <= 256 */
@@ -145,6 +158,28 @@ int32_t vg_rerank(vg_index *idx, const float *queries, int64_t nq, const uint32_
 /* exact scores only, scores[nq*nc] in candidate order (invalid ids → +Inf / -Inf) */
 int32_t vg_score_candidates(vg_index *idx, const float *queries, int64_t nq,
                             const uint32_t *cand_ids, int32_t nc, float *scores, void *stream);
+
+/* flat.Segment.Search, fp32 branch (flat/segment.go:691-701) == exact brute force:
+ * distance.SquaredL2 / distance.Dot of every row (squaredL2Avx512 / dotProductAvx512
+ * order), best k by (Score, RowID) (segment.go:714-721).  Also hnsw.BruteSearch
+ * (hnsw.go:2021-2101).  Candidates come from a batched query x base fp32 MFMA GEMM
+ * (||x||^2 - 2 q.x); the survivors are re-scored in the reference's summation order and the
+ * result is verified against the GEMM error bound (a query that fails the check is
+ * recomputed by the exhaustive exact kernel), so ids and scores equal the reference's.
+ * Metric L2 → ascending squared L2; Dot / Cosine → descending dot product
+ * (distance.Provider, distance/distance.go:91-106).  k <= 32. */
+int32_t vg_search_flat(vg_index *idx, const float *queries, int64_t nq, int32_t k, uint32_t *ids,
+                       float *scores, void *stream);
+
+/* engine fan-in (engine/search.go:904-908: per-segment candidate lists merged into one
+ * bounded heap, ordered by searcher/candidate_queue.go:12-23).  Here the "segments" are row
+ * shards, one per GPU: lists[l] holds nq*k (id, score) results of shard l, ids local to the
+ * shard; id_offsets[l] (may be NULL = all 0) is added to make them global.  Output: the k best
+ * of the union per query, best first.  metric picks the direction (L2 ascending, Dot/Cosine
+ * descending).  ids_in/scores_in are [lists][nq][k] contiguous. */
+int32_t vg_merge_topk(vg_ctx *ctx, const uint32_t *ids_in, const float *scores_in, int32_t lists,
+                      int64_t nq, int32_t k, int32_t metric, const uint32_t *id_offsets,
+                      uint32_t *ids, float *scores, void *stream);
 
 /* flat.Segment.Search, PQ branch (flat/segment.go:476-483 LUT, :678-689 ADC
  * = simd.PqAdcLookup in pqAdcLookupAvx512 order, :714-721 top-k with the

@@ -1,0 +1,97 @@
+"""Exact brute-force search on the GPU (MFMA GEMM candidates + exact re-score + proof) vs
+the oracle's flat scan (flat/segment.go:691-721): ids and scores bit-exact."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as o
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(x):
+    return np.asarray(x, np.float32).view(np.uint32)
+
+
+@pytest.fixture(scope="module")
+def vg():
+    import vecgo_amd
+    return vecgo_amd
+
+
+@pytest.fixture(scope="module")
+def ctx(vg):
+    return vg.Context(0)
+
+
+def check(vg, ctx, n, dim, nq, k, metric, rng, base=None):
+    if base is None:
+        base = rng.standard_normal((n, dim)).astype(np.float32)
+    q = rng.standard_normal((nq, dim)).astype(np.float32)
+    idx = vg.Index(ctx, n, dim, vg.Metric(metric))
+    idx.set_vectors(base)
+    ids, scores = idx.search_flat(q, k)
+    for qi in range(nq):
+        eid, esc = o.flat_search_f32(base, dim, q[qi], k, metric)
+        r = eid.size
+        assert np.array_equal(ids[qi, :r], eid), (qi, ids[qi], eid)
+        assert np.array_equal(bits(scores[qi, :r]), bits(esc))
+        assert np.all(ids[qi, r:] == 0xFFFFFFFF)
+    return idx, base, q
+
+
+@pytest.mark.parametrize("n,dim,nq,k,metric", [
+    (10000, 128, 20, 10, 0),    # BASELINE config 1: flat exact L2 10k x 128
+    (20000, 768, 9, 10, 0),
+    (5000, 100, 5, 10, 0),      # dim not a multiple of 32: ragged K edge of the GEMM
+    (3000, 777, 3, 5, 0),       # unaligned rows
+    (300, 64, 130, 32, 0),      # more than one query tile, k = 32
+    (40, 64, 3, 10, 0),         # fewer rows than candidates
+    (7, 32, 2, 10, 0),          # fewer rows than k
+    (10000, 128, 20, 10, 2),    # Dot: descending
+    (4000, 768, 4, 10, 1),      # Cosine -> Dot provider (distance.go:91-106)
+])
+def test_flat_matches_oracle(vg, ctx, n, dim, nq, k, metric):
+    check(vg, ctx, n, dim, nq, k, metric, np.random.default_rng(n + dim + nq))
+
+
+def test_flat_duplicates_and_near_ties(vg, ctx):
+    """Rows that differ in the last bits and exact duplicates: the proof step must either
+    accept or fall back, and ties resolve by RowID."""
+    rng = np.random.default_rng(2)
+    base = rng.standard_normal((2000, 128)).astype(np.float32)
+    base[1000:1010] = base[5]           # exact duplicates of one row
+    base[1500] = base[7] * np.float32(1.0000001)
+    check(vg, ctx, 2000, 128, 6, 12, 0, rng, base=base)
+
+
+def test_flat_forced_exhaustive_path(vg, ctx):
+    """The fallback kernel (step 4) alone must give the same answer."""
+    os.environ["VG_FLAT_FORCE_EXACT"] = "1"
+    try:
+        check(vg, ctx, 6000, 128, 4, 10, 0, np.random.default_rng(8))
+        check(vg, ctx, 3000, 96, 3, 10, 2, np.random.default_rng(9))
+    finally:
+        os.environ.pop("VG_FLAT_FORCE_EXACT")
+
+
+def test_flat_clustered_data_triggers_fallback_safely(vg, ctx):
+    """All rows within a tiny ball: GEMM-form scores cannot separate them, so the proof fails
+    and the exhaustive kernel must take over; results still exact."""
+    rng = np.random.default_rng(4)
+    center = rng.standard_normal(128).astype(np.float32) * 10
+    base = (center + rng.standard_normal((3000, 128)).astype(np.float32) * 1e-4).astype(np.float32)
+    check(vg, ctx, 3000, 128, 3, 10, 0, rng, base=base)
+
+
+def test_flat_errors(vg, ctx):
+    idx = vg.Index(ctx, 10, 16)
+    with pytest.raises(vg.VecgoHipError) as e:
+        idx.search_flat(np.zeros((1, 16), np.float32), 3)
+    assert e.value.status == -9
+    with pytest.raises(vg.VecgoHipError):
+        idx.search_flat(np.zeros((1, 15), np.float32), 3)
+    with pytest.raises(vg.VecgoHipError) as e:  # distance.go:103-105
+        vg.Index(ctx, 10, 16, vg.Metric.HAMMING).set_vectors(np.zeros((10, 16), np.float32))
+    assert e.value.status == -5

@@ -1,0 +1,76 @@
+"""N>1 path on CPU: two gloo ranks, row-sharded corpus, one all-gather of per-shard top-k,
+merge with the reference tie-break.  The local scorer and the merge are injected (oracle /
+numpy) because no HIP device exists here; what is under test is vecgo_amd.sharded's
+partitioning, collective layout and id offsets."""
+import os
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = Path(__file__).resolve().parents[1]
+
+
+def _np_merge(ids, scores, k, off):
+    ids = ids.numpy().view(np.uint32).astype(np.int64) + off.numpy().astype(np.int64)[:, None, None]
+    sc = scores.numpy()
+    world, nq, kk = sc.shape
+    out_i = np.zeros((nq, k), np.uint32); out_s = np.zeros((nq, k), np.float32)
+    for q in range(nq):
+        cand = [(sc[w, q, j], ids[w, q, j]) for w in range(world) for j in range(kk)
+                if ids[w, q, j] - off.numpy()[w] != 0xFFFFFFFF]
+        cand.sort()
+        for j, (s, i) in enumerate(cand[:k]):
+            out_i[q, j] = i; out_s[q, j] = s
+    return torch.from_numpy(out_i.view(np.int32)), torch.from_numpy(out_s)
+
+
+def _worker(rank, world, port, n, dim, nq, k, ret):
+    sys.path.insert(0, str(ROOT))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import oracle as o
+    from vecgo_amd import sharded
+    rng = np.random.default_rng(123)
+    base = rng.standard_normal((n, dim)).astype(np.float32)
+    queries = rng.standard_normal((nq, dim)).astype(np.float32)
+    bounds = sharded.partition(n, world)
+    lo, hi = bounds[rank], bounds[rank + 1]
+
+    def local(q, kk):
+        ids = np.full((nq, kk), 0xFFFFFFFF, np.uint32); sc = np.full((nq, kk), np.inf, np.float32)
+        for i in range(nq):
+            a, b = o.flat_search_f32(base[lo:hi], dim, q[i], kk)
+            ids[i, :a.size] = a; sc[i, :b.size] = b
+        return torch.from_numpy(ids.view(np.int32)), torch.from_numpy(sc)
+
+    ids, sc = sharded.sharded_search(local, _np_merge, queries, k, bounds)
+    ok = True
+    for i in range(nq):
+        eid, esc = o.flat_search_f32(base, dim, queries[i], k)
+        ok &= np.array_equal(ids[i].numpy().view(np.uint32), eid)
+        ok &= np.array_equal(sc[i].numpy().view(np.uint32), esc.view(np.uint32))
+    ret[rank] = bool(ok)
+    dist.destroy_process_group()
+
+
+def test_partition_covers_rows():
+    from vecgo_amd import sharded
+    for n in (0, 1, 7, 1000, 1_000_003):
+        for w in (1, 2, 3, 8):
+            b = sharded.partition(n, w)
+            assert b[0] == 0 and b[-1] == n and all(b[i] <= b[i + 1] for i in range(w))
+
+
+@pytest.mark.parametrize("n", [501, 64])
+def test_two_rank_sharded_search_equals_single_segment(n):
+    world = 2
+    port = 29500 + (os.getpid() % 2000)
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, port, n, 32, 5, 10, ret), nprocs=world, join=True)
+    assert ret[0] and ret[1]

@@ -5,7 +5,7 @@ Python binding the tests and bench.py drive it with; names mirror the reference'
 interfaces (distance.Metric, quantization.ProductQuantizer, ...).
 """
 from .api import (Context, Index, Metric, ProductQuantizer, VecgoHipError, dot_batch,  # noqa: F401
-                  squared_l2_batch)
+                  merge_topk, squared_l2_batch)
 
 __all__ = ["Context", "Index", "Metric", "ProductQuantizer", "VecgoHipError", "dot_batch",
-           "squared_l2_batch"]
+           "merge_topk", "squared_l2_batch"]

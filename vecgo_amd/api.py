@@ -53,10 +53,21 @@ def _ptr(x, dtype, count=None):
 
 def _stream_ptr(stream):
     if stream is None:
+        # Device tensors handed to the library are produced on torch's current stream; run on
+        # it by default so that producer and consumer are ordered.  (The C ABI's own default,
+        # NULL = the context's private stream, is for host-buffer callers such as cgo.)
+        if torch is not None and torch.cuda.is_available() and torch.cuda.is_initialized():
+            return _handle(torch.cuda.current_stream().cuda_stream)
         return None
     if torch is not None and isinstance(stream, torch.cuda.Stream):
-        return C.c_void_p(stream.cuda_stream)
-    return C.c_void_p(int(stream))
+        return _handle(stream.cuda_stream)
+    return _handle(int(stream))
+
+
+def _handle(h: int):
+    # torch's default stream is HIP's legacy default stream, handle 0; the C ABI reserves NULL
+    # for "the context's own stream", so the legacy stream travels as VG_STREAM_LEGACY (= 1)
+    return C.c_void_p(h if h != 0 else 1)
 
 
 class Context:
@@ -82,6 +93,15 @@ class Context:
 
     def synchronize(self, stream=None):
         check(self._lib.vg_ctx_synchronize(self._h, _stream_ptr(stream)))
+
+    def profile_enable(self, on: bool = True):
+        check(self._lib.vg_profile_enable(self._h, C.c_int32(1 if on else 0)))
+
+    def profile_read(self, kernel: str):
+        """(launches, total_ms) of `kernel` since the last read (HIP events on the launch stream)."""
+        n = C.c_int64(); ms = C.c_double()
+        check(self._lib.vg_profile_read(self._h, kernel.encode(), C.byref(n), C.byref(ms)))
+        return n.value, ms.value
 
     def device_info(self):
         arch = C.create_string_buffer(64)
@@ -109,6 +129,24 @@ def _batch(ctx, fn, query, targets, dim, out, stream):
         out = _empty_like(targets, (n,), np.float32)
     o, po = _ptr(out, np.float32, n)
     check(fn(ctx._h, pq_, pt, C.c_int64(dim), C.c_int64(n), po, _stream_ptr(stream)))
+    return out
+
+
+def merge_topk(ctx: Context, ids_in, scores_in, k: int, metric=0, id_offsets=None, out=None,
+               stream=None):
+    """engine fan-in (engine/search.go:904-908): ids_in/scores_in are [lists, nq, k]."""
+    shape = tuple(ids_in.shape)
+    lists, nq = shape[0], shape[1]
+    assert shape[2] == k
+    i, pi = _ptr(ids_in, np.uint32)
+    s, ps = _ptr(scores_in, np.float32)
+    o, po = _ptr(id_offsets, np.uint32, lists) if id_offsets is not None else (None, None)
+    if out is None:
+        out = (_empty_like(ids_in, (nq, k), np.uint32), _empty_like(ids_in, (nq, k), np.float32))
+    oi, poi = _ptr(out[0], np.uint32, nq * k)
+    os_, pos = _ptr(out[1], np.float32, nq * k)
+    check(ctx._lib.vg_merge_topk(ctx._h, pi, ps, C.c_int32(lists), C.c_int64(nq), C.c_int32(k),
+                                 C.c_int32(int(metric)), po, poi, pos, _stream_ptr(stream)))
     return out
 
 
@@ -297,6 +335,10 @@ class Index:
         s, ps = _ptr(scores, np.float32, nq * k)
         check(fn(self._h, pq_, C.c_int64(nq), C.c_int32(k), *extra, pi, ps, _stream_ptr(stream)))
         return ids, scores
+
+    def search_flat(self, queries, k, out=None, stream=None):
+        """flat.Segment.Search fp32 branch / hnsw.BruteSearch: exact brute force."""
+        return self._search(self._lib.vg_search_flat, queries, k, out=out, stream=stream)
 
     def search_pq_adc(self, queries, k, out=None, stream=None):
         """flat.Segment.Search PQ branch (flat/segment.go:476-483,678-689,714-721)."""

@@ -305,24 +305,8 @@ __global__ __launch_bounds__(kAdcThreads) void pq_adc_scan_kernel(
     }
     uint64_t *out = partial + (static_cast<int64_t>(q) * slices + s) * k;
     if (SMALLK) {
-        // Rank-merge the 16 per-wave sorted lists: a key's final position is its own index
-        // plus the number of smaller keys in every other wave's list (keys are unique).
-        uint64_t *lists = buf;              // [kAdcWaves][64]
-        int *valid = reinterpret_cast<int *>(buf + kAdcWaves * 64);
-        lists[wave * 64 + lane] = wtk.list;
-        const int nvalid = __popcll(__ballot(wtk.list != kKeyMax));
-        if (lane == 0) valid[wave] = nvalid;
-        __syncthreads();
-        const uint64_t e = wtk.list;
-        if (e != kKeyMax) {
-            int rank = lane;
-            for (int w = 0; w < kAdcWaves; w++)
-                if (w != wave) rank += lower_bound64(lists + w * 64, e);
-            if (rank < k) out[rank] = e;
-        }
-        int total = 0;
-        for (int w = 0; w < kAdcWaves; w++) total += valid[w];
-        for (int i = total + tid; i < k; i += kAdcThreads) out[i] = kKeyMax;
+        wg_rank_merge<kAdcWaves>(wtk, buf, reinterpret_cast<int *>(buf + kAdcWaves * 64), wave, lane,
+                                 tid, k, out);
         return;
     }
     const int have = sh->cnt;
@@ -337,12 +321,14 @@ constexpr int kMergeThreads = 256;
 constexpr int kMergeBuf = 4096;
 __global__ __launch_bounds__(kMergeThreads) void topk_merge_kernel(
     const uint64_t *__restrict__ partial, int lists, int k, bool descending,
-    uint32_t *__restrict__ ids, float *__restrict__ scores)
+    uint32_t *__restrict__ ids, float *__restrict__ scores, const int *__restrict__ only_if,
+    const int *__restrict__ always)
 {
     __shared__ uint64_t buf[kMergeBuf];
     __shared__ unsigned long long tmin;
     __shared__ int cnt;
     const int q = blockIdx.x;
+    if (only_if && !only_if[q] && !(always && always[0])) return;  // query not selected
     const int tid = threadIdx.x;
     const uint64_t *src = partial + static_cast<int64_t>(q) * lists * k;
     const int64_t total = static_cast<int64_t>(lists) * k;
@@ -424,11 +410,12 @@ __global__ __launch_bounds__(kMergeThreads) void topk_merge_kernel(
 }
 
 int32_t launch_topk_merge(const uint64_t *partial, int64_t nq, int lists, int k, bool descending,
-                          uint32_t *ids, float *scores, hipStream_t st)
+                          uint32_t *ids, float *scores, hipStream_t st, const int *only_if = nullptr,
+                          const int *always = nullptr)
 {
     if (nq == 0 || k == 0) return VG_OK;
     hipLaunchKernelGGL(topk_merge_kernel, dim3(static_cast<unsigned>(nq)), dim3(kMergeThreads), 0,
-                       st, partial, lists, k, descending, ids, scores);
+                       st, partial, lists, k, descending, ids, scores, only_if, always);
     VG_HIP(hipGetLastError());
     return VG_OK;
 }
@@ -464,6 +451,7 @@ static int32_t launch_scan(const vg_index *idx, const float *tables, int64_t nq,
     const int64_t max_q = (1ll << 30) / slices;
     for (int64_t q0 = 0; q0 < nq; q0 += max_q) {
         int64_t cnt = nq - q0 < max_q ? nq - q0 : max_q;
+        ProfScope prof(idx->ctx, "pq_adc_scan", st);
         hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(cnt * slices)), dim3(kAdcThreads), lds,
                            st, reinterpret_cast<const uint4 *>(idx->d_pq_tiles), idx->n,
                            idx->n_tiles, pq->m, idx->pq_groups,
@@ -475,6 +463,66 @@ static int32_t launch_scan(const vg_index *idx, const float *tables, int64_t nq,
 }
 
 }  // namespace vg
+
+namespace vg {
+// (id, score) lists [lists][nq][k] -> keys [nq][lists][k] (ascending per list is preserved)
+__global__ void pack_keys_kernel(const uint32_t *__restrict__ ids, const float *__restrict__ scores,
+                                 int lists, int64_t nq, int k, bool descending,
+                                 const uint32_t *__restrict__ offsets, uint64_t *__restrict__ keys)
+{
+    const int64_t gid = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    const int64_t total = static_cast<int64_t>(lists) * nq * k;
+    if (gid >= total) return;
+    const int i = static_cast<int>(gid % k);
+    const int64_t q = (gid / k) % nq;
+    const int l = static_cast<int>(gid / (static_cast<int64_t>(k) * nq));
+    const uint32_t id = ids[gid];
+    uint64_t key = kKeyMax;
+    if (id != VG_INVALID_ID) key = make_key(scores[gid], id + (offsets ? offsets[l] : 0u), descending);
+    keys[(q * lists + l) * k + i] = key;
+}
+}  // namespace vg
+
+VG_API int32_t vg_merge_topk(vg_ctx *ctx, const uint32_t *ids_in, const float *scores_in, int32_t lists,
+                             int64_t nq, int32_t k, int32_t metric, const uint32_t *id_offsets,
+                             uint32_t *ids, float *scores, void *stream)
+{
+    VG_CHECK(ctx, VG_ERR_INVALID_ARG, "vg_merge_topk: ctx is NULL");
+    VG_CHECK(lists >= 0 && nq >= 0 && k >= 0, VG_ERR_INVALID_ARG, "vg_merge_topk: negative count");
+    if (nq == 0 || k == 0) return VG_OK;
+    VG_CHECK(ids && scores, VG_ERR_INVALID_ARG, "vg_merge_topk: NULL output");
+    VG_CHECK(lists == 0 || (ids_in && scores_in), VG_ERR_INVALID_ARG, "vg_merge_topk: NULL input");
+    VG_CHECK(k <= vg::kAdcMaxK, VG_ERR_UNSUPPORTED, "vg_merge_topk: k=%d exceeds %d", k, vg::kAdcMaxK);
+    VG_CHECK(metric >= VG_METRIC_L2 && metric <= VG_METRIC_DOT, VG_ERR_UNSUPPORTED,
+             "vg_merge_topk: unsupported metric %d", metric);
+    VG_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = vg::pick_stream(ctx, stream);
+    const bool desc = metric != VG_METRIC_L2;
+    const size_t total = static_cast<size_t>(lists) * nq * k;
+    vg::DevIn<uint32_t> i_in, offs;
+    vg::DevIn<float> s_in;
+    vg::DevOut<uint32_t> oid;
+    vg::DevOut<float> osc;
+    VG_TRY(i_in.init(ids_in, total, st));
+    VG_TRY(s_in.init(scores_in, total, st));
+    VG_TRY(offs.init(id_offsets, id_offsets ? static_cast<size_t>(lists) : 0, st));
+    VG_TRY(oid.init(ids, static_cast<size_t>(nq) * k, st));
+    VG_TRY(osc.init(scores, static_cast<size_t>(nq) * k, st));
+    const int nl = lists > 0 ? lists : 1;
+    vg::DevTmp<uint64_t> keys;
+    VG_TRY(keys.init(static_cast<size_t>(nl) * nq * k, st));
+    if (lists == 0) {
+        VG_HIP(hipMemsetAsync(keys.ptr, 0xFF, static_cast<size_t>(nq) * k * 8, st));
+    } else {
+        hipLaunchKernelGGL(vg::pack_keys_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256),
+                           0, st, i_in.ptr, s_in.ptr, lists, nq, k, desc, offs.ptr, keys.ptr);
+    }
+    VG_TRY(vg::launch_topk_merge(keys.ptr, nq, nl, k, desc, oid.ptr, osc.ptr, st));
+    VG_TRY(oid.finish());
+    VG_TRY(osc.finish());
+    if (oid.on_host() || osc.on_host()) VG_HIP(hipStreamSynchronize(st));
+    return VG_OK;
+}
 
 VG_API int32_t vg_index_set_pq_codes(vg_index *idx, vg_pq *pq, const uint8_t *codes, void *stream)
 {

@@ -1,0 +1,399 @@
+// k_flat.hip — exact brute-force search (flat/segment.go:691-721, hnsw.go:2021-2101):
+//   1. scores[q][n] = ||x_n||^2 - 2 q.x_n  (L2)  or  -q.x_n  (Dot)   fp32 MFMA GEMM
+//   2. per query: the kc smallest scores                              streaming select
+//   3. exact re-scoring of those kc rows in the reference's summation order, top-k by
+//      (Score, RowID), and a proof that no other row can belong to the top-k
+//   4. queries whose proof fails are recomputed by the exhaustive exact kernel
+// Steps 1-2 only nominate candidates; every reported id/score comes from step 3/4.
+#include <algorithm>
+
+#include "vg_device.hpp"
+#include "vg_exact.hpp"
+#include "vg_internal.hpp"
+
+namespace vg {
+
+int32_t launch_topk_merge(const uint64_t *partial, int64_t nq, int lists, int k, bool descending,
+                          uint32_t *ids, float *scores, hipStream_t st, const int *only_if = nullptr,
+                          const int *always = nullptr);
+
+// ---- 1. GEMM ---------------------------------------------------------------------------------
+// C tile 128 (queries) x 128 (rows) per workgroup, K step 32, 4 waves as 2x2, each wave 64x64 =
+// 2x2 v_mfma_f32_32x32x2_f32 tiles.  Operands sit row-major in LDS with a leading dimension of
+// 33 floats: the MFMA operand read (lane l: row l&31, k = l>>5) then touches 32 consecutive
+// banks.  Registers prefetch the next K step while the current one is multiplied.
+constexpr int kGemmBM = 128, kGemmBN = 128, kGemmBK = 32, kGemmLd = kGemmBK + 1;
+constexpr int kGemmThreads = 256;
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+template <bool DOT>
+__global__ __launch_bounds__(kGemmThreads) void flat_gemm_kernel(
+    const float *__restrict__ queries, int64_t nq, const float *__restrict__ base, int64_t n,
+    int dim, const float *__restrict__ norms, float *__restrict__ scores /* [nq][n] */)
+{
+    __shared__ float As[kGemmBM * kGemmLd];
+    __shared__ float Bs[kGemmBN * kGemmLd];
+    // block order: the query tiles of one row tile are adjacent so they share the row tile in L2
+    const int mtiles = static_cast<int>((nq + kGemmBM - 1) / kGemmBM);
+    const int64_t bt = blockIdx.x;
+    const int64_t tn = bt / mtiles;
+    const int tm = static_cast<int>(bt % mtiles);
+    const int64_t q0 = static_cast<int64_t>(tm) * kGemmBM;
+    const int64_t n0 = tn * kGemmBN;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+
+    // staging map: 8 lanes cover one row's 32 floats (128 B), 32 rows per pass, 4 passes
+    const int srow = tid >> 3;       // 0..31
+    const int sk = (tid & 7) * 4;    // 0,4,..,28
+    const float *aptr[4];
+    const float *bptr[4];
+#pragma unroll
+    for (int p = 0; p < 4; p++) {
+        int64_t qa = q0 + p * 32 + srow;
+        if (qa >= nq) qa = nq - 1;
+        int64_t nb = n0 + p * 32 + srow;
+        if (nb >= n) nb = n - 1;
+        aptr[p] = queries + qa * dim + sk;
+        bptr[p] = base + nb * dim + sk;
+    }
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.0f;
+
+    float4 ra[4], rb[4];
+    const int ksteps = (dim + kGemmBK - 1) / kGemmBK;
+    const int full_steps = dim / kGemmBK;  // K steps with no ragged edge (uniform per kernel)
+    auto load_tile = [&](int kt) {
+        const int k0 = kt * kGemmBK;
+        if (kt < full_steps) {  // unguarded: 8 independent 16-byte loads in flight
+#pragma unroll
+            for (int p = 0; p < 4; p++) {
+                ra[p] = *reinterpret_cast<const float4 *>(aptr[p] + k0);
+                rb[p] = *reinterpret_cast<const float4 *>(bptr[p] + k0);
+            }
+        } else {  // ragged K edge: element-wise with zero fill
+#pragma unroll
+            for (int p = 0; p < 4; p++) {
+                float ta[4] = {0, 0, 0, 0}, tb[4] = {0, 0, 0, 0};
+                for (int e = 0; e < 4; e++)
+                    if (k0 + sk + e < dim) {
+                        ta[e] = aptr[p][k0 + e];
+                        tb[e] = bptr[p][k0 + e];
+                    }
+                ra[p] = make_float4(ta[0], ta[1], ta[2], ta[3]);
+                rb[p] = make_float4(tb[0], tb[1], tb[2], tb[3]);
+            }
+        }
+    };
+    load_tile(0);
+    for (int kt = 0; kt < ksteps; kt++) {
+        __syncthreads();  // previous step's operand reads are done
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+            float *da = As + (p * 32 + srow) * kGemmLd + sk;
+            float *db = Bs + (p * 32 + srow) * kGemmLd + sk;
+            da[0] = ra[p].x; da[1] = ra[p].y; da[2] = ra[p].z; da[3] = ra[p].w;
+            db[0] = rb[p].x; db[1] = rb[p].y; db[2] = rb[p].z; db[3] = rb[p].w;
+        }
+        __syncthreads();
+        if (kt + 1 < ksteps) load_tile(kt + 1);
+        const float *a_base = As + (wr * 64 + (lane & 31)) * kGemmLd + (lane >> 5);
+        const float *b_base = Bs + (wc * 64 + (lane & 31)) * kGemmLd + (lane >> 5);
+#pragma unroll
+        for (int kk = 0; kk < kGemmBK; kk += 2) {
+            const float a0 = a_base[kk], a1 = a_base[32 * kGemmLd + kk];
+            const float b0 = b_base[kk], b1 = b_base[32 * kGemmLd + kk];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+    }
+    // epilogue: C/D map of 32x32: col = lane&31 (row index n), row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        const int64_t nn = n0 + wc * 64 + j * 32 + (lane & 31);
+        const float xn = (!DOT && nn < n) ? norms[nn] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int64_t qq = q0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (qq < nq && nn < n) {
+                    const float dotv = acc[i][j][r];
+                    scores[qq * n + nn] = DOT ? -dotv : __builtin_fmaf(-2.0f, dotv, xn);
+                }
+            }
+        }
+    }
+}
+
+// ---- 2. per-query streaming select of the kc smallest scores -------------------------------
+constexpr int kSelWaves = 4;
+constexpr int kSelThreads = kSelWaves * 64;
+__global__ __launch_bounds__(kSelThreads) void flat_select_kernel(const float *__restrict__ scores,
+                                                                  int64_t n, int slices, int kc,
+                                                                  uint64_t *__restrict__ partial)
+{
+    __shared__ uint64_t lists[kSelWaves * 64];
+    __shared__ int valid[kSelWaves];
+    const int s = blockIdx.x;
+    const int64_t q = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t r0 = n * s / slices, r1 = n * (s + 1) / slices;
+    const float *row = scores + q * n;
+    WaveTopK tk;
+    tk.init(kc);
+    for (int64_t i0 = r0 + wave * 64; i0 < r1; i0 += kSelThreads) {
+        const int64_t i = i0 + lane;
+        uint64_t key = kKeyMax;
+        if (i < r1) key = make_key(row[i], static_cast<uint32_t>(i), false);
+        tk.offer(key, lane);
+    }
+    wg_rank_merge<kSelWaves>(tk, lists, valid, wave, lane, tid, kc,
+                             partial + (q * slices + s) * kc);
+}
+
+// ---- 3. exact re-score + proof -----------------------------------------------------------------
+// cand_ids/cand_scores: the kc best GEMM scores per query, ascending.  One workgroup per query.
+template <bool DOT>
+__global__ __launch_bounds__(256) void flat_verify_kernel(
+    const float *__restrict__ base, int64_t n, int dim, const float *__restrict__ queries,
+    const float *__restrict__ norms_max /* [1] */, const uint32_t *__restrict__ cand_ids,
+    const float *__restrict__ cand_scores, int kc, int k, uint32_t *__restrict__ ids,
+    float *__restrict__ scores, int *__restrict__ fallback)
+{
+    __shared__ uint64_t keys[64];
+    const Sub16 sub = Sub16::make(threadIdx.x);
+    const int64_t q = blockIdx.x;
+    const float *qv = queries + q * dim;
+    for (int c = threadIdx.x >> 4; c < kc; c += 16) {
+        const uint32_t id = cand_ids[q * kc + c];
+        uint64_t key = kKeyMax;
+        if (id != VG_INVALID_ID) {
+            const float v = exact_pair16<DOT, kPair>(base + static_cast<int64_t>(id) * dim, qv, dim, sub);
+            key = make_key(v, id, DOT);
+        }
+        if ((threadIdx.x & 15) == 0) keys[c] = key;
+    }
+    __syncthreads();
+    if (threadIdx.x >= 64) return;
+    const int lane = threadIdx.x;
+    WaveTopK tk;
+    tk.init(k);
+    tk.offer(lane < kc ? keys[lane] : kKeyMax, lane);
+    // ||q||^2 (any order: only feeds the error bound)
+    float qn = 0.0f;
+    for (int j = lane; j < dim; j += 64) qn = __builtin_fmaf(qv[j], qv[j], qn);
+    for (int off = 32; off > 0; off >>= 1) qn += __shfl_xor(qn, off);
+    const uint64_t kth = readlane_u64(tk.list, k - 1);
+    bool ok = true;
+    const bool have_all = (n <= kc);  // every row is a candidate: nothing to prove
+    if (!have_all) {
+        const float tau = cand_scores[q * kc + (kc - 1)];  // worst nominated GEMM score
+        const float xmax = norms_max[0];
+        // fp32 GEMM-form vs exact: |err| <= ~ 2*dim*2^-24*(|q||x|) per dot; bound generously
+        const float eps = 4.0f * (static_cast<float>(dim) * 5.9604645e-8f) * (qn + xmax) + 1e-30f;
+        if (kth == kKeyMax) {
+            ok = false;
+        } else if (DOT) {
+            // outside rows: -q.x >= tau  =>  q.x <= -tau (+eps); need kth dot > that
+            const float dk = key_score(kth, true);
+            ok = dk > (-tau) + eps;
+        } else {
+            const float dk = key_score(kth, false);
+            ok = dk < (tau + qn) - eps;
+        }
+    }
+    if (lane < k) {
+        const uint64_t e = tk.list;
+        ids[q * k + lane] = e == kKeyMax ? VG_INVALID_ID : key_row(e);
+        scores[q * k + lane] = e == kKeyMax ? (DOT ? -INFINITY : INFINITY) : key_score(e, DOT);
+    }
+    if (lane == 0) fallback[q] = ok ? 0 : 1;
+}
+
+// ---- 4. exhaustive exact scan for the queries whose proof failed ---------------------------------
+template <bool DOT>
+__global__ __launch_bounds__(256) void flat_exact_kernel(const float *__restrict__ base, int64_t n,
+                                                         int dim, const float *__restrict__ queries,
+                                                         const int *__restrict__ fallback,
+                                                         const int *__restrict__ always,
+                                                         int slices, int k,
+                                                         uint64_t *__restrict__ partial)
+{
+    __shared__ uint64_t lists[4 * 64];
+    __shared__ int valid[4];
+    const int s = blockIdx.x;
+    const int64_t q = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint64_t *out = partial + (q * slices + s) * k;
+    if (!(always && always[0]) && !fallback[q]) return;
+    const Sub16 sub = Sub16::make(tid);
+    const float *qv = queries + q * dim;
+    const int64_t r0 = n * s / slices, r1 = n * (s + 1) / slices;
+    WaveTopK tk;
+    tk.init(k);
+    // 4 rows per wave step (one per 16-lane group)
+    for (int64_t i0 = r0 + wave * 4; i0 < r1; i0 += 16) {
+        const int64_t i = i0 + (lane >> 4);
+        uint64_t key = kKeyMax;
+        if (i < r1) {
+            const float v = exact_pair16<DOT, kPair>(base + i * dim, qv, dim, sub);
+            if ((lane & 15) == 0) key = make_key(v, static_cast<uint32_t>(i), DOT);
+        }
+        tk.offer(key, lane);
+    }
+    wg_rank_merge<4>(tk, lists, valid, wave, lane, tid, k, out);
+}
+
+// overwrite the results of the fallback queries from the exact scan's merged lists
+__global__ void flat_patch_kernel(const int *__restrict__ fallback, const int *__restrict__ always, int k,
+                                  const uint32_t *__restrict__ fids, const float *__restrict__ fscores,
+                                  uint32_t *__restrict__ ids, float *__restrict__ scores)
+{
+    const int64_t q = blockIdx.x;
+    if (!(always && always[0]) && !fallback[q]) return;
+    for (int i = threadIdx.x; i < k; i += blockDim.x) {
+        ids[q * k + i] = fids[q * k + i];
+        scores[q * k + i] = fscores[q * k + i];
+    }
+}
+
+__global__ void max_reduce_kernel(const float *__restrict__ v, int64_t n, float *__restrict__ out)
+{
+    __shared__ float sm[256];
+    float m = 0.0f;
+    for (int64_t i = threadIdx.x; i < n; i += 256) m = fmaxf(m, v[i]);
+    sm[threadIdx.x] = m;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) sm[threadIdx.x] = fmaxf(sm[threadIdx.x], sm[threadIdx.x + s]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = sm[0];
+}
+
+}  // namespace vg
+
+VG_API int32_t vg_search_flat(vg_index *idx, const float *queries, int64_t nq, int32_t k, uint32_t *ids,
+                              float *scores, void *stream)
+{
+    VG_CHECK(idx, VG_ERR_INVALID_ARG, "vg_search_flat: NULL index");
+    VG_CHECK(nq >= 0 && k >= 0, VG_ERR_INVALID_ARG, "vg_search_flat: negative nq or k");
+    if (nq == 0 || k == 0) return VG_OK;
+    VG_CHECK(idx->metric != VG_METRIC_HAMMING, VG_ERR_UNSUPPORTED, "unsupported metric for float32: Hamming");
+    VG_CHECK(idx->n == 0 || idx->d_vectors, VG_ERR_NOT_READY, "vg_search_flat: index has no fp32 vectors");
+    VG_CHECK(queries && ids && scores, VG_ERR_INVALID_ARG, "vg_search_flat: NULL buffer");
+    VG_CHECK(k <= 32, VG_ERR_UNSUPPORTED, "vg_search_flat: k=%d exceeds 32", k);
+    VG_HIP(hipSetDevice(idx->ctx->device));
+    hipStream_t st = vg::pick_stream(idx->ctx, stream);
+    const bool dot = idx->metric != VG_METRIC_L2;
+    const int64_t n = idx->n;
+    const int dim = idx->dim;
+    const int kc = 64;  // nominated candidates per query
+
+    vg::DevIn<float> q;
+    vg::DevOut<uint32_t> oid;
+    vg::DevOut<float> osc;
+    VG_TRY(q.init(queries, static_cast<size_t>(nq) * dim, st));
+    VG_TRY(oid.init(ids, static_cast<size_t>(nq) * k, st));
+    VG_TRY(osc.init(scores, static_cast<size_t>(nq) * k, st));
+
+    if (n == 0) {
+        vg::DevTmp<uint64_t> none;
+        VG_TRY(none.init(static_cast<size_t>(nq) * k, st));
+        VG_HIP(hipMemsetAsync(none.ptr, 0xFF, static_cast<size_t>(nq) * k * 8, st));
+        VG_TRY(vg::launch_topk_merge(none.ptr, nq, 1, k, dot, oid.ptr, osc.ptr, st));
+    } else {
+        // query chunk so that the score matrix stays <= 2 GiB
+        int64_t qc = (int64_t(2) << 30) / (n * 4);
+        if (qc < 1) qc = 1;
+        if (qc > nq) qc = nq;
+        if (qc > 4096) qc = 4096;
+        const int sel_slices = static_cast<int>(std::min<int64_t>(64, std::max<int64_t>(1, n / 4096)));
+        const int ex_slices = static_cast<int>(std::min<int64_t>(256, std::max<int64_t>(1, n / 64)));
+        vg::DevTmp<float> sc, cand_sc, fsc, xmax;
+        vg::DevTmp<uint64_t> partial, fpartial;
+        vg::DevTmp<uint32_t> cand_id, fid;
+        vg::DevTmp<int> flags;
+        VG_TRY(sc.init(static_cast<size_t>(qc) * n, st));
+        VG_TRY(partial.init(static_cast<size_t>(qc) * sel_slices * kc, st));
+        VG_TRY(cand_id.init(static_cast<size_t>(qc) * kc, st));
+        VG_TRY(cand_sc.init(static_cast<size_t>(qc) * kc, st));
+        VG_TRY(flags.init(static_cast<size_t>(qc) + 1, st));
+        VG_TRY(fpartial.init(static_cast<size_t>(qc) * ex_slices * k, st));
+        VG_TRY(fid.init(static_cast<size_t>(qc) * k, st));
+        VG_TRY(fsc.init(static_cast<size_t>(qc) * k, st));
+        VG_TRY(xmax.init(1, st));
+        hipLaunchKernelGGL(vg::max_reduce_kernel, dim3(1), dim3(256), 0, st, idx->d_norms, n, xmax.ptr);
+        const char *force = getenv("VG_FLAT_FORCE_EXACT");  // test hook: run step 4 for every query
+        int *always = flags.ptr + qc;
+        VG_HIP(hipMemsetAsync(always, 0, sizeof(int), st));
+        if (force && force[0] == '1') VG_HIP(hipMemsetAsync(always, 1, sizeof(int), st));
+        for (int64_t q0 = 0; q0 < nq; q0 += qc) {
+            const int64_t cnt = std::min(qc, nq - q0);
+            const float *qp = q.ptr + q0 * dim;
+            const int64_t mt = (cnt + vg::kGemmBM - 1) / vg::kGemmBM, nt = (n + vg::kGemmBN - 1) / vg::kGemmBN;
+            {
+            vg::ProfScope prof(idx->ctx, "flat_gemm", st);
+            if (dot)
+                hipLaunchKernelGGL(vg::flat_gemm_kernel<true>, dim3(static_cast<unsigned>(mt * nt)),
+                                   dim3(vg::kGemmThreads), 0, st, qp, cnt, idx->d_vectors, n, dim,
+                                   idx->d_norms, sc.ptr);
+            else
+                hipLaunchKernelGGL(vg::flat_gemm_kernel<false>, dim3(static_cast<unsigned>(mt * nt)),
+                                   dim3(vg::kGemmThreads), 0, st, qp, cnt, idx->d_vectors, n, dim,
+                                   idx->d_norms, sc.ptr);
+            }
+            {
+            vg::ProfScope prof(idx->ctx, "flat_select", st);
+            hipLaunchKernelGGL(vg::flat_select_kernel, dim3(sel_slices, static_cast<unsigned>(cnt)),
+                               dim3(vg::kSelThreads), 0, st, sc.ptr, n, sel_slices, kc, partial.ptr);
+            }
+            VG_TRY(vg::launch_topk_merge(partial.ptr, cnt, sel_slices, kc, false, cand_id.ptr, cand_sc.ptr, st));
+            if (dot)
+                hipLaunchKernelGGL(vg::flat_verify_kernel<true>, dim3(static_cast<unsigned>(cnt)), dim3(256), 0,
+                                   st, idx->d_vectors, n, dim, qp, xmax.ptr, cand_id.ptr, cand_sc.ptr, kc, k,
+                                   oid.ptr + q0 * k, osc.ptr + q0 * k, flags.ptr);
+            else
+                hipLaunchKernelGGL(vg::flat_verify_kernel<false>, dim3(static_cast<unsigned>(cnt)), dim3(256), 0,
+                                   st, idx->d_vectors, n, dim, qp, xmax.ptr, cand_id.ptr, cand_sc.ptr, kc, k,
+                                   oid.ptr + q0 * k, osc.ptr + q0 * k, flags.ptr);
+            // step 4 always launches; its workgroups exit at once unless the query is flagged
+            if (dot)
+                hipLaunchKernelGGL(vg::flat_exact_kernel<true>, dim3(ex_slices, static_cast<unsigned>(cnt)),
+                                   dim3(256), 0, st, idx->d_vectors, n, dim, qp, flags.ptr, always, ex_slices, k,
+                                   fpartial.ptr);
+            else
+                hipLaunchKernelGGL(vg::flat_exact_kernel<false>, dim3(ex_slices, static_cast<unsigned>(cnt)),
+                                   dim3(256), 0, st, idx->d_vectors, n, dim, qp, flags.ptr, always, ex_slices, k,
+                                   fpartial.ptr);
+            if (getenv("VG_FLAT_DEBUG")) {
+                std::vector<int> hf(cnt);
+                (void)hipMemcpyAsync(hf.data(), flags.ptr, sizeof(int) * cnt, hipMemcpyDeviceToHost, st);
+                (void)hipStreamSynchronize(st);
+                int64_t nf = 0;
+                for (int f : hf) nf += f != 0;
+                fprintf(stderr, "[vg_search_flat] chunk q0=%lld cnt=%lld: %lld queries failed the proof\n",
+                        (long long)q0, (long long)cnt, (long long)nf);
+            }
+            VG_TRY(vg::launch_topk_merge(fpartial.ptr, cnt, ex_slices, k, dot, fid.ptr, fsc.ptr, st, flags.ptr, always));
+            hipLaunchKernelGGL(vg::flat_patch_kernel, dim3(static_cast<unsigned>(cnt)), dim3(64), 0, st,
+                               flags.ptr, always, k, fid.ptr, fsc.ptr, oid.ptr + q0 * k, osc.ptr + q0 * k);
+        }
+        VG_HIP(hipGetLastError());
+    }
+    VG_TRY(oid.finish());
+    VG_TRY(osc.finish());
+    if (oid.on_host() || osc.on_host()) VG_HIP(hipStreamSynchronize(st));
+    return VG_OK;
+}

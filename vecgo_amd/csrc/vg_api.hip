@@ -116,6 +116,40 @@ VG_API int32_t vg_ctx_device_info(vg_ctx *ctx, char *arch, int32_t arch_len,
     return VG_OK;
 }
 
+VG_API int32_t vg_profile_enable(vg_ctx *ctx, int32_t on)
+{
+    VG_CHECK(ctx != nullptr, VG_ERR_INVALID_ARG, "vg_profile_enable: ctx is NULL");
+    ctx->profiling = on != 0;
+    return VG_OK;
+}
+
+VG_API int32_t vg_profile_read(vg_ctx *ctx, const char *kernel, int64_t *launches, double *total_ms)
+{
+    VG_CHECK(ctx && kernel && launches && total_ms, VG_ERR_INVALID_ARG, "vg_profile_read: NULL argument");
+    VG_HIP(hipSetDevice(ctx->device));
+    std::lock_guard<std::mutex> g(ctx->prof_mu);
+    int64_t n = 0;
+    double ms = 0.0;
+    std::vector<vg_prof_record> keep;
+    for (auto &r : ctx->prof) {
+        if (strcmp(r.name, kernel) != 0) {
+            keep.push_back(r);
+            continue;
+        }
+        float t = 0.0f;
+        if (hipEventSynchronize(r.stop) == hipSuccess && hipEventElapsedTime(&t, r.start, r.stop) == hipSuccess) {
+            n++;
+            ms += t;
+        }
+        (void)hipEventDestroy(r.start);
+        (void)hipEventDestroy(r.stop);
+    }
+    ctx->prof.swap(keep);
+    *launches = n;
+    *total_ms = ms;
+    return VG_OK;
+}
+
 VG_API int32_t vg_index_create(vg_ctx *ctx, int64_t n, int32_t dim, int32_t metric,
                                vg_index **out)
 {

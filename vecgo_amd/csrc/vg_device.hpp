@@ -133,4 +133,27 @@ __device__ __forceinline__ int lower_bound64(const uint64_t *sorted, uint64_t e)
     return pos + (sorted[pos] < e ? 1 : 0);
 }
 
+// Rank-merge of the per-wave sorted lists of one workgroup into `out[0..k)` (ascending,
+// kKeyMax padded): a key's final position is its own index plus the number of smaller keys in
+// every other wave's list (keys are unique).  `lists` = WAVES*64 keys of LDS, `valid` = WAVES ints.
+template <int WAVES>
+__device__ __forceinline__ void wg_rank_merge(const WaveTopK &tk, uint64_t *lists, int *valid,
+                                              int wave, int lane, int tid, int k, uint64_t *out)
+{
+    lists[wave * 64 + lane] = tk.list;
+    const int nvalid = __popcll(__ballot(tk.list != kKeyMax));
+    if (lane == 0) valid[wave] = nvalid;
+    __syncthreads();
+    const uint64_t e = tk.list;
+    if (e != kKeyMax) {
+        int rank = lane;
+        for (int w = 0; w < WAVES; w++)
+            if (w != wave) rank += lower_bound64(lists + w * 64, e);
+        if (rank < k) out[rank] = e;
+    }
+    int total = 0;
+    for (int w = 0; w < WAVES; w++) total += valid[w];
+    for (int i = total + tid; i < k; i += WAVES * 64) out[i] = kKeyMax;
+}
+
 }  // namespace vg

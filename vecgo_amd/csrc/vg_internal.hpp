@@ -49,13 +49,50 @@ bool is_device_ptr(const void *p);
 
 }  // namespace vg
 
+struct vg_prof_record {
+    const char *name;
+    hipEvent_t start, stop;
+};
+
 struct vg_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     int compute_units = 0;
     int64_t hbm_bytes = 0;
     char arch[64] = {0};
+    bool profiling = false;
+    std::mutex prof_mu;
+    std::vector<vg_prof_record> prof;
 };
+
+namespace vg {
+// RAII bracket around a kernel launch: records an event pair on `st` when profiling is on
+struct ProfScope {
+    vg_ctx *ctx;
+    hipStream_t st;
+    vg_prof_record rec{};
+    bool active = false;
+    ProfScope(vg_ctx *c, const char *name, hipStream_t s) : ctx(c), st(s)
+    {
+        if (!c->profiling) return;
+        if (hipEventCreate(&rec.start) != hipSuccess) return;
+        if (hipEventCreate(&rec.stop) != hipSuccess) {
+            (void)hipEventDestroy(rec.start);
+            return;
+        }
+        rec.name = name;
+        (void)hipEventRecord(rec.start, st);
+        active = true;
+    }
+    ~ProfScope()
+    {
+        if (!active) return;
+        (void)hipEventRecord(rec.stop, st);
+        std::lock_guard<std::mutex> g(ctx->prof_mu);
+        ctx->prof.push_back(rec);
+    }
+};
+}  // namespace vg
 
 namespace vg {
 
