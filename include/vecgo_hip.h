@@ -124,6 +124,23 @@ int32_t vg_pq_decode(vg_pq *pq, const uint8_t *codes, int64_t n, float *out, voi
 int32_t vg_pq_asymmetric_distance_batch(vg_pq *pq, const float *query, const uint8_t *codes,
                                         int64_t n, float *out, void *stream);
 
+/* ---- RaBitQ / binary (internal/quantization/rabitq.go, binary.go) -------------------- */
+/* BytesTotal rabitq.go:187-190: ((dim+63)/64)*8 + 4 */
+int64_t vg_rabitq_code_bytes(int32_t dim);
+/* Encode rabitq.go:51-78, batched: codes[n*code_bytes] = sign bits (bit i -> byte i/8, bit
+ * i%8; v >= 0 sets the bit) padded to 8-byte words, then the little-endian fp32 norm
+ * sqrt(Dot(v,v)) (dotProductAvx512 order, float64 sqrt rounded to fp32: simd/doc.go:58-60) */
+int32_t vg_rabitq_encode(vg_ctx *ctx, int32_t dim, const float *vectors, int64_t n, uint8_t *codes,
+                         void *stream);
+/* Distance rabitq.go:119-176 of one query against n codes (reference layout): out[n] =
+ * (|q|-|y|)^2 + (4*|q|*|y|/dim)*hamming, evaluated left to right in fp32 */
+int32_t vg_rabitq_distance_batch(vg_ctx *ctx, int32_t dim, const float *query, const uint8_t *codes,
+                                 int64_t n, float *out, void *stream);
+/* simd.Hamming kernels.go:71 (hammingAvx512, popcount_avx512.c:25-46), one nbytes-long code
+ * against n contiguous codes: out[n] (exact integers) */
+int32_t vg_hamming_batch(vg_ctx *ctx, const uint8_t *a, const uint8_t *codes, int64_t nbytes, int64_t n,
+                         int32_t *out, void *stream);
+
 /* ---- resident index ---------------------------------------------------------- */
 int32_t vg_index_create(vg_ctx *ctx, int64_t n, int32_t dim, int32_t metric, vg_index **out);
 int32_t vg_index_destroy(vg_index *idx);
@@ -132,6 +149,10 @@ int32_t vg_index_destroy(vg_index *idx);
  * library keeps its own HBM copy (re-tiled for coalesced 16-byte loads); the
  * quantizer handle must outlive the index. */
 int32_t vg_index_set_pq_codes(vg_index *idx, vg_pq *pq, const uint8_t *codes, void *stream);
+
+/* RaBitQ codes of a DiskANN segment: n*code_bytes row-major (diskann/segment.go:1393-1409).
+ * Re-tiled in HBM like the PQ codes (bits in 16-byte groups per 64-row tile, norms apart). */
+int32_t vg_index_set_rabitq_codes(vg_index *idx, const uint8_t *codes, void *stream);
 
 /* fp32 rows of the segment, n*dim row-major — the layout of
  * vectorstore.ColumnarStore (internal/vectorstore/columnar.go:21-24) and of
@@ -170,6 +191,13 @@ int32_t vg_score_candidates(vg_index *idx, const float *queries, int64_t nq,
  * (distance.Provider, distance/distance.go:91-106).  k <= 32. */
 int32_t vg_search_flat(vg_index *idx, const float *queries, int64_t nq, int32_t k, uint32_t *ids,
                        float *scores, void *stream);
+
+/* exhaustive scan of the RaBitQ codes: RaBitQuantizer.Distance (rabitq.go:119-176) for every
+ * row, best k by (Score, RowID).  The reference only scores RaBitQ codes node by node inside the
+ * Vamana search (diskann/segment.go:512-535); the scan is the sharded config-5 workload
+ * (SURVEY.md §8d).  k <= 64. */
+int32_t vg_search_rabitq(vg_index *idx, const float *queries, int64_t nq, int32_t k, uint32_t *ids,
+                         float *scores, void *stream);
 
 /* engine fan-in (engine/search.go:904-908: per-segment candidate lists merged into one
  * bounded heap, ordered by searcher/candidate_queue.go:12-23).  Here the "segments" are row

@@ -4,8 +4,8 @@ The product is libvecgo_hip.so (C ABI: include/vecgo_hip.h).  This package is th
 Python binding the tests and bench.py drive it with; names mirror the reference's Go
 interfaces (distance.Metric, quantization.ProductQuantizer, ...).
 """
-from .api import (Context, Index, Metric, ProductQuantizer, VecgoHipError, dot_batch,  # noqa: F401
-                  merge_topk, squared_l2_batch)
+from .api import (Context, Index, Metric, ProductQuantizer, RaBitQuantizer, VecgoHipError,  # noqa: F401
+                  dot_batch, hamming_batch, merge_topk, squared_l2_batch)
 
-__all__ = ["Context", "Index", "Metric", "ProductQuantizer", "VecgoHipError", "dot_batch",
-           "merge_topk", "squared_l2_batch"]
+__all__ = ["Context", "Index", "Metric", "ProductQuantizer", "RaBitQuantizer", "VecgoHipError",
+           "dot_batch", "hamming_batch", "merge_topk", "squared_l2_batch"]

@@ -150,6 +150,62 @@ def merge_topk(ctx: Context, ids_in, scores_in, k: int, metric=0, id_offsets=Non
     return out
 
 
+class RaBitQuantizer:
+    """quantization.RaBitQuantizer (internal/quantization/rabitq.go:26-49)."""
+
+    def __init__(self, ctx: Context, dimension: int):
+        if dimension <= 0:
+            raise VecgoHipError(-1, "dimension must be positive")
+        self.ctx, self.dimension = ctx, dimension
+        self._lib = ctx._lib
+        self._lib.vg_rabitq_code_bytes.restype = C.c_int64
+
+    def bytes_total(self) -> int:
+        """BytesTotal (rabitq.go:187-190)."""
+        return int(self._lib.vg_rabitq_code_bytes(C.c_int32(self.dimension)))
+
+    def encode(self, vectors, out=None, stream=None):
+        n = _rows(vectors, self.dimension)
+        v, pv = _ptr(vectors, np.float32)
+        if out is None:
+            out = _empty_like(vectors, (n, self.bytes_total()), np.uint8)
+        c, pc = _ptr(out, np.uint8, n * self.bytes_total())
+        check(self._lib.vg_rabitq_encode(self.ctx._h, C.c_int32(self.dimension), pv, C.c_int64(n), pc,
+                                         _stream_ptr(stream)))
+        return out
+
+    def distance(self, query, codes, out=None, stream=None):
+        """Distance (rabitq.go:119-176) of one query against n codes."""
+        if _rows(query, self.dimension) != 1:
+            raise VecgoHipError(-2, "vector dimension mismatch")
+        total = codes.numel() if _is_torch(codes) else np.asarray(codes).size
+        if total % self.bytes_total():
+            raise VecgoHipError(-4, "invalid code length")
+        n = total // self.bytes_total()
+        q, pq_ = _ptr(query, np.float32)
+        c, pc = _ptr(codes, np.uint8)
+        if out is None:
+            out = _empty_like(codes, (n,), np.float32)
+        o, po = _ptr(out, np.float32, n)
+        check(self._lib.vg_rabitq_distance_batch(self.ctx._h, C.c_int32(self.dimension), pq_, pc,
+                                                 C.c_int64(n), po, _stream_ptr(stream)))
+        return out
+
+
+def hamming_batch(ctx: Context, a, codes, out=None, stream=None):
+    """simd.Hamming (kernels.go:71) of one byte string against n contiguous ones."""
+    a_, pa = _ptr(a, np.uint8)
+    nbytes = a_.numel() if _is_torch(a_) else a_.size
+    total = codes.numel() if _is_torch(codes) else np.asarray(codes).size
+    n = total // nbytes if nbytes else 0
+    c, pc = _ptr(codes, np.uint8)
+    if out is None:
+        out = _empty_like(codes, (n,), np.int32)
+    o, po = _ptr(out, np.int32, n)
+    check(ctx._lib.vg_hamming_batch(ctx._h, pa, pc, C.c_int64(nbytes), C.c_int64(n), po, _stream_ptr(stream)))
+    return out
+
+
 class ProductQuantizer:
     """quantization.ProductQuantizer (internal/quantization/pq.go:20-29)."""
 
@@ -291,6 +347,17 @@ class Index:
         c, pc = _ptr(codes, np.uint8, self.n * pq.num_subvectors)
         self._keep.append(pq)
         check(self._lib.vg_index_set_pq_codes(self._h, pq._h, pc, _stream_ptr(stream)))
+
+    def set_rabitq_codes(self, codes, stream=None):
+        lib = self._lib
+        lib.vg_rabitq_code_bytes.restype = C.c_int64
+        cb = int(lib.vg_rabitq_code_bytes(C.c_int32(self.dim)))
+        c, pc = _ptr(codes, np.uint8, self.n * cb)
+        check(lib.vg_index_set_rabitq_codes(self._h, pc, _stream_ptr(stream)))
+
+    def search_rabitq(self, queries, k, out=None, stream=None):
+        """Exhaustive RaBitQ scan (rabitq.go:119-176 per row), top-k by (Score, RowID)."""
+        return self._search(self._lib.vg_search_rabitq, queries, k, out=out, stream=stream)
 
     def set_vectors(self, base, stream=None):
         """fp32 rows, n*dim row-major (vectorstore/columnar.go:21-24)."""

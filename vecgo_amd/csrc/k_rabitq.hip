@@ -1,0 +1,332 @@
+// k_rabitq.hip — RaBitQuantizer (internal/quantization/rabitq.go) and simd.Hamming on the device.
+#include "vg_device.hpp"
+#include "vg_exact.hpp"
+#include "vg_internal.hpp"
+
+namespace vg {
+
+int32_t launch_topk_merge(const uint64_t *partial, int64_t nq, int lists, int k, bool descending,
+                          uint32_t *ids, float *scores, hipStream_t st, const int *only_if = nullptr,
+                          const int *always = nullptr);
+
+__host__ __device__ inline int rq_words(int dim) { return (dim + 63) / 64; }
+
+// Encode (rabitq.go:51-78): 16 lanes per vector.  Norm: dotProductAvx512 order, float64 sqrt.
+// Bits: lane L of the group owns elements 4L..4L+3 of each 64-element word = one nibble.
+__global__ __launch_bounds__(256) void rabitq_encode_kernel(const float *__restrict__ vectors, int64_t n,
+                                                            int dim, uint8_t *__restrict__ codes)
+{
+    const int64_t row = static_cast<int64_t>(blockIdx.x) * 16 + (threadIdx.x >> 4);
+    if (row >= n) return;
+    const Sub16 sub = Sub16::make(threadIdx.x);
+    const int L = threadIdx.x & 15;
+    const float *v = vectors + row * dim;
+    const int nw = rq_words(dim);
+    const int64_t cb = static_cast<int64_t>(nw) * 8 + 4;
+    uint8_t *out = codes + row * cb;
+    const float sumsq = exact_pair16<true, kPair>(v, v, dim, sub);
+    const float norm = static_cast<float>(sqrt(static_cast<double>(sumsq)));
+    for (int w = 0; w < nw; w++) {
+        uint32_t nib = 0;
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const int e = w * 64 + 4 * L + t;
+            if (e < dim && v[e] >= 0.0f) nib |= 1u << t;
+        }
+        const uint32_t other = static_cast<uint32_t>(
+            __builtin_amdgcn_update_dpp(0, static_cast<int>(nib), kDppQuadXor1, 0xF, 0xF, false));
+        if ((L & 1) == 0) out[w * 8 + (L >> 1)] = static_cast<uint8_t>(nib | (other << 4));
+    }
+    if (L == 0) {
+        uint32_t nb = __float_as_uint(norm);
+        out[nw * 8 + 0] = nb & 0xFF;
+        out[nw * 8 + 1] = (nb >> 8) & 0xFF;
+        out[nw * 8 + 2] = (nb >> 16) & 0xFF;
+        out[nw * 8 + 3] = (nb >> 24) & 0xFF;
+    }
+}
+
+__device__ inline float rq_formula(float qn, float yn, float dimf, float hamming)
+{
+    // rabitq.go:170-175, fp32, left to right, no fusion
+    const float t1 = qn - yn;
+    const float t1sq = t1 * t1;
+    float t2 = 4.0f * qn;
+    t2 = t2 * yn;
+    t2 = t2 / dimf;
+    t2 = t2 * hamming;
+    return t1sq + t2;
+}
+
+// Distance of one query code (bits + norm, as produced by Encode) against n reference-layout
+// codes: thread per row.
+__global__ void rabitq_distance_kernel(const uint8_t *__restrict__ qcode, const uint8_t *__restrict__ codes,
+                                       int64_t n, int dim, float *__restrict__ out)
+{
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int nb = rq_words(dim) * 8;
+    const uint8_t *c = codes + i * (nb + 4);
+    int h = 0;
+    for (int b = 0; b < nb; b++) h += __popc(static_cast<unsigned>(qcode[b] ^ c[b]));
+    uint32_t qb = qcode[nb] | (qcode[nb + 1] << 8) | (qcode[nb + 2] << 16) | (static_cast<uint32_t>(qcode[nb + 3]) << 24);
+    uint32_t yb = c[nb] | (c[nb + 1] << 8) | (c[nb + 2] << 16) | (static_cast<uint32_t>(c[nb + 3]) << 24);
+    out[i] = rq_formula(__uint_as_float(qb), __uint_as_float(yb), static_cast<float>(dim), static_cast<float>(h));
+}
+
+__global__ void hamming_batch_kernel(const uint8_t *__restrict__ a, const uint8_t *__restrict__ codes,
+                                     int64_t nbytes, int64_t n, int32_t *__restrict__ out)
+{
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint8_t *c = codes + i * nbytes;
+    int h = 0;
+    for (int64_t b = 0; b < nbytes; b++) h += __popc(static_cast<unsigned>(a[b] ^ c[b]));
+    out[i] = h;
+}
+
+// reference layout -> [tile][group][lane] 16-byte pieces of the sign bits + norms[n]
+__global__ void rabitq_retile_kernel(const uint8_t *__restrict__ codes, int64_t n, int nb, int groups,
+                                     int64_t n_tiles, uint4 *__restrict__ tiles, float *__restrict__ norms)
+{
+    const int64_t gid = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    const int64_t total = n_tiles * groups * 64;
+    if (gid >= total) return;
+    const int lane = static_cast<int>(gid & 63);
+    const int64_t tg = gid >> 6;
+    const int g = static_cast<int>(tg % groups);
+    const int64_t row = (tg / groups) * 64 + lane;
+    uint32_t w[4] = {0, 0, 0, 0};
+    if (row < n) {
+        const uint8_t *src = codes + row * (nb + 4);
+        for (int b = 0; b < 16; b++) {
+            const int at = g * 16 + b;
+            if (at < nb) w[b >> 2] |= static_cast<uint32_t>(src[at]) << (8 * (b & 3));
+        }
+        if (g == 0) {
+            uint32_t yb = src[nb] | (src[nb + 1] << 8) | (src[nb + 2] << 16) | (static_cast<uint32_t>(src[nb + 3]) << 24);
+            norms[row] = __uint_as_float(yb);
+        }
+    }
+    tiles[gid] = make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+// Exhaustive RaBitQ scan with fused top-k.  HBM-bound: (16*groups + 4) bytes per row.
+constexpr int kRqWaves = 4;
+constexpr int kRqThreads = kRqWaves * 64;
+__global__ __launch_bounds__(kRqThreads) void rabitq_scan_kernel(
+    const uint4 *__restrict__ tiles, const float *__restrict__ norms, int64_t n_rows, int64_t n_tiles,
+    int groups, int dim, const uint8_t *__restrict__ qcodes /* nq * (nb+4) */, int nb, int slices, int nq,
+    int k, uint64_t *__restrict__ partial)
+{
+    __shared__ uint4 qbits[64];  // up to 1024 bytes of sign bits (dim <= 8192)
+    __shared__ uint64_t lists[kRqWaves * 64];
+    __shared__ int valid[kRqWaves];
+    const int b = blockIdx.x;
+    const int xcd = b & 7;
+    const int o = b >> 3;
+    const int q = o % nq;
+    const int s = (o / nq) * 8 + xcd;
+    const int64_t t0 = n_tiles * s / slices, t1 = n_tiles * (s + 1) / slices;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint8_t *qc = qcodes + static_cast<int64_t>(q) * (nb + 4);
+    if (tid < groups) {
+        uint32_t w[4] = {0, 0, 0, 0};
+        for (int bb = 0; bb < 16; bb++) {
+            const int at = tid * 16 + bb;
+            if (at < nb) w[bb >> 2] |= static_cast<uint32_t>(qc[at]) << (8 * (bb & 3));
+        }
+        qbits[tid] = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+    const uint32_t qnb = qc[nb] | (qc[nb + 1] << 8) | (qc[nb + 2] << 16) | (static_cast<uint32_t>(qc[nb + 3]) << 24);
+    const float qn = __uint_as_float(qnb);
+    const float dimf = static_cast<float>(dim);
+    __syncthreads();
+    WaveTopK tk;
+    tk.init(k);
+    for (int64_t tile = t0 + wave; tile < t1; tile += kRqWaves) {
+        const uint4 *tp = tiles + (tile * groups) * 64 + lane;
+        int h = 0;
+        for (int g = 0; g < groups; g++) {
+            const uint4 c = tp[g * 64];
+            const uint4 qq = qbits[g];
+            h += __popc(c.x ^ qq.x) + __popc(c.y ^ qq.y) + __popc(c.z ^ qq.z) + __popc(c.w ^ qq.w);
+        }
+        const int64_t row = tile * 64 + lane;
+        uint64_t key = kKeyMax;
+        if (row < n_rows) {
+            const float d = rq_formula(qn, norms[row], dimf, static_cast<float>(h));
+            key = make_key(d, static_cast<uint32_t>(row), false);
+        }
+        tk.offer(key, lane);
+    }
+    wg_rank_merge<kRqWaves>(tk, lists, valid, wave, lane, tid, k,
+                            partial + (static_cast<int64_t>(q) * slices + s) * k);
+}
+
+static int rq_slices(int64_t nq, int64_t n_tiles, int cus)
+{
+    int64_t s = (4 * cus + nq - 1) / nq;  // ~4 workgroups of 256 threads per CU
+    s = ((s + 7) / 8) * 8;
+    int64_t max_s = (n_tiles / 8) * 8;
+    if (max_s < 8) max_s = 8;
+    if (s > max_s) s = max_s;
+    if (s < 8) s = 8;
+    return static_cast<int>(s);
+}
+
+}  // namespace vg
+
+VG_API int64_t vg_rabitq_code_bytes(int32_t dim) { return static_cast<int64_t>((dim + 63) / 64) * 8 + 4; }
+
+VG_API int32_t vg_rabitq_encode(vg_ctx *ctx, int32_t dim, const float *vectors, int64_t n, uint8_t *codes,
+                                void *stream)
+{
+    VG_CHECK(ctx, VG_ERR_INVALID_ARG, "vg_rabitq_encode: ctx is NULL");
+    VG_CHECK(dim > 0 && n >= 0, VG_ERR_INVALID_ARG, "vg_rabitq_encode: bad dim or n");
+    if (n == 0) return VG_OK;
+    VG_CHECK(vectors && codes, VG_ERR_INVALID_ARG, "vg_rabitq_encode: NULL buffer");
+    VG_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = vg::pick_stream(ctx, stream);
+    const int64_t cb = vg_rabitq_code_bytes(dim);
+    vg::DevIn<float> v;
+    vg::DevOut<uint8_t> c;
+    VG_TRY(v.init(vectors, static_cast<size_t>(n) * dim, st));
+    VG_TRY(c.init(codes, static_cast<size_t>(n) * cb, st));
+    hipLaunchKernelGGL(vg::rabitq_encode_kernel, dim3(static_cast<unsigned>((n + 15) / 16)), dim3(256), 0, st,
+                       v.ptr, n, dim, c.ptr);
+    VG_HIP(hipGetLastError());
+    VG_TRY(c.finish());
+    if (c.on_host()) VG_HIP(hipStreamSynchronize(st));
+    return VG_OK;
+}
+
+VG_API int32_t vg_rabitq_distance_batch(vg_ctx *ctx, int32_t dim, const float *query, const uint8_t *codes,
+                                        int64_t n, float *out, void *stream)
+{
+    VG_CHECK(ctx, VG_ERR_INVALID_ARG, "vg_rabitq_distance_batch: ctx is NULL");
+    VG_CHECK(dim > 0 && n >= 0, VG_ERR_INVALID_ARG, "vg_rabitq_distance_batch: bad dim or n");
+    if (n == 0) return VG_OK;
+    VG_CHECK(query && codes && out, VG_ERR_INVALID_ARG, "vg_rabitq_distance_batch: NULL buffer");
+    VG_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = vg::pick_stream(ctx, stream);
+    const int64_t cb = vg_rabitq_code_bytes(dim);
+    vg::DevIn<float> q;
+    vg::DevIn<uint8_t> c;
+    vg::DevOut<float> o;
+    vg::DevTmp<uint8_t> qcode;
+    VG_TRY(q.init(query, static_cast<size_t>(dim), st));
+    VG_TRY(c.init(codes, static_cast<size_t>(n) * cb, st));
+    VG_TRY(o.init(out, static_cast<size_t>(n), st));
+    VG_TRY(qcode.init(static_cast<size_t>(cb), st));
+    hipLaunchKernelGGL(vg::rabitq_encode_kernel, dim3(1), dim3(256), 0, st, q.ptr, int64_t(1), dim, qcode.ptr);
+    hipLaunchKernelGGL(vg::rabitq_distance_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, st,
+                       qcode.ptr, c.ptr, n, dim, o.ptr);
+    VG_HIP(hipGetLastError());
+    VG_TRY(o.finish());
+    if (o.on_host()) VG_HIP(hipStreamSynchronize(st));
+    return VG_OK;
+}
+
+VG_API int32_t vg_hamming_batch(vg_ctx *ctx, const uint8_t *a, const uint8_t *codes, int64_t nbytes, int64_t n,
+                                int32_t *out, void *stream)
+{
+    VG_CHECK(ctx, VG_ERR_INVALID_ARG, "vg_hamming_batch: ctx is NULL");
+    VG_CHECK(nbytes >= 0 && n >= 0, VG_ERR_INVALID_ARG, "vg_hamming_batch: negative size");
+    if (n == 0) return VG_OK;
+    VG_CHECK(out && (nbytes == 0 || (a && codes)), VG_ERR_INVALID_ARG, "vg_hamming_batch: NULL buffer");
+    VG_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = vg::pick_stream(ctx, stream);
+    vg::DevIn<uint8_t> da, dc;
+    vg::DevOut<int32_t> o;
+    VG_TRY(da.init(a, static_cast<size_t>(nbytes), st));
+    VG_TRY(dc.init(codes, static_cast<size_t>(n) * nbytes, st));
+    VG_TRY(o.init(out, static_cast<size_t>(n), st));
+    hipLaunchKernelGGL(vg::hamming_batch_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, st,
+                       da.ptr, dc.ptr, nbytes, n, o.ptr);
+    VG_HIP(hipGetLastError());
+    VG_TRY(o.finish());
+    if (o.on_host()) VG_HIP(hipStreamSynchronize(st));
+    return VG_OK;
+}
+
+VG_API int32_t vg_index_set_rabitq_codes(vg_index *idx, const uint8_t *codes, void *stream)
+{
+    VG_CHECK(idx, VG_ERR_INVALID_ARG, "vg_index_set_rabitq_codes: NULL index");
+    VG_CHECK(idx->n == 0 || codes, VG_ERR_INVALID_ARG, "vg_index_set_rabitq_codes: codes is NULL");
+    VG_CHECK(idx->dim <= 8192, VG_ERR_UNSUPPORTED, "vg_index_set_rabitq_codes: dim %d > 8192", idx->dim);
+    VG_HIP(hipSetDevice(idx->ctx->device));
+    hipStream_t st = vg::pick_stream(idx->ctx, stream);
+    if (idx->d_rq_tiles) {
+        VG_HIP(hipStreamSynchronize(st));
+        VG_HIP(hipFree(idx->d_rq_tiles));
+        VG_HIP(hipFree(idx->d_rq_norms));
+        idx->d_rq_tiles = nullptr;
+        idx->d_rq_norms = nullptr;
+    }
+    const int nb = vg::rq_words(idx->dim) * 8;
+    idx->rq_groups = (nb + 15) / 16;
+    idx->n_tiles = (idx->n + 63) / 64;
+    if (idx->n == 0) return VG_OK;
+    const int64_t total = idx->n_tiles * idx->rq_groups * 64;
+    VG_HIP(hipMalloc(reinterpret_cast<void **>(&idx->d_rq_tiles), static_cast<size_t>(total) * 16));
+    VG_HIP(hipMalloc(reinterpret_cast<void **>(&idx->d_rq_norms), static_cast<size_t>(idx->n) * sizeof(float)));
+    vg::DevIn<uint8_t> in;
+    VG_TRY(in.init(codes, static_cast<size_t>(idx->n) * (nb + 4), st));
+    hipLaunchKernelGGL(vg::rabitq_retile_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, st,
+                       in.ptr, idx->n, nb, idx->rq_groups, idx->n_tiles, reinterpret_cast<uint4 *>(idx->d_rq_tiles),
+                       idx->d_rq_norms);
+    VG_HIP(hipGetLastError());
+    VG_HIP(hipStreamSynchronize(st));
+    return VG_OK;
+}
+
+VG_API int32_t vg_search_rabitq(vg_index *idx, const float *queries, int64_t nq, int32_t k, uint32_t *ids,
+                                float *scores, void *stream)
+{
+    VG_CHECK(idx, VG_ERR_INVALID_ARG, "vg_search_rabitq: NULL index");
+    VG_CHECK(nq >= 0 && k >= 0, VG_ERR_INVALID_ARG, "vg_search_rabitq: negative nq or k");
+    if (nq == 0 || k == 0) return VG_OK;
+    VG_CHECK(idx->n == 0 || idx->d_rq_tiles, VG_ERR_NOT_READY, "vg_search_rabitq: index has no RaBitQ codes");
+    VG_CHECK(queries && ids && scores, VG_ERR_INVALID_ARG, "vg_search_rabitq: NULL buffer");
+    VG_CHECK(k <= 64, VG_ERR_UNSUPPORTED, "vg_search_rabitq: k=%d exceeds 64", k);
+    VG_HIP(hipSetDevice(idx->ctx->device));
+    hipStream_t st = vg::pick_stream(idx->ctx, stream);
+    vg::DevIn<float> q;
+    vg::DevOut<uint32_t> oid;
+    vg::DevOut<float> osc;
+    VG_TRY(q.init(queries, static_cast<size_t>(nq) * idx->dim, st));
+    VG_TRY(oid.init(ids, static_cast<size_t>(nq) * k, st));
+    VG_TRY(osc.init(scores, static_cast<size_t>(nq) * k, st));
+    if (idx->n == 0) {
+        vg::DevTmp<uint64_t> none;
+        VG_TRY(none.init(static_cast<size_t>(nq) * k, st));
+        VG_HIP(hipMemsetAsync(none.ptr, 0xFF, static_cast<size_t>(nq) * k * 8, st));
+        VG_TRY(vg::launch_topk_merge(none.ptr, nq, 1, k, false, oid.ptr, osc.ptr, st));
+    } else {
+        const int nb = vg::rq_words(idx->dim) * 8;
+        const int slices = vg::rq_slices(nq, idx->n_tiles, idx->ctx->compute_units);
+        vg::DevTmp<uint8_t> qcodes;
+        vg::DevTmp<uint64_t> partial;
+        VG_TRY(qcodes.init(static_cast<size_t>(nq) * (nb + 4), st));
+        VG_TRY(partial.init(static_cast<size_t>(nq) * slices * k, st));
+        hipLaunchKernelGGL(vg::rabitq_encode_kernel, dim3(static_cast<unsigned>((nq + 15) / 16)), dim3(256), 0, st,
+                           q.ptr, nq, idx->dim, qcodes.ptr);
+        const int64_t max_q = (1ll << 30) / slices;
+        for (int64_t q0 = 0; q0 < nq; q0 += max_q) {
+            const int64_t cnt = nq - q0 < max_q ? nq - q0 : max_q;
+            vg::ProfScope prof(idx->ctx, "rabitq_scan", st);
+            hipLaunchKernelGGL(vg::rabitq_scan_kernel, dim3(static_cast<unsigned>(cnt * slices)),
+                               dim3(vg::kRqThreads), 0, st, reinterpret_cast<const uint4 *>(idx->d_rq_tiles),
+                               idx->d_rq_norms, idx->n, idx->n_tiles, idx->rq_groups, idx->dim,
+                               qcodes.ptr + q0 * (nb + 4), nb, slices, static_cast<int>(cnt), k,
+                               partial.ptr + q0 * slices * k);
+        }
+        VG_HIP(hipGetLastError());
+        VG_TRY(vg::launch_topk_merge(partial.ptr, nq, slices, k, false, oid.ptr, osc.ptr, st));
+    }
+    VG_TRY(oid.finish());
+    VG_TRY(osc.finish());
+    if (oid.on_host() || osc.on_host()) VG_HIP(hipStreamSynchronize(st));
+    return VG_OK;
+}

@@ -176,6 +176,8 @@ VG_API int32_t vg_index_destroy(vg_index *idx)
     if (idx->d_pq_tiles) (void)hipFree(idx->d_pq_tiles);
     if (idx->d_vectors) (void)hipFree(idx->d_vectors);
     if (idx->d_norms) (void)hipFree(idx->d_norms);
+    if (idx->d_rq_tiles) (void)hipFree(idx->d_rq_tiles);
+    if (idx->d_rq_norms) (void)hipFree(idx->d_rq_norms);
     delete idx;
     return VG_OK;
 }

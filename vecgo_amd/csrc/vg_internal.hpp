@@ -210,4 +210,8 @@ struct vg_index {
     // fp32 rows, row-major n*dim (reference layout), plus ||x||^2 for the GEMM path
     float *d_vectors = nullptr;
     float *d_norms = nullptr;
+    // RaBitQ: sign bits re-tiled [tile][group][lane][16 B] and the stored norms
+    uint8_t *d_rq_tiles = nullptr;
+    float *d_rq_norms = nullptr;
+    int32_t rq_groups = 0;  // ceil(((dim+63)/64*8) / 16)
 };
