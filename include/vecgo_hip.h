@@ -154,6 +154,24 @@ int32_t vg_index_set_pq_codes(vg_index *idx, vg_pq *pq, const uint8_t *codes, vo
  * Re-tiled in HBM like the PQ codes (bits in 16-byte groups per 64-row tile, norms apart). */
 int32_t vg_index_set_rabitq_codes(vg_index *idx, const uint8_t *codes, void *stream);
 
+/* HNSW graph of a memtable shard (internal/hnsw): only the adjacency the search reads.
+ *   l0[n*m0]            layer-0 neighbour ids in the node's stored order (node.go:62-80
+ *                       GetConnectionsRaw order), VG_INVALID_ID terminates a shorter list;
+ *                       m0 = 2*M <= 64 (hnsw.go:34-37 default M=32)
+ *   max_level           highest level that has nodes (0 = layer 0 only)
+ *   upper_slot[max_level*n]   for level L>=1: row of node in that level's table or VG_INVALID_ID
+ *   upper_adj, level_rows[max_level]  tables of level_rows[L-1]*m ids each, concatenated
+ *   entry_point         g.entryPointAtomic (hnsw.go:1800)
+ * Needs vg_index_set_vectors (the scoring reads the fp32 rows). */
+int32_t vg_index_set_hnsw_graph(vg_index *idx, int32_t m0, const uint32_t *l0, int32_t max_level,
+                                int32_t m, const uint32_t *upper_slot, const uint32_t *upper_adj,
+                                const int64_t *level_rows, uint32_t entry_point, void *stream);
+/* Vamana graph of a DiskANN segment: graph[n*r] (diskann/segment.go:671-681; VG_INVALID_ID =
+ * empty slot), entry point = header.Entrypoint.  Scoring uses whichever of the index's data the
+ * search call names. */
+int32_t vg_index_set_vamana_graph(vg_index *idx, int32_t r, const uint32_t *graph, uint32_t entry_point,
+                                  void *stream);
+
 /* fp32 rows of the segment, n*dim row-major — the layout of
  * vectorstore.ColumnarStore (internal/vectorstore/columnar.go:21-24) and of
  * flat.Segment.vectors (flat/segment.go:692).  Copied to HBM. */
@@ -198,6 +216,30 @@ int32_t vg_search_flat(vg_index *idx, const float *queries, int64_t nq, int32_t 
  * (SURVEY.md §8d).  k <= 64. */
 int32_t vg_search_rabitq(vg_index *idx, const float *queries, int64_t nq, int32_t k, uint32_t *ids,
                          float *scores, void *stream);
+
+/* per-query counters, the reference's FilterGateStats (searcher/searcher.go:114-137) */
+typedef struct vg_search_stats {
+    int64_t nodes_visited, distance_computations, distance_short_circuits, pops;
+} vg_search_stats;
+
+/* hnsw.KNNSearch (hnsw.go:1650-1755): greedySearch through the upper layers (:1897-1934), then
+ * searchLayerUnfiltered on layer 0 (:1220-1396) with the reference's exact heap semantics
+ * (searcher/queue.go 4-ary heaps: bounded result heap of ef, exploration heap capped at 2*ef with
+ * the adaptive shrink, strict comparisons), distance.SquaredL2Bounded short-circuit
+ * (bounded_l2_avx512.c order) once ef results exist, distFunc otherwise (L2 / -Dot / 0.5*L2:
+ * vectorstore/columnar.go:29-50).  One wavefront per query, many queries in flight; per query
+ * the result equals the sequential reference's.  ids/scores[nq*k] best first; stats[nq] may be
+ * NULL.  ef <= 512, k <= ef. */
+int32_t vg_search_hnsw(vg_index *idx, const float *queries, int64_t nq, int32_t k, int32_t ef,
+                       uint32_t *ids, float *scores, vg_search_stats *stats, void *stream);
+
+/* diskann.Segment.searchInternal (diskann/segment.go:503-706), filters nil.  kind selects the
+ * distFn: 0 = fp32 rows (distance.Provider(metric), :582-588), 1 = PQ
+ * ComputeAsymmetricDistance (:536-541, terms summed sequentially over the sub-quantizers),
+ * 2 = RaBitQ Distance (:512-519).  Unbounded exploration min-heap, top-k CandidateHeap,
+ * stop when the popped candidate is worse than the k-th result.  k <= 64. */
+int32_t vg_search_vamana(vg_index *idx, const float *queries, int64_t nq, int32_t k, int32_t kind,
+                         uint32_t *ids, float *scores, vg_search_stats *stats, void *stream);
 
 /* engine fan-in (engine/search.go:904-908: per-segment candidate lists merged into one
  * bounded heap, ordered by searcher/candidate_queue.go:12-23).  Here the "segments" are row

@@ -1,0 +1,98 @@
+"""CPU tests of the oracle's heaps and search loops against the properties the reference's own
+tests assert (searcher/queue_test.go, candidate_queue_test.go; hnsw/hnsw_test.go:43-103 recall
+vs brute force; diskann/extra_test.go:254-325)."""
+import numpy as np
+import pytest
+
+from oracle import oracle as o
+from tests import graphs
+
+
+def test_flat_search_is_sorted_and_tie_broken():
+    rng = np.random.default_rng(1)
+    base = rng.standard_normal((500, 32)).astype(np.float32)
+    base[100] = base[7]; base[300] = base[7]   # equal scores → RowID ascending
+    q = base[7].copy()
+    ids, sc = o.flat_search_f32(base, 32, q, 5)
+    assert list(ids[:3]) == [7, 100, 300] and np.all(sc[:3] == 0)
+    assert np.all(np.diff(sc) >= 0)
+    ids_d, sc_d = o.flat_search_f32(base, 32, q, 5, o.METRIC_DOT)
+    assert np.all(np.diff(sc_d) <= 0)
+
+
+@pytest.mark.parametrize("metric", [o.METRIC_L2, o.METRIC_DOT, o.METRIC_COSINE])
+def test_hnsw_oracle_recall_vs_brute_force(metric):
+    """hnsw_test.go:43-103 style: precision vs brute force on a well-connected graph."""
+    rng = np.random.default_rng(4711)
+    n, dim, k = 1000, 16, 10
+    base = rng.random((n, dim)).astype(np.float32)
+    if metric != o.METRIC_L2:
+        base /= np.linalg.norm(base, axis=1, keepdims=True)
+    l0, upper, entry = graphs.build_hnsw(base, m=8, seed=1, ragged=False)
+    idx = o.HnswIndex(base, dim, l0, upper, entry, metric=metric)
+    hits = 0
+    for t in range(30):
+        q = rng.random(dim).astype(np.float32)
+        if metric != o.METRIC_L2:
+            q /= np.linalg.norm(q)
+        ids, sc, st = idx.search(q, k, 200)
+        assert ids.size == k and st.distance_computations > 0 and st.pops > 0
+        d = ((base - q) ** 2).sum(1) if metric != o.METRIC_DOT else -(base @ q)
+        hits += len(set(ids.tolist()) & set(np.argsort(d, kind="stable")[:k].tolist()))
+        assert np.all(np.diff(sc) >= 0)
+    assert hits / (30 * k) >= 0.95
+
+
+def test_vamana_oracle_finds_neighbours():
+    rng = np.random.default_rng(3)
+    n, dim, k = 800, 24, 10
+    base = rng.standard_normal((n, dim)).astype(np.float32)
+    g, entry = graphs.build_vamana(base, r=16, seed=2)
+    v = o.VamanaIndex(g, entry, dim, o.VAMANA_F32, base=base)
+    hits = 0
+    for t in range(20):
+        q = rng.standard_normal(dim).astype(np.float32)
+        ids, sc, st = v.search(q, k)
+        assert ids.size == k and np.all(np.diff(sc) >= 0)
+        d = ((base - q) ** 2).sum(1)
+        hits += len(set(ids.tolist()) & set(np.argsort(d)[:k].tolist()))
+    assert hits / 200 >= 0.6
+    # PQ and RaBitQ distance functions return k results (diskann/extra_test.go:254-325)
+    opq = o.ProductQuantizer(dim, 6, 256); opq.train(base, iters=5, seed=1)
+    codes = opq.encode_batch(base)
+    ids, sc, _ = o.VamanaIndex(g, entry, dim, o.VAMANA_PQ, pq=opq, codes=codes).search(base[5], k)
+    assert ids.size == k
+    rc = o.rabitq_encode_batch(base, dim)
+    ids, sc, _ = o.VamanaIndex(g, entry, dim, o.VAMANA_RABITQ, codes=rc).search(base[5], k)
+    assert ids.size == k and np.all(sc >= 0)
+
+
+def test_kmeans_reference_properties():
+    """kmeans/kmeans_test.go:12-93: two obvious clusters separate; n<k → nil; bad metric → error;
+    FindClosestCentroids ordering."""
+    rng = np.random.default_rng(0)
+    a = rng.standard_normal((50, 4)).astype(np.float32) * 0.1
+    b = rng.standard_normal((50, 4)).astype(np.float32) * 0.1 + 10
+    x = np.concatenate([a, b])
+    c = o.kmeans_train(x, 4, 2, max_iter=10, seed=3).reshape(2, 4)
+    assert sorted(np.round(c.mean(1)).tolist()) == [0.0, 10.0]
+    assert o.kmeans_train(x[:1], 4, 2) is None
+    with pytest.raises(ValueError):
+        o.kmeans_train(x, 4, 2, metric=o.METRIC_HAMMING)
+    cents = np.array([[0, 0], [1, 1], [5, 5], [10, 10]], np.float32)
+    assert list(o.find_closest_centroids(np.array([0.9, 0.9], np.float32), cents, 2, 2)) == [1, 0]
+    assert o.assign_partition(np.array([9, 9], np.float32), cents, 2) == 3
+
+
+def test_pq_oracle_reference_assertions():
+    """pq_test.go:84-128: ADC ~= L2(q, Decode(code)) within 1e-3; LUT entries are the a8 terms."""
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((1000, 128)).astype(np.float32)
+    x /= np.linalg.norm(x, axis=1, keepdims=True)
+    pq = o.ProductQuantizer(128, 8, 256); pq.train(x, iters=20, seed=1)
+    q = x[1]; code = pq.encode(x[2])
+    dec = pq.decode(code)
+    assert float(np.mean((x[2] - dec) ** 2)) < 0.5
+    assert abs(float(pq.asym_distance(q, code)) - float(np.sum((q - dec) ** 2, dtype=np.float32))) <= 1e-3
+    table = pq.build_table(q)
+    assert abs(float(o.adc(table, code, 8)) - float(pq.asym_distance(q, code))) <= 1e-4

@@ -359,6 +359,52 @@ class Index:
         """Exhaustive RaBitQ scan (rabitq.go:119-176 per row), top-k by (Score, RowID)."""
         return self._search(self._lib.vg_search_rabitq, queries, k, out=out, stream=stream)
 
+    def set_hnsw_graph(self, l0, upper=(), entry_point=0, m=None, stream=None):
+        """l0: [n, m0] uint32 (0xFFFFFFFF terminates a list); upper: list of (slot[n], adj[rows, m])
+        for levels 1..L."""
+        l0a = np.ascontiguousarray(l0, np.uint32)
+        m0 = l0a.shape[1]
+        L = len(upper)
+        if L:
+            m_ = upper[0][1].shape[1]
+            slots = np.ascontiguousarray(np.stack([np.asarray(s_, np.uint32) for s_, _ in upper]))
+            adj = np.ascontiguousarray(np.concatenate([np.asarray(a, np.uint32).reshape(-1, m_) for _, a in upper]))
+            rows = np.array([np.asarray(a).reshape(-1, m_).shape[0] for _, a in upper], np.int64)
+            ps, pa, pr = (C.c_void_p(slots.ctypes.data), C.c_void_p(adj.ctypes.data),
+                          C.c_void_p(rows.ctypes.data))
+        else:
+            m_ = m if m is not None else max(1, m0 // 2)
+            ps = pa = pr = None
+        check(self._lib.vg_index_set_hnsw_graph(self._h, C.c_int32(m0), C.c_void_p(l0a.ctypes.data),
+                                                C.c_int32(L), C.c_int32(m_), ps, pa, pr,
+                                                C.c_uint32(entry_point), _stream_ptr(stream)))
+
+    def set_vamana_graph(self, graph, entry_point, stream=None):
+        g = np.ascontiguousarray(graph, np.uint32)
+        check(self._lib.vg_index_set_vamana_graph(self._h, C.c_int32(g.shape[1]), C.c_void_p(g.ctypes.data),
+                                                  C.c_uint32(entry_point), _stream_ptr(stream)))
+
+    def _graph_search(self, fn, queries, k, mid_arg, want_stats, stream):
+        nq = _rows(queries, self.dim)
+        q, pq_ = _ptr(queries, np.float32)
+        ids = _empty_like(queries, (nq, k), np.uint32)
+        scores = _empty_like(queries, (nq, k), np.float32)
+        i, pi = _ptr(ids, np.uint32)
+        s_, ps = _ptr(scores, np.float32)
+        stats = np.zeros((nq, 4), np.int64) if want_stats else None
+        pst = C.c_void_p(stats.ctypes.data) if want_stats else None
+        check(fn(self._h, pq_, C.c_int64(nq), C.c_int32(k), C.c_int32(mid_arg), pi, ps, pst, _stream_ptr(stream)))
+        return (ids, scores, stats) if want_stats else (ids, scores)
+
+    def search_hnsw(self, queries, k, ef, stats=False, stream=None):
+        """hnsw.KNNSearch (hnsw.go:1650-1755); stats columns: nodes_visited,
+        distance_computations, distance_short_circuits, pops."""
+        return self._graph_search(self._lib.vg_search_hnsw, queries, k, ef, stats, stream)
+
+    def search_vamana(self, queries, k, kind=0, stats=False, stream=None):
+        """diskann searchInternal (diskann/segment.go:503-706); kind 0 fp32, 1 PQ, 2 RaBitQ."""
+        return self._graph_search(self._lib.vg_search_vamana, queries, k, kind, stats, stream)
+
     def set_vectors(self, base, stream=None):
         """fp32 rows, n*dim row-major (vectorstore/columnar.go:21-24)."""
         b, pb = _ptr(base, np.float32, self.n * self.dim)

@@ -545,6 +545,13 @@ VG_API int32_t vg_index_set_pq_codes(vg_index *idx, vg_pq *pq, const uint8_t *co
     VG_HIP(hipMalloc(reinterpret_cast<void **>(&idx->d_pq_tiles), bytes));
     vg::DevIn<uint8_t> in;
     VG_TRY(in.init(codes, static_cast<size_t>(idx->n) * pq->m, st));
+    // row-major copy for random access by node id (Vamana search)
+    if (idx->d_pq_rows) {
+        VG_HIP(hipFree(idx->d_pq_rows));
+        idx->d_pq_rows = nullptr;
+    }
+    VG_HIP(hipMalloc(reinterpret_cast<void **>(&idx->d_pq_rows), static_cast<size_t>(idx->n) * pq->m));
+    VG_HIP(hipMemcpyAsync(idx->d_pq_rows, in.ptr, static_cast<size_t>(idx->n) * pq->m, hipMemcpyDeviceToDevice, st));
     int64_t total = idx->n_tiles * idx->pq_groups * 64;
     hipLaunchKernelGGL(vg::pq_retile_kernel, dim3(static_cast<unsigned>((total + 255) / 256)),
                        dim3(256), 0, st, in.ptr, idx->n, pq->m, idx->pq_groups, idx->n_tiles,

@@ -1,0 +1,624 @@
+// k_graph.hip — graph traversal with the reference's exact heap semantics:
+//   hnsw.KNNSearch: greedySearch (hnsw.go:1897-1934) + searchLayerUnfiltered (hnsw.go:1220-1396)
+//   diskann.Segment.searchInternal (diskann/segment.go:503-706)
+//
+// One wavefront per query.  The traversal itself is sequentially dependent (each pop depends on
+// the previous one), so throughput comes from many queries in flight while the per-query result
+// is the sequential reference's: the 4-ary PriorityQueue (internal/searcher/queue.go) is
+// restated operation by operation (same sift loops, same strict comparisons) on a per-wave
+// array, executed uniformly by the wave; the <=64 neighbours of a popped node are visited-tested,
+// gathered and scored in parallel (16 lanes per fp32 row, 4 rows at a time, reference summation
+// order), then fed to the heaps in the node's stored neighbour order.
+#include <algorithm>
+
+#include "vg_device.hpp"
+#include "vg_exact.hpp"
+#include "vg_internal.hpp"
+
+namespace vg {
+
+int32_t launch_pq_build_table(const vg_pq *pq, const float *d_queries, int64_t nq, float *d_tables,
+                              bool scan_layout, hipStream_t st);
+
+struct HItem {
+    uint32_t node;
+    float dist;
+};
+
+// ---- searcher.PriorityQueue (queue.go:161-183, 221-290), uniform over the wave ---------------
+template <bool MAX>
+__device__ __forceinline__ void heap_sift_up(HItem *h, int i)
+{
+    const HItem it = h[i];
+    while (i > 0) {
+        const int p = (i - 1) >> 2;
+        const float pd = h[p].dist;
+        if (MAX ? (it.dist <= pd) : (it.dist >= pd)) break;
+        h[i] = h[p];
+        i = p;
+    }
+    h[i] = it;
+}
+
+template <bool MAX>
+__device__ __forceinline__ void heap_sift_down(HItem *h, int n, int i)
+{
+    const HItem it = h[i];
+    for (;;) {
+        const int fc = 4 * i + 1;
+        if (fc >= n) break;
+        int best = fc;
+        float bd = h[fc].dist;
+        const int lc = fc + 4 < n ? fc + 4 : n;
+        for (int c = fc + 1; c < lc; c++) {
+            const float cd = h[c].dist;
+            if (MAX ? (cd > bd) : (cd < bd)) {
+                best = c;
+                bd = cd;
+            }
+        }
+        if (MAX ? (it.dist >= bd) : (it.dist <= bd)) break;
+        h[i] = h[best];
+        i = best;
+    }
+    h[i] = it;
+}
+
+template <bool MAX>
+__device__ __forceinline__ void heap_push(HItem *h, int &len, HItem it)
+{
+    h[len] = it;
+    len++;
+    heap_sift_up<MAX>(h, len - 1);
+}
+
+template <bool MAX>
+__device__ __forceinline__ HItem heap_pop(HItem *h, int &len)
+{
+    const HItem top = h[0];
+    h[0] = h[len - 1];
+    len--;
+    if (len > 0) heap_sift_down<MAX>(h, len, 0);
+    return top;
+}
+
+// PushItemBounded (queue.go:67-92) on the max-heap of results
+__device__ __forceinline__ void res_push_bounded(HItem *h, int &len, HItem it, int capacity)
+{
+    if (len < capacity) {
+        heap_push<true>(h, len, it);
+        return;
+    }
+    if (it.dist < h[0].dist) {
+        h[0] = it;
+        heap_sift_down<true>(h, len, 0);
+    }
+}
+
+// TryPushBounded (queue.go:190-215) on the MIN-heap of exploration candidates: at capacity the
+// new item replaces the top (the closest!) when it is farther — restated as written
+__device__ __forceinline__ void cand_try_push_bounded(HItem *h, int &len, HItem it, int max_size)
+{
+    if (len < max_size) {
+        heap_push<false>(h, len, it);
+        return;
+    }
+    if (it.dist <= h[0].dist) return;
+    h[0] = it;
+    heap_sift_down<false>(h, len, 0);
+}
+
+// next up-to-4 set bits of `mask` (ascending): the lane's 16-lane group gets the (lane>>4)-th
+__device__ __forceinline__ int take4(uint64_t &mask, int lane)
+{
+    int mine = -1;
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+        if (mask) {
+            const int j = __builtin_ctzll(mask);
+            mask &= mask - 1;
+            if ((lane >> 4) == g) mine = j;
+        }
+    }
+    return mine;
+}
+
+enum { kMetricL2 = 0, kMetricCos = 1, kMetricDot = 2 };
+
+// ---- HNSW ----------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void hnsw_search_kernel(
+    const float *__restrict__ base, int64_t n, int dim, int metric, const uint32_t *__restrict__ l0,
+    int m0, int max_level, int m, const uint32_t *__restrict__ slots, const uint32_t *__restrict__ adj,
+    const int64_t *__restrict__ level_off, uint32_t entry, const float *__restrict__ queries, int k, int ef,
+    uint32_t *__restrict__ visited_ws, int64_t vis_words, uint32_t *__restrict__ ids,
+    float *__restrict__ scores, vg_search_stats *__restrict__ stats)
+{
+    extern __shared__ __attribute__((aligned(8))) unsigned char smem[];
+    HItem *cand = reinterpret_cast<HItem *>(smem);
+    HItem *res = cand + 2 * ef;
+    float *nb_pair = reinterpret_cast<float *>(res + ef);
+    float *nb_bnd = nb_pair + 64;
+
+    const int64_t q = blockIdx.x;
+    const int lane = threadIdx.x;
+    const Sub16 sub = Sub16::make(lane);
+    const float *qv = queries + q * dim;
+    uint32_t *vis = visited_ws + q * vis_words;
+    int64_t st_visited = 0, st_dc = 0, st_sc = 0, st_pops = 0;
+
+    // distance of one node as hnsw wraps it (vectorstore/columnar.go:37-44)
+    auto node_dist = [&](uint32_t id) -> float {
+        const float *row = base + static_cast<int64_t>(id) * dim;
+        if (metric == kMetricDot) return -exact_pair16<true, kPair>(row, qv, dim, sub);
+        const float d = exact_pair16<false, kPair>(row, qv, dim, sub);
+        return metric == kMetricCos ? 0.5f * d : d;
+    };
+
+    // ---- greedySearch through the upper layers --------------------------------------------------
+    uint32_t cur = entry;
+    float cur_d = node_dist(cur);
+    for (int level = max_level; level > 0; level--) {
+        bool changed = true;
+        while (changed) {
+            changed = false;
+            const uint32_t slot = slots[static_cast<int64_t>(level - 1) * n + cur];
+            if (slot == VG_INVALID_ID) break;
+            const uint32_t *nbp = adj + (level_off[level - 1] + slot) * m;
+            const uint32_t id_lane = lane < m ? nbp[lane] : VG_INVALID_ID;
+            const uint64_t inval = __ballot(id_lane == VG_INVALID_ID);
+            const int count = inval ? __builtin_ctzll(inval) : 64;
+            uint64_t mask = count >= 64 ? ~0ull : ((1ull << count) - 1);
+            while (mask) {
+                const int mine = take4(mask, lane);
+                const uint32_t id = __shfl(id_lane, mine < 0 ? 0 : mine);
+                if (mine >= 0) {
+                    const float d = node_dist(id);
+                    if ((lane & 15) == 0) nb_pair[mine] = d;
+                }
+            }
+            __syncthreads();
+            // sequential `if nextDist < currDist` over the list == first strict minimum
+            float best_d = cur_d;
+            uint32_t best_id = cur;
+            for (int i = 0; i < count; i++) {
+                const float d = nb_pair[i];
+                if (d < best_d) {
+                    best_d = d;
+                    best_id = static_cast<uint32_t>(__builtin_amdgcn_readlane(id_lane, i));
+                    changed = true;
+                }
+            }
+            cur = best_id;
+            cur_d = best_d;
+            __syncthreads();
+        }
+    }
+
+    // ---- searchLayerUnfiltered on layer 0 ---------------------------------------------------------
+    int cand_len = 0, res_len = 0;
+    if (lane == 0) atomicOr(&vis[cur >> 5], 1u << (cur & 31));
+    heap_push<false>(cand, cand_len, HItem{cur, cur_d});
+    heap_push<true>(res, res_len, HItem{cur, cur_d});
+    const bool use_sc = metric == kMetricL2;
+    int cap = ef * 2;
+    int stagnant = 0;
+    float last_best = 3.40282346638528859811704183484516925440e+38f;
+    const int min_cap = ef + ef * 3 / 4;
+    __syncthreads();
+
+    while (cand_len > 0) {
+        const HItem c = heap_pop<false>(cand, cand_len);
+        st_pops++;
+        if (res_len > 0) {
+            const float worst = res[0].dist;
+            if (c.dist > worst && res_len >= ef) break;
+            if (worst < last_best * 0.999f) {
+                last_best = worst;
+                stagnant = 0;
+            } else if (res_len >= ef) {
+                stagnant++;
+                if (stagnant >= 8 && cap > min_cap) {
+                    cap -= ef / 8;
+                    if (cap < min_cap) cap = min_cap;
+                    stagnant = 0;
+                }
+            }
+        }
+        const uint32_t id_lane = lane < m0 ? l0[static_cast<int64_t>(c.node) * m0 + lane] : VG_INVALID_ID;
+        const uint64_t inval = __ballot(id_lane == VG_INVALID_ID);
+        const int count = inval ? __builtin_ctzll(inval) : 64;
+        // CheckAndVisit for the whole list at once (neighbour ids of a node are distinct)
+        // (a returning L2 atomic: a plain load could hit a stale L1 line of this very bitmap)
+        bool fresh = false;
+        if (lane < count) {
+            const uint32_t bit = 1u << (id_lane & 31);
+            fresh = (atomicOr(&vis[id_lane >> 5], bit) & bit) == 0;
+        }
+        const uint64_t newmask = __ballot(fresh);
+        st_visited += __popcll(newmask);
+        uint64_t mask = newmask;
+        while (mask) {
+            const int mine = take4(mask, lane);
+            const uint32_t id = __shfl(id_lane, mine < 0 ? 0 : mine);
+            if (mine >= 0) {
+                const float *row = base + static_cast<int64_t>(id) * dim;
+                float dp, db;
+                if (metric == kMetricDot) {
+                    dp = -exact_pair16<true, kPair>(row, qv, dim, sub);
+                    db = dp;
+                } else {
+                    exact_l2_both16(row, qv, dim, sub, dp, db);
+                    if (metric == kMetricCos) dp = 0.5f * dp;
+                }
+                if ((lane & 15) == 0) {
+                    nb_pair[mine] = dp;
+                    nb_bnd[mine] = db;
+                }
+            }
+        }
+        __syncthreads();
+        bool has_bound = res_len >= ef;
+        float bound = has_bound ? res[0].dist : 0.0f;
+        uint64_t todo = newmask;
+        while (todo) {
+            const int j = __builtin_ctzll(todo);
+            todo &= todo - 1;
+            const uint32_t id = static_cast<uint32_t>(__builtin_amdgcn_readlane(id_lane, j));
+            float nd;
+            st_dc++;
+            if (use_sc && has_bound) {
+                nd = nb_bnd[j];
+                if (nd > bound) {  // SquaredL2Bounded reported exceeded
+                    st_sc++;
+                    continue;
+                }
+            } else {
+                nd = nb_pair[j];
+            }
+            if (has_bound && nd > bound) continue;
+            cand_try_push_bounded(cand, cand_len, HItem{id, nd}, cap);
+            res_push_bounded(res, res_len, HItem{id, nd}, ef);
+            if (res_len >= ef) {
+                bound = res[0].dist;
+                has_bound = true;
+            }
+        }
+        __syncthreads();
+    }
+
+    // knnSearchInternal extraction (hnsw.go:1732-1751): drop the worst until k remain, then pop
+    while (res_len > k) (void)heap_pop<true>(res, res_len);
+    const int nres = res_len;
+    for (int i = nres - 1; i >= 0; i--) {
+        const HItem it = heap_pop<true>(res, res_len);
+        if (lane == 0) {
+            ids[q * k + i] = it.node;
+            scores[q * k + i] = it.dist;
+        }
+    }
+    for (int i = nres + lane; i < k; i += 64) {
+        ids[q * k + i] = VG_INVALID_ID;
+        scores[q * k + i] = INFINITY;
+    }
+    if (stats && lane == 0) {
+        stats[q].nodes_visited = st_visited;
+        stats[q].distance_computations = st_dc;
+        stats[q].distance_short_circuits = st_sc;
+        stats[q].pops = st_pops;
+    }
+}
+
+// ---- Vamana --------------------------------------------------------------------------------------
+enum { kVamanaF32 = 0, kVamanaPQ = 1, kVamanaRaBitQ = 2 };
+
+__device__ inline float rq_formula_g(float qn, float yn, float dimf, float hamming)
+{
+    const float t1 = qn - yn;
+    const float t1sq = t1 * t1;
+    float t2 = 4.0f * qn;
+    t2 = t2 * yn;
+    t2 = t2 / dimf;
+    t2 = t2 * hamming;
+    return t1sq + t2;
+}
+
+__global__ __launch_bounds__(64) void vamana_search_kernel(
+    int kind, int metric, int64_t n, int dim, const uint32_t *__restrict__ graph, int r, uint32_t entry,
+    const float *__restrict__ base, const uint8_t *__restrict__ pq_rows, int pq_m,
+    const float *__restrict__ luts /* nq * m * 256 */, const uint8_t *__restrict__ rq_rows,
+    const uint8_t *__restrict__ qcodes /* nq * (nb+4) */, int rq_nb, const float *__restrict__ queries,
+    int k, HItem *__restrict__ cand_ws, int64_t cand_cap, uint32_t *__restrict__ visited_ws,
+    int64_t vis_words, uint32_t *__restrict__ ids, float *__restrict__ scores,
+    vg_search_stats *__restrict__ stats)
+{
+    __shared__ float nb_d[64];
+    const int64_t q = blockIdx.x;
+    const int lane = threadIdx.x;
+    const Sub16 sub = Sub16::make(lane);
+    const float *qv = queries + q * dim;
+    uint32_t *vis = visited_ws + q * vis_words;
+    HItem *cand = cand_ws + q * cand_cap;
+    const bool desc = metric != kMetricL2;  // sc.Heap.Reset(s.Metric() != MetricL2), segment.go:597
+    const float *lut = luts ? luts + q * static_cast<int64_t>(pq_m) * 256 : nullptr;
+    const uint8_t *qc = qcodes ? qcodes + q * static_cast<int64_t>(rq_nb + 4) : nullptr;
+    float qn = 0.0f;
+    if (kind == kVamanaRaBitQ) {
+        const uint32_t b = qc[rq_nb] | (qc[rq_nb + 1] << 8) | (qc[rq_nb + 2] << 16) |
+                           (static_cast<uint32_t>(qc[rq_nb + 3]) << 24);
+        qn = __uint_as_float(b);
+    }
+    int64_t st_visited = 0, st_dc = 0, st_pops = 0;
+
+    // score the nodes held by the lanes in `mask` (one id per lane) into nb_d[lane]
+    auto score_mask = [&](uint64_t mask, uint32_t id_lane) {
+        if (kind == kVamanaF32) {
+            while (mask) {
+                const int mine = take4(mask, lane);
+                const uint32_t id = __shfl(id_lane, mine < 0 ? 0 : mine);
+                if (mine >= 0) {
+                    const float *row = base + static_cast<int64_t>(id) * dim;
+                    // distFunc(query, vec) = distance.Provider(metric): SquaredL2 or Dot
+                    const float d = desc ? exact_pair16<true, kPair>(row, qv, dim, sub)
+                                         : exact_pair16<false, kPair>(row, qv, dim, sub);
+                    if ((lane & 15) == 0) nb_d[mine] = d;
+                }
+            }
+        } else if ((mask >> lane) & 1) {
+            if (kind == kVamanaPQ) {
+                // ComputeAsymmetricDistance (pq.go:234-260): term(m) = BuildDistanceTable entry,
+                // summed sequentially over the sub-quantizers
+                const uint8_t *code = pq_rows + static_cast<int64_t>(id_lane) * pq_m;
+                float distance = 0.0f;
+                for (int s = 0; s < pq_m; s++) distance = distance + lut[s * 256 + code[s]];
+                nb_d[lane] = distance;
+            } else {
+                const uint8_t *code = rq_rows + static_cast<int64_t>(id_lane) * (rq_nb + 4);
+                int h = 0;
+                for (int b = 0; b < rq_nb; b++) h += __popc(static_cast<unsigned>(qc[b] ^ code[b]));
+                const uint32_t yb = code[rq_nb] | (code[rq_nb + 1] << 8) | (code[rq_nb + 2] << 16) |
+                                    (static_cast<uint32_t>(code[rq_nb + 3]) << 24);
+                nb_d[lane] = rq_formula_g(qn, __uint_as_float(yb), static_cast<float>(dim), static_cast<float>(h));
+            }
+        }
+        __syncthreads();
+    };
+
+    WaveTopK tk;  // sc.Heap: top-k by (Score, RowID) — candidate_queue.go:12-23
+    tk.init(k);
+    int heap_count = 0;  // min(k, candidates offered): sc.Heap.Len()
+    int cand_len = 0;
+
+    // start node (segment.go:603-636)
+    if (lane == 0) atomicOr(&vis[entry >> 5], 1u << (entry & 31));
+    score_mask(1ull, entry);
+    const float sd = nb_d[0];
+    st_dc++;
+    heap_push<false>(cand, cand_len, HItem{entry, sd});
+    tk.offer(lane == 0 ? make_key(sd, entry, desc) : kKeyMax, lane);
+    heap_count = 1 < k ? 1 : k;
+    __syncthreads();
+
+    while (cand_len > 0) {
+        const HItem c = heap_pop<false>(cand, cand_len);
+        st_pops++;
+        if (heap_count >= k) {
+            const float worst = key_score(tk.tau, desc);
+            if (c.dist > worst) break;
+        }
+        const uint32_t id_lane = lane < r ? graph[static_cast<int64_t>(c.node) * r + lane] : VG_INVALID_ID;
+        bool fresh = false;
+        if (id_lane != VG_INVALID_ID && id_lane < n) {
+            const uint32_t bit = 1u << (id_lane & 31);
+            fresh = (atomicOr(&vis[id_lane >> 5], bit) & bit) == 0;
+        }
+        const uint64_t newmask = __ballot(fresh);
+        if (!newmask) continue;
+        const int nnew = __popcll(newmask);
+        st_visited += nnew;
+        st_dc += nnew;
+        score_mask(newmask, id_lane);
+        const float myd = nb_d[lane];
+        // exploration heap: PushItem in the node's neighbour order (segment.go:695)
+        uint64_t todo = newmask;
+        while (todo) {
+            const int j = __builtin_ctzll(todo);
+            todo &= todo - 1;
+            if (cand_len < cand_cap)
+                heap_push<false>(cand, cand_len,
+                                 HItem{static_cast<uint32_t>(__builtin_amdgcn_readlane(id_lane, j)), nb_d[j]});
+        }
+        // result heap: TryPushBounded(k) — a set maintained by (score, id): order-free
+        tk.offer(fresh ? make_key(myd, id_lane, desc) : kKeyMax, lane);
+        heap_count = heap_count + nnew < k ? heap_count + nnew : k;
+        __syncthreads();
+    }
+    if (lane < k) {
+        const uint64_t e = tk.list;
+        ids[q * k + lane] = e == kKeyMax ? VG_INVALID_ID : key_row(e);
+        scores[q * k + lane] = e == kKeyMax ? (desc ? -INFINITY : INFINITY) : key_score(e, desc);
+    }
+    if (stats && lane == 0) {
+        stats[q].nodes_visited = st_visited;
+        stats[q].distance_computations = st_dc;
+        stats[q].distance_short_circuits = 0;
+        stats[q].pops = st_pops;
+    }
+}
+
+// sign bits + norm of each query (RaBitQ Encode, k_rabitq.hip)
+int32_t launch_rabitq_encode(const float *d_vectors, int64_t n, int dim, uint8_t *d_codes, hipStream_t st);
+
+}  // namespace vg
+
+template <typename T>
+static int32_t replace_device_array(T **slot, const T *src, size_t count, hipStream_t st)
+{
+    if (*slot) {
+        VG_HIP(hipStreamSynchronize(st));
+        VG_HIP(hipFree(*slot));
+        *slot = nullptr;
+    }
+    if (count == 0) return VG_OK;
+    VG_HIP(hipMalloc(reinterpret_cast<void **>(slot), count * sizeof(T)));
+    VG_HIP(hipMemcpyAsync(*slot, src, count * sizeof(T), hipMemcpyDefault, st));
+    return VG_OK;
+}
+
+VG_API int32_t vg_index_set_hnsw_graph(vg_index *idx, int32_t m0, const uint32_t *l0, int32_t max_level,
+                                       int32_t m, const uint32_t *upper_slot, const uint32_t *upper_adj,
+                                       const int64_t *level_rows, uint32_t entry_point, void *stream)
+{
+    VG_CHECK(idx, VG_ERR_INVALID_ARG, "vg_index_set_hnsw_graph: NULL index");
+    VG_CHECK(m0 > 0 && m0 <= 64 && m > 0 && m <= 64, VG_ERR_UNSUPPORTED,
+             "vg_index_set_hnsw_graph: degrees m0=%d m=%d must be in 1..64", m0, m);
+    VG_CHECK(max_level >= 0 && max_level < 64, VG_ERR_INVALID_ARG, "vg_index_set_hnsw_graph: bad max_level");
+    VG_CHECK(idx->n == 0 || l0, VG_ERR_INVALID_ARG, "vg_index_set_hnsw_graph: l0 is NULL");
+    VG_CHECK(max_level == 0 || (upper_slot && upper_adj && level_rows), VG_ERR_INVALID_ARG,
+             "vg_index_set_hnsw_graph: upper-layer arrays are NULL");
+    VG_CHECK(idx->n == 0 || entry_point < idx->n, VG_ERR_INVALID_ARG, "vg_index_set_hnsw_graph: entry point out of range");
+    VG_HIP(hipSetDevice(idx->ctx->device));
+    hipStream_t st = vg::pick_stream(idx->ctx, stream);
+    VG_TRY(replace_device_array(&idx->d_hnsw_l0, l0, static_cast<size_t>(idx->n) * m0, st));
+    std::vector<int64_t> off(max_level + 1, 0);
+    for (int l = 0; l < max_level; l++) {
+        VG_CHECK(level_rows[l] >= 0, VG_ERR_INVALID_ARG, "vg_index_set_hnsw_graph: negative level_rows");
+        off[l + 1] = off[l] + level_rows[l];
+    }
+    VG_TRY(replace_device_array(&idx->d_hnsw_slot, upper_slot, static_cast<size_t>(max_level) * idx->n, st));
+    VG_TRY(replace_device_array(&idx->d_hnsw_adj, upper_adj, static_cast<size_t>(off[max_level]) * m, st));
+    VG_TRY(replace_device_array(&idx->d_hnsw_level_off, off.data(), off.size(), st));
+    VG_HIP(hipStreamSynchronize(st));
+    idx->hnsw_m0 = m0;
+    idx->hnsw_m = m;
+    idx->hnsw_max_level = max_level;
+    idx->hnsw_entry = entry_point;
+    return VG_OK;
+}
+
+VG_API int32_t vg_index_set_vamana_graph(vg_index *idx, int32_t r, const uint32_t *graph, uint32_t entry_point,
+                                         void *stream)
+{
+    VG_CHECK(idx, VG_ERR_INVALID_ARG, "vg_index_set_vamana_graph: NULL index");
+    VG_CHECK(r > 0 && r <= 64, VG_ERR_UNSUPPORTED, "vg_index_set_vamana_graph: degree %d must be in 1..64", r);
+    VG_CHECK(idx->n == 0 || graph, VG_ERR_INVALID_ARG, "vg_index_set_vamana_graph: graph is NULL");
+    VG_CHECK(idx->n == 0 || entry_point < idx->n, VG_ERR_INVALID_ARG, "vg_index_set_vamana_graph: entry point out of range");
+    VG_HIP(hipSetDevice(idx->ctx->device));
+    hipStream_t st = vg::pick_stream(idx->ctx, stream);
+    VG_TRY(replace_device_array(&idx->d_vamana, graph, static_cast<size_t>(idx->n) * r, st));
+    VG_HIP(hipStreamSynchronize(st));
+    idx->vamana_r = r;
+    idx->vamana_entry = entry_point;
+    return VG_OK;
+}
+
+VG_API int32_t vg_search_hnsw(vg_index *idx, const float *queries, int64_t nq, int32_t k, int32_t ef,
+                              uint32_t *ids, float *scores, vg_search_stats *stats, void *stream)
+{
+    VG_CHECK(idx, VG_ERR_INVALID_ARG, "vg_search_hnsw: NULL index");
+    VG_CHECK(nq >= 0 && k >= 0, VG_ERR_INVALID_ARG, "vg_search_hnsw: negative nq or k");
+    if (nq == 0 || k == 0) return VG_OK;
+    VG_CHECK(idx->d_hnsw_l0 && idx->d_vectors, VG_ERR_NOT_READY, "vg_search_hnsw: index needs fp32 vectors and an HNSW graph");
+    VG_CHECK(idx->metric != VG_METRIC_HAMMING, VG_ERR_UNSUPPORTED, "unsupported metric for float32: Hamming");
+    VG_CHECK(queries && ids && scores, VG_ERR_INVALID_ARG, "vg_search_hnsw: NULL buffer");
+    if (ef < k) ef = k;  // determineEF hnsw.go:1891-1894
+    VG_CHECK(ef <= 512, VG_ERR_UNSUPPORTED, "vg_search_hnsw: ef=%d exceeds 512", ef);
+    VG_HIP(hipSetDevice(idx->ctx->device));
+    hipStream_t st = vg::pick_stream(idx->ctx, stream);
+    vg::DevIn<float> q;
+    vg::DevOut<uint32_t> oid;
+    vg::DevOut<float> osc;
+    vg::DevOut<vg_search_stats> ost;
+    VG_TRY(q.init(queries, static_cast<size_t>(nq) * idx->dim, st));
+    VG_TRY(oid.init(ids, static_cast<size_t>(nq) * k, st));
+    VG_TRY(osc.init(scores, static_cast<size_t>(nq) * k, st));
+    VG_TRY(ost.init(stats, stats ? static_cast<size_t>(nq) : 0, st));
+    const int64_t vis_words = (idx->n + 31) / 32;
+    int64_t chunk = std::max<int64_t>(1, (int64_t(1) << 28) / std::max<int64_t>(vis_words, 1));  // <= 1 GiB of bitmaps
+    chunk = std::min(chunk, nq);
+    vg::DevTmp<uint32_t> vis;
+    VG_TRY(vis.init(static_cast<size_t>(chunk) * vis_words, st));
+    const size_t lds = static_cast<size_t>(3 * ef) * sizeof(vg::HItem) + 128 * sizeof(float);
+    VG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(vg::hnsw_search_kernel),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+    for (int64_t q0 = 0; q0 < nq; q0 += chunk) {
+        const int64_t cnt = std::min(chunk, nq - q0);
+        VG_HIP(hipMemsetAsync(vis.ptr, 0, static_cast<size_t>(cnt) * vis_words * 4, st));
+        vg::ProfScope prof(idx->ctx, "hnsw_search", st);
+        hipLaunchKernelGGL(vg::hnsw_search_kernel, dim3(static_cast<unsigned>(cnt)), dim3(64), lds, st,
+                           idx->d_vectors, idx->n, idx->dim, idx->metric, idx->d_hnsw_l0, idx->hnsw_m0,
+                           idx->hnsw_max_level, idx->hnsw_m, idx->d_hnsw_slot, idx->d_hnsw_adj,
+                           idx->d_hnsw_level_off, idx->hnsw_entry, q.ptr + q0 * idx->dim, k, ef, vis.ptr,
+                           vis_words, oid.ptr + q0 * k, osc.ptr + q0 * k, ost.ptr ? ost.ptr + q0 : nullptr);
+    }
+    VG_HIP(hipGetLastError());
+    VG_TRY(oid.finish());
+    VG_TRY(osc.finish());
+    VG_TRY(ost.finish());
+    if (oid.on_host() || osc.on_host() || ost.on_host()) VG_HIP(hipStreamSynchronize(st));
+    return VG_OK;
+}
+
+VG_API int32_t vg_search_vamana(vg_index *idx, const float *queries, int64_t nq, int32_t k, int32_t kind,
+                                uint32_t *ids, float *scores, vg_search_stats *stats, void *stream)
+{
+    VG_CHECK(idx, VG_ERR_INVALID_ARG, "vg_search_vamana: NULL index");
+    VG_CHECK(nq >= 0 && k >= 0, VG_ERR_INVALID_ARG, "vg_search_vamana: negative nq or k");
+    if (nq == 0 || k == 0) return VG_OK;
+    VG_CHECK(idx->d_vamana, VG_ERR_NOT_READY, "vg_search_vamana: index has no Vamana graph");
+    VG_CHECK(kind >= 0 && kind <= 2, VG_ERR_INVALID_ARG, "vg_search_vamana: unknown kind %d", kind);
+    VG_CHECK(kind != 0 || idx->d_vectors, VG_ERR_NOT_READY, "vg_search_vamana: index has no fp32 vectors");
+    VG_CHECK(kind != 1 || (idx->d_pq_rows && idx->pq), VG_ERR_NOT_READY, "vg_search_vamana: index has no PQ codes");
+    VG_CHECK(kind != 2 || idx->d_rq_rows, VG_ERR_NOT_READY, "vg_search_vamana: index has no RaBitQ codes");
+    VG_CHECK(kind != 1 || idx->pq->k == 256, VG_ERR_UNSUPPORTED, "vg_search_vamana: PQ needs numCentroids == 256");
+    VG_CHECK(idx->metric != VG_METRIC_HAMMING, VG_ERR_UNSUPPORTED, "unsupported metric for float32: Hamming");
+    VG_CHECK(queries && ids && scores, VG_ERR_INVALID_ARG, "vg_search_vamana: NULL buffer");
+    VG_CHECK(k <= 64, VG_ERR_UNSUPPORTED, "vg_search_vamana: k=%d exceeds 64", k);
+    VG_HIP(hipSetDevice(idx->ctx->device));
+    hipStream_t st = vg::pick_stream(idx->ctx, stream);
+    vg::DevIn<float> q;
+    vg::DevOut<uint32_t> oid;
+    vg::DevOut<float> osc;
+    vg::DevOut<vg_search_stats> ost;
+    VG_TRY(q.init(queries, static_cast<size_t>(nq) * idx->dim, st));
+    VG_TRY(oid.init(ids, static_cast<size_t>(nq) * k, st));
+    VG_TRY(osc.init(scores, static_cast<size_t>(nq) * k, st));
+    VG_TRY(ost.init(stats, stats ? static_cast<size_t>(nq) : 0, st));
+    const int64_t vis_words = (idx->n + 31) / 32;
+    const int64_t cand_cap = std::min<int64_t>(idx->n, 65536);
+    const int64_t per_query = vis_words * 4 + cand_cap * 8;
+    int64_t chunk = std::max<int64_t>(1, (int64_t(1) << 30) / per_query);
+    chunk = std::min(chunk, nq);
+    vg::DevTmp<uint32_t> vis;
+    vg::DevTmp<vg::HItem> cand;
+    vg::DevTmp<float> luts;
+    vg::DevTmp<uint8_t> qcodes;
+    VG_TRY(vis.init(static_cast<size_t>(chunk) * vis_words, st));
+    VG_TRY(cand.init(static_cast<size_t>(chunk) * cand_cap, st));
+    const int rq_nb = ((idx->dim + 63) / 64) * 8;
+    const int pq_m = idx->pq ? idx->pq->m : 0;
+    if (kind == 1) {
+        VG_TRY(luts.init(static_cast<size_t>(nq) * pq_m * 256, st));
+        VG_TRY(vg::launch_pq_build_table(idx->pq, q.ptr, nq, luts.ptr, false, st));
+    }
+    if (kind == 2) {
+        VG_TRY(qcodes.init(static_cast<size_t>(nq) * (rq_nb + 4), st));
+        VG_TRY(vg::launch_rabitq_encode(q.ptr, nq, idx->dim, qcodes.ptr, st));
+    }
+    for (int64_t q0 = 0; q0 < nq; q0 += chunk) {
+        const int64_t cnt = std::min(chunk, nq - q0);
+        VG_HIP(hipMemsetAsync(vis.ptr, 0, static_cast<size_t>(cnt) * vis_words * 4, st));
+        vg::ProfScope prof(idx->ctx, "vamana_search", st);
+        hipLaunchKernelGGL(vg::vamana_search_kernel, dim3(static_cast<unsigned>(cnt)), dim3(64), 0, st, kind,
+                           idx->metric, idx->n, idx->dim, idx->d_vamana, idx->vamana_r, idx->vamana_entry,
+                           idx->d_vectors, idx->d_pq_rows, pq_m, kind == 1 ? luts.ptr + q0 * pq_m * 256 : nullptr,
+                           idx->d_rq_rows, kind == 2 ? qcodes.ptr + q0 * (rq_nb + 4) : nullptr, rq_nb,
+                           q.ptr + q0 * idx->dim, k, cand.ptr, cand_cap, vis.ptr, vis_words, oid.ptr + q0 * k,
+                           osc.ptr + q0 * k, ost.ptr ? ost.ptr + q0 : nullptr);
+    }
+    VG_HIP(hipGetLastError());
+    VG_TRY(oid.finish());
+    VG_TRY(osc.finish());
+    VG_TRY(ost.finish());
+    if (oid.on_host() || osc.on_host() || ost.on_host()) VG_HIP(hipStreamSynchronize(st));
+    return VG_OK;
+}

@@ -164,6 +164,15 @@ __global__ __launch_bounds__(kRqThreads) void rabitq_scan_kernel(
                             partial + (static_cast<int64_t>(q) * slices + s) * k);
 }
 
+int32_t launch_rabitq_encode(const float *d_vectors, int64_t n, int dim, uint8_t *d_codes, hipStream_t st)
+{
+    if (n == 0) return VG_OK;
+    hipLaunchKernelGGL(rabitq_encode_kernel, dim3(static_cast<unsigned>((n + 15) / 16)), dim3(256), 0, st,
+                       d_vectors, n, dim, d_codes);
+    VG_HIP(hipGetLastError());
+    return VG_OK;
+}
+
 static int rq_slices(int64_t nq, int64_t n_tiles, int cus)
 {
     int64_t s = (4 * cus + nq - 1) / nq;  // ~4 workgroups of 256 threads per CU
@@ -273,6 +282,12 @@ VG_API int32_t vg_index_set_rabitq_codes(vg_index *idx, const uint8_t *codes, vo
     VG_HIP(hipMalloc(reinterpret_cast<void **>(&idx->d_rq_norms), static_cast<size_t>(idx->n) * sizeof(float)));
     vg::DevIn<uint8_t> in;
     VG_TRY(in.init(codes, static_cast<size_t>(idx->n) * (nb + 4), st));
+    if (idx->d_rq_rows) {
+        VG_HIP(hipFree(idx->d_rq_rows));
+        idx->d_rq_rows = nullptr;
+    }
+    VG_HIP(hipMalloc(reinterpret_cast<void **>(&idx->d_rq_rows), static_cast<size_t>(idx->n) * (nb + 4)));
+    VG_HIP(hipMemcpyAsync(idx->d_rq_rows, in.ptr, static_cast<size_t>(idx->n) * (nb + 4), hipMemcpyDeviceToDevice, st));
     hipLaunchKernelGGL(vg::rabitq_retile_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, st,
                        in.ptr, idx->n, nb, idx->rq_groups, idx->n_tiles, reinterpret_cast<uint4 *>(idx->d_rq_tiles),
                        idx->d_rq_norms);

@@ -136,4 +136,62 @@ __device__ __forceinline__ float exact_pair16(const float *__restrict__ row,
     return total;
 }
 
+// L2 of one pair in BOTH reduction orders at once: `pair` = squaredL2Avx512 (what
+// distFunc/SquaredL2 returns), `bnd` = squaredL2BoundedAvx512 run to completion.  The HNSW
+// layer search needs both because which one the reference calls depends on heap state that
+// evolves inside the neighbour loop (hnsw.go:1353-1376).  Since every partial sum of the
+// bounded kernel is non-decreasing in the block index (squares are >= +0 and fp32 FMA / add
+// are monotone), "some 64-block partial > bound" <=> "bnd > bound": the early exit does not
+// have to be replayed.
+__device__ __forceinline__ void exact_l2_both16(const float *__restrict__ row,
+                                                const float *__restrict__ q, int dim, Sub16 sub,
+                                                float &pair, float &bnd)
+{
+    float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    const int nblk = dim >> 6;
+    const float4 *r4 = reinterpret_cast<const float4 *>(row) + sub.f4;
+    const float4 *q4 = reinterpret_cast<const float4 *>(q) + sub.f4;
+    for (int e = 0; e < nblk; e++) {
+        const float4 a = q4[e * 16];
+        const float4 b = r4[e * 16];
+        const float d0 = a.x - b.x, d1 = a.y - b.y, d2 = a.z - b.z, d3 = a.w - b.w;
+        acc[0] = __builtin_fmaf(d0, d0, acc[0]);
+        acc[1] = __builtin_fmaf(d1, d1, acc[1]);
+        acc[2] = __builtin_fmaf(d2, d2, acc[2]);
+        acc[3] = __builtin_fmaf(d3, d3, acc[3]);
+    }
+    float b[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        const float p = dpp_partner_add<kDppRowHalfMirror>(acc[t]);
+        const float s = dpp_partner_add<kDppRowMirror>(p);
+        const float a = dpp_partner_add<kDppQuadXor2>(s);
+        b[t] = dpp_partner_add<kDppQuadXor1>(a);
+    }
+    float tp = (b[0] + b[2]) + (b[1] + b[3]);
+    float tb = (b[0] + b[1]) + (b[2] + b[3]);
+    int j = nblk << 6;
+    int jb = j;
+    for (; jb + 8 <= dim; jb += 8) {
+        float qv[8];
+#pragma unroll
+        for (int l = 0; l < 8; l++) {
+            const float d = q[jb + l] - row[jb + l];
+            qv[l] = d * d;
+        }
+        const float p0 = qv[0] + qv[4], p1 = qv[1] + qv[5], p2 = qv[2] + qv[6], p3 = qv[3] + qv[7];
+        tb = tb + ((p0 + p1) + (p2 + p3));
+    }
+    for (; jb < dim; jb++) {
+        const float d = q[jb] - row[jb];
+        tb = __builtin_fmaf(d, d, tb);
+    }
+    for (; j < dim; j++) {
+        const float d = q[j] - row[j];
+        tp = __builtin_fmaf(d, d, tp);
+    }
+    pair = tp;
+    bnd = tb;
+}
+
 }  // namespace vg

@@ -214,4 +214,18 @@ struct vg_index {
     uint8_t *d_rq_tiles = nullptr;
     float *d_rq_norms = nullptr;
     int32_t rq_groups = 0;  // ceil(((dim+63)/64*8) / 16)
+    // HNSW adjacency
+    uint32_t *d_hnsw_l0 = nullptr;     // n*m0
+    uint32_t *d_hnsw_slot = nullptr;   // max_level*n
+    uint32_t *d_hnsw_adj = nullptr;    // concatenated level tables
+    int64_t *d_hnsw_level_off = nullptr;  // max_level+1 row offsets into d_hnsw_adj (in rows)
+    int32_t hnsw_m0 = 0, hnsw_m = 0, hnsw_max_level = 0;
+    uint32_t hnsw_entry = 0;
+    // Vamana adjacency
+    uint32_t *d_vamana = nullptr;      // n*r
+    int32_t vamana_r = 0;
+    uint32_t vamana_entry = 0;
+    // PQ codes in the reference's row-major layout (random access by node id in graph search)
+    uint8_t *d_pq_rows = nullptr;
+    uint8_t *d_rq_rows = nullptr;
 };
