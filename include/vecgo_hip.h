@@ -186,6 +186,38 @@ int32_t vg_squared_l2_batch(vg_ctx *ctx, const float *query, const float *target
 int32_t vg_dot_batch(vg_ctx *ctx, const float *query, const float *targets, int64_t dim,
                      int64_t n, float *out, void *stream);
 
+/* simd.SquaredL2Bounded (kernels.go:173 -> bounded_l2_avx512.c:19-108), one query against n
+ * contiguous targets with one bound each (bounds[n]) or a shared one (bounds[1], n_bounds=1).
+ * exceeded[i] = (distance > bound) exactly as the reference reports it; dist[i] is the
+ * bounded kernel's reduction order run to completion (the reference returns a partial sum when
+ * it exits early — its callers only use dist when !exceeded, hnsw.go:1357-1366). */
+int32_t vg_squared_l2_bounded_batch(vg_ctx *ctx, const float *query, const float *targets, int64_t dim,
+                                    int64_t n, const float *bounds, int64_t n_bounds, float *dist,
+                                    int32_t *exceeded, void *stream);
+/* simd.PqAdcLookup (kernels.go:56 -> pqAdcLookupAvx512, floats_avx512.c:135-167), batched:
+ * one table (m*256 fp32, stride 256) against n codes of m bytes: out[n] */
+int32_t vg_pq_adc_lookup_batch(vg_ctx *ctx, const float *table, const uint8_t *codes, int64_t m, int64_t n,
+                               float *out, void *stream);
+
+/* ---- internal/kmeans ------------------------------------------------------------------------- */
+/* TrainKMeans kmeans.go:16-138: Lloyd on flat vectors[n*dim]; init = the first k entries of a
+ * random permutation (seeded counter stream instead of the unseeded rand.Perm, kmeans.go:25),
+ * assignment by SquaredL2Batch argmin (strict <) or DotBatch argmax (strict >) for Dot/Cosine,
+ * update = index-ordered fp32 sums * (1/count), empty cluster -> random point, stop when no
+ * assignment changed.  *produced = 0 and nothing written when n < k (the reference returns
+ * (nil, nil), kmeans.go:17-20); metric Hamming -> VG_ERR_UNSUPPORTED. */
+int32_t vg_kmeans_train(vg_ctx *ctx, const float *vectors, int64_t n, int32_t dim, int32_t k, int32_t metric,
+                        int32_t max_iter, uint64_t seed, float *centroids, int32_t *produced, void *stream);
+/* AssignPartition kmeans.go:142-196, batched: out[n] = index of the closest centroid */
+int32_t vg_kmeans_assign(vg_ctx *ctx, const float *vectors, int64_t n, int32_t dim, const float *centroids,
+                         int32_t k, int32_t metric, int32_t *out, void *stream);
+/* FindClosestCentroids kmeans.go:217-280: the nprobe closest centroid indices for one query
+ * (selection when nprobe <= k/4 && nprobe < 16, otherwise a sort by distance; ties by index).
+ * Returns min(nprobe, k) indices in out; *n_out receives that count. */
+int32_t vg_find_closest_centroids(vg_ctx *ctx, const float *query, const float *centroids, int32_t dim,
+                                  int32_t k, int32_t nprobe, int32_t metric, int32_t *out, int32_t *n_out,
+                                  void *stream);
+
 /* ---- searches ---------------------------------------------------------------- */
 /* Segment.Rerank (flat/segment.go:754-780, diskann/segment.go:1093-1116,
  * engine/search.go:914-965): exact distance.SquaredL2 / distance.Dot

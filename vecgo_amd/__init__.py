@@ -5,7 +5,9 @@ Python binding the tests and bench.py drive it with; names mirror the reference'
 interfaces (distance.Metric, quantization.ProductQuantizer, ...).
 """
 from .api import (Context, Index, Metric, ProductQuantizer, RaBitQuantizer, VecgoHipError,  # noqa: F401
-                  dot_batch, hamming_batch, merge_topk, squared_l2_batch)
+                  dot_batch, find_closest_centroids, hamming_batch, kmeans_assign, kmeans_train,
+                  merge_topk, pq_adc_lookup_batch, squared_l2_batch, squared_l2_bounded_batch)
 
 __all__ = ["Context", "Index", "Metric", "ProductQuantizer", "RaBitQuantizer", "VecgoHipError",
-           "dot_batch", "hamming_batch", "merge_topk", "squared_l2_batch"]
+           "dot_batch", "find_closest_centroids", "hamming_batch", "kmeans_assign", "kmeans_train",
+           "merge_topk", "pq_adc_lookup_batch", "squared_l2_batch", "squared_l2_bounded_batch"]

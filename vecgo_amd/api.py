@@ -150,6 +150,74 @@ def merge_topk(ctx: Context, ids_in, scores_in, k: int, metric=0, id_offsets=Non
     return out
 
 
+def squared_l2_bounded_batch(ctx: Context, query, targets, dim: int, bounds, stream=None):
+    """simd.SquaredL2Bounded (kernels.go:173), one query vs n targets: (dist[n], exceeded[n])."""
+    n = (targets.numel() if _is_torch(targets) else np.asarray(targets).size) // dim if dim > 0 else 0
+    q, pq_ = _ptr(query, np.float32)
+    t, pt = _ptr(targets, np.float32)
+    b = np.atleast_1d(np.asarray(bounds, np.float32)) if not _is_torch(bounds) else bounds
+    b_, pb = _ptr(b, np.float32)
+    nb = b_.numel() if _is_torch(b_) else b_.size
+    dist = _empty_like(targets, (n,), np.float32)
+    exc = _empty_like(targets, (n,), np.int32)
+    d, pd = _ptr(dist, np.float32, n)
+    e, pe = _ptr(exc, np.int32, n)
+    check(ctx._lib.vg_squared_l2_bounded_batch(ctx._h, pq_, pt, C.c_int64(dim), C.c_int64(n), pb,
+                                               C.c_int64(nb), pd, pe, _stream_ptr(stream)))
+    return dist, exc
+
+
+def pq_adc_lookup_batch(ctx: Context, table, codes, m: int, stream=None):
+    """simd.PqAdcLookup (kernels.go:56), one table vs n codes."""
+    n = (codes.numel() if _is_torch(codes) else np.asarray(codes).size) // m if m > 0 else 0
+    t, pt = _ptr(table, np.float32, m * 256)
+    c, pc = _ptr(codes, np.uint8)
+    out = _empty_like(codes, (n,), np.float32)
+    o, po = _ptr(out, np.float32, n)
+    check(ctx._lib.vg_pq_adc_lookup_batch(ctx._h, pt, pc, C.c_int64(m), C.c_int64(n), po, _stream_ptr(stream)))
+    return out
+
+
+def kmeans_train(ctx: Context, vectors, dim: int, k: int, metric=0, max_iter: int = 10, seed: int = 1, stream=None):
+    """kmeans.TrainKMeans (kmeans.go:16-138): returns [k, dim] centroids or None when n < k."""
+    n = _rows(vectors, dim)
+    v, pv = _ptr(vectors, np.float32)
+    out = _empty_like(vectors, (k, dim), np.float32)
+    o, po = _ptr(out, np.float32)
+    produced = C.c_int32(0)
+    check(ctx._lib.vg_kmeans_train(ctx._h, pv, C.c_int64(n), C.c_int32(dim), C.c_int32(k), C.c_int32(int(metric)),
+                                   C.c_int32(max_iter), C.c_uint64(seed), po, C.byref(produced),
+                                   _stream_ptr(stream)))
+    return out if produced.value else None
+
+
+def kmeans_assign(ctx: Context, vectors, centroids, dim: int, metric=0, stream=None):
+    """kmeans.AssignPartition (kmeans.go:142-196), batched."""
+    n = _rows(vectors, dim)
+    k = _rows(centroids, dim)
+    v, pv = _ptr(vectors, np.float32)
+    c, pc = _ptr(centroids, np.float32)
+    out = _empty_like(vectors, (n,), np.int32)
+    o, po = _ptr(out, np.int32, n)
+    check(ctx._lib.vg_kmeans_assign(ctx._h, pv, C.c_int64(n), C.c_int32(dim), pc, C.c_int32(k),
+                                    C.c_int32(int(metric)), po, _stream_ptr(stream)))
+    return out
+
+
+def find_closest_centroids(ctx: Context, query, centroids, dim: int, nprobe: int, metric=0, stream=None):
+    """kmeans.FindClosestCentroids (kmeans.go:217-280)."""
+    k = _rows(centroids, dim)
+    q = np.ascontiguousarray(query, np.float32)
+    c = np.ascontiguousarray(centroids, np.float32)
+    out = np.empty(max(min(nprobe, k), 1), np.int32)
+    n_out = C.c_int32(0)
+    check(ctx._lib.vg_find_closest_centroids(ctx._h, C.c_void_p(q.ctypes.data), C.c_void_p(c.ctypes.data),
+                                             C.c_int32(dim), C.c_int32(k), C.c_int32(nprobe),
+                                             C.c_int32(int(metric)), C.c_void_p(out.ctypes.data),
+                                             C.byref(n_out), _stream_ptr(stream)))
+    return out[:n_out.value]
+
+
 class RaBitQuantizer:
     """quantization.RaBitQuantizer (internal/quantization/rabitq.go:26-49)."""
 

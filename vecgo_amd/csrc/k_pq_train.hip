@@ -4,7 +4,7 @@
 // Determinism: every fp32 operation the reference performs sequentially (k-means++ running
 // sums, the per-cluster coordinate sums of updateCentroids, the per-term int8-dequant L2) is
 // performed here in the same order, so for a given seed the device result equals the CPU
-// oracle's (oracle/vg_oracle.c) bit for bit.  Parallelism comes from the independent units:
+// oracle's bit for bit.  Parallelism comes from the independent units:
 // sub-quantizers x points (assignment), sub-quantizers x clusters x coordinates (update).
 #include "vg_device.hpp"
 #include "vg_internal.hpp"
