@@ -414,9 +414,8 @@ int32_t launch_topk_merge(const uint64_t *partial, int64_t nq, int lists, int k,
                           const int *always = nullptr)
 {
     if (nq == 0 || k == 0) return VG_OK;
-    hipLaunchKernelGGL(topk_merge_kernel, dim3(static_cast<unsigned>(nq)), dim3(kMergeThreads), 0,
+    VG_LAUNCH(topk_merge_kernel, dim3(static_cast<unsigned>(nq)), dim3(kMergeThreads), 0,
                        st, partial, lists, k, descending, ids, scores, only_if, always);
-    VG_HIP(hipGetLastError());
     return VG_OK;
 }
 
@@ -452,13 +451,12 @@ static int32_t launch_scan(const vg_index *idx, const float *tables, int64_t nq,
     for (int64_t q0 = 0; q0 < nq; q0 += max_q) {
         int64_t cnt = nq - q0 < max_q ? nq - q0 : max_q;
         ProfScope prof(idx->ctx, "pq_adc_scan", st);
-        hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(cnt * slices)), dim3(kAdcThreads), lds,
+        VG_LAUNCH(kern, dim3(static_cast<unsigned>(cnt * slices)), dim3(kAdcThreads), lds,
                            st, reinterpret_cast<const uint4 *>(idx->d_pq_tiles), idx->n,
                            idx->n_tiles, pq->m, idx->pq_groups,
                            tables + q0 * pq->m * 256, slices, static_cast<int>(cnt), k,
                            partial + q0 * slices * k);
     }
-    VG_HIP(hipGetLastError());
     return VG_OK;
 }
 
@@ -509,12 +507,14 @@ VG_API int32_t vg_merge_topk(vg_ctx *ctx, const uint32_t *ids_in, const float *s
     VG_TRY(oid.init(ids, static_cast<size_t>(nq) * k, st));
     VG_TRY(osc.init(scores, static_cast<size_t>(nq) * k, st));
     const int nl = lists > 0 ? lists : 1;
-    vg::DevTmp<uint64_t> keys;
-    VG_TRY(keys.init(static_cast<size_t>(nl) * nq * k, st));
+    vg::ArenaCall ar(ctx, st);
+    const int i_keys = ar.add(sizeof(uint64_t) * static_cast<size_t>(nl) * nq * k);
+    VG_TRY(ar.commit());
+    struct { uint64_t *ptr; } keys{ar.get<uint64_t>(i_keys)};
     if (lists == 0) {
         VG_HIP(hipMemsetAsync(keys.ptr, 0xFF, static_cast<size_t>(nq) * k * 8, st));
     } else {
-        hipLaunchKernelGGL(vg::pack_keys_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256),
+        VG_LAUNCH(vg::pack_keys_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256),
                            0, st, i_in.ptr, s_in.ptr, lists, nq, k, desc, offs.ptr, keys.ptr);
     }
     VG_TRY(vg::launch_topk_merge(keys.ptr, nq, nl, k, desc, oid.ptr, osc.ptr, st));
@@ -553,10 +553,9 @@ VG_API int32_t vg_index_set_pq_codes(vg_index *idx, vg_pq *pq, const uint8_t *co
     VG_HIP(hipMalloc(reinterpret_cast<void **>(&idx->d_pq_rows), static_cast<size_t>(idx->n) * pq->m));
     VG_HIP(hipMemcpyAsync(idx->d_pq_rows, in.ptr, static_cast<size_t>(idx->n) * pq->m, hipMemcpyDeviceToDevice, st));
     int64_t total = idx->n_tiles * idx->pq_groups * 64;
-    hipLaunchKernelGGL(vg::pq_retile_kernel, dim3(static_cast<unsigned>((total + 255) / 256)),
+    VG_LAUNCH(vg::pq_retile_kernel, dim3(static_cast<unsigned>((total + 255) / 256)),
                        dim3(256), 0, st, in.ptr, idx->n, pq->m, idx->pq_groups, idx->n_tiles,
                        reinterpret_cast<uint4 *>(idx->d_pq_tiles));
-    VG_HIP(hipGetLastError());
     VG_HIP(hipStreamSynchronize(st));
     return VG_OK;
 }
@@ -597,10 +596,12 @@ VG_API int32_t vg_search_pq_adc(vg_index *idx, const float *queries, int64_t nq,
         VG_TRY(vg::launch_topk_merge(none.ptr, nq, 1, k, false, oid.ptr, osc.ptr, st));
     } else {
         const int slices = vg::adc_slices(nq, idx->n_tiles, idx->ctx->compute_units);
-        vg::DevTmp<float> tables;
-        vg::DevTmp<uint64_t> partial;
-        VG_TRY(tables.init(static_cast<size_t>(nq) * pq->m * 256, st));
-        VG_TRY(partial.init(static_cast<size_t>(nq) * slices * k, st));
+        vg::ArenaCall ar(idx->ctx, st);
+        const int i_tables = ar.add(sizeof(float) * static_cast<size_t>(nq) * pq->m * 256);
+        const int i_partial = ar.add(sizeof(uint64_t) * static_cast<size_t>(nq) * slices * k);
+        VG_TRY(ar.commit());
+        struct { float *ptr; } tables{ar.get<float>(i_tables)};
+        struct { uint64_t *ptr; } partial{ar.get<uint64_t>(i_partial)};
         VG_TRY(vg::launch_pq_build_table(pq, q.ptr, nq, tables.ptr, true, st));
         if (pq->m == 96 && k <= 64)
             VG_TRY((vg::launch_scan<6, true>(idx, tables.ptr, nq, k, slices, partial.ptr, st)));

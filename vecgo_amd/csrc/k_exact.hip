@@ -82,6 +82,20 @@ __global__ __launch_bounds__(kExactThreads) void rerank_kernel(
     }
 }
 
+__global__ void norm_max_kernel(const float *__restrict__ v, int64_t n, float *__restrict__ out)
+{
+    __shared__ float sm[1024];
+    float m = 0.0f;
+    for (int64_t i = threadIdx.x; i < n; i += 1024) m = fmaxf(m, v[i]);
+    sm[threadIdx.x] = m;
+    __syncthreads();
+    for (int s = 512; s > 0; s >>= 1) {
+        if (threadIdx.x < s) sm[threadIdx.x] = fmaxf(sm[threadIdx.x], sm[threadIdx.x + s]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = sm[0];
+}
+
 __global__ void row_norms_kernel(const float *__restrict__ base, int64_t n, int dim,
                                  float *__restrict__ norms)
 {
@@ -114,16 +128,18 @@ VG_API int32_t vg_index_set_vectors(vg_index *idx, const float *base, void *stre
         VG_HIP(hipStreamSynchronize(st));
         VG_HIP(hipFree(idx->d_vectors));
         VG_HIP(hipFree(idx->d_norms));
-        idx->d_vectors = idx->d_norms = nullptr;
+        VG_HIP(hipFree(idx->d_norm_max));
+        idx->d_vectors = idx->d_norms = idx->d_norm_max = nullptr;
     }
     if (idx->n == 0) return VG_OK;
     size_t count = static_cast<size_t>(idx->n) * idx->dim;
     VG_HIP(hipMalloc(reinterpret_cast<void **>(&idx->d_vectors), count * sizeof(float)));
     VG_HIP(hipMalloc(reinterpret_cast<void **>(&idx->d_norms), static_cast<size_t>(idx->n) * sizeof(float)));
     VG_HIP(hipMemcpyAsync(idx->d_vectors, base, count * sizeof(float), hipMemcpyDefault, st));
-    hipLaunchKernelGGL(vg::row_norms_kernel, dim3(static_cast<unsigned>((idx->n + 3) / 4)), dim3(256),
+    VG_LAUNCH(vg::row_norms_kernel, dim3(static_cast<unsigned>((idx->n + 3) / 4)), dim3(256),
                        0, st, idx->d_vectors, idx->n, idx->dim, idx->d_norms);
-    VG_HIP(hipGetLastError());
+    VG_HIP(hipMalloc(reinterpret_cast<void **>(&idx->d_norm_max), sizeof(float)));
+    VG_LAUNCH(vg::norm_max_kernel, dim3(1), dim3(1024), 0, st, idx->d_norms, idx->n, idx->d_norm_max);
     VG_HIP(hipStreamSynchronize(st));
     return VG_OK;
 }
@@ -146,12 +162,11 @@ static int32_t batch_impl(vg_ctx *ctx, bool dot, const float *query, const float
     int64_t blocks = (n + 15) / 16;
     if (blocks > 4096) blocks = 4096;
     if (dot)
-        hipLaunchKernelGGL(vg::batch_kernel<true>, dim3(static_cast<unsigned>(blocks)),
+        VG_LAUNCH(vg::batch_kernel<true>, dim3(static_cast<unsigned>(blocks)),
                            dim3(vg::kExactThreads), 0, st, q.ptr, t.ptr, static_cast<int>(dim), n, o.ptr);
     else
-        hipLaunchKernelGGL(vg::batch_kernel<false>, dim3(static_cast<unsigned>(blocks)),
+        VG_LAUNCH(vg::batch_kernel<false>, dim3(static_cast<unsigned>(blocks)),
                            dim3(vg::kExactThreads), 0, st, q.ptr, t.ptr, static_cast<int>(dim), n, o.ptr);
-    VG_HIP(hipGetLastError());
     VG_TRY(o.finish());
     if (o.on_host()) VG_HIP(hipStreamSynchronize(st));
     return VG_OK;
@@ -194,15 +209,14 @@ VG_API int32_t vg_score_candidates(vg_index *idx, const float *queries, int64_t 
         int64_t cnt = nq - q0 < maxy ? nq - q0 : maxy;
         dim3 grid(gx, static_cast<unsigned>(cnt));
         if (dot)
-            hipLaunchKernelGGL(vg::score_candidates_kernel<true>, grid, dim3(vg::kExactThreads), 0, st,
+            VG_LAUNCH(vg::score_candidates_kernel<true>, grid, dim3(vg::kExactThreads), 0, st,
                                idx->d_vectors, idx->n, idx->dim, q.ptr + q0 * idx->dim,
                                c.ptr + q0 * nc, nc, o.ptr + q0 * nc);
         else
-            hipLaunchKernelGGL(vg::score_candidates_kernel<false>, grid, dim3(vg::kExactThreads), 0, st,
+            VG_LAUNCH(vg::score_candidates_kernel<false>, grid, dim3(vg::kExactThreads), 0, st,
                                idx->d_vectors, idx->n, idx->dim, q.ptr + q0 * idx->dim,
                                c.ptr + q0 * nc, nc, o.ptr + q0 * nc);
     }
-    VG_HIP(hipGetLastError());
     VG_TRY(o.finish());
     if (o.on_host()) VG_HIP(hipStreamSynchronize(st));
     return VG_OK;
@@ -235,9 +249,8 @@ VG_API int32_t vg_rerank(vg_index *idx, const float *queries, int64_t nq, const 
     auto kern = dot ? vg::rerank_kernel<true> : vg::rerank_kernel<false>;
     VG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
-    hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(nq)), dim3(vg::kExactThreads), lds, st,
+    VG_LAUNCH(kern, dim3(static_cast<unsigned>(nq)), dim3(vg::kExactThreads), lds, st,
                        idx->d_vectors, idx->n, idx->dim, q.ptr, c.ptr, nc, k, oid.ptr, osc.ptr);
-    VG_HIP(hipGetLastError());
     VG_TRY(oid.finish());
     VG_TRY(osc.finish());
     if (oid.on_host() || osc.on_host()) VG_HIP(hipStreamSynchronize(st));

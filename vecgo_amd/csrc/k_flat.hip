@@ -152,11 +152,42 @@ __global__ __launch_bounds__(kSelThreads) void flat_select_kernel(const float *_
     const float *row = scores + q * n;
     WaveTopK tk;
     tk.init(kc);
-    for (int64_t i0 = r0 + wave * 64; i0 < r1; i0 += kSelThreads) {
-        const int64_t i = i0 + lane;
-        uint64_t key = kKeyMax;
-        if (i < r1) key = make_key(row[i], static_cast<uint32_t>(i), false);
-        tk.offer(key, lane);
+    // each wave sweeps chunks of 64 lanes x 4 loads x 4 floats; the 4 loads are unguarded and in
+    // flight together (a guarded load would serialise on vmcnt(0)); a chunk whose minimum is not
+    // below the wave's k-th key is skipped with one ballot
+    const int64_t a0 = (r0 + 3) & ~int64_t(3);          // 16-byte aligned interior [a0, a1)
+    const int64_t a1 = a0 + ((r1 - a0) / 1024) * 1024;  // whole 1024-float chunks
+    if (a0 < r1 && a1 > a0) {
+        const float4 *row4 = reinterpret_cast<const float4 *>(row + a0);
+        const int64_t chunks = (a1 - a0) / 1024;
+        for (int64_t c = wave; c < chunks; c += kSelWaves) {
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) v[u] = row4[c * 256 + u * 64 + lane];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int64_t i = a0 + c * 1024 + (u * 64 + lane) * 4;
+                const float vals[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+                float mn = fminf(fminf(vals[0], vals[1]), fminf(vals[2], vals[3]));
+                if (!__ballot(make_key(mn, 0u, false) < tk.tau)) continue;
+#pragma unroll
+                for (int e = 0; e < 4; e++)
+                    tk.offer(make_key(vals[e], static_cast<uint32_t>(i + e), false), lane);
+            }
+        }
+    }
+    // ragged head and tail
+    {
+        const int64_t head_end = (a0 < r1 && a1 > a0) ? a0 : r1;
+        for (int64_t i0 = r0 + wave * 64; i0 < head_end; i0 += kSelThreads) {
+            const int64_t i = i0 + lane;
+            tk.offer(i < head_end ? make_key(row[i], static_cast<uint32_t>(i), false) : kKeyMax, lane);
+        }
+        const int64_t tail_begin = (a0 < r1 && a1 > a0) ? a1 : r1;
+        for (int64_t i0 = tail_begin + wave * 64; i0 < r1; i0 += kSelThreads) {
+            const int64_t i = i0 + lane;
+            tk.offer(i < r1 ? make_key(row[i], static_cast<uint32_t>(i), false) : kKeyMax, lane);
+        }
     }
     wg_rank_merge<kSelWaves>(tk, lists, valid, wave, lane, tid, kc,
                              partial + (q * slices + s) * kc);
@@ -268,20 +299,6 @@ __global__ void flat_patch_kernel(const int *__restrict__ fallback, const int *_
     }
 }
 
-__global__ void max_reduce_kernel(const float *__restrict__ v, int64_t n, float *__restrict__ out)
-{
-    __shared__ float sm[256];
-    float m = 0.0f;
-    for (int64_t i = threadIdx.x; i < n; i += 256) m = fmaxf(m, v[i]);
-    sm[threadIdx.x] = m;
-    __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-        if (threadIdx.x < s) sm[threadIdx.x] = fmaxf(sm[threadIdx.x], sm[threadIdx.x + s]);
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) out[0] = sm[0];
-}
-
 }  // namespace vg
 
 VG_API int32_t vg_search_flat(vg_index *idx, const float *queries, int64_t nq, int32_t k, uint32_t *ids,
@@ -321,20 +338,20 @@ VG_API int32_t vg_search_flat(vg_index *idx, const float *queries, int64_t nq, i
         if (qc > 4096) qc = 4096;
         const int sel_slices = static_cast<int>(std::min<int64_t>(64, std::max<int64_t>(1, n / 4096)));
         const int ex_slices = static_cast<int>(std::min<int64_t>(256, std::max<int64_t>(1, n / 64)));
-        vg::DevTmp<float> sc, cand_sc, fsc, xmax;
-        vg::DevTmp<uint64_t> partial, fpartial;
-        vg::DevTmp<uint32_t> cand_id, fid;
-        vg::DevTmp<int> flags;
-        VG_TRY(sc.init(static_cast<size_t>(qc) * n, st));
-        VG_TRY(partial.init(static_cast<size_t>(qc) * sel_slices * kc, st));
-        VG_TRY(cand_id.init(static_cast<size_t>(qc) * kc, st));
-        VG_TRY(cand_sc.init(static_cast<size_t>(qc) * kc, st));
-        VG_TRY(flags.init(static_cast<size_t>(qc) + 1, st));
-        VG_TRY(fpartial.init(static_cast<size_t>(qc) * ex_slices * k, st));
-        VG_TRY(fid.init(static_cast<size_t>(qc) * k, st));
-        VG_TRY(fsc.init(static_cast<size_t>(qc) * k, st));
-        VG_TRY(xmax.init(1, st));
-        hipLaunchKernelGGL(vg::max_reduce_kernel, dim3(1), dim3(256), 0, st, idx->d_norms, n, xmax.ptr);
+        vg::ArenaCall ar(idx->ctx, st);
+        const int i_sc = ar.add(sizeof(float) * static_cast<size_t>(qc) * n);
+        const int i_partial = ar.add(sizeof(uint64_t) * static_cast<size_t>(qc) * sel_slices * kc);
+        const int i_cand_id = ar.add(sizeof(uint32_t) * static_cast<size_t>(qc) * kc);
+        const int i_cand_sc = ar.add(sizeof(float) * static_cast<size_t>(qc) * kc);
+        const int i_flags = ar.add(sizeof(int) * (static_cast<size_t>(qc) + 1));
+        const int i_fpartial = ar.add(sizeof(uint64_t) * static_cast<size_t>(qc) * ex_slices * k);
+        const int i_fid = ar.add(sizeof(uint32_t) * static_cast<size_t>(qc) * k);
+        const int i_fsc = ar.add(sizeof(float) * static_cast<size_t>(qc) * k);
+        VG_TRY(ar.commit());
+        struct P { float *ptr; } sc{ar.get<float>(i_sc)}, cand_sc{ar.get<float>(i_cand_sc)}, fsc{ar.get<float>(i_fsc)};
+        struct PU { uint64_t *ptr; } partial{ar.get<uint64_t>(i_partial)}, fpartial{ar.get<uint64_t>(i_fpartial)};
+        struct PI { uint32_t *ptr; } cand_id{ar.get<uint32_t>(i_cand_id)}, fid{ar.get<uint32_t>(i_fid)};
+        struct PF { int *ptr; } flags{ar.get<int>(i_flags)};
         const char *force = getenv("VG_FLAT_FORCE_EXACT");  // test hook: run step 4 for every query
         int *always = flags.ptr + qc;
         VG_HIP(hipMemsetAsync(always, 0, sizeof(int), st));
@@ -346,35 +363,35 @@ VG_API int32_t vg_search_flat(vg_index *idx, const float *queries, int64_t nq, i
             {
             vg::ProfScope prof(idx->ctx, "flat_gemm", st);
             if (dot)
-                hipLaunchKernelGGL(vg::flat_gemm_kernel<true>, dim3(static_cast<unsigned>(mt * nt)),
+                VG_LAUNCH(vg::flat_gemm_kernel<true>, dim3(static_cast<unsigned>(mt * nt)),
                                    dim3(vg::kGemmThreads), 0, st, qp, cnt, idx->d_vectors, n, dim,
                                    idx->d_norms, sc.ptr);
             else
-                hipLaunchKernelGGL(vg::flat_gemm_kernel<false>, dim3(static_cast<unsigned>(mt * nt)),
+                VG_LAUNCH(vg::flat_gemm_kernel<false>, dim3(static_cast<unsigned>(mt * nt)),
                                    dim3(vg::kGemmThreads), 0, st, qp, cnt, idx->d_vectors, n, dim,
                                    idx->d_norms, sc.ptr);
             }
             {
             vg::ProfScope prof(idx->ctx, "flat_select", st);
-            hipLaunchKernelGGL(vg::flat_select_kernel, dim3(sel_slices, static_cast<unsigned>(cnt)),
+            VG_LAUNCH(vg::flat_select_kernel, dim3(sel_slices, static_cast<unsigned>(cnt)),
                                dim3(vg::kSelThreads), 0, st, sc.ptr, n, sel_slices, kc, partial.ptr);
             }
             VG_TRY(vg::launch_topk_merge(partial.ptr, cnt, sel_slices, kc, false, cand_id.ptr, cand_sc.ptr, st));
             if (dot)
-                hipLaunchKernelGGL(vg::flat_verify_kernel<true>, dim3(static_cast<unsigned>(cnt)), dim3(256), 0,
-                                   st, idx->d_vectors, n, dim, qp, xmax.ptr, cand_id.ptr, cand_sc.ptr, kc, k,
+                VG_LAUNCH(vg::flat_verify_kernel<true>, dim3(static_cast<unsigned>(cnt)), dim3(256), 0,
+                                   st, idx->d_vectors, n, dim, qp, idx->d_norm_max, cand_id.ptr, cand_sc.ptr, kc, k,
                                    oid.ptr + q0 * k, osc.ptr + q0 * k, flags.ptr);
             else
-                hipLaunchKernelGGL(vg::flat_verify_kernel<false>, dim3(static_cast<unsigned>(cnt)), dim3(256), 0,
-                                   st, idx->d_vectors, n, dim, qp, xmax.ptr, cand_id.ptr, cand_sc.ptr, kc, k,
+                VG_LAUNCH(vg::flat_verify_kernel<false>, dim3(static_cast<unsigned>(cnt)), dim3(256), 0,
+                                   st, idx->d_vectors, n, dim, qp, idx->d_norm_max, cand_id.ptr, cand_sc.ptr, kc, k,
                                    oid.ptr + q0 * k, osc.ptr + q0 * k, flags.ptr);
             // step 4 always launches; its workgroups exit at once unless the query is flagged
             if (dot)
-                hipLaunchKernelGGL(vg::flat_exact_kernel<true>, dim3(ex_slices, static_cast<unsigned>(cnt)),
+                VG_LAUNCH(vg::flat_exact_kernel<true>, dim3(ex_slices, static_cast<unsigned>(cnt)),
                                    dim3(256), 0, st, idx->d_vectors, n, dim, qp, flags.ptr, always, ex_slices, k,
                                    fpartial.ptr);
             else
-                hipLaunchKernelGGL(vg::flat_exact_kernel<false>, dim3(ex_slices, static_cast<unsigned>(cnt)),
+                VG_LAUNCH(vg::flat_exact_kernel<false>, dim3(ex_slices, static_cast<unsigned>(cnt)),
                                    dim3(256), 0, st, idx->d_vectors, n, dim, qp, flags.ptr, always, ex_slices, k,
                                    fpartial.ptr);
             if (getenv("VG_FLAT_DEBUG")) {
@@ -387,10 +404,9 @@ VG_API int32_t vg_search_flat(vg_index *idx, const float *queries, int64_t nq, i
                         (long long)q0, (long long)cnt, (long long)nf);
             }
             VG_TRY(vg::launch_topk_merge(fpartial.ptr, cnt, ex_slices, k, dot, fid.ptr, fsc.ptr, st, flags.ptr, always));
-            hipLaunchKernelGGL(vg::flat_patch_kernel, dim3(static_cast<unsigned>(cnt)), dim3(64), 0, st,
+            VG_LAUNCH(vg::flat_patch_kernel, dim3(static_cast<unsigned>(cnt)), dim3(64), 0, st,
                                flags.ptr, always, k, fid.ptr, fsc.ptr, oid.ptr + q0 * k, osc.ptr + q0 * k);
         }
-        VG_HIP(hipGetLastError());
     }
     VG_TRY(oid.finish());
     VG_TRY(osc.finish());

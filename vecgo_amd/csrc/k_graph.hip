@@ -535,8 +535,10 @@ VG_API int32_t vg_search_hnsw(vg_index *idx, const float *queries, int64_t nq, i
     const int64_t vis_words = (idx->n + 31) / 32;
     int64_t chunk = std::max<int64_t>(1, (int64_t(1) << 28) / std::max<int64_t>(vis_words, 1));  // <= 1 GiB of bitmaps
     chunk = std::min(chunk, nq);
-    vg::DevTmp<uint32_t> vis;
-    VG_TRY(vis.init(static_cast<size_t>(chunk) * vis_words, st));
+    vg::ArenaCall ar(idx->ctx, st);
+    const int i_vis = ar.add(sizeof(uint32_t) * static_cast<size_t>(chunk) * vis_words);
+    VG_TRY(ar.commit());
+    struct { uint32_t *ptr; } vis{ar.get<uint32_t>(i_vis)};
     const size_t lds = static_cast<size_t>(3 * ef) * sizeof(vg::HItem) + 128 * sizeof(float);
     VG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(vg::hnsw_search_kernel),
                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
@@ -544,13 +546,12 @@ VG_API int32_t vg_search_hnsw(vg_index *idx, const float *queries, int64_t nq, i
         const int64_t cnt = std::min(chunk, nq - q0);
         VG_HIP(hipMemsetAsync(vis.ptr, 0, static_cast<size_t>(cnt) * vis_words * 4, st));
         vg::ProfScope prof(idx->ctx, "hnsw_search", st);
-        hipLaunchKernelGGL(vg::hnsw_search_kernel, dim3(static_cast<unsigned>(cnt)), dim3(64), lds, st,
+        VG_LAUNCH(vg::hnsw_search_kernel, dim3(static_cast<unsigned>(cnt)), dim3(64), lds, st,
                            idx->d_vectors, idx->n, idx->dim, idx->metric, idx->d_hnsw_l0, idx->hnsw_m0,
                            idx->hnsw_max_level, idx->hnsw_m, idx->d_hnsw_slot, idx->d_hnsw_adj,
                            idx->d_hnsw_level_off, idx->hnsw_entry, q.ptr + q0 * idx->dim, k, ef, vis.ptr,
                            vis_words, oid.ptr + q0 * k, osc.ptr + q0 * k, ost.ptr ? ost.ptr + q0 : nullptr);
     }
-    VG_HIP(hipGetLastError());
     VG_TRY(oid.finish());
     VG_TRY(osc.finish());
     VG_TRY(ost.finish());
@@ -588,34 +589,35 @@ VG_API int32_t vg_search_vamana(vg_index *idx, const float *queries, int64_t nq,
     const int64_t per_query = vis_words * 4 + cand_cap * 8;
     int64_t chunk = std::max<int64_t>(1, (int64_t(1) << 30) / per_query);
     chunk = std::min(chunk, nq);
-    vg::DevTmp<uint32_t> vis;
-    vg::DevTmp<vg::HItem> cand;
-    vg::DevTmp<float> luts;
-    vg::DevTmp<uint8_t> qcodes;
-    VG_TRY(vis.init(static_cast<size_t>(chunk) * vis_words, st));
-    VG_TRY(cand.init(static_cast<size_t>(chunk) * cand_cap, st));
     const int rq_nb = ((idx->dim + 63) / 64) * 8;
     const int pq_m = idx->pq ? idx->pq->m : 0;
+    vg::ArenaCall ar(idx->ctx, st);
+    const int i_vis = ar.add(sizeof(uint32_t) * static_cast<size_t>(chunk) * vis_words);
+    const int i_cand = ar.add(sizeof(vg::HItem) * static_cast<size_t>(chunk) * cand_cap);
+    const int i_luts = ar.add(kind == 1 ? sizeof(float) * static_cast<size_t>(nq) * pq_m * 256 : 0);
+    const int i_qcodes = ar.add(kind == 2 ? static_cast<size_t>(nq) * (rq_nb + 4) : 0);
+    VG_TRY(ar.commit());
+    struct { uint32_t *ptr; } vis{ar.get<uint32_t>(i_vis)};
+    struct { vg::HItem *ptr; } cand{ar.get<vg::HItem>(i_cand)};
+    struct { float *ptr; } luts{ar.get<float>(i_luts)};
+    struct { uint8_t *ptr; } qcodes{ar.get<uint8_t>(i_qcodes)};
     if (kind == 1) {
-        VG_TRY(luts.init(static_cast<size_t>(nq) * pq_m * 256, st));
         VG_TRY(vg::launch_pq_build_table(idx->pq, q.ptr, nq, luts.ptr, false, st));
     }
     if (kind == 2) {
-        VG_TRY(qcodes.init(static_cast<size_t>(nq) * (rq_nb + 4), st));
         VG_TRY(vg::launch_rabitq_encode(q.ptr, nq, idx->dim, qcodes.ptr, st));
     }
     for (int64_t q0 = 0; q0 < nq; q0 += chunk) {
         const int64_t cnt = std::min(chunk, nq - q0);
         VG_HIP(hipMemsetAsync(vis.ptr, 0, static_cast<size_t>(cnt) * vis_words * 4, st));
         vg::ProfScope prof(idx->ctx, "vamana_search", st);
-        hipLaunchKernelGGL(vg::vamana_search_kernel, dim3(static_cast<unsigned>(cnt)), dim3(64), 0, st, kind,
+        VG_LAUNCH(vg::vamana_search_kernel, dim3(static_cast<unsigned>(cnt)), dim3(64), 0, st, kind,
                            idx->metric, idx->n, idx->dim, idx->d_vamana, idx->vamana_r, idx->vamana_entry,
                            idx->d_vectors, idx->d_pq_rows, pq_m, kind == 1 ? luts.ptr + q0 * pq_m * 256 : nullptr,
                            idx->d_rq_rows, kind == 2 ? qcodes.ptr + q0 * (rq_nb + 4) : nullptr, rq_nb,
                            q.ptr + q0 * idx->dim, k, cand.ptr, cand_cap, vis.ptr, vis_words, oid.ptr + q0 * k,
                            osc.ptr + q0 * k, ost.ptr ? ost.ptr + q0 : nullptr);
     }
-    VG_HIP(hipGetLastError());
     VG_TRY(oid.finish());
     VG_TRY(osc.finish());
     VG_TRY(ost.finish());

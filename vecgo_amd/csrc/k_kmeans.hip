@@ -164,12 +164,11 @@ VG_API int32_t vg_kmeans_assign(vg_ctx *ctx, const float *vectors, int64_t n, in
     VG_TRY(o.init(out, static_cast<size_t>(n), st));
     const unsigned gx = static_cast<unsigned>((n + 15) / 16);
     if (metric == VG_METRIC_L2)
-        hipLaunchKernelGGL(vg::km_assign_kernel<false>, dim3(gx), dim3(256), 0, st, v.ptr, n, dim, c.ptr, k, o.ptr,
+        VG_LAUNCH(vg::km_assign_kernel<false>, dim3(gx), dim3(256), 0, st, v.ptr, n, dim, c.ptr, k, o.ptr,
                            static_cast<int *>(nullptr));
     else
-        hipLaunchKernelGGL(vg::km_assign_kernel<true>, dim3(gx), dim3(256), 0, st, v.ptr, n, dim, c.ptr, k, o.ptr,
+        VG_LAUNCH(vg::km_assign_kernel<true>, dim3(gx), dim3(256), 0, st, v.ptr, n, dim, c.ptr, k, o.ptr,
                            static_cast<int *>(nullptr));
-    VG_HIP(hipGetLastError());
     VG_TRY(o.finish());
     if (o.on_host()) VG_HIP(hipStreamSynchronize(st));
     return VG_OK;
@@ -210,7 +209,7 @@ VG_API int32_t vg_kmeans_train(vg_ctx *ctx, const float *vectors, int64_t n, int
     VG_HIP(hipMemcpyAsync(rows.ptr, perm.data(), sizeof(int64_t) * k, hipMemcpyHostToDevice, st));
     VG_HIP(hipStreamSynchronize(st));  // perm is a local
     const int64_t tot = static_cast<int64_t>(k) * dim;
-    hipLaunchKernelGGL(vg::km_gather_rows_kernel, dim3(static_cast<unsigned>((tot + 255) / 256)), dim3(256), 0, st,
+    VG_LAUNCH(vg::km_gather_rows_kernel, dim3(static_cast<unsigned>((tot + 255) / 256)), dim3(256), 0, st,
                        v.ptr, dim, rows.ptr, k, cent.ptr);
     VG_HIP(hipMemsetAsync(assign.ptr, 0, sizeof(int32_t) * static_cast<size_t>(n), st));
     std::vector<int64_t> hcounts(static_cast<size_t>(k)), hoff(static_cast<size_t>(k));
@@ -219,14 +218,14 @@ VG_API int32_t vg_kmeans_train(vg_ctx *ctx, const float *vectors, int64_t n, int
     for (int it = 0; it < max_iter; it++) {
         VG_HIP(hipMemsetAsync(changed.ptr, 0, sizeof(int), st));
         if (metric == VG_METRIC_L2)
-            hipLaunchKernelGGL(vg::km_assign_kernel<false>, dim3(gx), dim3(256), 0, st, v.ptr, n, dim, cent.ptr, k,
+            VG_LAUNCH(vg::km_assign_kernel<false>, dim3(gx), dim3(256), 0, st, v.ptr, n, dim, cent.ptr, k,
                                assign.ptr, changed.ptr);
         else
-            hipLaunchKernelGGL(vg::km_assign_kernel<true>, dim3(gx), dim3(256), 0, st, v.ptr, n, dim, cent.ptr, k,
+            VG_LAUNCH(vg::km_assign_kernel<true>, dim3(gx), dim3(256), 0, st, v.ptr, n, dim, cent.ptr, k,
                                assign.ptr, changed.ptr);
         int hchanged = 0;
         VG_HIP(hipMemcpyAsync(&hchanged, changed.ptr, sizeof(int), hipMemcpyDeviceToHost, st));
-        hipLaunchKernelGGL(vg::km_count_kernel, dim3(kx), dim3(64), 0, st, assign.ptr, n, k, counts.ptr);
+        VG_LAUNCH(vg::km_count_kernel, dim3(kx), dim3(64), 0, st, assign.ptr, n, k, counts.ptr);
         VG_HIP(hipMemcpyAsync(hcounts.data(), counts.ptr, sizeof(int64_t) * k, hipMemcpyDeviceToHost, st));
         VG_HIP(hipStreamSynchronize(st));  // training is not a hot path: one sync per Lloyd iteration
         if (!hchanged) break;               // kmeans.go:101-103
@@ -236,13 +235,12 @@ VG_API int32_t vg_kmeans_train(vg_ctx *ctx, const float *vectors, int64_t n, int
             run += hcounts[static_cast<size_t>(c)];
         }
         VG_HIP(hipMemcpyAsync(offsets.ptr, hoff.data(), sizeof(int64_t) * k, hipMemcpyHostToDevice, st));
-        hipLaunchKernelGGL(vg::km_members_kernel, dim3(kx), dim3(64), 0, st, assign.ptr, n, k, offsets.ptr,
+        VG_LAUNCH(vg::km_members_kernel, dim3(kx), dim3(64), 0, st, assign.ptr, n, k, offsets.ptr,
                            members.ptr);
-        hipLaunchKernelGGL(vg::km_update_kernel, dim3(static_cast<unsigned>((dim + 255) / 256), k), dim3(256), 0, st,
+        VG_LAUNCH(vg::km_update_kernel, dim3(static_cast<unsigned>((dim + 255) / 256), k), dim3(256), 0, st,
                            v.ptr, n, dim, k, it, seed, counts.ptr, offsets.ptr, members.ptr, cent.ptr);
         VG_HIP(hipStreamSynchronize(st));  // hoff is reused next iteration
     }
-    VG_HIP(hipGetLastError());
     VG_TRY(cent.finish());
     VG_HIP(hipStreamSynchronize(st));
     if (produced) *produced = 1;
@@ -309,9 +307,8 @@ VG_API int32_t vg_squared_l2_bounded_batch(vg_ctx *ctx, const float *query, cons
     VG_TRY(od.init(dist, static_cast<size_t>(n), st));
     VG_TRY(oe.init(exceeded, static_cast<size_t>(n), st));
     int64_t blocks = std::min<int64_t>((n + 15) / 16, 4096);
-    hipLaunchKernelGGL(vg::bounded_batch_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, st, q.ptr, t.ptr,
+    VG_LAUNCH(vg::bounded_batch_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, st, q.ptr, t.ptr,
                        static_cast<int>(dim), n, b.ptr, n_bounds, od.ptr, oe.ptr);
-    VG_HIP(hipGetLastError());
     VG_TRY(od.finish());
     VG_TRY(oe.finish());
     if (od.on_host() || oe.on_host()) VG_HIP(hipStreamSynchronize(st));
@@ -333,9 +330,8 @@ VG_API int32_t vg_pq_adc_lookup_batch(vg_ctx *ctx, const float *table, const uin
     VG_TRY(t.init(table, static_cast<size_t>(m) * 256, st));
     VG_TRY(c.init(codes, static_cast<size_t>(n) * m, st));
     VG_TRY(o.init(out, static_cast<size_t>(n), st));
-    hipLaunchKernelGGL(vg::adc_lookup_batch_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, st,
+    VG_LAUNCH(vg::adc_lookup_batch_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, st,
                        t.ptr, c.ptr, static_cast<int>(m), n, o.ptr);
-    VG_HIP(hipGetLastError());
     VG_TRY(o.finish());
     if (o.on_host()) VG_HIP(hipStreamSynchronize(st));
     return VG_OK;

@@ -48,11 +48,10 @@ int32_t launch_pq_build_table(const vg_pq *pq, const float *d_queries, int64_t n
         int64_t cnt = nq - q0 < maxy ? nq - q0 : maxy;
         dim3 grid(static_cast<unsigned>(pq->m), static_cast<unsigned>(cnt));
         auto kern = scan_layout ? pq_build_table_kernel<true> : pq_build_table_kernel<false>;
-        hipLaunchKernelGGL(kern, grid, dim3(256), 0, st, d_queries + q0 * pq->dim,
+        VG_LAUNCH(kern, grid, dim3(256), 0, st, d_queries + q0 * pq->dim,
                            pq->d_codebooks, pq->d_scales, pq->d_offsets, pq->dim, pq->m, pq->k,
                            pq->subdim, d_tables + q0 * pq->m * pq->k);
     }
-    VG_HIP(hipGetLastError());
     return VG_OK;
 }
 

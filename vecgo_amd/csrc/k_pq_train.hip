@@ -403,22 +403,21 @@ VG_API int32_t vg_pq_train(vg_pq *pq, const float *vectors, int64_t n, int32_t i
     VG_HIP(hipMemsetAsync(flags.ptr, 0, sizeof(int) * 2 * m, st));
     int *changed = flags.ptr, *done = flags.ptr + m;
 
-    hipLaunchKernelGGL(vg::pq_kmeanspp_kernel, dim3(m), dim3(vg::kPPThreads), 0, st, v.ptr, n, dim, sd,
+    VG_LAUNCH(vg::pq_kmeanspp_kernel, dim3(m), dim3(vg::kPPThreads), 0, st, v.ptr, n, dim, sd,
                        k, seed, mind.ptr, cent.ptr);
     const size_t lds = static_cast<size_t>(k) * sd * sizeof(float);
     VG_CHECK(lds <= 64 * 1024, VG_ERR_UNSUPPORTED, "vg_pq_train: codebook of one sub-quantizer exceeds 64 KiB");
     const unsigned gx = static_cast<unsigned>((n + 255) / 256);
     const unsigned ux = static_cast<unsigned>((k * sd + 255) / 256);
     for (int it = 0; it < iters; it++) {
-        hipLaunchKernelGGL(vg::pq_assign_kernel, dim3(gx, m), dim3(256), lds, st, v.ptr, n, dim, sd, k,
+        VG_LAUNCH(vg::pq_assign_kernel, dim3(gx, m), dim3(256), lds, st, v.ptr, n, dim, sd, k,
                            cent.ptr, assign.ptr, changed, done);
-        hipLaunchKernelGGL(vg::pq_update_kernel, dim3(ux, m), dim3(256), 0, st, v.ptr, n, dim, sd, k, it,
+        VG_LAUNCH(vg::pq_update_kernel, dim3(ux, m), dim3(256), 0, st, v.ptr, n, dim, sd, k, it,
                            seed, assign.ptr, cent.ptr, changed, done);
-        hipLaunchKernelGGL(vg::pq_iter_end_kernel, dim3((m + 63) / 64), dim3(64), 0, st, m, changed, done);
+        VG_LAUNCH(vg::pq_iter_end_kernel, dim3((m + 63) / 64), dim3(64), 0, st, m, changed, done);
     }
-    hipLaunchKernelGGL(vg::pq_quantize_kernel, dim3(m), dim3(256), 0, st, cent.ptr, k, sd,
+    VG_LAUNCH(vg::pq_quantize_kernel, dim3(m), dim3(256), 0, st, cent.ptr, k, sd,
                        pq->d_codebooks, pq->d_scales, pq->d_offsets);
-    VG_HIP(hipGetLastError());
     VG_HIP(hipStreamSynchronize(st));
     pq->trained = true;
     return VG_OK;
@@ -440,10 +439,9 @@ VG_API int32_t vg_pq_encode(vg_pq *pq, const float *vectors, int64_t n, uint8_t 
     const size_t lds = static_cast<size_t>(pq->k) * pq->subdim * sizeof(float);
     VG_CHECK(lds <= 64 * 1024, VG_ERR_UNSUPPORTED, "vg_pq_encode: codebook of one sub-quantizer exceeds 64 KiB");
     // grid.y = m <= 65535 is guaranteed by dim limits; grid.x up to 2^31
-    hipLaunchKernelGGL(vg::pq_encode_kernel, dim3(static_cast<unsigned>((n + 255) / 256), pq->m), dim3(256),
+    VG_LAUNCH(vg::pq_encode_kernel, dim3(static_cast<unsigned>((n + 255) / 256), pq->m), dim3(256),
                        lds, st, v.ptr, n, pq->dim, pq->m, pq->subdim, pq->k, pq->d_codebooks, pq->d_scales,
                        pq->d_offsets, c.ptr);
-    VG_HIP(hipGetLastError());
     VG_TRY(c.finish());
     if (c.on_host()) VG_HIP(hipStreamSynchronize(st));
     return VG_OK;
@@ -463,10 +461,9 @@ VG_API int32_t vg_pq_decode(vg_pq *pq, const uint8_t *codes, int64_t n, float *o
     VG_TRY(c.init(codes, static_cast<size_t>(n) * pq->m, st));
     VG_TRY(o.init(out, static_cast<size_t>(n) * pq->dim, st));
     const int64_t total = n * pq->dim;
-    hipLaunchKernelGGL(vg::pq_decode_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0,
+    VG_LAUNCH(vg::pq_decode_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0,
                        st, c.ptr, n, pq->dim, pq->m, pq->subdim, pq->k, pq->d_codebooks, pq->d_scales,
                        pq->d_offsets, o.ptr);
-    VG_HIP(hipGetLastError());
     VG_TRY(o.finish());
     if (o.on_host()) VG_HIP(hipStreamSynchronize(st));
     return VG_OK;
@@ -488,10 +485,9 @@ VG_API int32_t vg_pq_asymmetric_distance_batch(vg_pq *pq, const float *query, co
     VG_TRY(q.init(query, static_cast<size_t>(pq->dim), st));
     VG_TRY(c.init(codes, static_cast<size_t>(n) * pq->m, st));
     VG_TRY(o.init(out, static_cast<size_t>(n), st));
-    hipLaunchKernelGGL(vg::pq_asym_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, st,
+    VG_LAUNCH(vg::pq_asym_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, st,
                        q.ptr, c.ptr, n, pq->dim, pq->m, pq->subdim, pq->k, pq->d_codebooks, pq->d_scales,
                        pq->d_offsets, o.ptr);
-    VG_HIP(hipGetLastError());
     VG_TRY(o.finish());
     if (o.on_host()) VG_HIP(hipStreamSynchronize(st));
     return VG_OK;

@@ -167,9 +167,8 @@ __global__ __launch_bounds__(kRqThreads) void rabitq_scan_kernel(
 int32_t launch_rabitq_encode(const float *d_vectors, int64_t n, int dim, uint8_t *d_codes, hipStream_t st)
 {
     if (n == 0) return VG_OK;
-    hipLaunchKernelGGL(rabitq_encode_kernel, dim3(static_cast<unsigned>((n + 15) / 16)), dim3(256), 0, st,
+    VG_LAUNCH(rabitq_encode_kernel, dim3(static_cast<unsigned>((n + 15) / 16)), dim3(256), 0, st,
                        d_vectors, n, dim, d_codes);
-    VG_HIP(hipGetLastError());
     return VG_OK;
 }
 
@@ -202,9 +201,8 @@ VG_API int32_t vg_rabitq_encode(vg_ctx *ctx, int32_t dim, const float *vectors, 
     vg::DevOut<uint8_t> c;
     VG_TRY(v.init(vectors, static_cast<size_t>(n) * dim, st));
     VG_TRY(c.init(codes, static_cast<size_t>(n) * cb, st));
-    hipLaunchKernelGGL(vg::rabitq_encode_kernel, dim3(static_cast<unsigned>((n + 15) / 16)), dim3(256), 0, st,
+    VG_LAUNCH(vg::rabitq_encode_kernel, dim3(static_cast<unsigned>((n + 15) / 16)), dim3(256), 0, st,
                        v.ptr, n, dim, c.ptr);
-    VG_HIP(hipGetLastError());
     VG_TRY(c.finish());
     if (c.on_host()) VG_HIP(hipStreamSynchronize(st));
     return VG_OK;
@@ -228,10 +226,9 @@ VG_API int32_t vg_rabitq_distance_batch(vg_ctx *ctx, int32_t dim, const float *q
     VG_TRY(c.init(codes, static_cast<size_t>(n) * cb, st));
     VG_TRY(o.init(out, static_cast<size_t>(n), st));
     VG_TRY(qcode.init(static_cast<size_t>(cb), st));
-    hipLaunchKernelGGL(vg::rabitq_encode_kernel, dim3(1), dim3(256), 0, st, q.ptr, int64_t(1), dim, qcode.ptr);
-    hipLaunchKernelGGL(vg::rabitq_distance_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, st,
+    VG_LAUNCH(vg::rabitq_encode_kernel, dim3(1), dim3(256), 0, st, q.ptr, int64_t(1), dim, qcode.ptr);
+    VG_LAUNCH(vg::rabitq_distance_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, st,
                        qcode.ptr, c.ptr, n, dim, o.ptr);
-    VG_HIP(hipGetLastError());
     VG_TRY(o.finish());
     if (o.on_host()) VG_HIP(hipStreamSynchronize(st));
     return VG_OK;
@@ -251,9 +248,8 @@ VG_API int32_t vg_hamming_batch(vg_ctx *ctx, const uint8_t *a, const uint8_t *co
     VG_TRY(da.init(a, static_cast<size_t>(nbytes), st));
     VG_TRY(dc.init(codes, static_cast<size_t>(n) * nbytes, st));
     VG_TRY(o.init(out, static_cast<size_t>(n), st));
-    hipLaunchKernelGGL(vg::hamming_batch_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, st,
+    VG_LAUNCH(vg::hamming_batch_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, st,
                        da.ptr, dc.ptr, nbytes, n, o.ptr);
-    VG_HIP(hipGetLastError());
     VG_TRY(o.finish());
     if (o.on_host()) VG_HIP(hipStreamSynchronize(st));
     return VG_OK;
@@ -288,10 +284,9 @@ VG_API int32_t vg_index_set_rabitq_codes(vg_index *idx, const uint8_t *codes, vo
     }
     VG_HIP(hipMalloc(reinterpret_cast<void **>(&idx->d_rq_rows), static_cast<size_t>(idx->n) * (nb + 4)));
     VG_HIP(hipMemcpyAsync(idx->d_rq_rows, in.ptr, static_cast<size_t>(idx->n) * (nb + 4), hipMemcpyDeviceToDevice, st));
-    hipLaunchKernelGGL(vg::rabitq_retile_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, st,
+    VG_LAUNCH(vg::rabitq_retile_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, st,
                        in.ptr, idx->n, nb, idx->rq_groups, idx->n_tiles, reinterpret_cast<uint4 *>(idx->d_rq_tiles),
                        idx->d_rq_norms);
-    VG_HIP(hipGetLastError());
     VG_HIP(hipStreamSynchronize(st));
     return VG_OK;
 }
@@ -321,23 +316,24 @@ VG_API int32_t vg_search_rabitq(vg_index *idx, const float *queries, int64_t nq,
     } else {
         const int nb = vg::rq_words(idx->dim) * 8;
         const int slices = vg::rq_slices(nq, idx->n_tiles, idx->ctx->compute_units);
-        vg::DevTmp<uint8_t> qcodes;
-        vg::DevTmp<uint64_t> partial;
-        VG_TRY(qcodes.init(static_cast<size_t>(nq) * (nb + 4), st));
-        VG_TRY(partial.init(static_cast<size_t>(nq) * slices * k, st));
-        hipLaunchKernelGGL(vg::rabitq_encode_kernel, dim3(static_cast<unsigned>((nq + 15) / 16)), dim3(256), 0, st,
+        vg::ArenaCall ar(idx->ctx, st);
+        const int i_qcodes = ar.add(static_cast<size_t>(nq) * (nb + 4));
+        const int i_partial = ar.add(sizeof(uint64_t) * static_cast<size_t>(nq) * slices * k);
+        VG_TRY(ar.commit());
+        struct { uint8_t *ptr; } qcodes{ar.get<uint8_t>(i_qcodes)};
+        struct { uint64_t *ptr; } partial{ar.get<uint64_t>(i_partial)};
+        VG_LAUNCH(vg::rabitq_encode_kernel, dim3(static_cast<unsigned>((nq + 15) / 16)), dim3(256), 0, st,
                            q.ptr, nq, idx->dim, qcodes.ptr);
         const int64_t max_q = (1ll << 30) / slices;
         for (int64_t q0 = 0; q0 < nq; q0 += max_q) {
             const int64_t cnt = nq - q0 < max_q ? nq - q0 : max_q;
             vg::ProfScope prof(idx->ctx, "rabitq_scan", st);
-            hipLaunchKernelGGL(vg::rabitq_scan_kernel, dim3(static_cast<unsigned>(cnt * slices)),
+            VG_LAUNCH(vg::rabitq_scan_kernel, dim3(static_cast<unsigned>(cnt * slices)),
                                dim3(vg::kRqThreads), 0, st, reinterpret_cast<const uint4 *>(idx->d_rq_tiles),
                                idx->d_rq_norms, idx->n, idx->n_tiles, idx->rq_groups, idx->dim,
                                qcodes.ptr + q0 * (nb + 4), nb, slices, static_cast<int>(cnt), k,
                                partial.ptr + q0 * slices * k);
         }
-        VG_HIP(hipGetLastError());
         VG_TRY(vg::launch_topk_merge(partial.ptr, nq, slices, k, false, oid.ptr, osc.ptr, st));
     }
     VG_TRY(oid.finish());

@@ -90,6 +90,9 @@ VG_API int32_t vg_ctx_destroy(vg_ctx *ctx)
 {
     if (!ctx) return VG_OK;
     (void)hipSetDevice(ctx->device);
+    (void)hipDeviceSynchronize();
+    for (auto &p : ctx->arenas)
+        if (p.second.base) (void)hipFree(p.second.base);
     if (ctx->stream) {
         (void)hipStreamSynchronize(ctx->stream);
         (void)hipStreamDestroy(ctx->stream);
@@ -176,6 +179,7 @@ VG_API int32_t vg_index_destroy(vg_index *idx)
     if (idx->d_pq_tiles) (void)hipFree(idx->d_pq_tiles);
     if (idx->d_vectors) (void)hipFree(idx->d_vectors);
     if (idx->d_norms) (void)hipFree(idx->d_norms);
+    if (idx->d_norm_max) (void)hipFree(idx->d_norm_max);
     if (idx->d_rq_tiles) (void)hipFree(idx->d_rq_tiles);
     if (idx->d_rq_norms) (void)hipFree(idx->d_rq_norms);
     if (idx->d_hnsw_l0) (void)hipFree(idx->d_hnsw_l0);

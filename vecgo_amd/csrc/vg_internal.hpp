@@ -31,6 +31,21 @@ void set_error(const char *fmt, ...);
         }                                                                                     \
     } while (0)
 
+// Kernel launch with error check.  HIP keeps a sticky "last error" that some successful calls
+// latch (e.g. pointer-attribute probes of plain host memory inside hipMemcpyDefault), so the
+// state is cleared right before the launch and read right after it.
+#define VG_LAUNCH(...)                                                                              \
+    do {                                                                                            \
+        (void)hipGetLastError();                                                                    \
+        hipLaunchKernelGGL(__VA_ARGS__);                                                            \
+        hipError_t _le = hipGetLastError();                                                         \
+        if (_le != hipSuccess) {                                                                    \
+            ::vg::set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(_le), __FILE__,   \
+                            __LINE__);                                                              \
+            return VG_ERR_HIP;                                                                      \
+        }                                                                                           \
+    } while (0)
+
 #define VG_CHECK(cond, status, ...)          \
     do {                                     \
         if (!(cond)) {                       \
@@ -54,8 +69,18 @@ struct vg_prof_record {
     hipEvent_t start, stop;
 };
 
+// Grow-only scratch arena, one per (context, stream): per-call hipMallocAsync of multi-GB
+// buffers costs milliseconds of host time; work enqueued on one stream is ordered, so the next
+// call on that stream may reuse the same bytes.
+struct vg_arena {
+    char *base = nullptr;
+    size_t cap = 0;
+};
+
 struct vg_ctx {
     int device = 0;
+    std::mutex arena_mu;
+    std::vector<std::pair<hipStream_t, vg_arena>> arenas;
     hipStream_t stream = nullptr;
     int compute_units = 0;
     int64_t hbm_bytes = 0;
@@ -168,6 +193,54 @@ struct DevOut {
     }
 };
 
+// Carves 256-byte aligned pieces out of the (context, stream) arena.  Usage: add() every piece,
+// then commit() once (grows the arena if needed: synchronises the stream only when it grows),
+// then get<T>(i).  The arena mutex is held until the ArenaCall is destroyed, i.e. for the
+// duration of the enqueue, which serialises concurrent callers of one (context, stream).
+struct ArenaCall {
+    vg_ctx *ctx;
+    hipStream_t st;
+    std::vector<size_t> offs;
+    size_t total = 0;
+    char *base = nullptr;
+    std::unique_lock<std::mutex> lock;
+    ArenaCall(vg_ctx *c, hipStream_t s) : ctx(c), st(s), lock(c->arena_mu) {}
+    int add(size_t bytes)
+    {
+        offs.push_back(total);
+        total += (bytes + 255) & ~size_t(255);
+        return static_cast<int>(offs.size()) - 1;
+    }
+    int32_t commit()
+    {
+        vg_arena *a = nullptr;
+        for (auto &p : ctx->arenas)
+            if (p.first == st) a = &p.second;
+        if (!a) {
+            ctx->arenas.emplace_back(st, vg_arena{});
+            a = &ctx->arenas.back().second;
+        }
+        if (a->cap < total) {
+            if (a->base) {
+                VG_HIP(hipStreamSynchronize(st));
+                VG_HIP(hipFree(a->base));
+                a->base = nullptr;
+                a->cap = 0;
+            }
+            size_t want = total + total / 4;
+            VG_HIP(hipMalloc(reinterpret_cast<void **>(&a->base), want));
+            a->cap = want;
+        }
+        base = a->base;
+        return VG_OK;
+    }
+    template <typename T>
+    T *get(int i) const
+    {
+        return reinterpret_cast<T *>(base + offs[static_cast<size_t>(i)]);
+    }
+};
+
 // Scratch in HBM for the duration of a call (stream-ordered pool allocation).
 template <typename T>
 struct DevTmp {
@@ -210,6 +283,7 @@ struct vg_index {
     // fp32 rows, row-major n*dim (reference layout), plus ||x||^2 for the GEMM path
     float *d_vectors = nullptr;
     float *d_norms = nullptr;
+    float *d_norm_max = nullptr;  // [1] max ||x||^2: error bound of the GEMM-form scores
     // RaBitQ: sign bits re-tiled [tile][group][lane][16 B] and the stored norms
     uint8_t *d_rq_tiles = nullptr;
     float *d_rq_norms = nullptr;
