@@ -76,6 +76,33 @@ def test_flat_forced_exhaustive_path(vg, ctx):
         os.environ.pop("VG_FLAT_FORCE_EXACT")
 
 
+def test_flat_unfused_path_matches_too(vg, ctx):
+    """The score-matrix variant (GEMM -> select) stays available behind VG_FLAT_UNFUSED=1."""
+    os.environ["VG_FLAT_UNFUSED"] = "1"
+    try:
+        check(vg, ctx, 20000, 128, 6, 10, 0, np.random.default_rng(18))
+        check(vg, ctx, 3000, 100, 3, 10, 2, np.random.default_rng(19))
+    finally:
+        os.environ.pop("VG_FLAT_UNFUSED")
+
+
+def test_flat_sorted_rows_and_candidate_overflow(vg, ctx):
+    """Rows sorted by distance to the query defeat the sampled threshold on purpose (the sample is
+    not representative, far more than 4096 rows pass): the overflow is detected and the
+    exhaustive kernel answers; results stay exact."""
+    rng = np.random.default_rng(23)
+    n, dim = 40000, 64
+    base = rng.standard_normal((n, dim)).astype(np.float32)
+    q = rng.standard_normal((2, dim)).astype(np.float32)
+    order = np.argsort(-((base - q[0]) ** 2).sum(1))   # farthest first: the sampled tiles are all far
+    base = np.ascontiguousarray(base[order])
+    idx = vg.Index(ctx, n, dim); idx.set_vectors(base)
+    ids, sc = idx.search_flat(q, 10)
+    for qi in range(2):
+        eid, esc = o.flat_search_f32(base, dim, q[qi], 10)
+        assert np.array_equal(ids[qi], eid) and np.array_equal(bits(sc[qi]), bits(esc))
+
+
 def test_flat_clustered_data_triggers_fallback_safely(vg, ctx):
     """All rows within a tiny ball: GEMM-form scores cannot separate them, so the proof fails
     and the exhaustive kernel must take over; results still exact."""

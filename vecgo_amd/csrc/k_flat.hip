@@ -23,13 +23,21 @@ int32_t launch_topk_merge(const uint64_t *partial, int64_t nq, int lists, int k,
 // 33 floats: the MFMA operand read (lane l: row l&31, k = l>>5) then touches 32 consecutive
 // banks.  Registers prefetch the next K step while the current one is multiplied.
 constexpr int kGemmBM = 128, kGemmBN = 128, kGemmBK = 32, kGemmLd = kGemmBK + 1;
+constexpr int kGemmPasses = kGemmBM * kGemmBK / 4 / 256;  // float4 loads per thread per operand tile
 constexpr int kGemmThreads = 256;
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
-template <bool DOT>
+// MODE 0: scores[q][n] for every row.  MODE 1: only every tile_stride-th row tile, written
+// compactly (row length out_cols; columns past n hold +Inf) — the sample that sets the per-query
+// threshold.  MODE 2: no score matrix at all: an element below its query's threshold is appended
+// (64-bit key) to that query's candidate buffer.  Whatever the threshold, every row NOT appended
+// has score >= threshold, which is all the proof in flat_verify_kernel needs.
+template <bool DOT, int MODE>
 __global__ __launch_bounds__(kGemmThreads) void flat_gemm_kernel(
     const float *__restrict__ queries, int64_t nq, const float *__restrict__ base, int64_t n,
-    int dim, const float *__restrict__ norms, float *__restrict__ scores /* [nq][n] */)
+    int dim, const float *__restrict__ norms, float *__restrict__ scores, int tile_stride,
+    int64_t out_cols, const float *__restrict__ thr, int thr_stride, int thr_off,
+    int *__restrict__ counts, uint64_t *__restrict__ cand, int cap)
 {
     __shared__ float As[kGemmBM * kGemmLd];
     __shared__ float Bs[kGemmBN * kGemmLd];
@@ -39,23 +47,25 @@ __global__ __launch_bounds__(kGemmThreads) void flat_gemm_kernel(
     const int64_t tn = bt / mtiles;
     const int tm = static_cast<int>(bt % mtiles);
     const int64_t q0 = static_cast<int64_t>(tm) * kGemmBM;
-    const int64_t n0 = tn * kGemmBN;
+    const int64_t n0 = (MODE == 1 ? tn * tile_stride : tn) * kGemmBN;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
 
-    // staging map: 8 lanes cover one row's 32 floats (128 B), 32 rows per pass, 4 passes
-    const int srow = tid >> 3;       // 0..31
-    const int sk = (tid & 7) * 4;    // 0,4,..,28
-    const float *aptr[4];
-    const float *bptr[4];
+    // staging map: BK/4 lanes cover one row's BK floats, 256/(BK/4) rows per pass
+    constexpr int kLanesPerRow = kGemmBK / 4;
+    constexpr int kRowsPerPass = kGemmThreads / kLanesPerRow;
+    const int srow = tid / kLanesPerRow;
+    const int sk = (tid % kLanesPerRow) * 4;
+    const float *aptr[kGemmPasses];
+    const float *bptr[kGemmPasses];
 #pragma unroll
-    for (int p = 0; p < 4; p++) {
-        int64_t qa = q0 + p * 32 + srow;
+    for (int p = 0; p < kGemmPasses; p++) {
+        int64_t qa = q0 + p * kRowsPerPass + srow;
         if (qa >= nq) qa = nq - 1;
-        int64_t nb = n0 + p * 32 + srow;
+        int64_t nb = n0 + p * kRowsPerPass + srow;
         if (nb >= n) nb = n - 1;
         aptr[p] = queries + qa * dim + sk;
         bptr[p] = base + nb * dim + sk;
@@ -68,20 +78,20 @@ __global__ __launch_bounds__(kGemmThreads) void flat_gemm_kernel(
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[i][j][r] = 0.0f;
 
-    float4 ra[4], rb[4];
+    float4 ra[kGemmPasses], rb[kGemmPasses];
     const int ksteps = (dim + kGemmBK - 1) / kGemmBK;
     const int full_steps = dim / kGemmBK;  // K steps with no ragged edge (uniform per kernel)
     auto load_tile = [&](int kt) {
         const int k0 = kt * kGemmBK;
         if (kt < full_steps) {  // unguarded: 8 independent 16-byte loads in flight
 #pragma unroll
-            for (int p = 0; p < 4; p++) {
+            for (int p = 0; p < kGemmPasses; p++) {
                 ra[p] = *reinterpret_cast<const float4 *>(aptr[p] + k0);
                 rb[p] = *reinterpret_cast<const float4 *>(bptr[p] + k0);
             }
         } else {  // ragged K edge: element-wise with zero fill
 #pragma unroll
-            for (int p = 0; p < 4; p++) {
+            for (int p = 0; p < kGemmPasses; p++) {
                 float ta[4] = {0, 0, 0, 0}, tb[4] = {0, 0, 0, 0};
                 for (int e = 0; e < 4; e++)
                     if (k0 + sk + e < dim) {
@@ -97,9 +107,9 @@ __global__ __launch_bounds__(kGemmThreads) void flat_gemm_kernel(
     for (int kt = 0; kt < ksteps; kt++) {
         __syncthreads();  // previous step's operand reads are done
 #pragma unroll
-        for (int p = 0; p < 4; p++) {
-            float *da = As + (p * 32 + srow) * kGemmLd + sk;
-            float *db = Bs + (p * 32 + srow) * kGemmLd + sk;
+        for (int p = 0; p < kGemmPasses; p++) {
+            float *da = As + (p * kRowsPerPass + srow) * kGemmLd + sk;
+            float *db = Bs + (p * kRowsPerPass + srow) * kGemmLd + sk;
             da[0] = ra[p].x; da[1] = ra[p].y; da[2] = ra[p].z; da[3] = ra[p].w;
             db[0] = rb[p].x; db[1] = rb[p].y; db[2] = rb[p].z; db[3] = rb[p].w;
         }
@@ -120,20 +130,65 @@ __global__ __launch_bounds__(kGemmThreads) void flat_gemm_kernel(
     // epilogue: C/D map of 32x32: col = lane&31 (row index n), row = (r&3) + 8*(r>>2) + 4*(lane>>5)
 #pragma unroll
     for (int j = 0; j < 2; j++) {
-        const int64_t nn = n0 + wc * 64 + j * 32 + (lane & 31);
+        const int col = wc * 64 + j * 32 + (lane & 31);
+        const int64_t nn = n0 + col;
         const float xn = (!DOT && nn < n) ? norms[nn] : 0.0f;
 #pragma unroll
         for (int i = 0; i < 2; i++) {
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 const int64_t qq = q0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (qq < nq && nn < n) {
-                    const float dotv = acc[i][j][r];
-                    scores[qq * n + nn] = DOT ? -dotv : __builtin_fmaf(-2.0f, dotv, xn);
+                if (qq >= nq) continue;
+                const float dotv = acc[i][j][r];
+                const float sc = DOT ? -dotv : __builtin_fmaf(-2.0f, dotv, xn);
+                if (MODE == 0) {
+                    if (nn < n) scores[qq * n + nn] = sc;
+                } else if (MODE == 1) {
+                    scores[qq * out_cols + tn * kGemmBN + col] = nn < n ? sc : INFINITY;
+                } else {
+                    if (nn < n && sc < thr[qq * thr_stride + thr_off]) {
+                        const int pos = atomicAdd(&counts[qq], 1);
+                        if (pos < cap) cand[qq * cap + pos] = make_key(sc, static_cast<uint32_t>(nn), false);
+                    }
                 }
             }
         }
     }
+}
+
+// per query: the kc best keys among the candidates the fused GEMM appended (count <= cap)
+__global__ __launch_bounds__(256) void flat_pick_kernel(const uint64_t *__restrict__ cand,
+                                                        const int *__restrict__ counts, int cap, int kc,
+                                                        uint32_t *__restrict__ cand_ids,
+                                                        float *__restrict__ cand_scores)
+{
+    __shared__ uint64_t lists[4 * 64];
+    __shared__ int valid[4];
+    __shared__ uint64_t best[64];
+    const int64_t q = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int c = counts[q];
+    if (c > cap) c = cap;
+    const uint64_t *src = cand + q * cap;
+    WaveTopK tk;
+    tk.init(kc);
+    for (int i0 = wave * 64; i0 < c; i0 += 256) {
+        const int i = i0 + lane;
+        tk.offer(i < c ? src[i] : kKeyMax, lane);
+    }
+    wg_rank_merge<4>(tk, lists, valid, wave, lane, tid, kc, best);
+    __syncthreads();
+    if (tid < kc) {
+        const uint64_t e = best[tid];
+        cand_ids[q * kc + tid] = e == kKeyMax ? VG_INVALID_ID : key_row(e);
+        cand_scores[q * kc + tid] = e == kKeyMax ? INFINITY : key_score(e, false);
+    }
+}
+
+__global__ void fill_f32_kernel(float *p, int64_t n, float v)
+{
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
 }
 
 // ---- 2. per-query streaming select of the kc smallest scores -------------------------------
@@ -200,7 +255,8 @@ __global__ __launch_bounds__(256) void flat_verify_kernel(
     const float *__restrict__ base, int64_t n, int dim, const float *__restrict__ queries,
     const float *__restrict__ norms_max /* [1] */, const uint32_t *__restrict__ cand_ids,
     const float *__restrict__ cand_scores, int kc, int k, uint32_t *__restrict__ ids,
-    float *__restrict__ scores, int *__restrict__ fallback)
+    float *__restrict__ scores, int *__restrict__ fallback, const float *__restrict__ thr, int thr_stride,
+    int thr_off, const int *__restrict__ counts, int cap)
 {
     __shared__ uint64_t keys[64];
     const Sub16 sub = Sub16::make(threadIdx.x);
@@ -227,13 +283,27 @@ __global__ __launch_bounds__(256) void flat_verify_kernel(
     for (int off = 32; off > 0; off >>= 1) qn += __shfl_xor(qn, off);
     const uint64_t kth = readlane_u64(tk.list, k - 1);
     bool ok = true;
-    const bool have_all = (n <= kc);  // every row is a candidate: nothing to prove
-    if (!have_all) {
-        const float tau = cand_scores[q * kc + (kc - 1)];  // worst nominated GEMM score
+    // tau: a lower bound on the GEMM score of every row that was NOT nominated
+    float tau;
+    bool have_all;
+    if (thr) {  // fused path: rows not appended have score >= threshold; appended-but-not-picked
+                // rows have score >= the kc-th picked score
+        const float tq = thr[q * thr_stride + thr_off];
+        const int cnt = counts[q];
+        if (cnt > cap) ok = false;  // buffer overflow: some rows below the threshold were dropped
+        tau = cnt > kc ? fminf(tq, cand_scores[q * kc + (kc - 1)]) : tq;
+        have_all = (tq == INFINITY) && cnt <= kc;
+    } else {
+        tau = cand_scores[q * kc + (kc - 1)];  // worst nominated GEMM score
+        have_all = (n <= kc);                  // every row is a candidate: nothing to prove
+    }
+    if (ok && !have_all) {
         const float xmax = norms_max[0];
         // fp32 GEMM-form vs exact: |err| <= ~ 2*dim*2^-24*(|q||x|) per dot; bound generously
         const float eps = 4.0f * (static_cast<float>(dim) * 5.9604645e-8f) * (qn + xmax) + 1e-30f;
-        if (kth == kKeyMax) {
+        if (tau == INFINITY) {
+            ok = true;  // nothing was excluded
+        } else if (kth == kKeyMax) {
             ok = false;
         } else if (DOT) {
             // outside rows: -q.x >= tau  =>  q.x <= -tau (+eps); need kth dot > that
@@ -331,16 +401,34 @@ VG_API int32_t vg_search_flat(vg_index *idx, const float *queries, int64_t nq, i
         VG_HIP(hipMemsetAsync(none.ptr, 0xFF, static_cast<size_t>(nq) * k * 8, st));
         VG_TRY(vg::launch_topk_merge(none.ptr, nq, 1, k, dot, oid.ptr, osc.ptr, st));
     } else {
-        // query chunk so that the score matrix stays <= 2 GiB
-        int64_t qc = (int64_t(2) << 30) / (n * 4);
+        const char *unfused_env = getenv("VG_FLAT_UNFUSED");  // test hook: materialise the score matrix
+        const bool fused = !(unfused_env && unfused_env[0] == '1');
+        const int cap = 4096;          // candidate keys per query (fused path)
+        const int sample_j = 8;        // threshold = sample_j-th best score of the row sample
+        const int sample_stride = 64;  // every 64th 128-row tile is sampled
+        const int64_t nt = (n + vg::kGemmBN - 1) / vg::kGemmBN;
+        const int64_t nst = (nt + sample_stride - 1) / sample_stride;  // sampled tiles
+        const int64_t ns = nst * vg::kGemmBN;                          // sampled columns
+        const bool use_sample = fused && n > cap;  // n <= cap: threshold +Inf, every row is appended
+
+        // query chunk: whole 128-query tiles; unfused keeps the score matrix <= 2 GiB
+        int64_t qc = fused ? 4096 : (int64_t(2) << 30) / (n * 4);
+        if (qc > 4096) qc = 4096;
+        if (qc >= vg::kGemmBM) qc = (qc / vg::kGemmBM) * vg::kGemmBM;
         if (qc < 1) qc = 1;
         if (qc > nq) qc = nq;
-        if (qc > 4096) qc = 4096;
-        const int sel_slices = static_cast<int>(std::min<int64_t>(64, std::max<int64_t>(1, n / 4096)));
+        const int64_t sel_n = fused ? ns : n;
+        const int sel_slices = static_cast<int>(std::min<int64_t>(64, std::max<int64_t>(1, sel_n / 4096)));
+        const int sel_k = fused ? sample_j : kc;
         const int ex_slices = static_cast<int>(std::min<int64_t>(256, std::max<int64_t>(1, n / 64)));
+
         vg::ArenaCall ar(idx->ctx, st);
-        const int i_sc = ar.add(sizeof(float) * static_cast<size_t>(qc) * n);
-        const int i_partial = ar.add(sizeof(uint64_t) * static_cast<size_t>(qc) * sel_slices * kc);
+        const int i_sc = ar.add(sizeof(float) * static_cast<size_t>(qc) * (fused ? (use_sample ? ns : 1) : n));
+        const int i_partial = ar.add(sizeof(uint64_t) * static_cast<size_t>(qc) * sel_slices * sel_k);
+        const int i_sid = ar.add(sizeof(uint32_t) * static_cast<size_t>(qc) * sel_k);
+        const int i_thr = ar.add(sizeof(float) * static_cast<size_t>(qc) * sel_k);
+        const int i_counts = ar.add(sizeof(int) * static_cast<size_t>(qc));
+        const int i_cand = ar.add(fused ? sizeof(uint64_t) * static_cast<size_t>(qc) * cap : 0);
         const int i_cand_id = ar.add(sizeof(uint32_t) * static_cast<size_t>(qc) * kc);
         const int i_cand_sc = ar.add(sizeof(float) * static_cast<size_t>(qc) * kc);
         const int i_flags = ar.add(sizeof(int) * (static_cast<size_t>(qc) + 1));
@@ -348,64 +436,105 @@ VG_API int32_t vg_search_flat(vg_index *idx, const float *queries, int64_t nq, i
         const int i_fid = ar.add(sizeof(uint32_t) * static_cast<size_t>(qc) * k);
         const int i_fsc = ar.add(sizeof(float) * static_cast<size_t>(qc) * k);
         VG_TRY(ar.commit());
-        struct P { float *ptr; } sc{ar.get<float>(i_sc)}, cand_sc{ar.get<float>(i_cand_sc)}, fsc{ar.get<float>(i_fsc)};
-        struct PU { uint64_t *ptr; } partial{ar.get<uint64_t>(i_partial)}, fpartial{ar.get<uint64_t>(i_fpartial)};
-        struct PI { uint32_t *ptr; } cand_id{ar.get<uint32_t>(i_cand_id)}, fid{ar.get<uint32_t>(i_fid)};
-        struct PF { int *ptr; } flags{ar.get<int>(i_flags)};
+        float *sc = ar.get<float>(i_sc), *thr = ar.get<float>(i_thr);
+        float *cand_sc = ar.get<float>(i_cand_sc), *fsc = ar.get<float>(i_fsc);
+        uint64_t *partial = ar.get<uint64_t>(i_partial), *fpartial = ar.get<uint64_t>(i_fpartial);
+        uint64_t *cand = ar.get<uint64_t>(i_cand);
+        uint32_t *sid = ar.get<uint32_t>(i_sid), *cand_id = ar.get<uint32_t>(i_cand_id), *fid = ar.get<uint32_t>(i_fid);
+        int *counts = ar.get<int>(i_counts), *flags = ar.get<int>(i_flags);
+
         const char *force = getenv("VG_FLAT_FORCE_EXACT");  // test hook: run step 4 for every query
-        int *always = flags.ptr + qc;
+        int *always = flags + qc;
         VG_HIP(hipMemsetAsync(always, 0, sizeof(int), st));
         if (force && force[0] == '1') VG_HIP(hipMemsetAsync(always, 1, sizeof(int), st));
         for (int64_t q0 = 0; q0 < nq; q0 += qc) {
             const int64_t cnt = std::min(qc, nq - q0);
             const float *qp = q.ptr + q0 * dim;
-            const int64_t mt = (cnt + vg::kGemmBM - 1) / vg::kGemmBM, nt = (n + vg::kGemmBN - 1) / vg::kGemmBN;
-            {
-            vg::ProfScope prof(idx->ctx, "flat_gemm", st);
-            if (dot)
-                VG_LAUNCH(vg::flat_gemm_kernel<true>, dim3(static_cast<unsigned>(mt * nt)),
-                                   dim3(vg::kGemmThreads), 0, st, qp, cnt, idx->d_vectors, n, dim,
-                                   idx->d_norms, sc.ptr);
-            else
-                VG_LAUNCH(vg::flat_gemm_kernel<false>, dim3(static_cast<unsigned>(mt * nt)),
-                                   dim3(vg::kGemmThreads), 0, st, qp, cnt, idx->d_vectors, n, dim,
-                                   idx->d_norms, sc.ptr);
+            const int64_t mt = (cnt + vg::kGemmBM - 1) / vg::kGemmBM;
+            const unsigned ucnt = static_cast<unsigned>(cnt);
+            if (fused) {
+                // (a) threshold per query from a row sample
+                if (use_sample) {
+                    if (dot)
+                        VG_LAUNCH((vg::flat_gemm_kernel<true, 1>), dim3(static_cast<unsigned>(mt * nst)),
+                                  dim3(vg::kGemmThreads), 0, st, qp, cnt, idx->d_vectors, n, dim, idx->d_norms, sc,
+                                  sample_stride, ns, nullptr, 0, 0, nullptr, nullptr, 0);
+                    else
+                        VG_LAUNCH((vg::flat_gemm_kernel<false, 1>), dim3(static_cast<unsigned>(mt * nst)),
+                                  dim3(vg::kGemmThreads), 0, st, qp, cnt, idx->d_vectors, n, dim, idx->d_norms, sc,
+                                  sample_stride, ns, nullptr, 0, 0, nullptr, nullptr, 0);
+                    VG_LAUNCH(vg::flat_select_kernel, dim3(sel_slices, ucnt), dim3(vg::kSelThreads), 0, st, sc, ns,
+                              sel_slices, sel_k, partial);
+                    VG_TRY(vg::launch_topk_merge(partial, cnt, sel_slices, sel_k, false, sid, thr, st));
+                } else {
+                    VG_LAUNCH(vg::fill_f32_kernel, dim3(static_cast<unsigned>((cnt * sel_k + 255) / 256)), dim3(256),
+                              0, st, thr, cnt * sel_k, INFINITY);
+                }
+                // (b) the GEMM, appending every element below its query's threshold
+                VG_HIP(hipMemsetAsync(counts, 0, sizeof(int) * static_cast<size_t>(cnt), st));
+                {
+                    vg::ProfScope prof(idx->ctx, "flat_gemm", st);
+                    if (dot)
+                        VG_LAUNCH((vg::flat_gemm_kernel<true, 2>), dim3(static_cast<unsigned>(mt * nt)),
+                                  dim3(vg::kGemmThreads), 0, st, qp, cnt, idx->d_vectors, n, dim, idx->d_norms,
+                                  nullptr, 1, 0, thr, sel_k, sel_k - 1, counts, cand, cap);
+                    else
+                        VG_LAUNCH((vg::flat_gemm_kernel<false, 2>), dim3(static_cast<unsigned>(mt * nt)),
+                                  dim3(vg::kGemmThreads), 0, st, qp, cnt, idx->d_vectors, n, dim, idx->d_norms,
+                                  nullptr, 1, 0, thr, sel_k, sel_k - 1, counts, cand, cap);
+                }
+                // (c) the kc best appended keys
+                VG_LAUNCH(vg::flat_pick_kernel, dim3(ucnt), dim3(256), 0, st, cand, counts, cap, kc, cand_id, cand_sc);
+            } else {
+                {
+                    vg::ProfScope prof(idx->ctx, "flat_gemm", st);
+                    if (dot)
+                        VG_LAUNCH((vg::flat_gemm_kernel<true, 0>), dim3(static_cast<unsigned>(mt * nt)),
+                                  dim3(vg::kGemmThreads), 0, st, qp, cnt, idx->d_vectors, n, dim, idx->d_norms, sc, 1,
+                                  n, nullptr, 0, 0, nullptr, nullptr, 0);
+                    else
+                        VG_LAUNCH((vg::flat_gemm_kernel<false, 0>), dim3(static_cast<unsigned>(mt * nt)),
+                                  dim3(vg::kGemmThreads), 0, st, qp, cnt, idx->d_vectors, n, dim, idx->d_norms, sc, 1,
+                                  n, nullptr, 0, 0, nullptr, nullptr, 0);
+                }
+                {
+                    vg::ProfScope prof(idx->ctx, "flat_select", st);
+                    VG_LAUNCH(vg::flat_select_kernel, dim3(sel_slices, ucnt), dim3(vg::kSelThreads), 0, st, sc, n,
+                              sel_slices, kc, partial);
+                }
+                VG_TRY(vg::launch_topk_merge(partial, cnt, sel_slices, kc, false, cand_id, cand_sc, st));
             }
-            {
-            vg::ProfScope prof(idx->ctx, "flat_select", st);
-            VG_LAUNCH(vg::flat_select_kernel, dim3(sel_slices, static_cast<unsigned>(cnt)),
-                               dim3(vg::kSelThreads), 0, st, sc.ptr, n, sel_slices, kc, partial.ptr);
-            }
-            VG_TRY(vg::launch_topk_merge(partial.ptr, cnt, sel_slices, kc, false, cand_id.ptr, cand_sc.ptr, st));
+            const float *vthr = fused ? thr : nullptr;
             if (dot)
-                VG_LAUNCH(vg::flat_verify_kernel<true>, dim3(static_cast<unsigned>(cnt)), dim3(256), 0,
-                                   st, idx->d_vectors, n, dim, qp, idx->d_norm_max, cand_id.ptr, cand_sc.ptr, kc, k,
-                                   oid.ptr + q0 * k, osc.ptr + q0 * k, flags.ptr);
+                VG_LAUNCH(vg::flat_verify_kernel<true>, dim3(ucnt), dim3(256), 0, st, idx->d_vectors, n, dim, qp,
+                          idx->d_norm_max, cand_id, cand_sc, kc, k, oid.ptr + q0 * k, osc.ptr + q0 * k, flags, vthr,
+                          sel_k, sel_k - 1, counts, cap);
             else
-                VG_LAUNCH(vg::flat_verify_kernel<false>, dim3(static_cast<unsigned>(cnt)), dim3(256), 0,
-                                   st, idx->d_vectors, n, dim, qp, idx->d_norm_max, cand_id.ptr, cand_sc.ptr, kc, k,
-                                   oid.ptr + q0 * k, osc.ptr + q0 * k, flags.ptr);
+                VG_LAUNCH(vg::flat_verify_kernel<false>, dim3(ucnt), dim3(256), 0, st, idx->d_vectors, n, dim, qp,
+                          idx->d_norm_max, cand_id, cand_sc, kc, k, oid.ptr + q0 * k, osc.ptr + q0 * k, flags, vthr,
+                          sel_k, sel_k - 1, counts, cap);
             // step 4 always launches; its workgroups exit at once unless the query is flagged
             if (dot)
-                VG_LAUNCH(vg::flat_exact_kernel<true>, dim3(ex_slices, static_cast<unsigned>(cnt)),
-                                   dim3(256), 0, st, idx->d_vectors, n, dim, qp, flags.ptr, always, ex_slices, k,
-                                   fpartial.ptr);
+                VG_LAUNCH(vg::flat_exact_kernel<true>, dim3(ex_slices, ucnt), dim3(256), 0, st, idx->d_vectors, n, dim,
+                          qp, flags, always, ex_slices, k, fpartial);
             else
-                VG_LAUNCH(vg::flat_exact_kernel<false>, dim3(ex_slices, static_cast<unsigned>(cnt)),
-                                   dim3(256), 0, st, idx->d_vectors, n, dim, qp, flags.ptr, always, ex_slices, k,
-                                   fpartial.ptr);
+                VG_LAUNCH(vg::flat_exact_kernel<false>, dim3(ex_slices, ucnt), dim3(256), 0, st, idx->d_vectors, n, dim,
+                          qp, flags, always, ex_slices, k, fpartial);
             if (getenv("VG_FLAT_DEBUG")) {
-                std::vector<int> hf(cnt);
-                (void)hipMemcpyAsync(hf.data(), flags.ptr, sizeof(int) * cnt, hipMemcpyDeviceToHost, st);
+                std::vector<int> hf(cnt), hc(cnt);
+                (void)hipMemcpyAsync(hf.data(), flags, sizeof(int) * cnt, hipMemcpyDeviceToHost, st);
+                (void)hipMemcpyAsync(hc.data(), counts, sizeof(int) * cnt, hipMemcpyDeviceToHost, st);
                 (void)hipStreamSynchronize(st);
-                int64_t nf = 0;
+                int64_t nf = 0, csum = 0, cmax = 0;
                 for (int f : hf) nf += f != 0;
-                fprintf(stderr, "[vg_search_flat] chunk q0=%lld cnt=%lld: %lld queries failed the proof\n",
-                        (long long)q0, (long long)cnt, (long long)nf);
+                for (int c : hc) { csum += c; cmax = std::max<int64_t>(cmax, c); }
+                fprintf(stderr, "[vg_search_flat] chunk q0=%lld cnt=%lld: %lld queries failed the proof; "
+                        "appended candidates avg %.1f max %lld\n", (long long)q0, (long long)cnt, (long long)nf,
+                        fused ? double(csum) / cnt : 0.0, (long long)(fused ? cmax : 0));
             }
-            VG_TRY(vg::launch_topk_merge(fpartial.ptr, cnt, ex_slices, k, dot, fid.ptr, fsc.ptr, st, flags.ptr, always));
-            VG_LAUNCH(vg::flat_patch_kernel, dim3(static_cast<unsigned>(cnt)), dim3(64), 0, st,
-                               flags.ptr, always, k, fid.ptr, fsc.ptr, oid.ptr + q0 * k, osc.ptr + q0 * k);
+            VG_TRY(vg::launch_topk_merge(fpartial, cnt, ex_slices, k, dot, fid, fsc, st, flags, always));
+            VG_LAUNCH(vg::flat_patch_kernel, dim3(ucnt), dim3(64), 0, st, flags, always, k, fid, fsc,
+                      oid.ptr + q0 * k, osc.ptr + q0 * k);
         }
     }
     VG_TRY(oid.finish());
