@@ -9,8 +9,9 @@ namespace vg {
 //   v = float32(code)*scale + offset ; d = q - v ; sum += d*d   — five separately
 // rounded fp32 ops per term, sequential over the sub-dimension (Go on amd64 does not
 // fuse; this TU is built with -ffp-contract=off).
-// SCAN_LAYOUT: write the image the ADC scan keeps in LDS (k_adc.hip): sub-quantizers of the
-// full 16-wide groups as [g][c][l], the m%16 tail rows after them as [j][c].  Same values.
+// SCAN_LAYOUT: write the image the ADC scan keeps in LDS (k_adc.hip): the full 16-wide groups
+// in pairs, word = ((g>>1)*256 + c)*32 + (g&1)*16 + l (an odd last group leaves half a block
+// unused), then the m%16 tail rows as [j][c].  Same values.
 template <bool SCAN_LAYOUT>
 __global__ void pq_build_table_kernel(const float *__restrict__ queries,
                                       const int8_t *__restrict__ codebooks,
@@ -33,9 +34,18 @@ __global__ void pq_build_table_kernel(const float *__restrict__ queries,
             float dd = d * d;
             sum = sum + dd;
         }
-        int64_t at = static_cast<int64_t>(j) * k + c;
-        if (SCAN_LAYOUT && j < (m & ~15)) at = (static_cast<int64_t>(j >> 4) * 256 + c) * 16 + (j & 15);
-        tables[static_cast<int64_t>(q) * m * k + at] = sum;
+        if (SCAN_LAYOUT) {
+            const int gfull = m >> 4;
+            const int64_t words = static_cast<int64_t>((gfull + 1) >> 1) * 8192 + static_cast<int64_t>(m & 15) * 256;
+            int64_t at;
+            if (j < gfull * 16)
+                at = (static_cast<int64_t>(j >> 5) * 256 + c) * 32 + ((j >> 4) & 1) * 16 + (j & 15);
+            else
+                at = static_cast<int64_t>((gfull + 1) >> 1) * 8192 + static_cast<int64_t>(j - gfull * 16) * 256 + c;
+            tables[static_cast<int64_t>(q) * words + at] = sum;
+        } else {
+            tables[static_cast<int64_t>(q) * m * k + static_cast<int64_t>(j) * k + c] = sum;
+        }
     }
 }
 
@@ -50,7 +60,10 @@ int32_t launch_pq_build_table(const vg_pq *pq, const float *d_queries, int64_t n
         auto kern = scan_layout ? pq_build_table_kernel<true> : pq_build_table_kernel<false>;
         VG_LAUNCH(kern, grid, dim3(256), 0, st, d_queries + q0 * pq->dim,
                            pq->d_codebooks, pq->d_scales, pq->d_offsets, pq->dim, pq->m, pq->k,
-                           pq->subdim, d_tables + q0 * pq->m * pq->k);
+                           pq->subdim,
+                           d_tables + q0 * (scan_layout ? (static_cast<int64_t>(((pq->m >> 4) + 1) >> 1) * 8192 +
+                                                           static_cast<int64_t>(pq->m & 15) * 256)
+                                                        : static_cast<int64_t>(pq->m) * pq->k));
     }
     return VG_OK;
 }
