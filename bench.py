@@ -139,13 +139,24 @@ def adc_scan_roofline(vg, ctx, stream, device):
     kern_ms = ms / max(launches, 1)
     achieved = n * m / (kern_ms * 1e-3) / 1e9
     res = {"workload": "pq_adc_scan_10Mx768_m96_K256_k10_nq1", "bound": "hbm", "achieved": achieved,
-           "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": achieved / PEAK_HBM_GBS, "traffic": None,
+           "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": achieved / PEAK_HBM_GBS, "traffic": measured_traffic("pq_adc_scan"),
            "kernel": "pq_adc_scan_kernel<6,true>", "kernel_ms": kern_ms,
            "bytes_per_launch": n * m, "search_call_ms": e0.elapsed_time(e1) / reps,
            "qps_single_query_passes": 1e3 / (e0.elapsed_time(e1) / reps)}
     idx.close()
     pq.close()
     return res
+
+
+def measured_traffic(key: str):
+    """HBM bytes per launch from the committed PMC passes (profiles/r01_traffic.json: rocprofv3
+    --pmc FETCH_SIZE / WRITE_SIZE, gfx950 correction applied).  PMC counters cannot be read from
+    inside this process; the file names the exact commands."""
+    try:
+        t = json.loads((ROOT / "profiles" / "r01_traffic.json").read_text())[key]
+        return float(t["traffic_bytes"])
+    except Exception:
+        return None
 
 
 def main():
@@ -246,7 +257,8 @@ def main():
                    "parallelism": f"row-shard x{world}, all-gather of per-shard top-k" if world > 1 else "1 GPU"},
         "recall_at_10": recall,
         "roofline": {"bound": "mfma", "achieved": achieved_tf, "peak": PEAK_MFMA_F32_TFLOPS,
-                     "unit": "TFLOP/s", "frac": achieved_tf / PEAK_MFMA_F32_TFLOPS, "traffic": None,
+                     "unit": "TFLOP/s", "frac": achieved_tf / PEAK_MFMA_F32_TFLOPS,
+                     "traffic": measured_traffic("flat_gemm") if world == 1 else None,
                      "kernel": "flat_gemm_kernel<false>", "kernel_ms": gemm_avg_ms,
                      "launches": launches, "flops_per_launch": flops_per_launch},
     }

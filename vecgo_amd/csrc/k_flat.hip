@@ -41,11 +41,17 @@ __global__ __launch_bounds__(kGemmThreads) void flat_gemm_kernel(
 {
     __shared__ float As[kGemmBM * kGemmLd];
     __shared__ float Bs[kGemmBN * kGemmLd];
-    // block order: the query tiles of one row tile are adjacent so they share the row tile in L2
+    // XCD-aware block order: blocks b, b+8, ... share an XCD (and its L2).  All query tiles of
+    // one row tile go to the same XCD, back to back, so the row tile crosses the fabric once
+    // instead of once per query tile (measured: FETCH_SIZE 12.4 GB -> see DESIGN.md §4).
     const int mtiles = static_cast<int>((nq + kGemmBM - 1) / kGemmBM);
+    const int64_t ntiles = MODE == 1 ? (((n + kGemmBN - 1) / kGemmBN) + tile_stride - 1) / tile_stride
+                                     : (n + kGemmBN - 1) / kGemmBN;
     const int64_t bt = blockIdx.x;
-    const int64_t tn = bt / mtiles;
-    const int tm = static_cast<int>(bt % mtiles);
+    const int64_t xcd = bt & 7, jx = bt >> 3;
+    const int64_t tn = (jx / mtiles) * 8 + xcd;
+    const int tm = static_cast<int>(jx % mtiles);
+    if (tn >= ntiles) return;
     const int64_t q0 = static_cast<int64_t>(tm) * kGemmBM;
     const int64_t n0 = (MODE == 1 ? tn * tile_stride : tn) * kGemmBN;
 
@@ -456,11 +462,11 @@ VG_API int32_t vg_search_flat(vg_index *idx, const float *queries, int64_t nq, i
                 // (a) threshold per query from a row sample
                 if (use_sample) {
                     if (dot)
-                        VG_LAUNCH((vg::flat_gemm_kernel<true, 1>), dim3(static_cast<unsigned>(mt * nst)),
+                        VG_LAUNCH((vg::flat_gemm_kernel<true, 1>), dim3(static_cast<unsigned>(mt * ((nst + 7) / 8) * 8)),
                                   dim3(vg::kGemmThreads), 0, st, qp, cnt, idx->d_vectors, n, dim, idx->d_norms, sc,
                                   sample_stride, ns, nullptr, 0, 0, nullptr, nullptr, 0);
                     else
-                        VG_LAUNCH((vg::flat_gemm_kernel<false, 1>), dim3(static_cast<unsigned>(mt * nst)),
+                        VG_LAUNCH((vg::flat_gemm_kernel<false, 1>), dim3(static_cast<unsigned>(mt * ((nst + 7) / 8) * 8)),
                                   dim3(vg::kGemmThreads), 0, st, qp, cnt, idx->d_vectors, n, dim, idx->d_norms, sc,
                                   sample_stride, ns, nullptr, 0, 0, nullptr, nullptr, 0);
                     VG_LAUNCH(vg::flat_select_kernel, dim3(sel_slices, ucnt), dim3(vg::kSelThreads), 0, st, sc, ns,
@@ -475,11 +481,11 @@ VG_API int32_t vg_search_flat(vg_index *idx, const float *queries, int64_t nq, i
                 {
                     vg::ProfScope prof(idx->ctx, "flat_gemm", st);
                     if (dot)
-                        VG_LAUNCH((vg::flat_gemm_kernel<true, 2>), dim3(static_cast<unsigned>(mt * nt)),
+                        VG_LAUNCH((vg::flat_gemm_kernel<true, 2>), dim3(static_cast<unsigned>(mt * ((nt + 7) / 8) * 8)),
                                   dim3(vg::kGemmThreads), 0, st, qp, cnt, idx->d_vectors, n, dim, idx->d_norms,
                                   nullptr, 1, 0, thr, sel_k, sel_k - 1, counts, cand, cap);
                     else
-                        VG_LAUNCH((vg::flat_gemm_kernel<false, 2>), dim3(static_cast<unsigned>(mt * nt)),
+                        VG_LAUNCH((vg::flat_gemm_kernel<false, 2>), dim3(static_cast<unsigned>(mt * ((nt + 7) / 8) * 8)),
                                   dim3(vg::kGemmThreads), 0, st, qp, cnt, idx->d_vectors, n, dim, idx->d_norms,
                                   nullptr, 1, 0, thr, sel_k, sel_k - 1, counts, cand, cap);
                 }
@@ -489,11 +495,11 @@ VG_API int32_t vg_search_flat(vg_index *idx, const float *queries, int64_t nq, i
                 {
                     vg::ProfScope prof(idx->ctx, "flat_gemm", st);
                     if (dot)
-                        VG_LAUNCH((vg::flat_gemm_kernel<true, 0>), dim3(static_cast<unsigned>(mt * nt)),
+                        VG_LAUNCH((vg::flat_gemm_kernel<true, 0>), dim3(static_cast<unsigned>(mt * ((nt + 7) / 8) * 8)),
                                   dim3(vg::kGemmThreads), 0, st, qp, cnt, idx->d_vectors, n, dim, idx->d_norms, sc, 1,
                                   n, nullptr, 0, 0, nullptr, nullptr, 0);
                     else
-                        VG_LAUNCH((vg::flat_gemm_kernel<false, 0>), dim3(static_cast<unsigned>(mt * nt)),
+                        VG_LAUNCH((vg::flat_gemm_kernel<false, 0>), dim3(static_cast<unsigned>(mt * ((nt + 7) / 8) * 8)),
                                   dim3(vg::kGemmThreads), 0, st, qp, cnt, idx->d_vectors, n, dim, idx->d_norms, sc, 1,
                                   n, nullptr, 0, 0, nullptr, nullptr, 0);
                 }
