@@ -136,6 +136,33 @@ def test_adc_device_buffers(vg, ctx):
         assert np.array_equal(bits(scores[qi]), bits(esc))
 
 
+def test_adc_big_k_proof_and_fallback(vg, ctx):
+    """k > 64: per-wave 64-lists + proof.  Rows sorted by score put all the best rows into a few
+    waves (their lists overflow), so the proof must fail and the exhaustive scan take over."""
+    import os
+    rng = np.random.default_rng(31)
+    dim, m, n, k = 128, 16, 60000, 500
+    opq = _random_pq(rng, dim, m)
+    codes = rng.integers(0, 256, (n, m)).astype(np.uint8)
+    q = rng.standard_normal((2, dim)).astype(np.float32)
+    # sort rows by ADC distance to query 0: its top-500 are rows 0..499, i.e. ~8 tiles
+    t = opq.build_table(q[0])
+    d = np.array([o.adc(t, codes[i], m) for i in range(n)])
+    codes = np.ascontiguousarray(codes[np.argsort(d, kind="stable")])
+    pq, idx = _mk(vg, ctx, opq, codes, n)
+    for env in (None, "1"):
+        if env:
+            os.environ["VG_ADC_BIGK_EXHAUSTIVE"] = env
+        try:
+            ids, scores = idx.search_pq_adc(q, k)
+        finally:
+            os.environ.pop("VG_ADC_BIGK_EXHAUSTIVE", None)
+        for qi in range(2):
+            eid, esc = o.flat_search_pq(opq, codes, q[qi], k)
+            assert np.array_equal(ids[qi], eid)
+            assert np.array_equal(bits(scores[qi]), bits(esc))
+
+
 def test_adc_skewed_kernel_is_bit_exact_too(vg, ctx):
     """The opt-in conflict-free (A/B-skewed) m=96 scan must give the same ids and scores."""
     import os

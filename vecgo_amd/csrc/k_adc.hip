@@ -25,6 +25,8 @@
 // Per-row arithmetic = pqAdcLookupAvx512 (internal/simd/src/floats_avx512.c:135-167):
 // 16 lane accumulators acc[l] += table[(16g+l)*256 + code[16g+l]] for g ascending, the
 // _mm512_reduce_add_ps tree, then the m%16 tail added sequentially.  fp32 adds only.
+#include <algorithm>
+
 #include "vg_device.hpp"
 #include "vg_internal.hpp"
 
@@ -142,7 +144,8 @@ struct AdcShared {
 template <int GF, bool SMALLK>
 __global__ __launch_bounds__(kAdcThreads) void pq_adc_scan_kernel(
     const uint4 *__restrict__ tiles, int64_t n_rows, int64_t n_tiles, int m, int groups,
-    const float *__restrict__ tables, int slices, int nq, int k, uint64_t *__restrict__ partial)
+    const float *__restrict__ tables, int slices, int nq, int k, uint64_t *__restrict__ partial,
+    int raw_lists, const int *__restrict__ only_if)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float *lut = reinterpret_cast<float *>(smem);
@@ -159,6 +162,7 @@ __global__ __launch_bounds__(kAdcThreads) void pq_adc_scan_kernel(
     const int o = b >> 3;
     const int q = o % nq;
     const int s = (o / nq) * 8 + xcd;
+    if (only_if && !only_if[q]) return;  // fallback launch: only the flagged queries run
     const int64_t t0 = n_tiles * s / slices;
     const int64_t t1 = n_tiles * (s + 1) / slices;
 
@@ -192,7 +196,7 @@ __global__ __launch_bounds__(kAdcThreads) void pq_adc_scan_kernel(
     __syncthreads();
     uint64_t tau = kKeyMax;
     WaveTopK wtk;
-    wtk.init(k);
+    wtk.init(raw_lists ? 64 : k);  // raw mode: every wave keeps its 64 best whatever k is
 
     const int gfull = (GF >= 0) ? GF : (m >> 4);
     const int tail = (GF >= 0) ? 0 : (m & 15);
@@ -313,6 +317,10 @@ __global__ __launch_bounds__(kAdcThreads) void pq_adc_scan_kernel(
             }
             tau = sh->tau;
         }
+    }
+    if (SMALLK && raw_lists) {
+        partial[((static_cast<int64_t>(q) * slices + s) * kAdcWaves + wave) * 64 + lane] = wtk.list;
+        return;
     }
     uint64_t *out = partial + (static_cast<int64_t>(q) * slices + s) * k;
     if (SMALLK) {
@@ -593,6 +601,113 @@ __global__ __launch_bounds__(kMergeThreads) void topk_merge_kernel(
     }
 }
 
+// k > 64: per query, the k best keys of the union of `lists` per-wave lists (64 keys each,
+// ascending, kKeyMax padded) and a proof that nothing better was dropped: a wave only ever
+// discards keys above its own 64th key, so the result is exact iff the k-th selected key is not
+// above T = min over FULL lists of their 64th key.  flag[q] = 1 asks for the exhaustive path.
+__global__ __launch_bounds__(kMergeThreads) void topk_select_verify_kernel(
+    const uint64_t *__restrict__ raw, int lists, int k, bool descending, uint32_t *__restrict__ ids,
+    float *__restrict__ scores, int *__restrict__ flags)
+{
+    __shared__ uint64_t buf[kMergeBuf];
+    __shared__ unsigned long long tsafe;
+    const int64_t q = blockIdx.x;
+    const int tid = threadIdx.x;
+    const uint64_t *src = raw + q * lists * 64;
+    const int64_t total = static_cast<int64_t>(lists) * 64;
+    if (tid == 0) tsafe = kKeyMax;
+    __syncthreads();
+    uint64_t t = kKeyMax;
+    for (int l = tid; l < lists; l += kMergeThreads) {
+        const uint64_t v = src[static_cast<int64_t>(l) * 64 + 63];
+        t = v < t ? v : t;
+    }
+    if (t != kKeyMax) atomicMin(&tsafe, static_cast<unsigned long long>(t));
+    __shared__ int cnt;
+    __shared__ unsigned long long tcut_s;
+    bool done = false;
+    if (total > kMergeBuf && lists <= kMergeBuf) {
+        // Prune before sorting.  An upper bound on the k-th smallest key of the union:
+        //   lists >= k : the k-th smallest list HEAD (k distinct keys are <= it)
+        //   otherwise  : max_l list_l[j-1], j = ceil(k / lists) (the first j of every list are k keys)
+        uint64_t tcut;
+        if (lists >= k) {
+            for (int i = tid; i < kMergeBuf; i += kMergeThreads)
+                buf[i] = i < lists ? src[static_cast<int64_t>(i) * 64] : kKeyMax;
+            __syncthreads();
+            bitonic_sort_lds(buf, kMergeBuf, tid, kMergeThreads);
+            tcut = buf[k - 1];
+            __syncthreads();
+        } else {
+            const int j = (k + lists - 1) / lists;  // <= 64 because k <= lists * 64 is checked by the host
+            if (tid == 0) tcut_s = 0;
+            __syncthreads();
+            uint64_t mx = 0;
+            for (int l = tid; l < lists; l += kMergeThreads) {
+                const uint64_t v = src[static_cast<int64_t>(l) * 64 + (j - 1)];
+                mx = v > mx ? v : mx;
+            }
+            atomicMax(&tcut_s, static_cast<unsigned long long>(mx));
+            __syncthreads();
+            tcut = tcut_s;
+        }
+        if (tid == 0) cnt = 0;
+        __syncthreads();
+        for (int l = tid; l < lists; l += kMergeThreads) {  // lists are ascending: stop at the cut
+            const uint64_t *lp = src + static_cast<int64_t>(l) * 64;
+            for (int i = 0; i < 64; i++) {
+                const uint64_t key = lp[i];
+                if (key == kKeyMax || key > tcut) break;
+                const int p = atomicAdd(&cnt, 1);
+                if (p < kMergeBuf) buf[p] = key;
+            }
+        }
+        __syncthreads();
+        const int c = cnt;
+        if (c <= kMergeBuf) {
+            for (int i = c + tid; i < kMergeBuf; i += kMergeThreads) buf[i] = kKeyMax;
+            __syncthreads();
+            bitonic_sort_lds(buf, kMergeBuf, tid, kMergeThreads);
+            done = true;
+        }
+        __syncthreads();
+    }
+    if (!done) {
+        int kept = 0;
+        int64_t pos = 0;
+        do {
+            const int room = kMergeBuf - kept;
+            const int take = static_cast<int>((total - pos) < room ? (total - pos) : room);
+            for (int i = tid; i < take; i += kMergeThreads) buf[kept + i] = src[pos + i];
+            for (int i = kept + take + tid; i < kMergeBuf; i += kMergeThreads) buf[i] = kKeyMax;
+            __syncthreads();
+            bitonic_sort_lds(buf, kMergeBuf, tid, kMergeThreads);
+            pos += take;
+            kept = k;
+        } while (pos < total);
+    }
+    const uint64_t T = tsafe;
+    const uint64_t kth = buf[k - 1];
+    if (tid == 0) flags[q] = (T == kKeyMax || (kth != kKeyMax && kth <= T)) ? 0 : 1;
+    for (int i = tid; i < k; i += kMergeThreads) {
+        const uint64_t e = buf[i];
+        ids[q * k + i] = e == kKeyMax ? VG_INVALID_ID : key_row(e);
+        scores[q * k + i] = e == kKeyMax ? (descending ? -INFINITY : INFINITY) : key_score(e, descending);
+    }
+}
+
+__global__ void patch_results_kernel(const int *__restrict__ flags, int k, const uint32_t *__restrict__ fids,
+                                     const float *__restrict__ fscores, uint32_t *__restrict__ ids,
+                                     float *__restrict__ scores)
+{
+    const int64_t q = blockIdx.x;
+    if (!flags[q]) return;
+    for (int i = threadIdx.x; i < k; i += blockDim.x) {
+        ids[q * k + i] = fids[q * k + i];
+        scores[q * k + i] = fscores[q * k + i];
+    }
+}
+
 int32_t launch_topk_merge(const uint64_t *partial, int64_t nq, int lists, int k, bool descending,
                           uint32_t *ids, float *scores, hipStream_t st, const int *only_if = nullptr,
                           const int *always = nullptr)
@@ -622,7 +737,8 @@ static int adc_slices(int64_t nq, int64_t n_tiles, int cus)
 
 template <int GF, bool SMALLK>
 static int32_t launch_scan(const vg_index *idx, const float *tables, int64_t nq, int k,
-                           int slices, uint64_t *partial, hipStream_t st)
+                           int slices, uint64_t *partial, hipStream_t st, int raw_lists = 0,
+                           const int *only_if = nullptr)
 {
     const vg_pq *pq = idx->pq;
     size_t lds = static_cast<size_t>(lut_image_words(pq->m)) * sizeof(float) + kAdcBuf * sizeof(uint64_t) +
@@ -639,7 +755,8 @@ static int32_t launch_scan(const vg_index *idx, const float *tables, int64_t nq,
                            st, reinterpret_cast<const uint4 *>(idx->d_pq_tiles), idx->n,
                            idx->n_tiles, pq->m, idx->pq_groups,
                            tables + q0 * lut_image_words(pq->m), slices, static_cast<int>(cnt), k,
-                           partial + q0 * slices * k);
+                           partial + q0 * slices * (raw_lists ? kAdcWaves * 64 : k), raw_lists,
+                           only_if ? only_if + q0 : nullptr);
     }
     return VG_OK;
 }
@@ -796,14 +913,53 @@ VG_API int32_t vg_search_pq_adc(vg_index *idx, const float *queries, int64_t nq,
         VG_HIP(hipMemsetAsync(none.ptr, 0xFF, static_cast<size_t>(nq) * k * 8, st));
         VG_TRY(vg::launch_topk_merge(none.ptr, nq, 1, k, false, oid.ptr, osc.ptr, st));
     } else {
-        const int slices = vg::adc_slices(nq, idx->n_tiles, idx->ctx->compute_units);
+        int slices = vg::adc_slices(nq, idx->n_tiles, idx->ctx->compute_units);
+        const bool bigk = k > 64;
+        const char *slow_env = getenv("VG_ADC_BIGK_EXHAUSTIVE");  // test hook: LDS-buffer path only
+        const bool bigk_fast = bigk && !(slow_env && slow_env[0] == '1');
+        if (bigk_fast) {
+            // enough waves that a wave expects <= ~8 of the k best rows (capacity 64 each)
+            int64_t want = ((static_cast<int64_t>(k) / 64 + 7) / 8) * 8;
+            int64_t max_s = (((idx->n_tiles + vg::kAdcWaves - 1) / vg::kAdcWaves) / 8) * 8;
+            if (max_s < 8) max_s = 8;
+            if (want > max_s) want = max_s;
+            if (want > slices) slices = static_cast<int>(want);
+        }
         vg::ArenaCall ar(idx->ctx, st);
         const int i_tables = ar.add(sizeof(float) * static_cast<size_t>(nq) * vg::lut_image_words(pq->m));
-        const int i_partial = ar.add(sizeof(uint64_t) * static_cast<size_t>(nq) * slices * k);
+        const int i_partial = ar.add(sizeof(uint64_t) * static_cast<size_t>(nq) * slices *
+                                     (bigk_fast ? std::max(k, vg::kAdcWaves * 64) : k));
+        const int i_flags = ar.add(bigk_fast ? sizeof(int) * static_cast<size_t>(nq) : 0);
+        const int i_fid = ar.add(bigk_fast ? sizeof(uint32_t) * static_cast<size_t>(nq) * k : 0);
+        const int i_fsc = ar.add(bigk_fast ? sizeof(float) * static_cast<size_t>(nq) * k : 0);
         VG_TRY(ar.commit());
         struct { float *ptr; } tables{ar.get<float>(i_tables)};
         struct { uint64_t *ptr; } partial{ar.get<uint64_t>(i_partial)};
         VG_TRY(vg::launch_pq_build_table(pq, q.ptr, nq, tables.ptr, true, st));
+        if (bigk_fast) {
+            int *flags = ar.get<int>(i_flags);
+            uint32_t *fid = ar.get<uint32_t>(i_fid);
+            float *fsc = ar.get<float>(i_fsc);
+            // (1) every wave keeps its 64 best; (2) select k of the union and prove it; (3) the
+            // exhaustive LDS-buffer scan re-runs only for queries whose proof failed
+            if (pq->m == 96)
+                VG_TRY((vg::launch_scan<6, true>(idx, tables.ptr, nq, k, slices, partial.ptr, st, 1)));
+            else
+                VG_TRY((vg::launch_scan<-1, true>(idx, tables.ptr, nq, k, slices, partial.ptr, st, 1)));
+            VG_LAUNCH(vg::topk_select_verify_kernel, dim3(static_cast<unsigned>(nq)), dim3(vg::kMergeThreads), 0, st,
+                      partial.ptr, slices * vg::kAdcWaves, k, false, oid.ptr, osc.ptr, flags);
+            if (pq->m == 96)
+                VG_TRY((vg::launch_scan<6, false>(idx, tables.ptr, nq, k, slices, partial.ptr, st, 0, flags)));
+            else
+                VG_TRY((vg::launch_scan<-1, false>(idx, tables.ptr, nq, k, slices, partial.ptr, st, 0, flags)));
+            VG_TRY(vg::launch_topk_merge(partial.ptr, nq, slices, k, false, fid, fsc, st, flags));
+            VG_LAUNCH(vg::patch_results_kernel, dim3(static_cast<unsigned>(nq)), dim3(64), 0, st, flags, k, fid, fsc,
+                      oid.ptr, osc.ptr);
+            VG_TRY(oid.finish());
+            VG_TRY(osc.finish());
+            if (oid.on_host() || osc.on_host()) VG_HIP(hipStreamSynchronize(st));
+            return VG_OK;
+        }
         // The A/B-skewed scan is conflict-free in LDS but, as compiled today, spends ~7 VALU ops per
         // lookup on lane-dependent address selects and is VALU-bound (70k vs 80k queries/s at
         // 1M x 96 B); it stays opt-in until its address arithmetic is cut down.
