@@ -148,6 +148,52 @@ def adc_scan_roofline(vg, ctx, stream, device):
     return res
 
 
+def hnsw_layer0(vg, ctx, rows, queries, gt_ids, stream):
+    """BASELINE configs[2]: HNSW ef=128 layer-0 search, 1M x 768 L2.  Graph CONSTRUCTION is out of
+    scope (and non-deterministic in the reference), so the graph is the exact 31-NN graph of the
+    corpus, built here with this library's own flat search (untimed).  On i.i.d. normal data in
+    768 dimensions such a graph is barely navigable: the recall printed next to the QPS is what
+    the reference's algorithm reaches on it, not a kernel property."""
+    n, deg, ef = rows.shape[0], 32, 128
+    idx = vg.Index(ctx, n, DIM)
+    idx.set_vectors(rows)
+    l0 = torch.empty((n, deg), dtype=torch.int32, device=rows.device)
+    sc = torch.empty((4096, deg), device=rows.device)
+    t0 = time.time()
+    for s in range(0, n, 4096):
+        e = min(n, s + 4096)
+        idx.search_flat(rows[s:e], deg, out=(l0[s:e], sc[:e - s]), stream=stream)
+    torch.cuda.synchronize()
+    build_s = time.time() - t0
+    l0 = l0.cpu().numpy().view(np.uint32)
+    l0 = np.where(l0 == np.arange(n, dtype=np.uint32)[:, None], np.uint32(0xFFFFFFFF), l0)
+    l0 = np.take_along_axis(l0, np.argsort(l0 == 0xFFFFFFFF, axis=1, kind="stable"), axis=1)
+    idx.set_hnsw_graph(l0, (), entry_point=0, m=16)
+    q = queries.reshape(-1, DIM)[:8192]
+    ids, _, st = idx.search_hnsw(q, K, ef, stats=True, stream=stream)
+    torch.cuda.synchronize()
+    ctx.profile_read("hnsw_search")
+    ctx.profile_enable(True)
+    reps = 5
+    for _ in range(reps):
+        idx.search_hnsw(q, K, ef, stream=stream)
+    torch.cuda.synchronize()
+    launches, ms = ctx.profile_read("hnsw_search")
+    ctx.profile_enable(False)
+    kern_ms = ms / max(launches, 1)
+    got = ids.cpu().numpy().view(np.uint32)[:gt_ids.shape[0]]
+    rec = float(np.mean([len(set(got[i]) & set(gt_ids[i])) / K for i in range(gt_ids.shape[0])]))
+    dc = float(st[:, 1].sum())
+    gathered = dc * DIM * 4 + float(st[:, 3].sum()) * deg * 4
+    idx.close()
+    return {"workload": "hnsw_layer0_1Mx768_ef128_k10 on the exact 31-NN graph, 8192 queries in flight",
+            "bound": "hbm", "achieved": gathered / (kern_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+            "frac": gathered / (kern_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, "traffic": None,
+            "kernel": "hnsw_search_kernel", "kernel_ms": kern_ms, "qps": q.shape[0] / (kern_ms * 1e-3),
+            "recall_at_10": rec, "distance_computations_per_query": dc / q.shape[0],
+            "bytes_per_launch": gathered, "graph_build_s": build_s}
+
+
 def measured_traffic(key: str):
     """HBM bytes per launch from the committed PMC passes (profiles/r01_traffic.json: rocprofv3
     --pmc FETCH_SIZE / WRITE_SIZE, gfx950 correction applied).  PMC counters cannot be read from
@@ -166,6 +212,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-adc", action="store_true")
+    ap.add_argument("--no-hnsw", action="store_true")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -262,6 +309,8 @@ def main():
                      "kernel": "flat_gemm_kernel<false>", "kernel_ms": gemm_avg_ms,
                      "launches": launches, "flops_per_launch": flops_per_launch},
     }
+    if world == 1 and not args.no_hnsw:
+        out["hnsw_layer0"] = hnsw_layer0(vg, ctx, rows, queries, gt[:nrec], stream)
     if world == 1 and not args.no_adc:
         del index
         out["adc_scan"] = adc_scan_roofline(vg, ctx, stream, device)
