@@ -1,0 +1,345 @@
+// vecgo_hip.hpp — C++ host-side mirror of the reference's Go interfaces over the C ABI.
+//
+// The reference is compiled Go; no Go toolchain exists in the build image, so the host side
+// above the C ABI is C++ (header-only, no dependency beyond vecgo_hip.h).  Names, argument
+// meaning and error behaviour follow the reference:
+//   vecgo::distance::Metric / Provider           distance/distance.go:66-116
+//   vecgo::quantization::Quantizer               internal/quantization/quantizer.go:12-24
+//   vecgo::quantization::ProductQuantizer        internal/quantization/pq.go:20-500
+//   vecgo::quantization::RaBitQuantizer          internal/quantization/rabitq.go:26-190
+//   vecgo::kmeans::TrainKMeans / AssignPartition internal/kmeans/kmeans.go:16-280
+//   vecgo::Segment                               flat.Segment.Search / Rerank, hnsw.KNNSearch,
+//                                                diskann searchInternal (one query batch per call)
+// Go's (value, error) becomes a thrown vecgo::Error carrying the Go error string.
+#pragma once
+
+#include <algorithm>
+#include <cstdint>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "vecgo_hip.h"
+
+namespace vecgo {
+
+class Error : public std::runtime_error {
+public:
+    Error(int32_t status, const std::string &msg) : std::runtime_error(msg), status_(status) {}
+    int32_t status() const { return status_; }
+
+private:
+    int32_t status_;
+};
+
+inline void check(int32_t status)
+{
+    if (status == VG_OK) return;
+    const char *m = vg_last_error();
+    throw Error(status, (m && *m) ? m : vg_status_string(status));
+}
+
+// One per (process, GPU).
+class Context {
+public:
+    explicit Context(int device = 0) { check(vg_ctx_create(device, &h_)); }
+    ~Context() { vg_ctx_destroy(h_); }
+    Context(const Context &) = delete;
+    Context &operator=(const Context &) = delete;
+    vg_ctx *handle() const { return h_; }
+
+private:
+    vg_ctx *h_ = nullptr;
+};
+
+namespace distance {
+
+// distance.Metric (distance/distance.go:66-73)
+enum class Metric : int32_t { L2 = VG_METRIC_L2, Cosine = VG_METRIC_COSINE, Dot = VG_METRIC_DOT, Hamming = VG_METRIC_HAMMING };
+
+inline const char *String(Metric m)
+{
+    switch (m) {
+    case Metric::L2: return "L2";
+    case Metric::Cosine: return "Cosine";
+    case Metric::Dot: return "Dot";
+    case Metric::Hamming: return "Hamming";
+    }
+    return "Unknown";
+}
+
+// distance.Func is a single-pair function in the reference; on the GPU the unit is one query
+// against n contiguous targets (simd.SquaredL2Batch / DotBatch, internal/simd/kernels.go:61-68).
+using BatchFunc = void (*)(const Context &, const float *query, const float *targets, int64_t dim, int64_t n, float *out);
+
+inline void SquaredL2Batch(const Context &c, const float *q, const float *t, int64_t dim, int64_t n, float *out)
+{
+    check(vg_squared_l2_batch(c.handle(), q, t, dim, n, out, nullptr));
+}
+inline void DotBatch(const Context &c, const float *q, const float *t, int64_t dim, int64_t n, float *out)
+{
+    check(vg_dot_batch(c.handle(), q, t, dim, n, out, nullptr));
+}
+
+// distance.Provider (distance/distance.go:91-106)
+inline BatchFunc Provider(Metric m)
+{
+    switch (m) {
+    case Metric::L2: return SquaredL2Batch;
+    case Metric::Cosine:
+    case Metric::Dot: return DotBatch;
+    default: throw Error(VG_ERR_UNSUPPORTED, std::string("unsupported metric for float32: ") + String(m));
+    }
+}
+
+}  // namespace distance
+
+namespace quantization {
+
+// quantization.Quantizer (internal/quantization/quantizer.go:12-24)
+class Quantizer {
+public:
+    virtual ~Quantizer() = default;
+    virtual std::vector<uint8_t> Encode(const std::vector<float> &v) = 0;
+    virtual std::vector<float> Decode(const std::vector<uint8_t> &b) = 0;
+    virtual void Train(const std::vector<std::vector<float>> &vectors) = 0;
+    virtual int BytesPerDimension() const = 0;
+};
+
+// quantization.ProductQuantizer (pq.go:20-29)
+class ProductQuantizer : public Quantizer {
+public:
+    // NewProductQuantizer (pq.go:36-64)
+    ProductQuantizer(std::shared_ptr<Context> ctx, int dimension, int numSubvectors, int numCentroids)
+        : ctx_(std::move(ctx)), dim_(dimension), m_(numSubvectors), k_(numCentroids)
+    {
+        check(vg_pq_create(ctx_->handle(), dimension, numSubvectors, numCentroids, &h_));
+    }
+    ~ProductQuantizer() override { vg_pq_destroy(h_); }
+    vg_pq *handle() const { return h_; }
+
+    // Train (pq.go:68-143); the reference runs 20 Lloyd iterations
+    void Train(const std::vector<std::vector<float>> &vectors) override
+    {
+        if (vectors.empty()) throw Error(VG_ERR_INVALID_ARG, "no vectors provided for training");
+        if (static_cast<int>(vectors[0].size()) != dim_) throw Error(VG_ERR_DIM_MISMATCH, "vector dimension mismatch");
+        std::vector<float> flat;
+        flat.reserve(vectors.size() * static_cast<size_t>(dim_));
+        for (const auto &v : vectors) flat.insert(flat.end(), v.begin(), v.end());
+        TrainFlat(flat.data(), static_cast<int64_t>(vectors.size()), 20, seed_);
+    }
+    void TrainFlat(const float *vectors, int64_t n, int iters, uint64_t seed)
+    {
+        check(vg_pq_train(h_, vectors, n, iters, seed, nullptr));
+    }
+    void SetSeed(uint64_t seed) { seed_ = seed; }
+
+    // Encode (pq.go:147-176)
+    std::vector<uint8_t> Encode(const std::vector<float> &vec) override
+    {
+        if (!IsTrained()) throw Error(VG_ERR_NOT_TRAINED, "ProductQuantizer not trained");
+        if (static_cast<int>(vec.size()) != dim_) throw Error(VG_ERR_DIM_MISMATCH, "vector dimension mismatch");
+        std::vector<uint8_t> codes(static_cast<size_t>(m_));
+        check(vg_pq_encode(h_, vec.data(), 1, codes.data(), nullptr));
+        return codes;
+    }
+    void EncodeBatch(const float *vectors, int64_t n, uint8_t *codes) { check(vg_pq_encode(h_, vectors, n, codes, nullptr)); }
+
+    // Decode (pq.go:185-229)
+    std::vector<float> Decode(const std::vector<uint8_t> &codes) override
+    {
+        if (!IsTrained()) throw Error(VG_ERR_NOT_TRAINED, "ProductQuantizer not trained");
+        if (static_cast<int>(codes.size()) != m_) throw Error(VG_ERR_CODE_LENGTH, "invalid code length");
+        std::vector<float> out(static_cast<size_t>(dim_));
+        check(vg_pq_decode(h_, codes.data(), 1, out.data(), nullptr));
+        return out;
+    }
+
+    // ComputeAsymmetricDistance (pq.go:234-260)
+    float ComputeAsymmetricDistance(const std::vector<float> &query, const std::vector<uint8_t> &codes)
+    {
+        if (!IsTrained()) throw Error(VG_ERR_NOT_TRAINED, "ProductQuantizer not trained");
+        float d = 0.0f;
+        check(vg_pq_asymmetric_distance_batch(h_, query.data(), codes.data(), 1, &d, nullptr));
+        return d;
+    }
+
+    // BuildDistanceTable (pq.go:468-491) / AdcDistance (pq.go:495-500)
+    std::vector<float> BuildDistanceTable(const std::vector<float> &query)
+    {
+        if (static_cast<int>(query.size()) != dim_)
+            throw Error(VG_ERR_DIM_MISMATCH, "query dimension mismatch: expected " + std::to_string(dim_) + ", got " +
+                                                 std::to_string(query.size()));
+        std::vector<float> table(static_cast<size_t>(m_) * k_);
+        check(vg_pq_build_distance_table(h_, query.data(), 1, table.data(), nullptr));
+        return table;
+    }
+    float AdcDistance(const std::vector<float> &table, const std::vector<uint8_t> &codes)
+    {
+        if (static_cast<int>(codes.size()) != m_) throw Error(VG_ERR_CODE_LENGTH, "codes length mismatch");
+        float d = 0.0f;
+        check(vg_pq_adc_lookup_batch(ctx_->handle(), table.data(), codes.data(), m_, 1, &d, nullptr));
+        return d;
+    }
+
+    // Codebooks / SetCodebooks (pq.go:452-464)
+    void SetCodebooks(const std::vector<int8_t> &codebooks, const std::vector<float> &scales, const std::vector<float> &offsets)
+    {
+        check(vg_pq_set_codebooks(h_, codebooks.data(), scales.data(), offsets.data()));
+    }
+    void Codebooks(std::vector<int8_t> &codebooks, std::vector<float> &scales, std::vector<float> &offsets)
+    {
+        codebooks.resize(static_cast<size_t>(m_) * k_ * (dim_ / m_));
+        scales.resize(static_cast<size_t>(m_));
+        offsets.resize(static_cast<size_t>(m_));
+        check(vg_pq_get_codebooks(h_, codebooks.data(), scales.data(), offsets.data()));
+    }
+
+    int BytesPerDimension() const override { return 0; }
+    int BytesPerVector() const { return m_; }                                         // pq.go:263-265
+    double CompressionRatio() const { return static_cast<double>(dim_) * 4.0 / m_; }  // pq.go:268-272
+    int NumSubvectors() const { return m_; }
+    int NumCentroids() const { return k_; }
+    bool IsTrained() const { return vg_pq_is_trained(h_) != 0; }
+
+private:
+    std::shared_ptr<Context> ctx_;
+    vg_pq *h_ = nullptr;
+    int dim_, m_, k_;
+    uint64_t seed_ = 1;
+};
+
+// quantization.RaBitQuantizer (rabitq.go:26-49)
+class RaBitQuantizer : public Quantizer {
+public:
+    RaBitQuantizer(std::shared_ptr<Context> ctx, int dimension) : ctx_(std::move(ctx)), dim_(dimension) {}
+    std::vector<uint8_t> Encode(const std::vector<float> &v) override
+    {
+        if (static_cast<int>(v.size()) != dim_) throw Error(VG_ERR_DIM_MISMATCH, "vector dimension mismatch");
+        std::vector<uint8_t> out(static_cast<size_t>(BytesTotal()));
+        check(vg_rabitq_encode(ctx_->handle(), dim_, v.data(), 1, out.data(), nullptr));
+        return out;
+    }
+    std::vector<float> Decode(const std::vector<uint8_t> &) override
+    {
+        throw Error(VG_ERR_UNSUPPORTED, "RaBitQuantizer.Decode is not on the hot path");
+    }
+    void Train(const std::vector<std::vector<float>> &) override {}  // rabitq.go:179-181: no-op
+    // Distance (rabitq.go:119-176)
+    float Distance(const std::vector<float> &query, const std::vector<uint8_t> &code)
+    {
+        if (static_cast<int64_t>(code.size()) < BytesTotal()) throw Error(VG_ERR_CODE_LENGTH, "invalid code length");
+        float d = 0.0f;
+        check(vg_rabitq_distance_batch(ctx_->handle(), dim_, query.data(), code.data(), 1, &d, nullptr));
+        return d;
+    }
+    int BytesPerDimension() const override { return 0; }                   // rabitq.go:183-185
+    int64_t BytesTotal() const { return vg_rabitq_code_bytes(dim_); }      // rabitq.go:187-190
+
+private:
+    std::shared_ptr<Context> ctx_;
+    int dim_;
+};
+
+}  // namespace quantization
+
+namespace kmeans {
+
+// TrainKMeans (kmeans.go:16-138): empty result when n < k (the reference returns (nil, nil))
+inline std::vector<float> TrainKMeans(const Context &c, const std::vector<float> &vectors, int dim, int k,
+                                      distance::Metric metric, int maxIter, uint64_t seed = 1)
+{
+    std::vector<float> cent(static_cast<size_t>(k) * dim);
+    int32_t produced = 0;
+    check(vg_kmeans_train(c.handle(), vectors.data(), static_cast<int64_t>(vectors.size() / dim), dim, k,
+                          static_cast<int32_t>(metric), maxIter, seed, cent.data(), &produced, nullptr));
+    if (!produced) cent.clear();
+    return cent;
+}
+
+// AssignPartition (kmeans.go:142-196)
+inline int AssignPartition(const Context &c, const std::vector<float> &vec, const std::vector<float> &centroids, int dim,
+                           distance::Metric metric)
+{
+    int32_t out = -1;
+    check(vg_kmeans_assign(c.handle(), vec.data(), 1, dim, centroids.data(), static_cast<int32_t>(centroids.size() / dim),
+                           static_cast<int32_t>(metric), &out, nullptr));
+    return out;
+}
+
+// FindClosestCentroids (kmeans.go:217-280)
+inline std::vector<int> FindClosestCentroids(const Context &c, const std::vector<float> &query,
+                                             const std::vector<float> &centroids, int dim, int n, distance::Metric metric)
+{
+    const int k = static_cast<int>(centroids.size() / dim);
+    std::vector<int32_t> out(static_cast<size_t>(std::max(1, std::min(n, k))));
+    int32_t cnt = 0;
+    check(vg_find_closest_centroids(c.handle(), query.data(), centroids.data(), dim, k, n, static_cast<int32_t>(metric),
+                                    out.data(), &cnt, nullptr));
+    return std::vector<int>(out.begin(), out.begin() + cnt);
+}
+
+}  // namespace kmeans
+
+struct Result {
+    std::vector<uint32_t> ids;   // [nq * k], best first, VG_INVALID_ID padded
+    std::vector<float> scores;   // [nq * k]
+};
+
+// One resident segment (flat / memtable-HNSW / DiskANN): the batch-level search entry points.
+class Segment {
+public:
+    Segment(std::shared_ptr<Context> ctx, int64_t rows, int dim, distance::Metric metric)
+        : ctx_(std::move(ctx)), n_(rows), dim_(dim)
+    {
+        check(vg_index_create(ctx_->handle(), rows, dim, static_cast<int32_t>(metric), &h_));
+    }
+    ~Segment() { vg_index_destroy(h_); }
+    Segment(const Segment &) = delete;
+    Segment &operator=(const Segment &) = delete;
+
+    void SetVectors(const float *base) { check(vg_index_set_vectors(h_, base, nullptr)); }
+    void SetPQCodes(std::shared_ptr<quantization::ProductQuantizer> pq, const uint8_t *codes)
+    {
+        pq_ = std::move(pq);
+        check(vg_index_set_pq_codes(h_, pq_->handle(), codes, nullptr));
+    }
+    void SetRaBitQCodes(const uint8_t *codes) { check(vg_index_set_rabitq_codes(h_, codes, nullptr)); }
+    void SetVamanaGraph(int r, const uint32_t *graph, uint32_t entry) { check(vg_index_set_vamana_graph(h_, r, graph, entry, nullptr)); }
+    void SetHNSWLayer0(int m0, const uint32_t *l0, uint32_t entry)
+    {
+        check(vg_index_set_hnsw_graph(h_, m0, l0, 0, m0 / 2 > 0 ? m0 / 2 : 1, nullptr, nullptr, nullptr, entry, nullptr));
+    }
+
+    // flat.Segment.Search fp32 branch (flat/segment.go:691-721)
+    Result SearchFlat(const float *queries, int64_t nq, int k) { return run(nq, k, [&](Result &r) { return vg_search_flat(h_, queries, nq, k, r.ids.data(), r.scores.data(), nullptr); }); }
+    // flat.Segment.Search PQ branch (flat/segment.go:476-483,678-689)
+    Result SearchPQ(const float *queries, int64_t nq, int k) { return run(nq, k, [&](Result &r) { return vg_search_pq_adc(h_, queries, nq, k, r.ids.data(), r.scores.data(), nullptr); }); }
+    Result SearchRaBitQ(const float *queries, int64_t nq, int k) { return run(nq, k, [&](Result &r) { return vg_search_rabitq(h_, queries, nq, k, r.ids.data(), r.scores.data(), nullptr); }); }
+    // hnsw.KNNSearch (hnsw.go:1650-1755)
+    Result SearchHNSW(const float *queries, int64_t nq, int k, int ef) { return run(nq, k, [&](Result &r) { return vg_search_hnsw(h_, queries, nq, k, ef, r.ids.data(), r.scores.data(), nullptr, nullptr); }); }
+    // diskann searchInternal (diskann/segment.go:503-706); kind 0 fp32, 1 PQ, 2 RaBitQ
+    Result SearchVamana(const float *queries, int64_t nq, int k, int kind) { return run(nq, k, [&](Result &r) { return vg_search_vamana(h_, queries, nq, k, kind, r.ids.data(), r.scores.data(), nullptr, nullptr); }); }
+    // Segment.Rerank (flat/segment.go:754-780) + top-k
+    Result Rerank(const float *queries, int64_t nq, const uint32_t *cand, int nc, int k) { return run(nq, k, [&](Result &r) { return vg_rerank(h_, queries, nq, cand, nc, k, r.ids.data(), r.scores.data(), nullptr); }); }
+
+private:
+    template <typename F>
+    Result run(int64_t nq, int k, F f)
+    {
+        Result r;
+        r.ids.resize(static_cast<size_t>(nq) * k);
+        r.scores.resize(static_cast<size_t>(nq) * k);
+        check(f(r));
+        return r;
+    }
+    std::shared_ptr<Context> ctx_;
+    std::shared_ptr<quantization::ProductQuantizer> pq_;
+    vg_index *h_ = nullptr;
+    int64_t n_;
+    int dim_;
+};
+
+}  // namespace vecgo

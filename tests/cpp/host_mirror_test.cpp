@@ -1,0 +1,199 @@
+// host_mirror_test.cpp — exercises include/vecgo_hip.hpp (the C++ mirror of the reference's Go
+// interfaces) the way the reference's own tests exercise the Go ones:
+//   internal/quantization/pq_test.go:10-140, rabitq_test.go:10-97, internal/kmeans/kmeans_test.go:12-93,
+//   distance/distance_test.go, internal/segment/flat/pq_test.go:17-93.
+// The flat search is checked bit-for-bit against the CPU oracle (test infrastructure).
+// Exit code 0 = all checks passed; 77 = no gfx950 device (the mirror refused to run: there is no
+// CPU fallback).
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <random>
+
+#include "vecgo_hip.hpp"
+#include "vg_oracle.h"
+
+using namespace vecgo;
+using quantization::ProductQuantizer;
+using quantization::RaBitQuantizer;
+
+static int g_fail = 0;
+#define EXPECT(cond)                                                         \
+    do {                                                                     \
+        if (!(cond)) {                                                       \
+            std::fprintf(stderr, "FAIL %s:%d: %s\n", __FILE__, __LINE__, #cond); \
+            g_fail++;                                                        \
+        }                                                                    \
+    } while (0)
+
+template <typename F>
+static int32_t status_of(F f)
+{
+    try {
+        f();
+    } catch (const Error &e) {
+        return e.status();
+    }
+    return VG_OK;
+}
+
+static std::vector<std::vector<float>> unit_vectors(std::mt19937 &rng, int n, int dim)
+{
+    std::normal_distribution<float> nd;
+    std::vector<std::vector<float>> out(n, std::vector<float>(dim));
+    for (auto &v : out) {
+        double s = 0;
+        for (auto &x : v) {
+            x = nd(rng);
+            s += double(x) * x;
+        }
+        const float inv = float(1.0 / std::sqrt(s));
+        for (auto &x : v) x *= inv;
+    }
+    return out;
+}
+
+int main()
+{
+    std::shared_ptr<Context> ctx;
+    try {
+        ctx = std::make_shared<Context>(0);
+    } catch (const Error &e) {
+        std::printf("no usable device: status %d (%s)\n", e.status(), e.what());
+        return e.status() == VG_ERR_NO_DEVICE ? 77 : 1;
+    }
+    std::mt19937 rng(0);
+
+    // ---- ProductQuantizer (pq_test.go) ----------------------------------------------------
+    {
+        const int dim = 128, m = 8, k = 256;
+        ProductQuantizer pq(ctx, dim, m, k);
+        EXPECT(!pq.IsTrained());
+        auto probe = unit_vectors(rng, 1, dim)[0];
+        EXPECT(status_of([&] { pq.Encode(probe); }) == VG_ERR_NOT_TRAINED);  // pq.go:148-150
+        auto train = unit_vectors(rng, 1000, dim);
+        pq.Train(train);
+        EXPECT(pq.IsTrained());
+        auto test = unit_vectors(rng, 2, dim);
+        auto codes = pq.Encode(test[0]);
+        EXPECT(int(codes.size()) == m);
+        auto rec = pq.Decode(codes);
+        EXPECT(int(rec.size()) == dim);
+        double mse = 0;
+        for (int i = 0; i < dim; i++) mse += double(test[0][i] - rec[i]) * (test[0][i] - rec[i]);
+        EXPECT(mse / dim < 0.5);                                             // pq_test.go:58-71
+        EXPECT(std::fabs(pq.CompressionRatio() - double(dim) * 4 / m) < 1e-9);
+        const float adc = pq.ComputeAsymmetricDistance(test[1], codes);      // pq_test.go:84-128
+        float full = 0;
+        for (int i = 0; i < dim; i++) full += (test[1][i] - rec[i]) * (test[1][i] - rec[i]);
+        EXPECT(std::fabs(adc - full) <= 1e-3f);
+        auto table = pq.BuildDistanceTable(test[1]);
+        EXPECT(int(table.size()) == m * k);
+        EXPECT(std::fabs(pq.AdcDistance(table, codes) - adc) <= 1e-4f);
+        EXPECT(status_of([&] { pq.Encode(std::vector<float>(100)); }) == VG_ERR_DIM_MISMATCH);
+        EXPECT(status_of([&] { pq.Decode(std::vector<uint8_t>(3)); }) == VG_ERR_CODE_LENGTH);
+        EXPECT(status_of([&] { ProductQuantizer bad(ctx, 100, 7, 256); }) == VG_ERR_INVALID_ARG);  // pq_test.go:130-136
+        EXPECT(status_of([&] { ProductQuantizer bad(ctx, 128, 8, 257); }) == VG_ERR_INVALID_ARG);
+        // SetCodebooks round trip (pq.go:452-464)
+        std::vector<int8_t> cb;
+        std::vector<float> sc, of;
+        pq.Codebooks(cb, sc, of);
+        ProductQuantizer pq2(ctx, dim, m, k);
+        pq2.SetCodebooks(cb, sc, of);
+        EXPECT(pq2.Encode(test[0]) == codes);
+    }
+
+    // ---- RaBitQuantizer (rabitq_test.go) --------------------------------------------------
+    {
+        const int dim = 128;
+        RaBitQuantizer rq(ctx, dim);
+        std::uniform_real_distribution<float> ud(-1.f, 1.f);
+        std::vector<float> v(dim), q(dim);
+        double ss = 0;
+        for (auto &x : v) {
+            x = ud(rng);
+            ss += double(x) * x;
+        }
+        for (auto &x : q) x = ud(rng);
+        auto code = rq.Encode(v);
+        EXPECT(int64_t(code.size()) == ((dim + 63) / 64 * 8) + 4);
+        float stored;
+        std::memcpy(&stored, code.data() + code.size() - 4, 4);
+        EXPECT(std::fabs(stored - float(std::sqrt(ss))) < 1e-5f);
+        EXPECT(rq.Distance(q, code) >= 0.0f);
+        EXPECT(status_of([&] { rq.Encode(std::vector<float>(dim - 1)); }) == VG_ERR_DIM_MISMATCH);
+        EXPECT(status_of([&] { rq.Distance(q, std::vector<uint8_t>(5)); }) == VG_ERR_CODE_LENGTH);
+    }
+
+    // ---- kmeans (kmeans_test.go) --------------------------------------------------------------
+    {
+        std::normal_distribution<float> nd;
+        std::vector<float> x;
+        for (int i = 0; i < 100; i++)
+            for (int d = 0; d < 4; d++) x.push_back(nd(rng) * 0.1f + (i < 50 ? 0.f : 10.f));
+        auto c = kmeans::TrainKMeans(*ctx, x, 4, 2, distance::Metric::L2, 10, 3);
+        EXPECT(c.size() == 8);
+        const float m0 = (c[0] + c[1] + c[2] + c[3]) / 4, m1 = (c[4] + c[5] + c[6] + c[7]) / 4;
+        EXPECT(std::fabs(std::min(m0, m1)) < 0.5f && std::fabs(std::max(m0, m1) - 10.f) < 0.5f);
+        EXPECT(kmeans::TrainKMeans(*ctx, std::vector<float>(4, 1.f), 4, 2, distance::Metric::L2, 10).empty());
+        EXPECT(status_of([&] { kmeans::TrainKMeans(*ctx, x, 4, 2, distance::Metric::Hamming, 10); }) == VG_ERR_UNSUPPORTED);
+        std::vector<float> cents = {0, 0, 1, 1, 5, 5, 10, 10};
+        auto near = kmeans::FindClosestCentroids(*ctx, {0.9f, 0.9f}, cents, 2, 2, distance::Metric::L2);
+        EXPECT(near.size() == 2 && near[0] == 1 && near[1] == 0);
+        EXPECT(kmeans::AssignPartition(*ctx, {9.f, 9.f}, cents, 2, distance::Metric::L2) == 3);
+    }
+
+    // ---- distance.Provider -----------------------------------------------------------------------
+    {
+        std::vector<float> a = {1, 2, 3}, b = {4, 5, 6};
+        float out = 0;
+        distance::Provider(distance::Metric::L2)(*ctx, a.data(), b.data(), 3, 1, &out);
+        EXPECT(out == 27.0f);  // floats_test.go:61
+        distance::Provider(distance::Metric::Cosine)(*ctx, a.data(), b.data(), 3, 1, &out);
+        EXPECT(out == 32.0f);  // floats_test.go:17
+        EXPECT(status_of([&] { distance::Provider(distance::Metric::Hamming); }) == VG_ERR_UNSUPPORTED);
+    }
+
+    // ---- flat segment: exact search and PQ search, vs the oracle ------------------------------
+    {
+        const int n = 4000, dim = 128, k = 10, nq = 5;
+        std::normal_distribution<float> nd;
+        std::vector<float> base(size_t(n) * dim), q(size_t(nq) * dim);
+        for (auto &x : base) x = nd(rng);
+        for (auto &x : q) x = nd(rng);
+        Segment seg(ctx, n, dim, distance::Metric::L2);
+        seg.SetVectors(base.data());
+        auto r = seg.SearchFlat(q.data(), nq, k);
+        for (int i = 0; i < nq; i++) {
+            uint32_t eid[k];
+            float esc[k];
+            vgo_flat_search_f32(base.data(), n, dim, VGO_METRIC_L2, q.data() + size_t(i) * dim, k, eid, esc);
+            EXPECT(std::memcmp(eid, r.ids.data() + size_t(i) * k, sizeof eid) == 0);
+            EXPECT(std::memcmp(esc, r.scores.data() + size_t(i) * k, sizeof esc) == 0);
+        }
+        // flat/pq_test.go:17-93: the zero query finds the zero vector with a small score
+        auto pq = std::make_shared<ProductQuantizer>(ctx, dim, 16, 256);
+        std::vector<float> with_zero(base);
+        std::fill(with_zero.begin() + 7 * dim, with_zero.begin() + 8 * dim, 0.0f);
+        pq->TrainFlat(with_zero.data(), 1000, 20, 1);
+        std::vector<uint8_t> codes(size_t(n) * 16);
+        pq->EncodeBatch(with_zero.data(), n, codes.data());
+        Segment pseg(ctx, n, dim, distance::Metric::L2);
+        pseg.SetVectors(with_zero.data());
+        pseg.SetPQCodes(pq, codes.data());
+        std::vector<float> zero(dim, 0.0f);
+        auto pr = pseg.SearchPQ(zero.data(), 1, 10);
+        bool found = false;
+        for (int i = 0; i < 10; i++) found |= pr.ids[i] == 7u;
+        EXPECT(found);
+        auto rr = pseg.Rerank(zero.data(), 1, pr.ids.data(), 10, 1);
+        EXPECT(rr.ids[0] == 7u && rr.scores[0] == 0.0f);
+    }
+
+    if (g_fail) {
+        std::fprintf(stderr, "%d check(s) failed\n", g_fail);
+        return 1;
+    }
+    std::printf("host mirror: all checks passed\n");
+    return 0;
+}

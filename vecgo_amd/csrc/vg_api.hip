@@ -27,6 +27,99 @@ bool is_device_ptr(const void *p)
     return a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeManaged;
 }
 
+namespace {
+struct ScratchBlock {
+    void *p;
+    size_t cap;
+    int device;
+    hipStream_t st;
+    bool in_use;
+};
+std::mutex g_scratch_mu;
+std::vector<ScratchBlock> g_scratch;
+
+size_t scratch_round(size_t bytes)
+{
+    if (bytes <= (size_t(1) << 20)) {  // powers of two from 256 B to 1 MiB
+        size_t c = 256;
+        while (c < bytes) c <<= 1;
+        return c;
+    }
+    const size_t mib = size_t(1) << 20;
+    return (bytes + bytes / 8 + mib - 1) / mib * mib;  // 12.5 % slack, whole MiB
+}
+}  // namespace
+
+int32_t scratch_alloc(void **out, size_t bytes, hipStream_t s)
+{
+    *out = nullptr;
+    if (bytes == 0) return VG_OK;
+    int dev = 0;
+    VG_HIP(hipGetDevice(&dev));
+    const size_t want = scratch_round(bytes);
+    {
+        std::lock_guard<std::mutex> g(g_scratch_mu);
+        ScratchBlock *best = nullptr;
+        for (auto &b : g_scratch) {
+            if (b.in_use || b.device != dev || b.st != s || b.cap < bytes || b.cap > 2 * want) continue;
+            if (!best || b.cap < best->cap) best = &b;
+        }
+        if (best) {
+            best->in_use = true;
+            *out = best->p;
+            return VG_OK;
+        }
+    }
+    void *p = nullptr;
+    hipError_t e = hipMalloc(&p, want);
+    if (e != hipSuccess) {  // out of HBM: give the cached, idle blocks back and retry once
+        (void)hipGetLastError();
+        scratch_trim(dev);
+        e = hipMalloc(&p, want);
+    }
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        set_error("hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+        return VG_ERR_HIP;
+    }
+    std::lock_guard<std::mutex> g(g_scratch_mu);
+    g_scratch.push_back(ScratchBlock{p, want, dev, s, true});
+    *out = p;
+    return VG_OK;
+}
+
+void scratch_free(void *p)
+{
+    if (!p) return;
+    std::lock_guard<std::mutex> g(g_scratch_mu);
+    for (auto &b : g_scratch)
+        if (b.p == p) {
+            b.in_use = false;
+            return;
+        }
+}
+
+// Returns every idle block of `device` to the driver.  Work that last used them may still be in
+// flight, so the device is drained first.
+void scratch_trim(int device)
+{
+    std::vector<void *> victims;
+    {
+        std::lock_guard<std::mutex> g(g_scratch_mu);
+        size_t w = 0;
+        for (size_t i = 0; i < g_scratch.size(); i++) {
+            if (!g_scratch[i].in_use && g_scratch[i].device == device)
+                victims.push_back(g_scratch[i].p);
+            else
+                g_scratch[w++] = g_scratch[i];
+        }
+        g_scratch.resize(w);
+    }
+    if (victims.empty()) return;
+    (void)hipDeviceSynchronize();
+    for (void *p : victims) (void)hipFree(p);
+}
+
 }  // namespace vg
 
 VG_API int32_t vg_abi_version(void) { return VG_ABI_VERSION; }
@@ -93,6 +186,7 @@ VG_API int32_t vg_ctx_destroy(vg_ctx *ctx)
     (void)hipDeviceSynchronize();
     for (auto &p : ctx->arenas)
         if (p.second.base) (void)hipFree(p.second.base);
+    vg::scratch_trim(ctx->device);
     if (ctx->stream) {
         (void)hipStreamSynchronize(ctx->stream);
         (void)hipStreamDestroy(ctx->stream);

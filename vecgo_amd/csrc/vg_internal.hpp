@@ -62,6 +62,15 @@ void set_error(const char *fmt, ...);
 
 bool is_device_ptr(const void *p);
 
+// Per-call HBM scratch.  Blocks come from a process-wide cache keyed by (device, stream): a block
+// released by one call is handed to the next call on the SAME stream, where stream order makes
+// the reuse safe without waiting.  (The runtime's own stream-ordered pool, hipMallocAsync, was
+// dropped: on ROCm 7.2 / gfx950 a block it recycled after a pool trim came back zero-filled
+// after the copy into it had completed — see DESIGN.md "Scratch memory".)
+int32_t scratch_alloc(void **out, size_t bytes, hipStream_t s);
+void scratch_free(void *p);
+void scratch_trim(int device);
+
 }  // namespace vg
 
 struct vg_prof_record {
@@ -143,14 +152,15 @@ struct DevIn {
             ptr = p;
             return VG_OK;
         }
-        VG_HIP(hipMallocAsync(reinterpret_cast<void **>(&owned), count * sizeof(T), s));
+        // Host buffers are the slow path (cgo, tests): staged through a cached HBM block
+        VG_TRY(scratch_alloc(reinterpret_cast<void **>(&owned), count * sizeof(T), s));
         VG_HIP(hipMemcpyAsync(owned, p, count * sizeof(T), hipMemcpyHostToDevice, s));
         ptr = owned;
         return VG_OK;
     }
     ~DevIn()
     {
-        if (owned) (void)hipFreeAsync(owned, st);
+        if (owned) scratch_free(owned);
     }
 };
 
@@ -175,7 +185,7 @@ struct DevOut {
             return VG_OK;
         }
         host = p;
-        VG_HIP(hipMallocAsync(reinterpret_cast<void **>(&owned), n * sizeof(T), s));
+        VG_TRY(scratch_alloc(reinterpret_cast<void **>(&owned), n * sizeof(T), s));
         ptr = owned;
         return VG_OK;
     }
@@ -184,12 +194,13 @@ struct DevOut {
     {
         if (host && count) {
             VG_HIP(hipMemcpyAsync(host, owned, count * sizeof(T), hipMemcpyDeviceToHost, st));
+            VG_HIP(hipStreamSynchronize(st));
         }
         return VG_OK;
     }
     ~DevOut()
     {
-        if (owned) (void)hipFreeAsync(owned, st);
+        if (owned) scratch_free(owned);
     }
 };
 
@@ -241,7 +252,7 @@ struct ArenaCall {
     }
 };
 
-// Scratch in HBM for the duration of a call (stream-ordered pool allocation).
+// Scratch in HBM for the duration of a call (cached block, see scratch_alloc).
 template <typename T>
 struct DevTmp {
     T *ptr = nullptr;
@@ -250,12 +261,12 @@ struct DevTmp {
     {
         st = s;
         if (count == 0) return VG_OK;
-        VG_HIP(hipMallocAsync(reinterpret_cast<void **>(&ptr), count * sizeof(T), s));
+        VG_TRY(scratch_alloc(reinterpret_cast<void **>(&ptr), count * sizeof(T), s));
         return VG_OK;
     }
     ~DevTmp()
     {
-        if (ptr) (void)hipFreeAsync(ptr, st);
+        if (ptr) scratch_free(ptr);
     }
 };
 
