@@ -241,6 +241,10 @@ int32_t vg_score_candidates(vg_index *idx, const float *queries, int64_t nq,
  * (distance.Provider, distance/distance.go:91-106).  k <= 32. */
 int32_t vg_search_flat(vg_index *idx, const float *queries, int64_t nq, int32_t k, uint32_t *ids,
                        float *scores, void *stream);
+/* diagnostics of vg_search_flat since vg_index_set_vectors: how many queries were searched and
+ * how many of them were answered by the exhaustive kernel instead of GEMM candidates + proof
+ * (either pointer may be NULL).  Synchronises the stream. */
+int32_t vg_index_flat_stats(vg_index *idx, int64_t *queries, int64_t *exhaustive, void *stream);
 
 /* exhaustive scan of the RaBitQ codes: RaBitQuantizer.Distance (rabitq.go:119-176) for every
  * row, best k by (Score, RowID).  The reference only scores RaBitQ codes node by node inside the

@@ -56,6 +56,24 @@ def test_flat_matches_oracle(vg, ctx, n, dim, nq, k, metric):
     check(vg, ctx, n, dim, nq, k, metric, np.random.default_rng(n + dim + nq))
 
 
+@pytest.mark.parametrize("dim,metric,nodma", [(768, 0, False), (128, 0, False), (100, 0, False), (36, 2, False),
+                                              (768, 0, True), (100, 2, True), (777, 0, False)])
+def test_flat_fast_path_answers_random_data(vg, ctx, dim, metric, nodma):
+    """On random data the GEMM candidates + proof must answer (nearly) every query: a wrong GEMM
+    (bad LDS image, bad fragment pairing) would still be *correct* through the exhaustive fallback,
+    so this checks the counter.  Covers the LDS-DMA kernel (dim % 4 == 0, incl. a ragged K edge)
+    and the register-staged one (dim % 4 != 0, or forced)."""
+    if nodma:
+        os.environ["VG_FLAT_NO_DMA"] = "1"
+    try:
+        idx, _, _ = check(vg, ctx, 6000, dim, 140, 10, metric, np.random.default_rng(dim + metric))
+        searched, exhaustive = idx.flat_stats()
+        assert searched == 140
+        assert exhaustive <= 2, exhaustive
+    finally:
+        os.environ.pop("VG_FLAT_NO_DMA", None)
+
+
 def test_flat_duplicates_and_near_ties(vg, ctx):
     """Rows that differ in the last bits and exact duplicates: the proof step must either
     accept or fall back, and ties resolve by RowID."""
@@ -70,7 +88,8 @@ def test_flat_forced_exhaustive_path(vg, ctx):
     """The fallback kernel (step 4) alone must give the same answer."""
     os.environ["VG_FLAT_FORCE_EXACT"] = "1"
     try:
-        check(vg, ctx, 6000, 128, 4, 10, 0, np.random.default_rng(8))
+        idx, _, _ = check(vg, ctx, 6000, 128, 4, 10, 0, np.random.default_rng(8))
+        assert idx.flat_stats() == (4, 4)
         check(vg, ctx, 3000, 96, 3, 10, 2, np.random.default_rng(9))
     finally:
         os.environ.pop("VG_FLAT_FORCE_EXACT")

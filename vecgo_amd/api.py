@@ -521,6 +521,12 @@ class Index:
         """flat.Segment.Search fp32 branch / hnsw.BruteSearch: exact brute force."""
         return self._search(self._lib.vg_search_flat, queries, k, out=out, stream=stream)
 
+    def flat_stats(self, stream=None):
+        """(queries searched, queries answered by the exhaustive kernel) since set_vectors."""
+        q, e = C.c_int64(0), C.c_int64(0)
+        check(self._lib.vg_index_flat_stats(self._h, C.byref(q), C.byref(e), _stream_ptr(stream)))
+        return q.value, e.value
+
     def search_pq_adc(self, queries, k, out=None, stream=None):
         """flat.Segment.Search PQ branch (flat/segment.go:476-483,678-689,714-721)."""
         return self._search(self._lib.vg_search_pq_adc, queries, k, out=out, stream=stream)

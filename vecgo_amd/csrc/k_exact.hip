@@ -129,7 +129,9 @@ VG_API int32_t vg_index_set_vectors(vg_index *idx, const float *base, void *stre
         VG_HIP(hipFree(idx->d_vectors));
         VG_HIP(hipFree(idx->d_norms));
         VG_HIP(hipFree(idx->d_norm_max));
+        VG_HIP(hipFree(idx->d_flat_stats));
         idx->d_vectors = idx->d_norms = idx->d_norm_max = nullptr;
+        idx->d_flat_stats = nullptr;
     }
     if (idx->n == 0) return VG_OK;
     size_t count = static_cast<size_t>(idx->n) * idx->dim;
@@ -140,6 +142,8 @@ VG_API int32_t vg_index_set_vectors(vg_index *idx, const float *base, void *stre
                        0, st, idx->d_vectors, idx->n, idx->dim, idx->d_norms);
     VG_HIP(hipMalloc(reinterpret_cast<void **>(&idx->d_norm_max), sizeof(float)));
     VG_LAUNCH(vg::norm_max_kernel, dim3(1), dim3(1024), 0, st, idx->d_norms, idx->n, idx->d_norm_max);
+    VG_HIP(hipMalloc(reinterpret_cast<void **>(&idx->d_flat_stats), 2 * sizeof(unsigned long long)));
+    VG_HIP(hipMemsetAsync(idx->d_flat_stats, 0, 2 * sizeof(unsigned long long), st));
     VG_HIP(hipStreamSynchronize(st));
     return VG_OK;
 }

@@ -9,6 +9,7 @@
 
 #include "vg_device.hpp"
 #include "vg_exact.hpp"
+#include "vg_flat_gemm.hpp"
 #include "vg_internal.hpp"
 
 namespace vg {
@@ -17,148 +18,67 @@ int32_t launch_topk_merge(const uint64_t *partial, int64_t nq, int lists, int k,
                           uint32_t *ids, float *scores, hipStream_t st, const int *only_if = nullptr,
                           const int *always = nullptr);
 
-// ---- 1. GEMM ---------------------------------------------------------------------------------
-// C tile 128 (queries) x 128 (rows) per workgroup, K step 32, 4 waves as 2x2, each wave 64x64 =
-// 2x2 v_mfma_f32_32x32x2_f32 tiles.  Operands sit row-major in LDS with a leading dimension of
-// 33 floats: the MFMA operand read (lane l: row l&31, k = l>>5) then touches 32 consecutive
-// banks.  Registers prefetch the next K step while the current one is multiplied.
-constexpr int kGemmBM = 128, kGemmBN = 128, kGemmBK = 32, kGemmLd = kGemmBK + 1;
-constexpr int kGemmPasses = kGemmBM * kGemmBK / 4 / 256;  // float4 loads per thread per operand tile
-constexpr int kGemmThreads = 256;
-using f32x16 = __attribute__((ext_vector_type(16))) float;
+// One GEMM launch.  `dma` picks the LDS-DMA kernel (16-byte aligned operands, dim % 4 == 0);
+// both kernels need more dynamic LDS than the 64 KiB a kernel gets by default.
+struct GemmArgs {
+    const float *queries;
+    int64_t nq;
+    const float *base;
+    int64_t n;
+    int dim;
+    const float *norms;
+    float *scores;
+    int tile_stride;
+    int64_t out_cols;
+    const float *thr;
+    int thr_stride, thr_off;
+    int *counts;
+    uint64_t *cand;
+    int cap;
+};
 
-// MODE 0: scores[q][n] for every row.  MODE 1: only every tile_stride-th row tile, written
-// compactly (row length out_cols; columns past n hold +Inf) — the sample that sets the per-query
-// threshold.  MODE 2: no score matrix at all: an element below its query's threshold is appended
-// (64-bit key) to that query's candidate buffer.  Whatever the threshold, every row NOT appended
-// has score >= threshold, which is all the proof in flat_verify_kernel needs.
 template <bool DOT, int MODE>
-__global__ __launch_bounds__(kGemmThreads) void flat_gemm_kernel(
-    const float *__restrict__ queries, int64_t nq, const float *__restrict__ base, int64_t n,
-    int dim, const float *__restrict__ norms, float *__restrict__ scores, int tile_stride,
-    int64_t out_cols, const float *__restrict__ thr, int thr_stride, int thr_off,
-    int *__restrict__ counts, uint64_t *__restrict__ cand, int cap)
+static int32_t launch_gemm_t(bool dma, unsigned blocks, hipStream_t st, const GemmArgs &a)
 {
-    __shared__ float As[kGemmBM * kGemmLd];
-    __shared__ float Bs[kGemmBN * kGemmLd];
-    // XCD-aware block order: blocks b, b+8, ... share an XCD (and its L2).  All query tiles of
-    // one row tile go to the same XCD, back to back, so the row tile crosses the fabric once
-    // instead of once per query tile (measured: FETCH_SIZE 12.4 GB -> see DESIGN.md §4).
-    const int mtiles = static_cast<int>((nq + kGemmBM - 1) / kGemmBM);
-    const int64_t ntiles = MODE == 1 ? (((n + kGemmBN - 1) / kGemmBN) + tile_stride - 1) / tile_stride
-                                     : (n + kGemmBN - 1) / kGemmBN;
-    const int64_t bt = blockIdx.x;
-    const int64_t xcd = bt & 7, jx = bt >> 3;
-    const int64_t tn = (jx / mtiles) * 8 + xcd;
-    const int tm = static_cast<int>(jx % mtiles);
-    if (tn >= ntiles) return;
-    const int64_t q0 = static_cast<int64_t>(tm) * kGemmBM;
-    const int64_t n0 = (MODE == 1 ? tn * tile_stride : tn) * kGemmBN;
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int wr = wave >> 1, wc = wave & 1;
-
-    // staging map: BK/4 lanes cover one row's BK floats, 256/(BK/4) rows per pass
-    constexpr int kLanesPerRow = kGemmBK / 4;
-    constexpr int kRowsPerPass = kGemmThreads / kLanesPerRow;
-    const int srow = tid / kLanesPerRow;
-    const int sk = (tid % kLanesPerRow) * 4;
-    const float *aptr[kGemmPasses];
-    const float *bptr[kGemmPasses];
-#pragma unroll
-    for (int p = 0; p < kGemmPasses; p++) {
-        int64_t qa = q0 + p * kRowsPerPass + srow;
-        if (qa >= nq) qa = nq - 1;
-        int64_t nb = n0 + p * kRowsPerPass + srow;
-        if (nb >= n) nb = n - 1;
-        aptr[p] = queries + qa * dim + sk;
-        bptr[p] = base + nb * dim + sk;
+    if (dma) {
+        auto kern = flat_gemm_dma_kernel<DOT, MODE>;
+        VG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   static_cast<int>(kDmaLdsBytes)));
+        VG_LAUNCH(kern, dim3(blocks), dim3(kGemmThreads), kDmaLdsBytes, st, a.queries, a.nq, a.base, a.n, a.dim,
+                  a.norms, a.scores, a.tile_stride, a.out_cols, a.thr, a.thr_stride, a.thr_off, a.counts, a.cand,
+                  a.cap);
+    } else {
+        auto kern = flat_gemm_kernel<DOT, MODE>;
+        VG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   static_cast<int>(kGemmLdsBytes)));
+        VG_LAUNCH(kern, dim3(blocks), dim3(kGemmThreads), kGemmLdsBytes, st, a.queries, a.nq, a.base, a.n, a.dim,
+                  a.norms, a.scores, a.tile_stride, a.out_cols, a.thr, a.thr_stride, a.thr_off, a.counts, a.cand,
+                  a.cap);
     }
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; i++)
-#pragma unroll
-        for (int j = 0; j < 2; j++)
-#pragma unroll
-            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.0f;
+    return VG_OK;
+}
 
-    float4 ra[kGemmPasses], rb[kGemmPasses];
-    const int ksteps = (dim + kGemmBK - 1) / kGemmBK;
-    const int full_steps = dim / kGemmBK;  // K steps with no ragged edge (uniform per kernel)
-    auto load_tile = [&](int kt) {
-        const int k0 = kt * kGemmBK;
-        if (kt < full_steps) {  // unguarded: 8 independent 16-byte loads in flight
-#pragma unroll
-            for (int p = 0; p < kGemmPasses; p++) {
-                ra[p] = *reinterpret_cast<const float4 *>(aptr[p] + k0);
-                rb[p] = *reinterpret_cast<const float4 *>(bptr[p] + k0);
-            }
-        } else {  // ragged K edge: element-wise with zero fill
-#pragma unroll
-            for (int p = 0; p < kGemmPasses; p++) {
-                float ta[4] = {0, 0, 0, 0}, tb[4] = {0, 0, 0, 0};
-                for (int e = 0; e < 4; e++)
-                    if (k0 + sk + e < dim) {
-                        ta[e] = aptr[p][k0 + e];
-                        tb[e] = bptr[p][k0 + e];
-                    }
-                ra[p] = make_float4(ta[0], ta[1], ta[2], ta[3]);
-                rb[p] = make_float4(tb[0], tb[1], tb[2], tb[3]);
-            }
-        }
-    };
-    load_tile(0);
-    for (int kt = 0; kt < ksteps; kt++) {
-        __syncthreads();  // previous step's operand reads are done
-#pragma unroll
-        for (int p = 0; p < kGemmPasses; p++) {
-            float *da = As + (p * kRowsPerPass + srow) * kGemmLd + sk;
-            float *db = Bs + (p * kRowsPerPass + srow) * kGemmLd + sk;
-            da[0] = ra[p].x; da[1] = ra[p].y; da[2] = ra[p].z; da[3] = ra[p].w;
-            db[0] = rb[p].x; db[1] = rb[p].y; db[2] = rb[p].z; db[3] = rb[p].w;
-        }
-        __syncthreads();
-        if (kt + 1 < ksteps) load_tile(kt + 1);
-        const float *a_base = As + (wr * 64 + (lane & 31)) * kGemmLd + (lane >> 5);
-        const float *b_base = Bs + (wc * 64 + (lane & 31)) * kGemmLd + (lane >> 5);
-#pragma unroll
-        for (int kk = 0; kk < kGemmBK; kk += 2) {
-            const float a0 = a_base[kk], a1 = a_base[32 * kGemmLd + kk];
-            const float b0 = b_base[kk], b1 = b_base[32 * kGemmLd + kk];
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
-        }
-    }
-    // epilogue: C/D map of 32x32: col = lane&31 (row index n), row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-#pragma unroll
-    for (int j = 0; j < 2; j++) {
-        const int col = wc * 64 + j * 32 + (lane & 31);
-        const int64_t nn = n0 + col;
-        const float xn = (!DOT && nn < n) ? norms[nn] : 0.0f;
-#pragma unroll
-        for (int i = 0; i < 2; i++) {
-#pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int64_t qq = q0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (qq >= nq) continue;
-                const float dotv = acc[i][j][r];
-                const float sc = DOT ? -dotv : __builtin_fmaf(-2.0f, dotv, xn);
-                if (MODE == 0) {
-                    if (nn < n) scores[qq * n + nn] = sc;
-                } else if (MODE == 1) {
-                    scores[qq * out_cols + tn * kGemmBN + col] = nn < n ? sc : INFINITY;
-                } else {
-                    if (nn < n && sc < thr[qq * thr_stride + thr_off]) {
-                        const int pos = atomicAdd(&counts[qq], 1);
-                        if (pos < cap) cand[qq * cap + pos] = make_key(sc, static_cast<uint32_t>(nn), false);
-                    }
-                }
-            }
-        }
+template <int MODE>
+static int32_t launch_gemm(bool dot, bool dma, unsigned blocks, hipStream_t st, const GemmArgs &a)
+{
+    return dot ? launch_gemm_t<true, MODE>(dma, blocks, st, a) : launch_gemm_t<false, MODE>(dma, blocks, st, a);
+}
+
+// bookkeeping for vg_index_flat_stats: stats[0] += queries of the chunk, stats[1] += those whose
+// proof failed (or that were forced) and went to the exhaustive kernel
+__global__ void flat_stats_kernel(const int *__restrict__ flags, const int *__restrict__ always, int cnt,
+                                  unsigned long long *__restrict__ stats)
+{
+    __shared__ int total;
+    if (threadIdx.x == 0) total = 0;
+    __syncthreads();
+    int mine = 0;
+    for (int i = threadIdx.x; i < cnt; i += blockDim.x) mine += (flags[i] != 0 || *always != 0);
+    if (mine) atomicAdd(&total, mine);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(&stats[0], static_cast<unsigned long long>(cnt));
+        atomicAdd(&stats[1], static_cast<unsigned long long>(total));
     }
 }
 
@@ -458,17 +378,15 @@ VG_API int32_t vg_search_flat(vg_index *idx, const float *queries, int64_t nq, i
             const float *qp = q.ptr + q0 * dim;
             const int64_t mt = (cnt + vg::kGemmBM - 1) / vg::kGemmBM;
             const unsigned ucnt = static_cast<unsigned>(cnt);
+            const char *nodma = getenv("VG_FLAT_NO_DMA");  // test hook: force the register-staged GEMM
+            const bool dma = dim % 4 == 0 && (reinterpret_cast<uintptr_t>(qp) & 15) == 0 &&
+                             (reinterpret_cast<uintptr_t>(idx->d_vectors) & 15) == 0 && !(nodma && nodma[0] == '1');
             if (fused) {
                 // (a) threshold per query from a row sample
                 if (use_sample) {
-                    if (dot)
-                        VG_LAUNCH((vg::flat_gemm_kernel<true, 1>), dim3(static_cast<unsigned>(mt * ((nst + 7) / 8) * 8)),
-                                  dim3(vg::kGemmThreads), 0, st, qp, cnt, idx->d_vectors, n, dim, idx->d_norms, sc,
-                                  sample_stride, ns, nullptr, 0, 0, nullptr, nullptr, 0);
-                    else
-                        VG_LAUNCH((vg::flat_gemm_kernel<false, 1>), dim3(static_cast<unsigned>(mt * ((nst + 7) / 8) * 8)),
-                                  dim3(vg::kGemmThreads), 0, st, qp, cnt, idx->d_vectors, n, dim, idx->d_norms, sc,
-                                  sample_stride, ns, nullptr, 0, 0, nullptr, nullptr, 0);
+                    VG_TRY(vg::launch_gemm<1>(dot, dma, static_cast<unsigned>(mt * ((nst + 7) / 8) * 8), st,
+                                              {qp, cnt, idx->d_vectors, n, dim, idx->d_norms, sc, sample_stride, ns,
+                                               nullptr, 0, 0, nullptr, nullptr, 0}));
                     VG_LAUNCH(vg::flat_select_kernel, dim3(sel_slices, ucnt), dim3(vg::kSelThreads), 0, st, sc, ns,
                               sel_slices, sel_k, partial);
                     VG_TRY(vg::launch_topk_merge(partial, cnt, sel_slices, sel_k, false, sid, thr, st));
@@ -480,28 +398,18 @@ VG_API int32_t vg_search_flat(vg_index *idx, const float *queries, int64_t nq, i
                 VG_HIP(hipMemsetAsync(counts, 0, sizeof(int) * static_cast<size_t>(cnt), st));
                 {
                     vg::ProfScope prof(idx->ctx, "flat_gemm", st);
-                    if (dot)
-                        VG_LAUNCH((vg::flat_gemm_kernel<true, 2>), dim3(static_cast<unsigned>(mt * ((nt + 7) / 8) * 8)),
-                                  dim3(vg::kGemmThreads), 0, st, qp, cnt, idx->d_vectors, n, dim, idx->d_norms,
-                                  nullptr, 1, 0, thr, sel_k, sel_k - 1, counts, cand, cap);
-                    else
-                        VG_LAUNCH((vg::flat_gemm_kernel<false, 2>), dim3(static_cast<unsigned>(mt * ((nt + 7) / 8) * 8)),
-                                  dim3(vg::kGemmThreads), 0, st, qp, cnt, idx->d_vectors, n, dim, idx->d_norms,
-                                  nullptr, 1, 0, thr, sel_k, sel_k - 1, counts, cand, cap);
+                    VG_TRY(vg::launch_gemm<2>(dot, dma, static_cast<unsigned>(mt * ((nt + 7) / 8) * 8), st,
+                                              {qp, cnt, idx->d_vectors, n, dim, idx->d_norms, nullptr, 1, 0, thr,
+                                               sel_k, sel_k - 1, counts, cand, cap}));
                 }
                 // (c) the kc best appended keys
                 VG_LAUNCH(vg::flat_pick_kernel, dim3(ucnt), dim3(256), 0, st, cand, counts, cap, kc, cand_id, cand_sc);
             } else {
                 {
                     vg::ProfScope prof(idx->ctx, "flat_gemm", st);
-                    if (dot)
-                        VG_LAUNCH((vg::flat_gemm_kernel<true, 0>), dim3(static_cast<unsigned>(mt * ((nt + 7) / 8) * 8)),
-                                  dim3(vg::kGemmThreads), 0, st, qp, cnt, idx->d_vectors, n, dim, idx->d_norms, sc, 1,
-                                  n, nullptr, 0, 0, nullptr, nullptr, 0);
-                    else
-                        VG_LAUNCH((vg::flat_gemm_kernel<false, 0>), dim3(static_cast<unsigned>(mt * ((nt + 7) / 8) * 8)),
-                                  dim3(vg::kGemmThreads), 0, st, qp, cnt, idx->d_vectors, n, dim, idx->d_norms, sc, 1,
-                                  n, nullptr, 0, 0, nullptr, nullptr, 0);
+                    VG_TRY(vg::launch_gemm<0>(dot, dma, static_cast<unsigned>(mt * ((nt + 7) / 8) * 8), st,
+                                              {qp, cnt, idx->d_vectors, n, dim, idx->d_norms, sc, 1, n, nullptr, 0, 0,
+                                               nullptr, nullptr, 0}));
                 }
                 {
                     vg::ProfScope prof(idx->ctx, "flat_select", st);
@@ -526,6 +434,8 @@ VG_API int32_t vg_search_flat(vg_index *idx, const float *queries, int64_t nq, i
             else
                 VG_LAUNCH(vg::flat_exact_kernel<false>, dim3(ex_slices, ucnt), dim3(256), 0, st, idx->d_vectors, n, dim,
                           qp, flags, always, ex_slices, k, fpartial);
+            VG_LAUNCH(vg::flat_stats_kernel, dim3(1), dim3(256), 0, st, flags, always, static_cast<int>(cnt),
+                      idx->d_flat_stats);
             if (getenv("VG_FLAT_DEBUG")) {
                 std::vector<int> hf(cnt), hc(cnt);
                 (void)hipMemcpyAsync(hf.data(), flags, sizeof(int) * cnt, hipMemcpyDeviceToHost, st);
@@ -546,5 +456,19 @@ VG_API int32_t vg_search_flat(vg_index *idx, const float *queries, int64_t nq, i
     VG_TRY(oid.finish());
     VG_TRY(osc.finish());
     if (oid.on_host() || osc.on_host()) VG_HIP(hipStreamSynchronize(st));
+    return VG_OK;
+}
+
+VG_API int32_t vg_index_flat_stats(vg_index *idx, int64_t *queries, int64_t *exhaustive, void *stream)
+{
+    VG_CHECK(idx, VG_ERR_INVALID_ARG, "vg_index_flat_stats: NULL index");
+    VG_CHECK(idx->d_flat_stats, VG_ERR_INVALID_ARG, "vg_index_flat_stats: no fp32 vectors attached");
+    VG_HIP(hipSetDevice(idx->ctx->device));
+    hipStream_t st = vg::pick_stream(idx->ctx, stream);
+    unsigned long long h[2] = {0, 0};
+    VG_HIP(hipMemcpyAsync(h, idx->d_flat_stats, sizeof h, hipMemcpyDeviceToHost, st));
+    VG_HIP(hipStreamSynchronize(st));
+    if (queries) *queries = static_cast<int64_t>(h[0]);
+    if (exhaustive) *exhaustive = static_cast<int64_t>(h[1]);
     return VG_OK;
 }
