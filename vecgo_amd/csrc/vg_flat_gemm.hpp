@@ -24,29 +24,33 @@ constexpr size_t kGemmLdsBytes = 4 * kGemmTile * sizeof(float);  // A,B double-b
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
 // Epilogue shared by both GEMM kernels.  C/D map of the 32x32 MFMA: col = lane&31 (row index n),
-// row = (r&3) + 8*(r>>2) + 4*(lane>>5).  MODE 2 stages the 128 thresholds of the tile's queries
-// in LDS (`lds`, free once the K loop is over): 64 dependent global loads per lane cost 6 % of
-// the kernel when they were read in place.
+// row = (r&3) + 8*(r>>2) + 4*(lane>>5).  MODE 2 compares every element with its query's threshold.
+// Read in place the thresholds were 64 dependent global loads per lane (6 % of the kernel); read
+// one by one from LDS between the branches of the append they were 64 serialised LDS round trips.
+// Now: thr_reg (thread t < 128: threshold of query q0+t) and xn (||x||^2 of this lane's two
+// columns) are loaded by the caller BEFORE the K loop; the epilogue stages the 128 thresholds in
+// LDS (`lds_thr`, free once the K loop is over) and every lane pulls its 32 with 8 ds_read_b128.
 template <bool DOT, int MODE>
-__device__ __forceinline__ void gemm_epilogue(const f32x16 (&acc)[2][2], float *lds, int tid, int lane, int wr,
-                                              int wc, int64_t q0, int64_t nq, int64_t n0, int64_t n, int64_t tn,
-                                              const float *__restrict__ norms, float *__restrict__ scores,
-                                              int64_t out_cols, const float *__restrict__ thr, int thr_stride,
-                                              int thr_off, int *__restrict__ counts, uint64_t *__restrict__ cand,
-                                              int cap)
+__device__ __forceinline__ void gemm_epilogue(const f32x16 (&acc)[2][2], float *lds_thr, float thr_reg,
+                                              const float (&xn)[2], int tid, int lane, int wr, int wc, int64_t q0,
+                                              int64_t nq, int64_t n0, int64_t n, int64_t tn,
+                                              float *__restrict__ scores, int64_t out_cols,
+                                              int *__restrict__ counts, uint64_t *__restrict__ cand, int cap)
 {
+    float4 t4[2][4];  // thresholds of rows i*32 + 8*g + 4*(lane>>5) + 0..3
     if (MODE == 2) {
-        if (tid < kGemmBM) {
-            const int64_t qq = q0 + tid;
-            lds[tid] = qq < nq ? thr[qq * thr_stride + thr_off] : -INFINITY;  // -Inf: nothing passes
-        }
+        if (tid < kGemmBM) lds_thr[tid] = thr_reg;
         __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int g = 0; g < 4; g++)
+                t4[i][g] = *reinterpret_cast<const float4 *>(lds_thr + wr * 64 + i * 32 + 8 * g + 4 * (lane >> 5));
     }
 #pragma unroll
     for (int j = 0; j < 2; j++) {
         const int col = wc * 64 + j * 32 + (lane & 31);
         const int64_t nn = n0 + col;
-        const float xn = (!DOT && nn < n) ? norms[nn] : 0.0f;
 #pragma unroll
         for (int i = 0; i < 2; i++) {
 #pragma unroll
@@ -54,19 +58,37 @@ __device__ __forceinline__ void gemm_epilogue(const f32x16 (&acc)[2][2], float *
                 const int ql = wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 const int64_t qq = q0 + ql;
                 const float dotv = acc[i][j][r];
-                const float sc = DOT ? -dotv : __builtin_fmaf(-2.0f, dotv, xn);
+                const float sc = DOT ? -dotv : __builtin_fmaf(-2.0f, dotv, xn[j]);
                 if (MODE == 0) {
                     if (qq < nq && nn < n) scores[qq * n + nn] = sc;
                 } else if (MODE == 1) {
                     if (qq < nq) scores[qq * out_cols + tn * kGemmBN + col] = nn < n ? sc : INFINITY;
                 } else {
-                    if (nn < n && sc < lds[ql]) {
+                    const float4 tv = t4[i][r >> 2];
+                    const float t = (r & 3) == 0 ? tv.x : (r & 3) == 1 ? tv.y : (r & 3) == 2 ? tv.z : tv.w;
+                    if (nn < n && sc < t) {
                         const int pos = atomicAdd(&counts[qq], 1);
                         if (pos < cap) cand[qq * cap + pos] = make_key(sc, static_cast<uint32_t>(nn), false);
                     }
                 }
             }
         }
+    }
+}
+
+// the caller-side loads that go with it
+template <bool DOT, int MODE>
+__device__ __forceinline__ void gemm_epilogue_inputs(float &thr_reg, float (&xn)[2], int tid, int lane, int wc,
+                                                     int64_t q0, int64_t nq, int64_t n0, int64_t n,
+                                                     const float *__restrict__ norms,
+                                                     const float *__restrict__ thr, int thr_stride, int thr_off)
+{
+    thr_reg = -INFINITY;  // -Inf: nothing passes (queries past nq)
+    if (MODE == 2 && tid < kGemmBM && q0 + tid < nq) thr_reg = thr[(q0 + tid) * thr_stride + thr_off];
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        const int64_t nn = n0 + wc * 64 + j * 32 + (lane & 31);
+        xn[j] = (!DOT && nn < n) ? norms[nn] : 0.0f;
     }
 }
 
@@ -164,6 +186,8 @@ __global__ __launch_bounds__(kGemmThreads) void flat_gemm_kernel(
         db[0] = rb[p].x; db[1] = rb[p].y; db[2] = rb[p].z; db[3] = rb[p].w;
     };
     static_assert(kGemmPasses == 4 && kGemmBK == 32, "pipeline below is written for 4 passes and 8 groups");
+    float thr_reg, xn[2];
+    gemm_epilogue_inputs<DOT, MODE>(thr_reg, xn, tid, lane, wc, q0, nq, n0, n, norms, thr, thr_stride, thr_off);
     load_tile(0);
 #pragma unroll
     for (int p = 0; p < kGemmPasses; p++) store_pass(As0, Bs0, p);
@@ -217,8 +241,8 @@ __global__ __launch_bounds__(kGemmThreads) void flat_gemm_kernel(
         if (t == 123.456f) scores[0] = t;
         return;
     }
-    gemm_epilogue<DOT, MODE>(acc, gemm_lds, tid, lane, wr, wc, q0, nq, n0, n, tn, norms, scores, out_cols, thr,
-                             thr_stride, thr_off, counts, cand, cap);
+    gemm_epilogue<DOT, MODE>(acc, gemm_lds, thr_reg, xn, tid, lane, wr, wc, q0, nq, n0, n, tn, scores, out_cols,
+                             counts, cand, cap);
 }
 
 // ---- the same GEMM with LDS-DMA staging (dim % 4 == 0) -----------------------------------------
@@ -349,6 +373,8 @@ __global__ __launch_bounds__(kGemmThreads) void flat_gemm_dma_kernel(
     const int a_row = (wr * 64 + (lane & 31)) * kGemmBK;
     const int b_row = (wc * 64 + (lane & 31)) * kGemmBK;
 
+    float thr_reg, xn[2];
+    gemm_epilogue_inputs<DOT, MODE>(thr_reg, xn, tid, lane, wc, q0, nq, n0, n, norms, thr, thr_stride, thr_off);
     dma_tile(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -395,8 +421,8 @@ __global__ __launch_bounds__(kGemmThreads) void flat_gemm_dma_kernel(
         if (t == 123.456f) scores[0] = t;
         return;
     }
-    gemm_epilogue<DOT, MODE>(acc, gemm_lds, tid, lane, wr, wc, q0, nq, n0, n, tn, norms, scores, out_cols, thr,
-                             thr_stride, thr_off, counts, cand, cap);
+    gemm_epilogue<DOT, MODE>(acc, gemm_lds, thr_reg, xn, tid, lane, wr, wc, q0, nq, n0, n, tn, scores, out_cols,
+                             counts, cand, cap);
 }
 
 }  // namespace vg
