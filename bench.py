@@ -13,7 +13,8 @@ merge with the reference tie-break (vecgo_amd/sharded.py).
 
 One JSON line on rank 0; extra objects: `roofline` (dominant kernel of the timed region, HIP
 events from inside the library), `adc_scan` (PQ-ADC scan, BASELINE configs[3]: 10M x 96 B codes,
-HBM roofline), `cpu_baseline` (the CPU oracle = port of the reference's AVX-512 path, timed on
+HBM roofline), `rabitq_scan` (RaBitQ scan, configs[4] shape on one GPU: 10M x 100 B),
+`hnsw_layer0` (configs[2]), `cpu_baseline` (the CPU oracle = port of the reference's AVX-512 path, timed on
 this host's cores on a bounded sample).
 """
 from __future__ import annotations
@@ -145,6 +146,45 @@ def adc_scan_roofline(vg, ctx, stream, device):
            "qps_single_query_passes": 1e3 / (e0.elapsed_time(e1) / reps)}
     idx.close()
     pq.close()
+    return res
+
+
+def rabitq_scan_roofline(vg, ctx, stream, device):
+    """BASELINE configs[4], one GPU's view: exhaustive RaBitQ scan, 10M x 768 -> 100 B per row
+    (96 B of sign bits + f32 norm): algorithmic bytes = N*100 per launch."""
+    n = 10_000_000
+    cb = (DIM + 63) // 64 * 8 + 4
+    g = torch.Generator(device=device)
+    g.manual_seed(11)
+    codes = torch.randint(0, 256, (n, cb), dtype=torch.uint8, device=device, generator=g)
+    codes[:, cb - 4:] = (torch.rand(n, device=device, generator=g) * 5 + 25).view(torch.uint8).reshape(n, 4)
+    idx = vg.Index(ctx, n, DIM)
+    idx.set_rabitq_codes(codes)
+    del codes
+    q = torch.randn((1, DIM), device=device)
+    out = (torch.empty((1, K), dtype=torch.int32, device=device), torch.empty((1, K), device=device))
+    for _ in range(5):
+        idx.search_rabitq(q, K, out=out, stream=stream)
+    torch.cuda.synchronize()
+    ctx.profile_read("rabitq_scan")
+    ctx.profile_enable(True)
+    reps = 20
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(stream)
+    for _ in range(reps):
+        idx.search_rabitq(q, K, out=out, stream=stream)
+    e1.record(stream)
+    torch.cuda.synchronize()
+    launches, ms = ctx.profile_read("rabitq_scan")
+    ctx.profile_enable(False)
+    kern_ms = ms / max(launches, 1)
+    achieved = n * cb / (kern_ms * 1e-3) / 1e9
+    res = {"workload": "rabitq_scan_10Mx768_100B_k10_nq1", "bound": "hbm", "achieved": achieved,
+           "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": achieved / PEAK_HBM_GBS,
+           "traffic": measured_traffic("rabitq_scan"), "kernel": "rabitq_scan_kernel", "kernel_ms": kern_ms,
+           "bytes_per_launch": n * cb, "search_call_ms": e0.elapsed_time(e1) / reps,
+           "qps_single_query_passes": 1e3 / (e0.elapsed_time(e1) / reps)}
+    idx.close()
     return res
 
 
@@ -306,7 +346,7 @@ def main():
         "roofline": {"bound": "mfma", "achieved": achieved_tf, "peak": PEAK_MFMA_F32_TFLOPS,
                      "unit": "TFLOP/s", "frac": achieved_tf / PEAK_MFMA_F32_TFLOPS,
                      "traffic": measured_traffic("flat_gemm") if world == 1 else None,
-                     "kernel": "flat_gemm_kernel<false>", "kernel_ms": gemm_avg_ms,
+                     "kernel": "flat_gemm_dma_kernel<false,2>", "kernel_ms": gemm_avg_ms,
                      "launches": launches, "flops_per_launch": flops_per_launch},
     }
     if world == 1 and not args.no_hnsw:
@@ -314,6 +354,7 @@ def main():
     if world == 1 and not args.no_adc:
         del index
         out["adc_scan"] = adc_scan_roofline(vg, ctx, stream, device)
+        out["rabitq_scan"] = rabitq_scan_roofline(vg, ctx, stream, device)
     if world == 1 and not args.no_cpu_baseline:
         nsample = 2 * (os.cpu_count() or 1)
         out["cpu_baseline"] = cpu_baseline(rows.cpu().numpy(), queries[1][:nsample].cpu().numpy(), K)
