@@ -144,14 +144,9 @@ __global__ __launch_bounds__(kRqThreads) void rabitq_scan_kernel(
     __syncthreads();
     WaveTopK tk;
     tk.init(k);
-    for (int64_t tile = t0 + wave; tile < t1; tile += kRqWaves) {
-        const uint4 *tp = tiles + (tile * groups) * 64 + lane;
-        int h = 0;
-        for (int g = 0; g < groups; g++) {
-            const uint4 c = tp[g * 64];
-            const uint4 qq = qbits[g];
-            h += __popc(c.x ^ qq.x) + __popc(c.y ^ qq.y) + __popc(c.z ^ qq.z) + __popc(c.w ^ qq.w);
-        }
+    // two tiles per trip: 2 * groups independent 16-byte loads in flight per lane before the first
+    // popcount (one tile per trip left the wave idle for a full HBM round trip per 64 rows)
+    auto score = [&](int64_t tile, int h) {
         const int64_t row = tile * 64 + lane;
         uint64_t key = kKeyMax;
         if (row < n_rows) {
@@ -159,6 +154,45 @@ __global__ __launch_bounds__(kRqThreads) void rabitq_scan_kernel(
             key = make_key(d, static_cast<uint32_t>(row), false);
         }
         tk.offer(key, lane);
+    };
+    int64_t tile = t0 + wave;
+    if (groups == 6) {  // d = 768: fully unrolled
+        for (; tile + kRqWaves < t1; tile += 2 * kRqWaves) {
+            const uint4 *tp0 = tiles + (tile * 6) * 64 + lane;
+            const uint4 *tp1 = tiles + ((tile + kRqWaves) * 6) * 64 + lane;
+            uint4 c0[6], c1[6];
+#pragma unroll
+            for (int g = 0; g < 6; g++) c0[g] = tp0[g * 64];
+#pragma unroll
+            for (int g = 0; g < 6; g++) c1[g] = tp1[g * 64];
+            const float y0 = (tile * 64 + lane) < n_rows ? norms[tile * 64 + lane] : 0.0f;
+            const float y1 = ((tile + kRqWaves) * 64 + lane) < n_rows ? norms[(tile + kRqWaves) * 64 + lane] : 0.0f;
+            int h0 = 0, h1 = 0;
+#pragma unroll
+            for (int g = 0; g < 6; g++) {
+                const uint4 qq = qbits[g];
+                h0 += __popc(c0[g].x ^ qq.x) + __popc(c0[g].y ^ qq.y) + __popc(c0[g].z ^ qq.z) + __popc(c0[g].w ^ qq.w);
+                h1 += __popc(c1[g].x ^ qq.x) + __popc(c1[g].y ^ qq.y) + __popc(c1[g].z ^ qq.z) + __popc(c1[g].w ^ qq.w);
+            }
+            uint64_t k0 = kKeyMax, k1 = kKeyMax;
+            if (tile * 64 + lane < n_rows)
+                k0 = make_key(rq_formula(qn, y0, dimf, static_cast<float>(h0)), static_cast<uint32_t>(tile * 64 + lane), false);
+            if ((tile + kRqWaves) * 64 + lane < n_rows)
+                k1 = make_key(rq_formula(qn, y1, dimf, static_cast<float>(h1)),
+                              static_cast<uint32_t>((tile + kRqWaves) * 64 + lane), false);
+            tk.offer(k0, lane);
+            tk.offer(k1, lane);
+        }
+    }
+    for (; tile < t1; tile += kRqWaves) {
+        const uint4 *tp = tiles + (tile * groups) * 64 + lane;
+        int h = 0;
+        for (int g = 0; g < groups; g++) {
+            const uint4 c = tp[g * 64];
+            const uint4 qq = qbits[g];
+            h += __popc(c.x ^ qq.x) + __popc(c.y ^ qq.y) + __popc(c.z ^ qq.z) + __popc(c.w ^ qq.w);
+        }
+        score(tile, h);
     }
     wg_rank_merge<kRqWaves>(tk, lists, valid, wave, lane, tid, k,
                             partial + (static_cast<int64_t>(q) * slices + s) * k);
@@ -174,7 +208,9 @@ int32_t launch_rabitq_encode(const float *d_vectors, int64_t n, int dim, uint8_t
 
 static int rq_slices(int64_t nq, int64_t n_tiles, int cus)
 {
-    int64_t s = (4 * cus + nq - 1) / nq;  // ~4 workgroups of 256 threads per CU
+    const char *e = getenv("VG_RQ_WG_PER_CU");
+    const int per_cu = e ? atoi(e) : 4;
+    int64_t s = (static_cast<int64_t>(per_cu) * cus + nq - 1) / nq;  // ~4 workgroups of 256 threads per CU
     s = ((s + 7) / 8) * 8;
     int64_t max_s = (n_tiles / 8) * 8;
     if (max_s < 8) max_s = 8;
