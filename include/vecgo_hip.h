@@ -114,6 +114,17 @@ int32_t vg_pq_build_distance_table(vg_pq *pq, const float *queries, int64_t nq, 
  * The reference uses iters = 20. */
 int32_t vg_pq_train(vg_pq *pq, const float *vectors, int64_t n, int32_t iters, uint64_t seed,
                     void *stream);
+/* The same for the sub-quantizers [sub_begin, sub_begin + sub_count) only.  The reference trains
+ * the sub-quantizers as independent goroutines (pq.go:83-138); on several GPUs each rank trains a
+ * range, the ranges are exchanged (vg_pq_get_codebooks_range -> all-gather -> vg_pq_set_codebooks)
+ * and, the random stream being keyed by (seed, sub-quantizer), the result equals vg_pq_train's bit
+ * for bit.  The quantizer counts as trained only after the full range [0, m) was trained in one
+ * call or the codebooks were set. */
+int32_t vg_pq_train_subset(vg_pq *pq, const float *vectors, int64_t n, int32_t iters, uint64_t seed,
+                           int32_t sub_begin, int32_t sub_count, void *stream);
+/* codebooks[sub_count*k*subdim], scales[sub_count], offsets[sub_count] of that range (trained or not) */
+int32_t vg_pq_get_codebooks_range(vg_pq *pq, int32_t sub_begin, int32_t sub_count, int8_t *codebooks,
+                                  float *scales, float *offsets);
 /* Encode pq.go:147-176, batched: codes[n*m]; code = FindNearestCentroidInt8
  * (internal/simd/kernels.go:376-396: strict '<', lowest index wins ties) */
 int32_t vg_pq_encode(vg_pq *pq, const float *vectors, int64_t n, uint8_t *codes, void *stream);

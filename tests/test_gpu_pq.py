@@ -109,3 +109,26 @@ def test_reference_quantizer_assertions(vg, ctx):
     assert abs(adc - full) <= 1e-3
     with pytest.raises(vg.VecgoHipError):
         pq.encode(np.zeros(100, np.float32))  # dimension mismatch
+
+
+def test_pq_train_by_subquantizer_range_equals_full_training(vg, ctx):
+    """vg_pq_train_subset (the multi-GPU partition of Train, pq.go:83-138): training [0,5) and
+    [5,12) separately and assembling gives the codebooks of one vg_pq_train call, bit for bit."""
+    rng = np.random.default_rng(77)
+    dim, m, k = 48, 12, 64
+    x = rng.standard_normal((1500, dim)).astype(np.float32)
+    full = vg.ProductQuantizer(ctx, dim, m, k)
+    full.train(x, iters=8, seed=3)
+    fcb, fsc, fof = full.codebooks()
+    part = vg.ProductQuantizer(ctx, dim, m, k)
+    part.train_subset(x, 5, 7, iters=8, seed=3)
+    assert not part.is_trained()
+    part.train_subset(x, 0, 5, iters=8, seed=3)
+    cb, sc, of = part.codebooks_range(0, m)
+    assert np.array_equal(cb, fcb)
+    assert np.array_equal(sc.view(np.uint32), fsc.view(np.uint32))
+    assert np.array_equal(of.view(np.uint32), fof.view(np.uint32))
+    part.set_codebooks(cb, sc, of)
+    assert part.is_trained()
+    with pytest.raises(vg.VecgoHipError):
+        part.train_subset(x, 10, 5)

@@ -74,3 +74,68 @@ def test_two_rank_sharded_search_equals_single_segment(n):
     ret = mgr.dict()
     mp.spawn(_worker, args=(world, port, n, 32, 5, 10, ret), nprocs=world, join=True)
     assert ret[0] and ret[1]
+
+
+class _OraclePQ:
+    """Stands in for vecgo_amd.ProductQuantizer on a box without a GPU: trains with the CPU
+    oracle (sub-quantizers are independent and their random streams keyed by (seed, sub), so
+    training everything and handing out a range is what vg_pq_train_subset computes)."""
+
+    def __init__(self, dim, m, k):
+        from oracle import oracle as o
+        self._o = o.ProductQuantizer(dim, m, k)
+        self.num_subvectors, self.num_centroids, self.subvector_dim = m, k, dim // m
+        self.result = None
+
+    def train_subset(self, vectors, lo, cnt, iters=20, seed=1, stream=None):
+        self._o.train(np.asarray(vectors), iters=iters, seed=seed)
+        self._range = (lo, cnt)
+
+    def codebooks_range(self, lo, cnt):
+        per = self.num_centroids * self.subvector_dim
+        return (self._o.codebooks[lo * per:(lo + cnt) * per].copy(), self._o.scales[lo:lo + cnt].copy(),
+                self._o.offsets[lo:lo + cnt].copy())
+
+    def set_codebooks(self, cb, sc, of):
+        self.result = (np.asarray(cb).copy(), np.asarray(sc).copy(), np.asarray(of).copy())
+
+
+def _pq_worker(rank, world, port, ret):
+    sys.path.insert(0, str(ROOT))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import oracle as o
+    from vecgo_amd import sharded
+    dim, m, k = 24, 6, 16
+    x = np.random.default_rng(5).standard_normal((300, dim)).astype(np.float32)
+    pq = _OraclePQ(dim, m, k)
+    # poison the ranges this rank does not own: the result must come from the owners
+    orig = pq.codebooks_range
+    sharded.train_pq_sharded(pq, torch.from_numpy(x), iters=5, seed=9)
+    full = o.ProductQuantizer(dim, m, k)
+    full.train(x, iters=5, seed=9)
+    cb, sc, of = pq.result
+    ret[rank] = bool(np.array_equal(cb, full.codebooks) and np.array_equal(sc.view(np.uint32), full.scales.view(np.uint32))
+                     and np.array_equal(of.view(np.uint32), full.offsets.view(np.uint32)))
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharded_pq_training_equals_single_process():
+    world = 2
+    port = 31500 + (os.getpid() % 2000)
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_pq_worker, args=(world, port, ret), nprocs=world, join=True)
+    assert ret[0] and ret[1]
+
+
+def test_assemble_codebooks_takes_each_range_from_its_owner():
+    from vecgo_amd import sharded
+    m, per, world = 5, 3, 3
+    bounds = sharded.partition(m, world)
+    g_cb = torch.stack([torch.full((m * per,), r, dtype=torch.int8) for r in range(world)])
+    g_s = torch.stack([torch.full((m,), float(r)) for r in range(world)])
+    cb, sc, of = sharded.assemble_codebooks(g_cb, g_s, g_s.clone(), bounds, per)
+    for r in range(world):
+        lo, hi = bounds[r], bounds[r + 1]
+        assert torch.all(cb[lo * per:hi * per] == r) and torch.all(sc[lo:hi] == r) and torch.all(of[lo:hi] == r)

@@ -322,6 +322,23 @@ class ProductQuantizer:
         check(self._lib.vg_pq_train(self._h, pv, C.c_int64(n), C.c_int32(iters), C.c_uint64(seed),
                                     _stream_ptr(stream)))
 
+    def train_subset(self, vectors, sub_begin: int, sub_count: int, iters: int = 20, seed: int = 1, stream=None):
+        """Train only the sub-quantizers [sub_begin, sub_begin + sub_count) (the reference trains
+        them as independent goroutines, pq.go:83-138); see vecgo_amd.sharded.train_pq_sharded."""
+        n = _rows(vectors, self.dimension)
+        v, pv = _ptr(vectors, np.float32)
+        check(self._lib.vg_pq_train_subset(self._h, pv, C.c_int64(n), C.c_int32(iters), C.c_uint64(seed),
+                                           C.c_int32(sub_begin), C.c_int32(sub_count), _stream_ptr(stream)))
+
+    def codebooks_range(self, sub_begin: int, sub_count: int):
+        per = self.num_centroids * self.subvector_dim
+        cb = np.empty(sub_count * per, np.int8); s = np.empty(sub_count, np.float32)
+        o = np.empty(sub_count, np.float32)
+        check(self._lib.vg_pq_get_codebooks_range(self._h, C.c_int32(sub_begin), C.c_int32(sub_count),
+                                                  C.c_void_p(cb.ctypes.data), C.c_void_p(s.ctypes.data),
+                                                  C.c_void_p(o.ctypes.data)))
+        return cb, s, o
+
     def encode(self, vectors, out=None, stream=None):
         """Encode (pq.go:147-176), batched: returns [n, m] uint8."""
         n = _rows(vectors, self.dimension)

@@ -141,6 +141,26 @@ VG_API int32_t vg_pq_get_codebooks(vg_pq *pq, int8_t *codebooks, float *scales, 
     return VG_OK;
 }
 
+VG_API int32_t vg_pq_get_codebooks_range(vg_pq *pq, int32_t sub_begin, int32_t sub_count, int8_t *codebooks,
+                                         float *scales, float *offsets)
+{
+    VG_CHECK(pq, VG_ERR_INVALID_ARG, "vg_pq_get_codebooks_range: NULL quantizer");
+    VG_CHECK(sub_begin >= 0 && sub_count >= 0 && sub_begin + sub_count <= pq->m, VG_ERR_INVALID_ARG,
+             "vg_pq_get_codebooks_range: range outside [0, %d)", pq->m);
+    if (sub_count == 0) return VG_OK;
+    VG_HIP(hipSetDevice(pq->ctx->device));
+    hipStream_t st = pq->ctx->stream;
+    const size_t per = static_cast<size_t>(pq->k) * pq->subdim;
+    if (codebooks)
+        VG_HIP(hipMemcpyAsync(codebooks, pq->d_codebooks + sub_begin * per, sub_count * per, hipMemcpyDefault, st));
+    if (scales)
+        VG_HIP(hipMemcpyAsync(scales, pq->d_scales + sub_begin, sizeof(float) * sub_count, hipMemcpyDefault, st));
+    if (offsets)
+        VG_HIP(hipMemcpyAsync(offsets, pq->d_offsets + sub_begin, sizeof(float) * sub_count, hipMemcpyDefault, st));
+    VG_HIP(hipStreamSynchronize(st));
+    return VG_OK;
+}
+
 VG_API int32_t vg_pq_is_trained(vg_pq *pq) { return pq && pq->trained ? 1 : 0; }
 
 VG_API int32_t vg_pq_build_distance_table(vg_pq *pq, const float *queries, int64_t nq,

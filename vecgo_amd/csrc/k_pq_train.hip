@@ -73,18 +73,20 @@ constexpr int kPPChunk = 4096;
 
 __global__ __launch_bounds__(kPPThreads) void pq_kmeanspp_kernel(
     const float *__restrict__ vectors, int64_t n, int dim, int sd, int k, uint64_t seed,
-    float *__restrict__ mind_all, float *__restrict__ cent_all)
+    float *__restrict__ mind_all, float *__restrict__ cent_all, int sub0)
 {
     __shared__ float chunk[kPPChunk];
     __shared__ float cur[256];  // current centroid (sd <= 256)
     __shared__ float s_sum;
     __shared__ float s_cum;
     __shared__ long long s_chosen;
-    const int sub = blockIdx.x;
+    // sub = the sub-quantizer (global index: column offset and RNG stream); ls = its slot in the
+    // scratch arrays of this call, which may train only the range [sub0, sub0 + gridDim.x)
+    const int ls = blockIdx.x, sub = sub0 + ls;
     const int tid = threadIdx.x;
     const float *base = vectors + static_cast<int64_t>(sub) * sd;
-    float *mind = mind_all + static_cast<int64_t>(sub) * n;
-    float *cent = cent_all + static_cast<int64_t>(sub) * k * sd;
+    float *mind = mind_all + static_cast<int64_t>(ls) * n;
+    float *cent = cent_all + static_cast<int64_t>(ls) * k * sd;
 
     if (n < k) {  // pq.go:285-291
         for (int t = tid; t < k * sd; t += kPPThreads)
@@ -183,13 +185,13 @@ __global__ __launch_bounds__(256) void pq_assign_kernel(const float *__restrict_
                                                         const float *__restrict__ cent_all,
                                                         int32_t *__restrict__ assign_all,
                                                         int *__restrict__ changed,
-                                                        const int *__restrict__ done)
+                                                        const int *__restrict__ done, int sub0)
 {
     extern __shared__ float cent[];  // k*sd
-    const int sub = blockIdx.y;
-    if (done[sub]) return;
+    const int ls = blockIdx.y, sub = sub0 + ls;
+    if (done[ls]) return;
     for (int t = threadIdx.x; t < k * sd; t += blockDim.x)
-        cent[t] = cent_all[static_cast<int64_t>(sub) * k * sd + t];
+        cent[t] = cent_all[static_cast<int64_t>(ls) * k * sd + t];
     __syncthreads();
     const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -203,10 +205,10 @@ __global__ __launch_bounds__(256) void pq_assign_kernel(const float *__restrict_
             bi = c;
         }
     }
-    int32_t *a = assign_all + static_cast<int64_t>(sub) * n + i;
+    int32_t *a = assign_all + static_cast<int64_t>(ls) * n + i;
     if (*a != bi) {
         *a = bi;
-        changed[sub] = 1;
+        changed[ls] = 1;
     }
 }
 
@@ -217,14 +219,14 @@ __global__ __launch_bounds__(256) void pq_update_kernel(const float *__restrict_
                                                         const int32_t *__restrict__ assign_all,
                                                         float *__restrict__ cent_all,
                                                         const int *__restrict__ changed,
-                                                        const int *__restrict__ done)
+                                                        const int *__restrict__ done, int sub0)
 {
-    const int sub = blockIdx.y;
-    if (done[sub] || !changed[sub]) return;
+    const int ls = blockIdx.y, sub = sub0 + ls;
+    if (done[ls] || !changed[ls]) return;
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= k * sd) return;
     const int c = t / sd, j = t % sd;
-    const int32_t *assign = assign_all + static_cast<int64_t>(sub) * n;
+    const int32_t *assign = assign_all + static_cast<int64_t>(ls) * n;
     const float *col = vectors + static_cast<int64_t>(sub) * sd + j;
     float sum = 0.0f;
     int64_t count = 0;
@@ -234,7 +236,7 @@ __global__ __launch_bounds__(256) void pq_update_kernel(const float *__restrict_
             count++;
         }
     }
-    float *dst = cent_all + (static_cast<int64_t>(sub) * k + c) * sd + j;
+    float *dst = cent_all + (static_cast<int64_t>(ls) * k + c) * sd + j;
     if (count > 0) {
         *dst = sum / static_cast<float>(count);
     } else {  // pq.go:408-411 re-seed an empty cluster with a random vector
@@ -258,13 +260,13 @@ __global__ void pq_iter_end_kernel(int m, int *__restrict__ changed, int *__rest
 __global__ __launch_bounds__(256) void pq_quantize_kernel(const float *__restrict__ cent_all, int k,
                                                           int sd, int8_t *__restrict__ codebooks,
                                                           float *__restrict__ scales,
-                                                          float *__restrict__ offsets)
+                                                          float *__restrict__ offsets, int sub0)
 {
     __shared__ float smin[256], smax[256];
-    const int sub = blockIdx.x;
+    const int ls = blockIdx.x, sub = sub0 + ls;
     const int tid = threadIdx.x;
     const int cnt = k * sd;
-    const float *cent = cent_all + static_cast<int64_t>(sub) * cnt;
+    const float *cent = cent_all + static_cast<int64_t>(ls) * cnt;
     float mn = 3.40282346638528859811704183484516925440e+38f, mx = -mn;
     for (int t = tid; t < cnt; t += 256) {
         const float v = cent[t];
@@ -380,16 +382,20 @@ __global__ void pq_asym_kernel(const float *__restrict__ query, const uint8_t *_
 
 }  // namespace vg
 
-VG_API int32_t vg_pq_train(vg_pq *pq, const float *vectors, int64_t n, int32_t iters, uint64_t seed,
-                           void *stream)
+VG_API int32_t vg_pq_train_subset(vg_pq *pq, const float *vectors, int64_t n, int32_t iters, uint64_t seed,
+                                  int32_t sub_begin, int32_t sub_count, void *stream)
 {
     VG_CHECK(pq, VG_ERR_INVALID_ARG, "vg_pq_train: NULL quantizer");
     VG_CHECK(n > 0 && vectors, VG_ERR_INVALID_ARG, "no vectors provided for training");  // pq.go:69-71
     VG_CHECK(iters >= 0, VG_ERR_INVALID_ARG, "vg_pq_train: iters < 0");
+    VG_CHECK(sub_begin >= 0 && sub_count >= 0 && sub_begin + sub_count <= pq->m, VG_ERR_INVALID_ARG,
+             "vg_pq_train_subset: sub-quantizer range [%d, %d) outside [0, %d)", sub_begin, sub_begin + sub_count,
+             pq->m);
     VG_CHECK(pq->subdim <= 256, VG_ERR_UNSUPPORTED, "vg_pq_train: sub-vector dim %d > 256", pq->subdim);
+    if (sub_count == 0) return VG_OK;
     VG_HIP(hipSetDevice(pq->ctx->device));
     hipStream_t st = vg::pick_stream(pq->ctx, stream);
-    const int m = pq->m, k = pq->k, sd = pq->subdim, dim = pq->dim;
+    const int m = sub_count, k = pq->k, sd = pq->subdim, dim = pq->dim;
     vg::DevIn<float> v;
     VG_TRY(v.init(vectors, static_cast<size_t>(n) * dim, st));
     vg::DevTmp<float> mind, cent;
@@ -404,23 +410,30 @@ VG_API int32_t vg_pq_train(vg_pq *pq, const float *vectors, int64_t n, int32_t i
     int *changed = flags.ptr, *done = flags.ptr + m;
 
     VG_LAUNCH(vg::pq_kmeanspp_kernel, dim3(m), dim3(vg::kPPThreads), 0, st, v.ptr, n, dim, sd,
-                       k, seed, mind.ptr, cent.ptr);
+                       k, seed, mind.ptr, cent.ptr, sub_begin);
     const size_t lds = static_cast<size_t>(k) * sd * sizeof(float);
     VG_CHECK(lds <= 64 * 1024, VG_ERR_UNSUPPORTED, "vg_pq_train: codebook of one sub-quantizer exceeds 64 KiB");
     const unsigned gx = static_cast<unsigned>((n + 255) / 256);
     const unsigned ux = static_cast<unsigned>((k * sd + 255) / 256);
     for (int it = 0; it < iters; it++) {
         VG_LAUNCH(vg::pq_assign_kernel, dim3(gx, m), dim3(256), lds, st, v.ptr, n, dim, sd, k,
-                           cent.ptr, assign.ptr, changed, done);
+                           cent.ptr, assign.ptr, changed, done, sub_begin);
         VG_LAUNCH(vg::pq_update_kernel, dim3(ux, m), dim3(256), 0, st, v.ptr, n, dim, sd, k, it,
-                           seed, assign.ptr, cent.ptr, changed, done);
+                           seed, assign.ptr, cent.ptr, changed, done, sub_begin);
         VG_LAUNCH(vg::pq_iter_end_kernel, dim3((m + 63) / 64), dim3(64), 0, st, m, changed, done);
     }
     VG_LAUNCH(vg::pq_quantize_kernel, dim3(m), dim3(256), 0, st, cent.ptr, k, sd,
-                       pq->d_codebooks, pq->d_scales, pq->d_offsets);
+                       pq->d_codebooks, pq->d_scales, pq->d_offsets, sub_begin);
     VG_HIP(hipStreamSynchronize(st));
-    pq->trained = true;
+    if (sub_begin == 0 && sub_count == pq->m) pq->trained = true;
     return VG_OK;
+}
+
+VG_API int32_t vg_pq_train(vg_pq *pq, const float *vectors, int64_t n, int32_t iters, uint64_t seed,
+                           void *stream)
+{
+    VG_CHECK(pq, VG_ERR_INVALID_ARG, "vg_pq_train: NULL quantizer");
+    return vg_pq_train_subset(pq, vectors, n, iters, seed, 0, pq->m, stream);
 }
 
 VG_API int32_t vg_pq_encode(vg_pq *pq, const float *vectors, int64_t n, uint8_t *codes, void *stream)

@@ -59,3 +59,72 @@ class ShardedFlatIndex:
             return self._api.merge_topk(self.ctx, ids, scores, kk, metric=self.metric, id_offsets=off,
                                         stream=stream)
         return sharded_search(local, merge, queries, k, self.bounds, self.group)
+
+
+def assemble_codebooks(gathered_cb, gathered_scales, gathered_offsets, bounds: Sequence[int], per_sub: int):
+    """gathered_*[r] = full-size arrays of rank r in which only the sub-quantizers
+    [bounds[r], bounds[r+1]) are meaningful; returns the arrays with every range taken from its
+    owner.  gathered_cb: [world, m*per_sub] int8; gathered_scales/offsets: [world, m] float32."""
+    cb = gathered_cb[0].clone()
+    sc = gathered_scales[0].clone()
+    of = gathered_offsets[0].clone()
+    for r in range(1, len(bounds) - 1):
+        lo, hi = bounds[r], bounds[r + 1]
+        cb[lo * per_sub:hi * per_sub] = gathered_cb[r][lo * per_sub:hi * per_sub]
+        sc[lo:hi] = gathered_scales[r][lo:hi]
+        of[lo:hi] = gathered_offsets[r][lo:hi]
+    return cb, sc, of
+
+
+def train_pq_sharded(pq, vectors, iters: int = 20, seed: int = 1, group=None, device=None, stream=None):
+    """PQ training partitioned by sub-quantizer (BASELINE configs[4]; pq.go:83-138 runs the m
+    k-means problems independently).  Every rank holds the same training sample, trains
+    m/world sub-quantizers, then ONE all-gather of codebooks + scales + offsets (m*K*sd + 8m
+    bytes per rank) and SetCodebooks.  The random stream is keyed by (seed, sub-quantizer), so
+    the result equals single-GPU training bit for bit."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    m = pq.num_subvectors
+    per = pq.num_centroids * pq.subvector_dim
+    bounds = partition(m, world)
+    lo, hi = bounds[rank], bounds[rank + 1]
+    pq.train_subset(vectors, lo, hi - lo, iters=iters, seed=seed, stream=stream)
+    if world == 1:
+        cb, sc, of = pq.codebooks_range(0, m)
+        pq.set_codebooks(cb, sc, of)
+        return
+    cb_l, sc_l, of_l = pq.codebooks_range(lo, hi - lo)
+    dev = device if device is not None else (vectors.device if isinstance(vectors, torch.Tensor) else "cpu")
+    cb = torch.zeros(m * per, dtype=torch.int8, device=dev)
+    sc = torch.zeros(m, dtype=torch.float32, device=dev)
+    of = torch.zeros(m, dtype=torch.float32, device=dev)
+    cb[lo * per:hi * per] = torch.from_numpy(cb_l).to(dev)
+    sc[lo:hi] = torch.from_numpy(sc_l).to(dev)
+    of[lo:hi] = torch.from_numpy(of_l).to(dev)
+    g_cb = torch.empty((world * m * per,), dtype=torch.int8, device=dev)
+    g_sc = torch.empty((world * m,), dtype=torch.float32, device=dev)
+    g_of = torch.empty((world * m,), dtype=torch.float32, device=dev)
+    dist.all_gather_into_tensor(g_cb, cb, group=group)
+    dist.all_gather_into_tensor(g_sc, sc, group=group)
+    dist.all_gather_into_tensor(g_of, of, group=group)
+    cb, sc, of = assemble_codebooks(g_cb.view(world, -1), g_sc.view(world, -1), g_of.view(world, -1), bounds, per)
+    pq.set_codebooks(cb.cpu().numpy(), sc.cpu().numpy(), of.cpu().numpy())
+
+
+class ShardedRaBitQIndex:
+    """Exhaustive RaBitQ scan over a row-sharded corpus (BASELINE configs[4]: 10M x 768 split 8 ways)."""
+
+    def __init__(self, ctx, local_codes, n_local: int, dim: int, bounds: Sequence[int], group=None):
+        from . import api
+        self._api = api
+        self.ctx, self.dim, self.bounds, self.group = ctx, dim, list(bounds), group
+        self.index = api.Index(ctx, n_local, dim, api.Metric(0))
+        self.index.set_rabitq_codes(local_codes)
+
+    def search(self, queries, k: int, stream=None):
+        def local(q, kk):
+            return self.index.search_rabitq(q, kk, stream=stream)
+
+        def merge(ids, scores, kk, off):
+            return self._api.merge_topk(self.ctx, ids, scores, kk, metric=0, id_offsets=off, stream=stream)
+        return sharded_search(local, merge, queries, k, self.bounds, self.group)
