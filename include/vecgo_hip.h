@@ -69,6 +69,7 @@ typedef enum vg_metric {
 typedef struct vg_ctx vg_ctx;     /* one per (process, GPU) */
 typedef struct vg_pq vg_pq;       /* quantization.ProductQuantizer — pq.go:20-29 */
 typedef struct vg_index vg_index; /* device-resident rows / codes / graph of one segment */
+typedef struct vg_sq8 vg_sq8;     /* quantization.ScalarQuantizer — quantizer.go:27-39 */
 
 /* ---- context ------------------------------------------------------------ */
 int32_t vg_abi_version(void);
@@ -263,6 +264,34 @@ int32_t vg_index_flat_stats(vg_index *idx, int64_t *queries, int64_t *exhaustive
  * (SURVEY.md §8d).  k <= 64. */
 int32_t vg_search_rabitq(vg_index *idx, const float *queries, int64_t nq, int32_t k, uint32_t *ids,
                          float *scores, void *stream);
+
+/* ---- SQ8 (internal/quantization/quantizer.go, internal/simd/src/sq8_avx512.c) ---------- */
+/* NewScalarQuantizer quantizer.go:119-125 */
+int32_t vg_sq8_create(vg_ctx *ctx, int32_t dim, vg_sq8 **out);
+int32_t vg_sq8_destroy(vg_sq8 *sq);
+int32_t vg_sq8_is_trained(vg_sq8 *sq);
+/* Train quantizer.go:127-180: per-dimension min / max over vectors[n*dim]; a constant dimension
+ * gets max = min + 1e-6; scale = 255 / range, invScale = range / 255 */
+int32_t vg_sq8_train(vg_sq8 *sq, const float *vectors, int64_t n, void *stream);
+/* SetBounds quantizer.go:52-78 (max - min < 1e-9 zeroes both scales) */
+int32_t vg_sq8_set_bounds(vg_sq8 *sq, const float *mins, const float *maxs);
+/* Mins / Maxs and the derived scales, dim floats each (any pointer may be NULL) */
+int32_t vg_sq8_get_params(vg_sq8 *sq, float *mins, float *maxs, float *scales, float *inv_scales);
+/* EncodeInto quantizer.go:198-222, batched: codes[n*dim] = uint8((clamp(v) - min) * scale + 0.5) */
+int32_t vg_sq8_encode(vg_sq8 *sq, const float *vectors, int64_t n, uint8_t *codes, void *stream);
+/* DecodeInto quantizer.go:240-250, batched: out[n*dim] = float32(code) * invScale + min */
+int32_t vg_sq8_decode(vg_sq8 *sq, const uint8_t *codes, int64_t n, float *out, void *stream);
+/* L2DistanceBatch quantizer.go:93-106 = simd.Sq8uL2BatchPerDimension in
+ * sq8uL2BatchPerDimensionAvx512 order (sq8_avx512.c:59-103): out[n] */
+int32_t vg_sq8_l2_distance_batch(vg_sq8 *sq, const float *query, const uint8_t *codes, int64_t n,
+                                 float *out, void *stream);
+/* codes[n*dim] in the reference's row-major layout (flat/segment.go s.codes); re-tiled on the
+ * device for the scan.  The quantizer must outlive the index. */
+int32_t vg_index_set_sq8_codes(vg_index *idx, vg_sq8 *sq, const uint8_t *codes, void *stream);
+/* flat.Segment.Search, SQ8 branch (flat/segment.go:517-604, L2 only): L2DistanceBatch of every
+ * row, best k by (Score, RowID).  k <= 64. */
+int32_t vg_search_sq8(vg_index *idx, const float *queries, int64_t nq, int32_t k, uint32_t *ids,
+                      float *scores, void *stream);
 
 /* per-query counters, the reference's FilterGateStats (searcher/searcher.go:114-137) */
 typedef struct vg_search_stats {

@@ -243,6 +243,85 @@ private:
     int dim_;
 };
 
+// quantization.ScalarQuantizer (quantizer.go:27-39)
+class ScalarQuantizer : public Quantizer {
+public:
+    // NewScalarQuantizer (quantizer.go:119-125)
+    ScalarQuantizer(std::shared_ptr<Context> ctx, int dimension) : ctx_(std::move(ctx)), dim_(dimension)
+    {
+        check(vg_sq8_create(ctx_->handle(), dimension, &h_));
+    }
+    ~ScalarQuantizer() override { vg_sq8_destroy(h_); }
+    vg_sq8 *handle() const { return h_; }
+    bool IsTrained() const { return vg_sq8_is_trained(h_) != 0; }
+
+    // Train (quantizer.go:127-180)
+    void Train(const std::vector<std::vector<float>> &vectors) override
+    {
+        if (vectors.empty()) throw Error(VG_ERR_INVALID_ARG, "no vectors provided for training");
+        if (static_cast<int>(vectors[0].size()) != dim_) throw Error(VG_ERR_DIM_MISMATCH, "vector dimension mismatch");
+        std::vector<float> flat;
+        flat.reserve(vectors.size() * static_cast<size_t>(dim_));
+        for (const auto &v : vectors) {
+            if (static_cast<int>(v.size()) != dim_) throw Error(VG_ERR_DIM_MISMATCH, "inconsistent vector dimension");
+            flat.insert(flat.end(), v.begin(), v.end());
+        }
+        check(vg_sq8_train(h_, flat.data(), static_cast<int64_t>(vectors.size()), nullptr));
+    }
+    // SetBounds (quantizer.go:52-78)
+    void SetBounds(const std::vector<float> &mins, const std::vector<float> &maxs)
+    {
+        if (static_cast<int>(mins.size()) != dim_ || static_cast<int>(maxs.size()) != dim_)
+            throw Error(VG_ERR_DIM_MISMATCH, "dimension mismatch");
+        check(vg_sq8_set_bounds(h_, mins.data(), maxs.data()));
+    }
+    std::vector<float> Mins() const
+    {
+        std::vector<float> v(static_cast<size_t>(dim_));
+        check(vg_sq8_get_params(h_, v.data(), nullptr, nullptr, nullptr));
+        return v;
+    }
+    std::vector<float> Maxs() const
+    {
+        std::vector<float> v(static_cast<size_t>(dim_));
+        check(vg_sq8_get_params(h_, nullptr, v.data(), nullptr, nullptr));
+        return v;
+    }
+    // Encode / Decode (quantizer.go:183-250)
+    std::vector<uint8_t> Encode(const std::vector<float> &v) override
+    {
+        if (!IsTrained()) throw Error(VG_ERR_NOT_TRAINED, "ScalarQuantizer not trained");
+        if (static_cast<int>(v.size()) != dim_) throw Error(VG_ERR_DIM_MISMATCH, "vector dimension mismatch");
+        std::vector<uint8_t> out(static_cast<size_t>(dim_));
+        check(vg_sq8_encode(h_, v.data(), 1, out.data(), nullptr));
+        return out;
+    }
+    std::vector<float> Decode(const std::vector<uint8_t> &b) override
+    {
+        if (!IsTrained()) throw Error(VG_ERR_NOT_TRAINED, "ScalarQuantizer not trained");
+        if (static_cast<int>(b.size()) != dim_) throw Error(VG_ERR_DIM_MISMATCH, "vector dimension mismatch");
+        std::vector<float> out(static_cast<size_t>(dim_));
+        check(vg_sq8_decode(h_, b.data(), 1, out.data(), nullptr));
+        return out;
+    }
+    // L2DistanceBatch (quantizer.go:93-106)
+    void L2DistanceBatch(const std::vector<float> &q, const std::vector<uint8_t> &codes, int n, std::vector<float> &out)
+    {
+        if (static_cast<int>(q.size()) != dim_) throw Error(VG_ERR_DIM_MISMATCH, "query dimension mismatch");
+        if (static_cast<int64_t>(codes.size()) < static_cast<int64_t>(n) * dim_)
+            throw Error(VG_ERR_INVALID_ARG, "codes buffer too small");
+        if (static_cast<int>(out.size()) < n) throw Error(VG_ERR_INVALID_ARG, "output buffer too small");
+        check(vg_sq8_l2_distance_batch(h_, q.data(), codes.data(), n, out.data(), nullptr));
+    }
+    int BytesPerDimension() const override { return 1; }
+    double CompressionRatio() const { return 4.0; }
+
+private:
+    std::shared_ptr<Context> ctx_;
+    int dim_;
+    vg_sq8 *h_ = nullptr;
+};
+
 }  // namespace quantization
 
 namespace kmeans {

@@ -110,6 +110,11 @@ _sig("vgo_flat_search_f32", C.c_int32, _f32p, C.c_int64, C.c_int32, C.c_int32, _
      _u32p, _f32p)
 _sig("vgo_flat_search_pq", C.c_int32, C.POINTER(PQ), _u8p, C.c_int64, _f32p, C.c_int32, _u32p, _f32p)
 _sig("vgo_flat_search_rabitq", C.c_int32, _u8p, C.c_int64, C.c_int32, _f32p, C.c_int32, _u32p, _f32p)
+_sig("vgo_sq8u_l2_batch", None, _f32p, _u8p, _f32p, _f32p, C.c_int64, C.c_int64, _f32p)
+_sig("vgo_sq8_train", None, _f32p, C.c_int64, C.c_int32, _f32p, _f32p, _f32p, _f32p)
+_sig("vgo_sq8_encode", None, _f32p, C.c_int32, _f32p, _f32p, _f32p, _u8p)
+_sig("vgo_sq8_decode", None, _u8p, C.c_int32, _f32p, _f32p, _f32p)
+_sig("vgo_flat_search_sq8", C.c_int32, _u8p, C.c_int64, C.c_int32, _f32p, _f32p, _f32p, C.c_int32, _u32p, _f32p)
 _sig("vgo_rerank_f32", None, _f32p, C.c_int32, C.c_int32, _f32p, _u32p, C.c_int32, _f32p)
 _sig("vgo_hnsw_search", C.c_int32, C.POINTER(HnswGraph), _f32p, C.c_int32, C.c_int32, _u32p,
      _f32p, C.POINTER(SearchStats))
@@ -347,6 +352,60 @@ def rng_u64(seed, a, b, c):
     return int(lib.vgo_rng_u64(seed, a, b, c))
 
 
+# ---- SQ8 ----------------------------------------------------------------------
+def sq8u_l2_batch(query, codes, mins, inv_scales, dim):
+    q, pq_ = _f(query); c, pc = _u8(codes); mn, pm = _f(mins); iv, pi = _f(inv_scales)
+    n = c.size // dim if dim else 0
+    out = np.zeros(n, np.float32)
+    if n and dim:  # kernels_amd64.go:363-375: nothing happens for an empty batch
+        lib.vgo_sq8u_l2_batch(pq_, pc, pm, pi, dim, n, out.ctypes.data_as(_f32p))
+    return out
+
+
+class ScalarQuantizer:
+    """Oracle-side quantization.ScalarQuantizer (internal/quantization/quantizer.go:27-250)."""
+
+    def __init__(self, dim):
+        self.dim = dim
+        self.mins = np.zeros(dim, np.float32); self.maxs = np.zeros(dim, np.float32)
+        self.scales = np.zeros(dim, np.float32); self.inv_scales = np.zeros(dim, np.float32)
+        self.trained = False
+
+    def train(self, vectors):
+        v, pv = _f(vectors)
+        lib.vgo_sq8_train(pv, v.size // self.dim, self.dim, self.mins.ctypes.data_as(_f32p),
+                          self.maxs.ctypes.data_as(_f32p), self.scales.ctypes.data_as(_f32p),
+                          self.inv_scales.ctypes.data_as(_f32p))
+        self.trained = True
+
+    def encode(self, vec):
+        v, pv = _f(vec)
+        out = np.empty(self.dim, np.uint8)
+        lib.vgo_sq8_encode(pv, self.dim, self.mins.ctypes.data_as(_f32p), self.maxs.ctypes.data_as(_f32p),
+                           self.scales.ctypes.data_as(_f32p), out.ctypes.data_as(_u8p))
+        return out
+
+    def encode_batch(self, vecs):
+        v = np.ascontiguousarray(vecs, np.float32).reshape(-1, self.dim)
+        return np.stack([self.encode(r) for r in v]) if len(v) else np.zeros((0, self.dim), np.uint8)
+
+    def decode(self, code):
+        c, pc = _u8(code)
+        out = np.empty(self.dim, np.float32)
+        lib.vgo_sq8_decode(pc, self.dim, self.mins.ctypes.data_as(_f32p), self.inv_scales.ctypes.data_as(_f32p),
+                           out.ctypes.data_as(_f32p))
+        return out
+
+
+def flat_search_sq8(sq: ScalarQuantizer, codes, query, k):
+    c, pc = _u8(codes); q, pq_ = _f(query)
+    n = c.size // sq.dim
+    ids = np.empty(k, np.uint32); sc = np.empty(k, np.float32)
+    r = lib.vgo_flat_search_sq8(pc, n, sq.dim, sq.mins.ctypes.data_as(_f32p), sq.inv_scales.ctypes.data_as(_f32p),
+                                pq_, k, ids.ctypes.data_as(_u32p), sc.ctypes.data_as(_f32p))
+    return ids[:r], sc[:r]
+
+
 # ---- scans --------------------------------------------------------------------
 def flat_search_f32(base, dim, query, k, metric=METRIC_L2):
     b, pb = _f(base); q, pq_ = _f(query)
@@ -463,6 +522,9 @@ def load_ref():
     for n in ("dotProductAvx512", "squaredL2Avx512", "squaredL2BatchAvx512", "dotBatchAvx512",
               "squaredL2BoundedAvx512", "pqAdcLookupAvx512"):
         getattr(r, n).restype = None
+    if hasattr(r, "sq8uL2BatchPerDimensionAvx512"):  # sq8_avx512.c joined the recipe later
+        r.sq8uL2BatchPerDimensionAvx512.argtypes = [vp, vp, vp, vp, C.c_int64, C.c_int64, vp]
+        r.sq8uL2BatchPerDimensionAvx512.restype = None
     return r
 
 
@@ -524,6 +586,16 @@ class Ref:
             self.lib.pqAdcLookupAvx512(t.ctypes.data, c.ctypes.data, m, r.ctypes.data,
                                        self._off.ctypes.data)
         return r[0]
+
+    def sq8u_l2_batch(self, query, codes, mins, inv_scales, dim):
+        q = np.ascontiguousarray(query, np.float32); c = np.ascontiguousarray(codes, np.uint8)
+        mn = np.ascontiguousarray(mins, np.float32); iv = np.ascontiguousarray(inv_scales, np.float32)
+        n = c.size // dim if dim else 0
+        out = np.zeros(n, np.float32)
+        if n and dim:
+            self.lib.sq8uL2BatchPerDimensionAvx512(q.ctypes.data, c.ctypes.data, mn.ctypes.data, iv.ctypes.data,
+                                                   dim, n, out.ctypes.data)
+        return out
 
     def hamming(self, a, b):
         a = np.ascontiguousarray(a, np.uint8); b = np.ascontiguousarray(b, np.uint8)

@@ -1184,3 +1184,101 @@ int32_t vgo_vamana_search(const vgo_vamana *v, const float *query, int32_t k, ui
     if (stats) *stats = st;
     return r;
 }
+
+/* ------------------------------------------------------------------ */
+/* SQ8                                           */
+/* ------------------------------------------------------------------ */
+/* internal/simd/src/sq8_avx512.c:59-103 sq8uL2BatchPerDimensionAvx512, one row: 16 lane
+ * accumulators over 16-element blocks (rec = fma(code, invScale, min); diff = q - rec;
+ * sum[l] = fma(diff, diff, sum[l])), _mm512_reduce_add_ps, then a scalar tail that clang
+ * contracts (rec = fma, total = fma(diff, diff, total)). */
+static float sq8u_l2_one(const float *q, const uint8_t *code, const float *mins, const float *inv, int64_t dim)
+{
+    float sum[16];
+    memset(sum, 0, sizeof sum);
+    int64_t j = 0;
+    for (; j <= dim - 16; j += 16)
+        for (int l = 0; l < 16; l++) {
+            float rec = FMA((float)code[j + l], inv[j + l], mins[j + l]);
+            float diff = q[j + l] - rec;
+            sum[l] = FMA(diff, diff, sum[l]);
+        }
+    float total = reduce16(sum);
+    for (; j < dim; j++) {
+        float rec = FMA((float)code[j], inv[j], mins[j]);
+        float diff = q[j] - rec;
+        total = FMA(diff, diff, total);
+    }
+    return total;
+}
+
+void vgo_sq8u_l2_batch(const float *query, const uint8_t *codes, const float *mins, const float *inv_scales,
+                       int64_t dim, int64_t n, float *out)
+{
+    for (int64_t i = 0; i < n; i++) out[i] = sq8u_l2_one(query, codes + i * dim, mins, inv_scales, dim);
+}
+
+/* internal/quantization/quantizer.go:127-180 ScalarQuantizer.Train: per-dimension min / max
+ * (a constant dimension gets max = min + 1e-6, :168-170), scale = 255 / range,
+ * invScale = range / 255 (fp32 divisions) */
+void vgo_sq8_train(const float *vectors, int64_t n, int32_t dim, float *mins, float *maxs, float *scales,
+                   float *inv_scales)
+{
+    for (int d = 0; d < dim; d++) {
+        mins[d] = 3.40282346638528859811704183484516925440e+38f;
+        maxs[d] = -3.40282346638528859811704183484516925440e+38f;
+    }
+    for (int64_t i = 0; i < n; i++)
+        for (int d = 0; d < dim; d++) {
+            float v = vectors[i * dim + d];
+            if (v < mins[d]) mins[d] = v;
+            if (v > maxs[d]) maxs[d] = v;
+        }
+    for (int d = 0; d < dim; d++) {
+        if (mins[d] == maxs[d]) maxs[d] = mins[d] + 1e-6f;
+        float range = maxs[d] - mins[d];
+        scales[d] = 255.0f / range;
+        inv_scales[d] = range / 255.0f;
+    }
+}
+
+/* quantizer.go:198-222 EncodeInto: clamp to [min, max], (val - min) * scale, uint8(x + 0.5)
+ * (Go float->uint8 conversion truncates; the value is within [0.5, 255.5]) */
+void vgo_sq8_encode(const float *v, int32_t dim, const float *mins, const float *maxs, const float *scales,
+                    uint8_t *out)
+{
+    for (int d = 0; d < dim; d++) {
+        float val = v[d];
+        if (val < mins[d]) val = mins[d];
+        else if (val > maxs[d]) val = maxs[d];
+        float normalized = (val - mins[d]) * scales[d];
+        float r = normalized + 0.5f;
+        out[d] = (uint8_t)(int32_t)r;
+    }
+}
+
+/* quantizer.go:240-250 DecodeInto: float32(code) * invScale + min (two roundings, Go does not fuse) */
+void vgo_sq8_decode(const uint8_t *code, int32_t dim, const float *mins, const float *inv_scales, float *out)
+{
+    for (int d = 0; d < dim; d++) {
+        float t = (float)code[d] * inv_scales[d];
+        out[d] = t + mins[d];
+    }
+}
+
+/* flat/segment.go:517-604: the SQ8 branch of Segment.Search (L2 only): L2DistanceBatch over
+ * 256-row batches, candidates pushed with the (Score, RowID) order */
+int32_t vgo_flat_search_sq8(const uint8_t *codes, int64_t n, int32_t dim, const float *mins,
+                            const float *inv_scales, const float *query, int32_t k, uint32_t *ids,
+                            float *scores)
+{
+    vgo_candheap h;
+    vgo_candheap_init(&h, k, 0);
+    for (int64_t i = 0; i < n; i++) {
+        float d = sq8u_l2_one(query, codes + i * dim, mins, inv_scales, dim);
+        vgo_candheap_try_push_bounded(&h, (vgo_cand){0, (uint32_t)i, d}, k);
+    }
+    int32_t r = emit_sorted(&h, ids, scores);
+    vgo_candheap_free(&h);
+    return r;
+}

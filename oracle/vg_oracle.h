@@ -176,6 +176,18 @@ typedef struct {
 int32_t vgo_vamana_search(const vgo_vamana *v, const float *query, int32_t k,
                           uint32_t *ids, float *scores, vgo_search_stats *stats);
 
+/* SQ8 (sq8_avx512.c:59-103, quantizer.go:27-250, flat/segment.go:517-604) */
+void vgo_sq8u_l2_batch(const float *query, const uint8_t *codes, const float *mins, const float *inv_scales,
+                       int64_t dim, int64_t n, float *out);
+void vgo_sq8_train(const float *vectors, int64_t n, int32_t dim, float *mins, float *maxs, float *scales,
+                   float *inv_scales);
+void vgo_sq8_encode(const float *v, int32_t dim, const float *mins, const float *maxs, const float *scales,
+                    uint8_t *out);
+void vgo_sq8_decode(const uint8_t *code, int32_t dim, const float *mins, const float *inv_scales, float *out);
+int32_t vgo_flat_search_sq8(const uint8_t *codes, int64_t n, int32_t dim, const float *mins,
+                            const float *inv_scales, const float *query, int32_t k, uint32_t *ids,
+                            float *scores);
+
 #ifdef __cplusplus
 }
 #endif

@@ -125,6 +125,27 @@ int main()
         EXPECT(status_of([&] { rq.Distance(q, std::vector<uint8_t>(5)); }) == VG_ERR_CODE_LENGTH);
     }
 
+    // ---- ScalarQuantizer (quantizer_test.go) ---------------------------------------------------
+    {
+        quantization::ScalarQuantizer sq(ctx, 3);
+        EXPECT(status_of([&] { sq.Encode({1.f, 2.f, 3.f}); }) == VG_ERR_NOT_TRAINED);
+        sq.Train({{-1.0f, 0.0f, 1.0f}, {-0.5f, 0.5f, 2.0f}, {-2.0f, 1.0f, 3.0f}});  // quantizer_test.go:8-37
+        auto mins = sq.Mins(), maxs = sq.Maxs();
+        EXPECT(mins[0] == -2.0f && maxs[0] == -0.5f && mins[2] == 1.0f && maxs[2] == 3.0f);
+        quantization::ScalarQuantizer sq4(ctx, 4);                                  // quantizer_test.go:230-271
+        sq4.SetBounds({0, 0, 0, 0}, {10, 10, 10, 10});
+        auto c1 = sq4.Encode({1, 2, 3, 4}), c2 = sq4.Encode({2, 3, 4, 5});
+        std::vector<uint8_t> codes(c1);
+        codes.insert(codes.end(), c2.begin(), c2.end());
+        std::vector<float> out(2);
+        sq4.L2DistanceBatch({1, 2, 3, 4}, codes, 2, out);
+        EXPECT(out[0] <= 0.1f && std::fabs(out[1] - 4.0f) <= 0.2f);
+        auto dec = sq4.Decode(sq4.Encode({-5.f, 5.f, 20.f, 10.f}));                 // clamping, :148-179
+        EXPECT(dec[0] >= -0.01f && dec[2] <= 10.01f && std::fabs(dec[1] - 5.f) <= 10.f / 255.f);
+        EXPECT(status_of([&] { sq4.Encode(std::vector<float>(3)); }) == VG_ERR_DIM_MISMATCH);
+        EXPECT(sq4.BytesPerDimension() == 1 && sq4.CompressionRatio() == 4.0);
+    }
+
     // ---- kmeans (kmeans_test.go) --------------------------------------------------------------
     {
         std::normal_distribution<float> nd;

@@ -1,0 +1,110 @@
+"""SQ8 on the GPU (quantizer.go, sq8_avx512.c, flat/segment.go:517-604) vs the oracle: codes,
+decoded values, distances and search results bit-exact."""
+import numpy as np
+import pytest
+
+from oracle import oracle as o
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(x):
+    return np.asarray(x, np.float32).view(np.uint32)
+
+
+@pytest.fixture(scope="module")
+def vg():
+    import vecgo_amd
+    return vecgo_amd
+
+
+@pytest.fixture(scope="module")
+def ctx(vg):
+    return vg.Context(0)
+
+
+@pytest.mark.parametrize("n,dim", [(500, 128), (300, 768), (257, 100), (64, 17), (5, 3), (1000, 16)])
+def test_train_encode_decode_match_oracle(vg, ctx, n, dim):
+    rng = np.random.default_rng(n + dim)
+    x = rng.standard_normal((n, dim)).astype(np.float32)
+    x[:, dim // 2] = 1.25  # a constant dimension: max = min + 1e-6 (quantizer.go:168-170)
+    sq = vg.ScalarQuantizer(ctx, dim)
+    assert not sq.is_trained()
+    with pytest.raises(vg.VecgoHipError):
+        sq.encode(x[:1])
+    sq.train(x)
+    ref = o.ScalarQuantizer(dim); ref.train(x)
+    mins, maxs, scales, inv = sq.params()
+    for a, b in ((mins, ref.mins), (maxs, ref.maxs), (scales, ref.scales), (inv, ref.inv_scales)):
+        assert np.array_equal(bits(a), bits(b))
+    y = np.vstack([x[:40], x[:3] * 10.0, x[:3] * -10.0]).astype(np.float32)  # incl. values to clamp
+    codes = sq.encode(y)
+    assert np.array_equal(codes, ref.encode_batch(y))
+    dec = sq.decode(codes)
+    assert np.array_equal(bits(dec), bits(np.stack([ref.decode(c) for c in codes])))
+
+
+def test_set_bounds_and_reference_kats(vg, ctx):
+    sq = vg.ScalarQuantizer(ctx, 5)
+    sq.set_bounds(np.full(5, -1.0, np.float32), np.full(5, 1.0, np.float32))
+    code = sq.encode(np.array([[-1.0, -0.5, 0.0, 0.5, 1.0]], np.float32))[0]
+    assert code[0] == 0 and code[4] == 255  # quantizer_test.go:39-86
+    dec = sq.decode(code)[0]
+    assert np.max(np.abs(dec - np.array([-1.0, -0.5, 0.0, 0.5, 1.0], np.float32))) <= (2.0 / 255.0) * 1.1
+    sq3 = vg.ScalarQuantizer(ctx, 3)
+    sq3.set_bounds(np.array([0, 0, 2], np.float32), np.array([1, 1, 2], np.float32))  # zero range: scales 0
+    _, _, scales, inv = sq3.params()
+    assert scales[2] == 0.0 and inv[2] == 0.0 and scales[0] == np.float32(255.0)
+    d = sq3.decode(sq3.encode(np.array([[-1.0, 0.5, 2.0]], np.float32)))[0]
+    assert d[0] >= -0.01 and d[1] <= 1.01  # clamping, quantizer_test.go:148-179
+
+
+@pytest.mark.parametrize("dim", [1, 7, 8, 15, 16, 17, 31, 32, 33, 100, 768])
+def test_l2_distance_batch_matches_oracle(vg, ctx, dim):
+    rng = np.random.default_rng(dim)
+    n = 300
+    x = rng.standard_normal((n, dim)).astype(np.float32)
+    sq = vg.ScalarQuantizer(ctx, dim); sq.train(x)
+    ref = o.ScalarQuantizer(dim); ref.train(x)
+    codes = sq.encode(x)
+    q = rng.standard_normal(dim).astype(np.float32)
+    got = sq.l2_distance_batch(q, codes)
+    want = o.sq8u_l2_batch(q, codes, ref.mins, ref.inv_scales, dim)
+    assert np.array_equal(bits(got), bits(want))
+
+
+@pytest.mark.parametrize("n,dim,nq,k", [(5000, 128, 6, 10), (3000, 768, 4, 10), (2000, 100, 3, 5),
+                                         (130, 24, 2, 64), (40, 16, 2, 10), (7, 5, 1, 10)])
+def test_search_sq8_matches_oracle(vg, ctx, n, dim, nq, k):
+    rng = np.random.default_rng(n + dim)
+    x = rng.standard_normal((n, dim)).astype(np.float32)
+    if n > 50:
+        x[37] = x[12]  # identical codes: tie broken by RowID
+    sq = vg.ScalarQuantizer(ctx, dim); sq.train(x)
+    ref = o.ScalarQuantizer(dim); ref.train(x)
+    codes = sq.encode(x)
+    idx = vg.Index(ctx, n, dim)
+    idx.set_sq8_codes(sq, codes)
+    q = rng.standard_normal((nq, dim)).astype(np.float32)
+    q[0] = x[12 % n] + 0.001
+    ids, sc = idx.search_sq8(q, k)
+    for i in range(nq):
+        eid, esc = o.flat_search_sq8(ref, codes, q[i], k)
+        r = eid.size
+        assert np.array_equal(ids[i, :r], eid), (i, ids[i], eid)
+        assert np.array_equal(bits(sc[i, :r]), bits(esc))
+        assert np.all(ids[i, r:] == 0xFFFFFFFF)
+
+
+def test_sq8_errors(vg, ctx):
+    sq = vg.ScalarQuantizer(ctx, 8)
+    idx = vg.Index(ctx, 10, 8)
+    with pytest.raises(vg.VecgoHipError):
+        idx.set_sq8_codes(sq, np.zeros((10, 8), np.uint8))  # not trained
+    sq.train(np.random.default_rng(0).standard_normal((20, 8)).astype(np.float32))
+    with pytest.raises(vg.VecgoHipError):
+        idx.search_sq8(np.zeros((1, 8), np.float32), 5)      # no codes attached
+    dot = vg.Index(ctx, 10, 8, vg.Metric(2))
+    dot.set_sq8_codes(sq, np.zeros((10, 8), np.uint8))
+    with pytest.raises(vg.VecgoHipError):
+        dot.search_sq8(np.zeros((1, 8), np.float32), 5)      # L2 only (flat/segment.go:517)

@@ -260,6 +260,93 @@ class RaBitQuantizer:
         return out
 
 
+class ScalarQuantizer:
+    """quantization.ScalarQuantizer (internal/quantization/quantizer.go:27-39): 8 bits per
+    dimension, per-dimension min / max."""
+
+    def __init__(self, ctx: Context, dimension: int):
+        self.ctx, self.dimension = ctx, dimension
+        self._lib = ctx._lib
+        h = C.c_void_p()
+        check(self._lib.vg_sq8_create(ctx._h, C.c_int32(dimension), C.byref(h)))
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.vg_sq8_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def is_trained(self) -> bool:
+        return bool(self._lib.vg_sq8_is_trained(self._h))
+
+    def bytes_per_dimension(self) -> int:
+        return 1
+
+    def compression_ratio(self) -> float:
+        return 4.0
+
+    def train(self, vectors, stream=None):
+        """Train (quantizer.go:127-180)."""
+        n = _rows(vectors, self.dimension)
+        v, pv = _ptr(vectors, np.float32)
+        check(self._lib.vg_sq8_train(self._h, pv, C.c_int64(n), _stream_ptr(stream)))
+
+    def set_bounds(self, mins, maxs):
+        """SetBounds (quantizer.go:52-78)."""
+        a, pa = _ptr(mins, np.float32, self.dimension)
+        b, pb = _ptr(maxs, np.float32, self.dimension)
+        check(self._lib.vg_sq8_set_bounds(self._h, pa, pb))
+
+    def params(self):
+        """(mins, maxs, scales, inv_scales) as numpy arrays."""
+        out = [np.empty(self.dimension, np.float32) for _ in range(4)]
+        check(self._lib.vg_sq8_get_params(self._h, *[C.c_void_p(a.ctypes.data) for a in out]))
+        return tuple(out)
+
+    def encode(self, vectors, out=None, stream=None):
+        """Encode (quantizer.go:183-222), batched: returns [n, dim] uint8."""
+        n = _rows(vectors, self.dimension)
+        v, pv = _ptr(vectors, np.float32)
+        if out is None:
+            out = _empty_like(vectors, (n, self.dimension), np.uint8)
+        c, pc = _ptr(out, np.uint8, n * self.dimension)
+        check(self._lib.vg_sq8_encode(self._h, pv, C.c_int64(n), pc, _stream_ptr(stream)))
+        return out
+
+    def decode(self, codes, out=None, stream=None):
+        """Decode (quantizer.go:225-250), batched: returns [n, dim] float32."""
+        total = codes.numel() if _is_torch(codes) else np.asarray(codes).size
+        if total % self.dimension:
+            raise VecgoHipError(-2, "vector dimension mismatch")
+        n = total // self.dimension
+        c, pc = _ptr(codes, np.uint8)
+        if out is None:
+            out = _empty_like(codes, (n, self.dimension), np.float32)
+        o, po = _ptr(out, np.float32, n * self.dimension)
+        check(self._lib.vg_sq8_decode(self._h, pc, C.c_int64(n), po, _stream_ptr(stream)))
+        return out
+
+    def l2_distance_batch(self, query, codes, out=None, stream=None):
+        """L2DistanceBatch (quantizer.go:93-106): one query against n codes."""
+        if _rows(query, self.dimension) != 1:
+            raise VecgoHipError(-2, "query dimension mismatch")
+        total = codes.numel() if _is_torch(codes) else np.asarray(codes).size
+        n = total // self.dimension
+        q, pq_ = _ptr(query, np.float32)
+        c, pc = _ptr(codes, np.uint8)
+        if out is None:
+            out = _empty_like(codes, (n,), np.float32)
+        o, po = _ptr(out, np.float32, n)
+        check(self._lib.vg_sq8_l2_distance_batch(self._h, pq_, pc, C.c_int64(n), po, _stream_ptr(stream)))
+        return out
+
+
 def hamming_batch(ctx: Context, a, codes, out=None, stream=None):
     """simd.Hamming (kernels.go:71) of one byte string against n contiguous ones."""
     a_, pa = _ptr(a, np.uint8)
@@ -432,6 +519,15 @@ class Index:
         c, pc = _ptr(codes, np.uint8, self.n * pq.num_subvectors)
         self._keep.append(pq)
         check(self._lib.vg_index_set_pq_codes(self._h, pq._h, pc, _stream_ptr(stream)))
+
+    def set_sq8_codes(self, sq: "ScalarQuantizer", codes, stream=None):
+        c, pc = _ptr(codes, np.uint8, self.n * self.dim)
+        self._keep.append(sq)
+        check(self._lib.vg_index_set_sq8_codes(self._h, sq._h, pc, _stream_ptr(stream)))
+
+    def search_sq8(self, queries, k, out=None, stream=None):
+        """flat.Segment.Search SQ8 branch (flat/segment.go:517-604)."""
+        return self._search(self._lib.vg_search_sq8, queries, k, out=out, stream=stream)
 
     def set_rabitq_codes(self, codes, stream=None):
         lib = self._lib

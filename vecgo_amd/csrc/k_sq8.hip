@@ -1,0 +1,479 @@
+// k_sq8.hip — 8-bit scalar quantization:
+//   quantization.ScalarQuantizer   internal/quantization/quantizer.go:27-250
+//   simd.Sq8uL2BatchPerDimension   internal/simd/src/sq8_avx512.c:59-103
+//   flat.Segment.Search, SQ8 branch internal/segment/flat/segment.go:517-604
+// Numerics contract (sq8_avx512.c): per row 16 lane accumulators over 16-element blocks,
+//   rec = fma(float(code), invScale[j], min[j]); diff = q[j] - rec; sum[l] = fma(diff, diff, sum[l])
+// then the _mm512_reduce_add_ps tree and an FMA-contracted scalar tail.  Here ONE GPU lane owns a
+// row and keeps the 16 accumulators in registers, so a wave scores 64 rows at a time; the scan
+// reads codes re-tiled to [tile of 64 rows][16-byte group][lane] (one coalesced 1 KiB request per
+// wave-instruction, exactly dim bytes per row when 16 | dim).  q, min and invScale are the same
+// for every lane: they are read through wave-uniform (scalar) loads, not per lane.
+#include <algorithm>
+
+#include "vg_device.hpp"
+#include "vg_internal.hpp"
+
+struct vg_sq8 {
+    vg_ctx *ctx = nullptr;
+    int32_t dim = 0;
+    bool trained = false;
+    float *d_mins = nullptr, *d_maxs = nullptr, *d_scales = nullptr, *d_inv = nullptr;  // [dim] each
+};
+
+namespace vg {
+
+int32_t launch_topk_merge(const uint64_t *partial, int64_t nq, int lists, int k, bool descending,
+                          uint32_t *ids, float *scores, hipStream_t st, const int *only_if = nullptr,
+                          const int *always = nullptr);
+
+constexpr float kF32Max = 3.40282346638528859811704183484516925440e+38f;
+
+// ---- Train (quantizer.go:127-180) ----------------------------------------------------------------
+// stage 1: thread = (row chunk, dimension): min / max over the chunk's rows (order-free, exact)
+__global__ void sq8_minmax_kernel(const float *__restrict__ v, int64_t n, int dim, int chunks,
+                                  float *__restrict__ pmin, float *__restrict__ pmax)
+{
+    const int d = blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = blockIdx.y;
+    if (d >= dim) return;
+    const int64_t r0 = n * c / chunks, r1 = n * (c + 1) / chunks;
+    float mn = kF32Max, mx = -kF32Max;
+    for (int64_t i = r0; i < r1; i++) {
+        const float x = v[i * dim + d];
+        if (x < mn) mn = x;
+        if (x > mx) mx = x;
+    }
+    pmin[static_cast<int64_t>(c) * dim + d] = mn;
+    pmax[static_cast<int64_t>(c) * dim + d] = mx;
+}
+
+// stage 2 + scales.  from_train: a constant dimension gets max = min + 1e-6 (quantizer.go:168-170);
+// SetBounds instead zeroes both scales when max - min < 1e-9 (quantizer.go:64-72).
+__global__ void sq8_finish_kernel(const float *__restrict__ pmin, const float *__restrict__ pmax, int chunks,
+                                  int dim, bool from_train, float *__restrict__ mins, float *__restrict__ maxs,
+                                  float *__restrict__ scales, float *__restrict__ inv)
+{
+    const int d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= dim) return;
+    float mn, mx;
+    if (from_train) {
+        mn = kF32Max;
+        mx = -kF32Max;
+        for (int c = 0; c < chunks; c++) {
+            const float a = pmin[static_cast<int64_t>(c) * dim + d], b = pmax[static_cast<int64_t>(c) * dim + d];
+            if (a < mn) mn = a;
+            if (b > mx) mx = b;
+        }
+        if (mn == mx) mx = mn + 1e-6f;
+        const float range = mx - mn;
+        scales[d] = 255.0f / range;
+        inv[d] = range / 255.0f;
+    } else {
+        mn = pmin[d];
+        mx = pmax[d];
+        const float diff = mx - mn;
+        if (diff < 1e-9f) {
+            scales[d] = 0.0f;
+            inv[d] = 0.0f;
+        } else {
+            scales[d] = 255.0f / diff;
+            inv[d] = diff / 255.0f;
+        }
+    }
+    mins[d] = mn;
+    maxs[d] = mx;
+}
+
+// ---- EncodeInto / DecodeInto (quantizer.go:198-250): thread per element -----------------------------
+__global__ void sq8_encode_kernel(const float *__restrict__ v, int64_t total, int dim,
+                                  const float *__restrict__ mins, const float *__restrict__ maxs,
+                                  const float *__restrict__ scales, uint8_t *__restrict__ out)
+{
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int d = static_cast<int>(i % dim);
+    float val = v[i];
+    const float mn = mins[d], mx = maxs[d];
+    if (val < mn)
+        val = mn;
+    else if (val > mx)
+        val = mx;
+    const float normalized = (val - mn) * scales[d];
+    const float r = normalized + 0.5f;
+    out[i] = static_cast<uint8_t>(static_cast<int>(r));  // Go uint8(float32): truncation
+}
+
+__global__ void sq8_decode_kernel(const uint8_t *__restrict__ codes, int64_t total, int dim,
+                                  const float *__restrict__ mins, const float *__restrict__ inv,
+                                  float *__restrict__ out)
+{
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int d = static_cast<int>(i % dim);
+    const float t = static_cast<float>(codes[i]) * inv[d];
+    out[i] = t + mins[d];
+}
+
+// ---- the row kernel --------------------------------------------------------------------------------
+// 16 bytes = one 16-element block of one row: lane accumulators l = 0..15 get one FMA each.
+// qv / mn / iv point at the block's 16 floats and are wave-uniform.
+__device__ __forceinline__ void sq8_block16(float (&acc)[16], const uint4 c, const float *__restrict__ qv,
+                                            const float *__restrict__ mn, const float *__restrict__ iv)
+{
+    const uint32_t w[4] = {c.x, c.y, c.z, c.w};
+#pragma unroll
+    for (int l = 0; l < 16; l++) {
+        const float cf = static_cast<float>((w[l >> 2] >> (8 * (l & 3))) & 0xFFu);
+        const float rec = __builtin_fmaf(cf, iv[l], mn[l]);
+        const float diff = qv[l] - rec;
+        acc[l] = __builtin_fmaf(diff, diff, acc[l]);
+    }
+}
+
+// the tail of a row (dim % 16 elements, bytes in the low lanes of the last group)
+__device__ __forceinline__ float sq8_tail(float total, const uint4 c, int cnt, const float *__restrict__ qv,
+                                          const float *__restrict__ mn, const float *__restrict__ iv)
+{
+    const uint32_t w[4] = {c.x, c.y, c.z, c.w};
+    for (int l = 0; l < cnt; l++) {
+        const float cf = static_cast<float>((w[l >> 2] >> (8 * (l & 3))) & 0xFFu);
+        const float rec = __builtin_fmaf(cf, iv[l], mn[l]);
+        const float diff = qv[l] - rec;
+        total = __builtin_fmaf(diff, diff, total);
+    }
+    return total;
+}
+
+// L2DistanceBatch on the reference layout (codes n*dim): lane per row, 16 bytes at a time.  The
+// interface path for small batches (the reference calls it with 256 rows, flat/segment.go:487,550).
+__global__ __launch_bounds__(256) void sq8_l2_batch_kernel(const float *__restrict__ query,
+                                                           const uint8_t *__restrict__ codes, int64_t n, int dim,
+                                                           const float *__restrict__ mins,
+                                                           const float *__restrict__ inv, float *__restrict__ out)
+{
+    const int64_t row = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (row >= n) return;
+    const uint8_t *cp = codes + row * dim;
+    float acc[16];
+#pragma unroll
+    for (int l = 0; l < 16; l++) acc[l] = 0.0f;
+    int j = 0;
+    for (; j + 16 <= dim; j += 16) {
+        uint32_t w[4];
+#pragma unroll
+        for (int t = 0; t < 4; t++)  // rows are only byte-aligned
+            w[t] = cp[j + 4 * t] | (cp[j + 4 * t + 1] << 8) | (cp[j + 4 * t + 2] << 16) |
+                   (static_cast<uint32_t>(cp[j + 4 * t + 3]) << 24);
+        sq8_block16(acc, make_uint4(w[0], w[1], w[2], w[3]), query + j, mins + j, inv + j);
+    }
+    float total = reduce16_regs(acc);
+    for (; j < dim; j++) {
+        const float rec = __builtin_fmaf(static_cast<float>(cp[j]), inv[j], mins[j]);
+        const float diff = query[j] - rec;
+        total = __builtin_fmaf(diff, diff, total);
+    }
+    out[row] = total;
+}
+
+// reference layout -> [tile][group][lane] 16-byte pieces (zero padded past dim and past n)
+__global__ void sq8_retile_kernel(const uint8_t *__restrict__ codes, int64_t n, int dim, int groups,
+                                  int64_t n_tiles, uint4 *__restrict__ tiles)
+{
+    const int64_t gid = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    const int64_t total = n_tiles * groups * 64;
+    if (gid >= total) return;
+    const int lane = static_cast<int>(gid & 63);
+    const int64_t tg = gid >> 6;
+    const int g = static_cast<int>(tg % groups);
+    const int64_t row = (tg / groups) * 64 + lane;
+    uint32_t w[4] = {0, 0, 0, 0};
+    if (row < n) {
+        const uint8_t *src = codes + row * dim;
+        for (int b = 0; b < 16; b++) {
+            const int at = g * 16 + b;
+            if (at < dim) w[b >> 2] |= static_cast<uint32_t>(src[at]) << (8 * (b & 3));
+        }
+    }
+    tiles[gid] = make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+// Exhaustive SQ8 scan with fused top-k.  HBM-bound by design: 16*groups bytes per row.
+constexpr int kSqWaves = 4;
+constexpr int kSqThreads = kSqWaves * 64;
+__global__ __launch_bounds__(kSqThreads) void sq8_scan_kernel(
+    const uint4 *__restrict__ tiles, int64_t n_rows, int64_t n_tiles, int groups, int dim,
+    const float *__restrict__ queries, const float *__restrict__ mins, const float *__restrict__ inv, int slices,
+    int nq, int k, uint64_t *__restrict__ partial)
+{
+    __shared__ uint64_t lists[kSqWaves * 64];
+    __shared__ int valid[kSqWaves];
+    const int b = blockIdx.x;
+    const int xcd = b & 7;
+    const int o = b >> 3;
+    const int q = o % nq;
+    const int s = (o / nq) * 8 + xcd;
+    const int64_t t0 = n_tiles * s / slices, t1 = n_tiles * (s + 1) / slices;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float *qv = queries + static_cast<int64_t>(q) * dim;
+    const int full = dim >> 4, tail = dim & 15;
+    WaveTopK tk;
+    tk.init(k);
+    for (int64_t tile = t0 + wave; tile < t1; tile += kSqWaves) {
+        const uint4 *tp = tiles + (tile * groups) * 64 + lane;
+        float acc[16];
+#pragma unroll
+        for (int l = 0; l < 16; l++) acc[l] = 0.0f;
+        uint4 c = tp[0];
+        for (int g = 0; g < full; g++) {
+            const uint4 cn = tp[(g + 1 < groups ? g + 1 : g) * 64];  // next group in flight
+            sq8_block16(acc, c, qv + g * 16, mins + g * 16, inv + g * 16);
+            c = cn;
+        }
+        float total = reduce16_regs(acc);
+        if (tail) total = sq8_tail(total, c, tail, qv + full * 16, mins + full * 16, inv + full * 16);
+        const int64_t row = tile * 64 + lane;
+        tk.offer(row < n_rows ? make_key(total, static_cast<uint32_t>(row), false) : kKeyMax, lane);
+    }
+    wg_rank_merge<kSqWaves>(tk, lists, valid, wave, lane, tid, k,
+                            partial + (static_cast<int64_t>(q) * slices + s) * k);
+}
+
+static int sq_slices(int64_t nq, int64_t n_tiles, int cus)
+{
+    int64_t s = (4 * static_cast<int64_t>(cus) + nq - 1) / nq;  // ~4 workgroups of 256 threads per CU
+    s = ((s + 7) / 8) * 8;
+    int64_t max_s = (n_tiles / 8) * 8;
+    if (max_s < 8) max_s = 8;
+    if (s > max_s) s = max_s;
+    if (s < 8) s = 8;
+    return static_cast<int>(s);
+}
+
+}  // namespace vg
+
+// ---- C ABI --------------------------------------------------------------------------------------------
+VG_API int32_t vg_sq8_create(vg_ctx *ctx, int32_t dim, vg_sq8 **out)
+{
+    VG_CHECK(out, VG_ERR_INVALID_ARG, "vg_sq8_create: out is NULL");
+    *out = nullptr;
+    VG_CHECK(ctx, VG_ERR_INVALID_ARG, "vg_sq8_create: ctx is NULL");
+    VG_CHECK(dim > 0, VG_ERR_INVALID_ARG, "vg_sq8_create: dim must be positive");
+    VG_HIP(hipSetDevice(ctx->device));
+    vg_sq8 *sq = new vg_sq8;
+    sq->ctx = ctx;
+    sq->dim = dim;
+    float *block = nullptr;
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&block), sizeof(float) * 4 * static_cast<size_t>(dim));
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        delete sq;
+        vg::set_error("vg_sq8_create: hipMalloc failed: %s", hipGetErrorString(e));
+        return VG_ERR_HIP;
+    }
+    sq->d_mins = block;
+    sq->d_maxs = block + dim;
+    sq->d_scales = block + 2 * dim;
+    sq->d_inv = block + 3 * dim;
+    *out = sq;
+    return VG_OK;
+}
+
+VG_API int32_t vg_sq8_destroy(vg_sq8 *sq)
+{
+    if (!sq) return VG_OK;
+    (void)hipSetDevice(sq->ctx->device);
+    if (sq->d_mins) (void)hipFree(sq->d_mins);
+    delete sq;
+    return VG_OK;
+}
+
+VG_API int32_t vg_sq8_is_trained(vg_sq8 *sq) { return sq && sq->trained ? 1 : 0; }
+
+VG_API int32_t vg_sq8_train(vg_sq8 *sq, const float *vectors, int64_t n, void *stream)
+{
+    VG_CHECK(sq, VG_ERR_INVALID_ARG, "vg_sq8_train: NULL quantizer");
+    VG_CHECK(n > 0 && vectors, VG_ERR_INVALID_ARG, "no vectors provided for training");  // quantizer.go:128-130
+    VG_HIP(hipSetDevice(sq->ctx->device));
+    hipStream_t st = vg::pick_stream(sq->ctx, stream);
+    const int dim = sq->dim;
+    vg::DevIn<float> v;
+    VG_TRY(v.init(vectors, static_cast<size_t>(n) * dim, st));
+    int chunks = static_cast<int>(std::min<int64_t>(n, 1024));
+    vg::DevTmp<float> pmin, pmax;
+    VG_TRY(pmin.init(static_cast<size_t>(chunks) * dim, st));
+    VG_TRY(pmax.init(static_cast<size_t>(chunks) * dim, st));
+    VG_LAUNCH(vg::sq8_minmax_kernel, dim3((dim + 255) / 256, chunks), dim3(256), 0, st, v.ptr, n, dim, chunks,
+              pmin.ptr, pmax.ptr);
+    VG_LAUNCH(vg::sq8_finish_kernel, dim3((dim + 255) / 256), dim3(256), 0, st, pmin.ptr, pmax.ptr, chunks, dim,
+              true, sq->d_mins, sq->d_maxs, sq->d_scales, sq->d_inv);
+    VG_HIP(hipStreamSynchronize(st));
+    sq->trained = true;
+    return VG_OK;
+}
+
+VG_API int32_t vg_sq8_set_bounds(vg_sq8 *sq, const float *mins, const float *maxs)
+{
+    VG_CHECK(sq, VG_ERR_INVALID_ARG, "vg_sq8_set_bounds: NULL quantizer");
+    VG_CHECK(mins && maxs, VG_ERR_INVALID_ARG, "vg_sq8_set_bounds: NULL bounds");
+    VG_HIP(hipSetDevice(sq->ctx->device));
+    hipStream_t st = sq->ctx->stream;
+    vg::DevIn<float> a, b;
+    VG_TRY(a.init(mins, static_cast<size_t>(sq->dim), st));
+    VG_TRY(b.init(maxs, static_cast<size_t>(sq->dim), st));
+    VG_LAUNCH(vg::sq8_finish_kernel, dim3((sq->dim + 255) / 256), dim3(256), 0, st, a.ptr, b.ptr, 1, sq->dim, false,
+              sq->d_mins, sq->d_maxs, sq->d_scales, sq->d_inv);
+    VG_HIP(hipStreamSynchronize(st));
+    sq->trained = true;
+    return VG_OK;
+}
+
+VG_API int32_t vg_sq8_get_params(vg_sq8 *sq, float *mins, float *maxs, float *scales, float *inv_scales)
+{
+    VG_CHECK(sq, VG_ERR_INVALID_ARG, "vg_sq8_get_params: NULL quantizer");
+    VG_CHECK(sq->trained, VG_ERR_NOT_TRAINED, "ScalarQuantizer not trained");
+    VG_HIP(hipSetDevice(sq->ctx->device));
+    hipStream_t st = sq->ctx->stream;
+    const size_t b = sizeof(float) * static_cast<size_t>(sq->dim);
+    if (mins) VG_HIP(hipMemcpyAsync(mins, sq->d_mins, b, hipMemcpyDefault, st));
+    if (maxs) VG_HIP(hipMemcpyAsync(maxs, sq->d_maxs, b, hipMemcpyDefault, st));
+    if (scales) VG_HIP(hipMemcpyAsync(scales, sq->d_scales, b, hipMemcpyDefault, st));
+    if (inv_scales) VG_HIP(hipMemcpyAsync(inv_scales, sq->d_inv, b, hipMemcpyDefault, st));
+    VG_HIP(hipStreamSynchronize(st));
+    return VG_OK;
+}
+
+VG_API int32_t vg_sq8_encode(vg_sq8 *sq, const float *vectors, int64_t n, uint8_t *codes, void *stream)
+{
+    VG_CHECK(sq, VG_ERR_INVALID_ARG, "vg_sq8_encode: NULL quantizer");
+    VG_CHECK(sq->trained, VG_ERR_NOT_TRAINED, "ScalarQuantizer not trained");  // quantizer.go:184-186
+    VG_CHECK(n >= 0, VG_ERR_INVALID_ARG, "vg_sq8_encode: n < 0");
+    if (n == 0) return VG_OK;
+    VG_CHECK(vectors && codes, VG_ERR_INVALID_ARG, "vg_sq8_encode: NULL buffer");
+    VG_HIP(hipSetDevice(sq->ctx->device));
+    hipStream_t st = vg::pick_stream(sq->ctx, stream);
+    const int64_t total = n * sq->dim;
+    vg::DevIn<float> v;
+    vg::DevOut<uint8_t> c;
+    VG_TRY(v.init(vectors, static_cast<size_t>(total), st));
+    VG_TRY(c.init(codes, static_cast<size_t>(total), st));
+    VG_LAUNCH(vg::sq8_encode_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, st, v.ptr, total,
+              sq->dim, sq->d_mins, sq->d_maxs, sq->d_scales, c.ptr);
+    VG_TRY(c.finish());
+    return VG_OK;
+}
+
+VG_API int32_t vg_sq8_decode(vg_sq8 *sq, const uint8_t *codes, int64_t n, float *out, void *stream)
+{
+    VG_CHECK(sq, VG_ERR_INVALID_ARG, "vg_sq8_decode: NULL quantizer");
+    VG_CHECK(sq->trained, VG_ERR_NOT_TRAINED, "ScalarQuantizer not trained");
+    VG_CHECK(n >= 0, VG_ERR_INVALID_ARG, "vg_sq8_decode: n < 0");
+    if (n == 0) return VG_OK;
+    VG_CHECK(codes && out, VG_ERR_INVALID_ARG, "vg_sq8_decode: NULL buffer");
+    VG_HIP(hipSetDevice(sq->ctx->device));
+    hipStream_t st = vg::pick_stream(sq->ctx, stream);
+    const int64_t total = n * sq->dim;
+    vg::DevIn<uint8_t> c;
+    vg::DevOut<float> o;
+    VG_TRY(c.init(codes, static_cast<size_t>(total), st));
+    VG_TRY(o.init(out, static_cast<size_t>(total), st));
+    VG_LAUNCH(vg::sq8_decode_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, st, c.ptr, total,
+              sq->dim, sq->d_mins, sq->d_inv, o.ptr);
+    VG_TRY(o.finish());
+    return VG_OK;
+}
+
+VG_API int32_t vg_sq8_l2_distance_batch(vg_sq8 *sq, const float *query, const uint8_t *codes, int64_t n,
+                                        float *out, void *stream)
+{
+    VG_CHECK(sq, VG_ERR_INVALID_ARG, "vg_sq8_l2_distance_batch: NULL quantizer");
+    VG_CHECK(sq->trained, VG_ERR_NOT_TRAINED, "ScalarQuantizer not trained");
+    VG_CHECK(n >= 0, VG_ERR_INVALID_ARG, "vg_sq8_l2_distance_batch: n < 0");
+    if (n == 0) return VG_OK;
+    VG_CHECK(query && codes && out, VG_ERR_INVALID_ARG, "vg_sq8_l2_distance_batch: NULL buffer");
+    VG_HIP(hipSetDevice(sq->ctx->device));
+    hipStream_t st = vg::pick_stream(sq->ctx, stream);
+    vg::DevIn<float> q;
+    vg::DevIn<uint8_t> c;
+    vg::DevOut<float> o;
+    VG_TRY(q.init(query, static_cast<size_t>(sq->dim), st));
+    VG_TRY(c.init(codes, static_cast<size_t>(n) * sq->dim, st));
+    VG_TRY(o.init(out, static_cast<size_t>(n), st));
+    VG_LAUNCH(vg::sq8_l2_batch_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, st, q.ptr, c.ptr, n,
+              sq->dim, sq->d_mins, sq->d_inv, o.ptr);
+    VG_TRY(o.finish());
+    return VG_OK;
+}
+
+VG_API int32_t vg_index_set_sq8_codes(vg_index *idx, vg_sq8 *sq, const uint8_t *codes, void *stream)
+{
+    VG_CHECK(idx && sq, VG_ERR_INVALID_ARG, "vg_index_set_sq8_codes: NULL index or quantizer");
+    VG_CHECK(sq->trained, VG_ERR_NOT_TRAINED, "ScalarQuantizer not trained");
+    VG_CHECK(sq->dim == idx->dim, VG_ERR_DIM_MISMATCH, "vector dimension mismatch");
+    VG_CHECK(idx->n == 0 || codes, VG_ERR_INVALID_ARG, "vg_index_set_sq8_codes: codes is NULL");
+    VG_HIP(hipSetDevice(idx->ctx->device));
+    hipStream_t st = vg::pick_stream(idx->ctx, stream);
+    if (idx->d_sq_tiles) {
+        VG_HIP(hipStreamSynchronize(st));
+        VG_HIP(hipFree(idx->d_sq_tiles));
+        idx->d_sq_tiles = nullptr;
+    }
+    idx->sq = sq;
+    idx->sq_groups = (idx->dim + 15) / 16;
+    idx->n_tiles = (idx->n + 63) / 64;
+    if (idx->n == 0) return VG_OK;
+    const int64_t total = idx->n_tiles * idx->sq_groups * 64;
+    VG_HIP(hipMalloc(reinterpret_cast<void **>(&idx->d_sq_tiles), static_cast<size_t>(total) * 16));
+    vg::DevIn<uint8_t> in;
+    VG_TRY(in.init(codes, static_cast<size_t>(idx->n) * idx->dim, st));
+    VG_LAUNCH(vg::sq8_retile_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, st, in.ptr, idx->n,
+              idx->dim, idx->sq_groups, idx->n_tiles, reinterpret_cast<uint4 *>(idx->d_sq_tiles));
+    VG_HIP(hipStreamSynchronize(st));
+    return VG_OK;
+}
+
+VG_API int32_t vg_search_sq8(vg_index *idx, const float *queries, int64_t nq, int32_t k, uint32_t *ids,
+                             float *scores, void *stream)
+{
+    VG_CHECK(idx, VG_ERR_INVALID_ARG, "vg_search_sq8: NULL index");
+    VG_CHECK(nq >= 0 && k >= 0, VG_ERR_INVALID_ARG, "vg_search_sq8: negative nq or k");
+    if (nq == 0 || k == 0) return VG_OK;
+    VG_CHECK(idx->metric == VG_METRIC_L2, VG_ERR_UNSUPPORTED,
+             "vg_search_sq8: the reference's SQ8 scan exists for L2 only (flat/segment.go:517)");
+    VG_CHECK(idx->n == 0 || idx->d_sq_tiles, VG_ERR_NOT_READY, "vg_search_sq8: index has no SQ8 codes");
+    VG_CHECK(queries && ids && scores, VG_ERR_INVALID_ARG, "vg_search_sq8: NULL buffer");
+    VG_CHECK(k <= 64, VG_ERR_UNSUPPORTED, "vg_search_sq8: k=%d exceeds 64", k);
+    VG_HIP(hipSetDevice(idx->ctx->device));
+    hipStream_t st = vg::pick_stream(idx->ctx, stream);
+    vg::DevIn<float> q;
+    vg::DevOut<uint32_t> oid;
+    vg::DevOut<float> osc;
+    VG_TRY(q.init(queries, static_cast<size_t>(nq) * idx->dim, st));
+    VG_TRY(oid.init(ids, static_cast<size_t>(nq) * k, st));
+    VG_TRY(osc.init(scores, static_cast<size_t>(nq) * k, st));
+    if (idx->n == 0) {
+        vg::DevTmp<uint64_t> none;
+        VG_TRY(none.init(static_cast<size_t>(nq) * k, st));
+        VG_HIP(hipMemsetAsync(none.ptr, 0xFF, static_cast<size_t>(nq) * k * 8, st));
+        VG_TRY(vg::launch_topk_merge(none.ptr, nq, 1, k, false, oid.ptr, osc.ptr, st));
+    } else {
+        const int slices = vg::sq_slices(nq, idx->n_tiles, idx->ctx->compute_units);
+        vg::ArenaCall ar(idx->ctx, st);
+        const int i_partial = ar.add(sizeof(uint64_t) * static_cast<size_t>(nq) * slices * k);
+        VG_TRY(ar.commit());
+        uint64_t *partial = ar.get<uint64_t>(i_partial);
+        const int64_t max_q = (1ll << 30) / slices;
+        for (int64_t q0 = 0; q0 < nq; q0 += max_q) {
+            const int64_t cnt = nq - q0 < max_q ? nq - q0 : max_q;
+            vg::ProfScope prof(idx->ctx, "sq8_scan", st);
+            VG_LAUNCH(vg::sq8_scan_kernel, dim3(static_cast<unsigned>(cnt * slices)), dim3(vg::kSqThreads), 0, st,
+                      reinterpret_cast<const uint4 *>(idx->d_sq_tiles), idx->n, idx->n_tiles, idx->sq_groups, idx->dim,
+                      q.ptr + q0 * idx->dim, idx->sq->d_mins, idx->sq->d_inv, slices, static_cast<int>(cnt), k,
+                      partial + q0 * slices * k);
+        }
+        VG_TRY(vg::launch_topk_merge(partial, nq, slices, k, false, oid.ptr, osc.ptr, st));
+    }
+    VG_TRY(oid.finish());
+    VG_TRY(osc.finish());
+    return VG_OK;
+}

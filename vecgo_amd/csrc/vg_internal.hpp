@@ -281,6 +281,8 @@ struct vg_pq {
     float *d_offsets = nullptr;     // m
 };
 
+struct vg_sq8;
+
 struct vg_index {
     vg_ctx *ctx = nullptr;
     int64_t n = 0;
@@ -314,4 +316,8 @@ struct vg_index {
     // PQ codes in the reference's row-major layout (random access by node id in graph search)
     uint8_t *d_pq_rows = nullptr;
     uint8_t *d_rq_rows = nullptr;
+    // SQ8 codes, re-tiled like the PQ codes: [tile][group of 16 dims][lane][16 B]; see k_sq8.hip
+    vg_sq8 *sq = nullptr;
+    uint8_t *d_sq_tiles = nullptr;
+    int32_t sq_groups = 0;  // ceil(dim/16)
 };
