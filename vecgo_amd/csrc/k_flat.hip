@@ -64,22 +64,37 @@ static int32_t launch_gemm(bool dot, bool dma, unsigned blocks, hipStream_t st, 
     return dot ? launch_gemm_t<true, MODE>(dma, blocks, st, a) : launch_gemm_t<false, MODE>(dma, blocks, st, a);
 }
 
-// bookkeeping for vg_index_flat_stats: stats[0] += queries of the chunk, stats[1] += those whose
-// proof failed (or that were forced) and went to the exhaustive kernel
-__global__ void flat_stats_kernel(const int *__restrict__ flags, const int *__restrict__ always, int cnt,
-                                  unsigned long long *__restrict__ stats)
+// After the proofs: the work list of step 4 (todo[0] = how many queries need the exhaustive scan,
+// todo[1 + j] = the j-th of them, ascending) and the bookkeeping for vg_index_flat_stats
+// (stats[0] += queries of the chunk, stats[1] += those sent to the exhaustive kernel).
+__global__ __launch_bounds__(256) void flat_todo_kernel(const int *__restrict__ flags, const int *__restrict__ always,
+                                                        int cnt, int *__restrict__ todo,
+                                                        unsigned long long *__restrict__ stats)
 {
-    __shared__ int total;
-    if (threadIdx.x == 0) total = 0;
-    __syncthreads();
+    __shared__ int part[256];
+    const int tid = threadIdx.x;
+    const int per = (cnt + 255) / 256;
+    const int lo = tid * per < cnt ? tid * per : cnt, hi = lo + per < cnt ? lo + per : cnt;
+    const bool all = *always != 0;
     int mine = 0;
-    for (int i = threadIdx.x; i < cnt; i += blockDim.x) mine += (flags[i] != 0 || *always != 0);
-    if (mine) atomicAdd(&total, mine);
+    for (int i = lo; i < hi; i++) mine += (all || flags[i] != 0);
+    part[tid] = mine;
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (tid == 0) {
+        int run = 0;
+        for (int t = 0; t < 256; t++) {
+            const int c = part[t];
+            part[t] = run;
+            run += c;
+        }
+        todo[0] = run;
         atomicAdd(&stats[0], static_cast<unsigned long long>(cnt));
-        atomicAdd(&stats[1], static_cast<unsigned long long>(total));
+        atomicAdd(&stats[1], static_cast<unsigned long long>(run));
     }
+    __syncthreads();
+    int at = part[tid];
+    for (int i = lo; i < hi; i++)
+        if (all || flags[i] != 0) todo[1 + at++] = i;
 }
 
 // per query: the kc best keys among the candidates the fused GEMM appended (count <= cap)
@@ -249,37 +264,41 @@ __global__ __launch_bounds__(256) void flat_verify_kernel(
 }
 
 // ---- 4. exhaustive exact scan for the queries whose proof failed ---------------------------------
+// grid = (slices, slots): slot y takes the work-list entries y, y + slots, ...; with an empty list
+// (the normal case) the whole launch is a few thousand workgroups that read one word and leave.
+constexpr int kExactSlots = 32;
 template <bool DOT>
 __global__ __launch_bounds__(256) void flat_exact_kernel(const float *__restrict__ base, int64_t n,
                                                          int dim, const float *__restrict__ queries,
-                                                         const int *__restrict__ fallback,
-                                                         const int *__restrict__ always,
-                                                         int slices, int k,
+                                                         const int *__restrict__ todo, int slices, int k,
                                                          uint64_t *__restrict__ partial)
 {
     __shared__ uint64_t lists[4 * 64];
     __shared__ int valid[4];
     const int s = blockIdx.x;
-    const int64_t q = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    uint64_t *out = partial + (q * slices + s) * k;
-    if (!(always && always[0]) && !fallback[q]) return;
+    const int ntodo = todo[0];
     const Sub16 sub = Sub16::make(tid);
-    const float *qv = queries + q * dim;
     const int64_t r0 = n * s / slices, r1 = n * (s + 1) / slices;
-    WaveTopK tk;
-    tk.init(k);
-    // 4 rows per wave step (one per 16-lane group)
-    for (int64_t i0 = r0 + wave * 4; i0 < r1; i0 += 16) {
-        const int64_t i = i0 + (lane >> 4);
-        uint64_t key = kKeyMax;
-        if (i < r1) {
-            const float v = exact_pair16<DOT, kPair>(base + i * dim, qv, dim, sub);
-            if ((lane & 15) == 0) key = make_key(v, static_cast<uint32_t>(i), DOT);
+    for (int j = blockIdx.y; j < ntodo; j += gridDim.y) {
+        const int64_t q = todo[1 + j];
+        uint64_t *out = partial + (q * slices + s) * k;
+        const float *qv = queries + q * dim;
+        WaveTopK tk;
+        tk.init(k);
+        // 4 rows per wave step (one per 16-lane group)
+        for (int64_t i0 = r0 + wave * 4; i0 < r1; i0 += 16) {
+            const int64_t i = i0 + (lane >> 4);
+            uint64_t key = kKeyMax;
+            if (i < r1) {
+                const float v = exact_pair16<DOT, kPair>(base + i * dim, qv, dim, sub);
+                if ((lane & 15) == 0) key = make_key(v, static_cast<uint32_t>(i), DOT);
+            }
+            tk.offer(key, lane);
         }
-        tk.offer(key, lane);
+        wg_rank_merge<4>(tk, lists, valid, wave, lane, tid, k, out);
+        __syncthreads();  // lists / valid are reused by the next work item
     }
-    wg_rank_merge<4>(tk, lists, valid, wave, lane, tid, k, out);
 }
 
 // overwrite the results of the fallback queries from the exact scan's merged lists
@@ -358,6 +377,7 @@ VG_API int32_t vg_search_flat(vg_index *idx, const float *queries, int64_t nq, i
         const int i_cand_id = ar.add(sizeof(uint32_t) * static_cast<size_t>(qc) * kc);
         const int i_cand_sc = ar.add(sizeof(float) * static_cast<size_t>(qc) * kc);
         const int i_flags = ar.add(sizeof(int) * (static_cast<size_t>(qc) + 1));
+        const int i_todo = ar.add(sizeof(int) * (static_cast<size_t>(qc) + 1));
         const int i_fpartial = ar.add(sizeof(uint64_t) * static_cast<size_t>(qc) * ex_slices * k);
         const int i_fid = ar.add(sizeof(uint32_t) * static_cast<size_t>(qc) * k);
         const int i_fsc = ar.add(sizeof(float) * static_cast<size_t>(qc) * k);
@@ -367,7 +387,7 @@ VG_API int32_t vg_search_flat(vg_index *idx, const float *queries, int64_t nq, i
         uint64_t *partial = ar.get<uint64_t>(i_partial), *fpartial = ar.get<uint64_t>(i_fpartial);
         uint64_t *cand = ar.get<uint64_t>(i_cand);
         uint32_t *sid = ar.get<uint32_t>(i_sid), *cand_id = ar.get<uint32_t>(i_cand_id), *fid = ar.get<uint32_t>(i_fid);
-        int *counts = ar.get<int>(i_counts), *flags = ar.get<int>(i_flags);
+        int *counts = ar.get<int>(i_counts), *flags = ar.get<int>(i_flags), *todo = ar.get<int>(i_todo);
 
         const char *force = getenv("VG_FLAT_FORCE_EXACT");  // test hook: run step 4 for every query
         int *always = flags + qc;
@@ -427,15 +447,18 @@ VG_API int32_t vg_search_flat(vg_index *idx, const float *queries, int64_t nq, i
                 VG_LAUNCH(vg::flat_verify_kernel<false>, dim3(ucnt), dim3(256), 0, st, idx->d_vectors, n, dim, qp,
                           idx->d_norm_max, cand_id, cand_sc, kc, k, oid.ptr + q0 * k, osc.ptr + q0 * k, flags, vthr,
                           sel_k, sel_k - 1, counts, cap);
-            // step 4 always launches; its workgroups exit at once unless the query is flagged
-            if (dot)
-                VG_LAUNCH(vg::flat_exact_kernel<true>, dim3(ex_slices, ucnt), dim3(256), 0, st, idx->d_vectors, n, dim,
-                          qp, flags, always, ex_slices, k, fpartial);
-            else
-                VG_LAUNCH(vg::flat_exact_kernel<false>, dim3(ex_slices, ucnt), dim3(256), 0, st, idx->d_vectors, n, dim,
-                          qp, flags, always, ex_slices, k, fpartial);
-            VG_LAUNCH(vg::flat_stats_kernel, dim3(1), dim3(256), 0, st, flags, always, static_cast<int>(cnt),
+            // step 4 always launches, on the work list the proofs left behind (normally empty)
+            VG_LAUNCH(vg::flat_todo_kernel, dim3(1), dim3(256), 0, st, flags, always, static_cast<int>(cnt), todo,
                       idx->d_flat_stats);
+            {
+                const unsigned slots = static_cast<unsigned>(std::min<int64_t>(cnt, vg::kExactSlots));
+                if (dot)
+                    VG_LAUNCH(vg::flat_exact_kernel<true>, dim3(ex_slices, slots), dim3(256), 0, st, idx->d_vectors, n,
+                              dim, qp, todo, ex_slices, k, fpartial);
+                else
+                    VG_LAUNCH(vg::flat_exact_kernel<false>, dim3(ex_slices, slots), dim3(256), 0, st, idx->d_vectors, n,
+                              dim, qp, todo, ex_slices, k, fpartial);
+            }
             if (getenv("VG_FLAT_DEBUG")) {
                 std::vector<int> hf(cnt), hc(cnt);
                 (void)hipMemcpyAsync(hf.data(), flags, sizeof(int) * cnt, hipMemcpyDeviceToHost, st);
