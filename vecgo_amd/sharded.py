@@ -4,7 +4,7 @@ The reference is single-process; its engine fans a query out over segments and m
 per-segment candidate lists into one bounded heap (internal/engine/search.go:835-908).  Here
 the "segments" are contiguous row shards, one per rank: every rank scores the same query batch
 against its shard, the per-shard top-k (k ids + k scores per query) is exchanged with ONE
-all-gather (RCCL over xGMI; nq*k*8 bytes per rank), and every rank merges with the reference's
+all-gather (RCCL over xGMI; nq*k*8 bytes per rank, ids and score bits in one buffer), and every rank merges with the reference's
 tie-break (score, then RowID — searcher/candidate_queue.go:12-23).  No other collective.
 """
 from __future__ import annotations
@@ -31,13 +31,16 @@ def sharded_search(local_search: Callable, merge: Callable, queries, k: int, bou
         off = torch.tensor([bounds[0]], dtype=torch.int32, device=ids.device)
         return merge(ids.unsqueeze(0), scores.unsqueeze(0), k, off)
     nq = ids.shape[0]
-    # gathered layout = concatenation along dim 0 (accepted by both RCCL and gloo): [world*nq, k]
-    all_ids = torch.empty((world * nq, k), dtype=ids.dtype, device=ids.device)
-    all_scores = torch.empty((world * nq, k), dtype=scores.dtype, device=scores.device)
-    dist.all_gather_into_tensor(all_ids, ids.contiguous(), group=group)
-    dist.all_gather_into_tensor(all_scores, scores.contiguous(), group=group)
+    # ONE collective per search: ids and the scores' bit patterns travel in the same int32 buffer
+    # ([2, nq, k] per rank); gathered layout = concatenation along dim 0 (accepted by RCCL and gloo)
+    mine = torch.stack((ids.contiguous().view(torch.int32), scores.contiguous().view(torch.int32)))
+    gathered = torch.empty((world * 2 * nq, k), dtype=torch.int32, device=ids.device)
+    dist.all_gather_into_tensor(gathered, mine.view(2 * nq, k), group=group)
+    gathered = gathered.view(world, 2, nq, k)
+    all_ids = gathered[:, 0].contiguous().view(ids.dtype)
+    all_scores = gathered[:, 1].contiguous().view(torch.float32)
     off = torch.tensor(list(bounds[:-1]), dtype=torch.int32, device=ids.device)
-    return merge(all_ids.view(world, nq, k), all_scores.view(world, nq, k), k, off)
+    return merge(all_ids, all_scores, k, off)
 
 
 class ShardedFlatIndex:
