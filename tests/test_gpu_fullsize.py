@@ -1,0 +1,203 @@
+"""Parity at BASELINE.json's FULL sizes, where the oracle cannot scan the corpus in seconds:
+size-independent properties checked on the GPU results, plus the oracle on exactly the rows the
+GPU reported.
+
+  * every reported (row, score) pair is re-scored by the oracle on that row: bit-exact;
+  * results are ordered by (score, RowID) — searcher/candidate_queue.go:12-23;
+  * partition property: top-k of the whole corpus == merge of the top-k of its two halves
+    (engine/search.go:904-908 fan-in), i.e. nothing depends on how rows are tiled;
+  * two independent device paths agree (GEMM candidates + proof vs the exhaustive exact kernel);
+  * a random sample of rows holds no row that beats the reported k-th;
+  * idempotence: the same call twice gives the same bits.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as o
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def bits(x):
+    return np.asarray(x, np.float32).view(np.uint32)
+
+
+@pytest.fixture(scope="module")
+def vg():
+    import vecgo_amd
+    return vecgo_amd
+
+
+@pytest.fixture(scope="module")
+def ctx(vg):
+    return vg.Context(0)
+
+
+def np_(t):
+    return t.cpu().numpy() if hasattr(t, "cpu") else np.asarray(t)
+
+
+def assert_ordered(ids, sc, descending=False):
+    ids = np_(ids).view(np.uint32).astype(np.int64); sc = np_(sc)
+    for i in range(ids.shape[0]):
+        key = list(zip((-sc[i] if descending else sc[i]).tolist(), ids[i].tolist()))
+        assert key == sorted(key), i
+
+
+def test_flat_exact_1m_x_768(vg, ctx):
+    """BASELINE configs[1]: 1M x 768 fp32, exact top-10."""
+    n, dim, nq, k = 1_000_000, 768, 96, 10
+    g = torch.Generator(device="cuda"); g.manual_seed(20260130)
+    base = torch.randn(n, dim, device="cuda", generator=g)
+    q = torch.randn(nq, dim, device="cuda", generator=g)
+    idx = vg.Index(ctx, n, dim); idx.set_vectors(base)
+    ids, sc = idx.search_flat(q, k)
+    ids2, sc2 = idx.search_flat(q, k)
+    assert torch.equal(ids, ids2) and torch.equal(sc.view(torch.int32), sc2.view(torch.int32))  # idempotent
+    searched, exhaustive = idx.flat_stats()
+    assert searched == 2 * nq and exhaustive == 0          # answered by GEMM candidates + proof
+    assert_ordered(ids, sc)
+    # (1) oracle on the reported rows
+    hid = np_(ids).view(np.uint32).astype(np.int64)
+    rows = base[torch.from_numpy(hid.reshape(-1)).cuda()].cpu().numpy().reshape(nq, k, dim)
+    hq = q.cpu().numpy()
+    for i in range(nq):
+        want = np.array([o.l2(hq[i], rows[i, j]) for j in range(k)], np.float32)
+        assert np.array_equal(bits(np_(sc)[i]), bits(want)), i
+    # (2) the exhaustive exact kernel (no GEMM, no proof) gives the same bits
+    os.environ["VG_FLAT_FORCE_EXACT"] = "1"
+    try:
+        eids, esc = idx.search_flat(q[:32], k)
+    finally:
+        os.environ.pop("VG_FLAT_FORCE_EXACT")
+    assert torch.equal(eids, ids[:32]) and torch.equal(esc.view(torch.int32), sc[:32].view(torch.int32))
+    # (3) partition property
+    half = n // 2
+    a = vg.Index(ctx, half, dim); a.set_vectors(base[:half])
+    b = vg.Index(ctx, n - half, dim); b.set_vectors(base[half:])
+    ia, sa = a.search_flat(q, k); ib, sb = b.search_flat(q, k)
+    off = torch.tensor([0, half], dtype=torch.int32, device="cuda")
+    mi, ms = vg.merge_topk(ctx, torch.stack((ia, ib)), torch.stack((sa, sb)), k, metric=0, id_offsets=off)
+    assert torch.equal(mi, ids) and torch.equal(ms.view(torch.int32), sc.view(torch.int32))
+    # (4) no sampled row beats the k-th
+    sample = torch.randint(0, n, (20000,), device="cuda", generator=g)
+    d = torch.cdist(q.double(), base[sample].double()) ** 2
+    assert bool((d.min(dim=1).values.float() >= sc[:, 0] * (1 - 1e-5)).all())
+    srt = d.sort(dim=1).values
+    assert bool((srt[:, 0].float() * (1 + 1e-5) >= sc[:, 0]).all())
+
+
+def _train_small_pq(vg, ctx, dim, m):
+    rng = np.random.default_rng(3)
+    pq = vg.ProductQuantizer(ctx, dim, m, 256)
+    pq.set_codebooks(rng.integers(-128, 128, m * 256 * (dim // m)).astype(np.int8),
+                     (rng.random(m) * 0.02 + 0.005).astype(np.float32),
+                     (rng.standard_normal(m) * 0.1).astype(np.float32))
+    return pq
+
+
+def test_pq_adc_scan_10m_x_96(vg, ctx):
+    """BASELINE configs[3]: 10M rows of m=96 PQ codes, LUT scan with fused top-k."""
+    n, dim, m, nq, k = 10_000_000, 768, 96, 6, 10
+    g = torch.Generator(device="cuda"); g.manual_seed(7)
+    codes = torch.randint(0, 256, (n, m), dtype=torch.uint8, device="cuda", generator=g)
+    codes[123_456] = codes[9_000_001]      # a tie between far-apart rows: RowID decides
+    pq = _train_small_pq(vg, ctx, dim, m)
+    idx = vg.Index(ctx, n, dim); idx.set_pq_codes(pq, codes)
+    q = torch.randn(nq, dim, device="cuda", generator=g)
+    ids, sc = idx.search_pq_adc(q, k)
+    ids2, sc2 = idx.search_pq_adc(q, k)
+    assert torch.equal(ids, ids2) and torch.equal(sc.view(torch.int32), sc2.view(torch.int32))
+    assert_ordered(ids, sc)
+    # oracle on the reported rows: BuildDistanceTable + pqAdcLookupAvx512 order
+    cb, s_, of_ = pq.codebooks()
+    opq = o.ProductQuantizer(dim, m, 256); opq.set_codebooks(cb, s_, of_)
+    hid = np_(ids).view(np.uint32).astype(np.int64)
+    hq = q.cpu().numpy()
+    for i in range(nq):
+        table = opq.build_table(hq[i])
+        rc = codes[torch.from_numpy(hid[i]).cuda()].cpu().numpy()
+        want = np.array([o.adc(table, rc[j], m) for j in range(k)], np.float32)
+        assert np.array_equal(bits(np_(sc)[i]), bits(want)), i
+    # partition property
+    half = n // 2
+    a = vg.Index(ctx, half, dim); a.set_pq_codes(pq, codes[:half])
+    b = vg.Index(ctx, n - half, dim); b.set_pq_codes(pq, codes[half:])
+    ia, sa = a.search_pq_adc(q, k); ib, sb = b.search_pq_adc(q, k)
+    off = torch.tensor([0, half], dtype=torch.int32, device="cuda")
+    mi, ms = vg.merge_topk(ctx, torch.stack((ia, ib)), torch.stack((sa, sb)), k, metric=0, id_offsets=off)
+    assert torch.equal(mi, ids) and torch.equal(ms.view(torch.int32), sc.view(torch.int32))
+    # big-k path (64 < k <= 1024) contains the small-k answer as its prefix
+    i100, s100 = idx.search_pq_adc(q, 100)
+    assert torch.equal(i100[:, :k], ids) and torch.equal(s100[:, :k].view(torch.int32), sc.view(torch.int32))
+    assert_ordered(i100, s100)
+    # a sample of rows scored by the batch entry point holds nothing better than the k-th
+    table = pq.build_distance_table(q[:1])
+    lo = 4_000_000
+    d = vg.pq_adc_lookup_batch(ctx, table, codes[lo:lo + 500_000], m)
+    kth = float(np_(sc)[0, k - 1]); worst_id = int(hid[0, k - 1])
+    better = torch.nonzero(d < kth).flatten() + lo
+    assert set(np_(better).tolist()) <= set(hid[0].tolist()), (better, worst_id)
+
+
+def test_rabitq_scan_10m_x_768(vg, ctx):
+    """BASELINE configs[4] on one GPU: 10M RaBitQ codes of 100 bytes."""
+    n, dim, nq, k = 10_000_000, 768, 4, 10
+    cb = (dim + 63) // 64 * 8 + 4
+    g = torch.Generator(device="cuda"); g.manual_seed(11)
+    codes = torch.randint(0, 256, (n, cb), dtype=torch.uint8, device="cuda", generator=g)
+    codes[:, cb - 4:] = (torch.rand(n, device="cuda", generator=g) * 5 + 25).view(torch.uint8).reshape(n, 4)
+    idx = vg.Index(ctx, n, dim); idx.set_rabitq_codes(codes)
+    q = torch.randn(nq, dim, device="cuda", generator=g)
+    ids, sc = idx.search_rabitq(q, k)
+    assert_ordered(ids, sc)
+    hid = np_(ids).view(np.uint32).astype(np.int64)
+    hq = q.cpu().numpy()
+    for i in range(nq):
+        rc = codes[torch.from_numpy(hid[i]).cuda()].cpu().numpy()
+        want = np.array([o.rabitq_distance(hq[i], rc[j]) for j in range(k)], np.float32)
+        assert np.array_equal(bits(np_(sc)[i]), bits(want)), i
+    half = n // 2
+    a = vg.Index(ctx, half, dim); a.set_rabitq_codes(codes[:half])
+    b = vg.Index(ctx, n - half, dim); b.set_rabitq_codes(codes[half:])
+    ia, sa = a.search_rabitq(q, k); ib, sb = b.search_rabitq(q, k)
+    off = torch.tensor([0, half], dtype=torch.int32, device="cuda")
+    mi, ms = vg.merge_topk(ctx, torch.stack((ia, ib)), torch.stack((sa, sb)), k, metric=0, id_offsets=off)
+    assert torch.equal(mi, ids) and torch.equal(ms.view(torch.int32), sc.view(torch.int32))
+    # rabitq scores are heavily tied: the order must still be (score, RowID)
+    rq = vg.RaBitQuantizer(ctx, dim)
+    d = rq.distance(q[:1], codes[:300_000])
+    kth = float(np_(sc)[0, k - 1])
+    better = torch.nonzero(d < kth).flatten()
+    assert set(np_(better).tolist()) <= set(hid[0].tolist())
+
+
+def test_hnsw_layer0_1m_x_768(vg, ctx):
+    """BASELINE configs[2]: layer-0 search, ef = 128, over a 1M x 768 corpus.  The graph is a
+    random 32-regular graph (search parity does not depend on graph quality; building a real one
+    takes minutes); 6 queries are replayed by the oracle over the same graph: ids, scores and
+    counters bit-exact."""
+    n, dim, m0, nq, k, ef = 1_000_000, 768, 32, 64, 10, 128
+    g = torch.Generator(device="cuda"); g.manual_seed(5)
+    base = torch.randn(n, dim, device="cuda", generator=g)
+    l0 = torch.randint(0, n, (n, m0), dtype=torch.int32, device="cuda", generator=g)
+    q = torch.randn(nq, dim, device="cuda", generator=g)
+    idx = vg.Index(ctx, n, dim); idx.set_vectors(base)
+    hl0 = l0.cpu().numpy().view(np.uint32)
+    idx.set_hnsw_graph(hl0, (), entry_point=12345, m=m0 // 2)
+    ids, sc, stats = idx.search_hnsw(q, k, ef, stats=True)
+    ids2, sc2 = idx.search_hnsw(q, k, ef)
+    assert torch.equal(ids, ids2) and torch.equal(sc.view(torch.int32), sc2.view(torch.int32))
+    assert_ordered(ids, sc)
+    hbase = base.cpu().numpy(); hq = q.cpu().numpy()
+    graph = o.HnswIndex(hbase, dim, hl0, (), entry_point=12345, m=m0 // 2)
+    hid = np_(ids).view(np.uint32); hsc = np_(sc)
+    for i in range(6):
+        eid, esc, est = graph.search(hq[i], k, ef)
+        assert np.array_equal(hid[i, :eid.size], eid), i
+        assert np.array_equal(bits(hsc[i, :eid.size]), bits(esc)), i
+        assert tuple(int(x) for x in stats[i][:3]) == \
+               (est.nodes_visited, est.distance_computations, est.distance_short_circuits), i
