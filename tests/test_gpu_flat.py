@@ -74,6 +74,23 @@ def test_flat_fast_path_answers_random_data(vg, ctx, dim, metric, nodma):
         os.environ.pop("VG_FLAT_NO_DMA", None)
 
 
+@pytest.mark.parametrize("n,dim,nq,k,metric", [(30000, 768, 1, 10, 0), (9000, 128, 8, 32, 0), (5000, 1024, 3, 10, 2),
+                                                 (3000, 100, 7, 10, 0), (100, 64, 5, 10, 0), (20000, 256, 2, 10, 1)])
+def test_flat_small_batch_scan_matches_oracle(vg, ctx, n, dim, nq, k, metric):
+    """nq <= 8: the HBM-bound multi-query exact scan (no GEMM, no proof) answers; the same inputs
+    through the GEMM path (VG_FLAT_NO_SCAN=1) give the same bits."""
+    rng = np.random.default_rng(n + dim + nq)
+    idx, base, q = check(vg, ctx, n, dim, nq, k, metric, rng)
+    assert idx.flat_stats() == (nq, 0)
+    ids, sc = idx.search_flat(q, k)
+    os.environ["VG_FLAT_NO_SCAN"] = "1"
+    try:
+        ids2, sc2 = idx.search_flat(q, k)
+    finally:
+        os.environ.pop("VG_FLAT_NO_SCAN")
+    assert np.array_equal(ids, ids2) and np.array_equal(bits(sc), bits(sc2))
+
+
 def test_flat_duplicates_and_near_ties(vg, ctx):
     """Rows that differ in the last bits and exact duplicates: the proof step must either
     accept or fall back, and ties resolve by RowID."""

@@ -75,6 +75,10 @@ __global__ __launch_bounds__(256) void flat_todo_kernel(const int *__restrict__ 
     const int tid = threadIdx.x;
     const int per = (cnt + 255) / 256;
     const int lo = tid * per < cnt ? tid * per : cnt, hi = lo + per < cnt ? lo + per : cnt;
+    if (!flags) {  // a path with no proof step: only count the queries
+        if (tid == 0) atomicAdd(&stats[0], static_cast<unsigned long long>(cnt));
+        return;
+    }
     const bool all = *always != 0;
     int mine = 0;
     for (int i = lo; i < hi; i++) mine += (all || flags[i] != 0);
@@ -301,6 +305,105 @@ __global__ __launch_bounds__(256) void flat_exact_kernel(const float *__restrict
     }
 }
 
+// ---- small query batches: one HBM pass scores every row against up to 8 queries --------------------
+// Below ~8 queries the GEMM path is far from either roofline (a 128-query tile does 128 queries'
+// worth of MFMA work and 1/8 of the tiles' loads for whatever is in it: 1.65 ms at 1M x 768).
+// This kernel is the HBM-bound alternative: a 16-lane group loads a row ONCE into registers
+// (dim <= 1024: 16 float4 per lane) and scores it against QB queries held in LDS, each in the
+// reference's summation order (vg_exact.hpp, kPair) — exact by construction, no proof step.
+template <bool DOT>
+__device__ __forceinline__ float exact_rowregs16(const float4 (&rr)[16], int nblk, const float *__restrict__ row,
+                                                 const float *__restrict__ q, int dim, Sub16 sub)
+{
+    float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    const float4 *q4 = reinterpret_cast<const float4 *>(q) + sub.f4;
+#pragma unroll
+    for (int e = 0; e < 16; e++) {
+        if (e < nblk) {
+            const float4 a = q4[e * 16];
+            const float4 b = rr[e];
+            if (DOT) {
+                acc[0] = __builtin_fmaf(a.x, b.x, acc[0]);
+                acc[1] = __builtin_fmaf(a.y, b.y, acc[1]);
+                acc[2] = __builtin_fmaf(a.z, b.z, acc[2]);
+                acc[3] = __builtin_fmaf(a.w, b.w, acc[3]);
+            } else {
+                const float d0 = a.x - b.x, d1 = a.y - b.y, d2 = a.z - b.z, d3 = a.w - b.w;
+                acc[0] = __builtin_fmaf(d0, d0, acc[0]);
+                acc[1] = __builtin_fmaf(d1, d1, acc[1]);
+                acc[2] = __builtin_fmaf(d2, d2, acc[2]);
+                acc[3] = __builtin_fmaf(d3, d3, acc[3]);
+            }
+        }
+    }
+    float b[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        const float p = dpp_partner_add<kDppRowHalfMirror>(acc[t]);
+        const float s2 = dpp_partner_add<kDppRowMirror>(p);
+        const float a = dpp_partner_add<kDppQuadXor2>(s2);
+        b[t] = dpp_partner_add<kDppQuadXor1>(a);
+    }
+    float total = (b[0] + b[2]) + (b[1] + b[3]);
+    for (int j = nblk << 6; j < dim; j++) {  // scalar tail (FMA-contracted in the reference)
+        if (DOT) {
+            total = __builtin_fmaf(q[j], row[j], total);
+        } else {
+            const float d = q[j] - row[j];
+            total = __builtin_fmaf(d, d, total);
+        }
+    }
+    return total;
+}
+
+constexpr int kScanQB = 8;  // queries per pass
+template <bool DOT>
+__global__ __launch_bounds__(256) void flat_scan_mq_kernel(const float *__restrict__ base, int64_t n, int dim,
+                                                           const float *__restrict__ queries, int nq, int slices,
+                                                           int k, uint64_t *__restrict__ partial)
+{
+    extern __shared__ float qlds[];  // nq * dim floats, then the merge scratch
+    uint64_t *lists = reinterpret_cast<uint64_t *>(qlds + static_cast<size_t>(kScanQB) * dim);
+    int *valid = reinterpret_cast<int *>(lists + 4 * 64);
+    const int s = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int t = tid; t < nq * dim; t += 256) qlds[t] = queries[t];
+    __syncthreads();
+    const Sub16 sub = Sub16::make(tid);
+    const int nblk = dim >> 6;
+    const int64_t r0 = n * s / slices, r1 = n * (s + 1) / slices;
+    WaveTopK tk[kScanQB];
+#pragma unroll
+    for (int qi = 0; qi < kScanQB; qi++) tk[qi].init(k);
+    for (int64_t i0 = r0 + wave * 4; i0 < r1; i0 += 16) {
+        const int64_t i = i0 + (lane >> 4);
+        const bool live = i < r1;
+        const float *row = base + (live ? i : r1 - 1) * dim;
+        float4 rr[16];
+        const float4 *r4 = reinterpret_cast<const float4 *>(row) + sub.f4;
+#pragma unroll
+        for (int e = 0; e < 16; e++)
+            if (e < nblk) rr[e] = r4[e * 16];
+#pragma unroll
+        for (int qi = 0; qi < kScanQB; qi++) {
+            if (qi < nq) {
+                const float v = exact_rowregs16<DOT>(rr, nblk, row, qlds + static_cast<size_t>(qi) * dim, dim, sub);
+                uint64_t key = kKeyMax;
+                if (live && (lane & 15) == 0) key = make_key(v, static_cast<uint32_t>(i), DOT);
+                tk[qi].offer(key, lane);
+            }
+        }
+    }
+#pragma unroll
+    for (int qi = 0; qi < kScanQB; qi++) {
+        if (qi < nq) {
+            wg_rank_merge<4>(tk[qi], lists, valid, wave, lane, tid, k,
+                             partial + (static_cast<int64_t>(qi) * slices + s) * k);
+            __syncthreads();
+        }
+    }
+}
+
 // overwrite the results of the fallback queries from the exact scan's merged lists
 __global__ void flat_patch_kernel(const int *__restrict__ fallback, const int *__restrict__ always, int k,
                                   const uint32_t *__restrict__ fids, const float *__restrict__ fscores,
@@ -345,6 +448,29 @@ VG_API int32_t vg_search_flat(vg_index *idx, const float *queries, int64_t nq, i
         VG_TRY(none.init(static_cast<size_t>(nq) * k, st));
         VG_HIP(hipMemsetAsync(none.ptr, 0xFF, static_cast<size_t>(nq) * k * 8, st));
         VG_TRY(vg::launch_topk_merge(none.ptr, nq, 1, k, dot, oid.ptr, osc.ptr, st));
+    } else if (nq <= vg::kScanQB && dim % 4 == 0 && dim <= 1024 && dim >= 64 && !getenv("VG_FLAT_NO_SCAN") &&
+               !getenv("VG_FLAT_FORCE_EXACT") && !getenv("VG_FLAT_UNFUSED") &&
+               (reinterpret_cast<uintptr_t>(idx->d_vectors) & 15) == 0) {
+        // small batch: HBM-bound exact scan, kScanQB queries per pass over the rows
+        const int slices = static_cast<int>(std::min<int64_t>(4 * idx->ctx->compute_units, std::max<int64_t>(1, n / 64)));
+        vg::ArenaCall ar(idx->ctx, st);
+        const int i_partial = ar.add(sizeof(uint64_t) * static_cast<size_t>(nq) * slices * k);
+        VG_TRY(ar.commit());
+        uint64_t *partial = ar.get<uint64_t>(i_partial);
+        const size_t lds = sizeof(float) * static_cast<size_t>(vg::kScanQB) * dim + 4 * 64 * sizeof(uint64_t) + 64;
+        for (int64_t q0 = 0; q0 < nq; q0 += vg::kScanQB) {
+            const int cnt = static_cast<int>(std::min<int64_t>(vg::kScanQB, nq - q0));
+            vg::ProfScope prof(idx->ctx, "flat_scan", st);
+            if (dot)
+                VG_LAUNCH(vg::flat_scan_mq_kernel<true>, dim3(slices), dim3(256), lds, st, idx->d_vectors, n, dim,
+                          q.ptr + q0 * dim, cnt, slices, k, partial + q0 * slices * k);
+            else
+                VG_LAUNCH(vg::flat_scan_mq_kernel<false>, dim3(slices), dim3(256), lds, st, idx->d_vectors, n, dim,
+                          q.ptr + q0 * dim, cnt, slices, k, partial + q0 * slices * k);
+        }
+        VG_TRY(vg::launch_topk_merge(partial, nq, slices, k, dot, oid.ptr, osc.ptr, st));
+        VG_LAUNCH(vg::flat_todo_kernel, dim3(1), dim3(256), 0, st, nullptr, nullptr, static_cast<int>(nq), nullptr,
+                  idx->d_flat_stats);
     } else {
         const char *unfused_env = getenv("VG_FLAT_UNFUSED");  // test hook: materialise the score matrix
         const bool fused = !(unfused_env && unfused_env[0] == '1');
