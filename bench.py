@@ -149,6 +149,35 @@ def adc_scan_roofline(vg, ctx, stream, device):
     return res
 
 
+def flat_small_batch(vg, ctx, idx, queries, stream):
+    """BASELINE configs[1] below the MFMA regime (HBM-bound for Q < ~40): one
+    query per call = one pass over the 1M x 768 fp32 rows, N*d*4 algorithmic bytes."""
+    res = {"bound": "hbm", "peak": PEAK_HBM_GBS, "unit": "GB/s", "bytes_per_pass": N_ROWS * DIM * 4}
+    for nq in (1, 8):
+        q = queries[:nq].contiguous()
+        out = (torch.empty((nq, K), dtype=torch.int32, device=q.device), torch.empty((nq, K), device=q.device))
+        for _ in range(3):
+            idx.search_flat(q, K, out=out, stream=stream)
+        torch.cuda.synchronize()
+        ctx.profile_read("flat_scan")
+        ctx.profile_enable(True)
+        reps = 10
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for _ in range(reps):
+            idx.search_flat(q, K, out=out, stream=stream)
+        e1.record(stream)
+        torch.cuda.synchronize()
+        launches, ms = ctx.profile_read("flat_scan")
+        ctx.profile_enable(False)
+        kern_ms = ms / max(launches, 1)
+        res[f"q{nq}"] = {"call_ms": e0.elapsed_time(e1) / reps, "kernel": "flat_scan_mq_kernel<false>",
+                         "kernel_ms": kern_ms, "achieved": N_ROWS * DIM * 4 / (kern_ms * 1e-3) / 1e9,
+                         "frac": N_ROWS * DIM * 4 / (kern_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                         "qps": nq * 1e3 / (e0.elapsed_time(e1) / reps)}
+    return res
+
+
 def rabitq_scan_roofline(vg, ctx, stream, device):
     """BASELINE configs[4], one GPU's view: exhaustive RaBitQ scan, 10M x 768 -> 100 B per row
     (96 B of sign bits + f32 norm): algorithmic bytes = N*100 per launch."""
@@ -349,6 +378,8 @@ def main():
                      "kernel": "flat_gemm_dma_kernel<false,2>", "kernel_ms": gemm_avg_ms,
                      "launches": launches, "flops_per_launch": flops_per_launch},
     }
+    if world == 1:
+        out["flat_small_batch"] = flat_small_batch(vg, ctx, index.index, queries[2], stream)
     if world == 1 and not args.no_hnsw:
         out["hnsw_layer0"] = hnsw_layer0(vg, ctx, rows, queries, gt[:nrec], stream)
     if world == 1 and not args.no_adc:
