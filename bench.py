@@ -254,13 +254,49 @@ def hnsw_layer0(vg, ctx, rows, queries, gt_ids, stream):
     rec = float(np.mean([len(set(got[i]) & set(gt_ids[i])) / K for i in range(gt_ids.shape[0])]))
     dc = float(st[:, 1].sum())
     gathered = dc * DIM * 4 + float(st[:, 3].sum()) * deg * 4
+    vam = vamana_pq(vg, ctx, idx, rows, l0, q, gt_ids, stream)
     idx.close()
-    return {"workload": "hnsw_layer0_1Mx768_ef128_k10 on the exact 31-NN graph, 8192 queries in flight",
+    return {"vamana_pq": vam,
+            "workload": "hnsw_layer0_1Mx768_ef128_k10 on the exact 31-NN graph, 8192 queries in flight",
             "bound": "hbm", "achieved": gathered / (kern_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
             "frac": gathered / (kern_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, "traffic": None,
             "kernel": "hnsw_search_kernel", "kernel_ms": kern_ms, "qps": q.shape[0] / (kern_ms * 1e-3),
             "recall_at_10": rec, "distance_computations_per_query": dc / q.shape[0],
             "bytes_per_launch": gathered, "graph_build_s": build_s}
+
+
+def vamana_pq(vg, ctx, idx, rows, graph, q, gt_ids, stream):
+    """BASELINE configs[3], graph half: Vamana beam search (diskann/segment.go:503-706) over the
+    same 31-NN graph with PQ (m=96, K=256) node scoring = ComputeAsymmetricDistance per visited
+    node (no LUT, :536-557).  PQ trained on the GPU on a 32768-row sample."""
+    pq = vg.ProductQuantizer(ctx, DIM, 96, 256)
+    t0 = time.perf_counter()
+    pq.train(rows[:32768], iters=10, seed=1)
+    codes = pq.encode(rows)
+    torch.cuda.synchronize()
+    prep_s = time.perf_counter() - t0
+    idx.set_pq_codes(pq, codes)
+    idx.set_vamana_graph(graph, 0)
+    ids, _, st = idx.search_vamana(q, K, kind=1, stats=True, stream=stream)
+    torch.cuda.synchronize()
+    ctx.profile_read("vamana_search")
+    ctx.profile_enable(True)
+    reps = 3
+    for _ in range(reps):
+        idx.search_vamana(q, K, kind=1, stream=stream)
+    torch.cuda.synchronize()
+    launches, ms = ctx.profile_read("vamana_search")
+    ctx.profile_enable(False)
+    kern_ms = ms / max(launches, 1)
+    got = ids.cpu().numpy().view(np.uint32)[:gt_ids.shape[0]]
+    rec = float(np.mean([len(set(got[i]) & set(gt_ids[i])) / K for i in range(gt_ids.shape[0])]))
+    dc = float(st[:, 1].sum())
+    gathered = dc * 96 + float(st[:, 3].sum()) * graph.shape[1] * 4
+    return {"workload": "vamana_pq_1Mx768_m96_K256_k10 on the exact 31-NN graph, 8192 queries in flight",
+            "kernel": "vamana_search_kernel", "kernel_ms": kern_ms, "qps": q.shape[0] / (kern_ms * 1e-3),
+            "recall_at_10_before_rerank": rec, "distance_computations_per_query": dc / q.shape[0],
+            "bytes_per_launch": gathered, "gathered_gbs": gathered / (kern_ms * 1e-3) / 1e9,
+            "pq_train_encode_s": prep_s}
 
 
 def measured_traffic(key: str):
