@@ -55,7 +55,9 @@ typedef enum vg_status {
     VG_ERR_OUT_OF_MEMORY = -6,
     VG_ERR_HIP = -7,                /* a HIP runtime call failed */
     VG_ERR_NO_DEVICE = -8,          /* no gfx950 device / extension not usable */
-    VG_ERR_NOT_READY = -9           /* index lacks the data this search needs */
+    VG_ERR_NOT_READY = -9,          /* index lacks the data this search needs */
+    VG_ERR_FORMAT = -10,            /* segment image: "invalid magic number", "file too short for ..." */
+    VG_ERR_CHECKSUM = -11           /* segment image: "checksum mismatch: expected %x, got %x" */
 } vg_status;
 
 /* distance.Metric — distance/distance.go:66-73 */
@@ -70,6 +72,7 @@ typedef struct vg_ctx vg_ctx;     /* one per (process, GPU) */
 typedef struct vg_pq vg_pq;       /* quantization.ProductQuantizer — pq.go:20-29 */
 typedef struct vg_index vg_index; /* device-resident rows / codes / graph of one segment */
 typedef struct vg_sq8 vg_sq8;     /* quantization.ScalarQuantizer — quantizer.go:27-39 */
+typedef struct vg_segment vg_segment; /* an opened flat / DiskANN segment image: index + quantizers */
 
 /* ---- context ------------------------------------------------------------ */
 int32_t vg_abi_version(void);
@@ -292,6 +295,39 @@ int32_t vg_index_set_sq8_codes(vg_index *idx, vg_sq8 *sq, const uint8_t *codes, 
  * row, best k by (Score, RowID).  k <= 64. */
 int32_t vg_search_sq8(vg_index *idx, const float *queries, int64_t nq, int32_t k, uint32_t *ids,
                       float *scores, void *stream);
+
+/* ---- on-disk segment images --------------------------------------- */
+enum { VG_QUANT_NONE = 0, VG_QUANT_PQ = 1, VG_QUANT_SQ8 = 3, VG_QUANT_RABITQ = 5 }; /* quantization.Type, types.go:6-14 */
+typedef struct vg_segment_info {
+    uint64_t segment_id;
+    int64_t rows;
+    int32_t dim, metric;
+    int32_t kind;          /* 0 = flat segment, 1 = DiskANN segment */
+    int32_t quantization;  /* VG_QUANT_* */
+    int32_t pq_m, pq_k;
+    int32_t max_degree, search_list_size; /* DiskANN R and L (diskann/format.go:26-27) */
+    uint32_t entrypoint;
+} vg_segment_info;
+/* flat.Open (flat/segment.go:105-300) over a whole segment file held in host memory (mmap or
+ * read): header (flat/format.go:11-165), optional CRC32C of the body, SQ8 bounds / PQ codebooks,
+ * codes and fp32 rows are uploaded as they lie in the file.  The result owns a vg_index (and the
+ * quantizer the file describes); search it with vg_search_flat / vg_search_sq8 / vg_search_pq_adc
+ * / vg_rerank.  Errors carry the reference's messages ("invalid magic number", "unsupported
+ * version", "file too short for vectors", "checksum mismatch: ..."). */
+int32_t vg_segment_open_flat(vg_ctx *ctx, const void *image, int64_t size, int32_t verify_checksum,
+                             vg_segment **out, void *stream);
+/* diskann segment (diskann/format.go:8-119, segment.go:165-440,1393-1408): fp32 rows, the
+ * N x R uint32 graph and entry point, PQ codebooks + codes or RaBitQ codes; search with
+ * vg_search_vamana (kind 0 / 1 / 2).  LZ4-compressed vector blocks and INT4 are not supported. */
+int32_t vg_segment_open_diskann(vg_ctx *ctx, const void *image, int64_t size, int32_t verify_checksum,
+                                vg_segment **out, void *stream);
+int32_t vg_segment_get_info(vg_segment *seg, vg_segment_info *info);
+vg_index *vg_segment_index(vg_segment *seg); /* borrowed: valid until vg_segment_close */
+vg_pq *vg_segment_pq(vg_segment *seg);       /* NULL unless the segment is PQ-quantized */
+vg_sq8 *vg_segment_sq8(vg_segment *seg);     /* NULL unless the segment is SQ8-quantized */
+int32_t vg_segment_close(vg_segment *seg);
+/* hash.CRC32C (internal/hash/crc32c.go:15-17) */
+uint32_t vg_crc32c(const void *data, int64_t size);
 
 /* per-query counters, the reference's FilterGateStats (searcher/searcher.go:114-137) */
 typedef struct vg_search_stats {

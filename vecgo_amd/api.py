@@ -504,9 +504,20 @@ class Index:
         self.n, self.dim, self.metric = n, dim, Metric(metric)
         self._keep = []
 
+    @classmethod
+    def _borrowed(cls, ctx: Context, handle, n: int, dim: int, metric: int, owner):
+        """An Index view of a handle owned by something else (a Segment)."""
+        self = cls.__new__(cls)
+        self._lib, self.ctx, self._h = ctx._lib, ctx, handle
+        self.n, self.dim, self.metric = n, dim, Metric(metric)
+        self._keep = [owner]
+        self._borrowed_handle = True
+        return self
+
     def close(self):
         if getattr(self, "_h", None):
-            self._lib.vg_index_destroy(self._h)
+            if not getattr(self, "_borrowed_handle", False):
+                self._lib.vg_index_destroy(self._h)
             self._h = None
 
     def __del__(self):
@@ -643,3 +654,53 @@ class Index:
     def search_pq_adc(self, queries, k, out=None, stream=None):
         """flat.Segment.Search PQ branch (flat/segment.go:476-483,678-689,714-721)."""
         return self._search(self._lib.vg_search_pq_adc, queries, k, out=out, stream=stream)
+
+
+class SegmentInfo(C.Structure):
+    _fields_ = [("segment_id", C.c_uint64), ("rows", C.c_int64), ("dim", C.c_int32), ("metric", C.c_int32),
+                ("kind", C.c_int32), ("quantization", C.c_int32), ("pq_m", C.c_int32), ("pq_k", C.c_int32),
+                ("max_degree", C.c_int32), ("search_list_size", C.c_int32), ("entrypoint", C.c_uint32)]
+
+
+class Segment:
+    """A flat or DiskANN segment file of the reference (internal/segment/flat/format.go,
+    internal/segment/diskann/format.go) opened straight onto the GPU: `image` is the whole file
+    as bytes / numpy uint8 / np.memmap.  `index` is searched like any other Index."""
+
+    def __init__(self, ctx: Context, image, kind: str = "flat", verify_checksum: bool = True, stream=None):
+        self._lib, self.ctx = ctx._lib, ctx
+        buf = np.frombuffer(image, np.uint8) if isinstance(image, (bytes, bytearray, memoryview)) else \
+            np.ascontiguousarray(image, np.uint8)
+        fn = {"flat": self._lib.vg_segment_open_flat, "diskann": self._lib.vg_segment_open_diskann}[kind]
+        h = C.c_void_p()
+        check(fn(ctx._h, C.c_void_p(buf.ctypes.data), C.c_int64(buf.size), C.c_int32(int(verify_checksum)),
+                 C.byref(h), _stream_ptr(stream)))
+        self._h = h
+        info = SegmentInfo()
+        check(self._lib.vg_segment_get_info(self._h, C.byref(info)))
+        self.info = info
+        self._lib.vg_segment_index.restype = C.c_void_p
+        ih = C.c_void_p(self._lib.vg_segment_index(self._h))
+        self.index = Index._borrowed(ctx, ih, int(info.rows), int(info.dim), int(info.metric), self)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.index._h = None
+            self._lib.vg_segment_close(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def crc32c(data) -> int:
+    """hash.CRC32C (internal/hash/crc32c.go:15-17) as computed by the library."""
+    from . import _lib
+    lib = _lib.load()
+    lib.vg_crc32c.restype = C.c_uint32
+    buf = np.frombuffer(data, np.uint8) if isinstance(data, (bytes, bytearray, memoryview)) else \
+        np.ascontiguousarray(data, np.uint8)
+    return int(lib.vg_crc32c(C.c_void_p(buf.ctypes.data), C.c_int64(buf.size)))

@@ -139,6 +139,8 @@ VG_API const char *vg_status_string(int32_t s)
     case VG_ERR_HIP: return "HIP runtime error";
     case VG_ERR_NO_DEVICE: return "no usable gfx950 device";
     case VG_ERR_NOT_READY: return "index lacks the data this search needs";
+    case VG_ERR_FORMAT: return "malformed segment image";
+    case VG_ERR_CHECKSUM: return "checksum mismatch";
     default: return "unknown status";
     }
 }

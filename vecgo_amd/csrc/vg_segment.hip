@@ -1,0 +1,288 @@
+// vg_segment.hip — SURVEY.md §8(f) rank 2: the reference's on-disk segment images straight to a
+// resident index ("zero-parse": the file is already laid out as the arrays the kernels want).
+//   flat segment     internal/segment/flat/format.go:11-165 (header), segment.go:105-300 (Open)
+//   DiskANN segment  internal/segment/diskann/format.go:8-119 (header), segment.go:165-440, 1393-1408
+// Only the sections on the hot path are read: fp32 rows, quantizer parameters, codes, the graph.
+// Primary keys, metadata, block statistics and the inverted index stay with the host database.
+// Host code only (no kernels of its own): everything goes through the C ABI of the other files.
+#include <cstring>
+
+#include "vg_internal.hpp"
+
+struct vg_segment {
+    vg_ctx *ctx = nullptr;
+    vg_index *idx = nullptr;
+    vg_pq *pq = nullptr;
+    vg_sq8 *sq = nullptr;
+    vg_segment_info info{};
+};
+
+namespace {
+
+uint32_t rd32(const uint8_t *p)
+{
+    return static_cast<uint32_t>(p[0]) | (static_cast<uint32_t>(p[1]) << 8) | (static_cast<uint32_t>(p[2]) << 16) |
+           (static_cast<uint32_t>(p[3]) << 24);
+}
+uint16_t rd16(const uint8_t *p) { return static_cast<uint16_t>(p[0] | (p[1] << 8)); }
+uint64_t rd64(const uint8_t *p) { return static_cast<uint64_t>(rd32(p)) | (static_cast<uint64_t>(rd32(p + 4)) << 32); }
+
+// CRC-32C (Castagnoli, reflected polynomial 0x82F63B78) — internal/hash/crc32c.go:15-17
+uint32_t crc32c(const uint8_t *data, size_t n)
+{
+    static uint32_t table[8][256];
+    static bool ready = false;
+    if (!ready) {
+        for (uint32_t i = 0; i < 256; i++) {
+            uint32_t c = i;
+            for (int k = 0; k < 8; k++) c = (c & 1) ? (c >> 1) ^ 0x82F63B78u : c >> 1;
+            table[0][i] = c;
+        }
+        for (uint32_t i = 0; i < 256; i++)
+            for (int t = 1; t < 8; t++) table[t][i] = (table[t - 1][i] >> 8) ^ table[0][table[t - 1][i] & 0xFF];
+        ready = true;
+    }
+    uint32_t c = 0xFFFFFFFFu;
+    while (n >= 8) {  // slicing-by-8
+        const uint32_t lo = rd32(data) ^ c, hi = rd32(data + 4);
+        c = table[7][lo & 0xFF] ^ table[6][(lo >> 8) & 0xFF] ^ table[5][(lo >> 16) & 0xFF] ^ table[4][lo >> 24] ^
+            table[3][hi & 0xFF] ^ table[2][(hi >> 8) & 0xFF] ^ table[1][(hi >> 16) & 0xFF] ^ table[0][hi >> 24];
+        data += 8;
+        n -= 8;
+    }
+    while (n--) c = table[0][(c ^ *data++) & 0xFF] ^ (c >> 8);
+    return c ^ 0xFFFFFFFFu;
+}
+
+constexpr uint32_t kFlatMagic = 0x56454331;     // "VEC1" flat/format.go:12
+constexpr uint32_t kDiskMagic = 0x4449534B;     // "DISK" diskann/format.go:9
+constexpr size_t kFlatHeader = 152;             // flat/format.go:113
+constexpr size_t kDiskHeader = 160;             // diskann/format.go:49
+
+void close_partial(vg_segment *s)
+{
+    if (!s) return;
+    if (s->idx) (void)vg_index_destroy(s->idx);
+    if (s->pq) (void)vg_pq_destroy(s->pq);
+    if (s->sq) (void)vg_sq8_destroy(s->sq);
+    delete s;
+}
+
+// a failed open must not leak: run `expr`, on error drop the half-built segment and propagate
+#define SEG_TRY(expr)               \
+    do {                            \
+        int32_t _s = (expr);        \
+        if (_s != VG_OK) {          \
+            close_partial(seg);     \
+            return _s;              \
+        }                           \
+    } while (0)
+#define SEG_CHECK(cond, status, ...)      \
+    do {                                  \
+        if (!(cond)) {                    \
+            ::vg::set_error(__VA_ARGS__); \
+            close_partial(seg);           \
+            return (status);              \
+        }                                 \
+    } while (0)
+
+int32_t verify_body(const uint8_t *data, uint64_t size, size_t header, uint32_t want)
+{
+    if (want == 0 || size <= header) return VG_OK;  // segment.go: `Checksum != 0`
+    const uint32_t got = crc32c(data + header, static_cast<size_t>(size - header));
+    if (got != want) {
+        ::vg::set_error("checksum mismatch: expected %x, got %x", want, got);
+        return VG_ERR_CHECKSUM;
+    }
+    return VG_OK;
+}
+
+}  // namespace
+
+VG_API uint32_t vg_crc32c(const void *data, int64_t size)
+{
+    return data && size > 0 ? crc32c(static_cast<const uint8_t *>(data), static_cast<size_t>(size)) : 0;
+}
+
+VG_API int32_t vg_segment_open_flat(vg_ctx *ctx, const void *image, int64_t size, int32_t verify_checksum,
+                                    vg_segment **out, void *stream)
+{
+    VG_CHECK(out, VG_ERR_INVALID_ARG, "vg_segment_open_flat: out is NULL");
+    *out = nullptr;
+    VG_CHECK(ctx && image && size >= 0, VG_ERR_INVALID_ARG, "vg_segment_open_flat: NULL context or image");
+    const uint8_t *data = static_cast<const uint8_t *>(image);
+    const uint64_t len = static_cast<uint64_t>(size);
+    VG_CHECK(len >= kFlatHeader, VG_ERR_FORMAT, "buffer too small for header");  // format.go:138-140
+    VG_CHECK(rd32(data) == kFlatMagic, VG_ERR_FORMAT, "invalid magic number");
+    VG_CHECK(rd32(data + 4) == 1, VG_ERR_FORMAT, "unsupported version");
+    vg_segment *seg = new vg_segment;
+    seg->ctx = ctx;
+    vg_segment_info &h = seg->info;
+    h.kind = 0;
+    h.segment_id = rd64(data + 8);
+    h.rows = rd32(data + 16);
+    h.dim = static_cast<int32_t>(rd32(data + 20));
+    h.metric = data[24];
+    const uint32_t partitions = rd32(data + 28);
+    const int qtype = data[32];  // format.go:22-26: 0 none, 1 SQ8, 2 PQ
+    const uint64_t q_off = rd64(data + 56), codes_off = rd64(data + 64), vec_off = rd64(data + 72);
+    const uint32_t checksum = rd32(data + 104);
+    (void)partitions;  // IVF partitions only order the rows; an exhaustive scan ignores them
+    SEG_CHECK(h.dim > 0, VG_ERR_FORMAT, "flat segment: dimension 0");
+    SEG_CHECK(h.metric <= VG_METRIC_DOT, VG_ERR_UNSUPPORTED, "flat segment: metric %d has no float32 kernels", h.metric);
+    if (verify_checksum) SEG_TRY(verify_body(data, len, kFlatHeader, checksum));
+    const uint64_t n = static_cast<uint64_t>(h.rows), dim = static_cast<uint64_t>(h.dim);
+    SEG_TRY(vg_index_create(ctx, h.rows, h.dim, h.metric, &seg->idx));
+    if (qtype == 1) {  // segment.go:209-233: mins[dim] then maxs[dim], SetBounds, codes n*dim
+        SEG_CHECK(len >= q_off + dim * 8 && q_off + dim * 8 >= q_off, VG_ERR_FORMAT,
+                  "file too short for quantization metadata");
+        SEG_CHECK(len >= codes_off + n * dim && codes_off + n * dim >= codes_off, VG_ERR_FORMAT,
+                  "file too short for codes");
+        SEG_TRY(vg_sq8_create(ctx, h.dim, &seg->sq));
+        std::vector<float> mm(2 * dim);  // the image is only byte-aligned
+        memcpy(mm.data(), data + q_off, dim * 8);
+        SEG_TRY(vg_sq8_set_bounds(seg->sq, mm.data(), mm.data() + dim));
+        h.quantization = VG_QUANT_SQ8;
+        if (h.metric == VG_METRIC_L2)  // the reference scans SQ8 codes for L2 only (segment.go:517)
+            SEG_TRY(vg_index_set_sq8_codes(seg->idx, seg->sq, data + codes_off, stream));
+    } else if (qtype == 2) {  // segment.go:234-281: m, k, scales[m], offsets[m], codebooks[m*k*dsub], codes n*m
+        SEG_CHECK(len >= q_off + 8 && q_off + 8 >= q_off, VG_ERR_FORMAT, "file too short for PQ metadata");
+        const uint64_t m = rd32(data + q_off), k = rd32(data + q_off + 4);
+        SEG_CHECK(m > 0 && dim % m == 0, VG_ERR_FORMAT, "flat segment: %llu sub-quantizers do not divide dimension %llu",
+                  static_cast<unsigned long long>(m), static_cast<unsigned long long>(dim));
+        const uint64_t cb = m * k * (dim / m), meta = 8 + m * 8 + cb;
+        SEG_CHECK(len >= q_off + meta && q_off + meta >= q_off, VG_ERR_FORMAT, "file too short for PQ metadata");
+        SEG_CHECK(len >= codes_off + n * m && codes_off + n * m >= codes_off, VG_ERR_FORMAT, "file too short for codes");
+        SEG_TRY(vg_pq_create(ctx, h.dim, static_cast<int32_t>(m), static_cast<int32_t>(k), &seg->pq));
+        std::vector<float> so(2 * m);
+        memcpy(so.data(), data + q_off + 8, m * 8);
+        SEG_TRY(vg_pq_set_codebooks(seg->pq, reinterpret_cast<const int8_t *>(data + q_off + 8 + m * 8), so.data(),
+                                    so.data() + m));
+        h.quantization = VG_QUANT_PQ;
+        h.pq_m = static_cast<int32_t>(m);
+        h.pq_k = static_cast<int32_t>(k);
+        if (k == 256) SEG_TRY(vg_index_set_pq_codes(seg->idx, seg->pq, data + codes_off, stream));
+    } else {
+        SEG_CHECK(qtype == 0, VG_ERR_FORMAT, "flat segment: unknown quantization type %d", qtype);
+        h.quantization = VG_QUANT_NONE;
+    }
+    SEG_CHECK(len >= vec_off + n * dim * 4 && vec_off + n * dim * 4 >= vec_off, VG_ERR_FORMAT,
+              "file too short for vectors");  // segment.go:283-289
+    if (n) {
+        if (reinterpret_cast<uintptr_t>(data + vec_off) % 4 == 0) {
+            SEG_TRY(vg_index_set_vectors(seg->idx, reinterpret_cast<const float *>(data + vec_off), stream));
+        } else {
+            std::vector<float> v(n * dim);
+            memcpy(v.data(), data + vec_off, n * dim * 4);
+            SEG_TRY(vg_index_set_vectors(seg->idx, v.data(), stream));
+        }
+    }
+    *out = seg;
+    return VG_OK;
+}
+
+VG_API int32_t vg_segment_open_diskann(vg_ctx *ctx, const void *image, int64_t size, int32_t verify_checksum,
+                                       vg_segment **out, void *stream)
+{
+    VG_CHECK(out, VG_ERR_INVALID_ARG, "vg_segment_open_diskann: out is NULL");
+    *out = nullptr;
+    VG_CHECK(ctx && image && size >= 0, VG_ERR_INVALID_ARG, "vg_segment_open_diskann: NULL context or image");
+    const uint8_t *data = static_cast<const uint8_t *>(image);
+    const uint64_t len = static_cast<uint64_t>(size);
+    VG_CHECK(len >= kDiskHeader, VG_ERR_FORMAT, "buffer too small for header");  // format.go:81-83
+    VG_CHECK(rd32(data) == kDiskMagic, VG_ERR_FORMAT, "invalid magic number");
+    const uint32_t version = rd32(data + 4);
+    VG_CHECK(version == 2 || version == 1, VG_ERR_FORMAT, "unsupported version");
+    vg_segment *seg = new vg_segment;
+    seg->ctx = ctx;
+    vg_segment_info &h = seg->info;
+    h.kind = 1;
+    h.segment_id = rd64(data + 8);
+    h.rows = rd32(data + 16);
+    h.dim = static_cast<int32_t>(rd32(data + 20));
+    h.metric = data[24];
+    h.max_degree = static_cast<int32_t>(rd32(data + 25));
+    h.search_list_size = static_cast<int32_t>(rd32(data + 29));
+    h.entrypoint = rd32(data + 33);
+    const int qtype = data[37];  // quantization.Type (types.go:6-14): 1 PQ, 5 RaBitQ, 6 INT4
+    h.pq_m = rd16(data + 38);
+    h.pq_k = rd16(data + 40);
+    const int compression = version >= 2 ? data[42] : 0;
+    const uint64_t vec_off = rd64(data + 48), graph_off = rd64(data + 56), pq_codes_off = rd64(data + 64),
+                   bq_codes_off = rd64(data + 72), cb_off = rd64(data + 80), pk_off = rd64(data + 88);
+    const uint32_t checksum = rd32(data + 120);
+    SEG_CHECK(h.dim > 0, VG_ERR_FORMAT, "diskann segment: dimension 0");
+    SEG_CHECK(h.metric <= VG_METRIC_DOT, VG_ERR_UNSUPPORTED, "diskann segment: metric %d has no float32 kernels", h.metric);
+    SEG_CHECK(compression == 0, VG_ERR_UNSUPPORTED, "diskann segment: LZ4-compressed vector blocks are not supported");
+    if (verify_checksum) SEG_TRY(verify_body(data, len, kDiskHeader, checksum));
+    const uint64_t n = static_cast<uint64_t>(h.rows), dim = static_cast<uint64_t>(h.dim);
+    SEG_CHECK(len >= pk_off + n * 8, VG_ERR_FORMAT, "file size too small: expected at least %llu, got %llu",
+              static_cast<unsigned long long>(pk_off + n * 8), static_cast<unsigned long long>(len));  // segment.go:177-182
+    SEG_CHECK(len >= vec_off + n * dim * 4 && vec_off + n * dim * 4 >= vec_off, VG_ERR_FORMAT,
+              "vector section out of bounds");
+    const uint64_t r = static_cast<uint64_t>(h.max_degree);
+    SEG_CHECK(len >= graph_off + n * r * 4 && graph_off + n * r * 4 >= graph_off, VG_ERR_FORMAT,
+              "graph section out of bounds");
+    SEG_TRY(vg_index_create(ctx, h.rows, h.dim, h.metric, &seg->idx));
+    auto aligned_or_copy = [&](uint64_t off, uint64_t bytes, std::vector<uint32_t> &tmp) -> const void * {
+        if (reinterpret_cast<uintptr_t>(data + off) % 4 == 0) return data + off;
+        tmp.resize((bytes + 3) / 4);
+        memcpy(tmp.data(), data + off, bytes);
+        return tmp.data();
+    };
+    std::vector<uint32_t> tmp;
+    if (n) {
+        SEG_TRY(vg_index_set_vectors(seg->idx, static_cast<const float *>(aligned_or_copy(vec_off, n * dim * 4, tmp)),
+                                     stream));
+        if (r)
+            SEG_TRY(vg_index_set_vamana_graph(seg->idx, h.max_degree,
+                                              static_cast<const uint32_t *>(aligned_or_copy(graph_off, n * r * 4, tmp)),
+                                              h.entrypoint, stream));
+    }
+    h.quantization = VG_QUANT_NONE;
+    if (qtype == 1) {  // segment.go:305-376 loadPQ: codes n*m; scales[m], offsets[m], codebooks[m*k*subDim]
+        const uint64_t m = static_cast<uint64_t>(h.pq_m), k = static_cast<uint64_t>(h.pq_k);
+        SEG_CHECK(m > 0 && dim % m == 0, VG_ERR_FORMAT, "diskann segment: %llu sub-quantizers do not divide dimension %llu",
+                  static_cast<unsigned long long>(m), static_cast<unsigned long long>(dim));
+        SEG_CHECK(len >= pq_codes_off + n * m && pq_codes_off + n * m >= pq_codes_off, VG_ERR_FORMAT,
+                  "PQ codes section out of bounds");
+        const uint64_t cb = m * k * (dim / m);
+        SEG_CHECK(len >= cb_off + m * 8 + cb && cb_off + m * 8 + cb >= cb_off, VG_ERR_FORMAT,
+                  "failed to read PQ codebooks: out of bounds");
+        SEG_TRY(vg_pq_create(ctx, h.dim, h.pq_m, h.pq_k, &seg->pq));
+        std::vector<float> so(2 * m);
+        memcpy(so.data(), data + cb_off, m * 8);
+        SEG_TRY(vg_pq_set_codebooks(seg->pq, reinterpret_cast<const int8_t *>(data + cb_off + m * 8), so.data(),
+                                    so.data() + m));
+        if (n && k == 256) SEG_TRY(vg_index_set_pq_codes(seg->idx, seg->pq, data + pq_codes_off, stream));
+        h.quantization = VG_QUANT_PQ;
+    } else if (qtype == 5) {  // segment.go:1393-1408 loadRaBitQ: n * (((dim+63)/64)*8 + 4) bytes
+        const uint64_t per = static_cast<uint64_t>(vg_rabitq_code_bytes(h.dim));
+        SEG_CHECK(len >= bq_codes_off + n * per && bq_codes_off + n * per >= bq_codes_off, VG_ERR_FORMAT,
+                  "RaBitQ codes section out of bounds");
+        if (n) SEG_TRY(vg_index_set_rabitq_codes(seg->idx, data + bq_codes_off, stream));
+        h.quantization = VG_QUANT_RABITQ;
+    } else {
+        SEG_CHECK(qtype == 0, VG_ERR_UNSUPPORTED,
+                  "diskann segment: quantization type %d (OPQ / SQ8 / BQ / INT4) has no device scorer yet", qtype);
+    }
+    *out = seg;
+    return VG_OK;
+}
+
+VG_API int32_t vg_segment_get_info(vg_segment *seg, vg_segment_info *info)
+{
+    VG_CHECK(seg && info, VG_ERR_INVALID_ARG, "vg_segment_get_info: NULL argument");
+    *info = seg->info;
+    return VG_OK;
+}
+
+VG_API vg_index *vg_segment_index(vg_segment *seg) { return seg ? seg->idx : nullptr; }
+VG_API vg_pq *vg_segment_pq(vg_segment *seg) { return seg ? seg->pq : nullptr; }
+VG_API vg_sq8 *vg_segment_sq8(vg_segment *seg) { return seg ? seg->sq : nullptr; }
+
+VG_API int32_t vg_segment_close(vg_segment *seg)
+{
+    close_partial(seg);
+    return VG_OK;
+}
