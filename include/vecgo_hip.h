@@ -72,6 +72,7 @@ typedef struct vg_ctx vg_ctx;     /* one per (process, GPU) */
 typedef struct vg_pq vg_pq;       /* quantization.ProductQuantizer — pq.go:20-29 */
 typedef struct vg_index vg_index; /* device-resident rows / codes / graph of one segment */
 typedef struct vg_sq8 vg_sq8;     /* quantization.ScalarQuantizer — quantizer.go:27-39 */
+typedef struct vg_int4 vg_int4;   /* quantization.Int4Quantizer — int4.go:12-20 */
 typedef struct vg_segment vg_segment; /* an opened flat / DiskANN segment image: index + quantizers */
 
 /* ---- context ------------------------------------------------------------ */
@@ -296,8 +297,34 @@ int32_t vg_index_set_sq8_codes(vg_index *idx, vg_sq8 *sq, const uint8_t *codes, 
 int32_t vg_search_sq8(vg_index *idx, const float *queries, int64_t nq, int32_t k, uint32_t *ids,
                       float *scores, void *stream);
 
+/* ---- INT4 (internal/quantization/int4.go, internal/simd/src/int4_avx512.c) -------------- */
+int32_t vg_int4_create(vg_ctx *ctx, int32_t dim, vg_int4 **out);
+int32_t vg_int4_destroy(vg_int4 *iq);
+int32_t vg_int4_is_trained(vg_int4 *iq);
+/* Train int4.go:29-62: per-dimension min and diff = max - min (0 -> 1), then
+ * simd.BuildInt4LookupTable (kernels.go:94-103) */
+int32_t vg_int4_train(vg_int4 *iq, const float *vectors, int64_t n, void *stream);
+/* UnmarshalBinary int4.go:190-219: min[dim], diff[dim] as stored, lookup table rebuilt */
+int32_t vg_int4_set_params(vg_int4 *iq, const float *min_val, const float *diff);
+/* min[dim], diff[dim], table[dim*16] (any pointer may be NULL) */
+int32_t vg_int4_get_params(vg_int4 *iq, float *min_val, float *diff, float *table);
+int64_t vg_int4_code_bytes(int32_t dim); /* (dim + 1) / 2 */
+/* Encode int4.go:65-105, batched: two dimensions per byte, the even one in the high nibble,
+ * quant = byte(math.Round(float64(clamp((v - min) / diff)) * 15)) */
+int32_t vg_int4_encode(vg_int4 *iq, const float *vectors, int64_t n, uint8_t *codes, void *stream);
+/* Decode int4.go:108-130, batched: float32(q)/15.0*diff + min */
+int32_t vg_int4_decode(vg_int4 *iq, const uint8_t *codes, int64_t n, float *out, void *stream);
+/* precomputed = 0: L2DistanceBatch (int4.go:150-164) = int4L2DistanceBatchAvx512 order
+ * (int4_avx512.c:191-299); precomputed = 1: L2Distance (int4.go:133-147) =
+ * int4L2DistancePrecomputedAvx512 order (:127-189) for each of the n codes.  out[n]. */
+int32_t vg_int4_l2_distance_batch(vg_int4 *iq, const float *query, const uint8_t *codes, int64_t n,
+                                  int32_t precomputed, float *out, void *stream);
+/* INT4 codes of a DiskANN segment (diskann/segment.go:378-416), n * ceil(dim/2) bytes; scored by
+ * vg_search_vamana kind 3.  The quantizer must outlive the index. */
+int32_t vg_index_set_int4_codes(vg_index *idx, vg_int4 *iq, const uint8_t *codes, void *stream);
+
 /* ---- on-disk segment images --------------------------------------- */
-enum { VG_QUANT_NONE = 0, VG_QUANT_PQ = 1, VG_QUANT_SQ8 = 3, VG_QUANT_RABITQ = 5 }; /* quantization.Type, types.go:6-14 */
+enum { VG_QUANT_NONE = 0, VG_QUANT_PQ = 1, VG_QUANT_SQ8 = 3, VG_QUANT_RABITQ = 5, VG_QUANT_INT4 = 6 }; /* quantization.Type, types.go:6-14 */
 typedef struct vg_segment_info {
     uint64_t segment_id;
     int64_t rows;
@@ -318,13 +345,15 @@ int32_t vg_segment_open_flat(vg_ctx *ctx, const void *image, int64_t size, int32
                              vg_segment **out, void *stream);
 /* diskann segment (diskann/format.go:8-119, segment.go:165-440,1393-1408): fp32 rows, the
  * N x R uint32 graph and entry point, PQ codebooks + codes or RaBitQ codes; search with
- * vg_search_vamana (kind 0 / 1 / 2).  LZ4-compressed vector blocks and INT4 are not supported. */
+ * or INT4 parameters + codes; search with vg_search_vamana (kind 0 / 1 / 2 / 3).  LZ4-compressed
+ * vector blocks are not supported. */
 int32_t vg_segment_open_diskann(vg_ctx *ctx, const void *image, int64_t size, int32_t verify_checksum,
                                 vg_segment **out, void *stream);
 int32_t vg_segment_get_info(vg_segment *seg, vg_segment_info *info);
 vg_index *vg_segment_index(vg_segment *seg); /* borrowed: valid until vg_segment_close */
 vg_pq *vg_segment_pq(vg_segment *seg);       /* NULL unless the segment is PQ-quantized */
 vg_sq8 *vg_segment_sq8(vg_segment *seg);     /* NULL unless the segment is SQ8-quantized */
+vg_int4 *vg_segment_int4(vg_segment *seg);   /* NULL unless the segment is INT4-quantized */
 int32_t vg_segment_close(vg_segment *seg);
 /* hash.CRC32C (internal/hash/crc32c.go:15-17) */
 uint32_t vg_crc32c(const void *data, int64_t size);
@@ -348,7 +377,8 @@ int32_t vg_search_hnsw(vg_index *idx, const float *queries, int64_t nq, int32_t 
 /* diskann.Segment.searchInternal (diskann/segment.go:503-706), filters nil.  kind selects the
  * distFn: 0 = fp32 rows (distance.Provider(metric), :582-588), 1 = PQ
  * ComputeAsymmetricDistance (:536-541, terms summed sequentially over the sub-quantizers),
- * 2 = RaBitQ Distance (:512-519).  Unbounded exploration min-heap, top-k CandidateHeap,
+ * 2 = RaBitQ Distance (:512-519), 3 = INT4 L2Distance (:558-565).  Unbounded exploration
+ * min-heap, top-k CandidateHeap,
  * stop when the popped candidate is worse than the k-th result.  k <= 64. */
 int32_t vg_search_vamana(vg_index *idx, const float *queries, int64_t nq, int32_t k, int32_t kind,
                          uint32_t *ids, float *scores, vg_search_stats *stats, void *stream);

@@ -15,7 +15,7 @@ import numpy as np
 _HERE = Path(__file__).resolve().parent
 
 METRIC_L2, METRIC_COSINE, METRIC_DOT, METRIC_HAMMING = 0, 1, 2, 3
-VAMANA_F32, VAMANA_PQ, VAMANA_RABITQ = 0, 1, 2
+VAMANA_F32, VAMANA_PQ, VAMANA_RABITQ, VAMANA_INT4 = 0, 1, 2, 3
 
 _f32p = C.POINTER(C.c_float)
 _u8p = C.POINTER(C.c_uint8)
@@ -58,7 +58,7 @@ class HnswGraph(C.Structure):
 class Vamana(C.Structure):
     _fields_ = [("n", C.c_int64), ("dim", C.c_int32), ("r", C.c_int32), ("graph", _u32p),
                 ("entry_point", C.c_uint32), ("kind", C.c_int32), ("metric", C.c_int32),
-                ("base", _f32p), ("pq", C.POINTER(PQ)), ("codes", _u8p)]
+                ("base", _f32p), ("pq", C.POINTER(PQ)), ("codes", _u8p), ("int4_table", _f32p)]
 
 
 class SearchStats(C.Structure):
@@ -115,6 +115,13 @@ _sig("vgo_sq8_train", None, _f32p, C.c_int64, C.c_int32, _f32p, _f32p, _f32p, _f
 _sig("vgo_sq8_encode", None, _f32p, C.c_int32, _f32p, _f32p, _f32p, _u8p)
 _sig("vgo_sq8_decode", None, _u8p, C.c_int32, _f32p, _f32p, _f32p)
 _sig("vgo_flat_search_sq8", C.c_int32, _u8p, C.c_int64, C.c_int32, _f32p, _f32p, _f32p, C.c_int32, _u32p, _f32p)
+_sig("vgo_int4_l2", C.c_float, _f32p, _u8p, C.c_int64, _f32p, _f32p)
+_sig("vgo_int4_l2_batch", None, _f32p, _u8p, C.c_int64, C.c_int64, _f32p, _f32p, _f32p)
+_sig("vgo_int4_build_lut", None, _f32p, _f32p, C.c_int32, _f32p)
+_sig("vgo_int4_l2_precomputed", C.c_float, _f32p, _u8p, C.c_int64, _f32p)
+_sig("vgo_int4_train", None, _f32p, C.c_int64, C.c_int32, _f32p, _f32p)
+_sig("vgo_int4_encode", None, _f32p, C.c_int32, _f32p, _f32p, _u8p)
+_sig("vgo_int4_decode", None, _u8p, C.c_int32, _f32p, _f32p, _f32p)
 _sig("vgo_rerank_f32", None, _f32p, C.c_int32, C.c_int32, _f32p, _u32p, C.c_int32, _f32p)
 _sig("vgo_hnsw_search", C.c_int32, C.POINTER(HnswGraph), _f32p, C.c_int32, C.c_int32, _u32p,
      _f32p, C.POINTER(SearchStats))
@@ -406,6 +413,68 @@ def flat_search_sq8(sq: ScalarQuantizer, codes, query, k):
     return ids[:r], sc[:r]
 
 
+# ---- INT4 ---------------------------------------------------------------------
+class Int4Quantizer:
+    """Oracle-side quantization.Int4Quantizer (internal/quantization/int4.go)."""
+
+    def __init__(self, dim):
+        self.dim = dim
+        self.min = np.zeros(dim, np.float32); self.diff = np.ones(dim, np.float32)
+        self.table = None
+
+    def set_params(self, min_val, diff):  # UnmarshalBinary (int4.go:190-219)
+        self.min = np.ascontiguousarray(min_val, np.float32); self.diff = np.ascontiguousarray(diff, np.float32)
+        self._build()
+
+    def _build(self):
+        self.table = np.empty(self.dim * 16, np.float32)
+        lib.vgo_int4_build_lut(self.min.ctypes.data_as(_f32p), self.diff.ctypes.data_as(_f32p), self.dim,
+                               self.table.ctypes.data_as(_f32p))
+
+    def train(self, vectors):
+        v, pv = _f(vectors)
+        lib.vgo_int4_train(pv, v.size // self.dim, self.dim, self.min.ctypes.data_as(_f32p),
+                           self.diff.ctypes.data_as(_f32p))
+        self._build()
+
+    @property
+    def code_size(self):
+        return (self.dim + 1) // 2
+
+    def encode(self, vec):
+        v, pv = _f(vec)
+        out = np.empty(self.code_size, np.uint8)
+        lib.vgo_int4_encode(pv, self.dim, self.min.ctypes.data_as(_f32p), self.diff.ctypes.data_as(_f32p),
+                            out.ctypes.data_as(_u8p))
+        return out
+
+    def encode_batch(self, vecs):
+        v = np.ascontiguousarray(vecs, np.float32).reshape(-1, self.dim)
+        return np.stack([self.encode(r) for r in v]) if len(v) else np.zeros((0, self.code_size), np.uint8)
+
+    def decode(self, code):
+        c, pc = _u8(code)
+        out = np.empty(self.dim, np.float32)
+        lib.vgo_int4_decode(pc, self.dim, self.min.ctypes.data_as(_f32p), self.diff.ctypes.data_as(_f32p),
+                            out.ctypes.data_as(_f32p))
+        return out
+
+    def l2_distance(self, query, code):
+        """L2Distance (int4.go:133-147): the table exists after Train / UnmarshalBinary."""
+        q, pq_ = _f(query); c, pc = _u8(code)
+        return np.float32(lib.vgo_int4_l2_precomputed(pq_, pc, self.dim, self.table.ctypes.data_as(_f32p)))
+
+    def l2_distance_batch(self, query, codes):
+        """L2DistanceBatch (int4.go:150-164) = simd.Int4L2DistanceBatch."""
+        q, pq_ = _f(query); c, pc = _u8(codes)
+        n = c.size // self.code_size
+        out = np.zeros(n, np.float32)
+        if n:
+            lib.vgo_int4_l2_batch(pq_, pc, self.dim, n, self.min.ctypes.data_as(_f32p),
+                                  self.diff.ctypes.data_as(_f32p), out.ctypes.data_as(_f32p))
+        return out
+
+
 # ---- scans --------------------------------------------------------------------
 def flat_search_f32(base, dim, query, k, metric=METRIC_L2):
     b, pb = _f(base); q, pq_ = _f(query)
@@ -478,7 +547,8 @@ class HnswIndex:
 
 class VamanaIndex:
     def __init__(self, graph, entry_point, dim, kind=VAMANA_F32, metric=METRIC_L2, base=None,
-                 pq: ProductQuantizer | None = None, codes=None):
+                 pq: ProductQuantizer | None = None, codes=None, int4_table=None):
+        self.int4_table = None if int4_table is None else np.ascontiguousarray(int4_table, np.float32)
         self.graph = np.ascontiguousarray(graph, np.uint32)
         self.n, self.r = self.graph.shape
         self.entry_point, self.dim, self.kind, self.metric = entry_point, dim, kind, metric
@@ -495,7 +565,8 @@ class VamanaIndex:
                    self.kind, self.metric,
                    self.base.ctypes.data_as(_f32p) if self.base is not None else None,
                    C.pointer(pqc) if pqc is not None else None,
-                   self.codes.ctypes.data_as(_u8p) if self.codes is not None else None)
+                   self.codes.ctypes.data_as(_u8p) if self.codes is not None else None,
+                   self.int4_table.ctypes.data_as(_f32p) if self.int4_table is not None else None)
         r = lib.vgo_vamana_search(C.byref(v), pq_, k, ids.ctypes.data_as(_u32p),
                                   sc.ctypes.data_as(_f32p), C.byref(st))
         return ids[:r], sc[:r], st
@@ -522,6 +593,12 @@ def load_ref():
     for n in ("dotProductAvx512", "squaredL2Avx512", "squaredL2BatchAvx512", "dotBatchAvx512",
               "squaredL2BoundedAvx512", "pqAdcLookupAvx512"):
         getattr(r, n).restype = None
+    if hasattr(r, "int4L2DistanceBatchAvx512"):
+        r.int4L2DistanceAvx512.argtypes = [vp, vp, C.c_int64, vp, vp, vp]
+        r.int4L2DistancePrecomputedAvx512.argtypes = [vp, vp, C.c_int64, vp, vp]
+        r.int4L2DistanceBatchAvx512.argtypes = [vp, vp, C.c_int64, C.c_int64, vp, vp, vp]
+        for n in ("int4L2DistanceAvx512", "int4L2DistancePrecomputedAvx512", "int4L2DistanceBatchAvx512"):
+            getattr(r, n).restype = None
     if hasattr(r, "sq8uL2BatchPerDimensionAvx512"):  # sq8_avx512.c joined the recipe later
         r.sq8uL2BatchPerDimensionAvx512.argtypes = [vp, vp, vp, vp, C.c_int64, C.c_int64, vp]
         r.sq8uL2BatchPerDimensionAvx512.restype = None
@@ -586,6 +663,33 @@ class Ref:
             self.lib.pqAdcLookupAvx512(t.ctypes.data, c.ctypes.data, m, r.ctypes.data,
                                        self._off.ctypes.data)
         return r[0]
+
+    def int4_l2(self, query, code, min_val, diff):
+        q = np.ascontiguousarray(query, np.float32); c = np.ascontiguousarray(code, np.uint8)
+        mn = np.ascontiguousarray(min_val, np.float32); df = np.ascontiguousarray(diff, np.float32)
+        r = np.zeros(1, np.float32)
+        if q.size:  # kernels_amd64.go: empty query -> 0
+            self.lib.int4L2DistanceAvx512(q.ctypes.data, c.ctypes.data, q.size, mn.ctypes.data, df.ctypes.data,
+                                          r.ctypes.data)
+        return r[0]
+
+    def int4_l2_precomputed(self, query, code, table):
+        q = np.ascontiguousarray(query, np.float32); c = np.ascontiguousarray(code, np.uint8)
+        t = np.ascontiguousarray(table, np.float32)
+        r = np.zeros(1, np.float32)
+        if q.size:
+            self.lib.int4L2DistancePrecomputedAvx512(q.ctypes.data, c.ctypes.data, q.size, t.ctypes.data, r.ctypes.data)
+        return r[0]
+
+    def int4_l2_batch(self, query, codes, dim, min_val, diff):
+        q = np.ascontiguousarray(query, np.float32); c = np.ascontiguousarray(codes, np.uint8)
+        mn = np.ascontiguousarray(min_val, np.float32); df = np.ascontiguousarray(diff, np.float32)
+        n = c.size // ((dim + 1) // 2) if dim else 0
+        out = np.zeros(n, np.float32)
+        if n and dim:
+            self.lib.int4L2DistanceBatchAvx512(q.ctypes.data, c.ctypes.data, dim, n, mn.ctypes.data, df.ctypes.data,
+                                               out.ctypes.data)
+        return out
 
     def sq8u_l2_batch(self, query, codes, mins, inv_scales, dim):
         q = np.ascontiguousarray(query, np.float32); c = np.ascontiguousarray(codes, np.uint8)

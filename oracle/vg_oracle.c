@@ -1132,6 +1132,8 @@ static float vamana_dist(const vgo_vamana *v, const float *q, uint32_t id)
         return vgo_pq_asym_distance(v->pq, q, v->codes + (int64_t)id * v->pq->m);
     case VGO_VAMANA_RABITQ: /* segment.go:512-519 */
         return vgo_rabitq_distance(q, v->dim, v->codes + (int64_t)id * vgo_rabitq_code_bytes(v->dim));
+    case VGO_VAMANA_INT4: /* segment.go:558-565: iq.L2Distance -> lookup-table kernel (int4.go:140-147) */
+        return vgo_int4_l2_precomputed(q, v->codes + (int64_t)id * ((v->dim + 1) / 2), v->dim, v->int4_table);
     default: /* segment.go:582-588, distFunc = Provider(metric) */
         return v->metric == VGO_METRIC_L2
                    ? vgo_l2_avx512(q, v->base + (int64_t)id * v->dim, v->dim)
@@ -1281,4 +1283,152 @@ int32_t vgo_flat_search_sq8(const uint8_t *codes, int64_t n, int32_t dim, const 
     int32_t r = emit_sorted(&h, ids, scores);
     vgo_candheap_free(&h);
     return r;
+}
+
+/* ------------------------------------------------------------------ */
+/* INT4                                          */
+/* ------------------------------------------------------------------ */
+/* 1/15 as the reference materialises it: bits 0x3d888889 (int4_avx512.c:13-19,35-38) */
+static float inv15(void)
+{
+    uint32_t b = 0x3d888889u;
+    float f;
+    memcpy(&f, &b, 4);
+    return f;
+}
+
+/* element j of a packed code: even j = high nibble of byte j/2, odd j = low nibble (int4.go:93) */
+static inline float nib(const uint8_t *code, int64_t j)
+{
+    uint8_t b = code[j / 2];
+    return (float)((j & 1) ? (b & 0x0F) : ((b >> 4) & 0x0F));
+}
+
+/* internal/simd/src/int4_avx512.c:21-125 int4L2DistanceAvx512 == :191-299 int4L2DistanceBatchAvx512
+ * per row: two 16-lane accumulators; 64-element blocks put sub-blocks 0,1 into sum1 and 2,3 into
+ * sum2, 32-element blocks both into sum1; dq = fma(f * inv15, diff, min) (the product rounded first);
+ * sum1 + sum2, _mm512_reduce_add_ps, then a scalar tail that clang contracts the same way. */
+float vgo_int4_l2(const float *query, const uint8_t *code, int64_t dim, const float *min_val, const float *diff)
+{
+    float s1[16], s2[16];
+    memset(s1, 0, sizeof s1);
+    memset(s2, 0, sizeof s2);
+    const float sc = inv15();
+    int64_t i = 0;
+#define INT4_BLOCK(acc, base)                                                  \
+    for (int l = 0; l < 16; l++) {                                             \
+        int64_t j = (base) + l;                                                \
+        float f = nib(code, j) * sc;                                           \
+        float dq = FMA(f, diff[j], min_val[j]);                                \
+        float d = query[j] - dq;                                               \
+        acc[l] = FMA(d, d, acc[l]);                                            \
+    }
+    for (; i <= dim - 64; i += 64) {
+        INT4_BLOCK(s1, i)
+        INT4_BLOCK(s1, i + 16)
+        INT4_BLOCK(s2, i + 32)
+        INT4_BLOCK(s2, i + 48)
+    }
+    for (; i <= dim - 32; i += 32) {
+        INT4_BLOCK(s1, i)
+        INT4_BLOCK(s1, i + 16)
+    }
+#undef INT4_BLOCK
+    for (int l = 0; l < 16; l++) s1[l] = s1[l] + s2[l];
+    float total = reduce16(s1);
+    for (; i < dim; i++) { /* `for (; i < dim; i += 2)` with the i+1 < dim guard, element by element */
+        float f = nib(code, i) * sc;
+        float v = FMA(f, diff[i], min_val[i]);
+        float d = query[i] - v;
+        total = FMA(d, d, total);
+    }
+    return total;
+}
+
+void vgo_int4_l2_batch(const float *query, const uint8_t *codes, int64_t dim, int64_t n, const float *min_val,
+                       const float *diff, float *out)
+{
+    int64_t cs = (dim + 1) / 2;
+    for (int64_t j = 0; j < n; j++) out[j] = vgo_int4_l2(query, codes + j * cs, dim, min_val, diff);
+}
+
+/* internal/simd/kernels.go:94-103 BuildInt4LookupTable: (float32(q)/15.0)*diff + min, three
+ * separately rounded fp32 operations (Go on amd64 does not fuse) */
+void vgo_int4_build_lut(const float *min_val, const float *diff, int32_t dim, float *table)
+{
+    for (int d = 0; d < dim; d++)
+        for (int q = 0; q < 16; q++) {
+            float a = (float)q / 15.0f;
+            float b = a * diff[d];
+            table[d * 16 + q] = b + min_val[d];
+        }
+}
+
+/* internal/simd/src/int4_avx512.c:127-189 int4L2DistancePrecomputedAvx512: one 16-lane accumulator
+ * over 16-element blocks of table values, reduce tree, contracted scalar tail.  This is what
+ * Int4Quantizer.L2Distance runs once the table exists (int4.go:140-147), i.e. the DiskANN node scorer. */
+float vgo_int4_l2_precomputed(const float *query, const uint8_t *code, int64_t dim, const float *table)
+{
+    float sum[16];
+    memset(sum, 0, sizeof sum);
+    int64_t i = 0;
+    for (; i <= dim - 16; i += 16)
+        for (int l = 0; l < 16; l++) {
+            int64_t j = i + l;
+            float v = table[j * 16 + (int)nib(code, j)];
+            float d = query[j] - v;
+            sum[l] = FMA(d, d, sum[l]);
+        }
+    float total = reduce16(sum);
+    for (; i < dim; i++) {
+        float v = table[i * 16 + (int)nib(code, i)];
+        float d = query[i] - v;
+        total = FMA(d, d, total);
+    }
+    return total;
+}
+
+/* internal/quantization/int4.go:29-62 Train: min / max per dimension starting from vectors[0],
+ * diff = max - min, 0 -> 1 */
+void vgo_int4_train(const float *vectors, int64_t n, int32_t dim, float *min_val, float *diff)
+{
+    for (int d = 0; d < dim; d++) {
+        float mn = vectors[d], mx = vectors[d];
+        for (int64_t i = 1; i < n; i++) {
+            float v = vectors[i * dim + d];
+            if (v < mn) mn = v;
+            if (v > mx) mx = v;
+        }
+        min_val[d] = mn;
+        float df = mx - mn;
+        diff[d] = df == 0.0f ? 1.0f : df;
+    }
+}
+
+static uint8_t int4_quant(float v, float mn, float df)
+{
+    float norm = (v - mn) / df; /* int4.go:75-81 */
+    if (norm < 0.0f) norm = 0.0f;
+    else if (norm > 1.0f) norm = 1.0f;
+    return (uint8_t)round((double)norm * 15.0); /* byte(math.Round(float64(norm) * 15)) */
+}
+
+/* int4.go:65-105 Encode: two dimensions per byte, the even one in the high nibble */
+void vgo_int4_encode(const float *v, int32_t dim, const float *min_val, const float *diff, uint8_t *out)
+{
+    for (int i = 0; i < dim; i += 2) {
+        uint8_t q1 = int4_quant(v[i], min_val[i], diff[i]);
+        uint8_t q2 = i + 1 < dim ? int4_quant(v[i + 1], min_val[i + 1], diff[i + 1]) : 0;
+        out[i / 2] = (uint8_t)((q1 << 4) | (q2 & 0x0F));
+    }
+}
+
+/* int4.go:108-130 Decode: float32(q)/15.0*diff + min, left to right, no fusion */
+void vgo_int4_decode(const uint8_t *code, int32_t dim, const float *min_val, const float *diff, float *out)
+{
+    for (int i = 0; i < dim; i++) {
+        float a = nib(code, i) / 15.0f;
+        float b = a * diff[i];
+        out[i] = b + min_val[i];
+    }
 }

@@ -159,7 +159,7 @@ typedef struct {
 int32_t vgo_hnsw_search(const vgo_hnsw_graph *g, const float *query, int32_t k, int32_t ef,
                         uint32_t *ids, float *scores, vgo_search_stats *stats);
 
-enum { VGO_VAMANA_F32 = 0, VGO_VAMANA_PQ = 1, VGO_VAMANA_RABITQ = 2 };
+enum { VGO_VAMANA_F32 = 0, VGO_VAMANA_PQ = 1, VGO_VAMANA_RABITQ = 2, VGO_VAMANA_INT4 = 3 };
 typedef struct {
     int64_t n;
     int32_t dim;
@@ -170,7 +170,8 @@ typedef struct {
     int32_t metric;        /* for VGO_VAMANA_F32: L2 / Dot */
     const float *base;     /* F32 */
     const vgo_pq *pq;      /* PQ */
-    const uint8_t *codes;  /* PQ: n*m ; RABITQ: n*code_bytes */
+    const uint8_t *codes;  /* PQ: n*m ; RABITQ: n*code_bytes ; INT4: n*ceil(dim/2) */
+    const float *int4_table; /* INT4: BuildInt4LookupTable, dim*16 (appended field) */
 } vgo_vamana;
 /* diskann/segment.go:503-706 searchInternal, no filters */
 int32_t vgo_vamana_search(const vgo_vamana *v, const float *query, int32_t k,
@@ -187,6 +188,16 @@ void vgo_sq8_decode(const uint8_t *code, int32_t dim, const float *mins, const f
 int32_t vgo_flat_search_sq8(const uint8_t *codes, int64_t n, int32_t dim, const float *mins,
                             const float *inv_scales, const float *query, int32_t k, uint32_t *ids,
                             float *scores);
+
+/* INT4 (int4_avx512.c, int4.go, kernels.go:94-103) */
+float vgo_int4_l2(const float *query, const uint8_t *code, int64_t dim, const float *min_val, const float *diff);
+void vgo_int4_l2_batch(const float *query, const uint8_t *codes, int64_t dim, int64_t n, const float *min_val,
+                       const float *diff, float *out);
+void vgo_int4_build_lut(const float *min_val, const float *diff, int32_t dim, float *table);
+float vgo_int4_l2_precomputed(const float *query, const uint8_t *code, int64_t dim, const float *table);
+void vgo_int4_train(const float *vectors, int64_t n, int32_t dim, float *min_val, float *diff);
+void vgo_int4_encode(const float *v, int32_t dim, const float *min_val, const float *diff, uint8_t *out);
+void vgo_int4_decode(const uint8_t *code, int32_t dim, const float *min_val, const float *diff, float *out);
 
 #ifdef __cplusplus
 }

@@ -68,7 +68,7 @@ def write_flat(vectors, metric=0, segment_id=7, sq=None, pq=None, codes=None, ch
     return bytes(h) + bytes(body)
 
 
-def write_diskann(vectors, graph, entry, metric=0, segment_id=9, pq=None, pq_codes=None, rabitq_codes=None,
+def write_diskann(vectors, graph, entry, metric=0, segment_id=9, pq=None, pq_codes=None, rabitq_codes=None, int4=None,
                   search_list=100, checksum=True, version=2, compression=0, qtype=None):
     v = np.ascontiguousarray(vectors, np.float32)
     g = np.ascontiguousarray(graph, np.uint32)
@@ -91,6 +91,12 @@ def write_diskann(vectors, graph, entry, metric=0, segment_id=9, pq=None, pq_cod
     elif rabitq_codes is not None:
         qt = 5
         bq_off = DISK_HEADER + len(body); body += np.ascontiguousarray(rabitq_codes, np.uint8).tobytes(); _pad8(body)
+    if int4 is not None:   # (min, diff, codes): MarshalBinary params end where the PK section starts (segment.go:384)
+        mn, df, icodes = int4
+        qt = 6
+        pqc_off = DISK_HEADER + len(body); body += np.ascontiguousarray(icodes, np.uint8).tobytes(); _pad8(body)
+        cb_off = DISK_HEADER + len(body)
+        body += struct.pack("<I", dim) + np.asarray(mn, np.float32).tobytes() + np.asarray(df, np.float32).tobytes()
     if qtype is not None:
         qt = qtype
     pk_off = DISK_HEADER + len(body)

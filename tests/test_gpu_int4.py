@@ -1,0 +1,94 @@
+"""INT4 on the GPU (int4.go, int4_avx512.c, diskann/segment.go:378-416,558-565) vs the oracle:
+parameters, codes, decoded values, both distance orders and the Vamana search with INT4 node
+scoring, bit-exact."""
+import numpy as np
+import pytest
+
+from oracle import oracle as o
+from tests import segfile
+from tests.graphs import build_vamana
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(x):
+    return np.asarray(x, np.float32).view(np.uint32)
+
+
+@pytest.fixture(scope="module")
+def vg():
+    import vecgo_amd
+    return vecgo_amd
+
+
+@pytest.fixture(scope="module")
+def ctx(vg):
+    return vg.Context(0)
+
+
+@pytest.mark.parametrize("n,dim", [(400, 128), (200, 768), (257, 100), (64, 17), (1, 3), (300, 33), (500, 64)])
+def test_train_encode_decode_distances_match_oracle(vg, ctx, n, dim):
+    rng = np.random.default_rng(n + dim)
+    x = rng.standard_normal((n, dim)).astype(np.float32)
+    x[:, dim // 2] = -0.75   # constant dimension: diff 0 -> 1 (int4.go:53-58)
+    iq = vg.Int4Quantizer(ctx, dim)
+    assert not iq.is_trained()
+    with pytest.raises(vg.VecgoHipError):
+        iq.encode(x[:1])
+    iq.train(x)
+    ref = o.Int4Quantizer(dim); ref.train(x)
+    mn, df, tb = iq.params()
+    assert np.array_equal(bits(mn), bits(ref.min)) and np.array_equal(bits(df), bits(ref.diff))
+    assert np.array_equal(bits(tb), bits(ref.table))
+    y = np.vstack([x[:30], x[:2] * 9.0, x[:2] * -9.0]).astype(np.float32)   # incl. values to clamp
+    codes = iq.encode(y)
+    assert codes.shape == (y.shape[0], (dim + 1) // 2)
+    assert np.array_equal(codes, ref.encode_batch(y))
+    assert np.array_equal(bits(iq.decode(codes)), bits(np.stack([ref.decode(c) for c in codes])))
+    q = rng.standard_normal(dim).astype(np.float32)
+    assert np.array_equal(bits(iq.l2_distance_batch(q, codes)), bits(ref.l2_distance_batch(q, codes)))
+    want = np.array([ref.l2_distance(q, c) for c in codes], np.float32)
+    assert np.array_equal(bits(iq.l2_distance(q, codes)), bits(want))
+
+
+def test_set_params_is_unmarshal_binary(vg, ctx):
+    rng = np.random.default_rng(4)
+    dim = 48
+    mn = rng.standard_normal(dim).astype(np.float32); df = (rng.random(dim) + 0.2).astype(np.float32)
+    iq = vg.Int4Quantizer(ctx, dim); iq.set_params(mn, df)
+    ref = o.Int4Quantizer(dim); ref.set_params(mn, df)
+    assert iq.is_trained()
+    assert np.array_equal(bits(iq.params()[2]), bits(ref.table))
+
+
+def test_vamana_search_with_int4_codes_and_segment_file(vg, ctx):
+    rng = np.random.default_rng(8)
+    n, dim, nq, k, r = 1200, 96, 6, 10, 16
+    x = rng.standard_normal((n, dim)).astype(np.float32)
+    q = rng.standard_normal((nq, dim)).astype(np.float32)
+    g, entry = build_vamana(x, r=r, seed=2)
+    ref = o.Int4Quantizer(dim); ref.train(x)
+    codes = ref.encode_batch(x)
+    oracle_index = o.VamanaIndex(g, entry, dim, kind=o.VAMANA_INT4, codes=codes, int4_table=ref.table)
+    # through the API
+    iq = vg.Int4Quantizer(ctx, dim); iq.train(x)
+    idx = vg.Index(ctx, n, dim)
+    idx.set_vamana_graph(g, entry)
+    with pytest.raises(vg.VecgoHipError):
+        idx.search_vamana(q, k, kind=3)                    # no INT4 codes attached yet
+    idx.set_int4_codes(iq, codes)
+    # and through a DiskANN segment image (quantization type 6, params before the PK section)
+    seg = vg.Segment(ctx, segfile.write_diskann(x, g, entry, int4=(ref.min, ref.diff, codes)), kind="diskann")
+    assert seg.info.quantization == 6
+    for index in (idx, seg.index):
+        ids, sc, st = index.search_vamana(q, k, kind=3, stats=True)
+        for i in range(nq):
+            eid, esc, est = oracle_index.search(q[i], k)
+            assert np.array_equal(ids[i, :eid.size], eid), i
+            assert np.array_equal(bits(sc[i, :eid.size]), bits(esc)), i
+            assert int(st[i, 1]) == est.distance_computations
+    seg.close()
+    bad = segfile.write_diskann(x, g, entry, int4=(ref.min[:-1], ref.diff[:-1], codes))
+    with pytest.raises(vg.VecgoHipError) as e:
+        vg.Segment(ctx, bad, kind="diskann", verify_checksum=False)
+    assert "data size mismatch" in str(e.value)            # int4.go:196-199

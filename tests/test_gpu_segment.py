@@ -125,7 +125,8 @@ def test_segment_errors(vg, ctx):
     assert "invalid magic number" in msg(good, kind="diskann")
     g = np.zeros((50, 4), np.uint32)
     assert "LZ4" in msg(segfile.write_diskann(x, g, 0, compression=1), kind="diskann")
-    assert "quantization type 6" in msg(segfile.write_diskann(x, g, 0, qtype=6), kind="diskann")  # INT4
+    assert "quantization type 4" in msg(segfile.write_diskann(x, g, 0, qtype=4), kind="diskann")  # BQ
+    assert "missing INT4 params" in msg(segfile.write_diskann(x, g, 0, qtype=6), kind="diskann")
     d = segfile.write_diskann(x, g, 0)
     assert "file size too small" in msg(d[:segfile.DISK_HEADER + 64], kind="diskann", verify_checksum=False)
     empty = vg.Segment(ctx, segfile.write_flat(np.zeros((0, 16), np.float32)))

@@ -347,6 +347,104 @@ class ScalarQuantizer:
         return out
 
 
+class Int4Quantizer:
+    """quantization.Int4Quantizer (internal/quantization/int4.go:12-20): 4 bits per dimension."""
+
+    def __init__(self, ctx: Context, dimension: int):
+        self.ctx, self.dimension = ctx, dimension
+        self._lib = ctx._lib
+        self._lib.vg_int4_code_bytes.restype = C.c_int64
+        h = C.c_void_p()
+        check(self._lib.vg_int4_create(ctx._h, C.c_int32(dimension), C.byref(h)))
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.vg_int4_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def is_trained(self) -> bool:
+        return bool(self._lib.vg_int4_is_trained(self._h))
+
+    @property
+    def code_bytes(self) -> int:
+        return (self.dimension + 1) // 2
+
+    def bytes_per_dimension(self) -> int:
+        return 0  # sub-byte (int4.go:167-169)
+
+    def train(self, vectors, stream=None):
+        """Train (int4.go:29-62)."""
+        n = _rows(vectors, self.dimension)
+        v, pv = _ptr(vectors, np.float32)
+        check(self._lib.vg_int4_train(self._h, pv, C.c_int64(n), _stream_ptr(stream)))
+
+    def set_params(self, min_val, diff):
+        """UnmarshalBinary (int4.go:190-219)."""
+        a, pa = _ptr(min_val, np.float32, self.dimension)
+        b, pb = _ptr(diff, np.float32, self.dimension)
+        check(self._lib.vg_int4_set_params(self._h, pa, pb))
+
+    def params(self):
+        """(min, diff, lookup table[dim*16]) as numpy arrays."""
+        mn, df = np.empty(self.dimension, np.float32), np.empty(self.dimension, np.float32)
+        tb = np.empty(self.dimension * 16, np.float32)
+        check(self._lib.vg_int4_get_params(self._h, C.c_void_p(mn.ctypes.data), C.c_void_p(df.ctypes.data),
+                                           C.c_void_p(tb.ctypes.data)))
+        return mn, df, tb
+
+    def encode(self, vectors, out=None, stream=None):
+        """Encode (int4.go:65-105), batched: returns [n, ceil(dim/2)] uint8."""
+        n = _rows(vectors, self.dimension)
+        v, pv = _ptr(vectors, np.float32)
+        if out is None:
+            out = _empty_like(vectors, (n, self.code_bytes), np.uint8)
+        c, pc = _ptr(out, np.uint8, n * self.code_bytes)
+        check(self._lib.vg_int4_encode(self._h, pv, C.c_int64(n), pc, _stream_ptr(stream)))
+        return out
+
+    def decode(self, codes, out=None, stream=None):
+        """Decode (int4.go:108-130), batched: returns [n, dim] float32."""
+        total = codes.numel() if _is_torch(codes) else np.asarray(codes).size
+        if total % self.code_bytes:
+            raise VecgoHipError(-2, "dimension mismatch")
+        n = total // self.code_bytes
+        c, pc = _ptr(codes, np.uint8)
+        if out is None:
+            out = _empty_like(codes, (n, self.dimension), np.float32)
+        o, po = _ptr(out, np.float32, n * self.dimension)
+        check(self._lib.vg_int4_decode(self._h, pc, C.c_int64(n), po, _stream_ptr(stream)))
+        return out
+
+    def _dist(self, query, codes, precomputed, out, stream):
+        if _rows(query, self.dimension) != 1:
+            raise VecgoHipError(-2, "dimension mismatch")
+        total = codes.numel() if _is_torch(codes) else np.asarray(codes).size
+        n = total // self.code_bytes
+        q, pq_ = _ptr(query, np.float32)
+        c, pc = _ptr(codes, np.uint8)
+        if out is None:
+            out = _empty_like(codes, (n,), np.float32)
+        o, po = _ptr(out, np.float32, n)
+        check(self._lib.vg_int4_l2_distance_batch(self._h, pq_, pc, C.c_int64(n), C.c_int32(precomputed), po,
+                                                  _stream_ptr(stream)))
+        return out
+
+    def l2_distance_batch(self, query, codes, out=None, stream=None):
+        """L2DistanceBatch (int4.go:150-164)."""
+        return self._dist(query, codes, 0, out, stream)
+
+    def l2_distance(self, query, codes, out=None, stream=None):
+        """L2Distance (int4.go:133-147) of one query against each of n codes."""
+        return self._dist(query, codes, 1, out, stream)
+
+
 def hamming_batch(ctx: Context, a, codes, out=None, stream=None):
     """simd.Hamming (kernels.go:71) of one byte string against n contiguous ones."""
     a_, pa = _ptr(a, np.uint8)
@@ -536,6 +634,11 @@ class Index:
         self._keep.append(sq)
         check(self._lib.vg_index_set_sq8_codes(self._h, sq._h, pc, _stream_ptr(stream)))
 
+    def set_int4_codes(self, iq: "Int4Quantizer", codes, stream=None):
+        c, pc = _ptr(codes, np.uint8, self.n * iq.code_bytes)
+        self._keep.append(iq)
+        check(self._lib.vg_index_set_int4_codes(self._h, iq._h, pc, _stream_ptr(stream)))
+
     def search_sq8(self, queries, k, out=None, stream=None):
         """flat.Segment.Search SQ8 branch (flat/segment.go:517-604)."""
         return self._search(self._lib.vg_search_sq8, queries, k, out=out, stream=stream)
@@ -594,7 +697,7 @@ class Index:
         return self._graph_search(self._lib.vg_search_hnsw, queries, k, ef, stats, stream)
 
     def search_vamana(self, queries, k, kind=0, stats=False, stream=None):
-        """diskann searchInternal (diskann/segment.go:503-706); kind 0 fp32, 1 PQ, 2 RaBitQ."""
+        """diskann searchInternal (diskann/segment.go:503-706); kind 0 fp32, 1 PQ, 2 RaBitQ, 3 INT4."""
         return self._graph_search(self._lib.vg_search_vamana, queries, k, kind, stats, stream)
 
     def set_vectors(self, base, stream=None):

@@ -309,7 +309,7 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(
 }
 
 // ---- Vamana --------------------------------------------------------------------------------------
-enum { kVamanaF32 = 0, kVamanaPQ = 1, kVamanaRaBitQ = 2 };
+enum { kVamanaF32 = 0, kVamanaPQ = 1, kVamanaRaBitQ = 2, kVamanaInt4 = 3 };
 
 __device__ inline float rq_formula_g(float qn, float yn, float dimf, float hamming)
 {
@@ -326,8 +326,8 @@ __global__ __launch_bounds__(64) void vamana_search_kernel(
     int kind, int metric, int64_t n, int dim, const uint32_t *__restrict__ graph, int r, uint32_t entry,
     const float *__restrict__ base, const uint8_t *__restrict__ pq_rows, int pq_m,
     const float *__restrict__ luts /* nq * m * 256 */, const uint8_t *__restrict__ rq_rows,
-    const uint8_t *__restrict__ qcodes /* nq * (nb+4) */, int rq_nb, const float *__restrict__ queries,
-    int k, HItem *__restrict__ cand_ws, int64_t cand_cap, uint32_t *__restrict__ visited_ws,
+    const uint8_t *__restrict__ qcodes /* nq * (nb+4) */, int rq_nb, const uint8_t *__restrict__ int4_rows,
+    const float *__restrict__ int4_table, const float *__restrict__ queries, int k, HItem *__restrict__ cand_ws, int64_t cand_cap, uint32_t *__restrict__ visited_ws,
     int64_t vis_words, uint32_t *__restrict__ ids, float *__restrict__ scores,
     vg_search_stats *__restrict__ stats)
 {
@@ -371,6 +371,10 @@ __global__ __launch_bounds__(64) void vamana_search_kernel(
                 float distance = 0.0f;
                 for (int s = 0; s < pq_m; s++) distance = distance + lut[s * 256 + code[s]];
                 nb_d[lane] = distance;
+            } else if (kind == kVamanaInt4) {
+                // iq.L2Distance (diskann/segment.go:558-565) = int4L2DistancePrecomputedAvx512 order
+                nb_d[lane] = int4_l2_precomputed(qv, int4_rows + static_cast<int64_t>(id_lane) * ((dim + 1) / 2), dim,
+                                                 int4_table);
             } else {
                 const uint8_t *code = rq_rows + static_cast<int64_t>(id_lane) * (rq_nb + 4);
                 int h = 0;
@@ -566,7 +570,9 @@ VG_API int32_t vg_search_vamana(vg_index *idx, const float *queries, int64_t nq,
     VG_CHECK(nq >= 0 && k >= 0, VG_ERR_INVALID_ARG, "vg_search_vamana: negative nq or k");
     if (nq == 0 || k == 0) return VG_OK;
     VG_CHECK(idx->d_vamana, VG_ERR_NOT_READY, "vg_search_vamana: index has no Vamana graph");
-    VG_CHECK(kind >= 0 && kind <= 2, VG_ERR_INVALID_ARG, "vg_search_vamana: unknown kind %d", kind);
+    VG_CHECK(kind >= 0 && kind <= 3, VG_ERR_INVALID_ARG, "vg_search_vamana: unknown kind %d", kind);
+    VG_CHECK(kind != 3 || (idx->d_int4_rows && idx->int4_table), VG_ERR_NOT_READY,
+             "vg_search_vamana: index has no INT4 codes");
     VG_CHECK(kind != 0 || idx->d_vectors, VG_ERR_NOT_READY, "vg_search_vamana: index has no fp32 vectors");
     VG_CHECK(kind != 1 || (idx->d_pq_rows && idx->pq), VG_ERR_NOT_READY, "vg_search_vamana: index has no PQ codes");
     VG_CHECK(kind != 2 || idx->d_rq_rows, VG_ERR_NOT_READY, "vg_search_vamana: index has no RaBitQ codes");
@@ -615,7 +621,7 @@ VG_API int32_t vg_search_vamana(vg_index *idx, const float *queries, int64_t nq,
                            idx->metric, idx->n, idx->dim, idx->d_vamana, idx->vamana_r, idx->vamana_entry,
                            idx->d_vectors, idx->d_pq_rows, pq_m, kind == 1 ? luts.ptr + q0 * pq_m * 256 : nullptr,
                            idx->d_rq_rows, kind == 2 ? qcodes.ptr + q0 * (rq_nb + 4) : nullptr, rq_nb,
-                           q.ptr + q0 * idx->dim, k, cand.ptr, cand_cap, vis.ptr, vis_words, oid.ptr + q0 * k,
+                           idx->d_int4_rows, idx->int4_table, q.ptr + q0 * idx->dim, k, cand.ptr, cand_cap, vis.ptr, vis_words, oid.ptr + q0 * k,
                            osc.ptr + q0 * k, ost.ptr ? ost.ptr + q0 : nullptr);
     }
     VG_TRY(oid.finish());

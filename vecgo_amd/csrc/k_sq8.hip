@@ -14,6 +14,14 @@
 #include "vg_device.hpp"
 #include "vg_internal.hpp"
 
+struct vg_int4 {
+    vg_ctx *ctx = nullptr;
+    int32_t dim = 0;
+    bool trained = false;
+    float *d_min = nullptr, *d_diff = nullptr;  // [dim] each
+    float *d_table = nullptr;                   // [dim * 16] BuildInt4LookupTable
+};
+
 struct vg_sq8 {
     vg_ctx *ctx = nullptr;
     int32_t dim = 0;
@@ -237,6 +245,142 @@ __global__ __launch_bounds__(kSqThreads) void sq8_scan_kernel(
     }
     wg_rank_merge<kSqWaves>(tk, lists, valid, wave, lane, tid, k,
                             partial + (static_cast<int64_t>(q) * slices + s) * k);
+}
+
+// ==== INT4 (internal/quantization/int4.go, internal/simd/src/int4_avx512.c) ===========================
+// stage 2 of Train (int4.go:52-61): diff = max - min, 0 -> 1; then BuildInt4LookupTable
+// (kernels.go:94-103): table[d*16+q] = (float32(q)/15.0)*diff + min, three rounded operations
+__global__ void int4_finish_kernel(const float *__restrict__ pmin, const float *__restrict__ pmax, int chunks,
+                                   int dim, bool from_train, float *__restrict__ mins, float *__restrict__ diff)
+{
+    const int d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= dim) return;
+    if (from_train) {
+        float mn = kF32Max, mx = -kF32Max;
+        for (int c = 0; c < chunks; c++) {
+            const float a = pmin[static_cast<int64_t>(c) * dim + d], b = pmax[static_cast<int64_t>(c) * dim + d];
+            if (a < mn) mn = a;
+            if (b > mx) mx = b;
+        }
+        const float df = mx - mn;
+        mins[d] = mn;
+        diff[d] = df == 0.0f ? 1.0f : df;
+    }
+}
+
+__global__ void int4_table_kernel(const float *__restrict__ mins, const float *__restrict__ diff, int dim,
+                                  float *__restrict__ table)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= dim * 16) return;
+    const int d = t >> 4, q = t & 15;
+    const float a = static_cast<float>(q) / 15.0f;
+    const float b = a * diff[d];
+    table[t] = b + mins[d];
+}
+
+__device__ __forceinline__ uint32_t int4_quant(float v, float mn, float df)
+{
+    float norm = (v - mn) / df;  // int4.go:75-81
+    if (norm < 0.0f)
+        norm = 0.0f;
+    else if (norm > 1.0f)
+        norm = 1.0f;
+    return static_cast<uint32_t>(round(static_cast<double>(norm) * 15.0));  // math.Round(float64(norm) * 15)
+}
+
+// Encode (int4.go:65-105): thread per output byte
+__global__ void int4_encode_kernel(const float *__restrict__ v, int64_t n, int dim, const float *__restrict__ mins,
+                                   const float *__restrict__ diff, uint8_t *__restrict__ out)
+{
+    const int cs = (dim + 1) / 2;
+    const int64_t t = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (t >= n * cs) return;
+    const int64_t row = t / cs;
+    const int i = static_cast<int>(t % cs) * 2;
+    const float *x = v + row * dim;
+    const uint32_t q1 = int4_quant(x[i], mins[i], diff[i]);
+    const uint32_t q2 = i + 1 < dim ? int4_quant(x[i + 1], mins[i + 1], diff[i + 1]) : 0u;
+    out[t] = static_cast<uint8_t>((q1 << 4) | (q2 & 0x0Fu));
+}
+
+// Decode (int4.go:108-130): float32(q)/15.0*diff + min, left to right
+__global__ void int4_decode_kernel(const uint8_t *__restrict__ codes, int64_t n, int dim,
+                                   const float *__restrict__ mins, const float *__restrict__ diff,
+                                   float *__restrict__ out)
+{
+    const int cs = (dim + 1) / 2;
+    const int64_t t = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (t >= n * dim) return;
+    const int64_t row = t / dim;
+    const int i = static_cast<int>(t % dim);
+    const uint8_t b = codes[row * cs + i / 2];
+    const float a = static_cast<float>((i & 1) ? (b & 0x0F) : (b >> 4)) / 15.0f;
+    const float c = a * diff[i];
+    out[t] = c + mins[i];
+}
+
+__device__ __forceinline__ float int4_nib(const uint8_t *code, int j)
+{
+    const uint8_t b = code[j >> 1];
+    return static_cast<float>((j & 1) ? (b & 0x0F) : (b >> 4));
+}
+
+// int4L2DistanceBatchAvx512 (int4_avx512.c:191-299), lane per row: 64-element blocks feed sub-blocks
+// 0,1 into sum1 and 2,3 into sum2, 32-element blocks both into sum1; dq = fma(f * (1/15), diff, min)
+__global__ __launch_bounds__(256) void int4_l2_batch_kernel(const float *__restrict__ query,
+                                                            const uint8_t *__restrict__ codes, int64_t n, int dim,
+                                                            const float *__restrict__ mins,
+                                                            const float *__restrict__ diff, float *__restrict__ out)
+{
+    const int64_t row = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (row >= n) return;
+    const uint8_t *code = codes + row * ((dim + 1) / 2);
+    const float sc = __uint_as_float(0x3d888889u);  // int4_avx512.c:35
+    float s1[16], s2[16];
+#pragma unroll
+    for (int l = 0; l < 16; l++) s1[l] = s2[l] = 0.0f;
+    auto block = [&](float (&acc)[16], int base) {
+#pragma unroll
+        for (int l = 0; l < 16; l++) {
+            const int j = base + l;
+            const float f = int4_nib(code, j) * sc;
+            const float dq = __builtin_fmaf(f, diff[j], mins[j]);
+            const float d = query[j] - dq;
+            acc[l] = __builtin_fmaf(d, d, acc[l]);
+        }
+    };
+    int i = 0;
+    for (; i <= dim - 64; i += 64) {
+        block(s1, i);
+        block(s1, i + 16);
+        block(s2, i + 32);
+        block(s2, i + 48);
+    }
+    for (; i <= dim - 32; i += 32) {
+        block(s1, i);
+        block(s1, i + 16);
+    }
+#pragma unroll
+    for (int l = 0; l < 16; l++) s1[l] = s1[l] + s2[l];
+    float total = reduce16_regs(s1);
+    for (; i < dim; i++) {
+        const float f = int4_nib(code, i) * sc;
+        const float v = __builtin_fmaf(f, diff[i], mins[i]);
+        const float d = query[i] - v;
+        total = __builtin_fmaf(d, d, total);
+    }
+    out[row] = total;
+}
+
+__global__ __launch_bounds__(256) void int4_l2_precomputed_kernel(const float *__restrict__ query,
+                                                                  const uint8_t *__restrict__ codes, int64_t n,
+                                                                  int dim, const float *__restrict__ table,
+                                                                  float *__restrict__ out)
+{
+    const int64_t row = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (row >= n) return;
+    out[row] = int4_l2_precomputed(query, codes + row * ((dim + 1) / 2), dim, table);
 }
 
 static int sq_slices(int64_t nq, int64_t n_tiles, int cus)
@@ -475,5 +619,193 @@ VG_API int32_t vg_search_sq8(vg_index *idx, const float *queries, int64_t nq, in
     }
     VG_TRY(oid.finish());
     VG_TRY(osc.finish());
+    return VG_OK;
+}
+
+// ---- INT4 C ABI ---------------------------------------------------------------------------------------
+static int32_t int4_rebuild_table(vg_int4 *iq, hipStream_t st)
+{
+    VG_LAUNCH(vg::int4_table_kernel, dim3((iq->dim * 16 + 255) / 256), dim3(256), 0, st, iq->d_min, iq->d_diff,
+              iq->dim, iq->d_table);
+    VG_HIP(hipStreamSynchronize(st));
+    iq->trained = true;
+    return VG_OK;
+}
+
+VG_API int32_t vg_int4_create(vg_ctx *ctx, int32_t dim, vg_int4 **out)
+{
+    VG_CHECK(out, VG_ERR_INVALID_ARG, "vg_int4_create: out is NULL");
+    *out = nullptr;
+    VG_CHECK(ctx, VG_ERR_INVALID_ARG, "vg_int4_create: ctx is NULL");
+    VG_CHECK(dim > 0, VG_ERR_INVALID_ARG, "vg_int4_create: dim must be positive");
+    VG_HIP(hipSetDevice(ctx->device));
+    vg_int4 *iq = new vg_int4;
+    iq->ctx = ctx;
+    iq->dim = dim;
+    float *block = nullptr;
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&block), sizeof(float) * 18 * static_cast<size_t>(dim));
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        delete iq;
+        vg::set_error("vg_int4_create: hipMalloc failed: %s", hipGetErrorString(e));
+        return VG_ERR_HIP;
+    }
+    iq->d_min = block;
+    iq->d_diff = block + dim;
+    iq->d_table = block + 2 * static_cast<size_t>(dim);
+    *out = iq;
+    return VG_OK;
+}
+
+VG_API int32_t vg_int4_destroy(vg_int4 *iq)
+{
+    if (!iq) return VG_OK;
+    (void)hipSetDevice(iq->ctx->device);
+    if (iq->d_min) (void)hipFree(iq->d_min);
+    delete iq;
+    return VG_OK;
+}
+
+VG_API int32_t vg_int4_is_trained(vg_int4 *iq) { return iq && iq->trained ? 1 : 0; }
+
+VG_API int32_t vg_int4_train(vg_int4 *iq, const float *vectors, int64_t n, void *stream)
+{
+    VG_CHECK(iq, VG_ERR_INVALID_ARG, "vg_int4_train: NULL quantizer");
+    VG_CHECK(n > 0 && vectors, VG_ERR_INVALID_ARG, "no vectors provided for training");  // int4.go:30-32
+    VG_HIP(hipSetDevice(iq->ctx->device));
+    hipStream_t st = vg::pick_stream(iq->ctx, stream);
+    const int dim = iq->dim;
+    vg::DevIn<float> v;
+    VG_TRY(v.init(vectors, static_cast<size_t>(n) * dim, st));
+    int chunks = static_cast<int>(std::min<int64_t>(n, 1024));
+    vg::DevTmp<float> pmin, pmax;
+    VG_TRY(pmin.init(static_cast<size_t>(chunks) * dim, st));
+    VG_TRY(pmax.init(static_cast<size_t>(chunks) * dim, st));
+    VG_LAUNCH(vg::sq8_minmax_kernel, dim3((dim + 255) / 256, chunks), dim3(256), 0, st, v.ptr, n, dim, chunks,
+              pmin.ptr, pmax.ptr);
+    VG_LAUNCH(vg::int4_finish_kernel, dim3((dim + 255) / 256), dim3(256), 0, st, pmin.ptr, pmax.ptr, chunks, dim, true,
+              iq->d_min, iq->d_diff);
+    return int4_rebuild_table(iq, st);
+}
+
+/* UnmarshalBinary (int4.go:190-219): min[dim], diff[dim] as stored, table rebuilt */
+VG_API int32_t vg_int4_set_params(vg_int4 *iq, const float *min_val, const float *diff)
+{
+    VG_CHECK(iq, VG_ERR_INVALID_ARG, "vg_int4_set_params: NULL quantizer");
+    VG_CHECK(min_val && diff, VG_ERR_INVALID_ARG, "vg_int4_set_params: NULL parameters");
+    VG_HIP(hipSetDevice(iq->ctx->device));
+    hipStream_t st = iq->ctx->stream;
+    const size_t b = sizeof(float) * static_cast<size_t>(iq->dim);
+    VG_HIP(hipMemcpyAsync(iq->d_min, min_val, b, hipMemcpyDefault, st));
+    VG_HIP(hipMemcpyAsync(iq->d_diff, diff, b, hipMemcpyDefault, st));
+    return int4_rebuild_table(iq, st);
+}
+
+VG_API int32_t vg_int4_get_params(vg_int4 *iq, float *min_val, float *diff, float *table)
+{
+    VG_CHECK(iq, VG_ERR_INVALID_ARG, "vg_int4_get_params: NULL quantizer");
+    VG_CHECK(iq->trained, VG_ERR_NOT_TRAINED, "Int4Quantizer not trained");
+    VG_HIP(hipSetDevice(iq->ctx->device));
+    hipStream_t st = iq->ctx->stream;
+    const size_t b = sizeof(float) * static_cast<size_t>(iq->dim);
+    if (min_val) VG_HIP(hipMemcpyAsync(min_val, iq->d_min, b, hipMemcpyDefault, st));
+    if (diff) VG_HIP(hipMemcpyAsync(diff, iq->d_diff, b, hipMemcpyDefault, st));
+    if (table) VG_HIP(hipMemcpyAsync(table, iq->d_table, 16 * b, hipMemcpyDefault, st));
+    VG_HIP(hipStreamSynchronize(st));
+    return VG_OK;
+}
+
+VG_API int64_t vg_int4_code_bytes(int32_t dim) { return (static_cast<int64_t>(dim) + 1) / 2; }
+
+VG_API int32_t vg_int4_encode(vg_int4 *iq, const float *vectors, int64_t n, uint8_t *codes, void *stream)
+{
+    VG_CHECK(iq, VG_ERR_INVALID_ARG, "vg_int4_encode: NULL quantizer");
+    VG_CHECK(iq->trained, VG_ERR_NOT_TRAINED, "Int4Quantizer not trained");
+    VG_CHECK(n >= 0, VG_ERR_INVALID_ARG, "vg_int4_encode: n < 0");
+    if (n == 0) return VG_OK;
+    VG_CHECK(vectors && codes, VG_ERR_INVALID_ARG, "vg_int4_encode: NULL buffer");
+    VG_HIP(hipSetDevice(iq->ctx->device));
+    hipStream_t st = vg::pick_stream(iq->ctx, stream);
+    const int64_t cs = vg_int4_code_bytes(iq->dim);
+    vg::DevIn<float> v;
+    vg::DevOut<uint8_t> c;
+    VG_TRY(v.init(vectors, static_cast<size_t>(n) * iq->dim, st));
+    VG_TRY(c.init(codes, static_cast<size_t>(n * cs), st));
+    VG_LAUNCH(vg::int4_encode_kernel, dim3(static_cast<unsigned>((n * cs + 255) / 256)), dim3(256), 0, st, v.ptr, n,
+              iq->dim, iq->d_min, iq->d_diff, c.ptr);
+    VG_TRY(c.finish());
+    return VG_OK;
+}
+
+VG_API int32_t vg_int4_decode(vg_int4 *iq, const uint8_t *codes, int64_t n, float *out, void *stream)
+{
+    VG_CHECK(iq, VG_ERR_INVALID_ARG, "vg_int4_decode: NULL quantizer");
+    VG_CHECK(iq->trained, VG_ERR_NOT_TRAINED, "Int4Quantizer not trained");
+    VG_CHECK(n >= 0, VG_ERR_INVALID_ARG, "vg_int4_decode: n < 0");
+    if (n == 0) return VG_OK;
+    VG_CHECK(codes && out, VG_ERR_INVALID_ARG, "vg_int4_decode: NULL buffer");
+    VG_HIP(hipSetDevice(iq->ctx->device));
+    hipStream_t st = vg::pick_stream(iq->ctx, stream);
+    const int64_t cs = vg_int4_code_bytes(iq->dim);
+    vg::DevIn<uint8_t> c;
+    vg::DevOut<float> o;
+    VG_TRY(c.init(codes, static_cast<size_t>(n * cs), st));
+    VG_TRY(o.init(out, static_cast<size_t>(n) * iq->dim, st));
+    VG_LAUNCH(vg::int4_decode_kernel, dim3(static_cast<unsigned>((n * iq->dim + 255) / 256)), dim3(256), 0, st, c.ptr, n,
+              iq->dim, iq->d_min, iq->d_diff, o.ptr);
+    VG_TRY(o.finish());
+    return VG_OK;
+}
+
+// precomputed = 0: L2DistanceBatch (int4.go:150-164, batch kernel order);
+// precomputed = 1: L2Distance per code (int4.go:133-147, lookup-table kernel order)
+VG_API int32_t vg_int4_l2_distance_batch(vg_int4 *iq, const float *query, const uint8_t *codes, int64_t n,
+                                         int32_t precomputed, float *out, void *stream)
+{
+    VG_CHECK(iq, VG_ERR_INVALID_ARG, "vg_int4_l2_distance_batch: NULL quantizer");
+    VG_CHECK(iq->trained, VG_ERR_NOT_TRAINED, "Int4Quantizer not trained");
+    VG_CHECK(n >= 0, VG_ERR_INVALID_ARG, "vg_int4_l2_distance_batch: n < 0");
+    if (n == 0) return VG_OK;
+    VG_CHECK(query && codes && out, VG_ERR_INVALID_ARG, "vg_int4_l2_distance_batch: NULL buffer");
+    VG_HIP(hipSetDevice(iq->ctx->device));
+    hipStream_t st = vg::pick_stream(iq->ctx, stream);
+    const int64_t cs = vg_int4_code_bytes(iq->dim);
+    vg::DevIn<float> q;
+    vg::DevIn<uint8_t> c;
+    vg::DevOut<float> o;
+    VG_TRY(q.init(query, static_cast<size_t>(iq->dim), st));
+    VG_TRY(c.init(codes, static_cast<size_t>(n * cs), st));
+    VG_TRY(o.init(out, static_cast<size_t>(n), st));
+    if (precomputed)
+        VG_LAUNCH(vg::int4_l2_precomputed_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, st, q.ptr,
+                  c.ptr, n, iq->dim, iq->d_table, o.ptr);
+    else
+        VG_LAUNCH(vg::int4_l2_batch_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, st, q.ptr, c.ptr,
+                  n, iq->dim, iq->d_min, iq->d_diff, o.ptr);
+    VG_TRY(o.finish());
+    return VG_OK;
+}
+
+// INT4 codes of a DiskANN segment, n * ceil(dim/2) bytes row-major (diskann/segment.go:378-416):
+// kept in that layout, the graph search reads them by node id
+VG_API int32_t vg_index_set_int4_codes(vg_index *idx, vg_int4 *iq, const uint8_t *codes, void *stream)
+{
+    VG_CHECK(idx && iq, VG_ERR_INVALID_ARG, "vg_index_set_int4_codes: NULL index or quantizer");
+    VG_CHECK(iq->trained, VG_ERR_NOT_TRAINED, "Int4Quantizer not trained");
+    VG_CHECK(iq->dim == idx->dim, VG_ERR_DIM_MISMATCH, "dimension mismatch");
+    VG_CHECK(idx->n == 0 || codes, VG_ERR_INVALID_ARG, "vg_index_set_int4_codes: codes is NULL");
+    VG_HIP(hipSetDevice(idx->ctx->device));
+    hipStream_t st = vg::pick_stream(idx->ctx, stream);
+    if (idx->d_int4_rows) {
+        VG_HIP(hipStreamSynchronize(st));
+        VG_HIP(hipFree(idx->d_int4_rows));
+        idx->d_int4_rows = nullptr;
+    }
+    idx->int4_table = iq->d_table;
+    if (idx->n == 0) return VG_OK;
+    const size_t bytes = static_cast<size_t>(idx->n) * static_cast<size_t>(vg_int4_code_bytes(idx->dim));
+    VG_HIP(hipMalloc(reinterpret_cast<void **>(&idx->d_int4_rows), bytes));
+    VG_HIP(hipMemcpyAsync(idx->d_int4_rows, codes, bytes, hipMemcpyDefault, st));
+    VG_HIP(hipStreamSynchronize(st));
     return VG_OK;
 }

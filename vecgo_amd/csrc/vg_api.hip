@@ -287,6 +287,7 @@ VG_API int32_t vg_index_destroy(vg_index *idx)
     if (idx->d_pq_rows) (void)hipFree(idx->d_pq_rows);
     if (idx->d_rq_rows) (void)hipFree(idx->d_rq_rows);
     if (idx->d_sq_tiles) (void)hipFree(idx->d_sq_tiles);
+    if (idx->d_int4_rows) (void)hipFree(idx->d_int4_rows);
     delete idx;
     return VG_OK;
 }

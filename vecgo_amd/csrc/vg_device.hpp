@@ -123,6 +123,35 @@ struct WaveTopK {
     }
 };
 
+// int4L2DistancePrecomputedAvx512 (int4_avx512.c:127-189) of one code: what Int4Quantizer.L2Distance
+// runs (int4.go:140-147) and therefore the DiskANN node scorer
+__device__ __forceinline__ float int4_l2_precomputed(const float *__restrict__ query, const uint8_t *__restrict__ code, int dim,
+                                     const float *__restrict__ table)
+{
+    float sum[16];
+#pragma unroll
+    for (int l = 0; l < 16; l++) sum[l] = 0.0f;
+    int i = 0;
+    for (; i <= dim - 16; i += 16) {
+#pragma unroll
+        for (int l = 0; l < 16; l++) {
+            const int j = i + l;
+            const uint8_t b = code[j >> 1];
+            const int qv = (j & 1) ? (b & 0x0F) : (b >> 4);
+            const float d = query[j] - table[j * 16 + qv];
+            sum[l] = __builtin_fmaf(d, d, sum[l]);
+        }
+    }
+    float total = reduce16_regs(sum);
+    for (; i < dim; i++) {
+        const uint8_t b = code[i >> 1];
+        const int qv = (i & 1) ? (b & 0x0F) : (b >> 4);
+        const float d = query[i] - table[i * 16 + qv];
+        total = __builtin_fmaf(d, d, total);
+    }
+    return total;
+}
+
 // number of keys < e in sorted[0..64) (ascending; unused slots hold kKeyMax)
 __device__ __forceinline__ int lower_bound64(const uint64_t *sorted, uint64_t e)
 {

@@ -282,6 +282,7 @@ struct vg_pq {
 };
 
 struct vg_sq8;
+struct vg_int4;
 
 struct vg_index {
     vg_ctx *ctx = nullptr;
@@ -320,4 +321,7 @@ struct vg_index {
     vg_sq8 *sq = nullptr;
     uint8_t *d_sq_tiles = nullptr;
     int32_t sq_groups = 0;  // ceil(dim/16)
+    // INT4 codes of a DiskANN segment, row-major n * ceil(dim/2), and the quantizer's lookup table
+    uint8_t *d_int4_rows = nullptr;
+    const float *int4_table = nullptr;  // borrowed from the vg_int4
 };

@@ -14,6 +14,7 @@ struct vg_segment {
     vg_index *idx = nullptr;
     vg_pq *pq = nullptr;
     vg_sq8 *sq = nullptr;
+    vg_int4 *iq = nullptr;
     vg_segment_info info{};
 };
 
@@ -65,6 +66,7 @@ void close_partial(vg_segment *s)
     if (s->idx) (void)vg_index_destroy(s->idx);
     if (s->pq) (void)vg_pq_destroy(s->pq);
     if (s->sq) (void)vg_sq8_destroy(s->sq);
+    if (s->iq) (void)vg_int4_destroy(s->iq);
     delete s;
 }
 
@@ -262,9 +264,26 @@ VG_API int32_t vg_segment_open_diskann(vg_ctx *ctx, const void *image, int64_t s
                   "RaBitQ codes section out of bounds");
         if (n) SEG_TRY(vg_index_set_rabitq_codes(seg->idx, data + bq_codes_off, stream));
         h.quantization = VG_QUANT_RABITQ;
+    } else if (qtype == 6) {  // segment.go:378-416 loadINT4: params = [dim u32][min f32 x dim][diff f32 x dim]
+        SEG_CHECK(cb_off != 0, VG_ERR_FORMAT, "missing INT4 params");
+        SEG_CHECK(pk_off > cb_off, VG_ERR_FORMAT, "invalid INT4 params size");
+        const uint64_t psize = pk_off - cb_off;
+        SEG_CHECK(len >= cb_off + psize, VG_ERR_FORMAT, "INT4 params out of bounds");
+        SEG_CHECK(psize >= 4, VG_ERR_FORMAT, "data too short");                       // int4.go:191-193
+        SEG_CHECK(rd32(data + cb_off) == dim && psize == 4 + dim * 8, VG_ERR_FORMAT, "data size mismatch");
+        SEG_CHECK(pq_codes_off != 0, VG_ERR_FORMAT, "missing INT4 codes");
+        const uint64_t cs = (dim + 1) / 2;
+        SEG_CHECK(len >= pq_codes_off + n * cs && pq_codes_off + n * cs >= pq_codes_off, VG_ERR_FORMAT,
+                  "INT4 codes out of bounds");
+        SEG_TRY(vg_int4_create(ctx, h.dim, &seg->iq));
+        std::vector<float> md(2 * dim);
+        memcpy(md.data(), data + cb_off + 4, dim * 8);
+        SEG_TRY(vg_int4_set_params(seg->iq, md.data(), md.data() + dim));
+        if (n) SEG_TRY(vg_index_set_int4_codes(seg->idx, seg->iq, data + pq_codes_off, stream));
+        h.quantization = VG_QUANT_INT4;
     } else {
         SEG_CHECK(qtype == 0, VG_ERR_UNSUPPORTED,
-                  "diskann segment: quantization type %d (OPQ / SQ8 / BQ / INT4) has no device scorer yet", qtype);
+                  "diskann segment: quantization type %d (OPQ / SQ8 / BQ) has no device scorer yet", qtype);
     }
     *out = seg;
     return VG_OK;
@@ -280,6 +299,7 @@ VG_API int32_t vg_segment_get_info(vg_segment *seg, vg_segment_info *info)
 VG_API vg_index *vg_segment_index(vg_segment *seg) { return seg ? seg->idx : nullptr; }
 VG_API vg_pq *vg_segment_pq(vg_segment *seg) { return seg ? seg->pq : nullptr; }
 VG_API vg_sq8 *vg_segment_sq8(vg_segment *seg) { return seg ? seg->sq : nullptr; }
+VG_API vg_int4 *vg_segment_int4(vg_segment *seg) { return seg ? seg->iq : nullptr; }
 
 VG_API int32_t vg_segment_close(vg_segment *seg)
 {
