@@ -91,6 +91,24 @@ def test_flat_small_batch_scan_matches_oracle(vg, ctx, n, dim, nq, k, metric):
     assert np.array_equal(ids, ids2) and np.array_equal(bits(sc), bits(sc2))
 
 
+def test_flat_more_queries_than_one_chunk(vg, ctx):
+    """nq > 4096: the host loop walks the batch in chunks of whole query tiles; every 37th query is
+    checked against the oracle, all of them against a second call in a different chunking (two
+    halves)."""
+    rng = np.random.default_rng(77)
+    n, dim, nq, k = 3000, 32, 4300, 5
+    base = rng.standard_normal((n, dim)).astype(np.float32)
+    q = rng.standard_normal((nq, dim)).astype(np.float32)
+    idx = vg.Index(ctx, n, dim); idx.set_vectors(base)
+    ids, sc = idx.search_flat(q, k)
+    for qi in range(0, nq, 37):
+        eid, esc = o.flat_search_f32(base, dim, q[qi], k)
+        assert np.array_equal(ids[qi], eid) and np.array_equal(bits(sc[qi]), bits(esc)), qi
+    a = idx.search_flat(q[:2150], k); b = idx.search_flat(q[2150:], k)
+    assert np.array_equal(np.vstack([a[0], b[0]]), ids) and np.array_equal(bits(np.vstack([a[1], b[1]])), bits(sc))
+    assert idx.flat_stats()[0] == 2 * nq
+
+
 def test_flat_duplicates_and_near_ties(vg, ctx):
     """Rows that differ in the last bits and exact duplicates: the proof step must either
     accept or fall back, and ties resolve by RowID."""
