@@ -208,9 +208,7 @@ int32_t launch_rabitq_encode(const float *d_vectors, int64_t n, int dim, uint8_t
 
 static int rq_slices(int64_t nq, int64_t n_tiles, int cus)
 {
-    const char *e = getenv("VG_RQ_WG_PER_CU");
-    const int per_cu = e ? atoi(e) : 4;
-    int64_t s = (static_cast<int64_t>(per_cu) * cus + nq - 1) / nq;  // ~4 workgroups of 256 threads per CU
+    int64_t s = (4 * static_cast<int64_t>(cus) + nq - 1) / nq;  // ~4 workgroups of 256 threads per CU (swept 2..8: 3-4 best)
     s = ((s + 7) / 8) * 8;
     int64_t max_s = (n_tiles / 8) * 8;
     if (max_s < 8) max_s = 8;
