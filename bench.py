@@ -318,6 +318,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-adc", action="store_true")
     ap.add_argument("--no-hnsw", action="store_true")
+    ap.add_argument("--backend", default="nccl",
+                    help="torch.distributed backend; 'gloo' lets several ranks share one GPU to smoke-test the N>1 path")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -325,10 +327,15 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    if args.backend != "nccl":
+        local_rank %= torch.cuda.device_count()  # debugging only: ranks may share a device
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(args.backend)
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     import vecgo_amd as vg
