@@ -29,20 +29,24 @@ uint16_t rd16(const uint8_t *p) { return static_cast<uint16_t>(p[0] | (p[1] << 8
 uint64_t rd64(const uint8_t *p) { return static_cast<uint64_t>(rd32(p)) | (static_cast<uint64_t>(rd32(p + 4)) << 32); }
 
 // CRC-32C (Castagnoli, reflected polynomial 0x82F63B78) — internal/hash/crc32c.go:15-17
-uint32_t crc32c(const uint8_t *data, size_t n)
-{
-    static uint32_t table[8][256];
-    static bool ready = false;
-    if (!ready) {
+struct Crc32cTables {
+    uint32_t t[8][256];
+    Crc32cTables()
+    {
         for (uint32_t i = 0; i < 256; i++) {
             uint32_t c = i;
             for (int k = 0; k < 8; k++) c = (c & 1) ? (c >> 1) ^ 0x82F63B78u : c >> 1;
-            table[0][i] = c;
+            t[0][i] = c;
         }
         for (uint32_t i = 0; i < 256; i++)
-            for (int t = 1; t < 8; t++) table[t][i] = (table[t - 1][i] >> 8) ^ table[0][table[t - 1][i] & 0xFF];
-        ready = true;
+            for (int s = 1; s < 8; s++) t[s][i] = (t[s - 1][i] >> 8) ^ t[0][t[s - 1][i] & 0xFF];
     }
+};
+
+uint32_t crc32c(const uint8_t *data, size_t n)
+{
+    static const Crc32cTables tables;  // built once, thread-safe (C++11 static initialisation)
+    const uint32_t(&table)[8][256] = tables.t;
     uint32_t c = 0xFFFFFFFFu;
     while (n >= 8) {  // slicing-by-8
         const uint32_t lo = rd32(data) ^ c, hi = rd32(data + 4);
