@@ -150,16 +150,19 @@ def adc_scan_roofline(vg, ctx, stream, device):
 
 
 def flat_small_batch(vg, ctx, idx, queries, stream):
-    """BASELINE configs[1] below the MFMA regime (HBM-bound for Q < ~40): one
-    query per call = one pass over the 1M x 768 fp32 rows, N*d*4 algorithmic bytes."""
+    """BASELINE configs[1] below the MFMA regime (HBM-bound for Q < ~40): a batch
+    of 1 (exact scan) or 32 (32-query GEMM tile) = one pass over the 1M x 768 fp32 rows, N*d*4
+    algorithmic bytes."""
     res = {"bound": "hbm", "peak": PEAK_HBM_GBS, "unit": "GB/s", "bytes_per_pass": N_ROWS * DIM * 4}
-    for nq in (1, 8):
+    for nq in (1, 32):
+        label, kname = ("flat_scan", "flat_scan_mq_kernel<false>") if nq <= 4 else \
+            ("flat_gemm", "flat_gemm_dma32_kernel<false,2>")
         q = queries[:nq].contiguous()
         out = (torch.empty((nq, K), dtype=torch.int32, device=q.device), torch.empty((nq, K), device=q.device))
         for _ in range(3):
             idx.search_flat(q, K, out=out, stream=stream)
         torch.cuda.synchronize()
-        ctx.profile_read("flat_scan")
+        ctx.profile_read(label)
         ctx.profile_enable(True)
         reps = 10
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -168,10 +171,10 @@ def flat_small_batch(vg, ctx, idx, queries, stream):
             idx.search_flat(q, K, out=out, stream=stream)
         e1.record(stream)
         torch.cuda.synchronize()
-        launches, ms = ctx.profile_read("flat_scan")
+        launches, ms = ctx.profile_read(label)
         ctx.profile_enable(False)
         kern_ms = ms / max(launches, 1)
-        res[f"q{nq}"] = {"call_ms": e0.elapsed_time(e1) / reps, "kernel": "flat_scan_mq_kernel<false>",
+        res[f"q{nq}"] = {"call_ms": e0.elapsed_time(e1) / reps, "kernel": kname,
                          "kernel_ms": kern_ms, "achieved": N_ROWS * DIM * 4 / (kern_ms * 1e-3) / 1e9,
                          "frac": N_ROWS * DIM * 4 / (kern_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
                          "qps": nq * 1e3 / (e0.elapsed_time(e1) / reps)}

@@ -77,8 +77,9 @@ def test_flat_fast_path_answers_random_data(vg, ctx, dim, metric, nodma):
 @pytest.mark.parametrize("n,dim,nq,k,metric", [(30000, 768, 1, 10, 0), (9000, 128, 8, 32, 0), (5000, 1024, 3, 10, 2),
                                                  (3000, 100, 7, 10, 0), (100, 64, 5, 10, 0), (20000, 256, 2, 10, 1)])
 def test_flat_small_batch_scan_matches_oracle(vg, ctx, n, dim, nq, k, metric):
-    """nq <= 8: the HBM-bound multi-query exact scan (no GEMM, no proof) answers; the same inputs
-    through the GEMM path (VG_FLAT_NO_SCAN=1) give the same bits."""
+    """Small batches: nq <= 4 is answered by the HBM-bound multi-query exact scan (no GEMM, no proof),
+    5..32 by the 32-query GEMM tile; the same inputs through the other GEMM path (VG_FLAT_NO_SCAN=1)
+    give the same bits."""
     rng = np.random.default_rng(n + dim + nq)
     idx, base, q = check(vg, ctx, n, dim, nq, k, metric, rng)
     assert idx.flat_stats() == (nq, 0)

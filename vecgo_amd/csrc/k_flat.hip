@@ -40,7 +40,16 @@ struct GemmArgs {
 template <bool DOT, int MODE>
 static int32_t launch_gemm_t(bool dma, unsigned blocks, hipStream_t st, const GemmArgs &a)
 {
-    if (dma) {
+    if (dma && MODE != 0 && a.nq <= kG32BM) {  // one 32-query block: the HBM-bound tile shape
+        auto kern = flat_gemm_dma32_kernel<DOT, MODE == 0 ? 1 : MODE>;
+        VG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   static_cast<int>(kG32LdsBytes)));
+        const int64_t tiles = (a.n + kGemmBN - 1) / kGemmBN;
+        const int64_t grid = MODE == 1 ? (tiles + a.tile_stride - 1) / a.tile_stride : tiles;
+        VG_LAUNCH(kern, dim3(static_cast<unsigned>(grid)), dim3(kGemmThreads), kG32LdsBytes, st, a.queries, a.nq, a.base,
+                  a.n, a.dim, a.norms, a.scores, a.tile_stride, a.out_cols, a.thr, a.thr_stride, a.thr_off, a.counts,
+                  a.cand, a.cap);
+    } else if (dma) {
         auto kern = flat_gemm_dma_kernel<DOT, MODE>;
         VG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    static_cast<int>(kDmaLdsBytes)));
@@ -306,7 +315,7 @@ __global__ __launch_bounds__(256) void flat_exact_kernel(const float *__restrict
 }
 
 // ---- small query batches: one HBM pass scores every row against up to 8 queries --------------------
-// Below ~8 queries the GEMM path is far from either roofline (a 128-query tile does 128 queries'
+// Below ~5 queries even the 32-query GEMM tile is slower than a plain scan (a 128-query tile does 128 queries'
 // worth of MFMA work and 1/8 of the tiles' loads for whatever is in it: 1.65 ms at 1M x 768).
 // This kernel is the HBM-bound alternative: a 16-lane group loads a row ONCE into registers
 // (dim <= 1024: 16 float4 per lane) and scores it against QB queries held in LDS, each in the
@@ -356,7 +365,8 @@ __device__ __forceinline__ float exact_rowregs16(const float4 (&rr)[16], int nbl
     return total;
 }
 
-constexpr int kScanQB = 8;  // queries per pass
+constexpr int kScanQB = 8;        // queries one pass can carry
+constexpr int kScanMaxBatch = 4;  // ... and the batch size up to which the scan beats the 32-query GEMM tile
 template <bool DOT>
 __global__ __launch_bounds__(256) void flat_scan_mq_kernel(const float *__restrict__ base, int64_t n, int dim,
                                                            const float *__restrict__ queries, int nq, int slices,
@@ -448,7 +458,7 @@ VG_API int32_t vg_search_flat(vg_index *idx, const float *queries, int64_t nq, i
         VG_TRY(none.init(static_cast<size_t>(nq) * k, st));
         VG_HIP(hipMemsetAsync(none.ptr, 0xFF, static_cast<size_t>(nq) * k * 8, st));
         VG_TRY(vg::launch_topk_merge(none.ptr, nq, 1, k, dot, oid.ptr, osc.ptr, st));
-    } else if (nq <= vg::kScanQB && dim % 4 == 0 && dim <= 1024 && dim >= 64 && !getenv("VG_FLAT_NO_SCAN") &&
+    } else if (nq <= vg::kScanMaxBatch && dim % 4 == 0 && dim <= 1024 && dim >= 64 && !getenv("VG_FLAT_NO_SCAN") &&
                !getenv("VG_FLAT_FORCE_EXACT") && !getenv("VG_FLAT_UNFUSED") &&
                (reinterpret_cast<uintptr_t>(idx->d_vectors) & 15) == 0) {
         // small batch: HBM-bound exact scan, kScanQB queries per pass over the rows
