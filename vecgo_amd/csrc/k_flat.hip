@@ -40,13 +40,17 @@ struct GemmArgs {
 template <bool DOT, int MODE>
 static int32_t launch_gemm_t(bool dma, unsigned blocks, hipStream_t st, const GemmArgs &a)
 {
-    if (dma && MODE != 0 && a.nq <= kG32BM) {  // one 32-query block: the HBM-bound tile shape
-        auto kern = flat_gemm_dma32_kernel<DOT, MODE == 0 ? 1 : MODE>;
+    const char *big = getenv("VG_FLAT_NO_SMALL_TILE");  // test hook: always the 128-query tile
+    if (dma && MODE != 0 && a.nq <= 2 * kG32BM && !(big && big[0] == '1')) {  // 1-2 blocks of 32 queries: HBM-bound shapes
+        constexpr int M = MODE == 0 ? 1 : MODE;
+        const bool one = a.nq <= kG32BM;
+        auto kern = one ? flat_gemm_dma32_kernel<DOT, M, 1> : flat_gemm_dma32_kernel<DOT, M, 2>;
+        const size_t lds = one ? g32_lds_bytes<1>() : g32_lds_bytes<2>();
         VG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   static_cast<int>(kG32LdsBytes)));
+                                   static_cast<int>(lds)));
         const int64_t tiles = (a.n + kGemmBN - 1) / kGemmBN;
         const int64_t grid = MODE == 1 ? (tiles + a.tile_stride - 1) / a.tile_stride : tiles;
-        VG_LAUNCH(kern, dim3(static_cast<unsigned>(grid)), dim3(kGemmThreads), kG32LdsBytes, st, a.queries, a.nq, a.base,
+        VG_LAUNCH(kern, dim3(static_cast<unsigned>(grid)), dim3(kGemmThreads), lds, st, a.queries, a.nq, a.base,
                   a.n, a.dim, a.norms, a.scores, a.tile_stride, a.out_cols, a.thr, a.thr_stride, a.thr_off, a.counts,
                   a.cand, a.cap);
     } else if (dma) {

@@ -425,18 +425,18 @@ __global__ __launch_bounds__(kGemmThreads) void flat_gemm_dma_kernel(
                              counts, cand, cap);
 }
 
-// ---- 9..32 queries: the same pipeline with a 32 x 128 tile ---------------------------------------
+// ---- 5..64 queries: the same pipeline with a 32 x 128 or 64 x 128 tile ------------------------------
 // A 128-query tile does 128 queries' worth of MFMA work whatever it holds (1.65 ms per pass over
-// 1M x 768 rows).  With one 32-row query block the MFMA time drops 4x and the pass becomes
-// HBM-bound like the Q <= 8 scan: 4 waves as 1 x 4, each one 32 x 32 accumulator; per K step a
-// workgroup moves 16 KiB of rows and 4 KiB of queries by LDS-DMA (5 pieces per wave) for 16 MFMAs
-// per wave.  LDS per workgroup: 2 x (4 + 16) KiB, so three to four workgroups share a CU.
-// nq <= 32 only (one query block; the grid covers the row tiles).  MODE 1 / 2 as above.
+// 1M x 768 rows).  With RB = 1 or 2 blocks of 32 query rows the MFMA time drops 4x / 2x and the pass
+// becomes HBM-bound like the small-batch scan: 4 waves as 1 x 4, each RB accumulators of 32 x 32; per
+// K step a workgroup moves 16 KiB of rows and RB * 4 KiB of queries by LDS-DMA for RB * 16 MFMAs per
+// wave.  LDS per workgroup: 2 x (RB * 4 + 16) KiB, so three to four workgroups share a CU.
+// nq <= RB * 32 only (one query tile; the grid covers the row tiles).  MODE 1 / 2 as above.
 constexpr int kG32BM = 32;
-constexpr int kG32ATile = kG32BM * kGemmBK;                                  // floats
-constexpr size_t kG32LdsBytes = 2 * (kG32ATile + kDmaTile) * sizeof(float);  // A0 | B0 | A1 | B1: 40 KiB
+template <int RB>
+constexpr size_t g32_lds_bytes() { return 2 * (RB * kG32BM * kGemmBK + kDmaTile) * sizeof(float); }
 
-template <bool DOT, int MODE>
+template <bool DOT, int MODE, int RB>
 __global__ __launch_bounds__(kGemmThreads) void flat_gemm_dma32_kernel(
     const float *__restrict__ queries, int64_t nq, const float *__restrict__ base, int64_t n,
     int dim, const float *__restrict__ norms, float *__restrict__ scores, int tile_stride,
@@ -444,6 +444,7 @@ __global__ __launch_bounds__(kGemmThreads) void flat_gemm_dma32_kernel(
     int *__restrict__ counts, uint64_t *__restrict__ cand, int cap)
 {
     extern __shared__ float gemm_lds[];
+    constexpr int kATile = RB * kG32BM * kGemmBK;  // floats
     const int64_t ntiles = MODE == 1 ? (((n + kGemmBN - 1) / kGemmBN) + tile_stride - 1) / tile_stride
                                      : (n + kGemmBN - 1) / kGemmBN;
     const int64_t tn = blockIdx.x;
@@ -455,50 +456,57 @@ __global__ __launch_bounds__(kGemmThreads) void flat_gemm_dma32_kernel(
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
     // DMA map of the B tile as in flat_gemm_dma_kernel (pass p, wave w: rows p*32 + w*8 .. +8); the
-    // A tile is one pass: wave w fills query rows w*8 .. +8
+    // A tile is RB passes of the same shape over the query rows
     const int drow = wave * 8 + (lane >> 3);
     const int dgl = (lane & 7) ^ ((wave * 4 + (lane >> 4)) & 7);
     const float *const bbase = base + n0 * dim;
-    uint32_t boff[kGemmPasses];
+    uint32_t boff[kGemmPasses], aoff[RB];
 #pragma unroll
     for (int p = 0; p < kGemmPasses; p++) {
         int64_t nb = n0 + p * 32 + drow;
         if (nb >= n) nb = n - 1;
         boff[p] = static_cast<uint32_t>(((nb - n0) * dim + dgl * 4) * 4);
     }
-    int64_t qa = drow;
-    if (qa >= nq) qa = nq - 1;
-    const uint32_t aoff = static_cast<uint32_t>((qa * dim + dgl * 4) * 4);
+#pragma unroll
+    for (int p = 0; p < RB; p++) {
+        int64_t qa = p * 32 + drow;
+        if (qa >= nq) qa = nq - 1;
+        aoff[p] = static_cast<uint32_t>((qa * dim + dgl * 4) * 4);
+    }
     const int ksteps = (dim + kGemmBK - 1) / kGemmBK;
     const int full_steps = dim / kGemmBK;
     const uint32_t lds0 = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(
         (__attribute__((address_space(3))) void *)gemm_lds));
-    constexpr int kBuf = kG32ATile + kDmaTile;  // floats per buffer: A (32 rows) then B (128 rows)
-    auto a_piece = [&](int b) {
+    constexpr int kBuf = kATile + kDmaTile;  // floats per buffer: A (RB * 32 rows) then B (128 rows)
+    auto a_piece = [&](int b, int p) {
         return static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(
-            static_cast<int>(lds0 + (b * kBuf + wave * 8 * kGemmBK) * 4)));
+            static_cast<int>(lds0 + (b * kBuf + (p * 32 + wave * 8) * kGemmBK) * 4)));
     };
     auto b_piece = [&](int b, int p) {
         return static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(
-            static_cast<int>(lds0 + (b * kBuf + kG32ATile + (p * 32 + wave * 8) * kGemmBK) * 4)));
+            static_cast<int>(lds0 + (b * kBuf + kATile + (p * 32 + wave * 8) * kGemmBK) * 4)));
     };
     auto dma_tile = [&](int kt) {
         const int k0 = kt * kGemmBK, b = kt & 1;
         if (kt < full_steps) {
-            glds16(queries + k0, aoff, a_piece(b));
+#pragma unroll
+            for (int p = 0; p < RB; p++) glds16(queries + k0, aoff[p], a_piece(b, p));
 #pragma unroll
             for (int p = 0; p < kGemmPasses; p++) glds16(bbase + k0, boff[p], b_piece(b, p));
         } else {  // ragged K edge; dim % 4 == 0, so a granule is inside or outside as a whole
             const float *zeros = reinterpret_cast<const float *>(&g_gemm_zero16);
             const bool in = k0 + dgl * 4 < dim;
-            glds16(in ? queries + k0 + aoff / 4 : zeros, a_piece(b));
+#pragma unroll
+            for (int p = 0; p < RB; p++) glds16(in ? queries + k0 + aoff[p] / 4 : zeros, a_piece(b, p));
 #pragma unroll
             for (int p = 0; p < kGemmPasses; p++) glds16(in ? bbase + k0 + boff[p] / 4 : zeros, b_piece(b, p));
         }
     };
-    f32x16 acc;
+    f32x16 acc[RB];
 #pragma unroll
-    for (int r = 0; r < 16; r++) acc[r] = 0.0f;
+    for (int i = 0; i < RB; i++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[i][r] = 0.0f;
     const int h = lane >> 5, f = (lane >> 1) & 7;
     int goff[4];
 #pragma unroll
@@ -506,10 +514,10 @@ __global__ __launch_bounds__(kGemmThreads) void flat_gemm_dma32_kernel(
     const int a_row = (lane & 31) * kGemmBK;
     const int b_row = (wave * 32 + (lane & 31)) * kGemmBK;
 
-    // epilogue inputs before the K loop: thread t < 32 holds the threshold of query t, every lane
+    // epilogue inputs before the K loop: thread t < RB*32 holds the threshold of query t, every lane
     // the norm of its column
     float thr_reg = -INFINITY;
-    if (MODE == 2 && tid < kG32BM && tid < nq) thr_reg = thr[static_cast<int64_t>(tid) * thr_stride + thr_off];
+    if (MODE == 2 && tid < RB * kG32BM && tid < nq) thr_reg = thr[static_cast<int64_t>(tid) * thr_stride + thr_off];
     const int col = wave * 32 + (lane & 31);
     const int64_t nn = n0 + col;
     const float xn = (!DOT && nn < n) ? norms[nn] : 0.0f;
@@ -518,48 +526,61 @@ __global__ __launch_bounds__(kGemmThreads) void flat_gemm_dma32_kernel(
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     for (int kt = 0; kt < ksteps; kt++) {
-        const float *As = gemm_lds + (kt & 1) * kBuf, *Bs = As + kG32ATile;
+        const float *As = gemm_lds + (kt & 1) * kBuf, *Bs = As + kATile;
         if (kt + 1 < ksteps) dma_tile(kt + 1);
-        float4 fa[2], fb[2];  // [parity]
-        fa[0] = *reinterpret_cast<const float4 *>(As + a_row + goff[0]);
+        float4 fa[2][RB], fb[2];  // [parity]
+#pragma unroll
+        for (int i = 0; i < RB; i++) fa[0][i] = *reinterpret_cast<const float4 *>(As + i * 32 * kGemmBK + a_row + goff[0]);
         fb[0] = *reinterpret_cast<const float4 *>(Bs + b_row + goff[0]);
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const int c = j & 1, nx = c ^ 1;
             if (j < 3) {
-                fa[nx] = *reinterpret_cast<const float4 *>(As + a_row + goff[j + 1]);
+#pragma unroll
+                for (int i = 0; i < RB; i++)
+                    fa[nx][i] = *reinterpret_cast<const float4 *>(As + i * 32 * kGemmBK + a_row + goff[j + 1]);
                 fb[nx] = *reinterpret_cast<const float4 *>(Bs + b_row + goff[j + 1]);
             }
             __builtin_amdgcn_sched_barrier(0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c].x, fb[c].x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c].y, fb[c].y, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c].z, fb[c].z, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c].w, fb[c].w, acc, 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < RB; i++) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][i].x, fb[c].x, acc[i], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < RB; i++) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][i].y, fb[c].y, acc[i], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < RB; i++) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][i].z, fb[c].z, acc[i], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < RB; i++) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][i].w, fb[c].w, acc[i], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
-    float4 t4[4];  // thresholds of rows 8*g + 4*(lane>>5) + 0..3
+    float4 t4[RB][4];  // thresholds of rows i*32 + 8*g + 4*(lane>>5) + 0..3
     if (MODE == 2) {
-        if (tid < kG32BM) gemm_lds[tid] = thr_reg;
+        if (tid < RB * kG32BM) gemm_lds[tid] = thr_reg;
         __syncthreads();
 #pragma unroll
-        for (int g = 0; g < 4; g++) t4[g] = *reinterpret_cast<const float4 *>(gemm_lds + 8 * g + 4 * (lane >> 5));
+        for (int i = 0; i < RB; i++)
+#pragma unroll
+            for (int g = 0; g < 4; g++)
+                t4[i][g] = *reinterpret_cast<const float4 *>(gemm_lds + i * 32 + 8 * g + 4 * (lane >> 5));
     }
 #pragma unroll
-    for (int r = 0; r < 16; r++) {
-        const int ql = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        const float dotv = acc[r];
-        const float sc = DOT ? -dotv : __builtin_fmaf(-2.0f, dotv, xn);
-        if (MODE == 1) {
-            if (ql < nq) scores[static_cast<int64_t>(ql) * out_cols + tn * kGemmBN + col] = nn < n ? sc : INFINITY;
-        } else {
-            const float4 tv = t4[r >> 2];
-            const float t = (r & 3) == 0 ? tv.x : (r & 3) == 1 ? tv.y : (r & 3) == 2 ? tv.z : tv.w;
-            if (nn < n && sc < t) {
-                const int pos = atomicAdd(&counts[ql], 1);
-                if (pos < cap) cand[static_cast<int64_t>(ql) * cap + pos] = make_key(sc, static_cast<uint32_t>(nn), false);
+    for (int i = 0; i < RB; i++) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int ql = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            const float dotv = acc[i][r];
+            const float sc = DOT ? -dotv : __builtin_fmaf(-2.0f, dotv, xn);
+            if (MODE == 1) {
+                if (ql < nq) scores[static_cast<int64_t>(ql) * out_cols + tn * kGemmBN + col] = nn < n ? sc : INFINITY;
+            } else {
+                const float4 tv = t4[i][r >> 2];
+                const float t = (r & 3) == 0 ? tv.x : (r & 3) == 1 ? tv.y : (r & 3) == 2 ? tv.z : tv.w;
+                if (nn < n && sc < t) {
+                    const int pos = atomicAdd(&counts[ql], 1);
+                    if (pos < cap) cand[static_cast<int64_t>(ql) * cap + pos] = make_key(sc, static_cast<uint32_t>(nn), false);
+                }
             }
         }
     }
