@@ -50,6 +50,8 @@ struct Sub16 {
 };
 
 enum ExactMode { kPair = 0, kBatch = 1, kBounded = 2 };
+constexpr int kExactChunk = 12;      // 64-float blocks whose loads are issued together (768 floats = one chunk)
+constexpr int kExactChunkSmall = 4;  // ... and the size tried next for what is left
 
 // One pair.  `row` and `q` point at dim floats (16-byte aligned when dim % 4 == 0, which the
 // fast path requires; other dims take the scalar route below).  All 16 lanes of the group
@@ -62,9 +64,10 @@ __device__ __forceinline__ float exact_pair16(const float *__restrict__ row,
     const int nblk = dim >> 6;
     const float4 *r4 = reinterpret_cast<const float4 *>(row) + sub.f4;
     const float4 *q4 = reinterpret_cast<const float4 *>(q) + sub.f4;
-    for (int e = 0; e < nblk; e++) {
-        const float4 a = q4[e * 16];
-        const float4 b = r4[e * 16];
+    // kExactChunk blocks at a time: their 2 * kExactChunk loads are issued together (a one-block loop
+    // serialises one memory round trip per 64 floats: 12 per 768-d row, which is what bounded the
+    // graph searches).  The FMAs still run in block order, so every accumulator chain is unchanged.
+    auto step = [&](const float4 a, const float4 b) {
         if (DOT) {
             acc[0] = __builtin_fmaf(a.x, b.x, acc[0]);
             acc[1] = __builtin_fmaf(a.y, b.y, acc[1]);
@@ -77,7 +80,29 @@ __device__ __forceinline__ float exact_pair16(const float *__restrict__ row,
             acc[2] = __builtin_fmaf(d2, d2, acc[2]);
             acc[3] = __builtin_fmaf(d3, d3, acc[3]);
         }
+    };
+    int e = 0;
+    for (; e + kExactChunk <= nblk; e += kExactChunk) {
+        float4 a[kExactChunk], b[kExactChunk];
+#pragma unroll
+        for (int u = 0; u < kExactChunk; u++) {
+            a[u] = q4[(e + u) * 16];
+            b[u] = r4[(e + u) * 16];
+        }
+#pragma unroll
+        for (int u = 0; u < kExactChunk; u++) step(a[u], b[u]);
     }
+    for (; e + kExactChunkSmall <= nblk; e += kExactChunkSmall) {
+        float4 a[kExactChunkSmall], b[kExactChunkSmall];
+#pragma unroll
+        for (int u = 0; u < kExactChunkSmall; u++) {
+            a[u] = q4[(e + u) * 16];
+            b[u] = r4[(e + u) * 16];
+        }
+#pragma unroll
+        for (int u = 0; u < kExactChunkSmall; u++) step(a[u], b[u]);
+    }
+    for (; e < nblk; e++) step(q4[e * 16], r4[e * 16]);
     float s[4];
 #pragma unroll
     for (int t = 0; t < 4; t++) {
@@ -151,15 +176,35 @@ __device__ __forceinline__ void exact_l2_both16(const float *__restrict__ row,
     const int nblk = dim >> 6;
     const float4 *r4 = reinterpret_cast<const float4 *>(row) + sub.f4;
     const float4 *q4 = reinterpret_cast<const float4 *>(q) + sub.f4;
-    for (int e = 0; e < nblk; e++) {
-        const float4 a = q4[e * 16];
-        const float4 b = r4[e * 16];
+    auto step = [&](const float4 a, const float4 b) {
         const float d0 = a.x - b.x, d1 = a.y - b.y, d2 = a.z - b.z, d3 = a.w - b.w;
         acc[0] = __builtin_fmaf(d0, d0, acc[0]);
         acc[1] = __builtin_fmaf(d1, d1, acc[1]);
         acc[2] = __builtin_fmaf(d2, d2, acc[2]);
         acc[3] = __builtin_fmaf(d3, d3, acc[3]);
+    };
+    int e = 0;
+    for (; e + kExactChunk <= nblk; e += kExactChunk) {  // see exact_pair16
+        float4 qa[kExactChunk], rb[kExactChunk];
+#pragma unroll
+        for (int u = 0; u < kExactChunk; u++) {
+            qa[u] = q4[(e + u) * 16];
+            rb[u] = r4[(e + u) * 16];
+        }
+#pragma unroll
+        for (int u = 0; u < kExactChunk; u++) step(qa[u], rb[u]);
     }
+    for (; e + kExactChunkSmall <= nblk; e += kExactChunkSmall) {
+        float4 qa[kExactChunkSmall], rb[kExactChunkSmall];
+#pragma unroll
+        for (int u = 0; u < kExactChunkSmall; u++) {
+            qa[u] = q4[(e + u) * 16];
+            rb[u] = r4[(e + u) * 16];
+        }
+#pragma unroll
+        for (int u = 0; u < kExactChunkSmall; u++) step(qa[u], rb[u]);
+    }
+    for (; e < nblk; e++) step(q4[e * 16], r4[e * 16]);
     float b[4];
 #pragma unroll
     for (int t = 0; t < 4; t++) {
