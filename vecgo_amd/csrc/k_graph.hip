@@ -367,20 +367,45 @@ __global__ __launch_bounds__(64) void vamana_search_kernel(
             if (kind == kVamanaPQ) {
                 // ComputeAsymmetricDistance (pq.go:234-260): term(m) = BuildDistanceTable entry,
                 // summed sequentially over the sub-quantizers
+                // (16 sub-quantizers at a time: the code bytes come as one 16-byte load when the row is
+                // aligned, the 16 table reads are issued together; the sum stays sequential in s)
                 const uint8_t *code = pq_rows + static_cast<int64_t>(id_lane) * pq_m;
                 float distance = 0.0f;
-                for (int s = 0; s < pq_m; s++) distance = distance + lut[s * 256 + code[s]];
+                int s0 = 0;
+                if ((pq_m & 15) == 0) {
+                    for (; s0 < pq_m; s0 += 16) {
+                        const uint4 c = *reinterpret_cast<const uint4 *>(code + s0);
+                        const uint32_t w[4] = {c.x, c.y, c.z, c.w};
+                        float t[16];
+#pragma unroll
+                        for (int u = 0; u < 16; u++)
+                            t[u] = lut[(s0 + u) * 256 + ((w[u >> 2] >> (8 * (u & 3))) & 0xFFu)];
+#pragma unroll
+                        for (int u = 0; u < 16; u++) distance = distance + t[u];
+                    }
+                }
+                for (int s = s0; s < pq_m; s++) distance = distance + lut[s * 256 + code[s]];
                 nb_d[lane] = distance;
             } else if (kind == kVamanaInt4) {
                 // iq.L2Distance (diskann/segment.go:558-565) = int4L2DistancePrecomputedAvx512 order
                 nb_d[lane] = int4_l2_precomputed(qv, int4_rows + static_cast<int64_t>(id_lane) * ((dim + 1) / 2), dim,
                                                  int4_table);
             } else {
-                const uint8_t *code = rq_rows + static_cast<int64_t>(id_lane) * (rq_nb + 4);
+                // rows are rq_nb + 4 bytes with rq_nb a multiple of 8: every row is 4-byte aligned, so the
+                // bits and the norm are read as dwords, 8 loads in flight at a time
+                const uint32_t *cw = reinterpret_cast<const uint32_t *>(rq_rows + static_cast<int64_t>(id_lane) * (rq_nb + 4));
+                const uint32_t *qw = reinterpret_cast<const uint32_t *>(qc);
+                const int nw = rq_nb >> 2;
                 int h = 0;
-                for (int b = 0; b < rq_nb; b++) h += __popc(static_cast<unsigned>(qc[b] ^ code[b]));
-                const uint32_t yb = code[rq_nb] | (code[rq_nb + 1] << 8) | (code[rq_nb + 2] << 16) |
-                                    (static_cast<uint32_t>(code[rq_nb + 3]) << 24);
+                for (int b0 = 0; b0 < nw; b0 += 8) {
+                    uint32_t x[8];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) x[u] = b0 + u < nw ? cw[b0 + u] : 0u;
+#pragma unroll
+                    for (int u = 0; u < 8; u++)
+                        if (b0 + u < nw) h += __popc(x[u] ^ qw[b0 + u]);
+                }
+                const uint32_t yb = cw[nw];
                 nb_d[lane] = rq_formula_g(qn, __uint_as_float(yb), static_cast<float>(dim), static_cast<float>(h));
             }
         }
