@@ -126,12 +126,37 @@ struct WaveTopK {
 // int4L2DistancePrecomputedAvx512 (int4_avx512.c:127-189) of one code: what Int4Quantizer.L2Distance
 // runs (int4.go:140-147) and therefore the DiskANN node scorer
 __device__ __forceinline__ float int4_l2_precomputed(const float *__restrict__ query, const uint8_t *__restrict__ code, int dim,
-                                     const float *__restrict__ table)
+                                                     const float *__restrict__ table)
 {
     float sum[16];
 #pragma unroll
     for (int l = 0; l < 16; l++) sum[l] = 0.0f;
     int i = 0;
+    // 32 elements at a time when the code is 16-byte aligned: one 16-byte load of nibbles, then 32
+    // table reads in flight; the two 16-element blocks still feed sum[] in order
+    if ((reinterpret_cast<uintptr_t>(code) & 15) == 0) {
+        for (; i <= dim - 32; i += 32) {
+            const uint4 c = *reinterpret_cast<const uint4 *>(code + (i >> 1));
+            const uint32_t w[4] = {c.x, c.y, c.z, c.w};
+            float t[32];
+#pragma unroll
+            for (int l = 0; l < 32; l++) {
+                const uint32_t b = (w[l >> 3] >> (8 * ((l >> 1) & 3))) & 0xFFu;
+                const int qv = (l & 1) ? (b & 0x0F) : (b >> 4);
+                t[l] = table[(i + l) * 16 + qv];
+            }
+#pragma unroll
+            for (int l = 0; l < 16; l++) {
+                const float d = query[i + l] - t[l];
+                sum[l] = __builtin_fmaf(d, d, sum[l]);
+            }
+#pragma unroll
+            for (int l = 0; l < 16; l++) {
+                const float d = query[i + 16 + l] - t[16 + l];
+                sum[l] = __builtin_fmaf(d, d, sum[l]);
+            }
+        }
+    }
     for (; i <= dim - 16; i += 16) {
 #pragma unroll
         for (int l = 0; l < 16; l++) {
