@@ -58,6 +58,29 @@ __device__ inline float rq_formula(float qn, float yn, float dimf, float hamming
     return t1sq + t2;
 }
 
+// popcount(a ^ c) over nbytes bytes: dwords, 8 loads in flight at a time, when both are 4-byte aligned
+__device__ __forceinline__ int hamming_bytes(const uint8_t *__restrict__ a, const uint8_t *__restrict__ c, int64_t nbytes)
+{
+    int h = 0;
+    int64_t b = 0;
+    if (((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(c)) & 3) == 0) {
+        const uint32_t *aw = reinterpret_cast<const uint32_t *>(a), *cw = reinterpret_cast<const uint32_t *>(c);
+        const int64_t nw = nbytes >> 2;
+        int64_t w = 0;
+        for (; w + 8 <= nw; w += 8) {
+            uint32_t x[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) x[u] = cw[w + u];
+#pragma unroll
+            for (int u = 0; u < 8; u++) h += __popc(x[u] ^ aw[w + u]);
+        }
+        for (; w < nw; w++) h += __popc(cw[w] ^ aw[w]);
+        b = nw << 2;
+    }
+    for (; b < nbytes; b++) h += __popc(static_cast<unsigned>(a[b] ^ c[b]));
+    return h;
+}
+
 // Distance of one query code (bits + norm, as produced by Encode) against n reference-layout
 // codes: thread per row.
 __global__ void rabitq_distance_kernel(const uint8_t *__restrict__ qcode, const uint8_t *__restrict__ codes,
@@ -67,8 +90,7 @@ __global__ void rabitq_distance_kernel(const uint8_t *__restrict__ qcode, const 
     if (i >= n) return;
     const int nb = rq_words(dim) * 8;
     const uint8_t *c = codes + i * (nb + 4);
-    int h = 0;
-    for (int b = 0; b < nb; b++) h += __popc(static_cast<unsigned>(qcode[b] ^ c[b]));
+    const int h = hamming_bytes(qcode, c, nb);
     uint32_t qb = qcode[nb] | (qcode[nb + 1] << 8) | (qcode[nb + 2] << 16) | (static_cast<uint32_t>(qcode[nb + 3]) << 24);
     uint32_t yb = c[nb] | (c[nb + 1] << 8) | (c[nb + 2] << 16) | (static_cast<uint32_t>(c[nb + 3]) << 24);
     out[i] = rq_formula(__uint_as_float(qb), __uint_as_float(yb), static_cast<float>(dim), static_cast<float>(h));
@@ -79,10 +101,7 @@ __global__ void hamming_batch_kernel(const uint8_t *__restrict__ a, const uint8_
 {
     const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const uint8_t *c = codes + i * nbytes;
-    int h = 0;
-    for (int64_t b = 0; b < nbytes; b++) h += __popc(static_cast<unsigned>(a[b] ^ c[b]));
-    out[i] = h;
+    out[i] = hamming_bytes(a, codes + i * nbytes, nbytes);
 }
 
 // reference layout -> [tile][group][lane] 16-byte pieces of the sign bits + norms[n]
