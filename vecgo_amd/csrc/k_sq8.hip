@@ -207,6 +207,7 @@ __global__ void sq8_retile_kernel(const uint8_t *__restrict__ codes, int64_t n, 
 }
 
 // Exhaustive SQ8 scan with fused top-k.  HBM-bound by design: 16*groups bytes per row.
+constexpr int kSqAhead = 4;  // 16-byte code groups in flight per lane
 constexpr int kSqWaves = 4;
 constexpr int kSqThreads = kSqWaves * 64;
 __global__ __launch_bounds__(kSqThreads) void sq8_scan_kernel(
@@ -232,14 +233,24 @@ __global__ __launch_bounds__(kSqThreads) void sq8_scan_kernel(
         float acc[16];
 #pragma unroll
         for (int l = 0; l < 16; l++) acc[l] = 0.0f;
-        uint4 c = tp[0];
-        for (int g = 0; g < full; g++) {
-            const uint4 cn = tp[(g + 1 < groups ? g + 1 : g) * 64];  // next group in flight
-            sq8_block16(acc, c, qv + g * 16, mins + g * 16, inv + g * 16);
-            c = cn;
+        // kSqAhead groups of codes in flight per lane (one ahead left the wave waiting on HBM every
+        // 64 VALU instructions); addresses past the row's last group are clamped to it
+        uint4 ring[kSqAhead];
+        const int glast = groups - 1;
+#pragma unroll
+        for (int a = 0; a < kSqAhead; a++) ring[a] = tp[(a < glast ? a : glast) * 64];
+        for (int g0 = 0; g0 < full; g0 += kSqAhead) {
+#pragma unroll
+            for (int a = 0; a < kSqAhead; a++) {
+                const int g = g0 + a;
+                const uint4 c = ring[a];
+                const int gn = g + kSqAhead;
+                ring[a] = tp[(gn < glast ? gn : glast) * 64];
+                if (g < full) sq8_block16(acc, c, qv + g * 16, mins + g * 16, inv + g * 16);
+            }
         }
         float total = reduce16_regs(acc);
-        if (tail) total = sq8_tail(total, c, tail, qv + full * 16, mins + full * 16, inv + full * 16);
+        if (tail) total = sq8_tail(total, tp[full * 64], tail, qv + full * 16, mins + full * 16, inv + full * 16);
         const int64_t row = tile * 64 + lane;
         tk.offer(row < n_rows ? make_key(total, static_cast<uint32_t>(row), false) : kKeyMax, lane);
     }
