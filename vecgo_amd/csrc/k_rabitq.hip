@@ -131,6 +131,7 @@ __global__ void rabitq_retile_kernel(const uint8_t *__restrict__ codes, int64_t 
 }
 
 // Exhaustive RaBitQ scan with fused top-k.  HBM-bound: (16*groups + 4) bytes per row.
+constexpr int kRqTiles = 2;  // 64-row tiles per trip of the d = 768 scan (4 is no faster)
 constexpr int kRqWaves = 4;
 constexpr int kRqThreads = kRqWaves * 64;
 __global__ __launch_bounds__(kRqThreads) void rabitq_scan_kernel(
@@ -163,8 +164,8 @@ __global__ __launch_bounds__(kRqThreads) void rabitq_scan_kernel(
     __syncthreads();
     WaveTopK tk;
     tk.init(k);
-    // two tiles per trip: 2 * groups independent 16-byte loads in flight per lane before the first
-    // popcount (one tile per trip left the wave idle for a full HBM round trip per 64 rows)
+    // several tiles per trip: kRqTiles * groups independent 16-byte loads in flight per lane before the
+    // first popcount (one tile per trip left the wave idle for a full HBM round trip per 64 rows)
     auto score = [&](int64_t tile, int h) {
         const int64_t row = tile * 64 + lane;
         uint64_t key = kKeyMax;
@@ -175,32 +176,40 @@ __global__ __launch_bounds__(kRqThreads) void rabitq_scan_kernel(
         tk.offer(key, lane);
     };
     int64_t tile = t0 + wave;
-    if (groups == 6) {  // d = 768: fully unrolled
-        for (; tile + kRqWaves < t1; tile += 2 * kRqWaves) {
-            const uint4 *tp0 = tiles + (tile * 6) * 64 + lane;
-            const uint4 *tp1 = tiles + ((tile + kRqWaves) * 6) * 64 + lane;
-            uint4 c0[6], c1[6];
+    if (groups == 6) {  // d = 768: fully unrolled, kRqTiles tiles (6 * kRqTiles 16-byte loads) per trip
+        for (; tile + static_cast<int64_t>(kRqTiles - 1) * kRqWaves < t1; tile += kRqTiles * kRqWaves) {
+            uint4 c[kRqTiles][6];
+            float y[kRqTiles];
 #pragma unroll
-            for (int g = 0; g < 6; g++) c0[g] = tp0[g * 64];
+            for (int t = 0; t < kRqTiles; t++) {
+                const uint4 *tp = tiles + ((tile + t * kRqWaves) * 6) * 64 + lane;
 #pragma unroll
-            for (int g = 0; g < 6; g++) c1[g] = tp1[g * 64];
-            const float y0 = (tile * 64 + lane) < n_rows ? norms[tile * 64 + lane] : 0.0f;
-            const float y1 = ((tile + kRqWaves) * 64 + lane) < n_rows ? norms[(tile + kRqWaves) * 64 + lane] : 0.0f;
-            int h0 = 0, h1 = 0;
+                for (int g = 0; g < 6; g++) c[t][g] = tp[g * 64];
+            }
+#pragma unroll
+            for (int t = 0; t < kRqTiles; t++) {
+                const int64_t row = (tile + t * kRqWaves) * 64 + lane;
+                y[t] = row < n_rows ? norms[row] : 0.0f;
+            }
+            int h[kRqTiles];
+#pragma unroll
+            for (int t = 0; t < kRqTiles; t++) h[t] = 0;
 #pragma unroll
             for (int g = 0; g < 6; g++) {
                 const uint4 qq = qbits[g];
-                h0 += __popc(c0[g].x ^ qq.x) + __popc(c0[g].y ^ qq.y) + __popc(c0[g].z ^ qq.z) + __popc(c0[g].w ^ qq.w);
-                h1 += __popc(c1[g].x ^ qq.x) + __popc(c1[g].y ^ qq.y) + __popc(c1[g].z ^ qq.z) + __popc(c1[g].w ^ qq.w);
+#pragma unroll
+                for (int t = 0; t < kRqTiles; t++)
+                    h[t] += __popc(c[t][g].x ^ qq.x) + __popc(c[t][g].y ^ qq.y) + __popc(c[t][g].z ^ qq.z) +
+                            __popc(c[t][g].w ^ qq.w);
             }
-            uint64_t k0 = kKeyMax, k1 = kKeyMax;
-            if (tile * 64 + lane < n_rows)
-                k0 = make_key(rq_formula(qn, y0, dimf, static_cast<float>(h0)), static_cast<uint32_t>(tile * 64 + lane), false);
-            if ((tile + kRqWaves) * 64 + lane < n_rows)
-                k1 = make_key(rq_formula(qn, y1, dimf, static_cast<float>(h1)),
-                              static_cast<uint32_t>((tile + kRqWaves) * 64 + lane), false);
-            tk.offer(k0, lane);
-            tk.offer(k1, lane);
+#pragma unroll
+            for (int t = 0; t < kRqTiles; t++) {
+                const int64_t row = (tile + t * kRqWaves) * 64 + lane;
+                uint64_t key = kKeyMax;
+                if (row < n_rows)
+                    key = make_key(rq_formula(qn, y[t], dimf, static_cast<float>(h[t])), static_cast<uint32_t>(row), false);
+                tk.offer(key, lane);
+            }
         }
     }
     for (; tile < t1; tile += kRqWaves) {
