@@ -322,6 +322,75 @@ private:
     vg_sq8 *h_ = nullptr;
 };
 
+// quantization.Int4Quantizer (int4.go:12-20)
+class Int4Quantizer : public Quantizer {
+public:
+    Int4Quantizer(std::shared_ptr<Context> ctx, int dimension) : ctx_(std::move(ctx)), dim_(dimension)
+    {
+        check(vg_int4_create(ctx_->handle(), dimension, &h_));
+    }
+    ~Int4Quantizer() override { vg_int4_destroy(h_); }
+    vg_int4 *handle() const { return h_; }
+    bool IsTrained() const { return vg_int4_is_trained(h_) != 0; }
+
+    // Train (int4.go:29-62)
+    void Train(const std::vector<std::vector<float>> &vectors) override
+    {
+        if (vectors.empty()) throw Error(VG_ERR_INVALID_ARG, "no vectors provided for training");
+        std::vector<float> flat;
+        flat.reserve(vectors.size() * static_cast<size_t>(dim_));
+        for (const auto &v : vectors) {
+            if (static_cast<int>(v.size()) != dim_) throw Error(VG_ERR_DIM_MISMATCH, "dimension mismatch");
+            flat.insert(flat.end(), v.begin(), v.end());
+        }
+        check(vg_int4_train(h_, flat.data(), static_cast<int64_t>(vectors.size()), nullptr));
+    }
+    // UnmarshalBinary (int4.go:190-219): min[dim] then diff[dim]
+    void SetParams(const std::vector<float> &minVal, const std::vector<float> &diff)
+    {
+        if (static_cast<int>(minVal.size()) != dim_ || static_cast<int>(diff.size()) != dim_)
+            throw Error(VG_ERR_DIM_MISMATCH, "data size mismatch");
+        check(vg_int4_set_params(h_, minVal.data(), diff.data()));
+    }
+    // Encode / Decode (int4.go:65-130)
+    std::vector<uint8_t> Encode(const std::vector<float> &v) override
+    {
+        if (static_cast<int>(v.size()) != dim_) throw Error(VG_ERR_DIM_MISMATCH, "dimension mismatch");
+        std::vector<uint8_t> out(static_cast<size_t>((dim_ + 1) / 2));
+        check(vg_int4_encode(h_, v.data(), 1, out.data(), nullptr));
+        return out;
+    }
+    std::vector<float> Decode(const std::vector<uint8_t> &b) override
+    {
+        if (static_cast<int>(b.size()) != (dim_ + 1) / 2) throw Error(VG_ERR_DIM_MISMATCH, "dimension mismatch");
+        std::vector<float> out(static_cast<size_t>(dim_));
+        check(vg_int4_decode(h_, b.data(), 1, out.data(), nullptr));
+        return out;
+    }
+    // L2Distance (int4.go:133-147: lookup-table kernel) / L2DistanceBatch (int4.go:150-164)
+    float L2Distance(const std::vector<float> &query, const std::vector<uint8_t> &code)
+    {
+        if (static_cast<int>(query.size()) != dim_ || static_cast<int>(code.size()) != (dim_ + 1) / 2)
+            throw Error(VG_ERR_DIM_MISMATCH, "dimension mismatch");
+        float d = 0.0f;
+        check(vg_int4_l2_distance_batch(h_, query.data(), code.data(), 1, 1, &d, nullptr));
+        return d;
+    }
+    void L2DistanceBatch(const std::vector<float> &query, const std::vector<uint8_t> &codes, int n, std::vector<float> &out)
+    {
+        if (static_cast<int64_t>(codes.size()) < static_cast<int64_t>(n) * ((dim_ + 1) / 2))
+            throw Error(VG_ERR_INVALID_ARG, "codes buffer too small");
+        if (static_cast<int>(out.size()) < n) throw Error(VG_ERR_INVALID_ARG, "output buffer too small");
+        check(vg_int4_l2_distance_batch(h_, query.data(), codes.data(), n, 0, out.data(), nullptr));
+    }
+    int BytesPerDimension() const override { return 0; }  // sub-byte (int4.go:167-169)
+
+private:
+    std::shared_ptr<Context> ctx_;
+    int dim_;
+    vg_int4 *h_ = nullptr;
+};
+
 }  // namespace quantization
 
 namespace kmeans {

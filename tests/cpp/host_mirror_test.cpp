@@ -146,6 +146,27 @@ int main()
         EXPECT(sq4.BytesPerDimension() == 1 && sq4.CompressionRatio() == 4.0);
     }
 
+    // ---- Int4Quantizer (int4_test.go) ------------------------------------------------------------
+    {
+        quantization::Int4Quantizer odd(ctx, 3);
+        odd.Train({{0.1f, 0.5f, 0.9f}});                                   // int4_test.go:50-66
+        auto enc = odd.Encode({0.1f, 0.5f, 0.9f});
+        EXPECT(enc.size() == 2 && (enc[1] & 0x0F) == 0);
+        auto dec = odd.Decode(enc);
+        EXPECT(dec.size() == 3 && std::fabs(dec[0] - 0.1f) <= 0.1f && std::fabs(dec[1] - 0.5f) <= 0.1f &&
+               std::fabs(dec[2] - 0.9f) <= 0.1f);
+        quantization::Int4Quantizer iq(ctx, 4);
+        iq.SetParams({0, 0, 0, 0}, {1, 1, 1, 1});
+        auto c = iq.Encode({0.0f, 1.0f, 0.5f, 2.0f});                      // 0, 15, round(7.5) = 8, clamp -> 15
+        EXPECT(c.size() == 2 && c[0] == 0x0F && c[1] == 0x8F);
+        const float d1 = iq.L2Distance({0.0f, 1.0f, 8.0f / 15.0f, 1.0f}, c);
+        std::vector<float> out(1);
+        iq.L2DistanceBatch({0.0f, 1.0f, 8.0f / 15.0f, 1.0f}, c, 1, out);
+        EXPECT(d1 < 1e-9f && out[0] < 1e-9f);
+        EXPECT(status_of([&] { iq.Encode(std::vector<float>(3)); }) == VG_ERR_DIM_MISMATCH);
+        EXPECT(iq.BytesPerDimension() == 0);
+    }
+
     // ---- kmeans (kmeans_test.go) --------------------------------------------------------------
     {
         std::normal_distribution<float> nd;
