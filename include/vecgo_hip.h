@@ -323,6 +323,24 @@ int32_t vg_int4_l2_distance_batch(vg_int4 *iq, const float *query, const uint8_t
  * vg_search_vamana kind 3.  The quantizer must outlive the index. */
 int32_t vg_index_set_int4_codes(vg_index *idx, vg_int4 *iq, const uint8_t *codes, void *stream);
 
+/* ---- graph construction: neighbour selection ---------------------- */
+/* Vamana robustPrune (diskann/writer.go:571-625) for n_nodes nodes at once.  cands[n_nodes*nc]
+ * holds, per node, the search results and the node's current neighbours (what the reference's
+ * `unique` map holds); VG_INVALID_ID entries, duplicates and the node itself are dropped.
+ * Candidates are visited by ascending (distance to the node, id) — the reference's order among
+ * equal distances is unspecified (map iteration + unstable sort) — and kept unless
+ * alpha * dist(candidate, kept) < dist(candidate, node) for some already kept one.
+ * out[n_nodes*r] (VG_INVALID_ID padded), counts[n_nodes].  nc <= 1024, r <= 256. */
+int32_t vg_robust_prune(vg_index *idx, const uint32_t *nodes, int64_t n_nodes, const uint32_t *cands,
+                        int32_t nc, int32_t r, float alpha, uint32_t *out, int32_t *counts, void *stream);
+/* HNSW selectNeighborsHeuristic (hnsw.go:1009-1106: applyHeuristic + fillUpNeighbors; all the
+ * candidates when there are at most m).  cand_ids / cand_dists[n_nodes*nc]: nearest first, with the
+ * distance to the source as the caller's queue held it; lists may end in VG_INVALID_ID.
+ * out[n_nodes*m], counts[n_nodes].  nc <= 1024, m <= 256. */
+int32_t vg_hnsw_select_neighbors(vg_index *idx, int64_t n_nodes, const uint32_t *cand_ids,
+                                 const float *cand_dists, int32_t nc, int32_t m, uint32_t *out,
+                                 int32_t *counts, void *stream);
+
 /* ---- on-disk segment images --------------------------------------- */
 enum { VG_QUANT_NONE = 0, VG_QUANT_PQ = 1, VG_QUANT_SQ8 = 3, VG_QUANT_RABITQ = 5, VG_QUANT_INT4 = 6 }; /* quantization.Type, types.go:6-14 */
 typedef struct vg_segment_info {

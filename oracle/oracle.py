@@ -122,6 +122,10 @@ _sig("vgo_int4_l2_precomputed", C.c_float, _f32p, _u8p, C.c_int64, _f32p)
 _sig("vgo_int4_train", None, _f32p, C.c_int64, C.c_int32, _f32p, _f32p)
 _sig("vgo_int4_encode", None, _f32p, C.c_int32, _f32p, _f32p, _u8p)
 _sig("vgo_int4_decode", None, _u8p, C.c_int32, _f32p, _f32p, _f32p)
+_sig("vgo_robust_prune", C.c_int32, _f32p, C.c_int64, C.c_int32, C.c_int32, C.c_uint32, _u32p, C.c_int32, C.c_int32,
+     C.c_float, _u32p)
+_sig("vgo_hnsw_select_neighbors", C.c_int32, _f32p, C.c_int64, C.c_int32, C.c_int32, _u32p, _f32p, C.c_int32,
+     C.c_int32, _u32p)
 _sig("vgo_rerank_f32", None, _f32p, C.c_int32, C.c_int32, _f32p, _u32p, C.c_int32, _f32p)
 _sig("vgo_hnsw_search", C.c_int32, C.POINTER(HnswGraph), _f32p, C.c_int32, C.c_int32, _u32p,
      _f32p, C.POINTER(SearchStats))
@@ -473,6 +477,25 @@ class Int4Quantizer:
             lib.vgo_int4_l2_batch(pq_, pc, self.dim, n, self.min.ctypes.data_as(_f32p),
                                   self.diff.ctypes.data_as(_f32p), out.ctypes.data_as(_f32p))
         return out
+
+
+# ---- construction-time neighbour selection -------------------------------------
+def robust_prune(base, dim, node, cands, r, alpha, metric=METRIC_L2):
+    b, pb = _f(base)
+    c = np.ascontiguousarray(cands, np.uint32)
+    out = np.empty(r, np.uint32)
+    k = lib.vgo_robust_prune(pb, b.size // dim, dim, metric, node, c.ctypes.data_as(_u32p), c.size, r,
+                             C.c_float(alpha), out.ctypes.data_as(_u32p))
+    return out[:k]
+
+
+def hnsw_select_neighbors(base, dim, cand_ids, cand_dists, m, metric=METRIC_L2):
+    b, pb = _f(base)
+    ci = np.ascontiguousarray(cand_ids, np.uint32); cd = np.ascontiguousarray(cand_dists, np.float32)
+    out = np.empty(m, np.uint32)
+    k = lib.vgo_hnsw_select_neighbors(pb, b.size // dim, dim, metric, ci.ctypes.data_as(_u32p),
+                                      cd.ctypes.data_as(_f32p), ci.size, m, out.ctypes.data_as(_u32p))
+    return out[:k]
 
 
 # ---- scans --------------------------------------------------------------------

@@ -1432,3 +1432,90 @@ void vgo_int4_decode(const uint8_t *code, int32_t dim, const float *min_val, con
         out[i] = b + min_val[i];
     }
 }
+
+/* ------------------------------------------------------------------ */
+/* construction-time neighbour selection         */
+/* ------------------------------------------------------------------ */
+static float provider_dist(const float *base, int32_t dim, int32_t metric, uint32_t a, uint32_t b)
+{
+    /* distance.Provider(metric) (distance.go:91-106): SquaredL2 or Dot */
+    const float *va = base + (int64_t)a * dim, *vb = base + (int64_t)b * dim;
+    return metric == VGO_METRIC_L2 ? vgo_l2_avx512(va, vb, dim) : vgo_dot_avx512(va, vb, dim);
+}
+
+/* diskann/writer.go:571-625 robustPrune.  `cands` is what the reference's `unique` map holds
+ * (search results + current neighbours); duplicates, the node itself, 0xFFFFFFFF and ids >= n are
+ * dropped here.  The reference sorts with slices.SortFunc on dist only, over a map iteration order
+ * (non-deterministic among equal distances): ties are ordered by id here.  Returns the number of
+ * selected ids written to out[0..r). */
+int32_t vgo_robust_prune(const float *base, int64_t n, int32_t dim, int32_t metric, uint32_t node,
+                         const uint32_t *cands, int32_t nc, int32_t r, float alpha, uint32_t *out)
+{
+    typedef struct { float d; uint32_t id; } dn;
+    dn *c = (dn *)malloc(sizeof(dn) * (size_t)(nc > 0 ? nc : 1));
+    int m = 0;
+    for (int i = 0; i < nc; i++) {
+        uint32_t id = cands[i];
+        if (id == 0xFFFFFFFFu || (int64_t)id >= n || id == node) continue;
+        int dup = 0;
+        for (int j = 0; j < m; j++)
+            if (c[j].id == id) { dup = 1; break; }
+        if (dup) continue;
+        c[m].id = id;
+        c[m].d = provider_dist(base, dim, metric, id, node); /* w.dist(w.vectors[id], nodeVec) */
+        m++;
+    }
+    for (int i = 1; i < m; i++) { /* ascending (dist, id) */
+        dn x = c[i];
+        int j = i - 1;
+        while (j >= 0 && (c[j].d > x.d || (c[j].d == x.d && c[j].id > x.id))) { c[j + 1] = c[j]; j--; }
+        c[j + 1] = x;
+    }
+    int sel = 0;
+    for (int i = 0; i < m && sel < r; i++) {
+        int diverse = 1;
+        for (int s = 0; s < sel; s++) {
+            float dcs = provider_dist(base, dim, metric, c[i].id, out[s]);
+            float lhs = alpha * dcs;
+            if (lhs < c[i].d) { diverse = 0; break; }
+        }
+        if (diverse) out[sel++] = c[i].id;
+    }
+    free(c);
+    return sel;
+}
+
+/* hnsw.go:1009-1106 selectNeighborsHeuristic: candidates (nearest first, with their distance to the
+ * source as the caller's queue held it) -> at most m neighbours: all of them if nc <= m; else the
+ * relative-neighbourhood heuristic (applyHeuristic: keep a candidate unless it is closer to an
+ * already kept one than to the source), then fillUpNeighbors in candidate order.  distanceFunc as
+ * hnsw wraps it: L2 -> SquaredL2, Cosine -> 0.5 * SquaredL2, Dot -> -Dot. */
+int32_t vgo_hnsw_select_neighbors(const float *base, int64_t n, int32_t dim, int32_t metric,
+                                  const uint32_t *cand_ids, const float *cand_dists, int32_t nc, int32_t m,
+                                  uint32_t *out)
+{
+    if (nc <= m) {
+        for (int i = 0; i < nc; i++) out[i] = cand_ids[i];
+        return nc;
+    }
+    int sel = 0;
+    for (int i = 0; i < nc && sel < m; i++) {
+        int good = 1;
+        const float *cv = base + (int64_t)cand_ids[i] * dim;
+        for (int s = 0; s < sel; s++) {
+            const float *rv = base + (int64_t)out[s] * dim;
+            float d = metric == VGO_METRIC_DOT ? -vgo_dot_avx512(cv, rv, dim) : vgo_l2_avx512(cv, rv, dim);
+            if (metric == VGO_METRIC_COSINE) d = 0.5f * d;
+            if (d < cand_dists[i]) { good = 0; break; }
+        }
+        if (good) out[sel++] = cand_ids[i];
+    }
+    for (int i = 0; i < nc && sel < m; i++) { /* fillUpNeighbors */
+        int found = 0;
+        for (int s = 0; s < sel; s++)
+            if (out[s] == cand_ids[i]) { found = 1; break; }
+        if (!found) out[sel++] = cand_ids[i];
+    }
+    (void)n;
+    return sel;
+}

@@ -199,6 +199,13 @@ void vgo_int4_train(const float *vectors, int64_t n, int32_t dim, float *min_val
 void vgo_int4_encode(const float *v, int32_t dim, const float *min_val, const float *diff, uint8_t *out);
 void vgo_int4_decode(const uint8_t *code, int32_t dim, const float *min_val, const float *diff, float *out);
 
+/* construction-time neighbour selection (diskann/writer.go:571-625, hnsw.go:1009-1106) */
+int32_t vgo_robust_prune(const float *base, int64_t n, int32_t dim, int32_t metric, uint32_t node,
+                         const uint32_t *cands, int32_t nc, int32_t r, float alpha, uint32_t *out);
+int32_t vgo_hnsw_select_neighbors(const float *base, int64_t n, int32_t dim, int32_t metric,
+                                  const uint32_t *cand_ids, const float *cand_dists, int32_t nc, int32_t m,
+                                  uint32_t *out);
+
 #ifdef __cplusplus
 }
 #endif

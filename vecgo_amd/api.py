@@ -719,6 +719,31 @@ class Index:
                                   _stream_ptr(stream)))
         return out
 
+    def robust_prune(self, nodes, cands, r, alpha=1.2, stream=None):
+        """Vamana robustPrune (diskann/writer.go:571-625) for a batch of nodes: cands is [n_nodes, nc]
+        uint32 (VG_INVALID_ID padded); returns (kept[n_nodes, r], counts[n_nodes])."""
+        nd = np.ascontiguousarray(nodes, np.uint32)
+        cd = np.ascontiguousarray(cands, np.uint32).reshape(nd.size, -1)
+        out = np.empty((nd.size, r), np.uint32); cnt = np.empty(nd.size, np.int32)
+        check(self._lib.vg_robust_prune(self._h, C.c_void_p(nd.ctypes.data), C.c_int64(nd.size),
+                                        C.c_void_p(cd.ctypes.data), C.c_int32(cd.shape[1]), C.c_int32(r),
+                                        C.c_float(alpha), C.c_void_p(out.ctypes.data), C.c_void_p(cnt.ctypes.data),
+                                        _stream_ptr(stream)))
+        return out, cnt
+
+    def hnsw_select_neighbors(self, cand_ids, cand_dists, m, stream=None):
+        """HNSW selectNeighborsHeuristic (hnsw.go:1009-1106) for a batch of nodes: cand_ids / cand_dists
+        are [n_nodes, nc], nearest first; returns (kept[n_nodes, m], counts[n_nodes])."""
+        ci = np.ascontiguousarray(cand_ids, np.uint32)
+        cdst = np.ascontiguousarray(cand_dists, np.float32)
+        nn, nc = ci.shape
+        out = np.empty((nn, m), np.uint32); cnt = np.empty(nn, np.int32)
+        check(self._lib.vg_hnsw_select_neighbors(self._h, C.c_int64(nn), C.c_void_p(ci.ctypes.data),
+                                                 C.c_void_p(cdst.ctypes.data), C.c_int32(nc), C.c_int32(m),
+                                                 C.c_void_p(out.ctypes.data), C.c_void_p(cnt.ctypes.data),
+                                                 _stream_ptr(stream)))
+        return out, cnt
+
     def score_candidates(self, queries, cand_ids, out=None, stream=None):
         nq = _rows(queries, self.dim)
         nc = (cand_ids.numel() if _is_torch(cand_ids) else np.asarray(cand_ids).size) // max(nq, 1)
