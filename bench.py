@@ -13,7 +13,8 @@ merge with the reference tie-break (vecgo_amd/sharded.py).
 
 One JSON line on rank 0; extra objects: `roofline` (dominant kernel of the timed region, HIP
 events from inside the library), `adc_scan` (PQ-ADC scan, BASELINE configs[3]: 10M x 96 B codes,
-HBM roofline), `rabitq_scan` (RaBitQ scan, configs[4] shape on one GPU: 10M x 100 B),
+HBM roofline), `rabitq_scan` (RaBitQ scan, configs[4] shape on one GPU: 10M x 100 B), `sq8_scan`,
+`flat_small_batch` (configs[1] below the MFMA regime),
 `hnsw_layer0` (configs[2]), `cpu_baseline` (the CPU oracle = port of the reference's AVX-512 path, timed on
 this host's cores on a bounded sample).
 """
@@ -217,6 +218,44 @@ def rabitq_scan_roofline(vg, ctx, stream, device):
            "bytes_per_launch": n * cb, "search_call_ms": e0.elapsed_time(e1) / reps,
            "qps_single_query_passes": 1e3 / (e0.elapsed_time(e1) / reps)}
     idx.close()
+    return res
+
+
+def sq8_scan_roofline(vg, ctx, stream, device):
+    """exhaustive SQ8 scan (flat/segment.go:517-604), 4M x 768 one-byte codes
+    = 3.07 GB per pass (the byte count of the fp32 1M x 768 corpus)."""
+    n = 4_000_000
+    g = torch.Generator(device=device)
+    g.manual_seed(17)
+    codes = torch.randint(0, 256, (n, DIM), dtype=torch.uint8, device=device, generator=g)
+    sq = vg.ScalarQuantizer(ctx, DIM)
+    sq.set_bounds(np.full(DIM, -4.0, np.float32), np.full(DIM, 4.0, np.float32))
+    idx = vg.Index(ctx, n, DIM)
+    idx.set_sq8_codes(sq, codes)
+    del codes
+    q = torch.randn((1, DIM), device=device)
+    out = (torch.empty((1, K), dtype=torch.int32, device=device), torch.empty((1, K), device=device))
+    for _ in range(3):
+        idx.search_sq8(q, K, out=out, stream=stream)
+    torch.cuda.synchronize()
+    ctx.profile_read("sq8_scan")
+    ctx.profile_enable(True)
+    reps = 10
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(stream)
+    for _ in range(reps):
+        idx.search_sq8(q, K, out=out, stream=stream)
+    e1.record(stream)
+    torch.cuda.synchronize()
+    launches, ms = ctx.profile_read("sq8_scan")
+    ctx.profile_enable(False)
+    kern_ms = ms / max(launches, 1)
+    achieved = n * DIM / (kern_ms * 1e-3) / 1e9
+    res = {"workload": "sq8_scan_4Mx768_k10_nq1", "bound": "hbm", "achieved": achieved, "peak": PEAK_HBM_GBS,
+           "unit": "GB/s", "frac": achieved / PEAK_HBM_GBS, "traffic": None, "kernel": "sq8_scan_kernel",
+           "kernel_ms": kern_ms, "bytes_per_launch": n * DIM, "search_call_ms": e0.elapsed_time(e1) / reps}
+    idx.close()
+    sq.close()
     return res
 
 
@@ -432,6 +471,7 @@ def main():
         del index
         out["adc_scan"] = adc_scan_roofline(vg, ctx, stream, device)
         out["rabitq_scan"] = rabitq_scan_roofline(vg, ctx, stream, device)
+        out["sq8_scan"] = sq8_scan_roofline(vg, ctx, stream, device)
     if world == 1 and not args.no_cpu_baseline:
         nsample = 2 * (os.cpu_count() or 1)
         out["cpu_baseline"] = cpu_baseline(rows.cpu().numpy(), queries[1][:nsample].cpu().numpy(), K)

@@ -201,3 +201,34 @@ def test_hnsw_layer0_1m_x_768(vg, ctx):
         assert np.array_equal(bits(hsc[i, :eid.size]), bits(esc)), i
         assert tuple(int(x) for x in stats[i][:3]) == \
                (est.nodes_visited, est.distance_computations, est.distance_short_circuits), i
+
+
+def test_sq8_scan_10m_x_768(vg, ctx):
+    """SURVEY.md §8f rank 3 at the config-4 row count: 10M x 768 SQ8 codes (7.7 GB), exhaustive scan."""
+    n, dim, nq, k = 10_000_000, 768, 3, 10
+    g = torch.Generator(device="cuda"); g.manual_seed(13)
+    codes = torch.randint(0, 256, (n, dim), dtype=torch.uint8, device="cuda", generator=g)
+    codes[6_000_123] = codes[42]
+    rng = np.random.default_rng(1)
+    mins = (rng.standard_normal(dim) - 4).astype(np.float32); maxs = (mins + 8 + rng.random(dim)).astype(np.float32)
+    sq = vg.ScalarQuantizer(ctx, dim); sq.set_bounds(mins, maxs)
+    idx = vg.Index(ctx, n, dim); idx.set_sq8_codes(sq, codes)
+    q = torch.randn(nq, dim, device="cuda", generator=g)
+    ids, sc = idx.search_sq8(q, k)
+    assert_ordered(ids, sc)
+    _, _, _, inv = sq.params()
+    hid = np_(ids).view(np.uint32).astype(np.int64); hq = q.cpu().numpy()
+    for i in range(nq):
+        rc = codes[torch.from_numpy(hid[i]).cuda()].cpu().numpy()
+        want = o.sq8u_l2_batch(hq[i], rc, mins, inv, dim)
+        assert np.array_equal(bits(np_(sc)[i]), bits(want)), i
+    half = n // 2
+    a = vg.Index(ctx, half, dim); a.set_sq8_codes(sq, codes[:half])
+    b = vg.Index(ctx, n - half, dim); b.set_sq8_codes(sq, codes[half:])
+    ia, sa = a.search_sq8(q, k); ib, sb = b.search_sq8(q, k)
+    off = torch.tensor([0, half], dtype=torch.int32, device="cuda")
+    mi, ms = vg.merge_topk(ctx, torch.stack((ia, ib)), torch.stack((sa, sb)), k, metric=0, id_offsets=off)
+    assert torch.equal(mi, ids) and torch.equal(ms.view(torch.int32), sc.view(torch.int32))
+    d = sq.l2_distance_batch(q[:1], codes[2_000_000:2_200_000])
+    better = torch.nonzero(d < float(np_(sc)[0, k - 1])).flatten() + 2_000_000
+    assert set(np_(better).tolist()) <= set(hid[0].tolist())
