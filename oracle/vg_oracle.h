@@ -12,8 +12,15 @@
  * accumulators, FMA, _mm512_reduce_add_ps tree) in scalar C, so results are
  * bit-identical to the clang-built reference objects (pinned by
  * tests/golden/ fixtures generated from those objects, see
- * tests/golden/make_golden.py, and cross-checked live against oracle/_ref
- * when that library is present).
+ * tests/golden/make_golden*.py, and cross-checked live against oracle/_ref
+ * when that library is present): L2 / Dot / batch / bounded / ADC / Hamming /
+ * SQ8 / INT4 kernels.  The parts of the reference written in Go (PQ, RaBitQ,
+ * ScalarQuantizer, Int4Quantizer, k-means, the heaps and search loops, the
+ * neighbour selections of the builders) cannot be compiled here; they are
+ * pinned by the reference tests' known answers (tests/golden/reference_kats.json,
+ * tests/test_oracle_*.py).  PARITY UNPINNED for whatever the reference leaves to
+ * an unseeded RNG or an unspecified order: trained codebooks, built graphs, the
+ * order of equal-distance candidates in robustPrune.
  *
  * Build: gcc/clang, -ffp-contract=off (every FMA below is an explicit
  * __builtin_fmaf; everything else is a separately rounded IEEE fp32 op).
