@@ -339,6 +339,77 @@ __global__ __launch_bounds__(256) void pq_encode_kernel(const float *__restrict_
     codes[i * m + sub] = static_cast<uint8_t>(best);
 }
 
+// Encode for sub-vector dims that are a multiple of 4 (8 at the BASELINE shape): the dequantised
+// centroid is read from LDS as float4 broadcasts (sd/4 reads instead of sd) and every thread scores
+// kEncRows rows against it, so the 256 x sd table walk is amortised over kEncRows rows.  Same
+// arithmetic as pq_encode_kernel: per dimension d = q - v, dd = d * d, sum = sum + dd, in order.
+constexpr int kEncRows = 4;
+template <int SD>
+__global__ __launch_bounds__(256) void pq_encode_vec_kernel(const float *__restrict__ vectors, int64_t n,
+                                                            int dim, int m, int k,
+                                                            const int8_t *__restrict__ codebooks,
+                                                            const float *__restrict__ scales,
+                                                            const float *__restrict__ offsets,
+                                                            uint8_t *__restrict__ codes)
+{
+    extern __shared__ float deq[];  // k*SD
+    const int sub = blockIdx.y;
+    const float scale = scales[sub], offset = offsets[sub];
+    for (int t = threadIdx.x; t < k * SD; t += blockDim.x) {
+        float v = static_cast<float>(codebooks[static_cast<int64_t>(sub) * k * SD + t]) * scale;
+        deq[t] = v + offset;
+    }
+    __syncthreads();
+    const int64_t i0 = (static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x) * kEncRows;
+    if (i0 >= n) return;
+    float q[kEncRows][SD];
+#pragma unroll
+    for (int r = 0; r < kEncRows; r++) {
+        const int64_t i = i0 + r < n ? i0 + r : n - 1;
+        const float4 *v4 = reinterpret_cast<const float4 *>(vectors + i * dim + static_cast<int64_t>(sub) * SD);
+#pragma unroll
+        for (int t = 0; t < SD / 4; t++) {
+            const float4 x = v4[t];
+            q[r][4 * t] = x.x; q[r][4 * t + 1] = x.y; q[r][4 * t + 2] = x.z; q[r][4 * t + 3] = x.w;
+        }
+    }
+    int best[kEncRows];
+    float bd[kEncRows];
+#pragma unroll
+    for (int r = 0; r < kEncRows; r++) {
+        best[r] = 0;
+        bd[r] = 3.40282346638528859811704183484516925440e+38f;
+    }
+    for (int c = 0; c < k; c++) {
+        float cv[SD];
+        const float4 *c4 = reinterpret_cast<const float4 *>(deq + c * SD);
+#pragma unroll
+        for (int t = 0; t < SD / 4; t++) {
+            const float4 x = c4[t];
+            cv[4 * t] = x.x; cv[4 * t + 1] = x.y; cv[4 * t + 2] = x.z; cv[4 * t + 3] = x.w;
+        }
+#pragma unroll
+        for (int r = 0; r < kEncRows; r++) {
+            float sum = 0.0f;
+#pragma unroll
+            for (int t = 0; t < SD; t++) {
+                const float d = q[r][t] - cv[t];
+                const float dd = d * d;
+                sum = sum + dd;
+            }
+            // FindNearestCentroidInt8 (kernels.go:376-396): centroid 0 seeds the minimum whatever its
+            // distance is (NaN included), later ones need a strict '<'
+            if (c == 0 || sum < bd[r]) {
+                bd[r] = sum;
+                best[r] = c;
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < kEncRows; r++)
+        if (i0 + r < n) codes[(i0 + r) * m + sub] = static_cast<uint8_t>(best[r]);
+}
+
 __global__ void pq_decode_kernel(const uint8_t *__restrict__ codes, int64_t n, int dim, int m, int sd,
                                  int k, const int8_t *__restrict__ codebooks,
                                  const float *__restrict__ scales, const float *__restrict__ offsets,
@@ -452,9 +523,21 @@ VG_API int32_t vg_pq_encode(vg_pq *pq, const float *vectors, int64_t n, uint8_t 
     const size_t lds = static_cast<size_t>(pq->k) * pq->subdim * sizeof(float);
     VG_CHECK(lds <= 64 * 1024, VG_ERR_UNSUPPORTED, "vg_pq_encode: codebook of one sub-quantizer exceeds 64 KiB");
     // grid.y = m <= 65535 is guaranteed by dim limits; grid.x up to 2^31
-    VG_LAUNCH(vg::pq_encode_kernel, dim3(static_cast<unsigned>((n + 255) / 256), pq->m), dim3(256),
-                       lds, st, v.ptr, n, pq->dim, pq->m, pq->subdim, pq->k, pq->d_codebooks, pq->d_scales,
-                       pq->d_offsets, c.ptr);
+    const bool vec_ok = pq->dim % 4 == 0 && (reinterpret_cast<uintptr_t>(v.ptr) & 15) == 0;
+    const unsigned gx_vec = static_cast<unsigned>((n + 256 * vg::kEncRows - 1) / (256 * vg::kEncRows));
+    if (vec_ok && pq->subdim == 8)
+        VG_LAUNCH(vg::pq_encode_vec_kernel<8>, dim3(gx_vec, pq->m), dim3(256), lds, st, v.ptr, n, pq->dim, pq->m, pq->k,
+                  pq->d_codebooks, pq->d_scales, pq->d_offsets, c.ptr);
+    else if (vec_ok && pq->subdim == 4)
+        VG_LAUNCH(vg::pq_encode_vec_kernel<4>, dim3(gx_vec, pq->m), dim3(256), lds, st, v.ptr, n, pq->dim, pq->m, pq->k,
+                  pq->d_codebooks, pq->d_scales, pq->d_offsets, c.ptr);
+    else if (vec_ok && pq->subdim == 16)
+        VG_LAUNCH(vg::pq_encode_vec_kernel<16>, dim3(gx_vec, pq->m), dim3(256), lds, st, v.ptr, n, pq->dim, pq->m,
+                  pq->k, pq->d_codebooks, pq->d_scales, pq->d_offsets, c.ptr);
+    else
+        VG_LAUNCH(vg::pq_encode_kernel, dim3(static_cast<unsigned>((n + 255) / 256), pq->m), dim3(256),
+                  lds, st, v.ptr, n, pq->dim, pq->m, pq->subdim, pq->k, pq->d_codebooks, pq->d_scales,
+                  pq->d_offsets, c.ptr);
     VG_TRY(c.finish());
     if (c.on_host()) VG_HIP(hipStreamSynchronize(st));
     return VG_OK;
