@@ -67,36 +67,122 @@ __device__ inline float l2_deq_thread(const float *q, const float *v, int n)
     return sum;
 }
 
+// ---- training layout: the sub-vectors of one sub-quantizer made contiguous ([m][n][sd]) so that
+// every training kernel streams its own slab instead of 32-byte slices of 3 KiB rows ----------
+__global__ void pq_slab_kernel(const float *__restrict__ vectors, int64_t n, int dim, int sd, int sub0,
+                               float *__restrict__ slabs)
+{
+    const int ls = blockIdx.y;
+    const int64_t e = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (e >= n * sd) return;
+    const int64_t i = e / sd;
+    const int j = static_cast<int>(e % sd);
+    slabs[static_cast<int64_t>(ls) * n * sd + e] = vectors[i * dim + static_cast<int64_t>(sub0 + ls) * sd + j];
+}
+
+// squaredL2Avx512 of a slab row against a centroid in LDS.  SD in {4, 8, 16}: the row comes in as
+// float4 loads and the whole distance is the FMA-contracted scalar tail (n < 64); SD == 0 is the
+// generic path.
+template <int SD>
+__device__ __forceinline__ float l2_train(const float *__restrict__ row, const float *cen, int sd)
+{
+    if constexpr (SD == 0) {
+        return l2_avx512_thread(row, cen, sd);
+    } else {
+        float total = 0.0f;
+#pragma unroll
+        for (int t = 0; t < SD / 4; t++) {
+            const float4 x = reinterpret_cast<const float4 *>(row)[t];
+            const float4 c = reinterpret_cast<const float4 *>(cen)[t];
+            float d = x.x - c.x;
+            total = __builtin_fmaf(d, d, total);
+            d = x.y - c.y;
+            total = __builtin_fmaf(d, d, total);
+            d = x.z - c.z;
+            total = __builtin_fmaf(d, d, total);
+            d = x.w - c.w;
+            total = __builtin_fmaf(d, d, total);
+        }
+        return total;
+    }
+}
+
 // ---- k-means++ (pq.go:281-338): one workgroup per sub-quantizer -----------------------------
+// The reference keeps minDistSq[] and, per new centroid, (1) updates it, (2) adds it up
+// sequentially, (3) walks the same running sum again until it passes rand*sum.  (2) is a chain of
+// n dependent fp32 adds that cannot be reordered, so it sets the pace: wave 0 runs the chain over
+// one LDS chunk while waves 1-3 compute the distances of the next chunk into the other buffer.
+// The chain records its value every kPPBlock elements; since the terms are non-negative the
+// running sum is monotone, so (3) becomes "first recorded prefix that is not below the target"
+// plus a rescan of that one block from the previous prefix — the same adds, the same index.
 constexpr int kPPThreads = 256;
 constexpr int kPPChunk = 4096;
+constexpr int kPPBlock = 64;
 
-__global__ __launch_bounds__(kPPThreads) void pq_kmeanspp_kernel(
-    const float *__restrict__ vectors, int64_t n, int dim, int sd, int k, uint64_t seed,
-    float *__restrict__ mind_all, float *__restrict__ cent_all, int sub0)
+__device__ __forceinline__ void pp_load_half(float4 (&x)[kPPBlock / 8], const float *src)
 {
-    __shared__ float chunk[kPPChunk];
-    __shared__ float cur[256];  // current centroid (sd <= 256)
+#pragma unroll
+    for (int u = 0; u < kPPBlock / 8; u++) x[u] = reinterpret_cast<const float4 *>(src)[u];
+}
+__device__ __forceinline__ float pp_add_half(float sum, const float4 (&x)[kPPBlock / 8])
+{
+#pragma unroll
+    for (int u = 0; u < kPPBlock / 8; u++) {
+        sum += x[u].x;
+        sum += x[u].y;
+        sum += x[u].z;
+        sum += x[u].w;
+    }
+    return sum;
+}
+
+template <int SD>
+__device__ __forceinline__ void pp_distances(const float *__restrict__ slab, const float *cur, int sd,
+                                             float *__restrict__ mind, float *buf, int64_t c0, int len,
+                                             bool first_centroid, int t0, int nthreads)
+{
+    for (int t = t0; t < len; t += nthreads) {
+        const int64_t i = c0 + t;
+        const float d = l2_train<SD>(slab + i * sd, cur, sd);
+        float mv = d;
+        if (!first_centroid) {
+            const float old = mind[i];
+            mv = d < old ? d : old;
+        }
+        mind[i] = mv;
+        buf[t] = mv;
+    }
+}
+
+template <int SD>
+__global__ __launch_bounds__(kPPThreads) void pq_kmeanspp_kernel(
+    const float *__restrict__ slabs, int64_t n, int sd_rt, int k, uint64_t seed,
+    float *__restrict__ mind_all, float *__restrict__ pref_all, float *__restrict__ cent_all, int sub0)
+{
+    __shared__ __attribute__((aligned(16))) float buf[2][kPPChunk];
+    __shared__ __attribute__((aligned(16))) float cur[256];  // current centroid (sd <= 256)
     __shared__ float s_sum;
-    __shared__ float s_cum;
+    __shared__ int s_blk;
     __shared__ long long s_chosen;
-    // sub = the sub-quantizer (global index: column offset and RNG stream); ls = its slot in the
-    // scratch arrays of this call, which may train only the range [sub0, sub0 + gridDim.x)
+    // sub = the sub-quantizer (global index: RNG stream); ls = its slot in the scratch arrays of
+    // this call, which may train only the range [sub0, sub0 + gridDim.x)
+    const int sd = SD ? SD : sd_rt;
     const int ls = blockIdx.x, sub = sub0 + ls;
     const int tid = threadIdx.x;
-    const float *base = vectors + static_cast<int64_t>(sub) * sd;
+    const int64_t nblk = (n + kPPBlock - 1) / kPPBlock;
+    const float *slab = slabs + static_cast<int64_t>(ls) * n * sd;
     float *mind = mind_all + static_cast<int64_t>(ls) * n;
+    float *pref = pref_all + static_cast<int64_t>(ls) * nblk;
     float *cent = cent_all + static_cast<int64_t>(ls) * k * sd;
 
     if (n < k) {  // pq.go:285-291
-        for (int t = tid; t < k * sd; t += kPPThreads)
-            cent[t] = base[static_cast<int64_t>((t / sd) % n) * dim + (t % sd)];
+        for (int t = tid; t < k * sd; t += kPPThreads) cent[t] = slab[static_cast<int64_t>((t / sd) % n) * sd + (t % sd)];
         return;
     }
     uint64_t ctr = 0;
     long long first = static_cast<long long>(rng_u64(seed, sub, 1, ctr++) % static_cast<uint64_t>(n));
     for (int t = tid; t < sd; t += kPPThreads) {
-        cur[t] = base[first * dim + t];
+        cur[t] = slab[first * sd + t];
         cent[t] = cur[t];
     }
     __syncthreads();
@@ -109,41 +195,48 @@ __global__ __launch_bounds__(kPPThreads) void pq_kmeanspp_kernel(
                 ctr++;
                 __syncthreads();
                 const long long ch = s_chosen;
-                for (int t = tid; t < sd; t += kPPThreads) cent[c * sd + t] = base[ch * dim + t];
+                for (int t = tid; t < sd; t += kPPThreads) cent[c * sd + t] = slab[ch * sd + t];
                 __syncthreads();
                 continue;
             }
             const float target = rng_f32(rng_u64(seed, sub, 1, ctr)) * sum;
             ctr++;
             if (tid == 0) {
-                s_cum = 0.0f;
+                s_blk = 0x7fffffff;
                 s_chosen = -1;
             }
             __syncthreads();
-            // sequential cumsum (pq.go:315-323), staged through LDS chunk by chunk
-            for (int64_t c0 = 0; c0 < n; c0 += kPPChunk) {
-                if (s_chosen >= 0) break;
-                const int len = static_cast<int>(n - c0 < kPPChunk ? n - c0 : kPPChunk);
-                for (int t = tid; t < len; t += kPPThreads) chunk[t] = mind[c0 + t];
+            // pq.go:315-323 walks cum += minDistSq[i] until cum >= target.  `!(prefix < target)` also
+            // stops at a NaN prefix: from there on the reference never hits either.
+            for (int64_t b = tid; b < nblk; b += kPPThreads)
+                if (!(pref[b] < target)) {
+                    atomicMin(&s_blk, static_cast<int>(b));
+                    break;
+                }
+            __syncthreads();
+            const int blk = s_blk;
+            if (blk != 0x7fffffff) {
+                const int64_t e0 = static_cast<int64_t>(blk) * kPPBlock;
+                const int len = static_cast<int>(n - e0 < kPPBlock ? n - e0 : kPPBlock);
+                if (tid < len) buf[0][tid] = mind[e0 + tid];
                 __syncthreads();
                 if (tid == 0) {
-                    float cum = s_cum;
+                    float cum = blk ? pref[blk - 1] : 0.0f;
                     long long ch = -1;
                     for (int t = 0; t < len; t++) {
-                        cum += chunk[t];
+                        cum += buf[0][t];
                         if (cum >= target) {
-                            ch = c0 + t;
+                            ch = e0 + t;
                             break;
                         }
                     }
-                    s_cum = cum;
                     s_chosen = ch;
                 }
                 __syncthreads();
             }
             const long long ch = s_chosen >= 0 ? s_chosen : 0;  // pq.go:317 `chosen := 0`
             for (int t = tid; t < sd; t += kPPThreads) {
-                cur[t] = base[ch * dim + t];
+                cur[t] = slab[ch * sd + t];
                 cent[c * sd + t] = cur[t];
             }
             __syncthreads();
@@ -153,49 +246,66 @@ __global__ __launch_bounds__(kPPThreads) void pq_kmeanspp_kernel(
             // never read again, skip the pass
             break;
         }
-        // update minDistSq with the new centroid, then the sequential running sum
-        if (tid == 0) s_sum = 0.0f;
+        // update minDistSq with the new centroid and add it up in index order
+        {
+            const int len0 = static_cast<int>(n < kPPChunk ? n : kPPChunk);
+            pp_distances<SD>(slab, cur, sd, mind, buf[0], 0, len0, c == 0, tid, kPPThreads);
+        }
         __syncthreads();
-        for (int64_t c0 = 0; c0 < n; c0 += kPPChunk) {
+        float sum = 0.0f;  // live in wave 0 only
+        int pb = 0;
+        for (int64_t c0 = 0; c0 < n; c0 += kPPChunk, pb ^= 1) {
             const int len = static_cast<int>(n - c0 < kPPChunk ? n - c0 : kPPChunk);
-            for (int t = tid; t < len; t += kPPThreads) {
-                const float d = l2_avx512_thread(base + (c0 + t) * dim, cur, sd);
-                float mv = d;
-                if (c >= 1) {
-                    const float old = mind[c0 + t];
-                    mv = d < old ? d : old;
+            if (tid < 64) {
+                const float *src = buf[pb];
+                float *pr = pref + c0 / kPPBlock;
+                const int full = len / kPPBlock;
+                // two register images of half a block each: the LDS reads of one half are in
+                // flight while the dependent adds of the other issue back to back (at most 16
+                // reads outstanding, the limit of lgkmcnt)
+                float4 xa[kPPBlock / 8], xb[kPPBlock / 8];
+                if (full > 0) pp_load_half(xa, src);
+                for (int g = 0; g < full; g++) {
+                    pp_load_half(xb, src + g * kPPBlock + kPPBlock / 2);
+                    __builtin_amdgcn_sched_barrier(0);
+                    sum = pp_add_half(sum, xa);
+                    pp_load_half(xa, src + (g + 1 < full ? g + 1 : g) * kPPBlock);  // last one unused
+                    __builtin_amdgcn_sched_barrier(0);
+                    sum = pp_add_half(sum, xb);
+                    if (tid == 0) pr[g] = sum;
                 }
-                mind[c0 + t] = mv;
-                chunk[t] = mv;
-            }
-            __syncthreads();
-            if (tid == 0) {
-                float sum = s_sum;
-                for (int t = 0; t < len; t++) sum += chunk[t];
-                s_sum = sum;
+                if (len % kPPBlock) {
+                    for (int t = full * kPPBlock; t < len; t++) sum += src[t];
+                    if (tid == 0) pr[full] = sum;
+                }
+            } else if (c0 + kPPChunk < n) {
+                const int64_t n0 = c0 + kPPChunk;
+                const int nlen = static_cast<int>(n - n0 < kPPChunk ? n - n0 : kPPChunk);
+                pp_distances<SD>(slab, cur, sd, mind, buf[pb ^ 1], n0, nlen, c == 0, tid - 64, kPPThreads - 64);
             }
             __syncthreads();
         }
+        if (tid == 0) s_sum = sum;
+        __syncthreads();
     }
 }
 
 // ---- Lloyd assignment (pq.go:353-386, :416-433): thread per (point, sub-quantizer) ----------
-__global__ __launch_bounds__(256) void pq_assign_kernel(const float *__restrict__ vectors, int64_t n,
-                                                        int dim, int sd, int k,
-                                                        const float *__restrict__ cent_all,
+__global__ __launch_bounds__(256) void pq_assign_kernel(const float *__restrict__ slabs, int64_t n, int sd,
+                                                        int k, const float *__restrict__ cent_all,
                                                         int32_t *__restrict__ assign_all,
                                                         int *__restrict__ changed,
-                                                        const int *__restrict__ done, int sub0)
+                                                        const int *__restrict__ done)
 {
     extern __shared__ float cent[];  // k*sd
-    const int ls = blockIdx.y, sub = sub0 + ls;
+    const int ls = blockIdx.y;
     if (done[ls]) return;
     for (int t = threadIdx.x; t < k * sd; t += blockDim.x)
         cent[t] = cent_all[static_cast<int64_t>(ls) * k * sd + t];
     __syncthreads();
     const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const float *v = vectors + i * dim + static_cast<int64_t>(sub) * sd;
+    const float *v = slabs + (static_cast<int64_t>(ls) * n + i) * sd;
     float best = 3.40282346638528859811704183484516925440e+38f;
     int bi = 0;
     for (int c = 0; c < k; c++) {
@@ -212,11 +322,163 @@ __global__ __launch_bounds__(256) void pq_assign_kernel(const float *__restrict_
     }
 }
 
-// ---- Lloyd update (pq.go:388-414): thread per (sub-quantizer, cluster, coordinate); the sum
-// runs over the points in index order exactly like the reference's single loop ----------------
-__global__ __launch_bounds__(256) void pq_update_kernel(const float *__restrict__ vectors, int64_t n,
-                                                        int dim, int sd, int k, int iter, uint64_t seed,
-                                                        const int32_t *__restrict__ assign_all,
+// The same for sub-vector dims 4 / 8 / 16: rows in registers (kAssignRows per thread), centroids as
+// float4 LDS broadcasts.  Distances are the n < 64 form of squaredL2Avx512: one FMA chain.
+constexpr int kAssignRows = 4;
+typedef float float2v __attribute__((ext_vector_type(2)));
+template <int SD>
+__global__ __launch_bounds__(256) void pq_assign_vec_kernel(const float *__restrict__ slabs, int64_t n, int k,
+                                                            const float *__restrict__ cent_all,
+                                                            int32_t *__restrict__ assign_all,
+                                                            int *__restrict__ changed,
+                                                            const int *__restrict__ done)
+{
+    extern __shared__ float cent[];  // k*SD
+    const int ls = blockIdx.y;
+    if (done[ls]) return;
+    for (int t = threadIdx.x; t < k * SD; t += blockDim.x)
+        cent[t] = cent_all[static_cast<int64_t>(ls) * k * SD + t];
+    __syncthreads();
+    const int64_t i0 = (static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x) * kAssignRows;
+    if (i0 >= n) return;
+    // rows go in pairs through the packed fp32 ALU ops (v_pk_add_f32 / v_pk_fma_f32): each half is the
+    // IEEE op of its own row, so the per-row FMA chain is unchanged
+    static_assert(kAssignRows % 2 == 0, "rows are processed in pairs");
+    float2v q[kAssignRows / 2][SD];
+#pragma unroll
+    for (int r = 0; r < kAssignRows; r++) {
+        const int64_t i = i0 + r < n ? i0 + r : n - 1;
+        const float4 *v4 = reinterpret_cast<const float4 *>(slabs + (static_cast<int64_t>(ls) * n + i) * SD);
+#pragma unroll
+        for (int t = 0; t < SD / 4; t++) {
+            const float4 x = v4[t];
+            q[r / 2][4 * t][r & 1] = x.x;
+            q[r / 2][4 * t + 1][r & 1] = x.y;
+            q[r / 2][4 * t + 2][r & 1] = x.z;
+            q[r / 2][4 * t + 3][r & 1] = x.w;
+        }
+    }
+    int bi[kAssignRows];
+    float best[kAssignRows];
+#pragma unroll
+    for (int r = 0; r < kAssignRows; r++) {
+        bi[r] = 0;
+        best[r] = 3.40282346638528859811704183484516925440e+38f;
+    }
+    for (int c = 0; c < k; c++) {
+        float cv[SD];
+        const float4 *c4 = reinterpret_cast<const float4 *>(cent + c * SD);
+#pragma unroll
+        for (int t = 0; t < SD / 4; t++) {
+            const float4 x = c4[t];
+            cv[4 * t] = x.x; cv[4 * t + 1] = x.y; cv[4 * t + 2] = x.z; cv[4 * t + 3] = x.w;
+        }
+#pragma unroll
+        for (int rp = 0; rp < kAssignRows / 2; rp++) {
+            float2v total = {0.0f, 0.0f};
+#pragma unroll
+            for (int t = 0; t < SD; t++) {
+                const float2v cc = {cv[t], cv[t]};
+                const float2v d = q[rp][t] - cc;
+                total = __builtin_elementwise_fma(d, d, total);
+            }
+#pragma unroll
+            for (int h = 0; h < 2; h++)
+                if (total[h] < best[2 * rp + h]) {
+                    best[2 * rp + h] = total[h];
+                    bi[2 * rp + h] = c;
+                }
+        }
+    }
+    bool any = false;
+#pragma unroll
+    for (int r = 0; r < kAssignRows; r++)
+        if (i0 + r < n) {
+            int32_t *a = assign_all + static_cast<int64_t>(ls) * n + i0 + r;
+            if (*a != bi[r]) {
+                *a = bi[r];
+                any = true;
+            }
+        }
+    if (any) changed[ls] = 1;
+}
+
+// ---- Lloyd update (pq.go:388-414).  The reference sums every cluster's points in index order in a
+// single pass; the same order comes out of a stable counting sort of the point ids by cluster
+// (one workgroup per sub-quantizer) followed by one thread per (cluster, coordinate) walking its
+// own segment ----
+constexpr int kBucketThreads = 256;
+
+__global__ __launch_bounds__(kBucketThreads) void pq_bucket_kernel(int64_t n, int k,
+                                                                  const int32_t *__restrict__ assign_all,
+                                                                  int32_t *__restrict__ order_all,
+                                                                  int32_t *__restrict__ seg_all,
+                                                                  const int *__restrict__ changed,
+                                                                  const int *__restrict__ done)
+{
+    const int ls = blockIdx.x, t = threadIdx.x;
+    if (done[ls] || !changed[ls]) return;
+    static_assert(kBucketThreads == 256, "one thread per cluster id in the base update");
+    __shared__ int32_t cnt[256];
+    __shared__ int32_t base[256];
+    __shared__ int32_t wcnt[kBucketThreads / 64][256];  // per wave: members of each cluster in this chunk
+    const int32_t *assign = assign_all + static_cast<int64_t>(ls) * n;
+    int32_t *order = order_all + static_cast<int64_t>(ls) * n;
+    int32_t *seg = seg_all + static_cast<int64_t>(ls) * 2 * k;
+    const int w = t >> 6, lane = t & 63;
+    cnt[t] = 0;
+    for (int u = 0; u < kBucketThreads / 64; u++) wcnt[u][t] = 0;
+    __syncthreads();
+    for (int64_t i = t; i < n; i += kBucketThreads) atomicAdd(&cnt[assign[i]], 1);
+    __syncthreads();
+    if (t == 0) {
+        int32_t run = 0;
+        for (int c = 0; c < k; c++) {
+            base[c] = run;
+            seg[2 * c] = run;
+            seg[2 * c + 1] = cnt[c];
+            run += cnt[c];
+        }
+    }
+    __syncthreads();
+    for (int64_t i0 = 0; i0 < n; i0 += kBucketThreads) {
+        const int64_t i = i0 + t;
+        const bool active = i < n;
+        const int32_t key = active ? assign[i] : 0;
+        // lanes of this wave holding the same cluster id (ids < 256: eight ballots)
+        uint64_t peers = __ballot(active);
+#pragma unroll
+        for (int bit = 0; bit < 8; bit++) {
+            const bool set = (key >> bit) & 1;
+            const uint64_t bb = __ballot(set);
+            peers &= set ? bb : ~bb;
+        }
+        const int rank_w = __popcll(peers & ((1ull << lane) - 1ull));
+        if (active && rank_w == 0) wcnt[w][key] = __popcll(peers);
+        __syncthreads();
+        if (active) {
+            int r = rank_w;  // stable: earlier waves of the chunk first, then earlier lanes
+            for (int u = 0; u < w; u++) r += wcnt[u][key];
+            order[base[key] + r] = static_cast<int32_t>(i);
+        }
+        __syncthreads();
+        {
+            int32_t add = 0;
+#pragma unroll
+            for (int u = 0; u < kBucketThreads / 64; u++) {
+                add += wcnt[u][t];
+                wcnt[u][t] = 0;
+            }
+            base[t] += add;
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void pq_update_kernel(const float *__restrict__ slabs, int64_t n,
+                                                        int sd, int k, int iter, uint64_t seed,
+                                                        const int32_t *__restrict__ order_all,
+                                                        const int32_t *__restrict__ seg_all,
                                                         float *__restrict__ cent_all,
                                                         const int *__restrict__ changed,
                                                         const int *__restrict__ done, int sub0)
@@ -226,23 +488,19 @@ __global__ __launch_bounds__(256) void pq_update_kernel(const float *__restrict_
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= k * sd) return;
     const int c = t / sd, j = t % sd;
-    const int32_t *assign = assign_all + static_cast<int64_t>(ls) * n;
-    const float *col = vectors + static_cast<int64_t>(sub) * sd + j;
+    const int32_t *order = order_all + static_cast<int64_t>(ls) * n;
+    const int32_t *seg = seg_all + static_cast<int64_t>(ls) * 2 * k;
+    const float *col = slabs + static_cast<int64_t>(ls) * n * sd + j;
+    const int32_t start = seg[2 * c], count = seg[2 * c + 1];
     float sum = 0.0f;
-    int64_t count = 0;
-    for (int64_t i = 0; i < n; i++) {
-        if (assign[i] == c) {
-            sum += col[i * dim];
-            count++;
-        }
-    }
+    for (int32_t p = 0; p < count; p++) sum += col[static_cast<int64_t>(order[start + p]) * sd];
     float *dst = cent_all + (static_cast<int64_t>(ls) * k + c) * sd + j;
     if (count > 0) {
         *dst = sum / static_cast<float>(count);
     } else {  // pq.go:408-411 re-seed an empty cluster with a random vector
         const int64_t idx = static_cast<int64_t>(rng_u64(seed, sub, 2 + static_cast<uint64_t>(iter), c) %
                                                  static_cast<uint64_t>(n));
-        *dst = col[idx * dim];
+        *dst = col[idx * sd];
     }
 }
 
@@ -362,7 +620,10 @@ __global__ __launch_bounds__(256) void pq_encode_vec_kernel(const float *__restr
     __syncthreads();
     const int64_t i0 = (static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x) * kEncRows;
     if (i0 >= n) return;
-    float q[kEncRows][SD];
+    // rows in pairs through the packed fp32 ops (v_pk_add_f32 / v_pk_mul_f32), each half the IEEE op
+    // of its own row
+    static_assert(kEncRows % 2 == 0, "rows are processed in pairs");
+    float2v q[kEncRows / 2][SD];
 #pragma unroll
     for (int r = 0; r < kEncRows; r++) {
         const int64_t i = i0 + r < n ? i0 + r : n - 1;
@@ -370,7 +631,10 @@ __global__ __launch_bounds__(256) void pq_encode_vec_kernel(const float *__restr
 #pragma unroll
         for (int t = 0; t < SD / 4; t++) {
             const float4 x = v4[t];
-            q[r][4 * t] = x.x; q[r][4 * t + 1] = x.y; q[r][4 * t + 2] = x.z; q[r][4 * t + 3] = x.w;
+            q[r / 2][4 * t][r & 1] = x.x;
+            q[r / 2][4 * t + 1][r & 1] = x.y;
+            q[r / 2][4 * t + 2][r & 1] = x.z;
+            q[r / 2][4 * t + 3][r & 1] = x.w;
         }
     }
     int best[kEncRows];
@@ -389,20 +653,23 @@ __global__ __launch_bounds__(256) void pq_encode_vec_kernel(const float *__restr
             cv[4 * t] = x.x; cv[4 * t + 1] = x.y; cv[4 * t + 2] = x.z; cv[4 * t + 3] = x.w;
         }
 #pragma unroll
-        for (int r = 0; r < kEncRows; r++) {
-            float sum = 0.0f;
+        for (int rp = 0; rp < kEncRows / 2; rp++) {
+            float2v sum = {0.0f, 0.0f};
 #pragma unroll
             for (int t = 0; t < SD; t++) {
-                const float d = q[r][t] - cv[t];
-                const float dd = d * d;
+                const float2v cc = {cv[t], cv[t]};
+                const float2v d = q[rp][t] - cc;
+                const float2v dd = d * d;
                 sum = sum + dd;
             }
             // FindNearestCentroidInt8 (kernels.go:376-396): centroid 0 seeds the minimum whatever its
             // distance is (NaN included), later ones need a strict '<'
-            if (c == 0 || sum < bd[r]) {
-                bd[r] = sum;
-                best[r] = c;
-            }
+#pragma unroll
+            for (int h = 0; h < 2; h++)
+                if (c == 0 || sum[h] < bd[2 * rp + h]) {
+                    bd[2 * rp + h] = sum[h];
+                    best[2 * rp + h] = c;
+                }
         }
     }
 #pragma unroll
@@ -459,6 +726,7 @@ VG_API int32_t vg_pq_train_subset(vg_pq *pq, const float *vectors, int64_t n, in
     VG_CHECK(pq, VG_ERR_INVALID_ARG, "vg_pq_train: NULL quantizer");
     VG_CHECK(n > 0 && vectors, VG_ERR_INVALID_ARG, "no vectors provided for training");  // pq.go:69-71
     VG_CHECK(iters >= 0, VG_ERR_INVALID_ARG, "vg_pq_train: iters < 0");
+    VG_CHECK(n <= INT32_MAX, VG_ERR_UNSUPPORTED, "vg_pq_train: more than 2^31-1 training vectors");
     VG_CHECK(sub_begin >= 0 && sub_count >= 0 && sub_begin + sub_count <= pq->m, VG_ERR_INVALID_ARG,
              "vg_pq_train_subset: sub-quantizer range [%d, %d) outside [0, %d)", sub_begin, sub_begin + sub_count,
              pq->m);
@@ -469,30 +737,56 @@ VG_API int32_t vg_pq_train_subset(vg_pq *pq, const float *vectors, int64_t n, in
     const int m = sub_count, k = pq->k, sd = pq->subdim, dim = pq->dim;
     vg::DevIn<float> v;
     VG_TRY(v.init(vectors, static_cast<size_t>(n) * dim, st));
-    vg::DevTmp<float> mind, cent;
-    vg::DevTmp<int32_t> assign;
+    vg::DevTmp<float> mind, cent, slabs, pref;
+    vg::DevTmp<int32_t> assign, order, seg;
     vg::DevTmp<int> flags;
+    const size_t nblk = static_cast<size_t>((n + vg::kPPBlock - 1) / vg::kPPBlock);
+    VG_TRY(slabs.init(static_cast<size_t>(m) * n * sd, st));
     VG_TRY(mind.init(static_cast<size_t>(m) * n, st));
+    VG_TRY(pref.init(static_cast<size_t>(m) * nblk, st));
     VG_TRY(cent.init(static_cast<size_t>(m) * k * sd, st));
     VG_TRY(assign.init(static_cast<size_t>(m) * n, st));
+    VG_TRY(order.init(static_cast<size_t>(m) * n, st));
+    VG_TRY(seg.init(static_cast<size_t>(m) * 2 * k, st));
     VG_TRY(flags.init(static_cast<size_t>(2 * m), st));
     VG_HIP(hipMemsetAsync(assign.ptr, 0, sizeof(int32_t) * static_cast<size_t>(m) * n, st));
     VG_HIP(hipMemsetAsync(flags.ptr, 0, sizeof(int) * 2 * m, st));
     int *changed = flags.ptr, *done = flags.ptr + m;
 
-    VG_LAUNCH(vg::pq_kmeanspp_kernel, dim3(m), dim3(vg::kPPThreads), 0, st, v.ptr, n, dim, sd,
-                       k, seed, mind.ptr, cent.ptr, sub_begin);
+    VG_LAUNCH(vg::pq_slab_kernel, dim3(static_cast<unsigned>((n * sd + 255) / 256), m), dim3(256), 0, st, v.ptr, n, dim,
+              sd, sub_begin, slabs.ptr);
     const size_t lds = static_cast<size_t>(k) * sd * sizeof(float);
     VG_CHECK(lds <= 64 * 1024, VG_ERR_UNSUPPORTED, "vg_pq_train: codebook of one sub-quantizer exceeds 64 KiB");
     const unsigned gx = static_cast<unsigned>((n + 255) / 256);
+    const unsigned gx_vec = static_cast<unsigned>((n + 256 * vg::kAssignRows - 1) / (256 * vg::kAssignRows));
     const unsigned ux = static_cast<unsigned>((k * sd + 255) / 256);
-    for (int it = 0; it < iters; it++) {
-        VG_LAUNCH(vg::pq_assign_kernel, dim3(gx, m), dim3(256), lds, st, v.ptr, n, dim, sd, k,
-                           cent.ptr, assign.ptr, changed, done, sub_begin);
-        VG_LAUNCH(vg::pq_update_kernel, dim3(ux, m), dim3(256), 0, st, v.ptr, n, dim, sd, k, it,
-                           seed, assign.ptr, cent.ptr, changed, done, sub_begin);
-        VG_LAUNCH(vg::pq_iter_end_kernel, dim3((m + 63) / 64), dim3(64), 0, st, m, changed, done);
-    }
+#define VG_PQ_TRAIN_SD(SD)                                                                                       \
+    do {                                                                                                         \
+        VG_LAUNCH(vg::pq_kmeanspp_kernel<SD>, dim3(m), dim3(vg::kPPThreads), 0, st, slabs.ptr, n, sd, k, seed,   \
+                  mind.ptr, pref.ptr, cent.ptr, sub_begin);                                                      \
+        for (int it = 0; it < iters; it++) {                                                                     \
+            if (SD)                                                                                              \
+                VG_LAUNCH(vg::pq_assign_vec_kernel<(SD ? SD : 4)>, dim3(gx_vec, m), dim3(256), lds, st, slabs.ptr, n, k, \
+                          cent.ptr, assign.ptr, changed, done);                                                  \
+            else                                                                                                 \
+                VG_LAUNCH(vg::pq_assign_kernel, dim3(gx, m), dim3(256), lds, st, slabs.ptr, n, sd, k, cent.ptr,  \
+                          assign.ptr, changed, done);                                                            \
+            VG_LAUNCH(vg::pq_bucket_kernel, dim3(m), dim3(vg::kBucketThreads), 0, st, n, k, assign.ptr,          \
+                      order.ptr, seg.ptr, changed, done);                                                        \
+            VG_LAUNCH(vg::pq_update_kernel, dim3(ux, m), dim3(256), 0, st, slabs.ptr, n, sd, k, it, seed,        \
+                      order.ptr, seg.ptr, cent.ptr, changed, done, sub_begin);                                   \
+            VG_LAUNCH(vg::pq_iter_end_kernel, dim3((m + 63) / 64), dim3(64), 0, st, m, changed, done);           \
+        }                                                                                                        \
+    } while (0)
+    if (sd == 8)
+        VG_PQ_TRAIN_SD(8);
+    else if (sd == 4)
+        VG_PQ_TRAIN_SD(4);
+    else if (sd == 16)
+        VG_PQ_TRAIN_SD(16);
+    else
+        VG_PQ_TRAIN_SD(0);
+#undef VG_PQ_TRAIN_SD
     VG_LAUNCH(vg::pq_quantize_kernel, dim3(m), dim3(256), 0, st, cent.ptr, k, sd,
                        pq->d_codebooks, pq->d_scales, pq->d_offsets, sub_begin);
     VG_HIP(hipStreamSynchronize(st));
