@@ -27,7 +27,12 @@ def ctx(vg):
 
 @pytest.mark.parametrize("n,dim,k,metric,iters", [(400, 16, 8, 0, 10), (1000, 128, 12, 0, 10),
                                                   (300, 100, 5, 0, 6), (500, 64, 7, 2, 10),
-                                                  (500, 768, 4, 1, 5), (64, 8, 64, 0, 3)])
+                                                  (500, 768, 4, 1, 5), (64, 8, 64, 0, 3),
+                                                  # several 2048-point parts of the member sort, ragged centroid tile,
+                                                  # odd n for the two-rows-per-group assignment
+                                                  (5001, 128, 37, 0, 4), (4500, 1024, 9, 2, 3), (2500, 64, 130, 0, 3),
+                                                  # more clusters than LDS counters: the walk-all member kernels
+                                                  (6000, 8, 5000, 0, 2)])
 def test_kmeans_train_matches_oracle(vg, ctx, n, dim, k, metric, iters):
     rng = np.random.default_rng(n + dim + k)
     x = rng.standard_normal((n, dim)).astype(np.float32)

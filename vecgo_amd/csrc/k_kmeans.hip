@@ -71,8 +71,222 @@ __global__ void km_count_kernel(const int32_t *__restrict__ assign, int64_t n, i
     counts[c] = cnt;
 }
 
+// ---- the same assignment with the point rows held in registers (dim = 64 * NBLK <= 1024) ----
+// A 16-lane group owns kKmRows points (16 float4 per lane and point); the centroids go through LDS
+// kKmTile at a time and every LDS read serves all of the group's points.  With dim % 64 == 0 the
+// batch kernel has no 16-wide tail, so the order is the 4x16 accumulators + reduce_add tree of
+// vg_exact.hpp; the two halves of a float4 go through the packed fp32 ops, each lane the IEEE op of
+// its own accumulator chain.
+constexpr int kKmRows = 2;
+constexpr int kKmTile = 8;
+typedef float km_f2 __attribute__((ext_vector_type(2)));
+typedef float km_f4 __attribute__((ext_vector_type(4)));  // whole-register copies (HIP's float4 is a union struct)
+
+template <int DIM, int STAGE>
+__device__ __forceinline__ void km_fetch_tile(km_f4 (&stage)[STAGE], const float *__restrict__ centroids, int c0, int k,
+                                              int tid)
+{
+    const int cnt4 = (k - c0 < kKmTile ? k - c0 : kKmTile) * (DIM / 4);
+    const km_f4 *src = reinterpret_cast<const km_f4 *>(centroids + static_cast<int64_t>(c0) * DIM);
+#pragma unroll
+    for (int u = 0; u < STAGE; u++) {
+        const int t = tid + u * 256;
+        stage[u] = src[t < cnt4 ? t : cnt4 - 1];
+    }
+}
+
+template <bool DOT, int NBLK>
+__global__ __launch_bounds__(256) void km_assign_regs_kernel(const float *__restrict__ vectors, int64_t n,
+                                                             const float *__restrict__ centroids, int k,
+                                                             int32_t *__restrict__ assign, int *__restrict__ changed)
+{
+    constexpr int dim = NBLK * 64;
+    __shared__ __attribute__((aligned(16))) float ctile[kKmTile * dim];
+    const int tid = threadIdx.x;
+    const Sub16 sub = Sub16::make(tid);
+    const int64_t i0 = (static_cast<int64_t>(blockIdx.x) * 16 + (tid >> 4)) * kKmRows;
+    float4 rr[kKmRows][NBLK];
+#pragma unroll
+    for (int p = 0; p < kKmRows; p++) {
+        const int64_t i = i0 + p < n ? i0 + p : n - 1;
+        const float4 *r4 = reinterpret_cast<const float4 *>(vectors + i * dim) + sub.f4;
+#pragma unroll
+        for (int e = 0; e < NBLK; e++) rr[p][e] = r4[e * 16];
+    }
+    float bd[kKmRows];
+    int best[kKmRows];
+#pragma unroll
+    for (int p = 0; p < kKmRows; p++) {
+        bd[p] = 0.0f;
+        best[p] = 0;
+    }
+    constexpr int tile4 = kKmTile * dim / 4;         // float4 per full tile
+    constexpr int kStage = (tile4 + 255) / 256;      // ... and per thread
+    // the next tile travels through registers while the current one is scored; a ragged last tile
+    // re-reads its final float4 instead of branching (those slots are never scored)
+    km_f4 stage[kStage];
+    km_fetch_tile<dim, kStage>(stage, centroids, 0, k, tid);
+    for (int c0 = 0; c0 < k; c0 += kKmTile) {
+        __syncthreads();  // the previous tile is no longer read
+#pragma unroll
+        for (int u = 0; u < kStage; u++) {
+            const int t = tid + u * 256;
+            if (tile4 % 256 == 0 || t < tile4) reinterpret_cast<km_f4 *>(ctile)[t] = stage[u];
+        }
+        __syncthreads();
+        km_fetch_tile<dim, kStage>(stage, centroids, c0 + kKmTile < k ? c0 + kKmTile : c0, k, tid);  // last: unused
+        const int cnt = k - c0 < kKmTile ? k - c0 : kKmTile;
+        for (int cc = 0; cc < cnt; cc++) {
+            const float4 *q4 = reinterpret_cast<const float4 *>(ctile + cc * dim) + sub.f4;
+            km_f2 acc[kKmRows][2];
+#pragma unroll
+            for (int p = 0; p < kKmRows; p++) {
+                acc[p][0] = km_f2{0.0f, 0.0f};
+                acc[p][1] = km_f2{0.0f, 0.0f};
+            }
+            // the centroid's NBLK float4 are requested together (one LDS round trip per centroid
+            // instead of one per 64-float block)
+            float4 av4[NBLK];
+#pragma unroll
+            for (int e = 0; e < NBLK; e++) av4[e] = q4[e * 16];
+#pragma unroll
+            for (int e = 0; e < NBLK; e++) {
+                const float4 a = av4[e];
+                const km_f2 alo = {a.x, a.y}, ahi = {a.z, a.w};
+#pragma unroll
+                for (int p = 0; p < kKmRows; p++) {
+                    const km_f2 blo = {rr[p][e].x, rr[p][e].y}, bhi = {rr[p][e].z, rr[p][e].w};
+                    if (DOT) {
+                        acc[p][0] = __builtin_elementwise_fma(alo, blo, acc[p][0]);
+                        acc[p][1] = __builtin_elementwise_fma(ahi, bhi, acc[p][1]);
+                    } else {
+                        const km_f2 dlo = alo - blo, dhi = ahi - bhi;
+                        acc[p][0] = __builtin_elementwise_fma(dlo, dlo, acc[p][0]);
+                        acc[p][1] = __builtin_elementwise_fma(dhi, dhi, acc[p][1]);
+                    }
+                }
+            }
+            const int c = c0 + cc;
+#pragma unroll
+            for (int p = 0; p < kKmRows; p++) {
+                const float av[4] = {acc[p][0].x, acc[p][0].y, acc[p][1].x, acc[p][1].y};
+                float b[4];
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    const float h = dpp_partner_add<kDppRowHalfMirror>(av[t]);
+                    const float s2 = dpp_partner_add<kDppRowMirror>(h);
+                    const float x2 = dpp_partner_add<kDppQuadXor2>(s2);
+                    b[t] = dpp_partner_add<kDppQuadXor1>(x2);
+                }
+                const float total = (b[0] + b[2]) + (b[1] + b[3]);
+                if (c == 0 || (DOT ? (total > bd[p]) : (total < bd[p]))) {
+                    bd[p] = total;
+                    best[p] = c;
+                }
+            }
+        }
+    }
+    if ((tid & 15) == 0) {
+#pragma unroll
+        for (int p = 0; p < kKmRows; p++)
+            if (i0 + p < n) {
+                if (changed && assign[i0 + p] != best[p]) *changed = 1;
+                assign[i0 + p] = best[p];
+            }
+    }
+}
+
+// ---- member lists in index order: a stable counting sort of the point ids by cluster ----------
+// Parts of kKmPartRows consecutive points; (1) per-part histograms, (2) cluster totals, offsets and
+// every part's starting rank inside each cluster, (3) one wave per part places its points, ranks
+// inside a 64-point chunk from ballots over the bits of the cluster id.
+constexpr int kKmLdsK = 4096;       // clusters whose per-part counters fit LDS; above: the walk-all kernels
+constexpr int kKmPartRows = 2048;
+
+__global__ __launch_bounds__(256) void km_hist_kernel(const int32_t *__restrict__ assign, int64_t n, int k,
+                                                      int32_t *__restrict__ hist)
+{
+    __shared__ int32_t h[kKmLdsK];
+    const int part = blockIdx.x;
+    for (int c = threadIdx.x; c < k; c += 256) h[c] = 0;
+    __syncthreads();
+    const int64_t r0 = static_cast<int64_t>(part) * kKmPartRows;
+    const int64_t r1 = r0 + kKmPartRows < n ? r0 + kKmPartRows : n;
+    for (int64_t i = r0 + threadIdx.x; i < r1; i += 256) atomicAdd(&h[assign[i]], 1);
+    __syncthreads();
+    for (int c = threadIdx.x; c < k; c += 256) hist[static_cast<int64_t>(part) * k + c] = h[c];
+}
+
+// hist[part][c] becomes the number of cluster-c points in earlier parts; counts / offsets as the
+// update kernel wants them
+__global__ __launch_bounds__(256) void km_scan_kernel(int32_t *__restrict__ hist, int parts, int k,
+                                                      int64_t *__restrict__ counts, int64_t *__restrict__ offsets)
+{
+    __shared__ int64_t seg[256];
+    const int tid = threadIdx.x;
+    const int per = (k + 255) / 256;
+    const int cb = tid * per, ce = cb + per < k ? cb + per : k;
+    int64_t mine = 0;
+    for (int c = cb; c < ce; c++) {
+        int32_t run = 0;
+        for (int p = 0; p < parts; p++) {
+            const int32_t v = hist[static_cast<int64_t>(p) * k + c];
+            hist[static_cast<int64_t>(p) * k + c] = run;
+            run += v;
+        }
+        counts[c] = run;
+        mine += run;
+    }
+    seg[tid] = mine;
+    __syncthreads();
+    if (tid == 0) {
+        int64_t run = 0;
+        for (int t = 0; t < 256; t++) {
+            const int64_t v = seg[t];
+            seg[t] = run;
+            run += v;
+        }
+    }
+    __syncthreads();
+    int64_t run = seg[tid];
+    for (int c = cb; c < ce; c++) {
+        offsets[c] = run;
+        run += counts[c];
+    }
+}
+
+__global__ __launch_bounds__(64) void km_scatter_kernel(const int32_t *__restrict__ assign, int64_t n, int k, int kbits,
+                                                        const int32_t *__restrict__ hist,
+                                                        const int64_t *__restrict__ offsets,
+                                                        int64_t *__restrict__ members)
+{
+    __shared__ int32_t base[kKmLdsK];
+    const int part = blockIdx.x, lane = threadIdx.x;
+    for (int c = lane; c < k; c += 64) base[c] = hist[static_cast<int64_t>(part) * k + c];
+    __syncthreads();
+    const int64_t r0 = static_cast<int64_t>(part) * kKmPartRows;
+    const int64_t r1 = r0 + kKmPartRows < n ? r0 + kKmPartRows : n;
+    for (int64_t c0 = r0; c0 < r1; c0 += 64) {
+        const int64_t i = c0 + lane;
+        const bool active = i < r1;
+        const int32_t key = active ? assign[i] : 0;
+        uint64_t peers = __ballot(active);
+        for (int bit = 0; bit < kbits; bit++) {
+            const bool set = (key >> bit) & 1;
+            const uint64_t bb = __ballot(set);
+            peers &= set ? bb : ~bb;
+        }
+        const int rank = __popcll(peers & ((1ull << lane) - 1ull));
+        if (active) members[offsets[key] + base[key] + rank] = i;
+        __syncthreads();
+        if (active && rank == 0) base[key] += __popcll(peers);
+        __syncthreads();
+    }
+}
+
 // update (kmeans.go:107-135): per (cluster, coordinate) the sum runs over the members in index
 // order (= the reference's single loop over i), then sums * (1/count)
+constexpr int kKmAhead = 16;
 __global__ __launch_bounds__(256) void km_update_kernel(const float *__restrict__ vectors, int64_t n, int dim,
                                                         int k, int iter, uint64_t seed,
                                                         const int64_t *__restrict__ counts,
@@ -88,7 +302,16 @@ __global__ __launch_bounds__(256) void km_update_kernel(const float *__restrict_
     if (cnt > 0) {
         const int64_t *mem = members + offsets[c];
         float sum = 0.0f;
-        for (int64_t j = 0; j < cnt; j++) sum += vectors[mem[j] * dim + d];
+        int64_t j = 0;
+        // kKmAhead gathered loads in flight, added in member order
+        for (; j + kKmAhead <= cnt; j += kKmAhead) {
+            float x[kKmAhead];
+#pragma unroll
+            for (int u = 0; u < kKmAhead; u++) x[u] = vectors[mem[j + u] * dim + d];
+#pragma unroll
+            for (int u = 0; u < kKmAhead; u++) sum += x[u];
+        }
+        for (; j < cnt; j++) sum += vectors[mem[j] * dim + d];
         const float scale = 1.0f / static_cast<float>(cnt);
         *dst = sum * scale;
     } else {
@@ -145,6 +368,43 @@ __global__ void adc_lookup_batch_kernel(const float *__restrict__ table, const u
 
 }  // namespace vg
 
+// pick the register-resident assignment when the row shape allows it
+template <int NBLK>
+static int32_t km_launch_regs(bool dot, const float *v, int64_t n, const float *cent, int k, int32_t *assign, int *changed,
+                              hipStream_t st)
+{
+    const unsigned gx = static_cast<unsigned>((n + 16 * vg::kKmRows - 1) / (16 * vg::kKmRows));
+    if (dot)
+        VG_LAUNCH((vg::km_assign_regs_kernel<true, NBLK>), dim3(gx), dim3(256), 0, st, v, n, cent, k, assign, changed);
+    else
+        VG_LAUNCH((vg::km_assign_regs_kernel<false, NBLK>), dim3(gx), dim3(256), 0, st, v, n, cent, k, assign, changed);
+    return VG_OK;
+}
+
+static int32_t km_launch_assign(bool dot, const float *v, int64_t n, int dim, const float *cent, int k, int32_t *assign,
+                                int *changed, hipStream_t st)
+{
+    const bool aligned = (reinterpret_cast<uintptr_t>(v) & 15) == 0 && (reinterpret_cast<uintptr_t>(cent) & 15) == 0;
+    if (aligned) {
+        switch (dim) {
+        case 64: return km_launch_regs<1>(dot, v, n, cent, k, assign, changed, st);
+        case 128: return km_launch_regs<2>(dot, v, n, cent, k, assign, changed, st);
+        case 256: return km_launch_regs<4>(dot, v, n, cent, k, assign, changed, st);
+        case 384: return km_launch_regs<6>(dot, v, n, cent, k, assign, changed, st);
+        case 512: return km_launch_regs<8>(dot, v, n, cent, k, assign, changed, st);
+        case 768: return km_launch_regs<12>(dot, v, n, cent, k, assign, changed, st);
+        case 1024: return km_launch_regs<16>(dot, v, n, cent, k, assign, changed, st);
+        default: break;
+        }
+    }
+    const unsigned gx = static_cast<unsigned>((n + 15) / 16);
+    if (dot)
+        VG_LAUNCH(vg::km_assign_kernel<true>, dim3(gx), dim3(256), 0, st, v, n, dim, cent, k, assign, changed);
+    else
+        VG_LAUNCH(vg::km_assign_kernel<false>, dim3(gx), dim3(256), 0, st, v, n, dim, cent, k, assign, changed);
+    return VG_OK;
+}
+
 static bool km_metric_ok(int32_t metric) { return metric == VG_METRIC_L2 || metric == VG_METRIC_DOT || metric == VG_METRIC_COSINE; }
 
 VG_API int32_t vg_kmeans_assign(vg_ctx *ctx, const float *vectors, int64_t n, int32_t dim, const float *centroids,
@@ -162,13 +422,7 @@ VG_API int32_t vg_kmeans_assign(vg_ctx *ctx, const float *vectors, int64_t n, in
     VG_TRY(v.init(vectors, static_cast<size_t>(n) * dim, st));
     VG_TRY(c.init(centroids, static_cast<size_t>(k) * dim, st));
     VG_TRY(o.init(out, static_cast<size_t>(n), st));
-    const unsigned gx = static_cast<unsigned>((n + 15) / 16);
-    if (metric == VG_METRIC_L2)
-        VG_LAUNCH(vg::km_assign_kernel<false>, dim3(gx), dim3(256), 0, st, v.ptr, n, dim, c.ptr, k, o.ptr,
-                           static_cast<int *>(nullptr));
-    else
-        VG_LAUNCH(vg::km_assign_kernel<true>, dim3(gx), dim3(256), 0, st, v.ptr, n, dim, c.ptr, k, o.ptr,
-                           static_cast<int *>(nullptr));
+    VG_TRY(km_launch_assign(metric != VG_METRIC_L2, v.ptr, n, dim, c.ptr, k, o.ptr, nullptr, st));
     VG_TRY(o.finish());
     if (o.on_host()) VG_HIP(hipStreamSynchronize(st));
     return VG_OK;
@@ -212,34 +466,43 @@ VG_API int32_t vg_kmeans_train(vg_ctx *ctx, const float *vectors, int64_t n, int
     VG_LAUNCH(vg::km_gather_rows_kernel, dim3(static_cast<unsigned>((tot + 255) / 256)), dim3(256), 0, st,
                        v.ptr, dim, rows.ptr, k, cent.ptr);
     VG_HIP(hipMemsetAsync(assign.ptr, 0, sizeof(int32_t) * static_cast<size_t>(n), st));
-    std::vector<int64_t> hcounts(static_cast<size_t>(k)), hoff(static_cast<size_t>(k));
-    const unsigned gx = static_cast<unsigned>((n + 15) / 16);
     const unsigned kx = static_cast<unsigned>((k + 63) / 64);
+    const bool sorted = k <= vg::kKmLdsK;
+    const int parts = static_cast<int>((n + vg::kKmPartRows - 1) / vg::kKmPartRows);
+    int kbits = 0;
+    while ((1 << kbits) < k) kbits++;
+    vg::DevTmp<int32_t> hist;
+    if (sorted) VG_TRY(hist.init(static_cast<size_t>(parts) * k, st));
+    std::vector<int64_t> hcounts, hoff;
     for (int it = 0; it < max_iter; it++) {
         VG_HIP(hipMemsetAsync(changed.ptr, 0, sizeof(int), st));
-        if (metric == VG_METRIC_L2)
-            VG_LAUNCH(vg::km_assign_kernel<false>, dim3(gx), dim3(256), 0, st, v.ptr, n, dim, cent.ptr, k,
-                               assign.ptr, changed.ptr);
-        else
-            VG_LAUNCH(vg::km_assign_kernel<true>, dim3(gx), dim3(256), 0, st, v.ptr, n, dim, cent.ptr, k,
-                               assign.ptr, changed.ptr);
+        VG_TRY(km_launch_assign(metric != VG_METRIC_L2, v.ptr, n, dim, cent.ptr, k, assign.ptr, changed.ptr, st));
         int hchanged = 0;
         VG_HIP(hipMemcpyAsync(&hchanged, changed.ptr, sizeof(int), hipMemcpyDeviceToHost, st));
-        VG_LAUNCH(vg::km_count_kernel, dim3(kx), dim3(64), 0, st, assign.ptr, n, k, counts.ptr);
-        VG_HIP(hipMemcpyAsync(hcounts.data(), counts.ptr, sizeof(int64_t) * k, hipMemcpyDeviceToHost, st));
-        VG_HIP(hipStreamSynchronize(st));  // training is not a hot path: one sync per Lloyd iteration
+        VG_HIP(hipStreamSynchronize(st));  // one sync per Lloyd iteration: the convergence test is the host's
         if (!hchanged) break;               // kmeans.go:101-103
-        int64_t run = 0;
-        for (int c = 0; c < k; c++) {
-            hoff[static_cast<size_t>(c)] = run;
-            run += hcounts[static_cast<size_t>(c)];
+        if (sorted) {
+            VG_LAUNCH(vg::km_hist_kernel, dim3(parts), dim3(256), 0, st, assign.ptr, n, k, hist.ptr);
+            VG_LAUNCH(vg::km_scan_kernel, dim3(1), dim3(256), 0, st, hist.ptr, parts, k, counts.ptr, offsets.ptr);
+            VG_LAUNCH(vg::km_scatter_kernel, dim3(parts), dim3(64), 0, st, assign.ptr, n, k, kbits, hist.ptr, offsets.ptr,
+                      members.ptr);
+        } else {  // more clusters than LDS counters: every cluster walks the assignment array
+            hcounts.resize(static_cast<size_t>(k));
+            hoff.resize(static_cast<size_t>(k));
+            VG_LAUNCH(vg::km_count_kernel, dim3(kx), dim3(64), 0, st, assign.ptr, n, k, counts.ptr);
+            VG_HIP(hipMemcpyAsync(hcounts.data(), counts.ptr, sizeof(int64_t) * k, hipMemcpyDeviceToHost, st));
+            VG_HIP(hipStreamSynchronize(st));
+            int64_t run = 0;
+            for (int c = 0; c < k; c++) {
+                hoff[static_cast<size_t>(c)] = run;
+                run += hcounts[static_cast<size_t>(c)];
+            }
+            VG_HIP(hipMemcpyAsync(offsets.ptr, hoff.data(), sizeof(int64_t) * k, hipMemcpyHostToDevice, st));
+            VG_LAUNCH(vg::km_members_kernel, dim3(kx), dim3(64), 0, st, assign.ptr, n, k, offsets.ptr, members.ptr);
         }
-        VG_HIP(hipMemcpyAsync(offsets.ptr, hoff.data(), sizeof(int64_t) * k, hipMemcpyHostToDevice, st));
-        VG_LAUNCH(vg::km_members_kernel, dim3(kx), dim3(64), 0, st, assign.ptr, n, k, offsets.ptr,
-                           members.ptr);
         VG_LAUNCH(vg::km_update_kernel, dim3(static_cast<unsigned>((dim + 255) / 256), k), dim3(256), 0, st,
                            v.ptr, n, dim, k, it, seed, counts.ptr, offsets.ptr, members.ptr, cent.ptr);
-        VG_HIP(hipStreamSynchronize(st));  // hoff is reused next iteration
+        if (!sorted) VG_HIP(hipStreamSynchronize(st));  // hoff is reused next iteration
     }
     VG_TRY(cent.finish());
     VG_HIP(hipStreamSynchronize(st));
