@@ -20,6 +20,20 @@ def partition(n: int, world: int) -> list[int]:
     return [n * r // world for r in range(world + 1)]
 
 
+_OFFSETS = {}
+
+
+def _shard_offsets(bounds: Sequence[int], world: int, device):
+    """First global row of every shard as a device tensor, built once per (bounds, device): creating
+    it per search is a synchronous host-to-device copy that keeps the host from running ahead."""
+    key = (tuple(bounds[:world]), str(device))
+    off = _OFFSETS.get(key)
+    if off is None:
+        off = torch.tensor(list(bounds[:world]), dtype=torch.int32, device=device)
+        _OFFSETS[key] = off
+    return off
+
+
 def sharded_search(local_search: Callable, merge: Callable, queries, k: int, bounds: Sequence[int],
                    group=None):
     """local_search(queries, k) -> (ids[nq,k] int32 bit-pattern of uint32, LOCAL row ids;
@@ -28,8 +42,7 @@ def sharded_search(local_search: Callable, merge: Callable, queries, k: int, bou
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     ids, scores = local_search(queries, k)
     if world == 1:
-        off = torch.tensor([bounds[0]], dtype=torch.int32, device=ids.device)
-        return merge(ids.unsqueeze(0), scores.unsqueeze(0), k, off)
+        return merge(ids.unsqueeze(0), scores.unsqueeze(0), k, _shard_offsets(bounds, 1, ids.device))
     nq = ids.shape[0]
     # ONE collective per search: ids and the scores' bit patterns travel in the same int32 buffer
     # ([2, nq, k] per rank); gathered layout = concatenation along dim 0 (accepted by RCCL and gloo)
@@ -39,8 +52,7 @@ def sharded_search(local_search: Callable, merge: Callable, queries, k: int, bou
     gathered = gathered.view(world, 2, nq, k)
     all_ids = gathered[:, 0].contiguous().view(ids.dtype)
     all_scores = gathered[:, 1].contiguous().view(torch.float32)
-    off = torch.tensor(list(bounds[:-1]), dtype=torch.int32, device=ids.device)
-    return merge(all_ids, all_scores, k, off)
+    return merge(all_ids, all_scores, k, _shard_offsets(bounds, world, ids.device))
 
 
 class ShardedFlatIndex:
