@@ -363,8 +363,9 @@ int32_t vg_segment_open_flat(vg_ctx *ctx, const void *image, int64_t size, int32
                              vg_segment **out, void *stream);
 /* diskann segment (diskann/format.go:8-119, segment.go:165-440,1393-1408): fp32 rows, the
  * N x R uint32 graph and entry point, PQ codebooks + codes or RaBitQ codes; search with
- * or INT4 parameters + codes; search with vg_search_vamana (kind 0 / 1 / 2 / 3).  LZ4-compressed
- * vector blocks are not supported. */
+ * or INT4 parameters + codes; search with vg_search_vamana (kind 0 / 1 / 2 / 3).  The header's
+ * CompressionType byte is ignored exactly as segment.go ignores it: the reference writer records
+ * LZ4 there by default (writer.go:92) while writing every section raw (writer.go:697-740). */
 int32_t vg_segment_open_diskann(vg_ctx *ctx, const void *image, int64_t size, int32_t verify_checksum,
                                 vg_segment **out, void *stream);
 int32_t vg_segment_get_info(vg_segment *seg, vg_segment_info *info);

@@ -69,7 +69,7 @@ def write_flat(vectors, metric=0, segment_id=7, sq=None, pq=None, codes=None, ch
 
 
 def write_diskann(vectors, graph, entry, metric=0, segment_id=9, pq=None, pq_codes=None, rabitq_codes=None, int4=None,
-                  search_list=100, checksum=True, version=2, compression=0, qtype=None):
+                  search_list=100, checksum=True, version=2, compression=1, qtype=None):
     v = np.ascontiguousarray(vectors, np.float32)
     g = np.ascontiguousarray(graph, np.uint32)
     n, dim = v.shape

@@ -213,13 +213,14 @@ VG_API int32_t vg_segment_open_diskann(vg_ctx *ctx, const void *image, int64_t s
     const int qtype = data[37];  // quantization.Type (types.go:6-14): 1 PQ, 5 RaBitQ, 6 INT4
     h.pq_m = rd16(data + 38);
     h.pq_k = rd16(data + 40);
-    const int compression = version >= 2 ? data[42] : 0;
+    // data[42] = CompressionType (format.go:32).  The writer records its option there (LZ4 by default,
+    // writer.go:92,676) but streams every section raw (writer.go:697-740) and Open never consults the
+    // field (segment.go:165-440), so neither does this reader: a default reference segment has 1 here.
     const uint64_t vec_off = rd64(data + 48), graph_off = rd64(data + 56), pq_codes_off = rd64(data + 64),
                    bq_codes_off = rd64(data + 72), cb_off = rd64(data + 80), pk_off = rd64(data + 88);
     const uint32_t checksum = rd32(data + 120);
     SEG_CHECK(h.dim > 0, VG_ERR_FORMAT, "diskann segment: dimension 0");
     SEG_CHECK(h.metric <= VG_METRIC_DOT, VG_ERR_UNSUPPORTED, "diskann segment: metric %d has no float32 kernels", h.metric);
-    SEG_CHECK(compression == 0, VG_ERR_UNSUPPORTED, "diskann segment: LZ4-compressed vector blocks are not supported");
     if (verify_checksum) SEG_TRY(verify_body(data, len, kDiskHeader, checksum));
     const uint64_t n = static_cast<uint64_t>(h.rows), dim = static_cast<uint64_t>(h.dim);
     SEG_CHECK(len >= pk_off + n * 8, VG_ERR_FORMAT, "file size too small: expected at least %llu, got %llu",
