@@ -292,8 +292,9 @@ int32_t vg_sq8_l2_distance_batch(vg_sq8 *sq, const float *query, const uint8_t *
 /* codes[n*dim] in the reference's row-major layout (flat/segment.go s.codes); re-tiled on the
  * device for the scan.  The quantizer must outlive the index. */
 int32_t vg_index_set_sq8_codes(vg_index *idx, vg_sq8 *sq, const uint8_t *codes, void *stream);
-/* flat.Segment.Search, SQ8 branch (flat/segment.go:517-604, L2 only): L2DistanceBatch of every
- * row, best k by (Score, RowID).  k <= 64. */
+/* flat.Segment.Search, SQ8 branch: L2 segments score every row with L2DistanceBatch
+ * (flat/segment.go:517-604), Dot / Cosine segments with ScalarQuantizer.DotProduct (:659-667,
+ * quantizer.go:109-119: a sequential fp32 loop, largest first); best k by (Score, RowID).  k <= 64. */
 int32_t vg_search_sq8(vg_index *idx, const float *queries, int64_t nq, int32_t k, uint32_t *ids,
                       float *scores, void *stream);
 
@@ -341,6 +342,20 @@ int32_t vg_hnsw_select_neighbors(vg_index *idx, int64_t n_nodes, const uint32_t 
                                  const float *cand_dists, int32_t nc, int32_t m, uint32_t *out,
                                  int32_t *counts, void *stream);
 
+/* ---- IVF partitions of a flat segment (flat/segment.go:187-207, :727-749) ------------------- */
+/* centroids[num_partitions*dim] and part_offsets[num_partitions+1] (first row of every partition,
+ * non-decreasing, last <= rows) as the flat writer lays them out (rows grouped by partition).
+ * num_partitions == 0 removes them. */
+int32_t vg_index_set_partitions(vg_index *idx, const float *centroids, const uint32_t *part_offsets,
+                                int32_t num_partitions, void *stream);
+enum { VG_SCAN_F32 = 0, VG_SCAN_PQ = 1, VG_SCAN_SQ8 = 2 };
+/* The partition-probed scan of flat.Segment.Search: per query kmeans.FindClosestCentroids(nprobes)
+ * (kmeans.go:217-280; nprobes <= 0 means 1), then the chosen scan over those partitions' row ranges
+ * only, one top-k by (score, row id).  With at most one partition it is vg_search_flat /
+ * vg_search_pq_adc / vg_search_sq8.  k <= 64, nprobes <= 64. */
+int32_t vg_search_flat_probed(vg_index *idx, const float *queries, int64_t nq, int32_t k, int32_t nprobes,
+                              int32_t scan, uint32_t *ids, float *scores, void *stream);
+
 /* ---- on-disk segment images --------------------------------------- */
 enum { VG_QUANT_NONE = 0, VG_QUANT_PQ = 1, VG_QUANT_SQ8 = 3, VG_QUANT_RABITQ = 5, VG_QUANT_INT4 = 6 }; /* quantization.Type, types.go:6-14 */
 typedef struct vg_segment_info {
@@ -352,6 +367,7 @@ typedef struct vg_segment_info {
     int32_t pq_m, pq_k;
     int32_t max_degree, search_list_size; /* DiskANN R and L (diskann/format.go:26-27) */
     uint32_t entrypoint;
+    int32_t num_partitions; /* flat segment: IVF partitions (flat/format.go:37) */
 } vg_segment_info;
 /* flat.Open (flat/segment.go:105-300) over a whole segment file held in host memory (mmap or
  * read): header (flat/format.go:11-165), optional CRC32C of the body, SQ8 bounds / PQ codebooks,
@@ -361,6 +377,13 @@ typedef struct vg_segment_info {
  * version", "file too short for vectors", "checksum mismatch: ..."). */
 int32_t vg_segment_open_flat(vg_ctx *ctx, const void *image, int64_t size, int32_t verify_checksum,
                              vg_segment **out, void *stream);
+/* flat.Segment.Search (flat/segment.go:447-751, filter == nil) for a batch of queries: the scan type
+ * follows the segment (SQ8 codes: L2Distance / DotProduct by metric; PQ: table lookups, L2 segments
+ * only — see vg_segment.hip; else fp32 rows) and, when the segment has more than one IVF partition,
+ * only the nprobes closest partitions are scanned (:727-744; nprobes <= 0 means 1).  k <= 64 and
+ * nprobes <= 64 on the partitioned path. */
+int32_t vg_segment_search(vg_segment *seg, const float *queries, int64_t nq, int32_t k, int32_t nprobes,
+                          uint32_t *ids, float *scores, void *stream);
 /* diskann segment (diskann/format.go:8-119, segment.go:165-440,1393-1408): fp32 rows, the
  * N x R uint32 graph and entry point, PQ codebooks + codes or RaBitQ codes; search with
  * or INT4 parameters + codes; search with vg_search_vamana (kind 0 / 1 / 2 / 3).  The header's

@@ -61,6 +61,12 @@ class Vamana(C.Structure):
                 ("base", _f32p), ("pq", C.POINTER(PQ)), ("codes", _u8p), ("int4_table", _f32p)]
 
 
+class FlatSeg(C.Structure):
+    _fields_ = [("n", C.c_int64), ("dim", C.c_int32), ("metric", C.c_int32), ("base", _f32p),
+                ("pq", C.POINTER(PQ)), ("codes", _u8p), ("sq_mins", _f32p), ("sq_inv_scales", _f32p),
+                ("num_partitions", C.c_int32), ("centroids", _f32p), ("part_offsets", _u32p)]
+
+
 class SearchStats(C.Structure):
     _fields_ = [("nodes_visited", C.c_int64), ("distance_computations", C.c_int64),
                 ("distance_short_circuits", C.c_int64), ("pops", C.c_int64)]
@@ -115,6 +121,8 @@ _sig("vgo_sq8_train", None, _f32p, C.c_int64, C.c_int32, _f32p, _f32p, _f32p, _f
 _sig("vgo_sq8_encode", None, _f32p, C.c_int32, _f32p, _f32p, _f32p, _u8p)
 _sig("vgo_sq8_decode", None, _u8p, C.c_int32, _f32p, _f32p, _f32p)
 _sig("vgo_flat_search_sq8", C.c_int32, _u8p, C.c_int64, C.c_int32, _f32p, _f32p, _f32p, C.c_int32, _u32p, _f32p)
+_sig("vgo_sq8_dot", C.c_float, _f32p, _u8p, C.c_int32, _f32p, _f32p)
+_sig("vgo_flat_segment_search", C.c_int32, C.POINTER(FlatSeg), _f32p, C.c_int32, C.c_int32, _u32p, _f32p)
 _sig("vgo_int4_l2", C.c_float, _f32p, _u8p, C.c_int64, _f32p, _f32p)
 _sig("vgo_int4_l2_batch", None, _f32p, _u8p, C.c_int64, C.c_int64, _f32p, _f32p, _f32p)
 _sig("vgo_int4_build_lut", None, _f32p, _f32p, C.c_int32, _f32p)
@@ -593,6 +601,37 @@ class VamanaIndex:
         r = lib.vgo_vamana_search(C.byref(v), pq_, k, ids.ctypes.data_as(_u32p),
                                   sc.ctypes.data_as(_f32p), C.byref(st))
         return ids[:r], sc[:r], st
+
+
+class FlatSegment:
+    """flat.Segment.Search (flat/segment.go:447-751) over a whole flat segment: scan type by
+    quantization, IVF partitions (centroids [P, dim], part_offsets [P + 1]) probed when P > 1."""
+
+    def __init__(self, base, dim, metric=METRIC_L2, pq: "ProductQuantizer | None" = None, codes=None,
+                 sq: "ScalarQuantizer | None" = None, centroids=None, part_offsets=None):
+        self.base = np.ascontiguousarray(base, np.float32).reshape(-1, dim)
+        self.n, self.dim, self.metric = self.base.shape[0], dim, metric
+        self.pq, self.sq = pq, sq
+        self.codes = None if codes is None else np.ascontiguousarray(codes, np.uint8)
+        self.centroids = None if centroids is None else np.ascontiguousarray(centroids, np.float32).reshape(-1, dim)
+        self.part_offsets = None if part_offsets is None else np.ascontiguousarray(part_offsets, np.uint32)
+        self.num_partitions = 0 if self.centroids is None else self.centroids.shape[0]
+
+    def search(self, query, k, nprobes=0):
+        q, pq_ = _f(query)
+        ids = np.empty(max(k, 1), np.uint32); sc = np.empty(max(k, 1), np.float32)
+        pqc = self.pq._c() if self.pq is not None else None
+        seg = FlatSeg(self.n, self.dim, self.metric, self.base.ctypes.data_as(_f32p),
+                      C.pointer(pqc) if pqc is not None else None,
+                      self.codes.ctypes.data_as(_u8p) if self.codes is not None else None,
+                      self.sq.mins.ctypes.data_as(_f32p) if self.sq is not None else None,
+                      self.sq.inv_scales.ctypes.data_as(_f32p) if self.sq is not None else None,
+                      self.num_partitions,
+                      self.centroids.ctypes.data_as(_f32p) if self.centroids is not None else None,
+                      self.part_offsets.ctypes.data_as(_u32p) if self.part_offsets is not None else None)
+        r = lib.vgo_flat_segment_search(C.byref(seg), pq_, k, nprobes, ids.ctypes.data_as(_u32p),
+                                        sc.ctypes.data_as(_f32p))
+        return ids[:r], sc[:r]
 
 
 # ---- the compiled reference objects (only where oracle/_ref was built) -------

@@ -1285,6 +1285,83 @@ int32_t vgo_flat_search_sq8(const uint8_t *codes, int64_t n, int32_t dim, const 
     return r;
 }
 
+/* ScalarQuantizer.DotProduct — internal/quantization/quantizer.go:109-119: a scalar Go loop, no FMA
+ * on amd64: val = mins[i] + float32(code[i])*invScales[i]; dot += q[i]*val */
+float vgo_sq8_dot(const float *q, const uint8_t *code, int32_t dim, const float *mins, const float *inv_scales)
+{
+    float dot = 0.0f;
+    for (int32_t i = 0; i < dim; i++) {
+        float t = (float)code[i] * inv_scales[i];
+        float val = mins[i] + t;
+        float p = q[i] * val;
+        dot = dot + p;
+    }
+    return dot;
+}
+
+/* ------------------------------------------------------------------ */
+/* flat.Segment.Search with IVF partitions — flat/segment.go:447-751     */
+/* ------------------------------------------------------------------ */
+/* The scan type follows the segment's quantization (PQ table lookups :678-689, SQ8 batches for L2
+ * :517-604, fp32 otherwise :691-701); with more than one partition only the nprobes closest
+ * centroids' row ranges are scanned (:727-744, nprobes <= 0 -> 1), all into the same bounded heap.
+ * The heap's order is total (score, then row id), so the order of the probed partitions does not
+ * matter; only the probed SET does, and FindClosestCentroids' ties are measure-zero. */
+int32_t vgo_flat_segment_search(const vgo_flat_segment *s, const float *query, int32_t k, int32_t nprobes,
+                                uint32_t *ids, float *scores)
+{
+    /* segment.go:657-701: SQ8 codes first (L2Distance / DotProduct by metric), else PQ, else fp32.
+     * The reference's heap direction follows the metric for every branch (:449); for a Dot-metric PQ
+     * segment that keeps the k largest squared-L2 ADC distances — not restated: PQ is ascending here
+     * and the device entry point refuses that combination. */
+    const int use_sq = s->sq_mins != NULL;
+    const int use_pq = !use_sq && s->pq != NULL;
+    const int desc = s->metric != VGO_METRIC_L2 && !use_pq;
+    float *table = NULL;
+    if (use_pq) {
+        table = (float *)calloc((size_t)s->pq->m * 256, sizeof(float));
+        float *t = (float *)malloc(sizeof(float) * (size_t)s->pq->m * s->pq->k);
+        vgo_pq_build_table(s->pq, query, t);
+        for (int m = 0; m < s->pq->m; m++)
+            memcpy(table + (int64_t)m * 256, t + (int64_t)m * s->pq->k, sizeof(float) * s->pq->k);
+        free(t);
+    }
+    vgo_candheap h;
+    vgo_candheap_init(&h, k, desc);
+    int32_t np = 1;
+    int32_t *parts = NULL;
+    if (s->num_partitions > 1) {
+        if (nprobes <= 0) nprobes = 1;
+        parts = (int32_t *)malloc(sizeof(int32_t) * (size_t)s->num_partitions);
+        np = vgo_find_closest_centroids(query, s->centroids, s->dim, s->num_partitions, nprobes, s->metric, parts);
+    }
+    for (int32_t j = 0; j < np; j++) {
+        int64_t start = 0, end = s->n;
+        if (parts) {
+            start = s->part_offsets[parts[j]];
+            end = s->part_offsets[parts[j] + 1];
+        }
+        for (int64_t i = start; i < end; i++) {
+            float d;
+            if (use_pq)
+                d = vgo_adc_avx512(table, s->codes + i * s->pq->m, s->pq->m);
+            else if (use_sq)
+                d = s->metric == VGO_METRIC_L2
+                        ? sq8u_l2_one(query, s->codes + i * s->dim, s->sq_mins, s->sq_inv_scales, s->dim)
+                        : vgo_sq8_dot(query, s->codes + i * s->dim, s->dim, s->sq_mins, s->sq_inv_scales);
+            else
+                d = desc ? vgo_dot_avx512(query, s->base + i * s->dim, s->dim)
+                         : vgo_l2_avx512(query, s->base + i * s->dim, s->dim);
+            vgo_candheap_try_push_bounded(&h, (vgo_cand){0, (uint32_t)i, d}, k);
+        }
+    }
+    int32_t r = emit_sorted(&h, ids, scores);
+    vgo_candheap_free(&h);
+    free(parts);
+    free(table);
+    return r;
+}
+
 /* ------------------------------------------------------------------ */
 /* INT4                                          */
 /* ------------------------------------------------------------------ */

@@ -196,6 +196,24 @@ int32_t vgo_flat_search_sq8(const uint8_t *codes, int64_t n, int32_t dim, const 
                             const float *inv_scales, const float *query, int32_t k, uint32_t *ids,
                             float *scores);
 
+float vgo_sq8_dot(const float *q, const uint8_t *code, int32_t dim, const float *mins, const float *inv_scales);
+/* flat.Segment.Search (flat/segment.go:447-751) over a whole flat segment: scan type by quantization
+ * (sq_mins != NULL: SQ8 L2Distance / DotProduct by metric; else pq != NULL: ADC; else fp32), IVF partitions probed when
+ * num_partitions > 1 (:727-744). */
+typedef struct {
+    int64_t n;
+    int32_t dim, metric;
+    const float *base;          /* n*dim fp32 rows */
+    const vgo_pq *pq;           /* PQ segment: codes = n*m */
+    const uint8_t *codes;       /* PQ or SQ8 codes */
+    const float *sq_mins, *sq_inv_scales; /* SQ8 segment */
+    int32_t num_partitions;
+    const float *centroids;     /* num_partitions*dim */
+    const uint32_t *part_offsets; /* num_partitions+1 */
+} vgo_flat_segment;
+int32_t vgo_flat_segment_search(const vgo_flat_segment *s, const float *query, int32_t k, int32_t nprobes,
+                                uint32_t *ids, float *scores);
+
 /* INT4 (int4_avx512.c, int4.go, kernels.go:94-103) */
 float vgo_int4_l2(const float *query, const uint8_t *code, int64_t dim, const float *min_val, const float *diff);
 void vgo_int4_l2_batch(const float *query, const uint8_t *codes, int64_t dim, int64_t n, const float *min_val,

@@ -32,12 +32,19 @@ def _pad8(buf: bytearray):
 
 
 def write_flat(vectors, metric=0, segment_id=7, sq=None, pq=None, codes=None, checksum=True, magic=FLAT_MAGIC,
-               version=1):
-    """sq = (mins, maxs); pq = (m, k, scales, offsets, codebooks int8); codes uint8 [n, dim] or [n, m]."""
+               version=1, partitions=None):
+    """sq = (mins, maxs); pq = (m, k, scales, offsets, codebooks int8); codes uint8 [n, dim] or [n, m];
+    partitions = (centroids [P, dim] fp32, offsets [P + 1] uint32) with the rows already grouped by partition."""
     v = np.ascontiguousarray(vectors, np.float32)
     n, dim = v.shape
     body = bytearray()
     qtype = q_off = c_off = 0
+    nparts = cent_off = poff_off = 0
+    if partitions is not None:  # flat/writer.go: centroids, then the partition offsets
+        cent = np.ascontiguousarray(partitions[0], np.float32).reshape(-1, dim)
+        nparts = cent.shape[0]
+        cent_off = FLAT_HEADER + len(body); body += cent.tobytes(); _pad8(body)
+        poff_off = FLAT_HEADER + len(body); body += np.ascontiguousarray(partitions[1], np.uint32).tobytes(); _pad8(body)
     if sq is not None:
         qtype, q_off = 1, FLAT_HEADER + len(body)
         body += np.asarray(sq[0], np.float32).tobytes() + np.asarray(sq[1], np.float32).tobytes()
@@ -61,9 +68,9 @@ def write_flat(vectors, metric=0, segment_id=7, sq=None, pq=None, codes=None, ch
     h = bytearray(FLAT_HEADER)
     struct.pack_into("<IIQII", h, 0, magic, version, segment_id, n, dim)
     h[24] = metric
-    struct.pack_into("<I", h, 28, 0)       # NumPartitions
+    struct.pack_into("<I", h, 28, nparts)  # NumPartitions
     h[32] = qtype
-    struct.pack_into("<QQQQQQQQ", h, 40, 0, 0, q_off, c_off, v_off, pk_off, 0, 0)
+    struct.pack_into("<QQQQQQQQ", h, 40, cent_off, poff_off, q_off, c_off, v_off, pk_off, 0, 0)
     struct.pack_into("<I", h, 104, crc32c_py(bytes(body)) if checksum else 0)
     return bytes(h) + bytes(body)
 

@@ -1,0 +1,148 @@
+"""flat.Segment.Search over IVF partitions (flat/segment.go:727-749) on the GPU vs the oracle: the
+nprobes closest centroids' row ranges, scanned with the segment's scan type, ids and scores bit-exact."""
+import numpy as np
+import pytest
+
+from oracle import oracle as o
+from tests import segfile
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(x):
+    return np.asarray(x, np.float32).view(np.uint32)
+
+
+@pytest.fixture(scope="module")
+def vg():
+    import vecgo_amd
+    return vecgo_amd
+
+
+@pytest.fixture(scope="module")
+def ctx(vg):
+    return vg.Context(0)
+
+
+def partitioned(rng, n, dim, parts, metric=0, empty=()):
+    """Rows grouped by their closest centroid, the way flat/writer.go lays a partitioned segment out;
+    the partitions listed in `empty` get no rows (their rows go to the next one)."""
+    x = rng.standard_normal((n, dim)).astype(np.float32)
+    cent = (rng.standard_normal((parts, dim)) * 0.7).astype(np.float32)
+    a = np.array([o.assign_partition(x[i], cent, dim, metric) for i in range(n)], np.int64)
+    for e in empty:
+        a[a == e] = (e + 1) % parts
+    order = np.argsort(a, kind="stable")
+    x, a = x[order], a[order]
+    off = np.searchsorted(a, np.arange(parts + 1)).astype(np.uint32)
+    return x, cent, off
+
+
+def check(ids, sc, seg, q, k, nprobes):
+    for i in range(q.shape[0]):
+        eid, esc = seg.search(q[i], k, nprobes)
+        r = eid.size
+        assert np.array_equal(ids[i, :r], eid), (i, nprobes, ids[i], eid)
+        assert np.array_equal(bits(sc[i, :r]), bits(esc)), (i, nprobes)
+        assert np.all(ids[i, r:] == 0xFFFFFFFF)
+
+
+@pytest.mark.parametrize("n,dim,parts,metric", [(3000, 64, 7, 0), (2000, 100, 12, 2), (5000, 768, 5, 0),
+                                                (900, 24, 40, 1), (400, 8, 3, 0)])
+def test_probed_fp32_scan(vg, ctx, n, dim, parts, metric):
+    rng = np.random.default_rng(n + dim + parts)
+    x, cent, off = partitioned(rng, n, dim, parts, metric, empty=(1,) if parts > 4 else ())
+    idx = vg.Index(ctx, n, dim, vg.Metric(metric))
+    idx.set_vectors(x)
+    idx.set_partitions(cent, off)
+    seg = o.FlatSegment(x, dim, metric=metric, centroids=cent, part_offsets=off)
+    q = rng.standard_normal((9, dim)).astype(np.float32)
+    for nprobes, k in ((0, 10), (1, 1), (3, 10), (parts, 64), (parts + 5, 17)):
+        ids, sc = idx.search_flat_probed(q, k, nprobes, scan=idx.SCAN_F32)
+        check(ids, sc, seg, q, k, nprobes)
+    # every partition probed = the exhaustive search
+    ids, sc = idx.search_flat_probed(q, 10, parts, scan=idx.SCAN_F32)
+    fid, fsc = idx.search_flat(q, 10)
+    assert np.array_equal(ids, fid) and np.array_equal(bits(sc), bits(fsc))
+    idx.set_partitions(None, [])
+    ids, sc = idx.search_flat_probed(q, 10, 1, scan=idx.SCAN_F32)  # no partitions: one range, the whole segment
+    assert np.array_equal(ids, fid) and np.array_equal(bits(sc), bits(fsc))
+
+
+@pytest.mark.parametrize("n,dim,m,parts", [(4000, 64, 8, 9), (3000, 96, 96, 6), (1500, 40, 20, 4)])
+def test_probed_pq_scan(vg, ctx, n, dim, m, parts):
+    rng = np.random.default_rng(n + m)
+    x, cent, off = partitioned(rng, n, dim, parts)
+    pq = vg.ProductQuantizer(ctx, dim, m, 256)
+    pq.train(x, iters=4, seed=2)
+    codes = pq.encode(x)
+    cb, scales, offsets = pq.codebooks()
+    opq = o.ProductQuantizer(dim, m, 256); opq.set_codebooks(cb, scales, offsets)
+    idx = vg.Index(ctx, n, dim)
+    idx.set_pq_codes(pq, codes)
+    idx.set_partitions(cent, off)
+    seg = o.FlatSegment(x, dim, pq=opq, codes=codes, centroids=cent, part_offsets=off)
+    q = rng.standard_normal((6, dim)).astype(np.float32)
+    for nprobes, k in ((1, 10), (2, 64), (parts, 10)):
+        ids, sc = idx.search_flat_probed(q, k, nprobes, scan=idx.SCAN_PQ)
+        check(ids, sc, seg, q, k, nprobes)
+    many = rng.standard_normal((300, dim)).astype(np.float32)  # more queries than compute units: split = 1
+    ids, sc = idx.search_flat_probed(many, 10, 3, scan=idx.SCAN_PQ)
+    check(ids[:8], sc[:8], seg, many[:8], 10, 3)
+
+
+@pytest.mark.parametrize("n,dim,parts,metric", [(3000, 64, 6, 0), (2500, 100, 10, 0), (1200, 17, 4, 2)])
+def test_probed_sq8_scan(vg, ctx, n, dim, parts, metric):
+    rng = np.random.default_rng(n + dim)
+    x, cent, off = partitioned(rng, n, dim, parts, metric)
+    sq = vg.ScalarQuantizer(ctx, dim); sq.train(x)
+    ref = o.ScalarQuantizer(dim); ref.train(x)
+    codes = sq.encode(x)
+    idx = vg.Index(ctx, n, dim, vg.Metric(metric))
+    idx.set_sq8_codes(sq, codes)
+    idx.set_partitions(cent, off)
+    seg = o.FlatSegment(x, dim, metric=metric, sq=ref, codes=codes, centroids=cent, part_offsets=off)
+    q = rng.standard_normal((5, dim)).astype(np.float32)
+    for nprobes, k in ((1, 10), (3, 33), (parts, 64)):
+        ids, sc = idx.search_flat_probed(q, k, nprobes, scan=idx.SCAN_SQ8)
+        check(ids, sc, seg, q, k, nprobes)
+
+
+def test_partitioned_segment_file(vg, ctx):
+    """A flat segment image with partitions: Segment.search = flat.Segment.Search with NProbes."""
+    rng = np.random.default_rng(77)
+    n, dim, parts = 2500, 48, 8
+    x, cent, off = partitioned(rng, n, dim, parts)
+    q = rng.standard_normal((4, dim)).astype(np.float32)
+    seg = vg.Segment(ctx, segfile.write_flat(x, partitions=(cent, off)))
+    assert seg.info.num_partitions == parts
+    ref = o.FlatSegment(x, dim, centroids=cent, part_offsets=off)
+    for nprobes in (0, 2, parts):
+        ids, sc = seg.search(q, 10, nprobes)
+        check(ids, sc, ref, q, 10, nprobes)
+    seg.close()
+    sq = o.ScalarQuantizer(dim); sq.train(x)
+    codes = sq.encode_batch(x)
+    seg = vg.Segment(ctx, segfile.write_flat(x, sq=(sq.mins, sq.maxs), codes=codes, partitions=(cent, off)))
+    ref = o.FlatSegment(x, dim, sq=sq, codes=codes, centroids=cent, part_offsets=off)
+    ids, sc = seg.search(q, 10, 3)
+    check(ids, sc, ref, q, 10, 3)
+    seg.close()
+    plain = vg.Segment(ctx, segfile.write_flat(x))              # no partitions: the whole segment
+    ids, sc = plain.search(q, 10, 5)
+    check(ids, sc, o.FlatSegment(x, dim), q, 10, 5)
+    plain.close()
+
+
+def test_probe_errors(vg, ctx):
+    idx = vg.Index(ctx, 100, 8)
+    idx.set_vectors(np.zeros((100, 8), np.float32))
+    with pytest.raises(vg.VecgoHipError):
+        idx.set_partitions(np.zeros((2, 8), np.float32), [0, 60, 50])   # offsets decrease
+    with pytest.raises(vg.VecgoHipError):
+        idx.set_partitions(np.zeros((2, 8), np.float32), [0, 60, 101])  # past the last row
+    idx.set_partitions(np.zeros((2, 8), np.float32), [0, 60, 100])
+    with pytest.raises(vg.VecgoHipError):
+        idx.search_flat_probed(np.zeros((1, 8), np.float32), 65, 1)     # k <= 64
+    with pytest.raises(vg.VecgoHipError):
+        idx.search_flat_probed(np.zeros((1, 8), np.float32), 5, 1, scan=idx.SCAN_PQ)  # no PQ codes

@@ -104,7 +104,26 @@ def test_sq8_errors(vg, ctx):
     sq.train(np.random.default_rng(0).standard_normal((20, 8)).astype(np.float32))
     with pytest.raises(vg.VecgoHipError):
         idx.search_sq8(np.zeros((1, 8), np.float32), 5)      # no codes attached
-    dot = vg.Index(ctx, 10, 8, vg.Metric(2))
-    dot.set_sq8_codes(sq, np.zeros((10, 8), np.uint8))
     with pytest.raises(vg.VecgoHipError):
-        dot.search_sq8(np.zeros((1, 8), np.float32), 5)      # L2 only (flat/segment.go:517)
+        idx.search_sq8(np.zeros((1, 8), np.float32), 65)     # k <= 64
+
+
+@pytest.mark.parametrize("n,dim,nq,k,metric", [(700, 128, 5, 10, 2), (300, 100, 3, 7, 1), (130, 17, 2, 64, 2)])
+def test_sq8_dot_product_scan_matches_oracle(vg, ctx, n, dim, nq, k, metric):
+    """Dot / Cosine SQ8 segments are scored with ScalarQuantizer.DotProduct (flat/segment.go:659-667,
+    quantizer.go:109-119: one sequential fp32 sum per row), largest first."""
+    rng = np.random.default_rng(n + dim + metric)
+    x = rng.standard_normal((n, dim)).astype(np.float32)
+    x[41] = x[9]
+    sq = vg.ScalarQuantizer(ctx, dim); sq.train(x)
+    ref = o.ScalarQuantizer(dim); ref.train(x)
+    codes = sq.encode(x)
+    idx = vg.Index(ctx, n, dim, vg.Metric(metric))
+    idx.set_sq8_codes(sq, codes)
+    q = rng.standard_normal((nq, dim)).astype(np.float32)
+    ids, sc = idx.search_sq8(q, k)
+    seg = o.FlatSegment(x, dim, metric=metric, sq=ref, codes=codes)
+    for i in range(nq):
+        eid, esc = seg.search(q[i], k)
+        assert np.array_equal(ids[i, :eid.size], eid), (i, ids[i], eid)
+        assert np.array_equal(bits(sc[i, :eid.size]), bits(esc))

@@ -1,0 +1,92 @@
+"""Oracle checks for the partitioned flat.Segment.Search restatement (flat/segment.go:447-751) and
+ScalarQuantizer.DotProduct (quantizer.go:109-119).  No GPU."""
+import numpy as np
+
+from oracle import oracle as o
+
+
+def bits(x):
+    return np.asarray(x, np.float32).view(np.uint32)
+
+
+def grouped(rng, n, dim, parts):
+    x = rng.standard_normal((n, dim)).astype(np.float32)
+    cent = rng.standard_normal((parts, dim)).astype(np.float32)
+    a = np.array([o.assign_partition(x[i], cent, dim) for i in range(n)])
+    order = np.argsort(a, kind="stable")
+    x, a = x[order], a[order]
+    return x, cent, np.searchsorted(a, np.arange(parts + 1)).astype(np.uint32)
+
+
+def test_unpartitioned_segment_equals_the_plain_scans():
+    rng = np.random.default_rng(1)
+    n, dim, k = 400, 32, 10
+    x = rng.standard_normal((n, dim)).astype(np.float32)
+    q = rng.standard_normal(dim).astype(np.float32)
+    for metric in (0, 2):
+        a = o.FlatSegment(x, dim, metric=metric).search(q, k, nprobes=3)
+        b = o.flat_search_f32(x, dim, q, k, metric)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(bits(a[1]), bits(b[1]))
+    sq = o.ScalarQuantizer(dim); sq.train(x)
+    codes = sq.encode_batch(x)
+    a = o.FlatSegment(x, dim, sq=sq, codes=codes).search(q, k)
+    b = o.flat_search_sq8(sq, codes, q, k)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(bits(a[1]), bits(b[1]))
+    pq = o.ProductQuantizer(dim, 4, 256); pq.train(x, iters=3, seed=1)
+    pc = np.stack([pq.encode(r) for r in x])
+    a = o.FlatSegment(x, dim, pq=pq, codes=pc).search(q, k)
+    b = o.flat_search_pq(pq, pc, q, k)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(bits(a[1]), bits(b[1]))
+
+
+def test_probing_scans_exactly_the_closest_partitions():
+    rng = np.random.default_rng(2)
+    n, dim, parts, k = 900, 24, 6, 8
+    x, cent, off = grouped(rng, n, dim, parts)
+    seg = o.FlatSegment(x, dim, centroids=cent, part_offsets=off)
+    full = o.FlatSegment(x, dim)
+    for t in range(5):
+        q = rng.standard_normal(dim).astype(np.float32)
+        ids_all, sc_all = seg.search(q, k, nprobes=parts)            # every partition = exhaustive
+        fid, fsc = full.search(q, k)
+        assert np.array_equal(ids_all, fid) and np.array_equal(bits(sc_all), bits(fsc))
+        for nprobes in (0, 1, 3):
+            want = max(nprobes, 1)                                   # segment.go:728-731
+            probed = o.find_closest_centroids(q, cent, dim, want)
+            rows = np.concatenate([np.arange(off[p], off[p + 1]) for p in probed])
+            ids, sc = seg.search(q, k, nprobes)
+            assert set(ids) <= set(rows)
+            sub_ids, sub_sc = o.flat_search_f32(x[rows], dim, q, k)  # brute force over just those rows
+            assert np.array_equal(rows[sub_ids], ids) and np.array_equal(bits(sub_sc), bits(sc))
+
+
+def test_sq8_dot_product_is_the_sequential_go_loop():
+    rng = np.random.default_rng(3)
+    for dim in (1, 7, 16, 100):
+        q = rng.standard_normal(dim).astype(np.float32)
+        mins = rng.standard_normal(dim).astype(np.float32)
+        inv = (rng.random(dim).astype(np.float32) * np.float32(0.02)).astype(np.float32)
+        code = rng.integers(0, 256, dim).astype(np.uint8)
+        dot = np.float32(0.0)
+        for i in range(dim):  # quantizer.go:114-117, every operation rounded to float32
+            val = np.float32(mins[i] + np.float32(np.float32(code[i]) * inv[i]))
+            dot = np.float32(dot + np.float32(q[i] * val))
+        got = o.lib.vgo_sq8_dot(q.ctypes.data_as(o._f32p), code.ctypes.data_as(o._u8p), dim,
+                                mins.ctypes.data_as(o._f32p), inv.ctypes.data_as(o._f32p))
+        assert bits(got) == bits(dot)
+
+
+def test_sq8_segments_follow_the_metric():
+    """L2: sq8u batch order, ascending; Dot: DotProduct, descending (segment.go:449,659-667)."""
+    rng = np.random.default_rng(4)
+    n, dim, k = 300, 20, 5
+    x = rng.standard_normal((n, dim)).astype(np.float32)
+    sq = o.ScalarQuantizer(dim); sq.train(x)
+    codes = sq.encode_batch(x)
+    q = rng.standard_normal(dim).astype(np.float32)
+    ids, sc = o.FlatSegment(x, dim, metric=2, sq=sq, codes=codes).search(q, k)
+    dots = np.array([o.lib.vgo_sq8_dot(q.ctypes.data_as(o._f32p), codes[i].ctypes.data_as(o._u8p), dim,
+                                       sq.mins.ctypes.data_as(o._f32p), sq.inv_scales.ctypes.data_as(o._f32p))
+                     for i in range(n)], np.float32)
+    order = np.lexsort((np.arange(n), -dots))[:k]
+    assert np.array_equal(ids, order.astype(np.uint32)) and np.array_equal(bits(sc), bits(dots[order]))

@@ -639,6 +639,26 @@ class Index:
         self._keep.append(iq)
         check(self._lib.vg_index_set_int4_codes(self._h, iq._h, pc, _stream_ptr(stream)))
 
+    def set_partitions(self, centroids, part_offsets, stream=None):
+        """IVF partitions of a flat segment (flat/segment.go:187-207): centroids [P, dim] fp32 and the
+        first row of every partition [P + 1] uint32; None / empty removes them."""
+        if centroids is None or len(part_offsets) == 0:
+            check(self._lib.vg_index_set_partitions(self._h, None, None, C.c_int32(0), _stream_ptr(stream)))
+            return
+        c = np.ascontiguousarray(centroids, np.float32).reshape(-1, self.dim)
+        o = np.ascontiguousarray(part_offsets, np.uint32)
+        if o.size != c.shape[0] + 1:
+            raise ValueError("part_offsets must have one entry more than there are centroids")
+        check(self._lib.vg_index_set_partitions(self._h, C.c_void_p(c.ctypes.data), C.c_void_p(o.ctypes.data),
+                                                C.c_int32(c.shape[0]), _stream_ptr(stream)))
+
+    SCAN_F32, SCAN_PQ, SCAN_SQ8 = 0, 1, 2
+
+    def search_flat_probed(self, queries, k, nprobes=0, scan=0, out=None, stream=None):
+        """flat.Segment.Search over the nprobes closest IVF partitions (flat/segment.go:727-749)."""
+        return self._search(self._lib.vg_search_flat_probed, queries, k, extra=(C.c_int32(nprobes), C.c_int32(scan)),
+                            out=out, stream=stream)
+
     def search_sq8(self, queries, k, out=None, stream=None):
         """flat.Segment.Search SQ8 branch (flat/segment.go:517-604)."""
         return self._search(self._lib.vg_search_sq8, queries, k, out=out, stream=stream)
@@ -787,7 +807,8 @@ class Index:
 class SegmentInfo(C.Structure):
     _fields_ = [("segment_id", C.c_uint64), ("rows", C.c_int64), ("dim", C.c_int32), ("metric", C.c_int32),
                 ("kind", C.c_int32), ("quantization", C.c_int32), ("pq_m", C.c_int32), ("pq_k", C.c_int32),
-                ("max_degree", C.c_int32), ("search_list_size", C.c_int32), ("entrypoint", C.c_uint32)]
+                ("max_degree", C.c_int32), ("search_list_size", C.c_int32), ("entrypoint", C.c_uint32),
+                ("num_partitions", C.c_int32)]
 
 
 class Segment:
@@ -810,6 +831,15 @@ class Segment:
         self._lib.vg_segment_index.restype = C.c_void_p
         ih = C.c_void_p(self._lib.vg_segment_index(self._h))
         self.index = Index._borrowed(ctx, ih, int(info.rows), int(info.dim), int(info.metric), self)
+
+    def search(self, queries, k, nprobes=0, out=None, stream=None):
+        """flat.Segment.Search (flat/segment.go:447-751): scan type by the segment's quantization,
+        IVF partitions probed when the segment has more than one."""
+        seg = self._h
+
+        def fn(_index_handle, *args):  # same argument list as the index searches, segment handle first
+            return self._lib.vg_segment_search(seg, *args)
+        return self.index._search(fn, queries, k, extra=(C.c_int32(nprobes),), out=out, stream=stream)
 
     def close(self):
         if getattr(self, "_h", None):

@@ -734,6 +734,91 @@ int32_t launch_topk_merge(const uint64_t *partial, int64_t nq, int lists, int k,
 int32_t launch_pq_build_table(const vg_pq *pq, const float *d_queries, int64_t nq,
                               float *d_tables, bool scan_layout, hipStream_t st);
 
+// ---- partition-probed ADC scan (flat/segment.go:727-744 over the :678-689 branch) -----------------
+// One workgroup per (query, share of its probe list): the query's table is staged once, then the
+// tiles covering each probed partition's row range [R0, R1) are scanned with the rows outside the
+// range masked (partition bounds are not tile-aligned).  A few thousand rows per partition: the
+// plain gather loop, no hand pipelining.  k <= 64.
+__global__ __launch_bounds__(kAdcThreads) void pq_adc_probe_kernel(
+    const uint4 *__restrict__ tiles, int64_t n_rows, int m, int groups, const float *__restrict__ tables,
+    const uint32_t *__restrict__ probes, const uint32_t *__restrict__ part_off, int np, int split, int k,
+    uint64_t *__restrict__ partial)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float *lut = reinterpret_cast<float *>(smem);
+    const int lut_words = lut_image_words(m);
+    const int lut_tail_word = (((m >> 4) + 1) >> 1) * 8192;
+    uint64_t *buf = reinterpret_cast<uint64_t *>(smem + static_cast<size_t>(lut_words) * sizeof(float));
+    const int y = blockIdx.x;
+    const int64_t q = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int rot = lane & 15;
+    {
+        const float4 *src = reinterpret_cast<const float4 *>(tables + q * lut_words);
+        float4 *dst = reinterpret_cast<float4 *>(lut);
+        const int n4 = lut_words / 4;
+        const int rounds = n4 / kAdcThreads;
+        int r = 0;
+        for (; r + 4 <= rounds; r += 4) {
+            float4 tmp[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) tmp[u] = src[(r + u) * kAdcThreads + tid];
+#pragma unroll
+            for (int u = 0; u < 4; u++) dst[(r + u) * kAdcThreads + tid] = tmp[u];
+        }
+        for (int i = r * kAdcThreads + tid; i < n4; i += kAdcThreads) dst[i] = src[i];
+    }
+    __syncthreads();
+    const int gfull = m >> 4, tail = m & 15;
+    WaveTopK wtk;
+    wtk.init(k);
+    for (int j = y; j < np; j += split) {
+        const uint32_t p = probes[q * np + j];
+        const int64_t R0 = part_off[p], R1 = part_off[p + 1];
+        const int64_t tt0 = R0 >> 6, tt1 = (R1 + 63) >> 6;
+        for (int64_t tile = tt0 + wave; tile < tt1; tile += kAdcWaves) {
+            const uint4 *tp = tiles + (tile * groups) * 64 + lane;
+            float acc[16];
+#pragma unroll
+            for (int l = 0; l < 16; l++) acc[l] = 0.0f;
+            for (int g = 0; g < gfull; g++) {
+                const uint4 c = tp[g * 64];
+#pragma unroll
+                for (int sl = 0; sl < 16; sl++)
+                    acc[sl] = acc[sl] + lut[((g >> 1) * 256 + code_byte(c, sl)) * 32 + (g & 1) * 16 + ((sl + rot) & 15)];
+            }
+            float total = reduce16_regs(acc);
+            if (tail) {
+                const uint4 c = tp[gfull * 64];
+                for (int l = 0; l < tail; l++) total = total + lut[lut_tail_word + l * 256 + code_byte(c, l)];
+            }
+            const int64_t row = tile * 64 + lane;
+            wtk.offer(row >= R0 && row < R1 && row < n_rows ? make_key(total, static_cast<uint32_t>(row), false) : kKeyMax,
+                      lane);
+        }
+    }
+    wg_rank_merge<kAdcWaves>(wtk, buf, reinterpret_cast<int *>(buf + kAdcWaves * 64), wave, lane, tid, k,
+                             partial + (q * split + y) * k);
+}
+
+int32_t launch_probe_scan_adc(const vg_index *idx, const float *tables, const uint32_t *probes, int64_t nq, int np,
+                              int split, int k, uint64_t *partial, hipStream_t st)
+{
+    const vg_pq *pq = idx->pq;
+    const size_t lds = static_cast<size_t>(lut_image_words(pq->m)) * sizeof(float) + kAdcWaves * 64 * sizeof(uint64_t) + 64;
+    VG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(pq_adc_probe_kernel),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+    for (int64_t q0 = 0; q0 < nq; q0 += 65535) {
+        const int64_t cnt = nq - q0 < 65535 ? nq - q0 : 65535;
+        ProfScope prof(idx->ctx, "pq_adc_probe", st);
+        VG_LAUNCH(pq_adc_probe_kernel, dim3(static_cast<unsigned>(split), static_cast<unsigned>(cnt)), dim3(kAdcThreads),
+                  lds, st, reinterpret_cast<const uint4 *>(idx->d_pq_tiles), idx->n, pq->m, idx->pq_groups,
+                  tables + q0 * lut_image_words(pq->m), probes + q0 * np, idx->d_part_off, np, split, k,
+                  partial + q0 * split * k);
+    }
+    return VG_OK;
+}
+
 static int adc_slices(int64_t nq, int64_t n_tiles, int cus)
 {
     // smallest multiple of 8 (one group per XCD) with slices*nq >= #CUs, at least one

@@ -153,6 +153,33 @@ __device__ __forceinline__ float sq8_tail(float total, const uint4 c, int cnt, c
     return total;
 }
 
+// ScalarQuantizer.DotProduct (quantizer.go:109-119) over `cnt` (<= 16) elements of one row: a plain Go
+// loop — val = mins[i] + float32(code[i])*invScales[i], dot += q[i]*val, four separately rounded
+// operations (no FMA on amd64), one running sum in element order.
+__device__ __forceinline__ float sq8_dot16(float total, const uint4 c, int cnt, const float *__restrict__ qv,
+                                           const float *__restrict__ mn, const float *__restrict__ iv)
+{
+    const uint32_t w[4] = {c.x, c.y, c.z, c.w};
+#pragma unroll
+    for (int l = 0; l < 16; l++) {
+        if (l < cnt) {
+            const float cf = static_cast<float>((w[l >> 2] >> (8 * (l & 3))) & 0xFFu);
+            const float t = cf * iv[l];
+            const float val = mn[l] + t;
+            const float prod = qv[l] * val;
+            total = total + prod;
+        }
+    }
+    return total;
+}
+
+// one row's score from its tile pieces: L2 = the 16 lane accumulators of sq8u_l2_batch + tail,
+// DOT = the sequential sum above
+template <bool DOT>
+__device__ __forceinline__ float sq8_row_score(const uint4 *__restrict__ tp, int groups, int full, int tail,
+                                               const float *__restrict__ qv, const float *__restrict__ mins,
+                                               const float *__restrict__ inv);
+
 // L2DistanceBatch on the reference layout (codes n*dim): lane per row, 16 bytes at a time.  The
 // interface path for small batches (the reference calls it with 256 rows, flat/segment.go:487,550).
 __global__ __launch_bounds__(256) void sq8_l2_batch_kernel(const float *__restrict__ query,
@@ -210,6 +237,46 @@ __global__ void sq8_retile_kernel(const uint8_t *__restrict__ codes, int64_t n, 
 constexpr int kSqAhead = 4;  // 16-byte code groups in flight per lane
 constexpr int kSqWaves = 4;
 constexpr int kSqThreads = kSqWaves * 64;
+template <bool DOT>
+__device__ __forceinline__ float sq8_row_score(const uint4 *__restrict__ tp, int groups, int full, int tail,
+                                               const float *__restrict__ qv, const float *__restrict__ mins,
+                                               const float *__restrict__ inv)
+{
+    float acc[16];
+#pragma unroll
+    for (int l = 0; l < 16; l++) acc[l] = 0.0f;
+    float run = 0.0f;
+    // kSqAhead groups of codes in flight per lane (one ahead left the wave waiting on HBM every
+    // 64 VALU instructions); addresses past the row's last group are clamped to it
+    uint4 ring[kSqAhead];
+    const int glast = groups - 1;
+#pragma unroll
+    for (int a = 0; a < kSqAhead; a++) ring[a] = tp[(a < glast ? a : glast) * 64];
+    for (int g0 = 0; g0 < full; g0 += kSqAhead) {
+#pragma unroll
+        for (int a = 0; a < kSqAhead; a++) {
+            const int g = g0 + a;
+            const uint4 c = ring[a];
+            const int gn = g + kSqAhead;
+            ring[a] = tp[(gn < glast ? gn : glast) * 64];
+            if (g < full) {
+                if (DOT)
+                    run = sq8_dot16(run, c, 16, qv + g * 16, mins + g * 16, inv + g * 16);
+                else
+                    sq8_block16(acc, c, qv + g * 16, mins + g * 16, inv + g * 16);
+            }
+        }
+    }
+    if (DOT) {
+        if (tail) run = sq8_dot16(run, tp[full * 64], tail, qv + full * 16, mins + full * 16, inv + full * 16);
+        return run;
+    }
+    float total = reduce16_regs(acc);
+    if (tail) total = sq8_tail(total, tp[full * 64], tail, qv + full * 16, mins + full * 16, inv + full * 16);
+    return total;
+}
+
+template <bool DOT>
 __global__ __launch_bounds__(kSqThreads) void sq8_scan_kernel(
     const uint4 *__restrict__ tiles, int64_t n_rows, int64_t n_tiles, int groups, int dim,
     const float *__restrict__ queries, const float *__restrict__ mins, const float *__restrict__ inv, int slices,
@@ -229,33 +296,56 @@ __global__ __launch_bounds__(kSqThreads) void sq8_scan_kernel(
     WaveTopK tk;
     tk.init(k);
     for (int64_t tile = t0 + wave; tile < t1; tile += kSqWaves) {
-        const uint4 *tp = tiles + (tile * groups) * 64 + lane;
-        float acc[16];
-#pragma unroll
-        for (int l = 0; l < 16; l++) acc[l] = 0.0f;
-        // kSqAhead groups of codes in flight per lane (one ahead left the wave waiting on HBM every
-        // 64 VALU instructions); addresses past the row's last group are clamped to it
-        uint4 ring[kSqAhead];
-        const int glast = groups - 1;
-#pragma unroll
-        for (int a = 0; a < kSqAhead; a++) ring[a] = tp[(a < glast ? a : glast) * 64];
-        for (int g0 = 0; g0 < full; g0 += kSqAhead) {
-#pragma unroll
-            for (int a = 0; a < kSqAhead; a++) {
-                const int g = g0 + a;
-                const uint4 c = ring[a];
-                const int gn = g + kSqAhead;
-                ring[a] = tp[(gn < glast ? gn : glast) * 64];
-                if (g < full) sq8_block16(acc, c, qv + g * 16, mins + g * 16, inv + g * 16);
-            }
-        }
-        float total = reduce16_regs(acc);
-        if (tail) total = sq8_tail(total, tp[full * 64], tail, qv + full * 16, mins + full * 16, inv + full * 16);
+        const float total = sq8_row_score<DOT>(tiles + (tile * groups) * 64 + lane, groups, full, tail, qv, mins, inv);
         const int64_t row = tile * 64 + lane;
-        tk.offer(row < n_rows ? make_key(total, static_cast<uint32_t>(row), false) : kKeyMax, lane);
+        tk.offer(row < n_rows ? make_key(total, static_cast<uint32_t>(row), DOT) : kKeyMax, lane);
     }
     wg_rank_merge<kSqWaves>(tk, lists, valid, wave, lane, tid, k,
                             partial + (static_cast<int64_t>(q) * slices + s) * k);
+}
+
+// Partition-probed SQ8 scan (flat/segment.go:727-744 over the :517-604 branch): workgroup =
+// (slice of one probed partition's tiles, probe, query); rows outside the partition's range are masked.
+template <bool DOT>
+__global__ __launch_bounds__(kSqThreads) void sq8_probe_kernel(
+    const uint4 *__restrict__ tiles, int64_t n_rows, int groups, int dim, const float *__restrict__ queries,
+    const float *__restrict__ mins, const float *__restrict__ inv, const uint32_t *__restrict__ probes,
+    const uint32_t *__restrict__ part_off, int np, int sub, int k, uint64_t *__restrict__ partial)
+{
+    __shared__ uint64_t lists[kSqWaves * 64];
+    __shared__ int valid[kSqWaves];
+    const int s = blockIdx.x, j = blockIdx.y;
+    const int64_t q = blockIdx.z;
+    const uint32_t p = probes[q * np + j];
+    const int64_t R0 = part_off[p], R1 = part_off[p + 1];
+    const int64_t tt0 = R0 >> 6, tt1 = (R1 + 63) >> 6;
+    const int64_t t0 = tt0 + (tt1 - tt0) * s / sub, t1 = tt0 + (tt1 - tt0) * (s + 1) / sub;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float *qv = queries + q * dim;
+    const int full = dim >> 4, tail = dim & 15;
+    WaveTopK tk;
+    tk.init(k);
+    for (int64_t tile = t0 + wave; tile < t1; tile += kSqWaves) {
+        const float total = sq8_row_score<DOT>(tiles + (tile * groups) * 64 + lane, groups, full, tail, qv, mins, inv);
+        const int64_t row = tile * 64 + lane;
+        tk.offer(row >= R0 && row < R1 && row < n_rows ? make_key(total, static_cast<uint32_t>(row), DOT) : kKeyMax, lane);
+    }
+    wg_rank_merge<kSqWaves>(tk, lists, valid, wave, lane, tid, k, partial + ((q * np + j) * sub + s) * k);
+}
+
+int32_t launch_probe_scan_sq8(const vg_index *idx, const float *queries, const uint32_t *probes, int64_t nq, int np,
+                              int sub, int k, uint64_t *partial, hipStream_t st)
+{
+    for (int64_t q0 = 0; q0 < nq; q0 += 65535) {
+        const int64_t cnt = nq - q0 < 65535 ? nq - q0 : 65535;
+        ProfScope prof(idx->ctx, "sq8_probe", st);
+        auto kern = idx->metric != VG_METRIC_L2 ? sq8_probe_kernel<true> : sq8_probe_kernel<false>;
+        VG_LAUNCH(kern, dim3(static_cast<unsigned>(sub), static_cast<unsigned>(np), static_cast<unsigned>(cnt)),
+                  dim3(kSqThreads), 0, st, reinterpret_cast<const uint4 *>(idx->d_sq_tiles), idx->n, idx->sq_groups, idx->dim,
+                  queries + q0 * idx->dim, idx->sq->d_mins, idx->sq->d_inv, probes + q0 * np, idx->d_part_off, np, sub, k,
+                  partial + q0 * np * sub * k);
+    }
+    return VG_OK;
 }
 
 // ==== INT4 (internal/quantization/int4.go, internal/simd/src/int4_avx512.c) ===========================
@@ -593,8 +683,8 @@ VG_API int32_t vg_search_sq8(vg_index *idx, const float *queries, int64_t nq, in
     VG_CHECK(idx, VG_ERR_INVALID_ARG, "vg_search_sq8: NULL index");
     VG_CHECK(nq >= 0 && k >= 0, VG_ERR_INVALID_ARG, "vg_search_sq8: negative nq or k");
     if (nq == 0 || k == 0) return VG_OK;
-    VG_CHECK(idx->metric == VG_METRIC_L2, VG_ERR_UNSUPPORTED,
-             "vg_search_sq8: the reference's SQ8 scan exists for L2 only (flat/segment.go:517)");
+    VG_CHECK(idx->metric != VG_METRIC_HAMMING, VG_ERR_UNSUPPORTED, "unsupported metric for float32: Hamming");
+    const bool dot = idx->metric != VG_METRIC_L2;  // segment.go:659-667: sq.L2Distance or sq.DotProduct
     VG_CHECK(idx->n == 0 || idx->d_sq_tiles, VG_ERR_NOT_READY, "vg_search_sq8: index has no SQ8 codes");
     VG_CHECK(queries && ids && scores, VG_ERR_INVALID_ARG, "vg_search_sq8: NULL buffer");
     VG_CHECK(k <= 64, VG_ERR_UNSUPPORTED, "vg_search_sq8: k=%d exceeds 64", k);
@@ -621,12 +711,13 @@ VG_API int32_t vg_search_sq8(vg_index *idx, const float *queries, int64_t nq, in
         for (int64_t q0 = 0; q0 < nq; q0 += max_q) {
             const int64_t cnt = nq - q0 < max_q ? nq - q0 : max_q;
             vg::ProfScope prof(idx->ctx, "sq8_scan", st);
-            VG_LAUNCH(vg::sq8_scan_kernel, dim3(static_cast<unsigned>(cnt * slices)), dim3(vg::kSqThreads), 0, st,
+            auto kern = dot ? vg::sq8_scan_kernel<true> : vg::sq8_scan_kernel<false>;
+            VG_LAUNCH(kern, dim3(static_cast<unsigned>(cnt * slices)), dim3(vg::kSqThreads), 0, st,
                       reinterpret_cast<const uint4 *>(idx->d_sq_tiles), idx->n, idx->n_tiles, idx->sq_groups, idx->dim,
                       q.ptr + q0 * idx->dim, idx->sq->d_mins, idx->sq->d_inv, slices, static_cast<int>(cnt), k,
                       partial + q0 * slices * k);
         }
-        VG_TRY(vg::launch_topk_merge(partial, nq, slices, k, false, oid.ptr, osc.ptr, st));
+        VG_TRY(vg::launch_topk_merge(partial, nq, slices, k, dot, oid.ptr, osc.ptr, st));
     }
     VG_TRY(oid.finish());
     VG_TRY(osc.finish());

@@ -130,10 +130,10 @@ VG_API int32_t vg_segment_open_flat(vg_ctx *ctx, const void *image, int64_t size
     h.dim = static_cast<int32_t>(rd32(data + 20));
     h.metric = data[24];
     const uint32_t partitions = rd32(data + 28);
+    const uint64_t cent_off = rd64(data + 40), poff_off = rd64(data + 48);
     const int qtype = data[32];  // format.go:22-26: 0 none, 1 SQ8, 2 PQ
     const uint64_t q_off = rd64(data + 56), codes_off = rd64(data + 64), vec_off = rd64(data + 72);
     const uint32_t checksum = rd32(data + 104);
-    (void)partitions;  // IVF partitions only order the rows; an exhaustive scan ignores them
     SEG_CHECK(h.dim > 0, VG_ERR_FORMAT, "flat segment: dimension 0");
     SEG_CHECK(h.metric <= VG_METRIC_DOT, VG_ERR_UNSUPPORTED, "flat segment: metric %d has no float32 kernels", h.metric);
     if (verify_checksum) SEG_TRY(verify_body(data, len, kFlatHeader, checksum));
@@ -149,8 +149,8 @@ VG_API int32_t vg_segment_open_flat(vg_ctx *ctx, const void *image, int64_t size
         memcpy(mm.data(), data + q_off, dim * 8);
         SEG_TRY(vg_sq8_set_bounds(seg->sq, mm.data(), mm.data() + dim));
         h.quantization = VG_QUANT_SQ8;
-        if (h.metric == VG_METRIC_L2)  // the reference scans SQ8 codes for L2 only (segment.go:517)
-            SEG_TRY(vg_index_set_sq8_codes(seg->idx, seg->sq, data + codes_off, stream));
+        // segment.go:659-667: an SQ8 segment is scored from its codes for every metric (L2Distance / DotProduct)
+        SEG_TRY(vg_index_set_sq8_codes(seg->idx, seg->sq, data + codes_off, stream));
     } else if (qtype == 2) {  // segment.go:234-281: m, k, scales[m], offsets[m], codebooks[m*k*dsub], codes n*m
         SEG_CHECK(len >= q_off + 8 && q_off + 8 >= q_off, VG_ERR_FORMAT, "file too short for PQ metadata");
         const uint64_t m = rd32(data + q_off), k = rd32(data + q_off + 4);
@@ -183,8 +183,41 @@ VG_API int32_t vg_segment_open_flat(vg_ctx *ctx, const void *image, int64_t size
             SEG_TRY(vg_index_set_vectors(seg->idx, v.data(), stream));
         }
     }
+    h.num_partitions = static_cast<int32_t>(partitions);
+    if (partitions > 0) {  // segment.go:187-207: centroids [P*dim] fp32, partition offsets [P+1] uint32
+        const uint64_t cbytes = static_cast<uint64_t>(partitions) * dim * 4, pbytes = (static_cast<uint64_t>(partitions) + 1) * 4;
+        SEG_CHECK(len >= cent_off + cbytes && cent_off + cbytes >= cent_off, VG_ERR_FORMAT, "file too short for centroids");
+        SEG_CHECK(len >= poff_off + pbytes && poff_off + pbytes >= poff_off, VG_ERR_FORMAT,
+                  "file too short for partition offsets");
+        std::vector<float> cent(static_cast<size_t>(partitions) * dim);  // the image is only byte-aligned
+        std::vector<uint32_t> poff(static_cast<size_t>(partitions) + 1);
+        memcpy(cent.data(), data + cent_off, cbytes);
+        memcpy(poff.data(), data + poff_off, pbytes);
+        SEG_TRY(vg_index_set_partitions(seg->idx, cent.data(), poff.data(), static_cast<int32_t>(partitions), stream));
+    }
     *out = seg;
     return VG_OK;
+}
+
+VG_API int32_t vg_segment_search(vg_segment *seg, const float *queries, int64_t nq, int32_t k, int32_t nprobes,
+                                 uint32_t *ids, float *scores, void *stream)
+{
+    VG_CHECK(seg && seg->idx, VG_ERR_INVALID_ARG, "vg_segment_search: NULL segment");
+    VG_CHECK(seg->info.kind == 0, VG_ERR_UNSUPPORTED,
+             "vg_segment_search: flat segments only (a DiskANN segment is searched with vg_search_vamana)");
+    // flat/segment.go:657-701: SQ8 codes if the segment has them, else PQ table lookups, else fp32 rows
+    int32_t scan = VG_SCAN_F32;
+    if (seg->info.quantization == VG_QUANT_SQ8) {
+        scan = VG_SCAN_SQ8;
+    } else if (seg->info.quantization == VG_QUANT_PQ) {
+        // the reference's heap direction follows the segment metric (segment.go:449) while AdcDistance is
+        // always a squared L2: a Dot / Cosine PQ segment keeps its k FARTHEST rows there.  Not reproduced.
+        VG_CHECK(seg->info.metric == VG_METRIC_L2, VG_ERR_UNSUPPORTED,
+                 "vg_segment_search: PQ segment with metric %d (the reference keeps the largest ADC distances)",
+                 seg->info.metric);
+        scan = VG_SCAN_PQ;
+    }
+    return vg_search_flat_probed(seg->idx, queries, nq, k, nprobes, scan, ids, scores, stream);
 }
 
 VG_API int32_t vg_segment_open_diskann(vg_ctx *ctx, const void *image, int64_t size, int32_t verify_checksum,
