@@ -466,6 +466,13 @@ public:
     // flat.Segment.Search PQ branch (flat/segment.go:476-483,678-689)
     Result SearchPQ(const float *queries, int64_t nq, int k) { return run(nq, k, [&](Result &r) { return vg_search_pq_adc(h_, queries, nq, k, r.ids.data(), r.scores.data(), nullptr); }); }
     Result SearchRaBitQ(const float *queries, int64_t nq, int k) { return run(nq, k, [&](Result &r) { return vg_search_rabitq(h_, queries, nq, k, r.ids.data(), r.scores.data(), nullptr); }); }
+    // IVF partitions (flat/segment.go:187-207) and the probed scan of flat.Segment.Search (:727-749):
+    // scan = VG_SCAN_F32 / VG_SCAN_PQ / VG_SCAN_SQ8, nprobes <= 0 means 1 as in the reference
+    void SetPartitions(const float *centroids, const uint32_t *part_offsets, int num_partitions)
+    {
+        check(vg_index_set_partitions(h_, centroids, part_offsets, num_partitions, nullptr));
+    }
+    Result SearchProbed(const float *queries, int64_t nq, int k, int nprobes, int scan) { return run(nq, k, [&](Result &r) { return vg_search_flat_probed(h_, queries, nq, k, nprobes, scan, r.ids.data(), r.scores.data(), nullptr); }); }
     // hnsw.KNNSearch (hnsw.go:1650-1755)
     Result SearchHNSW(const float *queries, int64_t nq, int k, int ef) { return run(nq, k, [&](Result &r) { return vg_search_hnsw(h_, queries, nq, k, ef, r.ids.data(), r.scores.data(), nullptr, nullptr); }); }
     // diskann searchInternal (diskann/segment.go:503-706); kind 0 fp32, 1 PQ, 2 RaBitQ
