@@ -1,5 +1,7 @@
 """flat.Segment.Search over IVF partitions (flat/segment.go:727-749) on the GPU vs the oracle: the
 nprobes closest centroids' row ranges, scanned with the segment's scan type, ids and scores bit-exact."""
+import os
+
 import numpy as np
 import pytest
 
@@ -60,6 +62,17 @@ def test_probed_fp32_scan(vg, ctx, n, dim, parts, metric):
     for nprobes, k in ((0, 10), (1, 1), (3, 10), (parts, 64), (parts + 5, 17)):
         ids, sc = idx.search_flat_probed(q, k, nprobes, scan=idx.SCAN_F32)
         check(ids, sc, seg, q, k, nprobes)
+    # a batch large enough for full groups of queries per partition; the grouped scan (rows read once
+    # per group of 8 queries) and the pair-by-pair scan give the same lists
+    many = rng.standard_normal((150, dim)).astype(np.float32)
+    ids, sc = idx.search_flat_probed(many, 10, 2, scan=idx.SCAN_F32)
+    check(ids[:6], sc[:6], seg, many[:6], 10, 2)
+    os.environ["VG_PROBE_NO_GROUP"] = "1"
+    try:
+        pid, psc = idx.search_flat_probed(many, 10, 2, scan=idx.SCAN_F32)
+    finally:
+        del os.environ["VG_PROBE_NO_GROUP"]
+    assert np.array_equal(ids, pid) and np.array_equal(bits(sc), bits(psc))
     # every partition probed = the exhaustive search
     ids, sc = idx.search_flat_probed(q, 10, parts, scan=idx.SCAN_F32)
     fid, fsc = idx.search_flat(q, 10)

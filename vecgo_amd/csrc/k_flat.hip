@@ -324,51 +324,6 @@ __global__ __launch_bounds__(256) void flat_exact_kernel(const float *__restrict
 // This kernel is the HBM-bound alternative: a 16-lane group loads a row ONCE into registers
 // (dim <= 1024: 16 float4 per lane) and scores it against QB queries held in LDS, each in the
 // reference's summation order (vg_exact.hpp, kPair) — exact by construction, no proof step.
-template <bool DOT>
-__device__ __forceinline__ float exact_rowregs16(const float4 (&rr)[16], int nblk, const float *__restrict__ row,
-                                                 const float *__restrict__ q, int dim, Sub16 sub)
-{
-    float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-    const float4 *q4 = reinterpret_cast<const float4 *>(q) + sub.f4;
-#pragma unroll
-    for (int e = 0; e < 16; e++) {
-        if (e < nblk) {
-            const float4 a = q4[e * 16];
-            const float4 b = rr[e];
-            if (DOT) {
-                acc[0] = __builtin_fmaf(a.x, b.x, acc[0]);
-                acc[1] = __builtin_fmaf(a.y, b.y, acc[1]);
-                acc[2] = __builtin_fmaf(a.z, b.z, acc[2]);
-                acc[3] = __builtin_fmaf(a.w, b.w, acc[3]);
-            } else {
-                const float d0 = a.x - b.x, d1 = a.y - b.y, d2 = a.z - b.z, d3 = a.w - b.w;
-                acc[0] = __builtin_fmaf(d0, d0, acc[0]);
-                acc[1] = __builtin_fmaf(d1, d1, acc[1]);
-                acc[2] = __builtin_fmaf(d2, d2, acc[2]);
-                acc[3] = __builtin_fmaf(d3, d3, acc[3]);
-            }
-        }
-    }
-    float b[4];
-#pragma unroll
-    for (int t = 0; t < 4; t++) {
-        const float p = dpp_partner_add<kDppRowHalfMirror>(acc[t]);
-        const float s2 = dpp_partner_add<kDppRowMirror>(p);
-        const float a = dpp_partner_add<kDppQuadXor2>(s2);
-        b[t] = dpp_partner_add<kDppQuadXor1>(a);
-    }
-    float total = (b[0] + b[2]) + (b[1] + b[3]);
-    for (int j = nblk << 6; j < dim; j++) {  // scalar tail (FMA-contracted in the reference)
-        if (DOT) {
-            total = __builtin_fmaf(q[j], row[j], total);
-        } else {
-            const float d = q[j] - row[j];
-            total = __builtin_fmaf(d, d, total);
-        }
-    }
-    return total;
-}
-
 constexpr int kScanQB = 8;        // queries one pass can carry
 constexpr int kScanMaxBatch = 4;  // ... and the batch size up to which the scan beats the 32-query GEMM tile
 template <bool DOT>

@@ -88,6 +88,133 @@ __global__ __launch_bounds__(256) void probe_scan_f32_kernel(const float *__rest
     wg_rank_merge<4>(tk, lists, valid, wave, lane, tid, k, partial + ((q * np + j) * sub_n + s) * k);
 }
 
+// ---- 2b. fp32 scan, queries grouped by partition ---------------------------------------------------
+// With many (query, probe) pairs the same partition is probed by many queries: the pairs are bucketed
+// by partition and cut into groups of up to kProbeQB; a workgroup then loads each row of its slice
+// ONCE into registers and scores it against the group's queries held in LDS (the multi-query scan of
+// k_flat.hip), instead of one pass over the partition per pair.
+constexpr int kProbeQB = 8;
+struct ProbeGroup {
+    uint32_t part;   // partition
+    uint32_t first;  // first entry of the group in pair_of[]
+    uint32_t count;  // 1..kProbeQB
+};
+
+// one workgroup: bucket the pairs by partition, cut the buckets into groups.  counts[parts + 1] is
+// zeroed by the caller; cursor / gstart are scratch of parts + 1 words; ngroups[0] receives the total.
+__global__ __launch_bounds__(1024) void probe_group_kernel(const uint32_t *__restrict__ probes, int64_t pairs,
+                                                           int parts, uint32_t *__restrict__ counts,
+                                                           uint32_t *__restrict__ cursor, uint32_t *__restrict__ gstart,
+                                                           uint32_t *__restrict__ pair_of,
+                                                           ProbeGroup *__restrict__ groups, uint32_t *__restrict__ ngroups)
+{
+    __shared__ uint32_t seg_c[1024], seg_g[1024];
+    const int tid = threadIdx.x;
+    for (int64_t i = tid; i < pairs; i += 1024) atomicAdd(&counts[probes[i]], 1u);
+    __syncthreads();
+    const int per = (parts + 1023) / 1024;
+    const int pb = tid * per < parts ? tid * per : parts, pe = pb + per < parts ? pb + per : parts;
+    uint32_t mc = 0, mg = 0;
+    for (int p = pb; p < pe; p++) {
+        mc += counts[p];
+        mg += (counts[p] + kProbeQB - 1) / kProbeQB;
+    }
+    seg_c[tid] = mc;
+    seg_g[tid] = mg;
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t rc = 0, rg = 0;
+        for (int t = 0; t < 1024; t++) {
+            const uint32_t c = seg_c[t], g = seg_g[t];
+            seg_c[t] = rc;
+            seg_g[t] = rg;
+            rc += c;
+            rg += g;
+        }
+        ngroups[0] = rg;
+    }
+    __syncthreads();
+    uint32_t rc = seg_c[tid], rg = seg_g[tid];
+    for (int p = pb; p < pe; p++) {
+        const uint32_t c = counts[p];
+        cursor[p] = rc;
+        gstart[p] = rg;
+        const uint32_t ng = (c + kProbeQB - 1) / kProbeQB;
+        for (uint32_t gi = 0; gi < ng; gi++) {
+            ProbeGroup g;
+            g.part = static_cast<uint32_t>(p);
+            g.first = rc + gi * kProbeQB;
+            g.count = c - gi * kProbeQB < kProbeQB ? c - gi * kProbeQB : kProbeQB;
+            groups[rg + gi] = g;
+        }
+        rc += c;
+        rg += ng;
+    }
+    __syncthreads();
+    for (int64_t i = tid; i < pairs; i += 1024) pair_of[atomicAdd(&cursor[probes[i]], 1u)] = static_cast<uint32_t>(i);
+}
+
+template <bool DOT>
+__global__ __launch_bounds__(256) void probe_scan_f32_mq_kernel(const float *__restrict__ base, int dim,
+                                                                const float *__restrict__ queries,
+                                                                const uint32_t *__restrict__ part_off,
+                                                                const uint32_t *__restrict__ pair_of,
+                                                                const ProbeGroup *__restrict__ groups,
+                                                                const uint32_t *__restrict__ ngroups, int np,
+                                                                int sub_n, int k, uint64_t *__restrict__ partial)
+{
+    extern __shared__ float qlds[];  // kProbeQB * dim floats, then the merge scratch
+    uint64_t *lists = reinterpret_cast<uint64_t *>(qlds + static_cast<size_t>(kProbeQB) * dim);
+    int *valid = reinterpret_cast<int *>(lists + 4 * 64);
+    __shared__ uint32_t pair[kProbeQB];
+    if (blockIdx.y >= ngroups[0]) return;
+    const ProbeGroup g = groups[blockIdx.y];
+    const int s = blockIdx.x;
+    const int cnt = static_cast<int>(g.count);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid < cnt) pair[tid] = pair_of[g.first + tid];
+    __syncthreads();
+    for (int qi = 0; qi < cnt; qi++) {
+        const float *src = queries + static_cast<int64_t>(pair[qi] / np) * dim;
+        for (int t = tid; t < dim; t += 256) qlds[qi * dim + t] = src[t];
+    }
+    __syncthreads();
+    const Sub16 sub = Sub16::make(tid);
+    const int nblk = dim >> 6;
+    const int64_t R0 = part_off[g.part], R1 = part_off[g.part + 1];
+    const int64_t r0 = R0 + (R1 - R0) * s / sub_n, r1 = R0 + (R1 - R0) * (s + 1) / sub_n;
+    WaveTopK tk[kProbeQB];
+#pragma unroll
+    for (int qi = 0; qi < kProbeQB; qi++) tk[qi].init(k);
+    for (int64_t i0 = r0 + wave * 4; i0 < r1; i0 += 16) {
+        const int64_t i = i0 + (lane >> 4);
+        const bool live = i < r1;
+        const float *row = base + (live ? i : r1 - 1) * dim;
+        float4 rr[16];
+        const float4 *r4 = reinterpret_cast<const float4 *>(row) + sub.f4;
+#pragma unroll
+        for (int e = 0; e < 16; e++)
+            if (e < nblk) rr[e] = r4[e * 16];
+#pragma unroll
+        for (int qi = 0; qi < kProbeQB; qi++) {
+            if (qi < cnt) {
+                const float v = exact_rowregs16<DOT>(rr, nblk, row, qlds + static_cast<size_t>(qi) * dim, dim, sub);
+                uint64_t key = kKeyMax;
+                if (live && (lane & 15) == 0) key = make_key(v, static_cast<uint32_t>(i), DOT);
+                tk[qi].offer(key, lane);
+            }
+        }
+    }
+#pragma unroll
+    for (int qi = 0; qi < kProbeQB; qi++) {
+        if (qi < cnt) {
+            wg_rank_merge<4>(tk[qi], lists, valid, wave, lane, tid, k,
+                             partial + (static_cast<int64_t>(pair[qi]) * sub_n + s) * k);
+            __syncthreads();
+        }
+    }
+}
+
 }  // namespace vg
 
 VG_API int32_t vg_index_set_partitions(vg_index *idx, const float *centroids, const uint32_t *part_offsets,
@@ -166,13 +293,32 @@ VG_API int32_t vg_search_flat_probed(vg_index *idx, const float *queries, int64_
 
     // enough workgroups to fill the device when there are few (query, probe) pairs
     const int64_t pairs = nq * np;
+    // fp32: with enough pairs the queries are grouped by partition (rows read once per group); the
+    // row-in-registers scan needs 16-byte aligned rows of at most 1024 floats
+    const char *nogroup = getenv("VG_PROBE_NO_GROUP");  // test hook: one pass per (query, probe) pair
+    const bool grouped = scan == VG_SCAN_F32 && pairs >= 16 && idx->dim % 4 == 0 && idx->dim <= 1024 &&
+                         (reinterpret_cast<uintptr_t>(idx->d_vectors) & 15) == 0 && !(nogroup && nogroup[0] == '1');
     const int want = 4 * idx->ctx->compute_units;
     int sub = static_cast<int>(std::min<int64_t>(32, std::max<int64_t>(1, (want + pairs - 1) / pairs)));
     int split = static_cast<int>(std::min<int64_t>(np, std::max<int64_t>(1, (idx->ctx->compute_units + nq - 1) / nq)));
+    if (grouped) {  // workgroups are (group of up to kProbeQB pairs) x slice: size the slices for the groups
+        const int64_t g_est = std::max<int64_t>(1, pairs / vg::kProbeQB) + std::min<int64_t>(idx->num_partitions, pairs) / 2;
+        sub = static_cast<int>(std::min<int64_t>(32, std::max<int64_t>(1, (want + g_est - 1) / g_est)));
+    }
     const int lists = scan == VG_SCAN_PQ ? split : np * sub;
     const int lut_words = scan == VG_SCAN_PQ ? (((idx->pq->m >> 4) + 1) >> 1) * 8192 + (idx->pq->m & 15) * 256 : 0;
 
+    const int64_t qchunk = std::max<int64_t>(1, 65535 / np);
+    const int64_t chunk_pairs = std::min<int64_t>(nq, qchunk) * np;
+    const size_t gwords = grouped ? static_cast<size_t>(idx->num_partitions) + 1 : 0;
+
     vg::ArenaCall ar(idx->ctx, st);
+    const int i_gcounts = ar.add(sizeof(uint32_t) * gwords);
+    const int i_gcursor = ar.add(sizeof(uint32_t) * gwords);
+    const int i_gstart = ar.add(sizeof(uint32_t) * gwords);
+    const int i_pair_of = ar.add(grouped ? sizeof(uint32_t) * static_cast<size_t>(chunk_pairs) : 0);
+    const int i_groups = ar.add(grouped ? sizeof(vg::ProbeGroup) * static_cast<size_t>(chunk_pairs) : 0);
+    const int i_ngroups = ar.add(grouped ? 256 : 0);
     const int i_probes = ar.add(sizeof(uint32_t) * static_cast<size_t>(nq) * np);
     const int i_partial = ar.add(sizeof(uint64_t) * static_cast<size_t>(nq) * lists * k);
     const int i_tables = ar.add(sizeof(float) * static_cast<size_t>(nq) * lut_words);
@@ -180,6 +326,10 @@ VG_API int32_t vg_search_flat_probed(vg_index *idx, const float *queries, int64_
     uint32_t *probes = ar.get<uint32_t>(i_probes);
     uint64_t *partial = ar.get<uint64_t>(i_partial);
     float *tables = ar.get<float>(i_tables);
+    uint32_t *gcounts = ar.get<uint32_t>(i_gcounts), *gcursor = ar.get<uint32_t>(i_gcursor);
+    uint32_t *gstart = ar.get<uint32_t>(i_gstart), *pair_of = ar.get<uint32_t>(i_pair_of);
+    uint32_t *ngroups = ar.get<uint32_t>(i_ngroups);
+    vg::ProbeGroup *groups = ar.get<vg::ProbeGroup>(i_groups);
 
     if (dot)
         VG_LAUNCH(vg::probe_select_kernel<true>, dim3(static_cast<unsigned>(nq)), dim3(256), 0, st, q.ptr, idx->dim,
@@ -187,7 +337,24 @@ VG_API int32_t vg_search_flat_probed(vg_index *idx, const float *queries, int64_
     else
         VG_LAUNCH(vg::probe_select_kernel<false>, dim3(static_cast<unsigned>(nq)), dim3(256), 0, st, q.ptr, idx->dim,
                   idx->d_centroids, idx->num_partitions, np, probes);
-    if (scan == VG_SCAN_F32) {
+    if (scan == VG_SCAN_F32 && grouped) {
+        const size_t lds = sizeof(float) * vg::kProbeQB * static_cast<size_t>(idx->dim) + 4 * 64 * sizeof(uint64_t) + 64;
+        auto kern = dot ? vg::probe_scan_f32_mq_kernel<true> : vg::probe_scan_f32_mq_kernel<false>;
+        VG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   static_cast<int>(lds)));
+        for (int64_t q0 = 0; q0 < nq; q0 += qchunk) {
+            const int64_t cnt = std::min<int64_t>(qchunk, nq - q0);
+            const int64_t cpairs = cnt * np;
+            const unsigned gmax = static_cast<unsigned>(std::min<int64_t>(cpairs, cpairs / vg::kProbeQB + idx->num_partitions));
+            VG_HIP(hipMemsetAsync(gcounts, 0, sizeof(uint32_t) * (static_cast<size_t>(idx->num_partitions) + 1), st));
+            VG_LAUNCH(vg::probe_group_kernel, dim3(1), dim3(1024), 0, st, probes + q0 * np, cpairs, idx->num_partitions,
+                      gcounts, gcursor, gstart, pair_of, groups, ngroups);
+            vg::ProfScope prof(idx->ctx, "flat_probe", st);
+            VG_LAUNCH(kern, dim3(static_cast<unsigned>(sub), gmax), dim3(256), lds, st, idx->d_vectors, idx->dim,
+                      q.ptr + q0 * idx->dim, idx->d_part_off, pair_of, groups, ngroups, np, sub, k,
+                      partial + q0 * lists * k);
+        }
+    } else if (scan == VG_SCAN_F32) {
         for (int64_t q0 = 0; q0 < nq; q0 += 65535) {
             const int64_t cnt = std::min<int64_t>(65535, nq - q0);
             const dim3 grid(static_cast<unsigned>(sub), static_cast<unsigned>(np), static_cast<unsigned>(cnt));
