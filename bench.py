@@ -15,7 +15,8 @@ One JSON line on rank 0; extra objects: `roofline` (dominant kernel of the timed
 events from inside the library), `adc_scan` (PQ-ADC scan, BASELINE configs[3]: 10M x 96 B codes,
 HBM roofline), `rabitq_scan` (RaBitQ scan, configs[4] shape on one GPU: 10M x 100 B), `sq8_scan`,
 `flat_small_batch` (configs[1] below the MFMA regime),
-`hnsw_layer0` (configs[2]), `cpu_baseline` (the CPU oracle = port of the reference's AVX-512 path, timed on
+`hnsw_layer0` (configs[2]), `flat_ivf_probe` (the partition-probed flat search the reference runs on
+compacted segments), `cpu_baseline` (the CPU oracle = port of the reference's AVX-512 path, timed on
 this host's cores on a bounded sample).
 """
 from __future__ import annotations
@@ -341,6 +342,50 @@ def vamana_pq(vg, ctx, idx, rows, graph, q, gt_ids, stream):
             "pq_train_encode_s": prep_s}
 
 
+def flat_ivf_probe(vg, ctx, rows, queries, gt_ids, stream):
+    """flat.Segment.Search over an IVF-partitioned segment (flat/segment.go:727-749): the corpus in
+    rows/8192 k-means partitions as compaction writes it (engine/compaction.go:137-141), trained and
+    assigned on the GPU (untimed), 1024 queries, nprobes = 1 (the reference's default) and 8.  The
+    recall printed is what probing reaches on i.i.d. normal data, not a kernel property."""
+    n = rows.shape[0]
+    parts = n // 8192
+    t0 = time.perf_counter()
+    cent = vg.kmeans_train(ctx, rows, DIM, parts, max_iter=10, seed=1)
+    assign = vg.kmeans_assign(ctx, rows, cent, DIM).to(torch.int64)
+    order = torch.argsort(assign, stable=True)
+    grouped = rows[order].contiguous()
+    off = np.concatenate([[0], np.cumsum(torch.bincount(assign, minlength=parts).cpu().numpy())]).astype(np.uint32)
+    torch.cuda.synchronize()
+    prep_s = time.perf_counter() - t0
+    idx = vg.Index(ctx, n, DIM)
+    idx.set_vectors(grouped)
+    idx.set_partitions(cent.cpu().numpy(), off)
+    q = queries.reshape(-1, DIM)[:Q_BATCH]
+    order_h = order.cpu().numpy()
+    res = {"workload": f"flat_ivf_probe_1Mx768_{parts}_partitions_k10, {Q_BATCH} queries per call", "kmeans_assign_sort_s": prep_s}
+    for nprobes in (1, 8):
+        ids, _ = idx.search_flat_probed(q, K, nprobes, scan=idx.SCAN_F32, stream=stream)
+        torch.cuda.synchronize()
+        ctx.profile_read("flat_probe")
+        ctx.profile_enable(True)
+        reps = 5
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for _ in range(reps):
+            idx.search_flat_probed(q, K, nprobes, scan=idx.SCAN_F32, stream=stream)
+        e1.record(stream)
+        torch.cuda.synchronize()
+        launches, ms = ctx.profile_read("flat_probe")
+        ctx.profile_enable(False)
+        call_ms = e0.elapsed_time(e1) / reps
+        got = order_h[ids.cpu().numpy().view(np.uint32)[:gt_ids.shape[0]].astype(np.int64)]  # back to corpus row ids
+        rec = float(np.mean([len(set(got[i]) & set(gt_ids[i])) / K for i in range(gt_ids.shape[0])]))
+        res[f"nprobes_{nprobes}"] = {"call_ms": call_ms, "qps": Q_BATCH / (call_ms * 1e-3),
+                                     "scan_kernel_ms": ms / max(launches, 1), "recall_at_10": rec}
+    idx.close()
+    return res
+
+
 def measured_traffic(key: str):
     """HBM bytes per launch from the committed PMC passes (profiles/r01_traffic.json: rocprofv3
     --pmc FETCH_SIZE / WRITE_SIZE, gfx950 correction applied).  PMC counters cannot be read from
@@ -467,6 +512,8 @@ def main():
         out["flat_small_batch"] = flat_small_batch(vg, ctx, index.index, queries[2], stream)
     if world == 1 and not args.no_hnsw:
         out["hnsw_layer0"] = hnsw_layer0(vg, ctx, rows, queries, gt[:nrec], stream)
+    if world == 1 and not args.no_hnsw:
+        out["flat_ivf_probe"] = flat_ivf_probe(vg, ctx, rows, queries, gt[:nrec], stream)
     if world == 1 and not args.no_adc:
         del index
         out["adc_scan"] = adc_scan_roofline(vg, ctx, stream, device)
