@@ -186,23 +186,40 @@ __global__ __launch_bounds__(256) void probe_scan_f32_mq_kernel(const float *__r
     WaveTopK tk[kProbeQB];
 #pragma unroll
     for (int qi = 0; qi < kProbeQB; qi++) tk[qi].init(k);
-    for (int64_t i0 = r0 + wave * 4; i0 < r1; i0 += 16) {
-        const int64_t i = i0 + (lane >> 4);
-        const bool live = i < r1;
-        const float *row = base + (live ? i : r1 - 1) * dim;
-        float4 rr[16];
-        const float4 *r4 = reinterpret_cast<const float4 *>(row) + sub.f4;
+    // a wave step = 8 rows, two per 16-lane group (rows i and i + 4): each LDS read of a query is used twice
+    for (int64_t i0 = r0 + wave * 8; i0 < r1; i0 += 32) {
+        const int64_t ia = i0 + (lane >> 4), ib = ia + 4;
+        const bool livea = ia < r1, liveb = ib < r1;
+        const float *rowa = base + (livea ? ia : r1 - 1) * dim;
+        const float *rowb = base + (liveb ? ib : r1 - 1) * dim;
+        float4 ra[16], rb[16];
+        const float4 *a4 = reinterpret_cast<const float4 *>(rowa) + sub.f4;
+        const float4 *b4 = reinterpret_cast<const float4 *>(rowb) + sub.f4;
 #pragma unroll
         for (int e = 0; e < 16; e++)
-            if (e < nblk) rr[e] = r4[e * 16];
-#pragma unroll
-        for (int qi = 0; qi < kProbeQB; qi++) {
-            if (qi < cnt) {
-                const float v = exact_rowregs16<DOT>(rr, nblk, row, qlds + static_cast<size_t>(qi) * dim, dim, sub);
-                uint64_t key = kKeyMax;
-                if (live && (lane & 15) == 0) key = make_key(v, static_cast<uint32_t>(i), DOT);
-                tk[qi].offer(key, lane);
+            if (e < nblk) {
+                ra[e] = a4[e * 16];
+                rb[e] = b4[e * 16];
             }
+        // lane 0 of a group carries row i, lane 1 row i + 4: one offer per 8 rows and query
+        auto score = [&](int qi) {
+            float va, vb;
+            exact_rowregs16x2<DOT>(ra, rb, nblk, rowa, rowb, qlds + static_cast<size_t>(qi) * dim, dim, sub, va, vb);
+            uint64_t key = kKeyMax;
+            if ((lane & 15) == 0 && livea) key = make_key(va, static_cast<uint32_t>(ia), DOT);
+            if ((lane & 15) == 1 && liveb) key = make_key(vb, static_cast<uint32_t>(ib), DOT);
+            return key;
+        };
+        if (cnt == kProbeQB) {  // a full group: no per-query branches, the scores of all the queries first
+            uint64_t keys[kProbeQB];
+#pragma unroll
+            for (int qi = 0; qi < kProbeQB; qi++) keys[qi] = score(qi);
+#pragma unroll
+            for (int qi = 0; qi < kProbeQB; qi++) tk[qi].offer(keys[qi], lane);
+        } else {
+#pragma unroll
+            for (int qi = 0; qi < kProbeQB; qi++)
+                if (qi < cnt) tk[qi].offer(score(qi), lane);
         }
     }
 #pragma unroll

@@ -241,31 +241,32 @@ __device__ __forceinline__ void exact_l2_both16(const float *__restrict__ row,
 
 // One pair with the row already in registers (dim <= 1024, dim % 4 == 0: 16 float4 per lane of the
 // 16-lane group, loaded by the caller) and the query in LDS; kPair order.
+typedef float exact_f2 __attribute__((ext_vector_type(2)));
 template <bool DOT>
 __device__ __forceinline__ float exact_rowregs16(const float4 (&rr)[16], int nblk, const float *__restrict__ row,
                                                  const float *__restrict__ q, int dim, Sub16 sub)
 {
-    float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    // the four accumulator chains of a lane go through the packed fp32 ops two at a time
+    // (v_pk_add_f32 / v_pk_fma_f32): every half is the IEEE operation of its own chain
+    exact_f2 lo = {0.0f, 0.0f}, hi = {0.0f, 0.0f};
     const float4 *q4 = reinterpret_cast<const float4 *>(q) + sub.f4;
 #pragma unroll
     for (int e = 0; e < 16; e++) {
         if (e < nblk) {
             const float4 a = q4[e * 16];
             const float4 b = rr[e];
+            const exact_f2 alo = {a.x, a.y}, ahi = {a.z, a.w}, blo = {b.x, b.y}, bhi = {b.z, b.w};
             if (DOT) {
-                acc[0] = __builtin_fmaf(a.x, b.x, acc[0]);
-                acc[1] = __builtin_fmaf(a.y, b.y, acc[1]);
-                acc[2] = __builtin_fmaf(a.z, b.z, acc[2]);
-                acc[3] = __builtin_fmaf(a.w, b.w, acc[3]);
+                lo = __builtin_elementwise_fma(alo, blo, lo);
+                hi = __builtin_elementwise_fma(ahi, bhi, hi);
             } else {
-                const float d0 = a.x - b.x, d1 = a.y - b.y, d2 = a.z - b.z, d3 = a.w - b.w;
-                acc[0] = __builtin_fmaf(d0, d0, acc[0]);
-                acc[1] = __builtin_fmaf(d1, d1, acc[1]);
-                acc[2] = __builtin_fmaf(d2, d2, acc[2]);
-                acc[3] = __builtin_fmaf(d3, d3, acc[3]);
+                const exact_f2 dlo = alo - blo, dhi = ahi - bhi;
+                lo = __builtin_elementwise_fma(dlo, dlo, lo);
+                hi = __builtin_elementwise_fma(dhi, dhi, hi);
             }
         }
     }
+    const float acc[4] = {lo.x, lo.y, hi.x, hi.y};
     float b[4];
 #pragma unroll
     for (int t = 0; t < 4; t++) {
@@ -284,6 +285,64 @@ __device__ __forceinline__ float exact_rowregs16(const float4 (&rr)[16], int nbl
         }
     }
     return total;
+}
+
+// The same for TWO rows held in registers: every LDS read of the query serves both rows (LDS
+// bandwidth, not VALU issue, bounds the one-row form once several queries share a row pass).
+template <bool DOT>
+__device__ __forceinline__ void exact_rowregs16x2(const float4 (&ra)[16], const float4 (&rb)[16], int nblk,
+                                                  const float *__restrict__ rowa, const float *__restrict__ rowb,
+                                                  const float *__restrict__ q, int dim, Sub16 sub, float &va, float &vb)
+{
+    exact_f2 alo_acc = {0.0f, 0.0f}, ahi_acc = {0.0f, 0.0f}, blo_acc = {0.0f, 0.0f}, bhi_acc = {0.0f, 0.0f};
+    const float4 *q4 = reinterpret_cast<const float4 *>(q) + sub.f4;
+#pragma unroll
+    for (int e = 0; e < 16; e++) {
+        if (e < nblk) {
+            const float4 x = q4[e * 16];
+            const exact_f2 xlo = {x.x, x.y}, xhi = {x.z, x.w};
+            const exact_f2 alo = {ra[e].x, ra[e].y}, ahi = {ra[e].z, ra[e].w};
+            const exact_f2 blo = {rb[e].x, rb[e].y}, bhi = {rb[e].z, rb[e].w};
+            if (DOT) {
+                alo_acc = __builtin_elementwise_fma(xlo, alo, alo_acc);
+                ahi_acc = __builtin_elementwise_fma(xhi, ahi, ahi_acc);
+                blo_acc = __builtin_elementwise_fma(xlo, blo, blo_acc);
+                bhi_acc = __builtin_elementwise_fma(xhi, bhi, bhi_acc);
+            } else {
+                const exact_f2 d0 = xlo - alo, d1 = xhi - ahi, d2 = xlo - blo, d3 = xhi - bhi;
+                alo_acc = __builtin_elementwise_fma(d0, d0, alo_acc);
+                ahi_acc = __builtin_elementwise_fma(d1, d1, ahi_acc);
+                blo_acc = __builtin_elementwise_fma(d2, d2, blo_acc);
+                bhi_acc = __builtin_elementwise_fma(d3, d3, bhi_acc);
+            }
+        }
+    }
+    const float acc[2][4] = {{alo_acc.x, alo_acc.y, ahi_acc.x, ahi_acc.y}, {blo_acc.x, blo_acc.y, bhi_acc.x, bhi_acc.y}};
+    float tot[2];
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+        float b[4];
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const float p = dpp_partner_add<kDppRowHalfMirror>(acc[r][t]);
+            const float s2 = dpp_partner_add<kDppRowMirror>(p);
+            const float a = dpp_partner_add<kDppQuadXor2>(s2);
+            b[t] = dpp_partner_add<kDppQuadXor1>(a);
+        }
+        tot[r] = (b[0] + b[2]) + (b[1] + b[3]);
+    }
+    for (int j = nblk << 6; j < dim; j++) {  // scalar tail (FMA-contracted in the reference)
+        if (DOT) {
+            tot[0] = __builtin_fmaf(q[j], rowa[j], tot[0]);
+            tot[1] = __builtin_fmaf(q[j], rowb[j], tot[1]);
+        } else {
+            const float da = q[j] - rowa[j], db = q[j] - rowb[j];
+            tot[0] = __builtin_fmaf(da, da, tot[0]);
+            tot[1] = __builtin_fmaf(db, db, tot[1]);
+        }
+    }
+    va = tot[0];
+    vb = tot[1];
 }
 
 }  // namespace vg
