@@ -141,7 +141,9 @@ struct AdcShared {
 // or -1 for the generic shape (runtime full groups + tail).
 // SMALLK: k <= 64 — each wave keeps its top-k in registers (WaveTopK) and the scan loop has
 // no workgroup barrier; otherwise candidates go through the shared LDS buffer.
-template <int GF, bool SMALLK>
+// ONCE: one query per pass — nobody re-reads the codes, so they are streamed (load_stream); with several
+// queries the blocks of an XCD share a slice through L2 and the loads stay plain.
+template <int GF, bool SMALLK, bool ONCE>
 __global__ __launch_bounds__(kAdcThreads) void pq_adc_scan_kernel(
     const uint4 *__restrict__ tiles, int64_t n_rows, int64_t n_tiles, int m, int groups,
     const float *__restrict__ tables, int slices, int nq, int k, uint64_t *__restrict__ partial,
@@ -216,7 +218,7 @@ __global__ __launch_bounds__(kAdcThreads) void pq_adc_scan_kernel(
         const int64_t tile0 = min64(t0 + wave, tlast);
         const uint4 *tp0 = tiles + (tile0 * groups) * 64 + lane;
 #pragma unroll
-        for (int g = 0; g < GF; g++) nxt[g] = tp0[g * 64];
+        for (int g = 0; g < GF; g++) nxt[g] = ONCE ? load_stream(tp0 + g * 64) : tp0[g * 64];
     }
     for (int it = 0; it < iters; it++) {
         const int64_t tile = t0 + static_cast<int64_t>(it) * kAdcWaves + wave;
@@ -233,7 +235,7 @@ __global__ __launch_bounds__(kAdcThreads) void pq_adc_scan_kernel(
                     const int64_t tile1 = min64(tile + kAdcWaves, tlast);
                     const uint4 *tn = tiles + (tile1 * groups) * 64 + lane;
 #pragma unroll
-                    for (int g = 0; g < 6; g++) nxt[g] = tn[g * 64];
+                    for (int g = 0; g < 6; g++) nxt[g] = ONCE ? load_stream(tn + g * 64) : tn[g * 64];
                 }
                 // two register sets ping-pong: the next 8 lookups are in flight while the
                 // previous 8 retire (same order of additions per slot: g ascending)
@@ -265,7 +267,7 @@ __global__ __launch_bounds__(kAdcThreads) void pq_adc_scan_kernel(
                     const int64_t tile1 = min64(tile + kAdcWaves, tlast);
                     const uint4 *tn = tiles + (tile1 * groups) * 64 + lane;
 #pragma unroll
-                    for (int g = 0; g < GF; g++) nxt[g] = tn[g * 64];
+                    for (int g = 0; g < GF; g++) nxt[g] = ONCE ? load_stream(tn + g * 64) : tn[g * 64];
                 }
 #pragma unroll
                 for (int g = 0; g < GF; g++) {
@@ -841,7 +843,7 @@ static int32_t launch_scan(const vg_index *idx, const float *tables, int64_t nq,
     const vg_pq *pq = idx->pq;
     size_t lds = static_cast<size_t>(lut_image_words(pq->m)) * sizeof(float) + kAdcBuf * sizeof(uint64_t) +
                  sizeof(AdcShared);
-    auto kern = pq_adc_scan_kernel<GF, SMALLK>;
+    auto kern = nq == 1 ? pq_adc_scan_kernel<GF, SMALLK, true> : pq_adc_scan_kernel<GF, SMALLK, false>;
     VG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
     // grid.x limit is 2^31-1; chunk the queries if needed

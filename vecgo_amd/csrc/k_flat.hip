@@ -352,7 +352,7 @@ __global__ __launch_bounds__(256) void flat_scan_mq_kernel(const float *__restri
         const float4 *r4 = reinterpret_cast<const float4 *>(row) + sub.f4;
 #pragma unroll
         for (int e = 0; e < 16; e++)
-            if (e < nblk) rr[e] = r4[e * 16];
+            if (e < nblk) rr[e] = load_stream(r4 + e * 16);
 #pragma unroll
         for (int qi = 0; qi < kScanQB; qi++) {
             if (qi < nq) {

@@ -184,7 +184,7 @@ __global__ __launch_bounds__(kRqThreads) void rabitq_scan_kernel(
             for (int t = 0; t < kRqTiles; t++) {
                 const uint4 *tp = tiles + ((tile + t * kRqWaves) * 6) * 64 + lane;
 #pragma unroll
-                for (int g = 0; g < 6; g++) c[t][g] = tp[g * 64];
+                for (int g = 0; g < 6; g++) c[t][g] = load_stream(tp + g * 64);
             }
 #pragma unroll
             for (int t = 0; t < kRqTiles; t++) {
@@ -216,7 +216,7 @@ __global__ __launch_bounds__(kRqThreads) void rabitq_scan_kernel(
         const uint4 *tp = tiles + (tile * groups) * 64 + lane;
         int h = 0;
         for (int g = 0; g < groups; g++) {
-            const uint4 c = tp[g * 64];
+            const uint4 c = load_stream(tp + g * 64);
             const uint4 qq = qbits[g];
             h += __popc(c.x ^ qq.x) + __popc(c.y ^ qq.y) + __popc(c.z ^ qq.z) + __popc(c.w ^ qq.w);
         }

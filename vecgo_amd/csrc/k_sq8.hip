@@ -251,14 +251,14 @@ __device__ __forceinline__ float sq8_row_score(const uint4 *__restrict__ tp, int
     uint4 ring[kSqAhead];
     const int glast = groups - 1;
 #pragma unroll
-    for (int a = 0; a < kSqAhead; a++) ring[a] = tp[(a < glast ? a : glast) * 64];
+    for (int a = 0; a < kSqAhead; a++) ring[a] = load_stream(tp + (a < glast ? a : glast) * 64);
     for (int g0 = 0; g0 < full; g0 += kSqAhead) {
 #pragma unroll
         for (int a = 0; a < kSqAhead; a++) {
             const int g = g0 + a;
             const uint4 c = ring[a];
             const int gn = g + kSqAhead;
-            ring[a] = tp[(gn < glast ? gn : glast) * 64];
+            ring[a] = load_stream(tp + (gn < glast ? gn : glast) * 64);
             if (g < full) {
                 if (DOT)
                     run = sq8_dot16(run, c, 16, qv + g * 16, mins + g * 16, inv + g * 16);

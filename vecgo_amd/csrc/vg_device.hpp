@@ -92,6 +92,23 @@ __device__ __forceinline__ uint64_t readlane_u64(uint64_t v, int lane)
     return (static_cast<uint64_t>(hi) << 32) | lo;
 }
 
+// A 16-byte load of data that is read once (a scan's codes / rows): the nontemporal hint keeps the
+// stream from displacing what the kernel does reuse and measures 5 % faster on gfx950 (3 GiB read:
+// 6.62 vs 6.31 TB/s, tools/ubench/stream_read.hip).  HIP's uint4 / float4 are union structs the builtin
+// does not take, hence the native vector types.
+typedef unsigned int vg_u4v __attribute__((ext_vector_type(4)));
+typedef float vg_f4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 load_stream(const uint4 *p)
+{
+    const vg_u4v v = __builtin_nontemporal_load(reinterpret_cast<const vg_u4v *>(p));
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ float4 load_stream(const float4 *p)
+{
+    const vg_f4v v = __builtin_nontemporal_load(reinterpret_cast<const vg_f4v *>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+
 struct WaveTopK {
     uint64_t list;  // lane i: i-th smallest key of this wave so far
     uint64_t tau;   // wave-uniform: key at lane k-1 (kKeyMax until k keys were seen)

@@ -19,6 +19,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include "vg_device.hpp"
+
 namespace vg {
 
 constexpr int kDppQuadXor1 = 0xB1;       // quad_perm [1,0,3,2]
@@ -56,7 +58,7 @@ constexpr int kExactChunkSmall = 4;  // ... and the size tried next for what is 
 // One pair.  `row` and `q` point at dim floats (16-byte aligned when dim % 4 == 0, which the
 // fast path requires; other dims take the scalar route below).  All 16 lanes of the group
 // return the same value.
-template <bool DOT, int MODE>
+template <bool DOT, int MODE, bool STREAM = false>
 __device__ __forceinline__ float exact_pair16(const float *__restrict__ row,
                                               const float *__restrict__ q, int dim, Sub16 sub)
 {
@@ -87,7 +89,7 @@ __device__ __forceinline__ float exact_pair16(const float *__restrict__ row,
 #pragma unroll
         for (int u = 0; u < kExactChunk; u++) {
             a[u] = q4[(e + u) * 16];
-            b[u] = r4[(e + u) * 16];
+            b[u] = STREAM ? load_stream(r4 + (e + u) * 16) : r4[(e + u) * 16];
         }
 #pragma unroll
         for (int u = 0; u < kExactChunk; u++) step(a[u], b[u]);
@@ -97,12 +99,12 @@ __device__ __forceinline__ float exact_pair16(const float *__restrict__ row,
 #pragma unroll
         for (int u = 0; u < kExactChunkSmall; u++) {
             a[u] = q4[(e + u) * 16];
-            b[u] = r4[(e + u) * 16];
+            b[u] = STREAM ? load_stream(r4 + (e + u) * 16) : r4[(e + u) * 16];
         }
 #pragma unroll
         for (int u = 0; u < kExactChunkSmall; u++) step(a[u], b[u]);
     }
-    for (; e < nblk; e++) step(q4[e * 16], r4[e * 16]);
+    for (; e < nblk; e++) step(q4[e * 16], STREAM ? load_stream(r4 + e * 16) : r4[e * 16]);
     float s[4];
 #pragma unroll
     for (int t = 0; t < 4; t++) {
@@ -168,6 +170,7 @@ __device__ __forceinline__ float exact_pair16(const float *__restrict__ row,
 // bounded kernel is non-decreasing in the block index (squares are >= +0 and fp32 FMA / add
 // are monotone), "some 64-block partial > bound" <=> "bnd > bound": the early exit does not
 // have to be replayed.
+template <bool STREAM = false>
 __device__ __forceinline__ void exact_l2_both16(const float *__restrict__ row,
                                                 const float *__restrict__ q, int dim, Sub16 sub,
                                                 float &pair, float &bnd)
@@ -189,7 +192,7 @@ __device__ __forceinline__ void exact_l2_both16(const float *__restrict__ row,
 #pragma unroll
         for (int u = 0; u < kExactChunk; u++) {
             qa[u] = q4[(e + u) * 16];
-            rb[u] = r4[(e + u) * 16];
+            rb[u] = STREAM ? load_stream(r4 + (e + u) * 16) : r4[(e + u) * 16];
         }
 #pragma unroll
         for (int u = 0; u < kExactChunk; u++) step(qa[u], rb[u]);
@@ -199,12 +202,12 @@ __device__ __forceinline__ void exact_l2_both16(const float *__restrict__ row,
 #pragma unroll
         for (int u = 0; u < kExactChunkSmall; u++) {
             qa[u] = q4[(e + u) * 16];
-            rb[u] = r4[(e + u) * 16];
+            rb[u] = STREAM ? load_stream(r4 + (e + u) * 16) : r4[(e + u) * 16];
         }
 #pragma unroll
         for (int u = 0; u < kExactChunkSmall; u++) step(qa[u], rb[u]);
     }
-    for (; e < nblk; e++) step(q4[e * 16], r4[e * 16]);
+    for (; e < nblk; e++) step(q4[e * 16], STREAM ? load_stream(r4 + e * 16) : r4[e * 16]);
     float b[4];
 #pragma unroll
     for (int t = 0; t < 4; t++) {

@@ -289,6 +289,17 @@ __device__ __forceinline__ void glds16(const float *base, uint32_t byte_off, uin
                  : "memory");
 }
 
+// The same with the nontemporal hint, for base rows a kernel reads exactly once (the small-batch tile:
+// one workgroup per row tile, nobody else touches those rows).
+__device__ __forceinline__ void glds16_stream(const float *base, uint32_t byte_off, uint32_t lds_base)
+{
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3 nt\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(byte_off), "s"(lds_base), "s"(base)
+                 : "memory");
+}
+
 template <bool DOT, int MODE, int PROBE = 0>
 __global__ __launch_bounds__(kGemmThreads) void flat_gemm_dma_kernel(
     const float *__restrict__ queries, int64_t nq, const float *__restrict__ base, int64_t n,
@@ -492,7 +503,7 @@ __global__ __launch_bounds__(kGemmThreads) void flat_gemm_dma32_kernel(
 #pragma unroll
             for (int p = 0; p < RB; p++) glds16(queries + k0, aoff[p], a_piece(b, p));
 #pragma unroll
-            for (int p = 0; p < kGemmPasses; p++) glds16(bbase + k0, boff[p], b_piece(b, p));
+            for (int p = 0; p < kGemmPasses; p++) glds16_stream(bbase + k0, boff[p], b_piece(b, p));
         } else {  // ragged K edge; dim % 4 == 0, so a granule is inside or outside as a whole
             const float *zeros = reinterpret_cast<const float *>(&g_gemm_zero16);
             const bool in = k0 + dgl * 4 < dim;
