@@ -47,7 +47,18 @@ __global__ void sq8_minmax_kernel(const float *__restrict__ v, int64_t n, int di
     if (d >= dim) return;
     const int64_t r0 = n * c / chunks, r1 = n * (c + 1) / chunks;
     float mn = kF32Max, mx = -kF32Max;
-    for (int64_t i = r0; i < r1; i++) {
+    int64_t i = r0;
+    for (; i + 8 <= r1; i += 8) {  // 8 rows in flight per thread; the data is read once
+        float x[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) x[u] = __builtin_nontemporal_load(v + (i + u) * dim + d);
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            if (x[u] < mn) mn = x[u];
+            if (x[u] > mx) mx = x[u];
+        }
+    }
+    for (; i < r1; i++) {
         const float x = v[i * dim + d];
         if (x < mn) mn = x;
         if (x > mx) mx = x;
