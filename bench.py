@@ -181,7 +181,7 @@ def adc_scan_roofline(vg, ctx, stream, device):
     achieved = n * m / (kern_ms * 1e-3) / 1e9
     res = {"workload": "pq_adc_scan_10Mx768_m96_K256_k10_nq1", "bound": "hbm", "achieved": achieved,
            "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": achieved / PEAK_HBM_GBS, "traffic": measured_traffic("pq_adc_scan"),
-           "kernel": "pq_adc_scan_kernel<6,true>", "kernel_ms": kern_ms,
+           "kernel": "pq_adc_scan_kernel<6,true,true>", "kernel_ms": kern_ms,
            "bytes_per_launch": n * m, "search_call_ms": e0.elapsed_time(e1) / reps,
            "qps_single_query_passes": 1e3 / (e0.elapsed_time(e1) / reps)}
     idx.close()
