@@ -208,6 +208,7 @@ __global__ __launch_bounds__(kAdcThreads) void pq_adc_scan_kernel(
     // software pipeline: the next tile's 16-byte code words are in flight while this
     // tile's lookups run (GF known at compile time)
     uint4 nxt[GF > 0 ? GF : 1];
+    uint4 nxt2[GF == 6 ? 6 : 1];  // m = 96 single-query passes keep two tiles in flight per wave
     uint32_t rotoff[16];
 #pragma unroll
     for (int sl = 0; sl < 16; sl++) rotoff[sl] = static_cast<uint32_t>(((sl + rot) & 15) * 4);
@@ -219,6 +220,12 @@ __global__ __launch_bounds__(kAdcThreads) void pq_adc_scan_kernel(
         const uint4 *tp0 = tiles + (tile0 * groups) * 64 + lane;
 #pragma unroll
         for (int g = 0; g < GF; g++) nxt[g] = ONCE ? load_stream(tp0 + g * 64) : tp0[g * 64];
+        if (GF == 6 && ONCE) {
+            const int64_t tile1 = min64(t0 + wave + kAdcWaves, tlast);
+            const uint4 *tp1 = tiles + (tile1 * groups) * 64 + lane;
+#pragma unroll
+            for (int g = 0; g < 6; g++) nxt2[g] = load_stream(tp1 + g * 64);
+        }
     }
     for (int it = 0; it < iters; it++) {
         const int64_t tile = t0 + static_cast<int64_t>(it) * kAdcWaves + wave;
@@ -231,11 +238,19 @@ __global__ __launch_bounds__(kAdcThreads) void pq_adc_scan_kernel(
                 uint4 c[6];
 #pragma unroll
                 for (int g = 0; g < 6; g++) c[g] = nxt[g];
-                {
+                if (ONCE) {  // two tiles ahead: ~96 KiB of code loads in flight per CU instead of 48
+                    const int64_t tile2 = min64(tile + 2 * kAdcWaves, tlast);
+                    const uint4 *tn = tiles + (tile2 * groups) * 64 + lane;
+#pragma unroll
+                    for (int g = 0; g < 6; g++) {
+                        nxt[g] = nxt2[g];
+                        nxt2[g] = load_stream(tn + g * 64);
+                    }
+                } else {
                     const int64_t tile1 = min64(tile + kAdcWaves, tlast);
                     const uint4 *tn = tiles + (tile1 * groups) * 64 + lane;
 #pragma unroll
-                    for (int g = 0; g < 6; g++) nxt[g] = ONCE ? load_stream(tn + g * 64) : tn[g * 64];
+                    for (int g = 0; g < 6; g++) nxt[g] = tn[g * 64];
                 }
                 // two register sets ping-pong: the next 8 lookups are in flight while the
                 // previous 8 retire (same order of additions per slot: g ascending)
