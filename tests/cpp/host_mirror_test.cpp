@@ -230,6 +230,25 @@ int main()
         EXPECT(found);
         auto rr = pseg.Rerank(zero.data(), 1, pr.ids.data(), 10, 1);
         EXPECT(rr.ids[0] == 7u && rr.scores[0] == 0.0f);
+
+        // IVF partitions (flat/segment.go:727-749): four row ranges with the first rows of each as
+        // centroids; NProbes 2 scans the two closest partitions only — vs the oracle's restatement
+        const int parts = 4;
+        std::vector<uint32_t> off = {0, 1000, 1900, 3100, 4000};
+        std::vector<float> cent(size_t(parts) * dim);
+        for (int p = 0; p < parts; p++) std::copy_n(base.data() + size_t(off[p]) * dim, dim, cent.data() + size_t(p) * dim);
+        seg.SetPartitions(cent.data(), off.data(), parts);
+        auto probed = seg.SearchProbed(q.data(), nq, k, 2, VG_SCAN_F32);
+        vgo_flat_segment os{};
+        os.n = n; os.dim = dim; os.metric = VGO_METRIC_L2; os.base = base.data();
+        os.num_partitions = parts; os.centroids = cent.data(); os.part_offsets = off.data();
+        for (int i = 0; i < nq; i++) {
+            uint32_t eid[k];
+            float esc[k];
+            EXPECT(vgo_flat_segment_search(&os, q.data() + size_t(i) * dim, k, 2, eid, esc) == k);
+            EXPECT(std::memcmp(eid, probed.ids.data() + size_t(i) * k, sizeof eid) == 0);
+            EXPECT(std::memcmp(esc, probed.scores.data() + size_t(i) * k, sizeof esc) == 0);
+        }
     }
 
     if (g_fail) {
