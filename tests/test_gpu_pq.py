@@ -36,6 +36,7 @@ def unit_vectors(rng, n, dim):
     (100, 32, 4, 256, 5),       # n < k: pq.go:285-291 path
     (500, 768, 96, 64, 3),      # BASELINE sub-dim 8, many sub-quantizers
     (400, 256, 2, 32, 4),       # sub-dim 128 >= 64: 4x16 accumulator order in training
+    (600, 192, 2, 256, 3),      # sub-dim 96 x 256 centroids: 96 KiB of centroids in LDS (generic kernels)
     (9001, 32, 4, 64, 3),       # several 4096-point chunks of the k-means++ sum chain, ragged tail
     (8192, 24, 2, 32, 2),       # whole chunks only; sub-dim 12 takes the generic kernels
 ])

@@ -1,0 +1,96 @@
+"""Randomised differential test of the search entry points against the oracle: odd dims, tiny and
+ragged n, k around n, every metric.  Prints every mismatch with the configuration that produced it;
+exit code 1 if any.  `python tools/fuzz_parity.py [seconds] [seed]`"""
+import sys, time
+from pathlib import Path
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+import numpy as np
+import vecgo_amd as vg
+from oracle import oracle as o
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+rng = np.random.default_rng(seed)
+ctx = vg.Context(0)
+bits = lambda x: np.asarray(x, np.float32).view(np.uint32)
+fails = 0
+runs = 0
+
+
+def compare(tag, cfg, ids, sc, exp):
+    global fails
+    for i, (eid, esc) in enumerate(exp):
+        r = eid.size
+        ok = np.array_equal(ids[i, :r], eid) and np.array_equal(bits(sc[i, :r]), bits(esc)) and \
+            np.all(ids[i, r:] == 0xFFFFFFFF)
+        if not ok:
+            fails += 1
+            print(f"MISMATCH {tag} {cfg} query {i}: got {ids[i]} {sc[i]} want {eid} {esc}", flush=True)
+            return
+
+
+t_end = time.time() + budget
+while time.time() < t_end:
+    runs += 1
+    dim = int(rng.choice([1, 3, 4, 7, 8, 15, 16, 17, 31, 32, 48, 63, 64, 65, 96, 100, 127, 128, 130, 256, 300, 768, 1024, 1100]))
+    n = int(rng.choice([1, 2, 5, 15, 16, 17, 63, 64, 65, 100, 255, 256, 257, 1000, 3000]))
+    nq = int(rng.choice([1, 2, 3, 5, 9, 33, 70]))
+    k = int(rng.choice([1, 2, 5, 10, 31, 32]))
+    metric = int(rng.choice([0, 1, 2]))
+    x = rng.standard_normal((n, dim)).astype(np.float32)
+    if n > 3 and rng.random() < 0.5:
+        x[n // 2] = x[0]                                  # duplicates: ties broken by row id
+    q = rng.standard_normal((nq, dim)).astype(np.float32)
+    cfg = dict(n=n, dim=dim, nq=nq, k=k, metric=metric)
+    idx = vg.Index(ctx, n, dim, vg.Metric(metric))
+    idx.set_vectors(x)
+    which = rng.integers(0, 5)
+    try:
+        if which == 0:
+            ids, sc = idx.search_flat(q, k)
+            compare("flat", cfg, ids, sc, [o.flat_search_f32(x, dim, q[i], k, metric) for i in range(nq)])
+        elif which == 1:
+            parts = int(rng.integers(2, 9))
+            cuts = np.sort(rng.integers(0, n + 1, parts - 1))
+            off = np.concatenate([[0], cuts, [n]]).astype(np.uint32)
+            cent = rng.standard_normal((parts, dim)).astype(np.float32)
+            nprobes = int(rng.integers(0, parts + 2))
+            idx.set_partitions(cent, off)
+            kk = min(k, 64)
+            ids, sc = idx.search_flat_probed(q, kk, nprobes, scan=idx.SCAN_F32)
+            seg = o.FlatSegment(x, dim, metric=metric, centroids=cent, part_offsets=off)
+            compare("probed", dict(cfg, parts=parts, nprobes=nprobes, off=off.tolist()), ids, sc,
+                    [seg.search(q[i], kk, nprobes) for i in range(nq)])
+        elif which == 2 and metric != 1:
+            sq = vg.ScalarQuantizer(ctx, dim); sq.train(x)
+            ref = o.ScalarQuantizer(dim); ref.train(x)
+            codes = sq.encode(x)
+            idx.set_sq8_codes(sq, codes)
+            ids, sc = idx.search_sq8(q, k)
+            seg = o.FlatSegment(x, dim, metric=metric, sq=ref, codes=codes)
+            compare("sq8", cfg, ids, sc, [seg.search(q[i], k) for i in range(nq)])
+        elif which == 3 and metric == 0:
+            codes = vg.RaBitQuantizer(ctx, dim).encode(x)
+            idx.set_rabitq_codes(codes)
+            ids, sc = idx.search_rabitq(q, k)
+            compare("rabitq", cfg, ids, sc, [o.flat_search_rabitq(codes, dim, q[i], k) for i in range(nq)])
+        elif which == 4 and metric == 0 and n >= 256:
+            ms = [d for d in (1, 2, 4, 8, 16, 20, 96) if dim % d == 0 and dim // d <= 152]  # K*subdim*4 <= 152 KiB of LDS
+            if not ms:
+                idx.close()
+                continue
+            m = int(rng.choice(ms))
+            pq = vg.ProductQuantizer(ctx, dim, m, 256)
+            pq.train(x, iters=2, seed=int(rng.integers(1, 100)))
+            codes = pq.encode(x)
+            cb, scales, offsets = pq.codebooks()
+            opq = o.ProductQuantizer(dim, m, 256); opq.set_codebooks(cb, scales, offsets)
+            idx.set_pq_codes(pq, codes)
+            ids, sc = idx.search_pq_adc(q, k)
+            compare("pq_adc", dict(cfg, m=m), ids, sc, [o.flat_search_pq(opq, codes, q[i], k) for i in range(nq)])
+    except vg.VecgoHipError as e:
+        fails += 1
+        print(f"ERROR {cfg} which={which}: {e}", flush=True)
+    idx.close()
+print(f"{runs} configurations, {fails} failures")
+sys.exit(1 if fails else 0)

@@ -756,7 +756,11 @@ VG_API int32_t vg_pq_train_subset(vg_pq *pq, const float *vectors, int64_t n, in
     VG_LAUNCH(vg::pq_slab_kernel, dim3(static_cast<unsigned>((n * sd + 255) / 256), m), dim3(256), 0, st, v.ptr, n, dim,
               sd, sub_begin, slabs.ptr);
     const size_t lds = static_cast<size_t>(k) * sd * sizeof(float);
-    VG_CHECK(lds <= 64 * 1024, VG_ERR_UNSUPPORTED, "vg_pq_train: codebook of one sub-quantizer exceeds 64 KiB");
+    // one sub-quantizer's centroids live in LDS during assignment: up to 152 KiB of the CU's 160
+    VG_CHECK(lds <= 152 * 1024, VG_ERR_UNSUPPORTED, "vg_pq_train: codebook of one sub-quantizer exceeds 152 KiB");
+    if (lds > 48 * 1024)
+        VG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(vg::pq_assign_kernel),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
     const unsigned gx = static_cast<unsigned>((n + 255) / 256);
     const unsigned gx_vec = static_cast<unsigned>((n + 256 * vg::kAssignRows - 1) / (256 * vg::kAssignRows));
     const unsigned ux = static_cast<unsigned>((k * sd + 255) / 256);
@@ -815,7 +819,10 @@ VG_API int32_t vg_pq_encode(vg_pq *pq, const float *vectors, int64_t n, uint8_t 
     VG_TRY(v.init(vectors, static_cast<size_t>(n) * pq->dim, st));
     VG_TRY(c.init(codes, static_cast<size_t>(n) * pq->m, st));
     const size_t lds = static_cast<size_t>(pq->k) * pq->subdim * sizeof(float);
-    VG_CHECK(lds <= 64 * 1024, VG_ERR_UNSUPPORTED, "vg_pq_encode: codebook of one sub-quantizer exceeds 64 KiB");
+    VG_CHECK(lds <= 152 * 1024, VG_ERR_UNSUPPORTED, "vg_pq_encode: codebook of one sub-quantizer exceeds 152 KiB");
+    if (lds > 48 * 1024)
+        VG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(vg::pq_encode_kernel),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
     // grid.y = m <= 65535 is guaranteed by dim limits; grid.x up to 2^31
     const bool vec_ok = pq->dim % 4 == 0 && (reinterpret_cast<uintptr_t>(v.ptr) & 15) == 0;
     const unsigned gx_vec = static_cast<unsigned>((n + 256 * vg::kEncRows - 1) / (256 * vg::kEncRows));
