@@ -7,6 +7,7 @@ sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
 import numpy as np
 import vecgo_amd as vg
 from oracle import oracle as o
+from tests import graphs
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
@@ -44,7 +45,7 @@ while time.time() < t_end:
     cfg = dict(n=n, dim=dim, nq=nq, k=k, metric=metric)
     idx = vg.Index(ctx, n, dim, vg.Metric(metric))
     idx.set_vectors(x)
-    which = rng.integers(0, 5)
+    which = rng.integers(0, 7)
     try:
         if which == 0:
             ids, sc = idx.search_flat(q, k)
@@ -88,6 +89,31 @@ while time.time() < t_end:
             idx.set_pq_codes(pq, codes)
             ids, sc = idx.search_pq_adc(q, k)
             compare("pq_adc", dict(cfg, m=m), ids, sc, [o.flat_search_pq(opq, codes, q[i], k) for i in range(nq)])
+        elif which == 5 and n >= 16:
+            gm = int(rng.choice([4, 8, 16]))
+            l0, upper, entry = graphs.build_hnsw(x, m=gm, seed=int(rng.integers(0, 1000)))
+            ef = int(rng.choice([1, 8, 33, 100, 300]))
+            kk = min(k, 64)
+            oidx = o.HnswIndex(x, dim, l0, upper, entry, metric=metric)
+            idx.set_hnsw_graph(l0, upper, entry, m=gm)
+            ids, sc, st = idx.search_hnsw(q, kk, ef, stats=True)
+            exp = [oidx.search(q[i], kk, ef) for i in range(nq)]
+            compare("hnsw", dict(cfg, m=gm, ef=ef), ids, sc, [(e[0], e[1]) for e in exp])
+            for i in range(nq):
+                est = exp[i][2]
+                want = (est.nodes_visited, est.distance_computations, est.distance_short_circuits, est.pops)
+                if tuple(int(v) for v in st[i]) != want:
+                    fails += 1
+                    print(f"STATS MISMATCH hnsw {cfg} m={gm} ef={ef} query {i}: {st[i]} want {want}", flush=True)
+                    break
+        elif which == 6 and n >= 16 and metric != 1:
+            r = int(rng.choice([8, 16, 32]))
+            g, entry = graphs.build_vamana(x, r=r, seed=int(rng.integers(0, 1000)))
+            kk = min(k, 64)
+            oidx = o.VamanaIndex(g, entry, dim, kind=0, metric=metric, base=x)
+            idx.set_vamana_graph(g, entry)
+            ids, sc, st = idx.search_vamana(q, kk, kind=0, stats=True)
+            compare("vamana", dict(cfg, r=r), ids, sc, [oidx.search(q[i], kk)[:2] for i in range(nq)])
     except vg.VecgoHipError as e:
         fails += 1
         print(f"ERROR {cfg} which={which}: {e}", flush=True)
