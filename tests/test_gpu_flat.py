@@ -181,3 +181,26 @@ def test_flat_errors(vg, ctx):
     with pytest.raises(vg.VecgoHipError) as e:  # distance.go:103-105
         vg.Index(ctx, 10, 16, vg.Metric.HAMMING).set_vectors(np.zeros((10, 16), np.float32))
     assert e.value.status == -5
+
+
+@pytest.mark.parametrize("n,dim,nq,k,metric", [(3000, 128, 20, 64, 0), (2500, 768, 9, 40, 2), (1500, 100, 6, 50, 0),
+                                               (700, 30, 3, 33, 1), (40, 64, 5, 64, 0)])
+def test_k_above_the_gemm_budget(vg, ctx, n, dim, nq, k, metric):
+    """32 < k <= 64: the GEMM path proves at most 32 results per query, larger k goes through the
+    exhaustive exact scan (register scan for 16-byte aligned rows of 64..1024 floats, the generic exact
+    kernel otherwise) and matches the oracle like every other k."""
+    rng = np.random.default_rng(n + dim + k)
+    x = rng.standard_normal((n, dim)).astype(np.float32)
+    x[n // 3] = x[5]
+    q = rng.standard_normal((nq, dim)).astype(np.float32)
+    idx = vg.Index(ctx, n, dim, vg.Metric(metric))
+    idx.set_vectors(x)
+    ids, sc = idx.search_flat(q, k)
+    for i in range(nq):
+        eid, esc = o.flat_search_f32(x, dim, q[i], k, metric)
+        r = eid.size
+        assert np.array_equal(ids[i, :r], eid), (i, ids[i], eid)
+        assert np.array_equal(sc[i, :r].view(np.uint32), esc.view(np.uint32))
+        assert np.all(ids[i, r:] == 0xFFFFFFFF)
+    with pytest.raises(vg.VecgoHipError):
+        idx.search_flat(q, 65)

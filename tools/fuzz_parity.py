@@ -36,7 +36,7 @@ while time.time() < t_end:
     dim = int(rng.choice([1, 3, 4, 7, 8, 15, 16, 17, 31, 32, 48, 63, 64, 65, 96, 100, 127, 128, 130, 256, 300, 768, 1024, 1100]))
     n = int(rng.choice([1, 2, 5, 15, 16, 17, 63, 64, 65, 100, 255, 256, 257, 1000, 3000]))
     nq = int(rng.choice([1, 2, 3, 5, 9, 33, 70]))
-    k = int(rng.choice([1, 2, 5, 10, 31, 32]))
+    k = int(rng.choice([1, 2, 5, 10, 31, 32, 33, 64]))
     metric = int(rng.choice([0, 1, 2]))
     x = rng.standard_normal((n, dim)).astype(np.float32)
     if n > 3 and rng.random() < 0.5:

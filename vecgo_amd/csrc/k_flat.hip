@@ -397,7 +397,7 @@ VG_API int32_t vg_search_flat(vg_index *idx, const float *queries, int64_t nq, i
     VG_CHECK(idx->metric != VG_METRIC_HAMMING, VG_ERR_UNSUPPORTED, "unsupported metric for float32: Hamming");
     VG_CHECK(idx->n == 0 || idx->d_vectors, VG_ERR_NOT_READY, "vg_search_flat: index has no fp32 vectors");
     VG_CHECK(queries && ids && scores, VG_ERR_INVALID_ARG, "vg_search_flat: NULL buffer");
-    VG_CHECK(k <= 32, VG_ERR_UNSUPPORTED, "vg_search_flat: k=%d exceeds 32", k);
+    VG_CHECK(k <= 64, VG_ERR_UNSUPPORTED, "vg_search_flat: k=%d exceeds 64", k);
     VG_HIP(hipSetDevice(idx->ctx->device));
     hipStream_t st = vg::pick_stream(idx->ctx, stream);
     const bool dot = idx->metric != VG_METRIC_L2;
@@ -417,10 +417,11 @@ VG_API int32_t vg_search_flat(vg_index *idx, const float *queries, int64_t nq, i
         VG_TRY(none.init(static_cast<size_t>(nq) * k, st));
         VG_HIP(hipMemsetAsync(none.ptr, 0xFF, static_cast<size_t>(nq) * k * 8, st));
         VG_TRY(vg::launch_topk_merge(none.ptr, nq, 1, k, dot, oid.ptr, osc.ptr, st));
-    } else if (nq <= vg::kScanMaxBatch && dim % 4 == 0 && dim <= 1024 && dim >= 64 && !getenv("VG_FLAT_NO_SCAN") &&
+    } else if ((nq <= vg::kScanMaxBatch || k > 32) && dim % 4 == 0 && dim <= 1024 && dim >= 64 && !getenv("VG_FLAT_NO_SCAN") &&
                !getenv("VG_FLAT_FORCE_EXACT") && !getenv("VG_FLAT_UNFUSED") &&
                (reinterpret_cast<uintptr_t>(idx->d_vectors) & 15) == 0) {
-        // small batch: HBM-bound exact scan, kScanQB queries per pass over the rows
+        // small batch: HBM-bound exact scan, kScanQB queries per pass over the rows.  Also every batch with
+        // 32 < k <= 64: the GEMM path nominates 64 candidates per query and proves the best 32 of them
         const int slices = static_cast<int>(std::min<int64_t>(4 * idx->ctx->compute_units, std::max<int64_t>(1, n / 64)));
         vg::ArenaCall ar(idx->ctx, st);
         const int i_partial = ar.add(sizeof(uint64_t) * static_cast<size_t>(nq) * slices * k);
@@ -440,6 +441,33 @@ VG_API int32_t vg_search_flat(vg_index *idx, const float *queries, int64_t nq, i
         VG_TRY(vg::launch_topk_merge(partial, nq, slices, k, dot, oid.ptr, osc.ptr, st));
         VG_LAUNCH(vg::flat_todo_kernel, dim3(1), dim3(256), 0, st, nullptr, nullptr, static_cast<int>(nq), nullptr,
                   idx->d_flat_stats);
+    } else if (k > 32) {
+        // 32 < k <= 64 on rows the register scan does not take (dim % 4, dim < 64 or > 1024): the
+        // exhaustive exact kernel for every query, one pass over the rows per query
+        const int ex_slices = static_cast<int>(std::min<int64_t>(256, std::max<int64_t>(1, n / 64)));
+        const int64_t qc = std::min<int64_t>(nq, 4096);
+        vg::ArenaCall ar(idx->ctx, st);
+        const int i_flags = ar.add(sizeof(int) * (static_cast<size_t>(qc) + 1));
+        const int i_todo = ar.add(sizeof(int) * (static_cast<size_t>(qc) + 1));
+        const int i_fpartial = ar.add(sizeof(uint64_t) * static_cast<size_t>(qc) * ex_slices * k);
+        VG_TRY(ar.commit());
+        int *flags = ar.get<int>(i_flags), *todo = ar.get<int>(i_todo);
+        uint64_t *fpartial = ar.get<uint64_t>(i_fpartial);
+        VG_HIP(hipMemsetAsync(flags, 0, sizeof(int) * static_cast<size_t>(qc), st));
+        VG_HIP(hipMemsetAsync(flags + qc, 1, sizeof(int), st));  // "every query" switch of flat_todo_kernel
+        for (int64_t q0 = 0; q0 < nq; q0 += qc) {
+            const int64_t cnt = std::min(qc, nq - q0);
+            VG_LAUNCH(vg::flat_todo_kernel, dim3(1), dim3(256), 0, st, flags, flags + qc, static_cast<int>(cnt), todo,
+                      idx->d_flat_stats);
+            const unsigned slots = static_cast<unsigned>(std::min<int64_t>(cnt, vg::kExactSlots));
+            if (dot)
+                VG_LAUNCH(vg::flat_exact_kernel<true>, dim3(ex_slices, slots), dim3(256), 0, st, idx->d_vectors, n, dim,
+                          q.ptr + q0 * dim, todo, ex_slices, k, fpartial);
+            else
+                VG_LAUNCH(vg::flat_exact_kernel<false>, dim3(ex_slices, slots), dim3(256), 0, st, idx->d_vectors, n, dim,
+                          q.ptr + q0 * dim, todo, ex_slices, k, fpartial);
+            VG_TRY(vg::launch_topk_merge(fpartial, cnt, ex_slices, k, dot, oid.ptr + q0 * k, osc.ptr + q0 * k, st));
+        }
     } else {
         const char *unfused_env = getenv("VG_FLAT_UNFUSED");  // test hook: materialise the score matrix
         const bool fused = !(unfused_env && unfused_env[0] == '1');
