@@ -232,3 +232,45 @@ def test_sq8_scan_10m_x_768(vg, ctx):
     d = sq.l2_distance_batch(q[:1], codes[2_000_000:2_200_000])
     better = torch.nonzero(d < float(np_(sc)[0, k - 1])).flatten() + 2_000_000
     assert set(np_(better).tolist()) <= set(hid[0].tolist())
+
+
+def test_partition_probed_flat_1m_x_768(vg, ctx):
+    """flat.Segment.Search over a compacted-size flat segment (flat/segment.go:727-749): 1M x 768 in
+    rows/8192 = 122 k-means partitions (trained, assigned and grouped on the GPU), 96 queries.
+    The oracle replays whole queries over just the probed partitions (2 x ~8k rows each), the rest is
+    checked through properties: probed rows only, ordered, idempotent, grouped == pair-by-pair scan."""
+    n, dim, nq, k, nprobes = 1_000_000, 768, 96, 10, 2
+    g = torch.Generator(device="cuda"); g.manual_seed(20260131)
+    base = torch.randn(n, dim, device="cuda", generator=g)
+    q = torch.randn(nq, dim, device="cuda", generator=g)
+    parts = n // 8192
+    cent = vg.kmeans_train(ctx, base, dim, parts, max_iter=4, seed=5)
+    assign = vg.kmeans_assign(ctx, base, cent, dim).to(torch.int64)
+    order = torch.argsort(assign, stable=True)
+    base = base[order].contiguous()
+    off = np.concatenate([[0], np.cumsum(torch.bincount(assign, minlength=parts).cpu().numpy())]).astype(np.uint32)
+    cent_h = cent.cpu().numpy()
+    idx = vg.Index(ctx, n, dim); idx.set_vectors(base); idx.set_partitions(cent_h, off)
+    ids, sc = idx.search_flat_probed(q, k, nprobes, scan=idx.SCAN_F32)
+    ids2, sc2 = idx.search_flat_probed(q, k, nprobes, scan=idx.SCAN_F32)
+    assert torch.equal(ids, ids2) and torch.equal(sc.view(torch.int32), sc2.view(torch.int32))
+    assert_ordered(ids, sc)
+    os.environ["VG_PROBE_NO_GROUP"] = "1"
+    try:
+        pid, psc = idx.search_flat_probed(q, k, nprobes, scan=idx.SCAN_F32)
+    finally:
+        del os.environ["VG_PROBE_NO_GROUP"]
+    assert torch.equal(ids, pid) and torch.equal(sc.view(torch.int32), psc.view(torch.int32))
+    ids_h = np_(ids).view(np.uint32); sc_h = np_(sc); q_h = np_(q)
+    for i in range(0, nq, 12):  # whole-query replay by the oracle on the probed partitions' rows
+        probed = o.find_closest_centroids(q_h[i], cent_h, dim, nprobes)
+        rows = np.concatenate([np.arange(off[p], off[p + 1]) for p in probed])
+        assert set(ids_h[i].tolist()) <= set(rows.tolist())
+        sub = np_(base[torch.as_tensor(rows, device="cuda")])
+        eid, esc = o.flat_search_f32(sub, dim, q_h[i], k)
+        assert np.array_equal(rows[eid], ids_h[i]) and np.array_equal(bits(esc), bits(sc_h[i]))
+    # one probe of every query = the reference's default (NProbes <= 0 -> 1)
+    d_ids, d_sc = idx.search_flat_probed(q, k, 0, scan=idx.SCAN_F32)
+    o_ids, o_sc = idx.search_flat_probed(q, k, 1, scan=idx.SCAN_F32)
+    assert torch.equal(d_ids, o_ids) and torch.equal(d_sc.view(torch.int32), o_sc.view(torch.int32))
+    idx.close()
