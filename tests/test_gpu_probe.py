@@ -119,6 +119,16 @@ def test_probed_sq8_scan(vg, ctx, n, dim, parts, metric):
     for nprobes, k in ((1, 10), (3, 33), (parts, 64)):
         ids, sc = idx.search_flat_probed(q, k, nprobes, scan=idx.SCAN_SQ8)
         check(ids, sc, seg, q, k, nprobes)
+    # a batch with full groups of queries per partition: codes decoded once per group of 8 queries
+    many = rng.standard_normal((120, dim)).astype(np.float32)
+    ids, sc = idx.search_flat_probed(many, 10, 2, scan=idx.SCAN_SQ8)
+    check(ids[:6], sc[:6], seg, many[:6], 10, 2)
+    os.environ["VG_PROBE_NO_GROUP"] = "1"
+    try:
+        pid, psc = idx.search_flat_probed(many, 10, 2, scan=idx.SCAN_SQ8)
+    finally:
+        del os.environ["VG_PROBE_NO_GROUP"]
+    assert np.array_equal(ids, pid) and np.array_equal(bits(sc), bits(psc))
 
 
 def test_partitioned_segment_file(vg, ctx):

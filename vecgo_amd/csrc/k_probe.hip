@@ -24,6 +24,9 @@ int32_t launch_probe_scan_adc(const vg_index *idx, const float *tables, const ui
                               int split, int k, uint64_t *partial, hipStream_t st);
 int32_t launch_probe_scan_sq8(const vg_index *idx, const float *queries, const uint32_t *probes, int64_t nq, int np,
                               int sub, int k, uint64_t *partial, hipStream_t st);
+int32_t launch_probe_scan_sq8_grouped(const vg_index *idx, const float *queries, const uint32_t *pair_of,
+                                      const ProbeGroup *groups, const uint32_t *ngroups, unsigned gmax, int np, int sub,
+                                      int k, uint64_t *partial, hipStream_t st);
 
 // ---- 1. the nprobes closest centroids (kmeans.go:217-280) -----------------------------------------
 // 16 lanes per centroid, batch-kernel order; for Dot / Cosine the reference sorts -dot ascending,
@@ -93,12 +96,6 @@ __global__ __launch_bounds__(256) void probe_scan_f32_kernel(const float *__rest
 // by partition and cut into groups of up to kProbeQB; a workgroup then loads each row of its slice
 // ONCE into registers and scores it against the group's queries held in LDS (the multi-query scan of
 // k_flat.hip), instead of one pass over the partition per pair.
-constexpr int kProbeQB = 8;
-struct ProbeGroup {
-    uint32_t part;   // partition
-    uint32_t first;  // first entry of the group in pair_of[]
-    uint32_t count;  // 1..kProbeQB
-};
 
 // one workgroup: bucket the pairs by partition, cut the buckets into groups.  counts[parts + 1] is
 // zeroed by the caller; cursor / gstart are scratch of parts + 1 words; ngroups[0] receives the total.
@@ -313,8 +310,13 @@ VG_API int32_t vg_search_flat_probed(vg_index *idx, const float *queries, int64_
     // fp32: with enough pairs the queries are grouped by partition (rows read once per group); the
     // row-in-registers scan needs 16-byte aligned rows of at most 1024 floats
     const char *nogroup = getenv("VG_PROBE_NO_GROUP");  // test hook: one pass per (query, probe) pair
-    const bool grouped = scan == VG_SCAN_F32 && pairs >= 16 && idx->dim % 4 == 0 && idx->dim <= 1024 &&
-                         (reinterpret_cast<uintptr_t>(idx->d_vectors) & 15) == 0 && !(nogroup && nogroup[0] == '1');
+    const bool group_ok = pairs >= 16 && !(nogroup && nogroup[0] == '1');
+    const bool grouped_f32 = scan == VG_SCAN_F32 && group_ok && idx->dim % 4 == 0 && idx->dim <= 1024 &&
+                             (reinterpret_cast<uintptr_t>(idx->d_vectors) & 15) == 0;
+    // SQ8: the group's queries (padded to whole 16-dimension groups) have to fit LDS next to the merge scratch
+    const bool grouped_sq8 = scan == VG_SCAN_SQ8 && group_ok &&
+                             sizeof(float) * vg::kProbeQB * static_cast<size_t>(idx->sq_groups) * 16 <= 128 * 1024;
+    const bool grouped = grouped_f32 || grouped_sq8;
     const int want = 4 * idx->ctx->compute_units;
     int sub = static_cast<int>(std::min<int64_t>(32, std::max<int64_t>(1, (want + pairs - 1) / pairs)));
     int split = static_cast<int>(std::min<int64_t>(np, std::max<int64_t>(1, (idx->ctx->compute_units + nq - 1) / nq)));
@@ -354,7 +356,7 @@ VG_API int32_t vg_search_flat_probed(vg_index *idx, const float *queries, int64_
     else
         VG_LAUNCH(vg::probe_select_kernel<false>, dim3(static_cast<unsigned>(nq)), dim3(256), 0, st, q.ptr, idx->dim,
                   idx->d_centroids, idx->num_partitions, np, probes);
-    if (scan == VG_SCAN_F32 && grouped) {
+    if (grouped) {
         const size_t lds = sizeof(float) * vg::kProbeQB * static_cast<size_t>(idx->dim) + 4 * 64 * sizeof(uint64_t) + 64;
         auto kern = dot ? vg::probe_scan_f32_mq_kernel<true> : vg::probe_scan_f32_mq_kernel<false>;
         VG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -366,6 +368,11 @@ VG_API int32_t vg_search_flat_probed(vg_index *idx, const float *queries, int64_
             VG_HIP(hipMemsetAsync(gcounts, 0, sizeof(uint32_t) * (static_cast<size_t>(idx->num_partitions) + 1), st));
             VG_LAUNCH(vg::probe_group_kernel, dim3(1), dim3(1024), 0, st, probes + q0 * np, cpairs, idx->num_partitions,
                       gcounts, gcursor, gstart, pair_of, groups, ngroups);
+            if (grouped_sq8) {
+                VG_TRY(vg::launch_probe_scan_sq8_grouped(idx, q.ptr + q0 * idx->dim, pair_of, groups, ngroups, gmax, np, sub, k,
+                                                         partial + q0 * lists * k, st));
+                continue;
+            }
             vg::ProfScope prof(idx->ctx, "flat_probe", st);
             VG_LAUNCH(kern, dim3(static_cast<unsigned>(sub), gmax), dim3(256), lds, st, idx->d_vectors, idx->dim,
                       q.ptr + q0 * idx->dim, idx->d_part_off, pair_of, groups, ngroups, np, sub, k,

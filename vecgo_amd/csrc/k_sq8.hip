@@ -344,6 +344,174 @@ __global__ __launch_bounds__(kSqThreads) void sq8_probe_kernel(
     wg_rank_merge<kSqWaves>(tk, lists, valid, wave, lane, tid, k, partial + ((q * np + j) * sub + s) * k);
 }
 
+// The same with the pairs grouped by partition (k_probe.hip): a lane decodes its row's 16 codes of a
+// dimension group ONCE and applies them to up to kProbeQB queries held in LDS — the decode (cvt + fma)
+// and the code traffic are shared, each query keeps its own 16 lane accumulators (L2) or running sum
+// (DotProduct), i.e. exactly the arithmetic of sq8_row_score per (row, query).
+constexpr int kSqProbeQ = 4;  // queries per decode pass: 4 x 16 lane accumulators keep two waves per SIMD
+template <bool DOT, bool FULL>
+__device__ __forceinline__ void sq8_row_scores_mq(const uint4 *__restrict__ tp, int groups, int full, int tail, int cnt,
+                                                  const float *qlds, int dimp, const float *__restrict__ mins,
+                                                  const float *__restrict__ inv, float (&total)[kSqProbeQ])
+{
+    float acc[DOT ? 1 : kSqProbeQ][16];
+    float run[kSqProbeQ];
+#pragma unroll
+    for (int qi = 0; qi < kSqProbeQ; qi++) {
+        run[qi] = 0.0f;
+        if (!DOT) {
+#pragma unroll
+            for (int l = 0; l < 16; l++) acc[qi][l] = 0.0f;
+        }
+    }
+    uint4 ring[kSqAhead];
+    const int glast = groups - 1;
+#pragma unroll
+    for (int a = 0; a < kSqAhead; a++) ring[a] = tp[(a < glast ? a : glast) * 64];
+    const int ngr = full + (tail ? 1 : 0);
+    for (int g0 = 0; g0 < ngr; g0 += kSqAhead) {
+#pragma unroll
+        for (int a = 0; a < kSqAhead; a++) {
+            const int g = g0 + a;
+            const uint4 c = ring[a];
+            const int gn = g + kSqAhead;
+            ring[a] = tp[(gn < glast ? gn : glast) * 64];
+            if (g >= ngr) continue;
+            if (g == full && !DOT) continue;  // the L2 tail is added after the lane tree, below
+            const int lim = g < full ? 16 : tail;
+            const uint32_t w[4] = {c.x, c.y, c.z, c.w};
+            const float *mn = mins + g * 16, *iv = inv + g * 16;
+            float rec[16];
+#pragma unroll
+            for (int l = 0; l < 16; l++) {
+                const float cf = static_cast<float>((w[l >> 2] >> (8 * (l & 3))) & 0xFFu);
+                if (DOT) {
+                    const float t = cf * iv[l < lim ? l : 0];
+                    rec[l] = mn[l < lim ? l : 0] + t;
+                } else {
+                    rec[l] = __builtin_fmaf(cf, iv[l], mn[l]);
+                }
+            }
+#pragma unroll
+            for (int qi = 0; qi < kSqProbeQ; qi++) {
+                if (FULL || qi < cnt) {
+                    const float4 *q4 = reinterpret_cast<const float4 *>(qlds + qi * dimp + g * 16);
+                    float qv[16];
+#pragma unroll
+                    for (int t = 0; t < 4; t++) {
+                        const float4 x = q4[t];
+                        qv[4 * t] = x.x; qv[4 * t + 1] = x.y; qv[4 * t + 2] = x.z; qv[4 * t + 3] = x.w;
+                    }
+                    if (DOT) {
+#pragma unroll
+                        for (int l = 0; l < 16; l++)
+                            if (l < lim) {
+                                const float prod = qv[l] * rec[l];
+                                run[qi] = run[qi] + prod;
+                            }
+                    } else {
+#pragma unroll
+                        for (int l = 0; l < 16; l++) {
+                            const float diff = qv[l] - rec[l];
+                            acc[qi][l] = __builtin_fmaf(diff, diff, acc[qi][l]);
+                        }
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int qi = 0; qi < kSqProbeQ; qi++) {
+        if (DOT) {
+            total[qi] = run[qi];
+        } else if (FULL || qi < cnt) {
+            float t = reduce16_regs(acc[qi]);
+            if (tail) t = sq8_tail(t, tp[full * 64], tail, qlds + qi * dimp + full * 16, mins + full * 16, inv + full * 16);
+            total[qi] = t;
+        } else {
+            total[qi] = 0.0f;
+        }
+    }
+}
+
+template <bool DOT>
+__global__ __launch_bounds__(kSqThreads) void sq8_probe_mq_kernel(
+    const uint4 *__restrict__ tiles, int64_t n_rows, int groups, int dim, const float *__restrict__ queries,
+    const float *__restrict__ mins, const float *__restrict__ inv, const uint32_t *__restrict__ part_off,
+    const uint32_t *__restrict__ pair_of, const ProbeGroup *__restrict__ pgroups, const uint32_t *__restrict__ ngroups,
+    int np, int sub, int k, uint64_t *__restrict__ partial)
+{
+    extern __shared__ __attribute__((aligned(16))) float qlds[];  // kProbeQB * dimp floats, then the merge scratch
+    const int dimp = groups * 16;
+    uint64_t *lists = reinterpret_cast<uint64_t *>(qlds + static_cast<size_t>(kProbeQB) * dimp);
+    int *valid = reinterpret_cast<int *>(lists + kSqWaves * 64);
+    __shared__ uint32_t pair[kProbeQB];
+    if (blockIdx.y >= ngroups[0]) return;
+    const ProbeGroup pg = pgroups[blockIdx.y];
+    const int s = blockIdx.x, cnt = static_cast<int>(pg.count);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid < cnt) pair[tid] = pair_of[pg.first + tid];
+    __syncthreads();
+    for (int qi = 0; qi < cnt; qi++) {
+        const float *src = queries + static_cast<int64_t>(pair[qi] / np) * dim;
+        for (int t = tid; t < dimp; t += kSqThreads) qlds[qi * dimp + t] = t < dim ? src[t] : 0.0f;
+    }
+    __syncthreads();
+    const int64_t R0 = part_off[pg.part], R1 = part_off[pg.part + 1];
+    const int64_t tt0 = R0 >> 6, tt1 = (R1 + 63) >> 6;
+    const int64_t t0 = tt0 + (tt1 - tt0) * s / sub, t1 = tt0 + (tt1 - tt0) * (s + 1) / sub;
+    const int full = dim >> 4, tail = dim & 15;
+    WaveTopK tk[kProbeQB];
+#pragma unroll
+    for (int qi = 0; qi < kProbeQB; qi++) tk[qi].init(k);
+    for (int64_t tile = t0 + wave; tile < t1; tile += kSqWaves) {
+        const uint4 *tp = tiles + (tile * groups) * 64 + lane;
+        const int64_t row = tile * 64 + lane;
+        const bool live = row >= R0 && row < R1 && row < n_rows;
+        // the group's queries in passes of kSqProbeQ (the second pass finds the tile's codes in L1 / L2)
+#pragma unroll
+        for (int qb = 0; qb < kProbeQB; qb += kSqProbeQ) {
+            if (qb < cnt) {
+                float total[kSqProbeQ];
+                const int left = cnt - qb;
+                if (left >= kSqProbeQ)
+                    sq8_row_scores_mq<DOT, true>(tp, groups, full, tail, left, qlds + qb * dimp, dimp, mins, inv, total);
+                else
+                    sq8_row_scores_mq<DOT, false>(tp, groups, full, tail, left, qlds + qb * dimp, dimp, mins, inv, total);
+#pragma unroll
+                for (int qi = 0; qi < kSqProbeQ; qi++)
+                    if (qb + qi < cnt)
+                        tk[qb + qi].offer(live ? make_key(total[qi], static_cast<uint32_t>(row), DOT) : kKeyMax, lane);
+            }
+        }
+    }
+#pragma unroll
+    for (int qi = 0; qi < kProbeQB; qi++) {
+        if (qi < cnt) {
+            wg_rank_merge<kSqWaves>(tk[qi], lists, valid, wave, lane, tid, k,
+                                    partial + (static_cast<int64_t>(pair[qi]) * sub + s) * k);
+            __syncthreads();
+        }
+    }
+}
+
+int32_t launch_probe_scan_sq8_grouped(const vg_index *idx, const float *queries, const uint32_t *pair_of,
+                                      const ProbeGroup *groups, const uint32_t *ngroups, unsigned gmax, int np, int sub,
+                                      int k, uint64_t *partial, hipStream_t st)
+{
+    const bool dot = idx->metric != VG_METRIC_L2;
+    auto kern = dot ? sq8_probe_mq_kernel<true> : sq8_probe_mq_kernel<false>;
+    const size_t lds = sizeof(float) * kProbeQB * static_cast<size_t>(idx->sq_groups) * 16 + kSqWaves * 64 * sizeof(uint64_t) + 64;
+    VG_CHECK(lds <= 152 * 1024, VG_ERR_UNSUPPORTED, "sq8 grouped probe: %d dimensions do not fit LDS", idx->dim);
+    VG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               static_cast<int>(lds)));
+    ProfScope prof(idx->ctx, "sq8_probe", st);
+    VG_LAUNCH(kern, dim3(static_cast<unsigned>(sub), gmax), dim3(kSqThreads), lds, st,
+              reinterpret_cast<const uint4 *>(idx->d_sq_tiles), idx->n, idx->sq_groups, idx->dim, queries, idx->sq->d_mins,
+              idx->sq->d_inv, idx->d_part_off, pair_of, groups, ngroups, np, sub, k, partial);
+    return VG_OK;
+}
+
 int32_t launch_probe_scan_sq8(const vg_index *idx, const float *queries, const uint32_t *probes, int64_t nq, int np,
                               int sub, int k, uint64_t *partial, hipStream_t st)
 {

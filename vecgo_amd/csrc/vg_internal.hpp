@@ -284,6 +284,17 @@ struct vg_pq {
 struct vg_sq8;
 struct vg_int4;
 
+namespace vg {
+// Partition-probed scans (k_probe.hip): (query, probe) pairs bucketed by partition and cut into groups
+// of up to kProbeQB pairs; one workgroup scores a slice of the partition's rows against a whole group.
+constexpr int kProbeQB = 8;
+struct ProbeGroup {
+    uint32_t part;   // partition
+    uint32_t first;  // first entry of the group in pair_of[]
+    uint32_t count;  // 1..kProbeQB
+};
+}  // namespace vg
+
 struct vg_index {
     vg_ctx *ctx = nullptr;
     int64_t n = 0;
