@@ -434,6 +434,59 @@ __device__ __forceinline__ void sq8_row_scores_mq(const uint4 *__restrict__ tp, 
     }
 }
 
+// Exhaustive scan of several queries: workgroup = (group of kSqProbeQ queries, slice), every code decoded
+// once per group.  Same block order as sq8_scan_kernel: the groups of one slice share an XCD's L2.
+template <bool DOT>
+__global__ __launch_bounds__(kSqThreads) void sq8_scan_mq_kernel(
+    const uint4 *__restrict__ tiles, int64_t n_rows, int64_t n_tiles, int groups, int dim,
+    const float *__restrict__ queries, const float *__restrict__ mins, const float *__restrict__ inv, int slices,
+    int nq, int k, uint64_t *__restrict__ partial)
+{
+    extern __shared__ __attribute__((aligned(16))) float qlds[];  // kSqProbeQ * dimp floats, then the merge scratch
+    const int dimp = groups * 16;
+    uint64_t *lists = reinterpret_cast<uint64_t *>(qlds + static_cast<size_t>(kSqProbeQ) * dimp);
+    int *valid = reinterpret_cast<int *>(lists + kSqWaves * 64);
+    const int ng = (nq + kSqProbeQ - 1) / kSqProbeQ;
+    const int b = blockIdx.x;
+    const int xcd = b & 7;
+    const int o = b >> 3;
+    const int qg = o % ng;
+    const int s = (o / ng) * 8 + xcd;
+    const int q0 = qg * kSqProbeQ;
+    const int cnt = nq - q0 < kSqProbeQ ? nq - q0 : kSqProbeQ;
+    const int64_t t0 = n_tiles * s / slices, t1 = n_tiles * (s + 1) / slices;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int qi = 0; qi < cnt; qi++) {
+        const float *src = queries + static_cast<int64_t>(q0 + qi) * dim;
+        for (int t = tid; t < dimp; t += kSqThreads) qlds[qi * dimp + t] = t < dim ? src[t] : 0.0f;
+    }
+    __syncthreads();
+    const int full = dim >> 4, tail = dim & 15;
+    WaveTopK tk[kSqProbeQ];
+#pragma unroll
+    for (int qi = 0; qi < kSqProbeQ; qi++) tk[qi].init(k);
+    for (int64_t tile = t0 + wave; tile < t1; tile += kSqWaves) {
+        const uint4 *tp = tiles + (tile * groups) * 64 + lane;
+        float total[kSqProbeQ];
+        if (cnt == kSqProbeQ)
+            sq8_row_scores_mq<DOT, true>(tp, groups, full, tail, cnt, qlds, dimp, mins, inv, total);
+        else
+            sq8_row_scores_mq<DOT, false>(tp, groups, full, tail, cnt, qlds, dimp, mins, inv, total);
+        const int64_t row = tile * 64 + lane;
+#pragma unroll
+        for (int qi = 0; qi < kSqProbeQ; qi++)
+            if (qi < cnt) tk[qi].offer(row < n_rows ? make_key(total[qi], static_cast<uint32_t>(row), DOT) : kKeyMax, lane);
+    }
+#pragma unroll
+    for (int qi = 0; qi < kSqProbeQ; qi++) {
+        if (qi < cnt) {
+            wg_rank_merge<kSqWaves>(tk[qi], lists, valid, wave, lane, tid, k,
+                                    partial + (static_cast<int64_t>(q0 + qi) * slices + s) * k);
+            __syncthreads();
+        }
+    }
+}
+
 template <bool DOT>
 __global__ __launch_bounds__(kSqThreads) void sq8_probe_mq_kernel(
     const uint4 *__restrict__ tiles, int64_t n_rows, int groups, int dim, const float *__restrict__ queries,
@@ -881,20 +934,41 @@ VG_API int32_t vg_search_sq8(vg_index *idx, const float *queries, int64_t nq, in
         VG_HIP(hipMemsetAsync(none.ptr, 0xFF, static_cast<size_t>(nq) * k * 8, st));
         VG_TRY(vg::launch_topk_merge(none.ptr, nq, 1, k, false, oid.ptr, osc.ptr, st));
     } else {
-        const int slices = vg::sq_slices(nq, idx->n_tiles, idx->ctx->compute_units);
+        // two or more queries: groups of kSqProbeQ share every decode (sq8_scan_mq_kernel)
+        const size_t mq_lds = sizeof(float) * vg::kSqProbeQ * static_cast<size_t>(idx->sq_groups) * 16 +
+                              vg::kSqWaves * 64 * sizeof(uint64_t) + 64;
+        const bool mq = nq >= 2 && mq_lds <= 128 * 1024;
+        const int64_t units = mq ? (nq + vg::kSqProbeQ - 1) / vg::kSqProbeQ : nq;  // workgroups per slice
+        const int slices = vg::sq_slices(units, idx->n_tiles, idx->ctx->compute_units);
         vg::ArenaCall ar(idx->ctx, st);
         const int i_partial = ar.add(sizeof(uint64_t) * static_cast<size_t>(nq) * slices * k);
         VG_TRY(ar.commit());
         uint64_t *partial = ar.get<uint64_t>(i_partial);
-        const int64_t max_q = (1ll << 30) / slices;
-        for (int64_t q0 = 0; q0 < nq; q0 += max_q) {
-            const int64_t cnt = nq - q0 < max_q ? nq - q0 : max_q;
-            vg::ProfScope prof(idx->ctx, "sq8_scan", st);
-            auto kern = dot ? vg::sq8_scan_kernel<true> : vg::sq8_scan_kernel<false>;
-            VG_LAUNCH(kern, dim3(static_cast<unsigned>(cnt * slices)), dim3(vg::kSqThreads), 0, st,
-                      reinterpret_cast<const uint4 *>(idx->d_sq_tiles), idx->n, idx->n_tiles, idx->sq_groups, idx->dim,
-                      q.ptr + q0 * idx->dim, idx->sq->d_mins, idx->sq->d_inv, slices, static_cast<int>(cnt), k,
-                      partial + q0 * slices * k);
+        if (mq) {
+            auto kern = dot ? vg::sq8_scan_mq_kernel<true> : vg::sq8_scan_mq_kernel<false>;
+            VG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       static_cast<int>(mq_lds)));
+            const int64_t max_q = ((1ll << 30) / slices) * vg::kSqProbeQ;  // whole groups per launch
+            for (int64_t q0 = 0; q0 < nq; q0 += max_q) {
+                const int64_t cnt = nq - q0 < max_q ? nq - q0 : max_q;
+                const int64_t ng = (cnt + vg::kSqProbeQ - 1) / vg::kSqProbeQ;
+                vg::ProfScope prof(idx->ctx, "sq8_scan", st);
+                VG_LAUNCH(kern, dim3(static_cast<unsigned>(ng * slices)), dim3(vg::kSqThreads), mq_lds, st,
+                          reinterpret_cast<const uint4 *>(idx->d_sq_tiles), idx->n, idx->n_tiles, idx->sq_groups, idx->dim,
+                          q.ptr + q0 * idx->dim, idx->sq->d_mins, idx->sq->d_inv, slices, static_cast<int>(cnt), k,
+                          partial + q0 * slices * k);
+            }
+        } else {
+            const int64_t max_q = (1ll << 30) / slices;
+            for (int64_t q0 = 0; q0 < nq; q0 += max_q) {
+                const int64_t cnt = nq - q0 < max_q ? nq - q0 : max_q;
+                vg::ProfScope prof(idx->ctx, "sq8_scan", st);
+                auto kern = dot ? vg::sq8_scan_kernel<true> : vg::sq8_scan_kernel<false>;
+                VG_LAUNCH(kern, dim3(static_cast<unsigned>(cnt * slices)), dim3(vg::kSqThreads), 0, st,
+                          reinterpret_cast<const uint4 *>(idx->d_sq_tiles), idx->n, idx->n_tiles, idx->sq_groups, idx->dim,
+                          q.ptr + q0 * idx->dim, idx->sq->d_mins, idx->sq->d_inv, slices, static_cast<int>(cnt), k,
+                          partial + q0 * slices * k);
+            }
         }
         VG_TRY(vg::launch_topk_merge(partial, nq, slices, k, dot, oid.ptr, osc.ptr, st));
     }
