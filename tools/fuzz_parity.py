@@ -58,9 +58,31 @@ while time.time() < t_end:
             nprobes = int(rng.integers(0, parts + 2))
             idx.set_partitions(cent, off)
             kk = min(k, 64)
-            ids, sc = idx.search_flat_probed(q, kk, nprobes, scan=idx.SCAN_F32)
-            seg = o.FlatSegment(x, dim, metric=metric, centroids=cent, part_offsets=off)
-            compare("probed", dict(cfg, parts=parts, nprobes=nprobes, off=off.tolist()), ids, sc,
+            kind = int(rng.integers(0, 3))
+            if kind == 1 and metric != 1:        # SQ8 codes: L2Distance / DotProduct by metric
+                sq = vg.ScalarQuantizer(ctx, dim); sq.train(x)
+                ref = o.ScalarQuantizer(dim); ref.train(x)
+                codes = sq.encode(x)
+                idx.set_sq8_codes(sq, codes)
+                ids, sc = idx.search_flat_probed(q, kk, nprobes, scan=idx.SCAN_SQ8)
+                seg = o.FlatSegment(x, dim, metric=metric, sq=ref, codes=codes, centroids=cent, part_offsets=off)
+                tag = "probed_sq8"
+            elif kind == 2 and metric == 0 and n >= 256 and [d for d in (1, 2, 4, 8, 16, 20) if dim % d == 0 and dim // d <= 152]:
+                m = int(rng.choice([d for d in (1, 2, 4, 8, 16, 20) if dim % d == 0 and dim // d <= 152]))
+                pq = vg.ProductQuantizer(ctx, dim, m, 256)
+                pq.train(x, iters=2, seed=3)
+                codes = pq.encode(x)
+                cb, scales, offsets = pq.codebooks()
+                opq = o.ProductQuantizer(dim, m, 256); opq.set_codebooks(cb, scales, offsets)
+                idx.set_pq_codes(pq, codes)
+                ids, sc = idx.search_flat_probed(q, kk, nprobes, scan=idx.SCAN_PQ)
+                seg = o.FlatSegment(x, dim, pq=opq, codes=codes, centroids=cent, part_offsets=off)
+                tag = "probed_pq"
+            else:
+                ids, sc = idx.search_flat_probed(q, kk, nprobes, scan=idx.SCAN_F32)
+                seg = o.FlatSegment(x, dim, metric=metric, centroids=cent, part_offsets=off)
+                tag = "probed"
+            compare(tag, dict(cfg, parts=parts, nprobes=nprobes, off=off.tolist()), ids, sc,
                     [seg.search(q[i], kk, nprobes) for i in range(nq)])
         elif which == 2 and metric != 1:
             sq = vg.ScalarQuantizer(ctx, dim); sq.train(x)
