@@ -382,7 +382,10 @@ int32_t vg_segment_open_flat(vg_ctx *ctx, const void *image, int64_t size, int32
  * follows the segment (SQ8 codes: L2Distance / DotProduct by metric; PQ: table lookups, L2 segments
  * only — see vg_segment.hip; else fp32 rows) and, when the segment has more than one IVF partition,
  * only the nprobes closest partitions are scanned (:727-744; nprobes <= 0 means 1).  k <= 64 and
- * nprobes <= 64 on the partitioned path. */
+ * nprobes <= 64 on the partitioned path.
+ * On a DiskANN segment: diskann.Segment.Search (diskann/segment.go:487-706) = vg_search_vamana with
+ * the distFn of the segment's quantization (RaBitQ, else PQ, else INT4, else fp32); nprobes is unused,
+ * like the search-list size the reference computes and never reads. */
 int32_t vg_segment_search(vg_segment *seg, const float *queries, int64_t nq, int32_t k, int32_t nprobes,
                           uint32_t *ids, float *scores, void *stream);
 /* diskann segment (diskann/format.go:8-119, segment.go:165-440,1393-1408): fp32 rows, the

@@ -100,6 +100,9 @@ def test_diskann_segment_fp32_pq_rabitq(vg, ctx):
             assert np.array_equal(ids[i, :eid.size], eid), (kind, i)
             assert np.array_equal(bits(sc[i, :eid.size]), bits(esc)), (kind, i)
             assert int(st[i, 1]) == est.distance_computations
+        # Segment.search = diskann.Segment.Search: the distFn follows the file's quantization
+        sid, ssc = seg.search(q, k)
+        assert np.array_equal(sid, ids) and np.array_equal(bits(ssc), bits(sc))
         seg.close()
 
 

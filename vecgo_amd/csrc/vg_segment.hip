@@ -203,8 +203,16 @@ VG_API int32_t vg_segment_search(vg_segment *seg, const float *queries, int64_t 
                                  uint32_t *ids, float *scores, void *stream)
 {
     VG_CHECK(seg && seg->idx, VG_ERR_INVALID_ARG, "vg_segment_search: NULL segment");
-    VG_CHECK(seg->info.kind == 0, VG_ERR_UNSUPPORTED,
-             "vg_segment_search: flat segments only (a DiskANN segment is searched with vg_search_vamana)");
+    if (seg->info.kind == 1) {
+        // diskann.Segment.Search (diskann/segment.go:487-706): the search-list size it derives from k and
+        // RefineFactor is never read by searchInternal, so the call is the beam search with the distFn the
+        // segment's quantization selects (:512-588: RaBitQ, else PQ, else INT4, else fp32 rows)
+        const int32_t kind = seg->info.quantization == VG_QUANT_RABITQ ? 2
+                             : seg->info.quantization == VG_QUANT_PQ   ? 1
+                             : seg->info.quantization == VG_QUANT_INT4 ? 3
+                                                                       : 0;
+        return vg_search_vamana(seg->idx, queries, nq, k, kind, ids, scores, nullptr, stream);
+    }
     // flat/segment.go:657-701: SQ8 codes if the segment has them, else PQ table lookups, else fp32 rows
     int32_t scan = VG_SCAN_F32;
     if (seg->info.quantization == VG_QUANT_SQ8) {
