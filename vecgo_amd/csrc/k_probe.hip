@@ -248,10 +248,7 @@ VG_API int32_t vg_index_set_partitions(vg_index *idx, const float *centroids, co
     VG_CHECK(centroids && part_offsets, VG_ERR_INVALID_ARG, "vg_index_set_partitions: NULL buffer");
     // the offsets come from a file: check them once here instead of in every scan
     std::vector<uint32_t> off(static_cast<size_t>(num_partitions) + 1);
-    hipPointerAttribute_t attr;
-    const bool on_device = hipPointerGetAttributes(&attr, part_offsets) == hipSuccess && attr.type == hipMemoryTypeDevice;
-    if (!on_device) (void)hipGetLastError();
-    VG_HIP(hipMemcpy(off.data(), part_offsets, off.size() * sizeof(uint32_t), hipMemcpyDefault));
+    VG_HIP(hipMemcpy(off.data(), part_offsets, off.size() * sizeof(uint32_t), hipMemcpyDefault));  // host or device
     for (size_t p = 0; p + 1 < off.size(); p++)
         VG_CHECK(off[p] <= off[p + 1], VG_ERR_INVALID_ARG, "vg_index_set_partitions: partition offsets decrease at %zu", p);
     VG_CHECK(static_cast<int64_t>(off.back()) <= idx->n, VG_ERR_INVALID_ARG,
