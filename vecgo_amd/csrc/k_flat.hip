@@ -325,6 +325,7 @@ __global__ __launch_bounds__(256) void flat_exact_kernel(const float *__restrict
 // (dim <= 1024: 16 float4 per lane) and scores it against QB queries held in LDS, each in the
 // reference's summation order (vg_exact.hpp, kPair) — exact by construction, no proof step.
 constexpr int kScanQB = 8;        // queries one pass can carry
+constexpr int kGemmMaxK = 48;     // largest k the 64-candidate nomination + proof serves (above: exhaustive scan)
 constexpr int kScanMaxBatch = 4;  // ... and the batch size up to which the scan beats the 32-query GEMM tile
 template <bool DOT>
 __global__ __launch_bounds__(256) void flat_scan_mq_kernel(const float *__restrict__ base, int64_t n, int dim,
@@ -417,11 +418,12 @@ VG_API int32_t vg_search_flat(vg_index *idx, const float *queries, int64_t nq, i
         VG_TRY(none.init(static_cast<size_t>(nq) * k, st));
         VG_HIP(hipMemsetAsync(none.ptr, 0xFF, static_cast<size_t>(nq) * k * 8, st));
         VG_TRY(vg::launch_topk_merge(none.ptr, nq, 1, k, dot, oid.ptr, osc.ptr, st));
-    } else if ((nq <= vg::kScanMaxBatch || k > 32) && dim % 4 == 0 && dim <= 1024 && dim >= 64 && !getenv("VG_FLAT_NO_SCAN") &&
+    } else if ((nq <= vg::kScanMaxBatch || k > vg::kGemmMaxK) && dim % 4 == 0 && dim <= 1024 && dim >= 64 && !getenv("VG_FLAT_NO_SCAN") &&
                !getenv("VG_FLAT_FORCE_EXACT") && !getenv("VG_FLAT_UNFUSED") &&
                (reinterpret_cast<uintptr_t>(idx->d_vectors) & 15) == 0) {
         // small batch: HBM-bound exact scan, kScanQB queries per pass over the rows.  Also every batch with
-        // 32 < k <= 64: the GEMM path nominates 64 candidates per query and proves the best 32 of them
+        // kGemmMaxK < k <= 64: the GEMM path nominates 64 candidates per query; its proof needs a margin
+        // between the k-th exact score and the 64th nominated one, which k close to 64 does not leave
         const int slices = static_cast<int>(std::min<int64_t>(4 * idx->ctx->compute_units, std::max<int64_t>(1, n / 64)));
         vg::ArenaCall ar(idx->ctx, st);
         const int i_partial = ar.add(sizeof(uint64_t) * static_cast<size_t>(nq) * slices * k);
@@ -441,8 +443,8 @@ VG_API int32_t vg_search_flat(vg_index *idx, const float *queries, int64_t nq, i
         VG_TRY(vg::launch_topk_merge(partial, nq, slices, k, dot, oid.ptr, osc.ptr, st));
         VG_LAUNCH(vg::flat_todo_kernel, dim3(1), dim3(256), 0, st, nullptr, nullptr, static_cast<int>(nq), nullptr,
                   idx->d_flat_stats);
-    } else if (k > 32) {
-        // 32 < k <= 64 on rows the register scan does not take (dim % 4, dim < 64 or > 1024): the
+    } else if (k > vg::kGemmMaxK) {
+        // kGemmMaxK < k <= 64 on rows the register scan does not take (dim % 4, dim < 64 or > 1024): the
         // exhaustive exact kernel for every query, one pass over the rows per query
         const int ex_slices = static_cast<int>(std::min<int64_t>(256, std::max<int64_t>(1, n / 64)));
         const int64_t qc = std::min<int64_t>(nq, 4096);
