@@ -1,5 +1,5 @@
 """vg_search_flat by k at 1M x 768, 1024 queries: ms per call and how many queries the proof sent to the
-exhaustive kernel (k <= 48: GEMM nomination of 64 candidates + proof; above: exhaustive scan)."""
+exhaustive kernel (k <= 48: the 64 best GEMM scores are re-scored and proved; above: every appended row)."""
 import sys, time
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parents[1]))

@@ -2,7 +2,8 @@
 //   1. scores[q][n] = ||x_n||^2 - 2 q.x_n  (L2)  or  -q.x_n  (Dot)   fp32 MFMA GEMM
 //   2. per query: the kc smallest scores                              streaming select
 //   3. exact re-scoring of those kc rows in the reference's summation order, top-k by
-//      (Score, RowID), and a proof that no other row can belong to the top-k
+//      (Score, RowID), and a proof that no other row can belong to the top-k (k > 48: every row whose
+//      GEMM score is under the query's threshold is re-scored, the proof is against the threshold)
 //   4. queries whose proof fails are recomputed by the exhaustive exact kernel
 // Steps 1-2 only nominate candidates; every reported id/score comes from step 3/4.
 #include <algorithm>
@@ -280,6 +281,64 @@ __global__ __launch_bounds__(256) void flat_verify_kernel(
     if (lane == 0) fallback[q] = ok ? 0 : 1;
 }
 
+// The same for k beyond the 64-candidate budget: EVERY appended row (GEMM score below the query's
+// threshold, ~500 of them) is re-scored exactly, so the only rows left to argue about are the ones the
+// threshold excluded: the proof compares the k-th exact score with the threshold itself.
+template <bool DOT>
+__global__ __launch_bounds__(256) void flat_verify_all_kernel(
+    const float *__restrict__ base, int dim, const float *__restrict__ queries,
+    const float *__restrict__ norms_max /* [1] */, const uint64_t *__restrict__ cand, const int *__restrict__ counts,
+    int cap, int k, uint32_t *__restrict__ ids, float *__restrict__ scores, int *__restrict__ fallback,
+    const float *__restrict__ thr, int thr_stride, int thr_off)
+{
+    __shared__ uint64_t lists[4 * 64];
+    __shared__ int valid[4];
+    __shared__ uint64_t best[64];
+    const Sub16 sub = Sub16::make(threadIdx.x);
+    const int64_t q = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float *qv = queries + q * dim;
+    const int total = counts[q];
+    const int cnt = total < cap ? total : cap;
+    WaveTopK tk;
+    tk.init(k);
+    for (int c0 = wave * 4; c0 < cnt; c0 += 16) {  // 4 candidates per wave step, one per 16-lane group
+        const int c = c0 + (lane >> 4);
+        uint64_t key = kKeyMax;
+        if (c < cnt) {
+            const uint32_t id = key_row(cand[q * cap + c]);
+            const float v = exact_pair16<DOT, kPair>(base + static_cast<int64_t>(id) * dim, qv, dim, sub);
+            if ((lane & 15) == 0) key = make_key(v, id, DOT);
+        }
+        tk.offer(key, lane);
+    }
+    wg_rank_merge<4>(tk, lists, valid, wave, lane, tid, k, best);
+    __syncthreads();
+    if (tid >= 64) return;
+    float qn = 0.0f;  // ||q||^2 (any order: only feeds the error bound)
+    for (int j = lane; j < dim; j += 64) qn = __builtin_fmaf(qv[j], qv[j], qn);
+    for (int off = 32; off > 0; off >>= 1) qn += __shfl_xor(qn, off);
+    const uint64_t kth = best[k - 1];
+    const float tau = thr[q * thr_stride + thr_off];  // every row that was not appended scores >= tau
+    bool ok = total <= cap;                           // overflow: rows below the threshold were dropped
+    if (ok && tau != INFINITY) {
+        const float xmax = norms_max[0];
+        const float eps = 4.0f * (static_cast<float>(dim) * 5.9604645e-8f) * (qn + xmax) + 1e-30f;
+        if (kth == kKeyMax)
+            ok = false;
+        else if (DOT)
+            ok = key_score(kth, true) > (-tau) + eps;
+        else
+            ok = key_score(kth, false) < (tau + qn) - eps;
+    }
+    if (lane < k) {
+        const uint64_t e = best[lane];
+        ids[q * k + lane] = e == kKeyMax ? VG_INVALID_ID : key_row(e);
+        scores[q * k + lane] = e == kKeyMax ? (DOT ? -INFINITY : INFINITY) : key_score(e, DOT);
+    }
+    if (lane == 0) fallback[q] = ok ? 0 : 1;
+}
+
 // ---- 4. exhaustive exact scan for the queries whose proof failed ---------------------------------
 // grid = (slices, slots): slot y takes the work-list entries y, y + slots, ...; with an empty list
 // (the normal case) the whole launch is a few thousand workgroups that read one word and leave.
@@ -325,7 +384,7 @@ __global__ __launch_bounds__(256) void flat_exact_kernel(const float *__restrict
 // (dim <= 1024: 16 float4 per lane) and scores it against QB queries held in LDS, each in the
 // reference's summation order (vg_exact.hpp, kPair) — exact by construction, no proof step.
 constexpr int kScanQB = 8;        // queries one pass can carry
-constexpr int kGemmMaxK = 48;     // largest k the 64-candidate nomination + proof serves (above: exhaustive scan)
+constexpr int kGemmMaxK = 48;     // largest k the 64-candidate nomination + proof serves (above: flat_verify_all_kernel)
 constexpr int kScanMaxBatch = 4;  // ... and the batch size up to which the scan beats the 32-query GEMM tile
 template <bool DOT>
 __global__ __launch_bounds__(256) void flat_scan_mq_kernel(const float *__restrict__ base, int64_t n, int dim,
@@ -405,6 +464,10 @@ VG_API int32_t vg_search_flat(vg_index *idx, const float *queries, int64_t nq, i
     const int64_t n = idx->n;
     const int dim = idx->dim;
     const int kc = 64;  // nominated candidates per query
+    // k beyond what 64 nominated candidates can prove: the fused GEMM path re-scores every appended row
+    // (flat_verify_all_kernel); without the fused path (test hook) the exhaustive scans take over
+    const char *unfused_hook = getenv("VG_FLAT_UNFUSED");
+    const bool big_k_scan = k > vg::kGemmMaxK && unfused_hook && unfused_hook[0] == '1';
 
     vg::DevIn<float> q;
     vg::DevOut<uint32_t> oid;
@@ -418,7 +481,7 @@ VG_API int32_t vg_search_flat(vg_index *idx, const float *queries, int64_t nq, i
         VG_TRY(none.init(static_cast<size_t>(nq) * k, st));
         VG_HIP(hipMemsetAsync(none.ptr, 0xFF, static_cast<size_t>(nq) * k * 8, st));
         VG_TRY(vg::launch_topk_merge(none.ptr, nq, 1, k, dot, oid.ptr, osc.ptr, st));
-    } else if ((nq <= vg::kScanMaxBatch || k > vg::kGemmMaxK) && dim % 4 == 0 && dim <= 1024 && dim >= 64 && !getenv("VG_FLAT_NO_SCAN") &&
+    } else if ((nq <= vg::kScanMaxBatch || big_k_scan) && dim % 4 == 0 && dim <= 1024 && dim >= 64 && !getenv("VG_FLAT_NO_SCAN") &&
                !getenv("VG_FLAT_FORCE_EXACT") && !getenv("VG_FLAT_UNFUSED") &&
                (reinterpret_cast<uintptr_t>(idx->d_vectors) & 15) == 0) {
         // small batch: HBM-bound exact scan, kScanQB queries per pass over the rows.  Also every batch with
@@ -443,7 +506,7 @@ VG_API int32_t vg_search_flat(vg_index *idx, const float *queries, int64_t nq, i
         VG_TRY(vg::launch_topk_merge(partial, nq, slices, k, dot, oid.ptr, osc.ptr, st));
         VG_LAUNCH(vg::flat_todo_kernel, dim3(1), dim3(256), 0, st, nullptr, nullptr, static_cast<int>(nq), nullptr,
                   idx->d_flat_stats);
-    } else if (k > vg::kGemmMaxK) {
+    } else if (big_k_scan) {
         // kGemmMaxK < k <= 64 on rows the register scan does not take (dim % 4, dim < 64 or > 1024): the
         // exhaustive exact kernel for every query, one pass over the rows per query
         const int ex_slices = static_cast<int>(std::min<int64_t>(256, std::max<int64_t>(1, n / 64)));
@@ -547,8 +610,9 @@ VG_API int32_t vg_search_flat(vg_index *idx, const float *queries, int64_t nq, i
                                               {qp, cnt, idx->d_vectors, n, dim, idx->d_norms, nullptr, 1, 0, thr,
                                                sel_k, sel_k - 1, counts, cand, cap}));
                 }
-                // (c) the kc best appended keys
-                VG_LAUNCH(vg::flat_pick_kernel, dim3(ucnt), dim3(256), 0, st, cand, counts, cap, kc, cand_id, cand_sc);
+                // (c) the kc best appended keys (k > kGemmMaxK: all of them go to the exact re-score below)
+                if (k <= vg::kGemmMaxK)
+                    VG_LAUNCH(vg::flat_pick_kernel, dim3(ucnt), dim3(256), 0, st, cand, counts, cap, kc, cand_id, cand_sc);
             } else {
                 {
                     vg::ProfScope prof(idx->ctx, "flat_gemm", st);
@@ -564,7 +628,16 @@ VG_API int32_t vg_search_flat(vg_index *idx, const float *queries, int64_t nq, i
                 VG_TRY(vg::launch_topk_merge(partial, cnt, sel_slices, kc, false, cand_id, cand_sc, st));
             }
             const float *vthr = fused ? thr : nullptr;
-            if (dot)
+            if (fused && k > vg::kGemmMaxK) {
+                if (dot)
+                    VG_LAUNCH(vg::flat_verify_all_kernel<true>, dim3(ucnt), dim3(256), 0, st, idx->d_vectors, dim, qp,
+                              idx->d_norm_max, cand, counts, cap, k, oid.ptr + q0 * k, osc.ptr + q0 * k, flags, thr, sel_k,
+                              sel_k - 1);
+                else
+                    VG_LAUNCH(vg::flat_verify_all_kernel<false>, dim3(ucnt), dim3(256), 0, st, idx->d_vectors, dim, qp,
+                              idx->d_norm_max, cand, counts, cap, k, oid.ptr + q0 * k, osc.ptr + q0 * k, flags, thr, sel_k,
+                              sel_k - 1);
+            } else if (dot)
                 VG_LAUNCH(vg::flat_verify_kernel<true>, dim3(ucnt), dim3(256), 0, st, idx->d_vectors, n, dim, qp,
                           idx->d_norm_max, cand_id, cand_sc, kc, k, oid.ptr + q0 * k, osc.ptr + q0 * k, flags, vthr,
                           sel_k, sel_k - 1, counts, cap);
