@@ -254,9 +254,10 @@ int32_t vg_score_candidates(vg_index *idx, const float *queries, int64_t nq,
  * result is verified against the GEMM error bound (a query that fails the check is
  * recomputed by the exhaustive exact kernel), so ids and scores equal the reference's.
  * Metric L2 → ascending squared L2; Dot / Cosine → descending dot product
- * (distance.Provider, distance/distance.go:91-106).  k <= 64: up to k = 48 the 64 best GEMM
- * scores per query are re-scored and proved, above that every row under the query's threshold
- * (a few hundred) is; batches of up to 4 queries take the exhaustive exact scan instead. */
+ * (distance.Provider, distance/distance.go:91-106).  k <= 512: up to k = 48 the 64 best GEMM
+ * scores per query are re-scored and proved; above that every row under the query's threshold is
+ * (the threshold is taken deeper in the sample for k > 64, ~3k rows pass it, sorted in LDS); batches
+ * of up to 4 queries with k <= 64 take the exhaustive exact scan instead. */
 int32_t vg_search_flat(vg_index *idx, const float *queries, int64_t nq, int32_t k, uint32_t *ids,
                        float *scores, void *stream);
 /* diagnostics of vg_search_flat since vg_index_set_vectors: how many queries were searched and

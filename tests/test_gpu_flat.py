@@ -203,4 +203,36 @@ def test_k_above_the_gemm_budget(vg, ctx, n, dim, nq, k, metric):
         assert np.array_equal(sc[i, :r].view(np.uint32), esc.view(np.uint32))
         assert np.all(ids[i, r:] == 0xFFFFFFFF)
     with pytest.raises(vg.VecgoHipError):
-        idx.search_flat(q, 65)
+        idx.search_flat(q, 513)
+
+
+@pytest.mark.parametrize("n,dim,nq,k,metric", [(6000, 128, 7, 100, 0), (9000, 768, 5, 256, 2), (5000, 100, 3, 512, 0),
+                                               (300, 64, 4, 400, 0), (20000, 32, 70, 65, 1), (4500, 30, 2, 130, 0)])
+def test_k_above_64(vg, ctx, n, dim, nq, k, metric):
+    """64 < k <= 512: the threshold is taken deeper in the sample (~3k rows pass it), every appended row is
+    re-scored exactly and sorted in LDS, the proof is against the threshold.  The fall-back of a failed proof
+    (forced here through VG_FLAT_FORCE_EXACT) pages through the exhaustive kernel 64 results at a time."""
+    rng = np.random.default_rng(n + dim + k)
+    x = rng.standard_normal((n, dim)).astype(np.float32)
+    x[n // 3] = x[5]
+    q = rng.standard_normal((nq, dim)).astype(np.float32)
+    idx = vg.Index(ctx, n, dim, vg.Metric(metric))
+    idx.set_vectors(x)
+    exp = [o.flat_search_f32(x, dim, q[i], k, metric) for i in range(nq)]
+
+    def check(ids, sc):
+        for i in range(nq):
+            eid, esc = exp[i]
+            r = eid.size
+            assert np.array_equal(ids[i, :r], eid), (i, np.flatnonzero(ids[i, :r] != eid)[:5])
+            assert np.array_equal(sc[i, :r].view(np.uint32), esc.view(np.uint32))
+            assert np.all(ids[i, r:] == 0xFFFFFFFF)
+
+    ids, sc = idx.search_flat(q, k)
+    check(ids, sc)
+    os.environ["VG_FLAT_FORCE_EXACT"] = "1"
+    try:
+        ids, sc = idx.search_flat(q, k)
+    finally:
+        del os.environ["VG_FLAT_FORCE_EXACT"]
+    check(ids, sc)

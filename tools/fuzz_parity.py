@@ -36,7 +36,7 @@ while time.time() < t_end:
     dim = int(rng.choice([1, 3, 4, 7, 8, 15, 16, 17, 31, 32, 48, 63, 64, 65, 96, 100, 127, 128, 130, 256, 300, 768, 1024, 1100]))
     n = int(rng.choice([1, 2, 5, 15, 16, 17, 63, 64, 65, 100, 255, 256, 257, 1000, 3000]))
     nq = int(rng.choice([1, 2, 3, 5, 9, 33, 70]))
-    k = int(rng.choice([1, 2, 5, 10, 31, 32, 33, 64]))
+    k = int(rng.choice([1, 2, 5, 10, 31, 32, 33, 64, 65, 200]))
     metric = int(rng.choice([0, 1, 2]))
     x = rng.standard_normal((n, dim)).astype(np.float32)
     if n > 3 and rng.random() < 0.5:
@@ -89,14 +89,16 @@ while time.time() < t_end:
             ref = o.ScalarQuantizer(dim); ref.train(x)
             codes = sq.encode(x)
             idx.set_sq8_codes(sq, codes)
-            ids, sc = idx.search_sq8(q, k)
+            kk = min(k, 64)
+            ids, sc = idx.search_sq8(q, kk)
             seg = o.FlatSegment(x, dim, metric=metric, sq=ref, codes=codes)
-            compare("sq8", cfg, ids, sc, [seg.search(q[i], k) for i in range(nq)])
+            compare("sq8", cfg, ids, sc, [seg.search(q[i], kk) for i in range(nq)])
         elif which == 3 and metric == 0:
             codes = vg.RaBitQuantizer(ctx, dim).encode(x)
             idx.set_rabitq_codes(codes)
-            ids, sc = idx.search_rabitq(q, k)
-            compare("rabitq", cfg, ids, sc, [o.flat_search_rabitq(codes, dim, q[i], k) for i in range(nq)])
+            kk = min(k, 64)
+            ids, sc = idx.search_rabitq(q, kk)
+            compare("rabitq", cfg, ids, sc, [o.flat_search_rabitq(codes, dim, q[i], kk) for i in range(nq)])
         elif which == 4 and metric == 0 and n >= 256:
             ms = [d for d in (1, 2, 4, 8, 16, 20, 96) if dim % d == 0 and dim // d <= 152]  # K*subdim*4 <= 152 KiB of LDS
             if not ms:

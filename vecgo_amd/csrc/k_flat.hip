@@ -339,6 +339,60 @@ __global__ __launch_bounds__(256) void flat_verify_all_kernel(
     if (lane == 0) fallback[q] = ok ? 0 : 1;
 }
 
+// k > 64 (one wave's register list holds 64 keys): the exact keys of every appended row are sorted in
+// LDS instead; the proof is the same as above.  n2 = the power of two the workgroup sorts (>= appended rows).
+template <bool DOT>
+__global__ __launch_bounds__(256) void flat_verify_sort_kernel(
+    const float *__restrict__ base, int dim, const float *__restrict__ queries,
+    const float *__restrict__ norms_max /* [1] */, const uint64_t *__restrict__ cand, const int *__restrict__ counts,
+    int cap, int k, uint32_t *__restrict__ ids, float *__restrict__ scores, int *__restrict__ fallback,
+    const float *__restrict__ thr, int thr_stride, int thr_off)
+{
+    extern __shared__ uint64_t sortbuf[];  // cap keys
+    const Sub16 sub = Sub16::make(threadIdx.x);
+    const int64_t q = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const float *qv = queries + q * dim;
+    const int total = counts[q];
+    const int cnt = total < cap ? total : cap;
+    int n2 = 64;
+    while (n2 < cnt) n2 <<= 1;
+    for (int c0 = 0; c0 < cnt; c0 += 16) {  // 16 candidates per step, one per 16-lane group
+        const int c = c0 + (tid >> 4);
+        if (c < cnt) {
+            const uint32_t id = key_row(cand[q * cap + c]);
+            const float v = exact_pair16<DOT, kPair>(base + static_cast<int64_t>(id) * dim, qv, dim, sub);
+            if ((tid & 15) == 0) sortbuf[c] = make_key(v, id, DOT);
+        }
+    }
+    for (int i = cnt + tid; i < n2; i += 256) sortbuf[i] = kKeyMax;
+    __syncthreads();
+    bitonic_sort_lds(sortbuf, n2, tid, 256);
+    for (int i = tid; i < k; i += 256) {
+        const uint64_t e = i < n2 ? sortbuf[i] : kKeyMax;
+        ids[q * k + i] = e == kKeyMax ? VG_INVALID_ID : key_row(e);
+        scores[q * k + i] = e == kKeyMax ? (DOT ? -INFINITY : INFINITY) : key_score(e, DOT);
+    }
+    if (tid >= 64) return;
+    float qn = 0.0f;
+    for (int j = lane; j < dim; j += 64) qn = __builtin_fmaf(qv[j], qv[j], qn);
+    for (int off = 32; off > 0; off >>= 1) qn += __shfl_xor(qn, off);
+    const uint64_t kth = k - 1 < n2 ? sortbuf[k - 1] : kKeyMax;
+    const float tau = thr[q * thr_stride + thr_off];
+    bool ok = total <= cap;
+    if (ok && tau != INFINITY) {
+        const float xmax = norms_max[0];
+        const float eps = 4.0f * (static_cast<float>(dim) * 5.9604645e-8f) * (qn + xmax) + 1e-30f;
+        if (kth == kKeyMax)
+            ok = false;
+        else if (DOT)
+            ok = key_score(kth, true) > (-tau) + eps;
+        else
+            ok = key_score(kth, false) < (tau + qn) - eps;
+    }
+    if (lane == 0) fallback[q] = ok ? 0 : 1;
+}
+
 // ---- 4. exhaustive exact scan for the queries whose proof failed ---------------------------------
 // grid = (slices, slots): slot y takes the work-list entries y, y + slots, ...; with an empty list
 // (the normal case) the whole launch is a few thousand workgroups that read one word and leave.
@@ -347,7 +401,8 @@ template <bool DOT>
 __global__ __launch_bounds__(256) void flat_exact_kernel(const float *__restrict__ base, int64_t n,
                                                          int dim, const float *__restrict__ queries,
                                                          const int *__restrict__ todo, int slices, int k,
-                                                         uint64_t *__restrict__ partial)
+                                                         uint64_t *__restrict__ partial,
+                                                         const uint64_t *__restrict__ min_keys = nullptr)
 {
     __shared__ uint64_t lists[4 * 64];
     __shared__ int valid[4];
@@ -360,6 +415,8 @@ __global__ __launch_bounds__(256) void flat_exact_kernel(const float *__restrict
         const int64_t q = todo[1 + j];
         uint64_t *out = partial + (q * slices + s) * k;
         const float *qv = queries + q * dim;
+        // paged results (k > 64): only keys after the last one of the previous page count
+        const uint64_t floor_key = min_keys ? min_keys[q] : 0;
         WaveTopK tk;
         tk.init(k);
         // 4 rows per wave step (one per 16-lane group)
@@ -368,7 +425,10 @@ __global__ __launch_bounds__(256) void flat_exact_kernel(const float *__restrict
             uint64_t key = kKeyMax;
             if (i < r1) {
                 const float v = exact_pair16<DOT, kPair>(base + i * dim, qv, dim, sub);
-                if ((lane & 15) == 0) key = make_key(v, static_cast<uint32_t>(i), DOT);
+                if ((lane & 15) == 0) {
+                    key = make_key(v, static_cast<uint32_t>(i), DOT);
+                    if (min_keys && key <= floor_key) key = kKeyMax;
+                }
             }
             tk.offer(key, lane);
         }
@@ -385,6 +445,7 @@ __global__ __launch_bounds__(256) void flat_exact_kernel(const float *__restrict
 // reference's summation order (vg_exact.hpp, kPair) — exact by construction, no proof step.
 constexpr int kScanQB = 8;        // queries one pass can carry
 constexpr int kGemmMaxK = 48;     // largest k the 64-candidate nomination + proof serves (above: flat_verify_all_kernel)
+constexpr int kFlatMaxK = 512;    // candidates appended per query stay well under the 4096-key buffer (3k expected)
 constexpr int kScanMaxBatch = 4;  // ... and the batch size up to which the scan beats the 32-query GEMM tile
 template <bool DOT>
 __global__ __launch_bounds__(256) void flat_scan_mq_kernel(const float *__restrict__ base, int64_t n, int dim,
@@ -446,6 +507,25 @@ __global__ void flat_patch_kernel(const int *__restrict__ fallback, const int *_
     }
 }
 
+// page `off / 64` of a paged exhaustive result (k > 64): kk results per flagged query land at ids[q*k + off ..),
+// and the last key of the page becomes the floor of the next one (kKeyMax when the rows ran out)
+__global__ void flat_page_patch_kernel(const int *__restrict__ fallback, const int *__restrict__ always, int k, int off,
+                                       int kk, bool descending, const uint32_t *__restrict__ fids,
+                                       const float *__restrict__ fscores, uint32_t *__restrict__ ids,
+                                       float *__restrict__ scores, uint64_t *__restrict__ min_keys)
+{
+    const int64_t q = blockIdx.x;
+    if (!(always && always[0]) && !fallback[q]) return;
+    for (int i = threadIdx.x; i < kk; i += blockDim.x) {
+        ids[q * k + off + i] = fids[q * kk + i];
+        scores[q * k + off + i] = fscores[q * kk + i];
+    }
+    if (threadIdx.x == 0) {
+        const uint32_t last = fids[q * kk + kk - 1];
+        min_keys[q] = last == VG_INVALID_ID ? kKeyMax : make_key(fscores[q * kk + kk - 1], last, descending);
+    }
+}
+
 }  // namespace vg
 
 VG_API int32_t vg_search_flat(vg_index *idx, const float *queries, int64_t nq, int32_t k, uint32_t *ids,
@@ -457,7 +537,7 @@ VG_API int32_t vg_search_flat(vg_index *idx, const float *queries, int64_t nq, i
     VG_CHECK(idx->metric != VG_METRIC_HAMMING, VG_ERR_UNSUPPORTED, "unsupported metric for float32: Hamming");
     VG_CHECK(idx->n == 0 || idx->d_vectors, VG_ERR_NOT_READY, "vg_search_flat: index has no fp32 vectors");
     VG_CHECK(queries && ids && scores, VG_ERR_INVALID_ARG, "vg_search_flat: NULL buffer");
-    VG_CHECK(k <= 64, VG_ERR_UNSUPPORTED, "vg_search_flat: k=%d exceeds 64", k);
+    VG_CHECK(k <= vg::kFlatMaxK, VG_ERR_UNSUPPORTED, "vg_search_flat: k=%d exceeds %d", k, vg::kFlatMaxK);
     VG_HIP(hipSetDevice(idx->ctx->device));
     hipStream_t st = vg::pick_stream(idx->ctx, stream);
     const bool dot = idx->metric != VG_METRIC_L2;
@@ -468,6 +548,7 @@ VG_API int32_t vg_search_flat(vg_index *idx, const float *queries, int64_t nq, i
     // (flat_verify_all_kernel); without the fused path (test hook) the exhaustive scans take over
     const char *unfused_hook = getenv("VG_FLAT_UNFUSED");
     const bool big_k_scan = k > vg::kGemmMaxK && unfused_hook && unfused_hook[0] == '1';
+    VG_CHECK(k <= 64 || !big_k_scan, VG_ERR_UNSUPPORTED, "vg_search_flat: k=%d needs the fused GEMM path", k);
 
     vg::DevIn<float> q;
     vg::DevOut<uint32_t> oid;
@@ -481,7 +562,7 @@ VG_API int32_t vg_search_flat(vg_index *idx, const float *queries, int64_t nq, i
         VG_TRY(none.init(static_cast<size_t>(nq) * k, st));
         VG_HIP(hipMemsetAsync(none.ptr, 0xFF, static_cast<size_t>(nq) * k * 8, st));
         VG_TRY(vg::launch_topk_merge(none.ptr, nq, 1, k, dot, oid.ptr, osc.ptr, st));
-    } else if ((nq <= vg::kScanMaxBatch || big_k_scan) && dim % 4 == 0 && dim <= 1024 && dim >= 64 && !getenv("VG_FLAT_NO_SCAN") &&
+    } else if (((nq <= vg::kScanMaxBatch && k <= 64) || big_k_scan) && dim % 4 == 0 && dim <= 1024 && dim >= 64 && !getenv("VG_FLAT_NO_SCAN") &&
                !getenv("VG_FLAT_FORCE_EXACT") && !getenv("VG_FLAT_UNFUSED") &&
                (reinterpret_cast<uintptr_t>(idx->d_vectors) & 15) == 0) {
         // small batch: HBM-bound exact scan, kScanQB queries per pass over the rows.  Also every batch with
@@ -537,7 +618,8 @@ VG_API int32_t vg_search_flat(vg_index *idx, const float *queries, int64_t nq, i
         const char *unfused_env = getenv("VG_FLAT_UNFUSED");  // test hook: materialise the score matrix
         const bool fused = !(unfused_env && unfused_env[0] == '1');
         const int cap = 4096;          // candidate keys per query (fused path)
-        const int sample_j = 8;        // threshold = sample_j-th best score of the row sample
+        // threshold = sample_j-th best score of the row sample: ~64 * sample_j rows pass it (k > 64: ~3k of them)
+        const int sample_j = k <= 64 ? 8 : std::min(64, std::max(8, (3 * k + 63) / 64));
         const int sample_stride = 64;  // every 64th 128-row tile is sampled
         const int64_t nt = (n + vg::kGemmBN - 1) / vg::kGemmBN;
         const int64_t nst = (nt + sample_stride - 1) / sample_stride;  // sampled tiles
@@ -566,14 +648,17 @@ VG_API int32_t vg_search_flat(vg_index *idx, const float *queries, int64_t nq, i
         const int i_cand_sc = ar.add(sizeof(float) * static_cast<size_t>(qc) * kc);
         const int i_flags = ar.add(sizeof(int) * (static_cast<size_t>(qc) + 1));
         const int i_todo = ar.add(sizeof(int) * (static_cast<size_t>(qc) + 1));
-        const int i_fpartial = ar.add(sizeof(uint64_t) * static_cast<size_t>(qc) * ex_slices * k);
-        const int i_fid = ar.add(sizeof(uint32_t) * static_cast<size_t>(qc) * k);
-        const int i_fsc = ar.add(sizeof(float) * static_cast<size_t>(qc) * k);
+        const int pk = std::min(k, 64);  // results per page of the exhaustive fallback
+        const int i_fpartial = ar.add(sizeof(uint64_t) * static_cast<size_t>(qc) * ex_slices * pk);
+        const int i_fid = ar.add(sizeof(uint32_t) * static_cast<size_t>(qc) * pk);
+        const int i_fsc = ar.add(sizeof(float) * static_cast<size_t>(qc) * pk);
+        const int i_minkeys = ar.add(sizeof(uint64_t) * static_cast<size_t>(qc));
         VG_TRY(ar.commit());
         float *sc = ar.get<float>(i_sc), *thr = ar.get<float>(i_thr);
         float *cand_sc = ar.get<float>(i_cand_sc), *fsc = ar.get<float>(i_fsc);
         uint64_t *partial = ar.get<uint64_t>(i_partial), *fpartial = ar.get<uint64_t>(i_fpartial);
         uint64_t *cand = ar.get<uint64_t>(i_cand);
+        uint64_t *min_keys = ar.get<uint64_t>(i_minkeys);
         uint32_t *sid = ar.get<uint32_t>(i_sid), *cand_id = ar.get<uint32_t>(i_cand_id), *fid = ar.get<uint32_t>(i_fid);
         int *counts = ar.get<int>(i_counts), *flags = ar.get<int>(i_flags), *todo = ar.get<int>(i_todo);
 
@@ -628,7 +713,12 @@ VG_API int32_t vg_search_flat(vg_index *idx, const float *queries, int64_t nq, i
                 VG_TRY(vg::launch_topk_merge(partial, cnt, sel_slices, kc, false, cand_id, cand_sc, st));
             }
             const float *vthr = fused ? thr : nullptr;
-            if (fused && k > vg::kGemmMaxK) {
+            if (fused && k > 64) {
+                const size_t sort_lds = sizeof(uint64_t) * static_cast<size_t>(cap);
+                auto vk = dot ? vg::flat_verify_sort_kernel<true> : vg::flat_verify_sort_kernel<false>;
+                VG_LAUNCH(vk, dim3(ucnt), dim3(256), sort_lds, st, idx->d_vectors, dim, qp, idx->d_norm_max, cand, counts, cap,
+                          k, oid.ptr + q0 * k, osc.ptr + q0 * k, flags, thr, sel_k, sel_k - 1);
+            } else if (fused && k > vg::kGemmMaxK) {
                 if (dot)
                     VG_LAUNCH(vg::flat_verify_all_kernel<true>, dim3(ucnt), dim3(256), 0, st, idx->d_vectors, dim, qp,
                               idx->d_norm_max, cand, counts, cap, k, oid.ptr + q0 * k, osc.ptr + q0 * k, flags, thr, sel_k,
@@ -648,15 +738,6 @@ VG_API int32_t vg_search_flat(vg_index *idx, const float *queries, int64_t nq, i
             // step 4 always launches, on the work list the proofs left behind (normally empty)
             VG_LAUNCH(vg::flat_todo_kernel, dim3(1), dim3(256), 0, st, flags, always, static_cast<int>(cnt), todo,
                       idx->d_flat_stats);
-            {
-                const unsigned slots = static_cast<unsigned>(std::min<int64_t>(cnt, vg::kExactSlots));
-                if (dot)
-                    VG_LAUNCH(vg::flat_exact_kernel<true>, dim3(ex_slices, slots), dim3(256), 0, st, idx->d_vectors, n,
-                              dim, qp, todo, ex_slices, k, fpartial);
-                else
-                    VG_LAUNCH(vg::flat_exact_kernel<false>, dim3(ex_slices, slots), dim3(256), 0, st, idx->d_vectors, n,
-                              dim, qp, todo, ex_slices, k, fpartial);
-            }
             if (getenv("VG_FLAT_DEBUG")) {
                 std::vector<int> hf(cnt), hc(cnt);
                 (void)hipMemcpyAsync(hf.data(), flags, sizeof(int) * cnt, hipMemcpyDeviceToHost, st);
@@ -669,9 +750,26 @@ VG_API int32_t vg_search_flat(vg_index *idx, const float *queries, int64_t nq, i
                         "appended candidates avg %.1f max %lld\n", (long long)q0, (long long)cnt, (long long)nf,
                         fused ? double(csum) / cnt : 0.0, (long long)(fused ? cmax : 0));
             }
-            VG_TRY(vg::launch_topk_merge(fpartial, cnt, ex_slices, k, dot, fid, fsc, st, flags, always));
-            VG_LAUNCH(vg::flat_patch_kernel, dim3(ucnt), dim3(64), 0, st, flags, always, k, fid, fsc,
-                      oid.ptr + q0 * k, osc.ptr + q0 * k);
+            // the exhaustive kernel keeps 64 keys per wave: k > 64 comes in pages of 64, each page scanning
+            // for the keys after the previous page's last one
+            const unsigned slots = static_cast<unsigned>(std::min<int64_t>(cnt, vg::kExactSlots));
+            for (int off = 0; off < k; off += 64) {
+                const int kk = std::min(64, k - off);
+                const uint64_t *floor_keys = off ? min_keys : nullptr;
+                if (dot)
+                    VG_LAUNCH(vg::flat_exact_kernel<true>, dim3(ex_slices, slots), dim3(256), 0, st, idx->d_vectors, n,
+                              dim, qp, todo, ex_slices, kk, fpartial, floor_keys);
+                else
+                    VG_LAUNCH(vg::flat_exact_kernel<false>, dim3(ex_slices, slots), dim3(256), 0, st, idx->d_vectors, n,
+                              dim, qp, todo, ex_slices, kk, fpartial, floor_keys);
+                VG_TRY(vg::launch_topk_merge(fpartial, cnt, ex_slices, kk, dot, fid, fsc, st, flags, always));
+                if (k <= 64)
+                    VG_LAUNCH(vg::flat_patch_kernel, dim3(ucnt), dim3(64), 0, st, flags, always, k, fid, fsc,
+                              oid.ptr + q0 * k, osc.ptr + q0 * k);
+                else
+                    VG_LAUNCH(vg::flat_page_patch_kernel, dim3(ucnt), dim3(64), 0, st, flags, always, k, off, kk, dot, fid,
+                              fsc, oid.ptr + q0 * k, osc.ptr + q0 * k, min_keys);
+            }
         }
     }
     VG_TRY(oid.finish());
