@@ -297,7 +297,8 @@ int32_t vg_sq8_l2_distance_batch(vg_sq8 *sq, const float *query, const uint8_t *
 int32_t vg_index_set_sq8_codes(vg_index *idx, vg_sq8 *sq, const uint8_t *codes, void *stream);
 /* flat.Segment.Search, SQ8 branch: L2 segments score every row with L2DistanceBatch
  * (flat/segment.go:517-604), Dot / Cosine segments with ScalarQuantizer.DotProduct (:659-667,
- * quantizer.go:109-119: a sequential fp32 loop, largest first); best k by (Score, RowID).  k <= 64. */
+ * quantizer.go:109-119: a sequential fp32 loop, largest first); best k by (Score, RowID).  k <= 512
+ * (beyond 64 results the scan runs once per page of 64, each page after the previous one's last key). */
 int32_t vg_search_sq8(vg_index *idx, const float *queries, int64_t nq, int32_t k, uint32_t *ids,
                       float *scores, void *stream);
 

@@ -105,7 +105,7 @@ def test_sq8_errors(vg, ctx):
     with pytest.raises(vg.VecgoHipError):
         idx.search_sq8(np.zeros((1, 8), np.float32), 5)      # no codes attached
     with pytest.raises(vg.VecgoHipError):
-        idx.search_sq8(np.zeros((1, 8), np.float32), 65)     # k <= 64
+        idx.search_sq8(np.zeros((1, 8), np.float32), 513)    # k <= 512
 
 
 @pytest.mark.parametrize("n,dim,nq,k,metric", [(700, 128, 5, 10, 2), (300, 100, 3, 7, 1), (130, 17, 2, 64, 2)])
@@ -127,3 +127,28 @@ def test_sq8_dot_product_scan_matches_oracle(vg, ctx, n, dim, nq, k, metric):
         eid, esc = seg.search(q[i], k)
         assert np.array_equal(ids[i, :eid.size], eid), (i, ids[i], eid)
         assert np.array_equal(bits(sc[i, :eid.size]), bits(esc))
+
+
+@pytest.mark.parametrize("n,dim,nq,k,metric", [(3000, 64, 5, 100, 0), (1500, 100, 1, 200, 0), (900, 48, 3, 65, 2),
+                                               (90, 16, 2, 128, 0)])
+def test_sq8_scan_pages_beyond_64_results(vg, ctx, n, dim, nq, k, metric):
+    """k > 64: the scan runs once per page of 64 results, each page taking only keys after the previous
+    page's last one; duplicates straddling a page boundary are the interesting case."""
+    rng = np.random.default_rng(n + k)
+    x = rng.standard_normal((n, dim)).astype(np.float32)
+    x[n // 2:n // 2 + 70] = x[3]          # 71 identical codes: a run of equal scores longer than a page
+    sq = vg.ScalarQuantizer(ctx, dim); sq.train(x)
+    ref = o.ScalarQuantizer(dim); ref.train(x)
+    codes = sq.encode(x)
+    idx = vg.Index(ctx, n, dim, vg.Metric(metric))
+    idx.set_sq8_codes(sq, codes)
+    q = rng.standard_normal((nq, dim)).astype(np.float32)
+    q[0] = x[3]
+    ids, sc = idx.search_sq8(q, k)
+    seg = o.FlatSegment(x, dim, metric=metric, sq=ref, codes=codes)
+    for i in range(nq):
+        eid, esc = seg.search(q[i], k)
+        r = eid.size
+        assert np.array_equal(ids[i, :r], eid), (i, np.flatnonzero(ids[i, :r] != eid)[:5])
+        assert np.array_equal(bits(sc[i, :r]), bits(esc))
+        assert np.all(ids[i, r:] == 0xFFFFFFFF)

@@ -515,7 +515,7 @@ __global__ void flat_page_patch_kernel(const int *__restrict__ fallback, const i
                                        float *__restrict__ scores, uint64_t *__restrict__ min_keys)
 {
     const int64_t q = blockIdx.x;
-    if (!(always && always[0]) && !fallback[q]) return;
+    if (!(always && always[0]) && !(fallback && fallback[q])) return;
     for (int i = threadIdx.x; i < kk; i += blockDim.x) {
         ids[q * k + off + i] = fids[q * kk + i];
         scores[q * k + off + i] = fscores[q * kk + i];
@@ -524,6 +524,17 @@ __global__ void flat_page_patch_kernel(const int *__restrict__ fallback, const i
         const uint32_t last = fids[q * kk + kk - 1];
         min_keys[q] = last == VG_INVALID_ID ? kKeyMax : make_key(fscores[q * kk + kk - 1], last, descending);
     }
+}
+
+// all queries of a paged scan (k > 64 through a kernel that keeps 64 keys per wave): copy page `off / 64` and
+// make its last key the floor of the next page
+int32_t launch_page_patch(int64_t nq, int k, int off, int kk, bool descending, const int *always_one,
+                          const uint32_t *fids, const float *fscores, uint32_t *ids, float *scores, uint64_t *min_keys,
+                          hipStream_t st)
+{
+    VG_LAUNCH(flat_page_patch_kernel, dim3(static_cast<unsigned>(nq)), dim3(64), 0, st, nullptr, always_one, k, off, kk,
+              descending, fids, fscores, ids, scores, min_keys);
+    return VG_OK;
 }
 
 }  // namespace vg

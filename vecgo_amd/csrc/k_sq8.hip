@@ -31,6 +31,9 @@ struct vg_sq8 {
 
 namespace vg {
 
+int32_t launch_page_patch(int64_t nq, int k, int off, int kk, bool descending, const int *always_one,
+                          const uint32_t *fids, const float *fscores, uint32_t *ids, float *scores, uint64_t *min_keys,
+                          hipStream_t st);
 int32_t launch_topk_merge(const uint64_t *partial, int64_t nq, int lists, int k, bool descending,
                           uint32_t *ids, float *scores, hipStream_t st, const int *only_if = nullptr,
                           const int *always = nullptr);
@@ -291,7 +294,7 @@ template <bool DOT>
 __global__ __launch_bounds__(kSqThreads) void sq8_scan_kernel(
     const uint4 *__restrict__ tiles, int64_t n_rows, int64_t n_tiles, int groups, int dim,
     const float *__restrict__ queries, const float *__restrict__ mins, const float *__restrict__ inv, int slices,
-    int nq, int k, uint64_t *__restrict__ partial)
+    int nq, int k, uint64_t *__restrict__ partial, const uint64_t *__restrict__ min_keys)
 {
     __shared__ uint64_t lists[kSqWaves * 64];
     __shared__ int valid[kSqWaves];
@@ -309,7 +312,9 @@ __global__ __launch_bounds__(kSqThreads) void sq8_scan_kernel(
     for (int64_t tile = t0 + wave; tile < t1; tile += kSqWaves) {
         const float total = sq8_row_score<DOT>(tiles + (tile * groups) * 64 + lane, groups, full, tail, qv, mins, inv);
         const int64_t row = tile * 64 + lane;
-        tk.offer(row < n_rows ? make_key(total, static_cast<uint32_t>(row), DOT) : kKeyMax, lane);
+        uint64_t key = row < n_rows ? make_key(total, static_cast<uint32_t>(row), DOT) : kKeyMax;
+        if (min_keys && key <= min_keys[q]) key = kKeyMax;  // paged results: only keys after the previous page
+        tk.offer(key, lane);
     }
     wg_rank_merge<kSqWaves>(tk, lists, valid, wave, lane, tid, k,
                             partial + (static_cast<int64_t>(q) * slices + s) * k);
@@ -440,7 +445,7 @@ template <bool DOT>
 __global__ __launch_bounds__(kSqThreads) void sq8_scan_mq_kernel(
     const uint4 *__restrict__ tiles, int64_t n_rows, int64_t n_tiles, int groups, int dim,
     const float *__restrict__ queries, const float *__restrict__ mins, const float *__restrict__ inv, int slices,
-    int nq, int k, uint64_t *__restrict__ partial)
+    int nq, int k, uint64_t *__restrict__ partial, const uint64_t *__restrict__ min_keys)
 {
     extern __shared__ __attribute__((aligned(16))) float qlds[];  // kSqProbeQ * dimp floats, then the merge scratch
     const int dimp = groups * 16;
@@ -475,7 +480,11 @@ __global__ __launch_bounds__(kSqThreads) void sq8_scan_mq_kernel(
         const int64_t row = tile * 64 + lane;
 #pragma unroll
         for (int qi = 0; qi < kSqProbeQ; qi++)
-            if (qi < cnt) tk[qi].offer(row < n_rows ? make_key(total[qi], static_cast<uint32_t>(row), DOT) : kKeyMax, lane);
+            if (qi < cnt) {
+                uint64_t key = row < n_rows ? make_key(total[qi], static_cast<uint32_t>(row), DOT) : kKeyMax;
+                if (min_keys && key <= min_keys[q0 + qi]) key = kKeyMax;
+                tk[qi].offer(key, lane);
+            }
     }
 #pragma unroll
     for (int qi = 0; qi < kSqProbeQ; qi++) {
@@ -919,7 +928,7 @@ VG_API int32_t vg_search_sq8(vg_index *idx, const float *queries, int64_t nq, in
     const bool dot = idx->metric != VG_METRIC_L2;  // segment.go:659-667: sq.L2Distance or sq.DotProduct
     VG_CHECK(idx->n == 0 || idx->d_sq_tiles, VG_ERR_NOT_READY, "vg_search_sq8: index has no SQ8 codes");
     VG_CHECK(queries && ids && scores, VG_ERR_INVALID_ARG, "vg_search_sq8: NULL buffer");
-    VG_CHECK(k <= 64, VG_ERR_UNSUPPORTED, "vg_search_sq8: k=%d exceeds 64", k);
+    VG_CHECK(k <= 512, VG_ERR_UNSUPPORTED, "vg_search_sq8: k=%d exceeds 512", k);
     VG_HIP(hipSetDevice(idx->ctx->device));
     hipStream_t st = vg::pick_stream(idx->ctx, stream);
     vg::DevIn<float> q;
@@ -940,37 +949,61 @@ VG_API int32_t vg_search_sq8(vg_index *idx, const float *queries, int64_t nq, in
         const bool mq = nq >= 2 && mq_lds <= 128 * 1024;
         const int64_t units = mq ? (nq + vg::kSqProbeQ - 1) / vg::kSqProbeQ : nq;  // workgroups per slice
         const int slices = vg::sq_slices(units, idx->n_tiles, idx->ctx->compute_units);
+        // a wave keeps 64 keys: k > 64 comes in pages of 64, every page a scan for the keys after the previous
+        // page's last one (ceil(k / 64) scans)
+        const bool paged = k > 64;
+        const int pk = paged ? 64 : k;
         vg::ArenaCall ar(idx->ctx, st);
-        const int i_partial = ar.add(sizeof(uint64_t) * static_cast<size_t>(nq) * slices * k);
+        const int i_partial = ar.add(sizeof(uint64_t) * static_cast<size_t>(nq) * slices * pk);
+        const int i_pid = ar.add(paged ? sizeof(uint32_t) * static_cast<size_t>(nq) * pk : 0);
+        const int i_psc = ar.add(paged ? sizeof(float) * static_cast<size_t>(nq) * pk : 0);
+        const int i_floor = ar.add(paged ? sizeof(uint64_t) * static_cast<size_t>(nq) : 0);
+        const int i_one = ar.add(paged ? 256 : 0);
         VG_TRY(ar.commit());
-        uint64_t *partial = ar.get<uint64_t>(i_partial);
+        uint64_t *partial = ar.get<uint64_t>(i_partial), *floor_keys = ar.get<uint64_t>(i_floor);
+        uint32_t *pid = ar.get<uint32_t>(i_pid);
+        float *psc = ar.get<float>(i_psc);
+        int *one = ar.get<int>(i_one);
+        if (paged) VG_HIP(hipMemsetAsync(one, 1, sizeof(int), st));
         if (mq) {
             auto kern = dot ? vg::sq8_scan_mq_kernel<true> : vg::sq8_scan_mq_kernel<false>;
             VG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        static_cast<int>(mq_lds)));
-            const int64_t max_q = ((1ll << 30) / slices) * vg::kSqProbeQ;  // whole groups per launch
-            for (int64_t q0 = 0; q0 < nq; q0 += max_q) {
-                const int64_t cnt = nq - q0 < max_q ? nq - q0 : max_q;
-                const int64_t ng = (cnt + vg::kSqProbeQ - 1) / vg::kSqProbeQ;
-                vg::ProfScope prof(idx->ctx, "sq8_scan", st);
-                VG_LAUNCH(kern, dim3(static_cast<unsigned>(ng * slices)), dim3(vg::kSqThreads), mq_lds, st,
-                          reinterpret_cast<const uint4 *>(idx->d_sq_tiles), idx->n, idx->n_tiles, idx->sq_groups, idx->dim,
-                          q.ptr + q0 * idx->dim, idx->sq->d_mins, idx->sq->d_inv, slices, static_cast<int>(cnt), k,
-                          partial + q0 * slices * k);
+        }
+        for (int off = 0; off < k; off += 64) {
+            const int kk = paged ? std::min(64, k - off) : k;
+            const uint64_t *floor = off ? floor_keys : nullptr;
+            if (mq) {
+                auto kern = dot ? vg::sq8_scan_mq_kernel<true> : vg::sq8_scan_mq_kernel<false>;
+                const int64_t max_q = ((1ll << 30) / slices) * vg::kSqProbeQ;  // whole groups per launch
+                for (int64_t q0 = 0; q0 < nq; q0 += max_q) {
+                    const int64_t cnt = nq - q0 < max_q ? nq - q0 : max_q;
+                    const int64_t ng = (cnt + vg::kSqProbeQ - 1) / vg::kSqProbeQ;
+                    vg::ProfScope prof(idx->ctx, "sq8_scan", st);
+                    VG_LAUNCH(kern, dim3(static_cast<unsigned>(ng * slices)), dim3(vg::kSqThreads), mq_lds, st,
+                              reinterpret_cast<const uint4 *>(idx->d_sq_tiles), idx->n, idx->n_tiles, idx->sq_groups, idx->dim,
+                              q.ptr + q0 * idx->dim, idx->sq->d_mins, idx->sq->d_inv, slices, static_cast<int>(cnt), kk,
+                              partial + q0 * slices * kk, floor ? floor + q0 : nullptr);
+                }
+            } else {
+                const int64_t max_q = (1ll << 30) / slices;
+                for (int64_t q0 = 0; q0 < nq; q0 += max_q) {
+                    const int64_t cnt = nq - q0 < max_q ? nq - q0 : max_q;
+                    vg::ProfScope prof(idx->ctx, "sq8_scan", st);
+                    auto kern = dot ? vg::sq8_scan_kernel<true> : vg::sq8_scan_kernel<false>;
+                    VG_LAUNCH(kern, dim3(static_cast<unsigned>(cnt * slices)), dim3(vg::kSqThreads), 0, st,
+                              reinterpret_cast<const uint4 *>(idx->d_sq_tiles), idx->n, idx->n_tiles, idx->sq_groups, idx->dim,
+                              q.ptr + q0 * idx->dim, idx->sq->d_mins, idx->sq->d_inv, slices, static_cast<int>(cnt), kk,
+                              partial + q0 * slices * kk, floor ? floor + q0 : nullptr);
+                }
             }
-        } else {
-            const int64_t max_q = (1ll << 30) / slices;
-            for (int64_t q0 = 0; q0 < nq; q0 += max_q) {
-                const int64_t cnt = nq - q0 < max_q ? nq - q0 : max_q;
-                vg::ProfScope prof(idx->ctx, "sq8_scan", st);
-                auto kern = dot ? vg::sq8_scan_kernel<true> : vg::sq8_scan_kernel<false>;
-                VG_LAUNCH(kern, dim3(static_cast<unsigned>(cnt * slices)), dim3(vg::kSqThreads), 0, st,
-                          reinterpret_cast<const uint4 *>(idx->d_sq_tiles), idx->n, idx->n_tiles, idx->sq_groups, idx->dim,
-                          q.ptr + q0 * idx->dim, idx->sq->d_mins, idx->sq->d_inv, slices, static_cast<int>(cnt), k,
-                          partial + q0 * slices * k);
+            if (!paged) {
+                VG_TRY(vg::launch_topk_merge(partial, nq, slices, k, dot, oid.ptr, osc.ptr, st));
+            } else {
+                VG_TRY(vg::launch_topk_merge(partial, nq, slices, kk, dot, pid, psc, st));
+                VG_TRY(vg::launch_page_patch(nq, k, off, kk, dot, one, pid, psc, oid.ptr, osc.ptr, floor_keys, st));
             }
         }
-        VG_TRY(vg::launch_topk_merge(partial, nq, slices, k, dot, oid.ptr, osc.ptr, st));
     }
     VG_TRY(oid.finish());
     VG_TRY(osc.finish());
