@@ -268,7 +268,7 @@ int32_t vg_index_flat_stats(vg_index *idx, int64_t *queries, int64_t *exhaustive
 /* exhaustive scan of the RaBitQ codes: RaBitQuantizer.Distance (rabitq.go:119-176) for every
  * row, best k by (Score, RowID).  The reference only scores RaBitQ codes node by node inside the
  * Vamana search (diskann/segment.go:512-535); the scan is the sharded config-5 workload
- * (SURVEY.md §8d).  k <= 64. */
+ * (SURVEY.md §8d).  k <= 512 (pages of 64 results, one scan per page). */
 int32_t vg_search_rabitq(vg_index *idx, const float *queries, int64_t nq, int32_t k, uint32_t *ids,
                          float *scores, void *stream);
 

@@ -88,3 +88,26 @@ def test_rabitq_errors(vg, ctx):
         rq.encode(np.zeros(63, np.float32))
     with pytest.raises(vg.VecgoHipError):  # rabitq.go:123-125
         rq.distance(np.zeros(64, np.float32), np.zeros(11, np.uint8))
+
+
+@pytest.mark.parametrize("n,dim,nq,k", [(3000, 128, 4, 100), (700, 768, 2, 300), (100, 64, 3, 128)])
+def test_scan_pages_beyond_64_results(vg, ctx, n, dim, nq, k):
+    """k > 64: one scan per page of 64 results, each page after the previous page's last key.  RaBitQ
+    distances collide a lot (few distinct hamming counts x norms), so pages regularly split a run of ties."""
+    rng = np.random.default_rng(n + k)
+    x = rng.standard_normal((n, dim)).astype(np.float32)
+    x[10:90] = x[5]                                  # 81 identical codes: one tie run longer than a page
+    codes = vg.RaBitQuantizer(ctx, dim).encode(x)
+    idx = vg.Index(ctx, n, dim)
+    idx.set_rabitq_codes(codes)
+    q = rng.standard_normal((nq, dim)).astype(np.float32)
+    q[0] = x[5]
+    ids, sc = idx.search_rabitq(q, k)
+    for i in range(nq):
+        eid, esc = o.flat_search_rabitq(codes, dim, q[i], k)
+        r = eid.size
+        assert np.array_equal(ids[i, :r], eid), (i, np.flatnonzero(ids[i, :r] != eid)[:5])
+        assert np.array_equal(np.asarray(sc[i, :r]).view(np.uint32), esc.view(np.uint32))
+        assert np.all(ids[i, r:] == 0xFFFFFFFF)
+    with pytest.raises(vg.VecgoHipError):
+        idx.search_rabitq(q, 513)

@@ -1,10 +1,15 @@
 // k_rabitq.hip — RaBitQuantizer (internal/quantization/rabitq.go) and simd.Hamming on the device.
+#include <algorithm>
+
 #include "vg_device.hpp"
 #include "vg_exact.hpp"
 #include "vg_internal.hpp"
 
 namespace vg {
 
+int32_t launch_page_patch(int64_t nq, int k, int off, int kk, bool descending, const int *always_one,
+                          const uint32_t *fids, const float *fscores, uint32_t *ids, float *scores, uint64_t *min_keys,
+                          hipStream_t st);
 int32_t launch_topk_merge(const uint64_t *partial, int64_t nq, int lists, int k, bool descending,
                           uint32_t *ids, float *scores, hipStream_t st, const int *only_if = nullptr,
                           const int *always = nullptr);
@@ -137,7 +142,7 @@ constexpr int kRqThreads = kRqWaves * 64;
 __global__ __launch_bounds__(kRqThreads) void rabitq_scan_kernel(
     const uint4 *__restrict__ tiles, const float *__restrict__ norms, int64_t n_rows, int64_t n_tiles,
     int groups, int dim, const uint8_t *__restrict__ qcodes /* nq * (nb+4) */, int nb, int slices, int nq,
-    int k, uint64_t *__restrict__ partial)
+    int k, uint64_t *__restrict__ partial, const uint64_t *__restrict__ min_keys)
 {
     __shared__ uint4 qbits[64];  // up to 1024 bytes of sign bits (dim <= 8192)
     __shared__ uint64_t lists[kRqWaves * 64];
@@ -164,6 +169,9 @@ __global__ __launch_bounds__(kRqThreads) void rabitq_scan_kernel(
     __syncthreads();
     WaveTopK tk;
     tk.init(k);
+    // paged results (k > 64): only keys after the previous page's last one (the first page passes no floor)
+    const bool paged = min_keys != nullptr;
+    const uint64_t floor_key = paged ? min_keys[q] : 0;
     // several tiles per trip: kRqTiles * groups independent 16-byte loads in flight per lane before the
     // first popcount (one tile per trip left the wave idle for a full HBM round trip per 64 rows)
     auto score = [&](int64_t tile, int h) {
@@ -172,6 +180,7 @@ __global__ __launch_bounds__(kRqThreads) void rabitq_scan_kernel(
         if (row < n_rows) {
             const float d = rq_formula(qn, norms[row], dimf, static_cast<float>(h));
             key = make_key(d, static_cast<uint32_t>(row), false);
+            if (paged && key <= floor_key) key = kKeyMax;
         }
         tk.offer(key, lane);
     };
@@ -206,8 +215,10 @@ __global__ __launch_bounds__(kRqThreads) void rabitq_scan_kernel(
             for (int t = 0; t < kRqTiles; t++) {
                 const int64_t row = (tile + t * kRqWaves) * 64 + lane;
                 uint64_t key = kKeyMax;
-                if (row < n_rows)
+                if (row < n_rows) {
                     key = make_key(rq_formula(qn, y[t], dimf, static_cast<float>(h[t])), static_cast<uint32_t>(row), false);
+                    if (paged && key <= floor_key) key = kKeyMax;
+                }
                 tk.offer(key, lane);
             }
         }
@@ -361,7 +372,7 @@ VG_API int32_t vg_search_rabitq(vg_index *idx, const float *queries, int64_t nq,
     if (nq == 0 || k == 0) return VG_OK;
     VG_CHECK(idx->n == 0 || idx->d_rq_tiles, VG_ERR_NOT_READY, "vg_search_rabitq: index has no RaBitQ codes");
     VG_CHECK(queries && ids && scores, VG_ERR_INVALID_ARG, "vg_search_rabitq: NULL buffer");
-    VG_CHECK(k <= 64, VG_ERR_UNSUPPORTED, "vg_search_rabitq: k=%d exceeds 64", k);
+    VG_CHECK(k <= 512, VG_ERR_UNSUPPORTED, "vg_search_rabitq: k=%d exceeds 512", k);
     VG_HIP(hipSetDevice(idx->ctx->device));
     hipStream_t st = vg::pick_stream(idx->ctx, stream);
     vg::DevIn<float> q;
@@ -380,23 +391,43 @@ VG_API int32_t vg_search_rabitq(vg_index *idx, const float *queries, int64_t nq,
         const int slices = vg::rq_slices(nq, idx->n_tiles, idx->ctx->compute_units);
         vg::ArenaCall ar(idx->ctx, st);
         const int i_qcodes = ar.add(static_cast<size_t>(nq) * (nb + 4));
-        const int i_partial = ar.add(sizeof(uint64_t) * static_cast<size_t>(nq) * slices * k);
+        // a wave keeps 64 keys: k > 64 comes in pages of 64, one scan per page
+        const bool paged = k > 64;
+        const int pk = paged ? 64 : k;
+        const int i_partial = ar.add(sizeof(uint64_t) * static_cast<size_t>(nq) * slices * pk);
+        const int i_pid = ar.add(paged ? sizeof(uint32_t) * static_cast<size_t>(nq) * pk : 0);
+        const int i_psc = ar.add(paged ? sizeof(float) * static_cast<size_t>(nq) * pk : 0);
+        const int i_floor = ar.add(paged ? sizeof(uint64_t) * static_cast<size_t>(nq) : 0);
+        const int i_one = ar.add(paged ? 256 : 0);
         VG_TRY(ar.commit());
         struct { uint8_t *ptr; } qcodes{ar.get<uint8_t>(i_qcodes)};
         struct { uint64_t *ptr; } partial{ar.get<uint64_t>(i_partial)};
+        uint64_t *floor_keys = ar.get<uint64_t>(i_floor);
+        uint32_t *pid = ar.get<uint32_t>(i_pid);
+        float *psc = ar.get<float>(i_psc);
+        int *one = ar.get<int>(i_one);
+        if (paged) VG_HIP(hipMemsetAsync(one, 1, sizeof(int), st));
         VG_LAUNCH(vg::rabitq_encode_kernel, dim3(static_cast<unsigned>((nq + 15) / 16)), dim3(256), 0, st,
                            q.ptr, nq, idx->dim, qcodes.ptr);
         const int64_t max_q = (1ll << 30) / slices;
-        for (int64_t q0 = 0; q0 < nq; q0 += max_q) {
-            const int64_t cnt = nq - q0 < max_q ? nq - q0 : max_q;
-            vg::ProfScope prof(idx->ctx, "rabitq_scan", st);
-            VG_LAUNCH(vg::rabitq_scan_kernel, dim3(static_cast<unsigned>(cnt * slices)),
-                               dim3(vg::kRqThreads), 0, st, reinterpret_cast<const uint4 *>(idx->d_rq_tiles),
-                               idx->d_rq_norms, idx->n, idx->n_tiles, idx->rq_groups, idx->dim,
-                               qcodes.ptr + q0 * (nb + 4), nb, slices, static_cast<int>(cnt), k,
-                               partial.ptr + q0 * slices * k);
+        for (int off = 0; off < k; off += 64) {
+            const int kk = paged ? std::min(64, k - off) : k;
+            for (int64_t q0 = 0; q0 < nq; q0 += max_q) {
+                const int64_t cnt = nq - q0 < max_q ? nq - q0 : max_q;
+                vg::ProfScope prof(idx->ctx, "rabitq_scan", st);
+                VG_LAUNCH(vg::rabitq_scan_kernel, dim3(static_cast<unsigned>(cnt * slices)),
+                                   dim3(vg::kRqThreads), 0, st, reinterpret_cast<const uint4 *>(idx->d_rq_tiles),
+                                   idx->d_rq_norms, idx->n, idx->n_tiles, idx->rq_groups, idx->dim,
+                                   qcodes.ptr + q0 * (nb + 4), nb, slices, static_cast<int>(cnt), kk,
+                                   partial.ptr + q0 * slices * kk, off ? floor_keys + q0 : nullptr);
+            }
+            if (!paged) {
+                VG_TRY(vg::launch_topk_merge(partial.ptr, nq, slices, k, false, oid.ptr, osc.ptr, st));
+            } else {
+                VG_TRY(vg::launch_topk_merge(partial.ptr, nq, slices, kk, false, pid, psc, st));
+                VG_TRY(vg::launch_page_patch(nq, k, off, kk, false, one, pid, psc, oid.ptr, osc.ptr, floor_keys, st));
+            }
         }
-        VG_TRY(vg::launch_topk_merge(partial.ptr, nq, slices, k, false, oid.ptr, osc.ptr, st));
     }
     VG_TRY(oid.finish());
     VG_TRY(osc.finish());
