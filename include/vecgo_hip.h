@@ -356,7 +356,7 @@ enum { VG_SCAN_F32 = 0, VG_SCAN_PQ = 1, VG_SCAN_SQ8 = 2 };
 /* The partition-probed scan of flat.Segment.Search: per query kmeans.FindClosestCentroids(nprobes)
  * (kmeans.go:217-280; nprobes <= 0 means 1), then the chosen scan over those partitions' row ranges
  * only, one top-k by (score, row id).  With at most one partition it is vg_search_flat /
- * vg_search_pq_adc / vg_search_sq8.  k <= 64, nprobes <= 64. */
+ * vg_search_pq_adc / vg_search_sq8.  k <= 512 (pages of 64 results), nprobes <= 64. */
 int32_t vg_search_flat_probed(vg_index *idx, const float *queries, int64_t nq, int32_t k, int32_t nprobes,
                               int32_t scan, uint32_t *ids, float *scores, void *stream);
 
@@ -384,7 +384,7 @@ int32_t vg_segment_open_flat(vg_ctx *ctx, const void *image, int64_t size, int32
 /* flat.Segment.Search (flat/segment.go:447-751, filter == nil) for a batch of queries: the scan type
  * follows the segment (SQ8 codes: L2Distance / DotProduct by metric; PQ: table lookups, L2 segments
  * only — see vg_segment.hip; else fp32 rows) and, when the segment has more than one IVF partition,
- * only the nprobes closest partitions are scanned (:727-744; nprobes <= 0 means 1).  k <= 64 and
+ * only the nprobes closest partitions are scanned (:727-744; nprobes <= 0 means 1).  k <= 512 and
  * nprobes <= 64 on the partitioned path.
  * On a DiskANN segment: diskann.Segment.Search (diskann/segment.go:487-706) = vg_search_vamana with
  * the distFn of the segment's quantization (RaBitQ, else PQ, else INT4, else fp32); nprobes is unused,

@@ -166,6 +166,42 @@ def test_probe_errors(vg, ctx):
         idx.set_partitions(np.zeros((2, 8), np.float32), [0, 60, 101])  # past the last row
     idx.set_partitions(np.zeros((2, 8), np.float32), [0, 60, 100])
     with pytest.raises(vg.VecgoHipError):
-        idx.search_flat_probed(np.zeros((1, 8), np.float32), 65, 1)     # k <= 64
+        idx.search_flat_probed(np.zeros((1, 8), np.float32), 513, 1)    # k <= 512
     with pytest.raises(vg.VecgoHipError):
         idx.search_flat_probed(np.zeros((1, 8), np.float32), 5, 1, scan=idx.SCAN_PQ)  # no PQ codes
+
+
+@pytest.mark.parametrize("scan_name", ["f32", "sq8", "pq"])
+def test_probed_scans_page_beyond_64_results(vg, ctx, scan_name):
+    """k > 64 on the probed path: pages of 64 results, each page a scan of the same probed ranges for the keys
+    after the previous page's last one — pair-by-pair and grouped kernels, every scan type."""
+    rng = np.random.default_rng(99)
+    n, dim, parts = 4000, 64, 5
+    x, cent, off = partitioned(rng, n, dim, parts)
+    x[off[2] + 5:off[2] + 80] = x[off[2] + 1]      # a run of equal scores longer than a page, inside one partition
+    idx = vg.Index(ctx, n, dim)
+    kw = {}
+    if scan_name == "f32":
+        idx.set_vectors(x); scan = idx.SCAN_F32
+    elif scan_name == "sq8":
+        sq = vg.ScalarQuantizer(ctx, dim); sq.train(x)
+        ref = o.ScalarQuantizer(dim); ref.train(x)
+        codes = sq.encode(x)
+        idx.set_sq8_codes(sq, codes); scan = idx.SCAN_SQ8
+        kw = dict(sq=ref, codes=codes)
+    else:
+        pq = vg.ProductQuantizer(ctx, dim, 8, 256); pq.train(x, iters=3, seed=4)
+        codes = pq.encode(x)
+        cb, scales, offsets = pq.codebooks()
+        opq = o.ProductQuantizer(dim, 8, 256); opq.set_codebooks(cb, scales, offsets)
+        idx.set_pq_codes(pq, codes); scan = idx.SCAN_PQ
+        kw = dict(pq=opq, codes=codes)
+    idx.set_partitions(cent, off)
+    seg = o.FlatSegment(x, dim, centroids=cent, part_offsets=off, **kw)
+    few = rng.standard_normal((3, dim)).astype(np.float32)       # 3 x 2 pairs: the pair-by-pair kernels
+    few[0] = x[off[2] + 1]
+    many = rng.standard_normal((40, dim)).astype(np.float32)     # 40 x 3 pairs: the grouped kernels
+    many[0] = x[off[2] + 1]
+    for q, nprobes, k in ((few, 2, 100), (many, 3, 200), (few, parts, 512)):
+        ids, sc = idx.search_flat_probed(q, k, nprobes, scan=scan)
+        check(ids[:5], sc[:5], seg, q[:5], k, nprobes)

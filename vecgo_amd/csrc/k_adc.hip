@@ -759,7 +759,7 @@ int32_t launch_pq_build_table(const vg_pq *pq, const float *d_queries, int64_t n
 __global__ __launch_bounds__(kAdcThreads) void pq_adc_probe_kernel(
     const uint4 *__restrict__ tiles, int64_t n_rows, int m, int groups, const float *__restrict__ tables,
     const uint32_t *__restrict__ probes, const uint32_t *__restrict__ part_off, int np, int split, int k,
-    uint64_t *__restrict__ partial)
+    uint64_t *__restrict__ partial, const uint64_t *__restrict__ min_keys)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float *lut = reinterpret_cast<float *>(smem);
@@ -810,8 +810,9 @@ __global__ __launch_bounds__(kAdcThreads) void pq_adc_probe_kernel(
                 for (int l = 0; l < tail; l++) total = total + lut[lut_tail_word + l * 256 + code_byte(c, l)];
             }
             const int64_t row = tile * 64 + lane;
-            wtk.offer(row >= R0 && row < R1 && row < n_rows ? make_key(total, static_cast<uint32_t>(row), false) : kKeyMax,
-                      lane);
+            uint64_t key = row >= R0 && row < R1 && row < n_rows ? make_key(total, static_cast<uint32_t>(row), false) : kKeyMax;
+            if (min_keys && key <= min_keys[q]) key = kKeyMax;  // paged results (k > 64)
+            wtk.offer(key, lane);
         }
     }
     wg_rank_merge<kAdcWaves>(wtk, buf, reinterpret_cast<int *>(buf + kAdcWaves * 64), wave, lane, tid, k,
@@ -819,7 +820,7 @@ __global__ __launch_bounds__(kAdcThreads) void pq_adc_probe_kernel(
 }
 
 int32_t launch_probe_scan_adc(const vg_index *idx, const float *tables, const uint32_t *probes, int64_t nq, int np,
-                              int split, int k, uint64_t *partial, hipStream_t st)
+                              int split, int k, uint64_t *partial, const uint64_t *min_keys, hipStream_t st)
 {
     const vg_pq *pq = idx->pq;
     const size_t lds = static_cast<size_t>(lut_image_words(pq->m)) * sizeof(float) + kAdcWaves * 64 * sizeof(uint64_t) + 64;
@@ -831,7 +832,7 @@ int32_t launch_probe_scan_adc(const vg_index *idx, const float *tables, const ui
         VG_LAUNCH(pq_adc_probe_kernel, dim3(static_cast<unsigned>(split), static_cast<unsigned>(cnt)), dim3(kAdcThreads),
                   lds, st, reinterpret_cast<const uint4 *>(idx->d_pq_tiles), idx->n, pq->m, idx->pq_groups,
                   tables + q0 * lut_image_words(pq->m), probes + q0 * np, idx->d_part_off, np, split, k,
-                  partial + q0 * split * k);
+                  partial + q0 * split * k, min_keys ? min_keys + q0 : nullptr);
     }
     return VG_OK;
 }

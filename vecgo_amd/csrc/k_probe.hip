@@ -21,12 +21,15 @@ int32_t launch_topk_merge(const uint64_t *partial, int64_t nq, int lists, int k,
 int32_t launch_pq_build_table(const vg_pq *pq, const float *d_queries, int64_t nq, float *d_tables,
                               bool scan_layout, hipStream_t st);
 int32_t launch_probe_scan_adc(const vg_index *idx, const float *tables, const uint32_t *probes, int64_t nq, int np,
-                              int split, int k, uint64_t *partial, hipStream_t st);
+                              int split, int k, uint64_t *partial, const uint64_t *min_keys, hipStream_t st);
 int32_t launch_probe_scan_sq8(const vg_index *idx, const float *queries, const uint32_t *probes, int64_t nq, int np,
-                              int sub, int k, uint64_t *partial, hipStream_t st);
+                              int sub, int k, uint64_t *partial, const uint64_t *min_keys, hipStream_t st);
 int32_t launch_probe_scan_sq8_grouped(const vg_index *idx, const float *queries, const uint32_t *pair_of,
                                       const ProbeGroup *groups, const uint32_t *ngroups, unsigned gmax, int np, int sub,
-                                      int k, uint64_t *partial, hipStream_t st);
+                                      int k, uint64_t *partial, const uint64_t *min_keys, hipStream_t st);
+int32_t launch_page_patch(int64_t nq, int k, int off, int kk, bool descending, const int *always_one,
+                          const uint32_t *fids, const float *fscores, uint32_t *ids, float *scores, uint64_t *min_keys,
+                          hipStream_t st);
 
 // ---- 1. the nprobes closest centroids (kmeans.go:217-280) -----------------------------------------
 // 16 lanes per centroid, batch-kernel order; for Dot / Cosine the reference sorts -dot ascending,
@@ -65,7 +68,8 @@ __global__ __launch_bounds__(256) void probe_scan_f32_kernel(const float *__rest
                                                              const float *__restrict__ queries,
                                                              const uint32_t *__restrict__ probes,
                                                              const uint32_t *__restrict__ part_off, int np, int sub_n,
-                                                             int k, uint64_t *__restrict__ partial)
+                                                             int k, uint64_t *__restrict__ partial,
+                                                             const uint64_t *__restrict__ min_keys)
 {
     __shared__ uint64_t lists[4 * 64];
     __shared__ int valid[4];
@@ -84,7 +88,10 @@ __global__ __launch_bounds__(256) void probe_scan_f32_kernel(const float *__rest
         uint64_t key = kKeyMax;
         if (i < r1) {
             const float v = exact_pair16<DOT, kPair>(base + i * dim, qv, dim, sub);
-            if ((lane & 15) == 0) key = make_key(v, static_cast<uint32_t>(i), DOT);
+            if ((lane & 15) == 0) {
+                key = make_key(v, static_cast<uint32_t>(i), DOT);
+                if (min_keys && key <= min_keys[q]) key = kKeyMax;  // paged results (k > 64)
+            }
         }
         tk.offer(key, lane);
     }
@@ -158,7 +165,8 @@ __global__ __launch_bounds__(256) void probe_scan_f32_mq_kernel(const float *__r
                                                                 const uint32_t *__restrict__ pair_of,
                                                                 const ProbeGroup *__restrict__ groups,
                                                                 const uint32_t *__restrict__ ngroups, int np,
-                                                                int sub_n, int k, uint64_t *__restrict__ partial)
+                                                                int sub_n, int k, uint64_t *__restrict__ partial,
+                                                                const uint64_t *__restrict__ min_keys)
 {
     extern __shared__ float qlds[];  // kProbeQB * dim floats, then the merge scratch
     uint64_t *lists = reinterpret_cast<uint64_t *>(qlds + static_cast<size_t>(kProbeQB) * dim);
@@ -205,6 +213,7 @@ __global__ __launch_bounds__(256) void probe_scan_f32_mq_kernel(const float *__r
             uint64_t key = kKeyMax;
             if ((lane & 15) == 0 && livea) key = make_key(va, static_cast<uint32_t>(ia), DOT);
             if ((lane & 15) == 1 && liveb) key = make_key(vb, static_cast<uint32_t>(ib), DOT);
+            if (min_keys && key != kKeyMax && key <= min_keys[pair[qi] / np]) key = kKeyMax;  // paged results (k > 64)
             return key;
         };
         if (cnt == kProbeQB) {  // a full group: no per-query branches, the scores of all the queries first
@@ -278,7 +287,7 @@ VG_API int32_t vg_search_flat_probed(vg_index *idx, const float *queries, int64_
     VG_CHECK(nq >= 0 && k >= 0, VG_ERR_INVALID_ARG, "vg_search_flat_probed: negative nq or k");
     if (nq == 0 || k == 0) return VG_OK;
     VG_CHECK(queries && ids && scores, VG_ERR_INVALID_ARG, "vg_search_flat_probed: NULL buffer");
-    VG_CHECK(k <= 64, VG_ERR_UNSUPPORTED, "vg_search_flat_probed: k=%d exceeds 64", k);
+    VG_CHECK(k <= 512, VG_ERR_UNSUPPORTED, "vg_search_flat_probed: k=%d exceeds 512", k);
     VG_CHECK(idx->metric != VG_METRIC_HAMMING, VG_ERR_UNSUPPORTED, "unsupported metric for float32: Hamming");
     int np = nprobes <= 0 ? 1 : nprobes;  // segment.go:728-731
     if (np > idx->num_partitions) np = idx->num_partitions;  // kmeans.go:219-221
@@ -335,13 +344,23 @@ VG_API int32_t vg_search_flat_probed(vg_index *idx, const float *queries, int64_
     const int i_pair_of = ar.add(grouped ? sizeof(uint32_t) * static_cast<size_t>(chunk_pairs) : 0);
     const int i_groups = ar.add(grouped ? sizeof(vg::ProbeGroup) * static_cast<size_t>(chunk_pairs) : 0);
     const int i_ngroups = ar.add(grouped ? 256 : 0);
+    const bool paged = k > 64;
+    const int pk = paged ? 64 : k;
     const int i_probes = ar.add(sizeof(uint32_t) * static_cast<size_t>(nq) * np);
-    const int i_partial = ar.add(sizeof(uint64_t) * static_cast<size_t>(nq) * lists * k);
+    const int i_partial = ar.add(sizeof(uint64_t) * static_cast<size_t>(nq) * lists * pk);
+    const int i_pid = ar.add(paged ? sizeof(uint32_t) * static_cast<size_t>(nq) * pk : 0);
+    const int i_psc = ar.add(paged ? sizeof(float) * static_cast<size_t>(nq) * pk : 0);
+    const int i_floor = ar.add(paged ? sizeof(uint64_t) * static_cast<size_t>(nq) : 0);
+    const int i_one = ar.add(paged ? 256 : 0);
     const int i_tables = ar.add(sizeof(float) * static_cast<size_t>(nq) * lut_words);
     VG_TRY(ar.commit());
     uint32_t *probes = ar.get<uint32_t>(i_probes);
     uint64_t *partial = ar.get<uint64_t>(i_partial);
     float *tables = ar.get<float>(i_tables);
+    uint32_t *pid = ar.get<uint32_t>(i_pid);
+    float *psc = ar.get<float>(i_psc);
+    uint64_t *floor_keys = ar.get<uint64_t>(i_floor);
+    int *one = ar.get<int>(i_one);
     uint32_t *gcounts = ar.get<uint32_t>(i_gcounts), *gcursor = ar.get<uint32_t>(i_gcursor);
     uint32_t *gstart = ar.get<uint32_t>(i_gstart), *pair_of = ar.get<uint32_t>(i_pair_of);
     uint32_t *ngroups = ar.get<uint32_t>(i_ngroups);
@@ -353,48 +372,58 @@ VG_API int32_t vg_search_flat_probed(vg_index *idx, const float *queries, int64_
     else
         VG_LAUNCH(vg::probe_select_kernel<false>, dim3(static_cast<unsigned>(nq)), dim3(256), 0, st, q.ptr, idx->dim,
                   idx->d_centroids, idx->num_partitions, np, probes);
-    if (grouped) {
-        const size_t lds = sizeof(float) * vg::kProbeQB * static_cast<size_t>(idx->dim) + 4 * 64 * sizeof(uint64_t) + 64;
-        auto kern = dot ? vg::probe_scan_f32_mq_kernel<true> : vg::probe_scan_f32_mq_kernel<false>;
-        VG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   static_cast<int>(lds)));
-        for (int64_t q0 = 0; q0 < nq; q0 += qchunk) {
-            const int64_t cnt = std::min<int64_t>(qchunk, nq - q0);
-            const int64_t cpairs = cnt * np;
-            const unsigned gmax = static_cast<unsigned>(std::min<int64_t>(cpairs, cpairs / vg::kProbeQB + idx->num_partitions));
-            VG_HIP(hipMemsetAsync(gcounts, 0, sizeof(uint32_t) * (static_cast<size_t>(idx->num_partitions) + 1), st));
-            VG_LAUNCH(vg::probe_group_kernel, dim3(1), dim3(1024), 0, st, probes + q0 * np, cpairs, idx->num_partitions,
-                      gcounts, gcursor, gstart, pair_of, groups, ngroups);
-            if (grouped_sq8) {
-                VG_TRY(vg::launch_probe_scan_sq8_grouped(idx, q.ptr + q0 * idx->dim, pair_of, groups, ngroups, gmax, np, sub, k,
-                                                         partial + q0 * lists * k, st));
-                continue;
+    const bool desc = scan != VG_SCAN_PQ && dot;  // table-lookup scores are squared L2 (ascending); fp32 and SQ8 follow the metric
+    const size_t mq_lds = sizeof(float) * vg::kProbeQB * static_cast<size_t>(idx->dim) + 4 * 64 * sizeof(uint64_t) + 64;
+    auto mq_kern = dot ? vg::probe_scan_f32_mq_kernel<true> : vg::probe_scan_f32_mq_kernel<false>;
+    if (grouped_f32)
+        VG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(mq_kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   static_cast<int>(mq_lds)));
+    if (scan == VG_SCAN_PQ) VG_TRY(vg::launch_pq_build_table(idx->pq, q.ptr, nq, tables, true, st));
+    if (paged) VG_HIP(hipMemsetAsync(one, 1, sizeof(int), st));
+    // a wave keeps 64 keys: k > 64 comes in pages of 64 results, each page a scan of the probed ranges for the
+    // keys after the previous page's last one
+    for (int off = 0; off < k; off += 64) {
+        const int kk = paged ? std::min(64, k - off) : k;
+        const uint64_t *floor = off ? floor_keys : nullptr;
+        if (grouped) {
+            for (int64_t q0 = 0; q0 < nq; q0 += qchunk) {
+                const int64_t cnt = std::min<int64_t>(qchunk, nq - q0);
+                const int64_t cpairs = cnt * np;
+                const unsigned gmax = static_cast<unsigned>(std::min<int64_t>(cpairs, cpairs / vg::kProbeQB + idx->num_partitions));
+                VG_HIP(hipMemsetAsync(gcounts, 0, sizeof(uint32_t) * (static_cast<size_t>(idx->num_partitions) + 1), st));
+                VG_LAUNCH(vg::probe_group_kernel, dim3(1), dim3(1024), 0, st, probes + q0 * np, cpairs, idx->num_partitions,
+                          gcounts, gcursor, gstart, pair_of, groups, ngroups);
+                if (grouped_sq8) {
+                    VG_TRY(vg::launch_probe_scan_sq8_grouped(idx, q.ptr + q0 * idx->dim, pair_of, groups, ngroups, gmax, np, sub, kk,
+                                                             partial + q0 * lists * kk, floor ? floor + q0 : nullptr, st));
+                    continue;
+                }
+                vg::ProfScope prof(idx->ctx, "flat_probe", st);
+                VG_LAUNCH(mq_kern, dim3(static_cast<unsigned>(sub), gmax), dim3(256), mq_lds, st, idx->d_vectors, idx->dim,
+                          q.ptr + q0 * idx->dim, idx->d_part_off, pair_of, groups, ngroups, np, sub, kk,
+                          partial + q0 * lists * kk, floor ? floor + q0 : nullptr);
             }
-            vg::ProfScope prof(idx->ctx, "flat_probe", st);
-            VG_LAUNCH(kern, dim3(static_cast<unsigned>(sub), gmax), dim3(256), lds, st, idx->d_vectors, idx->dim,
-                      q.ptr + q0 * idx->dim, idx->d_part_off, pair_of, groups, ngroups, np, sub, k,
-                      partial + q0 * lists * k);
+        } else if (scan == VG_SCAN_F32) {
+            for (int64_t q0 = 0; q0 < nq; q0 += 65535) {
+                const int64_t cnt = std::min<int64_t>(65535, nq - q0);
+                const dim3 grid(static_cast<unsigned>(sub), static_cast<unsigned>(np), static_cast<unsigned>(cnt));
+                vg::ProfScope prof(idx->ctx, "flat_probe", st);
+                auto kern = dot ? vg::probe_scan_f32_kernel<true> : vg::probe_scan_f32_kernel<false>;
+                VG_LAUNCH(kern, grid, dim3(256), 0, st, idx->d_vectors, idx->dim, q.ptr + q0 * idx->dim, probes + q0 * np,
+                          idx->d_part_off, np, sub, kk, partial + q0 * lists * kk, floor ? floor + q0 : nullptr);
+            }
+        } else if (scan == VG_SCAN_PQ) {
+            VG_TRY(vg::launch_probe_scan_adc(idx, tables, probes, nq, np, split, kk, partial, floor, st));
+        } else {
+            VG_TRY(vg::launch_probe_scan_sq8(idx, q.ptr, probes, nq, np, sub, kk, partial, floor, st));
         }
-    } else if (scan == VG_SCAN_F32) {
-        for (int64_t q0 = 0; q0 < nq; q0 += 65535) {
-            const int64_t cnt = std::min<int64_t>(65535, nq - q0);
-            const dim3 grid(static_cast<unsigned>(sub), static_cast<unsigned>(np), static_cast<unsigned>(cnt));
-            vg::ProfScope prof(idx->ctx, "flat_probe", st);
-            if (dot)
-                VG_LAUNCH(vg::probe_scan_f32_kernel<true>, grid, dim3(256), 0, st, idx->d_vectors, idx->dim,
-                          q.ptr + q0 * idx->dim, probes + q0 * np, idx->d_part_off, np, sub, k, partial + q0 * lists * k);
-            else
-                VG_LAUNCH(vg::probe_scan_f32_kernel<false>, grid, dim3(256), 0, st, idx->d_vectors, idx->dim,
-                          q.ptr + q0 * idx->dim, probes + q0 * np, idx->d_part_off, np, sub, k, partial + q0 * lists * k);
+        if (!paged) {
+            VG_TRY(vg::launch_topk_merge(partial, nq, lists, k, desc, oid.ptr, osc.ptr, st));
+        } else {
+            VG_TRY(vg::launch_topk_merge(partial, nq, lists, kk, desc, pid, psc, st));
+            VG_TRY(vg::launch_page_patch(nq, k, off, kk, desc, one, pid, psc, oid.ptr, osc.ptr, floor_keys, st));
         }
-    } else if (scan == VG_SCAN_PQ) {
-        VG_TRY(vg::launch_pq_build_table(idx->pq, q.ptr, nq, tables, true, st));
-        VG_TRY(vg::launch_probe_scan_adc(idx, tables, probes, nq, np, split, k, partial, st));
-    } else {
-        VG_TRY(vg::launch_probe_scan_sq8(idx, q.ptr, probes, nq, np, sub, k, partial, st));
     }
-    // table-lookup scores are squared L2 (ascending); fp32 and SQ8 (L2Distance / DotProduct) follow the metric
-    VG_TRY(vg::launch_topk_merge(partial, nq, lists, k, scan != VG_SCAN_PQ && dot, oid.ptr, osc.ptr, st));
     VG_TRY(oid.finish());
     VG_TRY(osc.finish());
     if (oid.on_host() || osc.on_host()) VG_HIP(hipStreamSynchronize(st));

@@ -326,7 +326,8 @@ template <bool DOT>
 __global__ __launch_bounds__(kSqThreads) void sq8_probe_kernel(
     const uint4 *__restrict__ tiles, int64_t n_rows, int groups, int dim, const float *__restrict__ queries,
     const float *__restrict__ mins, const float *__restrict__ inv, const uint32_t *__restrict__ probes,
-    const uint32_t *__restrict__ part_off, int np, int sub, int k, uint64_t *__restrict__ partial)
+    const uint32_t *__restrict__ part_off, int np, int sub, int k, uint64_t *__restrict__ partial,
+    const uint64_t *__restrict__ min_keys)
 {
     __shared__ uint64_t lists[kSqWaves * 64];
     __shared__ int valid[kSqWaves];
@@ -344,7 +345,9 @@ __global__ __launch_bounds__(kSqThreads) void sq8_probe_kernel(
     for (int64_t tile = t0 + wave; tile < t1; tile += kSqWaves) {
         const float total = sq8_row_score<DOT>(tiles + (tile * groups) * 64 + lane, groups, full, tail, qv, mins, inv);
         const int64_t row = tile * 64 + lane;
-        tk.offer(row >= R0 && row < R1 && row < n_rows ? make_key(total, static_cast<uint32_t>(row), DOT) : kKeyMax, lane);
+        uint64_t key = row >= R0 && row < R1 && row < n_rows ? make_key(total, static_cast<uint32_t>(row), DOT) : kKeyMax;
+        if (min_keys && key <= min_keys[q]) key = kKeyMax;  // paged results (k > 64)
+        tk.offer(key, lane);
     }
     wg_rank_merge<kSqWaves>(tk, lists, valid, wave, lane, tid, k, partial + ((q * np + j) * sub + s) * k);
 }
@@ -501,7 +504,7 @@ __global__ __launch_bounds__(kSqThreads) void sq8_probe_mq_kernel(
     const uint4 *__restrict__ tiles, int64_t n_rows, int groups, int dim, const float *__restrict__ queries,
     const float *__restrict__ mins, const float *__restrict__ inv, const uint32_t *__restrict__ part_off,
     const uint32_t *__restrict__ pair_of, const ProbeGroup *__restrict__ pgroups, const uint32_t *__restrict__ ngroups,
-    int np, int sub, int k, uint64_t *__restrict__ partial)
+    int np, int sub, int k, uint64_t *__restrict__ partial, const uint64_t *__restrict__ min_keys)
 {
     extern __shared__ __attribute__((aligned(16))) float qlds[];  // kProbeQB * dimp floats, then the merge scratch
     const int dimp = groups * 16;
@@ -542,8 +545,11 @@ __global__ __launch_bounds__(kSqThreads) void sq8_probe_mq_kernel(
                     sq8_row_scores_mq<DOT, false>(tp, groups, full, tail, left, qlds + qb * dimp, dimp, mins, inv, total);
 #pragma unroll
                 for (int qi = 0; qi < kSqProbeQ; qi++)
-                    if (qb + qi < cnt)
-                        tk[qb + qi].offer(live ? make_key(total[qi], static_cast<uint32_t>(row), DOT) : kKeyMax, lane);
+                    if (qb + qi < cnt) {
+                        uint64_t key = live ? make_key(total[qi], static_cast<uint32_t>(row), DOT) : kKeyMax;
+                        if (min_keys && key <= min_keys[pair[qb + qi] / np]) key = kKeyMax;  // paged results (k > 64)
+                        tk[qb + qi].offer(key, lane);
+                    }
             }
         }
     }
@@ -559,7 +565,7 @@ __global__ __launch_bounds__(kSqThreads) void sq8_probe_mq_kernel(
 
 int32_t launch_probe_scan_sq8_grouped(const vg_index *idx, const float *queries, const uint32_t *pair_of,
                                       const ProbeGroup *groups, const uint32_t *ngroups, unsigned gmax, int np, int sub,
-                                      int k, uint64_t *partial, hipStream_t st)
+                                      int k, uint64_t *partial, const uint64_t *min_keys, hipStream_t st)
 {
     const bool dot = idx->metric != VG_METRIC_L2;
     auto kern = dot ? sq8_probe_mq_kernel<true> : sq8_probe_mq_kernel<false>;
@@ -570,12 +576,12 @@ int32_t launch_probe_scan_sq8_grouped(const vg_index *idx, const float *queries,
     ProfScope prof(idx->ctx, "sq8_probe", st);
     VG_LAUNCH(kern, dim3(static_cast<unsigned>(sub), gmax), dim3(kSqThreads), lds, st,
               reinterpret_cast<const uint4 *>(idx->d_sq_tiles), idx->n, idx->sq_groups, idx->dim, queries, idx->sq->d_mins,
-              idx->sq->d_inv, idx->d_part_off, pair_of, groups, ngroups, np, sub, k, partial);
+              idx->sq->d_inv, idx->d_part_off, pair_of, groups, ngroups, np, sub, k, partial, min_keys);
     return VG_OK;
 }
 
 int32_t launch_probe_scan_sq8(const vg_index *idx, const float *queries, const uint32_t *probes, int64_t nq, int np,
-                              int sub, int k, uint64_t *partial, hipStream_t st)
+                              int sub, int k, uint64_t *partial, const uint64_t *min_keys, hipStream_t st)
 {
     for (int64_t q0 = 0; q0 < nq; q0 += 65535) {
         const int64_t cnt = nq - q0 < 65535 ? nq - q0 : 65535;
@@ -584,7 +590,7 @@ int32_t launch_probe_scan_sq8(const vg_index *idx, const float *queries, const u
         VG_LAUNCH(kern, dim3(static_cast<unsigned>(sub), static_cast<unsigned>(np), static_cast<unsigned>(cnt)),
                   dim3(kSqThreads), 0, st, reinterpret_cast<const uint4 *>(idx->d_sq_tiles), idx->n, idx->sq_groups, idx->dim,
                   queries + q0 * idx->dim, idx->sq->d_mins, idx->sq->d_inv, probes + q0 * np, idx->d_part_off, np, sub, k,
-                  partial + q0 * np * sub * k);
+                  partial + q0 * np * sub * k, min_keys ? min_keys + q0 : nullptr);
     }
     return VG_OK;
 }
