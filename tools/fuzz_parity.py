@@ -57,7 +57,7 @@ while time.time() < t_end:
             cent = rng.standard_normal((parts, dim)).astype(np.float32)
             nprobes = int(rng.integers(0, parts + 2))
             idx.set_partitions(cent, off)
-            kk = min(k, 64)
+            kk = k
             kind = int(rng.integers(0, 3))
             if kind == 1 and metric != 1:        # SQ8 codes: L2Distance / DotProduct by metric
                 sq = vg.ScalarQuantizer(ctx, dim); sq.train(x)
@@ -89,14 +89,14 @@ while time.time() < t_end:
             ref = o.ScalarQuantizer(dim); ref.train(x)
             codes = sq.encode(x)
             idx.set_sq8_codes(sq, codes)
-            kk = min(k, 64)
+            kk = k
             ids, sc = idx.search_sq8(q, kk)
             seg = o.FlatSegment(x, dim, metric=metric, sq=ref, codes=codes)
             compare("sq8", cfg, ids, sc, [seg.search(q[i], kk) for i in range(nq)])
         elif which == 3 and metric == 0:
             codes = vg.RaBitQuantizer(ctx, dim).encode(x)
             idx.set_rabitq_codes(codes)
-            kk = min(k, 64)
+            kk = k
             ids, sc = idx.search_rabitq(q, kk)
             compare("rabitq", cfg, ids, sc, [o.flat_search_rabitq(codes, dim, q[i], kk) for i in range(nq)])
         elif which == 4 and metric == 0 and n >= 256:
