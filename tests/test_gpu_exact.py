@@ -96,3 +96,26 @@ def test_rerank_fewer_candidates_than_k(vg, ctx):
     with pytest.raises(vg.VecgoHipError) as e:
         vg.Index(ctx, 5, 64).rerank(q, np.zeros((1, 4), np.uint32), 2)
     assert e.value.status == -9
+
+
+@pytest.mark.parametrize("dim,metric,nc,k", [(128, 0, 700, 100), (96, 2, 300, 256), (64, 0, 90, 128)])
+def test_rerank_more_than_64_results(vg, ctx, dim, metric, nc, k):
+    """k > 64: the exact keys are sorted in LDS; a row listed twice is reported once."""
+    rng = np.random.default_rng(dim + k)
+    n, nq = 2000, 4
+    base = rng.standard_normal((n, dim)).astype(np.float32)
+    q = rng.standard_normal((nq, dim)).astype(np.float32)
+    idx = vg.Index(ctx, n, dim, vg.Metric(metric))
+    idx.set_vectors(base)
+    cand = np.stack([rng.permutation(n)[:nc] for _ in range(nq)]).astype(np.uint32)
+    cand[:, 7] = cand[:, 3]          # a duplicate candidate
+    cand[1, 11] = 0xFFFFFFFF
+    ids, scores = idx.rerank(q, cand, k)
+    for qi in range(nq):
+        uniq = np.unique(cand[qi][cand[qi] != 0xFFFFFFFF])
+        exp = o.rerank_f32(base, dim, q[qi], uniq, metric)
+        order = sorted(range(exp.size), key=lambda i: ((-exp[i] if metric else exp[i]), uniq[i]))[:k]
+        r = len(order)
+        assert np.array_equal(ids[qi, :r], uniq[order])
+        assert np.array_equal(bits(scores[qi, :r]), bits(exp[order]))
+        assert np.all(ids[qi, r:] == 0xFFFFFFFF)

@@ -64,6 +64,31 @@ __global__ __launch_bounds__(kExactThreads) void rerank_kernel(
         if ((threadIdx.x & 15) == 0) keys[c] = key;
     }
     __syncthreads();
+    if (k > 64) {  // more than one wave's register list: sort the keys in LDS (n2 = the padded power of two)
+        int n2 = 64;
+        while (n2 < nc) n2 <<= 1;
+        for (int c = nc + threadIdx.x; c < n2; c += kExactThreads) keys[c] = kKeyMax;
+        __syncthreads();
+        bitonic_sort_lds(keys, n2, threadIdx.x, kExactThreads);
+        if (threadIdx.x == 0) {  // the same row may appear twice in a candidate list: equal keys, keep one copy
+            int out = 0;
+            uint64_t prev = kKeyMax;
+            for (int c = 0; c < n2 && out < k; c++) {
+                const uint64_t e = keys[c];
+                if (e == kKeyMax) break;
+                if (c > 0 && e == prev) continue;
+                prev = e;
+                ids[q * k + out] = key_row(e);
+                scores[q * k + out] = key_score(e, DOT);
+                out++;
+            }
+            for (; out < k; out++) {
+                ids[q * k + out] = VG_INVALID_ID;
+                scores[q * k + out] = DOT ? -INFINITY : INFINITY;
+            }
+        }
+        return;
+    }
     if (threadIdx.x < 64) {  // wave 0 selects the k best (k <= 64)
         const int lane = threadIdx.x;
         WaveTopK tk;
@@ -235,8 +260,13 @@ VG_API int32_t vg_rerank(vg_index *idx, const float *queries, int64_t nq, const 
     VG_CHECK(idx->d_vectors, VG_ERR_NOT_READY, "vg_rerank: index has no fp32 vectors");
     VG_CHECK(queries && ids && scores && (nc == 0 || cand_ids), VG_ERR_INVALID_ARG,
              "vg_rerank: NULL buffer");
-    VG_CHECK(k <= 64, VG_ERR_UNSUPPORTED, "vg_rerank: k=%d exceeds 64", k);
-    VG_CHECK(static_cast<size_t>(nc) * 8 <= 160 * 1024 - 1024, VG_ERR_UNSUPPORTED,
+    VG_CHECK(k <= 512, VG_ERR_UNSUPPORTED, "vg_rerank: k=%d exceeds 512", k);
+    size_t key_slots = static_cast<size_t>(nc > 0 ? nc : 1);
+    if (k > 64) {  // sorted in LDS: padded to a power of two
+        key_slots = 64;
+        while (key_slots < static_cast<size_t>(nc)) key_slots <<= 1;
+    }
+    VG_CHECK(key_slots * 8 <= 160 * 1024 - 1024, VG_ERR_UNSUPPORTED,
              "vg_rerank: nc=%d candidates per query exceed the LDS key buffer", nc);
     VG_HIP(hipSetDevice(idx->ctx->device));
     hipStream_t st = vg::pick_stream(idx->ctx, stream);
@@ -249,7 +279,7 @@ VG_API int32_t vg_rerank(vg_index *idx, const float *queries, int64_t nq, const 
     VG_TRY(oid.init(ids, static_cast<size_t>(nq) * k, st));
     VG_TRY(osc.init(scores, static_cast<size_t>(nq) * k, st));
     const bool dot = metric_is_dot(idx->metric);
-    size_t lds = static_cast<size_t>(nc > 0 ? nc : 1) * 8;
+    size_t lds = key_slots * 8;
     auto kern = dot ? vg::rerank_kernel<true> : vg::rerank_kernel<false>;
     VG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
