@@ -239,7 +239,8 @@ int32_t vg_find_closest_centroids(vg_ctx *ctx, const float *query, const float *
  * engine/search.go:914-965): exact distance.SquaredL2 / distance.Dot
  * (squaredL2Avx512 / dotProductAvx512 order) of each query against its own nc
  * candidate rows, then the best k by (Score, RowID).  cand_ids[nq*nc] may hold
- * VG_INVALID_ID (skipped) and repeated rows (reported once).  k <= 512. */
+ * VG_INVALID_ID (skipped); a row listed twice is scored and reported twice, as in the reference's
+ * loop.  k <= 512. */
 int32_t vg_rerank(vg_index *idx, const float *queries, int64_t nq, const uint32_t *cand_ids,
                   int32_t nc, int32_t k, uint32_t *ids, float *scores, void *stream);
 /* exact scores only, scores[nq*nc] in candidate order (invalid ids → +Inf / -Inf) */

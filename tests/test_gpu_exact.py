@@ -100,7 +100,8 @@ def test_rerank_fewer_candidates_than_k(vg, ctx):
 
 @pytest.mark.parametrize("dim,metric,nc,k", [(128, 0, 700, 100), (96, 2, 300, 256), (64, 0, 90, 128)])
 def test_rerank_more_than_64_results(vg, ctx, dim, metric, nc, k):
-    """k > 64: the exact keys are sorted in LDS; a row listed twice is reported once."""
+    """k > 64: the exact keys are sorted in LDS; a row listed twice is reported twice (the reference's loop
+    re-scores whatever it is handed, flat/segment.go:757-779)."""
     rng = np.random.default_rng(dim + k)
     n, nq = 2000, 4
     base = rng.standard_normal((n, dim)).astype(np.float32)
@@ -112,7 +113,7 @@ def test_rerank_more_than_64_results(vg, ctx, dim, metric, nc, k):
     cand[1, 11] = 0xFFFFFFFF
     ids, scores = idx.rerank(q, cand, k)
     for qi in range(nq):
-        uniq = np.unique(cand[qi][cand[qi] != 0xFFFFFFFF])
+        uniq = cand[qi][cand[qi] != 0xFFFFFFFF]
         exp = o.rerank_f32(base, dim, q[qi], uniq, metric)
         order = sorted(range(exp.size), key=lambda i: ((-exp[i] if metric else exp[i]), uniq[i]))[:k]
         r = len(order)

@@ -70,22 +70,11 @@ __global__ __launch_bounds__(kExactThreads) void rerank_kernel(
         for (int c = nc + threadIdx.x; c < n2; c += kExactThreads) keys[c] = kKeyMax;
         __syncthreads();
         bitonic_sort_lds(keys, n2, threadIdx.x, kExactThreads);
-        if (threadIdx.x == 0) {  // the same row may appear twice in a candidate list: equal keys, keep one copy
-            int out = 0;
-            uint64_t prev = kKeyMax;
-            for (int c = 0; c < n2 && out < k; c++) {
-                const uint64_t e = keys[c];
-                if (e == kKeyMax) break;
-                if (c > 0 && e == prev) continue;
-                prev = e;
-                ids[q * k + out] = key_row(e);
-                scores[q * k + out] = key_score(e, DOT);
-                out++;
-            }
-            for (; out < k; out++) {
-                ids[q * k + out] = VG_INVALID_ID;
-                scores[q * k + out] = DOT ? -INFINITY : INFINITY;
-            }
+        // a row listed twice is scored twice and reported twice, like the reference's loop (segment.go:757-779)
+        for (int i = threadIdx.x; i < k; i += kExactThreads) {
+            const uint64_t e = i < n2 ? keys[i] : kKeyMax;
+            ids[q * k + i] = e == kKeyMax ? VG_INVALID_ID : key_row(e);
+            scores[q * k + i] = e == kKeyMax ? (DOT ? -INFINITY : INFINITY) : key_score(e, DOT);
         }
         return;
     }
@@ -96,7 +85,7 @@ __global__ __launch_bounds__(kExactThreads) void rerank_kernel(
         for (int c0 = 0; c0 < nc; c0 += 64) {
             const int c = c0 + lane;
             uint64_t key = c < nc ? keys[c] : kKeyMax;
-            // the same row may appear twice in a candidate list: keep one copy (keys are equal)
+            // a row listed twice is scored twice and reported twice, like the reference's loop
             tk.offer(key, lane);
         }
         if (lane < k) {
