@@ -429,7 +429,7 @@ int32_t vg_search_hnsw(vg_index *idx, const float *queries, int64_t nq, int32_t 
  * ComputeAsymmetricDistance (:536-541, terms summed sequentially over the sub-quantizers),
  * 2 = RaBitQ Distance (:512-519), 3 = INT4 L2Distance (:558-565).  Unbounded exploration
  * min-heap, top-k CandidateHeap,
- * stop when the popped candidate is worse than the k-th result.  k <= 64. */
+ * stop when the popped candidate is worse than the k-th result.  k <= 512. */
 int32_t vg_search_vamana(vg_index *idx, const float *queries, int64_t nq, int32_t k, int32_t kind,
                          uint32_t *ids, float *scores, vg_search_stats *stats, void *stream);
 

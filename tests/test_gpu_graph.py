@@ -82,7 +82,8 @@ def test_hnsw_duplicate_distances(vg, ctx):
 
 
 @pytest.mark.parametrize("kind", [0, 1, 2])
-@pytest.mark.parametrize("n,dim,r,k", [(1500, 32, 16, 10), (800, 768, 32, 10), (400, 96, 12, 3)])
+@pytest.mark.parametrize("n,dim,r,k", [(1500, 32, 16, 10), (800, 768, 32, 10), (400, 96, 12, 3),
+                                       (1200, 32, 16, 100), (600, 64, 16, 300), (90, 16, 8, 128)])  # k > 64: LDS result list
 def test_vamana_matches_oracle(vg, ctx, kind, n, dim, r, k):
     rng = np.random.default_rng(n + dim + kind)
     base = rng.standard_normal((n, dim)).astype(np.float32)

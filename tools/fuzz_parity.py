@@ -133,7 +133,7 @@ while time.time() < t_end:
         elif which == 6 and n >= 16 and metric != 1:
             r = int(rng.choice([8, 16, 32]))
             g, entry = graphs.build_vamana(x, r=r, seed=int(rng.integers(0, 1000)))
-            kk = min(k, 64)
+            kk = k
             oidx = o.VamanaIndex(g, entry, dim, kind=0, metric=metric, base=x)
             idx.set_vamana_graph(g, entry)
             ids, sc, st = idx.search_vamana(q, kk, kind=0, stats=True)

@@ -322,6 +322,8 @@ __device__ inline float rq_formula_g(float qn, float yn, float dimf, float hammi
     return t1sq + t2;
 }
 
+constexpr int kVamanaMaxK = 512;  // results per query: one per lane up to 64, a sorted LDS list beyond
+
 __global__ __launch_bounds__(64) void vamana_search_kernel(
     int kind, int metric, int64_t n, int dim, const uint32_t *__restrict__ graph, int r, uint32_t entry,
     const float *__restrict__ base, const uint8_t *__restrict__ pq_rows, int pq_m,
@@ -332,6 +334,7 @@ __global__ __launch_bounds__(64) void vamana_search_kernel(
     vg_search_stats *__restrict__ stats)
 {
     __shared__ float nb_d[64];
+    __shared__ uint64_t res[kVamanaMaxK];  // the result set when k > 64
     const int64_t q = blockIdx.x;
     const int lane = threadIdx.x;
     const Sub16 sub = Sub16::make(lane);
@@ -413,7 +416,51 @@ __global__ __launch_bounds__(64) void vamana_search_kernel(
     };
 
     WaveTopK tk;  // sc.Heap: top-k by (Score, RowID) — candidate_queue.go:12-23
-    tk.init(k);
+    tk.init(k < 64 ? k : 64);
+    // k > 64: the k best keys as a sorted list in LDS instead of one key per lane (wave-uniform bookkeeping)
+    const bool big = k > 64;
+    int res_n = 0;
+    uint64_t res_tau = kKeyMax;
+    auto res_insert = [&](uint64_t c) {  // c < res_tau, every lane calls it with the same key
+        int lo = 0, hi = res_n;          // first position whose key is >= c (keys are distinct)
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (res[mid] < c)
+                lo = mid + 1;
+            else
+                hi = mid;
+        }
+        const int newn = res_n < k ? res_n + 1 : k;
+        uint64_t moved[kVamanaMaxK / 64];
+#pragma unroll
+        for (int u = 0; u < kVamanaMaxK / 64; u++) {
+            const int i = lo + lane + u * 64;
+            moved[u] = i < newn - 1 ? res[i] : kKeyMax;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < kVamanaMaxK / 64; u++) {
+            const int i = lo + lane + u * 64;
+            if (i < newn - 1) res[i + 1] = moved[u];
+        }
+        if (lane == 0) res[lo] = c;
+        __syncthreads();
+        res_n = newn;
+        res_tau = res_n >= k ? res[k - 1] : kKeyMax;
+    };
+    auto offer = [&](uint64_t key) {
+        if (!big) {
+            tk.offer(key, lane);
+            return;
+        }
+        uint64_t mask = __ballot(key < res_tau);
+        while (mask) {
+            const int j = __builtin_ctzll(mask);
+            mask &= mask - 1;
+            const uint64_t c = readlane_u64(key, j);
+            if (c < res_tau) res_insert(c);  // the bound may have dropped since the ballot
+        }
+    };
     int heap_count = 0;  // min(k, candidates offered): sc.Heap.Len()
     int cand_len = 0;
 
@@ -423,7 +470,7 @@ __global__ __launch_bounds__(64) void vamana_search_kernel(
     const float sd = nb_d[0];
     st_dc++;
     heap_push<false>(cand, cand_len, HItem{entry, sd});
-    tk.offer(lane == 0 ? make_key(sd, entry, desc) : kKeyMax, lane);
+    offer(lane == 0 ? make_key(sd, entry, desc) : kKeyMax);
     heap_count = 1 < k ? 1 : k;
     __syncthreads();
 
@@ -431,7 +478,7 @@ __global__ __launch_bounds__(64) void vamana_search_kernel(
         const HItem c = heap_pop<false>(cand, cand_len);
         st_pops++;
         if (heap_count >= k) {
-            const float worst = key_score(tk.tau, desc);
+            const float worst = key_score(big ? res_tau : tk.tau, desc);
             if (c.dist > worst) break;
         }
         const uint32_t id_lane = lane < r ? graph[static_cast<int64_t>(c.node) * r + lane] : VG_INVALID_ID;
@@ -457,11 +504,17 @@ __global__ __launch_bounds__(64) void vamana_search_kernel(
                                  HItem{static_cast<uint32_t>(__builtin_amdgcn_readlane(id_lane, j)), nb_d[j]});
         }
         // result heap: TryPushBounded(k) — a set maintained by (score, id): order-free
-        tk.offer(fresh ? make_key(myd, id_lane, desc) : kKeyMax, lane);
+        offer(fresh ? make_key(myd, id_lane, desc) : kKeyMax);
         heap_count = heap_count + nnew < k ? heap_count + nnew : k;
         __syncthreads();
     }
-    if (lane < k) {
+    if (big) {
+        for (int i = lane; i < k; i += 64) {
+            const uint64_t e = i < res_n ? res[i] : kKeyMax;
+            ids[q * k + i] = e == kKeyMax ? VG_INVALID_ID : key_row(e);
+            scores[q * k + i] = e == kKeyMax ? (desc ? -INFINITY : INFINITY) : key_score(e, desc);
+        }
+    } else if (lane < k) {
         const uint64_t e = tk.list;
         ids[q * k + lane] = e == kKeyMax ? VG_INVALID_ID : key_row(e);
         scores[q * k + lane] = e == kKeyMax ? (desc ? -INFINITY : INFINITY) : key_score(e, desc);
@@ -604,7 +657,7 @@ VG_API int32_t vg_search_vamana(vg_index *idx, const float *queries, int64_t nq,
     VG_CHECK(kind != 1 || idx->pq->k == 256, VG_ERR_UNSUPPORTED, "vg_search_vamana: PQ needs numCentroids == 256");
     VG_CHECK(idx->metric != VG_METRIC_HAMMING, VG_ERR_UNSUPPORTED, "unsupported metric for float32: Hamming");
     VG_CHECK(queries && ids && scores, VG_ERR_INVALID_ARG, "vg_search_vamana: NULL buffer");
-    VG_CHECK(k <= 64, VG_ERR_UNSUPPORTED, "vg_search_vamana: k=%d exceeds 64", k);
+    VG_CHECK(k <= vg::kVamanaMaxK, VG_ERR_UNSUPPORTED, "vg_search_vamana: k=%d exceeds %d", k, vg::kVamanaMaxK);
     VG_HIP(hipSetDevice(idx->ctx->device));
     hipStream_t st = vg::pick_stream(idx->ctx, stream);
     vg::DevIn<float> q;
