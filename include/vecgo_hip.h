@@ -182,6 +182,25 @@ int32_t vg_index_set_rabitq_codes(vg_index *idx, const uint8_t *codes, void *str
 int32_t vg_index_set_hnsw_graph(vg_index *idx, int32_t m0, const uint32_t *l0, int32_t max_level,
                                 int32_t m, const uint32_t *upper_slot, const uint32_t *upper_adj,
                                 const int64_t *level_rows, uint32_t entry_point, void *stream);
+/* HNSW construction over the index's fp32 rows: hnsw.Insert for rows 0..n-1 (hnsw.go:713-984 insert /
+ * insertNode, :986-1106 selectNeighborsHeuristic, :455-555 addConnection / addConnectionPrune, :885-900
+ * updateEntryPoint) with ApplyInsert's ids and levels (:629-684: id = row number, level =
+ * layerForApplyInsert(id) :2103-2116, M0 = 2M :28).  Rows are inserted in id order in batches of
+ * clamp(inserted / growth_div, 1, max_batch): every node of a batch searches the graph as it stood when
+ * the batch began (what ApplyBatchInsert's goroutines see of one another), then the batch's links are
+ * applied in id order; max_batch = 1 is the sequential Insert loop.  ef_construction = Options.EF
+ * (hnsw.go:37 default 300).  The graph replaces the index's HNSW graph (vg_search_hnsw reads it).
+ * 2 <= m <= 32, ef_construction <= 1024. */
+int32_t vg_hnsw_build(vg_index *idx, int32_t m, int32_t ef_construction, int32_t max_batch,
+                      int32_t growth_div, void *stream);
+/* layerForApplyInsert (hnsw.go:2103-2116) with layerMultiplier = 1/ln(m) (hnsw.go:218) */
+int32_t vg_hnsw_level_for_id(uint64_t id, int32_t m);
+/* The index's HNSW graph in vg_index_set_hnsw_graph's layout.  Every output may be NULL; call once for
+ * the sizes (m0, m, max_level, level_rows[max_level]), then with buffers: l0[n*m0],
+ * upper_slot[max_level*n], upper_adj[sum(level_rows)*m] (host or device). */
+int32_t vg_index_get_hnsw_graph(const vg_index *idx, int32_t *m0, int32_t *m, int32_t *max_level,
+                                uint32_t *entry_point, int64_t *level_rows, uint32_t *l0,
+                                uint32_t *upper_slot, uint32_t *upper_adj, void *stream);
 /* Vamana graph of a DiskANN segment: graph[n*r] (diskann/segment.go:671-681; VG_INVALID_ID =
  * empty slot), entry point = header.Entrypoint.  Scoring uses whichever of the index's data the
  * search call names. */

@@ -139,6 +139,12 @@ _sig("vgo_hnsw_search", C.c_int32, C.POINTER(HnswGraph), _f32p, C.c_int32, C.c_i
      _f32p, C.POINTER(SearchStats))
 _sig("vgo_vamana_search", C.c_int32, C.POINTER(Vamana), _f32p, C.c_int32, _u32p, _f32p,
      C.POINTER(SearchStats))
+_i64p = C.POINTER(C.c_int64)
+_sig("vgo_hnsw_level_for_id", C.c_int32, C.c_uint64, C.c_int32)
+_sig("vgo_hnsw_build_layout", C.c_int32, C.c_int64, C.c_int32, _i32p, _i64p)
+_sig("vgo_hnsw_build_batch", C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_int32)
+_sig("vgo_hnsw_build", C.c_int32, _f32p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+     C.c_int32, _u32p, _u32p, _u32p, _u32p, _i32p)
 
 
 def _f(a):
@@ -504,6 +510,36 @@ def hnsw_select_neighbors(base, dim, cand_ids, cand_dists, m, metric=METRIC_L2):
     k = lib.vgo_hnsw_select_neighbors(pb, b.size // dim, dim, metric, ci.ctypes.data_as(_u32p),
                                       cd.ctypes.data_as(_f32p), ci.size, m, out.ctypes.data_as(_u32p))
     return out[:k]
+
+
+def hnsw_layout(n, m):
+    """levels[n] of ApplyInsert's ids (layerForApplyInsert hnsw.go:2103-2116), rows per upper level, top level."""
+    levels = np.empty(n, np.int32)
+    rows = np.zeros(63, np.int64)
+    top = lib.vgo_hnsw_build_layout(n, m, levels.ctypes.data_as(_i32p), rows.ctypes.data_as(_i64p))
+    return levels, rows[:top].copy(), top
+
+
+def hnsw_build(base, dim, m=32, ef=300, metric=METRIC_L2, max_batch=1, growth_div=32):
+    """hnsw insert loop (hnsw.go:713-984) over rows 0..n-1; returns (l0[n,2m], upper, entry_point) with
+    upper = [(slot[n], adj[rows, m]) per level 1..top] — the layout HnswIndex / the C-ABI take."""
+    b, pb = _f(base)
+    n = b.size // dim
+    _, rows, top = hnsw_layout(n, m)
+    l0 = np.empty((n, 2 * m), np.uint32)
+    slots = np.empty((max(top, 1), n), np.uint32)
+    adj = np.empty((max(int(rows.sum()), 1), m), np.uint32)
+    entry = C.c_uint32(0)
+    mx = C.c_int32(0)
+    r = lib.vgo_hnsw_build(pb, n, dim, metric, m, ef, max_batch, growth_div, l0.ctypes.data_as(_u32p),
+                           slots.ctypes.data_as(_u32p), adj.ctypes.data_as(_u32p), C.byref(entry), C.byref(mx))
+    if r != 0:
+        raise ValueError("vgo_hnsw_build: bad arguments")
+    upper, off = [], 0
+    for l in range(top):
+        upper.append((slots[l].copy(), adj[off:off + int(rows[l])].copy()))
+        off += int(rows[l])
+    return l0, upper, int(entry.value)
 
 
 # ---- scans --------------------------------------------------------------------

@@ -1014,6 +1014,105 @@ static float hnsw_dist(const vgo_hnsw_graph *g, const float *q, uint32_t id)
     }
 }
 
+/* neighbour list of `node` on `level`: layer 0 rows hold m0 ids, upper rows m ids, 0xFFFFFFFF ends a list */
+static const uint32_t *hnsw_neighbours(const vgo_hnsw_graph *g, uint32_t node, int level, int *deg)
+{
+    if (level == 0) {
+        *deg = g->m0;
+        return g->l0 + (int64_t)node * g->m0;
+    }
+    *deg = g->m;
+    uint32_t slot = g->slot[level - 1][node];
+    if (slot == 0xFFFFFFFFu) {
+        *deg = 0;
+        return NULL;
+    }
+    return g->adj[level - 1] + (int64_t)slot * g->m;
+}
+
+/* searchLayerUnfiltered hnsw.go:1220-1396 (initializeSearch :1567, processEntryPointUnfiltered :1560).
+ * `visited` is an epoch array of n words: a node counts as visited when visited[id] == epoch.
+ * `cand` (min-heap) and `res` (max-heap) are reset here; `res` is left exactly as the search left it
+ * (insertNode reads it through MinItem and selectNeighbors, hnsw.go:942-957). */
+void vgo_hnsw_search_layer(const vgo_hnsw_graph *g, const float *query, uint32_t ep, float ep_d,
+                           int32_t level, int32_t ef, uint32_t *visited, uint32_t epoch,
+                           vgo_prioq *candp, vgo_prioq *resp, vgo_search_stats *stp)
+{
+    vgo_search_stats st = *stp;
+    vgo_prioq cand = *candp, res = *resp;
+    cand.len = 0;
+    res.len = 0;
+    visited[ep] = epoch;
+    vgo_prioq_push(&cand, (vgo_pq_item){ep, ep_d});
+    vgo_prioq_push(&res, (vgo_pq_item){ep, ep_d});
+
+    int use_sc = g->metric == VGO_METRIC_L2;
+    int cap = ef * 2;
+    int stagnant = 0;
+    float last_best = 3.40282346638528859811704183484516925440e+38f;
+    const int min_cap = ef + ef * 3 / 4;
+
+    vgo_pq_item c;
+    while (cand.len > 0) {
+        vgo_prioq_pop(&cand, &c);
+        st.pops++;
+        if (res.len > 0) {
+            vgo_pq_item worst = res.items[0];
+            if (c.dist > worst.dist && res.len >= ef) break;
+            if (worst.dist < last_best * 0.999f) { /* float32 * untyped const -> float32 */
+                last_best = worst.dist;
+                stagnant = 0;
+            } else if (res.len >= ef) {
+                stagnant++;
+                if (stagnant >= 8 && cap > min_cap) {
+                    cap -= ef / 8;
+                    if (cap < min_cap) cap = min_cap;
+                    stagnant = 0;
+                }
+            }
+        }
+        int deg;
+        const uint32_t *nb = hnsw_neighbours(g, c.node, level, &deg);
+        int has_bound = res.len >= ef;
+        float bound = has_bound ? res.items[0].dist : 0.0f;
+        for (int i = 0; i < deg && nb[i] != 0xFFFFFFFFu; i++) {
+            uint32_t id = nb[i];
+            if (visited[id] == epoch) continue;
+            visited[id] = epoch;
+            st.nodes_visited++;
+            float nd;
+            if (use_sc && has_bound) {
+                int32_t ex;
+                vgo_l2_bounded_avx512(query, g->base + (int64_t)id * g->dim, g->dim, bound, &nd,
+                                      &ex);
+                st.distance_computations++;
+                if (ex) {
+                    st.distance_short_circuits++;
+                    continue;
+                }
+            } else {
+                nd = hnsw_dist(g, query, id);
+                st.distance_computations++;
+            }
+            if (has_bound && nd > bound) continue;
+            vgo_prioq_try_push_bounded(&cand, (vgo_pq_item){id, nd}, cap);
+            vgo_prioq_push_bounded(&res, (vgo_pq_item){id, nd}, ef);
+            if (res.len >= ef) {
+                bound = res.items[0].dist;
+                has_bound = 1;
+            }
+        }
+    }
+    *candp = cand;
+    *resp = res;
+    *stp = st;
+}
+
+float vgo_hnsw_node_distance(const vgo_hnsw_graph *g, const float *query, uint32_t id)
+{
+    return hnsw_dist(g, query, id);
+}
+
 int32_t vgo_hnsw_search(const vgo_hnsw_graph *g, const float *query, int32_t k, int32_t ef,
                         uint32_t *ids, float *scores, vgo_search_stats *stats)
 {
@@ -1041,71 +1140,12 @@ int32_t vgo_hnsw_search(const vgo_hnsw_graph *g, const float *query, int32_t k, 
         }
     }
 
-    /* searchLayerUnfiltered hnsw.go:1220-1396 */
-    uint8_t *visited = (uint8_t *)calloc((size_t)g->n, 1);
+    /* searchLayerUnfiltered hnsw.go:1220-1396 on layer 0 */
+    uint32_t *visited = (uint32_t *)calloc((size_t)g->n, sizeof(uint32_t));
     vgo_prioq cand, res;
     vgo_prioq_init(&cand, 0, ef * 2);
     vgo_prioq_init(&res, 1, ef);
-    visited[cur] = 1;
-    vgo_prioq_push(&cand, (vgo_pq_item){cur, cur_d});
-    vgo_prioq_push(&res, (vgo_pq_item){cur, cur_d});
-
-    int use_sc = g->metric == VGO_METRIC_L2;
-    int cap = ef * 2;
-    int stagnant = 0;
-    float last_best = 3.40282346638528859811704183484516925440e+38f;
-    const int min_cap = ef + ef * 3 / 4;
-
-    vgo_pq_item c;
-    while (cand.len > 0) {
-        vgo_prioq_pop(&cand, &c);
-        st.pops++;
-        if (res.len > 0) {
-            vgo_pq_item worst = res.items[0];
-            if (c.dist > worst.dist && res.len >= ef) break;
-            if (worst.dist < last_best * 0.999f) { /* float32 * untyped const → float32 */
-                last_best = worst.dist;
-                stagnant = 0;
-            } else if (res.len >= ef) {
-                stagnant++;
-                if (stagnant >= 8 && cap > min_cap) {
-                    cap -= ef / 8;
-                    if (cap < min_cap) cap = min_cap;
-                    stagnant = 0;
-                }
-            }
-        }
-        const uint32_t *nb = g->l0 + (int64_t)c.node * g->m0;
-        int has_bound = res.len >= ef;
-        float bound = has_bound ? res.items[0].dist : 0.0f;
-        for (int i = 0; i < g->m0 && nb[i] != 0xFFFFFFFFu; i++) {
-            uint32_t id = nb[i];
-            if (visited[id]) continue;
-            visited[id] = 1;
-            st.nodes_visited++;
-            float nd;
-            if (use_sc && has_bound) {
-                int32_t ex;
-                vgo_l2_bounded_avx512(query, g->base + (int64_t)id * g->dim, g->dim, bound, &nd,
-                                      &ex);
-                st.distance_computations++;
-                if (ex) {
-                    st.distance_short_circuits++;
-                    continue;
-                }
-            } else {
-                nd = hnsw_dist(g, query, id);
-                st.distance_computations++;
-            }
-            if (has_bound && nd > bound) continue;
-            vgo_prioq_try_push_bounded(&cand, (vgo_pq_item){id, nd}, cap);
-            vgo_prioq_push_bounded(&res, (vgo_pq_item){id, nd}, ef);
-            if (res.len >= ef) {
-                bound = res.items[0].dist;
-                has_bound = 1;
-            }
-        }
-    }
+    vgo_hnsw_search_layer(g, query, cur, cur_d, 0, ef, visited, 1, &cand, &res, &st);
     /* knnSearchInternal extraction hnsw.go:1732-1751 */
     vgo_pq_item it;
     while (res.len > k) vgo_prioq_pop(&res, &it);

@@ -166,6 +166,31 @@ typedef struct {
 int32_t vgo_hnsw_search(const vgo_hnsw_graph *g, const float *query, int32_t k, int32_t ef,
                         uint32_t *ids, float *scores, vgo_search_stats *stats);
 
+/* one layer of the search, shared by vgo_hnsw_search and the builder (hnsw.go:1220-1396) */
+void vgo_hnsw_search_layer(const vgo_hnsw_graph *g, const float *query, uint32_t ep, float ep_d,
+                           int32_t level, int32_t ef, uint32_t *visited, uint32_t epoch,
+                           vgo_prioq *cand, vgo_prioq *res, vgo_search_stats *st);
+float vgo_hnsw_node_distance(const vgo_hnsw_graph *g, const float *query, uint32_t id);
+
+/* ---- HNSW construction (vg_oracle_hnsw_build.c) ------------------------------------------------
+ * hnsw.go:713-984 insert / insertNode with the ids and levels of ApplyInsert (hnsw.go:629-684:
+ * ids are the row numbers, level = layerForApplyInsert(id) hnsw.go:2103-2116), selectNeighbors
+ * (:986-1106) and addConnection / addConnectionPrune (:455-555).  Nodes are inserted in id order in
+ * batches: every node of a batch searches the graph as it stood when the batch began (the view a
+ * goroutine of ApplyBatchInsert has of the nodes its siblings are inserting), then the batch's links
+ * are applied in id order.  batch size = clamp(inserted / growth_div, 1, max_batch); max_batch = 1 is
+ * the reference's sequential Insert loop. */
+int32_t vgo_hnsw_level_for_id(uint64_t id, int32_t m);
+/* levels[n] (may be NULL), level_rows[l] = nodes with level >= l+1 for l < 63; returns the highest level */
+int32_t vgo_hnsw_build_layout(int64_t n, int32_t m, int32_t *levels, int64_t *level_rows);
+/* next batch size of the schedule above */
+int64_t vgo_hnsw_build_batch(int64_t inserted, int64_t n, int32_t max_batch, int32_t growth_div);
+/* l0: n*2m ids; slots: max_level*n; adj: (sum level_rows)*m ids, level tables concatenated (the C-ABI's
+ * vg_index_set_hnsw_graph layout); every list is 0xFFFFFFFF-terminated.  Returns 0, or -1 on bad input. */
+int32_t vgo_hnsw_build(const float *base, int64_t n, int32_t dim, int32_t metric, int32_t m, int32_t ef,
+                       int32_t max_batch, int32_t growth_div, uint32_t *l0, uint32_t *slots, uint32_t *adj,
+                       uint32_t *entry_point, int32_t *max_level);
+
 enum { VGO_VAMANA_F32 = 0, VGO_VAMANA_PQ = 1, VGO_VAMANA_RABITQ = 2, VGO_VAMANA_INT4 = 3 };
 typedef struct {
     int64_t n;

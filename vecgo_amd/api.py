@@ -694,6 +694,32 @@ class Index:
                                                 C.c_int32(L), C.c_int32(m_), ps, pa, pr,
                                                 C.c_uint32(entry_point), _stream_ptr(stream)))
 
+    def build_hnsw(self, m=32, ef_construction=300, max_batch=8192, growth_div=32, stream=None):
+        """hnsw.Insert over rows 0..n-1 on the GPU (hnsw.go:713-984; ids and levels of ApplyInsert); the
+        graph becomes the index's HNSW graph.  max_batch=1 is the reference's sequential loop."""
+        check(self._lib.vg_hnsw_build(self._h, C.c_int32(m), C.c_int32(ef_construction), C.c_int32(max_batch),
+                                      C.c_int32(growth_div), _stream_ptr(stream)))
+
+    def get_hnsw_graph(self, stream=None):
+        """(l0[n, m0], upper=[(slot[n], adj[rows, m])...], entry_point) — set_hnsw_graph's arguments."""
+        m0, m_, L, ep = C.c_int32(), C.c_int32(), C.c_int32(), C.c_uint32()
+        rows = np.zeros(64, np.int64)
+        sp = _stream_ptr(stream)
+        check(self._lib.vg_index_get_hnsw_graph(self._h, C.byref(m0), C.byref(m_), C.byref(L), C.byref(ep),
+                                                C.c_void_p(rows.ctypes.data), None, None, None, sp))
+        L = L.value
+        rows = rows[:L]
+        l0 = np.empty((self.n, m0.value), np.uint32)
+        slots = np.empty((max(L, 1), self.n), np.uint32)
+        adj = np.empty((max(int(rows.sum()), 1), m_.value), np.uint32)
+        check(self._lib.vg_index_get_hnsw_graph(self._h, None, None, None, None, None, C.c_void_p(l0.ctypes.data),
+                                                C.c_void_p(slots.ctypes.data), C.c_void_p(adj.ctypes.data), sp))
+        upper, off = [], 0
+        for l in range(L):
+            upper.append((slots[l].copy(), adj[off:off + int(rows[l])].copy()))
+            off += int(rows[l])
+        return l0, upper, int(ep.value)
+
     def set_vamana_graph(self, graph, entry_point, stream=None):
         g = np.ascontiguousarray(graph, np.uint32)
         check(self._lib.vg_index_set_vamana_graph(self._h, C.c_int32(g.shape[1]), C.c_void_p(g.ctypes.data),

@@ -13,6 +13,8 @@
 
 #include "vg_device.hpp"
 #include "vg_exact.hpp"
+#include "vg_heap.hpp"
+#include "vg_hnsw_layer.hpp"
 #include "vg_internal.hpp"
 
 namespace vg {
@@ -20,271 +22,45 @@ namespace vg {
 int32_t launch_pq_build_table(const vg_pq *pq, const float *d_queries, int64_t nq, float *d_tables,
                               bool scan_layout, hipStream_t st);
 
-struct HItem {
-    uint32_t node;
-    float dist;
-};
-
-// ---- searcher.PriorityQueue (queue.go:161-183, 221-290), uniform over the wave ---------------
-template <bool MAX>
-__device__ __forceinline__ void heap_sift_up(HItem *h, int i)
-{
-    const HItem it = h[i];
-    while (i > 0) {
-        const int p = (i - 1) >> 2;
-        const float pd = h[p].dist;
-        if (MAX ? (it.dist <= pd) : (it.dist >= pd)) break;
-        h[i] = h[p];
-        i = p;
-    }
-    h[i] = it;
-}
-
-template <bool MAX>
-__device__ __forceinline__ void heap_sift_down(HItem *h, int n, int i)
-{
-    const HItem it = h[i];
-    for (;;) {
-        const int fc = 4 * i + 1;
-        if (fc >= n) break;
-        int best = fc;
-        float bd = h[fc].dist;
-        const int lc = fc + 4 < n ? fc + 4 : n;
-        for (int c = fc + 1; c < lc; c++) {
-            const float cd = h[c].dist;
-            if (MAX ? (cd > bd) : (cd < bd)) {
-                best = c;
-                bd = cd;
-            }
-        }
-        if (MAX ? (it.dist >= bd) : (it.dist <= bd)) break;
-        h[i] = h[best];
-        i = best;
-    }
-    h[i] = it;
-}
-
-template <bool MAX>
-__device__ __forceinline__ void heap_push(HItem *h, int &len, HItem it)
-{
-    h[len] = it;
-    len++;
-    heap_sift_up<MAX>(h, len - 1);
-}
-
-template <bool MAX>
-__device__ __forceinline__ HItem heap_pop(HItem *h, int &len)
-{
-    const HItem top = h[0];
-    h[0] = h[len - 1];
-    len--;
-    if (len > 0) heap_sift_down<MAX>(h, len, 0);
-    return top;
-}
-
-// PushItemBounded (queue.go:67-92) on the max-heap of results
-__device__ __forceinline__ void res_push_bounded(HItem *h, int &len, HItem it, int capacity)
-{
-    if (len < capacity) {
-        heap_push<true>(h, len, it);
-        return;
-    }
-    if (it.dist < h[0].dist) {
-        h[0] = it;
-        heap_sift_down<true>(h, len, 0);
-    }
-}
-
-// TryPushBounded (queue.go:190-215) on the MIN-heap of exploration candidates: at capacity the
-// new item replaces the top (the closest!) when it is farther — restated as written
-__device__ __forceinline__ void cand_try_push_bounded(HItem *h, int &len, HItem it, int max_size)
-{
-    if (len < max_size) {
-        heap_push<false>(h, len, it);
-        return;
-    }
-    if (it.dist <= h[0].dist) return;
-    h[0] = it;
-    heap_sift_down<false>(h, len, 0);
-}
-
-// next up-to-4 set bits of `mask` (ascending): the lane's 16-lane group gets the (lane>>4)-th
-__device__ __forceinline__ int take4(uint64_t &mask, int lane)
-{
-    int mine = -1;
-#pragma unroll
-    for (int g = 0; g < 4; g++) {
-        if (mask) {
-            const int j = __builtin_ctzll(mask);
-            mask &= mask - 1;
-            if ((lane >> 4) == g) mine = j;
-        }
-    }
-    return mine;
-}
-
-enum { kMetricL2 = 0, kMetricCos = 1, kMetricDot = 2 };
 
 // ---- HNSW ----------------------------------------------------------------------------------------
+// heap_ws == nullptr: both heaps of the query live in LDS (3 * ef items); otherwise in HBM scratch
+// (large ef: 3 * ef * 8 bytes per query would leave one or two waves per CU)
 __global__ __launch_bounds__(64) void hnsw_search_kernel(
     const float *__restrict__ base, int64_t n, int dim, int metric, const uint32_t *__restrict__ l0,
     int m0, int max_level, int m, const uint32_t *__restrict__ slots, const uint32_t *__restrict__ adj,
     const int64_t *__restrict__ level_off, uint32_t entry, const float *__restrict__ queries, int k, int ef,
-    uint32_t *__restrict__ visited_ws, int64_t vis_words, uint32_t *__restrict__ ids,
-    float *__restrict__ scores, vg_search_stats *__restrict__ stats)
+    uint32_t *__restrict__ visited_ws, int64_t vis_words, HItem *__restrict__ heap_ws,
+    uint32_t *__restrict__ ids, float *__restrict__ scores, vg_search_stats *__restrict__ stats)
 {
     extern __shared__ __attribute__((aligned(8))) unsigned char smem[];
-    HItem *cand = reinterpret_cast<HItem *>(smem);
-    HItem *res = cand + 2 * ef;
-    float *nb_pair = reinterpret_cast<float *>(res + ef);
-    float *nb_bnd = nb_pair + 64;
-
     const int64_t q = blockIdx.x;
     const int lane = threadIdx.x;
+    float *nb_pair = reinterpret_cast<float *>(smem);
+    float *nb_bnd = nb_pair + 64;
+    HItem *cand = heap_ws ? heap_ws + q * 3 * ef : reinterpret_cast<HItem *>(nb_bnd + 64);
+    HItem *res = cand + 2 * ef;
     const Sub16 sub = Sub16::make(lane);
     const float *qv = queries + q * dim;
     uint32_t *vis = visited_ws + q * vis_words;
-    int64_t st_visited = 0, st_dc = 0, st_sc = 0, st_pops = 0;
-
-    // distance of one node as hnsw wraps it (vectorstore/columnar.go:37-44)
-    auto node_dist = [&](uint32_t id) -> float {
-        const float *row = base + static_cast<int64_t>(id) * dim;
-        if (metric == kMetricDot) return -exact_pair16<true, kPair>(row, qv, dim, sub);
-        const float d = exact_pair16<false, kPair>(row, qv, dim, sub);
-        return metric == kMetricCos ? 0.5f * d : d;
-    };
 
     // ---- greedySearch through the upper layers --------------------------------------------------
     uint32_t cur = entry;
-    float cur_d = node_dist(cur);
+    float cur_d = hnsw_node_dist(base, dim, metric, qv, cur, sub);
     for (int level = max_level; level > 0; level--) {
-        bool changed = true;
-        while (changed) {
-            changed = false;
-            const uint32_t slot = slots[static_cast<int64_t>(level - 1) * n + cur];
-            if (slot == VG_INVALID_ID) break;
-            const uint32_t *nbp = adj + (level_off[level - 1] + slot) * m;
-            const uint32_t id_lane = lane < m ? nbp[lane] : VG_INVALID_ID;
-            const uint64_t inval = __ballot(id_lane == VG_INVALID_ID);
-            const int count = inval ? __builtin_ctzll(inval) : 64;
-            uint64_t mask = count >= 64 ? ~0ull : ((1ull << count) - 1);
-            while (mask) {
-                const int mine = take4(mask, lane);
-                const uint32_t id = __shfl(id_lane, mine < 0 ? 0 : mine);
-                if (mine >= 0) {
-                    const float d = node_dist(id);
-                    if ((lane & 15) == 0) nb_pair[mine] = d;
-                }
-            }
-            __syncthreads();
-            // sequential `if nextDist < currDist` over the list == first strict minimum
-            float best_d = cur_d;
-            uint32_t best_id = cur;
-            for (int i = 0; i < count; i++) {
-                const float d = nb_pair[i];
-                if (d < best_d) {
-                    best_d = d;
-                    best_id = static_cast<uint32_t>(__builtin_amdgcn_readlane(id_lane, i));
-                    changed = true;
-                }
-            }
-            cur = best_id;
-            cur_d = best_d;
-            __syncthreads();
-        }
+        auto row_of = [&](uint32_t node) -> const uint32_t * {
+            const uint32_t slot = slots[static_cast<int64_t>(level - 1) * n + node];
+            return slot == VG_INVALID_ID ? nullptr : adj + (level_off[level - 1] + slot) * m;
+        };
+        greedy_layer(base, dim, metric, qv, sub, lane, row_of, m, nb_pair, cur, cur_d);
     }
 
     // ---- searchLayerUnfiltered on layer 0 ---------------------------------------------------------
-    int cand_len = 0, res_len = 0;
-    if (lane == 0) atomicOr(&vis[cur >> 5], 1u << (cur & 31));
-    heap_push<false>(cand, cand_len, HItem{cur, cur_d});
-    heap_push<true>(res, res_len, HItem{cur, cur_d});
-    const bool use_sc = metric == kMetricL2;
-    int cap = ef * 2;
-    int stagnant = 0;
-    float last_best = 3.40282346638528859811704183484516925440e+38f;
-    const int min_cap = ef + ef * 3 / 4;
-    __syncthreads();
-
-    while (cand_len > 0) {
-        const HItem c = heap_pop<false>(cand, cand_len);
-        st_pops++;
-        if (res_len > 0) {
-            const float worst = res[0].dist;
-            if (c.dist > worst && res_len >= ef) break;
-            if (worst < last_best * 0.999f) {
-                last_best = worst;
-                stagnant = 0;
-            } else if (res_len >= ef) {
-                stagnant++;
-                if (stagnant >= 8 && cap > min_cap) {
-                    cap -= ef / 8;
-                    if (cap < min_cap) cap = min_cap;
-                    stagnant = 0;
-                }
-            }
-        }
-        const uint32_t id_lane = lane < m0 ? l0[static_cast<int64_t>(c.node) * m0 + lane] : VG_INVALID_ID;
-        const uint64_t inval = __ballot(id_lane == VG_INVALID_ID);
-        const int count = inval ? __builtin_ctzll(inval) : 64;
-        // CheckAndVisit for the whole list at once (neighbour ids of a node are distinct)
-        // (a returning L2 atomic: a plain load could hit a stale L1 line of this very bitmap)
-        bool fresh = false;
-        if (lane < count) {
-            const uint32_t bit = 1u << (id_lane & 31);
-            fresh = (atomicOr(&vis[id_lane >> 5], bit) & bit) == 0;
-        }
-        const uint64_t newmask = __ballot(fresh);
-        st_visited += __popcll(newmask);
-        uint64_t mask = newmask;
-        while (mask) {
-            const int mine = take4(mask, lane);
-            const uint32_t id = __shfl(id_lane, mine < 0 ? 0 : mine);
-            if (mine >= 0) {
-                const float *row = base + static_cast<int64_t>(id) * dim;
-                float dp, db;
-                if (metric == kMetricDot) {
-                    dp = -exact_pair16<true, kPair>(row, qv, dim, sub);
-                    db = dp;
-                } else {
-                    exact_l2_both16(row, qv, dim, sub, dp, db);
-                    if (metric == kMetricCos) dp = 0.5f * dp;
-                }
-                if ((lane & 15) == 0) {
-                    nb_pair[mine] = dp;
-                    nb_bnd[mine] = db;
-                }
-            }
-        }
-        __syncthreads();
-        bool has_bound = res_len >= ef;
-        float bound = has_bound ? res[0].dist : 0.0f;
-        uint64_t todo = newmask;
-        while (todo) {
-            const int j = __builtin_ctzll(todo);
-            todo &= todo - 1;
-            const uint32_t id = static_cast<uint32_t>(__builtin_amdgcn_readlane(id_lane, j));
-            float nd;
-            st_dc++;
-            if (use_sc && has_bound) {
-                nd = nb_bnd[j];
-                if (nd > bound) {  // SquaredL2Bounded reported exceeded
-                    st_sc++;
-                    continue;
-                }
-            } else {
-                nd = nb_pair[j];
-            }
-            if (has_bound && nd > bound) continue;
-            cand_try_push_bounded(cand, cand_len, HItem{id, nd}, cap);
-            res_push_bounded(res, res_len, HItem{id, nd}, ef);
-            if (res_len >= ef) {
-                bound = res[0].dist;
-                has_bound = true;
-            }
-        }
-        __syncthreads();
-    }
+    int res_len = 0;
+    LayerStats st;
+    auto row0 = [&](uint32_t node) -> const uint32_t * { return l0 + static_cast<int64_t>(node) * m0; };
+    search_layer(base, dim, metric, qv, sub, lane, row0, m0, cur, cur_d, ef, cand, res, nb_pair, nb_bnd, vis,
+                 res_len, st);
 
     // knnSearchInternal extraction (hnsw.go:1732-1751): drop the worst until k remain, then pop
     while (res_len > k) (void)heap_pop<true>(res, res_len);
@@ -301,10 +77,10 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(
         scores[q * k + i] = INFINITY;
     }
     if (stats && lane == 0) {
-        stats[q].nodes_visited = st_visited;
-        stats[q].distance_computations = st_dc;
-        stats[q].distance_short_circuits = st_sc;
-        stats[q].pops = st_pops;
+        stats[q].nodes_visited = st.visited;
+        stats[q].distance_computations = st.dc;
+        stats[q].distance_short_circuits = st.sc;
+        stats[q].pops = st.pops;
     }
 }
 
@@ -322,6 +98,8 @@ __device__ inline float rq_formula_g(float qn, float yn, float dimf, float hammi
     return t1sq + t2;
 }
 
+constexpr int kHnswLdsEf = 512;     // heaps of a query in LDS up to this ef
+constexpr int kHnswMaxEf = 1 << 20;  // ... in HBM scratch beyond
 constexpr int kVamanaMaxK = 512;  // results per query: one per lane up to 64, a sorted LDS list beyond
 
 __global__ __launch_bounds__(64) void vamana_search_kernel(
@@ -603,7 +381,7 @@ VG_API int32_t vg_search_hnsw(vg_index *idx, const float *queries, int64_t nq, i
     VG_CHECK(idx->metric != VG_METRIC_HAMMING, VG_ERR_UNSUPPORTED, "unsupported metric for float32: Hamming");
     VG_CHECK(queries && ids && scores, VG_ERR_INVALID_ARG, "vg_search_hnsw: NULL buffer");
     if (ef < k) ef = k;  // determineEF hnsw.go:1891-1894
-    VG_CHECK(ef <= 512, VG_ERR_UNSUPPORTED, "vg_search_hnsw: ef=%d exceeds 512", ef);
+    VG_CHECK(ef <= vg::kHnswMaxEf, VG_ERR_UNSUPPORTED, "vg_search_hnsw: ef=%d exceeds %d", ef, vg::kHnswMaxEf);
     VG_HIP(hipSetDevice(idx->ctx->device));
     hipStream_t st = vg::pick_stream(idx->ctx, stream);
     vg::DevIn<float> q;
@@ -615,13 +393,19 @@ VG_API int32_t vg_search_hnsw(vg_index *idx, const float *queries, int64_t nq, i
     VG_TRY(osc.init(scores, static_cast<size_t>(nq) * k, st));
     VG_TRY(ost.init(stats, stats ? static_cast<size_t>(nq) : 0, st));
     const int64_t vis_words = (idx->n + 31) / 32;
-    int64_t chunk = std::max<int64_t>(1, (int64_t(1) << 28) / std::max<int64_t>(vis_words, 1));  // <= 1 GiB of bitmaps
+    // heaps in LDS up to kHnswLdsEf (12 KiB per query: the waves of a CU are then bounded by registers, not
+    // LDS), beyond it in HBM scratch
+    const bool lds_heaps = ef <= vg::kHnswLdsEf;
+    const int64_t heap_bytes = lds_heaps ? 0 : static_cast<int64_t>(3) * ef * sizeof(vg::HItem);
+    int64_t chunk = std::max<int64_t>(1, (int64_t(1) << 30) / std::max<int64_t>(vis_words * 4 + heap_bytes, 1));  // <= 1 GiB of scratch
     chunk = std::min(chunk, nq);
     vg::ArenaCall ar(idx->ctx, st);
     const int i_vis = ar.add(sizeof(uint32_t) * static_cast<size_t>(chunk) * vis_words);
+    const int i_heap = ar.add(static_cast<size_t>(chunk) * heap_bytes);
     VG_TRY(ar.commit());
     struct { uint32_t *ptr; } vis{ar.get<uint32_t>(i_vis)};
-    const size_t lds = static_cast<size_t>(3 * ef) * sizeof(vg::HItem) + 128 * sizeof(float);
+    vg::HItem *heap_ws = lds_heaps ? nullptr : ar.get<vg::HItem>(i_heap);
+    const size_t lds = (lds_heaps ? static_cast<size_t>(3 * ef) * sizeof(vg::HItem) : 0) + 128 * sizeof(float);
     VG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(vg::hnsw_search_kernel),
                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
     for (int64_t q0 = 0; q0 < nq; q0 += chunk) {
@@ -632,7 +416,7 @@ VG_API int32_t vg_search_hnsw(vg_index *idx, const float *queries, int64_t nq, i
                            idx->d_vectors, idx->n, idx->dim, idx->metric, idx->d_hnsw_l0, idx->hnsw_m0,
                            idx->hnsw_max_level, idx->hnsw_m, idx->d_hnsw_slot, idx->d_hnsw_adj,
                            idx->d_hnsw_level_off, idx->hnsw_entry, q.ptr + q0 * idx->dim, k, ef, vis.ptr,
-                           vis_words, oid.ptr + q0 * k, osc.ptr + q0 * k, ost.ptr ? ost.ptr + q0 : nullptr);
+                           vis_words, heap_ws, oid.ptr + q0 * k, osc.ptr + q0 * k, ost.ptr ? ost.ptr + q0 : nullptr);
     }
     VG_TRY(oid.finish());
     VG_TRY(osc.finish());

@@ -1,0 +1,785 @@
+// k_hnsw_build.hip — HNSW construction on the GPU: hnsw.go:713-984 (insert / insertNode), :986-1106
+// (selectNeighbors*, applyHeuristic, fillUpNeighbors), :455-555 (addConnection*), :885-900
+// (updateEntryPoint), with the ids and levels of ApplyInsert / ApplyBatchInsert (:629-684: ids are the
+// row numbers, level = layerForApplyInsert(id) :2103-2116).
+//
+// Nodes are inserted in id order in batches; a batch is what ApplyBatchInsert's goroutines are to each
+// other: every node of the batch searches the graph as it stood when the batch began, then the batch's
+// links are applied in id order.  batch = clamp(inserted / growth_div, 1, max_batch); max_batch = 1 is the
+// reference's sequential Insert loop.  Per batch:
+//   1. build_search_kernel   one wavefront per new node: greedy descent above its level, then
+//                            searchLayerUnfiltered(ef) on every level it owns (vg_hnsw_layer.hpp); the
+//                            results heap is popped into a best-first candidate list per (node, level).
+//   2. build_select_kernel   one workgroup per (node, level): selectNeighborsHeuristic over the list; the
+//                            node's own row is written, and one back-link record per chosen neighbour.
+//   3. build_count / offsets / fill kernels group the back-link records by target row;
+//      build_link_kernel     one wavefront per target row applies its records in id order: append while
+//                            the row has room (addConnectionSimple), else addConnectionPrune.
+//
+// What makes addConnectionPrune affordable: a row keeps, next to the ids and the cached distances the
+// reference keeps (node.go Neighbor{ID, Dist}), a 64 x 64 BIT matrix: bit j of bits[i] = "d(c_i, c_j) <
+// d(s, c_i)", the only thing applyHeuristic ever asks about a pair of candidates.  The reference recomputes
+// ~2000 pair distances of 768 floats on every back link of a full row (64 back links per insert); here a
+// back link costs the 64 distances between the new node and the row's members, the heuristic itself is a
+// replay over bit masks.  Every distance is the reference's kernel in its summation order (vg_exact.hpp) and
+// every candidate order is the order the reference's 4-ary heap would pop (rank by distance; on equal
+// distances the heap is replayed in LDS), so the graph equals the one oracle/vg_oracle_hnsw_build.c builds
+// by the letter of hnsw.go — bit for bit, ties included.
+#include <algorithm>
+#include <cmath>
+#include <vector>
+
+#include "vg_device.hpp"
+#include "vg_exact.hpp"
+#include "vg_heap.hpp"
+#include "vg_hnsw_layer.hpp"
+#include "vg_internal.hpp"
+
+namespace vg {
+
+constexpr int kBuildMaxEf = 1024;   // candidates per (node, level); heaps of the insert search live in LDS
+constexpr int kSelThreads = 256;
+
+// The graph under construction.  Rows: layer 0 row of node i = i (m0 slots); the row of node i on level
+// l >= 1 = n + level_off[l-1] + slots[(l-1)*n + i] (m slots).  Slot arrays are laid out as one array with
+// the n*m0 layer-0 slots first: that prefix IS the l0 table of vg_index_set_hnsw_graph, the rest its adj.
+struct BuildGraph {
+    const float *base;
+    int64_t n;
+    int dim, metric, m0, m;
+    uint32_t *ids;    // 0xFFFFFFFF beyond cnt
+    float *dist;      // d(row's node, member) as the insert search computed it
+    uint64_t *bits;   // bit j of bits[slot i]: d(member i, member j) < dist[i]
+    int32_t *cnt;     // per row
+    const uint32_t *slots;
+    const int64_t *level_off;
+};
+
+__device__ __forceinline__ int64_t bg_row(const BuildGraph &g, uint32_t node, int level)
+{
+    if (level == 0) return node;
+    return g.n + g.level_off[level - 1] + g.slots[static_cast<int64_t>(level - 1) * g.n + node];
+}
+__device__ __forceinline__ int64_t bg_off(const BuildGraph &g, int64_t row)
+{
+    return row < g.n ? row * g.m0 : g.n * g.m0 + (row - g.n) * g.m;
+}
+__device__ __forceinline__ int bg_deg(const BuildGraph &g, int64_t row) { return row < g.n ? g.m0 : g.m; }
+
+// h.distanceFunc (newDistanceFunc hnsw.go:2218-2238) of two rows, all lanes of the 16-lane group
+__device__ __forceinline__ float bg_pair(const BuildGraph &g, uint32_t a, uint32_t b, Sub16 sub)
+{
+    return hnsw_node_dist(g.base, g.dim, g.metric, g.base + static_cast<int64_t>(b) * g.dim, a, sub);
+}
+
+// ---- 1. insert search -----------------------------------------------------------------------------
+// pair_base[t] = index of node t's first (node, level) pair counted from node 0 (levels min(level,top)..0
+// → pair index + level); the batch's lists are stored relative to pair_base[t0].
+__global__ __launch_bounds__(64) void build_search_kernel(BuildGraph g, int64_t t0, uint32_t entry, int cur_top,
+                                                          const int32_t *__restrict__ levels,
+                                                          const int64_t *__restrict__ pair_base, int ef,
+                                                          uint32_t *__restrict__ visited_ws, int64_t vis_words,
+                                                          uint32_t *__restrict__ cand_ids,
+                                                          float *__restrict__ cand_d, int32_t *__restrict__ cand_n)
+{
+    extern __shared__ __attribute__((aligned(8))) unsigned char smem[];
+    float *nb_pair = reinterpret_cast<float *>(smem);
+    float *nb_bnd = nb_pair + 64;
+    HItem *cand = reinterpret_cast<HItem *>(nb_bnd + 64);
+    HItem *res = cand + 2 * ef;
+    const int lane = threadIdx.x;
+    const int64_t t = t0 + blockIdx.x;
+    const Sub16 sub = Sub16::make(lane);
+    const float *qv = g.base + t * g.dim;
+    uint32_t *vis = visited_ws + static_cast<int64_t>(blockIdx.x) * vis_words;
+    const int lt = levels[t];
+    const int64_t pair0 = pair_base[t] - pair_base[t0];
+
+    uint32_t cur = entry;
+    float cur_d = hnsw_node_dist(g.base, g.dim, g.metric, qv, cur, sub);
+    for (int level = cur_top; level > lt; level--) {  // hnsw.go:918-934
+        auto row_of = [&](uint32_t node) -> const uint32_t * { return g.ids + bg_off(g, bg_row(g, node, level)); };
+        greedy_layer(g.base, g.dim, g.metric, qv, sub, lane, row_of, g.m, nb_pair, cur, cur_d);
+    }
+    const int first = lt < cur_top ? lt : cur_top;
+    LayerStats st;
+    for (int level = first; level >= 0; level--) {  // hnsw.go:940-957
+        if (level != first) {  // initializeSearch: Visited.Reset()
+            for (int64_t w = lane; w < vis_words; w += 64) vis[w] = 0;
+            __threadfence();
+            __syncthreads();
+        }
+        const int deg = level == 0 ? g.m0 : g.m;
+        auto row_of = [&](uint32_t node) -> const uint32_t * { return g.ids + bg_off(g, bg_row(g, node, level)); };
+        int res_len = 0;
+        search_layer(g.base, g.dim, g.metric, qv, sub, lane, row_of, deg, cur, cur_d, ef, cand, res, nb_pair,
+                     nb_bnd, vis, res_len, st);
+        // candidates.MinItem() (queue.go:46-57): the first minimum in heap-array order
+        uint64_t best = kKeyMax;
+        for (int i = lane; i < res_len; i += 64) {
+            const uint64_t key = (static_cast<uint64_t>(f32_ordered(res[i].dist)) << 32) | static_cast<uint32_t>(i);
+            best = key < best ? key : best;
+        }
+#pragma unroll
+        for (int s = 32; s > 0; s >>= 1) {
+            const uint32_t lo = __shfl_xor(static_cast<uint32_t>(best), s);
+            const uint32_t hi = __shfl_xor(static_cast<uint32_t>(best >> 32), s);
+            const uint64_t o = (static_cast<uint64_t>(hi) << 32) | lo;
+            best = o < best ? o : best;
+        }
+        const HItem bi = res[static_cast<uint32_t>(best)];
+        cur = bi.node;
+        cur_d = bi.dist;
+        // extractSortedCandidates (hnsw.go:1026-1046) / selectNeighborsSimple: pop everything, nearest first
+        const int64_t p = pair0 + level;
+        const int nres = res_len;
+        for (int i = nres - 1; i >= 0; i--) {
+            const HItem it = heap_pop<true>(res, res_len);
+            if (lane == 0) {
+                cand_ids[p * ef + i] = it.node;
+                cand_d[p * ef + i] = it.dist;
+            }
+        }
+        if (lane == 0) cand_n[p] = nres;
+        __syncthreads();
+    }
+}
+
+// ---- 2. the new node's own neighbours ----------------------------------------------------------------
+// pair_node / pair_level: the (node, level) of every pair of the batch
+struct SelShared {
+    float dm[64][65];     // pair distances between the members of the final list
+    float dtmp[64];       // distances of the candidate under test to the selected ones
+    uint32_t fid[64];     // final list: node ids
+    float fd[64];         //             their distance to the new node
+    int fsel[64];         //             1 = chosen by the heuristic, 0 = filled up
+    int flag, nsel, nfinal;
+};
+
+__global__ __launch_bounds__(kSelThreads) void build_select_kernel(BuildGraph g, const uint32_t *__restrict__ pair_node,
+                                                                   const int32_t *__restrict__ pair_level, int ef,
+                                                                   const uint32_t *__restrict__ cand_ids,
+                                                                   const float *__restrict__ cand_d,
+                                                                   const int32_t *__restrict__ cand_n, int rec_stride,
+                                                                   uint32_t *__restrict__ rec_row,
+                                                                   uint32_t *__restrict__ rec_t, float *__restrict__ rec_d)
+{
+    __shared__ SelShared sh;
+    const int64_t p = blockIdx.x;
+    const int tid = threadIdx.x, grp = tid >> 4;
+    const Sub16 sub = Sub16::make(tid);
+    const uint32_t t = pair_node[p];
+    const int level = pair_level[p];
+    const int64_t row = bg_row(g, t, level);
+    const int64_t off = bg_off(g, row);
+    const int m = bg_deg(g, row);
+    const int nc = cand_n[p];
+    const uint32_t *cid = cand_ids + p * ef;
+    const float *cdist = cand_d + p * ef;
+
+    if (nc <= m) {  // selectNeighborsSimple (hnsw.go:993-1009): everything, nearest first
+        for (int i = tid; i < nc; i += kSelThreads) {
+            sh.fid[i] = cid[i];
+            sh.fd[i] = cdist[i];
+            sh.fsel[i] = 0;
+        }
+        if (tid == 0) {
+            sh.nsel = 0;
+            sh.nfinal = nc;
+        }
+        __syncthreads();
+    } else {
+        if (tid == 0) sh.nsel = 0;
+        __syncthreads();
+        for (int i = 0; i < nc; i++) {  // applyHeuristic (hnsw.go:1048-1085)
+            const int nk = sh.nsel;
+            if (nk >= m) break;
+            const uint32_t id = cid[i];
+            const float cd = cdist[i];
+            if (tid == 0) sh.flag = 0;
+            __syncthreads();
+            for (int s0 = 0; s0 < nk; s0 += kSelThreads / 16) {
+                const int s = s0 + grp;
+                if (s < nk) {
+                    const float d = bg_pair(g, id, sh.fid[s], sub);
+                    if ((tid & 15) == 0) {
+                        sh.dtmp[s] = d;
+                        if (d < cd) sh.flag = 1;
+                    }
+                }
+            }
+            __syncthreads();
+            if (!sh.flag) {
+                for (int s = tid; s < nk; s += kSelThreads) {
+                    sh.dm[nk][s] = sh.dtmp[s];
+                    sh.dm[s][nk] = sh.dtmp[s];
+                }
+                if (tid == 0) {
+                    sh.fid[nk] = id;
+                    sh.fd[nk] = cd;
+                    sh.fsel[nk] = 1;
+                    sh.nsel = nk + 1;
+                }
+            }
+            __syncthreads();
+        }
+        if (tid == 0) {  // fillUpNeighbors (hnsw.go:1087-1106)
+            int nk = sh.nsel;
+            const int nsel = nk;
+            for (int i = 0; i < nc && nk < m; i++) {
+                bool found = false;
+                for (int s = 0; s < nsel; s++) found |= sh.fid[s] == cid[i];
+                if (!found) {
+                    sh.fid[nk] = cid[i];
+                    sh.fd[nk] = cdist[i];
+                    sh.fsel[nk] = 0;
+                    nk++;
+                }
+            }
+            sh.nfinal = nk;
+        }
+        __syncthreads();
+    }
+    // pair distances the heuristic did not need: every pair with a filled-up member
+    const int nf = sh.nfinal, nsel = sh.nsel;
+    const int nfill = nf - nsel;
+    for (int e0 = 0; e0 < nfill * nf; e0 += kSelThreads / 16) {
+        const int e = e0 + grp;
+        if (e < nfill * nf) {
+            const int a = nsel + e / nf, b = e % nf;
+            if (b < a) {  // b selected, or an earlier fill-up
+                const float d = bg_pair(g, sh.fid[a], sh.fid[b], sub);
+                if ((tid & 15) == 0) {
+                    sh.dm[a][b] = d;
+                    sh.dm[b][a] = d;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // the row: setConnections (hnsw.go:445-453), plus the bit matrix, plus one back-link record per member
+    for (int i = tid; i < m; i += kSelThreads) {
+        uint64_t bits = 0;
+        if (i < nf) {
+            const float di = sh.fd[i];
+            for (int j = 0; j < nf; j++)
+                if (j != i && sh.dm[i][j] < di) bits |= 1ull << j;
+        }
+        g.ids[off + i] = i < nf ? sh.fid[i] : VG_INVALID_ID;
+        g.dist[off + i] = i < nf ? sh.fd[i] : 0.0f;
+        g.bits[off + i] = bits;
+        if (i < rec_stride) {
+            rec_row[p * rec_stride + i] = i < nf ? static_cast<uint32_t>(bg_row(g, sh.fid[i], level)) : VG_INVALID_ID;
+            rec_t[p * rec_stride + i] = t;
+            rec_d[p * rec_stride + i] = i < nf ? sh.fd[i] : 0.0f;
+        }
+    }
+    for (int i = m + tid; i < rec_stride; i += kSelThreads) rec_row[p * rec_stride + i] = VG_INVALID_ID;
+    if (tid == 0) g.cnt[row] = nf;
+}
+
+// ---- 3. back links ---------------------------------------------------------------------------------
+struct LinkCounters {
+    unsigned int nwork, total;
+};
+
+__global__ void build_count_kernel(const uint32_t *__restrict__ rec_row, int64_t nrec, int32_t *__restrict__ rcnt,
+                                   uint32_t *__restrict__ work, LinkCounters *__restrict__ ctr)
+{
+    const int64_t r = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (r >= nrec) return;
+    const uint32_t row = rec_row[r];
+    if (row == VG_INVALID_ID) return;
+    if (atomicAdd(&rcnt[row], 1) == 0) work[atomicAdd(&ctr->nwork, 1u)] = row;
+}
+
+__global__ void build_offsets_kernel(const uint32_t *__restrict__ work, const int32_t *__restrict__ rcnt,
+                                     uint32_t *__restrict__ roff, LinkCounters *__restrict__ ctr)
+{
+    const unsigned int w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= ctr->nwork) return;
+    const uint32_t row = work[w];
+    roff[row] = atomicAdd(&ctr->total, static_cast<unsigned int>(rcnt[row]));
+}
+
+__global__ void build_fill_kernel(const uint32_t *__restrict__ rec_row, const uint32_t *__restrict__ rec_t,
+                                  const float *__restrict__ rec_d, int64_t nrec, const uint32_t *__restrict__ roff,
+                                  int32_t *__restrict__ rfill, uint32_t *__restrict__ srt_t, float *__restrict__ srt_d)
+{
+    const int64_t r = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (r >= nrec) return;
+    const uint32_t row = rec_row[r];
+    if (row == VG_INVALID_ID) return;
+    const uint32_t pos = roff[row] + static_cast<uint32_t>(atomicAdd(&rfill[row], 1));
+    srt_t[pos] = rec_t[r];
+    srt_d[pos] = rec_d[r];
+}
+
+struct LinkShared {
+    HItem heap[65];
+    float pd[64];
+    float cd[65];          // candidate distances (slot 0..deg-1, then the new node)
+    uint64_t cbits[65];    // bits over the old slots
+    uint32_t ctbit[65];    // bit against the new node
+    uint32_t cid[65];
+    int seq[65];           // candidates in the order extractSortedCandidates would give (nearest first)
+    int newpos[65];        // their slot after the prune, -1 = dropped
+};
+
+// one wavefront per target row: the row's records in ascending id of the new node (the order a sequential
+// pass over the batch applies them), each one = addConnection (hnsw.go:455-499)
+__global__ __launch_bounds__(64) void build_link_kernel(BuildGraph g, const uint32_t *__restrict__ work,
+                                                        const LinkCounters *__restrict__ ctr,
+                                                        int32_t *__restrict__ rcnt, int32_t *__restrict__ rfill,
+                                                        const uint32_t *__restrict__ roff,
+                                                        const uint32_t *__restrict__ srt_t,
+                                                        const float *__restrict__ srt_d)
+{
+    __shared__ LinkShared sh;
+    if (blockIdx.x >= ctr->nwork) return;
+    const int lane = threadIdx.x;
+    const Sub16 sub = Sub16::make(lane);
+    const int64_t row = work[blockIdx.x];
+    const int64_t off = bg_off(g, row);
+    const int deg = bg_deg(g, row);
+    const int nadd = rcnt[row];
+    const uint32_t *at = srt_t + roff[row];
+    const float *ad = srt_d + roff[row];
+    int cnt = g.cnt[row];
+    uint32_t id = lane < deg ? g.ids[off + lane] : VG_INVALID_ID;
+    float dist = lane < deg ? g.dist[off + lane] : 0.0f;
+    uint64_t bits = lane < deg ? g.bits[off + lane] : 0;
+
+    uint64_t last = 0;  // (t + 1) of the record applied last; records of a row have distinct t
+    for (int a = 0; a < nadd; a++) {
+        // next record in ascending t
+        uint64_t best = kKeyMax;
+        for (int i = lane; i < nadd; i += 64) {
+            const uint64_t key = ((static_cast<uint64_t>(at[i]) + 1) << 32) | static_cast<uint32_t>(i);
+            if ((key >> 32) > last && key < best) best = key;
+        }
+#pragma unroll
+        for (int s = 32; s > 0; s >>= 1) {
+            const uint32_t lo = __shfl_xor(static_cast<uint32_t>(best), s);
+            const uint32_t hi = __shfl_xor(static_cast<uint32_t>(best >> 32), s);
+            const uint64_t o = (static_cast<uint64_t>(hi) << 32) | lo;
+            best = o < best ? o : best;
+        }
+        last = best >> 32;
+        const uint32_t t = at[static_cast<uint32_t>(best)];
+        const float dt = ad[static_cast<uint32_t>(best)];
+        if (__ballot(lane < cnt && id == t)) continue;  // already connected (hnsw.go:477-486)
+
+        // distances between the new node and the row's members
+        uint64_t mask = cnt >= 64 ? ~0ull : ((1ull << cnt) - 1);
+        while (mask) {
+            const int mine = take4(mask, lane);
+            const uint32_t other = __shfl(id, mine < 0 ? 0 : mine);
+            if (mine >= 0) {
+                const float d = bg_pair(g, other, t, sub);
+                if ((lane & 15) == 0) sh.pd[mine] = d;
+            }
+        }
+        __syncthreads();
+        const float pd = lane < cnt ? sh.pd[lane] : 0.0f;
+        const uint64_t tbits = __ballot(lane < cnt && pd < dt);   // row of the new node
+        const uint32_t colbit = (lane < cnt && pd < dist) ? 1u : 0u;  // bit (member, new node)
+        if (cnt < deg) {  // addConnectionSimple (hnsw.go:501-518)
+            if (lane < cnt) bits |= static_cast<uint64_t>(colbit) << cnt;
+            if (lane == cnt) {
+                id = t;
+                dist = dt;
+                bits = tbits;
+            }
+            cnt++;
+            __syncthreads();
+            continue;
+        }
+        // addConnectionPrune (hnsw.go:520-555): members in list order, then the new node, through the max-heap
+        // and back out nearest first.  Distinct distances: the order is the sort by distance.  Equal
+        // distances: whatever the heap does, so the heap is replayed.
+        const int nc = deg + 1;
+        if (lane < deg) {
+            sh.cd[lane] = dist;
+            sh.cbits[lane] = bits;
+            sh.ctbit[lane] = colbit;
+            sh.cid[lane] = id;
+        }
+        if (lane == 0) {
+            sh.cd[deg] = dt;
+            sh.cbits[deg] = tbits;
+            sh.ctbit[deg] = 0;
+            sh.cid[deg] = t;
+        }
+        __syncthreads();
+        int rank = 0;
+        bool tie = false;
+        if (lane < deg) {
+            for (int j = 0; j < nc; j++) {
+                const float dj = sh.cd[j];
+                rank += dj < dist ? 1 : 0;
+                tie |= (j != lane) && dj == dist;
+            }
+        }
+        int rank_t = 0;
+        for (int j = 0; j < deg; j++) rank_t += sh.cd[j] < dt ? 1 : 0;
+        if (__ballot(tie)) {
+            int hl = 0;
+            for (int j = 0; j < nc; j++) heap_push<true>(sh.heap, hl, HItem{static_cast<uint32_t>(j), sh.cd[j]});
+            for (int j = nc - 1; j >= 0; j--) {
+                const HItem it = heap_pop<true>(sh.heap, hl);
+                if (lane == 0) sh.seq[j] = static_cast<int>(it.node);
+            }
+        } else {
+            if (lane < deg) sh.seq[rank] = lane;
+            if (lane == 0) sh.seq[rank_t] = deg;
+        }
+        if (lane < nc) sh.newpos[lane] = -1;
+        if (lane == 0) sh.newpos[64] = -1;
+        __syncthreads();
+        // applyHeuristic + fillUpNeighbors over the bit rows (wave-uniform)
+        uint64_t selmask = 0;
+        bool sel_t = false;
+        int nsel = 0;
+        for (int p = 0; p < nc && nsel < deg; p++) {
+            const int ci = sh.seq[p];
+            const bool bad = (sh.cbits[ci] & selmask) != 0 || (sh.ctbit[ci] != 0 && sel_t);
+            if (!bad) {
+                if (ci == deg)
+                    sel_t = true;
+                else
+                    selmask |= 1ull << ci;
+                if (lane == 0) sh.newpos[ci] = nsel;
+                nsel++;
+            }
+        }
+        for (int p = 0; p < nc && nsel < deg; p++) {
+            const int ci = sh.seq[p];
+            const bool chosen = ci == deg ? sel_t : ((selmask >> ci) & 1) != 0;
+            if (!chosen) {
+                if (lane == 0) sh.newpos[ci] = nsel;
+                nsel++;
+            }
+        }
+        __syncthreads();
+        // the row in its new order; columns of the bit matrix move with their members
+        int src = -1;
+        for (int j = 0; j < nc; j++)
+            if (sh.newpos[j] == lane) src = j;
+        uint64_t nb = 0;
+        if (src >= 0) {
+            const uint64_t ob = sh.cbits[src];
+            for (int j = 0; j < deg; j++) {
+                const int np = sh.newpos[j];
+                if (np >= 0) nb |= ((ob >> j) & 1ull) << np;
+            }
+            const int npt = sh.newpos[deg];
+            if (npt >= 0) nb |= static_cast<uint64_t>(sh.ctbit[src]) << npt;
+            id = sh.cid[src];
+            dist = sh.cd[src];
+        } else {
+            id = VG_INVALID_ID;
+            dist = 0.0f;
+        }
+        bits = nb;
+        cnt = nsel;
+        __syncthreads();
+    }
+    if (lane < deg) {
+        g.ids[off + lane] = lane < cnt ? id : VG_INVALID_ID;
+        g.dist[off + lane] = lane < cnt ? dist : 0.0f;
+        g.bits[off + lane] = lane < cnt ? bits : 0;
+    }
+    if (lane == 0) {
+        g.cnt[row] = cnt;
+        rcnt[row] = 0;
+        rfill[row] = 0;
+    }
+}
+
+__global__ void fill_u32_kernel(uint32_t *p, int64_t n, uint32_t v)
+{
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+// layerForApplyInsert (hnsw.go:2103-2116), layerMultiplier = 1 / ln(M) (hnsw.go:218)
+static int32_t level_for_id(uint64_t id, double mult)
+{
+    uint64_t x = id + 0x9e3779b97f4a7c15ull;
+    x = (x ^ (x >> 30)) * 0xbf58476d1ce4e5b9ull;
+    x = (x ^ (x >> 27)) * 0x94d049bb133111ebull;
+    x ^= x >> 31;
+    const double inv = 1.0 / 9007199254740992.0;
+    double r = static_cast<double>(x >> 11) * inv;
+    if (r == 0) r = inv;
+    const int32_t lv = static_cast<int32_t>(std::floor(-std::log(r) * mult));
+    return lv > 62 ? 62 : lv;
+}
+
+template <typename T>
+struct DevBuf {
+    T *p = nullptr;
+    ~DevBuf()
+    {
+        if (p) (void)hipFree(p);
+    }
+    int32_t alloc(size_t count)
+    {
+        VG_HIP(hipMalloc(reinterpret_cast<void **>(&p), std::max<size_t>(count, 1) * sizeof(T)));
+        return VG_OK;
+    }
+    T *release()
+    {
+        T *r = p;
+        p = nullptr;
+        return r;
+    }
+};
+
+}  // namespace vg
+
+VG_API int32_t vg_hnsw_level_for_id(uint64_t id, int32_t m)
+{
+    return vg::level_for_id(id, 1.0 / std::log(static_cast<double>(m < 2 ? 2 : m)));
+}
+
+VG_API int32_t vg_hnsw_build(vg_index *idx, int32_t m, int32_t ef_construction, int32_t max_batch,
+                             int32_t growth_div, void *stream)
+{
+    VG_CHECK(idx, VG_ERR_INVALID_ARG, "vg_hnsw_build: NULL index");
+    VG_CHECK(idx->d_vectors && idx->n > 0, VG_ERR_NOT_READY, "vg_hnsw_build: index has no fp32 vectors");
+    VG_CHECK(idx->metric != VG_METRIC_HAMMING, VG_ERR_UNSUPPORTED, "unsupported metric for float32: Hamming");
+    VG_CHECK(m >= 2 && m <= 32, VG_ERR_UNSUPPORTED, "vg_hnsw_build: M=%d must be in 2..32 (M0 = 2M <= 64)", m);
+    VG_CHECK(ef_construction >= 1 && ef_construction <= vg::kBuildMaxEf, VG_ERR_UNSUPPORTED,
+             "vg_hnsw_build: ef_construction=%d must be in 1..%d", ef_construction, vg::kBuildMaxEf);
+    VG_CHECK(max_batch >= 1 && growth_div >= 1, VG_ERR_INVALID_ARG, "vg_hnsw_build: max_batch and growth_div must be >= 1");
+    VG_CHECK(idx->n < (int64_t(1) << 31), VG_ERR_UNSUPPORTED, "vg_hnsw_build: at most 2^31 rows");
+    VG_HIP(hipSetDevice(idx->ctx->device));
+    hipStream_t st = vg::pick_stream(idx->ctx, stream);
+    const int64_t n = idx->n;
+    const int m0 = 2 * m;  // mmax0Multiplier hnsw.go:28
+    const int ef = ef_construction;
+
+    // levels, slots, and what every node's insert will see as the top level (all known up front: ids and
+    // levels are deterministic and so is the batch schedule)
+    const double mult = 1.0 / std::log(static_cast<double>(m));
+    std::vector<int32_t> levels(static_cast<size_t>(n));
+    int top = 0;
+    for (int64_t i = 0; i < n; i++) {
+        levels[i] = vg::level_for_id(static_cast<uint64_t>(i), mult);
+        top = std::max(top, levels[i]);
+    }
+    std::vector<int64_t> level_rows(static_cast<size_t>(top), 0), level_off(static_cast<size_t>(top) + 1, 0);
+    std::vector<uint32_t> slots(static_cast<size_t>(top) * n);
+    for (int l = 0; l < top; l++) {
+        uint32_t next = 0;
+        for (int64_t i = 0; i < n; i++) slots[static_cast<size_t>(l) * n + i] = levels[i] >= l + 1 ? next++ : VG_INVALID_ID;
+        level_rows[l] = next;
+        level_off[l + 1] = level_off[l] + next;
+    }
+    const int64_t upper_rows = level_off[top];
+    const int64_t total_rows = n + upper_rows;
+    VG_CHECK(total_rows < (int64_t(1) << 32) - 1, VG_ERR_UNSUPPORTED, "vg_hnsw_build: too many rows");
+    const int64_t total_slots = n * m0 + upper_rows * m;
+
+    struct Batch {
+        int64_t t0, size, npairs;
+        uint32_t entry;
+        int cur_top;
+    };
+    std::vector<Batch> batches;
+    std::vector<int64_t> pair_base(static_cast<size_t>(n) + 1, 0);
+    std::vector<uint32_t> pair_node;
+    std::vector<int32_t> pair_level;
+    {
+        uint32_t entry = 0;
+        int cur_top = levels[0];
+        int64_t done = 1;
+        pair_base[1] = 0;
+        int64_t max_pairs = 0;
+        while (done < n) {
+            int64_t b = done / growth_div;
+            b = std::max<int64_t>(1, std::min<int64_t>(b, max_batch));
+            b = std::min(b, n - done);
+            Batch bt{done, b, 0, entry, cur_top};
+            for (int64_t t = done; t < done + b; t++) {
+                const int np = std::min(levels[t], cur_top) + 1;
+                pair_base[t + 1] = pair_base[t] + np;
+                bt.npairs += np;
+            }
+            for (int64_t t = done; t < done + b; t++)  // updateEntryPoint hnsw.go:885-900
+                if (levels[t] > cur_top) {
+                    cur_top = levels[t];
+                    entry = static_cast<uint32_t>(t);
+                }
+            batches.push_back(bt);
+            max_pairs = std::max(max_pairs, bt.npairs);
+            done += b;
+        }
+        pair_node.resize(static_cast<size_t>(pair_base[n]));
+        pair_level.resize(static_cast<size_t>(pair_base[n]));
+        for (const Batch &bt : batches)
+            for (int64_t t = bt.t0; t < bt.t0 + bt.size; t++)
+                for (int l = 0; l <= std::min(levels[t], bt.cur_top); l++) {
+                    pair_node[static_cast<size_t>(pair_base[t] + l)] = static_cast<uint32_t>(t);
+                    pair_level[static_cast<size_t>(pair_base[t] + l)] = l;
+                }
+    }
+    int64_t max_pairs = 1, max_b = 1;
+    for (const auto &bt : batches) {
+        max_pairs = std::max(max_pairs, bt.npairs);
+        max_b = std::max(max_b, bt.size);
+    }
+    const int64_t vis_words_max = (n + 31) / 32;
+    // visited bitmaps: one per node of a batch, at most 4 GiB — larger batches are not worth more
+    VG_CHECK(max_b * vis_words_max * 4 <= (int64_t(1) << 32), VG_ERR_UNSUPPORTED,
+             "vg_hnsw_build: max_batch=%d needs more than 4 GiB of visited bitmaps at %lld rows", max_batch,
+             static_cast<long long>(n));
+
+    vg::DevBuf<uint32_t> d_ids, d_slots, d_vis, d_cand_ids, d_rec_row, d_rec_t, d_work, d_roff, d_srt_t, d_pair_node;
+    vg::DevBuf<float> d_dist, d_cand_d, d_rec_d, d_srt_d;
+    vg::DevBuf<uint64_t> d_bits;
+    vg::DevBuf<int32_t> d_cnt, d_levels, d_cand_n, d_rcnt, d_rfill, d_pair_level;
+    vg::DevBuf<int64_t> d_level_off, d_pair_base;
+    vg::DevBuf<vg::LinkCounters> d_ctr;
+    VG_TRY(d_ids.alloc(static_cast<size_t>(total_slots)));
+    VG_TRY(d_dist.alloc(static_cast<size_t>(total_slots)));
+    VG_TRY(d_bits.alloc(static_cast<size_t>(total_slots)));
+    VG_TRY(d_cnt.alloc(static_cast<size_t>(total_rows)));
+    VG_TRY(d_slots.alloc(slots.size()));
+    VG_TRY(d_level_off.alloc(level_off.size()));
+    VG_TRY(d_levels.alloc(static_cast<size_t>(n)));
+    VG_TRY(d_pair_base.alloc(pair_base.size()));
+    VG_TRY(d_pair_node.alloc(pair_node.size()));
+    VG_TRY(d_pair_level.alloc(pair_level.size()));
+    VG_TRY(d_vis.alloc(static_cast<size_t>(max_b * vis_words_max)));
+    VG_TRY(d_cand_ids.alloc(static_cast<size_t>(max_pairs) * ef));
+    VG_TRY(d_cand_d.alloc(static_cast<size_t>(max_pairs) * ef));
+    VG_TRY(d_cand_n.alloc(static_cast<size_t>(max_pairs)));
+    const int64_t max_rec = max_pairs * m0;
+    VG_TRY(d_rec_row.alloc(static_cast<size_t>(max_rec)));
+    VG_TRY(d_rec_t.alloc(static_cast<size_t>(max_rec)));
+    VG_TRY(d_rec_d.alloc(static_cast<size_t>(max_rec)));
+    VG_TRY(d_srt_t.alloc(static_cast<size_t>(max_rec)));
+    VG_TRY(d_srt_d.alloc(static_cast<size_t>(max_rec)));
+    VG_TRY(d_work.alloc(static_cast<size_t>(std::min(max_rec, total_rows))));
+    VG_TRY(d_roff.alloc(static_cast<size_t>(total_rows)));
+    VG_TRY(d_rcnt.alloc(static_cast<size_t>(total_rows)));
+    VG_TRY(d_rfill.alloc(static_cast<size_t>(total_rows)));
+    VG_TRY(d_ctr.alloc(1));
+    VG_HIP(hipMemsetAsync(d_ids.p, 0xFF, static_cast<size_t>(total_slots) * 4, st));
+    VG_HIP(hipMemsetAsync(d_dist.p, 0, static_cast<size_t>(total_slots) * 4, st));
+    VG_HIP(hipMemsetAsync(d_bits.p, 0, static_cast<size_t>(total_slots) * 8, st));
+    VG_HIP(hipMemsetAsync(d_cnt.p, 0, static_cast<size_t>(total_rows) * 4, st));
+    VG_HIP(hipMemsetAsync(d_rcnt.p, 0, static_cast<size_t>(total_rows) * 4, st));
+    VG_HIP(hipMemsetAsync(d_rfill.p, 0, static_cast<size_t>(total_rows) * 4, st));
+    VG_HIP(hipMemcpyAsync(d_slots.p, slots.data(), slots.size() * 4, hipMemcpyHostToDevice, st));
+    VG_HIP(hipMemcpyAsync(d_level_off.p, level_off.data(), level_off.size() * 8, hipMemcpyHostToDevice, st));
+    VG_HIP(hipMemcpyAsync(d_levels.p, levels.data(), levels.size() * 4, hipMemcpyHostToDevice, st));
+    VG_HIP(hipMemcpyAsync(d_pair_base.p, pair_base.data(), pair_base.size() * 8, hipMemcpyHostToDevice, st));
+    VG_HIP(hipMemcpyAsync(d_pair_node.p, pair_node.data(), pair_node.size() * 4, hipMemcpyHostToDevice, st));
+    VG_HIP(hipMemcpyAsync(d_pair_level.p, pair_level.data(), pair_level.size() * 4, hipMemcpyHostToDevice, st));
+    VG_HIP(hipStreamSynchronize(st));  // the host vectors above go out of use only at return, but be explicit
+
+    vg::BuildGraph g{idx->d_vectors, n, idx->dim, idx->metric, m0, m, d_ids.p, d_dist.p, d_bits.p, d_cnt.p,
+                     d_slots.p, d_level_off.p};
+    const size_t lds = static_cast<size_t>(3 * ef) * sizeof(vg::HItem) + 128 * sizeof(float);
+    VG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(vg::build_search_kernel),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+    for (const Batch &bt : batches) {
+        const int64_t vis_words = (bt.t0 + 31) / 32;  // only nodes below t0 are reachable
+        const int64_t nrec = bt.npairs * m0;
+        VG_HIP(hipMemsetAsync(d_vis.p, 0, static_cast<size_t>(bt.size * vis_words) * 4, st));
+        VG_HIP(hipMemsetAsync(d_ctr.p, 0, sizeof(vg::LinkCounters), st));
+        {
+            vg::ProfScope prof(idx->ctx, "hnsw_build_search", st);
+            VG_LAUNCH(vg::build_search_kernel, dim3(static_cast<unsigned>(bt.size)), dim3(64), lds, st, g, bt.t0,
+                      bt.entry, bt.cur_top, d_levels.p, d_pair_base.p, ef, d_vis.p, vis_words, d_cand_ids.p,
+                      d_cand_d.p, d_cand_n.p);
+        }
+        const int64_t pb = pair_base[bt.t0];
+        {
+            vg::ProfScope prof(idx->ctx, "hnsw_build_select", st);
+            VG_LAUNCH(vg::build_select_kernel, dim3(static_cast<unsigned>(bt.npairs)), dim3(vg::kSelThreads), 0, st, g,
+                      d_pair_node.p + pb, d_pair_level.p + pb, ef, d_cand_ids.p, d_cand_d.p, d_cand_n.p, m0,
+                      d_rec_row.p, d_rec_t.p, d_rec_d.p);
+        }
+        vg::ProfScope prof(idx->ctx, "hnsw_build_link", st);
+        const unsigned gb = static_cast<unsigned>((nrec + 255) / 256);
+        VG_LAUNCH(vg::build_count_kernel, dim3(gb), dim3(256), 0, st, d_rec_row.p, nrec, d_rcnt.p, d_work.p, d_ctr.p);
+        const int64_t max_work = std::min(nrec, total_rows);
+        VG_LAUNCH(vg::build_offsets_kernel, dim3(static_cast<unsigned>((max_work + 255) / 256)), dim3(256), 0, st,
+                  d_work.p, d_rcnt.p, d_roff.p, d_ctr.p);
+        VG_LAUNCH(vg::build_fill_kernel, dim3(gb), dim3(256), 0, st, d_rec_row.p, d_rec_t.p, d_rec_d.p, nrec,
+                  d_roff.p, d_rfill.p, d_srt_t.p, d_srt_d.p);
+        VG_LAUNCH(vg::build_link_kernel, dim3(static_cast<unsigned>(max_work)), dim3(64), 0, st, g, d_work.p, d_ctr.p,
+                  d_rcnt.p, d_rfill.p, d_roff.p, d_srt_t.p, d_srt_d.p);
+    }
+    VG_HIP(hipStreamSynchronize(st));
+
+    // hand the graph to the index in vg_index_set_hnsw_graph's layout
+    uint32_t entry = 0;
+    int cur_top = levels[0];
+    for (int64_t t = 1; t < n; t++)
+        if (levels[t] > cur_top) {
+            cur_top = levels[t];
+            entry = static_cast<uint32_t>(t);
+        }
+    for (uint32_t **slot : {&idx->d_hnsw_l0, &idx->d_hnsw_slot, &idx->d_hnsw_adj})
+        if (*slot) {
+            VG_HIP(hipFree(*slot));
+            *slot = nullptr;
+        }
+    if (idx->d_hnsw_level_off) {
+        VG_HIP(hipFree(idx->d_hnsw_level_off));
+        idx->d_hnsw_level_off = nullptr;
+    }
+    vg::DevBuf<uint32_t> l0, adj;
+    VG_TRY(l0.alloc(static_cast<size_t>(n) * m0));
+    VG_TRY(adj.alloc(static_cast<size_t>(upper_rows) * m));
+    VG_HIP(hipMemcpyAsync(l0.p, d_ids.p, static_cast<size_t>(n) * m0 * 4, hipMemcpyDeviceToDevice, st));
+    if (upper_rows)
+        VG_HIP(hipMemcpyAsync(adj.p, d_ids.p + n * m0, static_cast<size_t>(upper_rows) * m * 4,
+                              hipMemcpyDeviceToDevice, st));
+    VG_HIP(hipStreamSynchronize(st));
+    idx->d_hnsw_l0 = l0.release();
+    idx->d_hnsw_adj = adj.release();
+    idx->d_hnsw_slot = d_slots.release();
+    idx->d_hnsw_level_off = d_level_off.release();
+    idx->hnsw_m0 = m0;
+    idx->hnsw_m = m;
+    idx->hnsw_max_level = cur_top;
+    idx->hnsw_entry = entry;
+    return VG_OK;
+}
+
+VG_API int32_t vg_index_get_hnsw_graph(const vg_index *idx, int32_t *m0, int32_t *m, int32_t *max_level,
+                                       uint32_t *entry_point, int64_t *level_rows, uint32_t *l0,
+                                       uint32_t *upper_slot, uint32_t *upper_adj, void *stream)
+{
+    VG_CHECK(idx, VG_ERR_INVALID_ARG, "vg_index_get_hnsw_graph: NULL index");
+    VG_CHECK(idx->d_hnsw_l0, VG_ERR_NOT_READY, "vg_index_get_hnsw_graph: index has no HNSW graph");
+    VG_HIP(hipSetDevice(idx->ctx->device));
+    hipStream_t st = vg::pick_stream(idx->ctx, stream);
+    const int L = idx->hnsw_max_level;
+    std::vector<int64_t> off(static_cast<size_t>(L) + 1, 0);
+    if (L > 0)
+        VG_HIP(hipMemcpyAsync(off.data(), idx->d_hnsw_level_off, off.size() * 8, hipMemcpyDeviceToHost, st));
+    VG_HIP(hipStreamSynchronize(st));
+    if (m0) *m0 = idx->hnsw_m0;
+    if (m) *m = idx->hnsw_m;
+    if (max_level) *max_level = L;
+    if (entry_point) *entry_point = idx->hnsw_entry;
+    if (level_rows)
+        for (int l = 0; l < L; l++) level_rows[l] = off[l + 1] - off[l];
+    if (l0)
+        VG_HIP(hipMemcpyAsync(l0, idx->d_hnsw_l0, static_cast<size_t>(idx->n) * idx->hnsw_m0 * 4, hipMemcpyDefault, st));
+    if (upper_slot && L > 0)
+        VG_HIP(hipMemcpyAsync(upper_slot, idx->d_hnsw_slot, static_cast<size_t>(L) * idx->n * 4, hipMemcpyDefault, st));
+    if (upper_adj && L > 0)
+        VG_HIP(hipMemcpyAsync(upper_adj, idx->d_hnsw_adj, static_cast<size_t>(off[L]) * idx->hnsw_m * 4,
+                              hipMemcpyDefault, st));
+    VG_HIP(hipStreamSynchronize(st));
+    return VG_OK;
+}
