@@ -439,9 +439,17 @@ typedef struct vg_search_stats {
  * (bounded_l2_avx512.c order) once ef results exist, distFunc otherwise (L2 / -Dot / 0.5*L2:
  * vectorstore/columnar.go:29-50).  One wavefront per query, many queries in flight; per query
  * the result equals the sequential reference's.  ids/scores[nq*k] best first; stats[nq] may be
- * NULL.  ef <= 512, k <= ef. */
+ * NULL.  k <= ef (a smaller ef is raised to k, determineEF hnsw.go:1891-1894); the two heaps of a query live
+ * in LDS up to ef = 512 and in HBM scratch beyond. */
 int32_t vg_search_hnsw(vg_index *idx, const float *queries, int64_t nq, int32_t k, int32_t ef,
                        uint32_t *ids, float *scores, vg_search_stats *stats, void *stream);
+/* The same walk scored from the nodes' PQ codes instead of their fp32 rows: distFunc =
+ * pq.ComputeAsymmetricDistance (pq.go:234-260), the way the reference scores graph nodes from PQ codes
+ * (diskann/segment.go:536-557); no SquaredL2Bounded short-circuit (that kernel reads fp32 rows).  scores =
+ * the PQ distances.  Candidate stage of graph -> PQ -> exact rerank (engine/search.go:914-965): ask for
+ * k = ef candidates, then vg_rerank.  Needs vg_index_set_pq_codes (numCentroids 256) and metric L2. */
+int32_t vg_search_hnsw_pq(vg_index *idx, const float *queries, int64_t nq, int32_t k, int32_t ef,
+                          uint32_t *ids, float *scores, vg_search_stats *stats, void *stream);
 
 /* diskann.Segment.searchInternal (diskann/segment.go:503-706), filters nil.  kind selects the
  * distFn: 0 = fp32 rows (distance.Provider(metric), :582-588), 1 = PQ
@@ -461,6 +469,36 @@ int32_t vg_search_vamana(vg_index *idx, const float *queries, int64_t nq, int32_
 int32_t vg_merge_topk(vg_ctx *ctx, const uint32_t *ids_in, const float *scores_in, int32_t lists,
                       int64_t nq, int32_t k, int32_t metric, const uint32_t *id_offsets,
                       uint32_t *ids, float *scores, void *stream);
+/* The same merge over the all-gathered image of vg_comm_all_gather_topk: packed[lists][2][nq][k] uint32 in
+ * device memory, [l][0] = ids of list l, [l][1] = the bit patterns of its fp32 scores. */
+int32_t vg_merge_topk_packed(vg_ctx *ctx, const uint32_t *packed, int32_t lists, int64_t nq, int32_t k,
+                             int32_t metric, const uint32_t *id_offsets, uint32_t *ids, float *scores,
+                             void *stream);
+
+/* ---- multi-GPU: the one exchange step of a row-sharded search --------------------------------------
+ * One process (or OS thread) per GPU, each with its own vg_ctx and its shard of the rows resident
+ * (rows are independent, ids are global row numbers).  The reference merges per-segment
+ * candidate lists into one bounded heap in-process (engine/search.go:835-908); here the lists cross GPUs:
+ * ONE ncclAllGather (RCCL over xGMI) of nq*k*8 bytes per rank on the caller's stream, then vg_merge_topk
+ * with the reference's tie-break on every rank.  RCCL is dlopen'ed on first use.
+ *   vg_comm_unique_id   rank 0 fills id[VG_COMM_ID_BYTES] (ncclGetUniqueId); the host hands the bytes to
+ *                       the other ranks by whatever channel it has (Go: a pipe, a file, its RPC layer)
+ *   vg_comm_create      collective: every rank calls it with the same id (ncclCommInitRank)
+ *   vg_comm_all_gather_topk   local_ids / local_scores [nq*k] = this rank's vg_search_* output (local row
+ *                       numbers), id_offsets[world] = first global row of every shard; ids / scores [nq*k]
+ *                       = the merged global top-k, identical on every rank
+ *   vg_comm_all_gather  raw bytes (device buffers): e.g. the codebooks of a PQ trained by sub-quantizer
+ *                       ranges (vg_pq_train_subset + vg_pq_get_codebooks_range) */
+#define VG_COMM_ID_BYTES 128
+typedef struct vg_comm vg_comm;
+int32_t vg_comm_unique_id(uint8_t *id);
+int32_t vg_comm_create(vg_ctx *ctx, int32_t world, int32_t rank, const uint8_t *id, vg_comm **out);
+int32_t vg_comm_destroy(vg_comm *comm);
+int32_t vg_comm_info(const vg_comm *comm, int32_t *world, int32_t *rank);
+int32_t vg_comm_all_gather(vg_comm *comm, const void *send, void *recv, int64_t bytes_per_rank, void *stream);
+int32_t vg_comm_all_gather_topk(vg_comm *comm, const uint32_t *local_ids, const float *local_scores,
+                                int64_t nq, int32_t k, int32_t metric, const uint32_t *id_offsets,
+                                uint32_t *ids, float *scores, void *stream);
 
 /* flat.Segment.Search, PQ branch (flat/segment.go:476-483 LUT, :678-689 ADC
  * = simd.PqAdcLookup in pqAdcLookupAvx512 order, :714-721 top-k with the

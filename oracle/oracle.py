@@ -52,7 +52,7 @@ class HnswGraph(C.Structure):
     _fields_ = [("n", C.c_int64), ("dim", C.c_int32), ("metric", C.c_int32), ("base", _f32p),
                 ("m0", C.c_int32), ("l0", _u32p), ("max_level", C.c_int32), ("m", C.c_int32),
                 ("slot", C.POINTER(_u32p)), ("adj", C.POINTER(_u32p)),
-                ("entry_point", C.c_uint32)]
+                ("entry_point", C.c_uint32), ("pq", C.POINTER(PQ)), ("codes", _u8p)]
 
 
 class Vamana(C.Structure):
@@ -581,7 +581,9 @@ def rerank_f32(base, dim, query, ids, metric=METRIC_L2):
 class HnswIndex:
     """Host-side graph in the layout the C-ABI uploads (see include/vecgo_hip.h)."""
 
-    def __init__(self, base, dim, l0, upper=(), entry_point=0, metric=METRIC_L2, m=None):
+    def __init__(self, base, dim, l0, upper=(), entry_point=0, metric=METRIC_L2, m=None, pq=None, codes=None):
+        self.pq = pq  # score nodes from PQ codes (ComputeAsymmetricDistance) instead of fp32 rows
+        self.codes = None if codes is None else np.ascontiguousarray(codes, np.uint8)
         self.base = np.ascontiguousarray(base, np.float32).reshape(-1, dim)
         self.dim = dim
         self.n = self.base.shape[0]
@@ -598,9 +600,11 @@ class HnswIndex:
         nl = len(self.upper)
         self._slots = (_u32p * max(nl, 1))(*[s.ctypes.data_as(_u32p) for s, _ in self.upper])
         self._adjs = (_u32p * max(nl, 1))(*[a.ctypes.data_as(_u32p) for _, a in self.upper])
+        self._pqc = self.pq._c() if self.pq is not None else None
         return HnswGraph(self.n, self.dim, self.metric, self.base.ctypes.data_as(_f32p), self.m0,
                          self.l0.ctypes.data_as(_u32p), nl, self.m, self._slots, self._adjs,
-                         self.entry_point)
+                         self.entry_point, C.pointer(self._pqc) if self._pqc is not None else None,
+                         self.codes.ctypes.data_as(_u8p) if self.codes is not None else None)
 
     def search(self, query, k, ef):
         q, pq_ = _f(query)
@@ -804,3 +808,105 @@ class Ref:
         if a.size == 0:
             return 0
         return int(self.lib.hammingAvx512(a.ctypes.data, b.ctypes.data, a.size))
+
+
+# ---- timed CPU baseline (oracle/vg_cpu_bench.c): C threads, one query per thread ------------------------
+BENCH_FLAT, BENCH_HNSW, BENCH_ADC, BENCH_RABITQ, BENCH_VAMANA = 0, 1, 2, 3, 4
+
+
+class KernelHooks(C.Structure):
+    _fields_ = [("l2", C.c_void_p), ("dot", C.c_void_p), ("l2_bounded", C.c_void_p), ("l2_batch", C.c_void_p),
+                ("adc", C.c_void_p), ("hamming", C.c_void_p)]
+
+
+class BenchJob(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("base", _f32p), ("n", C.c_int64), ("dim", C.c_int32), ("metric", C.c_int32),
+                ("hnsw", C.POINTER(HnswGraph)), ("vamana", C.POINTER(Vamana)), ("pq", C.POINTER(PQ)),
+                ("codes", _u8p), ("queries", _f32p), ("nq", C.c_int64), ("k", C.c_int32), ("ef", C.c_int32),
+                ("ids", _u32p), ("dist_comps", _i64p)]
+
+
+_sig("vgo_set_kernel_hooks", None, C.POINTER(KernelHooks))
+_sig("vgo_bench_interleaved_copy", C.c_void_p, C.c_void_p, C.c_size_t, _i32p)
+_sig("vgo_bench_free", None, C.c_void_p, C.c_size_t)
+_sig("vgo_bench_run", C.c_int64, C.POINTER(BenchJob), C.c_int32, C.c_double, C.POINTER(C.c_double))
+
+
+def use_reference_kernels(on=True) -> bool:
+    """Route the oracle's L2 / Dot / bounded / ADC / Hamming calls through the reference's compiled AVX-512
+    kernels (oracle/_ref) — for the timed CPU baseline.  Returns False (and leaves the scalar port active) when
+    _ref is absent or the host has no AVX-512."""
+    if not on:
+        lib.vgo_set_kernel_hooks(None)
+        return False
+    r = load_ref()
+    if r is None:
+        lib.vgo_set_kernel_hooks(None)
+        return False
+    addr = lambda name: C.cast(getattr(r, name), C.c_void_p).value
+    h = KernelHooks(addr("squaredL2Avx512"), addr("dotProductAvx512"), addr("squaredL2BoundedAvx512"),
+                    addr("squaredL2BatchAvx512"), addr("pqAdcLookupAvx512"), addr("hammingAvx512"))
+    lib.vgo_set_kernel_hooks(C.byref(h))
+    return True
+
+
+class InterleavedCopy:
+    """A page-interleaved (MPOL_INTERLEAVE over the online NUMA nodes) copy of a host array."""
+
+    def __init__(self, arr):
+        a = np.ascontiguousarray(arr)
+        il = C.c_int32(0)
+        self.nbytes = a.nbytes
+        self.ptr = lib.vgo_bench_interleaved_copy(a.ctypes.data, a.nbytes, C.byref(il))
+        if not self.ptr:
+            raise MemoryError("vgo_bench_interleaved_copy")
+        self.numa_nodes = int(il.value)
+        self.array = np.ctypeslib.as_array(C.cast(self.ptr, C.POINTER(C.c_uint8)), (a.nbytes,)).view(a.dtype).reshape(a.shape)
+
+    def close(self):
+        if self.ptr:
+            self.array = None
+            lib.vgo_bench_free(self.ptr, self.nbytes)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def bench_run(kind, queries, k, threads, budget_s, base=None, dim=None, metric=METRIC_L2, hnsw: "HnswIndex" = None,
+              ef=0, pq: "ProductQuantizer" = None, codes=None, n=None, vamana: "VamanaIndex" = None, want_ids=False):
+    """One query per C thread for ~budget_s seconds.  Returns dict(queries, seconds, qps, ids, dist_comps)."""
+    q = np.ascontiguousarray(queries, np.float32)
+    nq, d = q.shape
+    job = BenchJob()
+    job.kind = kind
+    job.dim = d if dim is None else dim
+    job.metric = metric
+    job.queries = q.ctypes.data_as(_f32p)
+    job.nq, job.k, job.ef = nq, k, ef
+    keep = [q]
+    if base is not None:
+        job.base = base.ctypes.data_as(_f32p)
+        job.n = base.shape[0]
+    if n is not None:
+        job.n = n
+    if hnsw is not None:
+        g = hnsw._c(); keep.append(g)
+        job.hnsw = C.pointer(g)
+    if pq is not None:
+        pc = pq._c(); keep.append(pc)
+        job.pq = C.pointer(pc)
+    if codes is not None:
+        cd = np.ascontiguousarray(codes, np.uint8); keep.append(cd)
+        job.codes = cd.ctypes.data_as(_u8p)
+    ids = np.full((nq, k), 0xFFFFFFFF, np.uint32) if want_ids else None
+    dc = np.full(nq, -1, np.int64) if want_ids else None
+    if want_ids:
+        job.ids = ids.ctypes.data_as(_u32p)
+        job.dist_comps = dc.ctypes.data_as(_i64p)
+    secs = C.c_double(0)
+    done = lib.vgo_bench_run(C.byref(job), threads, budget_s, C.byref(secs))
+    return dict(queries=int(done), seconds=float(secs.value), qps=done / max(secs.value, 1e-9), ids=ids, dist_comps=dc)

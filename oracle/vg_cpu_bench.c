@@ -1,0 +1,198 @@
+/*
+ * vg_cpu_bench.c — the timed CPU baseline of bench.py (TEST / MEASUREMENT INFRASTRUCTURE ONLY, see
+ * vg_oracle.h): the reference's CPU algorithm on the host's cores with the reference's concurrency model,
+ * one query per thread (one goroutine per query, benchmark_test FastConcurrentSearch), nothing but C
+ * inside the timed region.  The loops are the oracle's restatements (flat/segment.go scan loops,
+ * hnsw.go searchExecute, diskann/segment.go searchInternal); when oracle/_ref is present the caller installs
+ * the reference's own compiled AVX-512 kernels through vgo_set_kernel_hooks, so the arithmetic runs at the
+ * reference's speed ("kind": "reference"), otherwise the scalar restatement runs ("kind": "port").
+ */
+#define _GNU_SOURCE
+#include <pthread.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <sys/mman.h>
+#include <sys/syscall.h>
+#include <time.h>
+#include <unistd.h>
+
+#include "vg_oracle.h"
+
+static double now_s(void)
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+/* ---- NUMA-interleaved copy of a corpus ---------------------------------------------------------------
+ * A corpus that one thread first-touched sits on one socket's DRAM; the scan baseline would then measure
+ * that socket's memory controller.  mbind(MPOL_INTERLEAVE) over the online nodes before the pages are
+ * touched (raw syscall: no libnuma in the image); failure is not an error, the copy is then ordinary. */
+typedef struct {
+    char *dst;
+    const char *src;
+    size_t bytes;
+} copy_job;
+static void *copy_worker(void *p)
+{
+    copy_job *j = (copy_job *)p;
+    memcpy(j->dst, j->src, j->bytes);
+    return NULL;
+}
+
+static int online_nodes(void)
+{
+    FILE *f = fopen("/sys/devices/system/node/online", "r");
+    if (!f) return 1;
+    int lo = 0, hi = 0, n = fscanf(f, "%d-%d", &lo, &hi);
+    fclose(f);
+    if (n == 2) return hi + 1;
+    return 1;
+}
+
+void *vgo_bench_interleaved_copy(const void *src, size_t bytes, int32_t *interleaved)
+{
+    size_t len = (bytes + 4095) & ~(size_t)4095;
+    void *p = mmap(NULL, len, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+    if (p == MAP_FAILED) return NULL;
+    int nodes = online_nodes();
+    int ok = 0;
+    if (nodes > 1 && nodes <= 64) {
+        unsigned long mask = nodes >= 64 ? ~0ul : ((1ul << nodes) - 1);
+#ifdef SYS_mbind
+        ok = syscall(SYS_mbind, p, len, 3 /* MPOL_INTERLEAVE */, &mask, (unsigned long)(nodes + 1), 0u) == 0;
+#endif
+    }
+    if (interleaved) *interleaved = ok ? nodes : 0;
+    enum { T = 16 };
+    pthread_t th[T];
+    copy_job jobs[T];
+    size_t per = ((bytes / T) + 4095) & ~(size_t)4095;
+    int used = 0;
+    for (int t = 0; t < T; t++) {
+        size_t off = (size_t)t * per;
+        if (off >= bytes) break;
+        jobs[t].dst = (char *)p + off;
+        jobs[t].src = (const char *)src + off;
+        jobs[t].bytes = off + per <= bytes ? per : bytes - off;
+        pthread_create(&th[t], NULL, copy_worker, &jobs[t]);
+        used++;
+    }
+    for (int t = 0; t < used; t++) pthread_join(th[t], NULL);
+    return p;
+}
+
+void vgo_bench_free(void *p, size_t bytes)
+{
+    if (p) munmap(p, (bytes + 4095) & ~(size_t)4095);
+}
+
+/* ---- one query per thread until the deadline ------------------------------------------------------- */
+enum { VGO_BENCH_FLAT = 0, VGO_BENCH_HNSW = 1, VGO_BENCH_ADC = 2, VGO_BENCH_RABITQ = 3, VGO_BENCH_VAMANA = 4 };
+
+typedef struct {
+    int32_t kind;
+    /* corpus */
+    const float *base;
+    int64_t n;
+    int32_t dim, metric;
+    const vgo_hnsw_graph *hnsw;
+    const vgo_vamana *vamana;
+    const vgo_pq *pq;
+    const uint8_t *codes;
+    /* queries */
+    const float *queries;
+    int64_t nq;
+    int32_t k, ef;
+    /* outputs of the first pass over the queries (may be NULL): ids[nq*k] */
+    uint32_t *ids;
+    int64_t *dist_comps; /* [nq] HNSW / Vamana: DistanceComputations */
+} vgo_bench_job;
+
+typedef struct {
+    const vgo_bench_job *job;
+    int tid, nthreads;
+    double deadline;
+    int64_t done;
+} worker;
+
+static void run_one(const vgo_bench_job *j, int64_t qi, uint32_t *ids, float *scores, uint32_t *visited, uint32_t epoch)
+{
+    const float *q = j->queries + qi * j->dim;
+    vgo_search_stats st = {0, 0, 0, 0};
+    int32_t r = 0;
+    switch (j->kind) {
+    case VGO_BENCH_FLAT:
+        r = vgo_flat_search_f32(j->base, j->n, j->dim, j->metric, q, j->k, ids, scores);
+        break;
+    case VGO_BENCH_HNSW:
+        r = vgo_hnsw_search_ws(j->hnsw, q, j->k, j->ef, ids, scores, &st, visited, epoch);
+        break;
+    case VGO_BENCH_ADC:
+        r = vgo_flat_search_pq(j->pq, j->codes, j->n, q, j->k, ids, scores);
+        break;
+    case VGO_BENCH_RABITQ:
+        r = vgo_flat_search_rabitq(j->codes, j->n, j->dim, q, j->k, ids, scores);
+        break;
+    case VGO_BENCH_VAMANA:
+        r = vgo_vamana_search(j->vamana, q, j->k, ids, scores, &st);
+        break;
+    }
+    for (int i = r; i < j->k; i++) ids[i] = 0xFFFFFFFFu;
+    if (j->dist_comps) j->dist_comps[qi] = st.distance_computations;
+}
+
+static void *bench_worker(void *p)
+{
+    worker *w = (worker *)p;
+    const vgo_bench_job *j = w->job;
+    uint32_t *ids = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)(j->k > 0 ? j->k : 1));
+    float *scores = (float *)malloc(sizeof(float) * (size_t)(j->k > 0 ? j->k : 1));
+    uint32_t *visited = j->kind == VGO_BENCH_HNSW ? (uint32_t *)calloc((size_t)j->hnsw->n, sizeof(uint32_t)) : NULL;
+    uint32_t epoch = 0;
+    int64_t i = w->tid;
+    for (;;) {
+        const int64_t qi = i % j->nq;
+        const int first_pass = i < j->nq;
+        if (++epoch == 0 && visited) { /* visited.go:60-75: clear on wrap-around */
+            memset(visited, 0, sizeof(uint32_t) * (size_t)j->hnsw->n);
+            epoch = 1;
+        }
+        run_one(j, qi, (first_pass && j->ids) ? j->ids + qi * j->k : ids, scores, visited, epoch);
+        w->done++;
+        i += w->nthreads;
+        if (now_s() >= w->deadline) break;
+    }
+    free(ids);
+    free(scores);
+    free(visited);
+    return NULL;
+}
+
+/* Runs for about budget_s seconds of wall time (every thread finishes the query it is on).  Returns
+ * queries completed; *seconds = wall time from the first thread's start to the last one's end. */
+int64_t vgo_bench_run(const vgo_bench_job *job, int32_t nthreads, double budget_s, double *seconds)
+{
+    if (nthreads < 1) nthreads = 1;
+    worker *ws = (worker *)calloc((size_t)nthreads, sizeof(worker));
+    pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)nthreads);
+    const double t0 = now_s();
+    for (int t = 0; t < nthreads; t++) {
+        ws[t].job = job;
+        ws[t].tid = t;
+        ws[t].nthreads = nthreads;
+        ws[t].deadline = t0 + budget_s;
+        pthread_create(&th[t], NULL, bench_worker, &ws[t]);
+    }
+    int64_t total = 0;
+    for (int t = 0; t < nthreads; t++) {
+        pthread_join(th[t], NULL);
+        total += ws[t].done;
+    }
+    *seconds = now_s() - t0;
+    free(ws);
+    free(th);
+    return total;
+}

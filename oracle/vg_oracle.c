@@ -9,6 +9,65 @@
 #include <stdlib.h>
 #include <string.h>
 
+/* ------------------------------------------------------------------ */
+/* Optional kernel hooks (bench.py's cpu_baseline only): when oracle/_ref is   */
+/* present the timed CPU loops call the REFERENCE's compiled AVX-512 kernels   */
+/* instead of the scalar restatements below (bit-identical results, see        */
+/* tests/test_oracle_golden.py), so that the reported baseline is the          */
+/* reference's arithmetic at the reference's speed.  Set once, before threads. */
+/* ------------------------------------------------------------------ */
+vgo_kernel_hooks vgo_hooks = {0, 0, 0, 0, 0, 0};
+void vgo_set_kernel_hooks(const vgo_kernel_hooks *h)
+{
+    if (h)
+        vgo_hooks = *h;
+    else
+        memset(&vgo_hooks, 0, sizeof vgo_hooks);
+}
+static inline float hk_l2(const float *a, const float *b, int64_t n)
+{
+    if (vgo_hooks.l2 && n > 0) {
+        float r;
+        vgo_hooks.l2((float *)a, (float *)b, n, &r);
+        return r;
+    }
+    return vgo_l2_avx512(a, b, n);
+}
+static inline float hk_dot(const float *a, const float *b, int64_t n)
+{
+    if (vgo_hooks.dot && n > 0) {
+        float r;
+        vgo_hooks.dot((float *)a, (float *)b, n, &r);
+        return r;
+    }
+    return vgo_dot_avx512(a, b, n);
+}
+static inline float hk_adc(const float *table, const uint8_t *codes, int64_t m)
+{
+    if (vgo_hooks.adc && m > 0) {
+        /* kernels_amd64.go:38-44 pqAdcOffsets[i] = i*256, 64-byte aligned */
+        static const int32_t offs[16] __attribute__((aligned(64))) = {0, 256, 512, 768, 1024, 1280, 1536, 1792,
+                                                                      2048, 2304, 2560, 2816, 3072, 3328, 3584, 3840};
+        float r;
+        vgo_hooks.adc((float *)table, (uint8_t *)codes, m, &r, offs);
+        return r;
+    }
+    return vgo_adc_avx512(table, codes, m);
+}
+static inline int64_t hk_hamming(const uint8_t *a, const uint8_t *b, int64_t n)
+{
+    if (vgo_hooks.hamming) return (int64_t)vgo_hooks.hamming(a, b, n);
+    return vgo_hamming(a, b, n);
+}
+static inline void hk_l2_bounded(const float *a, const float *b, int64_t n, float bound, float *out, int32_t *ex)
+{
+    if (vgo_hooks.l2_bounded && n > 0)
+        vgo_hooks.l2_bounded((float *)a, (float *)b, n, bound, out, ex);
+    else
+        vgo_l2_bounded_avx512(a, b, n, bound, out, ex);
+}
+
+
 #if defined(__clang__)
 #pragma clang fp contract(off)
 #elif defined(__GNUC__)
@@ -535,11 +594,11 @@ float vgo_rabitq_distance(const float *query, int32_t dim, const uint8_t *code)
     int64_t nb = (int64_t)nw * 8;
     float ynorm;
     memcpy(&ynorm, code + nb, 4);
-    float qnorm = vgo_sqrt(vgo_dot_avx512(query, query, dim));
+    float qnorm = vgo_sqrt(hk_dot(query, query, dim));
     uint64_t qc[64];
     uint64_t *q = nw <= 64 ? qc : (uint64_t *)malloc(sizeof(uint64_t) * (size_t)nw);
     vgo_binary_encode_u64(query, dim, 0.0f, q);
-    float hamming = (float)vgo_hamming((const uint8_t *)q, code, nb);
+    float hamming = (float)hk_hamming((const uint8_t *)q, code, nb);
     if (q != qc) free(q);
     float t1 = qnorm - ynorm;
     float t1sq = t1 * t1;
@@ -940,8 +999,7 @@ int32_t vgo_flat_search_f32(const float *base, int64_t n, int32_t dim, int32_t m
     vgo_candheap h;
     vgo_candheap_init(&h, k, desc);
     for (int64_t i = 0; i < n; i++) { /* segment.go:691-701 */
-        float d = desc ? vgo_dot_avx512(query, base + i * dim, dim)
-                       : vgo_l2_avx512(query, base + i * dim, dim);
+        float d = desc ? hk_dot(query, base + i * dim, dim) : hk_l2(query, base + i * dim, dim);
         vgo_candheap_try_push_bounded(&h, (vgo_cand){0, (uint32_t)i, d}, k);
     }
     int32_t r = emit_sorted(&h, ids, scores);
@@ -963,7 +1021,7 @@ int32_t vgo_flat_search_pq(const vgo_pq *pq, const uint8_t *codes, int64_t n,
     vgo_candheap h;
     vgo_candheap_init(&h, k, 0);
     for (int64_t i = 0; i < n; i++) { /* segment.go:678-689 */
-        float d = vgo_adc_avx512(table, codes + i * pq->m, pq->m);
+        float d = hk_adc(table, codes + i * pq->m, pq->m);
         vgo_candheap_try_push_bounded(&h, (vgo_cand){0, (uint32_t)i, d}, k);
     }
     int32_t r = emit_sorted(&h, ids, scores);
@@ -1003,14 +1061,15 @@ void vgo_rerank_f32(const float *base, int32_t dim, int32_t metric, const float 
 /* vectorstore/columnar.go:29-50 snapshot distance: L2, -Dot, 0.5*L2 */
 static float hnsw_dist(const vgo_hnsw_graph *g, const float *q, uint32_t id)
 {
+    if (g->pq) return vgo_pq_asym_distance(g->pq, q, g->codes + (int64_t)id * g->pq->m);
     const float *v = g->base + (int64_t)id * g->dim;
     switch (g->metric) {
     case VGO_METRIC_L2:
-        return vgo_l2_avx512(v, q, g->dim);
+        return hk_l2(v, q, g->dim);
     case VGO_METRIC_DOT:
-        return -vgo_dot_avx512(v, q, g->dim);
+        return -hk_dot(v, q, g->dim);
     default:
-        return 0.5f * vgo_l2_avx512(v, q, g->dim);
+        return 0.5f * hk_l2(v, q, g->dim);
     }
 }
 
@@ -1046,7 +1105,7 @@ void vgo_hnsw_search_layer(const vgo_hnsw_graph *g, const float *query, uint32_t
     vgo_prioq_push(&cand, (vgo_pq_item){ep, ep_d});
     vgo_prioq_push(&res, (vgo_pq_item){ep, ep_d});
 
-    int use_sc = g->metric == VGO_METRIC_L2;
+    int use_sc = g->metric == VGO_METRIC_L2 && !g->pq;
     int cap = ef * 2;
     int stagnant = 0;
     float last_best = 3.40282346638528859811704183484516925440e+38f;
@@ -1083,8 +1142,7 @@ void vgo_hnsw_search_layer(const vgo_hnsw_graph *g, const float *query, uint32_t
             float nd;
             if (use_sc && has_bound) {
                 int32_t ex;
-                vgo_l2_bounded_avx512(query, g->base + (int64_t)id * g->dim, g->dim, bound, &nd,
-                                      &ex);
+                hk_l2_bounded(query, g->base + (int64_t)id * g->dim, g->dim, bound, &nd, &ex);
                 st.distance_computations++;
                 if (ex) {
                     st.distance_short_circuits++;
@@ -1116,6 +1174,15 @@ float vgo_hnsw_node_distance(const vgo_hnsw_graph *g, const float *query, uint32
 int32_t vgo_hnsw_search(const vgo_hnsw_graph *g, const float *query, int32_t k, int32_t ef,
                         uint32_t *ids, float *scores, vgo_search_stats *stats)
 {
+    return vgo_hnsw_search_ws(g, query, k, ef, ids, scores, stats, NULL, 1);
+}
+
+/* the same with a caller-owned visited array (n words, all != epoch): searcher.VisitedSet is an epoch array
+ * reused across queries (visited.go:12-129), which is what a timed loop should pay for */
+int32_t vgo_hnsw_search_ws(const vgo_hnsw_graph *g, const float *query, int32_t k, int32_t ef,
+                           uint32_t *ids, float *scores, vgo_search_stats *stats, uint32_t *visited_ws,
+                           uint32_t epoch)
+{
     vgo_search_stats st = {0, 0, 0, 0};
     if (ef < k) ef = k; /* determineEF hnsw.go:1891-1894 */
 
@@ -1141,11 +1208,11 @@ int32_t vgo_hnsw_search(const vgo_hnsw_graph *g, const float *query, int32_t k, 
     }
 
     /* searchLayerUnfiltered hnsw.go:1220-1396 on layer 0 */
-    uint32_t *visited = (uint32_t *)calloc((size_t)g->n, sizeof(uint32_t));
+    uint32_t *visited = visited_ws ? visited_ws : (uint32_t *)calloc((size_t)g->n, sizeof(uint32_t));
     vgo_prioq cand, res;
     vgo_prioq_init(&cand, 0, ef * 2);
     vgo_prioq_init(&res, 1, ef);
-    vgo_hnsw_search_layer(g, query, cur, cur_d, 0, ef, visited, 1, &cand, &res, &st);
+    vgo_hnsw_search_layer(g, query, cur, cur_d, 0, ef, visited, epoch, &cand, &res, &st);
     /* knnSearchInternal extraction hnsw.go:1732-1751 */
     vgo_pq_item it;
     while (res.len > k) vgo_prioq_pop(&res, &it);
@@ -1157,7 +1224,7 @@ int32_t vgo_hnsw_search(const vgo_hnsw_graph *g, const float *query, int32_t k, 
     }
     vgo_prioq_free(&cand);
     vgo_prioq_free(&res);
-    free(visited);
+    if (!visited_ws) free(visited);
     if (stats) *stats = st;
     return nres;
 }

@@ -155,6 +155,11 @@ typedef struct {
     const uint32_t *const *slot;
     const uint32_t *const *adj;
     uint32_t entry_point;
+    /* appended: when pq != NULL the nodes are scored from their PQ codes (n*m bytes) with
+     * ComputeAsymmetricDistance (pq.go:234-260) instead of their fp32 rows — distFunc the way
+     * diskann/segment.go:536-557 builds it; no SquaredL2Bounded short-circuit then */
+    const vgo_pq *pq;
+    const uint8_t *codes;
 } vgo_hnsw_graph;
 
 typedef struct {
@@ -165,6 +170,19 @@ typedef struct {
  * then knnSearchInternal's extraction: best-first k results. */
 int32_t vgo_hnsw_search(const vgo_hnsw_graph *g, const float *query, int32_t k, int32_t ef,
                         uint32_t *ids, float *scores, vgo_search_stats *stats);
+
+/* see vg_oracle.c "Optional kernel hooks": the reference's compiled kernels (oracle/_ref) for the timed CPU
+ * baseline; signatures are the reference's C ABI (the _avx512.c files of internal/simd/src) */
+typedef struct {
+    void (*l2)(float *, float *, int64_t, float *);
+    void (*dot)(float *, float *, int64_t, float *);
+    void (*l2_bounded)(float *, float *, int64_t, float, float *, int32_t *);
+    void (*l2_batch)(float *, float *, int64_t, int64_t, float *);
+    void (*adc)(float *, uint8_t *, int64_t, float *, const void *);
+    long long (*hamming)(const uint8_t *, const uint8_t *, int64_t);
+} vgo_kernel_hooks;
+extern vgo_kernel_hooks vgo_hooks;
+void vgo_set_kernel_hooks(const vgo_kernel_hooks *h);
 
 /* one layer of the search, shared by vgo_hnsw_search and the builder (hnsw.go:1220-1396) */
 void vgo_hnsw_search_layer(const vgo_hnsw_graph *g, const float *query, uint32_t ep, float ep_d,
@@ -190,6 +208,10 @@ int64_t vgo_hnsw_build_batch(int64_t inserted, int64_t n, int32_t max_batch, int
 int32_t vgo_hnsw_build(const float *base, int64_t n, int32_t dim, int32_t metric, int32_t m, int32_t ef,
                        int32_t max_batch, int32_t growth_div, uint32_t *l0, uint32_t *slots, uint32_t *adj,
                        uint32_t *entry_point, int32_t *max_level);
+
+int32_t vgo_hnsw_search_ws(const vgo_hnsw_graph *g, const float *query, int32_t k, int32_t ef,
+                           uint32_t *ids, float *scores, vgo_search_stats *stats, uint32_t *visited_ws,
+                           uint32_t epoch);
 
 enum { VGO_VAMANA_F32 = 0, VGO_VAMANA_PQ = 1, VGO_VAMANA_RABITQ = 2, VGO_VAMANA_INT4 = 3 };
 typedef struct {

@@ -1,0 +1,80 @@
+"""The exchange step behind the C ABI (vg_comm.hip) as far as one GPU can exercise it: RCCL is loaded and
+joined with world = 1 (the all-gather is then a copy), and the packed merge is checked with several lists
+against the dense merge and the oracle's CandidateHeap order."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def vg():
+    import vecgo_amd
+    return vecgo_amd
+
+
+@pytest.fixture(scope="module")
+def ctx(vg):
+    return vg.Context(0)
+
+
+def test_packed_merge_equals_dense_merge(vg, ctx):
+    import torch
+    from vecgo_amd import api
+    rng = np.random.default_rng(1)
+    lists, nq, k = 5, 37, 10
+    ids = rng.integers(0, 1000, (lists, nq, k)).astype(np.uint32)
+    sc = np.sort(rng.integers(0, 50, (lists, nq, k)).astype(np.float32), axis=2)  # ties across lists
+    ids[2, :, 7:] = 0xFFFFFFFF                                                    # short lists
+    off = (np.arange(lists) * 1000).astype(np.uint32)
+    dense = api.merge_topk(ctx, ids, sc, k, metric=0, id_offsets=off)
+    packed = np.stack([ids.view(np.int32), sc.view(np.int32)], axis=1)            # [lists, 2, nq, k]
+    dev = torch.device("cuda", 0)
+    p = torch.from_numpy(packed).to(dev)
+    o = torch.from_numpy(off.view(np.int32)).to(dev)
+    got = api.merge_topk_packed(ctx, p, lists, nq, k, metric=0, id_offsets=o)
+    assert np.array_equal(got[0].cpu().numpy().view(np.uint32), dense[0])
+    assert np.array_equal(got[1].cpu().numpy().view(np.uint32), dense[1].view(np.uint32))
+    # and both are the k smallest (score, global id) pairs
+    for q in range(nq):
+        cand = sorted((float(sc[l, q, j]), int(ids[l, q, j]) + int(off[l])) for l in range(lists) for j in range(k)
+                      if ids[l, q, j] != 0xFFFFFFFF)[:k]
+        assert [c[1] for c in cand] == dense[0][q].tolist()
+
+
+def test_comm_world_of_one(vg, ctx):
+    import torch
+    from vecgo_amd import api
+    uid = api.Comm.unique_id()
+    assert len(uid) == 128
+    comm = api.Comm(ctx, 1, 0, uid)
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(2)
+    nq, k = 19, 10
+    sc = np.sort(rng.standard_normal((nq, k)).astype(np.float32), axis=1)
+    ids = rng.integers(0, 500, (nq, k)).astype(np.uint32)
+    out = comm.all_gather_topk(torch.from_numpy(ids.view(np.int32)).to(dev), torch.from_numpy(sc).to(dev), k,
+                               id_offsets=torch.tensor([7], dtype=torch.int32, device=dev))
+    want = api.merge_topk(ctx, ids[None], sc[None], k, metric=0, id_offsets=np.array([7], np.uint32))
+    assert np.array_equal(out[0].cpu().numpy().view(np.uint32), want[0])
+    assert np.array_equal(out[1].cpu().numpy().view(np.uint32), want[1].view(np.uint32))
+    a = torch.arange(1000, dtype=torch.uint8, device=dev)
+    b = torch.zeros(1000, dtype=torch.uint8, device=dev)
+    comm.all_gather_bytes(a, b)
+    torch.cuda.synchronize()
+    assert torch.equal(a, b)
+    comm.close()
+
+
+def test_sharded_flat_index_on_one_rank(vg, ctx):
+    """world = 1 through vecgo_amd.sharded: the packed block written in place by the local search, merged."""
+    import torch
+    from vecgo_amd import sharded
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev); g.manual_seed(3)
+    rows = torch.randn((5000, 64), device=dev, generator=g)
+    q = torch.randn((33, 64), device=dev, generator=g)
+    idx = sharded.ShardedFlatIndex(ctx, rows, 64, [0, 5000])
+    ids, sc = idx.search(q, 10)
+    want = idx.index.search_flat(q, 10)
+    assert torch.equal(ids, want[0]) and torch.equal(sc, want[1])

@@ -144,3 +144,50 @@ def test_graph_errors(vg, ctx):
     assert e.value.status == -9
     with pytest.raises(vg.VecgoHipError):
         idx.set_vamana_graph(np.zeros((10, 65), np.uint32), 0)
+
+
+@pytest.mark.parametrize("n,dim,m,ef,k", [(3000, 32, 8, 600, 10), (2500, 64, 16, 1500, 100), (1200, 16, 8, 4000, 10)])
+def test_hnsw_large_ef_heaps_in_hbm(vg, ctx, n, dim, m, ef, k):
+    """ef > 512: the two heaps of a query live in HBM scratch; same ids, scores and counters."""
+    rng = np.random.default_rng(ef)
+    base = rng.standard_normal((n, dim)).astype(np.float32)
+    l0, upper, entry = graphs.build_hnsw(base, m=m, seed=2)
+    oidx = o.HnswIndex(base, dim, l0, upper, entry)
+    idx = vg.Index(ctx, n, dim)
+    idx.set_vectors(base)
+    idx.set_hnsw_graph(l0, upper, entry, m=m)
+    q = rng.standard_normal((6, dim)).astype(np.float32)
+    ids, sc, st = idx.search_hnsw(q, k, ef, stats=True)
+    for qi in range(6):
+        eid, esc, est = oidx.search(q[qi], k, ef)
+        assert np.array_equal(ids[qi, :eid.size], eid)
+        assert np.array_equal(bits(sc[qi, :eid.size]), bits(esc))
+        assert tuple(int(x) for x in st[qi]) == _stats_tuple(est)
+
+
+@pytest.mark.parametrize("n,dim,m,ef,k", [(2000, 32, 8, 64, 10), (1500, 768, 16, 128, 128), (1000, 96, 8, 700, 50)])
+def test_hnsw_pq_scored_matches_oracle(vg, ctx, n, dim, m, ef, k):
+    """vg_search_hnsw_pq: the layer walk with distFunc = ComputeAsymmetricDistance over PQ codes."""
+    rng = np.random.default_rng(n + ef)
+    base = rng.standard_normal((n, dim)).astype(np.float32)
+    l0, upper, entry = graphs.build_hnsw(base, m=m, seed=4)
+    pm = dim // 8
+    opq = o.ProductQuantizer(dim, pm, 256)
+    opq.set_codebooks(rng.integers(-128, 128, pm * 256 * 8).astype(np.int8),
+                      (rng.random(pm) * 0.02 + 0.005).astype(np.float32),
+                      ((rng.random(pm) * 2 - 1) * 0.1).astype(np.float32))
+    codes = opq.encode_batch(base)
+    oidx = o.HnswIndex(base, dim, l0, upper, entry, pq=opq, codes=codes)
+    pq = vg.ProductQuantizer(ctx, dim, pm, 256)
+    pq.set_codebooks(opq.codebooks, opq.scales, opq.offsets)
+    idx = vg.Index(ctx, n, dim)
+    idx.set_vectors(base)
+    idx.set_pq_codes(pq, codes)
+    idx.set_hnsw_graph(l0, upper, entry, m=m)
+    q = rng.standard_normal((8, dim)).astype(np.float32)
+    ids, sc, st = idx.search_hnsw_pq(q, k, ef, stats=True)
+    for qi in range(8):
+        eid, esc, est = oidx.search(q[qi], k, ef)
+        assert np.array_equal(ids[qi, :eid.size], eid), (qi, ids[qi], eid)
+        assert np.array_equal(bits(sc[qi, :eid.size]), bits(esc))
+        assert tuple(int(x) for x in st[qi]) == _stats_tuple(est)

@@ -15,7 +15,9 @@ import torch.multiprocessing as mp
 ROOT = Path(__file__).resolve().parents[1]
 
 
-def _np_merge(ids, scores, k, off):
+def _np_merge(packed, k, off):
+    """the packed image sharded_search hands to vg_merge_topk_packed: [world, 2, nq, k] int32"""
+    ids, scores = packed[:, 0], packed[:, 1].contiguous().view(torch.float32)
     ids = ids.numpy().view(np.uint32).astype(np.int64) + off.numpy().astype(np.int64)[:, None, None]
     sc = scores.numpy()
     world, nq, kk = sc.shape
@@ -41,11 +43,14 @@ def _worker(rank, world, port, n, dim, nq, k, ret):
     bounds = sharded.partition(n, world)
     lo, hi = bounds[rank], bounds[rank + 1]
 
-    def local(q, kk):
+    def local(q, kk, out):
         ids = np.full((nq, kk), 0xFFFFFFFF, np.uint32); sc = np.full((nq, kk), np.inf, np.float32)
         for i in range(nq):
             a, b = o.flat_search_f32(base[lo:hi], dim, q[i], kk)
             ids[i, :a.size] = a; sc[i, :b.size] = b
+        if rank == 0:   # one rank fills the caller's block in place, the other returns fresh tensors
+            out[0].copy_(torch.from_numpy(ids.view(np.int32))); out[1].copy_(torch.from_numpy(sc))
+            return out
         return torch.from_numpy(ids.view(np.int32)), torch.from_numpy(sc)
 
     ids, sc = sharded.sharded_search(local, _np_merge, queries, k, bounds)
@@ -127,15 +132,3 @@ def test_two_rank_sharded_pq_training_equals_single_process():
     ret = mgr.dict()
     mp.spawn(_pq_worker, args=(world, port, ret), nprocs=world, join=True)
     assert ret[0] and ret[1]
-
-
-def test_assemble_codebooks_takes_each_range_from_its_owner():
-    from vecgo_amd import sharded
-    m, per, world = 5, 3, 3
-    bounds = sharded.partition(m, world)
-    g_cb = torch.stack([torch.full((m * per,), r, dtype=torch.int8) for r in range(world)])
-    g_s = torch.stack([torch.full((m,), float(r)) for r in range(world)])
-    cb, sc, of = sharded.assemble_codebooks(g_cb, g_s, g_s.clone(), bounds, per)
-    for r in range(world):
-        lo, hi = bounds[r], bounds[r + 1]
-        assert torch.all(cb[lo * per:hi * per] == r) and torch.all(sc[lo:hi] == r) and torch.all(of[lo:hi] == r)

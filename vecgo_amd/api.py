@@ -150,6 +150,73 @@ def merge_topk(ctx: Context, ids_in, scores_in, k: int, metric=0, id_offsets=Non
     return out
 
 
+class Comm:
+    """vg_comm: the exchange step of a row-sharded search through the C ABI (direct ncclAllGather on the
+    caller's stream + merge).  Rank 0 makes the id (Comm.unique_id()), the host distributes the bytes."""
+
+    ID_BYTES = 128
+
+    @staticmethod
+    def unique_id() -> bytes:
+        lib = _lib.load()
+        buf = (C.c_uint8 * Comm.ID_BYTES)()
+        check(lib.vg_comm_unique_id(buf))
+        return bytes(buf)
+
+    def __init__(self, ctx: Context, world: int, rank: int, unique_id: bytes):
+        self._lib = ctx._lib
+        self.ctx, self.world, self.rank = ctx, world, rank
+        h = C.c_void_p()
+        buf = (C.c_uint8 * Comm.ID_BYTES).from_buffer_copy(unique_id)
+        check(self._lib.vg_comm_create(ctx._h, C.c_int32(world), C.c_int32(rank), buf, C.byref(h)))
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.vg_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def all_gather_topk(self, local_ids, local_scores, k: int, metric=0, id_offsets=None, out=None, stream=None):
+        """local_ids/local_scores [nq, k] (device) -> merged global (ids, scores) [nq, k]."""
+        nq = local_ids.shape[0]
+        i, pi = _ptr(local_ids, np.uint32, nq * k)
+        s_, ps = _ptr(local_scores, np.float32, nq * k)
+        o, po = _ptr(id_offsets, np.uint32, self.world) if id_offsets is not None else (None, None)
+        if out is None:
+            out = (_empty_like(local_ids, (nq, k), np.uint32), _empty_like(local_ids, (nq, k), np.float32))
+        oi, poi = _ptr(out[0], np.uint32, nq * k)
+        os_, pos = _ptr(out[1], np.float32, nq * k)
+        check(self._lib.vg_comm_all_gather_topk(self._h, pi, ps, C.c_int64(nq), C.c_int32(k), C.c_int32(int(metric)),
+                                                po, poi, pos, _stream_ptr(stream)))
+        return out
+
+    def all_gather_bytes(self, send, recv, stream=None):
+        """send: uint8 device tensor of this rank; recv: uint8 device tensor, world times as long."""
+        a, pa = _ptr(send, np.uint8)
+        b, pb = _ptr(recv, np.uint8, a.numel() * self.world)
+        check(self._lib.vg_comm_all_gather(self._h, pa, pb, C.c_int64(a.numel()), _stream_ptr(stream)))
+        return recv
+
+
+def merge_topk_packed(ctx: Context, packed, lists: int, nq: int, k: int, metric=0, id_offsets=None, out=None, stream=None):
+    """vg_merge_topk_packed: packed is a device int32/uint32 tensor [lists, 2, nq, k]."""
+    p_, pp = _ptr(packed, np.uint32, lists * 2 * nq * k)
+    o, po = _ptr(id_offsets, np.uint32, lists) if id_offsets is not None else (None, None)
+    if out is None:
+        out = (_empty_like(packed, (nq, k), np.uint32), _empty_like(packed, (nq, k), np.float32))
+    oi, poi = _ptr(out[0], np.uint32, nq * k)
+    os_, pos = _ptr(out[1], np.float32, nq * k)
+    check(ctx._lib.vg_merge_topk_packed(ctx._h, pp, C.c_int32(lists), C.c_int64(nq), C.c_int32(k), C.c_int32(int(metric)),
+                                        po, poi, pos, _stream_ptr(stream)))
+    return out
+
+
 def squared_l2_bounded_batch(ctx: Context, query, targets, dim: int, bounds, stream=None):
     """simd.SquaredL2Bounded (kernels.go:173), one query vs n targets: (dist[n], exceeded[n])."""
     n = (targets.numel() if _is_torch(targets) else np.asarray(targets).size) // dim if dim > 0 else 0
@@ -741,6 +808,11 @@ class Index:
         """hnsw.KNNSearch (hnsw.go:1650-1755); stats columns: nodes_visited,
         distance_computations, distance_short_circuits, pops."""
         return self._graph_search(self._lib.vg_search_hnsw, queries, k, ef, stats, stream)
+
+    def search_hnsw_pq(self, queries, k, ef, stats=False, stream=None):
+        """searchLayer with distFunc = pq.ComputeAsymmetricDistance over the nodes' PQ codes (the candidate
+        stage of graph -> PQ -> exact rerank); scores are PQ distances."""
+        return self._graph_search(self._lib.vg_search_hnsw_pq, queries, k, ef, stats, stream)
 
     def search_vamana(self, queries, k, kind=0, stats=False, stream=None):
         """diskann searchInternal (diskann/segment.go:503-706); kind 0 fp32, 1 PQ, 2 RaBitQ, 3 INT4."""

@@ -898,8 +898,10 @@ static int32_t launch_scan96(const vg_index *idx, const float *tables, int64_t n
 
 namespace vg {
 // (id, score) lists [lists][nq][k] -> keys [nq][lists][k] (ascending per list is preserved)
+// list_stride: elements between the starts of two lists in ids[] / scores[] (nq*k when the lists are dense;
+// 2*nq*k for the all-gathered [list][ids | score bits][nq][k] image of vg_comm.hip)
 __global__ void pack_keys_kernel(const uint32_t *__restrict__ ids, const float *__restrict__ scores,
-                                 int lists, int64_t nq, int k, bool descending,
+                                 int lists, int64_t nq, int k, int64_t list_stride, bool descending,
                                  const uint32_t *__restrict__ offsets, uint64_t *__restrict__ keys)
 {
     const int64_t gid = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -908,16 +910,38 @@ __global__ void pack_keys_kernel(const uint32_t *__restrict__ ids, const float *
     const int i = static_cast<int>(gid % k);
     const int64_t q = (gid / k) % nq;
     const int l = static_cast<int>(gid / (static_cast<int64_t>(k) * nq));
-    const uint32_t id = ids[gid];
+    const int64_t src = l * list_stride + q * k + i;
+    const uint32_t id = ids[src];
     uint64_t key = kKeyMax;
-    if (id != VG_INVALID_ID) key = make_key(scores[gid], id + (offsets ? offsets[l] : 0u), descending);
+    if (id != VG_INVALID_ID) key = make_key(scores[src], id + (offsets ? offsets[l] : 0u), descending);
     keys[(q * lists + l) * k + i] = key;
 }
 }  // namespace vg
 
+static int32_t merge_topk_impl(vg_ctx *ctx, const uint32_t *ids_in, const float *scores_in, int64_t list_stride,
+                               int32_t lists, int64_t nq, int32_t k, int32_t metric, const uint32_t *id_offsets,
+                               uint32_t *ids, float *scores, void *stream);
+
 VG_API int32_t vg_merge_topk(vg_ctx *ctx, const uint32_t *ids_in, const float *scores_in, int32_t lists,
                              int64_t nq, int32_t k, int32_t metric, const uint32_t *id_offsets,
                              uint32_t *ids, float *scores, void *stream)
+{
+    return merge_topk_impl(ctx, ids_in, scores_in, nq * k, lists, nq, k, metric, id_offsets, ids, scores, stream);
+}
+
+VG_API int32_t vg_merge_topk_packed(vg_ctx *ctx, const uint32_t *packed, int32_t lists, int64_t nq, int32_t k,
+                                    int32_t metric, const uint32_t *id_offsets, uint32_t *ids, float *scores,
+                                    void *stream)
+{
+    VG_CHECK(lists == 0 || nq == 0 || k == 0 || (packed && vg::is_device_ptr(packed)), VG_ERR_INVALID_ARG,
+             "vg_merge_topk_packed: packed must be device memory");
+    return merge_topk_impl(ctx, packed, reinterpret_cast<const float *>(packed) + nq * k, 2 * nq * k, lists, nq, k,
+                           metric, id_offsets, ids, scores, stream);
+}
+
+static int32_t merge_topk_impl(vg_ctx *ctx, const uint32_t *ids_in, const float *scores_in, int64_t list_stride,
+                               int32_t lists, int64_t nq, int32_t k, int32_t metric, const uint32_t *id_offsets,
+                               uint32_t *ids, float *scores, void *stream)
 {
     VG_CHECK(ctx, VG_ERR_INVALID_ARG, "vg_merge_topk: ctx is NULL");
     VG_CHECK(lists >= 0 && nq >= 0 && k >= 0, VG_ERR_INVALID_ARG, "vg_merge_topk: negative count");
@@ -931,12 +955,18 @@ VG_API int32_t vg_merge_topk(vg_ctx *ctx, const uint32_t *ids_in, const float *s
     hipStream_t st = vg::pick_stream(ctx, stream);
     const bool desc = metric != VG_METRIC_L2;
     const size_t total = static_cast<size_t>(lists) * nq * k;
+    const bool dense = list_stride == nq * k;  // the packed image is device memory already (checked by the caller)
     vg::DevIn<uint32_t> i_in, offs;
     vg::DevIn<float> s_in;
     vg::DevOut<uint32_t> oid;
     vg::DevOut<float> osc;
-    VG_TRY(i_in.init(ids_in, total, st));
-    VG_TRY(s_in.init(scores_in, total, st));
+    if (dense) {
+        VG_TRY(i_in.init(ids_in, total, st));
+        VG_TRY(s_in.init(scores_in, total, st));
+    } else {
+        i_in.ptr = ids_in;
+        s_in.ptr = scores_in;
+    }
     VG_TRY(offs.init(id_offsets, id_offsets ? static_cast<size_t>(lists) : 0, st));
     VG_TRY(oid.init(ids, static_cast<size_t>(nq) * k, st));
     VG_TRY(osc.init(scores, static_cast<size_t>(nq) * k, st));
@@ -949,7 +979,7 @@ VG_API int32_t vg_merge_topk(vg_ctx *ctx, const uint32_t *ids_in, const float *s
         VG_HIP(hipMemsetAsync(keys.ptr, 0xFF, static_cast<size_t>(nq) * k * 8, st));
     } else {
         VG_LAUNCH(vg::pack_keys_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256),
-                           0, st, i_in.ptr, s_in.ptr, lists, nq, k, desc, offs.ptr, keys.ptr);
+                           0, st, i_in.ptr, s_in.ptr, lists, nq, k, list_stride, desc, offs.ptr, keys.ptr);
     }
     VG_TRY(vg::launch_topk_merge(keys.ptr, nq, nl, k, desc, oid.ptr, osc.ptr, st));
     VG_TRY(oid.finish());

@@ -10,6 +10,7 @@
 // gathered and scored in parallel (16 lanes per fp32 row, 4 rows at a time, reference summation
 // order), then fed to the heaps in the node's stored neighbour order.
 #include <algorithm>
+#include <type_traits>
 
 #include "vg_device.hpp"
 #include "vg_exact.hpp"
@@ -25,11 +26,16 @@ int32_t launch_pq_build_table(const vg_pq *pq, const float *d_queries, int64_t n
 
 // ---- HNSW ----------------------------------------------------------------------------------------
 // heap_ws == nullptr: both heaps of the query live in LDS (3 * ef items); otherwise in HBM scratch
-// (large ef: 3 * ef * 8 bytes per query would leave one or two waves per CU)
+// (large ef: 3 * ef * 8 bytes per query would leave one or two waves per CU).
+// PQ = false: nodes scored from their fp32 rows (hnsw.KNNSearch).  PQ = true: from their PQ codes with the
+// query's distance table `luts` (ComputeAsymmetricDistance order), the candidate stage of the
+// graph -> PQ -> exact-rerank pipeline.
+template <bool PQ>
 __global__ __launch_bounds__(64) void hnsw_search_kernel(
     const float *__restrict__ base, int64_t n, int dim, int metric, const uint32_t *__restrict__ l0,
     int m0, int max_level, int m, const uint32_t *__restrict__ slots, const uint32_t *__restrict__ adj,
-    const int64_t *__restrict__ level_off, uint32_t entry, const float *__restrict__ queries, int k, int ef,
+    const int64_t *__restrict__ level_off, uint32_t entry, const float *__restrict__ queries,
+    const uint8_t *__restrict__ pq_rows, int pq_m, const float *__restrict__ luts, int k, int ef,
     uint32_t *__restrict__ visited_ws, int64_t vis_words, HItem *__restrict__ heap_ws,
     uint32_t *__restrict__ ids, float *__restrict__ scores, vg_search_stats *__restrict__ stats)
 {
@@ -40,27 +46,36 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(
     float *nb_bnd = nb_pair + 64;
     HItem *cand = heap_ws ? heap_ws + q * 3 * ef : reinterpret_cast<HItem *>(nb_bnd + 64);
     HItem *res = cand + 2 * ef;
-    const Sub16 sub = Sub16::make(lane);
-    const float *qv = queries + q * dim;
     uint32_t *vis = visited_ws + q * vis_words;
+    typename std::conditional<PQ, PqScorer, F32Scorer>::type sc;
+    if constexpr (PQ) {
+        sc.rows = pq_rows;
+        sc.lut = luts + q * static_cast<int64_t>(pq_m) * 256;
+        sc.m = pq_m;
+    } else {
+        sc.base = base;
+        sc.qv = queries + q * dim;
+        sc.dim = dim;
+        sc.metric = metric;
+        sc.sub = Sub16::make(lane);
+    }
 
     // ---- greedySearch through the upper layers --------------------------------------------------
     uint32_t cur = entry;
-    float cur_d = hnsw_node_dist(base, dim, metric, qv, cur, sub);
+    float cur_d = sc.one(cur);
     for (int level = max_level; level > 0; level--) {
         auto row_of = [&](uint32_t node) -> const uint32_t * {
             const uint32_t slot = slots[static_cast<int64_t>(level - 1) * n + node];
             return slot == VG_INVALID_ID ? nullptr : adj + (level_off[level - 1] + slot) * m;
         };
-        greedy_layer(base, dim, metric, qv, sub, lane, row_of, m, nb_pair, cur, cur_d);
+        greedy_layer(sc, lane, row_of, m, nb_pair, nb_bnd, cur, cur_d);
     }
 
     // ---- searchLayerUnfiltered on layer 0 ---------------------------------------------------------
     int res_len = 0;
     LayerStats st;
     auto row0 = [&](uint32_t node) -> const uint32_t * { return l0 + static_cast<int64_t>(node) * m0; };
-    search_layer(base, dim, metric, qv, sub, lane, row0, m0, cur, cur_d, ef, cand, res, nb_pair, nb_bnd, vis,
-                 res_len, st);
+    search_layer(sc, metric == kMetricL2, lane, row0, m0, cur, cur_d, ef, cand, res, nb_pair, nb_bnd, vis, res_len, st);
 
     // knnSearchInternal extraction (hnsw.go:1732-1751): drop the worst until k remain, then pop
     while (res_len > k) (void)heap_pop<true>(res, res_len);
@@ -371,17 +386,23 @@ VG_API int32_t vg_index_set_vamana_graph(vg_index *idx, int32_t r, const uint32_
     return VG_OK;
 }
 
-VG_API int32_t vg_search_hnsw(vg_index *idx, const float *queries, int64_t nq, int32_t k, int32_t ef,
-                              uint32_t *ids, float *scores, vg_search_stats *stats, void *stream)
+static int32_t search_hnsw_impl(vg_index *idx, bool pq, const float *queries, int64_t nq, int32_t k, int32_t ef,
+                                uint32_t *ids, float *scores, vg_search_stats *stats, void *stream)
 {
-    VG_CHECK(idx, VG_ERR_INVALID_ARG, "vg_search_hnsw: NULL index");
-    VG_CHECK(nq >= 0 && k >= 0, VG_ERR_INVALID_ARG, "vg_search_hnsw: negative nq or k");
+    const char *fn = pq ? "vg_search_hnsw_pq" : "vg_search_hnsw";
+    VG_CHECK(idx, VG_ERR_INVALID_ARG, "%s: NULL index", fn);
+    VG_CHECK(nq >= 0 && k >= 0, VG_ERR_INVALID_ARG, "%s: negative nq or k", fn);
     if (nq == 0 || k == 0) return VG_OK;
-    VG_CHECK(idx->d_hnsw_l0 && idx->d_vectors, VG_ERR_NOT_READY, "vg_search_hnsw: index needs fp32 vectors and an HNSW graph");
+    VG_CHECK(idx->d_hnsw_l0, VG_ERR_NOT_READY, "%s: index has no HNSW graph", fn);
+    VG_CHECK(pq || idx->d_vectors, VG_ERR_NOT_READY, "%s: index has no fp32 vectors", fn);
+    VG_CHECK(!pq || (idx->d_pq_rows && idx->pq), VG_ERR_NOT_READY, "%s: index has no PQ codes", fn);
+    VG_CHECK(!pq || idx->pq->k == 256, VG_ERR_UNSUPPORTED, "%s: PQ needs numCentroids == 256", fn);
+    VG_CHECK(!pq || idx->metric == VG_METRIC_L2, VG_ERR_UNSUPPORTED,
+             "%s: ComputeAsymmetricDistance is an L2 distance; metric must be L2", fn);
     VG_CHECK(idx->metric != VG_METRIC_HAMMING, VG_ERR_UNSUPPORTED, "unsupported metric for float32: Hamming");
-    VG_CHECK(queries && ids && scores, VG_ERR_INVALID_ARG, "vg_search_hnsw: NULL buffer");
+    VG_CHECK(queries && ids && scores, VG_ERR_INVALID_ARG, "%s: NULL buffer", fn);
     if (ef < k) ef = k;  // determineEF hnsw.go:1891-1894
-    VG_CHECK(ef <= vg::kHnswMaxEf, VG_ERR_UNSUPPORTED, "vg_search_hnsw: ef=%d exceeds %d", ef, vg::kHnswMaxEf);
+    VG_CHECK(ef <= vg::kHnswMaxEf, VG_ERR_UNSUPPORTED, "%s: ef=%d exceeds %d", fn, ef, vg::kHnswMaxEf);
     VG_HIP(hipSetDevice(idx->ctx->device));
     hipStream_t st = vg::pick_stream(idx->ctx, stream);
     vg::DevIn<float> q;
@@ -393,36 +414,62 @@ VG_API int32_t vg_search_hnsw(vg_index *idx, const float *queries, int64_t nq, i
     VG_TRY(osc.init(scores, static_cast<size_t>(nq) * k, st));
     VG_TRY(ost.init(stats, stats ? static_cast<size_t>(nq) : 0, st));
     const int64_t vis_words = (idx->n + 31) / 32;
+    const int pq_m = pq ? idx->pq->m : 0;
     // heaps in LDS up to kHnswLdsEf (12 KiB per query: the waves of a CU are then bounded by registers, not
     // LDS), beyond it in HBM scratch
     const bool lds_heaps = ef <= vg::kHnswLdsEf;
     const int64_t heap_bytes = lds_heaps ? 0 : static_cast<int64_t>(3) * ef * sizeof(vg::HItem);
-    int64_t chunk = std::max<int64_t>(1, (int64_t(1) << 30) / std::max<int64_t>(vis_words * 4 + heap_bytes, 1));  // <= 1 GiB of scratch
+    const int64_t lut_bytes = static_cast<int64_t>(pq_m) * 256 * sizeof(float);
+    int64_t chunk = std::max<int64_t>(1, (int64_t(1) << 30) / std::max<int64_t>(vis_words * 4 + heap_bytes + lut_bytes, 1));  // <= 1 GiB of scratch
     chunk = std::min(chunk, nq);
     vg::ArenaCall ar(idx->ctx, st);
     const int i_vis = ar.add(sizeof(uint32_t) * static_cast<size_t>(chunk) * vis_words);
     const int i_heap = ar.add(static_cast<size_t>(chunk) * heap_bytes);
+    const int i_luts = ar.add(static_cast<size_t>(chunk) * lut_bytes);
     VG_TRY(ar.commit());
     struct { uint32_t *ptr; } vis{ar.get<uint32_t>(i_vis)};
     vg::HItem *heap_ws = lds_heaps ? nullptr : ar.get<vg::HItem>(i_heap);
+    float *luts = pq ? ar.get<float>(i_luts) : nullptr;
     const size_t lds = (lds_heaps ? static_cast<size_t>(3 * ef) * sizeof(vg::HItem) : 0) + 128 * sizeof(float);
-    VG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(vg::hnsw_search_kernel),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+    const void *kfn = pq ? reinterpret_cast<const void *>(vg::hnsw_search_kernel<true>)
+                         : reinterpret_cast<const void *>(vg::hnsw_search_kernel<false>);
+    VG_HIP(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
     for (int64_t q0 = 0; q0 < nq; q0 += chunk) {
         const int64_t cnt = std::min(chunk, nq - q0);
         VG_HIP(hipMemsetAsync(vis.ptr, 0, static_cast<size_t>(cnt) * vis_words * 4, st));
-        vg::ProfScope prof(idx->ctx, "hnsw_search", st);
-        VG_LAUNCH(vg::hnsw_search_kernel, dim3(static_cast<unsigned>(cnt)), dim3(64), lds, st,
-                           idx->d_vectors, idx->n, idx->dim, idx->metric, idx->d_hnsw_l0, idx->hnsw_m0,
-                           idx->hnsw_max_level, idx->hnsw_m, idx->d_hnsw_slot, idx->d_hnsw_adj,
-                           idx->d_hnsw_level_off, idx->hnsw_entry, q.ptr + q0 * idx->dim, k, ef, vis.ptr,
-                           vis_words, heap_ws, oid.ptr + q0 * k, osc.ptr + q0 * k, ost.ptr ? ost.ptr + q0 : nullptr);
+        if (pq) VG_TRY(vg::launch_pq_build_table(idx->pq, q.ptr + q0 * idx->dim, cnt, luts, false, st));
+        vg::ProfScope prof(idx->ctx, pq ? "hnsw_search_pq" : "hnsw_search", st);
+        if (pq) {
+            VG_LAUNCH(vg::hnsw_search_kernel<true>, dim3(static_cast<unsigned>(cnt)), dim3(64), lds, st,
+                      idx->d_vectors, idx->n, idx->dim, idx->metric, idx->d_hnsw_l0, idx->hnsw_m0,
+                      idx->hnsw_max_level, idx->hnsw_m, idx->d_hnsw_slot, idx->d_hnsw_adj, idx->d_hnsw_level_off,
+                      idx->hnsw_entry, q.ptr + q0 * idx->dim, idx->d_pq_rows, pq_m, luts, k, ef, vis.ptr, vis_words,
+                      heap_ws, oid.ptr + q0 * k, osc.ptr + q0 * k, ost.ptr ? ost.ptr + q0 : nullptr);
+        } else {
+            VG_LAUNCH(vg::hnsw_search_kernel<false>, dim3(static_cast<unsigned>(cnt)), dim3(64), lds, st,
+                      idx->d_vectors, idx->n, idx->dim, idx->metric, idx->d_hnsw_l0, idx->hnsw_m0,
+                      idx->hnsw_max_level, idx->hnsw_m, idx->d_hnsw_slot, idx->d_hnsw_adj, idx->d_hnsw_level_off,
+                      idx->hnsw_entry, q.ptr + q0 * idx->dim, nullptr, 0, nullptr, k, ef, vis.ptr, vis_words,
+                      heap_ws, oid.ptr + q0 * k, osc.ptr + q0 * k, ost.ptr ? ost.ptr + q0 : nullptr);
+        }
     }
     VG_TRY(oid.finish());
     VG_TRY(osc.finish());
     VG_TRY(ost.finish());
     if (oid.on_host() || osc.on_host() || ost.on_host()) VG_HIP(hipStreamSynchronize(st));
     return VG_OK;
+}
+
+VG_API int32_t vg_search_hnsw(vg_index *idx, const float *queries, int64_t nq, int32_t k, int32_t ef,
+                              uint32_t *ids, float *scores, vg_search_stats *stats, void *stream)
+{
+    return search_hnsw_impl(idx, false, queries, nq, k, ef, ids, scores, stats, stream);
+}
+
+VG_API int32_t vg_search_hnsw_pq(vg_index *idx, const float *queries, int64_t nq, int32_t k, int32_t ef,
+                                 uint32_t *ids, float *scores, vg_search_stats *stats, void *stream)
+{
+    return search_hnsw_impl(idx, true, queries, nq, k, ef, ids, scores, stats, stream);
 }
 
 VG_API int32_t vg_search_vamana(vg_index *idx, const float *queries, int64_t nq, int32_t k, int32_t kind,

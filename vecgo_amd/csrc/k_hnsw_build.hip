@@ -23,8 +23,8 @@
 // back link costs the 64 distances between the new node and the row's members, the heuristic itself is a
 // replay over bit masks.  Every distance is the reference's kernel in its summation order (vg_exact.hpp) and
 // every candidate order is the order the reference's 4-ary heap would pop (rank by distance; on equal
-// distances the heap is replayed in LDS), so the graph equals the one oracle/vg_oracle_hnsw_build.c builds
-// by the letter of hnsw.go — bit for bit, ties included.
+// distances the heap is replayed in LDS), so the graph equals what a letter-by-letter CPU run of hnsw.go builds
+// (the test oracle) — bit for bit, ties included.
 #include <algorithm>
 #include <cmath>
 #include <vector>
@@ -89,17 +89,21 @@ __global__ __launch_bounds__(64) void build_search_kernel(BuildGraph g, int64_t 
     HItem *res = cand + 2 * ef;
     const int lane = threadIdx.x;
     const int64_t t = t0 + blockIdx.x;
-    const Sub16 sub = Sub16::make(lane);
-    const float *qv = g.base + t * g.dim;
+    F32Scorer sc;
+    sc.base = g.base;
+    sc.qv = g.base + t * g.dim;
+    sc.dim = g.dim;
+    sc.metric = g.metric;
+    sc.sub = Sub16::make(lane);
     uint32_t *vis = visited_ws + static_cast<int64_t>(blockIdx.x) * vis_words;
     const int lt = levels[t];
     const int64_t pair0 = pair_base[t] - pair_base[t0];
 
     uint32_t cur = entry;
-    float cur_d = hnsw_node_dist(g.base, g.dim, g.metric, qv, cur, sub);
+    float cur_d = sc.one(cur);
     for (int level = cur_top; level > lt; level--) {  // hnsw.go:918-934
         auto row_of = [&](uint32_t node) -> const uint32_t * { return g.ids + bg_off(g, bg_row(g, node, level)); };
-        greedy_layer(g.base, g.dim, g.metric, qv, sub, lane, row_of, g.m, nb_pair, cur, cur_d);
+        greedy_layer(sc, lane, row_of, g.m, nb_pair, nb_bnd, cur, cur_d);
     }
     const int first = lt < cur_top ? lt : cur_top;
     LayerStats st;
@@ -112,8 +116,8 @@ __global__ __launch_bounds__(64) void build_search_kernel(BuildGraph g, int64_t 
         const int deg = level == 0 ? g.m0 : g.m;
         auto row_of = [&](uint32_t node) -> const uint32_t * { return g.ids + bg_off(g, bg_row(g, node, level)); };
         int res_len = 0;
-        search_layer(g.base, g.dim, g.metric, qv, sub, lane, row_of, deg, cur, cur_d, ef, cand, res, nb_pair,
-                     nb_bnd, vis, res_len, st);
+        search_layer(sc, g.metric == kMetricL2, lane, row_of, deg, cur, cur_d, ef, cand, res, nb_pair, nb_bnd, vis,
+                     res_len, st);
         // candidates.MinItem() (queue.go:46-57): the first minimum in heap-array order
         uint64_t best = kKeyMax;
         for (int i = lane; i < res_len; i += 64) {

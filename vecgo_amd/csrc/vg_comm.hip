@@ -1,0 +1,170 @@
+// vg_comm.hip — the one exchange step of the sharded searches, behind the C ABI: per-shard top-k lists are
+// all-gathered over RCCL (xGMI inside a node) on the caller's stream and merged with the reference's
+// tie-break (searcher/candidate_queue.go:12-23), the way the engine merges per-segment candidate lists into
+// one bounded heap (engine/search.go:904-908).  A Go host can therefore shard a corpus
+// across the GPUs of a node with one process (or one OS thread) per GPU and no Python / torch in between.
+//
+// RCCL is loaded at run time (dlopen of librccl.so.1), so the library has no link-time dependency on it and
+// single-GPU users never load it.  One collective per search: ids and score bits of a rank travel as one
+// [2][nq][k] int32 block; the gathered [world][2][nq][k] image goes straight into the merge kernel.
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <mutex>
+
+#include "vg_device.hpp"
+#include "vg_internal.hpp"
+
+namespace vg {
+
+struct RcclApi {
+    void *handle = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+};
+
+static RcclApi g_rccl;
+static std::mutex g_rccl_mu;
+
+static int32_t load_rccl()
+{
+    std::lock_guard<std::mutex> lk(g_rccl_mu);
+    if (g_rccl.handle) return VG_OK;
+    void *h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    VG_CHECK(h, VG_ERR_UNSUPPORTED, "vg_comm: cannot load librccl.so.1: %s", dlerror());
+    RcclApi a;
+    a.GetUniqueId = reinterpret_cast<decltype(a.GetUniqueId)>(dlsym(h, "ncclGetUniqueId"));
+    a.CommInitRank = reinterpret_cast<decltype(a.CommInitRank)>(dlsym(h, "ncclCommInitRank"));
+    a.CommDestroy = reinterpret_cast<decltype(a.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
+    a.AllGather = reinterpret_cast<decltype(a.AllGather)>(dlsym(h, "ncclAllGather"));
+    a.GetErrorString = reinterpret_cast<decltype(a.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
+    VG_CHECK(a.GetUniqueId && a.CommInitRank && a.CommDestroy && a.AllGather && a.GetErrorString, VG_ERR_UNSUPPORTED,
+             "vg_comm: librccl.so.1 lacks a required symbol");
+    a.handle = h;
+    g_rccl = a;
+    return VG_OK;
+}
+
+#define VG_RCCL(expr)                                                                                   \
+    do {                                                                                                \
+        ncclResult_t _r = (expr);                                                                       \
+        if (_r != ncclSuccess) {                                                                        \
+            ::vg::set_error("%s failed: %s (%s:%d)", #expr, ::vg::g_rccl.GetErrorString(_r), __FILE__,   \
+                            __LINE__);                                                                  \
+            return VG_ERR_HIP;                                                                          \
+        }                                                                                               \
+    } while (0)
+
+// local (ids, scores) [nq][k] -> one [2][nq][k] int32 block
+__global__ void pack_topk_kernel(const uint32_t *__restrict__ ids, const float *__restrict__ scores, int64_t count,
+                                 uint32_t *__restrict__ block)
+{
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    block[i] = ids[i];
+    block[count + i] = __float_as_uint(scores[i]);
+}
+
+}  // namespace vg
+
+struct vg_comm {
+    vg_ctx *ctx = nullptr;
+    ncclComm_t comm = nullptr;
+    int32_t world = 1, rank = 0;
+};
+
+VG_API int32_t vg_comm_unique_id(uint8_t *id)
+{
+    VG_CHECK(id, VG_ERR_INVALID_ARG, "vg_comm_unique_id: NULL buffer");
+    VG_TRY(vg::load_rccl());
+    ncclUniqueId u;
+    VG_RCCL(vg::g_rccl.GetUniqueId(&u));
+    static_assert(sizeof(u) == VG_COMM_ID_BYTES, "ncclUniqueId size");
+    std::memcpy(id, &u, sizeof(u));
+    return VG_OK;
+}
+
+VG_API int32_t vg_comm_create(vg_ctx *ctx, int32_t world, int32_t rank, const uint8_t *id, vg_comm **out)
+{
+    VG_CHECK(ctx && out, VG_ERR_INVALID_ARG, "vg_comm_create: NULL argument");
+    VG_CHECK(world >= 1 && rank >= 0 && rank < world, VG_ERR_INVALID_ARG, "vg_comm_create: rank %d of %d", rank, world);
+    VG_CHECK(id, VG_ERR_INVALID_ARG, "vg_comm_create: NULL unique id");
+    VG_TRY(vg::load_rccl());
+    VG_HIP(hipSetDevice(ctx->device));
+    ncclUniqueId u;
+    std::memcpy(&u, id, sizeof(u));
+    vg_comm *c = new vg_comm;
+    c->ctx = ctx;
+    c->world = world;
+    c->rank = rank;
+    ncclResult_t r = vg::g_rccl.CommInitRank(&c->comm, world, u, rank);
+    if (r != ncclSuccess) {
+        vg::set_error("ncclCommInitRank failed: %s", vg::g_rccl.GetErrorString(r));
+        delete c;
+        return VG_ERR_HIP;
+    }
+    *out = c;
+    return VG_OK;
+}
+
+VG_API int32_t vg_comm_destroy(vg_comm *comm)
+{
+    if (!comm) return VG_OK;
+    if (comm->comm) (void)vg::g_rccl.CommDestroy(comm->comm);
+    delete comm;
+    return VG_OK;
+}
+
+VG_API int32_t vg_comm_info(const vg_comm *comm, int32_t *world, int32_t *rank)
+{
+    VG_CHECK(comm, VG_ERR_INVALID_ARG, "vg_comm_info: NULL communicator");
+    if (world) *world = comm->world;
+    if (rank) *rank = comm->rank;
+    return VG_OK;
+}
+
+VG_API int32_t vg_comm_all_gather(vg_comm *comm, const void *send, void *recv, int64_t bytes_per_rank, void *stream)
+{
+    VG_CHECK(comm, VG_ERR_INVALID_ARG, "vg_comm_all_gather: NULL communicator");
+    VG_CHECK(bytes_per_rank >= 0, VG_ERR_INVALID_ARG, "vg_comm_all_gather: negative size");
+    if (bytes_per_rank == 0) return VG_OK;
+    VG_CHECK(send && recv, VG_ERR_INVALID_ARG, "vg_comm_all_gather: NULL buffer");
+    VG_CHECK(vg::is_device_ptr(send) && vg::is_device_ptr(recv), VG_ERR_INVALID_ARG,
+             "vg_comm_all_gather: buffers must be device memory");
+    VG_HIP(hipSetDevice(comm->ctx->device));
+    hipStream_t st = vg::pick_stream(comm->ctx, stream);
+    VG_RCCL(vg::g_rccl.AllGather(send, recv, static_cast<size_t>(bytes_per_rank), ncclInt8, comm->comm, st));
+    return VG_OK;
+}
+
+VG_API int32_t vg_comm_all_gather_topk(vg_comm *comm, const uint32_t *local_ids, const float *local_scores,
+                                       int64_t nq, int32_t k, int32_t metric, const uint32_t *id_offsets,
+                                       uint32_t *ids, float *scores, void *stream)
+{
+    VG_CHECK(comm, VG_ERR_INVALID_ARG, "vg_comm_all_gather_topk: NULL communicator");
+    VG_CHECK(nq >= 0 && k >= 0, VG_ERR_INVALID_ARG, "vg_comm_all_gather_topk: negative count");
+    if (nq == 0 || k == 0) return VG_OK;
+    VG_CHECK(local_ids && local_scores && ids && scores, VG_ERR_INVALID_ARG, "vg_comm_all_gather_topk: NULL buffer");
+    vg_ctx *ctx = comm->ctx;
+    VG_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = vg::pick_stream(ctx, stream);
+    const size_t count = static_cast<size_t>(nq) * k;
+    vg::DevIn<uint32_t> li;
+    vg::DevIn<float> ls;
+    VG_TRY(li.init(local_ids, count, st));
+    VG_TRY(ls.init(local_scores, count, st));
+    vg::DevTmp<uint32_t> mine, all;
+    VG_TRY(mine.init(2 * count, st));
+    VG_TRY(all.init(2 * count * comm->world, st));
+    VG_LAUNCH(vg::pack_topk_kernel, dim3(static_cast<unsigned>((count + 255) / 256)), dim3(256), 0, st, li.ptr, ls.ptr,
+              static_cast<int64_t>(count), mine.ptr);
+    {
+        vg::ProfScope prof(ctx, "comm_all_gather", st);
+        VG_RCCL(vg::g_rccl.AllGather(mine.ptr, all.ptr, 2 * count * sizeof(uint32_t), ncclInt8, comm->comm, st));
+    }
+    return vg_merge_topk_packed(ctx, all.ptr, comm->world, nq, k, metric, id_offsets, ids, scores, stream);
+}

@@ -29,13 +29,84 @@ __device__ __forceinline__ float hnsw_node_dist(const float *__restrict__ base, 
     return metric == kMetricCos ? 0.5f * d : d;
 }
 
+// ---- node scorers ------------------------------------------------------------------------------------
+// A scorer fills nb_pair[j] (what distFunc returns) and nb_bnd[j] (what SquaredL2Bounded run to completion
+// returns) for every lane j set in `mask`, lane j holding node id_lane.
+struct F32Scorer {  // fp32 rows: 16 lanes per row, 4 rows at a time, reference summation order
+    const float *base;
+    const float *qv;
+    int dim, metric;
+    Sub16 sub;
+    static constexpr bool kBounded = true;  // SquaredL2Bounded exists for the L2 metric (hnsw.go:1353-1366)
+    __device__ __forceinline__ float one(uint32_t id) const { return hnsw_node_dist(base, dim, metric, qv, id, sub); }
+    __device__ __forceinline__ void many(uint64_t mask, uint32_t id_lane, int lane, float *nb_pair, float *nb_bnd) const
+    {
+        while (mask) {
+            const int mine = take4(mask, lane);
+            const uint32_t id = __shfl(id_lane, mine < 0 ? 0 : mine);
+            if (mine >= 0) {
+                const float *row = base + static_cast<int64_t>(id) * dim;
+                float dp, db;
+                if (metric == kMetricDot) {
+                    dp = -exact_pair16<true, kPair>(row, qv, dim, sub);
+                    db = dp;
+                } else {
+                    exact_l2_both16(row, qv, dim, sub, dp, db);
+                    if (metric == kMetricCos) dp = 0.5f * dp;
+                }
+                if ((lane & 15) == 0) {
+                    nb_pair[mine] = dp;
+                    nb_bnd[mine] = db;
+                }
+            }
+        }
+    }
+};
+
+// PQ codes: pq.ComputeAsymmetricDistance (pq.go:234-260) — the way the reference scores graph nodes from PQ
+// codes (diskann/segment.go:536-557): term(s) = the BuildDistanceTable entry of the node's code byte, summed
+// sequentially over the sub-quantizers.  One node per lane; the query's table (m * 256 floats) is in HBM/L2.
+struct PqScorer {
+    const uint8_t *rows;  // n * m code bytes
+    const float *lut;     // m * 256
+    int m;
+    static constexpr bool kBounded = false;
+    __device__ __forceinline__ float lane_score(uint32_t id) const
+    {
+        const uint8_t *code = rows + static_cast<int64_t>(id) * m;
+        float distance = 0.0f;
+        int s0 = 0;
+        if ((m & 15) == 0) {
+            for (; s0 < m; s0 += 16) {
+                const uint4 c = *reinterpret_cast<const uint4 *>(code + s0);
+                const uint32_t w[4] = {c.x, c.y, c.z, c.w};
+                float t[16];
+#pragma unroll
+                for (int u = 0; u < 16; u++) t[u] = lut[(s0 + u) * 256 + ((w[u >> 2] >> (8 * (u & 3))) & 0xFFu)];
+#pragma unroll
+                for (int u = 0; u < 16; u++) distance = distance + t[u];
+            }
+        }
+        for (int s = s0; s < m; s++) distance = distance + lut[s * 256 + code[s]];
+        return distance;
+    }
+    __device__ __forceinline__ float one(uint32_t id) const { return lane_score(id); }
+    __device__ __forceinline__ void many(uint64_t mask, uint32_t id_lane, int lane, float *nb_pair, float *nb_bnd) const
+    {
+        if ((mask >> lane) & 1) {
+            const float d = lane_score(id_lane);
+            nb_pair[lane] = d;
+            nb_bnd[lane] = d;
+        }
+    }
+};
+
 // greedy descent on one layer: repeat { for each neighbour in list order: if nextDist < currDist take it }
 // until a pass changes nothing.  row_of(node) -> the node's list on this layer (deg ids, 0xFFFFFFFF ends
 // it) or nullptr.  nb_pair: 64 floats of LDS.
-template <typename RowFn>
-__device__ __forceinline__ void greedy_layer(const float *__restrict__ base, int dim, int metric,
-                                             const float *__restrict__ qv, Sub16 sub, int lane, RowFn row_of,
-                                             int deg, float *nb_pair, uint32_t &cur, float &cur_d)
+template <typename Scorer, typename RowFn>
+__device__ __forceinline__ void greedy_layer(const Scorer &sc, int lane, RowFn row_of, int deg, float *nb_pair,
+                                             float *nb_bnd, uint32_t &cur, float &cur_d)
 {
     bool changed = true;
     while (changed) {
@@ -46,14 +117,7 @@ __device__ __forceinline__ void greedy_layer(const float *__restrict__ base, int
         const uint64_t inval = __ballot(id_lane == VG_INVALID_ID);
         const int count = inval ? __builtin_ctzll(inval) : 64;
         uint64_t mask = count >= 64 ? ~0ull : ((1ull << count) - 1);
-        while (mask) {
-            const int mine = take4(mask, lane);
-            const uint32_t id = __shfl(id_lane, mine < 0 ? 0 : mine);
-            if (mine >= 0) {
-                const float d = hnsw_node_dist(base, dim, metric, qv, id, sub);
-                if ((lane & 15) == 0) nb_pair[mine] = d;
-            }
-        }
+        sc.many(mask, id_lane, lane, nb_pair, nb_bnd);
         __syncthreads();
         // sequential `if nextDist < currDist` over the list == first strict minimum
         float best_d = cur_d;
@@ -74,10 +138,9 @@ __device__ __forceinline__ void greedy_layer(const float *__restrict__ base, int
 
 // searchLayerUnfiltered from (ep, ep_d).  `vis`: this wave's visited bitmap, already clear.  On return
 // res[0..res_len) is the results max-heap exactly as the reference's search leaves it.
-template <typename RowFn>
-__device__ __forceinline__ void search_layer(const float *__restrict__ base, int dim, int metric,
-                                             const float *__restrict__ qv, Sub16 sub, int lane, RowFn row_of,
-                                             int deg, uint32_t ep, float ep_d, int ef, HItem *cand, HItem *res,
+template <typename Scorer, typename RowFn>
+__device__ __forceinline__ void search_layer(const Scorer &sc, bool l2_metric, int lane, RowFn row_of, int deg,
+                                             uint32_t ep, float ep_d, int ef, HItem *cand, HItem *res,
                                              float *nb_pair, float *nb_bnd, uint32_t *vis, int &res_len_out,
                                              LayerStats &st)
 {
@@ -85,7 +148,7 @@ __device__ __forceinline__ void search_layer(const float *__restrict__ base, int
     if (lane == 0) atomicOr(&vis[ep >> 5], 1u << (ep & 31));
     heap_push<false>(cand, cand_len, HItem{ep, ep_d});
     heap_push<true>(res, res_len, HItem{ep, ep_d});
-    const bool use_sc = metric == kMetricL2;
+    const bool use_sc = Scorer::kBounded && l2_metric;
     int cap = ef * 2;
     int stagnant = 0;
     float last_best = 3.40282346638528859811704183484516925440e+38f;
@@ -123,26 +186,7 @@ __device__ __forceinline__ void search_layer(const float *__restrict__ base, int
         }
         const uint64_t newmask = __ballot(fresh);
         st.visited += __popcll(newmask);
-        uint64_t mask = newmask;
-        while (mask) {
-            const int mine = take4(mask, lane);
-            const uint32_t id = __shfl(id_lane, mine < 0 ? 0 : mine);
-            if (mine >= 0) {
-                const float *row = base + static_cast<int64_t>(id) * dim;
-                float dp, db;
-                if (metric == kMetricDot) {
-                    dp = -exact_pair16<true, kPair>(row, qv, dim, sub);
-                    db = dp;
-                } else {
-                    exact_l2_both16(row, qv, dim, sub, dp, db);
-                    if (metric == kMetricCos) dp = 0.5f * dp;
-                }
-                if ((lane & 15) == 0) {
-                    nb_pair[mine] = dp;
-                    nb_bnd[mine] = db;
-                }
-            }
-        }
+        sc.many(newmask, id_lane, lane, nb_pair, nb_bnd);
         __syncthreads();
         bool has_bound = res_len >= ef;
         float bound = has_bound ? res[0].dist : 0.0f;

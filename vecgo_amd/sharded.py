@@ -35,63 +35,87 @@ def _shard_offsets(bounds: Sequence[int], world: int, device):
 
 
 def sharded_search(local_search: Callable, merge: Callable, queries, k: int, bounds: Sequence[int],
-                   group=None):
-    """local_search(queries, k) -> (ids[nq,k] int32 bit-pattern of uint32, LOCAL row ids;
-    scores[nq,k] f32) on this rank's shard.  merge(ids[world,nq,k], scores[world,nq,k], k,
-    offsets[world]) -> (ids[nq,k], scores[nq,k]) global.  Returns the merged global result."""
+                   group=None, comm=None, metric=0, stream=None):
+    """local_search(queries, k, out=(ids, scores)) -> (ids[nq,k] int32 bit-pattern of uint32, LOCAL row ids;
+    scores[nq,k] f32) on this rank's shard.  merge(packed[world,2,nq,k], k, offsets[world]) -> (ids[nq,k],
+    scores[nq,k]) global.  ONE collective per search: ids and the scores' bit patterns of a rank are one
+    [2, nq, k] int32 block, written in place by the local search; the gathered [world, 2, nq, k] image goes to
+    the merge kernel as it lies (vg_merge_topk_packed).  comm = a vecgo_amd.Comm: the exchange runs through the
+    C ABI (direct ncclAllGather); otherwise torch.distributed (RCCL on GPUs, gloo in the CPU tests)."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
-    ids, scores = local_search(queries, k)
+    nq = queries.shape[0]
+    if comm is not None:
+        ids, scores = local_search(queries, k, None)
+        return comm.all_gather_topk(ids, scores, k, metric=metric, id_offsets=_shard_offsets(bounds, world, ids.device),
+                                    stream=stream)
+    dev = queries.device if isinstance(queries, torch.Tensor) else "cpu"
+    mine = torch.empty((2, nq, k), dtype=torch.int32, device=dev)
+    out = local_search(queries, k, (mine[0], mine[1].view(torch.float32)))
+    if out[0].data_ptr() != mine.data_ptr():   # a local search that does not take `out`
+        mine[0].copy_(out[0].view(torch.int32))
+        mine[1].copy_(out[1].view(torch.int32))
     if world == 1:
-        return merge(ids.unsqueeze(0), scores.unsqueeze(0), k, _shard_offsets(bounds, 1, ids.device))
-    nq = ids.shape[0]
-    # ONE collective per search: ids and the scores' bit patterns travel in the same int32 buffer
-    # ([2, nq, k] per rank); gathered layout = concatenation along dim 0 (accepted by RCCL and gloo)
-    mine = torch.stack((ids.contiguous().view(torch.int32), scores.contiguous().view(torch.int32)))
-    gathered = torch.empty((world * 2 * nq, k), dtype=torch.int32, device=ids.device)
+        return merge(mine.view(1, 2, nq, k), k, _shard_offsets(bounds, 1, dev))
+    gathered = torch.empty((world * 2 * nq, k), dtype=torch.int32, device=dev)
     dist.all_gather_into_tensor(gathered, mine.view(2 * nq, k), group=group)
-    gathered = gathered.view(world, 2, nq, k)
-    all_ids = gathered[:, 0].contiguous().view(ids.dtype)
-    all_scores = gathered[:, 1].contiguous().view(torch.float32)
-    return merge(all_ids, all_scores, k, _shard_offsets(bounds, world, ids.device))
+    return merge(gathered.view(world, 2, nq, k), k, _shard_offsets(bounds, world, dev))
+
+
+def make_comm(ctx, group=None):
+    """A vecgo_amd.Comm spanning the process group: rank 0's id travels over torch.distributed's store.  Returns
+    None (callers fall back to torch.distributed collectives) when the world is 1, the backend is not RCCL, or
+    any rank failed to join."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1 or dist.get_backend(group) != "nccl":
+        return None
+    from . import api
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    box = [None]
+    if rank == 0:
+        try:
+            box[0] = api.Comm.unique_id()
+        except Exception:
+            box[0] = None
+    dist.broadcast_object_list(box, src=0, group=group)
+    if box[0] is None:
+        return None
+    comm, ok = None, 1
+    try:
+        comm = api.Comm(ctx, world, rank, box[0])
+    except Exception:
+        ok = 0
+    flag = torch.tensor([ok], dtype=torch.int32, device=torch.device("cuda", torch.cuda.current_device()))
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+    if int(flag.item()) == 0:
+        if comm is not None:
+            comm.close()
+        return None
+    return comm
 
 
 class ShardedFlatIndex:
     """Exact brute force over a row-sharded corpus (BASELINE config 2 at N GPUs)."""
 
-    def __init__(self, ctx, local_rows, dim: int, bounds: Sequence[int], metric=0, group=None):
+    def __init__(self, ctx, local_rows, dim: int, bounds: Sequence[int], metric=0, group=None, comm=None):
         from . import api
         self._api = api
-        self.ctx, self.dim, self.bounds, self.metric, self.group = ctx, dim, list(bounds), metric, group
+        self.ctx, self.dim, self.bounds, self.metric, self.group, self.comm = ctx, dim, list(bounds), metric, group, comm
         n_local = local_rows.shape[0]
         self.index = api.Index(ctx, n_local, dim, api.Metric(metric))
         self.index.set_vectors(local_rows)
 
     def search(self, queries, k: int, stream=None):
-        def local(q, kk):
-            return self.index.search_flat(q, kk, stream=stream)
+        def local(q, kk, out):
+            return self.index.search_flat(q, kk, out=out, stream=stream)
 
-        def merge(ids, scores, kk, off):
-            return self._api.merge_topk(self.ctx, ids, scores, kk, metric=self.metric, id_offsets=off,
-                                        stream=stream)
-        return sharded_search(local, merge, queries, k, self.bounds, self.group)
-
-
-def assemble_codebooks(gathered_cb, gathered_scales, gathered_offsets, bounds: Sequence[int], per_sub: int):
-    """gathered_*[r] = full-size arrays of rank r in which only the sub-quantizers
-    [bounds[r], bounds[r+1]) are meaningful; returns the arrays with every range taken from its
-    owner.  gathered_cb: [world, m*per_sub] int8; gathered_scales/offsets: [world, m] float32."""
-    cb = gathered_cb[0].clone()
-    sc = gathered_scales[0].clone()
-    of = gathered_offsets[0].clone()
-    for r in range(1, len(bounds) - 1):
-        lo, hi = bounds[r], bounds[r + 1]
-        cb[lo * per_sub:hi * per_sub] = gathered_cb[r][lo * per_sub:hi * per_sub]
-        sc[lo:hi] = gathered_scales[r][lo:hi]
-        of[lo:hi] = gathered_offsets[r][lo:hi]
-    return cb, sc, of
+        def merge(packed, kk, off):
+            lists, _, nq, _ = packed.shape
+            return self._api.merge_topk_packed(self.ctx, packed, lists, nq, kk, metric=self.metric, id_offsets=off,
+                                               stream=stream)
+        return sharded_search(local, merge, queries, k, self.bounds, self.group, comm=self.comm, metric=self.metric,
+                              stream=stream)
 
 
-def train_pq_sharded(pq, vectors, iters: int = 20, seed: int = 1, group=None, device=None, stream=None):
+def train_pq_sharded(pq, vectors, iters: int = 20, seed: int = 1, group=None, device=None, stream=None, comm=None):
     """PQ training partitioned by sub-quantizer (BASELINE configs[4]; pq.go:83-138 runs the m
     k-means problems independently).  Every rank holds the same training sample, trains
     m/world sub-quantizers, then ONE all-gather of codebooks + scales + offsets (m*K*sd + 8m
@@ -109,37 +133,54 @@ def train_pq_sharded(pq, vectors, iters: int = 20, seed: int = 1, group=None, de
         pq.set_codebooks(cb, sc, of)
         return
     cb_l, sc_l, of_l = pq.codebooks_range(lo, hi - lo)
-    dev = device if device is not None else (vectors.device if isinstance(vectors, torch.Tensor) else "cpu")
-    cb = torch.zeros(m * per, dtype=torch.int8, device=dev)
-    sc = torch.zeros(m, dtype=torch.float32, device=dev)
-    of = torch.zeros(m, dtype=torch.float32, device=dev)
-    cb[lo * per:hi * per] = torch.from_numpy(cb_l).to(dev)
-    sc[lo:hi] = torch.from_numpy(sc_l).to(dev)
-    of[lo:hi] = torch.from_numpy(of_l).to(dev)
-    g_cb = torch.empty((world * m * per,), dtype=torch.int8, device=dev)
-    g_sc = torch.empty((world * m,), dtype=torch.float32, device=dev)
-    g_of = torch.empty((world * m,), dtype=torch.float32, device=dev)
-    dist.all_gather_into_tensor(g_cb, cb, group=group)
-    dist.all_gather_into_tensor(g_sc, sc, group=group)
-    dist.all_gather_into_tensor(g_of, of, group=group)
-    cb, sc, of = assemble_codebooks(g_cb.view(world, -1), g_sc.view(world, -1), g_of.view(world, -1), bounds, per)
-    pq.set_codebooks(cb.cpu().numpy(), sc.cpu().numpy(), of.cpu().numpy())
+    if device is not None:
+        dev = device
+    elif isinstance(vectors, torch.Tensor):
+        dev = vectors.device
+    elif dist.get_backend(group) == "nccl":   # host training sample on a GPU rank: RCCL needs device buffers
+        dev = torch.device("cuda", torch.cuda.current_device())
+    else:
+        dev = "cpu"
+    # ONE buffer per rank: [codebooks m*per int8 | scales 4m bytes | offsets 4m bytes], own range filled in
+    import numpy as np
+    nb = m * per + 8 * m
+    host = np.zeros(nb, np.uint8)
+    host[lo * per:hi * per] = cb_l.view(np.uint8)
+    host[m * per + 4 * lo:m * per + 4 * hi] = sc_l.astype(np.float32).view(np.uint8)
+    host[m * per + 4 * m + 4 * lo:m * per + 4 * m + 4 * hi] = of_l.astype(np.float32).view(np.uint8)
+    mine = torch.from_numpy(host).to(dev)
+    gathered = torch.empty((world * nb,), dtype=torch.uint8, device=dev)
+    if comm is not None:
+        comm.all_gather_bytes(mine, gathered, stream=stream)
+    else:
+        dist.all_gather_into_tensor(gathered, mine, group=group)
+    g = gathered.view(world, nb).cpu().numpy()
+    cb = np.empty(m * per, np.int8)
+    sc = np.empty(m, np.float32)
+    of = np.empty(m, np.float32)
+    for r in range(world):
+        a_, b_ = bounds[r], bounds[r + 1]
+        cb[a_ * per:b_ * per] = g[r, a_ * per:b_ * per].view(np.int8)
+        sc[a_:b_] = g[r, m * per + 4 * a_:m * per + 4 * b_].view(np.float32)
+        of[a_:b_] = g[r, m * per + 4 * m + 4 * a_:m * per + 4 * m + 4 * b_].view(np.float32)
+    pq.set_codebooks(cb, sc, of)
 
 
 class ShardedRaBitQIndex:
     """Exhaustive RaBitQ scan over a row-sharded corpus (BASELINE configs[4]: 10M x 768 split 8 ways)."""
 
-    def __init__(self, ctx, local_codes, n_local: int, dim: int, bounds: Sequence[int], group=None):
+    def __init__(self, ctx, local_codes, n_local: int, dim: int, bounds: Sequence[int], group=None, comm=None):
         from . import api
         self._api = api
-        self.ctx, self.dim, self.bounds, self.group = ctx, dim, list(bounds), group
+        self.ctx, self.dim, self.bounds, self.group, self.comm = ctx, dim, list(bounds), group, comm
         self.index = api.Index(ctx, n_local, dim, api.Metric(0))
         self.index.set_rabitq_codes(local_codes)
 
     def search(self, queries, k: int, stream=None):
-        def local(q, kk):
-            return self.index.search_rabitq(q, kk, stream=stream)
+        def local(q, kk, out):
+            return self.index.search_rabitq(q, kk, out=out, stream=stream)
 
-        def merge(ids, scores, kk, off):
-            return self._api.merge_topk(self.ctx, ids, scores, kk, metric=0, id_offsets=off, stream=stream)
-        return sharded_search(local, merge, queries, k, self.bounds, self.group)
+        def merge(packed, kk, off):
+            lists, _, nq, _ = packed.shape
+            return self._api.merge_topk_packed(self.ctx, packed, lists, nq, kk, metric=0, id_offsets=off, stream=stream)
+        return sharded_search(local, merge, queries, k, self.bounds, self.group, comm=self.comm, metric=0, stream=stream)
