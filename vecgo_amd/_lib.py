@@ -6,11 +6,13 @@ visible, every entry point of this package raises.
 from __future__ import annotations
 
 import ctypes as C
+import os
 import re
 from pathlib import Path
 
 _PKG = Path(__file__).resolve().parent
-LIB_PATH = _PKG / "libvecgo_hip.so"
+# VECGO_HIP_LIB: another build of the same library (tools/build_variant.sh: kernel experiments)
+LIB_PATH = Path(os.environ["VECGO_HIP_LIB"]) if os.environ.get("VECGO_HIP_LIB") else _PKG / "libvecgo_hip.so"
 HEADER_PATH = _PKG.parent / "include" / "vecgo_hip.h"
 
 _lib = None

@@ -32,7 +32,20 @@
 
 namespace vg {
 
-constexpr int kAdcWaves = 8;                  // 512 threads, one workgroup per CU (LDS holds the LUT):
+// with more than two waves per SIMD the per-wave register budget is what counts: keep hipcc from hoisting
+// the byte extraction of a whole tile (96 temporaries) above the lookups it feeds
+#if defined(VG_ADC_FENCE) && VG_ADC_FENCE
+#define VG_ADC_SCHED_FENCE __builtin_amdgcn_sched_barrier(0);
+#else
+#define VG_ADC_SCHED_FENCE
+#endif
+#ifndef VG_ADC_DEAL
+#define VG_ADC_DEAL 1
+#endif
+#ifndef VG_ADC_WAVES
+#define VG_ADC_WAVES 8
+#endif
+constexpr int kAdcWaves = VG_ADC_WAVES;       // 512 threads, one workgroup per CU (LDS holds the LUT):
                                               // 2 waves/SIMD leaves each wave 256 VGPRs for deep prefetch
 constexpr int kAdcThreads = kAdcWaves * kWave;
 constexpr int kAdcSyncEvery = 2;              // iterations between candidate-buffer checks
@@ -113,7 +126,11 @@ __device__ __forceinline__ void issue_half(Vals8 &dst, const uint4 &c, const uin
     for (int i = 0; i < 8; i++) {
         const int sl = H * 8 + i;
         const uint32_t addr = (code_byte(c, sl) << 7) + rotoff[sl] + BUMP;
+#ifdef VG_ADC_PROBE_NO_LDS   // stage probe (tools/build_variant.sh): the address arithmetic without the lookup
+        dst.v[i] = __uint_as_float(addr + OFF);
+#else
         dst.v[i] = lds_read_off<OFF>(addr);
+#endif
     }
 }
 
@@ -202,34 +219,46 @@ __global__ __launch_bounds__(kAdcThreads) void pq_adc_scan_kernel(
 
     const int gfull = (GF >= 0) ? GF : (m >> 4);
     const int tail = (GF >= 0) ? 0 : (m & 15);
-    const int64_t span = t1 - t0;
-    const int iters = static_cast<int>((span + kAdcWaves - 1) / kAdcWaves);
+    // Which tiles a workgroup takes.  Several queries per pass: a contiguous slice [t0, t1), so that the blocks of
+    // an XCD re-read one slice through their L2.  One query per pass (ONCE): the tiles are dealt round-robin over
+    // the workgroups — trip `it` of workgroup s, wave w is tile (it * slices + s) * waves + w — so that at any
+    // moment the whole chip streams ONE moving window of the code array instead of `slices` distant ones (DRAM
+    // pages stay open, the stream runs at the rate of a plain sequential read).
+    constexpr bool kDealt = ONCE && VG_ADC_DEAL;
+    const int64_t tstride = kDealt ? static_cast<int64_t>(slices) * kAdcWaves : kAdcWaves;
+    const int64_t tbase = kDealt ? static_cast<int64_t>(s) * kAdcWaves : t0;
+    const int64_t tend = kDealt ? n_tiles : t1;
+    const int64_t span = tend - tbase;
+    const int iters = span > 0 ? static_cast<int>((span + tstride - 1) / tstride) : 0;
 
     // software pipeline: the next tile's 16-byte code words are in flight while this
     // tile's lookups run (GF known at compile time)
     uint4 nxt[GF > 0 ? GF : 1];
-    uint4 nxt2[GF == 6 ? 6 : 1];  // m = 96 single-query passes keep two tiles in flight per wave
+    // m = 96 single-query passes keep two tiles in flight per wave when the workgroup has 8 waves (256 VGPRs
+    // each); with more waves per SIMD the same bytes are in flight one tile ahead
+    constexpr bool kTwoAhead = GF == 6 && ONCE && kAdcWaves <= 8;
+    uint4 nxt2[kTwoAhead ? 6 : 1];
     uint32_t rotoff[16];
 #pragma unroll
     for (int sl = 0; sl < 16; sl++) rotoff[sl] = static_cast<uint32_t>(((sl + rot) & 15) * 4);
     // Prefetch loads are UNGUARDED (a guarded load makes hipcc wait vmcnt(0) at the join): past
     // the end of the slice the address is clamped to the slice's last tile and the data unused.
-    const int64_t tlast = t1 - 1;
-    if (GF > 0 && span_nonempty(t0, t1)) {
-        const int64_t tile0 = min64(t0 + wave, tlast);
+    const int64_t tlast = tend - 1;
+    if (GF > 0 && span > 0) {
+        const int64_t tile0 = min64(tbase + wave, tlast);
         const uint4 *tp0 = tiles + (tile0 * groups) * 64 + lane;
 #pragma unroll
         for (int g = 0; g < GF; g++) nxt[g] = ONCE ? load_stream(tp0 + g * 64) : tp0[g * 64];
-        if (GF == 6 && ONCE) {
-            const int64_t tile1 = min64(t0 + wave + kAdcWaves, tlast);
+        if (kTwoAhead) {
+            const int64_t tile1 = min64(tbase + wave + tstride, tlast);
             const uint4 *tp1 = tiles + (tile1 * groups) * 64 + lane;
 #pragma unroll
             for (int g = 0; g < 6; g++) nxt2[g] = load_stream(tp1 + g * 64);
         }
     }
     for (int it = 0; it < iters; it++) {
-        const int64_t tile = t0 + static_cast<int64_t>(it) * kAdcWaves + wave;
-        if (tile < t1) {
+        const int64_t tile = tbase + static_cast<int64_t>(it) * tstride + wave;
+        if (tile < tend) {
             const uint4 *tp = tiles + (tile * groups) * 64 + lane;
             float acc[16];
 #pragma unroll
@@ -238,8 +267,8 @@ __global__ __launch_bounds__(kAdcThreads) void pq_adc_scan_kernel(
                 uint4 c[6];
 #pragma unroll
                 for (int g = 0; g < 6; g++) c[g] = nxt[g];
-                if (ONCE) {  // two tiles ahead: ~96 KiB of code loads in flight per CU instead of 48
-                    const int64_t tile2 = min64(tile + 2 * kAdcWaves, tlast);
+                if (kTwoAhead) {  // two tiles ahead: ~96 KiB of code loads in flight per CU instead of 48
+                    const int64_t tile2 = min64(tile + 2 * tstride, tlast);
                     const uint4 *tn = tiles + (tile2 * groups) * 64 + lane;
 #pragma unroll
                     for (int g = 0; g < 6; g++) {
@@ -247,11 +276,18 @@ __global__ __launch_bounds__(kAdcThreads) void pq_adc_scan_kernel(
                         nxt2[g] = load_stream(tn + g * 64);
                     }
                 } else {
-                    const int64_t tile1 = min64(tile + kAdcWaves, tlast);
+                    const int64_t tile1 = min64(tile + tstride, tlast);
                     const uint4 *tn = tiles + (tile1 * groups) * 64 + lane;
 #pragma unroll
-                    for (int g = 0; g < 6; g++) nxt[g] = tn[g * 64];
+                    for (int g = 0; g < 6; g++) nxt[g] = ONCE ? load_stream(tn + g * 64) : tn[g * 64];
                 }
+#ifdef VG_ADC_PROBE_NO_HBM   // stage probe: every tile re-uses the first tile's code words (no loads in the loop)
+#pragma unroll
+                for (int g = 0; g < 6; g++) {
+                    nxt[g] = c[g];
+                    if (kTwoAhead) nxt2[g] = c[g];
+                }
+#endif
                 // two register sets ping-pong: the next 8 lookups are in flight while the
                 // previous 8 retire (same order of additions per slot: g ascending)
                 Vals8 va, vb;
@@ -259,7 +295,8 @@ __global__ __launch_bounds__(kAdcThreads) void pq_adc_scan_kernel(
 #define VG_STEP(GA, HA, GB, HB, X, Y)            \
     issue_half<GB, HB>(Y, c[GB], rotoff);        \
     lds_wait<8>(X);                              \
-    accumulate_half<HA>(acc, X);
+    accumulate_half<HA>(acc, X);                 \
+    VG_ADC_SCHED_FENCE
                 VG_STEP(0, 0, 0, 1, va, vb)
                 VG_STEP(0, 1, 1, 0, vb, va)
                 VG_STEP(1, 0, 1, 1, va, vb)
@@ -279,7 +316,7 @@ __global__ __launch_bounds__(kAdcThreads) void pq_adc_scan_kernel(
 #pragma unroll
                 for (int g = 0; g < GF; g++) c[g] = nxt[g];
                 {
-                    const int64_t tile1 = min64(tile + kAdcWaves, tlast);
+                    const int64_t tile1 = min64(tile + tstride, tlast);
                     const uint4 *tn = tiles + (tile1 * groups) * 64 + lane;
 #pragma unroll
                     for (int g = 0; g < GF; g++) nxt[g] = ONCE ? load_stream(tn + g * 64) : tn[g * 64];

@@ -109,8 +109,12 @@ struct ProfScope {
     ProfScope(vg_ctx *c, const char *name, hipStream_t s) : ctx(c), st(s)
     {
         if (!c->profiling) return;
-        if (hipEventCreate(&rec.start) != hipSuccess) return;
-        if (hipEventCreate(&rec.stop) != hipSuccess) {
+        // hipEventReleaseToDevice: the event's release is device scope.  A default event makes the kernel in front
+        // of it end with a SYSTEM-scope release (L2 write-back walk), which a kernel pays only because it is being
+        // timed: measured +6..10 us on a 160 us scan that writes 20 KB (HIP: "useful to obtain more precise
+        // timings of commands between events").
+        if (hipEventCreateWithFlags(&rec.start, hipEventReleaseToDevice) != hipSuccess) return;
+        if (hipEventCreateWithFlags(&rec.stop, hipEventReleaseToDevice) != hipSuccess) {
             (void)hipEventDestroy(rec.start);
             return;
         }
