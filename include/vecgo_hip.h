@@ -253,6 +253,32 @@ int32_t vg_find_closest_centroids(vg_ctx *ctx, const float *query, const float *
                                   int32_t k, int32_t nprobe, int32_t metric, int32_t *out, int32_t *n_out,
                                   void *stream);
 
+/* ---- BinaryQuantizer (internal/quantization/binary.go) and NormalizeL2InPlace ------------------------
+ * vg_binary_train   Train (:59-79): *threshold = float32(mean of every component, accumulated in float64).
+ *                   The reference walks one float64 accumulator over the values in order; the device adds
+ *                   float64 chunk sums, so the float32 result can differ by one ulp when the mean falls on
+ *                   a rounding boundary (never observed) — the only entry point here that is not bit-exact.
+ * vg_binary_encode  Encode / EncodeUint64Into (:86-154): bit i = (v[i] >= threshold), ceil(dim/64) little-
+ *                   endian uint64 words per vector (threshold 0 = the sign bits RaBitQ stores).
+ * vg_binary_decode  Decode (:173-188): threshold +- 0.5; code_bytes = bytes per code the caller holds
+ *                   (bits beyond it read as 0).
+ * vg_binary_hamming_batch   ComputeHammingDistance (:158-171) of one float query against n codes:
+ *                   out[i] = popcount(encode(query) xor code_i) (HammingDistance :221-239 = simd.Hamming). */
+int64_t vg_binary_code_bytes(int32_t dim);
+int32_t vg_binary_train(vg_ctx *ctx, int32_t dim, const float *vectors, int64_t n, float *threshold, void *stream);
+int32_t vg_binary_encode(vg_ctx *ctx, int32_t dim, float threshold, const float *vectors, int64_t n,
+                         uint8_t *codes, void *stream);
+int32_t vg_binary_decode(vg_ctx *ctx, int32_t dim, float threshold, const uint8_t *codes, int64_t n,
+                         int32_t code_bytes, float *out, void *stream);
+int32_t vg_binary_hamming_batch(vg_ctx *ctx, int32_t dim, float threshold, const float *query,
+                                const uint8_t *codes, int64_t n, int32_t *out, void *stream);
+/* distance.NormalizeL2InPlace (distance/distance.go:40-53) of n rows in place: norm2 = simd.Dot(v, v)
+ * (dotProductAvx512 order), inv = 1 / simd.Sqrt(norm2) (float64 sqrt rounded to float32, float32 divide),
+ * v[i] *= inv (scaleAvx512).  ok[row] (may be NULL) = 0 where the norm is zero (the row is left as it is —
+ * the reference returns false) or dim == 0, else 1.  What cosine callers run before every insert / query
+ * (engine/search.go:171-184, hnsw.go:799-818). */
+int32_t vg_normalize_l2(vg_ctx *ctx, float *vectors, int64_t n, int32_t dim, uint8_t *ok, void *stream);
+
 /* ---- searches ---------------------------------------------------------------- */
 /* Segment.Rerank (flat/segment.go:754-780, diskann/segment.go:1093-1116,
  * engine/search.go:914-965): exact distance.SquaredL2 / distance.Dot

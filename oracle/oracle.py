@@ -106,6 +106,9 @@ _sig("vgo_rabitq_code_bytes", C.c_int64, C.c_int32)
 _sig("vgo_rabitq_encode", None, _f32p, C.c_int32, _u8p)
 _sig("vgo_rabitq_distance", C.c_float, _f32p, C.c_int32, _u8p)
 _sig("vgo_binary_encode_u64", None, _f32p, C.c_int32, C.c_float, _u64p)
+_sig("vgo_binary_train", C.c_float, _f32p, C.c_int64, C.c_int32)
+_sig("vgo_binary_decode", None, _u8p, C.c_int32, C.c_int32, C.c_float, _f32p)
+_sig("vgo_normalize_l2", C.c_int32, _f32p, C.c_int32)
 _sig("vgo_kmeans_train", C.c_int, _f32p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
      C.c_uint64, _f32p)
 _sig("vgo_assign_partition", C.c_int32, _f32p, _f32p, C.c_int32, C.c_int32, C.c_int32)
@@ -336,6 +339,25 @@ def rabitq_encode_batch(vecs, dim):
 def rabitq_distance(query, code):
     q, pq_ = _f(query); c, pc = _u8(code)
     return np.float32(lib.vgo_rabitq_distance(pq_, q.size, pc))
+
+
+def binary_train(vectors, dim):
+    v, pv = _f(vectors)
+    return np.float32(lib.vgo_binary_train(pv, v.size // dim, dim))
+
+
+def binary_decode(code, dim, threshold):
+    c = np.ascontiguousarray(code, np.uint8)
+    out = np.empty(dim, np.float32)
+    lib.vgo_binary_decode(c.ctypes.data_as(_u8p), c.size, dim, threshold, out.ctypes.data_as(_f32p))
+    return out
+
+
+def normalize_l2(v):
+    """(normalized copy, ok) — distance.NormalizeL2Copy"""
+    a = np.array(v, np.float32, copy=True)
+    ok = lib.vgo_normalize_l2(a.ctypes.data_as(_f32p), a.size)
+    return a, bool(ok)
 
 
 def binary_encode_u64(v, threshold=0.0):

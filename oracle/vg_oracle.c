@@ -578,6 +578,39 @@ void vgo_rabitq_encode(const float *v, int32_t dim, uint8_t *out)
     memcpy(out + nb, &norm, 4); /* little endian f32 */
 }
 
+/* internal/quantization/binary.go:59-79 Train: one float64 accumulator over every component in order */
+float vgo_binary_train(const float *vectors, int64_t n, int32_t dim)
+{
+    double sum = 0.0;
+    int64_t count = 0;
+    for (int64_t i = 0; i < n; i++)
+        for (int j = 0; j < dim; j++) {
+            sum += (double)vectors[i * dim + j];
+            count++;
+        }
+    return count > 0 ? (float)(sum / (double)count) : 0.0f;
+}
+
+/* internal/quantization/binary.go:173-188 Decode */
+void vgo_binary_decode(const uint8_t *code, int32_t code_bytes, int32_t dim, float threshold, float *out)
+{
+    for (int i = 0; i < dim; i++) {
+        int byte = i / 8, bit = i % 8;
+        out[i] = (byte < code_bytes && (code[byte] & (1u << bit))) ? threshold + 0.5f : threshold - 0.5f;
+    }
+}
+
+/* distance/distance.go:40-53 NormalizeL2InPlace; returns 0 for an empty or zero-norm vector */
+int32_t vgo_normalize_l2(float *v, int32_t dim)
+{
+    if (dim == 0) return 0;
+    float norm2 = vgo_dot_avx512(v, v, dim);
+    if (norm2 == 0.0f) return 0;
+    float inv = 1.0f / vgo_sqrt(norm2);
+    vgo_scale(v, dim, inv);
+    return 1;
+}
+
 /* internal/quantization/binary.go:130-154 EncodeUint64Into */
 void vgo_binary_encode_u64(const float *v, int32_t dim, float threshold, uint64_t *dst)
 {

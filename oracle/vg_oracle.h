@@ -82,6 +82,9 @@ int64_t vgo_rabitq_code_bytes(int32_t dim);
 void vgo_rabitq_encode(const float *v, int32_t dim, uint8_t *out);
 float vgo_rabitq_distance(const float *query, int32_t dim, const uint8_t *code);
 void vgo_binary_encode_u64(const float *v, int32_t dim, float threshold, uint64_t *dst);
+float vgo_binary_train(const float *vectors, int64_t n, int32_t dim);
+void vgo_binary_decode(const uint8_t *code, int32_t code_bytes, int32_t dim, float threshold, float *out);
+int32_t vgo_normalize_l2(float *v, int32_t dim);
 
 /* ---- internal/kmeans -------------------------------------------------- */
 enum { VGO_METRIC_L2 = 0, VGO_METRIC_COSINE = 1, VGO_METRIC_DOT = 2, VGO_METRIC_HAMMING = 3 };

@@ -150,6 +150,82 @@ def merge_topk(ctx: Context, ids_in, scores_in, k: int, metric=0, id_offsets=Non
     return out
 
 
+class BinaryQuantizer:
+    """quantization.BinaryQuantizer (binary.go:23-262): 1 bit per dimension against a threshold."""
+
+    def __init__(self, ctx: Context, dimension: int):
+        self._lib = ctx._lib
+        self._lib.vg_binary_code_bytes.restype = C.c_int64
+        self.ctx, self.dimension = ctx, dimension
+        self.threshold, self.trained = np.float32(0.0), False
+
+    def with_threshold(self, threshold: float):
+        self.threshold, self.trained = np.float32(threshold), True
+        return self
+
+    @property
+    def words(self) -> int:
+        return (self.dimension + 63) // 64
+
+    def bytes_total(self) -> int:            # BytesTotal (binary.go:198-200)
+        return (self.dimension + 7) // 8
+
+    def train(self, vectors, stream=None):
+        n = _rows(vectors, self.dimension)
+        if n == 0:
+            raise ValueError("no vectors provided for training")
+        v, pv = _ptr(vectors, np.float32)
+        th = np.zeros(1, np.float32)
+        check(self._lib.vg_binary_train(self.ctx._h, C.c_int32(self.dimension), pv, C.c_int64(n),
+                                        C.c_void_p(th.ctypes.data), _stream_ptr(stream)))
+        self.threshold, self.trained = th[0], True
+
+    def encode(self, vectors, out=None, stream=None):
+        """[n, dim] float32 -> [n, words*8] uint8 (the uint64 words of EncodeUint64Into, little endian)."""
+        n = _rows(vectors, self.dimension)
+        v, pv = _ptr(vectors, np.float32)
+        if out is None:
+            out = _empty_like(vectors, (n, self.words * 8), np.uint8)
+        o, po = _ptr(out, np.uint8, n * self.words * 8)
+        check(self._lib.vg_binary_encode(self.ctx._h, C.c_int32(self.dimension), C.c_float(float(self.threshold)), pv,
+                                         C.c_int64(n), po, _stream_ptr(stream)))
+        return out
+
+    def decode(self, codes, out=None, stream=None):
+        c, pc = _ptr(codes, np.uint8)
+        total = c.numel() if _is_torch(c) else c.size
+        cb = c.shape[-1] if len(c.shape) > 1 else total
+        n = total // max(cb, 1)
+        if out is None:
+            out = _empty_like(codes, (n, self.dimension), np.float32)
+        o, po = _ptr(out, np.float32, n * self.dimension)
+        check(self._lib.vg_binary_decode(self.ctx._h, C.c_int32(self.dimension), C.c_float(float(self.threshold)), pc,
+                                         C.c_int64(n), C.c_int32(cb), po, _stream_ptr(stream)))
+        return out
+
+    def compute_hamming_distance(self, query, codes, out=None, stream=None):
+        """ComputeHammingDistance (binary.go:158-171) of one float query against [n, words*8] codes."""
+        c, pc = _ptr(codes, np.uint8)
+        n = (c.numel() if _is_torch(c) else c.size) // (self.words * 8)
+        q, pq_ = _ptr(query, np.float32, self.dimension)
+        if out is None:
+            out = _empty_like(codes, (n,), np.int32)
+        o, po = _ptr(out, np.int32, n)
+        check(self._lib.vg_binary_hamming_batch(self.ctx._h, C.c_int32(self.dimension), C.c_float(float(self.threshold)),
+                                                pq_, pc, C.c_int64(n), po, _stream_ptr(stream)))
+        return out
+
+
+def normalize_l2(ctx: Context, vectors, dim: int, stream=None):
+    """distance.NormalizeL2InPlace over the rows of `vectors` (in place); returns ok[n] uint8."""
+    n = _rows(vectors, dim)
+    v, pv = _ptr(vectors, np.float32)
+    ok = _empty_like(vectors, (n,), np.uint8)
+    o, po = _ptr(ok, np.uint8, n)
+    check(ctx._lib.vg_normalize_l2(ctx._h, pv, C.c_int64(n), C.c_int32(dim), po, _stream_ptr(stream)))
+    return ok
+
+
 class Comm:
     """vg_comm: the exchange step of a row-sharded search through the C ABI (direct ncclAllGather on the
     caller's stream + merge).  Rank 0 makes the id (Comm.unique_id()), the host distributes the bytes."""
