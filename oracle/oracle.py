@@ -143,6 +143,13 @@ _sig("vgo_hnsw_search", C.c_int32, C.POINTER(HnswGraph), _f32p, C.c_int32, C.c_i
 _sig("vgo_vamana_search", C.c_int32, C.POINTER(Vamana), _f32p, C.c_int32, _u32p, _f32p,
      C.POINTER(SearchStats))
 _i64p = C.POINTER(C.c_int64)
+_sig("vgo_opq_block_size", C.c_int32, C.c_int32, C.c_int32)
+_sig("vgo_opq_rotate", None, _f32p, C.c_int32, C.c_int32, _f32p, _f32p)
+_sig("vgo_opq_unrotate", None, _f32p, C.c_int32, C.c_int32, _f32p, _f32p)
+_sig("vgo_procrustes", None, _f32p, C.c_int32, _f32p)
+_sig("vgo_opq_accumulate_m", None, _f32p, _f32p, C.c_int64, C.c_int32, C.c_int32, _f32p)
+_sig("vgo_opq_train", C.c_int32, _f32p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+     C.c_uint64, _f32p, _i8p, _f32p, _f32p)
 _sig("vgo_hnsw_level_for_id", C.c_int32, C.c_uint64, C.c_int32)
 _sig("vgo_hnsw_build_layout", C.c_int32, C.c_int64, C.c_int32, _i32p, _i64p)
 _sig("vgo_hnsw_build_batch", C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_int32)
@@ -534,6 +541,67 @@ def hnsw_select_neighbors(base, dim, cand_ids, cand_dists, m, metric=METRIC_L2):
     return out[:k]
 
 
+class OptimizedProductQuantizer:
+    """quantization.OptimizedProductQuantizer (opq.go): block-diagonal rotation + ProductQuantizer."""
+
+    def __init__(self, dim, m, k=256, num_iterations=2):
+        self.dim, self.m, self.k, self.num_iterations = dim, m, k, num_iterations
+        self.block = int(lib.vgo_opq_block_size(dim, m))
+        self.nblocks = dim // self.block
+        self.rotations = np.tile(np.eye(self.block, dtype=np.float32), (self.nblocks, 1, 1))
+        self.pq = ProductQuantizer(dim, m, k)
+        self.trained = False
+
+    def train(self, vectors, pq_iters=20, seed=1):
+        v, pv = _f(vectors)
+        n = v.size // self.dim
+        sd = self.dim // self.m
+        cb = np.zeros(self.m * self.k * sd, np.int8); sc = np.zeros(self.m, np.float32); of = np.zeros(self.m, np.float32)
+        rot = np.zeros((self.nblocks, self.block, self.block), np.float32)
+        r = lib.vgo_opq_train(pv, n, self.dim, self.m, self.k, self.num_iterations, pq_iters, seed,
+                              rot.ctypes.data_as(_f32p), cb.ctypes.data_as(_i8p), sc.ctypes.data_as(_f32p),
+                              of.ctypes.data_as(_f32p))
+        if r != 0:
+            raise ValueError("vgo_opq_train failed")
+        self.rotations = rot
+        self.pq.set_codebooks(cb, sc, of)
+        self.trained = True
+
+    def rotate(self, vec):
+        v, pv = _f(vec)
+        out = np.empty(self.dim, np.float32)
+        lib.vgo_opq_rotate(self.rotations.ctypes.data_as(_f32p), self.dim, self.block, pv, out.ctypes.data_as(_f32p))
+        return out
+
+    def encode(self, vec):
+        return self.pq.encode(self.rotate(vec))
+
+    def decode(self, codes):
+        r = np.ascontiguousarray(self.pq.decode(codes), np.float32)
+        out = np.empty(self.dim, np.float32)
+        lib.vgo_opq_unrotate(self.rotations.ctypes.data_as(_f32p), self.dim, self.block, r.ctypes.data_as(_f32p),
+                             out.ctypes.data_as(_f32p))
+        return out
+
+    def asym_distance(self, query, codes):
+        return self.pq.asym_distance(self.rotate(query), codes)
+
+
+def procrustes(m_matrix):
+    m = np.array(m_matrix, np.float32, copy=True)
+    n = m.shape[0]
+    r = np.empty((n, n), np.float32)
+    lib.vgo_procrustes(m.ctypes.data_as(_f32p), n, r.ctypes.data_as(_f32p))
+    return r
+
+
+def opq_accumulate_m(x, y, dim, block):
+    a, pa = _f(x); b, pb = _f(y)
+    out = np.empty((dim // block, block, block), np.float32)
+    lib.vgo_opq_accumulate_m(pa, pb, a.size // dim, dim, block, out.ctypes.data_as(_f32p))
+    return out
+
+
 def hnsw_layout(n, m):
     """levels[n] of ApplyInsert's ids (layerForApplyInsert hnsw.go:2103-2116), rows per upper level, top level."""
     levels = np.empty(n, np.int32)
@@ -649,17 +717,20 @@ class VamanaIndex:
         self.pq = pq
         self.codes = None if codes is None else np.ascontiguousarray(codes, np.uint8)
 
+    def _c(self):
+        self._pqc = self.pq._c() if self.pq is not None else None
+        return Vamana(self.n, self.dim, self.r, self.graph.ctypes.data_as(_u32p), self.entry_point,
+                      self.kind, self.metric,
+                      self.base.ctypes.data_as(_f32p) if self.base is not None else None,
+                      C.pointer(self._pqc) if self._pqc is not None else None,
+                      self.codes.ctypes.data_as(_u8p) if self.codes is not None else None,
+                      self.int4_table.ctypes.data_as(_f32p) if self.int4_table is not None else None)
+
     def search(self, query, k):
         q, pq_ = _f(query)
         ids = np.empty(max(k, 1), np.uint32); sc = np.empty(max(k, 1), np.float32)
         st = SearchStats()
-        pqc = self.pq._c() if self.pq is not None else None
-        v = Vamana(self.n, self.dim, self.r, self.graph.ctypes.data_as(_u32p), self.entry_point,
-                   self.kind, self.metric,
-                   self.base.ctypes.data_as(_f32p) if self.base is not None else None,
-                   C.pointer(pqc) if pqc is not None else None,
-                   self.codes.ctypes.data_as(_u8p) if self.codes is not None else None,
-                   self.int4_table.ctypes.data_as(_f32p) if self.int4_table is not None else None)
+        v = self._c()
         r = lib.vgo_vamana_search(C.byref(v), pq_, k, ids.ctypes.data_as(_u32p),
                                   sc.ctypes.data_as(_f32p), C.byref(st))
         return ids[:r], sc[:r], st
@@ -833,7 +904,7 @@ class Ref:
 
 
 # ---- timed CPU baseline (oracle/vg_cpu_bench.c): C threads, one query per thread ------------------------
-BENCH_FLAT, BENCH_HNSW, BENCH_ADC, BENCH_RABITQ, BENCH_VAMANA = 0, 1, 2, 3, 4
+BENCH_FLAT, BENCH_HNSW, BENCH_ADC, BENCH_RABITQ, BENCH_VAMANA, BENCH_SQ8 = 0, 1, 2, 3, 4, 5
 
 
 class KernelHooks(C.Structure):
@@ -845,7 +916,7 @@ class BenchJob(C.Structure):
     _fields_ = [("kind", C.c_int32), ("base", _f32p), ("n", C.c_int64), ("dim", C.c_int32), ("metric", C.c_int32),
                 ("hnsw", C.POINTER(HnswGraph)), ("vamana", C.POINTER(Vamana)), ("pq", C.POINTER(PQ)),
                 ("codes", _u8p), ("queries", _f32p), ("nq", C.c_int64), ("k", C.c_int32), ("ef", C.c_int32),
-                ("ids", _u32p), ("dist_comps", _i64p)]
+                ("ids", _u32p), ("dist_comps", _i64p), ("scores", _f32p), ("sq_mins", _f32p), ("sq_inv_scales", _f32p)]
 
 
 _sig("vgo_set_kernel_hooks", None, C.POINTER(KernelHooks))
@@ -899,8 +970,11 @@ class InterleavedCopy:
 
 
 def bench_run(kind, queries, k, threads, budget_s, base=None, dim=None, metric=METRIC_L2, hnsw: "HnswIndex" = None,
-              ef=0, pq: "ProductQuantizer" = None, codes=None, n=None, vamana: "VamanaIndex" = None, want_ids=False):
-    """One query per C thread for ~budget_s seconds.  Returns dict(queries, seconds, qps, ids, dist_comps)."""
+              ef=0, pq: "ProductQuantizer" = None, codes=None, n=None, vamana: "VamanaIndex" = None, want_ids=False,
+              sq_mins=None, sq_inv_scales=None):
+    """One query per C thread for ~budget_s seconds (budget 0: every thread runs exactly one query).  Returns
+    dict(queries, seconds, qps, ids, scores, dist_comps); ids / scores / dist_comps cover the first pass over the
+    queries (rows a thread did not reach keep 0xFFFFFFFF / -1)."""
     q = np.ascontiguousarray(queries, np.float32)
     nq, d = q.shape
     job = BenchJob()
@@ -924,11 +998,35 @@ def bench_run(kind, queries, k, threads, budget_s, base=None, dim=None, metric=M
     if codes is not None:
         cd = np.ascontiguousarray(codes, np.uint8); keep.append(cd)
         job.codes = cd.ctypes.data_as(_u8p)
+    if vamana is not None:
+        vc = vamana._c(); keep.append(vc)
+        job.vamana = C.pointer(vc)
+    if sq_mins is not None:
+        mn = np.ascontiguousarray(sq_mins, np.float32); iv = np.ascontiguousarray(sq_inv_scales, np.float32)
+        keep += [mn, iv]
+        job.sq_mins, job.sq_inv_scales = mn.ctypes.data_as(_f32p), iv.ctypes.data_as(_f32p)
     ids = np.full((nq, k), 0xFFFFFFFF, np.uint32) if want_ids else None
+    scs = np.zeros((nq, k), np.float32) if want_ids else None
     dc = np.full(nq, -1, np.int64) if want_ids else None
     if want_ids:
         job.ids = ids.ctypes.data_as(_u32p)
+        job.scores = scs.ctypes.data_as(_f32p)
         job.dist_comps = dc.ctypes.data_as(_i64p)
     secs = C.c_double(0)
     done = lib.vgo_bench_run(C.byref(job), threads, budget_s, C.byref(secs))
-    return dict(queries=int(done), seconds=float(secs.value), qps=done / max(secs.value, 1e-9), ids=ids, dist_comps=dc)
+    return dict(queries=int(done), seconds=float(secs.value), qps=done / max(secs.value, 1e-9), ids=ids, scores=scs,
+                dist_comps=dc)
+
+
+def replay(kind, queries, k, **kw):
+    """Whole queries through the oracle's loops, one C thread per query, the reference's compiled kernels when
+    oracle/_ref is present (bit-identical to the scalar restatement, tests/test_oracle_golden.py): what the
+    full-size parity tests use to replay a few queries over 1M..10M rows in seconds.  Returns (ids, scores)."""
+    q = np.ascontiguousarray(queries, np.float32)
+    use_reference_kernels(True)
+    try:
+        r = bench_run(kind, q, k, q.shape[0], 0.0, want_ids=True, **kw)
+    finally:
+        use_reference_kernels(False)
+    assert (r["dist_comps"] >= 0).all()
+    return r["ids"], r["scores"]

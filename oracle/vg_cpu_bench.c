@@ -90,7 +90,7 @@ void vgo_bench_free(void *p, size_t bytes)
 }
 
 /* ---- one query per thread until the deadline ------------------------------------------------------- */
-enum { VGO_BENCH_FLAT = 0, VGO_BENCH_HNSW = 1, VGO_BENCH_ADC = 2, VGO_BENCH_RABITQ = 3, VGO_BENCH_VAMANA = 4 };
+enum { VGO_BENCH_FLAT = 0, VGO_BENCH_HNSW = 1, VGO_BENCH_ADC = 2, VGO_BENCH_RABITQ = 3, VGO_BENCH_VAMANA = 4, VGO_BENCH_SQ8 = 5 };
 
 typedef struct {
     int32_t kind;
@@ -109,6 +109,8 @@ typedef struct {
     /* outputs of the first pass over the queries (may be NULL): ids[nq*k] */
     uint32_t *ids;
     int64_t *dist_comps; /* [nq] HNSW / Vamana: DistanceComputations */
+    float *scores;       /* [nq*k] next to ids (may be NULL) */
+    const float *sq_mins, *sq_inv_scales; /* SQ8 scan */
 } vgo_bench_job;
 
 typedef struct {
@@ -139,6 +141,9 @@ static void run_one(const vgo_bench_job *j, int64_t qi, uint32_t *ids, float *sc
     case VGO_BENCH_VAMANA:
         r = vgo_vamana_search(j->vamana, q, j->k, ids, scores, &st);
         break;
+    case VGO_BENCH_SQ8:
+        r = vgo_flat_search_sq8(j->codes, j->n, j->dim, j->sq_mins, j->sq_inv_scales, q, j->k, ids, scores);
+        break;
     }
     for (int i = r; i < j->k; i++) ids[i] = 0xFFFFFFFFu;
     if (j->dist_comps) j->dist_comps[qi] = st.distance_computations;
@@ -160,7 +165,8 @@ static void *bench_worker(void *p)
             memset(visited, 0, sizeof(uint32_t) * (size_t)j->hnsw->n);
             epoch = 1;
         }
-        run_one(j, qi, (first_pass && j->ids) ? j->ids + qi * j->k : ids, scores, visited, epoch);
+        const int keep = first_pass && j->ids;
+        run_one(j, qi, keep ? j->ids + qi * j->k : ids, (keep && j->scores) ? j->scores + qi * j->k : scores, visited, epoch);
         w->done++;
         i += w->nthreads;
         if (now_s() >= w->deadline) break;

@@ -193,6 +193,16 @@ void vgo_hnsw_search_layer(const vgo_hnsw_graph *g, const float *query, uint32_t
                            vgo_prioq *cand, vgo_prioq *res, vgo_search_stats *st);
 float vgo_hnsw_node_distance(const vgo_hnsw_graph *g, const float *query, uint32_t id);
 
+/* ---- OptimizedProductQuantizer (vg_oracle_opq.c; opq.go, svd.go) -------------------------------------- */
+int32_t vgo_opq_block_size(int32_t dim, int32_t m);
+/* rot = [dim/block][block][block] row-major */
+void vgo_opq_rotate(const float *rot, int32_t dim, int32_t block, const float *src, float *dst);
+void vgo_opq_unrotate(const float *rot, int32_t dim, int32_t block, const float *src, float *dst);
+void vgo_procrustes(float *m_matrix /* n*n, destroyed */, int32_t n, float *r_out);
+void vgo_opq_accumulate_m(const float *x, const float *y, int64_t n, int32_t dim, int32_t block, float *m_out);
+int vgo_opq_train(const float *vectors, int64_t n, int32_t dim, int32_t m, int32_t k, int32_t opq_iters,
+                  int32_t pq_iters, uint64_t seed, float *rot, int8_t *codebooks, float *scales, float *offsets);
+
 /* ---- HNSW construction (vg_oracle_hnsw_build.c) ------------------------------------------------
  * hnsw.go:713-984 insert / insertNode with the ids and levels of ApplyInsert (hnsw.go:629-684:
  * ids are the row numbers, level = layerForApplyInsert(id) hnsw.go:2103-2116), selectNeighbors

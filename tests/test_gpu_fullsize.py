@@ -8,7 +8,10 @@ GPU reported.
     (engine/search.go:904-908 fan-in), i.e. nothing depends on how rows are tiled;
   * two independent device paths agree (GEMM candidates + proof vs the exhaustive exact kernel);
   * a random sample of rows holds no row that beats the reported k-th;
-  * idempotence: the same call twice gives the same bits.
+  * idempotence: the same call twice gives the same bits;
+  * WHOLE queries replayed by the oracle over the full corpus (oracle.replay: the oracle's scan / search
+    loops, one C thread per query, the reference's compiled AVX-512 kernels when oracle/_ref is present):
+    ids and scores of two queries per scan, so a row missed anywhere in the corpus cannot pass.
 """
 import os
 
@@ -67,6 +70,11 @@ def test_flat_exact_1m_x_768(vg, ctx):
     for i in range(nq):
         want = np.array([o.l2(hq[i], rows[i, j]) for j in range(k)], np.float32)
         assert np.array_equal(bits(np_(sc)[i]), bits(want)), i
+    # (1b) two whole queries replayed by the oracle over all 1M rows
+    hbase = base.cpu().numpy()
+    rid, rsc = o.replay(o.BENCH_FLAT, hq[:2], k, base=hbase)
+    assert np.array_equal(rid, np_(ids).view(np.uint32)[:2]) and np.array_equal(bits(rsc), bits(np_(sc)[:2]))
+    del hbase
     # (2) the exhaustive exact kernel (no GEMM, no proof) gives the same bits
     os.environ["VG_FLAT_FORCE_EXACT"] = "1"
     try:
@@ -122,6 +130,9 @@ def test_pq_adc_scan_10m_x_96(vg, ctx):
         rc = codes[torch.from_numpy(hid[i]).cuda()].cpu().numpy()
         want = np.array([o.adc(table, rc[j], m) for j in range(k)], np.float32)
         assert np.array_equal(bits(np_(sc)[i]), bits(want)), i
+    # two whole queries replayed by the oracle over all 10M codes
+    rid, rsc = o.replay(o.BENCH_ADC, hq[:2], k, pq=opq, codes=codes.cpu().numpy(), n=n)
+    assert np.array_equal(rid, np_(ids).view(np.uint32)[:2]) and np.array_equal(bits(rsc), bits(np_(sc)[:2]))
     # partition property
     half = n // 2
     a = vg.Index(ctx, half, dim); a.set_pq_codes(pq, codes[:half])
@@ -160,6 +171,9 @@ def test_rabitq_scan_10m_x_768(vg, ctx):
         rc = codes[torch.from_numpy(hid[i]).cuda()].cpu().numpy()
         want = np.array([o.rabitq_distance(hq[i], rc[j]) for j in range(k)], np.float32)
         assert np.array_equal(bits(np_(sc)[i]), bits(want)), i
+    # two whole queries replayed by the oracle over all 10M codes
+    rid, rsc = o.replay(o.BENCH_RABITQ, hq[:2], k, codes=codes.cpu().numpy(), n=n, dim=dim)
+    assert np.array_equal(rid, np_(ids).view(np.uint32)[:2]) and np.array_equal(bits(rsc), bits(np_(sc)[:2]))
     half = n // 2
     a = vg.Index(ctx, half, dim); a.set_rabitq_codes(codes[:half])
     b = vg.Index(ctx, n - half, dim); b.set_rabitq_codes(codes[half:])
@@ -222,6 +236,9 @@ def test_sq8_scan_10m_x_768(vg, ctx):
         rc = codes[torch.from_numpy(hid[i]).cuda()].cpu().numpy()
         want = o.sq8u_l2_batch(hq[i], rc, mins, inv, dim)
         assert np.array_equal(bits(np_(sc)[i]), bits(want)), i
+    # two whole queries replayed by the oracle over all 10M codes
+    rid, rsc = o.replay(o.BENCH_SQ8, hq[:2], k, codes=codes.cpu().numpy(), n=n, dim=dim, sq_mins=mins, sq_inv_scales=inv)
+    assert np.array_equal(rid, np_(ids).view(np.uint32)[:2]) and np.array_equal(bits(rsc), bits(np_(sc)[:2]))
     half = n // 2
     a = vg.Index(ctx, half, dim); a.set_sq8_codes(sq, codes[:half])
     b = vg.Index(ctx, n - half, dim); b.set_sq8_codes(sq, codes[half:])
@@ -273,4 +290,92 @@ def test_partition_probed_flat_1m_x_768(vg, ctx):
     d_ids, d_sc = idx.search_flat_probed(q, k, 0, scan=idx.SCAN_F32)
     o_ids, o_sc = idx.search_flat_probed(q, k, 1, scan=idx.SCAN_F32)
     assert torch.equal(d_ids, o_ids) and torch.equal(d_sc.view(torch.int32), o_sc.view(torch.int32))
+    idx.close()
+
+
+def test_built_hnsw_graph_1m_x_768(vg, ctx):
+    """The bench's own configuration: HNSW built by vg_hnsw_build (M = 32, M0 = 64, EF = 300) on 1M x 768, then
+    searched at ef = 128 (heaps in LDS) and ef = 1024 (heaps in HBM scratch), on fp32 rows and on PQ codes, and
+    walked as a Vamana graph (layer 0, R = 64) with PQ and RaBitQ scoring.  Whole queries are replayed by the
+    oracle over the same graph: ids and scores bit-exact."""
+    n, dim, k = 1_000_000, 768, 10
+    g = torch.Generator(device="cuda"); g.manual_seed(20260130)
+    base = torch.randn(n, dim, device="cuda", generator=g)
+    q = torch.randn(16, dim, device="cuda", generator=g)
+    idx = vg.Index(ctx, n, dim); idx.set_vectors(base)
+    idx.build_hnsw(m=32, ef_construction=300, max_batch=8192, growth_div=32)
+    l0, upper, entry = idx.get_hnsw_graph()
+    deg = (l0 != 0xFFFFFFFF).sum(1)
+    assert deg.min() >= 1 and deg.mean() > 48          # layer-0 rows fill up (M0 = 64)
+    lv = np.array([vg._lib.load().vg_hnsw_level_for_id(i, 32) for i in range(0, n, 997)])
+    assert len(upper) >= lv.max()                        # the top level is at least what the sample saw
+    hbase = base.cpu().numpy(); hq = q.cpu().numpy()
+    oidx = o.HnswIndex(hbase, dim, l0, upper, entry, m=32)
+    for ef, nrep in ((128, 4), (1024, 2)):
+        ids, sc = idx.search_hnsw(q, k, ef)
+        rid, rsc = o.replay(o.BENCH_HNSW, hq[:nrep], k, hnsw=oidx, ef=ef)
+        assert np.array_equal(rid, np_(ids).view(np.uint32)[:nrep]), ef
+        assert np.array_equal(bits(rsc), bits(np_(sc)[:nrep])), ef
+    # PQ codes: graph walk on ComputeAsymmetricDistance, and the Vamana beam over layer 0
+    pq = _train_small_pq(vg, ctx, dim, 96)
+    codes = pq.encode(base)
+    idx.set_pq_codes(pq, codes)
+    cb, s_, of_ = pq.codebooks()
+    opq = o.ProductQuantizer(dim, 96, 256); opq.set_codebooks(cb, s_, of_)
+    hcodes = codes.cpu().numpy()
+    ids, sc = idx.search_hnsw_pq(q, 64, 256)
+    opidx = o.HnswIndex(hbase, dim, l0, upper, entry, m=32, pq=opq, codes=hcodes)
+    rid, rsc = o.replay(o.BENCH_HNSW, hq[:2], 64, hnsw=opidx, ef=256)
+    assert np.array_equal(rid, np_(ids).view(np.uint32)[:2]) and np.array_equal(bits(rsc), bits(np_(sc)[:2]))
+    idx.set_vamana_graph(l0, entry)
+    ids, sc = idx.search_vamana(q, k, kind=1)
+    ov = o.VamanaIndex(l0, entry, dim, o.VAMANA_PQ, pq=opq, codes=hcodes)
+    rid, rsc = o.replay(o.BENCH_VAMANA, hq[:4], k, vamana=ov)
+    assert np.array_equal(rid, np_(ids).view(np.uint32)[:4]) and np.array_equal(bits(rsc), bits(np_(sc)[:4]))
+    rcodes = vg.RaBitQuantizer(ctx, dim).encode(base)
+    idx.set_rabitq_codes(rcodes)
+    ids, sc = idx.search_vamana(q, k, kind=2)
+    ov = o.VamanaIndex(l0, entry, dim, o.VAMANA_RABITQ, codes=rcodes.cpu().numpy())
+    rid, rsc = o.replay(o.BENCH_VAMANA, hq[:4], k, vamana=ov)
+    assert np.array_equal(rid, np_(ids).view(np.uint32)[:4]) and np.array_equal(bits(rsc), bits(np_(sc)[:4]))
+    idx.close()
+
+
+def test_vamana_10m_nodes_r64(vg, ctx):
+    """BASELINE configs[3]: Vamana + PQ (m = 96, 256 centroids) at 10M nodes, R = 64 — and the RaBitQ flavour.
+    The graph is a random 64-regular graph with holes (search parity does not depend on graph quality); the codes
+    are random bytes.  Four whole queries per flavour are replayed by the oracle: ids, scores, counters."""
+    n, dim, r, k = 10_000_000, 768, 64, 10
+    rng = np.random.default_rng(99)
+    graph = rng.integers(0, n, (n, r), dtype=np.uint32)
+    graph[rng.integers(0, n, n // 50), rng.integers(0, r, n // 50)] = 0xFFFFFFFF   # empty slots (segment.go:671-681)
+    g = torch.Generator(device="cuda"); g.manual_seed(31)
+    q = torch.randn(32, dim, device="cuda", generator=g)
+    hq = q.cpu().numpy()
+    idx = vg.Index(ctx, n, dim)
+    idx.set_vamana_graph(graph, 4242)
+    pq = _train_small_pq(vg, ctx, dim, 96)
+    codes = torch.randint(0, 256, (n, 96), dtype=torch.uint8, device="cuda", generator=g)
+    idx.set_pq_codes(pq, codes)
+    cb, s_, of_ = pq.codebooks()
+    opq = o.ProductQuantizer(dim, 96, 256); opq.set_codebooks(cb, s_, of_)
+    ids, sc, st = idx.search_vamana(q, k, kind=1, stats=True)
+    ov = o.VamanaIndex(graph, 4242, dim, o.VAMANA_PQ, pq=opq, codes=codes.cpu().numpy())
+    for i in range(4):
+        eid, esc, est = ov.search(hq[i], k)
+        assert np.array_equal(np_(ids).view(np.uint32)[i, :eid.size], eid), i
+        assert np.array_equal(bits(np_(sc)[i, :eid.size]), bits(esc)), i
+        assert (int(st[i][0]), int(st[i][1]), int(st[i][3])) == (est.nodes_visited, est.distance_computations, est.pops)
+    del codes
+    cbytes = (dim + 63) // 64 * 8 + 4
+    rcodes = torch.randint(0, 256, (n, cbytes), dtype=torch.uint8, device="cuda", generator=g)
+    rcodes[:, cbytes - 4:] = (torch.rand(n, device="cuda", generator=g) * 5 + 25).view(torch.uint8).reshape(n, 4)
+    idx.set_rabitq_codes(rcodes)
+    ids, sc, st = idx.search_vamana(q, k, kind=2, stats=True)
+    ov = o.VamanaIndex(graph, 4242, dim, o.VAMANA_RABITQ, codes=rcodes.cpu().numpy())
+    for i in range(4):
+        eid, esc, est = ov.search(hq[i], k)
+        assert np.array_equal(np_(ids).view(np.uint32)[i, :eid.size], eid), i
+        assert np.array_equal(bits(np_(sc)[i, :eid.size]), bits(esc)), i
+        assert (int(st[i][0]), int(st[i][1]), int(st[i][3])) == (est.nodes_visited, est.distance_computations, est.pops)
     idx.close()
