@@ -140,6 +140,35 @@ int32_t vg_pq_decode(vg_pq *pq, const uint8_t *codes, int64_t n, float *out, voi
 int32_t vg_pq_asymmetric_distance_batch(vg_pq *pq, const float *query, const uint8_t *codes,
                                         int64_t n, float *out, void *stream);
 
+/* ---- OptimizedProductQuantizer (internal/quantization/opq.go, svd.go) ------------------------------------
+ * A block-diagonal rotation in front of a ProductQuantizer; blocks = vg_opq_block_size (opq.go:38-58: the
+ * multiple of dim/m dividing dim nearest 32; the whole vector up to 64 dims; blocks above 64 dims are refused).
+ *   vg_opq_rotate     rotateVector (:196-215): out[b*bs+i] = simd.Dot(R_b[i], v_b), dotProductAvx512 order
+ *   vg_opq_encode     Encode (:218-231) = rotate + ProductQuantizer.Encode        -> codes[n*m]
+ *   vg_opq_decode     Decode (:234-269) = ProductQuantizer.Decode + R^T, summed left to right
+ *   vg_opq_asymmetric_distance_batch   ComputeAsymmetricDistance (:272-286): rotate the query once, then PQ's
+ *   vg_opq_train      Train (:89-193): num_iterations x { rotate all, ProductQuantizer.Train(pq_iters; the
+ *                     reference's 20) from scratch with the stream seed + iteration, M_b = sum_i x_b^T yhat_b in
+ *                     vector order, R_b = Procrustes(M_b) by one-sided Jacobi SVD (svd.go) }.  As in the reference
+ *                     the last rotations are solved after the last PQ training.  Same seeded stream as
+ *                     vg_pq_train: equals the CPU restatement bit for bit; the reference itself is unseeded.
+ *   vg_opq_pq         the inner ProductQuantizer (codebooks: vg_pq_get_codebooks / vg_pq_set_codebooks)
+ *   vg_opq_get/set_rotations   [nblocks][block][block] fp32 row-major, host memory. */
+typedef struct vg_opq vg_opq;
+int32_t vg_opq_block_size(int32_t dim, int32_t m);
+int32_t vg_opq_create(vg_ctx *ctx, int32_t dim, int32_t m, int32_t k, int32_t num_iterations, vg_opq **out);
+int32_t vg_opq_destroy(vg_opq *opq);
+vg_pq *vg_opq_pq(vg_opq *opq);
+int32_t vg_opq_is_trained(vg_opq *opq);
+int32_t vg_opq_get_rotations(vg_opq *opq, int32_t *block, int32_t *nblocks, float *rotations);
+int32_t vg_opq_set_rotations(vg_opq *opq, const float *rotations);
+int32_t vg_opq_train(vg_opq *opq, const float *vectors, int64_t n, int32_t pq_iters, uint64_t seed, void *stream);
+int32_t vg_opq_rotate(vg_opq *opq, const float *vectors, int64_t n, float *out, void *stream);
+int32_t vg_opq_encode(vg_opq *opq, const float *vectors, int64_t n, uint8_t *codes, void *stream);
+int32_t vg_opq_decode(vg_opq *opq, const uint8_t *codes, int64_t n, float *out, void *stream);
+int32_t vg_opq_asymmetric_distance_batch(vg_opq *opq, const float *query, const uint8_t *codes, int64_t n,
+                                         float *out, void *stream);
+
 /* ---- RaBitQ / binary (internal/quantization/rabitq.go, binary.go) -------------------- */
 /* BytesTotal rabitq.go:187-190: ((dim+63)/64)*8 + 4 */
 int64_t vg_rabitq_code_bytes(int32_t dim);

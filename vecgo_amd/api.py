@@ -150,6 +150,90 @@ def merge_topk(ctx: Context, ids_in, scores_in, k: int, metric=0, id_offsets=Non
     return out
 
 
+class OptimizedProductQuantizer:
+    """quantization.OptimizedProductQuantizer (opq.go): block-diagonal rotation + ProductQuantizer."""
+
+    def __init__(self, ctx: Context, dimension: int, num_subvectors: int, num_centroids: int = 256, num_iterations: int = 2):
+        self._lib = ctx._lib
+        self._lib.vg_opq_pq.restype = C.c_void_p
+        self.ctx, self.dimension, self.num_subvectors, self.num_centroids = ctx, dimension, num_subvectors, num_centroids
+        h = C.c_void_p()
+        check(self._lib.vg_opq_create(ctx._h, C.c_int32(dimension), C.c_int32(num_subvectors), C.c_int32(num_centroids),
+                                      C.c_int32(num_iterations), C.byref(h)))
+        self._h = h
+        self.pq = ProductQuantizer._borrowed(ctx, C.c_void_p(self._lib.vg_opq_pq(h)), dimension, num_subvectors, num_centroids, self)
+        b, nb = C.c_int32(), C.c_int32()
+        check(self._lib.vg_opq_get_rotations(h, C.byref(b), C.byref(nb), None))
+        self.block, self.nblocks = b.value, nb.value
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.vg_opq_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def is_trained(self) -> bool:
+        return bool(self._lib.vg_opq_is_trained(self._h))
+
+    def rotations(self):
+        r = np.empty((self.nblocks, self.block, self.block), np.float32)
+        check(self._lib.vg_opq_get_rotations(self._h, None, None, C.c_void_p(r.ctypes.data)))
+        return r
+
+    def set_rotations(self, rotations):
+        r = np.ascontiguousarray(rotations, np.float32)
+        assert r.size == self.nblocks * self.block * self.block
+        check(self._lib.vg_opq_set_rotations(self._h, C.c_void_p(r.ctypes.data)))
+
+    def train(self, vectors, pq_iters: int = 20, seed: int = 1, stream=None):
+        n = _rows(vectors, self.dimension)
+        v, pv = _ptr(vectors, np.float32)
+        check(self._lib.vg_opq_train(self._h, pv, C.c_int64(n), C.c_int32(pq_iters), C.c_uint64(seed), _stream_ptr(stream)))
+
+    def rotate(self, vectors, out=None, stream=None):
+        n = _rows(vectors, self.dimension)
+        v, pv = _ptr(vectors, np.float32)
+        if out is None:
+            out = _empty_like(vectors, (n, self.dimension), np.float32)
+        o, po = _ptr(out, np.float32, n * self.dimension)
+        check(self._lib.vg_opq_rotate(self._h, pv, C.c_int64(n), po, _stream_ptr(stream)))
+        return out
+
+    def encode(self, vectors, out=None, stream=None):
+        n = _rows(vectors, self.dimension)
+        v, pv = _ptr(vectors, np.float32)
+        if out is None:
+            out = _empty_like(vectors, (n, self.num_subvectors), np.uint8)
+        o, po = _ptr(out, np.uint8, n * self.num_subvectors)
+        check(self._lib.vg_opq_encode(self._h, pv, C.c_int64(n), po, _stream_ptr(stream)))
+        return out
+
+    def decode(self, codes, out=None, stream=None):
+        c, pc = _ptr(codes, np.uint8)
+        n = (c.numel() if _is_torch(c) else c.size) // self.num_subvectors
+        if out is None:
+            out = _empty_like(codes, (n, self.dimension), np.float32)
+        o, po = _ptr(out, np.float32, n * self.dimension)
+        check(self._lib.vg_opq_decode(self._h, pc, C.c_int64(n), po, _stream_ptr(stream)))
+        return out
+
+    def asymmetric_distance(self, query, codes, out=None, stream=None):
+        c, pc = _ptr(codes, np.uint8)
+        n = (c.numel() if _is_torch(c) else c.size) // self.num_subvectors
+        q, pq_ = _ptr(query, np.float32, self.dimension)
+        if out is None:
+            out = _empty_like(codes, (n,), np.float32)
+        o, po = _ptr(out, np.float32, n)
+        check(self._lib.vg_opq_asymmetric_distance_batch(self._h, pq_, pc, C.c_int64(n), po, _stream_ptr(stream)))
+        return out
+
+
 class BinaryQuantizer:
     """quantization.BinaryQuantizer (binary.go:23-262): 1 bit per dimension against a threshold."""
 
@@ -614,10 +698,19 @@ class ProductQuantizer:
         self.dimension, self.num_subvectors, self.num_centroids = dimension, num_subvectors, num_centroids
         self.subvector_dim = dimension // num_subvectors
 
+    @classmethod
+    def _borrowed(cls, ctx: Context, handle, dimension: int, num_subvectors: int, num_centroids: int, owner):
+        """A view of a quantizer another object owns (the inner PQ of an OptimizedProductQuantizer)."""
+        self = cls.__new__(cls)
+        self._lib, self.ctx, self._h, self._owner = ctx._lib, ctx, handle, owner
+        self.dimension, self.num_subvectors, self.num_centroids = dimension, num_subvectors, num_centroids
+        self.subvector_dim = dimension // num_subvectors
+        return self
+
     def close(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and getattr(self, "_owner", None) is None:
             self._lib.vg_pq_destroy(self._h)
-            self._h = None
+        self._h = None
 
     def __del__(self):
         try:
