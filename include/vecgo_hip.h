@@ -186,6 +186,12 @@ int32_t vg_rabitq_distance_batch(vg_ctx *ctx, int32_t dim, const float *query, c
 int32_t vg_hamming_batch(vg_ctx *ctx, const uint8_t *a, const uint8_t *codes, int64_t nbytes, int64_t n,
                          int32_t *out, void *stream);
 
+/* Test hooks (process-wide): force an alternative path so that tests can compare the paths bit for bit.
+ * Names: VG_FLAT_NO_SMALL_TILE, VG_FLAT_UNFUSED, VG_FLAT_NO_SCAN, VG_FLAT_FORCE_EXACT, VG_FLAT_NO_DMA,
+ * VG_FLAT_DEBUG, VG_PROBE_NO_GROUP, VG_ADC_BIGK_EXHAUSTIVE, VG_ADC_SKEW.  The environment variable of the same
+ * name ("1") gives the initial value, read once; the search entry points never call getenv. */
+int32_t vg_debug_set_hook(const char *name, int32_t on);
+
 /* ---- resident index ---------------------------------------------------------- */
 int32_t vg_index_create(vg_ctx *ctx, int64_t n, int32_t dim, int32_t metric, vg_index **out);
 int32_t vg_index_destroy(vg_index *idx);
@@ -482,7 +488,10 @@ int32_t vg_segment_close(vg_segment *seg);
 /* hash.CRC32C (internal/hash/crc32c.go:15-17) */
 uint32_t vg_crc32c(const void *data, int64_t size);
 
-/* per-query counters, the reference's FilterGateStats (searcher/searcher.go:114-137) */
+/* per-query counters, the reference's FilterGateStats (searcher/searcher.go:114-137).  vg_search_vamana has
+ * no short-circuit path; it reports in distance_short_circuits the candidates it could NOT push because the
+ * per-query exploration heap (min(rows, 65536) entries; the reference's is unbounded) was full — 0 in every
+ * search that followed the reference exactly. */
 typedef struct vg_search_stats {
     int64_t nodes_visited, distance_computations, distance_short_circuits, pops;
 } vg_search_stats;

@@ -7,6 +7,7 @@ import numpy as np
 import pytest
 
 from oracle import oracle as o
+from tests import hooks
 
 pytestmark = pytest.mark.gpu
 
@@ -152,11 +153,11 @@ def test_adc_big_k_proof_and_fallback(vg, ctx):
     pq, idx = _mk(vg, ctx, opq, codes, n)
     for env in (None, "1"):
         if env:
-            os.environ["VG_ADC_BIGK_EXHAUSTIVE"] = env
+            hooks.set_hook("VG_ADC_BIGK_EXHAUSTIVE", env)
         try:
             ids, scores = idx.search_pq_adc(q, k)
         finally:
-            os.environ.pop("VG_ADC_BIGK_EXHAUSTIVE", None)
+            hooks.set_hook("VG_ADC_BIGK_EXHAUSTIVE", 0)
         for qi in range(2):
             eid, esc = o.flat_search_pq(opq, codes, q[qi], k)
             assert np.array_equal(ids[qi], eid)
@@ -166,7 +167,7 @@ def test_adc_big_k_proof_and_fallback(vg, ctx):
 def test_adc_skewed_kernel_is_bit_exact_too(vg, ctx):
     """The opt-in conflict-free (A/B-skewed) m=96 scan must give the same ids and scores."""
     import os
-    os.environ["VG_ADC_SKEW"] = "1"
+    hooks.set_hook("VG_ADC_SKEW", "1")
     try:
         for n, nq in ((10000, 3), (777, 2), (64, 1), (200000, 2)):
             rng = np.random.default_rng(n)
@@ -180,7 +181,7 @@ def test_adc_skewed_kernel_is_bit_exact_too(vg, ctx):
                 assert np.array_equal(ids[qi, :eid.size], eid)
                 assert np.array_equal(bits(scores[qi, :eid.size]), bits(esc))
     finally:
-        os.environ.pop("VG_ADC_SKEW")
+        hooks.set_hook("VG_ADC_SKEW", 0)
 
 
 def test_adc_errors(vg, ctx):

@@ -6,6 +6,7 @@ import numpy as np
 import pytest
 
 from oracle import oracle as o
+from tests import hooks
 
 pytestmark = pytest.mark.gpu
 
@@ -64,14 +65,14 @@ def test_flat_fast_path_answers_random_data(vg, ctx, dim, metric, nodma):
     so this checks the counter.  Covers the LDS-DMA kernel (dim % 4 == 0, incl. a ragged K edge)
     and the register-staged one (dim % 4 != 0, or forced)."""
     if nodma:
-        os.environ["VG_FLAT_NO_DMA"] = "1"
+        hooks.set_hook("VG_FLAT_NO_DMA", "1")
     try:
         idx, _, _ = check(vg, ctx, 6000, dim, 140, 10, metric, np.random.default_rng(dim + metric))
         searched, exhaustive = idx.flat_stats()
         assert searched == 140
         assert exhaustive <= 2, exhaustive
     finally:
-        os.environ.pop("VG_FLAT_NO_DMA", None)
+        hooks.set_hook("VG_FLAT_NO_DMA", 0)
 
 
 @pytest.mark.parametrize("n,dim,nq,k,metric", [(30000, 768, 1, 10, 0), (9000, 128, 8, 32, 0), (5000, 1024, 3, 10, 2),
@@ -86,13 +87,13 @@ def test_flat_small_batch_paths_match_oracle(vg, ctx, n, dim, nq, k, metric):
     idx, base, q = check(vg, ctx, n, dim, nq, k, metric, rng)
     assert idx.flat_stats()[0] == nq and idx.flat_stats()[1] <= 1
     ids, sc = idx.search_flat(q, k)
-    os.environ["VG_FLAT_NO_SCAN"] = "1"
-    os.environ["VG_FLAT_NO_SMALL_TILE"] = "1"
+    hooks.set_hook("VG_FLAT_NO_SCAN", "1")
+    hooks.set_hook("VG_FLAT_NO_SMALL_TILE", "1")
     try:
         ids2, sc2 = idx.search_flat(q, k)   # the 128-query tile
     finally:
-        os.environ.pop("VG_FLAT_NO_SCAN")
-        os.environ.pop("VG_FLAT_NO_SMALL_TILE")
+        hooks.set_hook("VG_FLAT_NO_SCAN", 0)
+        hooks.set_hook("VG_FLAT_NO_SMALL_TILE", 0)
     assert np.array_equal(ids, ids2) and np.array_equal(bits(sc), bits(sc2))
 
 
@@ -126,23 +127,23 @@ def test_flat_duplicates_and_near_ties(vg, ctx):
 
 def test_flat_forced_exhaustive_path(vg, ctx):
     """The fallback kernel (step 4) alone must give the same answer."""
-    os.environ["VG_FLAT_FORCE_EXACT"] = "1"
+    hooks.set_hook("VG_FLAT_FORCE_EXACT", "1")
     try:
         idx, _, _ = check(vg, ctx, 6000, 128, 4, 10, 0, np.random.default_rng(8))
         assert idx.flat_stats() == (4, 4)
         check(vg, ctx, 3000, 96, 3, 10, 2, np.random.default_rng(9))
     finally:
-        os.environ.pop("VG_FLAT_FORCE_EXACT")
+        hooks.set_hook("VG_FLAT_FORCE_EXACT", 0)
 
 
 def test_flat_unfused_path_matches_too(vg, ctx):
     """The score-matrix variant (GEMM -> select) stays available behind VG_FLAT_UNFUSED=1."""
-    os.environ["VG_FLAT_UNFUSED"] = "1"
+    hooks.set_hook("VG_FLAT_UNFUSED", "1")
     try:
         check(vg, ctx, 20000, 128, 6, 10, 0, np.random.default_rng(18))
         check(vg, ctx, 3000, 100, 3, 10, 2, np.random.default_rng(19))
     finally:
-        os.environ.pop("VG_FLAT_UNFUSED")
+        hooks.set_hook("VG_FLAT_UNFUSED", 0)
 
 
 def test_flat_sorted_rows_and_candidate_overflow(vg, ctx):
@@ -230,9 +231,9 @@ def test_k_above_64(vg, ctx, n, dim, nq, k, metric):
 
     ids, sc = idx.search_flat(q, k)
     check(ids, sc)
-    os.environ["VG_FLAT_FORCE_EXACT"] = "1"
+    hooks.set_hook("VG_FLAT_FORCE_EXACT", "1")
     try:
         ids, sc = idx.search_flat(q, k)
     finally:
-        del os.environ["VG_FLAT_FORCE_EXACT"]
+        hooks.set_hook("VG_FLAT_FORCE_EXACT", 0)
     check(ids, sc)

@@ -19,6 +19,7 @@ import numpy as np
 import pytest
 
 from oracle import oracle as o
+from tests import hooks
 
 pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
@@ -76,11 +77,11 @@ def test_flat_exact_1m_x_768(vg, ctx):
     assert np.array_equal(rid, np_(ids).view(np.uint32)[:2]) and np.array_equal(bits(rsc), bits(np_(sc)[:2]))
     del hbase
     # (2) the exhaustive exact kernel (no GEMM, no proof) gives the same bits
-    os.environ["VG_FLAT_FORCE_EXACT"] = "1"
+    hooks.set_hook("VG_FLAT_FORCE_EXACT", "1")
     try:
         eids, esc = idx.search_flat(q[:32], k)
     finally:
-        os.environ.pop("VG_FLAT_FORCE_EXACT")
+        hooks.set_hook("VG_FLAT_FORCE_EXACT", 0)
     assert torch.equal(eids, ids[:32]) and torch.equal(esc.view(torch.int32), sc[:32].view(torch.int32))
     # (3) partition property
     half = n // 2
@@ -272,11 +273,11 @@ def test_partition_probed_flat_1m_x_768(vg, ctx):
     ids2, sc2 = idx.search_flat_probed(q, k, nprobes, scan=idx.SCAN_F32)
     assert torch.equal(ids, ids2) and torch.equal(sc.view(torch.int32), sc2.view(torch.int32))
     assert_ordered(ids, sc)
-    os.environ["VG_PROBE_NO_GROUP"] = "1"
+    hooks.set_hook("VG_PROBE_NO_GROUP", "1")
     try:
         pid, psc = idx.search_flat_probed(q, k, nprobes, scan=idx.SCAN_F32)
     finally:
-        del os.environ["VG_PROBE_NO_GROUP"]
+        hooks.set_hook("VG_PROBE_NO_GROUP", 0)
     assert torch.equal(ids, pid) and torch.equal(sc.view(torch.int32), psc.view(torch.int32))
     ids_h = np_(ids).view(np.uint32); sc_h = np_(sc); q_h = np_(q)
     for i in range(0, nq, 12):  # whole-query replay by the oracle on the probed partitions' rows

@@ -191,3 +191,24 @@ def test_hnsw_pq_scored_matches_oracle(vg, ctx, n, dim, m, ef, k):
         assert np.array_equal(ids[qi, :eid.size], eid), (qi, ids[qi], eid)
         assert np.array_equal(bits(sc[qi, :eid.size]), bits(esc))
         assert tuple(int(x) for x in st[qi]) == _stats_tuple(est)
+
+
+def test_adjacency_ids_are_validated(vg, ctx):
+    """A neighbour id that is neither a row nor VG_INVALID_ID would index the visited bitmap and the row
+    arrays out of bounds: refused when the graph is set."""
+    rng = np.random.default_rng(1)
+    base = rng.standard_normal((100, 8)).astype(np.float32)
+    idx = vg.Index(ctx, 100, 8); idx.set_vectors(base)
+    l0 = rng.integers(0, 100, (100, 8)).astype(np.uint32)
+    l0[17, 3] = 100
+    with pytest.raises(vg.VecgoHipError) as e:
+        idx.set_hnsw_graph(l0, (), 0, m=4)
+    assert e.value.status == -1 and "neighbour ids" in e.value.message
+    with pytest.raises(vg.VecgoHipError):      # and nothing half-set is searchable
+        idx.search_hnsw(base[:1], 3, 10)
+    with pytest.raises(vg.VecgoHipError) as e:
+        idx.set_vamana_graph(l0, 0)
+    assert "neighbour ids" in e.value.message
+    l0[17, 3] = 0xFFFFFFFF
+    idx.set_hnsw_graph(l0, (), 0, m=4); idx.set_vamana_graph(l0, 0)
+    idx.search_hnsw(base[:1], 3, 10); idx.search_vamana(base[:1], 3)

@@ -6,6 +6,7 @@ import numpy as np
 import pytest
 
 from oracle import oracle as o
+from tests import hooks
 from tests import segfile
 
 pytestmark = pytest.mark.gpu
@@ -67,11 +68,11 @@ def test_probed_fp32_scan(vg, ctx, n, dim, parts, metric):
     many = rng.standard_normal((150, dim)).astype(np.float32)
     ids, sc = idx.search_flat_probed(many, 10, 2, scan=idx.SCAN_F32)
     check(ids[:6], sc[:6], seg, many[:6], 10, 2)
-    os.environ["VG_PROBE_NO_GROUP"] = "1"
+    hooks.set_hook("VG_PROBE_NO_GROUP", "1")
     try:
         pid, psc = idx.search_flat_probed(many, 10, 2, scan=idx.SCAN_F32)
     finally:
-        del os.environ["VG_PROBE_NO_GROUP"]
+        hooks.set_hook("VG_PROBE_NO_GROUP", 0)
     assert np.array_equal(ids, pid) and np.array_equal(bits(sc), bits(psc))
     # every partition probed = the exhaustive search
     ids, sc = idx.search_flat_probed(q, 10, parts, scan=idx.SCAN_F32)
@@ -123,11 +124,11 @@ def test_probed_sq8_scan(vg, ctx, n, dim, parts, metric):
     many = rng.standard_normal((120, dim)).astype(np.float32)
     ids, sc = idx.search_flat_probed(many, 10, 2, scan=idx.SCAN_SQ8)
     check(ids[:6], sc[:6], seg, many[:6], 10, 2)
-    os.environ["VG_PROBE_NO_GROUP"] = "1"
+    hooks.set_hook("VG_PROBE_NO_GROUP", "1")
     try:
         pid, psc = idx.search_flat_probed(many, 10, 2, scan=idx.SCAN_SQ8)
     finally:
-        del os.environ["VG_PROBE_NO_GROUP"]
+        hooks.set_hook("VG_PROBE_NO_GROUP", 0)
     assert np.array_equal(ids, pid) and np.array_equal(bits(sc), bits(psc))
 
 

@@ -136,3 +136,50 @@ def test_segment_errors(vg, ctx):
     empty = vg.Segment(ctx, segfile.write_flat(np.zeros((0, 16), np.float32)))
     ids, sc = empty.index.search_flat(np.zeros((1, 16), np.float32), 3)
     assert np.all(ids == 0xFFFFFFFF)
+
+
+def test_hostile_headers_do_not_wrap(vg, ctx):
+    """Header fields are untrusted 32/64-bit numbers: a row count x dimension x 4 that wraps around 2^64 (or an
+    offset near 2^64) must be refused by the section checks, not pass them (`x + y >= x` does not catch a wrapped
+    product)."""
+    import struct
+    rng = np.random.default_rng(4)
+    x = rng.standard_normal((64, 16)).astype(np.float32)
+    good = bytearray(segfile.write_flat(x, checksum=False))
+
+    def refused(image, kind="flat"):
+        with pytest.raises(vg.VecgoHipError) as e:
+            vg.Segment(ctx, bytes(image), kind=kind, verify_checksum=False)
+        assert e.value.status == -10, e.value
+        return str(e.value)
+
+    img = bytearray(good)                       # rows * dim * 4 = 2^64 + small: the product wraps to a tiny number
+    struct.pack_into("<I", img, 16, 0x80000000)  # rows = 2^31
+    struct.pack_into("<I", img, 20, 0x40000000)  # dim  = 2^30: rows * dim * 4 = 2^63, + the offset
+    assert "too short" in refused(img)
+    img = bytearray(good)
+    struct.pack_into("<I", img, 16, 0xFFFFFFFF)
+    struct.pack_into("<I", img, 20, 0x7FFFFFFF)
+    assert "too short" in refused(img)
+    img = bytearray(good)
+    struct.pack_into("<Q", img, 72, 0xFFFFFFFFFFFFFFF0)   # vector offset near 2^64: offset + bytes wraps
+    assert "too short" in refused(img)
+    g = np.zeros((64, 4), np.uint32)
+    d = bytearray(segfile.write_diskann(x, g, 0, checksum=False))
+    img = bytearray(d)
+    struct.pack_into("<I", img, 25, 0x80000001)           # max degree: was cast to int32 and sign-extended
+    seg = vg.Segment(ctx, bytes(img), kind="diskann", verify_checksum=False)   # opens (the reference checks no graph bounds in Open)
+    with pytest.raises(vg.VecgoHipError) as e:                               # ... and has no graph to walk
+        seg.index.search_vamana(np.zeros((1, 16), np.float32), 3)
+    assert e.value.status == -9
+    seg.close()
+    img = bytearray(d)
+    struct.pack_into("<Q", img, 56, 0xFFFFFFFFFFFFFF00)   # graph offset near 2^64
+    seg = vg.Segment(ctx, bytes(img), kind="diskann", verify_checksum=False)
+    with pytest.raises(vg.VecgoHipError):
+        seg.index.search_vamana(np.zeros((1, 16), np.float32), 3)
+    seg.close()
+    img = bytearray(d)
+    struct.pack_into("<I", img, 16, 0xFFFFFFFF)           # rows
+    struct.pack_into("<I", img, 20, 0x7FFFFFFF)           # dim
+    assert "too small" in refused(img, "diskann") or "out of bounds" in refused(img, "diskann")

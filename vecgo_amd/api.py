@@ -310,6 +310,26 @@ def normalize_l2(ctx: Context, vectors, dim: int, stream=None):
     return ok
 
 
+class debug_hook:
+    """with vecgo_amd.api.debug_hook("VG_FLAT_FORCE_EXACT"): ... — a test hook switched on for the block
+    (vg_debug_set_hook)."""
+
+    def __init__(self, *names):
+        self.names = names
+
+    def __enter__(self):
+        lib = _lib.load()
+        for n in self.names:
+            check(lib.vg_debug_set_hook(n.encode(), 1))
+        return self
+
+    def __exit__(self, *exc):
+        lib = _lib.load()
+        for n in self.names:
+            lib.vg_debug_set_hook(n.encode(), 0)
+        return False
+
+
 class Comm:
     """vg_comm: the exchange step of a row-sharded search through the C ABI (direct ncclAllGather on the
     caller's stream + merge).  Rank 0 makes the id (Comm.unique_id()), the host distributes the bytes."""

@@ -1098,8 +1098,7 @@ VG_API int32_t vg_search_pq_adc(vg_index *idx, const float *queries, int64_t nq,
     } else {
         int slices = vg::adc_slices(nq, idx->n_tiles, idx->ctx->compute_units);
         const bool bigk = k > 64;
-        const char *slow_env = getenv("VG_ADC_BIGK_EXHAUSTIVE");  // test hook: LDS-buffer path only
-        const bool bigk_fast = bigk && !(slow_env && slow_env[0] == '1');
+        const bool bigk_fast = bigk && !vg::hook(vg::kHookAdcBigkExhaustive);  // test hook: LDS-buffer path only
         if (bigk_fast) {
             // enough waves that a wave expects <= ~8 of the k best rows (capacity 64 each)
             int64_t want = ((static_cast<int64_t>(k) / 64 + 7) / 8) * 8;
@@ -1146,8 +1145,7 @@ VG_API int32_t vg_search_pq_adc(vg_index *idx, const float *queries, int64_t nq,
         // The A/B-skewed scan is conflict-free in LDS but, as compiled today, spends ~7 VALU ops per
         // lookup on lane-dependent address selects and is VALU-bound (70k vs 80k queries/s at
         // 1M x 96 B); it stays opt-in until its address arithmetic is cut down.
-        const char *skew = getenv("VG_ADC_SKEW");
-        if (pq->m == 96 && k <= 64 && skew && skew[0] == '1')
+        if (pq->m == 96 && k <= 64 && vg::hook(vg::kHookAdcSkew))
             VG_TRY(vg::launch_scan96(idx, tables.ptr, nq, k, slices, partial.ptr, st));
         else if (pq->m == 96 && k <= 64)
             VG_TRY((vg::launch_scan<6, true>(idx, tables.ptr, nq, k, slices, partial.ptr, st)));

@@ -148,18 +148,31 @@ VG_API int32_t vg_index_set_vectors(vg_index *idx, const float *base, void *stre
         idx->d_flat_stats = nullptr;
     }
     if (idx->n == 0) return VG_OK;
-    size_t count = static_cast<size_t>(idx->n) * idx->dim;
-    VG_HIP(hipMalloc(reinterpret_cast<void **>(&idx->d_vectors), count * sizeof(float)));
-    VG_HIP(hipMalloc(reinterpret_cast<void **>(&idx->d_norms), static_cast<size_t>(idx->n) * sizeof(float)));
-    VG_HIP(hipMemcpyAsync(idx->d_vectors, base, count * sizeof(float), hipMemcpyDefault, st));
-    VG_LAUNCH(vg::row_norms_kernel, dim3(static_cast<unsigned>((idx->n + 3) / 4)), dim3(256),
-                       0, st, idx->d_vectors, idx->n, idx->dim, idx->d_norms);
-    VG_HIP(hipMalloc(reinterpret_cast<void **>(&idx->d_norm_max), sizeof(float)));
-    VG_LAUNCH(vg::norm_max_kernel, dim3(1), dim3(1024), 0, st, idx->d_norms, idx->n, idx->d_norm_max);
-    VG_HIP(hipMalloc(reinterpret_cast<void **>(&idx->d_flat_stats), 2 * sizeof(unsigned long long)));
-    VG_HIP(hipMemsetAsync(idx->d_flat_stats, 0, 2 * sizeof(unsigned long long), st));
-    VG_HIP(hipStreamSynchronize(st));
-    return VG_OK;
+    // all four allocations or none: a search must never find rows without their norms / counters
+    const int32_t status = [&]() -> int32_t {
+        size_t count = static_cast<size_t>(idx->n) * idx->dim;
+        VG_HIP(hipMalloc(reinterpret_cast<void **>(&idx->d_vectors), count * sizeof(float)));
+        VG_HIP(hipMalloc(reinterpret_cast<void **>(&idx->d_norms), static_cast<size_t>(idx->n) * sizeof(float)));
+        VG_HIP(hipMalloc(reinterpret_cast<void **>(&idx->d_norm_max), sizeof(float)));
+        VG_HIP(hipMalloc(reinterpret_cast<void **>(&idx->d_flat_stats), 2 * sizeof(unsigned long long)));
+        VG_HIP(hipMemcpyAsync(idx->d_vectors, base, count * sizeof(float), hipMemcpyDefault, st));
+        VG_LAUNCH(vg::row_norms_kernel, dim3(static_cast<unsigned>((idx->n + 3) / 4)), dim3(256),
+                           0, st, idx->d_vectors, idx->n, idx->dim, idx->d_norms);
+        VG_LAUNCH(vg::norm_max_kernel, dim3(1), dim3(1024), 0, st, idx->d_norms, idx->n, idx->d_norm_max);
+        VG_HIP(hipMemsetAsync(idx->d_flat_stats, 0, 2 * sizeof(unsigned long long), st));
+        VG_HIP(hipStreamSynchronize(st));
+        return VG_OK;
+    }();
+    if (status != VG_OK) {
+        (void)hipStreamSynchronize(st);
+        if (idx->d_vectors) (void)hipFree(idx->d_vectors);
+        if (idx->d_norms) (void)hipFree(idx->d_norms);
+        if (idx->d_norm_max) (void)hipFree(idx->d_norm_max);
+        if (idx->d_flat_stats) (void)hipFree(idx->d_flat_stats);
+        idx->d_vectors = idx->d_norms = idx->d_norm_max = nullptr;
+        idx->d_flat_stats = nullptr;
+    }
+    return status;
 }
 
 static int32_t batch_impl(vg_ctx *ctx, bool dot, const float *query, const float *targets,

@@ -41,8 +41,8 @@ struct GemmArgs {
 template <bool DOT, int MODE>
 static int32_t launch_gemm_t(bool dma, unsigned blocks, hipStream_t st, const GemmArgs &a)
 {
-    const char *big = getenv("VG_FLAT_NO_SMALL_TILE");  // test hook: always the 128-query tile
-    if (dma && MODE != 0 && a.nq <= 2 * kG32BM && !(big && big[0] == '1')) {  // 1-2 blocks of 32 queries: HBM-bound shapes
+    // (test hook kHookFlatNoSmallTile: always the 128-query tile)
+    if (dma && MODE != 0 && a.nq <= 2 * kG32BM && !hook(kHookFlatNoSmallTile)) {  // 1-2 blocks of 32 queries: HBM-bound shapes
         constexpr int M = MODE == 0 ? 1 : MODE;
         const bool one = a.nq <= kG32BM;
         auto kern = one ? flat_gemm_dma32_kernel<DOT, M, 1> : flat_gemm_dma32_kernel<DOT, M, 2>;
@@ -556,10 +556,10 @@ VG_API int32_t vg_search_flat(vg_index *idx, const float *queries, int64_t nq, i
     const int dim = idx->dim;
     const int kc = 64;  // nominated candidates per query
     // k beyond what 64 nominated candidates can prove: the fused GEMM path re-scores every appended row
-    // (flat_verify_all_kernel); without the fused path (test hook) the exhaustive scans take over
-    const char *unfused_hook = getenv("VG_FLAT_UNFUSED");
-    const bool big_k_scan = k > vg::kGemmMaxK && unfused_hook && unfused_hook[0] == '1';
-    VG_CHECK(k <= 64 || !big_k_scan, VG_ERR_UNSUPPORTED, "vg_search_flat: k=%d needs the fused GEMM path", k);
+    // (flat_verify_all_kernel); the unfused score-matrix variant (test hook) stops at 64
+    const bool unfused = vg::hook(vg::kHookFlatUnfused);
+    const bool big_k_scan = k > vg::kGemmMaxK && unfused;  // unfused: 64 nominated candidates cannot prove k near 64
+    VG_CHECK(k <= 64 || !unfused, VG_ERR_UNSUPPORTED, "vg_search_flat: k=%d needs the fused GEMM path", k);
 
     vg::DevIn<float> q;
     vg::DevOut<uint32_t> oid;
@@ -573,12 +573,9 @@ VG_API int32_t vg_search_flat(vg_index *idx, const float *queries, int64_t nq, i
         VG_TRY(none.init(static_cast<size_t>(nq) * k, st));
         VG_HIP(hipMemsetAsync(none.ptr, 0xFF, static_cast<size_t>(nq) * k * 8, st));
         VG_TRY(vg::launch_topk_merge(none.ptr, nq, 1, k, dot, oid.ptr, osc.ptr, st));
-    } else if (((nq <= vg::kScanMaxBatch && k <= 64) || big_k_scan) && dim % 4 == 0 && dim <= 1024 && dim >= 64 && !getenv("VG_FLAT_NO_SCAN") &&
-               !getenv("VG_FLAT_FORCE_EXACT") && !getenv("VG_FLAT_UNFUSED") &&
-               (reinterpret_cast<uintptr_t>(idx->d_vectors) & 15) == 0) {
-        // small batch: HBM-bound exact scan, kScanQB queries per pass over the rows.  Also every batch with
-        // kGemmMaxK < k <= 64: the GEMM path nominates 64 candidates per query; its proof needs a margin
-        // between the k-th exact score and the 64th nominated one, which k close to 64 does not leave
+    } else if (nq <= vg::kScanMaxBatch && k <= 64 && dim % 4 == 0 && dim <= 1024 && dim >= 64 && !vg::hook(vg::kHookFlatNoScan) &&
+               !vg::hook(vg::kHookFlatForceExact) && !unfused && (reinterpret_cast<uintptr_t>(idx->d_vectors) & 15) == 0) {
+        // small batch: HBM-bound exact scan, kScanQB queries per pass over the rows
         const int slices = static_cast<int>(std::min<int64_t>(4 * idx->ctx->compute_units, std::max<int64_t>(1, n / 64)));
         vg::ArenaCall ar(idx->ctx, st);
         const int i_partial = ar.add(sizeof(uint64_t) * static_cast<size_t>(nq) * slices * k);
@@ -626,8 +623,7 @@ VG_API int32_t vg_search_flat(vg_index *idx, const float *queries, int64_t nq, i
             VG_TRY(vg::launch_topk_merge(fpartial, cnt, ex_slices, k, dot, oid.ptr + q0 * k, osc.ptr + q0 * k, st));
         }
     } else {
-        const char *unfused_env = getenv("VG_FLAT_UNFUSED");  // test hook: materialise the score matrix
-        const bool fused = !(unfused_env && unfused_env[0] == '1');
+        const bool fused = !unfused;  // test hook: materialise the score matrix
         const int cap = 4096;          // candidate keys per query (fused path)
         // threshold = sample_j-th best score of the row sample: ~64 * sample_j rows pass it (k > 64: ~3k of them)
         const int sample_j = k <= 64 ? 8 : std::min(64, std::max(8, (3 * k + 63) / 64));
@@ -673,18 +669,16 @@ VG_API int32_t vg_search_flat(vg_index *idx, const float *queries, int64_t nq, i
         uint32_t *sid = ar.get<uint32_t>(i_sid), *cand_id = ar.get<uint32_t>(i_cand_id), *fid = ar.get<uint32_t>(i_fid);
         int *counts = ar.get<int>(i_counts), *flags = ar.get<int>(i_flags), *todo = ar.get<int>(i_todo);
 
-        const char *force = getenv("VG_FLAT_FORCE_EXACT");  // test hook: run step 4 for every query
-        int *always = flags + qc;
-        VG_HIP(hipMemsetAsync(always, 0, sizeof(int), st));
-        if (force && force[0] == '1') VG_HIP(hipMemsetAsync(always, 1, sizeof(int), st));
+        int *always = flags + qc;  // test hook kHookFlatForceExact: run step 4 for every query
+        VG_HIP(hipMemsetAsync(always, vg::hook(vg::kHookFlatForceExact) ? 1 : 0, sizeof(int), st));
         for (int64_t q0 = 0; q0 < nq; q0 += qc) {
             const int64_t cnt = std::min(qc, nq - q0);
             const float *qp = q.ptr + q0 * dim;
             const int64_t mt = (cnt + vg::kGemmBM - 1) / vg::kGemmBM;
             const unsigned ucnt = static_cast<unsigned>(cnt);
-            const char *nodma = getenv("VG_FLAT_NO_DMA");  // test hook: force the register-staged GEMM
+            // (test hook kHookFlatNoDma: force the register-staged GEMM)
             const bool dma = dim % 4 == 0 && (reinterpret_cast<uintptr_t>(qp) & 15) == 0 &&
-                             (reinterpret_cast<uintptr_t>(idx->d_vectors) & 15) == 0 && !(nodma && nodma[0] == '1');
+                             (reinterpret_cast<uintptr_t>(idx->d_vectors) & 15) == 0 && !vg::hook(vg::kHookFlatNoDma);
             if (fused) {
                 // (a) threshold per query from a row sample
                 if (use_sample) {
@@ -749,7 +743,7 @@ VG_API int32_t vg_search_flat(vg_index *idx, const float *queries, int64_t nq, i
             // step 4 always launches, on the work list the proofs left behind (normally empty)
             VG_LAUNCH(vg::flat_todo_kernel, dim3(1), dim3(256), 0, st, flags, always, static_cast<int>(cnt), todo,
                       idx->d_flat_stats);
-            if (getenv("VG_FLAT_DEBUG")) {
+            if (vg::hook(vg::kHookFlatDebug)) {
                 std::vector<int> hf(cnt), hc(cnt);
                 (void)hipMemcpyAsync(hf.data(), flags, sizeof(int) * cnt, hipMemcpyDeviceToHost, st);
                 (void)hipMemcpyAsync(hc.data(), counts, sizeof(int) * cnt, hipMemcpyDeviceToHost, st);

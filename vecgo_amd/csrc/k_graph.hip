@@ -143,7 +143,7 @@ __global__ __launch_bounds__(64) void vamana_search_kernel(
                            (static_cast<uint32_t>(qc[rq_nb + 3]) << 24);
         qn = __uint_as_float(b);
     }
-    int64_t st_visited = 0, st_dc = 0, st_pops = 0;
+    int64_t st_visited = 0, st_dc = 0, st_pops = 0, st_dropped = 0;
 
     // score the nodes held by the lanes in `mask` (one id per lane) into nb_d[lane]
     auto score_mask = [&](uint64_t mask, uint32_t id_lane) {
@@ -295,6 +295,8 @@ __global__ __launch_bounds__(64) void vamana_search_kernel(
             if (cand_len < cand_cap)
                 heap_push<false>(cand, cand_len,
                                  HItem{static_cast<uint32_t>(__builtin_amdgcn_readlane(id_lane, j)), nb_d[j]});
+            else
+                st_dropped++;  // the reference's heap is unbounded: reported, see vg_search_stats
         }
         // result heap: TryPushBounded(k) — a set maintained by (score, id): order-free
         offer(fresh ? make_key(myd, id_lane, desc) : kKeyMax);
@@ -315,7 +317,7 @@ __global__ __launch_bounds__(64) void vamana_search_kernel(
     if (stats && lane == 0) {
         stats[q].nodes_visited = st_visited;
         stats[q].distance_computations = st_dc;
-        stats[q].distance_short_circuits = 0;
+        stats[q].distance_short_circuits = st_dropped;
         stats[q].pops = st_pops;
     }
 }
@@ -324,6 +326,33 @@ __global__ __launch_bounds__(64) void vamana_search_kernel(
 int32_t launch_rabitq_encode(const float *d_vectors, int64_t n, int dim, uint8_t *d_codes, hipStream_t st);
 
 }  // namespace vg
+
+namespace vg {
+// adjacency ids must be rows of the index or VG_INVALID_ID: the searches index the visited bitmap and the
+// row arrays with them unchecked
+__global__ void count_bad_ids_kernel(const uint32_t *__restrict__ ids, int64_t count, uint32_t n, unsigned int *__restrict__ bad)
+{
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const uint32_t id = ids[i];
+    if (id != VG_INVALID_ID && id >= n) atomicAdd(bad, 1u);
+}
+}  // namespace vg
+
+static int32_t check_adjacency(const uint32_t *d_ids, int64_t count, int64_t n, hipStream_t st, const char *what)
+{
+    if (count == 0) return VG_OK;
+    vg::DevTmp<unsigned int> bad;
+    VG_TRY(bad.init(1, st));
+    VG_HIP(hipMemsetAsync(bad.ptr, 0, sizeof(unsigned int), st));
+    VG_LAUNCH(vg::count_bad_ids_kernel, dim3(static_cast<unsigned>((count + 255) / 256)), dim3(256), 0, st, d_ids, count,
+              static_cast<uint32_t>(n), bad.ptr);
+    unsigned int h = 0;
+    VG_HIP(hipMemcpyAsync(&h, bad.ptr, sizeof(h), hipMemcpyDeviceToHost, st));
+    VG_HIP(hipStreamSynchronize(st));
+    VG_CHECK(h == 0, VG_ERR_INVALID_ARG, "%s: %u neighbour ids are neither rows of the index nor VG_INVALID_ID", what, h);
+    return VG_OK;
+}
 
 template <typename T>
 static int32_t replace_device_array(T **slot, const T *src, size_t count, hipStream_t st)
@@ -363,6 +392,13 @@ VG_API int32_t vg_index_set_hnsw_graph(vg_index *idx, int32_t m0, const uint32_t
     VG_TRY(replace_device_array(&idx->d_hnsw_adj, upper_adj, static_cast<size_t>(off[max_level]) * m, st));
     VG_TRY(replace_device_array(&idx->d_hnsw_level_off, off.data(), off.size(), st));
     VG_HIP(hipStreamSynchronize(st));
+    int32_t bad = check_adjacency(idx->d_hnsw_l0, idx->n * m0, idx->n, st, "vg_index_set_hnsw_graph (layer 0)");
+    if (bad == VG_OK) bad = check_adjacency(idx->d_hnsw_adj, off[max_level] * m, idx->n, st, "vg_index_set_hnsw_graph (upper layers)");
+    if (bad != VG_OK) {  // a graph that failed the check is not searchable
+        (void)hipFree(idx->d_hnsw_l0);
+        idx->d_hnsw_l0 = nullptr;
+        return bad;
+    }
     idx->hnsw_m0 = m0;
     idx->hnsw_m = m;
     idx->hnsw_max_level = max_level;
@@ -381,6 +417,12 @@ VG_API int32_t vg_index_set_vamana_graph(vg_index *idx, int32_t r, const uint32_
     hipStream_t st = vg::pick_stream(idx->ctx, stream);
     VG_TRY(replace_device_array(&idx->d_vamana, graph, static_cast<size_t>(idx->n) * r, st));
     VG_HIP(hipStreamSynchronize(st));
+    const int32_t bad = check_adjacency(idx->d_vamana, idx->n * r, idx->n, st, "vg_index_set_vamana_graph");
+    if (bad != VG_OK) {
+        (void)hipFree(idx->d_vamana);
+        idx->d_vamana = nullptr;
+        return bad;
+    }
     idx->vamana_r = r;
     idx->vamana_entry = entry_point;
     return VG_OK;

@@ -315,8 +315,7 @@ VG_API int32_t vg_search_flat_probed(vg_index *idx, const float *queries, int64_
     const int64_t pairs = nq * np;
     // fp32: with enough pairs the queries are grouped by partition (rows read once per group); the
     // row-in-registers scan needs 16-byte aligned rows of at most 1024 floats
-    const char *nogroup = getenv("VG_PROBE_NO_GROUP");  // test hook: one pass per (query, probe) pair
-    const bool group_ok = pairs >= 16 && !(nogroup && nogroup[0] == '1');
+    const bool group_ok = pairs >= 16 && !vg::hook(vg::kHookProbeNoGroup);  // test hook: one pass per (query, probe) pair
     const bool grouped_f32 = scan == VG_SCAN_F32 && group_ok && idx->dim % 4 == 0 && idx->dim <= 1024 &&
                              (reinterpret_cast<uintptr_t>(idx->d_vectors) & 15) == 0;
     // SQ8: the group's queries (padded to whole 16-dimension groups) have to fit LDS next to the merge scratch

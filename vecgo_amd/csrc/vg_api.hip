@@ -293,3 +293,38 @@ VG_API int32_t vg_index_destroy(vg_index *idx)
     delete idx;
     return VG_OK;
 }
+
+// ---- test hooks ------------------------------------------------------------------------------------
+#include <atomic>
+namespace vg {
+static std::atomic<int> g_hooks[kHookCount];
+static std::once_flag g_hooks_once;
+static const char *const kHookNames[kHookCount] = {"VG_FLAT_NO_SMALL_TILE", "VG_FLAT_UNFUSED", "VG_FLAT_NO_SCAN",
+                                                   "VG_FLAT_FORCE_EXACT", "VG_FLAT_NO_DMA", "VG_FLAT_DEBUG",
+                                                   "VG_PROBE_NO_GROUP", "VG_ADC_BIGK_EXHAUSTIVE", "VG_ADC_SKEW"};
+static void hooks_from_env()
+{
+    for (int h = 0; h < kHookCount; h++) {
+        const char *e = getenv(kHookNames[h]);
+        g_hooks[h].store(e && e[0] == '1' ? 1 : 0, std::memory_order_relaxed);
+    }
+}
+bool hook(Hook h)
+{
+    std::call_once(g_hooks_once, hooks_from_env);
+    return g_hooks[h].load(std::memory_order_relaxed) != 0;
+}
+}  // namespace vg
+
+VG_API int32_t vg_debug_set_hook(const char *name, int32_t on)
+{
+    VG_CHECK(name, VG_ERR_INVALID_ARG, "vg_debug_set_hook: NULL name");
+    std::call_once(vg::g_hooks_once, vg::hooks_from_env);
+    for (int h = 0; h < vg::kHookCount; h++)
+        if (std::strcmp(name, vg::kHookNames[h]) == 0) {
+            vg::g_hooks[h].store(on ? 1 : 0, std::memory_order_relaxed);
+            return VG_OK;
+        }
+    vg::set_error("vg_debug_set_hook: unknown hook %s", name);
+    return VG_ERR_INVALID_ARG;
+}

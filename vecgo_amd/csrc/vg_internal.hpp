@@ -62,6 +62,23 @@ void set_error(const char *fmt, ...);
 
 bool is_device_ptr(const void *p);
 
+// Test hooks: switches that force a slower or alternative path so the tests can compare the paths.  Read from
+// the environment ONCE (first use) and changed afterwards only through vg_debug_set_hook — the entry points
+// test one relaxed atomic, never getenv.
+enum Hook {
+    kHookFlatNoSmallTile,     // VG_FLAT_NO_SMALL_TILE   always the 128-query GEMM tile
+    kHookFlatUnfused,         // VG_FLAT_UNFUSED         materialise the score matrix
+    kHookFlatNoScan,          // VG_FLAT_NO_SCAN         no small-batch register scan
+    kHookFlatForceExact,      // VG_FLAT_FORCE_EXACT     exhaustive exact kernel for every query
+    kHookFlatNoDma,           // VG_FLAT_NO_DMA          register-staged GEMM
+    kHookFlatDebug,           // VG_FLAT_DEBUG           print per-call counters
+    kHookProbeNoGroup,        // VG_PROBE_NO_GROUP       one pass per (query, probe) pair
+    kHookAdcBigkExhaustive,   // VG_ADC_BIGK_EXHAUSTIVE  LDS-buffer path for k > 64
+    kHookAdcSkew,             // VG_ADC_SKEW             the A/B-skewed scan
+    kHookCount
+};
+bool hook(Hook h);
+
 // Per-call HBM scratch.  Blocks come from a process-wide cache keyed by (device, stream): a block
 // released by one call is handed to the next call on the SAME stream, where stream order makes
 // the reuse safe without waiting.  (The runtime's own stream-ordered pool, hipMallocAsync, was

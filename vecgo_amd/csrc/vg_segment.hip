@@ -110,6 +110,19 @@ VG_API uint32_t vg_crc32c(const void *data, int64_t size)
     return data && size > 0 ? crc32c(static_cast<const uint8_t *>(data), static_cast<size_t>(size)) : 0;
 }
 
+// off + a*b*c <= len with every quantity an untrusted 64-bit header field: checked by division, no product is
+// ever formed before it is known to fit (a wrapped product passes an `x + y >= x` guard)
+static bool fits(uint64_t len, uint64_t off, uint64_t a, uint64_t b = 1, uint64_t c = 1)
+{
+    if (off > len) return false;
+    if (a == 0 || b == 0 || c == 0) return true;
+    const uint64_t room = len - off;
+    if (a > room) return false;
+    const uint64_t per_a = room / a;
+    if (b > per_a) return false;
+    return c <= per_a / b;
+}
+
 VG_API int32_t vg_segment_open_flat(vg_ctx *ctx, const void *image, int64_t size, int32_t verify_checksum,
                                     vg_segment **out, void *stream)
 {
@@ -140,10 +153,8 @@ VG_API int32_t vg_segment_open_flat(vg_ctx *ctx, const void *image, int64_t size
     const uint64_t n = static_cast<uint64_t>(h.rows), dim = static_cast<uint64_t>(h.dim);
     SEG_TRY(vg_index_create(ctx, h.rows, h.dim, h.metric, &seg->idx));
     if (qtype == 1) {  // segment.go:209-233: mins[dim] then maxs[dim], SetBounds, codes n*dim
-        SEG_CHECK(len >= q_off + dim * 8 && q_off + dim * 8 >= q_off, VG_ERR_FORMAT,
-                  "file too short for quantization metadata");
-        SEG_CHECK(len >= codes_off + n * dim && codes_off + n * dim >= codes_off, VG_ERR_FORMAT,
-                  "file too short for codes");
+        SEG_CHECK(fits(len, q_off, dim, 8), VG_ERR_FORMAT, "file too short for quantization metadata");
+        SEG_CHECK(fits(len, codes_off, n, dim), VG_ERR_FORMAT, "file too short for codes");
         SEG_TRY(vg_sq8_create(ctx, h.dim, &seg->sq));
         std::vector<float> mm(2 * dim);  // the image is only byte-aligned
         memcpy(mm.data(), data + q_off, dim * 8);
@@ -152,13 +163,13 @@ VG_API int32_t vg_segment_open_flat(vg_ctx *ctx, const void *image, int64_t size
         // segment.go:659-667: an SQ8 segment is scored from its codes for every metric (L2Distance / DotProduct)
         SEG_TRY(vg_index_set_sq8_codes(seg->idx, seg->sq, data + codes_off, stream));
     } else if (qtype == 2) {  // segment.go:234-281: m, k, scales[m], offsets[m], codebooks[m*k*dsub], codes n*m
-        SEG_CHECK(len >= q_off + 8 && q_off + 8 >= q_off, VG_ERR_FORMAT, "file too short for PQ metadata");
+        SEG_CHECK(fits(len, q_off, 8), VG_ERR_FORMAT, "file too short for PQ metadata");
         const uint64_t m = rd32(data + q_off), k = rd32(data + q_off + 4);
         SEG_CHECK(m > 0 && dim % m == 0, VG_ERR_FORMAT, "flat segment: %llu sub-quantizers do not divide dimension %llu",
                   static_cast<unsigned long long>(m), static_cast<unsigned long long>(dim));
-        const uint64_t cb = m * k * (dim / m), meta = 8 + m * 8 + cb;
-        SEG_CHECK(len >= q_off + meta && q_off + meta >= q_off, VG_ERR_FORMAT, "file too short for PQ metadata");
-        SEG_CHECK(len >= codes_off + n * m && codes_off + n * m >= codes_off, VG_ERR_FORMAT, "file too short for codes");
+        SEG_CHECK(fits(len, q_off, 8 + m * 8) && fits(len, q_off + 8 + m * 8, m, k, dim / m), VG_ERR_FORMAT,
+                  "file too short for PQ metadata");
+        SEG_CHECK(fits(len, codes_off, n, m), VG_ERR_FORMAT, "file too short for codes");
         SEG_TRY(vg_pq_create(ctx, h.dim, static_cast<int32_t>(m), static_cast<int32_t>(k), &seg->pq));
         std::vector<float> so(2 * m);
         memcpy(so.data(), data + q_off + 8, m * 8);
@@ -172,8 +183,7 @@ VG_API int32_t vg_segment_open_flat(vg_ctx *ctx, const void *image, int64_t size
         SEG_CHECK(qtype == 0, VG_ERR_FORMAT, "flat segment: unknown quantization type %d", qtype);
         h.quantization = VG_QUANT_NONE;
     }
-    SEG_CHECK(len >= vec_off + n * dim * 4 && vec_off + n * dim * 4 >= vec_off, VG_ERR_FORMAT,
-              "file too short for vectors");  // segment.go:283-289
+    SEG_CHECK(fits(len, vec_off, n, dim, 4), VG_ERR_FORMAT, "file too short for vectors");  // segment.go:283-289
     if (n) {
         if (reinterpret_cast<uintptr_t>(data + vec_off) % 4 == 0) {
             SEG_TRY(vg_index_set_vectors(seg->idx, reinterpret_cast<const float *>(data + vec_off), stream));
@@ -186,8 +196,8 @@ VG_API int32_t vg_segment_open_flat(vg_ctx *ctx, const void *image, int64_t size
     h.num_partitions = static_cast<int32_t>(partitions);
     if (partitions > 0) {  // segment.go:187-207: centroids [P*dim] fp32, partition offsets [P+1] uint32
         const uint64_t cbytes = static_cast<uint64_t>(partitions) * dim * 4, pbytes = (static_cast<uint64_t>(partitions) + 1) * 4;
-        SEG_CHECK(len >= cent_off + cbytes && cent_off + cbytes >= cent_off, VG_ERR_FORMAT, "file too short for centroids");
-        SEG_CHECK(len >= poff_off + pbytes && poff_off + pbytes >= poff_off, VG_ERR_FORMAT,
+        SEG_CHECK(fits(len, cent_off, static_cast<uint64_t>(partitions), dim, 4), VG_ERR_FORMAT, "file too short for centroids");
+        SEG_CHECK(fits(len, poff_off, static_cast<uint64_t>(partitions) + 1, 4), VG_ERR_FORMAT,
                   "file too short for partition offsets");
         std::vector<float> cent(static_cast<size_t>(partitions) * dim);  // the image is only byte-aligned
         std::vector<uint32_t> poff(static_cast<size_t>(partitions) + 1);
@@ -248,7 +258,8 @@ VG_API int32_t vg_segment_open_diskann(vg_ctx *ctx, const void *image, int64_t s
     h.rows = rd32(data + 16);
     h.dim = static_cast<int32_t>(rd32(data + 20));
     h.metric = data[24];
-    h.max_degree = static_cast<int32_t>(rd32(data + 25));
+    const uint32_t max_degree_raw = rd32(data + 25);
+    h.max_degree = max_degree_raw > 0x7FFFFFFFu ? 0x7FFFFFFF : static_cast<int32_t>(max_degree_raw);
     h.search_list_size = static_cast<int32_t>(rd32(data + 29));
     h.entrypoint = rd32(data + 33);
     const int qtype = data[37];  // quantization.Type (types.go:6-14): 1 PQ, 5 RaBitQ, 6 INT4
@@ -264,13 +275,14 @@ VG_API int32_t vg_segment_open_diskann(vg_ctx *ctx, const void *image, int64_t s
     SEG_CHECK(h.metric <= VG_METRIC_DOT, VG_ERR_UNSUPPORTED, "diskann segment: metric %d has no float32 kernels", h.metric);
     if (verify_checksum) SEG_TRY(verify_body(data, len, kDiskHeader, checksum));
     const uint64_t n = static_cast<uint64_t>(h.rows), dim = static_cast<uint64_t>(h.dim);
-    SEG_CHECK(len >= pk_off + n * 8, VG_ERR_FORMAT, "file size too small: expected at least %llu, got %llu",
+    SEG_CHECK(fits(len, pk_off, n, 8), VG_ERR_FORMAT, "file size too small: expected at least %llu, got %llu",
               static_cast<unsigned long long>(pk_off + n * 8), static_cast<unsigned long long>(len));  // segment.go:177-182
-    SEG_CHECK(len >= vec_off + n * dim * 4 && vec_off + n * dim * 4 >= vec_off, VG_ERR_FORMAT,
-              "vector section out of bounds");
-    const uint64_t r = static_cast<uint64_t>(h.max_degree);
-    SEG_CHECK(len >= graph_off + n * r * 4 && graph_off + n * r * 4 >= graph_off, VG_ERR_FORMAT,
-              "graph section out of bounds");
+    SEG_CHECK(fits(len, vec_off, n, dim, 4), VG_ERR_FORMAT, "vector section out of bounds");
+    // the reference reads a node's neighbour list when a search visits it (segment.go:1376-1391) and never
+    // checks the graph section in Open: a segment whose graph section does not fit (or whose degree this
+    // library cannot walk) opens without a graph, and searching it fails then
+    const uint64_t r = max_degree_raw;
+    const bool graph_ok = r >= 1 && r <= 64 && fits(len, graph_off, n, r, 4);
     SEG_TRY(vg_index_create(ctx, h.rows, h.dim, h.metric, &seg->idx));
     auto aligned_or_copy = [&](uint64_t off, uint64_t bytes, std::vector<uint32_t> &tmp) -> const void * {
         if (reinterpret_cast<uintptr_t>(data + off) % 4 == 0) return data + off;
@@ -282,7 +294,7 @@ VG_API int32_t vg_segment_open_diskann(vg_ctx *ctx, const void *image, int64_t s
     if (n) {
         SEG_TRY(vg_index_set_vectors(seg->idx, static_cast<const float *>(aligned_or_copy(vec_off, n * dim * 4, tmp)),
                                      stream));
-        if (r)
+        if (graph_ok)
             SEG_TRY(vg_index_set_vamana_graph(seg->idx, h.max_degree,
                                               static_cast<const uint32_t *>(aligned_or_copy(graph_off, n * r * 4, tmp)),
                                               h.entrypoint, stream));
@@ -292,10 +304,8 @@ VG_API int32_t vg_segment_open_diskann(vg_ctx *ctx, const void *image, int64_t s
         const uint64_t m = static_cast<uint64_t>(h.pq_m), k = static_cast<uint64_t>(h.pq_k);
         SEG_CHECK(m > 0 && dim % m == 0, VG_ERR_FORMAT, "diskann segment: %llu sub-quantizers do not divide dimension %llu",
                   static_cast<unsigned long long>(m), static_cast<unsigned long long>(dim));
-        SEG_CHECK(len >= pq_codes_off + n * m && pq_codes_off + n * m >= pq_codes_off, VG_ERR_FORMAT,
-                  "PQ codes section out of bounds");
-        const uint64_t cb = m * k * (dim / m);
-        SEG_CHECK(len >= cb_off + m * 8 + cb && cb_off + m * 8 + cb >= cb_off, VG_ERR_FORMAT,
+        SEG_CHECK(fits(len, pq_codes_off, n, m), VG_ERR_FORMAT, "PQ codes section out of bounds");
+        SEG_CHECK(fits(len, cb_off, m * 8) && fits(len, cb_off + m * 8, m, k, dim / m), VG_ERR_FORMAT,
                   "failed to read PQ codebooks: out of bounds");
         SEG_TRY(vg_pq_create(ctx, h.dim, h.pq_m, h.pq_k, &seg->pq));
         std::vector<float> so(2 * m);
@@ -306,21 +316,19 @@ VG_API int32_t vg_segment_open_diskann(vg_ctx *ctx, const void *image, int64_t s
         h.quantization = VG_QUANT_PQ;
     } else if (qtype == 5) {  // segment.go:1393-1408 loadRaBitQ: n * (((dim+63)/64)*8 + 4) bytes
         const uint64_t per = static_cast<uint64_t>(vg_rabitq_code_bytes(h.dim));
-        SEG_CHECK(len >= bq_codes_off + n * per && bq_codes_off + n * per >= bq_codes_off, VG_ERR_FORMAT,
-                  "RaBitQ codes section out of bounds");
+        SEG_CHECK(fits(len, bq_codes_off, n, per), VG_ERR_FORMAT, "RaBitQ codes section out of bounds");
         if (n) SEG_TRY(vg_index_set_rabitq_codes(seg->idx, data + bq_codes_off, stream));
         h.quantization = VG_QUANT_RABITQ;
     } else if (qtype == 6) {  // segment.go:378-416 loadINT4: params = [dim u32][min f32 x dim][diff f32 x dim]
         SEG_CHECK(cb_off != 0, VG_ERR_FORMAT, "missing INT4 params");
         SEG_CHECK(pk_off > cb_off, VG_ERR_FORMAT, "invalid INT4 params size");
         const uint64_t psize = pk_off - cb_off;
-        SEG_CHECK(len >= cb_off + psize, VG_ERR_FORMAT, "INT4 params out of bounds");
+        SEG_CHECK(fits(len, cb_off, psize), VG_ERR_FORMAT, "INT4 params out of bounds");
         SEG_CHECK(psize >= 4, VG_ERR_FORMAT, "data too short");                       // int4.go:191-193
         SEG_CHECK(rd32(data + cb_off) == dim && psize == 4 + dim * 8, VG_ERR_FORMAT, "data size mismatch");
         SEG_CHECK(pq_codes_off != 0, VG_ERR_FORMAT, "missing INT4 codes");
         const uint64_t cs = (dim + 1) / 2;
-        SEG_CHECK(len >= pq_codes_off + n * cs && pq_codes_off + n * cs >= pq_codes_off, VG_ERR_FORMAT,
-                  "INT4 codes out of bounds");
+        SEG_CHECK(fits(len, pq_codes_off, n, cs), VG_ERR_FORMAT, "INT4 codes out of bounds");
         SEG_TRY(vg_int4_create(ctx, h.dim, &seg->iq));
         std::vector<float> md(2 * dim);
         memcpy(md.data(), data + cb_off + 4, dim * 8);
