@@ -1451,12 +1451,11 @@ int32_t vgo_flat_segment_search(const vgo_flat_segment *s, const float *query, i
                                 uint32_t *ids, float *scores)
 {
     /* segment.go:657-701: SQ8 codes first (L2Distance / DotProduct by metric), else PQ, else fp32.
-     * The reference's heap direction follows the metric for every branch (:449); for a Dot-metric PQ
-     * segment that keeps the k largest squared-L2 ADC distances — not restated: PQ is ascending here
-     * and the device entry point refuses that combination. */
+     * The reference's heap direction follows the metric for every branch (:449); for a Dot- or
+     * Cosine-metric PQ segment that keeps the k LARGEST squared-L2 ADC distances — restated as written. */
     const int use_sq = s->sq_mins != NULL;
     const int use_pq = !use_sq && s->pq != NULL;
-    const int desc = s->metric != VGO_METRIC_L2 && !use_pq;
+    const int desc = s->metric != VGO_METRIC_L2;
     float *table = NULL;
     if (use_pq) {
         table = (float *)calloc((size_t)s->pq->m * 256, sizeof(float));

@@ -68,6 +68,11 @@ def test_build_distance_table_bit_exact(vg, ctx, dim, m):
     (3000, 272, 17, 1, 2),       # k = 1
     (20000, 128, 16, 200, 2),    # larger k
     (70000, 64, 4, 1000, 1),     # k near the fused limit, many compactions
+    (9000, 1536, 192, 10, 3),    # d = 1536 at 8 dims per sub-quantizer: the table (192 KiB) is walked in two chunks
+    (5000, 1024, 128, 10, 2),    # 8 groups: a 6-group chunk and a 2-group chunk
+    (4000, 800, 100, 10, 2),     # 6 full groups + a 4-wide tail: past one LDS image with the top-k buffers
+    (3000, 1600, 200, 64, 2),    # 12 groups + 8 tail, k = 64
+    (130, 1536, 192, 10, 1),     # fewer tiles than a batch
 ])
 def test_adc_scan_matches_oracle(vg, ctx, n, dim, m, k, nq):
     rng = np.random.default_rng(n + dim + m + k)
@@ -83,6 +88,16 @@ def test_adc_scan_matches_oracle(vg, ctx, n, dim, m, k, nq):
         assert np.array_equal(ids[qi, :r], eid)
         assert np.array_equal(bits(scores[qi, :r]), bits(esc))
         assert np.all(ids[qi, r:] == 0xFFFFFFFF) and np.all(np.isinf(scores[qi, r:]))
+
+
+def test_wide_table_limits(vg, ctx):
+    rng = np.random.default_rng(5)
+    opq = _random_pq(rng, 1536, 192)
+    codes = rng.integers(0, 256, (500, 192)).astype(np.uint8)
+    pq, idx = _mk(vg, ctx, opq, codes, 500)
+    with pytest.raises(vg.VecgoHipError) as e:          # the chunked scan keeps its top-k in registers
+        idx.search_pq_adc(rng.standard_normal((1, 1536)).astype(np.float32), 100)
+    assert e.value.status == -5
 
 
 def test_adc_ties_break_by_row_id(vg, ctx):

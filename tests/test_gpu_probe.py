@@ -105,6 +105,30 @@ def test_probed_pq_scan(vg, ctx, n, dim, m, parts):
     check(ids[:8], sc[:8], seg, many[:8], 10, 3)
 
 
+@pytest.mark.parametrize("metric", [2, 1])
+def test_probed_pq_scan_dot_and_cosine_keep_the_largest(vg, ctx, metric):
+    """flat/segment.go:449: the result heap's direction follows the segment metric for every scan type, while
+    AdcDistance is always a squared L2 — a Dot / Cosine PQ segment keeps its k LARGEST table-lookup distances.
+    Matched as written (the oracle restates it), not 'fixed'."""
+    rng = np.random.default_rng(70 + metric)
+    n, dim, m, parts = 3000, 64, 8, 5
+    x, cent, off = partitioned(rng, n, dim, parts)
+    pq = vg.ProductQuantizer(ctx, dim, m, 256)
+    pq.train(x, iters=4, seed=2)
+    codes = pq.encode(x)
+    cb, scales, offsets = pq.codebooks()
+    opq = o.ProductQuantizer(dim, m, 256); opq.set_codebooks(cb, scales, offsets)
+    idx = vg.Index(ctx, n, dim, vg.Metric(metric))
+    idx.set_pq_codes(pq, codes)
+    idx.set_partitions(cent, off)
+    seg = o.FlatSegment(x, dim, metric=metric, pq=opq, codes=codes, centroids=cent, part_offsets=off)
+    q = rng.standard_normal((5, dim)).astype(np.float32)
+    for nprobes, k in ((1, 10), (parts, 70)):
+        ids, sc = idx.search_flat_probed(q, k, nprobes, scan=idx.SCAN_PQ)
+        check(ids, sc, seg, q, k, nprobes)
+        assert np.all(np.diff(sc[:, :min(k, 10)], axis=1) <= 0)      # largest first
+
+
 @pytest.mark.parametrize("n,dim,parts,metric", [(3000, 64, 6, 0), (2500, 100, 10, 0), (1200, 17, 4, 2)])
 def test_probed_sq8_scan(vg, ctx, n, dim, parts, metric):
     rng = np.random.default_rng(n + dim)

@@ -796,7 +796,7 @@ int32_t launch_pq_build_table(const vg_pq *pq, const float *d_queries, int64_t n
 __global__ __launch_bounds__(kAdcThreads) void pq_adc_probe_kernel(
     const uint4 *__restrict__ tiles, int64_t n_rows, int m, int groups, const float *__restrict__ tables,
     const uint32_t *__restrict__ probes, const uint32_t *__restrict__ part_off, int np, int split, int k,
-    uint64_t *__restrict__ partial, const uint64_t *__restrict__ min_keys)
+    uint64_t *__restrict__ partial, const uint64_t *__restrict__ min_keys, bool desc)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float *lut = reinterpret_cast<float *>(smem);
@@ -847,7 +847,7 @@ __global__ __launch_bounds__(kAdcThreads) void pq_adc_probe_kernel(
                 for (int l = 0; l < tail; l++) total = total + lut[lut_tail_word + l * 256 + code_byte(c, l)];
             }
             const int64_t row = tile * 64 + lane;
-            uint64_t key = row >= R0 && row < R1 && row < n_rows ? make_key(total, static_cast<uint32_t>(row), false) : kKeyMax;
+            uint64_t key = row >= R0 && row < R1 && row < n_rows ? make_key(total, static_cast<uint32_t>(row), desc) : kKeyMax;
             if (min_keys && key <= min_keys[q]) key = kKeyMax;  // paged results (k > 64)
             wtk.offer(key, lane);
         }
@@ -857,7 +857,7 @@ __global__ __launch_bounds__(kAdcThreads) void pq_adc_probe_kernel(
 }
 
 int32_t launch_probe_scan_adc(const vg_index *idx, const float *tables, const uint32_t *probes, int64_t nq, int np,
-                              int split, int k, uint64_t *partial, const uint64_t *min_keys, hipStream_t st)
+                              int split, int k, uint64_t *partial, const uint64_t *min_keys, bool desc, hipStream_t st)
 {
     const vg_pq *pq = idx->pq;
     const size_t lds = static_cast<size_t>(lut_image_words(pq->m)) * sizeof(float) + kAdcWaves * 64 * sizeof(uint64_t) + 64;
@@ -869,7 +869,7 @@ int32_t launch_probe_scan_adc(const vg_index *idx, const float *tables, const ui
         VG_LAUNCH(pq_adc_probe_kernel, dim3(static_cast<unsigned>(split), static_cast<unsigned>(cnt)), dim3(kAdcThreads),
                   lds, st, reinterpret_cast<const uint4 *>(idx->d_pq_tiles), idx->n, pq->m, idx->pq_groups,
                   tables + q0 * lut_image_words(pq->m), probes + q0 * np, idx->d_part_off, np, split, k,
-                  partial + q0 * split * k, min_keys ? min_keys + q0 : nullptr);
+                  partial + q0 * split * k, min_keys ? min_keys + q0 : nullptr, desc);
     }
     return VG_OK;
 }
@@ -910,6 +910,113 @@ static int32_t launch_scan(const vg_index *idx, const float *tables, int64_t nq,
                            tables + q0 * lut_image_words(pq->m), slices, static_cast<int>(cnt), k,
                            partial + q0 * slices * (raw_lists ? kAdcWaves * 64 : k), raw_lists,
                            only_if ? only_if + q0 : nullptr);
+    }
+    return VG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// m above what one LDS image holds (fp32 table of m KiB: m > 96 with the top-k buffers; d = 1536 at 8 dims per
+// sub-quantizer is m = 192).  The table is walked in CHUNKS of up to 6 full groups (96 KiB): a workgroup takes a
+// batch of kWideTiles tiles per wave, keeps their 16 slot accumulators in registers, and for each chunk stages
+// that chunk's table rows into LDS and adds the chunk's groups for every tile of the batch.  Every row still
+// adds its groups in ascending order into the same 16 accumulators, so the sum is pqAdcLookupAvx512's.  The
+// table is re-staged once per batch (m KiB from L2 against kAdcWaves * kWideTiles * 64 * m bytes of codes: a
+// quarter of the code traffic at 4 tiles per wave).  k <= 64.
+// ---------------------------------------------------------------------------------------------
+constexpr int kWideTiles = 4;
+constexpr int kWideChunkGroups = 6;
+constexpr int kWideChunkWords = (kWideChunkGroups / 2) * 8192;
+
+__global__ __launch_bounds__(kAdcThreads) void pq_adc_scan_wide_kernel(
+    const uint4 *__restrict__ tiles, int64_t n_rows, int64_t n_tiles, int m, int groups,
+    const float *__restrict__ tables, int slices, int nq, int k, uint64_t *__restrict__ partial)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float *lut = reinterpret_cast<float *>(smem);                  // one chunk: [pair][c][32]
+    float *lut_tail = lut + kWideChunkWords;                       // m % 16 natural rows [j][c]
+    uint64_t *buf = reinterpret_cast<uint64_t *>(lut_tail + 15 * 256);
+    const int b = blockIdx.x;
+    const int xcd = b & 7, o = b >> 3;
+    const int q = o % nq;
+    const int s = (o / nq) * 8 + xcd;
+    const int64_t t0 = n_tiles * s / slices, t1 = n_tiles * (s + 1) / slices;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, rot = lane & 15;
+    const int gfull = m >> 4, tail = m & 15;
+    const int nchunks = gfull ? (gfull + kWideChunkGroups - 1) / kWideChunkGroups : 1;
+    const float *image = tables + static_cast<int64_t>(q) * lut_image_words(m);
+    const int tail_word = ((gfull + 1) >> 1) * 8192;
+    WaveTopK wtk;
+    wtk.init(k);
+    for (int64_t b0 = t0; b0 < t1; b0 += static_cast<int64_t>(kAdcWaves) * kWideTiles) {
+        float acc[kWideTiles][16];
+#pragma unroll
+        for (int tb = 0; tb < kWideTiles; tb++)
+#pragma unroll
+            for (int l = 0; l < 16; l++) acc[tb][l] = 0.0f;
+        for (int c = 0; c < nchunks; c++) {
+            const int g0 = c * kWideChunkGroups;
+            const int gc = gfull - g0 < kWideChunkGroups ? gfull - g0 : kWideChunkGroups;
+            __syncthreads();  // the previous chunk's lookups are done
+            {
+                const int words = ((gc + 1) >> 1) * 8192;
+                const float4 *src = reinterpret_cast<const float4 *>(image + (g0 >> 1) * 8192);
+                float4 *dst = reinterpret_cast<float4 *>(lut);
+                for (int i = tid; i < words / 4; i += kAdcThreads) dst[i] = src[i];
+                if (c == nchunks - 1 && tail) {
+                    const float4 *ts = reinterpret_cast<const float4 *>(image + tail_word);
+                    float4 *td = reinterpret_cast<float4 *>(lut_tail);
+                    for (int i = tid; i < tail * 64; i += kAdcThreads) td[i] = ts[i];
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int tb = 0; tb < kWideTiles; tb++) {
+                const int64_t tile = b0 + static_cast<int64_t>(tb) * kAdcWaves + wave;
+                if (tile < t1) {
+                    const uint4 *tp = tiles + (tile * groups) * 64 + lane;
+                    for (int g = 0; g < gc; g++) {
+                        const uint4 cw = tp[(g0 + g) * 64];
+#pragma unroll
+                        for (int sl = 0; sl < 16; sl++)
+                            acc[tb][sl] = acc[tb][sl] + lut[((g >> 1) * 256 + code_byte(cw, sl)) * 32 + (g & 1) * 16 + ((sl + rot) & 15)];
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int tb = 0; tb < kWideTiles; tb++) {
+            const int64_t tile = b0 + static_cast<int64_t>(tb) * kAdcWaves + wave;
+            uint64_t key = kKeyMax;
+            if (tile < t1) {
+                float total = reduce16_regs(acc[tb]);
+                if (tail) {
+                    const uint4 cw = tiles[(tile * groups + gfull) * 64 + lane];
+                    for (int l = 0; l < tail; l++) total = total + lut_tail[l * 256 + code_byte(cw, l)];
+                }
+                const int64_t row = tile * 64 + lane;
+                if (row < n_rows) key = make_key(total, static_cast<uint32_t>(row), false);
+            }
+            wtk.offer(key, lane);
+        }
+    }
+    __syncthreads();
+    uint64_t *out = partial + (static_cast<int64_t>(q) * slices + s) * k;
+    wg_rank_merge<kAdcWaves>(wtk, buf, reinterpret_cast<int *>(buf + kAdcWaves * 64), wave, lane, tid, k, out);
+}
+
+static int32_t launch_scan_wide(const vg_index *idx, const float *tables, int64_t nq, int k, int slices,
+                                uint64_t *partial, hipStream_t st)
+{
+    const size_t lds = (kWideChunkWords + 15 * 256) * sizeof(float) + kAdcWaves * 64 * sizeof(uint64_t) + 64;
+    VG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(pq_adc_scan_wide_kernel),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+    const int64_t max_q = (1ll << 30) / slices;
+    for (int64_t q0 = 0; q0 < nq; q0 += max_q) {
+        const int64_t cnt = nq - q0 < max_q ? nq - q0 : max_q;
+        ProfScope prof(idx->ctx, "pq_adc_scan", st);
+        VG_LAUNCH(pq_adc_scan_wide_kernel, dim3(static_cast<unsigned>(cnt * slices)), dim3(kAdcThreads), lds, st,
+                  reinterpret_cast<const uint4 *>(idx->d_pq_tiles), idx->n, idx->n_tiles, idx->pq->m, idx->pq_groups,
+                  tables + q0 * lut_image_words(idx->pq->m), slices, static_cast<int>(cnt), k, partial + q0 * slices * k);
     }
     return VG_OK;
 }
@@ -1078,8 +1185,10 @@ VG_API int32_t vg_search_pq_adc(vg_index *idx, const float *queries, int64_t nq,
     VG_CHECK(pq->k == 256, VG_ERR_UNSUPPORTED,
              "vg_search_pq_adc: LUT scan needs numCentroids == 256 (got %d)", pq->k);
     size_t lds = static_cast<size_t>(vg::lut_image_words(pq->m)) * 4 + vg::kAdcBuf * 8 + sizeof(vg::AdcShared);
-    VG_CHECK(lds <= 160 * 1024, VG_ERR_UNSUPPORTED,
-             "vg_search_pq_adc: m=%d lookup table does not fit the 160 KiB LDS", pq->m);
+    // a table beyond one LDS image (m > 96 at fp32) is walked in 96 KiB chunks: pq_adc_scan_wide_kernel, k <= 64
+    const bool wide = lds > 160 * 1024;
+    VG_CHECK(!wide || k <= 64, VG_ERR_UNSUPPORTED,
+             "vg_search_pq_adc: m=%d lookup table does not fit the 160 KiB LDS; the chunked scan takes k <= 64", pq->m);
     VG_HIP(hipSetDevice(idx->ctx->device));
     hipStream_t st = vg::pick_stream(idx->ctx, stream);
 
@@ -1145,7 +1254,9 @@ VG_API int32_t vg_search_pq_adc(vg_index *idx, const float *queries, int64_t nq,
         // The A/B-skewed scan is conflict-free in LDS but, as compiled today, spends ~7 VALU ops per
         // lookup on lane-dependent address selects and is VALU-bound (70k vs 80k queries/s at
         // 1M x 96 B); it stays opt-in until its address arithmetic is cut down.
-        if (pq->m == 96 && k <= 64 && vg::hook(vg::kHookAdcSkew))
+        if (wide)
+            VG_TRY(vg::launch_scan_wide(idx, tables.ptr, nq, k, slices, partial.ptr, st));
+        else if (pq->m == 96 && k <= 64 && vg::hook(vg::kHookAdcSkew))
             VG_TRY(vg::launch_scan96(idx, tables.ptr, nq, k, slices, partial.ptr, st));
         else if (pq->m == 96 && k <= 64)
             VG_TRY((vg::launch_scan<6, true>(idx, tables.ptr, nq, k, slices, partial.ptr, st)));

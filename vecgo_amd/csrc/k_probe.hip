@@ -21,7 +21,7 @@ int32_t launch_topk_merge(const uint64_t *partial, int64_t nq, int lists, int k,
 int32_t launch_pq_build_table(const vg_pq *pq, const float *d_queries, int64_t nq, float *d_tables,
                               bool scan_layout, hipStream_t st);
 int32_t launch_probe_scan_adc(const vg_index *idx, const float *tables, const uint32_t *probes, int64_t nq, int np,
-                              int split, int k, uint64_t *partial, const uint64_t *min_keys, hipStream_t st);
+                              int split, int k, uint64_t *partial, const uint64_t *min_keys, bool desc, hipStream_t st);
 int32_t launch_probe_scan_sq8(const vg_index *idx, const float *queries, const uint32_t *probes, int64_t nq, int np,
                               int sub, int k, uint64_t *partial, const uint64_t *min_keys, hipStream_t st);
 int32_t launch_probe_scan_sq8_grouped(const vg_index *idx, const float *queries, const uint32_t *pair_of,
@@ -371,7 +371,9 @@ VG_API int32_t vg_search_flat_probed(vg_index *idx, const float *queries, int64_
     else
         VG_LAUNCH(vg::probe_select_kernel<false>, dim3(static_cast<unsigned>(nq)), dim3(256), 0, st, q.ptr, idx->dim,
                   idx->d_centroids, idx->num_partitions, np, probes);
-    const bool desc = scan != VG_SCAN_PQ && dot;  // table-lookup scores are squared L2 (ascending); fp32 and SQ8 follow the metric
+    // the heap direction follows the segment metric for EVERY scan (flat/segment.go:449): with Dot / Cosine a PQ
+    // scan therefore keeps the k LARGEST table-lookup (squared-L2) distances — the reference as written
+    const bool desc = dot;
     const size_t mq_lds = sizeof(float) * vg::kProbeQB * static_cast<size_t>(idx->dim) + 4 * 64 * sizeof(uint64_t) + 64;
     auto mq_kern = dot ? vg::probe_scan_f32_mq_kernel<true> : vg::probe_scan_f32_mq_kernel<false>;
     if (grouped_f32)
@@ -412,7 +414,7 @@ VG_API int32_t vg_search_flat_probed(vg_index *idx, const float *queries, int64_
                           idx->d_part_off, np, sub, kk, partial + q0 * lists * kk, floor ? floor + q0 : nullptr);
             }
         } else if (scan == VG_SCAN_PQ) {
-            VG_TRY(vg::launch_probe_scan_adc(idx, tables, probes, nq, np, split, kk, partial, floor, st));
+            VG_TRY(vg::launch_probe_scan_adc(idx, tables, probes, nq, np, split, kk, partial, floor, desc, st));
         } else {
             VG_TRY(vg::launch_probe_scan_sq8(idx, q.ptr, probes, nq, np, sub, kk, partial, floor, st));
         }

@@ -228,11 +228,8 @@ VG_API int32_t vg_segment_search(vg_segment *seg, const float *queries, int64_t 
     if (seg->info.quantization == VG_QUANT_SQ8) {
         scan = VG_SCAN_SQ8;
     } else if (seg->info.quantization == VG_QUANT_PQ) {
-        // the reference's heap direction follows the segment metric (segment.go:449) while AdcDistance is
-        // always a squared L2: a Dot / Cosine PQ segment keeps its k FARTHEST rows there.  Not reproduced.
-        VG_CHECK(seg->info.metric == VG_METRIC_L2, VG_ERR_UNSUPPORTED,
-                 "vg_segment_search: PQ segment with metric %d (the reference keeps the largest ADC distances)",
-                 seg->info.metric);
+        // the reference's heap direction follows the segment metric (segment.go:449) while AdcDistance is always a
+        // squared L2: a Dot / Cosine PQ segment keeps its k largest ADC distances there — and here
         scan = VG_SCAN_PQ;
     }
     return vg_search_flat_probed(seg->idx, queries, nq, k, nprobes, scan, ids, scores, stream);
