@@ -164,27 +164,9 @@ def adc_scan_roofline(vg, ctx, stream, device, with_cpu=False):
                      (rng.random(m) * 0.02 + 0.005).astype(np.float32), np.zeros(m, np.float32))
     idx = vg.Index(ctx, n, DIM)
     idx.set_pq_codes(pq, codes)
-    cpu = None
-    if with_cpu:  # flat.Segment.Search's PQ branch on the host: BuildDistanceTable + pqAdcLookupAvx512 per row
-        from oracle import oracle as o
-        opq = o.ProductQuantizer(DIM, m, 256)
-        opq.set_codebooks(*[np.asarray(x) for x in pq.codebooks()])
-        ic = o.InterleavedCopy(codes.cpu().numpy())
-        try:
-            qh = np.random.default_rng(3).standard_normal((effective_cpus(), DIM)).astype(np.float32)
-            r = cpu_leg(o.BENCH_ADC, qh, K, 5.0, pq=opq, codes=ic.array, n=n, want_ids=True)
-            gi, _ = idx.search_pq_adc(torch.from_numpy(qh[:4]).to(device), K)
-            gi = gi.cpu().numpy().view(np.uint32)
-            filled = [i for i in range(4) if r["dist_comps"][i] >= 0]
-            cpu = {"qps": r["qps"], "cores": r["cores"], "kind": r["kind"], "queries": r["queries"], "seconds": r["seconds"],
-                   "scan_gbs": r["queries"] * n * m / r["seconds"] / 1e9, "numa_interleave_nodes": ic.numa_nodes,
-                   "ids_equal_gpu": bool(filled) and all(np.array_equal(r["ids"][i], gi[i]) for i in filled)}
-        finally:
-            ic.close()
-    del codes
     q = torch.randn((1, DIM), device=device)
     out = (torch.empty((1, K), dtype=torch.int32, device=device), torch.empty((1, K), device=device))
-    for _ in range(5):
+    for _ in range(200):   # ~50 ms: an idle GPU needs more than a handful of launches to reach its clocks
         idx.search_pq_adc(q, K, out=out, stream=stream)
     torch.cuda.synchronize()
     ctx.profile_read("pq_adc_scan")
@@ -205,6 +187,24 @@ def adc_scan_roofline(vg, ctx, stream, device, with_cpu=False):
            "kernel": "pq_adc_scan_kernel<6,true,true>", "kernel_ms": kern_ms,
            "bytes_per_launch": n * m, "search_call_ms": e0.elapsed_time(e1) / reps,
            "qps_single_query_passes": 1e3 / (e0.elapsed_time(e1) / reps)}
+    cpu = None
+    if with_cpu:  # flat.Segment.Search's PQ branch on the host: BuildDistanceTable + pqAdcLookupAvx512 per row
+        from oracle import oracle as o
+        opq = o.ProductQuantizer(DIM, m, 256)
+        opq.set_codebooks(*[np.asarray(x) for x in pq.codebooks()])
+        ic = o.InterleavedCopy(codes.cpu().numpy())
+        try:
+            qh = np.random.default_rng(3).standard_normal((effective_cpus(), DIM)).astype(np.float32)
+            r = cpu_leg(o.BENCH_ADC, qh, K, 5.0, pq=opq, codes=ic.array, n=n, want_ids=True)
+            gi, _ = idx.search_pq_adc(torch.from_numpy(qh[:4]).to(device), K)
+            gi = gi.cpu().numpy().view(np.uint32)
+            filled = [i for i in range(4) if r["dist_comps"][i] >= 0]
+            cpu = {"qps": r["qps"], "cores": r["cores"], "kind": r["kind"], "queries": r["queries"], "seconds": r["seconds"],
+                   "scan_gbs": r["queries"] * n * m / r["seconds"] / 1e9, "numa_interleave_nodes": ic.numa_nodes,
+                   "ids_equal_gpu": bool(filled) and all(np.array_equal(r["ids"][i], gi[i]) for i in filled)}
+        finally:
+            ic.close()
+    del codes
     if cpu:
         res["cpu"] = cpu
     idx.close()
@@ -222,7 +222,7 @@ def flat_small_batch(vg, ctx, idx, queries, stream):
             ("flat_gemm", "flat_gemm_dma32_kernel<false,2>")
         q = queries[:nq].contiguous()
         out = (torch.empty((nq, K), dtype=torch.int32, device=q.device), torch.empty((nq, K), device=q.device))
-        for _ in range(3):
+        for _ in range(60):
             idx.search_flat(q, K, out=out, stream=stream)
         torch.cuda.synchronize()
         ctx.profile_read(label)
@@ -255,6 +255,29 @@ def rabitq_scan_roofline(vg, ctx, stream, device, with_cpu=False):
     codes[:, cb - 4:] = (torch.rand(n, device=device, generator=g) * 5 + 25).view(torch.uint8).reshape(n, 4)
     idx = vg.Index(ctx, n, DIM)
     idx.set_rabitq_codes(codes)
+    q = torch.randn((1, DIM), device=device)
+    out = (torch.empty((1, K), dtype=torch.int32, device=device), torch.empty((1, K), device=device))
+    for _ in range(200):
+        idx.search_rabitq(q, K, out=out, stream=stream)
+    torch.cuda.synchronize()
+    ctx.profile_read("rabitq_scan")
+    ctx.profile_enable(True)
+    reps = 20
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(stream)
+    for _ in range(reps):
+        idx.search_rabitq(q, K, out=out, stream=stream)
+    e1.record(stream)
+    torch.cuda.synchronize()
+    launches, ms = ctx.profile_read("rabitq_scan")
+    ctx.profile_enable(False)
+    kern_ms = ms / max(launches, 1)
+    achieved = n * cb / (kern_ms * 1e-3) / 1e9
+    res = {"workload": "rabitq_scan_10Mx768_100B_k10_nq1", "bound": "hbm", "achieved": achieved,
+           "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": achieved / PEAK_HBM_GBS,
+           "traffic": measured_traffic("rabitq_scan"), "kernel": "rabitq_scan_kernel", "kernel_ms": kern_ms,
+           "bytes_per_launch": n * cb, "search_call_ms": e0.elapsed_time(e1) / reps,
+           "qps_single_query_passes": 1e3 / (e0.elapsed_time(e1) / reps)}
     cpu = None
     if with_cpu:  # rq.Distance per row (rabitq.go:119-176: query norm + sign-pack recomputed per call, hammingAvx512)
         from oracle import oracle as o
@@ -280,29 +303,6 @@ def rabitq_scan_roofline(vg, ctx, stream, device, with_cpu=False):
             ic.close()
             sidx.close()
     del codes
-    q = torch.randn((1, DIM), device=device)
-    out = (torch.empty((1, K), dtype=torch.int32, device=device), torch.empty((1, K), device=device))
-    for _ in range(5):
-        idx.search_rabitq(q, K, out=out, stream=stream)
-    torch.cuda.synchronize()
-    ctx.profile_read("rabitq_scan")
-    ctx.profile_enable(True)
-    reps = 20
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record(stream)
-    for _ in range(reps):
-        idx.search_rabitq(q, K, out=out, stream=stream)
-    e1.record(stream)
-    torch.cuda.synchronize()
-    launches, ms = ctx.profile_read("rabitq_scan")
-    ctx.profile_enable(False)
-    kern_ms = ms / max(launches, 1)
-    achieved = n * cb / (kern_ms * 1e-3) / 1e9
-    res = {"workload": "rabitq_scan_10Mx768_100B_k10_nq1", "bound": "hbm", "achieved": achieved,
-           "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": achieved / PEAK_HBM_GBS,
-           "traffic": measured_traffic("rabitq_scan"), "kernel": "rabitq_scan_kernel", "kernel_ms": kern_ms,
-           "bytes_per_launch": n * cb, "search_call_ms": e0.elapsed_time(e1) / reps,
-           "qps_single_query_passes": 1e3 / (e0.elapsed_time(e1) / reps)}
     if cpu:
         res["cpu"] = cpu
     idx.close()
@@ -323,7 +323,7 @@ def sq8_scan_roofline(vg, ctx, stream, device):
     del codes
     q = torch.randn((1, DIM), device=device)
     out = (torch.empty((1, K), dtype=torch.int32, device=device), torch.empty((1, K), device=device))
-    for _ in range(3):
+    for _ in range(40):
         idx.search_sq8(q, K, out=out, stream=stream)
     torch.cuda.synchronize()
     ctx.profile_read("sq8_scan")
@@ -340,7 +340,7 @@ def sq8_scan_roofline(vg, ctx, stream, device):
     kern_ms = ms / max(launches, 1)
     achieved = n * DIM / (kern_ms * 1e-3) / 1e9
     res = {"workload": "sq8_scan_4Mx768_k10_nq1", "bound": "hbm", "achieved": achieved, "peak": PEAK_HBM_GBS,
-           "unit": "GB/s", "frac": achieved / PEAK_HBM_GBS, "traffic": None, "kernel": "sq8_scan_kernel",
+           "unit": "GB/s", "frac": achieved / PEAK_HBM_GBS, "traffic": measured_traffic("sq8_scan"), "kernel": "sq8_scan_kernel",
            "kernel_ms": kern_ms, "bytes_per_launch": n * DIM, "search_call_ms": e0.elapsed_time(e1) / reps}
     idx.close()
     sq.close()
@@ -446,7 +446,9 @@ def hnsw_pq_frontier(vg, ctx, rows, queries, gt_ids, exact_ms_per_1024, stream, 
     e128 = f32[0]
     rep128 = {"workload": f"hnsw_ef128_1Mx768_k10 on the built graph (M0 = {2 * HNSW_M}), {q.shape[0]} queries in flight",
               "bound": "hbm", "achieved": e128["gathered_gbs"], "peak": PEAK_HBM_GBS, "unit": "GB/s",
-              "frac": e128["gathered_gbs"] / PEAK_HBM_GBS, "traffic": None, "kernel": "hnsw_search_kernel<false>",
+              "frac": e128["gathered_gbs"] / PEAK_HBM_GBS,
+              "traffic": measured_traffic("hnsw_search", e128["gathered_gbs"] * 1e9 * e128["kernel_ms"] * 1e-3),
+              "kernel": "hnsw_search_kernel<false>",
               "kernel_ms": e128["kernel_ms"], "bytes_per_launch": e128["gathered_gbs"] * 1e9 * e128["kernel_ms"] * 1e-3,
               "recall_at_10": e128["recall_at_10"],
               "distance_computations_per_query": e128["distance_computations_per_query"],
@@ -636,12 +638,15 @@ def multi_gpu_legs(vg, ctx, sharded, world, rank, device, stream, comm):
     return out
 
 
-def measured_traffic(key: str):
-    """HBM bytes per launch from the committed PMC passes (profiles/r01_traffic.json: rocprofv3
-    --pmc FETCH_SIZE / WRITE_SIZE, gfx950 correction applied).  PMC counters cannot be read from
-    inside this process; the file names the exact commands."""
+def measured_traffic(key: str, algorithmic_bytes: float = None):
+    """HBM bytes per launch from the committed PMC passes (profiles/r02_traffic.json: rocprofv3 --pmc FETCH_SIZE /
+    WRITE_SIZE by tools/collect_pmc.sh, gfx950 correction applied).  PMC counters cannot be read from inside this
+    process.  Where the PMC run used another launch size than this bench (graph searches: a 200k-row graph), the
+    measured traffic per algorithmic byte is applied to this launch's algorithmic bytes."""
     try:
-        t = json.loads((ROOT / "profiles" / "r01_traffic.json").read_text())[key]
+        t = json.loads((ROOT / "profiles" / "r02_traffic.json").read_text())[key]
+        if algorithmic_bytes is not None:
+            return float(t["traffic_per_algorithmic_byte"]) * float(algorithmic_bytes)
         return float(t["traffic_bytes"])
     except Exception:
         return None
