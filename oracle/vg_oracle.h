@@ -22,6 +22,11 @@
  * an unseeded RNG or an unspecified order: trained codebooks, built graphs, the
  * order of equal-distance candidates in robustPrune.
  *
+ * Files: vg_oracle.c (kernels, quantizers, heaps, scans, searches), vg_oracle_hnsw_build.c (hnsw.Insert),
+ * vg_oracle_opq.c (opq.go, svd.go), vg_cpu_bench.c (the C-threaded harness behind bench.py's CPU twins and the
+ * full-size replays; with vgo_set_kernel_hooks the timed loops call the REFERENCE's compiled kernels from
+ * oracle/_ref — bit-identical to the restatements, see tests/test_oracle_golden.py).
+ *
  * Build: gcc/clang, -ffp-contract=off (every FMA below is an explicit
  * __builtin_fmaf; everything else is a separately rounded IEEE fp32 op).
  */
