@@ -399,7 +399,7 @@ def hnsw_pq_frontier(vg, ctx, rows, queries, gt_ids, exact_ms_per_1024, stream, 
 
     f32 = []
     for ef in EFS_F32:
-        ids, _, st = idx.search_hnsw(q, K, ef, stats=True, stream=stream)
+        ids, _, st = idx.search_hnsw(q, K, ef, stats="full", stream=stream)
         ctx.profile_read("hnsw_search")
         ctx.profile_enable(True)
         ms = timed(lambda: idx.search_hnsw(q, K, ef, stream=stream))
@@ -409,7 +409,10 @@ def hnsw_pq_frontier(vg, ctx, rows, queries, gt_ids, exact_ms_per_1024, stream, 
         f32.append({"ef": ef, "recall_at_10": recall_at_k(ids.cpu().numpy().view(np.uint32)[:nrec], gt_ids),
                     "qps": q.shape[0] / (ms * 1e-3), "ms_per_1024": ms * 1024 / q.shape[0], "kernel_ms": kern_ms,
                     "distance_computations_per_query": dc, "pops_per_query": float(st[:, 3].mean()),
-                    "gathered_gbs": (float(st[:, 1].sum()) * DIM * 4 + float(st[:, 3].sum()) * 2 * HNSW_M * 4) / (kern_ms * 1e-3) / 1e9})
+                    "descent_distance_computations_per_query": float(st[:, 4].mean()),
+                    # rows scored = layer-0 DistanceComputations + the descent's (uncounted by the reference's stats)
+                    "gathered_gbs": ((float(st[:, 1].sum()) + float(st[:, 4].sum())) * DIM * 4
+                                     + float(st[:, 3].sum()) * 2 * HNSW_M * 4) / (kern_ms * 1e-3) / 1e9})
     pqr = []
     for ef in EFS_PQ:
         cand, _, st = idx.search_hnsw_pq(q, ef, ef, stats=True, stream=stream)

@@ -188,7 +188,7 @@ int32_t vg_hamming_batch(vg_ctx *ctx, const uint8_t *a, const uint8_t *codes, in
 
 /* Test hooks (process-wide): force an alternative path so that tests can compare the paths bit for bit.
  * Names: VG_FLAT_NO_SMALL_TILE, VG_FLAT_UNFUSED, VG_FLAT_NO_SCAN, VG_FLAT_FORCE_EXACT, VG_FLAT_NO_DMA,
- * VG_FLAT_DEBUG, VG_PROBE_NO_GROUP, VG_ADC_BIGK_EXHAUSTIVE, VG_ADC_SKEW.  The environment variable of the same
+ * VG_FLAT_DEBUG, VG_PROBE_NO_GROUP, VG_ADC_BIGK_EXHAUSTIVE, VG_ADC_SKEW, VG_BUILD_DEBUG.  The environment variable of the same
  * name ("1") gives the initial value, read once; the search entry points never call getenv. */
 int32_t vg_debug_set_hook(const char *name, int32_t on);
 
@@ -494,6 +494,9 @@ uint32_t vg_crc32c(const void *data, int64_t size);
  * search that followed the reference exactly. */
 typedef struct vg_search_stats {
     int64_t nodes_visited, distance_computations, distance_short_circuits, pops;
+    /* not a FilterGateStats field: rows scored by greedySearch on the way down through the upper layers
+     * (hnsw.go:1897-1934 does not count them) — part of a query's gathered bytes all the same */
+    int64_t descent_distance_computations;
 } vg_search_stats;
 
 /* hnsw.KNNSearch (hnsw.go:1650-1755): greedySearch through the upper layers (:1897-1934), then

@@ -988,14 +988,16 @@ class Index:
         scores = _empty_like(queries, (nq, k), np.float32)
         i, pi = _ptr(ids, np.uint32)
         s_, ps = _ptr(scores, np.float32)
-        stats = np.zeros((nq, 4), np.int64) if want_stats else None
+        stats = np.zeros((nq, 5), np.int64) if want_stats else None
         pst = C.c_void_p(stats.ctypes.data) if want_stats else None
         check(fn(self._h, pq_, C.c_int64(nq), C.c_int32(k), C.c_int32(mid_arg), pi, ps, pst, _stream_ptr(stream)))
+        if want_stats and want_stats != "full":
+            stats = stats[:, :4]     # the reference's FilterGateStats columns; "full" adds descent_distance_computations
         return (ids, scores, stats) if want_stats else (ids, scores)
 
     def search_hnsw(self, queries, k, ef, stats=False, stream=None):
         """hnsw.KNNSearch (hnsw.go:1650-1755); stats columns: nodes_visited,
-        distance_computations, distance_short_circuits, pops."""
+        distance_computations, distance_short_circuits, pops (stats="full": + rows scored by the descent)."""
         return self._graph_search(self._lib.vg_search_hnsw, queries, k, ef, stats, stream)
 
     def search_hnsw_pq(self, queries, k, ef, stats=False, stream=None):

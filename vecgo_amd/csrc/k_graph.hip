@@ -63,12 +63,13 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(
     // ---- greedySearch through the upper layers --------------------------------------------------
     uint32_t cur = entry;
     float cur_d = sc.one(cur);
+    int64_t st_descent = 1;
     for (int level = max_level; level > 0; level--) {
         auto row_of = [&](uint32_t node) -> const uint32_t * {
             const uint32_t slot = slots[static_cast<int64_t>(level - 1) * n + node];
             return slot == VG_INVALID_ID ? nullptr : adj + (level_off[level - 1] + slot) * m;
         };
-        greedy_layer(sc, lane, row_of, m, nb_pair, nb_bnd, cur, cur_d);
+        greedy_layer(sc, lane, row_of, m, nb_pair, nb_bnd, cur, cur_d, &st_descent);
     }
 
     // ---- searchLayerUnfiltered on layer 0 ---------------------------------------------------------
@@ -96,6 +97,7 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(
         stats[q].distance_computations = st.dc;
         stats[q].distance_short_circuits = st.sc;
         stats[q].pops = st.pops;
+        stats[q].descent_distance_computations = st_descent;
     }
 }
 
@@ -319,6 +321,7 @@ __global__ __launch_bounds__(64) void vamana_search_kernel(
         stats[q].distance_computations = st_dc;
         stats[q].distance_short_circuits = st_dropped;
         stats[q].pops = st_pops;
+        stats[q].descent_distance_computations = 0;
     }
 }
 

@@ -13,8 +13,9 @@
 //   2. build_select_kernel   one workgroup per (node, level): selectNeighborsHeuristic over the list; the
 //                            node's own row is written, and one back-link record per chosen neighbour.
 //   3. build_count / offsets / fill kernels group the back-link records by target row;
-//      build_link_kernel     one wavefront per target row applies its records in id order: append while
-//                            the row has room (addConnectionSimple), else addConnectionPrune.
+//      build_link_kernel     one workgroup (4 waves) per target row applies its records in id order: append while
+//                            the row has room (addConnectionSimple), else addConnectionPrune; the four waves share
+//                            the 64 pair distances of a link, wave 0 keeps the row.
 //
 // What makes addConnectionPrune affordable: a row keeps, next to the ids and the cached distances the
 // reference keeps (node.go Neighbor{ID, Dist}), a 64 x 64 BIT matrix: bit j of bits[i] = "d(c_i, c_j) <
@@ -51,6 +52,7 @@ struct BuildGraph {
     float *dist;      // d(row's node, member) as the insert search computed it
     uint64_t *bits;   // bit j of bits[slot i]: d(member i, member j) < dist[i]
     int32_t *cnt;     // per row
+    uint8_t *good;    // per row: full, and every member was CHOSEN by the heuristic (none filled up): see build_link_kernel
     const uint32_t *slots;
     const int64_t *level_off;
 };
@@ -279,31 +281,59 @@ __global__ __launch_bounds__(kSelThreads) void build_select_kernel(BuildGraph g,
         }
     }
     for (int i = m + tid; i < rec_stride; i += kSelThreads) rec_row[p * rec_stride + i] = VG_INVALID_ID;
-    if (tid == 0) g.cnt[row] = nf;
+    if (tid == 0) {
+        g.cnt[row] = nf;
+        g.good[row] = nf == m && nsel == m ? 1 : 0;
+    }
 }
 
 // ---- 3. back links ---------------------------------------------------------------------------------
 struct LinkCounters {
     unsigned int nwork, total;
 };
+struct LinkTotals {  // over the whole build (VG_BUILD_DEBUG prints them)
+    unsigned long long records, skipped, appended, pruned, good_rows_seen, longest_chain;
+};
 
+// Both kernels append to ONE counter: a per-thread atomicAdd on it would serialise ~400 k atomics per batch on one
+// L2 line (measured: most of the back-link stage).  The lanes of a wave are counted with a ballot / summed with a
+// shuffle scan and the wave does one atomicAdd.
 __global__ void build_count_kernel(const uint32_t *__restrict__ rec_row, int64_t nrec, int32_t *__restrict__ rcnt,
                                    uint32_t *__restrict__ work, LinkCounters *__restrict__ ctr)
 {
     const int64_t r = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (r >= nrec) return;
-    const uint32_t row = rec_row[r];
-    if (row == VG_INVALID_ID) return;
-    if (atomicAdd(&rcnt[row], 1) == 0) work[atomicAdd(&ctr->nwork, 1u)] = row;
+    const int lane = threadIdx.x & 63;
+    uint32_t row = VG_INVALID_ID;
+    if (r < nrec) row = rec_row[r];
+    const bool first = row != VG_INVALID_ID && atomicAdd(&rcnt[row], 1) == 0;  // the row's first record this batch
+    const uint64_t m = __ballot(first);
+    if (m == 0) return;
+    unsigned int base = 0;
+    if (lane == __builtin_ctzll(m)) base = atomicAdd(&ctr->nwork, static_cast<unsigned int>(__popcll(m)));
+    base = __shfl(base, __builtin_ctzll(m));
+    if (first) work[base + __popcll(m & ((1ull << lane) - 1))] = row;
 }
 
 __global__ void build_offsets_kernel(const uint32_t *__restrict__ work, const int32_t *__restrict__ rcnt,
                                      uint32_t *__restrict__ roff, LinkCounters *__restrict__ ctr)
 {
     const unsigned int w = blockIdx.x * blockDim.x + threadIdx.x;
-    if (w >= ctr->nwork) return;
-    const uint32_t row = work[w];
-    roff[row] = atomicAdd(&ctr->total, static_cast<unsigned int>(rcnt[row]));
+    const int lane = threadIdx.x & 63;
+    const bool live = w < ctr->nwork;
+    const uint32_t row = live ? work[w] : 0;
+    const unsigned int mine = live ? static_cast<unsigned int>(rcnt[row]) : 0u;
+    unsigned int incl = mine;  // inclusive scan over the wave
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const unsigned int up = __shfl_up(incl, d);
+        if (lane >= d) incl += up;
+    }
+    const unsigned int total = __shfl(incl, 63);
+    if (total == 0) return;
+    unsigned int base = 0;
+    if (lane == 63) base = atomicAdd(&ctr->total, total);
+    base = __shfl(base, 63);
+    if (live) roff[row] = base + incl - mine;
 }
 
 __global__ void build_fill_kernel(const uint32_t *__restrict__ rec_row, const uint32_t *__restrict__ rec_t,
@@ -328,20 +358,40 @@ struct LinkShared {
     uint32_t cid[65];
     int seq[65];           // candidates in the order extractSortedCandidates would give (nearest first)
     int newpos[65];        // their slot after the prune, -1 = dropped
+    uint32_t mid[64];      // the row's member ids, for the scoring waves
+    uint32_t t;            // the record being applied
+    int action;            // 0 = nothing to score for this record, 1 = score the new node against the members
+    int cnt;
 };
 
-// one wavefront per target row: the row's records in ascending id of the new node (the order a sequential
-// pass over the batch applies them), each one = addConnection (hnsw.go:455-499)
-__global__ __launch_bounds__(64) void build_link_kernel(BuildGraph g, const uint32_t *__restrict__ work,
-                                                        const LinkCounters *__restrict__ ctr,
-                                                        int32_t *__restrict__ rcnt, int32_t *__restrict__ rfill,
-                                                        const uint32_t *__restrict__ roff,
-                                                        const uint32_t *__restrict__ srt_t,
-                                                        const float *__restrict__ srt_d)
+constexpr int kLinkWaves = 4;
+constexpr int kLinkThreads = kLinkWaves * 64;
+
+// LDS hand-over inside ONE wave (the bookkeeping wave below): its LDS instructions execute in order, so all it takes
+// is that the compiler does not move them across this point
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// One workgroup of four waves per target row: the row's records in ascending id of the new node (the order a
+// sequential pass over the batch applies them), each one = addConnection (hnsw.go:455-499).  Wave 0 keeps the row
+// (lane i = slot i: id, cached distance, bit row) and does the bookkeeping; for a record that needs them, the 64
+// distances between the new node and the row's members are scored by all four waves at once (16 members each, 4
+// rows in flight per wave).  A row's records are a serial chain — a hub row (near to very many nodes, as
+// high-dimensional data has them) can receive thousands per batch — so what counts is the latency of one link.
+__global__ __launch_bounds__(kLinkThreads) void build_link_kernel(BuildGraph g, const uint32_t *__restrict__ work,
+                                                                  const LinkCounters *__restrict__ ctr,
+                                                                  int32_t *__restrict__ rcnt, int32_t *__restrict__ rfill,
+                                                                  const uint32_t *__restrict__ roff,
+                                                                  const uint32_t *__restrict__ srt_t,
+                                                                  const float *__restrict__ srt_d,
+                                                                  uint32_t *__restrict__ ord, LinkTotals *__restrict__ totals)
 {
     __shared__ LinkShared sh;
     if (blockIdx.x >= ctr->nwork) return;
-    const int lane = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const Sub16 sub = Sub16::make(lane);
     const int64_t row = work[blockIdx.x];
     const int64_t off = bg_off(g, row);
@@ -349,155 +399,216 @@ __global__ __launch_bounds__(64) void build_link_kernel(BuildGraph g, const uint
     const int nadd = rcnt[row];
     const uint32_t *at = srt_t + roff[row];
     const float *ad = srt_d + roff[row];
-    int cnt = g.cnt[row];
-    uint32_t id = lane < deg ? g.ids[off + lane] : VG_INVALID_ID;
-    float dist = lane < deg ? g.dist[off + lane] : 0.0f;
-    uint64_t bits = lane < deg ? g.bits[off + lane] : 0;
+    uint32_t *my_ord = ord + roff[row];
+    // the records in ascending t (distinct per row): rank sort by the whole workgroup, once
+    for (int i = tid; i < nadd; i += kLinkThreads) {
+        const uint32_t ti = at[i];
+        int rank = 0;
+        for (int j = 0; j < nadd; j++) rank += at[j] < ti ? 1 : 0;
+        my_ord[rank] = static_cast<uint32_t>(i);
+    }
+    __threadfence_block();
+    __syncthreads();
 
-    uint64_t last = 0;  // (t + 1) of the record applied last; records of a row have distinct t
+    // row state: wave 0 only
+    int cnt = 0;
+    uint32_t id = VG_INVALID_ID;
+    float dist = 0.0f;
+    uint64_t bits = 0;
+    bool good = false, ties = false;
+    unsigned int n_skip = 0, n_app = 0, n_prune = 0;
+    auto row_has_ties = [&]() {
+        const float nxt = __shfl_down(dist, 1);
+        return __ballot(lane + 1 < cnt && dist == nxt) != 0;
+    };
+    if (wave == 0) {
+        cnt = g.cnt[row];
+        id = lane < deg ? g.ids[off + lane] : VG_INVALID_ID;
+        dist = lane < deg ? g.dist[off + lane] : 0.0f;
+        bits = lane < deg ? g.bits[off + lane] : 0;
+        // The cheap way out.  `good` = the row is full and applyHeuristic CHOSE every member (nothing was filled up),
+        // so the row is in ascending distance order.  A new node farther than the farthest member then sorts last, the
+        // heuristic re-chooses the 64 members, stops (len(result) >= m, hnsw.go:1054) and never looks at the newcomer:
+        // the row is left exactly as it is — unless two members are equally far, in which case the reference's heap
+        // may hand them back in another order, so rows with ties take the long way.  75 % of the back links of the
+        // 1M x 768 build end here.
+        good = g.good[row] != 0;
+        ties = row_has_ties();
+        sh.mid[lane] = id;
+    }
+
     for (int a = 0; a < nadd; a++) {
-        // next record in ascending t
-        uint64_t best = kKeyMax;
-        for (int i = lane; i < nadd; i += 64) {
-            const uint64_t key = ((static_cast<uint64_t>(at[i]) + 1) << 32) | static_cast<uint32_t>(i);
-            if ((key >> 32) > last && key < best) best = key;
-        }
-#pragma unroll
-        for (int s = 32; s > 0; s >>= 1) {
-            const uint32_t lo = __shfl_xor(static_cast<uint32_t>(best), s);
-            const uint32_t hi = __shfl_xor(static_cast<uint32_t>(best >> 32), s);
-            const uint64_t o = (static_cast<uint64_t>(hi) << 32) | lo;
-            best = o < best ? o : best;
-        }
-        last = best >> 32;
-        const uint32_t t = at[static_cast<uint32_t>(best)];
-        const float dt = ad[static_cast<uint32_t>(best)];
-        if (__ballot(lane < cnt && id == t)) continue;  // already connected (hnsw.go:477-486)
-
-        // distances between the new node and the row's members
-        uint64_t mask = cnt >= 64 ? ~0ull : ((1ull << cnt) - 1);
-        while (mask) {
-            const int mine = take4(mask, lane);
-            const uint32_t other = __shfl(id, mine < 0 ? 0 : mine);
-            if (mine >= 0) {
-                const float d = bg_pair(g, other, t, sub);
-                if ((lane & 15) == 0) sh.pd[mine] = d;
+        uint32_t t = 0;
+        float dt = 0.0f;
+        if (wave == 0) {
+            const uint32_t ri = my_ord[a];
+            t = at[ri];
+            dt = ad[ri];
+            int action = 1;
+            if (__ballot(lane < cnt && id == t)) {
+                action = 0;  // already connected (hnsw.go:477-486)
+            } else if (cnt == deg && good && !ties && dt > __shfl(dist, deg - 1)) {
+                action = 0;
+                n_skip++;
+            }
+            if (lane == 0) {
+                sh.t = t;
+                sh.action = action;
+                sh.cnt = cnt;
             }
         }
         __syncthreads();
-        const float pd = lane < cnt ? sh.pd[lane] : 0.0f;
-        const uint64_t tbits = __ballot(lane < cnt && pd < dt);   // row of the new node
-        const uint32_t colbit = (lane < cnt && pd < dist) ? 1u : 0u;  // bit (member, new node)
-        if (cnt < deg) {  // addConnectionSimple (hnsw.go:501-518)
-            if (lane < cnt) bits |= static_cast<uint64_t>(colbit) << cnt;
-            if (lane == cnt) {
-                id = t;
-                dist = dt;
-                bits = tbits;
-            }
-            cnt++;
-            __syncthreads();
+        if (sh.action == 0) {
+            __syncthreads();  // sh.action is rewritten by wave 0 in the next trip
             continue;
         }
-        // addConnectionPrune (hnsw.go:520-555): members in list order, then the new node, through the max-heap
-        // and back out nearest first.  Distinct distances: the order is the sort by distance.  Equal
-        // distances: whatever the heap does, so the heap is replayed.
-        const int nc = deg + 1;
+        {   // distances between the new node and the row's members: wave w scores members 16w .. 16w+15
+            const uint32_t tt = sh.t;
+            const int c = sh.cnt;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int j = wave * 16 + r * 4 + (lane >> 4);
+                if (j < c) {
+                    const float d = bg_pair(g, sh.mid[j], tt, sub);
+                    if ((lane & 15) == 0) sh.pd[j] = d;
+                }
+            }
+        }
+        __syncthreads();
+        if (wave == 0) {
+            const float pd = lane < cnt ? sh.pd[lane] : 0.0f;
+            const uint64_t tbits = __ballot(lane < cnt && pd < dt);       // row of the new node
+            const uint32_t colbit = (lane < cnt && pd < dist) ? 1u : 0u;  // bit (member, new node)
+            if (cnt < deg) {  // addConnectionSimple (hnsw.go:501-518)
+                if (lane < cnt) bits |= static_cast<uint64_t>(colbit) << cnt;
+                if (lane == cnt) {
+                    id = t;
+                    dist = dt;
+                    bits = tbits;
+                }
+                cnt++;
+                n_app++;
+                good = false;  // appended, not chosen
+                ties = row_has_ties();
+            } else {
+                // addConnectionPrune (hnsw.go:520-555): members in list order, then the new node, through the max-heap
+                // and back out nearest first.  Distinct distances: the order is the sort by distance.  Equal
+                // distances: whatever the heap does, so the heap is replayed.
+                n_prune++;
+                const int nc = deg + 1;
+                if (lane < deg) {
+                    sh.cd[lane] = dist;
+                    sh.cbits[lane] = bits;
+                    sh.ctbit[lane] = colbit;
+                    sh.cid[lane] = id;
+                }
+                if (lane == 0) {
+                    sh.cd[deg] = dt;
+                    sh.cbits[deg] = tbits;
+                    sh.ctbit[deg] = 0;
+                    sh.cid[deg] = t;
+                }
+                wave_sync();
+                int rank = 0;
+                bool tie = false;
+                if (lane < deg) {
+                    for (int j = 0; j < nc; j++) {
+                        const float dj = sh.cd[j];
+                        rank += dj < dist ? 1 : 0;
+                        tie |= (j != lane) && dj == dist;
+                    }
+                }
+                int rank_t = 0;
+                for (int j = 0; j < deg; j++) rank_t += sh.cd[j] < dt ? 1 : 0;
+                if (__ballot(tie)) {
+                    int hl = 0;
+                    for (int j = 0; j < nc; j++) heap_push<true>(sh.heap, hl, HItem{static_cast<uint32_t>(j), sh.cd[j]});
+                    for (int j = nc - 1; j >= 0; j--) {
+                        const HItem it = heap_pop<true>(sh.heap, hl);
+                        if (lane == 0) sh.seq[j] = static_cast<int>(it.node);
+                    }
+                } else {
+                    if (lane < deg) sh.seq[rank] = lane;
+                    if (lane == 0) sh.seq[rank_t] = deg;
+                }
+                if (lane < nc) sh.newpos[lane] = -1;
+                if (lane == 0) sh.newpos[64] = -1;
+                wave_sync();
+                // applyHeuristic + fillUpNeighbors over the bit rows (wave-uniform)
+                uint64_t selmask = 0;
+                bool sel_t = false;
+                int nsel = 0;
+                for (int p = 0; p < nc && nsel < deg; p++) {
+                    const int ci = sh.seq[p];
+                    const bool bad = (sh.cbits[ci] & selmask) != 0 || (sh.ctbit[ci] != 0 && sel_t);
+                    if (!bad) {
+                        if (ci == deg)
+                            sel_t = true;
+                        else
+                            selmask |= 1ull << ci;
+                        if (lane == 0) sh.newpos[ci] = nsel;
+                        nsel++;
+                    }
+                }
+                const int nchosen = nsel;
+                for (int p = 0; p < nc && nsel < deg; p++) {
+                    const int ci = sh.seq[p];
+                    const bool chosen = ci == deg ? sel_t : ((selmask >> ci) & 1) != 0;
+                    if (!chosen) {
+                        if (lane == 0) sh.newpos[ci] = nsel;
+                        nsel++;
+                    }
+                }
+                wave_sync();
+                // the row in its new order; columns of the bit matrix move with their members
+                int src = -1;
+                for (int j = 0; j < nc; j++)
+                    if (sh.newpos[j] == lane) src = j;
+                uint64_t nb = 0;
+                if (src >= 0) {
+                    const uint64_t ob = sh.cbits[src];
+                    for (int j = 0; j < deg; j++) {
+                        const int np = sh.newpos[j];
+                        if (np >= 0) nb |= ((ob >> j) & 1ull) << np;
+                    }
+                    const int npt = sh.newpos[deg];
+                    if (npt >= 0) nb |= static_cast<uint64_t>(sh.ctbit[src]) << npt;
+                    id = sh.cid[src];
+                    dist = sh.cd[src];
+                } else {
+                    id = VG_INVALID_ID;
+                    dist = 0.0f;
+                }
+                bits = nb;
+                cnt = nsel;
+                good = nchosen == deg;
+                ties = row_has_ties();
+            }
+            wave_sync();
+            sh.mid[lane] = id;
+        }
+        __syncthreads();
+    }
+    if (wave == 0) {
         if (lane < deg) {
-            sh.cd[lane] = dist;
-            sh.cbits[lane] = bits;
-            sh.ctbit[lane] = colbit;
-            sh.cid[lane] = id;
+            g.ids[off + lane] = lane < cnt ? id : VG_INVALID_ID;
+            g.dist[off + lane] = lane < cnt ? dist : 0.0f;
+            g.bits[off + lane] = lane < cnt ? bits : 0;
         }
         if (lane == 0) {
-            sh.cd[deg] = dt;
-            sh.cbits[deg] = tbits;
-            sh.ctbit[deg] = 0;
-            sh.cid[deg] = t;
-        }
-        __syncthreads();
-        int rank = 0;
-        bool tie = false;
-        if (lane < deg) {
-            for (int j = 0; j < nc; j++) {
-                const float dj = sh.cd[j];
-                rank += dj < dist ? 1 : 0;
-                tie |= (j != lane) && dj == dist;
+            if (totals) {
+                atomicAdd(&totals->records, static_cast<unsigned long long>(nadd));
+                atomicAdd(&totals->skipped, static_cast<unsigned long long>(n_skip));
+                atomicAdd(&totals->appended, static_cast<unsigned long long>(n_app));
+                atomicAdd(&totals->pruned, static_cast<unsigned long long>(n_prune));
+                atomicAdd(&totals->good_rows_seen, static_cast<unsigned long long>(g.good[row] ? 1 : 0));
+                atomicMax(&totals->longest_chain, static_cast<unsigned long long>(nadd));
             }
+            g.cnt[row] = cnt;
+            g.good[row] = good ? 1 : 0;
+            rcnt[row] = 0;
+            rfill[row] = 0;
         }
-        int rank_t = 0;
-        for (int j = 0; j < deg; j++) rank_t += sh.cd[j] < dt ? 1 : 0;
-        if (__ballot(tie)) {
-            int hl = 0;
-            for (int j = 0; j < nc; j++) heap_push<true>(sh.heap, hl, HItem{static_cast<uint32_t>(j), sh.cd[j]});
-            for (int j = nc - 1; j >= 0; j--) {
-                const HItem it = heap_pop<true>(sh.heap, hl);
-                if (lane == 0) sh.seq[j] = static_cast<int>(it.node);
-            }
-        } else {
-            if (lane < deg) sh.seq[rank] = lane;
-            if (lane == 0) sh.seq[rank_t] = deg;
-        }
-        if (lane < nc) sh.newpos[lane] = -1;
-        if (lane == 0) sh.newpos[64] = -1;
-        __syncthreads();
-        // applyHeuristic + fillUpNeighbors over the bit rows (wave-uniform)
-        uint64_t selmask = 0;
-        bool sel_t = false;
-        int nsel = 0;
-        for (int p = 0; p < nc && nsel < deg; p++) {
-            const int ci = sh.seq[p];
-            const bool bad = (sh.cbits[ci] & selmask) != 0 || (sh.ctbit[ci] != 0 && sel_t);
-            if (!bad) {
-                if (ci == deg)
-                    sel_t = true;
-                else
-                    selmask |= 1ull << ci;
-                if (lane == 0) sh.newpos[ci] = nsel;
-                nsel++;
-            }
-        }
-        for (int p = 0; p < nc && nsel < deg; p++) {
-            const int ci = sh.seq[p];
-            const bool chosen = ci == deg ? sel_t : ((selmask >> ci) & 1) != 0;
-            if (!chosen) {
-                if (lane == 0) sh.newpos[ci] = nsel;
-                nsel++;
-            }
-        }
-        __syncthreads();
-        // the row in its new order; columns of the bit matrix move with their members
-        int src = -1;
-        for (int j = 0; j < nc; j++)
-            if (sh.newpos[j] == lane) src = j;
-        uint64_t nb = 0;
-        if (src >= 0) {
-            const uint64_t ob = sh.cbits[src];
-            for (int j = 0; j < deg; j++) {
-                const int np = sh.newpos[j];
-                if (np >= 0) nb |= ((ob >> j) & 1ull) << np;
-            }
-            const int npt = sh.newpos[deg];
-            if (npt >= 0) nb |= static_cast<uint64_t>(sh.ctbit[src]) << npt;
-            id = sh.cid[src];
-            dist = sh.cd[src];
-        } else {
-            id = VG_INVALID_ID;
-            dist = 0.0f;
-        }
-        bits = nb;
-        cnt = nsel;
-        __syncthreads();
-    }
-    if (lane < deg) {
-        g.ids[off + lane] = lane < cnt ? id : VG_INVALID_ID;
-        g.dist[off + lane] = lane < cnt ? dist : 0.0f;
-        g.bits[off + lane] = lane < cnt ? bits : 0;
-    }
-    if (lane == 0) {
-        g.cnt[row] = cnt;
-        rcnt[row] = 0;
-        rfill[row] = 0;
     }
 }
 
@@ -641,16 +752,20 @@ VG_API int32_t vg_hnsw_build(vg_index *idx, int32_t m, int32_t ef_construction, 
              "vg_hnsw_build: max_batch=%d needs more than 4 GiB of visited bitmaps at %lld rows", max_batch,
              static_cast<long long>(n));
 
-    vg::DevBuf<uint32_t> d_ids, d_slots, d_vis, d_cand_ids, d_rec_row, d_rec_t, d_work, d_roff, d_srt_t, d_pair_node;
+    vg::DevBuf<uint32_t> d_ids, d_slots, d_vis, d_cand_ids, d_rec_row, d_rec_t, d_work, d_roff, d_srt_t, d_pair_node, d_ord;
     vg::DevBuf<float> d_dist, d_cand_d, d_rec_d, d_srt_d;
     vg::DevBuf<uint64_t> d_bits;
     vg::DevBuf<int32_t> d_cnt, d_levels, d_cand_n, d_rcnt, d_rfill, d_pair_level;
+    vg::DevBuf<uint8_t> d_good;
     vg::DevBuf<int64_t> d_level_off, d_pair_base;
     vg::DevBuf<vg::LinkCounters> d_ctr;
+    vg::DevBuf<vg::LinkTotals> d_totals;
+    const bool debug = vg::hook(vg::kHookBuildDebug);
     VG_TRY(d_ids.alloc(static_cast<size_t>(total_slots)));
     VG_TRY(d_dist.alloc(static_cast<size_t>(total_slots)));
     VG_TRY(d_bits.alloc(static_cast<size_t>(total_slots)));
     VG_TRY(d_cnt.alloc(static_cast<size_t>(total_rows)));
+    VG_TRY(d_good.alloc(static_cast<size_t>(total_rows)));
     VG_TRY(d_slots.alloc(slots.size()));
     VG_TRY(d_level_off.alloc(level_off.size()));
     VG_TRY(d_levels.alloc(static_cast<size_t>(n)));
@@ -667,15 +782,19 @@ VG_API int32_t vg_hnsw_build(vg_index *idx, int32_t m, int32_t ef_construction, 
     VG_TRY(d_rec_d.alloc(static_cast<size_t>(max_rec)));
     VG_TRY(d_srt_t.alloc(static_cast<size_t>(max_rec)));
     VG_TRY(d_srt_d.alloc(static_cast<size_t>(max_rec)));
+    VG_TRY(d_ord.alloc(static_cast<size_t>(max_rec)));
     VG_TRY(d_work.alloc(static_cast<size_t>(std::min(max_rec, total_rows))));
     VG_TRY(d_roff.alloc(static_cast<size_t>(total_rows)));
     VG_TRY(d_rcnt.alloc(static_cast<size_t>(total_rows)));
     VG_TRY(d_rfill.alloc(static_cast<size_t>(total_rows)));
     VG_TRY(d_ctr.alloc(1));
+    VG_TRY(d_totals.alloc(1));
+    VG_HIP(hipMemsetAsync(d_totals.p, 0, sizeof(vg::LinkTotals), st));
     VG_HIP(hipMemsetAsync(d_ids.p, 0xFF, static_cast<size_t>(total_slots) * 4, st));
     VG_HIP(hipMemsetAsync(d_dist.p, 0, static_cast<size_t>(total_slots) * 4, st));
     VG_HIP(hipMemsetAsync(d_bits.p, 0, static_cast<size_t>(total_slots) * 8, st));
     VG_HIP(hipMemsetAsync(d_cnt.p, 0, static_cast<size_t>(total_rows) * 4, st));
+    VG_HIP(hipMemsetAsync(d_good.p, 0, static_cast<size_t>(total_rows), st));
     VG_HIP(hipMemsetAsync(d_rcnt.p, 0, static_cast<size_t>(total_rows) * 4, st));
     VG_HIP(hipMemsetAsync(d_rfill.p, 0, static_cast<size_t>(total_rows) * 4, st));
     VG_HIP(hipMemcpyAsync(d_slots.p, slots.data(), slots.size() * 4, hipMemcpyHostToDevice, st));
@@ -686,7 +805,7 @@ VG_API int32_t vg_hnsw_build(vg_index *idx, int32_t m, int32_t ef_construction, 
     VG_HIP(hipMemcpyAsync(d_pair_level.p, pair_level.data(), pair_level.size() * 4, hipMemcpyHostToDevice, st));
     VG_HIP(hipStreamSynchronize(st));  // the host vectors above go out of use only at return, but be explicit
 
-    vg::BuildGraph g{idx->d_vectors, n, idx->dim, idx->metric, m0, m, d_ids.p, d_dist.p, d_bits.p, d_cnt.p,
+    vg::BuildGraph g{idx->d_vectors, n, idx->dim, idx->metric, m0, m, d_ids.p, d_dist.p, d_bits.p, d_cnt.p, d_good.p,
                      d_slots.p, d_level_off.p};
     const size_t lds = static_cast<size_t>(3 * ef) * sizeof(vg::HItem) + 128 * sizeof(float);
     VG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(vg::build_search_kernel),
@@ -717,10 +836,17 @@ VG_API int32_t vg_hnsw_build(vg_index *idx, int32_t m, int32_t ef_construction, 
                   d_work.p, d_rcnt.p, d_roff.p, d_ctr.p);
         VG_LAUNCH(vg::build_fill_kernel, dim3(gb), dim3(256), 0, st, d_rec_row.p, d_rec_t.p, d_rec_d.p, nrec,
                   d_roff.p, d_rfill.p, d_srt_t.p, d_srt_d.p);
-        VG_LAUNCH(vg::build_link_kernel, dim3(static_cast<unsigned>(max_work)), dim3(64), 0, st, g, d_work.p, d_ctr.p,
-                  d_rcnt.p, d_rfill.p, d_roff.p, d_srt_t.p, d_srt_d.p);
+        VG_LAUNCH(vg::build_link_kernel, dim3(static_cast<unsigned>(max_work)), dim3(vg::kLinkThreads), 0, st, g, d_work.p,
+                  d_ctr.p, d_rcnt.p, d_rfill.p, d_roff.p, d_srt_t.p, d_srt_d.p, d_ord.p, debug ? d_totals.p : nullptr);
     }
     VG_HIP(hipStreamSynchronize(st));
+    if (debug) {
+        vg::LinkTotals t{};
+        VG_HIP(hipMemcpy(&t, d_totals.p, sizeof(t), hipMemcpyDeviceToHost));
+        fprintf(stderr, "vg_hnsw_build: back links %llu = %llu skipped (farther than a fully chosen row's last member) + %llu appended + "
+                        "%llu pruned; target-row visits that found the row fully chosen %llu; longest per-row chain in one batch %llu\n",
+                t.records, t.skipped, t.appended, t.pruned, t.good_rows_seen, t.longest_chain);
+    }
 
     // hand the graph to the index in vg_index_set_hnsw_graph's layout
     uint32_t entry = 0;

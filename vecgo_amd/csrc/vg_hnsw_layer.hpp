@@ -106,7 +106,7 @@ struct PqScorer {
 // it) or nullptr.  nb_pair: 64 floats of LDS.
 template <typename Scorer, typename RowFn>
 __device__ __forceinline__ void greedy_layer(const Scorer &sc, int lane, RowFn row_of, int deg, float *nb_pair,
-                                             float *nb_bnd, uint32_t &cur, float &cur_d)
+                                             float *nb_bnd, uint32_t &cur, float &cur_d, int64_t *scored = nullptr)
 {
     bool changed = true;
     while (changed) {
@@ -117,6 +117,7 @@ __device__ __forceinline__ void greedy_layer(const Scorer &sc, int lane, RowFn r
         const uint64_t inval = __ballot(id_lane == VG_INVALID_ID);
         const int count = inval ? __builtin_ctzll(inval) : 64;
         uint64_t mask = count >= 64 ? ~0ull : ((1ull << count) - 1);
+        if (scored) *scored += count;
         sc.many(mask, id_lane, lane, nb_pair, nb_bnd);
         __syncthreads();
         // sequential `if nextDist < currDist` over the list == first strict minimum
