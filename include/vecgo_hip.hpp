@@ -15,6 +15,7 @@
 
 #include <algorithm>
 #include <cstdint>
+#include <cstring>
 #include <memory>
 #include <stdexcept>
 #include <string>
@@ -81,6 +82,15 @@ inline void SquaredL2Batch(const Context &c, const float *q, const float *t, int
 inline void DotBatch(const Context &c, const float *q, const float *t, int64_t dim, int64_t n, float *out)
 {
     check(vg_dot_batch(c.handle(), q, t, dim, n, out, nullptr));
+}
+
+// distance.NormalizeL2InPlace (distance/distance.go:40-53): false for an empty or zero-norm vector (left untouched)
+inline bool NormalizeL2InPlace(const Context &c, std::vector<float> &v)
+{
+    if (v.empty()) return false;
+    uint8_t ok = 0;
+    check(vg_normalize_l2(c.handle(), v.data(), 1, static_cast<int32_t>(v.size()), &ok, nullptr));
+    return ok != 0;
 }
 
 // distance.Provider (distance/distance.go:91-106)
@@ -241,6 +251,127 @@ public:
 private:
     std::shared_ptr<Context> ctx_;
     int dim_;
+};
+
+// quantization.BinaryQuantizer (binary.go:23-262)
+class BinaryQuantizer : public Quantizer {
+public:
+    BinaryQuantizer(std::shared_ptr<Context> ctx, int dimension) : ctx_(std::move(ctx)), dim_(dimension) {}
+    BinaryQuantizer &WithThreshold(float t)  // binary.go:52-56
+    {
+        threshold_ = t;
+        trained_ = true;
+        return *this;
+    }
+    void Train(const std::vector<std::vector<float>> &vectors) override  // binary.go:59-79
+    {
+        if (vectors.empty()) throw Error(VG_ERR_INVALID_ARG, "no vectors provided for training");
+        std::vector<float> flat;
+        for (const auto &v : vectors) flat.insert(flat.end(), v.begin(), v.end());
+        check(vg_binary_train(ctx_->handle(), dim_, flat.data(), static_cast<int64_t>(vectors.size()), &threshold_, nullptr));
+        trained_ = true;
+    }
+    std::vector<uint8_t> Encode(const std::vector<float> &v) override  // binary.go:86-115 (= EncodeUint64's words)
+    {
+        if (static_cast<int>(v.size()) != dim_) throw Error(VG_ERR_DIM_MISMATCH, "vector dimension mismatch");
+        std::vector<uint8_t> out(static_cast<size_t>(vg_binary_code_bytes(dim_)));
+        check(vg_binary_encode(ctx_->handle(), dim_, threshold_, v.data(), 1, out.data(), nullptr));
+        return out;
+    }
+    std::vector<uint64_t> EncodeUint64(const std::vector<float> &v)  // binary.go:118-154
+    {
+        const auto bytes = Encode(v);
+        std::vector<uint64_t> words(bytes.size() / 8);
+        std::memcpy(words.data(), bytes.data(), bytes.size());
+        return words;
+    }
+    std::vector<float> Decode(const std::vector<uint8_t> &b) override  // binary.go:173-188
+    {
+        std::vector<float> out(static_cast<size_t>(dim_));
+        check(vg_binary_decode(ctx_->handle(), dim_, threshold_, b.data(), 1, static_cast<int32_t>(b.size()), out.data(), nullptr));
+        return out;
+    }
+    int ComputeHammingDistance(const std::vector<float> &query, const std::vector<uint64_t> &codes)  // binary.go:158-171
+    {
+        if (static_cast<int>(query.size()) != dim_) throw Error(VG_ERR_DIM_MISMATCH, "vector dimension mismatch");
+        std::vector<uint64_t> padded(static_cast<size_t>((dim_ + 63) / 64), 0);  // HammingDistance truncates to the shorter
+        std::memcpy(padded.data(), codes.data(), std::min(codes.size(), padded.size()) * 8);
+        int32_t d = 0;
+        check(vg_binary_hamming_batch(ctx_->handle(), dim_, threshold_, query.data(),
+                                      reinterpret_cast<const uint8_t *>(padded.data()), 1, &d, nullptr));
+        return d;
+    }
+    int BytesPerDimension() const override { return 0; }     // binary.go:193-195
+    int BytesTotal() const { return (dim_ + 7) / 8; }        // binary.go:198-200
+    float Threshold() const { return threshold_; }
+    bool IsTrained() const { return trained_; }
+    float CompressionRatio() const { return 32.0f; }
+
+private:
+    std::shared_ptr<Context> ctx_;
+    int dim_;
+    float threshold_ = 0.0f;
+    bool trained_ = false;
+};
+
+// quantization.OptimizedProductQuantizer (opq.go:15-307)
+class OptimizedProductQuantizer : public Quantizer {
+public:
+    OptimizedProductQuantizer(std::shared_ptr<Context> ctx, int dimension, int numSubvectors, int numCentroids, int numIterations)
+        : ctx_(std::move(ctx)), dim_(dimension), m_(numSubvectors)
+    {
+        check(vg_opq_create(ctx_->handle(), dimension, numSubvectors, numCentroids, numIterations, &h_));
+    }
+    ~OptimizedProductQuantizer() override { vg_opq_destroy(h_); }
+    OptimizedProductQuantizer(const OptimizedProductQuantizer &) = delete;
+    OptimizedProductQuantizer &operator=(const OptimizedProductQuantizer &) = delete;
+    void Train(const std::vector<std::vector<float>> &vectors) override  // opq.go:89-193
+    {
+        if (vectors.empty()) throw Error(VG_ERR_INVALID_ARG, "no vectors provided for training");
+        if (static_cast<int>(vectors[0].size()) != dim_) throw Error(VG_ERR_DIM_MISMATCH, "vector dimension mismatch");
+        std::vector<float> flat;
+        for (const auto &v : vectors) flat.insert(flat.end(), v.begin(), v.end());
+        check(vg_opq_train(h_, flat.data(), static_cast<int64_t>(vectors.size()), 20, 1, nullptr));
+    }
+    std::vector<uint8_t> Encode(const std::vector<float> &v) override  // opq.go:218-231
+    {
+        if (static_cast<int>(v.size()) != dim_) throw Error(VG_ERR_DIM_MISMATCH, "vector dimension mismatch");
+        std::vector<uint8_t> out(static_cast<size_t>(m_));
+        check(vg_opq_encode(h_, v.data(), 1, out.data(), nullptr));
+        return out;
+    }
+    std::vector<float> Decode(const std::vector<uint8_t> &b) override  // opq.go:234-269
+    {
+        if (static_cast<int>(b.size()) != m_) throw Error(VG_ERR_CODE_LENGTH, "invalid code length");
+        std::vector<float> out(static_cast<size_t>(dim_));
+        check(vg_opq_decode(h_, b.data(), 1, out.data(), nullptr));
+        return out;
+    }
+    float ComputeAsymmetricDistance(const std::vector<float> &query, const std::vector<uint8_t> &codes)  // opq.go:272-286
+    {
+        float d = 0.0f;
+        check(vg_opq_asymmetric_distance_batch(h_, query.data(), codes.data(), 1, &d, nullptr));
+        return d;
+    }
+    std::vector<float> Rotations(int &blockSize, int &numBlocks) const
+    {
+        int32_t b = 0, nb = 0;
+        check(vg_opq_get_rotations(h_, &b, &nb, nullptr));
+        std::vector<float> r(static_cast<size_t>(nb) * b * b);
+        check(vg_opq_get_rotations(h_, nullptr, nullptr, r.data()));
+        blockSize = b;
+        numBlocks = nb;
+        return r;
+    }
+    int BytesPerDimension() const override { return 0; }
+    int BytesPerVector() const { return m_; }                               // opq.go:289-291
+    double CompressionRatio() const { return double(dim_) * 4.0 / m_; }     // opq.go:294-296
+    bool IsTrained() const { return vg_opq_is_trained(h_) != 0; }
+
+private:
+    std::shared_ptr<Context> ctx_;
+    vg_opq *h_ = nullptr;
+    int dim_, m_;
 };
 
 // quantization.ScalarQuantizer (quantizer.go:27-39)
@@ -473,6 +604,13 @@ public:
         check(vg_index_set_partitions(h_, centroids, part_offsets, num_partitions, nullptr));
     }
     Result SearchProbed(const float *queries, int64_t nq, int k, int nprobes, int scan) { return run(nq, k, [&](Result &r) { return vg_search_flat_probed(h_, queries, nq, k, nprobes, scan, r.ids.data(), r.scores.data(), nullptr); }); }
+    // hnsw.Insert over the segment's rows (hnsw.go:713-984, ids and levels of ApplyInsert); replaces the segment's graph
+    void BuildHNSW(int m = 32, int efConstruction = 300, int maxBatch = 8192, int growthDiv = 32)
+    {
+        check(vg_hnsw_build(h_, m, efConstruction, maxBatch, growthDiv, nullptr));
+    }
+    // the graph walk scored from PQ codes (candidates for Rerank, engine/search.go:914-965)
+    Result SearchHNSWPQ(const float *queries, int64_t nq, int k, int ef) { return run(nq, k, [&](Result &r) { return vg_search_hnsw_pq(h_, queries, nq, k, ef, r.ids.data(), r.scores.data(), nullptr, nullptr); }); }
     // hnsw.KNNSearch (hnsw.go:1650-1755)
     Result SearchHNSW(const float *queries, int64_t nq, int k, int ef) { return run(nq, k, [&](Result &r) { return vg_search_hnsw(h_, queries, nq, k, ef, r.ids.data(), r.scores.data(), nullptr, nullptr); }); }
     // diskann searchInternal (diskann/segment.go:503-706); kind 0 fp32, 1 PQ, 2 RaBitQ

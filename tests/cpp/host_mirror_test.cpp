@@ -251,6 +251,89 @@ int main()
         }
     }
 
+    // ---- BinaryQuantizer (binary_test.go) ---------------------------------------------------
+    {
+        vecgo::quantization::BinaryQuantizer bq(ctx, 128);
+        std::vector<float> v(128);
+        for (int i = 0; i < 128; i++) v[i] = i % 2 == 0 ? 1.0f : -1.0f;
+        auto w = bq.EncodeUint64(v);                                         // binary_test.go:9-39
+        EXPECT(w.size() == 2 && w[0] == 0x5555555555555555ull && w[1] == 0x5555555555555555ull);
+        vecgo::quantization::BinaryQuantizer b4(ctx, 4);
+        b4.Train({{1, 2, 3, 4}, {5, 6, 7, 8}});                              // binary_test.go:41-63
+        EXPECT(b4.IsTrained() && b4.Threshold() == 4.5f);
+        EXPECT(status_of([&] { b4.Train({}); }) == VG_ERR_INVALID_ARG);
+        vecgo::quantization::BinaryQuantizer b8(ctx, 8);
+        b8.WithThreshold(0.5f);                                              // binary_test.go:64-100
+        auto code = b8.Encode({0.1f, 0.9f, 0.5f, 0.4f, 0.6f, 0.3f, 0.8f, 0.2f});
+        EXPECT(code[0] == 0b01010110);
+        auto dec = b8.Decode(code);
+        EXPECT(dec[0] == 0.0f && dec[1] == 1.0f && dec[2] == 1.0f && dec[3] == 0.0f);
+        std::vector<float> a(128, 1.0f), b(128, 1.0f);
+        for (int i = 0; i < 10; i++) b[i * 7] = -1.0f;
+        EXPECT(bq.ComputeHammingDistance(a, bq.EncodeUint64(b)) == 10);      // binary_test.go:102-123 shape
+        EXPECT(bq.BytesTotal() == 16 && bq.CompressionRatio() == 32.0f);
+        EXPECT(status_of([&] { bq.Encode(std::vector<float>(3)); }) == VG_ERR_DIM_MISMATCH);
+    }
+
+    // ---- NormalizeL2InPlace (distance_test.go) ----------------------------------------------
+    {
+        std::vector<float> v{3.0f, 4.0f};
+        EXPECT(vecgo::distance::NormalizeL2InPlace(*ctx, v));
+        EXPECT(std::fabs(v[0] - 0.6f) < 1e-6f && std::fabs(v[1] - 0.8f) < 1e-6f);
+        std::vector<float> z{0.0f, 0.0f, 0.0f}, e;
+        EXPECT(!vecgo::distance::NormalizeL2InPlace(*ctx, z) && z[0] == 0.0f);
+        EXPECT(!vecgo::distance::NormalizeL2InPlace(*ctx, e));
+    }
+
+    // ---- OptimizedProductQuantizer (opq_test.go) --------------------------------------------
+    {
+        const int dim = 32, m = 8;
+        vecgo::quantization::OptimizedProductQuantizer opq(ctx, dim, m, 16, 3);
+        EXPECT(!opq.IsTrained());
+        EXPECT(status_of([&] { opq.Encode(std::vector<float>(dim)); }) == VG_ERR_NOT_READY);   // "not trained" opq_test.go:202-221
+        EXPECT(status_of([&] { vecgo::quantization::OptimizedProductQuantizer bad(ctx, 30, 8, 16, 1); }) == VG_ERR_INVALID_ARG);
+        auto train = unit_vectors(rng, 400, dim);
+        opq.Train(train);                                                    // opq_test.go:26-54
+        EXPECT(opq.IsTrained());
+        auto codes = opq.Encode(train[0]);
+        EXPECT(int(codes.size()) == m && opq.BytesPerVector() == m);
+        auto rec = opq.Decode(codes);
+        EXPECT(int(rec.size()) == dim);
+        EXPECT(std::fabs(opq.CompressionRatio() - 16.0) < 0.1);
+        int bs = 0, nb = 0;                                                  // opq_test.go:56-99: R R^T = I
+        auto rot = opq.Rotations(bs, nb);
+        EXPECT(bs * nb == dim);
+        for (int b = 0; b < nb; b++)
+            for (int i = 0; i < bs; i++)
+                for (int j = 0; j < bs; j++) {
+                    float s = 0;
+                    for (int k2 = 0; k2 < bs; k2++) s += rot[(size_t(b) * bs + i) * bs + k2] * rot[(size_t(b) * bs + j) * bs + k2];
+                    EXPECT(std::fabs(s - (i == j ? 1.0f : 0.0f)) < 0.1f);
+                }
+        const float self = opq.ComputeAsymmetricDistance(train[0], codes);   // opq_test.go:101-131
+        const float other = opq.ComputeAsymmetricDistance(train[1], codes);
+        EXPECT(other > 0.0f && self < other);
+    }
+
+    // ---- hnsw build + search (hnsw_test.go:43-60: 1000 x 16, M = 8, EF = 200 -> precision >= 0.99) ----
+    {
+        const int n = 1000, dim = 16, k = 10, nq = 50;
+        std::uniform_real_distribution<float> ud(0.f, 1.f);
+        std::vector<float> base(size_t(n) * dim), q(size_t(nq) * dim);
+        for (auto &x : base) x = ud(rng);
+        for (auto &x : q) x = ud(rng);
+        Segment seg(ctx, n, dim, distance::Metric::L2);
+        seg.SetVectors(base.data());
+        seg.BuildHNSW(8, 200, 16, 32);
+        auto got = seg.SearchHNSW(q.data(), nq, k, 200);
+        auto want = seg.SearchFlat(q.data(), nq, k);
+        int hit = 0;
+        for (int i = 0; i < nq; i++)
+            for (int a = 0; a < k; a++)
+                for (int b = 0; b < k; b++) hit += got.ids[size_t(i) * k + a] == want.ids[size_t(i) * k + b];
+        EXPECT(hit >= int(0.99 * nq * k));
+    }
+
     if (g_fail) {
         std::fprintf(stderr, "%d check(s) failed\n", g_fail);
         return 1;
