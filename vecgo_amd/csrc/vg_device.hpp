@@ -194,16 +194,6 @@ __device__ __forceinline__ float int4_l2_precomputed(const float *__restrict__ q
     return total;
 }
 
-// number of keys < e in sorted[0..64) (ascending; unused slots hold kKeyMax)
-__device__ __forceinline__ int lower_bound64(const uint64_t *sorted, uint64_t e)
-{
-    int pos = 0;
-#pragma unroll
-    for (int step = 32; step > 0; step >>= 1)
-        if (sorted[pos + step - 1] < e) pos += step;
-    return pos + (sorted[pos] < e ? 1 : 0);
-}
-
 // Rank-merge of the per-wave sorted lists of one workgroup into `out[0..k)` (ascending,
 // kKeyMax padded): a key's final position is its own index plus the number of smaller keys in
 // every other wave's list (keys are unique).  `lists` = WAVES*64 keys of LDS, `valid` = WAVES ints.
@@ -217,9 +207,20 @@ __device__ __forceinline__ void wg_rank_merge(const WaveTopK &tk, uint64_t *list
     __syncthreads();
     const uint64_t e = tk.list;
     if (e != kKeyMax) {
-        int rank = lane;
-        for (int w = 0; w < WAVES; w++)
-            if (w != wave) rank += lower_bound64(lists + w * 64, e);
+        // the WAVES binary searches are independent: run them step by step side by side (7 rounds of WAVES
+        // LDS reads in flight instead of 7*WAVES dependent ones); in its own list a key's count is its lane
+        int pos[WAVES];
+#pragma unroll
+        for (int w = 0; w < WAVES; w++) pos[w] = 0;
+#pragma unroll
+        for (int step = 32; step > 0; step >>= 1) {
+#pragma unroll
+            for (int w = 0; w < WAVES; w++)
+                if (lists[w * 64 + pos[w] + step - 1] < e) pos[w] += step;
+        }
+        int rank = 0;
+#pragma unroll
+        for (int w = 0; w < WAVES; w++) rank += pos[w] + (lists[w * 64 + pos[w]] < e ? 1 : 0);
         if (rank < k) out[rank] = e;
     }
     int total = 0;
