@@ -290,14 +290,14 @@ __device__ __forceinline__ float sq8_row_score(const uint4 *__restrict__ tp, int
     return total;
 }
 
-template <bool DOT>
-__global__ __launch_bounds__(kSqThreads) void sq8_scan_kernel(
+template <bool DOT, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void sq8_scan_kernel(
     const uint4 *__restrict__ tiles, int64_t n_rows, int64_t n_tiles, int groups, int dim,
     const float *__restrict__ queries, const float *__restrict__ mins, const float *__restrict__ inv, int slices,
     int nq, int k, uint64_t *__restrict__ partial, const uint64_t *__restrict__ min_keys)
 {
-    __shared__ uint64_t lists[kSqWaves * 64];
-    __shared__ int valid[kSqWaves];
+    __shared__ uint64_t lists[WAVES * 64];
+    __shared__ int valid[WAVES];
     const int b = blockIdx.x;
     const int xcd = b & 7;
     const int o = b >> 3;
@@ -309,15 +309,20 @@ __global__ __launch_bounds__(kSqThreads) void sq8_scan_kernel(
     const int full = dim >> 4, tail = dim & 15;
     WaveTopK tk;
     tk.init(k);
-    for (int64_t tile = t0 + wave; tile < t1; tile += kSqWaves) {
+    // one-query passes deal the tiles round-robin over the workgroups (one moving window of the code array, see
+    // rabitq_scan_kernel); several queries keep the slice mapping and share the slice in their XCD's L2
+    const bool dealt = nq == 1;
+    const int64_t step = dealt ? static_cast<int64_t>(slices) * WAVES : WAVES;
+    const int64_t end = dealt ? n_tiles : t1;
+    for (int64_t tile = dealt ? static_cast<int64_t>(s) * WAVES + wave : t0 + wave; tile < end; tile += step) {
         const float total = sq8_row_score<DOT>(tiles + (tile * groups) * 64 + lane, groups, full, tail, qv, mins, inv);
         const int64_t row = tile * 64 + lane;
         uint64_t key = row < n_rows ? make_key(total, static_cast<uint32_t>(row), DOT) : kKeyMax;
         if (min_keys && key <= min_keys[q]) key = kKeyMax;  // paged results: only keys after the previous page
         tk.offer(key, lane);
     }
-    wg_rank_merge<kSqWaves>(tk, lists, valid, wave, lane, tid, k,
-                            partial + (static_cast<int64_t>(q) * slices + s) * k);
+    wg_rank_merge<WAVES>(tk, lists, valid, wave, lane, tid, k,
+                          partial + (static_cast<int64_t>(q) * slices + s) * k);
 }
 
 // Partition-probed SQ8 scan (flat/segment.go:727-744 over the :517-604 branch): workgroup =
@@ -733,7 +738,7 @@ __global__ __launch_bounds__(256) void int4_l2_precomputed_kernel(const float *_
 
 static int sq_slices(int64_t nq, int64_t n_tiles, int cus)
 {
-    int64_t s = (4 * static_cast<int64_t>(cus) + nq - 1) / nq;  // ~4 workgroups of 256 threads per CU
+    int64_t s = (4 * static_cast<int64_t>(cus) + nq - 1) / nq;  // ~4 workgroups per CU
     s = ((s + 7) / 8) * 8;
     int64_t max_s = (n_tiles / 8) * 8;
     if (max_s < 8) max_s = 8;
@@ -996,8 +1001,14 @@ VG_API int32_t vg_search_sq8(vg_index *idx, const float *queries, int64_t nq, in
                 for (int64_t q0 = 0; q0 < nq; q0 += max_q) {
                     const int64_t cnt = nq - q0 < max_q ? nq - q0 : max_q;
                     vg::ProfScope prof(idx->ctx, "sq8_scan", st);
-                    auto kern = dot ? vg::sq8_scan_kernel<true> : vg::sq8_scan_kernel<false>;
-                    VG_LAUNCH(kern, dim3(static_cast<unsigned>(cnt * slices)), dim3(vg::kSqThreads), 0, st,
+                    // one query: workgroups of 8 waves (32 waves per CU).  The row loop keeps fewer bytes in flight than
+                    // its load ring suggests (the compiler drains it at every group), so the single pass wants the
+                    // occupancy: 4M x 768 scan kernel 540 -> 518 us, call 590 -> 559 us (8 workgroups of 4 waves: 500 us,
+                    // but the merge of twice the lists gives it back)
+                    const bool wide = nq == 1 && idx->n_tiles >= static_cast<int64_t>(slices) * 8;
+                    auto kern = wide ? (dot ? vg::sq8_scan_kernel<true, 8> : vg::sq8_scan_kernel<false, 8>)
+                                     : (dot ? vg::sq8_scan_kernel<true, vg::kSqWaves> : vg::sq8_scan_kernel<false, vg::kSqWaves>);
+                    VG_LAUNCH(kern, dim3(static_cast<unsigned>(cnt * slices)), dim3(wide ? 512 : vg::kSqThreads), 0, st,
                               reinterpret_cast<const uint4 *>(idx->d_sq_tiles), idx->n, idx->n_tiles, idx->sq_groups, idx->dim,
                               q.ptr + q0 * idx->dim, idx->sq->d_mins, idx->sq->d_inv, slices, static_cast<int>(cnt), kk,
                               partial + q0 * slices * kk, floor ? floor + q0 : nullptr);
