@@ -356,7 +356,11 @@ __global__ __launch_bounds__(kGemmThreads) void flat_gemm_dma_kernel(
 #pragma unroll
             for (int p = 0; p < kGemmPasses; p++) {
                 glds16(abase + k0, aoff[p], piece(b, 0, p));
+#ifdef VG_GEMM_B_NT
+                if (!(PROBE & 64)) glds16_stream(bbase + k0, boff[p], piece(b, 1, p));
+#else
                 if (!(PROBE & 64)) glds16(bbase + k0, boff[p], piece(b, 1, p));  // PROBE bit 6: A tiles only
+#endif
             }
         } else {  // ragged K edge; dim % 4 == 0, so a granule is inside or outside as a whole
             const float *zeros = reinterpret_cast<const float *>(&g_gemm_zero16);
