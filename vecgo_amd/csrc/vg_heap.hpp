@@ -16,59 +16,82 @@ struct HItem {
 };
 
 // ---- searcher.PriorityQueue (queue.go:161-183, 221-290), uniform over the wave ---------------
-template <bool MAX>
-__device__ __forceinline__ void heap_sift_up(HItem *h, int i)
+// An item is one 8-byte access (the heaps may live in HBM scratch, where every access is an L2 round trip)
+__device__ __forceinline__ HItem heap_load(const HItem *p)
 {
-    const HItem it = h[i];
-    while (i > 0) {
-        const int p = (i - 1) >> 2;
-        const float pd = h[p].dist;
-        if (MAX ? (it.dist <= pd) : (it.dist >= pd)) break;
-        h[i] = h[p];
-        i = p;
-    }
-    h[i] = it;
+    const uint64_t v = *reinterpret_cast<const uint64_t *>(p);
+    HItem it;
+    it.node = static_cast<uint32_t>(v);
+    it.dist = __uint_as_float(static_cast<uint32_t>(v >> 32));
+    return it;
+}
+__device__ __forceinline__ void heap_store(HItem *p, HItem it)
+{
+    *reinterpret_cast<uint64_t *>(p) = static_cast<uint64_t>(it.node) | (static_cast<uint64_t>(__float_as_uint(it.dist)) << 32);
 }
 
+// `it` is the item that belongs at slot i (not yet stored there)
 template <bool MAX>
-__device__ __forceinline__ void heap_sift_down(HItem *h, int n, int i)
+__device__ __forceinline__ void heap_sift_up(HItem *h, int i, const HItem it)
 {
-    const HItem it = h[i];
+    while (i > 0) {
+        const int p = (i - 1) >> 2;
+        const HItem pi = heap_load(h + p);
+        if (MAX ? (it.dist <= pi.dist) : (it.dist >= pi.dist)) break;
+        heap_store(h + i, pi);
+        i = p;
+    }
+    heap_store(h + i, it);
+}
+
+// The up-to-4 children of a node are requested together (one round trip per level, not one per child plus one for
+// the move) and compared in the reference's order: first child, then each next one with a strict comparison.
+// `it` is the item that belongs at slot i (not yet stored there)
+template <bool MAX>
+__device__ __forceinline__ void heap_sift_down(HItem *h, int n, int i, const HItem it)
+{
     for (;;) {
         const int fc = 4 * i + 1;
         if (fc >= n) break;
+        const int last = n - 1;
+        const HItem c0 = heap_load(h + fc);
+        const HItem c1 = heap_load(h + (fc + 1 < last ? fc + 1 : last));
+        const HItem c2 = heap_load(h + (fc + 2 < last ? fc + 2 : last));
+        const HItem c3 = heap_load(h + (fc + 3 < last ? fc + 3 : last));
         int best = fc;
-        float bd = h[fc].dist;
-        const int lc = fc + 4 < n ? fc + 4 : n;
-        for (int c = fc + 1; c < lc; c++) {
-            const float cd = h[c].dist;
-            if (MAX ? (cd > bd) : (cd < bd)) {
-                best = c;
-                bd = cd;
-            }
+        HItem bi = c0;
+        if (fc + 1 < n && (MAX ? (c1.dist > bi.dist) : (c1.dist < bi.dist))) {
+            best = fc + 1;
+            bi = c1;
         }
-        if (MAX ? (it.dist >= bd) : (it.dist <= bd)) break;
-        h[i] = h[best];
+        if (fc + 2 < n && (MAX ? (c2.dist > bi.dist) : (c2.dist < bi.dist))) {
+            best = fc + 2;
+            bi = c2;
+        }
+        if (fc + 3 < n && (MAX ? (c3.dist > bi.dist) : (c3.dist < bi.dist))) {
+            best = fc + 3;
+            bi = c3;
+        }
+        if (MAX ? (it.dist >= bi.dist) : (it.dist <= bi.dist)) break;
+        heap_store(h + i, bi);
         i = best;
     }
-    h[i] = it;
+    heap_store(h + i, it);
 }
 
 template <bool MAX>
 __device__ __forceinline__ void heap_push(HItem *h, int &len, HItem it)
 {
-    h[len] = it;
     len++;
-    heap_sift_up<MAX>(h, len - 1);
+    heap_sift_up<MAX>(h, len - 1, it);
 }
 
 template <bool MAX>
 __device__ __forceinline__ HItem heap_pop(HItem *h, int &len)
 {
-    const HItem top = h[0];
-    h[0] = h[len - 1];
+    const HItem top = heap_load(h);
     len--;
-    if (len > 0) heap_sift_down<MAX>(h, len, 0);
+    if (len > 0) heap_sift_down<MAX>(h, len, 0, heap_load(h + len));
     return top;
 }
 
@@ -79,10 +102,7 @@ __device__ __forceinline__ void res_push_bounded(HItem *h, int &len, HItem it, i
         heap_push<true>(h, len, it);
         return;
     }
-    if (it.dist < h[0].dist) {
-        h[0] = it;
-        heap_sift_down<true>(h, len, 0);
-    }
+    if (it.dist < h[0].dist) heap_sift_down<true>(h, len, 0, it);
 }
 
 // TryPushBounded (queue.go:190-215) on the MIN-heap of exploration candidates: at capacity the
@@ -94,8 +114,7 @@ __device__ __forceinline__ void cand_try_push_bounded(HItem *h, int &len, HItem 
         return;
     }
     if (it.dist <= h[0].dist) return;
-    h[0] = it;
-    heap_sift_down<false>(h, len, 0);
+    heap_sift_down<false>(h, len, 0, it);
 }
 
 // next up-to-4 set bits of `mask` (ascending): the lane's 16-lane group gets the (lane>>4)-th
