@@ -25,12 +25,15 @@ int32_t launch_pq_build_table(const vg_pq *pq, const float *d_queries, int64_t n
 
 
 // ---- HNSW ----------------------------------------------------------------------------------------
-// heap_ws == nullptr: both heaps of the query live in LDS (3 * ef items); otherwise in HBM scratch
-// (large ef: 3 * ef * 8 bytes per query would leave one or two waves per CU).
+// SPLIT = false: both heaps of the query live in LDS (3 * ef items, ef <= kHnswLdsEf).  SPLIT = true (larger ef:
+// 3 * ef * 8 bytes per query would leave one or two waves per CU): the first kHnswLdsEf items of the results heap
+// and 2 * kHnswLdsEf of the candidates heap — the top levels, where the sifts spend their steps — stay in LDS,
+// the rest of each heap is HBM scratch.
 // PQ = false: nodes scored from their fp32 rows (hnsw.KNNSearch).  PQ = true: from their PQ codes with the
 // query's distance table `luts` (ComputeAsymmetricDistance order), the candidate stage of the
 // graph -> PQ -> exact-rerank pipeline.
-template <bool PQ>
+constexpr int kHnswLdsEf = 512;  // LDS items of the results heap (twice that for the candidates): 12 KiB per query
+template <bool PQ, bool SPLIT>
 __global__ __launch_bounds__(64) void hnsw_search_kernel(
     const float *__restrict__ base, int64_t n, int dim, int metric, const uint32_t *__restrict__ l0,
     int m0, int max_level, int m, const uint32_t *__restrict__ slots, const uint32_t *__restrict__ adj,
@@ -44,8 +47,15 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(
     const int lane = threadIdx.x;
     float *nb_pair = reinterpret_cast<float *>(smem);
     float *nb_bnd = nb_pair + 64;
-    HItem *cand = heap_ws ? heap_ws + q * 3 * ef : reinterpret_cast<HItem *>(nb_bnd + 64);
-    HItem *res = cand + 2 * ef;
+    typename std::conditional<SPLIT, SplitHeap, HItem *>::type cand, res;
+    if constexpr (SPLIT) {
+        HItem *lo = reinterpret_cast<HItem *>(nb_bnd + 64);
+        cand = SplitHeap{lo, heap_ws + q * 3 * ef, 2 * kHnswLdsEf};
+        res = SplitHeap{lo + 2 * kHnswLdsEf, heap_ws + q * 3 * ef + 2 * ef, kHnswLdsEf};
+    } else {
+        cand = reinterpret_cast<HItem *>(nb_bnd + 64);
+        res = cand + 2 * ef;
+    }
     uint32_t *vis = visited_ws + q * vis_words;
     typename std::conditional<PQ, PqScorer, F32Scorer>::type sc;
     if constexpr (PQ) {
@@ -115,7 +125,6 @@ __device__ inline float rq_formula_g(float qn, float yn, float dimf, float hammi
     return t1sq + t2;
 }
 
-constexpr int kHnswLdsEf = 512;     // heaps of a query in LDS up to this ef
 constexpr int kHnswMaxEf = 1 << 20;  // ... in HBM scratch beyond
 constexpr int kVamanaMaxK = 512;  // results per query: one per lane up to 64, a sorted LDS list beyond
 
@@ -461,7 +470,7 @@ static int32_t search_hnsw_impl(vg_index *idx, bool pq, const float *queries, in
     const int64_t vis_words = (idx->n + 31) / 32;
     const int pq_m = pq ? idx->pq->m : 0;
     // heaps in LDS up to kHnswLdsEf (12 KiB per query: the waves of a CU are then bounded by registers, not
-    // LDS), beyond it in HBM scratch
+    // LDS), beyond it split between those 12 KiB (the top levels) and HBM scratch
     const bool lds_heaps = ef <= vg::kHnswLdsEf;
     const int64_t heap_bytes = lds_heaps ? 0 : static_cast<int64_t>(3) * ef * sizeof(vg::HItem);
     const int64_t lut_bytes = static_cast<int64_t>(pq_m) * 256 * sizeof(float);
@@ -475,28 +484,21 @@ static int32_t search_hnsw_impl(vg_index *idx, bool pq, const float *queries, in
     struct { uint32_t *ptr; } vis{ar.get<uint32_t>(i_vis)};
     vg::HItem *heap_ws = lds_heaps ? nullptr : ar.get<vg::HItem>(i_heap);
     float *luts = pq ? ar.get<float>(i_luts) : nullptr;
-    const size_t lds = (lds_heaps ? static_cast<size_t>(3 * ef) * sizeof(vg::HItem) : 0) + 128 * sizeof(float);
-    const void *kfn = pq ? reinterpret_cast<const void *>(vg::hnsw_search_kernel<true>)
-                         : reinterpret_cast<const void *>(vg::hnsw_search_kernel<false>);
-    VG_HIP(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+    const size_t lds = static_cast<size_t>(3 * (lds_heaps ? ef : vg::kHnswLdsEf)) * sizeof(vg::HItem) + 128 * sizeof(float);
+    auto kern = pq ? (lds_heaps ? vg::hnsw_search_kernel<true, false> : vg::hnsw_search_kernel<true, true>)
+                   : (lds_heaps ? vg::hnsw_search_kernel<false, false> : vg::hnsw_search_kernel<false, true>);
+    VG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               static_cast<int>(lds)));
     for (int64_t q0 = 0; q0 < nq; q0 += chunk) {
         const int64_t cnt = std::min(chunk, nq - q0);
         VG_HIP(hipMemsetAsync(vis.ptr, 0, static_cast<size_t>(cnt) * vis_words * 4, st));
         if (pq) VG_TRY(vg::launch_pq_build_table(idx->pq, q.ptr + q0 * idx->dim, cnt, luts, false, st));
         vg::ProfScope prof(idx->ctx, pq ? "hnsw_search_pq" : "hnsw_search", st);
-        if (pq) {
-            VG_LAUNCH(vg::hnsw_search_kernel<true>, dim3(static_cast<unsigned>(cnt)), dim3(64), lds, st,
-                      idx->d_vectors, idx->n, idx->dim, idx->metric, idx->d_hnsw_l0, idx->hnsw_m0,
-                      idx->hnsw_max_level, idx->hnsw_m, idx->d_hnsw_slot, idx->d_hnsw_adj, idx->d_hnsw_level_off,
-                      idx->hnsw_entry, q.ptr + q0 * idx->dim, idx->d_pq_rows, pq_m, luts, k, ef, vis.ptr, vis_words,
-                      heap_ws, oid.ptr + q0 * k, osc.ptr + q0 * k, ost.ptr ? ost.ptr + q0 : nullptr);
-        } else {
-            VG_LAUNCH(vg::hnsw_search_kernel<false>, dim3(static_cast<unsigned>(cnt)), dim3(64), lds, st,
-                      idx->d_vectors, idx->n, idx->dim, idx->metric, idx->d_hnsw_l0, idx->hnsw_m0,
-                      idx->hnsw_max_level, idx->hnsw_m, idx->d_hnsw_slot, idx->d_hnsw_adj, idx->d_hnsw_level_off,
-                      idx->hnsw_entry, q.ptr + q0 * idx->dim, nullptr, 0, nullptr, k, ef, vis.ptr, vis_words,
-                      heap_ws, oid.ptr + q0 * k, osc.ptr + q0 * k, ost.ptr ? ost.ptr + q0 : nullptr);
-        }
+        VG_LAUNCH(kern, dim3(static_cast<unsigned>(cnt)), dim3(64), lds, st, idx->d_vectors, idx->n, idx->dim,
+                  idx->metric, idx->d_hnsw_l0, idx->hnsw_m0, idx->hnsw_max_level, idx->hnsw_m, idx->d_hnsw_slot,
+                  idx->d_hnsw_adj, idx->d_hnsw_level_off, idx->hnsw_entry, q.ptr + q0 * idx->dim,
+                  pq ? idx->d_pq_rows : nullptr, pq_m, luts, k, ef, vis.ptr, vis_words, heap_ws, oid.ptr + q0 * k,
+                  osc.ptr + q0 * k, ost.ptr ? ost.ptr + q0 : nullptr);
     }
     VG_TRY(oid.finish());
     VG_TRY(osc.finish());

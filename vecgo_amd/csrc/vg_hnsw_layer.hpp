@@ -3,7 +3,7 @@
 //   greedy_layer   the `for changed` loop of greedySearch / insertNode    (hnsw.go:1897-1934, :918-934)
 //   search_layer   searchLayerUnfiltered                                 (hnsw.go:1220-1396)
 // The heaps are the reference's (vg_heap.hpp), executed uniformly by the wave on arrays the caller owns
-// (LDS, or HBM scratch for large ef); the <= 64 neighbours of a popped node are visited-tested, gathered
+// (LDS; for large ef SPLIT between LDS and HBM scratch, vg_heap.hpp); the <= 64 neighbours of a popped node are visited-tested, gathered
 // and scored in parallel (16 lanes per fp32 row, 4 rows at a time, reference summation order), then fed
 // to the heaps in the node's stored neighbour order.
 #pragma once
@@ -139,9 +139,9 @@ __device__ __forceinline__ void greedy_layer(const Scorer &sc, int lane, RowFn r
 
 // searchLayerUnfiltered from (ep, ep_d).  `vis`: this wave's visited bitmap, already clear.  On return
 // res[0..res_len) is the results max-heap exactly as the reference's search leaves it.
-template <typename Scorer, typename RowFn>
+template <typename Scorer, typename RowFn, typename Heap>
 __device__ __forceinline__ void search_layer(const Scorer &sc, bool l2_metric, int lane, RowFn row_of, int deg,
-                                             uint32_t ep, float ep_d, int ef, HItem *cand, HItem *res,
+                                             uint32_t ep, float ep_d, int ef, Heap cand, Heap res,
                                              float *nb_pair, float *nb_bnd, uint32_t *vis, int &res_len_out,
                                              LayerStats &st)
 {
@@ -160,7 +160,7 @@ __device__ __forceinline__ void search_layer(const Scorer &sc, bool l2_metric, i
         const HItem c = heap_pop<false>(cand, cand_len);
         st.pops++;
         if (res_len > 0) {
-            const float worst = res[0].dist;
+            const float worst = heap_get(res, 0).dist;
             if (c.dist > worst && res_len >= ef) break;
             if (worst < last_best * 0.999f) {
                 last_best = worst;
@@ -190,7 +190,7 @@ __device__ __forceinline__ void search_layer(const Scorer &sc, bool l2_metric, i
         sc.many(newmask, id_lane, lane, nb_pair, nb_bnd);
         __syncthreads();
         bool has_bound = res_len >= ef;
-        float bound = has_bound ? res[0].dist : 0.0f;
+        float bound = has_bound ? heap_get(res, 0).dist : 0.0f;
         uint64_t todo = newmask;
         while (todo) {
             const int j = __builtin_ctzll(todo);
@@ -211,7 +211,7 @@ __device__ __forceinline__ void search_layer(const Scorer &sc, bool l2_metric, i
             cand_try_push_bounded(cand, cand_len, HItem{id, nd}, cap);
             res_push_bounded(res, res_len, HItem{id, nd}, ef);
             if (res_len >= ef) {
-                bound = res[0].dist;
+                bound = heap_get(res, 0).dist;
                 has_bound = true;
             }
         }
