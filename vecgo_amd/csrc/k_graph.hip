@@ -127,6 +127,7 @@ __device__ inline float rq_formula_g(float qn, float yn, float dimf, float hammi
 
 constexpr int kHnswMaxEf = 1 << 20;  // ... in HBM scratch beyond
 constexpr int kVamanaMaxK = 512;  // results per query: one per lane up to 64, a sorted LDS list beyond
+constexpr int kVamanaLdsCand = 1024;  // items of the exploration heap kept in LDS (8 KiB)
 
 __global__ __launch_bounds__(64) void vamana_search_kernel(
     int kind, int metric, int64_t n, int dim, const uint32_t *__restrict__ graph, int r, uint32_t entry,
@@ -139,12 +140,16 @@ __global__ __launch_bounds__(64) void vamana_search_kernel(
 {
     __shared__ float nb_d[64];
     __shared__ uint64_t res[kVamanaMaxK];  // the result set when k > 64
+    // the exploration heap is unbounded in the reference (up to cand_cap items of HBM scratch here); its first
+    // kVamanaLdsCand items — all of it for an ordinary k = 10 search, which scores ~1000 nodes — live in LDS: a
+    // popped node pushes up to R = 64 neighbours one after the other, each a sift of dependent accesses
+    __shared__ HItem cand_lo[kVamanaLdsCand];
     const int64_t q = blockIdx.x;
     const int lane = threadIdx.x;
     const Sub16 sub = Sub16::make(lane);
     const float *qv = queries + q * dim;
     uint32_t *vis = visited_ws + q * vis_words;
-    HItem *cand = cand_ws + q * cand_cap;
+    const SplitHeap cand{cand_lo, cand_ws + q * cand_cap, kVamanaLdsCand};
     const bool desc = metric != kMetricL2;  // sc.Heap.Reset(s.Metric() != MetricL2), segment.go:597
     const float *lut = luts ? luts + q * static_cast<int64_t>(pq_m) * 256 : nullptr;
     const uint8_t *qc = qcodes ? qcodes + q * static_cast<int64_t>(rq_nb + 4) : nullptr;
@@ -172,27 +177,9 @@ __global__ __launch_bounds__(64) void vamana_search_kernel(
             }
         } else if ((mask >> lane) & 1) {
             if (kind == kVamanaPQ) {
-                // ComputeAsymmetricDistance (pq.go:234-260): term(m) = BuildDistanceTable entry,
-                // summed sequentially over the sub-quantizers
-                // (16 sub-quantizers at a time: the code bytes come as one 16-byte load when the row is
-                // aligned, the 16 table reads are issued together; the sum stays sequential in s)
-                const uint8_t *code = pq_rows + static_cast<int64_t>(id_lane) * pq_m;
-                float distance = 0.0f;
-                int s0 = 0;
-                if ((pq_m & 15) == 0) {
-                    for (; s0 < pq_m; s0 += 16) {
-                        const uint4 c = *reinterpret_cast<const uint4 *>(code + s0);
-                        const uint32_t w[4] = {c.x, c.y, c.z, c.w};
-                        float t[16];
-#pragma unroll
-                        for (int u = 0; u < 16; u++)
-                            t[u] = lut[(s0 + u) * 256 + ((w[u >> 2] >> (8 * (u & 3))) & 0xFFu)];
-#pragma unroll
-                        for (int u = 0; u < 16; u++) distance = distance + t[u];
-                    }
-                }
-                for (int s = s0; s < pq_m; s++) distance = distance + lut[s * 256 + code[s]];
-                nb_d[lane] = distance;
+                // ComputeAsymmetricDistance (pq.go:234-260): term(m) = BuildDistanceTable entry, summed
+                // sequentially over the sub-quantizers (vg_hnsw_layer.hpp: loads batched, sum order kept)
+                nb_d[lane] = pq_asym_distance(pq_rows + static_cast<int64_t>(id_lane) * pq_m, lut, pq_m);
             } else if (kind == kVamanaInt4) {
                 // iq.L2Distance (diskann/segment.go:558-565) = int4L2DistancePrecomputedAvx512 order
                 nb_d[lane] = int4_l2_precomputed(qv, int4_rows + static_cast<int64_t>(id_lane) * ((dim + 1) / 2), dim,

@@ -63,6 +63,43 @@ struct F32Scorer {  // fp32 rows: 16 lanes per row, 4 rows at a time, reference 
     }
 };
 
+// ComputeAsymmetricDistance's sum over NG groups of 16 sub-quantizers starting at s0: the NG 16-byte code loads are
+// issued together, then the 16*NG table reads (their addresses depend on the code bytes) together — two dependent
+// round trips for the whole chunk — and the terms are added in sub-quantizer order, as the reference adds them.
+template <int NG>
+__device__ __forceinline__ float pq_asym_chunk(const uint8_t *__restrict__ code, const float *__restrict__ lut, int s0,
+                                               float distance)
+{
+    uint4 c[NG];
+#pragma unroll
+    for (int g = 0; g < NG; g++) c[g] = *reinterpret_cast<const uint4 *>(code + s0 + 16 * g);
+    float t[NG * 16];
+#pragma unroll
+    for (int g = 0; g < NG; g++) {
+        const uint32_t w[4] = {c[g].x, c[g].y, c[g].z, c[g].w};
+#pragma unroll
+        for (int u = 0; u < 16; u++) t[g * 16 + u] = lut[(s0 + g * 16 + u) * 256 + ((w[u >> 2] >> (8 * (u & 3))) & 0xFFu)];
+    }
+#pragma unroll
+    for (int i = 0; i < NG * 16; i++) distance = distance + t[i];
+    return distance;
+}
+
+// pq.ComputeAsymmetricDistance (pq.go:234-260) of one node's code from the query's table (m * 256 floats in HBM/L2):
+// term(s) = the BuildDistanceTable entry of code byte s, summed sequentially over the sub-quantizers.
+__device__ __forceinline__ float pq_asym_distance(const uint8_t *__restrict__ code, const float *__restrict__ lut, int m)
+{
+    float distance = 0.0f;
+    int s0 = 0;
+    if ((m & 15) == 0) {  // rows of 16-byte multiples are 16-byte aligned (the code array is)
+        for (; s0 + 96 <= m; s0 += 96) distance = pq_asym_chunk<6>(code, lut, s0, distance);
+        for (; s0 + 32 <= m; s0 += 32) distance = pq_asym_chunk<2>(code, lut, s0, distance);
+        for (; s0 + 16 <= m; s0 += 16) distance = pq_asym_chunk<1>(code, lut, s0, distance);
+    }
+    for (int s = s0; s < m; s++) distance = distance + lut[s * 256 + code[s]];
+    return distance;
+}
+
 // PQ codes: pq.ComputeAsymmetricDistance (pq.go:234-260) — the way the reference scores graph nodes from PQ
 // codes (diskann/segment.go:536-557): term(s) = the BuildDistanceTable entry of the node's code byte, summed
 // sequentially over the sub-quantizers.  One node per lane; the query's table (m * 256 floats) is in HBM/L2.
@@ -73,22 +110,7 @@ struct PqScorer {
     static constexpr bool kBounded = false;
     __device__ __forceinline__ float lane_score(uint32_t id) const
     {
-        const uint8_t *code = rows + static_cast<int64_t>(id) * m;
-        float distance = 0.0f;
-        int s0 = 0;
-        if ((m & 15) == 0) {
-            for (; s0 < m; s0 += 16) {
-                const uint4 c = *reinterpret_cast<const uint4 *>(code + s0);
-                const uint32_t w[4] = {c.x, c.y, c.z, c.w};
-                float t[16];
-#pragma unroll
-                for (int u = 0; u < 16; u++) t[u] = lut[(s0 + u) * 256 + ((w[u >> 2] >> (8 * (u & 3))) & 0xFFu)];
-#pragma unroll
-                for (int u = 0; u < 16; u++) distance = distance + t[u];
-            }
-        }
-        for (int s = s0; s < m; s++) distance = distance + lut[s * 256 + code[s]];
-        return distance;
+        return pq_asym_distance(rows + static_cast<int64_t>(id) * m, lut, m);
     }
     __device__ __forceinline__ float one(uint32_t id) const { return lane_score(id); }
     __device__ __forceinline__ void many(uint64_t mask, uint32_t id_lane, int lane, float *nb_pair, float *nb_bnd) const
