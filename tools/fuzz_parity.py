@@ -45,7 +45,7 @@ while time.time() < t_end:
     cfg = dict(n=n, dim=dim, nq=nq, k=k, metric=metric)
     idx = vg.Index(ctx, n, dim, vg.Metric(metric))
     idx.set_vectors(x)
-    which = rng.integers(0, 7)
+    which = rng.integers(0, 9)
     try:
         if which == 0:
             ids, sc = idx.search_flat(q, k)
@@ -116,7 +116,7 @@ while time.time() < t_end:
         elif which == 5 and n >= 16:
             gm = int(rng.choice([4, 8, 16]))
             l0, upper, entry = graphs.build_hnsw(x, m=gm, seed=int(rng.integers(0, 1000)))
-            ef = int(rng.choice([1, 8, 33, 100, 300]))
+            ef = int(rng.choice([1, 8, 33, 100, 300, 513, 600, 1500, 5000]))   # > 512: heaps split between LDS and HBM scratch
             kk = min(k, 64)
             oidx = o.HnswIndex(x, dim, l0, upper, entry, metric=metric)
             idx.set_hnsw_graph(l0, upper, entry, m=gm)
@@ -138,6 +138,37 @@ while time.time() < t_end:
             idx.set_vamana_graph(g, entry)
             ids, sc, st = idx.search_vamana(q, kk, kind=0, stats=True)
             compare("vamana", dict(cfg, r=r), ids, sc, [oidx.search(q[i], kk)[:2] for i in range(nq)])
+        elif which == 7 and 16 <= n <= 1000:
+            # hnsw.Insert loop on the GPU (batched) = the letter-by-letter CPU build, ties included; then a search over it
+            gm = int(rng.choice([4, 8, 16]))
+            efc = int(rng.choice([8, 40, 100]))
+            mb = int(rng.choice([1, 7, 64]))
+            gd = int(rng.choice([1, 4, 32]))
+            idx.build_hnsw(m=gm, ef_construction=efc, max_batch=mb, growth_div=gd)
+            l0, upper, entry = idx.get_hnsw_graph()
+            ol0, oupper, oentry = o.hnsw_build(x, dim, metric=metric, m=gm, ef=efc, max_batch=mb, growth_div=gd)
+            same = entry == oentry and np.array_equal(l0, ol0) and len(upper) == len(oupper) and \
+                all(np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) for a, b in zip(upper, oupper))
+            if not same:
+                fails += 1
+                print(f"MISMATCH hnsw_build {cfg} m={gm} ef={efc} max_batch={mb} growth_div={gd}", flush=True)
+        elif which == 8 and metric == 0 and n >= 256 and dim % 8 == 0 and dim // 8 <= 152:
+            # graph walk scored from PQ codes (ComputeAsymmetricDistance order), incl. the split-heap range
+            gm = int(rng.choice([4, 8, 16]))
+            l0, upper, entry = graphs.build_hnsw(x, m=gm, seed=int(rng.integers(0, 1000)))
+            m = 8
+            pq = vg.ProductQuantizer(ctx, dim, m, 256)
+            pq.train(x, iters=2, seed=5)
+            codes = pq.encode(x)
+            cb, scales, offsets = pq.codebooks()
+            opq = o.ProductQuantizer(dim, m, 256); opq.set_codebooks(cb, scales, offsets)
+            idx.set_hnsw_graph(l0, upper, entry, m=gm)
+            idx.set_pq_codes(pq, codes)
+            ef = int(rng.choice([10, 64, 300, 700, 2000]))
+            kk = min(k, 64)
+            ids, sc = idx.search_hnsw_pq(q, kk, ef)
+            oidx = o.HnswIndex(x, dim, l0, upper, entry, m=gm, pq=opq, codes=codes)
+            compare("hnsw_pq", dict(cfg, m=gm, ef=ef), ids, sc, [oidx.search(q[i], kk, ef)[:2] for i in range(nq)])
     except vg.VecgoHipError as e:
         fails += 1
         print(f"ERROR {cfg} which={which}: {e}", flush=True)
