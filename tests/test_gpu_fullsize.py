@@ -296,7 +296,8 @@ def test_partition_probed_flat_1m_x_768(vg, ctx):
 
 def test_built_hnsw_graph_1m_x_768(vg, ctx):
     """The bench's own configuration: HNSW built by vg_hnsw_build (M = 32, M0 = 64, EF = 300) on 1M x 768, then
-    searched at ef = 128 (heaps in LDS) and ef = 1024 (heaps in HBM scratch), on fp32 rows and on PQ codes, and
+    searched at ef = 128 (heaps in LDS) and ef = 1024 / 4096 (heaps split between LDS and HBM scratch), on fp32 rows and
+    on PQ codes (ef = 256 and 2048), and
     walked as a Vamana graph (layer 0, R = 64) with PQ and RaBitQ scoring.  Whole queries are replayed by the
     oracle over the same graph: ids and scores bit-exact."""
     n, dim, k = 1_000_000, 768, 10
@@ -312,7 +313,7 @@ def test_built_hnsw_graph_1m_x_768(vg, ctx):
     assert len(upper) >= lv.max()                        # the top level is at least what the sample saw
     hbase = base.cpu().numpy(); hq = q.cpu().numpy()
     oidx = o.HnswIndex(hbase, dim, l0, upper, entry, m=32)
-    for ef, nrep in ((128, 4), (1024, 2)):
+    for ef, nrep in ((128, 4), (1024, 2), (4096, 1)):
         ids, sc = idx.search_hnsw(q, k, ef)
         rid, rsc = o.replay(o.BENCH_HNSW, hq[:nrep], k, hnsw=oidx, ef=ef)
         assert np.array_equal(rid, np_(ids).view(np.uint32)[:nrep]), ef
@@ -328,6 +329,9 @@ def test_built_hnsw_graph_1m_x_768(vg, ctx):
     opidx = o.HnswIndex(hbase, dim, l0, upper, entry, m=32, pq=opq, codes=hcodes)
     rid, rsc = o.replay(o.BENCH_HNSW, hq[:2], 64, hnsw=opidx, ef=256)
     assert np.array_equal(rid, np_(ids).view(np.uint32)[:2]) and np.array_equal(bits(rsc), bits(np_(sc)[:2]))
+    ids, sc = idx.search_hnsw_pq(q, 64, 2048)
+    rid, rsc = o.replay(o.BENCH_HNSW, hq[:1], 64, hnsw=opidx, ef=2048)
+    assert np.array_equal(rid, np_(ids).view(np.uint32)[:1]) and np.array_equal(bits(rsc), bits(np_(sc)[:1]))
     idx.set_vamana_graph(l0, entry)
     ids, sc = idx.search_vamana(q, k, kind=1)
     ov = o.VamanaIndex(l0, entry, dim, o.VAMANA_PQ, pq=opq, codes=hcodes)
