@@ -789,7 +789,10 @@ def main():
 
     extra = {}
     if world > 1:   # BASELINE configs[4]: every rank takes part
-        extra = multi_gpu_legs(vg, ctx, sharded, world, rank, device, stream, comm)
+        try:
+            extra = multi_gpu_legs(vg, ctx, sharded, world, rank, device, stream, comm)
+        except Exception as e:   # an extra must not cost the run its headline line (the same error on every rank
+            extra = {"multi_gpu_legs_error": f"{type(e).__name__}: {e}"}   # leaves the ranks in step)
 
     if rank != 0:
         if world > 1:
