@@ -27,6 +27,7 @@
 // distances the heap is replayed in LDS), so the graph equals what a letter-by-letter CPU run of hnsw.go builds
 // (the test oracle) — bit for bit, ties included.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <vector>
 
@@ -293,6 +294,8 @@ struct LinkCounters {
 };
 struct LinkTotals {  // over the whole build (VG_BUILD_DEBUG prints them)
     unsigned long long records, skipped, appended, pruned, good_rows_seen, longest_chain;
+    // rows with >= 1000 records in a batch (hubs), 100 MHz ticks: where one workgroup's time goes
+    unsigned long long hub_rows, hub_records, hub_applied, hub_sort, hub_scan, hub_gather, hub_replay, hub_total, hub_ties, max_wg;
 };
 
 // Both kernels append to ONE counter: a per-thread atomicAdd on it would serialise ~400 k atomics per batch on one
@@ -387,7 +390,8 @@ __global__ __launch_bounds__(kLinkThreads) void build_link_kernel(BuildGraph g, 
                                                                   const uint32_t *__restrict__ roff,
                                                                   const uint32_t *__restrict__ srt_t,
                                                                   const float *__restrict__ srt_d,
-                                                                  uint32_t *__restrict__ ord, LinkTotals *__restrict__ totals)
+                                                                  uint32_t *__restrict__ ord, float *__restrict__ ord_d,
+                                                                  LinkTotals *__restrict__ totals)
 {
     __shared__ LinkShared sh;
     if (blockIdx.x >= ctr->nwork) return;
@@ -399,16 +403,22 @@ __global__ __launch_bounds__(kLinkThreads) void build_link_kernel(BuildGraph g, 
     const int nadd = rcnt[row];
     const uint32_t *at = srt_t + roff[row];
     const float *ad = srt_d + roff[row];
-    uint32_t *my_ord = ord + roff[row];
-    // the records in ascending t (distinct per row): rank sort by the whole workgroup, once
-    for (int i = tid; i < nadd; i += kLinkThreads) {
+    const unsigned long long tk_all = totals ? wall_clock64() : 0;
+    const bool timed = totals != nullptr && nadd >= 1000;
+    unsigned long long tk_sort = 0, tk_scan = 0, tk_gather = 0, tk_replay = 0;
+    const unsigned long long tk_begin = timed ? wall_clock64() : 0;
+    uint32_t *st = ord + roff[row];   // the row's records in ascending t (distinct per row): new node ...
+    float *sd = ord_d + roff[row];    // ... and its distance to the row's node
+    for (int i = tid; i < nadd; i += kLinkThreads) {  // rank sort by the whole workgroup, once
         const uint32_t ti = at[i];
         int rank = 0;
         for (int j = 0; j < nadd; j++) rank += at[j] < ti ? 1 : 0;
-        my_ord[rank] = static_cast<uint32_t>(i);
+        st[rank] = ti;
+        sd[rank] = ad[i];
     }
     __threadfence_block();
     __syncthreads();
+    if (timed) tk_sort = wall_clock64() - tk_begin;
 
     // row state: wave 0 only
     int cnt = 0;
@@ -416,7 +426,7 @@ __global__ __launch_bounds__(kLinkThreads) void build_link_kernel(BuildGraph g, 
     float dist = 0.0f;
     uint64_t bits = 0;
     bool good = false, ties = false;
-    unsigned int n_skip = 0, n_app = 0, n_prune = 0;
+    unsigned int n_skip = 0, n_app = 0, n_prune = 0, n_tie = 0;
     auto row_has_ties = [&]() {
         const float nxt = __shfl_down(dist, 1);
         return __ballot(lane + 1 < cnt && dist == nxt) != 0;
@@ -437,19 +447,41 @@ __global__ __launch_bounds__(kLinkThreads) void build_link_kernel(BuildGraph g, 
         sh.mid[lane] = id;
     }
 
-    for (int a = 0; a < nadd; a++) {
+    // Wave 0 walks the records 64 at a time (one coalesced load per chunk, lane i = record chunk*64 + i) and tests
+    // the cheap way out for a whole chunk at once: the row's state only changes when a record is actually applied,
+    // so everything up to the first record that needs work is skipped without a barrier or a memory access.  The
+    // other waves only see the records that need their 64 distances.
+    int a = 0, chunk = -1;
+    uint32_t ct = 0;
+    float cdist = 0.0f;
+    for (;;) {
         uint32_t t = 0;
         float dt = 0.0f;
+        const unsigned long long tk0 = timed ? wall_clock64() : 0;
         if (wave == 0) {
-            const uint32_t ri = my_ord[a];
-            t = at[ri];
-            dt = ad[ri];
-            int action = 1;
-            if (__ballot(lane < cnt && id == t)) {
-                action = 0;  // already connected (hnsw.go:477-486)
-            } else if (cnt == deg && good && !ties && dt > __shfl(dist, deg - 1)) {
-                action = 0;
-                n_skip++;
+            int action = 2;  // 2 = no record left
+            while (a < nadd) {
+                if ((a >> 6) != chunk) {
+                    chunk = a >> 6;
+                    const int i = chunk * 64 + lane;
+                    ct = i < nadd ? st[i] : 0u;
+                    cdist = i < nadd ? sd[i] : 0.0f;
+                }
+                const int i = chunk * 64 + lane;
+                const bool pending = i >= a && i < nadd;
+                const bool far = cnt == deg && good && !ties && cdist > __shfl(dist, deg - 1);
+                const uint64_t work = __ballot(pending && !far);  // records of this chunk that need a closer look
+                const int rest = nadd - chunk * 64 < 64 ? nadd - chunk * 64 : 64;  // records in this chunk
+                const int f = work ? __builtin_ctzll(work) : rest;                  // lane of the first of them
+                n_skip += static_cast<unsigned int>(f - (a & 63));
+                a = chunk * 64 + f;
+                if (f == rest) continue;  // the chunk is done: next chunk (or the end)
+                t = __shfl(ct, f);
+                dt = __shfl(cdist, f);
+                a++;
+                if (__ballot(lane < cnt && id == t)) continue;  // already connected (hnsw.go:477-486)
+                action = 1;
+                break;
             }
             if (lane == 0) {
                 sh.t = t;
@@ -458,10 +490,9 @@ __global__ __launch_bounds__(kLinkThreads) void build_link_kernel(BuildGraph g, 
             }
         }
         __syncthreads();
-        if (sh.action == 0) {
-            __syncthreads();  // sh.action is rewritten by wave 0 in the next trip
-            continue;
-        }
+        const unsigned long long tk1 = timed ? wall_clock64() : 0;
+        tk_scan += tk1 - tk0;
+        if (sh.action == 2) break;
         {   // distances between the new node and the row's members: wave w scores members 16w .. 16w+15
             const uint32_t tt = sh.t;
             const int c = sh.cnt;
@@ -475,6 +506,8 @@ __global__ __launch_bounds__(kLinkThreads) void build_link_kernel(BuildGraph g, 
             }
         }
         __syncthreads();
+        const unsigned long long tk2 = timed ? wall_clock64() : 0;
+        tk_gather += tk2 - tk1;
         if (wave == 0) {
             const float pd = lane < cnt ? sh.pd[lane] : 0.0f;
             const uint64_t tbits = __ballot(lane < cnt && pd < dt);       // row of the new node
@@ -521,6 +554,7 @@ __global__ __launch_bounds__(kLinkThreads) void build_link_kernel(BuildGraph g, 
                 int rank_t = 0;
                 for (int j = 0; j < deg; j++) rank_t += sh.cd[j] < dt ? 1 : 0;
                 if (__ballot(tie)) {
+                    n_tie++;
                     int hl = 0;
                     for (int j = 0; j < nc; j++) heap_push<true>(sh.heap, hl, HItem{static_cast<uint32_t>(j), sh.cd[j]});
                     for (int j = nc - 1; j >= 0; j--) {
@@ -531,48 +565,75 @@ __global__ __launch_bounds__(kLinkThreads) void build_link_kernel(BuildGraph g, 
                     if (lane < deg) sh.seq[rank] = lane;
                     if (lane == 0) sh.seq[rank_t] = deg;
                 }
-                if (lane < nc) sh.newpos[lane] = -1;
-                if (lane == 0) sh.newpos[64] = -1;
                 wave_sync();
-                // applyHeuristic + fillUpNeighbors over the bit rows (wave-uniform)
+                // applyHeuristic + fillUpNeighbors over the bit rows.  The greedy pass is sequential by nature; what
+                // it reads is brought into registers first — lane p: the candidate at sorted position p, its bit row and
+                // its bit against the new node (position 64, the last of 65, is kept as scalars) — so that a step is a
+                // few readlanes instead of a chain of dependent LDS reads (this loop was half of a back link's time).
+                const int my_ci = sh.seq[lane < nc ? lane : 0];
+                const uint64_t my_cb = sh.cbits[my_ci];
+                const uint32_t my_ctb = sh.ctbit[my_ci];
+                const int last_ci = sh.seq[nc - 1];  // only meaningful when nc == 65
+                const uint64_t last_cb = sh.cbits[last_ci];
+                const uint32_t last_ctb = sh.ctbit[last_ci];
+                int my_newpos = -1;  // lane j < deg: new slot of member j
+                int newpos_t = -1;   // new slot of the new node
                 uint64_t selmask = 0;
                 bool sel_t = false;
                 int nsel = 0;
                 for (int p = 0; p < nc && nsel < deg; p++) {
-                    const int ci = sh.seq[p];
-                    const bool bad = (sh.cbits[ci] & selmask) != 0 || (sh.ctbit[ci] != 0 && sel_t);
+                    int ci;
+                    uint64_t cb;
+                    uint32_t ctb;
+                    if (p < 64) {
+                        ci = __builtin_amdgcn_readlane(my_ci, p);
+                        cb = readlane_u64(my_cb, p);
+                        ctb = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(my_ctb), p));
+                    } else {
+                        ci = last_ci;
+                        cb = last_cb;
+                        ctb = last_ctb;
+                    }
+                    const bool bad = (cb & selmask) != 0 || (ctb != 0 && sel_t);
                     if (!bad) {
-                        if (ci == deg)
+                        if (ci == deg) {
                             sel_t = true;
-                        else
+                            newpos_t = nsel;
+                        } else {
                             selmask |= 1ull << ci;
-                        if (lane == 0) sh.newpos[ci] = nsel;
+                            if (lane == ci) my_newpos = nsel;
+                        }
                         nsel++;
                     }
                 }
                 const int nchosen = nsel;
                 for (int p = 0; p < nc && nsel < deg; p++) {
-                    const int ci = sh.seq[p];
+                    const int ci = p < 64 ? __builtin_amdgcn_readlane(my_ci, p) : last_ci;
                     const bool chosen = ci == deg ? sel_t : ((selmask >> ci) & 1) != 0;
                     if (!chosen) {
-                        if (lane == 0) sh.newpos[ci] = nsel;
+                        if (ci == deg)
+                            newpos_t = nsel;
+                        else if (lane == ci)
+                            my_newpos = nsel;
                         nsel++;
                     }
                 }
+                // the row in its new order (slot -> candidate through an LDS scatter); the columns of the bit matrix
+                // move with their members
+                sh.newpos[lane] = -1;  // reused as slot -> candidate
                 wave_sync();
-                // the row in its new order; columns of the bit matrix move with their members
-                int src = -1;
-                for (int j = 0; j < nc; j++)
-                    if (sh.newpos[j] == lane) src = j;
+                if (lane < deg && my_newpos >= 0) sh.newpos[my_newpos] = lane;
+                if (lane == 0 && newpos_t >= 0) sh.newpos[newpos_t] = deg;
+                wave_sync();
+                const int src = sh.newpos[lane];
                 uint64_t nb = 0;
                 if (src >= 0) {
                     const uint64_t ob = sh.cbits[src];
                     for (int j = 0; j < deg; j++) {
-                        const int np = sh.newpos[j];
+                        const int np = __builtin_amdgcn_readlane(my_newpos, j);
                         if (np >= 0) nb |= ((ob >> j) & 1ull) << np;
                     }
-                    const int npt = sh.newpos[deg];
-                    if (npt >= 0) nb |= static_cast<uint64_t>(sh.ctbit[src]) << npt;
+                    if (newpos_t >= 0) nb |= static_cast<uint64_t>(sh.ctbit[src]) << newpos_t;
                     id = sh.cid[src];
                     dist = sh.cd[src];
                 } else {
@@ -588,6 +649,7 @@ __global__ __launch_bounds__(kLinkThreads) void build_link_kernel(BuildGraph g, 
             sh.mid[lane] = id;
         }
         __syncthreads();
+        if (timed) tk_replay += wall_clock64() - tk2;
     }
     if (wave == 0) {
         if (lane < deg) {
@@ -603,6 +665,22 @@ __global__ __launch_bounds__(kLinkThreads) void build_link_kernel(BuildGraph g, 
                 atomicAdd(&totals->pruned, static_cast<unsigned long long>(n_prune));
                 atomicAdd(&totals->good_rows_seen, static_cast<unsigned long long>(g.good[row] ? 1 : 0));
                 atomicMax(&totals->longest_chain, static_cast<unsigned long long>(nadd));
+                if (timed) {
+                    atomicAdd(&totals->hub_rows, 1ull);
+                    atomicAdd(&totals->hub_records, static_cast<unsigned long long>(nadd));
+                    atomicAdd(&totals->hub_applied, static_cast<unsigned long long>(n_app + n_prune));
+                    atomicAdd(&totals->hub_sort, tk_sort);
+                    atomicAdd(&totals->hub_scan, tk_scan);
+                    atomicAdd(&totals->hub_gather, tk_gather);
+                    atomicAdd(&totals->hub_replay, tk_replay);
+                    atomicAdd(&totals->hub_total, wall_clock64() - tk_begin);
+                    atomicAdd(&totals->hub_ties, static_cast<unsigned long long>(n_tie));
+                }
+                {
+                    const unsigned long long tk = wall_clock64() - tk_all;
+                    atomicMax(&totals->max_wg, (tk << 40) | (static_cast<unsigned long long>(nadd & 0xFFFF) << 24) |
+                                                   (static_cast<unsigned long long>(n_prune & 0xFFFF) << 8) | (n_tie > 255 ? 255 : n_tie));
+                }
             }
             g.cnt[row] = cnt;
             g.good[row] = good ? 1 : 0;
@@ -753,7 +831,7 @@ VG_API int32_t vg_hnsw_build(vg_index *idx, int32_t m, int32_t ef_construction, 
              static_cast<long long>(n));
 
     vg::DevBuf<uint32_t> d_ids, d_slots, d_vis, d_cand_ids, d_rec_row, d_rec_t, d_work, d_roff, d_srt_t, d_pair_node, d_ord;
-    vg::DevBuf<float> d_dist, d_cand_d, d_rec_d, d_srt_d;
+    vg::DevBuf<float> d_dist, d_cand_d, d_rec_d, d_srt_d, d_ordd;
     vg::DevBuf<uint64_t> d_bits;
     vg::DevBuf<int32_t> d_cnt, d_levels, d_cand_n, d_rcnt, d_rfill, d_pair_level;
     vg::DevBuf<uint8_t> d_good;
@@ -783,6 +861,7 @@ VG_API int32_t vg_hnsw_build(vg_index *idx, int32_t m, int32_t ef_construction, 
     VG_TRY(d_srt_t.alloc(static_cast<size_t>(max_rec)));
     VG_TRY(d_srt_d.alloc(static_cast<size_t>(max_rec)));
     VG_TRY(d_ord.alloc(static_cast<size_t>(max_rec)));
+    VG_TRY(d_ordd.alloc(static_cast<size_t>(max_rec)));
     VG_TRY(d_work.alloc(static_cast<size_t>(std::min(max_rec, total_rows))));
     VG_TRY(d_roff.alloc(static_cast<size_t>(total_rows)));
     VG_TRY(d_rcnt.alloc(static_cast<size_t>(total_rows)));
@@ -810,6 +889,8 @@ VG_API int32_t vg_hnsw_build(vg_index *idx, int32_t m, int32_t ef_construction, 
     const size_t lds = static_cast<size_t>(3 * ef) * sizeof(vg::HItem) + 128 * sizeof(float);
     VG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(vg::build_search_kernel),
                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+    auto dbg_t0 = std::chrono::steady_clock::now();
+    unsigned long long dbg_max_chain = 0;
     for (const Batch &bt : batches) {
         const int64_t vis_words = (bt.t0 + 31) / 32;  // only nodes below t0 are reachable
         const int64_t nrec = bt.npairs * m0;
@@ -837,7 +918,24 @@ VG_API int32_t vg_hnsw_build(vg_index *idx, int32_t m, int32_t ef_construction, 
         VG_LAUNCH(vg::build_fill_kernel, dim3(gb), dim3(256), 0, st, d_rec_row.p, d_rec_t.p, d_rec_d.p, nrec,
                   d_roff.p, d_rfill.p, d_srt_t.p, d_srt_d.p);
         VG_LAUNCH(vg::build_link_kernel, dim3(static_cast<unsigned>(max_work)), dim3(vg::kLinkThreads), 0, st, g, d_work.p,
-                  d_ctr.p, d_rcnt.p, d_rfill.p, d_roff.p, d_srt_t.p, d_srt_d.p, d_ord.p, debug ? d_totals.p : nullptr);
+                  d_ctr.p, d_rcnt.p, d_rfill.p, d_roff.p, d_srt_t.p, d_srt_d.p, d_ord.p, d_ordd.p, debug ? d_totals.p : nullptr);
+        if (debug) {  // per-batch wall time and the batch's longest per-row chain (the chain is a running maximum: reset it)
+            VG_HIP(hipStreamSynchronize(st));
+            const auto now = std::chrono::steady_clock::now();
+            vg::LinkTotals t{};
+            VG_HIP(hipMemcpy(&t, d_totals.p, sizeof(t), hipMemcpyDeviceToHost));
+            const size_t bi = static_cast<size_t>(&bt - batches.data());
+            if (bi % 16 == 0 || bi + 1 == batches.size())
+                fprintf(stderr, "vg_hnsw_build: batch %zu: %lld nodes, %.2f ms, longest chain %llu; longest link workgroup %.2f ms "
+                                "(%llu records, %llu pruned, %llu heap replays)\n", bi, static_cast<long long>(bt.size),
+                        std::chrono::duration<double, std::milli>(now - dbg_t0).count(), t.longest_chain, (t.max_wg >> 40) / 1e5,
+                        (t.max_wg >> 24) & 0xFFFF, (t.max_wg >> 8) & 0xFFFF, t.max_wg & 0xFF);
+            dbg_t0 = now;
+            dbg_max_chain = std::max(dbg_max_chain, t.longest_chain);
+            const unsigned long long zero = 0;
+            VG_HIP(hipMemcpy(&d_totals.p->longest_chain, &zero, sizeof(zero), hipMemcpyHostToDevice));
+            VG_HIP(hipMemcpy(&d_totals.p->max_wg, &zero, sizeof(zero), hipMemcpyHostToDevice));
+        }
     }
     VG_HIP(hipStreamSynchronize(st));
     if (debug) {
@@ -845,7 +943,12 @@ VG_API int32_t vg_hnsw_build(vg_index *idx, int32_t m, int32_t ef_construction, 
         VG_HIP(hipMemcpy(&t, d_totals.p, sizeof(t), hipMemcpyDeviceToHost));
         fprintf(stderr, "vg_hnsw_build: back links %llu = %llu skipped (farther than a fully chosen row's last member) + %llu appended + "
                         "%llu pruned; target-row visits that found the row fully chosen %llu; longest per-row chain in one batch %llu\n",
-                t.records, t.skipped, t.appended, t.pruned, t.good_rows_seen, t.longest_chain);
+                t.records, t.skipped, t.appended, t.pruned, t.good_rows_seen, std::max(dbg_max_chain, t.longest_chain));
+        fprintf(stderr, "vg_hnsw_build: rows with >= 1000 back links in a batch: %llu visits, %llu records of which %llu applied; per visit "
+                        "%.1f us in all = sort %.1f + scan %.1f + gather %.1f + replay %.1f (us); heap replays (ties) %llu\n", t.hub_rows, t.hub_records, t.hub_applied,
+                t.hub_rows ? t.hub_total / 100.0 / t.hub_rows : 0.0, t.hub_rows ? t.hub_sort / 100.0 / t.hub_rows : 0.0,
+                t.hub_rows ? t.hub_scan / 100.0 / t.hub_rows : 0.0, t.hub_rows ? t.hub_gather / 100.0 / t.hub_rows : 0.0,
+                t.hub_rows ? t.hub_replay / 100.0 / t.hub_rows : 0.0, t.hub_ties);
     }
 
     // hand the graph to the index in vg_index_set_hnsw_graph's layout
