@@ -18,11 +18,13 @@ idx.set_pq_codes(pq, pq.encode(rows))
 l0, _, entry = idx.get_hnsw_graph(); idx.set_vamana_graph(l0, entry)
 q = bench.gen_queries(8, dev).reshape(-1, D)[:NQ].contiguous()
 out = {}
-for name, fn in (("hnsw_search", lambda s: idx.search_hnsw(q, K, 128, stats=s)),
-                 ("hnsw_search_pq", lambda s: idx.search_hnsw_pq(q, K, 128, stats=s)),
+for name, fn in (("hnsw_search", lambda s: idx.search_hnsw(q, K, 128, stats="full" if s else False)),
+                 ("hnsw_search_pq", lambda s: idx.search_hnsw_pq(q, K, 128, stats="full" if s else False)),
                  ("vamana_search", lambda s: idx.search_vamana(q, K, kind=1, stats=s))):
     _, _, st = fn(True)
     for _ in range(3): fn(False)
     torch.cuda.synchronize()
     out[name] = {"distance_computations_per_launch": float(st[:, 1].sum()), "pops_per_launch": float(st[:, 3].sum())}
+    if st.shape[1] > 4:
+        out[name]["descent_distance_computations_per_launch"] = float(st[:, 4].sum())
 print(json.dumps({"n": N, "nq": NQ, **out}))
