@@ -426,6 +426,7 @@ __global__ __launch_bounds__(kLinkThreads) void build_link_kernel(BuildGraph g, 
     float dist = 0.0f;
     uint64_t bits = 0;
     bool good = false, ties = false;
+    bool stable = false;  // a good row WITH ties that a far record was seen to leave exactly as it is (see below)
     unsigned int n_skip = 0, n_app = 0, n_prune = 0, n_tie = 0;
     auto row_has_ties = [&]() {
         const float nxt = __shfl_down(dist, 1);
@@ -440,7 +441,11 @@ __global__ __launch_bounds__(kLinkThreads) void build_link_kernel(BuildGraph g, 
         // so the row is in ascending distance order.  A new node farther than the farthest member then sorts last, the
         // heuristic re-chooses the 64 members, stops (len(result) >= m, hnsw.go:1054) and never looks at the newcomer:
         // the row is left exactly as it is — unless two members are equally far, in which case the reference's heap
-        // may hand them back in another order, so rows with ties take the long way.  75 % of the back links of the
+        // may hand them back in another order, so a row with ties takes the long way ONCE: a newcomer farther than
+        // every member compares the same way against everything whatever its distance, so if one such record leaves the
+        // row exactly as it was (every member re-chosen, in the same slots), every later one will too, until the row
+        // changes (`stable`).  Hub rows — thousands of back links per batch, and two bit-equal cached distances among
+        // their 64 almost always — would otherwise replay the heap for every record.  75 % of the back links of the
         // 1M x 768 build end here.
         good = g.good[row] != 0;
         ties = row_has_ties();
@@ -469,7 +474,7 @@ __global__ __launch_bounds__(kLinkThreads) void build_link_kernel(BuildGraph g, 
                 }
                 const int i = chunk * 64 + lane;
                 const bool pending = i >= a && i < nadd;
-                const bool far = cnt == deg && good && !ties && cdist > __shfl(dist, deg - 1);
+                const bool far = cnt == deg && good && (!ties || stable) && cdist > __shfl(dist, deg - 1);
                 const uint64_t work = __ballot(pending && !far);  // records of this chunk that need a closer look
                 const int rest = nadd - chunk * 64 < 64 ? nadd - chunk * 64 : 64;  // records in this chunk
                 const int f = work ? __builtin_ctzll(work) : rest;                  // lane of the first of them
@@ -521,6 +526,7 @@ __global__ __launch_bounds__(kLinkThreads) void build_link_kernel(BuildGraph g, 
                 }
                 cnt++;
                 n_app++;
+                stable = false;
                 good = false;  // appended, not chosen
                 ties = row_has_ties();
             } else {
@@ -528,6 +534,7 @@ __global__ __launch_bounds__(kLinkThreads) void build_link_kernel(BuildGraph g, 
                 // and back out nearest first.  Distinct distances: the order is the sort by distance.  Equal
                 // distances: whatever the heap does, so the heap is replayed.
                 n_prune++;
+                const bool was_far = good && dt > __shfl(dist, deg - 1);  // farther than every member of a fully chosen row
                 const int nc = deg + 1;
                 if (lane < deg) {
                     sh.cd[lane] = dist;
@@ -640,10 +647,15 @@ __global__ __launch_bounds__(kLinkThreads) void build_link_kernel(BuildGraph g, 
                     id = VG_INVALID_ID;
                     dist = 0.0f;
                 }
+                const bool unchanged = newpos_t < 0 && __ballot(lane < deg && src != lane) == 0;
                 bits = nb;
                 cnt = nsel;
                 good = nchosen == deg;
                 ties = row_has_ties();
+                if (!unchanged)
+                    stable = false;
+                else if (was_far && good)
+                    stable = true;
             }
             wave_sync();
             sh.mid[lane] = id;
