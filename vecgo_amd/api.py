@@ -1082,6 +1082,11 @@ class Index:
         """flat.Segment.Search fp32 branch / hnsw.BruteSearch: exact brute force."""
         return self._search(self._lib.vg_search_flat, queries, k, out=out, stream=stream)
 
+    def enable_bf16_filter(self, on: bool = True, stream=None):
+        """vg_index_enable_bf16_filter: nominate with a bfloat16 MFMA GEMM over a bf16 copy of the rows; the exact fp32
+        re-score and the (widened) proof keep ids and scores bit-identical."""
+        check(self._lib.vg_index_enable_bf16_filter(self._h, C.c_int32(1 if on else 0), _stream_ptr(stream)))
+
     def flat_stats(self, stream=None):
         """(queries searched, queries answered by the exhaustive kernel) since set_vectors."""
         q, e = C.c_int64(0), C.c_int64(0)

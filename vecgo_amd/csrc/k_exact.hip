@@ -144,8 +144,10 @@ VG_API int32_t vg_index_set_vectors(vg_index *idx, const float *base, void *stre
         VG_HIP(hipFree(idx->d_norms));
         VG_HIP(hipFree(idx->d_norm_max));
         VG_HIP(hipFree(idx->d_flat_stats));
+        if (idx->d_vectors_bf16) VG_HIP(hipFree(idx->d_vectors_bf16));  // a copy of the OLD rows: enable again after this
         idx->d_vectors = idx->d_norms = idx->d_norm_max = nullptr;
         idx->d_flat_stats = nullptr;
+        idx->d_vectors_bf16 = nullptr;
     }
     if (idx->n == 0) return VG_OK;
     // all four allocations or none: a search must never find rows without their norms / counters

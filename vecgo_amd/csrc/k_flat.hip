@@ -39,8 +39,18 @@ struct GemmArgs {
 };
 
 template <bool DOT, int MODE>
-static int32_t launch_gemm_t(bool dma, unsigned blocks, hipStream_t st, const GemmArgs &a)
+static int32_t launch_gemm_t(bool dma, unsigned blocks, hipStream_t st, const GemmArgs &a, bool bf16)
 {
+    if (bf16) {  // rows of bfloat16 (a.dim = 4-byte words per row): the 128-query LDS-DMA tile only
+        constexpr int M = MODE == 0 ? 1 : MODE;
+        auto kern = flat_gemm_dma_kernel<DOT, M, 0, true>;
+        VG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   static_cast<int>(kDmaLdsBytes)));
+        VG_LAUNCH(kern, dim3(blocks), dim3(kGemmThreads), kDmaLdsBytes, st, a.queries, a.nq, a.base, a.n, a.dim,
+                  a.norms, a.scores, a.tile_stride, a.out_cols, a.thr, a.thr_stride, a.thr_off, a.counts, a.cand,
+                  a.cap);
+        return VG_OK;
+    }
     // (test hook kHookFlatNoSmallTile: always the 128-query tile)
     if (dma && MODE != 0 && a.nq <= 2 * kG32BM && !hook(kHookFlatNoSmallTile)) {  // 1-2 blocks of 32 queries: HBM-bound shapes
         constexpr int M = MODE == 0 ? 1 : MODE;
@@ -73,9 +83,23 @@ static int32_t launch_gemm_t(bool dma, unsigned blocks, hipStream_t st, const Ge
 }
 
 template <int MODE>
-static int32_t launch_gemm(bool dot, bool dma, unsigned blocks, hipStream_t st, const GemmArgs &a)
+static int32_t launch_gemm(bool dot, bool dma, unsigned blocks, hipStream_t st, const GemmArgs &a, bool bf16 = false)
 {
-    return dot ? launch_gemm_t<true, MODE>(dma, blocks, st, a) : launch_gemm_t<false, MODE>(dma, blocks, st, a);
+    return dot ? launch_gemm_t<true, MODE>(dma, blocks, st, a, bf16) : launch_gemm_t<false, MODE>(dma, blocks, st, a, bf16);
+}
+
+// fp32 -> bfloat16, round to nearest even (NaN stays NaN)
+__global__ void f32_to_bf16_kernel(const float *__restrict__ src, int64_t count, uint16_t *__restrict__ dst)
+{
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const uint32_t u = __float_as_uint(src[i]);
+    uint16_t r;
+    if ((u & 0x7F800000u) == 0x7F800000u && (u & 0x007FFFFFu) != 0)
+        r = static_cast<uint16_t>((u >> 16) | 0x0040u);
+    else
+        r = static_cast<uint16_t>((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+    dst[i] = r;
 }
 
 // After the proofs: the work list of step 4 (todo[0] = how many queries need the exhaustive scan,
@@ -215,7 +239,7 @@ __global__ __launch_bounds__(256) void flat_verify_kernel(
     const float *__restrict__ norms_max /* [1] */, const uint32_t *__restrict__ cand_ids,
     const float *__restrict__ cand_scores, int kc, int k, uint32_t *__restrict__ ids,
     float *__restrict__ scores, int *__restrict__ fallback, const float *__restrict__ thr, int thr_stride,
-    int thr_off, const int *__restrict__ counts, int cap)
+    int thr_off, const int *__restrict__ counts, int cap, float eps_extra)
 {
     __shared__ uint64_t keys[64];
     const Sub16 sub = Sub16::make(threadIdx.x);
@@ -259,7 +283,8 @@ __global__ __launch_bounds__(256) void flat_verify_kernel(
     if (ok && !have_all) {
         const float xmax = norms_max[0];
         // fp32 GEMM-form vs exact: |err| <= ~ 2*dim*2^-24*(|q||x|) per dot; bound generously
-        const float eps = 4.0f * (static_cast<float>(dim) * 5.9604645e-8f) * (qn + xmax) + 1e-30f;
+        // (eps_extra: the bf16 filter's share, 0 for the fp32 GEMM — see vg_index_enable_bf16_filter)
+        const float eps = (4.0f * (static_cast<float>(dim) * 5.9604645e-8f) + eps_extra) * (qn + xmax) + 1e-30f;
         if (tau == INFINITY) {
             ok = true;  // nothing was excluded
         } else if (kth == kKeyMax) {
@@ -289,7 +314,7 @@ __global__ __launch_bounds__(256) void flat_verify_all_kernel(
     const float *__restrict__ base, int dim, const float *__restrict__ queries,
     const float *__restrict__ norms_max /* [1] */, const uint64_t *__restrict__ cand, const int *__restrict__ counts,
     int cap, int k, uint32_t *__restrict__ ids, float *__restrict__ scores, int *__restrict__ fallback,
-    const float *__restrict__ thr, int thr_stride, int thr_off)
+    const float *__restrict__ thr, int thr_stride, int thr_off, float eps_extra)
 {
     __shared__ uint64_t lists[4 * 64];
     __shared__ int valid[4];
@@ -323,7 +348,8 @@ __global__ __launch_bounds__(256) void flat_verify_all_kernel(
     bool ok = total <= cap;                           // overflow: rows below the threshold were dropped
     if (ok && tau != INFINITY) {
         const float xmax = norms_max[0];
-        const float eps = 4.0f * (static_cast<float>(dim) * 5.9604645e-8f) * (qn + xmax) + 1e-30f;
+        // (eps_extra: the bf16 filter's share, 0 for the fp32 GEMM — see vg_index_enable_bf16_filter)
+        const float eps = (4.0f * (static_cast<float>(dim) * 5.9604645e-8f) + eps_extra) * (qn + xmax) + 1e-30f;
         if (kth == kKeyMax)
             ok = false;
         else if (DOT)
@@ -346,7 +372,7 @@ __global__ __launch_bounds__(256) void flat_verify_sort_kernel(
     const float *__restrict__ base, int dim, const float *__restrict__ queries,
     const float *__restrict__ norms_max /* [1] */, const uint64_t *__restrict__ cand, const int *__restrict__ counts,
     int cap, int k, uint32_t *__restrict__ ids, float *__restrict__ scores, int *__restrict__ fallback,
-    const float *__restrict__ thr, int thr_stride, int thr_off)
+    const float *__restrict__ thr, int thr_stride, int thr_off, float eps_extra)
 {
     extern __shared__ uint64_t sortbuf[];  // cap keys
     const Sub16 sub = Sub16::make(threadIdx.x);
@@ -382,7 +408,8 @@ __global__ __launch_bounds__(256) void flat_verify_sort_kernel(
     bool ok = total <= cap;
     if (ok && tau != INFINITY) {
         const float xmax = norms_max[0];
-        const float eps = 4.0f * (static_cast<float>(dim) * 5.9604645e-8f) * (qn + xmax) + 1e-30f;
+        // (eps_extra: the bf16 filter's share, 0 for the fp32 GEMM — see vg_index_enable_bf16_filter)
+        const float eps = (4.0f * (static_cast<float>(dim) * 5.9604645e-8f) + eps_extra) * (qn + xmax) + 1e-30f;
         if (kth == kKeyMax)
             ok = false;
         else if (DOT)
@@ -660,7 +687,15 @@ VG_API int32_t vg_search_flat(vg_index *idx, const float *queries, int64_t nq, i
         const int i_fid = ar.add(sizeof(uint32_t) * static_cast<size_t>(qc) * pk);
         const int i_fsc = ar.add(sizeof(float) * static_cast<size_t>(qc) * pk);
         const int i_minkeys = ar.add(sizeof(uint64_t) * static_cast<size_t>(qc));
+        // the bfloat16 filter (vg_index_enable_bf16_filter): the two nomination GEMMs read bf16 copies of the rows and
+        // of the queries; what they nominate is re-scored exactly as before and the proof widens its margin by the
+        // rounding the copies can introduce: |score_bf16 - score| <= 2 * (2^-8 + 2^-18) * |q||x| <= 2^-8 * 1.01 * (|q|^2 + |x|^2)
+        const bool bf16 = idx->d_vectors_bf16 != nullptr && fused && dim % (2 * vg::kGemmBK) == 0 && nq > 2 * vg::kG32BM &&
+                          !vg::hook(vg::kHookFlatNoDma);
+        const float eps_extra = bf16 ? 0.00390625f * 1.02f : 0.0f;
+        const int i_qbf = ar.add(bf16 ? sizeof(uint16_t) * static_cast<size_t>(qc) * dim : 0);
         VG_TRY(ar.commit());
+        uint16_t *qbf = ar.get<uint16_t>(i_qbf);
         float *sc = ar.get<float>(i_sc), *thr = ar.get<float>(i_thr);
         float *cand_sc = ar.get<float>(i_cand_sc), *fsc = ar.get<float>(i_fsc);
         uint64_t *partial = ar.get<uint64_t>(i_partial), *fpartial = ar.get<uint64_t>(i_fpartial);
@@ -679,12 +714,22 @@ VG_API int32_t vg_search_flat(vg_index *idx, const float *queries, int64_t nq, i
             // (test hook kHookFlatNoDma: force the register-staged GEMM)
             const bool dma = dim % 4 == 0 && (reinterpret_cast<uintptr_t>(qp) & 15) == 0 &&
                              (reinterpret_cast<uintptr_t>(idx->d_vectors) & 15) == 0 && !vg::hook(vg::kHookFlatNoDma);
+            // operands of the nomination GEMMs
+            const float *ga = qp, *gb = idx->d_vectors;
+            int gdim = dim;
+            if (bf16) {
+                VG_LAUNCH(vg::f32_to_bf16_kernel, dim3(static_cast<unsigned>((cnt * dim + 255) / 256)), dim3(256), 0, st, qp,
+                          cnt * dim, qbf);
+                ga = reinterpret_cast<const float *>(qbf);
+                gb = reinterpret_cast<const float *>(idx->d_vectors_bf16);
+                gdim = dim / 2;
+            }
             if (fused) {
                 // (a) threshold per query from a row sample
                 if (use_sample) {
                     VG_TRY(vg::launch_gemm<1>(dot, dma, static_cast<unsigned>(mt * ((nst + 7) / 8) * 8), st,
-                                              {qp, cnt, idx->d_vectors, n, dim, idx->d_norms, sc, sample_stride, ns,
-                                               nullptr, 0, 0, nullptr, nullptr, 0}));
+                                              {ga, cnt, gb, n, gdim, idx->d_norms, sc, sample_stride, ns,
+                                               nullptr, 0, 0, nullptr, nullptr, 0}, bf16));
                     VG_LAUNCH(vg::flat_select_kernel, dim3(sel_slices, ucnt), dim3(vg::kSelThreads), 0, st, sc, ns,
                               sel_slices, sel_k, partial);
                     VG_TRY(vg::launch_topk_merge(partial, cnt, sel_slices, sel_k, false, sid, thr, st));
@@ -697,8 +742,8 @@ VG_API int32_t vg_search_flat(vg_index *idx, const float *queries, int64_t nq, i
                 {
                     vg::ProfScope prof(idx->ctx, "flat_gemm", st);
                     VG_TRY(vg::launch_gemm<2>(dot, dma, static_cast<unsigned>(mt * ((nt + 7) / 8) * 8), st,
-                                              {qp, cnt, idx->d_vectors, n, dim, idx->d_norms, nullptr, 1, 0, thr,
-                                               sel_k, sel_k - 1, counts, cand, cap}));
+                                              {ga, cnt, gb, n, gdim, idx->d_norms, nullptr, 1, 0, thr,
+                                               sel_k, sel_k - 1, counts, cand, cap}, bf16));
                 }
                 // (c) the kc best appended keys (k > kGemmMaxK: all of them go to the exact re-score below)
                 if (k <= vg::kGemmMaxK)
@@ -722,24 +767,24 @@ VG_API int32_t vg_search_flat(vg_index *idx, const float *queries, int64_t nq, i
                 const size_t sort_lds = sizeof(uint64_t) * static_cast<size_t>(cap);
                 auto vk = dot ? vg::flat_verify_sort_kernel<true> : vg::flat_verify_sort_kernel<false>;
                 VG_LAUNCH(vk, dim3(ucnt), dim3(256), sort_lds, st, idx->d_vectors, dim, qp, idx->d_norm_max, cand, counts, cap,
-                          k, oid.ptr + q0 * k, osc.ptr + q0 * k, flags, thr, sel_k, sel_k - 1);
+                          k, oid.ptr + q0 * k, osc.ptr + q0 * k, flags, thr, sel_k, sel_k - 1, eps_extra);
             } else if (fused && k > vg::kGemmMaxK) {
                 if (dot)
                     VG_LAUNCH(vg::flat_verify_all_kernel<true>, dim3(ucnt), dim3(256), 0, st, idx->d_vectors, dim, qp,
                               idx->d_norm_max, cand, counts, cap, k, oid.ptr + q0 * k, osc.ptr + q0 * k, flags, thr, sel_k,
-                              sel_k - 1);
+                              sel_k - 1, eps_extra);
                 else
                     VG_LAUNCH(vg::flat_verify_all_kernel<false>, dim3(ucnt), dim3(256), 0, st, idx->d_vectors, dim, qp,
                               idx->d_norm_max, cand, counts, cap, k, oid.ptr + q0 * k, osc.ptr + q0 * k, flags, thr, sel_k,
-                              sel_k - 1);
+                              sel_k - 1, eps_extra);
             } else if (dot)
                 VG_LAUNCH(vg::flat_verify_kernel<true>, dim3(ucnt), dim3(256), 0, st, idx->d_vectors, n, dim, qp,
                           idx->d_norm_max, cand_id, cand_sc, kc, k, oid.ptr + q0 * k, osc.ptr + q0 * k, flags, vthr,
-                          sel_k, sel_k - 1, counts, cap);
+                          sel_k, sel_k - 1, counts, cap, eps_extra);
             else
                 VG_LAUNCH(vg::flat_verify_kernel<false>, dim3(ucnt), dim3(256), 0, st, idx->d_vectors, n, dim, qp,
                           idx->d_norm_max, cand_id, cand_sc, kc, k, oid.ptr + q0 * k, osc.ptr + q0 * k, flags, vthr,
-                          sel_k, sel_k - 1, counts, cap);
+                          sel_k, sel_k - 1, counts, cap, eps_extra);
             // step 4 always launches, on the work list the proofs left behind (normally empty)
             VG_LAUNCH(vg::flat_todo_kernel, dim3(1), dim3(256), 0, st, flags, always, static_cast<int>(cnt), todo,
                       idx->d_flat_stats);
@@ -780,6 +825,26 @@ VG_API int32_t vg_search_flat(vg_index *idx, const float *queries, int64_t nq, i
     VG_TRY(oid.finish());
     VG_TRY(osc.finish());
     if (oid.on_host() || osc.on_host()) VG_HIP(hipStreamSynchronize(st));
+    return VG_OK;
+}
+
+VG_API int32_t vg_index_enable_bf16_filter(vg_index *idx, int32_t on, void *stream)
+{
+    VG_CHECK(idx, VG_ERR_INVALID_ARG, "vg_index_enable_bf16_filter: NULL index");
+    VG_HIP(hipSetDevice(idx->ctx->device));
+    hipStream_t st = vg::pick_stream(idx->ctx, stream);
+    if (idx->d_vectors_bf16) {
+        VG_HIP(hipStreamSynchronize(st));
+        VG_HIP(hipFree(idx->d_vectors_bf16));
+        idx->d_vectors_bf16 = nullptr;
+    }
+    if (!on) return VG_OK;
+    VG_CHECK(idx->d_vectors, VG_ERR_NOT_READY, "vg_index_enable_bf16_filter: index has no fp32 vectors");
+    const int64_t count = idx->n * idx->dim;
+    VG_HIP(hipMalloc(reinterpret_cast<void **>(&idx->d_vectors_bf16), static_cast<size_t>(count) * sizeof(uint16_t)));
+    VG_LAUNCH(vg::f32_to_bf16_kernel, dim3(static_cast<unsigned>((count + 255) / 256)), dim3(256), 0, st, idx->d_vectors,
+              count, idx->d_vectors_bf16);
+    VG_HIP(hipStreamSynchronize(st));
     return VG_OK;
 }
 

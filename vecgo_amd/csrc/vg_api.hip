@@ -277,6 +277,7 @@ VG_API int32_t vg_index_destroy(vg_index *idx)
     if (idx->d_norms) (void)hipFree(idx->d_norms);
     if (idx->d_norm_max) (void)hipFree(idx->d_norm_max);
     if (idx->d_flat_stats) (void)hipFree(idx->d_flat_stats);
+    if (idx->d_vectors_bf16) (void)hipFree(idx->d_vectors_bf16);
     if (idx->d_rq_tiles) (void)hipFree(idx->d_rq_tiles);
     if (idx->d_rq_norms) (void)hipFree(idx->d_rq_norms);
     if (idx->d_hnsw_l0) (void)hipFree(idx->d_hnsw_l0);

@@ -300,7 +300,14 @@ __device__ __forceinline__ void glds16_stream(const float *base, uint32_t byte_o
                  : "memory");
 }
 
-template <bool DOT, int MODE, int PROBE = 0>
+// BF16 = true: `queries` and `base` hold bfloat16 rows and `dim` counts 4-byte words per row (elements / 2): the tiles
+// are moved exactly as above (a K step is 128 bytes of a row either way, a 16-byte granule now 8 elements), only the
+// matrix instruction changes — v_mfma_f32_32x32x16_bf16 takes one granule per lane (lane (row, h): the 8 elements
+// 16j + 8h ..) where the fp32 form takes one float, so a K step is 16 instead of 64 matrix instructions per wave.
+// The scores are a FILTER for the exact fp32 re-score (vg_index_enable_bf16_filter, k_flat.hip); elements / 2 must be
+// a multiple of kGemmBK.
+typedef __bf16 vg_bf16x8 __attribute__((ext_vector_type(8)));
+template <bool DOT, int MODE, int PROBE = 0, bool BF16 = false>
 __global__ __launch_bounds__(kGemmThreads) void flat_gemm_dma_kernel(
     const float *__restrict__ queries, int64_t nq, const float *__restrict__ base, int64_t n,
     int dim, const float *__restrict__ norms, float *__restrict__ scores, int tile_stride,
@@ -418,10 +425,20 @@ __global__ __launch_bounds__(kGemmThreads) void flat_gemm_dma_kernel(
     acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][0].comp, fb[c][1].comp, acc[0][1], 0, 0, 0);    \
     acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][1].comp, fb[c][0].comp, acc[1][0], 0, 0, 0);    \
     acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][1].comp, fb[c][1].comp, acc[1][1], 0, 0, 0);
-            VG_MFMA4(x)
-            VG_MFMA4(y)
-            VG_MFMA4(z)
-            VG_MFMA4(w)
+            if constexpr (BF16) {
+#pragma unroll
+                for (int ai = 0; ai < 2; ai++)
+#pragma unroll
+                    for (int bi = 0; bi < 2; bi++)
+                        acc[ai][bi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(vg_bf16x8, fa[c][ai]),
+                                                                             __builtin_bit_cast(vg_bf16x8, fb[c][bi]),
+                                                                             acc[ai][bi], 0, 0, 0);
+            } else {
+                VG_MFMA4(x)
+                VG_MFMA4(y)
+                VG_MFMA4(z)
+                VG_MFMA4(w)
+            }
 #undef VG_MFMA4
             __builtin_amdgcn_sched_barrier(0);
         }

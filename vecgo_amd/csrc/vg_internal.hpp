@@ -331,6 +331,7 @@ struct vg_index {
     float *d_vectors = nullptr;
     float *d_norms = nullptr;
     float *d_norm_max = nullptr;  // [1] max ||x||^2: error bound of the GEMM-form scores
+    uint16_t *d_vectors_bf16 = nullptr;  // optional bfloat16 copy of the rows: vg_index_enable_bf16_filter
     unsigned long long *d_flat_stats = nullptr;  // [2] queries searched, queries sent to the exhaustive kernel
     // RaBitQ: sign bits re-tiled [tile][group][lane][16 B] and the stored norms
     uint8_t *d_rq_tiles = nullptr;
