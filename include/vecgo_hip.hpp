@@ -594,6 +594,8 @@ public:
 
     // flat.Segment.Search fp32 branch (flat/segment.go:691-721)
     Result SearchFlat(const float *queries, int64_t nq, int k) { return run(nq, k, [&](Result &r) { return vg_search_flat(h_, queries, nq, k, r.ids.data(), r.scores.data(), nullptr); }); }
+    // opt-in: nominate with a bfloat16 MFMA GEMM over a bf16 copy of the rows; results stay bit-identical (vecgo_hip.h)
+    void EnableBF16Filter(bool on = true) { check(vg_index_enable_bf16_filter(h_, on ? 1 : 0, nullptr)); }
     // flat.Segment.Search PQ branch (flat/segment.go:476-483,678-689)
     Result SearchPQ(const float *queries, int64_t nq, int k) { return run(nq, k, [&](Result &r) { return vg_search_pq_adc(h_, queries, nq, k, r.ids.data(), r.scores.data(), nullptr); }); }
     Result SearchRaBitQ(const float *queries, int64_t nq, int k) { return run(nq, k, [&](Result &r) { return vg_search_rabitq(h_, queries, nq, k, r.ids.data(), r.scores.data(), nullptr); }); }

@@ -213,6 +213,18 @@ int main()
             EXPECT(std::memcmp(eid, r.ids.data() + size_t(i) * k, sizeof eid) == 0);
             EXPECT(std::memcmp(esc, r.scores.data() + size_t(i) * k, sizeof esc) == 0);
         }
+        // the opt-in bfloat16 nomination filter (more than 64 queries): same ids, same fp32 scores
+        {
+            const int nq2 = 96;
+            std::vector<float> q2(size_t(nq2) * dim);
+            for (auto &x : q2) x = nd(rng);
+            auto plain = seg.SearchFlat(q2.data(), nq2, k);
+            seg.EnableBF16Filter(true);
+            auto filtered = seg.SearchFlat(q2.data(), nq2, k);
+            seg.EnableBF16Filter(false);
+            EXPECT(plain.ids == filtered.ids);
+            EXPECT(std::memcmp(plain.scores.data(), filtered.scores.data(), plain.scores.size() * sizeof(float)) == 0);
+        }
         // flat/pq_test.go:17-93: the zero query finds the zero vector with a small score
         auto pq = std::make_shared<ProductQuantizer>(ctx, dim, 16, 256);
         std::vector<float> with_zero(base);

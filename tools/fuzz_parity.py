@@ -48,8 +48,19 @@ while time.time() < t_end:
     which = rng.integers(0, 9)
     try:
         if which == 0:
+            tag = "flat"
+            if dim % 64 == 0 and rng.random() < 0.6:   # the bfloat16 nomination filter (takes effect above 64 queries)
+                nq = int(rng.choice([65, 70, 130]))
+                q = rng.standard_normal((nq, dim)).astype(np.float32)
+                if rng.random() < 0.3:                 # rows bf16 cannot tell apart: the proof must fail over to the scan
+                    x = (x[0] + 1e-4 * rng.standard_normal((n, dim))).astype(np.float32)
+                    q = (x[0] + 1e-4 * rng.standard_normal((nq, dim))).astype(np.float32)
+                    idx.set_vectors(x)
+                cfg = dict(cfg, nq=nq)
+                idx.enable_bf16_filter(True)
+                tag = "flat_bf16_filter"
             ids, sc = idx.search_flat(q, k)
-            compare("flat", cfg, ids, sc, [o.flat_search_f32(x, dim, q[i], k, metric) for i in range(nq)])
+            compare(tag, cfg, ids, sc, [o.flat_search_f32(x, dim, q[i], k, metric) for i in range(nq)])
         elif which == 1:
             parts = int(rng.integers(2, 9))
             cuts = np.sort(rng.integers(0, n + 1, parts - 1))
