@@ -83,6 +83,14 @@ def test_flat_exact_1m_x_768(vg, ctx):
     finally:
         hooks.set_hook("VG_FLAT_FORCE_EXACT", 0)
     assert torch.equal(eids, ids[:32]) and torch.equal(esc.view(torch.int32), sc[:32].view(torch.int32))
+    # (2b) the bfloat16 nomination filter: the same ids and fp32 score bits, still without a fall-back
+    _, e_before = idx.flat_stats()
+    idx.enable_bf16_filter(True)
+    fids, fsc = idx.search_flat(q, k)
+    _, e_after = idx.flat_stats()
+    idx.enable_bf16_filter(False)
+    assert torch.equal(fids, ids) and torch.equal(fsc.view(torch.int32), sc.view(torch.int32))
+    assert e_after == e_before
     # (3) partition property
     half = n // 2
     a = vg.Index(ctx, half, dim); a.set_vectors(base[:half])

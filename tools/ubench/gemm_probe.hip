@@ -28,11 +28,12 @@ __global__ void fill(float *p, size_t n, uint32_t seed)
     p[i] = (float(x >> 8) * (1.0f / 16777216.0f) - 0.5f) * 2.0f;
 }
 
-template <int MODE, int PROBE, bool DMA = false>
+template <int MODE, int PROBE, bool DMA = false, bool BF16 = false>
 static void run(const char *name, const float *q, int64_t nq, const float *base, int64_t n, int dim,
                 const float *norms, float *scores, const float *thr, int *counts, uint64_t *cand, int cap)
 {
-    auto kern = DMA ? vg::flat_gemm_dma_kernel<false, MODE, PROBE> : vg::flat_gemm_kernel<false, MODE, PROBE>;
+    auto kern = BF16 ? vg::flat_gemm_dma_kernel<false, MODE, PROBE, true>
+                     : (DMA ? vg::flat_gemm_dma_kernel<false, MODE, PROBE> : vg::flat_gemm_kernel<false, MODE, PROBE>);
     const size_t lds = DMA ? vg::kDmaLdsBytes : vg::kGemmLdsBytes;
     CK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
     const int64_t mt = (nq + vg::kGemmBM - 1) / vg::kGemmBM, nt = (n + vg::kGemmBN - 1) / vg::kGemmBN;
@@ -52,7 +53,7 @@ static void run(const char *name, const float *q, int64_t nq, const float *base,
         CK(hipEventElapsedTime(&ms, e0, e1));
         if (rep && ms < best) best = ms;
     }
-    const double tf = 2.0 * double(nq) * double(n) * dim / (best * 1e-3) / 1e12;
+    const double tf = 2.0 * double(nq) * double(n) * (BF16 ? 2 * dim : dim) / (best * 1e-3) / 1e12;
     printf("%-44s %8.3f ms  %6.1f TFLOP/s  (%.1f %% of 157.3)\n", name, best, tf, tf / 157.3 * 100);
 }
 
@@ -94,5 +95,18 @@ int main(int argc, char **argv)
     run<2, 1 | 2, true>("- epilogue - DMA", q, nq, base, n, dim, norms, scores, thr, counts, cand, cap);
     run<2, 1 | 2 | 8, true>("- epilogue - DMA - barrier", q, nq, base, n, dim, norms, scores, thr, counts, cand, cap);
     run<2, 1 | 2 | 8 | 16, true>("MFMA only", q, nq, base, n, dim, norms, scores, thr, counts, cand, cap);
+    // the same buffers read as bfloat16 rows of 768 elements = 384 words (what the values are does not matter here)
+    printf("bfloat16 LDS-DMA kernel (768 elements per row; %% of 157.3 is meaningless here):\n");
+    const int dw = dim / 2;
+    run<2, 0, true, true>("full kernel (MODE 2)", q, nq, base, n, dw, norms, scores, thr, counts, cand, cap);
+    run<2, 1, true, true>("- epilogue", q, nq, base, n, dw, norms, scores, thr, counts, cand, cap);
+    run<2, 1 | 32, true, true>("- epilogue, DMA re-fetches tile 0 (hot)", q, nq, base, n, dw, norms, scores, thr, counts, cand, cap);
+    run<2, 1 | 64, true, true>("- epilogue, DMA of A tiles only", q, nq, base, n, dw, norms, scores, thr, counts, cand, cap);
+    run<2, 1 | 128, true, true>("- epilogue, no vmcnt wait (racy)", q, nq, base, n, dw, norms, scores, thr, counts, cand, cap);
+    run<2, 1 | 128 | 8, true, true>("- epilogue, no vmcnt wait, no barrier", q, nq, base, n, dw, norms, scores, thr, counts, cand, cap);
+    run<2, 1 | 2, true, true>("- epilogue - DMA", q, nq, base, n, dw, norms, scores, thr, counts, cand, cap);
+    run<2, 1 | 2 | 8, true, true>("- epilogue - DMA - barrier", q, nq, base, n, dw, norms, scores, thr, counts, cand, cap);
+    run<2, 1 | 16, true, true>("- epilogue - LDS reads", q, nq, base, n, dw, norms, scores, thr, counts, cand, cap);
+    run<2, 1 | 2 | 8 | 16, true, true>("MFMA only", q, nq, base, n, dw, norms, scores, thr, counts, cand, cap);
     return 0;
 }
