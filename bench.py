@@ -713,6 +713,9 @@ def main():
     ap.add_argument("--no-adc", action="store_true")
     ap.add_argument("--no-hnsw", action="store_true")
     ap.add_argument("--torch-collective", action="store_true", help="N > 1: exchange through torch.distributed instead of vg_comm")
+    ap.add_argument("--bf16-filter", action="store_true",
+                    help="time the exact path WITH vg_index_enable_bf16_filter as the headline (default: the fp32 MFMA GEMM "
+                         "BASELINE's configs[1] names; the filtered path is reported as `flat_exact_bf16_filter` either way)")
     ap.add_argument("--backend", default="nccl",
                     help="torch.distributed backend; 'gloo' lets several ranks share one GPU to smoke-test the N>1 path")
     args = ap.parse_args()
@@ -745,6 +748,8 @@ def main():
     # torch.distributed's all-gather otherwise
     comm = sharded.make_comm(ctx) if (world > 1 and not args.torch_collective) else None
     index = sharded.ShardedFlatIndex(ctx, rows, DIM, bounds, metric=0, comm=comm)
+    if args.bf16_filter:
+        index.index.enable_bf16_filter(True)
     if comm is not None:   # untimed cross-check of the two exchange paths on one batch
         a_ids, a_sc = index.search(gen_queries(1, device)[0][:64], K, stream=stream)
         index.comm = None
@@ -857,12 +862,14 @@ def main():
         # averaged over the launches of the timed region
         flops_per_launch = 2.0 * Q_BATCH * rows_local * DIM * args.steps / max(launches, 1)
         achieved_tf = flops_per_launch / (kern_avg_ms * 1e-3) / 1e12 if launches else 0.0
-        roofline = {"bound": "mfma", "achieved": achieved_tf, "peak": PEAK_MFMA_F32_TFLOPS,
-                    "unit": "TFLOP/s", "frac": achieved_tf / PEAK_MFMA_F32_TFLOPS,
-                    "traffic": measured_traffic("flat_gemm") if world == 1 else None,
-                    "kernel": "flat_gemm_dma_kernel<false,2>", "kernel_ms": kern_avg_ms,
-                    "launches": launches, "flops_per_launch": flops_per_launch}
-        workload = "flat_exact_l2_1Mx768_top10 (BASELINE configs[1]): MFMA GEMM nomination + exact re-score + proof"
+        peak_tf = PEAK_MFMA_BF16_TFLOPS if args.bf16_filter else PEAK_MFMA_F32_TFLOPS
+        roofline = {"bound": "mfma", "achieved": achieved_tf, "peak": peak_tf,
+                    "unit": "TFLOP/s", "frac": achieved_tf / peak_tf,
+                    "traffic": measured_traffic("flat_gemm") if (world == 1 and not args.bf16_filter) else None,
+                    "kernel": "flat_gemm_dma_kernel<false,2,0,true> (bf16)" if args.bf16_filter else "flat_gemm_dma_kernel<false,2>",
+                    "kernel_ms": kern_avg_ms, "launches": launches, "flops_per_launch": flops_per_launch}
+        workload = "flat_exact_l2_1Mx768_top10 (BASELINE configs[1]): MFMA GEMM nomination + exact re-score + proof" + \
+            (" [nomination in bfloat16: --bf16-filter]" if args.bf16_filter else "")
     else:
         per_q = op["distance_computations_per_query"] * DIM * 4 if op["path"] == "hnsw_f32" else op["pq_scores_per_query"] * PQ_M
         bytes_per_launch = per_q * Q_BATCH
@@ -876,7 +883,8 @@ def main():
                   "recall bar, chosen from the measured frontier in `hnsw_pq`)",
         "value": qps, "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-        "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "scaling": "strong", "vs_baseline": None,
+        "dtype": "f32" if not args.bf16_filter else "f32 results; nomination GEMM in bf16 (--bf16-filter)", "data": "synthetic",
         "config": {"workload": workload, "operating_point": op["path"], "rows": N_ROWS,
                    "dim": DIM, "k": K, "queries_per_step": Q_BATCH,
                    "parallelism": (f"row-shard x{world}, one all-gather of per-shard top-k per step ("
@@ -900,6 +908,8 @@ def main():
         hidx.close()
         hpq.close()
     if world == 1:
+        if args.bf16_filter:
+            index.index.enable_bf16_filter(False)
         leg("flat_exact_bf16_filter", lambda: flat_bf16_filter(vg, ctx, index.index, queries, gt, args.steps, stream))
         if "qps" in out["flat_exact_bf16_filter"]:
             out["flat_exact_bf16_filter"]["over_fp32_headline"] = out["flat_exact_bf16_filter"]["qps"] / qps
