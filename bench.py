@@ -240,6 +240,19 @@ def flat_bf16_filter(vg, ctx, idx, queries, gt_ids, steps, stream):
         s1 = idx.flat_stats()
         ids, sc = idx.search_flat(queries[0], K, stream=stream)
         torch.cuda.synchronize()
+        small = {}
+        for nqs in (32, 64):   # the HBM-bound tiles: half the bytes per row
+            qs = queries[1][:nqs].contiguous()
+            for _ in range(20):
+                idx.search_flat(qs, K, stream=stream)
+            torch.cuda.synchronize()
+            s0e, s1e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s0e.record(stream)
+            for _ in range(10):
+                idx.search_flat(qs, K, stream=stream)
+            s1e.record(stream)
+            torch.cuda.synchronize()
+            small[f"q{nqs}_call_ms"] = s0e.elapsed_time(s1e) / 10
     finally:
         idx.enable_bf16_filter(False, stream=stream)
     step_ms = e0.elapsed_time(e1) / steps
@@ -253,7 +266,7 @@ def flat_bf16_filter(vg, ctx, idx, queries, gt_ids, steps, stream):
             "ids_equal_fp32_path": bool(torch.equal(ids, ref_ids)),
             "scores_bit_equal_fp32_path": bool(torch.equal(sc.view(torch.int32), ref_sc.view(torch.int32))),
             "proof_fallbacks": int(s1[1] - s0[1]), "queries": int(s1[0] - s0[0]),
-            "extra_hbm_bytes": N_ROWS * DIM * 2,
+            "extra_hbm_bytes": N_ROWS * DIM * 2, "small_batches": small,
             "roofline": {"bound": "mfma", "kernel": "flat_gemm_dma_kernel<false,2,0,true> (v_mfma_f32_32x32x16_bf16)",
                          "kernel_ms": kern_ms, "launches": launches, "flops_per_launch": flops,
                          "achieved": flops / (kern_ms * 1e-3) / 1e12, "peak": PEAK_MFMA_BF16_TFLOPS, "unit": "TFLOP/s",

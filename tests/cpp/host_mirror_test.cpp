@@ -213,7 +213,7 @@ int main()
             EXPECT(std::memcmp(eid, r.ids.data() + size_t(i) * k, sizeof eid) == 0);
             EXPECT(std::memcmp(esc, r.scores.data() + size_t(i) * k, sizeof esc) == 0);
         }
-        // the opt-in bfloat16 nomination filter (more than 64 queries): same ids, same fp32 scores
+        // the opt-in bfloat16 nomination filter: same ids, same fp32 scores
         {
             const int nq2 = 96;
             std::vector<float> q2(size_t(nq2) * dim);

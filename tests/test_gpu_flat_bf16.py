@@ -34,6 +34,9 @@ def ctx(vg):
     (20000, 768, 130, 10, 1),     # Cosine (the reference scores it as Dot on the rows as given)
     (3000, 64, 129, 64, 0),       # k = the candidate budget
     (30000, 192, 100, 100, 0),    # k > 64: every appended row is re-scored
+    (20000, 768, 5, 10, 0),       # one block of 32 queries (the HBM-bound tile)
+    (20000, 768, 33, 10, 0),      # two blocks
+    (20000, 768, 64, 10, 2),
 ])
 def test_filter_is_bit_identical(vg, ctx, n, dim, nq, k, metric):
     rng = np.random.default_rng(n + dim + nq + k + metric)

@@ -27,5 +27,17 @@ for name, on in (("fp32", False), ("bf16 filter", True), ("fp32 again", False)):
     res[name] = (idx.search_flat(q[0], 10, stream=st))
     print(f"{name:12s}: {e0.elapsed_time(e1) / 10:7.3f} ms per 1024 queries = {1024 / (e0.elapsed_time(e1) / 10) * 1e3:9.0f} queries/s; "
           f"nomination GEMM {ms / l:6.3f} ms per launch; proof fall-backs {s1[1] - s0[1]} of {s1[0] - s0[0]} queries")
+for nqs in (32, 64):
+    qs = q[0][:nqs].contiguous()
+    for on in (False, True):
+        idx.enable_bf16_filter(on)
+        for _ in range(20): idx.search_flat(qs, 10, stream=st)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(st)
+        for i in range(20): idx.search_flat(qs, 10, stream=st)
+        e1.record(st); torch.cuda.synchronize()
+        print(f"{nqs} queries, {'bf16 filter' if on else 'fp32':12s}: {e0.elapsed_time(e1) / 20:7.3f} ms per call = {nqs / (e0.elapsed_time(e1) / 20) * 1e3:9.0f} queries/s")
+idx.enable_bf16_filter(False)
 a, b = res["fp32"], res["bf16 filter"]
 print("ids equal:", bool(torch.equal(a[0], b[0])), " scores bit-equal:", bool(torch.equal(a[1].view(torch.int32), b[1].view(torch.int32))))

@@ -41,8 +41,21 @@ struct GemmArgs {
 template <bool DOT, int MODE>
 static int32_t launch_gemm_t(bool dma, unsigned blocks, hipStream_t st, const GemmArgs &a, bool bf16)
 {
-    if (bf16) {  // rows of bfloat16 (a.dim = 4-byte words per row): the 128-query LDS-DMA tile only
+    if (bf16) {  // rows of bfloat16 (a.dim = 4-byte words per row): the LDS-DMA tiles only
         constexpr int M = MODE == 0 ? 1 : MODE;
+        if (a.nq <= 2 * kG32BM && !hook(kHookFlatNoSmallTile)) {
+            const bool one = a.nq <= kG32BM;
+            auto kern = one ? flat_gemm_dma32_kernel<DOT, M, 1, true> : flat_gemm_dma32_kernel<DOT, M, 2, true>;
+            const size_t lds = one ? g32_lds_bytes<1>() : g32_lds_bytes<2>();
+            VG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       static_cast<int>(lds)));
+            const int64_t tiles = (a.n + kGemmBN - 1) / kGemmBN;
+            const int64_t grid = MODE == 1 ? (tiles + a.tile_stride - 1) / a.tile_stride : tiles;
+            VG_LAUNCH(kern, dim3(static_cast<unsigned>(grid)), dim3(kGemmThreads), lds, st, a.queries, a.nq, a.base,
+                      a.n, a.dim, a.norms, a.scores, a.tile_stride, a.out_cols, a.thr, a.thr_stride, a.thr_off, a.counts,
+                      a.cand, a.cap);
+            return VG_OK;
+        }
         auto kern = flat_gemm_dma_kernel<DOT, M, 0, true>;
         VG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    static_cast<int>(kDmaLdsBytes)));
@@ -690,8 +703,7 @@ VG_API int32_t vg_search_flat(vg_index *idx, const float *queries, int64_t nq, i
         // the bfloat16 filter (vg_index_enable_bf16_filter): the two nomination GEMMs read bf16 copies of the rows and
         // of the queries; what they nominate is re-scored exactly as before and the proof widens its margin by the
         // rounding the copies can introduce: |score_bf16 - score| <= 2 * (2^-8 + 2^-18) * |q||x| <= 2^-8 * 1.01 * (|q|^2 + |x|^2)
-        const bool bf16 = idx->d_vectors_bf16 != nullptr && fused && dim % (2 * vg::kGemmBK) == 0 && nq > 2 * vg::kG32BM &&
-                          !vg::hook(vg::kHookFlatNoDma);
+        const bool bf16 = idx->d_vectors_bf16 != nullptr && fused && dim % (2 * vg::kGemmBK) == 0 && !vg::hook(vg::kHookFlatNoDma);
         const float eps_extra = bf16 ? 0.00390625f * 1.02f : 0.0f;
         const int i_qbf = ar.add(bf16 ? sizeof(uint16_t) * static_cast<size_t>(qc) * dim : 0);
         VG_TRY(ar.commit());

@@ -468,7 +468,9 @@ constexpr int kG32BM = 32;
 template <int RB>
 constexpr size_t g32_lds_bytes() { return 2 * (RB * kG32BM * kGemmBK + kDmaTile) * sizeof(float); }
 
-template <bool DOT, int MODE, int RB>
+// BF16: as in flat_gemm_dma_kernel (rows of bfloat16, `dim` in 4-byte words) — the pass is HBM-bound, so half the bytes
+// per row is half the time.
+template <bool DOT, int MODE, int RB, bool BF16 = false>
 __global__ __launch_bounds__(kGemmThreads) void flat_gemm_dma32_kernel(
     const float *__restrict__ queries, int64_t nq, const float *__restrict__ base, int64_t n,
     int dim, const float *__restrict__ norms, float *__restrict__ scores, int tile_stride,
@@ -574,14 +576,21 @@ __global__ __launch_bounds__(kGemmThreads) void flat_gemm_dma32_kernel(
                 fb[nx] = *reinterpret_cast<const float4 *>(Bs + b_row + goff[j + 1]);
             }
             __builtin_amdgcn_sched_barrier(0);
+            if constexpr (BF16) {
 #pragma unroll
-            for (int i = 0; i < RB; i++) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][i].x, fb[c].x, acc[i], 0, 0, 0);
+                for (int i = 0; i < RB; i++)
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(vg_bf16x8, fa[c][i]),
+                                                                    __builtin_bit_cast(vg_bf16x8, fb[c]), acc[i], 0, 0, 0);
+            } else {
 #pragma unroll
-            for (int i = 0; i < RB; i++) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][i].y, fb[c].y, acc[i], 0, 0, 0);
+                for (int i = 0; i < RB; i++) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][i].x, fb[c].x, acc[i], 0, 0, 0);
 #pragma unroll
-            for (int i = 0; i < RB; i++) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][i].z, fb[c].z, acc[i], 0, 0, 0);
+                for (int i = 0; i < RB; i++) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][i].y, fb[c].y, acc[i], 0, 0, 0);
 #pragma unroll
-            for (int i = 0; i < RB; i++) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][i].w, fb[c].w, acc[i], 0, 0, 0);
+                for (int i = 0; i < RB; i++) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][i].z, fb[c].z, acc[i], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < RB; i++) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][i].w, fb[c].w, acc[i], 0, 0, 0);
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
