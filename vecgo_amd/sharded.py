@@ -95,13 +95,16 @@ def make_comm(ctx, group=None):
 class ShardedFlatIndex:
     """Exact brute force over a row-sharded corpus (BASELINE config 2 at N GPUs)."""
 
-    def __init__(self, ctx, local_rows, dim: int, bounds: Sequence[int], metric=0, group=None, comm=None):
+    def __init__(self, ctx, local_rows, dim: int, bounds: Sequence[int], metric=0, group=None, comm=None,
+                 bf16_filter: bool = False):
         from . import api
         self._api = api
         self.ctx, self.dim, self.bounds, self.metric, self.group, self.comm = ctx, dim, list(bounds), metric, group, comm
         n_local = local_rows.shape[0]
         self.index = api.Index(ctx, n_local, dim, api.Metric(metric))
         self.index.set_vectors(local_rows)
+        if bf16_filter:   # per-shard results stay exact, so the merged result does too
+            self.index.enable_bf16_filter(True)
 
     def search(self, queries, k: int, stream=None):
         def local(q, kk, out):
