@@ -350,6 +350,7 @@ __global__ __launch_bounds__(kGemmThreads) void flat_gemm_dma_kernel(
     }
     const int ksteps = (dim + kGemmBK - 1) / kGemmBK;
     const int full_steps = dim / kGemmBK;  // K steps with no ragged edge (uniform per kernel)
+    const int kstart = BF16 ? (tm * 5) % ksteps : 0;  // (5: coprime with the 12 steps of d = 768; 1-7 measured alike, 8 % over none)
     const uint32_t lds0 = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(
         (__attribute__((address_space(3))) void *)gemm_lds));
     // (LDS byte address of operand tile t of buffer b) + this wave's 1 KiB piece of pass p
@@ -358,7 +359,12 @@ __global__ __launch_bounds__(kGemmThreads) void flat_gemm_dma_kernel(
             static_cast<int>(lds0 + ((b * 2 + t) * kDmaTile + (p * 32 + wave * 8) * kGemmBK) * 4)));
     };
     auto dma_tile = [&](int kt) {
-        const int k0 = (PROBE & 32) ? 0 : kt * kGemmBK, b = kt & 1;  // PROBE bit 5: re-fetch tile 0 (cache-hot)
+        // BF16: the query tiles of one row tile (same XCD, resident together) walk K from staggered starting steps, so
+        // that a K slice of the rows is a miss for one of them and an L2 hit for the others instead of all of them
+        // waiting on the same miss at every step (the accumulation order differs per query tile: the scores are a
+        // filter with an order-free error bound).  The LDS buffer alternates with kt as before.
+        const int kk = BF16 ? (kt + kstart) % ksteps : kt;
+        const int k0 = (PROBE & 32) ? 0 : kk * kGemmBK, b = kt & 1;  // PROBE bit 5: re-fetch tile 0 (cache-hot)
         if (kt < full_steps) {
 #pragma unroll
             for (int p = 0; p < kGemmPasses; p++) {
