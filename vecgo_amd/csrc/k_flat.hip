@@ -852,6 +852,7 @@ VG_API int32_t vg_index_enable_bf16_filter(vg_index *idx, int32_t on, void *stre
     }
     if (!on) return VG_OK;
     VG_CHECK(idx->d_vectors, VG_ERR_NOT_READY, "vg_index_enable_bf16_filter: index has no fp32 vectors");
+    if (idx->dim % (2 * vg::kGemmBK) != 0) return VG_OK;  // the filter never applies to this shape: no copy to keep
     const int64_t count = idx->n * idx->dim;
     VG_HIP(hipMalloc(reinterpret_cast<void **>(&idx->d_vectors_bf16), static_cast<size_t>(count) * sizeof(uint16_t)));
     VG_LAUNCH(vg::f32_to_bf16_kernel, dim3(static_cast<unsigned>((count + 255) / 256)), dim3(256), 0, st, idx->d_vectors,
