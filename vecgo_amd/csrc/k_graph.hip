@@ -38,7 +38,8 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(
     const float *__restrict__ base, int64_t n, int dim, int metric, const uint32_t *__restrict__ l0,
     int m0, int max_level, int m, const uint32_t *__restrict__ slots, const uint32_t *__restrict__ adj,
     const int64_t *__restrict__ level_off, uint32_t entry, const float *__restrict__ queries,
-    const uint8_t *__restrict__ pq_rows, int pq_m, const float *__restrict__ luts, int k, int ef,
+    const uint8_t *__restrict__ pq_rows, int pq_m, const float *__restrict__ luts,
+    const int8_t *__restrict__ pq_cb, const float *__restrict__ pq_scales, const float *__restrict__ pq_offsets, int k, int ef,
     uint32_t *__restrict__ visited_ws, int64_t vis_words, HItem *__restrict__ heap_ws,
     uint32_t *__restrict__ ids, float *__restrict__ scores, vg_search_stats *__restrict__ stats)
 {
@@ -60,7 +61,11 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(
     typename std::conditional<PQ, PqScorer, F32Scorer>::type sc;
     if constexpr (PQ) {
         sc.rows = pq_rows;
-        sc.lut = luts + q * static_cast<int64_t>(pq_m) * 256;
+        sc.lut = luts ? luts + q * static_cast<int64_t>(pq_m) * 256 : nullptr;
+        sc.cb = pq_cb;  // direct form (sub-dimension 8): no table
+        sc.scales = pq_scales;
+        sc.offsets = pq_offsets;
+        sc.qv = queries + q * dim;
         sc.m = pq_m;
     } else {
         sc.base = base;
@@ -132,7 +137,8 @@ constexpr int kVamanaLdsCand = 1024;  // items of the exploration heap kept in L
 __global__ __launch_bounds__(64) void vamana_search_kernel(
     int kind, int metric, int64_t n, int dim, const uint32_t *__restrict__ graph, int r, uint32_t entry,
     const float *__restrict__ base, const uint8_t *__restrict__ pq_rows, int pq_m,
-    const float *__restrict__ luts /* nq * m * 256 */, const uint8_t *__restrict__ rq_rows,
+    const float *__restrict__ luts /* nq * m * 256, or nullptr: terms from the codebook */, const int8_t *__restrict__ pq_cb,
+    const float *__restrict__ pq_scales, const float *__restrict__ pq_offsets, const uint8_t *__restrict__ rq_rows,
     const uint8_t *__restrict__ qcodes /* nq * (nb+4) */, int rq_nb, const uint8_t *__restrict__ int4_rows,
     const float *__restrict__ int4_table, const float *__restrict__ queries, int k, HItem *__restrict__ cand_ws, int64_t cand_cap, uint32_t *__restrict__ visited_ws,
     int64_t vis_words, uint32_t *__restrict__ ids, float *__restrict__ scores,
@@ -179,7 +185,9 @@ __global__ __launch_bounds__(64) void vamana_search_kernel(
             if (kind == kVamanaPQ) {
                 // ComputeAsymmetricDistance (pq.go:234-260): term(m) = BuildDistanceTable entry, summed
                 // sequentially over the sub-quantizers (vg_hnsw_layer.hpp: loads batched, sum order kept)
-                nb_d[lane] = pq_asym_distance(pq_rows + static_cast<int64_t>(id_lane) * pq_m, lut, pq_m);
+                const uint8_t *code = pq_rows + static_cast<int64_t>(id_lane) * pq_m;
+                nb_d[lane] = lut ? pq_asym_distance(code, lut, pq_m)
+                                 : pq_direct_distance(code, pq_cb, pq_scales, pq_offsets, qv, pq_m);
             } else if (kind == kVamanaInt4) {
                 // iq.L2Distance (diskann/segment.go:558-565) = int4L2DistancePrecomputedAvx512 order
                 nb_d[lane] = int4_l2_precomputed(qv, int4_rows + static_cast<int64_t>(id_lane) * ((dim + 1) / 2), dim,
@@ -292,7 +300,8 @@ __global__ __launch_bounds__(64) void vamana_search_kernel(
             todo &= todo - 1;
             if (cand_len < cand_cap)
                 heap_push<false>(cand, cand_len,
-                                 HItem{static_cast<uint32_t>(__builtin_amdgcn_readlane(id_lane, j)), nb_d[j]});
+                                 HItem{static_cast<uint32_t>(__builtin_amdgcn_readlane(id_lane, j)),
+                                       __int_as_float(__builtin_amdgcn_readlane(__float_as_int(myd), j))});
             else
                 st_dropped++;  // the reference's heap is unbounded: reported, see vg_search_stats
         }
@@ -460,7 +469,9 @@ static int32_t search_hnsw_impl(vg_index *idx, bool pq, const float *queries, in
     // LDS), beyond it split between those 12 KiB (the top levels) and HBM scratch
     const bool lds_heaps = ef <= vg::kHnswLdsEf;
     const int64_t heap_bytes = lds_heaps ? 0 : static_cast<int64_t>(3) * ef * sizeof(vg::HItem);
-    const int64_t lut_bytes = static_cast<int64_t>(pq_m) * 256 * sizeof(float);
+    // sub-dimension 8: node terms straight from the codebook (vg_hnsw_layer.hpp PqScorer), no per-query table
+    const bool pq_direct = pq && idx->pq->subdim == 8 && (reinterpret_cast<uintptr_t>(idx->pq->d_codebooks) & 7) == 0;
+    const int64_t lut_bytes = pq_direct ? 0 : static_cast<int64_t>(pq_m) * 256 * sizeof(float);
     int64_t chunk = std::max<int64_t>(1, (int64_t(1) << 30) / std::max<int64_t>(vis_words * 4 + heap_bytes + lut_bytes, 1));  // <= 1 GiB of scratch
     chunk = std::min(chunk, nq);
     vg::ArenaCall ar(idx->ctx, st);
@@ -470,7 +481,7 @@ static int32_t search_hnsw_impl(vg_index *idx, bool pq, const float *queries, in
     VG_TRY(ar.commit());
     struct { uint32_t *ptr; } vis{ar.get<uint32_t>(i_vis)};
     vg::HItem *heap_ws = lds_heaps ? nullptr : ar.get<vg::HItem>(i_heap);
-    float *luts = pq ? ar.get<float>(i_luts) : nullptr;
+    float *luts = pq && !pq_direct ? ar.get<float>(i_luts) : nullptr;
     const size_t lds = static_cast<size_t>(3 * (lds_heaps ? ef : vg::kHnswLdsEf)) * sizeof(vg::HItem) + 128 * sizeof(float);
     auto kern = pq ? (lds_heaps ? vg::hnsw_search_kernel<true, false> : vg::hnsw_search_kernel<true, true>)
                    : (lds_heaps ? vg::hnsw_search_kernel<false, false> : vg::hnsw_search_kernel<false, true>);
@@ -479,12 +490,13 @@ static int32_t search_hnsw_impl(vg_index *idx, bool pq, const float *queries, in
     for (int64_t q0 = 0; q0 < nq; q0 += chunk) {
         const int64_t cnt = std::min(chunk, nq - q0);
         VG_HIP(hipMemsetAsync(vis.ptr, 0, static_cast<size_t>(cnt) * vis_words * 4, st));
-        if (pq) VG_TRY(vg::launch_pq_build_table(idx->pq, q.ptr + q0 * idx->dim, cnt, luts, false, st));
+        if (luts) VG_TRY(vg::launch_pq_build_table(idx->pq, q.ptr + q0 * idx->dim, cnt, luts, false, st));
         vg::ProfScope prof(idx->ctx, pq ? "hnsw_search_pq" : "hnsw_search", st);
         VG_LAUNCH(kern, dim3(static_cast<unsigned>(cnt)), dim3(64), lds, st, idx->d_vectors, idx->n, idx->dim,
                   idx->metric, idx->d_hnsw_l0, idx->hnsw_m0, idx->hnsw_max_level, idx->hnsw_m, idx->d_hnsw_slot,
                   idx->d_hnsw_adj, idx->d_hnsw_level_off, idx->hnsw_entry, q.ptr + q0 * idx->dim,
-                  pq ? idx->d_pq_rows : nullptr, pq_m, luts, k, ef, vis.ptr, vis_words, heap_ws, oid.ptr + q0 * k,
+                  pq ? idx->d_pq_rows : nullptr, pq_m, luts, pq_direct ? idx->pq->d_codebooks : nullptr,
+                  pq ? idx->pq->d_scales : nullptr, pq ? idx->pq->d_offsets : nullptr, k, ef, vis.ptr, vis_words, heap_ws, oid.ptr + q0 * k,
                   osc.ptr + q0 * k, ost.ptr ? ost.ptr + q0 : nullptr);
     }
     VG_TRY(oid.finish());
@@ -543,14 +555,15 @@ VG_API int32_t vg_search_vamana(vg_index *idx, const float *queries, int64_t nq,
     vg::ArenaCall ar(idx->ctx, st);
     const int i_vis = ar.add(sizeof(uint32_t) * static_cast<size_t>(chunk) * vis_words);
     const int i_cand = ar.add(sizeof(vg::HItem) * static_cast<size_t>(chunk) * cand_cap);
-    const int i_luts = ar.add(kind == 1 ? sizeof(float) * static_cast<size_t>(nq) * pq_m * 256 : 0);
+    const bool pq_direct = kind == 1 && idx->pq->subdim == 8 && (reinterpret_cast<uintptr_t>(idx->pq->d_codebooks) & 7) == 0;
+    const int i_luts = ar.add(kind == 1 && !pq_direct ? sizeof(float) * static_cast<size_t>(nq) * pq_m * 256 : 0);
     const int i_qcodes = ar.add(kind == 2 ? static_cast<size_t>(nq) * (rq_nb + 4) : 0);
     VG_TRY(ar.commit());
     struct { uint32_t *ptr; } vis{ar.get<uint32_t>(i_vis)};
     struct { vg::HItem *ptr; } cand{ar.get<vg::HItem>(i_cand)};
     struct { float *ptr; } luts{ar.get<float>(i_luts)};
     struct { uint8_t *ptr; } qcodes{ar.get<uint8_t>(i_qcodes)};
-    if (kind == 1) {
+    if (kind == 1 && !pq_direct) {
         VG_TRY(vg::launch_pq_build_table(idx->pq, q.ptr, nq, luts.ptr, false, st));
     }
     if (kind == 2) {
@@ -562,7 +575,9 @@ VG_API int32_t vg_search_vamana(vg_index *idx, const float *queries, int64_t nq,
         vg::ProfScope prof(idx->ctx, "vamana_search", st);
         VG_LAUNCH(vg::vamana_search_kernel, dim3(static_cast<unsigned>(cnt)), dim3(64), 0, st, kind,
                            idx->metric, idx->n, idx->dim, idx->d_vamana, idx->vamana_r, idx->vamana_entry,
-                           idx->d_vectors, idx->d_pq_rows, pq_m, kind == 1 ? luts.ptr + q0 * pq_m * 256 : nullptr,
+                           idx->d_vectors, idx->d_pq_rows, pq_m, kind == 1 && !pq_direct ? luts.ptr + q0 * pq_m * 256 : nullptr,
+                           pq_direct ? idx->pq->d_codebooks : nullptr, idx->pq ? idx->pq->d_scales : nullptr,
+                           idx->pq ? idx->pq->d_offsets : nullptr,
                            idx->d_rq_rows, kind == 2 ? qcodes.ptr + q0 * (rq_nb + 4) : nullptr, rq_nb,
                            idx->d_int4_rows, idx->int4_table, q.ptr + q0 * idx->dim, k, cand.ptr, cand_cap, vis.ptr, vis_words, oid.ptr + q0 * k,
                            osc.ptr + q0 * k, ost.ptr ? ost.ptr + q0 : nullptr);

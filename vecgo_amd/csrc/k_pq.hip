@@ -49,10 +49,48 @@ __global__ void pq_build_table_kernel(const float *__restrict__ queries,
     }
 }
 
+// The graph walks' tables ([sub-quantizer][centroid], k = 256, sub-dimension 8): one workgroup per query, thread c
+// owns centroid c of every sub-quantizer — one 8-byte codebook load and one coalesced 1 KiB row store per
+// sub-quantizer, the query's sub-vector, scale and offset through scalar loads.  (The kernel above launches m
+// workgroups of one table row each per query: 786 k workgroups for 8192 queries, 2.4 ms of which nearly all is
+// workgroup scheduling.)  Same five separately rounded operations per dimension, same order.
+__global__ __launch_bounds__(256) void pq_build_table_rows8_kernel(const float *__restrict__ queries,
+                                                                    const int8_t *__restrict__ codebooks,
+                                                                    const float *__restrict__ scales,
+                                                                    const float *__restrict__ offsets, int m,
+                                                                    float *__restrict__ tables)
+{
+    const int64_t q = blockIdx.x;
+    const int c = threadIdx.x;
+    const float *qv = queries + q * m * 8;
+    const uint2 *cb = reinterpret_cast<const uint2 *>(codebooks);
+    float *out = tables + q * m * 256;
+    for (int j = 0; j < m; j++) {
+        const uint2 e = cb[j * 256 + c];
+        const float scale = scales[j], offset = offsets[j];
+        float sum = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const uint32_t w = i < 4 ? e.x : e.y;
+            float v = static_cast<float>(static_cast<int>(static_cast<int8_t>(w >> (8 * (i & 3))))) * scale;
+            v = v + offset;
+            const float d = qv[j * 8 + i] - v;
+            const float dd = d * d;
+            sum = sum + dd;
+        }
+        out[j * 256 + c] = sum;
+    }
+}
+
 int32_t launch_pq_build_table(const vg_pq *pq, const float *d_queries, int64_t nq,
                               float *d_tables, bool scan_layout, hipStream_t st)
 {
     if (nq == 0) return VG_OK;
+    if (!scan_layout && pq->k == 256 && pq->subdim == 8 && (reinterpret_cast<uintptr_t>(pq->d_codebooks) & 7) == 0) {
+        VG_LAUNCH(pq_build_table_rows8_kernel, dim3(static_cast<unsigned>(nq)), dim3(256), 0, st, d_queries,
+                  pq->d_codebooks, pq->d_scales, pq->d_offsets, pq->m, d_tables);
+        return VG_OK;
+    }
     const int64_t maxy = 65535;
     for (int64_t q0 = 0; q0 < nq; q0 += maxy) {
         int64_t cnt = nq - q0 < maxy ? nq - q0 : maxy;

@@ -38,6 +38,7 @@ struct F32Scorer {  // fp32 rows: 16 lanes per row, 4 rows at a time, reference 
     int dim, metric;
     Sub16 sub;
     static constexpr bool kBounded = true;  // SquaredL2Bounded exists for the L2 metric (hnsw.go:1353-1366)
+    __device__ __forceinline__ static void sync() { __syncthreads(); }  // one wave per workgroup
     __device__ __forceinline__ float one(uint32_t id) const { return hnsw_node_dist(base, dim, metric, qv, id, sub); }
     __device__ __forceinline__ void many(uint64_t mask, uint32_t id_lane, int lane, float *nb_pair, float *nb_bnd) const
     {
@@ -100,17 +101,91 @@ __device__ __forceinline__ float pq_asym_distance(const uint8_t *__restrict__ co
     return distance;
 }
 
+// squaredL2Int8DequantizedGeneric (kernels.go:354-362) over one 8-dim sub-vector: the centroid's 8 int8 in `e`, the
+// query's sub-vector / scale / offset wave-uniform (scalar registers).  Five separately rounded fp32 operations per
+// dimension, summed in order — bit for bit the BuildDistanceTable entry of that centroid (pq.go:468-491).
+__device__ __forceinline__ float pq_term8(uint2 e, const float *__restrict__ q, float scale, float offset)
+{
+    float sum = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const uint32_t w = j < 4 ? e.x : e.y;
+        float v = static_cast<float>(static_cast<int>(static_cast<int8_t>(w >> (8 * (j & 3))))) * scale;
+        v = v + offset;
+        const float d = q[j] - v;
+        const float dd = d * d;
+        sum = sum + dd;
+    }
+    return sum;
+}
+
+// ComputeAsymmetricDistance as the reference runs it: no table.  The terms of NG groups of 16 sub-quantizers are
+// computed from the quantizer's own int8 codebook (m * 256 * 8 bytes, shared by every query: L2 / L1 hits) — the
+// 16 * NG centroid loads are issued together, the terms added in sub-quantizer order.
+template <int NG>
+__device__ __forceinline__ float pq_direct_chunk(const uint8_t *__restrict__ code, const uint2 *__restrict__ cb,
+                                                 const float *__restrict__ scales, const float *__restrict__ offsets,
+                                                 const float *__restrict__ qv, int s0, float distance)
+{
+    uint4 c[NG];
+#pragma unroll
+    for (int g = 0; g < NG; g++) c[g] = *reinterpret_cast<const uint4 *>(code + s0 + 16 * g);
+    uint2 e[NG * 16];
+#pragma unroll
+    for (int g = 0; g < NG; g++) {
+        const uint32_t w[4] = {c[g].x, c[g].y, c[g].z, c[g].w};
+#pragma unroll
+        for (int u = 0; u < 16; u++) e[g * 16 + u] = cb[(s0 + g * 16 + u) * 256 + ((w[u >> 2] >> (8 * (u & 3))) & 0xFFu)];
+    }
+    // four terms at a time: their query sub-vectors, scales and offsets are 40 scalar registers; the fence keeps the
+    // compiler from hoisting the scalar loads of the whole chunk (which spills)
+#pragma unroll
+    for (int i0 = 0; i0 < NG * 16; i0 += 4) {
+#pragma unroll
+        for (int i = i0; i < i0 + 4; i++)
+            distance = distance + pq_term8(e[i], qv + (s0 + i) * 8, scales[s0 + i], offsets[s0 + i]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    return distance;
+}
+
+__device__ __forceinline__ float pq_direct_distance(const uint8_t *__restrict__ code, const int8_t *__restrict__ codebooks,
+                                                    const float *__restrict__ scales, const float *__restrict__ offsets,
+                                                    const float *__restrict__ qv, int m)
+{
+    const uint2 *cb = reinterpret_cast<const uint2 *>(codebooks);
+    float distance = 0.0f;
+    int s0 = 0;
+    if ((m & 15) == 0) {
+        for (; s0 + 32 <= m; s0 += 32) distance = pq_direct_chunk<2>(code, cb, scales, offsets, qv, s0, distance);
+        for (; s0 + 16 <= m; s0 += 16) distance = pq_direct_chunk<1>(code, cb, scales, offsets, qv, s0, distance);
+    }
+    for (int s = s0; s < m; s++) distance = distance + pq_term8(cb[s * 256 + code[s]], qv + s * 8, scales[s], offsets[s]);
+    return distance;
+}
+
 // PQ codes: pq.ComputeAsymmetricDistance (pq.go:234-260) — the way the reference scores graph nodes from PQ
-// codes (diskann/segment.go:536-557): term(s) = the BuildDistanceTable entry of the node's code byte, summed
-// sequentially over the sub-quantizers.  One node per lane; the query's table (m * 256 floats) is in HBM/L2.
+// codes (diskann/segment.go:536-557): term(s) = squaredL2Int8Dequantized of the node's centroid, summed
+// sequentially over the sub-quantizers.  One node per lane.
+// r02 read every term from the query's BuildDistanceTable image (m * 256 floats = 96 KiB) in global memory: a popped
+// node's ~58 fresh neighbours look up random centroids of every sub-quantizer, so one pop pulls nearly the whole
+// table through L1, and thousands of resident queries' tables (805 MB for 8192 queries) live in neither L2 nor the
+// 256 MB memory-side cache — the walk ran at the HBM rate of its TABLE traffic (18.9 GB per launch against 0.93 GB
+// of codes, profiles/r02_traffic.json).  `cb` != nullptr (sub-dimension 8): the terms are computed from the shared
+// codebook instead, as the reference computes them; nothing per query is built or kept in memory.
 struct PqScorer {
     const uint8_t *rows;  // n * m code bytes
-    const float *lut;     // m * 256
+    const float *lut;     // m * 256 (table form: sub-dimensions other than 8)
+    const int8_t *cb;     // m * 256 * 8 int8 (direct form) or nullptr
+    const float *scales, *offsets, *qv;
     int m;
     static constexpr bool kBounded = false;
+    __device__ __forceinline__ static void sync() { __syncthreads(); }
     __device__ __forceinline__ float lane_score(uint32_t id) const
     {
-        return pq_asym_distance(rows + static_cast<int64_t>(id) * m, lut, m);
+        const uint8_t *code = rows + static_cast<int64_t>(id) * m;
+        if (cb) return pq_direct_distance(code, cb, scales, offsets, qv, m);
+        return pq_asym_distance(code, lut, m);
     }
     __device__ __forceinline__ float one(uint32_t id) const { return lane_score(id); }
     __device__ __forceinline__ void many(uint64_t mask, uint32_t id_lane, int lane, float *nb_pair, float *nb_bnd) const
@@ -141,21 +216,28 @@ __device__ __forceinline__ void greedy_layer(const Scorer &sc, int lane, RowFn r
         uint64_t mask = count >= 64 ? ~0ull : ((1ull << count) - 1);
         if (scored) *scored += count;
         sc.many(mask, id_lane, lane, nb_pair, nb_bnd);
-        __syncthreads();
-        // sequential `if nextDist < currDist` over the list == first strict minimum
+        Scorer::sync();
+        // sequential `if nextDist < currDist` over the list == the smallest distance, first of its equals, if it
+        // is below currDist: a wave minimum and one ballot instead of `count` dependent LDS reads
+        const float my_d = lane < count ? nb_pair[lane] : 3.40282346638528859811704183484516925440e+38f;
+        float mn = my_d;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float other = __shfl_xor(mn, o);
+            mn = other < mn ? other : mn;
+        }
         float best_d = cur_d;
         uint32_t best_id = cur;
-        for (int i = 0; i < count; i++) {
-            const float d = nb_pair[i];
-            if (d < best_d) {
-                best_d = d;
-                best_id = static_cast<uint32_t>(__builtin_amdgcn_readlane(id_lane, i));
-                changed = true;
-            }
+        if (count > 0 && mn < cur_d) {
+            const uint64_t at = __ballot(lane < count && my_d == mn);
+            const int first = __builtin_ctzll(at);
+            best_d = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_d), first));  // its own bits (-0 == +0)
+            best_id = static_cast<uint32_t>(__builtin_amdgcn_readlane(id_lane, first));
+            changed = true;
         }
         cur = best_id;
         cur_d = best_d;
-        __syncthreads();
+        Scorer::sync();
     }
 }
 
@@ -176,7 +258,7 @@ __device__ __forceinline__ void search_layer(const Scorer &sc, bool l2_metric, i
     int stagnant = 0;
     float last_best = 3.40282346638528859811704183484516925440e+38f;
     const int min_cap = ef + ef * 3 / 4;
-    __syncthreads();
+    Scorer::sync();
 
     while (cand_len > 0) {
         const HItem c = heap_pop<false>(cand, cand_len);
@@ -210,26 +292,27 @@ __device__ __forceinline__ void search_layer(const Scorer &sc, bool l2_metric, i
         const uint64_t newmask = __ballot(fresh);
         st.visited += __popcll(newmask);
         sc.many(newmask, id_lane, lane, nb_pair, nb_bnd);
-        __syncthreads();
+        Scorer::sync();
+        // lane j keeps node j's two distances; the loop below reads them with readlane, not from LDS
+        const float my_pair = nb_pair[lane];
+        const float my_nd = use_sc ? nb_bnd[lane] : my_pair;  // what the reference compares once a bound exists
         bool has_bound = res_len >= ef;
         float bound = has_bound ? heap_get(res, 0).dist : 0.0f;
         uint64_t todo = newmask;
+        st.dc += __popcll(newmask);
         while (todo) {
+            if (has_bound) {
+                // the bound only falls: a node above it now is above it at its turn (SquaredL2Bounded reports
+                // exceeded, or `nd > bound` skips it)
+                const uint64_t rej = __ballot(my_nd > bound) & todo;
+                if (use_sc) st.sc += __popcll(rej);
+                todo &= ~rej;
+                if (!todo) break;
+            }
             const int j = __builtin_ctzll(todo);
             todo &= todo - 1;
             const uint32_t id = static_cast<uint32_t>(__builtin_amdgcn_readlane(id_lane, j));
-            float nd;
-            st.dc++;
-            if (use_sc && has_bound) {
-                nd = nb_bnd[j];
-                if (nd > bound) {  // SquaredL2Bounded reported exceeded
-                    st.sc++;
-                    continue;
-                }
-            } else {
-                nd = nb_pair[j];
-            }
-            if (has_bound && nd > bound) continue;
+            const float nd = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(has_bound ? my_nd : my_pair), j));
             cand_try_push_bounded(cand, cand_len, HItem{id, nd}, cap);
             res_push_bounded(res, res_len, HItem{id, nd}, ef);
             if (res_len >= ef) {
@@ -237,7 +320,7 @@ __device__ __forceinline__ void search_layer(const Scorer &sc, bool l2_metric, i
                 has_bound = true;
             }
         }
-        __syncthreads();
+        Scorer::sync();
     }
     res_len_out = res_len;
 }
