@@ -33,8 +33,12 @@ int32_t launch_pq_build_table(const vg_pq *pq, const float *d_queries, int64_t n
 // query's distance table `luts` (ComputeAsymmetricDistance order), the candidate stage of the
 // graph -> PQ -> exact-rerank pipeline.
 constexpr int kHnswLdsEf = 512;  // LDS items of the results heap (twice that for the candidates): 12 KiB per query
-template <bool PQ, bool SPLIT>
-__global__ __launch_bounds__(64) void hnsw_search_kernel(
+#ifndef VG_HNSW_ATTR
+#define VG_HNSW_ATTR
+#endif
+// UK: the metric is not Dot, so every distance is >= +0 and the heaps compare bit patterns (heap_sift_down_uk).
+template <bool PQ, bool SPLIT, bool UK>
+__global__ __launch_bounds__(64) VG_HNSW_ATTR void hnsw_search_kernel(
     const float *__restrict__ base, int64_t n, int dim, int metric, const uint32_t *__restrict__ l0,
     int m0, int max_level, int m, const uint32_t *__restrict__ slots, const uint32_t *__restrict__ adj,
     const int64_t *__restrict__ level_off, uint32_t entry, const float *__restrict__ queries,
@@ -48,13 +52,15 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(
     const int lane = threadIdx.x;
     float *nb_pair = reinterpret_cast<float *>(smem);
     float *nb_bnd = nb_pair + 64;
+    float *qprep = nb_bnd + 64;  // PQ direct form: (pq_m / 2) * 20 floats (a multiple of 8 bytes), else nothing
+    HItem *heaps = reinterpret_cast<HItem *>(qprep + (PQ && pq_cb ? (pq_m >> 1) * kPqPairFloats : 0));
     typename std::conditional<SPLIT, SplitHeap, HItem *>::type cand, res;
     if constexpr (SPLIT) {
-        HItem *lo = reinterpret_cast<HItem *>(nb_bnd + 64);
+        HItem *lo = heaps;
         cand = SplitHeap{lo, heap_ws + q * 3 * ef, 2 * kHnswLdsEf};
         res = SplitHeap{lo + 2 * kHnswLdsEf, heap_ws + q * 3 * ef + 2 * ef, kHnswLdsEf};
     } else {
-        cand = reinterpret_cast<HItem *>(nb_bnd + 64);
+        cand = heaps;
         res = cand + 2 * ef;
     }
     uint32_t *vis = visited_ws + q * vis_words;
@@ -66,7 +72,12 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(
         sc.scales = pq_scales;
         sc.offsets = pq_offsets;
         sc.qv = queries + q * dim;
+        sc.qprep = qprep;
         sc.m = pq_m;
+        if (pq_cb) {
+            pq_direct_prepare(qprep, sc.qv, pq_scales, pq_offsets, pq_m, lane);
+            __syncthreads();
+        }
     } else {
         sc.base = base;
         sc.qv = queries + q * dim;
@@ -91,13 +102,13 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(
     int res_len = 0;
     LayerStats st;
     auto row0 = [&](uint32_t node) -> const uint32_t * { return l0 + static_cast<int64_t>(node) * m0; };
-    search_layer(sc, metric == kMetricL2, lane, row0, m0, cur, cur_d, ef, cand, res, nb_pair, nb_bnd, vis, res_len, st);
+    search_layer<UK>(sc, metric == kMetricL2, lane, row0, m0, cur, cur_d, ef, cand, res, nb_pair, nb_bnd, vis, res_len, st);
 
     // knnSearchInternal extraction (hnsw.go:1732-1751): drop the worst until k remain, then pop
-    while (res_len > k) (void)heap_pop<true>(res, res_len);
+    while (res_len > k) (void)heap_pop<true, UK>(res, res_len);
     const int nres = res_len;
     for (int i = nres - 1; i >= 0; i--) {
-        const HItem it = heap_pop<true>(res, res_len);
+        const HItem it = heap_pop<true, UK>(res, res_len);
         if (lane == 0) {
             ids[q * k + i] = it.node;
             scores[q * k + i] = it.dist;
@@ -113,6 +124,12 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(
         stats[q].distance_short_circuits = st.sc;
         stats[q].pops = st.pops;
         stats[q].descent_distance_computations = st_descent;
+#ifdef VG_WALK_TIMING
+        stats[q].nodes_visited = st.t_pop;
+        stats[q].distance_computations = st.t_adj;
+        stats[q].distance_short_circuits = st.t_score;
+        stats[q].descent_distance_computations = st.t_push;
+#endif
     }
 }
 
@@ -150,6 +167,7 @@ __global__ __launch_bounds__(64) void vamana_search_kernel(
     // kVamanaLdsCand items — all of it for an ordinary k = 10 search, which scores ~1000 nodes — live in LDS: a
     // popped node pushes up to R = 64 neighbours one after the other, each a sift of dependent accesses
     __shared__ HItem cand_lo[kVamanaLdsCand];
+    extern __shared__ __attribute__((aligned(16))) float vamana_qprep[];  // PQ direct form: pq_direct_prepare's image
     const int64_t q = blockIdx.x;
     const int lane = threadIdx.x;
     const Sub16 sub = Sub16::make(lane);
@@ -166,6 +184,10 @@ __global__ __launch_bounds__(64) void vamana_search_kernel(
         qn = __uint_as_float(b);
     }
     int64_t st_visited = 0, st_dc = 0, st_pops = 0, st_dropped = 0;
+    if (kind == kVamanaPQ && lut == nullptr) {
+        pq_direct_prepare(vamana_qprep, qv, pq_scales, pq_offsets, pq_m, lane);
+        __syncthreads();
+    }
 
     // score the nodes held by the lanes in `mask` (one id per lane) into nb_d[lane]
     auto score_mask = [&](uint64_t mask, uint32_t id_lane) {
@@ -187,7 +209,7 @@ __global__ __launch_bounds__(64) void vamana_search_kernel(
                 // sequentially over the sub-quantizers (vg_hnsw_layer.hpp: loads batched, sum order kept)
                 const uint8_t *code = pq_rows + static_cast<int64_t>(id_lane) * pq_m;
                 nb_d[lane] = lut ? pq_asym_distance(code, lut, pq_m)
-                                 : pq_direct_distance(code, pq_cb, pq_scales, pq_offsets, qv, pq_m);
+                                 : pq_direct_distance(code, pq_cb, pq_scales, pq_offsets, qv, vamana_qprep, pq_m);
             } else if (kind == kVamanaInt4) {
                 // iq.L2Distance (diskann/segment.go:558-565) = int4L2DistancePrecomputedAvx512 order
                 nb_d[lane] = int4_l2_precomputed(qv, int4_rows + static_cast<int64_t>(id_lane) * ((dim + 1) / 2), dim,
@@ -436,6 +458,16 @@ VG_API int32_t vg_index_set_vamana_graph(vg_index *idx, int32_t r, const uint32_
     return VG_OK;
 }
 
+// Per-query scratch of the graph searches (visited bitmap, HBM part of the heaps, exploration heap) is carved from
+// the arena for as many queries as fit under this cap; the rest of the batch goes into further launches.  1 GiB (r02)
+// cut 8192 Vamana queries over 1M nodes (650 KB each) into 5 launches of 1650 wavefronts — fewer than the 3072 the
+// chip holds.  1/16 of the device's memory, at most 16 GiB.
+static int64_t graph_scratch_cap(const vg_ctx *ctx)
+{
+    const int64_t gib = int64_t(1) << 30;
+    return std::min<int64_t>(16 * gib, std::max<int64_t>(gib, ctx->hbm_bytes / 16));
+}
+
 static int32_t search_hnsw_impl(vg_index *idx, bool pq, const float *queries, int64_t nq, int32_t k, int32_t ef,
                                 uint32_t *ids, float *scores, vg_search_stats *stats, void *stream)
 {
@@ -472,7 +504,7 @@ static int32_t search_hnsw_impl(vg_index *idx, bool pq, const float *queries, in
     // sub-dimension 8: node terms straight from the codebook (vg_hnsw_layer.hpp PqScorer), no per-query table
     const bool pq_direct = pq && idx->pq->subdim == 8 && (reinterpret_cast<uintptr_t>(idx->pq->d_codebooks) & 7) == 0;
     const int64_t lut_bytes = pq_direct ? 0 : static_cast<int64_t>(pq_m) * 256 * sizeof(float);
-    int64_t chunk = std::max<int64_t>(1, (int64_t(1) << 30) / std::max<int64_t>(vis_words * 4 + heap_bytes + lut_bytes, 1));  // <= 1 GiB of scratch
+    int64_t chunk = std::max<int64_t>(1, graph_scratch_cap(idx->ctx) / std::max<int64_t>(vis_words * 4 + heap_bytes + lut_bytes, 1));
     chunk = std::min(chunk, nq);
     vg::ArenaCall ar(idx->ctx, st);
     const int i_vis = ar.add(sizeof(uint32_t) * static_cast<size_t>(chunk) * vis_words);
@@ -482,9 +514,13 @@ static int32_t search_hnsw_impl(vg_index *idx, bool pq, const float *queries, in
     struct { uint32_t *ptr; } vis{ar.get<uint32_t>(i_vis)};
     vg::HItem *heap_ws = lds_heaps ? nullptr : ar.get<vg::HItem>(i_heap);
     float *luts = pq && !pq_direct ? ar.get<float>(i_luts) : nullptr;
-    const size_t lds = static_cast<size_t>(3 * (lds_heaps ? ef : vg::kHnswLdsEf)) * sizeof(vg::HItem) + 128 * sizeof(float);
-    auto kern = pq ? (lds_heaps ? vg::hnsw_search_kernel<true, false> : vg::hnsw_search_kernel<true, true>)
-                   : (lds_heaps ? vg::hnsw_search_kernel<false, false> : vg::hnsw_search_kernel<false, true>);
+    // + 4 items: heap_sift_down_uk reads slots fc .. fc+3 whatever the heap's length
+    const size_t lds = static_cast<size_t>(3 * (lds_heaps ? ef : vg::kHnswLdsEf) + 4) * sizeof(vg::HItem) + 128 * sizeof(float) +
+                       (pq_direct ? static_cast<size_t>(pq_m >> 1) * vg::kPqPairFloats * sizeof(float) : 0);
+    const bool uk = idx->metric != VG_METRIC_DOT;
+    auto kern = pq ? (lds_heaps ? vg::hnsw_search_kernel<true, false, true> : vg::hnsw_search_kernel<true, true, true>)
+                   : uk ? (lds_heaps ? vg::hnsw_search_kernel<false, false, true> : vg::hnsw_search_kernel<false, true, true>)
+                        : (lds_heaps ? vg::hnsw_search_kernel<false, false, false> : vg::hnsw_search_kernel<false, true, false>);
     VG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                static_cast<int>(lds)));
     for (int64_t q0 = 0; q0 < nq; q0 += chunk) {
@@ -548,7 +584,7 @@ VG_API int32_t vg_search_vamana(vg_index *idx, const float *queries, int64_t nq,
     const int64_t vis_words = (idx->n + 31) / 32;
     const int64_t cand_cap = std::min<int64_t>(idx->n, 65536);
     const int64_t per_query = vis_words * 4 + cand_cap * 8;
-    int64_t chunk = std::max<int64_t>(1, (int64_t(1) << 30) / per_query);
+    int64_t chunk = std::max<int64_t>(1, graph_scratch_cap(idx->ctx) / per_query);
     chunk = std::min(chunk, nq);
     const int rq_nb = ((idx->dim + 63) / 64) * 8;
     const int pq_m = idx->pq ? idx->pq->m : 0;
@@ -573,7 +609,8 @@ VG_API int32_t vg_search_vamana(vg_index *idx, const float *queries, int64_t nq,
         const int64_t cnt = std::min(chunk, nq - q0);
         VG_HIP(hipMemsetAsync(vis.ptr, 0, static_cast<size_t>(cnt) * vis_words * 4, st));
         vg::ProfScope prof(idx->ctx, "vamana_search", st);
-        VG_LAUNCH(vg::vamana_search_kernel, dim3(static_cast<unsigned>(cnt)), dim3(64), 0, st, kind,
+        VG_LAUNCH(vg::vamana_search_kernel, dim3(static_cast<unsigned>(cnt)), dim3(64),
+                  pq_direct ? static_cast<size_t>(pq_m >> 1) * vg::kPqPairFloats * sizeof(float) : 0, st, kind,
                            idx->metric, idx->n, idx->dim, idx->d_vamana, idx->vamana_r, idx->vamana_entry,
                            idx->d_vectors, idx->d_pq_rows, pq_m, kind == 1 && !pq_direct ? luts.ptr + q0 * pq_m * 256 : nullptr,
                            pq_direct ? idx->pq->d_codebooks : nullptr, idx->pq ? idx->pq->d_scales : nullptr,

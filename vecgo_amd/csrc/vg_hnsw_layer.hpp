@@ -17,7 +17,17 @@ namespace vg {
 
 struct LayerStats {
     int64_t visited = 0, dc = 0, sc = 0, pops = 0;
+#ifdef VG_WALK_TIMING  // stage probe (tools/build_variant.sh): s_memtime cycles per phase, reported in the stats columns
+    int64_t t_pop = 0, t_adj = 0, t_score = 0, t_push = 0;
+#endif
 };
+#ifdef VG_WALK_TIMING
+#define VG_T(var) const int64_t var = static_cast<int64_t>(__builtin_readcyclecounter())
+#define VG_TACC(acc, a, b) (acc) += (b) - (a)
+#else
+#define VG_T(var)
+#define VG_TACC(acc, a, b)
+#endif
 
 // distance of one node as hnsw wraps it (vectorstore/columnar.go:37-44), all lanes of the 16-lane group
 __device__ __forceinline__ float hnsw_node_dist(const float *__restrict__ base, int dim, int metric,
@@ -101,9 +111,63 @@ __device__ __forceinline__ float pq_asym_distance(const uint8_t *__restrict__ co
     return distance;
 }
 
-// squaredL2Int8DequantizedGeneric (kernels.go:354-362) over one 8-dim sub-vector: the centroid's 8 int8 in `e`, the
-// query's sub-vector / scale / offset wave-uniform (scalar registers).  Five separately rounded fp32 operations per
-// dimension, summed in order — bit for bit the BuildDistanceTable entry of that centroid (pq.go:468-491).
+// ---- ComputeAsymmetricDistance without a table (sub-dimension 8) ------------------------------------------------
+// term(s) = squaredL2Int8DequantizedGeneric (kernels.go:354-362) of the node's centroid of sub-quantizer s: per
+// dimension  v = float32(int8)*scale ; v = v + offset ; d = q - v ; dd = d*d ; sum = sum + dd  — five separately
+// rounded fp32 operations, summed in order: bit for bit the BuildDistanceTable entry of that centroid
+// (pq.go:468-491), computed from the quantizer's own int8 codebook (m * 256 * 8 bytes, shared by every query: L2 /
+// L1 hits) instead of being looked up in a per-query table.
+// One node per lane, TWO sub-quantizers at a time: every operation of the pair (s, s+1) is one packed-fp32
+// instruction on the register pair (term s, term s+1) — v_pk_mul_f32 / v_pk_add_f32 round each half exactly like
+// the scalar instruction — so a term costs 8 conversions + 20 half-instructions instead of 48.  The pair's constants
+// (its 2 x 8 query floats interleaved, the two scales, the two offsets: 20 floats) are laid out once per query in
+// the wave's LDS (pq_direct_prepare) and arrive by broadcast reads: no scalar-load round trip per term (the first
+// version waited ~96 of them per call), no vector instruction spent on constants.
+typedef float vg_f2 __attribute__((ext_vector_type(2)));
+constexpr int kPqPairFloats = 20;  // per pair of sub-quantizers: q interleaved [16], scales [2], offsets [2]
+
+// the wave lays out its query's constants: qprep[(s/2)*20 + ...]; m even
+__device__ __forceinline__ void pq_direct_prepare(float *qprep, const float *__restrict__ qv,
+                                                  const float *__restrict__ scales, const float *__restrict__ offsets,
+                                                  int m, int lane)
+{
+    for (int e = lane; e < (m >> 1) * kPqPairFloats; e += 64) {
+        const int p = e / kPqPairFloats, r = e - p * kPqPairFloats;
+        float v;
+        if (r < 16)
+            v = qv[(2 * p + (r & 1)) * 8 + (r >> 1)];
+        else if (r < 18)
+            v = scales[2 * p + (r - 16)];
+        else
+            v = offsets[2 * p + (r - 18)];
+        qprep[e] = v;
+    }
+}
+
+// terms of sub-quantizers (s, s+1): centroids ea / eb, constants at `pc` (LDS); returns (term s, term s+1)
+__device__ __forceinline__ vg_f2 pq_term8_pair(uint2 ea, uint2 eb, const float *pc)
+{
+    const float4 *c4 = reinterpret_cast<const float4 *>(pc);
+    const float4 k0 = c4[0], k1 = c4[1], k2 = c4[2], k3 = c4[3], k4 = c4[4];
+    const vg_f2 q[8] = {{k0.x, k0.y}, {k0.z, k0.w}, {k1.x, k1.y}, {k1.z, k1.w},
+                        {k2.x, k2.y}, {k2.z, k2.w}, {k3.x, k3.y}, {k3.z, k3.w}};
+    const vg_f2 scale = {k4.x, k4.y}, offset = {k4.z, k4.w};
+    vg_f2 sum = {0.0f, 0.0f};
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const uint32_t wa = j < 4 ? ea.x : ea.y, wb = j < 4 ? eb.x : eb.y;
+        const vg_f2 f = {static_cast<float>(static_cast<int>(static_cast<int8_t>(wa >> (8 * (j & 3))))),
+                         static_cast<float>(static_cast<int>(static_cast<int8_t>(wb >> (8 * (j & 3)))))};
+        vg_f2 v = f * scale;
+        v = v + offset;
+        const vg_f2 d = q[j] - v;
+        const vg_f2 dd = d * d;
+        sum = sum + dd;
+    }
+    return sum;
+}
+
+// scalar form (an odd last sub-quantizer; constants from global memory)
 __device__ __forceinline__ float pq_term8(uint2 e, const float *__restrict__ q, float scale, float offset)
 {
     float sum = 0.0f;
@@ -119,13 +183,14 @@ __device__ __forceinline__ float pq_term8(uint2 e, const float *__restrict__ q, 
     return sum;
 }
 
-// ComputeAsymmetricDistance as the reference runs it: no table.  The terms of NG groups of 16 sub-quantizers are
-// computed from the quantizer's own int8 codebook (m * 256 * 8 bytes, shared by every query: L2 / L1 hits) — the
-// 16 * NG centroid loads are issued together, the terms added in sub-quantizer order.
+#ifndef VG_PQ_DIRECT_NG
+#define VG_PQ_DIRECT_NG 2  // groups of 16 centroid loads in flight per lane (32 registers per group)
+#endif
+// NG groups of 16 sub-quantizers from s0: the NG code loads, then the 16 * NG centroid loads, are issued together;
+// the terms are added in sub-quantizer order
 template <int NG>
 __device__ __forceinline__ float pq_direct_chunk(const uint8_t *__restrict__ code, const uint2 *__restrict__ cb,
-                                                 const float *__restrict__ scales, const float *__restrict__ offsets,
-                                                 const float *__restrict__ qv, int s0, float distance)
+                                                 const float *qprep, int s0, float distance)
 {
     uint4 c[NG];
 #pragma unroll
@@ -137,30 +202,34 @@ __device__ __forceinline__ float pq_direct_chunk(const uint8_t *__restrict__ cod
 #pragma unroll
         for (int u = 0; u < 16; u++) e[g * 16 + u] = cb[(s0 + g * 16 + u) * 256 + ((w[u >> 2] >> (8 * (u & 3))) & 0xFFu)];
     }
-    // four terms at a time: their query sub-vectors, scales and offsets are 40 scalar registers; the fence keeps the
-    // compiler from hoisting the scalar loads of the whole chunk (which spills)
 #pragma unroll
-    for (int i0 = 0; i0 < NG * 16; i0 += 4) {
-#pragma unroll
-        for (int i = i0; i < i0 + 4; i++)
-            distance = distance + pq_term8(e[i], qv + (s0 + i) * 8, scales[s0 + i], offsets[s0 + i]);
-        __builtin_amdgcn_sched_barrier(0);
+    for (int i = 0; i < NG * 16; i += 2) {
+        const vg_f2 t = pq_term8_pair(e[i], e[i + 1], qprep + ((s0 + i) >> 1) * kPqPairFloats);
+        distance = distance + t.x;
+        distance = distance + t.y;
     }
     return distance;
 }
 
 __device__ __forceinline__ float pq_direct_distance(const uint8_t *__restrict__ code, const int8_t *__restrict__ codebooks,
                                                     const float *__restrict__ scales, const float *__restrict__ offsets,
-                                                    const float *__restrict__ qv, int m)
+                                                    const float *__restrict__ qv, const float *qprep, int m)
 {
     const uint2 *cb = reinterpret_cast<const uint2 *>(codebooks);
     float distance = 0.0f;
     int s0 = 0;
-    if ((m & 15) == 0) {
-        for (; s0 + 32 <= m; s0 += 32) distance = pq_direct_chunk<2>(code, cb, scales, offsets, qv, s0, distance);
-        for (; s0 + 16 <= m; s0 += 16) distance = pq_direct_chunk<1>(code, cb, scales, offsets, qv, s0, distance);
+    if ((m & 15) == 0) {  // rows of 16-byte multiples are 16-byte aligned (the code array is)
+        for (; s0 + 16 * VG_PQ_DIRECT_NG <= m; s0 += 16 * VG_PQ_DIRECT_NG)
+            distance = pq_direct_chunk<VG_PQ_DIRECT_NG>(code, cb, qprep, s0, distance);
+        for (; s0 + 16 <= m; s0 += 16) distance = pq_direct_chunk<1>(code, cb, qprep, s0, distance);
     }
-    for (int s = s0; s < m; s++) distance = distance + pq_term8(cb[s * 256 + code[s]], qv + s * 8, scales[s], offsets[s]);
+    for (; s0 + 2 <= m; s0 += 2) {
+        const vg_f2 t = pq_term8_pair(cb[s0 * 256 + code[s0]], cb[(s0 + 1) * 256 + code[s0 + 1]],
+                                      qprep + (s0 >> 1) * kPqPairFloats);
+        distance = distance + t.x;
+        distance = distance + t.y;
+    }
+    if (s0 < m) distance = distance + pq_term8(cb[s0 * 256 + code[s0]], qv + s0 * 8, scales[s0], offsets[s0]);
     return distance;
 }
 
@@ -178,13 +247,17 @@ struct PqScorer {
     const float *lut;     // m * 256 (table form: sub-dimensions other than 8)
     const int8_t *cb;     // m * 256 * 8 int8 (direct form) or nullptr
     const float *scales, *offsets, *qv;
+    const float *qprep;   // LDS: pq_direct_prepare's image of this query (direct form)
     int m;
     static constexpr bool kBounded = false;
     __device__ __forceinline__ static void sync() { __syncthreads(); }
     __device__ __forceinline__ float lane_score(uint32_t id) const
     {
+#if defined(VG_PQ_PROBE) && VG_PQ_PROBE == 2  // stage probe (tools/build_variant.sh): no scoring work at all
+        return __uint_as_float(0x40000000u | (((id * 2654435761u) ^ static_cast<uint32_t>(reinterpret_cast<uintptr_t>(qv) >> 4)) >> 9));
+#endif
         const uint8_t *code = rows + static_cast<int64_t>(id) * m;
-        if (cb) return pq_direct_distance(code, cb, scales, offsets, qv, m);
+        if (cb) return pq_direct_distance(code, cb, scales, offsets, qv, qprep, m);
         return pq_asym_distance(code, lut, m);
     }
     __device__ __forceinline__ float one(uint32_t id) const { return lane_score(id); }
@@ -243,7 +316,8 @@ __device__ __forceinline__ void greedy_layer(const Scorer &sc, int lane, RowFn r
 
 // searchLayerUnfiltered from (ep, ep_d).  `vis`: this wave's visited bitmap, already clear.  On return
 // res[0..res_len) is the results max-heap exactly as the reference's search leaves it.
-template <typename Scorer, typename RowFn, typename Heap>
+// UK: every distance is >= +0 (any metric but Dot), see heap_sift_down_uk (vg_heap.hpp)
+template <bool UK = false, typename Scorer, typename RowFn, typename Heap>
 __device__ __forceinline__ void search_layer(const Scorer &sc, bool l2_metric, int lane, RowFn row_of, int deg,
                                              uint32_t ep, float ep_d, int ef, Heap cand, Heap res,
                                              float *nb_pair, float *nb_bnd, uint32_t *vis, int &res_len_out,
@@ -261,7 +335,8 @@ __device__ __forceinline__ void search_layer(const Scorer &sc, bool l2_metric, i
     Scorer::sync();
 
     while (cand_len > 0) {
-        const HItem c = heap_pop<false>(cand, cand_len);
+        VG_T(t0);
+        const HItem c = heap_pop<false, UK>(cand, cand_len);
         st.pops++;
         if (res_len > 0) {
             const float worst = heap_get(res, 0).dist;
@@ -278,6 +353,7 @@ __device__ __forceinline__ void search_layer(const Scorer &sc, bool l2_metric, i
                 }
             }
         }
+        VG_T(t1);
         const uint32_t *nbp = row_of(c.node);
         const uint32_t id_lane = (nbp != nullptr && lane < deg) ? nbp[lane] : VG_INVALID_ID;
         const uint64_t inval = __ballot(id_lane == VG_INVALID_ID);
@@ -291,11 +367,13 @@ __device__ __forceinline__ void search_layer(const Scorer &sc, bool l2_metric, i
         }
         const uint64_t newmask = __ballot(fresh);
         st.visited += __popcll(newmask);
+        VG_T(t2);
         sc.many(newmask, id_lane, lane, nb_pair, nb_bnd);
         Scorer::sync();
         // lane j keeps node j's two distances; the loop below reads them with readlane, not from LDS
         const float my_pair = nb_pair[lane];
         const float my_nd = use_sc ? nb_bnd[lane] : my_pair;  // what the reference compares once a bound exists
+        VG_T(t3);
         bool has_bound = res_len >= ef;
         float bound = has_bound ? heap_get(res, 0).dist : 0.0f;
         uint64_t todo = newmask;
@@ -313,14 +391,23 @@ __device__ __forceinline__ void search_layer(const Scorer &sc, bool l2_metric, i
             todo &= todo - 1;
             const uint32_t id = static_cast<uint32_t>(__builtin_amdgcn_readlane(id_lane, j));
             const float nd = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(has_bound ? my_nd : my_pair), j));
-            cand_try_push_bounded(cand, cand_len, HItem{id, nd}, cap);
-            res_push_bounded(res, res_len, HItem{id, nd}, ef);
-            if (res_len >= ef) {
-                bound = heap_get(res, 0).dist;
-                has_bound = true;
+            cand_try_push_bounded<UK>(cand, cand_len, HItem{id, nd}, cap);
+            if (has_bound) {  // results heap full: its top is `bound`
+                res_replace_top<UK>(res, res_len, HItem{id, nd}, bound);
+            } else {
+                res_push_bounded<UK>(res, res_len, HItem{id, nd}, ef);
+                if (res_len >= ef) {
+                    bound = heap_get(res, 0).dist;
+                    has_bound = true;
+                }
             }
         }
         Scorer::sync();
+        VG_T(t4);
+        VG_TACC(st.t_pop, t0, t1);
+        VG_TACC(st.t_adj, t1, t2);
+        VG_TACC(st.t_score, t2, t3);
+        VG_TACC(st.t_push, t3, t4);
     }
     res_len_out = res_len;
 }
