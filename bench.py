@@ -47,6 +47,7 @@ BLOCK = 65536  # rows per generation block: data is identical for every world si
 PEAK_MFMA_F32_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32-input MFMA dense peak
 PEAK_MFMA_BF16_TFLOPS = 2500.0  # MI355X_MICROARCH.md: bf16 MFMA dense peak (16x the fp32 form)
 PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E spec peak
+RQ_MQ_INSTR_PER_ROW = 66       # vector instructions per 64 (row, query) pairs in rabitq_scan_mq_kernel<6>
 
 
 def gen_rows(lo: int, hi: int, device) -> torch.Tensor:
@@ -188,6 +189,11 @@ def adc_scan_roofline(vg, ctx, stream, device, with_cpu=False):
            "kernel": "pq_adc_scan_kernel<6,true,true>", "kernel_ms": kern_ms,
            "bytes_per_launch": n * m, "search_call_ms": e0.elapsed_time(e1) / reps,
            "qps_single_query_passes": 1e3 / (e0.elapsed_time(e1) / reps)}
+    res["batch"] = scan_batch(ctx, idx.search_pq_adc, "pq_adc_scan", n, m, stream, device,
+                              bound="lds", peak=PEAK_LDS_LOOKUPS_G, unit="G table lookups/s", per_row=m,
+                              note="one fp32 table (96 KiB) fills a workgroup's LDS, so a workgroup scores ONE query; the batch "
+                                   "shares each slice of codes through its XCD's L2 (block order) and runs at the LDS gather "
+                                   "rate: peak = 15 lookups/clk/CU (tools/ubench/lds_pattern.hip, rotated image) x 256 CUs x 2.4 GHz")
     cpu = None
     if with_cpu:  # flat.Segment.Search's PQ branch on the host: BuildDistanceTable + pqAdcLookupAvx512 per row
         from oracle import oracle as o
@@ -208,9 +214,47 @@ def adc_scan_roofline(vg, ctx, stream, device, with_cpu=False):
     del codes
     if cpu:
         res["cpu"] = cpu
+        res["batch"]["cpu_qps"] = cpu["qps"]   # the reference scans one query at a time whatever the batch
+        res["batch"]["gpu_over_cpu"] = res["batch"]["qps"] / cpu["qps"]
     idx.close()
     pq.close()
     return res
+
+
+PEAK_LDS_LOOKUPS_G = 15 * 256 * 2.4        # G ds_read_b32 gathers/s: 15 per clock and CU measured for the rotated table image
+PEAK_VALU_GINSTR = 256 * 4 * 2.4 / 4       # G wave-instructions/s: 4 SIMDs per CU, one 64-lane instruction per 4 clocks
+
+
+def scan_batch(ctx, search, prof, n, row_bytes, stream, device, bound, peak, unit, per_row, note, nq=1024):
+    """A batch of `nq` queries through one search call (the query-blocked scan kernels), 10M rows: queries/s, the
+    kernel's rate against the roofline that bounds it, and a check that a sample of the batch equals one-query passes
+    (which tests/test_gpu_fullsize.py pins to whole-query oracle replays)."""
+    q = gen_queries(1, device)[0][:nq].contiguous()
+    ids, sc = search(q, K, stream=stream)
+    torch.cuda.synchronize()
+    same = True
+    for i in (0, nq // 2 + 1, nq - 1):
+        i1, s1 = search(q[i:i + 1], K, stream=stream)
+        same &= bool(torch.equal(i1[0], ids[i]) and torch.equal(s1[0].view(torch.int32), sc[i].view(torch.int32)))
+    ctx.profile_read(prof)
+    ctx.profile_enable(True)
+    reps = 3
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(stream)
+    for _ in range(reps):
+        search(q, K, stream=stream)
+    e1.record(stream)
+    torch.cuda.synchronize()
+    launches, ms = ctx.profile_read(prof)
+    ctx.profile_enable(False)
+    call_ms = e0.elapsed_time(e1) / reps
+    kern_ms = ms / reps
+    achieved = n * nq * per_row / (kern_ms * 1e-3) / 1e9
+    return {"workload": f"{nq} queries x {n} rows, k={K}, one call", "qps": nq / (call_ms * 1e-3), "call_ms": call_ms,
+            "kernel_ms": kern_ms, "launches_per_call": launches // reps, "row_scores_per_s": n * nq / (kern_ms * 1e-3),
+            "code_bytes_scored_tbs": n * nq * row_bytes / (kern_ms * 1e-3) / 1e12,
+            "roofline": {"bound": bound, "achieved": achieved, "peak": peak, "unit": unit, "frac": achieved / peak, "note": note},
+            "sample_equals_one_query_passes": same}
 
 
 def flat_bf16_filter(vg, ctx, idx, queries, gt_ids, steps, stream):
@@ -340,6 +384,13 @@ def rabitq_scan_roofline(vg, ctx, stream, device, with_cpu=False):
            "traffic": measured_traffic("rabitq_scan"), "kernel": "rabitq_scan_kernel", "kernel_ms": kern_ms,
            "bytes_per_launch": n * cb, "search_call_ms": e0.elapsed_time(e1) / reps,
            "qps_single_query_passes": 1e3 / (e0.elapsed_time(e1) / reps)}
+    res["batch"] = scan_batch(ctx, idx.search_rabitq, "rabitq_scan_mq", n, cb, stream, device,
+                              bound="valu", peak=PEAK_VALU_GINSTR, unit="G wave-instructions/s", per_row=RQ_MQ_INSTR_PER_ROW / 64.0,
+                              note="rabitq_scan_mq_kernel: 16 queries per workgroup pass, a row's sign bits loaded once and kept in "
+                                   "registers; per (row, query) 2 vector instructions per 32 dimensions (xor + popcount-accumulate) "
+                                   "+ the formula with its IEEE division (rabitq.go:170-175) + the top-k pre-test = "
+                                   f"{RQ_MQ_INSTR_PER_ROW} instructions per 64 (row, query) pairs (ISA count); peak = 4 SIMDs x 256 CUs "
+                                   "x 2.4 GHz / 4 clocks per 64-lane instruction")
     cpu = None
     if with_cpu:  # rq.Distance per row (rabitq.go:119-176: query norm + sign-pack recomputed per call, hammingAvx512)
         from oracle import oracle as o
@@ -367,6 +418,8 @@ def rabitq_scan_roofline(vg, ctx, stream, device, with_cpu=False):
     del codes
     if cpu:
         res["cpu"] = cpu
+        res["batch"]["cpu_qps"] = cpu["qps_at_10M_rows"]   # the reference scans one query at a time whatever the batch
+        res["batch"]["gpu_over_cpu"] = res["batch"]["qps"] / cpu["qps_at_10M_rows"]
     idx.close()
     return res
 

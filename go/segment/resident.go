@@ -1,0 +1,271 @@
+//go:build hip && cgo
+
+// Package segment (HIP twin): a device-resident copy of one segment — what flat.Segment.Search
+// (internal/segment/flat/segment.go:447-749), the DiskANN beam search (diskann/segment.go:503-706), the memtable's
+// hnsw.KNNSearch (hnsw.go:1650-1755) and Segment.Rerank (flat/segment.go:754-780) run against, ONE call per query
+// batch instead of one distance call per candidate.  filter == nil paths only: metadata filters and tombstones stay
+// on the Go side.
+//
+// Ownership: Upload* copy the slices to HBM and retain nothing; results are written into caller-owned slices;
+// Close frees the device memory.
+package segment
+
+/*
+#cgo CFLAGS: -I${SRCDIR}/../../third_party/vecgo_hip/include
+#cgo LDFLAGS: -L${SRCDIR}/../../third_party/vecgo_hip -lvecgo_hip
+#include "vecgo_hip.h"
+*/
+import "C"
+
+import (
+	"unsafe"
+
+	"github.com/hupe1980/vecgo/distance"
+	"github.com/hupe1980/vecgo/internal/hipctx"
+)
+
+// Stats mirrors vg_search_stats = the reference's FilterGateStats counters (searcher/searcher.go:114-137) plus
+// the rows the greedy descent scored.  Its size is part of the ABI (VG_ABI_VERSION).
+type Stats struct {
+	NodesVisited, DistanceComputations, DistanceShortCircuits, Pops int64
+	DescentDistanceComputations                                    int64
+}
+
+const (
+	ScanF32 = int32(C.VG_SCAN_F32)
+	ScanPQ  = int32(C.VG_SCAN_PQ)
+	ScanSQ8 = int32(C.VG_SCAN_SQ8)
+)
+
+// Vamana node scorers (diskann/segment.go:512-589 distFn).
+const (
+	VamanaF32, VamanaPQ, VamanaRaBitQ, VamanaInt4 = 0, 1, 2, 3
+)
+
+type Resident struct {
+	ctx  *C.vg_ctx
+	h    *C.vg_index
+	seg  *C.vg_segment // set when opened from a segment image
+	rows int
+	dim  int
+}
+
+func fp(p []float32) *C.float  { return (*C.float)(unsafe.Pointer(&p[0])) }
+func up(p []uint32) *C.uint32_t { return (*C.uint32_t)(unsafe.Pointer(&p[0])) }
+func bp(p []byte) *C.uint8_t    { return (*C.uint8_t)(unsafe.Pointer(&p[0])) }
+
+// NewResident creates an empty twin of a segment of `rows` x `dim`.
+func NewResident(rows, dim int, metric distance.Metric) (*Resident, error) {
+	p, err := hipctx.Ptr()
+	if err != nil {
+		return nil, err
+	}
+	r := &Resident{ctx: (*C.vg_ctx)(p), rows: rows, dim: dim}
+	if st := C.vg_index_create(r.ctx, C.int64_t(rows), C.int32_t(dim), C.int32_t(metric), &r.h); st != C.VG_OK {
+		return nil, hipctx.Err(int32(st))
+	}
+	return r, nil
+}
+
+// OpenFlat / OpenDiskANN hand a whole segment file (mmap or read) to the library: header, section bounds and —
+// with verify — the CRC32C are checked as flat.Open / diskann Open check them (flat/segment.go:105-300,
+// diskann/segment.go:165-440); the sections are uploaded as they lie in the file.
+func OpenFlat(image []byte, verify bool) (*Resident, error)    { return open(image, verify, false) }
+func OpenDiskANN(image []byte, verify bool) (*Resident, error) { return open(image, verify, true) }
+
+func open(image []byte, verify, diskann bool) (*Resident, error) {
+	p, err := hipctx.Ptr()
+	if err != nil {
+		return nil, err
+	}
+	r := &Resident{ctx: (*C.vg_ctx)(p)}
+	v := C.int32_t(0)
+	if verify {
+		v = 1
+	}
+	var st C.int32_t
+	if diskann {
+		st = C.vg_segment_open_diskann(r.ctx, unsafe.Pointer(&image[0]), C.int64_t(len(image)), v, &r.seg, nil)
+	} else {
+		st = C.vg_segment_open_flat(r.ctx, unsafe.Pointer(&image[0]), C.int64_t(len(image)), v, &r.seg, nil)
+	}
+	if st != C.VG_OK {
+		return nil, hipctx.Err(int32(st)) // "invalid magic number", "checksum mismatch: ...", "file too short for ..."
+	}
+	var info C.vg_segment_info
+	if st := C.vg_segment_get_info(r.seg, &info); st != C.VG_OK {
+		C.vg_segment_close(r.seg)
+		return nil, hipctx.Err(int32(st))
+	}
+	r.h = C.vg_segment_index(r.seg) // borrowed: lives until vg_segment_close
+	r.rows, r.dim = int(info.rows), int(info.dim)
+	return r, nil
+}
+
+func (r *Resident) Close() {
+	if r.seg != nil {
+		C.vg_segment_close(r.seg)
+	} else if r.h != nil {
+		C.vg_index_destroy(r.h)
+	}
+	r.seg, r.h = nil, nil
+}
+
+// ---- uploads (the reference's in-memory layouts, copied) ---------------------------------------------------------
+
+// UploadVectors: one n*dim row-major array (vectorstore/columnar.go:21-24, flat/segment.go:692).
+func (r *Resident) UploadVectors(base []float32) error {
+	return hipctx.Err(int32(C.vg_index_set_vectors(r.h, fp(base), nil)))
+}
+
+// UploadPQCodes: n*m code bytes (flat/segment.go:678-680) scored with the quantizer behind `pq`
+// (HIPProductQuantizer.Handle()).
+func (r *Resident) UploadPQCodes(pq unsafe.Pointer, codes []byte) error {
+	return hipctx.Err(int32(C.vg_index_set_pq_codes(r.h, (*C.vg_pq)(pq), bp(codes), nil)))
+}
+
+// UploadSQ8Codes: n*dim code bytes (flat/segment.go:550) with the quantizer behind `sq`.
+func (r *Resident) UploadSQ8Codes(sq unsafe.Pointer, codes []byte) error {
+	return hipctx.Err(int32(C.vg_index_set_sq8_codes(r.h, (*C.vg_sq8)(sq), bp(codes), nil)))
+}
+
+// UploadInt4Codes: n*ceil(dim/2) code bytes (diskann/segment.go:378-416).
+func (r *Resident) UploadInt4Codes(iq unsafe.Pointer, codes []byte) error {
+	return hipctx.Err(int32(C.vg_index_set_int4_codes(r.h, (*C.vg_int4)(iq), bp(codes), nil)))
+}
+
+// UploadRaBitQCodes: n*BytesTotal() code bytes (diskann/segment.go:1393-1408).
+func (r *Resident) UploadRaBitQCodes(codes []byte) error {
+	return hipctx.Err(int32(C.vg_index_set_rabitq_codes(r.h, bp(codes), nil)))
+}
+
+// UploadPartitions: IVF centroids and the first row of every partition (flat/segment.go:727-749).
+func (r *Resident) UploadPartitions(centroids []float32, partitionOffsets []uint32, numPartitions int) error {
+	return hipctx.Err(int32(C.vg_index_set_partitions(r.h, fp(centroids), up(partitionOffsets), C.int32_t(numPartitions), nil)))
+}
+
+// UploadVamanaGraph: n*R neighbour ids, 0xFFFFFFFF = none (diskann/segment.go:1376-1391).
+func (r *Resident) UploadVamanaGraph(R int, graph []uint32, entry uint32) error {
+	return hipctx.Err(int32(C.vg_index_set_vamana_graph(r.h, C.int32_t(R), up(graph), C.uint32_t(entry), nil)))
+}
+
+// UploadHNSWGraph: layer 0 as n*m0 ids; the upper layers as per-level slot tables and adjacency rows.
+func (r *Resident) UploadHNSWGraph(m0 int, l0 []uint32, maxLevel, m int, upperSlot, upperAdj []uint32, levelRows []int64, entry uint32) error {
+	var slot, adj *C.uint32_t
+	var lr *C.int64_t
+	if maxLevel > 0 {
+		slot, adj, lr = up(upperSlot), up(upperAdj), (*C.int64_t)(unsafe.Pointer(&levelRows[0]))
+	}
+	return hipctx.Err(int32(C.vg_index_set_hnsw_graph(r.h, C.int32_t(m0), up(l0), C.int32_t(maxLevel), C.int32_t(m), slot, adj, lr,
+		C.uint32_t(entry), nil)))
+}
+
+// BuildHNSW: ApplyBatchInsert over the rows (hnsw.go:639-684): ids = row numbers, levels = layerForApplyInsert.
+func (r *Resident) BuildHNSW(m, efConstruction int) error {
+	return hipctx.Err(int32(C.vg_hnsw_build(r.h, C.int32_t(m), C.int32_t(efConstruction), 8192, 32, nil)))
+}
+
+// ---- searches: nq row-major queries in, nq*k (RowID, Score) best-first out -----------------------------------------
+
+func (r *Resident) out(nq, k int) ([]uint32, []float32) { return make([]uint32, nq*k), make([]float32, nq*k) }
+
+// SearchFlat: flat.Segment.Search's fp32 branch (flat/segment.go:691-721), hnsw.BruteSearch (hnsw.go:2021-2101).
+func (r *Resident) SearchFlat(queries []float32, nq, k int) ([]uint32, []float32, error) {
+	ids, sc := r.out(nq, k)
+	st := C.vg_search_flat(r.h, fp(queries), C.int64_t(nq), C.int32_t(k), up(ids), fp(sc), nil)
+	return ids, sc, hipctx.Err(int32(st))
+}
+
+// SearchPQ: the PQ branch (flat/segment.go:476-483,678-689): BuildDistanceTable + PqAdcLookup per row.
+func (r *Resident) SearchPQ(queries []float32, nq, k int) ([]uint32, []float32, error) {
+	ids, sc := r.out(nq, k)
+	st := C.vg_search_pq_adc(r.h, fp(queries), C.int64_t(nq), C.int32_t(k), up(ids), fp(sc), nil)
+	return ids, sc, hipctx.Err(int32(st))
+}
+
+// SearchSQ8: the SQ8 branch (flat/segment.go:517-604 L2, :659-667 Dot).
+func (r *Resident) SearchSQ8(queries []float32, nq, k int) ([]uint32, []float32, error) {
+	ids, sc := r.out(nq, k)
+	st := C.vg_search_sq8(r.h, fp(queries), C.int64_t(nq), C.int32_t(k), up(ids), fp(sc), nil)
+	return ids, sc, hipctx.Err(int32(st))
+}
+
+// SearchRaBitQ: exhaustive scan of the RaBitQ codes (rq.Distance per row).
+func (r *Resident) SearchRaBitQ(queries []float32, nq, k int) ([]uint32, []float32, error) {
+	ids, sc := r.out(nq, k)
+	st := C.vg_search_rabitq(r.h, fp(queries), C.int64_t(nq), C.int32_t(k), up(ids), fp(sc), nil)
+	return ids, sc, hipctx.Err(int32(st))
+}
+
+// SearchProbed: a partitioned flat segment, only the nprobes closest partitions (flat/segment.go:727-749).
+func (r *Resident) SearchProbed(queries []float32, nq, k, nprobes int, scan int32) ([]uint32, []float32, error) {
+	ids, sc := r.out(nq, k)
+	st := C.vg_search_flat_probed(r.h, fp(queries), C.int64_t(nq), C.int32_t(k), C.int32_t(nprobes), C.int32_t(scan), up(ids), fp(sc), nil)
+	return ids, sc, hipctx.Err(int32(st))
+}
+
+// Search: the whole of Segment.Search for a segment opened from its file: scan type / beam search by what the
+// file holds.
+func (r *Resident) Search(queries []float32, nq, k, nprobes int) ([]uint32, []float32, error) {
+	ids, sc := r.out(nq, k)
+	st := C.vg_segment_search(r.seg, fp(queries), C.int64_t(nq), C.int32_t(k), C.int32_t(nprobes), up(ids), fp(sc), nil)
+	return ids, sc, hipctx.Err(int32(st))
+}
+
+// SearchHNSW: hnsw.KNNSearch (hnsw.go:1650-1755).  stats may be nil; otherwise len(stats) >= nq.
+func (r *Resident) SearchHNSW(queries []float32, nq, k, ef int, stats []Stats) ([]uint32, []float32, error) {
+	ids, sc := r.out(nq, k)
+	var sp *C.vg_search_stats
+	if len(stats) >= nq && nq > 0 {
+		sp = (*C.vg_search_stats)(unsafe.Pointer(&stats[0]))
+	}
+	st := C.vg_search_hnsw(r.h, fp(queries), C.int64_t(nq), C.int32_t(k), C.int32_t(ef), up(ids), fp(sc), sp, nil)
+	return ids, sc, hipctx.Err(int32(st))
+}
+
+// SearchHNSWPQ: the graph walked on PQ codes (distFunc = pq.ComputeAsymmetricDistance, diskann/segment.go:536-557);
+// follow with Rerank (engine/search.go:914-965).
+func (r *Resident) SearchHNSWPQ(queries []float32, nq, k, ef int, stats []Stats) ([]uint32, []float32, error) {
+	ids, sc := r.out(nq, k)
+	var sp *C.vg_search_stats
+	if len(stats) >= nq && nq > 0 {
+		sp = (*C.vg_search_stats)(unsafe.Pointer(&stats[0]))
+	}
+	st := C.vg_search_hnsw_pq(r.h, fp(queries), C.int64_t(nq), C.int32_t(k), C.int32_t(ef), up(ids), fp(sc), sp, nil)
+	return ids, sc, hipctx.Err(int32(st))
+}
+
+// SearchVamana: diskann searchInternal (diskann/segment.go:503-706) with the given node scorer.
+func (r *Resident) SearchVamana(queries []float32, nq, k, kind int, stats []Stats) ([]uint32, []float32, error) {
+	ids, sc := r.out(nq, k)
+	var sp *C.vg_search_stats
+	if len(stats) >= nq && nq > 0 {
+		sp = (*C.vg_search_stats)(unsafe.Pointer(&stats[0]))
+	}
+	st := C.vg_search_vamana(r.h, fp(queries), C.int64_t(nq), C.int32_t(k), C.int32_t(kind), up(ids), fp(sc), sp, nil)
+	return ids, sc, hipctx.Err(int32(st))
+}
+
+// Rerank: Segment.Rerank + top-k (flat/segment.go:754-780, engine/search.go:914-965): nc candidate rows per query.
+func (r *Resident) Rerank(queries []float32, nq int, candidates []uint32, nc, k int) ([]uint32, []float32, error) {
+	ids, sc := r.out(nq, k)
+	st := C.vg_rerank(r.h, fp(queries), C.int64_t(nq), up(candidates), C.int32_t(nc), C.int32_t(k), up(ids), fp(sc), nil)
+	return ids, sc, hipctx.Err(int32(st))
+}
+
+// MergeTopK: the engine's fan-in over segments (engine/search.go:904-908) for `lists` resident segments' results:
+// ties by (score, RowID + idOffsets[list]).
+func MergeTopK(idsIn []uint32, scoresIn []float32, lists, nq, k int, metric distance.Metric, idOffsets []uint32) ([]uint32, []float32, error) {
+	p, err := hipctx.Ptr()
+	if err != nil {
+		return nil, nil, err
+	}
+	ids, sc := make([]uint32, nq*k), make([]float32, nq*k)
+	var off *C.uint32_t
+	if len(idOffsets) > 0 {
+		off = up(idOffsets)
+	}
+	st := C.vg_merge_topk((*C.vg_ctx)(p), up(idsIn), fp(scoresIn), C.int32_t(lists), C.int64_t(nq), C.int32_t(k), C.int32_t(metric), off,
+		up(ids), fp(sc), nil)
+	return ids, sc, hipctx.Err(int32(st))
+}

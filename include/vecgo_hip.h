@@ -38,7 +38,11 @@
 extern "C" {
 #endif
 
-#define VG_ABI_VERSION 1
+/* Bumped whenever a struct the caller allocates, or an entry point's argument list, changes; vg_abi_version()
+ * returns the value the library was built with — a host compares the two before its first call.
+ *   2: vg_search_stats has FIVE int64 (descent_distance_computations was appended): vg_search_hnsw / _hnsw_pq /
+ *      _vamana write nq * 5 values. */
+#define VG_ABI_VERSION 2
 #define VG_INVALID_ID 0xFFFFFFFFu
 #define VG_STREAM_LEGACY ((void *)1) /* == hipStreamLegacy */
 

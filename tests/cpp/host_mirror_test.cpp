@@ -53,8 +53,15 @@ static std::vector<std::vector<float>> unit_vectors(std::mt19937 &rng, int n, in
     return out;
 }
 
+// what a host allocates per query for the graph searches' counters (the struct grew from 4 to 5 fields)
+static_assert(sizeof(vg_search_stats) == 5 * sizeof(int64_t), "vg_search_stats is five int64: bump VG_ABI_VERSION with it");
+
 int main()
 {
+    if (vg_abi_version() != VG_ABI_VERSION) {
+        std::printf("libvecgo_hip.so has ABI version %d, the header %d\n", vg_abi_version(), VG_ABI_VERSION);
+        return 1;
+    }
     std::shared_ptr<Context> ctx;
     try {
         ctx = std::make_shared<Context>(0);

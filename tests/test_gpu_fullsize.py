@@ -183,6 +183,13 @@ def test_rabitq_scan_10m_x_768(vg, ctx):
     # two whole queries replayed by the oracle over all 10M codes
     rid, rsc = o.replay(o.BENCH_RABITQ, hq[:2], k, codes=codes.cpu().numpy(), n=n, dim=dim)
     assert np.array_equal(rid, np_(ids).view(np.uint32)[:2]) and np.array_equal(bits(rsc), bits(np_(sc)[:2]))
+    # nq >= 2 runs the query-blocked kernel (16 queries per workgroup pass), nq == 1 the one-query kernel: a ragged
+    # batch of 37 must give every query what its own pass gives
+    qb = torch.randn(37, dim, device="cuda", generator=g)
+    bi, bs = idx.search_rabitq(qb, k)
+    for i in (0, 15, 16, 36):
+        i1, s1 = idx.search_rabitq(qb[i:i + 1], k)
+        assert torch.equal(i1[0], bi[i]) and torch.equal(s1[0].view(torch.int32), bs[i].view(torch.int32)), i
     half = n // 2
     a = vg.Index(ctx, half, dim); a.set_rabitq_codes(codes[:half])
     b = vg.Index(ctx, n - half, dim); b.set_rabitq_codes(codes[half:])

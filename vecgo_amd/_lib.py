@@ -44,6 +44,9 @@ def load() -> C.CDLL:
     lib.vg_last_error.restype = C.c_char_p
     lib.vg_status_string.restype = C.c_char_p
     lib.vg_status_string.argtypes = [C.c_int32]
+    want = int(re.search(r"#define VG_ABI_VERSION (\d+)", HEADER_PATH.read_text()).group(1))
+    if lib.vg_abi_version() != want:
+        raise ImportError(f"{LIB_PATH} was built for ABI version {lib.vg_abi_version()}, include/vecgo_hip.h declares {want}: rebuild")
     _lib = lib
     return lib
 

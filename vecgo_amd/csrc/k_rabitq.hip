@@ -245,6 +245,131 @@ __global__ __launch_bounds__(kRqThreads) void rabitq_scan_kernel(
                             partial + (static_cast<int64_t>(q) * slices + s) * k);
 }
 
+// Exhaustive RaBitQ scan of a BATCH of queries.  The reference scans one query at a time (flat/segment.go:606-723);
+// run that way on the GPU every query streams all the codes again (r02: 1024 queries x 5M rows in 113 ms, the
+// codes served from L2).  Here a workgroup takes kRqMq queries over its slice: a wave loads a row's sign bits ONCE
+// (kRqMqTiles tiles of 64 rows: groups * kRqMqTiles 16-byte loads in flight per lane) and keeps them in registers
+// while the queries' bits arrive by LDS broadcast reads — per (row, query) 2 vector instructions per 32 dimensions
+// (v_xor + v_bcnt accumulate) + the distance formula with its true division (rabitq.go:170-175), i.e. bound by the
+// vector ALU, not by HBM or L2: ~65 instructions per 64 (row, query) pairs.  Every query keeps its own k best keys
+// (one per lane, registers); a float pre-test against the k-th score skips the key construction for rows that cannot
+// enter.  Block order as in the one-query kernel: the query blocks of one slice run on one XCD and share the slice
+// in its L2.
+constexpr int kRqMq = 16;      // queries per workgroup pass
+constexpr int kRqMqTiles = 2;  // 64-row tiles per trip
+template <int G>               // 16-byte groups per row, compile-time (6 at dim 768); 0 = runtime `groups`
+__global__ __launch_bounds__(kRqThreads) void rabitq_scan_mq_kernel(
+    const uint4 *__restrict__ tiles, const float *__restrict__ norms, int64_t n_rows, int64_t n_tiles,
+    int groups_rt, int dim, const uint8_t *__restrict__ qcodes /* nq * (nb+4) */, int nb, int slices, int nq,
+    int k, uint64_t *__restrict__ partial, const uint64_t *__restrict__ min_keys)
+{
+    extern __shared__ __attribute__((aligned(16))) uint4 rq_smem[];  // kRqMq * groups query bits, then merge scratch
+    const int groups = G ? G : groups_rt;
+    uint4 *qbits = rq_smem;
+    uint64_t *lists = reinterpret_cast<uint64_t *>(rq_smem + kRqMq * groups);
+    int *valid = reinterpret_cast<int *>(lists + kRqWaves * 64);
+    float *qnorm = reinterpret_cast<float *>(valid + kRqWaves);
+    const int ng = (nq + kRqMq - 1) / kRqMq;
+    const int b = blockIdx.x;
+    const int xcd = b & 7;
+    const int o = b >> 3;
+    const int qg = o % ng;
+    const int s = (o / ng) * 8 + xcd;
+    const int q0 = qg * kRqMq;
+    const int cnt = nq - q0 < kRqMq ? nq - q0 : kRqMq;
+    const int64_t t0 = n_tiles * s / slices, t1 = n_tiles * (s + 1) / slices;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int e = tid; e < cnt * groups; e += kRqThreads) {
+        const int qi = e / groups, g = e - qi * groups;
+        const uint8_t *qc = qcodes + static_cast<int64_t>(q0 + qi) * (nb + 4);
+        uint32_t w[4] = {0, 0, 0, 0};
+        for (int bb = 0; bb < 16; bb++) {
+            const int at = g * 16 + bb;
+            if (at < nb) w[bb >> 2] |= static_cast<uint32_t>(qc[at]) << (8 * (bb & 3));
+        }
+        qbits[e] = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+    if (tid < cnt) {
+        const uint8_t *qc = qcodes + static_cast<int64_t>(q0 + tid) * (nb + 4);
+        qnorm[tid] = __uint_as_float(qc[nb] | (qc[nb + 1] << 8) | (qc[nb + 2] << 16) | (static_cast<uint32_t>(qc[nb + 3]) << 24));
+    }
+    __syncthreads();
+    const float dimf = static_cast<float>(dim);
+    WaveTopK tk[kRqMq];
+    float tau_d[kRqMq];  // score of the k-th key (+inf until k keys were seen): rows above it cannot enter
+#pragma unroll
+    for (int qi = 0; qi < kRqMq; qi++) {
+        tk[qi].init(k);
+        tau_d[qi] = INFINITY;
+    }
+    const bool paged = min_keys != nullptr;
+    constexpr int GM = G ? G : 1;
+    for (int64_t tile = t0 + wave * kRqMqTiles; tile < t1; tile += kRqWaves * kRqMqTiles) {
+        uint4 c[kRqMqTiles][GM];
+        float y[kRqMqTiles];
+        bool live[kRqMqTiles];
+#pragma unroll
+        for (int t = 0; t < kRqMqTiles; t++) {
+            const int64_t tt = tile + t < t1 ? tile + t : tile;  // a trip's second tile may lie past the slice
+            const int64_t row = tt * 64 + lane;
+            live[t] = tile + t < t1 && row < n_rows;
+            if (G) {
+#pragma unroll
+                for (int g = 0; g < GM; g++) c[t][g] = tiles[(tt * G + g) * 64 + lane];
+            }
+            y[t] = live[t] ? norms[row] : 0.0f;
+        }
+#pragma unroll
+        for (int qi = 0; qi < kRqMq; qi++) {
+            if (qi < cnt) {
+                int h[kRqMqTiles];
+#pragma unroll
+                for (int t = 0; t < kRqMqTiles; t++) h[t] = 0;
+                if (G) {
+#pragma unroll
+                    for (int g = 0; g < GM; g++) {
+                        const uint4 qq = qbits[qi * G + g];
+#pragma unroll
+                        for (int t = 0; t < kRqMqTiles; t++)
+                            h[t] += __popc(c[t][g].x ^ qq.x) + __popc(c[t][g].y ^ qq.y) + __popc(c[t][g].z ^ qq.z) +
+                                    __popc(c[t][g].w ^ qq.w);
+                    }
+                } else {
+                    for (int g = 0; g < groups; g++) {
+                        const uint4 qq = qbits[qi * groups + g];
+#pragma unroll
+                        for (int t = 0; t < kRqMqTiles; t++) {
+                            const int64_t tt = tile + t < t1 ? tile + t : tile;
+                            const uint4 cc = tiles[(tt * groups + g) * 64 + lane];
+                            h[t] += __popc(cc.x ^ qq.x) + __popc(cc.y ^ qq.y) + __popc(cc.z ^ qq.z) + __popc(cc.w ^ qq.w);
+                        }
+                    }
+                }
+                const float qn = qnorm[qi];
+#pragma unroll
+                for (int t = 0; t < kRqMqTiles; t++) {
+                    const float d = rq_formula(qn, y[t], dimf, static_cast<float>(h[t]));
+                    if (__ballot(live[t] && d <= tau_d[qi])) {
+                        const int64_t row = (tile + t) * 64 + lane;
+                        uint64_t key = live[t] ? make_key(d, static_cast<uint32_t>(row), false) : kKeyMax;
+                        if (paged && key <= min_keys[q0 + qi]) key = kKeyMax;
+                        tk[qi].offer(key, lane);
+                        tau_d[qi] = tk[qi].tau == kKeyMax ? INFINITY : key_score(tk[qi].tau, false);
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int qi = 0; qi < kRqMq; qi++) {
+        if (qi < cnt) {
+            wg_rank_merge<kRqWaves>(tk[qi], lists, valid, wave, lane, tid, k,
+                                    partial + (static_cast<int64_t>(q0 + qi) * slices + s) * k);
+            __syncthreads();
+        }
+    }
+}
+
 int32_t launch_rabitq_encode(const float *d_vectors, int64_t n, int dim, uint8_t *d_codes, hipStream_t st)
 {
     if (n == 0) return VG_OK;
@@ -396,7 +521,12 @@ VG_API int32_t vg_search_rabitq(vg_index *idx, const float *queries, int64_t nq,
         VG_TRY(vg::launch_topk_merge(none.ptr, nq, 1, k, false, oid.ptr, osc.ptr, st));
     } else {
         const int nb = vg::rq_words(idx->dim) * 8;
-        const int slices = vg::rq_slices(nq, idx->n_tiles, idx->ctx->compute_units);
+        // two or more queries: blocks of kRqMq queries share every code load (rabitq_scan_mq_kernel)
+        const bool mq = nq >= 2;
+        const int64_t units = mq ? (nq + vg::kRqMq - 1) / vg::kRqMq : nq;  // workgroups per slice
+        const int slices = vg::rq_slices(units, idx->n_tiles, idx->ctx->compute_units);
+        const size_t mq_lds = static_cast<size_t>(vg::kRqMq) * idx->rq_groups * 16 + vg::kRqWaves * 64 * sizeof(uint64_t) +
+                              vg::kRqWaves * sizeof(int) + vg::kRqMq * sizeof(float);
         vg::ArenaCall ar(idx->ctx, st);
         const int i_qcodes = ar.add(static_cast<size_t>(nq) * (nb + 4));
         // a wave keeps 64 keys: k > 64 comes in pages of 64, one scan per page
@@ -420,7 +550,17 @@ VG_API int32_t vg_search_rabitq(vg_index *idx, const float *queries, int64_t nq,
         const int64_t max_q = (1ll << 30) / slices;
         for (int off = 0; off < k; off += 64) {
             const int kk = paged ? std::min(64, k - off) : k;
-            for (int64_t q0 = 0; q0 < nq; q0 += max_q) {
+            for (int64_t q0 = 0; mq && q0 < nq; q0 += max_q * vg::kRqMq) {  // whole query blocks per launch
+                const int64_t cnt = std::min<int64_t>(nq - q0, max_q * vg::kRqMq);
+                const int64_t ng = (cnt + vg::kRqMq - 1) / vg::kRqMq;
+                auto kern = idx->rq_groups == 6 ? vg::rabitq_scan_mq_kernel<6> : vg::rabitq_scan_mq_kernel<0>;
+                vg::ProfScope prof(idx->ctx, "rabitq_scan_mq", st);
+                VG_LAUNCH(kern, dim3(static_cast<unsigned>(ng * slices)), dim3(vg::kRqThreads), mq_lds, st,
+                          reinterpret_cast<const uint4 *>(idx->d_rq_tiles), idx->d_rq_norms, idx->n, idx->n_tiles,
+                          idx->rq_groups, idx->dim, qcodes.ptr + q0 * (nb + 4), nb, slices, static_cast<int>(cnt), kk,
+                          partial.ptr + q0 * slices * kk, off ? floor_keys + q0 : nullptr);
+            }
+            for (int64_t q0 = 0; !mq && q0 < nq; q0 += max_q) {
                 const int64_t cnt = nq - q0 < max_q ? nq - q0 : max_q;
                 vg::ProfScope prof(idx->ctx, "rabitq_scan", st);
                 VG_LAUNCH(vg::rabitq_scan_kernel, dim3(static_cast<unsigned>(cnt * slices)),
