@@ -576,6 +576,15 @@ int32_t vg_comm_unique_id(uint8_t *id);
 int32_t vg_comm_create(vg_ctx *ctx, int32_t world, int32_t rank, const uint8_t *id, vg_comm **out);
 int32_t vg_comm_destroy(vg_comm *comm);
 int32_t vg_comm_info(const vg_comm *comm, int32_t *world, int32_t *rank);
+/* vg_comm_probe: load RCCL without creating anything (NOT a collective): every rank calls it and the host agrees on
+ * the outcome BEFORE any rank enters vg_comm_create, which is a collective (ncclCommInitRank) — a rank that cannot
+ * load RCCL would otherwise leave its peers waiting inside it.  An RCCL that is already mapped into the process (e.g.
+ * PyTorch's torch/lib/librccl.so) is reused, never a second copy; rccl_path receives the file the symbols came from.
+ * vg_comm_describe: what RCCL itself says about the communicator (ncclCommCount / ncclCommUserRank /
+ * ncclCommCuDevice), for the run's record: a line that claims n_gpus = N should carry rccl_ranks = N. */
+int32_t vg_comm_probe(char *rccl_path, int32_t len);
+int32_t vg_comm_describe(const vg_comm *comm, int32_t *rccl_ranks, int32_t *rccl_rank, int32_t *rccl_device,
+                         int32_t *reused_mapped_rccl, char *rccl_path, int32_t len);
 int32_t vg_comm_all_gather(vg_comm *comm, const void *send, void *recv, int64_t bytes_per_rank, void *stream);
 int32_t vg_comm_all_gather_topk(vg_comm *comm, const uint32_t *local_ids, const float *local_scores,
                                 int64_t nq, int32_t k, int32_t metric, const uint32_t *id_offsets,

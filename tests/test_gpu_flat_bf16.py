@@ -96,3 +96,38 @@ def test_filter_needs_rows_and_follows_them(vg, ctx):
     eid, esc = o.flat_search_f32(b, 64, q[0], 5, 0)
     assert np.array_equal(ids[0], eid) and np.array_equal(bits(sc[0]), bits(esc))
     idx.close()
+
+
+def test_filter_worst_case_rounding(vg, ctx):
+    """the proof margin of the bf16 filter covered the rounding of a DOT product; an L2 score
+    (|x|^2 - 2 q.x) moves by twice that.  Components just under a bfloat16 rounding boundary (v = 1 + 2^-8 - 2^-20
+    rounds DOWN to 1.0) make it bite: the bf16 dot product of the query (all v) with a row of mostly v is short by 2^-7
+    of its value, so that row's nomination score is too large by 2^-6 * dim = 12, while rows of exactly representable
+    components (1.0 / 2.0) are off by only 6.  The three rows nearest to the query (true distances 3, 4, 5) then look
+    FARTHER (15, 16, 17) than eight thousand rows at true distance 6 or 7 (13 and 14), are not nominated, and with the
+    r02 margin (6.2 here) the proof of the nominated ones passed: 6.0 < 13 - 6.2.  With the margin L2 needs (12.3)
+    it fails, the exhaustive kernel runs, and the result is the reference's."""
+    dim, n, k = 768, 8192, 10
+    v = np.float32(1.0 + 2.0 ** -8 - 2.0 ** -20)
+    rng = np.random.default_rng(5)
+    base = np.ones((n, dim), np.float32)
+    for r in range(n):                      # C rows: p components 2.0: true distance p + 0.012
+        base[r, rng.choice(dim, 6 if r % 273 == 1 else 7, replace=False)] = np.float32(2.0)
+    near = {}
+    for j, row_id in ((3, 4000), (4, 17), (5, 8000)):   # B rows: all v, j components v + 1: true distance j
+        row = np.full(dim, v, np.float32)
+        row[rng.choice(dim, j, replace=False)] += np.float32(1.0)
+        base[row_id] = row
+        near[j] = row_id
+    queries = np.tile(np.full(dim, v, np.float32), (8, 1))
+    idx = vg.Index(ctx, n, dim, vg.Metric(0))
+    idx.set_vectors(base)
+    ids0, sc0 = idx.search_flat(queries, k)
+    idx.enable_bf16_filter(True)
+    ids1, sc1 = idx.search_flat(queries, k)
+    eid, esc = o.flat_search_f32(base, dim, queries[0], k, 0)
+    assert eid[:3].tolist() == [near[3], near[4], near[5]]
+    for qi in range(8):
+        assert np.array_equal(ids0[qi], eid) and np.array_equal(bits(sc0[qi]), bits(esc)), qi
+        assert np.array_equal(ids1[qi], eid) and np.array_equal(bits(sc1[qi]), bits(esc)), ("bf16 filter", qi, ids1[qi], eid)
+    idx.close()

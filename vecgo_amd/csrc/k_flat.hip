@@ -702,9 +702,14 @@ VG_API int32_t vg_search_flat(vg_index *idx, const float *queries, int64_t nq, i
         const int i_minkeys = ar.add(sizeof(uint64_t) * static_cast<size_t>(qc));
         // the bfloat16 filter (vg_index_enable_bf16_filter): the two nomination GEMMs read bf16 copies of the rows and
         // of the queries; what they nominate is re-scored exactly as before and the proof widens its margin by the
-        // rounding the copies can introduce: |score_bf16 - score| <= 2 * (2^-8 + 2^-18) * |q||x| <= 2^-8 * 1.01 * (|q|^2 + |x|^2)
+        // rounding the copies can introduce.  bfloat16 keeps 8 significant bits: rounding to nearest moves an operand
+        // by at most 2^-8 of its magnitude, a product q_i*x_i by at most (2^-7 + 2^-16)|q_i x_i|, the dot product by
+        // (2^-7 + 2^-16)|q||x| <= (2^-8 + 2^-17)(|q|^2 + |x|^2).  A Dot score is the dot product; an L2 score is
+        // |x|^2 - 2 q.x (norms from the fp32 rows), TWICE that: (2^-7 + 2^-16)(|q|^2 + |x|^2).  (r02 used the Dot
+        // bound for both — half of what L2 needs: ADVICE r02, tests/test_gpu_flat_bf16.py
+        // test_filter_worst_case_rounding.)  The verify kernels multiply eps_extra by |q|^2 + max|x|^2.
         const bool bf16 = idx->d_vectors_bf16 != nullptr && fused && dim % (2 * vg::kGemmBK) == 0 && !vg::hook(vg::kHookFlatNoDma);
-        const float eps_extra = bf16 ? 0.00390625f * 1.02f : 0.0f;
+        const float eps_extra = !bf16 ? 0.0f : (dot ? 0.00390625f : 0.0078125f) * 1.02f;
         const int i_qbf = ar.add(bf16 ? sizeof(uint16_t) * static_cast<size_t>(qc) * dim : 0);
         VG_TRY(ar.commit());
         uint16_t *qbf = ar.get<uint16_t>(i_qbf);

@@ -8,20 +8,36 @@
 // single-GPU users never load it.  One collective per search: ids and score bits of a rank travel as one
 // [2][nq][k] int32 block; the gathered [world][2][nq][k] image goes straight into the merge kernel.
 #include <dlfcn.h>
-#include <rccl/rccl.h>
 
+#include <cstdio>
 #include <mutex>
+#include <string>
 
 #include "vg_device.hpp"
 #include "vg_internal.hpp"
+
+// The few RCCL declarations this file needs, so that the library builds without RCCL's headers (it never links
+// against RCCL either): rccl.h's ABI for them has been the same since NCCL 2.
+typedef struct ncclComm *ncclComm_t;
+typedef struct {
+    char internal[128];
+} ncclUniqueId;
+typedef int ncclResult_t;
+typedef int ncclDataType_t;
+enum { ncclSuccess = 0, ncclInt8 = 0 };
 
 namespace vg {
 
 struct RcclApi {
     void *handle = nullptr;
+    std::string path;  // the file the symbols came from (dladdr)
+    bool reused = false;  // an RCCL that was already mapped into the process (PyTorch's) rather than a second copy
     ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;
+    ncclResult_t (*CommCuDevice)(const ncclComm_t, int *) = nullptr;
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int *) = nullptr;
     ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
 };
@@ -29,21 +45,58 @@ struct RcclApi {
 static RcclApi g_rccl;
 static std::mutex g_rccl_mu;
 
+// A process must not run two RCCLs: PyTorch maps its own copy (torch/lib/librccl.so) as soon as torch.distributed
+// creates an RCCL group.  Resolution order: (1) whatever RCCL is ALREADY mapped — by soname (RTLD_NOLOAD), then by
+// the path /proc/self/maps shows for a file named librccl*; (2) only if none is mapped, the system's librccl.so.1.
+static void *find_mapped_rccl(std::string &path)
+{
+    for (const char *name : {"librccl.so.1", "librccl.so"}) {
+        if (void *h = dlopen(name, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL)) {
+            path = name;
+            return h;
+        }
+    }
+    FILE *f = fopen("/proc/self/maps", "r");
+    if (!f) return nullptr;
+    char line[4096];
+    void *h = nullptr;
+    while (!h && fgets(line, sizeof(line), f)) {
+        const char *p = strstr(line, "librccl");
+        if (!p) continue;
+        const char *start = strchr(line, '/');
+        if (!start) continue;
+        std::string file(start);
+        while (!file.empty() && (file.back() == '\n' || file.back() == ' ')) file.pop_back();
+        h = dlopen(file.c_str(), RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
+        if (h) path = file;
+    }
+    fclose(f);
+    return h;
+}
+
 static int32_t load_rccl()
 {
     std::lock_guard<std::mutex> lk(g_rccl_mu);
     if (g_rccl.handle) return VG_OK;
-    void *h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    RcclApi a;
+    void *h = find_mapped_rccl(a.path);
+    a.reused = h != nullptr;
+    if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
     if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
     VG_CHECK(h, VG_ERR_UNSUPPORTED, "vg_comm: cannot load librccl.so.1: %s", dlerror());
-    RcclApi a;
     a.GetUniqueId = reinterpret_cast<decltype(a.GetUniqueId)>(dlsym(h, "ncclGetUniqueId"));
     a.CommInitRank = reinterpret_cast<decltype(a.CommInitRank)>(dlsym(h, "ncclCommInitRank"));
     a.CommDestroy = reinterpret_cast<decltype(a.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
+    a.CommCount = reinterpret_cast<decltype(a.CommCount)>(dlsym(h, "ncclCommCount"));
+    a.CommCuDevice = reinterpret_cast<decltype(a.CommCuDevice)>(dlsym(h, "ncclCommCuDevice"));
+    a.CommUserRank = reinterpret_cast<decltype(a.CommUserRank)>(dlsym(h, "ncclCommUserRank"));
     a.AllGather = reinterpret_cast<decltype(a.AllGather)>(dlsym(h, "ncclAllGather"));
     a.GetErrorString = reinterpret_cast<decltype(a.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
-    VG_CHECK(a.GetUniqueId && a.CommInitRank && a.CommDestroy && a.AllGather && a.GetErrorString, VG_ERR_UNSUPPORTED,
-             "vg_comm: librccl.so.1 lacks a required symbol");
+    VG_CHECK(a.GetUniqueId && a.CommInitRank && a.CommDestroy && a.AllGather && a.GetErrorString && a.CommCount &&
+                 a.CommCuDevice && a.CommUserRank,
+             VG_ERR_UNSUPPORTED, "vg_comm: librccl.so.1 lacks a required symbol");
+    Dl_info info;
+    if (dladdr(reinterpret_cast<void *>(a.AllGather), &info) && info.dli_fname) a.path = info.dli_fname;
     a.handle = h;
     g_rccl = a;
     return VG_OK;
@@ -124,6 +177,29 @@ VG_API int32_t vg_comm_info(const vg_comm *comm, int32_t *world, int32_t *rank)
     VG_CHECK(comm, VG_ERR_INVALID_ARG, "vg_comm_info: NULL communicator");
     if (world) *world = comm->world;
     if (rank) *rank = comm->rank;
+    return VG_OK;
+}
+
+VG_API int32_t vg_comm_probe(char *rccl_path, int32_t len)
+{
+    VG_TRY(vg::load_rccl());
+    if (rccl_path && len > 0) std::snprintf(rccl_path, static_cast<size_t>(len), "%s", vg::g_rccl.path.c_str());
+    return VG_OK;
+}
+
+VG_API int32_t vg_comm_describe(const vg_comm *comm, int32_t *rccl_ranks, int32_t *rccl_rank, int32_t *rccl_device,
+                                int32_t *reused_mapped_rccl, char *rccl_path, int32_t len)
+{
+    VG_CHECK(comm && comm->comm, VG_ERR_INVALID_ARG, "vg_comm_describe: NULL communicator");
+    int n = 0, r = 0, d = 0;
+    VG_RCCL(vg::g_rccl.CommCount(comm->comm, &n));
+    VG_RCCL(vg::g_rccl.CommUserRank(comm->comm, &r));
+    VG_RCCL(vg::g_rccl.CommCuDevice(comm->comm, &d));
+    if (rccl_ranks) *rccl_ranks = n;
+    if (rccl_rank) *rccl_rank = r;
+    if (rccl_device) *rccl_device = d;
+    if (reused_mapped_rccl) *reused_mapped_rccl = vg::g_rccl.reused ? 1 : 0;
+    if (rccl_path && len > 0) std::snprintf(rccl_path, static_cast<size_t>(len), "%s", vg::g_rccl.path.c_str());
     return VG_OK;
 }
 
