@@ -812,7 +812,9 @@ def main():
     rows = gen_rows(lo, hi, device)
     # the exchange step through the C ABI (vg_comm: direct ncclAllGather) when RCCL can be joined that way;
     # torch.distributed's all-gather otherwise
-    comm = sharded.make_comm(ctx) if (world > 1 and not args.torch_collective) else None
+    comm_report = {"collective": "none (1 GPU)" if world == 1 else "torch.distributed", "fell_back": False,
+                   "reason": "--torch-collective" if (world > 1 and args.torch_collective) else None}
+    comm = sharded.make_comm(ctx, report=comm_report) if (world > 1 and not args.torch_collective) else None
     index = sharded.ShardedFlatIndex(ctx, rows, DIM, bounds, metric=0, comm=comm)
     if args.bf16_filter:
         index.index.enable_bf16_filter(True)
@@ -826,6 +828,8 @@ def main():
             index.comm = comm
         else:
             comm = None
+            comm_report.update({"collective": "torch.distributed", "fell_back": True,
+                                "reason": "vg_comm and torch.distributed disagreed on a cross-check batch"})
     n_batches = 8
     queries = gen_queries(n_batches, device)
 
@@ -958,6 +962,8 @@ def main():
                    if world > 1 else "1 GPU"},
         "recall_at_10": recall, "recall_queries": int(min(got.shape[0], gt.shape[0])),
         "roofline": roofline,
+        # which exchange ran, witnessed by RCCL itself (ncclCommCount), and why if it is not the C-ABI one
+        "exchange": {**comm_report, "world_size": world, "torch_backend": args.backend if world > 1 else None},
     }
     out.update(extra)
 

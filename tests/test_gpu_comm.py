@@ -45,9 +45,17 @@ def test_packed_merge_equals_dense_merge(vg, ctx):
 def test_comm_world_of_one(vg, ctx):
     import torch
     from vecgo_amd import api
+    import torch.distributed  # noqa: F401  (torch maps its own librccl when RCCL is first used; probe() must reuse a mapped one)
+    path = api.Comm.probe()
+    assert "rccl" in path
     uid = api.Comm.unique_id()
     assert len(uid) == 128
     comm = api.Comm(ctx, 1, 0, uid)
+    d = comm.describe()      # what RCCL itself says about the communicator
+    assert d["rccl_ranks"] == 1 and d["rccl_rank"] == 0 and d["rccl_device"] == ctx.device and d["rccl_path"] == path
+    # one RCCL per process: if a librccl was mapped before ours was resolved, ours is that file
+    mapped = {line.split()[-1] for line in open("/proc/self/maps") if "librccl" in line}
+    assert len(mapped) == 1, mapped
     dev = torch.device("cuda", 0)
     rng = np.random.default_rng(2)
     nq, k = 19, 10

@@ -343,6 +343,23 @@ class Comm:
         check(lib.vg_comm_unique_id(buf))
         return bytes(buf)
 
+    @staticmethod
+    def probe() -> str:
+        """Load RCCL (not a collective) and return the file it came from; raises when it cannot be loaded.  Every
+        rank calls this and the ranks agree on the outcome BEFORE any of them enters Comm(), which is a collective."""
+        lib = _lib.load()
+        buf = C.create_string_buffer(1024)
+        check(lib.vg_comm_probe(buf, C.c_int32(1024)))
+        return buf.value.decode()
+
+    def describe(self) -> dict:
+        """What RCCL says about this communicator (ncclCommCount / UserRank / CuDevice) and which librccl is in use."""
+        n, r, d, reused = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+        buf = C.create_string_buffer(1024)
+        check(self._lib.vg_comm_describe(self._h, C.byref(n), C.byref(r), C.byref(d), C.byref(reused), buf, C.c_int32(1024)))
+        return {"rccl_ranks": n.value, "rccl_rank": r.value, "rccl_device": d.value,
+                "reused_mapped_rccl": bool(reused.value), "rccl_path": buf.value.decode()}
+
     def __init__(self, ctx: Context, world: int, rank: int, unique_id: bytes):
         self._lib = ctx._lib
         self.ctx, self.world, self.rank = ctx, world, rank

@@ -61,33 +61,55 @@ def sharded_search(local_search: Callable, merge: Callable, queries, k: int, bou
     return merge(gathered.view(world, 2, nq, k), k, _shard_offsets(bounds, world, dev))
 
 
-def make_comm(ctx, group=None):
+def make_comm(ctx, group=None, report: dict = None):
     """A vecgo_amd.Comm spanning the process group: rank 0's id travels over torch.distributed's store.  Returns
-    None (callers fall back to torch.distributed collectives) when the world is 1, the backend is not RCCL, or
-    any rank failed to join."""
-    if not dist.is_initialized() or dist.get_world_size(group) == 1 or dist.get_backend(group) != "nccl":
+    None (callers fall back to torch.distributed collectives) when the world is 1, the backend is not RCCL, or any
+    rank cannot load RCCL / join — and says WHY in `report` (the bench line carries it: a run must not degrade to
+    another collective silently).
+    Order matters: vg_comm_create is a collective (ncclCommInitRank), so everything that can fail on ONE rank —
+    loading RCCL, making the id — is done first and agreed on with an all-reduce; only then does every rank enter
+    the collective together (a rank that failed before it left its peers blocked inside it)."""
+    report = report if report is not None else {}
+    report.update({"collective": "torch.distributed", "fell_back": True, "reason": None})
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        report["reason"] = "world size 1"
+        return None
+    if dist.get_backend(group) != "nccl":
+        report["reason"] = f"torch.distributed backend is {dist.get_backend(group)}, not nccl (RCCL)"
         return None
     from . import api
     world, rank = dist.get_world_size(group), dist.get_rank(group)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    why = ""
+    try:
+        api.Comm.probe()
+        ok = 1
+    except Exception as e:
+        ok, why = 0, f"rank {rank}: {e}"
     box = [None]
-    if rank == 0:
+    if rank == 0 and ok:
         try:
             box[0] = api.Comm.unique_id()
-        except Exception:
-            box[0] = None
-    dist.broadcast_object_list(box, src=0, group=group)
-    if box[0] is None:
-        return None
-    comm, ok = None, 1
-    try:
-        comm = api.Comm(ctx, world, rank, box[0])
-    except Exception:
-        ok = 0
-    flag = torch.tensor([ok], dtype=torch.int32, device=torch.device("cuda", torch.cuda.current_device()))
+        except Exception as e:
+            ok, why = 0, f"rank 0: {e}"
+    flag = torch.tensor([ok], dtype=torch.int32, device=dev)
     dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
-    if int(flag.item()) == 0:
-        if comm is not None:
-            comm.close()
+    if int(flag.item()) == 0:          # some rank cannot load RCCL through the C ABI: nobody enters the collective
+        whys = [None] * world
+        dist.all_gather_object(whys, why, group=group)
+        report["reason"] = "; ".join(w for w in whys if w) or "a rank could not load RCCL"
+        return None
+    dist.broadcast_object_list(box, src=0, group=group)
+    comm = api.Comm(ctx, world, rank, box[0])     # collective; a failure here is a failure of the job
+    info = comm.describe()
+    devs = [None] * world
+    dist.all_gather_object(devs, {"rank": rank, "hip_device": ctx.device, **info}, group=group)
+    ranks_ok = all(d["rccl_ranks"] == world for d in devs)
+    report.update({"collective": "vg_comm (ncclAllGather through the C ABI)", "fell_back": not ranks_ok,
+                   "reason": None if ranks_ok else "ncclCommCount disagrees with the world size", "rccl_ranks": info["rccl_ranks"],
+                   "rccl_path": info["rccl_path"], "reused_mapped_rccl": info["reused_mapped_rccl"], "per_rank": devs})
+    if not ranks_ok:
+        comm.close()
         return None
     return comm
 
