@@ -971,15 +971,8 @@ VG_API int32_t vg_hnsw_build(vg_index *idx, int32_t m, int32_t ef_construction, 
             cur_top = levels[t];
             entry = static_cast<uint32_t>(t);
         }
-    for (uint32_t **slot : {&idx->d_hnsw_l0, &idx->d_hnsw_slot, &idx->d_hnsw_adj})
-        if (*slot) {
-            VG_HIP(hipFree(*slot));
-            *slot = nullptr;
-        }
-    if (idx->d_hnsw_level_off) {
-        VG_HIP(hipFree(idx->d_hnsw_level_off));
-        idx->d_hnsw_level_off = nullptr;
-    }
+    // the new arrays are allocated and filled BEFORE the index lets go of its previous graph: an allocation that
+    // fails here (the build's own scratch is still held) leaves the previous graph searchable, metadata and all
     vg::DevBuf<uint32_t> l0, adj;
     VG_TRY(l0.alloc(static_cast<size_t>(n) * m0));
     VG_TRY(adj.alloc(static_cast<size_t>(upper_rows) * m));
@@ -988,6 +981,15 @@ VG_API int32_t vg_hnsw_build(vg_index *idx, int32_t m, int32_t ef_construction, 
         VG_HIP(hipMemcpyAsync(adj.p, d_ids.p + n * m0, static_cast<size_t>(upper_rows) * m * 4,
                               hipMemcpyDeviceToDevice, st));
     VG_HIP(hipStreamSynchronize(st));
+    for (uint32_t **slot : {&idx->d_hnsw_l0, &idx->d_hnsw_slot, &idx->d_hnsw_adj})
+        if (*slot) {
+            (void)hipFree(*slot);
+            *slot = nullptr;
+        }
+    if (idx->d_hnsw_level_off) {
+        (void)hipFree(idx->d_hnsw_level_off);
+        idx->d_hnsw_level_off = nullptr;
+    }
     idx->d_hnsw_l0 = l0.release();
     idx->d_hnsw_adj = adj.release();
     idx->d_hnsw_slot = d_slots.release();
