@@ -65,6 +65,30 @@ def gen_rows(lo: int, hi: int, device) -> torch.Tensor:
     return out
 
 
+STRUCT_LATENT, STRUCT_NOISE = 16, 0.1
+
+
+def gen_structured(lo: int, hi: int, device, latent: int = STRUCT_LATENT, noise: float = STRUCT_NOISE, seed: int = 0) -> torch.Tensor:
+    """Rows [lo, hi) of the STRUCTURED extra corpus: x = z A + noise * e with z ~ N(0, I_latent), A a fixed latent x 768
+    matrix of N(0, 1/latent) entries (unit variance per dimension), e ~ N(0, I_768): data on a `latent`-dimensional
+    subspace plus isotropic noise — neighbourhoods a graph and an 8-dim sub-quantizer can exploit, unlike the
+    i.i.d. normal corpus of the headline.  Per 65536-row block with its own seed (identical for every world size);
+    seed 0 = corpus, 1 = queries."""
+    g = torch.Generator(device=device)
+    g.manual_seed(SEED_BASE * 16384 + 5)
+    a = torch.randn((latent, DIM), generator=g, device=device, dtype=torch.float32) / latent ** 0.5
+    out = torch.empty((hi - lo, DIM), dtype=torch.float32, device=device)
+    b = lo // BLOCK
+    while b * BLOCK < hi:
+        g.manual_seed(SEED_BASE * 32768 + 1000003 * seed + b)
+        z = torch.randn((BLOCK, latent), generator=g, device=device, dtype=torch.float32)
+        blk = z @ a + noise * torch.randn((BLOCK, DIM), generator=g, device=device, dtype=torch.float32)
+        s, e = max(lo, b * BLOCK), min(hi, (b + 1) * BLOCK)
+        out[s - lo:e - lo] = blk[s - b * BLOCK:e - b * BLOCK]
+        b += 1
+    return out
+
+
 def gen_queries(n_batches: int, device) -> torch.Tensor:
     g = torch.Generator(device=device)
     g.manual_seed(SEED_QUERY)
@@ -473,7 +497,8 @@ EFS_PQ = (128, 512, 2048, 8192)
 NQ_FLIGHT = 8192                               # graph searches are latency chains: many queries in flight
 
 
-def hnsw_pq_frontier(vg, ctx, rows, queries, gt_ids, exact_ms_per_1024, stream, with_cpu):
+def hnsw_pq_frontier(vg, ctx, rows, queries, gt_ids, exact_ms_per_1024, stream, with_cpu, efs_f32=None, efs_pq=None,
+                     cpu_efs=(128, 512, 2048)):
     """The metric's own configuration (BASELINE.json: recall@10 >= 0.95 on 1M x 768 HNSW+PQ), measured:
     real graph (vg_hnsw_build), PQ m = 96 trained + encoded on the GPU, then the (ef, recall, cost) frontier
     of (a) hnsw.KNNSearch on fp32 rows and (b) graph walk on PQ codes -> exact rerank of the ef results.
@@ -513,7 +538,7 @@ def hnsw_pq_frontier(vg, ctx, rows, queries, gt_ids, exact_ms_per_1024, stream, 
         return e0.elapsed_time(e1) / reps
 
     f32 = []
-    for ef in EFS_F32:
+    for ef in (efs_f32 or EFS_F32):
         ids, _, st = idx.search_hnsw(q, K, ef, stats="full", stream=stream)
         ctx.profile_read("hnsw_search")
         ctx.profile_enable(True)
@@ -529,7 +554,7 @@ def hnsw_pq_frontier(vg, ctx, rows, queries, gt_ids, exact_ms_per_1024, stream, 
                     "gathered_gbs": ((float(st[:, 1].sum()) + float(st[:, 4].sum())) * DIM * 4
                                      + float(st[:, 3].sum()) * 2 * HNSW_M * 4) / (kern_ms * 1e-3) / 1e9})
     pqr = []
-    for ef in EFS_PQ:
+    for ef in (efs_pq or EFS_PQ):
         cand, _, st = idx.search_hnsw_pq(q, ef, ef, stats=True, stream=stream)
         ids, _ = idx.rerank(q, cand, K, stream=stream)
         ms_walk = timed(lambda: idx.search_hnsw_pq(q, ef, ef, stream=stream))
@@ -559,7 +584,7 @@ def hnsw_pq_frontier(vg, ctx, rows, queries, gt_ids, exact_ms_per_1024, stream, 
         f"({best_f32['ms_per_1024']:.1f} ms per 1024 queries), PQ walk + rerank {best_pq['recall_at_10']:.3f} at ef={best_pq['ef']} "
         f"({best_pq['ms_per_1024']:.1f} ms); the exact path answers 1024 queries in {exact_ms_per_1024:.1f} ms at recall 1.0")
     if with_cpu:
-        rep["cpu"] = hnsw_cpu_twin(idx, rows, q, f32)
+        rep["cpu"] = hnsw_cpu_twin(idx, rows, q, f32, cpu_efs)
     # configs[2] as a bandwidth statement: ef = 128 on the real graph
     e128 = f32[0]
     rep128 = {"workload": f"hnsw_ef128_1Mx768_k10 on the built graph (M0 = {2 * HNSW_M}), {q.shape[0]} queries in flight",
@@ -574,7 +599,55 @@ def hnsw_pq_frontier(vg, ctx, rows, queries, gt_ids, exact_ms_per_1024, stream, 
     return rep, rep128, idx, pq
 
 
-def hnsw_cpu_twin(idx, rows, q, f32):
+def structured_corpus(vg, ctx, stream, device, with_cpu):
+    """The metric's NAMED pipeline at the NAMED bar, on data that has neighbourhoods: 1M x 768 rows on a 16-dimensional
+    subspace + isotropic noise (gen_structured; the headline's i.i.d. normal corpus has none, §5 of DESIGN.md).  Same
+    build, same PQ shape, same sweep as `hnsw_pq`; reports where HNSW fp32 and HNSW-on-PQ + exact rerank cross
+    recall@10 = 0.95, their queries/s, the exact path on the same rows, and the CPU twin on the same graph.  An
+    extra: `value` stays on the random-normal corpus BASELINE names."""
+    rows = gen_structured(0, N_ROWS, device, seed=0)
+    queries = gen_structured(0, 8 * Q_BATCH, device, seed=1).reshape(8, Q_BATCH, DIM)
+    flat = vg.Index(ctx, N_ROWS, DIM)
+    flat.set_vectors(rows)
+    for _ in range(2):
+        flat.search_flat(queries[1], K, stream=stream)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(stream)
+    for i in range(3):
+        flat.search_flat(queries[i], K, stream=stream)
+    e1.record(stream)
+    torch.cuda.synchronize()
+    exact_ms = e0.elapsed_time(e1) / 3
+    st0 = flat.flat_stats()
+    flat.close()
+    gi, _ = fp64_topk_local(rows, queries[0], 0, K)
+    rep, _, idx, pq = hnsw_pq_frontier(vg, ctx, rows, queries, gi.cpu().numpy(), exact_ms, stream, with_cpu,
+                                       efs_f32=(64, 128, 160, 192, 224, 256, 384), efs_pq=(64, 128, 160, 192, 224, 256, 384),
+                                       cpu_efs=(128, 256))
+    idx.close()
+    pq.close()
+    rep["workload"] = (f"STRUCTURED extra corpus: 1M x 768 = z A + {STRUCT_NOISE} e, z ~ N(0, I_{STRUCT_LATENT}) (bench.gen_structured, "
+                       "seeded), queries drawn the same way; ") + rep["workload"]
+
+    def first(front):
+        ok = [e for e in front if e["recall_at_10"] >= 0.95]
+        return max(ok, key=lambda e: e["qps"]) if ok else None
+    a, b = first(rep["frontier_f32"]), first(rep["frontier_pq_rerank"])
+    rep["at_recall_0_95"] = {"hnsw_f32": a and {k_: a[k_] for k_ in ("ef", "recall_at_10", "qps")},
+                             "hnsw_pq_rerank": b and {k_: b[k_] for k_ in ("ef", "recall_at_10", "qps")},
+                             "exact_qps": rep["exact_path"]["qps"], "exact_fallback_queries": int(st0[1])}
+    if with_cpu and "cpu" in rep:
+        cpu_best = max((c for c in rep["cpu"]["sweep"] if c["recall_at_10"] >= 0.95), key=lambda c: c["qps"], default=None)
+        if cpu_best and b:
+            rep["at_recall_0_95"]["cpu_hnsw_f32"] = {k_: cpu_best[k_] for k_ in ("ef", "recall_at_10", "qps", "cores", "ids_equal_gpu")}
+            rep["at_recall_0_95"]["gpu_hnsw_pq_rerank_over_cpu_hnsw"] = b["qps"] / cpu_best["qps"]
+            if a:
+                rep["at_recall_0_95"]["gpu_hnsw_f32_over_cpu_hnsw"] = a["qps"] / cpu_best["qps"]
+    return rep
+
+
+def hnsw_cpu_twin(idx, rows, q, f32, efs=(128, 512, 2048)):
     """The same searches on the host: the graph the GPU built, hnsw.KNNSearch restated in C (oracle), the
     reference's compiled AVX-512 distance kernels, one query per thread.  Same graph + same algorithm = same
     answers: the first queries' ids are compared with the GPU's."""
@@ -585,7 +658,7 @@ def hnsw_cpu_twin(idx, rows, q, f32):
         h = o.HnswIndex(ic.array, DIM, l0, upper, entry, m=HNSW_M)
         qh = q.cpu().numpy()
         out = []
-        for ef in (128, 512, 2048):
+        for ef in efs:
             r = cpu_leg(o.BENCH_HNSW, qh, K, 4.0, hnsw=h, ef=ef, want_ids=True)
             gids, _ = idx.search_hnsw(q[:256], K, ef)
             gids = gids.cpu().numpy().view(np.uint32)
@@ -615,15 +688,16 @@ def vamana_pq(vg, ctx, idx, q, gt_ids, stream):
     torch.cuda.synchronize()
     launches, ms = ctx.profile_read("vamana_search")
     ctx.profile_enable(False)
-    kern_ms = ms / max(launches, 1)
+    kern_ms = ms / 3     # the kernel launches of ONE call (r02 divided by launches: a call was 5 launches of 1650 queries)
     dc = float(st[:, 1].sum())
     gathered = dc * PQ_M + float(st[:, 3].sum()) * l0.shape[1] * 4
     return {"workload": f"vamana_pq_1Mx768_m96_K256_k10 over the built graph's layer 0 (R = {l0.shape[1]}), {q.shape[0]} queries in flight",
-            "kernel": "vamana_search_kernel", "kernel_ms": kern_ms, "node_scores_per_s": dc / (kern_ms * 1e-3),
+            "kernel": "vamana_search_kernel", "kernel_ms": kern_ms, "launches_per_call": launches // 3, "node_scores_per_s": dc / (kern_ms * 1e-3),
             "lut_lookups_per_s": dc * PQ_M / (kern_ms * 1e-3),
             "recall_at_10_before_rerank": recall_at_k(ids.cpu().numpy().view(np.uint32)[:gt_ids.shape[0]], gt_ids),
             "node_scores_per_query": dc / q.shape[0], "gathered_gbs": gathered / (kern_ms * 1e-3) / 1e9,
-            "bound": "latency of 96 dependent-address table reads per node (L2-resident 96 KiB table per query)"}
+            "bound": "vector-ALU issue of one wave's serial work: node terms computed from the shared int8 codebook (31 instructions per "
+                     "term, no per-query table) + the exploration heap's pushes; see DESIGN.md section 4 'Graph walks in r03'"}
 
 
 def flat_ivf_probe(vg, ctx, rows, queries, gt_ids, stream):
@@ -974,6 +1048,14 @@ def main():
             out[name] = {"error": f"{type(e).__name__}: {e}"}
 
     if hp is not None:
+        # does building in batches cost recall?  (tools/build_check.py on a GPU box: sequential hnsw.Insert, max_batch = 1,
+        # against this bench's 8192 / 32 setting on the same rows; committed tables)
+        try:
+            hp["build_check"] = {"source": "tools/build_check.py, profiles/r03_build_check_*.json",
+                                 **{f.stem.replace("r03_build_check_", "rows_"): json.loads(f.read_text())
+                                    for f in sorted((ROOT / "profiles").glob("r03_build_check_*.json"))}}
+        except Exception as e:
+            hp["build_check"] = {"error": str(e)}
         out["hnsw_pq"] = hp
         out["hnsw_layer0"] = hnsw128
         leg("vamana_pq", lambda: vamana_pq(vg, ctx, hidx, queries.reshape(-1, DIM)[:NQ_FLIGHT].contiguous(), gt1024, stream))
@@ -988,6 +1070,7 @@ def main():
         leg("flat_small_batch", lambda: flat_small_batch(vg, ctx, index.index, queries[2], stream))
     if world == 1 and not args.no_hnsw:
         leg("flat_ivf_probe", lambda: flat_ivf_probe(vg, ctx, rows, queries, gt[:64], stream))
+        leg("structured_corpus", lambda: structured_corpus(vg, ctx, stream, device, with_cpu=not args.no_cpu_baseline))
     cpu_on = world == 1 and not args.no_cpu_baseline
     if world == 1 and not args.no_adc:
         del index

@@ -1,27 +1,33 @@
 #!/bin/bash
-# rocprofv3 PMC passes behind profiles/r02_pmc_*.csv (run on the GPU box through gpurun; counters in their own
-# runs with --kernel-trace only, as the pool requires).  usage: tools/collect_pmc.sh [adc|graph|all]
-cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+# Every rocprofv3 --pmc pass behind profiles/r03_traffic.json, at the bench's own shapes (run on the GPU box through
+# gpurun; counters in their own runs with --kernel-trace only, as the pool requires).  Each pass leaves
+# gpurun_out/pmc/NAME.csv (per-kernel mean counter values per dispatch, tools/pmc_run.sh); tools/make_traffic_json.py
+# turns them into the JSON.  usage: tools/collect_pmc.sh [scans|gemm|walks|all]
 what=${1:-all}
-run() {  # name, counters, command...
-    name=$1; ctrs=$2; shift 2
-    rocprofv3 --pmc $ctrs --kernel-trace --output-format csv -d gpurun_out/pmc_$name -- "$@" > gpurun_out/pmc_$name.log 2>&1
-    python3 tools/pmc_summary.py gpurun_out/pmc_$name > gpurun_out/r02_pmc_$name.csv 2>> gpurun_out/pmc_$name.log
-    rm -rf gpurun_out/pmc_$name
-}
-if [ "$what" = adc ] || [ "$what" = all ]; then
-    run adc_lds "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_ACTIVE_INST_LDS" python3 tools/adc_prof.py 10000000 1 10
-    run adc_valu "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" python3 tools/adc_prof.py 10000000 1 10
-    run adc_wait "SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_WAVES SQ_INSTS_VMEM_RD" python3 tools/adc_prof.py 10000000 1 10
-    run adc_fetch "FETCH_SIZE" python3 tools/adc_prof.py 10000000 1 10
-    run adc_write "WRITE_SIZE" python3 tools/adc_prof.py 10000000 1 10
+P=tools/pmc_run.sh
+if [ "$what" = scans ] || [ "$what" = all ]; then
+    $P adc_fetch "FETCH_SIZE" python3 tools/adc_prof.py 10000000 1 10
+    $P adc_write "WRITE_SIZE" python3 tools/adc_prof.py 10000000 1 10
+    $P adc_lds "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_ACTIVE_INST_LDS" python3 tools/adc_prof.py 10000000 1 10
+    $P rq_fetch "FETCH_SIZE" python3 tools/rabitq_prof.py 10000000 1 10
+    $P rq_write "WRITE_SIZE" python3 tools/rabitq_prof.py 10000000 1 10
+    $P rqmq_fetch "FETCH_SIZE" python3 tools/scan_batch_time.py rabitq 10000000 1024
+    $P rqmq_valu "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS GRBM_GUI_ACTIVE SQ_WAVES" python3 tools/scan_batch_time.py rabitq 10000000 1024
+    $P adcmq_fetch "FETCH_SIZE" python3 tools/scan_batch_time.py adc 10000000 64
+    $P sq8_fetch "FETCH_SIZE" python3 tools/sq8_prof.py 4000000 1 10
 fi
-if [ "$what" = graph ] || [ "$what" = all ]; then
-    run graph_fetch "FETCH_SIZE" python3 tools/graph_prof.py 200000
-    run graph_write "WRITE_SIZE" python3 tools/graph_prof.py 200000
-    run graph_valu "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" python3 tools/graph_prof.py 200000
-    run graph_lds "SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD" python3 tools/graph_prof.py 200000
-    run sq8_fetch "FETCH_SIZE" python3 tools/sq8_prof.py 4000000 1 10
-    python3 tools/graph_prof.py 200000 > gpurun_out/r02_graph_prof_counts.json 2>/dev/null
+if [ "$what" = gemm ] || [ "$what" = all ]; then
+    $P gemm_fetch "FETCH_SIZE" python3 tools/flat_time.py
+    $P gemm_write "WRITE_SIZE" python3 tools/flat_time.py
+    $P gemm_mfma "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32" python3 tools/flat_time.py
 fi
-ls -la gpurun_out/r02_pmc_*.csv
+if [ "$what" = walks ] || [ "$what" = all ]; then
+    for m in "f32 128" "f32 2048" "pq 128" "vamana_pq"; do
+        tag=$(echo $m | tr ' ' '_')
+        $P walk_${tag}_fetch "FETCH_SIZE" python3 tools/walk_prof.py 1000000 $m
+        $P walk_${tag}_write "WRITE_SIZE" python3 tools/walk_prof.py 1000000 $m
+        $P walk_${tag}_valu "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS GRBM_GUI_ACTIVE SQ_WAVES" python3 tools/walk_prof.py 1000000 $m
+    done
+fi
+python3 tools/make_traffic_json.py gpurun_out/pmc > gpurun_out/pmc/r03_traffic.json
+ls gpurun_out/pmc/*.csv | wc -l

@@ -1,0 +1,88 @@
+"""gpurun_out/pmc/*.csv (tools/collect_pmc.sh) -> r03_traffic.json: HBM-side bytes per launch, corrected as
+MI355X_MICROARCH.md prescribes (FETCH_SIZE / WRITE_SIZE are KiB; on gfx950 FETCH_SIZE reports half of the bytes of
+wide reads, so the read side is doubled), next to the launch's algorithmic bytes, plus the
+vector-ALU / MFMA counters of the kernels that are not HBM-bound.  argv: directory of the csv files."""
+import csv, glob, json, os, re, sys
+
+d = sys.argv[1]
+
+
+def rows(name):
+    p = os.path.join(d, name + ".csv")
+    if not os.path.exists(p):
+        return []
+    return list(csv.DictReader(open(p)))
+
+
+def val(name, kernel_sub, counter):
+    for r in rows(name):
+        if kernel_sub in r["kernel"] and r["counter"] == counter:
+            return float(r["mean_per_dispatch"])
+    return None
+
+
+def counts(name):
+    """the JSON line tools/walk_prof.py printed under the profiler"""
+    p = os.path.join(d, name + ".log")
+    if not os.path.exists(p):
+        return None
+    for line in open(p):
+        if line.startswith("{") and '"distance_computations"' in line:
+            return json.loads(line)
+    return None
+
+
+def traffic(fetch_name, write_name, kernel_sub, algorithmic, extra=None):
+    f, w = val(fetch_name, kernel_sub, "FETCH_SIZE"), val(write_name, kernel_sub, "WRITE_SIZE") if write_name else None
+    if f is None:
+        return None
+    tb = f * 1024 * 2 + (w or 0) * 1024
+    out = {"kernel": kernel_sub, "fetch_size_kib": f, "write_size_kib": w, "traffic_bytes": tb}
+    if algorithmic:
+        out["algorithmic_bytes"] = algorithmic
+        out["traffic_per_algorithmic_byte"] = tb / algorithmic
+    if extra:
+        out.update(extra)
+    return out
+
+
+out = {"_comment": "HBM-side traffic per launch from rocprofv3 --pmc passes of THIS round's binary at the bench's own shapes "
+                   "(tools/collect_pmc.sh; counters in their own runs, --kernel-trace only), corrected as MI355X_MICROARCH.md "
+                   "section HBM prescribes (KiB; read side doubled on gfx950); per-kernel means in profiles/r03_pmc_*.csv"}
+out["pq_adc_scan"] = traffic("adc_fetch", "adc_write", "pq_adc_scan_kernel", 10_000_000 * 96, {
+    "workload": "10M x 96 B, 1 query",
+    "lds": {c: val("adc_lds", "pq_adc_scan_kernel", c) for c in ("SQ_INSTS_LDS", "SQ_LDS_IDX_ACTIVE", "SQ_LDS_BANK_CONFLICT", "SQ_ACTIVE_INST_LDS")}})
+if out["pq_adc_scan"] and out["pq_adc_scan"]["lds"]["SQ_LDS_IDX_ACTIVE"]:
+    l = out["pq_adc_scan"]["lds"]
+    l["bank_conflict_share_of_lds_active_cycles"] = l["SQ_LDS_BANK_CONFLICT"] / l["SQ_LDS_IDX_ACTIVE"]
+out["rabitq_scan"] = traffic("rq_fetch", "rq_write", "rabitq_scan_kernel", 10_000_000 * 100, {"workload": "10M x 100 B, 1 query"})
+mq = traffic("rqmq_fetch", None, "rabitq_scan_mq_kernel", None, {"workload": "10M x 100 B, 1024 queries in one call"})
+if mq:
+    valu, gui = val("rqmq_valu", "rabitq_scan_mq_kernel", "SQ_INSTS_VALU"), val("rqmq_valu", "rabitq_scan_mq_kernel", "GRBM_GUI_ACTIVE")
+    mq.update({"SQ_INSTS_VALU": valu, "GRBM_GUI_ACTIVE_sum_over_8_xcds": gui,
+               "valu_instructions_per_64_row_query_pairs": valu / (10_000_000 * 1024 / 64) if valu else None,
+               "valu_busy_fraction": valu * 4 / 1024 / (gui / 8) if valu and gui else None,
+               "note": "traffic_bytes = fabric reads of the whole call: the 1 GB of codes once per XCD-resident query block, "
+                       "the rest of the 64 query blocks' passes served by L2"})
+out["rabitq_scan_mq"] = mq
+out["pq_adc_scan_batch64"] = traffic("adcmq_fetch", None, "pq_adc_scan_kernel", None, {"workload": "10M x 96 B, 64 queries in one call (one pass per query, slices shared through L2)"})
+out["sq8_scan"] = traffic("sq8_fetch", None, "sq8_scan_kernel", 4_000_000 * 768, {"workload": "4M x 768 one-byte codes, 1 query"})
+g = traffic("gemm_fetch", "gemm_write", "flat_gemm_dma_kernel", 1_000_000 * 768 * 4 + 1024 * 768 * 4, {"workload": "1024 queries x 1M x 768 per launch"})
+if g:
+    busy, gui = val("gemm_mfma", "flat_gemm_dma_kernel", "SQ_VALU_MFMA_BUSY_CYCLES"), val("gemm_mfma", "flat_gemm_dma_kernel", "GRBM_GUI_ACTIVE")
+    g.update({"SQ_VALU_MFMA_BUSY_CYCLES": busy, "GRBM_GUI_ACTIVE_sum_over_8_xcds": gui,
+              "mfma_busy_fraction": busy / (1024 * gui / 8) if busy and gui else None})
+out["flat_gemm"] = g
+for tag, sub, per_score in (("f32_128", "hnsw_search_kernel<false", 768 * 4), ("f32_2048", "hnsw_search_kernel<false", 768 * 4),
+                            ("pq_128", "hnsw_search_kernel<true", 96), ("vamana_pq", "vamana_search_kernel", 96)):
+    c = counts(f"walk_{tag}_fetch")
+    alg = None
+    if c:
+        alg = (c["distance_computations"] + c.get("descent_distance_computations", 0)) * per_score + c["pops"] * 64 * 4
+    t = traffic(f"walk_{tag}_fetch", f"walk_{tag}_write", sub, alg, {"workload": f"graph built on 1M x 768 (M0 = 64), 8192 queries per call, {tag}", "counts": c})
+    if t:
+        valu, gui = val(f"walk_{tag}_valu", sub, "SQ_INSTS_VALU"), val(f"walk_{tag}_valu", sub, "GRBM_GUI_ACTIVE")
+        t.update({"SQ_INSTS_VALU": valu, "SQ_INSTS_SALU": val(f"walk_{tag}_valu", sub, "SQ_INSTS_SALU"),
+                  "GRBM_GUI_ACTIVE_sum_over_8_xcds": gui, "valu_busy_fraction": valu * 4 / 1024 / (gui / 8) if valu and gui else None})
+    out[{"f32_128": "hnsw_search", "f32_2048": "hnsw_search_ef2048", "pq_128": "hnsw_search_pq", "vamana_pq": "vamana_search_pq"}[tag]] = t
+print(json.dumps(out, indent=1))

@@ -44,6 +44,7 @@ __global__ __launch_bounds__(64) VG_HNSW_ATTR void hnsw_search_kernel(
     const int64_t *__restrict__ level_off, uint32_t entry, const float *__restrict__ queries,
     const uint8_t *__restrict__ pq_rows, int pq_m, const float *__restrict__ luts,
     const int8_t *__restrict__ pq_cb, const float *__restrict__ pq_scales, const float *__restrict__ pq_offsets, int k, int ef,
+    int lds_ef /* SPLIT: items of the results heap kept in LDS (twice that of the candidates heap) */,
     uint32_t *__restrict__ visited_ws, int64_t vis_words, HItem *__restrict__ heap_ws,
     uint32_t *__restrict__ ids, float *__restrict__ scores, vg_search_stats *__restrict__ stats)
 {
@@ -57,8 +58,8 @@ __global__ __launch_bounds__(64) VG_HNSW_ATTR void hnsw_search_kernel(
     typename std::conditional<SPLIT, SplitHeap, HItem *>::type cand, res;
     if constexpr (SPLIT) {
         HItem *lo = heaps;
-        cand = SplitHeap{lo, heap_ws + q * 3 * ef, 2 * kHnswLdsEf};
-        res = SplitHeap{lo + 2 * kHnswLdsEf, heap_ws + q * 3 * ef + 2 * ef, kHnswLdsEf};
+        cand = SplitHeap{lo, heap_ws + q * 3 * ef, 2 * lds_ef};
+        res = SplitHeap{lo + 2 * lds_ef, heap_ws + q * 3 * ef + 2 * ef, lds_ef};
     } else {
         cand = heaps;
         res = cand + 2 * ef;
@@ -499,7 +500,11 @@ static int32_t search_hnsw_impl(vg_index *idx, bool pq, const float *queries, in
     const int pq_m = pq ? idx->pq->m : 0;
     // heaps in LDS up to kHnswLdsEf (12 KiB per query: the waves of a CU are then bounded by registers, not
     // LDS), beyond it split between those 12 KiB (the top levels) and HBM scratch
+    // split heaps: the PQ walk also keeps its query's 3.75 KiB of constants in LDS and gathers 32x fewer bytes per
+    // node, so it prefers waves to LDS heap levels: 256 items (10 KiB per query in all); measured on one box at ef 2048:
+    // 86 ms per 8192 queries with 256, 100 ms with 512; the fp32 walk the other way round (119 vs 124)
     const bool lds_heaps = ef <= vg::kHnswLdsEf;
+    const int lds_ef = pq ? 256 : vg::kHnswLdsEf;
     const int64_t heap_bytes = lds_heaps ? 0 : static_cast<int64_t>(3) * ef * sizeof(vg::HItem);
     // sub-dimension 8: node terms straight from the codebook (vg_hnsw_layer.hpp PqScorer), no per-query table
     const bool pq_direct = pq && idx->pq->subdim == 8 && (reinterpret_cast<uintptr_t>(idx->pq->d_codebooks) & 7) == 0;
@@ -515,7 +520,7 @@ static int32_t search_hnsw_impl(vg_index *idx, bool pq, const float *queries, in
     vg::HItem *heap_ws = lds_heaps ? nullptr : ar.get<vg::HItem>(i_heap);
     float *luts = pq && !pq_direct ? ar.get<float>(i_luts) : nullptr;
     // + 4 items: heap_sift_down_uk reads slots fc .. fc+3 whatever the heap's length
-    const size_t lds = static_cast<size_t>(3 * (lds_heaps ? ef : vg::kHnswLdsEf) + 4) * sizeof(vg::HItem) + 128 * sizeof(float) +
+    const size_t lds = static_cast<size_t>(3 * (lds_heaps ? ef : lds_ef) + 4) * sizeof(vg::HItem) + 128 * sizeof(float) +
                        (pq_direct ? static_cast<size_t>(pq_m >> 1) * vg::kPqPairFloats * sizeof(float) : 0);
     const bool uk = idx->metric != VG_METRIC_DOT;
     auto kern = pq ? (lds_heaps ? vg::hnsw_search_kernel<true, false, true> : vg::hnsw_search_kernel<true, true, true>)
@@ -532,7 +537,7 @@ static int32_t search_hnsw_impl(vg_index *idx, bool pq, const float *queries, in
                   idx->metric, idx->d_hnsw_l0, idx->hnsw_m0, idx->hnsw_max_level, idx->hnsw_m, idx->d_hnsw_slot,
                   idx->d_hnsw_adj, idx->d_hnsw_level_off, idx->hnsw_entry, q.ptr + q0 * idx->dim,
                   pq ? idx->d_pq_rows : nullptr, pq_m, luts, pq_direct ? idx->pq->d_codebooks : nullptr,
-                  pq ? idx->pq->d_scales : nullptr, pq ? idx->pq->d_offsets : nullptr, k, ef, vis.ptr, vis_words, heap_ws, oid.ptr + q0 * k,
+                  pq ? idx->pq->d_scales : nullptr, pq ? idx->pq->d_offsets : nullptr, k, ef, lds_ef, vis.ptr, vis_words, heap_ws, oid.ptr + q0 * k,
                   osc.ptr + q0 * k, ost.ptr ? ost.ptr + q0 : nullptr);
     }
     VG_TRY(oid.finish());
