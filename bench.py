@@ -47,7 +47,8 @@ BLOCK = 65536  # rows per generation block: data is identical for every world si
 PEAK_MFMA_F32_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32-input MFMA dense peak
 PEAK_MFMA_BF16_TFLOPS = 2500.0  # MI355X_MICROARCH.md: bf16 MFMA dense peak (16x the fp32 form)
 PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E spec peak
-RQ_MQ_INSTR_PER_ROW = 66       # vector instructions per 64 (row, query) pairs in rabitq_scan_mq_kernel<6>
+RQ_MQ_INSTR_PER_ROW = 81.7     # vector instructions per 64 (row, query) pairs in rabitq_scan_mq_kernel<6>: SQ_INSTS_VALU of a
+                               # 10M x 1024 call / (10M * 1024 / 64), profiles/r03_traffic.json rabitq_scan_mq
 
 
 def gen_rows(lo: int, hi: int, device) -> torch.Tensor:
@@ -587,10 +588,16 @@ def hnsw_pq_frontier(vg, ctx, rows, queries, gt_ids, exact_ms_per_1024, stream, 
         rep["cpu"] = hnsw_cpu_twin(idx, rows, q, f32, cpu_efs)
     # configs[2] as a bandwidth statement: ef = 128 on the real graph
     e128 = f32[0]
+    alg128 = e128["gathered_gbs"] * 1e9 * e128["kernel_ms"] * 1e-3
+    tr128 = measured_traffic("hnsw_search", alg128)
     rep128 = {"workload": f"hnsw_ef128_1Mx768_k10 on the built graph (M0 = {2 * HNSW_M}), {q.shape[0]} queries in flight",
               "bound": "hbm", "achieved": e128["gathered_gbs"], "peak": PEAK_HBM_GBS, "unit": "GB/s",
-              "frac": e128["gathered_gbs"] / PEAK_HBM_GBS,
-              "traffic": measured_traffic("hnsw_search", e128["gathered_gbs"] * 1e9 * e128["kernel_ms"] * 1e-3),
+              # `achieved` counts every row the walk scored, some of them served by L2 / the memory-side cache (hub rows, the
+              # shared descent path): it is a GATHER rate set against the HBM peak, not an HBM fraction
+              "gather_rate_over_hbm_peak": e128["gathered_gbs"] / PEAK_HBM_GBS,
+              # the HBM-side fraction: fabric bytes (FETCH_SIZE x 2 + WRITE_SIZE, PMC) per second over the peak
+              "frac": (tr128 / (e128["kernel_ms"] * 1e-3) / 1e9 / PEAK_HBM_GBS) if tr128 else None,
+              "traffic": tr128,
               "kernel": "hnsw_search_kernel<false>",
               "kernel_ms": e128["kernel_ms"], "bytes_per_launch": e128["gathered_gbs"] * 1e9 * e128["kernel_ms"] * 1e-3,
               "recall_at_10": e128["recall_at_10"],
@@ -831,12 +838,12 @@ def multi_gpu_legs(vg, ctx, sharded, world, rank, device, stream, comm):
 
 
 def measured_traffic(key: str, algorithmic_bytes: float = None):
-    """HBM bytes per launch from the committed PMC passes (profiles/r02_traffic.json: rocprofv3 --pmc FETCH_SIZE /
-    WRITE_SIZE by tools/collect_pmc.sh, gfx950 correction applied).  PMC counters cannot be read from inside this
-    process.  Where the PMC run used another launch size than this bench (graph searches: a 200k-row graph), the
-    measured traffic per algorithmic byte is applied to this launch's algorithmic bytes."""
+    """HBM bytes per launch from the committed PMC passes (profiles/r03_traffic.json: rocprofv3 --pmc FETCH_SIZE /
+    WRITE_SIZE of this round's binary at this bench's shapes by tools/collect_pmc.sh, gfx950 correction applied).  PMC
+    counters cannot be read from inside this process.  For the graph searches the measured traffic per algorithmic
+    byte (same 1M-row graph, same 8192 queries) is applied to this launch's algorithmic bytes."""
     try:
-        t = json.loads((ROOT / "profiles" / "r02_traffic.json").read_text())[key]
+        t = json.loads((ROOT / "profiles" / "r03_traffic.json").read_text())[key]
         if algorithmic_bytes is not None:
             return float(t["traffic_per_algorithmic_byte"]) * float(algorithmic_bytes)
         return float(t["traffic_bytes"])

@@ -11,7 +11,12 @@ def rows(name):
     p = os.path.join(d, name + ".csv")
     if not os.path.exists(p):
         return []
-    return list(csv.DictReader(open(p)))
+    out = []   # kernel names carry commas (template arguments): split from the right
+    for line in list(open(p))[1:]:
+        parts = line.rstrip("\n").rsplit(",", 3)
+        if len(parts) == 4:
+            out.append({"kernel": parts[0].strip('"'), "counter": parts[1], "dispatches": parts[2], "mean_per_dispatch": parts[3]})
+    return out
 
 
 def val(name, kernel_sub, counter):
@@ -67,9 +72,9 @@ if mq:
 out["rabitq_scan_mq"] = mq
 out["pq_adc_scan_batch64"] = traffic("adcmq_fetch", None, "pq_adc_scan_kernel", None, {"workload": "10M x 96 B, 64 queries in one call (one pass per query, slices shared through L2)"})
 out["sq8_scan"] = traffic("sq8_fetch", None, "sq8_scan_kernel", 4_000_000 * 768, {"workload": "4M x 768 one-byte codes, 1 query"})
-g = traffic("gemm_fetch", "gemm_write", "flat_gemm_dma_kernel", 1_000_000 * 768 * 4 + 1024 * 768 * 4, {"workload": "1024 queries x 1M x 768 per launch"})
+g = traffic("gemm_fetch", "gemm_write", "flat_gemm_dma_kernel<false, 2, 0, false>", 1_000_000 * 768 * 4 + 1024 * 768 * 4, {"workload": "1024 queries x 1M x 768 per launch"})
 if g:
-    busy, gui = val("gemm_mfma", "flat_gemm_dma_kernel", "SQ_VALU_MFMA_BUSY_CYCLES"), val("gemm_mfma", "flat_gemm_dma_kernel", "GRBM_GUI_ACTIVE")
+    busy, gui = val("gemm_mfma", "flat_gemm_dma_kernel<false, 2, 0, false>", "SQ_VALU_MFMA_BUSY_CYCLES"), val("gemm_mfma", "flat_gemm_dma_kernel<false, 2, 0, false>", "GRBM_GUI_ACTIVE")
     g.update({"SQ_VALU_MFMA_BUSY_CYCLES": busy, "GRBM_GUI_ACTIVE_sum_over_8_xcds": gui,
               "mfma_busy_fraction": busy / (1024 * gui / 8) if busy and gui else None})
 out["flat_gemm"] = g

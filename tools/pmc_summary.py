@@ -7,7 +7,8 @@ for r in csv.DictReader(open(f)):
     k = r["Kernel_Name"].split("(")[0][-60:]
     if "vg::" not in r["Kernel_Name"]: continue
     agg[k][r["Counter_Name"]] += float(r["Counter_Value"]); cnt[(k, r["Counter_Name"])] += 1
-print("kernel,counter,dispatches,mean_per_dispatch")
+w = csv.writer(sys.stdout)   # kernel names carry commas (template arguments): quoted
+w.writerow(["kernel", "counter", "dispatches", "mean_per_dispatch"])
 for k, v in sorted(agg.items()):
     for a, b in sorted(v.items()):
-        print(f"{k},{a},{cnt[(k, a)]},{b / cnt[(k, a)]:.6g}")
+        w.writerow([k, a, cnt[(k, a)], f"{b / cnt[(k, a)]:.6g}"])

@@ -18,6 +18,8 @@ for name, fn in (("f32", idx.search_hnsw), ("pq", idx.search_hnsw_pq)):
         fn(q, k, ef)
         _, _, st = fn(q, k, ef, stats="full")
         pops = st[:, 3].astype(np.float64)
-        tot = st[:, [0, 1, 2, 4]].astype(np.float64)
-        per_pop = tot.sum(0) / pops.sum()
-        print(f"{name} ef={ef}: pops/query {pops.mean():.1f}; cycles per pop (100 MHz memtime ticks x?): pop {per_pop[0]:.0f} adj+visited {per_pop[1]:.0f} score {per_pop[2]:.0f} push {per_pop[3]:.0f}", flush=True)
+        lo = (st[:, [0, 1, 2]] & 0xFFFFFFFF).astype(np.float64); hi = (st[:, [0, 1, 2]] >> 32).astype(np.float64)
+        P = pops.sum(); npush = hi[:, 2].sum()
+        print(f"{name} ef={ef}: pops/query {pops.mean():.1f}; shader-clock cycles per pop: pop {lo[:, 0].sum() / P:.0f} adj+visited {lo[:, 1].sum() / P:.0f} "
+              f"score {lo[:, 2].sum() / P:.0f} push loop {st[:, 4].sum() / P:.0f}; pushed nodes per pop {npush / P:.1f}, per pushed node: "
+              f"cand push {hi[:, 0].sum() / npush:.0f} res push {hi[:, 1].sum() / npush:.0f} cycles", flush=True)

@@ -126,9 +126,9 @@ __global__ __launch_bounds__(64) VG_HNSW_ATTR void hnsw_search_kernel(
         stats[q].pops = st.pops;
         stats[q].descent_distance_computations = st_descent;
 #ifdef VG_WALK_TIMING
-        stats[q].nodes_visited = st.t_pop;
-        stats[q].distance_computations = st.t_adj;
-        stats[q].distance_short_circuits = st.t_score;
+        stats[q].nodes_visited = st.t_pop + (st.t_cand << 32);     // two 32-bit fields per column (probe only)
+        stats[q].distance_computations = st.t_adj + (st.t_res << 32);
+        stats[q].distance_short_circuits = st.t_score + (st.n_push << 32);
         stats[q].descent_distance_computations = st.t_push;
 #endif
     }

@@ -18,7 +18,7 @@ namespace vg {
 struct LayerStats {
     int64_t visited = 0, dc = 0, sc = 0, pops = 0;
 #ifdef VG_WALK_TIMING  // stage probe (tools/build_variant.sh): s_memtime cycles per phase, reported in the stats columns
-    int64_t t_pop = 0, t_adj = 0, t_score = 0, t_push = 0;
+    int64_t t_pop = 0, t_adj = 0, t_score = 0, t_push = 0, t_cand = 0, t_res = 0, n_push = 0;
 #endif
 };
 #ifdef VG_WALK_TIMING
@@ -391,7 +391,9 @@ __device__ __forceinline__ void search_layer(const Scorer &sc, bool l2_metric, i
             todo &= todo - 1;
             const uint32_t id = static_cast<uint32_t>(__builtin_amdgcn_readlane(id_lane, j));
             const float nd = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(has_bound ? my_nd : my_pair), j));
+            VG_T(tc0);
             cand_try_push_bounded<UK>(cand, cand_len, HItem{id, nd}, cap);
+            VG_T(tc1);
             if (has_bound) {  // results heap full: its top is `bound`
                 res_replace_top<UK>(res, res_len, HItem{id, nd}, bound);
             } else {
@@ -401,6 +403,12 @@ __device__ __forceinline__ void search_layer(const Scorer &sc, bool l2_metric, i
                     has_bound = true;
                 }
             }
+            VG_T(tc2);
+            VG_TACC(st.t_cand, tc0, tc1);
+            VG_TACC(st.t_res, tc1, tc2);
+#ifdef VG_WALK_TIMING
+            st.n_push++;
+#endif
         }
         Scorer::sync();
         VG_T(t4);
