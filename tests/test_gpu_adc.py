@@ -179,26 +179,6 @@ def test_adc_big_k_proof_and_fallback(vg, ctx):
             assert np.array_equal(bits(scores[qi]), bits(esc))
 
 
-def test_adc_skewed_kernel_is_bit_exact_too(vg, ctx):
-    """The opt-in conflict-free (A/B-skewed) m=96 scan must give the same ids and scores."""
-    import os
-    hooks.set_hook("VG_ADC_SKEW", "1")
-    try:
-        for n, nq in ((10000, 3), (777, 2), (64, 1), (200000, 2)):
-            rng = np.random.default_rng(n)
-            opq = _random_pq(rng, 768, 96)
-            codes = rng.integers(0, 256, (n, 96)).astype(np.uint8)
-            pq, idx = _mk(vg, ctx, opq, codes, n)
-            q = rng.standard_normal((nq, 768)).astype(np.float32)
-            ids, scores = idx.search_pq_adc(q, 10)
-            for qi in range(nq):
-                eid, esc = o.flat_search_pq(opq, codes, q[qi], 10)
-                assert np.array_equal(ids[qi, :eid.size], eid)
-                assert np.array_equal(bits(scores[qi, :eid.size]), bits(esc))
-    finally:
-        hooks.set_hook("VG_ADC_SKEW", 0)
-
-
 def test_adc_errors(vg, ctx):
     opq = _random_pq(np.random.default_rng(1), 128, 16)
     pq = vg.ProductQuantizer(ctx, 128, 16, 256)

@@ -386,178 +386,12 @@ __global__ __launch_bounds__(kAdcThreads) void pq_adc_scan_kernel(
     for (int i = tid; i < k; i += kAdcThreads) out[i] = (i < have) ? buf[i] : kKeyMax;
 }
 
-// ---------------------------------------------------------------------------------------------
-// m = 96, k <= 64: the conflict-free scan.
-//
-// ds_read_b32 serves a wave as two groups of 32 lanes over 32 banks.  In the pair-interleaved
-// image bank = 16*(g&1) + l: the 16 rotations of a group (l = (slot + lane) & 15) cover 16 banks,
-// and the two 16-lane halves of a 32-lane group must therefore be on groups of OPPOSITE parity.
-// Lanes with bit 4 set ("B") run one group behind the others ("A"): in step g of a tile A lanes
-// look up group g of their row, B lanes group g-1 of theirs (in step 0: group 5 of the row of
-// the PREVIOUS tile).  Every lane still adds its row's groups in ascending order into the same
-// 16 slot accumulators, so each row's sum is bit-identical to pqAdcLookupAvx512; a B row is
-// finished one step into the next tile (and by a trailing step after the last tile).
-// Measured (tools/ubench/lds_pattern.hip): 25 lookups/clk/CU for this pattern vs 15 for the
-// plain rotation and 9 for a [sub-quantizer][centroid] table.
-// ---------------------------------------------------------------------------------------------
-template <int H>
-__device__ __forceinline__ void issue_half_ab(Vals8 &dst, const uint4 &c, const uint32_t (&rotx)[16], uint32_t blk)
-{
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-        const int sl = H * 8 + i;
-        // byte*128 (bits 7..14) | slot/parity (bits 2..6) | block (bits 15..16): disjoint fields
-        const uint32_t addr = (code_byte(c, sl) << 7) + (rotx[sl] + blk);
-        dst.v[i] = lds_read_off<0>(addr);
-    }
-}
-
-__device__ __forceinline__ uint4 sel4(bool b, const uint4 &x, const uint4 &y)
-{
-    return make_uint4(b ? x.x : y.x, b ? x.y : y.y, b ? x.z : y.z, b ? x.w : y.w);
-}
-
-__global__ __launch_bounds__(kAdcThreads) void pq_adc_scan96_kernel(
-    const uint4 *__restrict__ tiles, int64_t n_rows, int64_t n_tiles, const float *__restrict__ tables,
-    int slices, int nq, int k, uint64_t *__restrict__ partial)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float *lut = reinterpret_cast<float *>(smem);
-    constexpr int kLutWords = 3 * 8192;
-    uint64_t *buf = reinterpret_cast<uint64_t *>(smem + kLutWords * sizeof(float));
-
-    const int b = blockIdx.x;
-    const int xcd = b & 7;
-    const int o = b >> 3;
-    const int q = o % nq;
-    const int s = (o / nq) * 8 + xcd;
-    const int64_t t0 = n_tiles * s / slices;
-    const int64_t t1 = n_tiles * (s + 1) / slices;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int rot = lane & 15;
-    const bool hB = (lane >> 4) & 1;
-    {
-        const float4 *src = reinterpret_cast<const float4 *>(tables + static_cast<int64_t>(q) * kLutWords);
-        float4 *dst = reinterpret_cast<float4 *>(lut);
-        constexpr int rounds = kLutWords / 4 / kAdcThreads;  // 12
-#pragma unroll
-        for (int r = 0; r < rounds; r += 4) {
-            float4 tmp[4];
-#pragma unroll
-            for (int u = 0; u < 4; u++) tmp[u] = src[(r + u) * kAdcThreads + tid];
-#pragma unroll
-            for (int u = 0; u < 4; u++) dst[(r + u) * kAdcThreads + tid] = tmp[u];
-        }
-    }
-    __syncthreads();
-    WaveTopK wtk;
-    wtk.init(k);
-
-    // slot byte offsets incl. the parity half each lane reads in even / odd steps
-    uint32_t rotE[16], rotO[16];
-#pragma unroll
-    for (int sl = 0; sl < 16; sl++) {
-        const uint32_t l4 = static_cast<uint32_t>(((sl + rot) & 15) * 4);
-        rotE[sl] = l4 + (hB ? 64u : 0u);  // even step: A on group g (even), B on group g-1 (odd)
-        rotO[sl] = l4 + (hB ? 0u : 64u);
-    }
-    // 32 KiB block of the group each lane reads in step g: A: g>>1, B: ((g+5)%6)>>1
-    uint32_t blk[6];
-#pragma unroll
-    for (int g = 0; g < 6; g++) blk[g] = static_cast<uint32_t>(hB ? (((g + 5) % 6) >> 1) : (g >> 1)) * 32768u;
-
-    const int64_t my_first = t0 + wave;
-    const int my_tiles = my_first < t1 ? static_cast<int>((t1 - my_first + kAdcWaves - 1) / kAdcWaves) : 0;
-    const int64_t tlast = t1 - 1;
-    uint4 nxt[6];
-    if (my_tiles > 0) {
-        const uint4 *tp0 = tiles + (my_first * 6) * 64 + lane;
-#pragma unroll
-        for (int g = 0; g < 6; g++) nxt[g] = tp0[g * 64];
-    }
-    float acc[16];
-#pragma unroll
-    for (int l = 0; l < 16; l++) acc[l] = 0.0f;
-    uint4 prev5 = make_uint4(0, 0, 0, 0);
-    int64_t row_prev = -1;
-
-    for (int it = 0; it <= my_tiles; it++) {  // one trailing pass finishes the B rows of the last tile
-        const bool live = it < my_tiles;
-        if (!live && my_tiles == 0) break;
-        const int64_t tile = my_first + static_cast<int64_t>(it) * kAdcWaves;
-        uint4 c[6];
-#pragma unroll
-        for (int g = 0; g < 6; g++) c[g] = nxt[g];
-        if (live) {  // unguarded prefetch of this wave's next tile (clamped inside the slice)
-            const int64_t tn = min64(tile + kAdcWaves, tlast);
-            const uint4 *tp = tiles + (tn * 6) * 64 + lane;
-#pragma unroll
-            for (int g = 0; g < 6; g++) nxt[g] = tp[g * 64];
-        }
-        // step 0: A rows start (acc = 0), B rows receive their last group
-#pragma unroll
-        for (int l = 0; l < 16; l++) acc[l] = hB ? acc[l] : 0.0f;
-        Vals8 va, vb;
-        const uint4 w0 = sel4(hB, prev5, c[0]);
-        issue_half_ab<0>(va, w0, rotE, blk[0]);
-        issue_half_ab<1>(vb, w0, rotE, blk[0]);
-        lds_wait<8>(va);
-        accumulate_half<0>(acc, va);
-        float totB = 0.0f, totA = 0.0f;
-        if (live) {
-            const uint4 w1 = sel4(hB, c[0], c[1]);
-            issue_half_ab<0>(va, w1, rotO, blk[1]);
-            lds_wait<8>(vb);
-            accumulate_half<1>(acc, vb);
-            totB = reduce16_regs(acc);  // B lanes: row of the previous tile is complete
-#pragma unroll
-            for (int l = 0; l < 16; l++) acc[l] = hB ? 0.0f : acc[l];
-#define VG_AB_STEP(G, ROT)                                  \
-    {                                                       \
-        issue_half_ab<1>(vb, w##G, ROT, blk[G]);            \
-        lds_wait<8>(va);                                    \
-        accumulate_half<0>(acc, va);                        \
-    }
-#define VG_AB_NEXT(G, GN, ROTN)                             \
-    const uint4 w##GN = sel4(hB, c[G], c[GN]);              \
-    {                                                       \
-        issue_half_ab<0>(va, w##GN, ROTN, blk[GN]);         \
-        lds_wait<8>(vb);                                    \
-        accumulate_half<1>(acc, vb);                        \
-    }
-            VG_AB_STEP(1, rotO)
-            VG_AB_NEXT(1, 2, rotE)
-            VG_AB_STEP(2, rotE)
-            VG_AB_NEXT(2, 3, rotO)
-            VG_AB_STEP(3, rotO)
-            VG_AB_NEXT(3, 4, rotE)
-            VG_AB_STEP(4, rotE)
-            VG_AB_NEXT(4, 5, rotO)
-            VG_AB_STEP(5, rotO)
-#undef VG_AB_STEP
-#undef VG_AB_NEXT
-            lds_wait<0>(vb);
-            accumulate_half<1>(acc, vb);
-            totA = reduce16_regs(acc);  // A lanes: this tile's row is complete
-        } else {
-            lds_wait<0>(vb);
-            accumulate_half<1>(acc, vb);
-            totB = reduce16_regs(acc);
-        }
-        const int64_t row_cur = tile * 64 + lane;
-        uint64_t key = kKeyMax;
-        if (hB) {
-            if (row_prev >= 0 && row_prev < n_rows) key = make_key(totB, static_cast<uint32_t>(row_prev), false);
-        } else if (live && row_cur < n_rows) {
-            key = make_key(totA, static_cast<uint32_t>(row_cur), false);
-        }
-        wtk.offer(key, lane);
-        prev5 = c[5];
-        row_prev = live ? row_cur : -1;
-    }
-    uint64_t *out = partial + (static_cast<int64_t>(q) * slices + s) * k;
-    wg_rank_merge<kAdcWaves>(wtk, buf, reinterpret_cast<int *>(buf + kAdcWaves * 64), wave, lane, tid, k, out);
-}
+// (r01/r02 carried a second m = 96 kernel here, `pq_adc_scan96_kernel`: 16-lane halves of a wave one group apart so
+// that no two lanes of a 32-lane LDS group share a bank — 25 lookups per clock and CU in the microbenchmark against
+// 15 for the rotated image below.  Bit-exact, but its lane-dependent address selects cost ~7 vector instructions per
+// lookup and it never won: 70 k vs 82 k queries/s at 1M rows (r01), and on the LDS-bound batch of r03 — 64 queries x
+// 10M rows — 7.0 k vs 8.2 k queries/s.  The one-query scan is bound by the HBM stream, not by LDS (r02 stage probes,
+// DESIGN.md section 4), so there was nothing for it to win there either.  Dropped in r03.)
 
 // One workgroup per query: merges `lists` ascending key lists of length k (kKeyMax padded)
 // into the k best keys, best first, and decodes them to (id, score).
@@ -1021,23 +855,6 @@ static int32_t launch_scan_wide(const vg_index *idx, const float *tables, int64_
     return VG_OK;
 }
 
-static int32_t launch_scan96(const vg_index *idx, const float *tables, int64_t nq, int k, int slices,
-                             uint64_t *partial, hipStream_t st)
-{
-    const size_t lds = 3 * 8192 * sizeof(float) + kAdcWaves * 64 * sizeof(uint64_t) + 64;
-    VG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(pq_adc_scan96_kernel),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
-    const int64_t max_q = (1ll << 30) / slices;
-    for (int64_t q0 = 0; q0 < nq; q0 += max_q) {
-        const int64_t cnt = nq - q0 < max_q ? nq - q0 : max_q;
-        ProfScope prof(idx->ctx, "pq_adc_scan", st);
-        VG_LAUNCH(pq_adc_scan96_kernel, dim3(static_cast<unsigned>(cnt * slices)), dim3(kAdcThreads), lds, st,
-                  reinterpret_cast<const uint4 *>(idx->d_pq_tiles), idx->n, idx->n_tiles, tables + q0 * 3 * 8192,
-                  slices, static_cast<int>(cnt), k, partial + q0 * slices * k);
-    }
-    return VG_OK;
-}
-
 }  // namespace vg
 
 namespace vg {
@@ -1251,13 +1068,8 @@ VG_API int32_t vg_search_pq_adc(vg_index *idx, const float *queries, int64_t nq,
             if (oid.on_host() || osc.on_host()) VG_HIP(hipStreamSynchronize(st));
             return VG_OK;
         }
-        // The A/B-skewed scan is conflict-free in LDS but, as compiled today, spends ~7 VALU ops per
-        // lookup on lane-dependent address selects and is VALU-bound (70k vs 80k queries/s at
-        // 1M x 96 B); it stays opt-in until its address arithmetic is cut down.
         if (wide)
             VG_TRY(vg::launch_scan_wide(idx, tables.ptr, nq, k, slices, partial.ptr, st));
-        else if (pq->m == 96 && k <= 64 && vg::hook(vg::kHookAdcSkew))
-            VG_TRY(vg::launch_scan96(idx, tables.ptr, nq, k, slices, partial.ptr, st));
         else if (pq->m == 96 && k <= 64)
             VG_TRY((vg::launch_scan<6, true>(idx, tables.ptr, nq, k, slices, partial.ptr, st)));
         else if (pq->m == 96)

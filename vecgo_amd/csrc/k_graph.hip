@@ -33,8 +33,13 @@ int32_t launch_pq_build_table(const vg_pq *pq, const float *d_queries, int64_t n
 // query's distance table `luts` (ComputeAsymmetricDistance order), the candidate stage of the
 // graph -> PQ -> exact-rerank pipeline.
 constexpr int kHnswLdsEf = 512;  // LDS items of the results heap (twice that for the candidates): 12 KiB per query
+// Split heaps on fp32 rows (ef > 512) wait on HBM round trips of the heaps' lower levels with neither the vector ALU
+// (41 % busy) nor HBM (4.6 TB/s) saturated: a fourth wave per SIMD (128 registers instead of 161, a few spills) and a
+// smaller LDS share of the heaps (384 items: 16 waves per CU fit) bought 1.26x (ef 1024: 58.8 -> 46.5 ms per 8192
+// queries, ef 2048: 120 -> 95 on one box).  The other instantiations keep the compiler's choice (a fifth wave spills
+// and is slower; the LDS-resident fp32 walk is HBM-bound as it is).
 #ifndef VG_HNSW_ATTR
-#define VG_HNSW_ATTR
+#define VG_HNSW_ATTR __attribute__((amdgpu_waves_per_eu(SPLIT ? 4 : 1, SPLIT ? 4 : 8)))
 #endif
 // UK: the metric is not Dot, so every distance is >= +0 and the heaps compare bit patterns (heap_sift_down_uk).
 template <bool PQ, bool SPLIT, bool UK>
@@ -502,9 +507,10 @@ static int32_t search_hnsw_impl(vg_index *idx, bool pq, const float *queries, in
     // LDS), beyond it split between those 12 KiB (the top levels) and HBM scratch
     // split heaps: the PQ walk also keeps its query's 3.75 KiB of constants in LDS and gathers 32x fewer bytes per
     // node, so it prefers waves to LDS heap levels: 256 items (10 KiB per query in all); measured on one box at ef 2048:
-    // 86 ms per 8192 queries with 256, 100 ms with 512; the fp32 walk the other way round (119 vs 124)
+    // 86 ms per 8192 queries with 256, 100 ms with 512; the fp32 walk, with a fourth wave per SIMD (VG_HNSW_ATTR): 384
     const bool lds_heaps = ef <= vg::kHnswLdsEf;
-    const int lds_ef = pq ? 256 : vg::kHnswLdsEf;
+    static const int lds_ef_env = getenv("VG_HNSW_LDS_EF") ? atoi(getenv("VG_HNSW_LDS_EF")) : 0;  // experiments only
+    const int lds_ef = lds_ef_env > 0 ? lds_ef_env : (pq ? 256 : 384);
     const int64_t heap_bytes = lds_heaps ? 0 : static_cast<int64_t>(3) * ef * sizeof(vg::HItem);
     // sub-dimension 8: node terms straight from the codebook (vg_hnsw_layer.hpp PqScorer), no per-query table
     const bool pq_direct = pq && idx->pq->subdim == 8 && (reinterpret_cast<uintptr_t>(idx->pq->d_codebooks) & 7) == 0;

@@ -74,7 +74,6 @@ enum Hook {
     kHookFlatDebug,           // VG_FLAT_DEBUG           print per-call counters
     kHookProbeNoGroup,        // VG_PROBE_NO_GROUP       one pass per (query, probe) pair
     kHookAdcBigkExhaustive,   // VG_ADC_BIGK_EXHAUSTIVE  LDS-buffer path for k > 64
-    kHookAdcSkew,             // VG_ADC_SKEW             the A/B-skewed scan
     kHookBuildDebug,          // VG_BUILD_DEBUG          vg_hnsw_build prints its back-link totals
     kHookCount
 };
