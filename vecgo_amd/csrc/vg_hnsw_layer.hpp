@@ -378,6 +378,9 @@ __device__ __forceinline__ void search_layer(const Scorer &sc, bool l2_metric, i
         float bound = has_bound ? heap_get(res, 0).dist : 0.0f;
         uint64_t todo = newmask;
         st.dc += __popcll(newmask);
+        // the heap updates are one wave's dependent chain: let it issue ahead of the waves that are scoring (3-4 % on
+        // the PQ walk at ef <= 512, nothing elsewhere)
+        __builtin_amdgcn_s_setprio(3);
         while (todo) {
             if (has_bound) {
                 // the bound only falls: a node above it now is above it at its turn (SquaredL2Bounded reports
@@ -410,6 +413,7 @@ __device__ __forceinline__ void search_layer(const Scorer &sc, bool l2_metric, i
             st.n_push++;
 #endif
         }
+        __builtin_amdgcn_s_setprio(0);
         Scorer::sync();
         VG_T(t4);
         VG_TACC(st.t_pop, t0, t1);
