@@ -167,7 +167,9 @@ while time.time() < t_end:
             # graph walk scored from PQ codes (ComputeAsymmetricDistance order), incl. the split-heap range
             gm = int(rng.choice([4, 8, 16]))
             l0, upper, entry = graphs.build_hnsw(x, m=gm, seed=int(rng.integers(0, 1000)))
-            m = 8
+            # sub-dimension 8 (m = dim / 8, odd m included): terms computed from the codebook (packed pairs, LDS-staged
+            # query constants); m = 8: the per-query table form
+            m = dim // 8 if rng.random() < 0.6 else 8
             pq = vg.ProductQuantizer(ctx, dim, m, 256)
             pq.train(x, iters=2, seed=5)
             codes = pq.encode(x)
@@ -179,7 +181,12 @@ while time.time() < t_end:
             kk = min(k, 64)
             ids, sc = idx.search_hnsw_pq(q, kk, ef)
             oidx = o.HnswIndex(x, dim, l0, upper, entry, m=gm, pq=opq, codes=codes)
-            compare("hnsw_pq", dict(cfg, m=gm, ef=ef), ids, sc, [oidx.search(q[i], kk, ef)[:2] for i in range(nq)])
+            compare("hnsw_pq", dict(cfg, m=gm, pq_m=m, ef=ef), ids, sc, [oidx.search(q[i], kk, ef)[:2] for i in range(nq)])
+            # the Vamana beam over layer 0 with the same PQ node scorer
+            idx.set_vamana_graph(l0, entry)
+            ids, sc = idx.search_vamana(q, kk, kind=1)
+            ov = o.VamanaIndex(l0, entry, dim, o.VAMANA_PQ, pq=opq, codes=codes)
+            compare("vamana_pq", dict(cfg, m=gm, pq_m=m), ids, sc, [ov.search(q[i], kk)[:2] for i in range(nq)])
     except vg.VecgoHipError as e:
         fails += 1
         print(f"ERROR {cfg} which={which}: {e}", flush=True)
