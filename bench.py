@@ -631,7 +631,7 @@ def structured_corpus(vg, ctx, stream, device, with_cpu):
     gi, _ = fp64_topk_local(rows, queries[0], 0, K)
     rep, _, idx, pq = hnsw_pq_frontier(vg, ctx, rows, queries, gi.cpu().numpy(), exact_ms, stream, with_cpu,
                                        efs_f32=(64, 128, 160, 192, 224, 256, 384), efs_pq=(64, 128, 160, 192, 224, 256, 384),
-                                       cpu_efs=(128, 256))
+                                       cpu_efs=(128, 192, 256))
     idx.close()
     pq.close()
     rep["workload"] = (f"STRUCTURED extra corpus: 1M x 768 = z A + {STRUCT_NOISE} e, z ~ N(0, I_{STRUCT_LATENT}) (bench.gen_structured, "
