@@ -49,7 +49,7 @@ __global__ __launch_bounds__(64) VG_HNSW_ATTR void hnsw_search_kernel(
     const int64_t *__restrict__ level_off, uint32_t entry, const float *__restrict__ queries,
     const uint8_t *__restrict__ pq_rows, int pq_m, const float *__restrict__ luts,
     const int8_t *__restrict__ pq_cb, const float *__restrict__ pq_scales, const float *__restrict__ pq_offsets, int k, int ef,
-    int lds_ef /* SPLIT: items of the results heap kept in LDS (twice that of the candidates heap) */,
+    int lds_cand, int lds_res /* SPLIT: items of the candidates / results heap kept in LDS */,
     uint32_t *__restrict__ visited_ws, int64_t vis_words, HItem *__restrict__ heap_ws,
     uint32_t *__restrict__ ids, float *__restrict__ scores, vg_search_stats *__restrict__ stats)
 {
@@ -63,8 +63,8 @@ __global__ __launch_bounds__(64) VG_HNSW_ATTR void hnsw_search_kernel(
     typename std::conditional<SPLIT, SplitHeap, HItem *>::type cand, res;
     if constexpr (SPLIT) {
         HItem *lo = heaps;
-        cand = SplitHeap{lo, heap_ws + q * 3 * ef, 2 * lds_ef};
-        res = SplitHeap{lo + 2 * lds_ef, heap_ws + q * 3 * ef + 2 * ef, lds_ef};
+        cand = SplitHeap{lo, heap_ws + q * 3 * ef, lds_cand};
+        res = SplitHeap{lo + lds_cand, heap_ws + q * 3 * ef + 2 * ef, lds_res};
     } else {
         cand = heaps;
         res = cand + 2 * ef;
@@ -509,8 +509,10 @@ static int32_t search_hnsw_impl(vg_index *idx, bool pq, const float *queries, in
     // node, so it prefers waves to LDS heap levels: 256 items (10 KiB per query in all); measured on one box at ef 2048:
     // 86 ms per 8192 queries with 256, 100 ms with 512; the fp32 walk, with a fourth wave per SIMD (VG_HNSW_ATTR): 384
     const bool lds_heaps = ef <= vg::kHnswLdsEf;
-    static const int lds_ef_env = getenv("VG_HNSW_LDS_EF") ? atoi(getenv("VG_HNSW_LDS_EF")) : 0;  // experiments only
-    const int lds_ef = lds_ef_env > 0 ? lds_ef_env : (pq ? 256 : 384);
+    // (swept on one box, ef 1024 / 2048: candidates : results = 768 : 384 46 / 94 ms, 128 : 768 47 / 95, 256 : 1024
+    // 50 / 107, 256 : 2048 51 / 124, 1024 : 2048 58 / 152 — waves in flight beat heap levels in LDS)
+    const int lds_ef = pq ? 256 : 384;
+    const int lds_cand = 2 * lds_ef, lds_res = lds_ef;
     const int64_t heap_bytes = lds_heaps ? 0 : static_cast<int64_t>(3) * ef * sizeof(vg::HItem);
     // sub-dimension 8: node terms straight from the codebook (vg_hnsw_layer.hpp PqScorer), no per-query table
     const bool pq_direct = pq && idx->pq->subdim == 8 && (reinterpret_cast<uintptr_t>(idx->pq->d_codebooks) & 7) == 0;
@@ -526,7 +528,7 @@ static int32_t search_hnsw_impl(vg_index *idx, bool pq, const float *queries, in
     vg::HItem *heap_ws = lds_heaps ? nullptr : ar.get<vg::HItem>(i_heap);
     float *luts = pq && !pq_direct ? ar.get<float>(i_luts) : nullptr;
     // + 4 items: heap_sift_down_uk reads slots fc .. fc+3 whatever the heap's length
-    const size_t lds = static_cast<size_t>(3 * (lds_heaps ? ef : lds_ef) + 4) * sizeof(vg::HItem) + 128 * sizeof(float) +
+    const size_t lds = static_cast<size_t>((lds_heaps ? 3 * ef : lds_cand + lds_res) + 4) * sizeof(vg::HItem) + 128 * sizeof(float) +
                        (pq_direct ? static_cast<size_t>(pq_m >> 1) * vg::kPqPairFloats * sizeof(float) : 0);
     const bool uk = idx->metric != VG_METRIC_DOT;
     auto kern = pq ? (lds_heaps ? vg::hnsw_search_kernel<true, false, true> : vg::hnsw_search_kernel<true, true, true>)
@@ -543,7 +545,7 @@ static int32_t search_hnsw_impl(vg_index *idx, bool pq, const float *queries, in
                   idx->metric, idx->d_hnsw_l0, idx->hnsw_m0, idx->hnsw_max_level, idx->hnsw_m, idx->d_hnsw_slot,
                   idx->d_hnsw_adj, idx->d_hnsw_level_off, idx->hnsw_entry, q.ptr + q0 * idx->dim,
                   pq ? idx->d_pq_rows : nullptr, pq_m, luts, pq_direct ? idx->pq->d_codebooks : nullptr,
-                  pq ? idx->pq->d_scales : nullptr, pq ? idx->pq->d_offsets : nullptr, k, ef, lds_ef, vis.ptr, vis_words, heap_ws, oid.ptr + q0 * k,
+                  pq ? idx->pq->d_scales : nullptr, pq ? idx->pq->d_offsets : nullptr, k, ef, lds_cand, lds_res, vis.ptr, vis_words, heap_ws, oid.ptr + q0 * k,
                   osc.ptr + q0 * k, ost.ptr ? ost.ptr + q0 : nullptr);
     }
     VG_TRY(oid.finish());
