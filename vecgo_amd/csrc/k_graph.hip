@@ -322,16 +322,20 @@ __global__ __launch_bounds__(64) void vamana_search_kernel(
         score_mask(newmask, id_lane);
         const float myd = nb_d[lane];
         // exploration heap: PushItem in the node's neighbour order (segment.go:695)
-        uint64_t todo = newmask;
-        while (todo) {
-            const int j = __builtin_ctzll(todo);
-            todo &= todo - 1;
-            if (cand_len < cand_cap)
-                heap_push<false>(cand, cand_len,
-                                 HItem{static_cast<uint32_t>(__builtin_amdgcn_readlane(id_lane, j)),
-                                       __int_as_float(__builtin_amdgcn_readlane(__float_as_int(myd), j))});
-            else
-                st_dropped++;  // the reference's heap is unbounded: reported, see vg_search_stats
+        if (cand_len + nnew <= cand_cap) {
+            heap_push_run_min(cand, cand_len, newmask, id_lane, myd);  // the run of pushes, parents tracked in registers
+        } else {
+            uint64_t todo = newmask;
+            while (todo) {
+                const int j = __builtin_ctzll(todo);
+                todo &= todo - 1;
+                if (cand_len < cand_cap)
+                    heap_push<false>(cand, cand_len,
+                                     HItem{static_cast<uint32_t>(__builtin_amdgcn_readlane(id_lane, j)),
+                                           __int_as_float(__builtin_amdgcn_readlane(__float_as_int(myd), j))});
+                else
+                    st_dropped++;  // the reference's heap is unbounded: reported, see vg_search_stats
+            }
         }
         // result heap: TryPushBounded(k) — a set maintained by (score, id): order-free
         offer(fresh ? make_key(myd, id_lane, desc) : kKeyMax);

@@ -258,6 +258,71 @@ __device__ __forceinline__ HItem heap_pop(H h, int &len)
     return top;
 }
 
+// ---- a run of PushItem calls on the MIN-heap of candidates, in the order of the set bits of `mask` ----------------
+// (lane j holds item j = {id_lane, d_lane}).  Pushed one by one, every item costs a dependent LDS round trip for its
+// parent before anything else can happen; a run of n pushes lands in the consecutive slots len .. len+n-1, whose
+// parents are at most n/4 + 2 consecutive slots that NO item of the run occupies (true once len >= 25), so they are
+// fetched ONCE into registers (lane t holds parent t) and the run is replayed against the registers: item and parent
+// distances meet by v_readlane, an item that stays below its parent (the common case) costs no memory access at all,
+// an item that climbs swaps with the register copy and continues through the untracked ancestors in memory exactly
+// as heap_sift_up does.  One store writes the run's slots, one writes the parents back.  Every comparison and its
+// order are the reference's (queue.go:221-245), so the heap ends byte for byte as n single pushes leave it.
+__device__ __forceinline__ void heap_store_lane(HItem *h, int i, uint32_t node, float dist) { heap_store(h + i, HItem{node, dist}); }
+__device__ __forceinline__ void heap_store_lane(const SplitHeap &h, int i, uint32_t node, float dist) { heap_put(h, i, HItem{node, dist}); }
+__device__ __forceinline__ HItem heap_load_lane(const HItem *h, int i) { return heap_load(h + i); }
+__device__ __forceinline__ HItem heap_load_lane(const SplitHeap &h, int i) { return heap_get(h, i); }
+
+template <typename H>
+__device__ __forceinline__ void heap_push_run_min(H h, int &len, uint64_t mask, uint32_t id_lane, float d_lane)
+{
+    const int n = __popcll(mask);
+    if (n == 0) return;
+    const int len0 = len;
+    if (len0 < 32 || n < 3) {  // tiny heaps (a run slot could be another's parent / a tracked slot an ancestor: len < 25) and short runs
+        while (mask) {
+            const int j = __builtin_ctzll(mask);
+            mask &= mask - 1;
+            heap_push<false>(h, len, HItem{heap_readlane(id_lane, j), __uint_as_float(heap_readlane(__float_as_uint(d_lane), j))});
+        }
+        return;
+    }
+    const int lane = heap_lane();
+    const int p0 = (len0 - 1) >> 2, np = ((len0 + n - 2) >> 2) - p0 + 1;  // tracked parents: slots p0 .. p0+np-1
+    HItem P{0u, 0.0f};
+    if (lane < np) P = heap_load_lane(h, p0 + lane);
+    uint32_t pend_n = id_lane;  // what the run's slot of this lane's item will hold
+    float pend_d = d_lane;
+    int r = 0;
+    for (uint64_t todo = mask; todo; todo &= todo - 1, r++) {
+        const int j = __builtin_ctzll(todo);
+        const int t = ((len0 + r - 1) >> 2) - p0;
+        const float itd = __uint_as_float(heap_readlane(__float_as_uint(d_lane), j));
+        const float pd = __uint_as_float(heap_readlane(__float_as_uint(P.dist), t));
+        if (itd >= pd) continue;  // heap_sift_up's first test: the item stays in its slot
+        const uint32_t itn = heap_readlane(id_lane, j);
+        const uint32_t pn = heap_readlane(P.node, t);
+        if (lane == j) {  // the parent steps down into the run's slot
+            pend_n = pn;
+            pend_d = pd;
+        }
+        // the item now stands at the tracked slot p0 + t; its ancestors are in memory
+        const int i = p0 + t;
+        HItem put{itn, itd};
+        if (i > 0) {
+            const int pp = (i - 1) >> 2;
+            const HItem gi = heap_get(h, pp);
+            if (!(itd >= gi.dist)) {  // climbs on: the grandparent steps down into the tracked slot
+                put = gi;
+                heap_sift_up<false>(h, pp, HItem{itn, itd});
+            }
+        }
+        if (lane == t) P = put;
+    }
+    if ((mask >> lane) & 1) heap_store_lane(h, len0 + __popcll(mask & ((1ull << lane) - 1)), pend_n, pend_d);
+    if (lane < np) heap_store_lane(h, p0 + lane, P.node, P.dist);
+    len = len0 + n;
+}
+
 // PushItemBounded (queue.go:67-92) on the max-heap of results
 template <bool UK = false, typename H>
 __device__ __forceinline__ void res_push_bounded(H h, int &len, HItem it, int capacity)

@@ -377,6 +377,7 @@ __device__ __forceinline__ void search_layer(const Scorer &sc, bool l2_metric, i
         bool has_bound = res_len >= ef;
         float bound = has_bound ? heap_get(res, 0).dist : 0.0f;
         uint64_t todo = newmask;
+        uint64_t accepted = 0, pre_bound = 0;
         st.dc += __popcll(newmask);
         // the heap updates are one wave's dependent chain: let it issue ahead of the waves that are scoring (3-4 % on
         // the PQ walk at ef <= 512, nothing elsewhere)
@@ -395,7 +396,8 @@ __device__ __forceinline__ void search_layer(const Scorer &sc, bool l2_metric, i
             const uint32_t id = static_cast<uint32_t>(__builtin_amdgcn_readlane(id_lane, j));
             const float nd = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(has_bound ? my_nd : my_pair), j));
             VG_T(tc0);
-            cand_try_push_bounded<UK>(cand, cand_len, HItem{id, nd}, cap);
+            accepted |= 1ull << j;  // its candidates-heap push happens after the loop (the two heaps are independent)
+            if (!has_bound) pre_bound |= 1ull << j;  // pushed with the SquaredL2 value, not the bounded kernel's
             VG_T(tc1);
             if (has_bound) {  // results heap full: its top is `bound`
                 res_replace_top<UK>(res, res_len, HItem{id, nd}, bound);
@@ -412,6 +414,32 @@ __device__ __forceinline__ void search_layer(const Scorer &sc, bool l2_metric, i
 #ifdef VG_WALK_TIMING
             st.n_push++;
 #endif
+        }
+        // TryPushBounded of the accepted nodes, in neighbour order (what the reference interleaves with the results
+        // heap's updates; neither heap reads the other).  While the heap is below its cap they are plain pushes: one run
+        // (heap_push_run_min); at the cap each one is the replace-the-closest path.
+        if (accepted) {
+            const float acc_d = ((pre_bound >> lane) & 1) ? my_pair : my_nd;  // the value the node was accepted with
+            int fit = cap - cand_len;
+            fit = fit < 0 ? 0 : fit;
+            uint64_t run = accepted, rest = 0;
+            if (__popcll(accepted) > fit) {
+                run = 0;
+                uint64_t a = accepted;
+                for (int c = 0; c < fit; c++) {
+                    run |= a & (~a + 1);
+                    a &= a - 1;
+                }
+                rest = a;
+            }
+            heap_push_run_min(cand, cand_len, run, id_lane, acc_d);
+            while (rest) {
+                const int j = __builtin_ctzll(rest);
+                rest &= rest - 1;
+                cand_try_push_bounded<UK>(cand, cand_len,
+                                          HItem{static_cast<uint32_t>(__builtin_amdgcn_readlane(id_lane, j)),
+                                                __int_as_float(__builtin_amdgcn_readlane(__float_as_int(acc_d), j))}, cap);
+            }
         }
         __builtin_amdgcn_s_setprio(0);
         Scorer::sync();
