@@ -794,7 +794,7 @@ def multi_gpu_legs(vg, ctx, sharded, world, rank, device, stream, comm):
         for _ in range(2):
             idx.search(q, K, stream=stream)
         sync()
-        ctx.profile_read("rabitq_scan")
+        ctx.profile_read("rabitq_scan_mq")      # nq >= 2: the query-blocked kernel
         ctx.profile_read("comm_all_gather")
         ctx.profile_enable(True)
         steps = 10
@@ -804,7 +804,7 @@ def multi_gpu_legs(vg, ctx, sharded, world, rank, device, stream, comm):
         sync()
         dt = wall_max(time.perf_counter() - t0)
         ctx.profile_enable(False)
-        launches, scan_ms = ctx.profile_read("rabitq_scan")
+        launches, scan_ms = ctx.profile_read("rabitq_scan_mq")
         cl, coll_ms = ctx.profile_read("comm_all_gather")
         res[mode] = {"rows_total": total, "rows_per_gpu": hi - lo, "queries_per_step": nq, "ms_per_step": dt / steps * 1e3,
                      "qps": steps * nq / dt, "rank0_scan_ms_per_step": scan_ms / steps,
