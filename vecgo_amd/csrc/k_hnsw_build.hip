@@ -78,6 +78,8 @@ __device__ __forceinline__ float bg_pair(const BuildGraph &g, uint32_t a, uint32
 // ---- 1. insert search -----------------------------------------------------------------------------
 // pair_base[t] = index of node t's first (node, level) pair counted from node 0 (levels min(level,top)..0
 // → pair index + level); the batch's lists are stored relative to pair_base[t0].
+// UK: the metric is not Dot, distances are >= +0 and the heaps compare bit patterns (heap_sift_down_uk, vg_heap.hpp)
+template <bool UK>
 __global__ __launch_bounds__(64) void build_search_kernel(BuildGraph g, int64_t t0, uint32_t entry, int cur_top,
                                                           const int32_t *__restrict__ levels,
                                                           const int64_t *__restrict__ pair_base, int ef,
@@ -119,8 +121,8 @@ __global__ __launch_bounds__(64) void build_search_kernel(BuildGraph g, int64_t 
         const int deg = level == 0 ? g.m0 : g.m;
         auto row_of = [&](uint32_t node) -> const uint32_t * { return g.ids + bg_off(g, bg_row(g, node, level)); };
         int res_len = 0;
-        search_layer(sc, g.metric == kMetricL2, lane, row_of, deg, cur, cur_d, ef, cand, res, nb_pair, nb_bnd, vis,
-                     res_len, st);
+        search_layer<UK>(sc, g.metric == kMetricL2, lane, row_of, deg, cur, cur_d, ef, cand, res, nb_pair, nb_bnd, vis,
+                         res_len, st);
         // candidates.MinItem() (queue.go:46-57): the first minimum in heap-array order
         uint64_t best = kKeyMax;
         for (int i = lane; i < res_len; i += 64) {
@@ -141,7 +143,7 @@ __global__ __launch_bounds__(64) void build_search_kernel(BuildGraph g, int64_t 
         const int64_t p = pair0 + level;
         const int nres = res_len;
         for (int i = nres - 1; i >= 0; i--) {
-            const HItem it = heap_pop<true>(res, res_len);
+            const HItem it = heap_pop<true, UK>(res, res_len);
             if (lane == 0) {
                 cand_ids[p * ef + i] = it.node;
                 cand_d[p * ef + i] = it.dist;
@@ -898,8 +900,9 @@ VG_API int32_t vg_hnsw_build(vg_index *idx, int32_t m, int32_t ef_construction, 
 
     vg::BuildGraph g{idx->d_vectors, n, idx->dim, idx->metric, m0, m, d_ids.p, d_dist.p, d_bits.p, d_cnt.p, d_good.p,
                      d_slots.p, d_level_off.p};
-    const size_t lds = static_cast<size_t>(3 * ef) * sizeof(vg::HItem) + 128 * sizeof(float);
-    VG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(vg::build_search_kernel),
+    const size_t lds = static_cast<size_t>(3 * ef + 4) * sizeof(vg::HItem) + 128 * sizeof(float);
+    auto search_kern = idx->metric != VG_METRIC_DOT ? vg::build_search_kernel<true> : vg::build_search_kernel<false>;
+    VG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(search_kern),
                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
     auto dbg_t0 = std::chrono::steady_clock::now();
     unsigned long long dbg_max_chain = 0;
@@ -910,7 +913,7 @@ VG_API int32_t vg_hnsw_build(vg_index *idx, int32_t m, int32_t ef_construction, 
         VG_HIP(hipMemsetAsync(d_ctr.p, 0, sizeof(vg::LinkCounters), st));
         {
             vg::ProfScope prof(idx->ctx, "hnsw_build_search", st);
-            VG_LAUNCH(vg::build_search_kernel, dim3(static_cast<unsigned>(bt.size)), dim3(64), lds, st, g, bt.t0,
+            VG_LAUNCH(search_kern, dim3(static_cast<unsigned>(bt.size)), dim3(64), lds, st, g, bt.t0,
                       bt.entry, bt.cur_top, d_levels.p, d_pair_base.p, ef, d_vis.p, vis_words, d_cand_ids.p,
                       d_cand_d.p, d_cand_n.p);
         }
