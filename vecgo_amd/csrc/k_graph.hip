@@ -33,14 +33,17 @@ int32_t launch_pq_build_table(const vg_pq *pq, const float *d_queries, int64_t n
 // query's distance table `luts` (ComputeAsymmetricDistance order), the candidate stage of the
 // graph -> PQ -> exact-rerank pipeline.
 constexpr int kHnswLdsEf = 512;  // LDS items of the results heap (twice that for the candidates): 12 KiB per query
-// Split heaps on fp32 rows (ef > 512) wait on HBM round trips of the heaps' lower levels with neither the vector ALU
-// (41 % busy) nor HBM (4.6 TB/s) saturated: a fourth wave per SIMD (128 registers instead of 161, a few spills) and a
-// smaller LDS share of the heaps (384 items: 16 waves per CU fit) bought 1.26x (ef 1024: 58.8 -> 46.5 ms per 8192
-// queries, ef 2048: 120 -> 95 on one box).  The other instantiations keep the compiler's choice (a fifth wave spills
-// and is slower; the LDS-resident fp32 walk is HBM-bound as it is).
-#ifndef VG_HNSW_ATTR
-#define VG_HNSW_ATTR __attribute__((amdgpu_waves_per_eu(SPLIT ? 4 : 1, SPLIT ? 4 : 8)))
+// Split heaps on fp32 rows (ef > 512): neither the vector ALU (41 % busy) nor HBM (4.6 TB/s) is saturated, the waves
+// wait on their own chains.  A fourth wave per SIMD (128 registers instead of 161) bought 1.26x (ef 1024: 58.8 -> 46.5
+// ms per 8192 queries, ef 2048: 120 -> 95 on one box); with the query in LDS (F32ScorerT<true>: its pieces are read
+// where they are used instead of being held beside the row's for a whole chunk: 20 registers spilled instead of 29, no
+// query traffic through L1) and 128 heap items in LDS (7 KiB per query in all, so that the 16 waves fit) another 9 %
+// (48.5 / 95.7 / 208.8 -> 44.2 / 88.8 / 191.7 ms at ef 1024 / 2048 / 4096).  A fifth wave spills 59 registers and gives
+// it all back; a sixth is 2x slower.  The other instantiations keep the compiler's choice.
+#ifndef VG_SPLIT_F32_WAVES
+#define VG_SPLIT_F32_WAVES 4
 #endif
+#define VG_HNSW_ATTR __attribute__((amdgpu_waves_per_eu(SPLIT ? (PQ ? 4 : VG_SPLIT_F32_WAVES) : 1, SPLIT ? (PQ ? 4 : VG_SPLIT_F32_WAVES) : 8)))
 // UK: the metric is not Dot, so every distance is >= +0 and the heaps compare bit patterns (heap_sift_down_uk).
 template <bool PQ, bool SPLIT, bool UK>
 __global__ __launch_bounds__(64) VG_HNSW_ATTR void hnsw_search_kernel(
@@ -58,8 +61,14 @@ __global__ __launch_bounds__(64) VG_HNSW_ATTR void hnsw_search_kernel(
     const int lane = threadIdx.x;
     float *nb_pair = reinterpret_cast<float *>(smem);
     float *nb_bnd = nb_pair + 64;
-    float *qprep = nb_bnd + 64;  // PQ direct form: (pq_m / 2) * 20 floats (a multiple of 8 bytes), else nothing
-    HItem *heaps = reinterpret_cast<HItem *>(qprep + (PQ && pq_cb ? (pq_m >> 1) * kPqPairFloats : 0));
+    float *qprep = nb_bnd + 64;  // PQ direct form: (pq_m / 2) * 20 floats (a multiple of 8 bytes)
+    // fp32 rows with split heaps: the query itself (dim floats, padded to 16 bytes) — F32ScorerT<true>
+#ifndef VG_SPLIT_F32_QLDS
+#define VG_SPLIT_F32_QLDS 1
+#endif
+    constexpr bool kQLds = !PQ && SPLIT && VG_SPLIT_F32_QLDS;
+    const int qwords = PQ ? (pq_cb ? (pq_m >> 1) * kPqPairFloats : 0) : (kQLds ? ((dim + 3) & ~3) : 0);
+    HItem *heaps = reinterpret_cast<HItem *>(qprep + qwords);
     typename std::conditional<SPLIT, SplitHeap, HItem *>::type cand, res;
     if constexpr (SPLIT) {
         HItem *lo = heaps;
@@ -70,7 +79,7 @@ __global__ __launch_bounds__(64) VG_HNSW_ATTR void hnsw_search_kernel(
         res = cand + 2 * ef;
     }
     uint32_t *vis = visited_ws + q * vis_words;
-    typename std::conditional<PQ, PqScorer, F32Scorer>::type sc;
+    typename std::conditional<PQ, PqScorer, F32ScorerT<kQLds>>::type sc;
     if constexpr (PQ) {
         sc.rows = pq_rows;
         sc.lut = luts ? luts + q * static_cast<int64_t>(pq_m) * 256 : nullptr;
@@ -87,6 +96,11 @@ __global__ __launch_bounds__(64) VG_HNSW_ATTR void hnsw_search_kernel(
     } else {
         sc.base = base;
         sc.qv = queries + q * dim;
+        if constexpr (kQLds) {
+            for (int i = lane; i < dim; i += 64) qprep[i] = sc.qv[i];
+            sc.qv = qprep;
+            __syncthreads();
+        }
         sc.dim = dim;
         sc.metric = metric;
         sc.sub = Sub16::make(lane);
@@ -515,7 +529,10 @@ static int32_t search_hnsw_impl(vg_index *idx, bool pq, const float *queries, in
     const bool lds_heaps = ef <= vg::kHnswLdsEf;
     // (swept on one box, ef 1024 / 2048: candidates : results = 768 : 384 46 / 94 ms, 128 : 768 47 / 95, 256 : 1024
     // 50 / 107, 256 : 2048 51 / 124, 1024 : 2048 58 / 152 — waves in flight beat heap levels in LDS)
-    const int lds_ef = pq ? 256 : 384;
+#ifndef VG_SPLIT_F32_LDS_EF
+#define VG_SPLIT_F32_LDS_EF 128
+#endif
+    const int lds_ef = pq ? 256 : VG_SPLIT_F32_LDS_EF;
     // (after heap_push_run_min the split hardly matters: 128 : 1024, 64 : 1088, 256 : 896, 384 : 768 all within 2 % of this)
     const int lds_cand = 2 * lds_ef, lds_res = lds_ef;
     const int64_t heap_bytes = lds_heaps ? 0 : static_cast<int64_t>(3) * ef * sizeof(vg::HItem);
@@ -534,7 +551,8 @@ static int32_t search_hnsw_impl(vg_index *idx, bool pq, const float *queries, in
     float *luts = pq && !pq_direct ? ar.get<float>(i_luts) : nullptr;
     // + 4 items: heap_sift_down_uk reads slots fc .. fc+3 whatever the heap's length
     const size_t lds = static_cast<size_t>((lds_heaps ? 3 * ef : lds_cand + lds_res) + 4) * sizeof(vg::HItem) + 128 * sizeof(float) +
-                       (pq_direct ? static_cast<size_t>(pq_m >> 1) * vg::kPqPairFloats * sizeof(float) : 0);
+                       (pq_direct ? static_cast<size_t>(pq_m >> 1) * vg::kPqPairFloats * sizeof(float) : 0) +
+                       (!pq && !lds_heaps && VG_SPLIT_F32_QLDS ? static_cast<size_t>((idx->dim + 3) & ~3) * sizeof(float) : 0);
     const bool uk = idx->metric != VG_METRIC_DOT;
     auto kern = pq ? (lds_heaps ? vg::hnsw_search_kernel<true, false, true> : vg::hnsw_search_kernel<true, true, true>)
                    : uk ? (lds_heaps ? vg::hnsw_search_kernel<false, false, true> : vg::hnsw_search_kernel<false, true, true>)

@@ -58,7 +58,7 @@ constexpr int kExactChunkSmall = 4;  // ... and the size tried next for what is 
 // One pair.  `row` and `q` point at dim floats (16-byte aligned when dim % 4 == 0, which the
 // fast path requires; other dims take the scalar route below).  All 16 lanes of the group
 // return the same value.
-template <bool DOT, int MODE, bool STREAM = false>
+template <bool DOT, int MODE, bool STREAM = false, bool QLDS = false>
 __device__ __forceinline__ float exact_pair16(const float *__restrict__ row,
                                               const float *__restrict__ q, int dim, Sub16 sub)
 {
@@ -84,7 +84,19 @@ __device__ __forceinline__ float exact_pair16(const float *__restrict__ row,
         }
     };
     int e = 0;
-    for (; e + kExactChunk <= nblk; e += kExactChunk) {
+    if (QLDS) {  // the query in LDS: read where used, not held beside the row (see exact_l2_both16)
+        for (; e + kExactChunk <= nblk; e += kExactChunk) {
+            float4 b[kExactChunk];
+#pragma unroll
+            for (int u = 0; u < kExactChunk; u++) b[u] = STREAM ? load_stream(r4 + (e + u) * 16) : r4[(e + u) * 16];
+#pragma unroll
+            for (int u = 0; u < kExactChunk; u++) {
+                step(q4[(e + u) * 16], b[u]);
+                if ((u & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    for (; !QLDS && e + kExactChunk <= nblk; e += kExactChunk) {
         float4 a[kExactChunk], b[kExactChunk];
 #pragma unroll
         for (int u = 0; u < kExactChunk; u++) {
@@ -170,7 +182,10 @@ __device__ __forceinline__ float exact_pair16(const float *__restrict__ row,
 // bounded kernel is non-decreasing in the block index (squares are >= +0 and fp32 FMA / add
 // are monotone), "some 64-block partial > bound" <=> "bnd > bound": the early exit does not
 // have to be replayed.
-template <bool STREAM = false>
+// QLDS: `q` points into LDS (the wave's copy of the query): the query's pieces are then read where they are used
+// (an LDS read is ~100 cycles, the compiler keeps a few ahead) instead of being held in registers next to the row's
+// for a whole chunk — 48 registers less, which is what lets the split-heap walk run a fifth wave per SIMD.
+template <bool STREAM = false, bool QLDS = false>
 __device__ __forceinline__ void exact_l2_both16(const float *__restrict__ row,
                                                 const float *__restrict__ q, int dim, Sub16 sub,
                                                 float &pair, float &bnd)
@@ -187,7 +202,19 @@ __device__ __forceinline__ void exact_l2_both16(const float *__restrict__ row,
         acc[3] = __builtin_fmaf(d3, d3, acc[3]);
     };
     int e = 0;
-    for (; e + kExactChunk <= nblk; e += kExactChunk) {  // see exact_pair16
+    if (QLDS) {
+        for (; e + kExactChunk <= nblk; e += kExactChunk) {
+            float4 rb[kExactChunk];
+#pragma unroll
+            for (int u = 0; u < kExactChunk; u++) rb[u] = STREAM ? load_stream(r4 + (e + u) * 16) : r4[(e + u) * 16];
+#pragma unroll
+            for (int u = 0; u < kExactChunk; u++) {
+                step(q4[(e + u) * 16], rb[u]);
+                if ((u & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // keep the LDS reads from being hoisted into registers
+            }
+        }
+    }
+    for (; !QLDS && e + kExactChunk <= nblk; e += kExactChunk) {  // see exact_pair16
         float4 qa[kExactChunk], rb[kExactChunk];
 #pragma unroll
         for (int u = 0; u < kExactChunk; u++) {

@@ -30,26 +30,28 @@ struct LayerStats {
 #endif
 
 // distance of one node as hnsw wraps it (vectorstore/columnar.go:37-44), all lanes of the 16-lane group
+template <bool QLDS = false>
 __device__ __forceinline__ float hnsw_node_dist(const float *__restrict__ base, int dim, int metric,
                                                 const float *__restrict__ qv, uint32_t id, Sub16 sub)
 {
     const float *row = base + static_cast<int64_t>(id) * dim;
-    if (metric == kMetricDot) return -exact_pair16<true, kPair>(row, qv, dim, sub);
-    const float d = exact_pair16<false, kPair>(row, qv, dim, sub);
+    if (metric == kMetricDot) return -exact_pair16<true, kPair, false, QLDS>(row, qv, dim, sub);
+    const float d = exact_pair16<false, kPair, false, QLDS>(row, qv, dim, sub);
     return metric == kMetricCos ? 0.5f * d : d;
 }
 
 // ---- node scorers ------------------------------------------------------------------------------------
 // A scorer fills nb_pair[j] (what distFunc returns) and nb_bnd[j] (what SquaredL2Bounded run to completion
 // returns) for every lane j set in `mask`, lane j holding node id_lane.
-struct F32Scorer {  // fp32 rows: 16 lanes per row, 4 rows at a time, reference summation order
+template <bool QLDS>
+struct F32ScorerT {  // fp32 rows: 16 lanes per row, 4 rows at a time, reference summation order; QLDS: qv points into LDS
     const float *base;
     const float *qv;
     int dim, metric;
     Sub16 sub;
     static constexpr bool kBounded = true;  // SquaredL2Bounded exists for the L2 metric (hnsw.go:1353-1366)
     __device__ __forceinline__ static void sync() { __syncthreads(); }  // one wave per workgroup
-    __device__ __forceinline__ float one(uint32_t id) const { return hnsw_node_dist(base, dim, metric, qv, id, sub); }
+    __device__ __forceinline__ float one(uint32_t id) const { return hnsw_node_dist<QLDS>(base, dim, metric, qv, id, sub); }
     __device__ __forceinline__ void many(uint64_t mask, uint32_t id_lane, int lane, float *nb_pair, float *nb_bnd) const
     {
         while (mask) {
@@ -59,10 +61,10 @@ struct F32Scorer {  // fp32 rows: 16 lanes per row, 4 rows at a time, reference 
                 const float *row = base + static_cast<int64_t>(id) * dim;
                 float dp, db;
                 if (metric == kMetricDot) {
-                    dp = -exact_pair16<true, kPair>(row, qv, dim, sub);
+                    dp = -exact_pair16<true, kPair, false, QLDS>(row, qv, dim, sub);
                     db = dp;
                 } else {
-                    exact_l2_both16(row, qv, dim, sub, dp, db);
+                    exact_l2_both16<false, QLDS>(row, qv, dim, sub, dp, db);
                     if (metric == kMetricCos) dp = 0.5f * dp;
                 }
                 if ((lane & 15) == 0) {
@@ -110,6 +112,8 @@ __device__ __forceinline__ float pq_asym_distance(const uint8_t *__restrict__ co
     for (int s = s0; s < m; s++) distance = distance + lut[s * 256 + code[s]];
     return distance;
 }
+
+using F32Scorer = F32ScorerT<false>;
 
 // ---- ComputeAsymmetricDistance without a table (sub-dimension 8) ------------------------------------------------
 // term(s) = squaredL2Int8DequantizedGeneric (kernels.go:354-362) of the node's centroid of sub-quantizer s: per
