@@ -38,12 +38,17 @@ constexpr int kHnswLdsEf = 512;  // LDS items of the results heap (twice that fo
 // ms per 8192 queries, ef 2048: 120 -> 95 on one box); with the query in LDS (F32ScorerT<true>: its pieces are read
 // where they are used instead of being held beside the row's for a whole chunk: 20 registers spilled instead of 29, no
 // query traffic through L1) and 128 heap items in LDS (7 KiB per query in all, so that the 16 waves fit) another 9 %
-// (48.5 / 95.7 / 208.8 -> 44.2 / 88.8 / 191.7 ms at ef 1024 / 2048 / 4096).  A fifth wave spills 59 registers and gives
-// it all back; a sixth is 2x slower.  The other instantiations keep the compiler's choice.
+// (48.5 / 95.7 / 208.8 -> 44.2 / 88.8 / 191.7 ms at ef 1024 / 2048 / 4096), and with 6 row blocks in flight instead of 12
+// (91 registers, nothing spilled) 42.7 / 84.6 / 182.4 = 5.4 / 5.2 / 4.9 TB/s of gathered rows.  A fifth wave then fits
+// without spills and changes nothing (43.3 / 83.6 / 183.4): the walk is no longer short of waves.  The other
+// instantiations keep the compiler's choice.
 #ifndef VG_SPLIT_F32_WAVES
 #define VG_SPLIT_F32_WAVES 4
 #endif
-#define VG_HNSW_ATTR __attribute__((amdgpu_waves_per_eu(SPLIT ? (PQ ? 4 : VG_SPLIT_F32_WAVES) : 1, SPLIT ? (PQ ? 4 : VG_SPLIT_F32_WAVES) : 8)))
+#ifndef VG_SPLIT_PQ_WAVES
+#define VG_SPLIT_PQ_WAVES 4
+#endif
+#define VG_HNSW_ATTR __attribute__((amdgpu_waves_per_eu(SPLIT ? (PQ ? VG_SPLIT_PQ_WAVES : VG_SPLIT_F32_WAVES) : 1, SPLIT ? (PQ ? VG_SPLIT_PQ_WAVES : VG_SPLIT_F32_WAVES) : 8)))
 // UK: the metric is not Dot, so every distance is >= +0 and the heaps compare bit patterns (heap_sift_down_uk).
 template <bool PQ, bool SPLIT, bool UK>
 __global__ __launch_bounds__(64) VG_HNSW_ATTR void hnsw_search_kernel(
@@ -523,16 +528,22 @@ static int32_t search_hnsw_impl(vg_index *idx, bool pq, const float *queries, in
     const int pq_m = pq ? idx->pq->m : 0;
     // heaps in LDS up to kHnswLdsEf (12 KiB per query: the waves of a CU are then bounded by registers, not
     // LDS), beyond it split between those 12 KiB (the top levels) and HBM scratch
-    // split heaps: the PQ walk also keeps its query's 3.75 KiB of constants in LDS and gathers 32x fewer bytes per
-    // node, so it prefers waves to LDS heap levels: 256 items (10 KiB per query in all); measured on one box at ef 2048:
-    // 86 ms per 8192 queries with 256, 100 ms with 512; the fp32 walk, with a fourth wave per SIMD (VG_HNSW_ATTR): 384
-    const bool lds_heaps = ef <= vg::kHnswLdsEf;
+    // split heaps: waves in flight beat heap levels in LDS.  The PQ walk (3.75 KiB of query constants in LDS): 128 items
+    // = 7.4 KiB per query, 16 waves per CU: ef 1024 / 2048 40.7 / 81.9 -> 35.6 / 68.5 ms per 8192 queries against 256 items
+    // (15 waves); the fp32 walk (the query itself in LDS): 128 items as well
+#ifndef VG_PQ_LDS_HEAPS_MAX
+#define VG_PQ_LDS_HEAPS_MAX 448  // PQ walk: all-LDS heaps at ef 512 are 16.7 KiB per query = 9 waves per CU (12.95 ms per 8192
+#endif                            // queries); split with 128 items in LDS: 16 waves, 12.47 ms; at ef 384 the other way round (7.95 vs 9.19)
+    const bool lds_heaps = ef <= (pq ? VG_PQ_LDS_HEAPS_MAX : vg::kHnswLdsEf);
     // (swept on one box, ef 1024 / 2048: candidates : results = 768 : 384 46 / 94 ms, 128 : 768 47 / 95, 256 : 1024
     // 50 / 107, 256 : 2048 51 / 124, 1024 : 2048 58 / 152 — waves in flight beat heap levels in LDS)
 #ifndef VG_SPLIT_F32_LDS_EF
 #define VG_SPLIT_F32_LDS_EF 128
 #endif
-    const int lds_ef = pq ? 256 : VG_SPLIT_F32_LDS_EF;
+#ifndef VG_SPLIT_PQ_LDS_EF
+#define VG_SPLIT_PQ_LDS_EF 128
+#endif
+    const int lds_ef = pq ? VG_SPLIT_PQ_LDS_EF : VG_SPLIT_F32_LDS_EF;
     // (after heap_push_run_min the split hardly matters: 128 : 1024, 64 : 1088, 256 : 896, 384 : 768 all within 2 % of this)
     const int lds_cand = 2 * lds_ef, lds_res = lds_ef;
     const int64_t heap_bytes = lds_heaps ? 0 : static_cast<int64_t>(3) * ef * sizeof(vg::HItem);

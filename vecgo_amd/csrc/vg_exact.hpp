@@ -54,6 +54,12 @@ struct Sub16 {
 enum ExactMode { kPair = 0, kBatch = 1, kBounded = 2 };
 constexpr int kExactChunk = 12;      // 64-float blocks whose loads are issued together (768 floats = one chunk)
 constexpr int kExactChunkSmall = 4;  // ... and the size tried next for what is left
+#ifndef VG_QLDS_CHUNK
+#define VG_QLDS_CHUNK 6
+#endif
+// the same for the query-in-LDS form (split-heap walks at 4 waves per SIMD): 6 blocks = 91 registers, nothing spilled
+// (12: 128 with 20 spilled; ef 1024 / 2048 per 8192 queries: 42.7 / 84.6 ms with 6, 43.3 / 86.2 with 8, 44.3 / 89.3 with 12)
+constexpr int kExactChunkQ = VG_QLDS_CHUNK;
 
 // One pair.  `row` and `q` point at dim floats (16-byte aligned when dim % 4 == 0, which the
 // fast path requires; other dims take the scalar route below).  All 16 lanes of the group
@@ -85,12 +91,12 @@ __device__ __forceinline__ float exact_pair16(const float *__restrict__ row,
     };
     int e = 0;
     if (QLDS) {  // the query in LDS: read where used, not held beside the row (see exact_l2_both16)
-        for (; e + kExactChunk <= nblk; e += kExactChunk) {
-            float4 b[kExactChunk];
+        for (; e + kExactChunkQ <= nblk; e += kExactChunkQ) {
+            float4 b[kExactChunkQ];
 #pragma unroll
-            for (int u = 0; u < kExactChunk; u++) b[u] = STREAM ? load_stream(r4 + (e + u) * 16) : r4[(e + u) * 16];
+            for (int u = 0; u < kExactChunkQ; u++) b[u] = STREAM ? load_stream(r4 + (e + u) * 16) : r4[(e + u) * 16];
 #pragma unroll
-            for (int u = 0; u < kExactChunk; u++) {
+            for (int u = 0; u < kExactChunkQ; u++) {
                 step(q4[(e + u) * 16], b[u]);
                 if ((u & 3) == 3) __builtin_amdgcn_sched_barrier(0);
             }
@@ -203,12 +209,12 @@ __device__ __forceinline__ void exact_l2_both16(const float *__restrict__ row,
     };
     int e = 0;
     if (QLDS) {
-        for (; e + kExactChunk <= nblk; e += kExactChunk) {
-            float4 rb[kExactChunk];
+        for (; e + kExactChunkQ <= nblk; e += kExactChunkQ) {
+            float4 rb[kExactChunkQ];
 #pragma unroll
-            for (int u = 0; u < kExactChunk; u++) rb[u] = STREAM ? load_stream(r4 + (e + u) * 16) : r4[(e + u) * 16];
+            for (int u = 0; u < kExactChunkQ; u++) rb[u] = STREAM ? load_stream(r4 + (e + u) * 16) : r4[(e + u) * 16];
 #pragma unroll
-            for (int u = 0; u < kExactChunk; u++) {
+            for (int u = 0; u < kExactChunkQ; u++) {
                 step(q4[(e + u) * 16], rb[u]);
                 if ((u & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // keep the LDS reads from being hoisted into registers
             }
