@@ -159,7 +159,7 @@ __global__ __launch_bounds__(64) VG_HNSW_ATTR void hnsw_search_kernel(
 }
 
 // ---- Vamana --------------------------------------------------------------------------------------
-enum { kVamanaF32 = 0, kVamanaPQ = 1, kVamanaRaBitQ = 2, kVamanaInt4 = 3 };
+enum { kVamanaF32 = 0, kVamanaPQ = 1, kVamanaRaBitQ = 2, kVamanaInt4 = 3, kVamanaPQDirect = 4 /* kernel instances only */ };
 
 __device__ inline float rq_formula_g(float qn, float yn, float dimf, float hamming)
 {
@@ -174,10 +174,30 @@ __device__ inline float rq_formula_g(float qn, float yn, float dimf, float hammi
 
 constexpr int kHnswMaxEf = 1 << 20;  // ... in HBM scratch beyond
 constexpr int kVamanaMaxK = 512;  // results per query: one per lane up to 64, a sorted LDS list beyond
-constexpr int kVamanaLdsCand = 1024;  // items of the exploration heap kept in LDS (8 KiB)
+#ifndef VG_VAMANA_LDS_CAND
+#define VG_VAMANA_LDS_CAND 512
+#endif
+constexpr int kVamanaLdsCand = VG_VAMANA_LDS_CAND;  // items of the exploration heap kept in LDS (4 KiB: 16 waves per CU next to the PQ constants)
 
-__global__ __launch_bounds__(64) void vamana_search_kernel(
-    int kind, int metric, int64_t n, int dim, const uint32_t *__restrict__ graph, int r, uint32_t entry,
+template <bool big>
+__device__ __forceinline__ uint64_t *vamana_result_list()
+{
+    if constexpr (big) {
+        __shared__ uint64_t list[kVamanaMaxK];
+        return list;
+    } else {
+        return nullptr;
+    }
+}
+
+// one instance per node scorer and per result-set form: the fp32 scorer's row blocks in flight do not set the
+// register budget of the code scorers, and the k <= 64 search carries no LDS result list
+#ifndef VG_VAMANA_PQ_WAVES
+#define VG_VAMANA_PQ_WAVES 4
+#endif
+template <int kind, bool big>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(kind == kVamanaPQDirect ? VG_VAMANA_PQ_WAVES : 1, 8))) void vamana_search_kernel(
+    int metric, int64_t n, int dim, const uint32_t *__restrict__ graph, int r, uint32_t entry,
     const float *__restrict__ base, const uint8_t *__restrict__ pq_rows, int pq_m,
     const float *__restrict__ luts /* nq * m * 256, or nullptr: terms from the codebook */, const int8_t *__restrict__ pq_cb,
     const float *__restrict__ pq_scales, const float *__restrict__ pq_offsets, const uint8_t *__restrict__ rq_rows,
@@ -189,7 +209,8 @@ __global__ __launch_bounds__(64) void vamana_search_kernel(
     __shared__ float nb_d[64];
     __shared__ uint64_t res[kVamanaMaxK];  // the result set when k > 64
     // the exploration heap is unbounded in the reference (up to cand_cap items of HBM scratch here); its first
-    // kVamanaLdsCand items — all of it for an ordinary k = 10 search, which scores ~1000 nodes — live in LDS: a
+    // kVamanaLdsCand items — the levels every pop and push touches; a k = 10 search scores ~1000 nodes and its
+    // heap peaks a little above that — live in LDS: a
     // popped node pushes up to R = 64 neighbours one after the other, each a sift of dependent accesses
     __shared__ HItem cand_lo[kVamanaLdsCand];
     extern __shared__ __attribute__((aligned(16))) float vamana_qprep[];  // PQ direct form: pq_direct_prepare's image
@@ -198,7 +219,11 @@ __global__ __launch_bounds__(64) void vamana_search_kernel(
     const Sub16 sub = Sub16::make(lane);
     const float *qv = queries + q * dim;
     uint32_t *vis = visited_ws + q * vis_words;
-    const SplitHeap cand{cand_lo, cand_ws + q * cand_cap, kVamanaLdsCand};
+    // (the flat address of cand_lo passes through a register: as a constant expression inside the heap's
+    // LDS-or-HBM selects this compiler emits v_cmp with src_shared_base as a VOP2 operand and rejects it)
+    HItem *cand_lo_flat = cand_lo;
+    asm volatile("" : "+s"(cand_lo_flat));
+    const SplitHeap cand{cand_lo_flat, cand_ws + q * cand_cap, kVamanaLdsCand};
     const bool desc = metric != kMetricL2;  // sc.Heap.Reset(s.Metric() != MetricL2), segment.go:597
     const float *lut = luts ? luts + q * static_cast<int64_t>(pq_m) * 256 : nullptr;
     const uint8_t *qc = qcodes ? qcodes + q * static_cast<int64_t>(rq_nb + 4) : nullptr;
@@ -209,7 +234,7 @@ __global__ __launch_bounds__(64) void vamana_search_kernel(
         qn = __uint_as_float(b);
     }
     int64_t st_visited = 0, st_dc = 0, st_pops = 0, st_dropped = 0;
-    if (kind == kVamanaPQ && lut == nullptr) {
+    if (kind == kVamanaPQDirect) {
         pq_direct_prepare(vamana_qprep, qv, pq_scales, pq_offsets, pq_m, lane);
         __syncthreads();
     }
@@ -229,12 +254,12 @@ __global__ __launch_bounds__(64) void vamana_search_kernel(
                 }
             }
         } else if ((mask >> lane) & 1) {
-            if (kind == kVamanaPQ) {
+            if (kind == kVamanaPQ || kind == kVamanaPQDirect) {
                 // ComputeAsymmetricDistance (pq.go:234-260): term(m) = BuildDistanceTable entry, summed
                 // sequentially over the sub-quantizers (vg_hnsw_layer.hpp: loads batched, sum order kept)
                 const uint8_t *code = pq_rows + static_cast<int64_t>(id_lane) * pq_m;
-                nb_d[lane] = lut ? pq_asym_distance(code, lut, pq_m)
-                                 : pq_direct_distance(code, pq_cb, pq_scales, pq_offsets, qv, vamana_qprep, pq_m);
+                nb_d[lane] = kind == kVamanaPQ ? pq_asym_distance(code, lut, pq_m)
+                                               : pq_direct_distance(code, pq_cb, pq_scales, pq_offsets, qv, vamana_qprep, pq_m);
             } else if (kind == kVamanaInt4) {
                 // iq.L2Distance (diskann/segment.go:558-565) = int4L2DistancePrecomputedAvx512 order
                 nb_d[lane] = int4_l2_precomputed(qv, int4_rows + static_cast<int64_t>(id_lane) * ((dim + 1) / 2), dim,
@@ -264,7 +289,6 @@ __global__ __launch_bounds__(64) void vamana_search_kernel(
     WaveTopK tk;  // sc.Heap: top-k by (Score, RowID) — candidate_queue.go:12-23
     tk.init(k < 64 ? k : 64);
     // k > 64: the k best keys as a sorted list in LDS instead of one key per lane (wave-uniform bookkeeping)
-    const bool big = k > 64;
     int res_n = 0;
     uint64_t res_tau = kKeyMax;
     auto res_insert = [&](uint64_t c) {  // c < res_tau, every lane calls it with the same key
@@ -277,6 +301,7 @@ __global__ __launch_bounds__(64) void vamana_search_kernel(
                 hi = mid;
         }
         const int newn = res_n < k ? res_n + 1 : k;
+        if constexpr (!big) return;
         uint64_t moved[kVamanaMaxK / 64];
 #pragma unroll
         for (int u = 0; u < kVamanaMaxK / 64; u++) {
@@ -656,15 +681,28 @@ VG_API int32_t vg_search_vamana(vg_index *idx, const float *queries, int64_t nq,
         const int64_t cnt = std::min(chunk, nq - q0);
         VG_HIP(hipMemsetAsync(vis.ptr, 0, static_cast<size_t>(cnt) * vis_words * 4, st));
         vg::ProfScope prof(idx->ctx, "vamana_search", st);
-        VG_LAUNCH(vg::vamana_search_kernel, dim3(static_cast<unsigned>(cnt)), dim3(64),
-                  pq_direct ? static_cast<size_t>(pq_m >> 1) * vg::kPqPairFloats * sizeof(float) : 0, st, kind,
-                           idx->metric, idx->n, idx->dim, idx->d_vamana, idx->vamana_r, idx->vamana_entry,
-                           idx->d_vectors, idx->d_pq_rows, pq_m, kind == 1 && !pq_direct ? luts.ptr + q0 * pq_m * 256 : nullptr,
-                           pq_direct ? idx->pq->d_codebooks : nullptr, idx->pq ? idx->pq->d_scales : nullptr,
-                           idx->pq ? idx->pq->d_offsets : nullptr,
-                           idx->d_rq_rows, kind == 2 ? qcodes.ptr + q0 * (rq_nb + 4) : nullptr, rq_nb,
-                           idx->d_int4_rows, idx->int4_table, q.ptr + q0 * idx->dim, k, cand.ptr, cand_cap, vis.ptr, vis_words, oid.ptr + q0 * k,
-                           osc.ptr + q0 * k, ost.ptr ? ost.ptr + q0 : nullptr);
+        auto launch = [&](auto kernel) -> int32_t {
+            VG_LAUNCH(kernel, dim3(static_cast<unsigned>(cnt)), dim3(64),
+                      pq_direct ? static_cast<size_t>(pq_m >> 1) * vg::kPqPairFloats * sizeof(float) : 0, st,
+                      idx->metric, idx->n, idx->dim, idx->d_vamana, idx->vamana_r, idx->vamana_entry,
+                      idx->d_vectors, idx->d_pq_rows, pq_m, kind == 1 && !pq_direct ? luts.ptr + q0 * pq_m * 256 : nullptr,
+                      pq_direct ? idx->pq->d_codebooks : nullptr, idx->pq ? idx->pq->d_scales : nullptr,
+                      idx->pq ? idx->pq->d_offsets : nullptr,
+                      idx->d_rq_rows, kind == 2 ? qcodes.ptr + q0 * (rq_nb + 4) : nullptr, rq_nb,
+                      idx->d_int4_rows, idx->int4_table, q.ptr + q0 * idx->dim, k, cand.ptr, cand_cap, vis.ptr, vis_words, oid.ptr + q0 * k,
+                      osc.ptr + q0 * k, ost.ptr ? ost.ptr + q0 : nullptr);
+            return VG_OK;
+        };
+        const bool big = k > 64;
+        int32_t rc;
+        switch (pq_direct ? vg::kVamanaPQDirect : kind) {
+        case 0: rc = big ? launch(vg::vamana_search_kernel<0, true>) : launch(vg::vamana_search_kernel<0, false>); break;
+        case 1: rc = big ? launch(vg::vamana_search_kernel<1, true>) : launch(vg::vamana_search_kernel<1, false>); break;
+        case 4: rc = big ? launch(vg::vamana_search_kernel<4, true>) : launch(vg::vamana_search_kernel<4, false>); break;
+        case 2: rc = big ? launch(vg::vamana_search_kernel<2, true>) : launch(vg::vamana_search_kernel<2, false>); break;
+        default: rc = big ? launch(vg::vamana_search_kernel<3, true>) : launch(vg::vamana_search_kernel<3, false>); break;
+        }
+        VG_TRY(rc);
     }
     VG_TRY(oid.finish());
     VG_TRY(osc.finish());
