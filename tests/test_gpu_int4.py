@@ -61,9 +61,11 @@ def test_set_params_is_unmarshal_binary(vg, ctx):
     assert np.array_equal(bits(iq.params()[2]), bits(ref.table))
 
 
-def test_vamana_search_with_int4_codes_and_segment_file(vg, ctx):
+# dim % 32 == 0: the walk evaluates the table's terms in place (int4_l2_direct); other dims read the table
+@pytest.mark.parametrize("dim", [96, 100, 32, 768, 47])
+def test_vamana_search_with_int4_codes_and_segment_file(vg, ctx, dim):
     rng = np.random.default_rng(8)
-    n, dim, nq, k, r = 1200, 96, 6, 10, 16
+    n, nq, k, r = 1200, 6, 10, 16
     x = rng.standard_normal((n, dim)).astype(np.float32)
     q = rng.standard_normal((nq, dim)).astype(np.float32)
     g, entry = build_vamana(x, r=r, seed=2)

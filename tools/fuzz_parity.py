@@ -149,6 +149,22 @@ while time.time() < t_end:
             idx.set_vamana_graph(g, entry)
             ids, sc, st = idx.search_vamana(q, kk, kind=0, stats=True)
             compare("vamana", dict(cfg, r=r), ids, sc, [oidx.search(q[i], kk)[:2] for i in range(nq)])
+            if metric == 0:
+                # the same beam scored from INT4 codes (dim % 32 == 0: terms evaluated in place, else the table) ...
+                oiq = o.Int4Quantizer(dim); oiq.train(x)
+                icodes = oiq.encode_batch(x)
+                iq = vg.Int4Quantizer(ctx, dim); iq.train(x)
+                idx.set_int4_codes(iq, icodes)
+                ids, sc = idx.search_vamana(q, kk, kind=3)
+                ov = o.VamanaIndex(g, entry, dim, kind=o.VAMANA_INT4, codes=icodes, int4_table=oiq.table)
+                compare("vamana_int4", dict(cfg, r=r), ids, sc, [ov.search(q[i], kk)[:2] for i in range(nq)])
+                # ... and from RaBitQ codes
+                rcodes = o.rabitq_encode_batch(x, dim)
+                idx.set_rabitq_codes(rcodes)
+                ids, sc = idx.search_vamana(q, kk, kind=2)
+                ov = o.VamanaIndex(g, entry, dim, kind=o.VAMANA_RABITQ, codes=rcodes)
+                compare("vamana_rabitq", dict(cfg, r=r), ids, sc, [ov.search(q[i], kk)[:2] for i in range(nq)])
+                iq.close()
         elif which == 7 and 16 <= n <= 1000:
             # hnsw.Insert loop on the GPU (batched) = the letter-by-letter CPU build, ties included; then a search over it
             gm = int(rng.choice([4, 8, 16]))

@@ -159,7 +159,7 @@ __global__ __launch_bounds__(64) VG_HNSW_ATTR void hnsw_search_kernel(
 }
 
 // ---- Vamana --------------------------------------------------------------------------------------
-enum { kVamanaF32 = 0, kVamanaPQ = 1, kVamanaRaBitQ = 2, kVamanaInt4 = 3, kVamanaPQDirect = 4 /* kernel instances only */ };
+enum { kVamanaF32 = 0, kVamanaPQ = 1, kVamanaRaBitQ = 2, kVamanaInt4 = 3, kVamanaPQDirect = 4, kVamanaInt4Direct = 5 /* 4, 5: kernel instances only */ };
 
 __device__ inline float rq_formula_g(float qn, float yn, float dimf, float hamming)
 {
@@ -202,7 +202,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(kind == kVam
     const float *__restrict__ luts /* nq * m * 256, or nullptr: terms from the codebook */, const int8_t *__restrict__ pq_cb,
     const float *__restrict__ pq_scales, const float *__restrict__ pq_offsets, const uint8_t *__restrict__ rq_rows,
     const uint8_t *__restrict__ qcodes /* nq * (nb+4) */, int rq_nb, const uint8_t *__restrict__ int4_rows,
-    const float *__restrict__ int4_table, const float *__restrict__ queries, int k, HItem *__restrict__ cand_ws, int64_t cand_cap, uint32_t *__restrict__ visited_ws,
+    const float *__restrict__ int4_table, const float *__restrict__ int4_min, const float *__restrict__ int4_diff,
+    const float *__restrict__ queries, int k, HItem *__restrict__ cand_ws, int64_t cand_cap, uint32_t *__restrict__ visited_ws,
     int64_t vis_words, uint32_t *__restrict__ ids, float *__restrict__ scores,
     vg_search_stats *__restrict__ stats)
 {
@@ -234,6 +235,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(kind == kVam
         qn = __uint_as_float(b);
     }
     int64_t st_visited = 0, st_dc = 0, st_pops = 0, st_dropped = 0;
+    __shared__ vg_f2v int4_pairs[256];  // INT4 direct form: code byte -> (hi / 15, lo / 15)
+    if (kind == kVamanaInt4Direct) {
+        int4_fill_pairs(int4_pairs, lane, 64);
+        __syncthreads();
+    }
     if (kind == kVamanaPQDirect) {
         pq_direct_prepare(vamana_qprep, qv, pq_scales, pq_offsets, pq_m, lane);
         __syncthreads();
@@ -260,6 +266,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(kind == kVam
                 const uint8_t *code = pq_rows + static_cast<int64_t>(id_lane) * pq_m;
                 nb_d[lane] = kind == kVamanaPQ ? pq_asym_distance(code, lut, pq_m)
                                                : pq_direct_distance(code, pq_cb, pq_scales, pq_offsets, qv, vamana_qprep, pq_m);
+            } else if (kind == kVamanaInt4Direct) {
+                // the same terms evaluated in place of the table read (vg_device.hpp)
+                nb_d[lane] = int4_l2_direct(qv, int4_rows + static_cast<int64_t>(id_lane) * (dim >> 1), dim, int4_min,
+                                            int4_diff, int4_pairs);
             } else if (kind == kVamanaInt4) {
                 // iq.L2Distance (diskann/segment.go:558-565) = int4L2DistancePrecomputedAvx512 order
                 nb_d[lane] = int4_l2_precomputed(qv, int4_rows + static_cast<int64_t>(id_lane) * ((dim + 1) / 2), dim,
@@ -664,6 +674,9 @@ VG_API int32_t vg_search_vamana(vg_index *idx, const float *queries, int64_t nq,
     const int i_vis = ar.add(sizeof(uint32_t) * static_cast<size_t>(chunk) * vis_words);
     const int i_cand = ar.add(sizeof(vg::HItem) * static_cast<size_t>(chunk) * cand_cap);
     const bool pq_direct = kind == 1 && idx->pq->subdim == 8 && (reinterpret_cast<uintptr_t>(idx->pq->d_codebooks) & 7) == 0;
+    // INT4: terms evaluated in place when the rows are whole 32-element blocks (16-byte aligned codes)
+    const bool int4_direct = kind == 3 && idx->dim % 32 == 0 && idx->int4_min && idx->int4_diff &&
+                             (reinterpret_cast<uintptr_t>(idx->d_int4_rows) & 15) == 0;
     const int i_luts = ar.add(kind == 1 && !pq_direct ? sizeof(float) * static_cast<size_t>(nq) * pq_m * 256 : 0);
     const int i_qcodes = ar.add(kind == 2 ? static_cast<size_t>(nq) * (rq_nb + 4) : 0);
     VG_TRY(ar.commit());
@@ -689,16 +702,17 @@ VG_API int32_t vg_search_vamana(vg_index *idx, const float *queries, int64_t nq,
                       pq_direct ? idx->pq->d_codebooks : nullptr, idx->pq ? idx->pq->d_scales : nullptr,
                       idx->pq ? idx->pq->d_offsets : nullptr,
                       idx->d_rq_rows, kind == 2 ? qcodes.ptr + q0 * (rq_nb + 4) : nullptr, rq_nb,
-                      idx->d_int4_rows, idx->int4_table, q.ptr + q0 * idx->dim, k, cand.ptr, cand_cap, vis.ptr, vis_words, oid.ptr + q0 * k,
+                      idx->d_int4_rows, idx->int4_table, idx->int4_min, idx->int4_diff, q.ptr + q0 * idx->dim, k, cand.ptr, cand_cap, vis.ptr, vis_words, oid.ptr + q0 * k,
                       osc.ptr + q0 * k, ost.ptr ? ost.ptr + q0 : nullptr);
             return VG_OK;
         };
         const bool big = k > 64;
         int32_t rc;
-        switch (pq_direct ? vg::kVamanaPQDirect : kind) {
+        switch (pq_direct ? vg::kVamanaPQDirect : int4_direct ? vg::kVamanaInt4Direct : kind) {
         case 0: rc = big ? launch(vg::vamana_search_kernel<0, true>) : launch(vg::vamana_search_kernel<0, false>); break;
         case 1: rc = big ? launch(vg::vamana_search_kernel<1, true>) : launch(vg::vamana_search_kernel<1, false>); break;
         case 4: rc = big ? launch(vg::vamana_search_kernel<4, true>) : launch(vg::vamana_search_kernel<4, false>); break;
+        case 5: rc = big ? launch(vg::vamana_search_kernel<5, true>) : launch(vg::vamana_search_kernel<5, false>); break;
         case 2: rc = big ? launch(vg::vamana_search_kernel<2, true>) : launch(vg::vamana_search_kernel<2, false>); break;
         default: rc = big ? launch(vg::vamana_search_kernel<3, true>) : launch(vg::vamana_search_kernel<3, false>); break;
         }

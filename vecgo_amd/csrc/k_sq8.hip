@@ -1207,6 +1207,8 @@ VG_API int32_t vg_index_set_int4_codes(vg_index *idx, vg_int4 *iq, const uint8_t
         idx->d_int4_rows = nullptr;
     }
     idx->int4_table = iq->d_table;
+    idx->int4_min = iq->d_min;
+    idx->int4_diff = iq->d_diff;
     if (idx->n == 0) return VG_OK;
     const size_t bytes = static_cast<size_t>(idx->n) * static_cast<size_t>(vg_int4_code_bytes(idx->dim));
     VG_HIP(hipMalloc(reinterpret_cast<void **>(&idx->d_int4_rows), bytes));

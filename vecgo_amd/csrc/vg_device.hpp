@@ -194,6 +194,58 @@ __device__ __forceinline__ float int4_l2_precomputed(const float *__restrict__ q
     return total;
 }
 
+// The same distance without the dim x 16 table (48 KiB at dim 768: more than a CU's L1, so a walk's lookups
+// are L2 round trips): table[j][v] = float(v) / 15 * diff[j] + min[j] (int4.go:152-163) evaluated in place.
+// `pairs` (LDS, 256 entries, int4_fill_pairs) maps a code byte to (float(hi) / 15, float(lo) / 15): the two
+// values a byte holds are neighbouring AVX-512 lanes, so every step is one packed-fp32 instruction on the
+// pair; diff / min / query are wave-uniform (scalar loads).  dim % 32 == 0 and 16-byte aligned codes.
+typedef float vg_f2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void int4_fill_pairs(vg_f2v *pairs, int tid, int nthreads)
+{
+    for (int b = tid; b < 256; b += nthreads) {
+        vg_f2v a;
+        a.x = static_cast<float>(b >> 4) / 15.0f;
+        a.y = static_cast<float>(b & 15) / 15.0f;
+        pairs[b] = a;
+    }
+}
+__device__ __forceinline__ float int4_l2_direct(const float *__restrict__ query, const uint8_t *__restrict__ code, int dim,
+                                                const float *__restrict__ mins, const float *__restrict__ diff,
+                                                const vg_f2v *pairs)
+{
+    vg_f2v sum[8];
+#pragma unroll
+    for (int p = 0; p < 8; p++) sum[p] = vg_f2v{0.0f, 0.0f};
+    for (int i = 0; i < dim; i += 32) {
+        const uint4 c = *reinterpret_cast<const uint4 *>(code + (i >> 1));
+        const uint32_t w[4] = {c.x, c.y, c.z, c.w};
+#pragma unroll
+        for (int h = 0; h < 2; h++) {  // the two 16-element blocks feed sum[] in order
+#pragma unroll
+            for (int p = 0; p < 8; p++) {
+                const int byte = 8 * h + p;
+                const uint32_t b = (w[byte >> 2] >> (8 * (byte & 3))) & 0xFFu;
+                const int j = i + 2 * byte;
+                const vg_f2v a = pairs[b];
+                const vg_f2v df = *reinterpret_cast<const vg_f2v *>(diff + j);
+                const vg_f2v mn = *reinterpret_cast<const vg_f2v *>(mins + j);
+                const vg_f2v qq = *reinterpret_cast<const vg_f2v *>(query + j);
+                vg_f2v t = a * df;
+                t = t + mn;
+                const vg_f2v d = qq - t;
+                sum[p] = __builtin_elementwise_fma(d, d, sum[p]);
+            }
+        }
+    }
+    float s16[16];
+#pragma unroll
+    for (int p = 0; p < 8; p++) {
+        s16[2 * p] = sum[p].x;
+        s16[2 * p + 1] = sum[p].y;
+    }
+    return reduce16_regs(s16);
+}
+
 // Rank-merge of the per-wave sorted lists of one workgroup into `out[0..k)` (ascending,
 // kKeyMax padded): a key's final position is its own index plus the number of smaller keys in
 // every other wave's list (keys are unique).  `lists` = WAVES*64 keys of LDS, `valid` = WAVES ints.

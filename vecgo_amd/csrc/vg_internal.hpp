@@ -357,6 +357,7 @@ struct vg_index {
     // INT4 codes of a DiskANN segment, row-major n * ceil(dim/2), and the quantizer's lookup table
     uint8_t *d_int4_rows = nullptr;
     const float *int4_table = nullptr;  // borrowed from the vg_int4
+    const float *int4_min = nullptr, *int4_diff = nullptr;  // (same)
     // IVF partitions of a flat segment: centroids [P*dim], first row of every partition [P+1]
     float *d_centroids = nullptr;
     uint32_t *d_part_off = nullptr;
