@@ -1,6 +1,6 @@
 """PQ-scored graph walks against the fp32 walk on one graph: `hnsw_search_kernel<PQ>` and `hnsw_search_kernel<fp32>`
 time per launch over ef, and `vamana_search_kernel` with the PQ node scorer, on the graph vg_hnsw_build makes of
-N x 768 i.i.d. normal rows; 8192 queries in flight.  Prints node scores/s, queries/s and an ids checksum so that
+N x 768 i.i.d. normal rows; NQ (env, default 8192) queries per call.  Prints node scores/s, queries/s and an ids checksum so that
 library variants (VECGO_HIP_LIB) can be compared.  argv: [N [ef ...]]."""
 import sys, os
 from pathlib import Path
@@ -10,7 +10,7 @@ import vecgo_amd as vg, bench
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 200_000
 efs = [int(a) for a in sys.argv[2:]] or [128, 512, 2048]
-D, K, NQ = 768, 10, 8192
+D, K, NQ = 768, 10, int(os.environ.get("NQ", 8192))
 ctx = vg.Context(0); dev = torch.device("cuda", 0)
 rows = bench.gen_rows(0, N, dev)
 idx = vg.Index(ctx, N, D); idx.set_vectors(rows)
@@ -18,7 +18,7 @@ idx.build_hnsw(m=32, ef_construction=300, max_batch=8192, growth_div=32)
 pq = vg.ProductQuantizer(ctx, D, 96, 256); pq.train(rows[:32768], iters=5, seed=1)
 idx.set_pq_codes(pq, pq.encode(rows))
 l0, _, entry = idx.get_hnsw_graph(); idx.set_vamana_graph(l0, entry)
-q = bench.gen_queries(8, dev).reshape(-1, D)[:NQ].contiguous()
+q = bench.gen_queries((NQ + 1023) // 1024, dev).reshape(-1, D)[:NQ].contiguous()
 st = torch.cuda.current_stream()
 tag = os.environ.get("VECGO_HIP_LIB", "default")
 

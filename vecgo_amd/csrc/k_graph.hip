@@ -29,7 +29,7 @@ int32_t launch_pq_build_table(const vg_pq *pq, const float *d_queries, int64_t n
 // 3 * ef * 8 bytes per query would leave one or two waves per CU): the first kHnswLdsEf items of the results heap
 // and 2 * kHnswLdsEf of the candidates heap — the top levels, where the sifts spend their steps — stay in LDS,
 // the rest of each heap is HBM scratch.
-// PQ = false: nodes scored from their fp32 rows (hnsw.KNNSearch).  PQ = true: from their PQ codes with the
+// PQM = 0: nodes scored from their fp32 rows (hnsw.KNNSearch).  PQM != 0: from their PQ codes, with the
 // query's distance table `luts` (ComputeAsymmetricDistance order), the candidate stage of the
 // graph -> PQ -> exact-rerank pipeline.
 constexpr int kHnswLdsEf = 512;  // LDS items of the results heap (twice that for the candidates): 12 KiB per query
@@ -48,9 +48,17 @@ constexpr int kHnswLdsEf = 512;  // LDS items of the results heap (twice that fo
 #ifndef VG_SPLIT_PQ_WAVES
 #define VG_SPLIT_PQ_WAVES 4
 #endif
-#define VG_HNSW_ATTR __attribute__((amdgpu_waves_per_eu(SPLIT ? (PQ ? VG_SPLIT_PQ_WAVES : VG_SPLIT_F32_WAVES) : 1, SPLIT ? (PQ ? VG_SPLIT_PQ_WAVES : VG_SPLIT_F32_WAVES) : 8)))
+// PQ walk with its heaps in LDS (direct form: 109 registers, 4 waves per SIMD): a fifth and a sixth wave (74 registers
+// with one group of centroid loads in flight, nothing spilled) change nothing — 2.34 / 2.37 / 2.40 ms per 8192 queries at
+// ef 128, 8.55 / 8.12 / 8.21 per 32768 — the waves' issue slots are what is used up (each wave issues 39 % of its
+// cycles, profiles/r03_pmc_walk_pq_128_issue.csv), so the compiler's choice stays
+#ifndef VG_LDS_PQ_WAVES
+#define VG_LDS_PQ_WAVES 1
+#endif
+#define VG_HNSW_ATTR __attribute__((amdgpu_waves_per_eu(SPLIT ? (PQM ? VG_SPLIT_PQ_WAVES : VG_SPLIT_F32_WAVES) : (PQM == 2 ? VG_LDS_PQ_WAVES : 1), SPLIT ? (PQM ? VG_SPLIT_PQ_WAVES : VG_SPLIT_F32_WAVES) : 8)))
 // UK: the metric is not Dot, so every distance is >= +0 and the heaps compare bit patterns (heap_sift_down_uk).
-template <bool PQ, bool SPLIT, bool UK>
+// PQM: 0 = fp32 rows, 1 = PQ codes scored from the query's table, 2 = PQ codes scored from the codebook (direct form)
+template <int PQM, bool SPLIT, bool UK>
 __global__ __launch_bounds__(64) VG_HNSW_ATTR void hnsw_search_kernel(
     const float *__restrict__ base, int64_t n, int dim, int metric, const uint32_t *__restrict__ l0,
     int m0, int max_level, int m, const uint32_t *__restrict__ slots, const uint32_t *__restrict__ adj,
@@ -62,6 +70,7 @@ __global__ __launch_bounds__(64) VG_HNSW_ATTR void hnsw_search_kernel(
     uint32_t *__restrict__ ids, float *__restrict__ scores, vg_search_stats *__restrict__ stats)
 {
     extern __shared__ __attribute__((aligned(8))) unsigned char smem[];
+    constexpr bool PQ = PQM != 0;
     const int64_t q = blockIdx.x;
     const int lane = threadIdx.x;
     float *nb_pair = reinterpret_cast<float *>(smem);
@@ -72,7 +81,7 @@ __global__ __launch_bounds__(64) VG_HNSW_ATTR void hnsw_search_kernel(
 #define VG_SPLIT_F32_QLDS 1
 #endif
     constexpr bool kQLds = !PQ && SPLIT && VG_SPLIT_F32_QLDS;
-    const int qwords = PQ ? (pq_cb ? (pq_m >> 1) * kPqPairFloats : 0) : (kQLds ? ((dim + 3) & ~3) : 0);
+    const int qwords = PQ ? (PQM == 2 ? (pq_m >> 1) * kPqPairFloats : 0) : (kQLds ? ((dim + 3) & ~3) : 0);
     HItem *heaps = reinterpret_cast<HItem *>(qprep + qwords);
     typename std::conditional<SPLIT, SplitHeap, HItem *>::type cand, res;
     if constexpr (SPLIT) {
@@ -84,7 +93,7 @@ __global__ __launch_bounds__(64) VG_HNSW_ATTR void hnsw_search_kernel(
         res = cand + 2 * ef;
     }
     uint32_t *vis = visited_ws + q * vis_words;
-    typename std::conditional<PQ, PqScorer, F32ScorerT<kQLds>>::type sc;
+    typename std::conditional<PQ, PqScorerT<PQM == 2>, F32ScorerT<kQLds>>::type sc;
     if constexpr (PQ) {
         sc.rows = pq_rows;
         sc.lut = luts ? luts + q * static_cast<int64_t>(pq_m) * 256 : nullptr;
@@ -94,7 +103,7 @@ __global__ __launch_bounds__(64) VG_HNSW_ATTR void hnsw_search_kernel(
         sc.qv = queries + q * dim;
         sc.qprep = qprep;
         sc.m = pq_m;
-        if (pq_cb) {
+        if constexpr (PQM == 2) {
             pq_direct_prepare(qprep, sc.qv, pq_scales, pq_offsets, pq_m, lane);
             __syncthreads();
         }
@@ -600,9 +609,10 @@ static int32_t search_hnsw_impl(vg_index *idx, bool pq, const float *queries, in
                        (pq_direct ? static_cast<size_t>(pq_m >> 1) * vg::kPqPairFloats * sizeof(float) : 0) +
                        (!pq && !lds_heaps && VG_SPLIT_F32_QLDS ? static_cast<size_t>((idx->dim + 3) & ~3) * sizeof(float) : 0);
     const bool uk = idx->metric != VG_METRIC_DOT;
-    auto kern = pq ? (lds_heaps ? vg::hnsw_search_kernel<true, false, true> : vg::hnsw_search_kernel<true, true, true>)
-                   : uk ? (lds_heaps ? vg::hnsw_search_kernel<false, false, true> : vg::hnsw_search_kernel<false, true, true>)
-                        : (lds_heaps ? vg::hnsw_search_kernel<false, false, false> : vg::hnsw_search_kernel<false, true, false>);
+    auto kern = pq_direct ? (lds_heaps ? vg::hnsw_search_kernel<2, false, true> : vg::hnsw_search_kernel<2, true, true>)
+                : pq      ? (lds_heaps ? vg::hnsw_search_kernel<1, false, true> : vg::hnsw_search_kernel<1, true, true>)
+                : uk      ? (lds_heaps ? vg::hnsw_search_kernel<0, false, true> : vg::hnsw_search_kernel<0, true, true>)
+                          : (lds_heaps ? vg::hnsw_search_kernel<0, false, false> : vg::hnsw_search_kernel<0, true, false>);
     VG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                static_cast<int>(lds)));
     for (int64_t q0 = 0; q0 < nq; q0 += chunk) {

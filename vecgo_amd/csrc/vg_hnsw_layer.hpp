@@ -246,7 +246,9 @@ __device__ __forceinline__ float pq_direct_distance(const uint8_t *__restrict__ 
 // 256 MB memory-side cache — the walk ran at the HBM rate of its TABLE traffic (18.9 GB per launch against 0.93 GB
 // of codes, profiles/r02_traffic.json).  `cb` != nullptr (sub-dimension 8): the terms are computed from the shared
 // codebook instead, as the reference computes them; nothing per query is built or kept in memory.
-struct PqScorer {
+// DIRECT: one kernel instance per form (the table form's loads beside the direct form's set a higher register budget)
+template <bool DIRECT>
+struct PqScorerT {
     const uint8_t *rows;  // n * m code bytes
     const float *lut;     // m * 256 (table form: sub-dimensions other than 8)
     const int8_t *cb;     // m * 256 * 8 int8 (direct form) or nullptr
@@ -261,8 +263,10 @@ struct PqScorer {
         return __uint_as_float(0x40000000u | (((id * 2654435761u) ^ static_cast<uint32_t>(reinterpret_cast<uintptr_t>(qv) >> 4)) >> 9));
 #endif
         const uint8_t *code = rows + static_cast<int64_t>(id) * m;
-        if (cb) return pq_direct_distance(code, cb, scales, offsets, qv, qprep, m);
-        return pq_asym_distance(code, lut, m);
+        if constexpr (DIRECT)
+            return pq_direct_distance(code, cb, scales, offsets, qv, qprep, m);
+        else
+            return pq_asym_distance(code, lut, m);
     }
     __device__ __forceinline__ float one(uint32_t id) const { return lane_score(id); }
     __device__ __forceinline__ void many(uint64_t mask, uint32_t id_lane, int lane, float *nb_pair, float *nb_bnd) const
