@@ -139,37 +139,64 @@ __global__ __launch_bounds__(64) VG_HNSW_ATTR void hnsw_search_kernel(
     search_layer<UK>(sc, metric == kMetricL2, lane, row0, m0, cur, cur_d, ef, cand, res, nb_pair, nb_bnd, vis, res_len, st);
 
     // knnSearchInternal extraction (hnsw.go:1732-1751): drop the worst until k remain, then pop — the k closest
-    // in ascending order, equal distances in whatever order the heap's layout pops them.  When no two of the
-    // results have the same distance that order is THE ascending order, and a sort of the items (a copy, in the
-    // finished candidates heap's LDS; an item's 8 bytes are its key: distance bits above the node id) writes it
-    // without the ef dependent sift-downs (ef 128: ~5 % of a PQ walk); any tie, or a NaN, takes the pops.
+    // in ascending order, equal distances in whatever order the heap's layout pops them.  Ties among the results
+    // that are dropped only change the order they are dropped in: when the k + 1 closest distances are distinct the
+    // output is THE ascending order of the k closest, and selecting / sorting the items (8 bytes = the key: distance
+    // bits above the node id) writes it without the ef dependent sift-downs — ~5 % of a PQ walk at ef 128, and with
+    // split heaps every one of them a chain of HBM round trips (fp32 walk, ef 2048: ~15 %).  A tie among those
+    // k + 1, or a NaN, takes the pops.
     bool sorted = false;
-    if constexpr (!SPLIT && UK) {
-        uint64_t *keys = reinterpret_cast<uint64_t *>(cand);
-        const uint64_t *items = reinterpret_cast<const uint64_t *>(res);
-        int n2 = 1;
-        while (n2 < res_len) n2 <<= 1;  // <= 2 * ef
-        bool bad = false;
-        __syncthreads();
-        for (int i = lane; i < n2; i += 64) {
-            uint64_t key = ~0ull;
-            if (i < res_len) {
-                key = items[i];
-                bad |= static_cast<uint32_t>(key >> 32) > 0x7F800000u;
+    if constexpr (UK) {
+        if (k < 64) {  // selection: lane i of a register list ends up with the i-th closest (WaveTopK)
+            WaveTopK tk;
+            tk.init(k + 1);
+            bool bad = false;
+            for (int i0 = 0; i0 < res_len; i0 += 64) {
+                uint64_t key = kKeyMax;
+                if (i0 + lane < res_len) {
+                    key = heap_load_u64(res, i0 + lane);
+                    bad |= static_cast<uint32_t>(key >> 32) > 0x7F800000u;
+                }
+                tk.offer(key, lane);
             }
-            keys[i] = key;
-        }
-        __syncthreads();
-        bitonic_sort_lds(keys, n2, lane, 64);
-        for (int i = lane; i + 1 < res_len; i += 64) bad |= (keys[i] >> 32) == (keys[i + 1] >> 32);
-        if (!__ballot(bad)) {
-            sorted = true;
-            const int take = res_len < k ? res_len : k;
-            for (int i = lane; i < take; i += 64) {
-                ids[q * k + i] = static_cast<uint32_t>(keys[i]);
-                scores[q * k + i] = __uint_as_float(static_cast<uint32_t>(keys[i] >> 32));
+            const int have = res_len < k + 1 ? res_len : k + 1;
+            const uint32_t next_d = __shfl_down(static_cast<uint32_t>(tk.list >> 32), 1);
+            bad |= lane + 1 < have && static_cast<uint32_t>(tk.list >> 32) == next_d;
+            if (!__ballot(bad)) {
+                sorted = true;
+                res_len = res_len < k ? res_len : k;
+                if (lane < res_len) {
+                    ids[q * k + lane] = static_cast<uint32_t>(tk.list);
+                    scores[q * k + lane] = __uint_as_float(static_cast<uint32_t>(tk.list >> 32));
+                }
             }
-            res_len = take;
+        } else if constexpr (!SPLIT) {  // a sort of a copy in the finished candidates heap's LDS (2 * ef items)
+            uint64_t *keys = reinterpret_cast<uint64_t *>(cand);
+            const uint64_t *items = reinterpret_cast<const uint64_t *>(res);
+            int n2 = 1;
+            while (n2 < res_len) n2 <<= 1;  // <= 2 * ef
+            bool bad = false;
+            __syncthreads();
+            for (int i = lane; i < n2; i += 64) {
+                uint64_t key = ~0ull;
+                if (i < res_len) {
+                    key = items[i];
+                    bad |= static_cast<uint32_t>(key >> 32) > 0x7F800000u;
+                }
+                keys[i] = key;
+            }
+            __syncthreads();
+            bitonic_sort_lds(keys, n2, lane, 64);
+            const int have = res_len < k + 1 ? res_len : k + 1;
+            for (int i = lane; i + 1 < have; i += 64) bad |= (keys[i] >> 32) == (keys[i + 1] >> 32);
+            if (!__ballot(bad)) {
+                sorted = true;
+                res_len = res_len < k ? res_len : k;
+                for (int i = lane; i < res_len; i += 64) {
+                    ids[q * k + i] = static_cast<uint32_t>(keys[i]);
+                    scores[q * k + i] = __uint_as_float(static_cast<uint32_t>(keys[i] >> 32));
+                }
+            }
         }
     }
     if (!sorted) {
