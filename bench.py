@@ -598,7 +598,7 @@ def hnsw_pq_frontier(vg, ctx, rows, queries, gt_ids, exact_ms_per_1024, stream, 
               # the HBM-side fraction: fabric bytes (FETCH_SIZE x 2 + WRITE_SIZE, PMC) per second over the peak
               "frac": (tr128 / (e128["kernel_ms"] * 1e-3) / 1e9 / PEAK_HBM_GBS) if tr128 else None,
               "traffic": tr128,
-              "kernel": "hnsw_search_kernel<false>",
+              "kernel": "hnsw_search_kernel<0, *>",
               "kernel_ms": e128["kernel_ms"], "bytes_per_launch": e128["gathered_gbs"] * 1e9 * e128["kernel_ms"] * 1e-3,
               "recall_at_10": e128["recall_at_10"],
               "distance_computations_per_query": e128["distance_computations_per_query"],
@@ -699,7 +699,7 @@ def vamana_pq(vg, ctx, idx, q, gt_ids, stream):
     dc = float(st[:, 1].sum())
     gathered = dc * PQ_M + float(st[:, 3].sum()) * l0.shape[1] * 4
     return {"workload": f"vamana_pq_1Mx768_m96_K256_k10 over the built graph's layer 0 (R = {l0.shape[1]}), {q.shape[0]} queries in flight",
-            "kernel": "vamana_search_kernel", "kernel_ms": kern_ms, "launches_per_call": launches // 3, "node_scores_per_s": dc / (kern_ms * 1e-3),
+            "kernel": "vamana_search_kernel<4, false>", "kernel_ms": kern_ms, "launches_per_call": launches // 3, "node_scores_per_s": dc / (kern_ms * 1e-3),
             "lut_lookups_per_s": dc * PQ_M / (kern_ms * 1e-3),
             "recall_at_10_before_rerank": recall_at_k(ids.cpu().numpy().view(np.uint32)[:gt_ids.shape[0]], gt_ids),
             "node_scores_per_query": dc / q.shape[0], "gathered_gbs": gathered / (kern_ms * 1e-3) / 1e9,

@@ -78,8 +78,8 @@ if g:
     g.update({"SQ_VALU_MFMA_BUSY_CYCLES": busy, "GRBM_GUI_ACTIVE_sum_over_8_xcds": gui,
               "mfma_busy_fraction": busy / (1024 * gui / 8) if busy and gui else None})
 out["flat_gemm"] = g
-for tag, sub, per_score in (("f32_128", "hnsw_search_kernel<false", 768 * 4), ("f32_2048", "hnsw_search_kernel<false", 768 * 4),
-                            ("pq_128", "hnsw_search_kernel<true", 96), ("vamana_pq", "vamana_search_kernel", 96)):
+for tag, sub, per_score in (("f32_128", "hnsw_search_kernel<0", 768 * 4), ("f32_2048", "hnsw_search_kernel<0", 768 * 4),
+                            ("pq_128", "hnsw_search_kernel<2", 96), ("vamana_pq", "vamana_search_kernel<4", 96)):
     c = counts(f"walk_{tag}_fetch")
     alg = None
     if c:
