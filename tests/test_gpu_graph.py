@@ -63,22 +63,43 @@ def test_hnsw_matches_oracle(vg, ctx, n, dim, m, metric, k, ef, nq):
         assert np.all(ids[qi, r:] == 0xFFFFFFFF)
 
 
-def test_hnsw_duplicate_distances(vg, ctx):
+# (k, ef): the extraction takes the register selection (k < 64), the LDS sort (k >= 64, heaps in LDS) or the pops (a tie
+# among the k + 1 closest; k >= 64 with split heaps) — ef > 512 (fp32) / 448 (PQ) = split heaps
+@pytest.mark.parametrize("k,ef", [(10, 32), (5, 200), (64, 64), (100, 300), (10, 600), (70, 700), (600, 600)])
+@pytest.mark.parametrize("grid", [3, 40])   # 3: nearly every distance tied; 40: a tie here and there
+def test_hnsw_duplicate_distances(vg, ctx, k, ef, grid):
     """Many equal distances: heap tie behaviour (strict comparisons, queue.go:161-290) decides
-    which ids survive."""
-    rng = np.random.default_rng(5)
-    pts = rng.integers(0, 3, (600, 8)).astype(np.float32)   # small integer grid: lots of ties
+    which ids survive and in which order they come out."""
+    rng = np.random.default_rng(5 + grid)
+    n = 1500
+    pts = rng.integers(0, grid, (n, 8)).astype(np.float32)   # integer grid: ties
     l0, upper, entry = graphs.build_hnsw(pts, m=8, seed=3)
     oidx = o.HnswIndex(pts, 8, l0, upper, entry)
-    idx = vg.Index(ctx, 600, 8)
+    idx = vg.Index(ctx, n, 8)
     idx.set_vectors(pts)
     idx.set_hnsw_graph(l0, upper, entry, m=8)
-    q = rng.integers(0, 3, (16, 8)).astype(np.float32)
-    ids, sc, st = idx.search_hnsw(q, 10, 32, stats=True)
+    q = rng.integers(0, grid, (16, 8)).astype(np.float32)
+    ids, sc, st = idx.search_hnsw(q, k, ef, stats=True)
     for qi in range(16):
-        eid, esc, est = oidx.search(q[qi], 10, 32)
-        assert np.array_equal(ids[qi], eid) and np.array_equal(bits(sc[qi]), bits(esc))
+        eid, esc, est = oidx.search(q[qi], k, ef)
+        r = eid.size
+        assert np.array_equal(ids[qi, :r], eid) and np.array_equal(bits(sc[qi, :r]), bits(esc)), (qi, k, ef)
+        assert np.all(ids[qi, r:] == 0xFFFFFFFF)
         assert tuple(int(x) for x in st[qi]) == _stats_tuple(est)
+    # the same walk scored from PQ codes (sub-dimension 8, one sub-quantizer: quantised sums tie even more)
+    cb = rng.integers(-128, 128, 256 * 8).astype(np.int8)
+    scales = np.array([0.02], np.float32); offsets = np.array([0.5], np.float32)
+    opq = o.ProductQuantizer(8, 1, 256); opq.set_codebooks(cb, scales, offsets)
+    pq = vg.ProductQuantizer(ctx, 8, 1, 256); pq.set_codebooks(cb, scales, offsets)
+    codes = opq.encode_batch(pts)
+    idx.set_pq_codes(pq, codes)
+    oq = o.HnswIndex(pts, 8, l0, upper, entry, m=8, pq=opq, codes=codes)
+    kk = min(k, ef)
+    ids, sc = idx.search_hnsw_pq(q, kk, ef)
+    for qi in range(16):
+        eid, esc = oq.search(q[qi], kk, ef)[:2]
+        r = eid.size
+        assert np.array_equal(ids[qi, :r], eid) and np.array_equal(bits(sc[qi, :r]), bits(esc)), ("pq", qi, k, ef)
 
 
 @pytest.mark.parametrize("kind", [0, 1, 2])
