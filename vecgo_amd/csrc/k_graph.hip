@@ -172,24 +172,7 @@ __global__ __launch_bounds__(64) VG_HNSW_ATTR void hnsw_search_kernel(
             }
         } else if constexpr (!SPLIT) {  // a sort of a copy in the finished candidates heap's LDS (2 * ef items)
             uint64_t *keys = reinterpret_cast<uint64_t *>(cand);
-            const uint64_t *items = reinterpret_cast<const uint64_t *>(res);
-            int n2 = 1;
-            while (n2 < res_len) n2 <<= 1;  // <= 2 * ef
-            bool bad = false;
-            __syncthreads();
-            for (int i = lane; i < n2; i += 64) {
-                uint64_t key = ~0ull;
-                if (i < res_len) {
-                    key = items[i];
-                    bad |= static_cast<uint32_t>(key >> 32) > 0x7F800000u;
-                }
-                keys[i] = key;
-            }
-            __syncthreads();
-            bitonic_sort_lds(keys, n2, lane, 64);
-            const int have = res_len < k + 1 ? res_len : k + 1;
-            for (int i = lane; i + 1 < have; i += 64) bad |= (keys[i] >> 32) == (keys[i + 1] >> 32);
-            if (!__ballot(bad)) {
+            if (results_sorted_lds(res, res_len, keys, k + 1, lane)) {
                 sorted = true;
                 res_len = res_len < k ? res_len : k;
                 for (int i = lane; i < res_len; i += 64) {

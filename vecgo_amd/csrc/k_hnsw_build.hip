@@ -142,7 +142,18 @@ __global__ __launch_bounds__(64) void build_search_kernel(BuildGraph g, int64_t 
         // extractSortedCandidates (hnsw.go:1026-1046) / selectNeighborsSimple: pop everything, nearest first
         const int64_t p = pair0 + level;
         const int nres = res_len;
-        for (int i = nres - 1; i >= 0; i--) {
+        bool sorted = false;
+        if constexpr (UK) {  // no two results tie: the pops' order is the ascending order (vg_hnsw_layer.hpp)
+            uint64_t *keys = reinterpret_cast<uint64_t *>(cand);
+            sorted = results_sorted_lds(res, nres, keys, nres, lane);
+            if (sorted) {
+                for (int i = lane; i < nres; i += 64) {
+                    cand_ids[p * ef + i] = static_cast<uint32_t>(keys[i]);
+                    cand_d[p * ef + i] = __uint_as_float(static_cast<uint32_t>(keys[i] >> 32));
+                }
+            }
+        }
+        for (int i = nres - 1; i >= 0 && !sorted; i--) {
             const HItem it = heap_pop<true, UK>(res, res_len);
             if (lane == 0) {
                 cand_ids[p * ef + i] = it.node;

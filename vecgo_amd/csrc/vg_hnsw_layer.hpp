@@ -460,4 +460,31 @@ __device__ __forceinline__ void search_layer(const Scorer &sc, bool l2_metric, i
     res_len_out = res_len;
 }
 
+// The results heap's items in ascending order without popping them: a sort of a copy (`keys`: the finished candidates
+// heap's LDS, 2 * ef items >= the next power of two of res_len; an item's 8 bytes are its key, distance bits above the
+// node id — distances >= +0, UK).  Popping the heap gives the same order exactly when no two of the `check` closest
+// distances are equal (ties pop in the order the heap's layout dictates) and none is a NaN: returns false then, and
+// the caller pops.
+__device__ __forceinline__ bool results_sorted_lds(const HItem *res, int res_len, uint64_t *keys, int check, int lane)
+{
+    const uint64_t *items = reinterpret_cast<const uint64_t *>(res);
+    int n2 = 1;
+    while (n2 < res_len) n2 <<= 1;
+    bool bad = false;
+    __syncthreads();
+    for (int i = lane; i < n2; i += 64) {
+        uint64_t key = ~0ull;
+        if (i < res_len) {
+            key = items[i];
+            bad |= static_cast<uint32_t>(key >> 32) > 0x7F800000u;
+        }
+        keys[i] = key;
+    }
+    __syncthreads();
+    bitonic_sort_lds(keys, n2, lane, 64);
+    const int have = res_len < check ? res_len : check;
+    for (int i = lane; i + 1 < have; i += 64) bad |= (keys[i] >> 32) == (keys[i + 1] >> 32);
+    return __ballot(bad) == 0;
+}
+
 }  // namespace vg
