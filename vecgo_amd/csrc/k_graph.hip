@@ -246,11 +246,16 @@ __device__ __forceinline__ uint64_t *vamana_result_list()
 
 // one instance per node scorer and per result-set form: the fp32 scorer's row blocks in flight do not set the
 // register budget of the code scorers, and the k <= 64 search carries no LDS result list
+// fp32 rows: the gather runs best with 3 waves per SIMD (131 registers: all 12 row blocks of a pass in flight); squeezed
+// to a fourth wave it is 6 % slower (3.85 vs 3.63 ms per 8192 queries on one box)
+#ifndef VG_VAMANA_F32_MAX_WAVES
+#define VG_VAMANA_F32_MAX_WAVES 3
+#endif
 #ifndef VG_VAMANA_PQ_WAVES
 #define VG_VAMANA_PQ_WAVES 4
 #endif
 template <int kind, bool big>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(kind == kVamanaPQDirect ? VG_VAMANA_PQ_WAVES : 1, 8))) void vamana_search_kernel(
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(kind == kVamanaPQDirect ? VG_VAMANA_PQ_WAVES : 1, kind == kVamanaF32 ? VG_VAMANA_F32_MAX_WAVES : 8))) void vamana_search_kernel(
     int metric, int64_t n, int dim, const uint32_t *__restrict__ graph, int r, uint32_t entry,
     const float *__restrict__ base, const uint8_t *__restrict__ pq_rows, int pq_m,
     const float *__restrict__ luts /* nq * m * 256, or nullptr: terms from the codebook */, const int8_t *__restrict__ pq_cb,
@@ -287,6 +292,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(kind == kVam
         const uint32_t b = qc[rq_nb] | (qc[rq_nb + 1] << 8) | (qc[rq_nb + 2] << 16) |
                            (static_cast<uint32_t>(qc[rq_nb + 3]) << 24);
         qn = __uint_as_float(b);
+        // the query's sign words in LDS (rq_nb bytes of the dynamic allocation; qcodes rows are 4-byte aligned)
+        for (int i = lane; i < (rq_nb >> 2); i += 64)
+            reinterpret_cast<uint32_t *>(vamana_qprep)[i] = reinterpret_cast<const uint32_t *>(qc)[i];
+        __syncthreads();
     }
     int64_t st_visited = 0, st_dc = 0, st_pops = 0, st_dropped = 0;
     __shared__ vg_f2v int4_pairs[256];  // INT4 direct form: code byte -> (hi / 15, lo / 15)
@@ -330,19 +339,21 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(kind == kVam
                                                  int4_table);
             } else {
                 // rows are rq_nb + 4 bytes with rq_nb a multiple of 8: every row is 4-byte aligned, so the
-                // bits and the norm are read as dwords, 8 loads in flight at a time
+                // bits and the norm are read as dwords, 8 loads in flight at a time; the query's words come from
+                // LDS (broadcast reads) — as scalar loads each one was a round trip the pass waited out
                 const uint32_t *cw = reinterpret_cast<const uint32_t *>(rq_rows + static_cast<int64_t>(id_lane) * (rq_nb + 4));
-                const uint32_t *qw = reinterpret_cast<const uint32_t *>(qc);
+                const uint32_t *qw = reinterpret_cast<const uint32_t *>(vamana_qprep);
                 const int nw = rq_nb >> 2;
                 int h = 0;
-                for (int b0 = 0; b0 < nw; b0 += 8) {
+                int b0 = 0;
+                for (; b0 + 8 <= nw; b0 += 8) {
                     uint32_t x[8];
 #pragma unroll
-                    for (int u = 0; u < 8; u++) x[u] = b0 + u < nw ? cw[b0 + u] : 0u;
+                    for (int u = 0; u < 8; u++) x[u] = cw[b0 + u];
 #pragma unroll
-                    for (int u = 0; u < 8; u++)
-                        if (b0 + u < nw) h += __popc(x[u] ^ qw[b0 + u]);
+                    for (int u = 0; u < 8; u++) h += __popc(x[u] ^ qw[b0 + u]);
                 }
+                for (; b0 < nw; b0++) h += __popc(cw[b0] ^ qw[b0]);
                 const uint32_t yb = cw[nw];
                 nb_d[lane] = rq_formula_g(qn, __uint_as_float(yb), static_cast<float>(dim), static_cast<float>(h));
             }
@@ -751,7 +762,7 @@ VG_API int32_t vg_search_vamana(vg_index *idx, const float *queries, int64_t nq,
         vg::ProfScope prof(idx->ctx, "vamana_search", st);
         auto launch = [&](auto kernel) -> int32_t {
             VG_LAUNCH(kernel, dim3(static_cast<unsigned>(cnt)), dim3(64),
-                      pq_direct ? static_cast<size_t>(pq_m >> 1) * vg::kPqPairFloats * sizeof(float) : 0, st,
+                      pq_direct ? static_cast<size_t>(pq_m >> 1) * vg::kPqPairFloats * sizeof(float) : (kind == 2 ? static_cast<size_t>(rq_nb) : 0), st,
                       idx->metric, idx->n, idx->dim, idx->d_vamana, idx->vamana_r, idx->vamana_entry,
                       idx->d_vectors, idx->d_pq_rows, pq_m, kind == 1 && !pq_direct ? luts.ptr + q0 * pq_m * 256 : nullptr,
                       pq_direct ? idx->pq->d_codebooks : nullptr, idx->pq ? idx->pq->d_scales : nullptr,

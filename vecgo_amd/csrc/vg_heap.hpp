@@ -39,21 +39,41 @@ struct SplitHeap {
     HItem *hi;  // HBM scratch, indexed by the item's heap index (its first nl entries are unused)
     int nl;
 };
+// (the struct carries generic pointers; telling the compiler which memory each side is keeps ds_read / global_load
+// where a merged branch would otherwise become a pointer select and a flat_load — slower for the LDS side, and
+// counted against both wait counters)
+__device__ __forceinline__ HItem *split_lo(const SplitHeap &h)
+{
+    HItem *p = h.lo;
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_assume(__builtin_amdgcn_is_shared(p));
+#endif
+    return p;
+}
+__device__ __forceinline__ HItem *split_hi(const SplitHeap &h)
+{
+    HItem *p = h.hi;
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_assume(!__builtin_amdgcn_is_shared(p));
+    __builtin_assume(!__builtin_amdgcn_is_private(p));
+#endif
+    return p;
+}
 __device__ __forceinline__ HItem heap_get(const HItem *h, int i) { return heap_load(h + i); }
 __device__ __forceinline__ void heap_put(HItem *h, int i, HItem it) { heap_store(h + i, it); }
 // (a wave-uniform branch, not a pointer select: each side keeps its address space — ds_read / global_load
 // instead of flat_load)
 __device__ __forceinline__ HItem heap_get(const SplitHeap &h, int i)
 {
-    if (i < h.nl) return heap_load(h.lo + i);
-    return heap_load(h.hi + i);
+    if (i < h.nl) return heap_load(split_lo(h) + i);
+    return heap_load(split_hi(h) + i);
 }
 __device__ __forceinline__ void heap_put(const SplitHeap &h, int i, HItem it)
 {
     if (i < h.nl)
-        heap_store(h.lo + i, it);
+        heap_store(split_lo(h) + i, it);
     else
-        heap_store(h.hi + i, it);
+        heap_store(split_hi(h) + i, it);
 }
 
 // the up-to-4 children fc .. fc+3 of a node (indices past `last` read `last` again), requested together
@@ -65,9 +85,9 @@ __device__ __forceinline__ void heap_get4(const HItem *h, int fc, int last, HIte
 __device__ __forceinline__ void heap_get4(const SplitHeap &h, int fc, int last, HItem (&c)[4])
 {
     if (fc + 3 < h.nl) {
-        heap_get4(h.lo, fc, last, c);
+        heap_get4(split_lo(h), fc, last, c);
     } else if (fc >= h.nl) {
-        heap_get4(h.hi, fc, last, c);
+        heap_get4(split_hi(h), fc, last, c);
     } else {
 #pragma unroll
         for (int j = 0; j < 4; j++) c[j] = heap_get(h, fc + j < last ? fc + j : last);
@@ -143,8 +163,30 @@ __device__ __forceinline__ uint32_t heap_readlane(uint32_t v, int l)
 __device__ __forceinline__ uint64_t heap_load_u64(const HItem *h, int i) { return *reinterpret_cast<const uint64_t *>(h + i); }
 __device__ __forceinline__ uint64_t heap_load_u64(const SplitHeap &h, int i)
 {
-    if (i < h.nl) return *reinterpret_cast<const uint64_t *>(h.lo + i);
-    return *reinterpret_cast<const uint64_t *>(h.hi + i);
+    if (i < h.nl) return *reinterpret_cast<const uint64_t *>(split_lo(h) + i);
+    return *reinterpret_cast<const uint64_t *>(split_hi(h) + i);
+}
+// lanes 0 .. cnt-1 read the run of slots first .. first+cnt-1 (those below n).  A run lies on one side of the split
+// nearly always: a wave-uniform branch per side keeps ds_read / global_load (a per-lane choice becomes a pointer select
+// and a flat_load); only a run that straddles the boundary chooses per lane
+__device__ __forceinline__ uint64_t heap_load_run_u64(const HItem *h, int first, int cnt, int n, int lane)
+{
+    uint64_t v = 0;
+    if (lane < cnt && first + lane < n) v = heap_load_u64(h, first + lane);
+    return v;
+}
+__device__ __forceinline__ uint64_t heap_load_run_u64(const SplitHeap &h, int first, int cnt, int n, int lane)
+{
+    uint64_t v = 0;
+    const bool mine = lane < cnt && first + lane < n;
+    if (first + cnt <= h.nl) {
+        if (mine) v = *reinterpret_cast<const uint64_t *>(split_lo(h) + first + lane);
+    } else if (first >= h.nl) {
+        if (mine) v = *reinterpret_cast<const uint64_t *>(split_hi(h) + first + lane);
+    } else if (mine) {
+        v = heap_load_u64(h, first + lane);
+    }
+    return v;
 }
 
 // the reference's choice among the `cnt` (1..4) children whose distances lanes l0 .. l0+cnt-1 hold in `vd`
@@ -203,11 +245,11 @@ __device__ __forceinline__ void heap_sift_down_uk(const SplitHeap &h, int n, int
         const int fc = 4 * i + 1;
         if (fc >= n) break;
         const int fg = 4 * fc + 1, fgg = 16 * fc + 5;  // first grandchild, first great-grandchild
-        uint64_t c = 0, g = 0, gg = 0;
-        if (lane < 4 && fc + lane < n) c = heap_load_u64(h, fc + lane);
+        uint64_t g = 0, gg = 0;
+        const uint64_t c = heap_load_run_u64(h, fc, 4, n, lane);
         if (fg < n) {
-            if (lane < 16 && fg + lane < n) g = heap_load_u64(h, fg + lane);
-            if (fgg < n && fgg + lane < n) gg = heap_load_u64(h, fgg + lane);
+            g = heap_load_run_u64(h, fg, 16, n, lane);
+            if (fgg < n) gg = heap_load_run_u64(h, fgg, 64, n, lane);
         }
         int b1, b2, b3;
         uint32_t bk;
