@@ -680,7 +680,7 @@ def hnsw_cpu_twin(idx, rows, q, f32, efs=(128, 512, 2048)):
         ic.close()
 
 
-def vamana_pq(vg, ctx, idx, q, gt_ids, stream):
+def vamana_pq(vg, ctx, idx, rows, q, gt_ids, stream):
     """BASELINE configs[3], graph half: Vamana beam search (diskann/segment.go:503-706) with PQ node scoring
     (ComputeAsymmetricDistance order) over the built graph's layer 0 as the adjacency (R = 64).  A node-scoring
     rate, not a QPS claim: the beam stops at k results (segment.go:655-668), recall before rerank is low."""
@@ -698,11 +698,31 @@ def vamana_pq(vg, ctx, idx, q, gt_ids, stream):
     kern_ms = ms / 3     # the kernel launches of ONE call (r02 divided by launches: a call was 5 launches of 1650 queries)
     dc = float(st[:, 1].sum())
     gathered = dc * PQ_M + float(st[:, 3].sum()) * l0.shape[1] * 4
+    # the same beam with the reference's other node scorers (diskann/segment.go:503-565): fp32 rows, RaBitQ codes,
+    # INT4 codes — one kernel instance each
+    others = {}
+    idx.set_rabitq_codes(vg.RaBitQuantizer(ctx, DIM).encode(rows))
+    iq = vg.Int4Quantizer(ctx, DIM); iq.train(rows[:65536])
+    idx.set_int4_codes(iq, iq.encode(rows))
+    for kind, name, row_bytes in ((0, "fp32", DIM * 4), (2, "rabitq", DIM // 8 + 4), (3, "int4", DIM // 2)):
+        _, _, st_k = idx.search_vamana(q, K, kind=kind, stats=True, stream=stream)
+        torch.cuda.synchronize()
+        ctx.profile_read("vamana_search")
+        ctx.profile_enable(True)
+        for _ in range(3):
+            idx.search_vamana(q, K, kind=kind, stream=stream)
+        torch.cuda.synchronize()
+        _, ms_k = ctx.profile_read("vamana_search")
+        ctx.profile_enable(False)
+        dck = float(st_k[:, 1].sum())
+        others[name] = {"kernel_ms": ms_k / 3, "node_scores_per_s": dck / (ms_k / 3 * 1e-3), "node_scores_per_query": dck / q.shape[0],
+                        "gathered_gbs": dck * row_bytes / (ms_k / 3 * 1e-3) / 1e9}
     return {"workload": f"vamana_pq_1Mx768_m96_K256_k10 over the built graph's layer 0 (R = {l0.shape[1]}), {q.shape[0]} queries in flight",
             "kernel": "vamana_search_kernel<4, false>", "kernel_ms": kern_ms, "launches_per_call": launches // 3, "node_scores_per_s": dc / (kern_ms * 1e-3),
             "lut_lookups_per_s": dc * PQ_M / (kern_ms * 1e-3),
             "recall_at_10_before_rerank": recall_at_k(ids.cpu().numpy().view(np.uint32)[:gt_ids.shape[0]], gt_ids),
             "node_scores_per_query": dc / q.shape[0], "gathered_gbs": gathered / (kern_ms * 1e-3) / 1e9,
+            "other_node_scorers": others,
             "bound": "vector-ALU issue of one wave's serial work: node terms computed from the shared int8 codebook (31 instructions per "
                      "term, no per-query table) + the exploration heap's pushes; see DESIGN.md section 4 'Graph walks in r03'"}
 
@@ -1065,7 +1085,7 @@ def main():
             hp["build_check"] = {"error": str(e)}
         out["hnsw_pq"] = hp
         out["hnsw_layer0"] = hnsw128
-        leg("vamana_pq", lambda: vamana_pq(vg, ctx, hidx, queries.reshape(-1, DIM)[:NQ_FLIGHT].contiguous(), gt1024, stream))
+        leg("vamana_pq", lambda: vamana_pq(vg, ctx, hidx, rows, queries.reshape(-1, DIM)[:NQ_FLIGHT].contiguous(), gt1024, stream))
         hidx.close()
         hpq.close()
     if world == 1:
