@@ -21,7 +21,7 @@ and `pq_train_sharded` are BASELINE configs[4].  A single graph does not shard (
 
 One JSON line on rank 0; extra objects: `roofline` (dominant kernel of the timed region, HIP events from inside
 the library), `adc_scan` (configs[3]: 10M x 96 B codes, HBM roofline), `rabitq_scan` (configs[4] on one GPU),
-`sq8_scan`, `flat_small_batch`, `hnsw_layer0` (configs[2]), `flat_ivf_probe`, `cpu_baseline`.
+`sq8_scan`, `int4_scan`, `flat_small_batch`, `hnsw_layer0` (configs[2]), `flat_ivf_probe`, `cpu_baseline`.
 """
 from __future__ import annotations
 
@@ -484,6 +484,39 @@ def sq8_scan_roofline(vg, ctx, stream, device):
            "kernel_ms": kern_ms, "bytes_per_launch": n * DIM, "search_call_ms": e0.elapsed_time(e1) / reps}
     idx.close()
     sq.close()
+    return res
+
+
+def int4_scan_roofline(vg, ctx, stream, device):
+    """Int4Quantizer.L2DistanceBatch / L2Distance of one query over 4M x 768 INT4 codes
+    (int4.go:133-164; 384 B per code = 1.54 GB per pass), both summation orders."""
+    n = 4_000_000
+    g = torch.Generator(device=device)
+    g.manual_seed(19)
+    train = torch.randn((65536, DIM), generator=g, device=device)
+    iq = vg.Int4Quantizer(ctx, DIM)
+    iq.train(train)
+    codes = torch.randint(0, 256, (n, DIM // 2), dtype=torch.uint8, device=device, generator=g)
+    q = torch.randn((DIM,), device=device, generator=g)
+    out = torch.empty((n,), device=device)
+    res = {"workload": "int4_l2_distance_4Mx768_nq1", "bound": "hbm", "peak": PEAK_HBM_GBS, "unit": "GB/s",
+           "bytes_per_launch": n * DIM // 2, "kernel": "int4_scan_tab_kernel",
+           "note": "bound by LDS issue next to the vector ALU (768 lookups of the dim x 16 table per code, conflict-free): DESIGN.md section 4"}
+    for name, fn in (("batch_order", iq.l2_distance_batch), ("lookup_table_order", iq.l2_distance)):
+        for _ in range(100):
+            fn(q, codes, out=out, stream=stream)
+        torch.cuda.synchronize()
+        ctx.profile_read("int4_scan")
+        ctx.profile_enable(True)
+        for _ in range(20):
+            fn(q, codes, out=out, stream=stream)
+        torch.cuda.synchronize()
+        launches, ms = ctx.profile_read("int4_scan")
+        ctx.profile_enable(False)
+        kern_ms = ms / max(launches, 1)
+        achieved = n * DIM / 2 / (kern_ms * 1e-3) / 1e9
+        res[name] = {"kernel_ms": kern_ms, "achieved": achieved, "frac": achieved / PEAK_HBM_GBS}
+    iq.close()
     return res
 
 
@@ -1104,6 +1137,7 @@ def main():
         leg("adc_scan", lambda: adc_scan_roofline(vg, ctx, stream, device, with_cpu=cpu_on))
         leg("rabitq_scan", lambda: rabitq_scan_roofline(vg, ctx, stream, device, with_cpu=cpu_on))
         leg("sq8_scan", lambda: sq8_scan_roofline(vg, ctx, stream, device))
+        leg("int4_scan", lambda: int4_scan_roofline(vg, ctx, stream, device))
     if cpu_on:
         leg("cpu_baseline", lambda: cpu_baseline(rows.cpu().numpy(), queries[1].cpu().numpy(), K))
         if "value" in out["cpu_baseline"]:

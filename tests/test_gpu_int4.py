@@ -51,6 +51,23 @@ def test_train_encode_decode_distances_match_oracle(vg, ctx, n, dim):
     assert np.array_equal(bits(iq.l2_distance(q, codes)), bits(want))
 
 
+# dim % 64 == 0: both distances run as streaming scans (int4_scan_kernel: rows turned through LDS, pair table);
+# row pieces of 128 / 96 / 64 / 32 bytes, ragged last tile and workgroup
+@pytest.mark.parametrize("n,dim", [(700, 192), (1000, 320), (513, 1024), (64, 64), (65, 256), (3000, 768)])
+def test_int4_scan_kernels_match_oracle(vg, ctx, n, dim):
+    rng = np.random.default_rng(n * 7 + dim)
+    x = (rng.standard_normal((n, dim)) * rng.random(dim) * 3).astype(np.float32)
+    iq = vg.Int4Quantizer(ctx, dim); iq.train(x)
+    ref = o.Int4Quantizer(dim); ref.train(x)
+    codes = iq.encode(x)
+    assert np.array_equal(codes, ref.encode_batch(x))
+    for qi in range(2):
+        q = (rng.standard_normal(dim) * 2).astype(np.float32)
+        assert np.array_equal(bits(iq.l2_distance_batch(q, codes)), bits(ref.l2_distance_batch(q, codes)))
+        want = np.array([ref.l2_distance(q, c) for c in codes], np.float32)
+        assert np.array_equal(bits(iq.l2_distance(q, codes)), bits(want))
+
+
 def test_set_params_is_unmarshal_binary(vg, ctx):
     rng = np.random.default_rng(4)
     dim = 48

@@ -11,6 +11,8 @@
 // for every lane: they are read through wave-uniform (scalar) loads, not per lane.
 #include <algorithm>
 
+#include <type_traits>
+
 #include "vg_device.hpp"
 #include "vg_internal.hpp"
 
@@ -736,6 +738,280 @@ __global__ __launch_bounds__(256) void int4_l2_precomputed_kernel(const float *_
     out[row] = int4_l2_precomputed(query, codes + row * ((dim + 1) / 2), dim, table);
 }
 
+// Both distances as a streaming scan (dim % 64 == 0): the lane-per-row kernels above read their rows 16 bytes at a
+// time at a dim/2-byte stride (64 lines per wave-instruction; 1.0 / 2.2 TB/s of codes at dim 768) and look every value
+// up in a 48 KiB table.  Here a wave takes 64 rows: 128-byte pieces of them (256 dimensions) arrive as whole lines
+// (8 lanes per row) and are turned through the wave's LDS (row stride 144 bytes = 16 x 9: the 16 lanes of a
+// ds_read_b128 group never share a bank slot), each lane then walks ITS row; a code byte becomes its two values by ONE
+// read of a 256-entry pair table in LDS (PRE: float(v) / 15, the table's own factor — int4.go:152-163; batch order:
+// float(v) * 0x3d888889 — int4_avx512.c:35), the two values of a byte are neighbouring AVX-512 lanes, so every step is
+// one packed-fp32 instruction on the pair with scalar-loaded diff / min / query: 2 - 2.5 vector instructions per
+// dimension.  Accumulators and their order are the kernels' above: PRE — both 16-element halves of a 32-block into
+// sum[]; batch order — sub-blocks 0, 1 of a 64-block into s1, 2, 3 into s2, s1 += s2 at the end.
+constexpr int kI4Waves = 4;
+constexpr int kI4Stride = 144;  // LDS bytes per staged row piece (128 + 16)
+template <bool PRE>
+__global__ __launch_bounds__(kI4Waves * 64) void int4_scan_kernel(const float *__restrict__ query,
+                                                                  const uint8_t *__restrict__ codes, int64_t n, int dim,
+                                                                  const float *__restrict__ mins,
+                                                                  const float *__restrict__ diff, float *__restrict__ out)
+{
+    __shared__ vg_f2v pairs[256];
+    __shared__ __attribute__((aligned(16))) unsigned char stage_all[kI4Waves][64 * kI4Stride];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    {
+        const float sc = __uint_as_float(0x3d888889u);
+        const int b = tid;  // 256 threads, 256 entries
+        vg_f2v a;
+        a.x = PRE ? static_cast<float>(b >> 4) / 15.0f : static_cast<float>(b >> 4) * sc;
+        a.y = PRE ? static_cast<float>(b & 15) / 15.0f : static_cast<float>(b & 15) * sc;
+        pairs[b] = a;
+    }
+    __syncthreads();
+    const int64_t tile = static_cast<int64_t>(blockIdx.x) * kI4Waves + wave;
+    const int64_t row0 = tile * 64;
+    if (row0 >= n) return;
+    unsigned char *stage = stage_all[wave];
+    const int row_bytes = dim >> 1;
+    vg_f2v s1[8], s2[8];
+#pragma unroll
+    for (int p = 0; p < 8; p++) s1[p] = s2[p] = vg_f2v{0.0f, 0.0f};
+    // one 32-element block (16 code bytes, `piece` of the staged row piece) into the accumulators
+    auto block32 = [&](int cb0, int piece, auto second_c) {
+        const uint4 c = *reinterpret_cast<const uint4 *>(stage + lane * kI4Stride + piece * 16);
+        const uint32_t w[4] = {c.x, c.y, c.z, c.w};
+        const int j0 = (cb0 + piece * 16) * 2;    // first dimension of the block
+        constexpr bool second = !PRE && decltype(second_c)::value;  // batch order: sub-blocks 2, 3 of the 64-block
+#pragma unroll
+        for (int b = 0; b < 16; b++) {
+            const uint32_t byte = (w[b >> 2] >> (8 * (b & 3))) & 0xFFu;
+            const int j = j0 + 2 * b;
+            const vg_f2v a = pairs[byte];
+            const vg_f2v df = *reinterpret_cast<const vg_f2v *>(diff + j);
+            const vg_f2v mn = *reinterpret_cast<const vg_f2v *>(mins + j);
+            const vg_f2v qq = *reinterpret_cast<const vg_f2v *>(query + j);
+            vg_f2v t;
+            if (PRE) {
+                t = a * df;
+                t = t + mn;
+            } else {
+                t = __builtin_elementwise_fma(a, df, mn);
+            }
+            const vg_f2v d = qq - t;
+            if (second)
+                s2[b & 7] = __builtin_elementwise_fma(d, d, s2[b & 7]);
+            else
+                s1[b & 7] = __builtin_elementwise_fma(d, d, s1[b & 7]);
+        }
+    };
+    // rows past n re-read row n - 1 (their result is not stored); loads are unguarded (a guarded load makes hipcc
+    // wait for the previous one at the join)
+    if ((row_bytes & 127) == 0) {
+        // whole 128-byte pieces: 8 lanes per row, the next piece's lines in flight while this one is scored
+        const int r = lane >> 3, part = lane & 7;
+        const uint8_t *src[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int64_t row = row0 + r + 8 * k < n ? row0 + r + 8 * k : n - 1;
+            src[k] = codes + row * row_bytes + part * 16;
+        }
+        uint4 u[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) u[k] = load_stream(reinterpret_cast<const uint4 *>(src[k]));
+        for (int cb0 = 0; cb0 < row_bytes; cb0 += 128) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) *reinterpret_cast<uint4 *>(stage + (r + 8 * k) * kI4Stride + part * 16) = u[k];
+            const int nxt = cb0 + 128 < row_bytes ? cb0 + 128 : cb0;  // (the last piece again: unused)
+#pragma unroll
+            for (int k = 0; k < 8; k++) u[k] = load_stream(reinterpret_cast<const uint4 *>(src[k] + nxt));
+            for (int piece = 0; piece < 8; piece += 2) {
+                block32(cb0, piece, std::false_type{});
+                block32(cb0, piece + 1, std::true_type{});
+            }
+        }
+    } else {
+        for (int cb0 = 0; cb0 < row_bytes; cb0 += 128) {
+            const int cb = row_bytes - cb0 < 128 ? row_bytes - cb0 : 128;  // bytes of this piece (a multiple of 32)
+            const int per_row = cb >> 4;                                    // 16-byte units per row
+            const int units = 64 * per_row;
+            uint4 u[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const int e = lane + 64 * k < units ? lane + 64 * k : units - 1;
+                const int r = e / per_row, part = e - r * per_row;
+                const int64_t row = row0 + r < n ? row0 + r : n - 1;
+                u[k] = load_stream(reinterpret_cast<const uint4 *>(codes + row * row_bytes + cb0 + part * 16));
+            }
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const int e = lane + 64 * k;
+                if (e < units) {
+                    const int r = e / per_row, part = e - r * per_row;
+                    *reinterpret_cast<uint4 *>(stage + r * kI4Stride + part * 16) = u[k];
+                }
+            }
+            for (int piece = 0; piece < per_row; piece += 2) {  // per_row is even (dim % 64 == 0)
+                block32(cb0, piece, std::false_type{});
+                block32(cb0, piece + 1, std::true_type{});
+            }
+        }
+    }
+    float s16[16];
+#pragma unroll
+    for (int p = 0; p < 8; p++) {
+        const vg_f2v v = PRE ? s1[p] : s1[p] + s2[p];
+        s16[2 * p] = v.x;
+        s16[2 * p + 1] = v.y;
+    }
+    const float total = reduce16_regs(s16);
+    if (row0 + lane < n) out[row0 + lane] = total;
+}
+
+// The same scan with the lookups free of bank conflicts (dim <= 1024): the pair table above puts a wave's 64 random
+// bytes on 32 bank slots — 62 % of its LDS cycles were conflicts and the LDS array was 89 % busy (3.65 TB/s of codes).
+// Here the workgroup (16 waves, one per CU, persistent over the tiles) builds the quantizer's own dim x 16 value table
+// in LDS (48 KiB at dim 768; PRE: float(v) / 15 * diff + min as BuildInt4LookupTable does; batch order:
+// fma(float(v) * 0x3d888889, diff, min)): the 64 lanes of a lookup share the dimension, so they touch at most 16
+// consecutive dwords — distinct banks or the same address.  A lookup's address is ONE v_perm_b32 (byte k of the
+// pre-masked nibbles under the block's base; the dimension's offset is the instruction's immediate), a dimension
+// costs 2 vector instructions (the table holds query[j] - value: a launch serves one query) and 2 LDS cycles per wave
+// instead of ~3.5.  Rows are staged 64 bytes at a time (stride 80 = 16 x 5).
+// (the lookups are issued in inline asm, eight at a time — the four code bytes of one dword — and a group is retired by
+// a COUNTED wait while the next group's eight are in flight: hipcc re-used one register pair per lookup and waited out
+// every LDS round trip.  hipcc does not track asm loads: every value is an in/out operand of the wait statement, so no
+// consumer can be scheduled above it.  LDS operations retire in order, scalar loads do not: nothing in the loop may
+// issue one, which is one reason the table holds query[j] - value and not the value)
+template <int OFF>
+__device__ __forceinline__ float i4_lds_read(uint32_t addr)
+{
+    float v;
+    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+    return v;
+}
+struct I4Vals8 {
+    float v[8];  // (hi, lo) of code bytes 4 WI .. 4 WI + 3
+};
+template <int N>
+__device__ __forceinline__ void i4_lds_wait(I4Vals8 &x)
+{
+    asm volatile("s_waitcnt lgkmcnt(%8)"
+                 : "+v"(x.v[0]), "+v"(x.v[1]), "+v"(x.v[2]), "+v"(x.v[3]), "+v"(x.v[4]), "+v"(x.v[5]), "+v"(x.v[6]), "+v"(x.v[7])
+                 : "n"(N));
+}
+template <int WI>
+__device__ __forceinline__ void i4_issue_word(I4Vals8 &x, uint32_t w, uint32_t base)
+{
+    const uint32_t hi4 = (w >> 2) & 0x3C3C3C3Cu;  // byte k: 4 * high nibble of code byte 4 WI + k
+    const uint32_t lo4 = (w << 2) & 0x3C3C3C3Cu;  //         4 * low nibble
+#define VG_I4_ONE(K)                                                                                              \
+    x.v[2 * K] = i4_lds_read<(2 * (4 * WI + K)) * 64>(__builtin_amdgcn_perm(base, hi4, 0x07060500u | K));         \
+    x.v[2 * K + 1] = i4_lds_read<(2 * (4 * WI + K) + 1) * 64>(__builtin_amdgcn_perm(base, lo4, 0x07060500u | K));
+    VG_I4_ONE(0)
+    VG_I4_ONE(1)
+    VG_I4_ONE(2)
+    VG_I4_ONE(3)
+#undef VG_I4_ONE
+}
+
+constexpr int kI4TabWaves = 16;
+constexpr int kI4TabStride = 80;
+constexpr int kI4TabMaxDim = 1024;
+template <bool PRE>
+__global__ __launch_bounds__(kI4TabWaves * 64) void int4_scan_tab_kernel(const float *__restrict__ query,
+                                                                         const uint8_t *__restrict__ codes, int64_t n, int dim,
+                                                                         const float *__restrict__ mins,
+                                                                         const float *__restrict__ diff, float *__restrict__ out)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char i4smem[];
+    float *table = reinterpret_cast<float *>(i4smem);  // [dim][16]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    unsigned char *stage = i4smem + static_cast<size_t>(dim) * 64 + wave * (64 * kI4TabStride);
+    for (int e = tid; e < dim * 16; e += kI4TabWaves * 64) {
+        const int d = e >> 4, v = e & 15;
+        float t;
+        if (PRE) {
+            const float a = static_cast<float>(v) / 15.0f;  // int4_table_kernel
+            const float b = a * diff[d];
+            t = b + mins[d];
+        } else {
+            const float f = static_cast<float>(v) * __uint_as_float(0x3d888889u);  // int4_l2_batch_kernel
+            t = __builtin_fmaf(f, diff[d], mins[d]);
+        }
+        table[e] = query[d] - t;  // the difference the kernels square: one query per launch
+    }
+    __syncthreads();
+    const int row_bytes = dim >> 1;
+    const int64_t n_tiles = (n + 63) / 64;
+    const int r = lane >> 2, part = lane & 3;  // staging: 4 lanes per row, 16 rows per load
+    for (int64_t tile = static_cast<int64_t>(blockIdx.x) * kI4TabWaves + wave; tile < n_tiles;
+         tile += static_cast<int64_t>(gridDim.x) * kI4TabWaves) {
+        const int64_t row0 = tile * 64;
+        // (named variables, not arrays: under this kernel's 1024-thread bound hipcc kept `uint4 u[4]` in scratch memory
+        // and waited out every load before storing it there)
+        auto row_ptr = [&](int k) {
+            const int64_t row = row0 + r + 16 * k < n ? row0 + r + 16 * k : n - 1;  // past n: row n - 1 again, not stored
+            return codes + row * row_bytes + part * 16;
+        };
+        const uint8_t *src0 = row_ptr(0), *src1 = row_ptr(1), *src2 = row_ptr(2), *src3 = row_ptr(3);
+        vg_f2v s1[8], s2[8];
+#pragma unroll
+        for (int p = 0; p < 8; p++) s1[p] = s2[p] = vg_f2v{0.0f, 0.0f};
+        uint4 u0 = *reinterpret_cast<const uint4 *>(src0), u1 = *reinterpret_cast<const uint4 *>(src1),
+              u2 = *reinterpret_cast<const uint4 *>(src2), u3 = *reinterpret_cast<const uint4 *>(src3);
+        unsigned char *wr = stage + r * kI4TabStride + part * 16;
+        for (int cb0 = 0; cb0 < row_bytes; cb0 += 64) {
+            *reinterpret_cast<uint4 *>(wr) = u0;
+            *reinterpret_cast<uint4 *>(wr + 16 * kI4TabStride) = u1;
+            *reinterpret_cast<uint4 *>(wr + 32 * kI4TabStride) = u2;
+            *reinterpret_cast<uint4 *>(wr + 48 * kI4TabStride) = u3;
+            const int nxt = cb0 + 64 < row_bytes ? cb0 + 64 : cb0;  // (the last piece again: unused)
+            u0 = *reinterpret_cast<const uint4 *>(src0 + nxt);
+            u1 = *reinterpret_cast<const uint4 *>(src1 + nxt);
+            u2 = *reinterpret_cast<const uint4 *>(src2 + nxt);
+            u3 = *reinterpret_cast<const uint4 *>(src3 + nxt);
+#pragma unroll
+            for (int piece = 0; piece < 4; piece++) {
+                const uint4 c = *reinterpret_cast<const uint4 *>(stage + lane * kI4TabStride + piece * 16);
+                const uint32_t w[4] = {c.x, c.y, c.z, c.w};
+                const int j0 = (cb0 + piece * 16) * 2;  // first dimension of this 32-element block
+                // its table rows: the table is the first thing in LDS (byte 0: nothing static in this kernel), j0 * 64 is a
+                // multiple of 2048, so the low byte is free for the nibble
+                const uint32_t base = static_cast<uint32_t>(j0) * 64u;
+                vg_f2v *acc = (!PRE && (piece & 1)) ? s2 : s1;
+                auto take = [&](const I4Vals8 &x, int wi) {  // code bytes 4 wi .. 4 wi + 3: accumulator pairs (4 wi + k) & 7
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const vg_f2v d = {x.v[2 * k], x.v[2 * k + 1]};
+                        acc[(4 * wi + k) & 7] = __builtin_elementwise_fma(d, d, acc[(4 * wi + k) & 7]);
+                    }
+                };
+                I4Vals8 va, vb;
+                i4_issue_word<0>(va, w[0], base);
+                i4_issue_word<1>(vb, w[1], base);
+                i4_lds_wait<8>(va);
+                take(va, 0);
+                i4_issue_word<2>(va, w[2], base);
+                i4_lds_wait<8>(vb);
+                take(vb, 1);
+                i4_issue_word<3>(vb, w[3], base);
+                i4_lds_wait<8>(va);
+                take(va, 2);
+                i4_lds_wait<0>(vb);
+                take(vb, 3);
+            }
+        }
+        float s16[16];
+#pragma unroll
+        for (int p = 0; p < 8; p++) {
+            const vg_f2v v = PRE ? s1[p] : s1[p] + s2[p];
+            s16[2 * p] = v.x;
+            s16[2 * p + 1] = v.y;
+        }
+        const float total = reduce16_regs(s16);
+        if (row0 + lane < n) out[row0 + lane] = total;
+    }
+}
+
 static int sq_slices(int64_t nq, int64_t n_tiles, int cus)
 {
     int64_t s = (4 * static_cast<int64_t>(cus) + nq - 1) / nq;  // ~4 workgroups per CU
@@ -1181,7 +1457,26 @@ VG_API int32_t vg_int4_l2_distance_batch(vg_int4 *iq, const float *query, const 
     VG_TRY(q.init(query, static_cast<size_t>(iq->dim), st));
     VG_TRY(c.init(codes, static_cast<size_t>(n * cs), st));
     VG_TRY(o.init(out, static_cast<size_t>(n), st));
-    if (precomputed)
+    const bool scan = iq->dim % 64 == 0 && (reinterpret_cast<uintptr_t>(c.ptr) & 15) == 0;
+    const unsigned scan_blocks = static_cast<unsigned>(((n + 63) / 64 + vg::kI4Waves - 1) / vg::kI4Waves);
+    vg::ProfScope prof(iq->ctx, "int4_scan", st);
+    if (scan && iq->dim % 128 == 0 && iq->dim <= vg::kI4TabMaxDim) {
+        const size_t lds = static_cast<size_t>(iq->dim) * 64 + static_cast<size_t>(vg::kI4TabWaves) * 64 * vg::kI4TabStride;
+        const int64_t tiles = (n + 63) / 64;
+        const unsigned blocks = static_cast<unsigned>(std::min<int64_t>((tiles + vg::kI4TabWaves - 1) / vg::kI4TabWaves,
+                                                                         std::max(iq->ctx->compute_units, 1)));
+        auto kern = precomputed ? vg::int4_scan_tab_kernel<true> : vg::int4_scan_tab_kernel<false>;
+        VG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   static_cast<int>(lds)));
+        VG_LAUNCH(kern, dim3(blocks), dim3(vg::kI4TabWaves * 64), lds, st, q.ptr, c.ptr, n, iq->dim, iq->d_min, iq->d_diff,
+                  o.ptr);
+    } else if (scan && precomputed)
+        VG_LAUNCH(vg::int4_scan_kernel<true>, dim3(scan_blocks), dim3(vg::kI4Waves * 64), 0, st, q.ptr, c.ptr, n, iq->dim,
+                  iq->d_min, iq->d_diff, o.ptr);
+    else if (scan)
+        VG_LAUNCH(vg::int4_scan_kernel<false>, dim3(scan_blocks), dim3(vg::kI4Waves * 64), 0, st, q.ptr, c.ptr, n, iq->dim,
+                  iq->d_min, iq->d_diff, o.ptr);
+    else if (precomputed)
         VG_LAUNCH(vg::int4_l2_precomputed_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, st, q.ptr,
                   c.ptr, n, iq->dim, iq->d_table, o.ptr);
     else
