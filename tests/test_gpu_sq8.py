@@ -59,10 +59,11 @@ def test_set_bounds_and_reference_kats(vg, ctx):
     assert d[0] >= -0.01 and d[1] <= 1.01  # clamping, quantizer_test.go:148-179
 
 
-@pytest.mark.parametrize("dim", [1, 7, 8, 15, 16, 17, 31, 32, 33, 100, 768])
-def test_l2_distance_batch_matches_oracle(vg, ctx, dim):
-    rng = np.random.default_rng(dim)
-    n = 300
+# dim % 128 == 0: rows turned through LDS (sq8_l2_batch_turn_kernel); n = 300: ragged last tile, 1000: several workgroups
+@pytest.mark.parametrize("n", [300, 1000])
+@pytest.mark.parametrize("dim", [1, 7, 8, 15, 16, 17, 31, 32, 33, 100, 128, 256, 768, 1024])
+def test_l2_distance_batch_matches_oracle(vg, ctx, dim, n):
+    rng = np.random.default_rng(dim + n)
     x = rng.standard_normal((n, dim)).astype(np.float32)
     sq = vg.ScalarQuantizer(ctx, dim); sq.train(x)
     ref = o.ScalarQuantizer(dim); ref.train(x)
