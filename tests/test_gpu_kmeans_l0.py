@@ -97,6 +97,19 @@ def test_bounded_batch_golden_and_kats(vg, ctx, golden_dir):
         assert bits(d[i]) == bits(full) and bool(e[i]) == bool(full > bounds[i])
 
 
+# m % 16 == 0: table in LDS, rows turned through LDS (adc_lookup_batch_lds_kernel; m = 96 its own instance, m = 128
+# fewer waves); other m: one lane per row.  Ragged last tile, several workgroups
+@pytest.mark.parametrize("m", [16, 32, 96, 112, 128, 100, 144])
+@pytest.mark.parametrize("n", [1, 63, 65, 1500])
+def test_adc_lookup_batch_matches_oracle(vg, ctx, m, n):
+    rng = np.random.default_rng(m * 31 + n)
+    table = rng.standard_normal(m * 256).astype(np.float32)
+    codes = rng.integers(0, 256, (n, m), dtype=np.uint8)
+    got = vg.pq_adc_lookup_batch(ctx, table, codes, m)
+    want = np.array([o.adc(table, codes[i], m) for i in range(n)], np.float32)
+    assert np.array_equal(bits(got), bits(want))
+
+
 def test_adc_lookup_batch_golden_and_kats(vg, ctx, golden_dir):
     g = np.load(golden_dir / "l0_ref.npz")   # outputs of the compiled pqAdcLookupAvx512
     to = co = 0

@@ -366,6 +366,63 @@ __global__ void adc_lookup_batch_kernel(const float *__restrict__ table, const u
     out[i] = total;
 }
 
+// The same sums as a streaming scan (m % 16 == 0, table <= 128 KiB): the kernel above reads a code byte by byte at an
+// m-byte stride and every table entry from global memory (0.86 TB/s of codes at m = 96).  Here the table sits in LDS
+// (m KiB, one persistent workgroup per CU), a wave takes 64 rows — one contiguous 64 m-byte block, read as whole lines —
+// and turns them through its LDS (row stride 16 x odd: conflict-free ds_read_b128); each lane then walks ITS code:
+// acc[l] += table[(j + l) * 256 + code[j + l]] for j ascending, the reduce tree — the arithmetic of pqAdcLookupAvx512.
+// (The re-tiled index scan, pq_adc_scan_kernel, pre-rotates the codes per lane so that its lookups avoid most bank
+// conflicts; a row-major batch cannot, and runs at the LDS rate of random 4-byte reads.)
+template <int M16>  // m / 16 when known at compile time, 0 = any
+__global__ __launch_bounds__(512) void adc_lookup_batch_lds_kernel(const float *__restrict__ table, const uint8_t *__restrict__ codes,
+                                                                   int m_rt, int stride, int64_t n, float *__restrict__ out)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char adc_smem[];
+    const int m = M16 ? M16 * 16 : m_rt;
+    const int m16 = M16 ? M16 : m_rt >> 4;
+    float *lut = reinterpret_cast<float *>(adc_smem);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, waves = blockDim.x >> 6;
+    {
+        const float4 *src = reinterpret_cast<const float4 *>(table);
+        float4 *dst = reinterpret_cast<float4 *>(lut);
+        for (int i = tid; i < m * 64; i += blockDim.x) dst[i] = src[i];
+    }
+    __syncthreads();
+    unsigned char *stage = adc_smem + static_cast<size_t>(m) * 1024 + static_cast<size_t>(wave) * 64 * stride;
+    const int64_t n_tiles = (n + 63) / 64;
+    const int units = 64 * m16;  // 16-byte units of a tile
+    for (int64_t tile = static_cast<int64_t>(blockIdx.x) * waves + wave; tile < n_tiles;
+         tile += static_cast<int64_t>(gridDim.x) * waves) {
+        const int64_t row0 = tile * 64;
+        const int64_t last_unit = (n - row0 < 64 ? n - row0 : 64) * m16 - 1;  // the block's last valid unit
+        const uint8_t *blk = codes + row0 * m;
+        for (int e0 = 0; e0 < units; e0 += 64) {
+            const int e = e0 + lane;
+            const int64_t ec = e <= last_unit ? e : last_unit;  // past n: valid memory, values unused
+            const uint4 u = *reinterpret_cast<const uint4 *>(blk + ec * 16);
+            if (e < units) {
+                const int r = e / m16, part = e - r * m16;
+                *reinterpret_cast<uint4 *>(stage + r * stride + part * 16) = u;
+            }
+        }
+        float acc[16];
+#pragma unroll
+        for (int l = 0; l < 16; l++) acc[l] = 0.0f;
+        for (int g = 0; g < m16; g++) {
+            const uint4 c = *reinterpret_cast<const uint4 *>(stage + lane * stride + g * 16);
+            const uint32_t w[4] = {c.x, c.y, c.z, c.w};
+            const float *row = lut + g * 16 * 256;
+            float t[16];
+#pragma unroll
+            for (int l = 0; l < 16; l++) t[l] = row[l * 256 + ((w[l >> 2] >> (8 * (l & 3))) & 0xFFu)];
+#pragma unroll
+            for (int l = 0; l < 16; l++) acc[l] = acc[l] + t[l];
+        }
+        const float total = reduce16_regs(acc);
+        if (row0 + lane < n) out[row0 + lane] = total;
+    }
+}
+
 }  // namespace vg
 
 // pick the register-resident assignment when the row shape allows it
@@ -593,8 +650,23 @@ VG_API int32_t vg_pq_adc_lookup_batch(vg_ctx *ctx, const float *table, const uin
     VG_TRY(t.init(table, static_cast<size_t>(m) * 256, st));
     VG_TRY(c.init(codes, static_cast<size_t>(n) * m, st));
     VG_TRY(o.init(out, static_cast<size_t>(n), st));
-    VG_LAUNCH(vg::adc_lookup_batch_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, st,
-                       t.ptr, c.ptr, static_cast<int>(m), n, o.ptr);
+    // table in LDS + rows turned through LDS when both fit (m % 16 == 0)
+    const int stride = static_cast<int>(16 * ((m >> 4) | 1));
+    const int64_t lds_free = 160 * 1024 - m * 1024;
+    const int waves = m > 0 && m % 16 == 0 ? static_cast<int>(std::min<int64_t>(8, lds_free / (64 * stride))) : 0;
+    const bool aligned = ((reinterpret_cast<uintptr_t>(c.ptr) | reinterpret_cast<uintptr_t>(t.ptr)) & 15) == 0;
+    if (waves >= 2 && aligned) {
+        const size_t lds = static_cast<size_t>(m) * 1024 + static_cast<size_t>(waves) * 64 * stride;
+        const int64_t tiles = (n + 63) / 64;
+        const unsigned blocks = static_cast<unsigned>(std::min<int64_t>((tiles + waves - 1) / waves, std::max(ctx->compute_units, 1)));
+        auto kern = m == 96 ? vg::adc_lookup_batch_lds_kernel<6> : vg::adc_lookup_batch_lds_kernel<0>;
+        VG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   static_cast<int>(lds)));
+        VG_LAUNCH(kern, dim3(blocks), dim3(waves * 64), lds, st, t.ptr, c.ptr, static_cast<int>(m), stride, n, o.ptr);
+    } else {
+        VG_LAUNCH(vg::adc_lookup_batch_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, st,
+                           t.ptr, c.ptr, static_cast<int>(m), n, o.ptr);
+    }
     VG_TRY(o.finish());
     if (o.on_host()) VG_HIP(hipStreamSynchronize(st));
     return VG_OK;
