@@ -36,3 +36,25 @@ timed("pq_adc_lookup_batch 10M x 96 B", lambda: vg.pq_adc_lookup_batch(ctx, tabl
 sq = vg.ScalarQuantizer(ctx, D); sq.train(rows[:65536])
 sc = sq.encode(rows)
 timed("ScalarQuantizer.l2_distance_batch 1M x 768 B", lambda: sq.l2_distance_batch(q, sc, out=out), N * D)
+# quantizer batch methods (one query against n codes; encode / decode of n rows)
+pq = vg.ProductQuantizer(ctx, D, 96, 256); pq.train(rows[:32768], iters=3, seed=1)
+pcodes = pq.encode(rows)
+timed("ProductQuantizer.asymmetric_distance 1M x 96 B", lambda: pq.asymmetric_distance(q, pcodes, out=out), N * 96)
+timed("ProductQuantizer.encode 1M x 768 fp32", lambda: pq.encode(rows, out=pcodes), N * D * 4, reps=3, warm=2)
+dec = torch.empty((N, D), device=dev)
+timed("ProductQuantizer.decode 1M x 96 B -> fp32", lambda: pq.decode(pcodes, out=dec), N * D * 4)
+rq = vg.RaBitQuantizer(ctx, D); rcodes = rq.encode(rows)
+timed("RaBitQuantizer.distance 1M x 100 B", lambda: rq.distance(q, rcodes, out=out), N * 100)
+timed("RaBitQuantizer.encode 1M x 768 fp32", lambda: rq.encode(rows, out=rcodes), N * D * 4)
+timed("ScalarQuantizer.encode 1M x 768 fp32", lambda: sq.encode(rows, out=sc), N * D * 4)
+timed("ScalarQuantizer.decode 1M x 768 B -> fp32", lambda: sq.decode(sc, out=dec), N * D * 4)
+iq = vg.Int4Quantizer(ctx, D); iq.train(rows[:65536]); icodes = iq.encode(rows)
+timed("Int4Quantizer.encode 1M x 768 fp32", lambda: iq.encode(rows, out=icodes), N * D * 4)
+timed("Int4Quantizer.decode 1M x 384 B -> fp32", lambda: iq.decode(icodes, out=dec), N * D * 4)
+bq = vg.BinaryQuantizer(ctx, D); bq.train(rows[:65536]) if hasattr(bq, "train") else None
+bcodes = bq.encode(rows)
+oi2 = torch.empty(N, dtype=torch.int32, device=dev)
+timed("BinaryQuantizer.compute_hamming_distance 1M x 96 B", lambda: bq.compute_hamming_distance(q, bcodes, out=oi2), N * 96)
+timed("BinaryQuantizer.encode 1M x 768 fp32", lambda: bq.encode(rows, out=bcodes), N * D * 4)
+bnd = torch.full((1,), 1400.0, device=dev)
+timed("squared_l2_bounded_batch 1M x 768 fp32", lambda: vg.squared_l2_bounded_batch(ctx, q, rows, D, bnd), N * D * 4)
