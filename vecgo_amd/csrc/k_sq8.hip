@@ -139,6 +139,60 @@ __global__ void sq8_decode_kernel(const uint8_t *__restrict__ codes, int64_t tot
     out[i] = t + mins[d];
 }
 
+// The element kernels above spend their time on `i % dim` (a 64-bit division per element): 1.6 - 1.75 TB/s.  dim % 4
+// == 0 and 16-byte aligned buffers: a thread owns four consecutive dimensions (its parameters loaded once) and walks
+// kRowsPerThread rows — no division, 16-byte loads / stores, the same operations per element.
+constexpr int kRowsPerThread = 16;  // at least; more when n / 16 exceeds the grid's y range
+static inline int rows_per_thread(int64_t n) { return static_cast<int>(std::max<int64_t>(kRowsPerThread, (n + 65534) / 65535)); }
+__global__ __launch_bounds__(256) void sq8_encode4_kernel(const float *__restrict__ v, int64_t n, int dim,
+                                                          const float *__restrict__ mins, const float *__restrict__ maxs,
+                                                          const float *__restrict__ scales, uint8_t *__restrict__ out, int rpt)
+{
+    const int cg = blockIdx.x * blockDim.x + threadIdx.x;
+    if (cg * 4 >= dim) return;
+    const float4 mn = *reinterpret_cast<const float4 *>(mins + cg * 4), mx = *reinterpret_cast<const float4 *>(maxs + cg * 4),
+                 sc = *reinterpret_cast<const float4 *>(scales + cg * 4);
+    const int64_t r0 = static_cast<int64_t>(blockIdx.y) * rpt;
+    auto enc = [](float val, float lo, float hi, float s) -> uint32_t {
+        if (val < lo)
+            val = lo;
+        else if (val > hi)
+            val = hi;
+        const float normalized = (val - lo) * s;
+        const float r = normalized + 0.5f;
+        return static_cast<uint32_t>(static_cast<uint8_t>(static_cast<int>(r)));  // Go uint8(float32): truncation
+    };
+    for (int64_t row = r0; row < r0 + rpt && row < n; row++) {
+        const float4 x = *reinterpret_cast<const float4 *>(v + row * dim + cg * 4);
+        const uint32_t w = enc(x.x, mn.x, mx.x, sc.x) | (enc(x.y, mn.y, mx.y, sc.y) << 8) | (enc(x.z, mn.z, mx.z, sc.z) << 16) |
+                           (enc(x.w, mn.w, mx.w, sc.w) << 24);
+        *reinterpret_cast<uint32_t *>(out + row * dim + cg * 4) = w;
+    }
+}
+__global__ __launch_bounds__(256) void sq8_decode4_kernel(const uint8_t *__restrict__ codes, int64_t n, int dim,
+                                                          const float *__restrict__ mins, const float *__restrict__ inv,
+                                                          float *__restrict__ out, int rpt)
+{
+    const int cg = blockIdx.x * blockDim.x + threadIdx.x;
+    if (cg * 4 >= dim) return;
+    const float4 mn = *reinterpret_cast<const float4 *>(mins + cg * 4), iv = *reinterpret_cast<const float4 *>(inv + cg * 4);
+    const int64_t r0 = static_cast<int64_t>(blockIdx.y) * rpt;
+    for (int64_t row = r0; row < r0 + rpt && row < n; row++) {
+        const uint32_t w = *reinterpret_cast<const uint32_t *>(codes + row * dim + cg * 4);
+        float4 o;
+        float t;
+        t = static_cast<float>(w & 0xFFu) * iv.x;
+        o.x = t + mn.x;
+        t = static_cast<float>((w >> 8) & 0xFFu) * iv.y;
+        o.y = t + mn.y;
+        t = static_cast<float>((w >> 16) & 0xFFu) * iv.z;
+        o.z = t + mn.z;
+        t = static_cast<float>(w >> 24) * iv.w;
+        o.w = t + mn.w;
+        *reinterpret_cast<float4 *>(out + row * dim + cg * 4) = o;
+    }
+}
+
 // ---- the row kernel --------------------------------------------------------------------------------
 // 16 bytes = one 16-element block of one row: lane accumulators l = 0..15 get one FMA each.
 // qv / mn / iv point at the block's 16 floats and are wave-uniform.
@@ -736,6 +790,57 @@ __global__ void int4_decode_kernel(const uint8_t *__restrict__ codes, int64_t n,
     out[t] = c + mins[i];
 }
 
+// dim % 8 == 0, aligned buffers: a thread owns eight consecutive dimensions = four code bytes (see sq8_encode4_kernel)
+__global__ __launch_bounds__(256) void int4_encode8_kernel(const float *__restrict__ v, int64_t n, int dim,
+                                                           const float *__restrict__ mins, const float *__restrict__ diff,
+                                                           uint8_t *__restrict__ out, int rpt)
+{
+    const int cg = blockIdx.x * blockDim.x + threadIdx.x;
+    if (cg * 8 >= dim) return;
+    const float4 mn0 = *reinterpret_cast<const float4 *>(mins + cg * 8), mn1 = *reinterpret_cast<const float4 *>(mins + cg * 8 + 4),
+                 df0 = *reinterpret_cast<const float4 *>(diff + cg * 8), df1 = *reinterpret_cast<const float4 *>(diff + cg * 8 + 4);
+    const int cs = dim >> 1;
+    const int64_t r0 = static_cast<int64_t>(blockIdx.y) * rpt;
+    for (int64_t row = r0; row < r0 + rpt && row < n; row++) {
+        const float4 a = *reinterpret_cast<const float4 *>(v + row * dim + cg * 8), b = *reinterpret_cast<const float4 *>(v + row * dim + cg * 8 + 4);
+        const uint32_t b0 = (int4_quant(a.x, mn0.x, df0.x) << 4) | (int4_quant(a.y, mn0.y, df0.y) & 0x0Fu);
+        const uint32_t b1 = (int4_quant(a.z, mn0.z, df0.z) << 4) | (int4_quant(a.w, mn0.w, df0.w) & 0x0Fu);
+        const uint32_t b2 = (int4_quant(b.x, mn1.x, df1.x) << 4) | (int4_quant(b.y, mn1.y, df1.y) & 0x0Fu);
+        const uint32_t b3 = (int4_quant(b.z, mn1.z, df1.z) << 4) | (int4_quant(b.w, mn1.w, df1.w) & 0x0Fu);
+        *reinterpret_cast<uint32_t *>(out + row * cs + cg * 4) = (b0 & 0xFFu) | ((b1 & 0xFFu) << 8) | ((b2 & 0xFFu) << 16) | (b3 << 24);
+    }
+}
+__global__ __launch_bounds__(256) void int4_decode8_kernel(const uint8_t *__restrict__ codes, int64_t n, int dim,
+                                                           const float *__restrict__ mins, const float *__restrict__ diff,
+                                                           float *__restrict__ out, int rpt)
+{
+    const int cg = blockIdx.x * blockDim.x + threadIdx.x;
+    if (cg * 8 >= dim) return;
+    const float4 mn0 = *reinterpret_cast<const float4 *>(mins + cg * 8), mn1 = *reinterpret_cast<const float4 *>(mins + cg * 8 + 4),
+                 df0 = *reinterpret_cast<const float4 *>(diff + cg * 8), df1 = *reinterpret_cast<const float4 *>(diff + cg * 8 + 4);
+    const int cs = dim >> 1;
+    const int64_t r0 = static_cast<int64_t>(blockIdx.y) * rpt;
+    auto dec = [](uint32_t q, float df, float mn) -> float {
+        const float a = static_cast<float>(q) / 15.0f;
+        const float c = a * df;
+        return c + mn;
+    };
+    for (int64_t row = r0; row < r0 + rpt && row < n; row++) {
+        const uint32_t w = *reinterpret_cast<const uint32_t *>(codes + row * cs + cg * 4);
+        float4 o0, o1;
+        o0.x = dec((w >> 4) & 0xFu, df0.x, mn0.x);
+        o0.y = dec(w & 0xFu, df0.y, mn0.y);
+        o0.z = dec((w >> 12) & 0xFu, df0.z, mn0.z);
+        o0.w = dec((w >> 8) & 0xFu, df0.w, mn0.w);
+        o1.x = dec((w >> 20) & 0xFu, df1.x, mn1.x);
+        o1.y = dec((w >> 16) & 0xFu, df1.y, mn1.y);
+        o1.z = dec(w >> 28, df1.z, mn1.z);
+        o1.w = dec((w >> 24) & 0xFu, df1.w, mn1.w);
+        *reinterpret_cast<float4 *>(out + row * dim + cg * 8) = o0;
+        *reinterpret_cast<float4 *>(out + row * dim + cg * 8 + 4) = o1;
+    }
+}
+
 __device__ __forceinline__ float int4_nib(const uint8_t *code, int j)
 {
     const uint8_t b = code[j >> 1];
@@ -1191,8 +1296,12 @@ VG_API int32_t vg_sq8_encode(vg_sq8 *sq, const float *vectors, int64_t n, uint8_
     vg::DevOut<uint8_t> c;
     VG_TRY(v.init(vectors, static_cast<size_t>(total), st));
     VG_TRY(c.init(codes, static_cast<size_t>(total), st));
-    VG_LAUNCH(vg::sq8_encode_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, st, v.ptr, total,
-              sq->dim, sq->d_mins, sq->d_maxs, sq->d_scales, c.ptr);
+    if (sq->dim % 4 == 0 && ((reinterpret_cast<uintptr_t>(v.ptr) | reinterpret_cast<uintptr_t>(c.ptr)) & 15) == 0)
+        VG_LAUNCH(vg::sq8_encode4_kernel, dim3((sq->dim / 4 + 255) / 256, static_cast<unsigned>((n + vg::rows_per_thread(n) - 1) / vg::rows_per_thread(n))),
+                  dim3(256), 0, st, v.ptr, n, sq->dim, sq->d_mins, sq->d_maxs, sq->d_scales, c.ptr, vg::rows_per_thread(n));
+    else
+        VG_LAUNCH(vg::sq8_encode_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, st, v.ptr, total,
+                  sq->dim, sq->d_mins, sq->d_maxs, sq->d_scales, c.ptr);
     VG_TRY(c.finish());
     return VG_OK;
 }
@@ -1211,8 +1320,12 @@ VG_API int32_t vg_sq8_decode(vg_sq8 *sq, const uint8_t *codes, int64_t n, float 
     vg::DevOut<float> o;
     VG_TRY(c.init(codes, static_cast<size_t>(total), st));
     VG_TRY(o.init(out, static_cast<size_t>(total), st));
-    VG_LAUNCH(vg::sq8_decode_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, st, c.ptr, total,
-              sq->dim, sq->d_mins, sq->d_inv, o.ptr);
+    if (sq->dim % 4 == 0 && ((reinterpret_cast<uintptr_t>(c.ptr) | reinterpret_cast<uintptr_t>(o.ptr)) & 15) == 0)
+        VG_LAUNCH(vg::sq8_decode4_kernel, dim3((sq->dim / 4 + 255) / 256, static_cast<unsigned>((n + vg::rows_per_thread(n) - 1) / vg::rows_per_thread(n))),
+                  dim3(256), 0, st, c.ptr, n, sq->dim, sq->d_mins, sq->d_inv, o.ptr, vg::rows_per_thread(n));
+    else
+        VG_LAUNCH(vg::sq8_decode_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, st, c.ptr, total,
+                  sq->dim, sq->d_mins, sq->d_inv, o.ptr);
     VG_TRY(o.finish());
     return VG_OK;
 }
@@ -1478,8 +1591,12 @@ VG_API int32_t vg_int4_encode(vg_int4 *iq, const float *vectors, int64_t n, uint
     vg::DevOut<uint8_t> c;
     VG_TRY(v.init(vectors, static_cast<size_t>(n) * iq->dim, st));
     VG_TRY(c.init(codes, static_cast<size_t>(n * cs), st));
-    VG_LAUNCH(vg::int4_encode_kernel, dim3(static_cast<unsigned>((n * cs + 255) / 256)), dim3(256), 0, st, v.ptr, n,
-              iq->dim, iq->d_min, iq->d_diff, c.ptr);
+    if (iq->dim % 8 == 0 && ((reinterpret_cast<uintptr_t>(v.ptr) | reinterpret_cast<uintptr_t>(c.ptr)) & 15) == 0)
+        VG_LAUNCH(vg::int4_encode8_kernel, dim3((iq->dim / 8 + 255) / 256, static_cast<unsigned>((n + vg::rows_per_thread(n) - 1) / vg::rows_per_thread(n))),
+                  dim3(256), 0, st, v.ptr, n, iq->dim, iq->d_min, iq->d_diff, c.ptr, vg::rows_per_thread(n));
+    else
+        VG_LAUNCH(vg::int4_encode_kernel, dim3(static_cast<unsigned>((n * cs + 255) / 256)), dim3(256), 0, st, v.ptr, n,
+                  iq->dim, iq->d_min, iq->d_diff, c.ptr);
     VG_TRY(c.finish());
     return VG_OK;
 }
@@ -1498,8 +1615,12 @@ VG_API int32_t vg_int4_decode(vg_int4 *iq, const uint8_t *codes, int64_t n, floa
     vg::DevOut<float> o;
     VG_TRY(c.init(codes, static_cast<size_t>(n * cs), st));
     VG_TRY(o.init(out, static_cast<size_t>(n) * iq->dim, st));
-    VG_LAUNCH(vg::int4_decode_kernel, dim3(static_cast<unsigned>((n * iq->dim + 255) / 256)), dim3(256), 0, st, c.ptr, n,
-              iq->dim, iq->d_min, iq->d_diff, o.ptr);
+    if (iq->dim % 8 == 0 && ((reinterpret_cast<uintptr_t>(c.ptr) | reinterpret_cast<uintptr_t>(o.ptr)) & 15) == 0)
+        VG_LAUNCH(vg::int4_decode8_kernel, dim3((iq->dim / 8 + 255) / 256, static_cast<unsigned>((n + vg::rows_per_thread(n) - 1) / vg::rows_per_thread(n))),
+                  dim3(256), 0, st, c.ptr, n, iq->dim, iq->d_min, iq->d_diff, o.ptr, vg::rows_per_thread(n));
+    else
+        VG_LAUNCH(vg::int4_decode_kernel, dim3(static_cast<unsigned>((n * iq->dim + 255) / 256)), dim3(256), 0, st, c.ptr, n,
+                  iq->dim, iq->d_min, iq->d_diff, o.ptr);
     VG_TRY(o.finish());
     return VG_OK;
 }
