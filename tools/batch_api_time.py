@@ -58,3 +58,12 @@ timed("BinaryQuantizer.compute_hamming_distance 1M x 96 B", lambda: bq.compute_h
 timed("BinaryQuantizer.encode 1M x 768 fp32", lambda: bq.encode(rows, out=bcodes), N * D * 4)
 bnd = torch.full((1,), 1400.0, device=dev)
 timed("squared_l2_bounded_batch 1M x 768 fp32", lambda: vg.squared_l2_bounded_batch(ctx, q, rows, D, bnd), N * D * 4)
+# the rest of the boundary's array-shaped entry points
+nv = rows.clone()
+timed("normalize_l2 1M x 768 fp32 (in place)", lambda: vg.normalize_l2(ctx, nv, D), N * D * 4 * 2)
+cent = vg.kmeans_train(ctx, rows[:131072], D, 122, max_iter=3, seed=1)
+timed("kmeans_assign 1M x 768 vs 122 centroids", lambda: vg.kmeans_assign(ctx, rows, cent, D), N * D * 4, reps=5, warm=5)
+q1024 = bench.gen_queries(1, dev)[0]
+tab = pq.build_distance_table(q1024) if hasattr(pq, "build_distance_table") else None
+if tab is not None:
+    timed("ProductQuantizer.build_distance_table 1024 queries", lambda: pq.build_distance_table(q1024), 1024 * 96 * 256 * 4)
