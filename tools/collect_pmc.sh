@@ -15,6 +15,9 @@ if [ "$what" = scans ] || [ "$what" = all ]; then
     $P rqmq_valu "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS GRBM_GUI_ACTIVE SQ_WAVES" python3 tools/scan_batch_time.py rabitq 10000000 1024
     $P adcmq_fetch "FETCH_SIZE" python3 tools/scan_batch_time.py adc 10000000 64
     $P sq8_fetch "FETCH_SIZE" python3 tools/sq8_prof.py 4000000 1 10
+    $P i4_fetch "FETCH_SIZE" python3 tools/int4_batch_time.py 4000000
+    $P i4_write "WRITE_SIZE" python3 tools/int4_batch_time.py 4000000
+    $P i4_lds "SQ_INSTS_VALU SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE" python3 tools/int4_batch_time.py 4000000
 fi
 if [ "$what" = gemm ] || [ "$what" = all ]; then
     $P gemm_fetch "FETCH_SIZE" python3 tools/flat_time.py

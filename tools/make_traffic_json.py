@@ -72,6 +72,15 @@ if mq:
 out["rabitq_scan_mq"] = mq
 out["pq_adc_scan_batch64"] = traffic("adcmq_fetch", None, "pq_adc_scan_kernel", None, {"workload": "10M x 96 B, 64 queries in one call (one pass per query, slices shared through L2)"})
 out["sq8_scan"] = traffic("sq8_fetch", None, "sq8_scan_kernel", 4_000_000 * 768, {"workload": "4M x 768 one-byte codes, 1 query"})
+i4 = traffic("i4_fetch", "i4_write", "int4_scan_tab_kernel<true>", 4_000_000 * 384 + 4_000_000 * 4, {"workload": "4M x 384 B INT4 codes, 1 query (+ 16 MB of distances written)"})
+if i4:
+    lds = {c: val("i4_lds", "int4_scan_tab_kernel<true>", c) for c in ("SQ_INSTS_VALU", "SQ_LDS_IDX_ACTIVE", "SQ_LDS_BANK_CONFLICT", "GRBM_GUI_ACTIVE")}
+    if lds["GRBM_GUI_ACTIVE"]:
+        cyc = lds["GRBM_GUI_ACTIVE"] / 8
+        lds["lds_array_busy_fraction"] = lds["SQ_LDS_IDX_ACTIVE"] / 256 / cyc
+        lds["valu_busy_fraction"] = lds["SQ_INSTS_VALU"] * 4 / 1024 / cyc
+    i4["counters"] = lds
+out["int4_scan"] = i4
 g = traffic("gemm_fetch", "gemm_write", "flat_gemm_dma_kernel<false, 2, 0, false>", 1_000_000 * 768 * 4 + 1024 * 768 * 4, {"workload": "1024 queries x 1M x 768 per launch"})
 if g:
     busy, gui = val("gemm_mfma", "flat_gemm_dma_kernel<false, 2, 0, false>", "SQ_VALU_MFMA_BUSY_CYCLES"), val("gemm_mfma", "flat_gemm_dma_kernel<false, 2, 0, false>", "GRBM_GUI_ACTIVE")

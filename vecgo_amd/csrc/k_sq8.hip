@@ -1109,32 +1109,37 @@ __global__ __launch_bounds__(kI4TabWaves * 64) void int4_scan_tab_kernel(const f
     const int row_bytes = dim >> 1;
     const int64_t n_tiles = (n + 63) / 64;
     const int r = lane >> 2, part = lane & 3;  // staging: 4 lanes per row, 16 rows per load
-    for (int64_t tile = static_cast<int64_t>(blockIdx.x) * kI4TabWaves + wave; tile < n_tiles;
-         tile += static_cast<int64_t>(gridDim.x) * kI4TabWaves) {
+    // (named variables, not arrays: under this kernel's 1024-thread bound hipcc kept `uint4 u[4]` in scratch memory and
+    // waited out every load before storing it there)
+    auto row_ptr = [&](int64_t tile, int k) {
+        const int64_t row = tile * 64 + r + 16 * k < n ? tile * 64 + r + 16 * k : n - 1;  // past n: row n - 1 again, not stored
+        return codes + row * row_bytes + part * 16;
+    };
+    const int64_t tile_step = static_cast<int64_t>(gridDim.x) * kI4TabWaves;
+    int64_t tile = static_cast<int64_t>(blockIdx.x) * kI4TabWaves + wave;
+    if (tile >= n_tiles) return;
+    const uint8_t *src0 = row_ptr(tile, 0), *src1 = row_ptr(tile, 1), *src2 = row_ptr(tile, 2), *src3 = row_ptr(tile, 3);
+    uint4 u0 = *reinterpret_cast<const uint4 *>(src0), u1 = *reinterpret_cast<const uint4 *>(src1),
+          u2 = *reinterpret_cast<const uint4 *>(src2), u3 = *reinterpret_cast<const uint4 *>(src3);
+    unsigned char *wr = stage + r * kI4TabStride + part * 16;
+    for (; tile < n_tiles; tile += tile_step) {
         const int64_t row0 = tile * 64;
-        // (named variables, not arrays: under this kernel's 1024-thread bound hipcc kept `uint4 u[4]` in scratch memory
-        // and waited out every load before storing it there)
-        auto row_ptr = [&](int k) {
-            const int64_t row = row0 + r + 16 * k < n ? row0 + r + 16 * k : n - 1;  // past n: row n - 1 again, not stored
-            return codes + row * row_bytes + part * 16;
-        };
-        const uint8_t *src0 = row_ptr(0), *src1 = row_ptr(1), *src2 = row_ptr(2), *src3 = row_ptr(3);
+        // the wave's next tile (its first piece is requested while this tile's last one is scored); none: this tile again
+        const int64_t tnext = tile + tile_step < n_tiles ? tile + tile_step : tile;
+        const uint8_t *nx0 = row_ptr(tnext, 0), *nx1 = row_ptr(tnext, 1), *nx2 = row_ptr(tnext, 2), *nx3 = row_ptr(tnext, 3);
         vg_f2v s1[8], s2[8];
 #pragma unroll
         for (int p = 0; p < 8; p++) s1[p] = s2[p] = vg_f2v{0.0f, 0.0f};
-        uint4 u0 = *reinterpret_cast<const uint4 *>(src0), u1 = *reinterpret_cast<const uint4 *>(src1),
-              u2 = *reinterpret_cast<const uint4 *>(src2), u3 = *reinterpret_cast<const uint4 *>(src3);
-        unsigned char *wr = stage + r * kI4TabStride + part * 16;
         for (int cb0 = 0; cb0 < row_bytes; cb0 += 64) {
             *reinterpret_cast<uint4 *>(wr) = u0;
             *reinterpret_cast<uint4 *>(wr + 16 * kI4TabStride) = u1;
             *reinterpret_cast<uint4 *>(wr + 32 * kI4TabStride) = u2;
             *reinterpret_cast<uint4 *>(wr + 48 * kI4TabStride) = u3;
-            const int nxt = cb0 + 64 < row_bytes ? cb0 + 64 : cb0;  // (the last piece again: unused)
-            u0 = *reinterpret_cast<const uint4 *>(src0 + nxt);
-            u1 = *reinterpret_cast<const uint4 *>(src1 + nxt);
-            u2 = *reinterpret_cast<const uint4 *>(src2 + nxt);
-            u3 = *reinterpret_cast<const uint4 *>(src3 + nxt);
+            const bool more = cb0 + 64 < row_bytes;  // (a pointer select, not a guarded load: hipcc waits at a join)
+            u0 = *reinterpret_cast<const uint4 *>(more ? src0 + cb0 + 64 : nx0);
+            u1 = *reinterpret_cast<const uint4 *>(more ? src1 + cb0 + 64 : nx1);
+            u2 = *reinterpret_cast<const uint4 *>(more ? src2 + cb0 + 64 : nx2);
+            u3 = *reinterpret_cast<const uint4 *>(more ? src3 + cb0 + 64 : nx3);
 #pragma unroll
             for (int piece = 0; piece < 4; piece++) {
                 const uint4 c = *reinterpret_cast<const uint4 *>(stage + lane * kI4TabStride + piece * 16);
@@ -1175,6 +1180,10 @@ __global__ __launch_bounds__(kI4TabWaves * 64) void int4_scan_tab_kernel(const f
         }
         const float total = reduce16_regs(s16);
         if (row0 + lane < n) out[row0 + lane] = total;
+        src0 = nx0;
+        src1 = nx1;
+        src2 = nx2;
+        src3 = nx3;
     }
 }
 
