@@ -1035,13 +1035,15 @@ __global__ __launch_bounds__(kI4Waves * 64) void int4_scan_kernel(const float *_
 
 // The same scan with the lookups free of bank conflicts (dim <= 1024): the pair table above puts a wave's 64 random
 // bytes on 32 bank slots — 62 % of its LDS cycles were conflicts and the LDS array was 89 % busy (3.65 TB/s of codes).
-// Here the workgroup (16 waves, one per CU, persistent over the tiles) builds the quantizer's own dim x 16 value table
+// Here the workgroup (12 waves, one per CU, persistent over the tiles) builds the quantizer's own dim x 16 value table
 // in LDS (48 KiB at dim 768; PRE: float(v) / 15 * diff + min as BuildInt4LookupTable does; batch order:
 // fma(float(v) * 0x3d888889, diff, min)): the 64 lanes of a lookup share the dimension, so they touch at most 16
 // consecutive dwords — distinct banks or the same address.  A lookup's address is ONE v_perm_b32 (byte k of the
 // pre-masked nibbles under the block's base; the dimension's offset is the instruction's immediate), a dimension
 // costs 2 vector instructions (the table holds query[j] - value: a launch serves one query) and 2 LDS cycles per wave
-// instead of ~3.5.  Rows are staged 64 bytes at a time (stride 80 = 16 x 5).
+// instead of ~3.5.  Rows are staged a whole 128-byte line at a time (stride 144 = 16 x 9; 12 waves beside the table:
+// with 64-byte pieces and 16 waves the second half of a line was requested a step after the first and had often left
+// L2 by then — the lines in flight on an XCD are about its 4 MiB — 1.34x the codes' bytes crossed the fabric).
 // (the lookups are issued in inline asm, eight at a time — the four code bytes of one dword — and a group is retired by
 // a COUNTED wait while the next group's eight are in flight: hipcc re-used one register pair per lookup and waited out
 // every LDS round trip.  hipcc does not track asm loads: every value is an in/out operand of the wait statement, so no
@@ -1079,8 +1081,8 @@ __device__ __forceinline__ void i4_issue_word(I4Vals8 &x, uint32_t w, uint32_t b
 #undef VG_I4_ONE
 }
 
-constexpr int kI4TabWaves = 16;
-constexpr int kI4TabStride = 80;
+constexpr int kI4TabWaves = 12;
+constexpr int kI4TabStride = 144;
 constexpr int kI4TabMaxDim = 1024;
 template <bool PRE>
 __global__ __launch_bounds__(kI4TabWaves * 64) void int4_scan_tab_kernel(const float *__restrict__ query,
@@ -1092,7 +1094,8 @@ __global__ __launch_bounds__(kI4TabWaves * 64) void int4_scan_tab_kernel(const f
     float *table = reinterpret_cast<float *>(i4smem);  // [dim][16]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     unsigned char *stage = i4smem + static_cast<size_t>(dim) * 64 + wave * (64 * kI4TabStride);
-    for (int e = tid; e < dim * 16; e += kI4TabWaves * 64) {
+    const int waves = blockDim.x >> 6;  // 12, fewer when the table leaves less room (dim 1024: 10)
+    for (int e = tid; e < dim * 16; e += blockDim.x) {
         const int d = e >> 4, v = e & 15;
         float t;
         if (PRE) {
@@ -1108,40 +1111,41 @@ __global__ __launch_bounds__(kI4TabWaves * 64) void int4_scan_tab_kernel(const f
     __syncthreads();
     const int row_bytes = dim >> 1;
     const int64_t n_tiles = (n + 63) / 64;
-    const int r = lane >> 2, part = lane & 3;  // staging: 4 lanes per row, 16 rows per load
-    // (named variables, not arrays: under this kernel's 1024-thread bound hipcc kept `uint4 u[4]` in scratch memory and
-    // waited out every load before storing it there)
+    const int r = lane >> 3, part = lane & 7;  // staging: 8 lanes per row (one 128-byte line), 8 rows per load
+    // (named variables, not arrays: under this kernel's large-workgroup bound hipcc kept `uint4 u[..]` in scratch memory
+    // and waited out every load before storing it there)
     auto row_ptr = [&](int64_t tile, int k) {
-        const int64_t row = tile * 64 + r + 16 * k < n ? tile * 64 + r + 16 * k : n - 1;  // past n: row n - 1 again, not stored
+        const int64_t row = tile * 64 + r + 8 * k < n ? tile * 64 + r + 8 * k : n - 1;  // past n: row n - 1 again, not stored
         return codes + row * row_bytes + part * 16;
     };
-    const int64_t tile_step = static_cast<int64_t>(gridDim.x) * kI4TabWaves;
-    int64_t tile = static_cast<int64_t>(blockIdx.x) * kI4TabWaves + wave;
+    const int64_t tile_step = static_cast<int64_t>(gridDim.x) * waves;
+    int64_t tile = static_cast<int64_t>(blockIdx.x) * waves + wave;
     if (tile >= n_tiles) return;
-    const uint8_t *src0 = row_ptr(tile, 0), *src1 = row_ptr(tile, 1), *src2 = row_ptr(tile, 2), *src3 = row_ptr(tile, 3);
-    uint4 u0 = *reinterpret_cast<const uint4 *>(src0), u1 = *reinterpret_cast<const uint4 *>(src1),
-          u2 = *reinterpret_cast<const uint4 *>(src2), u3 = *reinterpret_cast<const uint4 *>(src3);
+#define VG_I4_ROWS(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
+#define VG_I4_DECL(K) const uint8_t *src##K = row_ptr(tile, K); uint4 u##K = *reinterpret_cast<const uint4 *>(src##K);
+    VG_I4_ROWS(VG_I4_DECL)
+#undef VG_I4_DECL
     unsigned char *wr = stage + r * kI4TabStride + part * 16;
     for (; tile < n_tiles; tile += tile_step) {
         const int64_t row0 = tile * 64;
         // the wave's next tile (its first piece is requested while this tile's last one is scored); none: this tile again
         const int64_t tnext = tile + tile_step < n_tiles ? tile + tile_step : tile;
-        const uint8_t *nx0 = row_ptr(tnext, 0), *nx1 = row_ptr(tnext, 1), *nx2 = row_ptr(tnext, 2), *nx3 = row_ptr(tnext, 3);
+#define VG_I4_NEXT(K) const uint8_t *nx##K = row_ptr(tnext, K);
+        VG_I4_ROWS(VG_I4_NEXT)
+#undef VG_I4_NEXT
         vg_f2v s1[8], s2[8];
 #pragma unroll
         for (int p = 0; p < 8; p++) s1[p] = s2[p] = vg_f2v{0.0f, 0.0f};
-        for (int cb0 = 0; cb0 < row_bytes; cb0 += 64) {
-            *reinterpret_cast<uint4 *>(wr) = u0;
-            *reinterpret_cast<uint4 *>(wr + 16 * kI4TabStride) = u1;
-            *reinterpret_cast<uint4 *>(wr + 32 * kI4TabStride) = u2;
-            *reinterpret_cast<uint4 *>(wr + 48 * kI4TabStride) = u3;
-            const bool more = cb0 + 64 < row_bytes;  // (a pointer select, not a guarded load: hipcc waits at a join)
-            u0 = *reinterpret_cast<const uint4 *>(more ? src0 + cb0 + 64 : nx0);
-            u1 = *reinterpret_cast<const uint4 *>(more ? src1 + cb0 + 64 : nx1);
-            u2 = *reinterpret_cast<const uint4 *>(more ? src2 + cb0 + 64 : nx2);
-            u3 = *reinterpret_cast<const uint4 *>(more ? src3 + cb0 + 64 : nx3);
+        for (int cb0 = 0; cb0 < row_bytes; cb0 += 128) {
+#define VG_I4_PUT(K) *reinterpret_cast<uint4 *>(wr + 8 * K * kI4TabStride) = u##K;
+            VG_I4_ROWS(VG_I4_PUT)
+#undef VG_I4_PUT
+            const bool more = cb0 + 128 < row_bytes;  // (a pointer select, not a guarded load: hipcc waits at a join)
+#define VG_I4_GET(K) u##K = *reinterpret_cast<const uint4 *>(more ? src##K + cb0 + 128 : nx##K);
+            VG_I4_ROWS(VG_I4_GET)
+#undef VG_I4_GET
 #pragma unroll
-            for (int piece = 0; piece < 4; piece++) {
+            for (int piece = 0; piece < 8; piece++) {
                 const uint4 c = *reinterpret_cast<const uint4 *>(stage + lane * kI4TabStride + piece * 16);
                 const uint32_t w[4] = {c.x, c.y, c.z, c.w};
                 const int j0 = (cb0 + piece * 16) * 2;  // first dimension of this 32-element block
@@ -1180,10 +1184,10 @@ __global__ __launch_bounds__(kI4TabWaves * 64) void int4_scan_tab_kernel(const f
         }
         const float total = reduce16_regs(s16);
         if (row0 + lane < n) out[row0 + lane] = total;
-        src0 = nx0;
-        src1 = nx1;
-        src2 = nx2;
-        src3 = nx3;
+#define VG_I4_ADV(K) src##K = nx##K;
+        VG_I4_ROWS(VG_I4_ADV)
+#undef VG_I4_ADV
+#undef VG_I4_ROWS
     }
 }
 
@@ -1656,15 +1660,15 @@ VG_API int32_t vg_int4_l2_distance_batch(vg_int4 *iq, const float *query, const 
     const bool scan = iq->dim % 64 == 0 && (reinterpret_cast<uintptr_t>(c.ptr) & 15) == 0;
     const unsigned scan_blocks = static_cast<unsigned>(((n + 63) / 64 + vg::kI4Waves - 1) / vg::kI4Waves);
     vg::ProfScope prof(iq->ctx, "int4_scan", st);
-    if (scan && iq->dim % 128 == 0 && iq->dim <= vg::kI4TabMaxDim) {
-        const size_t lds = static_cast<size_t>(iq->dim) * 64 + static_cast<size_t>(vg::kI4TabWaves) * 64 * vg::kI4TabStride;
+    if (scan && iq->dim % 256 == 0 && iq->dim <= vg::kI4TabMaxDim) {
+        const int waves = static_cast<int>(std::min<int64_t>(vg::kI4TabWaves, (160 * 1024 - static_cast<int64_t>(iq->dim) * 64) / (64 * vg::kI4TabStride)));
+        const size_t lds = static_cast<size_t>(iq->dim) * 64 + static_cast<size_t>(waves) * 64 * vg::kI4TabStride;
         const int64_t tiles = (n + 63) / 64;
-        const unsigned blocks = static_cast<unsigned>(std::min<int64_t>((tiles + vg::kI4TabWaves - 1) / vg::kI4TabWaves,
-                                                                         std::max(iq->ctx->compute_units, 1)));
+        const unsigned blocks = static_cast<unsigned>(std::min<int64_t>((tiles + waves - 1) / waves, std::max(iq->ctx->compute_units, 1)));
         auto kern = precomputed ? vg::int4_scan_tab_kernel<true> : vg::int4_scan_tab_kernel<false>;
         VG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    static_cast<int>(lds)));
-        VG_LAUNCH(kern, dim3(blocks), dim3(vg::kI4TabWaves * 64), lds, st, q.ptr, c.ptr, n, iq->dim, iq->d_min, iq->d_diff,
+        VG_LAUNCH(kern, dim3(blocks), dim3(waves * 64), lds, st, q.ptr, c.ptr, n, iq->dim, iq->d_min, iq->d_diff,
                   o.ptr);
     } else if (scan && precomputed)
         VG_LAUNCH(vg::int4_scan_kernel<true>, dim3(scan_blocks), dim3(vg::kI4Waves * 64), 0, st, q.ptr, c.ptr, n, iq->dim,
