@@ -391,18 +391,50 @@ __global__ __launch_bounds__(512) void adc_lookup_batch_lds_kernel(const float *
     unsigned char *stage = adc_smem + static_cast<size_t>(m) * 1024 + static_cast<size_t>(wave) * 64 * stride;
     const int64_t n_tiles = (n + 63) / 64;
     const int units = 64 * m16;  // 16-byte units of a tile
-    for (int64_t tile = static_cast<int64_t>(blockIdx.x) * waves + wave; tile < n_tiles;
-         tile += static_cast<int64_t>(gridDim.x) * waves) {
+    const int64_t tile_step = static_cast<int64_t>(gridDim.x) * waves;
+    // unit e of tile t (past n: the tile's last valid unit again — valid memory, values unused)
+    auto get = [&](int64_t t, int e) {
+        const int64_t row0 = t * 64;
+        const int64_t last_unit = (n - row0 < 64 ? n - row0 : 64) * m16 - 1;
+        return *reinterpret_cast<const uint4 *>(codes + row0 * m + (e <= last_unit ? e : last_unit) * 16);
+    };
+    auto put = [&](int e, const uint4 u) {
+        const int r = e / m16, part = e - r * m16;
+        *reinterpret_cast<uint4 *>(stage + r * stride + part * 16) = u;
+    };
+    int64_t tile = static_cast<int64_t>(blockIdx.x) * waves + wave;
+    if (tile >= n_tiles) return;
+    // m = 96: a lane's six units of the NEXT tile are requested before this tile's lookups (8 waves per CU do not hide an
+    // HBM round trip per tile by themselves: the waves waited 72 % of their cycles)
+    uint4 p0, p1, p2, p3, p4, p5;
+    if (M16 == 6) {
+        p0 = get(tile, lane);
+        p1 = get(tile, lane + 64);
+        p2 = get(tile, lane + 128);
+        p3 = get(tile, lane + 192);
+        p4 = get(tile, lane + 256);
+        p5 = get(tile, lane + 320);
+    }
+    for (; tile < n_tiles; tile += tile_step) {
         const int64_t row0 = tile * 64;
-        const int64_t last_unit = (n - row0 < 64 ? n - row0 : 64) * m16 - 1;  // the block's last valid unit
-        const uint8_t *blk = codes + row0 * m;
-        for (int e0 = 0; e0 < units; e0 += 64) {
-            const int e = e0 + lane;
-            const int64_t ec = e <= last_unit ? e : last_unit;  // past n: valid memory, values unused
-            const uint4 u = *reinterpret_cast<const uint4 *>(blk + ec * 16);
-            if (e < units) {
-                const int r = e / m16, part = e - r * m16;
-                *reinterpret_cast<uint4 *>(stage + r * stride + part * 16) = u;
+        if (M16 == 6) {
+            put(lane, p0);
+            put(lane + 64, p1);
+            put(lane + 128, p2);
+            put(lane + 192, p3);
+            put(lane + 256, p4);
+            put(lane + 320, p5);
+            const int64_t tn = tile + tile_step < n_tiles ? tile + tile_step : tile;
+            p0 = get(tn, lane);
+            p1 = get(tn, lane + 64);
+            p2 = get(tn, lane + 128);
+            p3 = get(tn, lane + 192);
+            p4 = get(tn, lane + 256);
+            p5 = get(tn, lane + 320);
+        } else {
+            for (int e0 = 0; e0 < units; e0 += 64) {
+                const uint4 u = get(tile, e0 + lane);
+                if (e0 + lane < units) put(e0 + lane, u);
             }
         }
         float acc[16];
