@@ -169,7 +169,7 @@ func (r *Resident) BuildHNSW(m, efConstruction int) error {
 
 func (r *Resident) out(nq, k int) ([]uint32, []float32) { return make([]uint32, nq*k), make([]float32, nq*k) }
 
-// SearchFlat: flat.Segment.Search's fp32 branch (flat/segment.go:691-721), hnsw.BruteSearch (hnsw.go:2021-2101).
+// SearchFlat: flat.Segment.Search's fp32 branch (flat/segment.go:691-721); hnsw.BruteSearch is SearchHNSWBrute.
 func (r *Resident) SearchFlat(queries []float32, nq, k int) ([]uint32, []float32, error) {
 	ids, sc := r.out(nq, k)
 	st := C.vg_search_flat(r.h, fp(queries), C.int64_t(nq), C.int32_t(k), up(ids), fp(sc), nil)
@@ -232,6 +232,28 @@ func (r *Resident) SearchHNSWPQ(queries []float32, nq, k, ef int, stats []Stats)
 		sp = (*C.vg_search_stats)(unsafe.Pointer(&stats[0]))
 	}
 	st := C.vg_search_hnsw_pq(r.h, fp(queries), C.int64_t(nq), C.int32_t(k), C.int32_t(ef), up(ids), fp(sc), sp, nil)
+	return ids, sc, hipctx.Err(int32(st))
+}
+
+// BruteMode selects which of the HNSW index's exhaustive paths SearchHNSWBrute replays.
+type BruteMode int32
+
+const (
+	BruteScan   BruteMode = 0 // hnsw.BruteSearch + scanSegment (hnsw.go:2021-2101): PopItem + PushItem
+	BruteBitmap BruteMode = 1 // searchBitmap (hnsw.go:2240-2263): TryPushBounded(k)
+)
+
+// SearchHNSWBrute: BruteSearch / searchBitmap over the rows whose bit is set in mask (bit i of byte i/8; nil =
+// every row; len(mask) == ceil(n/8) for one mask, nq*maskStride for one per query), in ascending id through the
+// reference's PriorityQueue: ids AND their order among equal distances are the reference's.  Distances are the
+// index's (L2, -dot, 0.5*L2), best first.
+func (r *Resident) SearchHNSWBrute(queries []float32, nq, k int, mode BruteMode, mask []byte, maskStride int) ([]uint32, []float32, error) {
+	ids, sc := r.out(nq, k)
+	var mp *C.uint8_t
+	if len(mask) > 0 {
+		mp = (*C.uint8_t)(unsafe.Pointer(&mask[0]))
+	}
+	st := C.vg_search_hnsw_brute(r.h, fp(queries), C.int64_t(nq), C.int32_t(k), C.int32_t(mode), mp, C.int64_t(maskStride), up(ids), fp(sc), nil)
 	return ids, sc, hipctx.Err(int32(st))
 }
 

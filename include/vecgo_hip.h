@@ -192,9 +192,19 @@ int32_t vg_hamming_batch(vg_ctx *ctx, const uint8_t *a, const uint8_t *codes, in
 
 /* Test hooks (process-wide): force an alternative path so that tests can compare the paths bit for bit.
  * Names: VG_FLAT_NO_SMALL_TILE, VG_FLAT_UNFUSED, VG_FLAT_NO_SCAN, VG_FLAT_FORCE_EXACT, VG_FLAT_NO_DMA,
- * VG_FLAT_DEBUG, VG_PROBE_NO_GROUP, VG_ADC_BIGK_EXHAUSTIVE, VG_ADC_SKEW, VG_BUILD_DEBUG.  The environment variable of the same
+ * VG_FLAT_DEBUG, VG_PROBE_NO_GROUP, VG_ADC_BIGK_EXHAUSTIVE, VG_BUILD_DEBUG.  The environment variable of the same
  * name ("1") gives the initial value, read once; the search entry points never call getenv. */
 int32_t vg_debug_set_hook(const char *name, int32_t on);
+/* Test entry point: a script of searcher.PriorityQueue operations (queue.go) replayed by ONE wave on the device
+ * heap the graph searches use (csrc/vg_heap.hpp) — how the reference's own queue tests run against it.
+ * ops[n_ops*4] = {op, node, float32 bits of distance, arg (capacity / maxSize)}; out[n_ops*3] = {flag, node, bits}:
+ * flag = 1 pushed / accepted / item returned, 0 rejected / empty (VG_HEAP_LEN: the length).  is_max: NewPriorityQueue's
+ * isMaxHeap; unsigned_keys != 0 selects the scalar-ALU sift-downs the walks use for distances >= +0.  final_items =
+ * the heap array afterwards, item i = node | bits << 32; the script may hold at most cap (<= 8192) items. */
+enum { VG_HEAP_PUSH = 0, VG_HEAP_POP = 1, VG_HEAP_PUSH_BOUNDED = 2, VG_HEAP_TRY_PUSH_BOUNDED = 3, VG_HEAP_TOP = 4,
+       VG_HEAP_MIN_ITEM = 5, VG_HEAP_RESET = 6, VG_HEAP_LEN = 7 };
+int32_t vg_debug_heap_replay(vg_ctx *ctx, int32_t is_max, int32_t unsigned_keys, const int32_t *ops, int32_t n_ops,
+                             int32_t *out, int32_t *final_len, uint64_t *final_items, int32_t cap, void *stream);
 
 /* ---- resident index ---------------------------------------------------------- */
 int32_t vg_index_create(vg_ctx *ctx, int64_t n, int32_t dim, int32_t metric, vg_index **out);
@@ -333,8 +343,8 @@ int32_t vg_score_candidates(vg_index *idx, const float *queries, int64_t nq,
 
 /* flat.Segment.Search, fp32 branch (flat/segment.go:691-701) == exact brute force:
  * distance.SquaredL2 / distance.Dot of every row (squaredL2Avx512 / dotProductAvx512
- * order), best k by (Score, RowID) (segment.go:714-721).  Also hnsw.BruteSearch
- * (hnsw.go:2021-2101).  Candidates come from a batched query x base fp32 MFMA GEMM
+ * order), best k by (Score, RowID) (segment.go:714-721).  (hnsw.BruteSearch, which keeps its results in a
+ * PriorityQueue and reports HNSW distances, is vg_search_hnsw_brute.)  Candidates come from a batched query x base fp32 MFMA GEMM
  * (||x||^2 - 2 q.x); the survivors are re-scored in the reference's summation order and the
  * result is verified against the GEMM error bound (a query that fails the check is
  * recomputed by the exhaustive exact kernel), so ids and scores equal the reference's.
@@ -540,6 +550,26 @@ int32_t vg_search_hnsw_pq(vg_index *idx, const float *queries, int64_t nq, int32
  * stop when the popped candidate is worse than the k-th result.  k <= 512. */
 int32_t vg_search_vamana(vg_index *idx, const float *queries, int64_t nq, int32_t k, int32_t kind,
                          uint32_t *ids, float *scores, vg_search_stats *stats, void *stream);
+
+/* The HNSW index's two EXHAUSTIVE paths, each with the heap it is written with (searcher/queue.go) — which ids
+ * survive a tie at the k-th distance and the order of equal distances in the result follow from the heap's layout,
+ * so the heap is replayed operation by operation (vg_search_flat / vg_rerank order by (Score, RowID) instead, the
+ * CandidateHeap order of flat/segment.go:714-721, and report dot products; this entry reports HNSW distances):
+ *   VG_BRUTE_SCAN    hnsw.BruteSearch + scanSegment (hnsw.go:2021-2101): PriorityQueue(max); len < k -> PushItem,
+ *                    else `d < top.Distance` -> PopItem + PushItem; res[len-1 .. 0] = PopItem().
+ *   VG_BRUTE_BITMAP  searchBitmap (hnsw.go:2240-2263) + knnSearchInternal's extraction (:1732-1751):
+ *                    s.Candidates.TryPushBounded(item, k) (at capacity `d >= top` is rejected, else the item replaces
+ *                    the root and sifts down); popped, reversed.
+ * Rows are visited in ascending id (node segments in order; bm.ForEach ascending, segment/segment.go:154).  mask: bit i
+ * of byte i/8 set = row i takes part — for SCAN the rows that are live nodes and pass `filter`, for BITMAP the
+ * bitmap minus the tombstones; NULL = every row.  Query q reads mask + q*mask_stride (mask_stride 0 = one mask for
+ * the batch, else >= ceil(n/8)).  Distances as the index wraps them (hnsw.go:2218-2238, columnar.go:37-44): L2 ->
+ * squared L2, Dot -> -dot, Cosine -> 0.5 * squared L2 (rows and queries normalised by the caller, as for
+ * vg_search_hnsw).  ids/scores[nq*k] best first; unused slots VG_INVALID_ID / +Inf.  k <= 1024.  A NaN distance
+ * (NaN or Inf in a row or query) makes the result unspecified: the replay relies on the heap's top never rising. */
+enum { VG_BRUTE_SCAN = 0, VG_BRUTE_BITMAP = 1 };
+int32_t vg_search_hnsw_brute(vg_index *idx, const float *queries, int64_t nq, int32_t k, int32_t mode,
+                             const uint8_t *mask, int64_t mask_stride, uint32_t *ids, float *scores, void *stream);
 
 /* engine fan-in (engine/search.go:904-908: per-segment candidate lists merged into one
  * bounded heap, ordered by searcher/candidate_queue.go:12-23).  Here the "segments" are row

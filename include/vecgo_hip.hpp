@@ -615,6 +615,8 @@ public:
     Result SearchHNSWPQ(const float *queries, int64_t nq, int k, int ef) { return run(nq, k, [&](Result &r) { return vg_search_hnsw_pq(h_, queries, nq, k, ef, r.ids.data(), r.scores.data(), nullptr, nullptr); }); }
     // hnsw.KNNSearch (hnsw.go:1650-1755)
     Result SearchHNSW(const float *queries, int64_t nq, int k, int ef) { return run(nq, k, [&](Result &r) { return vg_search_hnsw(h_, queries, nq, k, ef, r.ids.data(), r.scores.data(), nullptr, nullptr); }); }
+    // hnsw.BruteSearch + scanSegment (hnsw.go:2021-2101; VG_BRUTE_SCAN) / searchBitmap (:2240-2263; VG_BRUTE_BITMAP)
+    Result SearchHNSWBrute(const float *queries, int64_t nq, int k, int mode, const uint8_t *mask = nullptr, int64_t mask_stride = 0) { return run(nq, k, [&](Result &r) { return vg_search_hnsw_brute(h_, queries, nq, k, mode, mask, mask_stride, r.ids.data(), r.scores.data(), nullptr); }); }
     // diskann searchInternal (diskann/segment.go:503-706); kind 0 fp32, 1 PQ, 2 RaBitQ
     Result SearchVamana(const float *queries, int64_t nq, int k, int kind) { return run(nq, k, [&](Result &r) { return vg_search_vamana(h_, queries, nq, k, kind, r.ids.data(), r.scores.data(), nullptr, nullptr); }); }
     // Segment.Rerank (flat/segment.go:754-780) + top-k

@@ -140,6 +140,7 @@ _sig("vgo_hnsw_select_neighbors", C.c_int32, _f32p, C.c_int64, C.c_int32, C.c_in
 _sig("vgo_rerank_f32", None, _f32p, C.c_int32, C.c_int32, _f32p, _u32p, C.c_int32, _f32p)
 _sig("vgo_hnsw_search", C.c_int32, C.POINTER(HnswGraph), _f32p, C.c_int32, C.c_int32, _u32p,
      _f32p, C.POINTER(SearchStats))
+_sig("vgo_hnsw_brute_search", C.c_int32, C.POINTER(HnswGraph), _f32p, C.c_int32, C.c_int32, _u8p, _u32p, _f32p)
 _sig("vgo_vamana_search", C.c_int32, C.POINTER(Vamana), _f32p, C.c_int32, _u32p, _f32p,
      C.POINTER(SearchStats))
 _i64p = C.POINTER(C.c_int64)
@@ -704,6 +705,104 @@ class HnswIndex:
         r = lib.vgo_hnsw_search(C.byref(g), pq_, k, ef, ids.ctypes.data_as(_u32p),
                                 sc.ctypes.data_as(_f32p), C.byref(st))
         return ids[:r], sc[:r], st
+
+
+BRUTE_SCAN, BRUTE_BITMAP = 0, 1
+
+_sig("vgo_prioq_replay", C.c_int32, C.c_int32, _i32p, C.c_int32, _i32p, C.POINTER(C.c_uint64), C.c_int32)
+HEAP_OPS = {"push": 0, "pop": 1, "push_bounded": 2, "try_push_bounded": 3, "top": 4, "min_item": 5, "reset": 6, "len": 7}
+
+
+def heap_script_array(script):
+    """[{op, node, dist, cap}, ...] (tests/golden/reference_kats.json searcher_priority_queue) or rows of
+    (op, node, dist, arg) -> int32[n, 4] in the encoding vgo_prioq_replay and vg_debug_heap_replay share."""
+    ops = np.zeros((len(script), 4), np.int32)
+    for i, st in enumerate(script):
+        if isinstance(st, dict):
+            st = (HEAP_OPS[st["op"]], st.get("node", 0), st.get("dist", 0.0), st.get("cap", 0))
+        ops[i] = (st[0], int(np.array(st[1], np.uint32).view(np.int32)),
+                  int(np.array(st[2], np.float32).view(np.int32)), st[3])
+    return ops
+
+
+def prioq_replay(is_max, script, cap=4096):
+    """-> (out[n, 3] int32 {flag, node, dist bits}, final heap items as (node[len] u32, dist[len] f32))."""
+    ops = heap_script_array(script)
+    out = np.zeros((ops.shape[0], 3), np.int32)
+    items = np.zeros(cap, np.uint64)
+    n = lib.vgo_prioq_replay(int(bool(is_max)), ops.ctypes.data_as(_i32p), ops.shape[0], out.ctypes.data_as(_i32p),
+                             items.ctypes.data_as(C.POINTER(C.c_uint64)), cap)
+    items = items[:n]
+    return out, ((items & 0xFFFFFFFF).astype(np.uint32), (items >> 32).astype(np.uint32).view(np.float32))
+
+
+class _Cand(C.Structure):
+    _fields_ = [("segment_id", C.c_uint32), ("row_id", C.c_uint32), ("score", C.c_float)]
+
+
+class _CandHeap(C.Structure):
+    _fields_ = [("c", C.POINTER(_Cand)), ("len", C.c_int32), ("cap", C.c_int32), ("descending", C.c_int32)]
+
+
+_sig("vgo_candheap_init", None, C.POINTER(_CandHeap), C.c_int32, C.c_int32)
+_sig("vgo_candheap_free", None, C.POINTER(_CandHeap))
+_sig("vgo_cand_better", C.c_int, _Cand, _Cand, C.c_int)
+_sig("vgo_candheap_try_push_bounded", C.c_int, C.POINTER(_CandHeap), _Cand, C.c_int32)
+_sig("vgo_candheap_pop", C.c_int, C.POINTER(_CandHeap), C.POINTER(_Cand))
+_sig("vgo_candheap_replace_top", C.c_int, C.POINTER(_CandHeap), _Cand)
+
+
+class CandidateHeap:
+    """searcher.CandidateHeap (candidate_queue.go) as the oracle restates it; Push = TryPushBounded with k = inf."""
+
+    def __init__(self, descending, cap=16):
+        self.h = _CandHeap()
+        lib.vgo_candheap_init(C.byref(self.h), cap, int(bool(descending)))
+
+    def __len__(self):
+        return self.h.len
+
+    def push(self, score, segment_id=0, row_id=0, k=1 << 30):
+        return bool(lib.vgo_candheap_try_push_bounded(C.byref(self.h), _Cand(segment_id, row_id, score), k))
+
+    def top(self):
+        c = self.h.c[0]
+        return (c.score, c.segment_id, c.row_id)
+
+    def pop(self):
+        c = _Cand()
+        ok = lib.vgo_candheap_pop(C.byref(self.h), C.byref(c))
+        return (c.score, c.segment_id, c.row_id) if ok else None
+
+    def replace_top(self, score, segment_id=0, row_id=0):
+        return bool(lib.vgo_candheap_replace_top(C.byref(self.h), _Cand(segment_id, row_id, score)))
+
+    def close(self):
+        lib.vgo_candheap_free(C.byref(self.h))
+
+
+def cand_better(a, b, descending):
+    """a, b = (score, segment_id, row_id)"""
+    return bool(lib.vgo_cand_better(_Cand(a[1], a[2], a[0]), _Cand(b[1], b[2], b[0]), int(bool(descending))))
+
+
+def _brute_search(self, query, k, mode=BRUTE_SCAN, mask=None):
+    """hnsw.BruteSearch / scanSegment (mode BRUTE_SCAN) or searchBitmap + extraction (BRUTE_BITMAP) over the rows
+    whose bit in `mask` (bool[n] or packed little-endian bits, None = all) is set."""
+    q, pq_ = _f(query)
+    ids = np.empty(max(k, 1), np.uint32); sc = np.empty(max(k, 1), np.float32)
+    mp = None
+    if mask is not None:
+        mask = np.asarray(mask)
+        if mask.dtype == np.bool_:
+            mask = np.packbits(mask, bitorder="little")
+        mask, mp = _u8(mask)
+    g = self._c()
+    r = lib.vgo_hnsw_brute_search(C.byref(g), pq_, k, mode, mp, ids.ctypes.data_as(_u32p), sc.ctypes.data_as(_f32p))
+    return ids[:r], sc[:r]
+
+
+HnswIndex.brute_search = _brute_search
 
 
 class VamanaIndex:

@@ -1010,6 +1010,99 @@ int32_t vgo_candheap_sorted(const vgo_candheap *h, vgo_cand *dst)
     return h->len;
 }
 
+/* CandidateHeap.Pop :65-72 (Swap(0, n), down(0, n), truncate) and ReplaceTop :97-100 — only the tests call them */
+int vgo_candheap_pop(vgo_candheap *h, vgo_cand *out)
+{
+    if (h->len == 0) return 0;
+    int n = h->len - 1;
+    vgo_cand t = h->c[0];
+    h->c[0] = h->c[n];
+    h->c[n] = t;
+    cand_down(h, 0, n);
+    *out = h->c[n];
+    h->len = n;
+    return 1;
+}
+int vgo_candheap_replace_top(vgo_candheap *h, vgo_cand x) /* TryReplaceTop :104-111 */
+{
+    if (h->len == 0) return 0;
+    h->c[0] = x;
+    cand_down(h, 0, h->len);
+    return 1;
+}
+
+/* A script of PriorityQueue operations (the op codes of include/vecgo_hip.h VG_HEAP_*: 0 PushItem, 1 PopItem,
+ * 2 PushItemBounded, 3 TryPushBounded, 4 TopItem, 5 MinItem, 6 Reset, 7 Len): ops[i] = {op, node, float bits, arg},
+ * out[i] = {flag, node, float bits}.  How the reference's queue tests (queue_test.go) and random scripts are run
+ * against this heap and, by the same script, against the device heap (vg_debug_heap_replay). */
+int32_t vgo_prioq_replay(int is_max, const int32_t *ops, int32_t n_ops, int32_t *out, uint64_t *final_items, int32_t cap)
+{
+    vgo_prioq q;
+    vgo_prioq_init(&q, is_max, cap > 0 ? cap : 1);
+    for (int i = 0; i < n_ops; i++) {
+        int op = ops[4 * i], arg = ops[4 * i + 3], flag = 0;
+        vgo_pq_item it, res = {0, 0.0f};
+        it.node = (uint32_t)ops[4 * i + 1];
+        memcpy(&it.dist, &ops[4 * i + 2], 4);
+        switch (op) {
+        case 0:
+            vgo_prioq_push(&q, it);
+            flag = 1;
+            break;
+        case 1:
+            flag = vgo_prioq_pop(&q, &res);
+            break;
+        case 2: /* PushItemBounded reports nothing; the flag says whether the item went in (capacity 0 on an
+                 * empty queue would index an empty slice in the reference: skipped) */
+            if (q.len < arg) {
+                flag = 1;
+                vgo_prioq_push_bounded(&q, it, arg);
+            } else if (q.len > 0) {
+                flag = is_max ? it.dist < q.items[0].dist : it.dist > q.items[0].dist;
+                vgo_prioq_push_bounded(&q, it, arg);
+            }
+            break;
+        case 3:
+            flag = vgo_prioq_try_push_bounded(&q, it, arg);
+            break;
+        case 4:
+            if (q.len) {
+                res = q.items[0];
+                flag = 1;
+            }
+            break;
+        case 5: /* MinItem queue.go:46-57 */
+            if (q.len) {
+                res = q.items[0];
+                for (int j = 1; j < q.len; j++)
+                    if (q.items[j].dist < res.dist) res = q.items[j];
+                flag = 1;
+            }
+            break;
+        case 6:
+            q.len = 0;
+            flag = 1;
+            break;
+        case 7:
+            flag = q.len;
+            break;
+        default:
+            flag = -1;
+        }
+        out[3 * i] = flag;
+        out[3 * i + 1] = (int32_t)res.node;
+        memcpy(&out[3 * i + 2], &res.dist, 4);
+    }
+    int32_t len = q.len;
+    for (int i = 0; i < len && i < cap; i++) {
+        uint32_t b;
+        memcpy(&b, &q.items[i].dist, 4);
+        final_items[i] = (uint64_t)q.items[i].node | ((uint64_t)b << 32);
+    }
+    vgo_prioq_free(&q);
+    return len;
+}
+
 /* ------------------------------------------------------------------ */
 /* flat scans — internal/segment/flat/segment.go:606-723                */
 /* ------------------------------------------------------------------ */
@@ -1259,6 +1352,47 @@ int32_t vgo_hnsw_search_ws(const vgo_hnsw_graph *g, const float *query, int32_t 
     vgo_prioq_free(&res);
     if (!visited_ws) free(visited);
     if (stats) *stats = st;
+    return nres;
+}
+
+/* hnsw.BruteSearch hnsw.go:2021-2073 + scanSegment :2075-2101, and searchBitmap :2240-2263 + knnSearchInternal's
+ * extraction :1732-1751 — the two exhaustive paths of the HNSW index, each with the heap discipline it is WRITTEN
+ * with (they differ, and with them the order in which equal distances leave the heap):
+ *   VGO_BRUTE_SCAN    max-heap PriorityQueue; len < k -> PushItem, else `d < top.Distance` -> PopItem + PushItem
+ *                     (the last leaf goes to the root and sifts down, then the new item sifts up from the end);
+ *   VGO_BRUTE_BITMAP  s.Candidates (max-heap, searcher.go) with TryPushBounded(k): at capacity `d >= top` is
+ *                     rejected, otherwise the new item REPLACES the root and sifts down.
+ * Rows are visited in ascending id (node segments in order / bm.ForEach ascending, segment.go:154); `mask`
+ * (bit i of byte i/8, NULL = every row) holds what survives node.IsZero()/filter (scan) or bitmap minus tombstones
+ * (bitmap).  Results: popped into res[len-1 .. 0] (BruteSearch) resp. popped then reversed (extraction) — the
+ * same best-first array.  Distances as the index wraps them (hnsw_dist: L2, -dot, 0.5*L2). */
+int32_t vgo_hnsw_brute_search(const vgo_hnsw_graph *g, const float *query, int32_t k, int32_t mode,
+                              const uint8_t *mask, uint32_t *ids, float *scores)
+{
+    if (k <= 0) return 0;
+    vgo_prioq q;
+    vgo_prioq_init(&q, 1, k + 1);
+    for (int64_t i = 0; i < g->n; i++) {
+        if (mask && !((mask[i >> 3] >> (i & 7)) & 1)) continue;
+        vgo_pq_item it = {(uint32_t)i, hnsw_dist(g, query, (uint32_t)i)};
+        if (mode == VGO_BRUTE_BITMAP) {
+            vgo_prioq_try_push_bounded(&q, it, k);
+        } else if (q.len < k) {
+            vgo_prioq_push(&q, it);
+        } else if (it.dist < q.items[0].dist) {
+            vgo_pq_item dropped;
+            vgo_prioq_pop(&q, &dropped);
+            vgo_prioq_push(&q, it);
+        }
+    }
+    int32_t nres = q.len;
+    for (int i = nres - 1; i >= 0; i--) {
+        vgo_pq_item it;
+        vgo_prioq_pop(&q, &it);
+        ids[i] = it.node;
+        scores[i] = it.dist;
+    }
+    vgo_prioq_free(&q);
     return nres;
 }
 

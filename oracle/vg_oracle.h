@@ -119,6 +119,8 @@ void vgo_prioq_push(vgo_prioq *q, vgo_pq_item it);
 void vgo_prioq_push_bounded(vgo_prioq *q, vgo_pq_item it, int32_t capacity);
 int vgo_prioq_try_push_bounded(vgo_prioq *q, vgo_pq_item it, int32_t max_size);
 int vgo_prioq_pop(vgo_prioq *q, vgo_pq_item *out);
+/* script of queue operations (op codes = VG_HEAP_* of include/vecgo_hip.h); returns the final length */
+int32_t vgo_prioq_replay(int is_max, const int32_t *ops, int32_t n_ops, int32_t *out, uint64_t *final_items, int32_t cap);
 
 typedef struct {
     uint32_t segment_id, row_id;
@@ -133,6 +135,8 @@ void vgo_candheap_init(vgo_candheap *h, int32_t cap, int descending);
 void vgo_candheap_free(vgo_candheap *h);
 int vgo_cand_better(vgo_cand a, vgo_cand b, int descending);
 int vgo_candheap_try_push_bounded(vgo_candheap *h, vgo_cand x, int32_t k);
+int vgo_candheap_pop(vgo_candheap *h, vgo_cand *out);
+int vgo_candheap_replace_top(vgo_candheap *h, vgo_cand x);
 /* best-first copy (SortedResults) */
 int32_t vgo_candheap_sorted(const vgo_candheap *h, vgo_cand *dst);
 
@@ -178,6 +182,12 @@ typedef struct {
  * then knnSearchInternal's extraction: best-first k results. */
 int32_t vgo_hnsw_search(const vgo_hnsw_graph *g, const float *query, int32_t k, int32_t ef,
                         uint32_t *ids, float *scores, vgo_search_stats *stats);
+
+/* hnsw.BruteSearch + scanSegment (hnsw.go:2021-2101) and searchBitmap (:2240-2263) + extraction (:1732-1751):
+ * exhaustive scans over the rows whose mask bit is set (NULL = all), each with its own heap discipline */
+enum { VGO_BRUTE_SCAN = 0, VGO_BRUTE_BITMAP = 1 };
+int32_t vgo_hnsw_brute_search(const vgo_hnsw_graph *g, const float *query, int32_t k, int32_t mode,
+                              const uint8_t *mask, uint32_t *ids, float *scores);
 
 /* see vg_oracle.c "Optional kernel hooks": the reference's compiled kernels (oracle/_ref) for the timed CPU
  * baseline; signatures are the reference's C ABI (the _avx512.c files of internal/simd/src) */

@@ -77,7 +77,7 @@ def test_shim_binds_every_reference_facing_entry_point():
     used = {n for p in GO for n, _ in c_calls(p.read_text())} - header_types()
     # not bound on purpose: profiling / debug hooks, the multi-process exchange (a Go host would bind RCCL itself
     # or use these from its own launcher), the builders' batched primitives, accessors the shim does not need
-    unbound_ok = {"vg_profile_enable", "vg_profile_read", "vg_debug_set_hook", "vg_ctx_device_info", "vg_comm_unique_id",
+    unbound_ok = {"vg_profile_enable", "vg_profile_read", "vg_debug_set_hook", "vg_debug_heap_replay", "vg_ctx_device_info", "vg_comm_unique_id",
                   "vg_comm_create", "vg_comm_destroy", "vg_comm_info", "vg_comm_probe", "vg_comm_describe", "vg_comm_all_gather", "vg_comm_all_gather_topk",
                   "vg_merge_topk_packed", "vg_robust_prune", "vg_hnsw_select_neighbors", "vg_score_candidates",
                   "vg_index_enable_bf16_filter", "vg_index_flat_stats", "vg_index_get_hnsw_graph", "vg_hnsw_level_for_id",

@@ -401,6 +401,21 @@ class Comm:
         return recv
 
 
+def heap_replay(ctx: Context, is_max: bool, ops, unsigned_keys: bool = False, cap: int = 4096, stream=None):
+    """vg_debug_heap_replay: ops int32[n, 4] = {op (VG_HEAP_*), node, float32 bits, arg}; returns (out int32[n, 3]
+    {flag, node, bits}, nodes uint32[len], dists float32[len]) — the device heap of csrc/vg_heap.hpp after the script."""
+    ops = np.ascontiguousarray(ops, np.int32).reshape(-1, 4)
+    out = np.zeros((ops.shape[0], 3), np.int32)
+    items = np.zeros(max(cap, 1), np.uint64)
+    flen = np.zeros(1, np.int32)
+    check(ctx._lib.vg_debug_heap_replay(ctx._h, C.c_int32(int(bool(is_max))), C.c_int32(int(bool(unsigned_keys))),
+                                        C.c_void_p(ops.ctypes.data), C.c_int32(ops.shape[0]), C.c_void_p(out.ctypes.data),
+                                        C.c_void_p(flen.ctypes.data), C.c_void_p(items.ctypes.data), C.c_int32(cap),
+                                        _stream_ptr(stream)))
+    items = items[:int(flen[0])]
+    return out, (items & 0xFFFFFFFF).astype(np.uint32), (items >> 32).astype(np.uint32).view(np.float32)
+
+
 def merge_topk_packed(ctx: Context, packed, lists: int, nq: int, k: int, metric=0, id_offsets=None, out=None, stream=None):
     """vg_merge_topk_packed: packed is a device int32/uint32 tensor [lists, 2, nq, k]."""
     p_, pp = _ptr(packed, np.uint32, lists * 2 * nq * k)
@@ -1021,6 +1036,33 @@ class Index:
         """searchLayer with distFunc = pq.ComputeAsymmetricDistance over the nodes' PQ codes (the candidate
         stage of graph -> PQ -> exact rerank); scores are PQ distances."""
         return self._graph_search(self._lib.vg_search_hnsw_pq, queries, k, ef, stats, stream)
+
+    BRUTE_SCAN, BRUTE_BITMAP = 0, 1
+
+    def search_hnsw_brute(self, queries, k, mode=0, mask=None, stream=None):
+        """hnsw.BruteSearch + scanSegment (hnsw.go:2021-2101; mode BRUTE_SCAN) or searchBitmap + extraction
+        (:2240-2263, :1732-1751; BRUTE_BITMAP): every row whose mask bit is set, in id order, through the
+        reference's PriorityQueue.  mask: None, bool[n] / packed bits for the whole batch, or bool[nq, n] / packed
+        [nq, ceil(n/8)] for one mask per query.  HNSW distances (L2, -dot, 0.5 * L2), best first."""
+        nq = _rows(queries, self.dim)
+        q, pq_ = _ptr(queries, np.float32)
+        ids = _empty_like(queries, (nq, k), np.uint32)
+        scores = _empty_like(queries, (nq, k), np.float32)
+        i, pi = _ptr(ids, np.uint32)
+        s_, ps = _ptr(scores, np.float32)
+        pm, stride = None, 0
+        if mask is not None:
+            m = np.asarray(mask)
+            if m.dtype == np.bool_:
+                m = np.packbits(m.reshape(-1, self.n) if m.ndim > 1 else m, axis=-1, bitorder="little")
+            m = np.ascontiguousarray(m, np.uint8)
+            if m.ndim > 1 and m.shape[0] > 1:
+                assert m.shape[0] == nq, "one mask per query"
+                stride = m.shape[1]
+            pm = C.c_void_p(m.ctypes.data)
+        check(self._lib.vg_search_hnsw_brute(self._h, pq_, C.c_int64(nq), C.c_int32(k), C.c_int32(mode), pm,
+                                             C.c_int64(stride), pi, ps, _stream_ptr(stream)))
+        return ids, scores
 
     def search_vamana(self, queries, k, kind=0, stats=False, stream=None):
         """diskann searchInternal (diskann/segment.go:503-706); kind 0 fp32, 1 PQ, 2 RaBitQ, 3 INT4."""
