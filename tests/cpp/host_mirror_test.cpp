@@ -351,6 +351,31 @@ int main()
             for (int a = 0; a < k; a++)
                 for (int b = 0; b < k; b++) hit += got.ids[size_t(i) * k + a] == want.ids[size_t(i) * k + b];
         EXPECT(hit >= int(0.99 * nq * k));
+        // hnsw.BruteSearch (hnsw.go:2021-2101) and searchBitmap (:2240-2263) vs the oracle's replay of the same heaps,
+        // on a tie-heavy copy of the rows (two decimals of a 16-dim uniform: equal distances do occur)
+        std::vector<float> coarse(base);
+        for (auto &x : coarse) x = std::floor(x * 3.0f);
+        Segment tie(ctx, n, dim, distance::Metric::L2);
+        tie.SetVectors(coarse.data());
+        std::vector<float> cq(q);
+        for (auto &x : cq) x = std::floor(x * 3.0f);
+        std::vector<uint8_t> mask((n + 7) / 8);
+        for (auto &b : mask) b = uint8_t(rng());
+        std::vector<uint32_t> none(size_t(n), 0xFFFFFFFFu);
+        vgo_hnsw_graph og{};
+        og.n = n, og.dim = dim, og.metric = VGO_METRIC_L2, og.base = coarse.data(), og.m0 = 1, og.l0 = none.data();
+        for (int mode = 0; mode < 2; mode++)
+            for (int masked = 0; masked < 2; masked++) {
+                auto br = tie.SearchHNSWBrute(cq.data(), nq, k, mode, masked ? mask.data() : nullptr);
+                for (int i = 0; i < nq; i++) {
+                    uint32_t eid[k];
+                    float esc[k];
+                    const int r = vgo_hnsw_brute_search(&og, cq.data() + size_t(i) * dim, k, mode, masked ? mask.data() : nullptr, eid, esc);
+                    EXPECT(r == k);
+                    EXPECT(std::memcmp(eid, br.ids.data() + size_t(i) * k, sizeof eid) == 0);
+                    EXPECT(std::memcmp(esc, br.scores.data() + size_t(i) * k, sizeof esc) == 0);
+                }
+            }
     }
 
     if (g_fail) {

@@ -399,3 +399,40 @@ def test_vamana_10m_nodes_r64(vg, ctx):
         assert np.array_equal(bits(np_(sc)[i, :eid.size]), bits(esc)), i
         assert (int(st[i][0]), int(st[i][1]), int(st[i][3])) == (est.nodes_visited, est.distance_computations, est.pops)
     idx.close()
+
+
+def test_hnsw_brute_1m_x_768(vg, ctx):
+    """hnsw.BruteSearch / searchBitmap (hnsw.go:2021-2101, 2240-2263) at 1M x 768: random-normal rows have no tied
+    distances, so both heap disciplines must return what flat.Segment.Search returns (ids, order, score bits — L2), the
+    replay of 245 steps of 4096 rows per query may not lose or reorder anything, a selective bitmap answers with its
+    own rows only, and two whole queries are re-run by the oracle over all rows."""
+    n, dim, nq, k = 1_000_000, 768, 24, 10
+    g = torch.Generator(device="cuda"); g.manual_seed(20260133)
+    base = torch.randn(n, dim, device="cuda", generator=g)
+    q = torch.randn(nq, dim, device="cuda", generator=g)
+    idx = vg.Index(ctx, n, dim); idx.set_vectors(base)
+    fi, fs = idx.search_flat(q, k)
+    for mode in (idx.BRUTE_SCAN, idx.BRUTE_BITMAP):
+        bi, bs = idx.search_hnsw_brute(q, k, mode)
+        assert torch.equal(bi, fi) and torch.equal(bs.view(torch.int32), fs.view(torch.int32)), mode
+    # a 1 % bitmap (searchBitmap's regime): results lie in the bitmap and equal a flat search over just those rows
+    rng = np.random.default_rng(5)
+    member = rng.random(n) < 0.01
+    mi, ms = idx.search_hnsw_brute(q, k, idx.BRUTE_BITMAP, member)
+    rows = np.nonzero(member)[0]
+    sub = vg.Index(ctx, rows.size, dim); sub.set_vectors(base[torch.from_numpy(rows).cuda()].contiguous())
+    si, ss = sub.search_flat(q, k)
+    assert np.array_equal(rows[np_(si).view(np.uint32).astype(np.int64)], np_(mi).view(np.uint32).astype(np.int64))
+    assert torch.equal(ss.view(torch.int32), ms.view(torch.int32))
+    sub.close()
+    # two whole queries by the oracle (its own heap, the reference's compiled distance kernel when present)
+    hbase = base.cpu().numpy(); hq = q.cpu().numpy()
+    oidx = o.HnswIndex(hbase, dim, np.full((n, 1), 0xFFFFFFFF, np.uint32))
+    was = o.use_reference_kernels(True)
+    try:
+        for qi in (0, nq - 1):
+            eid, esc = oidx.brute_search(hq[qi], k, o.BRUTE_SCAN)
+            assert np.array_equal(eid, np_(bi).view(np.uint32)[qi]) and np.array_equal(bits(esc), bits(np_(bs)[qi]))
+    finally:
+        o.use_reference_kernels(False)
+    idx.close()

@@ -60,36 +60,45 @@ def test_replay_rejects_overflow(vg, ctx):
         vg.heap_replay(ctx, True, o.heap_script_array([(0, i, 1.0, 0) for i in range(20)]), cap=8)
 
 
+def _best_first(vg, ctx, items, descending):
+    """(score, row) candidates -> best-first order by the GPU's CandidateHeap key: every candidate is its own one-entry
+    list (vg_merge_topk merges SORTED lists), padded to k with empty slots"""
+    n = len(items)
+    ids = np.full((n, 1, n), 0xFFFFFFFF, np.uint32)
+    sc = np.full((n, 1, n), -np.inf if descending else np.inf, np.float32)
+    for j, (score, row) in enumerate(items):
+        ids[j, 0, 0], sc[j, 0, 0] = row, score
+    bi, bs = vg.merge_topk(ctx, ids, sc, n, metric=2 if descending else 0)
+    return [(float(bs[0, j]), int(bi[0, j])) for j in range(n)]
+
+
 def test_candidate_heap_reference_tests_as_sort_keys(vg, ctx):
     g = heap_kats.KATS["searcher_candidate_heap"]
     for c in g["cases"]:
         if "push" not in c:
             continue
-        items = [(x["score"], x["row_id"]) for x in c["push"]]
-        for r in c.get("replace_top", []):   # ReplaceTop = drop the worst, add the new one
-            ids = np.array([[[i[1] for i in items]]], np.uint32); sc = np.array([[[i[0] for i in items]]], np.float32)
-            bi, bs = vg.merge_topk(ctx, ids, sc, len(items), metric=2 if c["descending"] else 0)
-            items = [(float(bs[0, j]), int(bi[0, j])) for j in range(len(items) - 1)] + [(r["with"]["score"], r["with"]["row_id"])]
-            ids = np.array([[[i[1] for i in items]]], np.uint32); sc = np.array([[[i[0] for i in items]]], np.float32)
-            bi, bs = vg.merge_topk(ctx, ids, sc, len(items), metric=2 if c["descending"] else 0)
-            assert bs[0, -1] == np.float32(r["expect_top_score"]), (c["name"], r)    # worst = last of best-first
-        ids = np.array([[[i[1] for i in items]]], np.uint32); sc = np.array([[[i[0] for i in items]]], np.float32)
-        bi, bs = vg.merge_topk(ctx, ids, sc, len(items), metric=2 if c["descending"] else 0)
-        if "expect_top_score" in c and "replace_top" not in c:
-            assert bs[0, -1] == np.float32(c["expect_top_score"]), c["name"]
+        # the reference's cases leave RowID 0 everywhere; a row can only be listed once per merge here, so a case
+        # whose candidates share (segment, row) gets the push index as its row — scores decide those cases anyway
+        rows = [x["row_id"] for x in c["push"]]
+        uniq = len(set(rows)) == len(rows)
+        items = [(x["score"], x["row_id"] if uniq else j) for j, x in enumerate(c["push"])]
+        for r in c.get("replace_top", []):   # ReplaceTop = drop the worst (last of best-first), add the new one
+            items = _best_first(vg, ctx, items, c["descending"])[:-1] + [(r["with"]["score"], 100 + len(items))]
+            assert _best_first(vg, ctx, items, c["descending"])[-1][0] == np.float32(r["expect_top_score"]), (c["name"], r)
+        order = _best_first(vg, ctx, items, c["descending"])
+        if "expect_top_score" in c:
+            assert order[-1][0] == np.float32(c["expect_top_score"]), c["name"]          # heap top = the worst
         if "expect_top_row" in c:
-            assert bi[0, -1] == c["expect_top_row"], c["name"]
+            assert order[-1][1] == c["expect_top_row"], c["name"]
         if "expect_pop_scores" in c:          # pops = worst first = the reverse of best-first
-            assert bs[0, ::-1].tolist() == [np.float32(x) for x in c["expect_pop_scores"]]
-    # InternalCandidateBetter's truth table through a 2-candidate merge (one segment: SegmentID ties are the engine's,
-    # rows of different shards differ by their id offset — see vg_merge_topk)
+            assert [x[0] for x in order[::-1]] == [np.float32(x) for x in c["expect_pop_scores"]]
+    # InternalCandidateBetter's truth table through a 2-candidate merge (one segment: rows of different shards differ
+    # by their id offset — see vg_merge_topk)
     for b in g["better"]:
         if b["a"]["segment_id"] != b["b"]["segment_id"]:
             continue
-        if (b["a"]["score"], b["a"]["row_id"]) == (b["b"]["score"], b["b"]["row_id"]):
-            continue
-        ids = np.array([[[b["a"]["row_id"], b["b"]["row_id"]]]], np.uint32)
-        sc = np.array([[[b["a"]["score"], b["b"]["score"]]]], np.float32)
-        bi, bs = vg.merge_topk(ctx, ids, sc, 2, metric=2 if b["descending"] else 0)
-        a_first = (bs[0, 0], bi[0, 0]) == (np.float32(b["a"]["score"]), b["a"]["row_id"])
-        assert a_first == b["expected"], b
+        ra, rb = b["a"]["row_id"], b["b"]["row_id"]
+        if ra == rb:
+            ra, rb = 1, 2     # scores differ in these cases: the rows do not decide
+        order = _best_first(vg, ctx, [(b["a"]["score"], ra), (b["b"]["score"], rb)], b["descending"])
+        assert (order[0] == (np.float32(b["a"]["score"]), ra)) == b["expected"], b
