@@ -625,6 +625,10 @@ def hnsw_pq_frontier(vg, ctx, rows, queries, gt_ids, exact_ms_per_1024, stream, 
         f"({best_pq['ms_per_1024']:.1f} ms); the exact path answers 1024 queries in {exact_ms_per_1024:.1f} ms at recall 1.0")
     if with_cpu:
         rep["cpu"] = hnsw_cpu_twin(idx, rows, q, f32, cpu_efs)
+        try:
+            rep["cpu_pq_rerank"] = hnsw_pq_cpu_twin(idx, pq, codes, rows, q, pqr, cpu_efs)
+        except Exception as e:   # an extra leg: named in the record, not fatal
+            rep["cpu_pq_rerank"] = {"error": f"{type(e).__name__}: {e}"}
     # configs[2] as a bandwidth statement: ef = 128 on the real graph
     e128 = f32[0]
     alg128 = e128["gathered_gbs"] * 1e9 * e128["kernel_ms"] * 1e-3
@@ -641,7 +645,10 @@ def hnsw_pq_frontier(vg, ctx, rows, queries, gt_ids, exact_ms_per_1024, stream, 
               "kernel_ms": e128["kernel_ms"], "bytes_per_launch": e128["gathered_gbs"] * 1e9 * e128["kernel_ms"] * 1e-3,
               "recall_at_10": e128["recall_at_10"],
               "distance_computations_per_query": e128["distance_computations_per_query"],
-              "note": "gather rate of the candidate-batch distance kernel; not a QPS claim (recall is far below the bar)"}
+              "note": "gather rate of the candidate-batch distance kernel; not a QPS claim (recall is far below the bar). "
+                      "`frac` is FABRIC bytes (FETCH_SIZE x 2 + WRITE_SIZE) over the HBM peak: FETCH_SIZE counts reads served by the "
+                      "memory-side Infinity Cache as well as HBM reads, so part of it is MALL — MI355X_MICROARCH.md measures "
+                      "5.7-5.8 TB/s for a pure-HBM gather of whole rows, below this kernel's fabric rate"}
     return rep, rep128, idx, pq
 
 
@@ -690,6 +697,12 @@ def structured_corpus(vg, ctx, stream, device, with_cpu):
             rep["at_recall_0_95"]["gpu_hnsw_pq_rerank_over_cpu_hnsw"] = b["qps"] / cpu_best["qps"]
             if a:
                 rep["at_recall_0_95"]["gpu_hnsw_f32_over_cpu_hnsw"] = a["qps"] / cpu_best["qps"]
+        # the same pipeline on both sides: HNSW on PQ codes + exact rerank, each at ITS fastest ef that meets the bar
+        cpu_pq = max((c for c in rep.get("cpu_pq_rerank", {}).get("sweep", []) if c["recall_at_10"] >= 0.95),
+                     key=lambda c: c["qps"], default=None)
+        if cpu_pq and b:
+            rep["at_recall_0_95"]["cpu_hnsw_pq_rerank"] = {k_: cpu_pq[k_] for k_ in ("ef", "recall_at_10", "qps", "cores", "ids_equal_gpu")}
+            rep["at_recall_0_95"]["gpu_hnsw_pq_rerank_over_cpu_hnsw_pq_rerank"] = b["qps"] / cpu_pq["qps"]
     return rep
 
 
@@ -715,6 +728,39 @@ def hnsw_cpu_twin(idx, rows, q, f32, efs=(128, 512, 2048)):
                         "seconds": r["seconds"], "ids_equal_gpu": same, "compared_queries": int(filled.size),
                         "recall_at_10": gpu["recall_at_10"], "gpu_qps": gpu["qps"], "gpu_over_cpu": gpu["qps"] / r["qps"]})
         return {"sweep": out, **host_info()}
+    finally:
+        ic.close()
+
+
+def hnsw_pq_cpu_twin(idx, pq, codes, rows, q, pqr, efs=(128, 512, 2048)):
+    """The metric's NAMED pipeline on the host: the same graph walked on the same PQ codes (oracle searchLayer with
+    distFunc = ComputeAsymmetricDistance, pq.go:234-260) for ef candidates, Segment.Rerank's exact distances
+    (the reference's compiled squaredL2Avx512) and the best k by (Score, RowID) — engine/search.go:914-965 — one
+    query per C thread.  Same graph + same codes + same algorithm = same answers: ids compared with the GPU's."""
+    from oracle import oracle as o
+    l0, upper, entry = idx.get_hnsw_graph()
+    opq = o.ProductQuantizer(DIM, PQ_M, 256)
+    opq.set_codebooks(*[np.asarray(x) for x in pq.codebooks()])
+    hcodes = codes.cpu().numpy() if hasattr(codes, "cpu") else np.asarray(codes)
+    ic = o.InterleavedCopy(rows.cpu().numpy())
+    try:
+        h = o.HnswIndex(ic.array, DIM, l0, upper, entry, m=HNSW_M, pq=opq, codes=hcodes)
+        qh = q.cpu().numpy()
+        out = []
+        for ef in efs:
+            gpu = next((e for e in pqr if e["ef"] == ef), None)
+            if gpu is None:
+                continue
+            r = cpu_leg(o.BENCH_HNSW_PQ_RERANK, qh, K, 4.0, hnsw=h, ef=ef, want_ids=True)
+            cand, _ = idx.search_hnsw_pq(q[:256], ef, ef)
+            gids, _ = idx.rerank(q[:256], cand, K)
+            gids = gids.cpu().numpy().view(np.uint32)
+            filled = np.nonzero(r["dist_comps"][:256] >= 0)[0]
+            same = bool(filled.size) and all(np.array_equal(r["ids"][i], gids[i]) for i in filled)
+            out.append({"ef": ef, "qps": r["qps"], "cores": r["cores"], "kind": r["kind"], "queries": r["queries"],
+                        "seconds": r["seconds"], "ids_equal_gpu": same, "compared_queries": int(filled.size),
+                        "recall_at_10": gpu["recall_at_10"], "gpu_qps": gpu["qps"], "gpu_over_cpu": gpu["qps"] / r["qps"]})
+        return {"pipeline": "hnsw walk on PQ codes (ef candidates) + exact rerank, top-10", "sweep": out}
     finally:
         ic.close()
 
@@ -896,18 +942,26 @@ def multi_gpu_legs(vg, ctx, sharded, world, rank, device, stream, comm):
     return out
 
 
+def traffic_file():
+    """the newest committed PMC summary: profiles/rNN_traffic.json of the highest round"""
+    files = sorted((ROOT / "profiles").glob("r[0-9][0-9]_traffic.json"))
+    return files[-1] if files else None
+
+
 def measured_traffic(key: str, algorithmic_bytes: float = None):
-    """HBM bytes per launch from the committed PMC passes (profiles/r03_traffic.json: rocprofv3 --pmc FETCH_SIZE /
-    WRITE_SIZE of this round's binary at this bench's shapes by tools/collect_pmc.sh, gfx950 correction applied).  PMC
-    counters cannot be read from inside this process.  For the graph searches the measured traffic per algorithmic
-    byte (same 1M-row graph, same 8192 queries) is applied to this launch's algorithmic bytes."""
+    """HBM bytes per launch from the committed PMC passes (profiles/rNN_traffic.json, newest round: rocprofv3 --pmc
+    FETCH_SIZE / WRITE_SIZE of that round's binary at this bench's shapes by tools/collect_pmc.sh, gfx950 correction
+    applied).  PMC counters cannot be read from inside this process: the value is a committed measurement, not one
+    taken in this run (`roofline.traffic_source` names the file).  For the graph searches the measured traffic per
+    algorithmic byte (same 1M-row graph, same 8192 queries) is applied to this launch's algorithmic bytes."""
     try:
-        t = json.loads((ROOT / "profiles" / "r03_traffic.json").read_text())[key]
+        t = json.loads(traffic_file().read_text())[key]
         if algorithmic_bytes is not None:
             return float(t["traffic_per_algorithmic_byte"]) * float(algorithmic_bytes)
         return float(t["traffic_bytes"])
     except Exception:
         return None
+
 
 
 BASELINE_METRIC = "QPS at recall@10≥0.95, 1M×768 HNSW+PQ; PQ-ADC HBM GB/s vs peak"   # BASELINE.json "metric", verbatim
@@ -1233,7 +1287,9 @@ def main():
                     "unit": "TFLOP/s", "frac": achieved_tf / peak_tf,
                     "traffic": measured_traffic("flat_gemm") if (world == 1 and not args.bf16_filter) else None,
                     "kernel": "flat_gemm_dma_kernel<false,2,0,true> (bf16)" if args.bf16_filter else "flat_gemm_dma_kernel<false,2>",
-                    "kernel_ms": kern_avg_ms, "launches": launches, "flops_per_launch": flops_per_launch}
+                    "kernel_ms": kern_avg_ms, "launches": launches, "flops_per_launch": flops_per_launch,
+                    "traffic_source": (traffic_file().name + " (committed rocprofv3 --pmc pass of the same kernel and shape; "
+                                       "not re-measured in this run)") if traffic_file() else None}
         workload = "flat_exact_l2_1Mx768_top10 (BASELINE configs[1]): MFMA GEMM nomination + exact re-score + proof" + \
             (" [nomination in bfloat16: --bf16-filter]" if args.bf16_filter else "")
     else:

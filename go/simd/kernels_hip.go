@@ -57,7 +57,9 @@ func dotBatchHIP(query []float32, targets []float32, dim int, out []float32) {
 }
 
 // SquaredL2BoundedBatch is SquaredL2Bounded (kernels.go:173) of one query against n contiguous rows.
-// bounds has 1 entry (shared) or n entries; dist[i], exceeded[i] as the pair the scalar kernel returns.
+// bounds has 1 entry (shared) or n entries; (dist[i], exceeded[i]) is the pair simd.SquaredL2Bounded returns for row i,
+// including the partial sum of the 64-float block at which squaredL2BoundedAvx512 exits when the bound is exceeded
+// (bounded_l2_avx512.c:60-75).
 func SquaredL2BoundedBatch(query, targets []float32, dim int, bounds []float32, dist []float32, exceeded []int32) {
 	n := len(dist)
 	if n == 0 {

@@ -272,9 +272,9 @@ int32_t vg_dot_batch(vg_ctx *ctx, const float *query, const float *targets, int6
 
 /* simd.SquaredL2Bounded (kernels.go:173 -> bounded_l2_avx512.c:19-108), one query against n
  * contiguous targets with one bound each (bounds[n]) or a shared one (bounds[1], n_bounds=1).
- * exceeded[i] = (distance > bound) exactly as the reference reports it; dist[i] is the
- * bounded kernel's reduction order run to completion (the reference returns a partial sum when
- * it exits early — its callers only use dist when !exceeded, hnsw.go:1357-1366). */
+ * (dist[i], exceeded[i]) = the pair the reference returns: the bounded kernel's reduction order run to completion
+ * when the bound holds, and when it does not the PARTIAL total of the 64-float block at which the reference exits
+ * (bounded_l2_avx512.c:60-75; an excess reached only in the 8-wide / scalar remainder returns the full sum). */
 int32_t vg_squared_l2_bounded_batch(vg_ctx *ctx, const float *query, const float *targets, int64_t dim,
                                     int64_t n, const float *bounds, int64_t n_bounds, float *dist,
                                     int32_t *exceeded, void *stream);
@@ -531,7 +531,10 @@ typedef struct vg_search_stats {
  * vectorstore/columnar.go:29-50).  One wavefront per query, many queries in flight; per query
  * the result equals the sequential reference's.  ids/scores[nq*k] best first; stats[nq] may be
  * NULL.  k <= ef (a smaller ef is raised to k, determineEF hnsw.go:1891-1894); the two heaps of a query live
- * in LDS up to ef = 512 and in HBM scratch beyond. */
+ * in LDS up to ef = 512 and in HBM scratch beyond.  NaN distances (NaN or Inf in a row or a query) are outside
+ * the contract: for L2 / Cosine the heaps order distances by their bit patterns (every distance >= +0), under which
+ * a NaN is the largest key, whereas every comparison with it is false in the reference — results are then
+ * unspecified (finite inputs only, as the reference's own tests use). */
 int32_t vg_search_hnsw(vg_index *idx, const float *queries, int64_t nq, int32_t k, int32_t ef,
                        uint32_t *ids, float *scores, vg_search_stats *stats, void *stream);
 /* The same walk scored from the nodes' PQ codes instead of their fp32 rows: distFunc =

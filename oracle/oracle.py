@@ -1003,7 +1003,7 @@ class Ref:
 
 
 # ---- timed CPU baseline (oracle/vg_cpu_bench.c): C threads, one query per thread ------------------------
-BENCH_FLAT, BENCH_HNSW, BENCH_ADC, BENCH_RABITQ, BENCH_VAMANA, BENCH_SQ8 = 0, 1, 2, 3, 4, 5
+BENCH_FLAT, BENCH_HNSW, BENCH_ADC, BENCH_RABITQ, BENCH_VAMANA, BENCH_SQ8, BENCH_HNSW_PQ_RERANK = 0, 1, 2, 3, 4, 5, 6
 
 
 class KernelHooks(C.Structure):

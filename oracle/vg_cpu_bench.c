@@ -90,7 +90,8 @@ void vgo_bench_free(void *p, size_t bytes)
 }
 
 /* ---- one query per thread until the deadline ------------------------------------------------------- */
-enum { VGO_BENCH_FLAT = 0, VGO_BENCH_HNSW = 1, VGO_BENCH_ADC = 2, VGO_BENCH_RABITQ = 3, VGO_BENCH_VAMANA = 4, VGO_BENCH_SQ8 = 5 };
+enum { VGO_BENCH_FLAT = 0, VGO_BENCH_HNSW = 1, VGO_BENCH_ADC = 2, VGO_BENCH_RABITQ = 3, VGO_BENCH_VAMANA = 4, VGO_BENCH_SQ8 = 5,
+       VGO_BENCH_HNSW_PQ_RERANK = 6 };
 
 typedef struct {
     int32_t kind;
@@ -132,6 +133,30 @@ static void run_one(const vgo_bench_job *j, int64_t qi, uint32_t *ids, float *sc
     case VGO_BENCH_HNSW:
         r = vgo_hnsw_search_ws(j->hnsw, q, j->k, j->ef, ids, scores, &st, visited, epoch);
         break;
+    case VGO_BENCH_HNSW_PQ_RERANK: {
+        /* the metric's named pipeline: the graph walked on PQ codes (hnsw graph with ->pq set: distFunc =
+         * ComputeAsymmetricDistance, pq.go:234-260) for ef candidates, then Segment.Rerank — the exact distance of
+         * every candidate (flat/segment.go:766-772) — and the best k by (Score, RowID) (engine/search.go:914-965) */
+        const int32_t ef = j->ef > j->k ? j->ef : j->k;
+        uint32_t *cand = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)ef);
+        float *cs = (float *)malloc(sizeof(float) * (size_t)ef);
+        const int32_t nc = vgo_hnsw_search_ws(j->hnsw, q, ef, ef, cand, cs, &st, visited, epoch);
+        vgo_rerank_f32(j->hnsw->base, j->hnsw->dim, j->hnsw->metric, q, cand, nc, cs);
+        vgo_candheap h;
+        vgo_candheap_init(&h, j->k > 0 ? j->k : 1, j->hnsw->metric != VGO_METRIC_L2);
+        for (int32_t c = 0; c < nc; c++) vgo_candheap_try_push_bounded(&h, (vgo_cand){0, cand[c], cs[c]}, j->k);
+        vgo_cand *sorted = (vgo_cand *)malloc(sizeof(vgo_cand) * (size_t)(h.len > 0 ? h.len : 1));
+        r = vgo_candheap_sorted(&h, sorted);
+        for (int32_t c = 0; c < r; c++) {
+            ids[c] = sorted[c].row_id;
+            scores[c] = sorted[c].score;
+        }
+        free(sorted);
+        vgo_candheap_free(&h);
+        free(cand);
+        free(cs);
+        break;
+    }
     case VGO_BENCH_ADC:
         r = vgo_flat_search_pq(j->pq, j->codes, j->n, q, j->k, ids, scores);
         break;
@@ -155,7 +180,8 @@ static void *bench_worker(void *p)
     const vgo_bench_job *j = w->job;
     uint32_t *ids = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)(j->k > 0 ? j->k : 1));
     float *scores = (float *)malloc(sizeof(float) * (size_t)(j->k > 0 ? j->k : 1));
-    uint32_t *visited = j->kind == VGO_BENCH_HNSW ? (uint32_t *)calloc((size_t)j->hnsw->n, sizeof(uint32_t)) : NULL;
+    const int walks = j->kind == VGO_BENCH_HNSW || j->kind == VGO_BENCH_HNSW_PQ_RERANK;
+    uint32_t *visited = walks ? (uint32_t *)calloc((size_t)j->hnsw->n, sizeof(uint32_t)) : NULL;
     uint32_t epoch = 0;
     int64_t i = w->tid;
     for (;;) {

@@ -73,9 +73,9 @@ def test_bounded_batch_golden_and_kats(vg, ctx, golden_dir):
                 bound = float(g["bounded_bound"][bi])
                 d, e = vg.squared_l2_bounded_batch(ctx, a, b, a.size, bound)
                 assert bool(e[0]) == bool(g["bounded_exceeded"][bi])
-                if not e[0]:
-                    assert bits(d[0]) == bits(g["bounded_dist"][bi])
-                else:
+                # the reference's value in both cases: the full sum, or the partial total of the block where it exits
+                assert bits(d[0]) == bits(g["bounded_dist"][bi]), (a.size, bound)
+                if e[0]:
                     assert d[0] >= bound   # floats_test.go:158-161
             bi += 1
     kats = json.loads((golden_dir / "reference_kats.json").read_text())
@@ -92,9 +92,21 @@ def test_bounded_batch_golden_and_kats(vg, ctx, golden_dir):
     q = rng.standard_normal(768).astype(np.float32); t = rng.standard_normal((50, 768)).astype(np.float32)
     bounds = (rng.random(50) * 3000).astype(np.float32)
     d, e = vg.squared_l2_bounded_batch(ctx, q, t, 768, bounds)
+    partials = 0
     for i in range(50):
         full, _ = o.l2_bounded(q, t[i], 1e30)
-        assert bits(d[i]) == bits(full) and bool(e[i]) == bool(full > bounds[i])
+        want, exc = o.l2_bounded(q, t[i], float(bounds[i]))
+        assert bits(d[i]) == bits(want) and bool(e[i]) == bool(exc) == bool(full > bounds[i])
+        partials += bits(want) != bits(full)
+    assert partials > 5      # the early exit's partial sums are exercised, per-row bounds
+    # ragged dims and rows that are not 16-byte aligned, shared bound
+    for dim in (67, 100, 130, 200):
+        q = rng.standard_normal(dim).astype(np.float32); t = rng.standard_normal((33, dim)).astype(np.float32)
+        for bound in (0.5 * dim, 1.5 * dim, 2.5 * dim):
+            d, e = vg.squared_l2_bounded_batch(ctx, q, t, dim, bound)
+            for i in range(33):
+                want, exc = o.l2_bounded(q, t[i], bound)
+                assert bits(d[i]) == bits(want) and bool(e[i]) == bool(exc), (dim, bound, i)
 
 
 # m % 16 == 0: table in LDS, rows turned through LDS (adc_lookup_batch_lds_kernel; m = 96 its own instance, m = 128

@@ -96,3 +96,26 @@ def test_pq_oracle_reference_assertions():
     assert abs(float(pq.asym_distance(q, code)) - float(np.sum((q - dec) ** 2, dtype=np.float32))) <= 1e-3
     table = pq.build_table(q)
     assert abs(float(o.adc(table, code, 8)) - float(pq.asym_distance(q, code))) <= 1e-4
+
+
+def test_cpu_twin_of_the_hnsw_pq_rerank_pipeline():
+    """oracle.BENCH_HNSW_PQ_RERANK (bench.py's CPU twin of the metric's named pipeline, vg_cpu_bench.c): the graph
+    walked on PQ codes for ef candidates, Segment.Rerank's exact distances, best k by (Score, RowID)
+    (engine/search.go:914-965) — equals the same pipeline composed by hand from the oracle's pieces."""
+    from tests import graphs
+    rng = np.random.default_rng(1)
+    n, dim, m = 3000, 32, 4
+    base = rng.standard_normal((n, dim)).astype(np.float32)
+    l0, upper, entry = graphs.build_hnsw(base, m=8, seed=1)
+    pq = o.ProductQuantizer(dim, m, 256)
+    pq.train(base[:1500], iters=4, seed=3)
+    codes = pq.encode_batch(base)
+    h = o.HnswIndex(base, dim, l0, upper, entry, m=8, pq=pq, codes=codes)
+    q = rng.standard_normal((16, dim)).astype(np.float32)
+    r = o.bench_run(o.BENCH_HNSW_PQ_RERANK, q, 10, 16, 0.0, hnsw=h, ef=64, want_ids=True)
+    for i in range(16):
+        cid, _, _ = h.search(q[i], 64, 64)
+        sc = np.array([o.l2(q[i], base[c]) for c in cid], np.float32)
+        order = sorted(range(len(cid)), key=lambda j: (sc[j], cid[j]))[:10]
+        assert np.array_equal(r["ids"][i], cid[order])
+        assert np.array_equal(r["scores"][i].view(np.uint32), sc[order].view(np.uint32))

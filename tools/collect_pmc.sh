@@ -1,9 +1,13 @@
 #!/bin/bash
-# Every rocprofv3 --pmc pass behind profiles/r03_traffic.json, at the bench's own shapes (run on the GPU box through
+# Every rocprofv3 --pmc pass behind profiles/rNN_traffic.json (ROUND=r04 by default), at the bench's own shapes (run on the GPU box through
 # gpurun; counters in their own runs with --kernel-trace only, as the pool requires).  Each pass leaves
 # gpurun_out/pmc/NAME.csv (per-kernel mean counter values per dispatch, tools/pmc_run.sh); tools/make_traffic_json.py
 # turns them into the JSON.  usage: tools/collect_pmc.sh [scans|gemm|walks|all]
+set -euo pipefail
+: "${GRAFT_REPO_ROOT:?run through gpurun (GRAFT_REPO_ROOT is the repository copy on the GPU box)}"
+cd "$GRAFT_REPO_ROOT"
 what=${1:-all}
+ROUND=${ROUND:-r04}
 P=tools/pmc_run.sh
 if [ "$what" = scans ] || [ "$what" = all ]; then
     $P adc_fetch "FETCH_SIZE" python3 tools/adc_prof.py 10000000 1 10
@@ -32,5 +36,5 @@ if [ "$what" = walks ] || [ "$what" = all ]; then
         $P walk_${tag}_valu "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS GRBM_GUI_ACTIVE SQ_WAVES" python3 tools/walk_prof.py 1000000 $m
     done
 fi
-python3 tools/make_traffic_json.py gpurun_out/pmc > gpurun_out/pmc/r03_traffic.json
+python3 tools/make_traffic_json.py gpurun_out/pmc > gpurun_out/pmc/${ROUND}_traffic.json
 ls gpurun_out/pmc/*.csv | wc -l

@@ -1,10 +1,13 @@
-"""gpurun_out/pmc/*.csv (tools/collect_pmc.sh) -> r03_traffic.json: HBM-side bytes per launch, corrected as
+"""gpurun_out/pmc/*.csv (tools/collect_pmc.sh) -> rNN_traffic.json: HBM-side bytes per launch, corrected as
 MI355X_MICROARCH.md prescribes (FETCH_SIZE / WRITE_SIZE are KiB; on gfx950 FETCH_SIZE reports half of the bytes of
 wide reads, so the read side is doubled), next to the launch's algorithmic bytes, plus the
 vector-ALU / MFMA counters of the kernels that are not HBM-bound.  argv: directory of the csv files."""
 import csv, glob, json, os, re, sys
 
 d = sys.argv[1]
+ROUND = os.environ.get("ROUND", "r04")
+if not glob.glob(os.path.join(d, "*.csv")):
+    sys.exit(f"make_traffic_json: no csv under {d}: every pmc pass failed (see the .log files)")
 
 
 def rows(name):
@@ -53,7 +56,7 @@ def traffic(fetch_name, write_name, kernel_sub, algorithmic, extra=None):
 
 out = {"_comment": "HBM-side traffic per launch from rocprofv3 --pmc passes of THIS round's binary at the bench's own shapes "
                    "(tools/collect_pmc.sh; counters in their own runs, --kernel-trace only), corrected as MI355X_MICROARCH.md "
-                   "section HBM prescribes (KiB; read side doubled on gfx950); per-kernel means in profiles/r03_pmc_*.csv"}
+                   "section HBM prescribes (KiB; read side doubled on gfx950); per-kernel means in profiles/" + ROUND + "_pmc_*.csv"}
 out["pq_adc_scan"] = traffic("adc_fetch", "adc_write", "pq_adc_scan_kernel", 10_000_000 * 96, {
     "workload": "10M x 96 B, 1 query",
     "lds": {c: val("adc_lds", "pq_adc_scan_kernel", c) for c in ("SQ_INSTS_LDS", "SQ_LDS_IDX_ACTIVE", "SQ_LDS_BANK_CONFLICT", "SQ_ACTIVE_INST_LDS")}})

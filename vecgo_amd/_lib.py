@@ -15,6 +15,10 @@ _PKG = Path(__file__).resolve().parent
 LIB_PATH = Path(os.environ["VECGO_HIP_LIB"]) if os.environ.get("VECGO_HIP_LIB") else _PKG / "libvecgo_hip.so"
 HEADER_PATH = _PKG.parent / "include" / "vecgo_hip.h"
 
+# the ABI this binding was written against; tests/test_abi_cpu.py asserts it equals include/vecgo_hip.h's
+# VG_ABI_VERSION, so the package does not need the source tree's include/ directory at import time
+ABI_VERSION = 2
+
 _lib = None
 
 
@@ -44,9 +48,8 @@ def load() -> C.CDLL:
     lib.vg_last_error.restype = C.c_char_p
     lib.vg_status_string.restype = C.c_char_p
     lib.vg_status_string.argtypes = [C.c_int32]
-    want = int(re.search(r"#define VG_ABI_VERSION (\d+)", HEADER_PATH.read_text()).group(1))
-    if lib.vg_abi_version() != want:
-        raise ImportError(f"{LIB_PATH} was built for ABI version {lib.vg_abi_version()}, include/vecgo_hip.h declares {want}: rebuild")
+    if lib.vg_abi_version() != ABI_VERSION:
+        raise ImportError(f"{LIB_PATH} was built for ABI version {lib.vg_abi_version()}, this binding expects {ABI_VERSION}: rebuild")
     _lib = lib
     return lib
 

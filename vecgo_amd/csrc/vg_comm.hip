@@ -48,12 +48,18 @@ static std::mutex g_rccl_mu;
 // A process must not run two RCCLs: PyTorch maps its own copy (torch/lib/librccl.so) as soon as torch.distributed
 // creates an RCCL group.  Resolution order: (1) whatever RCCL is ALREADY mapped — by soname (RTLD_NOLOAD), then by
 // the path /proc/self/maps shows for a file named librccl*; (2) only if none is mapped, the system's librccl.so.1.
+// a handle counts only if it really is RCCL (a mapped plugin such as librccl-net.so has "librccl" in its name too)
+static bool is_rccl(void *h) { return h && dlsym(h, "ncclGetUniqueId") && dlsym(h, "ncclAllGather"); }
+
 static void *find_mapped_rccl(std::string &path)
 {
     for (const char *name : {"librccl.so.1", "librccl.so"}) {
         if (void *h = dlopen(name, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL)) {
-            path = name;
-            return h;
+            if (is_rccl(h)) {
+                path = name;
+                return h;
+            }
+            dlclose(h);
         }
     }
     FILE *f = fopen("/proc/self/maps", "r");
@@ -61,14 +67,24 @@ static void *find_mapped_rccl(std::string &path)
     char line[4096];
     void *h = nullptr;
     while (!h && fgets(line, sizeof(line), f)) {
-        const char *p = strstr(line, "librccl");
-        if (!p) continue;
         const char *start = strchr(line, '/');
         if (!start) continue;
         std::string file(start);
         while (!file.empty() && (file.back() == '\n' || file.back() == ' ')) file.pop_back();
-        h = dlopen(file.c_str(), RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
-        if (h) path = file;
+        const std::string deleted = " (deleted)";
+        if (file.size() > deleted.size() && file.compare(file.size() - deleted.size(), deleted.size(), deleted) == 0)
+            continue;  // the file behind the mapping is gone: nothing dlopen could name
+        const size_t slash = file.rfind('/');
+        const std::string base = slash == std::string::npos ? file : file.substr(slash + 1);
+        // basename librccl.so, librccl.so.1, librccl.so.1.0.xxxx — not librccl-net.so, librccl-anp.so
+        if (base.compare(0, 10, "librccl.so") != 0 || (base.size() > 10 && base[10] != '.')) continue;
+        void *cand = dlopen(file.c_str(), RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
+        if (is_rccl(cand)) {
+            h = cand;
+            path = file;
+        } else if (cand) {
+            dlclose(cand);
+        }
     }
     fclose(f);
     return h;
@@ -81,9 +97,17 @@ static int32_t load_rccl()
     RcclApi a;
     void *h = find_mapped_rccl(a.path);
     a.reused = h != nullptr;
-    if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
-    VG_CHECK(h, VG_ERR_UNSUPPORTED, "vg_comm: cannot load librccl.so.1: %s", dlerror());
+    std::string why;
+    if (!h) {
+        (void)dlerror();  // the message below must be this dlopen's, not an earlier NOLOAD probe's
+        h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) {
+            const char *e = dlerror();
+            why = e ? e : "";
+            h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        }
+    }
+    VG_CHECK(h, VG_ERR_UNSUPPORTED, "vg_comm: cannot load librccl.so.1: %s", why.c_str());
     a.GetUniqueId = reinterpret_cast<decltype(a.GetUniqueId)>(dlsym(h, "ncclGetUniqueId"));
     a.CommInitRank = reinterpret_cast<decltype(a.CommInitRank)>(dlsym(h, "ncclCommInitRank"));
     a.CommDestroy = reinterpret_cast<decltype(a.CommDestroy)>(dlsym(h, "ncclCommDestroy"));

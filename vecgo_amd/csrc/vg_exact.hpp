@@ -181,6 +181,39 @@ __device__ __forceinline__ float exact_pair16(const float *__restrict__ row,
     return total;
 }
 
+// squaredL2BoundedAvx512's EARLY EXIT (bounded_l2_avx512.c:19-108): the partial total it returns when a 64-float
+// block's running sum first exceeds `bound` — the reduction (combine4 + hsum512) evaluated after every block, as the
+// reference does.  Only called for pairs already known to exceed (exact_pair16<false, kBounded> > bound), so the
+// block loop always terminates by its own test when the excess is reached inside the 64-blocks; an excess that only
+// the 8-wide / scalar remainder produces returns the full sum, like the reference.  All 16 lanes return the value.
+__device__ __forceinline__ float exact_l2_bounded_partial16(const float *__restrict__ row, const float *__restrict__ q,
+                                                            int dim, Sub16 sub, float bound, float full)
+{
+    float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    const int nblk = dim >> 6;
+    const float4 *r4 = reinterpret_cast<const float4 *>(row) + sub.f4;
+    const float4 *q4 = reinterpret_cast<const float4 *>(q) + sub.f4;
+    for (int e = 0; e < nblk; e++) {
+        const float4 a = q4[e * 16], b = r4[e * 16];
+        const float d0 = a.x - b.x, d1 = a.y - b.y, d2 = a.z - b.z, d3 = a.w - b.w;
+        acc[0] = __builtin_fmaf(d0, d0, acc[0]);
+        acc[1] = __builtin_fmaf(d1, d1, acc[1]);
+        acc[2] = __builtin_fmaf(d2, d2, acc[2]);
+        acc[3] = __builtin_fmaf(d3, d3, acc[3]);
+        float t[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const float p = dpp_partner_add<kDppRowHalfMirror>(acc[u]);
+            const float s = dpp_partner_add<kDppRowMirror>(p);
+            const float x = dpp_partner_add<kDppQuadXor2>(s);
+            t[u] = dpp_partner_add<kDppQuadXor1>(x);
+        }
+        const float total = (t[0] + t[1]) + (t[2] + t[3]);
+        if (total > bound) return total;  // the same bits in all 16 lanes: a uniform exit for the group
+    }
+    return full;
+}
+
 // L2 of one pair in BOTH reduction orders at once: `pair` = squaredL2Avx512 (what
 // distFunc/SquaredL2 returns), `bnd` = squaredL2BoundedAvx512 run to completion.  The HNSW
 // layer search needs both because which one the reference calls depends on heap state that
