@@ -1081,9 +1081,49 @@ __device__ __forceinline__ void i4_issue_word(I4Vals8 &x, uint32_t w, uint32_t b
 #undef VG_I4_ONE
 }
 
+#ifdef VG_I4_TIMING  // stage probe (tools/build_variant.sh): s_memtime per phase, totals written over out[] by lane 0
+#define VG_I4_T(var) const int64_t var = static_cast<int64_t>(__builtin_readcyclecounter())
+#define VG_I4_TACC(acc, a, b) (acc) += (b) - (a)
+#else
+#define VG_I4_T(var)
+#define VG_I4_TACC(acc, a, b)
+#endif
 constexpr int kI4TabWaves = 12;
 constexpr int kI4TabStride = 144;
 constexpr int kI4TabMaxDim = 1024;
+
+// the 16 code bytes of a 32-element block, read from the wave's staging buffer under the same in-order accounting as
+// the lookups ("memory": the staging writes before it stay before it, the next piece's writes stay after the last one)
+typedef uint32_t i4_u4 __attribute__((ext_vector_type(4)));  // one register tuple as an asm operand: no sub-register copies
+__device__ __forceinline__ i4_u4 i4_lds_read_block(uint32_t addr)
+{
+    i4_u4 c;
+    asm volatile("ds_read_b128 %0, %1" : "=v"(c) : "v"(addr) : "memory");
+    return c;
+}
+template <int N>
+__device__ __forceinline__ void i4_lds_wait_c(I4Vals8 &x, i4_u4 &c)
+{
+    asm volatile("s_waitcnt lgkmcnt(%9)"
+                 : "+v"(x.v[0]), "+v"(x.v[1]), "+v"(x.v[2]), "+v"(x.v[3]), "+v"(x.v[4]), "+v"(x.v[5]), "+v"(x.v[6]), "+v"(x.v[7]),
+                   "+v"(c)
+                 : "n"(N));
+}
+__device__ __forceinline__ void i4_lds_drain(i4_u4 &c)
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(c) : : "memory");
+}
+
+// r04: the lookups of a whole 128-byte piece (8 blocks x 4 words x 8 lookups) run as ONE software pipeline — two words
+// (16 lookups) in flight across block boundaries, the next block's 16 code bytes requested (asm, same queue) while the
+// current block's second word is still out — where r03 drained the queue at the end of every 32-element block and then
+// waited out the read of the next block's bytes: two LDS round trips per 32 dimensions with nothing of this wave in
+// flight (stage probe -DVG_I4_TIMING: 83 % of a wave's time is the lookup phase, and its rate was that of a loop with
+// those bubbles, not that of the vector ALU: tools/ubench/lds_valu_overlap.hip).  LDS operations of a wave return in
+// order, so "at most N outstanding" names exactly which word is back: per block the counted waits are 9, 9, 8, 8 (the
+// 9s have the next block's ds_read_b128 behind them).  The rows' addresses are a per-tile scalar base + a per-lane
+// 32-bit offset (global_load saddr form): no 64-bit pointer arithmetic or selects per piece (r03: 32 of the 544 vector
+// instructions of a piece).  Arithmetic and its order are unchanged: block b, words 0..3, accumulator (4 wi + k) & 7.
 template <bool PRE>
 __global__ __launch_bounds__(kI4TabWaves * 64) void int4_scan_tab_kernel(const float *__restrict__ query,
                                                                          const uint8_t *__restrict__ codes, int64_t n, int dim,
@@ -1092,7 +1132,8 @@ __global__ __launch_bounds__(kI4TabWaves * 64) void int4_scan_tab_kernel(const f
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char i4smem[];
     float *table = reinterpret_cast<float *>(i4smem);  // [dim][16]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // a scalar: the tile's base address lives in SGPRs
     unsigned char *stage = i4smem + static_cast<size_t>(dim) * 64 + wave * (64 * kI4TabStride);
     const int waves = blockDim.x >> 6;  // 12, fewer when the table leaves less room (dim 1024: 10)
     for (int e = tid; e < dim * 16; e += blockDim.x) {
@@ -1112,47 +1153,77 @@ __global__ __launch_bounds__(kI4TabWaves * 64) void int4_scan_tab_kernel(const f
     const int row_bytes = dim >> 1;
     const int64_t n_tiles = (n + 63) / 64;
     const int r = lane >> 3, part = lane & 7;  // staging: 8 lanes per row (one 128-byte line), 8 rows per load
-    // (named variables, not arrays: under this kernel's large-workgroup bound hipcc kept `uint4 u[..]` in scratch memory
-    // and waited out every load before storing it there)
-    auto row_ptr = [&](int64_t tile, int k) {
-        const int64_t row = tile * 64 + r + 8 * k < n ? tile * 64 + r + 8 * k : n - 1;  // past n: row n - 1 again, not stored
-        return codes + row * row_bytes + part * 16;
-    };
     const int64_t tile_step = static_cast<int64_t>(gridDim.x) * waves;
     int64_t tile = static_cast<int64_t>(blockIdx.x) * waves + wave;
     if (tile >= n_tiles) return;
+    // the table is the first thing in LDS: its real address (0 unless something static ever lands in this kernel's LDS)
+    // goes into every lookup's base, and must leave the low 11 bits of a block's base free for the nibble byte
+    const uint32_t table_lds = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(table));
+    const uint32_t stage_rd = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(stage)) + lane * kI4TabStride;
+    if ((table_lds & 2047u) != 0) __builtin_trap();
+    // per-lane byte offsets of the 8 rows this lane helps to load, relative to the tile's first row; rows past n
+    // (last tile only) read row n - 1 again and are not stored
+    auto offsets = [&](int64_t t, uint32_t (&vo)[8]) {
+        const int64_t left = n - t * 64;  // rows in the tile
+        const uint32_t lim = left >= 64 ? 63u : static_cast<uint32_t>(left - 1);
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const uint32_t rr = static_cast<uint32_t>(r + 8 * k);
+            vo[k] = (rr < lim ? rr : lim) * static_cast<uint32_t>(row_bytes) + static_cast<uint32_t>(part * 16);
+        }
+    };
+    uint32_t vo[8];
+    offsets(tile, vo);
+    const uint8_t *tbase = codes + tile * 64 * row_bytes;  // uniform
 #define VG_I4_ROWS(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
-#define VG_I4_DECL(K) const uint8_t *src##K = row_ptr(tile, K); uint4 u##K = *reinterpret_cast<const uint4 *>(src##K);
+#define VG_I4_DECL(K) uint4 u##K = *reinterpret_cast<const uint4 *>(tbase + vo[K]);
     VG_I4_ROWS(VG_I4_DECL)
 #undef VG_I4_DECL
     unsigned char *wr = stage + r * kI4TabStride + part * 16;
+#ifdef VG_I4_TIMING
+    int64_t t_vm = 0, t_ld = 0, t_look = 0, t_tiles = 0;
+    const int64_t t_begin = static_cast<int64_t>(__builtin_readcyclecounter());
+#endif
     for (; tile < n_tiles; tile += tile_step) {
+#ifdef VG_I4_TIMING
+        t_tiles++;
+#endif
         const int64_t row0 = tile * 64;
         // the wave's next tile (its first piece is requested while this tile's last one is scored); none: this tile again
         const int64_t tnext = tile + tile_step < n_tiles ? tile + tile_step : tile;
-#define VG_I4_NEXT(K) const uint8_t *nx##K = row_ptr(tnext, K);
-        VG_I4_ROWS(VG_I4_NEXT)
-#undef VG_I4_NEXT
+        const uint8_t *nbase = codes + tnext * 64 * row_bytes;
+        uint32_t von[8];
+        offsets(tnext, von);
         vg_f2v s1[8], s2[8];
 #pragma unroll
         for (int p = 0; p < 8; p++) s1[p] = s2[p] = vg_f2v{0.0f, 0.0f};
         for (int cb0 = 0; cb0 < row_bytes; cb0 += 128) {
+            VG_I4_T(tA);
 #define VG_I4_PUT(K) *reinterpret_cast<uint4 *>(wr + 8 * K * kI4TabStride) = u##K;
             VG_I4_ROWS(VG_I4_PUT)
 #undef VG_I4_PUT
-            const bool more = cb0 + 128 < row_bytes;  // (a pointer select, not a guarded load: hipcc waits at a join)
-#define VG_I4_GET(K) u##K = *reinterpret_cast<const uint4 *>(more ? src##K + cb0 + 128 : nx##K);
-            VG_I4_ROWS(VG_I4_GET)
+            VG_I4_T(tB);
+            VG_I4_TACC(t_vm, tA, tB);
+            i4_u4 c = i4_lds_read_block(stage_rd);
+            {   // the next piece of this tile, or the first piece of the wave's next tile: a scalar base and a per-lane
+                // 32-bit offset either way (uniform selects; a branch here became per-lane 64-bit pointers again)
+                const bool more = cb0 + 128 < row_bytes;
+                const uint8_t *pb = more ? tbase + cb0 + 128 : nbase;
+#define VG_I4_GET(K) u##K = *reinterpret_cast<const uint4 *>(pb + (more ? vo[K] : von[K]));
+                VG_I4_ROWS(VG_I4_GET)
 #undef VG_I4_GET
+            }
+            i4_lds_drain(c);  // the staging writes and the first block's bytes
+            VG_I4_T(tC);
+            VG_I4_TACC(t_ld, tB, tC);
+            const uint32_t pbase = table_lds + static_cast<uint32_t>(cb0) * 128u;  // table row of the piece's first dimension: j * 64 bytes
+            I4Vals8 va, vb;
+            i4_issue_word<0>(va, c.x, pbase);
+            i4_issue_word<1>(vb, c.y, pbase);
 #pragma unroll
-            for (int piece = 0; piece < 8; piece++) {
-                const uint4 c = *reinterpret_cast<const uint4 *>(stage + lane * kI4TabStride + piece * 16);
-                const uint32_t w[4] = {c.x, c.y, c.z, c.w};
-                const int j0 = (cb0 + piece * 16) * 2;  // first dimension of this 32-element block
-                // its table rows: the table is the first thing in LDS (byte 0: nothing static in this kernel), j0 * 64 is a
-                // multiple of 2048, so the low byte is free for the nibble
-                const uint32_t base = static_cast<uint32_t>(j0) * 64u;
-                vg_f2v *acc = (!PRE && (piece & 1)) ? s2 : s1;
+            for (int blk = 0; blk < 8; blk++) {
+                const uint32_t base = pbase + static_cast<uint32_t>(blk) * 2048u;  // 32 dimensions x 64 bytes
+                vg_f2v *acc = (!PRE && (blk & 1)) ? s2 : s1;
                 auto take = [&](const I4Vals8 &x, int wi) {  // code bytes 4 wi .. 4 wi + 3: accumulator pairs (4 wi + k) & 7
 #pragma unroll
                     for (int k = 0; k < 4; k++) {
@@ -1160,20 +1231,37 @@ __global__ __launch_bounds__(kI4TabWaves * 64) void int4_scan_tab_kernel(const f
                         acc[(4 * wi + k) & 7] = __builtin_elementwise_fma(d, d, acc[(4 * wi + k) & 7]);
                     }
                 };
-                I4Vals8 va, vb;
-                i4_issue_word<0>(va, w[0], base);
-                i4_issue_word<1>(vb, w[1], base);
-                i4_lds_wait<8>(va);
-                take(va, 0);
-                i4_issue_word<2>(va, w[2], base);
-                i4_lds_wait<8>(vb);
-                take(vb, 1);
-                i4_issue_word<3>(vb, w[3], base);
-                i4_lds_wait<8>(va);
-                take(va, 2);
-                i4_lds_wait<0>(vb);
-                take(vb, 3);
+                i4_u4 cn = c;
+                if (blk < 7) {
+                    cn = i4_lds_read_block(stage_rd + (blk + 1) * 16);
+                    i4_lds_wait<9>(va);  // behind word 0: word 1 and the next block's bytes
+                    take(va, 0);
+                    i4_issue_word<2>(va, c.z, base);
+                    i4_lds_wait<9>(vb);  // behind word 1: the bytes and word 2
+                    take(vb, 1);
+                    i4_issue_word<3>(vb, c.w, base);
+                    i4_lds_wait_c<8>(va, cn);  // behind word 2: word 3 — the next block's bytes are older, so they are back
+                    take(va, 2);
+                    i4_issue_word<0>(va, cn.x, base + 2048u);
+                    i4_lds_wait<8>(vb);
+                    take(vb, 3);
+                    i4_issue_word<1>(vb, cn.y, base + 2048u);
+                    c = cn;
+                } else {
+                    i4_lds_wait<8>(va);
+                    take(va, 0);
+                    i4_issue_word<2>(va, c.z, base);
+                    i4_lds_wait<8>(vb);
+                    take(vb, 1);
+                    i4_issue_word<3>(vb, c.w, base);
+                    i4_lds_wait<8>(va);
+                    take(va, 2);
+                    i4_lds_wait<0>(vb);
+                    take(vb, 3);
+                }
             }
+            VG_I4_T(tD);
+            VG_I4_TACC(t_look, tC, tD);
         }
         float s16[16];
 #pragma unroll
@@ -1184,11 +1272,22 @@ __global__ __launch_bounds__(kI4TabWaves * 64) void int4_scan_tab_kernel(const f
         }
         const float total = reduce16_regs(s16);
         if (row0 + lane < n) out[row0 + lane] = total;
-#define VG_I4_ADV(K) src##K = nx##K;
-        VG_I4_ROWS(VG_I4_ADV)
-#undef VG_I4_ADV
-#undef VG_I4_ROWS
+        tbase = nbase;
+#pragma unroll
+        for (int k = 0; k < 8; k++) vo[k] = von[k];
     }
+#undef VG_I4_ROWS
+#ifdef VG_I4_TIMING
+    if (lane == 0) {
+        const int64_t t_all = static_cast<int64_t>(__builtin_readcyclecounter()) - t_begin;
+        float *o = out + (static_cast<int64_t>(blockIdx.x) * waves + wave) * 8;
+        o[0] = static_cast<float>(t_tiles);
+        o[1] = static_cast<float>(t_all);
+        o[2] = static_cast<float>(t_vm);
+        o[3] = static_cast<float>(t_ld);
+        o[4] = static_cast<float>(t_look);
+    }
+#endif
 }
 
 static int sq_slices(int64_t nq, int64_t n_tiles, int cus)
