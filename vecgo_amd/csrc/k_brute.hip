@@ -68,6 +68,61 @@ __global__ __launch_bounds__(kBruteDistThreads) void brute_dist_kernel(const flo
     }
 }
 
+// The same distances for a BLOCK of queries: a 16-lane group keeps two rows in registers and scores them against up to
+// kBruteQB queries held in LDS (exact_rowregs16x2: every LDS read of a query piece serves both rows) — a row is read
+// from HBM once per query block instead of once per query through L2, with a quarter of the instructions per pair
+// (tools/brute_time.py, 256 queries x 1M x 768: 44 ms with the kernel above).  dim % 4 == 0, dim <= 1024; `mask` is
+// the batch's shared mask or none (per-query masks take the kernel above).
+constexpr int kBruteQB = 16;
+template <int METRIC>
+__global__ __launch_bounds__(kBruteDistThreads) void brute_dist_mq_kernel(const float *__restrict__ base, int64_t n, int dim,
+                                                                          const float *__restrict__ queries, int nq,
+                                                                          const uint8_t *__restrict__ mask,
+                                                                          float *__restrict__ dist)
+{
+    extern __shared__ float brute_q[];  // kBruteQB * dim
+    const int q0 = blockIdx.x * kBruteQB;
+    const int qn = nq - q0 < kBruteQB ? nq - q0 : kBruteQB;
+    for (int t = threadIdx.x; t < qn * dim; t += kBruteDistThreads) brute_q[t] = queries[static_cast<int64_t>(q0) * dim + t];
+    __syncthreads();
+    const Sub16 sub = Sub16::make(threadIdx.x);
+    const int nblk = dim >> 6;
+    const int grp = threadIdx.x >> 4;  // 16 groups, two rows each
+    constexpr bool DOT = METRIC == kMetricDot;
+    for (int64_t r0 = static_cast<int64_t>(blockIdx.y) * 32; r0 < n; r0 += static_cast<int64_t>(gridDim.y) * 32) {
+        const int64_t ia = r0 + 2 * grp, ib = ia + 1;
+        const bool la = ia < n && mask_bit(mask, ia), lb = ib < n && mask_bit(mask, ib);
+        if (!la && !lb) continue;  // (uniform over the 16 lanes of the group)
+        const float *rowa = base + (la ? ia : (lb ? ib : 0)) * dim;
+        const float *rowb = base + (lb ? ib : (la ? ia : 0)) * dim;
+        float4 ra[16], rb[16];
+        const float4 *a4 = reinterpret_cast<const float4 *>(rowa) + sub.f4;
+        const float4 *b4 = reinterpret_cast<const float4 *>(rowb) + sub.f4;
+#pragma unroll
+        for (int e = 0; e < 16; e++)
+            if (e < nblk) {
+                ra[e] = load_stream(a4 + e * 16);
+                rb[e] = load_stream(b4 + e * 16);
+            }
+        for (int qi = 0; qi < qn; qi++) {
+            float va, vb;
+            exact_rowregs16x2<DOT>(ra, rb, nblk, rowa, rowb, brute_q + static_cast<size_t>(qi) * dim, dim, sub, va, vb);
+            if (DOT) {
+                va = -va;
+                vb = -vb;
+            } else if (METRIC == kMetricCos) {
+                va = 0.5f * va;
+                vb = 0.5f * vb;
+            }
+            if ((threadIdx.x & 15) == 0) {
+                float *dq = dist + static_cast<int64_t>(q0 + qi) * n;
+                if (la) dq[ia] = va;
+                if (lb) dq[ib] = vb;
+            }
+        }
+    }
+}
+
 // one accepted-or-not decision of the reference's loop, uniform over wave 0
 template <int MODE>
 __device__ __forceinline__ void brute_offer(HItem *heap, int &len, int k, HItem it)
@@ -97,9 +152,10 @@ __global__ __launch_bounds__(kBruteThreads) void brute_replay_kernel(const float
     extern __shared__ uint64_t brute_lds[];
     HItem *heap = reinterpret_cast<HItem *>(brute_lds);           // k + 4 items
     HItem *list = heap + ((k + 4 + 3) & ~3);                        // kBruteStep items
-    __shared__ int wave_cnt[kBruteThreads / 64];
+    __shared__ int wave_cnt[2][kBruteThreads / 64];                 // (alternating: one barrier per step on the fast path)
     __shared__ int s_len;
     __shared__ float s_top;
+    __shared__ uint32_t s_hit[3];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t q = blockIdx.x;
     const float *dq = dist + q * n;
@@ -107,62 +163,160 @@ __global__ __launch_bounds__(kBruteThreads) void brute_replay_kernel(const float
     if (tid == 0) {
         s_len = 0;
         s_top = 0.0f;
+        s_hit[0] = s_hit[1] = s_hit[2] = 0u;
     }
     __syncthreads();
     int len = 0;  // wave 0's copy is the live one
-    for (int64_t base = 0; base < n; base += kBruteStep) {
-        const int cur_len = s_len;
-        const float top = s_top;
-        const int64_t i0 = base + static_cast<int64_t>(tid) * 4;
-        float d[4];
-        bool f[4];
-        if (i0 + 3 < n && mq == nullptr && (n & 3) == 0) {
-            const float4 v = *reinterpret_cast<const float4 *>(dq + i0);  // n*4 bytes per query row: 16-byte aligned when n % 4 == 0
-            d[0] = v.x, d[1] = v.y, d[2] = v.z, d[3] = v.w;
+    int64_t step_no = 0;
+    const bool vec = (n & 3) == 0;  // whole float4s, 16-byte aligned (each query's row starts at q * n floats)
+    constexpr int kSub = 4;         // 4096-row sub-steps per super-step: one barrier per 16384 rows when nothing qualifies
+    // a super-step's distances are requested one super-step ahead (a single workgroup streams its row: an exposed HBM
+    // round trip per step was most of a one-query call); masked-out rows hold whatever the scratch held: never used
+    auto fetch = [&](int64_t base, float (&d)[kSub][4], uint32_t &in) {
+        in = 0;
+        if (vec && base + static_cast<int64_t>(kSub) * kBruteStep <= n) {
+            // a whole super-step inside the row (uniform): straight-line loads, nothing waits between them
+            float4 v[kSub];
+            uint32_t mb[kSub];
 #pragma unroll
-            for (int e = 0; e < 4; e++) f[e] = cur_len < k || d[e] < top;
-        } else {
+            for (int c = 0; c < kSub; c++) {
+                const int64_t i0 = base + static_cast<int64_t>(c) * kBruteStep + static_cast<int64_t>(tid) * 4;
+                v[c] = *reinterpret_cast<const float4 *>(dq + i0);
+                mb[c] = mq ? mq[i0 >> 3] : 0xFFu;  // i0 is a multiple of 4: its four mask bits are one nibble of byte i0 / 8
+            }
+#pragma unroll
+            for (int c = 0; c < kSub; c++) {
+                const int sh = static_cast<int>((static_cast<int64_t>(c) * kBruteStep + static_cast<int64_t>(tid) * 4 + base) & 7);
+                d[c][0] = v[c].x, d[c][1] = v[c].y, d[c][2] = v[c].z, d[c][3] = v[c].w;
+                in |= ((mb[c] >> sh) & 15u) << (4 * c);
+            }
+            return;
+        }
+#pragma unroll
+        for (int c = 0; c < kSub; c++) {  // the row's last super-step, or a row that is not whole float4s
+            const int64_t i0 = base + static_cast<int64_t>(c) * kBruteStep + static_cast<int64_t>(tid) * 4;
 #pragma unroll
             for (int e = 0; e < 4; e++) {
-                const bool in = i0 + e < n && mask_bit(mq, i0 + e);
-                d[e] = in ? dq[i0 + e] : 0.0f;
-                f[e] = in && (cur_len < k || d[e] < top);
+                const bool ok = i0 + e < n && mask_bit(mq, i0 + e);
+                d[c][e] = ok ? dq[i0 + e] : 0.0f;
+                in |= static_cast<uint32_t>(ok) << (4 * c + e);
             }
         }
-        const int cnt = int(f[0]) + int(f[1]) + int(f[2]) + int(f[3]);
-        // ordered exclusive prefix over the workgroup: row order = thread order
-        int incl = cnt;
+    };
+    // Two super-steps of distances in flight (64 KiB each), in two FIXED register sets that are consumed and refilled in
+    // place (a rotating set costs register copies, and a copy of a set still in flight waits for it): one workgroup
+    // streams its query's row, and with one request outstanding every super-step paid a whole memory round trip.
+    constexpr int64_t kSuper = static_cast<int64_t>(kSub) * kBruteStep;
+    float ra[kSub][4], rb[kSub][4];
+    uint32_t ia = 0, ib = 0;
+    fetch(0, ra, ia);
+    if (kSuper < n) fetch(kSuper, rb, ib);
+    int par = 0;
+    // one super-step: `dd` / `in` are its distances and membership bits, `sbase` its first row
+    auto super_step = [&](const float (&dd)[kSub][4], const uint32_t in, const int64_t sbase) {
+        uint32_t hit;  // bit c: some row of sub-step c beats the top as it stands at the start of the super-step
+        {
+            const int cur_len = s_len;
+            const float top = s_top;
+            uint32_t mine = 0;
 #pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const int y = __shfl_up(incl, off);
-            if (lane >= off) incl += y;
-        }
-        if (lane == 63) wave_cnt[wave] = incl;
-        __syncthreads();
-        int before = 0, total = 0;
+            for (int c = 0; c < kSub; c++)
 #pragma unroll
-        for (int w = 0; w < kBruteThreads / 64; w++) {
-            const int c = wave_cnt[w];
-            if (w < wave) before += c;
-            total += c;
+                for (int e = 0; e < 4; e++)
+                    if (((in >> (4 * c + e)) & 1u) && (cur_len < k || dd[c][e] < top)) mine |= 1u << c;
+            // three alternating words: the one used two super-steps ago is cleared for the next one (every wave has
+            // passed the previous barrier, so it has read that word; nobody adds to it before this super-step's barrier)
+            const int slot = static_cast<int>(step_no % 3);
+            if (tid == 0) s_hit[(slot + 1) % 3] = 0u;
+            if (mine) atomicOr(&s_hit[slot], mine);
+            __syncthreads();
+            hit = s_hit[slot];
+            step_no++;
+            if (hit == 0) return;  // nothing of the 16384 rows can enter the heap: one barrier and on (the common case once it is full)
+#if defined(VG_BRUTE_PROBE) && VG_BRUTE_PROBE == 1
+            return;  // stage probe: streaming + the one barrier only
+#endif
         }
-        if (total == 0) {  // uniform: nothing in this step can enter the heap
-            __syncthreads();  // wave_cnt is rewritten by the next step
-            continue;
-        }
-        int pos = before + incl - cnt;
 #pragma unroll
-        for (int e = 0; e < 4; e++)
-            if (f[e]) heap_store(list + pos++, HItem{static_cast<uint32_t>(i0 + e), d[e]});
-        __syncthreads();
-        if (wave == 0) {
-            for (int j = 0; j < total; j++) brute_offer<MODE>(heap, len, k, heap_load(list + j));
-            if (lane == 0) {
-                s_len = len;
-                s_top = len > 0 ? heap_get(heap, 0).dist : 0.0f;
+        for (int c = 0; c < kSub; c++) {
+            if (!((hit >> c) & 1u)) continue;  // uniform: no candidate in this sub-step (the top only falls meanwhile)
+            par ^= 1;
+            const int64_t base = sbase + static_cast<int64_t>(c) * kBruteStep;
+            if (base >= n) break;  // uniform
+            const int cur_len = s_len;
+            const float top = s_top;
+            const int64_t i0 = base + static_cast<int64_t>(tid) * 4;
+            float d[4];
+            bool f[4];
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                d[e] = dd[c][e];
+                f[e] = ((in >> (4 * c + e)) & 1u) && (cur_len < k || d[e] < top);
             }
+            const int cnt = int(f[0]) + int(f[1]) + int(f[2]) + int(f[3]);
+            // ordered exclusive prefix over the workgroup: row order = thread order
+            int incl = cnt;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const int y = __shfl_up(incl, off);
+                if (lane >= off) incl += y;
+            }
+            if (lane == 63) wave_cnt[par][wave] = incl;
+            __syncthreads();
+            int before = 0, total = 0;
+#pragma unroll
+            for (int w = 0; w < kBruteThreads / 64; w++) {
+                const int cw = wave_cnt[par][w];
+                if (w < wave) before += cw;
+                total += cw;
+            }
+            if (total == 0) continue;  // uniform: nothing in this sub-step can enter the heap (the other counter set is next)
+            int pos = before + incl - cnt;
+#pragma unroll
+            for (int e = 0; e < 4; e++)
+                if (f[e]) heap_store(list + pos++, HItem{static_cast<uint32_t>(i0 + e), d[e]});
+            __syncthreads();
+#if defined(VG_BRUTE_PROBE) && VG_BRUTE_PROBE == 2
+            if (false) {
+#else
+            if (wave == 0) {
+#endif
+                // the list 64 items at a time (one LDS read per lane), the reference's test against the LIVE top in a
+                // register: only items that pass it reach the heap, in list order — a sub-step whose rows all beat a stale
+                // top (the first one: the heap is still filling) costs one ballot per 64 rows, not a heap round trip per row
+                float top_live = len >= k ? heap_get(heap, 0).dist : 0.0f;
+                for (int j0 = 0; j0 < total; j0 += 64) {
+                    const int j = j0 + lane;
+                    const HItem mine = j < total ? heap_load(list + j) : HItem{0u, 0.0f};
+                    uint64_t m = __ballot(j < total && (len < k || mine.dist < top_live));
+                    while (m) {
+                        const int b = __builtin_ctzll(m);
+                        m &= m - 1;
+                        const HItem x{heap_readlane(mine.node, b), __uint_as_float(heap_readlane(__float_as_uint(mine.dist), b))};
+                        if (len < k) {  // scanSegment hnsw.go:2089-2091 / TryPushBounded queue.go:192-196
+                            heap_push<true>(heap, len, x);
+                            if (len == k) top_live = heap_get(heap, 0).dist;
+                        } else if (x.dist < top_live) {  // hnsw.go:2093-2097 / queue.go:199-213 (`>=` rejects)
+                            brute_offer<MODE>(heap, len, k, x);
+                            top_live = heap_get(heap, 0).dist;
+                        }
+                    }
+                }
+                if (lane == 0) {
+                    s_len = len;
+                    s_top = len > 0 ? heap_get(heap, 0).dist : 0.0f;
+                }
+            }
+            __syncthreads();
         }
-        __syncthreads();
+    };
+    for (int64_t sbase = 0; sbase < n; sbase += 2 * kSuper) {
+        super_step(ra, ia, sbase);
+        if (sbase + 2 * kSuper < n) fetch(sbase + 2 * kSuper, ra, ia);
+        if (sbase + kSuper < n) {
+            super_step(rb, ib, sbase + kSuper);
+            if (sbase + 3 * kSuper < n) fetch(sbase + 3 * kSuper, rb, ib);
+        }
     }
     if (wave == 0) {
         // BruteSearch hnsw.go:2067-2071: res[i] = PopItem() for i = len-1 .. 0 (extraction :1738-1751 pops, then reverses)
@@ -328,19 +482,42 @@ VG_API int32_t vg_search_hnsw_brute(vg_index *idx, const float *queries, int64_t
     for (int64_t q0 = 0; q0 < nq; q0 += chunk) {
         const int64_t cnt = std::min(chunk, nq - q0);
         const uint8_t *m0 = mk.ptr ? mk.ptr + q0 * mask_stride : nullptr;
-        vg::ProfScope prof(idx->ctx, "hnsw_brute", st);
         if (n > 0) {
-            const dim3 grid(static_cast<unsigned>(cnt), row_blocks), block(vg::kBruteDistThreads);
-            if (idx->metric == VG_METRIC_L2)
-                VG_LAUNCH(vg::brute_dist_kernel<vg::kMetricL2>, grid, block, 0, st, idx->d_vectors, n, idx->dim,
-                          q.ptr + q0 * idx->dim, m0, mask_stride, dist);
-            else if (idx->metric == VG_METRIC_COSINE)
-                VG_LAUNCH(vg::brute_dist_kernel<vg::kMetricCos>, grid, block, 0, st, idx->d_vectors, n, idx->dim,
-                          q.ptr + q0 * idx->dim, m0, mask_stride, dist);
-            else
-                VG_LAUNCH(vg::brute_dist_kernel<vg::kMetricDot>, grid, block, 0, st, idx->d_vectors, n, idx->dim,
-                          q.ptr + q0 * idx->dim, m0, mask_stride, dist);
+            vg::ProfScope prof(idx->ctx, "hnsw_brute_dist", st);
+            const bool mq = cnt >= 2 && idx->dim % 4 == 0 && idx->dim <= 1024 && (m0 == nullptr || mask_stride == 0);
+            if (mq) {  // query-blocked: rows read once per 16 queries
+                const unsigned qblocks = static_cast<unsigned>((cnt + vg::kBruteQB - 1) / vg::kBruteQB);
+                const int64_t want = std::max<int64_t>(1, (int64_t(8) * std::max(idx->ctx->compute_units, 1) + qblocks - 1) / qblocks);
+                const unsigned rblocks = static_cast<unsigned>(std::min<int64_t>(std::min<int64_t>((n + 31) / 32, want), 65535));
+                const size_t qlds = static_cast<size_t>(vg::kBruteQB) * idx->dim * sizeof(float);
+                const dim3 grid(qblocks, rblocks), block(vg::kBruteDistThreads);
+                auto launch = [&](auto kern) -> int32_t {
+                    VG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               static_cast<int>(qlds)));
+                    VG_LAUNCH(kern, grid, block, qlds, st, idx->d_vectors, n, idx->dim, q.ptr + q0 * idx->dim,
+                              static_cast<int>(cnt), m0, dist);
+                    return VG_OK;
+                };
+                if (idx->metric == VG_METRIC_L2)
+                    VG_TRY(launch(vg::brute_dist_mq_kernel<vg::kMetricL2>));
+                else if (idx->metric == VG_METRIC_COSINE)
+                    VG_TRY(launch(vg::brute_dist_mq_kernel<vg::kMetricCos>));
+                else
+                    VG_TRY(launch(vg::brute_dist_mq_kernel<vg::kMetricDot>));
+            } else {
+                const dim3 grid(static_cast<unsigned>(cnt), row_blocks), block(vg::kBruteDistThreads);
+                if (idx->metric == VG_METRIC_L2)
+                    VG_LAUNCH(vg::brute_dist_kernel<vg::kMetricL2>, grid, block, 0, st, idx->d_vectors, n, idx->dim,
+                              q.ptr + q0 * idx->dim, m0, mask_stride, dist);
+                else if (idx->metric == VG_METRIC_COSINE)
+                    VG_LAUNCH(vg::brute_dist_kernel<vg::kMetricCos>, grid, block, 0, st, idx->d_vectors, n, idx->dim,
+                              q.ptr + q0 * idx->dim, m0, mask_stride, dist);
+                else
+                    VG_LAUNCH(vg::brute_dist_kernel<vg::kMetricDot>, grid, block, 0, st, idx->d_vectors, n, idx->dim,
+                              q.ptr + q0 * idx->dim, m0, mask_stride, dist);
+            }
         }
+        vg::ProfScope prof(idx->ctx, "hnsw_brute_replay", st);
         VG_LAUNCH(replay, dim3(static_cast<unsigned>(cnt)), dim3(vg::kBruteThreads), lds, st, dist, n, m0, mask_stride, k,
                   oid.ptr + q0 * k, osc.ptr + q0 * k);
     }
