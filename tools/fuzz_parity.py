@@ -45,7 +45,7 @@ while time.time() < t_end:
     cfg = dict(n=n, dim=dim, nq=nq, k=k, metric=metric)
     idx = vg.Index(ctx, n, dim, vg.Metric(metric))
     idx.set_vectors(x)
-    which = rng.integers(0, 9)
+    which = rng.integers(0, 11)
     try:
         if which == 0:
             tag = "flat"
@@ -203,6 +203,42 @@ while time.time() < t_end:
             ids, sc = idx.search_vamana(q, kk, kind=1)
             ov = o.VamanaIndex(l0, entry, dim, o.VAMANA_PQ, pq=opq, codes=codes)
             compare("vamana_pq", dict(cfg, m=gm, pq_m=m), ids, sc, [ov.search(q[i], kk)[:2] for i in range(nq)])
+        elif which == 9:
+            # hnsw.BruteSearch / searchBitmap replayed through the reference's PriorityQueue: tie-heavy integer grids
+            # half of the time (where the two disciplines return different ids), masks shared / per query / none
+            if rng.random() < 0.5:
+                grid = int(rng.choice([2, 3, 5, 30]))
+                x = rng.integers(0, grid, (n, dim)).astype(np.float32)
+                q = rng.integers(0, grid, (nq, dim)).astype(np.float32)
+                if metric == 1:
+                    x[np.abs(x).sum(1) == 0, 0] = 1; q[np.abs(q).sum(1) == 0, 0] = 1
+                    x /= np.linalg.norm(x, axis=1, keepdims=True); q /= np.linalg.norm(q, axis=1, keepdims=True)
+                idx.set_vectors(x)
+            mode = int(rng.integers(0, 2))
+            mk = int(rng.integers(0, 3))
+            mask = None if mk == 0 else (rng.random(n) < rng.choice([0.02, 0.5, 0.95]) if mk == 1 else rng.random((nq, n)) < 0.4)
+            kk = min(k, 1024)
+            oidx = o.HnswIndex(x, dim, np.full((n, 1), 0xFFFFFFFF, np.uint32), metric=metric)
+            ids, sc = idx.search_hnsw_brute(q, kk, mode, mask)
+            exp = [oidx.brute_search(q[i], kk, mode, None if mask is None else (mask if mask.ndim == 1 else mask[i])) for i in range(nq)]
+            for i, (eid, esc) in enumerate(exp):
+                r = eid.size
+                if not (np.array_equal(ids[i, :r], eid) and np.array_equal(bits(sc[i, :r]), bits(esc)) and np.all(ids[i, r:] == 0xFFFFFFFF)):
+                    fails += 1
+                    print(f"MISMATCH hnsw_brute {cfg} mode={mode} mask={mk} query {i}: got {ids[i]} want {eid}", flush=True)
+                    break
+        elif which == 10:
+            # searcher.PriorityQueue scripts on the device heap (vg_debug_heap_replay) vs the oracle's heap: flags, popped
+            # items and the final heap array, float and unsigned-key sifts
+            from tests import heap_kats
+            for is_max, script in heap_kats.random_scripts(int(rng.integers(0, 1 << 30)), n_scripts=6):
+                ops = o.heap_script_array(script)
+                want = o.prioq_replay(is_max, script)
+                for uk in (False, True):
+                    out, nodes, dists = vg.heap_replay(ctx, is_max, ops, unsigned_keys=uk, cap=4096)
+                    if not heap_kats.same((out, (nodes, dists)), want):
+                        fails += 1
+                        print(f"MISMATCH heap script is_max={is_max} uk={uk} ops={len(script)}", flush=True)
     except vg.VecgoHipError as e:
         fails += 1
         print(f"ERROR {cfg} which={which}: {e}", flush=True)
