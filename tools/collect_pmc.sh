@@ -22,6 +22,8 @@ if [ "$what" = scans ] || [ "$what" = all ]; then
     $P i4_fetch "FETCH_SIZE" python3 tools/int4_batch_time.py 4000000
     $P i4_write "WRITE_SIZE" python3 tools/int4_batch_time.py 4000000
     $P i4_lds "SQ_INSTS_VALU SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE" python3 tools/int4_batch_time.py 4000000
+    $P i4_issue "SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_WAVE_CYCLES GRBM_GUI_ACTIVE" python3 tools/int4_batch_time.py 4000000
+    $P i4_wait "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_WAVE_CYCLES GRBM_GUI_ACTIVE" python3 tools/int4_batch_time.py 4000000
 fi
 if [ "$what" = gemm ] || [ "$what" = all ]; then
     $P gemm_fetch "FETCH_SIZE" python3 tools/flat_time.py

@@ -83,6 +83,21 @@ if i4:
         lds["lds_array_busy_fraction"] = lds["SQ_LDS_IDX_ACTIVE"] / 256 / cyc
         lds["valu_busy_fraction"] = lds["SQ_INSTS_VALU"] * 4 / 1024 / cyc
     i4["counters"] = lds
+    # issue slots (r04, tools/collect_pmc.sh i4_issue): one slot = one SIMD x 4 cycles; ANY = VALU + LDS + scalar + VMEM + misc
+    iss = {c: val("i4_issue", "int4_scan_tab_kernel<true>", c) for c in ("SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS",
+                                                                            "SQ_ACTIVE_INST_SCA", "SQ_WAVE_CYCLES", "GRBM_GUI_ACTIVE")}
+    iss2 = {c: val("i4_wait", "int4_scan_tab_kernel<true>", c) for c in ("SQ_WAIT_INST_ANY", "SQ_WAIT_ANY", "SQ_WAIT_INST_LDS", "SQ_INSTS_LDS", "SQ_WAVE_CYCLES", "GRBM_GUI_ACTIVE")}
+    if iss.get("GRBM_GUI_ACTIVE") and iss.get("SQ_ACTIVE_INST_ANY"):
+        slots = 1024 * (iss["GRBM_GUI_ACTIVE"] / 8) / 4
+        iss["issue_slots"] = slots
+        iss["issue_slots_used_fraction"] = iss["SQ_ACTIVE_INST_ANY"] / slots
+        iss["valu_slot_fraction"] = iss["SQ_ACTIVE_INST_VALU"] / slots
+        iss["lds_slot_fraction"] = iss["SQ_ACTIVE_INST_LDS"] / slots
+    if iss2.get("SQ_WAVE_CYCLES"):
+        iss2["waiting_for_an_issue_slot_fraction_of_wave_cycles"] = iss2["SQ_WAIT_INST_ANY"] / iss2["SQ_WAVE_CYCLES"]
+        iss2["waiting_at_waitcnt_fraction_of_wave_cycles"] = iss2["SQ_WAIT_ANY"] / iss2["SQ_WAVE_CYCLES"]
+    i4["issue"] = iss
+    i4["waits"] = iss2
 out["int4_scan"] = i4
 g = traffic("gemm_fetch", "gemm_write", "flat_gemm_dma_kernel<false, 2, 0, false>", 1_000_000 * 768 * 4 + 1024 * 768 * 4, {"workload": "1024 queries x 1M x 768 per launch"})
 if g:
