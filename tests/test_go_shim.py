@@ -307,3 +307,66 @@ def test_stats_mirror_matches_the_struct():
 @pytest.mark.skipif(shutil.which("go") is None, reason="no Go toolchain in this image")
 def test_go_vet():
     subprocess.run(["gofmt", "-l", "."], cwd=ROOT / "go", check=True)
+
+
+# ---- lexical checks a `go build` would fail on (no toolchain here) -----------------------------------------------
+def _strip_go(src: str) -> str:
+    """source with comments, string / rune / raw-string literals and the cgo preamble blanked out"""
+    out, i, n = [], 0, len(src)
+    while i < n:
+        two = src[i:i + 2]
+        if two == "//":
+            j = src.find("\n", i)
+            i = n if j < 0 else j
+        elif two == "/*":
+            j = src.find("*/", i + 2)
+            assert j >= 0, "unterminated comment"
+            out.append("\n" * src.count("\n", i, j))
+            i = j + 2
+        elif src[i] in "\"'`":
+            q = src[i]
+            j = i + 1
+            while j < n and src[j] != q:
+                j += 2 if (src[j] == "\\" and q != "`") else 1
+            assert j < n, "unterminated literal"
+            out.append(q + q)
+            i = j + 1
+        else:
+            out.append(src[i])
+            i += 1
+    return "".join(out)
+
+
+@pytest.mark.parametrize("path", GO, ids=lambda p: str(p.relative_to(ROOT / "go")))
+def test_go_file_is_lexically_sound(path):
+    raw = path.read_text()
+    src = _strip_go(raw)
+    # balanced delimiters
+    stack, pairs = [], {")": "(", "]": "[", "}": "{"}
+    for ln, line in enumerate(src.splitlines(), 1):
+        for ch in line:
+            if ch in "([{":
+                stack.append((ch, ln))
+            elif ch in ")]}":
+                assert stack and stack[-1][0] == pairs[ch], f"{path.name}:{ln}: unbalanced {ch!r}"
+                stack.pop()
+    assert not stack, f"{path.name}: unclosed {stack[-1]}"
+    # one package clause, the directory's name
+    pk = re.findall(r"^package (\w+)$", src, flags=re.M)
+    assert pk == [path.parent.name], pk
+    # every import is used (an unused import is a compile error in Go); "C" is the cgo pseudo-package
+    imports = []
+    for m in re.finditer(r'^import\s+(?:(\w+)\s+)?"([^"]+)"$', raw, flags=re.M):
+        imports.append((m.group(1), m.group(2)))
+    for blk in re.finditer(r"^import \((.*?)^\)", raw, flags=re.S | re.M):
+        for m in re.finditer(r'^\s*(?:(\w+)\s+)?"([^"]+)"', blk.group(1), flags=re.M):
+            imports.append((m.group(1), m.group(2)))
+    assert ("", "C") in [(a or "", p_) for a, p_ in imports]
+    for alias, ipath in imports:
+        name = alias or ipath.rsplit("/", 1)[-1]
+        if name in ("C", "_"):
+            continue
+        assert re.search(rf"\b{re.escape(name)}\.", src), f"{path.name}: import {ipath!r} is not used"
+    # every function has a body or is a method expression; no `:=` at package level
+    for m in re.finditer(r"^func [^\n]*$", src, flags=re.M):
+        assert m.group(0).rstrip().endswith(("{", "}")) or "{" in m.group(0), f"{path.name}: {m.group(0)!r} has no body"

@@ -68,6 +68,27 @@ def test_int4_scan_kernels_match_oracle(vg, ctx, n, dim):
         assert np.array_equal(bits(iq.l2_distance(q, codes)), bits(want))
 
 
+@pytest.mark.parametrize("n,dim", [(400_003, 512), (250_001, 768), (230_000, 1024)])
+def test_int4_scan_persistent_waves_many_tiles(vg, ctx, n, dim):
+    """more tiles than the device holds waves (256 CUs x 12): every wave of int4_scan_tab_kernel walks several tiles —
+    the next tile's first piece requested during the last piece of the current one, the scalar tile base advanced, a
+    ragged last tile whose missing rows re-read row n - 1 — for both summation orders, every row compared"""
+    rng = np.random.default_rng(n + dim)
+    mn = (rng.standard_normal(dim) * 0.5).astype(np.float32); df = (rng.random(dim) * 3 + 0.1).astype(np.float32)
+    iq = vg.Int4Quantizer(ctx, dim); iq.set_params(mn, df)
+    ref = o.Int4Quantizer(dim); ref.set_params(mn, df)
+    codes = rng.integers(0, 256, (n, dim // 2), dtype=np.uint8)
+    q = (rng.standard_normal(dim) * 2).astype(np.float32)
+    assert np.array_equal(bits(iq.l2_distance_batch(q, codes)), bits(ref.l2_distance_batch(q, codes)))
+    got = iq.l2_distance(q, codes)
+    want = ref.l2_distance_many(q, codes) if hasattr(ref, "l2_distance_many") else None
+    if want is None:   # the per-code form row by row is slow in Python: every 97th row + the last tile
+        pick = np.unique(np.concatenate([np.arange(0, n, 97), np.arange(max(0, n - 130), n)]))
+        want = np.array([ref.l2_distance(q, codes[i]) for i in pick], np.float32)
+        got = got[pick]
+    assert np.array_equal(bits(got), bits(want))
+
+
 def test_set_params_is_unmarshal_binary(vg, ctx):
     rng = np.random.default_rng(4)
     dim = 48
