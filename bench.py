@@ -508,7 +508,7 @@ def int4_scan_roofline(vg, ctx, stream, device):
     res = {"workload": "int4_l2_distance_4Mx768_nq1", "bound": "hbm", "peak": PEAK_HBM_GBS, "unit": "GB/s",
            "bytes_per_launch": n * DIM // 2, "kernel": "int4_scan_tab_kernel",
            "note": "bound by INSTRUCTION ISSUE: 2.0 vector + 1.06 LDS instructions per (64 rows x 1 dimension), one issue slot per SIMD "
-                   "per 4 clocks whatever the unit — 92.7 % of all slots carry an instruction (profiles/r04_pmc_i4_issue_*.csv: "
+                   "per 4 clocks whatever the unit — 91-93 % of all slots carry an instruction (profiles/r04_pmc_i4_issue.csv, r04_traffic.json int4_scan.issue: "
                    "SQ_ACTIVE_INST_ANY / (SIMDs x cycles / 4)); a per-lane lookup per dimension is the floor of this formulation: DESIGN.md section 4"}
     for name, fn in (("batch_order", iq.l2_distance_batch), ("lookup_table_order", iq.l2_distance)):
         for _ in range(100):
