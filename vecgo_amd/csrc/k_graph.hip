@@ -52,8 +52,13 @@ constexpr int kHnswLdsEf = 512;  // LDS items of the results heap (twice that fo
 // with one group of centroid loads in flight, nothing spilled) change nothing — 2.34 / 2.37 / 2.40 ms per 8192 queries at
 // ef 128, 8.55 / 8.12 / 8.21 per 32768 — the waves' issue slots are what is used up (each wave issues 39 % of its
 // cycles, profiles/r03_pmc_walk_pq_128_issue.csv), so the compiler's choice stays
+// r04: the terms of four sub-quantizers are computed as two interleaved packed chains (pq_term8_quad: the s_nop after
+// every link of a lone packed chain is gone, 2049 -> 136 in this kernel); left alone the compiler then takes 183
+// registers (2 waves per SIMD: 3.06 ms per 8192 queries at ef 128); held to 4 waves 2.28-2.34 ms (2.36 before), 9.68-9.70
+// (9.83) at ef 512, Vamana-PQ 1.58-1.60 (1.64): 1-3 %, i.e. the padding was not what bounds the walk - its instruction
+// count is (SALU pads co-issue with other waves)
 #ifndef VG_LDS_PQ_WAVES
-#define VG_LDS_PQ_WAVES 1
+#define VG_LDS_PQ_WAVES 4
 #endif
 #define VG_HNSW_ATTR __attribute__((amdgpu_waves_per_eu(SPLIT ? (PQM ? VG_SPLIT_PQ_WAVES : VG_SPLIT_F32_WAVES) : (PQM == 2 ? VG_LDS_PQ_WAVES : 1), SPLIT ? (PQM ? VG_SPLIT_PQ_WAVES : VG_SPLIT_F32_WAVES) : 8)))
 // UK: the metric is not Dot, so every distance is >= +0 and the heaps compare bit patterns (heap_sift_down_uk).

@@ -171,6 +171,44 @@ __device__ __forceinline__ vg_f2 pq_term8_pair(uint2 ea, uint2 eb, const float *
     return sum;
 }
 
+// FOUR sub-quantizers (s .. s+3) as two packed pairs whose dependent chains are interleaved statement by statement: a
+// packed-fp32 result cannot feed the next instruction (the compiler pads every link of a lone chain with an s_nop:
+// 0.7 per v_pk op in the r03 walk), so a lane that carries one chain issues at half rate; two chains fill each other's
+// gaps.  Every operation and its operands are pq_term8_pair's: (term s, term s+1) -> a, (term s+2, term s+3) -> b.
+__device__ __forceinline__ void pq_term8_quad(uint2 e0, uint2 e1, uint2 e2, uint2 e3, const float *pc, vg_f2 &a, vg_f2 &b)
+{
+    const float4 *c4 = reinterpret_cast<const float4 *>(pc);
+    const float4 k0 = c4[0], k1 = c4[1], k2 = c4[2], k3 = c4[3], k4 = c4[4];
+    const float4 m0 = c4[5], m1 = c4[6], m2 = c4[7], m3 = c4[8], m4 = c4[9];  // the next pair's constants: + kPqPairFloats floats
+    const vg_f2 qa[8] = {{k0.x, k0.y}, {k0.z, k0.w}, {k1.x, k1.y}, {k1.z, k1.w},
+                         {k2.x, k2.y}, {k2.z, k2.w}, {k3.x, k3.y}, {k3.z, k3.w}};
+    const vg_f2 qb[8] = {{m0.x, m0.y}, {m0.z, m0.w}, {m1.x, m1.y}, {m1.z, m1.w},
+                         {m2.x, m2.y}, {m2.z, m2.w}, {m3.x, m3.y}, {m3.z, m3.w}};
+    const vg_f2 sa = {k4.x, k4.y}, oa = {k4.z, k4.w}, sb = {m4.x, m4.y}, ob = {m4.z, m4.w};
+    vg_f2 suma = {0.0f, 0.0f}, sumb = {0.0f, 0.0f};
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const int sh = 8 * (j & 3);
+        const uint32_t w0 = j < 4 ? e0.x : e0.y, w1 = j < 4 ? e1.x : e1.y, w2 = j < 4 ? e2.x : e2.y, w3 = j < 4 ? e3.x : e3.y;
+        const vg_f2 fa = {static_cast<float>(static_cast<int>(static_cast<int8_t>(w0 >> sh))),
+                          static_cast<float>(static_cast<int>(static_cast<int8_t>(w1 >> sh)))};
+        const vg_f2 fb = {static_cast<float>(static_cast<int>(static_cast<int8_t>(w2 >> sh))),
+                          static_cast<float>(static_cast<int>(static_cast<int8_t>(w3 >> sh)))};
+        vg_f2 va = fa * sa;
+        vg_f2 vb = fb * sb;
+        va = va + oa;
+        vb = vb + ob;
+        const vg_f2 da = qa[j] - va;
+        const vg_f2 db = qb[j] - vb;
+        const vg_f2 dda = da * da;
+        const vg_f2 ddb = db * db;
+        suma = suma + dda;
+        sumb = sumb + ddb;
+    }
+    a = suma;
+    b = sumb;
+}
+
 // scalar form (an odd last sub-quantizer; constants from global memory)
 __device__ __forceinline__ float pq_term8(uint2 e, const float *__restrict__ q, float scale, float offset)
 {
@@ -207,10 +245,13 @@ __device__ __forceinline__ float pq_direct_chunk(const uint8_t *__restrict__ cod
         for (int u = 0; u < 16; u++) e[g * 16 + u] = cb[(s0 + g * 16 + u) * 256 + ((w[u >> 2] >> (8 * (u & 3))) & 0xFFu)];
     }
 #pragma unroll
-    for (int i = 0; i < NG * 16; i += 2) {
-        const vg_f2 t = pq_term8_pair(e[i], e[i + 1], qprep + ((s0 + i) >> 1) * kPqPairFloats);
-        distance = distance + t.x;
-        distance = distance + t.y;
+    for (int i = 0; i < NG * 16; i += 4) {  // s0 is a multiple of 16: whole quads, pairs (s0 + i) / 2 and the next one
+        vg_f2 ta, tb;
+        pq_term8_quad(e[i], e[i + 1], e[i + 2], e[i + 3], qprep + ((s0 + i) >> 1) * kPqPairFloats, ta, tb);
+        distance = distance + ta.x;  // the terms join the sum in sub-quantizer order (pq.go:242-257)
+        distance = distance + ta.y;
+        distance = distance + tb.x;
+        distance = distance + tb.y;
     }
     return distance;
 }
