@@ -966,6 +966,53 @@ def measured_traffic(key: str, algorithmic_bytes: float = None):
 
 
 
+def live_traffic(kernel_sub: str, script: str, timeout_s: float = 150.0):
+    """HBM-side bytes per launch of `kernel_sub`, MEASURED IN THIS RUN: two child processes (never an exec of this one)
+    `rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python3 tools/<script>` — counters in their own passes with
+    --kernel-trace only, started from /tmp, as MI355X_MICROARCH.md's HBM section prescribes — at the headline's shape;
+    FETCH_SIZE / WRITE_SIZE are KiB and FETCH_SIZE reports half of wide reads on gfx950 (read side x 2).  Returns
+    (bytes, detail) or (None, reason): no rocprofv3, this process itself runs under a profiler, a pass failed or timed
+    out — the caller then falls back to the committed pass of the same kernel (profiles/rNN_traffic.json)."""
+    import csv
+    import shutil
+    import signal
+    import subprocess
+    import tempfile
+    if shutil.which("rocprofv3") is None:
+        return None, "rocprofv3 not on PATH"
+    if any(k.startswith(("ROCP", "ROCPROF")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+        return None, "this process runs under a profiler"
+    got = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        with tempfile.TemporaryDirectory(dir="/tmp", prefix="vg_pmc_") as d:
+            cmd = ["rocprofv3", "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "--",
+                   "python3", str(ROOT / "tools" / script)]
+            try:
+                pr = subprocess.Popen(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL,
+                                      stderr=subprocess.DEVNULL, start_new_session=True)
+                try:
+                    rc = pr.wait(timeout=timeout_s)
+                except subprocess.TimeoutExpired:
+                    os.killpg(pr.pid, signal.SIGKILL)     # the group this call started, nothing else
+                    pr.wait()
+                    return None, f"{counter} pass timed out after {timeout_s:.0f} s"
+                if rc != 0:
+                    return None, f"{counter} pass exited with {rc}"
+                files = list(Path(d).rglob("*counter_collection.csv"))
+                if not files:
+                    return None, f"{counter} pass wrote no counter_collection.csv"
+                vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(files[0]))
+                        if kernel_sub in r["Kernel_Name"] and r["Counter_Name"] == counter]
+                if not vals:
+                    return None, f"no {counter} rows for {kernel_sub}"
+                got[counter] = (sum(vals) / len(vals), len(vals))
+            except OSError as e:
+                return None, f"{type(e).__name__}: {e}"
+    f, w = got["FETCH_SIZE"][0], got["WRITE_SIZE"][0]
+    return f * 1024 * 2 + w * 1024, {"fetch_size_kib": f, "write_size_kib": w, "dispatches": got["FETCH_SIZE"][1],
+                                     "command": f"rocprofv3 --pmc <counter> --kernel-trace -- python3 tools/{script}"}
+
+
 BASELINE_METRIC = "QPS at recall@10≥0.95, 1M×768 HNSW+PQ; PQ-ADC HBM GB/s vs peak"   # BASELINE.json "metric", verbatim
 FULL_RECORD = "bench_full.json"
 LINE_LIMIT = 6000      # bytes: the driver could not parse r03's 22.7 KB line; r02's 10.8 KB one it could
@@ -993,7 +1040,7 @@ def compact_line(full: dict) -> dict:
     out.update(_pick(full, "recall_at_10", "recall_queries"))
     rf = full.get("roofline") or {}
     out["roofline"] = {**_pick(rf, "bound", "achieved", "peak", "unit", "frac"), "traffic": _r(rf.get("traffic")),
-                       **_pick(rf, "kernel", "kernel_ms", "launches")}
+                       **_pick(rf, "kernel", "kernel_ms", "launches", "traffic_source")}
     cb = full.get("cpu_baseline") or {}
     if "value" in cb:
         out["cpu_baseline"] = _pick(cb, "value", "unit", "cores", "kind", "sample", "cpu", "logical_cpus", "usable_cpus")
@@ -1127,6 +1174,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-adc", action="store_true")
     ap.add_argument("--no-hnsw", action="store_true")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="do not run the two rocprofv3 --pmc child passes that measure roofline.traffic in this run")
     ap.add_argument("--torch-collective", action="store_true", help="N > 1: exchange through torch.distributed instead of vg_comm")
     ap.add_argument("--bf16-filter", action="store_true",
                     help="time the exact path WITH vg_index_enable_bf16_filter as the headline (default: the fp32 MFMA GEMM "
@@ -1373,6 +1422,16 @@ def main():
         leg("cpu_baseline", lambda: cpu_baseline(rows.cpu().numpy(), queries[1].cpu().numpy(), K))
         if "value" in out["cpu_baseline"]:
             out["gpu_over_cpu_at_recall_bar"] = qps / out["cpu_baseline"]["value"]
+    # roofline.traffic measured in THIS run (after everything else: a profiler pass that went wrong cannot touch a timing)
+    if world == 1 and op["path"] == "flat_exact" and not args.bf16_filter and not args.no_live_traffic and not REDUCED:
+        tb, detail = live_traffic("flat_gemm_dma_kernel<false, 2, 0, false>", "flat_time.py")
+        if tb is not None:
+            out["roofline"]["traffic_committed"] = out["roofline"]["traffic"]
+            out["roofline"]["traffic"] = tb
+            out["roofline"]["traffic_source"] = "measured in this run: " + detail["command"] + " (two child passes, FETCH_SIZE x 2 + WRITE_SIZE, KiB)"
+            out["roofline"]["traffic_detail"] = detail
+        else:
+            out["roofline"]["traffic_source"] = (out["roofline"].get("traffic_source") or "none") + f"; live pass skipped: {detail}"
     emit(out)
     if world > 1:
         dist.barrier()
