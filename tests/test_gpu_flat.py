@@ -237,3 +237,45 @@ def test_k_above_64(vg, ctx, n, dim, nq, k, metric):
     finally:
         hooks.set_hook("VG_FLAT_FORCE_EXACT", 0)
     check(ids, sc)
+
+
+def test_flat_segment_reference_tests(vg, ctx):
+    """internal/segment/flat/{segment,quantization,partitioned}_test.go (reference_kats.json flat_segment_search)
+    through the C ABI: fp32 Segment.Search, SQ8 Segment.Search + Rerank, and the partition-probed search over k-means
+    partitions trained and assigned on the GPU"""
+    from tests import flat_segment_kats
+
+    def search(rows, q, k):
+        idx = vg.Index(ctx, rows.shape[0], rows.shape[1]); idx.set_vectors(rows)
+        ids, sc = idx.search_flat(q[None, :], k)
+        idx.close()
+        keep = ids[0] != 0xFFFFFFFF
+        return ids[0][keep], sc[0][keep]
+
+    def search_sq8_rerank(rows, q, k):
+        idx = vg.Index(ctx, rows.shape[0], rows.shape[1]); idx.set_vectors(rows)
+        sq = vg.ScalarQuantizer(ctx, rows.shape[1]); sq.train(rows)
+        idx.set_sq8_codes(sq, sq.encode(rows))
+        cand, _ = idx.search_sq8(q[None, :], k)
+        ids, sc = idx.rerank(q[None, :], cand, k)
+        idx.close(); sq.close()
+        keep = ids[0] != 0xFFFFFFFF
+        return ids[0][keep], sc[0][keep]
+
+    def partition(rows, parts):
+        dim = rows.shape[1]
+        cent = np.asarray(vg.kmeans_train(ctx, rows, dim, parts, max_iter=10, seed=1)).reshape(parts, dim)
+        assign = np.asarray(vg.kmeans_assign(ctx, rows, cent, dim)).astype(np.int64)
+        order = np.argsort(assign, kind="stable")
+        off = np.concatenate([[0], np.cumsum(np.bincount(assign, minlength=parts))]).astype(np.uint32)
+        return cent, off, rows[order]
+
+    def search_probed(rows, cent, off, q, k, nprobes):
+        idx = vg.Index(ctx, rows.shape[0], rows.shape[1]); idx.set_vectors(rows)
+        idx.set_partitions(cent, off)
+        ids, sc = idx.search_flat_probed(q[None, :], k, nprobes, scan=idx.SCAN_F32)
+        idx.close()
+        keep = ids[0] != 0xFFFFFFFF
+        return ids[0][keep], sc[0][keep]
+
+    flat_segment_kats.run(search, search_sq8_rerank, partition, search_probed)

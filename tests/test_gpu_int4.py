@@ -132,3 +132,34 @@ def test_vamana_search_with_int4_codes_and_segment_file(vg, ctx, dim):
     with pytest.raises(vg.VecgoHipError) as e:
         vg.Segment(ctx, bad, kind="diskann", verify_checksum=False)
     assert "data size mismatch" in str(e.value)            # int4.go:196-199
+
+
+def test_simd_int4_reference_tests(vg, ctx, golden_dir):
+    """internal/simd/int4_test.go (reference_kats.json simd_int4) through the C ABI: Int4L2DistanceBatch /
+    Int4L2DistancePrecomputed of the reference's own codes, BuildInt4LookupTable's corners — and the same bits as the oracle"""
+    import json
+    g = json.loads((golden_dir / "reference_kats.json").read_text())["simd_int4"]
+    for c in g["cases"]:
+        dim = c["dim"]
+        mn, df = np.array(c["min"], np.float32), np.array(c["diff"], np.float32)
+        iq = vg.Int4Quantizer(ctx, dim); iq.set_params(mn, df)
+        ref = o.Int4Quantizer(dim); ref.set_params(mn, df)
+        q = np.array(c["query"], np.float32)
+        codes = np.array(c["codes"], np.uint8)
+        batch, one = iq.l2_distance_batch(q, codes), iq.l2_distance(q, codes)
+        assert np.array_equal(bits(batch), bits(ref.l2_distance_batch(q, codes.reshape(-1))))
+        assert np.array_equal(bits(one), bits(np.array([ref.l2_distance(q, code) for code in codes], np.float32)))
+        if c.get("all_nonnegative"):
+            assert np.all(batch >= 0) and np.all(one >= 0)
+        for got in (batch, one):
+            for v, e in zip(got, c.get("expected", [])):
+                if e is not None:
+                    assert abs(float(v) - e) <= c["tol"], (c["name"], v, e)
+        if "table_len" in c:
+            assert iq.params()[2].size == c["table_len"]
+            assert np.all(np.abs(one - batch) <= c["precomputed_vs_direct_tol"])
+    for t in g["lookup_table"]:
+        iq = vg.Int4Quantizer(ctx, len(t["min"])); iq.set_params(np.array(t["min"], np.float32), np.array(t["diff"], np.float32))
+        table = iq.params()[2]
+        for e in t["expect"]:
+            assert abs(float(table[e["dim"] * 16 + e["q"]]) - e["value"]) <= t["tol"], e

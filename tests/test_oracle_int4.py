@@ -83,3 +83,30 @@ def test_int4_distance_close_to_decoded_l2():
         want = float(np.sum((q.astype(np.float64) - iq.decode(codes[i]).astype(np.float64)) ** 2))
         assert abs(d_batch[i] - want) <= 1e-4 * max(1.0, want)
         assert abs(iq.l2_distance(q, codes[i]) - want) <= 1e-4 * max(1.0, want)
+
+
+def test_simd_int4_reference_tests(golden_dir):
+    """internal/simd/int4_test.go as data (tests/golden/reference_kats.json simd_int4) against the oracle's three INT4
+    distance forms and BuildInt4LookupTable."""
+    import json
+    g = json.loads((golden_dir / "reference_kats.json").read_text())["simd_int4"]
+    for c in g["cases"]:
+        dim = c["dim"]
+        iq = o.Int4Quantizer(dim); iq.set_params(np.array(c["min"], np.float32), np.array(c["diff"], np.float32))
+        q = np.array(c["query"], np.float32)
+        codes = np.array(c["codes"], np.uint8)
+        batch = iq.l2_distance_batch(q, codes.reshape(-1))
+        one = np.array([iq.l2_distance(q, code) for code in codes], np.float32)
+        if c.get("all_nonnegative"):
+            assert np.all(batch >= 0) and np.all(one >= 0)
+        for got in (batch, one):
+            for v, e in zip(got, c.get("expected", [])):
+                if e is not None:
+                    assert abs(float(v) - e) <= c["tol"], (c["name"], v, e)
+        if "table_len" in c:
+            assert iq.table.size == c["table_len"]
+            assert np.all(np.abs(one - batch) <= c["precomputed_vs_direct_tol"])
+    for t in g["lookup_table"]:
+        iq = o.Int4Quantizer(len(t["min"])); iq.set_params(np.array(t["min"], np.float32), np.array(t["diff"], np.float32))
+        for e in t["expect"]:
+            assert abs(float(iq.table[e["dim"] * 16 + e["q"]]) - e["value"]) <= t["tol"], e

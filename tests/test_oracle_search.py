@@ -119,3 +119,30 @@ def test_cpu_twin_of_the_hnsw_pq_rerank_pipeline():
         order = sorted(range(len(cid)), key=lambda j: (sc[j], cid[j]))[:10]
         assert np.array_equal(r["ids"][i], cid[order])
         assert np.array_equal(r["scores"][i].view(np.uint32), sc[order].view(np.uint32))
+
+
+def test_flat_segment_reference_tests():
+    """flat/{segment,quantization,partitioned}_test.go (reference_kats.json flat_segment_search) against the oracle's
+    flat.Segment.Search / Rerank restatement"""
+    from tests import flat_segment_kats
+
+    def search(rows, q, k):
+        return o.FlatSegment(rows, rows.shape[1]).search(q, k)
+
+    def search_sq8_rerank(rows, q, k):
+        sq = o.ScalarQuantizer(rows.shape[1]); sq.train(rows)
+        codes = np.stack([sq.encode(r) for r in rows])
+        ids, _ = o.FlatSegment(rows, rows.shape[1], sq=sq, codes=codes).search(q, k)
+        return ids, o.rerank_f32(rows, rows.shape[1], q, ids)
+
+    def partition(rows, parts):
+        cent = o.kmeans_train(rows, rows.shape[1], parts, max_iter=10, seed=1)
+        assign = np.array([o.assign_partition(r, cent, rows.shape[1]) for r in rows])
+        order = np.argsort(assign, kind="stable")
+        off = np.concatenate([[0], np.cumsum(np.bincount(assign, minlength=parts))]).astype(np.uint32)
+        return cent.reshape(parts, -1), off, rows[order]
+
+    def search_probed(rows, cent, off, q, k, nprobes):
+        return o.FlatSegment(rows, rows.shape[1], centroids=cent, part_offsets=off).search(q, k, nprobes)
+
+    flat_segment_kats.run(search, search_sq8_rerank, partition, search_probed)
