@@ -137,3 +137,21 @@ def test_device_buffers_and_batches(vg, ctx):
     i1, s1 = idx.search_hnsw_brute(q[:3], 10, 0)
     assert np.array_equal(i1, ids[:3])
     idx.close()
+
+
+def test_hnsw_dot_product_distance_ordering_kat(vg, ctx, golden_dir):
+    """hnsw_test.go:104-159 through the C ABI: the graph built by vg_hnsw_build (M = 8, EF = 50), KNNSearch at EFSearch 100
+    and BruteSearch both return rows [1, 0, 2] with distances [-2, -1, 1] under the Dot metric"""
+    import json
+    c = json.loads((golden_dir / "reference_kats.json").read_text())["hnsw_dot_ordering"]
+    rows = np.array(c["rows"], np.float32); q = np.array(c["query"], np.float32)[None, :]
+    idx = vg.Index(ctx, 3, 3, vg.Metric(2))
+    idx.set_vectors(rows)
+    idx.build_hnsw(m=c["m"], ef_construction=c["ef_construction"], max_batch=1, growth_div=1)
+    want = np.array(c["expect_distances"], np.float32)
+    for mode in (idx.BRUTE_SCAN, idx.BRUTE_BITMAP):
+        ids, sc = idx.search_hnsw_brute(q, c["k"], mode)
+        assert ids[0].tolist() == c["expect_ids"] and np.all(np.abs(sc[0] - want) <= c["tol"])
+    ids, sc = idx.search_hnsw(q, c["k"], c["ef_search"])
+    assert ids[0].tolist() == c["expect_ids"] and np.all(np.abs(sc[0] - want) <= c["tol"])
+    idx.close()

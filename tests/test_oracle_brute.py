@@ -72,3 +72,19 @@ def test_edges(mode):
     ids, sc = h.brute_search(q, 7, mode)
     d = np.array([o.l2(v, q) for v in base], np.float32)
     assert np.array_equal(ids, np.argsort(d, kind="stable")[:7].astype(np.uint32))
+
+
+def test_hnsw_dot_product_distance_ordering_kat(golden_dir):
+    """hnsw_test.go:104-159: three rows under the Dot metric; BruteSearch and KNNSearch return [row 1, row 0, row 2] with
+    distances -dot = [-2, -1, 1] — the HNSW distance convention vg_search_hnsw_brute reports (vg_search_flat reports dot
+    products, largest first)."""
+    import json
+    c = json.loads((golden_dir / "reference_kats.json").read_text())["hnsw_dot_ordering"]
+    rows = np.array(c["rows"], np.float32); q = np.array(c["query"], np.float32)
+    l0, upper, entry = o.hnsw_build(rows, 3, metric=2, m=c["m"], ef=c["ef_construction"], max_batch=1, growth_div=1)
+    h = o.HnswIndex(rows, 3, l0, upper, entry, metric=2, m=c["m"])
+    for mode in (o.BRUTE_SCAN, o.BRUTE_BITMAP):
+        ids, sc = h.brute_search(q, c["k"], mode)
+        assert ids.tolist() == c["expect_ids"] and np.all(np.abs(sc - np.array(c["expect_distances"], np.float32)) <= c["tol"])
+    ids, sc, _ = h.search(q, c["k"], c["ef_search"])
+    assert ids.tolist() == c["expect_ids"] and np.all(np.abs(sc - np.array(c["expect_distances"], np.float32)) <= c["tol"])
