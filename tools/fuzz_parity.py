@@ -45,7 +45,7 @@ while time.time() < t_end:
     cfg = dict(n=n, dim=dim, nq=nq, k=k, metric=metric)
     idx = vg.Index(ctx, n, dim, vg.Metric(metric))
     idx.set_vectors(x)
-    which = rng.integers(0, 11)
+    which = rng.integers(0, 12)
     try:
         if which == 0:
             tag = "flat"
@@ -239,6 +239,35 @@ while time.time() < t_end:
                     if not heap_kats.same((out, (nodes, dists)), want):
                         fails += 1
                         print(f"MISMATCH heap script is_max={is_max} uk={uk} ops={len(script)}", flush=True)
+        elif which == 11:
+            # the L0 batch kernels (internal/simd: SquaredL2Batch / DotBatch / SquaredL2Bounded incl. the partial sum of
+            # its early exit / PqAdcLookup / Hamming) against the oracle's lane-order restatement, every dim
+            got = vg.squared_l2_batch(ctx, q[0], x, dim)
+            if not np.array_equal(bits(got), bits(o.l2_batch(q[0], x.reshape(-1), dim))):
+                fails += 1; print(f"MISMATCH l2_batch {cfg}", flush=True)
+            got = vg.dot_batch(ctx, q[0], x, dim)
+            if not np.array_equal(bits(got), bits(o.dot_batch(q[0], x.reshape(-1), dim))):
+                fails += 1; print(f"MISMATCH dot_batch {cfg}", flush=True)
+            full = o.l2_batch(q[0], x.reshape(-1), dim)
+            bounds = (full * rng.choice([0.3, 0.9, 1.0, 1.5], n)).astype(np.float32) if rng.random() < 0.7 else np.float32(np.median(full))
+            d, e = vg.squared_l2_bounded_batch(ctx, q[0], x, dim, bounds)
+            for i in range(n):
+                want, exc = o.l2_bounded(q[0], x[i], float(bounds[i] if np.ndim(bounds) else bounds))
+                if bits(d[i]) != bits(want) or bool(e[i]) != bool(exc):
+                    fails += 1; print(f"MISMATCH l2_bounded {cfg} row {i}: {d[i]} {e[i]} want {want} {exc}", flush=True)
+                    break
+            m = int(rng.choice([1, 2, 8, 15, 16, 17, 32, 96, 100]))
+            table = rng.standard_normal(m * 256).astype(np.float32)
+            codes = rng.integers(0, 256, (n, m), dtype=np.uint8)
+            got = vg.pq_adc_lookup_batch(ctx, table, codes, m)
+            want = np.array([o.adc(table, codes[i], m) for i in range(n)], np.float32)
+            if not np.array_equal(bits(got), bits(want)):
+                fails += 1; print(f"MISMATCH adc_lookup_batch {cfg} m={m}", flush=True)
+            nb = int(rng.choice([1, 8, 12, 16, 96, 100]))
+            a = rng.integers(0, 256, nb, dtype=np.uint8); cb = rng.integers(0, 256, (n, nb), dtype=np.uint8)
+            got = vg.hamming_batch(ctx, a, cb)
+            if not np.array_equal(np.asarray(got), np.array([o.hamming(a, cb[i]) for i in range(n)])):
+                fails += 1; print(f"MISMATCH hamming_batch {cfg} bytes={nb}", flush=True)
     except vg.VecgoHipError as e:
         fails += 1
         print(f"ERROR {cfg} which={which}: {e}", flush=True)
