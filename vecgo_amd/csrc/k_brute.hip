@@ -39,7 +39,9 @@ __device__ __forceinline__ bool mask_bit(const uint8_t *__restrict__ mask, int64
 }
 
 // dist[q][i] for the rows of block y; blockIdx.x = query (consecutive workgroups share a slice of rows through L2)
-template <int METRIC>
+// STREAM: one query — every row is read exactly once: nontemporal loads (0.535 -> 0.467 ms per 1M x 768 = 6.57 TB/s);
+// several queries with their own masks share rows through L2 and keep the cached loads
+template <int METRIC, bool STREAM>
 __global__ __launch_bounds__(kBruteDistThreads) void brute_dist_kernel(const float *__restrict__ base, int64_t n, int dim,
                                                                        const float *__restrict__ queries,
                                                                        const uint8_t *__restrict__ mask, int64_t mask_stride,
@@ -58,9 +60,9 @@ __global__ __launch_bounds__(kBruteDistThreads) void brute_dist_kernel(const flo
             const float *row = base + i * dim;
             float d;
             if (METRIC == kMetricDot) {
-                d = -exact_pair16<true, kPair>(row, qv, dim, sub);
+                d = -exact_pair16<true, kPair, STREAM>(row, qv, dim, sub);
             } else {
-                d = exact_pair16<false, kPair>(row, qv, dim, sub);
+                d = exact_pair16<false, kPair, STREAM>(row, qv, dim, sub);
                 if (METRIC == kMetricCos) d = 0.5f * d;
             }
             if ((threadIdx.x & 15) == 0) dq[i] = d;
@@ -506,15 +508,17 @@ VG_API int32_t vg_search_hnsw_brute(vg_index *idx, const float *queries, int64_t
                     VG_TRY(launch(vg::brute_dist_mq_kernel<vg::kMetricDot>));
             } else {
                 const dim3 grid(static_cast<unsigned>(cnt), row_blocks), block(vg::kBruteDistThreads);
+                auto launch1 = [&](auto kern) -> int32_t {
+                    VG_LAUNCH(kern, grid, block, 0, st, idx->d_vectors, n, idx->dim, q.ptr + q0 * idx->dim, m0, mask_stride, dist);
+                    return VG_OK;
+                };
+                const bool one = cnt == 1;
                 if (idx->metric == VG_METRIC_L2)
-                    VG_LAUNCH(vg::brute_dist_kernel<vg::kMetricL2>, grid, block, 0, st, idx->d_vectors, n, idx->dim,
-                              q.ptr + q0 * idx->dim, m0, mask_stride, dist);
+                    VG_TRY(one ? launch1(vg::brute_dist_kernel<vg::kMetricL2, true>) : launch1(vg::brute_dist_kernel<vg::kMetricL2, false>));
                 else if (idx->metric == VG_METRIC_COSINE)
-                    VG_LAUNCH(vg::brute_dist_kernel<vg::kMetricCos>, grid, block, 0, st, idx->d_vectors, n, idx->dim,
-                              q.ptr + q0 * idx->dim, m0, mask_stride, dist);
+                    VG_TRY(one ? launch1(vg::brute_dist_kernel<vg::kMetricCos, true>) : launch1(vg::brute_dist_kernel<vg::kMetricCos, false>));
                 else
-                    VG_LAUNCH(vg::brute_dist_kernel<vg::kMetricDot>, grid, block, 0, st, idx->d_vectors, n, idx->dim,
-                              q.ptr + q0 * idx->dim, m0, mask_stride, dist);
+                    VG_TRY(one ? launch1(vg::brute_dist_kernel<vg::kMetricDot, true>) : launch1(vg::brute_dist_kernel<vg::kMetricDot, false>));
             }
         }
         vg::ProfScope prof(idx->ctx, "hnsw_brute_replay", st);
