@@ -19,7 +19,7 @@ __global__ __launch_bounds__(kExactThreads) void batch_kernel(const float *__res
     const int64_t groups = static_cast<int64_t>(gridDim.x) * (kExactThreads / 16);
     for (int64_t i = static_cast<int64_t>(blockIdx.x) * (kExactThreads / 16) + (threadIdx.x >> 4);
          i < n; i += groups) {
-        const float v = exact_pair16<DOT, kBatch>(targets + i * dim, query, dim, sub);
+        const float v = exact_pair16<DOT, kBatch, true>(targets + i * dim, query, dim, sub);  // targets are read once: nontemporal
         if ((threadIdx.x & 15) == 0) out[i] = v;
     }
 }

@@ -337,7 +337,7 @@ __global__ __launch_bounds__(256) void bounded_batch_kernel(const float *__restr
     const Sub16 sub = Sub16::make(threadIdx.x);
     const int64_t groups = static_cast<int64_t>(gridDim.x) * 16;
     for (int64_t i = static_cast<int64_t>(blockIdx.x) * 16 + (threadIdx.x >> 4); i < n; i += groups) {
-        float v = exact_pair16<false, kBounded>(targets + i * dim, query, dim, sub);
+        float v = exact_pair16<false, kBounded, true>(targets + i * dim, query, dim, sub);  // (read once: nontemporal)
         const float b = bounds[n_bounds == 1 ? 0 : i];
         const bool over = v > b;  // partial sums never decrease: some block's partial > bound <=> the full sum is
         // the reference returns the PARTIAL total of the block where it stopped: replayed for the pairs that exceed
