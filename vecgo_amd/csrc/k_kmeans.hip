@@ -399,7 +399,7 @@ __global__ __launch_bounds__(512) void adc_lookup_batch_lds_kernel(const float *
     auto get = [&](int64_t t, int e) {
         const int64_t row0 = t * 64;
         const int64_t last_unit = (n - row0 < 64 ? n - row0 : 64) * m16 - 1;
-        return *reinterpret_cast<const uint4 *>(codes + row0 * m + (e <= last_unit ? e : last_unit) * 16);
+        return load_stream(reinterpret_cast<const uint4 *>(codes + row0 * m + (e <= last_unit ? e : last_unit) * 16));  // read once
     };
     auto put = [&](int e, const uint4 u) {
         const int r = e / m16, part = e - r * m16;

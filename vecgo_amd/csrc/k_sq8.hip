@@ -1176,7 +1176,7 @@ __global__ __launch_bounds__(kI4TabWaves * 64) void int4_scan_tab_kernel(const f
     offsets(tile, vo);
     const uint8_t *tbase = codes + tile * 64 * row_bytes;  // uniform
 #define VG_I4_ROWS(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
-#define VG_I4_DECL(K) uint4 u##K = *reinterpret_cast<const uint4 *>(tbase + vo[K]);
+#define VG_I4_DECL(K) uint4 u##K = load_stream(reinterpret_cast<const uint4 *>(tbase + vo[K]));
     VG_I4_ROWS(VG_I4_DECL)
 #undef VG_I4_DECL
     unsigned char *wr = stage + r * kI4TabStride + part * 16;
@@ -1209,7 +1209,7 @@ __global__ __launch_bounds__(kI4TabWaves * 64) void int4_scan_tab_kernel(const f
                 // 32-bit offset either way (uniform selects; a branch here became per-lane 64-bit pointers again)
                 const bool more = cb0 + 128 < row_bytes;
                 const uint8_t *pb = more ? tbase + cb0 + 128 : nbase;
-#define VG_I4_GET(K) u##K = *reinterpret_cast<const uint4 *>(pb + (more ? vo[K] : von[K]));
+#define VG_I4_GET(K) u##K = load_stream(reinterpret_cast<const uint4 *>(pb + (more ? vo[K] : von[K])));
                 VG_I4_ROWS(VG_I4_GET)
 #undef VG_I4_GET
             }
