@@ -966,7 +966,7 @@ def measured_traffic(key: str, algorithmic_bytes: float = None):
 
 
 
-def live_traffic(kernel_sub: str, script: str, timeout_s: float = 150.0):
+def live_traffic(kernel_sub: str, script: str, timeout_s: float = 150.0, script_args=()):
     """HBM-side bytes per launch of `kernel_sub`, MEASURED IN THIS RUN: two child processes (never an exec of this one)
     `rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python3 tools/<script>` — counters in their own passes with
     --kernel-trace only, started from /tmp, as MI355X_MICROARCH.md's HBM section prescribes — at the headline's shape;
@@ -986,7 +986,7 @@ def live_traffic(kernel_sub: str, script: str, timeout_s: float = 150.0):
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         with tempfile.TemporaryDirectory(dir="/tmp", prefix="vg_pmc_") as d:
             cmd = ["rocprofv3", "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "--",
-                   "python3", str(ROOT / "tools" / script)]
+                   "python3", str(ROOT / "tools" / script), *[str(a) for a in script_args]]
             try:
                 pr = subprocess.Popen(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL,
                                       stderr=subprocess.DEVNULL, start_new_session=True)
@@ -1010,7 +1010,8 @@ def live_traffic(kernel_sub: str, script: str, timeout_s: float = 150.0):
                 return None, f"{type(e).__name__}: {e}"
     f, w = got["FETCH_SIZE"][0], got["WRITE_SIZE"][0]
     return f * 1024 * 2 + w * 1024, {"fetch_size_kib": f, "write_size_kib": w, "dispatches": got["FETCH_SIZE"][1],
-                                     "command": f"rocprofv3 --pmc <counter> --kernel-trace -- python3 tools/{script}"}
+                                     "command": f"rocprofv3 --pmc <counter> --kernel-trace -- python3 tools/{script}" +
+                                                "".join(f" {a}" for a in script_args)}
 
 
 BASELINE_METRIC = "QPS at recall@10≥0.95, 1M×768 HNSW+PQ; PQ-ADC HBM GB/s vs peak"   # BASELINE.json "metric", verbatim
@@ -1065,7 +1066,7 @@ def compact_line(full: dict) -> dict:
 
     # configs[1]: the headline kernel (same numbers as `roofline`, in the per-config shape)
     row("configs[1] flat exact fp32 MFMA GEMM", {**rf, "workload": "flat_exact_l2_1Mx768_top10_nq1024"},
-        cpu_qps=cb.get("value"), qps=full.get("value"))
+        cpu_qps=cb.get("value"), qps=full.get("value"), traffic_live=("traffic_detail" in rf) or None)
     fs = full.get("flat_small_batch")
     if isinstance(fs, dict) and "q1" in fs:
         for nq in ("q1", "q32"):
@@ -1083,7 +1084,7 @@ def compact_line(full: dict) -> dict:
     if isinstance(a, dict):
         c = a.get("cpu") or {}
         row("configs[3] pq adc scan", a, qps=a.get("qps_single_query_passes"), cpu_qps=c.get("qps"), ids_equal=c.get("ids_equal_gpu"),
-            batch1024_qps=(a.get("batch") or {}).get("qps"))
+            batch1024_qps=(a.get("batch") or {}).get("qps"), traffic_live=("traffic_detail" in a) or None)
     v = full.get("vamana_pq")
     if isinstance(v, dict):
         row("configs[3] vamana beam, pq node scoring", v, node_scores_per_s=v.get("node_scores_per_s"),
@@ -1432,6 +1433,16 @@ def main():
             out["roofline"]["traffic_detail"] = detail
         else:
             out["roofline"]["traffic_source"] = (out["roofline"].get("traffic_source") or "none") + f"; live pass skipped: {detail}"
+        # ... and for the kernel the metric's second half names (PQ-ADC scan, configs[3]), same procedure
+        if tb is not None and isinstance(out.get("adc_scan"), dict) and "kernel_ms" in out["adc_scan"]:
+            ab, adetail = live_traffic("pq_adc_scan_kernel<6, true, true>", "adc_prof.py", script_args=(SCAN_ROWS, 1, K))
+            if ab is not None:
+                out["adc_scan"]["traffic_committed"] = out["adc_scan"].get("traffic")
+                out["adc_scan"]["traffic"] = ab
+                out["adc_scan"]["traffic_source"] = "measured in this run: " + adetail["command"]
+                out["adc_scan"]["traffic_detail"] = adetail
+            else:
+                out["adc_scan"]["traffic_source"] = f"committed pass ({traffic_file().name if traffic_file() else None}); live pass skipped: {adetail}"
     emit(out)
     if world > 1:
         dist.barrier()
