@@ -736,6 +736,18 @@ def prioq_replay(is_max, script, cap=4096):
     return out, ((items & 0xFFFFFFFF).astype(np.uint32), (items >> 32).astype(np.uint32).view(np.float32))
 
 
+_sig("vgo_visited_replay", C.c_int32, C.c_int32, _i64p, C.c_int32, _i64p)
+VISITED_OPS = {"visit": 0, "visited": 1, "check_and_visit": 2, "reset": 3, "ensure_capacity": 4, "capacity": 5}
+
+
+def visited_replay(capacity, script):
+    """[(op name, id)] through the literal restatement of searcher.VisitedSet -> list of results"""
+    ops = np.array([[VISITED_OPS[op], arg] for op, arg in script], np.int64).reshape(-1, 2)
+    out = np.zeros(ops.shape[0], np.int64)
+    lib.vgo_visited_replay(capacity, ops.ctypes.data_as(_i64p), ops.shape[0], out.ctypes.data_as(_i64p))
+    return out.tolist()
+
+
 class _Cand(C.Structure):
     _fields_ = [("segment_id", C.c_uint32), ("row_id", C.c_uint32), ("score", C.c_float)]
 

@@ -1103,6 +1103,49 @@ int32_t vgo_prioq_replay(int is_max, const int32_t *ops, int32_t n_ops, int32_t 
     return len;
 }
 
+/* searcher.VisitedSet (visited.go:12-129) as written: uint8 epochs, 0 = never visited, Reset = epoch++ and a full clear
+ * only on wrap-around, growth to max(2 * len, id + 1).  The searches above use a uint32 epoch array owned by the caller
+ * (the same observable set; vg_cpu_bench.c keeps one per thread) — this literal restatement exists so that the
+ * reference's own tests (visited_test.go) run against SOMETHING that follows the file line by line.  A script:
+ * ops[i] = {op, id-or-capacity}: 0 Visit, 1 Visited, 2 CheckAndVisit, 3 Reset, 4 EnsureCapacity, 5 Capacity;
+ * out[i] = the call's result (Visited / CheckAndVisit: 0/1, Capacity: len, others 0). */
+int32_t vgo_visited_replay(int32_t capacity, const int64_t *ops, int32_t n_ops, int64_t *out)
+{
+    int64_t len = capacity > 0 ? capacity : 0;
+    uint8_t *v = (uint8_t *)calloc((size_t)(len > 0 ? len : 1), 1);
+    uint8_t epoch = 1; /* NewVisitedSet :21-26 */
+    for (int i = 0; i < n_ops; i++) {
+        const int64_t op = ops[2 * i], id = ops[2 * i + 1];
+        int64_t r = 0;
+        if ((op == 0 || op == 2 || op == 4) && (op == 4 ? id > len : id >= len)) { /* grow :121-128 */
+            const int64_t want = op == 4 ? id : id + 1;
+            const int64_t cap = len * 2 > want ? len * 2 : want;
+            uint8_t *nv = (uint8_t *)calloc((size_t)cap, 1);
+            memcpy(nv, v, (size_t)len);
+            free(v);
+            v = nv;
+            len = cap;
+        }
+        switch (op) {
+        case 0: v[id] = epoch; break;                                   /* Visit :29-35 */
+        case 1: r = id < len && v[id] == epoch; break;                  /* Visited :38-44 */
+        case 2: r = v[id] == epoch; v[id] = epoch; break;               /* CheckAndVisit :50-65 */
+        case 3:                                                         /* Reset :102-109 */
+            epoch++;
+            if (epoch == 0) {
+                epoch = 1;
+                memset(v, 0, (size_t)len);
+            }
+            break;
+        case 5: r = len; break;                                         /* Capacity :118-120 */
+        default: break;
+        }
+        out[i] = r;
+    }
+    free(v);
+    return (int32_t)len;
+}
+
 /* ------------------------------------------------------------------ */
 /* flat scans — internal/segment/flat/segment.go:606-723                */
 /* ------------------------------------------------------------------ */

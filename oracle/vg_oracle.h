@@ -122,6 +122,9 @@ int vgo_prioq_pop(vgo_prioq *q, vgo_pq_item *out);
 /* script of queue operations (op codes = VG_HEAP_* of include/vecgo_hip.h); returns the final length */
 int32_t vgo_prioq_replay(int is_max, const int32_t *ops, int32_t n_ops, int32_t *out, uint64_t *final_items, int32_t cap);
 
+/* searcher.VisitedSet (visited.go) literally, driven by a script (see vg_oracle.c) */
+int32_t vgo_visited_replay(int32_t capacity, const int64_t *ops, int32_t n_ops, int64_t *out);
+
 typedef struct {
     uint32_t segment_id, row_id;
     float score;

@@ -69,3 +69,25 @@ def test_candidate_heap_determinism():
         h.close()
     assert runs[0] == runs[1]
     assert runs[0] == sorted(cands, reverse=True)
+
+
+def test_visited_set_reference_tests():
+    """a20's third structure: searcher.VisitedSet (visited.go:12-129) restated literally (uint8 epochs, growth, clear on
+    wrap-around) against the reference's own visited_test.go, as data in reference_kats.json.  On the device the set is a
+    per-query bitmap with an atomic test-and-set (vg_hnsw_layer.hpp); its observable effect — which nodes a walk scores,
+    `nodes_visited` — is pinned by the stats parity of tests/test_gpu_graph.py."""
+    g = heap_kats.KATS["searcher_visited_set"]
+    for c in g["cases"]:
+        if "script" in c:
+            assert o.visited_replay(c["capacity"], [tuple(s) for s in c["script"]]) == c["expect"], c["name"]
+    rng = np.random.default_rng(20260404)
+    ids = rng.integers(0, 5000, 100).tolist()
+    script = [("visit", i) for i in ids] + [("visited", i) for i in range(5000)] + [("reset", 0)] + [("visited", i) for i in range(5000)]
+    out = o.visited_replay(10, script)
+    member = set(ids)
+    assert out[100:5100] == [int(i in member) for i in range(5000)]
+    assert not any(out[5101:])
+    # the epoch wraps after 255 resets: everything is cleared, earlier visits do not come back (visited.go:102-109)
+    script = [("visit", 7)] + [("reset", 0)] * 255 + [("visited", 7), ("visit", 3), ("visited", 3), ("check_and_visit", 3), ("check_and_visit", 4),
+                                                       ("check_and_visit", 4)]
+    assert o.visited_replay(16, script)[-6:] == [0, 0, 1, 1, 0, 1]
