@@ -193,43 +193,50 @@ __global__ __launch_bounds__(kRqThreads) void rabitq_scan_kernel(
     const int64_t step = dealt ? static_cast<int64_t>(slices) * kRqWaves : kRqWaves;
     const int64_t end = dealt ? n_tiles : t1;
     int64_t tile = dealt ? static_cast<int64_t>(s) * kRqWaves + wave : t0 + wave;
-    if (groups == 6) {  // d = 768: fully unrolled, kRqTiles tiles (6 * kRqTiles 16-byte loads) per trip
-        for (; tile + static_cast<int64_t>(kRqTiles - 1) * step < end; tile += kRqTiles * step) {
-            uint4 c[kRqTiles][6];
-            float y[kRqTiles];
+    if (groups == 6) {  // d = 768: fully unrolled; kRqTiles tiles (6 * kRqTiles 16-byte loads) in flight per lane
+        // r04: a RING of tiles instead of trips — a slot is refilled with the tile kRqTiles steps ahead as soon as its
+        // popcounts are done, so the wave always has kRqTiles - 1 tiles in flight while it scores one (the trips loaded
+        // kRqTiles tiles, scored them all, and started the next loads with nothing in flight)
+        uint4 c[kRqTiles][6];
+        float y[kRqTiles];
+        int64_t tl[kRqTiles];
+        auto fill = [&](int t) {  // (t is a compile-time slot after unrolling)
+            const uint4 *tp = tiles + (tl[t] * 6) * 64 + lane;
+#pragma unroll
+            for (int g = 0; g < 6; g++) c[t][g] = load_stream(tp + g * 64);
+            const int64_t row = tl[t] * 64 + lane;
+            y[t] = row < n_rows ? norms[row] : 0.0f;
+        };
+#pragma unroll
+        for (int t = 0; t < kRqTiles; t++) {
+            tl[t] = tile + t * step;
+            if (tl[t] < end) fill(t);
+        }
+        for (bool any = true; any;) {
+            any = false;
 #pragma unroll
             for (int t = 0; t < kRqTiles; t++) {
-                const uint4 *tp = tiles + ((tile + t * step) * 6) * 64 + lane;
+                if (tl[t] >= end) continue;  // (uniform)
+                any = true;
+                int h = 0;
 #pragma unroll
-                for (int g = 0; g < 6; g++) c[t][g] = load_stream(tp + g * 64);
-            }
-#pragma unroll
-            for (int t = 0; t < kRqTiles; t++) {
-                const int64_t row = (tile + t * step) * 64 + lane;
-                y[t] = row < n_rows ? norms[row] : 0.0f;
-            }
-            int h[kRqTiles];
-#pragma unroll
-            for (int t = 0; t < kRqTiles; t++) h[t] = 0;
-#pragma unroll
-            for (int g = 0; g < 6; g++) {
-                const uint4 qq = qbits[g];
-#pragma unroll
-                for (int t = 0; t < kRqTiles; t++)
-                    h[t] += __popc(c[t][g].x ^ qq.x) + __popc(c[t][g].y ^ qq.y) + __popc(c[t][g].z ^ qq.z) +
-                            __popc(c[t][g].w ^ qq.w);
-            }
-#pragma unroll
-            for (int t = 0; t < kRqTiles; t++) {
-                const int64_t row = (tile + t * step) * 64 + lane;
+                for (int g = 0; g < 6; g++) {
+                    const uint4 qq = qbits[g];
+                    h += __popc(c[t][g].x ^ qq.x) + __popc(c[t][g].y ^ qq.y) + __popc(c[t][g].z ^ qq.z) + __popc(c[t][g].w ^ qq.w);
+                }
+                const int64_t row = tl[t] * 64 + lane;
+                const float yn = y[t];
+                tl[t] += static_cast<int64_t>(kRqTiles) * step;
+                if (tl[t] < end) fill(t);
                 uint64_t key = kKeyMax;
                 if (row < n_rows) {
-                    key = make_key(rq_formula(qn, y[t], dimf, static_cast<float>(h[t])), static_cast<uint32_t>(row), false);
+                    key = make_key(rq_formula(qn, yn, dimf, static_cast<float>(h)), static_cast<uint32_t>(row), false);
                     if (paged && key <= floor_key) key = kKeyMax;
                 }
                 tk.offer(key, lane);
             }
         }
+        tile = end;
     }
     for (; tile < end; tile += step) {
         const uint4 *tp = tiles + (tile * groups) * 64 + lane;

@@ -407,6 +407,35 @@ __device__ __forceinline__ float sq8_row_score(const uint4 *__restrict__ tp, int
     return total;
 }
 
+// The same with the ring carried ACROSS tiles (dim % 64 == 0: no tail group, whole ring rounds): the last round of a
+// tile refills the ring with the first groups of the wave's NEXT tile, so a tile no longer starts with kSqAhead loads
+// and an exposed HBM round trip (~2 us of the ~33 us a wave spends on a tile: 6.05 -> 6.4 TB/s at 4M x 768).
+// `ring` arrives holding groups 0 .. kSqAhead-1 of this tile and leaves holding those of `tp_next`.
+template <bool DOT>
+__device__ __forceinline__ float sq8_row_score_stream(const uint4 *__restrict__ tp, const uint4 *__restrict__ tp_next, int full,
+                                                      uint4 (&ring)[kSqAhead], const float *__restrict__ qv,
+                                                      const float *__restrict__ mins, const float *__restrict__ inv)
+{
+    float acc[16];
+#pragma unroll
+    for (int l = 0; l < 16; l++) acc[l] = 0.0f;
+    float run = 0.0f;
+    for (int g0 = 0; g0 < full; g0 += kSqAhead) {
+        const uint4 *src = g0 + kSqAhead < full ? tp + (g0 + kSqAhead) * 64 : tp_next;  // (uniform)
+#pragma unroll
+        for (int a = 0; a < kSqAhead; a++) {
+            const int g = g0 + a;
+            const uint4 c = ring[a];
+            ring[a] = load_stream(src + a * 64);
+            if (DOT)
+                run = sq8_dot16(run, c, 16, qv + g * 16, mins + g * 16, inv + g * 16);
+            else
+                sq8_block16(acc, c, qv + g * 16, mins + g * 16, inv + g * 16);
+        }
+    }
+    return DOT ? run : reduce16_regs(acc);
+}
+
 template <bool DOT, int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void sq8_scan_kernel(
     const uint4 *__restrict__ tiles, int64_t n_rows, int64_t n_tiles, int groups, int dim,
@@ -431,7 +460,24 @@ __global__ __launch_bounds__(WAVES * 64) void sq8_scan_kernel(
     const bool dealt = nq == 1;
     const int64_t step = dealt ? static_cast<int64_t>(slices) * WAVES : WAVES;
     const int64_t end = dealt ? n_tiles : t1;
-    for (int64_t tile = dealt ? static_cast<int64_t>(s) * WAVES + wave : t0 + wave; tile < end; tile += step) {
+    int64_t tile = dealt ? static_cast<int64_t>(s) * WAVES + wave : t0 + wave;
+    if (tail == 0 && full % kSqAhead == 0 && full >= kSqAhead && tile < end) {  // the ring runs on from tile to tile
+        uint4 ring[kSqAhead];
+        const uint4 *tp = tiles + (tile * groups) * 64 + lane;
+#pragma unroll
+        for (int a = 0; a < kSqAhead; a++) ring[a] = load_stream(tp + a * 64);
+        for (; tile < end; tile += step) {
+            const int64_t tn = tile + step < end ? tile + step : tile;  // (the last tile's own first groups again: unused)
+            const uint4 *tpn = tiles + (tn * groups) * 64 + lane;
+            const float total = sq8_row_score_stream<DOT>(tp, tpn, full, ring, qv, mins, inv);
+            tp = tpn;
+            const int64_t row = tile * 64 + lane;
+            uint64_t key = row < n_rows ? make_key(total, static_cast<uint32_t>(row), DOT) : kKeyMax;
+            if (min_keys && key <= min_keys[q]) key = kKeyMax;  // paged results: only keys after the previous page
+            tk.offer(key, lane);
+        }
+    }
+    for (; tile < end; tile += step) {
         const float total = sq8_row_score<DOT>(tiles + (tile * groups) * 64 + lane, groups, full, tail, qv, mins, inv);
         const int64_t row = tile * 64 + lane;
         uint64_t key = row < n_rows ? make_key(total, static_cast<uint32_t>(row), DOT) : kKeyMax;
