@@ -60,7 +60,8 @@ namespace distance {
 // distance.Metric (distance/distance.go:66-73)
 enum class Metric : int32_t { L2 = VG_METRIC_L2, Cosine = VG_METRIC_COSINE, Dot = VG_METRIC_DOT, Hamming = VG_METRIC_HAMMING };
 
-inline const char *String(Metric m)
+// Metric.String (distance/distance.go:75-88), "Unknown(%d)" for anything else
+inline std::string String(Metric m)
 {
     switch (m) {
     case Metric::L2: return "L2";
@@ -68,7 +69,7 @@ inline const char *String(Metric m)
     case Metric::Dot: return "Dot";
     case Metric::Hamming: return "Hamming";
     }
-    return "Unknown";
+    return "Unknown(" + std::to_string(static_cast<int32_t>(m)) + ")";
 }
 
 // distance.Func is a single-pair function in the reference; on the GPU the unit is one query

@@ -201,6 +201,11 @@ int main()
         distance::Provider(distance::Metric::Cosine)(*ctx, a.data(), b.data(), 3, 1, &out);
         EXPECT(out == 32.0f);  // floats_test.go:17
         EXPECT(status_of([&] { distance::Provider(distance::Metric::Hamming); }) == VG_ERR_UNSUPPORTED);
+        // distance_test.go:119-152 TestMetric: String() of every metric and of an unknown one, Provider's errors
+        EXPECT(distance::String(distance::Metric::L2) == "L2" && distance::String(distance::Metric::Cosine) == "Cosine");
+        EXPECT(distance::String(distance::Metric::Dot) == "Dot" && distance::String(distance::Metric::Hamming) == "Hamming");
+        EXPECT(distance::String(static_cast<distance::Metric>(99)) == "Unknown(99)");
+        EXPECT(status_of([&] { distance::Provider(static_cast<distance::Metric>(99)); }) == VG_ERR_UNSUPPORTED);
     }
 
     // ---- flat segment: exact search and PQ search, vs the oracle ------------------------------
