@@ -80,10 +80,18 @@ template <int METRIC>
 __global__ __launch_bounds__(kBruteDistThreads) void brute_dist_mq_kernel(const float *__restrict__ base, int64_t n, int dim,
                                                                           const float *__restrict__ queries, int nq,
                                                                           const uint8_t *__restrict__ mask,
-                                                                          float *__restrict__ dist)
+                                                                          float *__restrict__ dist, int qblocks, int slices)
 {
     extern __shared__ float brute_q[];  // kBruteQB * dim
-    const int q0 = blockIdx.x * kBruteQB;
+    // XCD-aware order (as the scans): workgroup b runs on XCD b % 8; the query blocks of ONE row slice are consecutive
+    // workgroups of one XCD and walk the slice together, so a row crosses the fabric once per slice, not once per query
+    // block (with blockIdx = (query block, row block) the 16 query blocks of a tile sat on all 8 XCDs)
+    const int b = blockIdx.x;
+    const int xcd = b & 7, o = b >> 3;
+    const int qb = o % qblocks;
+    const int sl = (o / qblocks) * 8 + xcd;
+    if (sl >= slices) return;
+    const int q0 = qb * kBruteQB;
     const int qn = nq - q0 < kBruteQB ? nq - q0 : kBruteQB;
     for (int t = threadIdx.x; t < qn * dim; t += kBruteDistThreads) brute_q[t] = queries[static_cast<int64_t>(q0) * dim + t];
     __syncthreads();
@@ -91,9 +99,10 @@ __global__ __launch_bounds__(kBruteDistThreads) void brute_dist_mq_kernel(const 
     const int nblk = dim >> 6;
     const int grp = threadIdx.x >> 4;  // 16 groups, two rows each
     constexpr bool DOT = METRIC == kMetricDot;
-    for (int64_t r0 = static_cast<int64_t>(blockIdx.y) * 32; r0 < n; r0 += static_cast<int64_t>(gridDim.y) * 32) {
+    const int64_t rs = (n * sl / slices) & ~int64_t(31), re = sl + 1 == slices ? n : ((n * (sl + 1) / slices) & ~int64_t(31));
+    for (int64_t r0 = rs; r0 < re; r0 += 32) {
         const int64_t ia = r0 + 2 * grp, ib = ia + 1;
-        const bool la = ia < n && mask_bit(mask, ia), lb = ib < n && mask_bit(mask, ib);
+        const bool la = ia < re && mask_bit(mask, ia), lb = ib < re && mask_bit(mask, ib);
         if (!la && !lb) continue;  // (uniform over the 16 lanes of the group)
         const float *rowa = base + (la ? ia : (lb ? ib : 0)) * dim;
         const float *rowb = base + (lb ? ib : (la ? ia : 0)) * dim;
@@ -488,16 +497,17 @@ VG_API int32_t vg_search_hnsw_brute(vg_index *idx, const float *queries, int64_t
             vg::ProfScope prof(idx->ctx, "hnsw_brute_dist", st);
             const bool mq = cnt >= 2 && idx->dim % 4 == 0 && idx->dim <= 1024 && (m0 == nullptr || mask_stride == 0);
             if (mq) {  // query-blocked: rows read once per 16 queries
-                const unsigned qblocks = static_cast<unsigned>((cnt + vg::kBruteQB - 1) / vg::kBruteQB);
-                const int64_t want = std::max<int64_t>(1, (int64_t(8) * std::max(idx->ctx->compute_units, 1) + qblocks - 1) / qblocks);
-                const unsigned rblocks = static_cast<unsigned>(std::min<int64_t>(std::min<int64_t>((n + 31) / 32, want), 65535));
+                const int qblocks = static_cast<int>((cnt + vg::kBruteQB - 1) / vg::kBruteQB);
+                // ~8 workgroups per CU in all; slices in whole groups of 8 (one per XCD), at least 32 rows each
+                int64_t slices = (int64_t(8) * std::max(idx->ctx->compute_units, 1) + qblocks - 1) / qblocks;
+                slices = std::min<int64_t>(((slices + 7) / 8) * 8, std::max<int64_t>(8, ((n + 31) / 32 / 8) * 8));
                 const size_t qlds = static_cast<size_t>(vg::kBruteQB) * idx->dim * sizeof(float);
-                const dim3 grid(qblocks, rblocks), block(vg::kBruteDistThreads);
+                const dim3 grid(static_cast<unsigned>(qblocks * slices)), block(vg::kBruteDistThreads);
                 auto launch = [&](auto kern) -> int32_t {
                     VG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                                static_cast<int>(qlds)));
                     VG_LAUNCH(kern, grid, block, qlds, st, idx->d_vectors, n, idx->dim, q.ptr + q0 * idx->dim,
-                              static_cast<int>(cnt), m0, dist);
+                              static_cast<int>(cnt), m0, dist, qblocks, static_cast<int>(slices));
                     return VG_OK;
                 };
                 if (idx->metric == VG_METRIC_L2)
