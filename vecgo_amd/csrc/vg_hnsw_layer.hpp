@@ -244,9 +244,29 @@ __device__ __forceinline__ float pq_direct_chunk(const uint8_t *__restrict__ cod
 #pragma unroll
         for (int u = 0; u < 16; u++) e[g * 16 + u] = cb[(s0 + g * 16 + u) * 256 + ((w[u >> 2] >> (8 * (u & 3))) & 0xFFu)];
     }
+#if defined(VG_PQ_LOAD_PROBE) && VG_PQ_LOAD_PROBE == 1  // stage probe (tools/build_variant.sh): every centroid gather twice
+#pragma unroll
+    for (int g = 0; g < NG; g++) {
+        const uint32_t w[4] = {c[g].x, c[g].y, c[g].z, c[g].w};
+#pragma unroll
+        for (int u = 0; u < 16; u++) {
+            const uint2 x = cb[(s0 + g * 16 + u) * 256 + (((w[u >> 2] >> (8 * (u & 3))) & 0xFFu) ^ 0x55u)];
+            asm volatile("" ::"v"(x.x), "v"(x.y));
+        }
+    }
+#endif
 #pragma unroll
     for (int i = 0; i < NG * 16; i += 4) {  // s0 is a multiple of 16: whole quads, pairs (s0 + i) / 2 and the next one
         vg_f2 ta, tb;
+#if defined(VG_PQ_LOAD_PROBE) && VG_PQ_LOAD_PROBE == 2  // stage probe: every term's arithmetic twice
+        {
+            uint2 a0 = e[i], a1 = e[i + 1], a2 = e[i + 2], a3 = e[i + 3];
+            asm volatile("" : "+v"(a0.x), "+v"(a1.x), "+v"(a2.x), "+v"(a3.x));
+            vg_f2 ua, ub;
+            pq_term8_quad(a0, a1, a2, a3, qprep + ((s0 + i) >> 1) * kPqPairFloats, ua, ub);
+            asm volatile("" ::"v"(ua.x), "v"(ua.y), "v"(ub.x), "v"(ub.y));
+        }
+#endif
         pq_term8_quad(e[i], e[i + 1], e[i + 2], e[i + 3], qprep + ((s0 + i) >> 1) * kPqPairFloats, ta, tb);
         distance = distance + ta.x;  // the terms join the sum in sub-quantizer order (pq.go:242-257)
         distance = distance + ta.y;
