@@ -1143,7 +1143,26 @@ def emit(full: dict):
     print(f"bench.py: full record ({len(text)} bytes) -> {FULL_RECORD}", file=sys.stderr, flush=True)
     line = json.dumps(compact_line(full), ensure_ascii=True, separators=(",", ":"))
     assert "\n" not in line
-    print(line, flush=True)
+    if _REAL_STDOUT_FD is not None:  # fd 1 itself points at stderr by now (guard_stdout)
+        sys.stdout.flush()
+        os.write(_REAL_STDOUT_FD, (line + "\n").encode("ascii"))
+    else:
+        print(line, flush=True)
+
+
+_REAL_STDOUT_FD = None
+
+
+def guard_stdout():
+    """The contract is ONE JSON line on stdout.  Libraries write there too — Gloo's "[Gloo] Rank 1 is connected to 7 peer
+    ranks" (seen with --backend gloo), RCCL's version banner, a stray print in a dependency — and every rank of a
+    torch.distributed.run job shares the launcher's stdout.  So a rank process keeps a private copy of the real stdout
+    for the line and points descriptor 1 (C stdio, C++ iostreams, Python's sys.stdout) at stderr for everything else."""
+    global _REAL_STDOUT_FD
+    if _REAL_STDOUT_FD is None:
+        sys.stdout.flush()
+        _REAL_STDOUT_FD = os.dup(1)
+        os.dup2(2, 1)
 
 
 def launch_ranks(args) -> int:
@@ -1187,6 +1206,7 @@ def main():
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args))
+    guard_stdout()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: refusing to report a line for a world it did not run")

@@ -93,3 +93,25 @@ def test_bench_gpus_n_launches_ranks_itself():
     assert r.returncode != 0 and not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert "torch.distributed.run" in r.stderr and "--nproc-per-node=2" in r.stderr
     assert r.stderr.count("needs an MI355X") >= 1
+
+
+def test_stdout_carries_only_the_line_whatever_libraries_print():
+    """Gloo ("[Gloo] Rank 1 is connected to 7 peer ranks"), RCCL banners and stray prints go to descriptor 1 of a rank
+    process; bench.guard_stdout points that at stderr and keeps the real stdout for the ONE line (seen with 8 gloo ranks
+    in r04: seven such lines in front of the JSON)."""
+    import subprocess
+    import sys
+    code = ("import os, sys, json, bench\n"
+            "bench.guard_stdout()\n"
+            "os.write(1, b'[Gloo] Rank 1 is connected to 7 peer ranks\\n')\n"
+            "print('a stray print')\n"
+            "os.system('echo a child process writing to stdout')\n"
+            "full = json.loads(open(sys.argv[1]).read())\n"
+            "bench.FULL_RECORD = os.devnull\n"
+            "bench.emit(full)\n")
+    full = str(ROOT / "profiles" / "r04_bench_full.json")
+    r = subprocess.run([sys.executable, "-c", code, full], cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = r.stdout.splitlines()
+    assert len(lines) == 1 and json.loads(lines[0])["metric"], r.stdout[:500]
+    assert "[Gloo]" in r.stderr and "a stray print" in r.stderr and "child process" in r.stderr
