@@ -14,18 +14,19 @@ pytestmark = pytest.mark.gpu
 ROOT = Path(__file__).resolve().parents[1]
 
 
-def test_bench_gpus2_self_launch_gloo():
+@pytest.mark.parametrize("world", [2, 8])   # 8: the node's size — 12 sub-quantizers per rank, an 8-list merge, eight writers of one stdout
+def test_bench_gpus2_self_launch_gloo(world):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", VECGO_BENCH_ROWS="200000", VECGO_BENCH_SCAN_ROWS="200000")
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    cmd = [sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "3", "--warmup", "1"]
+    cmd = [sys.executable, str(ROOT / "bench.py"), "--gpus", str(world), "--backend", "gloo", "--steps", "3", "--warmup", "1"]
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
-    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, r.stdout[-3000:]
+    lines = r.stdout.splitlines()
+    assert len(lines) == 1 and lines[0].startswith("{"), r.stdout[-3000:]   # nothing but the line (Gloo's own prints go to stderr)
     d = json.loads(lines[0])
     assert len(lines[0]) < 8192
-    assert d["n_gpus"] == 2 and d["exchange"]["world_size"] == 2 and d["exchange"]["torch_backend"] == "gloo"
+    assert d["n_gpus"] == world and d["exchange"]["world_size"] == world and d["exchange"]["torch_backend"] == "gloo"
     assert d["reduced_sizes"] is True and "multi_gpu_legs_error" not in d
     assert d["recall_at_10"] == 1.0                   # the sharded exact path against the fp64 ground truth
     names = {c["config"]: c for c in d["configs"]}
