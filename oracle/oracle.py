@@ -1129,6 +1129,77 @@ def bench_run(kind, queries, k, threads, budget_s, base=None, dim=None, metric=M
                 dist_comps=dc)
 
 
+# ---- build-side twins (oracle/vg_cpu_bench.c "build-side twins"): one unit per C thread ----------------------
+BUILD_KM_ASSIGN, BUILD_PQ_ENCODE, BUILD_PQ_LUT, BUILD_RERANK, BUILD_BRUTE, BUILD_PQ_TRAIN_SUB = 0, 1, 2, 3, 4, 5
+
+
+class BuildJob(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("units", _f32p), ("n_units", C.c_int64), ("dim", C.c_int32), ("metric", C.c_int32),
+                ("centroids", _f32p), ("k", C.c_int32), ("pq", C.POINTER(PQ)), ("base", _f32p), ("cand", _u32p),
+                ("nc", C.c_int32), ("topk", C.c_int32), ("hnsw", C.POINTER(HnswGraph)), ("mode", C.c_int32),
+                ("train_n", C.c_int64), ("pq_m", C.c_int32), ("pq_k", C.c_int32), ("iters", C.c_int32),
+                ("seed", C.c_uint64), ("out_assign", _i32p), ("out_codes", _u8p), ("out_ids", _u32p),
+                ("out_scores", _f32p), ("out_cent", _f32p)]
+
+
+_sig("vgo_bench_build_run", C.c_int64, C.POINTER(BuildJob), C.c_int32, C.c_double, C.POINTER(C.c_double))
+
+
+def bench_build_run(kind, units, threads, budget_s, metric=METRIC_L2, centroids=None, pq: "ProductQuantizer" = None,
+                    base=None, cand=None, topk=10, hnsw: "HnswIndex" = None, mode=0, pq_m=0, pq_k=0, iters=0, seed=0,
+                    want_out=False):
+    """One unit per C thread for ~budget_s seconds (0: every thread runs exactly one unit).  `units` = rows
+    (KM_ASSIGN, PQ_ENCODE), queries (PQ_LUT, RERANK, BRUTE) or the training rows (PQ_TRAIN_SUB: units are the pq_m
+    sub-quantizers).  Returns dict(units, seconds, rate, out) — `out` holds the first pass's results when want_out."""
+    u = np.ascontiguousarray(units, np.float32)
+    job = BuildJob()
+    job.kind = kind
+    job.units = u.ctypes.data_as(_f32p)
+    job.n_units = pq_m if kind == BUILD_PQ_TRAIN_SUB else u.shape[0]
+    job.dim = u.shape[1]
+    job.metric = metric
+    job.topk, job.mode = topk, mode
+    keep = [u]
+    out = {}
+    if centroids is not None:
+        c = np.ascontiguousarray(centroids, np.float32); keep.append(c)
+        job.centroids = c.ctypes.data_as(_f32p)
+        job.k = c.shape[0]
+    if pq is not None:
+        pc = pq._c(); keep.append(pc)
+        job.pq = C.pointer(pc)
+    if base is not None:
+        assert base.dtype == np.float32 and base.flags.c_contiguous
+        job.base = base.ctypes.data_as(_f32p)
+    if cand is not None:
+        cd = np.ascontiguousarray(cand, np.uint32); keep.append(cd)
+        job.cand = cd.ctypes.data_as(_u32p)
+        job.nc = cd.shape[1]
+    if hnsw is not None:
+        g = hnsw._c(); keep.append(g)
+        job.hnsw = C.pointer(g)
+    if kind == BUILD_PQ_TRAIN_SUB:
+        job.train_n, job.pq_m, job.pq_k, job.iters, job.seed = u.shape[0], pq_m, pq_k, iters, seed
+    if want_out:
+        if kind == BUILD_KM_ASSIGN:
+            out["assign"] = np.full(u.shape[0], -1, np.int32)
+            job.out_assign = out["assign"].ctypes.data_as(_i32p)
+        elif kind == BUILD_PQ_ENCODE:
+            out["codes"] = np.zeros((u.shape[0], pq.m), np.uint8)
+            job.out_codes = out["codes"].ctypes.data_as(_u8p)
+        elif kind in (BUILD_RERANK, BUILD_BRUTE):
+            out["ids"] = np.full((u.shape[0], topk), 0xFFFFFFFF, np.uint32)
+            out["scores"] = np.zeros((u.shape[0], topk), np.float32)
+            job.out_ids = out["ids"].ctypes.data_as(_u32p)
+            job.out_scores = out["scores"].ctypes.data_as(_f32p)
+        elif kind == BUILD_PQ_TRAIN_SUB:
+            out["cent"] = np.zeros((pq_m, pq_k, u.shape[1] // pq_m), np.float32)
+            job.out_cent = out["cent"].ctypes.data_as(_f32p)
+    secs = C.c_double(0)
+    done = lib.vgo_bench_build_run(C.byref(job), threads, budget_s, C.byref(secs))
+    return dict(units=int(done), seconds=float(secs.value), rate=done / max(secs.value, 1e-9), out=out)
+
+
 def replay(kind, queries, k, **kw):
     """Whole queries through the oracle's loops, one C thread per query, the reference's compiled kernels when
     oracle/_ref is present (bit-identical to the scalar restatement, tests/test_oracle_golden.py): what the

@@ -543,6 +543,13 @@ static void pq_kmeans_subspace(const float *vectors, int64_t n, int dim, int sub
     free(nc);
 }
 
+/* one sub-quantizer of Train (the unit the reference hands to a goroutine, pq.go:78-95): for the timed CPU twin */
+void vgo_pq_train_subspace(const float *vectors, int64_t n, int32_t dim, int32_t m, int32_t sub, int32_t k,
+                           int32_t iters, uint64_t seed, float *cent /* k * dim/m */)
+{
+    pq_kmeans_subspace(vectors, n, dim, sub, dim / m, k, iters, seed, cent);
+}
+
 /* internal/quantization/pq.go:68-143 Train */
 int vgo_pq_train(const float *vectors, int64_t n, int32_t dim, int32_t m, int32_t k,
                  int32_t iters, uint64_t seed, int8_t *codebooks, float *scales,
@@ -1219,8 +1226,7 @@ void vgo_rerank_f32(const float *base, int32_t dim, int32_t metric, const float 
 {
     for (int i = 0; i < n; i++) { /* flat/segment.go:766-772 */
         const float *v = base + (int64_t)ids[i] * dim;
-        scores[i] = metric == VGO_METRIC_L2 ? vgo_l2_avx512(query, v, dim)
-                                            : vgo_dot_avx512(query, v, dim);
+        scores[i] = metric == VGO_METRIC_L2 ? hk_l2(query, v, dim) : hk_dot(query, v, dim);
     }
 }
 

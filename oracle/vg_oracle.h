@@ -79,6 +79,8 @@ float vgo_pq_asym_distance(const vgo_pq *pq, const float *query, const uint8_t *
 void vgo_pq_quantize_centroids(const float *centroids, int64_t count, int8_t *out,
                                float *scale, float *offset);
 /* Lloyd iterations + k-means++ init for one subspace, deterministic RNG */
+void vgo_pq_train_subspace(const float *vectors, int64_t n, int32_t dim, int32_t m, int32_t sub, int32_t k,
+                           int32_t iters, uint64_t seed, float *cent);
 int vgo_pq_train(const float *vectors, int64_t n, int32_t dim, int32_t m, int32_t k,
                  int32_t iters, uint64_t seed, int8_t *codebooks, float *scales,
                  float *offsets, float *centroids_f32 /* optional m*k*subdim */);

@@ -287,8 +287,11 @@ VG_API int32_t vg_rerank(vg_index *idx, const float *queries, int64_t nq, const 
     auto kern = dot ? vg::rerank_kernel<true> : vg::rerank_kernel<false>;
     VG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
-    VG_LAUNCH(kern, dim3(static_cast<unsigned>(nq)), dim3(vg::kExactThreads), lds, st,
-                       idx->d_vectors, idx->n, idx->dim, q.ptr, c.ptr, nc, k, oid.ptr, osc.ptr);
+    {
+        vg::ProfScope prof(idx->ctx, "rerank", st);
+        VG_LAUNCH(kern, dim3(static_cast<unsigned>(nq)), dim3(vg::kExactThreads), lds, st,
+                  idx->d_vectors, idx->n, idx->dim, q.ptr, c.ptr, nc, k, oid.ptr, osc.ptr);
+    }
     VG_TRY(oid.finish());
     VG_TRY(osc.finish());
     if (oid.on_host() || osc.on_host()) VG_HIP(hipStreamSynchronize(st));

@@ -514,7 +514,10 @@ VG_API int32_t vg_kmeans_assign(vg_ctx *ctx, const float *vectors, int64_t n, in
     VG_TRY(v.init(vectors, static_cast<size_t>(n) * dim, st));
     VG_TRY(c.init(centroids, static_cast<size_t>(k) * dim, st));
     VG_TRY(o.init(out, static_cast<size_t>(n), st));
-    VG_TRY(km_launch_assign(metric != VG_METRIC_L2, v.ptr, n, dim, c.ptr, k, o.ptr, nullptr, st));
+    {
+        vg::ProfScope prof(ctx, "km_assign", st);
+        VG_TRY(km_launch_assign(metric != VG_METRIC_L2, v.ptr, n, dim, c.ptr, k, o.ptr, nullptr, st));
+    }
     VG_TRY(o.finish());
     if (o.on_host()) VG_HIP(hipStreamSynchronize(st));
     return VG_OK;
@@ -568,11 +571,15 @@ VG_API int32_t vg_kmeans_train(vg_ctx *ctx, const float *vectors, int64_t n, int
     std::vector<int64_t> hcounts, hoff;
     for (int it = 0; it < max_iter; it++) {
         VG_HIP(hipMemsetAsync(changed.ptr, 0, sizeof(int), st));
-        VG_TRY(km_launch_assign(metric != VG_METRIC_L2, v.ptr, n, dim, cent.ptr, k, assign.ptr, changed.ptr, st));
+        {
+            vg::ProfScope prof(ctx, "km_assign", st);
+            VG_TRY(km_launch_assign(metric != VG_METRIC_L2, v.ptr, n, dim, cent.ptr, k, assign.ptr, changed.ptr, st));
+        }
         int hchanged = 0;
         VG_HIP(hipMemcpyAsync(&hchanged, changed.ptr, sizeof(int), hipMemcpyDeviceToHost, st));
         VG_HIP(hipStreamSynchronize(st));  // one sync per Lloyd iteration: the convergence test is the host's
         if (!hchanged) break;               // kmeans.go:101-103
+        vg::ProfScope prof(ctx, "km_update", st);  // member lists + per-cluster sums in index order
         if (sorted) {
             VG_LAUNCH(vg::km_hist_kernel, dim3(parts), dim3(256), 0, st, assign.ptr, n, k, hist.ptr);
             VG_LAUNCH(vg::km_scan_kernel, dim3(1), dim3(256), 0, st, hist.ptr, parts, k, counts.ptr, offsets.ptr);

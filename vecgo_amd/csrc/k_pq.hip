@@ -215,7 +215,10 @@ VG_API int32_t vg_pq_build_distance_table(vg_pq *pq, const float *queries, int64
     vg::DevOut<float> t;
     VG_TRY(q.init(queries, static_cast<size_t>(nq) * pq->dim, st));
     VG_TRY(t.init(tables, static_cast<size_t>(nq) * pq->m * pq->k, st));
-    VG_TRY(vg::launch_pq_build_table(pq, q.ptr, nq, t.ptr, false, st));
+    {
+        vg::ProfScope prof(pq->ctx, "pq_build_table", st);
+        VG_TRY(vg::launch_pq_build_table(pq, q.ptr, nq, t.ptr, false, st));
+    }
     VG_TRY(t.finish());
     if (t.on_host()) VG_HIP(hipStreamSynchronize(st));
     return VG_OK;

@@ -826,15 +826,22 @@ VG_API int32_t vg_pq_train_subset(vg_pq *pq, const float *vectors, int64_t n, in
     const unsigned ux = static_cast<unsigned>((k * sd + 255) / 256);
 #define VG_PQ_TRAIN_SD(SD)                                                                                       \
     do {                                                                                                         \
-        VG_LAUNCH(vg::pq_kmeanspp_kernel<SD>, dim3(m), dim3(vg::kPPThreads), 0, st, slabs.ptr, n, sd, k, seed,   \
-                  mind.ptr, pref.ptr, cent.ptr, sub_begin);                                                      \
+        {                                                                                                        \
+            vg::ProfScope prof(pq->ctx, "pq_kmeanspp", st);                                                      \
+            VG_LAUNCH(vg::pq_kmeanspp_kernel<SD>, dim3(m), dim3(vg::kPPThreads), 0, st, slabs.ptr, n, sd, k, seed, \
+                      mind.ptr, pref.ptr, cent.ptr, sub_begin);                                                  \
+        }                                                                                                        \
         for (int it = 0; it < iters; it++) {                                                                     \
-            if (SD)                                                                                              \
-                VG_LAUNCH(vg::pq_assign_vec_kernel<(SD ? SD : 4)>, dim3(gx_vec, m), dim3(256), lds, st, slabs.ptr, n, k, \
-                          cent.ptr, assign.ptr, changed, done);                                                  \
-            else                                                                                                 \
-                VG_LAUNCH(vg::pq_assign_kernel, dim3(gx, m), dim3(256), lds, st, slabs.ptr, n, sd, k, cent.ptr,  \
-                          assign.ptr, changed, done);                                                            \
+            {                                                                                                    \
+                vg::ProfScope prof(pq->ctx, "pq_assign", st);                                                    \
+                if (SD)                                                                                          \
+                    VG_LAUNCH(vg::pq_assign_vec_kernel<(SD ? SD : 4)>, dim3(gx_vec, m), dim3(256), lds, st, slabs.ptr, n, k, \
+                              cent.ptr, assign.ptr, changed, done);                                              \
+                else                                                                                             \
+                    VG_LAUNCH(vg::pq_assign_kernel, dim3(gx, m), dim3(256), lds, st, slabs.ptr, n, sd, k, cent.ptr, \
+                              assign.ptr, changed, done);                                                        \
+            }                                                                                                    \
+            vg::ProfScope prof(pq->ctx, "pq_update", st);                                                        \
             VG_LAUNCH(vg::pq_bucket_kernel, dim3(m), dim3(vg::kBucketThreads), 0, st, n, k, assign.ptr,          \
                       order.ptr, seg.ptr, changed, done);                                                        \
             VG_LAUNCH(vg::pq_update_kernel, dim3(ux, m), dim3(256), 0, st, slabs.ptr, n, sd, k, it, seed,        \
@@ -886,6 +893,8 @@ VG_API int32_t vg_pq_encode(vg_pq *pq, const float *vectors, int64_t n, uint8_t 
     // grid.y = m <= 65535 is guaranteed by dim limits; grid.x up to 2^31
     const bool vec_ok = pq->dim % 4 == 0 && (reinterpret_cast<uintptr_t>(v.ptr) & 15) == 0;
     const unsigned gx_vec = static_cast<unsigned>((n + 256 * vg::kEncRows - 1) / (256 * vg::kEncRows));
+    {
+    vg::ProfScope prof(pq->ctx, "pq_encode", st);
     if (vec_ok && pq->subdim == 8)
         VG_LAUNCH(vg::pq_encode_vec_kernel<8>, dim3(gx_vec, pq->m), dim3(256), lds, st, v.ptr, n, pq->dim, pq->m, pq->k,
                   pq->d_codebooks, pq->d_scales, pq->d_offsets, c.ptr);
@@ -899,6 +908,7 @@ VG_API int32_t vg_pq_encode(vg_pq *pq, const float *vectors, int64_t n, uint8_t 
         VG_LAUNCH(vg::pq_encode_kernel, dim3(static_cast<unsigned>((n + 255) / 256), pq->m), dim3(256),
                   lds, st, v.ptr, n, pq->dim, pq->m, pq->subdim, pq->k, pq->d_codebooks, pq->d_scales,
                   pq->d_offsets, c.ptr);
+    }
     VG_TRY(c.finish());
     if (c.on_host()) VG_HIP(hipStreamSynchronize(st));
     return VG_OK;
