@@ -1200,6 +1200,13 @@ def bench_build_run(kind, units, threads, budget_s, metric=METRIC_L2, centroids=
     return dict(units=int(done), seconds=float(secs.value), rate=done / max(secs.value, 1e-9), out=out)
 
 
+def assign_partition_batch(vectors, centroids, metric=METRIC_L2, threads=8):
+    """kmeans.AssignPartition for every row (vgo_bench_build_run, one pass, `threads` C threads): int32[n]."""
+    r = bench_build_run(BUILD_KM_ASSIGN, vectors, threads, -1.0, metric=metric, centroids=centroids, want_out=True)
+    assert r["units"] == np.asarray(vectors).shape[0]
+    return r["out"]["assign"]
+
+
 def replay(kind, queries, k, **kw):
     """Whole queries through the oracle's loops, one C thread per query, the reference's compiled kernels when
     oracle/_ref is present (bit-identical to the scalar restatement, tests/test_oracle_golden.py): what the

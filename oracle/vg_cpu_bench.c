@@ -283,7 +283,7 @@ typedef struct {
 
 typedef struct {
     const vgo_build_job *job;
-    int tid, nthreads;
+    int tid, nthreads, one_pass;
     double deadline;
     int64_t done;
 } build_worker;
@@ -373,7 +373,7 @@ static void *build_thread(void *p)
         }
         w->done++;
         i += w->nthreads;
-        if (now_s() >= w->deadline) break;
+        if (w->one_pass ? i >= j->n_units : now_s() >= w->deadline) break;
     }
     (void)sink;
     free(dists);
@@ -387,7 +387,8 @@ static void *build_thread(void *p)
     return NULL;
 }
 
-/* as vgo_bench_run: ~budget_s seconds of wall time (0: every thread runs exactly one unit); returns units completed */
+/* as vgo_bench_run: ~budget_s seconds of wall time (0: every thread runs exactly one unit; < 0: exactly one pass over
+ * all the units — the multi-threaded batch form the parity tests use as their checker); returns units completed */
 int64_t vgo_bench_build_run(const vgo_build_job *job, int32_t nthreads, double budget_s, double *seconds)
 {
     if (nthreads < 1) nthreads = 1;
@@ -399,10 +400,13 @@ int64_t vgo_bench_build_run(const vgo_build_job *job, int32_t nthreads, double b
         ws[t].tid = t;
         ws[t].nthreads = nthreads;
         ws[t].deadline = t0 + budget_s;
+        ws[t].one_pass = budget_s < 0 && (int64_t)t < job->n_units;
+        if (budget_s < 0 && !ws[t].one_pass) continue; /* more threads than units */
         pthread_create(&th[t], NULL, build_thread, &ws[t]);
     }
     int64_t total = 0;
     for (int t = 0; t < nthreads; t++) {
+        if (budget_s < 0 && !ws[t].one_pass) continue;
         pthread_join(th[t], NULL);
         total += ws[t].done;
     }

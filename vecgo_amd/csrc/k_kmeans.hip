@@ -5,6 +5,7 @@
 
 #include "vg_device.hpp"
 #include "vg_exact.hpp"
+#include "vg_flat_gemm.hpp"
 #include "vg_internal.hpp"
 
 namespace vg {
@@ -27,14 +28,20 @@ __host__ __device__ inline uint64_t km_rng(uint64_t seed, uint64_t a, uint64_t b
 
 // assignment (kmeans.go:54-99): 16 lanes per point, centroids visited in index order;
 // SquaredL2Batch / DotBatch order (batch_avx512.c), strict comparison keeps the lowest index
-template <bool DOT>
+// LIST: the points are list[0 .. *list_count) (the ones the MFMA nomination below could not decide), a block walks
+// chunks of 16 list slots
+template <bool DOT, bool LIST = false>
 __global__ __launch_bounds__(256) void km_assign_kernel(const float *__restrict__ vectors, int64_t n, int dim,
                                                         const float *__restrict__ centroids, int k,
-                                                        int32_t *__restrict__ assign, int *__restrict__ changed)
+                                                        int32_t *__restrict__ assign, int *__restrict__ changed,
+                                                        const int32_t *__restrict__ list = nullptr,
+                                                        const int *__restrict__ list_count = nullptr)
 {
     const Sub16 sub = Sub16::make(threadIdx.x);
-    const int64_t i = static_cast<int64_t>(blockIdx.x) * 16 + (threadIdx.x >> 4);
-    if (i >= n) return;
+    const int64_t total = LIST ? *list_count : n;
+    for (int64_t slot = static_cast<int64_t>(blockIdx.x) * 16 + (threadIdx.x >> 4); slot < total;
+         slot += static_cast<int64_t>(gridDim.x) * 16) {
+    const int64_t i = LIST ? list[slot] : slot;
     const float *v = vectors + i * dim;
     int best = 0;
     float bd = exact_pair16<DOT, kBatch>(centroids, v, dim, sub);
@@ -48,6 +55,7 @@ __global__ __launch_bounds__(256) void km_assign_kernel(const float *__restrict_
     if ((threadIdx.x & 15) == 0) {
         if (changed && assign[i] != best) *changed = 1;
         assign[i] = best;
+    }
     }
 }
 
@@ -95,20 +103,29 @@ __device__ __forceinline__ void km_fetch_tile(km_f4 (&stage)[STAGE], const float
     }
 }
 
-template <bool DOT, int NBLK>
+template <bool DOT, int NBLK, bool LIST = false>
 __global__ __launch_bounds__(256) void km_assign_regs_kernel(const float *__restrict__ vectors, int64_t n,
                                                              const float *__restrict__ centroids, int k,
-                                                             int32_t *__restrict__ assign, int *__restrict__ changed)
+                                                             int32_t *__restrict__ assign, int *__restrict__ changed,
+                                                             const int32_t *__restrict__ list = nullptr,
+                                                             const int *__restrict__ list_count = nullptr)
 {
     constexpr int dim = NBLK * 64;
     __shared__ __attribute__((aligned(16))) float ctile[kKmTile * dim];
     const int tid = threadIdx.x;
     const Sub16 sub = Sub16::make(tid);
-    const int64_t i0 = (static_cast<int64_t>(blockIdx.x) * 16 + (tid >> 4)) * kKmRows;
+    // LIST: slots of the list instead of rows; a block walks chunks of 16 * kKmRows slots (uniform trip count: the
+    // barriers below are reached by every thread)
+    const int64_t total = LIST ? *list_count : n;
+    for (int64_t chunk = blockIdx.x; chunk * (16 * kKmRows) < total; chunk += gridDim.x) {
+    const int64_t i0 = (chunk * 16 + (tid >> 4)) * kKmRows;
+    int64_t row_of[kKmRows];
     float4 rr[kKmRows][NBLK];
 #pragma unroll
     for (int p = 0; p < kKmRows; p++) {
-        const int64_t i = i0 + p < n ? i0 + p : n - 1;
+        const int64_t slot = i0 + p < total ? i0 + p : total - 1;
+        const int64_t i = LIST ? list[slot] : slot;
+        row_of[p] = i;
         const float4 *r4 = reinterpret_cast<const float4 *>(vectors + i * dim) + sub.f4;
 #pragma unroll
         for (int e = 0; e < NBLK; e++) rr[p][e] = r4[e * 16];
@@ -189,10 +206,11 @@ __global__ __launch_bounds__(256) void km_assign_regs_kernel(const float *__rest
     if ((tid & 15) == 0) {
 #pragma unroll
         for (int p = 0; p < kKmRows; p++)
-            if (i0 + p < n) {
-                if (changed && assign[i0 + p] != best[p]) *changed = 1;
-                assign[i0 + p] = best[p];
+            if (i0 + p < total) {
+                if (changed && assign[row_of[p]] != best[p]) *changed = 1;
+                assign[row_of[p]] = best[p];
             }
+    }
     }
 }
 
@@ -217,26 +235,43 @@ __global__ __launch_bounds__(256) void km_hist_kernel(const int32_t *__restrict_
     for (int c = threadIdx.x; c < k; c += 256) hist[static_cast<int64_t>(part) * k + c] = h[c];
 }
 
-// hist[part][c] becomes the number of cluster-c points in earlier parts; counts / offsets as the
-// update kernel wants them
-__global__ __launch_bounds__(256) void km_scan_kernel(int32_t *__restrict__ hist, int parts, int k,
-                                                      int64_t *__restrict__ counts, int64_t *__restrict__ offsets)
+// hist[part][c] becomes the number of cluster-c points in earlier parts, counts[c] the cluster's size: one workgroup per
+// cluster scans its column of the histogram 256 parts at a time (the single-workgroup form walked parts x k counters
+// through one thread per cluster: 120 us per iteration at 489 parts)
+__global__ __launch_bounds__(256) void km_scan_parts_kernel(int32_t *__restrict__ hist, int parts, int k,
+                                                            int64_t *__restrict__ counts)
+{
+    __shared__ int32_t sc[256];
+    const int c = blockIdx.x, tid = threadIdx.x;
+    int32_t carry = 0;
+    for (int p0 = 0; p0 < parts; p0 += 256) {
+        const int p = p0 + tid;
+        const int32_t v = p < parts ? hist[static_cast<int64_t>(p) * k + c] : 0;
+        sc[tid] = v;
+        __syncthreads();
+        for (int off = 1; off < 256; off <<= 1) {  // inclusive scan
+            const int32_t add = tid >= off ? sc[tid - off] : 0;
+            __syncthreads();
+            sc[tid] += add;
+            __syncthreads();
+        }
+        if (p < parts) hist[static_cast<int64_t>(p) * k + c] = carry + sc[tid] - v;
+        const int32_t total = sc[255];
+        __syncthreads();
+        carry += total;
+    }
+    if (tid == 0) counts[c] = carry;
+}
+
+// offsets[c] = number of points in clusters before c
+__global__ __launch_bounds__(256) void km_offsets_kernel(int k, const int64_t *__restrict__ counts, int64_t *__restrict__ offsets)
 {
     __shared__ int64_t seg[256];
     const int tid = threadIdx.x;
     const int per = (k + 255) / 256;
     const int cb = tid * per, ce = cb + per < k ? cb + per : k;
     int64_t mine = 0;
-    for (int c = cb; c < ce; c++) {
-        int32_t run = 0;
-        for (int p = 0; p < parts; p++) {
-            const int32_t v = hist[static_cast<int64_t>(p) * k + c];
-            hist[static_cast<int64_t>(p) * k + c] = run;
-            run += v;
-        }
-        counts[c] = run;
-        mine += run;
-    }
+    for (int c = cb; c < ce; c++) mine += counts[c];
     seg[tid] = mine;
     __syncthreads();
     if (tid == 0) {
@@ -458,44 +493,472 @@ __global__ __launch_bounds__(512) void adc_lookup_batch_lds_kernel(const float *
     }
 }
 
+
+// ---- assignment by MFMA nomination + exact decision ------------------------------------------------------------------
+// The assignment pass is a [points x centroids x dim] product: n * k * dim fused multiply-adds on the matrix cores
+// instead of n * k * dim (sub, fma) pairs plus a 16-lane reduction per pair on the vector ALU.  The matrix cores do
+// not add in squaredL2BatchAvx512's order, so their scores only NOMINATE:
+//   1. km_gemm_kernel     s~(x, c) = |c|^2 - 2 x.c  (L2; -x.c for Dot / Cosine) for every pair — the pipeline of
+//                         flat_gemm_dma_kernel (vg_flat_gemm.hpp: LDS-DMA tiles, swizzled image, v_mfma_f32_32x32x2_f32)
+//                         with the centroids as the 128-row A tile and 128 points as the B tile; the epilogue keeps, per
+//                         point and centroid tile, the smallest score, its centroid and the second smallest score
+//   2. km_decide_kernel   merges the centroid tiles and compares the gap between the two smallest scores with a bound on
+//                         |s~ - s| + |D_ref - D| (below).  A gap above the bound PROVES that the reference's own
+//                         arithmetic picks the same centroid: the assignment is written.  Everything else — near ties,
+//                         duplicate centroids, non-finite input — goes on a list
+//   3. km_assign_*_kernel<LIST>  the reference-order kernels above over the listed points (all k centroids each)
+// so every assignment is either proven equal to, or computed by, the reference's arithmetic.
+//
+// The bound.  u = 2^-24, X = |x|^2, C = max_c |c|^2, D = |x - c|^2 = X + s, s = |c|^2 - 2 x.c (exact values).
+//   reference:  D_ref = D (1 + t), |t| <= g_r, r = dim/64 + 32: one rounding in x_i - c_i, one per fused multiply-add
+//               of the accumulator chain (dim/64 of them + up to 4 16-wide steps), 6 tree additions, < 16 scalar steps
+//   matrix:     |s~ - s| <= E = (2 dim + 16) u (2 sqrt(X C) + C): at most two roundings per product of the dot
+//               product (the guide: the fp32 MFMA is an fmaf chain), the norm |c|^2 (dim roundings), one final fma
+//   c* = the reference's choice, cm = the smallest score:  D_ref(c*) <= D_ref(cm)
+//               =>  s(c*) - s(cm) <= g_r (D(c*) + D(cm)) <= 2 g_r (sqrt X + sqrt C)^2
+//               =>  s~(c*) <= s~(cm) + 2 E + 2 g_r (sqrt X + sqrt C)^2 =: s~(cm) + margin
+//   A second-smallest score above s~(cm) + margin therefore leaves cm as the only possible c*.  Dot / Cosine: the same
+//   with D replaced by x.c; the L2 margin is the larger of the two and is used for both.  The margin is evaluated in
+//   fp32 with a 5 % allowance for its own rounding and for the rounding of X and C (computed in any order).
+struct KmPart {   // per (centroid tile, point): the two smallest scores with their centroids, and the third smallest
+    float m1, m2, m3;
+    int32_t i1, i2;
+    int32_t pad[3];
+};
+static_assert(sizeof(KmPart) == 32, "two 16-byte stores per point");
+
+// (m1, i1) <= (m2, i2) <= m3 of the union of two such triples (ties between scores: any order — a tie is never decided
+// by the scores)
+__device__ __forceinline__ void km_merge3(float &m1, int &i1, float &m2, int &i2, float &m3, float o1, int oi1, float o2,
+                                          int oi2, float o3)
+{
+    // the smallest three of {m1, m2, m3, o1, o2, o3}, each list sorted
+    const bool a = o1 < m1;                       // which list holds the smallest
+    const float f1 = a ? o1 : m1;
+    const int fi1 = a ? oi1 : i1;
+    const float x2 = a ? o2 : m2, y1 = a ? m1 : o1;   // next of the winner's list, head of the other
+    const int xi2 = a ? oi2 : i2, yi1 = a ? i1 : oi1;
+    const float x3 = a ? o3 : m3, y2 = a ? m2 : o2;
+    const bool b = y1 < x2;                       // second smallest: the other list's head or the winner's next
+    const float f2 = b ? y1 : x2;
+    const int fi2 = b ? yi1 : xi2;
+    const float f3 = b ? fminf(x2, y2) : fminf(x3, y1);
+    m1 = f1; i1 = fi1; m2 = f2; i2 = fi2; m3 = f3;
+}
+
+// |row|^2 in any order (feeds the bound only): one wave per row, 16-byte loads
+__global__ __launch_bounds__(256) void km_norms_kernel(const float *__restrict__ v, int64_t n, int dim, float *__restrict__ out)
+{
+    const int64_t row = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+    if (row >= n) return;
+    const int lane = threadIdx.x & 63;
+    const float4 *r4 = reinterpret_cast<const float4 *>(v + row * dim);
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+    for (int j = lane; j < dim / 4; j += 64) {
+        const float4 x = load_stream(r4 + j);
+        s0 = __builtin_fmaf(x.x, x.x, s0);
+        s1 = __builtin_fmaf(x.y, x.y, s1);
+        s2 = __builtin_fmaf(x.z, x.z, s2);
+        s3 = __builtin_fmaf(x.w, x.w, s3);
+    }
+    float s = (s0 + s1) + (s2 + s3);
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if (lane == 0) out[row] = s;
+}
+
+// the centroids' side of the epilogue: cadd[c] = |c|^2 (L2) or 0 (Dot) for c < k, +Inf for the padding of the last tile;
+// *cmax_bits = max |c|^2 as float bits (non-negative floats order like their bits; zeroed by the caller), +Inf when a
+// centroid holds a non-finite value (then nothing is decided by the matrix scores).  One wave per centroid.
+__global__ __launch_bounds__(256) void km_cent_norms_kernel(const float *__restrict__ cent, int k, int dim, bool dot,
+                                                            float *__restrict__ cadd, int kpad, int *__restrict__ cmax_bits)
+{
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (c >= kpad) return;
+    float s = 0.0f;
+    if (c < k)
+        for (int j = lane; j < dim; j += 64) {
+            const float x = cent[static_cast<int64_t>(c) * dim + j];
+            s = __builtin_fmaf(x, x, s);
+        }
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if (!(s <= 3.0e38f)) s = INFINITY;  // NaN or overflow
+    if (lane == 0) {
+        cadd[c] = c < k ? (dot ? 0.0f : s) : INFINITY;
+        atomicMax(cmax_bits, __float_as_int(s));
+    }
+}
+
+template <bool DOT>
+__global__ __launch_bounds__(kGemmThreads) void km_gemm_kernel(const float *__restrict__ centroids, int k,
+                                                              const float *__restrict__ vectors, int64_t n, int dim,
+                                                              const float *__restrict__ cadd, KmPart *__restrict__ part)
+{
+    extern __shared__ float gemm_lds[];
+    // block order as flat_gemm_dma_kernel: blocks b, b+8, ... share an XCD; the centroid tiles of one point tile run
+    // back to back on one XCD, so the points cross the fabric once
+    const int mtiles = (k + kGemmBM - 1) / kGemmBM;
+    const int64_t ntiles = (n + kGemmBN - 1) / kGemmBN;
+    const int64_t bt = blockIdx.x;
+    const int64_t xcd = bt & 7, jx = bt >> 3;
+    const int64_t tn = (jx / mtiles) * 8 + xcd;
+    const int tm = static_cast<int>(jx % mtiles);
+    if (tn >= ntiles) return;
+    const int q0 = tm * kGemmBM;
+    const int64_t n0 = tn * kGemmBN;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+
+    const int drow = wave * 8 + (lane >> 3);
+    const int dgl = (lane & 7) ^ ((wave * 4 + (lane >> 4)) & 7);
+    const float *const abase = centroids + static_cast<int64_t>(q0) * dim;
+    const float *const bbase = vectors + n0 * dim;
+    uint32_t aoff[kGemmPasses], boff[kGemmPasses];
+#pragma unroll
+    for (int p = 0; p < kGemmPasses; p++) {
+        int qa = q0 + p * 32 + drow;
+        if (qa >= k) qa = k - 1;  // padding rows re-read the last centroid; their scores are +Inf through cadd
+        int64_t nb = n0 + p * 32 + drow;
+        if (nb >= n) nb = n - 1;
+        aoff[p] = static_cast<uint32_t>((static_cast<int64_t>(qa - q0) * dim + dgl * 4) * 4);
+        boff[p] = static_cast<uint32_t>(((nb - n0) * dim + dgl * 4) * 4);
+    }
+    const int ksteps = (dim + kGemmBK - 1) / kGemmBK;
+    const int full_steps = dim / kGemmBK;
+    const uint32_t lds0 = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(
+        (__attribute__((address_space(3))) void *)gemm_lds));
+    auto piece = [&](int b, int t, int p) {
+        return static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(
+            static_cast<int>(lds0 + ((b * 2 + t) * kDmaTile + (p * 32 + wave * 8) * kGemmBK) * 4)));
+    };
+    auto dma_tile = [&](int kt) {
+        const int k0 = kt * kGemmBK, b = kt & 1;
+        if (kt < full_steps) {
+#pragma unroll
+            for (int p = 0; p < kGemmPasses; p++) {
+                glds16(abase + k0, aoff[p], piece(b, 0, p));
+                glds16(bbase + k0, boff[p], piece(b, 1, p));
+            }
+        } else {  // ragged K edge; dim % 4 == 0, so a granule is inside or outside as a whole
+            const float *zeros = reinterpret_cast<const float *>(&g_gemm_zero16);
+            const bool in = k0 + dgl * 4 < dim;
+#pragma unroll
+            for (int p = 0; p < kGemmPasses; p++) {
+                glds16(in ? abase + k0 + aoff[p] / 4 : zeros, piece(b, 0, p));
+                glds16(in ? bbase + k0 + boff[p] / 4 : zeros, piece(b, 1, p));
+            }
+        }
+    };
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.0f;
+    const int h = lane >> 5, f = (lane >> 1) & 7;
+    int goff[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) goff[j] = ((2 * j + h) ^ f) * 4;
+    const int a_row = (wr * 64 + (lane & 31)) * kGemmBK;
+    const int b_row = (wc * 64 + (lane & 31)) * kGemmBK;
+
+    const float cadd_reg = tid < kGemmBM ? cadd[q0 + tid] : 0.0f;  // before the K loop: off its tail
+    dma_tile(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int kt = 0; kt < ksteps; kt++) {
+        const float *As = gemm_lds + (kt & 1) * 2 * kDmaTile, *Bs = As + kDmaTile;
+        if (kt + 1 < ksteps) dma_tile(kt + 1);
+        float4 fa[2][2], fb[2][2];  // [parity][row block]
+        fa[0][0] = *reinterpret_cast<const float4 *>(As + a_row + goff[0]);
+        fa[0][1] = *reinterpret_cast<const float4 *>(As + a_row + 32 * kGemmBK + goff[0]);
+        fb[0][0] = *reinterpret_cast<const float4 *>(Bs + b_row + goff[0]);
+        fb[0][1] = *reinterpret_cast<const float4 *>(Bs + b_row + 32 * kGemmBK + goff[0]);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int c = j & 1, nx = c ^ 1;
+            if (j < 3) {
+                fa[nx][0] = *reinterpret_cast<const float4 *>(As + a_row + goff[j + 1]);
+                fa[nx][1] = *reinterpret_cast<const float4 *>(As + a_row + 32 * kGemmBK + goff[j + 1]);
+                fb[nx][0] = *reinterpret_cast<const float4 *>(Bs + b_row + goff[j + 1]);
+                fb[nx][1] = *reinterpret_cast<const float4 *>(Bs + b_row + 32 * kGemmBK + goff[j + 1]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#define VG_KM_MFMA4(comp)                                                                                  \
+    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][0].comp, fb[c][0].comp, acc[0][0], 0, 0, 0);    \
+    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][0].comp, fb[c][1].comp, acc[0][1], 0, 0, 0);    \
+    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][1].comp, fb[c][0].comp, acc[1][0], 0, 0, 0);    \
+    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][1].comp, fb[c][1].comp, acc[1][1], 0, 0, 0);
+            VG_KM_MFMA4(x)
+            VG_KM_MFMA4(y)
+            VG_KM_MFMA4(z)
+            VG_KM_MFMA4(w)
+#undef VG_KM_MFMA4
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of tile kt+1 have landed
+        __syncthreads();                                   // ... everyone's have; tile kt is free
+    }
+
+    // Epilogue.  C/D map of the 32x32 MFMA: column = lane & 31 (a point), row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+    // (a centroid).  A lane scans its 32 centroids of each of its 2 points for (smallest, where, second smallest),
+    // merges with lane ^ 32 (the other rows of the same columns), then the two waves of a column block merge in LDS.
+    float *lds_add = gemm_lds;                                     // [128]
+    float *lds_m = gemm_lds + kGemmBM;                             // [3][2 wr][128 points]
+    int *lds_i = reinterpret_cast<int *>(lds_m + 3 * 2 * kGemmBN);  // [2][2 wr][128 points]
+    if (tid < kGemmBM) lds_add[tid] = cadd_reg;
+    __syncthreads();
+    float4 t4[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int g = 0; g < 4; g++)
+            t4[i][g] = *reinterpret_cast<const float4 *>(lds_add + wr * 64 + i * 32 + 8 * g + 4 * h);
+    const float coef = DOT ? -1.0f : -2.0f;
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        float m1 = INFINITY, m2 = INFINITY, m3 = INFINITY;
+        int i1 = 0, i2 = 0;
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const float4 tv = t4[i][r >> 2];
+                const float add = (r & 3) == 0 ? tv.x : (r & 3) == 1 ? tv.y : (r & 3) == 2 ? tv.z : tv.w;
+                const float sc = __builtin_fmaf(coef, acc[i][j][r], add);
+                const int c = q0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                // m1 <= m2 <= m3: the middle one of (m2, sc, m3) is the new third, of (m1, sc, m2) the new second
+                m3 = __builtin_amdgcn_fmed3f(m2, sc, m3);
+                const bool lt1 = sc < m1, lt2 = sc < m2;
+                i2 = lt1 ? i1 : (lt2 ? c : i2);
+                m2 = __builtin_amdgcn_fmed3f(m1, sc, m2);
+                i1 = lt1 ? c : i1;
+                m1 = fminf(m1, sc);
+            }
+        }
+        km_merge3(m1, i1, m2, i2, m3, __shfl_xor(m1, 32), __shfl_xor(i1, 32), __shfl_xor(m2, 32), __shfl_xor(i2, 32),
+                  __shfl_xor(m3, 32));
+        if (h == 0) {
+            const int at = wr * kGemmBN + wc * 64 + j * 32 + (lane & 31);
+            lds_m[at] = m1;
+            lds_m[2 * kGemmBN + at] = m2;
+            lds_m[4 * kGemmBN + at] = m3;
+            lds_i[at] = i1;
+            lds_i[2 * kGemmBN + at] = i2;
+        }
+    }
+    __syncthreads();
+    if (tid < kGemmBN && n0 + tid < n) {
+        float m1 = lds_m[tid], m2 = lds_m[2 * kGemmBN + tid], m3 = lds_m[4 * kGemmBN + tid];
+        int i1 = lds_i[tid], i2 = lds_i[2 * kGemmBN + tid];
+        km_merge3(m1, i1, m2, i2, m3, lds_m[kGemmBN + tid], lds_i[kGemmBN + tid], lds_m[3 * kGemmBN + tid],
+                  lds_i[3 * kGemmBN + tid], lds_m[5 * kGemmBN + tid]);
+        float4 *dst = reinterpret_cast<float4 *>(part + static_cast<int64_t>(tm) * n + n0 + tid);
+        dst[0] = make_float4(m1, m2, m3, __int_as_float(i1));
+        dst[1] = make_float4(__int_as_float(i2), 0.0f, 0.0f, 0.0f);
+    }
+}
+
+// Three outcomes per point: the gap to the second smallest score exceeds the margin -> decided; only the gap to the THIRD
+// does -> the reference's choice is one of two centroids: (point, lo, hi) goes on the pair list; otherwise the point
+// goes on the full list.  List positions come from one atomic per workgroup and list (positions inside a workgroup by
+// an LDS counter): the order of a list is irrelevant, every entry is handled on its own.
+__global__ __launch_bounds__(256) void km_decide_kernel(const KmPart *__restrict__ part, int mtiles, int64_t n,
+                                                        const float *__restrict__ xnorm, float coef_e, float coef_r,
+                                                        int32_t *__restrict__ assign, int *__restrict__ changed,
+                                                        int32_t *__restrict__ list, int32_t *__restrict__ pairs /* [n][3] */,
+                                                        int *__restrict__ counts /* [0] full list, [1] pair list, [2] max |c|^2 bits */)
+{
+    __shared__ int s_cnt[2], s_base[2];
+    if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    int kind = 0, pos = 0;  // 0 decided (or past n), 1 full list, 2 pair list
+    int i1 = 0, i2 = 0;
+    if (i < n) {
+        float m1 = INFINITY, m2 = INFINITY, m3 = INFINITY;
+        for (int t = 0; t < mtiles; t++) {
+            const float4 *src = reinterpret_cast<const float4 *>(part + static_cast<int64_t>(t) * n + i);
+            const float4 a = src[0];
+            const int bi2 = __float_as_int(src[1].x);
+            km_merge3(m1, i1, m2, i2, m3, a.x, __float_as_int(a.w), a.y, bi2, a.z);
+        }
+        const float X = xnorm[i], C = __int_as_float(counts[2]);
+        const float sx = sqrtf(X), sc = sqrtf(C);
+        const float cross = 2.0f * sx * sc + C, dmax = (sx + sc) * (sx + sc);
+        const float margin = 1.05f * (coef_e * cross + coef_r * dmax) + 1e-30f;
+        // every comparison is false on NaN: non-finite rows, centroids or scores fall through to the full list
+        const bool finite = X + C < 1e30f;
+        if (finite && m2 - m1 > margin) {
+            if (changed && assign[i] != i1) *changed = 1;
+            assign[i] = i1;
+        } else {
+            kind = (finite && m3 - m1 > margin) ? 2 : 1;
+            pos = atomicAdd(&s_cnt[kind - 1], 1);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 && s_cnt[threadIdx.x] > 0) s_base[threadIdx.x] = atomicAdd(&counts[threadIdx.x], s_cnt[threadIdx.x]);
+    __syncthreads();
+    if (kind == 1) {
+        list[s_base[0] + pos] = static_cast<int32_t>(i);
+    } else if (kind == 2) {
+        int32_t *e = pairs + 3 * static_cast<int64_t>(s_base[1] + pos);
+        e[0] = static_cast<int32_t>(i);
+        e[1] = i1 < i2 ? i1 : i2;
+        e[2] = i1 < i2 ? i2 : i1;
+    }
+}
+
+// the pair list: the reference-order distance to the two candidates; the reference's scan (strict compare, lowest index
+// first) picks `hi` only if it is strictly better than `lo`
+template <bool DOT>
+__global__ __launch_bounds__(256) void km_pairs_kernel(const float *__restrict__ vectors, int dim,
+                                                       const float *__restrict__ centroids,
+                                                       const int32_t *__restrict__ pairs, const int *__restrict__ counts,
+                                                       int32_t *__restrict__ assign, int *__restrict__ changed)
+{
+    const Sub16 sub = Sub16::make(threadIdx.x);
+    const int total = counts[1];
+    for (int64_t e = static_cast<int64_t>(blockIdx.x) * 16 + (threadIdx.x >> 4); e < total;
+         e += static_cast<int64_t>(gridDim.x) * 16) {
+        const int64_t i = pairs[3 * e];
+        const int lo = pairs[3 * e + 1], hi = pairs[3 * e + 2];
+        const float *v = vectors + i * dim;
+        const float dl = exact_pair16<DOT, kBatch>(centroids + static_cast<int64_t>(lo) * dim, v, dim, sub);
+        const float dh = exact_pair16<DOT, kBatch>(centroids + static_cast<int64_t>(hi) * dim, v, dim, sub);
+        const int best = (DOT ? (dh > dl) : (dh < dl)) ? hi : lo;
+        if ((threadIdx.x & 15) == 0) {
+            if (changed && assign[i] != best) *changed = 1;
+            assign[i] = best;
+        }
+    }
+}
+
 }  // namespace vg
 
 // pick the register-resident assignment when the row shape allows it
+// list != nullptr: the points list[0 .. *list_count) (count known to the device only: the grid is sized for a share of n
+// and strides)
 template <int NBLK>
 static int32_t km_launch_regs(bool dot, const float *v, int64_t n, const float *cent, int k, int32_t *assign, int *changed,
-                              hipStream_t st)
+                              hipStream_t st, const int32_t *list, const int *list_count)
 {
-    const unsigned gx = static_cast<unsigned>((n + 16 * vg::kKmRows - 1) / (16 * vg::kKmRows));
+    const int64_t chunks = (n + 16 * vg::kKmRows - 1) / (16 * vg::kKmRows);
+    if (list) {
+        const unsigned gx = static_cast<unsigned>(std::min<int64_t>(chunks, 2048));
+        if (dot)
+            VG_LAUNCH((vg::km_assign_regs_kernel<true, NBLK, true>), dim3(gx), dim3(256), 0, st, v, n, cent, k, assign, changed,
+                      list, list_count);
+        else
+            VG_LAUNCH((vg::km_assign_regs_kernel<false, NBLK, true>), dim3(gx), dim3(256), 0, st, v, n, cent, k, assign, changed,
+                      list, list_count);
+        return VG_OK;
+    }
+    const unsigned gx = static_cast<unsigned>(chunks);
     if (dot)
-        VG_LAUNCH((vg::km_assign_regs_kernel<true, NBLK>), dim3(gx), dim3(256), 0, st, v, n, cent, k, assign, changed);
+        VG_LAUNCH((vg::km_assign_regs_kernel<true, NBLK>), dim3(gx), dim3(256), 0, st, v, n, cent, k, assign, changed, nullptr,
+                  nullptr);
     else
-        VG_LAUNCH((vg::km_assign_regs_kernel<false, NBLK>), dim3(gx), dim3(256), 0, st, v, n, cent, k, assign, changed);
+        VG_LAUNCH((vg::km_assign_regs_kernel<false, NBLK>), dim3(gx), dim3(256), 0, st, v, n, cent, k, assign, changed, nullptr,
+                  nullptr);
     return VG_OK;
 }
 
-static int32_t km_launch_assign(bool dot, const float *v, int64_t n, int dim, const float *cent, int k, int32_t *assign,
-                                int *changed, hipStream_t st)
+// the reference-order assignment (squaredL2BatchAvx512 / dotBatchAvx512 summation order)
+static int32_t km_launch_exact(bool dot, const float *v, int64_t n, int dim, const float *cent, int k, int32_t *assign,
+                               int *changed, hipStream_t st, const int32_t *list = nullptr, const int *list_count = nullptr)
 {
     const bool aligned = (reinterpret_cast<uintptr_t>(v) & 15) == 0 && (reinterpret_cast<uintptr_t>(cent) & 15) == 0;
     if (aligned) {
         switch (dim) {
-        case 64: return km_launch_regs<1>(dot, v, n, cent, k, assign, changed, st);
-        case 128: return km_launch_regs<2>(dot, v, n, cent, k, assign, changed, st);
-        case 256: return km_launch_regs<4>(dot, v, n, cent, k, assign, changed, st);
-        case 384: return km_launch_regs<6>(dot, v, n, cent, k, assign, changed, st);
-        case 512: return km_launch_regs<8>(dot, v, n, cent, k, assign, changed, st);
-        case 768: return km_launch_regs<12>(dot, v, n, cent, k, assign, changed, st);
-        case 1024: return km_launch_regs<16>(dot, v, n, cent, k, assign, changed, st);
+        case 64: return km_launch_regs<1>(dot, v, n, cent, k, assign, changed, st, list, list_count);
+        case 128: return km_launch_regs<2>(dot, v, n, cent, k, assign, changed, st, list, list_count);
+        case 256: return km_launch_regs<4>(dot, v, n, cent, k, assign, changed, st, list, list_count);
+        case 384: return km_launch_regs<6>(dot, v, n, cent, k, assign, changed, st, list, list_count);
+        case 512: return km_launch_regs<8>(dot, v, n, cent, k, assign, changed, st, list, list_count);
+        case 768: return km_launch_regs<12>(dot, v, n, cent, k, assign, changed, st, list, list_count);
+        case 1024: return km_launch_regs<16>(dot, v, n, cent, k, assign, changed, st, list, list_count);
         default: break;
         }
     }
-    const unsigned gx = static_cast<unsigned>((n + 15) / 16);
+    const int64_t groups = (n + 15) / 16;
+    if (list) {
+        const unsigned gx = static_cast<unsigned>(std::min<int64_t>(groups, 4096));
+        if (dot)
+            VG_LAUNCH((vg::km_assign_kernel<true, true>), dim3(gx), dim3(256), 0, st, v, n, dim, cent, k, assign, changed, list,
+                      list_count);
+        else
+            VG_LAUNCH((vg::km_assign_kernel<false, true>), dim3(gx), dim3(256), 0, st, v, n, dim, cent, k, assign, changed, list,
+                      list_count);
+        return VG_OK;
+    }
+    const unsigned gx = static_cast<unsigned>(groups);
     if (dot)
-        VG_LAUNCH(vg::km_assign_kernel<true>, dim3(gx), dim3(256), 0, st, v, n, dim, cent, k, assign, changed);
+        VG_LAUNCH((vg::km_assign_kernel<true>), dim3(gx), dim3(256), 0, st, v, n, dim, cent, k, assign, changed, nullptr, nullptr);
     else
-        VG_LAUNCH(vg::km_assign_kernel<false>, dim3(gx), dim3(256), 0, st, v, n, dim, cent, k, assign, changed);
+        VG_LAUNCH((vg::km_assign_kernel<false>), dim3(gx), dim3(256), 0, st, v, n, dim, cent, k, assign, changed, nullptr, nullptr);
     return VG_OK;
 }
+
+// MFMA nomination + exact decision (see km_gemm_kernel): scratch of one vg_kmeans_assign / vg_kmeans_train call
+struct KmMfma {
+    vg::DevTmp<float> xnorm, cadd;
+    vg::DevTmp<vg::KmPart> part;
+    vg::DevTmp<int32_t> list, pairs;
+    vg::DevTmp<int> count;  // [0] full list, [1] pair list, [2] max |c|^2 (float bits)
+    int mtiles = 0;
+    bool on = false;
+
+    static bool eligible(const float *v, int64_t n, int dim, const float *cent, int k)
+    {
+        const bool aligned = ((reinterpret_cast<uintptr_t>(v) | reinterpret_cast<uintptr_t>(cent)) & 15) == 0;
+        // below a few thousand points the passes around the GEMM cost more than the reference-order kernel
+        return aligned && dim % 4 == 0 && dim >= 32 && n >= 4096 && n <= INT32_MAX && k >= 2 && !vg::hook(vg::kHookKmNoMfma);
+    }
+    // allocates and computes |x|^2 (the points do not change between the iterations of a training run)
+    int32_t init(const float *v, int64_t n, int dim, int k, hipStream_t st)
+    {
+        mtiles = (k + vg::kGemmBM - 1) / vg::kGemmBM;
+        VG_TRY(xnorm.init(static_cast<size_t>(n), st));
+        VG_TRY(cadd.init(static_cast<size_t>(mtiles) * vg::kGemmBM, st));
+        VG_TRY(part.init(static_cast<size_t>(mtiles) * n, st));
+        VG_TRY(list.init(static_cast<size_t>(n), st));
+        VG_TRY(pairs.init(static_cast<size_t>(n) * 3, st));
+        VG_TRY(count.init(3, st));
+        VG_LAUNCH(vg::km_norms_kernel, dim3(static_cast<unsigned>((n + 3) / 4)), dim3(256), 0, st, v, n, dim, xnorm.ptr);
+        on = true;
+        return VG_OK;
+    }
+    int32_t assign(bool dot, const float *v, int64_t n, int dim, const float *cent, int k, int32_t *out, int *changed,
+                   hipStream_t st)
+    {
+        VG_HIP(hipMemsetAsync(count.ptr, 0, 3 * sizeof(int), st));
+        const int kpad = mtiles * vg::kGemmBM;
+        VG_LAUNCH(vg::km_cent_norms_kernel, dim3(static_cast<unsigned>((kpad + 3) / 4)), dim3(256), 0, st, cent, k, dim, dot,
+                  cadd.ptr, kpad, count.ptr + 2);
+        const int64_t ntiles = (n + vg::kGemmBN - 1) / vg::kGemmBN;
+        const unsigned blocks = static_cast<unsigned>(((ntiles + 7) / 8) * 8 * mtiles);
+        auto kern = dot ? vg::km_gemm_kernel<true> : vg::km_gemm_kernel<false>;
+        VG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   static_cast<int>(vg::kDmaLdsBytes)));
+        VG_LAUNCH(kern, dim3(blocks), dim3(vg::kGemmThreads), vg::kDmaLdsBytes, st, cent, k, v, n, dim, cadd.ptr, part.ptr);
+        const float u = 5.9604645e-8f;
+        float coef_e = 2.0f * (2.0f * dim + 16.0f) * u, coef_r = 2.0f * (dim / 64 + 32.0f) * u;
+        if (vg::hook(vg::kHookKmListAll)) coef_e = INFINITY;
+        VG_LAUNCH(vg::km_decide_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, st, part.ptr, mtiles, n,
+                  xnorm.ptr, coef_e, coef_r, out, changed, list.ptr, pairs.ptr, count.ptr);
+        const unsigned pg = static_cast<unsigned>(std::min<int64_t>((n + 15) / 16, 2048));
+        if (dot)
+            VG_LAUNCH(vg::km_pairs_kernel<true>, dim3(pg), dim3(256), 0, st, v, dim, cent, pairs.ptr, count.ptr, out, changed);
+        else
+            VG_LAUNCH(vg::km_pairs_kernel<false>, dim3(pg), dim3(256), 0, st, v, dim, cent, pairs.ptr, count.ptr, out, changed);
+        return km_launch_exact(dot, v, n, dim, cent, k, out, changed, st, list.ptr, count.ptr);
+    }
+};
 
 static bool km_metric_ok(int32_t metric) { return metric == VG_METRIC_L2 || metric == VG_METRIC_DOT || metric == VG_METRIC_COSINE; }
 
@@ -514,9 +977,14 @@ VG_API int32_t vg_kmeans_assign(vg_ctx *ctx, const float *vectors, int64_t n, in
     VG_TRY(v.init(vectors, static_cast<size_t>(n) * dim, st));
     VG_TRY(c.init(centroids, static_cast<size_t>(k) * dim, st));
     VG_TRY(o.init(out, static_cast<size_t>(n), st));
+    KmMfma mf;
+    if (KmMfma::eligible(v.ptr, n, dim, c.ptr, k)) VG_TRY(mf.init(v.ptr, n, dim, k, st));
     {
         vg::ProfScope prof(ctx, "km_assign", st);
-        VG_TRY(km_launch_assign(metric != VG_METRIC_L2, v.ptr, n, dim, c.ptr, k, o.ptr, nullptr, st));
+        if (mf.on)
+            VG_TRY(mf.assign(metric != VG_METRIC_L2, v.ptr, n, dim, c.ptr, k, o.ptr, nullptr, st));
+        else
+            VG_TRY(km_launch_exact(metric != VG_METRIC_L2, v.ptr, n, dim, c.ptr, k, o.ptr, nullptr, st));
     }
     VG_TRY(o.finish());
     if (o.on_host()) VG_HIP(hipStreamSynchronize(st));
@@ -569,11 +1037,16 @@ VG_API int32_t vg_kmeans_train(vg_ctx *ctx, const float *vectors, int64_t n, int
     vg::DevTmp<int32_t> hist;
     if (sorted) VG_TRY(hist.init(static_cast<size_t>(parts) * k, st));
     std::vector<int64_t> hcounts, hoff;
+    KmMfma mf;
+    if (KmMfma::eligible(v.ptr, n, dim, cent.ptr, k)) VG_TRY(mf.init(v.ptr, n, dim, k, st));
     for (int it = 0; it < max_iter; it++) {
         VG_HIP(hipMemsetAsync(changed.ptr, 0, sizeof(int), st));
         {
             vg::ProfScope prof(ctx, "km_assign", st);
-            VG_TRY(km_launch_assign(metric != VG_METRIC_L2, v.ptr, n, dim, cent.ptr, k, assign.ptr, changed.ptr, st));
+            if (mf.on)
+                VG_TRY(mf.assign(metric != VG_METRIC_L2, v.ptr, n, dim, cent.ptr, k, assign.ptr, changed.ptr, st));
+            else
+                VG_TRY(km_launch_exact(metric != VG_METRIC_L2, v.ptr, n, dim, cent.ptr, k, assign.ptr, changed.ptr, st));
         }
         int hchanged = 0;
         VG_HIP(hipMemcpyAsync(&hchanged, changed.ptr, sizeof(int), hipMemcpyDeviceToHost, st));
@@ -582,7 +1055,8 @@ VG_API int32_t vg_kmeans_train(vg_ctx *ctx, const float *vectors, int64_t n, int
         vg::ProfScope prof(ctx, "km_update", st);  // member lists + per-cluster sums in index order
         if (sorted) {
             VG_LAUNCH(vg::km_hist_kernel, dim3(parts), dim3(256), 0, st, assign.ptr, n, k, hist.ptr);
-            VG_LAUNCH(vg::km_scan_kernel, dim3(1), dim3(256), 0, st, hist.ptr, parts, k, counts.ptr, offsets.ptr);
+            VG_LAUNCH(vg::km_scan_parts_kernel, dim3(k), dim3(256), 0, st, hist.ptr, parts, k, counts.ptr);
+            VG_LAUNCH(vg::km_offsets_kernel, dim3(1), dim3(256), 0, st, k, counts.ptr, offsets.ptr);
             VG_LAUNCH(vg::km_scatter_kernel, dim3(parts), dim3(64), 0, st, assign.ptr, n, k, kbits, hist.ptr, offsets.ptr,
                       members.ptr);
         } else {  // more clusters than LDS counters: every cluster walks the assignment array

@@ -75,6 +75,8 @@ enum Hook {
     kHookProbeNoGroup,        // VG_PROBE_NO_GROUP       one pass per (query, probe) pair
     kHookAdcBigkExhaustive,   // VG_ADC_BIGK_EXHAUSTIVE  LDS-buffer path for k > 64
     kHookBuildDebug,          // VG_BUILD_DEBUG          vg_hnsw_build prints its back-link totals
+    kHookKmNoMfma,            // VG_KM_NO_MFMA           k-means assignment by the reference-order kernels only
+    kHookKmListAll,           // VG_KM_LIST_ALL          k-means: the matrix scores decide nothing, every point is listed
     kHookCount
 };
 bool hook(Hook h);
