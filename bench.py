@@ -826,12 +826,18 @@ def build_side_legs(vg, ctx, rows, queries, stream, with_cpu, rows_host=None):
     la, ta = pr["km_assign"]
     lu, tu = pr["km_update"]
     assign_ms = ta / max(la, 1)
-    # algorithmic work of one assignment pass: n x k x dim (sub, fma) pairs = 2 lane-ops per element — the bound the
-    # reference's own arithmetic (squaredL2BatchAvx512: vsubps + vfmadd231ps) sets for a vector-ALU kernel
-    row = valu_row(f"kmeans.TrainKMeans {n} x {DIM}, k = {k_parts}, 10 iterations: one assignment pass (kmeans.go:54-99)",
-                   "km_assign", assign_ms, 2.0 * n * k_parts * DIM,
-                   short=f"kmeans_{n}x{DIM}_k{k_parts}_10it", train_ms=wall, assign_launches=la, update_ms_per_iter=tu / max(lu, 1),
-                   lane_ops_per_pass=2.0 * n * k_parts * DIM)
+    # one assignment pass = km_gemm_kernel (fp32 MFMA: |c|^2 - 2 x.c for every pair) + the decision + the reference-order
+    # kernels over the points the matrix scores cannot decide; algorithmic work = 2 n k dim flops (one fused multiply-add
+    # per element) against the fp32 MFMA peak.  (r04's vector-ALU kernel did n k dim (sub, fma) pairs: 5.9 ms = 0.40 of
+    # the vector rate; `valu_equiv` is the same pass priced that way.)
+    km_flops = 2.0 * n * k_parts * DIM
+    km_tf = km_flops / (assign_ms * 1e-3) / 1e12
+    row = {"workload": f"kmeans.TrainKMeans {n} x {DIM}, k = {k_parts}, 10 iterations: one assignment pass (kmeans.go:54-99)",
+           "kernel": "km_gemm_kernel + km_decide / km_pairs / km_assign_regs<LIST>", "kernel_ms": assign_ms, "bound": "mfma",
+           "achieved": km_tf, "peak": PEAK_MFMA_F32_TFLOPS, "unit": "TFLOP/s", "frac": km_tf / PEAK_MFMA_F32_TFLOPS,
+           "valu_equiv": 2.0 * n * k_parts * DIM / (assign_ms * 1e-3) / PEAK_VALU_LANEOPS,
+           "short": f"kmeans_{n}x{DIM}_k{k_parts}_10it", "train_ms": wall, "assign_launches": la,
+           "update_ms_per_iter": tu / max(lu, 1), "flops_per_pass": km_flops}
     ga = vg.kmeans_assign(ctx, rows, cent, DIM, stream=stream)
     if with_cpu and rows_host is not None:
         r = _cpu_build(o.BUILD_KM_ASSIGN, rows_host, 4.0, centroids=cent.cpu().numpy())
