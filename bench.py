@@ -857,14 +857,18 @@ def build_side_legs(vg, ctx, rows, queries, stream, with_cpu, rows_host=None):
     las, tas = pr["pq_assign"]
     lup, tup = pr["pq_update"]
     sd = DIM // PQ_M
-    # seeding (pq.go:281-338): per sub-quantizer, per new centroid: n distances (sd (sub, fma) pairs) + a chain of n
-    # dependent fp32 adds that the reference runs in index order — the chain is the bound (latency, not throughput)
-    chain_adds = PQ_M * 255.0 * ntrain
+    # seeding (pq.go:281-338): per sub-quantizer and new centroid one pass over the sub-quantizer's slab (n x sd floats) and
+    # minDistSq (read + write): 96 slabs of 2 MB do not stay in the 4 MB L2s, so the passes stream from HBM / the memory-side
+    # cache.  (Through r04 the bound was the reference's chain of n dependent additions per centroid: 60 ms; the running sum
+    # is blocked since r05, one definition shared with the oracle — oracle/vg_oracle.c.)
+    seed_ms = tpp / max(lpp, 1)
+    seed_bytes = PQ_M * 255.0 * ntrain * (sd * 4 + 8)
     out["pq_train_seeding"] = {
         "workload": f"ProductQuantizer.Train {ntrain} x {DIM}, m = {PQ_M}, K = 256: k-means++ seeding (pq.go:281-338)",
-        "kernel": "pq_kmeanspp", "kernel_ms": tpp / max(lpp, 1), "bound": "dependent fp32 add chain",
-        "achieved": 255.0 * ntrain / (tpp / max(lpp, 1) * 1e-3) / 1e9, "unit": "G dependent adds/s per sub-quantizer",
-        "chain_adds_total": chain_adds, "train_ms": wall, "short": f"pq_train_{ntrain}x{DIM}_m{PQ_M}_K256_20it"}
+        "kernel": "pq_kmeanspp_kernel", "kernel_ms": seed_ms, "bound": "hbm",
+        "achieved": seed_bytes / (seed_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+        "frac": seed_bytes / (seed_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, "bytes": seed_bytes, "train_ms": wall,
+        "short": f"pq_train_{ntrain}x{DIM}_m{PQ_M}_K256_20it"}
     lloyd_ms = tas / max(las, 1)
     out["pq_train_lloyd"] = valu_row(
         f"ProductQuantizer.Train {ntrain} x {DIM}, m = {PQ_M}, K = 256: one Lloyd assignment pass (pq.go:353-386)",

@@ -457,6 +457,55 @@ static int nearest_f32(const float *v, const float *centroids, int k, int sd)
     return bi;
 }
 
+/* ---- the running sum of k-means++ seeding: ONE definition, shared with the device (k_pq_train.hip) ----------------
+ * DEVIATION from pq.go:296-336, stated once here.  The reference adds minDistSq[] up with one fp32 accumulator in
+ * index order (`sum += minDistSq[i]`, :300,:332) and walks the same running sum again to pick the next centroid
+ * (`cumsum += d; if cumsum >= target`, :317-323): per new centroid a chain of n dependent additions, 255 times per
+ * sub-quantizer.  The reference draws its random numbers from the unseeded global math/rand (:294,:307,:314), so no
+ * run of it can be reproduced bit for bit anyway (quality parity); what IS pinned is this oracle against
+ * the device.  Both therefore use the same BLOCKED running sum, still in index order:
+ *   T_b   = the sum of block b = elements 64 b .. 64 b + 63 (missing ones count as +0) by the balanced pairwise tree
+ *           ((m0 + m1) + (m2 + m3)) + ... : stride 1, 2, 4, 8, 16, 32
+ *   P_b   = P_(b-1) + T_b, one fp32 accumulator over the blocks in order; sum = P_last
+ *   pick  = the first block b* whose P_b is not below the target (as the reference's walk, a NaN prefix stops it too),
+ *           then cum = P_(b*-1); cum += m[i] over the block in order; the first i with cum >= target; if the block's
+ *           sequential walk ends below the target (the tree and the walk round differently) its last element.
+ * The sampling law is the reference's (index i with probability ~ minDistSq[i] / sum); the roundings of the sum are not. */
+#define VGO_PP_BLOCK 64
+static float pp_block_total(const float *m, int64_t i0, int64_t n)
+{
+    float a[VGO_PP_BLOCK];
+    for (int t = 0; t < VGO_PP_BLOCK; t++) a[t] = i0 + t < n ? m[i0 + t] : 0.0f;
+    for (int s = 1; s < VGO_PP_BLOCK; s <<= 1)
+        for (int t = 0; t + s < VGO_PP_BLOCK; t += 2 * s) a[t] = a[t] + a[t + s];
+    return a[0];
+}
+/* prefixes P_b of the block totals; returns sum */
+static float pp_prefixes(const float *mind, int64_t n, float *pref)
+{
+    const int64_t nblk = (n + VGO_PP_BLOCK - 1) / VGO_PP_BLOCK;
+    float run = 0.0f;
+    for (int64_t b = 0; b < nblk; b++) {
+        run = run + pp_block_total(mind, b * VGO_PP_BLOCK, n);
+        pref[b] = run;
+    }
+    return run;
+}
+static int64_t pp_pick(const float *mind, int64_t n, const float *pref, float target)
+{
+    const int64_t nblk = (n + VGO_PP_BLOCK - 1) / VGO_PP_BLOCK;
+    int64_t b = 0;
+    while (b < nblk && pref[b] < target) b++;
+    if (b == nblk) return 0; /* cannot happen for a finite sum (P_last = sum >= target); pq.go:317 `chosen := 0` */
+    const int64_t i0 = b * VGO_PP_BLOCK, i1 = i0 + VGO_PP_BLOCK < n ? i0 + VGO_PP_BLOCK : n;
+    float cum = b ? pref[b - 1] : 0.0f;
+    for (int64_t i = i0; i < i1; i++) {
+        cum = cum + mind[i];
+        if (cum >= target) return i;
+    }
+    return i1 - 1;
+}
+
 /* pq.go:275-414 kmeans for ONE subspace.  RNG draws come from
  * vgo_rng_u64(seed, subspace, purpose, counter) in place of math/rand. */
 static void pq_kmeans_subspace(const float *vectors, int64_t n, int dim, int sub, int sd, int k,
@@ -472,12 +521,9 @@ static void pq_kmeans_subspace(const float *vectors, int64_t n, int dim, int sub
         int64_t first = (int64_t)(vgo_rng_u64(seed, (uint64_t)sub, 1, ctr++) % (uint64_t)n);
         memcpy(cent, base + first * dim, sizeof(float) * sd);
         float *mind = (float *)malloc(sizeof(float) * n);
-        float sum = 0.0f;
-        for (int64_t i = 0; i < n; i++) {
-            float d = vgo_l2_avx512(base + i * dim, cent, sd);
-            mind[i] = d;
-            sum += d;
-        }
+        float *pref = (float *)malloc(sizeof(float) * (size_t)((n + VGO_PP_BLOCK - 1) / VGO_PP_BLOCK));
+        for (int64_t i = 0; i < n; i++) mind[i] = vgo_l2_avx512(base + i * dim, cent, sd);
+        float sum = pp_prefixes(mind, n, pref);
         for (int c = 1; c < k; c++) {
             if (sum == 0.0f) {
                 int64_t idx = (int64_t)(vgo_rng_u64(seed, (uint64_t)sub, 1, ctr++) % (uint64_t)n);
@@ -485,24 +531,17 @@ static void pq_kmeans_subspace(const float *vectors, int64_t n, int dim, int sub
                 continue;
             }
             float target = rng_f32(vgo_rng_u64(seed, (uint64_t)sub, 1, ctr++)) * sum;
-            float cum = 0.0f;
-            int64_t chosen = 0;
-            for (int64_t i = 0; i < n; i++) {
-                cum += mind[i];
-                if (cum >= target) {
-                    chosen = i;
-                    break;
-                }
-            }
+            int64_t chosen = pp_pick(mind, n, pref, target);
             memcpy(cent + (int64_t)c * sd, base + chosen * dim, sizeof(float) * sd);
-            sum = 0.0f;
+            if (c == k - 1) break; /* the reference updates minDistSq once more; nothing reads it */
             for (int64_t i = 0; i < n; i++) {
                 float d = vgo_l2_avx512(base + i * dim, cent + (int64_t)c * sd, sd);
                 if (d < mind[i]) mind[i] = d;
-                sum += mind[i];
             }
+            sum = pp_prefixes(mind, n, pref);
         }
         free(mind);
+        free(pref);
     }
     /* runKMeansIterations pq.go:340-351 */
     int32_t *assign = (int32_t *)calloc((size_t)n, sizeof(int32_t));

@@ -111,50 +111,44 @@ __device__ __forceinline__ float l2_train(const float *__restrict__ row, const f
 }
 
 // ---- k-means++ (pq.go:281-338): one workgroup per sub-quantizer -----------------------------
-// The reference keeps minDistSq[] and, per new centroid, (1) updates it, (2) adds it up
-// sequentially, (3) walks the same running sum again until it passes rand*sum.  (2) is a chain of
-// n dependent fp32 adds that cannot be reordered, so it sets the pace: wave 0 runs the chain over
-// one LDS chunk while waves 1-3 compute the distances of the next chunk into the other buffer.
-// The chain records its value every kPPBlock elements; since the terms are non-negative the
-// running sum is monotone, so (3) becomes "first recorded prefix that is not below the target"
-// plus a rescan of that one block from the previous prefix — the same adds, the same index.
-constexpr int kPPThreads = 256;
-constexpr int kPPChunk = 4096;
+// The reference keeps minDistSq[] and, per new centroid, (1) updates it, (2) adds it up, (3) walks the same running
+// sum until it passes rand * sum.  Through r04 (2) was the reference's own chain of n dependent fp32 additions (60 ms of
+// the 88 ms Train at 65 536 x 768, and the same 60 ms however few sub-quantizers a GPU of a sharded Train holds).
+// Since r05 the running sum is BLOCKED — one definition shared with the oracle, stated and justified as a deviation
+// in oracle/vg_oracle.c ("the running sum of k-means++ seeding"): T_b = the balanced pairwise tree over the 64
+// elements of block b (the six shuffle steps of a wave that holds the block one element per lane), P_b = P_(b-1) + T_b
+// over the blocks in order, sum = P_last; the pick = first block whose prefix is not below the target, then the
+// reference's sequential walk inside that block from P_(b-1) (the block's last element if that walk ends below).
+// So per new centroid: every wave updates and sums whole blocks (coalesced: a block is 64 consecutive slab rows), one
+// lane scans the n / 64 block totals in LDS, and the pick reads one block.
+constexpr int kPPThreads = 1024;
 constexpr int kPPBlock = 64;
+constexpr int kPPScan = 4096;  // block totals scanned per LDS chunk (n <= 262 144 never leaves LDS)
 
-__device__ __forceinline__ void pp_load_half(float4 (&x)[kPPBlock / 8], const float *src)
+// tot[0 .. len): block totals -> prefixes continuing `run`; one thread, the LDS reads 16 ahead of the additions
+__device__ __forceinline__ float pp_scan_chunk(float *tot, int len, float run)
 {
+    int t = 0;
+    for (; t + 16 <= len; t += 16) {
+        float4 x[4];
 #pragma unroll
-    for (int u = 0; u < kPPBlock / 8; u++) x[u] = reinterpret_cast<const float4 *>(src)[u];
-}
-__device__ __forceinline__ float pp_add_half(float sum, const float4 (&x)[kPPBlock / 8])
-{
+        for (int u = 0; u < 4; u++) x[u] = reinterpret_cast<const float4 *>(tot + t)[u];
+        float4 y[4];
 #pragma unroll
-    for (int u = 0; u < kPPBlock / 8; u++) {
-        sum += x[u].x;
-        sum += x[u].y;
-        sum += x[u].z;
-        sum += x[u].w;
-    }
-    return sum;
-}
-
-template <int SD>
-__device__ __forceinline__ void pp_distances(const float *__restrict__ slab, const float *cur, int sd,
-                                             float *__restrict__ mind, float *buf, int64_t c0, int len,
-                                             bool first_centroid, int t0, int nthreads)
-{
-    for (int t = t0; t < len; t += nthreads) {
-        const int64_t i = c0 + t;
-        const float d = l2_train<SD>(slab + i * sd, cur, sd);
-        float mv = d;
-        if (!first_centroid) {
-            const float old = mind[i];
-            mv = d < old ? d : old;
+        for (int u = 0; u < 4; u++) {
+            run = run + x[u].x; y[u].x = run;
+            run = run + x[u].y; y[u].y = run;
+            run = run + x[u].z; y[u].z = run;
+            run = run + x[u].w; y[u].w = run;
         }
-        mind[i] = mv;
-        buf[t] = mv;
+#pragma unroll
+        for (int u = 0; u < 4; u++) reinterpret_cast<float4 *>(tot + t)[u] = y[u];
     }
+    for (; t < len; t++) {
+        run = run + tot[t];
+        tot[t] = run;
+    }
+    return run;
 }
 
 template <int SD>
@@ -162,8 +156,9 @@ __global__ __launch_bounds__(kPPThreads) void pq_kmeanspp_kernel(
     const float *__restrict__ slabs, int64_t n, int sd_rt, int k, uint64_t seed,
     float *__restrict__ mind_all, float *__restrict__ pref_all, float *__restrict__ cent_all, int sub0)
 {
-    __shared__ __attribute__((aligned(16))) float buf[2][kPPChunk];
+    __shared__ __attribute__((aligned(16))) float tot[kPPScan];
     __shared__ __attribute__((aligned(16))) float cur[256];  // current centroid (sd <= 256)
+    __shared__ float walk[kPPBlock];
     __shared__ float s_sum;
     __shared__ int s_blk;
     __shared__ long long s_chosen;
@@ -171,8 +166,9 @@ __global__ __launch_bounds__(kPPThreads) void pq_kmeanspp_kernel(
     // this call, which may train only the range [sub0, sub0 + gridDim.x)
     const int sd = SD ? SD : sd_rt;
     const int ls = blockIdx.x, sub = sub0 + ls;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t nblk = (n + kPPBlock - 1) / kPPBlock;
+    const bool in_lds = nblk <= kPPScan;  // the prefixes live in LDS for the whole kernel
     const float *slab = slabs + static_cast<int64_t>(ls) * n * sd;
     float *mind = mind_all + static_cast<int64_t>(ls) * n;
     float *pref = pref_all + static_cast<int64_t>(ls) * nblk;
@@ -206,13 +202,12 @@ __global__ __launch_bounds__(kPPThreads) void pq_kmeanspp_kernel(
             ctr++;
             if (tid == 0) {
                 s_blk = 0x7fffffff;
-                s_chosen = -1;
+                s_chosen = 0;  // pq.go:317 `chosen := 0`
             }
             __syncthreads();
-            // pq.go:315-323 walks cum += minDistSq[i] until cum >= target.  `!(prefix < target)` also
-            // stops at a NaN prefix: from there on the reference never hits either.
+            // first block whose prefix is not below the target (`!(prefix < target)` also stops at a NaN prefix)
             for (int64_t b = tid; b < nblk; b += kPPThreads)
-                if (!(pref[b] < target)) {
+                if (!((in_lds ? tot[b] : pref[b]) < target)) {
                     atomicMin(&s_blk, static_cast<int>(b));
                     break;
                 }
@@ -221,13 +216,13 @@ __global__ __launch_bounds__(kPPThreads) void pq_kmeanspp_kernel(
             if (blk != 0x7fffffff) {
                 const int64_t e0 = static_cast<int64_t>(blk) * kPPBlock;
                 const int len = static_cast<int>(n - e0 < kPPBlock ? n - e0 : kPPBlock);
-                if (tid < len) buf[0][tid] = mind[e0 + tid];
+                if (tid < len) walk[tid] = mind[e0 + tid];
                 __syncthreads();
                 if (tid == 0) {
-                    float cum = blk ? pref[blk - 1] : 0.0f;
-                    long long ch = -1;
+                    float cum = blk ? (in_lds ? tot[blk - 1] : pref[blk - 1]) : 0.0f;
+                    long long ch = e0 + len - 1;  // the sequential walk may end below the tree's total
                     for (int t = 0; t < len; t++) {
-                        cum += buf[0][t];
+                        cum = cum + walk[t];
                         if (cum >= target) {
                             ch = e0 + t;
                             break;
@@ -237,7 +232,7 @@ __global__ __launch_bounds__(kPPThreads) void pq_kmeanspp_kernel(
                 }
                 __syncthreads();
             }
-            const long long ch = s_chosen >= 0 ? s_chosen : 0;  // pq.go:317 `chosen := 0`
+            const long long ch = s_chosen;
             for (int t = tid; t < sd; t += kPPThreads) {
                 cur[t] = slab[ch * sd + t];
                 cent[c * sd + t] = cur[t];
@@ -249,46 +244,96 @@ __global__ __launch_bounds__(kPPThreads) void pq_kmeanspp_kernel(
             // never read again, skip the pass
             break;
         }
-        // update minDistSq with the new centroid and add it up in index order
-        {
-            const int len0 = static_cast<int>(n < kPPChunk ? n : kPPChunk);
-            pp_distances<SD>(slab, cur, sd, mind, buf[0], 0, len0, c == 0, tid, kPPThreads);
+        // (1) minDistSq against the new centroid and the block totals: a wave per block of 64 consecutive points,
+        // kPPUnroll blocks per trip with all their loads issued first (one block per trip ran at one L2 round trip per
+        // block: 70 us per centroid)
+        auto finish_block = [&](int64_t b, float mv) {
+            float x = mv;  // balanced pairwise tree: lane 0 ends with ((m0 + m1) + (m2 + m3)) + ...
+#pragma unroll
+            for (int sft = 1; sft < 64; sft <<= 1) x = x + __shfl_down(x, sft);
+            if (lane == 0) {
+                if (in_lds)
+                    tot[b] = x;
+                else
+                    pref[b] = x;
+            }
+        };
+        if constexpr (SD != 0) {
+            constexpr int kPPUnroll = 8;
+            float cv[SD];
+#pragma unroll
+            for (int t = 0; t < SD; t++) cv[t] = cur[t];
+            for (int64_t b0 = static_cast<int64_t>(wave) * kPPUnroll; b0 < nblk; b0 += (kPPThreads / 64) * kPPUnroll) {
+                float4 r[kPPUnroll][SD / 4];
+                float old[kPPUnroll];
+#pragma unroll
+                for (int u = 0; u < kPPUnroll; u++) {
+                    const int64_t i = (b0 + u) * kPPBlock + lane;
+                    const int64_t ic = i < n ? i : n - 1;  // past the end: a valid address, the value is not used
+                    const float4 *v4 = reinterpret_cast<const float4 *>(slab + ic * SD);
+#pragma unroll
+                    for (int t = 0; t < SD / 4; t++) r[u][t] = v4[t];
+                    old[u] = c != 0 ? mind[ic] : 0.0f;
+                }
+#pragma unroll
+                for (int u = 0; u < kPPUnroll; u++) {
+                    const int64_t b = b0 + u;
+                    if (b >= nblk) break;  // uniform per wave
+                    const int64_t i = b * kPPBlock + lane;
+                    float total = 0.0f;  // l2_train<SD>: the n < 64 form of squaredL2Avx512, one FMA chain
+#pragma unroll
+                    for (int t = 0; t < SD / 4; t++) {
+                        float d = r[u][t].x - cv[4 * t];
+                        total = __builtin_fmaf(d, d, total);
+                        d = r[u][t].y - cv[4 * t + 1];
+                        total = __builtin_fmaf(d, d, total);
+                        d = r[u][t].z - cv[4 * t + 2];
+                        total = __builtin_fmaf(d, d, total);
+                        d = r[u][t].w - cv[4 * t + 3];
+                        total = __builtin_fmaf(d, d, total);
+                    }
+                    float mv = 0.0f;  // elements past n count as +0
+                    if (i < n) {
+                        mv = total;
+                        if (c != 0) mv = total < old[u] ? total : old[u];
+                        mind[i] = mv;
+                    }
+                    finish_block(b, mv);
+                }
+            }
+        } else {
+            for (int64_t b = wave; b < nblk; b += kPPThreads / 64) {
+                const int64_t i = b * kPPBlock + lane;
+                float mv = 0.0f;
+                if (i < n) {
+                    const float d = l2_train<SD>(slab + i * sd, cur, sd);
+                    mv = d;
+                    if (c != 0) {
+                        const float oldv = mind[i];
+                        mv = d < oldv ? d : oldv;
+                    }
+                    mind[i] = mv;
+                }
+                finish_block(b, mv);
+            }
         }
         __syncthreads();
-        float sum = 0.0f;  // live in wave 0 only
-        int pb = 0;
-        for (int64_t c0 = 0; c0 < n; c0 += kPPChunk, pb ^= 1) {
-            const int len = static_cast<int>(n - c0 < kPPChunk ? n - c0 : kPPChunk);
-            if (tid < 64) {
-                const float *src = buf[pb];
-                float *pr = pref + c0 / kPPBlock;
-                const int full = len / kPPBlock;
-                // two register images of half a block each: the LDS reads of one half are in
-                // flight while the dependent adds of the other issue back to back (at most 16
-                // reads outstanding, the limit of lgkmcnt)
-                float4 xa[kPPBlock / 8], xb[kPPBlock / 8];
-                if (full > 0) pp_load_half(xa, src);
-                for (int g = 0; g < full; g++) {
-                    pp_load_half(xb, src + g * kPPBlock + kPPBlock / 2);
-                    __builtin_amdgcn_sched_barrier(0);
-                    sum = pp_add_half(sum, xa);
-                    pp_load_half(xa, src + (g + 1 < full ? g + 1 : g) * kPPBlock);  // last one unused
-                    __builtin_amdgcn_sched_barrier(0);
-                    sum = pp_add_half(sum, xb);
-                    if (tid == 0) pr[g] = sum;
-                }
-                if (len % kPPBlock) {
-                    for (int t = full * kPPBlock; t < len; t++) sum += src[t];
-                    if (tid == 0) pr[full] = sum;
-                }
-            } else if (c0 + kPPChunk < n) {
-                const int64_t n0 = c0 + kPPChunk;
-                const int nlen = static_cast<int>(n - n0 < kPPChunk ? n - n0 : kPPChunk);
-                pp_distances<SD>(slab, cur, sd, mind, buf[pb ^ 1], n0, nlen, c == 0, tid - 64, kPPThreads - 64);
+        // (2) prefixes of the block totals, in block order, by one thread
+        if (in_lds) {
+            if (tid == 0) s_sum = pp_scan_chunk(tot, static_cast<int>(nblk), 0.0f);
+        } else {
+            float run = 0.0f;  // live in thread 0
+            for (int64_t b0 = 0; b0 < nblk; b0 += kPPScan) {
+                const int len = static_cast<int>(nblk - b0 < kPPScan ? nblk - b0 : kPPScan);
+                for (int t = tid; t < len; t += kPPThreads) tot[t] = pref[b0 + t];
+                __syncthreads();
+                if (tid == 0) run = pp_scan_chunk(tot, len, run);
+                __syncthreads();
+                for (int t = tid; t < len; t += kPPThreads) pref[b0 + t] = tot[t];
+                __syncthreads();
             }
-            __syncthreads();
+            if (tid == 0) s_sum = run;
         }
-        if (tid == 0) s_sum = sum;
         __syncthreads();
     }
 }
