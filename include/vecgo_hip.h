@@ -531,10 +531,10 @@ typedef struct vg_search_stats {
  * vectorstore/columnar.go:29-50).  One wavefront per query, many queries in flight; per query
  * the result equals the sequential reference's.  ids/scores[nq*k] best first; stats[nq] may be
  * NULL.  k <= ef (a smaller ef is raised to k, determineEF hnsw.go:1891-1894); the two heaps of a query live
- * in LDS up to ef = 512 and in HBM scratch beyond.  NaN distances (NaN or Inf in a row or a query) are outside
- * the contract: for L2 / Cosine the heaps order distances by their bit patterns (every distance >= +0), under which
- * a NaN is the largest key, whereas every comparison with it is false in the reference — results are then
- * unspecified (finite inputs only, as the reference's own tests use). */
+ * in LDS up to ef = 512 and in HBM scratch beyond.  NaN distances (a NaN or an Inf in a row or in a query): every
+ * comparison with a NaN is false in the reference (queue.go:75-82,199-203, hnsw.go:1376), and the result is the
+ * reference's here too — a walk that scores a NaN stops and the query is answered by a second pass that compares
+ * floats exactly as the reference's loop is written (r04 and before: unspecified, and an Inf in a query could fault). */
 int32_t vg_search_hnsw(vg_index *idx, const float *queries, int64_t nq, int32_t k, int32_t ef,
                        uint32_t *ids, float *scores, vg_search_stats *stats, void *stream);
 /* The same walk scored from the nodes' PQ codes instead of their fp32 rows: distFunc =

@@ -63,7 +63,8 @@ constexpr int kHnswLdsEf = 512;  // LDS items of the results heap (twice that fo
 #define VG_HNSW_ATTR __attribute__((amdgpu_waves_per_eu(SPLIT ? (PQM ? VG_SPLIT_PQ_WAVES : VG_SPLIT_F32_WAVES) : (PQM == 2 ? VG_LDS_PQ_WAVES : 1), SPLIT ? (PQM ? VG_SPLIT_PQ_WAVES : VG_SPLIT_F32_WAVES) : 8)))
 // UK: the metric is not Dot, so every distance is >= +0 and the heaps compare bit patterns (heap_sift_down_uk).
 // PQM: 0 = fp32 rows, 1 = PQ codes scored from the query's table, 2 = PQ codes scored from the codebook (direct form)
-template <int PQM, bool SPLIT, bool UK>
+// STRICT (UK = false): the second pass over the queries whose first pass met a NaN distance (search_layer)
+template <int PQM, bool SPLIT, bool UK, bool STRICT = false>
 __global__ __launch_bounds__(64) VG_HNSW_ATTR void hnsw_search_kernel(
     const float *__restrict__ base, int64_t n, int dim, int metric, const uint32_t *__restrict__ l0,
     int m0, int max_level, int m, const uint32_t *__restrict__ slots, const uint32_t *__restrict__ adj,
@@ -72,12 +73,22 @@ __global__ __launch_bounds__(64) VG_HNSW_ATTR void hnsw_search_kernel(
     const int8_t *__restrict__ pq_cb, const float *__restrict__ pq_scales, const float *__restrict__ pq_offsets, int k, int ef,
     int lds_cand, int lds_res /* SPLIT: items of the candidates / results heap kept in LDS */,
     uint32_t *__restrict__ visited_ws, int64_t vis_words, HItem *__restrict__ heap_ws,
-    uint32_t *__restrict__ ids, float *__restrict__ scores, vg_search_stats *__restrict__ stats)
+    uint32_t *__restrict__ ids, float *__restrict__ scores, vg_search_stats *__restrict__ stats,
+    uint8_t *__restrict__ redo /* first pass: redo[q] = 1 when the walk met a NaN distance and stopped; STRICT: only the
+                                  queries so marked, every comparison as the reference writes it */)
 {
     extern __shared__ __attribute__((aligned(8))) unsigned char smem[];
     constexpr bool PQ = PQM != 0;
     const int64_t q = blockIdx.x;
     const int lane = threadIdx.x;
+    static_assert(!(STRICT && UK), "the second pass compares floats");
+    if constexpr (STRICT) {
+        if (!redo[q]) return;
+        // the first pass left its marks in this query's visited bitmap
+        for (int64_t w = lane; w < vis_words; w += 64) visited_ws[q * vis_words + w] = 0;
+        __threadfence();
+        __syncthreads();
+    }
     float *nb_pair = reinterpret_cast<float *>(smem);
     float *nb_bnd = nb_pair + 64;
     float *qprep = nb_bnd + 64;  // PQ direct form: (pq_m / 2) * 20 floats (a multiple of 8 bytes)
@@ -125,6 +136,17 @@ __global__ __launch_bounds__(64) VG_HNSW_ATTR void hnsw_search_kernel(
         sc.sub = Sub16::make(lane);
     }
 
+    if constexpr (PQ && !STRICT) {
+        // a PQ distance is a NaN only if the query holds a non-finite value (the codes and the codebook cannot): one look
+        // at the query instead of a watch on every neighbour list
+        bool bad = false;
+        for (int i = lane; i < dim; i += 64) bad |= !(fabsf(queries[q * dim + i]) <= 3.40282346638528859811704183484516925440e+38f);
+        if (__ballot(bad)) {
+            if (lane == 0) redo[q] = 1;
+            return;
+        }
+    }
+
     // ---- greedySearch through the upper layers --------------------------------------------------
     uint32_t cur = entry;
     float cur_d = sc.one(cur);
@@ -141,7 +163,19 @@ __global__ __launch_bounds__(64) VG_HNSW_ATTR void hnsw_search_kernel(
     int res_len = 0;
     LayerStats st;
     auto row0 = [&](uint32_t node) -> const uint32_t * { return l0 + static_cast<int64_t>(node) * m0; };
-    search_layer<UK>(sc, metric == kMetricL2, lane, row0, m0, cur, cur_d, ef, cand, res, nb_pair, nb_bnd, vis, res_len, st);
+    bool odd = false;
+    search_layer<UK, STRICT>(sc, metric == kMetricL2, lane, row0, m0, cur, cur_d, ef, cand, res, nb_pair, nb_bnd, vis, res_len,
+#ifdef VG_NO_ODD_WATCH  // stage probe (tools/build_variant.sh): the first pass without its NaN watch
+                             st, nullptr);
+#else
+                             // (PQ codes hold no NaN: the query was checked once, above — the per-list watch cost the
+                             // split-heap PQ walk 5 %: 9.71 -> 10.24 ms per 8192 queries at ef 512)
+                             st, STRICT || PQ ? nullptr : &odd);
+#endif
+    if (odd) {  // a NaN distance: this query is answered by the second pass (search_hnsw_impl)
+        if (lane == 0) redo[q] = 1;
+        return;
+    }
 
     // knnSearchInternal extraction (hnsw.go:1732-1751): drop the worst until k remain, then pop — the k closest
     // in ascending order, equal distances in whatever order the heap's layout pops them.  Ties among the results
@@ -661,6 +695,7 @@ static int32_t search_hnsw_impl(vg_index *idx, bool pq, const float *queries, in
     const int i_vis = ar.add(sizeof(uint32_t) * static_cast<size_t>(chunk) * vis_words);
     const int i_heap = ar.add(static_cast<size_t>(chunk) * heap_bytes);
     const int i_luts = ar.add(static_cast<size_t>(chunk) * lut_bytes);
+    const int i_redo = ar.add(static_cast<size_t>(chunk));
     VG_TRY(ar.commit());
     struct { uint32_t *ptr; } vis{ar.get<uint32_t>(i_vis)};
     vg::HItem *heap_ws = lds_heaps ? nullptr : ar.get<vg::HItem>(i_heap);
@@ -669,24 +704,42 @@ static int32_t search_hnsw_impl(vg_index *idx, bool pq, const float *queries, in
     const size_t lds = static_cast<size_t>((lds_heaps ? 3 * ef : lds_cand + lds_res) + 4) * sizeof(vg::HItem) + 128 * sizeof(float) +
                        (pq_direct ? static_cast<size_t>(pq_m >> 1) * vg::kPqPairFloats * sizeof(float) : 0) +
                        (!pq && !lds_heaps && VG_SPLIT_F32_QLDS ? static_cast<size_t>((idx->dim + 3) & ~3) * sizeof(float) : 0);
-    const bool uk = idx->metric != VG_METRIC_DOT;
+    const bool uk = pq || idx->metric != VG_METRIC_DOT;
+    uint8_t *redo = ar.get<uint8_t>(i_redo);
     auto kern = pq_direct ? (lds_heaps ? vg::hnsw_search_kernel<2, false, true> : vg::hnsw_search_kernel<2, true, true>)
                 : pq      ? (lds_heaps ? vg::hnsw_search_kernel<1, false, true> : vg::hnsw_search_kernel<1, true, true>)
                 : uk      ? (lds_heaps ? vg::hnsw_search_kernel<0, false, true> : vg::hnsw_search_kernel<0, true, true>)
                           : (lds_heaps ? vg::hnsw_search_kernel<0, false, false> : vg::hnsw_search_kernel<0, true, false>);
+    // the unsigned-key kernels stop a walk at the first NaN / negative distance and mark the query; this pass — the same
+    // walk with the float sift-downs, i.e. the reference's comparisons as written — answers the marked queries
+    auto kern_f32 = pq_direct ? (lds_heaps ? vg::hnsw_search_kernel<2, false, false, true> : vg::hnsw_search_kernel<2, true, false, true>)
+                    : pq      ? (lds_heaps ? vg::hnsw_search_kernel<1, false, false, true> : vg::hnsw_search_kernel<1, true, false, true>)
+                              : (lds_heaps ? vg::hnsw_search_kernel<0, false, false, true> : vg::hnsw_search_kernel<0, true, false, true>);
     VG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               static_cast<int>(lds)));
+    VG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern_f32), hipFuncAttributeMaxDynamicSharedMemorySize,
                                static_cast<int>(lds)));
     for (int64_t q0 = 0; q0 < nq; q0 += chunk) {
         const int64_t cnt = std::min(chunk, nq - q0);
         VG_HIP(hipMemsetAsync(vis.ptr, 0, static_cast<size_t>(cnt) * vis_words * 4, st));
         if (luts) VG_TRY(vg::launch_pq_build_table(idx->pq, q.ptr + q0 * idx->dim, cnt, luts, false, st));
-        vg::ProfScope prof(idx->ctx, pq ? "hnsw_search_pq" : "hnsw_search", st);
-        VG_LAUNCH(kern, dim3(static_cast<unsigned>(cnt)), dim3(64), lds, st, idx->d_vectors, idx->n, idx->dim,
-                  idx->metric, idx->d_hnsw_l0, idx->hnsw_m0, idx->hnsw_max_level, idx->hnsw_m, idx->d_hnsw_slot,
-                  idx->d_hnsw_adj, idx->d_hnsw_level_off, idx->hnsw_entry, q.ptr + q0 * idx->dim,
-                  pq ? idx->d_pq_rows : nullptr, pq_m, luts, pq_direct ? idx->pq->d_codebooks : nullptr,
-                  pq ? idx->pq->d_scales : nullptr, pq ? idx->pq->d_offsets : nullptr, k, ef, lds_cand, lds_res, vis.ptr, vis_words, heap_ws, oid.ptr + q0 * k,
-                  osc.ptr + q0 * k, ost.ptr ? ost.ptr + q0 : nullptr);
+        VG_HIP(hipMemsetAsync(redo, 0, static_cast<size_t>(cnt), st));
+        {
+            vg::ProfScope prof(idx->ctx, pq ? "hnsw_search_pq" : "hnsw_search", st);
+            VG_LAUNCH(kern, dim3(static_cast<unsigned>(cnt)), dim3(64), lds, st, idx->d_vectors, idx->n, idx->dim,
+                      idx->metric, idx->d_hnsw_l0, idx->hnsw_m0, idx->hnsw_max_level, idx->hnsw_m, idx->d_hnsw_slot,
+                      idx->d_hnsw_adj, idx->d_hnsw_level_off, idx->hnsw_entry, q.ptr + q0 * idx->dim,
+                      pq ? idx->d_pq_rows : nullptr, pq_m, luts, pq_direct ? idx->pq->d_codebooks : nullptr,
+                      pq ? idx->pq->d_scales : nullptr, pq ? idx->pq->d_offsets : nullptr, k, ef, lds_cand, lds_res, vis.ptr,
+                      vis_words, heap_ws, oid.ptr + q0 * k, osc.ptr + q0 * k, ost.ptr ? ost.ptr + q0 : nullptr, redo);
+        }
+        // (every workgroup of an ordinary batch leaves at its first instruction)
+        VG_LAUNCH(kern_f32, dim3(static_cast<unsigned>(cnt)), dim3(64), lds, st, idx->d_vectors, idx->n, idx->dim,
+                      idx->metric, idx->d_hnsw_l0, idx->hnsw_m0, idx->hnsw_max_level, idx->hnsw_m, idx->d_hnsw_slot,
+                      idx->d_hnsw_adj, idx->d_hnsw_level_off, idx->hnsw_entry, q.ptr + q0 * idx->dim,
+                      pq ? idx->d_pq_rows : nullptr, pq_m, luts, pq_direct ? idx->pq->d_codebooks : nullptr,
+                      pq ? idx->pq->d_scales : nullptr, pq ? idx->pq->d_offsets : nullptr, k, ef, lds_cand, lds_res, vis.ptr,
+                      vis_words, heap_ws, oid.ptr + q0 * k, osc.ptr + q0 * k, ost.ptr ? ost.ptr + q0 : nullptr, redo);
     }
     VG_TRY(oid.finish());
     VG_TRY(osc.finish());

@@ -361,7 +361,11 @@ __device__ __forceinline__ void greedy_layer(const Scorer &sc, int lane, RowFn r
         Scorer::sync();
         // sequential `if nextDist < currDist` over the list == the smallest distance, first of its equals, if it
         // is below currDist: a wave minimum and one ballot instead of `count` dependent LDS reads
-        const float my_d = lane < count ? nb_pair[lane] : 3.40282346638528859811704183484516925440e+38f;
+        // (lanes past the list, and NaN distances, stand as +Inf: neither can ever be `< currDist`.  r04 padded with
+        // MaxFloat32: against a list of +Inf distances — an Inf in the query — the minimum was then the PADDING, no lane
+        // held it, and the lane index taken from an empty ballot read a wild neighbour id: a memory fault)
+        const float raw_d = lane < count ? nb_pair[lane] : INFINITY;
+        const float my_d = raw_d == raw_d ? raw_d : INFINITY;
         float mn = my_d;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
@@ -370,7 +374,7 @@ __device__ __forceinline__ void greedy_layer(const Scorer &sc, int lane, RowFn r
         }
         float best_d = cur_d;
         uint32_t best_id = cur;
-        if (count > 0 && mn < cur_d) {
+        if (count > 0 && mn < cur_d) {  // mn is finite here: some lane of the list holds it
             const uint64_t at = __ballot(lane < count && my_d == mn);
             const int first = __builtin_ctzll(at);
             best_d = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_d), first));  // its own bits (-0 == +0)
@@ -386,12 +390,29 @@ __device__ __forceinline__ void greedy_layer(const Scorer &sc, int lane, RowFn r
 // searchLayerUnfiltered from (ep, ep_d).  `vis`: this wave's visited bitmap, already clear.  On return
 // res[0..res_len) is the results max-heap exactly as the reference's search leaves it.
 // UK: every distance is >= +0 (any metric but Dot), see heap_sift_down_uk (vg_heap.hpp)
-template <bool UK = false, typename Scorer, typename RowFn, typename Heap>
+// NaN distances (a NaN or an Inf in a row or in the query).  Every comparison with a NaN is FALSE in the reference
+// (queue.go:75-82,199-203; hnsw.go:1376 `nextDist > bound`), which this walk relies on NOT happening in two places: the
+// unsigned-key sifts order a NaN's bit pattern as the largest key, and the neighbour loop rejects every lane above the
+// bound at once because "the bound only falls" — with a NaN inside the results heap a sift-down can bring it to the
+// root, and against a NaN bound nothing is rejected any more.  So:
+//   `odd_out` != nullptr  one ballot over each scored neighbour list watches for a distance that is a NaN (UK: any bit
+//                         pattern above +Inf's, which covers negative values too); at the first one the walk stops with
+//                         *odd_out = true, and the caller runs the query again, with UK = false and
+//   STRICT                every lane tested against the bound at ITS turn, as the reference's loop is written.
+// nullptr / false: the fast form (the builder, and every query that meets no NaN).
+template <bool UK = false, bool STRICT = false, typename Scorer, typename RowFn, typename Heap>
 __device__ __forceinline__ void search_layer(const Scorer &sc, bool l2_metric, int lane, RowFn row_of, int deg,
                                              uint32_t ep, float ep_d, int ef, Heap cand, Heap res,
                                              float *nb_pair, float *nb_bnd, uint32_t *vis, int &res_len_out,
-                                             LayerStats &st)
+                                             LayerStats &st, bool *odd_out = nullptr)
 {
+    constexpr bool strict = STRICT;
+    auto is_odd = [](float d) { return UK ? __float_as_uint(d) > 0x7F800000u : d != d; };
+    if (odd_out && is_odd(ep_d)) {  // wave-uniform
+        *odd_out = true;
+        res_len_out = 0;
+        return;
+    }
     int cand_len = 0, res_len = 0;
     if (lane == 0) atomicOr(&vis[ep >> 5], 1u << (ep & 31));
     heap_push<false>(cand, cand_len, HItem{ep, ep_d});
@@ -442,6 +463,11 @@ __device__ __forceinline__ void search_layer(const Scorer &sc, bool l2_metric, i
         // lane j keeps node j's two distances; the loop below reads them with readlane, not from LDS
         const float my_pair = nb_pair[lane];
         const float my_nd = use_sc ? nb_bnd[lane] : my_pair;  // what the reference compares once a bound exists
+        if (odd_out && __ballot(((newmask >> lane) & 1) && (is_odd(my_pair) || is_odd(my_nd)))) {
+            *odd_out = true;
+            res_len_out = 0;
+            return;
+        }
         VG_T(t3);
         bool has_bound = res_len >= ef;
         float bound = has_bound ? heap_get(res, 0).dist : 0.0f;
@@ -452,7 +478,7 @@ __device__ __forceinline__ void search_layer(const Scorer &sc, bool l2_metric, i
         // the PQ walk at ef <= 512, nothing elsewhere)
         __builtin_amdgcn_s_setprio(3);
         while (todo) {
-            if (has_bound) {
+            if (has_bound && !strict) {
                 // the bound only falls: a node above it now is above it at its turn (SquaredL2Bounded reports
                 // exceeded, or `nd > bound` skips it)
                 const uint64_t rej = __ballot(my_nd > bound) & todo;
@@ -464,6 +490,10 @@ __device__ __forceinline__ void search_layer(const Scorer &sc, bool l2_metric, i
             todo &= todo - 1;
             const uint32_t id = static_cast<uint32_t>(__builtin_amdgcn_readlane(id_lane, j));
             const float nd = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(has_bound ? my_nd : my_pair), j));
+            if (strict && has_bound && nd > bound) {  // at its turn, against the bound as it stands now
+                if (use_sc) st.sc++;
+                continue;
+            }
             VG_T(tc0);
             accepted |= 1ull << j;  // its candidates-heap push happens after the loop (the two heaps are independent)
             if (!has_bound) pre_bound |= 1ull << j;  // pushed with the SquaredL2 value, not the bounded kernel's
