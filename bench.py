@@ -1208,19 +1208,22 @@ def live_traffic(kernel_sub: str, script: str, timeout_s: float = 150.0, script_
     got = {}
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         with tempfile.TemporaryDirectory(dir="/tmp", prefix="vg_pmc_") as d:
+            # the interpreter that runs THIS process (the one that has torch and vecgo_amd), directly after `--`
             cmd = ["rocprofv3", "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "--",
-                   "python3", str(ROOT / "tools" / script), *[str(a) for a in script_args]]
+                   sys.executable, str(ROOT / "tools" / script), *[str(a) for a in script_args]]
             try:
-                pr = subprocess.Popen(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL,
-                                      stderr=subprocess.DEVNULL, start_new_session=True)
-                try:
-                    rc = pr.wait(timeout=timeout_s)
-                except subprocess.TimeoutExpired:
-                    os.killpg(pr.pid, signal.SIGKILL)     # the group this call started, nothing else
-                    pr.wait()
-                    return None, f"{counter} pass timed out after {timeout_s:.0f} s"
-                if rc != 0:
-                    return None, f"{counter} pass exited with {rc}"
+                with open(Path(d) / "child_stderr.txt", "wb") as errf:
+                    pr = subprocess.Popen(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL,
+                                          stderr=errf, start_new_session=True)
+                    try:
+                        rc = pr.wait(timeout=timeout_s)
+                    except subprocess.TimeoutExpired:
+                        os.killpg(pr.pid, signal.SIGKILL)     # the group this call started, nothing else
+                        pr.wait()
+                        return None, f"{counter} pass timed out after {timeout_s:.0f} s"
+                if rc != 0:   # the end of what the child said, so that a broken pass can be diagnosed from the line's source
+                    tail = (Path(d) / "child_stderr.txt").read_bytes()[-300:].decode("utf-8", "replace").strip().replace("\n", " | ")
+                    return None, f"{counter} pass exited with {rc}: {tail}"
                 files = list(Path(d).rglob("*counter_collection.csv"))
                 if not files:
                     return None, f"{counter} pass wrote no counter_collection.csv"
@@ -1239,7 +1242,7 @@ def live_traffic(kernel_sub: str, script: str, timeout_s: float = 150.0, script_
 
 BASELINE_METRIC = "QPS at recall@10≥0.95, 1M×768 HNSW+PQ; PQ-ADC HBM GB/s vs peak"   # BASELINE.json "metric", verbatim
 FULL_RECORD = "bench_full.json"
-LINE_LIMIT = 6000      # bytes: the driver could not parse r03's 22.7 KB line; r02's 10.8 KB one it could
+LINE_LIMIT = 8000      # bytes: the driver could not parse r03's 22.7 KB line; r02's 10.8 KB one it could
 
 
 def _r(x, sig=6):

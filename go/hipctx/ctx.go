@@ -46,6 +46,10 @@ func Ptr() (unsafe.Pointer, error) {
 	return unsafe.Pointer(ctx), cerr
 }
 
+// ABIMinor: the library's count of entry-point additions (vecgo_hip.h VG_ABI_MINOR); a caller that wants an entry point
+// added after minor m checks ABIMinor() >= m before using it.
+func ABIMinor() int { return int(C.vg_abi_minor()) }
+
 // Close destroys the context (tests / orderly shutdown).
 func Close() {
 	if ctx != nil {

@@ -18,6 +18,7 @@ package segment
 import "C"
 
 import (
+	"fmt"
 	"unsafe"
 
 	"github.com/hupe1980/vecgo/distance"
@@ -251,6 +252,17 @@ func (r *Resident) SearchHNSWBrute(queries []float32, nq, k int, mode BruteMode,
 	ids, sc := r.out(nq, k)
 	var mp *C.uint8_t
 	if len(mask) > 0 {
+		// the library reads ceil(rows/8) bytes per mask, query q's at q*maskStride: a shorter slice would be read past its end
+		need := (r.rows + 7) / 8
+		if maskStride != 0 {
+			if maskStride < need {
+				return nil, nil, fmt.Errorf("SearchHNSWBrute: maskStride %d is shorter than a mask (%d bytes)", maskStride, need)
+			}
+			need += (nq - 1) * maskStride
+		}
+		if len(mask) < need {
+			return nil, nil, fmt.Errorf("SearchHNSWBrute: mask holds %d bytes, %d needed", len(mask), need)
+		}
 		mp = (*C.uint8_t)(unsafe.Pointer(&mask[0]))
 	}
 	st := C.vg_search_hnsw_brute(r.h, fp(queries), C.int64_t(nq), C.int32_t(k), C.int32_t(mode), mp, C.int64_t(maskStride), up(ids), fp(sc), nil)

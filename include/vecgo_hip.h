@@ -43,6 +43,12 @@ extern "C" {
  *   2: vg_search_stats has FIVE int64 (descent_distance_computations was appended): vg_search_hnsw / _hnsw_pq /
  *      _vamana write nq * 5 values. */
 #define VG_ABI_VERSION 2
+/* Bumped whenever entry points are ADDED (nothing existing changes): a binding that wants a newer entry point compares
+ * vg_abi_minor() with the value below before it looks the symbol up, instead of failing on first use.
+ *   1: (r04) vg_search_hnsw_brute, vg_debug_heap_replay
+ *   2: (r05) vg_abi_minor itself; no other symbol added — vg_search_hnsw / _hnsw_pq answer NaN distances as the reference
+ *      does, vg_kmeans_* decide assignments on the matrix cores, the k-means++ running sum of vg_pq_train is blocked */
+#define VG_ABI_MINOR 2
 #define VG_INVALID_ID 0xFFFFFFFFu
 #define VG_STREAM_LEGACY ((void *)1) /* == hipStreamLegacy */
 
@@ -81,6 +87,7 @@ typedef struct vg_segment vg_segment; /* an opened flat / DiskANN segment image:
 
 /* ---- context ------------------------------------------------------------ */
 int32_t vg_abi_version(void);
+int32_t vg_abi_minor(void);
 /* device = HIP ordinal (LOCAL_RANK in a one-process-per-GPU job) */
 int32_t vg_ctx_create(int32_t device, vg_ctx **out);
 int32_t vg_ctx_destroy(vg_ctx *ctx);

@@ -60,7 +60,19 @@ namespace distance {
 // distance.Metric (distance/distance.go:66-73)
 enum class Metric : int32_t { L2 = VG_METRIC_L2, Cosine = VG_METRIC_COSINE, Dot = VG_METRIC_DOT, Hamming = VG_METRIC_HAMMING };
 
-// Metric.String (distance/distance.go:75-88), "Unknown(%d)" for anything else
+// Metric.String (distance/distance.go:75-88), "Unknown(%d)" for anything else.  (Returns std::string since r04, when
+// the "Unknown(%d)" form was added — a source break for `const char *s = String(m)`; CString keeps the C-string form
+// for the four named metrics and says "Unknown" for the rest.)
+inline const char *CString(Metric m)
+{
+    switch (m) {
+    case Metric::L2: return "L2";
+    case Metric::Cosine: return "Cosine";
+    case Metric::Dot: return "Dot";
+    case Metric::Hamming: return "Hamming";
+    }
+    return "Unknown";
+}
 inline std::string String(Metric m)
 {
     switch (m) {

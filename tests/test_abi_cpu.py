@@ -21,6 +21,8 @@ def test_abi_version_and_status_strings():
     import re
     want = int(re.search(r"#define VG_ABI_VERSION (\d+)", _lib.HEADER_PATH.read_text()).group(1))
     assert lib.vg_abi_version() == want == _lib.ABI_VERSION == 2   # 2: vg_search_stats has five int64
+    minor = int(re.search(r"#define\s+VG_ABI_MINOR\s+(\d+)", _lib.HEADER_PATH.read_text()).group(1))
+    assert lib.vg_abi_minor() == minor >= 2                        # additions only: the minor says which symbols exist
     assert lib.vg_status_string(0) == b"ok"
     # the Go error strings the shim maps to (pq.go:148-153, rabitq.go:53)
     assert lib.vg_status_string(-2) == b"vector dimension mismatch"

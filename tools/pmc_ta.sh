@@ -1,6 +1,9 @@
 #!/bin/bash
 # texture-path counters of one graph-walk kernel, ONE hardware block per pass (a request that mixes TA and TCP blocks
 # did not fit and made rocprofv3 abort, r04): tools/pmc_ta.sh TAG "MODE EF"   (through gpurun)
+set -euo pipefail
+: "${GRAFT_REPO_ROOT:?run through gpurun}"
+cd "$GRAFT_REPO_ROOT"
 tag=$1; m=$2
 export PMC_TIMEOUT=${PMC_TIMEOUT:-200}
 tools/pmc_run.sh ta_${tag}_a "TA_TA_BUSY_sum GRBM_GUI_ACTIVE" python3 tools/walk_prof.py 1000000 $m

@@ -1054,10 +1054,15 @@ class Index:
         if mask is not None:
             m = np.asarray(mask)
             if m.dtype == np.bool_:
+                if m.shape[-1] != self.n:   # the C side reads ceil(n / 8) bytes per mask: a short one would be read past its end
+                    raise ValueError(f"search_hnsw_brute: a bool mask has one entry per row ({self.n}), got {m.shape[-1]}")
                 m = np.packbits(m.reshape(-1, self.n) if m.ndim > 1 else m, axis=-1, bitorder="little")
             m = np.ascontiguousarray(m, np.uint8)
+            if m.shape[-1] < (self.n + 7) // 8:
+                raise ValueError(f"search_hnsw_brute: a packed mask holds ceil(n / 8) = {(self.n + 7) // 8} bytes, got {m.shape[-1]}")
             if m.ndim > 1 and m.shape[0] > 1:
-                assert m.shape[0] == nq, "one mask per query"
+                if m.shape[0] != nq:
+                    raise ValueError(f"search_hnsw_brute: one mask per query ({nq}), got {m.shape[0]}")
                 stride = m.shape[1]
             pm = C.c_void_p(m.ctypes.data)
         check(self._lib.vg_search_hnsw_brute(self._h, pq_, C.c_int64(nq), C.c_int32(k), C.c_int32(mode), pm,

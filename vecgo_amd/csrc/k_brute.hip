@@ -477,13 +477,26 @@ VG_API int32_t vg_search_hnsw_brute(vg_index *idx, const float *queries, int64_t
     VG_TRY(oid.init(ids, static_cast<size_t>(nq) * k, st));
     VG_TRY(osc.init(scores, static_cast<size_t>(nq) * k, st));
     const int64_t n = idx->n;
-    const int64_t cap = std::min<int64_t>(int64_t(16) << 30, std::max<int64_t>(int64_t(1) << 30, idx->ctx->hbm_bytes / 16));
-    int64_t chunk = std::max<int64_t>(1, cap / std::max<int64_t>(n * 4, 1));
+    // dist[q][row] of one chunk of queries.  The query-blocked kernel gets its row reuse from kBruteQB = 16 queries per
+    // workgroup, so a chunk of thousands of queries buys nothing: 2 GiB of distances (512 queries at 1M rows), but at
+    // least one block of 16 queries while that stays within 1/16 of the device's memory.  The buffer comes from the
+    // scratch cache (idle blocks go back to the driver when an allocation fails, and with the context), not from the
+    // grow-only arena — r04 took up to 16 GiB from the arena and kept it until the context was destroyed.  When the
+    // index leaves no room, the chunk is halved until the allocation succeeds.
+    const int64_t row_bytes = std::max<int64_t>(n, 1) * 4;
+    const int64_t cap16 = std::min<int64_t>(int64_t(16) << 30, std::max<int64_t>(int64_t(1) << 30, idx->ctx->hbm_bytes / 16));
+    int64_t chunk = std::max<int64_t>(1, (int64_t(2) << 30) / row_bytes);
+    if (chunk < vg::kBruteQB) chunk = std::max<int64_t>(1, std::min<int64_t>(vg::kBruteQB, cap16 / row_bytes));
     chunk = std::min<int64_t>(std::min(chunk, nq), 65535);
-    vg::ArenaCall ar(idx->ctx, st);
-    const int i_dist = ar.add(sizeof(float) * static_cast<size_t>(chunk) * std::max<int64_t>(n, 1));
-    VG_TRY(ar.commit());
-    float *dist = ar.get<float>(i_dist);
+    vg::DevTmp<float> dist_buf;
+    for (;;) {
+        const int32_t rc = dist_buf.init(static_cast<size_t>(chunk) * static_cast<size_t>(std::max<int64_t>(n, 1)), st);
+        if (rc == VG_OK) break;
+        VG_CHECK(chunk > 1, rc, "vg_search_hnsw_brute: no room for one query's %lld distances: %s", static_cast<long long>(n),
+                 vg_last_error());
+        chunk = (chunk + 1) / 2;
+    }
+    float *dist = dist_buf.ptr;
     const size_t lds = (static_cast<size_t>((k + 4 + 3) & ~3) + vg::kBruteStep) * sizeof(vg::HItem);
     auto replay = mode == VG_BRUTE_SCAN ? vg::brute_replay_kernel<VG_BRUTE_SCAN> : vg::brute_replay_kernel<VG_BRUTE_BITMAP>;
     VG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(replay), hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -123,6 +123,7 @@ void scratch_trim(int device)
 }  // namespace vg
 
 VG_API int32_t vg_abi_version(void) { return VG_ABI_VERSION; }
+VG_API int32_t vg_abi_minor(void) { return VG_ABI_MINOR; }
 
 VG_API const char *vg_last_error(void) { return vg::g_last_error.c_str(); }
 
