@@ -824,6 +824,232 @@ __global__ __launch_bounds__(256) void pq_asym_direct_kernel(const float *__rest
     out[i] = pq_direct_distance(codes + i * m, codebooks, scales, offsets, query, asym_qprep, m);
 }
 
+
+// ---- nearest centroid of every (row, sub-quantizer) by MFMA nomination + exact decision (sub-dimension 8, K = 256) ----
+// Encode (pq.go:147-176, FindNearestCentroidInt8) and the Lloyd assignment pass of Train (pq.go:353-386) are both
+// "256 eight-dimensional distances per (row, sub-quantizer), keep the smallest": 3 (Encode: sub, mul, add — Go does not
+// fuse) or 2 (Train: sub, fma) vector lane-operations per element when computed as the reference writes them, and the
+// r04 kernels ran at 0.66 / 0.58 of that rate.  The matrix cores compute s~(c) = |v_c|^2 - 2 x.v_c with one fused
+// multiply-add per element (v_mfma_f32_32x32x2_f32, five of them for a 32 centroids x 32 rows tile: the eight dimensions
+// and a ninth k slot that adds |v_c|^2 against a row of ones); the vector ALU only keeps, per row, the
+// smallest score, where it was, and the second smallest (4 instructions per score).  As for k-means (k_kmeans.hip: the
+// derivation is the same with dim = 8) a gap between the two smallest scores above
+//     margin = 2 * 32 u (2 sqrt(X C) + C) + 2 * 12 u (sqrt X + sqrt C)^2      (u = 2^-24, X = |x_sub|^2, C = max_c |v_c|^2)
+// proves that the reference's arithmetic picks the same centroid; every other (row, sub-quantizer) pair — one in ~10^4
+// on random data — goes on a list and is decided by the reference-order loop (pq_fix_kernel).  Operand layout: the
+// MFMA's two k slots of step kk are dimensions kk (lanes 0-31) and 4 + kk (lanes 32-63), so a lane's A and B operands
+// are one 16-byte half of a centroid / of a row's sub-vector.
+using pq_f32x16 = __attribute__((ext_vector_type(16))) float;
+constexpr int kNomRowsPerWave = 1024, kNomRowsPerBlock = 4 * kNomRowsPerWave;  // (the centroid set-up of a block is ~2 us)
+
+struct PqNomList {  // (row, sub-quantizer slot) pairs the scores could not decide
+    int32_t row, sub;
+};
+
+// ENC: rows = vectors [n][dim], sub-quantizer blockIdx.y, centroids dequantised from the int8 codebook, out = codes.
+// !ENC: rows = the training slabs [ls][n][8], centroids = cent_all [ls][256][8] fp32, out = assign_all (+ changed).
+template <bool ENC>
+__global__ __launch_bounds__(256) void pq_nominate_kernel(const float *__restrict__ rows, int64_t n, int dim, int m,
+                                                          const int8_t *__restrict__ codebooks, const float *__restrict__ scales,
+                                                          const float *__restrict__ offsets, const float *__restrict__ cent_all,
+                                                          uint8_t *__restrict__ codes, int32_t *__restrict__ assign_all,
+                                                          int *__restrict__ changed, const int *__restrict__ done,
+                                                          PqNomList *__restrict__ list, int *__restrict__ list_count,
+                                                          int64_t row_first /* rows [row_first, n) of `rows` */,
+                                                          float extra_margin /* test hook: +Inf lists every pair */)
+{
+    __shared__ float s_cmax[4];
+    const int sub = blockIdx.y;
+    if (!ENC && done[sub]) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = lane >> 5, c_in = lane & 31;
+    // A operands of the 8 centroid blocks: -2 v (exact), and the ninth k slot: |v|^2 of this lane's centroid against a
+    // row of ones (lanes 0-31; the tenth slot, lanes 32-63, multiplies zeros) — a fifth MFMA per tile instead of a
+    // 128-register image of the |v|^2 column as the accumulators' starting value (which left one wave per SIMD)
+    float4 a[8];
+    float acn[8];
+    float cmax = 0.0f;
+#pragma unroll
+    for (int cb = 0; cb < 8; cb++) {
+        const int c = cb * 32 + c_in;
+        float4 v;
+        if (ENC) {
+            const uint32_t w = reinterpret_cast<const uint32_t *>(codebooks)[(static_cast<int64_t>(sub) * 256 + c) * 2 + h];
+            const float scale = scales[sub], offset = offsets[sub];
+            float t0 = static_cast<float>(static_cast<int>(static_cast<int8_t>(w))) * scale;
+            float t1 = static_cast<float>(static_cast<int>(static_cast<int8_t>(w >> 8))) * scale;
+            float t2 = static_cast<float>(static_cast<int>(static_cast<int8_t>(w >> 16))) * scale;
+            float t3 = static_cast<float>(static_cast<int>(static_cast<int8_t>(w >> 24))) * scale;
+            v = make_float4(t0 + offset, t1 + offset, t2 + offset, t3 + offset);  // pq.go:205-215's two rounded operations
+        } else {
+            v = *reinterpret_cast<const float4 *>(cent_all + (static_cast<int64_t>(sub) * 256 + c) * 8 + 4 * h);
+        }
+        a[cb] = make_float4(-2.0f * v.x, -2.0f * v.y, -2.0f * v.z, -2.0f * v.w);
+        float part = v.x * v.x;
+        part = __builtin_fmaf(v.y, v.y, part);
+        part = __builtin_fmaf(v.z, v.z, part);
+        part = __builtin_fmaf(v.w, v.w, part);
+        const float cnv = part + __shfl_xor(part, 32);
+        acn[cb] = h == 0 ? cnv : 0.0f;
+        cmax = fmaxf(cmax, cnv == cnv ? cnv : INFINITY);
+    }
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) cmax = fmaxf(cmax, __shfl_xor(cmax, off));
+    if (lane == 0) s_cmax[wave] = cmax;   // (every wave holds all 256 centroids: the four values are equal)
+    __syncthreads();
+    const float C = s_cmax[0], sqc = sqrtf(C);
+    const float ones = h == 0 ? 1.0f : 0.0f;
+    const float u = 5.9604645e-8f;
+    const int64_t row0 = row_first + static_cast<int64_t>(blockIdx.x) * kNomRowsPerBlock + wave * kNomRowsPerWave;
+    const int64_t stride = ENC ? dim : 8;
+    const float *xbase = ENC ? rows + static_cast<int64_t>(sub) * 8 : rows + static_cast<int64_t>(sub) * n * 8;
+    auto load_rows = [&](int pb) {  // this lane's half of the sub-vector of row pb * 32 + (lane & 31) (past the end: the last row)
+        const int64_t p = row0 + pb * 32 + c_in;
+        const int64_t pc = p < n ? p : n - 1;
+        return *reinterpret_cast<const float4 *>(xbase + pc * stride + 4 * h);
+    };
+    float4 xnext = load_rows(0);
+    for (int pb = 0; pb < kNomRowsPerWave / 32; pb++) {
+        const int64_t p = row0 + pb * 32 + c_in;
+        if (row0 + pb * 32 >= n) break;  // wave-uniform
+        const float4 xb = xnext;
+        xnext = load_rows(pb + 1 < kNomRowsPerWave / 32 ? pb + 1 : pb);  // in flight under this block's 32 MFMAs
+        float xp = xb.x * xb.x;
+        xp = __builtin_fmaf(xb.y, xb.y, xp);
+        xp = __builtin_fmaf(xb.z, xb.z, xp);
+        xp = __builtin_fmaf(xb.w, xb.w, xp);
+        const float X = xp + __shfl_xor(xp, 32);
+        float m1 = INFINITY, m2 = INFINITY;
+        int ir = 0, bcb = 0;
+        // two accumulator sets: the four MFMAs of block cb + 1 are issued before the vector ALU reads block cb (one set
+        // made every block wait for the previous one's 64 reads: 4400 cycles per 32 rows where the matrix unit needs 2048)
+        auto tile = [&](int cb) {
+            pq_f32x16 acc = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+#if defined(VG_NOM_PROBE) && VG_NOM_PROBE == 2  // stage probe (tools/build_variant.sh): no matrix instructions
+            for (int r = 0; r < 16; r++) acc[r] = a[cb].x * xb.y + static_cast<float>(r);
+            return acc;
+#endif
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(acn[cb], ones, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cb].x, xb.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cb].y, xb.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cb].z, xb.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cb].w, xb.w, acc, 0, 0, 0);
+            return acc;
+        };
+        auto scan = [&](const pq_f32x16 &acc, int cb) {
+#if defined(VG_NOM_PROBE) && VG_NOM_PROBE == 1  // stage probe: the matrix results are not scanned
+            m1 = fminf(m1, acc[cb & 15]);
+            return;
+#endif
+            const float before = m1;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const float sc = acc[r];
+                m2 = __builtin_amdgcn_fmed3f(m1, sc, m2);  // m1 <= m2: the middle one is the new second smallest
+                const bool lt = sc < m1;                   // one compare feeds both selects (fminf would add a canonicalising
+                ir = lt ? r : ir;                          // v_max per value: the scores come straight from the matrix unit)
+                m1 = lt ? sc : m1;
+            }
+            bcb = m1 < before ? cb : bcb;
+        };
+        pq_f32x16 acc_a = tile(0), acc_b;
+#pragma unroll
+        for (int cb = 0; cb < 8; cb += 2) {
+            acc_b = tile(cb + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            scan(acc_a, cb);
+            __builtin_amdgcn_sched_barrier(0);
+            if (cb + 2 < 8) acc_a = tile(cb + 2);
+            __builtin_amdgcn_sched_barrier(0);
+            scan(acc_b, cb + 1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        int idx = bcb * 32 + (ir & 3) + 8 * (ir >> 2) + 4 * h;
+        const float om1 = __shfl_xor(m1, 32), om2 = __shfl_xor(m2, 32);
+        const int oidx = __shfl_xor(idx, 32);
+        m2 = fminf(fmaxf(m1, om1), fminf(m2, om2));
+        idx = om1 < m1 ? oidx : idx;
+        m1 = fminf(m1, om1);
+        if (h == 0 && p < n) {
+            const float sx = sqrtf(X);
+            const float cross = 2.0f * sx * sqc + C, dmax = (sx + sqc) * (sx + sqc);
+            const float margin = 1.05f * (64.0f * u * cross + 24.0f * u * dmax) + 1e-30f + extra_margin;
+            // every comparison is false on NaN: non-finite rows, centroids or scores go on the list
+            if (X + C < 1e30f && m2 - m1 > margin) {
+                if (ENC) {
+                    codes[p * m + sub] = static_cast<uint8_t>(idx);
+                } else {
+                    int32_t *dst = assign_all + static_cast<int64_t>(sub) * n + p;
+                    if (*dst != idx) {
+                        *dst = idx;
+                        changed[sub] = 1;
+                    }
+                }
+            } else {
+                const int at = atomicAdd(list_count, 1);
+                list[at] = PqNomList{static_cast<int32_t>(p), sub};
+            }
+        }
+    }
+}
+
+// the listed pairs, decided as the reference writes the loop
+template <bool ENC>
+__global__ __launch_bounds__(256) void pq_fix_kernel(const float *__restrict__ rows, int64_t n, int dim, int m,
+                                                     const int8_t *__restrict__ codebooks, const float *__restrict__ scales,
+                                                     const float *__restrict__ offsets, const float *__restrict__ cent_all,
+                                                     uint8_t *__restrict__ codes, int32_t *__restrict__ assign_all,
+                                                     int *__restrict__ changed, const PqNomList *__restrict__ list,
+                                                     const int *__restrict__ list_count)
+{
+    const int total = *list_count;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+        const int64_t p = list[e].row;
+        const int sub = list[e].sub;
+        if (ENC) {
+            const float *x = rows + p * dim + static_cast<int64_t>(sub) * 8;
+            const float scale = scales[sub], offset = offsets[sub];
+            float q[8];
+            for (int t = 0; t < 8; t++) q[t] = x[t];
+            int best = 0;
+            float bd = 0.0f;
+            for (int c = 0; c < 256; c++) {  // FindNearestCentroidInt8 (kernels.go:376-396)
+                const int8_t *cb = codebooks + (static_cast<int64_t>(sub) * 256 + c) * 8;
+                float sum = 0.0f;
+                for (int t = 0; t < 8; t++) {
+                    float v = static_cast<float>(cb[t]) * scale;
+                    v = v + offset;
+                    const float d = q[t] - v;
+                    const float dd = d * d;
+                    sum = sum + dd;
+                }
+                if (c == 0 || sum < bd) {
+                    bd = sum;
+                    best = c;
+                }
+            }
+            codes[p * m + sub] = static_cast<uint8_t>(best);
+        } else {
+            const float *x = rows + (static_cast<int64_t>(sub) * n + p) * 8;
+            const float *cent = cent_all + static_cast<int64_t>(sub) * 256 * 8;
+            float best = 3.40282346638528859811704183484516925440e+38f;
+            int bi = 0;
+            for (int c = 0; c < 256; c++) {  // findNearestCentroid (pq.go:416-433)
+                const float d = l2_train<8>(x, cent + c * 8, 8);
+                if (d < best) {
+                    best = d;
+                    bi = c;
+                }
+            }
+            int32_t *dst = assign_all + static_cast<int64_t>(sub) * n + p;
+            if (*dst != bi) {
+                *dst = bi;
+                changed[sub] = 1;
+            }
+        }
+    }
+}
+
 }  // namespace vg
 
 VG_API int32_t vg_pq_train_subset(vg_pq *pq, const float *vectors, int64_t n, int32_t iters, uint64_t seed,
@@ -869,6 +1095,16 @@ VG_API int32_t vg_pq_train_subset(vg_pq *pq, const float *vectors, int64_t n, in
                                    hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
     const unsigned gx = static_cast<unsigned>((n + 255) / 256);
     const unsigned gx_vec = static_cast<unsigned>((n + 256 * vg::kAssignRows - 1) / (256 * vg::kAssignRows));
+    // Lloyd assignment on the matrix cores (pq_nominate_kernel) when the shape is the one it is written for
+    const bool nominate = sd == 8 && k == 256 && !vg::hook(vg::kHookPqNoMfma);
+    const unsigned nom_gx = static_cast<unsigned>((n + vg::kNomRowsPerBlock - 1) / vg::kNomRowsPerBlock);
+    const float nom_extra = vg::hook(vg::kHookPqListAll) ? INFINITY : 0.0f;
+    vg::DevTmp<vg::PqNomList> nom_list;
+    vg::DevTmp<int> nom_count;
+    if (nominate) {
+        VG_TRY(nom_list.init(static_cast<size_t>(m) * n, st));
+        VG_TRY(nom_count.init(1, st));
+    }
     const unsigned ux = static_cast<unsigned>((k * sd + 255) / 256);
 #define VG_PQ_TRAIN_SD(SD)                                                                                       \
     do {                                                                                                         \
@@ -880,7 +1116,14 @@ VG_API int32_t vg_pq_train_subset(vg_pq *pq, const float *vectors, int64_t n, in
         for (int it = 0; it < iters; it++) {                                                                     \
             {                                                                                                    \
                 vg::ProfScope prof(pq->ctx, "pq_assign", st);                                                    \
-                if (SD)                                                                                          \
+                if (nominate) {                                                                                  \
+                    VG_HIP(hipMemsetAsync(nom_count.ptr, 0, sizeof(int), st));                                   \
+                    VG_LAUNCH(vg::pq_nominate_kernel<false>, dim3(nom_gx, m), dim3(256), 0, st, slabs.ptr, n, dim, m, nullptr, \
+                              nullptr, nullptr, cent.ptr, nullptr, assign.ptr, changed, done, nom_list.ptr, nom_count.ptr,  \
+                              int64_t(0), nom_extra);                                                            \
+                    VG_LAUNCH(vg::pq_fix_kernel<false>, dim3(64), dim3(256), 0, st, slabs.ptr, n, dim, m, nullptr, nullptr, \
+                              nullptr, cent.ptr, nullptr, assign.ptr, changed, nom_list.ptr, nom_count.ptr);     \
+                } else if (SD)                                                                                   \
                     VG_LAUNCH(vg::pq_assign_vec_kernel<(SD ? SD : 4)>, dim3(gx_vec, m), dim3(256), lds, st, slabs.ptr, n, k, \
                               cent.ptr, assign.ptr, changed, done);                                              \
                 else                                                                                             \
@@ -941,7 +1184,27 @@ VG_API int32_t vg_pq_encode(vg_pq *pq, const float *vectors, int64_t n, uint8_t 
     const unsigned gx_vec = static_cast<unsigned>((n + 256 * vg::kEncRows - 1) / (256 * vg::kEncRows));
     {
     vg::ProfScope prof(pq->ctx, "pq_encode", st);
-    if (vec_ok && pq->subdim == 8)
+    if (vec_ok && pq->subdim == 8 && pq->k == 256 && n <= INT32_MAX && !vg::hook(vg::kHookPqNoMfma)) {
+        // nearest centroids on the matrix cores (pq_nominate_kernel), the pairs they cannot decide by the reference's loop;
+        // in chunks of rows so that the list of a chunk (worst case: every pair) stays below 256 MB
+        const int64_t chunk = std::max<int64_t>(vg::kNomRowsPerBlock, ((int64_t(256) << 20) / (static_cast<int64_t>(pq->m) * 8)) /
+                                                                           vg::kNomRowsPerBlock * vg::kNomRowsPerBlock);
+        vg::DevTmp<vg::PqNomList> nom_list;
+        vg::DevTmp<int> nom_count;
+        VG_TRY(nom_list.init(static_cast<size_t>(std::min(chunk, n)) * pq->m, st));
+        VG_TRY(nom_count.init(1, st));
+        const float extra = vg::hook(vg::kHookPqListAll) ? INFINITY : 0.0f;
+        for (int64_t r0 = 0; r0 < n; r0 += chunk) {
+            const int64_t r1 = std::min(n, r0 + chunk);
+            VG_HIP(hipMemsetAsync(nom_count.ptr, 0, sizeof(int), st));
+            const unsigned gxn = static_cast<unsigned>((r1 - r0 + vg::kNomRowsPerBlock - 1) / vg::kNomRowsPerBlock);
+            VG_LAUNCH(vg::pq_nominate_kernel<true>, dim3(gxn, pq->m), dim3(256), 0, st, v.ptr, r1, pq->dim, pq->m, pq->d_codebooks,
+                      pq->d_scales, pq->d_offsets, nullptr, c.ptr, nullptr, nullptr, nullptr, nom_list.ptr, nom_count.ptr, r0,
+                      extra);
+            VG_LAUNCH(vg::pq_fix_kernel<true>, dim3(64), dim3(256), 0, st, v.ptr, r1, pq->dim, pq->m, pq->d_codebooks,
+                      pq->d_scales, pq->d_offsets, nullptr, c.ptr, nullptr, nullptr, nom_list.ptr, nom_count.ptr);
+        }
+    } else if (vec_ok && pq->subdim == 8)
         VG_LAUNCH(vg::pq_encode_vec_kernel<8>, dim3(gx_vec, pq->m), dim3(256), lds, st, v.ptr, n, pq->dim, pq->m, pq->k,
                   pq->d_codebooks, pq->d_scales, pq->d_offsets, c.ptr);
     else if (vec_ok && pq->subdim == 4)
