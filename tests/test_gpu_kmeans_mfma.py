@@ -121,6 +121,25 @@ def test_forced_paths_agree(vg, ctx):
                 set_hook(hook, 0)
 
 
+@pytest.mark.parametrize("hook", ["VG_KM_BF16"])
+def test_bfloat16_split_passes(vg, ctx, hook):
+    """The assignment pass on bfloat16 splits ([hi | lo | hi] x [hi | hi | lo]: what a training run of three or more
+    iterations uses), forced for single assignments: the adversarial inputs above, unchanged answers."""
+    set_hook(hook, 1)
+    try:
+        rng = np.random.default_rng(12)
+        for n, dim, k in ((8192, 768, 122), (5000, 128, 37), (4200, 64, 300)):
+            x = rng.standard_normal((n, dim)).astype(np.float32)
+            for c in (x[rng.choice(n, k, replace=False)].copy(), (rng.standard_normal((k, dim)) * 0.05).astype(np.float32)):
+                check(vg, ctx, x, c, 0)
+                check(vg, ctx, x, c, 2)
+        test_exact_ties_pick_the_lowest_index(vg, ctx)
+        test_near_ties_inside_the_error_bound(vg, ctx)
+        test_scales_and_degenerate_inputs(vg, ctx)
+    finally:
+        set_hook(hook, 0)
+
+
 def test_train_at_a_size_the_matrix_path_serves(vg, ctx):
     rng = np.random.default_rng(9)
     for n, dim, k, metric in ((20000, 64, 16, 0), (9000, 128, 130, 2)):

@@ -584,6 +584,30 @@ __global__ __launch_bounds__(256) void km_norms_kernel(const float *__restrict__
     if (lane == 0) out[row] = s;
 }
 
+// rows of fp32 -> rows of bfloat16 splits, 3 dim elements each: POINTS as [hi | lo | hi], CENTROIDS as [hi | hi | lo]
+// (see km_gemm_kernel<.., BF16>).  hi = round-to-nearest-even of the value, lo = the same of the (exact) remainder.
+__device__ __forceinline__ uint16_t km_bf16_rne(float x)
+{
+    const uint32_t b = __float_as_uint(x);
+    return static_cast<uint16_t>((b + 0x7FFFu + ((b >> 16) & 1u)) >> 16);
+}
+template <bool CENTROID>
+__global__ __launch_bounds__(256) void km_split_kernel(const float *__restrict__ src, int64_t rows, int dim,
+                                                       uint16_t *__restrict__ dst)
+{
+    const int64_t e = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (e >= rows * dim) return;
+    const int64_t r = e / dim;
+    const int j = static_cast<int>(e - r * dim);
+    const float x = src[e];
+    const uint16_t hi = km_bf16_rne(x);
+    const uint16_t lo = km_bf16_rne(x - __uint_as_float(static_cast<uint32_t>(hi) << 16));
+    uint16_t *o = dst + r * 3 * dim;
+    o[j] = hi;
+    o[dim + j] = CENTROID ? hi : lo;
+    o[2 * dim + j] = CENTROID ? lo : hi;
+}
+
 // the centroids' side of the epilogue: cadd[c] = |c|^2 (L2) or 0 (Dot) for c < k, +Inf for the padding of the last tile;
 // *cmax_bits = max |c|^2 as float bits (non-negative floats order like their bits; zeroed by the caller), +Inf when a
 // centroid holds a non-finite value (then nothing is decided by the matrix scores).  One wave per centroid.
@@ -606,7 +630,12 @@ __global__ __launch_bounds__(256) void km_cent_norms_kernel(const float *__restr
     }
 }
 
-template <bool DOT>
+// BF16: both operands are rows of bfloat16 SPLITS — a point as [hi | lo | hi], a centroid as [hi | hi | lo] (km_split_kernel:
+// hi = the value rounded to bfloat16, lo = the remainder rounded to bfloat16) — so that one pass of the 16x faster
+// v_mfma_f32_32x32x16_bf16 over the 3 dim elements of a row adds up x_hi c_hi + x_lo c_hi + x_hi c_lo; `dim` then counts
+// the 4-byte words of such a row (3 dim / 2).  What the split drops is x_lo c_lo and the second remainders: at most
+// 3 * 2^-16 |x_i| |c_i| per element, which enters the bound of km_decide_kernel in place of the fp32 products' roundings.
+template <bool DOT, bool BF16 = false>
 __global__ __launch_bounds__(kGemmThreads) void km_gemm_kernel(const float *__restrict__ centroids, int k,
                                                               const float *__restrict__ vectors, int64_t n, int dim,
                                                               const float *__restrict__ cadd, KmPart *__restrict__ part)
@@ -710,10 +739,20 @@ __global__ __launch_bounds__(kGemmThreads) void km_gemm_kernel(const float *__re
     acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][0].comp, fb[c][1].comp, acc[0][1], 0, 0, 0);    \
     acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][1].comp, fb[c][0].comp, acc[1][0], 0, 0, 0);    \
     acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][1].comp, fb[c][1].comp, acc[1][1], 0, 0, 0);
-            VG_KM_MFMA4(x)
-            VG_KM_MFMA4(y)
-            VG_KM_MFMA4(z)
-            VG_KM_MFMA4(w)
+            if constexpr (BF16) {
+#pragma unroll
+                for (int ai = 0; ai < 2; ai++)
+#pragma unroll
+                    for (int bi = 0; bi < 2; bi++)
+                        acc[ai][bi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(vg_bf16x8, fa[c][ai]),
+                                                                             __builtin_bit_cast(vg_bf16x8, fb[c][bi]),
+                                                                             acc[ai][bi], 0, 0, 0);
+            } else {
+                VG_KM_MFMA4(x)
+                VG_KM_MFMA4(y)
+                VG_KM_MFMA4(z)
+                VG_KM_MFMA4(w)
+            }
 #undef VG_KM_MFMA4
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -925,6 +964,8 @@ static int32_t km_launch_exact(bool dot, const float *v, int64_t n, int dim, con
 // MFMA nomination + exact decision (see km_gemm_kernel): scratch of one vg_kmeans_assign / vg_kmeans_train call
 struct KmMfma {
     vg::DevTmp<float> xnorm, cadd;
+    vg::DevTmp<uint16_t> xsplit, csplit;  // bf16 splits of the points (made once) and of the centroids (every pass)
+    bool bf16 = false;
     vg::DevTmp<vg::KmPart> part;
     vg::DevTmp<int32_t> list, pairs;
     vg::DevTmp<int> count;  // [0] full list, [1] pair list, [2] max |c|^2 (float bits)
@@ -937,10 +978,23 @@ struct KmMfma {
         // below a few thousand points the passes around the GEMM cost more than the reference-order kernel
         return aligned && dim % 4 == 0 && dim >= 32 && n >= 4096 && n <= INT32_MAX && k >= 2 && !vg::hook(vg::kHookKmNoMfma);
     }
-    // allocates and computes |x|^2 (the points do not change between the iterations of a training run)
-    int32_t init(const float *v, int64_t n, int dim, int k, hipStream_t st)
+    // allocates and computes |x|^2 (the points do not change between the iterations of a training run).
+    // passes: how many assignment passes will follow — with three or more, and rows of whole 64-element blocks, the points
+    // are also split into bfloat16 [hi | lo | hi] (4.6 GB per 1M x 768, written once) and the passes run on the 16x faster
+    // bf16 matrix instruction, HBM-bound instead of MFMA-bound (1.64 -> see DESIGN.md §12 ms per 1M x 768 x 122)
+    int32_t init(const float *v, int64_t n, int dim, int k, hipStream_t st, int passes = 1, int64_t hbm_bytes = 0)
     {
         mtiles = (k + vg::kGemmBM - 1) / vg::kGemmBM;
+        const int64_t split_bytes = n * 3 * dim * 2;
+        bf16 = dim % 64 == 0 && (passes >= 3 || vg::hook(vg::kHookKmBf16)) && !vg::hook(vg::kHookKmNoBf16) &&
+               (hbm_bytes == 0 || split_bytes <= hbm_bytes / 8);
+        if (bf16) {
+            VG_TRY(xsplit.init(static_cast<size_t>(n) * 3 * dim, st));
+            VG_TRY(csplit.init(static_cast<size_t>(mtiles) * vg::kGemmBM * 3 * dim, st));
+            const int64_t tot = n * dim;
+            VG_LAUNCH(vg::km_split_kernel<false>, dim3(static_cast<unsigned>((tot + 255) / 256)), dim3(256), 0, st, v, n, dim,
+                      xsplit.ptr);
+        }
         VG_TRY(xnorm.init(static_cast<size_t>(n), st));
         VG_TRY(cadd.init(static_cast<size_t>(mtiles) * vg::kGemmBM, st));
         VG_TRY(part.init(static_cast<size_t>(mtiles) * n, st));
@@ -960,12 +1014,28 @@ struct KmMfma {
                   cadd.ptr, kpad, count.ptr + 2);
         const int64_t ntiles = (n + vg::kGemmBN - 1) / vg::kGemmBN;
         const unsigned blocks = static_cast<unsigned>(((ntiles + 7) / 8) * 8 * mtiles);
-        auto kern = dot ? vg::km_gemm_kernel<true> : vg::km_gemm_kernel<false>;
-        VG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   static_cast<int>(vg::kDmaLdsBytes)));
-        VG_LAUNCH(kern, dim3(blocks), dim3(vg::kGemmThreads), vg::kDmaLdsBytes, st, cent, k, v, n, dim, cadd.ptr, part.ptr);
         const float u = 5.9604645e-8f;
         float coef_e = 2.0f * (2.0f * dim + 16.0f) * u, coef_r = 2.0f * (dim / 64 + 32.0f) * u;
+        if (bf16) {
+            const int64_t tot = static_cast<int64_t>(k) * dim;
+            VG_LAUNCH(vg::km_split_kernel<true>, dim3(static_cast<unsigned>((tot + 255) / 256)), dim3(256), 0, st, cent, k, dim,
+                      csplit.ptr);
+            auto kern = dot ? vg::km_gemm_kernel<true, true> : vg::km_gemm_kernel<false, true>;
+            VG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       static_cast<int>(vg::kDmaLdsBytes)));
+            VG_LAUNCH(kern, dim3(blocks), dim3(vg::kGemmThreads), vg::kDmaLdsBytes, st, reinterpret_cast<const float *>(csplit.ptr),
+                      k, reinterpret_cast<const float *>(xsplit.ptr), n, 3 * dim / 2, cadd.ptr, part.ptr);
+            // |s~ - s|: the split drops at most 3 * 2^-16 |x_i| |c_i| per element (x = hi + lo + r, |r| <= 2^-16 |x|, the
+            // same for c; the dropped terms are lo lo, x r_c, r_x c); the products of bfloat16 values are exact in fp32 and
+            // every one of the 3 dim additions into the fp32 accumulator is taken to round (the matrix unit's internal
+            // order is not documented: the worst case of any order), + the |c|^2 column and the final fused multiply-add
+            coef_e = 2.0f * (3.0f * 1.52587890625e-5f * 1.01f + (3.0f * dim + 3.0f * dim / 16 + 16.0f + dim) * u);
+        } else {
+            auto kern = dot ? vg::km_gemm_kernel<true> : vg::km_gemm_kernel<false>;
+            VG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       static_cast<int>(vg::kDmaLdsBytes)));
+            VG_LAUNCH(kern, dim3(blocks), dim3(vg::kGemmThreads), vg::kDmaLdsBytes, st, cent, k, v, n, dim, cadd.ptr, part.ptr);
+        }
         if (vg::hook(vg::kHookKmListAll)) coef_e = INFINITY;
         VG_LAUNCH(vg::km_decide_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, st, part.ptr, mtiles, n,
                   xnorm.ptr, coef_e, coef_r, out, changed, list.ptr, pairs.ptr, count.ptr);
@@ -996,7 +1066,7 @@ VG_API int32_t vg_kmeans_assign(vg_ctx *ctx, const float *vectors, int64_t n, in
     VG_TRY(c.init(centroids, static_cast<size_t>(k) * dim, st));
     VG_TRY(o.init(out, static_cast<size_t>(n), st));
     KmMfma mf;
-    if (KmMfma::eligible(v.ptr, n, dim, c.ptr, k)) VG_TRY(mf.init(v.ptr, n, dim, k, st));
+    if (KmMfma::eligible(v.ptr, n, dim, c.ptr, k)) VG_TRY(mf.init(v.ptr, n, dim, k, st, 1, ctx->hbm_bytes));
     {
         vg::ProfScope prof(ctx, "km_assign", st);
         if (mf.on)
@@ -1056,7 +1126,7 @@ VG_API int32_t vg_kmeans_train(vg_ctx *ctx, const float *vectors, int64_t n, int
     if (sorted) VG_TRY(hist.init(static_cast<size_t>(parts) * k, st));
     std::vector<int64_t> hcounts, hoff;
     KmMfma mf;
-    if (KmMfma::eligible(v.ptr, n, dim, cent.ptr, k)) VG_TRY(mf.init(v.ptr, n, dim, k, st));
+    if (KmMfma::eligible(v.ptr, n, dim, cent.ptr, k)) VG_TRY(mf.init(v.ptr, n, dim, k, st, max_iter, ctx->hbm_bytes));
     for (int it = 0; it < max_iter; it++) {
         VG_HIP(hipMemsetAsync(changed.ptr, 0, sizeof(int), st));
         {

@@ -77,6 +77,8 @@ enum Hook {
     kHookBuildDebug,          // VG_BUILD_DEBUG          vg_hnsw_build prints its back-link totals
     kHookKmNoMfma,            // VG_KM_NO_MFMA           k-means assignment by the reference-order kernels only
     kHookKmListAll,           // VG_KM_LIST_ALL          k-means: the matrix scores decide nothing, every point is listed
+    kHookKmBf16,              // VG_KM_BF16              k-means: the bfloat16-split passes even for a single assignment
+    kHookKmNoBf16,            // VG_KM_NO_BF16           k-means: fp32 matrix passes only
     kHookPqNoMfma,            // VG_PQ_NO_MFMA           PQ Encode / Lloyd assignment by the reference-order kernels only
     kHookPqListAll,           // VG_PQ_LIST_ALL          PQ Encode / assignment: every (row, sub-quantizer) pair is listed
     kHookCount
