@@ -846,6 +846,24 @@ struct PqNomList {  // (row, sub-quantizer slot) pairs the scores could not deci
     int32_t row, sub;
 };
 
+// Block -> (sub-quantizer, row tile) of a 1-D grid of tiles * m workgroups: the m sub-quantizers of one row tile are
+// consecutive workgroups, and (m a multiple of 32) the four sub-quantizers whose 32-byte pieces share a 128-byte line of
+// a row go to the SAME XCD (workgroups b, b + 8, b + 16, ... share an XCD and its L2), 8 dispatch slots apart — the line
+// is then fetched from HBM once instead of four times (grid.x = tiles, grid.y = sub-quantizer: every sub-quantizer
+// streamed the rows again, 12 GB of line traffic per 1M x 768 Encode)
+__device__ __forceinline__ void pq_nom_block(int m, int &sub, int &tile_x)
+{
+    const int b = blockIdx.x;
+    tile_x = b / m;
+    const int bp = b - tile_x * m;
+    if ((m & 31) == 0) {
+        const int xcd = bp & 7, slot = bp >> 3;             // slot 0 .. m/8 - 1
+        sub = 4 * (xcd + 8 * (slot >> 2)) + (slot & 3);     // line group xcd + 8 * (slot / 4), piece slot % 4
+    } else {
+        sub = bp;
+    }
+}
+
 // ENC: rows = vectors [n][dim], sub-quantizer blockIdx.y, centroids dequantised from the int8 codebook, out = codes.
 // !ENC: rows = the training slabs [ls][n][8], centroids = cent_all [ls][256][8] fp32, out = assign_all (+ changed).
 template <bool ENC>
@@ -859,7 +877,8 @@ __global__ __launch_bounds__(256) void pq_nominate_kernel(const float *__restric
                                                           float extra_margin /* test hook: +Inf lists every pair */)
 {
     __shared__ float s_cmax[4];
-    const int sub = blockIdx.y;
+    int sub, tile_x;
+    pq_nom_block(m, sub, tile_x);
     if (!ENC && done[sub]) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h = lane >> 5, c_in = lane & 31;
@@ -900,7 +919,7 @@ __global__ __launch_bounds__(256) void pq_nominate_kernel(const float *__restric
     const float C = s_cmax[0], sqc = sqrtf(C);
     const float ones = h == 0 ? 1.0f : 0.0f;
     const float u = 5.9604645e-8f;
-    const int64_t row0 = row_first + static_cast<int64_t>(blockIdx.x) * kNomRowsPerBlock + wave * kNomRowsPerWave;
+    const int64_t row0 = row_first + static_cast<int64_t>(tile_x) * kNomRowsPerBlock + wave * kNomRowsPerWave;
     const int64_t stride = ENC ? dim : 8;
     const float *xbase = ENC ? rows + static_cast<int64_t>(sub) * 8 : rows + static_cast<int64_t>(sub) * n * 8;
     auto load_rows = [&](int pb) {  // this lane's half of the sub-vector of row pb * 32 + (lane & 31) (past the end: the last row)
@@ -989,6 +1008,219 @@ __global__ __launch_bounds__(256) void pq_nominate_kernel(const float *__restric
                 const int at = atomicAdd(list_count, 1);
                 list[at] = PqNomList{static_cast<int32_t>(p), sub};
             }
+        }
+    }
+}
+
+// ---- the same nomination on the bfloat16 matrix instruction, the scores scanned as packed keys ---------------------------
+// v_mfma_f32_32x32x2_f32 runs at 1/16 of the bf16 rate: pq_nominate_kernel spends 4.3 of its 6.3 ms per 1M x 768 inside
+// five fp32 MFMAs per tile, and the other 2 ms in 4 vector instructions per score.  Here
+//  * a tile is TWO v_mfma_f32_32x32x16_bf16: with x = x_hi + x_lo and w = -2 v = w_hi + w_lo (hi = the value rounded to
+//    bfloat16, lo = the remainder rounded to bfloat16) the 32 k slots hold  w_hi.x_hi (8) + w_lo.x_hi (8) + w_hi.x_lo (8),
+//    three slots |v|^2 (a 3-way bfloat16 split, exact) against ones, three slots ones against |x|^2 (1 + 2^-10) (the
+//    same): the accumulator is D~ = |x|^2 (1 + 2^-10) + |v|^2 - 2 x.v, POSITIVE (the 2^-10 |x|^2 outweighs every
+//    rounding below), so float order = unsigned order of the bit patterns;
+//  * a score's low 8 bits are replaced by its centroid's index inside the lane (v_and_or_b32) and the running smallest /
+//    second smallest are v_min_u32 / v_med3_u32 on these keys: 3 instructions per score, the index riding along.
+// Bound on |D~ - D - 2^-10 X| per score: the split drops w_lo.x_lo and the second remainders, <= 3 * 2^-16 |w| |x| = 3 * 2^-16 * 2 sqrt(X C);
+// bfloat16 products are exact in fp32 and each of the 30 additions is taken to round (any order): 32 u (2 sqrt(X C) + C +
+// 1.001 X); the key drops 8 bits: 2^-16 D~.  Everything is inside
+//     margin = 2 [ (3.1 * 2^-16 + 32 u) (2 sqrt(X C) + C) + (2^-16 * 1.01 + 32 u) * 1.002 (sqrt X + sqrt C)^2 ] + 2 * 12 u (..)^2
+// (the last term: the reference's own roundings, as before).
+typedef __bf16 pq_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 pq_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float pq_f32x2 __attribute__((ext_vector_type(2)));
+
+// (hi, lo) bfloat16 halves of two floats: hi = round-to-nearest-even, lo = the same of the exact remainder
+__device__ __forceinline__ void pq_split2(float a, float b, uint32_t &hi, uint32_t &lo)
+{
+    const pq_bf16x2 h = __builtin_convertvector(pq_f32x2{a, b}, pq_bf16x2);
+    hi = __builtin_bit_cast(uint32_t, h);
+    const float ra = a - __uint_as_float(hi << 16), rb = b - __uint_as_float(hi & 0xFFFF0000u);
+    lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(pq_f32x2{ra, rb}, pq_bf16x2));
+}
+// x = p0 + p1 + p2 exactly (three bfloat16: 24 significant bits), as the low halves of three words
+__device__ __forceinline__ void pq_split3(float x, uint32_t &p0, uint32_t &p1, uint32_t &p2)
+{
+    const pq_bf16x2 a = __builtin_convertvector(pq_f32x2{x, 0.0f}, pq_bf16x2);
+    p0 = __builtin_bit_cast(uint32_t, a) & 0xFFFFu;
+    const float r1 = x - __uint_as_float(p0 << 16);
+    const pq_bf16x2 b = __builtin_convertvector(pq_f32x2{r1, 0.0f}, pq_bf16x2);
+    p1 = __builtin_bit_cast(uint32_t, b) & 0xFFFFu;
+    const float r2 = r1 - __uint_as_float(p1 << 16);
+    const pq_bf16x2 c = __builtin_convertvector(pq_f32x2{r2, 0.0f}, pq_bf16x2);
+    p2 = __builtin_bit_cast(uint32_t, c) & 0xFFFFu;
+}
+
+// v_med3_u32 (no builtin; not volatile: the compiler may schedule it)
+__device__ __forceinline__ uint32_t pq_umed3(uint32_t a, uint32_t b, uint32_t c)
+{
+    uint32_t r;
+    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
+// (134 registers: three waves per SIMD; held to four — 128 registers, 11 spilled — it is slower, 0.276 vs 0.242 ms per
+// 65 536 x 96 pairs: the kernel is not short of waves)
+template <bool ENC>
+__global__ __launch_bounds__(256) void pq_nominate_bf16_kernel(const float *__restrict__ rows, int64_t n, int dim, int m,
+                                                               const int8_t *__restrict__ codebooks,
+                                                               const float *__restrict__ scales, const float *__restrict__ offsets,
+                                                               const float *__restrict__ cent_all, uint8_t *__restrict__ codes,
+                                                               int32_t *__restrict__ assign_all, int *__restrict__ changed,
+                                                               const int *__restrict__ done, PqNomList *__restrict__ list,
+                                                               int *__restrict__ list_count, int64_t row_first, float extra_margin)
+{
+    __shared__ float s_cmax[4];
+    int sub, tile_x;
+    pq_nom_block(m, sub, tile_x);
+    if (!ENC && done[sub]) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = lane >> 5, c_in = lane & 31;
+    // A operands of the 8 centroid blocks (uint4 = 8 bfloat16 = this lane's 8 k slots of one instruction)
+    uint4 a1[8], a2[8];
+    float cmax = 0.0f;
+#pragma unroll
+    for (int cb = 0; cb < 8; cb++) {
+        const int c = cb * 32 + c_in;
+        float v[8];
+        if (ENC) {
+            const uint2 w = reinterpret_cast<const uint2 *>(codebooks)[static_cast<int64_t>(sub) * 256 + c];
+            const float scale = scales[sub], offset = offsets[sub];
+#pragma unroll
+            for (int t = 0; t < 8; t++) {
+                const uint32_t ww = t < 4 ? w.x : w.y;
+                const float f = static_cast<float>(static_cast<int>(static_cast<int8_t>(ww >> (8 * (t & 3))))) * scale;
+                v[t] = f + offset;  // pq.go:205-215's two rounded operations
+            }
+        } else {
+            const float4 lo4 = *reinterpret_cast<const float4 *>(cent_all + (static_cast<int64_t>(sub) * 256 + c) * 8);
+            const float4 hi4 = *reinterpret_cast<const float4 *>(cent_all + (static_cast<int64_t>(sub) * 256 + c) * 8 + 4);
+            v[0] = lo4.x; v[1] = lo4.y; v[2] = lo4.z; v[3] = lo4.w;
+            v[4] = hi4.x; v[5] = hi4.y; v[6] = hi4.z; v[7] = hi4.w;
+        }
+        float cn = 0.0f;
+#pragma unroll
+        for (int t = 0; t < 8; t++) cn = __builtin_fmaf(v[t], v[t], cn);
+        uint32_t wh[4], wl[4];
+#pragma unroll
+        for (int t = 0; t < 4; t++) pq_split2(-2.0f * v[2 * t], -2.0f * v[2 * t + 1], wh[t], wl[t]);
+        uint32_t c0, c1, c2;
+        pq_split3(cn, c0, c1, c2);
+        const uint32_t one = 0x3F80u;  // bfloat16 1.0
+        // instruction 1: k 0-7 (h = 0) w_hi, k 8-15 (h = 1) w_lo; instruction 2: k 0-7 w_hi, k 8-15 (|v|^2 x 3, 1, 1, 1, 0, 0)
+        a1[cb] = h == 0 ? make_uint4(wh[0], wh[1], wh[2], wh[3]) : make_uint4(wl[0], wl[1], wl[2], wl[3]);
+        a2[cb] = h == 0 ? make_uint4(wh[0], wh[1], wh[2], wh[3]) : make_uint4(c0 | (c1 << 16), c2 | (one << 16), one | (one << 16), 0u);
+        cmax = fmaxf(cmax, cn == cn ? cn : INFINITY);
+    }
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) cmax = fmaxf(cmax, __shfl_xor(cmax, off));
+    if (lane == 0) s_cmax[wave] = cmax;
+    __syncthreads();
+    const float C = s_cmax[0], sqc = sqrtf(C);
+    const float u = 5.9604645e-8f, t16 = 1.52587890625e-5f;
+    const int64_t row0 = row_first + static_cast<int64_t>(tile_x) * kNomRowsPerBlock + wave * kNomRowsPerWave;
+    const int64_t stride = ENC ? dim : 8;
+    const float *xbase = ENC ? rows + static_cast<int64_t>(sub) * 8 : rows + static_cast<int64_t>(sub) * n * 8;
+    // the mask lives in a VGPR the compiler cannot see through: v_and_or_b32 then takes (score, mask, index) with the index
+    // as its one scalar operand — a literal mask leaves no room for a literal index and costs a v_and + v_or per score
+    uint32_t keep;
+    asm volatile("v_mov_b32 %0, 0xffffff00" : "=v"(keep));
+    auto load_rows = [&](int pb, float4 &lo4, float4 &hi4) {
+        const int64_t p = row0 + pb * 32 + c_in;
+        const int64_t pc = p < n ? p : n - 1;
+        lo4 = *reinterpret_cast<const float4 *>(xbase + pc * stride);
+        hi4 = *reinterpret_cast<const float4 *>(xbase + pc * stride + 4);
+    };
+    float4 nlo, nhi;
+    load_rows(0, nlo, nhi);
+    for (int pb = 0; pb < kNomRowsPerWave / 32; pb++) {
+        const int64_t p = row0 + pb * 32 + c_in;
+        if (row0 + pb * 32 >= n) break;  // wave-uniform
+        const float x[8] = {nlo.x, nlo.y, nlo.z, nlo.w, nhi.x, nhi.y, nhi.z, nhi.w};
+        load_rows(pb + 1 < kNomRowsPerWave / 32 ? pb + 1 : pb, nlo, nhi);  // in flight under this block's matrix work
+        float X = 0.0f;
+#pragma unroll
+        for (int t = 0; t < 8; t++) X = __builtin_fmaf(x[t], x[t], X);
+        uint32_t xh[4], xl[4];
+#pragma unroll
+        for (int t = 0; t < 4; t++) pq_split2(x[2 * t], x[2 * t + 1], xh[t], xl[t]);
+        uint32_t x0, x1, x2;
+        pq_split3(X * 1.0009765625f, x0, x1, x2);
+        const uint32_t one = 0x3F80u;
+        const uint4 b1 = make_uint4(xh[0], xh[1], xh[2], xh[3]);
+        const uint4 b2 = h == 0 ? make_uint4(xl[0], xl[1], xl[2], xl[3]) : make_uint4(one | (one << 16), one | (x0 << 16), x1 | (x2 << 16), 0u);
+        uint32_t m1 = 0xFFFFFFFFu, m2 = 0xFFFFFFFFu;
+        auto tile = [&](int cb) {
+            pq_f32x16 acc = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(pq_bf16x8, a1[cb]), __builtin_bit_cast(pq_bf16x8, b1), acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(pq_bf16x8, a2[cb]), __builtin_bit_cast(pq_bf16x8, b2), acc, 0, 0, 0);
+            return acc;
+        };
+        auto scan = [&](const pq_f32x16 &acc, int cb) {
+#if defined(VG_NOM_PROBE) && VG_NOM_PROBE == 1  // stage probe: the matrix results are not scanned
+            m1 = m1 < __float_as_uint(acc[cb]) ? m1 : __float_as_uint(acc[cb]);
+            return;
+#endif
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                // the centroid's index inside this lane's 128 (the h bit is added after the scan: it is the same for all of them)
+                const uint32_t key = (__float_as_uint(acc[r]) & keep) | static_cast<uint32_t>(cb * 32 + (r & 3) + 8 * (r >> 2));
+                m2 = pq_umed3(m1, key, m2);  // m1 <= m2: the middle one is the new second smallest
+                m1 = key < m1 ? key : m1;
+            }
+        };
+#if defined(VG_NOM_PROBE) && VG_NOM_PROBE == 3  // stage probe: loads and splits only
+        m1 = b1.x ^ b2.y ^ a1[pb & 7].x;
+        m2 = m1 + 512;
+#else
+        pq_f32x16 acc_a = tile(0), acc_b;
+#pragma unroll
+        for (int cb = 0; cb < 8; cb += 2) {
+            acc_b = tile(cb + 1);
+            scan(acc_a, cb);
+            if (cb + 2 < 8) acc_a = tile(cb + 2);
+            scan(acc_b, cb + 1);
+        }
+#endif
+        m1 |= static_cast<uint32_t>(4 * h);
+        m2 |= static_cast<uint32_t>(4 * h);
+        const uint32_t o1 = __shfl_xor(m1, 32), o2 = __shfl_xor(m2, 32);
+        const uint32_t lo1 = m1 < o1 ? m1 : o1, hi1 = m1 < o1 ? o1 : m1, lo2 = m2 < o2 ? m2 : o2;
+        m2 = hi1 < lo2 ? hi1 : lo2;
+        m1 = lo1;
+        bool listed = false;
+        if (h == 0 && p < n) {
+            const int idx = static_cast<int>(m1 & 0xFFu);
+            const float d1 = __uint_as_float(m1 & keep), d2 = __uint_as_float(m2 & keep);
+            const float sx = sqrtf(X);
+            const float cross = 2.0f * sx * sqc + C, dmax = (sx + sqc) * (sx + sqc);
+            const float margin = 1.05f * (2.0f * ((3.1f * t16 + 32.0f * u) * cross + (1.01f * t16 + 32.0f * u) * 1.002f * dmax) +
+                                          24.0f * u * dmax) + 1e-30f + extra_margin;
+            // every comparison is false on NaN: non-finite rows, centroids or scores go on the list (a NaN score's key has
+            // every exponent bit set: it can only be the LARGEST key, so a finite smallest key is a real smallest score)
+            if (X + C < 1e30f && d2 - d1 > margin) {
+                if (ENC) {
+                    codes[p * m + sub] = static_cast<uint8_t>(idx);
+                } else {
+                    int32_t *dst = assign_all + static_cast<int64_t>(sub) * n + p;
+                    if (*dst != idx) {
+                        *dst = idx;
+                        changed[sub] = 1;
+                    }
+                }
+            } else {
+                listed = true;
+            }
+        }
+        // one atomic per wave for its listed rows (one per row serialised on the counter: 270 k of them per 33 M pairs
+        // cost the first version of this kernel 2 of its 2.9 ms)
+        const uint64_t lm = __ballot(listed);
+        if (lm) {
+            int base = 0;
+            if (lane == __builtin_ctzll(lm)) base = atomicAdd(list_count, __popcll(lm));
+            base = __shfl(base, __builtin_ctzll(lm));
+            if (listed) list[base + __popcll(lm & ((1ull << lane) - 1ull))] = PqNomList{static_cast<int32_t>(p), sub};
         }
     }
 }
@@ -1099,6 +1331,7 @@ VG_API int32_t vg_pq_train_subset(vg_pq *pq, const float *vectors, int64_t n, in
     const bool nominate = sd == 8 && k == 256 && !vg::hook(vg::kHookPqNoMfma);
     const unsigned nom_gx = static_cast<unsigned>((n + vg::kNomRowsPerBlock - 1) / vg::kNomRowsPerBlock);
     const float nom_extra = vg::hook(vg::kHookPqListAll) ? INFINITY : 0.0f;
+    auto nom_kern = vg::hook(vg::kHookPqFp32Mfma) ? vg::pq_nominate_kernel<false> : vg::pq_nominate_bf16_kernel<false>;
     vg::DevTmp<vg::PqNomList> nom_list;
     vg::DevTmp<int> nom_count;
     if (nominate) {
@@ -1118,10 +1351,10 @@ VG_API int32_t vg_pq_train_subset(vg_pq *pq, const float *vectors, int64_t n, in
                 vg::ProfScope prof(pq->ctx, "pq_assign", st);                                                    \
                 if (nominate) {                                                                                  \
                     VG_HIP(hipMemsetAsync(nom_count.ptr, 0, sizeof(int), st));                                   \
-                    VG_LAUNCH(vg::pq_nominate_kernel<false>, dim3(nom_gx, m), dim3(256), 0, st, slabs.ptr, n, dim, m, nullptr, \
+                    VG_LAUNCH(nom_kern, dim3(nom_gx * m), dim3(256), 0, st, slabs.ptr, n, dim, m, nullptr, \
                               nullptr, nullptr, cent.ptr, nullptr, assign.ptr, changed, done, nom_list.ptr, nom_count.ptr,  \
                               int64_t(0), nom_extra);                                                            \
-                    VG_LAUNCH(vg::pq_fix_kernel<false>, dim3(64), dim3(256), 0, st, slabs.ptr, n, dim, m, nullptr, nullptr, \
+                    VG_LAUNCH(vg::pq_fix_kernel<false>, dim3(2048), dim3(64), 0, st, slabs.ptr, n, dim, m, nullptr, nullptr, \
                               nullptr, cent.ptr, nullptr, assign.ptr, changed, nom_list.ptr, nom_count.ptr);     \
                 } else if (SD)                                                                                   \
                     VG_LAUNCH(vg::pq_assign_vec_kernel<(SD ? SD : 4)>, dim3(gx_vec, m), dim3(256), lds, st, slabs.ptr, n, k, \
@@ -1198,10 +1431,11 @@ VG_API int32_t vg_pq_encode(vg_pq *pq, const float *vectors, int64_t n, uint8_t 
             const int64_t r1 = std::min(n, r0 + chunk);
             VG_HIP(hipMemsetAsync(nom_count.ptr, 0, sizeof(int), st));
             const unsigned gxn = static_cast<unsigned>((r1 - r0 + vg::kNomRowsPerBlock - 1) / vg::kNomRowsPerBlock);
-            VG_LAUNCH(vg::pq_nominate_kernel<true>, dim3(gxn, pq->m), dim3(256), 0, st, v.ptr, r1, pq->dim, pq->m, pq->d_codebooks,
+            auto nom_kern = vg::hook(vg::kHookPqFp32Mfma) ? vg::pq_nominate_kernel<true> : vg::pq_nominate_bf16_kernel<true>;
+            VG_LAUNCH(nom_kern, dim3(gxn * pq->m), dim3(256), 0, st, v.ptr, r1, pq->dim, pq->m, pq->d_codebooks,
                       pq->d_scales, pq->d_offsets, nullptr, c.ptr, nullptr, nullptr, nullptr, nom_list.ptr, nom_count.ptr, r0,
                       extra);
-            VG_LAUNCH(vg::pq_fix_kernel<true>, dim3(64), dim3(256), 0, st, v.ptr, r1, pq->dim, pq->m, pq->d_codebooks,
+            VG_LAUNCH(vg::pq_fix_kernel<true>, dim3(4096), dim3(64), 0, st, v.ptr, r1, pq->dim, pq->m, pq->d_codebooks,
                       pq->d_scales, pq->d_offsets, nullptr, c.ptr, nullptr, nullptr, nom_list.ptr, nom_count.ptr);
         }
     } else if (vec_ok && pq->subdim == 8)

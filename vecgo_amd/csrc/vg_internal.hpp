@@ -81,6 +81,7 @@ enum Hook {
     kHookKmNoBf16,            // VG_KM_NO_BF16           k-means: fp32 matrix passes only
     kHookPqNoMfma,            // VG_PQ_NO_MFMA           PQ Encode / Lloyd assignment by the reference-order kernels only
     kHookPqListAll,           // VG_PQ_LIST_ALL          PQ Encode / assignment: every (row, sub-quantizer) pair is listed
+    kHookPqFp32Mfma,          // VG_PQ_FP32_MFMA         PQ Encode / assignment: the fp32 matrix form (pq_nominate_kernel)
     kHookCount
 };
 bool hook(Hook h);
