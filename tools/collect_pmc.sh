@@ -2,7 +2,7 @@
 # Every rocprofv3 --pmc pass behind profiles/rNN_traffic.json (ROUND=r04 by default), at the bench's own shapes (run on the GPU box through
 # gpurun; counters in their own runs with --kernel-trace only, as the pool requires).  Each pass leaves
 # gpurun_out/pmc/NAME.csv (per-kernel mean counter values per dispatch, tools/pmc_run.sh); tools/make_traffic_json.py
-# turns them into the JSON.  usage: tools/collect_pmc.sh [scans|gemm|walks|all]
+# turns them into the JSON.  usage: tools/collect_pmc.sh [scans|gemm|walks|build|all]
 set -euo pipefail
 : "${GRAFT_REPO_ROOT:?run through gpurun (GRAFT_REPO_ROOT is the repository copy on the GPU box)}"
 cd "$GRAFT_REPO_ROOT"
@@ -37,6 +37,22 @@ if [ "$what" = walks ] || [ "$what" = all ]; then
         $P walk_${tag}_write "WRITE_SIZE" python3 tools/walk_prof.py 1000000 $m
         $P walk_${tag}_valu "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS GRBM_GUI_ACTIVE SQ_WAVES" python3 tools/walk_prof.py 1000000 $m
     done
+fi
+if [ "$what" = build ] || [ "$what" = all ]; then
+    # r05: the build-side kernels north_star names (k-means assignment, PQ Train, Encode): issue / wait / traffic / matrix-unit
+    # counters at the bench's shapes (profiles/r05_pmc_{kmeans,pqtrain,encode}_*.csv)
+    V="SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE"
+    M="SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_MFMA"
+    $P kmeans_valu "$V" python3 tools/kmeans_time.py
+    $P kmeans_mfma "$M" python3 tools/kmeans_time.py
+    $P kmeans_fetch "FETCH_SIZE" python3 tools/kmeans_time.py
+    $P kmeans_write "WRITE_SIZE" python3 tools/kmeans_time.py
+    $P pqtrain_valu "$V" python3 tools/pq_train_time.py
+    $P pqtrain_mfma "$M" python3 tools/pq_train_time.py
+    $P pqtrain_fetch "FETCH_SIZE" python3 tools/pq_train_time.py
+    $P encode_valu "$V" python3 tools/encode_one.py
+    $P encode_mfma "$M" python3 tools/encode_one.py
+    $P encode_fetch "FETCH_SIZE" python3 tools/encode_one.py
 fi
 python3 tools/make_traffic_json.py gpurun_out/pmc > gpurun_out/pmc/${ROUND}_traffic.json
 ls gpurun_out/pmc/*.csv | wc -l

@@ -11,7 +11,7 @@ ctx = vg.Context(0)
 g = torch.Generator(device="cuda"); g.manual_seed(2)
 x = torch.randn((n, 768), dtype=torch.float32, device="cuda", generator=g)
 pq = vg.ProductQuantizer(ctx, 768, 96, 256)
-pq.train(x[:32768].contiguous(), iters=3, seed=1)
+pq.train(x[:65536].contiguous(), iters=20, seed=1)
 out = torch.empty((n, 96), dtype=torch.uint8, device="cuda")
 for _ in range(2): pq.encode(x, out=out)
 torch.cuda.synchronize()
