@@ -236,6 +236,30 @@ func (r *Resident) SearchHNSWPQ(queries []float32, nq, k, ef int, stats []Stats)
 	return ids, sc, hipctx.Err(int32(st))
 }
 
+// SearchHNSWFiltered: searchExecute with a filter and a selectivity hint above 0.3 — searchLayerWithPostFilter
+// (hnsw.go:1159-1218).  mask: bit i of byte i/8 = row i passes (filter.Matches and not tombstoned), len(mask) ==
+// ceil(n/8) for one mask (maskStride 0) or nq*maskStride; ef is what determineEF returned.  A selectivity at or below
+// 0.3 is an error here (the reference walks predicate-aware there; use SearchHNSWBrute for selective bitmaps).
+func (r *Resident) SearchHNSWFiltered(queries []float32, nq, k, ef int, mask []byte, maskStride int, selectivity float64, stats []Stats) ([]uint32, []float32, error) {
+	ids, sc := r.out(nq, k)
+	need := (r.rows + 7) / 8
+	if maskStride != 0 {
+		if maskStride < need {
+			return nil, nil, fmt.Errorf("SearchHNSWFiltered: maskStride %d is shorter than a mask (%d bytes)", maskStride, need)
+		}
+		need += (nq - 1) * maskStride
+	}
+	if len(mask) < need {
+		return nil, nil, fmt.Errorf("SearchHNSWFiltered: mask holds %d bytes, %d needed", len(mask), need)
+	}
+	var sp *C.vg_search_stats
+	if len(stats) >= nq && nq > 0 {
+		sp = (*C.vg_search_stats)(unsafe.Pointer(&stats[0]))
+	}
+	st := C.vg_search_hnsw_filtered(r.h, fp(queries), C.int64_t(nq), C.int32_t(k), C.int32_t(ef), bp(mask), C.int64_t(maskStride), C.double(selectivity), up(ids), fp(sc), sp, nil)
+	return ids, sc, hipctx.Err(int32(st))
+}
+
 // BruteMode selects which of the HNSW index's exhaustive paths SearchHNSWBrute replays.
 type BruteMode int32
 

@@ -47,8 +47,9 @@ extern "C" {
  * vg_abi_minor() with the value below before it looks the symbol up, instead of failing on first use.
  *   1: (r04) vg_search_hnsw_brute, vg_debug_heap_replay
  *   2: (r05) vg_abi_minor itself; no other symbol added — vg_search_hnsw / _hnsw_pq answer NaN distances as the reference
- *      does, vg_kmeans_* decide assignments on the matrix cores, the k-means++ running sum of vg_pq_train is blocked */
-#define VG_ABI_MINOR 2
+ *      does, vg_kmeans_* decide assignments on the matrix cores, the k-means++ running sum of vg_pq_train is blocked
+ *   3: (r05) vg_search_hnsw_filtered */
+#define VG_ABI_MINOR 3
 #define VG_INVALID_ID 0xFFFFFFFFu
 #define VG_STREAM_LEGACY ((void *)1) /* == hipStreamLegacy */
 
@@ -544,6 +545,18 @@ typedef struct vg_search_stats {
  * floats exactly as the reference's loop is written (r04 and before: unspecified, and an Inf in a query could fault). */
 int32_t vg_search_hnsw(vg_index *idx, const float *queries, int64_t nq, int32_t k, int32_t ef,
                        uint32_t *ids, float *scores, vg_search_stats *stats, void *stream);
+/* searchExecute with a filter and a selectivity hint above highSelectivityThreshold = 0.3 (hnsw.go:1107-1146, :1791-1835):
+ * searchLayerWithPostFilter (hnsw.go:1159-1218) — the walk above with ef expanded to ef * (1 + (1 - selectivity) / 2)
+ * (at most 2 ef, at most 500), every result then popped worst first, the rows whose mask bit is set kept in that order and
+ * pushed back capped at ef — and knnSearchInternal's extraction.  mask: bit i of byte i/8 set = row i passes
+ * (filter.Matches and not tombstoned); query q reads mask + q * mask_stride (0 = one mask for the batch, else >=
+ * ceil(n/8)).  `ef` is what determineEF returned (its bitmap-cardinality expansion, hnsw.go:1863-1889, is the caller's).
+ * selectivity <= 0.3 -> VG_ERR_UNSUPPORTED: the reference walks predicate-aware there (searchLayerPredicateAware,
+ * hnsw.go:1406), which is not built; vg_search_hnsw_brute serves the selective end (KNNSearchWithBuffer's bitmap scan).
+ * (VG_ABI_MINOR 3.) */
+int32_t vg_search_hnsw_filtered(vg_index *idx, const float *queries, int64_t nq, int32_t k, int32_t ef,
+                                const uint8_t *mask, int64_t mask_stride, double selectivity, uint32_t *ids,
+                                float *scores, vg_search_stats *stats, void *stream);
 /* The same walk scored from the nodes' PQ codes instead of their fp32 rows: distFunc =
  * pq.ComputeAsymmetricDistance (pq.go:234-260), the way the reference scores graph nodes from PQ codes
  * (diskann/segment.go:536-557); no SquaredL2Bounded short-circuit (that kernel reads fp32 rows).  scores =

@@ -816,6 +816,30 @@ def _brute_search(self, query, k, mode=BRUTE_SCAN, mask=None):
 
 HnswIndex.brute_search = _brute_search
 
+_sig("vgo_hnsw_search_filtered", C.c_int32, C.POINTER(HnswGraph), _f32p, C.c_int32, C.c_int32, _u8p, C.c_double, _u32p, _f32p,
+     C.POINTER(SearchStats))
+
+
+def _search_filtered(self, query, k, ef, mask, selectivity):
+    """searchExecute with a filter and a selectivity hint > 0.3: searchLayerWithPostFilter (hnsw.go:1159-1218).  mask:
+    bool[n] or packed little-endian bits.  Returns (ids, scores, stats) or None when the selectivity is <= 0.3."""
+    q, pq_ = _f(query)
+    ids = np.empty(max(k, ef, 1), np.uint32); sc = np.empty(max(k, ef, 1), np.float32)
+    mask = np.asarray(mask)
+    if mask.dtype == np.bool_:
+        mask = np.packbits(mask, bitorder="little")
+    mask, mp = _u8(mask)
+    st = SearchStats()
+    g = self._c()
+    r = lib.vgo_hnsw_search_filtered(C.byref(g), pq_, k, ef, mp, float(selectivity), ids.ctypes.data_as(_u32p),
+                                     sc.ctypes.data_as(_f32p), C.byref(st))
+    if r < 0:
+        return None
+    return ids[:r], sc[:r], st
+
+
+HnswIndex.search_filtered = _search_filtered
+
 
 class VamanaIndex:
     def __init__(self, graph, entry_point, dim, kind=VAMANA_F32, metric=METRIC_L2, base=None,

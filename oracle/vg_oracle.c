@@ -1443,6 +1443,76 @@ int32_t vgo_hnsw_search_ws(const vgo_hnsw_graph *g, const float *query, int32_t 
     return nres;
 }
 
+/* searchExecute with a filter whose selectivity hint is above highSelectivityThreshold (hnsw.go:1107-1146):
+ * searchLayerWithPostFilter (hnsw.go:1159-1218) — the unfiltered walk with an expanded ef, then every result popped
+ * (worst first), the ones that pass the filter kept in that order and pushed back (PushItem below ef, PushItemBounded
+ * at it) — then knnSearchInternal's extraction.  `mask`: bit i of byte i/8 = row i passes (filter.Matches and not
+ * tombstoned); `ef` is what determineEF returned (its bitmap-cardinality expansion, hnsw.go:1863-1889, is the
+ * caller's).  Returns -1 for a selectivity at or below the threshold (searchLayerPredicateAware is not restated). */
+int32_t vgo_hnsw_search_filtered(const vgo_hnsw_graph *g, const float *query, int32_t k, int32_t ef, const uint8_t *mask,
+                                 double selectivity, uint32_t *ids, float *scores, vgo_search_stats *stats)
+{
+    if (!(selectivity > 0.3)) return -1;
+    vgo_search_stats st = {0, 0, 0, 0};
+    if (ef < k) ef = k;
+    uint32_t cur = g->entry_point;
+    float cur_d = hnsw_dist(g, query, cur);
+    for (int level = g->max_level; level > 0; level--) { /* greedySearch hnsw.go:1897-1934 */
+        int changed = 1;
+        while (changed) {
+            changed = 0;
+            uint32_t slot = g->slot[level - 1][cur];
+            if (slot == 0xFFFFFFFFu) continue;
+            const uint32_t *nb = g->adj[level - 1] + (int64_t)slot * g->m;
+            for (int i = 0; i < g->m && nb[i] != 0xFFFFFFFFu; i++) {
+                float d = hnsw_dist(g, query, nb[i]);
+                if (d < cur_d) {
+                    cur = nb[i];
+                    cur_d = d;
+                    changed = 1;
+                }
+            }
+        }
+    }
+    /* hnsw.go:1166-1183 */
+    int32_t expanded = (int32_t)((double)ef * (1.0 + (1.0 - selectivity) * 0.5));
+    if (expanded > ef * 2) expanded = ef * 2;
+    if (expanded > 500) expanded = 500;
+    if (expanded < 1) expanded = 1;
+    uint32_t *visited = (uint32_t *)calloc((size_t)g->n, sizeof(uint32_t));
+    vgo_prioq cand, res;
+    vgo_prioq_init(&cand, 0, expanded * 2);
+    vgo_prioq_init(&res, 1, expanded > ef ? expanded : ef);
+    vgo_hnsw_search_layer(g, query, cur, cur_d, 0, expanded, visited, 1, &cand, &res, &st);
+    /* hnsw.go:1187-1217: pop everything, keep what passes, push back capped at ef */
+    vgo_pq_item *keep = (vgo_pq_item *)malloc(sizeof(vgo_pq_item) * (size_t)(res.len > 0 ? res.len : 1));
+    int32_t nkeep = 0;
+    vgo_pq_item it;
+    while (res.len > 0) {
+        vgo_prioq_pop(&res, &it);
+        if (!mask || ((mask[it.node >> 3] >> (it.node & 7)) & 1)) keep[nkeep++] = it;
+    }
+    for (int32_t i = 0; i < nkeep; i++) {
+        if (res.len < ef)
+            vgo_prioq_push(&res, keep[i]);
+        else
+            vgo_prioq_push_bounded(&res, keep[i], ef);
+    }
+    free(keep);
+    while (res.len > k) vgo_prioq_pop(&res, &it); /* extraction hnsw.go:1732-1751 */
+    int32_t nres = res.len;
+    for (int i = nres - 1; i >= 0; i--) {
+        vgo_prioq_pop(&res, &it);
+        ids[i] = it.node;
+        scores[i] = it.dist;
+    }
+    vgo_prioq_free(&cand);
+    vgo_prioq_free(&res);
+    free(visited);
+    if (stats) *stats = st;
+    return nres;
+}
+
 /* hnsw.BruteSearch hnsw.go:2021-2073 + scanSegment :2075-2101, and searchBitmap :2240-2263 + knnSearchInternal's
  * extraction :1732-1751 — the two exhaustive paths of the HNSW index, each with the heap discipline it is WRITTEN
  * with (they differ, and with them the order in which equal distances leave the heap):

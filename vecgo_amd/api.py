@@ -1037,6 +1037,42 @@ class Index:
         stage of graph -> PQ -> exact rerank); scores are PQ distances."""
         return self._graph_search(self._lib.vg_search_hnsw_pq, queries, k, ef, stats, stream)
 
+    def _packed_mask(self, mask, nq, what):
+        """bool[n] / bool[nq, n] / packed little-endian bits -> (contiguous uint8 array, stride in bytes; 0 = one mask)."""
+        m = np.asarray(mask)
+        if m.dtype == np.bool_:
+            if m.shape[-1] != self.n:   # the C side reads ceil(n / 8) bytes per mask: a short one would be read past its end
+                raise ValueError(f"{what}: a bool mask has one entry per row ({self.n}), got {m.shape[-1]}")
+            m = np.packbits(m.reshape(-1, self.n) if m.ndim > 1 else m, axis=-1, bitorder="little")
+        m = np.ascontiguousarray(m, np.uint8)
+        if m.shape[-1] < (self.n + 7) // 8:
+            raise ValueError(f"{what}: a packed mask holds ceil(n / 8) = {(self.n + 7) // 8} bytes, got {m.shape[-1]}")
+        stride = 0
+        if m.ndim > 1 and m.shape[0] > 1:
+            if m.shape[0] != nq:
+                raise ValueError(f"{what}: one mask per query ({nq}), got {m.shape[0]}")
+            stride = m.shape[1]
+        return m, stride
+
+    def search_hnsw_filtered(self, queries, k, ef, mask, selectivity, stats=False, stream=None):
+        """searchExecute with a filter whose selectivity hint is above 0.3: searchLayerWithPostFilter (hnsw.go:1159-1218) —
+        the walk with an expanded ef, the results re-filtered through `mask` (bool[n] / packed bits, one for the batch or
+        one per query) and capped at ef.  `ef` = what determineEF returned."""
+        nq = _rows(queries, self.dim)
+        m, stride = self._packed_mask(mask, nq, "search_hnsw_filtered")
+        q, pq_ = _ptr(queries, np.float32)
+        ids = _empty_like(queries, (nq, k), np.uint32)
+        scores = _empty_like(queries, (nq, k), np.float32)
+        i, pi = _ptr(ids, np.uint32)
+        s_, ps = _ptr(scores, np.float32)
+        st = np.zeros((nq, 5), np.int64) if stats else None
+        pst = C.c_void_p(st.ctypes.data) if stats else None
+        check(self._lib.vg_search_hnsw_filtered(self._h, pq_, C.c_int64(nq), C.c_int32(k), C.c_int32(ef), C.c_void_p(m.ctypes.data),
+                                                C.c_int64(stride), C.c_double(float(selectivity)), pi, ps, pst, _stream_ptr(stream)))
+        if stats and stats != "full":
+            st = st[:, :4]
+        return (ids, scores, st) if stats else (ids, scores)
+
     BRUTE_SCAN, BRUTE_BITMAP = 0, 1
 
     def search_hnsw_brute(self, queries, k, mode=0, mask=None, stream=None):

@@ -75,7 +75,10 @@ __global__ __launch_bounds__(64) VG_HNSW_ATTR void hnsw_search_kernel(
     uint32_t *__restrict__ visited_ws, int64_t vis_words, HItem *__restrict__ heap_ws,
     uint32_t *__restrict__ ids, float *__restrict__ scores, vg_search_stats *__restrict__ stats,
     uint8_t *__restrict__ redo /* first pass: redo[q] = 1 when the walk met a NaN distance and stopped; STRICT: only the
-                                  queries so marked, every comparison as the reference writes it */)
+                                  queries so marked, every comparison as the reference writes it */,
+    const uint8_t *__restrict__ mask, int64_t mask_stride, int ef_keep /* searchLayerWithPostFilter (hnsw.go:1159-1218):
+                                  `ef` is the EXPANDED ef the walk runs with; afterwards every result is popped, the rows
+                                  whose mask bit is set are kept in that order and pushed back capped at ef_keep */)
 {
     extern __shared__ __attribute__((aligned(8))) unsigned char smem[];
     constexpr bool PQ = PQM != 0;
@@ -175,6 +178,23 @@ __global__ __launch_bounds__(64) VG_HNSW_ATTR void hnsw_search_kernel(
     if (odd) {  // a NaN distance: this query is answered by the second pass (search_hnsw_impl)
         if (lane == 0) redo[q] = 1;
         return;
+    }
+
+    if (mask) {  // hnsw.go:1187-1217
+        const uint8_t *mq = mask + q * mask_stride;
+        // (the finished candidates heap's storage holds the survivors: 2 * ef items >= res_len)
+        int keep = 0;
+        while (res_len > 0) {
+            const HItem it = heap_pop<true, UK>(res, res_len);
+            if ((mq[it.node >> 3] >> (it.node & 7)) & 1) heap_put(cand, keep++, it);
+        }
+        for (int i = 0; i < keep; i++) {
+            const HItem it = heap_get(cand, i);
+            if (res_len < ef_keep)
+                heap_push<true>(res, res_len, it);
+            else
+                res_push_bounded<UK>(res, res_len, it, ef_keep);
+        }
     }
 
     // knnSearchInternal extraction (hnsw.go:1732-1751): drop the worst until k remain, then pop — the k closest
@@ -637,9 +657,10 @@ static int64_t graph_scratch_cap(const vg_ctx *ctx)
 }
 
 static int32_t search_hnsw_impl(vg_index *idx, bool pq, const float *queries, int64_t nq, int32_t k, int32_t ef,
-                                uint32_t *ids, float *scores, vg_search_stats *stats, void *stream)
+                                uint32_t *ids, float *scores, vg_search_stats *stats, void *stream,
+                                const uint8_t *mask = nullptr, int64_t mask_stride = 0, double selectivity = 0.0)
 {
-    const char *fn = pq ? "vg_search_hnsw_pq" : "vg_search_hnsw";
+    const char *fn = mask ? "vg_search_hnsw_filtered" : pq ? "vg_search_hnsw_pq" : "vg_search_hnsw";
     VG_CHECK(idx, VG_ERR_INVALID_ARG, "%s: NULL index", fn);
     VG_CHECK(nq >= 0 && k >= 0, VG_ERR_INVALID_ARG, "%s: negative nq or k", fn);
     if (nq == 0 || k == 0) return VG_OK;
@@ -653,6 +674,14 @@ static int32_t search_hnsw_impl(vg_index *idx, bool pq, const float *queries, in
     VG_CHECK(queries && ids && scores, VG_ERR_INVALID_ARG, "%s: NULL buffer", fn);
     if (ef < k) ef = k;  // determineEF hnsw.go:1891-1894
     VG_CHECK(ef <= vg::kHnswMaxEf, VG_ERR_UNSUPPORTED, "%s: ef=%d exceeds %d", fn, ef, vg::kHnswMaxEf);
+    const int ef_keep = ef;
+    if (mask) {  // searchLayerWithPostFilter's expanded ef (hnsw.go:1166-1183); ef_keep caps the rebuilt results heap
+        int64_t expanded = static_cast<int64_t>(static_cast<double>(ef) * (1.0 + (1.0 - selectivity) * 0.5));
+        if (expanded > int64_t(ef) * 2) expanded = int64_t(ef) * 2;
+        if (expanded > 500) expanded = 500;
+        if (expanded < 1) expanded = 1;
+        ef = static_cast<int32_t>(expanded);
+    }
     VG_HIP(hipSetDevice(idx->ctx->device));
     hipStream_t st = vg::pick_stream(idx->ctx, stream);
     vg::DevIn<float> q;
@@ -663,6 +692,9 @@ static int32_t search_hnsw_impl(vg_index *idx, bool pq, const float *queries, in
     VG_TRY(oid.init(ids, static_cast<size_t>(nq) * k, st));
     VG_TRY(osc.init(scores, static_cast<size_t>(nq) * k, st));
     VG_TRY(ost.init(stats, stats ? static_cast<size_t>(nq) : 0, st));
+    vg::DevIn<uint8_t> mk;
+    const int64_t mask_bytes = (idx->n + 7) / 8;
+    VG_TRY(mk.init(mask, mask ? static_cast<size_t>(mask_stride ? (nq - 1) * mask_stride + mask_bytes : mask_bytes) : 0, st));
     const int64_t vis_words = (idx->n + 31) / 32;
     const int pq_m = pq ? idx->pq->m : 0;
     // heaps in LDS up to kHnswLdsEf (12 KiB per query: the waves of a CU are then bounded by registers, not
@@ -673,6 +705,9 @@ static int32_t search_hnsw_impl(vg_index *idx, bool pq, const float *queries, in
 #ifndef VG_PQ_LDS_HEAPS_MAX
 #define VG_PQ_LDS_HEAPS_MAX 448  // PQ walk: all-LDS heaps at ef 512 are 16.7 KiB per query = 9 waves per CU (12.95 ms per 8192
 #endif                            // queries); split with 128 items in LDS: 16 waves, 12.47 ms; at ef 384 the other way round (7.95 vs 9.19)
+    // (a post-filter walk capped at 500 may keep more results than it walked with: the heaps are sized for the larger)
+    const int ef_walk = ef;
+    if (ef_keep > ef) ef = ef_keep;
     const bool lds_heaps = ef <= (pq ? VG_PQ_LDS_HEAPS_MAX : vg::kHnswLdsEf);
     // (swept on one box, ef 1024 / 2048: candidates : results = 768 : 384 46 / 94 ms, 128 : 768 47 / 95, 256 : 1024
     // 50 / 107, 256 : 2048 51 / 124, 1024 : 2048 58 / 152 — waves in flight beat heap levels in LDS)
@@ -730,16 +765,18 @@ static int32_t search_hnsw_impl(vg_index *idx, bool pq, const float *queries, in
                       idx->metric, idx->d_hnsw_l0, idx->hnsw_m0, idx->hnsw_max_level, idx->hnsw_m, idx->d_hnsw_slot,
                       idx->d_hnsw_adj, idx->d_hnsw_level_off, idx->hnsw_entry, q.ptr + q0 * idx->dim,
                       pq ? idx->d_pq_rows : nullptr, pq_m, luts, pq_direct ? idx->pq->d_codebooks : nullptr,
-                      pq ? idx->pq->d_scales : nullptr, pq ? idx->pq->d_offsets : nullptr, k, ef, lds_cand, lds_res, vis.ptr,
-                      vis_words, heap_ws, oid.ptr + q0 * k, osc.ptr + q0 * k, ost.ptr ? ost.ptr + q0 : nullptr, redo);
+                      pq ? idx->pq->d_scales : nullptr, pq ? idx->pq->d_offsets : nullptr, k, ef_walk, lds_cand, lds_res, vis.ptr,
+                      vis_words, heap_ws, oid.ptr + q0 * k, osc.ptr + q0 * k, ost.ptr ? ost.ptr + q0 : nullptr, redo,
+                      mk.ptr ? mk.ptr + q0 * mask_stride : nullptr, mask_stride, ef_keep);
         }
         // (every workgroup of an ordinary batch leaves at its first instruction)
         VG_LAUNCH(kern_f32, dim3(static_cast<unsigned>(cnt)), dim3(64), lds, st, idx->d_vectors, idx->n, idx->dim,
                       idx->metric, idx->d_hnsw_l0, idx->hnsw_m0, idx->hnsw_max_level, idx->hnsw_m, idx->d_hnsw_slot,
                       idx->d_hnsw_adj, idx->d_hnsw_level_off, idx->hnsw_entry, q.ptr + q0 * idx->dim,
                       pq ? idx->d_pq_rows : nullptr, pq_m, luts, pq_direct ? idx->pq->d_codebooks : nullptr,
-                      pq ? idx->pq->d_scales : nullptr, pq ? idx->pq->d_offsets : nullptr, k, ef, lds_cand, lds_res, vis.ptr,
-                      vis_words, heap_ws, oid.ptr + q0 * k, osc.ptr + q0 * k, ost.ptr ? ost.ptr + q0 : nullptr, redo);
+                      pq ? idx->pq->d_scales : nullptr, pq ? idx->pq->d_offsets : nullptr, k, ef_walk, lds_cand, lds_res, vis.ptr,
+                      vis_words, heap_ws, oid.ptr + q0 * k, osc.ptr + q0 * k, ost.ptr ? ost.ptr + q0 : nullptr, redo,
+                      mk.ptr ? mk.ptr + q0 * mask_stride : nullptr, mask_stride, ef_keep);
     }
     VG_TRY(oid.finish());
     VG_TRY(osc.finish());
@@ -758,6 +795,24 @@ VG_API int32_t vg_search_hnsw_pq(vg_index *idx, const float *queries, int64_t nq
                                  uint32_t *ids, float *scores, vg_search_stats *stats, void *stream)
 {
     return search_hnsw_impl(idx, true, queries, nq, k, ef, ids, scores, stats, stream);
+}
+
+VG_API int32_t vg_search_hnsw_filtered(vg_index *idx, const float *queries, int64_t nq, int32_t k, int32_t ef,
+                                       const uint8_t *mask, int64_t mask_stride, double selectivity, uint32_t *ids,
+                                       float *scores, vg_search_stats *stats, void *stream)
+{
+    VG_CHECK(idx, VG_ERR_INVALID_ARG, "vg_search_hnsw_filtered: NULL index");
+    VG_CHECK(mask, VG_ERR_INVALID_ARG, "vg_search_hnsw_filtered: NULL mask (vg_search_hnsw is the unfiltered walk)");
+    // searchLayer's strategy choice (hnsw.go:1120-1145): above highSelectivityThreshold the unfiltered walk + post-filter;
+    // at or below it the reference walks predicate-aware (searchLayerPredicateAware, :1406), which is not built here
+    VG_CHECK(selectivity > 0.3, VG_ERR_UNSUPPORTED,
+             "vg_search_hnsw_filtered: selectivity %.3f is not above 0.3: the reference takes searchLayerPredicateAware there "
+             "(not implemented); vg_search_hnsw_brute serves selective masks", selectivity);
+    const int64_t mask_bytes = (idx->n + 7) / 8;
+    VG_CHECK(mask_stride == 0 || mask_stride >= mask_bytes, VG_ERR_INVALID_ARG,
+             "vg_search_hnsw_filtered: mask_stride %lld is shorter than a mask (%lld bytes)", static_cast<long long>(mask_stride),
+             static_cast<long long>(mask_bytes));
+    return search_hnsw_impl(idx, false, queries, nq, k, ef, ids, scores, stats, stream, mask, mask_stride, selectivity);
 }
 
 VG_API int32_t vg_search_vamana(vg_index *idx, const float *queries, int64_t nq, int32_t k, int32_t kind,
