@@ -449,9 +449,83 @@ __global__ __launch_bounds__(64) void heap_replay_kernel(int is_max, int uk, con
     for (int i = lane; i < len && i < cap; i += 64) final_items[i] = heap_load_u64(heap, i);
 }
 
+// The unmasked scan from vg_search_flat's answer: the PriorityQueue's final SET is the k smallest distances and its pops
+// leave in ascending distance — the heap's layout (the history of accepted rows) only decides between EQUAL distances.
+// `fid` / `fsc` = the k + 1 best rows by (score, id) with their exact scores (the same squaredL2Avx512 /
+// dotProductAvx512 values brute_dist_kernel computes).  If the k + 1 values are finite and pairwise different, rows
+// 0 .. k-1 ARE the reference's answer (Dot: the index's distance is -dot); any tie or NaN sends the query to the replay.
+__global__ void brute_from_flat_kernel(const uint32_t *__restrict__ fid, const float *__restrict__ fsc, int64_t nq, int k, bool dot,
+                                       uint32_t *__restrict__ ids, float *__restrict__ scores, int32_t *__restrict__ redo)
+{
+    const int64_t q = blockIdx.x;
+    const int lane = threadIdx.x;  // 64
+    bool bad = false;
+    for (int i = lane; i <= k; i += 64) {
+        const uint32_t id = fid[q * (k + 1) + i];
+        const float s = fsc[q * (k + 1) + i];
+        bad |= id == VG_INVALID_ID || !(fabsf(s) <= 3.40282346638528859811704183484516925440e+38f);
+        if (i > 0) bad |= __float_as_uint(fsc[q * (k + 1) + i - 1]) == __float_as_uint(s) || fsc[q * (k + 1) + i - 1] == s;
+    }
+    const bool any_bad = __ballot(bad) != 0;
+    if (lane == 0) redo[q] = any_bad ? 1 : 0;
+    if (any_bad) return;
+    for (int i = lane; i < k; i += 64) {
+        ids[q * k + i] = fid[q * (k + 1) + i];
+        const float s = fsc[q * (k + 1) + i];
+        scores[q * k + i] = dot ? -s : s;
+    }
+}
+
 }  // namespace vg
 
+static int32_t brute_impl(vg_index *idx, const float *queries, int64_t nq, int32_t k, int32_t mode, const uint8_t *mask,
+                          int64_t mask_stride, uint32_t *ids, float *scores, void *stream);
+
 VG_API int32_t vg_search_hnsw_brute(vg_index *idx, const float *queries, int64_t nq, int32_t k, int32_t mode,
+                                    const uint8_t *mask, int64_t mask_stride, uint32_t *ids, float *scores, void *stream)
+{
+    // Two or more unmasked queries under L2 / Dot: every (query, row) distance is a 1M x dim product per query — the
+    // flat search's MFMA nomination + exact re-score + proof answers "the k + 1 best by (score, id)" at 11 ms per 1024
+    // queries where brute_dist_mq_kernel's vector-ALU pass takes 16 ms per 256; brute_from_flat_kernel turns that answer
+    // into the reference's when no two of the k + 1 distances are equal, and the few queries with a tie are replayed
+    // as before.  (Cosine scores rows by 0.5 * L2 here and by the dot product in the flat search: not the same bits.)
+    const bool fast = idx && mask == nullptr && nq >= 2 && k >= 1 && queries && ids && scores && idx->d_vectors &&
+                      (idx->metric == VG_METRIC_L2 || idx->metric == VG_METRIC_DOT) && static_cast<int64_t>(k) + 1 <= idx->n &&
+                      k + 1 <= 512 /* vg_search_flat's kFlatMaxK */ && k <= vg::kBruteMaxK && (mode == VG_BRUTE_SCAN || mode == VG_BRUTE_BITMAP) &&
+                      !vg::hook(vg::kHookBruteNoFlat);
+    if (!fast) return brute_impl(idx, queries, nq, k, mode, mask, mask_stride, ids, scores, stream);
+    VG_HIP(hipSetDevice(idx->ctx->device));
+    hipStream_t st = vg::pick_stream(idx->ctx, stream);
+    vg::DevIn<float> q;
+    vg::DevOut<uint32_t> oid;
+    vg::DevOut<float> osc;
+    VG_TRY(q.init(queries, static_cast<size_t>(nq) * idx->dim, st));
+    VG_TRY(oid.init(ids, static_cast<size_t>(nq) * k, st));
+    VG_TRY(osc.init(scores, static_cast<size_t>(nq) * k, st));
+    vg::DevTmp<uint32_t> fid;
+    vg::DevTmp<float> fsc;
+    vg::DevTmp<int32_t> redo;
+    VG_TRY(fid.init(static_cast<size_t>(nq) * (k + 1), st));
+    VG_TRY(fsc.init(static_cast<size_t>(nq) * (k + 1), st));
+    VG_TRY(redo.init(static_cast<size_t>(nq), st));
+    {
+        vg::ProfScope prof(idx->ctx, "hnsw_brute_dist", st);  // (the distance work of this form)
+        VG_TRY(vg_search_flat(idx, q.ptr, nq, k + 1, fid.ptr, fsc.ptr, st));
+    }
+    VG_LAUNCH(vg::brute_from_flat_kernel, dim3(static_cast<unsigned>(nq)), dim3(64), 0, st, fid.ptr, fsc.ptr, nq, k,
+              idx->metric == VG_METRIC_DOT, oid.ptr, osc.ptr, redo.ptr);
+    std::vector<int32_t> h(static_cast<size_t>(nq));
+    VG_HIP(hipMemcpyAsync(h.data(), redo.ptr, sizeof(int32_t) * static_cast<size_t>(nq), hipMemcpyDeviceToHost, st));
+    VG_HIP(hipStreamSynchronize(st));
+    for (int64_t i = 0; i < nq; i++)  // ties / NaN: the heap's history decides — replayed one query at a time (rare)
+        if (h[static_cast<size_t>(i)])
+            VG_TRY(brute_impl(idx, q.ptr + i * idx->dim, 1, k, mode, nullptr, 0, oid.ptr + i * k, osc.ptr + i * k, st));
+    VG_TRY(oid.finish());
+    VG_TRY(osc.finish());
+    return VG_OK;
+}
+
+static int32_t brute_impl(vg_index *idx, const float *queries, int64_t nq, int32_t k, int32_t mode,
                                     const uint8_t *mask, int64_t mask_stride, uint32_t *ids, float *scores, void *stream)
 {
     VG_CHECK(idx, VG_ERR_INVALID_ARG, "vg_search_hnsw_brute: NULL index");

@@ -79,6 +79,7 @@ enum Hook {
     kHookKmListAll,           // VG_KM_LIST_ALL          k-means: the matrix scores decide nothing, every point is listed
     kHookKmBf16,              // VG_KM_BF16              k-means: the bfloat16-split passes even for a single assignment
     kHookKmNoBf16,            // VG_KM_NO_BF16           k-means: fp32 matrix passes only
+    kHookBruteNoFlat,         // VG_BRUTE_NO_FLAT        vg_search_hnsw_brute: always the distance matrix + replay
     kHookPqNoMfma,            // VG_PQ_NO_MFMA           PQ Encode / Lloyd assignment by the reference-order kernels only
     kHookPqListAll,           // VG_PQ_LIST_ALL          PQ Encode / assignment: every (row, sub-quantizer) pair is listed
     kHookPqFp32Mfma,          // VG_PQ_FP32_MFMA         PQ Encode / assignment: the fp32 matrix form (pq_nominate_kernel)
