@@ -595,17 +595,26 @@ template <bool CENTROID>
 __global__ __launch_bounds__(256) void km_split_kernel(const float *__restrict__ src, int64_t rows, int dim,
                                                        uint16_t *__restrict__ dst)
 {
-    const int64_t e = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    // four elements per thread: one 16-byte load, three 8-byte stores (dim % 64 == 0: a group never straddles a row)
+    const int64_t g = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    const int64_t e = g * 4;
     if (e >= rows * dim) return;
     const int64_t r = e / dim;
     const int j = static_cast<int>(e - r * dim);
-    const float x = src[e];
-    const uint16_t hi = km_bf16_rne(x);
-    const uint16_t lo = km_bf16_rne(x - __uint_as_float(static_cast<uint32_t>(hi) << 16));
-    uint16_t *o = dst + r * 3 * dim;
-    o[j] = hi;
-    o[dim + j] = CENTROID ? hi : lo;
-    o[2 * dim + j] = CENTROID ? lo : hi;
+    const float4 x = load_stream(reinterpret_cast<const float4 *>(src + e));
+    const float xs[4] = {x.x, x.y, x.z, x.w};
+    uint16_t hi[4], lo[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        hi[t] = km_bf16_rne(xs[t]);
+        lo[t] = km_bf16_rne(xs[t] - __uint_as_float(static_cast<uint32_t>(hi[t]) << 16));
+    }
+    const uint2 h2 = make_uint2(hi[0] | (static_cast<uint32_t>(hi[1]) << 16), hi[2] | (static_cast<uint32_t>(hi[3]) << 16));
+    const uint2 l2 = make_uint2(lo[0] | (static_cast<uint32_t>(lo[1]) << 16), lo[2] | (static_cast<uint32_t>(lo[3]) << 16));
+    uint16_t *o = dst + r * 3 * dim + j;
+    *reinterpret_cast<uint2 *>(o) = h2;
+    *reinterpret_cast<uint2 *>(o + dim) = CENTROID ? h2 : l2;
+    *reinterpret_cast<uint2 *>(o + 2 * dim) = CENTROID ? l2 : h2;
 }
 
 // the centroids' side of the epilogue: cadd[c] = |c|^2 (L2) or 0 (Dot) for c < k, +Inf for the padding of the last tile;
@@ -991,7 +1000,7 @@ struct KmMfma {
         if (bf16) {
             VG_TRY(xsplit.init(static_cast<size_t>(n) * 3 * dim, st));
             VG_TRY(csplit.init(static_cast<size_t>(mtiles) * vg::kGemmBM * 3 * dim, st));
-            const int64_t tot = n * dim;
+            const int64_t tot = n * dim / 4;
             VG_LAUNCH(vg::km_split_kernel<false>, dim3(static_cast<unsigned>((tot + 255) / 256)), dim3(256), 0, st, v, n, dim,
                       xsplit.ptr);
         }
@@ -1017,7 +1026,7 @@ struct KmMfma {
         const float u = 5.9604645e-8f;
         float coef_e = 2.0f * (2.0f * dim + 16.0f) * u, coef_r = 2.0f * (dim / 64 + 32.0f) * u;
         if (bf16) {
-            const int64_t tot = static_cast<int64_t>(k) * dim;
+            const int64_t tot = static_cast<int64_t>(k) * dim / 4;
             VG_LAUNCH(vg::km_split_kernel<true>, dim3(static_cast<unsigned>((tot + 255) / 256)), dim3(256), 0, st, cent, k, dim,
                       csplit.ptr);
             auto kern = dot ? vg::km_gemm_kernel<true, true> : vg::km_gemm_kernel<false, true>;
