@@ -205,6 +205,25 @@ func (r *Resident) SearchProbed(queries []float32, nq, k, nprobes int, scan int3
 	return ids, sc, hipctx.Err(int32(st))
 }
 
+// SearchFiltered: Segment.Search with `filter segment.Filter` set (flat/segment.go:631-635, :559-561): rows whose mask bit
+// is clear are skipped.  mask: bit i of byte i/8 = filter.Matches(i), len(mask) == ceil(rows/8) for one mask (maskStride 0)
+// or (nq-1)*maskStride + ceil(rows/8) for one per query.
+func (r *Resident) SearchFiltered(queries []float32, nq, k, nprobes int, scan int32, mask []byte, maskStride int) ([]uint32, []float32, error) {
+	ids, sc := r.out(nq, k)
+	need := (r.rows + 7) / 8
+	if maskStride != 0 {
+		if maskStride < need {
+			return nil, nil, fmt.Errorf("SearchFiltered: maskStride %d is shorter than a mask (%d bytes)", maskStride, need)
+		}
+		need += (nq - 1) * maskStride
+	}
+	if len(mask) < need {
+		return nil, nil, fmt.Errorf("SearchFiltered: mask holds %d bytes, %d needed", len(mask), need)
+	}
+	st := C.vg_search_flat_filtered(r.h, fp(queries), C.int64_t(nq), C.int32_t(k), C.int32_t(nprobes), C.int32_t(scan), bp(mask), C.int64_t(maskStride), up(ids), fp(sc), nil)
+	return ids, sc, hipctx.Err(int32(st))
+}
+
 // Search: the whole of Segment.Search for a segment opened from its file: scan type / beam search by what the
 // file holds.
 func (r *Resident) Search(queries []float32, nq, k, nprobes int) ([]uint32, []float32, error) {

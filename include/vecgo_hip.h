@@ -48,8 +48,9 @@ extern "C" {
  *   1: (r04) vg_search_hnsw_brute, vg_debug_heap_replay
  *   2: (r05) vg_abi_minor itself; no other symbol added — vg_search_hnsw / _hnsw_pq answer NaN distances as the reference
  *      does, vg_kmeans_* decide assignments on the matrix cores, the k-means++ running sum of vg_pq_train is blocked
- *   3: (r05) vg_search_hnsw_filtered */
-#define VG_ABI_MINOR 3
+ *   3: (r05) vg_search_hnsw_filtered
+ *   4: (r05) vg_search_flat_filtered */
+#define VG_ABI_MINOR 4
 #define VG_INVALID_ID 0xFFFFFFFFu
 #define VG_STREAM_LEGACY ((void *)1) /* == hipStreamLegacy */
 
@@ -472,6 +473,16 @@ enum { VG_SCAN_F32 = 0, VG_SCAN_PQ = 1, VG_SCAN_SQ8 = 2 };
  * vg_search_pq_adc / vg_search_sq8.  k <= 512 (pages of 64 results), nprobes <= 64. */
 int32_t vg_search_flat_probed(vg_index *idx, const float *queries, int64_t nq, int32_t k, int32_t nprobes,
                               int32_t scan, uint32_t *ids, float *scores, void *stream);
+/* flat.Segment.Search with `filter segment.Filter` set (flat/segment.go:447): a row whose filter.Matches(rowID) is false
+ * is skipped (fp32 / PQ rows before they are scored, :631-635; SQ8 L2 rows after their batch was scored, :559-561) — the
+ * k best (score, row id) keys of the matching rows of the probed partitions, or of the whole segment when it has at most
+ * one partition.  mask: bit i of byte i/8 set = filter.Matches(i) (tombstones are the caller's: clear their bits); query q
+ * reads mask + q * mask_stride (0 = one mask for the batch, else >= ceil(rows/8)); NULL = vg_search_flat_probed.  Block
+ * skipping by field statistics (MatchesBlock, :614-628) only ever skips rows no filter bit is set for.  k <= 512,
+ * nprobes <= 64.  (VG_ABI_MINOR 4.) */
+int32_t vg_search_flat_filtered(vg_index *idx, const float *queries, int64_t nq, int32_t k, int32_t nprobes,
+                                int32_t scan, const uint8_t *mask, int64_t mask_stride, uint32_t *ids, float *scores,
+                                void *stream);
 
 /* ---- on-disk segment images --------------------------------------- */
 enum { VG_QUANT_NONE = 0, VG_QUANT_PQ = 1, VG_QUANT_SQ8 = 3, VG_QUANT_RABITQ = 5, VG_QUANT_INT4 = 6 }; /* quantization.Type, types.go:6-14 */

@@ -618,6 +618,8 @@ public:
     {
         check(vg_index_set_partitions(h_, centroids, part_offsets, num_partitions, nullptr));
     }
+    // Segment.Search with a row filter (flat/segment.go:631-635): mask bit i of byte i/8 = filter.Matches(i)
+    Result SearchFiltered(const float *queries, int64_t nq, int k, int nprobes, int scan, const uint8_t *mask, int64_t mask_stride) { return run(nq, k, [&](Result &r) { return vg_search_flat_filtered(h_, queries, nq, k, nprobes, scan, mask, mask_stride, r.ids.data(), r.scores.data(), nullptr); }); }
     Result SearchProbed(const float *queries, int64_t nq, int k, int nprobes, int scan) { return run(nq, k, [&](Result &r) { return vg_search_flat_probed(h_, queries, nq, k, nprobes, scan, r.ids.data(), r.scores.data(), nullptr); }); }
     // hnsw.Insert over the segment's rows (hnsw.go:713-984, ids and levels of ApplyInsert); replaces the segment's graph
     void BuildHNSW(int m = 32, int efConstruction = 300, int maxBatch = 8192, int growthDiv = 32)

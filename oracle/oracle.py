@@ -126,6 +126,7 @@ _sig("vgo_sq8_decode", None, _u8p, C.c_int32, _f32p, _f32p, _f32p)
 _sig("vgo_flat_search_sq8", C.c_int32, _u8p, C.c_int64, C.c_int32, _f32p, _f32p, _f32p, C.c_int32, _u32p, _f32p)
 _sig("vgo_sq8_dot", C.c_float, _f32p, _u8p, C.c_int32, _f32p, _f32p)
 _sig("vgo_flat_segment_search", C.c_int32, C.POINTER(FlatSeg), _f32p, C.c_int32, C.c_int32, _u32p, _f32p)
+_sig("vgo_flat_segment_search_filtered", C.c_int32, C.POINTER(FlatSeg), _f32p, C.c_int32, C.c_int32, _u8p, _u32p, _f32p)
 _sig("vgo_int4_l2", C.c_float, _f32p, _u8p, C.c_int64, _f32p, _f32p)
 _sig("vgo_int4_l2_batch", None, _f32p, _u8p, C.c_int64, C.c_int64, _f32p, _f32p, _f32p)
 _sig("vgo_int4_build_lut", None, _f32p, _f32p, C.c_int32, _f32p)
@@ -885,7 +886,8 @@ class FlatSegment:
         self.part_offsets = None if part_offsets is None else np.ascontiguousarray(part_offsets, np.uint32)
         self.num_partitions = 0 if self.centroids is None else self.centroids.shape[0]
 
-    def search(self, query, k, nprobes=0):
+    def search(self, query, k, nprobes=0, mask=None):
+        """mask: bool[n] = filter.Matches per row (segment.go:631-635); None = no filter"""
         q, pq_ = _f(query)
         ids = np.empty(max(k, 1), np.uint32); sc = np.empty(max(k, 1), np.float32)
         pqc = self.pq._c() if self.pq is not None else None
@@ -897,8 +899,12 @@ class FlatSegment:
                       self.num_partitions,
                       self.centroids.ctypes.data_as(_f32p) if self.centroids is not None else None,
                       self.part_offsets.ctypes.data_as(_u32p) if self.part_offsets is not None else None)
-        r = lib.vgo_flat_segment_search(C.byref(seg), pq_, k, nprobes, ids.ctypes.data_as(_u32p),
-                                        sc.ctypes.data_as(_f32p))
+        pm = None
+        if mask is not None:
+            bits_ = np.packbits(np.asarray(mask, np.bool_).reshape(self.n), bitorder="little")
+            pm = bits_.ctypes.data_as(_u8p)
+        r = lib.vgo_flat_segment_search_filtered(C.byref(seg), pq_, k, nprobes, pm, ids.ctypes.data_as(_u32p),
+                                                 sc.ctypes.data_as(_f32p))
         return ids[:r], sc[:r]
 
 

@@ -1742,6 +1742,15 @@ float vgo_sq8_dot(const float *q, const uint8_t *code, int32_t dim, const float 
 int32_t vgo_flat_segment_search(const vgo_flat_segment *s, const float *query, int32_t k, int32_t nprobes,
                                 uint32_t *ids, float *scores)
 {
+    return vgo_flat_segment_search_filtered(s, query, k, nprobes, NULL, ids, scores);
+}
+
+/* The same with `filter segment.Filter` set: a row whose filter.Matches(rowID) is false is skipped before it is scored
+ * (segment.go:631-635; the SQ8 batch branch scores the batch first and skips the row at :559-561 — the candidates are the
+ * same).  mask: bit i of byte i/8 = filter.Matches(i); NULL = no filter. */
+int32_t vgo_flat_segment_search_filtered(const vgo_flat_segment *s, const float *query, int32_t k, int32_t nprobes,
+                                         const uint8_t *mask, uint32_t *ids, float *scores)
+{
     /* segment.go:657-701: SQ8 codes first (L2Distance / DotProduct by metric), else PQ, else fp32.
      * The reference's heap direction follows the metric for every branch (:449); for a Dot- or
      * Cosine-metric PQ segment that keeps the k LARGEST squared-L2 ADC distances — restated as written. */
@@ -1774,6 +1783,7 @@ int32_t vgo_flat_segment_search(const vgo_flat_segment *s, const float *query, i
         }
         for (int64_t i = start; i < end; i++) {
             float d;
+            if (mask && !((mask[i >> 3] >> (i & 7)) & 1)) continue;
             if (use_pq)
                 d = vgo_adc_avx512(table, s->codes + i * s->pq->m, s->pq->m);
             else if (use_sq)

@@ -297,6 +297,9 @@ typedef struct {
 } vgo_flat_segment;
 int32_t vgo_flat_segment_search(const vgo_flat_segment *s, const float *query, int32_t k, int32_t nprobes,
                                 uint32_t *ids, float *scores);
+/* with a row filter (segment.go:631-635, :559-561): mask bit i of byte i/8 = filter.Matches(i); NULL = none */
+int32_t vgo_flat_segment_search_filtered(const vgo_flat_segment *s, const float *query, int32_t k, int32_t nprobes,
+                                         const uint8_t *mask, uint32_t *ids, float *scores);
 
 /* INT4 (int4_avx512.c, int4.go, kernels.go:94-103) */
 float vgo_int4_l2(const float *query, const uint8_t *code, int64_t dim, const float *min_val, const float *diff);

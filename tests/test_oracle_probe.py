@@ -90,3 +90,35 @@ def test_sq8_segments_follow_the_metric():
                      for i in range(n)], np.float32)
     order = np.lexsort((np.arange(n), -dots))[:k]
     assert np.array_equal(ids, order.astype(np.uint32)) and np.array_equal(bits(sc), bits(dots[order]))
+
+
+def test_filtered_search_is_the_search_of_the_matching_rows():
+    """segment.go:631-635: a row whose filter.Matches is false is skipped — the result is the unfiltered search of a segment
+    holding only the matching rows, ids mapped back (the (score, row id) order keeps ascending ids among ties)."""
+    rng = np.random.default_rng(3)
+    n, dim, parts, k = 900, 24, 6, 12
+    x, cent, off = grouped(rng, n, dim, parts)
+    x[100:140] = x[100]                                              # ties across the filter
+    seg = o.FlatSegment(x, dim, centroids=cent, part_offsets=off)
+    full = o.FlatSegment(x, dim)
+    for t in range(4):
+        q = rng.standard_normal(dim).astype(np.float32) if t else x[100].copy()
+        mask = rng.random(n) < (0.5, 0.5, 0.05, 0.0)[t]
+        rows = np.flatnonzero(mask)
+        ids, sc = full.search(q, k, mask=mask)
+        if rows.size == 0:
+            assert ids.size == 0
+            continue
+        sid, ssc = o.flat_search_f32(x[rows], dim, q, k)
+        assert np.array_equal(rows[sid], ids) and np.array_equal(bits(ssc), bits(sc))
+        probed = o.find_closest_centroids(q, cent, dim, 2)
+        in_probed = np.zeros(n, bool)
+        for p in probed:
+            in_probed[off[p]:off[p + 1]] = True
+        rows = np.flatnonzero(mask & in_probed)
+        ids, sc = seg.search(q, k, 2, mask=mask)
+        sid, ssc = o.flat_search_f32(x[rows], dim, q, k)
+        assert np.array_equal(rows[sid], ids) and np.array_equal(bits(ssc), bits(sc))
+    all_ids, all_sc = full.search(q, k, mask=np.ones(n, bool))
+    nid, nsc = full.search(q, k)
+    assert np.array_equal(all_ids, nid) and np.array_equal(bits(all_sc), bits(nsc))

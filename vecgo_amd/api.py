@@ -947,6 +947,17 @@ class Index:
         return self._search(self._lib.vg_search_flat_probed, queries, k, extra=(C.c_int32(nprobes), C.c_int32(scan)),
                             out=out, stream=stream)
 
+    def search_flat_filtered(self, queries, k, mask, nprobes=0, scan=0, out=None, stream=None):
+        """flat.Segment.Search with a row filter (flat/segment.go:631-635, :559-561): the k best (score, row id) among the
+        rows whose mask entry is set, over the probed partitions or the whole segment.  mask: bool[n] / packed bits for the
+        batch, or bool[nq, n] / packed [nq, ceil(n/8)] for one filter per query; None = search_flat_probed."""
+        if mask is None:
+            return self.search_flat_probed(queries, k, nprobes, scan, out=out, stream=stream)
+        m, stride = self._packed_mask(mask, _rows(queries, self.dim), "search_flat_filtered")
+        return self._search(self._lib.vg_search_flat_filtered, queries, k,
+                            extra=(C.c_int32(nprobes), C.c_int32(scan), C.c_void_p(m.ctypes.data), C.c_int64(stride)),
+                            out=out, stream=stream)
+
     def search_sq8(self, queries, k, out=None, stream=None):
         """flat.Segment.Search SQ8 branch (flat/segment.go:517-604)."""
         return self._search(self._lib.vg_search_sq8, queries, k, out=out, stream=stream)

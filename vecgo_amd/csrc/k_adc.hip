@@ -630,7 +630,8 @@ int32_t launch_pq_build_table(const vg_pq *pq, const float *d_queries, int64_t n
 __global__ __launch_bounds__(kAdcThreads) void pq_adc_probe_kernel(
     const uint4 *__restrict__ tiles, int64_t n_rows, int m, int groups, const float *__restrict__ tables,
     const uint32_t *__restrict__ probes, const uint32_t *__restrict__ part_off, int np, int split, int k,
-    uint64_t *__restrict__ partial, const uint64_t *__restrict__ min_keys, bool desc)
+    uint64_t *__restrict__ partial, const uint64_t *__restrict__ min_keys, bool desc, const uint8_t *__restrict__ mask,
+    int64_t mask_stride)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float *lut = reinterpret_cast<float *>(smem);
@@ -658,6 +659,7 @@ __global__ __launch_bounds__(kAdcThreads) void pq_adc_probe_kernel(
     }
     __syncthreads();
     const int gfull = m >> 4, tail = m & 15;
+    const uint8_t *mq = mask ? mask + q * mask_stride : nullptr;  // filter.Matches (segment.go:631-635)
     WaveTopK wtk;
     wtk.init(k);
     for (int j = y; j < np; j += split) {
@@ -666,6 +668,9 @@ __global__ __launch_bounds__(kAdcThreads) void pq_adc_probe_kernel(
         const int64_t tt0 = R0 >> 6, tt1 = (R1 + 63) >> 6;
         for (int64_t tile = tt0 + wave; tile < tt1; tile += kAdcWaves) {
             const uint4 *tp = tiles + (tile * groups) * 64 + lane;
+            const int64_t row = tile * 64 + lane;
+            const bool live = row >= R0 && row < R1 && row < n_rows && mask_bit(mq, row);
+            if (mq && !__any(live)) continue;  // a tile the filter leaves nothing of: its codes are not read
             float acc[16];
 #pragma unroll
             for (int l = 0; l < 16; l++) acc[l] = 0.0f;
@@ -680,8 +685,7 @@ __global__ __launch_bounds__(kAdcThreads) void pq_adc_probe_kernel(
                 const uint4 c = tp[gfull * 64];
                 for (int l = 0; l < tail; l++) total = total + lut[lut_tail_word + l * 256 + code_byte(c, l)];
             }
-            const int64_t row = tile * 64 + lane;
-            uint64_t key = row >= R0 && row < R1 && row < n_rows ? make_key(total, static_cast<uint32_t>(row), desc) : kKeyMax;
+            uint64_t key = live ? make_key(total, static_cast<uint32_t>(row), desc) : kKeyMax;
             if (min_keys && key <= min_keys[q]) key = kKeyMax;  // paged results (k > 64)
             wtk.offer(key, lane);
         }
@@ -690,8 +694,9 @@ __global__ __launch_bounds__(kAdcThreads) void pq_adc_probe_kernel(
                              partial + (q * split + y) * k);
 }
 
-int32_t launch_probe_scan_adc(const vg_index *idx, const float *tables, const uint32_t *probes, int64_t nq, int np,
-                              int split, int k, uint64_t *partial, const uint64_t *min_keys, bool desc, hipStream_t st)
+int32_t launch_probe_scan_adc(const vg_index *idx, const float *tables, const uint32_t *probes, const uint32_t *part_off,
+                              int64_t nq, int np, int split, int k, uint64_t *partial, const uint64_t *min_keys, bool desc,
+                              const uint8_t *mask, int64_t mask_stride, hipStream_t st)
 {
     const vg_pq *pq = idx->pq;
     const size_t lds = static_cast<size_t>(lut_image_words(pq->m)) * sizeof(float) + kAdcWaves * 64 * sizeof(uint64_t) + 64;
@@ -702,8 +707,9 @@ int32_t launch_probe_scan_adc(const vg_index *idx, const float *tables, const ui
         ProfScope prof(idx->ctx, "pq_adc_probe", st);
         VG_LAUNCH(pq_adc_probe_kernel, dim3(static_cast<unsigned>(split), static_cast<unsigned>(cnt)), dim3(kAdcThreads),
                   lds, st, reinterpret_cast<const uint4 *>(idx->d_pq_tiles), idx->n, pq->m, idx->pq_groups,
-                  tables + q0 * lut_image_words(pq->m), probes + q0 * np, idx->d_part_off, np, split, k,
-                  partial + q0 * split * k, min_keys ? min_keys + q0 : nullptr, desc);
+                  tables + q0 * lut_image_words(pq->m), probes + q0 * np, part_off, np, split, k,
+                  partial + q0 * split * k, min_keys ? min_keys + q0 : nullptr, desc, mask ? mask + q0 * mask_stride : nullptr,
+                  mask_stride);
     }
     return VG_OK;
 }

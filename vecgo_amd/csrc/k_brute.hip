@@ -33,11 +33,6 @@ constexpr int kBruteMaxK = 1024;
 constexpr int kBruteDistThreads = 256;           // 16 pair-groups per workgroup
 constexpr int kBruteRowsPerBlock = 1024;
 
-__device__ __forceinline__ bool mask_bit(const uint8_t *__restrict__ mask, int64_t i)
-{
-    return mask == nullptr || ((mask[i >> 3] >> (i & 7)) & 1);
-}
-
 // dist[q][i] for the rows of block y; blockIdx.x = query (consecutive workgroups share a slice of rows through L2)
 // STREAM: one query — every row is read exactly once: nontemporal loads (0.535 -> 0.467 ms per 1M x 768 = 6.57 TB/s);
 // several queries with their own masks share rows through L2 and keep the cached loads

@@ -20,13 +20,16 @@ int32_t launch_topk_merge(const uint64_t *partial, int64_t nq, int lists, int k,
                           const int *always = nullptr);
 int32_t launch_pq_build_table(const vg_pq *pq, const float *d_queries, int64_t nq, float *d_tables,
                               bool scan_layout, hipStream_t st);
-int32_t launch_probe_scan_adc(const vg_index *idx, const float *tables, const uint32_t *probes, int64_t nq, int np,
-                              int split, int k, uint64_t *partial, const uint64_t *min_keys, bool desc, hipStream_t st);
-int32_t launch_probe_scan_sq8(const vg_index *idx, const float *queries, const uint32_t *probes, int64_t nq, int np,
-                              int sub, int k, uint64_t *partial, const uint64_t *min_keys, hipStream_t st);
-int32_t launch_probe_scan_sq8_grouped(const vg_index *idx, const float *queries, const uint32_t *pair_of,
-                                      const ProbeGroup *groups, const uint32_t *ngroups, unsigned gmax, int np, int sub,
-                                      int k, uint64_t *partial, const uint64_t *min_keys, hipStream_t st);
+int32_t launch_probe_scan_adc(const vg_index *idx, const float *tables, const uint32_t *probes, const uint32_t *part_off,
+                              int64_t nq, int np, int split, int k, uint64_t *partial, const uint64_t *min_keys, bool desc,
+                              const uint8_t *mask, int64_t mask_stride, hipStream_t st);
+int32_t launch_probe_scan_sq8(const vg_index *idx, const float *queries, const uint32_t *probes, const uint32_t *part_off,
+                              int64_t nq, int np, int sub, int k, uint64_t *partial, const uint64_t *min_keys,
+                              const uint8_t *mask, int64_t mask_stride, hipStream_t st);
+int32_t launch_probe_scan_sq8_grouped(const vg_index *idx, const float *queries, const uint32_t *part_off,
+                                      const uint32_t *pair_of, const ProbeGroup *groups, const uint32_t *ngroups, unsigned gmax,
+                                      int np, int sub, int k, uint64_t *partial, const uint64_t *min_keys, const uint8_t *mask,
+                                      int64_t mask_stride, hipStream_t st);
 int32_t launch_page_patch(int64_t nq, int k, int off, int kk, bool descending, const int *always_one,
                           const uint32_t *fids, const float *fscores, uint32_t *ids, float *scores, uint64_t *min_keys,
                           hipStream_t st);
@@ -63,13 +66,17 @@ __global__ __launch_bounds__(256) void probe_select_kernel(const float *__restri
 }
 
 // ---- 2. fp32 scan of one probed partition (segment.go:691-701) ------------------------------------
-template <bool DOT>
+// MASKED (filter.Matches, segment.go:631-635: a row that fails is skipped unscored): every 16-lane group walks its own
+// stream of rows (r0 + 4 * wave + group, step 16) and jumps over the rows whose bit is clear, so both the bytes and the
+// arithmetic follow the filter's selectivity; which group scores a row does not matter, the key order is total.
+template <bool DOT, bool MASKED>
 __global__ __launch_bounds__(256) void probe_scan_f32_kernel(const float *__restrict__ base, int dim,
                                                              const float *__restrict__ queries,
                                                              const uint32_t *__restrict__ probes,
                                                              const uint32_t *__restrict__ part_off, int np, int sub_n,
                                                              int k, uint64_t *__restrict__ partial,
-                                                             const uint64_t *__restrict__ min_keys)
+                                                             const uint64_t *__restrict__ min_keys,
+                                                             const uint8_t *__restrict__ mask, int64_t mask_stride)
 {
     __shared__ uint64_t lists[4 * 64];
     __shared__ int valid[4];
@@ -81,10 +88,18 @@ __global__ __launch_bounds__(256) void probe_scan_f32_kernel(const float *__rest
     const int64_t R0 = part_off[p], R1 = part_off[p + 1];
     const int64_t r0 = R0 + (R1 - R0) * s / sub_n, r1 = R0 + (R1 - R0) * (s + 1) / sub_n;
     const float *qv = queries + q * dim;
+    const uint8_t *mq = mask ? mask + q * mask_stride : nullptr;  // filter.Matches (segment.go:631-635): skipped unscored
     WaveTopK tk;
     tk.init(k);
-    for (int64_t i0 = r0 + wave * 4; i0 < r1; i0 += 16) {  // 4 rows per wave step, one per 16-lane group
-        const int64_t i = i0 + (lane >> 4);
+    int64_t cur = r0 + wave * 4 + (lane >> 4);
+    for (int64_t i0 = r0 + wave * 4; MASKED || i0 < r1; i0 += 16) {  // 4 rows per wave step, one per 16-lane group
+        int64_t i = i0 + (lane >> 4);
+        if (MASKED) {
+            while (cur < r1 && !mask_bit(mq, cur)) cur += 16;
+            i = cur;
+            cur += 16;
+            if (!__any(i < r1)) break;
+        }
         uint64_t key = kKeyMax;
         if (i < r1) {
             const float v = exact_pair16<DOT, kPair>(base + i * dim, qv, dim, sub);
@@ -158,7 +173,7 @@ __global__ __launch_bounds__(1024) void probe_group_kernel(const uint32_t *__res
     for (int64_t i = tid; i < pairs; i += 1024) pair_of[atomicAdd(&cursor[probes[i]], 1u)] = static_cast<uint32_t>(i);
 }
 
-template <bool DOT>
+template <bool DOT, bool MASKED>
 __global__ __launch_bounds__(256) void probe_scan_f32_mq_kernel(const float *__restrict__ base, int dim,
                                                                 const float *__restrict__ queries,
                                                                 const uint32_t *__restrict__ part_off,
@@ -166,18 +181,23 @@ __global__ __launch_bounds__(256) void probe_scan_f32_mq_kernel(const float *__r
                                                                 const ProbeGroup *__restrict__ groups,
                                                                 const uint32_t *__restrict__ ngroups, int np,
                                                                 int sub_n, int k, uint64_t *__restrict__ partial,
-                                                                const uint64_t *__restrict__ min_keys)
+                                                                const uint64_t *__restrict__ min_keys,
+                                                                const uint8_t *__restrict__ mask, int64_t mask_stride)
 {
     extern __shared__ float qlds[];  // kProbeQB * dim floats, then the merge scratch
     uint64_t *lists = reinterpret_cast<uint64_t *>(qlds + static_cast<size_t>(kProbeQB) * dim);
     int *valid = reinterpret_cast<int *>(lists + 4 * 64);
     __shared__ uint32_t pair[kProbeQB];
+    __shared__ uint32_t qof[kProbeQB];  // the pairs' queries
     if (blockIdx.y >= ngroups[0]) return;
     const ProbeGroup g = groups[blockIdx.y];
     const int s = blockIdx.x;
     const int cnt = static_cast<int>(g.count);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid < cnt) pair[tid] = pair_of[g.first + tid];
+    if (tid < cnt) {
+        pair[tid] = pair_of[g.first + tid];
+        qof[tid] = pair[tid] / np;
+    }
     __syncthreads();
     for (int qi = 0; qi < cnt; qi++) {
         const float *src = queries + static_cast<int64_t>(pair[qi] / np) * dim;
@@ -191,9 +211,30 @@ __global__ __launch_bounds__(256) void probe_scan_f32_mq_kernel(const float *__r
     WaveTopK tk[kProbeQB];
 #pragma unroll
     for (int qi = 0; qi < kProbeQB; qi++) tk[qi].init(k);
+    // MASKED: a row some query of the group wants (its filter bit is set, segment.go:631-635) — the 16-lane groups each walk
+    // their own stream of rows (r0 + 4 * wave + group, step 16) and jump over the others, so bytes and arithmetic follow the
+    // selectivity; the per-query bit is checked again where the key is made
+    auto wanted = [&](int64_t r) {
+        if (mask_stride == 0) return mask_bit(mask, r);
+        bool w = false;
+        for (int qi = 0; qi < cnt; qi++) w = w || mask_bit(mask + static_cast<int64_t>(qof[qi]) * mask_stride, r);
+        return w;
+    };
+    int64_t cur = r0 + wave * 4 + (lane >> 4);
+    auto next_wanted = [&]() {
+        while (cur < r1 && !wanted(cur)) cur += 16;
+        const int64_t r = cur < r1 ? cur : r1;
+        cur += 16;
+        return r;
+    };
     // a wave step = 8 rows, two per 16-lane group (rows i and i + 4): each LDS read of a query is used twice
-    for (int64_t i0 = r0 + wave * 8; i0 < r1; i0 += 32) {
-        const int64_t ia = i0 + (lane >> 4), ib = ia + 4;
+    for (int64_t i0 = r0 + wave * 8; MASKED || i0 < r1; i0 += 32) {
+        int64_t ia = i0 + (lane >> 4), ib = ia + 4;
+        if (MASKED) {
+            ia = next_wanted();
+            ib = next_wanted();
+            if (!__any(ia < r1)) break;
+        }
         const bool livea = ia < r1, liveb = ib < r1;
         const float *rowa = base + (livea ? ia : r1 - 1) * dim;
         const float *rowb = base + (liveb ? ib : r1 - 1) * dim;
@@ -213,7 +254,10 @@ __global__ __launch_bounds__(256) void probe_scan_f32_mq_kernel(const float *__r
             uint64_t key = kKeyMax;
             if ((lane & 15) == 0 && livea) key = make_key(va, static_cast<uint32_t>(ia), DOT);
             if ((lane & 15) == 1 && liveb) key = make_key(vb, static_cast<uint32_t>(ib), DOT);
-            if (min_keys && key != kKeyMax && key <= min_keys[pair[qi] / np]) key = kKeyMax;  // paged results (k > 64)
+            if (min_keys && key != kKeyMax && key <= min_keys[qof[qi]]) key = kKeyMax;  // paged results (k > 64)
+            if (MASKED && mask_stride != 0 && key != kKeyMax &&  // each query its own filter
+                !mask_bit(mask + static_cast<int64_t>(qof[qi]) * mask_stride, (lane & 15) == 0 ? ia : ib))
+                key = kKeyMax;
             return key;
         };
         if (cnt == kProbeQB) {  // a full group: no per-query branches, the scores of all the queries first
@@ -236,6 +280,17 @@ __global__ __launch_bounds__(256) void probe_scan_f32_mq_kernel(const float *__r
             __syncthreads();
         }
     }
+}
+
+// A filtered search of an unpartitioned segment (segment.go:745-749 with `filter` set): ONE range, the whole segment.  The
+// heap order is total, so the range is cut into `parts` equal pieces scanned like probed partitions — every query "probes"
+// all of them — to spread the rows over the device.
+__global__ void probe_whole_segment_kernel(int64_t n, int parts, int64_t pairs, uint32_t *__restrict__ part_off,
+                                           uint32_t *__restrict__ probes)
+{
+    const int64_t t = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (t <= parts) part_off[t] = static_cast<uint32_t>(n * t / parts);
+    if (t < pairs) probes[t] = static_cast<uint32_t>(t % parts);
 }
 
 }  // namespace vg
@@ -273,13 +328,35 @@ VG_API int32_t vg_index_set_partitions(vg_index *idx, const float *centroids, co
     return VG_OK;
 }
 
+static int32_t flat_probed_impl(vg_index *idx, const float *queries, int64_t nq, int32_t k, int32_t nprobes, int32_t scan,
+                                const uint8_t *mask, int64_t mask_stride, uint32_t *ids, float *scores, void *stream);
+
 VG_API int32_t vg_search_flat_probed(vg_index *idx, const float *queries, int64_t nq, int32_t k, int32_t nprobes,
                                      int32_t scan, uint32_t *ids, float *scores, void *stream)
+{
+    return flat_probed_impl(idx, queries, nq, k, nprobes, scan, nullptr, 0, ids, scores, stream);
+}
+
+VG_API int32_t vg_search_flat_filtered(vg_index *idx, const float *queries, int64_t nq, int32_t k, int32_t nprobes,
+                                       int32_t scan, const uint8_t *mask, int64_t mask_stride, uint32_t *ids, float *scores,
+                                       void *stream)
+{
+    VG_CHECK(idx, VG_ERR_INVALID_ARG, "vg_search_flat_filtered: NULL index");
+    const int64_t mask_bytes = (idx->n + 7) / 8;
+    VG_CHECK(mask == nullptr || mask_stride == 0 || mask_stride >= mask_bytes, VG_ERR_INVALID_ARG,
+             "vg_search_flat_filtered: mask_stride %lld is shorter than a mask (%lld bytes)", static_cast<long long>(mask_stride),
+             static_cast<long long>(mask_bytes));
+    return flat_probed_impl(idx, queries, nq, k, nprobes, scan, mask, mask_stride, ids, scores, stream);
+}
+
+static int32_t flat_probed_impl(vg_index *idx, const float *queries, int64_t nq, int32_t k, int32_t nprobes, int32_t scan,
+                                const uint8_t *mask, int64_t mask_stride, uint32_t *ids, float *scores, void *stream)
 {
     VG_CHECK(idx, VG_ERR_INVALID_ARG, "vg_search_flat_probed: NULL index");
     VG_CHECK(scan == VG_SCAN_F32 || scan == VG_SCAN_PQ || scan == VG_SCAN_SQ8, VG_ERR_INVALID_ARG,
              "vg_search_flat_probed: unknown scan type %d", scan);
-    if (idx->num_partitions <= 1) {  // segment.go:745-749: one range, the whole segment
+    const bool whole = idx->num_partitions <= 1;  // segment.go:745-749: one range, the whole segment
+    if (whole && mask == nullptr) {
         if (scan == VG_SCAN_PQ) return vg_search_pq_adc(idx, queries, nq, k, ids, scores, stream);
         if (scan == VG_SCAN_SQ8) return vg_search_sq8(idx, queries, nq, k, ids, scores, stream);
         return vg_search_flat(idx, queries, nq, k, ids, scores, stream);
@@ -291,6 +368,9 @@ VG_API int32_t vg_search_flat_probed(vg_index *idx, const float *queries, int64_
     VG_CHECK(idx->metric != VG_METRIC_HAMMING, VG_ERR_UNSUPPORTED, "unsupported metric for float32: Hamming");
     int np = nprobes <= 0 ? 1 : nprobes;  // segment.go:728-731
     if (np > idx->num_partitions) np = idx->num_partitions;  // kmeans.go:219-221
+    // filtered and unpartitioned: the one range in up to 64 pieces of at least 4096 rows (probe_whole_segment_kernel)
+    const int parts = whole ? static_cast<int>(std::min<int64_t>(64, std::max<int64_t>(1, idx->n / 4096))) : idx->num_partitions;
+    if (whole) np = parts;
     VG_CHECK(np <= 64, VG_ERR_UNSUPPORTED, "vg_search_flat_probed: nprobes=%d exceeds 64", np);
     const bool dot = idx->metric != VG_METRIC_L2;
     if (scan == VG_SCAN_F32) {
@@ -310,12 +390,16 @@ VG_API int32_t vg_search_flat_probed(vg_index *idx, const float *queries, int64_
     VG_TRY(q.init(queries, static_cast<size_t>(nq) * idx->dim, st));
     VG_TRY(oid.init(ids, static_cast<size_t>(nq) * k, st));
     VG_TRY(osc.init(scores, static_cast<size_t>(nq) * k, st));
+    vg::DevIn<uint8_t> mk;
+    const int64_t mask_bytes = (idx->n + 7) / 8;
+    VG_TRY(mk.init(mask, mask ? static_cast<size_t>(mask_stride ? (nq - 1) * mask_stride + mask_bytes : mask_bytes) : 0, st));
 
     // enough workgroups to fill the device when there are few (query, probe) pairs
     const int64_t pairs = nq * np;
     // fp32: with enough pairs the queries are grouped by partition (rows read once per group); the
     // row-in-registers scan needs 16-byte aligned rows of at most 1024 floats
-    const bool group_ok = pairs >= 16 && !vg::hook(vg::kHookProbeNoGroup);  // test hook: one pass per (query, probe) pair
+    // (a filtered whole segment is "probed" in every piece by every query: grouping pays from a handful of queries on)
+    const bool group_ok = (whole ? nq >= 4 : pairs >= 16) && !vg::hook(vg::kHookProbeNoGroup);  // test hook: one pass per pair
     const bool grouped_f32 = scan == VG_SCAN_F32 && group_ok && idx->dim % 4 == 0 && idx->dim <= 1024 &&
                              (reinterpret_cast<uintptr_t>(idx->d_vectors) & 15) == 0;
     // SQ8: the group's queries (padded to whole 16-dimension groups) have to fit LDS next to the merge scratch
@@ -326,7 +410,7 @@ VG_API int32_t vg_search_flat_probed(vg_index *idx, const float *queries, int64_
     int sub = static_cast<int>(std::min<int64_t>(32, std::max<int64_t>(1, (want + pairs - 1) / pairs)));
     int split = static_cast<int>(std::min<int64_t>(np, std::max<int64_t>(1, (idx->ctx->compute_units + nq - 1) / nq)));
     if (grouped) {  // workgroups are (group of up to kProbeQB pairs) x slice: size the slices for the groups
-        const int64_t g_est = std::max<int64_t>(1, pairs / vg::kProbeQB) + std::min<int64_t>(idx->num_partitions, pairs) / 2;
+        const int64_t g_est = std::max<int64_t>(1, pairs / vg::kProbeQB) + std::min<int64_t>(parts, pairs) / 2;
         sub = static_cast<int>(std::min<int64_t>(32, std::max<int64_t>(1, (want + g_est - 1) / g_est)));
     }
     const int lists = scan == VG_SCAN_PQ ? split : np * sub;
@@ -334,7 +418,7 @@ VG_API int32_t vg_search_flat_probed(vg_index *idx, const float *queries, int64_
 
     const int64_t qchunk = std::max<int64_t>(1, 65535 / np);
     const int64_t chunk_pairs = std::min<int64_t>(nq, qchunk) * np;
-    const size_t gwords = grouped ? static_cast<size_t>(idx->num_partitions) + 1 : 0;
+    const size_t gwords = grouped ? static_cast<size_t>(parts) + 1 : 0;
 
     vg::ArenaCall ar(idx->ctx, st);
     const int i_gcounts = ar.add(sizeof(uint32_t) * gwords);
@@ -352,6 +436,7 @@ VG_API int32_t vg_search_flat_probed(vg_index *idx, const float *queries, int64_
     const int i_floor = ar.add(paged ? sizeof(uint64_t) * static_cast<size_t>(nq) : 0);
     const int i_one = ar.add(paged ? 256 : 0);
     const int i_tables = ar.add(sizeof(float) * static_cast<size_t>(nq) * lut_words);
+    const int i_whole = ar.add(whole ? sizeof(uint32_t) * (static_cast<size_t>(parts) + 1) : 0);
     VG_TRY(ar.commit());
     uint32_t *probes = ar.get<uint32_t>(i_probes);
     uint64_t *partial = ar.get<uint64_t>(i_partial);
@@ -365,17 +450,24 @@ VG_API int32_t vg_search_flat_probed(vg_index *idx, const float *queries, int64_
     uint32_t *ngroups = ar.get<uint32_t>(i_ngroups);
     vg::ProbeGroup *groups = ar.get<vg::ProbeGroup>(i_groups);
 
-    if (dot)
+    const uint32_t *part_off = whole ? ar.get<uint32_t>(i_whole) : idx->d_part_off;
+    if (whole) {
+        const int64_t threads = std::max<int64_t>(pairs, parts + 1);
+        VG_LAUNCH(vg::probe_whole_segment_kernel, dim3(static_cast<unsigned>((threads + 255) / 256)), dim3(256), 0, st, idx->n, parts,
+                  pairs, ar.get<uint32_t>(i_whole), probes);
+    } else if (dot) {
         VG_LAUNCH(vg::probe_select_kernel<true>, dim3(static_cast<unsigned>(nq)), dim3(256), 0, st, q.ptr, idx->dim,
                   idx->d_centroids, idx->num_partitions, np, probes);
-    else
+    } else {
         VG_LAUNCH(vg::probe_select_kernel<false>, dim3(static_cast<unsigned>(nq)), dim3(256), 0, st, q.ptr, idx->dim,
                   idx->d_centroids, idx->num_partitions, np, probes);
+    }
     // the heap direction follows the segment metric for EVERY scan (flat/segment.go:449): with Dot / Cosine a PQ
     // scan therefore keeps the k LARGEST table-lookup (squared-L2) distances — the reference as written
     const bool desc = dot;
     const size_t mq_lds = sizeof(float) * vg::kProbeQB * static_cast<size_t>(idx->dim) + 4 * 64 * sizeof(uint64_t) + 64;
-    auto mq_kern = dot ? vg::probe_scan_f32_mq_kernel<true> : vg::probe_scan_f32_mq_kernel<false>;
+    auto mq_kern = mk.ptr ? (dot ? vg::probe_scan_f32_mq_kernel<true, true> : vg::probe_scan_f32_mq_kernel<false, true>)
+                          : (dot ? vg::probe_scan_f32_mq_kernel<true, false> : vg::probe_scan_f32_mq_kernel<false, false>);
     if (grouped_f32)
         VG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(mq_kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    static_cast<int>(mq_lds)));
@@ -390,33 +482,38 @@ VG_API int32_t vg_search_flat_probed(vg_index *idx, const float *queries, int64_
             for (int64_t q0 = 0; q0 < nq; q0 += qchunk) {
                 const int64_t cnt = std::min<int64_t>(qchunk, nq - q0);
                 const int64_t cpairs = cnt * np;
-                const unsigned gmax = static_cast<unsigned>(std::min<int64_t>(cpairs, cpairs / vg::kProbeQB + idx->num_partitions));
-                VG_HIP(hipMemsetAsync(gcounts, 0, sizeof(uint32_t) * (static_cast<size_t>(idx->num_partitions) + 1), st));
-                VG_LAUNCH(vg::probe_group_kernel, dim3(1), dim3(1024), 0, st, probes + q0 * np, cpairs, idx->num_partitions,
-                          gcounts, gcursor, gstart, pair_of, groups, ngroups);
+                const unsigned gmax = static_cast<unsigned>(std::min<int64_t>(cpairs, cpairs / vg::kProbeQB + parts));
+                const uint8_t *m0 = mk.ptr ? mk.ptr + q0 * mask_stride : nullptr;
+                VG_HIP(hipMemsetAsync(gcounts, 0, sizeof(uint32_t) * (static_cast<size_t>(parts) + 1), st));
+                VG_LAUNCH(vg::probe_group_kernel, dim3(1), dim3(1024), 0, st, probes + q0 * np, cpairs, parts, gcounts, gcursor,
+                          gstart, pair_of, groups, ngroups);
                 if (grouped_sq8) {
-                    VG_TRY(vg::launch_probe_scan_sq8_grouped(idx, q.ptr + q0 * idx->dim, pair_of, groups, ngroups, gmax, np, sub, kk,
-                                                             partial + q0 * lists * kk, floor ? floor + q0 : nullptr, st));
+                    VG_TRY(vg::launch_probe_scan_sq8_grouped(idx, q.ptr + q0 * idx->dim, part_off, pair_of, groups, ngroups, gmax, np,
+                                                             sub, kk, partial + q0 * lists * kk, floor ? floor + q0 : nullptr, m0,
+                                                             mask_stride, st));
                     continue;
                 }
                 vg::ProfScope prof(idx->ctx, "flat_probe", st);
                 VG_LAUNCH(mq_kern, dim3(static_cast<unsigned>(sub), gmax), dim3(256), mq_lds, st, idx->d_vectors, idx->dim,
-                          q.ptr + q0 * idx->dim, idx->d_part_off, pair_of, groups, ngroups, np, sub, kk,
-                          partial + q0 * lists * kk, floor ? floor + q0 : nullptr);
+                          q.ptr + q0 * idx->dim, part_off, pair_of, groups, ngroups, np, sub, kk,
+                          partial + q0 * lists * kk, floor ? floor + q0 : nullptr, m0, mask_stride);
             }
         } else if (scan == VG_SCAN_F32) {
             for (int64_t q0 = 0; q0 < nq; q0 += 65535) {
                 const int64_t cnt = std::min<int64_t>(65535, nq - q0);
                 const dim3 grid(static_cast<unsigned>(sub), static_cast<unsigned>(np), static_cast<unsigned>(cnt));
                 vg::ProfScope prof(idx->ctx, "flat_probe", st);
-                auto kern = dot ? vg::probe_scan_f32_kernel<true> : vg::probe_scan_f32_kernel<false>;
+                auto kern = mk.ptr ? (dot ? vg::probe_scan_f32_kernel<true, true> : vg::probe_scan_f32_kernel<false, true>)
+                                   : (dot ? vg::probe_scan_f32_kernel<true, false> : vg::probe_scan_f32_kernel<false, false>);
                 VG_LAUNCH(kern, grid, dim3(256), 0, st, idx->d_vectors, idx->dim, q.ptr + q0 * idx->dim, probes + q0 * np,
-                          idx->d_part_off, np, sub, kk, partial + q0 * lists * kk, floor ? floor + q0 : nullptr);
+                          part_off, np, sub, kk, partial + q0 * lists * kk, floor ? floor + q0 : nullptr,
+                          mk.ptr ? mk.ptr + q0 * mask_stride : nullptr, mask_stride);
             }
         } else if (scan == VG_SCAN_PQ) {
-            VG_TRY(vg::launch_probe_scan_adc(idx, tables, probes, nq, np, split, kk, partial, floor, desc, st));
+            VG_TRY(vg::launch_probe_scan_adc(idx, tables, probes, part_off, nq, np, split, kk, partial, floor, desc, mk.ptr,
+                                             mask_stride, st));
         } else {
-            VG_TRY(vg::launch_probe_scan_sq8(idx, q.ptr, probes, nq, np, sub, kk, partial, floor, st));
+            VG_TRY(vg::launch_probe_scan_sq8(idx, q.ptr, probes, part_off, nq, np, sub, kk, partial, floor, mk.ptr, mask_stride, st));
         }
         if (!paged) {
             VG_TRY(vg::launch_topk_merge(partial, nq, lists, k, desc, oid.ptr, osc.ptr, st));

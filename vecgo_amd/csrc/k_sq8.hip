@@ -495,7 +495,7 @@ __global__ __launch_bounds__(kSqThreads) void sq8_probe_kernel(
     const uint4 *__restrict__ tiles, int64_t n_rows, int groups, int dim, const float *__restrict__ queries,
     const float *__restrict__ mins, const float *__restrict__ inv, const uint32_t *__restrict__ probes,
     const uint32_t *__restrict__ part_off, int np, int sub, int k, uint64_t *__restrict__ partial,
-    const uint64_t *__restrict__ min_keys)
+    const uint64_t *__restrict__ min_keys, const uint8_t *__restrict__ mask, int64_t mask_stride)
 {
     __shared__ uint64_t lists[kSqWaves * 64];
     __shared__ int valid[kSqWaves];
@@ -507,13 +507,17 @@ __global__ __launch_bounds__(kSqThreads) void sq8_probe_kernel(
     const int64_t t0 = tt0 + (tt1 - tt0) * s / sub, t1 = tt0 + (tt1 - tt0) * (s + 1) / sub;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float *qv = queries + q * dim;
+    const uint8_t *mq = mask ? mask + q * mask_stride : nullptr;
     const int full = dim >> 4, tail = dim & 15;
     WaveTopK tk;
     tk.init(k);
     for (int64_t tile = t0 + wave; tile < t1; tile += kSqWaves) {
-        const float total = sq8_row_score<DOT>(tiles + (tile * groups) * 64 + lane, groups, full, tail, qv, mins, inv);
         const int64_t row = tile * 64 + lane;
-        uint64_t key = row >= R0 && row < R1 && row < n_rows ? make_key(total, static_cast<uint32_t>(row), DOT) : kKeyMax;
+        // filter.Matches after the batch was scored (segment.go:559-561): the candidates are the rows that pass
+        const bool live = row >= R0 && row < R1 && row < n_rows && mask_bit(mq, row);
+        if (mq && !__any(live)) continue;  // a tile the filter leaves nothing of: its codes are not read
+        const float total = sq8_row_score<DOT>(tiles + (tile * groups) * 64 + lane, groups, full, tail, qv, mins, inv);
+        uint64_t key = live ? make_key(total, static_cast<uint32_t>(row), DOT) : kKeyMax;
         if (min_keys && key <= min_keys[q]) key = kKeyMax;  // paged results (k > 64)
         tk.offer(key, lane);
     }
@@ -672,7 +676,8 @@ __global__ __launch_bounds__(kSqThreads) void sq8_probe_mq_kernel(
     const uint4 *__restrict__ tiles, int64_t n_rows, int groups, int dim, const float *__restrict__ queries,
     const float *__restrict__ mins, const float *__restrict__ inv, const uint32_t *__restrict__ part_off,
     const uint32_t *__restrict__ pair_of, const ProbeGroup *__restrict__ pgroups, const uint32_t *__restrict__ ngroups,
-    int np, int sub, int k, uint64_t *__restrict__ partial, const uint64_t *__restrict__ min_keys)
+    int np, int sub, int k, uint64_t *__restrict__ partial, const uint64_t *__restrict__ min_keys,
+    const uint8_t *__restrict__ mask, int64_t mask_stride)
 {
     extern __shared__ __attribute__((aligned(16))) float qlds[];  // kProbeQB * dimp floats, then the merge scratch
     const int dimp = groups * 16;
@@ -701,6 +706,7 @@ __global__ __launch_bounds__(kSqThreads) void sq8_probe_mq_kernel(
         const uint4 *tp = tiles + (tile * groups) * 64 + lane;
         const int64_t row = tile * 64 + lane;
         const bool live = row >= R0 && row < R1 && row < n_rows;
+        if (mask && mask_stride == 0 && !__any(live && mask_bit(mask, row))) continue;  // nothing of the tile passes the filter
         // the group's queries in passes of kSqProbeQ (the second pass finds the tile's codes in L1 / L2)
 #pragma unroll
         for (int qb = 0; qb < kProbeQB; qb += kSqProbeQ) {
@@ -716,6 +722,8 @@ __global__ __launch_bounds__(kSqThreads) void sq8_probe_mq_kernel(
                     if (qb + qi < cnt) {
                         uint64_t key = live ? make_key(total[qi], static_cast<uint32_t>(row), DOT) : kKeyMax;
                         if (min_keys && key <= min_keys[pair[qb + qi] / np]) key = kKeyMax;  // paged results (k > 64)
+                        if (mask && live && !mask_bit(mask + static_cast<int64_t>(pair[qb + qi] / np) * mask_stride, row))
+                            key = kKeyMax;  // filter.Matches (segment.go:559-561), each query its own mask
                         tk[qb + qi].offer(key, lane);
                     }
             }
@@ -731,9 +739,10 @@ __global__ __launch_bounds__(kSqThreads) void sq8_probe_mq_kernel(
     }
 }
 
-int32_t launch_probe_scan_sq8_grouped(const vg_index *idx, const float *queries, const uint32_t *pair_of,
-                                      const ProbeGroup *groups, const uint32_t *ngroups, unsigned gmax, int np, int sub,
-                                      int k, uint64_t *partial, const uint64_t *min_keys, hipStream_t st)
+int32_t launch_probe_scan_sq8_grouped(const vg_index *idx, const float *queries, const uint32_t *part_off,
+                                      const uint32_t *pair_of, const ProbeGroup *groups, const uint32_t *ngroups, unsigned gmax,
+                                      int np, int sub, int k, uint64_t *partial, const uint64_t *min_keys, const uint8_t *mask,
+                                      int64_t mask_stride, hipStream_t st)
 {
     const bool dot = idx->metric != VG_METRIC_L2;
     auto kern = dot ? sq8_probe_mq_kernel<true> : sq8_probe_mq_kernel<false>;
@@ -744,12 +753,13 @@ int32_t launch_probe_scan_sq8_grouped(const vg_index *idx, const float *queries,
     ProfScope prof(idx->ctx, "sq8_probe", st);
     VG_LAUNCH(kern, dim3(static_cast<unsigned>(sub), gmax), dim3(kSqThreads), lds, st,
               reinterpret_cast<const uint4 *>(idx->d_sq_tiles), idx->n, idx->sq_groups, idx->dim, queries, idx->sq->d_mins,
-              idx->sq->d_inv, idx->d_part_off, pair_of, groups, ngroups, np, sub, k, partial, min_keys);
+              idx->sq->d_inv, part_off, pair_of, groups, ngroups, np, sub, k, partial, min_keys, mask, mask_stride);
     return VG_OK;
 }
 
-int32_t launch_probe_scan_sq8(const vg_index *idx, const float *queries, const uint32_t *probes, int64_t nq, int np,
-                              int sub, int k, uint64_t *partial, const uint64_t *min_keys, hipStream_t st)
+int32_t launch_probe_scan_sq8(const vg_index *idx, const float *queries, const uint32_t *probes, const uint32_t *part_off,
+                              int64_t nq, int np, int sub, int k, uint64_t *partial, const uint64_t *min_keys,
+                              const uint8_t *mask, int64_t mask_stride, hipStream_t st)
 {
     for (int64_t q0 = 0; q0 < nq; q0 += 65535) {
         const int64_t cnt = nq - q0 < 65535 ? nq - q0 : 65535;
@@ -757,8 +767,9 @@ int32_t launch_probe_scan_sq8(const vg_index *idx, const float *queries, const u
         auto kern = idx->metric != VG_METRIC_L2 ? sq8_probe_kernel<true> : sq8_probe_kernel<false>;
         VG_LAUNCH(kern, dim3(static_cast<unsigned>(sub), static_cast<unsigned>(np), static_cast<unsigned>(cnt)),
                   dim3(kSqThreads), 0, st, reinterpret_cast<const uint4 *>(idx->d_sq_tiles), idx->n, idx->sq_groups, idx->dim,
-                  queries + q0 * idx->dim, idx->sq->d_mins, idx->sq->d_inv, probes + q0 * np, idx->d_part_off, np, sub, k,
-                  partial + q0 * np * sub * k, min_keys ? min_keys + q0 : nullptr);
+                  queries + q0 * idx->dim, idx->sq->d_mins, idx->sq->d_inv, probes + q0 * np, part_off, np, sub, k,
+                  partial + q0 * np * sub * k, min_keys ? min_keys + q0 : nullptr, mask ? mask + q0 * mask_stride : nullptr,
+                  mask_stride);
     }
     return VG_OK;
 }

@@ -109,6 +109,12 @@ __device__ __forceinline__ float4 load_stream(const float4 *p)
     return make_float4(v.x, v.y, v.z, v.w);
 }
 
+// row filters: bit i of byte i/8 set = row i takes part; no mask = every row
+__device__ __forceinline__ bool mask_bit(const uint8_t *__restrict__ mask, int64_t i)
+{
+    return mask == nullptr || ((mask[i >> 3] >> (i & 7)) & 1);
+}
+
 struct WaveTopK {
     uint64_t list;  // lane i: i-th smallest key of this wave so far
     uint64_t tau;   // wave-uniform: key at lane k-1 (kKeyMax until k keys were seen)
