@@ -1009,6 +1009,46 @@ def build_side_legs(vg, ctx, rows, queries, stream, with_cpu, rows_host=None):
                                 bool(np.array_equal(gs[:cov], r["out"]["scores"][:cov].view(np.uint32))))
     out["brute_q1"] = brute[1][0]
     out["brute_q256"] = brute[256][0]
+
+    # ---- flat.Segment.Search with `filter` set (flat/segment.go:631-635): 1024 queries, each its own filter keeping 1/8 of
+    # the rows (the AND of three random bytes); one query with one such filter (rows read = the rows it keeps)
+    nqf = min(1024, qf.shape[0])
+    g = torch.Generator(device=rows.device)
+    g.manual_seed(5)
+    nb = (n + 7) // 8
+    fm = torch.randint(0, 256, (nqf, nb), device=rows.device, generator=g, dtype=torch.uint8)
+    for _ in range(2):
+        fm &= torch.randint(0, 256, (nqf, nb), device=rows.device, generator=g, dtype=torch.uint8)
+    qb = qf[:nqf].contiguous()
+    pr, wall, fr = prof(("flat_gemm",), lambda: idx.search_flat_filtered(qb, K, fm, 0, stream=stream), reps=3)
+    lg, tg = pr["flat_gemm"]
+    g_ms = tg / max(lg, 1)
+    tf = 2.0 * nqf * n * DIM / (g_ms * 1e-3) / 1e12
+    row = {"workload": f"flat.Segment.Search with a row filter per query (1/8 of the rows pass): {nqf} queries x {n} x {DIM}, top-{K} "
+                       "(flat/segment.go:631-635)",
+           "kernel": "flat_gemm_dma_kernel<false,2> (filter bit read for the elements below the threshold)", "kernel_ms": g_ms, "bound": "mfma",
+           "achieved": tf, "peak": PEAK_MFMA_F32_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_MFMA_F32_TFLOPS, "call_ms": wall,
+           "queries_per_s": nqf / (wall * 1e-3), "short": f"flat_filtered_{nqf}q_{n}x{DIM}_keep0.125_top{K}"}
+    one = fm[0].contiguous()
+    pr1, wall1, _ = prof(("flat_probe",), lambda: idx.search_flat_filtered(qb[:1], K, one, 0, stream=stream), reps=5)
+    l1, t1 = pr1["flat_probe"]
+    kept = int(np.unpackbits(one.cpu().numpy(), bitorder="little")[:n].sum())
+    p_ms = t1 / max(l1, 1)
+    row.update(one_query_call_ms=wall1, one_query_kernel_ms=p_ms, one_query_rows_kept=kept,
+               one_query_gbs=kept * DIM * 4.0 / (p_ms * 1e-3) / 1e9)
+    if with_cpu and rows_host is not None:
+        seg = o.FlatSegment(rows_host, DIM)
+        same, t0 = True, time.perf_counter()
+        checked = 0
+        for i in (0, 1, nqf // 2, nqf - 1):
+            mi = np.unpackbits(fm[i].cpu().numpy(), bitorder="little")[:n].astype(bool)
+            eid, esc = seg.search(qb[i].cpu().numpy(), K, mask=mi)
+            same = same and np.array_equal(fr[0][i].cpu().numpy().view(np.uint32)[:eid.size], eid) and \
+                np.array_equal(fr[1][i].cpu().numpy().view(np.uint32)[:eid.size], esc.view(np.uint32))
+            checked += 1
+        row.update(cpu_qps=checked / (time.perf_counter() - t0), cpu_cores=1, cpu_kind="port", compared=checked, bits_equal=bool(same))
+    out["flat_filtered"] = row
+    del fm
     idx.close()
     pq.close()
     return out
@@ -1371,7 +1411,8 @@ def compact_line(full: dict) -> dict:
                           ("pq_train_seeding", "a11 pq.Train: k-means++ seeding"), ("pq_train_lloyd", "a11 pq.Train: Lloyd assignment pass"),
                           ("pq_encode", "a12 pq.Encode"), ("pq_build_table", "a13 pq.BuildDistanceTable"),
                           ("rerank", "f1 Segment.Rerank"), ("brute_q1", "a17 hnsw.BruteSearch, 1 query"),
-                          ("brute_q256", "a17 hnsw.BruteSearch, 256 queries")):
+                          ("brute_q256", "a17 hnsw.BruteSearch, 256 queries"),
+                          ("flat_filtered", "beyond s8: flat.Segment.Search with a filter, 1024 queries")):
             e = bs.get(key)
             if isinstance(e, dict):
                 row(name, {**e, "workload": e.get("short", e.get("workload"))}, bound=e.get("bound"),

@@ -174,3 +174,36 @@ def test_filtered_device_buffers_and_bad_masks(vg, ctx):
         idx.search_flat_filtered(q, 10, mask[:-9], 0)
     with pytest.raises(ValueError):
         idx.search_flat_filtered(q, 10, np.zeros((3, n), bool), 0)
+
+
+@pytest.mark.parametrize("metric", [0, 2])
+def test_filtered_batches_on_the_matrix_cores(vg, ctx, metric):
+    """8 queries up, a filtered fp32 search of an unpartitioned segment is nominated by the masked GEMM (k_flat.hip): thin
+    filters (fewer than k rows pass), k in the three proof regimes (<= 48, <= 64, pages beyond), the bf16 filter on top."""
+    rng = np.random.default_rng(40 + metric)
+    n, dim, nq = 20000, 64, 40
+    x = rng.standard_normal((n, dim)).astype(np.float32)
+    x[500:520] = x[500]                                     # ties inside and across the filter
+    idx = vg.Index(ctx, n, dim, vg.Metric(metric))
+    idx.set_vectors(x)
+    seg = o.FlatSegment(x, dim, metric=metric)
+    q = rng.standard_normal((nq, dim)).astype(np.float32)
+    q[3] = x[500]
+    sel = np.array([0, 3, 7, 21, 39])
+    for keep in (0.9, 0.2, 0.01, 0.0004):
+        per_query = rng.random((nq, n)) < keep
+        per_query[7, :] = False                             # a query whose filter rejects everything
+        for k in (10, 60, 150):
+            ids, sc = idx.search_flat_filtered(q, k, per_query, 0)
+            check(ids[sel], sc[sel], seg, q[sel], k, 0, per_query[sel])
+            ids, sc = idx.search_flat_filtered(q, k, per_query[0], 0)
+            check(ids[sel], sc[sel], seg, q[sel], k, 0, per_query[0])
+    idx.enable_bf16_filter(True)
+    per_query = rng.random((nq, n)) < 0.3
+    ids, sc = idx.search_flat_filtered(q, 10, per_query, 0)
+    check(ids[sel], sc[sel], seg, q[sel], 10, 0, per_query[sel])
+    # the unfiltered search is untouched by the mask plumbing
+    ids, sc = idx.search_flat(q, 10)
+    for i in sel:
+        eid, esc = seg.search(q[i], 10)
+        assert np.array_equal(ids[i], eid) and np.array_equal(bits(sc[i]), bits(esc))

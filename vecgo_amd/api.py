@@ -953,9 +953,9 @@ class Index:
         batch, or bool[nq, n] / packed [nq, ceil(n/8)] for one filter per query; None = search_flat_probed."""
         if mask is None:
             return self.search_flat_probed(queries, k, nprobes, scan, out=out, stream=stream)
-        m, stride = self._packed_mask(mask, _rows(queries, self.dim), "search_flat_filtered")
+        m, pm, stride = self._packed_mask(mask, _rows(queries, self.dim), "search_flat_filtered")
         return self._search(self._lib.vg_search_flat_filtered, queries, k,
-                            extra=(C.c_int32(nprobes), C.c_int32(scan), C.c_void_p(m.ctypes.data), C.c_int64(stride)),
+                            extra=(C.c_int32(nprobes), C.c_int32(scan), pm, C.c_int64(stride)),
                             out=out, stream=stream)
 
     def search_sq8(self, queries, k, out=None, stream=None):
@@ -1049,7 +1049,20 @@ class Index:
         return self._graph_search(self._lib.vg_search_hnsw_pq, queries, k, ef, stats, stream)
 
     def _packed_mask(self, mask, nq, what):
-        """bool[n] / bool[nq, n] / packed little-endian bits -> (contiguous uint8 array, stride in bytes; 0 = one mask)."""
+        """bool[n] / bool[nq, n] / packed little-endian bits -> (keepalive, void*, stride in bytes; 0 = one mask).  A torch
+        uint8 tensor (host or device) is taken as packed bits where it lies."""
+        if _is_torch(mask):
+            if mask.dtype != torch.uint8:
+                raise TypeError(f"{what}: a torch mask holds packed bits (uint8), got {mask.dtype}")
+            m = mask if mask.is_contiguous() else mask.contiguous()
+            if m.shape[-1] < (self.n + 7) // 8:
+                raise ValueError(f"{what}: a packed mask holds ceil(n / 8) = {(self.n + 7) // 8} bytes, got {m.shape[-1]}")
+            stride = 0
+            if m.ndim > 1 and m.shape[0] > 1:
+                if m.shape[0] != nq:
+                    raise ValueError(f"{what}: one mask per query ({nq}), got {m.shape[0]}")
+                stride = m.shape[1]
+            return m, C.c_void_p(m.data_ptr()), stride
         m = np.asarray(mask)
         if m.dtype == np.bool_:
             if m.shape[-1] != self.n:   # the C side reads ceil(n / 8) bytes per mask: a short one would be read past its end
@@ -1063,14 +1076,14 @@ class Index:
             if m.shape[0] != nq:
                 raise ValueError(f"{what}: one mask per query ({nq}), got {m.shape[0]}")
             stride = m.shape[1]
-        return m, stride
+        return m, C.c_void_p(m.ctypes.data), stride
 
     def search_hnsw_filtered(self, queries, k, ef, mask, selectivity, stats=False, stream=None):
         """searchExecute with a filter whose selectivity hint is above 0.3: searchLayerWithPostFilter (hnsw.go:1159-1218) —
         the walk with an expanded ef, the results re-filtered through `mask` (bool[n] / packed bits, one for the batch or
         one per query) and capped at ef.  `ef` = what determineEF returned."""
         nq = _rows(queries, self.dim)
-        m, stride = self._packed_mask(mask, nq, "search_hnsw_filtered")
+        m, pm, stride = self._packed_mask(mask, nq, "search_hnsw_filtered")
         q, pq_ = _ptr(queries, np.float32)
         ids = _empty_like(queries, (nq, k), np.uint32)
         scores = _empty_like(queries, (nq, k), np.float32)
@@ -1078,7 +1091,7 @@ class Index:
         s_, ps = _ptr(scores, np.float32)
         st = np.zeros((nq, 5), np.int64) if stats else None
         pst = C.c_void_p(st.ctypes.data) if stats else None
-        check(self._lib.vg_search_hnsw_filtered(self._h, pq_, C.c_int64(nq), C.c_int32(k), C.c_int32(ef), C.c_void_p(m.ctypes.data),
+        check(self._lib.vg_search_hnsw_filtered(self._h, pq_, C.c_int64(nq), C.c_int32(k), C.c_int32(ef), pm,
                                                 C.c_int64(stride), C.c_double(float(selectivity)), pi, ps, pst, _stream_ptr(stream)))
         if stats and stats != "full":
             st = st[:, :4]
@@ -1097,21 +1110,7 @@ class Index:
         scores = _empty_like(queries, (nq, k), np.float32)
         i, pi = _ptr(ids, np.uint32)
         s_, ps = _ptr(scores, np.float32)
-        pm, stride = None, 0
-        if mask is not None:
-            m = np.asarray(mask)
-            if m.dtype == np.bool_:
-                if m.shape[-1] != self.n:   # the C side reads ceil(n / 8) bytes per mask: a short one would be read past its end
-                    raise ValueError(f"search_hnsw_brute: a bool mask has one entry per row ({self.n}), got {m.shape[-1]}")
-                m = np.packbits(m.reshape(-1, self.n) if m.ndim > 1 else m, axis=-1, bitorder="little")
-            m = np.ascontiguousarray(m, np.uint8)
-            if m.shape[-1] < (self.n + 7) // 8:
-                raise ValueError(f"search_hnsw_brute: a packed mask holds ceil(n / 8) = {(self.n + 7) // 8} bytes, got {m.shape[-1]}")
-            if m.ndim > 1 and m.shape[0] > 1:
-                if m.shape[0] != nq:
-                    raise ValueError(f"search_hnsw_brute: one mask per query ({nq}), got {m.shape[0]}")
-                stride = m.shape[1]
-            pm = C.c_void_p(m.ctypes.data)
+        m, pm, stride = (None, None, 0) if mask is None else self._packed_mask(mask, nq, "search_hnsw_brute")
         check(self._lib.vg_search_hnsw_brute(self._h, pq_, C.c_int64(nq), C.c_int32(k), C.c_int32(mode), pm,
                                              C.c_int64(stride), pi, ps, _stream_ptr(stream)))
         return ids, scores

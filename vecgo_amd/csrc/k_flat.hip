@@ -36,6 +36,8 @@ struct GemmArgs {
     int *counts;
     uint64_t *cand;
     int cap;
+    const uint8_t *mask = nullptr;  // row filter of a filtered search (k_probe.hip): bit per (query, row), or one per row
+    int64_t mask_stride = 0;
 };
 
 template <bool DOT, int MODE>
@@ -53,7 +55,7 @@ static int32_t launch_gemm_t(bool dma, unsigned blocks, hipStream_t st, const Ge
             const int64_t grid = MODE == 1 ? (tiles + a.tile_stride - 1) / a.tile_stride : tiles;
             VG_LAUNCH(kern, dim3(static_cast<unsigned>(grid)), dim3(kGemmThreads), lds, st, a.queries, a.nq, a.base,
                       a.n, a.dim, a.norms, a.scores, a.tile_stride, a.out_cols, a.thr, a.thr_stride, a.thr_off, a.counts,
-                      a.cand, a.cap);
+                      a.cand, a.cap, a.mask, a.mask_stride);
             return VG_OK;
         }
         auto kern = flat_gemm_dma_kernel<DOT, M, 0, true>;
@@ -61,7 +63,7 @@ static int32_t launch_gemm_t(bool dma, unsigned blocks, hipStream_t st, const Ge
                                    static_cast<int>(kDmaLdsBytes)));
         VG_LAUNCH(kern, dim3(blocks), dim3(kGemmThreads), kDmaLdsBytes, st, a.queries, a.nq, a.base, a.n, a.dim,
                   a.norms, a.scores, a.tile_stride, a.out_cols, a.thr, a.thr_stride, a.thr_off, a.counts, a.cand,
-                  a.cap);
+                  a.cap, a.mask, a.mask_stride);
         return VG_OK;
     }
     // (test hook kHookFlatNoSmallTile: always the 128-query tile)
@@ -76,21 +78,21 @@ static int32_t launch_gemm_t(bool dma, unsigned blocks, hipStream_t st, const Ge
         const int64_t grid = MODE == 1 ? (tiles + a.tile_stride - 1) / a.tile_stride : tiles;
         VG_LAUNCH(kern, dim3(static_cast<unsigned>(grid)), dim3(kGemmThreads), lds, st, a.queries, a.nq, a.base,
                   a.n, a.dim, a.norms, a.scores, a.tile_stride, a.out_cols, a.thr, a.thr_stride, a.thr_off, a.counts,
-                  a.cand, a.cap);
+                  a.cand, a.cap, a.mask, a.mask_stride);
     } else if (dma) {
         auto kern = flat_gemm_dma_kernel<DOT, MODE>;
         VG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    static_cast<int>(kDmaLdsBytes)));
         VG_LAUNCH(kern, dim3(blocks), dim3(kGemmThreads), kDmaLdsBytes, st, a.queries, a.nq, a.base, a.n, a.dim,
                   a.norms, a.scores, a.tile_stride, a.out_cols, a.thr, a.thr_stride, a.thr_off, a.counts, a.cand,
-                  a.cap);
+                  a.cap, a.mask, a.mask_stride);
     } else {
         auto kern = flat_gemm_kernel<DOT, MODE>;
         VG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    static_cast<int>(kGemmLdsBytes)));
         VG_LAUNCH(kern, dim3(blocks), dim3(kGemmThreads), kGemmLdsBytes, st, a.queries, a.nq, a.base, a.n, a.dim,
                   a.norms, a.scores, a.tile_stride, a.out_cols, a.thr, a.thr_stride, a.thr_off, a.counts, a.cand,
-                  a.cap);
+                  a.cap, a.mask, a.mask_stride);
     }
     return VG_OK;
 }
@@ -442,7 +444,8 @@ __global__ __launch_bounds__(256) void flat_exact_kernel(const float *__restrict
                                                          int dim, const float *__restrict__ queries,
                                                          const int *__restrict__ todo, int slices, int k,
                                                          uint64_t *__restrict__ partial,
-                                                         const uint64_t *__restrict__ min_keys = nullptr)
+                                                         const uint64_t *__restrict__ min_keys = nullptr,
+                                                         const uint8_t *__restrict__ mask = nullptr, int64_t mask_stride = 0)
 {
     __shared__ uint64_t lists[4 * 64];
     __shared__ int valid[4];
@@ -457,13 +460,14 @@ __global__ __launch_bounds__(256) void flat_exact_kernel(const float *__restrict
         const float *qv = queries + q * dim;
         // paged results (k > 64): only keys after the last one of the previous page count
         const uint64_t floor_key = min_keys ? min_keys[q] : 0;
+        const uint8_t *mq = mask ? mask + q * mask_stride : nullptr;  // filtered search: rows the filter rejects are skipped
         WaveTopK tk;
         tk.init(k);
         // 4 rows per wave step (one per 16-lane group)
         for (int64_t i0 = r0 + wave * 4; i0 < r1; i0 += 16) {
             const int64_t i = i0 + (lane >> 4);
             uint64_t key = kKeyMax;
-            if (i < r1) {
+            if (i < r1 && mask_bit(mq, i)) {
                 const float v = exact_pair16<DOT, kPair>(base + i * dim, qv, dim, sub);
                 if ((lane & 15) == 0) {
                     key = make_key(v, static_cast<uint32_t>(i), DOT);
@@ -579,8 +583,23 @@ int32_t launch_page_patch(int64_t nq, int k, int off, int kk, bool descending, c
 
 }  // namespace vg
 
+namespace vg {
+int32_t flat_search_masked(vg_index *idx, const float *queries, int64_t nq, int32_t k, const uint8_t *mask, int64_t mask_stride,
+                           uint32_t *ids, float *scores, void *stream);
+}
+
 VG_API int32_t vg_search_flat(vg_index *idx, const float *queries, int64_t nq, int32_t k, uint32_t *ids,
                               float *scores, void *stream)
+{
+    return vg::flat_search_masked(idx, queries, nq, k, nullptr, 0, ids, scores, stream);
+}
+
+// vg_search_flat, and — with `mask` (a DEVICE pointer: bit i of byte i/8 of query q's mask at mask + q * mask_stride,
+// stride 0 = one mask) — the batched fp32 leg of vg_search_flat_filtered (k_probe.hip): the rows a query's filter rejects
+// are left out of its threshold sample and of its candidate list, so the proof argues about the rows it wants only
+// ("every wanted row not appended scores at or above the threshold"); the exhaustive fallback skips them too.
+int32_t vg::flat_search_masked(vg_index *idx, const float *queries, int64_t nq, int32_t k, const uint8_t *mask,
+                               int64_t mask_stride, uint32_t *ids, float *scores, void *stream)
 {
     VG_CHECK(idx, VG_ERR_INVALID_ARG, "vg_search_flat: NULL index");
     VG_CHECK(nq >= 0 && k >= 0, VG_ERR_INVALID_ARG, "vg_search_flat: negative nq or k");
@@ -597,7 +616,7 @@ VG_API int32_t vg_search_flat(vg_index *idx, const float *queries, int64_t nq, i
     const int kc = 64;  // nominated candidates per query
     // k beyond what 64 nominated candidates can prove: the fused GEMM path re-scores every appended row
     // (flat_verify_all_kernel); the unfused score-matrix variant (test hook) stops at 64
-    const bool unfused = vg::hook(vg::kHookFlatUnfused);
+    const bool unfused = vg::hook(vg::kHookFlatUnfused) && mask == nullptr;
     const bool big_k_scan = k > vg::kGemmMaxK && unfused;  // unfused: 64 nominated candidates cannot prove k near 64
     VG_CHECK(k <= 64 || !unfused, VG_ERR_UNSUPPORTED, "vg_search_flat: k=%d needs the fused GEMM path", k);
 
@@ -613,7 +632,7 @@ VG_API int32_t vg_search_flat(vg_index *idx, const float *queries, int64_t nq, i
         VG_TRY(none.init(static_cast<size_t>(nq) * k, st));
         VG_HIP(hipMemsetAsync(none.ptr, 0xFF, static_cast<size_t>(nq) * k * 8, st));
         VG_TRY(vg::launch_topk_merge(none.ptr, nq, 1, k, dot, oid.ptr, osc.ptr, st));
-    } else if (nq <= vg::kScanMaxBatch && k <= 64 && dim % 4 == 0 && dim <= 1024 && dim >= 64 && !vg::hook(vg::kHookFlatNoScan) &&
+    } else if (mask == nullptr && nq <= vg::kScanMaxBatch && k <= 64 && dim % 4 == 0 && dim <= 1024 && dim >= 64 && !vg::hook(vg::kHookFlatNoScan) &&
                !vg::hook(vg::kHookFlatForceExact) && !unfused && (reinterpret_cast<uintptr_t>(idx->d_vectors) & 15) == 0) {
         // small batch: HBM-bound exact scan, kScanQB queries per pass over the rows
         const int slices = static_cast<int>(std::min<int64_t>(4 * idx->ctx->compute_units, std::max<int64_t>(1, n / 64)));
@@ -726,6 +745,7 @@ VG_API int32_t vg_search_flat(vg_index *idx, const float *queries, int64_t nq, i
         for (int64_t q0 = 0; q0 < nq; q0 += qc) {
             const int64_t cnt = std::min(qc, nq - q0);
             const float *qp = q.ptr + q0 * dim;
+            const uint8_t *m0 = mask ? mask + q0 * mask_stride : nullptr;
             const int64_t mt = (cnt + vg::kGemmBM - 1) / vg::kGemmBM;
             const unsigned ucnt = static_cast<unsigned>(cnt);
             // (test hook kHookFlatNoDma: force the register-staged GEMM)
@@ -746,7 +766,7 @@ VG_API int32_t vg_search_flat(vg_index *idx, const float *queries, int64_t nq, i
                 if (use_sample) {
                     VG_TRY(vg::launch_gemm<1>(dot, dma, static_cast<unsigned>(mt * ((nst + 7) / 8) * 8), st,
                                               {ga, cnt, gb, n, gdim, idx->d_norms, sc, sample_stride, ns,
-                                               nullptr, 0, 0, nullptr, nullptr, 0}, bf16));
+                                               nullptr, 0, 0, nullptr, nullptr, 0, m0, mask_stride}, bf16));
                     VG_LAUNCH(vg::flat_select_kernel, dim3(sel_slices, ucnt), dim3(vg::kSelThreads), 0, st, sc, ns,
                               sel_slices, sel_k, partial);
                     VG_TRY(vg::launch_topk_merge(partial, cnt, sel_slices, sel_k, false, sid, thr, st));
@@ -760,7 +780,7 @@ VG_API int32_t vg_search_flat(vg_index *idx, const float *queries, int64_t nq, i
                     vg::ProfScope prof(idx->ctx, "flat_gemm", st);
                     VG_TRY(vg::launch_gemm<2>(dot, dma, static_cast<unsigned>(mt * ((nt + 7) / 8) * 8), st,
                                               {ga, cnt, gb, n, gdim, idx->d_norms, nullptr, 1, 0, thr,
-                                               sel_k, sel_k - 1, counts, cand, cap}, bf16));
+                                               sel_k, sel_k - 1, counts, cand, cap, m0, mask_stride}, bf16));
                 }
                 // (c) the kc best appended keys (k > kGemmMaxK: all of them go to the exact re-score below)
                 if (k <= vg::kGemmMaxK)
@@ -825,10 +845,10 @@ VG_API int32_t vg_search_flat(vg_index *idx, const float *queries, int64_t nq, i
                 const uint64_t *floor_keys = off ? min_keys : nullptr;
                 if (dot)
                     VG_LAUNCH(vg::flat_exact_kernel<true>, dim3(ex_slices, slots), dim3(256), 0, st, idx->d_vectors, n,
-                              dim, qp, todo, ex_slices, kk, fpartial, floor_keys);
+                              dim, qp, todo, ex_slices, kk, fpartial, floor_keys, m0, mask_stride);
                 else
                     VG_LAUNCH(vg::flat_exact_kernel<false>, dim3(ex_slices, slots), dim3(256), 0, st, idx->d_vectors, n,
-                              dim, qp, todo, ex_slices, kk, fpartial, floor_keys);
+                              dim, qp, todo, ex_slices, kk, fpartial, floor_keys, m0, mask_stride);
                 VG_TRY(vg::launch_topk_merge(fpartial, cnt, ex_slices, kk, dot, fid, fsc, st, flags, always));
                 if (k <= 64)
                     VG_LAUNCH(vg::flat_patch_kernel, dim3(ucnt), dim3(64), 0, st, flags, always, k, fid, fsc,

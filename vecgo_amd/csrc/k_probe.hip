@@ -30,6 +30,8 @@ int32_t launch_probe_scan_sq8_grouped(const vg_index *idx, const float *queries,
                                       const uint32_t *pair_of, const ProbeGroup *groups, const uint32_t *ngroups, unsigned gmax,
                                       int np, int sub, int k, uint64_t *partial, const uint64_t *min_keys, const uint8_t *mask,
                                       int64_t mask_stride, hipStream_t st);
+int32_t flat_search_masked(vg_index *idx, const float *queries, int64_t nq, int32_t k, const uint8_t *mask, int64_t mask_stride,
+                           uint32_t *ids, float *scores, void *stream);
 int32_t launch_page_patch(int64_t nq, int k, int off, int kk, bool descending, const int *always_one,
                           const uint32_t *fids, const float *fscores, uint32_t *ids, float *scores, uint64_t *min_keys,
                           hipStream_t st);
@@ -393,6 +395,18 @@ static int32_t flat_probed_impl(vg_index *idx, const float *queries, int64_t nq,
     vg::DevIn<uint8_t> mk;
     const int64_t mask_bytes = (idx->n + 7) / 8;
     VG_TRY(mk.init(mask, mask ? static_cast<size_t>(mask_stride ? (nq - 1) * mask_stride + mask_bytes : mask_bytes) : 0, st));
+
+    // A batch of filtered fp32 queries over the whole segment: the matrix-core nomination of vg_search_flat with the filter
+    // applied where candidates are sampled and appended (k_flat.hip) — its cost does not depend on the selectivity, the
+    // kernels below pay per wanted row: 8 queries up it wins or ties (tools/filtered_time.py).  Same results either way
+    // (the test hook keeps the batch on the kernels below).
+    if (whole && scan == VG_SCAN_F32 && mk.ptr && nq >= 8 && !vg::hook(vg::kHookProbeNoGroup)) {
+        VG_TRY(vg::flat_search_masked(idx, q.ptr, nq, k, mk.ptr, mask_stride, oid.ptr, osc.ptr, stream));
+        VG_TRY(oid.finish());
+        VG_TRY(osc.finish());
+        if (oid.on_host() || osc.on_host()) VG_HIP(hipStreamSynchronize(st));
+        return VG_OK;
+    }
 
     // enough workgroups to fill the device when there are few (query, probe) pairs
     const int64_t pairs = nq * np;

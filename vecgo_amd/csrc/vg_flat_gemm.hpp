@@ -35,7 +35,8 @@ __device__ __forceinline__ void gemm_epilogue(const f32x16 (&acc)[2][2], float *
                                               const float (&xn)[2], int tid, int lane, int wr, int wc, int64_t q0,
                                               int64_t nq, int64_t n0, int64_t n, int64_t tn,
                                               float *__restrict__ scores, int64_t out_cols,
-                                              int *__restrict__ counts, uint64_t *__restrict__ cand, int cap)
+                                              int *__restrict__ counts, uint64_t *__restrict__ cand, int cap,
+                                              const uint8_t *__restrict__ mask, int64_t mask_stride)
 {
     float4 t4[2][4];  // thresholds of rows i*32 + 8*g + 4*(lane>>5) + 0..3
     if (MODE == 2) {
@@ -62,11 +63,14 @@ __device__ __forceinline__ void gemm_epilogue(const f32x16 (&acc)[2][2], float *
                 if (MODE == 0) {
                     if (qq < nq && nn < n) scores[qq * n + nn] = sc;
                 } else if (MODE == 1) {
-                    if (qq < nq) scores[qq * out_cols + tn * kGemmBN + col] = nn < n ? sc : INFINITY;
+                    // (a row the query's filter rejects is not in the sample: the threshold is a quantile of the rows it wants)
+                    if (qq < nq)
+                        scores[qq * out_cols + tn * kGemmBN + col] = nn < n && mask_bit(mask ? mask + qq * mask_stride : nullptr, nn) ? sc : INFINITY;
                 } else {
                     const float4 tv = t4[i][r >> 2];
                     const float t = (r & 3) == 0 ? tv.x : (r & 3) == 1 ? tv.y : (r & 3) == 2 ? tv.z : tv.w;
-                    if (nn < n && sc < t) {
+                    // the filter bit is looked at only for the few elements below the threshold
+                    if (nn < n && sc < t && (mask == nullptr || mask_bit(mask + qq * mask_stride, nn))) {
                         const int pos = atomicAdd(&counts[qq], 1);
                         if (pos < cap) cand[qq * cap + pos] = make_key(sc, static_cast<uint32_t>(nn), false);
                     }
@@ -105,7 +109,8 @@ __global__ __launch_bounds__(kGemmThreads) void flat_gemm_kernel(
     const float *__restrict__ queries, int64_t nq, const float *__restrict__ base, int64_t n,
     int dim, const float *__restrict__ norms, float *__restrict__ scores, int tile_stride,
     int64_t out_cols, const float *__restrict__ thr, int thr_stride, int thr_off,
-    int *__restrict__ counts, uint64_t *__restrict__ cand, int cap)
+    int *__restrict__ counts, uint64_t *__restrict__ cand, int cap, const uint8_t *__restrict__ mask = nullptr,
+    int64_t mask_stride = 0)
 {
     extern __shared__ float gemm_lds[];  // A0 | B0 | A1 | B1, kGemmLdsBytes
     float *const As0 = gemm_lds, *const Bs0 = gemm_lds + kGemmTile;
@@ -242,7 +247,7 @@ __global__ __launch_bounds__(kGemmThreads) void flat_gemm_kernel(
         return;
     }
     gemm_epilogue<DOT, MODE>(acc, gemm_lds, thr_reg, xn, tid, lane, wr, wc, q0, nq, n0, n, tn, scores, out_cols,
-                             counts, cand, cap);
+                             counts, cand, cap, mask, mask_stride);
 }
 
 // ---- the same GEMM with LDS-DMA staging (dim % 4 == 0) -----------------------------------------
@@ -312,7 +317,8 @@ __global__ __launch_bounds__(kGemmThreads) void flat_gemm_dma_kernel(
     const float *__restrict__ queries, int64_t nq, const float *__restrict__ base, int64_t n,
     int dim, const float *__restrict__ norms, float *__restrict__ scores, int tile_stride,
     int64_t out_cols, const float *__restrict__ thr, int thr_stride, int thr_off,
-    int *__restrict__ counts, uint64_t *__restrict__ cand, int cap)
+    int *__restrict__ counts, uint64_t *__restrict__ cand, int cap, const uint8_t *__restrict__ mask = nullptr,
+    int64_t mask_stride = 0)
 {
     extern __shared__ float gemm_lds[];
     const int mtiles = static_cast<int>((nq + kGemmBM - 1) / kGemmBM);
@@ -460,7 +466,7 @@ __global__ __launch_bounds__(kGemmThreads) void flat_gemm_dma_kernel(
         return;
     }
     gemm_epilogue<DOT, MODE>(acc, gemm_lds, thr_reg, xn, tid, lane, wr, wc, q0, nq, n0, n, tn, scores, out_cols,
-                             counts, cand, cap);
+                             counts, cand, cap, mask, mask_stride);
 }
 
 // ---- 5..64 queries: the same pipeline with a 32 x 128 or 64 x 128 tile ------------------------------
@@ -481,7 +487,8 @@ __global__ __launch_bounds__(kGemmThreads) void flat_gemm_dma32_kernel(
     const float *__restrict__ queries, int64_t nq, const float *__restrict__ base, int64_t n,
     int dim, const float *__restrict__ norms, float *__restrict__ scores, int tile_stride,
     int64_t out_cols, const float *__restrict__ thr, int thr_stride, int thr_off,
-    int *__restrict__ counts, uint64_t *__restrict__ cand, int cap)
+    int *__restrict__ counts, uint64_t *__restrict__ cand, int cap, const uint8_t *__restrict__ mask = nullptr,
+    int64_t mask_stride = 0)
 {
     extern __shared__ float gemm_lds[];
     constexpr int kATile = RB * kG32BM * kGemmBK;  // floats
@@ -620,11 +627,13 @@ __global__ __launch_bounds__(kGemmThreads) void flat_gemm_dma32_kernel(
             const float dotv = acc[i][r];
             const float sc = DOT ? -dotv : __builtin_fmaf(-2.0f, dotv, xn);
             if (MODE == 1) {
-                if (ql < nq) scores[static_cast<int64_t>(ql) * out_cols + tn * kGemmBN + col] = nn < n ? sc : INFINITY;
+                if (ql < nq)
+                    scores[static_cast<int64_t>(ql) * out_cols + tn * kGemmBN + col] =
+                        nn < n && mask_bit(mask ? mask + ql * mask_stride : nullptr, nn) ? sc : INFINITY;
             } else {
                 const float4 tv = t4[i][r >> 2];
                 const float t = (r & 3) == 0 ? tv.x : (r & 3) == 1 ? tv.y : (r & 3) == 2 ? tv.z : tv.w;
-                if (nn < n && sc < t) {
+                if (nn < n && sc < t && (mask == nullptr || mask_bit(mask + ql * mask_stride, nn))) {
                     const int pos = atomicAdd(&counts[ql], 1);
                     if (pos < cap) cand[static_cast<int64_t>(ql) * cap + pos] = make_key(sc, static_cast<uint32_t>(nn), false);
                 }
