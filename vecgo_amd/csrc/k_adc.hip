@@ -160,11 +160,13 @@ struct AdcShared {
 // no workgroup barrier; otherwise candidates go through the shared LDS buffer.
 // ONCE: one query per pass — nobody re-reads the codes, so they are streamed (load_stream); with several
 // queries the blocks of an XCD share a slice through L2 and the loads stay plain.
-template <int GF, bool SMALLK, bool ONCE>
+// MASKED (SMALLK only): the filtered search of k_probe.hip — a row the query's filter rejects offers no key; desc: a Dot /
+// Cosine segment keeps the LARGEST lookups (flat/segment.go:449).  A template flag: the unfiltered scans stay as they were.
+template <int GF, bool SMALLK, bool ONCE, bool MASKED = false>
 __global__ __launch_bounds__(kAdcThreads) void pq_adc_scan_kernel(
     const uint4 *__restrict__ tiles, int64_t n_rows, int64_t n_tiles, int m, int groups,
     const float *__restrict__ tables, int slices, int nq, int k, uint64_t *__restrict__ partial,
-    int raw_lists, const int *__restrict__ only_if)
+    int raw_lists, const int *__restrict__ only_if, const uint8_t *__restrict__ mask, int64_t mask_stride, bool desc)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float *lut = reinterpret_cast<float *>(smem);
@@ -184,6 +186,7 @@ __global__ __launch_bounds__(kAdcThreads) void pq_adc_scan_kernel(
     if (only_if && !only_if[q]) return;  // fallback launch: only the flagged queries run
     const int64_t t0 = n_tiles * s / slices;
     const int64_t t1 = n_tiles * (s + 1) / slices;
+    const uint8_t *mq = MASKED && mask ? mask + q * mask_stride : nullptr;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -342,8 +345,8 @@ __global__ __launch_bounds__(kAdcThreads) void pq_adc_scan_kernel(
                     total = total + lut[lut_tail_word + l * 256 + code_byte(c, l)];
             }
             const int64_t row = tile * 64 + lane;
-            uint64_t key = (row < n_rows) ? make_key(total, static_cast<uint32_t>(row), false)
-                                          : kKeyMax;
+            uint64_t key = MASKED ? ((row < n_rows && mask_bit(mq, row)) ? make_key(total, static_cast<uint32_t>(row), desc) : kKeyMax)
+                                  : ((row < n_rows) ? make_key(total, static_cast<uint32_t>(row), false) : kKeyMax);
             if (SMALLK) {
                 wtk.offer(key, lane);
             } else if (key < tau) {
@@ -731,12 +734,14 @@ static int adc_slices(int64_t nq, int64_t n_tiles, int cus)
 template <int GF, bool SMALLK>
 static int32_t launch_scan(const vg_index *idx, const float *tables, int64_t nq, int k,
                            int slices, uint64_t *partial, hipStream_t st, int raw_lists = 0,
-                           const int *only_if = nullptr)
+                           const int *only_if = nullptr, const uint8_t *mask = nullptr, int64_t mask_stride = 0,
+                           bool desc = false)
 {
     const vg_pq *pq = idx->pq;
     size_t lds = static_cast<size_t>(lut_image_words(pq->m)) * sizeof(float) + kAdcBuf * sizeof(uint64_t) +
                  sizeof(AdcShared);
     auto kern = nq == 1 ? pq_adc_scan_kernel<GF, SMALLK, true> : pq_adc_scan_kernel<GF, SMALLK, false>;
+    if (SMALLK && (mask || desc)) kern = nq == 1 ? pq_adc_scan_kernel<GF, SMALLK, true, SMALLK> : pq_adc_scan_kernel<GF, SMALLK, false, SMALLK>;
     VG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
     // grid.x limit is 2^31-1; chunk the queries if needed
@@ -749,7 +754,7 @@ static int32_t launch_scan(const vg_index *idx, const float *tables, int64_t nq,
                            idx->n_tiles, pq->m, idx->pq_groups,
                            tables + q0 * lut_image_words(pq->m), slices, static_cast<int>(cnt), k,
                            partial + q0 * slices * (raw_lists ? kAdcWaves * 64 : k), raw_lists,
-                           only_if ? only_if + q0 : nullptr);
+                           only_if ? only_if + q0 : nullptr, mask ? mask + q0 * mask_stride : nullptr, mask_stride, desc);
     }
     return VG_OK;
 }
@@ -991,8 +996,21 @@ VG_API int32_t vg_index_set_pq_codes(vg_index *idx, vg_pq *pq, const uint8_t *co
     return VG_OK;
 }
 
+namespace vg {
+int32_t pq_adc_search_masked(vg_index *idx, const float *queries, int64_t nq, int32_t k, const uint8_t *mask, int64_t mask_stride,
+                             bool desc, uint32_t *ids, float *scores, void *stream);
+}
+
 VG_API int32_t vg_search_pq_adc(vg_index *idx, const float *queries, int64_t nq, int32_t k,
                                 uint32_t *ids, float *scores, void *stream)
+{
+    return vg::pq_adc_search_masked(idx, queries, nq, k, nullptr, 0, false, ids, scores, stream);
+}
+
+// vg_search_pq_adc, and — with `mask` (a DEVICE pointer, bit per row, query q's at mask + q * mask_stride) — the whole-segment
+// PQ leg of vg_search_flat_filtered (k_probe.hip; k <= 64 and a table that fits LDS, `desc` by the segment's metric)
+int32_t vg::pq_adc_search_masked(vg_index *idx, const float *queries, int64_t nq, int32_t k, const uint8_t *mask,
+                                 int64_t mask_stride, bool desc, uint32_t *ids, float *scores, void *stream)
 {
     VG_CHECK(idx, VG_ERR_INVALID_ARG, "vg_search_pq_adc: NULL index");
     VG_CHECK(idx->pq != nullptr, VG_ERR_NOT_READY, "vg_search_pq_adc: index has no PQ codes");
@@ -1010,6 +1028,7 @@ VG_API int32_t vg_search_pq_adc(vg_index *idx, const float *queries, int64_t nq,
     size_t lds = static_cast<size_t>(vg::lut_image_words(pq->m)) * 4 + vg::kAdcBuf * 8 + sizeof(vg::AdcShared);
     // a table beyond one LDS image (m > 96 at fp32) is walked in 96 KiB chunks: pq_adc_scan_wide_kernel, k <= 64
     const bool wide = lds > 160 * 1024;
+    VG_CHECK(mask == nullptr || (!wide && k <= 64), VG_ERR_UNSUPPORTED, "pq_adc_search_masked: k=%d / m=%d take the probe kernels", k, pq->m);
     VG_CHECK(!wide || k <= 64, VG_ERR_UNSUPPORTED,
              "vg_search_pq_adc: m=%d lookup table does not fit the 160 KiB LDS; the chunked scan takes k <= 64", pq->m);
     VG_HIP(hipSetDevice(idx->ctx->device));
@@ -1077,14 +1096,14 @@ VG_API int32_t vg_search_pq_adc(vg_index *idx, const float *queries, int64_t nq,
         if (wide)
             VG_TRY(vg::launch_scan_wide(idx, tables.ptr, nq, k, slices, partial.ptr, st));
         else if (pq->m == 96 && k <= 64)
-            VG_TRY((vg::launch_scan<6, true>(idx, tables.ptr, nq, k, slices, partial.ptr, st)));
+            VG_TRY((vg::launch_scan<6, true>(idx, tables.ptr, nq, k, slices, partial.ptr, st, 0, nullptr, mask, mask_stride, desc)));
         else if (pq->m == 96)
             VG_TRY((vg::launch_scan<6, false>(idx, tables.ptr, nq, k, slices, partial.ptr, st)));
         else if (k <= 64)
-            VG_TRY((vg::launch_scan<-1, true>(idx, tables.ptr, nq, k, slices, partial.ptr, st)));
+            VG_TRY((vg::launch_scan<-1, true>(idx, tables.ptr, nq, k, slices, partial.ptr, st, 0, nullptr, mask, mask_stride, desc)));
         else
             VG_TRY((vg::launch_scan<-1, false>(idx, tables.ptr, nq, k, slices, partial.ptr, st)));
-        VG_TRY(vg::launch_topk_merge(partial.ptr, nq, slices, k, false, oid.ptr, osc.ptr, st));
+        VG_TRY(vg::launch_topk_merge(partial.ptr, nq, slices, k, desc, oid.ptr, osc.ptr, st));
     }
     VG_TRY(oid.finish());
     VG_TRY(osc.finish());

@@ -32,6 +32,8 @@ int32_t launch_probe_scan_sq8_grouped(const vg_index *idx, const float *queries,
                                       int64_t mask_stride, hipStream_t st);
 int32_t flat_search_masked(vg_index *idx, const float *queries, int64_t nq, int32_t k, const uint8_t *mask, int64_t mask_stride,
                            uint32_t *ids, float *scores, void *stream);
+int32_t pq_adc_search_masked(vg_index *idx, const float *queries, int64_t nq, int32_t k, const uint8_t *mask, int64_t mask_stride,
+                             bool desc, uint32_t *ids, float *scores, void *stream);
 int32_t launch_page_patch(int64_t nq, int k, int off, int kk, bool descending, const int *always_one,
                           const uint32_t *fids, const float *fscores, uint32_t *ids, float *scores, uint64_t *min_keys,
                           hipStream_t st);
@@ -402,6 +404,16 @@ static int32_t flat_probed_impl(vg_index *idx, const float *queries, int64_t nq,
     // (the test hook keeps the batch on the kernels below).
     if (whole && scan == VG_SCAN_F32 && mk.ptr && nq >= 8 && !vg::hook(vg::kHookProbeNoGroup)) {
         VG_TRY(vg::flat_search_masked(idx, q.ptr, nq, k, mk.ptr, mask_stride, oid.ptr, osc.ptr, stream));
+        VG_TRY(oid.finish());
+        VG_TRY(osc.finish());
+        if (oid.on_host() || osc.on_host()) VG_HIP(hipStreamSynchronize(st));
+        return VG_OK;
+    }
+
+    // A filtered PQ scan of the whole segment, k <= 64 and a table that fits LDS: the pipelined scan of vg_search_pq_adc with
+    // the filter where keys are made (the probe kernel below is the plain loop, twice its time)
+    if (whole && scan == VG_SCAN_PQ && mk.ptr && k <= 64 && idx->pq->m <= 96 && !vg::hook(vg::kHookProbeNoGroup)) {
+        VG_TRY(vg::pq_adc_search_masked(idx, q.ptr, nq, k, mk.ptr, mask_stride, dot, oid.ptr, osc.ptr, stream));
         VG_TRY(oid.finish());
         VG_TRY(osc.finish());
         if (oid.on_host() || osc.on_host()) VG_HIP(hipStreamSynchronize(st));
