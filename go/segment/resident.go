@@ -323,6 +323,28 @@ func (r *Resident) SearchVamana(queries []float32, nq, k, kind int, stats []Stat
 	return ids, sc, hipctx.Err(int32(st))
 }
 
+// SearchVamanaFiltered: searchInternal with `filter` set (diskann/segment.go:616-627): a row whose mask bit is clear is walked
+// through but never enters the result heap.  mask as for SearchFiltered.
+func (r *Resident) SearchVamanaFiltered(queries []float32, nq, k, kind int, mask []byte, maskStride int, stats []Stats) ([]uint32, []float32, error) {
+	ids, sc := r.out(nq, k)
+	need := (r.rows + 7) / 8
+	if maskStride != 0 {
+		if maskStride < need {
+			return nil, nil, fmt.Errorf("SearchVamanaFiltered: maskStride %d is shorter than a mask (%d bytes)", maskStride, need)
+		}
+		need += (nq - 1) * maskStride
+	}
+	if len(mask) < need {
+		return nil, nil, fmt.Errorf("SearchVamanaFiltered: mask holds %d bytes, %d needed", len(mask), need)
+	}
+	var sp *C.vg_search_stats
+	if len(stats) >= nq && nq > 0 {
+		sp = (*C.vg_search_stats)(unsafe.Pointer(&stats[0]))
+	}
+	st := C.vg_search_vamana_filtered(r.h, fp(queries), C.int64_t(nq), C.int32_t(k), C.int32_t(kind), bp(mask), C.int64_t(maskStride), up(ids), fp(sc), sp, nil)
+	return ids, sc, hipctx.Err(int32(st))
+}
+
 // Rerank: Segment.Rerank + top-k (flat/segment.go:754-780, engine/search.go:914-965): nc candidate rows per query.
 func (r *Resident) Rerank(queries []float32, nq int, candidates []uint32, nc, k int) ([]uint32, []float32, error) {
 	ids, sc := r.out(nq, k)

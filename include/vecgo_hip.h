@@ -49,8 +49,9 @@ extern "C" {
  *   2: (r05) vg_abi_minor itself; no other symbol added — vg_search_hnsw / _hnsw_pq answer NaN distances as the reference
  *      does, vg_kmeans_* decide assignments on the matrix cores, the k-means++ running sum of vg_pq_train is blocked
  *   3: (r05) vg_search_hnsw_filtered
- *   4: (r05) vg_search_flat_filtered */
-#define VG_ABI_MINOR 4
+ *   4: (r05) vg_search_flat_filtered
+ *   5: (r05) vg_search_vamana_filtered */
+#define VG_ABI_MINOR 5
 #define VG_INVALID_ID 0xFFFFFFFFu
 #define VG_STREAM_LEGACY ((void *)1) /* == hipStreamLegacy */
 
@@ -584,6 +585,14 @@ int32_t vg_search_hnsw_pq(vg_index *idx, const float *queries, int64_t nq, int32
  * stop when the popped candidate is worse than the k-th result.  k <= 512. */
 int32_t vg_search_vamana(vg_index *idx, const float *queries, int64_t nq, int32_t k, int32_t kind,
                          uint32_t *ids, float *scores, vg_search_stats *stats, void *stream);
+/* The same with `filter segment.Filter` set: pushToHeap (diskann/segment.go:616-627) returns before TryPushBounded for a row
+ * whose filter.Matches is false — the traversal queue still takes the node, and the stop test reads the heap of MATCHING rows,
+ * so a selective filter walks further before it stops.  mask: bit i of byte i/8 set = filter.Matches(i) (and the metadata
+ * filter, :620-622, if any — the host ANDs them); query q reads mask + q * mask_stride (0 = one mask for the batch, else >=
+ * ceil(rows/8)); NULL = vg_search_vamana.  (VG_ABI_MINOR 5.) */
+int32_t vg_search_vamana_filtered(vg_index *idx, const float *queries, int64_t nq, int32_t k, int32_t kind,
+                                  const uint8_t *mask, int64_t mask_stride, uint32_t *ids, float *scores,
+                                  vg_search_stats *stats, void *stream);
 
 /* The HNSW index's two EXHAUSTIVE paths, each with the heap it is written with (searcher/queue.go) — which ids
  * survive a tie at the k-th distance and the order of equal distances in the result follow from the heap's layout,

@@ -633,6 +633,8 @@ public:
     // hnsw.BruteSearch + scanSegment (hnsw.go:2021-2101; VG_BRUTE_SCAN) / searchBitmap (:2240-2263; VG_BRUTE_BITMAP)
     Result SearchHNSWBrute(const float *queries, int64_t nq, int k, int mode, const uint8_t *mask = nullptr, int64_t mask_stride = 0) { return run(nq, k, [&](Result &r) { return vg_search_hnsw_brute(h_, queries, nq, k, mode, mask, mask_stride, r.ids.data(), r.scores.data(), nullptr); }); }
     // diskann searchInternal (diskann/segment.go:503-706); kind 0 fp32, 1 PQ, 2 RaBitQ
+    // searchInternal with a row filter (diskann/segment.go:616-627): mask bit i of byte i/8 = filter.Matches(i)
+    Result SearchVamanaFiltered(const float *queries, int64_t nq, int k, int kind, const uint8_t *mask, int64_t mask_stride) { return run(nq, k, [&](Result &r) { return vg_search_vamana_filtered(h_, queries, nq, k, kind, mask, mask_stride, r.ids.data(), r.scores.data(), nullptr, nullptr); }); }
     Result SearchVamana(const float *queries, int64_t nq, int k, int kind) { return run(nq, k, [&](Result &r) { return vg_search_vamana(h_, queries, nq, k, kind, r.ids.data(), r.scores.data(), nullptr, nullptr); }); }
     // Segment.Rerank (flat/segment.go:754-780) + top-k
     Result Rerank(const float *queries, int64_t nq, const uint32_t *cand, int nc, int k) { return run(nq, k, [&](Result &r) { return vg_rerank(h_, queries, nq, cand, nc, k, r.ids.data(), r.scores.data(), nullptr); }); }

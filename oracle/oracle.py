@@ -144,6 +144,8 @@ _sig("vgo_hnsw_search", C.c_int32, C.POINTER(HnswGraph), _f32p, C.c_int32, C.c_i
 _sig("vgo_hnsw_brute_search", C.c_int32, C.POINTER(HnswGraph), _f32p, C.c_int32, C.c_int32, _u8p, _u32p, _f32p)
 _sig("vgo_vamana_search", C.c_int32, C.POINTER(Vamana), _f32p, C.c_int32, _u32p, _f32p,
      C.POINTER(SearchStats))
+_sig("vgo_vamana_search_filtered", C.c_int32, C.POINTER(Vamana), _f32p, C.c_int32, _u8p, _u32p, _f32p,
+     C.POINTER(SearchStats))
 _i64p = C.POINTER(C.c_int64)
 _sig("vgo_opq_block_size", C.c_int32, C.c_int32, C.c_int32)
 _sig("vgo_opq_rotate", None, _f32p, C.c_int32, C.c_int32, _f32p, _f32p)
@@ -862,13 +864,18 @@ class VamanaIndex:
                       self.codes.ctypes.data_as(_u8p) if self.codes is not None else None,
                       self.int4_table.ctypes.data_as(_f32p) if self.int4_table is not None else None)
 
-    def search(self, query, k):
+    def search(self, query, k, mask=None):
+        """mask: bool[n] = filter.Matches per row (diskann/segment.go:616-627); None = no filter"""
         q, pq_ = _f(query)
         ids = np.empty(max(k, 1), np.uint32); sc = np.empty(max(k, 1), np.float32)
         st = SearchStats()
         v = self._c()
-        r = lib.vgo_vamana_search(C.byref(v), pq_, k, ids.ctypes.data_as(_u32p),
-                                  sc.ctypes.data_as(_f32p), C.byref(st))
+        pm = None
+        if mask is not None:
+            bits_ = np.packbits(np.asarray(mask, np.bool_).reshape(self.n), bitorder="little")
+            pm = bits_.ctypes.data_as(_u8p)
+        r = lib.vgo_vamana_search_filtered(C.byref(v), pq_, k, pm, ids.ctypes.data_as(_u32p),
+                                           sc.ctypes.data_as(_f32p), C.byref(st))
         return ids[:r], sc[:r], st
 
 

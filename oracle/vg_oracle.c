@@ -1576,6 +1576,16 @@ static float vamana_dist(const vgo_vamana *v, const float *q, uint32_t id)
 int32_t vgo_vamana_search(const vgo_vamana *v, const float *query, int32_t k, uint32_t *ids,
                           float *scores, vgo_search_stats *stats)
 {
+    return vgo_vamana_search_filtered(v, query, k, NULL, ids, scores, stats);
+}
+
+/* searchInternal with `filter` set (diskann/segment.go:616-627): pushToHeap returns before TryPushBounded for a row whose
+ * filter.Matches is false — the traversal queue still takes it, the pruning test reads the heap of MATCHING rows only.
+ * mask: bit i of byte i/8 = filter.Matches(i); NULL = no filter. */
+int32_t vgo_vamana_search_filtered(const vgo_vamana *v, const float *query, int32_t k, const uint8_t *mask, uint32_t *ids,
+                                   float *scores, vgo_search_stats *stats)
+{
+#define VAMANA_PASS(id) (!mask || ((mask[(id) >> 3] >> ((id) & 7)) & 1))
     vgo_search_stats st = {0, 0, 0, 0};
     int desc = v->metric != VGO_METRIC_L2; /* segment.go:597 */
     uint8_t *visited = (uint8_t *)calloc((size_t)v->n, 1);
@@ -1589,7 +1599,7 @@ int32_t vgo_vamana_search(const vgo_vamana *v, const float *query, int32_t k, ui
     float sd = vamana_dist(v, query, start);
     st.distance_computations++;
     vgo_prioq_push(&cand, (vgo_pq_item){start, sd});
-    vgo_candheap_try_push_bounded(&heap, (vgo_cand){0, start, sd}, k);
+    if (VAMANA_PASS(start)) vgo_candheap_try_push_bounded(&heap, (vgo_cand){0, start, sd}, k);
 
     vgo_pq_item c;
     while (cand.len > 0) {
@@ -1608,9 +1618,10 @@ int32_t vgo_vamana_search(const vgo_vamana *v, const float *query, int32_t k, ui
             float d = vamana_dist(v, query, id);
             st.distance_computations++;
             vgo_prioq_push(&cand, (vgo_pq_item){id, d});
-            vgo_candheap_try_push_bounded(&heap, (vgo_cand){0, id, d}, k);
+            if (VAMANA_PASS(id)) vgo_candheap_try_push_bounded(&heap, (vgo_cand){0, id, d}, k);
         }
     }
+#undef VAMANA_PASS
     int32_t r = emit_sorted(&heap, ids, scores);
     vgo_prioq_free(&cand);
     vgo_candheap_free(&heap);

@@ -267,6 +267,9 @@ typedef struct {
 /* diskann/segment.go:503-706 searchInternal, no filters */
 int32_t vgo_vamana_search(const vgo_vamana *v, const float *query, int32_t k,
                           uint32_t *ids, float *scores, vgo_search_stats *stats);
+/* with `filter` (segment.go:616-627: pushToHeap skips a row whose filter.Matches is false); mask bit i = Matches(i) */
+int32_t vgo_vamana_search_filtered(const vgo_vamana *v, const float *query, int32_t k, const uint8_t *mask, uint32_t *ids,
+                                   float *scores, vgo_search_stats *stats);
 
 /* SQ8 (sq8_avx512.c:59-103, quantizer.go:27-250, flat/segment.go:517-604) */
 void vgo_sq8u_l2_batch(const float *query, const uint8_t *codes, const float *mins, const float *inv_scales,

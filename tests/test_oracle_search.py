@@ -146,3 +146,25 @@ def test_flat_segment_reference_tests():
         return o.FlatSegment(rows, rows.shape[1], centroids=cent, part_offsets=off).search(q, k, nprobes)
 
     flat_segment_kats.run(search, search_sq8_rerank, partition, search_probed)
+
+
+def test_vamana_oracle_filter_only_touches_the_result_heap():
+    """diskann/segment.go:616-627: a filtered-out row still feeds the traversal; the results are matching rows, and with
+    every row matching the search is the unfiltered one, counters included.  A filter that rejects everything walks the whole
+    component (the stop test never fires: the result heap stays empty)."""
+    rng = np.random.default_rng(4)
+    n, dim, k = 700, 16, 10
+    base = rng.standard_normal((n, dim)).astype(np.float32)
+    g, entry = graphs.build_vamana(base, r=12, seed=2)
+    v = o.VamanaIndex(g, entry, dim, o.VAMANA_F32, base=base)
+    q = rng.standard_normal(dim).astype(np.float32)
+    uid, usc, ust = v.search(q, k)
+    aid, asc, ast = v.search(q, k, mask=np.ones(n, bool))
+    assert np.array_equal(uid, aid) and np.array_equal(usc, asc)
+    assert (ust.nodes_visited, ust.pops) == (ast.nodes_visited, ast.pops)
+    mask = rng.random(n) < 0.2
+    fid, fsc, fst = v.search(q, k, mask=mask)
+    assert fid.size == k and np.all(mask[fid]) and np.all(np.diff(fsc) >= 0)
+    assert fst.nodes_visited >= ust.nodes_visited                 # the stop test waits for k MATCHING rows
+    nid, nsc, nst = v.search(q, k, mask=np.zeros(n, bool))
+    assert nid.size == 0 and nst.nodes_visited >= fst.nodes_visited

@@ -1119,6 +1119,26 @@ class Index:
         """diskann searchInternal (diskann/segment.go:503-706); kind 0 fp32, 1 PQ, 2 RaBitQ, 3 INT4."""
         return self._graph_search(self._lib.vg_search_vamana, queries, k, kind, stats, stream)
 
+    def search_vamana_filtered(self, queries, k, mask, kind=0, stats=False, stream=None):
+        """searchInternal with `filter` set (diskann/segment.go:616-627): rows whose mask entry is clear are walked through
+        but never enter the result heap.  mask: bool[n] / packed bits for the batch, or one per query."""
+        if mask is None:
+            return self.search_vamana(queries, k, kind, stats, stream)
+        nq = _rows(queries, self.dim)
+        m, pm, stride = self._packed_mask(mask, nq, "search_vamana_filtered")
+        q, pq_ = _ptr(queries, np.float32)
+        ids = _empty_like(queries, (nq, k), np.uint32)
+        scores = _empty_like(queries, (nq, k), np.float32)
+        i, pi = _ptr(ids, np.uint32)
+        s_, ps = _ptr(scores, np.float32)
+        st = np.zeros((nq, 5), np.int64) if stats else None
+        pst = C.c_void_p(st.ctypes.data) if stats else None
+        check(self._lib.vg_search_vamana_filtered(self._h, pq_, C.c_int64(nq), C.c_int32(k), C.c_int32(kind), pm, C.c_int64(stride),
+                                                  pi, ps, pst, _stream_ptr(stream)))
+        if stats and stats != "full":
+            st = st[:, :4]
+        return (ids, scores, st) if stats else (ids, scores)
+
     def set_vectors(self, base, stream=None):
         """fp32 rows, n*dim row-major (vectorstore/columnar.go:21-24)."""
         b, pb = _ptr(base, np.float32, self.n * self.dim)

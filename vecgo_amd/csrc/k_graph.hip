@@ -323,7 +323,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(kind == kVam
     const float *__restrict__ int4_table, const float *__restrict__ int4_min, const float *__restrict__ int4_diff,
     const float *__restrict__ queries, int k, HItem *__restrict__ cand_ws, int64_t cand_cap, uint32_t *__restrict__ visited_ws,
     int64_t vis_words, uint32_t *__restrict__ ids, float *__restrict__ scores,
-    vg_search_stats *__restrict__ stats)
+    vg_search_stats *__restrict__ stats, const uint8_t *__restrict__ mask, int64_t mask_stride)
 {
     __shared__ float nb_d[64];
     __shared__ uint64_t res[kVamanaMaxK];  // the result set when k > 64
@@ -475,8 +475,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(kind == kVam
     const float sd = nb_d[0];
     st_dc++;
     heap_push<false>(cand, cand_len, HItem{entry, sd});
-    offer(lane == 0 ? make_key(sd, entry, desc) : kKeyMax);
-    heap_count = 1 < k ? 1 : k;
+    // pushToHeap (segment.go:616-627): a row whose filter.Matches is false goes to the traversal queue only — sc.Heap, and with it
+    // the pruning test below, holds matching rows
+    const uint8_t *mq = mask ? mask + blockIdx.x * mask_stride : nullptr;
+    const bool entry_ok = mask_bit(mq, entry);
+    offer(lane == 0 && entry_ok ? make_key(sd, entry, desc) : kKeyMax);
+    heap_count = entry_ok && 1 < k ? 1 : (entry_ok ? k : 0);
     __syncthreads();
 
     while (cand_len > 0) {
@@ -516,8 +520,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(kind == kVam
             }
         }
         // result heap: TryPushBounded(k) — a set maintained by (score, id): order-free
-        offer(fresh ? make_key(myd, id_lane, desc) : kKeyMax);
-        heap_count = heap_count + nnew < k ? heap_count + nnew : k;
+        const bool pass = fresh && mask_bit(mq, id_lane);
+        const int npass = mq ? __popcll(__ballot(pass)) : nnew;
+        offer(pass ? make_key(myd, id_lane, desc) : kKeyMax);
+        heap_count = heap_count + npass < k ? heap_count + npass : k;
         __syncthreads();
     }
     if (big) {
@@ -815,8 +821,29 @@ VG_API int32_t vg_search_hnsw_filtered(vg_index *idx, const float *queries, int6
     return search_hnsw_impl(idx, false, queries, nq, k, ef, ids, scores, stats, stream, mask, mask_stride, selectivity);
 }
 
+static int32_t vamana_impl(vg_index *idx, const float *queries, int64_t nq, int32_t k, int32_t kind, const uint8_t *mask,
+                           int64_t mask_stride, uint32_t *ids, float *scores, vg_search_stats *stats, void *stream);
+
 VG_API int32_t vg_search_vamana(vg_index *idx, const float *queries, int64_t nq, int32_t k, int32_t kind,
                                 uint32_t *ids, float *scores, vg_search_stats *stats, void *stream)
+{
+    return vamana_impl(idx, queries, nq, k, kind, nullptr, 0, ids, scores, stats, stream);
+}
+
+VG_API int32_t vg_search_vamana_filtered(vg_index *idx, const float *queries, int64_t nq, int32_t k, int32_t kind,
+                                         const uint8_t *mask, int64_t mask_stride, uint32_t *ids, float *scores,
+                                         vg_search_stats *stats, void *stream)
+{
+    VG_CHECK(idx, VG_ERR_INVALID_ARG, "vg_search_vamana_filtered: NULL index");
+    const int64_t mask_bytes = (idx->n + 7) / 8;
+    VG_CHECK(mask == nullptr || mask_stride == 0 || mask_stride >= mask_bytes, VG_ERR_INVALID_ARG,
+             "vg_search_vamana_filtered: mask_stride %lld is shorter than a mask (%lld bytes)", static_cast<long long>(mask_stride),
+             static_cast<long long>(mask_bytes));
+    return vamana_impl(idx, queries, nq, k, kind, mask, mask_stride, ids, scores, stats, stream);
+}
+
+static int32_t vamana_impl(vg_index *idx, const float *queries, int64_t nq, int32_t k, int32_t kind, const uint8_t *mask,
+                           int64_t mask_stride, uint32_t *ids, float *scores, vg_search_stats *stats, void *stream)
 {
     VG_CHECK(idx, VG_ERR_INVALID_ARG, "vg_search_vamana: NULL index");
     VG_CHECK(nq >= 0 && k >= 0, VG_ERR_INVALID_ARG, "vg_search_vamana: negative nq or k");
@@ -842,6 +869,8 @@ VG_API int32_t vg_search_vamana(vg_index *idx, const float *queries, int64_t nq,
     VG_TRY(oid.init(ids, static_cast<size_t>(nq) * k, st));
     VG_TRY(osc.init(scores, static_cast<size_t>(nq) * k, st));
     VG_TRY(ost.init(stats, stats ? static_cast<size_t>(nq) : 0, st));
+    vg::DevIn<uint8_t> mk;
+    VG_TRY(mk.init(mask, mask ? static_cast<size_t>(mask_stride ? (nq - 1) * mask_stride + (idx->n + 7) / 8 : (idx->n + 7) / 8) : 0, st));
     const int64_t vis_words = (idx->n + 31) / 32;
     const int64_t cand_cap = std::min<int64_t>(idx->n, 65536);
     const int64_t per_query = vis_words * 4 + cand_cap * 8;
@@ -882,7 +911,7 @@ VG_API int32_t vg_search_vamana(vg_index *idx, const float *queries, int64_t nq,
                       idx->pq ? idx->pq->d_offsets : nullptr,
                       idx->d_rq_rows, kind == 2 ? qcodes.ptr + q0 * (rq_nb + 4) : nullptr, rq_nb,
                       idx->d_int4_rows, idx->int4_table, idx->int4_min, idx->int4_diff, q.ptr + q0 * idx->dim, k, cand.ptr, cand_cap, vis.ptr, vis_words, oid.ptr + q0 * k,
-                      osc.ptr + q0 * k, ost.ptr ? ost.ptr + q0 : nullptr);
+                      osc.ptr + q0 * k, ost.ptr ? ost.ptr + q0 : nullptr, mk.ptr ? mk.ptr + q0 * mask_stride : nullptr, mask_stride);
             return VG_OK;
         };
         const bool big = k > 64;
