@@ -279,6 +279,46 @@ func (r *Resident) SearchHNSWFiltered(queries []float32, nq, k, ef int, mask []b
 	return ids, sc, hipctx.Err(int32(st))
 }
 
+// SearchHNSWPredicate: searchExecute with a filter whose selectivity hint is at or below 0.3, or unknown —
+// searchLayerPredicateAware (hnsw.go:1406-1558).  mask as for SearchHNSWFiltered (filter.Matches only); deleted: the
+// tombstone bitmap (ceil(n/8) bytes) or nil.  stats[i].ShortCircuits = ExpansionsSkipped.
+func (r *Resident) SearchHNSWPredicate(queries []float32, nq, k, ef int, mask []byte, maskStride int, deleted []byte, stats []Stats) ([]uint32, []float32, error) {
+	ids, sc := r.out(nq, k)
+	need := (r.rows + 7) / 8
+	if len(deleted) > 0 && len(deleted) < need {
+		return nil, nil, fmt.Errorf("SearchHNSWPredicate: deleted holds %d bytes, %d needed", len(deleted), need)
+	}
+	if maskStride != 0 {
+		if maskStride < need {
+			return nil, nil, fmt.Errorf("SearchHNSWPredicate: maskStride %d is shorter than a mask (%d bytes)", maskStride, need)
+		}
+		need += (nq - 1) * maskStride
+	}
+	if len(mask) < need {
+		return nil, nil, fmt.Errorf("SearchHNSWPredicate: mask holds %d bytes, %d needed", len(mask), need)
+	}
+	var sp *C.vg_search_stats
+	if len(stats) >= nq && nq > 0 {
+		sp = (*C.vg_search_stats)(unsafe.Pointer(&stats[0]))
+	}
+	var dp *C.uint8_t
+	if len(deleted) > 0 {
+		dp = bp(deleted)
+	}
+	st := C.vg_search_hnsw_predicate(r.h, fp(queries), C.int64_t(nq), C.int32_t(k), C.int32_t(ef), bp(mask), C.int64_t(maskStride), dp, up(ids), fp(sc), sp, nil)
+	return ids, sc, hipctx.Err(int32(st))
+}
+
+// SetHNSWEdgeDistances: the layer-0 lists' cached Neighbor.Dist (node.go:62-80), rows*m0 values slot for slot with the uploaded
+// lists; nil = recompute them from the fp32 rows.
+func (r *Resident) SetHNSWEdgeDistances(l0Dist []float32) error {
+	var p *C.float
+	if len(l0Dist) > 0 {
+		p = fp(l0Dist)
+	}
+	return hipctx.Err(int32(C.vg_index_set_hnsw_edge_distances(r.h, p, nil)))
+}
+
 // BruteMode selects which of the HNSW index's exhaustive paths SearchHNSWBrute replays.
 type BruteMode int32
 

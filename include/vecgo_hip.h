@@ -50,8 +50,9 @@ extern "C" {
  *      does, vg_kmeans_* decide assignments on the matrix cores, the k-means++ running sum of vg_pq_train is blocked
  *   3: (r05) vg_search_hnsw_filtered
  *   4: (r05) vg_search_flat_filtered
- *   5: (r05) vg_search_vamana_filtered */
-#define VG_ABI_MINOR 5
+ *   5: (r05) vg_search_vamana_filtered
+ *   6: (r05) vg_search_hnsw_predicate, vg_index_set_hnsw_edge_distances; vg_search_hnsw_filtered serves every selectivity */
+#define VG_ABI_MINOR 6
 #define VG_INVALID_ID 0xFFFFFFFFu
 #define VG_STREAM_LEGACY ((void *)1) /* == hipStreamLegacy */
 
@@ -563,12 +564,27 @@ int32_t vg_search_hnsw(vg_index *idx, const float *queries, int64_t nq, int32_t 
  * pushed back capped at ef — and knnSearchInternal's extraction.  mask: bit i of byte i/8 set = row i passes
  * (filter.Matches and not tombstoned); query q reads mask + q * mask_stride (0 = one mask for the batch, else >=
  * ceil(n/8)).  `ef` is what determineEF returned (its bitmap-cardinality expansion, hnsw.go:1863-1889, is the caller's).
- * selectivity <= 0.3 -> VG_ERR_UNSUPPORTED: the reference walks predicate-aware there (searchLayerPredicateAware,
- * hnsw.go:1406), which is not built; vg_search_hnsw_brute serves the selective end (KNNSearchWithBuffer's bitmap scan).
- * (VG_ABI_MINOR 3.) */
+ * selectivity <= 0.3 (0 = no hint): the reference walks predicate-aware there — vg_search_hnsw_predicate below with no
+ * tombstones (VG_ABI_MINOR 6; before it this returned VG_ERR_UNSUPPORTED).  (VG_ABI_MINOR 3.) */
 int32_t vg_search_hnsw_filtered(vg_index *idx, const float *queries, int64_t nq, int32_t k, int32_t ef,
                                 const uint8_t *mask, int64_t mask_stride, double selectivity, uint32_t *ids,
                                 float *scores, vg_search_stats *stats, void *stream);
+/* searchExecute with a filter and a selectivity hint at or below 0.3, or none: searchLayerPredicateAware (hnsw.go:1406-1558) on
+ * layer 0 — per neighbour, in list order: filter.Matches and the tombstone bit BEFORE any distance; a passing live node is
+ * scored; a rejected one is navigated by its cached edge distance (Neighbor.Dist > 0, node.go:62-80) while the results hold
+ * fewer than ef/2 items, scored while they hold fewer than ef unless more than 10 rejections came in a row or its edge
+ * distance exceeds 1.5 x the worst result, and skipped once they hold ef; the navigation queue is unbounded, the results are
+ * bounded by ef and take passing live nodes only; then knnSearchInternal's extraction.  mask as above (filter.Matches only);
+ * deleted: the tombstone bitmap, one for the batch, NULL = none.  stats: nodes_visited, distance_computations,
+ * distance_short_circuits = ExpansionsSkipped, pops.  ef <= 4096.  fp32 rows.  Needs the layer-0 edge distances:
+ * vg_index_set_hnsw_edge_distances, else they are recomputed from the rows at the first call.  (VG_ABI_MINOR 6.) */
+int32_t vg_search_hnsw_predicate(vg_index *idx, const float *queries, int64_t nq, int32_t k, int32_t ef,
+                                 const uint8_t *mask, int64_t mask_stride, const uint8_t *deleted, uint32_t *ids,
+                                 float *scores, vg_search_stats *stats, void *stream);
+/* The cached Neighbor.Dist of the layer-0 lists, l0_dist[n*m0] slot for slot with vg_index_set_hnsw_graph's l0 (the low 32
+ * bits of the reference's neighbour words, node.go:67-80); NULL = recompute them from the fp32 rows as the distance between
+ * the two nodes, which is what the insert stored (hnsw.go:516, :550, :964).  Dropped when the graph is replaced. */
+int32_t vg_index_set_hnsw_edge_distances(vg_index *idx, const float *l0_dist, void *stream);
 /* The same walk scored from the nodes' PQ codes instead of their fp32 rows: distFunc =
  * pq.ComputeAsymmetricDistance (pq.go:234-260), the way the reference scores graph nodes from PQ codes
  * (diskann/segment.go:536-557); no SquaredL2Bounded short-circuit (that kernel reads fp32 rows).  scores =

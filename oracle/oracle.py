@@ -843,6 +843,29 @@ def _search_filtered(self, query, k, ef, mask, selectivity):
 
 HnswIndex.search_filtered = _search_filtered
 
+_sig("vgo_hnsw_search_predicate", C.c_int32, C.POINTER(HnswGraph), _f32p, C.c_int32, C.c_int32, _u8p, _u8p, _f32p, _u32p, _f32p,
+     C.POINTER(SearchStats))
+
+
+def _search_predicate(self, query, k, ef, mask, deleted=None, l0_dist=None):
+    """searchExecute with a filter whose selectivity hint is <= 0.3 or unknown: searchLayerPredicateAware (hnsw.go:1406-1558).
+    mask / deleted: bool[n]; l0_dist: the cached Neighbor.Dist of the layer-0 lists [n, m0] (None = recomputed from the rows)."""
+    q, pq_ = _f(query)
+    ids = np.empty(max(k, ef, 1), np.uint32); sc = np.empty(max(k, ef, 1), np.float32)
+    mb = np.packbits(np.asarray(mask, np.bool_).reshape(self.n), bitorder="little")
+    db = None if deleted is None else np.packbits(np.asarray(deleted, np.bool_).reshape(self.n), bitorder="little")
+    ld = None if l0_dist is None else np.ascontiguousarray(l0_dist, np.float32)
+    st = SearchStats()
+    g = self._c()
+    r = lib.vgo_hnsw_search_predicate(C.byref(g), pq_, k, ef, mb.ctypes.data_as(_u8p),
+                                      db.ctypes.data_as(_u8p) if db is not None else None,
+                                      ld.ctypes.data_as(_f32p) if ld is not None else None,
+                                      ids.ctypes.data_as(_u32p), sc.ctypes.data_as(_f32p), C.byref(st))
+    return ids[:r], sc[:r], st
+
+
+HnswIndex.search_predicate = _search_predicate
+
 
 class VamanaIndex:
     def __init__(self, graph, entry_point, dim, kind=VAMANA_F32, metric=METRIC_L2, base=None,

@@ -1513,6 +1513,120 @@ int32_t vgo_hnsw_search_filtered(const vgo_hnsw_graph *g, const float *query, in
     return nres;
 }
 
+/* searchExecute with a filter whose selectivity hint is at or below highSelectivityThreshold, or unknown (hnsw.go:1107-1146):
+ * searchLayerPredicateAware (hnsw.go:1406-1558) on layer 0 after the usual greedy descent — restated statement by statement:
+ *   processEntryPoint (:1574-1583): the entry point always goes to the navigation queue (PushItem), to the results only when
+ *     it passes the filter and is not tombstoned (PushItem);
+ *   loop: pop the closest navigation candidate; stop when the results hold ef items and it is farther than the worst;
+ *   per neighbour, in list order: CheckAndVisit; passesFilter / isDeleted; consecutiveFilterMisses (reset by a pass);
+ *     a passing live node's distance is computed; a rejected one's comes from the cached edge distance (next.Dist > 0, else
+ *     computed) while results < ef/2; while results < ef it is skipped after more than 10 consecutive misses or when its
+ *     edge distance exceeds 1.5 x the worst result, else computed; with ef results it is skipped;
+ *     then, unless the results are full and the node is farther than the worst: PushItem to the navigation queue and — passing,
+ *     live nodes only — PushItemBounded(ef) to the results.
+ * mask: bit i = filter.Matches(i); deleted: bit i = tombstoned (NULL = none); l0_dist: the layer-0 lists' cached Neighbor.Dist
+ * values, n*m0 (node.go:62-80), NULL = recomputed as the distance between the two rows (what the insert stored, hnsw.go:516,550).
+ * stats: nodes_visited, distance_computations, distance_short_circuits = ExpansionsSkipped, pops. */
+int32_t vgo_hnsw_search_predicate(const vgo_hnsw_graph *g, const float *query, int32_t k, int32_t ef, const uint8_t *mask,
+                                  const uint8_t *deleted, const float *l0_dist, uint32_t *ids, float *scores,
+                                  vgo_search_stats *stats)
+{
+#define BIT(m, i) (((m)[(i) >> 3] >> ((i) & 7)) & 1)
+    vgo_search_stats st = {0, 0, 0, 0};
+    if (ef < k) ef = k;
+    uint32_t cur = g->entry_point;
+    float cur_d = hnsw_dist(g, query, cur);
+    for (int level = g->max_level; level > 0; level--) { /* greedySearch hnsw.go:1897-1934 */
+        int changed = 1;
+        while (changed) {
+            changed = 0;
+            uint32_t slot = g->slot[level - 1][cur];
+            if (slot == 0xFFFFFFFFu) continue;
+            const uint32_t *nb = g->adj[level - 1] + (int64_t)slot * g->m;
+            for (int i = 0; i < g->m && nb[i] != 0xFFFFFFFFu; i++) {
+                float d = hnsw_dist(g, query, nb[i]);
+                if (d < cur_d) {
+                    cur = nb[i];
+                    cur_d = d;
+                    changed = 1;
+                }
+            }
+        }
+    }
+    uint8_t *visited = (uint8_t *)calloc((size_t)g->n, 1);
+    vgo_prioq cand, res;
+    vgo_prioq_init(&cand, 0, ef * 2);
+    vgo_prioq_init(&res, 1, ef + 1);
+    visited[cur] = 1; /* initializeSearch */
+    vgo_prioq_push(&cand, (vgo_pq_item){cur, cur_d});
+    if ((!mask || BIT(mask, cur)) && !(deleted && BIT(deleted, cur))) vgo_prioq_push(&res, (vgo_pq_item){cur, cur_d});
+    int misses = 0;
+    vgo_pq_item c;
+    while (cand.len > 0) {
+        vgo_prioq_pop(&cand, &c);
+        st.pops++;
+        if (res.len >= ef && c.dist > res.items[0].dist) break;
+        const uint32_t *nb = g->l0 + (int64_t)c.node * g->m0;
+        for (int i = 0; i < g->m0 && nb[i] != 0xFFFFFFFFu; i++) {
+            const uint32_t id = nb[i];
+            if (visited[id]) continue;
+            visited[id] = 1;
+            st.nodes_visited++;
+            const int passes = !mask || BIT(mask, id);
+            const int dead = deleted && BIT(deleted, id);
+            if (passes) misses = 0;
+            else misses++;
+            float nd;
+            if (passes && !dead) {
+                nd = hnsw_dist(g, query, id);
+                st.distance_computations++;
+            } else {
+                const float edge = l0_dist ? l0_dist[(int64_t)c.node * g->m0 + i]
+                                           : hnsw_dist(g, g->base + (int64_t)c.node * g->dim, id);
+                if (res.len < ef / 2) {
+                    if (edge > 0) {
+                        nd = edge;
+                    } else {
+                        nd = hnsw_dist(g, query, id);
+                        st.distance_computations++;
+                    }
+                } else if (res.len < ef) {
+                    if (misses > 10) {
+                        st.distance_short_circuits++;
+                        continue;
+                    }
+                    if (edge > 0 && res.len > 0 && edge > res.items[0].dist * 1.5f) {
+                        st.distance_short_circuits++;
+                        continue;
+                    }
+                    nd = hnsw_dist(g, query, id);
+                    st.distance_computations++;
+                } else {
+                    st.distance_short_circuits++;
+                    continue;
+                }
+            }
+            if (res.len >= ef && nd > res.items[0].dist) continue;
+            vgo_prioq_push(&cand, (vgo_pq_item){id, nd});
+            if (passes && !dead) vgo_prioq_push_bounded(&res, (vgo_pq_item){id, nd}, ef);
+        }
+    }
+#undef BIT
+    vgo_pq_item it;
+    while (res.len > k) vgo_prioq_pop(&res, &it); /* extraction hnsw.go:1732-1751 */
+    int32_t nres = res.len;
+    for (int i = nres - 1; i >= 0; i--) {
+        vgo_prioq_pop(&res, &it);
+        ids[i] = it.node;
+        scores[i] = it.dist;
+    }
+    vgo_prioq_free(&cand);
+    vgo_prioq_free(&res);
+    free(visited);
+    if (stats) *stats = st;
+    return nres;
+}
+
 /* hnsw.BruteSearch hnsw.go:2021-2073 + scanSegment :2075-2101, and searchBitmap :2240-2263 + knnSearchInternal's
  * extraction :1732-1751 — the two exhaustive paths of the HNSW index, each with the heap discipline it is WRITTEN
  * with (they differ, and with them the order in which equal distances leave the heap):

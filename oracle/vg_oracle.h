@@ -192,6 +192,13 @@ int32_t vgo_hnsw_search(const vgo_hnsw_graph *g, const float *query, int32_t k, 
 int32_t vgo_hnsw_search_filtered(const vgo_hnsw_graph *g, const float *query, int32_t k, int32_t ef, const uint8_t *mask,
                                  double selectivity, uint32_t *ids, float *scores, vgo_search_stats *stats);
 
+/* searchLayerPredicateAware (hnsw.go:1406-1558) behind searchExecute — selectivity <= 0.3 or unknown.  mask = filter.Matches,
+ * deleted = tombstones (NULL = none), l0_dist = the layer-0 lists' cached Neighbor.Dist (n*m0; NULL = recomputed from the rows).
+ * stats->distance_short_circuits = ExpansionsSkipped. */
+int32_t vgo_hnsw_search_predicate(const vgo_hnsw_graph *g, const float *query, int32_t k, int32_t ef, const uint8_t *mask,
+                                  const uint8_t *deleted, const float *l0_dist, uint32_t *ids, float *scores,
+                                  vgo_search_stats *stats);
+
 /* hnsw.BruteSearch + scanSegment (hnsw.go:2021-2101) and searchBitmap (:2240-2263) + extraction (:1732-1751):
  * exhaustive scans over the rows whose mask bit is set (NULL = all), each with its own heap discipline */
 enum { VGO_BRUTE_SCAN = 0, VGO_BRUTE_BITMAP = 1 };

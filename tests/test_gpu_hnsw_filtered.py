@@ -91,9 +91,10 @@ def test_edges(vg, ctx):
     idx = vg.Index(ctx, n, dim)
     idx.set_vectors(base)
     idx.set_hnsw_graph(l0, upper, entry, m=8)
-    with pytest.raises(vg.VecgoHipError) as e:                             # the predicate-aware walk is not built
-        idx.search_hnsw_filtered(q, 10, 50, np.ones(n, bool), 0.2)
-    assert e.value.status == -5                                             # VG_ERR_UNSUPPORTED
+    # at or below 0.3 the same entry takes searchLayerPredicateAware (tests/test_gpu_hnsw_predicate.py)
+    pid, psc = idx.search_hnsw_filtered(q, 10, 50, only, 0.2)
+    eid, esc, _ = o.HnswIndex(base, dim, l0, upper, entry).search_predicate(q[0], 10, 50, only)
+    assert np.array_equal(pid[0, :eid.size], eid) and np.array_equal(bits(psc[0, :eid.size]), bits(esc))
     with pytest.raises(ValueError):
         idx.search_hnsw_filtered(q, 10, 50, np.ones(n - 1, bool), 0.5)    # a short mask never reaches the library
     assert o.HnswIndex(base, dim, l0, upper, entry).search_filtered(q[0], 10, 50, np.ones(n, bool), 0.3) is None

@@ -168,3 +168,29 @@ def test_vamana_oracle_filter_only_touches_the_result_heap():
     assert fst.nodes_visited >= ust.nodes_visited                 # the stop test waits for k MATCHING rows
     nid, nsc, nst = v.search(q, k, mask=np.zeros(n, bool))
     assert nid.size == 0 and nst.nodes_visited >= fst.nodes_visited
+
+
+def test_predicate_aware_oracle_properties():
+    """searchLayerPredicateAware restated (hnsw.go:1406-1558): every result passes the filter and is alive; with every row
+    passing no expansion is skipped and each visited node is scored once; tombstoned rows never surface; cached edge distances
+    change the navigation (a rejected node is not scored while results < ef/2), not the eligibility."""
+    rng = np.random.default_rng(6)
+    n, dim, k, ef = 1500, 16, 10, 64
+    base = rng.standard_normal((n, dim)).astype(np.float32)
+    l0, upper, entry = graphs.build_hnsw(base, m=8, seed=2)
+    h = o.HnswIndex(base, dim, l0, upper, entry)
+    q = rng.standard_normal(dim).astype(np.float32)
+    ids, sc, st = h.search_predicate(q, k, ef, np.ones(n, bool))
+    assert ids.size == k and np.all(np.diff(sc) >= 0)
+    assert st.distance_short_circuits == 0 and st.distance_computations == st.nodes_visited
+    mask = rng.random(n) < 0.15
+    dead = rng.random(n) < 0.3
+    ids, sc, st = h.search_predicate(q, k, ef, mask, deleted=dead)
+    assert np.all(mask[ids]) and not np.any(dead[ids]) and np.all(np.diff(sc) >= 0)
+    assert st.distance_computations < st.nodes_visited          # rejected nodes navigated by edge distance or skipped
+    d = ((base - q) ** 2).sum(1)
+    d[~mask | dead] = np.inf
+    assert len(set(ids.tolist()) & set(np.argsort(d)[:k].tolist())) >= 5
+    zero = np.zeros((n, l0.shape[1]), np.float32)                # no cached distances: every navigated node is scored
+    _, _, st0 = h.search_predicate(q, k, ef, mask, l0_dist=zero)
+    assert st0.distance_computations > st.distance_computations

@@ -1097,6 +1097,36 @@ class Index:
             st = st[:, :4]
         return (ids, scores, st) if stats else (ids, scores)
 
+    def set_hnsw_edge_distances(self, l0_dist=None, stream=None):
+        """The layer-0 lists' cached Neighbor.Dist [n, m0] (node.go:62-80) for search_hnsw_predicate; None = recompute them
+        from the fp32 rows (the distance between the two nodes, what the insert stored)."""
+        if l0_dist is None:
+            check(self._lib.vg_index_set_hnsw_edge_distances(self._h, None, _stream_ptr(stream)))
+            return
+        d, pd = _ptr(l0_dist, np.float32)
+        check(self._lib.vg_index_set_hnsw_edge_distances(self._h, pd, _stream_ptr(stream)))
+
+    def search_hnsw_predicate(self, queries, k, ef, mask, deleted=None, stats=False, stream=None):
+        """searchExecute with a filter whose selectivity hint is <= 0.3 or unknown: searchLayerPredicateAware
+        (hnsw.go:1406-1558).  mask: filter.Matches (bool[n] / packed bits, one for the batch or one per query); deleted: the
+        tombstone bitmap (bool[n] / packed bits) or None.  stats columns: nodes_visited, distance_computations,
+        ExpansionsSkipped, pops."""
+        nq = _rows(queries, self.dim)
+        m, pm, stride = self._packed_mask(mask, nq, "search_hnsw_predicate")
+        d, pdl, _ = (None, None, 0) if deleted is None else self._packed_mask(deleted, 1, "search_hnsw_predicate (deleted)")
+        q, pq_ = _ptr(queries, np.float32)
+        ids = _empty_like(queries, (nq, k), np.uint32)
+        scores = _empty_like(queries, (nq, k), np.float32)
+        i, pi = _ptr(ids, np.uint32)
+        s_, ps = _ptr(scores, np.float32)
+        st = np.zeros((nq, 5), np.int64) if stats else None
+        pst = C.c_void_p(st.ctypes.data) if stats else None
+        check(self._lib.vg_search_hnsw_predicate(self._h, pq_, C.c_int64(nq), C.c_int32(k), C.c_int32(ef), pm, C.c_int64(stride), pdl,
+                                                 pi, ps, pst, _stream_ptr(stream)))
+        if stats and stats != "full":
+            st = st[:, :4]
+        return (ids, scores, st) if stats else (ids, scores)
+
     BRUTE_SCAN, BRUTE_BITMAP = 0, 1
 
     def search_hnsw_brute(self, queries, k, mode=0, mask=None, stream=None):

@@ -607,6 +607,11 @@ VG_API int32_t vg_index_set_hnsw_graph(vg_index *idx, int32_t m0, const uint32_t
     VG_HIP(hipSetDevice(idx->ctx->device));
     hipStream_t st = vg::pick_stream(idx->ctx, stream);
     VG_TRY(replace_device_array(&idx->d_hnsw_l0, l0, static_cast<size_t>(idx->n) * m0, st));
+    if (idx->d_hnsw_l0_dist) {  // the old graph's edge distances (vg_index_set_hnsw_edge_distances)
+        VG_HIP(hipStreamSynchronize(st));
+        (void)hipFree(idx->d_hnsw_l0_dist);
+        idx->d_hnsw_l0_dist = nullptr;
+    }
     std::vector<int64_t> off(max_level + 1, 0);
     for (int l = 0; l < max_level; l++) {
         VG_CHECK(level_rows[l] >= 0, VG_ERR_INVALID_ARG, "vg_index_set_hnsw_graph: negative level_rows");
@@ -810,10 +815,9 @@ VG_API int32_t vg_search_hnsw_filtered(vg_index *idx, const float *queries, int6
     VG_CHECK(idx, VG_ERR_INVALID_ARG, "vg_search_hnsw_filtered: NULL index");
     VG_CHECK(mask, VG_ERR_INVALID_ARG, "vg_search_hnsw_filtered: NULL mask (vg_search_hnsw is the unfiltered walk)");
     // searchLayer's strategy choice (hnsw.go:1120-1145): above highSelectivityThreshold the unfiltered walk + post-filter;
-    // at or below it the reference walks predicate-aware (searchLayerPredicateAware, :1406), which is not built here
-    VG_CHECK(selectivity > 0.3, VG_ERR_UNSUPPORTED,
-             "vg_search_hnsw_filtered: selectivity %.3f is not above 0.3: the reference takes searchLayerPredicateAware there "
-             "(not implemented); vg_search_hnsw_brute serves selective masks", selectivity);
+    // at or below it (0 = unknown) the predicate-aware walk (searchLayerPredicateAware, :1406; k_hnsw_predicate.hip), no tombstones
+    if (!(selectivity > 0.3))
+        return vg_search_hnsw_predicate(idx, queries, nq, k, ef, mask, mask_stride, nullptr, ids, scores, stats, stream);
     const int64_t mask_bytes = (idx->n + 7) / 8;
     VG_CHECK(mask_stride == 0 || mask_stride >= mask_bytes, VG_ERR_INVALID_ARG,
              "vg_search_hnsw_filtered: mask_stride %lld is shorter than a mask (%lld bytes)", static_cast<long long>(mask_stride),

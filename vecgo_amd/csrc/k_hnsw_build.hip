@@ -1005,6 +1005,10 @@ VG_API int32_t vg_hnsw_build(vg_index *idx, int32_t m, int32_t ef_construction, 
         idx->d_hnsw_level_off = nullptr;
     }
     idx->d_hnsw_l0 = l0.release();
+    if (idx->d_hnsw_l0_dist) {  // the old graph's edge distances
+        (void)hipFree(idx->d_hnsw_l0_dist);
+        idx->d_hnsw_l0_dist = nullptr;
+    }
     idx->d_hnsw_adj = adj.release();
     idx->d_hnsw_slot = d_slots.release();
     idx->d_hnsw_level_off = d_level_off.release();

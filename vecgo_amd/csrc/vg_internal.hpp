@@ -346,6 +346,7 @@ struct vg_index {
     int32_t rq_groups = 0;  // ceil(((dim+63)/64*8) / 16)
     // HNSW adjacency
     uint32_t *d_hnsw_l0 = nullptr;     // n*m0
+    float *d_hnsw_l0_dist = nullptr;   // n*m0 cached edge distances (Neighbor.Dist) for the predicate-aware walk, or null
     uint32_t *d_hnsw_slot = nullptr;   // max_level*n
     uint32_t *d_hnsw_adj = nullptr;    // concatenated level tables
     int64_t *d_hnsw_level_off = nullptr;  // max_level+1 row offsets into d_hnsw_adj (in rows)
