@@ -1,6 +1,6 @@
 """Randomised differential run of the filtered searches against the oracle: vg_search_flat_filtered (fp32 / PQ / SQ8 scans,
-partitions or whole segment, few queries or a matrix-core batch, pages beyond 64 results) and vg_search_vamana_filtered
-(fp32 / PQ / RaBitQ / INT4 node scorers).  Row structure (ties included), filter selectivity (down to nothing passing), shapes and
+partitions or whole segment, few queries or a matrix-core batch, pages beyond 64 results) vg_search_vamana_filtered
+(fp32 / PQ / RaBitQ / INT4 node scorers) and vg_search_hnsw_predicate (tombstones, host-held edge distances).  Row structure (ties included), filter selectivity (down to nothing passing), shapes and
 k are drawn at random; every mismatch is printed with its configuration; exit code 1 if any.
 `python tools/fuzz_filtered.py [seconds] [seed]`"""
 import sys, time
@@ -17,7 +17,7 @@ rng = np.random.default_rng(seed)
 ctx = vg.Context(0)
 bits = lambda x: np.asarray(x, np.float32).view(np.uint32)
 fails = 0
-runs = {"flat_f32": 0, "flat_pq": 0, "flat_sq8": 0, "vamana": 0}
+runs = {"flat_f32": 0, "flat_pq": 0, "flat_sq8": 0, "vamana": 0, "hnsw_predicate": 0}
 
 
 def rows(n, dim):
@@ -116,6 +116,42 @@ while time.time() < t_end:
                 r = eid.size
                 if not (np.array_equal(ids[qi, :r], eid) and np.array_equal(bits(sc[qi, :r]), bits(esc)) and np.all(ids[qi, r:] == 0xFFFFFFFF)):
                     report(which, cfg, f"query {qi}: got {ids[qi, :4]} want {eid[:4]}")
+                    break
+            idx.close()
+        elif which == "hnsw_predicate":
+            dim = int(rng.choice([8, 16, 33, 64, 128]))
+            n = int(rng.choice([200, 1000, 2500]))
+            metric = int(rng.choice([0, 1, 2]))
+            base = rows(n, dim)
+            if metric:
+                base = np.ascontiguousarray(base / np.maximum(np.linalg.norm(base, axis=1, keepdims=True), 1e-30), np.float32)
+            mdeg = int(rng.choice([4, 8, 16]))
+            l0, upper, entry = graphs.build_hnsw(base, m=mdeg, seed=int(rng.integers(0, 99)))
+            oidx = o.HnswIndex(base, dim, l0, upper, entry, metric=metric)
+            idx = vg.Index(ctx, n, dim, vg.Metric(metric))
+            idx.set_vectors(base)
+            idx.set_hnsw_graph(l0, upper, entry, m=mdeg)
+            l0_dist = None
+            if rng.random() < 0.4:      # host-held edge distances that are not the recomputed ones (zeros included)
+                l0_dist = (rng.random(l0.shape) * float(rng.choice([0.1, 10.0]))).astype(np.float32)
+                l0_dist[rng.random(l0.shape) < 0.3] = 0.0
+                idx.set_hnsw_edge_distances(l0_dist)
+            nq = int(rng.choice([1, 3, 9]))
+            q = rows(nq, dim)
+            k = int(rng.choice([1, 5, 10, 64, 100]))
+            ef = int(rng.choice([1, 10, 50, 128, 300, 1000]))
+            mask, keep, per_query = make_mask(nq, n)
+            dead = (rng.random(n) < float(rng.choice([0.05, 0.5]))) if rng.random() < 0.4 else None
+            cfg = dict(n=n, dim=dim, metric=metric, m=mdeg, k=k, ef=ef, keep=keep, per_query=per_query, dead=dead is not None,
+                       own_edges=l0_dist is not None)
+            ids, sc, st = idx.search_hnsw_predicate(q, k, ef, mask, deleted=dead, stats=True)
+            for qi in range(nq):
+                eid, esc, est = oidx.search_predicate(q[qi], k, ef, mask[qi] if per_query else mask, deleted=dead, l0_dist=l0_dist)
+                r = eid.size
+                if not (np.array_equal(ids[qi, :r], eid) and np.array_equal(bits(sc[qi, :r]), bits(esc)) and
+                        tuple(int(v) for v in st[qi]) == (est.nodes_visited, est.distance_computations,
+                                                          est.distance_short_circuits, est.pops)):
+                    report(which, cfg, f"query {qi}")
                     break
             idx.close()
         else:
