@@ -309,6 +309,18 @@ func (r *Resident) SearchHNSWPredicate(queries []float32, nq, k, ef int, mask []
 	return ids, sc, hipctx.Err(int32(st))
 }
 
+// SetHNSWTombstones: g.tombstones (hnsw.go:95) as a bitmap, ceil(rows/8) bytes, nil = none: deleted nodes are walked
+// through but never returned by the HNSW searches (hnsw.go:1381-1390).
+func (r *Resident) SetHNSWTombstones(deleted []byte) error {
+	if len(deleted) == 0 {
+		return hipctx.Err(int32(C.vg_index_set_hnsw_tombstones(r.h, nil, nil)))
+	}
+	if need := (r.rows + 7) / 8; len(deleted) < need {
+		return fmt.Errorf("SetHNSWTombstones: bitmap holds %d bytes, %d needed", len(deleted), need)
+	}
+	return hipctx.Err(int32(C.vg_index_set_hnsw_tombstones(r.h, bp(deleted), nil)))
+}
+
 // SetHNSWEdgeDistances: the layer-0 lists' cached Neighbor.Dist (node.go:62-80), rows*m0 values slot for slot with the uploaded
 // lists; nil = recompute them from the fp32 rows.
 func (r *Resident) SetHNSWEdgeDistances(l0Dist []float32) error {

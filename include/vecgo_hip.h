@@ -51,8 +51,9 @@ extern "C" {
  *   3: (r05) vg_search_hnsw_filtered
  *   4: (r05) vg_search_flat_filtered
  *   5: (r05) vg_search_vamana_filtered
- *   6: (r05) vg_search_hnsw_predicate, vg_index_set_hnsw_edge_distances; vg_search_hnsw_filtered serves every selectivity */
-#define VG_ABI_MINOR 6
+ *   6: (r05) vg_search_hnsw_predicate, vg_index_set_hnsw_edge_distances; vg_search_hnsw_filtered serves every selectivity
+ *   7: (r05) vg_index_set_hnsw_tombstones */
+#define VG_ABI_MINOR 7
 #define VG_INVALID_ID 0xFFFFFFFFu
 #define VG_STREAM_LEGACY ((void *)1) /* == hipStreamLegacy */
 
@@ -585,6 +586,14 @@ int32_t vg_search_hnsw_predicate(vg_index *idx, const float *queries, int64_t nq
  * bits of the reference's neighbour words, node.go:67-80); NULL = recompute them from the fp32 rows as the distance between
  * the two nodes, which is what the insert stored (hnsw.go:516, :550, :964).  Dropped when the graph is replaced. */
 int32_t vg_index_set_hnsw_edge_distances(vg_index *idx, const float *l0_dist, void *stream);
+/* g.tombstones (hnsw.go:95, Delete :1601-1617) as a bitmap: bit i of byte i/8 set = node i deleted, ceil(n/8) bytes; NULL = no
+ * deleted node.  A deleted node is walked through but never enters the results, so it never moves the bound either
+ * (searchLayerUnfiltered hnsw.go:1381-1390, processEntryPointUnfiltered :1559-1565, the post-filter's re-filter :1198,
+ * searchLayerPredicateAware :1485, :1580).  Read by vg_search_hnsw, _hnsw_pq, _hnsw_filtered and — when its own `deleted`
+ * argument is NULL — vg_search_hnsw_predicate; while it is set the unfiltered / post-filter walks run as the pass that
+ * compares as the reference writes it (the one that answers NaN distances), somewhat slower than the tuned walk.
+ * vg_search_hnsw_brute takes the tombstones inside its mask, as before.  (VG_ABI_MINOR 7.) */
+int32_t vg_index_set_hnsw_tombstones(vg_index *idx, const uint8_t *deleted, void *stream);
 /* The same walk scored from the nodes' PQ codes instead of their fp32 rows: distFunc =
  * pq.ComputeAsymmetricDistance (pq.go:234-260), the way the reference scores graph nodes from PQ codes
  * (diskann/segment.go:536-557); no SquaredL2Bounded short-circuit (that kernel reads fp32 rows).  scores =

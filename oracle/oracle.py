@@ -52,7 +52,7 @@ class HnswGraph(C.Structure):
     _fields_ = [("n", C.c_int64), ("dim", C.c_int32), ("metric", C.c_int32), ("base", _f32p),
                 ("m0", C.c_int32), ("l0", _u32p), ("max_level", C.c_int32), ("m", C.c_int32),
                 ("slot", C.POINTER(_u32p)), ("adj", C.POINTER(_u32p)),
-                ("entry_point", C.c_uint32), ("pq", C.POINTER(PQ)), ("codes", _u8p)]
+                ("entry_point", C.c_uint32), ("pq", C.POINTER(PQ)), ("codes", _u8p), ("tombstones", _u8p)]
 
 
 class Vamana(C.Structure):
@@ -698,7 +698,12 @@ class HnswIndex:
         return HnswGraph(self.n, self.dim, self.metric, self.base.ctypes.data_as(_f32p), self.m0,
                          self.l0.ctypes.data_as(_u32p), nl, self.m, self._slots, self._adjs,
                          self.entry_point, C.pointer(self._pqc) if self._pqc is not None else None,
-                         self.codes.ctypes.data_as(_u8p) if self.codes is not None else None)
+                         self.codes.ctypes.data_as(_u8p) if self.codes is not None else None,
+                         self._tomb.ctypes.data_as(_u8p) if getattr(self, "_tomb", None) is not None else None)
+
+    def set_tombstones(self, deleted):
+        """g.tombstones (hnsw.go:95): bool[n], None clears — deleted nodes are walked through, never returned"""
+        self._tomb = None if deleted is None else np.packbits(np.asarray(deleted, np.bool_).reshape(self.n), bitorder="little")
 
     def search(self, query, k, ef):
         q, pq_ = _f(query)

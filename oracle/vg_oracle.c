@@ -1315,9 +1315,10 @@ void vgo_hnsw_search_layer(const vgo_hnsw_graph *g, const float *query, uint32_t
     vgo_prioq cand = *candp, res = *resp;
     cand.len = 0;
     res.len = 0;
+#define TOMB(id) (g->tombstones && ((g->tombstones[(id) >> 3] >> ((id) & 7)) & 1))
     visited[ep] = epoch;
     vgo_prioq_push(&cand, (vgo_pq_item){ep, ep_d});
-    vgo_prioq_push(&res, (vgo_pq_item){ep, ep_d});
+    if (!TOMB(ep)) vgo_prioq_push(&res, (vgo_pq_item){ep, ep_d}); /* processEntryPointUnfiltered hnsw.go:1559-1565 */
 
     int use_sc = g->metric == VGO_METRIC_L2 && !g->pq;
     int cap = ef * 2;
@@ -1368,6 +1369,7 @@ void vgo_hnsw_search_layer(const vgo_hnsw_graph *g, const float *query, uint32_t
             }
             if (has_bound && nd > bound) continue;
             vgo_prioq_try_push_bounded(&cand, (vgo_pq_item){id, nd}, cap);
+            if (TOMB(id)) continue; /* hnsw.go:1381-1390: only live nodes enter the results (and move the bound) */
             vgo_prioq_push_bounded(&res, (vgo_pq_item){id, nd}, ef);
             if (res.len >= ef) {
                 bound = res.items[0].dist;
@@ -1375,6 +1377,7 @@ void vgo_hnsw_search_layer(const vgo_hnsw_graph *g, const float *query, uint32_t
             }
         }
     }
+#undef TOMB
     *candp = cand;
     *resp = res;
     *stp = st;
@@ -1490,7 +1493,9 @@ int32_t vgo_hnsw_search_filtered(const vgo_hnsw_graph *g, const float *query, in
     vgo_pq_item it;
     while (res.len > 0) {
         vgo_prioq_pop(&res, &it);
-        if (!mask || ((mask[it.node >> 3] >> (it.node & 7)) & 1)) keep[nkeep++] = it;
+        if ((!mask || ((mask[it.node >> 3] >> (it.node & 7)) & 1)) &&
+            !(g->tombstones && ((g->tombstones[it.node >> 3] >> (it.node & 7)) & 1)))
+            keep[nkeep++] = it; /* hnsw.go:1198 */
     }
     for (int32_t i = 0; i < nkeep; i++) {
         if (res.len < ef)
@@ -1534,6 +1539,7 @@ int32_t vgo_hnsw_search_predicate(const vgo_hnsw_graph *g, const float *query, i
 #define BIT(m, i) (((m)[(i) >> 3] >> ((i) & 7)) & 1)
     vgo_search_stats st = {0, 0, 0, 0};
     if (ef < k) ef = k;
+    if (!deleted) deleted = g->tombstones;
     uint32_t cur = g->entry_point;
     float cur_d = hnsw_dist(g, query, cur);
     for (int level = g->max_level; level > 0; level--) { /* greedySearch hnsw.go:1897-1934 */

@@ -177,6 +177,9 @@ typedef struct {
      * diskann/segment.go:536-557 builds it; no SquaredL2Bounded short-circuit then */
     const vgo_pq *pq;
     const uint8_t *codes;
+    /* appended: g.tombstones (hnsw.go:95) as a bitmap, bit i of byte i/8 = node i deleted; NULL = none.  A deleted node is
+     * walked through but never enters the results (hnsw.go:1381-1390, :1562, :1198, :1485, :1580). */
+    const uint8_t *tombstones;
 } vgo_hnsw_graph;
 
 typedef struct {

@@ -1106,6 +1106,15 @@ class Index:
         d, pd = _ptr(l0_dist, np.float32)
         check(self._lib.vg_index_set_hnsw_edge_distances(self._h, pd, _stream_ptr(stream)))
 
+    def set_hnsw_tombstones(self, deleted=None, stream=None):
+        """g.tombstones (hnsw.go:95): bool[n] / packed bits, None clears.  Deleted nodes are walked through, never returned
+        (hnsw.go:1381-1390); read by search_hnsw, search_hnsw_pq, search_hnsw_filtered, search_hnsw_predicate."""
+        if deleted is None:
+            check(self._lib.vg_index_set_hnsw_tombstones(self._h, None, _stream_ptr(stream)))
+            return
+        d, pd, _ = self._packed_mask(deleted, 1, "set_hnsw_tombstones")
+        check(self._lib.vg_index_set_hnsw_tombstones(self._h, pd, _stream_ptr(stream)))
+
     def search_hnsw_predicate(self, queries, k, ef, mask, deleted=None, stats=False, stream=None):
         """searchExecute with a filter whose selectivity hint is <= 0.3 or unknown: searchLayerPredicateAware
         (hnsw.go:1406-1558).  mask: filter.Matches (bool[n] / packed bits, one for the batch or one per query); deleted: the

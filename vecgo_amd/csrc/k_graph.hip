@@ -78,7 +78,9 @@ __global__ __launch_bounds__(64) VG_HNSW_ATTR void hnsw_search_kernel(
                                   queries so marked, every comparison as the reference writes it */,
     const uint8_t *__restrict__ mask, int64_t mask_stride, int ef_keep /* searchLayerWithPostFilter (hnsw.go:1159-1218):
                                   `ef` is the EXPANDED ef the walk runs with; afterwards every result is popped, the rows
-                                  whose mask bit is set are kept in that order and pushed back capped at ef_keep */)
+                                  whose mask bit is set are kept in that order and pushed back capped at ef_keep */,
+    const uint8_t *__restrict__ dead /* g.tombstones (vg_index_set_hnsw_tombstones) or nullptr; read by the STRICT instances,
+                                        which answer every query of a tombstoned graph */)
 {
     extern __shared__ __attribute__((aligned(8))) unsigned char smem[];
     constexpr bool PQ = PQM != 0;
@@ -173,7 +175,7 @@ __global__ __launch_bounds__(64) VG_HNSW_ATTR void hnsw_search_kernel(
 #else
                              // (PQ codes hold no NaN: the query was checked once, above — the per-list watch cost the
                              // split-heap PQ walk 5 %: 9.71 -> 10.24 ms per 8192 queries at ef 512)
-                             st, STRICT || PQ ? nullptr : &odd);
+                             st, STRICT || PQ ? nullptr : &odd, STRICT ? dead : nullptr);
 #endif
     if (odd) {  // a NaN distance: this query is answered by the second pass (search_hnsw_impl)
         if (lane == 0) redo[q] = 1;
@@ -186,7 +188,7 @@ __global__ __launch_bounds__(64) VG_HNSW_ATTR void hnsw_search_kernel(
         int keep = 0;
         while (res_len > 0) {
             const HItem it = heap_pop<true, UK>(res, res_len);
-            if ((mq[it.node >> 3] >> (it.node & 7)) & 1) heap_put(cand, keep++, it);
+            if (((mq[it.node >> 3] >> (it.node & 7)) & 1) && !(dead && mask_bit(dead, it.node))) heap_put(cand, keep++, it);  // :1198
         }
         for (int i = 0; i < keep; i++) {
             const HItem it = heap_get(cand, i);
@@ -769,8 +771,10 @@ static int32_t search_hnsw_impl(vg_index *idx, bool pq, const float *queries, in
         const int64_t cnt = std::min(chunk, nq - q0);
         VG_HIP(hipMemsetAsync(vis.ptr, 0, static_cast<size_t>(cnt) * vis_words * 4, st));
         if (luts) VG_TRY(vg::launch_pq_build_table(idx->pq, q.ptr + q0 * idx->dim, cnt, luts, false, st));
-        VG_HIP(hipMemsetAsync(redo, 0, static_cast<size_t>(cnt), st));
-        {
+        // a graph with tombstones: every query takes the pass that walks as the reference writes it (float comparisons, each lane
+        // at its turn) and reads the bitmap — the fast pass is tuned to its register budget without it
+        VG_HIP(hipMemsetAsync(redo, idx->d_hnsw_tomb ? 1 : 0, static_cast<size_t>(cnt), st));
+        if (!idx->d_hnsw_tomb) {
             vg::ProfScope prof(idx->ctx, pq ? "hnsw_search_pq" : "hnsw_search", st);
             VG_LAUNCH(kern, dim3(static_cast<unsigned>(cnt)), dim3(64), lds, st, idx->d_vectors, idx->n, idx->dim,
                       idx->metric, idx->d_hnsw_l0, idx->hnsw_m0, idx->hnsw_max_level, idx->hnsw_m, idx->d_hnsw_slot,
@@ -778,16 +782,17 @@ static int32_t search_hnsw_impl(vg_index *idx, bool pq, const float *queries, in
                       pq ? idx->d_pq_rows : nullptr, pq_m, luts, pq_direct ? idx->pq->d_codebooks : nullptr,
                       pq ? idx->pq->d_scales : nullptr, pq ? idx->pq->d_offsets : nullptr, k, ef_walk, lds_cand, lds_res, vis.ptr,
                       vis_words, heap_ws, oid.ptr + q0 * k, osc.ptr + q0 * k, ost.ptr ? ost.ptr + q0 : nullptr, redo,
-                      mk.ptr ? mk.ptr + q0 * mask_stride : nullptr, mask_stride, ef_keep);
+                      mk.ptr ? mk.ptr + q0 * mask_stride : nullptr, mask_stride, ef_keep, idx->d_hnsw_tomb);
         }
         // (every workgroup of an ordinary batch leaves at its first instruction)
+        vg::ProfScope prof_strict(idx->ctx, idx->d_hnsw_tomb ? (pq ? "hnsw_search_pq" : "hnsw_search") : "hnsw_search_redo", st);
         VG_LAUNCH(kern_f32, dim3(static_cast<unsigned>(cnt)), dim3(64), lds, st, idx->d_vectors, idx->n, idx->dim,
                       idx->metric, idx->d_hnsw_l0, idx->hnsw_m0, idx->hnsw_max_level, idx->hnsw_m, idx->d_hnsw_slot,
                       idx->d_hnsw_adj, idx->d_hnsw_level_off, idx->hnsw_entry, q.ptr + q0 * idx->dim,
                       pq ? idx->d_pq_rows : nullptr, pq_m, luts, pq_direct ? idx->pq->d_codebooks : nullptr,
                       pq ? idx->pq->d_scales : nullptr, pq ? idx->pq->d_offsets : nullptr, k, ef_walk, lds_cand, lds_res, vis.ptr,
                       vis_words, heap_ws, oid.ptr + q0 * k, osc.ptr + q0 * k, ost.ptr ? ost.ptr + q0 : nullptr, redo,
-                      mk.ptr ? mk.ptr + q0 * mask_stride : nullptr, mask_stride, ef_keep);
+                      mk.ptr ? mk.ptr + q0 * mask_stride : nullptr, mask_stride, ef_keep, idx->d_hnsw_tomb);
     }
     VG_TRY(oid.finish());
     VG_TRY(osc.finish());

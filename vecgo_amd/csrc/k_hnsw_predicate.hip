@@ -244,6 +244,30 @@ VG_API int32_t vg_index_set_hnsw_edge_distances(vg_index *idx, const float *l0_d
     return vg::hnsw_edge_distances(idx, l0_dist, vg::pick_stream(idx->ctx, stream));
 }
 
+VG_API int32_t vg_index_set_hnsw_tombstones(vg_index *idx, const uint8_t *deleted, void *stream)
+{
+    VG_CHECK(idx, VG_ERR_INVALID_ARG, "vg_index_set_hnsw_tombstones: NULL index");
+    VG_HIP(hipSetDevice(idx->ctx->device));
+    hipStream_t st = vg::pick_stream(idx->ctx, stream);
+    VG_HIP(hipStreamSynchronize(st));  // earlier searches may still read the old bitmap
+    if (idx->d_hnsw_tomb) {
+        VG_HIP(hipFree(idx->d_hnsw_tomb));
+        idx->d_hnsw_tomb = nullptr;
+    }
+    const size_t bytes = static_cast<size_t>((idx->n + 7) / 8);
+    if (deleted == nullptr || bytes == 0) return VG_OK;
+    uint8_t *d = nullptr;
+    VG_HIP(hipMalloc(reinterpret_cast<void **>(&d), bytes));
+    const hipError_t e = hipMemcpyAsync(d, deleted, bytes, hipMemcpyDefault, st);
+    if (e != hipSuccess) {
+        (void)hipFree(d);
+        VG_HIP(e);
+    }
+    VG_HIP(hipStreamSynchronize(st));
+    idx->d_hnsw_tomb = d;
+    return VG_OK;
+}
+
 VG_API int32_t vg_search_hnsw_predicate(vg_index *idx, const float *queries, int64_t nq, int32_t k, int32_t ef, const uint8_t *mask,
                                         int64_t mask_stride, const uint8_t *deleted, uint32_t *ids, float *scores,
                                         vg_search_stats *stats, void *stream)
@@ -299,7 +323,7 @@ VG_API int32_t vg_search_hnsw_predicate(vg_index *idx, const float *queries, int
         VG_LAUNCH(vg::hnsw_predicate_kernel, dim3(static_cast<unsigned>(cnt)), dim3(64), lds, st, idx->d_vectors, idx->n, idx->dim,
                   idx->metric, idx->d_hnsw_l0, idx->d_hnsw_l0_dist, idx->hnsw_m0, idx->hnsw_max_level, idx->hnsw_m, idx->d_hnsw_slot,
                   idx->d_hnsw_adj, idx->d_hnsw_level_off, idx->hnsw_entry, q.ptr + q0 * idx->dim, k, ef, mk.ptr + q0 * mask_stride,
-                  mask_stride, dl.ptr, vis, vis_words, cand, cand_cap, oid.ptr + q0 * k, osc.ptr + q0 * k,
+                  mask_stride, deleted ? dl.ptr : idx->d_hnsw_tomb, vis, vis_words, cand, cand_cap, oid.ptr + q0 * k, osc.ptr + q0 * k,
                   ost.ptr ? ost.ptr + q0 : nullptr);
     }
     VG_TRY(oid.finish());

@@ -283,6 +283,7 @@ VG_API int32_t vg_index_destroy(vg_index *idx)
     if (idx->d_rq_norms) (void)hipFree(idx->d_rq_norms);
     if (idx->d_hnsw_l0) (void)hipFree(idx->d_hnsw_l0);
     if (idx->d_hnsw_l0_dist) (void)hipFree(idx->d_hnsw_l0_dist);
+    if (idx->d_hnsw_tomb) (void)hipFree(idx->d_hnsw_tomb);
     if (idx->d_hnsw_slot) (void)hipFree(idx->d_hnsw_slot);
     if (idx->d_hnsw_adj) (void)hipFree(idx->d_hnsw_adj);
     if (idx->d_hnsw_level_off) (void)hipFree(idx->d_hnsw_level_off);

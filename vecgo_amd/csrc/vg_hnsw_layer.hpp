@@ -404,8 +404,10 @@ template <bool UK = false, bool STRICT = false, typename Scorer, typename RowFn,
 __device__ __forceinline__ void search_layer(const Scorer &sc, bool l2_metric, int lane, RowFn row_of, int deg,
                                              uint32_t ep, float ep_d, int ef, Heap cand, Heap res,
                                              float *nb_pair, float *nb_bnd, uint32_t *vis, int &res_len_out,
-                                             LayerStats &st, bool *odd_out = nullptr)
+                                             LayerStats &st, bool *odd_out = nullptr, const uint8_t *dead = nullptr)
 {
+    // dead (STRICT instances only): g.tombstones as a bitmap — a deleted node goes to the exploration queue like any other but
+    // never to the results, and so never moves the bound (hnsw.go:1381-1390; entry point :1559-1565)
     constexpr bool strict = STRICT;
     auto is_odd = [](float d) { return UK ? __float_as_uint(d) > 0x7F800000u : d != d; };
     if (odd_out && is_odd(ep_d)) {  // wave-uniform
@@ -416,7 +418,7 @@ __device__ __forceinline__ void search_layer(const Scorer &sc, bool l2_metric, i
     int cand_len = 0, res_len = 0;
     if (lane == 0) atomicOr(&vis[ep >> 5], 1u << (ep & 31));
     heap_push<false>(cand, cand_len, HItem{ep, ep_d});
-    heap_push<true>(res, res_len, HItem{ep, ep_d});
+    if (!(STRICT && dead && mask_bit(dead, ep))) heap_push<true>(res, res_len, HItem{ep, ep_d});
     const bool use_sc = Scorer::kBounded && l2_metric;
     int cap = ef * 2;
     int stagnant = 0;
@@ -456,6 +458,10 @@ __device__ __forceinline__ void search_layer(const Scorer &sc, bool l2_metric, i
             fresh = (atomicOr(&vis[id_lane >> 5], bit) & bit) == 0;
         }
         const uint64_t newmask = __ballot(fresh);
+        uint64_t deadmask = 0;
+        if constexpr (STRICT) {
+            if (dead) deadmask = __ballot(fresh && mask_bit(dead, id_lane));
+        }
         st.visited += __popcll(newmask);
         VG_T(t2);
         sc.many(newmask, id_lane, lane, nb_pair, nb_bnd);
@@ -497,6 +503,7 @@ __device__ __forceinline__ void search_layer(const Scorer &sc, bool l2_metric, i
             VG_T(tc0);
             accepted |= 1ull << j;  // its candidates-heap push happens after the loop (the two heaps are independent)
             if (!has_bound) pre_bound |= 1ull << j;  // pushed with the SquaredL2 value, not the bounded kernel's
+            if (STRICT && ((deadmask >> j) & 1)) continue;  // tombstoned: the exploration queue only
             VG_T(tc1);
             if (has_bound) {  // results heap full: its top is `bound`
                 res_replace_top<UK>(res, res_len, HItem{id, nd}, bound);

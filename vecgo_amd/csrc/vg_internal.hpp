@@ -347,6 +347,7 @@ struct vg_index {
     // HNSW adjacency
     uint32_t *d_hnsw_l0 = nullptr;     // n*m0
     float *d_hnsw_l0_dist = nullptr;   // n*m0 cached edge distances (Neighbor.Dist) for the predicate-aware walk, or null
+    uint8_t *d_hnsw_tomb = nullptr;    // g.tombstones as a bitmap (ceil(n/8) bytes), or null: no deleted node
     uint32_t *d_hnsw_slot = nullptr;   // max_level*n
     uint32_t *d_hnsw_adj = nullptr;    // concatenated level tables
     int64_t *d_hnsw_level_off = nullptr;  // max_level+1 row offsets into d_hnsw_adj (in rows)
