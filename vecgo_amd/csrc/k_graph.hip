@@ -315,7 +315,9 @@ __device__ __forceinline__ uint64_t *vamana_result_list()
 #ifndef VG_VAMANA_PQ_WAVES
 #define VG_VAMANA_PQ_WAVES 4
 #endif
-template <int kind, bool big>
+// MASKED: vg_search_vamana_filtered (pushToHeap's filter, segment.go:616-627) — a template flag: the unfiltered instances keep
+// their register budgets (a runtime mask cost 13 registers: the PQ-direct scorer spilled, the others lost a wave per SIMD)
+template <int kind, bool big, bool MASKED = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(kind == kVamanaPQDirect ? VG_VAMANA_PQ_WAVES : 1, kind == kVamanaF32 ? VG_VAMANA_F32_MAX_WAVES : 8))) void vamana_search_kernel(
     int metric, int64_t n, int dim, const uint32_t *__restrict__ graph, int r, uint32_t entry,
     const float *__restrict__ base, const uint8_t *__restrict__ pq_rows, int pq_m,
@@ -479,8 +481,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(kind == kVam
     heap_push<false>(cand, cand_len, HItem{entry, sd});
     // pushToHeap (segment.go:616-627): a row whose filter.Matches is false goes to the traversal queue only — sc.Heap, and with it
     // the pruning test below, holds matching rows
-    const uint8_t *mq = mask ? mask + blockIdx.x * mask_stride : nullptr;
-    const bool entry_ok = mask_bit(mq, entry);
+    const uint8_t *mq = MASKED ? mask + blockIdx.x * mask_stride : nullptr;
+    const bool entry_ok = !MASKED || mask_bit(mq, entry);
     offer(lane == 0 && entry_ok ? make_key(sd, entry, desc) : kKeyMax);
     heap_count = entry_ok && 1 < k ? 1 : (entry_ok ? k : 0);
     __syncthreads();
@@ -522,8 +524,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(kind == kVam
             }
         }
         // result heap: TryPushBounded(k) — a set maintained by (score, id): order-free
-        const bool pass = fresh && mask_bit(mq, id_lane);
-        const int npass = mq ? __popcll(__ballot(pass)) : nnew;
+        const bool pass = fresh && (!MASKED || mask_bit(mq, id_lane));
+        const int npass = MASKED ? __popcll(__ballot(pass)) : nnew;
         offer(pass ? make_key(myd, id_lane, desc) : kKeyMax);
         heap_count = heap_count + npass < k ? heap_count + npass : k;
         __syncthreads();
@@ -925,14 +927,24 @@ static int32_t vamana_impl(vg_index *idx, const float *queries, int64_t nq, int3
         };
         const bool big = k > 64;
         int32_t rc;
-        switch (pq_direct ? vg::kVamanaPQDirect : int4_direct ? vg::kVamanaInt4Direct : kind) {
-        case 0: rc = big ? launch(vg::vamana_search_kernel<0, true>) : launch(vg::vamana_search_kernel<0, false>); break;
-        case 1: rc = big ? launch(vg::vamana_search_kernel<1, true>) : launch(vg::vamana_search_kernel<1, false>); break;
-        case 4: rc = big ? launch(vg::vamana_search_kernel<4, true>) : launch(vg::vamana_search_kernel<4, false>); break;
-        case 5: rc = big ? launch(vg::vamana_search_kernel<5, true>) : launch(vg::vamana_search_kernel<5, false>); break;
-        case 2: rc = big ? launch(vg::vamana_search_kernel<2, true>) : launch(vg::vamana_search_kernel<2, false>); break;
-        default: rc = big ? launch(vg::vamana_search_kernel<3, true>) : launch(vg::vamana_search_kernel<3, false>); break;
+        const int inst = pq_direct ? vg::kVamanaPQDirect : int4_direct ? vg::kVamanaInt4Direct : kind;
+#define VG_VAMANA_CASE(K)                                                                                                   \
+    case K:                                                                                                                 \
+        rc = mk.ptr ? (big ? launch(vg::vamana_search_kernel<K, true, true>) : launch(vg::vamana_search_kernel<K, false, true>)) \
+                    : (big ? launch(vg::vamana_search_kernel<K, true>) : launch(vg::vamana_search_kernel<K, false>));       \
+        break;
+        switch (inst) {
+            VG_VAMANA_CASE(0)
+            VG_VAMANA_CASE(1)
+            VG_VAMANA_CASE(4)
+            VG_VAMANA_CASE(5)
+            VG_VAMANA_CASE(2)
+        default:
+            rc = mk.ptr ? (big ? launch(vg::vamana_search_kernel<3, true, true>) : launch(vg::vamana_search_kernel<3, false, true>))
+                        : (big ? launch(vg::vamana_search_kernel<3, true>) : launch(vg::vamana_search_kernel<3, false>));
+            break;
         }
+#undef VG_VAMANA_CASE
         VG_TRY(rc);
     }
     VG_TRY(oid.finish());

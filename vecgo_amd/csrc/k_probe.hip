@@ -232,13 +232,7 @@ __global__ __launch_bounds__(256) void probe_scan_f32_mq_kernel(const float *__r
         return r;
     };
     // a wave step = 8 rows, two per 16-lane group (rows i and i + 4): each LDS read of a query is used twice
-    for (int64_t i0 = r0 + wave * 8; MASKED || i0 < r1; i0 += 32) {
-        int64_t ia = i0 + (lane >> 4), ib = ia + 4;
-        if (MASKED) {
-            ia = next_wanted();
-            ib = next_wanted();
-            if (!__any(ia < r1)) break;
-        }
+    auto step = [&](const int64_t ia, const int64_t ib) {
         const bool livea = ia < r1, liveb = ib < r1;
         const float *rowa = base + (livea ? ia : r1 - 1) * dim;
         const float *rowb = base + (liveb ? ib : r1 - 1) * dim;
@@ -258,7 +252,7 @@ __global__ __launch_bounds__(256) void probe_scan_f32_mq_kernel(const float *__r
             uint64_t key = kKeyMax;
             if ((lane & 15) == 0 && livea) key = make_key(va, static_cast<uint32_t>(ia), DOT);
             if ((lane & 15) == 1 && liveb) key = make_key(vb, static_cast<uint32_t>(ib), DOT);
-            if (min_keys && key != kKeyMax && key <= min_keys[qof[qi]]) key = kKeyMax;  // paged results (k > 64)
+            if (min_keys && key != kKeyMax && key <= min_keys[pair[qi] / np]) key = kKeyMax;  // paged results (k > 64)
             if (MASKED && mask_stride != 0 && key != kKeyMax &&  // each query its own filter
                 !mask_bit(mask + static_cast<int64_t>(qof[qi]) * mask_stride, (lane & 15) == 0 ? ia : ib))
                 key = kKeyMax;
@@ -275,6 +269,15 @@ __global__ __launch_bounds__(256) void probe_scan_f32_mq_kernel(const float *__r
             for (int qi = 0; qi < kProbeQB; qi++)
                 if (qi < cnt) tk[qi].offer(score(qi), lane);
         }
+    };
+    if constexpr (MASKED) {
+        for (;;) {
+            const int64_t ia = next_wanted(), ib = next_wanted();
+            if (!__any(ia < r1)) break;
+            step(ia, ib);
+        }
+    } else {
+        for (int64_t i0 = r0 + wave * 8; i0 < r1; i0 += 32) step(i0 + (lane >> 4), i0 + (lane >> 4) + 4);
     }
 #pragma unroll
     for (int qi = 0; qi < kProbeQB; qi++) {

@@ -490,7 +490,7 @@ __global__ __launch_bounds__(WAVES * 64) void sq8_scan_kernel(
 
 // Partition-probed SQ8 scan (flat/segment.go:727-744 over the :517-604 branch): workgroup =
 // (slice of one probed partition's tiles, probe, query); rows outside the partition's range are masked.
-template <bool DOT>
+template <bool DOT, bool MASKED>
 __global__ __launch_bounds__(kSqThreads) void sq8_probe_kernel(
     const uint4 *__restrict__ tiles, int64_t n_rows, int groups, int dim, const float *__restrict__ queries,
     const float *__restrict__ mins, const float *__restrict__ inv, const uint32_t *__restrict__ probes,
@@ -507,15 +507,15 @@ __global__ __launch_bounds__(kSqThreads) void sq8_probe_kernel(
     const int64_t t0 = tt0 + (tt1 - tt0) * s / sub, t1 = tt0 + (tt1 - tt0) * (s + 1) / sub;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float *qv = queries + q * dim;
-    const uint8_t *mq = mask ? mask + q * mask_stride : nullptr;
+    const uint8_t *mq = MASKED ? mask + q * mask_stride : nullptr;
     const int full = dim >> 4, tail = dim & 15;
     WaveTopK tk;
     tk.init(k);
     for (int64_t tile = t0 + wave; tile < t1; tile += kSqWaves) {
         const int64_t row = tile * 64 + lane;
         // filter.Matches after the batch was scored (segment.go:559-561): the candidates are the rows that pass
-        const bool live = row >= R0 && row < R1 && row < n_rows && mask_bit(mq, row);
-        if (mq && !__any(live)) continue;  // a tile the filter leaves nothing of: its codes are not read
+        const bool live = row >= R0 && row < R1 && row < n_rows && (!MASKED || mask_bit(mq, row));
+        if (MASKED && !__any(live)) continue;  // a tile the filter leaves nothing of: its codes are not read
         const float total = sq8_row_score<DOT>(tiles + (tile * groups) * 64 + lane, groups, full, tail, qv, mins, inv);
         uint64_t key = live ? make_key(total, static_cast<uint32_t>(row), DOT) : kKeyMax;
         if (min_keys && key <= min_keys[q]) key = kKeyMax;  // paged results (k > 64)
@@ -764,7 +764,8 @@ int32_t launch_probe_scan_sq8(const vg_index *idx, const float *queries, const u
     for (int64_t q0 = 0; q0 < nq; q0 += 65535) {
         const int64_t cnt = nq - q0 < 65535 ? nq - q0 : 65535;
         ProfScope prof(idx->ctx, "sq8_probe", st);
-        auto kern = idx->metric != VG_METRIC_L2 ? sq8_probe_kernel<true> : sq8_probe_kernel<false>;
+        auto kern = mask ? (idx->metric != VG_METRIC_L2 ? sq8_probe_kernel<true, true> : sq8_probe_kernel<false, true>)
+                         : (idx->metric != VG_METRIC_L2 ? sq8_probe_kernel<true, false> : sq8_probe_kernel<false, false>);
         VG_LAUNCH(kern, dim3(static_cast<unsigned>(sub), static_cast<unsigned>(np), static_cast<unsigned>(cnt)),
                   dim3(kSqThreads), 0, st, reinterpret_cast<const uint4 *>(idx->d_sq_tiles), idx->n, idx->sq_groups, idx->dim,
                   queries + q0 * idx->dim, idx->sq->d_mins, idx->sq->d_inv, probes + q0 * np, part_off, np, sub, k,
