@@ -205,6 +205,23 @@ func (r *Resident) SearchProbed(queries []float32, nq, k, nprobes int, scan int3
 	return ids, sc, hipctx.Err(int32(st))
 }
 
+// SearchSegmentFiltered: Segment.Search with a filter for a segment opened from its file (flat or DiskANN, by what it holds).
+func (r *Resident) SearchSegmentFiltered(queries []float32, nq, k, nprobes int, mask []byte, maskStride int) ([]uint32, []float32, error) {
+	ids, sc := r.out(nq, k)
+	need := (r.rows + 7) / 8
+	if maskStride != 0 {
+		if maskStride < need {
+			return nil, nil, fmt.Errorf("SearchSegmentFiltered: maskStride %d is shorter than a mask (%d bytes)", maskStride, need)
+		}
+		need += (nq - 1) * maskStride
+	}
+	if len(mask) < need {
+		return nil, nil, fmt.Errorf("SearchSegmentFiltered: mask holds %d bytes, %d needed", len(mask), need)
+	}
+	st := C.vg_segment_search_filtered(r.seg, fp(queries), C.int64_t(nq), C.int32_t(k), C.int32_t(nprobes), bp(mask), C.int64_t(maskStride), up(ids), fp(sc), nil)
+	return ids, sc, hipctx.Err(int32(st))
+}
+
 // SearchFiltered: Segment.Search with `filter segment.Filter` set (flat/segment.go:631-635, :559-561): rows whose mask bit
 // is clear are skipped.  mask: bit i of byte i/8 = filter.Matches(i), len(mask) == ceil(rows/8) for one mask (maskStride 0)
 // or (nq-1)*maskStride + ceil(rows/8) for one per query.

@@ -52,8 +52,9 @@ extern "C" {
  *   4: (r05) vg_search_flat_filtered
  *   5: (r05) vg_search_vamana_filtered
  *   6: (r05) vg_search_hnsw_predicate, vg_index_set_hnsw_edge_distances; vg_search_hnsw_filtered serves every selectivity
- *   7: (r05) vg_index_set_hnsw_tombstones */
-#define VG_ABI_MINOR 7
+ *   7: (r05) vg_index_set_hnsw_tombstones
+ *   8: (r05) vg_segment_search_filtered */
+#define VG_ABI_MINOR 8
 #define VG_INVALID_ID 0xFFFFFFFFu
 #define VG_STREAM_LEGACY ((void *)1) /* == hipStreamLegacy */
 
@@ -518,6 +519,11 @@ int32_t vg_segment_open_flat(vg_ctx *ctx, const void *image, int64_t size, int32
  * like the search-list size the reference computes and never reads. */
 int32_t vg_segment_search(vg_segment *seg, const float *queries, int64_t nq, int32_t k, int32_t nprobes,
                           uint32_t *ids, float *scores, void *stream);
+/* Segment.Search with `filter` set, by what the file holds: vg_search_flat_filtered (flat/segment.go:631-635) or
+ * vg_search_vamana_filtered (diskann/segment.go:616-627).  mask: bit i of byte i/8 = filter.Matches(i), query q's at
+ * mask + q * mask_stride (0 = one for the batch); NULL = vg_segment_search.  (VG_ABI_MINOR 8.) */
+int32_t vg_segment_search_filtered(vg_segment *seg, const float *queries, int64_t nq, int32_t k, int32_t nprobes,
+                                   const uint8_t *mask, int64_t mask_stride, uint32_t *ids, float *scores, void *stream);
 /* diskann segment (diskann/format.go:8-119, segment.go:165-440,1393-1408): fp32 rows, the
  * N x R uint32 graph and entry point, PQ codebooks + codes or RaBitQ codes; search with
  * or INT4 parameters + codes; search with vg_search_vamana (kind 0 / 1 / 2 / 3).  The header's

@@ -207,3 +207,37 @@ def test_filtered_batches_on_the_matrix_cores(vg, ctx, metric):
     for i in sel:
         eid, esc = seg.search(q[i], 10)
         assert np.array_equal(ids[i], eid) and np.array_equal(bits(sc[i]), bits(esc))
+
+
+def test_segment_files_with_a_filter(vg, ctx):
+    """vg_segment_search_filtered: a flat image (partitions, SQ8 codes) and a DiskANN image, each through the filtered search of
+    what the file holds."""
+    from tests import graphs, segfile
+    rng = np.random.default_rng(78)
+    n, dim, parts = 2500, 48, 8
+    x, cent, off = partitioned(rng, n, dim, parts)
+    q = rng.standard_normal((4, dim)).astype(np.float32)
+    mask = rng.random((4, n)) < 0.3
+    seg = vg.Segment(ctx, segfile.write_flat(x, partitions=(cent, off)))
+    ref = o.FlatSegment(x, dim, centroids=cent, part_offsets=off)
+    for nprobes in (0, 2, parts):
+        ids, sc = seg.search_filtered(q, 10, mask, nprobes)
+        check(ids, sc, ref, q, 10, nprobes, mask)
+    a = seg.search_filtered(q, 10, None, 2)
+    b = seg.search(q, 10, 2)
+    assert np.array_equal(a[0], b[0])
+    seg.close()
+    sq = o.ScalarQuantizer(dim); sq.train(x)
+    codes = sq.encode_batch(x)
+    seg = vg.Segment(ctx, segfile.write_flat(x, sq=(sq.mins, sq.maxs), codes=codes))
+    ids, sc = seg.search_filtered(q, 10, mask[0], 0)
+    check(ids, sc, o.FlatSegment(x, dim, sq=sq, codes=codes), q, 10, 0, mask[0])
+    seg.close()
+    g, entry = graphs.build_vamana(x, r=16, seed=2)
+    seg = vg.Segment(ctx, segfile.write_diskann(x, g, entry), kind="diskann")
+    ov = o.VamanaIndex(g, entry, dim, o.VAMANA_F32, base=x)
+    ids, sc = seg.search_filtered(q, 10, mask)
+    for qi in range(4):
+        eid, esc, _ = ov.search(q[qi], 10, mask=mask[qi])
+        assert np.array_equal(ids[qi, :eid.size], eid) and np.array_equal(bits(sc[qi, :eid.size]), bits(esc))
+    seg.close()

@@ -1304,6 +1304,18 @@ class Segment:
             return self._lib.vg_segment_search(seg, *args)
         return self.index._search(fn, queries, k, extra=(C.c_int32(nprobes),), out=out, stream=stream)
 
+    def search_filtered(self, queries, k, mask, nprobes=0, out=None, stream=None):
+        """Segment.Search with a row filter (flat/segment.go:631-635, diskann/segment.go:616-627): mask bool[n] / packed bits
+        for the batch or one per query; None = search."""
+        if mask is None:
+            return self.search(queries, k, nprobes, out=out, stream=stream)
+        seg = self._h
+        m, pm, stride = self.index._packed_mask(mask, _rows(queries, self.index.dim), "Segment.search_filtered")
+
+        def fn(_index_handle, *args):
+            return self._lib.vg_segment_search_filtered(seg, *args)
+        return self.index._search(fn, queries, k, extra=(C.c_int32(nprobes), pm, C.c_int64(stride)), out=out, stream=stream)
+
     def close(self):
         if getattr(self, "_h", None):
             self.index._h = None

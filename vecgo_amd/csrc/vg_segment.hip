@@ -212,7 +212,20 @@ VG_API int32_t vg_segment_open_flat(vg_ctx *ctx, const void *image, int64_t size
 VG_API int32_t vg_segment_search(vg_segment *seg, const float *queries, int64_t nq, int32_t k, int32_t nprobes,
                                  uint32_t *ids, float *scores, void *stream)
 {
+    return vg_segment_search_filtered(seg, queries, nq, k, nprobes, nullptr, 0, ids, scores, stream);
+}
+
+VG_API int32_t vg_segment_search_filtered(vg_segment *seg, const float *queries, int64_t nq, int32_t k, int32_t nprobes,
+                                          const uint8_t *mask, int64_t mask_stride, uint32_t *ids, float *scores, void *stream)
+{
     VG_CHECK(seg && seg->idx, VG_ERR_INVALID_ARG, "vg_segment_search: NULL segment");
+    if (seg->info.kind == 1 && mask) {  // pushToHeap's filter (diskann/segment.go:616-627)
+        const int32_t kind = seg->info.quantization == VG_QUANT_RABITQ ? 2
+                             : seg->info.quantization == VG_QUANT_PQ   ? 1
+                             : seg->info.quantization == VG_QUANT_INT4 ? 3
+                                                                       : 0;
+        return vg_search_vamana_filtered(seg->idx, queries, nq, k, kind, mask, mask_stride, ids, scores, nullptr, stream);
+    }
     if (seg->info.kind == 1) {
         // diskann.Segment.Search (diskann/segment.go:487-706): the search-list size it derives from k and
         // RefineFactor is never read by searchInternal, so the call is the beam search with the distFn the
@@ -232,7 +245,8 @@ VG_API int32_t vg_segment_search(vg_segment *seg, const float *queries, int64_t 
         // squared L2: a Dot / Cosine PQ segment keeps its k largest ADC distances there — and here
         scan = VG_SCAN_PQ;
     }
-    return vg_search_flat_probed(seg->idx, queries, nq, k, nprobes, scan, ids, scores, stream);
+    // (a NULL mask is the unfiltered probed scan; filter.Matches: flat/segment.go:631-635)
+    return vg_search_flat_filtered(seg->idx, queries, nq, k, nprobes, scan, mask, mask_stride, ids, scores, stream);
 }
 
 VG_API int32_t vg_segment_open_diskann(vg_ctx *ctx, const void *image, int64_t size, int32_t verify_checksum,
