@@ -110,3 +110,27 @@ def test_predicate_errors_and_the_filtered_entry(vg, ctx):
     b = idx.search_hnsw_filtered(q, 5, 20, mask, 0.15)              # selectivity <= 0.3 routes here
     c = idx.search_hnsw_filtered(q, 5, 20, mask, 0.0)               # unknown selectivity too
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[0], c[0]) and np.array_equal(bits(a[1]), bits(b[1]))
+
+
+def test_a_queue_that_outgrows_its_first_pass_slots(vg, ctx):
+    """The navigation queue is unbounded: a filter nothing passes walks the whole component on edge distances and queues every
+    node.  More rows than the first pass's 131072 slots: the walk is run again with a slot per row — same answer and counters
+    as the oracle; ordinary queries of the same batch are untouched."""
+    rng = np.random.default_rng(31)
+    n, dim, m = 140000, 8, 8
+    base = rng.standard_normal((n, dim)).astype(np.float32)
+    idx = vg.Index(ctx, n, dim)
+    idx.set_vectors(base)
+    idx.build_hnsw(m=m, ef_construction=40)
+    l0, upper, entry = idx.get_hnsw_graph()
+    oidx = o.HnswIndex(base, dim, l0, upper, entry, m=m)
+    q = rng.standard_normal((3, dim)).astype(np.float32)
+    masks = np.zeros((3, n), bool)
+    masks[1] = rng.random(n) < 0.05
+    masks[2, rng.integers(0, n, 3)] = True          # three rows pass: the queue grows until they are found, and beyond
+    ids, sc, st = idx.search_hnsw_predicate(q, 5, 32, masks, stats=True)
+    assert int(st[0][0]) > 131072                   # the whole component was visited (and queued)
+    for qi in range(3):
+        eid, esc, est = oidx.search_predicate(q[qi], 5, 32, masks[qi])
+        assert np.array_equal(ids[qi, :eid.size], eid) and np.array_equal(bits(sc[qi, :eid.size]), bits(esc)), qi
+        assert tuple(int(x) for x in st[qi]) == (est.nodes_visited, est.distance_computations, est.distance_short_circuits, est.pops), qi

@@ -53,19 +53,27 @@ __global__ __launch_bounds__(64) void hnsw_predicate_kernel(
     const int64_t *__restrict__ level_off, uint32_t entry, const float *__restrict__ queries, int k, int ef,
     const uint8_t *__restrict__ mask, int64_t mask_stride, const uint8_t *__restrict__ deleted, uint32_t *__restrict__ visited_ws,
     int64_t vis_words, HItem *__restrict__ cand_ws, int64_t cand_cap, uint32_t *__restrict__ ids, float *__restrict__ scores,
-    vg_search_stats *__restrict__ stats)
+    vg_search_stats *__restrict__ stats, uint8_t *__restrict__ redo, int64_t redo_first /* < 0: first pass — a walk whose
+    navigation queue outgrows cand_cap stops and sets redo[q]; >= 0: second pass over the queries [redo_first, redo_first +
+    gridDim.x) of the chunk, only the marked ones, with a queue of one slot per row */)
 {
     extern __shared__ __attribute__((aligned(8))) unsigned char smem[];
     float *nb_pair = reinterpret_cast<float *>(smem);
     float *nb_bnd = nb_pair + 64;
     HItem *cand_lo = reinterpret_cast<HItem *>(nb_bnd + 64);
     HItem *res = cand_lo + kPredLdsCand;  // ef + 1 items
-    const int64_t q = blockIdx.x;
+    const int64_t q = redo_first < 0 ? blockIdx.x : redo_first + blockIdx.x;
     const int lane = threadIdx.x;
+    uint32_t *vis = visited_ws + q * vis_words;
+    if (redo_first >= 0) {
+        if (!redo[q]) return;
+        for (int64_t w = lane; w < vis_words; w += 64) vis[w] = 0;  // the first pass left its marks
+        __threadfence();
+        __syncthreads();
+    }
     HItem *cand_lo_flat = cand_lo;  // (see vamana_search_kernel: the flat LDS address has to pass through a register)
     asm volatile("" : "+s"(cand_lo_flat));
-    const SplitHeap cand{cand_lo_flat, cand_ws + q * cand_cap, kPredLdsCand};
-    uint32_t *vis = visited_ws + q * vis_words;
+    const SplitHeap cand{cand_lo_flat, cand_ws + static_cast<int64_t>(blockIdx.x) * cand_cap, kPredLdsCand};
     const uint8_t *mq = mask + q * mask_stride;
     F32ScorerT<false> sc;
     sc.base = base;
@@ -168,10 +176,15 @@ __global__ __launch_bounds__(64) void hnsw_predicate_kernel(
                 continue;
             }
             if (res_len >= ef && nd > heap_get(res, 0).dist) continue;  // shouldExplore
-            if (cand_len < cand_cap)
-                heap_push<false>(cand, cand_len, HItem{id, nd});
-            else
-                st_dropped++;  // cand_cap = rows: every node is pushed at most once, so this cannot happen
+            if (cand_len >= cand_cap) {  // first pass only (the second has a slot per row: a node is pushed at most once)
+                if (redo_first < 0) {
+                    if (lane == 0) redo[q] = 1;
+                    return;
+                }
+                st_dropped++;
+                continue;
+            }
+            heap_push<false>(cand, cand_len, HItem{id, nd});
             if (live) res_push_bounded<false>(res, res_len, HItem{id, nd}, ef);
         }
         __syncthreads();
@@ -301,8 +314,11 @@ VG_API int32_t vg_search_hnsw_predicate(vg_index *idx, const float *queries, int
     VG_TRY(osc.init(scores, static_cast<size_t>(nq) * k, st));
     VG_TRY(ost.init(stats, stats ? static_cast<size_t>(nq) : 0, st));
     const int64_t vis_words = (idx->n + 31) / 32;
-    const int64_t cand_cap = idx->n;  // every node enters the navigation queue at most once
-    const int64_t per_query = vis_words * 4 + cand_cap * 8;
+    // The navigation queue is unbounded in the reference and can take every row (a filter nothing passes walks the whole
+    // component on edge distances).  First pass: 128 k slots per query (an ordinary walk queues a few thousand nodes); a walk that
+    // outgrows them stops and is run again with a slot per row, a few queries per launch (2 GiB of scratch, returned after the call)
+    const int64_t cand_cap = std::min<int64_t>(idx->n, int64_t(1) << 17);
+    const int64_t per_query = vis_words * 4 + cand_cap * 8 + 1;
     const int64_t gib = int64_t(1) << 30;
     const int64_t scratch = std::min<int64_t>(16 * gib, std::max<int64_t>(gib, idx->ctx->hbm_bytes / 16));
     int64_t chunk = std::max<int64_t>(1, scratch / per_query);
@@ -310,7 +326,13 @@ VG_API int32_t vg_search_hnsw_predicate(vg_index *idx, const float *queries, int
     vg::ArenaCall ar(idx->ctx, st);
     const int i_vis = ar.add(sizeof(uint32_t) * static_cast<size_t>(chunk) * vis_words);
     const int i_cand = ar.add(sizeof(vg::HItem) * static_cast<size_t>(chunk) * cand_cap);
+    const int i_redo = ar.add(static_cast<size_t>(chunk));
     VG_TRY(ar.commit());
+    uint8_t *redo = ar.get<uint8_t>(i_redo);
+    const bool second_pass = cand_cap < idx->n;
+    const int64_t big_chunk = second_pass ? std::max<int64_t>(1, (int64_t(2) << 30) / (idx->n * 8)) : 0;
+    vg::DevTmp<vg::HItem> big;
+    if (second_pass) VG_TRY(big.init(static_cast<size_t>(std::min(big_chunk, chunk)) * idx->n, st));
     uint32_t *vis = ar.get<uint32_t>(i_vis);
     vg::HItem *cand = ar.get<vg::HItem>(i_cand);
     const size_t lds = 128 * sizeof(float) + sizeof(vg::HItem) * (vg::kPredLdsCand + static_cast<size_t>(ef) + 1);
@@ -319,12 +341,21 @@ VG_API int32_t vg_search_hnsw_predicate(vg_index *idx, const float *queries, int
     for (int64_t q0 = 0; q0 < nq; q0 += chunk) {
         const int64_t cnt = std::min(chunk, nq - q0);
         VG_HIP(hipMemsetAsync(vis, 0, static_cast<size_t>(cnt) * vis_words * 4, st));
+        VG_HIP(hipMemsetAsync(redo, 0, static_cast<size_t>(cnt), st));
         vg::ProfScope prof(idx->ctx, "hnsw_predicate", st);
         VG_LAUNCH(vg::hnsw_predicate_kernel, dim3(static_cast<unsigned>(cnt)), dim3(64), lds, st, idx->d_vectors, idx->n, idx->dim,
                   idx->metric, idx->d_hnsw_l0, idx->d_hnsw_l0_dist, idx->hnsw_m0, idx->hnsw_max_level, idx->hnsw_m, idx->d_hnsw_slot,
                   idx->d_hnsw_adj, idx->d_hnsw_level_off, idx->hnsw_entry, q.ptr + q0 * idx->dim, k, ef, mk.ptr + q0 * mask_stride,
                   mask_stride, deleted ? dl.ptr : idx->d_hnsw_tomb, vis, vis_words, cand, cand_cap, oid.ptr + q0 * k, osc.ptr + q0 * k,
-                  ost.ptr ? ost.ptr + q0 : nullptr);
+                  ost.ptr ? ost.ptr + q0 : nullptr, redo, int64_t(-1));
+        for (int64_t r0 = 0; second_pass && r0 < cnt; r0 += big_chunk) {  // (every workgroup of an ordinary batch leaves at once)
+            const int64_t rc = std::min(big_chunk, cnt - r0);
+            VG_LAUNCH(vg::hnsw_predicate_kernel, dim3(static_cast<unsigned>(rc)), dim3(64), lds, st, idx->d_vectors, idx->n, idx->dim,
+                      idx->metric, idx->d_hnsw_l0, idx->d_hnsw_l0_dist, idx->hnsw_m0, idx->hnsw_max_level, idx->hnsw_m,
+                      idx->d_hnsw_slot, idx->d_hnsw_adj, idx->d_hnsw_level_off, idx->hnsw_entry, q.ptr + q0 * idx->dim, k, ef,
+                      mk.ptr + q0 * mask_stride, mask_stride, deleted ? dl.ptr : idx->d_hnsw_tomb, vis, vis_words, big.ptr, idx->n,
+                      oid.ptr + q0 * k, osc.ptr + q0 * k, ost.ptr ? ost.ptr + q0 : nullptr, redo, r0);
+        }
     }
     VG_TRY(oid.finish());
     VG_TRY(osc.finish());
