@@ -584,8 +584,8 @@ __global__ __launch_bounds__(256) void km_norms_kernel(const float *__restrict__
     if (lane == 0) out[row] = s;
 }
 
-// rows of fp32 -> rows of bfloat16 splits, 3 dim elements each: POINTS as [hi | lo | hi], CENTROIDS as [hi | hi | lo]
-// (see km_gemm_kernel<.., BF16>).  hi = round-to-nearest-even of the value, lo = the same of the (exact) remainder.
+// rows of fp32 -> rows of bfloat16 splits, 2 dim elements each: [hi | lo] (see km_gemm_kernel<.., BF16>).  hi =
+// round-to-nearest-even of the value, lo = the same of the (exact) remainder.
 __device__ __forceinline__ uint16_t km_bf16_rne(float x)
 {
     const uint32_t b = __float_as_uint(x);
@@ -595,7 +595,7 @@ template <bool CENTROID>
 __global__ __launch_bounds__(256) void km_split_kernel(const float *__restrict__ src, int64_t rows, int dim,
                                                        uint16_t *__restrict__ dst)
 {
-    // four elements per thread: one 16-byte load, three 8-byte stores (dim % 64 == 0: a group never straddles a row)
+    // four elements per thread: one 16-byte load, two 8-byte stores (dim % 64 == 0: a group never straddles a row)
     const int64_t g = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     const int64_t e = g * 4;
     if (e >= rows * dim) return;
@@ -611,10 +611,9 @@ __global__ __launch_bounds__(256) void km_split_kernel(const float *__restrict__
     }
     const uint2 h2 = make_uint2(hi[0] | (static_cast<uint32_t>(hi[1]) << 16), hi[2] | (static_cast<uint32_t>(hi[3]) << 16));
     const uint2 l2 = make_uint2(lo[0] | (static_cast<uint32_t>(lo[1]) << 16), lo[2] | (static_cast<uint32_t>(lo[3]) << 16));
-    uint16_t *o = dst + r * 3 * dim + j;
+    uint16_t *o = dst + r * 2 * dim + j;
     *reinterpret_cast<uint2 *>(o) = h2;
-    *reinterpret_cast<uint2 *>(o + dim) = CENTROID ? h2 : l2;
-    *reinterpret_cast<uint2 *>(o + 2 * dim) = CENTROID ? l2 : h2;
+    *reinterpret_cast<uint2 *>(o + dim) = l2;
 }
 
 // the centroids' side of the epilogue: cadd[c] = |c|^2 (L2) or 0 (Dot) for c < k, +Inf for the padding of the last tile;
@@ -639,10 +638,12 @@ __global__ __launch_bounds__(256) void km_cent_norms_kernel(const float *__restr
     }
 }
 
-// BF16: both operands are rows of bfloat16 SPLITS — a point as [hi | lo | hi], a centroid as [hi | hi | lo] (km_split_kernel:
-// hi = the value rounded to bfloat16, lo = the remainder rounded to bfloat16) — so that one pass of the 16x faster
-// v_mfma_f32_32x32x16_bf16 over the 3 dim elements of a row adds up x_hi c_hi + x_lo c_hi + x_hi c_lo; `dim` then counts
-// the 4-byte words of such a row (3 dim / 2).  What the split drops is x_lo c_lo and the second remainders: at most
+// BF16: both operands are rows of bfloat16 SPLITS [hi | lo] (km_split_kernel: hi = the value rounded to bfloat16, lo = the
+// remainder rounded to bfloat16); `dim` then counts the 4-byte words of such a row (= the row's dimension).  The K loop takes
+// every 64-element chunk three times — x_hi c_hi, x_hi c_lo, x_lo c_hi — with the 16x faster v_mfma_f32_32x32x16_bf16, so the
+// accumulators add up x_hi c_hi + x_hi c_lo + x_lo c_hi.  (r05 first stored points as [hi | lo | hi] and centroids as
+// [hi | hi | lo], one pass over 3 dim elements: 6 bytes per element from HBM; now 4 — the second use of a point chunk's hi
+// half comes from L2, one K step after the first.)  What the split drops is x_lo c_lo and the second remainders: at most
 // 3 * 2^-16 |x_i| |c_i| per element, which enters the bound of km_decide_kernel in place of the fp32 products' roundings.
 template <bool DOT, bool BF16 = false>
 __global__ __launch_bounds__(kGemmThreads) void km_gemm_kernel(const float *__restrict__ centroids, int k,
@@ -681,8 +682,9 @@ __global__ __launch_bounds__(kGemmThreads) void km_gemm_kernel(const float *__re
         aoff[p] = static_cast<uint32_t>((static_cast<int64_t>(qa - q0) * dim + dgl * 4) * 4);
         boff[p] = static_cast<uint32_t>(((nb - n0) * dim + dgl * 4) * 4);
     }
-    const int ksteps = (dim + kGemmBK - 1) / kGemmBK;
-    const int full_steps = dim / kGemmBK;
+    const int half = dim / 2;  // BF16: words of the hi (and of the lo) part of a row
+    const int ksteps = BF16 ? 3 * (half / kGemmBK) : (dim + kGemmBK - 1) / kGemmBK;
+    const int full_steps = BF16 ? ksteps : dim / kGemmBK;
     const uint32_t lds0 = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(
         (__attribute__((address_space(3))) void *)gemm_lds));
     auto piece = [&](int b, int t, int p) {
@@ -691,7 +693,16 @@ __global__ __launch_bounds__(kGemmThreads) void km_gemm_kernel(const float *__re
     };
     auto dma_tile = [&](int kt) {
         const int k0 = kt * kGemmBK, b = kt & 1;
-        if (kt < full_steps) {
+        if constexpr (BF16) {
+            // chunk kc three times: (c_hi, x_hi), (c_lo, x_hi), (c_hi, x_lo) — A = centroids, B = points
+            const int kc = kt / 3, t = kt - 3 * kc;
+            const int ka = kc * kGemmBK + (t == 1 ? half : 0), kb = kc * kGemmBK + (t == 2 ? half : 0);
+#pragma unroll
+            for (int p = 0; p < kGemmPasses; p++) {
+                glds16(abase + ka, aoff[p], piece(b, 0, p));
+                glds16(bbase + kb, boff[p], piece(b, 1, p));
+            }
+        } else if (kt < full_steps) {
 #pragma unroll
             for (int p = 0; p < kGemmPasses; p++) {
                 glds16(abase + k0, aoff[p], piece(b, 0, p));
@@ -989,17 +1000,17 @@ struct KmMfma {
     }
     // allocates and computes |x|^2 (the points do not change between the iterations of a training run).
     // passes: how many assignment passes will follow — with three or more, and rows of whole 64-element blocks, the points
-    // are also split into bfloat16 [hi | lo | hi] (4.6 GB per 1M x 768, written once) and the passes run on the 16x faster
+    // are also split into bfloat16 [hi | lo] (3.1 GB per 1M x 768, written once) and the passes run on the 16x faster
     // bf16 matrix instruction, HBM-bound instead of MFMA-bound (1.64 -> see DESIGN.md §12 ms per 1M x 768 x 122)
     int32_t init(const float *v, int64_t n, int dim, int k, hipStream_t st, int passes = 1, int64_t hbm_bytes = 0)
     {
         mtiles = (k + vg::kGemmBM - 1) / vg::kGemmBM;
-        const int64_t split_bytes = n * 3 * dim * 2;
+        const int64_t split_bytes = n * 2 * dim * 2;
         bf16 = dim % 64 == 0 && (passes >= 3 || vg::hook(vg::kHookKmBf16)) && !vg::hook(vg::kHookKmNoBf16) &&
                (hbm_bytes == 0 || split_bytes <= hbm_bytes / 8);
         if (bf16) {
-            VG_TRY(xsplit.init(static_cast<size_t>(n) * 3 * dim, st));
-            VG_TRY(csplit.init(static_cast<size_t>(mtiles) * vg::kGemmBM * 3 * dim, st));
+            VG_TRY(xsplit.init(static_cast<size_t>(n) * 2 * dim, st));
+            VG_TRY(csplit.init(static_cast<size_t>(mtiles) * vg::kGemmBM * 2 * dim, st));
             const int64_t tot = n * dim / 4;
             VG_LAUNCH(vg::km_split_kernel<false>, dim3(static_cast<unsigned>((tot + 255) / 256)), dim3(256), 0, st, v, n, dim,
                       xsplit.ptr);
@@ -1033,7 +1044,7 @@ struct KmMfma {
             VG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        static_cast<int>(vg::kDmaLdsBytes)));
             VG_LAUNCH(kern, dim3(blocks), dim3(vg::kGemmThreads), vg::kDmaLdsBytes, st, reinterpret_cast<const float *>(csplit.ptr),
-                      k, reinterpret_cast<const float *>(xsplit.ptr), n, 3 * dim / 2, cadd.ptr, part.ptr);
+                      k, reinterpret_cast<const float *>(xsplit.ptr), n, dim, cadd.ptr, part.ptr);
             // |s~ - s|: the split drops at most 3 * 2^-16 |x_i| |c_i| per element (x = hi + lo + r, |r| <= 2^-16 |x|, the
             // same for c; the dropped terms are lo lo, x r_c, r_x c); the products of bfloat16 values are exact in fp32 and
             // every one of the 3 dim additions into the fp32 accumulator is taken to round (the matrix unit's internal
