@@ -694,13 +694,24 @@ __global__ __launch_bounds__(kGemmThreads) void km_gemm_kernel(const float *__re
     auto dma_tile = [&](int kt) {
         const int k0 = kt * kGemmBK, b = kt & 1;
         if constexpr (BF16) {
-            // chunk kc three times: (c_hi, x_hi), (c_lo, x_hi), (c_hi, x_lo) — A = centroids, B = points
+            // chunk kc three times: (c_hi, x_hi), (c_lo, x_hi), (c_hi, x_lo) — A = centroids, B = points — and every tile
+            // staged ONCE: x_hi stays in B slot 0 for the first two steps, x_lo goes to B slot 1; c_hi sits in A slot kc & 1
+            // for steps 0 and 2, c_lo in the other for step 1.  What step kt + 1 needs that is not in LDS yet is requested
+            // during step kt, always into a slot step kt does not read (slots: see the loop).
             const int kc = kt / 3, t = kt - 3 * kc;
-            const int ka = kc * kGemmBK + (t == 1 ? half : 0), kb = kc * kGemmBK + (t == 2 ? half : 0);
+            const int sa = kc & 1;
+            if (t == 0) {
 #pragma unroll
-            for (int p = 0; p < kGemmPasses; p++) {
-                glds16(abase + ka, aoff[p], piece(b, 0, p));
-                glds16(bbase + kb, boff[p], piece(b, 1, p));
+                for (int p = 0; p < kGemmPasses; p++) {
+                    glds16(abase + kc * kGemmBK, aoff[p], piece(sa, 0, p));
+                    glds16(bbase + kc * kGemmBK, boff[p], piece(0, 1, p));
+                }
+            } else if (t == 1) {
+#pragma unroll
+                for (int p = 0; p < kGemmPasses; p++) glds16(abase + kc * kGemmBK + half, aoff[p], piece(sa ^ 1, 0, p));
+            } else {
+#pragma unroll
+                for (int p = 0; p < kGemmPasses; p++) glds16(bbase + kc * kGemmBK + half, boff[p], piece(1, 1, p));
             }
         } else if (kt < full_steps) {
 #pragma unroll
@@ -738,6 +749,11 @@ __global__ __launch_bounds__(kGemmThreads) void km_gemm_kernel(const float *__re
     __syncthreads();
     for (int kt = 0; kt < ksteps; kt++) {
         const float *As = gemm_lds + (kt & 1) * 2 * kDmaTile, *Bs = As + kDmaTile;
+        if constexpr (BF16) {
+            const int kc = kt / 3, t = kt - 3 * kc;
+            As = gemm_lds + ((kc & 1) ^ (t == 1 ? 1 : 0)) * 2 * kDmaTile;
+            Bs = gemm_lds + (t == 2 ? 1 : 0) * 2 * kDmaTile + kDmaTile;
+        }
         if (kt + 1 < ksteps) dma_tile(kt + 1);
         float4 fa[2][2], fb[2][2];  // [parity][row block]
         fa[0][0] = *reinterpret_cast<const float4 *>(As + a_row + goff[0]);
