@@ -249,9 +249,19 @@ __global__ __launch_bounds__(kPPThreads) void pq_kmeanspp_kernel(
         // kPPUnroll blocks per trip with all their loads issued first (one block per trip ran at one L2 round trip per
         // block: 70 us per centroid)
         auto finish_block = [&](int64_t b, float mv) {
-            float x = mv;  // balanced pairwise tree: lane 0 ends with ((m0 + m1) + (m2 + m3)) + ...
-#pragma unroll
-            for (int sft = 1; sft < 64; sft <<= 1) x = x + __shfl_down(x, sft);
+            // balanced pairwise tree: ((m0 + m1) + (m2 + m3)) + ... — lane i += lane i + 1, + 2, + 4, + 8 inside its row of 16
+            // (DPP row_shl: one full-rate vector instruction each; the ds_bpermute form of __shfl_down was six LDS round trips
+            // per 64 points), then the four row sums as (r0 + r16) + (r32 + r48): the same tree
+            float x = mv;
+            x = x + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x101, 0xF, 0xF, false));
+            x = x + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x102, 0xF, 0xF, false));
+            x = x + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x104, 0xF, 0xF, false));
+            x = x + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x108, 0xF, 0xF, false));
+            const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 0));
+            const float r16 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 16));
+            const float r32 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 32));
+            const float r48 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 48));
+            x = (r0 + r16) + (r32 + r48);
             if (lane == 0) {
                 if (in_lds)
                     tot[b] = x;
@@ -259,14 +269,24 @@ __global__ __launch_bounds__(kPPThreads) void pq_kmeanspp_kernel(
                     pref[b] = x;
             }
         };
+#if defined(VG_PP_PROBE) && VG_PP_PROBE == 1  // stage probe (tools/build_variant.sh): no distance pass after the first
+        if (c >= 1) {
+            __syncthreads();
+            continue;
+        }
+#endif
         if constexpr (SD != 0) {
-            constexpr int kPPUnroll = 8;
+            // software-pipelined: the loads of the wave's next kPPUnroll blocks are in flight while the current ones are
+            // reduced (r05: one trip at a time — 8 trips of 128 blocks, each a full round trip to the memory-side cache the
+            // 2 MB slab lives in — ran a CU at 52 GB/s: 49 us per centroid)
+            constexpr int kPPUnroll = SD >= 16 ? 2 : (SD >= 8 ? 3 : 4);  // two sets of these blocks live in registers
+            constexpr int64_t kTrip = (kPPThreads / 64) * kPPUnroll;
             float cv[SD];
 #pragma unroll
             for (int t = 0; t < SD; t++) cv[t] = cur[t];
-            for (int64_t b0 = static_cast<int64_t>(wave) * kPPUnroll; b0 < nblk; b0 += (kPPThreads / 64) * kPPUnroll) {
-                float4 r[kPPUnroll][SD / 4];
-                float old[kPPUnroll];
+            float4 ra[kPPUnroll][SD / 4], rb[kPPUnroll][SD / 4];
+            float oa[kPPUnroll], ob[kPPUnroll];
+            auto load = [&](int64_t b0, float4 (&r)[kPPUnroll][SD / 4], float (&old)[kPPUnroll]) {
 #pragma unroll
                 for (int u = 0; u < kPPUnroll; u++) {
                     const int64_t i = (b0 + u) * kPPBlock + lane;
@@ -274,8 +294,14 @@ __global__ __launch_bounds__(kPPThreads) void pq_kmeanspp_kernel(
                     const float4 *v4 = reinterpret_cast<const float4 *>(slab + ic * SD);
 #pragma unroll
                     for (int t = 0; t < SD / 4; t++) r[u][t] = v4[t];
+#if defined(VG_PP_PROBE) && VG_PP_PROBE == 3  // stage probe: no minDistSq traffic
+                    old[u] = 1.0f;
+#else
                     old[u] = c != 0 ? mind[ic] : 0.0f;
+#endif
                 }
+            };
+            auto work = [&](int64_t b0, const float4 (&r)[kPPUnroll][SD / 4], const float (&old)[kPPUnroll]) {
 #pragma unroll
                 for (int u = 0; u < kPPUnroll; u++) {
                     const int64_t b = b0 + u;
@@ -297,9 +323,26 @@ __global__ __launch_bounds__(kPPThreads) void pq_kmeanspp_kernel(
                     if (i < n) {
                         mv = total;
                         if (c != 0) mv = total < old[u] ? total : old[u];
+#if !(defined(VG_PP_PROBE) && VG_PP_PROBE == 3)
                         mind[i] = mv;
+#endif
                     }
+#if defined(VG_PP_PROBE) && VG_PP_PROBE == 4  // stage probe: no block totals
+                    if (lane == 0 && mv == 12345.0f) tot[b] = mv;
+#else
                     finish_block(b, mv);
+#endif
+                }
+            };
+            int64_t b0 = static_cast<int64_t>(wave) * kPPUnroll;
+            if (b0 < nblk) load(b0, ra, oa);
+            for (; b0 < nblk; b0 += 2 * kTrip) {
+                const bool more = b0 + kTrip < nblk;
+                if (more) load(b0 + kTrip, rb, ob);
+                work(b0, ra, oa);
+                if (more) {
+                    if (b0 + 2 * kTrip < nblk) load(b0 + 2 * kTrip, ra, oa);
+                    work(b0 + kTrip, rb, ob);
                 }
             }
         } else {
@@ -320,6 +363,11 @@ __global__ __launch_bounds__(kPPThreads) void pq_kmeanspp_kernel(
         }
         __syncthreads();
         // (2) prefixes of the block totals, in block order, by one thread
+#if defined(VG_PP_PROBE) && VG_PP_PROBE == 2  // stage probe: no prefix scan
+        if (tid == 0) s_sum = 1.0f;
+        __syncthreads();
+        continue;
+#endif
         if (in_lds) {
             if (tid == 0) s_sum = pp_scan_chunk(tot, static_cast<int>(nblk), 0.0f);
         } else {
