@@ -985,8 +985,10 @@ def build_side_legs(vg, ctx, rows, queries, stream, with_cpu, rows_host=None):
         d_ms = td / 3
         if nq == 1:
             ach = n * DIM * 4.0 / (d_ms * 1e-3) / 1e9
-            e = {"kernel": "brute_dist_kernel", "kernel_ms": d_ms, "bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                 "frac": ach / PEAK_HBM_GBS}
+            # one unmasked query: vg_search_flat's exact scan for k + 1 results (flat_scan_mq_kernel + merge), turned into the
+            # reference's answer by brute_from_flat_kernel when no two of the k + 1 distances tie (else: distance pass + replay)
+            e = {"kernel": "flat_scan_mq_kernel (k + 1) + topk_merge + brute_from_flat_kernel", "kernel_ms": d_ms, "bound": "hbm", "achieved": ach,
+                 "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": ach / PEAK_HBM_GBS}
         else:
             # two or more unmasked queries: vg_search_flat's MFMA nomination + exact re-score + proof for k + 1 results,
             # turned into the reference's answer when no two of the k + 1 distances are equal (ties: the replay)

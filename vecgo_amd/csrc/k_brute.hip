@@ -479,12 +479,13 @@ static int32_t brute_impl(vg_index *idx, const float *queries, int64_t nq, int32
 VG_API int32_t vg_search_hnsw_brute(vg_index *idx, const float *queries, int64_t nq, int32_t k, int32_t mode,
                                     const uint8_t *mask, int64_t mask_stride, uint32_t *ids, float *scores, void *stream)
 {
-    // Two or more unmasked queries under L2 / Dot: every (query, row) distance is a 1M x dim product per query — the
+    // Unmasked queries under L2 / Dot: every (query, row) distance is a 1M x dim product per query — the
     // flat search's MFMA nomination + exact re-score + proof answers "the k + 1 best by (score, id)" at 11 ms per 1024
     // queries where brute_dist_mq_kernel's vector-ALU pass takes 16 ms per 256; brute_from_flat_kernel turns that answer
     // into the reference's when no two of the k + 1 distances are equal, and the few queries with a tie are replayed
     // as before.  (Cosine scores rows by 0.5 * L2 here and by the dot product in the flat search: not the same bits.)
-    const bool fast = idx && mask == nullptr && nq >= 2 && k >= 1 && queries && ids && scores && idx->d_vectors &&
+    // (one query too: its exact scan + merge is 0.48 ms at 1M x 768 where the distance pass + heap replay took 0.74)
+    const bool fast = idx && mask == nullptr && nq >= 1 && k >= 1 && queries && ids && scores && idx->d_vectors &&
                       (idx->metric == VG_METRIC_L2 || idx->metric == VG_METRIC_DOT) && static_cast<int64_t>(k) + 1 <= idx->n &&
                       k + 1 <= 512 /* vg_search_flat's kFlatMaxK */ && k <= vg::kBruteMaxK && (mode == VG_BRUTE_SCAN || mode == VG_BRUTE_BITMAP) &&
                       !vg::hook(vg::kHookBruteNoFlat);
