@@ -155,3 +155,36 @@ def test_hnsw_dot_product_distance_ordering_kat(vg, ctx, golden_dir):
     ids, sc = idx.search_hnsw(q, c["k"], c["ef_search"])
     assert ids[0].tolist() == c["expect_ids"] and np.all(np.abs(sc[0] - want) <= c["tol"])
     idx.close()
+
+
+@pytest.mark.parametrize("metric", [0, 2])
+@pytest.mark.parametrize("mode", [0, 1])
+def test_masked_batches_through_the_masked_nomination(vg, ctx, metric, mode):
+    """8 queries up, a masked batch takes the flat search's matrix-core nomination with the mask in its epilogue (k + 1 best of
+    the rows that take part), turned into the heap's answer when no two of them tie; ties and masks that leave fewer than
+    k + 1 rows are replayed — a few queries one by one, most of a batch in one pass.  Same answers as the replay alone."""
+    from tests import hooks
+    rng = np.random.default_rng(50 + metric + 2 * mode)
+    n, dim, nq, k = 20000, 32, 24, 10
+    base = rng.standard_normal((n, dim)).astype(np.float32)
+    base[100:120] = base[100]                      # ties
+    q = rng.standard_normal((nq, dim)).astype(np.float32)
+    q[2] = base[100]
+    idx = vg.Index(ctx, n, dim, vg.Metric(metric))
+    idx.set_vectors(base)
+    oidx = _oidx(base, metric)
+    for keep, few in ((0.5, 3), (0.02, 3), (0.5, 20)):
+        mask = rng.random((nq, n)) < keep
+        for j in range(few):                       # these queries' masks leave fewer than k + 1 rows (some: none)
+            mask[j * 1] = False
+            mask[j, rng.integers(0, n, j)] = True
+        _check(idx, oidx, q, k, mode, mask, per_query=True)
+        _check(idx, oidx, q, k, mode, mask[5])     # one mask for the batch
+        hooks.set_hook("VG_BRUTE_NO_FLAT", "1")
+        try:
+            ref = idx.search_hnsw_brute(q, k, mode, mask)
+        finally:
+            hooks.set_hook("VG_BRUTE_NO_FLAT", 0)
+        got = idx.search_hnsw_brute(q, k, mode, mask)
+        assert np.array_equal(ref[0], got[0]) and np.array_equal(bits(ref[1]), bits(got[1]))
+    idx.close()
