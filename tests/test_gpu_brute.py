@@ -157,7 +157,7 @@ def test_hnsw_dot_product_distance_ordering_kat(vg, ctx, golden_dir):
     idx.close()
 
 
-@pytest.mark.parametrize("metric", [0, 2])
+@pytest.mark.parametrize("metric", [0, 1, 2])
 @pytest.mark.parametrize("mode", [0, 1])
 def test_masked_batches_through_the_masked_nomination(vg, ctx, metric, mode):
     """8 queries up, a masked batch takes the flat search's matrix-core nomination with the mask in its epilogue (k + 1 best of
@@ -167,8 +167,12 @@ def test_masked_batches_through_the_masked_nomination(vg, ctx, metric, mode):
     rng = np.random.default_rng(50 + metric + 2 * mode)
     n, dim, nq, k = 20000, 32, 24, 10
     base = rng.standard_normal((n, dim)).astype(np.float32)
+    if metric == 1:                                # Cosine: rows and queries normalised by the caller, distance 0.5 * L2
+        base /= np.linalg.norm(base, axis=1, keepdims=True)
     base[100:120] = base[100]                      # ties
     q = rng.standard_normal((nq, dim)).astype(np.float32)
+    if metric == 1:
+        q /= np.linalg.norm(q, axis=1, keepdims=True)
     q[2] = base[100]
     idx = vg.Index(ctx, n, dim, vg.Metric(metric))
     idx.set_vectors(base)
@@ -187,4 +191,6 @@ def test_masked_batches_through_the_masked_nomination(vg, ctx, metric, mode):
             hooks.set_hook("VG_BRUTE_NO_FLAT", 0)
         got = idx.search_hnsw_brute(q, k, mode, mask)
         assert np.array_equal(ref[0], got[0]) and np.array_equal(bits(ref[1]), bits(got[1]))
+    _check(idx, oidx, q, k, mode, None)            # unmasked, every metric through the flat search
+    _check(idx, oidx, q[:1], k, mode, None)
     idx.close()

@@ -463,24 +463,31 @@ __global__ __launch_bounds__(256) void mask_popcount_kernel(const uint8_t *__res
 // `fid` / `fsc` = the k + 1 best rows by (score, id) with their exact scores (the same squaredL2Avx512 /
 // dotProductAvx512 values brute_dist_kernel computes).  If the k + 1 values are finite and pairwise different, rows
 // 0 .. k-1 ARE the reference's answer (Dot: the index's distance is -dot); any tie or NaN sends the query to the replay.
-__global__ void brute_from_flat_kernel(const uint32_t *__restrict__ fid, const float *__restrict__ fsc, int64_t nq, int k, bool dot,
+// conv: 0 = L2 (the score), 1 = Dot (-score), 2 = Cosine (0.5 * the squared L2 the flat search was asked for: the halving is
+// monotone, and exact except at the bottom of the range — so the ties are looked for among the HALVED values)
+__global__ void brute_from_flat_kernel(const uint32_t *__restrict__ fid, const float *__restrict__ fsc, int64_t nq, int k, int conv,
                                        uint32_t *__restrict__ ids, float *__restrict__ scores, int32_t *__restrict__ redo)
 {
     const int64_t q = blockIdx.x;
     const int lane = threadIdx.x;  // 64
+    const bool dot = conv == 1;
+    auto as_index = [&](float s) { return conv == 2 ? 0.5f * s : s; };
     bool bad = false;
     for (int i = lane; i <= k; i += 64) {
         const uint32_t id = fid[q * (k + 1) + i];
-        const float s = fsc[q * (k + 1) + i];
+        const float s = as_index(fsc[q * (k + 1) + i]);
         bad |= id == VG_INVALID_ID || !(fabsf(s) <= 3.40282346638528859811704183484516925440e+38f);
-        if (i > 0) bad |= __float_as_uint(fsc[q * (k + 1) + i - 1]) == __float_as_uint(s) || fsc[q * (k + 1) + i - 1] == s;
+        if (i > 0) {
+            const float p = as_index(fsc[q * (k + 1) + i - 1]);
+            bad |= __float_as_uint(p) == __float_as_uint(s) || p == s;
+        }
     }
     const bool any_bad = __ballot(bad) != 0;
     if (lane == 0) redo[q] = any_bad ? 1 : 0;
     if (any_bad) return;
     for (int i = lane; i < k; i += 64) {
         ids[q * k + i] = fid[q * (k + 1) + i];
-        const float s = fsc[q * (k + 1) + i];
+        const float s = as_index(fsc[q * (k + 1) + i]);
         scores[q * k + i] = dot ? -s : s;
     }
 }
@@ -491,7 +498,7 @@ static int32_t brute_impl(vg_index *idx, const float *queries, int64_t nq, int32
                           int64_t mask_stride, uint32_t *ids, float *scores, void *stream);
 namespace vg {
 int32_t flat_search_masked(vg_index *idx, const float *queries, int64_t nq, int32_t k, const uint8_t *mask, int64_t mask_stride,
-                           uint32_t *ids, float *scores, void *stream);
+                           uint32_t *ids, float *scores, void *stream, bool l2_scores = false);
 }
 
 VG_API int32_t vg_search_hnsw_brute(vg_index *idx, const float *queries, int64_t nq, int32_t k, int32_t mode,
@@ -501,14 +508,15 @@ VG_API int32_t vg_search_hnsw_brute(vg_index *idx, const float *queries, int64_t
     // flat search's MFMA nomination + exact re-score + proof answers "the k + 1 best by (score, id)" at 11 ms per 1024
     // queries where brute_dist_mq_kernel's vector-ALU pass takes 16 ms per 256; brute_from_flat_kernel turns that answer
     // into the reference's when no two of the k + 1 distances are equal, and the few queries with a tie are replayed
-    // as before.  (Cosine scores rows by 0.5 * L2 here and by the dot product in the flat search: not the same bits.)
+    // as before.
     // (one query too: its exact scan + merge is 0.48 ms at 1M x 768 where the distance pass + heap replay took 0.74)
     // With a mask (rows that take part): the same through the masked nomination (vg::flat_search_masked, k_flat.hip) for
     // batches — a query whose mask leaves fewer than k + 1 rows, or a tie, is replayed like the others.
     const int64_t mask_bytes_fast = idx ? (idx->n + 7) / 8 : 0;
     const bool mask_ok = mask == nullptr || (nq >= 8 && (mask_stride == 0 || mask_stride >= mask_bytes_fast));
     const bool fast = idx && mask_ok && nq >= 1 && k >= 1 && queries && ids && scores && idx->d_vectors &&
-                      (idx->metric == VG_METRIC_L2 || idx->metric == VG_METRIC_DOT) && static_cast<int64_t>(k) + 1 <= idx->n &&
+                      (idx->metric == VG_METRIC_L2 || idx->metric == VG_METRIC_DOT || idx->metric == VG_METRIC_COSINE) &&
+                      static_cast<int64_t>(k) + 1 <= idx->n &&
                       k + 1 <= 512 /* vg_search_flat's kFlatMaxK */ && k <= vg::kBruteMaxK && (mode == VG_BRUTE_SCAN || mode == VG_BRUTE_BITMAP) &&
                       !vg::hook(vg::kHookBruteNoFlat);
     if (!fast) return brute_impl(idx, queries, nq, k, mode, mask, mask_stride, ids, scores, stream);
@@ -546,10 +554,11 @@ VG_API int32_t vg_search_hnsw_brute(vg_index *idx, const float *queries, int64_t
     }
     {
         vg::ProfScope prof(idx->ctx, "hnsw_brute_dist", st);  // (the distance work of this form)
-        VG_TRY(vg::flat_search_masked(idx, q.ptr, nq, k + 1, mk.ptr, mask_stride, fid.ptr, fsc.ptr, st));
+        // (Cosine: the index's distance is 0.5 * squared L2 of the normalised rows — the flat search is asked for L2 scores)
+        VG_TRY(vg::flat_search_masked(idx, q.ptr, nq, k + 1, mk.ptr, mask_stride, fid.ptr, fsc.ptr, st, idx->metric == VG_METRIC_COSINE));
     }
     VG_LAUNCH(vg::brute_from_flat_kernel, dim3(static_cast<unsigned>(nq)), dim3(64), 0, st, fid.ptr, fsc.ptr, nq, k,
-              idx->metric == VG_METRIC_DOT, oid.ptr, osc.ptr, redo.ptr);
+              idx->metric == VG_METRIC_DOT ? 1 : idx->metric == VG_METRIC_COSINE ? 2 : 0, oid.ptr, osc.ptr, redo.ptr);
     std::vector<int32_t> h(static_cast<size_t>(nq));
     VG_HIP(hipMemcpyAsync(h.data(), redo.ptr, sizeof(int32_t) * static_cast<size_t>(nq), hipMemcpyDeviceToHost, st));
     VG_HIP(hipStreamSynchronize(st));

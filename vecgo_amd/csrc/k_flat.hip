@@ -585,7 +585,7 @@ int32_t launch_page_patch(int64_t nq, int k, int off, int kk, bool descending, c
 
 namespace vg {
 int32_t flat_search_masked(vg_index *idx, const float *queries, int64_t nq, int32_t k, const uint8_t *mask, int64_t mask_stride,
-                           uint32_t *ids, float *scores, void *stream);
+                           uint32_t *ids, float *scores, void *stream, bool l2_scores = false);
 }
 
 VG_API int32_t vg_search_flat(vg_index *idx, const float *queries, int64_t nq, int32_t k, uint32_t *ids,
@@ -598,8 +598,10 @@ VG_API int32_t vg_search_flat(vg_index *idx, const float *queries, int64_t nq, i
 // stride 0 = one mask) — the batched fp32 leg of vg_search_flat_filtered (k_probe.hip): the rows a query's filter rejects
 // are left out of its threshold sample and of its candidate list, so the proof argues about the rows it wants only
 // ("every wanted row not appended scores at or above the threshold"); the exhaustive fallback skips them too.
+// l2_scores: squared-L2 scores whatever the index's metric (vg_search_hnsw_brute on a Cosine index: hnsw's distance there is
+// 0.5 * squared L2, flat.Segment's is the dot product)
 int32_t vg::flat_search_masked(vg_index *idx, const float *queries, int64_t nq, int32_t k, const uint8_t *mask,
-                               int64_t mask_stride, uint32_t *ids, float *scores, void *stream)
+                               int64_t mask_stride, uint32_t *ids, float *scores, void *stream, bool l2_scores)
 {
     VG_CHECK(idx, VG_ERR_INVALID_ARG, "vg_search_flat: NULL index");
     VG_CHECK(nq >= 0 && k >= 0, VG_ERR_INVALID_ARG, "vg_search_flat: negative nq or k");
@@ -610,7 +612,7 @@ int32_t vg::flat_search_masked(vg_index *idx, const float *queries, int64_t nq, 
     VG_CHECK(k <= vg::kFlatMaxK, VG_ERR_UNSUPPORTED, "vg_search_flat: k=%d exceeds %d", k, vg::kFlatMaxK);
     VG_HIP(hipSetDevice(idx->ctx->device));
     hipStream_t st = vg::pick_stream(idx->ctx, stream);
-    const bool dot = idx->metric != VG_METRIC_L2;
+    const bool dot = idx->metric != VG_METRIC_L2 && !l2_scores;
     const int64_t n = idx->n;
     const int dim = idx->dim;
     const int kc = 64;  // nominated candidates per query
