@@ -867,6 +867,91 @@ int32_t vg::flat_search_masked(vg_index *idx, const float *queries, int64_t nq, 
     return VG_OK;
 }
 
+// The nomination + proof of vg_search_flat over MANY (queries, rows) problems in one set of launches: the partition-probed search
+// of k_probe.hip.  pair_queries: the (query, probe) pairs' query vectors bucketed by partition ([pairs, dim]); groups[g]: partition
+// g's pairs and rows; first_block_*: each group's first workgroup in the sample / main GEMM launch (device; the totals are not
+// known to the host: the grids are the host's upper bounds, surplus workgroups leave at once).  Per pair: ids / scores [pairs, k]
+// = its partition's k best rows by (score, row id) with exact scores, and fail[pair] = 1 where the proof does not hold (the caller
+// answers those queries with the exact probe kernels).  k <= kGemmMaxK; fp32 rows, dim % 4 == 0, 16-byte aligned.
+namespace vg {
+// (scratch: one piece of the caller's arena — the caller holds the arena for the call — carved here; the layout in one place)
+struct ProbeGemmLayout {
+    size_t sc, partial, sid, thr, counts, cand, cid, csc, total;
+    int sel_slices;
+};
+static ProbeGemmLayout probe_gemm_layout(int64_t pairs, int64_t ns_max)
+{
+    constexpr int kc = 64, cap = 4096, sel_k = 8;
+    ProbeGemmLayout l;
+    l.sel_slices = static_cast<int>(std::min<int64_t>(8, std::max<int64_t>(1, ns_max / 1024)));
+    size_t at = 0;
+    auto piece = [&](size_t bytes) {
+        const size_t o = at;
+        at += (bytes + 255) & ~size_t(255);
+        return o;
+    };
+    l.sc = piece(sizeof(float) * static_cast<size_t>(pairs) * ns_max);
+    l.partial = piece(sizeof(uint64_t) * static_cast<size_t>(pairs) * l.sel_slices * sel_k);
+    l.sid = piece(sizeof(uint32_t) * static_cast<size_t>(pairs) * sel_k);
+    l.thr = piece(sizeof(float) * static_cast<size_t>(pairs) * sel_k);
+    l.counts = piece(sizeof(int) * static_cast<size_t>(pairs));
+    l.cand = piece(sizeof(uint64_t) * static_cast<size_t>(pairs) * cap);
+    l.cid = piece(sizeof(uint32_t) * static_cast<size_t>(pairs) * kc);
+    l.csc = piece(sizeof(float) * static_cast<size_t>(pairs) * kc);
+    l.total = at;
+    return l;
+}
+size_t flat_probe_gemm_scratch_bytes(int64_t pairs, int64_t ns_max) { return probe_gemm_layout(pairs, ns_max).total; }
+
+int32_t flat_probe_gemm(vg_index *idx, const float *pair_queries, int64_t pairs, const GemmGroup *groups, const int64_t *first_block_sample,
+                        const int64_t *first_block_main, int ngroups, int64_t grid_sample, int64_t grid_main, int sample_stride,
+                        int64_t ns_max, int k, uint32_t *pair_ids, float *pair_scores, int *fail, char *scratch, hipStream_t st)
+{
+    const bool dot = idx->metric != VG_METRIC_L2;
+    const int dim = idx->dim;
+    const int kc = 64, cap = 4096, sel_k = 8;
+    const ProbeGemmLayout l = probe_gemm_layout(pairs, ns_max);
+    const int sel_slices = l.sel_slices;
+    float *sc = reinterpret_cast<float *>(scratch + l.sc), *thr = reinterpret_cast<float *>(scratch + l.thr);
+    float *cand_sc = reinterpret_cast<float *>(scratch + l.csc);
+    uint64_t *partial = reinterpret_cast<uint64_t *>(scratch + l.partial), *cand = reinterpret_cast<uint64_t *>(scratch + l.cand);
+    uint32_t *sid = reinterpret_cast<uint32_t *>(scratch + l.sid), *cand_id = reinterpret_cast<uint32_t *>(scratch + l.cid);
+    int *counts = reinterpret_cast<int *>(scratch + l.counts);
+    const unsigned upairs = static_cast<unsigned>(pairs);
+    // (a) a threshold per pair: the sel_k-th best score of every sample_stride-th row tile of its partition (columns no tile
+    // writes — smaller partitions — hold +Inf)
+    VG_LAUNCH(fill_f32_kernel, dim3(static_cast<unsigned>((pairs * ns_max + 255) / 256)), dim3(256), 0, st, sc, pairs * ns_max, INFINITY);
+    {
+        auto kern = dot ? flat_gemm_dma_grouped_kernel<true, 1> : flat_gemm_dma_grouped_kernel<false, 1>;
+        VG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   static_cast<int>(kDmaLdsBytes)));
+        VG_LAUNCH(kern, dim3(static_cast<unsigned>(grid_sample)), dim3(kGemmThreads), kDmaLdsBytes, st, groups, first_block_sample, ngroups,
+                  pair_queries, idx->d_vectors, dim, idx->d_norms, sc, sample_stride, ns_max, nullptr, 0, 0, nullptr, nullptr, 0);
+    }
+    VG_LAUNCH(flat_select_kernel, dim3(sel_slices, upairs), dim3(kSelThreads), 0, st, sc, ns_max, sel_slices, sel_k, partial);
+    VG_TRY(launch_topk_merge(partial, pairs, sel_slices, sel_k, false, sid, thr, st));
+    // (b) every element below its pair's threshold is appended to the pair's candidates
+    VG_HIP(hipMemsetAsync(counts, 0, sizeof(int) * static_cast<size_t>(pairs), st));
+    {
+        ProfScope prof(idx->ctx, "flat_probe_gemm", st);
+        auto kern = dot ? flat_gemm_dma_grouped_kernel<true, 2> : flat_gemm_dma_grouped_kernel<false, 2>;
+        VG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   static_cast<int>(kDmaLdsBytes)));
+        VG_LAUNCH(kern, dim3(static_cast<unsigned>(grid_main)), dim3(kGemmThreads), kDmaLdsBytes, st, groups, first_block_main, ngroups,
+                  pair_queries, idx->d_vectors, dim, idx->d_norms, nullptr, 1, 0, thr, sel_k, sel_k - 1, counts, cand, cap);
+    }
+    // (c) the kc best of them, (d) re-scored exactly, the k best, and the proof against everything not nominated
+    VG_LAUNCH(flat_pick_kernel, dim3(upairs), dim3(256), 0, st, cand, counts, cap, kc, cand_id, cand_sc);
+    if (dot)
+        VG_LAUNCH(flat_verify_kernel<true>, dim3(upairs), dim3(256), 0, st, idx->d_vectors, idx->n, dim, pair_queries, idx->d_norm_max,
+                  cand_id, cand_sc, kc, k, pair_ids, pair_scores, fail, thr, sel_k, sel_k - 1, counts, cap, 0.0f);
+    else
+        VG_LAUNCH(flat_verify_kernel<false>, dim3(upairs), dim3(256), 0, st, idx->d_vectors, idx->n, dim, pair_queries, idx->d_norm_max,
+                  cand_id, cand_sc, kc, k, pair_ids, pair_scores, fail, thr, sel_k, sel_k - 1, counts, cap, 0.0f);
+    return VG_OK;
+}
+}  // namespace vg
+
 VG_API int32_t vg_index_enable_bf16_filter(vg_index *idx, int32_t on, void *stream)
 {
     VG_CHECK(idx, VG_ERR_INVALID_ARG, "vg_index_enable_bf16_filter: NULL index");

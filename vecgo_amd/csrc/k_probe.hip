@@ -11,6 +11,7 @@
 
 #include "vg_device.hpp"
 #include "vg_exact.hpp"
+#include "vg_flat_gemm.hpp"
 #include "vg_internal.hpp"
 
 namespace vg {
@@ -34,6 +35,10 @@ int32_t flat_search_masked(vg_index *idx, const float *queries, int64_t nq, int3
                            uint32_t *ids, float *scores, void *stream, bool l2_scores = false);
 int32_t pq_adc_search_masked(vg_index *idx, const float *queries, int64_t nq, int32_t k, const uint8_t *mask, int64_t mask_stride,
                              bool desc, uint32_t *ids, float *scores, void *stream);
+size_t flat_probe_gemm_scratch_bytes(int64_t pairs, int64_t ns_max);
+int32_t flat_probe_gemm(vg_index *idx, const float *pair_queries, int64_t pairs, const GemmGroup *groups, const int64_t *first_block_sample,
+                        const int64_t *first_block_main, int ngroups, int64_t grid_sample, int64_t grid_main, int sample_stride,
+                        int64_t ns_max, int k, uint32_t *pair_ids, float *pair_scores, int *fail, char *scratch, hipStream_t st);
 int32_t launch_page_patch(int64_t nq, int k, int off, int kk, bool descending, const int *always_one,
                           const uint32_t *fids, const float *fscores, uint32_t *ids, float *scores, uint64_t *min_keys,
                           hipStream_t st);
@@ -80,12 +85,14 @@ __global__ __launch_bounds__(256) void probe_scan_f32_kernel(const float *__rest
                                                              const uint32_t *__restrict__ part_off, int np, int sub_n,
                                                              int k, uint64_t *__restrict__ partial,
                                                              const uint64_t *__restrict__ min_keys,
-                                                             const uint8_t *__restrict__ mask, int64_t mask_stride)
+                                                             const uint8_t *__restrict__ mask, int64_t mask_stride,
+                                                             const int *__restrict__ only_if = nullptr)
 {
     __shared__ uint64_t lists[4 * 64];
     __shared__ int valid[4];
     const int s = blockIdx.x, j = blockIdx.y;
     const int64_t q = blockIdx.z;
+    if (only_if && !only_if[q]) return;  // the matrix-core path's fallback: only the flagged queries
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const Sub16 sub = Sub16::make(tid);
     const uint32_t p = probes[q * np + j];
@@ -289,6 +296,114 @@ __global__ __launch_bounds__(256) void probe_scan_f32_mq_kernel(const float *__r
     }
 }
 
+// ---- 2c. fp32 scan through the matrix cores: nomination + proof per (query, probe) pair ------------------------------------
+// A batch whose partitions are each probed by many queries is a set of dense [queries of p] x [rows of p] products: the pairs
+// are bucketed by partition, their query vectors gathered into one matrix, and vg_search_flat's machinery — threshold from a
+// row sample, fp32 MFMA GEMM appending what falls below it, exact re-score of the 64 best, proof — runs over all partitions in
+// one grouped launch per stage (flat_probe_gemm, k_flat.hip); a pair's k best rows are exact or its query is flagged, and the
+// flagged queries are answered by the kernels above.  The per-query merge of the np lists is the usual one.
+constexpr int kProbeSampleStride = 8;  // every 8th row tile of a partition sets its pairs' thresholds
+
+__global__ __launch_bounds__(256) void probe_bucket_count_kernel(const uint32_t *__restrict__ probes, int64_t pairs,
+                                                                 uint32_t *__restrict__ counts)
+{
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i < pairs) atomicAdd(&counts[probes[i]], 1u);
+}
+
+// one workgroup: the groups (pairs and rows of each partition) and each group's first workgroup in the two GEMM launches
+__global__ __launch_bounds__(1024) void probe_bucket_scan_kernel(const uint32_t *__restrict__ counts, const uint32_t *__restrict__ part_off,
+                                                                 int parts, uint32_t *__restrict__ cursor, GemmGroup *__restrict__ groups,
+                                                                 int64_t *__restrict__ fb_sample, int64_t *__restrict__ fb_main)
+{
+    __shared__ int64_t seg_c[1024], seg_s[1024], seg_m[1024];
+    const int tid = threadIdx.x;
+    const int per = (parts + 1023) / 1024;
+    const int pb = tid * per < parts ? tid * per : parts, pe = pb + per < parts ? pb + per : parts;
+    auto blocks = [&](int p, int64_t &bs, int64_t &bm) {
+        const int64_t cnt = counts[p], rows = static_cast<int64_t>(part_off[p + 1]) - part_off[p];
+        const int64_t mt = (cnt + kGemmBM - 1) / kGemmBM, nt = (rows + kGemmBN - 1) / kGemmBN;
+        const int64_t nst = (nt + kProbeSampleStride - 1) / kProbeSampleStride;
+        bs = cnt && rows ? mt * ((nst + 7) / 8) * 8 : 0;
+        bm = cnt && rows ? mt * ((nt + 7) / 8) * 8 : 0;
+    };
+    int64_t mc = 0, ms = 0, mm = 0;
+    for (int p = pb; p < pe; p++) {
+        int64_t bs, bm;
+        blocks(p, bs, bm);
+        mc += counts[p];
+        ms += bs;
+        mm += bm;
+    }
+    seg_c[tid] = mc;
+    seg_s[tid] = ms;
+    seg_m[tid] = mm;
+    __syncthreads();
+    if (tid == 0) {
+        int64_t rc = 0, rs = 0, rm = 0;
+        for (int t = 0; t < 1024; t++) {
+            const int64_t c = seg_c[t], s = seg_s[t], m = seg_m[t];
+            seg_c[t] = rc;
+            seg_s[t] = rs;
+            seg_m[t] = rm;
+            rc += c;
+            rs += s;
+            rm += m;
+        }
+        fb_sample[parts] = rs;
+        fb_main[parts] = rm;
+    }
+    __syncthreads();
+    int64_t rc = seg_c[tid], rs = seg_s[tid], rm = seg_m[tid];
+    for (int p = pb; p < pe; p++) {
+        int64_t bs, bm;
+        blocks(p, bs, bm);
+        GemmGroup g;
+        g.a_off = rc;
+        g.b_off = part_off[p];
+        g.a_cnt = static_cast<int32_t>(counts[p]);
+        g.b_cnt = static_cast<int32_t>(part_off[p + 1] - part_off[p]);
+        groups[p] = g;
+        cursor[p] = static_cast<uint32_t>(rc);
+        fb_sample[p] = rs;
+        fb_main[p] = rm;
+        rc += counts[p];
+        rs += bs;
+        rm += bm;
+    }
+}
+
+__global__ __launch_bounds__(256) void probe_bucket_fill_kernel(const uint32_t *__restrict__ probes, int64_t pairs,
+                                                                uint32_t *__restrict__ cursor, uint32_t *__restrict__ pair_of)
+{
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i < pairs) pair_of[atomicAdd(&cursor[probes[i]], 1u)] = static_cast<uint32_t>(i);
+}
+
+// row `pos` of the pair matrix = the query of the pos-th bucketed pair (dim % 4 == 0, 16-byte aligned)
+__global__ __launch_bounds__(256) void probe_gather_queries_kernel(const float *__restrict__ queries, const uint32_t *__restrict__ pair_of,
+                                                                   int np, int dim, float *__restrict__ out)
+{
+    const int64_t pos = blockIdx.x;
+    const float4 *src = reinterpret_cast<const float4 *>(queries + static_cast<int64_t>(pair_of[pos] / np) * dim);
+    float4 *dst = reinterpret_cast<float4 *>(out + pos * dim);
+    for (int t = threadIdx.x; t < dim / 4; t += 256) dst[t] = src[t];
+}
+
+// a pair's k results as keys in the slot of its (query, probe) in the per-query lists; a failed proof flags the query
+__global__ __launch_bounds__(64) void probe_pack_kernel(const uint32_t *__restrict__ pair_of, const uint32_t *__restrict__ ids,
+                                                        const float *__restrict__ scores, const int *__restrict__ fail, int k, int np,
+                                                        bool desc, uint64_t *__restrict__ partial, int *__restrict__ qfail)
+{
+    const int64_t pos = blockIdx.x;
+    const uint32_t pr = pair_of[pos];
+    for (int i = threadIdx.x; i < k; i += 64) {
+        const uint32_t id = ids[pos * k + i];
+        partial[static_cast<int64_t>(pr) * k + i] = id == VG_INVALID_ID ? kKeyMax : make_key(scores[pos * k + i], id, desc);
+    }
+    if (threadIdx.x == 0 && fail[pos]) qfail[pr / np] = 1;
+}
+
 // A filtered search of an unpartitioned segment (segment.go:745-749 with `filter` set): ONE range, the whole segment.  The
 // heap order is total, so the range is cut into `parts` equal pieces scanned like probed partitions — every query "probes"
 // all of them — to spread the rows over the device.
@@ -315,6 +430,7 @@ VG_API int32_t vg_index_set_partitions(vg_index *idx, const float *centroids, co
     idx->d_centroids = nullptr;
     idx->d_part_off = nullptr;
     idx->num_partitions = 0;
+    idx->h_part_off.clear();
     if (num_partitions == 0) return VG_OK;
     VG_CHECK(centroids && part_offsets, VG_ERR_INVALID_ARG, "vg_index_set_partitions: NULL buffer");
     // the offsets come from a file: check them once here instead of in every scan
@@ -332,6 +448,7 @@ VG_API int32_t vg_index_set_partitions(vg_index *idx, const float *centroids, co
     VG_HIP(hipMemcpyAsync(idx->d_part_off, off.data(), off.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
     VG_HIP(hipStreamSynchronize(st));  // `off` is a local; the caller's buffers are free again
     idx->num_partitions = num_partitions;
+    idx->h_part_off = off;
     return VG_OK;
 }
 
@@ -466,6 +583,42 @@ static int32_t flat_probed_impl(vg_index *idx, const float *queries, int64_t nq,
     const int i_one = ar.add(paged ? 256 : 0);
     const int i_tables = ar.add(sizeof(float) * static_cast<size_t>(nq) * lut_words);
     const int i_whole = ar.add(whole ? sizeof(uint32_t) * (static_cast<size_t>(parts) + 1) : 0);
+    // fp32, unfiltered, partitions probed by 24 or more queries each on average: nomination + proof on the matrix cores (2c)
+    // (1M x 768 in 122 partitions, 1024 queries, ms per call, exact kernels -> this: nprobes 2 (17 per partition) 2.0 -> 2.5,
+    // 4: 3.75 -> 2.35, 8: 7.25 -> 2.64, 16: 11.6 -> 4.4, 32: 20.9 -> 7.0; tools/probe_time.py)
+    const bool gemm = scan == VG_SCAN_F32 && !mk.ptr && !whole && k <= 48 && idx->dim % 4 == 0 && pairs <= 65535 &&
+                      pairs >= 24 * static_cast<int64_t>(parts) && (reinterpret_cast<uintptr_t>(idx->d_vectors) & 15) == 0 &&
+                      (reinterpret_cast<uintptr_t>(q.ptr) & 15) == 0 && static_cast<int>(idx->h_part_off.size()) == parts + 1 &&
+                      !vg::hook(vg::kHookProbeNoGroup) && !vg::hook(vg::kHookProbeNoGemm);
+    int64_t grid_sample = 0, grid_main = 0, ns_max = 0;
+    if (gemm) {  // launch bounds from the partition sizes: one query tile per partition + the batch's further tiles on the largest
+        int64_t sum_s = 0, sum_m = 0, max_s = 0, max_m = 0;
+        for (int p = 0; p < parts; p++) {
+            const int64_t rows = static_cast<int64_t>(idx->h_part_off[p + 1]) - idx->h_part_off[p];
+            const int64_t nt = (rows + vg::kGemmBN - 1) / vg::kGemmBN, nst = (nt + vg::kProbeSampleStride - 1) / vg::kProbeSampleStride;
+            const int64_t bs = ((nst + 7) / 8) * 8, bm = ((nt + 7) / 8) * 8;
+            sum_s += bs;
+            sum_m += bm;
+            max_s = std::max(max_s, bs);
+            max_m = std::max(max_m, bm);
+            ns_max = std::max(ns_max, nst * vg::kGemmBN);
+        }
+        grid_sample = sum_s + (pairs / vg::kGemmBM) * max_s;
+        grid_main = sum_m + (pairs / vg::kGemmBM) * max_m;
+    }
+    const size_t gw = gemm ? static_cast<size_t>(parts) + 1 : 0;
+    const int i_bcnt = ar.add(sizeof(uint32_t) * gw);
+    const int i_bcur = ar.add(sizeof(uint32_t) * gw);
+    const int i_bgrp = ar.add(sizeof(vg::GemmGroup) * gw);
+    const int i_fbs = ar.add(sizeof(int64_t) * gw);
+    const int i_fbm = ar.add(sizeof(int64_t) * gw);
+    const int i_bpair = ar.add(gemm ? sizeof(uint32_t) * static_cast<size_t>(pairs) : 0);
+    const int i_pairq = ar.add(gemm ? sizeof(float) * static_cast<size_t>(pairs) * idx->dim : 0);
+    const int i_pids = ar.add(gemm ? sizeof(uint32_t) * static_cast<size_t>(pairs) * k : 0);
+    const int i_pscore = ar.add(gemm ? sizeof(float) * static_cast<size_t>(pairs) * k : 0);
+    const int i_pfail = ar.add(gemm ? sizeof(int) * static_cast<size_t>(pairs) : 0);
+    const int i_qfail = ar.add(gemm ? sizeof(int) * static_cast<size_t>(nq) : 0);
+    const int i_gscr = ar.add(gemm ? vg::flat_probe_gemm_scratch_bytes(pairs, ns_max) : 0);
     VG_TRY(ar.commit());
     uint32_t *probes = ar.get<uint32_t>(i_probes);
     uint64_t *partial = ar.get<uint64_t>(i_partial);
@@ -494,6 +647,44 @@ static int32_t flat_probed_impl(vg_index *idx, const float *queries, int64_t nq,
     // the heap direction follows the segment metric for EVERY scan (flat/segment.go:449): with Dot / Cosine a PQ
     // scan therefore keeps the k LARGEST table-lookup (squared-L2) distances — the reference as written
     const bool desc = dot;
+    if (gemm) {
+        uint32_t *bcnt = ar.get<uint32_t>(i_bcnt), *bcur = ar.get<uint32_t>(i_bcur), *bpair = ar.get<uint32_t>(i_bpair);
+        vg::GemmGroup *bgrp = ar.get<vg::GemmGroup>(i_bgrp);
+        int64_t *fbs = ar.get<int64_t>(i_fbs), *fbm = ar.get<int64_t>(i_fbm);
+        float *pairq = ar.get<float>(i_pairq), *pair_sc = ar.get<float>(i_pscore);
+        uint32_t *pair_ids = ar.get<uint32_t>(i_pids);
+        int *pfail = ar.get<int>(i_pfail), *qfail = ar.get<int>(i_qfail);
+        const unsigned pb = static_cast<unsigned>((pairs + 255) / 256);
+        VG_HIP(hipMemsetAsync(bcnt, 0, sizeof(uint32_t) * (static_cast<size_t>(parts) + 1), st));
+        VG_HIP(hipMemsetAsync(qfail, 0, sizeof(int) * static_cast<size_t>(nq), st));
+        VG_LAUNCH(vg::probe_bucket_count_kernel, dim3(pb), dim3(256), 0, st, probes, pairs, bcnt);
+        VG_LAUNCH(vg::probe_bucket_scan_kernel, dim3(1), dim3(1024), 0, st, bcnt, part_off, parts, bcur, bgrp, fbs, fbm);
+        VG_LAUNCH(vg::probe_bucket_fill_kernel, dim3(pb), dim3(256), 0, st, probes, pairs, bcur, bpair);
+        VG_LAUNCH(vg::probe_gather_queries_kernel, dim3(static_cast<unsigned>(pairs)), dim3(256), 0, st, q.ptr, bpair, np, idx->dim, pairq);
+        {
+            vg::ProfScope prof(idx->ctx, "flat_probe", st);
+            VG_TRY(vg::flat_probe_gemm(idx, pairq, pairs, bgrp, fbs, fbm, parts, grid_sample, grid_main, vg::kProbeSampleStride, ns_max, k,
+                                       pair_ids, pair_sc, pfail, ar.get<char>(i_gscr), st));
+        }
+        // lists = np * sub in this configuration; the pairs' k results fill the first np lists' worth of `partial`
+        VG_LAUNCH(vg::probe_pack_kernel, dim3(static_cast<unsigned>(pairs)), dim3(64), 0, st, bpair, pair_ids, pair_sc, pfail, k, np, desc,
+                  partial, qfail);
+        VG_TRY(vg::launch_topk_merge(partial, nq, np, k, desc, oid.ptr, osc.ptr, st));
+        // the queries with a failed proof (ties at the k-th score, more than 4096 rows below a threshold): the exact kernel, one
+        // workgroup per (slice, probe, query) that leaves at once unless its query is flagged
+        for (int64_t q0 = 0; q0 < nq; q0 += 65535) {
+            const int64_t cnt = std::min<int64_t>(65535, nq - q0);
+            const dim3 grid(static_cast<unsigned>(sub), static_cast<unsigned>(np), static_cast<unsigned>(cnt));
+            auto kern = dot ? vg::probe_scan_f32_kernel<true, false> : vg::probe_scan_f32_kernel<false, false>;
+            VG_LAUNCH(kern, grid, dim3(256), 0, st, idx->d_vectors, idx->dim, q.ptr + q0 * idx->dim, probes + q0 * np, part_off, np, sub, k,
+                      partial + q0 * lists * k, nullptr, nullptr, int64_t(0), qfail + q0);
+        }
+        VG_TRY(vg::launch_topk_merge(partial, nq, lists, k, desc, oid.ptr, osc.ptr, st, qfail));
+        VG_TRY(oid.finish());
+        VG_TRY(osc.finish());
+        if (oid.on_host() || osc.on_host()) VG_HIP(hipStreamSynchronize(st));
+        return VG_OK;
+    }
     const size_t mq_lds = sizeof(float) * vg::kProbeQB * static_cast<size_t>(idx->dim) + 4 * 64 * sizeof(uint64_t) + 64;
     auto mq_kern = mk.ptr ? (dot ? vg::probe_scan_f32_mq_kernel<true, true> : vg::probe_scan_f32_mq_kernel<false, true>)
                           : (dot ? vg::probe_scan_f32_mq_kernel<true, false> : vg::probe_scan_f32_mq_kernel<false, false>);
@@ -536,7 +727,7 @@ static int32_t flat_probed_impl(vg_index *idx, const float *queries, int64_t nq,
                                    : (dot ? vg::probe_scan_f32_kernel<true, false> : vg::probe_scan_f32_kernel<false, false>);
                 VG_LAUNCH(kern, grid, dim3(256), 0, st, idx->d_vectors, idx->dim, q.ptr + q0 * idx->dim, probes + q0 * np,
                           part_off, np, sub, kk, partial + q0 * lists * kk, floor ? floor + q0 : nullptr,
-                          mk.ptr ? mk.ptr + q0 * mask_stride : nullptr, mask_stride);
+                          mk.ptr ? mk.ptr + q0 * mask_stride : nullptr, mask_stride, nullptr);
             }
         } else if (scan == VG_SCAN_PQ) {
             VG_TRY(vg::launch_probe_scan_adc(idx, tables, probes, part_off, nq, np, split, kk, partial, floor, desc, mk.ptr,

@@ -36,7 +36,7 @@ __device__ __forceinline__ void gemm_epilogue(const f32x16 (&acc)[2][2], float *
                                               int64_t nq, int64_t n0, int64_t n, int64_t tn,
                                               float *__restrict__ scores, int64_t out_cols,
                                               int *__restrict__ counts, uint64_t *__restrict__ cand, int cap,
-                                              const uint8_t *__restrict__ mask, int64_t mask_stride)
+                                              const uint8_t *__restrict__ mask, int64_t mask_stride, uint32_t row_base = 0)
 {
     float4 t4[2][4];  // thresholds of rows i*32 + 8*g + 4*(lane>>5) + 0..3
     if (MODE == 2) {
@@ -72,7 +72,7 @@ __device__ __forceinline__ void gemm_epilogue(const f32x16 (&acc)[2][2], float *
                     // the filter bit is looked at only for the few elements below the threshold
                     if (nn < n && sc < t && (mask == nullptr || mask_bit(mask + qq * mask_stride, nn))) {
                         const int pos = atomicAdd(&counts[qq], 1);
-                        if (pos < cap) cand[qq * cap + pos] = make_key(sc, static_cast<uint32_t>(nn), false);
+                        if (pos < cap) cand[qq * cap + pos] = make_key(sc, static_cast<uint32_t>(nn) + row_base, false);
                     }
                 }
             }
@@ -312,19 +312,21 @@ __device__ __forceinline__ void glds16_stream(const float *base, uint32_t byte_o
 // The scores are a FILTER for the exact fp32 re-score (vg_index_enable_bf16_filter, k_flat.hip); elements / 2 must be
 // a multiple of kGemmBK.
 typedef __bf16 vg_bf16x8 __attribute__((ext_vector_type(8)));
-template <bool DOT, int MODE, int PROBE = 0, bool BF16 = false>
-__global__ __launch_bounds__(kGemmThreads) void flat_gemm_dma_kernel(
+// (the kernel's body as a function: flat_gemm_dma_kernel runs it on one problem, flat_gemm_dma_grouped_kernel on the problem its
+// workgroup belongs to.  bt = the workgroup's index within its problem; GROUPED: row ids in the appended keys are row_base + the
+// row's index in `base`)
+template <bool DOT, int MODE, int PROBE, bool BF16, bool GROUPED>
+__device__ __forceinline__ void flat_gemm_dma_body(
     const float *__restrict__ queries, int64_t nq, const float *__restrict__ base, int64_t n,
     int dim, const float *__restrict__ norms, float *__restrict__ scores, int tile_stride,
     int64_t out_cols, const float *__restrict__ thr, int thr_stride, int thr_off,
-    int *__restrict__ counts, uint64_t *__restrict__ cand, int cap, const uint8_t *__restrict__ mask = nullptr,
-    int64_t mask_stride = 0)
+    int *__restrict__ counts, uint64_t *__restrict__ cand, int cap, const uint8_t *__restrict__ mask,
+    int64_t mask_stride, int64_t bt, uint32_t row_base)
 {
     extern __shared__ float gemm_lds[];
     const int mtiles = static_cast<int>((nq + kGemmBM - 1) / kGemmBM);
     const int64_t ntiles = MODE == 1 ? (((n + kGemmBN - 1) / kGemmBN) + tile_stride - 1) / tile_stride
                                      : (n + kGemmBN - 1) / kGemmBN;
-    const int64_t bt = blockIdx.x;
     const int64_t xcd = bt & 7, jx = bt >> 3;
     const int64_t tn = (jx / mtiles) * 8 + xcd;
     const int tm = static_cast<int>(jx % mtiles);
@@ -466,7 +468,54 @@ __global__ __launch_bounds__(kGemmThreads) void flat_gemm_dma_kernel(
         return;
     }
     gemm_epilogue<DOT, MODE>(acc, gemm_lds, thr_reg, xn, tid, lane, wr, wc, q0, nq, n0, n, tn, scores, out_cols,
-                             counts, cand, cap, mask, mask_stride);
+                             counts, cand, cap, mask, mask_stride, GROUPED ? row_base : 0u);
+}
+
+template <bool DOT, int MODE, int PROBE = 0, bool BF16 = false>
+__global__ __launch_bounds__(kGemmThreads) void flat_gemm_dma_kernel(
+    const float *__restrict__ queries, int64_t nq, const float *__restrict__ base, int64_t n,
+    int dim, const float *__restrict__ norms, float *__restrict__ scores, int tile_stride,
+    int64_t out_cols, const float *__restrict__ thr, int thr_stride, int thr_off,
+    int *__restrict__ counts, uint64_t *__restrict__ cand, int cap, const uint8_t *__restrict__ mask = nullptr,
+    int64_t mask_stride = 0)
+{
+    flat_gemm_dma_body<DOT, MODE, PROBE, BF16, false>(queries, nq, base, n, dim, norms, scores, tile_stride, out_cols, thr, thr_stride,
+                                                       thr_off, counts, cand, cap, mask, mask_stride, blockIdx.x, 0u);
+}
+
+// One launch over MANY problems that share the row matrix (the partition-probed flat search, k_probe.hip: problem p = the queries
+// probing partition p x that partition's rows): group g multiplies the a_cnt query rows from a_off on (of `queries`, the pairs'
+// query vectors bucketed by partition) with the b_cnt rows from b_off on; scores / thresholds / counts / candidate lists are
+// indexed by the PAIR (a_off + local row), the appended keys carry global row ids.  first_block[g] (a multiple of 8, so that the
+// XCD-aware tile order holds inside a group) = the group's first workgroup; first_block[ngroups] = their total.
+struct GemmGroup {
+    int64_t a_off, b_off;
+    int32_t a_cnt, b_cnt;
+};
+template <bool DOT, int MODE>
+__global__ __launch_bounds__(kGemmThreads) void flat_gemm_dma_grouped_kernel(
+    const GemmGroup *__restrict__ groups, const int64_t *__restrict__ first_block, int ngroups,
+    const float *__restrict__ queries, const float *__restrict__ base, int dim, const float *__restrict__ norms,
+    float *__restrict__ scores, int tile_stride, int64_t out_cols, const float *__restrict__ thr, int thr_stride, int thr_off,
+    int *__restrict__ counts, uint64_t *__restrict__ cand, int cap)
+{
+    const int64_t b = blockIdx.x;
+    if (b >= first_block[ngroups]) return;
+    int lo = 0, hi = ngroups - 1;  // the last group whose first workgroup is <= b
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (first_block[mid] <= b)
+            lo = mid;
+        else
+            hi = mid - 1;
+    }
+    const GemmGroup g = groups[lo];
+    if (g.a_cnt == 0 || g.b_cnt == 0) return;
+    flat_gemm_dma_body<DOT, MODE, 0, false, true>(
+        queries + g.a_off * dim, g.a_cnt, base + g.b_off * dim, g.b_cnt, dim, norms + g.b_off,
+        scores ? scores + g.a_off * out_cols : nullptr, tile_stride, out_cols, thr ? thr + g.a_off * thr_stride : nullptr, thr_stride,
+        thr_off, counts ? counts + g.a_off : nullptr, cand ? cand + g.a_off * cap : nullptr, cap, nullptr, 0, b - first_block[lo],
+        static_cast<uint32_t>(g.b_off));
 }
 
 // ---- 5..64 queries: the same pipeline with a 32 x 128 or 64 x 128 tile ------------------------------

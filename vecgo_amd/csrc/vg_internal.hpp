@@ -83,6 +83,7 @@ enum Hook {
     kHookPqNoMfma,            // VG_PQ_NO_MFMA           PQ Encode / Lloyd assignment by the reference-order kernels only
     kHookPqListAll,           // VG_PQ_LIST_ALL          PQ Encode / assignment: every (row, sub-quantizer) pair is listed
     kHookPqFp32Mfma,          // VG_PQ_FP32_MFMA         PQ Encode / assignment: the fp32 matrix form (pq_nominate_kernel)
+    kHookProbeNoGemm,         // VG_PROBE_NO_GEMM        probed fp32 scan: the exact kernels only, no matrix-core nomination
     kHookCount
 };
 bool hook(Hook h);
@@ -371,5 +372,6 @@ struct vg_index {
     // IVF partitions of a flat segment: centroids [P*dim], first row of every partition [P+1]
     float *d_centroids = nullptr;
     uint32_t *d_part_off = nullptr;
+    std::vector<uint32_t> h_part_off;  // the same on the host (launch bounds of the grouped GEMM, k_probe.hip)
     int32_t num_partitions = 0;
 };
