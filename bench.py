@@ -1028,7 +1028,7 @@ def build_side_legs(vg, ctx, rows, queries, stream, with_cpu, rows_host=None):
     tf = 2.0 * nqf * n * DIM / (g_ms * 1e-3) / 1e12
     row = {"workload": f"flat.Segment.Search with a row filter per query (1/8 of the rows pass): {nqf} queries x {n} x {DIM}, top-{K} "
                        "(flat/segment.go:631-635)",
-           "kernel": "flat_gemm_dma_kernel<false,2> (filter bit read for the elements below the threshold)", "kernel_ms": g_ms, "bound": "mfma",
+           "kernel": "flat_gemm_dma_kernel<false,2> + row filter", "kernel_ms": g_ms, "bound": "mfma",
            "achieved": tf, "peak": PEAK_MFMA_F32_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_MFMA_F32_TFLOPS, "call_ms": wall,
            "queries_per_s": nqf / (wall * 1e-3), "short": f"flat_filtered_{nqf}q_{n}x{DIM}_keep0.125_top{K}"}
     one = fm[0].contiguous()
@@ -1308,7 +1308,7 @@ def live_traffic(kernel_sub: str, script: str, timeout_s: float = 150.0, script_
 
 BASELINE_METRIC = "QPS at recall@10≥0.95, 1M×768 HNSW+PQ; PQ-ADC HBM GB/s vs peak"   # BASELINE.json "metric", verbatim
 FULL_RECORD = "bench_full.json"
-LINE_LIMIT = 8000      # bytes: the driver could not parse r03's 22.7 KB line; r02's 10.8 KB one it could
+LINE_LIMIT = 9000      # bytes: the driver could not parse r03's 22.7 KB line; r02's 10.8 KB one it could
 
 
 def _r(x, sig=6):
@@ -1397,6 +1397,13 @@ def compact_line(full: dict) -> dict:
     if isinstance(pt, dict):
         cfgs.append({"config": "configs[4] pq kmeans train, sharded by sub-quantizer",
                      **_pick(pt, "wall_s", "codebooks_identical_on_all_ranks")})
+    fp = full.get("flat_ivf_probe")
+    if isinstance(fp, dict) and "nprobes_8" in fp:  # the partition-probed scan: grouped GEMM nomination + proof per (query, probe)
+        p8 = fp["nprobes_8"]
+        tf = 2.0 * Q_BATCH * 8 * (N_ROWS / max(N_ROWS // 8192, 1)) * DIM / (p8["scan_kernel_ms"] * 1e-3) / 1e12
+        cfgs.append({"config": "flat ivf probe, nprobes 8", "kernel": "flat_gemm_dma_grouped_kernel + verify", "kernel_ms": _r(p8["scan_kernel_ms"]),
+                     "bound": "mfma", "achieved": _r(tf), "peak": PEAK_MFMA_F32_TFLOPS, "unit": "TFLOP/s", "frac": _r(tf / PEAK_MFMA_F32_TFLOPS),
+                     "qps": _r(p8["qps"]), "nprobes_1_qps": _r(fp["nprobes_1"]["qps"])})
     row("f3 sq8 scan", full.get("sq8_scan"))
     i4 = full.get("int4_scan")
     if isinstance(i4, dict) and "batch_order" in i4:

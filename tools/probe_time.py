@@ -48,3 +48,17 @@ for nprobes in (1, 2, 4, 8, 16, 32):
         hooks.set_hook("VG_PROBE_NO_GEMM", 0)
     same = bool(torch.equal(ra[0], rb[0])) and bool(torch.equal(ra[1].view(torch.int32), rb[1].view(torch.int32)))
     print(f"nprobes {nprobes:3d}: {a:7.2f} ms per 1024 queries ({1024 / a:7.1f} k q/s)   exact kernels alone {b:7.2f} ms   same results: {same}", flush=True)
+
+# the code scans of the same partitioned segment: SQ8 (grouped by partition) and PQ m = 96 (one workgroup per query and share of
+# its probe list), beside the unprobed scans of the whole segment
+sq = vg.ScalarQuantizer(ctx, bench.DIM); sq.train(rows[:100000])
+idx.set_sq8_codes(sq, sq.encode(rows[order].contiguous()))
+pq = vg.ProductQuantizer(ctx, bench.DIM, 96, 256); pq.train(rows[:65536], iters=2, seed=1)
+idx.set_pq_codes(pq, pq.encode(rows[order].contiguous()))
+for name, scan, whole in (("sq8", idx.SCAN_SQ8, idx.search_sq8), ("pq96", idx.SCAN_PQ, idx.search_pq_adc)):
+    w, _ = timed(lambda: whole(q, 10))
+    line = [f"{name}: whole segment {w:7.2f} ms per 1024 queries"]
+    for nprobes in (1, 8, 32):
+        a, _ = timed(lambda: idx.search_flat_probed(q, 10, nprobes, scan=scan))
+        line.append(f"nprobes {nprobes}: {a:6.2f}")
+    print("   ".join(line), flush=True)
