@@ -302,7 +302,7 @@ __global__ __launch_bounds__(256) void probe_scan_f32_mq_kernel(const float *__r
 // row sample, fp32 MFMA GEMM appending what falls below it, exact re-score of the 64 best, proof — runs over all partitions in
 // one grouped launch per stage (flat_probe_gemm, k_flat.hip); a pair's k best rows are exact or its query is flagged, and the
 // flagged queries are answered by the kernels above.  The per-query merge of the np lists is the usual one.
-constexpr int kProbeSampleStride = 8;  // every 8th row tile of a partition sets its pairs' thresholds
+constexpr int kProbeSampleStride = 8;  // every 8th row tile of a partition sets its pairs' thresholds (16: the same times)
 
 __global__ __launch_bounds__(256) void probe_bucket_count_kernel(const uint32_t *__restrict__ probes, int64_t pairs,
                                                                  uint32_t *__restrict__ counts)
