@@ -40,7 +40,13 @@ def timed(fn, reps=3):
 
 
 for nprobes in (1, 2, 4, 8, 16, 32):
+    ctx.profile_read("flat_probe_gemm")
+    ctx.profile_enable(True)
     a, ra = timed(lambda: idx.search_flat_probed(q, 10, nprobes))
+    gl, gms = ctx.profile_read("flat_probe_gemm")
+    ctx.profile_enable(False)
+    if gl:
+        print(f"             main grouped GEMM {gms / gl:6.2f} ms of it", flush=True)
     hooks.set_hook("VG_PROBE_NO_GEMM", "1")
     try:
         b, rb = timed(lambda: idx.search_flat_probed(q, 10, nprobes))

@@ -36,9 +36,9 @@ int32_t flat_search_masked(vg_index *idx, const float *queries, int64_t nq, int3
 int32_t pq_adc_search_masked(vg_index *idx, const float *queries, int64_t nq, int32_t k, const uint8_t *mask, int64_t mask_stride,
                              bool desc, uint32_t *ids, float *scores, void *stream);
 size_t flat_probe_gemm_scratch_bytes(int64_t pairs, int64_t ns_max);
-int32_t flat_probe_gemm(vg_index *idx, const float *pair_queries, int64_t pairs, const GemmGroup *groups, const int64_t *first_block_sample,
-                        const int64_t *first_block_main, int ngroups, int64_t grid_sample, int64_t grid_main, int sample_stride,
-                        int64_t ns_max, int k, uint32_t *pair_ids, float *pair_scores, int *fail, char *scratch, hipStream_t st);
+int32_t flat_probe_gemm(vg_index *idx, const float *pair_queries, int64_t pairs, const GemmGroup *groups, const int64_t *const first_block[4],
+                        int ngroups, const int64_t grid[4], int sample_stride, int64_t ns_max, int k, uint32_t *pair_ids,
+                        float *pair_scores, int *fail, char *scratch, hipStream_t st);
 int32_t launch_page_patch(int64_t nq, int k, int off, int kk, bool descending, const int *always_one,
                           const uint32_t *fids, const float *fscores, uint32_t *ids, float *scores, uint64_t *min_keys,
                           hipStream_t st);
@@ -314,50 +314,66 @@ __global__ __launch_bounds__(256) void probe_bucket_count_kernel(const uint32_t 
 // one workgroup: the groups (pairs and rows of each partition) and each group's first workgroup in the two GEMM launches
 __global__ __launch_bounds__(1024) void probe_bucket_scan_kernel(const uint32_t *__restrict__ counts, const uint32_t *__restrict__ part_off,
                                                                  int parts, uint32_t *__restrict__ cursor, GemmGroup *__restrict__ groups,
-                                                                 int64_t *__restrict__ fb_sample, int64_t *__restrict__ fb_main)
+                                                                 int64_t *__restrict__ fb_sample, int64_t *__restrict__ fb_main,
+                                                                 int64_t *__restrict__ fb_sample_small, int64_t *__restrict__ fb_main_small)
 {
-    __shared__ int64_t seg_c[1024], seg_s[1024], seg_m[1024];
+    // a group of at most 64 pairs takes the 64-query tile (flat_gemm_dma32_grouped_kernel<.., 2>: one workgroup per row tile,
+    // HBM-bound whatever the tile holds), a larger one the 128-query tiles; each group has workgroups in one of the two launches
+    __shared__ int64_t seg_c[1024], seg_s[1024], seg_m[1024], seg_ss[1024], seg_sm[1024];
     const int tid = threadIdx.x;
     const int per = (parts + 1023) / 1024;
     const int pb = tid * per < parts ? tid * per : parts, pe = pb + per < parts ? pb + per : parts;
-    auto blocks = [&](int p, int64_t &bs, int64_t &bm) {
+    auto blocks = [&](int p, int64_t &bs, int64_t &bm, int64_t &ss, int64_t &sm) {
         const int64_t cnt = counts[p], rows = static_cast<int64_t>(part_off[p + 1]) - part_off[p];
         const int64_t mt = (cnt + kGemmBM - 1) / kGemmBM, nt = (rows + kGemmBN - 1) / kGemmBN;
         const int64_t nst = (nt + kProbeSampleStride - 1) / kProbeSampleStride;
-        bs = cnt && rows ? mt * ((nst + 7) / 8) * 8 : 0;
-        bm = cnt && rows ? mt * ((nt + 7) / 8) * 8 : 0;
+        const bool any = cnt && rows, small = cnt <= 2 * kG32BM;
+        bs = any && !small ? mt * ((nst + 7) / 8) * 8 : 0;
+        bm = any && !small ? mt * ((nt + 7) / 8) * 8 : 0;
+        ss = any && small ? nst : 0;
+        sm = any && small ? nt : 0;
     };
-    int64_t mc = 0, ms = 0, mm = 0;
+    int64_t mc = 0, ms = 0, mm = 0, mss = 0, msm = 0;
     for (int p = pb; p < pe; p++) {
-        int64_t bs, bm;
-        blocks(p, bs, bm);
+        int64_t bs, bm, ss, sm;
+        blocks(p, bs, bm, ss, sm);
         mc += counts[p];
         ms += bs;
         mm += bm;
+        mss += ss;
+        msm += sm;
     }
     seg_c[tid] = mc;
     seg_s[tid] = ms;
     seg_m[tid] = mm;
+    seg_ss[tid] = mss;
+    seg_sm[tid] = msm;
     __syncthreads();
     if (tid == 0) {
-        int64_t rc = 0, rs = 0, rm = 0;
+        int64_t rc = 0, rs = 0, rm = 0, rss = 0, rsm = 0;
         for (int t = 0; t < 1024; t++) {
-            const int64_t c = seg_c[t], s = seg_s[t], m = seg_m[t];
+            const int64_t c = seg_c[t], s = seg_s[t], m = seg_m[t], a = seg_ss[t], b = seg_sm[t];
             seg_c[t] = rc;
             seg_s[t] = rs;
             seg_m[t] = rm;
+            seg_ss[t] = rss;
+            seg_sm[t] = rsm;
             rc += c;
             rs += s;
             rm += m;
+            rss += a;
+            rsm += b;
         }
         fb_sample[parts] = rs;
         fb_main[parts] = rm;
+        fb_sample_small[parts] = rss;
+        fb_main_small[parts] = rsm;
     }
     __syncthreads();
-    int64_t rc = seg_c[tid], rs = seg_s[tid], rm = seg_m[tid];
+    int64_t rc = seg_c[tid], rs = seg_s[tid], rm = seg_m[tid], rss = seg_ss[tid], rsm = seg_sm[tid];
     for (int p = pb; p < pe; p++) {
-        int64_t bs, bm;
-        blocks(p, bs, bm);
+        int64_t bs, bm, ss, sm;
+        blocks(p, bs, bm, ss, sm);
         GemmGroup g;
         g.a_off = rc;
         g.b_off = part_off[p];
@@ -367,9 +383,13 @@ __global__ __launch_bounds__(1024) void probe_bucket_scan_kernel(const uint32_t 
         cursor[p] = static_cast<uint32_t>(rc);
         fb_sample[p] = rs;
         fb_main[p] = rm;
+        fb_sample_small[p] = rss;
+        fb_main_small[p] = rsm;
         rc += counts[p];
         rs += bs;
         rm += bm;
+        rss += ss;
+        rsm += sm;
     }
 }
 
@@ -583,14 +603,14 @@ static int32_t flat_probed_impl(vg_index *idx, const float *queries, int64_t nq,
     const int i_one = ar.add(paged ? 256 : 0);
     const int i_tables = ar.add(sizeof(float) * static_cast<size_t>(nq) * lut_words);
     const int i_whole = ar.add(whole ? sizeof(uint32_t) * (static_cast<size_t>(parts) + 1) : 0);
-    // fp32, unfiltered, partitions probed by 24 or more queries each on average: nomination + proof on the matrix cores (2c)
-    // (1M x 768 in 122 partitions, 1024 queries, ms per call, exact kernels -> this: nprobes 2 (17 per partition) 2.0 -> 2.5,
-    // 4: 3.75 -> 2.35, 8: 7.25 -> 2.64, 16: 11.6 -> 4.4, 32: 20.9 -> 7.0; tools/probe_time.py)
+    // fp32, unfiltered, partitions probed by 12 or more queries each on average: nomination + proof on the matrix cores (2c)
+    // (1M x 768 in 122 partitions, 1024 queries, ms per call, exact kernels -> this: nprobes 1 (8 per partition) 1.21 -> 1.18,
+    // 2: 2.1 -> 1.4, 4: 3.75 -> 1.3, 8: 7.25 -> 2.3, 16: 11.6 -> 4.5, 32: 21.0 -> 7.0; tools/probe_time.py)
     const bool gemm = scan == VG_SCAN_F32 && !mk.ptr && !whole && k <= 48 && idx->dim % 4 == 0 && pairs <= 65535 &&
-                      pairs >= 24 * static_cast<int64_t>(parts) && (reinterpret_cast<uintptr_t>(idx->d_vectors) & 15) == 0 &&
+                      pairs >= 12 * static_cast<int64_t>(parts) && (reinterpret_cast<uintptr_t>(idx->d_vectors) & 15) == 0 &&
                       (reinterpret_cast<uintptr_t>(q.ptr) & 15) == 0 && static_cast<int>(idx->h_part_off.size()) == parts + 1 &&
                       !vg::hook(vg::kHookProbeNoGroup) && !vg::hook(vg::kHookProbeNoGemm);
-    int64_t grid_sample = 0, grid_main = 0, ns_max = 0;
+    int64_t grids[4] = {0, 0, 0, 0}, ns_max = 0;  // sample / main of the 128-query tiles, sample / main of the 64-query tiles
     if (gemm) {  // launch bounds from the partition sizes: one query tile per partition + the batch's further tiles on the largest
         int64_t sum_s = 0, sum_m = 0, max_s = 0, max_m = 0;
         for (int p = 0; p < parts; p++) {
@@ -601,10 +621,12 @@ static int32_t flat_probed_impl(vg_index *idx, const float *queries, int64_t nq,
             sum_m += bm;
             max_s = std::max(max_s, bs);
             max_m = std::max(max_m, bm);
+            grids[2] += nst;
+            grids[3] += nt;
             ns_max = std::max(ns_max, nst * vg::kGemmBN);
         }
-        grid_sample = sum_s + (pairs / vg::kGemmBM) * max_s;
-        grid_main = sum_m + (pairs / vg::kGemmBM) * max_m;
+        grids[0] = sum_s + (pairs / vg::kGemmBM) * max_s;
+        grids[1] = sum_m + (pairs / vg::kGemmBM) * max_m;
     }
     const size_t gw = gemm ? static_cast<size_t>(parts) + 1 : 0;
     const int i_bcnt = ar.add(sizeof(uint32_t) * gw);
@@ -612,6 +634,8 @@ static int32_t flat_probed_impl(vg_index *idx, const float *queries, int64_t nq,
     const int i_bgrp = ar.add(sizeof(vg::GemmGroup) * gw);
     const int i_fbs = ar.add(sizeof(int64_t) * gw);
     const int i_fbm = ar.add(sizeof(int64_t) * gw);
+    const int i_fbss = ar.add(sizeof(int64_t) * gw);
+    const int i_fbsm = ar.add(sizeof(int64_t) * gw);
     const int i_bpair = ar.add(gemm ? sizeof(uint32_t) * static_cast<size_t>(pairs) : 0);
     const int i_pairq = ar.add(gemm ? sizeof(float) * static_cast<size_t>(pairs) * idx->dim : 0);
     const int i_pids = ar.add(gemm ? sizeof(uint32_t) * static_cast<size_t>(pairs) * k : 0);
@@ -650,7 +674,7 @@ static int32_t flat_probed_impl(vg_index *idx, const float *queries, int64_t nq,
     if (gemm) {
         uint32_t *bcnt = ar.get<uint32_t>(i_bcnt), *bcur = ar.get<uint32_t>(i_bcur), *bpair = ar.get<uint32_t>(i_bpair);
         vg::GemmGroup *bgrp = ar.get<vg::GemmGroup>(i_bgrp);
-        int64_t *fbs = ar.get<int64_t>(i_fbs), *fbm = ar.get<int64_t>(i_fbm);
+        int64_t *fbs = ar.get<int64_t>(i_fbs), *fbm = ar.get<int64_t>(i_fbm), *fbss = ar.get<int64_t>(i_fbss), *fbsm = ar.get<int64_t>(i_fbsm);
         float *pairq = ar.get<float>(i_pairq), *pair_sc = ar.get<float>(i_pscore);
         uint32_t *pair_ids = ar.get<uint32_t>(i_pids);
         int *pfail = ar.get<int>(i_pfail), *qfail = ar.get<int>(i_qfail);
@@ -658,13 +682,14 @@ static int32_t flat_probed_impl(vg_index *idx, const float *queries, int64_t nq,
         VG_HIP(hipMemsetAsync(bcnt, 0, sizeof(uint32_t) * (static_cast<size_t>(parts) + 1), st));
         VG_HIP(hipMemsetAsync(qfail, 0, sizeof(int) * static_cast<size_t>(nq), st));
         VG_LAUNCH(vg::probe_bucket_count_kernel, dim3(pb), dim3(256), 0, st, probes, pairs, bcnt);
-        VG_LAUNCH(vg::probe_bucket_scan_kernel, dim3(1), dim3(1024), 0, st, bcnt, part_off, parts, bcur, bgrp, fbs, fbm);
+        VG_LAUNCH(vg::probe_bucket_scan_kernel, dim3(1), dim3(1024), 0, st, bcnt, part_off, parts, bcur, bgrp, fbs, fbm, fbss, fbsm);
         VG_LAUNCH(vg::probe_bucket_fill_kernel, dim3(pb), dim3(256), 0, st, probes, pairs, bcur, bpair);
         VG_LAUNCH(vg::probe_gather_queries_kernel, dim3(static_cast<unsigned>(pairs)), dim3(256), 0, st, q.ptr, bpair, np, idx->dim, pairq);
         {
             vg::ProfScope prof(idx->ctx, "flat_probe", st);
-            VG_TRY(vg::flat_probe_gemm(idx, pairq, pairs, bgrp, fbs, fbm, parts, grid_sample, grid_main, vg::kProbeSampleStride, ns_max, k,
-                                       pair_ids, pair_sc, pfail, ar.get<char>(i_gscr), st));
+            const int64_t *const fb[4] = {fbs, fbm, fbss, fbsm};
+            VG_TRY(vg::flat_probe_gemm(idx, pairq, pairs, bgrp, fb, parts, grids, vg::kProbeSampleStride, ns_max, k, pair_ids, pair_sc,
+                                       pfail, ar.get<char>(i_gscr), st));
         }
         // lists = np * sub in this configuration; the pairs' k results fill the first np lists' worth of `partial`
         VG_LAUNCH(vg::probe_pack_kernel, dim3(static_cast<unsigned>(pairs)), dim3(64), 0, st, bpair, pair_ids, pair_sc, pfail, k, np, desc,

@@ -531,19 +531,19 @@ constexpr size_t g32_lds_bytes() { return 2 * (RB * kG32BM * kGemmBK + kDmaTile)
 
 // BF16: as in flat_gemm_dma_kernel (rows of bfloat16, `dim` in 4-byte words) — the pass is HBM-bound, so half the bytes
 // per row is half the time.
-template <bool DOT, int MODE, int RB, bool BF16 = false>
-__global__ __launch_bounds__(kGemmThreads) void flat_gemm_dma32_kernel(
+// (body / kernel / grouped kernel as for flat_gemm_dma_kernel: tn = the workgroup's row tile within its problem, row_base as there)
+template <bool DOT, int MODE, int RB, bool BF16, bool GROUPED>
+__device__ __forceinline__ void flat_gemm_dma32_body(
     const float *__restrict__ queries, int64_t nq, const float *__restrict__ base, int64_t n,
     int dim, const float *__restrict__ norms, float *__restrict__ scores, int tile_stride,
     int64_t out_cols, const float *__restrict__ thr, int thr_stride, int thr_off,
-    int *__restrict__ counts, uint64_t *__restrict__ cand, int cap, const uint8_t *__restrict__ mask = nullptr,
-    int64_t mask_stride = 0)
+    int *__restrict__ counts, uint64_t *__restrict__ cand, int cap, const uint8_t *__restrict__ mask,
+    int64_t mask_stride, int64_t tn, uint32_t row_base)
 {
     extern __shared__ float gemm_lds[];
     constexpr int kATile = RB * kG32BM * kGemmBK;  // floats
     const int64_t ntiles = MODE == 1 ? (((n + kGemmBN - 1) / kGemmBN) + tile_stride - 1) / tile_stride
                                      : (n + kGemmBN - 1) / kGemmBN;
-    const int64_t tn = blockIdx.x;
     if (tn >= ntiles) return;
     const int64_t n0 = (MODE == 1 ? tn * tile_stride : tn) * kGemmBN;
 
@@ -684,11 +684,51 @@ __global__ __launch_bounds__(kGemmThreads) void flat_gemm_dma32_kernel(
                 const float t = (r & 3) == 0 ? tv.x : (r & 3) == 1 ? tv.y : (r & 3) == 2 ? tv.z : tv.w;
                 if (nn < n && sc < t && (mask == nullptr || mask_bit(mask + ql * mask_stride, nn))) {
                     const int pos = atomicAdd(&counts[ql], 1);
-                    if (pos < cap) cand[static_cast<int64_t>(ql) * cap + pos] = make_key(sc, static_cast<uint32_t>(nn), false);
+                    if (pos < cap)
+                        cand[static_cast<int64_t>(ql) * cap + pos] = make_key(sc, static_cast<uint32_t>(nn) + (GROUPED ? row_base : 0u), false);
                 }
             }
         }
     }
+}
+
+template <bool DOT, int MODE, int RB, bool BF16 = false>
+__global__ __launch_bounds__(kGemmThreads) void flat_gemm_dma32_kernel(
+    const float *__restrict__ queries, int64_t nq, const float *__restrict__ base, int64_t n,
+    int dim, const float *__restrict__ norms, float *__restrict__ scores, int tile_stride,
+    int64_t out_cols, const float *__restrict__ thr, int thr_stride, int thr_off,
+    int *__restrict__ counts, uint64_t *__restrict__ cand, int cap, const uint8_t *__restrict__ mask = nullptr,
+    int64_t mask_stride = 0)
+{
+    flat_gemm_dma32_body<DOT, MODE, RB, BF16, false>(queries, nq, base, n, dim, norms, scores, tile_stride, out_cols, thr, thr_stride,
+                                                      thr_off, counts, cand, cap, mask, mask_stride, blockIdx.x, 0u);
+}
+
+// the grouped form for groups of at most RB * 32 query rows (one workgroup per row tile of the group; first_block as above)
+template <bool DOT, int MODE, int RB>
+__global__ __launch_bounds__(kGemmThreads) void flat_gemm_dma32_grouped_kernel(
+    const GemmGroup *__restrict__ groups, const int64_t *__restrict__ first_block, int ngroups,
+    const float *__restrict__ queries, const float *__restrict__ base, int dim, const float *__restrict__ norms,
+    float *__restrict__ scores, int tile_stride, int64_t out_cols, const float *__restrict__ thr, int thr_stride, int thr_off,
+    int *__restrict__ counts, uint64_t *__restrict__ cand, int cap)
+{
+    const int64_t b = blockIdx.x;
+    if (b >= first_block[ngroups]) return;
+    int lo = 0, hi = ngroups - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (first_block[mid] <= b)
+            lo = mid;
+        else
+            hi = mid - 1;
+    }
+    const GemmGroup g = groups[lo];
+    if (g.a_cnt == 0 || g.b_cnt == 0) return;
+    flat_gemm_dma32_body<DOT, MODE, RB, false, true>(
+        queries + g.a_off * dim, g.a_cnt, base + g.b_off * dim, g.b_cnt, dim, norms + g.b_off,
+        scores ? scores + g.a_off * out_cols : nullptr, tile_stride, out_cols, thr ? thr + g.a_off * thr_stride : nullptr, thr_stride,
+        thr_off, counts ? counts + g.a_off : nullptr, cand ? cand + g.a_off * cap : nullptr, cap, nullptr, 0, b - first_block[lo],
+        static_cast<uint32_t>(g.b_off));
 }
 
 }  // namespace vg
