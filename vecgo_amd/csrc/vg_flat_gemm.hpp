@@ -65,12 +65,13 @@ __device__ __forceinline__ void gemm_epilogue(const f32x16 (&acc)[2][2], float *
                 } else if (MODE == 1) {
                     // (a row the query's filter rejects is not in the sample: the threshold is a quantile of the rows it wants)
                     if (qq < nq)
-                        scores[qq * out_cols + tn * kGemmBN + col] = nn < n && mask_bit(mask ? mask + qq * mask_stride : nullptr, nn) ? sc : INFINITY;
+                        scores[qq * out_cols + tn * kGemmBN + col] =
+                            nn < n && mask_bit(mask ? mask + qq * mask_stride : nullptr, nn + row_base) ? sc : INFINITY;
                 } else {
                     const float4 tv = t4[i][r >> 2];
                     const float t = (r & 3) == 0 ? tv.x : (r & 3) == 1 ? tv.y : (r & 3) == 2 ? tv.z : tv.w;
                     // the filter bit is looked at only for the few elements below the threshold
-                    if (nn < n && sc < t && (mask == nullptr || mask_bit(mask + qq * mask_stride, nn))) {
+                    if (nn < n && sc < t && (mask == nullptr || mask_bit(mask + qq * mask_stride, nn + row_base))) {
                         const int pos = atomicAdd(&counts[qq], 1);
                         if (pos < cap) cand[qq * cap + pos] = make_key(sc, static_cast<uint32_t>(nn) + row_base, false);
                     }
@@ -497,7 +498,8 @@ __global__ __launch_bounds__(kGemmThreads) void flat_gemm_dma_grouped_kernel(
     const GemmGroup *__restrict__ groups, const int64_t *__restrict__ first_block, int ngroups,
     const float *__restrict__ queries, const float *__restrict__ base, int dim, const float *__restrict__ norms,
     float *__restrict__ scores, int tile_stride, int64_t out_cols, const float *__restrict__ thr, int thr_stride, int thr_off,
-    int *__restrict__ counts, uint64_t *__restrict__ cand, int cap)
+    int *__restrict__ counts, uint64_t *__restrict__ cand, int cap, const uint8_t *__restrict__ mask /* one row filter for every
+    pair (bit per GLOBAL row), or nullptr */)
 {
     const int64_t b = blockIdx.x;
     if (b >= first_block[ngroups]) return;
@@ -514,7 +516,7 @@ __global__ __launch_bounds__(kGemmThreads) void flat_gemm_dma_grouped_kernel(
     flat_gemm_dma_body<DOT, MODE, 0, false, true>(
         queries + g.a_off * dim, g.a_cnt, base + g.b_off * dim, g.b_cnt, dim, norms + g.b_off,
         scores ? scores + g.a_off * out_cols : nullptr, tile_stride, out_cols, thr ? thr + g.a_off * thr_stride : nullptr, thr_stride,
-        thr_off, counts ? counts + g.a_off : nullptr, cand ? cand + g.a_off * cap : nullptr, cap, nullptr, 0, b - first_block[lo],
+        thr_off, counts ? counts + g.a_off : nullptr, cand ? cand + g.a_off * cap : nullptr, cap, mask, 0, b - first_block[lo],
         static_cast<uint32_t>(g.b_off));
 }
 
@@ -678,11 +680,11 @@ __device__ __forceinline__ void flat_gemm_dma32_body(
             if (MODE == 1) {
                 if (ql < nq)
                     scores[static_cast<int64_t>(ql) * out_cols + tn * kGemmBN + col] =
-                        nn < n && mask_bit(mask ? mask + ql * mask_stride : nullptr, nn) ? sc : INFINITY;
+                        nn < n && mask_bit(mask ? mask + ql * mask_stride : nullptr, nn + (GROUPED ? row_base : 0u)) ? sc : INFINITY;
             } else {
                 const float4 tv = t4[i][r >> 2];
                 const float t = (r & 3) == 0 ? tv.x : (r & 3) == 1 ? tv.y : (r & 3) == 2 ? tv.z : tv.w;
-                if (nn < n && sc < t && (mask == nullptr || mask_bit(mask + ql * mask_stride, nn))) {
+                if (nn < n && sc < t && (mask == nullptr || mask_bit(mask + ql * mask_stride, nn + (GROUPED ? row_base : 0u)))) {
                     const int pos = atomicAdd(&counts[ql], 1);
                     if (pos < cap)
                         cand[static_cast<int64_t>(ql) * cap + pos] = make_key(sc, static_cast<uint32_t>(nn) + (GROUPED ? row_base : 0u), false);
@@ -710,7 +712,7 @@ __global__ __launch_bounds__(kGemmThreads) void flat_gemm_dma32_grouped_kernel(
     const GemmGroup *__restrict__ groups, const int64_t *__restrict__ first_block, int ngroups,
     const float *__restrict__ queries, const float *__restrict__ base, int dim, const float *__restrict__ norms,
     float *__restrict__ scores, int tile_stride, int64_t out_cols, const float *__restrict__ thr, int thr_stride, int thr_off,
-    int *__restrict__ counts, uint64_t *__restrict__ cand, int cap)
+    int *__restrict__ counts, uint64_t *__restrict__ cand, int cap, const uint8_t *__restrict__ mask)
 {
     const int64_t b = blockIdx.x;
     if (b >= first_block[ngroups]) return;
@@ -727,7 +729,7 @@ __global__ __launch_bounds__(kGemmThreads) void flat_gemm_dma32_grouped_kernel(
     flat_gemm_dma32_body<DOT, MODE, RB, false, true>(
         queries + g.a_off * dim, g.a_cnt, base + g.b_off * dim, g.b_cnt, dim, norms + g.b_off,
         scores ? scores + g.a_off * out_cols : nullptr, tile_stride, out_cols, thr ? thr + g.a_off * thr_stride : nullptr, thr_stride,
-        thr_off, counts ? counts + g.a_off : nullptr, cand ? cand + g.a_off * cap : nullptr, cap, nullptr, 0, b - first_block[lo],
+        thr_off, counts ? counts + g.a_off : nullptr, cand ? cand + g.a_off * cap : nullptr, cap, mask, 0, b - first_block[lo],
         static_cast<uint32_t>(g.b_off));
 }
 
