@@ -162,11 +162,16 @@ struct AdcShared {
 // queries the blocks of an XCD share a slice through L2 and the loads stay plain.
 // MASKED (SMALLK only): the filtered search of k_probe.hip — a row the query's filter rejects offers no key; desc: a Dot /
 // Cosine segment keeps the LARGEST lookups (flat/segment.go:449).  A template flag: the unfiltered scans stay as they were.
-template <int GF, bool SMALLK, bool ONCE, bool MASKED = false>
+// PROBED (SMALLK only): the partition-probed scan (flat/segment.go:727-744) — workgroup (query q, share s of `slices`) walks the
+// tile ranges of probes s, s + slices, ... of its query with the same pipelined loop, rows outside a partition's range masked
+// (partition bounds are not tile-aligned); min_keys: paged results.  (r05 ran these through a plain gather loop: 2x the time.)
+template <int GF, bool SMALLK, bool ONCE, bool MASKED = false, bool PROBED = false>
 __global__ __launch_bounds__(kAdcThreads) void pq_adc_scan_kernel(
     const uint4 *__restrict__ tiles, int64_t n_rows, int64_t n_tiles, int m, int groups,
     const float *__restrict__ tables, int slices, int nq, int k, uint64_t *__restrict__ partial,
-    int raw_lists, const int *__restrict__ only_if, const uint8_t *__restrict__ mask, int64_t mask_stride, bool desc)
+    int raw_lists, const int *__restrict__ only_if, const uint8_t *__restrict__ mask, int64_t mask_stride, bool desc,
+    const uint32_t *__restrict__ probes = nullptr, const uint32_t *__restrict__ part_off = nullptr, int np = 0,
+    const uint64_t *__restrict__ min_keys = nullptr)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float *lut = reinterpret_cast<float *>(smem);
@@ -181,12 +186,13 @@ __global__ __launch_bounds__(kAdcThreads) void pq_adc_scan_kernel(
     const int b = blockIdx.x;
     const int xcd = b & 7;
     const int o = b >> 3;
-    const int q = o % nq;
-    const int s = (o / nq) * 8 + xcd;
+    const int q = PROBED ? b / slices : o % nq;
+    const int s = PROBED ? b % slices : (o / nq) * 8 + xcd;
     if (only_if && !only_if[q]) return;  // fallback launch: only the flagged queries run
-    const int64_t t0 = n_tiles * s / slices;
-    const int64_t t1 = n_tiles * (s + 1) / slices;
-    const uint8_t *mq = MASKED && mask ? mask + q * mask_stride : nullptr;
+    int64_t t0 = n_tiles * s / slices;
+    int64_t t1 = n_tiles * (s + 1) / slices;
+    int64_t R0 = 0, R1 = n_rows;  // PROBED: the probed partition's rows
+    const uint8_t *mq = MASKED && mask ? mask + static_cast<int64_t>(q) * mask_stride : nullptr;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -227,7 +233,15 @@ __global__ __launch_bounds__(kAdcThreads) void pq_adc_scan_kernel(
     // the workgroups — trip `it` of workgroup s, wave w is tile (it * slices + s) * waves + w — so that at any
     // moment the whole chip streams ONE moving window of the code array instead of `slices` distant ones (DRAM
     // pages stay open, the stream runs at the rate of a plain sequential read).
-    constexpr bool kDealt = ONCE && VG_ADC_DEAL;
+    constexpr bool kDealt = ONCE && VG_ADC_DEAL && !PROBED;
+    for (int jr = PROBED ? s : 0; jr < (PROBED ? np : 1); jr += PROBED ? slices : 1) {
+    if (PROBED) {
+        const uint32_t pp = probes[static_cast<int64_t>(q) * np + jr];
+        R0 = part_off[pp];
+        R1 = part_off[pp + 1];
+        t0 = R0 >> 6;
+        t1 = (R1 + 63) >> 6;
+    }
     const int64_t tstride = kDealt ? static_cast<int64_t>(slices) * kAdcWaves : kAdcWaves;
     const int64_t tbase = kDealt ? static_cast<int64_t>(s) * kAdcWaves : t0;
     const int64_t tend = kDealt ? n_tiles : t1;
@@ -345,8 +359,14 @@ __global__ __launch_bounds__(kAdcThreads) void pq_adc_scan_kernel(
                     total = total + lut[lut_tail_word + l * 256 + code_byte(c, l)];
             }
             const int64_t row = tile * 64 + lane;
-            uint64_t key = MASKED ? ((row < n_rows && mask_bit(mq, row)) ? make_key(total, static_cast<uint32_t>(row), desc) : kKeyMax)
-                                  : ((row < n_rows) ? make_key(total, static_cast<uint32_t>(row), false) : kKeyMax);
+            uint64_t key;
+            if constexpr (MASKED || PROBED) {
+                const bool live = row < n_rows && (!PROBED || (row >= R0 && row < R1)) && (!MASKED || mask_bit(mq, row));
+                key = live ? make_key(total, static_cast<uint32_t>(row), desc) : kKeyMax;
+                if (PROBED && min_keys && key <= min_keys[q]) key = kKeyMax;  // paged results (k > 64)
+            } else {
+                key = (row < n_rows) ? make_key(total, static_cast<uint32_t>(row), false) : kKeyMax;
+            }
             if (SMALLK) {
                 wtk.offer(key, lane);
             } else if (key < tau) {
@@ -375,6 +395,7 @@ __global__ __launch_bounds__(kAdcThreads) void pq_adc_scan_kernel(
             tau = sh->tau;
         }
     }
+    }  // probed ranges
     if (SMALLK && raw_lists) {
         partial[((static_cast<int64_t>(q) * slices + s) * kAdcWaves + wave) * 64 + lane] = wtk.list;
         return;
@@ -702,6 +723,28 @@ int32_t launch_probe_scan_adc(const vg_index *idx, const float *tables, const ui
                               const uint8_t *mask, int64_t mask_stride, hipStream_t st)
 {
     const vg_pq *pq = idx->pq;
+    // a table that fits LDS next to the scan kernel's buffers, k <= 64: the pipelined scan kernel over the probed ranges
+    const size_t scan_lds = static_cast<size_t>(lut_image_words(pq->m)) * sizeof(float) + kAdcBuf * sizeof(uint64_t) + sizeof(AdcShared);
+    if (k <= 64 && scan_lds <= 160 * 1024 && !hook(kHookProbeNoGroup)) {
+        auto pick = [&](auto masked_tag) {
+            constexpr bool M = decltype(masked_tag)::value;
+            return pq->m == 96 ? pq_adc_scan_kernel<6, true, false, M, true> : pq_adc_scan_kernel<-1, true, false, M, true>;
+        };
+        auto kern = mask ? pick(std::true_type{}) : pick(std::false_type{});
+        VG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   static_cast<int>(scan_lds)));
+        const int64_t max_q = (int64_t(1) << 30) / split;
+        for (int64_t q0 = 0; q0 < nq; q0 += max_q) {
+            const int64_t cnt = nq - q0 < max_q ? nq - q0 : max_q;
+            ProfScope prof(idx->ctx, "pq_adc_probe", st);
+            VG_LAUNCH(kern, dim3(static_cast<unsigned>(cnt * split)), dim3(kAdcThreads), scan_lds, st,
+                      reinterpret_cast<const uint4 *>(idx->d_pq_tiles), idx->n, idx->n_tiles, pq->m, idx->pq_groups,
+                      tables + q0 * lut_image_words(pq->m), split, static_cast<int>(cnt), k, partial + q0 * split * k, 0, nullptr,
+                      mask ? mask + q0 * mask_stride : nullptr, mask_stride, desc, probes + q0 * np, part_off, np,
+                      min_keys ? min_keys + q0 : nullptr);
+        }
+        return VG_OK;
+    }
     const size_t lds = static_cast<size_t>(lut_image_words(pq->m)) * sizeof(float) + kAdcWaves * 64 * sizeof(uint64_t) + 64;
     VG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(pq_adc_probe_kernel),
                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
@@ -754,7 +797,9 @@ static int32_t launch_scan(const vg_index *idx, const float *tables, int64_t nq,
                            idx->n_tiles, pq->m, idx->pq_groups,
                            tables + q0 * lut_image_words(pq->m), slices, static_cast<int>(cnt), k,
                            partial + q0 * slices * (raw_lists ? kAdcWaves * 64 : k), raw_lists,
-                           only_if ? only_if + q0 : nullptr, mask ? mask + q0 * mask_stride : nullptr, mask_stride, desc);
+                           only_if ? only_if + q0 : nullptr, mask ? mask + q0 * mask_stride : nullptr, mask_stride, desc,
+                           static_cast<const uint32_t *>(nullptr), static_cast<const uint32_t *>(nullptr), 0,
+                           static_cast<const uint64_t *>(nullptr));
     }
     return VG_OK;
 }
