@@ -605,7 +605,7 @@ static int32_t flat_probed_impl(vg_index *idx, const float *queries, int64_t nq,
     const int i_whole = ar.add(whole ? sizeof(uint32_t) * (static_cast<size_t>(parts) + 1) : 0);
     // fp32, unfiltered, partitions probed by 12 or more queries each on average: nomination + proof on the matrix cores (2c)
     // (1M x 768 in 122 partitions, 1024 queries, ms per call, exact kernels -> this: nprobes 1 (8 per partition) 1.21 -> 1.18,
-    // 2: 2.1 -> 1.4, 4: 3.75 -> 1.3, 8: 7.25 -> 2.3, 16: 11.6 -> 4.5, 32: 21.0 -> 7.0; tools/probe_time.py)
+    // 2: 2.1 -> 1.4, 4: 3.75 -> 1.3, 8: 7.25 -> 2.3, 16: 11.6 -> 4.5, 32: 21.0 -> 7.0; tools/probe_gemm_time.py)
     // (a filtered batch too when it carries ONE filter: the grouped kernels index a pair's rows, not its query)
     const bool gemm = scan == VG_SCAN_F32 && (!mk.ptr || mask_stride == 0) && !whole && k <= 48 && idx->dim % 4 == 0 && pairs <= 65535 &&
                       pairs >= 12 * static_cast<int64_t>(parts) && (reinterpret_cast<uintptr_t>(idx->d_vectors) & 15) == 0 &&
