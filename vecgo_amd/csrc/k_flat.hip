@@ -905,8 +905,8 @@ size_t flat_probe_gemm_scratch_bytes(int64_t pairs, int64_t ns_max) { return pro
 
 int32_t flat_probe_gemm(vg_index *idx, const float *pair_queries, int64_t pairs, const GemmGroup *groups, const int64_t *const first_block[4],
                         int ngroups, const int64_t grid[4], int sample_stride, int64_t ns_max, int k, uint32_t *pair_ids,
-                        float *pair_scores, int *fail, char *scratch, const uint8_t *mask /* one row filter for the batch, or null */,
-                        hipStream_t st)
+                        float *pair_scores, int *fail, char *scratch, const uint8_t *mask /* the batch's row filters, or null */,
+                        const int64_t *mask_off /* [pairs]: byte offset of each bucketed pair's filter in `mask` */, hipStream_t st)
 {
     // first_block / grid: [0] sample, [1] main launch of the 128-query tiles (groups of more than 64 pairs); [2], [3] the same of
     // the 64-query tiles (flat_gemm_dma32_grouped_kernel<.., 2>: a group of at most 64 pairs is one query tile, one workgroup per
@@ -931,13 +931,13 @@ int32_t flat_probe_gemm(vg_index *idx, const float *pair_queries, int64_t pairs,
                                    static_cast<int>(kDmaLdsBytes)));
         if (grid[0])
             VG_LAUNCH(kern, dim3(static_cast<unsigned>(grid[0])), dim3(kGemmThreads), kDmaLdsBytes, st, groups, first_block[0], ngroups,
-                      pair_queries, idx->d_vectors, dim, idx->d_norms, sc, sample_stride, ns_max, nullptr, 0, 0, nullptr, nullptr, 0, mask);
+                      pair_queries, idx->d_vectors, dim, idx->d_norms, sc, sample_stride, ns_max, nullptr, 0, 0, nullptr, nullptr, 0, mask, mask_off);
         auto kern32 = dot ? flat_gemm_dma32_grouped_kernel<true, 1, 2> : flat_gemm_dma32_grouped_kernel<false, 1, 2>;
         VG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern32), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    static_cast<int>(g32_lds_bytes<2>())));
         if (grid[2])
             VG_LAUNCH(kern32, dim3(static_cast<unsigned>(grid[2])), dim3(kGemmThreads), g32_lds_bytes<2>(), st, groups, first_block[2], ngroups,
-                      pair_queries, idx->d_vectors, dim, idx->d_norms, sc, sample_stride, ns_max, nullptr, 0, 0, nullptr, nullptr, 0, mask);
+                      pair_queries, idx->d_vectors, dim, idx->d_norms, sc, sample_stride, ns_max, nullptr, 0, 0, nullptr, nullptr, 0, mask, mask_off);
     }
     VG_LAUNCH(flat_select_kernel, dim3(sel_slices, upairs), dim3(kSelThreads), 0, st, sc, ns_max, sel_slices, sel_k, partial);
     VG_TRY(launch_topk_merge(partial, pairs, sel_slices, sel_k, false, sid, thr, st));
@@ -950,13 +950,13 @@ int32_t flat_probe_gemm(vg_index *idx, const float *pair_queries, int64_t pairs,
                                    static_cast<int>(kDmaLdsBytes)));
         if (grid[1])
             VG_LAUNCH(kern, dim3(static_cast<unsigned>(grid[1])), dim3(kGemmThreads), kDmaLdsBytes, st, groups, first_block[1], ngroups,
-                      pair_queries, idx->d_vectors, dim, idx->d_norms, nullptr, 1, 0, thr, sel_k, sel_k - 1, counts, cand, cap, mask);
+                      pair_queries, idx->d_vectors, dim, idx->d_norms, nullptr, 1, 0, thr, sel_k, sel_k - 1, counts, cand, cap, mask, mask_off);
         auto kern32 = dot ? flat_gemm_dma32_grouped_kernel<true, 2, 2> : flat_gemm_dma32_grouped_kernel<false, 2, 2>;
         VG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern32), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    static_cast<int>(g32_lds_bytes<2>())));
         if (grid[3])
             VG_LAUNCH(kern32, dim3(static_cast<unsigned>(grid[3])), dim3(kGemmThreads), g32_lds_bytes<2>(), st, groups, first_block[3], ngroups,
-                      pair_queries, idx->d_vectors, dim, idx->d_norms, nullptr, 1, 0, thr, sel_k, sel_k - 1, counts, cand, cap, mask);
+                      pair_queries, idx->d_vectors, dim, idx->d_norms, nullptr, 1, 0, thr, sel_k, sel_k - 1, counts, cand, cap, mask, mask_off);
     }
     // (c) the kc best of them, (d) re-scored exactly, the k best, and the proof against everything not nominated
     VG_LAUNCH(flat_pick_kernel, dim3(upairs), dim3(256), 0, st, cand, counts, cap, kc, cand_id, cand_sc);

@@ -38,7 +38,7 @@ int32_t pq_adc_search_masked(vg_index *idx, const float *queries, int64_t nq, in
 size_t flat_probe_gemm_scratch_bytes(int64_t pairs, int64_t ns_max);
 int32_t flat_probe_gemm(vg_index *idx, const float *pair_queries, int64_t pairs, const GemmGroup *groups, const int64_t *const first_block[4],
                         int ngroups, const int64_t grid[4], int sample_stride, int64_t ns_max, int k, uint32_t *pair_ids,
-                        float *pair_scores, int *fail, char *scratch, const uint8_t *mask, hipStream_t st);
+                        float *pair_scores, int *fail, char *scratch, const uint8_t *mask, const int64_t *mask_off, hipStream_t st);
 int32_t launch_page_patch(int64_t nq, int k, int off, int kk, bool descending, const int *always_one,
                           const uint32_t *fids, const float *fscores, uint32_t *ids, float *scores, uint64_t *min_keys,
                           hipStream_t st);
@@ -402,9 +402,11 @@ __global__ __launch_bounds__(256) void probe_bucket_fill_kernel(const uint32_t *
 
 // row `pos` of the pair matrix = the query of the pos-th bucketed pair (dim % 4 == 0, 16-byte aligned)
 __global__ __launch_bounds__(256) void probe_gather_queries_kernel(const float *__restrict__ queries, const uint32_t *__restrict__ pair_of,
-                                                                   int np, int dim, float *__restrict__ out)
+                                                                   int np, int dim, float *__restrict__ out, int64_t mask_stride,
+                                                                   int64_t *__restrict__ mask_off)
 {
     const int64_t pos = blockIdx.x;
+    if (threadIdx.x == 0) mask_off[pos] = static_cast<int64_t>(pair_of[pos] / np) * mask_stride;  // the pair's query's filter
     const float4 *src = reinterpret_cast<const float4 *>(queries + static_cast<int64_t>(pair_of[pos] / np) * dim);
     float4 *dst = reinterpret_cast<float4 *>(out + pos * dim);
     for (int t = threadIdx.x; t < dim / 4; t += 256) dst[t] = src[t];
@@ -606,8 +608,8 @@ static int32_t flat_probed_impl(vg_index *idx, const float *queries, int64_t nq,
     // fp32, unfiltered, partitions probed by 12 or more queries each on average: nomination + proof on the matrix cores (2c)
     // (1M x 768 in 122 partitions, 1024 queries, ms per call, exact kernels -> this: nprobes 1 (8 per partition) 1.21 -> 1.18,
     // 2: 2.1 -> 1.4, 4: 3.75 -> 1.3, 8: 7.25 -> 2.3, 16: 11.6 -> 4.5, 32: 21.0 -> 7.0; tools/probe_gemm_time.py)
-    // (a filtered batch too when it carries ONE filter: the grouped kernels index a pair's rows, not its query)
-    const bool gemm = scan == VG_SCAN_F32 && (!mk.ptr || mask_stride == 0) && !whole && k <= 48 && idx->dim % 4 == 0 && pairs <= 65535 &&
+    // (a filtered batch too: a pair's filter is its query's — probe_gather_queries_kernel notes where each starts)
+    const bool gemm = scan == VG_SCAN_F32 && !whole && k <= 48 && idx->dim % 4 == 0 && pairs <= 65535 &&
                       pairs >= 12 * static_cast<int64_t>(parts) && (reinterpret_cast<uintptr_t>(idx->d_vectors) & 15) == 0 &&
                       (reinterpret_cast<uintptr_t>(q.ptr) & 15) == 0 && static_cast<int>(idx->h_part_off.size()) == parts + 1 &&
                       !vg::hook(vg::kHookProbeNoGroup) && !vg::hook(vg::kHookProbeNoGemm);
@@ -643,6 +645,7 @@ static int32_t flat_probed_impl(vg_index *idx, const float *queries, int64_t nq,
     const int i_pscore = ar.add(gemm ? sizeof(float) * static_cast<size_t>(pairs) * k : 0);
     const int i_pfail = ar.add(gemm ? sizeof(int) * static_cast<size_t>(pairs) : 0);
     const int i_qfail = ar.add(gemm ? sizeof(int) * static_cast<size_t>(nq) : 0);
+    const int i_moff = ar.add(gemm ? sizeof(int64_t) * static_cast<size_t>(pairs) : 0);
     const int i_gscr = ar.add(gemm ? vg::flat_probe_gemm_scratch_bytes(pairs, ns_max) : 0);
     VG_TRY(ar.commit());
     uint32_t *probes = ar.get<uint32_t>(i_probes);
@@ -685,12 +688,14 @@ static int32_t flat_probed_impl(vg_index *idx, const float *queries, int64_t nq,
         VG_LAUNCH(vg::probe_bucket_count_kernel, dim3(pb), dim3(256), 0, st, probes, pairs, bcnt);
         VG_LAUNCH(vg::probe_bucket_scan_kernel, dim3(1), dim3(1024), 0, st, bcnt, part_off, parts, bcur, bgrp, fbs, fbm, fbss, fbsm);
         VG_LAUNCH(vg::probe_bucket_fill_kernel, dim3(pb), dim3(256), 0, st, probes, pairs, bcur, bpair);
-        VG_LAUNCH(vg::probe_gather_queries_kernel, dim3(static_cast<unsigned>(pairs)), dim3(256), 0, st, q.ptr, bpair, np, idx->dim, pairq);
+        int64_t *moff = ar.get<int64_t>(i_moff);
+        VG_LAUNCH(vg::probe_gather_queries_kernel, dim3(static_cast<unsigned>(pairs)), dim3(256), 0, st, q.ptr, bpair, np, idx->dim, pairq,
+                  mask_stride, moff);
         {
             vg::ProfScope prof(idx->ctx, "flat_probe", st);
             const int64_t *const fb[4] = {fbs, fbm, fbss, fbsm};
             VG_TRY(vg::flat_probe_gemm(idx, pairq, pairs, bgrp, fb, parts, grids, vg::kProbeSampleStride, ns_max, k, pair_ids, pair_sc,
-                                       pfail, ar.get<char>(i_gscr), mk.ptr, st));
+                                       pfail, ar.get<char>(i_gscr), mk.ptr, moff, st));
         }
         // lists = np * sub in this configuration; the pairs' k results fill the first np lists' worth of `partial`
         VG_LAUNCH(vg::probe_pack_kernel, dim3(static_cast<unsigned>(pairs)), dim3(64), 0, st, bpair, pair_ids, pair_sc, pfail, k, np, desc,
@@ -704,7 +709,7 @@ static int32_t flat_probed_impl(vg_index *idx, const float *queries, int64_t nq,
             auto kern = mk.ptr ? (dot ? vg::probe_scan_f32_kernel<true, true> : vg::probe_scan_f32_kernel<false, true>)
                                : (dot ? vg::probe_scan_f32_kernel<true, false> : vg::probe_scan_f32_kernel<false, false>);
             VG_LAUNCH(kern, grid, dim3(256), 0, st, idx->d_vectors, idx->dim, q.ptr + q0 * idx->dim, probes + q0 * np, part_off, np, sub, k,
-                      partial + q0 * lists * k, nullptr, mk.ptr, int64_t(0), qfail + q0);
+                      partial + q0 * lists * k, nullptr, mk.ptr ? mk.ptr + q0 * mask_stride : nullptr, mask_stride, qfail + q0);
         }
         VG_TRY(vg::launch_topk_merge(partial, nq, lists, k, desc, oid.ptr, osc.ptr, st, qfail));
         VG_TRY(oid.finish());

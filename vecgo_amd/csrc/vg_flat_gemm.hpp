@@ -36,8 +36,11 @@ __device__ __forceinline__ void gemm_epilogue(const f32x16 (&acc)[2][2], float *
                                               int64_t nq, int64_t n0, int64_t n, int64_t tn,
                                               float *__restrict__ scores, int64_t out_cols,
                                               int *__restrict__ counts, uint64_t *__restrict__ cand, int cap,
-                                              const uint8_t *__restrict__ mask, int64_t mask_stride, uint32_t row_base = 0)
+                                              const uint8_t *__restrict__ mask, int64_t mask_stride, uint32_t row_base = 0,
+                                              const int64_t *__restrict__ mask_off = nullptr /* grouped: byte offset of query
+                                              row qq's filter in `mask` (a pair's query), instead of qq * mask_stride */)
 {
+    auto filter_of = [&](int64_t qq) { return mask_off ? mask + mask_off[qq] : mask + qq * mask_stride; };
     float4 t4[2][4];  // thresholds of rows i*32 + 8*g + 4*(lane>>5) + 0..3
     if (MODE == 2) {
         if (tid < kGemmBM) lds_thr[tid] = thr_reg;
@@ -66,12 +69,12 @@ __device__ __forceinline__ void gemm_epilogue(const f32x16 (&acc)[2][2], float *
                     // (a row the query's filter rejects is not in the sample: the threshold is a quantile of the rows it wants)
                     if (qq < nq)
                         scores[qq * out_cols + tn * kGemmBN + col] =
-                            nn < n && mask_bit(mask ? mask + qq * mask_stride : nullptr, nn + row_base) ? sc : INFINITY;
+                            nn < n && (mask == nullptr || mask_bit(filter_of(qq), nn + row_base)) ? sc : INFINITY;
                 } else {
                     const float4 tv = t4[i][r >> 2];
                     const float t = (r & 3) == 0 ? tv.x : (r & 3) == 1 ? tv.y : (r & 3) == 2 ? tv.z : tv.w;
                     // the filter bit is looked at only for the few elements below the threshold
-                    if (nn < n && sc < t && (mask == nullptr || mask_bit(mask + qq * mask_stride, nn + row_base))) {
+                    if (nn < n && sc < t && (mask == nullptr || mask_bit(filter_of(qq), nn + row_base))) {
                         const int pos = atomicAdd(&counts[qq], 1);
                         if (pos < cap) cand[qq * cap + pos] = make_key(sc, static_cast<uint32_t>(nn) + row_base, false);
                     }
@@ -322,7 +325,7 @@ __device__ __forceinline__ void flat_gemm_dma_body(
     int dim, const float *__restrict__ norms, float *__restrict__ scores, int tile_stride,
     int64_t out_cols, const float *__restrict__ thr, int thr_stride, int thr_off,
     int *__restrict__ counts, uint64_t *__restrict__ cand, int cap, const uint8_t *__restrict__ mask,
-    int64_t mask_stride, int64_t bt, uint32_t row_base)
+    int64_t mask_stride, int64_t bt, uint32_t row_base, const int64_t *__restrict__ mask_off = nullptr)
 {
     extern __shared__ float gemm_lds[];
     const int mtiles = static_cast<int>((nq + kGemmBM - 1) / kGemmBM);
@@ -469,7 +472,7 @@ __device__ __forceinline__ void flat_gemm_dma_body(
         return;
     }
     gemm_epilogue<DOT, MODE>(acc, gemm_lds, thr_reg, xn, tid, lane, wr, wc, q0, nq, n0, n, tn, scores, out_cols,
-                             counts, cand, cap, mask, mask_stride, GROUPED ? row_base : 0u);
+                             counts, cand, cap, mask, mask_stride, GROUPED ? row_base : 0u, GROUPED ? mask_off : nullptr);
 }
 
 template <bool DOT, int MODE, int PROBE = 0, bool BF16 = false>
@@ -498,8 +501,8 @@ __global__ __launch_bounds__(kGemmThreads) void flat_gemm_dma_grouped_kernel(
     const GemmGroup *__restrict__ groups, const int64_t *__restrict__ first_block, int ngroups,
     const float *__restrict__ queries, const float *__restrict__ base, int dim, const float *__restrict__ norms,
     float *__restrict__ scores, int tile_stride, int64_t out_cols, const float *__restrict__ thr, int thr_stride, int thr_off,
-    int *__restrict__ counts, uint64_t *__restrict__ cand, int cap, const uint8_t *__restrict__ mask /* one row filter for every
-    pair (bit per GLOBAL row), or nullptr */)
+    int *__restrict__ counts, uint64_t *__restrict__ cand, int cap, const uint8_t *__restrict__ mask /* row filters (bit per
+    GLOBAL row), or nullptr */, const int64_t *__restrict__ mask_off /* [pairs]: where pair i's filter starts in `mask` */)
 {
     const int64_t b = blockIdx.x;
     if (b >= first_block[ngroups]) return;
@@ -517,7 +520,7 @@ __global__ __launch_bounds__(kGemmThreads) void flat_gemm_dma_grouped_kernel(
         queries + g.a_off * dim, g.a_cnt, base + g.b_off * dim, g.b_cnt, dim, norms + g.b_off,
         scores ? scores + g.a_off * out_cols : nullptr, tile_stride, out_cols, thr ? thr + g.a_off * thr_stride : nullptr, thr_stride,
         thr_off, counts ? counts + g.a_off : nullptr, cand ? cand + g.a_off * cap : nullptr, cap, mask, 0, b - first_block[lo],
-        static_cast<uint32_t>(g.b_off));
+        static_cast<uint32_t>(g.b_off), mask ? mask_off + g.a_off : nullptr);
 }
 
 // ---- 5..64 queries: the same pipeline with a 32 x 128 or 64 x 128 tile ------------------------------
@@ -540,8 +543,9 @@ __device__ __forceinline__ void flat_gemm_dma32_body(
     int dim, const float *__restrict__ norms, float *__restrict__ scores, int tile_stride,
     int64_t out_cols, const float *__restrict__ thr, int thr_stride, int thr_off,
     int *__restrict__ counts, uint64_t *__restrict__ cand, int cap, const uint8_t *__restrict__ mask,
-    int64_t mask_stride, int64_t tn, uint32_t row_base)
+    int64_t mask_stride, int64_t tn, uint32_t row_base, const int64_t *__restrict__ mask_off = nullptr)
 {
+    auto filter_of = [&](int ql) { return GROUPED && mask_off ? mask + mask_off[ql] : mask + ql * mask_stride; };
     extern __shared__ float gemm_lds[];
     constexpr int kATile = RB * kG32BM * kGemmBK;  // floats
     const int64_t ntiles = MODE == 1 ? (((n + kGemmBN - 1) / kGemmBN) + tile_stride - 1) / tile_stride
@@ -680,11 +684,11 @@ __device__ __forceinline__ void flat_gemm_dma32_body(
             if (MODE == 1) {
                 if (ql < nq)
                     scores[static_cast<int64_t>(ql) * out_cols + tn * kGemmBN + col] =
-                        nn < n && mask_bit(mask ? mask + ql * mask_stride : nullptr, nn + (GROUPED ? row_base : 0u)) ? sc : INFINITY;
+                        nn < n && (mask == nullptr || mask_bit(filter_of(ql), nn + (GROUPED ? row_base : 0u))) ? sc : INFINITY;
             } else {
                 const float4 tv = t4[i][r >> 2];
                 const float t = (r & 3) == 0 ? tv.x : (r & 3) == 1 ? tv.y : (r & 3) == 2 ? tv.z : tv.w;
-                if (nn < n && sc < t && (mask == nullptr || mask_bit(mask + ql * mask_stride, nn + (GROUPED ? row_base : 0u)))) {
+                if (nn < n && sc < t && (mask == nullptr || mask_bit(filter_of(ql), nn + (GROUPED ? row_base : 0u)))) {
                     const int pos = atomicAdd(&counts[ql], 1);
                     if (pos < cap)
                         cand[static_cast<int64_t>(ql) * cap + pos] = make_key(sc, static_cast<uint32_t>(nn) + (GROUPED ? row_base : 0u), false);
@@ -712,7 +716,8 @@ __global__ __launch_bounds__(kGemmThreads) void flat_gemm_dma32_grouped_kernel(
     const GemmGroup *__restrict__ groups, const int64_t *__restrict__ first_block, int ngroups,
     const float *__restrict__ queries, const float *__restrict__ base, int dim, const float *__restrict__ norms,
     float *__restrict__ scores, int tile_stride, int64_t out_cols, const float *__restrict__ thr, int thr_stride, int thr_off,
-    int *__restrict__ counts, uint64_t *__restrict__ cand, int cap, const uint8_t *__restrict__ mask)
+    int *__restrict__ counts, uint64_t *__restrict__ cand, int cap, const uint8_t *__restrict__ mask,
+    const int64_t *__restrict__ mask_off)
 {
     const int64_t b = blockIdx.x;
     if (b >= first_block[ngroups]) return;
@@ -730,7 +735,7 @@ __global__ __launch_bounds__(kGemmThreads) void flat_gemm_dma32_grouped_kernel(
         queries + g.a_off * dim, g.a_cnt, base + g.b_off * dim, g.b_cnt, dim, norms + g.b_off,
         scores ? scores + g.a_off * out_cols : nullptr, tile_stride, out_cols, thr ? thr + g.a_off * thr_stride : nullptr, thr_stride,
         thr_off, counts ? counts + g.a_off : nullptr, cand ? cand + g.a_off * cap : nullptr, cap, mask, 0, b - first_block[lo],
-        static_cast<uint32_t>(g.b_off));
+        static_cast<uint32_t>(g.b_off), mask ? mask_off + g.a_off : nullptr);
 }
 
 }  // namespace vg
