@@ -874,6 +874,9 @@ int32_t vg::flat_search_masked(vg_index *idx, const float *queries, int64_t nq, 
 // = its partition's k best rows by (score, row id) with exact scores, and fail[pair] = 1 where the proof does not hold (the caller
 // answers those queries with the exact probe kernels).  k <= kGemmMaxK; fp32 rows, dim % 4 == 0, 16-byte aligned.
 namespace vg {
+// candidate keys per pair: ~64 rows fall below a pair's threshold (8th best of 1/8 of its partition); 2048 leaves 30x, and a
+// batch of 65535 pairs holds 1 GiB of them (4096, the flat search's, would be 2)
+constexpr int kProbeGemmCap = 2048;
 // (scratch: one piece of the caller's arena — the caller holds the arena for the call — carved here; the layout in one place)
 struct ProbeGemmLayout {
     size_t sc, partial, sid, thr, counts, cand, cid, csc, total;
@@ -881,7 +884,7 @@ struct ProbeGemmLayout {
 };
 static ProbeGemmLayout probe_gemm_layout(int64_t pairs, int64_t ns_max)
 {
-    constexpr int kc = 64, cap = 4096, sel_k = 8;
+    constexpr int kc = 64, cap = kProbeGemmCap, sel_k = 8;
     ProbeGemmLayout l;
     l.sel_slices = static_cast<int>(std::min<int64_t>(8, std::max<int64_t>(1, ns_max / 1024)));
     size_t at = 0;
@@ -913,7 +916,7 @@ int32_t flat_probe_gemm(vg_index *idx, const float *pair_queries, int64_t pairs,
     // row tile, HBM-bound — a 128-query tile would spend the matrix cores on padding)
     const bool dot = idx->metric != VG_METRIC_L2;
     const int dim = idx->dim;
-    const int kc = 64, cap = 4096, sel_k = 8;
+    const int kc = 64, cap = kProbeGemmCap, sel_k = 8;
     const ProbeGemmLayout l = probe_gemm_layout(pairs, ns_max);
     const int sel_slices = l.sel_slices;
     float *sc = reinterpret_cast<float *>(scratch + l.sc), *thr = reinterpret_cast<float *>(scratch + l.thr);
