@@ -1051,6 +1051,25 @@ def build_side_legs(vg, ctx, rows, queries, stream, with_cpu, rows_host=None):
         row.update(cpu_qps=checked / (time.perf_counter() - t0), cpu_cores=1, cpu_kind="port", compared=checked, bits_equal=bool(same))
     out["flat_filtered"] = row
     del fm
+
+    # ---- flat.Segment.Search, SQ8 branch, 1024 queries: the multi-query scan (every code decoded once per 4 queries, vector-ALU
+    # bound) and the opt-in bf16 nomination (vg_index_enable_sq8_nomination) + exact re-score from the codes + proof
+    sq = vg.ScalarQuantizer(ctx, DIM)
+    sq.train(rows[:200000])
+    idx.set_sq8_codes(sq, sq.encode(rows))
+    pr, wall_scan, r_scan = prof(("sq8_scan",), lambda: idx.search_sq8(qb, K, stream=stream), reps=1)
+    idx.enable_sq8_nomination(True)
+    pr, wall_nom, r_nom = prof(("sq8_nominate_gemm",), lambda: idx.search_sq8(qb, K, stream=stream), reps=3)
+    lg, tg = pr["sq8_nominate_gemm"]
+    g_ms = tg / max(lg, 1)
+    tf = 2.0 * nqf * n * DIM / (g_ms * 1e-3) / 1e12
+    out["sq8_batch"] = {"workload": f"flat.Segment.Search SQ8 branch, {nqf} queries x {n} x {DIM}, top-{K} (flat/segment.go:517-604): bf16 nomination "
+                                    "over the dequantised rows + L2Distance of the 64 nominated rows from the codes + proof",
+                        "kernel": "flat_gemm_dma_kernel<false,2,0,true> (bf16) + sq8_verify_kernel", "kernel_ms": g_ms, "bound": "mfma",
+                        "achieved": tf, "peak": PEAK_MFMA_BF16_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_MFMA_BF16_TFLOPS, "call_ms": wall_nom,
+                        "queries_per_s": nqf / (wall_nom * 1e-3), "scan_call_ms": wall_scan, "scan_queries_per_s": nqf / (wall_scan * 1e-3),
+                        "bits_equal": bool(torch.equal(r_scan[0], r_nom[0]) and torch.equal(r_scan[1].view(torch.int32), r_nom[1].view(torch.int32))),
+                        "compared": nqf, "short": f"sq8_batch_{nqf}q_{n}x{DIM}_top{K}"}
     idx.close()
     pq.close()
     return out
@@ -1421,7 +1440,8 @@ def compact_line(full: dict) -> dict:
                           ("pq_encode", "a12 pq.Encode"), ("pq_build_table", "a13 pq.BuildDistanceTable"),
                           ("rerank", "f1 Segment.Rerank"), ("brute_q1", "a17 hnsw.BruteSearch, 1 query"),
                           ("brute_q256", "a17 hnsw.BruteSearch, 256 queries"),
-                          ("flat_filtered", "beyond s8: flat.Segment.Search with a filter, 1024 queries")):
+                          ("flat_filtered", "beyond s8: flat.Segment.Search with a filter, 1024 queries"),
+                          ("sq8_batch", "f3 sq8 batch, 1024 queries (bf16 nomination)")):
             e = bs.get(key)
             if isinstance(e, dict):
                 row(name, {**e, "workload": e.get("short", e.get("workload"))}, bound=e.get("bound"),

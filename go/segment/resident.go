@@ -191,6 +191,16 @@ func (r *Resident) SearchSQ8(queries []float32, nq, k int) ([]uint32, []float32,
 	return ids, sc, hipctx.Err(int32(st))
 }
 
+// EnableSQ8Nomination: batches of SearchSQ8 are nominated by a bfloat16 MFMA GEMM over the dequantised rows (+ rows*dim*2 bytes of
+// device memory) and re-scored exactly from the codes; results unchanged.
+func (r *Resident) EnableSQ8Nomination(on bool) error {
+	v := C.int32_t(0)
+	if on {
+		v = 1
+	}
+	return hipctx.Err(int32(C.vg_index_enable_sq8_nomination(r.h, v, nil)))
+}
+
 // SearchRaBitQ: exhaustive scan of the RaBitQ codes (rq.Distance per row).
 func (r *Resident) SearchRaBitQ(queries []float32, nq, k int) ([]uint32, []float32, error) {
 	ids, sc := r.out(nq, k)

@@ -53,8 +53,9 @@ extern "C" {
  *   5: (r05) vg_search_vamana_filtered
  *   6: (r05) vg_search_hnsw_predicate, vg_index_set_hnsw_edge_distances; vg_search_hnsw_filtered serves every selectivity
  *   7: (r05) vg_index_set_hnsw_tombstones
- *   8: (r05) vg_segment_search_filtered */
-#define VG_ABI_MINOR 8
+ *   8: (r05) vg_segment_search_filtered
+ *   9: (r05) vg_index_enable_sq8_nomination */
+#define VG_ABI_MINOR 9
 #define VG_INVALID_ID 0xFFFFFFFFu
 #define VG_STREAM_LEGACY ((void *)1) /* == hipStreamLegacy */
 
@@ -417,6 +418,13 @@ int32_t vg_index_set_sq8_codes(vg_index *idx, vg_sq8 *sq, const uint8_t *codes, 
  * (flat/segment.go:517-604), Dot / Cosine segments with ScalarQuantizer.DotProduct (:659-667,
  * quantizer.go:109-119: a sequential fp32 loop, largest first); best k by (Score, RowID).  k <= 512
  * (beyond 64 results the scan runs once per page of 64, each page after the previous one's last key). */
+/* Optional bfloat16 NOMINATION for batches of vg_search_sq8 (no reference counterpart; the results stay the reference's).
+ * on != 0: keeps the dequantised rows rounded to bfloat16 (rows * dim * 2 bytes: twice the codes) and their norms.  A batch
+ * of 16 or more queries on an L2 index (k <= 48, dim % 64 == 0) is then nominated by the bf16 MFMA GEMM of the flat search,
+ * its 64 best rows per query re-scored with L2Distance from the CODES, and a bound on the nomination's error proves no other
+ * row can enter the k best; a query whose proof fails is scanned as before.  Other shapes keep the scan.  Dropped by
+ * vg_index_set_sq8_codes.  (VG_ABI_MINOR 9.) */
+int32_t vg_index_enable_sq8_nomination(vg_index *idx, int32_t on, void *stream);
 int32_t vg_search_sq8(vg_index *idx, const float *queries, int64_t nq, int32_t k, uint32_t *ids,
                       float *scores, void *stream);
 

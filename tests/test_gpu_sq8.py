@@ -153,3 +153,33 @@ def test_sq8_scan_pages_beyond_64_results(vg, ctx, n, dim, nq, k, metric):
         assert np.array_equal(ids[i, :r], eid), (i, np.flatnonzero(ids[i, :r] != eid)[:5])
         assert np.array_equal(bits(sc[i, :r]), bits(esc))
         assert np.all(ids[i, r:] == 0xFFFFFFFF)
+
+
+@pytest.mark.parametrize("n,dim,nq,k", [(20000, 128, 40, 10), (9000, 768, 24, 10), (30000, 64, 130, 48), (3000, 64, 20, 5)])
+def test_batches_through_the_bf16_nomination(vg, ctx, n, dim, nq, k):
+    """vg_index_enable_sq8_nomination: 16 queries up, an L2 batch is nominated by the bfloat16 GEMM over the dequantised rows, its
+    64 best re-scored from the CODES (the reference's L2Distance), the rest excluded by a proof — same ids and score bits as the
+    scan and as the oracle; duplicate codes (ties) and clustered rows included; small batches and Dot keep the scan."""
+    rng = np.random.default_rng(n + dim)
+    cent = rng.standard_normal((30, dim)).astype(np.float32) * 2
+    x = (cent[rng.integers(0, 30, n)] + rng.standard_normal((n, dim)).astype(np.float32) * 0.5).astype(np.float32)
+    x[100:110] = x[100]
+    sq = vg.ScalarQuantizer(ctx, dim); sq.train(x)
+    ref = o.ScalarQuantizer(dim); ref.train(x)
+    codes = sq.encode(x)
+    idx = vg.Index(ctx, n, dim)
+    idx.set_sq8_codes(sq, codes)
+    q = (cent[rng.integers(0, 30, nq)] + rng.standard_normal((nq, dim)).astype(np.float32) * 0.5).astype(np.float32)
+    q[1] = x[100]
+    plain = idx.search_sq8(q, k)
+    idx.enable_sq8_nomination(True)
+    got = idx.search_sq8(q, k)
+    assert np.array_equal(plain[0], got[0]) and np.array_equal(bits(plain[1]), bits(got[1]))
+    for i in (0, 1, nq // 2, nq - 1):
+        eid, esc = o.flat_search_sq8(ref, codes, q[i], k)
+        assert np.array_equal(got[0][i, :eid.size], eid) and np.array_equal(bits(got[1][i, :eid.size]), bits(esc))
+    few = idx.search_sq8(q[:3], k)                     # below 16 queries: the scan
+    assert np.array_equal(few[0], plain[0][:3])
+    idx.enable_sq8_nomination(False)
+    again = idx.search_sq8(q, k)
+    assert np.array_equal(again[0], plain[0])

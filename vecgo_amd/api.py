@@ -958,6 +958,12 @@ class Index:
                             extra=(C.c_int32(nprobes), C.c_int32(scan), pm, C.c_int64(stride)),
                             out=out, stream=stream)
 
+    def enable_sq8_nomination(self, on: bool = True, stream=None):
+        """vg_index_enable_sq8_nomination: batches of search_sq8 (L2, 16 queries up, k <= 48, dim % 64 == 0) are nominated by a
+        bfloat16 MFMA GEMM over the dequantised rows (+ n * dim * 2 bytes), re-scored exactly from the codes and proven: ids and
+        scores stay bit-identical."""
+        check(self._lib.vg_index_enable_sq8_nomination(self._h, C.c_int32(1 if on else 0), _stream_ptr(stream)))
+
     def search_sq8(self, queries, k, out=None, stream=None):
         """flat.Segment.Search SQ8 branch (flat/segment.go:517-604)."""
         return self._search(self._lib.vg_search_sq8, queries, k, out=out, stream=stream)

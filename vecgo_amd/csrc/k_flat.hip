@@ -973,6 +973,72 @@ int32_t flat_probe_gemm(vg_index *idx, const float *pair_queries, int64_t pairs,
 }
 }  // namespace vg
 
+// The nomination stage of the fused flat search over ANY bfloat16 row image with its norms: thresholds from a row sample, the
+// bf16 MFMA GEMM appending what falls below them, the kc best per query — for a caller that re-scores and proves with its own
+// exact distance (the SQ8 batch search, k_sq8.hip: rows = the dequantised codes rounded to bfloat16, norms = |x^|^2).  L2 scores.
+// queries: cnt x dim fp32 (device, 16-byte aligned), dim % 64 == 0, cnt <= 4096.  Outputs (device, caller's):
+// thr[cnt * 8] (the threshold is entry 7 of a query's 8), counts[cnt], cand_id / cand_sc[cnt * 64] ascending.
+namespace vg {
+constexpr int kNomSelK = 8, kNomKc = 64, kNomCap = 4096, kNomStride = 64;
+struct NominateLayout {
+    size_t qbf, sc, partial, sid, cand, total;
+    int sel_slices;
+    int64_t ns;
+};
+static NominateLayout nominate_layout(int64_t cnt, int64_t n, int dim)
+{
+    NominateLayout l;
+    const int64_t nt = (n + kGemmBN - 1) / kGemmBN, nst = (nt + kNomStride - 1) / kNomStride;
+    l.ns = nst * kGemmBN;
+    l.sel_slices = static_cast<int>(std::min<int64_t>(64, std::max<int64_t>(1, l.ns / 4096)));
+    size_t at = 0;
+    auto piece = [&](size_t bytes) {
+        const size_t o = at;
+        at += (bytes + 255) & ~size_t(255);
+        return o;
+    };
+    l.qbf = piece(sizeof(uint16_t) * static_cast<size_t>(cnt) * dim);
+    l.sc = piece(sizeof(float) * static_cast<size_t>(cnt) * l.ns);
+    l.partial = piece(sizeof(uint64_t) * static_cast<size_t>(cnt) * l.sel_slices * kNomSelK);
+    l.sid = piece(sizeof(uint32_t) * static_cast<size_t>(cnt) * kNomSelK);
+    l.cand = piece(sizeof(uint64_t) * static_cast<size_t>(cnt) * kNomCap);
+    l.total = at;
+    return l;
+}
+size_t flat_nominate_bf16_scratch(int64_t cnt, int64_t n, int dim) { return nominate_layout(cnt, n, dim).total; }
+
+int32_t flat_nominate_bf16(vg_ctx *ctx, const uint16_t *rows_bf16, const float *norms, int64_t n, int dim, const float *queries,
+                           int64_t cnt, char *scratch, float *thr, int *counts, uint32_t *cand_id, float *cand_sc, hipStream_t st)
+{
+    const NominateLayout l = nominate_layout(cnt, n, dim);
+    uint16_t *qbf = reinterpret_cast<uint16_t *>(scratch + l.qbf);
+    float *sc = reinterpret_cast<float *>(scratch + l.sc);
+    uint64_t *partial = reinterpret_cast<uint64_t *>(scratch + l.partial), *cand = reinterpret_cast<uint64_t *>(scratch + l.cand);
+    uint32_t *sid = reinterpret_cast<uint32_t *>(scratch + l.sid);
+    const int64_t mt = (cnt + kGemmBM - 1) / kGemmBM, nt = (n + kGemmBN - 1) / kGemmBN, nst = l.ns / kGemmBN;
+    VG_LAUNCH(f32_to_bf16_kernel, dim3(static_cast<unsigned>((cnt * dim + 255) / 256)), dim3(256), 0, st, queries, cnt * dim, qbf);
+    const float *ga = reinterpret_cast<const float *>(qbf), *gb = reinterpret_cast<const float *>(rows_bf16);
+    const int gdim = dim / 2;
+    if (n > kNomCap) {
+        VG_TRY(launch_gemm<1>(false, true, static_cast<unsigned>(mt * ((nst + 7) / 8) * 8), st,
+                              {ga, cnt, gb, n, gdim, norms, sc, kNomStride, l.ns, nullptr, 0, 0, nullptr, nullptr, 0, nullptr, 0}, true));
+        VG_LAUNCH(flat_select_kernel, dim3(l.sel_slices, static_cast<unsigned>(cnt)), dim3(kSelThreads), 0, st, sc, l.ns, l.sel_slices,
+                  kNomSelK, partial);
+        VG_TRY(launch_topk_merge(partial, cnt, l.sel_slices, kNomSelK, false, sid, thr, st));
+    } else {
+        VG_LAUNCH(fill_f32_kernel, dim3(static_cast<unsigned>((cnt * kNomSelK + 255) / 256)), dim3(256), 0, st, thr, cnt * kNomSelK, INFINITY);
+    }
+    VG_HIP(hipMemsetAsync(counts, 0, sizeof(int) * static_cast<size_t>(cnt), st));
+    {
+        ProfScope prof(ctx, "sq8_nominate_gemm", st);
+        VG_TRY(launch_gemm<2>(false, true, static_cast<unsigned>(mt * ((nt + 7) / 8) * 8), st,
+                              {ga, cnt, gb, n, gdim, norms, nullptr, 1, 0, thr, kNomSelK, kNomSelK - 1, counts, cand, kNomCap, nullptr, 0}, true));
+    }
+    VG_LAUNCH(flat_pick_kernel, dim3(static_cast<unsigned>(cnt)), dim3(256), 0, st, cand, counts, kNomCap, kNomKc, cand_id, cand_sc);
+    return VG_OK;
+}
+}  // namespace vg
+
 VG_API int32_t vg_index_enable_bf16_filter(vg_index *idx, int32_t on, void *stream)
 {
     VG_CHECK(idx, VG_ERR_INVALID_ARG, "vg_index_enable_bf16_filter: NULL index");

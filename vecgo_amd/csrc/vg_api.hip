@@ -291,6 +291,9 @@ VG_API int32_t vg_index_destroy(vg_index *idx)
     if (idx->d_pq_rows) (void)hipFree(idx->d_pq_rows);
     if (idx->d_rq_rows) (void)hipFree(idx->d_rq_rows);
     if (idx->d_sq_tiles) (void)hipFree(idx->d_sq_tiles);
+    if (idx->d_sq_bf16) (void)hipFree(idx->d_sq_bf16);
+    if (idx->d_sq_norms) (void)hipFree(idx->d_sq_norms);
+    if (idx->d_sq_norm_max) (void)hipFree(idx->d_sq_norm_max);
     if (idx->d_int4_rows) (void)hipFree(idx->d_int4_rows);
     if (idx->d_centroids) (void)hipFree(idx->d_centroids);
     if (idx->d_part_off) (void)hipFree(idx->d_part_off);
