@@ -183,3 +183,38 @@ def test_batches_through_the_bf16_nomination(vg, ctx, n, dim, nq, k):
     idx.enable_sq8_nomination(False)
     again = idx.search_sq8(q, k)
     assert np.array_equal(again[0], plain[0])
+
+
+@pytest.mark.parametrize("metric", [0, 2])
+def test_nomination_with_dot_metric_and_filters(vg, ctx, metric):
+    """the same for a Dot segment (DotProduct, the largest first) and for filtered batches over the whole segment (one filter for
+    the batch, one per query, filters that leave fewer than k rows): nomination on = nomination off = the oracle"""
+    rng = np.random.default_rng(90 + metric)
+    n, dim, nq, k = 16000, 128, 36, 10
+    cent = rng.standard_normal((20, dim)).astype(np.float32) * 2
+    x = (cent[rng.integers(0, 20, n)] + rng.standard_normal((n, dim)).astype(np.float32) * 0.6).astype(np.float32)
+    x[50:58] = x[50]
+    sq = vg.ScalarQuantizer(ctx, dim); sq.train(x)
+    ref = o.ScalarQuantizer(dim); ref.train(x)
+    codes = sq.encode(x)
+    idx = vg.Index(ctx, n, dim, vg.Metric(metric))
+    idx.set_sq8_codes(sq, codes)
+    seg = o.FlatSegment(x, dim, metric=metric, sq=ref, codes=codes)
+    q = (cent[rng.integers(0, 20, nq)] + rng.standard_normal((nq, dim)).astype(np.float32) * 0.6).astype(np.float32)
+    q[2] = x[50]
+    masks = rng.random((nq, n)) < 0.3
+    masks[4, :] = False
+    masks[4, rng.integers(0, n, 4)] = True            # four rows pass
+    masks[5, :] = False
+    off = (idx.search_sq8(q, k), idx.search_flat_filtered(q, k, masks, 0, scan=idx.SCAN_SQ8),
+           idx.search_flat_filtered(q, k, masks[0], 0, scan=idx.SCAN_SQ8))
+    idx.enable_sq8_nomination(True)
+    on = (idx.search_sq8(q, k), idx.search_flat_filtered(q, k, masks, 0, scan=idx.SCAN_SQ8),
+          idx.search_flat_filtered(q, k, masks[0], 0, scan=idx.SCAN_SQ8))
+    for a, b in zip(off, on):
+        assert np.array_equal(a[0], b[0]) and np.array_equal(bits(a[1]), bits(b[1]))
+    for i in (0, 2, 4, 5, nq - 1):
+        for got, m in ((on[0], None), (on[1], masks[i]), (on[2], masks[0])):
+            eid, esc = seg.search(q[i], k, mask=m)
+            assert np.array_equal(got[0][i, :eid.size], eid) and np.array_equal(bits(got[1][i, :eid.size]), bits(esc))
+            assert np.all(got[0][i, eid.size:] == 0xFFFFFFFF)

@@ -1008,8 +1008,11 @@ static NominateLayout nominate_layout(int64_t cnt, int64_t n, int dim)
 size_t flat_nominate_bf16_scratch(int64_t cnt, int64_t n, int dim) { return nominate_layout(cnt, n, dim).total; }
 
 int32_t flat_nominate_bf16(vg_ctx *ctx, const uint16_t *rows_bf16, const float *norms, int64_t n, int dim, const float *queries,
-                           int64_t cnt, char *scratch, float *thr, int *counts, uint32_t *cand_id, float *cand_sc, hipStream_t st)
+                           int64_t cnt, char *scratch, float *thr, int *counts, uint32_t *cand_id, float *cand_sc, hipStream_t st,
+                           bool dot, const uint8_t *mask, int64_t mask_stride)
 {
+    // dot: scores are -q.x (the largest dot products first); mask: a row filter per query (mask + q * mask_stride) or for the
+    // batch (stride 0) — rejected rows are left out of the sample and of the candidates, as in flat_search_masked
     const NominateLayout l = nominate_layout(cnt, n, dim);
     uint16_t *qbf = reinterpret_cast<uint16_t *>(scratch + l.qbf);
     float *sc = reinterpret_cast<float *>(scratch + l.sc);
@@ -1020,8 +1023,8 @@ int32_t flat_nominate_bf16(vg_ctx *ctx, const uint16_t *rows_bf16, const float *
     const float *ga = reinterpret_cast<const float *>(qbf), *gb = reinterpret_cast<const float *>(rows_bf16);
     const int gdim = dim / 2;
     if (n > kNomCap) {
-        VG_TRY(launch_gemm<1>(false, true, static_cast<unsigned>(mt * ((nst + 7) / 8) * 8), st,
-                              {ga, cnt, gb, n, gdim, norms, sc, kNomStride, l.ns, nullptr, 0, 0, nullptr, nullptr, 0, nullptr, 0}, true));
+        VG_TRY(launch_gemm<1>(dot, true, static_cast<unsigned>(mt * ((nst + 7) / 8) * 8), st,
+                              {ga, cnt, gb, n, gdim, norms, sc, kNomStride, l.ns, nullptr, 0, 0, nullptr, nullptr, 0, mask, mask_stride}, true));
         VG_LAUNCH(flat_select_kernel, dim3(l.sel_slices, static_cast<unsigned>(cnt)), dim3(kSelThreads), 0, st, sc, l.ns, l.sel_slices,
                   kNomSelK, partial);
         VG_TRY(launch_topk_merge(partial, cnt, l.sel_slices, kNomSelK, false, sid, thr, st));
@@ -1031,8 +1034,9 @@ int32_t flat_nominate_bf16(vg_ctx *ctx, const uint16_t *rows_bf16, const float *
     VG_HIP(hipMemsetAsync(counts, 0, sizeof(int) * static_cast<size_t>(cnt), st));
     {
         ProfScope prof(ctx, "sq8_nominate_gemm", st);
-        VG_TRY(launch_gemm<2>(false, true, static_cast<unsigned>(mt * ((nt + 7) / 8) * 8), st,
-                              {ga, cnt, gb, n, gdim, norms, nullptr, 1, 0, thr, kNomSelK, kNomSelK - 1, counts, cand, kNomCap, nullptr, 0}, true));
+        VG_TRY(launch_gemm<2>(dot, true, static_cast<unsigned>(mt * ((nt + 7) / 8) * 8), st,
+                              {ga, cnt, gb, n, gdim, norms, nullptr, 1, 0, thr, kNomSelK, kNomSelK - 1, counts, cand, kNomCap, mask, mask_stride},
+                              true));
     }
     VG_LAUNCH(flat_pick_kernel, dim3(static_cast<unsigned>(cnt)), dim3(256), 0, st, cand, counts, kNomCap, kNomKc, cand_id, cand_sc);
     return VG_OK;

@@ -39,6 +39,9 @@ size_t flat_probe_gemm_scratch_bytes(int64_t pairs, int64_t ns_max);
 int32_t flat_probe_gemm(vg_index *idx, const float *pair_queries, int64_t pairs, const GemmGroup *groups, const int64_t *const first_block[4],
                         int ngroups, const int64_t grid[4], int sample_stride, int64_t ns_max, int k, uint32_t *pair_ids,
                         float *pair_scores, int *fail, char *scratch, const uint8_t *mask, const int64_t *mask_off, hipStream_t st);
+bool sq8_nomination_applies(const vg_index *idx, const float *d_queries, int64_t nq, int k);
+int32_t sq8_nominated_pass(vg_index *idx, const float *q, int64_t nq, int k, const uint8_t *mask, int64_t mask_stride, uint32_t *oid,
+                           float *osc, hipStream_t st, std::vector<int> &failed);
 int32_t launch_page_patch(int64_t nq, int k, int off, int kk, bool descending, const int *always_one,
                           const uint32_t *fids, const float *fscores, uint32_t *ids, float *scores, uint64_t *min_keys,
                           hipStream_t st);
@@ -475,7 +478,8 @@ VG_API int32_t vg_index_set_partitions(vg_index *idx, const float *centroids, co
 }
 
 static int32_t flat_probed_impl(vg_index *idx, const float *queries, int64_t nq, int32_t k, int32_t nprobes, int32_t scan,
-                                const uint8_t *mask, int64_t mask_stride, uint32_t *ids, float *scores, void *stream);
+                                const uint8_t *mask, int64_t mask_stride, uint32_t *ids, float *scores, void *stream,
+                                bool allow_nomination = true);
 
 VG_API int32_t vg_search_flat_probed(vg_index *idx, const float *queries, int64_t nq, int32_t k, int32_t nprobes,
                                      int32_t scan, uint32_t *ids, float *scores, void *stream)
@@ -496,7 +500,8 @@ VG_API int32_t vg_search_flat_filtered(vg_index *idx, const float *queries, int6
 }
 
 static int32_t flat_probed_impl(vg_index *idx, const float *queries, int64_t nq, int32_t k, int32_t nprobes, int32_t scan,
-                                const uint8_t *mask, int64_t mask_stride, uint32_t *ids, float *scores, void *stream)
+                                const uint8_t *mask, int64_t mask_stride, uint32_t *ids, float *scores, void *stream,
+                                bool allow_nomination)
 {
     VG_CHECK(idx, VG_ERR_INVALID_ARG, "vg_search_flat_probed: NULL index");
     VG_CHECK(scan == VG_SCAN_F32 || scan == VG_SCAN_PQ || scan == VG_SCAN_SQ8, VG_ERR_INVALID_ARG,
@@ -546,6 +551,43 @@ static int32_t flat_probed_impl(vg_index *idx, const float *queries, int64_t nq,
     // (the test hook keeps the batch on the kernels below).
     if (whole && scan == VG_SCAN_F32 && mk.ptr && nq >= 8 && !vg::hook(vg::kHookProbeNoGroup)) {
         VG_TRY(vg::flat_search_masked(idx, q.ptr, nq, k, mk.ptr, mask_stride, oid.ptr, osc.ptr, stream));
+        VG_TRY(oid.finish());
+        VG_TRY(osc.finish());
+        if (oid.on_host() || osc.on_host()) VG_HIP(hipStreamSynchronize(st));
+        return VG_OK;
+    }
+
+    // A filtered SQ8 batch over the whole segment with vg_index_enable_sq8_nomination: the bf16 nomination with the filter in its
+    // epilogue, the exact re-score from the codes, the proof (k_sq8.hip); queries whose proof fails take the kernels below
+    if (whole && scan == VG_SCAN_SQ8 && mk.ptr && allow_nomination && vg::sq8_nomination_applies(idx, q.ptr, nq, k) &&
+        !vg::hook(vg::kHookProbeNoGroup)) {
+        std::vector<int> failed;
+        VG_TRY(vg::sq8_nominated_pass(idx, q.ptr, nq, k, mk.ptr, mask_stride, oid.ptr, osc.ptr, st, failed));
+        if (!failed.empty()) {
+            const int64_t nf = static_cast<int64_t>(failed.size());
+            vg::DevTmp<float> fq;
+            vg::DevTmp<uint32_t> fid;
+            vg::DevTmp<float> fsc;
+            vg::DevTmp<uint8_t> fm;
+            VG_TRY(fq.init(static_cast<size_t>(nf) * idx->dim, st));
+            VG_TRY(fid.init(static_cast<size_t>(nf) * k, st));
+            VG_TRY(fsc.init(static_cast<size_t>(nf) * k, st));
+            VG_TRY(fm.init(mask_stride ? static_cast<size_t>(nf) * mask_bytes : 0, st));
+            for (int64_t i = 0; i < nf; i++) {
+                const int64_t src = failed[static_cast<size_t>(i)];
+                VG_HIP(hipMemcpyAsync(fq.ptr + i * idx->dim, q.ptr + src * idx->dim, sizeof(float) * idx->dim, hipMemcpyDeviceToDevice, st));
+                if (mask_stride)
+                    VG_HIP(hipMemcpyAsync(fm.ptr + i * mask_bytes, mk.ptr + src * mask_stride, static_cast<size_t>(mask_bytes),
+                                          hipMemcpyDeviceToDevice, st));
+            }
+            VG_TRY(flat_probed_impl(idx, fq.ptr, nf, k, nprobes, scan, mask_stride ? fm.ptr : mk.ptr, mask_stride ? mask_bytes : 0, fid.ptr,
+                                    fsc.ptr, st, false));
+            for (int64_t i = 0; i < nf; i++) {
+                const int64_t at = static_cast<int64_t>(failed[static_cast<size_t>(i)]) * k;
+                VG_HIP(hipMemcpyAsync(oid.ptr + at, fid.ptr + i * k, sizeof(uint32_t) * k, hipMemcpyDeviceToDevice, st));
+                VG_HIP(hipMemcpyAsync(osc.ptr + at, fsc.ptr + i * k, sizeof(float) * k, hipMemcpyDeviceToDevice, st));
+            }
+        }
         VG_TRY(oid.finish());
         VG_TRY(osc.finish());
         if (oid.on_host() || osc.on_host()) VG_HIP(hipStreamSynchronize(st));

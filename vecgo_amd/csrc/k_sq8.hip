@@ -1537,7 +1537,8 @@ VG_API int32_t vg_sq8_l2_distance_batch(vg_sq8 *sq, const float *query, const ui
 namespace vg {
 size_t flat_nominate_bf16_scratch(int64_t cnt, int64_t n, int dim);
 int32_t flat_nominate_bf16(vg_ctx *ctx, const uint16_t *rows_bf16, const float *norms, int64_t n, int dim, const float *queries,
-                           int64_t cnt, char *scratch, float *thr, int *counts, uint32_t *cand_id, float *cand_sc, hipStream_t st);
+                           int64_t cnt, char *scratch, float *thr, int *counts, uint32_t *cand_id, float *cand_sc, hipStream_t st,
+                           bool dot, const uint8_t *mask, int64_t mask_stride);
 
 __device__ __forceinline__ uint16_t sq8_bf16_rne(float x)
 {
@@ -1589,7 +1590,8 @@ __global__ __launch_bounds__(64) void sq8_dequant_bf16_kernel(const uint4 *__res
     if (lane == 0) atomicMax(norm_max_bits, __float_as_int(mx));  // non-negative floats order like their bits
 }
 
-// per query: exact L2Distance of its 64 nominated rows from the codes, the k best by (score, row id), and the proof
+// per query: exact L2Distance / DotProduct of its 64 nominated rows from the codes, the k best by (score, row id), and the proof
+template <bool DOT>
 __global__ __launch_bounds__(64) void sq8_verify_kernel(const uint4 *__restrict__ tiles, int groups, int dim, const float *__restrict__ mins,
                                                         const float *__restrict__ inv, const float *__restrict__ queries,
                                                         const float *__restrict__ norm_max, const uint32_t *__restrict__ cand_ids,
@@ -1604,9 +1606,9 @@ __global__ __launch_bounds__(64) void sq8_verify_kernel(const uint4 *__restrict_
     const uint32_t id = cand_ids[q * kc + lane];
     uint64_t key = kKeyMax;
     if (id != VG_INVALID_ID) {
-        const float d = sq8_row_score<false>(tiles + (static_cast<int64_t>(id >> 6) * groups) * 64 + (id & 63), groups, dim >> 4, dim & 15,
-                                             qv, mins, inv);
-        key = make_key(d, id, false);
+        const float d = sq8_row_score<DOT>(tiles + (static_cast<int64_t>(id >> 6) * groups) * 64 + (id & 63), groups, dim >> 4, dim & 15,
+                                           qv, mins, inv);
+        key = make_key(d, id, DOT);
     }
     WaveTopK tk;
     tk.init(k);
@@ -1623,13 +1625,19 @@ __global__ __launch_bounds__(64) void sq8_verify_kernel(const uint4 *__restrict_
     if (ok && !have_all && tau != INFINITY) {
         // |s~ + |q|^2 - L2Distance|: bfloat16 rounding of q and x^ ((2^-7 + 2^-16)(|q|^2 + |x^|^2), as for the fp32 rows' bf16
         // filter), the GEMM's fp32 accumulation and the reference's own 16-lane sums ((2 dim + dim/8 + 32) u of the same)
-        const float eps = (4.0f * (static_cast<float>(dim) * 5.9604645e-8f) + 0.0078125f * 1.02f) * (qn + norm_max[0]) + 1e-30f;
-        ok = kth != kKeyMax && key_score(kth, false) < (tau + qn) - eps;
+        // (Dot: the score is -q.x^, half the L2 form's cross term: 2^-8 in place of 2^-7)
+        const float eps = (4.0f * (static_cast<float>(dim) * 5.9604645e-8f) + (DOT ? 0.00390625f : 0.0078125f) * 1.02f) * (qn + norm_max[0]) + 1e-30f;
+        if (kth == kKeyMax)
+            ok = false;
+        else if (DOT)
+            ok = key_score(kth, true) > (-tau) + eps;  // outside rows: -q.x >= tau
+        else
+            ok = key_score(kth, false) < (tau + qn) - eps;
     }
     if (lane < k) {
         const uint64_t e = tk.list;
         ids[q * k + lane] = e == kKeyMax ? VG_INVALID_ID : key_row(e);
-        scores[q * k + lane] = e == kKeyMax ? INFINITY : key_score(e, false);
+        scores[q * k + lane] = e == kKeyMax ? (DOT ? -INFINITY : INFINITY) : key_score(e, DOT);
     }
     if (lane == 0) fail[q] = ok ? 0 : 1;
 }
@@ -1650,7 +1658,7 @@ VG_API int32_t vg_index_enable_sq8_nomination(vg_index *idx, int32_t on, void *s
     }
     if (!on) return VG_OK;
     VG_CHECK(idx->sq && idx->d_sq_tiles, VG_ERR_NOT_READY, "vg_index_enable_sq8_nomination: index has no SQ8 codes");
-    if (idx->dim % 64 != 0 || idx->metric != VG_METRIC_L2) return VG_OK;  // the nomination never applies: no image to keep
+    if (idx->dim % 64 != 0) return VG_OK;  // the nomination never applies: no image to keep
     VG_HIP(hipMalloc(reinterpret_cast<void **>(&idx->d_sq_bf16), static_cast<size_t>(idx->n) * idx->dim * sizeof(uint16_t)));
     VG_HIP(hipMalloc(reinterpret_cast<void **>(&idx->d_sq_norms), static_cast<size_t>(idx->n) * sizeof(float)));
     VG_HIP(hipMalloc(reinterpret_cast<void **>(&idx->d_sq_norm_max), sizeof(float)));
@@ -1696,6 +1704,49 @@ VG_API int32_t vg_index_set_sq8_codes(vg_index *idx, vg_sq8 *sq, const uint8_t *
     return VG_OK;
 }
 
+namespace vg {
+// whether a batch takes the nomination (vg_index_enable_sq8_nomination; device queries)
+bool sq8_nomination_applies(const vg_index *idx, const float *d_queries, int64_t nq, int k)
+{
+    return idx->d_sq_bf16 && nq >= 16 && k <= 48 && idx->n > k && (reinterpret_cast<uintptr_t>(d_queries) & 15) == 0;
+}
+// The nomination + exact re-score + proof for a batch (device buffers; mask: a device row filter per query / for the batch, or
+// null): writes every query's k results and lists the queries whose proof failed — the caller scans those.  4096 queries a pass.
+int32_t sq8_nominated_pass(vg_index *idx, const float *q, int64_t nq, int k, const uint8_t *mask, int64_t mask_stride, uint32_t *oid,
+                           float *osc, hipStream_t st, std::vector<int> &failed)
+{
+    const bool dot = idx->metric != VG_METRIC_L2;
+    for (int64_t q0 = 0; q0 < nq; q0 += 4096) {
+        const int64_t cnt = std::min<int64_t>(4096, nq - q0);
+        std::vector<int> h(static_cast<size_t>(cnt));
+        {
+            ArenaCall ar(idx->ctx, st);
+            const int i_scr = ar.add(flat_nominate_bf16_scratch(cnt, idx->n, idx->dim));
+            const int i_thr = ar.add(sizeof(float) * static_cast<size_t>(cnt) * 8);
+            const int i_cnt = ar.add(sizeof(int) * static_cast<size_t>(cnt));
+            const int i_cid = ar.add(sizeof(uint32_t) * static_cast<size_t>(cnt) * 64);
+            const int i_csc = ar.add(sizeof(float) * static_cast<size_t>(cnt) * 64);
+            const int i_fail = ar.add(sizeof(int) * static_cast<size_t>(cnt));
+            VG_TRY(ar.commit());
+            float *thr = ar.get<float>(i_thr), *csc = ar.get<float>(i_csc);
+            int *counts = ar.get<int>(i_cnt), *fail = ar.get<int>(i_fail);
+            uint32_t *cid = ar.get<uint32_t>(i_cid);
+            VG_TRY(flat_nominate_bf16(idx->ctx, idx->d_sq_bf16, idx->d_sq_norms, idx->n, idx->dim, q + q0 * idx->dim, cnt, ar.get<char>(i_scr),
+                                      thr, counts, cid, csc, st, dot, mask ? mask + q0 * mask_stride : nullptr, mask_stride));
+            auto kern = dot ? sq8_verify_kernel<true> : sq8_verify_kernel<false>;
+            VG_LAUNCH(kern, dim3(static_cast<unsigned>(cnt)), dim3(64), 0, st, reinterpret_cast<const uint4 *>(idx->d_sq_tiles), idx->sq_groups,
+                      idx->dim, idx->sq->d_mins, idx->sq->d_inv, q + q0 * idx->dim, idx->d_sq_norm_max, cid, csc, k, oid + q0 * k, osc + q0 * k,
+                      fail, thr, counts, 4096);
+            VG_HIP(hipMemcpyAsync(h.data(), fail, sizeof(int) * static_cast<size_t>(cnt), hipMemcpyDeviceToHost, st));
+            VG_HIP(hipStreamSynchronize(st));
+        }
+        for (int64_t i = 0; i < cnt; i++)
+            if (h[static_cast<size_t>(i)]) failed.push_back(static_cast<int>(q0 + i));
+    }
+    return VG_OK;
+}
+}  // namespace vg
+
 static int32_t sq8_search_impl(vg_index *idx, const float *queries, int64_t nq, int32_t k, uint32_t *ids, float *scores, void *stream,
                                bool allow_nomination);
 
@@ -1729,37 +1780,9 @@ static int32_t sq8_search_impl(vg_index *idx, const float *queries, int64_t nq, 
         VG_TRY(none.init(static_cast<size_t>(nq) * k, st));
         VG_HIP(hipMemsetAsync(none.ptr, 0xFF, static_cast<size_t>(nq) * k * 8, st));
         VG_TRY(vg::launch_topk_merge(none.ptr, nq, 1, k, false, oid.ptr, osc.ptr, st));
-    } else if (allow_nomination && idx->d_sq_bf16 && !dot && nq >= 16 && k <= 48 && idx->n > k &&
-               (reinterpret_cast<uintptr_t>(q.ptr) & 15) == 0) {
-        // vg_index_enable_sq8_nomination: bf16 nomination + exact re-score from the codes + proof (see above), 4096 queries a pass
+    } else if (allow_nomination && vg::sq8_nomination_applies(idx, q.ptr, nq, k)) {
         std::vector<int> failed;
-        for (int64_t q0 = 0; q0 < nq; q0 += 4096) {
-            const int64_t cnt = std::min<int64_t>(4096, nq - q0);
-            std::vector<int> h(static_cast<size_t>(cnt));
-            {
-                vg::ArenaCall ar(idx->ctx, st);
-                const int i_scr = ar.add(vg::flat_nominate_bf16_scratch(cnt, idx->n, idx->dim));
-                const int i_thr = ar.add(sizeof(float) * static_cast<size_t>(cnt) * 8);
-                const int i_cnt = ar.add(sizeof(int) * static_cast<size_t>(cnt));
-                const int i_cid = ar.add(sizeof(uint32_t) * static_cast<size_t>(cnt) * 64);
-                const int i_csc = ar.add(sizeof(float) * static_cast<size_t>(cnt) * 64);
-                const int i_fail = ar.add(sizeof(int) * static_cast<size_t>(cnt));
-                VG_TRY(ar.commit());
-                float *thr = ar.get<float>(i_thr), *csc = ar.get<float>(i_csc);
-                int *counts = ar.get<int>(i_cnt), *fail = ar.get<int>(i_fail);
-                uint32_t *cid = ar.get<uint32_t>(i_cid);
-                VG_TRY(vg::flat_nominate_bf16(idx->ctx, idx->d_sq_bf16, idx->d_sq_norms, idx->n, idx->dim, q.ptr + q0 * idx->dim, cnt,
-                                              ar.get<char>(i_scr), thr, counts, cid, csc, st));
-                VG_LAUNCH(vg::sq8_verify_kernel, dim3(static_cast<unsigned>(cnt)), dim3(64), 0, st,
-                          reinterpret_cast<const uint4 *>(idx->d_sq_tiles), idx->sq_groups, idx->dim, idx->sq->d_mins, idx->sq->d_inv,
-                          q.ptr + q0 * idx->dim, idx->d_sq_norm_max, cid, csc, k, oid.ptr + q0 * k, osc.ptr + q0 * k, fail, thr, counts,
-                          4096);
-                VG_HIP(hipMemcpyAsync(h.data(), fail, sizeof(int) * static_cast<size_t>(cnt), hipMemcpyDeviceToHost, st));
-                VG_HIP(hipStreamSynchronize(st));
-            }
-            for (int64_t i = 0; i < cnt; i++)
-                if (h[static_cast<size_t>(i)]) failed.push_back(static_cast<int>(q0 + i));
-        }
+        VG_TRY(vg::sq8_nominated_pass(idx, q.ptr, nq, k, nullptr, 0, oid.ptr, osc.ptr, st, failed));
         if (!failed.empty()) {  // the scan kernels for the queries whose proof failed (ties at the k-th score, thresholds too tight)
             const int64_t nf = static_cast<int64_t>(failed.size());
             vg::DevTmp<float> fq;
