@@ -218,3 +218,35 @@ def test_nomination_with_dot_metric_and_filters(vg, ctx, metric):
             eid, esc = seg.search(q[i], k, mask=m)
             assert np.array_equal(got[0][i, :eid.size], eid) and np.array_equal(bits(got[1][i, :eid.size]), bits(esc))
             assert np.all(got[0][i, eid.size:] == 0xFFFFFFFF)
+
+
+@pytest.mark.parametrize("metric", [0, 2])
+def test_probed_batches_through_the_grouped_nomination(vg, ctx, metric):
+    """a partitioned SQ8 segment, partitions probed by many queries each: the grouped bf16 nomination per (query, probe) pair +
+    sq8_verify_kernel — nomination on = off = the oracle, with and without a filter"""
+    from tests.test_gpu_probe import partitioned
+    rng = np.random.default_rng(70 + metric)
+    n, dim, parts, nq, k = 12000, 64, 6, 120, 10
+    x, cent, off = partitioned(rng, n, dim, parts, metric)
+    x[200:206] = x[200]
+    sq = vg.ScalarQuantizer(ctx, dim); sq.train(x)
+    ref = o.ScalarQuantizer(dim); ref.train(x)
+    codes = sq.encode(x)
+    idx = vg.Index(ctx, n, dim, vg.Metric(metric))
+    idx.set_sq8_codes(sq, codes)
+    idx.set_partitions(cent, off)
+    seg = o.FlatSegment(x, dim, metric=metric, sq=ref, codes=codes, centroids=cent, part_offsets=off)
+    q = rng.standard_normal((nq, dim)).astype(np.float32)
+    q[3] = x[200]
+    masks = rng.random((nq, n)) < 0.4
+    res = {}
+    for on in (False, True):
+        idx.enable_sq8_nomination(on)
+        res[on] = [idx.search_flat_probed(q, k, np_, scan=idx.SCAN_SQ8) for np_ in (2, parts)] + \
+                  [idx.search_flat_filtered(q, k, masks, 2, scan=idx.SCAN_SQ8), idx.search_flat_filtered(q, k, masks[0], 2, scan=idx.SCAN_SQ8)]
+    for a, b in zip(res[False], res[True]):
+        assert np.array_equal(a[0], b[0]) and np.array_equal(bits(a[1]), bits(b[1]))
+    for i in (0, 3, 60, nq - 1):
+        for got, np_, m in ((res[True][0], 2, None), (res[True][1], parts, None), (res[True][2], 2, masks[i]), (res[True][3], 2, masks[0])):
+            eid, esc = seg.search(q[i], k, np_, mask=m)
+            assert np.array_equal(got[0][i, :eid.size], eid) and np.array_equal(bits(got[1][i, :eid.size]), bits(esc))

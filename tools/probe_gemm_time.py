@@ -61,7 +61,9 @@ sq = vg.ScalarQuantizer(ctx, bench.DIM); sq.train(rows[:100000])
 idx.set_sq8_codes(sq, sq.encode(rows[order].contiguous()))
 pq = vg.ProductQuantizer(ctx, bench.DIM, 96, 256); pq.train(rows[:65536], iters=2, seed=1)
 idx.set_pq_codes(pq, pq.encode(rows[order].contiguous()))
-for name, scan, whole in (("sq8", idx.SCAN_SQ8, idx.search_sq8), ("pq96", idx.SCAN_PQ, idx.search_pq_adc)):
+for name, scan, whole in (("sq8", idx.SCAN_SQ8, idx.search_sq8), ("sq8 + bf16 nomination", idx.SCAN_SQ8, idx.search_sq8),
+                          ("pq96", idx.SCAN_PQ, idx.search_pq_adc)):
+    idx.enable_sq8_nomination(name.endswith("nomination"))
     w, _ = timed(lambda: whole(q, 10))
     line = [f"{name}: whole segment {w:7.2f} ms per 1024 queries"]
     for nprobes in (1, 8, 32):

@@ -874,15 +874,22 @@ int32_t vg::flat_search_masked(vg_index *idx, const float *queries, int64_t nq, 
 // = its partition's k best rows by (score, row id) with exact scores, and fail[pair] = 1 where the proof does not hold (the caller
 // answers those queries with the exact probe kernels).  k <= kGemmMaxK; fp32 rows, dim % 4 == 0, 16-byte aligned.
 namespace vg {
+struct ProbeNominated {  // where flat_probe_gemm left the nomination when the caller re-scores (rows_bf16 form)
+    float *thr;
+    int *counts;
+    uint32_t *cand_id;
+    float *cand_sc;
+    int cap;
+};
 // candidate keys per pair: ~64 rows fall below a pair's threshold (8th best of 1/8 of its partition); 2048 leaves 30x, and a
 // batch of 65535 pairs holds 1 GiB of them (4096, the flat search's, would be 2)
 constexpr int kProbeGemmCap = 2048;
 // (scratch: one piece of the caller's arena — the caller holds the arena for the call — carved here; the layout in one place)
 struct ProbeGemmLayout {
-    size_t sc, partial, sid, thr, counts, cand, cid, csc, total;
+    size_t sc, partial, sid, thr, counts, cand, cid, csc, qbf, total;
     int sel_slices;
 };
-static ProbeGemmLayout probe_gemm_layout(int64_t pairs, int64_t ns_max)
+static ProbeGemmLayout probe_gemm_layout(int64_t pairs, int64_t ns_max, int dim = 0 /* > 0: room for the pairs' queries in bfloat16 */)
 {
     constexpr int kc = 64, cap = kProbeGemmCap, sel_k = 8;
     ProbeGemmLayout l;
@@ -901,24 +908,41 @@ static ProbeGemmLayout probe_gemm_layout(int64_t pairs, int64_t ns_max)
     l.cand = piece(sizeof(uint64_t) * static_cast<size_t>(pairs) * cap);
     l.cid = piece(sizeof(uint32_t) * static_cast<size_t>(pairs) * kc);
     l.csc = piece(sizeof(float) * static_cast<size_t>(pairs) * kc);
+    l.qbf = piece(sizeof(uint16_t) * static_cast<size_t>(pairs) * dim);
     l.total = at;
     return l;
 }
-size_t flat_probe_gemm_scratch_bytes(int64_t pairs, int64_t ns_max) { return probe_gemm_layout(pairs, ns_max).total; }
+size_t flat_probe_gemm_scratch_bytes(int64_t pairs, int64_t ns_max, int bf16_dim) { return probe_gemm_layout(pairs, ns_max, bf16_dim).total; }
 
 int32_t flat_probe_gemm(vg_index *idx, const float *pair_queries, int64_t pairs, const GemmGroup *groups, const int64_t *const first_block[4],
                         int ngroups, const int64_t grid[4], int sample_stride, int64_t ns_max, int k, uint32_t *pair_ids,
                         float *pair_scores, int *fail, char *scratch, const uint8_t *mask /* the batch's row filters, or null */,
-                        const int64_t *mask_off /* [pairs]: byte offset of each bucketed pair's filter in `mask` */, hipStream_t st)
+                        const int64_t *mask_off /* [pairs]: byte offset of each bucketed pair's filter in `mask` */, hipStream_t st,
+                        const uint16_t *rows_bf16, const float *rows_norms, ProbeNominated *nominated)
 {
+    // rows_bf16 != null: nominate on that bfloat16 row image (with its norms) instead of the fp32 rows, and leave the exact
+    // re-score + proof to the caller: *nominated = where the per-pair thresholds / counts / 64 candidates are (the partition-probed
+    // SQ8 scan, k_sq8.hip)
     // first_block / grid: [0] sample, [1] main launch of the 128-query tiles (groups of more than 64 pairs); [2], [3] the same of
     // the 64-query tiles (flat_gemm_dma32_grouped_kernel<.., 2>: a group of at most 64 pairs is one query tile, one workgroup per
     // row tile, HBM-bound — a 128-query tile would spend the matrix cores on padding)
     const bool dot = idx->metric != VG_METRIC_L2;
     const int dim = idx->dim;
     const int kc = 64, cap = kProbeGemmCap, sel_k = 8;
-    const ProbeGemmLayout l = probe_gemm_layout(pairs, ns_max);
+    const bool bf16 = rows_bf16 != nullptr;
+    const ProbeGemmLayout l = probe_gemm_layout(pairs, ns_max, bf16 ? idx->dim : 0);
     const int sel_slices = l.sel_slices;
+    const float *grows = idx->d_vectors, *gnorms = idx->d_norms;
+    int gdim = idx->dim;
+    if (bf16) {
+        uint16_t *qbf = reinterpret_cast<uint16_t *>(scratch + l.qbf);
+        VG_LAUNCH(f32_to_bf16_kernel, dim3(static_cast<unsigned>((pairs * idx->dim + 255) / 256)), dim3(256), 0, st, pair_queries,
+                  pairs * idx->dim, qbf);
+        pair_queries = reinterpret_cast<const float *>(qbf);
+        grows = reinterpret_cast<const float *>(rows_bf16);
+        gnorms = rows_norms;
+        gdim = idx->dim / 2;
+    }
     float *sc = reinterpret_cast<float *>(scratch + l.sc), *thr = reinterpret_cast<float *>(scratch + l.thr);
     float *cand_sc = reinterpret_cast<float *>(scratch + l.csc);
     uint64_t *partial = reinterpret_cast<uint64_t *>(scratch + l.partial), *cand = reinterpret_cast<uint64_t *>(scratch + l.cand);
@@ -929,18 +953,20 @@ int32_t flat_probe_gemm(vg_index *idx, const float *pair_queries, int64_t pairs,
     // writes — smaller partitions — hold +Inf)
     VG_LAUNCH(fill_f32_kernel, dim3(static_cast<unsigned>((pairs * ns_max + 255) / 256)), dim3(256), 0, st, sc, pairs * ns_max, INFINITY);
     {
-        auto kern = dot ? flat_gemm_dma_grouped_kernel<true, 1> : flat_gemm_dma_grouped_kernel<false, 1>;
+        auto kern = bf16 ? (dot ? flat_gemm_dma_grouped_kernel<true, 1, true> : flat_gemm_dma_grouped_kernel<false, 1, true>)
+                         : (dot ? flat_gemm_dma_grouped_kernel<true, 1> : flat_gemm_dma_grouped_kernel<false, 1>);
         VG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    static_cast<int>(kDmaLdsBytes)));
         if (grid[0])
             VG_LAUNCH(kern, dim3(static_cast<unsigned>(grid[0])), dim3(kGemmThreads), kDmaLdsBytes, st, groups, first_block[0], ngroups,
-                      pair_queries, idx->d_vectors, dim, idx->d_norms, sc, sample_stride, ns_max, nullptr, 0, 0, nullptr, nullptr, 0, mask, mask_off);
-        auto kern32 = dot ? flat_gemm_dma32_grouped_kernel<true, 1, 2> : flat_gemm_dma32_grouped_kernel<false, 1, 2>;
+                      pair_queries, grows, gdim, gnorms, sc, sample_stride, ns_max, nullptr, 0, 0, nullptr, nullptr, 0, mask, mask_off);
+        auto kern32 = bf16 ? (dot ? flat_gemm_dma32_grouped_kernel<true, 1, 2, true> : flat_gemm_dma32_grouped_kernel<false, 1, 2, true>)
+                           : (dot ? flat_gemm_dma32_grouped_kernel<true, 1, 2> : flat_gemm_dma32_grouped_kernel<false, 1, 2>);
         VG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern32), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    static_cast<int>(g32_lds_bytes<2>())));
         if (grid[2])
             VG_LAUNCH(kern32, dim3(static_cast<unsigned>(grid[2])), dim3(kGemmThreads), g32_lds_bytes<2>(), st, groups, first_block[2], ngroups,
-                      pair_queries, idx->d_vectors, dim, idx->d_norms, sc, sample_stride, ns_max, nullptr, 0, 0, nullptr, nullptr, 0, mask, mask_off);
+                      pair_queries, grows, gdim, gnorms, sc, sample_stride, ns_max, nullptr, 0, 0, nullptr, nullptr, 0, mask, mask_off);
     }
     VG_LAUNCH(flat_select_kernel, dim3(sel_slices, upairs), dim3(kSelThreads), 0, st, sc, ns_max, sel_slices, sel_k, partial);
     VG_TRY(launch_topk_merge(partial, pairs, sel_slices, sel_k, false, sid, thr, st));
@@ -948,21 +974,31 @@ int32_t flat_probe_gemm(vg_index *idx, const float *pair_queries, int64_t pairs,
     VG_HIP(hipMemsetAsync(counts, 0, sizeof(int) * static_cast<size_t>(pairs), st));
     {
         ProfScope prof(idx->ctx, "flat_probe_gemm", st);
-        auto kern = dot ? flat_gemm_dma_grouped_kernel<true, 2> : flat_gemm_dma_grouped_kernel<false, 2>;
+        auto kern = bf16 ? (dot ? flat_gemm_dma_grouped_kernel<true, 2, true> : flat_gemm_dma_grouped_kernel<false, 2, true>)
+                         : (dot ? flat_gemm_dma_grouped_kernel<true, 2> : flat_gemm_dma_grouped_kernel<false, 2>);
         VG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    static_cast<int>(kDmaLdsBytes)));
         if (grid[1])
             VG_LAUNCH(kern, dim3(static_cast<unsigned>(grid[1])), dim3(kGemmThreads), kDmaLdsBytes, st, groups, first_block[1], ngroups,
-                      pair_queries, idx->d_vectors, dim, idx->d_norms, nullptr, 1, 0, thr, sel_k, sel_k - 1, counts, cand, cap, mask, mask_off);
-        auto kern32 = dot ? flat_gemm_dma32_grouped_kernel<true, 2, 2> : flat_gemm_dma32_grouped_kernel<false, 2, 2>;
+                      pair_queries, grows, gdim, gnorms, nullptr, 1, 0, thr, sel_k, sel_k - 1, counts, cand, cap, mask, mask_off);
+        auto kern32 = bf16 ? (dot ? flat_gemm_dma32_grouped_kernel<true, 2, 2, true> : flat_gemm_dma32_grouped_kernel<false, 2, 2, true>)
+                           : (dot ? flat_gemm_dma32_grouped_kernel<true, 2, 2> : flat_gemm_dma32_grouped_kernel<false, 2, 2>);
         VG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern32), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    static_cast<int>(g32_lds_bytes<2>())));
         if (grid[3])
             VG_LAUNCH(kern32, dim3(static_cast<unsigned>(grid[3])), dim3(kGemmThreads), g32_lds_bytes<2>(), st, groups, first_block[3], ngroups,
-                      pair_queries, idx->d_vectors, dim, idx->d_norms, nullptr, 1, 0, thr, sel_k, sel_k - 1, counts, cand, cap, mask, mask_off);
+                      pair_queries, grows, gdim, gnorms, nullptr, 1, 0, thr, sel_k, sel_k - 1, counts, cand, cap, mask, mask_off);
     }
     // (c) the kc best of them, (d) re-scored exactly, the k best, and the proof against everything not nominated
     VG_LAUNCH(flat_pick_kernel, dim3(upairs), dim3(256), 0, st, cand, counts, cap, kc, cand_id, cand_sc);
+    if (bf16) {
+        nominated->thr = thr;
+        nominated->counts = counts;
+        nominated->cand_id = cand_id;
+        nominated->cand_sc = cand_sc;
+        nominated->cap = cap;
+        return VG_OK;
+    }
     if (dot)
         VG_LAUNCH(flat_verify_kernel<true>, dim3(upairs), dim3(256), 0, st, idx->d_vectors, idx->n, dim, pair_queries, idx->d_norm_max,
                   cand_id, cand_sc, kc, k, pair_ids, pair_scores, fail, thr, sel_k, sel_k - 1, counts, cap, 0.0f);

@@ -35,10 +35,20 @@ int32_t flat_search_masked(vg_index *idx, const float *queries, int64_t nq, int3
                            uint32_t *ids, float *scores, void *stream, bool l2_scores = false);
 int32_t pq_adc_search_masked(vg_index *idx, const float *queries, int64_t nq, int32_t k, const uint8_t *mask, int64_t mask_stride,
                              bool desc, uint32_t *ids, float *scores, void *stream);
-size_t flat_probe_gemm_scratch_bytes(int64_t pairs, int64_t ns_max);
+struct ProbeNominated {
+    float *thr;
+    int *counts;
+    uint32_t *cand_id;
+    float *cand_sc;
+    int cap;
+};
+size_t flat_probe_gemm_scratch_bytes(int64_t pairs, int64_t ns_max, int bf16_dim);
+int32_t launch_sq8_verify(vg_index *idx, const float *queries, int64_t nq, const ProbeNominated &nom, int k, uint32_t *ids, float *scores,
+                          int *fail, hipStream_t st);
 int32_t flat_probe_gemm(vg_index *idx, const float *pair_queries, int64_t pairs, const GemmGroup *groups, const int64_t *const first_block[4],
                         int ngroups, const int64_t grid[4], int sample_stride, int64_t ns_max, int k, uint32_t *pair_ids,
-                        float *pair_scores, int *fail, char *scratch, const uint8_t *mask, const int64_t *mask_off, hipStream_t st);
+                        float *pair_scores, int *fail, char *scratch, const uint8_t *mask, const int64_t *mask_off, hipStream_t st,
+                        const uint16_t *rows_bf16, const float *rows_norms, ProbeNominated *nominated);
 bool sq8_nomination_applies(const vg_index *idx, const float *d_queries, int64_t nq, int k);
 int32_t sq8_nominated_pass(vg_index *idx, const float *q, int64_t nq, int k, const uint8_t *mask, int64_t mask_stride, uint32_t *oid,
                            float *osc, hipStream_t st, std::vector<int> &failed);
@@ -651,10 +661,14 @@ static int32_t flat_probed_impl(vg_index *idx, const float *queries, int64_t nq,
     // (1M x 768 in 122 partitions, 1024 queries, ms per call, exact kernels -> this: nprobes 1 (8 per partition) 1.21 -> 1.18,
     // 2: 2.1 -> 1.4, 4: 3.75 -> 1.3, 8: 7.25 -> 2.3, 16: 11.6 -> 4.5, 32: 21.0 -> 7.0; tools/probe_gemm_time.py)
     // (a filtered batch too: a pair's filter is its query's — probe_gather_queries_kernel notes where each starts)
-    const bool gemm = scan == VG_SCAN_F32 && !whole && k <= 48 && idx->dim % 4 == 0 && pairs <= 65535 &&
-                      pairs >= 12 * static_cast<int64_t>(parts) && (reinterpret_cast<uintptr_t>(idx->d_vectors) & 15) == 0 &&
-                      (reinterpret_cast<uintptr_t>(q.ptr) & 15) == 0 && static_cast<int>(idx->h_part_off.size()) == parts + 1 &&
-                      !vg::hook(vg::kHookProbeNoGroup) && !vg::hook(vg::kHookProbeNoGemm);
+    const bool gemm_shape = !whole && k <= 48 && idx->dim % 4 == 0 && pairs <= 65535 && pairs >= 12 * static_cast<int64_t>(parts) &&
+                            (reinterpret_cast<uintptr_t>(q.ptr) & 15) == 0 && static_cast<int>(idx->h_part_off.size()) == parts + 1 &&
+                            !vg::hook(vg::kHookProbeNoGroup) && !vg::hook(vg::kHookProbeNoGemm);
+    const bool gemm_f32 = scan == VG_SCAN_F32 && gemm_shape && (reinterpret_cast<uintptr_t>(idx->d_vectors) & 15) == 0;
+    // SQ8 with vg_index_enable_sq8_nomination: the same grouped nomination on the bfloat16 image of the dequantised rows, the
+    // pairs' 64 candidates re-scored from the codes and proven by sq8_verify_kernel (k_sq8.hip)
+    const bool gemm_sq8 = scan == VG_SCAN_SQ8 && gemm_shape && allow_nomination && idx->d_sq_bf16 != nullptr;
+    const bool gemm = gemm_f32 || gemm_sq8;
     int64_t grids[4] = {0, 0, 0, 0}, ns_max = 0;  // sample / main of the 128-query tiles, sample / main of the 64-query tiles
     if (gemm) {  // launch bounds from the partition sizes: one query tile per partition + the batch's further tiles on the largest
         int64_t sum_s = 0, sum_m = 0, max_s = 0, max_m = 0;
@@ -688,7 +702,7 @@ static int32_t flat_probed_impl(vg_index *idx, const float *queries, int64_t nq,
     const int i_pfail = ar.add(gemm ? sizeof(int) * static_cast<size_t>(pairs) : 0);
     const int i_qfail = ar.add(gemm ? sizeof(int) * static_cast<size_t>(nq) : 0);
     const int i_moff = ar.add(gemm ? sizeof(int64_t) * static_cast<size_t>(pairs) : 0);
-    const int i_gscr = ar.add(gemm ? vg::flat_probe_gemm_scratch_bytes(pairs, ns_max) : 0);
+    const int i_gscr = ar.add(gemm ? vg::flat_probe_gemm_scratch_bytes(pairs, ns_max, gemm_sq8 ? idx->dim : 0) : 0);
     VG_TRY(ar.commit());
     uint32_t *probes = ar.get<uint32_t>(i_probes);
     uint64_t *partial = ar.get<uint64_t>(i_partial);
@@ -736,13 +750,54 @@ static int32_t flat_probed_impl(vg_index *idx, const float *queries, int64_t nq,
         {
             vg::ProfScope prof(idx->ctx, "flat_probe", st);
             const int64_t *const fb[4] = {fbs, fbm, fbss, fbsm};
+            vg::ProbeNominated nom{};
             VG_TRY(vg::flat_probe_gemm(idx, pairq, pairs, bgrp, fb, parts, grids, vg::kProbeSampleStride, ns_max, k, pair_ids, pair_sc,
-                                       pfail, ar.get<char>(i_gscr), mk.ptr, moff, st));
+                                       pfail, ar.get<char>(i_gscr), mk.ptr, moff, st, gemm_sq8 ? idx->d_sq_bf16 : nullptr,
+                                       gemm_sq8 ? idx->d_sq_norms : nullptr, &nom));
+            if (gemm_sq8) VG_TRY(vg::launch_sq8_verify(idx, pairq, pairs, nom, k, pair_ids, pair_sc, pfail, st));
         }
         // lists = np * sub in this configuration; the pairs' k results fill the first np lists' worth of `partial`
         VG_LAUNCH(vg::probe_pack_kernel, dim3(static_cast<unsigned>(pairs)), dim3(64), 0, st, bpair, pair_ids, pair_sc, pfail, k, np, desc,
                   partial, qfail);
         VG_TRY(vg::launch_topk_merge(partial, nq, np, k, desc, oid.ptr, osc.ptr, st));
+        if (gemm_sq8) {  // the flagged queries (normally none) go through the scan kernels: read the flags, search that subset
+            std::vector<int> hq(static_cast<size_t>(nq));
+            VG_HIP(hipMemcpyAsync(hq.data(), qfail, sizeof(int) * static_cast<size_t>(nq), hipMemcpyDeviceToHost, st));
+            VG_HIP(hipStreamSynchronize(st));
+            std::vector<int> failed;
+            for (int64_t i = 0; i < nq; i++)
+                if (hq[static_cast<size_t>(i)]) failed.push_back(static_cast<int>(i));
+            ar.lock.unlock();  // the subset's own search takes the arena
+            if (!failed.empty()) {
+                const int64_t nf = static_cast<int64_t>(failed.size());
+                vg::DevTmp<float> fq;
+                vg::DevTmp<uint32_t> fid;
+                vg::DevTmp<float> fsc;
+                vg::DevTmp<uint8_t> fm;
+                VG_TRY(fq.init(static_cast<size_t>(nf) * idx->dim, st));
+                VG_TRY(fid.init(static_cast<size_t>(nf) * k, st));
+                VG_TRY(fsc.init(static_cast<size_t>(nf) * k, st));
+                VG_TRY(fm.init(mk.ptr && mask_stride ? static_cast<size_t>(nf) * mask_bytes : 0, st));
+                for (int64_t i = 0; i < nf; i++) {
+                    const int64_t src = failed[static_cast<size_t>(i)];
+                    VG_HIP(hipMemcpyAsync(fq.ptr + i * idx->dim, q.ptr + src * idx->dim, sizeof(float) * idx->dim, hipMemcpyDeviceToDevice, st));
+                    if (mk.ptr && mask_stride)
+                        VG_HIP(hipMemcpyAsync(fm.ptr + i * mask_bytes, mk.ptr + src * mask_stride, static_cast<size_t>(mask_bytes),
+                                              hipMemcpyDeviceToDevice, st));
+                }
+                VG_TRY(flat_probed_impl(idx, fq.ptr, nf, k, nprobes, scan, mk.ptr ? (mask_stride ? fm.ptr : mk.ptr) : nullptr,
+                                        mask_stride ? mask_bytes : 0, fid.ptr, fsc.ptr, st, false));
+                for (int64_t i = 0; i < nf; i++) {
+                    const int64_t at = static_cast<int64_t>(failed[static_cast<size_t>(i)]) * k;
+                    VG_HIP(hipMemcpyAsync(oid.ptr + at, fid.ptr + i * k, sizeof(uint32_t) * k, hipMemcpyDeviceToDevice, st));
+                    VG_HIP(hipMemcpyAsync(osc.ptr + at, fsc.ptr + i * k, sizeof(float) * k, hipMemcpyDeviceToDevice, st));
+                }
+            }
+            VG_TRY(oid.finish());
+            VG_TRY(osc.finish());
+            if (oid.on_host() || osc.on_host()) VG_HIP(hipStreamSynchronize(st));
+            return VG_OK;
+        }
         // the queries with a failed proof (ties at the k-th score, more than 4096 rows below a threshold): the exact kernel, one
         // workgroup per (slice, probe, query) that leaves at once unless its query is flagged
         for (int64_t q0 = 0; q0 < nq; q0 += 65535) {

@@ -1705,6 +1705,25 @@ VG_API int32_t vg_index_set_sq8_codes(vg_index *idx, vg_sq8 *sq, const uint8_t *
 }
 
 namespace vg {
+struct ProbeNominated {
+    float *thr;
+    int *counts;
+    uint32_t *cand_id;
+    float *cand_sc;
+    int cap;
+};
+// sq8_verify_kernel over nq query rows whose nomination (8 thresholds, count, 64 candidates each) another file produced: the
+// partition-probed scan's (query, probe) pairs (k_probe.hip)
+int32_t launch_sq8_verify(vg_index *idx, const float *queries, int64_t nq, const ProbeNominated &nom, int k, uint32_t *ids, float *scores,
+                          int *fail, hipStream_t st)
+{
+    const bool dot = idx->metric != VG_METRIC_L2;
+    auto kern = dot ? sq8_verify_kernel<true> : sq8_verify_kernel<false>;
+    VG_LAUNCH(kern, dim3(static_cast<unsigned>(nq)), dim3(64), 0, st, reinterpret_cast<const uint4 *>(idx->d_sq_tiles), idx->sq_groups, idx->dim,
+              idx->sq->d_mins, idx->sq->d_inv, queries, idx->d_sq_norm_max, nom.cand_id, nom.cand_sc, k, ids, scores, fail, nom.thr, nom.counts,
+              nom.cap);
+    return VG_OK;
+}
 // whether a batch takes the nomination (vg_index_enable_sq8_nomination; device queries)
 bool sq8_nomination_applies(const vg_index *idx, const float *d_queries, int64_t nq, int k)
 {

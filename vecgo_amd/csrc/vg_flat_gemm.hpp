@@ -496,7 +496,7 @@ struct GemmGroup {
     int64_t a_off, b_off;
     int32_t a_cnt, b_cnt;
 };
-template <bool DOT, int MODE>
+template <bool DOT, int MODE, bool BF16 = false>
 __global__ __launch_bounds__(kGemmThreads) void flat_gemm_dma_grouped_kernel(
     const GemmGroup *__restrict__ groups, const int64_t *__restrict__ first_block, int ngroups,
     const float *__restrict__ queries, const float *__restrict__ base, int dim, const float *__restrict__ norms,
@@ -516,7 +516,7 @@ __global__ __launch_bounds__(kGemmThreads) void flat_gemm_dma_grouped_kernel(
     }
     const GemmGroup g = groups[lo];
     if (g.a_cnt == 0 || g.b_cnt == 0) return;
-    flat_gemm_dma_body<DOT, MODE, 0, false, true>(
+    flat_gemm_dma_body<DOT, MODE, 0, BF16, true>(
         queries + g.a_off * dim, g.a_cnt, base + g.b_off * dim, g.b_cnt, dim, norms + g.b_off,
         scores ? scores + g.a_off * out_cols : nullptr, tile_stride, out_cols, thr ? thr + g.a_off * thr_stride : nullptr, thr_stride,
         thr_off, counts ? counts + g.a_off : nullptr, cand ? cand + g.a_off * cap : nullptr, cap, mask, 0, b - first_block[lo],
@@ -711,7 +711,7 @@ __global__ __launch_bounds__(kGemmThreads) void flat_gemm_dma32_kernel(
 }
 
 // the grouped form for groups of at most RB * 32 query rows (one workgroup per row tile of the group; first_block as above)
-template <bool DOT, int MODE, int RB>
+template <bool DOT, int MODE, int RB, bool BF16 = false>
 __global__ __launch_bounds__(kGemmThreads) void flat_gemm_dma32_grouped_kernel(
     const GemmGroup *__restrict__ groups, const int64_t *__restrict__ first_block, int ngroups,
     const float *__restrict__ queries, const float *__restrict__ base, int dim, const float *__restrict__ norms,
@@ -731,7 +731,7 @@ __global__ __launch_bounds__(kGemmThreads) void flat_gemm_dma32_grouped_kernel(
     }
     const GemmGroup g = groups[lo];
     if (g.a_cnt == 0 || g.b_cnt == 0) return;
-    flat_gemm_dma32_body<DOT, MODE, RB, false, true>(
+    flat_gemm_dma32_body<DOT, MODE, RB, BF16, true>(
         queries + g.a_off * dim, g.a_cnt, base + g.b_off * dim, g.b_cnt, dim, norms + g.b_off,
         scores ? scores + g.a_off * out_cols : nullptr, tile_stride, out_cols, thr ? thr + g.a_off * thr_stride : nullptr, thr_stride,
         thr_off, counts ? counts + g.a_off : nullptr, cand ? cand + g.a_off * cap : nullptr, cap, mask, 0, b - first_block[lo],
