@@ -1330,8 +1330,8 @@ FULL_RECORD = "bench_full.json"
 LINE_LIMIT = 9000      # bytes: the driver could not parse r03's 22.7 KB line; r02's 10.8 KB one it could
 
 
-def _r(x, sig=6):
-    """Numbers of the compact line carry 6 significant digits; everything else passes through."""
+def _r(x, sig=5):
+    """Numbers of the compact line carry 5 significant digits; everything else passes through."""
     if isinstance(x, bool) or not isinstance(x, float):
         return x
     return float(f"{x:.{sig}g}")
@@ -1352,10 +1352,12 @@ def compact_line(full: dict) -> dict:
     out.update(_pick(full, "recall_at_10", "recall_queries"))
     rf = full.get("roofline") or {}
     out["roofline"] = {**_pick(rf, "bound", "achieved", "peak", "unit", "frac"), "traffic": _r(rf.get("traffic")),
-                       **_pick(rf, "kernel", "kernel_ms", "launches", "traffic_source")}
+                       **_pick(rf, "kernel", "kernel_ms", "launches")}  # (traffic_source: the full record)
     cb = full.get("cpu_baseline") or {}
     if "value" in cb:
-        out["cpu_baseline"] = _pick(cb, "value", "unit", "cores", "kind", "sample", "cpu", "logical_cpus", "usable_cpus")
+        out["cpu_baseline"] = _pick(cb, "value", "unit", "cores", "kind", "sample", "logical_cpus", "usable_cpus")
+        if isinstance(out["cpu_baseline"].get("sample"), str):  # the whole sentence (and the CPU's name) stay in the full record
+            out["cpu_baseline"]["sample"] = out["cpu_baseline"]["sample"][:110]
         out["gpu_over_cpu"] = _r(full["value"] / cb["value"])
     elif cb:
         out["cpu_baseline"] = cb                      # {"error": ...}
@@ -1440,8 +1442,8 @@ def compact_line(full: dict) -> dict:
                           ("pq_encode", "a12 pq.Encode"), ("pq_build_table", "a13 pq.BuildDistanceTable"),
                           ("rerank", "f1 Segment.Rerank"), ("brute_q1", "a17 hnsw.BruteSearch, 1 query"),
                           ("brute_q256", "a17 hnsw.BruteSearch, 256 queries"),
-                          ("flat_filtered", "beyond s8: flat.Segment.Search with a filter, 1024 queries"),
-                          ("sq8_batch", "f3 sq8 batch, 1024 queries (bf16 nomination)")):
+                          ("flat_filtered", "flat search, a filter per query, 1024 queries"),
+                          ("sq8_batch", "f3 sq8 batch, 1024 queries")):
             e = bs.get(key)
             if isinstance(e, dict):
                 row(name, {**e, "workload": e.get("short", e.get("workload"))}, bound=e.get("bound"),
