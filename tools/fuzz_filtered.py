@@ -95,6 +95,8 @@ while time.time() < t_end:
                 sq = vg.ScalarQuantizer(ctx, dim); sq.train(x)
                 codes = np.asarray(sq.encode(x))
                 idx.set_sq8_codes(sq, codes)
+                nominate = bool(rng.integers(0, 2))      # the bf16 nomination (dim % 64 == 0, 16 queries up) or the scans
+                idx.enable_sq8_nomination(nominate)
                 keep_alive.append(sq)
                 kw = dict(sq=ref, codes=codes)
                 scan = idx.SCAN_SQ8
@@ -108,7 +110,8 @@ while time.time() < t_end:
             k = int(rng.choice([1, 10, 48, 64, 65, 200]))
             nprobes = int(rng.choice([0, 1, 2, max(parts, 1)]))
             mask, keep, per_query = make_mask(nq, n)
-            cfg = dict(n=n, dim=dim, metric=metric, parts=parts, nq=nq, k=k, nprobes=nprobes, keep=keep, per_query=per_query)
+            cfg = dict(n=n, dim=dim, metric=metric, parts=parts, nq=nq, k=k, nprobes=nprobes, keep=keep, per_query=per_query,
+                       nominate=(which == "flat_sq8" and nominate))
             ids, sc = idx.search_flat_filtered(q, k, mask, nprobes, scan=scan)
             for qi in sorted(set([0, nq // 2, nq - 1])):
                 mi = mask[qi] if per_query else mask
