@@ -230,3 +230,24 @@ def test_probed_scans_page_beyond_64_results(vg, ctx, scan_name):
     for q, nprobes, k in ((few, 2, 100), (many, 3, 200), (few, parts, 512)):
         ids, sc = idx.search_flat_probed(q, k, nprobes, scan=scan)
         check(ids[:5], sc[:5], seg, q[:5], k, nprobes)
+
+
+def test_probed_fp32_batches_with_the_bf16_filter(vg, ctx):
+    """vg_index_enable_bf16_filter on a partitioned segment: the grouped nomination runs on the bfloat16 copy of the rows, the exact
+    re-score and the widened proof keep ids and scores — equal to the search without the filter and to the oracle"""
+    rng = np.random.default_rng(91)
+    n, dim, parts, nq = 14000, 64, 6, 150
+    x, cent, off = partitioned(rng, n, dim, parts)
+    x[300:306] = x[300]
+    idx = vg.Index(ctx, n, dim)
+    idx.set_vectors(x)
+    idx.set_partitions(cent, off)
+    seg = o.FlatSegment(x, dim, centroids=cent, part_offsets=off)
+    q = rng.standard_normal((nq, dim)).astype(np.float32)
+    q[5] = x[300]
+    plain = [idx.search_flat_probed(q, 10, np_, scan=idx.SCAN_F32) for np_ in (2, parts)]
+    idx.enable_bf16_filter(True)
+    filt = [idx.search_flat_probed(q, 10, np_, scan=idx.SCAN_F32) for np_ in (2, parts)]
+    for a, b in zip(plain, filt):
+        assert np.array_equal(a[0], b[0]) and np.array_equal(bits(a[1]), bits(b[1]))
+    check(filt[0][0][:8], filt[0][1][:8], seg, q[:8], 10, 2)

@@ -929,7 +929,11 @@ int32_t flat_probe_gemm(vg_index *idx, const float *pair_queries, int64_t pairs,
     const bool dot = idx->metric != VG_METRIC_L2;
     const int dim = idx->dim;
     const int kc = 64, cap = kProbeGemmCap, sel_k = 8;
+    // (rows_bf16 == idx->d_vectors_bf16: the fp32 rows' own bf16 filter, vg_index_enable_bf16_filter — the nomination runs on it,
+    // the re-score and the proof below stay, the proof's margin widened as in vg_search_flat)
     const bool bf16 = rows_bf16 != nullptr;
+    const bool own_filter = bf16 && rows_bf16 == idx->d_vectors_bf16;
+    const float *const queries_f32 = pair_queries;
     const ProbeGemmLayout l = probe_gemm_layout(pairs, ns_max, bf16 ? idx->dim : 0);
     const int sel_slices = l.sel_slices;
     const float *grows = idx->d_vectors, *gnorms = idx->d_norms;
@@ -991,7 +995,7 @@ int32_t flat_probe_gemm(vg_index *idx, const float *pair_queries, int64_t pairs,
     }
     // (c) the kc best of them, (d) re-scored exactly, the k best, and the proof against everything not nominated
     VG_LAUNCH(flat_pick_kernel, dim3(upairs), dim3(256), 0, st, cand, counts, cap, kc, cand_id, cand_sc);
-    if (bf16) {
+    if (bf16 && !own_filter) {
         nominated->thr = thr;
         nominated->counts = counts;
         nominated->cand_id = cand_id;
@@ -999,12 +1003,13 @@ int32_t flat_probe_gemm(vg_index *idx, const float *pair_queries, int64_t pairs,
         nominated->cap = cap;
         return VG_OK;
     }
+    const float eps_extra = own_filter ? (dot ? 0.00390625f : 0.0078125f) * 1.02f : 0.0f;
     if (dot)
-        VG_LAUNCH(flat_verify_kernel<true>, dim3(upairs), dim3(256), 0, st, idx->d_vectors, idx->n, dim, pair_queries, idx->d_norm_max,
-                  cand_id, cand_sc, kc, k, pair_ids, pair_scores, fail, thr, sel_k, sel_k - 1, counts, cap, 0.0f);
+        VG_LAUNCH(flat_verify_kernel<true>, dim3(upairs), dim3(256), 0, st, idx->d_vectors, idx->n, dim, queries_f32, idx->d_norm_max,
+                  cand_id, cand_sc, kc, k, pair_ids, pair_scores, fail, thr, sel_k, sel_k - 1, counts, cap, eps_extra);
     else
-        VG_LAUNCH(flat_verify_kernel<false>, dim3(upairs), dim3(256), 0, st, idx->d_vectors, idx->n, dim, pair_queries, idx->d_norm_max,
-                  cand_id, cand_sc, kc, k, pair_ids, pair_scores, fail, thr, sel_k, sel_k - 1, counts, cap, 0.0f);
+        VG_LAUNCH(flat_verify_kernel<false>, dim3(upairs), dim3(256), 0, st, idx->d_vectors, idx->n, dim, queries_f32, idx->d_norm_max,
+                  cand_id, cand_sc, kc, k, pair_ids, pair_scores, fail, thr, sel_k, sel_k - 1, counts, cap, eps_extra);
     return VG_OK;
 }
 }  // namespace vg

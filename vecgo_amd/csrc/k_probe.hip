@@ -702,7 +702,9 @@ static int32_t flat_probed_impl(vg_index *idx, const float *queries, int64_t nq,
     const int i_pfail = ar.add(gemm ? sizeof(int) * static_cast<size_t>(pairs) : 0);
     const int i_qfail = ar.add(gemm ? sizeof(int) * static_cast<size_t>(nq) : 0);
     const int i_moff = ar.add(gemm ? sizeof(int64_t) * static_cast<size_t>(pairs) : 0);
-    const int i_gscr = ar.add(gemm ? vg::flat_probe_gemm_scratch_bytes(pairs, ns_max, gemm_sq8 ? idx->dim : 0) : 0);
+    // (fp32 rows with vg_index_enable_bf16_filter: the grouped nomination on that image too)
+    const bool gemm_f32_bf16 = gemm_f32 && idx->d_vectors_bf16 != nullptr && idx->dim % 64 == 0;
+    const int i_gscr = ar.add(gemm ? vg::flat_probe_gemm_scratch_bytes(pairs, ns_max, gemm_sq8 || gemm_f32_bf16 ? idx->dim : 0) : 0);
     VG_TRY(ar.commit());
     uint32_t *probes = ar.get<uint32_t>(i_probes);
     uint64_t *partial = ar.get<uint64_t>(i_partial);
@@ -752,8 +754,9 @@ static int32_t flat_probed_impl(vg_index *idx, const float *queries, int64_t nq,
             const int64_t *const fb[4] = {fbs, fbm, fbss, fbsm};
             vg::ProbeNominated nom{};
             VG_TRY(vg::flat_probe_gemm(idx, pairq, pairs, bgrp, fb, parts, grids, vg::kProbeSampleStride, ns_max, k, pair_ids, pair_sc,
-                                       pfail, ar.get<char>(i_gscr), mk.ptr, moff, st, gemm_sq8 ? idx->d_sq_bf16 : nullptr,
-                                       gemm_sq8 ? idx->d_sq_norms : nullptr, &nom));
+                                       pfail, ar.get<char>(i_gscr), mk.ptr, moff, st,
+                                       gemm_sq8 ? idx->d_sq_bf16 : gemm_f32_bf16 ? idx->d_vectors_bf16 : nullptr,
+                                       gemm_sq8 ? idx->d_sq_norms : gemm_f32_bf16 ? idx->d_norms : nullptr, &nom));
             if (gemm_sq8) VG_TRY(vg::launch_sq8_verify(idx, pairq, pairs, nom, k, pair_ids, pair_sc, pfail, st));
         }
         // lists = np * sub in this configuration; the pairs' k results fill the first np lists' worth of `partial`
