@@ -86,3 +86,19 @@ def test_sharded_flat_index_on_one_rank(vg, ctx):
     ids, sc = idx.search(q, 10)
     want = idx.index.search_flat(q, 10)
     assert torch.equal(ids, want[0]) and torch.equal(sc, want[1])
+
+
+def test_sharded_flat_index_with_a_filter(vg, ctx):
+    """ShardedFlatIndex.search_filtered on one rank = the index's own filtered search (every rank filters its own rows)"""
+    import torch
+    from vecgo_amd import sharded
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev); g.manual_seed(4)
+    rows = torch.randn((6000, 64), device=dev, generator=g)
+    q = torch.randn((20, 64), device=dev, generator=g)
+    mask = (torch.rand((20, 6000), device=dev, generator=g) < 0.3).cpu().numpy()
+    idx = sharded.ShardedFlatIndex(ctx, rows, 64, [0, 6000])
+    ids, sc = idx.search_filtered(q, 10, mask)
+    want = idx.index.search_flat_filtered(q, 10, mask, 0)
+    assert torch.equal(ids, want[0]) and torch.equal(sc, want[1])
+    assert mask[np.arange(20)[:, None], ids.cpu().numpy().astype(np.int64)].all()

@@ -139,6 +139,19 @@ class ShardedFlatIndex:
         return sharded_search(local, merge, queries, k, self.bounds, self.group, comm=self.comm, metric=self.metric,
                               stream=stream)
 
+    def search_filtered(self, queries, k: int, local_mask, stream=None):
+        """flat.Segment.Search with a row filter over the sharded corpus: every rank passes the filter bits of ITS rows
+        (bool[n_local] / packed bits, one for the batch or one per query); the fan-in is the unfiltered one."""
+        def local(q, kk, out):
+            return self.index.search_flat_filtered(q, kk, local_mask, 0, out=out, stream=stream)
+
+        def merge(packed, kk, off):
+            lists, _, nq, _ = packed.shape
+            return self._api.merge_topk_packed(self.ctx, packed, lists, nq, kk, metric=self.metric, id_offsets=off,
+                                               stream=stream)
+        return sharded_search(local, merge, queries, k, self.bounds, self.group, comm=self.comm, metric=self.metric,
+                              stream=stream)
+
 
 def train_pq_sharded(pq, vectors, iters: int = 20, seed: int = 1, group=None, device=None, stream=None, comm=None):
     """PQ training partitioned by sub-quantizer (BASELINE configs[4]; pq.go:83-138 runs the m
