@@ -251,3 +251,39 @@ def test_probed_fp32_batches_with_the_bf16_filter(vg, ctx):
     for a, b in zip(plain, filt):
         assert np.array_equal(a[0], b[0]) and np.array_equal(bits(a[1]), bits(b[1]))
     check(filt[0][0][:8], filt[0][1][:8], seg, q[:8], 10, 2)
+
+
+@pytest.mark.parametrize("metric", [0, 2])
+def test_probed_fp32_batches_with_k_beyond_the_64_candidate_budget(vg, ctx, metric):
+    """the grouped nomination for 48 < k <= 160: a deeper threshold per (query, probe) pair, EVERY row below it re-scored
+    (flat_verify_all / _sort), flagged queries searched again as a subset — ids and score bits of the oracle, duplicates (ties at
+    the k-th place), a filter per query, and partitions smaller than the threshold's sample included"""
+    rng = np.random.default_rng(130 + metric)
+    n, dim, parts, nq = 16000, 64, 6, 160
+    x, cent, off = partitioned(rng, n, dim, parts, metric)
+    x[300:420] = x[300]                                # 120 equal rows: a tie across the k-th place for one query
+    idx = vg.Index(ctx, n, dim, vg.Metric(metric))
+    idx.set_vectors(x)
+    idx.set_partitions(cent, off)
+    seg = o.FlatSegment(x, dim, metric=metric, centroids=cent, part_offsets=off)
+    q = rng.standard_normal((nq, dim)).astype(np.float32)
+    q[5] = x[300]
+    masks = rng.random((nq, n)) < 0.5
+    for k in (49, 64, 100, 160):
+        for nprobes in (2, parts):
+            ids, sc = idx.search_flat_probed(q, k, nprobes, scan=idx.SCAN_F32)
+            check(ids[:8], sc[:8], seg, q[:8], k, nprobes)
+            check(ids[-2:], sc[-2:], seg, q[-2:], k, nprobes)
+        ids, sc = idx.search_flat_filtered(q, k, masks, 2, scan=idx.SCAN_F32)
+        for i in (0, 5, nq - 1):
+            eid, esc = seg.search(q[i], k, 2, mask=masks[i])
+            assert np.array_equal(ids[i, :eid.size], eid) and np.array_equal(bits(sc[i, :eid.size]), bits(esc))
+    # small partitions: the sample holds fewer rows than thresholds are kept, every row passes
+    n2, parts2 = 3000, 5
+    x2, cent2, off2 = partitioned(rng, n2, dim, parts2, metric)
+    idx2 = vg.Index(ctx, n2, dim, vg.Metric(metric))
+    idx2.set_vectors(x2)
+    idx2.set_partitions(cent2, off2)
+    seg2 = o.FlatSegment(x2, dim, metric=metric, centroids=cent2, part_offsets=off2)
+    ids, sc = idx2.search_flat_probed(q, 100, 3, scan=idx2.SCAN_F32)
+    check(ids[:6], sc[:6], seg2, q[:6], 100, 3)

@@ -250,3 +250,51 @@ def test_probed_batches_through_the_grouped_nomination(vg, ctx, metric):
         for got, np_, m in ((res[True][0], 2, None), (res[True][1], parts, None), (res[True][2], 2, masks[i]), (res[True][3], 2, masks[0])):
             eid, esc = seg.search(q[i], k, np_, mask=m)
             assert np.array_equal(got[0][i, :eid.size], eid) and np.array_equal(bits(got[1][i, :eid.size]), bits(esc))
+
+
+@pytest.mark.parametrize("metric", [0, 2])
+def test_nomination_with_k_beyond_the_64_candidate_budget(vg, ctx, metric):
+    """48 < k <= 256 over the whole segment, up to 160 over probed partitions: every row below the (deeper) threshold is re-scored
+    from the codes and sorted (sq8_verify_sort_kernel) — nomination on = off = the oracle, ties across the k-th place and
+    filters included"""
+    from tests.test_gpu_probe import partitioned
+    rng = np.random.default_rng(170 + metric)
+    n, dim, parts, nq = 16000, 64, 6, 130
+    x, cent, off = partitioned(rng, n, dim, parts, metric)
+    x[200:330] = x[200]
+    sq = vg.ScalarQuantizer(ctx, dim); sq.train(x)
+    ref = o.ScalarQuantizer(dim); ref.train(x)
+    codes = sq.encode(x)
+    flat = vg.Index(ctx, n, dim, vg.Metric(metric))    # one range; and the same rows partitioned
+    flat.set_sq8_codes(sq, codes)
+    idx = vg.Index(ctx, n, dim, vg.Metric(metric))
+    idx.set_sq8_codes(sq, codes)
+    idx.set_partitions(cent, off)
+    whole = o.FlatSegment(x, dim, metric=metric, sq=ref, codes=codes)
+    seg = o.FlatSegment(x, dim, metric=metric, sq=ref, codes=codes, centroids=cent, part_offsets=off)
+    q = rng.standard_normal((nq, dim)).astype(np.float32)
+    q[3] = x[200]
+    masks = rng.random((nq, n)) < 0.4
+
+    def run(k):
+        out = [flat.search_sq8(q, k), flat.search_flat_filtered(q, k, masks, 0, scan=flat.SCAN_SQ8)]
+        if k <= 160:
+            out += [idx.search_flat_probed(q, k, 2, scan=idx.SCAN_SQ8), idx.search_flat_filtered(q, k, masks[0], parts, scan=idx.SCAN_SQ8)]
+        return out
+
+    for k in (49, 100, 160, 256):
+        for ix in (flat, idx):
+            ix.enable_sq8_nomination(False)
+        plain = run(k)
+        for ix in (flat, idx):
+            ix.enable_sq8_nomination(True)
+        nom = run(k)
+        for a, b in zip(plain, nom):
+            assert np.array_equal(a[0], b[0]) and np.array_equal(bits(a[1]), bits(b[1])), k
+        for i in (0, 3, nq - 1):
+            cases = [(nom[0], whole, 0, None), (nom[1], whole, 0, masks[i])]
+            if k <= 160:
+                cases += [(nom[2], seg, 2, None), (nom[3], seg, parts, masks[0])]
+            for got, s, np_, m in cases:
+                eid, esc = s.search(q[i], k, np_, mask=m)
+                assert np.array_equal(got[0][i, :eid.size], eid) and np.array_equal(bits(got[1][i, :eid.size]), bits(esc)), (k, i, np_)

@@ -874,13 +874,11 @@ int32_t vg::flat_search_masked(vg_index *idx, const float *queries, int64_t nq, 
 // = its partition's k best rows by (score, row id) with exact scores, and fail[pair] = 1 where the proof does not hold (the caller
 // answers those queries with the exact probe kernels).  k <= kGemmMaxK; fp32 rows, dim % 4 == 0, 16-byte aligned.
 namespace vg {
-struct ProbeNominated {  // where flat_probe_gemm left the nomination when the caller re-scores (rows_bf16 form)
-    float *thr;
-    int *counts;
-    uint32_t *cand_id;
-    float *cand_sc;
-    int cap;
-};
+// thresholds kept per pair: the 8th best of the 1/8 row sample passes ~64 rows — enough for the 64-candidate re-score (k <= 48);
+// a larger k re-scores everything that passed and wants ~3k of them — ~5k under a bfloat16 nomination, whose proof needs the
+// threshold 2^-7 (|q|^2 + |x|^2) above the k-th score: at 3k, random-normal rows of dim 768 in partitions of 8192 failed the
+// proof for about every other query of 8 probes (the rank of a sampled threshold varies by 1 / sqrt(sel_k))
+int probe_gemm_sel_k(int k, bool bf16) { return k <= kGemmMaxK ? 8 : std::min(64, std::max(8, ((bf16 ? 5 : 3) * k + 7) / 8)); }
 // candidate keys per pair: ~64 rows fall below a pair's threshold (8th best of 1/8 of its partition); 2048 leaves 30x, and a
 // batch of 65535 pairs holds 1 GiB of them (4096, the flat search's, would be 2)
 constexpr int kProbeGemmCap = 2048;
@@ -889,9 +887,10 @@ struct ProbeGemmLayout {
     size_t sc, partial, sid, thr, counts, cand, cid, csc, qbf, total;
     int sel_slices;
 };
-static ProbeGemmLayout probe_gemm_layout(int64_t pairs, int64_t ns_max, int dim = 0 /* > 0: room for the pairs' queries in bfloat16 */)
+static ProbeGemmLayout probe_gemm_layout(int64_t pairs, int64_t ns_max, int k, int dim = 0 /* > 0: room for the pairs' queries in bfloat16 */)
 {
-    constexpr int kc = 64, cap = kProbeGemmCap, sel_k = 8;
+    constexpr int kc = 64, cap = kProbeGemmCap;
+    const int sel_k = probe_gemm_sel_k(k, dim > 0);
     ProbeGemmLayout l;
     l.sel_slices = static_cast<int>(std::min<int64_t>(8, std::max<int64_t>(1, ns_max / 1024)));
     size_t at = 0;
@@ -912,7 +911,7 @@ static ProbeGemmLayout probe_gemm_layout(int64_t pairs, int64_t ns_max, int dim 
     l.total = at;
     return l;
 }
-size_t flat_probe_gemm_scratch_bytes(int64_t pairs, int64_t ns_max, int bf16_dim) { return probe_gemm_layout(pairs, ns_max, bf16_dim).total; }
+size_t flat_probe_gemm_scratch_bytes(int64_t pairs, int64_t ns_max, int k, int bf16_dim) { return probe_gemm_layout(pairs, ns_max, k, bf16_dim).total; }
 
 int32_t flat_probe_gemm(vg_index *idx, const float *pair_queries, int64_t pairs, const GemmGroup *groups, const int64_t *const first_block[4],
                         int ngroups, const int64_t grid[4], int sample_stride, int64_t ns_max, int k, uint32_t *pair_ids,
@@ -928,13 +927,13 @@ int32_t flat_probe_gemm(vg_index *idx, const float *pair_queries, int64_t pairs,
     // row tile, HBM-bound — a 128-query tile would spend the matrix cores on padding)
     const bool dot = idx->metric != VG_METRIC_L2;
     const int dim = idx->dim;
-    const int kc = 64, cap = kProbeGemmCap, sel_k = 8;
     // (rows_bf16 == idx->d_vectors_bf16: the fp32 rows' own bf16 filter, vg_index_enable_bf16_filter — the nomination runs on it,
     // the re-score and the proof below stay, the proof's margin widened as in vg_search_flat)
     const bool bf16 = rows_bf16 != nullptr;
+    const int kc = 64, cap = kProbeGemmCap, sel_k = probe_gemm_sel_k(k, bf16);
     const bool own_filter = bf16 && rows_bf16 == idx->d_vectors_bf16;
     const float *const queries_f32 = pair_queries;
-    const ProbeGemmLayout l = probe_gemm_layout(pairs, ns_max, bf16 ? idx->dim : 0);
+    const ProbeGemmLayout l = probe_gemm_layout(pairs, ns_max, k, bf16 ? idx->dim : 0);
     const int sel_slices = l.sel_slices;
     const float *grows = idx->d_vectors, *gnorms = idx->d_norms;
     int gdim = idx->dim;
@@ -994,17 +993,28 @@ int32_t flat_probe_gemm(vg_index *idx, const float *pair_queries, int64_t pairs,
                       pair_queries, grows, gdim, gnorms, nullptr, 1, 0, thr, sel_k, sel_k - 1, counts, cand, cap, mask, mask_off);
     }
     // (c) the kc best of them, (d) re-scored exactly, the k best, and the proof against everything not nominated
-    VG_LAUNCH(flat_pick_kernel, dim3(upairs), dim3(256), 0, st, cand, counts, cap, kc, cand_id, cand_sc);
+    // (k > kGemmMaxK: every appended row is re-scored — flat_verify_all / _sort, as in vg_search_flat)
+    if (k <= kGemmMaxK) VG_LAUNCH(flat_pick_kernel, dim3(upairs), dim3(256), 0, st, cand, counts, cap, kc, cand_id, cand_sc);
     if (bf16 && !own_filter) {
         nominated->thr = thr;
         nominated->counts = counts;
         nominated->cand_id = cand_id;
         nominated->cand_sc = cand_sc;
         nominated->cap = cap;
+        nominated->sel_k = sel_k;
+        nominated->cand = cand;
         return VG_OK;
     }
     const float eps_extra = own_filter ? (dot ? 0.00390625f : 0.0078125f) * 1.02f : 0.0f;
-    if (dot)
+    if (k > 64) {
+        auto vk = dot ? flat_verify_sort_kernel<true> : flat_verify_sort_kernel<false>;
+        VG_LAUNCH(vk, dim3(upairs), dim3(256), sizeof(uint64_t) * static_cast<size_t>(cap), st, idx->d_vectors, dim, queries_f32,
+                  idx->d_norm_max, cand, counts, cap, k, pair_ids, pair_scores, fail, thr, sel_k, sel_k - 1, eps_extra);
+    } else if (k > kGemmMaxK) {
+        auto vk = dot ? flat_verify_all_kernel<true> : flat_verify_all_kernel<false>;
+        VG_LAUNCH(vk, dim3(upairs), dim3(256), 0, st, idx->d_vectors, dim, queries_f32, idx->d_norm_max, cand, counts, cap, k, pair_ids,
+                  pair_scores, fail, thr, sel_k, sel_k - 1, eps_extra);
+    } else if (dot)
         VG_LAUNCH(flat_verify_kernel<true>, dim3(upairs), dim3(256), 0, st, idx->d_vectors, idx->n, dim, queries_f32, idx->d_norm_max,
                   cand_id, cand_sc, kc, k, pair_ids, pair_scores, fail, thr, sel_k, sel_k - 1, counts, cap, eps_extra);
     else
@@ -1018,15 +1028,15 @@ int32_t flat_probe_gemm(vg_index *idx, const float *pair_queries, int64_t pairs,
 // bf16 MFMA GEMM appending what falls below them, the kc best per query — for a caller that re-scores and proves with its own
 // exact distance (the SQ8 batch search, k_sq8.hip: rows = the dequantised codes rounded to bfloat16, norms = |x^|^2).  L2 scores.
 // queries: cnt x dim fp32 (device, 16-byte aligned), dim % 64 == 0, cnt <= 4096.  Outputs (device, caller's):
-// thr[cnt * 8] (the threshold is entry 7 of a query's 8), counts[cnt], cand_id / cand_sc[cnt * 64] ascending.
+// thr[cnt * sel_k] (the threshold is a query's last entry), counts[cnt], cand_id / cand_sc[cnt * 64] ascending (pick only).
 namespace vg {
-constexpr int kNomSelK = 8, kNomKc = 64, kNomCap = 4096, kNomStride = 64;
+constexpr int kNomKc = 64, kNomCap = 4096, kNomStride = 64;
 struct NominateLayout {
     size_t qbf, sc, partial, sid, cand, total;
     int sel_slices;
     int64_t ns;
 };
-static NominateLayout nominate_layout(int64_t cnt, int64_t n, int dim)
+static NominateLayout nominate_layout(int64_t cnt, int64_t n, int dim, int sel_k)
 {
     NominateLayout l;
     const int64_t nt = (n + kGemmBN - 1) / kGemmBN, nst = (nt + kNomStride - 1) / kNomStride;
@@ -1040,21 +1050,23 @@ static NominateLayout nominate_layout(int64_t cnt, int64_t n, int dim)
     };
     l.qbf = piece(sizeof(uint16_t) * static_cast<size_t>(cnt) * dim);
     l.sc = piece(sizeof(float) * static_cast<size_t>(cnt) * l.ns);
-    l.partial = piece(sizeof(uint64_t) * static_cast<size_t>(cnt) * l.sel_slices * kNomSelK);
-    l.sid = piece(sizeof(uint32_t) * static_cast<size_t>(cnt) * kNomSelK);
+    l.partial = piece(sizeof(uint64_t) * static_cast<size_t>(cnt) * l.sel_slices * sel_k);
+    l.sid = piece(sizeof(uint32_t) * static_cast<size_t>(cnt) * sel_k);
     l.cand = piece(sizeof(uint64_t) * static_cast<size_t>(cnt) * kNomCap);
     l.total = at;
     return l;
 }
-size_t flat_nominate_bf16_scratch(int64_t cnt, int64_t n, int dim) { return nominate_layout(cnt, n, dim).total; }
+size_t flat_nominate_bf16_scratch(int64_t cnt, int64_t n, int dim, int sel_k) { return nominate_layout(cnt, n, dim, sel_k).total; }
 
 int32_t flat_nominate_bf16(vg_ctx *ctx, const uint16_t *rows_bf16, const float *norms, int64_t n, int dim, const float *queries,
                            int64_t cnt, char *scratch, float *thr, int *counts, uint32_t *cand_id, float *cand_sc, hipStream_t st,
-                           bool dot, const uint8_t *mask, int64_t mask_stride)
+                           bool dot, const uint8_t *mask, int64_t mask_stride, int sel_k, bool pick, const uint64_t **cand_keys, int *cap)
 {
     // dot: scores are -q.x (the largest dot products first); mask: a row filter per query (mask + q * mask_stride) or for the
     // batch (stride 0) — rejected rows are left out of the sample and of the candidates, as in flat_search_masked
-    const NominateLayout l = nominate_layout(cnt, n, dim);
+    // sel_k: thresholds kept per query (thr[cnt * sel_k], the last is the query's: ~64 * sel_k rows pass it); pick: the 64 best
+    // appended rows into cand_id / cand_sc; *cand_keys / *cap: every appended key, cap per query (in `scratch`)
+    const NominateLayout l = nominate_layout(cnt, n, dim, sel_k);
     uint16_t *qbf = reinterpret_cast<uint16_t *>(scratch + l.qbf);
     float *sc = reinterpret_cast<float *>(scratch + l.sc);
     uint64_t *partial = reinterpret_cast<uint64_t *>(scratch + l.partial), *cand = reinterpret_cast<uint64_t *>(scratch + l.cand);
@@ -1067,19 +1079,21 @@ int32_t flat_nominate_bf16(vg_ctx *ctx, const uint16_t *rows_bf16, const float *
         VG_TRY(launch_gemm<1>(dot, true, static_cast<unsigned>(mt * ((nst + 7) / 8) * 8), st,
                               {ga, cnt, gb, n, gdim, norms, sc, kNomStride, l.ns, nullptr, 0, 0, nullptr, nullptr, 0, mask, mask_stride}, true));
         VG_LAUNCH(flat_select_kernel, dim3(l.sel_slices, static_cast<unsigned>(cnt)), dim3(kSelThreads), 0, st, sc, l.ns, l.sel_slices,
-                  kNomSelK, partial);
-        VG_TRY(launch_topk_merge(partial, cnt, l.sel_slices, kNomSelK, false, sid, thr, st));
+                  sel_k, partial);
+        VG_TRY(launch_topk_merge(partial, cnt, l.sel_slices, sel_k, false, sid, thr, st));
     } else {
-        VG_LAUNCH(fill_f32_kernel, dim3(static_cast<unsigned>((cnt * kNomSelK + 255) / 256)), dim3(256), 0, st, thr, cnt * kNomSelK, INFINITY);
+        VG_LAUNCH(fill_f32_kernel, dim3(static_cast<unsigned>((cnt * sel_k + 255) / 256)), dim3(256), 0, st, thr, cnt * sel_k, INFINITY);
     }
     VG_HIP(hipMemsetAsync(counts, 0, sizeof(int) * static_cast<size_t>(cnt), st));
     {
         ProfScope prof(ctx, "sq8_nominate_gemm", st);
         VG_TRY(launch_gemm<2>(dot, true, static_cast<unsigned>(mt * ((nt + 7) / 8) * 8), st,
-                              {ga, cnt, gb, n, gdim, norms, nullptr, 1, 0, thr, kNomSelK, kNomSelK - 1, counts, cand, kNomCap, mask, mask_stride},
+                              {ga, cnt, gb, n, gdim, norms, nullptr, 1, 0, thr, sel_k, sel_k - 1, counts, cand, kNomCap, mask, mask_stride},
                               true));
     }
-    VG_LAUNCH(flat_pick_kernel, dim3(static_cast<unsigned>(cnt)), dim3(256), 0, st, cand, counts, kNomCap, kNomKc, cand_id, cand_sc);
+    if (pick) VG_LAUNCH(flat_pick_kernel, dim3(static_cast<unsigned>(cnt)), dim3(256), 0, st, cand, counts, kNomCap, kNomKc, cand_id, cand_sc);
+    *cand_keys = cand;
+    *cap = kNomCap;
     return VG_OK;
 }
 }  // namespace vg

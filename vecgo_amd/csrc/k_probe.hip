@@ -35,14 +35,7 @@ int32_t flat_search_masked(vg_index *idx, const float *queries, int64_t nq, int3
                            uint32_t *ids, float *scores, void *stream, bool l2_scores = false);
 int32_t pq_adc_search_masked(vg_index *idx, const float *queries, int64_t nq, int32_t k, const uint8_t *mask, int64_t mask_stride,
                              bool desc, uint32_t *ids, float *scores, void *stream);
-struct ProbeNominated {
-    float *thr;
-    int *counts;
-    uint32_t *cand_id;
-    float *cand_sc;
-    int cap;
-};
-size_t flat_probe_gemm_scratch_bytes(int64_t pairs, int64_t ns_max, int bf16_dim);
+size_t flat_probe_gemm_scratch_bytes(int64_t pairs, int64_t ns_max, int k, int bf16_dim);
 int32_t launch_sq8_verify(vg_index *idx, const float *queries, int64_t nq, const ProbeNominated &nom, int k, uint32_t *ids, float *scores,
                           int *fail, hipStream_t st);
 int32_t flat_probe_gemm(vg_index *idx, const float *pair_queries, int64_t pairs, const GemmGroup *groups, const int64_t *const first_block[4],
@@ -650,7 +643,9 @@ static int32_t flat_probed_impl(vg_index *idx, const float *queries, int64_t nq,
     const bool paged = k > 64;
     const int pk = paged ? 64 : k;
     const int i_probes = ar.add(sizeof(uint32_t) * static_cast<size_t>(nq) * np);
-    const int i_partial = ar.add(sizeof(uint64_t) * static_cast<size_t>(nq) * lists * pk);
+    // (the grouped nomination leaves k keys per pair there, also when k is paged for the scan kernels)
+    const size_t partial_keys = std::max(static_cast<size_t>(nq) * lists * pk, whole || k > vg::kProbeGemmMaxK ? size_t(0) : static_cast<size_t>(pairs) * k);
+    const int i_partial = ar.add(sizeof(uint64_t) * partial_keys);
     const int i_pid = ar.add(paged ? sizeof(uint32_t) * static_cast<size_t>(nq) * pk : 0);
     const int i_psc = ar.add(paged ? sizeof(float) * static_cast<size_t>(nq) * pk : 0);
     const int i_floor = ar.add(paged ? sizeof(uint64_t) * static_cast<size_t>(nq) : 0);
@@ -661,7 +656,10 @@ static int32_t flat_probed_impl(vg_index *idx, const float *queries, int64_t nq,
     // (1M x 768 in 122 partitions, 1024 queries, ms per call, exact kernels -> this: nprobes 1 (8 per partition) 1.21 -> 1.18,
     // 2: 2.1 -> 1.4, 4: 3.75 -> 1.3, 8: 7.25 -> 2.3, 16: 11.6 -> 4.5, 32: 21.0 -> 7.0; tools/probe_gemm_time.py)
     // (a filtered batch too: a pair's filter is its query's — probe_gather_queries_kernel notes where each starts)
-    const bool gemm_shape = !whole && k <= 48 && idx->dim % 4 == 0 && pairs <= 65535 && pairs >= 12 * static_cast<int64_t>(parts) &&
+    // (k <= 48: the pairs' 64 best nominees re-scored; up to kProbeGemmMaxK: everything below a deeper threshold re-scored, and the
+    // flagged queries — normally none — searched again as a subset, the scan kernels' k > 64 being paged)
+    const bool gemm_shape = !whole && k <= vg::kProbeGemmMaxK && (k <= 64 || allow_nomination) && idx->dim % 4 == 0 && pairs <= 65535 &&
+                            pairs >= 12 * static_cast<int64_t>(parts) &&
                             (reinterpret_cast<uintptr_t>(q.ptr) & 15) == 0 && static_cast<int>(idx->h_part_off.size()) == parts + 1 &&
                             !vg::hook(vg::kHookProbeNoGroup) && !vg::hook(vg::kHookProbeNoGemm);
     const bool gemm_f32 = scan == VG_SCAN_F32 && gemm_shape && (reinterpret_cast<uintptr_t>(idx->d_vectors) & 15) == 0;
@@ -704,7 +702,7 @@ static int32_t flat_probed_impl(vg_index *idx, const float *queries, int64_t nq,
     const int i_moff = ar.add(gemm ? sizeof(int64_t) * static_cast<size_t>(pairs) : 0);
     // (fp32 rows with vg_index_enable_bf16_filter: the grouped nomination on that image too)
     const bool gemm_f32_bf16 = gemm_f32 && idx->d_vectors_bf16 != nullptr && idx->dim % 64 == 0;
-    const int i_gscr = ar.add(gemm ? vg::flat_probe_gemm_scratch_bytes(pairs, ns_max, gemm_sq8 || gemm_f32_bf16 ? idx->dim : 0) : 0);
+    const int i_gscr = ar.add(gemm ? vg::flat_probe_gemm_scratch_bytes(pairs, ns_max, k, gemm_sq8 || gemm_f32_bf16 ? idx->dim : 0) : 0);
     VG_TRY(ar.commit());
     uint32_t *probes = ar.get<uint32_t>(i_probes);
     uint64_t *partial = ar.get<uint64_t>(i_partial);
@@ -763,7 +761,7 @@ static int32_t flat_probed_impl(vg_index *idx, const float *queries, int64_t nq,
         VG_LAUNCH(vg::probe_pack_kernel, dim3(static_cast<unsigned>(pairs)), dim3(64), 0, st, bpair, pair_ids, pair_sc, pfail, k, np, desc,
                   partial, qfail);
         VG_TRY(vg::launch_topk_merge(partial, nq, np, k, desc, oid.ptr, osc.ptr, st));
-        if (gemm_sq8) {  // the flagged queries (normally none) go through the scan kernels: read the flags, search that subset
+        if (gemm_sq8 || k > 64) {  // the flagged queries (normally none) go through the scan kernels: read the flags, search that subset
             std::vector<int> hq(static_cast<size_t>(nq));
             VG_HIP(hipMemcpyAsync(hq.data(), qfail, sizeof(int) * static_cast<size_t>(nq), hipMemcpyDeviceToHost, st));
             VG_HIP(hipStreamSynchronize(st));

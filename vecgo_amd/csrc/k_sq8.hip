@@ -1535,10 +1535,16 @@ VG_API int32_t vg_sq8_l2_distance_batch(vg_sq8 *sq, const float *query, const ui
 // outside them can enter the k best: outside rows have GEMM score >= tau, and |GEMM score + |q|^2 - L2Distance| <= eps (bfloat16
 // rounding of both operands, fp32 accumulation, the reference's own rounding).  A query whose proof fails is scanned as before.
 namespace vg {
-size_t flat_nominate_bf16_scratch(int64_t cnt, int64_t n, int dim);
+size_t flat_nominate_bf16_scratch(int64_t cnt, int64_t n, int dim, int sel_k);
 int32_t flat_nominate_bf16(vg_ctx *ctx, const uint16_t *rows_bf16, const float *norms, int64_t n, int dim, const float *queries,
                            int64_t cnt, char *scratch, float *thr, int *counts, uint32_t *cand_id, float *cand_sc, hipStream_t st,
-                           bool dot, const uint8_t *mask, int64_t mask_stride);
+                           bool dot, const uint8_t *mask, int64_t mask_stride, int sel_k, bool pick, const uint64_t **cand_keys, int *cap);
+// k <= 48: the 64 best nominees are re-scored (sq8_verify_kernel); up to 256: everything below the threshold
+// (sq8_verify_sort_kernel) — the 8th best of the 1/64 row sample passes ~512 rows, the 16th ~1024, the 32nd ~2048.  (The proof
+// wants the threshold 2^-7 (|q|^2 + |x^|^2) above the k-th score: ~512 rows for k = 100 left enough queries to the scan — random-
+// normal rows, 1M x 768 — that the batch took 8.3 ms, ~1024 rows 3 ms.)
+constexpr int kSq8PickMaxK = 48, kSq8NomMaxK = 256;
+static int sq8_nominate_sel_k(int k) { return k <= kSq8PickMaxK ? 8 : k <= 128 ? 16 : 32; }
 
 __device__ __forceinline__ uint16_t sq8_bf16_rne(float x)
 {
@@ -1597,7 +1603,7 @@ __global__ __launch_bounds__(64) void sq8_verify_kernel(const uint4 *__restrict_
                                                         const float *__restrict__ norm_max, const uint32_t *__restrict__ cand_ids,
                                                         const float *__restrict__ cand_scores, int k, uint32_t *__restrict__ ids,
                                                         float *__restrict__ scores, int *__restrict__ fail, const float *__restrict__ thr,
-                                                        const int *__restrict__ counts, int cap)
+                                                        const int *__restrict__ counts, int cap, int thr_stride)
 {
     constexpr int kc = 64;
     const int64_t q = blockIdx.x;
@@ -1617,7 +1623,7 @@ __global__ __launch_bounds__(64) void sq8_verify_kernel(const uint4 *__restrict_
     for (int j = lane; j < dim; j += 64) qn = __builtin_fmaf(qv[j], qv[j], qn);
     for (int off = 32; off > 0; off >>= 1) qn += __shfl_xor(qn, off);
     const uint64_t kth = readlane_u64(tk.list, k - 1);
-    const float tq = thr[q * 8 + 7];
+    const float tq = thr[q * thr_stride + (thr_stride - 1)];
     const int cnt = counts[q];
     bool ok = cnt <= cap;  // overflow: rows below the threshold were dropped
     const float tau = cnt > kc ? fminf(tq, cand_scores[q * kc + (kc - 1)]) : tq;
@@ -1638,6 +1644,59 @@ __global__ __launch_bounds__(64) void sq8_verify_kernel(const uint4 *__restrict_
         const uint64_t e = tk.list;
         ids[q * k + lane] = e == kKeyMax ? VG_INVALID_ID : key_row(e);
         scores[q * k + lane] = e == kKeyMax ? (DOT ? -INFINITY : INFINITY) : key_score(e, DOT);
+    }
+    if (lane == 0) fail[q] = ok ? 0 : 1;
+}
+
+// The same for k beyond the 64-candidate budget (flat_verify_sort_kernel's counterpart): EVERY appended row is re-scored from
+// the codes — one lane per row — and sorted; what is left to argue about is what the threshold excluded, so the proof compares
+// the k-th exact score with the threshold itself.  Dynamic LDS: cap keys.
+template <bool DOT>
+__global__ __launch_bounds__(256) void sq8_verify_sort_kernel(const uint4 *__restrict__ tiles, int groups, int dim, const float *__restrict__ mins,
+                                                              const float *__restrict__ inv, const float *__restrict__ queries,
+                                                              const float *__restrict__ norm_max, const uint64_t *__restrict__ cand,
+                                                              const int *__restrict__ counts, int cap, int k, uint32_t *__restrict__ ids,
+                                                              float *__restrict__ scores, int *__restrict__ fail, const float *__restrict__ thr,
+                                                              int thr_stride)
+{
+    extern __shared__ uint64_t sortbuf[];
+    const int64_t q = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const float *qv = queries + q * dim;
+    const int total = counts[q];
+    const int cnt = total < cap ? total : cap;
+    int n2 = 64;
+    while (n2 < cnt) n2 <<= 1;
+    for (int c = tid; c < cnt; c += 256) {
+        const uint32_t id = key_row(cand[q * cap + c]);
+        const float d = sq8_row_score<DOT>(tiles + (static_cast<int64_t>(id >> 6) * groups) * 64 + (id & 63), groups, dim >> 4, dim & 15,
+                                           qv, mins, inv);
+        sortbuf[c] = make_key(d, id, DOT);
+    }
+    for (int i = cnt + tid; i < n2; i += 256) sortbuf[i] = kKeyMax;
+    __syncthreads();
+    bitonic_sort_lds(sortbuf, n2, tid, 256);
+    for (int i = tid; i < k; i += 256) {
+        const uint64_t e = i < n2 ? sortbuf[i] : kKeyMax;
+        ids[q * k + i] = e == kKeyMax ? VG_INVALID_ID : key_row(e);
+        scores[q * k + i] = e == kKeyMax ? (DOT ? -INFINITY : INFINITY) : key_score(e, DOT);
+    }
+    if (tid >= 64) return;
+    float qn = 0.0f;
+    for (int j = lane; j < dim; j += 64) qn = __builtin_fmaf(qv[j], qv[j], qn);
+    for (int off = 32; off > 0; off >>= 1) qn += __shfl_xor(qn, off);
+    const uint64_t kth = k - 1 < n2 ? sortbuf[k - 1] : kKeyMax;
+    const float tau = thr[q * thr_stride + (thr_stride - 1)];
+    bool ok = total <= cap;
+    if (ok && tau != INFINITY) {  // (tau == +Inf: no threshold was set, every accepted row was appended)
+        // (the margin: sq8_verify_kernel's)
+        const float eps = (4.0f * (static_cast<float>(dim) * 5.9604645e-8f) + (DOT ? 0.00390625f : 0.0078125f) * 1.02f) * (qn + norm_max[0]) + 1e-30f;
+        if (kth == kKeyMax)
+            ok = false;
+        else if (DOT)
+            ok = key_score(kth, true) > (-tau) + eps;
+        else
+            ok = key_score(kth, false) < (tau + qn) - eps;
     }
     if (lane == 0) fail[q] = ok ? 0 : 1;
 }
@@ -1705,29 +1764,29 @@ VG_API int32_t vg_index_set_sq8_codes(vg_index *idx, vg_sq8 *sq, const uint8_t *
 }
 
 namespace vg {
-struct ProbeNominated {
-    float *thr;
-    int *counts;
-    uint32_t *cand_id;
-    float *cand_sc;
-    int cap;
-};
 // sq8_verify_kernel over nq query rows whose nomination (8 thresholds, count, 64 candidates each) another file produced: the
 // partition-probed scan's (query, probe) pairs (k_probe.hip)
 int32_t launch_sq8_verify(vg_index *idx, const float *queries, int64_t nq, const ProbeNominated &nom, int k, uint32_t *ids, float *scores,
                           int *fail, hipStream_t st)
 {
     const bool dot = idx->metric != VG_METRIC_L2;
+    if (k > kSq8PickMaxK) {
+        auto kern = dot ? sq8_verify_sort_kernel<true> : sq8_verify_sort_kernel<false>;
+        VG_LAUNCH(kern, dim3(static_cast<unsigned>(nq)), dim3(256), sizeof(uint64_t) * static_cast<size_t>(nom.cap), st,
+                  reinterpret_cast<const uint4 *>(idx->d_sq_tiles), idx->sq_groups, idx->dim, idx->sq->d_mins, idx->sq->d_inv, queries,
+                  idx->d_sq_norm_max, nom.cand, nom.counts, nom.cap, k, ids, scores, fail, nom.thr, nom.sel_k);
+        return VG_OK;
+    }
     auto kern = dot ? sq8_verify_kernel<true> : sq8_verify_kernel<false>;
     VG_LAUNCH(kern, dim3(static_cast<unsigned>(nq)), dim3(64), 0, st, reinterpret_cast<const uint4 *>(idx->d_sq_tiles), idx->sq_groups, idx->dim,
               idx->sq->d_mins, idx->sq->d_inv, queries, idx->d_sq_norm_max, nom.cand_id, nom.cand_sc, k, ids, scores, fail, nom.thr, nom.counts,
-              nom.cap);
+              nom.cap, nom.sel_k);
     return VG_OK;
 }
 // whether a batch takes the nomination (vg_index_enable_sq8_nomination; device queries)
 bool sq8_nomination_applies(const vg_index *idx, const float *d_queries, int64_t nq, int k)
 {
-    return idx->d_sq_bf16 && nq >= 16 && k <= 48 && idx->n > k && (reinterpret_cast<uintptr_t>(d_queries) & 15) == 0;
+    return idx->d_sq_bf16 && nq >= 16 && k <= kSq8NomMaxK && idx->n > k && (reinterpret_cast<uintptr_t>(d_queries) & 15) == 0;
 }
 // The nomination + exact re-score + proof for a batch (device buffers; mask: a device row filter per query / for the batch, or
 // null): writes every query's k results and lists the queries whose proof failed — the caller scans those.  4096 queries a pass.
@@ -1740,8 +1799,9 @@ int32_t sq8_nominated_pass(vg_index *idx, const float *q, int64_t nq, int k, con
         std::vector<int> h(static_cast<size_t>(cnt));
         {
             ArenaCall ar(idx->ctx, st);
-            const int i_scr = ar.add(flat_nominate_bf16_scratch(cnt, idx->n, idx->dim));
-            const int i_thr = ar.add(sizeof(float) * static_cast<size_t>(cnt) * 8);
+            const int sel_k = sq8_nominate_sel_k(k);
+            const int i_scr = ar.add(flat_nominate_bf16_scratch(cnt, idx->n, idx->dim, sel_k));
+            const int i_thr = ar.add(sizeof(float) * static_cast<size_t>(cnt) * sel_k);
             const int i_cnt = ar.add(sizeof(int) * static_cast<size_t>(cnt));
             const int i_cid = ar.add(sizeof(uint32_t) * static_cast<size_t>(cnt) * 64);
             const int i_csc = ar.add(sizeof(float) * static_cast<size_t>(cnt) * 64);
@@ -1750,12 +1810,11 @@ int32_t sq8_nominated_pass(vg_index *idx, const float *q, int64_t nq, int k, con
             float *thr = ar.get<float>(i_thr), *csc = ar.get<float>(i_csc);
             int *counts = ar.get<int>(i_cnt), *fail = ar.get<int>(i_fail);
             uint32_t *cid = ar.get<uint32_t>(i_cid);
+            ProbeNominated nom{thr, counts, cid, csc, 0, sel_k, nullptr};
             VG_TRY(flat_nominate_bf16(idx->ctx, idx->d_sq_bf16, idx->d_sq_norms, idx->n, idx->dim, q + q0 * idx->dim, cnt, ar.get<char>(i_scr),
-                                      thr, counts, cid, csc, st, dot, mask ? mask + q0 * mask_stride : nullptr, mask_stride));
-            auto kern = dot ? sq8_verify_kernel<true> : sq8_verify_kernel<false>;
-            VG_LAUNCH(kern, dim3(static_cast<unsigned>(cnt)), dim3(64), 0, st, reinterpret_cast<const uint4 *>(idx->d_sq_tiles), idx->sq_groups,
-                      idx->dim, idx->sq->d_mins, idx->sq->d_inv, q + q0 * idx->dim, idx->d_sq_norm_max, cid, csc, k, oid + q0 * k, osc + q0 * k,
-                      fail, thr, counts, 4096);
+                                      thr, counts, cid, csc, st, dot, mask ? mask + q0 * mask_stride : nullptr, mask_stride, sel_k,
+                                      k <= kSq8PickMaxK, &nom.cand, &nom.cap));
+            VG_TRY(launch_sq8_verify(idx, q + q0 * idx->dim, cnt, nom, k, oid + q0 * k, osc + q0 * k, fail, st));
             VG_HIP(hipMemcpyAsync(h.data(), fail, sizeof(int) * static_cast<size_t>(cnt), hipMemcpyDeviceToHost, st));
             VG_HIP(hipStreamSynchronize(st));
         }

@@ -323,6 +323,19 @@ struct ProbeGroup {
     uint32_t first;  // first entry of the group in pair_of[]
     uint32_t count;  // 1..kProbeQB
 };
+// The grouped nomination of the probed scans (flat_probe_gemm, k_flat.hip), where the caller re-scores with its own exact
+// distance (SQ8: launch_sq8_verify, k_sq8.hip): per (query, probe) pair its thresholds, how many rows fell below the last one,
+// and those rows.
+struct ProbeNominated {
+    float *thr;            // [pairs, sel_k]: the pair's threshold is entry sel_k - 1
+    int *counts;           // [pairs]
+    uint32_t *cand_id;     // [pairs, 64]: the 64 best appended rows ascending by nomination score (k <= 48 only)
+    float *cand_sc;
+    int cap;               // appended keys kept per pair (counts above it: rows were dropped)
+    int sel_k;
+    const uint64_t *cand;  // [pairs, cap]: every appended key (k > 48: all of them are re-scored)
+};
+constexpr int kProbeGemmMaxK = 160;  // deepest threshold: the 60th best of the 1/8 row sample, ~480 rows pass it
 }  // namespace vg
 
 struct vg_index {
