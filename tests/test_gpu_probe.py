@@ -287,3 +287,37 @@ def test_probed_fp32_batches_with_k_beyond_the_64_candidate_budget(vg, ctx, metr
     seg2 = o.FlatSegment(x2, dim, metric=metric, centroids=cent2, part_offsets=off2)
     ids, sc = idx2.search_flat_probed(q, 100, 3, scan=idx2.SCAN_F32)
     check(ids[:6], sc[:6], seg2, q[:6], 100, 3)
+
+
+@pytest.mark.parametrize("metric", [0, 2])
+@pytest.mark.parametrize("scan_name", ["f32", "sq8"])
+def test_probes_with_equal_centroid_distances_follow_the_selection_loop(vg, ctx, metric, scan_name):
+    """duplicated centroids: FindClosestCentroids' selection loop (kmeans.go:255-269, nprobes <= parts/4) takes the first minimum
+    by POSITION after its swaps — not by centroid id — and the probed partitions are exactly the oracle's; the full-sort shape
+    (nprobes > parts/4) beside it"""
+    rng = np.random.default_rng(400 + metric)
+    n, dim, parts = 2400, 32, 12
+    x = rng.standard_normal((n, dim)).astype(np.float32)
+    cent = (rng.standard_normal((parts, dim)) * 0.7).astype(np.float32)
+    cent[5] = cent[1]; cent[9] = cent[1]; cent[7] = cent[2]; cent[10] = cent[0]; cent[11] = cent[0]
+    off = (np.arange(parts + 1) * (n // parts)).astype(np.uint32)       # rows in every partition, duplicates included
+    idx = vg.Index(ctx, n, dim, vg.Metric(metric))
+    kw = {}
+    if scan_name == "sq8":
+        sq = vg.ScalarQuantizer(ctx, dim); sq.train(x)
+        ref = o.ScalarQuantizer(dim); ref.train(x)
+        codes = sq.encode(x)
+        idx.set_sq8_codes(sq, codes)
+        kw = dict(sq=ref, codes=codes)
+        scan = idx.SCAN_SQ8
+    else:
+        idx.set_vectors(x)
+        scan = idx.SCAN_F32
+    idx.set_partitions(cent, off)
+    seg = o.FlatSegment(x, dim, metric=metric, centroids=cent, part_offsets=off, **kw)
+    for nq in (3, 60):
+        q = rng.standard_normal((nq, dim)).astype(np.float32)
+        q[0] = cent[1]; q[1] = cent[0] * 1.5; q[2] = cent[2]
+        for nprobes in (1, 2, 3, 4):
+            ids, sc = idx.search_flat_probed(q, 10, nprobes, scan=scan)
+            check(ids, sc, seg, q, 10, nprobes)

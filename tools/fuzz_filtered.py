@@ -2,7 +2,7 @@
 partitions or whole segment, few queries or a matrix-core batch, pages beyond 64 results) vg_search_vamana_filtered
 (fp32 / PQ / RaBitQ / INT4 node scorers) and vg_search_hnsw_predicate (tombstones, host-held edge distances).  Row structure (ties included), filter selectivity (down to nothing passing), shapes and
 k are drawn at random; every mismatch is printed with its configuration; exit code 1 if any.
-`python tools/fuzz_filtered.py [seconds] [seed]`"""
+`python tools/fuzz_filtered.py [seconds] [seed] [family ...]` (families: flat_f32 flat_pq flat_sq8 vamana hnsw_predicate)"""
 import sys, time
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
@@ -18,6 +18,7 @@ ctx = vg.Context(0)
 bits = lambda x: np.asarray(x, np.float32).view(np.uint32)
 fails = 0
 runs = {"flat_f32": 0, "flat_pq": 0, "flat_sq8": 0, "vamana": 0, "hnsw_predicate": 0}
+only = [a for a in sys.argv[3:] if a in runs]
 
 
 def rows(n, dim):
@@ -58,7 +59,7 @@ def partition(x, dim, parts, metric):
 
 t_end = time.time() + budget
 while time.time() < t_end:
-    which = rng.choice(list(runs))
+    which = rng.choice(only or list(runs))
     runs[which] += 1
     try:
         if which.startswith("flat"):
@@ -107,7 +108,7 @@ while time.time() < t_end:
             q = rows(nq, dim)
             if rng.random() < 0.3:
                 q[0] = x[rng.integers(0, n)]
-            k = int(rng.choice([1, 10, 48, 64, 65, 200]))
+            k = int(rng.choice([1, 10, 48, 49, 64, 65, 100, 160, 200, 256]))
             nprobes = int(rng.choice([0, 1, 2, max(parts, 1)]))
             mask, keep, per_query = make_mask(nq, n)
             cfg = dict(n=n, dim=dim, metric=metric, parts=parts, nq=nq, k=k, nprobes=nprobes, keep=keep, per_query=per_query,

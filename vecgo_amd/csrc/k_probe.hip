@@ -52,20 +52,30 @@ int32_t launch_page_patch(int64_t nq, int k, int off, int kk, bool descending, c
 // ---- 1. the nprobes closest centroids (kmeans.go:217-280) -----------------------------------------
 // 16 lanes per centroid, batch-kernel order; for Dot / Cosine the reference sorts -dot ascending,
 // i.e. the largest dot products first, which is the DOT key order.
+// Equal distances (duplicated centroids): the reference's full sort (kmeans.go:272, pdqsort) leaves their order unpinned — by
+// centroid id here, as in the oracle — but its SELECTION loop (n <= k/4 && n < 16, kmeans.go:255-269) is deterministic and not
+// by id: each step takes the first minimum by POSITION and swaps it with the element at position i, which moves that element
+// behind others of its own distance.  `emulate` (the host sets it when the selection loop is the reference's path): np + 1 keys
+// are kept, and when two neighbours among them are equal the loop itself is replayed on all the distances in LDS (dynamic:
+// parts floats + parts positions); with no tie among them every step's minimum is unique and the key order IS the loop's.
 template <bool DOT>
 __global__ __launch_bounds__(256) void probe_select_kernel(const float *__restrict__ queries, int dim,
                                                            const float *__restrict__ centroids, int parts, int np,
-                                                           uint32_t *__restrict__ probes)
+                                                           uint32_t *__restrict__ probes, int emulate)
 {
+    extern __shared__ float sel_dist[];
     __shared__ uint64_t lists[4 * 64];
     __shared__ int valid[4];
     __shared__ uint64_t best[64];
+    __shared__ float red_d[4];
+    __shared__ uint32_t red_p[4], red_c[4];
     const int64_t q = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const Sub16 sub = Sub16::make(tid);
     const float *qv = queries + q * dim;
+    const int want = emulate ? np + 1 : np;
     WaveTopK tk;
-    tk.init(np);
+    tk.init(want);
     for (int c0 = wave * 4; c0 < parts; c0 += 16) {
         const int c = c0 + (lane >> 4);
         uint64_t key = kKeyMax;
@@ -75,9 +85,79 @@ __global__ __launch_bounds__(256) void probe_select_kernel(const float *__restri
         }
         tk.offer(key, lane);
     }
-    wg_rank_merge<4>(tk, lists, valid, wave, lane, tid, np, best);
+    wg_rank_merge<4>(tk, lists, valid, wave, lane, tid, want, best);
     __syncthreads();
-    if (tid < np) probes[q * np + tid] = key_row(best[tid]);
+    bool tie = false;
+    if (emulate)
+        for (int i = 0; i + 1 < want; i++)
+            tie = tie || (best[i + 1] != kKeyMax && key_score(best[i], DOT) == key_score(best[i + 1], DOT));
+    if (!tie) {
+        if (tid < np) probes[q * np + tid] = key_row(best[tid]);
+        return;
+    }
+    constexpr uint32_t kNone = 0xFFFFFFFFu;
+    uint32_t *sel_pos = reinterpret_cast<uint32_t *>(sel_dist + parts);  // where each centroid's entry stands; kNone: taken
+    for (int c0 = wave * 4; c0 < parts; c0 += 16) {
+        const int c = c0 + (lane >> 4);
+        if (c < parts) {
+            const float v = exact_pair16<DOT, kBatch>(centroids + static_cast<int64_t>(c) * dim, qv, dim, sub);
+            if ((lane & 15) == 0) {
+                sel_dist[c] = DOT ? -v : v;  // kmeans.go:240: the dot product negated
+                sel_pos[c] = static_cast<uint32_t>(c);
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = 0; i < np; i++) {
+        float bd = 0.0f;
+        uint32_t bp = kNone, bc = kNone;  // the first minimum by position among the entries not taken yet
+        for (int c = tid; c < parts; c += 256) {
+            const uint32_t p = sel_pos[c];
+            if (p == kNone) continue;
+            const float d = sel_dist[c];
+            if (bc == kNone || d < bd || (d == bd && p < bp)) {
+                bd = d;
+                bp = p;
+                bc = static_cast<uint32_t>(c);
+            }
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            const float od = __shfl_xor(bd, off);
+            const uint32_t op = __shfl_xor(bp, off), oc = __shfl_xor(bc, off);
+            if (oc != kNone && (bc == kNone || od < bd || (od == bd && op < bp))) {
+                bd = od;
+                bp = op;
+                bc = oc;
+            }
+        }
+        if (lane == 0) {
+            red_d[wave] = bd;
+            red_p[wave] = bp;
+            red_c[wave] = bc;
+        }
+        __syncthreads();
+        bd = red_d[0];
+        bp = red_p[0];
+        bc = red_c[0];
+        for (int w = 1; w < 4; w++) {
+            const float od = red_d[w];
+            const uint32_t op = red_p[w], oc = red_c[w];
+            if (oc != kNone && (bc == kNone || od < bd || (od == bd && op < bp))) {
+                bd = od;
+                bp = op;
+                bc = oc;
+            }
+        }
+        __syncthreads();
+        // dists[i], dists[minIdx] = dists[minIdx], dists[i]: the entry standing at position i goes where the minimum stood
+        for (int c = tid; c < parts; c += 256)
+            if (sel_pos[c] == static_cast<uint32_t>(i) && static_cast<uint32_t>(c) != bc) sel_pos[c] = bp;
+        if (tid == 0) {
+            sel_pos[bc] = kNone;
+            probes[q * np + i] = bc;
+        }
+        __syncthreads();
+    }
 }
 
 // ---- 2. fp32 scan of one probed partition (segment.go:691-701) ------------------------------------
@@ -721,12 +801,17 @@ static int32_t flat_probed_impl(vg_index *idx, const float *queries, int64_t nq,
         const int64_t threads = std::max<int64_t>(pairs, parts + 1);
         VG_LAUNCH(vg::probe_whole_segment_kernel, dim3(static_cast<unsigned>((threads + 255) / 256)), dim3(256), 0, st, idx->n, parts,
                   pairs, ar.get<uint32_t>(i_whole), probes);
-    } else if (dot) {
-        VG_LAUNCH(vg::probe_select_kernel<true>, dim3(static_cast<unsigned>(nq)), dim3(256), 0, st, q.ptr, idx->dim,
-                  idx->d_centroids, idx->num_partitions, np, probes);
     } else {
-        VG_LAUNCH(vg::probe_select_kernel<false>, dim3(static_cast<unsigned>(nq)), dim3(256), 0, st, q.ptr, idx->dim,
-                  idx->d_centroids, idx->num_partitions, np, probes);
+        // the reference's selection loop (kmeans.go:255: n <= k/4 && n < 16) is replayed where centroid distances tie; its LDS
+        // (8 bytes per partition) bounds that to 20 000 partitions — beyond, ties are broken by centroid id
+        const size_t sel_lds = 8 * static_cast<size_t>(idx->num_partitions);
+        const int emulate = np <= idx->num_partitions / 4 && np < 16 && sel_lds <= 160 * 1024;
+        auto kern = dot ? vg::probe_select_kernel<true> : vg::probe_select_kernel<false>;
+        if (emulate && sel_lds > 48 * 1024)
+            VG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       static_cast<int>(sel_lds)));
+        VG_LAUNCH(kern, dim3(static_cast<unsigned>(nq)), dim3(256), emulate ? sel_lds : 0, st, q.ptr, idx->dim, idx->d_centroids,
+                  idx->num_partitions, np, probes, emulate);
     }
     // the heap direction follows the segment metric for EVERY scan (flat/segment.go:449): with Dot / Cosine a PQ
     // scan therefore keeps the k LARGEST table-lookup (squared-L2) distances — the reference as written
