@@ -1,6 +1,7 @@
 """Randomised differential test of the search entry points against the oracle: odd dims, tiny and
 ragged n, k around n, every metric.  Prints every mismatch with the configuration that produced it;
-exit code 1 if any.  `python tools/fuzz_parity.py [seconds] [seed]`"""
+exit code 1 if any.  `python tools/fuzz_parity.py [seconds] [seed] [structured]` (structured: clustered /
+integer-grid / repeated rows and queries that are rows — equal scores everywhere)"""
 import sys, time
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
@@ -11,6 +12,7 @@ from tests import graphs
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+STRUCTURED = len(sys.argv) > 3 and sys.argv[3] == "structured"
 rng = np.random.default_rng(seed)
 ctx = vg.Context(0)
 bits = lambda x: np.asarray(x, np.float32).view(np.uint32)
@@ -38,10 +40,24 @@ while time.time() < t_end:
     nq = int(rng.choice([1, 2, 3, 5, 9, 33, 70]))
     k = int(rng.choice([1, 2, 5, 10, 31, 32, 33, 64, 65, 200]))
     metric = int(rng.choice([0, 1, 2]))
-    x = rng.standard_normal((n, dim)).astype(np.float32)
+    structured = STRUCTURED and rng.random() < 0.6         # argv[3] == "structured": rows with MANY equal scores
+    if structured:
+        kind = int(rng.integers(0, 3))
+        if kind == 0:                                      # a few clusters, tight or loose
+            c = rng.standard_normal((int(rng.integers(2, 40)), dim)) * rng.choice([0.5, 3.0, 30.0])
+            x = c[rng.integers(0, c.shape[0], n)] + rng.standard_normal((n, dim)) * rng.choice([0.0, 1e-3, 0.1])
+        elif kind == 1:
+            x = rng.integers(-2, 3, (n, dim)).astype(np.float64)                     # integer grid
+        else:
+            x = np.repeat(rng.standard_normal(((n + 7) // 8, dim)), 8, axis=0)[:n]   # every row eight times
+        x = np.ascontiguousarray(x * float(rng.choice([1e-3, 1.0, 1.0, 100.0])), np.float32)
+    else:
+        x = rng.standard_normal((n, dim)).astype(np.float32)
     if n > 3 and rng.random() < 0.5:
         x[n // 2] = x[0]                                  # duplicates: ties broken by row id
     q = rng.standard_normal((nq, dim)).astype(np.float32)
+    if structured and rng.random() < 0.5:
+        q = x[rng.integers(0, n, nq)].copy()               # queries that ARE rows
     cfg = dict(n=n, dim=dim, nq=nq, k=k, metric=metric)
     idx = vg.Index(ctx, n, dim, vg.Metric(metric))
     idx.set_vectors(x)
@@ -66,6 +82,8 @@ while time.time() < t_end:
             cuts = np.sort(rng.integers(0, n + 1, parts - 1))
             off = np.concatenate([[0], cuts, [n]]).astype(np.uint32)
             cent = rng.standard_normal((parts, dim)).astype(np.float32)
+            if structured:                             # centroids that are rows: equal centroid distances
+                cent = x[rng.integers(0, n, parts)].copy()
             nprobes = int(rng.integers(0, parts + 2))
             idx.set_partitions(cent, off)
             kk = k
