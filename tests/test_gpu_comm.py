@@ -102,3 +102,29 @@ def test_sharded_flat_index_with_a_filter(vg, ctx):
     want = idx.index.search_flat_filtered(q, 10, mask, 0)
     assert torch.equal(ids, want[0]) and torch.equal(sc, want[1])
     assert mask[np.arange(20)[:, None], ids.cpu().numpy().astype(np.int64)].all()
+
+
+def test_sharded_sq8_index_on_one_rank(vg, ctx):
+    """train_sq8_sharded = ScalarQuantizer.Train bit for bit; ShardedSQ8Index (nomination on) = the index's own searches"""
+    import torch
+    from vecgo_amd import sharded
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev); g.manual_seed(5)
+    rows = torch.randn((7000, 64), device=dev, generator=g)
+    rows[:, 9] = 2.5
+    q = torch.randn((24, 64), device=dev, generator=g)
+    sq = vg.ScalarQuantizer(ctx, 64)
+    sharded.train_sq8_sharded(sq, rows)
+    full = vg.ScalarQuantizer(ctx, 64); full.train(rows)
+    for a, b in zip(sq.params(), full.params()):
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    codes = sq.encode(rows)
+    idx = sharded.ShardedSQ8Index(ctx, sq, codes, 7000, 64, [0, 7000], nomination=True)
+    mask = (torch.rand((24, 7000), device=dev, generator=g) < 0.3).cpu().numpy()
+    for k in (10, 100):
+        ids, sc = idx.search(q, k)
+        want = idx.index.search_sq8(q, k)
+        assert torch.equal(ids, want[0]) and torch.equal(sc, want[1])
+        ids, sc = idx.search_filtered(q, k, mask)
+        want = idx.index.search_flat_filtered(q, k, mask, 0, scan=idx.index.SCAN_SQ8)
+        assert torch.equal(ids, want[0]) and torch.equal(sc, want[1])

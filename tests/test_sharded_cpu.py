@@ -132,3 +132,35 @@ def test_two_rank_sharded_pq_training_equals_single_process():
     ret = mgr.dict()
     mp.spawn(_pq_worker, args=(world, port, ret), nprocs=world, join=True)
     assert ret[0] and ret[1]
+
+
+def _sq_worker(rank, world, port, ret):
+    sys.path.insert(0, str(ROOT))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import oracle as o
+    from vecgo_amd import sharded
+    dim = 20
+    x = np.random.default_rng(8).standard_normal((301, dim)).astype(np.float32)
+    x[:, 3] = 5.0                                   # a constant dimension: Train's own handling (max = min + 1e-6), not SetBounds'
+    x[:150, 7] = 100.0                              # constant on rank 0's rows only
+    bounds = sharded.partition(x.shape[0], world)
+    ok = True
+    for rows in (x[bounds[rank]:bounds[rank + 1]], torch.from_numpy(x[bounds[rank]:bounds[rank + 1]]),
+                 x[:0] if rank == 1 else x):        # numpy shards, torch shards, an empty shard on rank 1
+        sq = o.ScalarQuantizer(dim)
+        sharded.train_sq8_sharded(sq, rows)
+        full = o.ScalarQuantizer(dim); full.train(x)
+        for a, b in ((sq.mins, full.mins), (sq.maxs, full.maxs), (sq.scales, full.scales), (sq.inv_scales, full.inv_scales)):
+            ok &= bool(np.array_equal(a.view(np.uint32), b.view(np.uint32)))
+    ret[rank] = ok
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharded_sq8_training_equals_single_process():
+    world = 2
+    port = 33500 + (os.getpid() % 2000)
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_sq_worker, args=(world, port, ret), nprocs=world, join=True)
+    assert ret[0] and ret[1]

@@ -11,6 +11,7 @@ from __future__ import annotations
 
 from typing import Callable, Sequence
 
+import numpy as np
 import torch
 import torch.distributed as dist
 
@@ -202,6 +203,62 @@ def train_pq_sharded(pq, vectors, iters: int = 20, seed: int = 1, group=None, de
         sc[a_:b_] = g[r, m * per + 4 * a_:m * per + 4 * b_].view(np.float32)
         of[a_:b_] = g[r, m * per + 4 * m + 4 * a_:m * per + 4 * m + 4 * b_].view(np.float32)
     pq.set_codebooks(cb, sc, of)
+
+
+def train_sq8_sharded(sq, local_rows, group=None):
+    """ScalarQuantizer.Train (quantizer.go:127-180) over a row-sharded corpus.  Train depends on the rows only through the
+    per-dimension minimum and maximum, and those are associative: every rank reduces ITS rows, one all-reduce (MIN, MAX) makes
+    them global, and Train itself runs on the two-row matrix [mins; maxs] — so the degenerate-dimension handling is Train's own
+    (not SetBounds', which differs for max == min) and the quantizer equals the single-process one bit for bit.
+    sq: a vecgo_amd.ScalarQuantizer (or anything with .train(rows)); local_rows: [n_local, dim] torch tensor or numpy array,
+    n_local may be 0."""
+    big = float(np.finfo(np.float32).max)
+    if isinstance(local_rows, torch.Tensor):
+        dim = local_rows.shape[1]
+        if local_rows.shape[0]:
+            lo, hi = local_rows.amin(dim=0).float(), local_rows.amax(dim=0).float()
+        else:
+            lo = torch.full((dim,), big, dtype=torch.float32, device=local_rows.device)
+            hi = -lo
+    else:
+        x = np.asarray(local_rows, np.float32)
+        dim = x.shape[1]
+        lo = torch.from_numpy(x.min(axis=0) if x.shape[0] else np.full(dim, big, np.float32))
+        hi = torch.from_numpy(x.max(axis=0) if x.shape[0] else np.full(dim, -big, np.float32))
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=group)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=group)
+    sq.train(torch.stack([lo, hi]).cpu().numpy())
+
+
+class ShardedSQ8Index:
+    """flat.Segment.Search, SQ8 branch, over a row-sharded corpus: one quantizer for all shards (train_sq8_sharded), every rank
+    scans the codes of its rows, the fan-in is the flat index's.  nomination: vg_index_enable_sq8_nomination on every shard
+    (per-shard results stay exact, so the merged result does)."""
+
+    def __init__(self, ctx, sq, local_codes, n_local: int, dim: int, bounds: Sequence[int], metric=0, group=None, comm=None,
+                 nomination: bool = False):
+        from . import api
+        self._api = api
+        self.ctx, self.dim, self.bounds, self.metric, self.group, self.comm = ctx, dim, list(bounds), metric, group, comm
+        self.index = api.Index(ctx, n_local, dim, api.Metric(metric))
+        self.index.set_sq8_codes(sq, local_codes)
+        if nomination:
+            self.index.enable_sq8_nomination(True)
+
+    def _run(self, local, queries, k, stream):
+        def merge(packed, kk, off):
+            lists, _, nq, _ = packed.shape
+            return self._api.merge_topk_packed(self.ctx, packed, lists, nq, kk, metric=self.metric, id_offsets=off, stream=stream)
+        return sharded_search(local, merge, queries, k, self.bounds, self.group, comm=self.comm, metric=self.metric, stream=stream)
+
+    def search(self, queries, k: int, stream=None):
+        return self._run(lambda q, kk, out: self.index.search_sq8(q, kk, out=out, stream=stream), queries, k, stream)
+
+    def search_filtered(self, queries, k: int, local_mask, stream=None):
+        """with a row filter: every rank passes the filter bits of ITS rows (ShardedFlatIndex.search_filtered)"""
+        return self._run(lambda q, kk, out: self.index.search_flat_filtered(q, kk, local_mask, 0, scan=self.index.SCAN_SQ8, out=out,
+                                                                           stream=stream), queries, k, stream)
 
 
 class ShardedRaBitQIndex:
