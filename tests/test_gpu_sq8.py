@@ -157,7 +157,7 @@ def test_sq8_scan_pages_beyond_64_results(vg, ctx, n, dim, nq, k, metric):
 
 @pytest.mark.parametrize("n,dim,nq,k", [(20000, 128, 40, 10), (9000, 768, 24, 10), (30000, 64, 130, 48), (3000, 64, 20, 5)])
 def test_batches_through_the_bf16_nomination(vg, ctx, n, dim, nq, k):
-    """vg_index_enable_sq8_nomination: 16 queries up, an L2 batch is nominated by the bfloat16 GEMM over the dequantised rows, its
+    """vg_index_enable_sq8_nomination: 5 queries up, an L2 batch is nominated by the bfloat16 GEMM over the dequantised rows, its
     64 best re-scored from the CODES (the reference's L2Distance), the rest excluded by a proof — same ids and score bits as the
     scan and as the oracle; duplicate codes (ties) and clustered rows included; small batches and Dot keep the scan."""
     rng = np.random.default_rng(n + dim)
@@ -178,7 +178,7 @@ def test_batches_through_the_bf16_nomination(vg, ctx, n, dim, nq, k):
     for i in (0, 1, nq // 2, nq - 1):
         eid, esc = o.flat_search_sq8(ref, codes, q[i], k)
         assert np.array_equal(got[0][i, :eid.size], eid) and np.array_equal(bits(got[1][i, :eid.size]), bits(esc))
-    few = idx.search_sq8(q[:3], k)                     # below 16 queries: the scan
+    few = idx.search_sq8(q[:3], k)                     # below 5 queries: the scan
     assert np.array_equal(few[0], plain[0][:3])
     idx.enable_sq8_nomination(False)
     again = idx.search_sq8(q, k)

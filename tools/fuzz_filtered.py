@@ -96,7 +96,7 @@ while time.time() < t_end:
                 sq = vg.ScalarQuantizer(ctx, dim); sq.train(x)
                 codes = np.asarray(sq.encode(x))
                 idx.set_sq8_codes(sq, codes)
-                nominate = bool(rng.integers(0, 2))      # the bf16 nomination (dim % 64 == 0, 16 queries up) or the scans
+                nominate = bool(rng.integers(0, 2))      # the bf16 nomination (dim % 64 == 0, 5 queries up) or the scans
                 idx.enable_sq8_nomination(nominate)
                 keep_alive.append(sq)
                 kw = dict(sq=ref, codes=codes)

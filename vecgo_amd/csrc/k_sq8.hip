@@ -1544,6 +1544,9 @@ int32_t flat_nominate_bf16(vg_ctx *ctx, const uint16_t *rows_bf16, const float *
 // wants the threshold 2^-7 (|q|^2 + |x^|^2) above the k-th score: ~512 rows for k = 100 left enough queries to the scan — random-
 // normal rows, 1M x 768 — that the batch took 8.3 ms, ~1024 rows 3 ms.)
 constexpr int kSq8PickMaxK = 48, kSq8NomMaxK = 256;
+#ifndef VG_SQ8_NOM_MIN_Q
+#define VG_SQ8_NOM_MIN_Q 5  // smallest batch the nomination takes: 1M x 768, scan / nominated ms: 4 queries 0.34 / 0.37, 6: 0.51 / 0.38, 16: 0.94 / 0.37
+#endif
 static int sq8_nominate_sel_k(int k) { return k <= kSq8PickMaxK ? 8 : k <= 128 ? 16 : 32; }
 
 __device__ __forceinline__ uint16_t sq8_bf16_rne(float x)
@@ -1786,7 +1789,7 @@ int32_t launch_sq8_verify(vg_index *idx, const float *queries, int64_t nq, const
 // whether a batch takes the nomination (vg_index_enable_sq8_nomination; device queries)
 bool sq8_nomination_applies(const vg_index *idx, const float *d_queries, int64_t nq, int k)
 {
-    return idx->d_sq_bf16 && nq >= 16 && k <= kSq8NomMaxK && idx->n > k && (reinterpret_cast<uintptr_t>(d_queries) & 15) == 0;
+    return idx->d_sq_bf16 && nq >= VG_SQ8_NOM_MIN_Q && k <= kSq8NomMaxK && idx->n > k && (reinterpret_cast<uintptr_t>(d_queries) & 15) == 0;
 }
 // The nomination + exact re-score + proof for a batch (device buffers; mask: a device row filter per query / for the batch, or
 // null): writes every query's k results and lists the queries whose proof failed — the caller scans those.  4096 queries a pass.
