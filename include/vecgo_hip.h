@@ -483,7 +483,9 @@ enum { VG_SCAN_F32 = 0, VG_SCAN_PQ = 1, VG_SCAN_SQ8 = 2 };
 /* The partition-probed scan of flat.Segment.Search: per query kmeans.FindClosestCentroids(nprobes)
  * (kmeans.go:217-280; nprobes <= 0 means 1), then the chosen scan over those partitions' row ranges
  * only, one top-k by (score, row id).  With at most one partition it is vg_search_flat /
- * vg_search_pq_adc / vg_search_sq8.  k <= 512 (pages of 64 results), nprobes <= 64. */
+ * vg_search_pq_adc / vg_search_sq8.  k <= 512 (pages of 64 results), nprobes <= 64.  Equal centroid distances: the
+ * reference's selection loop (kmeans.go:255-269, taken for nprobes <= partitions / 4 && nprobes < 16) is replayed, so the
+ * probed partitions are the reference's also among duplicated centroids; its full sort leaves ties unpinned (by id here). */
 int32_t vg_search_flat_probed(vg_index *idx, const float *queries, int64_t nq, int32_t k, int32_t nprobes,
                               int32_t scan, uint32_t *ids, float *scores, void *stream);
 /* flat.Segment.Search with `filter segment.Filter` set (flat/segment.go:447): a row whose filter.Matches(rowID) is false
