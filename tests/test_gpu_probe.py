@@ -321,3 +321,37 @@ def test_probes_with_equal_centroid_distances_follow_the_selection_loop(vg, ctx,
         for nprobes in (1, 2, 3, 4):
             ids, sc = idx.search_flat_probed(q, 10, nprobes, scan=scan)
             check(ids, sc, seg, q, 10, nprobes)
+
+
+@pytest.mark.parametrize("scan_name", ["f32", "sq8"])
+def test_probed_batches_beyond_65535_pairs_run_in_chunks(vg, ctx, scan_name):
+    """8200 queries x 8 probes: more (query, probe) pairs than one grouped nomination takes — the batch is cut into chunks of
+    queries that fit; the queries either side of the cut and a filter per query included"""
+    rng = np.random.default_rng(77)
+    n, dim, parts, nq, k = 4000, 64, 12, 8200, 10
+    x, cent, off = partitioned(rng, n, dim, parts)
+    idx = vg.Index(ctx, n, dim)
+    kw = {}
+    if scan_name == "sq8":
+        sq = vg.ScalarQuantizer(ctx, dim); sq.train(x)
+        ref = o.ScalarQuantizer(dim); ref.train(x)
+        codes = sq.encode(x)
+        idx.set_sq8_codes(sq, codes)
+        idx.enable_sq8_nomination(True)
+        kw = dict(sq=ref, codes=codes)
+        scan = idx.SCAN_SQ8
+    else:
+        idx.set_vectors(x)
+        scan = idx.SCAN_F32
+    idx.set_partitions(cent, off)
+    seg = o.FlatSegment(x, dim, centroids=cent, part_offsets=off, **kw)
+    q = rng.standard_normal((nq, dim)).astype(np.float32)
+    ids, sc = idx.search_flat_probed(q, k, 8, scan=scan)
+    cut = 65535 // 8
+    rows = [0, cut - 1, cut, cut + 1, nq - 1]
+    check(ids[rows], sc[rows], seg, q[rows], k, 8)
+    masks = np.packbits(rng.random((nq, n)) < 0.5, axis=1, bitorder="little")
+    ids, sc = idx.search_flat_filtered(q, k, masks, 8, scan=scan)
+    for i in rows:
+        eid, esc = seg.search(q[i], k, 8, mask=np.unpackbits(masks[i], bitorder="little")[:n].astype(bool))
+        assert np.array_equal(ids[i, :eid.size], eid) and np.array_equal(bits(sc[i, :eid.size]), bits(esc)), i

@@ -55,6 +55,17 @@ for nprobes in (1, 2, 4, 8, 16, 32):
     same = bool(torch.equal(ra[0], rb[0])) and bool(torch.equal(ra[1].view(torch.int32), rb[1].view(torch.int32)))
     print(f"nprobes {nprobes:3d}: {a:7.2f} ms per 1024 queries ({1024 / a:7.1f} k q/s)   exact kernels alone {b:7.2f} ms   same results: {same}", flush=True)
 
+# 8192 queries x 8 probes: 65536 pairs, one more than a grouped nomination takes — the batch runs in two chunks of queries
+q8 = torch.randn((8192, bench.DIM), device=dev, dtype=torch.float32)
+a, ra = timed(lambda: idx.search_flat_probed(q8, 10, 8))
+hooks.set_hook("VG_PROBE_NO_GEMM", "1")
+try:
+    b, rb = timed(lambda: idx.search_flat_probed(q8, 10, 8), reps=1)
+finally:
+    hooks.set_hook("VG_PROBE_NO_GEMM", 0)
+same = bool(torch.equal(ra[0], rb[0])) and bool(torch.equal(ra[1].view(torch.int32), rb[1].view(torch.int32)))
+print(f"8192 queries, nprobes 8: {a:7.2f} ms ({8192 / a:7.1f} k q/s)   exact kernels alone {b:7.2f} ms   same results: {same}", flush=True)
+
 # the code scans of the same partitioned segment: SQ8 (grouped by partition) and PQ m = 96 (one workgroup per query and share of
 # its probe list), beside the unprobed scans of the whole segment
 sq = vg.ScalarQuantizer(ctx, bench.DIM); sq.train(rows[:100000])
