@@ -741,7 +741,7 @@ static int32_t flat_probed_impl(vg_index *idx, const float *queries, int64_t nq,
     const int pk = paged ? 64 : k;
     const int i_probes = ar.add(sizeof(uint32_t) * static_cast<size_t>(nq) * np);
     // (the grouped nomination leaves k keys per pair there, also when k is paged for the scan kernels)
-    const size_t partial_keys = std::max(static_cast<size_t>(nq) * lists * pk, whole || k > vg::kProbeGemmMaxK ? size_t(0) : static_cast<size_t>(pairs) * k);
+    const size_t partial_keys = std::max(static_cast<size_t>(nq) * lists * pk, whole || k > vg::kProbeGemmMaxK || scan == VG_SCAN_PQ || pairs > 65535 ? size_t(0) : static_cast<size_t>(pairs) * k);
     const int i_partial = ar.add(sizeof(uint64_t) * partial_keys);
     const int i_pid = ar.add(paged ? sizeof(uint32_t) * static_cast<size_t>(nq) * pk : 0);
     const int i_psc = ar.add(paged ? sizeof(float) * static_cast<size_t>(nq) * pk : 0);
