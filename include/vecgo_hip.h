@@ -419,12 +419,13 @@ int32_t vg_index_set_sq8_codes(vg_index *idx, vg_sq8 *sq, const uint8_t *codes, 
  * quantizer.go:109-119: a sequential fp32 loop, largest first); best k by (Score, RowID).  k <= 512
  * (beyond 64 results the scan runs once per page of 64, each page after the previous one's last key). */
 /* Optional bfloat16 NOMINATION for batches of vg_search_sq8 (no reference counterpart; the results stay the reference's).
- * on != 0: keeps the dequantised rows rounded to bfloat16 (rows * dim * 2 bytes: twice the codes) and their norms.  A batch
- * of 5 or more queries (k <= 256, dim % 64 == 0) is then nominated by the bf16 MFMA GEMM of the flat search, its 64 best rows
- * per query (k > 48: every row below a sampled threshold) re-scored with L2Distance / DotProduct (by the metric) from the CODES,
- * and a bound on the nomination's error proves no other row can enter the k best; a query whose proof fails is scanned as before.  Filtered batches over an unpartitioned
- * segment (vg_search_flat_filtered, VG_SCAN_SQ8) take it too.  Other shapes keep the scan.  Dropped by vg_index_set_sq8_codes.
- * (VG_ABI_MINOR 9.) */
+ * on != 0: keeps the dequantised rows rounded to bfloat16 (rows * dim * 2 bytes, dim rounded up to a multiple of 64: twice
+ * the codes) and their norms.  A batch of 5 or more queries (k <= 256) is then nominated by the bf16 MFMA GEMM of the flat
+ * search, its 64 best rows per query (k > 48: every row below a sampled threshold) re-scored with L2Distance / DotProduct
+ * (by the metric) from the CODES, and a bound on the nomination's error proves no other row can enter the k best; a query
+ * whose proof fails is scanned as before.  Filtered batches over an unpartitioned segment (vg_search_flat_filtered,
+ * VG_SCAN_SQ8) and partitions probed by 12 or more queries each (k <= 160, dim % 4 == 0) take it too.  Other shapes keep
+ * the scan.  Dropped by vg_index_set_sq8_codes.  (VG_ABI_MINOR 9.) */
 int32_t vg_index_enable_sq8_nomination(vg_index *idx, int32_t on, void *stream);
 int32_t vg_search_sq8(vg_index *idx, const float *queries, int64_t nq, int32_t k, uint32_t *ids,
                       float *scores, void *stream);

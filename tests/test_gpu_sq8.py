@@ -155,7 +155,8 @@ def test_sq8_scan_pages_beyond_64_results(vg, ctx, n, dim, nq, k, metric):
         assert np.all(ids[i, r:] == 0xFFFFFFFF)
 
 
-@pytest.mark.parametrize("n,dim,nq,k", [(20000, 128, 40, 10), (9000, 768, 24, 10), (30000, 64, 130, 48), (3000, 64, 20, 5)])
+@pytest.mark.parametrize("n,dim,nq,k", [(20000, 128, 40, 10), (9000, 768, 24, 10), (30000, 64, 130, 48), (3000, 64, 20, 5),
+                                        (12000, 100, 33, 10), (6000, 17, 20, 100), (7000, 300, 9, 10)])
 def test_batches_through_the_bf16_nomination(vg, ctx, n, dim, nq, k):
     """vg_index_enable_sq8_nomination: 5 queries up, an L2 batch is nominated by the bfloat16 GEMM over the dequantised rows, its
     64 best re-scored from the CODES (the reference's L2Distance), the rest excluded by a proof — same ids and score bits as the
@@ -220,13 +221,14 @@ def test_nomination_with_dot_metric_and_filters(vg, ctx, metric):
             assert np.all(got[0][i, eid.size:] == 0xFFFFFFFF)
 
 
+@pytest.mark.parametrize("dim", [64, 100])
 @pytest.mark.parametrize("metric", [0, 2])
-def test_probed_batches_through_the_grouped_nomination(vg, ctx, metric):
+def test_probed_batches_through_the_grouped_nomination(vg, ctx, metric, dim):
     """a partitioned SQ8 segment, partitions probed by many queries each: the grouped bf16 nomination per (query, probe) pair +
     sq8_verify_kernel — nomination on = off = the oracle, with and without a filter"""
     from tests.test_gpu_probe import partitioned
     rng = np.random.default_rng(70 + metric)
-    n, dim, parts, nq, k = 12000, 64, 6, 120, 10
+    n, parts, nq, k = 12000, 6, 120, 10               # (dim 100: the bf16 image padded to 128)
     x, cent, off = partitioned(rng, n, dim, parts, metric)
     x[200:206] = x[200]
     sq = vg.ScalarQuantizer(ctx, dim); sq.train(x)

@@ -117,6 +117,22 @@ __global__ void f32_to_bf16_kernel(const float *__restrict__ src, int64_t count,
     dst[i] = r;
 }
 
+// the same for rows of `dim` floats written as rows of `dim_pad` bfloat16, the tail zeros (images padded to whole K steps)
+__global__ void f32_to_bf16_pad_kernel(const float *__restrict__ src, int64_t rows, int dim, int dim_pad, uint16_t *__restrict__ dst)
+{
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= rows * dim_pad) return;
+    const int64_t r = i / dim_pad;
+    const int j = static_cast<int>(i - r * dim_pad);
+    const uint32_t u = j < dim ? __float_as_uint(src[r * dim + j]) : 0u;
+    uint16_t v;
+    if ((u & 0x7F800000u) == 0x7F800000u && (u & 0x007FFFFFu) != 0)
+        v = static_cast<uint16_t>((u >> 16) | 0x0040u);
+    else
+        v = static_cast<uint16_t>((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+    dst[i] = v;
+}
+
 // After the proofs: the work list of step 4 (todo[0] = how many queries need the exhaustive scan,
 // todo[1 + j] = the j-th of them, ascending) and the bookkeeping for vg_index_flat_stats
 // (stats[0] += queries of the chunk, stats[1] += those sent to the exhaustive kernel).
@@ -933,18 +949,19 @@ int32_t flat_probe_gemm(vg_index *idx, const float *pair_queries, int64_t pairs,
     const int kc = 64, cap = kProbeGemmCap, sel_k = probe_gemm_sel_k(k, bf16);
     const bool own_filter = bf16 && rows_bf16 == idx->d_vectors_bf16;
     const float *const queries_f32 = pair_queries;
-    const ProbeGemmLayout l = probe_gemm_layout(pairs, ns_max, k, bf16 ? idx->dim : 0);
+    const int bdim = !bf16 ? 0 : own_filter ? idx->dim : idx->sq_bf16_dim;  // row length of the bfloat16 image
+    const ProbeGemmLayout l = probe_gemm_layout(pairs, ns_max, k, bdim);
     const int sel_slices = l.sel_slices;
     const float *grows = idx->d_vectors, *gnorms = idx->d_norms;
     int gdim = idx->dim;
     if (bf16) {
         uint16_t *qbf = reinterpret_cast<uint16_t *>(scratch + l.qbf);
-        VG_LAUNCH(f32_to_bf16_kernel, dim3(static_cast<unsigned>((pairs * idx->dim + 255) / 256)), dim3(256), 0, st, pair_queries,
-                  pairs * idx->dim, qbf);
+        VG_LAUNCH(f32_to_bf16_pad_kernel, dim3(static_cast<unsigned>((pairs * bdim + 255) / 256)), dim3(256), 0, st, pair_queries,
+                  pairs, idx->dim, bdim, qbf);
         pair_queries = reinterpret_cast<const float *>(qbf);
         grows = reinterpret_cast<const float *>(rows_bf16);
         gnorms = rows_norms;
-        gdim = idx->dim / 2;
+        gdim = bdim / 2;
     }
     float *sc = reinterpret_cast<float *>(scratch + l.sc), *thr = reinterpret_cast<float *>(scratch + l.thr);
     float *cand_sc = reinterpret_cast<float *>(scratch + l.csc);
@@ -1027,7 +1044,7 @@ int32_t flat_probe_gemm(vg_index *idx, const float *pair_queries, int64_t pairs,
 // The nomination stage of the fused flat search over ANY bfloat16 row image with its norms: thresholds from a row sample, the
 // bf16 MFMA GEMM appending what falls below them, the kc best per query — for a caller that re-scores and proves with its own
 // exact distance (the SQ8 batch search, k_sq8.hip: rows = the dequantised codes rounded to bfloat16, norms = |x^|^2).  L2 scores.
-// queries: cnt x dim fp32 (device, 16-byte aligned), dim % 64 == 0, cnt <= 4096.  Outputs (device, caller's):
+// queries: cnt x dim fp32 (device), cnt <= 4096; rows_bf16: n x dim_pad (dim rounded up to a multiple of 64, the tail zeros).  Outputs (device, caller's):
 // thr[cnt * sel_k] (the threshold is a query's last entry), counts[cnt], cand_id / cand_sc[cnt * 64] ascending (pick only).
 namespace vg {
 constexpr int kNomKc = 64, kNomCap = 4096, kNomStride = 64;
@@ -1058,7 +1075,7 @@ static NominateLayout nominate_layout(int64_t cnt, int64_t n, int dim, int sel_k
 }
 size_t flat_nominate_bf16_scratch(int64_t cnt, int64_t n, int dim, int sel_k) { return nominate_layout(cnt, n, dim, sel_k).total; }
 
-int32_t flat_nominate_bf16(vg_ctx *ctx, const uint16_t *rows_bf16, const float *norms, int64_t n, int dim, const float *queries,
+int32_t flat_nominate_bf16(vg_ctx *ctx, const uint16_t *rows_bf16, const float *norms, int64_t n, int dim, int dim_pad, const float *queries,
                            int64_t cnt, char *scratch, float *thr, int *counts, uint32_t *cand_id, float *cand_sc, hipStream_t st,
                            bool dot, const uint8_t *mask, int64_t mask_stride, int sel_k, bool pick, const uint64_t **cand_keys, int *cap)
 {
@@ -1066,15 +1083,16 @@ int32_t flat_nominate_bf16(vg_ctx *ctx, const uint16_t *rows_bf16, const float *
     // batch (stride 0) — rejected rows are left out of the sample and of the candidates, as in flat_search_masked
     // sel_k: thresholds kept per query (thr[cnt * sel_k], the last is the query's: ~64 * sel_k rows pass it); pick: the 64 best
     // appended rows into cand_id / cand_sc; *cand_keys / *cap: every appended key, cap per query (in `scratch`)
-    const NominateLayout l = nominate_layout(cnt, n, dim, sel_k);
+    // dim_pad: the image's row length (dim rounded up to whole 64-element K steps, the tail zeros); the queries are padded alike
+    const NominateLayout l = nominate_layout(cnt, n, dim_pad, sel_k);
     uint16_t *qbf = reinterpret_cast<uint16_t *>(scratch + l.qbf);
     float *sc = reinterpret_cast<float *>(scratch + l.sc);
     uint64_t *partial = reinterpret_cast<uint64_t *>(scratch + l.partial), *cand = reinterpret_cast<uint64_t *>(scratch + l.cand);
     uint32_t *sid = reinterpret_cast<uint32_t *>(scratch + l.sid);
     const int64_t mt = (cnt + kGemmBM - 1) / kGemmBM, nt = (n + kGemmBN - 1) / kGemmBN, nst = l.ns / kGemmBN;
-    VG_LAUNCH(f32_to_bf16_kernel, dim3(static_cast<unsigned>((cnt * dim + 255) / 256)), dim3(256), 0, st, queries, cnt * dim, qbf);
+    VG_LAUNCH(f32_to_bf16_pad_kernel, dim3(static_cast<unsigned>((cnt * dim_pad + 255) / 256)), dim3(256), 0, st, queries, cnt, dim, dim_pad, qbf);
     const float *ga = reinterpret_cast<const float *>(qbf), *gb = reinterpret_cast<const float *>(rows_bf16);
-    const int gdim = dim / 2;
+    const int gdim = dim_pad / 2;
     if (n > kNomCap) {
         VG_TRY(launch_gemm<1>(dot, true, static_cast<unsigned>(mt * ((nst + 7) / 8) * 8), st,
                               {ga, cnt, gb, n, gdim, norms, sc, kNomStride, l.ns, nullptr, 0, 0, nullptr, nullptr, 0, mask, mask_stride}, true));

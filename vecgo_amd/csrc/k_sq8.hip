@@ -1536,7 +1536,7 @@ VG_API int32_t vg_sq8_l2_distance_batch(vg_sq8 *sq, const float *query, const ui
 // rounding of both operands, fp32 accumulation, the reference's own rounding).  A query whose proof fails is scanned as before.
 namespace vg {
 size_t flat_nominate_bf16_scratch(int64_t cnt, int64_t n, int dim, int sel_k);
-int32_t flat_nominate_bf16(vg_ctx *ctx, const uint16_t *rows_bf16, const float *norms, int64_t n, int dim, const float *queries,
+int32_t flat_nominate_bf16(vg_ctx *ctx, const uint16_t *rows_bf16, const float *norms, int64_t n, int dim, int dim_pad, const float *queries,
                            int64_t cnt, char *scratch, float *thr, int *counts, uint32_t *cand_id, float *cand_sc, hipStream_t st,
                            bool dot, const uint8_t *mask, int64_t mask_stride, int sel_k, bool pick, const uint64_t **cand_keys, int *cap);
 // k <= 48: the 64 best nominees are re-scored (sq8_verify_kernel); up to 256: everything below the threshold
@@ -1556,9 +1556,10 @@ __device__ __forceinline__ uint16_t sq8_bf16_rne(float x)
 }
 
 // one lane per row of a 64-row tile: dequantise, round, write the row's bf16 image and its norm
+// (rows of dim_pad elements: the dimensions from dim on are zeros, which add nothing to a dot product)
 __global__ __launch_bounds__(64) void sq8_dequant_bf16_kernel(const uint4 *__restrict__ tiles, int64_t n, int dim, int groups,
                                                               const float *__restrict__ mins, const float *__restrict__ inv,
-                                                              uint16_t *__restrict__ out, float *__restrict__ norms,
+                                                              uint16_t *__restrict__ out, int dim_pad, float *__restrict__ norms,
                                                               int *__restrict__ norm_max_bits)
 {
     const int64_t tile = blockIdx.x;
@@ -1566,8 +1567,8 @@ __global__ __launch_bounds__(64) void sq8_dequant_bf16_kernel(const uint4 *__res
     const int64_t row = tile * 64 + lane;
     float nrm = 0.0f;
     if (row < n) {
-        for (int g = 0; g < groups; g++) {
-            const uint4 c = tiles[(tile * groups + g) * 64 + lane];
+        for (int g = 0; g < dim_pad / 16; g++) {
+            const uint4 c = g < groups ? tiles[(tile * groups + g) * 64 + lane] : make_uint4(0, 0, 0, 0);
             const uint32_t w[4] = {c.x, c.y, c.z, c.w};
             uint32_t packed[8];
 #pragma unroll
@@ -1586,11 +1587,9 @@ __global__ __launch_bounds__(64) void sq8_dequant_bf16_kernel(const uint4 *__res
                 }
                 packed[t >> 1] = pair;
             }
-            if (g * 16 + 16 <= dim) {
-                uint4 *dst = reinterpret_cast<uint4 *>(out + row * dim + g * 16);
-                dst[0] = make_uint4(packed[0], packed[1], packed[2], packed[3]);
-                dst[1] = make_uint4(packed[4], packed[5], packed[6], packed[7]);
-            }
+            uint4 *dst = reinterpret_cast<uint4 *>(out + row * dim_pad + g * 16);
+            dst[0] = make_uint4(packed[0], packed[1], packed[2], packed[3]);
+            dst[1] = make_uint4(packed[4], packed[5], packed[6], packed[7]);
         }
         norms[row] = nrm;
     }
@@ -1720,14 +1719,14 @@ VG_API int32_t vg_index_enable_sq8_nomination(vg_index *idx, int32_t on, void *s
     }
     if (!on) return VG_OK;
     VG_CHECK(idx->sq && idx->d_sq_tiles, VG_ERR_NOT_READY, "vg_index_enable_sq8_nomination: index has no SQ8 codes");
-    if (idx->dim % 64 != 0) return VG_OK;  // the nomination never applies: no image to keep
-    VG_HIP(hipMalloc(reinterpret_cast<void **>(&idx->d_sq_bf16), static_cast<size_t>(idx->n) * idx->dim * sizeof(uint16_t)));
+    idx->sq_bf16_dim = (idx->dim + 63) & ~63;  // whole K steps of the bf16 GEMM; the padding is zeros
+    VG_HIP(hipMalloc(reinterpret_cast<void **>(&idx->d_sq_bf16), static_cast<size_t>(idx->n) * idx->sq_bf16_dim * sizeof(uint16_t)));
     VG_HIP(hipMalloc(reinterpret_cast<void **>(&idx->d_sq_norms), static_cast<size_t>(idx->n) * sizeof(float)));
     VG_HIP(hipMalloc(reinterpret_cast<void **>(&idx->d_sq_norm_max), sizeof(float)));
     VG_HIP(hipMemsetAsync(idx->d_sq_norm_max, 0, sizeof(float), st));
     VG_LAUNCH(vg::sq8_dequant_bf16_kernel, dim3(static_cast<unsigned>(idx->n_tiles)), dim3(64), 0, st,
               reinterpret_cast<const uint4 *>(idx->d_sq_tiles), idx->n, idx->dim, idx->sq_groups, idx->sq->d_mins, idx->sq->d_inv,
-              idx->d_sq_bf16, idx->d_sq_norms, reinterpret_cast<int *>(idx->d_sq_norm_max));
+              idx->d_sq_bf16, idx->sq_bf16_dim, idx->d_sq_norms, reinterpret_cast<int *>(idx->d_sq_norm_max));
     VG_HIP(hipStreamSynchronize(st));
     return VG_OK;
 }
@@ -1803,7 +1802,7 @@ int32_t sq8_nominated_pass(vg_index *idx, const float *q, int64_t nq, int k, con
         {
             ArenaCall ar(idx->ctx, st);
             const int sel_k = sq8_nominate_sel_k(k);
-            const int i_scr = ar.add(flat_nominate_bf16_scratch(cnt, idx->n, idx->dim, sel_k));
+            const int i_scr = ar.add(flat_nominate_bf16_scratch(cnt, idx->n, idx->sq_bf16_dim, sel_k));
             const int i_thr = ar.add(sizeof(float) * static_cast<size_t>(cnt) * sel_k);
             const int i_cnt = ar.add(sizeof(int) * static_cast<size_t>(cnt));
             const int i_cid = ar.add(sizeof(uint32_t) * static_cast<size_t>(cnt) * 64);
@@ -1814,7 +1813,7 @@ int32_t sq8_nominated_pass(vg_index *idx, const float *q, int64_t nq, int k, con
             int *counts = ar.get<int>(i_cnt), *fail = ar.get<int>(i_fail);
             uint32_t *cid = ar.get<uint32_t>(i_cid);
             ProbeNominated nom{thr, counts, cid, csc, 0, sel_k, nullptr};
-            VG_TRY(flat_nominate_bf16(idx->ctx, idx->d_sq_bf16, idx->d_sq_norms, idx->n, idx->dim, q + q0 * idx->dim, cnt, ar.get<char>(i_scr),
+            VG_TRY(flat_nominate_bf16(idx->ctx, idx->d_sq_bf16, idx->d_sq_norms, idx->n, idx->dim, idx->sq_bf16_dim, q + q0 * idx->dim, cnt, ar.get<char>(i_scr),
                                       thr, counts, cid, csc, st, dot, mask ? mask + q0 * mask_stride : nullptr, mask_stride, sel_k,
                                       k <= kSq8PickMaxK, &nom.cand, &nom.cap));
             VG_TRY(launch_sq8_verify(idx, q + q0 * idx->dim, cnt, nom, k, oid + q0 * k, osc + q0 * k, fail, st));

@@ -376,7 +376,8 @@ struct vg_index {
     uint8_t *d_rq_rows = nullptr;
     // SQ8 codes, re-tiled like the PQ codes: [tile][group of 16 dims][lane][16 B]; see k_sq8.hip
     vg_sq8 *sq = nullptr;
-    uint16_t *d_sq_bf16 = nullptr;     // vg_index_enable_sq8_nomination: the dequantised codes rounded to bfloat16, n*dim, or null
+    uint16_t *d_sq_bf16 = nullptr;     // vg_index_enable_sq8_nomination: the dequantised codes rounded to bfloat16, n*sq_bf16_dim, or null
+    int32_t sq_bf16_dim = 0;           // its row length: dim padded with zeros to whole 64-element K steps of the bf16 GEMM
     float *d_sq_norms = nullptr;       // ... their |x^|^2 (fp32 of the unrounded values), n, and the largest of them
     float *d_sq_norm_max = nullptr;
     uint8_t *d_sq_tiles = nullptr;
