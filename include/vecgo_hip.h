@@ -370,10 +370,10 @@ int32_t vg_score_candidates(vg_index *idx, const float *queries, int64_t nq,
 int32_t vg_search_flat(vg_index *idx, const float *queries, int64_t nq, int32_t k, uint32_t *ids,
                        float *scores, void *stream);
 /* Optional bfloat16 FILTER for vg_search_flat (no reference counterpart; the results stay the reference's).  on != 0:
- * the index keeps a bfloat16 copy of its fp32 rows (n*dim*2 bytes more HBM; made from the rows attached by
- * vg_index_set_vectors, to be enabled again after the rows are replaced).  Searches of more than 4 queries (smaller
- * batches take the exact scan, which has no nomination step) with dim % 64 == 0 then NOMINATE with v_mfma_f32_32x32x16_bf16 over the copies instead of the fp32 MFMA GEMM; the
- * nominated rows are re-scored from the fp32 rows in the reference's summation order exactly as without the filter,
+ * the index keeps a bfloat16 copy of its fp32 rows (n*dim*2 bytes more HBM, dim rounded up to a multiple of 64 with
+ * zeros; made from the rows attached by vg_index_set_vectors, to be enabled again after the rows are replaced).  Searches
+ * of more than 4 queries (smaller batches take the exact scan, which has no nomination step) then NOMINATE with
+ * v_mfma_f32_32x32x16_bf16 over the copies instead of the fp32 MFMA GEMM; the nominated rows are re-scored from the fp32 rows in the reference's summation order exactly as without the filter,
  * and the proof that no other row can enter the top k widens its margin by what the rounding of the copies can change
  * (<= 2^-8 * 1.02 * (|q|^2 + max|x|^2)); a query whose proof fails goes to the exhaustive exact kernel as before.
  * Ids and scores are therefore bit-identical with and without the filter.  on == 0 drops the copy. */

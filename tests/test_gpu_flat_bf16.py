@@ -37,6 +37,10 @@ def ctx(vg):
     (20000, 768, 5, 10, 0),       # one block of 32 queries (the HBM-bound tile)
     (20000, 768, 33, 10, 0),      # two blocks
     (20000, 768, 64, 10, 2),
+    (15000, 100, 130, 10, 0),     # dim % 64 != 0: the copies are zero-padded to whole K steps (128)
+    (15000, 300, 40, 10, 2),
+    (8000, 17, 70, 100, 0),       # dim % 4 != 0 too
+    (6000, 3, 33, 10, 0),
 ])
 def test_filter_is_bit_identical(vg, ctx, n, dim, nq, k, metric):
     rng = np.random.default_rng(n + dim + nq + k + metric)

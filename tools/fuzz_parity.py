@@ -65,7 +65,7 @@ while time.time() < t_end:
     try:
         if which == 0:
             tag = "flat"
-            if dim % 64 == 0 and rng.random() < 0.6:   # the bfloat16 nomination filter (takes effect above 4 queries)
+            if rng.random() < 0.6:                     # the bfloat16 nomination filter (takes effect above 4 queries; any dim)
                 nq = int(rng.choice([5, 33, 64, 65, 130]))
                 q = rng.standard_normal((nq, dim)).astype(np.float32)
                 if rng.random() < 0.3:                 # rows bf16 cannot tell apart: the proof must fail over to the scan

@@ -959,7 +959,7 @@ class Index:
                             out=out, stream=stream)
 
     def enable_sq8_nomination(self, on: bool = True, stream=None):
-        """vg_index_enable_sq8_nomination: batches of search_sq8 (L2 or Dot, 5 queries up, k <= 256, dim % 64 == 0) are nominated by a
+        """vg_index_enable_sq8_nomination: batches of search_sq8 (L2 or Dot, 5 queries up, k <= 256, any dim) are nominated by a
         bfloat16 MFMA GEMM over the dequantised rows (+ n * dim * 2 bytes), re-scored exactly from the codes and proven: ids and
         scores stay bit-identical."""
         check(self._lib.vg_index_enable_sq8_nomination(self._h, C.c_int32(1 if on else 0), _stream_ptr(stream)))

@@ -103,21 +103,8 @@ static int32_t launch_gemm(bool dot, bool dma, unsigned blocks, hipStream_t st, 
     return dot ? launch_gemm_t<true, MODE>(dma, blocks, st, a, bf16) : launch_gemm_t<false, MODE>(dma, blocks, st, a, bf16);
 }
 
-// fp32 -> bfloat16, round to nearest even (NaN stays NaN)
-__global__ void f32_to_bf16_kernel(const float *__restrict__ src, int64_t count, uint16_t *__restrict__ dst)
-{
-    const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (i >= count) return;
-    const uint32_t u = __float_as_uint(src[i]);
-    uint16_t r;
-    if ((u & 0x7F800000u) == 0x7F800000u && (u & 0x007FFFFFu) != 0)
-        r = static_cast<uint16_t>((u >> 16) | 0x0040u);
-    else
-        r = static_cast<uint16_t>((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
-    dst[i] = r;
-}
-
-// the same for rows of `dim` floats written as rows of `dim_pad` bfloat16, the tail zeros (images padded to whole K steps)
+// fp32 -> bfloat16, round to nearest even (NaN stays NaN): rows of `dim` floats written as rows of `dim_pad` bfloat16, the tail
+// zeros (operands of the bf16 GEMM are padded to whole K steps)
 __global__ void f32_to_bf16_pad_kernel(const float *__restrict__ src, int64_t rows, int dim, int dim_pad, uint16_t *__restrict__ dst)
 {
     const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -745,9 +732,11 @@ int32_t vg::flat_search_masked(vg_index *idx, const float *queries, int64_t nq, 
         // |x|^2 - 2 q.x (norms from the fp32 rows), TWICE that: (2^-7 + 2^-16)(|q|^2 + |x|^2).  (r02 used the Dot
         // bound for both — half of what L2 needs: ADVICE r02, tests/test_gpu_flat_bf16.py
         // test_filter_worst_case_rounding.)  The verify kernels multiply eps_extra by |q|^2 + max|x|^2.
-        const bool bf16 = idx->d_vectors_bf16 != nullptr && fused && dim % (2 * vg::kGemmBK) == 0 && !vg::hook(vg::kHookFlatNoDma);
+        // (any dim: the copies' rows are padded with zeros to whole K steps, vectors_bf16_dim)
+        const bool bf16 = idx->d_vectors_bf16 != nullptr && fused && !vg::hook(vg::kHookFlatNoDma);
+        const int bdim = idx->vectors_bf16_dim;
         const float eps_extra = !bf16 ? 0.0f : (dot ? 0.00390625f : 0.0078125f) * 1.02f;
-        const int i_qbf = ar.add(bf16 ? sizeof(uint16_t) * static_cast<size_t>(qc) * dim : 0);
+        const int i_qbf = ar.add(bf16 ? sizeof(uint16_t) * static_cast<size_t>(qc) * bdim : 0);
         VG_TRY(ar.commit());
         uint16_t *qbf = ar.get<uint16_t>(i_qbf);
         float *sc = ar.get<float>(i_sc), *thr = ar.get<float>(i_thr);
@@ -773,11 +762,11 @@ int32_t vg::flat_search_masked(vg_index *idx, const float *queries, int64_t nq, 
             const float *ga = qp, *gb = idx->d_vectors;
             int gdim = dim;
             if (bf16) {
-                VG_LAUNCH(vg::f32_to_bf16_kernel, dim3(static_cast<unsigned>((cnt * dim + 255) / 256)), dim3(256), 0, st, qp,
-                          cnt * dim, qbf);
+                VG_LAUNCH(vg::f32_to_bf16_pad_kernel, dim3(static_cast<unsigned>((cnt * bdim + 255) / 256)), dim3(256), 0, st, qp,
+                          cnt, dim, bdim, qbf);
                 ga = reinterpret_cast<const float *>(qbf);
                 gb = reinterpret_cast<const float *>(idx->d_vectors_bf16);
-                gdim = dim / 2;
+                gdim = bdim / 2;
             }
             if (fused) {
                 // (a) threshold per query from a row sample
@@ -949,7 +938,7 @@ int32_t flat_probe_gemm(vg_index *idx, const float *pair_queries, int64_t pairs,
     const int kc = 64, cap = kProbeGemmCap, sel_k = probe_gemm_sel_k(k, bf16);
     const bool own_filter = bf16 && rows_bf16 == idx->d_vectors_bf16;
     const float *const queries_f32 = pair_queries;
-    const int bdim = !bf16 ? 0 : own_filter ? idx->dim : idx->sq_bf16_dim;  // row length of the bfloat16 image
+    const int bdim = !bf16 ? 0 : own_filter ? idx->vectors_bf16_dim : idx->sq_bf16_dim;  // row length of the bfloat16 image
     const ProbeGemmLayout l = probe_gemm_layout(pairs, ns_max, k, bdim);
     const int sel_slices = l.sel_slices;
     const float *grows = idx->d_vectors, *gnorms = idx->d_norms;
@@ -1128,11 +1117,12 @@ VG_API int32_t vg_index_enable_bf16_filter(vg_index *idx, int32_t on, void *stre
     }
     if (!on) return VG_OK;
     VG_CHECK(idx->d_vectors, VG_ERR_NOT_READY, "vg_index_enable_bf16_filter: index has no fp32 vectors");
-    if (idx->dim % (2 * vg::kGemmBK) != 0) return VG_OK;  // the filter never applies to this shape: no copy to keep
-    const int64_t count = idx->n * idx->dim;
+    // rows of whole K steps (2 * kGemmBK = 64 bfloat16): the dimensions from dim on are zeros, which add nothing to a dot product
+    idx->vectors_bf16_dim = (idx->dim + 2 * vg::kGemmBK - 1) / (2 * vg::kGemmBK) * (2 * vg::kGemmBK);
+    const int64_t count = idx->n * idx->vectors_bf16_dim;
     VG_HIP(hipMalloc(reinterpret_cast<void **>(&idx->d_vectors_bf16), static_cast<size_t>(count) * sizeof(uint16_t)));
-    VG_LAUNCH(vg::f32_to_bf16_kernel, dim3(static_cast<unsigned>((count + 255) / 256)), dim3(256), 0, st, idx->d_vectors,
-              count, idx->d_vectors_bf16);
+    VG_LAUNCH(vg::f32_to_bf16_pad_kernel, dim3(static_cast<unsigned>((count + 255) / 256)), dim3(256), 0, st, idx->d_vectors,
+              idx->n, idx->dim, idx->vectors_bf16_dim, idx->d_vectors_bf16);
     VG_HIP(hipStreamSynchronize(st));
     return VG_OK;
 }

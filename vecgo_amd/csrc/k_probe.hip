@@ -798,8 +798,8 @@ static int32_t flat_probed_impl(vg_index *idx, const float *queries, int64_t nq,
     const int i_qfail = ar.add(gemm ? sizeof(int) * static_cast<size_t>(nq) : 0);
     const int i_moff = ar.add(gemm ? sizeof(int64_t) * static_cast<size_t>(pairs) : 0);
     // (fp32 rows with vg_index_enable_bf16_filter: the grouped nomination on that image too)
-    const bool gemm_f32_bf16 = gemm_f32 && idx->d_vectors_bf16 != nullptr && idx->dim % 64 == 0;
-    const int i_gscr = ar.add(gemm ? vg::flat_probe_gemm_scratch_bytes(pairs, ns_max, k, gemm_sq8 ? idx->sq_bf16_dim : gemm_f32_bf16 ? idx->dim : 0) : 0);
+    const bool gemm_f32_bf16 = gemm_f32 && idx->d_vectors_bf16 != nullptr;
+    const int i_gscr = ar.add(gemm ? vg::flat_probe_gemm_scratch_bytes(pairs, ns_max, k, gemm_sq8 ? idx->sq_bf16_dim : gemm_f32_bf16 ? idx->vectors_bf16_dim : 0) : 0);
     VG_TRY(ar.commit());
     uint32_t *probes = ar.get<uint32_t>(i_probes);
     uint64_t *partial = ar.get<uint64_t>(i_partial);

@@ -353,6 +353,7 @@ struct vg_index {
     float *d_norms = nullptr;
     float *d_norm_max = nullptr;  // [1] max ||x||^2: error bound of the GEMM-form scores
     uint16_t *d_vectors_bf16 = nullptr;  // optional bfloat16 copy of the rows: vg_index_enable_bf16_filter
+    int32_t vectors_bf16_dim = 0;        // its row length: dim padded with zeros to whole 64-element K steps of the bf16 GEMM
     unsigned long long *d_flat_stats = nullptr;  // [2] queries searched, queries sent to the exhaustive kernel
     // RaBitQ: sign bits re-tiled [tile][group][lane][16 B] and the stored norms
     uint8_t *d_rq_tiles = nullptr;
