@@ -820,9 +820,10 @@ static int32_t flat_probed_impl(vg_index *idx, const float *queries, int64_t nq,
                   pairs, ar.get<uint32_t>(i_whole), probes);
     } else {
         // the reference's selection loop (kmeans.go:255: n <= k/4 && n < 16) is replayed where centroid distances tie; its LDS
-        // (8 bytes per partition) bounds that to 20 000 partitions — beyond, ties are broken by centroid id
+        // (8 bytes per partition, beside the kernel's 2.6 KB of static LDS) bounds that to 19 968 partitions — beyond, ties are
+        // broken by centroid id
         const size_t sel_lds = 8 * static_cast<size_t>(idx->num_partitions);
-        const int emulate = np <= idx->num_partitions / 4 && np < 16 && sel_lds <= 160 * 1024;
+        const int emulate = np <= idx->num_partitions / 4 && np < 16 && sel_lds <= 156 * 1024;
         auto kern = dot ? vg::probe_select_kernel<true> : vg::probe_select_kernel<false>;
         if (emulate && sel_lds > 48 * 1024)
             VG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
