@@ -122,3 +122,24 @@ def test_filtered_search_is_the_search_of_the_matching_rows():
     all_ids, all_sc = full.search(q, k, mask=np.ones(n, bool))
     nid, nsc = full.search(q, k)
     assert np.array_equal(all_ids, nid) and np.array_equal(bits(all_sc), bits(nsc))
+
+
+def test_selection_loop_breaks_equal_distances_by_position_not_by_id():
+    """kmeans.go:255-269 (n <= k/4 && n < 16): each step takes the FIRST minimum by position, then swaps it with position i — which
+    moves the entry that stood there behind others of its own distance.  Worked by hand from the Go loop:
+    distances [5, 5, 1, 9 x 9] (12 centroids), n = 2: step 0 picks position 2 and swaps -> [1, 5(id 1), 5(id 0), ...]; step 1 scans from
+    position 1 and keeps the first 5 it meets: id 1, not id 0.  The full sort (n > k/4) is by (distance, id) in the oracle."""
+    dim = 1
+    # L2 distance of a query at 0 to a centroid at sqrt(d) is d
+    d = np.array([5, 5, 1] + [9] * 9, np.float32)
+    cent = np.sqrt(d).reshape(-1, dim).astype(np.float32)
+    q = np.zeros(dim, np.float32)
+    assert list(o.find_closest_centroids(q, cent, dim, 2)) == [2, 1]
+    # position 0 holds the minimum already: nothing moves, the tie goes to the lower position
+    d2 = np.array([1, 5, 5] + [9] * 9, np.float32)
+    assert list(o.find_closest_centroids(q, np.sqrt(d2).reshape(-1, dim).astype(np.float32), dim, 2)) == [0, 1]
+    # three steps: [5, 3, 5, 1, 9...] -> pick 3 (swap with 0: [1,3,5,5(id 0)]), pick 1, then the first 5 by position: id 2
+    d3 = np.array([5, 3, 5, 1] + [9] * 8, np.float32)
+    assert list(o.find_closest_centroids(q, np.sqrt(d3).reshape(-1, dim).astype(np.float32), dim, 3)) == [3, 1, 2]
+    # the same distances through the full sort (n = 4 > 12 / 4): by (distance, id)
+    assert list(o.find_closest_centroids(q, np.sqrt(d3).reshape(-1, dim).astype(np.float32), dim, 4)) == [3, 1, 0, 2]
