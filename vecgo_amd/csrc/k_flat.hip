@@ -58,6 +58,17 @@ static int32_t launch_gemm_t(bool dma, unsigned blocks, hipStream_t st, const Ge
                       a.cand, a.cap, a.mask, a.mask_stride);
             return VG_OK;
         }
+        if (MODE == 2 && a.nq > kGemmBM && !hook(kHookFlatNoBigTile)) {  // more than one 128-query tile: the 256 x 256 tile
+            const bool two = hook(kHookFlatBigTile2);
+            auto kern = two ? flat_gemm_bf16_big_kernel<DOT, 2> : flat_gemm_bf16_big_kernel<DOT, 3>;
+            const size_t lds = two ? big_lds_bytes<2>() : big_lds_bytes<3>();
+            VG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       static_cast<int>(lds)));
+            const int64_t mt = (a.nq + kBigBM - 1) / kBigBM, nt = (a.n + kBigBN - 1) / kBigBN;
+            VG_LAUNCH(kern, dim3(static_cast<unsigned>(mt * ((nt + 7) / 8) * 8)), dim3(kBigThreads), lds, st, a.queries, a.nq,
+                      a.base, a.n, a.dim, a.norms, a.thr, a.thr_stride, a.thr_off, a.counts, a.cand, a.cap, a.mask, a.mask_stride);
+            return VG_OK;
+        }
         auto kern = flat_gemm_dma_kernel<DOT, M, 0, true>;
         VG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    static_cast<int>(kDmaLdsBytes)));

@@ -1124,6 +1124,13 @@ __device__ __forceinline__ uint32_t pq_umed3(uint32_t a, uint32_t b, uint32_t c)
     return r;
 }
 
+__device__ __forceinline__ uint32_t pq_umin3(uint32_t a, uint32_t b, uint32_t c)
+{
+    uint32_t r;
+    asm("v_min3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
 // (134 registers: three waves per SIMD; held to four — 128 registers, 11 spilled — it is slower, 0.276 vs 0.242 ms per
 // 65 536 x 96 pairs: the kernel is not short of waves)
 template <bool ENC>
@@ -1136,6 +1143,7 @@ __global__ __launch_bounds__(256) void pq_nominate_bf16_kernel(const float *__re
                                                                int *__restrict__ list_count, int64_t row_first, float extra_margin)
 {
     __shared__ float s_cmax[4];
+    __shared__ uint16_t s_dec[4][kNomRowsPerWave];  // per wave and row: the nominated centroid | 0x100 = undecided (listed)
     int sub, tile_x;
     pq_nom_block(m, sub, tile_x);
     if (!ENC && done[sub]) return;
@@ -1196,13 +1204,20 @@ __global__ __launch_bounds__(256) void pq_nominate_bf16_kernel(const float *__re
         lo4 = *reinterpret_cast<const float4 *>(xbase + pc * stride);
         hi4 = *reinterpret_cast<const float4 *>(xbase + pc * stride + 4);
     };
-    float4 nlo, nhi;
+    // rows two blocks ahead: a block's 32-byte pieces are in flight for two iterations of the other waves' work
+    constexpr int kNb = kNomRowsPerWave / 32;
+    float4 nlo, nhi, n2lo, n2hi;
     load_rows(0, nlo, nhi);
-    for (int pb = 0; pb < kNomRowsPerWave / 32; pb++) {
+    load_rows(1, n2lo, n2hi);
+    for (int pb = 0; pb < kNb; pb++) {
         const int64_t p = row0 + pb * 32 + c_in;
         if (row0 + pb * 32 >= n) break;  // wave-uniform
         const float x[8] = {nlo.x, nlo.y, nlo.z, nlo.w, nhi.x, nhi.y, nhi.z, nhi.w};
-        load_rows(pb + 1 < kNomRowsPerWave / 32 ? pb + 1 : pb, nlo, nhi);  // in flight under this block's matrix work
+#if !(defined(VG_NOM_PROBE) && VG_NOM_PROBE == 4)  // stage probe 4: the first block's rows again and again (no loads in the loop)
+        nlo = n2lo;
+        nhi = n2hi;
+        load_rows(pb + 2 < kNb ? pb + 2 : kNb - 1, n2lo, n2hi);
+#endif
         float X = 0.0f;
 #pragma unroll
         for (int t = 0; t < 8; t++) X = __builtin_fmaf(x[t], x[t], X);
@@ -1217,6 +1232,10 @@ __global__ __launch_bounds__(256) void pq_nominate_bf16_kernel(const float *__re
         uint32_t m1 = 0xFFFFFFFFu, m2 = 0xFFFFFFFFu;
         auto tile = [&](int cb) {
             pq_f32x16 acc = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+#if defined(VG_NOM_PROBE) && VG_NOM_PROBE == 5  // stage probe 5: no matrix instructions (the scan reads operand words)
+            for (int r = 0; r < 16; r++) acc[r] = __uint_as_float((&a1[cb].x)[r & 3] ^ (&b1.x)[(r >> 2) & 3]);
+            return acc;
+#endif
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(pq_bf16x8, a1[cb]), __builtin_bit_cast(pq_bf16x8, b1), acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(pq_bf16x8, a2[cb]), __builtin_bit_cast(pq_bf16x8, b2), acc, 0, 0, 0);
             return acc;
@@ -1226,12 +1245,22 @@ __global__ __launch_bounds__(256) void pq_nominate_bf16_kernel(const float *__re
             m1 = m1 < __float_as_uint(acc[cb]) ? m1 : __float_as_uint(acc[cb]);
             return;
 #endif
+            // Four keys at a time.  With m1 <= m2 the two smallest of {m1, m2, a, b} are min3(m1, a, b) and
+            // min(m2, med3(m1, a, b)) (the second smallest of {m1, a, b}; m2 can only replace it from above), so two pairs cost
+            // 2 med3 + 2 min3 + one min3 that folds both medians into m2: 5 instructions per 4 keys where the one-key-at-a-time
+            // form (med3 + min per key) took 8 — and the chain through m1 is half as long.  (tools/ubench/valu_rate.hip: these
+            // integer / 3-operand forms all issue at the same rate, ~3 cycles per wave-instruction and SIMD at three waves.)
 #pragma unroll
-            for (int r = 0; r < 16; r++) {
-                // the centroid's index inside this lane's 128 (the h bit is added after the scan: it is the same for all of them)
-                const uint32_t key = (__float_as_uint(acc[r]) & keep) | static_cast<uint32_t>(cb * 32 + (r & 3) + 8 * (r >> 2));
-                m2 = pq_umed3(m1, key, m2);  // m1 <= m2: the middle one is the new second smallest
-                m1 = key < m1 ? key : m1;
+            for (int r = 0; r < 16; r += 4) {
+                uint32_t key[4];
+#pragma unroll
+                for (int e = 0; e < 4; e++)  // the centroid's index inside this lane's 128 (the h bit is added after the scan)
+                    key[e] = (__float_as_uint(acc[r + e]) & keep) | static_cast<uint32_t>(cb * 32 + ((r + e) & 3) + 8 * ((r + e) >> 2));
+                const uint32_t t1 = pq_umed3(m1, key[0], key[1]);
+                m1 = pq_umin3(m1, key[0], key[1]);
+                const uint32_t t2 = pq_umed3(m1, key[2], key[3]);
+                m1 = pq_umin3(m1, key[2], key[3]);
+                m2 = pq_umin3(m2, t1, t2);
             }
         };
 #if defined(VG_NOM_PROBE) && VG_NOM_PROBE == 3  // stage probe: loads and splits only
@@ -1253,9 +1282,8 @@ __global__ __launch_bounds__(256) void pq_nominate_bf16_kernel(const float *__re
         const uint32_t lo1 = m1 < o1 ? m1 : o1, hi1 = m1 < o1 ? o1 : m1, lo2 = m2 < o2 ? m2 : o2;
         m2 = hi1 < lo2 ? hi1 : lo2;
         m1 = lo1;
-        bool listed = false;
         if (h == 0 && p < n) {
-            const int idx = static_cast<int>(m1 & 0xFFu);
+            const uint32_t idx = m1 & 0xFFu;
             const float d1 = __uint_as_float(m1 & keep), d2 = __uint_as_float(m2 & keep);
             const float sx = sqrtf(X);
             const float cross = 2.0f * sx * sqc + C, dmax = (sx + sqc) * (sx + sqc);
@@ -1263,30 +1291,54 @@ __global__ __launch_bounds__(256) void pq_nominate_bf16_kernel(const float *__re
                                           24.0f * u * dmax) + 1e-30f + extra_margin;
             // every comparison is false on NaN: non-finite rows, centroids or scores go on the list (a NaN score's key has
             // every exponent bit set: it can only be the LARGEST key, so a finite smallest key is a real smallest score)
-            if (X + C < 1e30f && d2 - d1 > margin) {
-                if (ENC) {
-                    codes[p * m + sub] = static_cast<uint8_t>(idx);
-                } else {
-                    int32_t *dst = assign_all + static_cast<int64_t>(sub) * n + p;
-                    if (*dst != idx) {
-                        *dst = idx;
-                        changed[sub] = 1;
-                    }
-                }
-            } else {
-                listed = true;
-            }
-        }
-        // one atomic per wave for its listed rows (one per row serialised on the counter: 270 k of them per 33 M pairs
-        // cost the first version of this kernel 2 of its 2.9 ms)
-        const uint64_t lm = __ballot(listed);
-        if (lm) {
-            int base = 0;
-            if (lane == __builtin_ctzll(lm)) base = atomicAdd(list_count, __popcll(lm));
-            base = __shfl(base, __builtin_ctzll(lm));
-            if (listed) list[base + __popcll(lm & ((1ull << lane) - 1ull))] = PqNomList{static_cast<int32_t>(p), sub};
+            bool listed = !(X + C < 1e30f && d2 - d1 > margin);
+#if defined(VG_NOM_PROBE)  // stage probes compute garbage: nothing goes to pq_fix_kernel, whose time would drown the stage's
+            listed = false;
+#endif
+            // The decision goes to LDS, not to memory: a byte store per row here (and, for Train, a load of the row's previous
+            // assignment first) is a vector-memory operation in front of the next block's `s_waitcnt vmcnt(0)` for its rows —
+            // every block waited out a store's (or a dependent load's) round trip, and one block in eight a returning atomic for
+            // its listed rows: r05's kernel spent half its time there (stage probes: 4.4 ms with, 2.2 ms without the loop's
+            // memory traffic).  The wave's 1024 decisions leave together after the loop.
+            s_dec[wave][pb * 32 + c_in] = static_cast<uint16_t>(idx | (listed ? 0x100u : 0u));
         }
     }
+    // flush: this wave's rows [row0, row0 + rows_mine): codes / assignments of the decided rows, one atomic for the listed ones
+    const int64_t left = n - row0;
+    const int rows_mine = left <= 0 ? 0 : (left < kNomRowsPerWave ? static_cast<int>(left) : kNomRowsPerWave);
+    int total = 0;
+    for (int i0 = 0; i0 < rows_mine; i0 += 64) {
+        const int i = i0 + lane;
+        total += __popcll(__ballot(i < rows_mine && (s_dec[wave][i] & 0x100u)));
+    }
+    int at = 0;
+    if (total) {
+        if (lane == 0) at = atomicAdd(list_count, total);
+        at = __shfl(at, 0);
+    }
+    bool any_changed = false;
+    for (int i0 = 0; i0 < rows_mine; i0 += 64) {
+        const int i = i0 + lane;
+        const bool in = i < rows_mine;
+        const uint32_t v = in ? s_dec[wave][i] : 0u;
+        const bool listed = in && (v & 0x100u);
+        const int64_t pr = row0 + i;
+        if (in && !listed) {
+            if (ENC) {
+                codes[pr * m + sub] = static_cast<uint8_t>(v);
+            } else {
+                int32_t *dst = assign_all + static_cast<int64_t>(sub) * n + pr;
+                if (*dst != static_cast<int32_t>(v)) {
+                    *dst = static_cast<int32_t>(v);
+                    any_changed = true;
+                }
+            }
+        }
+        const uint64_t lm = __ballot(listed);
+        if (listed) list[at + __popcll(lm & ((1ull << lane) - 1ull))] = PqNomList{static_cast<int32_t>(pr), sub};
+        at += __popcll(lm);
+    }
+    if (!ENC && __ballot(any_changed) && lane == 0) changed[sub] = 1;
 }
 
 // the listed pairs, decided as the reference writes the loop

@@ -523,6 +523,224 @@ __global__ __launch_bounds__(kGemmThreads) void flat_gemm_dma_grouped_kernel(
         static_cast<uint32_t>(g.b_off), mask ? mask_off + g.a_off : nullptr);
 }
 
+// ---- bfloat16, more than 128 queries: a 256 x 256 tile, 8 waves --------------------------------------------------------
+// The 128 x 128 tile above moves 32 KiB into LDS per K step for 16 matrix instructions per wave: at the bf16 rate (16x the fp32
+// one) two resident workgroups ask the L2 -> LDS path for 64 B per clock and CU, and the kernel ran at a third of the matrix
+// peak waiting for tiles (r05: 834 TFLOP/s).  Here a workgroup is 8 waves as 2 (queries) x 4 (rows), each wave 128 x 64 =
+// 4 x 2 accumulators of v_mfma_f32_32x32x16_bf16: 64 KiB per K step for 32 instructions per wave and two waves per SIMD — half
+// the bytes per flop through the fill path, and 6 instead of 8 ds_read_b128 per 8 matrix instructions on the LDS side.  Tiles,
+// swizzle and the operand reads are flat_gemm_dma_body's (a K step = 128 bytes of a row; piece = 8 rows x 128 B per
+// wave-instruction; slot s of row R holds granule s ^ ((R >> 1) & 7)).  What differs:
+//  * one workgroup per CU (LDS), so nothing else hides a barrier: the K loop is rotated by one operand group — the wait for
+//    tile t+1 and the barrier sit BEFORE the last 8 matrix instructions of tile t, whose operands are already in registers; they
+//    and the first operand reads of tile t+1 overlap the barrier skew and the issue of the next fills;
+//  * NB = 3: the row tiles (first touch = an HBM miss) are fetched TWO K steps ahead into a ring of three buffers, the query
+//    tiles (L2-resident) one step ahead into two; 160 KiB of LDS, the whole CU.  NB = 2: one step ahead for both (128 KiB);
+//  * MODE 2 only (the append): the row sample of MODE 1 is 1/64 of the work and stays on the 128 x 128 tile.
+// WAR / RAW on the tiles as MI355X_MICROARCH.md prescribes for LDS-DMA: a wave waits for its own pieces (counted vmcnt), then the
+// barrier publishes them; a buffer is refilled only after a barrier that every wave passed with its reads retired (lgkmcnt(0)).
+constexpr int kBigBM = 256, kBigBN = 256, kBigThreads = 512;
+constexpr int kBigTile = kBigBM * kGemmBK;  // floats per operand tile (256 rows x 128 B = 32 KiB)
+template <int NB>
+constexpr size_t big_lds_bytes() { return (2 + NB) * kBigTile * sizeof(float); }
+
+template <bool DOT, int NB, int PROBE = 0>
+__global__ __launch_bounds__(kBigThreads) void flat_gemm_bf16_big_kernel(
+    const float *__restrict__ queries, int64_t nq, const float *__restrict__ base, int64_t n, int dim /* 4-byte words per row */,
+    const float *__restrict__ norms, const float *__restrict__ thr, int thr_stride, int thr_off, int *__restrict__ counts,
+    uint64_t *__restrict__ cand, int cap, const uint8_t *__restrict__ mask, int64_t mask_stride)
+{
+    static_assert(NB == 2 || NB == 3, "two or three row-tile buffers");
+    extern __shared__ float gemm_lds[];
+    const int mtiles = static_cast<int>((nq + kBigBM - 1) / kBigBM);
+    const int64_t ntiles = (n + kBigBN - 1) / kBigBN;
+    const int64_t bt = blockIdx.x;
+    const int64_t xcd = bt & 7, jx = bt >> 3;  // all query tiles of a row tile on one XCD, back to back (see flat_gemm_kernel)
+    const int64_t tn = (jx / mtiles) * 8 + xcd;
+    const int tm = static_cast<int>(jx % mtiles);
+    if (tn >= ntiles) return;
+    const int64_t q0 = static_cast<int64_t>(tm) * kBigBM, n0 = tn * kBigBN;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+
+    // DMA map: pass p (0..3), wave w (0..7) fill rows p*64 + w*8 .. +8 of a tile
+    const int drow = wave * 8 + (lane >> 3);
+    const int dgl = (lane & 7) ^ ((wave * 4 + (lane >> 4)) & 7);
+    const float *const abase = queries + q0 * dim;
+    const float *const bbase = base + n0 * dim;
+    uint32_t aoff[4], boff[4];
+#pragma unroll
+    for (int p = 0; p < 4; p++) {
+        int64_t qa = q0 + p * 64 + drow;
+        if (qa >= nq) qa = nq - 1;
+        int64_t nb = n0 + p * 64 + drow;
+        if (nb >= n) nb = n - 1;
+        aoff[p] = static_cast<uint32_t>(((qa - q0) * dim + dgl * 4) * 4);
+        boff[p] = static_cast<uint32_t>(((nb - n0) * dim + dgl * 4) * 4);
+    }
+    const int ksteps = dim / kGemmBK;  // whole K steps (the bf16 images are padded to them)
+    const uint32_t lds0 = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(
+        (__attribute__((address_space(3))) void *)gemm_lds));
+    // tile buffers: A0 A1 | B0 .. B(NB-1)
+    auto piece = [&](int buf, int p) {
+        return static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(
+            static_cast<int>(lds0 + (buf * kBigTile + (p * 64 + wave * 8) * kGemmBK) * 4)));
+    };
+    // K order: the query tiles of one row tile (resident together on one XCD) start at staggered K steps, as in
+    // flat_gemm_dma_body<BF16>; ka / kb = the K step of the next query / row tile to fetch, ia / ib = its buffer
+    const int kstart = (tm * 5) % ksteps;
+    int ka = kstart, kb = kstart, ia = 0, ib = 0;
+    auto stage_a = [&]() {
+#pragma unroll
+        for (int p = 0; p < 4; p++) glds16(abase + ka * kGemmBK, aoff[p], piece(ia, p));
+        ka = ka + 1 == ksteps ? 0 : ka + 1;
+        ia ^= 1;
+    };
+    auto stage_b = [&]() {
+        if (!(PROBE & 64)) {
+#pragma unroll
+            for (int p = 0; p < 4; p++) glds16(bbase + kb * kGemmBK, boff[p], piece(2 + ib, p));
+        }
+        kb = kb + 1 == ksteps ? 0 : kb + 1;
+        ib = ib + 1 == NB ? 0 : ib + 1;
+    };
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.0f;
+
+    const int h = lane >> 5, f = (lane >> 1) & 7;
+    int goff[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) goff[j] = ((2 * j + h) ^ f) * 4;
+    const int a_row = (wr * 128 + (lane & 31)) * kGemmBK;
+    const int b_row = (wc * 64 + (lane & 31)) * kGemmBK;
+
+    // epilogue inputs before the K loop: thread t < 256 holds the threshold of query q0 + t, every lane the norms of its two columns
+    float thr_reg = -INFINITY, xn[2];
+    if (tid < kBigBM && q0 + tid < nq) thr_reg = thr[(q0 + tid) * thr_stride + thr_off];
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        const int64_t nn = n0 + wc * 64 + j * 32 + (lane & 31);
+        xn[j] = (!DOT && nn < n) ? norms[nn] : 0.0f;
+    }
+
+    float4 fa[2][4], fb[2][2];  // [set][block]: operand granules of one group (16 k) — the group being multiplied / the next one
+    auto read_group = [&](const float *As, const float *Bs, int j, int set) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) fa[set][i] = *reinterpret_cast<const float4 *>(As + a_row + i * 32 * kGemmBK + goff[j]);
+#pragma unroll
+        for (int i = 0; i < 2; i++) fb[set][i] = *reinterpret_cast<const float4 *>(Bs + b_row + i * 32 * kGemmBK + goff[j]);
+    };
+    auto mfma_group = [&](int set) {
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int j = 0; j < 2; j++)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(vg_bf16x8, fa[set][i]),
+                                                                   __builtin_bit_cast(vg_bf16x8, fb[set][j]), acc[i][j], 0, 0, 0);
+    };
+
+    // prologue: tile 0 (NB = 3: and row tile 1) in flight, published; then the fills of the next step and the first operands
+    stage_a();
+    stage_b();
+    if (NB == 3 && ksteps > 1) {
+        stage_b();
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    int ra = 0, rb = 0;  // buffers the current tile is read from
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): no scalar load pending at the loop's entry (see the wait inside it)
+    read_group(gemm_lds, gemm_lds + 2 * kBigTile, 0, 0);
+    // Step t: the four operand groups of tile t, group j+1 read from LDS while group j is multiplied; the fills of the NEXT step's
+    // tiles — query tile t+1, row tile t+NB-1, into the buffers the barrier at the end of step t-1 freed — go out behind the
+    // first two groups' matrix instructions (an LDS-DMA piece costs the issuing wave ~60 cycles: eight of them right behind the
+    // barrier would leave the matrix pipe empty there), queries first: the wait below counts on that order.
+    // The body is the same straight line for every tile — the last one also passes the barrier and reads "the next tile's" first
+    // group (stale LDS, never multiplied): with a branch around that block the compiler merges two LDS-counter states in front
+    // of the last matrix group and waits lgkmcnt(0) there, i.e. for the reads just issued — the overlap the rotation exists for.
+    for (int t = 0; t < ksteps; t++) {
+        const float *As = gemm_lds + ra * kBigTile, *Bs = gemm_lds + (2 + rb) * kBigTile;
+        if (!(PROBE & 16)) read_group(As, Bs, 1, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_group(0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (t + 1 < ksteps && !(PROBE & 2)) stage_a();
+        if (!(PROBE & 16)) read_group(As, Bs, 2, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_group(1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (t + NB - 1 < ksteps && !(PROBE & 2)) stage_b();
+        if (!(PROBE & 16)) read_group(As, Bs, 3, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_group(0);
+        __builtin_amdgcn_sched_barrier(0);
+        ra ^= 1;
+        rb = rb + 1 == NB ? 0 : rb + 1;
+        // lgkmcnt(0): this wave's reads of tile t are retired (its buffers are refilled in the next step).  It is the builtin, which
+        // the compiler's own counter bookkeeping sees: after it, it knows that no LDS read — and no scalar load, which would force
+        // every later LDS wait to lgkmcnt(0) — is pending.  The DMA wait stays asm (the compiler knows nothing of the fills):
+        // tile t+1 = everything this wave has in flight but (NB = 3) the row tile t+2 issued after query tile t+1.
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        if (NB == 3 && t + 2 < ksteps)
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (!(PROBE & 8)) __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (!(PROBE & 16)) read_group(gemm_lds + ra * kBigTile, gemm_lds + (2 + rb) * kBigTile, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_group(1);  // group 3 of tile t, from registers
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (PROBE & 1) {  // keep the accumulators alive without an epilogue
+        float t = 0.0f;
+        for (int i = 0; i < 4; i++)
+            for (int j = 0; j < 2; j++)
+                for (int r = 0; r < 16; r++) t += acc[i][j][r];
+        if (t == 123.456f) counts[0] = 1;
+        return;
+    }
+    // epilogue: the 256 thresholds through LDS (free once every wave has read its last operands), 32 per lane as 8 ds_read_b128
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (tid < kBigBM) gemm_lds[tid] = thr_reg;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        float4 t4[4];  // thresholds of rows i*32 + 8*g + 4*(lane>>5) + 0..3
+#pragma unroll
+        for (int g = 0; g < 4; g++) t4[g] = *reinterpret_cast<const float4 *>(gemm_lds + wr * 128 + i * 32 + 8 * g + 4 * h);
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const int64_t nn = n0 + wc * 64 + j * 32 + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int64_t qq = q0 + wr * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const float dotv = acc[i][j][r];
+                const float sc = DOT ? -dotv : __builtin_fmaf(-2.0f, dotv, xn[j]);
+                const float4 tv = t4[r >> 2];
+                const float t = (r & 3) == 0 ? tv.x : (r & 3) == 1 ? tv.y : (r & 3) == 2 ? tv.z : tv.w;
+                // (queries past nq carry the threshold -Inf: nothing passes; the filter bit is looked at only below the threshold)
+                if (nn < n && sc < t && (mask == nullptr || mask_bit(mask + qq * mask_stride, nn))) {
+                    const int pos = atomicAdd(&counts[qq], 1);
+                    if (pos < cap) cand[qq * cap + pos] = make_key(sc, static_cast<uint32_t>(nn), false);
+                }
+            }
+        }
+    }
+}
+
 // ---- 5..64 queries: the same pipeline with a 32 x 128 or 64 x 128 tile ------------------------------
 // A 128-query tile does 128 queries' worth of MFMA work whatever it holds (1.65 ms per pass over
 // 1M x 768 rows).  With RB = 1 or 2 blocks of 32 query rows the MFMA time drops 4x / 2x and the pass

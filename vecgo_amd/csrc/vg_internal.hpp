@@ -84,6 +84,8 @@ enum Hook {
     kHookPqListAll,           // VG_PQ_LIST_ALL          PQ Encode / assignment: every (row, sub-quantizer) pair is listed
     kHookPqFp32Mfma,          // VG_PQ_FP32_MFMA         PQ Encode / assignment: the fp32 matrix form (pq_nominate_kernel)
     kHookProbeNoGemm,         // VG_PROBE_NO_GEMM        probed fp32 scan: the exact kernels only, no matrix-core nomination
+    kHookFlatNoBigTile,       // VG_FLAT_NO_BIG_TILE     bf16 nomination: the 128 x 128 tile even above 128 queries
+    kHookFlatBigTile2,        // VG_FLAT_BIG_TILE_2      bf16 256 x 256 tile with two row-tile buffers (128 KiB) instead of three
     kHookCount
 };
 bool hook(Hook h);

@@ -6,6 +6,11 @@ the "segments" are contiguous row shards, one per rank: every rank scores the sa
 against its shard, the per-shard top-k (k ids + k scores per query) is exchanged with ONE
 all-gather (RCCL over xGMI; nq*k*8 bytes per rank, ids and score bits in one buffer), and every rank merges with the reference's
 tie-break (score, then RowID — searcher/candidate_queue.go:12-23).  No other collective.
+
+Graph search does not shard by rows (a traversal needs the whole graph: SURVEY.md section 8e, "replicas only"): there every rank
+holds a REPLICA and takes a contiguous slice of the query batch (replicated_search, ReplicatedGraphIndex) — the reference's
+analogue is one goroutine per query over one shared index (engine/search.go:835-908 fans out per segment, benchmark_test's
+concurrent searches per query).  One all-gather of the per-slice results, concatenated in query order; nothing to merge.
 """
 from __future__ import annotations
 
@@ -154,6 +159,56 @@ class ShardedFlatIndex:
                               stream=stream)
 
 
+def replicated_search(local_search: Callable, queries, k: int, group=None):
+    """Query-sharded search over replicas: rank r answers queries[qb[r]:qb[r+1]] (qb = partition(nq, world)) with
+    local_search(q_slice, k) -> (ids[nq_r, k] int32 bit-pattern of uint32 GLOBAL row ids, scores[nq_r, k] f32) on its replica,
+    and ONE all-gather of the [2, nq_pad, k] int32 blocks (ids + score bits; nq_pad = the largest slice, so that every rank
+    contributes the same count) puts the whole batch on every rank, in query order.  No merge: a query is answered by exactly
+    one rank, with the ids and score bits the single-process search returns."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    nq = queries.shape[0]
+    qb = partition(nq, world)
+    lo, hi = qb[rank], qb[rank + 1]
+    pad = max(qb[r + 1] - qb[r] for r in range(world))
+    q_local = queries[lo:hi]
+    is_t = isinstance(queries, torch.Tensor)
+    dev = queries.device if is_t else "cpu"
+    mine = torch.zeros((2, pad, k), dtype=torch.int32, device=dev)
+    if hi > lo:
+        ids, scores = local_search(q_local, k)
+        ids = ids if isinstance(ids, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(ids).view(np.int32))
+        scores = scores if isinstance(scores, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(scores, np.float32))
+        mine[0, :hi - lo].copy_(ids.view(torch.int32).reshape(hi - lo, k))
+        mine[1, :hi - lo].copy_(scores.reshape(hi - lo, k).view(torch.int32))
+    if world == 1:
+        return mine[0, :nq], mine[1, :nq].view(torch.float32)
+    gathered = torch.empty((world, 2, pad, k), dtype=torch.int32, device=dev)
+    dist.all_gather_into_tensor(gathered.view(world * 2 * pad, k), mine.view(2 * pad, k), group=group)
+    ids = torch.cat([gathered[r, 0, :qb[r + 1] - qb[r]] for r in range(world)])
+    scores = torch.cat([gathered[r, 1, :qb[r + 1] - qb[r]] for r in range(world)]).view(torch.float32)
+    return ids, scores
+
+
+class ReplicatedGraphIndex:
+    """The metric's pipeline — HNSW walk on PQ codes (ef candidates) + exact rerank (engine/search.go:914-965) — at N GPUs:
+    every rank holds the whole index (graph + PQ codes + fp32 rows: 3.3 GB at 1M x 768, of 288 GB) and answers a contiguous
+    slice of the query batch.  `index`: a vecgo_amd.Index with vectors, PQ codes and an HNSW graph attached."""
+
+    def __init__(self, index, group=None):
+        self.index, self.group = index, group
+
+    def search(self, queries, k: int, ef: int, stream=None):
+        def local(q, kk):
+            cand, _ = self.index.search_hnsw_pq(q, ef, ef, stream=stream)
+            return self.index.rerank(q, cand, kk, stream=stream)
+        return replicated_search(local, queries, k, self.group)
+
+    def search_f32(self, queries, k: int, ef: int, stream=None):
+        """the fp32 walk (hnsw.KNNSearch) over the replicas, for the same split"""
+        return replicated_search(lambda q, kk: self.index.search_hnsw(q, kk, ef, stream=stream), queries, k, self.group)
+
+
 def train_pq_sharded(pq, vectors, iters: int = 20, seed: int = 1, group=None, device=None, stream=None, comm=None):
     """PQ training partitioned by sub-quantizer (BASELINE configs[4]; pq.go:83-138 runs the m
     k-means problems independently).  Every rank holds the same training sample, trains
@@ -213,21 +268,31 @@ def train_sq8_sharded(sq, local_rows, group=None):
     sq: a vecgo_amd.ScalarQuantizer (or anything with .train(rows)); local_rows: [n_local, dim] torch tensor or numpy array,
     n_local may be 0."""
     big = float(np.finfo(np.float32).max)
+    # the reference's loop (`val < min` / `val > max`, quantizer.go:156-163) never takes a NaN: it is skipped, not propagated
+    # (torch.amin / np.min would poison the dimension's bounds on every rank) — NaN -> +big for the minimum, -big for the maximum
     if isinstance(local_rows, torch.Tensor):
-        dim = local_rows.shape[1]
-        if local_rows.shape[0]:
-            lo, hi = local_rows.amin(dim=0).float(), local_rows.amax(dim=0).float()
+        dim, count = local_rows.shape[1], local_rows.shape[0]
+        if count:
+            x = local_rows.float()
+            nan = torch.isnan(x)
+            lo = torch.where(nan, torch.full_like(x, big), x).amin(dim=0)
+            hi = torch.where(nan, torch.full_like(x, -big), x).amax(dim=0)
         else:
             lo = torch.full((dim,), big, dtype=torch.float32, device=local_rows.device)
             hi = -lo
     else:
         x = np.asarray(local_rows, np.float32)
-        dim = x.shape[1]
-        lo = torch.from_numpy(x.min(axis=0) if x.shape[0] else np.full(dim, big, np.float32))
-        hi = torch.from_numpy(x.max(axis=0) if x.shape[0] else np.full(dim, -big, np.float32))
+        dim, count = x.shape[1], x.shape[0]
+        nan = np.isnan(x)
+        lo = torch.from_numpy(np.where(nan, np.float32(big), x).min(axis=0) if count else np.full(dim, big, np.float32))
+        hi = torch.from_numpy(np.where(nan, np.float32(-big), x).max(axis=0) if count else np.full(dim, -big, np.float32))
+    total = torch.tensor([count], dtype=torch.int64, device=lo.device)
     if dist.is_initialized() and dist.get_world_size(group) > 1:
         dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=group)
         dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=group)
+        dist.all_reduce(total, op=dist.ReduceOp.SUM, group=group)
+    if int(total.item()) == 0:
+        raise ValueError("no vectors provided")   # quantizer.go:128-130, as single-process Train on an empty corpus
     sq.train(torch.stack([lo, hi]).cpu().numpy())
 
 
