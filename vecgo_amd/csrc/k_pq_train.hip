@@ -1133,8 +1133,11 @@ __device__ __forceinline__ uint32_t pq_umin3(uint32_t a, uint32_t b, uint32_t c)
 
 // (134 registers: three waves per SIMD; held to four — 128 registers, 11 spilled — it is slower, 0.276 vs 0.242 ms per
 // 65 536 x 96 pairs: the kernel is not short of waves)
+#ifndef VG_NOM_WAVES_ATTR
+#define VG_NOM_WAVES_ATTR
+#endif
 template <bool ENC>
-__global__ __launch_bounds__(256) void pq_nominate_bf16_kernel(const float *__restrict__ rows, int64_t n, int dim, int m,
+__global__ __launch_bounds__(256) VG_NOM_WAVES_ATTR void pq_nominate_bf16_kernel(const float *__restrict__ rows, int64_t n, int dim, int m,
                                                                const int8_t *__restrict__ codebooks,
                                                                const float *__restrict__ scales, const float *__restrict__ offsets,
                                                                const float *__restrict__ cent_all, uint8_t *__restrict__ codes,
@@ -1198,25 +1201,28 @@ __global__ __launch_bounds__(256) void pq_nominate_bf16_kernel(const float *__re
     // as its one scalar operand — a literal mask leaves no room for a literal index and costs a v_and + v_or per score
     uint32_t keep;
     asm volatile("v_mov_b32 %0, 0xffffff00" : "=v"(keep));
-    auto load_rows = [&](int pb, float4 &lo4, float4 &hi4) {
-        const int64_t p = row0 + pb * 32 + c_in;
-        const int64_t pc = p < n ? p : n - 1;
-        lo4 = *reinterpret_cast<const float4 *>(xbase + pc * stride);
-        hi4 = *reinterpret_cast<const float4 *>(xbase + pc * stride + 4);
-    };
-    // rows two blocks ahead: a block's 32-byte pieces are in flight for two iterations of the other waves' work
+    // this wave's rows [row0, row0 + rows_mine); a lane's row of block pb: pb * 32 + (lane & 31), past the end the last one
+    // (32-bit offsets from the wave's first row: at most 1024 rows of `stride` floats)
+    const int64_t left = n - row0;
+    const int rows_mine = left <= 0 ? 0 : (left < kNomRowsPerWave ? static_cast<int>(left) : kNomRowsPerWave);
     constexpr int kNb = kNomRowsPerWave / 32;
-    float4 nlo, nhi, n2lo, n2hi;
-    load_rows(0, nlo, nhi);
-    load_rows(1, n2lo, n2hi);
+    const float *const wbase = xbase + row0 * stride;
+    const uint32_t ustride = static_cast<uint32_t>(stride);
+    auto load_rows = [&](int pb, float4 &lo4, float4 &hi4) {
+        int rel = pb * 32 + c_in;
+        rel = rel < rows_mine ? rel : rows_mine - 1;
+        const float *src = wbase + static_cast<uint32_t>(rel) * ustride;
+        lo4 = *reinterpret_cast<const float4 *>(src);
+        hi4 = *reinterpret_cast<const float4 *>(src + 4);
+    };
+    float4 nlo = make_float4(0.0f, 0.0f, 0.0f, 0.0f), nhi = nlo;
+    if (rows_mine > 0) load_rows(0, nlo, nhi);
     for (int pb = 0; pb < kNb; pb++) {
         const int64_t p = row0 + pb * 32 + c_in;
-        if (row0 + pb * 32 >= n) break;  // wave-uniform
+        if (pb * 32 >= rows_mine) break;  // wave-uniform
         const float x[8] = {nlo.x, nlo.y, nlo.z, nlo.w, nhi.x, nhi.y, nhi.z, nhi.w};
 #if !(defined(VG_NOM_PROBE) && VG_NOM_PROBE == 4)  // stage probe 4: the first block's rows again and again (no loads in the loop)
-        nlo = n2lo;
-        nhi = n2hi;
-        load_rows(pb + 2 < kNb ? pb + 2 : kNb - 1, n2lo, n2hi);
+        load_rows(pb + 1 < kNb ? pb + 1 : pb, nlo, nhi);  // in flight under this block's work (nothing else of the loop touches memory)
 #endif
         float X = 0.0f;
 #pragma unroll
@@ -1285,7 +1291,7 @@ __global__ __launch_bounds__(256) void pq_nominate_bf16_kernel(const float *__re
         if (h == 0 && p < n) {
             const uint32_t idx = m1 & 0xFFu;
             const float d1 = __uint_as_float(m1 & keep), d2 = __uint_as_float(m2 & keep);
-            const float sx = sqrtf(X);
+            const float sx = __builtin_amdgcn_sqrtf(X);  // v_sqrt_f32, 1 ulp (the IEEE sqrtf is ~15 instructions): inside the 1.05
             const float cross = 2.0f * sx * sqc + C, dmax = (sx + sqc) * (sx + sqc);
             const float margin = 1.05f * (2.0f * ((3.1f * t16 + 32.0f * u) * cross + (1.01f * t16 + 32.0f * u) * 1.002f * dmax) +
                                           24.0f * u * dmax) + 1e-30f + extra_margin;
@@ -1304,8 +1310,6 @@ __global__ __launch_bounds__(256) void pq_nominate_bf16_kernel(const float *__re
         }
     }
     // flush: this wave's rows [row0, row0 + rows_mine): codes / assignments of the decided rows, one atomic for the listed ones
-    const int64_t left = n - row0;
-    const int rows_mine = left <= 0 ? 0 : (left < kNomRowsPerWave ? static_cast<int>(left) : kNomRowsPerWave);
     int total = 0;
     for (int i0 = 0; i0 < rows_mine; i0 += 64) {
         const int i = i0 + lane;
