@@ -770,6 +770,9 @@ def hnsw_pq_cpu_twin(idx, pq, codes, rows, q, pqr, efs=(128, 512, 2048)):
         ic.close()
 
 
+PQ_SCORE_VALU_SLOTS = 24 * 213  # vector issue slots per PQ node score (m = 96): see vamana_pq
+NOMINATE_VALU_PER_BLOCK = 428  # vector instructions pq_nominate_bf16_kernel executes per (32 rows, sub-quantizer) block of a wave:
+                               # SQ_INSTS_VALU / blocks (profiles/r06_pmc_encode_inst.csv; tools/isa_count.py on the hot loop: 404 + the flush)
 PEAK_VALU_LANEOPS = 78.6e12    # fp32 vector lane-operations per second: 256 CUs x 4 SIMD-32 x 2.4 GHz (MI355X_MICROARCH.md:
                                # "4 SIMD-32 units", v_fma_f32 wave64 = 2 cycles); an FMA counts as ONE lane-op here, so the
                                # same rate is the guide's 157.3 TFLOP/s vector peak
@@ -826,19 +829,19 @@ def build_side_legs(vg, ctx, rows, queries, stream, with_cpu, rows_host=None):
     la, ta = pr["km_assign"]
     lu, tu = pr["km_update"]
     assign_ms = ta / max(la, 1)
-    # One assignment pass = km_gemm_kernel (a training run of >= 3 iterations: bfloat16 splits [hi|lo|hi] x [hi|hi|lo] on
-    # v_mfma_f32_32x32x16_bf16) + the decision + the reference-order kernels over the points the matrix scores cannot
-    # decide.  Priced two ways: `frac` = against the bound of the REFERENCE's arithmetic on the vector ALU (n k dim (sub, fma)
-    # pairs = 2 lane-ops per element: r04's kernel ran at 0.40 of it; above 1 = faster than any kernel that computes the
-    # distances as the reference writes them), and `own_frac` = against what limits THIS pass: every point read once,
-    # n dim 4 algorithmic bytes over the HBM peak (the split image actually read is 1.5x that).
+    # One assignment pass = km_gemm_kernel (a training run of >= 3 iterations: bfloat16 splits [hi|lo] x [hi|lo] on
+    # v_mfma_f32_32x32x16_bf16, three products per 64-element chunk) + the decision + the reference-order kernels over the points
+    # the matrix scores cannot decide.  `bound` / `frac` = what limits THIS pass: every point read once, n dim 4 algorithmic bytes
+    # over the HBM peak (the [hi|lo] image read is the same 4 bytes per element).  `over_reference_valu` = the pass's n k dim
+    # element-steps priced as the REFERENCE writes them — (sub, fma) = 2 lane-operations on the vector ALU — over the vector peak:
+    # above 1 = faster than any kernel that computes the distances that way (r04's ran at 0.40); it is not a fraction of anything
+    # this kernel executes.
     km_ops = 2.0 * n * k_parts * DIM
     km_gbs = n * DIM * 4.0 / (assign_ms * 1e-3) / 1e9
     row = {"workload": f"kmeans.TrainKMeans {n} x {DIM}, k = {k_parts}, 10 iterations: one assignment pass (kmeans.go:54-99)",
            "kernel": "km_gemm_kernel<bf16 splits> + km_decide / km_pairs / km_assign_regs<LIST>", "kernel_ms": assign_ms,
-           "bound": "valu_reference", "achieved": km_ops / (assign_ms * 1e-3) / 1e12, "peak": PEAK_VALU_LANEOPS / 1e12,
-           "unit": "T lane-ops/s", "frac": km_ops / (assign_ms * 1e-3) / PEAK_VALU_LANEOPS,
-           "own_bound": "hbm", "own_frac": km_gbs / PEAK_HBM_GBS, "own_achieved_gbs": km_gbs,
+           "bound": "hbm", "achieved": km_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": km_gbs / PEAK_HBM_GBS,
+           "over_reference_valu": km_ops / (assign_ms * 1e-3) / PEAK_VALU_LANEOPS,
            "mfma_f32_equiv": km_ops / (assign_ms * 1e-3) / 1e12 / PEAK_MFMA_F32_TFLOPS,
            "short": f"kmeans_{n}x{DIM}_k{k_parts}_10it", "train_ms": wall, "assign_launches": la,
            "update_ms_per_iter": tu / max(lu, 1), "lane_ops_per_pass": km_ops}
@@ -876,17 +879,22 @@ def build_side_legs(vg, ctx, rows, queries, stream, with_cpu, rows_host=None):
     lloyd_ms = tas / max(las, 1)
 
     def mfma_row(workload, kernel, kernel_ms, pairs, valu_ops_per_elem, **extra):
-        """pq_nominate_bf16_kernel: `pairs` (row, sub-quantizer) pairs x 256 centroids x 8 dimensions.  `frac` = against the
-        bound of the REFERENCE's arithmetic on the vector ALU (valu_ops_per_elem lane-ops per element; r04's kernels: 0.58 /
-        0.66; above 1 = faster than any kernel computing the distances as the reference writes them); `own_frac` = against
-        this kernel's own vector work: 3 instructions per score (key, second smallest, smallest) at the vector rate —
-        the arithmetic itself is on the bf16 matrix cores (2 instructions per 1024 scores)."""
+        """pq_nominate_bf16_kernel: `pairs` (row, sub-quantizer) pairs x 256 centroids x 8 dimensions.  `bound` / `frac` = what
+        limits the kernel: vector-ALU issue.  Its loop executes NOMINATE_VALU_PER_BLOCK vector instructions per (32 rows,
+        sub-quantizer) block of a wave (tools/isa_count.py on the kernel's hot loop; 2.25 of them per score keep the smallest /
+        second smallest key: v_and_or + med3 / min3 over four keys), and none of them is the fp32 add / fma that gfx950 issues at
+        twice the rate: every one costs a SIMD 4 cycles (tools/ubench/valu_rate.hip; the SQ counts them so: SQ_ACTIVE_INST_VALU =
+        SQ_INSTS_VALU quad-cycles, profiles/r06_pmc_encode_valu.csv) — peak = 256 CUs x 4 SIMDs x 2.4 GHz / 4 wave-instructions/s.
+        The arithmetic itself is on the bf16 matrix cores (2 instructions per 1024 scores, ~25 % busy).  `over_reference_valu` =
+        the reference's arithmetic (valu_ops_per_elem lane-operations per element) over the vector peak: above 1 = faster than any
+        kernel computing the distances as the reference writes them; not a fraction of anything this kernel executes."""
         ops = valu_ops_per_elem * pairs * 256 * sd
-        scan = 3.0 * pairs * 256
-        return {"workload": workload, "kernel": kernel, "kernel_ms": kernel_ms, "bound": "valu_reference",
-                "achieved": ops / (kernel_ms * 1e-3) / 1e12, "peak": PEAK_VALU_LANEOPS / 1e12, "unit": "T lane-ops/s",
-                "frac": ops / (kernel_ms * 1e-3) / PEAK_VALU_LANEOPS, "own_bound": "valu (3 per score)",
-                "own_frac": scan / (kernel_ms * 1e-3) / PEAK_VALU_LANEOPS,
+        blocks = pairs / 32.0
+        ginstr = NOMINATE_VALU_PER_BLOCK * blocks / (kernel_ms * 1e-3) / 1e9
+        return {"workload": workload, "kernel": kernel, "kernel_ms": kernel_ms, "bound": "valu_issue",
+                "achieved": ginstr, "peak": PEAK_VALU_GINSTR, "unit": "G wave-instructions/s", "frac": ginstr / PEAK_VALU_GINSTR,
+                "valu_instructions_per_block": NOMINATE_VALU_PER_BLOCK,
+                "over_reference_valu": ops / (kernel_ms * 1e-3) / PEAK_VALU_LANEOPS,
                 "mfma_f32_equiv": 2.0 * pairs * 256 * sd / (kernel_ms * 1e-3) / 1e12 / PEAK_MFMA_F32_TFLOPS, **extra}
 
     out["pq_train_lloyd"] = mfma_row(
@@ -1118,8 +1126,15 @@ def vamana_pq(vg, ctx, idx, rows, q, gt_ids, stream):
             "recall_at_10_before_rerank": recall_at_k(ids.cpu().numpy().view(np.uint32)[:gt_ids.shape[0]], gt_ids),
             "node_scores_per_query": dc / q.shape[0], "gathered_gbs": gathered / (kern_ms * 1e-3) / 1e9,
             "other_node_scorers": others,
-            "bound": "vector-ALU issue of one wave's serial work: node terms computed from the shared int8 codebook (31 instructions per "
-                     "term, no per-query table) + the exploration heap's pushes; see DESIGN.md section 4 'Graph walks in r03'"}
+            # the node scorer's own bound: vector-ALU issue.  pq_term8_quad (vg_hnsw_layer.hpp:178-210) is 213 issue slots per four
+            # (node, sub-quantizer) terms on one lane's node (tools/isa_count.py on tools/ubench/pq_slice.hip's scoring loop: 57
+            # single + 78 packed-fp32 instructions, a packed one = 2 slots) = 24 x 213 = 5112 slots per node score at m = 96, one node
+            # per lane: 64 scores per wave-instruction slot at the fp32 rate (2 cycles per slot and SIMD)
+            "bound": "valu_issue", "achieved": dc * PQ_SCORE_VALU_SLOTS / (kern_ms * 1e-3) / 1e12, "peak": PEAK_VALU_LANEOPS / 1e12,
+            "unit": "T lane-ops/s", "frac": dc * PQ_SCORE_VALU_SLOTS / (kern_ms * 1e-3) / PEAK_VALU_LANEOPS,
+            "valu_slots_per_node_score": PQ_SCORE_VALU_SLOTS, "gathered_frac_of_hbm": gathered / (kern_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
+            "bound_note": "vector-ALU issue of the node terms computed from the shared int8 codebook (no per-query table) next to the "
+                          "heaps' serial work on the same ALU (scoring = 36 % of a wave's pop, r04 timing build): DESIGN.md"}
 
 
 def flat_ivf_probe(vg, ctx, rows, queries, gt_ids, stream):
@@ -1374,7 +1389,7 @@ def compact_line(full: dict) -> dict:
         if "error" in src:
             cfgs.append({"config": name, "error": str(src["error"])[:160]})
             return
-        cfgs.append({"config": name, **_pick(src, "workload", "kernel", "kernel_ms", "achieved", "peak", "unit", "frac", "traffic"),
+        cfgs.append({"config": name, **_pick(src, "workload", "kernel", "kernel_ms", "bound", "achieved", "peak", "unit", "frac", "traffic"),
                      **{k: _r(v) for k, v in extra.items() if v is not None}})
 
     # configs[1]: the headline kernel (same numbers as `roofline`, in the per-config shape)
@@ -1383,7 +1398,7 @@ def compact_line(full: dict) -> dict:
     fs = full.get("flat_small_batch")
     if isinstance(fs, dict) and "q1" in fs:
         for nq in ("q1", "q32"):
-            row(f"configs[1] {nq} (HBM-bound batch)", {**fs[nq], "peak": fs["peak"], "unit": fs["unit"],
+            row(f"configs[1] {nq} (HBM-bound batch)", {**fs[nq], "bound": fs.get("bound", "hbm"), "peak": fs["peak"], "unit": fs["unit"],
                                                        "workload": f"flat_exact_l2_1Mx768_top10_n{nq}"}, qps=fs[nq].get("qps"))
     else:
         row("configs[1] small batches", fs)
@@ -1446,8 +1461,8 @@ def compact_line(full: dict) -> dict:
                           ("sq8_batch", "f3 sq8 batch, 1024 queries")):
             e = bs.get(key)
             if isinstance(e, dict):
-                row(name, {**e, "workload": e.get("short", e.get("workload"))}, bound=e.get("bound"),
-                    **{k: e.get(k) for k in ("own_bound", "own_frac", "train_ms", "cpu_ms", "cpu_train_ms", "cpu_qps", "bits_equal")})
+                row(name, {**e, "workload": e.get("short", e.get("workload"))},
+                    **{k: e.get(k) for k in ("over_reference_valu", "train_ms", "cpu_ms", "cpu_train_ms", "cpu_qps", "bits_equal")})
 
     # the metric's NAMED pipeline (HNSW on PQ codes + exact rerank, recall@10 >= 0.95): what it reaches on BASELINE's corpus
     # (the best recall inside the sweep — below the bar) and on the structured extra corpus (the fastest entry at the bar)

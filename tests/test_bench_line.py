@@ -54,6 +54,16 @@ def test_compact_line_survives_failed_legs():
     assert len(line) < bench.LINE_LIMIT
 
 
+def _check_fractions(d):
+    """Every configs[] row that quotes a fraction quotes it against the PHYSICAL bound of the kernel that runs:
+    a named bound and 0 < frac <= 1; ratios against arithmetic the kernel does not execute live under other keys."""
+    for c in d["configs"]:
+        if "frac" in c:
+            assert c.get("bound"), c
+            assert 0 < c["frac"] <= 1, c
+            assert "valu_reference" not in str(c["bound"]), c
+
+
 def test_captured_line_of_this_round():
     """The line bench.py printed on the GPU box this round (copied from gpurun_out/ into profiles/)."""
     cap = sorted((ROOT / "profiles").glob("r0[4-9]_bench_stdout.txt"))
@@ -61,7 +71,19 @@ def test_captured_line_of_this_round():
         pytest.skip("no captured line committed yet this round")
     lines = [ln for ln in cap[-1].read_text().splitlines() if ln.strip()]
     assert len(lines) == 1, "bench.py must print exactly one stdout line"
-    _check(lines[0])
+    d = _check(lines[0])
+    if cap[-1].name >= "r06":
+        _check_fractions(d)
+
+
+def test_every_fraction_is_against_a_physical_bound():
+    """compact_line over the newest committed full record: rows built by THIS bench.py carry bound + 0 < frac <= 1."""
+    import bench
+    full_files = sorted((ROOT / "profiles").glob("r0[6-9]_bench_full.json"))
+    if not full_files:
+        pytest.skip("no full record of this round committed yet")
+    full = json.loads(full_files[-1].read_text())
+    _check_fractions(bench.compact_line(full))
 
 
 def _run_bench(args, **env_over):

@@ -1,5 +1,5 @@
 // The bfloat16 nomination GEMM (MODE 2: append what falls below each query's threshold), 1024 queries x N rows x 768 elements:
-// the 128 x 128 tile (flat_gemm_dma_kernel<.., true>) against the 256 x 256 tile (flat_gemm_bf16_big_kernel, NB = 2 / 3) and
+// the 128 x 128 tile (flat_gemm_dma_kernel<.., true>) against the persistent 256 x 256 tile (flat_gemm_bf16_big_kernel, NB = 2 / 3) and
 // its stage probes, on REAL bfloat16 data (uniform [-1, 1): what the operands are sets the clock the chip holds —
 // MI355X_MICROARCH.md 'DVFS give-back').  Checks the appended (query, row) sets of the two tiles against each other.
 //   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -std=c++17 -I../../vecgo_amd/csrc -I../../include \
@@ -109,8 +109,10 @@ static void run_big(const char *name, const Bufs &b)
     const size_t lds = vg::big_lds_bytes<NB>();
     CK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
     const int64_t mt = (b.nq + vg::kBigBM - 1) / vg::kBigBM, nt = (b.n + vg::kBigBN - 1) / vg::kBigBN;
+    const int64_t slots = mt * ((nt + 7) / 8) * 8;  // persistent: one workgroup per CU
+    const unsigned grid = unsigned(slots < 256 ? slots : 256);
     const float ms = time_ms(b, [&] {
-        hipLaunchKernelGGL(kern, dim3(unsigned(mt * ((nt + 7) / 8) * 8)), dim3(vg::kBigThreads), lds, 0, b.q, b.nq, b.base, b.n, b.dw, b.norms,
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(vg::kBigThreads), lds, 0, b.q, b.nq, b.base, b.n, b.dw, b.norms,
                            b.thr, 1, 0, b.counts, b.cand, b.cap, (const uint8_t *)nullptr, int64_t(0));
     });
     report(name, b, ms);
@@ -196,6 +198,11 @@ int main(int argc, char **argv)
         printf("    appended pairs %zu; only in the 128-tile set %zu, only in this set %zu (scores next to the threshold), scores off by > 1e-3: %zu\n",
                total, only_ref, only_got, score_off);
     }
+    run_big<3, 512>("NB = 3: full kernel, row fills behind the FIRST group", b);
+    run_big<3, 4096>("NB = 3: keys stored without atomics (slots 0 / 1 of a list)", b);
+    run_big<3, 2048>("NB = 3: passing elements collected and dropped", b);
+    run_big<3, 256>("NB = 3: the block maxima only, nothing appended", b);
+    run_big<3, 1 | 1024>("NB = 3: - epilogue, accumulators start at 0", b);
     run_big<2, 1>("NB = 2: - epilogue", b);
     run_big<3, 1>("NB = 3: - epilogue", b);
     run_big<3, 1 | 64>("NB = 3: - epilogue, query tiles only by DMA", b);

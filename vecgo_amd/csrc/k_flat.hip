@@ -38,6 +38,7 @@ struct GemmArgs {
     int cap;
     const uint8_t *mask = nullptr;  // row filter of a filtered search (k_probe.hip): bit per (query, row), or one per row
     int64_t mask_stride = 0;
+    int cus = 256;  // compute units of the device (the persistent bf16 tile launches one workgroup per CU)
 };
 
 template <bool DOT, int MODE>
@@ -58,14 +59,17 @@ static int32_t launch_gemm_t(bool dma, unsigned blocks, hipStream_t st, const Ge
                       a.cand, a.cap, a.mask, a.mask_stride);
             return VG_OK;
         }
-        if (MODE == 2 && a.nq > kGemmBM && !hook(kHookFlatNoBigTile)) {  // more than one 128-query tile: the 256 x 256 tile
+        // more than one 128-query tile: the persistent 256 x 256 tile (32-bit candidate offsets: nq * cap < 2^31)
+        if (MODE == 2 && a.nq > kGemmBM && a.nq * static_cast<int64_t>(a.cap) < (int64_t(1) << 31) && a.thr_stride < 65536 &&
+            !hook(kHookFlatNoBigTile)) {
             const bool two = hook(kHookFlatBigTile2);
             auto kern = two ? flat_gemm_bf16_big_kernel<DOT, 2> : flat_gemm_bf16_big_kernel<DOT, 3>;
             const size_t lds = two ? big_lds_bytes<2>() : big_lds_bytes<3>();
             VG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        static_cast<int>(lds)));
             const int64_t mt = (a.nq + kBigBM - 1) / kBigBM, nt = (a.n + kBigBN - 1) / kBigBN;
-            VG_LAUNCH(kern, dim3(static_cast<unsigned>(mt * ((nt + 7) / 8) * 8)), dim3(kBigThreads), lds, st, a.queries, a.nq,
+            const int64_t slots = mt * ((nt + 7) / 8) * 8, per_cu = std::max(a.cus / 8, 1) * 8;  // (one workgroup per CU: LDS)
+            VG_LAUNCH(kern, dim3(static_cast<unsigned>(std::min(slots, per_cu))), dim3(kBigThreads), lds, st, a.queries, a.nq,
                       a.base, a.n, a.dim, a.norms, a.thr, a.thr_stride, a.thr_off, a.counts, a.cand, a.cap, a.mask, a.mask_stride);
             return VG_OK;
         }
@@ -798,7 +802,7 @@ int32_t vg::flat_search_masked(vg_index *idx, const float *queries, int64_t nq, 
                     vg::ProfScope prof(idx->ctx, "flat_gemm", st);
                     VG_TRY(vg::launch_gemm<2>(dot, dma, static_cast<unsigned>(mt * ((nt + 7) / 8) * 8), st,
                                               {ga, cnt, gb, n, gdim, idx->d_norms, nullptr, 1, 0, thr,
-                                               sel_k, sel_k - 1, counts, cand, cap, m0, mask_stride}, bf16));
+                                               sel_k, sel_k - 1, counts, cand, cap, m0, mask_stride, idx->ctx->compute_units}, bf16));
                 }
                 // (c) the kc best appended keys (k > kGemmMaxK: all of them go to the exact re-score below)
                 if (k <= vg::kGemmMaxK)
@@ -1106,7 +1110,8 @@ int32_t flat_nominate_bf16(vg_ctx *ctx, const uint16_t *rows_bf16, const float *
     {
         ProfScope prof(ctx, "sq8_nominate_gemm", st);
         VG_TRY(launch_gemm<2>(dot, true, static_cast<unsigned>(mt * ((nt + 7) / 8) * 8), st,
-                              {ga, cnt, gb, n, gdim, norms, nullptr, 1, 0, thr, sel_k, sel_k - 1, counts, cand, kNomCap, mask, mask_stride},
+                              {ga, cnt, gb, n, gdim, norms, nullptr, 1, 0, thr, sel_k, sel_k - 1, counts, cand, kNomCap, mask, mask_stride,
+                               ctx->compute_units},
                               true));
     }
     if (pick) VG_LAUNCH(flat_pick_kernel, dim3(static_cast<unsigned>(cnt)), dim3(256), 0, st, cand, counts, kNomCap, kNomKc, cand_id, cand_sc);

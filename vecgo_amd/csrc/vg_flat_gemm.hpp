@@ -523,26 +523,64 @@ __global__ __launch_bounds__(kGemmThreads) void flat_gemm_dma_grouped_kernel(
         static_cast<uint32_t>(g.b_off), mask ? mask_off + g.a_off : nullptr);
 }
 
-// ---- bfloat16, more than 128 queries: a 256 x 256 tile, 8 waves --------------------------------------------------------
+// ---- bfloat16, more than 128 queries: a 256 x 256 tile, 8 waves, one persistent workgroup per CU ---------------------------
 // The 128 x 128 tile above moves 32 KiB into LDS per K step for 16 matrix instructions per wave: at the bf16 rate (16x the fp32
 // one) two resident workgroups ask the L2 -> LDS path for 64 B per clock and CU, and the kernel ran at a third of the matrix
-// peak waiting for tiles (r05: 834 TFLOP/s).  Here a workgroup is 8 waves as 2 (queries) x 4 (rows), each wave 128 x 64 =
-// 4 x 2 accumulators of v_mfma_f32_32x32x16_bf16: 64 KiB per K step for 32 instructions per wave and two waves per SIMD — half
-// the bytes per flop through the fill path, and 6 instead of 8 ds_read_b128 per 8 matrix instructions on the LDS side.  Tiles,
-// swizzle and the operand reads are flat_gemm_dma_body's (a K step = 128 bytes of a row; piece = 8 rows x 128 B per
+// peak waiting for tiles (r05: 834 TFLOP/s; profiles/r06_pmc_gemm_bf16_*.csv).  Here a workgroup is 8 waves as 2 (queries) x 4
+// (rows), each wave 128 x 64 = 4 x 2 accumulators of v_mfma_f32_32x32x16_bf16: 64 KiB per K step for 32 instructions per wave
+// and two waves per SIMD — half the bytes per flop through the fill path, 6 instead of 8 ds_read_b128 per 8 matrix instructions.
+// Tiles, swizzle and operand reads are flat_gemm_dma_body's (a K step = 128 bytes of a row; piece = 8 rows x 128 B per
 // wave-instruction; slot s of row R holds granule s ^ ((R >> 1) & 7)).  What differs:
-//  * one workgroup per CU (LDS), so nothing else hides a barrier: the K loop is rotated by one operand group — the wait for
-//    tile t+1 and the barrier sit BEFORE the last 8 matrix instructions of tile t, whose operands are already in registers; they
-//    and the first operand reads of tile t+1 overlap the barrier skew and the issue of the next fills;
-//  * NB = 3: the row tiles (first touch = an HBM miss) are fetched TWO K steps ahead into a ring of three buffers, the query
-//    tiles (L2-resident) one step ahead into two; 160 KiB of LDS, the whole CU.  NB = 2: one step ahead for both (128 KiB);
+//  * one workgroup per CU (160 KiB of LDS), so nothing else hides a barrier: the K loop is rotated by one operand group — the
+//    wait for the next step's tiles and the barrier sit BEFORE the last 8 matrix instructions of a step, whose operands are
+//    already in registers; they and the first operand reads of the next step overlap the barrier skew;
+//  * the row tiles (first touch = an HBM miss) are fetched TWO K steps ahead into a ring of three buffers (NB = 3), the query
+//    tiles (L2-resident) one step ahead into two;
+//  * PERSISTENT: the grid is one workgroup per CU and a workgroup walks its tiles (bt, bt + grid, ...: the same XCD, the same
+//    XCD-aware order as above) as ONE stream of K steps — the fills of the next tile's first steps are in flight while the
+//    current tile finishes, and its epilogue runs under them.  With a workgroup per tile every tile paid a launch, a cold first
+//    fill and a drained pipe: 3.9 of 14.4 us per tile with nothing but matrix instructions in the loop (tools/ubench/gemm_bf16_probe);
+//  * the epilogue is a sign test: the accumulators START at (t_q - |x_r|^2) / 2 (L2; t_q for Dot: t = the query's threshold) —
+//    eight extra matrix instructions per tile on a 3-way bfloat16 split of t/2 against ones and of -|x|^2/2 — so that
+//    score < t  <=>  accumulator > 0, found with 8 v_max3 per 16 scores; only a (wave, 32 x 32 block) with a hit looks at its
+//    elements.  (fma + compare + branch per score cost 0.35 of 1.78 ms.)  The appended key's score is t - 2 acc (t - acc);
 //  * MODE 2 only (the append): the row sample of MODE 1 is 1/64 of the work and stays on the 128 x 128 tile.
+// The scores differ from the 128-tile kernel's by roundings only (the accumulation starts from another value): they are a filter
+// whose error bound does not depend on the order (flat_verify_kernel's eps_extra).
 // WAR / RAW on the tiles as MI355X_MICROARCH.md prescribes for LDS-DMA: a wave waits for its own pieces (counted vmcnt), then the
 // barrier publishes them; a buffer is refilled only after a barrier that every wave passed with its reads retired (lgkmcnt(0)).
 constexpr int kBigBM = 256, kBigBN = 256, kBigThreads = 512;
 constexpr int kBigTile = kBigBM * kGemmBK;  // floats per operand tile (256 rows x 128 B = 32 KiB)
 template <int NB>
 constexpr size_t big_lds_bytes() { return (2 + NB) * kBigTile * sizeof(float); }
+
+// x = p0 + p1 + p2 exactly (three bfloat16 = 24 significant bits; x finite), the three as the low halves of p0, p1, p2
+__device__ __forceinline__ void big_split3(float x, uint32_t &p0, uint32_t &p1, uint32_t &p2)
+{
+    auto rne = [](float v) {
+        const uint32_t u = __float_as_uint(v);
+        return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+    };
+    p0 = rne(x);
+    const float r1 = x - __uint_as_float(p0 << 16);
+    p1 = rne(r1);
+    const float r2 = r1 - __uint_as_float(p1 << 16);
+    p2 = rne(r2);
+}
+// lane `sel` of dst = val (both wave-uniform); the other lanes keep theirs
+__device__ __forceinline__ void big_writelane(uint32_t &dst, uint32_t val, int sel)
+{
+    uint32_t keep;  // (one scalar operand per instruction on gfx9: the lane select goes through M0, saved and restored)
+    asm volatile("s_mov_b32 %1, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tv_writelane_b32 %0, %2, m0\n\ts_mov_b32 m0, %1"
+                 : "+v"(dst), "=&s"(keep)
+                 : "s"(val), "s"(sel));
+}
+__device__ __forceinline__ int big_max3_i32(int a, int b, int c)
+{
+    int r;
+    asm("v_max3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
 
 template <bool DOT, int NB, int PROBE = 0>
 __global__ __launch_bounds__(kBigThreads) void flat_gemm_bf16_big_kernel(
@@ -553,35 +591,49 @@ __global__ __launch_bounds__(kBigThreads) void flat_gemm_bf16_big_kernel(
     static_assert(NB == 2 || NB == 3, "two or three row-tile buffers");
     extern __shared__ float gemm_lds[];
     const int mtiles = static_cast<int>((nq + kBigBM - 1) / kBigBM);
-    const int64_t ntiles = (n + kBigBN - 1) / kBigBN;
-    const int64_t bt = blockIdx.x;
-    const int64_t xcd = bt & 7, jx = bt >> 3;  // all query tiles of a row tile on one XCD, back to back (see flat_gemm_kernel)
-    const int64_t tn = (jx / mtiles) * 8 + xcd;
-    const int tm = static_cast<int>(jx % mtiles);
-    if (tn >= ntiles) return;
-    const int64_t q0 = static_cast<int64_t>(tm) * kBigBM, n0 = tn * kBigBN;
+    const int ntiles = static_cast<int>((n + kBigBN - 1) / kBigBN);
+    // Tile slots: slot bt = 8 jx + xcd holds (query tile tm = jx % mtiles, row tile tn = 8 (jx / mtiles) + xcd) — all query tiles
+    // of a row tile on one XCD, back to back (see flat_gemm_kernel); the last 8 row tiles may have holes (tn >= ntiles).  A
+    // workgroup's slots are blockIdx.x + i * gridDim.x (gridDim.x a multiple of 8: always the same XCD); a position keeps jx's
+    // quotient and remainder by mtiles and steps them by the constants dq / dr — no division in the K-step loop (a 64-bit one is
+    // ~120 scalar instructions, and the loop needed eight of them at every tile boundary, in front of the matrix instructions).
+    const int total = mtiles * ((ntiles + 7) / 8) * 8, G = static_cast<int>(gridDim.x), xcd = static_cast<int>(blockIdx.x & 7);
+    const int dq = (G >> 3) / mtiles, dr = (G >> 3) % mtiles;
+    struct Pos {
+        int bt, quo, rem;  // slot; (bt >> 3) / mtiles and % mtiles
+    };
+    auto tm_of = [&](const Pos &p) { return p.rem; };
+    auto tn_of = [&](const Pos &p) { return p.quo * 8 + xcd; };
+    auto step = [&](Pos &p) {  // this workgroup's next slot that holds a tile (bt >= total: none)
+        do {
+            p.bt += G;
+            p.quo += dq;
+            p.rem += dr;
+            if (p.rem >= mtiles) {
+                p.rem -= mtiles;
+                p.quo++;
+            }
+        } while (p.bt < total && tn_of(p) >= ntiles);
+    };
+    Pos pos0;
+    pos0.bt = static_cast<int>(blockIdx.x);
+    pos0.quo = (pos0.bt >> 3) / mtiles;
+    pos0.rem = (pos0.bt >> 3) % mtiles;
+    if (pos0.bt < total && tn_of(pos0) >= ntiles) step(pos0);
+    if (pos0.bt >= total) return;
+    int my_tiles = 0;
+    for (Pos p = pos0; p.bt < total; step(p)) my_tiles++;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
+    const int ksteps = dim / kGemmBK;  // whole K steps (the bf16 images are padded to them)
+    const int S = my_tiles * ksteps;   // this workgroup's stream of K steps
 
     // DMA map: pass p (0..3), wave w (0..7) fill rows p*64 + w*8 .. +8 of a tile
     const int drow = wave * 8 + (lane >> 3);
     const int dgl = (lane & 7) ^ ((wave * 4 + (lane >> 4)) & 7);
-    const float *const abase = queries + q0 * dim;
-    const float *const bbase = base + n0 * dim;
-    uint32_t aoff[4], boff[4];
-#pragma unroll
-    for (int p = 0; p < 4; p++) {
-        int64_t qa = q0 + p * 64 + drow;
-        if (qa >= nq) qa = nq - 1;
-        int64_t nb = n0 + p * 64 + drow;
-        if (nb >= n) nb = n - 1;
-        aoff[p] = static_cast<uint32_t>(((qa - q0) * dim + dgl * 4) * 4);
-        boff[p] = static_cast<uint32_t>(((nb - n0) * dim + dgl * 4) * 4);
-    }
-    const int ksteps = dim / kGemmBK;  // whole K steps (the bf16 images are padded to them)
     const uint32_t lds0 = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(
         (__attribute__((address_space(3))) void *)gemm_lds));
     // tile buffers: A0 A1 | B0 .. B(NB-1)
@@ -589,54 +641,235 @@ __global__ __launch_bounds__(kBigThreads) void flat_gemm_bf16_big_kernel(
         return static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(
             static_cast<int>(lds0 + (buf * kBigTile + (p * 64 + wave * 8) * kGemmBK) * 4)));
     };
-    // K order: the query tiles of one row tile (resident together on one XCD) start at staggered K steps, as in
-    // flat_gemm_dma_body<BF16>; ka / kb = the K step of the next query / row tile to fetch, ia / ib = its buffer
-    const int kstart = (tm * 5) % ksteps;
-    int ka = kstart, kb = kstart, ia = 0, ib = 0;
-    auto stage_a = [&]() {
+    // fetch cursors: the (tile, K step) the next query / row tile fill is for, its source and the buffer it goes to.  A piece's
+    // source = a wave-uniform address (tile base + K step + the piece's first row: scalar arithmetic) + ONE per-lane offset
+    // (row within the piece, swizzled granule) for all pieces; only a tile that sticks out of the matrix (a_last / b_last < 255:
+    // its rows past the end re-read the last one — their results are never appended) computes a per-piece offset.
+    Pos a_pos = pos0, b_pos = pos0;
+    int a_k = 0, b_k = 0, ia = 0, ib = 0;
+    const float *abase, *bbase;
+    int a_last, b_last;  // last row of the tile that exists (255 for a whole tile)
+    const uint32_t off0 = static_cast<uint32_t>((drow * dim + dgl * 4) * 4);
+    auto set_a = [&](const Pos &ps) {
+        const int64_t q0 = static_cast<int64_t>(tm_of(ps)) * kBigBM;
+        abase = queries + q0 * dim;
+        a_last = static_cast<int>(nq - q0 < kBigBM ? nq - q0 : kBigBM) - 1;
+    };
+    auto set_b = [&](const Pos &ps) {
+        const int64_t n0 = static_cast<int64_t>(tn_of(ps)) * kBigBN;
+        bbase = base + n0 * dim;
+        b_last = static_cast<int>(n - n0 < kBigBN ? n - n0 : kBigBN) - 1;
+    };
+    auto fill = [&](const float *src /* tile base + K step */, int last, int buf) {
+        if (last == kBigBM - 1) {
 #pragma unroll
-        for (int p = 0; p < 4; p++) glds16(abase + ka * kGemmBK, aoff[p], piece(ia, p));
-        ka = ka + 1 == ksteps ? 0 : ka + 1;
+            for (int p = 0; p < 4; p++) glds16(src + static_cast<int64_t>(p) * 64 * dim, off0, piece(buf, p));
+        } else {
+#pragma unroll
+            for (int p = 0; p < 4; p++) {
+                const int row = p * 64 + drow < last ? p * 64 + drow : last;
+                glds16(src, static_cast<uint32_t>((row * dim + dgl * 4) * 4), piece(buf, p));
+            }
+        }
+    };
+    auto stage_a = [&]() {
+        fill(abase + a_k * kGemmBK, a_last, ia);
         ia ^= 1;
+        if (++a_k == ksteps) {
+            a_k = 0;
+            step(a_pos);
+            if (a_pos.bt < total) set_a(a_pos);
+        }
     };
     auto stage_b = [&]() {
-        if (!(PROBE & 64)) {
-#pragma unroll
-            for (int p = 0; p < 4; p++) glds16(bbase + kb * kGemmBK, boff[p], piece(2 + ib, p));
-        }
-        kb = kb + 1 == ksteps ? 0 : kb + 1;
+        if (!(PROBE & 64)) fill(bbase + b_k * kGemmBK, b_last, 2 + ib);
         ib = ib + 1 == NB ? 0 : ib + 1;
+        if (++b_k == ksteps) {
+            b_k = 0;
+            step(b_pos);
+            if (b_pos.bt < total) set_b(b_pos);
+        }
     };
+    set_a(pos0);
+    set_b(pos0);
+
     f32x16 acc[4][2];
-#pragma unroll
-    for (int i = 0; i < 4; i++)
-#pragma unroll
-        for (int j = 0; j < 2; j++)
-#pragma unroll
-            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.0f;
-
     const int h = lane >> 5, f = (lane >> 1) & 7;
-    int goff[4];
+    int lpart[4];  // floats: this lane's row within a 32-row block + its swizzled granule of group j
 #pragma unroll
-    for (int j = 0; j < 4; j++) goff[j] = ((2 * j + h) ^ f) * 4;
-    const int a_row = (wr * 128 + (lane & 31)) * kGemmBK;
-    const int b_row = (wc * 64 + (lane & 31)) * kGemmBK;
+    for (int j = 0; j < 4; j++) lpart[j] = (lane & 31) * kGemmBK + ((2 * j + h) ^ f) * 4;
+    const int a_wave = wr * 128 * kGemmBK, b_wave = wc * 64 * kGemmBK;  // wave-uniform
 
-    // epilogue inputs before the K loop: thread t < 256 holds the threshold of query q0 + t, every lane the norms of its two columns
-    float thr_reg = -INFINITY, xn[2];
-    if (tid < kBigBM && q0 + tid < nq) thr_reg = thr[(q0 + tid) * thr_stride + thr_off];
+    // Per tile: lane l keeps the thresholds of the wave's query rows l and 64 + l and the norm of its row column l, loaded a
+    // matrix group before the tile starts; tile_init hands every lane those of ITS rows (32 i + (l & 31)) and columns
+    // (32 j + (l & 31)) by ds_bpermute and turns them into the accumulators' starting values (see the header).
+    constexpr float kThrClamp = 1e30f;  // +-Inf thresholds (no sample / queries past nq) stay finite in the matrix unit
+    Pos c_pos = pos0;                   // the tile being computed
+    // (every load is unconditional — indices clamped, the values of rows / queries that do not exist replaced afterwards — and a
+    // tile's loads are always followed by its tile_init: a load under a condition leaves the compiler with a "maybe pending"
+    // register, and it drains the whole vector-memory queue, the fills in flight included, before the next tile overwrites it)
+    float tq2[2], xq1;
+    auto tile_loads = [&](const Pos &ps) {
+        const int64_t q0 = static_cast<int64_t>(tm_of(ps)) * kBigBM, n0 = static_cast<int64_t>(tn_of(ps)) * kBigBN;
 #pragma unroll
-    for (int j = 0; j < 2; j++) {
-        const int64_t nn = n0 + wc * 64 + j * 32 + (lane & 31);
-        xn[j] = (!DOT && nn < n) ? norms[nn] : 0.0f;
-    }
+        for (int i = 0; i < 2; i++) {
+            const int64_t qq = q0 + wr * 128 + i * 64 + lane;
+            tq2[i] = thr[(qq < nq ? qq : nq - 1) * thr_stride + thr_off];
+        }
+        const int64_t nn = n0 + wc * 64 + lane;
+        xq1 = norms[nn < n ? nn : n - 1];
+    };
+    auto tile_init = [&]() {
+        const uint32_t one = 0x3F80u;  // bfloat16 1.0
+        uint4 ta[4], xb[2];
+        // (the tile being initialised: c_pos; queries past nq get -Inf = nothing passes, rows past n are never appended)
+        const int64_t iq0 = static_cast<int64_t>(tm_of(c_pos)) * kBigBM;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            float t = __shfl(tq2[i >> 1], (i & 1) * 32 + (lane & 31));
+            t = iq0 + wr * 128 + i * 32 + (lane & 31) < nq ? t : -INFINITY;
+            t = t < kThrClamp ? t : kThrClamp;    // (NaN -> the clamp: everything passes, the search falls back to its exact kernel)
+            t = t > -kThrClamp ? t : -kThrClamp;
+            uint32_t p0, p1, p2;
+            big_split3(DOT ? t : 0.5f * t, p0, p1, p2);
+            ta[i] = h == 0 ? make_uint4(p0 | (p1 << 16), p2 | (one << 16), one | (one << 16), 0u) : make_uint4(0u, 0u, 0u, 0u);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            uint32_t p0 = 0, p1 = 0, p2 = 0;
+            if (!DOT) big_split3(-0.5f * __shfl(xq1, j * 32 + (lane & 31)), p0, p1, p2);
+            xb[j] = h == 0 ? make_uint4(one | (one << 16), one | (p0 << 16), p1 | (p2 << 16), 0u) : make_uint4(0u, 0u, 0u, 0u);
+        }
+        const f32x16 zero = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int j = 0; j < 2; j++)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(vg_bf16x8, ta[i]),
+                                                                   __builtin_bit_cast(vg_bf16x8, xb[j]), zero, 0, 0, 0);
+    };
+    // The appends.  The elements of a finished tile whose accumulator is positive go to their queries' candidate lists — about four
+    // per wave and tile (0.05 % of 1024 x 8192).  An append is a RETURNING atomic on the query's counter, and vector-memory
+    // operations retire in order: the fills of the following K steps cannot be seen to have landed before the atomic is back.
+    // Waited for where it is issued, every passing element was a 1.5 us round trip with the matrix pipe idle (4.9 of a tile's
+    // 20 us).  So a lane parks up to two passing elements per tile (query, row, accumulator), issues their atomics and the loads
+    // of their thresholds at the END of the tile's scan and finishes them (key = t - 2 acc, stored at the returned position) a tile
+    // later, behind the next scan; a third element of one lane in one tile takes the immediate path.
+    // What this still costs is measured (tools/ubench/gemm_bf16_probe): the kernel without any append 1.20 ms, with the
+    // scan's maxima 1.27, elements collected and dropped 1.30, keys stored without atomics 1.32, with them 1.52 — the atomic is
+    // still in front of the next step's fills and takes longer than a step.  Alternatives measured and not kept: a log per wave
+    // (plain stores, a scatter kernel behind: a store to a line that has left the L2 retires as slowly as the atomic, 1.59 + 0.06;
+    // nontemporal, flushed every few tiles 1.48 + 0.06) and a pool of registers per wave written out once (v_readlane /
+    // v_writelane per element: 1.69 + 0.06, scalar registers spilled).
+    int pend = 0;  // parked elements of this lane whose atomics are in flight (0..2)
+    uint32_t p_q[2] = {0u, 0u}, p_row[2] = {0u, 0u};
+    float p_a[2] = {0.0f, 0.0f}, p_t[2] = {0.0f, 0.0f};  // accumulator; threshold (in flight)
+    int p_pos[2] = {0, 0};                                 // position in the query's list (in flight)
+    auto finish = [&](uint32_t qq, uint32_t row, float a, float t, int pos) {
+        t = t < kThrClamp ? t : kThrClamp;
+        const float sc = DOT ? t - a : __builtin_fmaf(-2.0f, a, t);
+        if (pos < cap) cand[qq * static_cast<uint32_t>(cap) + static_cast<uint32_t>(pos)] = make_key(sc, row, false);
+    };
+    auto finish_parked = [&]() {
+        if (pend > 0) finish(p_q[0], p_row[0], p_a[0], p_t[0], p_pos[0]);
+        if (pend > 1) finish(p_q[1], p_row[1], p_a[1], p_t[1], p_pos[1]);
+        pend = 0;
+    };
+    auto tile_append = [&](const Pos &ps) {
+        // (this tile's elements are collected in c_*; the previous tile's parked ones are finished AFTER the scan: the wait for
+        // their atomics is a wait for everything older in the vector-memory queue — the compiler counts only the operations it
+        // can see, not the LDS-DMA fills — and by then the fills issued a K step ago have landed)
+        int cnt = 0;
+        uint32_t c_q[2] = {0u, 0u}, c_row[2] = {0u, 0u};
+        float c_a[2] = {0.0f, 0.0f};
+        const int64_t q0 = static_cast<int64_t>(tm_of(ps)) * kBigBM, n0 = static_cast<int64_t>(tn_of(ps)) * kBigBN;
+        const int n_in = static_cast<int>(n - n0 < kBigBN ? n - n0 : kBigBN);
+        // (everything below that depends only on the lane is derived from these two INSIDE the K-step loop: left to itself the
+        // compiler computes the 64 query indices of a lane once, ahead of the loop, and keeps them in 64 registers)
+        int hv = 4 * h, lv = lane & 31;
+        asm volatile("" : "+v"(hv), "+v"(lv));
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                // the largest of a lane's 16 elements, through the largest of each group of four (registers 4g .. 4g+3 = four
+                // consecutive queries): 10 instructions; a block in which some lane has a positive one (two in five) then looks at
+                // the four groups, and at the elements of a group only where a lane's group maximum is positive
+                // (a positive float is a positive int; a NaN with a clear sign bit gets here too and fails the float test below)
+                int gm[4];
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    const int m3 = big_max3_i32(__float_as_int(acc[i][j][4 * g]), __float_as_int(acc[i][j][4 * g + 1]),
+                                                __float_as_int(acc[i][j][4 * g + 2]));
+                    gm[g] = m3 > __float_as_int(acc[i][j][4 * g + 3]) ? m3 : __float_as_int(acc[i][j][4 * g + 3]);
+                }
+                int mx = big_max3_i32(gm[0], gm[1], gm[2]);
+                mx = mx > gm[3] ? mx : gm[3];
+                if (__builtin_amdgcn_ballot_w64(mx > 0) == 0) continue;  // wave-uniform: nothing of this 32 x 32 block passes
+                if (PROBE & 256) {  // (stage probe: the maxima only, kept alive)
+                    if (mx == 0x12345678) counts[0] = 1;
+                    continue;
+                }
+                // the few passing elements: 32-bit offsets from the (wave-uniform) array bases (nq * cap < 2^31: the launcher checks)
+                const int nl = wc * 64 + j * 32 + lv;  // row index inside the tile
+                if (nl >= n_in) continue;              // (per lane: a row past the end of the matrix)
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    if (gm[g] <= 0) continue;
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        const int r = 4 * g + e;
+                        const float a = acc[i][j][r];
+                        // (queries past nq started at -1e30 and never get here)
+                        if (a > 0.0f) {
+                            const uint32_t qq = static_cast<uint32_t>(q0) + static_cast<uint32_t>(wr * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + hv);
+                            const int64_t nn = n0 + nl;
+                            // (the filter bit is looked at only for the few elements that pass)
+                            if (mask == nullptr || mask_bit(mask + static_cast<int64_t>(qq) * mask_stride, nn)) {
+                                if (cnt < 2) {
+                                    const bool first = cnt == 0;
+                                    c_q[0] = first ? qq : c_q[0];
+                                    c_row[0] = first ? static_cast<uint32_t>(nn) : c_row[0];
+                                    c_a[0] = first ? a : c_a[0];
+                                    c_q[1] = first ? c_q[1] : qq;
+                                    c_row[1] = first ? c_row[1] : static_cast<uint32_t>(nn);
+                                    c_a[1] = first ? c_a[1] : a;
+                                    cnt++;
+                                } else {
+                                    finish(qq, static_cast<uint32_t>(nn), a, thr[qq * static_cast<uint32_t>(thr_stride) + static_cast<uint32_t>(thr_off)],
+                                           atomicAdd(&counts[qq], 1));
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        finish_parked();
+        pend = (PROBE & 2048) ? 0 : cnt;  // (stage probe: the passing elements are collected and dropped)
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+            p_q[e] = c_q[e];
+            p_row[e] = c_row[e];
+            p_a[e] = c_a[e];
+        }
+        if (pend > 0) {
+            p_pos[0] = (PROBE & 4096) ? 0 : atomicAdd(&counts[p_q[0]], 1);  // (stage probe 4096: no atomics, slot 0 / 1 of every list)
+            p_t[0] = thr[p_q[0] * static_cast<uint32_t>(thr_stride) + static_cast<uint32_t>(thr_off)];
+        }
+        if (pend > 1) {
+            p_pos[1] = (PROBE & 4096) ? 1 : atomicAdd(&counts[p_q[1]], 1);
+            p_t[1] = thr[p_q[1] * static_cast<uint32_t>(thr_stride) + static_cast<uint32_t>(thr_off)];
+        }
+    };
 
     float4 fa[2][4], fb[2][2];  // [set][block]: operand granules of one group (16 k) — the group being multiplied / the next one
     auto read_group = [&](const float *As, const float *Bs, int j, int set) {
+        const float *pa = As + a_wave + lpart[j], *pb = Bs + b_wave + lpart[j];
 #pragma unroll
-        for (int i = 0; i < 4; i++) fa[set][i] = *reinterpret_cast<const float4 *>(As + a_row + i * 32 * kGemmBK + goff[j]);
+        for (int i = 0; i < 4; i++) fa[set][i] = *reinterpret_cast<const float4 *>(pa + i * 32 * kGemmBK);
 #pragma unroll
-        for (int i = 0; i < 2; i++) fb[set][i] = *reinterpret_cast<const float4 *>(Bs + b_row + i * 32 * kGemmBK + goff[j]);
+        for (int i = 0; i < 2; i++) fb[set][i] = *reinterpret_cast<const float4 *>(pb + i * 32 * kGemmBK);
     };
     auto mfma_group = [&](int set) {
 #pragma unroll
@@ -647,51 +880,65 @@ __global__ __launch_bounds__(kBigThreads) void flat_gemm_bf16_big_kernel(
                                                                    __builtin_bit_cast(vg_bf16x8, fb[set][j]), acc[i][j], 0, 0, 0);
     };
 
-    // prologue: tile 0 (NB = 3: and row tile 1) in flight, published; then the fills of the next step and the first operands
+    // prologue: the first step's tiles (NB = 3: and the second step's row tile) in flight, the first tile's starting values
+    // computed under them, then published
+    tile_loads(pos0);
     stage_a();
     stage_b();
-    if (NB == 3 && ksteps > 1) {
-        stage_b();
+    if (NB == 3 && S > 1) stage_b();
+    tile_init();
+    if (NB == 3 && S > 1)
         asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    } else {
+    else
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    int ra = 0, rb = 0;  // buffers the current tile is read from
+    int ra = 0, rb = 0;  // buffers the current step is read from
     __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): no scalar load pending at the loop's entry (see the wait inside it)
     read_group(gemm_lds, gemm_lds + 2 * kBigTile, 0, 0);
-    // Step t: the four operand groups of tile t, group j+1 read from LDS while group j is multiplied; the fills of the NEXT step's
-    // tiles — query tile t+1, row tile t+NB-1, into the buffers the barrier at the end of step t-1 freed — go out behind the
-    // first two groups' matrix instructions (an LDS-DMA piece costs the issuing wave ~60 cycles: eight of them right behind the
-    // barrier would leave the matrix pipe empty there), queries first: the wait below counts on that order.
-    // The body is the same straight line for every tile — the last one also passes the barrier and reads "the next tile's" first
+    // Step g: the four operand groups of the step's tiles, group j+1 read from LDS while group j is multiplied; the fills of the
+    // NEXT step's tiles — query tile g+1, row tile g+NB-1, into the buffers the barrier at the end of step g-1 freed — go out
+    // behind the first two groups' matrix instructions (an LDS-DMA piece costs the issuing wave ~60 cycles: eight of them right
+    // behind the barrier would leave the matrix pipe empty there), queries first: the wait below counts on that order.
+    // The body is the same straight line for every step — the last one also passes the barrier and reads "the next step's" first
     // group (stale LDS, never multiplied): with a branch around that block the compiler merges two LDS-counter states in front
     // of the last matrix group and waits lgkmcnt(0) there, i.e. for the reads just issued — the overlap the rotation exists for.
-    for (int t = 0; t < ksteps; t++) {
+    int t = 0;  // the K step of the tile being computed (c_pos)
+    for (int g = 0; g < S; g++) {
         const float *As = gemm_lds + ra * kBigTile, *Bs = gemm_lds + (2 + rb) * kBigTile;
+        const bool last = t == ksteps - 1;
+        Pos n_pos = c_pos;
+        if (last) {
+            // the next tile's thresholds and norms, a whole K step before tile_init wants them and OLDER in the vector-memory
+            // queue than this step's fills: the wait at the end of the step covers them (the compiler's own wait in front of
+            // tile_init counts only what it can see and so asks for the fills issued behind them as well: by then a step old)
+            step(n_pos);
+            if (n_pos.bt >= total) n_pos = c_pos;  // (after the last tile: its own values once more, 8 idle matrix instructions)
+            tile_loads(n_pos);
+        }
         if (!(PROBE & 16)) read_group(As, Bs, 1, 1);
         __builtin_amdgcn_sched_barrier(0);
         mfma_group(0);
         __builtin_amdgcn_sched_barrier(0);
-        if (t + 1 < ksteps && !(PROBE & 2)) stage_a();
+        if (g + 1 < S && !(PROBE & 2)) stage_a();
+        if (g + NB - 1 < S && !(PROBE & 2) && (PROBE & 512)) stage_b();  // (stage probe: the row tile's fill one group earlier)
         if (!(PROBE & 16)) read_group(As, Bs, 2, 0);
         __builtin_amdgcn_sched_barrier(0);
         mfma_group(1);
         __builtin_amdgcn_sched_barrier(0);
-        if (t + NB - 1 < ksteps && !(PROBE & 2)) stage_b();
+        if (g + NB - 1 < S && !(PROBE & 2) && !(PROBE & 512)) stage_b();
         if (!(PROBE & 16)) read_group(As, Bs, 3, 1);
         __builtin_amdgcn_sched_barrier(0);
         mfma_group(0);
         __builtin_amdgcn_sched_barrier(0);
         ra ^= 1;
         rb = rb + 1 == NB ? 0 : rb + 1;
-        // lgkmcnt(0): this wave's reads of tile t are retired (its buffers are refilled in the next step).  It is the builtin, which
+        // lgkmcnt(0): this wave's reads of step g are retired (its buffers are refilled in the next step).  It is the builtin, which
         // the compiler's own counter bookkeeping sees: after it, it knows that no LDS read — and no scalar load, which would force
         // every later LDS wait to lgkmcnt(0) — is pending.  The DMA wait stays asm (the compiler knows nothing of the fills):
-        // tile t+1 = everything this wave has in flight but (NB = 3) the row tile t+2 issued after query tile t+1.
+        // step g+1's tiles = everything this wave has in flight but (NB = 3) the row tile g+2 issued after query tile g+1.
         __builtin_amdgcn_s_waitcnt(0xC07F);
-        if (NB == 3 && t + 2 < ksteps)
+        if (NB == 3 && g + 2 < S)
             asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -699,46 +946,35 @@ __global__ __launch_bounds__(kBigThreads) void flat_gemm_bf16_big_kernel(
         asm volatile("" ::: "memory");
         if (!(PROBE & 16)) read_group(gemm_lds + ra * kBigTile, gemm_lds + (2 + rb) * kBigTile, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
-        mfma_group(1);  // group 3 of tile t, from registers
+        mfma_group(1);  // group 3 of step g, from registers
         __builtin_amdgcn_sched_barrier(0);
-    }
-    if (PROBE & 1) {  // keep the accumulators alive without an epilogue
-        float t = 0.0f;
-        for (int i = 0; i < 4; i++)
-            for (int j = 0; j < 2; j++)
-                for (int r = 0; r < 16; r++) t += acc[i][j][r];
-        if (t == 123.456f) counts[0] = 1;
-        return;
-    }
-    // epilogue: the 256 thresholds through LDS (free once every wave has read its last operands), 32 per lane as 8 ds_read_b128
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    if (tid < kBigBM) gemm_lds[tid] = thr_reg;
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        float4 t4[4];  // thresholds of rows i*32 + 8*g + 4*(lane>>5) + 0..3
-#pragma unroll
-        for (int g = 0; g < 4; g++) t4[g] = *reinterpret_cast<const float4 *>(gemm_lds + wr * 128 + i * 32 + 8 * g + 4 * h);
-#pragma unroll
-        for (int j = 0; j < 2; j++) {
-            const int64_t nn = n0 + wc * 64 + j * 32 + (lane & 31);
-#pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int64_t qq = q0 + wr * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                const float dotv = acc[i][j][r];
-                const float sc = DOT ? -dotv : __builtin_fmaf(-2.0f, dotv, xn[j]);
-                const float4 tv = t4[r >> 2];
-                const float t = (r & 3) == 0 ? tv.x : (r & 3) == 1 ? tv.y : (r & 3) == 2 ? tv.z : tv.w;
-                // (queries past nq carry the threshold -Inf: nothing passes; the filter bit is looked at only below the threshold)
-                if (nn < n && sc < t && (mask == nullptr || mask_bit(mask + qq * mask_stride, nn))) {
-                    const int pos = atomicAdd(&counts[qq], 1);
-                    if (pos < cap) cand[qq * cap + pos] = make_key(sc, static_cast<uint32_t>(nn), false);
-                }
+        if (last) {
+            if (!(PROBE & 1)) {
+                tile_append(c_pos);
+            } else {  // stage probe: keep the accumulators alive without an epilogue
+                float sum = 0.0f;
+                for (int i = 0; i < 4; i++)
+                    for (int j = 0; j < 2; j++)
+                        for (int r = 0; r < 16; r++) sum += acc[i][j][r];
+                if (sum == 123.456f) counts[0] = 1;
             }
+            c_pos = n_pos;
+            t = 0;
+            if (PROBE & 1024) {  // (stage probe: the accumulators start at zero — no thresholds, no norms, no extra matrix group)
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+#pragma unroll
+                    for (int j = 0; j < 2; j++)
+#pragma unroll
+                        for (int r = 0; r < 16; r++) acc[i][j][r] = 0.0f;
+            } else {
+                tile_init();
+            }
+        } else {
+            t++;
         }
     }
+    finish_parked();
 }
 
 // ---- 5..64 queries: the same pipeline with a 32 x 128 or 64 x 128 tile ------------------------------
