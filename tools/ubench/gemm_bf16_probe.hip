@@ -68,7 +68,7 @@ static float time_ms(const Bufs &b, F launch, int reps = 5)
     CK(hipEventCreate(&e1));
     float best = 1e30f;
     for (int rep = 0; rep < reps; rep++) {
-        CK(hipMemset(b.counts, 0, sizeof(int) * b.nq));
+        CK(hipMemset(b.counts, 0, sizeof(int) * (b.nq + 1)));
         CK(hipEventRecord(e0));
         launch();
         CK(hipEventRecord(e1));
@@ -152,7 +152,7 @@ int main(int argc, char **argv)
     CK(hipMalloc(&base, n * dim * 2));
     CK(hipMalloc(&norms, n * 4));
     CK(hipMalloc(&thr, nq * 4));
-    CK(hipMalloc(&b.counts, nq * 4));
+    CK(hipMalloc(&b.counts, (nq + 1) * 4));
     CK(hipMalloc(&b.cand, nq * cap * 8));
     fill_bf16<<<unsigned((nq * dim + 255) / 256), 256>>>(q, nq * dim, 1);
     fill_bf16<<<unsigned((n * dim + 255) / 256), 256>>>(base, n * dim, 2);
@@ -197,6 +197,12 @@ int main(int argc, char **argv)
         }
         printf("    appended pairs %zu; only in the 128-tile set %zu, only in this set %zu (scores next to the threshold), scores off by > 1e-3: %zu\n",
                total, only_ref, only_got, score_off);
+    }
+    run_big<3, 32768>("NB = 3: full kernel, counting the flushes", b);
+    {
+        int fl = 0;
+        CK(hipMemcpy(&fl, b.counts + nq, 4, hipMemcpyDeviceToHost));
+        printf("    flushes of parked elements: %d over 2048 waves x 61 tiles (%.2f per wave)\n", fl, fl / 2048.0);
     }
     run_big<3, 512>("NB = 3: full kernel, row fills behind the FIRST group", b);
     run_big<3, 4096>("NB = 3: keys stored without atomics (slots 0 / 1 of a list)", b);

@@ -752,36 +752,55 @@ __global__ __launch_bounds__(kBigThreads) void flat_gemm_bf16_big_kernel(
     // per wave and tile (0.05 % of 1024 x 8192).  An append is a RETURNING atomic on the query's counter, and vector-memory
     // operations retire in order: the fills of the following K steps cannot be seen to have landed before the atomic is back.
     // Waited for where it is issued, every passing element was a 1.5 us round trip with the matrix pipe idle (4.9 of a tile's
-    // 20 us).  So a lane parks up to two passing elements per tile (query, row, accumulator), issues their atomics and the loads
-    // of their thresholds at the END of the tile's scan and finishes them (key = t - 2 acc, stored at the returned position) a tile
-    // later, behind the next scan; a third element of one lane in one tile takes the immediate path.
-    // What this still costs is measured (tools/ubench/gemm_bf16_probe): the kernel without any append 1.20 ms, with the
-    // scan's maxima 1.27, elements collected and dropped 1.30, keys stored without atomics 1.32, with them 1.52 — the atomic is
-    // still in front of the next step's fills and takes longer than a step.  Alternatives measured and not kept: a log per wave
-    // (plain stores, a scatter kernel behind: a store to a line that has left the L2 retires as slowly as the atomic, 1.59 + 0.06;
-    // nontemporal, flushed every few tiles 1.48 + 0.06) and a pool of registers per wave written out once (v_readlane /
-    // v_writelane per element: 1.69 + 0.06, scalar registers spilled).
-    int pend = 0;  // parked elements of this lane whose atomics are in flight (0..2)
-    uint32_t p_q[2] = {0u, 0u}, p_row[2] = {0u, 0u};
-    float p_a[2] = {0.0f, 0.0f}, p_t[2] = {0.0f, 0.0f};  // accumulator; threshold (in flight)
-    int p_pos[2] = {0, 0};                                 // position in the query's list (in flight)
+    // 20 us); parked for one tile and finished behind the next scan it still sat in front of the next step's fills and took
+    // longer than a step (3.3 us per tile).  So a lane parks its passing elements (query, row, accumulator) ACROSS tiles, up to
+    // kPark of them, and the whole workgroup appends every kFlushEvery-th tile: the atomics and threshold loads of all parked
+    // elements of a wave go out together and are waited for once.  Measured (tools/ubench/gemm_bf16_probe): the
+    // kernel without any append 1.13 ms, with the scan's maxima 1.17, elements collected and dropped 1.24, all of it 1.3x.
+    // Also measured and not kept: a log per wave with a scatter kernel behind (a plain store to a line that has left the L2
+    // retires as slowly as an atomic: 1.59 + 0.06 ms; nontemporal 1.48 + 0.06) and a pool of registers per wave written out
+    // once (v_readlane / v_writelane per element, scalar registers spilled: 1.69 + 0.06).
+    constexpr int kPark = 4;
+    int pend = 0;  // parked elements of this lane (0..kPark)
+    uint32_t p_q[kPark], p_row[kPark];
+    float p_a[kPark];
+#pragma unroll
+    for (int e = 0; e < kPark; e++) {
+        p_q[e] = 0u;
+        p_row[e] = 0u;
+        p_a[e] = 0.0f;
+    }
+    constexpr int kFlushEvery = 6;
+    int flushes = 0, tiles_done = static_cast<int>(blockIdx.x >> 3) % kFlushEvery;  // (the workgroups take turns: all of them
+                                                                                     // at once is 45 k atomics on 1024 counters)
     auto finish = [&](uint32_t qq, uint32_t row, float a, float t, int pos) {
         t = t < kThrClamp ? t : kThrClamp;
         const float sc = DOT ? t - a : __builtin_fmaf(-2.0f, a, t);
         if (pos < cap) cand[qq * static_cast<uint32_t>(cap) + static_cast<uint32_t>(pos)] = make_key(sc, row, false);
     };
-    auto finish_parked = [&]() {
-        if (pend > 0) finish(p_q[0], p_row[0], p_a[0], p_t[0], p_pos[0]);
-        if (pend > 1) finish(p_q[1], p_row[1], p_a[1], p_t[1], p_pos[1]);
+    // every parked element of the wave: the atomics and the threshold loads of all of them go out together, ONE round trip
+    auto flush_parked = [&]() {
+        int pos[kPark];
+        float tt[kPark];
+#pragma unroll
+        for (int e = 0; e < kPark; e++) {
+            pos[e] = 0;
+            tt[e] = 0.0f;
+            if (pend > e) {
+                pos[e] = (PROBE & 4096) ? e : atomicAdd(&counts[p_q[e]], 1);  // (stage probe 4096: no atomics, slot e of every list)
+                tt[e] = thr[p_q[e] * static_cast<uint32_t>(thr_stride) + static_cast<uint32_t>(thr_off)];
+            }
+        }
+        // (ONE wait, and one the compiler's bookkeeping sees: left to place its own it waits in front of every store for results
+        // that "may be pending" under the conditions above — and so for the store before it, four write round trips in a row)
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+#pragma unroll
+        for (int e = 0; e < kPark; e++)
+            if (pend > e) finish(p_q[e], p_row[e], p_a[e], tt[e], pos[e]);
         pend = 0;
+        flushes++;
     };
     auto tile_append = [&](const Pos &ps) {
-        // (this tile's elements are collected in c_*; the previous tile's parked ones are finished AFTER the scan: the wait for
-        // their atomics is a wait for everything older in the vector-memory queue — the compiler counts only the operations it
-        // can see, not the LDS-DMA fills — and by then the fills issued a K step ago have landed)
-        int cnt = 0;
-        uint32_t c_q[2] = {0u, 0u}, c_row[2] = {0u, 0u};
-        float c_a[2] = {0.0f, 0.0f};
         const int64_t q0 = static_cast<int64_t>(tm_of(ps)) * kBigBM, n0 = static_cast<int64_t>(tn_of(ps)) * kBigBN;
         const int n_in = static_cast<int>(n - n0 < kBigBN ? n - n0 : kBigBN);
         // (everything below that depends only on the lane is derived from these two INSIDE the K-step loop: left to itself the
@@ -826,15 +845,15 @@ __global__ __launch_bounds__(kBigThreads) void flat_gemm_bf16_big_kernel(
                             const int64_t nn = n0 + nl;
                             // (the filter bit is looked at only for the few elements that pass)
                             if (mask == nullptr || mask_bit(mask + static_cast<int64_t>(qq) * mask_stride, nn)) {
-                                if (cnt < 2) {
-                                    const bool first = cnt == 0;
-                                    c_q[0] = first ? qq : c_q[0];
-                                    c_row[0] = first ? static_cast<uint32_t>(nn) : c_row[0];
-                                    c_a[0] = first ? a : c_a[0];
-                                    c_q[1] = first ? c_q[1] : qq;
-                                    c_row[1] = first ? c_row[1] : static_cast<uint32_t>(nn);
-                                    c_a[1] = first ? c_a[1] : a;
-                                    cnt++;
+                                if (pend < kPark) {
+#pragma unroll
+                                    for (int s2 = 0; s2 < kPark; s2++) {
+                                        const bool here = pend == s2;
+                                        p_q[s2] = here ? qq : p_q[s2];
+                                        p_row[s2] = here ? static_cast<uint32_t>(nn) : p_row[s2];
+                                        p_a[s2] = here ? a : p_a[s2];
+                                    }
+                                    pend++;
                                 } else {
                                     finish(qq, static_cast<uint32_t>(nn), a, thr[qq * static_cast<uint32_t>(thr_stride) + static_cast<uint32_t>(thr_off)],
                                            atomicAdd(&counts[qq], 1));
@@ -845,22 +864,12 @@ __global__ __launch_bounds__(kBigThreads) void flat_gemm_bf16_big_kernel(
                 }
             }
         }
-        finish_parked();
-        pend = (PROBE & 2048) ? 0 : cnt;  // (stage probe: the passing elements are collected and dropped)
-#pragma unroll
-        for (int e = 0; e < 2; e++) {
-            p_q[e] = c_q[e];
-            p_row[e] = c_row[e];
-            p_a[e] = c_a[e];
-        }
-        if (pend > 0) {
-            p_pos[0] = (PROBE & 4096) ? 0 : atomicAdd(&counts[p_q[0]], 1);  // (stage probe 4096: no atomics, slot 0 / 1 of every list)
-            p_t[0] = thr[p_q[0] * static_cast<uint32_t>(thr_stride) + static_cast<uint32_t>(thr_off)];
-        }
-        if (pend > 1) {
-            p_pos[1] = (PROBE & 4096) ? 1 : atomicAdd(&counts[p_q[1]], 1);
-            p_t[1] = thr[p_q[1] * static_cast<uint32_t>(thr_stride) + static_cast<uint32_t>(thr_off)];
-        }
+        if (PROBE & 2048) pend = 0;  // (stage probe: the passing elements are collected and dropped)
+        // Every kFlushEvery-th tile, ALL waves of the workgroup append what they have parked: one wave waiting for its atomics
+        // holds the other seven at the next barrier, so flushes decided wave by wave (some lane nearly full: 9 per wave, 72 per
+        // workgroup and 61 tiles) stalled the workgroup at nearly every tile.  (A lane that fills its kPark slots in between
+        // takes the immediate path.)
+        if (++tiles_done % kFlushEvery == 0) flush_parked();
     };
 
     float4 fa[2][4], fb[2][2];  // [set][block]: operand granules of one group (16 k) — the group being multiplied / the next one
@@ -974,7 +983,8 @@ __global__ __launch_bounds__(kBigThreads) void flat_gemm_bf16_big_kernel(
             t++;
         }
     }
-    finish_parked();
+    flush_parked();
+    if ((PROBE & 32768) && lane == 0) atomicAdd(&counts[nq], flushes);  // (stage probe: how often a wave flushed, counts[nq])
 }
 
 // ---- 5..64 queries: the same pipeline with a 32 x 128 or 64 x 128 tile ------------------------------
