@@ -1264,7 +1264,63 @@ def multi_gpu_legs(vg, ctx, sharded, world, rank, device, stream, comm):
     dist.all_reduce(hi_, op=dist.ReduceOp.MAX)
     out["pq_train_sharded"]["codebooks_identical_on_all_ranks"] = bool(lo_.item() == hi_.item())
     pq.close()
+    try:
+        out["hnsw_pq_replicas"] = hnsw_pq_replicas(vg, ctx, sharded, world, rank, device, stream, wall_max, sync)
+    except Exception as e:  # an extra leg: named in the record, not fatal
+        out["hnsw_pq_replicas"] = {"error": f"{type(e).__name__}: {e}"}
     return out
+
+
+REPLICA_ROWS = 200_000 if N_ROWS >= 1_000_000 else 50_000   # rows of the replicated graph (every rank builds the same one: the
+                                                             # build is deterministic; fewer in the reduced-size test runs)
+
+
+def hnsw_pq_replicas(vg, ctx, sharded, world, rank, device, stream, wall_max, sync):
+    """The metric's pipeline at N GPUs (graph search = replicas, queries sharded): every rank holds the
+    whole index — HNSW graph + PQ codes + fp32 rows of the structured corpus (the one on which the pipeline reaches the recall
+    bar; REPLICA_ROWS rows so that `world` builds on one box stay short) — and answers a contiguous slice of the batch
+    (sharded.ReplicatedGraphIndex: walk on PQ codes, ef candidates, exact rerank), ONE all-gather of [2][nq/world][k] per search.
+    Reports whole-batch queries/s (max over ranks), recall@10 and equality with the single-GPU search of the same batch."""
+    n, nq, ef = REPLICA_ROWS, NQ_FLIGHT, 192
+    rows = gen_structured(0, n, device, seed=0)
+    q = gen_structured(0, nq, device, seed=1)
+    idx = vg.Index(ctx, n, DIM)
+    idx.set_vectors(rows)
+    idx.build_hnsw(m=HNSW_M, ef_construction=HNSW_EFC, max_batch=8192, growth_div=32, stream=stream)
+    pq = vg.ProductQuantizer(ctx, DIM, PQ_M, 256)
+    pq.train(rows[:65536], iters=20, seed=1, stream=stream)
+    idx.set_pq_codes(pq, pq.encode(rows, stream=stream), stream=stream)
+    rep = sharded.ReplicatedGraphIndex(idx)
+    cand, _ = idx.search_hnsw_pq(q, ef, ef, stream=stream)            # the single-GPU answer to the whole batch
+    want_i, want_s = idx.rerank(q, cand, K, stream=stream)
+    for _ in range(2):
+        got_i, got_s = rep.search(q, K, ef, stream=stream)
+    sync()
+    steps = 5
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        rep.search(q, K, ef, stream=stream)
+    sync()
+    dt = wall_max(time.perf_counter() - t0)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        c_, _ = idx.search_hnsw_pq(q, ef, ef, stream=stream)
+        idx.rerank(q, c_, K, stream=stream)
+    sync()
+    dt1 = wall_max(time.perf_counter() - t0)
+    gi, _ = fp64_topk_local(rows, q[:1000], 0, K)
+    same = bool(torch.equal(got_i.view(torch.int32), want_i.view(torch.int32)) and
+                torch.equal(got_s.view(torch.int32), want_s.view(torch.int32)))
+    res = {"workload": f"hnsw walk on PQ codes (ef = {ef}) + exact rerank, top-{K}: structured corpus {n} x {DIM}, {nq} queries per "
+                       f"search split over {world} replicas, one all-gather",
+           "qps": steps * nq / dt, "ms_per_search": dt / steps * 1e3, "one_replica_whole_batch_qps": steps * nq / dt1,
+           "recall_at_10": recall_at_k(got_i.cpu().numpy().view(np.uint32)[:1000], gi.cpu().numpy()),
+           "ids_equal_single_gpu": same, "replicas": world,
+           "note": "ranks sharing ONE GPU (tests, --backend gloo on a 1-GPU box) split the GPU, not the work: the scaling figure needs "
+                   "one GPU per rank"}
+    idx.close()
+    pq.close()
+    return res
 
 
 def traffic_file():
@@ -1429,6 +1485,11 @@ def compact_line(full: dict) -> dict:
                 cfgs.append({"config": f"configs[4] rabitq sharded ({mode})", "collective": rs.get("collective"),
                              **_pick(rs[mode], "rows_total", "rows_per_gpu", "ms_per_step", "qps", "rank0_scan_ms_per_step",
                                      "rank0_all_gather_ms_per_step")})
+    hr = full.get("hnsw_pq_replicas")
+    if isinstance(hr, dict):
+        cfgs.append({"config": "metric pipeline over query-sharded replicas (structured corpus)",
+                     **({"error": str(hr["error"])[:160]} if "error" in hr else
+                        _pick(hr, "replicas", "qps", "one_replica_whole_batch_qps", "recall_at_10", "ids_equal_single_gpu"))})
     pt = full.get("pq_train_sharded")
     if isinstance(pt, dict):
         cfgs.append({"config": "configs[4] pq kmeans train, sharded by sub-quantizer",

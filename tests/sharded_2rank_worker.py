@@ -53,6 +53,18 @@ def main():
         gi, gs = sharded.sharded_search(lambda qq, kk, out: fl(qq, kk, out=out), merge, q, k, bounds, None, metric=0)
         assert torch.equal(gi, wi) and torch.equal(gs.view(torch.int32), ws.view(torch.int32)), name
         checks += 1
+    # 3. the metric's pipeline over query-sharded replicas (sharded.ReplicatedGraphIndex): every rank holds the whole index
+    # (graph + PQ codes + fp32 rows) and answers its slice of the batch; the gathered result = the single-process one, in order
+    whole.build_hnsw(m=8, ef_construction=100, max_batch=64, growth_div=32)
+    for ef in (32, 64):
+        cand, _ = whole.search_hnsw_pq(q, ef, ef)
+        wi, ws = whole.rerank(q, cand, k)
+        gi, gs = sharded.ReplicatedGraphIndex(whole).search(q, k, ef)
+        assert torch.equal(gi.view(torch.int32), wi.view(torch.int32)) and torch.equal(gs.view(torch.int32), ws.view(torch.int32)), "replicas"
+        fi, fs = whole.search_hnsw(q, k, ef)
+        gi, gs = sharded.ReplicatedGraphIndex(whole).search_f32(q, k, ef)
+        assert torch.equal(gi.view(torch.int32), fi.view(torch.int32)) and torch.equal(gs.view(torch.int32), fs.view(torch.int32)), "replicas f32"
+        checks += 2
     dist.barrier()
     if rank == 0:
         print(f"OK {checks}", flush=True)

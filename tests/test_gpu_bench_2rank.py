@@ -33,5 +33,7 @@ def test_bench_gpus2_self_launch_gloo(world):
     assert names["configs[4] rabitq sharded (strong)"]["qps"] > 0
     assert names["configs[4] rabitq sharded (weak)"]["rows_per_gpu"] == 200000
     assert names["configs[4] pq kmeans train, sharded by sub-quantizer"]["codebooks_identical_on_all_ranks"] is True
+    rep = names["metric pipeline over query-sharded replicas (structured corpus)"]   # graph search = replicas
+    assert rep["replicas"] == world and rep["ids_equal_single_gpu"] is True and rep["qps"] > 0 and rep["recall_at_10"] > 0.5
     assert "not measured" in d["scaling_curve"]
 

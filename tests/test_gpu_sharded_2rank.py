@@ -23,4 +23,4 @@ def test_two_ranks_on_one_gpu():
            "--master-port", str(port), str(ROOT / "tests" / "sharded_2rank_worker.py")]
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
-    assert "OK 3" in r.stdout, r.stdout[-2000:]
+    assert "OK 7" in r.stdout, r.stdout[-2000:]

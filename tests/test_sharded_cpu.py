@@ -164,3 +164,64 @@ def test_two_rank_sharded_sq8_training_equals_single_process():
     ret = mgr.dict()
     mp.spawn(_sq_worker, args=(world, port, ret), nprocs=world, join=True)
     assert ret[0] and ret[1]
+
+
+def _replica_worker(rank, world, port, nq, ret):
+    """Query-sharded replicas (sharded.replicated_search): every rank holds the whole corpus and answers its slice of the batch;
+    the local search is the oracle's HNSW-style stand-in (exact flat search: what is under test is the split, the padding of the
+    ragged last slice, the single all-gather and the order of the concatenation)."""
+    sys.path.insert(0, str(ROOT))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import oracle as o
+    from vecgo_amd import sharded
+    rng = np.random.default_rng(77)
+    dim, n, k = 24, 400, 7
+    base = rng.standard_normal((n, dim)).astype(np.float32)
+    queries = rng.standard_normal((nq, dim)).astype(np.float32)
+    calls = []
+
+    def local(q, kk):
+        calls.append(len(q))
+        ids = np.zeros((len(q), kk), np.uint32); sc = np.zeros((len(q), kk), np.float32)
+        for i in range(len(q)):
+            ids[i], sc[i] = o.flat_search_f32(base, dim, q[i], kk)
+        return (torch.from_numpy(ids.view(np.int32)), torch.from_numpy(sc)) if rank == 0 else (ids, sc)   # tensors or arrays
+
+    ids, sc = sharded.replicated_search(local, torch.from_numpy(queries) if rank == 0 else queries, k)
+    ok = ids.shape == (nq, k) and sc.shape == (nq, k)
+    qb = sharded.partition(nq, world)
+    ok &= calls == ([qb[rank + 1] - qb[rank]] if qb[rank + 1] > qb[rank] else [])     # one local call, on this rank's slice only
+    for i in range(nq):
+        eid, esc = o.flat_search_f32(base, dim, queries[i], k)
+        ok &= np.array_equal(ids[i].numpy().view(np.uint32), eid) and np.array_equal(sc[i].numpy().view(np.uint32), esc.view(np.uint32))
+    ret[rank] = bool(ok)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("nq", [9, 1, 2])      # ragged slices; fewer queries than ranks (an empty slice)
+def test_two_rank_query_sharded_replicas_equal_single_process(nq):
+    world = 2
+    port = 35500 + (os.getpid() % 2000) + nq
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_replica_worker, args=(world, port, nq, ret), nprocs=world, join=True)
+    assert ret[0] and ret[1]
+
+
+def test_sq8_sharded_train_skips_nan_and_refuses_empty():
+    """train_sq8_sharded at world 1: a NaN is skipped as the reference's `val < min` / `val > max` loop skips it
+    (quantizer.go:156-163), and a corpus with no rows is an error as in Train (quantizer.go:128-130)."""
+    from oracle import oracle as o
+    from vecgo_amd import sharded
+    x = np.random.default_rng(4).standard_normal((50, 6)).astype(np.float32)
+    y = x.copy(); y[7, 2] = np.nan
+    clean = np.delete(x, 7, axis=0) if False else x.copy()
+    clean[7, 2] = x[:, 2].min()          # replacing the NaN by a value inside the range leaves min / max as if it were skipped
+    for rows in (y, torch.from_numpy(y)):
+        a, b = o.ScalarQuantizer(6), o.ScalarQuantizer(6)
+        sharded.train_sq8_sharded(a, rows)
+        b.train(clean)
+        assert np.array_equal(a.mins.view(np.uint32), b.mins.view(np.uint32)) and np.array_equal(a.maxs.view(np.uint32), b.maxs.view(np.uint32))
+    with pytest.raises(ValueError):
+        sharded.train_sq8_sharded(o.ScalarQuantizer(6), x[:0])
