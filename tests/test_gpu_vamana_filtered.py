@@ -84,3 +84,28 @@ def test_filtered_vamana_dot_metric(vg, ctx):
     idx.set_vectors(base); idx.set_vamana_graph(g, entry)
     q = rng.standard_normal((6, 16)).astype(np.float32)
     check(idx, ov, q, 5, 0, rng.random((6, 600)) < 0.3)
+
+
+def test_selective_filter_on_a_large_segment_drops_nothing(vg, ctx):
+    """with a selective filter the walk goes on until k MATCHING rows are in the heap — here there are fewer than k, so
+    it visits the whole component — and the traversal queue outgrows the 65 536 items the unfiltered walk is given (every node is
+    discovered long before it is popped: ~94 k queued at the peak).  The reference's queue is unbounded (diskann/segment.go:641-703):
+    ids, scores and counters must still equal the oracle's, i.e. nothing may be dropped."""
+    n, dim, r, k = 100_000, 8, 16, 50
+    rng = np.random.default_rng(2025)
+    base = rng.standard_normal((n, dim)).astype(np.float32)
+    g = rng.integers(0, n, (n, r)).astype(np.uint32)      # a random regular digraph: any adjacency is a valid graph to walk
+    ov = o.VamanaIndex(g, 0, dim, o.VAMANA_F32, base=base)
+    idx = vg.Index(ctx, n, dim)
+    idx.set_vectors(base)
+    idx.set_vamana_graph(g, 0)
+    q = rng.standard_normal((3, dim)).astype(np.float32)
+    mask = rng.random(n) < 0.0003                          # ~30 matching rows < k
+    assert 0 < mask.sum() < k
+    ids, sc, st = idx.search_vamana_filtered(q, k, mask, kind=0, stats=True)
+    for qi in range(q.shape[0]):
+        eid, esc, est = ov.search(q[qi], k, mask=mask)
+        assert est.nodes_visited > 90_000                  # the whole component was walked
+        assert np.array_equal(ids[qi, :eid.size], eid) and np.array_equal(bits(sc[qi, :eid.size]), bits(esc))
+        assert np.all(ids[qi, eid.size:] == 0xFFFFFFFF)
+        assert (int(st[qi][0]), int(st[qi][1]), int(st[qi][2]), int(st[qi][3])) == (est.nodes_visited, est.distance_computations, 0, est.pops)

@@ -883,7 +883,11 @@ static int32_t vamana_impl(vg_index *idx, const float *queries, int64_t nq, int3
     vg::DevIn<uint8_t> mk;
     VG_TRY(mk.init(mask, mask ? static_cast<size_t>(mask_stride ? (nq - 1) * mask_stride + (idx->n + 7) / 8 : (idx->n + 7) / 8) : 0, st));
     const int64_t vis_words = (idx->n + 31) / 32;
-    const int64_t cand_cap = std::min<int64_t>(idx->n, 65536);
+    // The reference's exploration heap is unbounded (ScratchCandidates, diskann/segment.go:641-703).  A node enters it at most once
+    // (the visited test), so n items are "unbounded" here.  The unfiltered walk stops at k results long before 65 536; a walk with a
+    // selective row filter goes on until k MATCHING rows are found and can fill any smaller heap (pushes were then
+    // dropped silently): with a filter the cap is n — nothing is ever dropped — at the price of fewer queries per launch.
+    const int64_t cand_cap = mask ? idx->n : std::min<int64_t>(idx->n, 65536);
     const int64_t per_query = vis_words * 4 + cand_cap * 8;
     int64_t chunk = std::max<int64_t>(1, graph_scratch_cap(idx->ctx) / per_query);
     chunk = std::min(chunk, nq);
