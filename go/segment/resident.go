@@ -285,7 +285,8 @@ func (r *Resident) SearchHNSWPQ(queries []float32, nq, k, ef int, stats []Stats)
 // SearchHNSWFiltered: searchExecute with a filter and a selectivity hint above 0.3 — searchLayerWithPostFilter
 // (hnsw.go:1159-1218).  mask: bit i of byte i/8 = row i passes (filter.Matches and not tombstoned), len(mask) ==
 // ceil(n/8) for one mask (maskStride 0) or nq*maskStride; ef is what determineEF returned.  A selectivity at or below
-// 0.3 is an error here (the reference walks predicate-aware there; use SearchHNSWBrute for selective bitmaps).
+// 0.3 (or unknown, < 0) is routed by the library to the predicate-aware walk, as searchExecute does (hnsw.go:1086-1157):
+// the same as calling SearchHNSWPredicate.
 func (r *Resident) SearchHNSWFiltered(queries []float32, nq, k, ef int, mask []byte, maskStride int, selectivity float64, stats []Stats) ([]uint32, []float32, error) {
 	ids, sc := r.out(nq, k)
 	need := (r.rows + 7) / 8

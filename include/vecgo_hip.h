@@ -134,7 +134,14 @@ int32_t vg_pq_build_distance_table(vg_pq *pq, const float *queries, int64_t nq, 
  * The reference draws from the unseeded global math/rand (pq.go:294,308,314,409), so trained
  * codebooks are not reproducible there; here every draw comes from a counter-based stream
  * keyed by `seed` (the CPU oracle uses the same stream, so GPU == oracle bit for bit).
- * The reference uses iters = 20. */
+ * The reference uses iters = 20.
+ * STATED DEVIATION from the reference's arithmetic (not a restatement): the k-means++ seeding adds
+ * minDistSq up — for the total and again for the pick — in blocks of 64 with a pairwise tree inside a
+ * block and a sequential sum over the block totals, where pq.go:296-336 runs ONE fp32 accumulator over
+ * all n values in index order.  For the same draw the picked row can therefore differ from the
+ * reference's where the target lies within rounding distance of a prefix sum; the reference's own draws
+ * are unseeded, so no trained codebook of it can be reproduced either way (trained
+ * codebooks are quality-parity only).  The oracle implements the same blocked sum (oracle/vg_oracle.c). */
 int32_t vg_pq_train(vg_pq *pq, const float *vectors, int64_t n, int32_t iters, uint64_t seed,
                     void *stream);
 /* The same for the sub-quantizers [sub_begin, sub_begin + sub_count) only.  The reference trains

@@ -323,6 +323,28 @@ def test_probes_with_equal_centroid_distances_follow_the_selection_loop(vg, ctx,
             check(ids, sc, seg, q, 10, nprobes)
 
 
+def test_probes_with_nan_centroid_distances_follow_the_selection_loop(vg, ctx):
+    """A centroid with a NaN coordinate has a NaN distance to every query: `dists[j].dist < dists[minIdx].dist` (kmeans.go:261) is
+    false either way, so the selection loop TAKES a NaN entry when it stands at position i and never moves to one behind it —
+    the probed partitions (and with them ids and scores) equal the oracle's, which runs the loop as written."""
+    rng = np.random.default_rng(515)
+    n, dim, parts = 2400, 32, 12
+    x = rng.standard_normal((n, dim)).astype(np.float32)
+    off = (np.arange(parts + 1) * (n // parts)).astype(np.uint32)
+    q = rng.standard_normal((20, dim)).astype(np.float32)
+    for nan_at in ((0,), (1,), (0, 2), (11,)):
+        cent = (rng.standard_normal((parts, dim)) * 0.7).astype(np.float32)
+        for c in nan_at:
+            cent[c, 3] = np.nan
+        idx = vg.Index(ctx, n, dim)
+        idx.set_vectors(x)
+        idx.set_partitions(cent, off)
+        seg = o.FlatSegment(x, dim, metric=0, centroids=cent, part_offsets=off)
+        for nprobes in (1, 2, 3):
+            ids, sc = idx.search_flat_probed(q, 10, nprobes, scan=idx.SCAN_F32)
+            check(ids, sc, seg, q, 10, nprobes)
+
+
 @pytest.mark.parametrize("scan_name", ["f32", "sq8"])
 def test_probed_batches_beyond_65535_pairs_run_in_chunks(vg, ctx, scan_name):
     """8200 queries x 8 probes: more (query, probe) pairs than one grouped nomination takes — the batch is cut into chunks of

@@ -74,20 +74,27 @@ __global__ __launch_bounds__(256) void probe_select_kernel(const float *__restri
     const Sub16 sub = Sub16::make(tid);
     const float *qv = queries + q * dim;
     const int want = emulate ? np + 1 : np;
+    __shared__ int any_nan;
+    if (tid == 0) any_nan = 0;
+    __syncthreads();
     WaveTopK tk;
     tk.init(want);
+    bool nan_seen = false;
     for (int c0 = wave * 4; c0 < parts; c0 += 16) {
         const int c = c0 + (lane >> 4);
         uint64_t key = kKeyMax;
         if (c < parts) {
             const float v = exact_pair16<DOT, kBatch>(centroids + static_cast<int64_t>(c) * dim, qv, dim, sub);
             if ((lane & 15) == 0) key = make_key(v, static_cast<uint32_t>(c), DOT);
+            nan_seen = nan_seen || v != v;
         }
         tk.offer(key, lane);
     }
+    if (emulate && nan_seen) any_nan = 1;
     wg_rank_merge<4>(tk, lists, valid, wave, lane, tid, want, best);
     __syncthreads();
-    bool tie = false;
+    // (a NaN distance anywhere: the selection loop takes a NaN standing at position i — the keys never would — so it is replayed)
+    bool tie = emulate && any_nan != 0;
     if (emulate)
         for (int i = 0; i + 1 < want; i++)
             tie = tie || (best[i + 1] != kKeyMax && key_score(best[i], DOT) == key_score(best[i + 1], DOT));
@@ -114,7 +121,14 @@ __global__ __launch_bounds__(256) void probe_select_kernel(const float *__restri
         for (int c = tid; c < parts; c += 256) {
             const uint32_t p = sel_pos[c];
             if (p == kNone) continue;
-            const float d = sel_dist[c];
+            float d = sel_dist[c];
+            // a NaN distance: `dists[j].dist < dists[minIdx].dist` is false either way, so the loop keeps minIdx = i when the
+            // entry AT position i is NaN (it is taken: -Inf here, and position i wins every tie) and never moves to a NaN
+            // behind it (skipped)
+            if (d != d) {
+                if (p != static_cast<uint32_t>(i)) continue;
+                d = -INFINITY;
+            }
             if (bc == kNone || d < bd || (d == bd && p < bp)) {
                 bd = d;
                 bp = p;

@@ -1593,7 +1593,9 @@ __global__ __launch_bounds__(64) void sq8_dequant_bf16_kernel(const uint4 *__res
         }
         norms[row] = nrm;
     }
-    float mx = row < n ? nrm : 0.0f;
+    // a NaN norm (a NaN in mins / inv) must reach norm_max — fmaxf would drop it, and a finite bound over a row whose GEMM score is
+    // NaN would let the proof pass: NaN -> +Inf (the largest bit pattern below), the proof's comparisons then fail and the scan answers
+    float mx = row < n ? (nrm == nrm ? nrm : INFINITY) : 0.0f;
     for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
     if (lane == 0) atomicMax(norm_max_bits, __float_as_int(mx));  // non-negative floats order like their bits
 }
@@ -1719,15 +1721,32 @@ VG_API int32_t vg_index_enable_sq8_nomination(vg_index *idx, int32_t on, void *s
     }
     if (!on) return VG_OK;
     VG_CHECK(idx->sq && idx->d_sq_tiles, VG_ERR_NOT_READY, "vg_index_enable_sq8_nomination: index has no SQ8 codes");
-    idx->sq_bf16_dim = (idx->dim + 63) & ~63;  // whole K steps of the bf16 GEMM; the padding is zeros
-    VG_HIP(hipMalloc(reinterpret_cast<void **>(&idx->d_sq_bf16), static_cast<size_t>(idx->n) * idx->sq_bf16_dim * sizeof(uint16_t)));
-    VG_HIP(hipMalloc(reinterpret_cast<void **>(&idx->d_sq_norms), static_cast<size_t>(idx->n) * sizeof(float)));
-    VG_HIP(hipMalloc(reinterpret_cast<void **>(&idx->d_sq_norm_max), sizeof(float)));
-    VG_HIP(hipMemsetAsync(idx->d_sq_norm_max, 0, sizeof(float), st));
-    VG_LAUNCH(vg::sq8_dequant_bf16_kernel, dim3(static_cast<unsigned>(idx->n_tiles)), dim3(64), 0, st,
-              reinterpret_cast<const uint4 *>(idx->d_sq_tiles), idx->n, idx->dim, idx->sq_groups, idx->sq->d_mins, idx->sq->d_inv,
-              idx->d_sq_bf16, idx->sq_bf16_dim, idx->d_sq_norms, reinterpret_cast<int *>(idx->d_sq_norm_max));
-    VG_HIP(hipStreamSynchronize(st));
+    const int bdim = (idx->dim + 63) & ~63;  // whole K steps of the bf16 GEMM; the padding is zeros
+    // the three arrays are published together, after the image is built: a failure half way leaves the index as it was (the
+    // batch search tests d_sq_bf16 alone — ADVICE r05: a failed second allocation left it set next to null norms)
+    uint16_t *img = nullptr;
+    float *norms = nullptr, *norm_max = nullptr;
+    auto give_up = [&](hipError_t e) {
+        (void)hipFree(img);
+        (void)hipFree(norms);
+        (void)hipFree(norm_max);
+        return e;
+    };
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&img), static_cast<size_t>(idx->n) * bdim * sizeof(uint16_t));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&norms), static_cast<size_t>(idx->n) * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&norm_max), sizeof(float));
+    if (e == hipSuccess) e = hipMemsetAsync(norm_max, 0, sizeof(float), st);
+    if (e != hipSuccess) VG_HIP(give_up(e));
+    hipLaunchKernelGGL(vg::sq8_dequant_bf16_kernel, dim3(static_cast<unsigned>(idx->n_tiles)), dim3(64), 0, st,
+                       reinterpret_cast<const uint4 *>(idx->d_sq_tiles), idx->n, idx->dim, idx->sq_groups, idx->sq->d_mins, idx->sq->d_inv,
+                       img, bdim, norms, reinterpret_cast<int *>(norm_max));
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) VG_HIP(give_up(e));
+    idx->sq_bf16_dim = bdim;
+    idx->d_sq_bf16 = img;
+    idx->d_sq_norms = norms;
+    idx->d_sq_norm_max = norm_max;
     return VG_OK;
 }
 
