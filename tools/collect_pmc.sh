@@ -7,7 +7,7 @@ set -euo pipefail
 : "${GRAFT_REPO_ROOT:?run through gpurun (GRAFT_REPO_ROOT is the repository copy on the GPU box)}"
 cd "$GRAFT_REPO_ROOT"
 what=${1:-all}
-ROUND=${ROUND:-r04}
+ROUND=${ROUND:-r06}
 P=tools/pmc_run.sh
 if [ "$what" = scans ] || [ "$what" = all ]; then
     $P adc_fetch "FETCH_SIZE" python3 tools/adc_prof.py 10000000 1 10
@@ -30,6 +30,29 @@ if [ "$what" = gemm ] || [ "$what" = all ]; then
     $P gemm_write "WRITE_SIZE" python3 tools/flat_time.py
     $P gemm_mfma "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32" python3 tools/flat_time.py
 fi
+if [ "$what" = gemm16 ] || [ "$what" = all ]; then
+    # r06: the bfloat16 nomination GEMMs — the persistent 256 x 256 tile (flat_gemm_bf16_big_kernel, the bf16 flat filter and the
+    # SQ8 batch), the 128 x 128 tile it replaced above 128 queries (VG_FLAT_NO_BIG_TILE=1: tools/flat_bf16_time.py reads the hook
+    # from its first argument) and the grouped GEMM of the partition-probed search
+    M16="SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_MFMA"
+    W16="SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES GRBM_GUI_ACTIVE"
+    L16="SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_ACTIVE_INST_LDS"
+    T16="TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum"
+    for v in big tile128; do
+        a=""; [ $v = tile128 ] && a="no_big_tile"
+        $P gemm16_${v}_fetch "FETCH_SIZE" python3 tools/flat_bf16_time.py $a
+        $P gemm16_${v}_write "WRITE_SIZE" python3 tools/flat_bf16_time.py $a
+        $P gemm16_${v}_mfma "$M16" python3 tools/flat_bf16_time.py $a
+        $P gemm16_${v}_wait "$W16" python3 tools/flat_bf16_time.py $a
+        $P gemm16_${v}_lds "$L16" python3 tools/flat_bf16_time.py $a
+        $P gemm16_${v}_tcc "$T16" python3 tools/flat_bf16_time.py $a
+    done
+    $P grouped_fetch "FETCH_SIZE" python3 tools/probe_gemm_time.py
+    $P grouped_mfma "$M16" python3 tools/probe_gemm_time.py
+    $P grouped_wait "$W16" python3 tools/probe_gemm_time.py
+    $P sq8nom_fetch "FETCH_SIZE" python3 tools/sq8_nominate_time.py
+    $P sq8nom_mfma "$M16" python3 tools/sq8_nominate_time.py
+fi
 if [ "$what" = walks ] || [ "$what" = all ]; then
     for m in "f32 128" "f32 2048" "pq 128" "vamana_pq"; do
         tag=$(echo $m | tr ' ' '_')
@@ -50,9 +73,12 @@ if [ "$what" = build ] || [ "$what" = all ]; then
     $P pqtrain_valu "$V" python3 tools/pq_train_time.py
     $P pqtrain_mfma "$M" python3 tools/pq_train_time.py
     $P pqtrain_fetch "FETCH_SIZE" python3 tools/pq_train_time.py
+    $P kmeans_wait "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES GRBM_GUI_ACTIVE" python3 tools/kmeans_time.py
     $P encode_valu "$V" python3 tools/encode_one.py
     $P encode_mfma "$M" python3 tools/encode_one.py
     $P encode_fetch "FETCH_SIZE" python3 tools/encode_one.py
+    $P encode_inst "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVES SQ_VALU_MFMA_BUSY_CYCLES" python3 tools/encode_one.py
+    $P encode_wait "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" python3 tools/encode_one.py
 fi
 python3 tools/make_traffic_json.py gpurun_out/pmc > gpurun_out/pmc/${ROUND}_traffic.json
 ls gpurun_out/pmc/*.csv | wc -l

@@ -6,7 +6,11 @@ sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
 import torch
 import vecgo_amd as vg, bench
 ctx = vg.Context(0); dev = torch.device("cuda", 0)
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
+args = [a for a in sys.argv[1:] if a != "no_big_tile"]
+if "no_big_tile" in sys.argv[1:]:      # (the 128 x 128 tile above 128 queries too: what the persistent 256 x 256 tile replaced)
+    from tests import hooks
+    hooks.set_hook("VG_FLAT_NO_BIG_TILE", 1)
+n = int(args[0]) if args else 1_000_000
 rows = bench.gen_rows(0, n, dev)
 q = bench.gen_queries(2, dev)
 idx = vg.Index(ctx, n, 768); idx.set_vectors(rows)

@@ -5,7 +5,7 @@ vector-ALU / MFMA counters of the kernels that are not HBM-bound.  argv: directo
 import csv, glob, json, os, re, sys
 
 d = sys.argv[1]
-ROUND = os.environ.get("ROUND", "r04")
+ROUND = os.environ.get("ROUND", "r06")
 if not glob.glob(os.path.join(d, "*.csv")):
     sys.exit(f"make_traffic_json: no csv under {d}: every pmc pass failed (see the .log files)")
 
@@ -117,4 +117,54 @@ for tag, sub, per_score in (("f32_128", "hnsw_search_kernel<0", 768 * 4), ("f32_
         t.update({"SQ_INSTS_VALU": valu, "SQ_INSTS_SALU": val(f"walk_{tag}_valu", sub, "SQ_INSTS_SALU"),
                   "GRBM_GUI_ACTIVE_sum_over_8_xcds": gui, "valu_busy_fraction": valu * 4 / 1024 / (gui / 8) if valu and gui else None})
     out[{"f32_128": "hnsw_search", "f32_2048": "hnsw_search_ef2048", "pq_128": "hnsw_search_pq", "vamana_pq": "vamana_search_pq"}[tag]] = t
+
+# ---- r06: the bfloat16 nomination GEMMs, the build-side matrix kernels -------------------------------------------------------------
+def unit_counters(name, sub, keys):
+    return {c: val(name, sub, c) for c in keys}
+
+
+def gemm16(tag, sub):
+    t = traffic(f"gemm16_{tag}_fetch", f"gemm16_{tag}_write", sub, 1_000_000 * 768 * 2 + 1024 * 768 * 2,
+                {"workload": "bf16 nomination GEMM of the flat search, 1024 queries x 1M x 768 per launch"})
+    if not t:
+        return None
+    m = unit_counters(f"gemm16_{tag}_mfma", sub, ("SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "GRBM_GUI_ACTIVE", "SQ_INSTS_MFMA"))
+    if m.get("GRBM_GUI_ACTIVE"):
+        m["mfma_busy_fraction"] = m["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024 * m["GRBM_GUI_ACTIVE"] / 8)
+    w = unit_counters(f"gemm16_{tag}_wait", sub, ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES"))
+    if w.get("SQ_WAVE_CYCLES"):
+        w["parked_at_waitcnt_or_barrier_fraction_of_wave_cycles"] = w["SQ_WAIT_ANY"] / w["SQ_WAVE_CYCLES"]
+        w["issue_stall_fraction_of_wave_cycles"] = w["SQ_WAIT_INST_ANY"] / w["SQ_WAVE_CYCLES"]
+    l = unit_counters(f"gemm16_{tag}_lds", sub, ("SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "SQ_INSTS_LDS", "SQ_ACTIVE_INST_LDS"))
+    c = unit_counters(f"gemm16_{tag}_tcc", sub, ("TCC_HIT_sum", "TCC_MISS_sum", "TCC_REQ_sum"))
+    if c.get("TCC_REQ_sum"):
+        c["l2_hit_fraction"] = c["TCC_HIT_sum"] / c["TCC_REQ_sum"]
+        c["l2_request_bytes_at_128"] = c["TCC_REQ_sum"] * 128
+    t.update({"matrix_unit": m, "waits": w, "lds": l, "l2": c})
+    return t
+
+
+out["flat_gemm_bf16_big"] = gemm16("big", "flat_gemm_bf16_big_kernel<false, 3, 0>")
+out["flat_gemm_bf16_tile128"] = gemm16("tile128", "flat_gemm_dma_kernel<false, 2, 0, true>")
+gr = traffic("grouped_fetch", None, "flat_gemm_dma_grouped_kernel<false, 2", None, {"workload": "partition-probed fp32 search: grouped GEMM (tools/probe_gemm_time.py)"})
+if gr:
+    gr["matrix_unit"] = unit_counters("grouped_mfma", "flat_gemm_dma_grouped_kernel<false, 2", ("SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE", "SQ_INSTS_MFMA"))
+    gr["waits"] = unit_counters("grouped_wait", "flat_gemm_dma_grouped_kernel<false, 2", ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_WAVE_CYCLES"))
+out["flat_gemm_grouped"] = gr
+km = traffic("kmeans_fetch", "kmeans_write", "km_gemm_kernel<false, true>", 1_000_000 * 768 * 4, {"workload": "k-means assignment GEMM, 1M x 768 x 122, bf16 [hi|lo] splits"})
+if km:
+    km["matrix_unit"] = unit_counters("kmeans_mfma", "km_gemm_kernel<false, true>", ("SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE", "SQ_INSTS_MFMA"))
+    km["valu"] = unit_counters("kmeans_valu", "km_gemm_kernel<false, true>", ("SQ_INSTS_VALU", "SQ_WAVE_CYCLES", "SQ_WAIT_INST_ANY"))
+out["km_gemm"] = km
+out["km_update"] = traffic("kmeans_fetch", "kmeans_write", "km_update_kernel", 1_000_000 * 768 * 4, {"workload": "k-means update, 1M x 768 x 122: every row once, by member list"})
+en = traffic("encode_fetch", None, "pq_nominate_bf16_kernel<true>", 348_160 * 768 * 4, {"workload": "ProductQuantizer.Encode, one launch = 348 160 rows x 768 (a 1M-row Encode is three)"})
+if en:
+    en["instructions"] = unit_counters("encode_inst", "pq_nominate_bf16_kernel<true>", ("SQ_INSTS_VALU", "SQ_INSTS_MFMA", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_WAVES", "SQ_VALU_MFMA_BUSY_CYCLES"))
+    en["waits"] = unit_counters("encode_wait", "pq_nominate_bf16_kernel<true>", ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES", "GRBM_GUI_ACTIVE"))
+    i, w = en["instructions"], en["waits"]
+    if i.get("SQ_INSTS_VALU"):
+        i["valu_instructions_per_block_of_32_rows_x_1_subquantizer"] = i["SQ_INSTS_VALU"] / (348_160 / 32 * 96)
+    if w.get("GRBM_GUI_ACTIVE") and w.get("SQ_ACTIVE_INST_VALU"):
+        w["valu_busy_fraction_at_4_cycles_per_instruction"] = w["SQ_ACTIVE_INST_VALU"] * 4 / (1024 * w["GRBM_GUI_ACTIVE"] / 8)
+out["pq_nominate_encode"] = en
 print(json.dumps(out, indent=1))
