@@ -1445,8 +1445,12 @@ def compact_line(full: dict) -> dict:
         if "error" in src:
             cfgs.append({"config": name, "error": str(src["error"])[:160]})
             return
-        cfgs.append({"config": name, **_pick(src, "workload", "kernel", "kernel_ms", "bound", "achieved", "peak", "unit", "frac", "traffic"),
-                     **{k: _r(v) for k, v in extra.items() if v is not None}})
+        r = {"config": name, **_pick(src, "workload", "kernel", "kernel_ms", "bound", "achieved", "peak", "unit", "frac", "traffic"),
+             **{k: _r(v) for k, v in extra.items() if v is not None}}
+        for k in ("workload", "kernel"):   # (the whole sentences stay in the full record: the line has a size budget)
+            if isinstance(r.get(k), str) and len(r[k]) > 64:
+                r[k] = r[k][:61] + "..."
+        cfgs.append(r)
 
     # configs[1]: the headline kernel (same numbers as `roofline`, in the per-config shape)
     row("configs[1] flat exact fp32 MFMA GEMM", {**rf, "workload": "flat_exact_l2_1Mx768_top10_nq1024"},

@@ -1017,7 +1017,7 @@ struct KmMfma {
     // allocates and computes |x|^2 (the points do not change between the iterations of a training run).
     // passes: how many assignment passes will follow — with three or more, and rows of whole 64-element blocks, the points
     // are also split into bfloat16 [hi | lo] (3.1 GB per 1M x 768, written once) and the passes run on the 16x faster
-    // bf16 matrix instruction, HBM-bound instead of MFMA-bound (1.64 -> see DESIGN.md §12 ms per 1M x 768 x 122)
+    // bf16 matrix instruction, HBM-bound instead of MFMA-bound (1.64 -> 0.69 ms per 1M x 768 x 122: DESIGN.md section 8)
     int32_t init(const float *v, int64_t n, int dim, int k, hipStream_t st, int passes = 1, int64_t hbm_bytes = 0)
     {
         mtiles = (k + vg::kGemmBM - 1) / vg::kGemmBM;

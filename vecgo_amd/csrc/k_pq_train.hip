@@ -115,7 +115,7 @@ __device__ __forceinline__ float l2_train(const float *__restrict__ row, const f
 // sum until it passes rand * sum.  Through r04 (2) was the reference's own chain of n dependent fp32 additions (60 ms of
 // the 88 ms Train at 65 536 x 768, and the same 60 ms however few sub-quantizers a GPU of a sharded Train holds).
 // Since r05 the running sum is BLOCKED — one definition, the same in the CPU restatement the tests check this kernel
-// against, stated and justified as a deviation from pq.go:296-336 in DESIGN.md §12 (the reference's random numbers
+// against, stated and justified as a deviation from pq.go:296-336 in docs/history/rounds_r02_r05.md §12.4 and include/vecgo_hip.h (the reference's random numbers
 // are unseeded, so no run of it can be reproduced bit for bit anyway): T_b = the balanced pairwise tree over the 64
 // elements of block b (the six shuffle steps of a wave that holds the block one element per lane), P_b = P_(b-1) + T_b
 // over the blocks in order, sum = P_last; the pick = first block whose prefix is not below the target, then the
