@@ -342,11 +342,11 @@ def flat_bf16_filter(vg, ctx, idx, queries, gt_ids, steps, stream):
             "scores_bit_equal_fp32_path": bool(torch.equal(sc.view(torch.int32), ref_sc.view(torch.int32))),
             "proof_fallbacks": int(s1[1] - s0[1]), "queries": int(s1[0] - s0[0]),
             "extra_hbm_bytes": N_ROWS * DIM * 2, "small_batches": small,
-            "roofline": {"bound": "mfma", "kernel": "flat_gemm_dma_kernel<false,2,0,true> (v_mfma_f32_32x32x16_bf16)",
+            "roofline": {"bound": "mfma", "kernel": "flat_gemm_bf16_big_kernel<false,3> (v_mfma_f32_32x32x16_bf16)",
                          "kernel_ms": kern_ms, "launches": launches, "flops_per_launch": flops,
                          "achieved": flops / (kern_ms * 1e-3) / 1e12, "peak": PEAK_MFMA_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": flops / (kern_ms * 1e-3) / 1e12 / PEAK_MFMA_BF16_TFLOPS,
-                         "note": "bound by moving the tiles (L2 -> LDS: 24.6 GB per launch), not by the matrix cores"}}
+                         "note": "persistent 256 x 256 tile, one workgroup per CU; the matrix-only loop of this tile runs at 0.78 ms, the K loop with its LDS traffic and barrier at ~1.0, the threshold epilogue adds the rest (profiles/r06_gemm_bf16_probe.txt)"}}
 
 
 def flat_small_batch(vg, ctx, idx, queries, stream):
@@ -1073,7 +1073,7 @@ def build_side_legs(vg, ctx, rows, queries, stream, with_cpu, rows_host=None):
     tf = 2.0 * nqf * n * DIM / (g_ms * 1e-3) / 1e12
     out["sq8_batch"] = {"workload": f"flat.Segment.Search SQ8 branch, {nqf} queries x {n} x {DIM}, top-{K} (flat/segment.go:517-604): bf16 nomination "
                                     "over the dequantised rows + L2Distance of the 64 nominated rows from the codes + proof",
-                        "kernel": "flat_gemm_dma_kernel<false,2,0,true> (bf16) + sq8_verify_kernel", "kernel_ms": g_ms, "bound": "mfma",
+                        "kernel": "flat_gemm_bf16_big_kernel<false,3> + sq8_verify_kernel", "kernel_ms": g_ms, "bound": "mfma",
                         "achieved": tf, "peak": PEAK_MFMA_BF16_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_MFMA_BF16_TFLOPS, "call_ms": wall_nom,
                         "queries_per_s": nqf / (wall_nom * 1e-3), "scan_call_ms": wall_scan, "scan_queries_per_s": nqf / (wall_scan * 1e-3),
                         "bits_equal": bool(torch.equal(r_scan[0], r_nom[0]) and torch.equal(r_scan[1].view(torch.int32), r_nom[1].view(torch.int32))),
@@ -1787,7 +1787,7 @@ def main():
         roofline = {"bound": "mfma", "achieved": achieved_tf, "peak": peak_tf,
                     "unit": "TFLOP/s", "frac": achieved_tf / peak_tf,
                     "traffic": measured_traffic("flat_gemm") if (world == 1 and not args.bf16_filter) else None,
-                    "kernel": "flat_gemm_dma_kernel<false,2,0,true> (bf16)" if args.bf16_filter else "flat_gemm_dma_kernel<false,2>",
+                    "kernel": "flat_gemm_bf16_big_kernel<false,3>" if args.bf16_filter else "flat_gemm_dma_kernel<false,2>",
                     "kernel_ms": kern_avg_ms, "launches": launches, "flops_per_launch": flops_per_launch,
                     "traffic_source": (traffic_file().name + " (committed rocprofv3 --pmc pass of the same kernel and shape; "
                                        "not re-measured in this run)") if traffic_file() else None}

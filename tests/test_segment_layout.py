@@ -77,11 +77,15 @@ def test_tables_are_consistent():
     assert segfile.FLAT_MAGIC == 0x56454331 and segfile.DISK_MAGIC == 0x4449534B   # format.go:12 / :9
 
 
+LAYOUT_HPP = ROOT / "vecgo_amd" / "csrc" / "vg_segment_layout.hpp"
+
+
 def reader_accesses(func: str):
-    """{offset: width} of every header access in vg_segment_open_<func>: rdNN(data + K), rdNN(data), data[K]."""
-    src = (ROOT / "vecgo_amd" / "csrc" / "vg_segment.hip").read_text()
-    body = src[src.index(f"VG_API int32_t vg_segment_open_{func}("):]
-    body = body[:body.index("\nVG_API", 10)] if "\nVG_API" in body[10:] else body
+    """{offset: width} of every header access in seglayout::parse_<func> (vg_segment_layout.hpp, what vg_segment_open_<func>
+    validates an image with): rdNN(data + K), rdNN(data), data[K]."""
+    src = LAYOUT_HPP.read_text()
+    body = src[src.index(f"inline int32_t parse_{func}("):]
+    body = body[:body.index("\n}\n")]
     acc = {}
     for m in re.finditer(r"\brd(16|32|64)\(data(?: \+ (\d+))?\)", body):
         acc[int(m.group(2) or 0)] = int(m.group(1)) // 8
@@ -97,9 +101,9 @@ def test_reader_reads_the_fields_where_the_reference_writes_them():
         acc = reader_accesses(func)
         assert len(acc) >= 10, acc
         for off, width in acc.items():
-            assert off in by_off, f"vg_segment_open_{func} reads header offset {off}: not a field of the reference's header"
+            assert off in by_off, f"parse_{func} reads header offset {off}: not a field of the reference's header"
             assert by_off[off][1] == width, f"{func}: {by_off[off][0]} is {by_off[off][1]} bytes, read as {width}"
-        src = (ROOT / "vecgo_amd" / "csrc" / "vg_segment.hip").read_text()
+        src = LAYOUT_HPP.read_text()
         hname, hsize, mname, magic = consts
         assert re.search(rf"{hname}\s*=\s*{hsize}\b", src) and re.search(rf"{mname}\s*=\s*0x{magic:08X}", src, flags=re.I)
     # the fields the searches depend on are all read

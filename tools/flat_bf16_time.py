@@ -6,7 +6,10 @@ sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
 import torch
 import vecgo_amd as vg, bench
 ctx = vg.Context(0); dev = torch.device("cuda", 0)
-args = [a for a in sys.argv[1:] if a != "no_big_tile"]
+args = [a for a in sys.argv[1:] if a not in ("no_big_tile", "early_b")]
+if "early_b" in sys.argv[1:]:          # (row-tile fills behind the first matrix group: DESIGN.md section 9 item 3)
+    from tests import hooks
+    hooks.set_hook("VG_FLAT_BIG_EARLY_B", 1)
 if "no_big_tile" in sys.argv[1:]:      # (the 128 x 128 tile above 128 queries too: what the persistent 256 x 256 tile replaced)
     from tests import hooks
     hooks.set_hook("VG_FLAT_NO_BIG_TILE", 1)

@@ -63,7 +63,7 @@ static int32_t launch_gemm_t(bool dma, unsigned blocks, hipStream_t st, const Ge
         if (MODE == 2 && a.nq > kGemmBM && a.nq * static_cast<int64_t>(a.cap) < (int64_t(1) << 31) && a.thr_stride < 65536 &&
             !hook(kHookFlatNoBigTile)) {
             const bool two = hook(kHookFlatBigTile2);
-            auto kern = two ? flat_gemm_bf16_big_kernel<DOT, 2> : flat_gemm_bf16_big_kernel<DOT, 3>;
+            auto kern = two ? flat_gemm_bf16_big_kernel<DOT, 2> : hook(kHookFlatBigEarlyB) ? flat_gemm_bf16_big_kernel<DOT, 3, 512> : flat_gemm_bf16_big_kernel<DOT, 3>;
             const size_t lds = two ? big_lds_bytes<2>() : big_lds_bytes<3>();
             VG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        static_cast<int>(lds)));

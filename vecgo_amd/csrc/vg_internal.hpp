@@ -86,6 +86,7 @@ enum Hook {
     kHookProbeNoGemm,         // VG_PROBE_NO_GEMM        probed fp32 scan: the exact kernels only, no matrix-core nomination
     kHookFlatNoBigTile,       // VG_FLAT_NO_BIG_TILE     bf16 nomination: the 128 x 128 tile even above 128 queries
     kHookFlatBigTile2,        // VG_FLAT_BIG_TILE_2      bf16 256 x 256 tile with two row-tile buffers (128 KiB) instead of three
+    kHookFlatBigEarlyB,       // VG_FLAT_BIG_EARLY_B     bf16 256 x 256 tile: row-tile fills behind the first matrix group of a step
     kHookCount
 };
 bool hook(Hook h);
