@@ -1078,6 +1078,25 @@ def build_side_legs(vg, ctx, rows, queries, stream, with_cpu, rows_host=None):
                         "queries_per_s": nqf / (wall_nom * 1e-3), "scan_call_ms": wall_scan, "scan_queries_per_s": nqf / (wall_scan * 1e-3),
                         "bits_equal": bool(torch.equal(r_scan[0], r_nom[0]) and torch.equal(r_scan[1].view(torch.int32), r_nom[1].view(torch.int32))),
                         "compared": nqf, "short": f"sq8_batch_{nqf}q_{n}x{DIM}_top{K}"}
+    idx.enable_sq8_nomination(False)
+
+    # ---- flat.Segment.Search, PQ branch, 1024 queries: one table scan per query (LDS gather rate) and the opt-in bf16 nomination
+    # over the DECODED rows (vg_index_enable_pq_nomination) + table sums of the nominated rows from the codes + proof
+    idx.set_pq_codes(pq, codes, stream=stream)
+    pr, wall_scan, r_scan = prof(("pq_adc_scan",), lambda: idx.search_pq_adc(qb, K, stream=stream), reps=1)
+    idx.enable_pq_nomination(True)
+    pr, wall_nom, r_nom = prof(("sq8_nominate_gemm",), lambda: idx.search_pq_adc(qb, K, stream=stream), reps=3)
+    lg, tg = pr["sq8_nominate_gemm"]
+    g_ms = tg / max(lg, 1)
+    tf = 2.0 * nqf * n * DIM / (g_ms * 1e-3) / 1e12
+    out["pq_batch"] = {"workload": f"flat.Segment.Search PQ branch, {nqf} queries x {n} x m{PQ_M}, top-{K} (flat/segment.go:476-483,678-689): bf16 "
+                                   "nomination over the decoded rows + BuildDistanceTable / pqAdcLookup sums of the 64 nominated rows + proof",
+                       "kernel": "flat_gemm_bf16_big_kernel<false,3> + pq_verify_kernel", "kernel_ms": g_ms, "bound": "mfma",
+                       "achieved": tf, "peak": PEAK_MFMA_BF16_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_MFMA_BF16_TFLOPS, "call_ms": wall_nom,
+                       "queries_per_s": nqf / (wall_nom * 1e-3), "scan_call_ms": wall_scan, "scan_queries_per_s": nqf / (wall_scan * 1e-3),
+                       "extra_hbm_bytes": n * ((DIM + 63) // 64 * 64) * 2,
+                       "bits_equal": bool(torch.equal(r_scan[0], r_nom[0]) and torch.equal(r_scan[1].view(torch.int32), r_nom[1].view(torch.int32))),
+                       "compared": nqf, "short": f"pq_batch_{nqf}q_{n}x{DIM}_m{PQ_M}_top{K}"}
     idx.close()
     pq.close()
     return out
@@ -1523,7 +1542,7 @@ def compact_line(full: dict) -> dict:
                           ("rerank", "f1 Segment.Rerank"), ("brute_q1", "a17 hnsw.BruteSearch, 1 query"),
                           ("brute_q256", "a17 hnsw.BruteSearch, 256 queries"),
                           ("flat_filtered", "flat search, a filter per query, 1024 queries"),
-                          ("sq8_batch", "f3 sq8 batch, 1024 queries")):
+                          ("sq8_batch", "f3 sq8 batch, 1024 queries"), ("pq_batch", "pq adc batch, 1024 queries")):
             e = bs.get(key)
             if isinstance(e, dict):
                 row(name, {**e, "workload": e.get("short", e.get("workload"))},

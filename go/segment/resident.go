@@ -201,6 +201,16 @@ func (r *Resident) EnableSQ8Nomination(on bool) error {
 	return hipctx.Err(int32(C.vg_index_enable_sq8_nomination(r.h, v, nil)))
 }
 
+// EnablePQNomination: batches of SearchPQ (queries x rows >= 24M, k <= 256) are nominated by a bfloat16 MFMA GEMM over the decoded
+// rows (+ rows*dim*2 bytes of device memory) and re-scored from the codes against the query's distance table; results unchanged.
+func (r *Resident) EnablePQNomination(on bool) error {
+	v := C.int32_t(0)
+	if on {
+		v = 1
+	}
+	return hipctx.Err(int32(C.vg_index_enable_pq_nomination(r.h, v, nil)))
+}
+
 // SearchRaBitQ: exhaustive scan of the RaBitQ codes (rq.Distance per row).
 func (r *Resident) SearchRaBitQ(queries []float32, nq, k int) ([]uint32, []float32, error) {
 	ids, sc := r.out(nq, k)

@@ -54,8 +54,9 @@ extern "C" {
  *   6: (r05) vg_search_hnsw_predicate, vg_index_set_hnsw_edge_distances; vg_search_hnsw_filtered serves every selectivity
  *   7: (r05) vg_index_set_hnsw_tombstones
  *   8: (r05) vg_segment_search_filtered
- *   9: (r05) vg_index_enable_sq8_nomination */
-#define VG_ABI_MINOR 9
+ *   9: (r05) vg_index_enable_sq8_nomination
+ *  10: (r06) vg_index_enable_pq_nomination */
+#define VG_ABI_MINOR 10
 #define VG_INVALID_ID 0xFFFFFFFFu
 #define VG_STREAM_LEGACY ((void *)1) /* == hipStreamLegacy */
 
@@ -719,6 +720,16 @@ int32_t vg_comm_all_gather_topk(vg_comm *comm, const uint32_t *local_ids, const 
  * queries[nq*dim] → ids[nq*k], scores[nq*k], best first.  k <= 1024. */
 int32_t vg_search_pq_adc(vg_index *idx, const float *queries, int64_t nq, int32_t k,
                          uint32_t *ids, float *scores, void *stream);
+/* Optional bfloat16 NOMINATION for batches of vg_search_pq_adc (no reference counterpart; the results stay the reference's).
+ * A row's table sum is the squared distance to its DECODED vector (ProductQuantizer.Decode, pq.go:185-229: the table's
+ * entries, pq.go:468-491, are computed from the same fp32 centroid values).  on != 0 keeps the decoded rows rounded to
+ * bfloat16 (rows * dim * 2 bytes, dim rounded up to a multiple of 64 — 2 * dim / m times the codes: 16x at 8 dimensions per
+ * sub-quantizer) and their norms.  A batch of queries x rows >= 24M (k <= 256, numCentroids == 256) is then nominated by the
+ * bf16 MFMA GEMM of the flat search, its 64 best rows per query (k > 48: every row below a sampled threshold) re-scored
+ * from the CODES against the query's BuildDistanceTable in pqAdcLookupAvx512 order, and a bound on the nomination's error
+ * proves no other row can enter the k best; a query whose proof fails is scanned as before.  Smaller batches and the
+ * filtered / probed searches keep the table scan.  Dropped by vg_index_set_pq_codes.  (VG_ABI_MINOR 10.) */
+int32_t vg_index_enable_pq_nomination(vg_index *idx, int32_t on, void *stream);
 
 #ifdef __cplusplus
 }

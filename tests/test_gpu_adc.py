@@ -198,3 +198,137 @@ def test_adc_errors(vg, ctx):
     idx.set_pq_codes(pq, np.zeros((10, 16), np.uint8))
     ids, sc = idx.search_pq_adc(np.zeros((0, 128), np.float32), 5)
     assert ids.shape == (0, 5)
+
+
+# ---- batches through the bfloat16 nomination (vg_index_enable_pq_nomination) -------------------------------------------------
+def _decoded(opq, codes):
+    """ProductQuantizer.Decode of every row (pq.go:185-229): float32(int8) * scale, + offset, two rounded operations"""
+    sd = opq.dim // opq.m
+    cb = np.asarray(opq.codebooks, np.int8).reshape(opq.m, opq.k, sd).astype(np.float32)
+    v = cb * np.asarray(opq.scales, np.float32)[:, None, None]
+    v = (v + np.asarray(opq.offsets, np.float32)[:, None, None]).astype(np.float32)
+    return v[np.arange(opq.m)[None, :], codes].reshape(codes.shape[0], opq.dim)
+
+
+@pytest.fixture
+def nominate_always():
+    """the library nominates from 24M (query, row) pairs up; the tests' segments are smaller"""
+    hooks.set_hook("VG_PQ_NOM_ALWAYS", 1)
+    yield
+    hooks.set_hook("VG_PQ_NOM_ALWAYS", 0)
+
+
+def _clustered_codes(rng, n, m, clusters=40, flip=0.3):
+    """codes around a few prototypes: neighbours exist (a uniform draw has none in 96 sub-spaces)"""
+    proto = rng.integers(0, 256, (clusters, m)).astype(np.uint8)
+    codes = proto[rng.integers(0, clusters, n)]
+    noise = rng.integers(0, 256, (n, m)).astype(np.uint8)
+    return np.where(rng.random((n, m)) < flip, noise, codes).astype(np.uint8)
+
+
+@pytest.mark.parametrize("n,dim,m,nq,k", [(20000, 128, 16, 64, 10), (9000, 768, 96, 50, 10), (30000, 64, 8, 130, 48),
+                                          (3000, 64, 4, 60, 5), (12000, 200, 25, 64, 10), (6000, 68, 17, 50, 100),
+                                          (7000, 64, 1, 48, 10), (16000, 128, 16, 130, 256), (5000, 128, 16, 300, 49)])
+def test_batches_through_the_bf16_nomination(vg, ctx, nominate_always, n, dim, m, nq, k):
+    """vg_index_enable_pq_nomination: a batch (queries x rows >= 24M; here: the test hook) is nominated by the bfloat16 GEMM over the DECODED rows, its 64 best
+    (k > 48: everything below the threshold) re-scored from the CODES against the query's table in pqAdcLookupAvx512 order, the
+    rest excluded by a proof — same ids and score bits as the table scan and as the oracle; duplicate codes (ties), image rows
+    padded to 64 elements, fewer rows than the append budget, m below / not a multiple of 16 included."""
+    rng = np.random.default_rng(n + dim + m)
+    opq = _random_pq(rng, dim, m)
+    codes = _clustered_codes(rng, n, m)
+    codes[100:110] = codes[100]
+    pq, idx = _mk(vg, ctx, opq, codes, n)
+    x = _decoded(opq, codes)
+    q = (x[rng.integers(0, n, nq)] + rng.standard_normal((nq, dim)).astype(np.float32) * 0.05).astype(np.float32)
+    q[1] = x[100]
+    plain = idx.search_pq_adc(q, k)
+    idx.enable_pq_nomination(True)
+    got = idx.search_pq_adc(q, k)
+    assert np.array_equal(plain[0], got[0]) and np.array_equal(bits(plain[1]), bits(got[1]))
+    for i in (0, 1, nq // 2, nq - 1):
+        eid, esc = o.flat_search_pq(opq, codes, q[i], k)
+        assert np.array_equal(got[0][i, :eid.size], eid) and np.array_equal(bits(got[1][i, :eid.size]), bits(esc))
+    few = idx.search_pq_adc(q[:7], k)                  # a few queries (one GEMM tile, mostly padding)
+    assert np.array_equal(few[0], plain[0][:7]) and np.array_equal(bits(few[1]), bits(plain[1][:7]))
+    hooks.set_hook("VG_PQ_NOM_ALWAYS", 0)              # without the hook a batch this small keeps the scan
+    assert np.array_equal(idx.search_pq_adc(q, k)[0], plain[0])
+    idx.enable_pq_nomination(False)
+    again = idx.search_pq_adc(q, k)
+    assert np.array_equal(again[0], plain[0]) and np.array_equal(bits(again[1]), bits(plain[1]))
+
+
+def test_nomination_with_far_queries_and_non_finite_values(vg, ctx, nominate_always):
+    """queries far from every row (the proof's margin scales with |q|^2: it fails, the scan answers), NaN / Inf queries, a NaN scale
+    in the quantizer (the norm bound becomes +Inf: every proof fails) — nomination on = off, bit for bit"""
+    rng = np.random.default_rng(321)
+    n, dim, m, nq, k = 12000, 128, 16, 70, 10
+    opq = _random_pq(rng, dim, m)
+    codes = _clustered_codes(rng, n, m)
+    x = _decoded(opq, codes)
+    q = (x[rng.integers(0, n, nq)] + rng.standard_normal((nq, dim)).astype(np.float32) * 0.05).astype(np.float32)
+    q[2] = rng.standard_normal(dim).astype(np.float32) * 1000.0
+    q[3, 5] = np.nan
+    q[4, :] = np.inf
+    q[5, 7] = -np.inf
+    q[6] = 0.0
+    for poison in (False, True):
+        if poison:
+            sc = np.array(opq.scales, np.float32)
+            sc[3] = np.nan
+            opq.set_codebooks(opq.codebooks, sc, opq.offsets)
+        pq, idx = _mk(vg, ctx, opq, codes, n)
+        plain = idx.search_pq_adc(q, k)
+        idx.enable_pq_nomination(True)
+        got = idx.search_pq_adc(q, k)
+        assert np.array_equal(plain[0], got[0]) and np.array_equal(bits(plain[1]), bits(got[1])), poison
+        if not poison:
+            for i in (0, 2, 6, nq - 1):
+                eid, esc = o.flat_search_pq(opq, codes, q[i], k)
+                assert np.array_equal(got[0][i], eid) and np.array_equal(bits(got[1][i]), bits(esc))
+
+
+def test_nomination_limits_and_lifetime(vg, ctx, nominate_always):
+    """k beyond 256 and k >= rows keep the scan; new codes drop the image; K != 256 is refused as the scan refuses it; device
+    buffers; an index without codes"""
+    torch = pytest.importorskip("torch")
+    rng = np.random.default_rng(77)
+    n, dim, m, nq = 9000, 128, 16, 64
+    opq = _random_pq(rng, dim, m)
+    codes = _clustered_codes(rng, n, m)
+    pq, idx = _mk(vg, ctx, opq, codes, n)
+    x = _decoded(opq, codes)
+    q = (x[rng.integers(0, n, nq)] + rng.standard_normal((nq, dim)).astype(np.float32) * 0.05).astype(np.float32)
+    ref = {k: idx.search_pq_adc(q, k) for k in (10, 300)}
+    idx.enable_pq_nomination(True)
+    for k in (10, 300):
+        got = idx.search_pq_adc(q, k)
+        assert np.array_equal(ref[k][0], got[0]) and np.array_equal(bits(ref[k][1]), bits(got[1]))
+    dq = torch.from_numpy(q).cuda()
+    ids, sc = idx.search_pq_adc(dq, 10, stream=torch.cuda.current_stream())
+    torch.cuda.synchronize()
+    assert np.array_equal(ids.cpu().numpy().view(np.uint32), ref[10][0]) and np.array_equal(bits(sc.cpu().numpy()), bits(ref[10][1]))
+    codes2 = _clustered_codes(rng, n, m)
+    idx.set_pq_codes(pq, codes2)                       # the image belonged to the old codes
+    got = idx.search_pq_adc(q, 10)
+    for i in (0, nq - 1):
+        eid, esc = o.flat_search_pq(opq, codes2, q[i], 10)
+        assert np.array_equal(got[0][i], eid) and np.array_equal(bits(got[1][i]), bits(esc))
+    idx.enable_pq_nomination(True)
+    again = idx.search_pq_adc(q, 10)
+    assert np.array_equal(got[0], again[0]) and np.array_equal(bits(got[1]), bits(again[1]))
+    small = vg.Index(ctx, 40, dim, vg.Metric.L2)       # fewer rows than k: the scan's padding
+    small.set_pq_codes(pq, codes[:40])
+    small.enable_pq_nomination(True)
+    r = small.search_pq_adc(q, 48)
+    assert np.all(r[0][:, 40:] == 0xFFFFFFFF) and np.array_equal(r[0], (small.enable_pq_nomination(False), small.search_pq_adc(q, 48))[1][0])
+    with pytest.raises(vg.VecgoHipError):
+        vg.Index(ctx, 10, dim, vg.Metric.L2).enable_pq_nomination(True)
+    o64 = _random_pq(rng, dim, m, k=64)
+    p64 = vg.ProductQuantizer(ctx, dim, m, 64)
+    p64.set_codebooks(o64.codebooks, o64.scales, o64.offsets)
+    i64 = vg.Index(ctx, 100, dim, vg.Metric.L2)
+    i64.set_pq_codes(p64, rng.integers(0, 64, (100, m)).astype(np.uint8))
+    with pytest.raises(vg.VecgoHipError) as e:
+        i64.enable_pq_nomination(True)
+    assert e.value.status == -5

@@ -958,6 +958,12 @@ class Index:
                             extra=(C.c_int32(nprobes), C.c_int32(scan), pm, C.c_int64(stride)),
                             out=out, stream=stream)
 
+    def enable_pq_nomination(self, on: bool = True, stream=None):
+        """vg_index_enable_pq_nomination: batches of search_pq_adc (queries x rows >= 24M, k <= 256, K = 256) are nominated by a bfloat16
+        MFMA GEMM over the decoded rows (+ n * dim * 2 bytes), re-scored from the codes against the query's distance table in
+        the reference's order and proven: ids and scores stay bit-identical."""
+        check(self._lib.vg_index_enable_pq_nomination(self._h, C.c_int32(1 if on else 0), _stream_ptr(stream)))
+
     def enable_sq8_nomination(self, on: bool = True, stream=None):
         """vg_index_enable_sq8_nomination: batches of search_sq8 (L2 or Dot, 5 queries up, k <= 256, any dim) are nominated by a
         bfloat16 MFMA GEMM over the dequantised rows (+ n * dim * 2 bytes), re-scored exactly from the codes and proven: ids and

@@ -1018,6 +1018,14 @@ VG_API int32_t vg_index_set_pq_codes(vg_index *idx, vg_pq *pq, const uint8_t *co
         VG_HIP(hipFree(idx->d_pq_tiles));
         idx->d_pq_tiles = nullptr;
     }
+    if (idx->d_pq_bf16) {  // the old codes' nomination image (vg_index_enable_pq_nomination again after new codes)
+        VG_HIP(hipStreamSynchronize(st));
+        VG_HIP(hipFree(idx->d_pq_bf16));
+        VG_HIP(hipFree(idx->d_pq_norms));
+        VG_HIP(hipFree(idx->d_pq_norm_max));
+        idx->d_pq_bf16 = nullptr;
+        idx->d_pq_norms = idx->d_pq_norm_max = nullptr;
+    }
     idx->pq = pq;
     idx->pq_groups = (pq->m + 15) / 16;
     idx->n_tiles = (idx->n + 63) / 64;
@@ -1041,6 +1049,269 @@ VG_API int32_t vg_index_set_pq_codes(vg_index *idx, vg_pq *pq, const uint8_t *co
     return VG_OK;
 }
 
+// ---- batched search through a bfloat16 nomination (vg_index_enable_pq_nomination) ----------------------------------------------
+// One table scan per query runs at the LDS gather rate: 12.5 ms for 1024 queries x 1M x m = 96.  A row's table sum IS a squared
+// distance — sum_j |q_j - C_j[code_j]|^2 = |q - x^|^2 for the DECODED row x^ (pq.go:185-229; the table entries are computed from
+// the same fp32 centroid values, pq.go:468-491) — so with the opt-in image (x^ rounded to bfloat16, 2 bytes per dimension) the fused
+// flat search's nomination runs on it (k_flat.hip flat_nominate_bf16: threshold from a row sample, bf16 MFMA GEMM, the 64 best per
+// query), and this file re-scores those with the reference's own arithmetic — BuildDistanceTable + pqAdcLookupAvx512 on the CODES
+// — and proves that no row outside them can enter the k best: outside rows have GEMM score >= tau, and
+// |GEMM score + |q|^2 - table sum| <= eps (bfloat16 rounding of both operands, fp32 accumulation on both sides).  A query whose
+// proof fails is scanned as before.  The structure is the SQ8 batch search's (k_sq8.hip).
+namespace vg {
+size_t flat_nominate_bf16_scratch(int64_t cnt, int64_t n, int dim, int sel_k);
+int32_t flat_nominate_bf16(vg_ctx *ctx, const uint16_t *rows_bf16, const float *norms, int64_t n, int dim, int dim_pad, const float *queries,
+                           int64_t cnt, char *scratch, float *thr, int *counts, uint32_t *cand_id, float *cand_sc, hipStream_t st,
+                           bool dot, const uint8_t *mask, int64_t mask_stride, int sel_k, bool pick, const uint64_t **cand_keys, int *cap);
+constexpr int kPqPickMaxK = 48, kPqNomMaxK = 256;  // as kSq8PickMaxK / kSq8NomMaxK
+// the batches the nomination takes: 1M x 768, m = 96, k = 10: 16 queries 0.24 ms scanned / 0.39 nominated, 32: 0.46 / 0.41, 64: 0.86 /
+// 0.43, 1024: 12.4 / 1.7 (tools/pq_nominate_time.py) — the scan costs ~12 us per query and 1M rows, the nomination ~0.4 ms up to
+// 128 queries; 100k rows: 128 queries 0.27 / 0.31, 256: 0.50 / 0.28 — from 24M (query, row) pairs up.  Test hook VG_PQ_NOM_ALWAYS:
+// every batch.
+constexpr int64_t kPqNomMinPairs = 24000000;
+static int pq_nominate_sel_k(int k) { return k <= kPqPickMaxK ? 8 : k <= 128 ? 16 : 32; }
+
+// one wave per row: lane l decodes sub-quantizers l, l + 64, ... — v = float32(int8) * scale ; v = v + offset, the two rounded
+// operations of the reference's dequantisation (pq.go:204-214) — rounds to bfloat16 (nearest even), writes the image row
+// (dim_pad elements, zeros from dim on) and the row's norm
+__global__ __launch_bounds__(256) void pq_decode_bf16_kernel(const uint8_t *__restrict__ codes, int64_t n, int m, int k, int sd,
+                                                             const int8_t *__restrict__ codebooks, const float *__restrict__ scales,
+                                                             const float *__restrict__ offsets, uint16_t *__restrict__ out, int dim_pad,
+                                                             float *__restrict__ norms, int *__restrict__ norm_max_bits)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t row = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+    if (row >= n) return;  // (whole waves)
+    uint16_t *dst = out + row * dim_pad;
+    float nrm = 0.0f;
+    for (int j = lane; j < m; j += 64) {
+        const int c = codes[row * m + j];
+        const int8_t *cb = codebooks + (static_cast<int64_t>(j) * k + c) * sd;
+        const float sc = scales[j], of = offsets[j];
+        for (int d = 0; d < sd; d++) {
+            float v = static_cast<float>(cb[d]) * sc;
+            v = v + of;
+            nrm = __builtin_fmaf(v, v, nrm);
+            const uint32_t b = __float_as_uint(v);
+            dst[j * sd + d] = static_cast<uint16_t>((b + 0x7FFFu + ((b >> 16) & 1u)) >> 16);
+        }
+    }
+    for (int j = m * sd + lane; j < dim_pad; j += 64) dst[j] = 0;
+    for (int off = 32; off > 0; off >>= 1) nrm += __shfl_xor(nrm, off);
+    if (lane == 0) {
+        norms[row] = nrm;
+        // a NaN norm (a NaN scale / offset) must reach norm_max: NaN -> +Inf, the proof's comparisons then fail and the scan answers
+        atomicMax(norm_max_bits, __float_as_int(nrm == nrm ? nrm : INFINITY));  // non-negative floats order like their bits
+    }
+}
+
+// pqAdcLookupAvx512 (internal/simd/src/floats_avx512.c:135-167) of one row's code against a query's table in the reference's
+// own layout (m rows of 256): 16 lane sums over the full groups, the _mm512_reduce_add_ps tree, the tail added in order — what
+// pq_adc_scan_kernel computes from its LDS image
+__device__ __forceinline__ float pq_adc_row_score(const float *__restrict__ lut, const uint8_t *__restrict__ code, int m)
+{
+    float s[16];
+#pragma unroll
+    for (int l = 0; l < 16; l++) s[l] = 0.0f;
+    int i = 0;
+    for (; i + 16 <= m; i += 16) {
+        float t[16];
+#pragma unroll
+        for (int l = 0; l < 16; l++) t[l] = lut[(i + l) * 256 + code[i + l]];
+#pragma unroll
+        for (int l = 0; l < 16; l++) s[l] = s[l] + t[l];
+    }
+    float total = reduce16_regs(s);
+    for (; i < m; i++) total = total + lut[i * 256 + code[i]];
+    return total;
+}
+
+// the proof's margin: |s~ + |q|^2 - table sum| for any row.  bfloat16 rounding of q and x^: (2^-7 + 2^-16)(|q|^2 + |x^|^2); the GEMM's
+// fp32 accumulation and the norm's: 2 dim u of the same; the table's entries ((sd + 2) u each, relative) and their 16-lane sum
+// ((m / 16 + 4 + 15) u): 2 (m + sd + 6) u of the same (|q - x^|^2 <= 2 (|q|^2 + |x^|^2)).
+__device__ __forceinline__ float pq_nominate_eps(int dim, int m, int sd, float qn, float norm_max)
+{
+    return ((4.0f * static_cast<float>(dim) + 2.0f * static_cast<float>(m + sd + 6)) * 5.9604645e-8f + 0.0078125f * 1.02f) * (qn + norm_max) + 1e-30f;
+}
+
+// per query: the table sum of its 64 nominated rows from the codes, the k best by (score, row id), and the proof (sq8_verify_kernel's)
+__global__ __launch_bounds__(64) void pq_verify_kernel(const uint8_t *__restrict__ codes, int m, int sd, const float *__restrict__ tables,
+                                                       const float *__restrict__ queries, const float *__restrict__ norm_max,
+                                                       const uint32_t *__restrict__ cand_ids, const float *__restrict__ cand_scores, int k,
+                                                       uint32_t *__restrict__ ids, float *__restrict__ scores, int *__restrict__ fail,
+                                                       const float *__restrict__ thr, const int *__restrict__ counts, int cap, int thr_stride)
+{
+    constexpr int kc = 64;
+    const int64_t q = blockIdx.x;
+    const int lane = threadIdx.x;
+    const int dim = m * sd;
+    const float *qv = queries + q * dim;
+    const uint32_t id = cand_ids[q * kc + lane];
+    uint64_t key = kKeyMax;
+    if (id != VG_INVALID_ID) key = make_key(pq_adc_row_score(tables + q * m * 256, codes + static_cast<int64_t>(id) * m, m), id, false);
+    WaveTopK tk;
+    tk.init(k);
+    tk.offer(key, lane);
+    float qn = 0.0f;
+    for (int j = lane; j < dim; j += 64) qn = __builtin_fmaf(qv[j], qv[j], qn);
+    for (int off = 32; off > 0; off >>= 1) qn += __shfl_xor(qn, off);
+    const uint64_t kth = readlane_u64(tk.list, k - 1);
+    const float tq = thr[q * thr_stride + (thr_stride - 1)];
+    const int cnt = counts[q];
+    bool ok = cnt <= cap;  // overflow: rows below the threshold were dropped
+    const float tau = cnt > kc ? fminf(tq, cand_scores[q * kc + (kc - 1)]) : tq;
+    const bool have_all = tq == INFINITY && cnt <= kc;
+    if (ok && !have_all && tau != INFINITY) {
+        const float eps = pq_nominate_eps(dim, m, sd, qn, norm_max[0]);
+        ok = kth != kKeyMax && key_score(kth, false) < (tau + qn) - eps;
+    }
+    if (lane < k) {
+        const uint64_t e = tk.list;
+        ids[q * k + lane] = e == kKeyMax ? VG_INVALID_ID : key_row(e);
+        scores[q * k + lane] = e == kKeyMax ? INFINITY : key_score(e, false);
+    }
+    if (lane == 0) fail[q] = ok ? 0 : 1;
+}
+
+// the same for k beyond the 64-candidate budget: EVERY appended row is re-scored — one lane per row — and sorted; the proof
+// compares the k-th exact score with the threshold itself (sq8_verify_sort_kernel's).  Dynamic LDS: cap keys.
+__global__ __launch_bounds__(256) void pq_verify_sort_kernel(const uint8_t *__restrict__ codes, int m, int sd, const float *__restrict__ tables,
+                                                             const float *__restrict__ queries, const float *__restrict__ norm_max,
+                                                             const uint64_t *__restrict__ cand, const int *__restrict__ counts, int cap, int k,
+                                                             uint32_t *__restrict__ ids, float *__restrict__ scores, int *__restrict__ fail,
+                                                             const float *__restrict__ thr, int thr_stride)
+{
+    extern __shared__ uint64_t sortbuf[];
+    const int64_t q = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int dim = m * sd;
+    const float *qv = queries + q * dim;
+    const int total = counts[q];
+    const int cnt = total < cap ? total : cap;
+    int n2 = 64;
+    while (n2 < cnt) n2 <<= 1;
+    for (int c = tid; c < cnt; c += 256) {
+        const uint32_t id = key_row(cand[q * cap + c]);
+        sortbuf[c] = make_key(pq_adc_row_score(tables + q * m * 256, codes + static_cast<int64_t>(id) * m, m), id, false);
+    }
+    for (int i = cnt + tid; i < n2; i += 256) sortbuf[i] = kKeyMax;
+    __syncthreads();
+    bitonic_sort_lds(sortbuf, n2, tid, 256);
+    for (int i = tid; i < k; i += 256) {
+        const uint64_t e = i < n2 ? sortbuf[i] : kKeyMax;
+        ids[q * k + i] = e == kKeyMax ? VG_INVALID_ID : key_row(e);
+        scores[q * k + i] = e == kKeyMax ? INFINITY : key_score(e, false);
+    }
+    if (tid >= 64) return;
+    float qn = 0.0f;
+    for (int j = lane; j < dim; j += 64) qn = __builtin_fmaf(qv[j], qv[j], qn);
+    for (int off = 32; off > 0; off >>= 1) qn += __shfl_xor(qn, off);
+    const uint64_t kth = k - 1 < n2 ? sortbuf[k - 1] : kKeyMax;
+    const float tau = thr[q * thr_stride + (thr_stride - 1)];
+    bool ok = total <= cap;
+    if (ok && tau != INFINITY)  // (tau == +Inf: no threshold was set, every row was appended)
+        ok = kth != kKeyMax && key_score(kth, false) < (tau + qn) - pq_nominate_eps(dim, m, sd, qn, norm_max[0]);
+    if (lane == 0) fail[q] = ok ? 0 : 1;
+}
+
+// whether a batch takes the nomination (device queries; ascending table sums over the whole segment, no row filter)
+static bool pq_nomination_applies(const vg_index *idx, const float *d_queries, int64_t nq, int k, const uint8_t *mask, bool desc)
+{
+    return idx->d_pq_bf16 && !mask && !desc && (nq * idx->n >= kPqNomMinPairs || hook(kHookPqNomAlways)) && k <= kPqNomMaxK && idx->n > k && idx->pq->k == 256 &&
+           (reinterpret_cast<uintptr_t>(d_queries) & 15) == 0;
+}
+
+// The nomination + table sums + proof for a batch (device buffers): writes every query's k results and lists the queries whose
+// proof failed — the caller scans those.  4096 queries a pass.
+static int32_t pq_nominated_pass(vg_index *idx, const float *q, int64_t nq, int k, uint32_t *oid, float *osc, hipStream_t st,
+                                 std::vector<int> &failed)
+{
+    const vg_pq *pq = idx->pq;
+    for (int64_t q0 = 0; q0 < nq; q0 += 4096) {
+        const int64_t cnt = std::min<int64_t>(4096, nq - q0);
+        std::vector<int> h(static_cast<size_t>(cnt));
+        {
+            ArenaCall ar(idx->ctx, st);
+            const int sel_k = pq_nominate_sel_k(k);
+            const int i_scr = ar.add(flat_nominate_bf16_scratch(cnt, idx->n, idx->pq_bf16_dim, sel_k));
+            const int i_thr = ar.add(sizeof(float) * static_cast<size_t>(cnt) * sel_k);
+            const int i_cnt = ar.add(sizeof(int) * static_cast<size_t>(cnt));
+            const int i_cid = ar.add(sizeof(uint32_t) * static_cast<size_t>(cnt) * 64);
+            const int i_csc = ar.add(sizeof(float) * static_cast<size_t>(cnt) * 64);
+            const int i_fail = ar.add(sizeof(int) * static_cast<size_t>(cnt));
+            const int i_tab = ar.add(sizeof(float) * static_cast<size_t>(cnt) * pq->m * 256);
+            VG_TRY(ar.commit());
+            float *thr = ar.get<float>(i_thr), *csc = ar.get<float>(i_csc), *tables = ar.get<float>(i_tab);
+            int *counts = ar.get<int>(i_cnt), *fail = ar.get<int>(i_fail);
+            uint32_t *cid = ar.get<uint32_t>(i_cid);
+            const float *qq = q + q0 * idx->dim;
+            const uint64_t *cand = nullptr;
+            int cap = 0;
+            VG_TRY(launch_pq_build_table(pq, qq, cnt, tables, false, st));
+            VG_TRY(flat_nominate_bf16(idx->ctx, idx->d_pq_bf16, idx->d_pq_norms, idx->n, idx->dim, idx->pq_bf16_dim, qq, cnt, ar.get<char>(i_scr),
+                                      thr, counts, cid, csc, st, false, nullptr, 0, sel_k, k <= kPqPickMaxK, &cand, &cap));
+            if (k <= kPqPickMaxK)
+                VG_LAUNCH(pq_verify_kernel, dim3(static_cast<unsigned>(cnt)), dim3(64), 0, st, idx->d_pq_rows, pq->m, pq->subdim, tables, qq,
+                          idx->d_pq_norm_max, cid, csc, k, oid + q0 * k, osc + q0 * k, fail, thr, counts, cap, sel_k);
+            else
+                VG_LAUNCH(pq_verify_sort_kernel, dim3(static_cast<unsigned>(cnt)), dim3(256), sizeof(uint64_t) * static_cast<size_t>(cap), st,
+                          idx->d_pq_rows, pq->m, pq->subdim, tables, qq, idx->d_pq_norm_max, cand, counts, cap, k, oid + q0 * k, osc + q0 * k,
+                          fail, thr, sel_k);
+            VG_HIP(hipMemcpyAsync(h.data(), fail, sizeof(int) * static_cast<size_t>(cnt), hipMemcpyDeviceToHost, st));
+            VG_HIP(hipStreamSynchronize(st));
+        }
+        for (int64_t i = 0; i < cnt; i++)
+            if (h[static_cast<size_t>(i)]) failed.push_back(static_cast<int>(q0 + i));
+    }
+    return VG_OK;
+}
+}  // namespace vg
+
+VG_API int32_t vg_index_enable_pq_nomination(vg_index *idx, int32_t on, void *stream)
+{
+    VG_CHECK(idx, VG_ERR_INVALID_ARG, "vg_index_enable_pq_nomination: NULL index");
+    VG_HIP(hipSetDevice(idx->ctx->device));
+    hipStream_t st = vg::pick_stream(idx->ctx, stream);
+    if (idx->d_pq_bf16) {
+        VG_HIP(hipStreamSynchronize(st));
+        VG_HIP(hipFree(idx->d_pq_bf16));
+        VG_HIP(hipFree(idx->d_pq_norms));
+        VG_HIP(hipFree(idx->d_pq_norm_max));
+        idx->d_pq_bf16 = nullptr;
+        idx->d_pq_norms = idx->d_pq_norm_max = nullptr;
+    }
+    if (!on) return VG_OK;
+    VG_CHECK(idx->pq && idx->d_pq_rows, VG_ERR_NOT_READY, "vg_index_enable_pq_nomination: index has no PQ codes");
+    const vg_pq *pq = idx->pq;
+    VG_CHECK(pq->trained, VG_ERR_NOT_TRAINED, "ProductQuantizer not trained");
+    VG_CHECK(pq->k == 256, VG_ERR_UNSUPPORTED, "vg_index_enable_pq_nomination: needs numCentroids == 256 (got %d), as the table scan does", pq->k);
+    const int bdim = (idx->dim + 63) & ~63;  // whole K steps of the bf16 GEMM; the padding is zeros
+    // the three arrays are published together, after the image is built: a failure half way leaves the index as it was
+    uint16_t *img = nullptr;
+    float *norms = nullptr, *norm_max = nullptr;
+    auto give_up = [&](hipError_t e) {
+        (void)hipFree(img);
+        (void)hipFree(norms);
+        (void)hipFree(norm_max);
+        return e;
+    };
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&img), static_cast<size_t>(idx->n) * bdim * sizeof(uint16_t));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&norms), static_cast<size_t>(idx->n) * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&norm_max), sizeof(float));
+    if (e == hipSuccess) e = hipMemsetAsync(norm_max, 0, sizeof(float), st);
+    if (e != hipSuccess) VG_HIP(give_up(e));
+    hipLaunchKernelGGL(vg::pq_decode_bf16_kernel, dim3(static_cast<unsigned>((idx->n + 3) / 4)), dim3(256), 0, st, idx->d_pq_rows, idx->n, pq->m,
+                       pq->k, pq->subdim, pq->d_codebooks, pq->d_scales, pq->d_offsets, img, bdim, norms, reinterpret_cast<int *>(norm_max));
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) VG_HIP(give_up(e));
+    idx->pq_bf16_dim = bdim;
+    idx->d_pq_bf16 = img;
+    idx->d_pq_norms = norms;
+    idx->d_pq_norm_max = norm_max;
+    return VG_OK;
+}
+
 namespace vg {
 int32_t pq_adc_search_masked(vg_index *idx, const float *queries, int64_t nq, int32_t k, const uint8_t *mask, int64_t mask_stride,
                              bool desc, uint32_t *ids, float *scores, void *stream);
@@ -1054,8 +1325,15 @@ VG_API int32_t vg_search_pq_adc(vg_index *idx, const float *queries, int64_t nq,
 
 // vg_search_pq_adc, and — with `mask` (a DEVICE pointer, bit per row, query q's at mask + q * mask_stride) — the whole-segment
 // PQ leg of vg_search_flat_filtered (k_probe.hip; k <= 64 and a table that fits LDS, `desc` by the segment's metric)
+static int32_t pq_adc_search_impl(vg_index *idx, const float *queries, int64_t nq, int32_t k, const uint8_t *mask, int64_t mask_stride,
+                                  bool desc, uint32_t *ids, float *scores, void *stream, bool allow_nomination);
 int32_t vg::pq_adc_search_masked(vg_index *idx, const float *queries, int64_t nq, int32_t k, const uint8_t *mask,
                                  int64_t mask_stride, bool desc, uint32_t *ids, float *scores, void *stream)
+{
+    return pq_adc_search_impl(idx, queries, nq, k, mask, mask_stride, desc, ids, scores, stream, true);
+}
+static int32_t pq_adc_search_impl(vg_index *idx, const float *queries, int64_t nq, int32_t k, const uint8_t *mask, int64_t mask_stride,
+                                  bool desc, uint32_t *ids, float *scores, void *stream, bool allow_nomination)
 {
     VG_CHECK(idx, VG_ERR_INVALID_ARG, "vg_search_pq_adc: NULL index");
     VG_CHECK(idx->pq != nullptr, VG_ERR_NOT_READY, "vg_search_pq_adc: index has no PQ codes");
@@ -1091,6 +1369,27 @@ int32_t vg::pq_adc_search_masked(vg_index *idx, const float *queries, int64_t nq
         VG_TRY(none.init(static_cast<size_t>(nq) * k, st));
         VG_HIP(hipMemsetAsync(none.ptr, 0xFF, static_cast<size_t>(nq) * k * 8, st));
         VG_TRY(vg::launch_topk_merge(none.ptr, nq, 1, k, false, oid.ptr, osc.ptr, st));
+    } else if (allow_nomination && vg::pq_nomination_applies(idx, q.ptr, nq, k, mask, desc)) {
+        std::vector<int> failed;
+        VG_TRY(vg::pq_nominated_pass(idx, q.ptr, nq, k, oid.ptr, osc.ptr, st, failed));
+        if (!failed.empty()) {  // the table scan for the queries whose proof failed (ties at the k-th score, thresholds too tight)
+            const int64_t nf = static_cast<int64_t>(failed.size());
+            vg::DevTmp<float> fq;
+            vg::DevTmp<uint32_t> fid;
+            vg::DevTmp<float> fsc;
+            VG_TRY(fq.init(static_cast<size_t>(nf) * idx->dim, st));
+            VG_TRY(fid.init(static_cast<size_t>(nf) * k, st));
+            VG_TRY(fsc.init(static_cast<size_t>(nf) * k, st));
+            for (int64_t i = 0; i < nf; i++)
+                VG_HIP(hipMemcpyAsync(fq.ptr + i * idx->dim, q.ptr + static_cast<int64_t>(failed[static_cast<size_t>(i)]) * idx->dim,
+                                      sizeof(float) * idx->dim, hipMemcpyDeviceToDevice, st));
+            VG_TRY(pq_adc_search_impl(idx, fq.ptr, nf, k, nullptr, 0, false, fid.ptr, fsc.ptr, st, false));
+            for (int64_t i = 0; i < nf; i++) {
+                const int64_t at = static_cast<int64_t>(failed[static_cast<size_t>(i)]) * k;
+                VG_HIP(hipMemcpyAsync(oid.ptr + at, fid.ptr + i * k, sizeof(uint32_t) * k, hipMemcpyDeviceToDevice, st));
+                VG_HIP(hipMemcpyAsync(osc.ptr + at, fsc.ptr + i * k, sizeof(float) * k, hipMemcpyDeviceToDevice, st));
+            }
+        }
     } else {
         int slices = vg::adc_slices(nq, idx->n_tiles, idx->ctx->compute_units);
         const bool bigk = k > 64;

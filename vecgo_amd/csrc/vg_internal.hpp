@@ -87,6 +87,7 @@ enum Hook {
     kHookFlatNoBigTile,       // VG_FLAT_NO_BIG_TILE     bf16 nomination: the 128 x 128 tile even above 128 queries
     kHookFlatBigTile2,        // VG_FLAT_BIG_TILE_2      bf16 256 x 256 tile with two row-tile buffers (128 KiB) instead of three
     kHookFlatBigEarlyB,       // VG_FLAT_BIG_EARLY_B     bf16 256 x 256 tile: row-tile fills behind the first matrix group of a step
+    kHookPqNomAlways,         // VG_PQ_NOM_ALWAYS        vg_index_enable_pq_nomination: batches of any size take the nomination
     kHookCount
 };
 bool hook(Hook h);
@@ -377,6 +378,10 @@ struct vg_index {
     uint32_t vamana_entry = 0;
     // PQ codes in the reference's row-major layout (random access by node id in graph search)
     uint8_t *d_pq_rows = nullptr;
+    uint16_t *d_pq_bf16 = nullptr;     // vg_index_enable_pq_nomination: the DECODED rows (pq.go:185-229) rounded to bfloat16, n*pq_bf16_dim, or null
+    int32_t pq_bf16_dim = 0;           // its row length: dim padded with zeros to whole 64-element K steps of the bf16 GEMM
+    float *d_pq_norms = nullptr;       // ... their |x^|^2 (fp32 of the unrounded values), n, and the largest of them
+    float *d_pq_norm_max = nullptr;
     uint8_t *d_rq_rows = nullptr;
     // SQ8 codes, re-tiled like the PQ codes: [tile][group of 16 dims][lane][16 B]; see k_sq8.hip
     vg_sq8 *sq = nullptr;
