@@ -1056,7 +1056,8 @@ int32_t vgo_candheap_sorted(const vgo_candheap *h, vgo_cand *dst)
     return h->len;
 }
 
-/* CandidateHeap.Pop :65-72 (Swap(0, n), down(0, n), truncate) and ReplaceTop :97-100 — only the tests call them */
+/* CandidateHeap.Pop :75-82 (Swap(0, n), down(0, n), truncate) — how the searches' results leave the heap (emit_sorted) — and
+ * ReplaceTop :100-103 */
 int vgo_candheap_pop(vgo_candheap *h, vgo_cand *out)
 {
     if (h->len == 0) return 0;
@@ -1195,15 +1196,20 @@ int32_t vgo_visited_replay(int32_t capacity, const int64_t *ops, int32_t n_ops, 
 /* ------------------------------------------------------------------ */
 /* flat scans — internal/segment/flat/segment.go:606-723                */
 /* ------------------------------------------------------------------ */
+/* What a caller of Segment.Search sees of the heap: the engine empties it with Pop() — worst first — into its buffer
+ * (engine/search.go:859-862 per segment, :915-918 after the merge); this file reports that sequence reversed, best first.
+ * (score, segment, row) is a total order on candidates WITHOUT NaN scores, and then any correct sort gives this sequence; a NaN
+ * score is neither better nor worse than anything (candidate_queue.go:12-38), the heap's layout — the history of every accepted
+ * candidate — then decides both which candidates it holds and the order they leave in, so it is popped, not sorted. */
 static int32_t emit_sorted(vgo_candheap *h, uint32_t *ids, float *scores)
 {
-    vgo_cand *tmp = (vgo_cand *)malloc(sizeof(vgo_cand) * (size_t)(h->len + 1));
-    int32_t n = vgo_candheap_sorted(h, tmp);
-    for (int i = 0; i < n; i++) {
-        ids[i] = tmp[i].row_id;
-        scores[i] = tmp[i].score;
+    int32_t n = h->len;
+    vgo_cand c;
+    for (int i = n - 1; i >= 0; i--) {
+        vgo_candheap_pop(h, &c);
+        ids[i] = c.row_id;
+        scores[i] = c.score;
     }
-    free(tmp);
     return n;
 }
 

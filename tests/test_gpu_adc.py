@@ -228,7 +228,8 @@ def _clustered_codes(rng, n, m, clusters=40, flip=0.3):
 
 @pytest.mark.parametrize("n,dim,m,nq,k", [(20000, 128, 16, 64, 10), (9000, 768, 96, 50, 10), (30000, 64, 8, 130, 48),
                                           (3000, 64, 4, 60, 5), (12000, 200, 25, 64, 10), (6000, 68, 17, 50, 100),
-                                          (7000, 64, 1, 48, 10), (16000, 128, 16, 130, 256), (5000, 128, 16, 300, 49)])
+                                          (7000, 64, 1, 48, 10), (16000, 128, 16, 130, 256), (5000, 128, 16, 300, 49),
+                                          (3000, 64, 8, 140, 10), (900, 128, 16, 200, 48)])
 def test_batches_through_the_bf16_nomination(vg, ctx, nominate_always, n, dim, m, nq, k):
     """vg_index_enable_pq_nomination: a batch (queries x rows >= 24M; here: the test hook) is nominated by the bfloat16 GEMM over the DECODED rows, its 64 best
     (k > 48: everything below the threshold) re-scored from the CODES against the query's table in pqAdcLookupAvx512 order, the

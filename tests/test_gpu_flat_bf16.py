@@ -41,6 +41,10 @@ def ctx(vg):
     (15000, 300, 40, 10, 2),
     (8000, 17, 70, 100, 0),       # dim % 4 != 0 too
     (6000, 3, 33, 10, 0),
+    (3000, 64, 140, 10, 2),       # no threshold sample (<= 4096 rows) and more than one query tile: the persistent 256 x 256 tile starts
+    (4000, 128, 300, 10, 1),      # from a threshold that stands for +Inf — r06 answered Dot segments of this shape wrongly
+    (1000, 64, 200, 48, 2),       # (flat_thr_cap_kernel)
+    (3000, 64, 140, 10, 0),
 ])
 def test_filter_is_bit_identical(vg, ctx, n, dim, nq, k, metric):
     rng = np.random.default_rng(n + dim + nq + k + metric)

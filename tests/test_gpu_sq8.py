@@ -156,7 +156,7 @@ def test_sq8_scan_pages_beyond_64_results(vg, ctx, n, dim, nq, k, metric):
 
 
 @pytest.mark.parametrize("n,dim,nq,k", [(20000, 128, 40, 10), (9000, 768, 24, 10), (30000, 64, 130, 48), (3000, 64, 20, 5),
-                                        (12000, 100, 33, 10), (6000, 17, 20, 100), (7000, 300, 9, 10)])
+                                        (12000, 100, 33, 10), (6000, 17, 20, 100), (7000, 300, 9, 10), (3000, 64, 140, 10), (900, 128, 200, 48)])
 def test_batches_through_the_bf16_nomination(vg, ctx, n, dim, nq, k):
     """vg_index_enable_sq8_nomination: 5 queries up, an L2 batch is nominated by the bfloat16 GEMM over the dequantised rows, its
     64 best re-scored from the CODES (the reference's L2Distance), the rest excluded by a proof — same ids and score bits as the
@@ -186,12 +186,13 @@ def test_batches_through_the_bf16_nomination(vg, ctx, n, dim, nq, k):
     assert np.array_equal(again[0], plain[0])
 
 
+@pytest.mark.parametrize("n,nq", [(16000, 36), (3500, 140)])   # (the second: no threshold sample and two query tiles of 128+)
 @pytest.mark.parametrize("metric", [0, 2])
-def test_nomination_with_dot_metric_and_filters(vg, ctx, metric):
+def test_nomination_with_dot_metric_and_filters(vg, ctx, metric, n, nq):
     """the same for a Dot segment (DotProduct, the largest first) and for filtered batches over the whole segment (one filter for
     the batch, one per query, filters that leave fewer than k rows): nomination on = nomination off = the oracle"""
     rng = np.random.default_rng(90 + metric)
-    n, dim, nq, k = 16000, 128, 36, 10
+    dim, k = 128, 10
     cent = rng.standard_normal((20, dim)).astype(np.float32) * 2
     x = (cent[rng.integers(0, 20, n)] + rng.standard_normal((n, dim)).astype(np.float32) * 0.6).astype(np.float32)
     x[50:58] = x[50]

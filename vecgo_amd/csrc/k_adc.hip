@@ -1062,7 +1062,8 @@ namespace vg {
 size_t flat_nominate_bf16_scratch(int64_t cnt, int64_t n, int dim, int sel_k);
 int32_t flat_nominate_bf16(vg_ctx *ctx, const uint16_t *rows_bf16, const float *norms, int64_t n, int dim, int dim_pad, const float *queries,
                            int64_t cnt, char *scratch, float *thr, int *counts, uint32_t *cand_id, float *cand_sc, hipStream_t st,
-                           bool dot, const uint8_t *mask, int64_t mask_stride, int sel_k, bool pick, const uint64_t **cand_keys, int *cap);
+                           bool dot, const uint8_t *mask, int64_t mask_stride, int sel_k, bool pick, const uint64_t **cand_keys, int *cap,
+                           const float *norm_max);
 constexpr int kPqPickMaxK = 48, kPqNomMaxK = 256;  // as kSq8PickMaxK / kSq8NomMaxK
 // the batches the nomination takes: 1M x 768, m = 96, k = 10: 16 queries 0.24 ms scanned / 0.39 nominated, 32: 0.46 / 0.41, 64: 0.86 /
 // 0.43, 1024: 12.4 / 1.7 (tools/pq_nominate_time.py) — the scan costs ~12 us per query and 1M rows, the nomination ~0.4 ms up to
@@ -1249,7 +1250,7 @@ static int32_t pq_nominated_pass(vg_index *idx, const float *q, int64_t nq, int 
             int cap = 0;
             VG_TRY(launch_pq_build_table(pq, qq, cnt, tables, false, st));
             VG_TRY(flat_nominate_bf16(idx->ctx, idx->d_pq_bf16, idx->d_pq_norms, idx->n, idx->dim, idx->pq_bf16_dim, qq, cnt, ar.get<char>(i_scr),
-                                      thr, counts, cid, csc, st, false, nullptr, 0, sel_k, k <= kPqPickMaxK, &cand, &cap));
+                                      thr, counts, cid, csc, st, false, nullptr, 0, sel_k, k <= kPqPickMaxK, &cand, &cap, idx->d_pq_norm_max));
             if (k <= kPqPickMaxK)
                 VG_LAUNCH(pq_verify_kernel, dim3(static_cast<unsigned>(cnt)), dim3(64), 0, st, idx->d_pq_rows, pq->m, pq->subdim, tables, qq,
                           idx->d_pq_norm_max, cid, csc, k, oid + q0 * k, osc + q0 * k, fail, thr, counts, cap, sel_k);

@@ -498,7 +498,7 @@ static int32_t brute_impl(vg_index *idx, const float *queries, int64_t nq, int32
                           int64_t mask_stride, uint32_t *ids, float *scores, void *stream);
 namespace vg {
 int32_t flat_search_masked(vg_index *idx, const float *queries, int64_t nq, int32_t k, const uint8_t *mask, int64_t mask_stride,
-                           uint32_t *ids, float *scores, void *stream, bool l2_scores = false);
+                           uint32_t *ids, float *scores, void *stream, bool l2_scores = false, bool cand_replay = true);
 }
 
 VG_API int32_t vg_search_hnsw_brute(vg_index *idx, const float *queries, int64_t nq, int32_t k, int32_t mode,
@@ -555,7 +555,7 @@ VG_API int32_t vg_search_hnsw_brute(vg_index *idx, const float *queries, int64_t
     {
         vg::ProfScope prof(idx->ctx, "hnsw_brute_dist", st);  // (the distance work of this form)
         // (Cosine: the index's distance is 0.5 * squared L2 of the normalised rows — the flat search is asked for L2 scores)
-        VG_TRY(vg::flat_search_masked(idx, q.ptr, nq, k + 1, mk.ptr, mask_stride, fid.ptr, fsc.ptr, st, idx->metric == VG_METRIC_COSINE));
+        VG_TRY(vg::flat_search_masked(idx, q.ptr, nq, k + 1, mk.ptr, mask_stride, fid.ptr, fsc.ptr, st, idx->metric == VG_METRIC_COSINE, false));
     }
     VG_LAUNCH(vg::brute_from_flat_kernel, dim3(static_cast<unsigned>(nq)), dim3(64), 0, st, fid.ptr, fsc.ptr, nq, k,
               idx->metric == VG_METRIC_DOT ? 1 : idx->metric == VG_METRIC_COSINE ? 2 : 0, oid.ptr, osc.ptr, redo.ptr);

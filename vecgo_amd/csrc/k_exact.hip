@@ -110,20 +110,29 @@ __global__ void norm_max_kernel(const float *__restrict__ v, int64_t n, float *_
     if (threadIdx.x == 0) out[0] = sm[0];
 }
 
+// (+ max |x| over every element, NaN / Inf counted as +Inf, into *maxabs_bits: what vg_cand_replay.hpp's risk test reads)
 __global__ void row_norms_kernel(const float *__restrict__ base, int64_t n, int dim,
-                                 float *__restrict__ norms)
+                                 float *__restrict__ norms, int *__restrict__ maxabs_bits)
 {
     // ||x||^2 for the GEMM-form candidate generation only (never reported): plain order
     const int64_t row = static_cast<int64_t>(blockIdx.x) * (blockDim.x / 64) + (threadIdx.x >> 6);
     if (row >= n) return;
     const int lane = threadIdx.x & 63;
-    float s = 0.0f;
+    float s = 0.0f, mx = 0.0f;
     for (int j = lane; j < dim; j += 64) {
         const float v = base[row * dim + j];
         s = __builtin_fmaf(v, v, s);
+        const float a = fabsf(v);
+        mx = fmaxf(mx, a == a ? a : INFINITY);
     }
-    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
-    if (lane == 0) norms[row] = s;
+    for (int off = 32; off > 0; off >>= 1) {
+        s += __shfl_xor(s, off);
+        mx = fmaxf(mx, __shfl_xor(mx, off));
+    }
+    if (lane == 0) {
+        norms[row] = s;
+        atomicMax(maxabs_bits, __float_as_int(mx));  // non-negative floats order like their bits
+    }
 }
 
 }  // namespace vg
@@ -155,11 +164,12 @@ VG_API int32_t vg_index_set_vectors(vg_index *idx, const float *base, void *stre
         size_t count = static_cast<size_t>(idx->n) * idx->dim;
         VG_HIP(hipMalloc(reinterpret_cast<void **>(&idx->d_vectors), count * sizeof(float)));
         VG_HIP(hipMalloc(reinterpret_cast<void **>(&idx->d_norms), static_cast<size_t>(idx->n) * sizeof(float)));
-        VG_HIP(hipMalloc(reinterpret_cast<void **>(&idx->d_norm_max), sizeof(float)));
+        VG_HIP(hipMalloc(reinterpret_cast<void **>(&idx->d_norm_max), 2 * sizeof(float)));  // [1]: max |x|, non-finite -> +Inf
+        VG_HIP(hipMemsetAsync(idx->d_norm_max, 0, 2 * sizeof(float), st));
         VG_HIP(hipMalloc(reinterpret_cast<void **>(&idx->d_flat_stats), 2 * sizeof(unsigned long long)));
         VG_HIP(hipMemcpyAsync(idx->d_vectors, base, count * sizeof(float), hipMemcpyDefault, st));
         VG_LAUNCH(vg::row_norms_kernel, dim3(static_cast<unsigned>((idx->n + 3) / 4)), dim3(256),
-                           0, st, idx->d_vectors, idx->n, idx->dim, idx->d_norms);
+                           0, st, idx->d_vectors, idx->n, idx->dim, idx->d_norms, reinterpret_cast<int *>(idx->d_norm_max + 1));
         VG_LAUNCH(vg::norm_max_kernel, dim3(1), dim3(1024), 0, st, idx->d_norms, idx->n, idx->d_norm_max);
         VG_HIP(hipMemsetAsync(idx->d_flat_stats, 0, 2 * sizeof(unsigned long long), st));
         VG_HIP(hipStreamSynchronize(st));

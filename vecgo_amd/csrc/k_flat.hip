@@ -10,6 +10,7 @@
 
 #include "vg_device.hpp"
 #include "vg_exact.hpp"
+#include "vg_cand_replay.hpp"
 #include "vg_flat_gemm.hpp"
 #include "vg_internal.hpp"
 
@@ -205,6 +206,28 @@ __global__ void fill_f32_kernel(float *p, int64_t n, float v)
 {
     const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (i < n) p[i] = v;
+}
+
+// A query's thresholds never above the largest score a row can have: 2 (|q|^2 + max |x|^2) >= |x|^2 + 2 |q| |x| (L2) >= |q.x|
+// (Dot), with room for the bfloat16 rounding of both operands.  "No threshold" (+Inf: no sample of a small segment, a filter that
+// leaves the sample short) means the same after it — every row passes — but the persistent bf16 tile (flat_gemm_bf16_big_kernel)
+// starts its accumulators at (t - |x|^2) / 2 and reads a row's score back as t - 2 acc: with t = 1e30 standing in for +Inf the dot
+// product is absorbed, every appended score comes back as ~0, and the 64 "best" of them were an arbitrary 64 (r06: Dot segments of
+// up to 4096 rows, batches above 128 queries, answered wrongly — tests/test_gpu_nonfinite.py found it).  One wave per query.
+__global__ __launch_bounds__(64) void flat_thr_cap_kernel(float *__restrict__ thr, int sel_k, const float *__restrict__ queries, int dim,
+                                                          const float *__restrict__ norm_max)
+{
+    const int64_t q = blockIdx.x;
+    const int lane = threadIdx.x;
+    float qn = 0.0f;
+    for (int j = lane; j < dim; j += 64) qn = __builtin_fmaf(queries[q * dim + j], queries[q * dim + j], qn);
+    for (int off = 32; off > 0; off >>= 1) qn += __shfl_xor(qn, off);
+    const float bound = 2.002f * (qn + norm_max[0]);
+    if (!(bound < 1e30f)) return;  // not finite: the tile's own clamp stands in, and every proof fails on its (infinite) margin
+    for (int i = lane; i < sel_k; i += 64) {
+        const float t = thr[q * sel_k + i];
+        if (!(t < bound)) thr[q * sel_k + i] = bound;  // (NaN too)
+    }
 }
 
 // ---- 2. per-query streaming select of the kc smallest scores -------------------------------
@@ -603,8 +626,43 @@ int32_t launch_page_patch(int64_t nq, int k, int off, int kk, bool descending, c
 
 namespace vg {
 int32_t flat_search_masked(vg_index *idx, const float *queries, int64_t nq, int32_t k, const uint8_t *mask, int64_t mask_stride,
-                           uint32_t *ids, float *scores, void *stream, bool l2_scores = false);
+                           uint32_t *ids, float *scores, void *stream, bool l2_scores = false, bool cand_replay = true);
 }
+
+namespace vg {
+// vg_cand_replay.hpp's scorer for the fp32 rows: distance.SquaredL2 / distance.Dot of flat/segment.go:691-701 (squaredL2Avx512 /
+// dotProductAvx512 order, 16 lanes per pair: 16 rows per step of the workgroup)
+struct FlatF32Scorer {
+    const float *base;
+    const float *maxabs;  // [1]: max |x| over the rows, +Inf when one of them is not finite (vg_index_set_vectors)
+    int dim;
+    bool dot;
+    __device__ bool risk(const float *q, int tid) const
+    {
+        __shared__ int flag;
+        const float ma = maxabs[0];
+        bool bad = !is_finite_f32(ma);
+        for (int j = tid; j < dim; j += kReplayThreads) {
+            const float v = q[j];
+            // a dot product of finite values is a NaN only through +Inf and -Inf partial sums: none can arise below dim * max|q| * max|x|
+            bad = bad || !is_finite_f32(v) || (dot && !(fabsf(v) * ma * static_cast<float>(dim) < 1e38f));
+        }
+        return block_any(bad, &flag, tid);
+    }
+    __device__ void prepare(const float *, int) const {}
+    __device__ void score_chunk(const float *q, int64_t row0, int64_t n, int tid, float *out) const
+    {
+        const Sub16 sub = Sub16::make(tid);
+        for (int r = tid >> 4; r < kReplayChunk; r += kReplayThreads / 16) {
+            const int64_t row = row0 + r;
+            if (row >= n) break;  // (a whole 16-lane group)
+            const float *x = base + row * dim;
+            const float v = dot ? exact_pair16<true, kPair>(x, q, dim, sub) : exact_pair16<false, kPair>(x, q, dim, sub);
+            if ((tid & 15) == 0) out[r] = v;
+        }
+    }
+};
+}  // namespace vg
 
 VG_API int32_t vg_search_flat(vg_index *idx, const float *queries, int64_t nq, int32_t k, uint32_t *ids,
                               float *scores, void *stream)
@@ -619,7 +677,7 @@ VG_API int32_t vg_search_flat(vg_index *idx, const float *queries, int64_t nq, i
 // l2_scores: squared-L2 scores whatever the index's metric (vg_search_hnsw_brute on a Cosine index: hnsw's distance there is
 // 0.5 * squared L2, flat.Segment's is the dot product)
 int32_t vg::flat_search_masked(vg_index *idx, const float *queries, int64_t nq, int32_t k, const uint8_t *mask,
-                               int64_t mask_stride, uint32_t *ids, float *scores, void *stream, bool l2_scores)
+                               int64_t mask_stride, uint32_t *ids, float *scores, void *stream, bool l2_scores, bool cand_replay)
 {
     VG_CHECK(idx, VG_ERR_INVALID_ARG, "vg_search_flat: NULL index");
     VG_CHECK(nq >= 0 && k >= 0, VG_ERR_INVALID_ARG, "vg_search_flat: negative nq or k");
@@ -796,6 +854,7 @@ int32_t vg::flat_search_masked(vg_index *idx, const float *queries, int64_t nq, 
                     VG_LAUNCH(vg::fill_f32_kernel, dim3(static_cast<unsigned>((cnt * sel_k + 255) / 256)), dim3(256),
                               0, st, thr, cnt * sel_k, INFINITY);
                 }
+                if (bf16) VG_LAUNCH(vg::flat_thr_cap_kernel, dim3(ucnt), dim3(64), 0, st, thr, sel_k, qp, dim, idx->d_norm_max);
                 // (b) the GEMM, appending every element below its query's threshold
                 VG_HIP(hipMemsetAsync(counts, 0, sizeof(int) * static_cast<size_t>(cnt), st));
                 {
@@ -881,6 +940,11 @@ int32_t vg::flat_search_masked(vg_index *idx, const float *queries, int64_t nq, 
             }
         }
     }
+    // queries whose scores may hold a NaN (a non-finite query value / row, an overflowing dot product): the reference's heap,
+    // operation by operation (vg_cand_replay.hpp); every other query returns from this launch at once
+    if (n > 0 && cand_replay)
+        VG_TRY(vg::launch_cand_replay(vg::FlatF32Scorer{idx->d_vectors, idx->d_norm_max + 1, dim, dot}, q.ptr, dim, n, nq, k, dot, mask, mask_stride,
+                                      oid.ptr, osc.ptr, st));
     VG_TRY(oid.finish());
     VG_TRY(osc.finish());
     if (oid.on_host() || osc.on_host()) VG_HIP(hipStreamSynchronize(st));
@@ -1081,7 +1145,8 @@ size_t flat_nominate_bf16_scratch(int64_t cnt, int64_t n, int dim, int sel_k) { 
 
 int32_t flat_nominate_bf16(vg_ctx *ctx, const uint16_t *rows_bf16, const float *norms, int64_t n, int dim, int dim_pad, const float *queries,
                            int64_t cnt, char *scratch, float *thr, int *counts, uint32_t *cand_id, float *cand_sc, hipStream_t st,
-                           bool dot, const uint8_t *mask, int64_t mask_stride, int sel_k, bool pick, const uint64_t **cand_keys, int *cap)
+                           bool dot, const uint8_t *mask, int64_t mask_stride, int sel_k, bool pick, const uint64_t **cand_keys, int *cap,
+                           const float *norm_max)
 {
     // dot: scores are -q.x (the largest dot products first); mask: a row filter per query (mask + q * mask_stride) or for the
     // batch (stride 0) — rejected rows are left out of the sample and of the candidates, as in flat_search_masked
@@ -1106,6 +1171,8 @@ int32_t flat_nominate_bf16(vg_ctx *ctx, const uint16_t *rows_bf16, const float *
     } else {
         VG_LAUNCH(fill_f32_kernel, dim3(static_cast<unsigned>((cnt * sel_k + 255) / 256)), dim3(256), 0, st, thr, cnt * sel_k, INFINITY);
     }
+    // (norm_max: the largest of `norms`, device)
+    VG_LAUNCH(flat_thr_cap_kernel, dim3(static_cast<unsigned>(cnt)), dim3(64), 0, st, thr, sel_k, queries, dim, norm_max);
     VG_HIP(hipMemsetAsync(counts, 0, sizeof(int) * static_cast<size_t>(cnt), st));
     {
         ProfScope prof(ctx, "sq8_nominate_gemm", st);

@@ -32,7 +32,7 @@ int32_t launch_probe_scan_sq8_grouped(const vg_index *idx, const float *queries,
                                       int np, int sub, int k, uint64_t *partial, const uint64_t *min_keys, const uint8_t *mask,
                                       int64_t mask_stride, hipStream_t st);
 int32_t flat_search_masked(vg_index *idx, const float *queries, int64_t nq, int32_t k, const uint8_t *mask, int64_t mask_stride,
-                           uint32_t *ids, float *scores, void *stream, bool l2_scores = false);
+                           uint32_t *ids, float *scores, void *stream, bool l2_scores = false, bool cand_replay = true);
 int32_t pq_adc_search_masked(vg_index *idx, const float *queries, int64_t nq, int32_t k, const uint8_t *mask, int64_t mask_stride,
                              bool desc, uint32_t *ids, float *scores, void *stream);
 size_t flat_probe_gemm_scratch_bytes(int64_t pairs, int64_t ns_max, int k, int bf16_dim);

@@ -1538,7 +1538,8 @@ namespace vg {
 size_t flat_nominate_bf16_scratch(int64_t cnt, int64_t n, int dim, int sel_k);
 int32_t flat_nominate_bf16(vg_ctx *ctx, const uint16_t *rows_bf16, const float *norms, int64_t n, int dim, int dim_pad, const float *queries,
                            int64_t cnt, char *scratch, float *thr, int *counts, uint32_t *cand_id, float *cand_sc, hipStream_t st,
-                           bool dot, const uint8_t *mask, int64_t mask_stride, int sel_k, bool pick, const uint64_t **cand_keys, int *cap);
+                           bool dot, const uint8_t *mask, int64_t mask_stride, int sel_k, bool pick, const uint64_t **cand_keys, int *cap,
+                           const float *norm_max);
 // k <= 48: the 64 best nominees are re-scored (sq8_verify_kernel); up to 256: everything below the threshold
 // (sq8_verify_sort_kernel) — the 8th best of the 1/64 row sample passes ~512 rows, the 16th ~1024, the 32nd ~2048.  (The proof
 // wants the threshold 2^-7 (|q|^2 + |x^|^2) above the k-th score: ~512 rows for k = 100 left enough queries to the scan — random-
@@ -1834,7 +1835,7 @@ int32_t sq8_nominated_pass(vg_index *idx, const float *q, int64_t nq, int k, con
             ProbeNominated nom{thr, counts, cid, csc, 0, sel_k, nullptr};
             VG_TRY(flat_nominate_bf16(idx->ctx, idx->d_sq_bf16, idx->d_sq_norms, idx->n, idx->dim, idx->sq_bf16_dim, q + q0 * idx->dim, cnt, ar.get<char>(i_scr),
                                       thr, counts, cid, csc, st, dot, mask ? mask + q0 * mask_stride : nullptr, mask_stride, sel_k,
-                                      k <= kSq8PickMaxK, &nom.cand, &nom.cap));
+                                      k <= kSq8PickMaxK, &nom.cand, &nom.cap, idx->d_sq_norm_max));
             VG_TRY(launch_sq8_verify(idx, q + q0 * idx->dim, cnt, nom, k, oid + q0 * k, osc + q0 * k, fail, st));
             VG_HIP(hipMemcpyAsync(h.data(), fail, sizeof(int) * static_cast<size_t>(cnt), hipMemcpyDeviceToHost, st));
             VG_HIP(hipStreamSynchronize(st));
