@@ -104,3 +104,106 @@ def test_flat_fp32_with_non_finite_rows(vg, ctx, metric, where):
     check(idx.search_flat(q, k), lambda i: o.flat_search_f32(x, dim, q[i], k, metric=metric), nq, k)
     if where == "root":
         assert np.all(idx.search_flat(q, 1)[0][:, 0] == 0)
+
+
+def _random_pq(rng, dim, m):
+    sd = dim // m
+    opq = o.ProductQuantizer(dim, m, 256)
+    cb = rng.integers(-128, 128, m * 256 * sd).astype(np.int8)
+    scales = (rng.random(m) * 0.02 + 0.005).astype(np.float32)
+    offsets = ((rng.random(m) * 2 - 1) * 0.1).astype(np.float32)
+    opq.set_codebooks(cb, scales, offsets)
+    return opq
+
+
+@pytest.mark.parametrize("n,dim,m,k", [(3000, 128, 16, 10), (2000, 200, 25, 1), (5000, 64, 4, 70), (50, 128, 16, 100), (9000, 768, 96, 10)])
+def test_pq_adc_with_non_finite_queries(vg, ctx, n, dim, m, k):
+    """vg_search_pq_adc: a NaN / Inf query value makes table entries NaN / +Inf — every row's sum holds them (NaN: all sums NaN, the
+    first k rows stay; +Inf: ties, by row id; both: by the heap).  With and without the bf16 nomination; and a NaN offset in the
+    quantizer (every query is at risk)."""
+    from tests import hooks
+    rng = np.random.default_rng(n + dim + m)
+    opq = _random_pq(rng, dim, m)
+    codes = rng.integers(0, 256, (n, m)).astype(np.uint8)
+    codes[10:14] = codes[10]
+    pq = vg.ProductQuantizer(ctx, dim, m, 256)
+    pq.set_codebooks(opq.codebooks, opq.scales, opq.offsets)
+    idx = vg.Index(ctx, n, dim, vg.Metric.L2)
+    idx.set_pq_codes(pq, codes)
+    nq = 14
+    q = poisoned_queries(rng, rng.standard_normal((n, dim)).astype(np.float32), nq)
+    want = lambda qq: (lambda i: o.flat_search_pq(opq, codes, qq[i], k))
+    check(idx.search_pq_adc(q, k), want(q), nq, k)
+    big = np.tile(q, (10, 1))
+    hooks.set_hook("VG_PQ_NOM_ALWAYS", 1)
+    try:
+        idx.enable_pq_nomination(True)
+        check(idx.search_pq_adc(big, k), want(big), big.shape[0], k)
+    finally:
+        hooks.set_hook("VG_PQ_NOM_ALWAYS", 0)
+    of = np.array(opq.offsets, np.float32)
+    of[m // 2] = np.nan
+    opq.set_codebooks(opq.codebooks, opq.scales, of)
+    pq2 = vg.ProductQuantizer(ctx, dim, m, 256)
+    pq2.set_codebooks(opq.codebooks, opq.scales, opq.offsets)
+    idx2 = vg.Index(ctx, n, dim, vg.Metric.L2)
+    idx2.set_pq_codes(pq2, codes)
+    check(idx2.search_pq_adc(q, k), want(q), nq, k)
+
+
+@pytest.mark.parametrize("metric", [0, 2])
+@pytest.mark.parametrize("n,dim,k", [(3000, 64, 10), (2500, 100, 1), (5000, 30, 70), (60, 64, 100)])
+def test_sq8_with_non_finite_queries_and_bounds(vg, ctx, metric, n, dim, k):
+    """vg_search_sq8 (L2Distance / DotProduct by the metric): poisoned queries; then a quantizer whose bounds hold a NaN"""
+    rng = np.random.default_rng(n + dim + k + metric)
+    x = rng.standard_normal((n, dim)).astype(np.float32)
+    x[40:44] = x[40]
+    nq = 14
+    q = poisoned_queries(rng, x, nq)
+    for poison in (False, True):
+        ref = o.ScalarQuantizer(dim)
+        sq = vg.ScalarQuantizer(ctx, dim)
+        if poison:
+            mins, maxs = x.min(0).copy(), x.max(0).copy()
+            mins[dim // 3] = np.nan
+            maxs[dim // 2] = np.inf
+            sq.set_bounds(mins, maxs)
+            codes = rng.integers(0, 256, (n, dim)).astype(np.uint8)
+        else:
+            sq.train(x)
+            codes = sq.encode(x)
+        for dst, src in zip((ref.mins, ref.maxs, ref.scales, ref.inv_scales), sq.params()):   # (SetBounds / Train parity: test_gpu_sq8.py)
+            dst[:] = src
+        ref.trained = True
+        idx = vg.Index(ctx, n, dim, vg.Metric(metric))
+        idx.set_sq8_codes(sq, codes)
+        seg = o.FlatSegment(x, dim, metric=metric, sq=ref, codes=codes)
+        check(idx.search_sq8(q, k), lambda i: seg.search(q[i], k), nq, k)
+        if not poison:
+            idx.enable_sq8_nomination(True)
+            big = np.tile(q, (10, 1))
+            check(idx.search_sq8(big, k), lambda i: seg.search(big[i], k), big.shape[0], k)
+
+
+@pytest.mark.parametrize("n,dim,k", [(3000, 64, 10), (2500, 100, 1), (5000, 200, 70), (60, 64, 100)])
+def test_rabitq_with_non_finite_queries_and_norms(vg, ctx, n, dim, k):
+    """vg_search_rabitq: a non-finite query gives a non-finite query norm (rabitq.go:119-176) — every distance a NaN or +Inf; a row
+    whose stored norm is a NaN / Inf puts every query at risk; 4 |q| |y| overflowing next to a Hamming distance of 0 is a NaN"""
+    rng = np.random.default_rng(n + dim + k)
+    x = rng.standard_normal((n, dim)).astype(np.float32)
+    x[40:44] = x[40]
+    nq = 14
+    q = poisoned_queries(rng, x, nq)
+    q[11] = x[7] * np.float32(3e18)                       # |q| ~ 2e19 finite, same sign bits as row 7: Hamming 0
+    codes = o.rabitq_encode_batch(x, dim)
+    cb = o.rabitq_code_bytes(dim)
+    for poison in (False, True):
+        c = codes.copy().reshape(n, cb)
+        if poison:
+            c[3, cb - 4:] = np.frombuffer(np.float32(np.nan).tobytes(), np.uint8)
+            c[n // 2, cb - 4:] = np.frombuffer(np.float32(np.inf).tobytes(), np.uint8)
+            c[7, cb - 4:] = np.frombuffer(np.float32(3e19).tobytes(), np.uint8)
+        idx = vg.Index(ctx, n, dim, vg.Metric.L2)
+        idx.set_rabitq_codes(c)
+        check(idx.search_rabitq(q, k), lambda i: o.flat_search_rabitq(c, dim, q[i], k), nq, k)
+        check(idx.search_rabitq(q[:1], k), lambda i: o.flat_search_rabitq(c, dim, q[i], k), 1, k)

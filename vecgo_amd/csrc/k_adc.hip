@@ -29,6 +29,7 @@
 
 #include "vg_device.hpp"
 #include "vg_internal.hpp"
+#include "vg_cand_replay.hpp"
 
 namespace vg {
 
@@ -1326,6 +1327,59 @@ VG_API int32_t vg_search_pq_adc(vg_index *idx, const float *queries, int64_t nq,
 
 // vg_search_pq_adc, and — with `mask` (a DEVICE pointer, bit per row, query q's at mask + q * mask_stride) — the whole-segment
 // PQ leg of vg_search_flat_filtered (k_probe.hip; k <= 64 and a table that fits LDS, `desc` by the segment's metric)
+namespace vg {
+// vg_cand_replay.hpp's scorer for the PQ table scan: pq.AdcDistance of a row's code (flat/segment.go:678-689) — the table's entries
+// (BuildDistanceTable, pq.go:468-491: five separately rounded operations per dimension) computed where they are used, summed in
+// pqAdcLookupAvx512 order; one lane per row of the row-major codes.  A NaN: a non-finite query value, scale or offset (the
+// entries are sums of squares: finite inputs give a finite value or +Inf).
+struct PqScorer {
+    const uint8_t *codes;     // n * m
+    const int8_t *codebooks;  // m * 256 * sd
+    const float *scales, *offsets;
+    int m, sd;
+    __device__ bool risk(int64_t, const float *q, int tid) const
+    {
+        __shared__ int flag;
+        bool bad = false;
+        for (int j = tid; j < m * sd; j += kReplayThreads) bad = bad || !is_finite_f32(q[j]);
+        for (int j = tid; j < m; j += kReplayThreads) bad = bad || !is_finite_f32(scales[j]) || !is_finite_f32(offsets[j]);
+        return block_any(bad, &flag, tid);
+    }
+    __device__ void prepare(int64_t, const float *, int) const {}
+    __device__ float entry(const float *q, int j, int c) const
+    {
+        const int8_t *cb = codebooks + (static_cast<int64_t>(j) * 256 + c) * sd;
+        const float scale = scales[j], offset = offsets[j];
+        const float *qs = q + j * sd;
+        float sum = 0.0f;
+        for (int i = 0; i < sd; i++) {
+            float v = static_cast<float>(cb[i]) * scale;
+            v = v + offset;
+            const float d = qs[i] - v;
+            const float dd = d * d;
+            sum = sum + dd;
+        }
+        return sum;
+    }
+    __device__ void score_chunk(int64_t, const float *q, int64_t row0, int64_t n, int tid, float *out) const
+    {
+        const int64_t row = row0 + tid;
+        if (row >= n) return;
+        const uint8_t *code = codes + row * m;
+        float s[16];
+#pragma unroll
+        for (int l = 0; l < 16; l++) s[l] = 0.0f;
+        int i = 0;
+        for (; i + 16 <= m; i += 16)
+#pragma unroll
+            for (int l = 0; l < 16; l++) s[l] = s[l] + entry(q, i + l, code[i + l]);
+        float total = reduce16_regs(s);
+        for (; i < m; i++) total = total + entry(q, i, code[i]);
+        out[tid] = total;
+    }
+};
+}  // namespace vg
+
 static int32_t pq_adc_search_impl(vg_index *idx, const float *queries, int64_t nq, int32_t k, const uint8_t *mask, int64_t mask_stride,
                                   bool desc, uint32_t *ids, float *scores, void *stream, bool allow_nomination);
 int32_t vg::pq_adc_search_masked(vg_index *idx, const float *queries, int64_t nq, int32_t k, const uint8_t *mask,
@@ -1365,6 +1419,13 @@ static int32_t pq_adc_search_impl(vg_index *idx, const float *queries, int64_t n
     VG_TRY(oid.init(ids, static_cast<size_t>(nq) * k, st));
     VG_TRY(osc.init(scores, static_cast<size_t>(nq) * k, st));
 
+    // queries whose table sums may hold a NaN: the reference's heap, operation by operation (vg_cand_replay.hpp; not for the queries
+    // this function sends to itself after a failed proof: the caller's pass covers them)
+    auto nan_replay = [&]() -> int32_t {
+        if (idx->n == 0 || !allow_nomination) return VG_OK;
+        return vg::launch_cand_replay(vg::PqScorer{idx->d_pq_rows, pq->d_codebooks, pq->d_scales, pq->d_offsets, pq->m, pq->subdim}, q.ptr, idx->dim,
+                                      idx->n, nq, k, desc, mask, mask_stride, oid.ptr, osc.ptr, st);
+    };
     if (idx->n == 0) {
         vg::DevTmp<uint64_t> none;
         VG_TRY(none.init(static_cast<size_t>(nq) * k, st));
@@ -1433,6 +1494,7 @@ static int32_t pq_adc_search_impl(vg_index *idx, const float *queries, int64_t n
             VG_TRY(vg::launch_topk_merge(partial.ptr, nq, slices, k, false, fid, fsc, st, flags));
             VG_LAUNCH(vg::patch_results_kernel, dim3(static_cast<unsigned>(nq)), dim3(64), 0, st, flags, k, fid, fsc,
                       oid.ptr, osc.ptr);
+            VG_TRY(nan_replay());
             VG_TRY(oid.finish());
             VG_TRY(osc.finish());
             if (oid.on_host() || osc.on_host()) VG_HIP(hipStreamSynchronize(st));
@@ -1450,6 +1512,7 @@ static int32_t pq_adc_search_impl(vg_index *idx, const float *queries, int64_t n
             VG_TRY((vg::launch_scan<-1, false>(idx, tables.ptr, nq, k, slices, partial.ptr, st)));
         VG_TRY(vg::launch_topk_merge(partial.ptr, nq, slices, k, desc, oid.ptr, osc.ptr, st));
     }
+    VG_TRY(nan_replay());
     VG_TRY(oid.finish());
     VG_TRY(osc.finish());
     if (oid.on_host() || osc.on_host()) VG_HIP(hipStreamSynchronize(st));

@@ -637,7 +637,7 @@ struct FlatF32Scorer {
     const float *maxabs;  // [1]: max |x| over the rows, +Inf when one of them is not finite (vg_index_set_vectors)
     int dim;
     bool dot;
-    __device__ bool risk(const float *q, int tid) const
+    __device__ bool risk(int64_t, const float *q, int tid) const
     {
         __shared__ int flag;
         const float ma = maxabs[0];
@@ -649,8 +649,8 @@ struct FlatF32Scorer {
         }
         return block_any(bad, &flag, tid);
     }
-    __device__ void prepare(const float *, int) const {}
-    __device__ void score_chunk(const float *q, int64_t row0, int64_t n, int tid, float *out) const
+    __device__ void prepare(int64_t, const float *, int) const {}
+    __device__ void score_chunk(int64_t, const float *q, int64_t row0, int64_t n, int tid, float *out) const
     {
         const Sub16 sub = Sub16::make(tid);
         for (int r = tid >> 4; r < kReplayChunk; r += kReplayThreads / 16) {

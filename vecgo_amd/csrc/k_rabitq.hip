@@ -4,6 +4,7 @@
 #include "vg_device.hpp"
 #include "vg_exact.hpp"
 #include "vg_internal.hpp"
+#include "vg_cand_replay.hpp"
 
 namespace vg {
 
@@ -385,6 +386,49 @@ int32_t launch_rabitq_encode(const float *d_vectors, int64_t n, int dim, uint8_t
     return VG_OK;
 }
 
+// max |v[i]| (NaN / Inf counted as +Inf) into *out_bits (zeroed by the caller; non-negative floats order like their bits)
+__global__ __launch_bounds__(256) void absmax_kernel(const float *__restrict__ v, int64_t n, int *__restrict__ out_bits)
+{
+    float mx = 0.0f;
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; i < n; i += static_cast<int64_t>(gridDim.x) * 256) {
+        const float a = fabsf(v[i]);
+        mx = fmaxf(mx, a == a ? a : INFINITY);
+    }
+    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+    if ((threadIdx.x & 63) == 0) atomicMax(out_bits, __float_as_int(mx));
+}
+
+// vg_cand_replay.hpp's scorer for the RaBitQ scan: rq.Distance of the query's code (sign bits + norm, rabitq.go:119-176) against a
+// row's, from the row-major copy of the codes.  A NaN: a non-finite norm on either side, or 4 |q| |y| overflowing to +Inf next
+// to a Hamming distance of 0 (rq_formula: t2 = 4 qn yn / dim * hamming).
+struct RabitqScorer {
+    const uint8_t *rows;     // n * (nb + 4)
+    const uint8_t *qcodes;   // nq * (nb + 4), the queries' own codes (rabitq_encode_kernel)
+    const float *norm_absmax;
+    int dim, nb;
+    __device__ const uint8_t *qcode(int64_t qi) const { return qcodes + qi * (nb + 4); }
+    __device__ static float norm_of(const uint8_t *c, int nb)
+    {
+        return __uint_as_float(c[nb] | (c[nb + 1] << 8) | (c[nb + 2] << 16) | (static_cast<uint32_t>(c[nb + 3]) << 24));
+    }
+    __device__ bool risk(int64_t qi, const float *, int tid) const
+    {
+        __shared__ int flag;
+        const float qn = norm_of(qcode(qi), nb), ma = norm_absmax[0];
+        const bool bad = !is_finite_f32(qn) || !is_finite_f32(ma) || !(4.0f * fabsf(qn) * ma < 1e38f);
+        return block_any(bad, &flag, tid);
+    }
+    __device__ void prepare(int64_t, const float *, int) const {}
+    __device__ void score_chunk(int64_t qi, const float *, int64_t row0, int64_t n, int tid, float *out) const
+    {
+        const int64_t row = row0 + tid;
+        if (row >= n) return;
+        const uint8_t *qc = qcode(qi), *c = rows + row * (nb + 4);
+        const int h = hamming_bytes(qc, c, nb);
+        out[tid] = rq_formula(norm_of(qc, nb), norm_of(c, nb), static_cast<float>(dim), static_cast<float>(h));
+    }
+};
+
 static int rq_slices(int64_t nq, int64_t n_tiles, int cus)
 {
     int64_t s = (4 * static_cast<int64_t>(cus) + nq - 1) / nq;  // ~4 workgroups of 256 threads per CU (swept 2..8: 3-4 best)
@@ -488,7 +532,9 @@ VG_API int32_t vg_index_set_rabitq_codes(vg_index *idx, const uint8_t *codes, vo
     if (idx->n == 0) return VG_OK;
     const int64_t total = idx->n_tiles * idx->rq_groups * 64;
     VG_HIP(hipMalloc(reinterpret_cast<void **>(&idx->d_rq_tiles), static_cast<size_t>(total) * 16));
-    VG_HIP(hipMalloc(reinterpret_cast<void **>(&idx->d_rq_norms), static_cast<size_t>(idx->n) * sizeof(float)));
+    // (+ one float: the largest |norm|, +Inf when one of them is not finite — vg_cand_replay.hpp's risk test)
+    VG_HIP(hipMalloc(reinterpret_cast<void **>(&idx->d_rq_norms), static_cast<size_t>(idx->n + 1) * sizeof(float)));
+    VG_HIP(hipMemsetAsync(idx->d_rq_norms + idx->n, 0, sizeof(float), st));
     vg::DevIn<uint8_t> in;
     VG_TRY(in.init(codes, static_cast<size_t>(idx->n) * (nb + 4), st));
     if (idx->d_rq_rows) {
@@ -500,6 +546,8 @@ VG_API int32_t vg_index_set_rabitq_codes(vg_index *idx, const uint8_t *codes, vo
     VG_LAUNCH(vg::rabitq_retile_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, st,
                        in.ptr, idx->n, nb, idx->rq_groups, idx->n_tiles, reinterpret_cast<uint4 *>(idx->d_rq_tiles),
                        idx->d_rq_norms);
+    VG_LAUNCH(vg::absmax_kernel, dim3(static_cast<unsigned>(std::min<int64_t>((idx->n + 255) / 256, 1024))), dim3(256), 0, st, idx->d_rq_norms,
+              idx->n, reinterpret_cast<int *>(idx->d_rq_norms + idx->n));
     VG_HIP(hipStreamSynchronize(st));
     return VG_OK;
 }
@@ -583,6 +631,9 @@ VG_API int32_t vg_search_rabitq(vg_index *idx, const float *queries, int64_t nq,
                 VG_TRY(vg::launch_page_patch(nq, k, off, kk, false, one, pid, psc, oid.ptr, osc.ptr, floor_keys, st));
             }
         }
+        // queries whose distances may hold a NaN: the reference's heap, operation by operation (vg_cand_replay.hpp)
+        VG_TRY(vg::launch_cand_replay(vg::RabitqScorer{idx->d_rq_rows, qcodes.ptr, idx->d_rq_norms + idx->n, idx->dim, nb}, q.ptr, idx->dim, idx->n, nq, k,
+                                      false, nullptr, 0, oid.ptr, osc.ptr, st));
     }
     VG_TRY(oid.finish());
     VG_TRY(osc.finish());

@@ -15,6 +15,7 @@
 
 #include "vg_device.hpp"
 #include "vg_internal.hpp"
+#include "vg_cand_replay.hpp"
 
 struct vg_int4 {
     vg_ctx *ctx = nullptr;
@@ -1847,6 +1848,47 @@ int32_t sq8_nominated_pass(vg_index *idx, const float *q, int64_t nq, int k, con
 }
 }  // namespace vg
 
+namespace vg {
+// vg_cand_replay.hpp's scorer for the SQ8 scan: sq.L2Distance / sq.DotProduct of a row's code (flat/segment.go:517-604, :659-667),
+// one lane per row of the re-tiled codes.  A NaN: a non-finite query value, minimum or inverse scale; for dot products a magnitude
+// whose partial sums could overflow (|x^_j| <= 255 |inv_j| + |min_j|).
+template <bool DOT>
+struct Sq8Scorer {
+    const uint4 *tiles;
+    const float *mins, *inv;
+    int groups, dim;
+    __device__ bool risk(int64_t, const float *q, int tid) const
+    {
+        __shared__ int flag;
+        __shared__ float bmax;
+        if (tid == 0) bmax = 0.0f;
+        __syncthreads();
+        bool bad = false;
+        float b = 0.0f;
+        for (int j = tid; j < dim; j += kReplayThreads) {
+            const float mn = mins[j], iv = inv[j];
+            bad = bad || !is_finite_f32(q[j]) || !is_finite_f32(mn) || !is_finite_f32(iv);
+            b = fmaxf(b, 255.0f * fabsf(iv) + fabsf(mn));
+        }
+        if (DOT) {
+            for (int off = 32; off > 0; off >>= 1) b = fmaxf(b, __shfl_xor(b, off));
+            if ((tid & 63) == 0) atomicMax(reinterpret_cast<int *>(&bmax), __float_as_int(b));  // non-negative floats order like their bits
+            __syncthreads();
+            const float bm = bmax;
+            for (int j = tid; j < dim; j += kReplayThreads) bad = bad || !(fabsf(q[j]) * bm * static_cast<float>(dim) < 1e38f);
+        }
+        return block_any(bad, &flag, tid);
+    }
+    __device__ void prepare(int64_t, const float *, int) const {}
+    __device__ void score_chunk(int64_t, const float *q, int64_t row0, int64_t n, int tid, float *out) const
+    {
+        const int64_t row = row0 + tid;  // (row0 is a multiple of 256: whole tiles of 64)
+        if (row >= n) return;
+        out[tid] = sq8_row_score<DOT>(tiles + ((row >> 6) * groups) * 64 + (row & 63), groups, dim >> 4, dim & 15, q, mins, inv);
+    }
+};
+}  // namespace vg
+
 static int32_t sq8_search_impl(vg_index *idx, const float *queries, int64_t nq, int32_t k, uint32_t *ids, float *scores, void *stream,
                                bool allow_nomination);
 
@@ -1969,6 +2011,17 @@ static int32_t sq8_search_impl(vg_index *idx, const float *queries, int64_t nq, 
                 VG_TRY(vg::launch_page_patch(nq, k, off, kk, dot, one, pid, psc, oid.ptr, osc.ptr, floor_keys, st));
             }
         }
+    }
+    // queries whose scores may hold a NaN: the reference's heap, operation by operation (vg_cand_replay.hpp; not for the
+    // queries this function sends to itself after a failed proof: the caller's pass covers them)
+    if (idx->n > 0 && allow_nomination) {
+        const uint4 *tiles = reinterpret_cast<const uint4 *>(idx->d_sq_tiles);
+        if (dot)
+            VG_TRY(vg::launch_cand_replay(vg::Sq8Scorer<true>{tiles, idx->sq->d_mins, idx->sq->d_inv, idx->sq_groups, idx->dim}, q.ptr, idx->dim,
+                                          idx->n, nq, k, true, nullptr, 0, oid.ptr, osc.ptr, st));
+        else
+            VG_TRY(vg::launch_cand_replay(vg::Sq8Scorer<false>{tiles, idx->sq->d_mins, idx->sq->d_inv, idx->sq_groups, idx->dim}, q.ptr, idx->dim,
+                                          idx->n, nq, k, false, nullptr, 0, oid.ptr, osc.ptr, st));
     }
     VG_TRY(oid.finish());
     VG_TRY(osc.finish());

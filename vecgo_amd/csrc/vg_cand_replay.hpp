@@ -100,16 +100,17 @@ constexpr int kReplayThreads = 256;
 constexpr int kReplayChunk = 256;  // rows scored per step
 
 // Scorer (by value; device pointers inside):
-//   bool risk(const float *q, int tid)            block-uniform: may a score of this query be a NaN?  (all threads call it)
-//   void prepare(const float *q, int tid)         once per risky query, before the first chunk (LDS staging, ...)
-//   void score_chunk(const float *q, int64_t row0, int64_t n, int tid, float *out)
+//   (qi: the query's index in the call, q: its vector)
+//   bool risk(int64_t qi, const float *q, int tid)  block-uniform: may a score of this query be a NaN?  (all threads call it)
+//   void prepare(int64_t qi, const float *q, int tid)  once per risky query, before the first chunk (LDS staging, ...)
+//   void score_chunk(int64_t qi, const float *q, int64_t row0, int64_t n, int tid, float *out)
 //                                                 out[i] = score of row row0 + i for i < min(kReplayChunk, n - row0), by all threads
 // mask: a row filter per query (bit i of byte i / 8: the row takes part), or null.
 template <class Scorer>
 __global__ __launch_bounds__(kReplayThreads) void cand_replay_kernel(Scorer sc, const float *__restrict__ queries, int dim, int64_t n, int k,
                                                                      bool desc, const uint8_t *__restrict__ mask, int64_t mask_stride,
                                                                      uint32_t *__restrict__ ids, float *__restrict__ scores,
-                                                                     int *__restrict__ replayed)
+                                                                     int *__restrict__ replayed, int64_t q_first)
 {
     extern __shared__ uint64_t replay_lds[];
     CItem *heap = reinterpret_cast<CItem *>(replay_lds);  // k items
@@ -117,14 +118,15 @@ __global__ __launch_bounds__(kReplayThreads) void cand_replay_kernel(Scorer sc, 
     const int tid = threadIdx.x, lane = tid & 63;
     const int64_t q = blockIdx.x;
     const float *qv = queries + q * dim;
-    if (!sc.risk(qv, tid)) return;
+    const int64_t qi = q_first + q;
+    if (!sc.risk(qi, qv, tid)) return;
     if (replayed && tid == 0) atomicAdd(replayed, 1);
     const uint8_t *mq = mask ? mask + q * mask_stride : nullptr;
-    sc.prepare(qv, tid);
+    sc.prepare(qi, qv, tid);
     int len = 0;  // wave 0's copy is the live one
     for (int64_t row0 = 0; row0 < n; row0 += kReplayChunk) {
         __syncthreads();  // the previous chunk has been replayed
-        sc.score_chunk(qv, row0, n, tid, chunk);
+        sc.score_chunk(qi, qv, row0, n, tid, chunk);
         __syncthreads();
         if (tid >= 64) continue;
         const int cnt = static_cast<int>(n - row0 < kReplayChunk ? n - row0 : kReplayChunk);
@@ -189,7 +191,7 @@ inline int32_t launch_cand_replay(const Scorer &sc, const float *queries, int di
     for (int64_t q0 = 0; q0 < nq; q0 += 1 << 30) {
         const int64_t cnt = std::min<int64_t>(nq - q0, 1 << 30);
         VG_LAUNCH((cand_replay_kernel<Scorer>), dim3(static_cast<unsigned>(cnt)), dim3(kReplayThreads), lds, st, sc, queries + q0 * dim, dim, n, k,
-                  desc, mask ? mask + q0 * mask_stride : nullptr, mask_stride, ids + q0 * k, scores + q0 * k, replayed);
+                  desc, mask ? mask + q0 * mask_stride : nullptr, mask_stride, ids + q0 * k, scores + q0 * k, replayed, q0);
     }
     return VG_OK;
 }
