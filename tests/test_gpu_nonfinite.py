@@ -207,3 +207,44 @@ def test_rabitq_with_non_finite_queries_and_norms(vg, ctx, n, dim, k):
         idx.set_rabitq_codes(c)
         check(idx.search_rabitq(q, k), lambda i: o.flat_search_rabitq(c, dim, q[i], k), nq, k)
         check(idx.search_rabitq(q[:1], k), lambda i: o.flat_search_rabitq(c, dim, q[i], k), 1, k)
+
+
+@pytest.mark.parametrize("metric", [0, 1, 2])
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("where", ["queries", "rows"])
+def test_hnsw_brute_with_nan_distances(vg, ctx, metric, mode, where):
+    """vg_search_hnsw_brute (hnsw.BruteSearch + scanSegment / searchBitmap + extraction): searcher.PriorityQueue with the tests of
+    hnsw.go:2089-2097 (`d < top.Distance`) / queue.go:199-203 (`d >= top.Distance` rejects — a NaN is NOT rejected there: it
+    replaces the root).  With a NaN inside the heap its top can rise, which the batched replay's flagging assumes it never does:
+    queries at risk are decided row by row against the live top.  Masks, per-query masks, k > n, ties."""
+    rng = np.random.default_rng(31 + metric + 7 * mode)
+    n, dim = 5003, 32
+    x = rng.integers(0, 4, (n, dim)).astype(np.float32)          # a grid: ties
+    nq = 14
+    if where == "rows":
+        bad = rng.random(n) < 0.05
+        col = rng.integers(0, dim, n)
+        kind = rng.integers(0, 3, n)
+        for i in np.flatnonzero(bad):
+            x[i, col[i]] = (np.nan, np.inf, -np.inf)[kind[i]]
+        x[2, 0] = np.nan                                          # one among the first k
+        q = rng.integers(0, 4, (nq, dim)).astype(np.float32)
+    else:
+        q = poisoned_queries(rng, x, nq)
+    idx = vg.Index(ctx, n, dim, vg.Metric(metric))
+    idx.set_vectors(x)
+    oidx = o.HnswIndex(x, dim, np.full((n, 2), 0xFFFFFFFF, np.uint32), metric=metric)
+    masks = rng.random((nq, n)) < 0.3
+    for k in (1, 10, 70):
+        for mask, per_query in ((None, False), (rng.random(n) < 0.5, False), (masks, True)):
+            ids, sc = idx.search_hnsw_brute(q, k, mode, mask)
+            for i in range(nq):
+                m = None if mask is None else (mask[i] if per_query else mask)
+                eid, esc = oidx.brute_search(q[i], k, mode, m)
+                r = eid.size
+                assert np.array_equal(ids[i, :r], eid), (k, per_query, i, ids[i, :r][:10], eid[:10])
+                assert same_scores(sc[i, :r], esc), (k, per_query, i)
+                assert np.all(ids[i, r:] == 0xFFFFFFFF)
+    one = idx.search_hnsw_brute(q[3:4], 10, mode, None)           # one query (its own fast path)
+    eid, esc = oidx.brute_search(q[3], 10, mode, None)
+    assert np.array_equal(one[0][0, :eid.size], eid) and same_scores(one[1][0, :eid.size], esc)

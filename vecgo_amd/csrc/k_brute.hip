@@ -22,6 +22,7 @@
 #include "vg_exact.hpp"
 #include "vg_heap.hpp"
 #include "vg_internal.hpp"
+#include "vg_cand_replay.hpp"
 
 #include <algorithm>
 
@@ -494,6 +495,40 @@ __global__ void brute_from_flat_kernel(const uint32_t *__restrict__ fid, const f
 
 }  // namespace vg
 
+namespace vg {
+// vg_cand_replay.hpp's heap for the two exhaustive paths of the HNSW index: searcher.PriorityQueue(max) driven as scanSegment
+// (hnsw.go:2089-2097) / TryPushBounded (queue.go:192-213) drive it — brute_offer above, whose comparisons are the reference's
+// floats.  brute_replay_kernel flags rows against the top as it stood at the start of a step, which is sound while the top
+// only falls; with a NaN inside the heap its order is broken and a later top can be LARGER than an earlier one, so queries
+// whose distances may hold a NaN are decided row by row against the live top here.
+template <int MODE>
+struct BruteHeapPolicy {
+    __device__ static bool accepts(const CItem x, int len, int k, const CItem root, bool)
+    {
+        return len < k || (MODE == VG_BRUTE_SCAN ? x.score < root.score : !(x.score >= root.score));
+    }
+    __device__ static void offer(CItem *h, int &len, int k, const CItem x, bool)
+    {
+        brute_offer<MODE>(reinterpret_cast<HItem *>(h), len, k, HItem{x.row, x.score});  // (both are {row, score bits} in 8 bytes)
+    }
+    __device__ static CItem pop(CItem *h, int &len, bool)
+    {
+        const HItem it = heap_pop<true>(reinterpret_cast<HItem *>(h), len);
+        return CItem{it.dist, it.node};
+    }
+};
+static int32_t brute_nan_replay(vg_index *idx, const float *d_queries, int64_t nq, int k, int mode, const uint8_t *d_mask, int64_t mask_stride,
+                                uint32_t *d_ids, float *d_scores, hipStream_t st)
+{
+    if (idx->n == 0) return VG_OK;
+    const bool dot = idx->metric == VG_METRIC_DOT;
+    const FlatF32Scorer sc{idx->d_vectors, idx->d_norm_max + 1, idx->dim, dot, dot ? 1 : idx->metric == VG_METRIC_COSINE ? 2 : 0};
+    if (mode == VG_BRUTE_SCAN)
+        return launch_cand_replay<BruteHeapPolicy<VG_BRUTE_SCAN>>(sc, d_queries, idx->dim, idx->n, nq, k, false, d_mask, mask_stride, d_ids, d_scores, st);
+    return launch_cand_replay<BruteHeapPolicy<VG_BRUTE_BITMAP>>(sc, d_queries, idx->dim, idx->n, nq, k, false, d_mask, mask_stride, d_ids, d_scores, st);
+}
+}  // namespace vg
+
 static int32_t brute_impl(vg_index *idx, const float *queries, int64_t nq, int32_t k, int32_t mode, const uint8_t *mask,
                           int64_t mask_stride, uint32_t *ids, float *scores, void *stream);
 namespace vg {
@@ -570,6 +605,7 @@ VG_API int32_t vg_search_hnsw_brute(vg_index *idx, const float *queries, int64_t
         if (h[static_cast<size_t>(i)])
             VG_TRY(brute_impl(idx, q.ptr + i * idx->dim, 1, k, mode, mk.ptr ? mk.ptr + i * mask_stride : nullptr, 0, oid.ptr + i * k,
                               osc.ptr + i * k, st));
+    VG_TRY(vg::brute_nan_replay(idx, q.ptr, nq, k, mode, mk.ptr, mask_stride, oid.ptr, osc.ptr, st));  // queries whose distances may hold a NaN
     VG_TRY(oid.finish());
     VG_TRY(osc.finish());
     return VG_OK;
@@ -672,6 +708,7 @@ static int32_t brute_impl(vg_index *idx, const float *queries, int64_t nq, int32
         VG_LAUNCH(replay, dim3(static_cast<unsigned>(cnt)), dim3(vg::kBruteThreads), lds, st, dist, n, m0, mask_stride, k,
                   oid.ptr + q0 * k, osc.ptr + q0 * k);
     }
+    VG_TRY(vg::brute_nan_replay(idx, q.ptr, nq, k, mode, mk.ptr, mask_stride, oid.ptr, osc.ptr, st));  // queries whose distances may hold a NaN
     VG_TRY(oid.finish());
     VG_TRY(osc.finish());
     return VG_OK;

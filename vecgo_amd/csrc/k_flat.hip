@@ -629,41 +629,6 @@ int32_t flat_search_masked(vg_index *idx, const float *queries, int64_t nq, int3
                            uint32_t *ids, float *scores, void *stream, bool l2_scores = false, bool cand_replay = true);
 }
 
-namespace vg {
-// vg_cand_replay.hpp's scorer for the fp32 rows: distance.SquaredL2 / distance.Dot of flat/segment.go:691-701 (squaredL2Avx512 /
-// dotProductAvx512 order, 16 lanes per pair: 16 rows per step of the workgroup)
-struct FlatF32Scorer {
-    const float *base;
-    const float *maxabs;  // [1]: max |x| over the rows, +Inf when one of them is not finite (vg_index_set_vectors)
-    int dim;
-    bool dot;
-    __device__ bool risk(int64_t, const float *q, int tid) const
-    {
-        __shared__ int flag;
-        const float ma = maxabs[0];
-        bool bad = !is_finite_f32(ma);
-        for (int j = tid; j < dim; j += kReplayThreads) {
-            const float v = q[j];
-            // a dot product of finite values is a NaN only through +Inf and -Inf partial sums: none can arise below dim * max|q| * max|x|
-            bad = bad || !is_finite_f32(v) || (dot && !(fabsf(v) * ma * static_cast<float>(dim) < 1e38f));
-        }
-        return block_any(bad, &flag, tid);
-    }
-    __device__ void prepare(int64_t, const float *, int) const {}
-    __device__ void score_chunk(int64_t, const float *q, int64_t row0, int64_t n, int tid, float *out) const
-    {
-        const Sub16 sub = Sub16::make(tid);
-        for (int r = tid >> 4; r < kReplayChunk; r += kReplayThreads / 16) {
-            const int64_t row = row0 + r;
-            if (row >= n) break;  // (a whole 16-lane group)
-            const float *x = base + row * dim;
-            const float v = dot ? exact_pair16<true, kPair>(x, q, dim, sub) : exact_pair16<false, kPair>(x, q, dim, sub);
-            if ((tid & 15) == 0) out[r] = v;
-        }
-    }
-};
-}  // namespace vg
-
 VG_API int32_t vg_search_flat(vg_index *idx, const float *queries, int64_t nq, int32_t k, uint32_t *ids,
                               float *scores, void *stream)
 {
@@ -943,7 +908,7 @@ int32_t vg::flat_search_masked(vg_index *idx, const float *queries, int64_t nq, 
     // queries whose scores may hold a NaN (a non-finite query value / row, an overflowing dot product): the reference's heap,
     // operation by operation (vg_cand_replay.hpp); every other query returns from this launch at once
     if (n > 0 && cand_replay)
-        VG_TRY(vg::launch_cand_replay(vg::FlatF32Scorer{idx->d_vectors, idx->d_norm_max + 1, dim, dot}, q.ptr, dim, n, nq, k, dot, mask, mask_stride,
+        VG_TRY(vg::launch_cand_replay(vg::FlatF32Scorer{idx->d_vectors, idx->d_norm_max + 1, dim, dot, 0}, q.ptr, dim, n, nq, k, dot, mask, mask_stride,
                                       oid.ptr, osc.ptr, st));
     VG_TRY(oid.finish());
     VG_TRY(osc.finish());

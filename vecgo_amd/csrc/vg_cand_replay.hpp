@@ -22,6 +22,7 @@
 #include <cstdint>
 
 #include "vg_device.hpp"
+#include "vg_exact.hpp"
 #include "vg_internal.hpp"
 
 namespace vg {
@@ -96,6 +97,22 @@ __device__ __forceinline__ CItem cand_pop(CItem *h, int &len, const bool desc)
     return root;
 }
 
+// the heap a search is written with: CandidateHeap here; searcher.PriorityQueue for hnsw.BruteSearch / searchBitmap (k_brute.hip)
+struct CandHeapPolicy {
+    // the reference's test in front of the heap operation, against the heap as it stands (flat/segment.go:714-721)
+    __device__ static bool accepts(const CItem x, int len, int k, const CItem root, bool desc) { return len < k || cand_better(x, root, desc); }
+    __device__ static void offer(CItem *h, int &len, int k, const CItem x, bool desc)
+    {
+        if (len < k) {  // h.Push(cand)
+            cand_up(h, len, x, desc);
+            len++;
+        } else {  // h.ReplaceTop(cand)
+            cand_down(h, 0, len, x, desc);
+        }
+    }
+    __device__ static CItem pop(CItem *h, int &len, bool desc) { return cand_pop(h, len, desc); }
+};
+
 constexpr int kReplayThreads = 256;
 constexpr int kReplayChunk = 256;  // rows scored per step
 
@@ -106,7 +123,7 @@ constexpr int kReplayChunk = 256;  // rows scored per step
 //   void score_chunk(int64_t qi, const float *q, int64_t row0, int64_t n, int tid, float *out)
 //                                                 out[i] = score of row row0 + i for i < min(kReplayChunk, n - row0), by all threads
 // mask: a row filter per query (bit i of byte i / 8: the row takes part), or null.
-template <class Scorer>
+template <class Scorer, class Heap>
 __global__ __launch_bounds__(kReplayThreads) void cand_replay_kernel(Scorer sc, const float *__restrict__ queries, int dim, int64_t n, int k,
                                                                      bool desc, const uint8_t *__restrict__ mask, int64_t mask_stride,
                                                                      uint32_t *__restrict__ ids, float *__restrict__ scores,
@@ -114,7 +131,7 @@ __global__ __launch_bounds__(kReplayThreads) void cand_replay_kernel(Scorer sc, 
 {
     extern __shared__ uint64_t replay_lds[];
     CItem *heap = reinterpret_cast<CItem *>(replay_lds);  // k items
-    float *chunk = reinterpret_cast<float *>(replay_lds + k);
+    float *chunk = reinterpret_cast<float *>(replay_lds + k + 4);
     const int tid = threadIdx.x, lane = tid & 63;
     const int64_t q = blockIdx.x;
     const float *qv = queries + q * dim;
@@ -139,17 +156,12 @@ __global__ __launch_bounds__(kReplayThreads) void cand_replay_kernel(Scorer sc, 
                 // the reference's test against the heap AS IT STANDS (flat/segment.go:714-721): a lane that fails it now is
                 // retested after every accepted row before it, so nothing is assumed about how the root moves
                 const CItem root = len > 0 ? cand_load(heap, 0) : CItem{0.0f, 0u};
-                const uint64_t m = __ballot(live && lane >= from && (len < k || cand_better(mine, root, desc)));
+                const uint64_t m = __ballot(live && lane >= from && Heap::accepts(mine, len, k, root, desc));
                 if (m == 0) break;
                 const int b = __builtin_ctzll(m);
                 const CItem x{__uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(mine.score), b)),
                               static_cast<uint32_t>(__builtin_amdgcn_readlane(mine.row, b))};
-                if (len < k) {  // h.Push(cand)
-                    cand_up(heap, len, x, desc);
-                    len++;
-                } else {  // h.ReplaceTop(cand)
-                    cand_down(heap, 0, len, x, desc);
-                }
+                Heap::offer(heap, len, k, x, desc);
                 from = b + 1;
             }
         }
@@ -157,7 +169,7 @@ __global__ __launch_bounds__(kReplayThreads) void cand_replay_kernel(Scorer sc, 
     if (tid >= 64) return;
     const int nres = len;
     for (int i = nres - 1; i >= 0; i--) {
-        const CItem it = cand_pop(heap, len, desc);
+        const CItem it = Heap::pop(heap, len, desc);
         if (lane == 0) {
             ids[q * k + i] = it.row;
             scores[q * k + i] = it.score;
@@ -182,18 +194,54 @@ __device__ __forceinline__ bool block_any(bool mine, int *flag, int tid)
 }
 __device__ __forceinline__ bool is_finite_f32(float x) { return (__float_as_uint(x) & 0x7F800000u) != 0x7F800000u; }
 
-template <class Scorer>
+template <class Heap = CandHeapPolicy, class Scorer>
 inline int32_t launch_cand_replay(const Scorer &sc, const float *queries, int dim, int64_t n, int64_t nq, int k, bool desc, const uint8_t *mask,
                                   int64_t mask_stride, uint32_t *ids, float *scores, hipStream_t st, int *replayed = nullptr)
 {
     if (nq == 0 || k == 0 || hook(kHookNoCandReplay)) return VG_OK;
-    const size_t lds = sizeof(uint64_t) * static_cast<size_t>(k) + sizeof(float) * kReplayChunk;
+    const size_t lds = sizeof(uint64_t) * (static_cast<size_t>(k) + 4) + sizeof(float) * kReplayChunk;  // (+ 4: vg_heap.hpp reads a node's four children together)
     for (int64_t q0 = 0; q0 < nq; q0 += 1 << 30) {
         const int64_t cnt = std::min<int64_t>(nq - q0, 1 << 30);
-        VG_LAUNCH((cand_replay_kernel<Scorer>), dim3(static_cast<unsigned>(cnt)), dim3(kReplayThreads), lds, st, sc, queries + q0 * dim, dim, n, k,
+        VG_LAUNCH((cand_replay_kernel<Scorer, Heap>), dim3(static_cast<unsigned>(cnt)), dim3(kReplayThreads), lds, st, sc, queries + q0 * dim, dim, n, k,
                   desc, mask ? mask + q0 * mask_stride : nullptr, mask_stride, ids + q0 * k, scores + q0 * k, replayed, q0);
     }
     return VG_OK;
 }
+
+// The scorer for fp32 rows: distance.SquaredL2 / distance.Dot of flat/segment.go:691-701 (squaredL2Avx512 / dotProductAvx512
+// order, 16 lanes per pair: 16 rows per step of the workgroup); conv: 0 the value, 1 its negative, 2 half of it — the HNSW index's
+// distances (-dot for Dot, 0.5 * squared L2 for Cosine: hnsw.go:2218-2238)
+struct FlatF32Scorer {
+    const float *base;
+    const float *maxabs;  // [1]: max |x| over the rows, +Inf when one of them is not finite (vg_index_set_vectors)
+    int dim;
+    bool dot;
+    int conv;
+    __device__ bool risk(int64_t, const float *q, int tid) const
+    {
+        __shared__ int flag;
+        const float ma = maxabs[0];
+        bool bad = !is_finite_f32(ma);
+        for (int j = tid; j < dim; j += kReplayThreads) {
+            const float v = q[j];
+            // a dot product of finite values is a NaN only through +Inf and -Inf partial sums: none can arise below dim * max|q| * max|x|
+            bad = bad || !is_finite_f32(v) || (dot && !(fabsf(v) * ma * static_cast<float>(dim) < 1e38f));
+        }
+        return block_any(bad, &flag, tid);
+    }
+    __device__ void prepare(int64_t, const float *, int) const {}
+    __device__ void score_chunk(int64_t, const float *q, int64_t row0, int64_t n, int tid, float *out) const
+    {
+        const Sub16 sub = Sub16::make(tid);
+        for (int r = tid >> 4; r < kReplayChunk; r += kReplayThreads / 16) {
+            const int64_t row = row0 + r;
+            if (row >= n) break;  // (a whole 16-lane group)
+            const float *x = base + row * dim;
+            float v = dot ? exact_pair16<true, kPair>(x, q, dim, sub) : exact_pair16<false, kPair>(x, q, dim, sub);
+            v = conv == 1 ? -v : conv == 2 ? 0.5f * v : v;
+            if ((tid & 15) == 0) out[r] = v;
+        }
+    }
+};
 
 }  // namespace vg
