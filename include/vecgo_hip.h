@@ -55,7 +55,7 @@ extern "C" {
  *   7: (r05) vg_index_set_hnsw_tombstones
  *   8: (r05) vg_segment_search_filtered
  *   9: (r05) vg_index_enable_sq8_nomination
- *  10: (r06) vg_index_enable_pq_nomination */
+ *  10: (r06) vg_index_enable_pq_nomination; NaN scores answered as the reference's heaps answer them (see "NaN scores") */
 #define VG_ABI_MINOR 10
 #define VG_INVALID_ID 0xFFFFFFFFu
 #define VG_STREAM_LEGACY ((void *)1) /* == hipStreamLegacy */
@@ -659,8 +659,10 @@ int32_t vg_search_vamana_filtered(vg_index *idx, const float *queries, int64_t n
  * bitmap minus the tombstones; NULL = every row.  Query q reads mask + q*mask_stride (mask_stride 0 = one mask for
  * the batch, else >= ceil(n/8)).  Distances as the index wraps them (hnsw.go:2218-2238, columnar.go:37-44): L2 ->
  * squared L2, Dot -> -dot, Cosine -> 0.5 * squared L2 (rows and queries normalised by the caller, as for
- * vg_search_hnsw).  ids/scores[nq*k] best first; unused slots VG_INVALID_ID / +Inf.  k <= 1024.  A NaN distance
- * (NaN or Inf in a row or query) makes the result unspecified: the replay relies on the heap's top never rising. */
+ * vg_search_hnsw).  ids/scores[nq*k] best first; unused slots VG_INVALID_ID / +Inf.  k <= 1024.  NaN distances (a NaN
+ * or Inf in a row or query; dot products overflowing both ways) are answered as the reference's loops answer them — `d <
+ * top.Distance` never admits a NaN once the heap is full, `d >= top.Distance` never rejects one — by a pass that decides every
+ * row against the live top (r05 and before: unspecified; see "NaN scores" below). */
 enum { VG_BRUTE_SCAN = 0, VG_BRUTE_BITMAP = 1 };
 int32_t vg_search_hnsw_brute(vg_index *idx, const float *queries, int64_t nq, int32_t k, int32_t mode,
                              const uint8_t *mask, int64_t mask_stride, uint32_t *ids, float *scores, void *stream);
@@ -713,6 +715,22 @@ int32_t vg_comm_all_gather(vg_comm *comm, const void *send, void *recv, int64_t 
 int32_t vg_comm_all_gather_topk(vg_comm *comm, const uint32_t *local_ids, const float *local_scores,
                                 int64_t nq, int32_t k, int32_t metric, const uint32_t *id_offsets,
                                 uint32_t *ids, float *scores, void *stream);
+
+/* NaN scores in the exhaustive searches and the beam search (vg_search_flat, vg_search_pq_adc, vg_search_sq8, vg_search_rabitq,
+ * vg_search_hnsw_brute, vg_search_vamana / _filtered; VG_ABI_MINOR 10).  The scans keep their best k by a 64-bit key (score
+ * bits, row id) — a total order, which is what the reference's heaps implement while no score is a NaN.  For a NaN every
+ * comparison of candidate_queue.go:12-38 / queue.go:75-82,199-203 is false: a NaN that enters while the heap fills stays, at
+ * the root it is never replaced (rows better than everything kept are turned away), as a first child it stops a sift.  That
+ * outcome is DEFINED — the loops are sequential — and these entry points return it: a query whose INPUTS could produce a NaN
+ * score (a non-finite query value; non-finite rows, quantizer parameters or stored norms; a dot product whose partial sums can
+ * reach +Inf and -Inf: dim * max|q| * max|x| >= 1e38; RaBitQ: 4 |q| |y| >= 1e38) is answered a second time by the reference's
+ * heap replayed operation by operation with float comparisons, rows in the reference's order, and overwrites the first answer.
+ * ids / scores then hold what the engine takes out of the heap — Pop() until empty (engine/search.go:859-862) — best first; a
+ * NaN score's sign and payload are the instruction set's, not the algorithm's.  Rare by construction (such inputs are garbage)
+ * and slow by design: one workgroup walks all rows per query (~n * dim / 100 GB/s); an index holding a non-finite row sends
+ * EVERY query there.  Every other query pays one extra kernel launch per call that returns at once.  Not covered: the
+ * partition-probed and the filtered SQ8 / PQ scans of vg_search_flat_probed / _filtered (the filtered fp32 and PQ scans over the
+ * whole segment are), vg_rerank, vg_merge_topk: NaN scores there order as the largest keys. */
 
 /* flat.Segment.Search, PQ branch (flat/segment.go:476-483 LUT, :678-689 ADC
  * = simd.PqAdcLookup in pqAdcLookupAvx512 order, :714-721 top-k with the

@@ -248,3 +248,67 @@ def test_hnsw_brute_with_nan_distances(vg, ctx, metric, mode, where):
     one = idx.search_hnsw_brute(q[3:4], 10, mode, None)           # one query (its own fast path)
     eid, esc = oidx.brute_search(q[3], 10, mode, None)
     assert np.array_equal(one[0][0, :eid.size], eid) and same_scores(one[1][0, :eid.size], esc)
+
+
+@pytest.mark.parametrize("kind", [0, 1, 2])
+@pytest.mark.parametrize("metric", [0, 2])
+@pytest.mark.parametrize("where", ["queries", "data"])
+def test_vamana_beam_with_nan_distances(vg, ctx, kind, metric, where):
+    """diskann.Segment.Search (segment.go:503-706): the traversal queue is a PriorityQueue (float comparisons in the kernel too), the
+    results a CandidateHeap whose root the stop test reads (`c.dist > heap[0].score`).  With NaN distances the heap's layout decides
+    its contents, its root — and so where the walk stops: ids, scores AND the walk's counters equal the oracle's.  fp32 / PQ / RaBitQ
+    node scorers, L2 and Dot, with and without a filter, k below and above 64."""
+    from tests import graphs
+    if metric == 2 and kind != 0:
+        pytest.skip("the code scorers have one distance")
+    rng = np.random.default_rng(77 + kind + metric)
+    n, dim, r = 1500, 32, 16
+    base = rng.standard_normal((n, dim)).astype(np.float32)
+    g, entry = graphs.build_vamana(base, r=r, seed=5)
+    nq = 14
+    q = poisoned_queries(rng, base, nq) if where == "queries" else rng.standard_normal((nq, dim)).astype(np.float32)
+    idx = vg.Index(ctx, n, dim, vg.Metric(metric))
+    idx.set_vamana_graph(g, entry)
+    if kind == 0:
+        rows = base.copy()
+        if where == "data":
+            hubs = np.bincount(g[g != 0xFFFFFFFF].astype(np.int64), minlength=n).argsort()[-4:]
+            rows[hubs[0], 3] = np.nan; rows[hubs[1], 0] = np.inf; rows[hubs[2], 5] = -np.inf
+            rows[entry, 1] = np.nan
+        ov = o.VamanaIndex(g, entry, dim, o.VAMANA_F32, metric=metric, base=rows)
+        idx.set_vectors(rows)
+    elif kind == 1:
+        m = dim // 8
+        opq = o.ProductQuantizer(dim, m, 256)
+        sc = (rng.random(m) * 0.02 + 0.005).astype(np.float32)
+        if where == "data":
+            sc[1] = np.nan
+        opq.set_codebooks(rng.integers(-128, 128, m * 256 * 8).astype(np.int8), sc, ((rng.random(m) * 2 - 1) * 0.1).astype(np.float32))
+        codes = rng.integers(0, 256, (n, m)).astype(np.uint8)
+        ov = o.VamanaIndex(g, entry, dim, o.VAMANA_PQ, pq=opq, codes=codes)
+        pq = vg.ProductQuantizer(ctx, dim, m, 256)
+        pq.set_codebooks(opq.codebooks, opq.scales, opq.offsets)
+        idx.set_pq_codes(pq, codes)
+    else:
+        codes = o.rabitq_encode_batch(base, dim)
+        if where == "data":
+            cb = codes.shape[1]
+            hubs = np.bincount(g[g != 0xFFFFFFFF].astype(np.int64), minlength=n).argsort()[-3:]
+            codes[hubs[0], cb - 4:] = np.frombuffer(np.float32(np.nan).tobytes(), np.uint8)
+            codes[hubs[1], cb - 4:] = np.frombuffer(np.float32(np.inf).tobytes(), np.uint8)
+        ov = o.VamanaIndex(g, entry, dim, o.VAMANA_RABITQ, codes=codes)
+        idx.set_rabitq_codes(codes)
+    masks = rng.random((nq, n)) < 0.4
+    for k in (1, 10, 100):
+        for mask in (None, masks):
+            if mask is None:
+                ids, sc, st = idx.search_vamana(q, k, kind=kind, stats=True)
+            else:
+                ids, sc, st = idx.search_vamana_filtered(q, k, mask, kind=kind, stats=True)
+            for i in range(nq):
+                eid, esc, est = ov.search(q[i], k, mask=None if mask is None else mask[i])
+                r_ = eid.size
+                assert np.array_equal(ids[i, :r_], eid), (k, mask is not None, i, ids[i, :r_][:10], eid[:10])
+                assert same_scores(sc[i, :r_], esc), (k, i)
+                assert np.all(ids[i, r_:] == 0xFFFFFFFF)
+                assert (int(st[i][0]), int(st[i][1]), int(st[i][3])) == (est.nodes_visited, est.distance_computations, est.pops), (k, i)

@@ -17,6 +17,7 @@
 #include "vg_heap.hpp"
 #include "vg_hnsw_layer.hpp"
 #include "vg_internal.hpp"
+#include "vg_cand_replay.hpp"
 
 namespace vg {
 
@@ -317,7 +318,13 @@ __device__ __forceinline__ uint64_t *vamana_result_list()
 #endif
 // MASKED: vg_search_vamana_filtered (pushToHeap's filter, segment.go:616-627) — a template flag: the unfiltered instances keep
 // their register budgets (a runtime mask cost 13 registers: the PQ-direct scorer spilled, the others lost a wave per SIMD)
-template <int kind, bool big, bool MASKED = false>
+// STRICT (with big and MASKED): the second pass over the queries whose distances may hold a NaN (a non-finite query value or index
+// datum; dot products that can overflow both ways; RaBitQ: 4 |q| |y| overflowing next to a Hamming distance of 0).  The result
+// set above is kept by 64-bit keys — a total order — while for the reference's CandidateHeap a NaN is neither better nor worse than
+// anything (candidate_queue.go:12-38): which rows it holds, the root the pruning test reads and the order they leave in are then
+// decided by the heap's layout.  This pass runs the reference's TryPushBounded / Pop on an LDS array with float comparisons
+// (vg_cand_replay.hpp), neighbour by neighbour in list order; a query without risk returns at once.
+template <int kind, bool big, bool MASKED = false, bool STRICT = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(kind == kVamanaPQDirect ? VG_VAMANA_PQ_WAVES : 1, kind == kVamanaF32 ? VG_VAMANA_F32_MAX_WAVES : 8))) void vamana_search_kernel(
     int metric, int64_t n, int dim, const uint32_t *__restrict__ graph, int r, uint32_t entry,
     const float *__restrict__ base, const uint8_t *__restrict__ pq_rows, int pq_m,
@@ -327,10 +334,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(kind == kVam
     const float *__restrict__ int4_table, const float *__restrict__ int4_min, const float *__restrict__ int4_diff,
     const float *__restrict__ queries, int k, HItem *__restrict__ cand_ws, int64_t cand_cap, uint32_t *__restrict__ visited_ws,
     int64_t vis_words, uint32_t *__restrict__ ids, float *__restrict__ scores,
-    vg_search_stats *__restrict__ stats, const uint8_t *__restrict__ mask, int64_t mask_stride)
+    vg_search_stats *__restrict__ stats, const uint8_t *__restrict__ mask, int64_t mask_stride,
+    const float *__restrict__ risk_absmax /* STRICT: max |x| of the rows (fp32) / max |norm| (RaBitQ), +Inf when one is not finite */)
 {
     __shared__ float nb_d[64];
-    __shared__ uint64_t res[kVamanaMaxK];  // the result set when k > 64
+    __shared__ uint64_t res[kVamanaMaxK];  // the result set when k > 64 (STRICT: the CandidateHeap's array)
     // the exploration heap is unbounded in the reference (up to cand_cap items of HBM scratch here); its first
     // kVamanaLdsCand items — the levels every pop and push touches; a k = 10 search scores ~1000 nodes and its
     // heap peaks a little above that — live in LDS: a
@@ -358,6 +366,28 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(kind == kVam
         // the query's sign words in LDS (rq_nb bytes of the dynamic allocation; qcodes rows are 4-byte aligned)
         for (int i = lane; i < (rq_nb >> 2); i += 64)
             reinterpret_cast<uint32_t *>(vamana_qprep)[i] = reinterpret_cast<const uint32_t *>(qc)[i];
+        __syncthreads();
+    }
+    if constexpr (STRICT) {
+        bool bad = false;
+        for (int j = lane; j < dim; j += 64) bad = bad || !is_finite_f32(qv[j]);
+        if (kind == kVamanaF32) {
+            const float ma = risk_absmax[0];
+            bad = bad || !is_finite_f32(ma);
+            if (desc)
+                for (int j = lane; j < dim; j += 64) bad = bad || !(fabsf(qv[j]) * ma * static_cast<float>(dim) < 1e38f);
+        } else if (kind == kVamanaRaBitQ) {
+            const float ma = risk_absmax[0];
+            bad = bad || !is_finite_f32(qn) || !is_finite_f32(ma) || !(4.0f * fabsf(qn) * ma < 1e38f);
+        } else if (kind == kVamanaPQ || kind == kVamanaPQDirect) {
+            for (int j = lane; j < pq_m; j += 64) bad = bad || !is_finite_f32(pq_scales[j]) || !is_finite_f32(pq_offsets[j]);
+        } else if (int4_min && int4_diff) {
+            for (int j = lane; j < dim; j += 64) bad = bad || !is_finite_f32(int4_min[j]) || !is_finite_f32(int4_diff[j]);
+        } else {
+            for (int j = lane; j < dim * 16; j += 64) bad = bad || !is_finite_f32(int4_table[j]);
+        }
+        if (!__any(bad)) return;
+        for (int64_t w = lane; w < vis_words; w += 64) vis[w] = 0u;  // the first pass's marks
         __syncthreads();
     }
     int64_t st_visited = 0, st_dc = 0, st_pops = 0, st_dropped = 0;
@@ -472,6 +502,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(kind == kVam
     };
     int heap_count = 0;  // min(k, candidates offered): sc.Heap.Len()
     int cand_len = 0;
+    CItem *rheap = reinterpret_cast<CItem *>(res);  // STRICT: sc.Heap itself
+    auto strict_offer = [&](uint32_t id, float d) {   // TryPushBounded(k), candidate_queue.go:120-132 (uniform over the wave)
+        const CItem x{d, id};
+        if (heap_count < k) {
+            cand_up(rheap, heap_count, x, desc);
+            heap_count++;
+        } else if (cand_better(x, cand_load(rheap, 0), desc)) {
+            cand_down(rheap, 0, heap_count, x, desc);
+        }
+    };
+    (void)strict_offer;
 
     // start node (segment.go:603-636)
     if (lane == 0) atomicOr(&vis[entry >> 5], 1u << (entry & 31));
@@ -481,17 +522,21 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(kind == kVam
     heap_push<false>(cand, cand_len, HItem{entry, sd});
     // pushToHeap (segment.go:616-627): a row whose filter.Matches is false goes to the traversal queue only — sc.Heap, and with it
     // the pruning test below, holds matching rows
-    const uint8_t *mq = MASKED ? mask + blockIdx.x * mask_stride : nullptr;
+    const uint8_t *mq = MASKED && mask ? mask + blockIdx.x * mask_stride : nullptr;
     const bool entry_ok = !MASKED || mask_bit(mq, entry);
-    offer(lane == 0 && entry_ok ? make_key(sd, entry, desc) : kKeyMax);
-    heap_count = entry_ok && 1 < k ? 1 : (entry_ok ? k : 0);
+    if constexpr (STRICT) {
+        if (entry_ok) strict_offer(entry, sd);
+    } else {
+        offer(lane == 0 && entry_ok ? make_key(sd, entry, desc) : kKeyMax);
+        heap_count = entry_ok && 1 < k ? 1 : (entry_ok ? k : 0);
+    }
     __syncthreads();
 
     while (cand_len > 0) {
         const HItem c = heap_pop<false>(cand, cand_len);
         st_pops++;
         if (heap_count >= k) {
-            const float worst = key_score(big ? res_tau : tk.tau, desc);
+            const float worst = STRICT ? cand_load(rheap, 0).score : key_score(big ? res_tau : tk.tau, desc);
             if (c.dist > worst) break;
         }
         const uint32_t id_lane = lane < r ? graph[static_cast<int64_t>(c.node) * r + lane] : VG_INVALID_ID;
@@ -507,6 +552,22 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(kind == kVam
         st_dc += nnew;
         score_mask(newmask, id_lane);
         const float myd = nb_d[lane];
+        if constexpr (STRICT) {  // neighbour by neighbour: PushItem, then pushToHeap (segment.go:690-700)
+            uint64_t todo = newmask;
+            while (todo) {
+                const int j = __builtin_ctzll(todo);
+                todo &= todo - 1;
+                const uint32_t id = static_cast<uint32_t>(__builtin_amdgcn_readlane(id_lane, j));
+                const float d = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(myd), j));
+                if (cand_len < cand_cap)
+                    heap_push<false>(cand, cand_len, HItem{id, d});
+                else
+                    st_dropped++;
+                if (mask_bit(mq, id)) strict_offer(id, d);
+            }
+            __syncthreads();
+            continue;
+        }
         // exploration heap: PushItem in the node's neighbour order (segment.go:695)
         if (cand_len + nnew <= cand_cap) {
             heap_push_run_min(cand, cand_len, newmask, id_lane, myd);  // the run of pushes, parents tracked in registers
@@ -530,7 +591,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(kind == kVam
         heap_count = heap_count + npass < k ? heap_count + npass : k;
         __syncthreads();
     }
-    if (big) {
+    if constexpr (STRICT) {  // the engine empties the heap with Pop() (engine/search.go:859-862): reported best first
+        const int nres = heap_count;
+        for (int i = nres - 1; i >= 0; i--) {
+            const CItem it = cand_pop(rheap, heap_count, desc);
+            if (lane == 0) {
+                ids[q * k + i] = it.row;
+                scores[q * k + i] = it.score;
+            }
+        }
+        for (int i = nres + lane; i < k; i += 64) {
+            ids[q * k + i] = VG_INVALID_ID;
+            scores[q * k + i] = desc ? -INFINITY : INFINITY;
+        }
+    } else if (big) {
         for (int i = lane; i < k; i += 64) {
             const uint64_t e = i < res_n ? res[i] : kKeyMax;
             ids[q * k + i] = e == kKeyMax ? VG_INVALID_ID : key_row(e);
@@ -926,7 +1000,8 @@ static int32_t vamana_impl(vg_index *idx, const float *queries, int64_t nq, int3
                       idx->pq ? idx->pq->d_offsets : nullptr,
                       idx->d_rq_rows, kind == 2 ? qcodes.ptr + q0 * (rq_nb + 4) : nullptr, rq_nb,
                       idx->d_int4_rows, idx->int4_table, idx->int4_min, idx->int4_diff, q.ptr + q0 * idx->dim, k, cand.ptr, cand_cap, vis.ptr, vis_words, oid.ptr + q0 * k,
-                      osc.ptr + q0 * k, ost.ptr ? ost.ptr + q0 : nullptr, mk.ptr ? mk.ptr + q0 * mask_stride : nullptr, mask_stride);
+                      osc.ptr + q0 * k, ost.ptr ? ost.ptr + q0 : nullptr, mk.ptr ? mk.ptr + q0 * mask_stride : nullptr, mask_stride,
+                      kind == 0 ? idx->d_norm_max + 1 : kind == 2 ? idx->d_rq_norms + idx->n : nullptr);
             return VG_OK;
         };
         const bool big = k > 64;
@@ -950,6 +1025,18 @@ static int32_t vamana_impl(vg_index *idx, const float *queries, int64_t nq, int3
         }
 #undef VG_VAMANA_CASE
         VG_TRY(rc);
+        // the queries whose distances may hold a NaN, again with the reference's CandidateHeap (every other query returns at once)
+        if (!vg::hook(vg::kHookNoCandReplay)) {
+            switch (inst) {
+            case 0: rc = launch(vg::vamana_search_kernel<0, true, true, true>); break;
+            case 1: rc = launch(vg::vamana_search_kernel<1, true, true, true>); break;
+            case 4: rc = launch(vg::vamana_search_kernel<4, true, true, true>); break;
+            case 5: rc = launch(vg::vamana_search_kernel<5, true, true, true>); break;
+            case 2: rc = launch(vg::vamana_search_kernel<2, true, true, true>); break;
+            default: rc = launch(vg::vamana_search_kernel<3, true, true, true>); break;
+            }
+            VG_TRY(rc);
+        }
     }
     VG_TRY(oid.finish());
     VG_TRY(osc.finish());
