@@ -1330,8 +1330,8 @@ VG_API int32_t vg_search_pq_adc(vg_index *idx, const float *queries, int64_t nq,
 namespace vg {
 // vg_cand_replay.hpp's scorer for the PQ table scan: pq.AdcDistance of a row's code (flat/segment.go:678-689) — the table's entries
 // (BuildDistanceTable, pq.go:468-491: five separately rounded operations per dimension) computed where they are used, summed in
-// pqAdcLookupAvx512 order; one lane per row of the row-major codes.  A NaN: a non-finite query value, scale or offset (the
-// entries are sums of squares: finite inputs give a finite value or +Inf).
+// pqAdcLookupAvx512 order; one lane per row of the row-major codes.  At risk: a non-finite query value, scale or offset, or
+// magnitudes whose squares could overflow.
 struct PqScorer {
     const uint8_t *codes;     // n * m
     const int8_t *codebooks;  // m * 256 * sd
@@ -1340,9 +1340,21 @@ struct PqScorer {
     __device__ bool risk(int64_t, const float *q, int tid) const
     {
         __shared__ int flag;
+        __shared__ float vmax;
+        if (tid == 0) vmax = 0.0f;
+        __syncthreads();
         bool bad = false;
-        for (int j = tid; j < m * sd; j += kReplayThreads) bad = bad || !is_finite_f32(q[j]);
-        for (int j = tid; j < m; j += kReplayThreads) bad = bad || !is_finite_f32(scales[j]) || !is_finite_f32(offsets[j]);
+        float b = 0.0f;
+        for (int j = tid; j < m; j += kReplayThreads) {
+            bad = bad || !is_finite_f32(scales[j]) || !is_finite_f32(offsets[j]);
+            b = fmaxf(b, 128.0f * fabsf(scales[j]) + fabsf(offsets[j]));  // |centroid value| <= 128 |scale| + |offset|
+        }
+        for (int off = 32; off > 0; off >>= 1) b = fmaxf(b, __shfl_xor(b, off));
+        if ((tid & 63) == 0) atomicMax(reinterpret_cast<int *>(&vmax), __float_as_int(b));  // non-negative floats order like their bits
+        __syncthreads();
+        const float vm = vmax;
+        for (int j = tid; j < m * sd; j += kReplayThreads)
+            bad = bad || !is_finite_f32(q[j]) || !(score_bound(fabsf(q[j]), vm, false) * static_cast<float>(m * sd) < 1e38f);
         return block_any(bad, &flag, tid);
     }
     __device__ void prepare(int64_t, const float *, int) const {}

@@ -371,20 +371,34 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(kind == kVam
     if constexpr (STRICT) {
         bool bad = false;
         for (int j = lane; j < dim; j += 64) bad = bad || !is_finite_f32(qv[j]);
+        // (the tests of vg_cand_replay.hpp's scorers: non-finite inputs, or magnitudes whose partial sums could overflow)
+        float vm = 0.0f;  // the largest |value| a row can hold
         if (kind == kVamanaF32) {
-            const float ma = risk_absmax[0];
-            bad = bad || !is_finite_f32(ma);
-            if (desc)
-                for (int j = lane; j < dim; j += 64) bad = bad || !(fabsf(qv[j]) * ma * static_cast<float>(dim) < 1e38f);
+            vm = risk_absmax[0];
         } else if (kind == kVamanaRaBitQ) {
             const float ma = risk_absmax[0];
-            bad = bad || !is_finite_f32(qn) || !is_finite_f32(ma) || !(4.0f * fabsf(qn) * ma < 1e38f);
+            bad = bad || !is_finite_f32(qn) || !is_finite_f32(ma) || !(4.0f * fabsf(qn) * ma < 1e38f) || !(score_bound(fabsf(qn), ma, false) < 1e38f);
         } else if (kind == kVamanaPQ || kind == kVamanaPQDirect) {
-            for (int j = lane; j < pq_m; j += 64) bad = bad || !is_finite_f32(pq_scales[j]) || !is_finite_f32(pq_offsets[j]);
+            for (int j = lane; j < pq_m; j += 64) {
+                bad = bad || !is_finite_f32(pq_scales[j]) || !is_finite_f32(pq_offsets[j]);
+                vm = fmaxf(vm, 128.0f * fabsf(pq_scales[j]) + fabsf(pq_offsets[j]));
+            }
         } else if (int4_min && int4_diff) {
-            for (int j = lane; j < dim; j += 64) bad = bad || !is_finite_f32(int4_min[j]) || !is_finite_f32(int4_diff[j]);
+            for (int j = lane; j < dim; j += 64) {
+                bad = bad || !is_finite_f32(int4_min[j]) || !is_finite_f32(int4_diff[j]);
+                vm = fmaxf(vm, fabsf(int4_min[j]) + fabsf(int4_diff[j]));
+            }
         } else {
-            for (int j = lane; j < dim * 16; j += 64) bad = bad || !is_finite_f32(int4_table[j]);
+            for (int j = lane; j < dim * 16; j += 64) {  // (the lookup table holds the decoded values)
+                bad = bad || !is_finite_f32(int4_table[j]);
+                vm = fmaxf(vm, fabsf(int4_table[j]));
+            }
+        }
+        if (kind != kVamanaRaBitQ) {
+            for (int off = 32; off > 0; off >>= 1) vm = fmaxf(vm, __shfl_xor(vm, off));
+            bad = bad || !is_finite_f32(vm);
+            const bool as_dot = kind == kVamanaF32 && desc;
+            for (int j = lane; j < dim; j += 64) bad = bad || !(score_bound(fabsf(qv[j]), vm, as_dot) * static_cast<float>(dim) < 1e38f);
         }
         if (!__any(bad)) return;
         for (int64_t w = lane; w < vis_words; w += 64) vis[w] = 0u;  // the first pass's marks

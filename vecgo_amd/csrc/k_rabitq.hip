@@ -415,7 +415,7 @@ struct RabitqScorer {
     {
         __shared__ int flag;
         const float qn = norm_of(qcode(qi), nb), ma = norm_absmax[0];
-        const bool bad = !is_finite_f32(qn) || !is_finite_f32(ma) || !(4.0f * fabsf(qn) * ma < 1e38f);
+        const bool bad = !is_finite_f32(qn) || !is_finite_f32(ma) || !(4.0f * fabsf(qn) * ma < 1e38f) || !(score_bound(fabsf(qn), ma, false) < 1e38f);
         return block_any(bad, &flag, tid);
     }
     __device__ void prepare(int64_t, const float *, int) const {}

@@ -1850,8 +1850,8 @@ int32_t sq8_nominated_pass(vg_index *idx, const float *q, int64_t nq, int k, con
 
 namespace vg {
 // vg_cand_replay.hpp's scorer for the SQ8 scan: sq.L2Distance / sq.DotProduct of a row's code (flat/segment.go:517-604, :659-667),
-// one lane per row of the re-tiled codes.  A NaN: a non-finite query value, minimum or inverse scale; for dot products a magnitude
-// whose partial sums could overflow (|x^_j| <= 255 |inv_j| + |min_j|).
+// one lane per row of the re-tiled codes.  At risk: a non-finite query value, minimum or inverse scale; magnitudes whose partial
+// sums could overflow (|x^_j| <= 255 |inv_j| + |min_j|).
 template <bool DOT>
 struct Sq8Scorer {
     const uint4 *tiles;
@@ -1870,13 +1870,11 @@ struct Sq8Scorer {
             bad = bad || !is_finite_f32(q[j]) || !is_finite_f32(mn) || !is_finite_f32(iv);
             b = fmaxf(b, 255.0f * fabsf(iv) + fabsf(mn));
         }
-        if (DOT) {
-            for (int off = 32; off > 0; off >>= 1) b = fmaxf(b, __shfl_xor(b, off));
-            if ((tid & 63) == 0) atomicMax(reinterpret_cast<int *>(&bmax), __float_as_int(b));  // non-negative floats order like their bits
-            __syncthreads();
-            const float bm = bmax;
-            for (int j = tid; j < dim; j += kReplayThreads) bad = bad || !(fabsf(q[j]) * bm * static_cast<float>(dim) < 1e38f);
-        }
+        for (int off = 32; off > 0; off >>= 1) b = fmaxf(b, __shfl_xor(b, off));
+        if ((tid & 63) == 0) atomicMax(reinterpret_cast<int *>(&bmax), __float_as_int(b));  // non-negative floats order like their bits
+        __syncthreads();
+        const float bm = bmax;
+        for (int j = tid; j < dim; j += kReplayThreads) bad = bad || !(score_bound(fabsf(q[j]), bm, DOT) * static_cast<float>(dim) < 1e38f);
         return block_any(bad, &flag, tid);
     }
     __device__ void prepare(int64_t, const float *, int) const {}

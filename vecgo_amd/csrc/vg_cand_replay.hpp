@@ -10,8 +10,9 @@
 // caller's exact row arithmetic, and wave 0 runs the reference's Push / ReplaceTop on an LDS array with float comparisons.  The
 // result is what the engine takes out of the heap: Pop() until empty (engine/search.go:859-862), reported best first.
 //
-// Which queries: Scorer::risk() — a conservative test on the INPUTS (a non-finite query component, non-finite index data, for
-// dot products a magnitude that could overflow to +Inf and -Inf in different lanes).  A query without risk returns at once (the
+// Which queries: Scorer::risk() — a conservative test on the INPUTS: could a score be a NaN or an Inf?  (A non-finite query value
+// or index datum; magnitudes whose partial sums could overflow.  +Inf scores are ties the reference breaks by row id INSIDE the
+// heap's history; the scans' pre-tests `score < bound` drop them while the bound is still +Inf.)  A query without risk returns at once (the
 // launch costs a few microseconds per search call); a query with risk overwrites what the fast path wrote for it.  Rare by
 // construction — such inputs are garbage — so the walk is written for exactness, not speed: ~n * dim / 100 GB/s per query.
 #pragma once
@@ -193,6 +194,8 @@ __device__ __forceinline__ bool block_any(bool mine, int *flag, int tid)
     return r;
 }
 __device__ __forceinline__ bool is_finite_f32(float x) { return (__float_as_uint(x) & 0x7F800000u) != 0x7F800000u; }
+// the largest |term| of a dot product / squared distance between a value of magnitude a and one of magnitude b
+__device__ __forceinline__ float score_bound(float a, float b, bool dot) { return dot ? a * b : (a + b) * (a + b); }
 
 template <class Heap = CandHeapPolicy, class Scorer>
 inline int32_t launch_cand_replay(const Scorer &sc, const float *queries, int dim, int64_t n, int64_t nq, int k, bool desc, const uint8_t *mask,
@@ -224,8 +227,9 @@ struct FlatF32Scorer {
         bool bad = !is_finite_f32(ma);
         for (int j = tid; j < dim; j += kReplayThreads) {
             const float v = q[j];
-            // a dot product of finite values is a NaN only through +Inf and -Inf partial sums: none can arise below dim * max|q| * max|x|
-            bad = bad || !is_finite_f32(v) || (dot && !(fabsf(v) * ma * static_cast<float>(dim) < 1e38f));
+            // finite values: no partial sum overflows below dim * max|q| * max|x| (dot products: a NaN needs +Inf and -Inf) resp.
+            // dim * (max|q| + max|x|)^2 (squared distances: +Inf scores — ties the scans' keys do not keep like the heap does)
+            bad = bad || !is_finite_f32(v) || !(score_bound(fabsf(v), ma, dot) * static_cast<float>(dim) < 1e38f);
         }
         return block_any(bad, &flag, tid);
     }

@@ -839,12 +839,14 @@ __global__ __launch_bounds__(kBigThreads) void flat_gemm_bf16_big_kernel(
                     for (int e = 0; e < 4; e++) {
                         const int r = 4 * g + e;
                         const float a = acc[i][j][r];
-                        // (queries past nq started at -1e30 and never get here)
                         if (a > 0.0f) {
                             const uint32_t qq = static_cast<uint32_t>(q0) + static_cast<uint32_t>(wr * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + hv);
                             const int64_t nn = n0 + nl;
-                            // (the filter bit is looked at only for the few elements that pass)
-                            if (mask == nullptr || mask_bit(mask + static_cast<int64_t>(qq) * mask_stride, nn)) {
+                            // Queries past nq started at -1e30 and get here only when a row's dot product is +Inf (an Inf or a 1e38
+                            // in the row times the re-read last query): they have no list — r06's first version appended to
+                            // counts[qq] / cand[qq * cap] beyond the arrays (a memory fault on Dot segments with such rows, found
+                            // by tools/fuzz_nonfinite.py).  (The filter bit is looked at only for the few elements that pass.)
+                            if (static_cast<int64_t>(qq) < nq && (mask == nullptr || mask_bit(mask + static_cast<int64_t>(qq) * mask_stride, nn))) {
                                 if (pend < kPark) {
 #pragma unroll
                                     for (int s2 = 0; s2 < kPark; s2++) {
