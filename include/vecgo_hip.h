@@ -722,8 +722,10 @@ int32_t vg_comm_all_gather_topk(vg_comm *comm, const uint32_t *local_ids, const 
  * comparison of candidate_queue.go:12-38 / queue.go:75-82,199-203 is false: a NaN that enters while the heap fills stays, at
  * the root it is never replaced (rows better than everything kept are turned away), as a first child it stops a sift.  That
  * outcome is DEFINED — the loops are sequential — and these entry points return it: a query whose INPUTS could produce a NaN
- * score (a non-finite query value; non-finite rows, quantizer parameters or stored norms; a dot product whose partial sums can
- * reach +Inf and -Inf: dim * max|q| * max|x| >= 1e38; RaBitQ: 4 |q| |y| >= 1e38) is answered a second time by the reference's
+ * or an infinite score (a non-finite query value; non-finite rows, quantizer parameters or stored norms; magnitudes whose
+ * partial sums can overflow: dim * max|q| * max|x| >= 1e38 for dot products, dim * (max|q| + max|x|)^2 >= 1e38 for squared
+ * distances; RaBitQ: 4 |q| |y| >= 1e38 — +Inf scores are ties the heap breaks by row id inside its history, which the scans'
+ * `score < bound` pre-tests do not reproduce while the bound is +Inf) is answered a second time by the reference's
  * heap replayed operation by operation with float comparisons, rows in the reference's order, and overwrites the first answer.
  * ids / scores then hold what the engine takes out of the heap — Pop() until empty (engine/search.go:859-862) — best first; a
  * NaN score's sign and payload are the instruction set's, not the algorithm's.  Rare by construction (such inputs are garbage)

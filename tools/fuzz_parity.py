@@ -8,7 +8,7 @@ sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
 import numpy as np
 import vecgo_amd as vg
 from oracle import oracle as o
-from tests import graphs
+from tests import graphs, hooks
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
@@ -66,7 +66,7 @@ while time.time() < t_end:
         if which == 0:
             tag = "flat"
             if rng.random() < 0.6:                     # the bfloat16 nomination filter (takes effect above 4 queries; any dim)
-                nq = int(rng.choice([5, 33, 64, 65, 130]))
+                nq = int(rng.choice([5, 33, 64, 65, 130, 200]))
                 q = rng.standard_normal((nq, dim)).astype(np.float32)
                 if rng.random() < 0.3:                 # rows bf16 cannot tell apart: the proof must fail over to the scan
                     x = (x[0] + 1e-4 * rng.standard_normal((n, dim))).astype(np.float32)
@@ -119,9 +119,18 @@ while time.time() < t_end:
             codes = sq.encode(x)
             idx.set_sq8_codes(sq, codes)
             kk = k
+            tag = "sq8"
+            if rng.random() < 0.5:                     # the bfloat16 nomination (5 queries up; more than 128: the persistent tile)
+                nq = int(rng.choice([5, 33, 64, 130, 200]))
+                q = rng.standard_normal((nq, dim)).astype(np.float32)
+                if structured:
+                    q = x[rng.integers(0, n, nq)].copy()
+                cfg = dict(cfg, nq=nq)
+                idx.enable_sq8_nomination(True)
+                tag = "sq8_nominated"
             ids, sc = idx.search_sq8(q, kk)
             seg = o.FlatSegment(x, dim, metric=metric, sq=ref, codes=codes)
-            compare("sq8", cfg, ids, sc, [seg.search(q[i], kk) for i in range(nq)])
+            compare(tag, cfg, ids, sc, [seg.search(q[i], kk) for i in range(nq)])
         elif which == 3 and metric == 0:
             codes = vg.RaBitQuantizer(ctx, dim).encode(x)
             idx.set_rabitq_codes(codes)
@@ -140,8 +149,19 @@ while time.time() < t_end:
             cb, scales, offsets = pq.codebooks()
             opq = o.ProductQuantizer(dim, m, 256); opq.set_codebooks(cb, scales, offsets)
             idx.set_pq_codes(pq, codes)
+            tag = "pq_adc"
+            if rng.random() < 0.5:                     # the bfloat16 nomination over the decoded rows (test hook: any batch size)
+                nq = int(rng.choice([5, 33, 64, 130, 200]))
+                q = rng.standard_normal((nq, dim)).astype(np.float32)
+                if structured:
+                    q = x[rng.integers(0, n, nq)].copy()
+                cfg = dict(cfg, nq=nq)
+                hooks.set_hook("VG_PQ_NOM_ALWAYS", 1)
+                idx.enable_pq_nomination(True)
+                tag = "pq_adc_nominated"
             ids, sc = idx.search_pq_adc(q, k)
-            compare("pq_adc", dict(cfg, m=m), ids, sc, [o.flat_search_pq(opq, codes, q[i], k) for i in range(nq)])
+            hooks.set_hook("VG_PQ_NOM_ALWAYS", 0)
+            compare(tag, dict(cfg, m=m), ids, sc, [o.flat_search_pq(opq, codes, q[i], k) for i in range(nq)])
         elif which == 5 and n >= 16:
             gm = int(rng.choice([4, 8, 16]))
             l0, upper, entry = graphs.build_hnsw(x, m=gm, seed=int(rng.integers(0, 1000)))
