@@ -1526,9 +1526,8 @@ def compact_line(full: dict) -> dict:
                      "qps": _r(p8["qps"]), "nprobes_1_qps": _r(fp["nprobes_1"]["qps"])})
     row("f3 sq8 scan", full.get("sq8_scan"))
     i4 = full.get("int4_scan")
-    if isinstance(i4, dict) and "batch_order" in i4:
-        for order in ("batch_order", "lookup_table_order"):
-            row(f"f3 int4 scan ({order})", {**i4, **i4[order]})
+    if isinstance(i4, dict) and "lookup_table_order" in i4:
+        row("f3 int4 scan (lookup_table_order)", {**i4, **i4["lookup_table_order"]})  # (batch_order: in the full record)
     else:
         row("f3 int4 scan", i4)
     # the north_star functions the search legs do not time (build_side_legs): bound, fraction, CPU twin, equality

@@ -113,7 +113,7 @@ static void run_big(const char *name, const Bufs &b)
     const unsigned grid = unsigned(slots < 256 ? slots : 256);
     const float ms = time_ms(b, [&] {
         hipLaunchKernelGGL(kern, dim3(grid), dim3(vg::kBigThreads), lds, 0, b.q, b.nq, b.base, b.n, b.dw, b.norms,
-                           b.thr, 1, 0, b.counts, b.cand, b.cap, (const uint8_t *)nullptr, int64_t(0));
+                           b.thr, 1, 0, b.counts, b.cand, b.cap, (const uint8_t *)nullptr, int64_t(0), 1);
     });
     report(name, b, ms);
 }

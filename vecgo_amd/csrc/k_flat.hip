@@ -40,7 +40,18 @@ struct GemmArgs {
     const uint8_t *mask = nullptr;  // row filter of a filtered search (k_probe.hip): bit per (query, row), or one per row
     int64_t mask_stride = 0;
     int cus = 256;  // compute units of the device (the persistent bf16 tile launches one workgroup per CU)
+    // nq * kCountLine ints of scratch: the persistent bf16 tile's counters, one 128-byte line per query.  An append is a returning
+    // atomic on its query's counter; 1024 counters in 32 lines are 16 k atomics per line and launch, and a line serves them one
+    // after the other (1024 queries x 1M x 768: 0.16 of the kernel's 1.35 ms went there — "keys stored without atomics" in
+    // profiles/r06_gemm_bf16_probe.txt).  Null: the tile counts in `counts` itself.
+    int *counts_wide = nullptr;
 };
+constexpr int kCountLine = 32;
+__global__ void counts_narrow_kernel(const int *__restrict__ wide, int64_t nq, int *__restrict__ counts)
+{
+    const int64_t q = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (q < nq) counts[q] = wide[q * kCountLine];
+}
 
 template <bool DOT, int MODE>
 static int32_t launch_gemm_t(bool dma, unsigned blocks, hipStream_t st, const GemmArgs &a, bool bf16)
@@ -70,8 +81,12 @@ static int32_t launch_gemm_t(bool dma, unsigned blocks, hipStream_t st, const Ge
                                        static_cast<int>(lds)));
             const int64_t mt = (a.nq + kBigBM - 1) / kBigBM, nt = (a.n + kBigBN - 1) / kBigBN;
             const int64_t slots = mt * ((nt + 7) / 8) * 8, per_cu = std::max(a.cus / 8, 1) * 8;  // (one workgroup per CU: LDS)
+            if (a.counts_wide) VG_HIP(hipMemsetAsync(a.counts_wide, 0, sizeof(int) * static_cast<size_t>(a.nq) * kCountLine, st));
             VG_LAUNCH(kern, dim3(static_cast<unsigned>(std::min(slots, per_cu))), dim3(kBigThreads), lds, st, a.queries, a.nq,
-                      a.base, a.n, a.dim, a.norms, a.thr, a.thr_stride, a.thr_off, a.counts, a.cand, a.cap, a.mask, a.mask_stride);
+                      a.base, a.n, a.dim, a.norms, a.thr, a.thr_stride, a.thr_off, a.counts_wide ? a.counts_wide : a.counts, a.cand, a.cap, a.mask,
+                      a.mask_stride, a.counts_wide ? kCountLine : 1);
+            if (a.counts_wide)
+                VG_LAUNCH(counts_narrow_kernel, dim3(static_cast<unsigned>((a.nq + 255) / 256)), dim3(256), 0, st, a.counts_wide, a.nq, a.counts);
             return VG_OK;
         }
         auto kern = flat_gemm_dma_kernel<DOT, M, 0, true>;
@@ -775,6 +790,7 @@ int32_t vg::flat_search_masked(vg_index *idx, const float *queries, int64_t nq, 
         const int bdim = idx->vectors_bf16_dim;
         const float eps_extra = !bf16 ? 0.0f : (dot ? 0.00390625f : 0.0078125f) * 1.02f;
         const int i_qbf = ar.add(bf16 ? sizeof(uint16_t) * static_cast<size_t>(qc) * bdim : 0);
+        const int i_cwide = ar.add(bf16 ? sizeof(int) * static_cast<size_t>(qc) * vg::kCountLine : 0);
         VG_TRY(ar.commit());
         uint16_t *qbf = ar.get<uint16_t>(i_qbf);
         float *sc = ar.get<float>(i_sc), *thr = ar.get<float>(i_thr);
@@ -784,6 +800,7 @@ int32_t vg::flat_search_masked(vg_index *idx, const float *queries, int64_t nq, 
         uint64_t *min_keys = ar.get<uint64_t>(i_minkeys);
         uint32_t *sid = ar.get<uint32_t>(i_sid), *cand_id = ar.get<uint32_t>(i_cand_id), *fid = ar.get<uint32_t>(i_fid);
         int *counts = ar.get<int>(i_counts), *flags = ar.get<int>(i_flags), *todo = ar.get<int>(i_todo);
+        int *counts_wide = bf16 ? ar.get<int>(i_cwide) : nullptr;
 
         int *always = flags + qc;  // test hook kHookFlatForceExact: run step 4 for every query
         VG_HIP(hipMemsetAsync(always, vg::hook(vg::kHookFlatForceExact) ? 1 : 0, sizeof(int), st));
@@ -826,7 +843,7 @@ int32_t vg::flat_search_masked(vg_index *idx, const float *queries, int64_t nq, 
                     vg::ProfScope prof(idx->ctx, "flat_gemm", st);
                     VG_TRY(vg::launch_gemm<2>(dot, dma, static_cast<unsigned>(mt * ((nt + 7) / 8) * 8), st,
                                               {ga, cnt, gb, n, gdim, idx->d_norms, nullptr, 1, 0, thr,
-                                               sel_k, sel_k - 1, counts, cand, cap, m0, mask_stride, idx->ctx->compute_units}, bf16));
+                                               sel_k, sel_k - 1, counts, cand, cap, m0, mask_stride, idx->ctx->compute_units, counts_wide}, bf16));
                 }
                 // (c) the kc best appended keys (k > kGemmMaxK: all of them go to the exact re-score below)
                 if (k <= vg::kGemmMaxK)
@@ -1082,7 +1099,7 @@ int32_t flat_probe_gemm(vg_index *idx, const float *pair_queries, int64_t pairs,
 namespace vg {
 constexpr int kNomKc = 64, kNomCap = 4096, kNomStride = 64;
 struct NominateLayout {
-    size_t qbf, sc, partial, sid, cand, total;
+    size_t qbf, sc, partial, sid, cand, cwide, total;
     int sel_slices;
     int64_t ns;
 };
@@ -1103,6 +1120,7 @@ static NominateLayout nominate_layout(int64_t cnt, int64_t n, int dim, int sel_k
     l.partial = piece(sizeof(uint64_t) * static_cast<size_t>(cnt) * l.sel_slices * sel_k);
     l.sid = piece(sizeof(uint32_t) * static_cast<size_t>(cnt) * sel_k);
     l.cand = piece(sizeof(uint64_t) * static_cast<size_t>(cnt) * kNomCap);
+    l.cwide = piece(sizeof(int) * static_cast<size_t>(cnt) * kCountLine);
     l.total = at;
     return l;
 }
@@ -1143,7 +1161,7 @@ int32_t flat_nominate_bf16(vg_ctx *ctx, const uint16_t *rows_bf16, const float *
         ProfScope prof(ctx, "sq8_nominate_gemm", st);
         VG_TRY(launch_gemm<2>(dot, true, static_cast<unsigned>(mt * ((nt + 7) / 8) * 8), st,
                               {ga, cnt, gb, n, gdim, norms, nullptr, 1, 0, thr, sel_k, sel_k - 1, counts, cand, kNomCap, mask, mask_stride,
-                               ctx->compute_units},
+                               ctx->compute_units, reinterpret_cast<int *>(scratch + l.cwide)},
                               true));
     }
     if (pick) VG_LAUNCH(flat_pick_kernel, dim3(static_cast<unsigned>(cnt)), dim3(256), 0, st, cand, counts, kNomCap, kNomKc, cand_id, cand_sc);

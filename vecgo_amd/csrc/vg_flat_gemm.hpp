@@ -586,7 +586,8 @@ template <bool DOT, int NB, int PROBE = 0>
 __global__ __launch_bounds__(kBigThreads) void flat_gemm_bf16_big_kernel(
     const float *__restrict__ queries, int64_t nq, const float *__restrict__ base, int64_t n, int dim /* 4-byte words per row */,
     const float *__restrict__ norms, const float *__restrict__ thr, int thr_stride, int thr_off, int *__restrict__ counts,
-    uint64_t *__restrict__ cand, int cap, const uint8_t *__restrict__ mask, int64_t mask_stride)
+    uint64_t *__restrict__ cand, int cap, const uint8_t *__restrict__ mask, int64_t mask_stride,
+    int count_stride /* ints between two queries' counters: 32 = a 128-byte line each (see launch_gemm_t) */)
 {
     static_assert(NB == 2 || NB == 3, "two or three row-tile buffers");
     extern __shared__ float gemm_lds[];
@@ -787,7 +788,7 @@ __global__ __launch_bounds__(kBigThreads) void flat_gemm_bf16_big_kernel(
             pos[e] = 0;
             tt[e] = 0.0f;
             if (pend > e) {
-                pos[e] = (PROBE & 4096) ? e : atomicAdd(&counts[p_q[e]], 1);  // (stage probe 4096: no atomics, slot e of every list)
+                pos[e] = (PROBE & 4096) ? e : atomicAdd(&counts[p_q[e] * static_cast<uint32_t>(count_stride)], 1);  // (stage probe 4096: no atomics, slot e of every list)
                 tt[e] = thr[p_q[e] * static_cast<uint32_t>(thr_stride) + static_cast<uint32_t>(thr_off)];
             }
         }
@@ -858,7 +859,7 @@ __global__ __launch_bounds__(kBigThreads) void flat_gemm_bf16_big_kernel(
                                     pend++;
                                 } else {
                                     finish(qq, static_cast<uint32_t>(nn), a, thr[qq * static_cast<uint32_t>(thr_stride) + static_cast<uint32_t>(thr_off)],
-                                           atomicAdd(&counts[qq], 1));
+                                           atomicAdd(&counts[qq * static_cast<uint32_t>(count_stride)], 1));
                                 }
                             }
                         }
@@ -986,7 +987,7 @@ __global__ __launch_bounds__(kBigThreads) void flat_gemm_bf16_big_kernel(
         }
     }
     flush_parked();
-    if ((PROBE & 32768) && lane == 0) atomicAdd(&counts[nq], flushes);  // (stage probe: how often a wave flushed, counts[nq])
+    if ((PROBE & 32768) && lane == 0) atomicAdd(&counts[nq * count_stride], flushes);  // (stage probe: how often a wave flushed, counts[nq])
 }
 
 // ---- 5..64 queries: the same pipeline with a 32 x 128 or 64 x 128 tile ------------------------------
