@@ -717,7 +717,7 @@ int32_t vg_comm_all_gather_topk(vg_comm *comm, const uint32_t *local_ids, const 
                                 uint32_t *ids, float *scores, void *stream);
 
 /* NaN scores in the exhaustive searches and the beam search (vg_search_flat, vg_search_pq_adc, vg_search_sq8, vg_search_rabitq,
- * vg_search_hnsw_brute, vg_search_vamana / _filtered; VG_ABI_MINOR 10).  The scans keep their best k by a 64-bit key (score
+ * vg_search_flat_probed / _filtered, vg_search_hnsw_brute, vg_search_vamana / _filtered; VG_ABI_MINOR 10).  The scans keep their best k by a 64-bit key (score
  * bits, row id) — a total order, which is what the reference's heaps implement while no score is a NaN.  For a NaN every
  * comparison of candidate_queue.go:12-38 / queue.go:75-82,199-203 is false: a NaN that enters while the heap fills stays, at
  * the root it is never replaced (rows better than everything kept are turned away), as a first child it stops a sift.  That
@@ -730,9 +730,13 @@ int32_t vg_comm_all_gather_topk(vg_comm *comm, const uint32_t *local_ids, const 
  * ids / scores then hold what the engine takes out of the heap — Pop() until empty (engine/search.go:859-862) — best first; a
  * NaN score's sign and payload are the instruction set's, not the algorithm's.  Rare by construction (such inputs are garbage)
  * and slow by design: one workgroup walks all rows per query (~n * dim / 100 GB/s); an index holding a non-finite row sends
- * EVERY query there.  Every other query pays one extra kernel launch per call that returns at once.  Not covered: the
- * partition-probed and the filtered SQ8 / PQ scans of vg_search_flat_probed / _filtered (the filtered fp32 and PQ scans over the
- * whole segment are), vg_rerank, vg_merge_topk: NaN scores there order as the largest keys. */
+ * EVERY query there.  Every other query pays one extra kernel launch per call that returns at once (the probed searches: two —
+ * the probe lists are selected again for the replay).  vg_search_flat_probed / vg_search_flat_filtered (and vg_segment_search
+ * through them) take part: the rows a query's filter lets through, the probed partitions' ranges in FindClosestCentroids'
+ * order — its selection loop and, up to 12 partitions, its full sort (Go's insertion sort, where a NaN distance compares equal
+ * to everything) are replayed; with more than 12 partitions AND NaN centroid distances the full sort is pdqsort proper, whose
+ * order is not restated (NaN distances sort last).  Not covered: vg_rerank and vg_merge_topk — NaN scores there order as the
+ * largest keys. */
 
 /* flat.Segment.Search, PQ branch (flat/segment.go:476-483 LUT, :678-689 ADC
  * = simd.PqAdcLookup in pqAdcLookupAvx512 order, :714-721 top-k with the

@@ -825,7 +825,11 @@ int vgo_find_closest_centroids(const float *query, const float *centroids, int32
             out[i] = d[i].id;
         }
     } else {
-        /* insertion sort by (dist, id): k is small (partitions) */
+        /* slices.SortFunc(dists, cmpCentroidDistByDist) (kmeans.go:205-213,272): for up to 12 entries Go's pdqsort IS this
+         * insertion sort (sort/zsortanyfunc.go insertionSortCmpFunc: an entry moves left while cmp < 0, i.e. dist <) — stable, ids
+         * ascending on entry, so the id comparison below never fires there, and a NaN distance (cmp == 0 against everything) stops
+         * every move, exactly as here.  Beyond 12 entries pdqsort proper runs: without ties and NaN any sort gives its order; WITH
+         * them its order is not restated (ties go by id here; NaN distances stay where the insertion sort leaves them). */
         for (int i = 1; i < k; i++) {
             cdist x = d[i];
             int j = i - 1;

@@ -312,3 +312,72 @@ def test_vamana_beam_with_nan_distances(vg, ctx, kind, metric, where):
                 assert same_scores(sc[i, :r_], esc), (k, i)
                 assert np.all(ids[i, r_:] == 0xFFFFFFFF)
                 assert (int(st[i][0]), int(st[i][1]), int(st[i][3])) == (est.nodes_visited, est.distance_computations, est.pops), (k, i)
+
+
+@pytest.mark.parametrize("scan", ["f32", "sq8", "pq"])
+@pytest.mark.parametrize("metric", [0, 2])
+@pytest.mark.parametrize("where", ["queries", "data"])
+def test_partition_probed_and_filtered_scans(vg, ctx, scan, metric, where):
+    """vg_search_flat_probed / vg_search_flat_filtered (flat/segment.go:727-749): the probed partitions' row ranges go into ONE
+    heap, in FindClosestCentroids' order — with NaN scores the order matters (without it does not: the key order is total).  fp32,
+    SQ8 and PQ scans; nprobes 1 / 3 / all; no filter, one for the batch, one per query; an unpartitioned segment with a filter."""
+    from tests.test_gpu_probe import partitioned
+    rng = np.random.default_rng(400 + metric + len(scan))
+    n, dim, parts, nq, k = 6000, 32, 6, 14, 10
+    x, cent, off = partitioned(rng, n, dim, parts, metric)
+    x[50:54] = x[50]
+    q = poisoned_queries(rng, x, nq) if where == "queries" else rng.standard_normal((nq, dim)).astype(np.float32)
+    rows = x
+    if where == "data" and scan == "f32":
+        rows = x.copy()
+        bad = rng.integers(0, n, 40)
+        rows[bad, rng.integers(0, dim, 40)] = np.array([np.nan, np.inf, -np.inf, 3e38], np.float32)[rng.integers(0, 4, 40)]
+        rows[off[2], 0] = np.nan                                  # the first row of a partition
+    masks = rng.random((nq, n)) < 0.4
+
+    def build(partitioned_):
+        idx = vg.Index(ctx, n, dim, vg.Metric(metric))
+        kw = dict(centroids=cent, part_offsets=off) if partitioned_ else {}
+        if scan == "f32":
+            idx.set_vectors(rows)
+            seg = o.FlatSegment(rows, dim, metric=metric, **kw)
+            code = idx.SCAN_F32
+        elif scan == "sq8":
+            sq = vg.ScalarQuantizer(ctx, dim)
+            mins, maxs = x.min(0).copy(), x.max(0).copy() + 1e-3
+            if where == "data":
+                mins[3] = np.nan
+            sq.set_bounds(mins, maxs)
+            ref = o.ScalarQuantizer(dim)
+            for dst, src in zip((ref.mins, ref.maxs, ref.scales, ref.inv_scales), sq.params()):
+                dst[:] = src
+            ref.trained = True
+            codes = rng.integers(0, 256, (n, dim)).astype(np.uint8)
+            idx.set_sq8_codes(sq, codes)
+            seg = o.FlatSegment(x, dim, metric=metric, sq=ref, codes=codes, **kw)
+            code = idx.SCAN_SQ8
+        else:
+            m = dim // 8
+            opq = o.ProductQuantizer(dim, m, 256)
+            offsets = ((rng.random(m) * 2 - 1) * 0.1).astype(np.float32)
+            if where == "data":
+                offsets[1] = np.inf
+            opq.set_codebooks(rng.integers(-128, 128, m * 256 * 8).astype(np.int8), (rng.random(m) * 0.02 + 0.005).astype(np.float32), offsets)
+            codes = rng.integers(0, 256, (n, m)).astype(np.uint8)
+            pq = vg.ProductQuantizer(ctx, dim, m, 256)
+            pq.set_codebooks(opq.codebooks, opq.scales, opq.offsets)
+            idx.set_pq_codes(pq, codes)
+            seg = o.FlatSegment(x, dim, metric=metric, pq=opq, codes=codes, **kw)
+            code = idx.SCAN_PQ
+        if partitioned_:
+            idx.set_partitions(cent, off)
+        return idx, seg, code
+
+    idx, seg, code = build(True)
+    for nprobes in (1, 3, parts):
+        check(idx.search_flat_probed(q, k, nprobes, scan=code), lambda i: seg.search(q[i], k, nprobes), nq, k)
+        check(idx.search_flat_filtered(q, k, masks, nprobes, scan=code), lambda i: seg.search(q[i], k, nprobes, mask=masks[i]), nq, k)
+        check(idx.search_flat_filtered(q, k, masks[0], nprobes, scan=code), lambda i: seg.search(q[i], k, nprobes, mask=masks[0]), nq, k)
+    idx, seg, code = build(False)
+    check(idx.search_flat_filtered(q, k, masks, 0, scan=code), lambda i: seg.search(q[i], k, mask=masks[i]), nq, k)
+    check(idx.search_flat_filtered(q[:3], 70, masks[1], 0, scan=code), lambda i: seg.search(q[i], 70, mask=masks[1]), 3, 70)

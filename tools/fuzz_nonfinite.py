@@ -83,7 +83,7 @@ while time.time() < t_end:
         xr = x.copy()
         xr[: min(n, k)] = poison(xr[: min(n, k)], 0.1)
     cfg = dict(n=n, dim=dim, nq=nq, k=k, metric=metric, what=str(what), run=runs, seed=seed)
-    which = int(rng.integers(0, 7))
+    which = int(rng.integers(0, 8))
     LAST = dict(x=x, xr=xr, q=q)
     if len(sys.argv) > 3:                                # a log of what is about to run: the last line names a crash
         with open(sys.argv[3], "a") as f:
@@ -192,6 +192,41 @@ while time.time() < t_end:
                 kind, tag = 2, "vamana_rabitq"
             ids, sc, st = idx.search_vamana(q, kk, kind=kind, stats=True)
             compare(tag, cfg, ids, sc, [ov.search(q[i], kk) for i in range(nq)], stats=st)
+        elif which == 7 and n >= 64:                     # partition-probed / filtered flat scans (fp32, SQ8)
+            parts = int(rng.integers(2, 7))
+            cuts = np.sort(rng.integers(0, n + 1, parts - 1))
+            off = np.concatenate([[0], cuts, [n]]).astype(np.uint32)
+            cent = rng.standard_normal((parts, dim)).astype(np.float32)
+            nprobes = int(rng.integers(1, parts + 1))
+            kk = min(k, 512)
+            idx = vg.Index(ctx, n, dim, vg.Metric(metric))
+            use_mask = str(rng.choice(["none", "one", "each"]))
+            mask = None if use_mask == "none" else (rng.random(n) < 0.5 if use_mask == "one" else rng.random((nq, n)) < 0.4)
+            if rng.random() < 0.5 or metric == 1:
+                idx.set_vectors(xr)
+                seg = o.FlatSegment(xr, dim, metric=metric, centroids=cent, part_offsets=off)
+                code, tag = idx.SCAN_F32, "probed_f32"
+            else:
+                sq = vg.ScalarQuantizer(ctx, dim)
+                mins, maxs = x.min(0), x.max(0) + 1e-3
+                if what in ("data", "both"):
+                    mins = poison(mins, 1.0 / dim)
+                sq.set_bounds(mins, maxs)
+                ref = o.ScalarQuantizer(dim)
+                for dst, src in zip((ref.mins, ref.maxs, ref.scales, ref.inv_scales), sq.params()):
+                    dst[:] = src
+                ref.trained = True
+                codes = rng.integers(0, 256, (n, dim)).astype(np.uint8)
+                idx.set_sq8_codes(sq, codes)
+                seg = o.FlatSegment(x, dim, metric=metric, sq=ref, codes=codes, centroids=cent, part_offsets=off)
+                code, tag = idx.SCAN_SQ8, "probed_sq8"
+            idx.set_partitions(cent, off)
+            if mask is None:
+                ids, sc = idx.search_flat_probed(q, kk, nprobes, scan=code)
+            else:
+                ids, sc = idx.search_flat_filtered(q, kk, mask, nprobes, scan=code)
+            compare(tag, dict(cfg, parts=parts, nprobes=nprobes, mask=use_mask, off=off.tolist()), ids, sc,
+                    [seg.search(q[i], kk, nprobes, mask=None if mask is None else (mask if mask.ndim == 1 else mask[i])) for i in range(nq)])
     except vg.VecgoHipError as e:
         if e.status != -5:                               # (an unsupported shape is not a finding)
             fails += 1

@@ -1392,6 +1392,19 @@ struct PqScorer {
 };
 }  // namespace vg
 
+namespace vg {
+// the replay for device buffers: the whole segment, or (probes: nq * np partition ids, part_off) the probed partitions; mask: a
+// device row filter per query / for the batch, or null; desc: a Dot / Cosine segment keeps the LARGEST sums (flat/segment.go:449)
+int32_t pq_nan_replay(vg_index *idx, const float *d_queries, int64_t nq, int k, bool desc, const uint8_t *d_mask, int64_t mask_stride,
+                      const uint32_t *d_probes, int np, const uint32_t *d_part_off, uint32_t *d_ids, float *d_scores, hipStream_t st)
+{
+    if (idx->n == 0) return VG_OK;
+    const vg_pq *pq = idx->pq;
+    return launch_cand_replay(PqScorer{idx->d_pq_rows, pq->d_codebooks, pq->d_scales, pq->d_offsets, pq->m, pq->subdim}, d_queries, idx->dim, idx->n, nq,
+                              k, desc, d_mask, mask_stride, d_ids, d_scores, st, nullptr, d_probes, np, d_part_off);
+}
+}  // namespace vg
+
 static int32_t pq_adc_search_impl(vg_index *idx, const float *queries, int64_t nq, int32_t k, const uint8_t *mask, int64_t mask_stride,
                                   bool desc, uint32_t *ids, float *scores, void *stream, bool allow_nomination);
 int32_t vg::pq_adc_search_masked(vg_index *idx, const float *queries, int64_t nq, int32_t k, const uint8_t *mask,
@@ -1434,9 +1447,8 @@ static int32_t pq_adc_search_impl(vg_index *idx, const float *queries, int64_t n
     // queries whose table sums may hold a NaN: the reference's heap, operation by operation (vg_cand_replay.hpp; not for the queries
     // this function sends to itself after a failed proof: the caller's pass covers them)
     auto nan_replay = [&]() -> int32_t {
-        if (idx->n == 0 || !allow_nomination) return VG_OK;
-        return vg::launch_cand_replay(vg::PqScorer{idx->d_pq_rows, pq->d_codebooks, pq->d_scales, pq->d_offsets, pq->m, pq->subdim}, q.ptr, idx->dim,
-                                      idx->n, nq, k, desc, mask, mask_stride, oid.ptr, osc.ptr, st);
+        if (!allow_nomination) return VG_OK;
+        return vg::pq_nan_replay(idx, q.ptr, nq, k, desc, mask, mask_stride, nullptr, 0, nullptr, oid.ptr, osc.ptr, st);
     };
     if (idx->n == 0) {
         vg::DevTmp<uint64_t> none;

@@ -13,6 +13,7 @@
 #include "vg_exact.hpp"
 #include "vg_flat_gemm.hpp"
 #include "vg_internal.hpp"
+#include "vg_cand_replay.hpp"
 
 namespace vg {
 
@@ -33,6 +34,10 @@ int32_t launch_probe_scan_sq8_grouped(const vg_index *idx, const float *queries,
                                       int64_t mask_stride, hipStream_t st);
 int32_t flat_search_masked(vg_index *idx, const float *queries, int64_t nq, int32_t k, const uint8_t *mask, int64_t mask_stride,
                            uint32_t *ids, float *scores, void *stream, bool l2_scores = false, bool cand_replay = true);
+int32_t sq8_nan_replay(vg_index *idx, const float *d_queries, int64_t nq, int k, const uint8_t *d_mask, int64_t mask_stride,
+                       const uint32_t *d_probes, int np, const uint32_t *d_part_off, uint32_t *d_ids, float *d_scores, hipStream_t st);
+int32_t pq_nan_replay(vg_index *idx, const float *d_queries, int64_t nq, int k, bool desc, const uint8_t *d_mask, int64_t mask_stride,
+                      const uint32_t *d_probes, int np, const uint32_t *d_part_off, uint32_t *d_ids, float *d_scores, hipStream_t st);
 int32_t pq_adc_search_masked(vg_index *idx, const float *queries, int64_t nq, int32_t k, const uint8_t *mask, int64_t mask_stride,
                              bool desc, uint32_t *ids, float *scores, void *stream);
 size_t flat_probe_gemm_scratch_bytes(int64_t pairs, int64_t ns_max, int k, int bf16_dim);
@@ -90,9 +95,37 @@ __global__ __launch_bounds__(256) void probe_select_kernel(const float *__restri
         }
         tk.offer(key, lane);
     }
-    if (emulate && nan_seen) any_nan = 1;
+    if (nan_seen) any_nan = 1;
     wg_rank_merge<4>(tk, lists, valid, wave, lane, tid, want, best);
     __syncthreads();
+    // The full sort (kmeans.go:272, slices.SortFunc with cmpCentroidDistByDist: a NaN compares EQUAL to everything) of up to 12
+    // entries is Go's insertionSortCmpFunc (sort/zsortanyfunc.go: pdqsort's small-slice case) — stable, so without a NaN it is the
+    // key order; with one it is replayed: an entry moves left while it is `<` its left neighbour, and nothing moves past a NaN.
+    // (More than 12 partitions: pdqsort proper, whose order with NaN distances is not restated — they sort last here.)
+    constexpr int kInsMax = 12;
+    __shared__ float ins_d[kInsMax];
+    if (!emulate && any_nan != 0 && parts <= kInsMax) {
+        for (int c0 = wave * 4; c0 < parts; c0 += 16) {
+            const int c = c0 + (lane >> 4);
+            if (c < parts) {
+                const float v = exact_pair16<DOT, kBatch>(centroids + static_cast<int64_t>(c) * dim, qv, dim, sub);
+                if ((lane & 15) == 0) ins_d[c] = DOT ? -v : v;
+            }
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int order[kInsMax];
+            for (int i = 0; i < parts; i++) order[i] = i;
+            for (int i = 1; i < parts; i++)
+                for (int j = i; j > 0 && ins_d[order[j]] < ins_d[order[j - 1]]; j--) {
+                    const int t = order[j];
+                    order[j] = order[j - 1];
+                    order[j - 1] = t;
+                }
+            for (int i = 0; i < np; i++) probes[q * np + i] = static_cast<uint32_t>(order[i]);
+        }
+        return;
+    }
     // (a NaN distance anywhere: the selection loop takes a NaN standing at position i — the keys never would — so it is replayed)
     bool tie = emulate && any_nan != 0;
     if (emulate)
@@ -578,10 +611,68 @@ static int32_t flat_probed_impl(vg_index *idx, const float *queries, int64_t nq,
                                 const uint8_t *mask, int64_t mask_stride, uint32_t *ids, float *scores, void *stream,
                                 bool allow_nomination = true);
 
+// kmeans.FindClosestCentroids for every query (device buffers): probes[q * np + j]
+static int32_t launch_probe_select(const vg_index *idx, const float *d_queries, int64_t nq, int np, bool dot, uint32_t *d_probes, hipStream_t st)
+{
+    const size_t sel_lds = 8 * static_cast<size_t>(idx->num_partitions);
+    const int emulate = np <= idx->num_partitions / 4 && np < 16 && sel_lds <= 156 * 1024;
+    auto kern = dot ? vg::probe_select_kernel<true> : vg::probe_select_kernel<false>;
+    if (emulate && sel_lds > 48 * 1024)
+        VG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   static_cast<int>(sel_lds)));
+    VG_LAUNCH(kern, dim3(static_cast<unsigned>(nq)), dim3(256), emulate ? sel_lds : 0, st, d_queries, idx->dim, idx->d_centroids,
+              idx->num_partitions, np, d_probes, emulate);
+    return VG_OK;
+}
+
+// The two entry points: flat_probed_impl on device buffers, then — include/vecgo_hip.h "NaN scores" — the queries whose scores may
+// hold a NaN or an Inf once more through the reference's heap (vg_cand_replay.hpp): the rows a query's filter lets through, in
+// the order the reference visits them (the whole range, or the probed partitions' ranges in FindClosestCentroids' order).
+static int32_t flat_probed_entry(vg_index *idx, const float *queries, int64_t nq, int32_t k, int32_t nprobes, int32_t scan,
+                                 const uint8_t *mask, int64_t mask_stride, uint32_t *ids, float *scores, void *stream)
+{
+    // (arguments flat_probed_impl refuses, and the unfiltered whole segment — vg_search_flat / _pq_adc / _sq8 replay for themselves)
+    if (!idx || nq <= 0 || k <= 0 || !queries || !ids || !scores || (scan != VG_SCAN_F32 && scan != VG_SCAN_PQ && scan != VG_SCAN_SQ8) ||
+        (idx->num_partitions <= 1 && mask == nullptr) || idx->n == 0 || vg::hook(vg::kHookNoCandReplay))
+        return flat_probed_impl(idx, queries, nq, k, nprobes, scan, mask, mask_stride, ids, scores, stream);
+    VG_HIP(hipSetDevice(idx->ctx->device));
+    hipStream_t st = vg::pick_stream(idx->ctx, stream);
+    vg::DevIn<float> q;
+    vg::DevIn<uint8_t> mk;
+    vg::DevOut<uint32_t> oid;
+    vg::DevOut<float> osc;
+    const int64_t mask_bytes = (idx->n + 7) / 8;
+    VG_TRY(q.init(queries, static_cast<size_t>(nq) * idx->dim, st));
+    VG_TRY(mk.init(mask, mask ? static_cast<size_t>(mask_stride ? (nq - 1) * mask_stride + mask_bytes : mask_bytes) : 0, st));
+    VG_TRY(oid.init(ids, static_cast<size_t>(nq) * k, st));
+    VG_TRY(osc.init(scores, static_cast<size_t>(nq) * k, st));
+    VG_TRY(flat_probed_impl(idx, q.ptr, nq, k, nprobes, scan, mk.ptr, mask_stride, oid.ptr, osc.ptr, st));
+    const bool whole = idx->num_partitions <= 1, dot = idx->metric != VG_METRIC_L2;
+    int np = nprobes <= 0 ? 1 : nprobes;
+    if (np > idx->num_partitions) np = idx->num_partitions;
+    vg::DevTmp<uint32_t> probes;
+    if (!whole) {
+        VG_TRY(probes.init(static_cast<size_t>(nq) * np, st));
+        VG_TRY(launch_probe_select(idx, q.ptr, nq, np, dot, probes.ptr, st));
+    }
+    const uint32_t *pr = whole ? nullptr : probes.ptr, *po = whole ? nullptr : idx->d_part_off;
+    if (scan == VG_SCAN_SQ8)
+        VG_TRY(vg::sq8_nan_replay(idx, q.ptr, nq, k, mk.ptr, mask_stride, pr, np, po, oid.ptr, osc.ptr, st));
+    else if (scan == VG_SCAN_PQ)
+        VG_TRY(vg::pq_nan_replay(idx, q.ptr, nq, k, dot, mk.ptr, mask_stride, pr, np, po, oid.ptr, osc.ptr, st));
+    else
+        VG_TRY(vg::launch_cand_replay(vg::FlatF32Scorer{idx->d_vectors, idx->d_norm_max + 1, idx->dim, dot, 0}, q.ptr, idx->dim, idx->n, nq, k, dot,
+                                      mk.ptr, mask_stride, oid.ptr, osc.ptr, st, nullptr, pr, np, po));
+    VG_TRY(oid.finish());
+    VG_TRY(osc.finish());
+    if (oid.on_host() || osc.on_host()) VG_HIP(hipStreamSynchronize(st));
+    return VG_OK;
+}
+
 VG_API int32_t vg_search_flat_probed(vg_index *idx, const float *queries, int64_t nq, int32_t k, int32_t nprobes,
                                      int32_t scan, uint32_t *ids, float *scores, void *stream)
 {
-    return flat_probed_impl(idx, queries, nq, k, nprobes, scan, nullptr, 0, ids, scores, stream);
+    return flat_probed_entry(idx, queries, nq, k, nprobes, scan, nullptr, 0, ids, scores, stream);
 }
 
 VG_API int32_t vg_search_flat_filtered(vg_index *idx, const float *queries, int64_t nq, int32_t k, int32_t nprobes,
@@ -593,7 +684,7 @@ VG_API int32_t vg_search_flat_filtered(vg_index *idx, const float *queries, int6
     VG_CHECK(mask == nullptr || mask_stride == 0 || mask_stride >= mask_bytes, VG_ERR_INVALID_ARG,
              "vg_search_flat_filtered: mask_stride %lld is shorter than a mask (%lld bytes)", static_cast<long long>(mask_stride),
              static_cast<long long>(mask_bytes));
-    return flat_probed_impl(idx, queries, nq, k, nprobes, scan, mask, mask_stride, ids, scores, stream);
+    return flat_probed_entry(idx, queries, nq, k, nprobes, scan, mask, mask_stride, ids, scores, stream);
 }
 
 static int32_t flat_probed_impl(vg_index *idx, const float *queries, int64_t nq, int32_t k, int32_t nprobes, int32_t scan,
@@ -836,14 +927,7 @@ static int32_t flat_probed_impl(vg_index *idx, const float *queries, int64_t nq,
         // the reference's selection loop (kmeans.go:255: n <= k/4 && n < 16) is replayed where centroid distances tie; its LDS
         // (8 bytes per partition, beside the kernel's 2.6 KB of static LDS) bounds that to 19 968 partitions — beyond, ties are
         // broken by centroid id
-        const size_t sel_lds = 8 * static_cast<size_t>(idx->num_partitions);
-        const int emulate = np <= idx->num_partitions / 4 && np < 16 && sel_lds <= 156 * 1024;
-        auto kern = dot ? vg::probe_select_kernel<true> : vg::probe_select_kernel<false>;
-        if (emulate && sel_lds > 48 * 1024)
-            VG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       static_cast<int>(sel_lds)));
-        VG_LAUNCH(kern, dim3(static_cast<unsigned>(nq)), dim3(256), emulate ? sel_lds : 0, st, q.ptr, idx->dim, idx->d_centroids,
-                  idx->num_partitions, np, probes, emulate);
+        VG_TRY(launch_probe_select(idx, q.ptr, nq, np, dot, probes, st));
     }
     // the heap direction follows the segment metric for EVERY scan (flat/segment.go:449): with Dot / Cosine a PQ
     // scan therefore keeps the k LARGEST table-lookup (squared-L2) distances — the reference as written

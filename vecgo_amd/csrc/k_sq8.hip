@@ -1887,6 +1887,22 @@ struct Sq8Scorer {
 };
 }  // namespace vg
 
+namespace vg {
+// the replay for device buffers: the whole segment, or (probes: nq * np partition ids, part_off) the probed partitions; mask: a
+// device row filter per query / for the batch, or null (k_probe.hip calls it for the filtered and the partition-probed scans)
+int32_t sq8_nan_replay(vg_index *idx, const float *d_queries, int64_t nq, int k, const uint8_t *d_mask, int64_t mask_stride,
+                       const uint32_t *d_probes, int np, const uint32_t *d_part_off, uint32_t *d_ids, float *d_scores, hipStream_t st)
+{
+    if (idx->n == 0) return VG_OK;
+    const uint4 *tiles = reinterpret_cast<const uint4 *>(idx->d_sq_tiles);
+    if (idx->metric != VG_METRIC_L2)
+        return launch_cand_replay(Sq8Scorer<true>{tiles, idx->sq->d_mins, idx->sq->d_inv, idx->sq_groups, idx->dim}, d_queries, idx->dim, idx->n, nq, k,
+                                  true, d_mask, mask_stride, d_ids, d_scores, st, nullptr, d_probes, np, d_part_off);
+    return launch_cand_replay(Sq8Scorer<false>{tiles, idx->sq->d_mins, idx->sq->d_inv, idx->sq_groups, idx->dim}, d_queries, idx->dim, idx->n, nq, k,
+                              false, d_mask, mask_stride, d_ids, d_scores, st, nullptr, d_probes, np, d_part_off);
+}
+}  // namespace vg
+
 static int32_t sq8_search_impl(vg_index *idx, const float *queries, int64_t nq, int32_t k, uint32_t *ids, float *scores, void *stream,
                                bool allow_nomination);
 
@@ -2012,15 +2028,7 @@ static int32_t sq8_search_impl(vg_index *idx, const float *queries, int64_t nq, 
     }
     // queries whose scores may hold a NaN: the reference's heap, operation by operation (vg_cand_replay.hpp; not for the
     // queries this function sends to itself after a failed proof: the caller's pass covers them)
-    if (idx->n > 0 && allow_nomination) {
-        const uint4 *tiles = reinterpret_cast<const uint4 *>(idx->d_sq_tiles);
-        if (dot)
-            VG_TRY(vg::launch_cand_replay(vg::Sq8Scorer<true>{tiles, idx->sq->d_mins, idx->sq->d_inv, idx->sq_groups, idx->dim}, q.ptr, idx->dim,
-                                          idx->n, nq, k, true, nullptr, 0, oid.ptr, osc.ptr, st));
-        else
-            VG_TRY(vg::launch_cand_replay(vg::Sq8Scorer<false>{tiles, idx->sq->d_mins, idx->sq->d_inv, idx->sq_groups, idx->dim}, q.ptr, idx->dim,
-                                          idx->n, nq, k, false, nullptr, 0, oid.ptr, osc.ptr, st));
-    }
+    if (idx->n > 0 && allow_nomination) VG_TRY(vg::sq8_nan_replay(idx, q.ptr, nq, k, nullptr, 0, nullptr, 0, nullptr, oid.ptr, osc.ptr, st));
     VG_TRY(oid.finish());
     VG_TRY(osc.finish());
     return VG_OK;

@@ -128,7 +128,9 @@ template <class Scorer, class Heap>
 __global__ __launch_bounds__(kReplayThreads) void cand_replay_kernel(Scorer sc, const float *__restrict__ queries, int dim, int64_t n, int k,
                                                                      bool desc, const uint8_t *__restrict__ mask, int64_t mask_stride,
                                                                      uint32_t *__restrict__ ids, float *__restrict__ scores,
-                                                                     int *__restrict__ replayed, int64_t q_first)
+                                                                     int *__restrict__ replayed, int64_t q_first,
+                                                                     const uint32_t *__restrict__ probes, int np,
+                                                                     const uint32_t *__restrict__ part_off)
 {
     extern __shared__ uint64_t replay_lds[];
     CItem *heap = reinterpret_cast<CItem *>(replay_lds);  // k items
@@ -142,12 +144,21 @@ __global__ __launch_bounds__(kReplayThreads) void cand_replay_kernel(Scorer sc, 
     const uint8_t *mq = mask ? mask + q * mask_stride : nullptr;
     sc.prepare(qi, qv, tid);
     int len = 0;  // wave 0's copy is the live one
-    for (int64_t row0 = 0; row0 < n; row0 += kReplayChunk) {
+    // the rows in the reference's order: the whole segment, or — a partitioned segment — the row ranges of the query's probed
+    // partitions in FindClosestCentroids' order, one after the other into the same heap (flat/segment.go:727-744)
+    for (int jr = 0; jr < (probes ? np : 1); jr++) {
+    int64_t r0 = 0, r1 = n;
+    if (probes) {
+        const uint32_t p = probes[q * np + jr];
+        r0 = part_off[p];
+        r1 = part_off[p + 1];
+    }
+    for (int64_t row0 = r0; row0 < r1; row0 += kReplayChunk) {
         __syncthreads();  // the previous chunk has been replayed
-        sc.score_chunk(qi, qv, row0, n, tid, chunk);
+        sc.score_chunk(qi, qv, row0, r1, tid, chunk);
         __syncthreads();
         if (tid >= 64) continue;
-        const int cnt = static_cast<int>(n - row0 < kReplayChunk ? n - row0 : kReplayChunk);
+        const int cnt = static_cast<int>(r1 - row0 < kReplayChunk ? r1 - row0 : kReplayChunk);
         for (int j0 = 0; j0 < cnt; j0 += 64) {
             const int j = j0 + lane;
             const bool live = j < cnt && mask_bit(mq, row0 + j);  // filter.Matches before the row is scored (flat/segment.go:631-635)
@@ -166,6 +177,7 @@ __global__ __launch_bounds__(kReplayThreads) void cand_replay_kernel(Scorer sc, 
                 from = b + 1;
             }
         }
+    }
     }
     if (tid >= 64) return;
     const int nres = len;
@@ -197,16 +209,18 @@ __device__ __forceinline__ bool is_finite_f32(float x) { return (__float_as_uint
 // the largest |term| of a dot product / squared distance between a value of magnitude a and one of magnitude b
 __device__ __forceinline__ float score_bound(float a, float b, bool dot) { return dot ? a * b : (a + b) * (a + b); }
 
+// probes / np / part_off: a partitioned segment's probe lists (device, nq * np partition ids) and partition bounds, or null
 template <class Heap = CandHeapPolicy, class Scorer>
 inline int32_t launch_cand_replay(const Scorer &sc, const float *queries, int dim, int64_t n, int64_t nq, int k, bool desc, const uint8_t *mask,
-                                  int64_t mask_stride, uint32_t *ids, float *scores, hipStream_t st, int *replayed = nullptr)
+                                  int64_t mask_stride, uint32_t *ids, float *scores, hipStream_t st, int *replayed = nullptr,
+                                  const uint32_t *probes = nullptr, int np = 0, const uint32_t *part_off = nullptr)
 {
     if (nq == 0 || k == 0 || hook(kHookNoCandReplay)) return VG_OK;
     const size_t lds = sizeof(uint64_t) * (static_cast<size_t>(k) + 4) + sizeof(float) * kReplayChunk;  // (+ 4: vg_heap.hpp reads a node's four children together)
     for (int64_t q0 = 0; q0 < nq; q0 += 1 << 30) {
         const int64_t cnt = std::min<int64_t>(nq - q0, 1 << 30);
         VG_LAUNCH((cand_replay_kernel<Scorer, Heap>), dim3(static_cast<unsigned>(cnt)), dim3(kReplayThreads), lds, st, sc, queries + q0 * dim, dim, n, k,
-                  desc, mask ? mask + q0 * mask_stride : nullptr, mask_stride, ids + q0 * k, scores + q0 * k, replayed, q0);
+                  desc, mask ? mask + q0 * mask_stride : nullptr, mask_stride, ids + q0 * k, scores + q0 * k, replayed, q0, probes ? probes + q0 * np : nullptr, np, part_off);
     }
     return VG_OK;
 }
