@@ -761,7 +761,13 @@ __global__ __launch_bounds__(kBigThreads) void flat_gemm_bf16_big_kernel(
     // Also measured and not kept: a log per wave with a scatter kernel behind (a plain store to a line that has left the L2
     // retires as slowly as an atomic: 1.59 + 0.06 ms; nontemporal 1.48 + 0.06) and a pool of registers per wave written out
     // once (v_readlane / v_writelane per element, scalar registers spilled: 1.69 + 0.06).
-    constexpr int kPark = 4;
+#ifndef VG_BIG_PARK
+#define VG_BIG_PARK 4
+#endif
+#ifndef VG_BIG_FLUSH_EVERY
+#define VG_BIG_FLUSH_EVERY 6
+#endif
+    constexpr int kPark = VG_BIG_PARK;
     int pend = 0;  // parked elements of this lane (0..kPark)
     uint32_t p_q[kPark], p_row[kPark];
     float p_a[kPark];
@@ -771,7 +777,7 @@ __global__ __launch_bounds__(kBigThreads) void flat_gemm_bf16_big_kernel(
         p_row[e] = 0u;
         p_a[e] = 0.0f;
     }
-    constexpr int kFlushEvery = 6;
+    constexpr int kFlushEvery = VG_BIG_FLUSH_EVERY;
     int flushes = 0, tiles_done = static_cast<int>(blockIdx.x >> 3) % kFlushEvery;  // (the workgroups take turns: all of them
                                                                                      // at once is 45 k atomics on 1024 counters)
     auto finish = [&](uint32_t qq, uint32_t row, float a, float t, int pos) {
