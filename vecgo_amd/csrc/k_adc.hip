@@ -1103,7 +1103,8 @@ __global__ __launch_bounds__(256) void pq_decode_bf16_kernel(const uint8_t *__re
     if (lane == 0) {
         norms[row] = nrm;
         // a NaN norm (a NaN scale / offset) must reach norm_max: NaN -> +Inf, the proof's comparisons then fail and the scan answers
-        atomicMax(norm_max_bits, __float_as_int(nrm == nrm ? nrm : INFINITY));  // non-negative floats order like their bits
+        const int nb = __float_as_int(nrm == nrm ? nrm : INFINITY);  // non-negative floats order like their bits
+        if (nb > *reinterpret_cast<volatile int *>(norm_max_bits)) atomicMax(norm_max_bits, nb);  // (a wave per row: only where it raises the value)
     }
 }
 

@@ -131,7 +131,9 @@ __global__ void row_norms_kernel(const float *__restrict__ base, int64_t n, int 
     }
     if (lane == 0) {
         norms[row] = s;
-        atomicMax(maxabs_bits, __float_as_int(mx));  // non-negative floats order like their bits
+        // (non-negative floats order like their bits; a million waves on one address: the atomic only where it would raise the value —
+        // unconditional it made this pass 11 ms instead of 0.5)
+        if (__float_as_int(mx) > *reinterpret_cast<volatile int *>(maxabs_bits)) atomicMax(maxabs_bits, __float_as_int(mx));
     }
 }
 

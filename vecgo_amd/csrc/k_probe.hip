@@ -607,9 +607,10 @@ VG_API int32_t vg_index_set_partitions(vg_index *idx, const float *centroids, co
     return VG_OK;
 }
 
+// probes_out: where the call leaves its probe lists (device, nq * np), or null: scratch
 static int32_t flat_probed_impl(vg_index *idx, const float *queries, int64_t nq, int32_t k, int32_t nprobes, int32_t scan,
                                 const uint8_t *mask, int64_t mask_stride, uint32_t *ids, float *scores, void *stream,
-                                bool allow_nomination = true);
+                                bool allow_nomination = true, uint32_t *probes_out = nullptr);
 
 // kmeans.FindClosestCentroids for every query (device buffers): probes[q * np + j]
 static int32_t launch_probe_select(const vg_index *idx, const float *d_queries, int64_t nq, int np, bool dot, uint32_t *d_probes, hipStream_t st)
@@ -646,15 +647,12 @@ static int32_t flat_probed_entry(vg_index *idx, const float *queries, int64_t nq
     VG_TRY(mk.init(mask, mask ? static_cast<size_t>(mask_stride ? (nq - 1) * mask_stride + mask_bytes : mask_bytes) : 0, st));
     VG_TRY(oid.init(ids, static_cast<size_t>(nq) * k, st));
     VG_TRY(osc.init(scores, static_cast<size_t>(nq) * k, st));
-    VG_TRY(flat_probed_impl(idx, q.ptr, nq, k, nprobes, scan, mk.ptr, mask_stride, oid.ptr, osc.ptr, st));
     const bool whole = idx->num_partitions <= 1, dot = idx->metric != VG_METRIC_L2;
     int np = nprobes <= 0 ? 1 : nprobes;
     if (np > idx->num_partitions) np = idx->num_partitions;
-    vg::DevTmp<uint32_t> probes;
-    if (!whole) {
-        VG_TRY(probes.init(static_cast<size_t>(nq) * np, st));
-        VG_TRY(launch_probe_select(idx, q.ptr, nq, np, dot, probes.ptr, st));
-    }
+    vg::DevTmp<uint32_t> probes;  // the search leaves its probe lists here: the replay walks the same partitions in the same order
+    if (!whole) VG_TRY(probes.init(static_cast<size_t>(nq) * np, st));
+    VG_TRY(flat_probed_impl(idx, q.ptr, nq, k, nprobes, scan, mk.ptr, mask_stride, oid.ptr, osc.ptr, st, true, whole ? nullptr : probes.ptr));
     const uint32_t *pr = whole ? nullptr : probes.ptr, *po = whole ? nullptr : idx->d_part_off;
     if (scan == VG_SCAN_SQ8)
         VG_TRY(vg::sq8_nan_replay(idx, q.ptr, nq, k, mk.ptr, mask_stride, pr, np, po, oid.ptr, osc.ptr, st));
@@ -689,7 +687,7 @@ VG_API int32_t vg_search_flat_filtered(vg_index *idx, const float *queries, int6
 
 static int32_t flat_probed_impl(vg_index *idx, const float *queries, int64_t nq, int32_t k, int32_t nprobes, int32_t scan,
                                 const uint8_t *mask, int64_t mask_stride, uint32_t *ids, float *scores, void *stream,
-                                bool allow_nomination)
+                                bool allow_nomination, uint32_t *probes_out)
 {
     VG_CHECK(idx, VG_ERR_INVALID_ARG, "vg_search_flat_probed: NULL index");
     VG_CHECK(scan == VG_SCAN_F32 || scan == VG_SCAN_PQ || scan == VG_SCAN_SQ8, VG_ERR_INVALID_ARG,
@@ -801,7 +799,8 @@ static int32_t flat_probed_impl(vg_index *idx, const float *queries, int64_t nq,
             for (int64_t q0 = 0; q0 < nq; q0 += qc) {
                 const int64_t cnt = std::min<int64_t>(qc, nq - q0);
                 VG_TRY(flat_probed_impl(idx, q.ptr + q0 * idx->dim, cnt, k, nprobes, scan, mk.ptr ? mk.ptr + q0 * mask_stride : nullptr,
-                                        mask_stride, oid.ptr + q0 * k, osc.ptr + q0 * k, st, allow_nomination));
+                                        mask_stride, oid.ptr + q0 * k, osc.ptr + q0 * k, st, allow_nomination,
+                                        probes_out ? probes_out + q0 * np : nullptr));
             }
             VG_TRY(oid.finish());
             VG_TRY(osc.finish());
@@ -906,7 +905,7 @@ static int32_t flat_probed_impl(vg_index *idx, const float *queries, int64_t nq,
     const bool gemm_f32_bf16 = gemm_f32 && idx->d_vectors_bf16 != nullptr;
     const int i_gscr = ar.add(gemm ? vg::flat_probe_gemm_scratch_bytes(pairs, ns_max, k, gemm_sq8 ? idx->sq_bf16_dim : gemm_f32_bf16 ? idx->vectors_bf16_dim : 0) : 0);
     VG_TRY(ar.commit());
-    uint32_t *probes = ar.get<uint32_t>(i_probes);
+    uint32_t *probes = probes_out && !whole ? probes_out : ar.get<uint32_t>(i_probes);
     uint64_t *partial = ar.get<uint64_t>(i_partial);
     float *tables = ar.get<float>(i_tables);
     uint32_t *pid = ar.get<uint32_t>(i_pid);
