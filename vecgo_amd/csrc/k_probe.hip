@@ -444,14 +444,19 @@ __global__ __launch_bounds__(256) void probe_bucket_count_kernel(const uint32_t 
     if (i < pairs) atomicAdd(&counts[probes[i]], 1u);
 }
 
+constexpr int64_t kProbeSmallMax = 512;  // pairs per partition up to which the 64-query tiles take the group
 // one workgroup: the groups (pairs and rows of each partition) and each group's first workgroup in the two GEMM launches
 __global__ __launch_bounds__(1024) void probe_bucket_scan_kernel(const uint32_t *__restrict__ counts, const uint32_t *__restrict__ part_off,
                                                                  int parts, uint32_t *__restrict__ cursor, GemmGroup *__restrict__ groups,
                                                                  int64_t *__restrict__ fb_sample, int64_t *__restrict__ fb_main,
                                                                  int64_t *__restrict__ fb_sample_small, int64_t *__restrict__ fb_main_small)
 {
-    // a group of at most 64 pairs takes the 64-query tile (flat_gemm_dma32_grouped_kernel<.., 2>: one workgroup per row tile,
-    // HBM-bound whatever the tile holds), a larger one the 128-query tiles; each group has workgroups in one of the two launches
+    // A group of up to kProbeSmallMax pairs takes 64-query tiles (flat_gemm_dma32_grouped_kernel<.., 2>: one workgroup per query tile
+    // and row tile), a larger one the 128-query tiles; each group has workgroups in one of the two launches.  A full 64-query tile
+    // costs half a 128-query one (6.2 against 16.6 us per 8192-row partition: the small tile is balanced between the matrix unit
+    // and the rows' bytes) and a group's last tile is half empty on average whatever its size — 1024 queries x 8 probes over 122
+    // partitions are groups of 67 +- 8 pairs: r05 sent those of more than 64 pairs (three in five) to one half-empty 128-query
+    // tile each.
     __shared__ int64_t seg_c[1024], seg_s[1024], seg_m[1024], seg_ss[1024], seg_sm[1024];
     const int tid = threadIdx.x;
     const int per = (parts + 1023) / 1024;
@@ -460,11 +465,12 @@ __global__ __launch_bounds__(1024) void probe_bucket_scan_kernel(const uint32_t 
         const int64_t cnt = counts[p], rows = static_cast<int64_t>(part_off[p + 1]) - part_off[p];
         const int64_t mt = (cnt + kGemmBM - 1) / kGemmBM, nt = (rows + kGemmBN - 1) / kGemmBN;
         const int64_t nst = (nt + kProbeSampleStride - 1) / kProbeSampleStride;
-        const bool any = cnt && rows, small = cnt <= 2 * kG32BM;
+        const bool any = cnt && rows, small = cnt <= kProbeSmallMax;
+        const int64_t mt64 = (cnt + 2 * kG32BM - 1) / (2 * kG32BM);
         bs = any && !small ? mt * ((nst + 7) / 8) * 8 : 0;
         bm = any && !small ? mt * ((nt + 7) / 8) * 8 : 0;
-        ss = any && small ? nst : 0;
-        sm = any && small ? nt : 0;
+        ss = any && small ? mt64 * nst : 0;
+        sm = any && small ? mt64 * nt : 0;
     };
     int64_t mc = 0, ms = 0, mm = 0, mss = 0, msm = 0;
     for (int p = pb; p < pe; p++) {
@@ -870,7 +876,7 @@ static int32_t flat_probed_impl(vg_index *idx, const float *queries, int64_t nq,
     const bool gemm = gemm_f32 || gemm_sq8;
     int64_t grids[4] = {0, 0, 0, 0}, ns_max = 0;  // sample / main of the 128-query tiles, sample / main of the 64-query tiles
     if (gemm) {  // launch bounds from the partition sizes: one query tile per partition + the batch's further tiles on the largest
-        int64_t sum_s = 0, sum_m = 0, max_s = 0, max_m = 0;
+        int64_t sum_s = 0, sum_m = 0, max_s = 0, max_m = 0, max_nst = 0, max_nt = 0;
         for (int p = 0; p < parts; p++) {
             const int64_t rows = static_cast<int64_t>(idx->h_part_off[p + 1]) - idx->h_part_off[p];
             const int64_t nt = (rows + vg::kGemmBN - 1) / vg::kGemmBN, nst = (nt + vg::kProbeSampleStride - 1) / vg::kProbeSampleStride;
@@ -881,10 +887,14 @@ static int32_t flat_probed_impl(vg_index *idx, const float *queries, int64_t nq,
             max_m = std::max(max_m, bm);
             grids[2] += nst;
             grids[3] += nt;
+            max_nst = std::max(max_nst, nst);
+            max_nt = std::max(max_nt, nt);
             ns_max = std::max(ns_max, nst * vg::kGemmBN);
         }
         grids[0] = sum_s + (pairs / vg::kGemmBM) * max_s;
         grids[1] = sum_m + (pairs / vg::kGemmBM) * max_m;
+        grids[2] += (pairs / (2 * vg::kG32BM)) * max_nst;  // (64-query tiles: a partition's first + the batch's further ones on the largest)
+        grids[3] += (pairs / (2 * vg::kG32BM)) * max_nt;
     }
     const size_t gw = gemm ? static_cast<size_t>(parts) + 1 : 0;
     const int i_bcnt = ar.add(sizeof(uint32_t) * gw);

@@ -1183,7 +1183,7 @@ __global__ __launch_bounds__(kGemmThreads) void flat_gemm_dma32_kernel(
                                                       thr_off, counts, cand, cap, mask, mask_stride, blockIdx.x, 0u);
 }
 
-// the grouped form for groups of at most RB * 32 query rows (one workgroup per row tile of the group; first_block as above)
+// the grouped form: a group's query rows in tiles of RB * 32 (one workgroup per query tile and row tile; first_block as above)
 template <bool DOT, int MODE, int RB, bool BF16 = false>
 __global__ __launch_bounds__(kGemmThreads) void flat_gemm_dma32_grouped_kernel(
     const GemmGroup *__restrict__ groups, const int64_t *__restrict__ first_block, int ngroups,
@@ -1204,11 +1204,19 @@ __global__ __launch_bounds__(kGemmThreads) void flat_gemm_dma32_grouped_kernel(
     }
     const GemmGroup g = groups[lo];
     if (g.a_cnt == 0 || g.b_cnt == 0) return;
+    // a group's workgroups: query tile by query tile (RB * 32 query rows each), a tile's row tiles (MODE 1: its sampled ones) in order
+    const int64_t rel = b - first_block[lo];
+    const int64_t nt = (static_cast<int64_t>(g.b_cnt) + kGemmBN - 1) / kGemmBN;
+    const int64_t per = MODE == 1 ? (nt + tile_stride - 1) / tile_stride : nt;
+    const int64_t qt = rel / per, tn = rel - qt * per;
+    const int64_t a_off = g.a_off + qt * (RB * kG32BM);
+    const int64_t a_cnt = std::min<int64_t>(RB * kG32BM, g.a_cnt - qt * (RB * kG32BM));
+    if (a_cnt <= 0) return;
     flat_gemm_dma32_body<DOT, MODE, RB, BF16, true>(
-        queries + g.a_off * dim, g.a_cnt, base + g.b_off * dim, g.b_cnt, dim, norms + g.b_off,
-        scores ? scores + g.a_off * out_cols : nullptr, tile_stride, out_cols, thr ? thr + g.a_off * thr_stride : nullptr, thr_stride,
-        thr_off, counts ? counts + g.a_off : nullptr, cand ? cand + g.a_off * cap : nullptr, cap, mask, 0, b - first_block[lo],
-        static_cast<uint32_t>(g.b_off), mask ? mask_off + g.a_off : nullptr);
+        queries + a_off * dim, a_cnt, base + g.b_off * dim, g.b_cnt, dim, norms + g.b_off,
+        scores ? scores + a_off * out_cols : nullptr, tile_stride, out_cols, thr ? thr + a_off * thr_stride : nullptr, thr_stride,
+        thr_off, counts ? counts + a_off : nullptr, cand ? cand + a_off * cap : nullptr, cap, mask, 0, tn,
+        static_cast<uint32_t>(g.b_off), mask ? mask_off + a_off : nullptr);
 }
 
 }  // namespace vg
