@@ -1030,12 +1030,12 @@ int32_t flat_probe_gemm(vg_index *idx, const float *pair_queries, int64_t pairs,
         if (grid[0])
             VG_LAUNCH(kern, dim3(static_cast<unsigned>(grid[0])), dim3(kGemmThreads), kDmaLdsBytes, st, groups, first_block[0], ngroups,
                       pair_queries, grows, gdim, gnorms, sc, sample_stride, ns_max, nullptr, 0, 0, nullptr, nullptr, 0, mask, mask_off);
-        auto kern32 = bf16 ? (dot ? flat_gemm_dma32_grouped_kernel<true, 1, 2, true> : flat_gemm_dma32_grouped_kernel<false, 1, 2, true>)
-                           : (dot ? flat_gemm_dma32_grouped_kernel<true, 1, 2> : flat_gemm_dma32_grouped_kernel<false, 1, 2>);
+        auto kern32 = bf16 ? (dot ? flat_gemm_dma32_grouped_kernel<true, 1, kProbeRB, true> : flat_gemm_dma32_grouped_kernel<false, 1, kProbeRB, true>)
+                           : (dot ? flat_gemm_dma32_grouped_kernel<true, 1, kProbeRB> : flat_gemm_dma32_grouped_kernel<false, 1, kProbeRB>);
         VG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern32), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   static_cast<int>(g32_lds_bytes<2>())));
+                                   static_cast<int>(g32_lds_bytes<kProbeRB>())));
         if (grid[2])
-            VG_LAUNCH(kern32, dim3(static_cast<unsigned>(grid[2])), dim3(kGemmThreads), g32_lds_bytes<2>(), st, groups, first_block[2], ngroups,
+            VG_LAUNCH(kern32, dim3(static_cast<unsigned>(grid[2])), dim3(kGemmThreads), g32_lds_bytes<kProbeRB>(), st, groups, first_block[2], ngroups,
                       pair_queries, grows, gdim, gnorms, sc, sample_stride, ns_max, nullptr, 0, 0, nullptr, nullptr, 0, mask, mask_off);
     }
     VG_LAUNCH(flat_select_kernel, dim3(sel_slices, upairs), dim3(kSelThreads), 0, st, sc, ns_max, sel_slices, sel_k, partial);
@@ -1051,12 +1051,12 @@ int32_t flat_probe_gemm(vg_index *idx, const float *pair_queries, int64_t pairs,
         if (grid[1])
             VG_LAUNCH(kern, dim3(static_cast<unsigned>(grid[1])), dim3(kGemmThreads), kDmaLdsBytes, st, groups, first_block[1], ngroups,
                       pair_queries, grows, gdim, gnorms, nullptr, 1, 0, thr, sel_k, sel_k - 1, counts, cand, cap, mask, mask_off);
-        auto kern32 = bf16 ? (dot ? flat_gemm_dma32_grouped_kernel<true, 2, 2, true> : flat_gemm_dma32_grouped_kernel<false, 2, 2, true>)
-                           : (dot ? flat_gemm_dma32_grouped_kernel<true, 2, 2> : flat_gemm_dma32_grouped_kernel<false, 2, 2>);
+        auto kern32 = bf16 ? (dot ? flat_gemm_dma32_grouped_kernel<true, 2, kProbeRB, true> : flat_gemm_dma32_grouped_kernel<false, 2, kProbeRB, true>)
+                           : (dot ? flat_gemm_dma32_grouped_kernel<true, 2, kProbeRB> : flat_gemm_dma32_grouped_kernel<false, 2, kProbeRB>);
         VG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern32), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   static_cast<int>(g32_lds_bytes<2>())));
+                                   static_cast<int>(g32_lds_bytes<kProbeRB>())));
         if (grid[3])
-            VG_LAUNCH(kern32, dim3(static_cast<unsigned>(grid[3])), dim3(kGemmThreads), g32_lds_bytes<2>(), st, groups, first_block[3], ngroups,
+            VG_LAUNCH(kern32, dim3(static_cast<unsigned>(grid[3])), dim3(kGemmThreads), g32_lds_bytes<kProbeRB>(), st, groups, first_block[3], ngroups,
                       pair_queries, grows, gdim, gnorms, nullptr, 1, 0, thr, sel_k, sel_k - 1, counts, cand, cap, mask, mask_off);
     }
     // (c) the kc best of them, (d) re-scored exactly, the k best, and the proof against everything not nominated

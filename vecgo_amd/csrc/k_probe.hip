@@ -466,7 +466,7 @@ __global__ __launch_bounds__(1024) void probe_bucket_scan_kernel(const uint32_t 
         const int64_t mt = (cnt + kGemmBM - 1) / kGemmBM, nt = (rows + kGemmBN - 1) / kGemmBN;
         const int64_t nst = (nt + kProbeSampleStride - 1) / kProbeSampleStride;
         const bool any = cnt && rows, small = cnt <= kProbeSmallMax;
-        const int64_t mt64 = (cnt + 2 * kG32BM - 1) / (2 * kG32BM);
+        const int64_t mt64 = (cnt + kProbeRB * kG32BM - 1) / (kProbeRB * kG32BM);
         bs = any && !small ? mt * ((nst + 7) / 8) * 8 : 0;
         bm = any && !small ? mt * ((nt + 7) / 8) * 8 : 0;
         ss = any && small ? mt64 * nst : 0;
@@ -893,8 +893,8 @@ static int32_t flat_probed_impl(vg_index *idx, const float *queries, int64_t nq,
         }
         grids[0] = sum_s + (pairs / vg::kGemmBM) * max_s;
         grids[1] = sum_m + (pairs / vg::kGemmBM) * max_m;
-        grids[2] += (pairs / (2 * vg::kG32BM)) * max_nst;  // (64-query tiles: a partition's first + the batch's further ones on the largest)
-        grids[3] += (pairs / (2 * vg::kG32BM)) * max_nt;
+        grids[2] += (pairs / (vg::kProbeRB * vg::kG32BM)) * max_nst;  // (64-query tiles: a partition's first + the batch's further ones on the largest)
+        grids[3] += (pairs / (vg::kProbeRB * vg::kG32BM)) * max_nt;
     }
     const size_t gw = gemm ? static_cast<size_t>(parts) + 1 : 0;
     const int i_bcnt = ar.add(sizeof(uint32_t) * gw);

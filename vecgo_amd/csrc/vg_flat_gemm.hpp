@@ -1004,6 +1004,10 @@ __global__ __launch_bounds__(kBigThreads) void flat_gemm_bf16_big_kernel(
 // wave.  LDS per workgroup: 2 x (RB * 4 + 16) KiB, so three to four workgroups share a CU.
 // nq <= RB * 32 only (one query tile; the grid covers the row tiles).  MODE 1 / 2 as above.
 constexpr int kG32BM = 32;
+#ifndef VG_PROBE_RB
+#define VG_PROBE_RB 4
+#endif
+constexpr int kProbeRB = VG_PROBE_RB;  // blocks of 32 query rows in a tile of the grouped (partition-probed) form: see probe_bucket_scan_kernel
 template <int RB>
 constexpr size_t g32_lds_bytes() { return 2 * (RB * kG32BM * kGemmBK + kDmaTile) * sizeof(float); }
 
@@ -1097,6 +1101,7 @@ __device__ __forceinline__ void flat_gemm_dma32_body(
     const int64_t nn = n0 + col;
     const float xn = (!DOT && nn < n) ? norms[nn] : 0.0f;
 
+    const int used = GROUPED ? static_cast<int>((nq + kG32BM - 1) / kG32BM) : RB;  // blocks of 32 query rows that hold a query
     dma_tile(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -1117,20 +1122,23 @@ __device__ __forceinline__ void flat_gemm_dma32_body(
                 fb[nx] = *reinterpret_cast<const float4 *>(Bs + b_row + goff[j + 1]);
             }
             __builtin_amdgcn_sched_barrier(0);
+            // (a block of 32 query rows that holds no query — the grouped form's last tile of a group is half empty on average — is
+            // not multiplied: `used` is uniform over the workgroup)
             if constexpr (BF16) {
 #pragma unroll
                 for (int i = 0; i < RB; i++)
-                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(vg_bf16x8, fa[c][i]),
-                                                                    __builtin_bit_cast(vg_bf16x8, fb[c]), acc[i], 0, 0, 0);
+                    if (i < used)
+                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(vg_bf16x8, fa[c][i]),
+                                                                        __builtin_bit_cast(vg_bf16x8, fb[c]), acc[i], 0, 0, 0);
             } else {
 #pragma unroll
-                for (int i = 0; i < RB; i++) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][i].x, fb[c].x, acc[i], 0, 0, 0);
-#pragma unroll
-                for (int i = 0; i < RB; i++) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][i].y, fb[c].y, acc[i], 0, 0, 0);
-#pragma unroll
-                for (int i = 0; i < RB; i++) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][i].z, fb[c].z, acc[i], 0, 0, 0);
-#pragma unroll
-                for (int i = 0; i < RB; i++) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][i].w, fb[c].w, acc[i], 0, 0, 0);
+                for (int i = 0; i < RB; i++)
+                    if (i < used) {
+                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][i].x, fb[c].x, acc[i], 0, 0, 0);
+                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][i].y, fb[c].y, acc[i], 0, 0, 0);
+                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][i].z, fb[c].z, acc[i], 0, 0, 0);
+                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][i].w, fb[c].w, acc[i], 0, 0, 0);
+                    }
             }
             __builtin_amdgcn_sched_barrier(0);
         }
