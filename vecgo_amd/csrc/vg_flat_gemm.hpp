@@ -567,14 +567,6 @@ __device__ __forceinline__ void big_split3(float x, uint32_t &p0, uint32_t &p1, 
     const float r2 = r1 - __uint_as_float(p1 << 16);
     p2 = rne(r2);
 }
-// lane `sel` of dst = val (both wave-uniform); the other lanes keep theirs
-__device__ __forceinline__ void big_writelane(uint32_t &dst, uint32_t val, int sel)
-{
-    uint32_t keep;  // (one scalar operand per instruction on gfx9: the lane select goes through M0, saved and restored)
-    asm volatile("s_mov_b32 %1, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tv_writelane_b32 %0, %2, m0\n\ts_mov_b32 m0, %1"
-                 : "+v"(dst), "=&s"(keep)
-                 : "s"(val), "s"(sel));
-}
 __device__ __forceinline__ int big_max3_i32(int a, int b, int c)
 {
     int r;
