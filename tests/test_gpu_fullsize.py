@@ -163,6 +163,41 @@ def test_pq_adc_scan_10m_x_96(vg, ctx):
     assert set(np_(better).tolist()) <= set(hid[0].tolist()), (better, worst_id)
 
 
+def test_pq_batches_through_the_bf16_nomination_1m_x_96(vg, ctx):
+    """vg_index_enable_pq_nomination at the bench's size: 1024 queries x 1M rows of m = 96 codes ENCODED from random-normal rows
+    (the nomination's bf16 image is the decoded rows), duplicates included.  Nominated batch == one table scan per query, bit for
+    bit; the oracle's table sums on the reported rows; two whole queries replayed by the oracle over all the codes; k = 100 (every
+    row below the threshold re-scored and sorted)."""
+    n, dim, m, nq, k = 1_000_000, 768, 96, 1024, 10
+    g = torch.Generator(device="cuda"); g.manual_seed(11)
+    rows = torch.randn(n, dim, device="cuda", generator=g)
+    pq = _train_small_pq(vg, ctx, dim, m)
+    codes = pq.encode(rows)
+    codes[123_456] = codes[900_001]
+    del rows
+    idx = vg.Index(ctx, n, dim); idx.set_pq_codes(pq, codes)
+    q = torch.randn(nq, dim, device="cuda", generator=g)
+    ids, sc = idx.search_pq_adc(q, k)
+    i100, s100 = idx.search_pq_adc(q[:256], 100)
+    idx.enable_pq_nomination(True)
+    nid, nsc = idx.search_pq_adc(q, k)
+    assert torch.equal(ids, nid) and torch.equal(sc.view(torch.int32), nsc.view(torch.int32))
+    n100, t100 = idx.search_pq_adc(q[:256], 100)
+    assert torch.equal(i100, n100) and torch.equal(s100.view(torch.int32), t100.view(torch.int32))
+    assert_ordered(nid, nsc)
+    cb, s_, of_ = pq.codebooks()
+    opq = o.ProductQuantizer(dim, m, 256); opq.set_codebooks(cb, s_, of_)
+    hid = np_(nid).view(np.uint32).astype(np.int64)
+    hq = q.cpu().numpy()
+    for i in (0, 1, 511, 1023):
+        table = opq.build_table(hq[i])
+        rc = codes[torch.from_numpy(hid[i]).cuda()].cpu().numpy()
+        want = np.array([o.adc(table, rc[j], m) for j in range(k)], np.float32)
+        assert np.array_equal(bits(np_(nsc)[i]), bits(want)), i
+    rid, rsc = o.replay(o.BENCH_ADC, hq[:2], k, pq=opq, codes=codes.cpu().numpy(), n=n)
+    assert np.array_equal(rid, np_(nid).view(np.uint32)[:2]) and np.array_equal(bits(rsc), bits(np_(nsc)[:2]))
+
+
 def test_rabitq_scan_10m_x_768(vg, ctx):
     """BASELINE configs[4] on one GPU: 10M RaBitQ codes of 100 bytes."""
     n, dim, nq, k = 10_000_000, 768, 4, 10
