@@ -137,3 +137,17 @@ def test_stdout_carries_only_the_line_whatever_libraries_print():
     lines = r.stdout.splitlines()
     assert len(lines) == 1 and json.loads(lines[0])["metric"], r.stdout[:500]
     assert "[Gloo]" in r.stderr and "a stray print" in r.stderr and "child process" in r.stderr
+
+
+def test_design_table_is_the_committed_record():
+    """DESIGN.md section 8's current-state table is generated from profiles/r06_bench_full.json (tools/design_table.py): the text
+    between its markers must be what the generator writes from the committed record — a number typed by hand, or a record
+    refreshed without the table, fails here."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("design_table", ROOT / "tools" / "design_table.py")
+    dt = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(dt)
+    text = (ROOT / "DESIGN.md").read_text()
+    a, b = text.index(dt.BEGIN) + len(dt.BEGIN), text.index(dt.END)
+    assert text[a:b].strip() == dt.table("r06").strip()
+    assert text[a:b].count("\n") >= 20            # every kernel family has its row
