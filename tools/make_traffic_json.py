@@ -162,10 +162,12 @@ def gemm16(tag, sub):
 
 out["flat_gemm_bf16_big"] = gemm16("big", "flat_gemm_bf16_big_kernel<false, 3, 0>")
 out["flat_gemm_bf16_tile128"] = gemm16("tile128", "flat_gemm_dma_kernel<false, 2, 0, true>")
-gr = traffic("grouped_fetch", None, "flat_gemm_dma_grouped_kernel<false, 2", None, {"workload": "partition-probed fp32 search: grouped GEMM (tools/probe_gemm_time.py)"})
+# (r06: groups of up to 512 pairs take the tiles of up to four 32-query blocks: flat_gemm_dma32_grouped_kernel<.., MODE 2, RB 4>)
+GROUPED = "flat_gemm_dma32_grouped_kernel<false, 2, 4, false>"
+gr = traffic("grouped_fetch", None, GROUPED, None, {"workload": "partition-probed fp32 search: the grouped GEMM, mean over tools/probe_gemm_time.py's calls (nprobes 1 .. 32, 1024 and 8192 queries)"})
 if gr:
-    gr["matrix_unit"] = unit_counters("grouped_mfma", "flat_gemm_dma_grouped_kernel<false, 2", ("SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE", "SQ_INSTS_MFMA"))
-    gr["waits"] = unit_counters("grouped_wait", "flat_gemm_dma_grouped_kernel<false, 2", ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_WAVE_CYCLES"))
+    gr["matrix_unit"] = unit_counters("grouped_mfma", GROUPED, ("SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE", "SQ_INSTS_MFMA"))
+    gr["waits"] = unit_counters("grouped_wait", GROUPED, ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_WAVE_CYCLES"))
 out["flat_gemm_grouped"] = gr
 km = traffic("kmeans_fetch", "kmeans_write", "km_gemm_kernel<false, true>", 1_000_000 * 768 * 4, {"workload": "k-means assignment GEMM, 1M x 768 x 122, bf16 [hi|lo] splits"})
 if km:
