@@ -150,8 +150,8 @@ __device__ __forceinline__ uint32_t heap_readlane(uint32_t v, int l)
 // squares; never the negated dot product), so the order of the floats is the order of their bit patterns as
 // unsigned integers and every comparison below is the reference's comparison.  (NOT for NaN: a NaN distance — NaN
 // or Inf in a row or a query — has a bit pattern above +Inf's and sorts as the largest key here, while in the
-// reference every comparison with it is false; the graph searches choose UK from the metric alone, so results for
-// inputs that produce NaN distances are unspecified, as include/vecgo_hip.h says of vg_search_hnsw.)  That moves a sift's decisions from
+// reference every comparison with it is false; the graph searches choose UK from the metric alone, watch every scored
+// neighbour list for a NaN, and answer a query that meets one with the float instantiation — k_graph.hip `redo`.)  That moves a sift's decisions from
 // the vector ALU — where a wave-uniform step costs a full 64-lane issue slot — to the scalar ALU, and lets one
 // round trip serve three heap levels:
 //  * which child is best does not depend on the item being sifted, and a sift only moves items UP its path, so the 4
