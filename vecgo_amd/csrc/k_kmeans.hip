@@ -108,10 +108,21 @@ __global__ __launch_bounds__(256) void km_assign_regs_kernel(const float *__rest
                                                              const float *__restrict__ centroids, int k,
                                                              int32_t *__restrict__ assign, int *__restrict__ changed,
                                                              const int32_t *__restrict__ list = nullptr,
-                                                             const int *__restrict__ list_count = nullptr)
+                                                             const int *__restrict__ list_count = nullptr,
+                                                             float *__restrict__ range_d = nullptr, int32_t *__restrict__ range_i = nullptr,
+                                                             int range_len = 0)
 {
     constexpr int dim = NBLK * 64;
     __shared__ __attribute__((aligned(16))) float ctile[kKmTile * dim];
+    // LIST with range_len > 0: the listed points are few (~1 % of a pass) and the walk over the k centroids is one chain of
+    // dependent tile fetches per chunk — 272 chunks on 256 CUs took as long as the chain (187 us at k = 122).  blockIdx.y cuts
+    // the centroids into ranges of range_len (a multiple of kKmTile); a workgroup leaves its range's best (value, centroid) per
+    // slot in range_d / range_i [slot * gridDim.y + range] and km_list_combine_kernel takes the first best over the ranges in
+    // order — the strict comparison of the loop below, so a tie still goes to the lowest centroid.
+    const bool ranged = LIST && range_len > 0;
+    const int c_lo = ranged ? static_cast<int>(blockIdx.y) * range_len : 0;
+    const int c_hi = ranged ? (c_lo + range_len < k ? c_lo + range_len : k) : k;
+    if (c_lo >= c_hi) return;
     const int tid = threadIdx.x;
     const Sub16 sub = Sub16::make(tid);
     // LIST: slots of the list instead of rows; a block walks chunks of 16 * kKmRows slots (uniform trip count: the
@@ -142,8 +153,8 @@ __global__ __launch_bounds__(256) void km_assign_regs_kernel(const float *__rest
     // the next tile travels through registers while the current one is scored; a ragged last tile
     // re-reads its final float4 instead of branching (those slots are never scored)
     km_f4 stage[kStage];
-    km_fetch_tile<dim, kStage>(stage, centroids, 0, k, tid);
-    for (int c0 = 0; c0 < k; c0 += kKmTile) {
+    km_fetch_tile<dim, kStage>(stage, centroids, c_lo, c_hi, tid);
+    for (int c0 = c_lo; c0 < c_hi; c0 += kKmTile) {
         __syncthreads();  // the previous tile is no longer read
 #pragma unroll
         for (int u = 0; u < kStage; u++) {
@@ -151,8 +162,8 @@ __global__ __launch_bounds__(256) void km_assign_regs_kernel(const float *__rest
             if (tile4 % 256 == 0 || t < tile4) reinterpret_cast<km_f4 *>(ctile)[t] = stage[u];
         }
         __syncthreads();
-        km_fetch_tile<dim, kStage>(stage, centroids, c0 + kKmTile < k ? c0 + kKmTile : c0, k, tid);  // last: unused
-        const int cnt = k - c0 < kKmTile ? k - c0 : kKmTile;
+        km_fetch_tile<dim, kStage>(stage, centroids, c0 + kKmTile < c_hi ? c0 + kKmTile : c0, c_hi, tid);  // last: unused
+        const int cnt = c_hi - c0 < kKmTile ? c_hi - c0 : kKmTile;
         for (int cc = 0; cc < cnt; cc++) {
             const float4 *q4 = reinterpret_cast<const float4 *>(ctile + cc * dim) + sub.f4;
             km_f2 acc[kKmRows][2];
@@ -196,7 +207,7 @@ __global__ __launch_bounds__(256) void km_assign_regs_kernel(const float *__rest
                     b[t] = dpp_partner_add<kDppQuadXor1>(x2);
                 }
                 const float total = (b[0] + b[2]) + (b[1] + b[3]);
-                if (c == 0 || (DOT ? (total > bd[p]) : (total < bd[p]))) {
+                if (c == c_lo || (DOT ? (total > bd[p]) : (total < bd[p]))) {
                     bd[p] = total;
                     best[p] = c;
                 }
@@ -207,10 +218,39 @@ __global__ __launch_bounds__(256) void km_assign_regs_kernel(const float *__rest
 #pragma unroll
         for (int p = 0; p < kKmRows; p++)
             if (i0 + p < total) {
-                if (changed && assign[row_of[p]] != best[p]) *changed = 1;
-                assign[row_of[p]] = best[p];
+                if (ranged) {
+                    range_d[(i0 + p) * gridDim.y + blockIdx.y] = bd[p];
+                    range_i[(i0 + p) * gridDim.y + blockIdx.y] = best[p];
+                } else {
+                    if (changed && assign[row_of[p]] != best[p]) *changed = 1;
+                    assign[row_of[p]] = best[p];
+                }
             }
     }
+    }
+}
+
+// the listed points' assignment from their ranges' bests (km_assign_regs_kernel<.., LIST> with ranges): the first best in
+// range order under the loop's own strict comparison
+template <bool DOT>
+__global__ __launch_bounds__(256) void km_list_combine_kernel(const int32_t *__restrict__ list, const int *__restrict__ list_count,
+                                                              const float *__restrict__ range_d, const int32_t *__restrict__ range_i, int ranges,
+                                                              int32_t *__restrict__ assign, int *__restrict__ changed)
+{
+    const int64_t total = *list_count;
+    for (int64_t slot = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; slot < total; slot += static_cast<int64_t>(gridDim.x) * 256) {
+        float bd = range_d[slot * ranges];
+        int best = range_i[slot * ranges];
+        for (int r = 1; r < ranges; r++) {
+            const float d = range_d[slot * ranges + r];
+            if (DOT ? (d > bd) : (d < bd)) {
+                bd = d;
+                best = range_i[slot * ranges + r];
+            }
+        }
+        const int64_t row = list[slot];
+        if (changed && assign[row] != best) *changed = 1;
+        assign[row] = best;
     }
 }
 
@@ -938,9 +978,24 @@ __global__ __launch_bounds__(256) void km_pairs_kernel(const float *__restrict__
 // and strides)
 template <int NBLK>
 static int32_t km_launch_regs(bool dot, const float *v, int64_t n, const float *cent, int k, int32_t *assign, int *changed,
-                              hipStream_t st, const int32_t *list, const int *list_count)
+                              hipStream_t st, const int32_t *list, const int *list_count, float *range_d = nullptr, int32_t *range_i = nullptr)
 {
     const int64_t chunks = (n + 16 * vg::kKmRows - 1) / (16 * vg::kKmRows);
+    // (the listed points by centroid ranges of 32 when the caller brought the scratch: see the kernel)
+    const int range_len = 4 * vg::kKmTile, ranges = (k + range_len - 1) / range_len;
+    if (list && range_d && ranges > 1 && !vg::hook(vg::kHookKmNoRanges)) {
+        const unsigned gx = static_cast<unsigned>(std::min<int64_t>(chunks, 2048));
+        if (dot) {
+            VG_LAUNCH((vg::km_assign_regs_kernel<true, NBLK, true>), dim3(gx, ranges), dim3(256), 0, st, v, n, cent, k, assign, changed,
+                      list, list_count, range_d, range_i, range_len);
+            VG_LAUNCH(vg::km_list_combine_kernel<true>, dim3(256), dim3(256), 0, st, list, list_count, range_d, range_i, ranges, assign, changed);
+        } else {
+            VG_LAUNCH((vg::km_assign_regs_kernel<false, NBLK, true>), dim3(gx, ranges), dim3(256), 0, st, v, n, cent, k, assign, changed,
+                      list, list_count, range_d, range_i, range_len);
+            VG_LAUNCH(vg::km_list_combine_kernel<false>, dim3(256), dim3(256), 0, st, list, list_count, range_d, range_i, ranges, assign, changed);
+        }
+        return VG_OK;
+    }
     if (list) {
         const unsigned gx = static_cast<unsigned>(std::min<int64_t>(chunks, 2048));
         if (dot)
@@ -963,18 +1018,19 @@ static int32_t km_launch_regs(bool dot, const float *v, int64_t n, const float *
 
 // the reference-order assignment (squaredL2BatchAvx512 / dotBatchAvx512 summation order)
 static int32_t km_launch_exact(bool dot, const float *v, int64_t n, int dim, const float *cent, int k, int32_t *assign,
-                               int *changed, hipStream_t st, const int32_t *list = nullptr, const int *list_count = nullptr)
+                               int *changed, hipStream_t st, const int32_t *list = nullptr, const int *list_count = nullptr,
+                               float *range_d = nullptr, int32_t *range_i = nullptr)
 {
     const bool aligned = (reinterpret_cast<uintptr_t>(v) & 15) == 0 && (reinterpret_cast<uintptr_t>(cent) & 15) == 0;
     if (aligned) {
         switch (dim) {
-        case 64: return km_launch_regs<1>(dot, v, n, cent, k, assign, changed, st, list, list_count);
-        case 128: return km_launch_regs<2>(dot, v, n, cent, k, assign, changed, st, list, list_count);
-        case 256: return km_launch_regs<4>(dot, v, n, cent, k, assign, changed, st, list, list_count);
-        case 384: return km_launch_regs<6>(dot, v, n, cent, k, assign, changed, st, list, list_count);
-        case 512: return km_launch_regs<8>(dot, v, n, cent, k, assign, changed, st, list, list_count);
-        case 768: return km_launch_regs<12>(dot, v, n, cent, k, assign, changed, st, list, list_count);
-        case 1024: return km_launch_regs<16>(dot, v, n, cent, k, assign, changed, st, list, list_count);
+        case 64: return km_launch_regs<1>(dot, v, n, cent, k, assign, changed, st, list, list_count, range_d, range_i);
+        case 128: return km_launch_regs<2>(dot, v, n, cent, k, assign, changed, st, list, list_count, range_d, range_i);
+        case 256: return km_launch_regs<4>(dot, v, n, cent, k, assign, changed, st, list, list_count, range_d, range_i);
+        case 384: return km_launch_regs<6>(dot, v, n, cent, k, assign, changed, st, list, list_count, range_d, range_i);
+        case 512: return km_launch_regs<8>(dot, v, n, cent, k, assign, changed, st, list, list_count, range_d, range_i);
+        case 768: return km_launch_regs<12>(dot, v, n, cent, k, assign, changed, st, list, list_count, range_d, range_i);
+        case 1024: return km_launch_regs<16>(dot, v, n, cent, k, assign, changed, st, list, list_count, range_d, range_i);
         default: break;
         }
     }
@@ -1004,6 +1060,8 @@ struct KmMfma {
     bool bf16 = false;
     vg::DevTmp<vg::KmPart> part;
     vg::DevTmp<int32_t> list, pairs;
+    vg::DevTmp<float> range_d;    // the listed points' bests by centroid range (km_assign_regs_kernel<.., LIST>): capacity slots x ranges
+    vg::DevTmp<int32_t> range_i;
     vg::DevTmp<int> count;  // [0] full list, [1] pair list, [2] max |c|^2 (float bits)
     int mtiles = 0;
     bool on = false;
@@ -1036,6 +1094,13 @@ struct KmMfma {
         VG_TRY(part.init(static_cast<size_t>(mtiles) * n, st));
         VG_TRY(list.init(static_cast<size_t>(n), st));
         VG_TRY(pairs.init(static_cast<size_t>(n) * 3, st));
+        {   // (ranges of 32 centroids for the listed points' exact pass: km_launch_regs — every point can be listed)
+            const int64_t ranges = (k + 4 * vg::kKmTile - 1) / (4 * vg::kKmTile);
+            if (ranges > 1 && n * ranges * 8 <= (int64_t(256) << 20)) {
+                VG_TRY(range_d.init(static_cast<size_t>(n * ranges), st));
+                VG_TRY(range_i.init(static_cast<size_t>(n * ranges), st));
+            }
+        }
         VG_TRY(count.init(3, st));
         VG_LAUNCH(vg::km_norms_kernel, dim3(static_cast<unsigned>((n + 3) / 4)), dim3(256), 0, st, v, n, dim, xnorm.ptr);
         on = true;
@@ -1080,7 +1145,7 @@ struct KmMfma {
             VG_LAUNCH(vg::km_pairs_kernel<true>, dim3(pg), dim3(256), 0, st, v, dim, cent, pairs.ptr, count.ptr, out, changed);
         else
             VG_LAUNCH(vg::km_pairs_kernel<false>, dim3(pg), dim3(256), 0, st, v, dim, cent, pairs.ptr, count.ptr, out, changed);
-        return km_launch_exact(dot, v, n, dim, cent, k, out, changed, st, list.ptr, count.ptr);
+        return km_launch_exact(dot, v, n, dim, cent, k, out, changed, st, list.ptr, count.ptr, range_d.ptr, range_i.ptr);
     }
 };
 

@@ -314,7 +314,7 @@ static const char *const kHookNames[kHookCount] = {"VG_FLAT_NO_SMALL_TILE", "VG_
                                                    "VG_PROBE_NO_GROUP", "VG_ADC_BIGK_EXHAUSTIVE", "VG_BUILD_DEBUG",
                                                    "VG_KM_NO_MFMA", "VG_KM_LIST_ALL", "VG_KM_BF16", "VG_KM_NO_BF16", "VG_BRUTE_NO_FLAT", "VG_PQ_NO_MFMA",
                                                    "VG_PQ_LIST_ALL", "VG_PQ_FP32_MFMA", "VG_PROBE_NO_GEMM", "VG_FLAT_NO_BIG_TILE",
-                                                   "VG_FLAT_BIG_TILE_2", "VG_FLAT_BIG_EARLY_B", "VG_PQ_NOM_ALWAYS", "VG_NO_CAND_REPLAY"};
+                                                   "VG_FLAT_BIG_TILE_2", "VG_FLAT_BIG_EARLY_B", "VG_PQ_NOM_ALWAYS", "VG_KM_NO_RANGES", "VG_NO_CAND_REPLAY"};
 static void hooks_from_env()
 {
     for (int h = 0; h < kHookCount; h++) {

@@ -88,6 +88,7 @@ enum Hook {
     kHookFlatBigTile2,        // VG_FLAT_BIG_TILE_2      bf16 256 x 256 tile with two row-tile buffers (128 KiB) instead of three
     kHookFlatBigEarlyB,       // VG_FLAT_BIG_EARLY_B     bf16 256 x 256 tile: row-tile fills behind the first matrix group of a step
     kHookPqNomAlways,         // VG_PQ_NOM_ALWAYS        vg_index_enable_pq_nomination: batches of any size take the nomination
+    kHookKmNoRanges,          // VG_KM_NO_RANGES         k-means: the listed points' exact pass in one walk over the centroids (no ranges)
     kHookNoCandReplay,        // VG_NO_CAND_REPLAY       no heap replay for queries whose scores may hold a NaN (vg_cand_replay.hpp): what the fast paths alone answer
     kHookCount
 };
