@@ -611,6 +611,8 @@ public:
     void EnableBF16Filter(bool on = true) { check(vg_index_enable_bf16_filter(h_, on ? 1 : 0, nullptr)); }
     // flat.Segment.Search PQ branch (flat/segment.go:476-483,678-689)
     Result SearchPQ(const float *queries, int64_t nq, int k) { return run(nq, k, [&](Result &r) { return vg_search_pq_adc(h_, queries, nq, k, r.ids.data(), r.scores.data(), nullptr); }); }
+    // opt-in: batches of SearchPQ nominated by a bfloat16 MFMA GEMM over the decoded rows, re-scored from the codes; results unchanged
+    void EnablePQNomination(bool on = true) { check(vg_index_enable_pq_nomination(h_, on ? 1 : 0, nullptr)); }
     Result SearchRaBitQ(const float *queries, int64_t nq, int k) { return run(nq, k, [&](Result &r) { return vg_search_rabitq(h_, queries, nq, k, r.ids.data(), r.scores.data(), nullptr); }); }
     // IVF partitions (flat/segment.go:187-207) and the probed scan of flat.Segment.Search (:727-749):
     // scan = VG_SCAN_F32 / VG_SCAN_PQ / VG_SCAN_SQ8, nprobes <= 0 means 1 as in the reference
