@@ -139,3 +139,26 @@ def test_filter_worst_case_rounding(vg, ctx):
         assert np.array_equal(ids0[qi], eid) and np.array_equal(bits(sc0[qi]), bits(esc)), qi
         assert np.array_equal(ids1[qi], eid) and np.array_equal(bits(sc1[qi]), bits(esc)), ("bf16 filter", qi, ids1[qi], eid)
     idx.close()
+
+
+def test_rows_with_inf_next_to_a_ragged_query_tile(vg, ctx):
+    """The case tools/fuzz_nonfinite.py caught in r06 (kept as found: tests/golden/r06_bf16_tile_inf_rows.npz — 1000 x 16 rows with
+    NaN / Inf / 3e38 among the first 64, 140 queries, Dot): the persistent bf16 tile gave the padding queries of its ragged query
+    tile -1e30 to start from, a row holding an Inf made their dot product +Inf, and the "passing" element was appended to a
+    candidate list that does not exist — a memory fault.  Now: no fault, and every query equals the oracle (the rows put every
+    query at risk: the heap replay answers, NaN scores compare equal)."""
+    from pathlib import Path
+    d = np.load(Path(__file__).resolve().parent / "golden" / "r06_bf16_tile_inf_rows.npz", allow_pickle=True)
+    x, q = d["xr"], d["q"]
+    n, dim = x.shape
+    for metric in (1, 0):
+        idx = vg.Index(ctx, n, dim, vg.Metric(metric))
+        idx.set_vectors(x)
+        idx.enable_bf16_filter(True)
+        ids, sc = idx.search_flat(q, 64)
+        for qi in range(0, q.shape[0], 7):
+            eid, esc = o.flat_search_f32(x, dim, q[qi], 64, metric)
+            assert np.array_equal(ids[qi, :eid.size], eid), (metric, qi)
+            a, b = sc[qi, :eid.size], esc
+            assert np.all((bits(a) == bits(b)) | (np.isnan(a) & np.isnan(b))), (metric, qi)
+        idx.close()
