@@ -735,8 +735,11 @@ int32_t vg_comm_all_gather_topk(vg_comm *comm, const uint32_t *local_ids, const 
  * through them) take part: the rows a query's filter lets through, the probed partitions' ranges in FindClosestCentroids'
  * order — its selection loop and, up to 12 partitions, its full sort (Go's insertion sort, where a NaN distance compares equal
  * to everything) are replayed; with more than 12 partitions AND NaN centroid distances the full sort is pdqsort proper, whose
- * order is not restated (NaN distances sort last).  Not covered: vg_rerank and vg_merge_topk — NaN scores there order as the
- * largest keys. */
+ * order is not restated (NaN distances sort last).  vg_merge_topk / _packed (and vg_comm_all_gather_topk through them) replay
+ * the engine's fan-in (engine/search.go:904-918: every list from its last valid entry to its first into one heap with
+ * TryPushBounded, then popped) for a query whose lists hold a NaN.  Not covered: vg_rerank — the order in which the engine hands
+ * it the candidates comes out of an unstable sort (search.go:921), so there is no defined outcome to reproduce; NaN scores
+ * order as the largest keys there. */
 
 /* flat.Segment.Search, PQ branch (flat/segment.go:476-483 LUT, :678-689 ADC
  * = simd.PqAdcLookup in pqAdcLookupAvx512 order, :714-721 top-k with the

@@ -381,3 +381,45 @@ def test_partition_probed_and_filtered_scans(vg, ctx, scan, metric, where):
     idx, seg, code = build(False)
     check(idx.search_flat_filtered(q, k, masks, 0, scan=code), lambda i: seg.search(q[i], k, mask=masks[i]), nq, k)
     check(idx.search_flat_filtered(q[:3], 70, masks[1], 0, scan=code), lambda i: seg.search(q[i], 70, mask=masks[1]), 3, 70)
+
+
+@pytest.mark.parametrize("metric", [0, 2])
+def test_merge_topk_with_nan_scores(vg, ctx, metric):
+    """vg_merge_topk / _packed = the engine's fan-in (engine/search.go:904-918): every segment's candidates, in the order they were
+    popped from its heap (worst first = a best-first list read backwards), into one CandidateHeap with TryPushBounded(k), then
+    popped.  With a NaN in a list the heap's layout decides; without one it is the key merge.  Ragged lists (padding), ties,
+    global ids through the per-list offsets."""
+    rng = np.random.default_rng(60 + metric)
+    lists, nq, k = 5, 12, 16
+    desc = metric != 0
+    ids = np.stack([rng.permutation(1000)[:nq * k].reshape(nq, k) for _ in range(lists)]).astype(np.uint32)
+    sc = rng.standard_normal((lists, nq, k)).astype(np.float32)
+    sc = np.sort(sc, axis=2)
+    if desc:
+        sc = sc[:, :, ::-1].copy()
+    sc[1, 2, 3] = np.nan; sc[0, 3, 0] = np.nan; sc[4, 3, k - 1] = np.nan; sc[2, 4, :] = np.nan
+    # (the lists stay best-first where no NaN is involved: that is the entry point's contract)
+    sc[3, 5, k - 1 if not desc else 0] = np.inf; sc[0, 6, 0 if not desc else k - 1] = -np.inf; sc[1, 7, 4] = sc[1, 7, 5]
+    ids[2, 8, 10:] = 0xFFFFFFFF                                   # a short list
+    ids[:, 9, :] = 0xFFFFFFFF                                     # nothing at all for query 9
+    sc[0, 10, 0] = np.nan; ids[1:, 10, :] = 0xFFFFFFFF            # one list, one NaN
+    off = (np.arange(lists) * 1000).astype(np.uint32)
+    got_i, got_s = vg.merge_topk(ctx, ids, sc, k, metric=metric, id_offsets=off)
+    for q in range(nq):
+        h = o.CandidateHeap(desc)
+        for l in range(lists):
+            valid = int(np.sum(ids[l, q] != 0xFFFFFFFF))
+            for i in range(valid - 1, -1, -1):
+                h.push(np.float32(sc[l, q, i]), l, int(ids[l, q, i]) + int(off[l]), k=k)
+        want = []
+        while True:
+            e = h.pop()
+            if e is None:
+                break
+            want.append(e)
+        h.close()
+        want = want[::-1]
+        r = len(want)
+        assert list(got_i[q, :r]) == [e[2] for e in want], (q, got_i[q], [e[2] for e in want])
+        assert same_scores(got_s[q, :r], np.array([e[0] for e in want], np.float32)), q
+        assert np.all(got_i[q, r:] == 0xFFFFFFFF)

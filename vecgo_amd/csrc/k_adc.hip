@@ -936,6 +936,64 @@ __global__ void pack_keys_kernel(const uint32_t *__restrict__ ids, const float *
 }
 }  // namespace vg
 
+namespace vg {
+// The engine's fan-in when a list holds a NaN score (include/vecgo_hip.h "NaN scores"): engine/search.go:904-908 pushes every
+// segment's candidates — in the order they were popped from the segment's heap, worst first, i.e. each list here from its last
+// valid entry to its first — into ONE CandidateHeap with TryPushBounded(k), then pops it (:915-918).  The key merge above is that
+// outcome while no score is a NaN; a query with one is replayed here by one wave and overwrites the key merge's answer.  Ids are
+// the offset (global) ones: offsets ascend with the segment, so (SegmentID, RowID) orders like the global id.
+__global__ __launch_bounds__(64) void merge_nan_replay_kernel(const uint32_t *__restrict__ ids_in, const float *__restrict__ scores_in, int lists,
+                                                              int64_t nq, int k, int64_t list_stride, bool desc,
+                                                              const uint32_t *__restrict__ offsets, uint32_t *__restrict__ ids,
+                                                              float *__restrict__ scores)
+{
+    extern __shared__ uint64_t merge_lds[];
+    CItem *heap = reinterpret_cast<CItem *>(merge_lds);
+    const int64_t q = blockIdx.x;
+    const int lane = threadIdx.x;
+    bool nan = false;
+    for (int t = lane; t < lists * k; t += 64) {
+        const int64_t src = static_cast<int64_t>(t / k) * list_stride + q * k + t % k;
+        if (ids_in[src] != VG_INVALID_ID) {
+            const float v = scores_in[src];
+            nan = nan || v != v;
+        }
+    }
+    if (!__any(nan)) return;
+    int len = 0;
+    for (int l = 0; l < lists; l++) {
+        const int64_t base = static_cast<int64_t>(l) * list_stride + q * k;
+        int cnt = 0;  // valid entries are a prefix of the list
+        for (int i0 = 0; i0 < k; i0 += 64) {
+            const bool valid = i0 + lane < k && ids_in[base + i0 + lane] != VG_INVALID_ID;
+            cnt += __popcll(__ballot(valid));
+        }
+        const uint32_t off = offsets ? offsets[l] : 0u;
+        for (int i = cnt - 1; i >= 0; i--) {
+            const CItem x{scores_in[base + i], ids_in[base + i] + off};
+            if (len < k) {
+                cand_up(heap, len, x, desc);
+                len++;
+            } else if (cand_better(x, cand_load(heap, 0), desc)) {
+                cand_down(heap, 0, len, x, desc);
+            }
+        }
+    }
+    const int nres = len;
+    for (int i = nres - 1; i >= 0; i--) {
+        const CItem it = cand_pop(heap, len, desc);
+        if (lane == 0) {
+            ids[q * k + i] = it.row;
+            scores[q * k + i] = it.score;
+        }
+    }
+    for (int i = nres + lane; i < k; i += 64) {
+        ids[q * k + i] = VG_INVALID_ID;
+        scores[q * k + i] = desc ? -INFINITY : INFINITY;
+    }
+}
+}  // namespace vg
+
 static int32_t merge_topk_impl(vg_ctx *ctx, const uint32_t *ids_in, const float *scores_in, int64_t list_stride,
                                int32_t lists, int64_t nq, int32_t k, int32_t metric, const uint32_t *id_offsets,
                                uint32_t *ids, float *scores, void *stream);
@@ -1000,6 +1058,9 @@ static int32_t merge_topk_impl(vg_ctx *ctx, const uint32_t *ids_in, const float 
                            0, st, i_in.ptr, s_in.ptr, lists, nq, k, list_stride, desc, offs.ptr, keys.ptr);
     }
     VG_TRY(vg::launch_topk_merge(keys.ptr, nq, nl, k, desc, oid.ptr, osc.ptr, st));
+    if (lists > 0 && !vg::hook(vg::kHookNoCandReplay))  // queries with a NaN score in a list: the engine's heap, operation by operation
+        VG_LAUNCH(vg::merge_nan_replay_kernel, dim3(static_cast<unsigned>(nq)), dim3(64), sizeof(uint64_t) * (static_cast<size_t>(k) + 4), st,
+                  i_in.ptr, s_in.ptr, lists, nq, k, list_stride, desc, offs.ptr, oid.ptr, osc.ptr);
     VG_TRY(oid.finish());
     VG_TRY(osc.finish());
     if (oid.on_host() || osc.on_host()) VG_HIP(hipStreamSynchronize(st));
