@@ -58,10 +58,13 @@ static int32_t launch_gemm_t(bool dma, unsigned blocks, hipStream_t st, const Ge
 {
     if (bf16) {  // rows of bfloat16 (a.dim = 4-byte words per row): the LDS-DMA tiles only
         constexpr int M = MODE == 0 ? 1 : MODE;
-        if (a.nq <= 2 * kG32BM && !hook(kHookFlatNoSmallTile)) {
+        // up to 128 queries: the tile of 1 .. 4 blocks of 32 query rows (HBM-bound at the bf16 rate: 65 .. 128 queries 0.44 .. 0.49 ms on
+        // the 128 x 128 tile, 0.40 .. 0.45 on this one — tools/mid_batch_time.py)
+        if (a.nq <= 4 * kG32BM && !hook(kHookFlatNoSmallTile)) {
             const bool one = a.nq <= kG32BM;
-            auto kern = one ? flat_gemm_dma32_kernel<DOT, M, 1, true> : flat_gemm_dma32_kernel<DOT, M, 2, true>;
-            const size_t lds = one ? g32_lds_bytes<1>() : g32_lds_bytes<2>();
+            const int rb = static_cast<int>((a.nq + kG32BM - 1) / kG32BM);
+            auto kern = one ? flat_gemm_dma32_kernel<DOT, M, 1, true> : rb == 2 ? flat_gemm_dma32_kernel<DOT, M, 2, true> : rb == 3 ? flat_gemm_dma32_kernel<DOT, M, 3, true> : flat_gemm_dma32_kernel<DOT, M, 4, true>;
+            const size_t lds = one ? g32_lds_bytes<1>() : rb == 2 ? g32_lds_bytes<2>() : rb == 3 ? g32_lds_bytes<3>() : g32_lds_bytes<4>();
             VG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        static_cast<int>(lds)));
             const int64_t tiles = (a.n + kGemmBN - 1) / kGemmBN;
@@ -98,11 +101,14 @@ static int32_t launch_gemm_t(bool dma, unsigned blocks, hipStream_t st, const Ge
         return VG_OK;
     }
     // (test hook kHookFlatNoSmallTile: always the 128-query tile)
-    if (dma && MODE != 0 && a.nq <= 2 * kG32BM && !hook(kHookFlatNoSmallTile)) {  // 1-2 blocks of 32 queries: HBM-bound shapes
+    // 1 - 3 blocks of 32 queries: the HBM-bound shapes, and 65 .. 96 queries at three quarters of the 128-query tile's matrix work
+    // (1.65 -> 1.28 ms per call at 1M x 768; 97 .. 128 queries: four blocks run as long as the 128 x 128 tile, which keeps them)
+    if (dma && MODE != 0 && a.nq <= 3 * kG32BM && !hook(kHookFlatNoSmallTile)) {
         constexpr int M = MODE == 0 ? 1 : MODE;
         const bool one = a.nq <= kG32BM;
-        auto kern = one ? flat_gemm_dma32_kernel<DOT, M, 1> : flat_gemm_dma32_kernel<DOT, M, 2>;
-        const size_t lds = one ? g32_lds_bytes<1>() : g32_lds_bytes<2>();
+        const int rb = static_cast<int>((a.nq + kG32BM - 1) / kG32BM);
+        auto kern = one ? flat_gemm_dma32_kernel<DOT, M, 1> : rb == 2 ? flat_gemm_dma32_kernel<DOT, M, 2> : flat_gemm_dma32_kernel<DOT, M, 3>;
+        const size_t lds = one ? g32_lds_bytes<1>() : rb == 2 ? g32_lds_bytes<2>() : g32_lds_bytes<3>();
         VG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    static_cast<int>(lds)));
         const int64_t tiles = (a.n + kGemmBN - 1) / kGemmBN;
