@@ -162,3 +162,27 @@ def test_rows_with_inf_next_to_a_ragged_query_tile(vg, ctx):
             a, b = sc[qi, :eid.size], esc
             assert np.all((bits(a) == bits(b)) | (np.isnan(a) & np.isnan(b))), (metric, qi)
         idx.close()
+
+
+@pytest.mark.parametrize("metric", [0, 2])
+@pytest.mark.parametrize("nq", [63, 64, 65, 95, 96, 97, 127, 128, 129])
+def test_query_tile_boundaries(vg, ctx, nq, metric):
+    """the flat search picks its query tile by the batch size — 1 .. 3 blocks of 32 rows up to 96 queries (fp32; up to 4 blocks = 128
+    queries on the bf16 image), the 128-query tile, the persistent 256 x 256 tile above 128 with the bf16 image: every boundary,
+    fp32 and bf16 nomination, L2 and Dot, against the oracle"""
+    rng = np.random.default_rng(700 + nq + metric)
+    n, dim, k = 9000, 128, 10
+    base = rng.standard_normal((n, dim)).astype(np.float32)
+    base[4000] = base[11]
+    q = rng.standard_normal((nq, dim)).astype(np.float32)
+    q[nq - 1] = base[11]
+    idx = vg.Index(ctx, n, dim, vg.Metric(metric))
+    idx.set_vectors(base)
+    plain = idx.search_flat(q, k)
+    idx.enable_bf16_filter(True)
+    filt = idx.search_flat(q, k)
+    assert np.array_equal(plain[0], filt[0]) and np.array_equal(bits(plain[1]), bits(filt[1]))
+    for qi in (0, nq // 2, nq - 1):
+        eid, esc = o.flat_search_f32(base, dim, q[qi], k, metric)
+        assert np.array_equal(plain[0][qi], eid) and np.array_equal(bits(plain[1][qi]), bits(esc)), qi
+    idx.close()
