@@ -730,7 +730,7 @@ int32_t vg_comm_all_gather_topk(vg_comm *comm, const uint32_t *local_ids, const 
  * ids / scores then hold what the engine takes out of the heap — Pop() until empty (engine/search.go:859-862) — best first; a
  * NaN score's sign and payload are the instruction set's, not the algorithm's.  Rare by construction (such inputs are garbage)
  * and slow by design: one workgroup walks all rows per query — measured at 1M x 768 (tools/nan_replay_time.py): a call of 1024
- * queries takes 11.6 ms with none at risk, 114 ms with one, 134 ms with 64, 817 ms with all of them; an index holding a non-finite
+ * queries takes 11.6 ms with none at risk, 90 ms with one, 101 ms with 64, 698 ms with all of them; an index holding a non-finite
  * row sends EVERY query there.  Every other query pays one extra kernel launch per call that returns at once (the probed searches: two —
  * the probe lists are selected again for the replay).  vg_search_flat_probed / vg_search_flat_filtered (and vg_segment_search
  * through them) take part: the rows a query's filter lets through, the probed partitions' ranges in FindClosestCentroids'

@@ -114,8 +114,10 @@ struct CandHeapPolicy {
     __device__ static CItem pop(CItem *h, int &len, bool desc) { return cand_pop(h, len, desc); }
 };
 
-constexpr int kReplayThreads = 256;
-constexpr int kReplayChunk = 256;  // rows scored per step
+// 16 waves score a step's rows (a row's score is a chain load -> arithmetic -> next row per 16-lane group or lane: the walk's pace is
+// how many of those chains run side by side — 256 threads: 114 ms for one query over 1M x 768, 1024: 90; tools/nan_replay_time.py)
+constexpr int kReplayThreads = 1024;
+constexpr int kReplayChunk = 1024;  // rows scored per step (the per-row scorers map thread t to row row0 + t)
 
 // Scorer (by value; device pointers inside):
 //   (qi: the query's index in the call, q: its vector)
